@@ -1,0 +1,90 @@
+// oracle/ref_shim.cpp — TEST INFRASTRUCTURE ONLY.
+//
+// Thin extern "C" window onto the *real* reference objects (compiled by oracle/Makefile from
+// /root/reference/src where they lie; this file is ours).  It lets tests and the golden-vector
+// generator call the reference's own functions one at a time:
+//
+//   BWT_Search       (reference src/bwt_search.cpp:121, declared src/structure.h:279)
+//   nw_alignment     (src/nw_alignment.cpp:18,   declared src/structure.h:289)
+//   ksw2_alignment   (src/ksw2_alignment.cpp:250, declared src/structure.h:292)
+//   ksw_extz2_sse    (src/ksw2_alignment.cpp:70; non-static, gives ez.score)
+//   bwa_idx_load / RestoreReferenceInfo (src/bwt_index.cpp:150,232)
+//
+// Nothing here restates the algorithm; the restatement is oracle/mcx_oracle.cpp.
+#include "structure.h"
+
+// ksw2_alignment.cpp keeps this struct private (ksw2_alignment.cpp:11-17); same layout here.
+// The typedef name is what the symbol is mangled with, so it must be spelled identically.
+typedef struct {
+    uint32_t max;
+    int max_q, max_t;
+    int mqe, mqe_t;
+    int mte, mte_q;
+    int score;
+} ksw_extz_t;
+extern string ksw_extz2_sse(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
+                            int8_t m, int8_t q, int8_t e, int w, ksw_extz_t *ez);
+extern bwtint_t bwt_sa(bwtint_t k);
+extern float MaxMisMatchRate;
+
+static bool g_loaded = false;
+
+extern "C" {
+
+// Load an index exactly as main() does (main.cpp:350-361) and set the defaults of main.cpp:159-191.
+int mcref_load_index(const char *prefix)
+{
+    if (g_loaded) return 0;
+    iThreadNum = 1; MaxPosDiff = 30; MaxMisMatchRate = 0.05f; NW_ALG = true; bUnique = true;
+    RefIdx = bwa_idx_load(prefix);
+    if (RefIdx == 0) return -1;
+    Refbwt = RefIdx->bwt;
+    RestoreReferenceInfo();
+    g_loaded = true;
+    return 0;
+}
+
+long long mcref_genome_size() { return (long long)GenomeSize; }
+
+// seq: codes 0..4.  loc must hold 50 entries.
+int mcref_bwt_search(const uint8_t *seq, int start, int stop, int *len, int *freq, uint64_t *loc)
+{
+    bwtSearchResult_t r = BWT_Search((uint8_t *)seq, start, stop);
+    *len = r.len; *freq = r.freq;
+    for (int i = 0; i < r.freq; i++) loc[i] = r.LocArr[i];
+    if (r.freq > 0) delete[] r.LocArr;
+    return 0;
+}
+
+unsigned long long mcref_bwt_sa(unsigned long long k) { return bwt_sa(k); }
+
+static int run_aln(bool nw, const char *s1, int m, const char *s2, int n, char *o1, char *o2, int cap)
+{
+    string a(s1, m), b(s2, n);
+    if (nw) nw_alignment(m, a, n, b); else ksw2_alignment(m, a, n, b);
+    if ((int)a.length() >= cap || (int)b.length() >= cap) return -1;
+    memcpy(o1, a.c_str(), a.length() + 1);
+    memcpy(o2, b.c_str(), b.length() + 1);
+    return (int)a.length() == (int)b.length() ? (int)a.length() : -2;
+}
+
+int mcref_nw(const char *s1, int m, const char *s2, int n, char *o1, char *o2, int cap)
+{ return run_aln(true, s1, m, s2, n, o1, o2, cap); }
+
+int mcref_ksw2(const char *s1, int m, const char *s2, int n, char *o1, char *o2, int cap)
+{ return run_aln(false, s1, m, s2, n, o1, o2, cap); }
+
+// q/t: codes 0..4 (query = read fragment, target = genome fragment), parameters exactly as
+// ksw2_alignment passes them (ksw2_alignment.cpp:260).  ops receives the *reversed* op string
+// (M/I/D) that ksw_backtrack returns; returns its length, *score = ez.score.
+int mcref_ksw2_extz(const uint8_t *q, int qlen, const uint8_t *t, int tlen, int *score, char *ops, int cap)
+{
+    ksw_extz_t ez;
+    string c = ksw_extz2_sse(qlen, q, tlen, t, 5, 2, 1, -1, &ez);
+    *score = ez.score;
+    if ((int)c.length() >= cap) return -1;
+    memcpy(ops, c.c_str(), c.length() + 1);
+    return (int)c.length();
+}
+
+}
