@@ -1,0 +1,129 @@
+/* include/mcx.h — C ABI of the MI355X seed-and-extend path (libmcx.so).
+ *
+ * MapCaller has no plugin/FFI interface: its seam is the set of extern C++ functions of
+ * reference src/structure.h:223-292 that the mapping driver calls.  This header is the batch
+ * C ABI that replaces them; each entry point names the reference interface it stands in for.
+ * Plain pointers and sizes only — no C++ or torch types.  INTEGRATION.md shows the shims with
+ * the reference's own signatures (BWT_Search, nw_alignment, ksw2_alignment) built on top.
+ *
+ * Conventions: functions return 0 on success and a negative mcx_status otherwise;
+ * mcx_last_error() gives a message.  A context is bound to one GPU and one host thread.
+ * Pointers named d_* are device (HBM) pointers, everything else is host memory.
+ */
+#ifndef MCX_H
+#define MCX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mcx_index mcx_index;
+typedef struct mcx_ctx mcx_ctx;
+
+enum mcx_status {
+    MCX_OK = 0,
+    MCX_ERR_IO = -1,        /* index or read file missing / truncated */
+    MCX_ERR_ARG = -2,
+    MCX_ERR_DEVICE = -3,    /* HIP runtime error (no GPU, out of memory, launch failure) */
+    MCX_ERR_CAPACITY = -4,  /* a pair exceeded the hard capacities of the last tier */
+    MCX_ERR_UNSUPPORTED = -5
+};
+
+const char *mcx_last_error(void);
+int mcx_device_count(void);
+
+/* ---- index ------------------------------------------------------------------------------
+ * Replaces bwa_idx_load + RestoreReferenceInfo (reference src/bwt_index.cpp:150-258, called
+ * from src/main.cpp:350-361): parses <prefix>.bwt/.sa/.pac/.ann/.amb (the byte-compatible BWA
+ * files `MapCaller index` writes) and stages them in HBM.  full_sa != 0 additionally expands
+ * the 1-in-32 sampled suffix array to every row on the GPU (bwt_sa then is one 8-byte gather). */
+int mcx_index_load(const char *prefix, int device, int full_sa, mcx_index **out);
+/* Replaces bwa_idx_build (reference src/BWT_Index/bwtindex.c:77; `MapCaller index ref.fa prefix`,
+ * src/main.cpp:199-207): builds BWT/occ/SA on the GPU from a FASTA file and writes the same
+ * five files. */
+int mcx_index_build(const char *fasta_path, const char *prefix, int device);
+void mcx_index_free(mcx_index *);
+int64_t mcx_index_genome_size(const mcx_index *);
+int32_t mcx_index_n_chr(const mcx_index *);
+const char *mcx_index_chr_name(const mcx_index *, int32_t i);
+int32_t mcx_index_chr_len(const mcx_index *, int32_t i);
+int64_t mcx_index_hbm_bytes(const mcx_index *);
+
+/* ---- options: the reference's globals that steer the path (src/main.cpp:159-191) ---------- */
+typedef struct mcx_opts {
+    int32_t alg;             /* 0 = nw (default, NW_ALG main.cpp:166), 1 = ksw2 (-alg) */
+    int32_t max_pos_diff;    /* MaxPosDiff, -indel, default 30 */
+    float max_mismatch_rate; /* MaxMisMatchRate, -maxmm, default 0.05 */
+    int32_t max_read_len;    /* longest read the context must hold (default 256) */
+    int64_t max_batch_reads; /* reads per batch the context is sized for */
+} mcx_opts;
+void mcx_opts_default(mcx_opts *);
+
+int mcx_ctx_create(const mcx_index *, const mcx_opts *, mcx_ctx **out);
+void mcx_ctx_free(mcx_ctx *);
+
+/* ---- per-call drop-ins ------------------------------------------------------------------
+ * BWT_Search (reference src/bwt_search.cpp:121, declared src/structure.h:279; only caller
+ * src/ReadMapping.cpp:138).  seqs: n concatenated code strings (0..4), seq_off[n+1]; each is
+ * searched from start[i] to its end.  len/freq: n each; loc: n*50 (freq[i] entries used). */
+int mcx_bwt_search_batch(mcx_ctx *, const uint8_t *seqs, const uint32_t *seq_off, const int32_t *start, uint32_t n,
+                         int32_t *len, int32_t *freq, uint64_t *loc);
+/* nw_alignment / ksw2_alignment (reference src/nw_alignment.cpp:18, src/ksw2_alignment.cpp:250;
+ * declared src/structure.h:289,292; called from src/ReadAlignment.cpp:186-187).  q = read
+ * fragments, t = genome fragments (ASCII), concatenated with offset arrays of n+1 entries.
+ * ops receives, for job i, ops_len[i] column codes 'M' (base/base), 'I' ('-' in the genome
+ * string) and 'D' ('-' in the read string) at ops + (q_off[i] + t_off[i]); score[i] is
+ * ez.score of ksw_extz2_sse for ksw2 and 2x the final s for nw. */
+int mcx_extend_batch(mcx_ctx *, int alg, const uint8_t *q, const uint32_t *q_off, const uint8_t *t,
+                     const uint32_t *t_off, uint32_t n, uint8_t *ops, int32_t *ops_len, int32_t *score);
+
+/* ---- the whole path -----------------------------------------------------------------------
+ * One record per read: what GeneratePairedSamStream / GenerateSingleSamStream print
+ * (reference src/SamReport.cpp:324-488) in the default unique mode. */
+typedef struct mcx_aln {
+    int64_t pos;       /* POS, 1-based; 0 = unmapped */
+    int64_t mate_pos;  /* PNEXT */
+    int32_t chr;       /* RNAME index, -1 = '*' */
+    int32_t flag;      /* FLAG */
+    int32_t mapq;      /* MAPQ */
+    int32_t tlen;      /* TLEN */
+    int32_t nm, as, xs;/* NM:i AS:i XS:i */
+    int32_t n_cigar;   /* words in this read's row of the cigar array: len << 4 | op, M=0 I=1 D=2 S=4 */
+    int32_t fwd;       /* 0: SEQ/QUAL are printed reverse-complemented / reversed */
+    int32_t has_mate;  /* RNEXT '=' */
+} mcx_aln;
+
+typedef struct mcx_stats {
+    int64_t reads, mapped, pairs, pair_dist_sum;
+    int64_t fm_ext_steps;   /* E of SURVEY.md §8d: sum of BWT_Search lengths */
+    int64_t fm_blocks;      /* 64-byte blocks the extension walk touched */
+    int64_t sa_hits;        /* H: suffix-array hits resolved */
+    int64_t dp_jobs, dp_cells;
+    int64_t tier1_pairs;    /* pairs re-run with the large capacities */
+    int64_t replayed_pairs; /* pairs re-run because the avgDist trajectory moved past their validity interval */
+    double ms_encode, ms_seed, ms_sa, ms_cluster, ms_rescue, ms_build, ms_dp, ms_finish, ms_total;
+} mcx_stats;
+
+#define MCX_CIGAR_STRIDE 32 /* words per read in the dense cigar array */
+
+/* Replaces the body of ReadMapping() for one batch (reference src/ReadMapping.cpp:416-646):
+ * seeding, clustering, pairing, rescue, extension, scoring, flags/MAPQ/CIGAR.  d_bases: ASCII
+ * reads in HBM, d_off: n_reads+1 byte offsets (device), paired: mates interleaved.
+ * avg_state[4] carries the reference's running insert-size estimate across batches
+ * {avgDist, iTotalPairedNum, TotalPairedDistance, reads seen} (ReadMapping.cpp:20-21,:538-539);
+ * initialise with mcx_avg_init.  Results (device): d_aln[n_reads], d_cigar[n_reads*MCX_CIGAR_STRIDE]. */
+void mcx_avg_init(int64_t avg_state[4]);
+int mcx_map_batch_dev(mcx_ctx *, const uint8_t *d_bases, const uint32_t *d_off, uint32_t n_reads, int paired,
+                      int64_t avg_state[4], mcx_aln *d_aln, uint32_t *d_cigar, mcx_stats *stats);
+/* same with host buffers (pinned staging inside) */
+int mcx_map_batch(mcx_ctx *, const uint8_t *bases, const uint32_t *off, uint32_t n_reads, int paired,
+                  int64_t avg_state[4], mcx_aln *aln, uint32_t *cigar, mcx_stats *stats);
+
+/* ---- files: MapCaller -i <prefix> -f A [-f2 B] -alg nw|ksw2 -sam out (src/main.cpp:212-321) */
+int mcx_map_files(mcx_ctx *, const char *fq1, const char *fq2, const char *sam_path, mcx_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

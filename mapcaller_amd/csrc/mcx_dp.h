@@ -1,0 +1,219 @@
+// mapcaller_amd/csrc/mcx_dp.h — gapped extension kernels for gfx950 (device only).
+//
+// Replaces ksw_extz2_sse + ksw_backtrack (reference src/ksw2_alignment.cpp:25-248, called with
+// m=5 q=2 e=1 w=-1 from ksw2_alignment :260) and nw_alignment (src/nw_alignment.cpp:18-83).
+//
+// Shape of the work: many tiny independent problems (median 3x3, p99
+// ~100x100), integer, no reuse -> not a contraction, no MFMA.  One wavefront owns one problem
+// and sweeps its anti-diagonals: lane t holds column t of the matrix (K columns per lane for
+// targets longer than 64), the difference-recurrence state (u,v,x,y / R,S,T) lives in VGPRs,
+// the left neighbour's values arrive by a one-lane wave shift, the query is read from LDS, and
+// the per-cell traceback codes go to an LDS-resident band buffer (spilling to a per-block HBM
+// scratch only for the rare large problem).  A single lane then walks the traceback and writes
+// the column string ('M','I','D') back to front into the caller's ops area.
+#ifndef MCX_DP_H
+#define MCX_DP_H
+#include "mcx_glue.h"
+
+namespace mcx {
+
+#if defined(__HIPCC__)
+
+constexpr int kDpLdsSeq = 2 * 1024;    // query + target codes in LDS (1 KB each)
+constexpr int kDpLdsDir = 12 * 1024;   // traceback bytes kept in LDS per wave
+constexpr int kDpSpillSeq = 4096;      // spill area reserved for sequences (2 KB each)
+
+// value of lane (lane-1); lane 0 receives `carry`
+static __device__ __forceinline__ int lane_shift_up(int v, int carry, int lane)
+{
+    int s = __shfl_up(v, 1, 64);
+    return lane == 0 ? carry : s;
+}
+
+struct DpBuf { uint8_t *q, *t, *dir; };
+
+// where a (qlen x tlen) problem keeps its sequences and traceback: LDS when it fits
+static __device__ __forceinline__ DpBuf dp_buffers(int qlen, int tlen, uint8_t *lds, uint8_t *spill)
+{
+    DpBuf b;
+    if (qlen <= kDpLdsSeq / 2 && tlen <= kDpLdsSeq / 2) { b.q = lds; b.t = lds + kDpLdsSeq / 2; }
+    else { b.q = spill; b.t = spill + kDpSpillSeq / 2; }
+    b.dir = ((int64_t)(qlen + tlen - 1) * tlen <= kDpLdsDir) ? lds + kDpLdsSeq : spill + kDpSpillSeq;
+    return b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ksw2: difference recurrence of ksw_extz2_sse, one int8 lane per column.
+// q/t: codes 0..4 (already staged, block synchronised).  ops: area of qlen+tlen bytes; the
+// column string is written back to front.  Returns its start offset in ops (all lanes);
+// length = qlen + tlen - offset; *score = ez.score.
+// ---------------------------------------------------------------------------------------------
+template <int K>
+static __device__ int dp_ksw2_core(int qlen, int tlen, const uint8_t *q, const uint8_t *t, uint8_t *dir, uint8_t *ops,
+                                   int *score)
+{
+    const int lane = threadIdx.x & 63;
+    const int Q = 2, QE = 3, QE2 = 6, MAX_SC = 7; // q, q+e, 2(q+e), mat[0] + 2(q+e)
+    int u[K], v[K], x[K], y[K], H[K], tc[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        u[k] = v[k] = x[k] = y[k] = 0; H[k] = -0x40000000;
+        const int tt = lane + 64 * k;
+        tc[k] = tt < tlen ? t[tt] : 4;
+    }
+    const int n_diag = qlen + tlen - 1;
+    for (int r = 0; r < n_diag; r++) {
+        const int st = r - qlen + 1 > 0 ? r - qlen + 1 : 0, en = r < tlen - 1 ? r : tlen - 1;
+        int cx_ = 0, cv_ = r ? Q : 0, cH_ = 0; // values entering column 0 (:163)
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int tt = lane + 64 * k;
+            if (64 * k <= en) { // wave-uniform
+                const int ox = x[k], ov = v[k], oH = H[k];
+                const int xl = lane_shift_up(ox, cx_, lane), vl = lane_shift_up(ov, cv_, lane), Hl = lane_shift_up(oH, cH_, lane);
+                cx_ = __shfl(ox, 63, 64); cv_ = __shfl(ov, 63, 64); cH_ = __shfl(oH, 63, 64);
+                if (tt == r) { y[k] = 0; u[k] = r ? Q : 0; } // first matrix row (:165)
+                if (tt >= st && tt <= en) {
+                    const int qb = q[r - tt], tb = tc[k];
+                    const int sc = (qb == 4 || tb == 4) ? 0 : (qb == tb ? 1 : -1);
+                    int z = sc + QE2;
+                    int a = (int8_t)(xl + vl);
+                    const int ut = u[k];
+                    int b = (int8_t)(y[k] + ut);
+                    int d = a > z ? 1 : 0;                     // signed (:187)
+                    z = z > a ? z : a;                         // signed max (:188)
+                    if (b > z) d = 2;                          // signed (:189)
+                    unsigned zu = (uint8_t)z, bu = (uint8_t)b; // unsigned max / min (:89-90)
+                    zu = zu > bu ? zu : bu;
+                    zu = zu < (unsigned)MAX_SC ? zu : (unsigned)MAX_SC;
+                    z = (int8_t)zu;
+                    u[k] = (int8_t)(z - vl);
+                    v[k] = (int8_t)(z - ut);
+                    z = (int8_t)(z - Q);
+                    a = (int8_t)(a - z);
+                    b = (int8_t)(b - z);
+                    if (a > 0) { x[k] = a; d |= 0x08; } else x[k] = 0;
+                    if (b > 0) { y[k] = b; d |= 0x10; } else y[k] = 0;
+                    dir[(int64_t)r * tlen + tt] = (uint8_t)d;
+                    // H bookkeeping (:200-239); u8/v8 are unsigned bytes there
+                    if (r == 0) H[k] = (int)(uint8_t)v[k] - QE - QE;
+                    else if (tt == en) H[k] = en > 0 ? Hl + (int)(uint8_t)u[k] - QE : oH + (int)(uint8_t)v[k] - QE;
+                    else H[k] = oH + (int)(uint8_t)v[k] - QE;
+                }
+            }
+        }
+    }
+    { // ez.score = H[tlen-1] after the last diagonal
+        const int kk = (tlen - 1) >> 6, ll = (tlen - 1) & 63;
+        int sc = 0;
+#pragma unroll
+        for (int k = 0; k < K; k++) { const int hv = __shfl(H[k], ll, 64); if (k == kk) sc = hv; }
+        *score = sc;
+    }
+    __syncthreads();
+    int w = qlen + tlen;
+    if (lane == 0) {
+        // ksw_backtrack (:25-68); full band: force_state never fires
+        int i = tlen - 1, j = qlen - 1, state = 0;
+        while (i >= 0 && j >= 0) {
+            const unsigned d = dir[(int64_t)(i + j) * tlen + i];
+            if (state == 0) state = d & 7;
+            else if (!((d >> (state + 2)) & 1)) state = 0;
+            if (state == 0) state = d & 7;
+            if (state == 0) { ops[--w] = 'M'; --i; --j; }
+            else if (state == 1 || state == 3) { ops[--w] = 'D'; --i; }
+            else { ops[--w] = 'I'; --j; }
+        }
+        for (; i >= 0; --i) ops[--w] = 'D';
+        for (; j >= 0; --j) ops[--w] = 'I';
+    }
+    w = __shfl(w, 0, 64);
+    __syncthreads();
+    return w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// nw: r/t/s recurrence of nw_alignment in doubled integers (all reference scores are multiples
+// of 0.5 and exact in float), equality-based traceback.  Rows i = read (q), columns j = genome.
+// ---------------------------------------------------------------------------------------------
+template <int K>
+static __device__ int dp_nw_core(int m, int n, const uint8_t *q, const uint8_t *t, uint8_t *dir, uint8_t *ops, int *score)
+{
+    const int lane = threadIdx.x & 63;
+    const int NEG = -131072, EXT = -1, NEW = -3;
+    int S[K], T[K], R[K], Sdiag[K], tc[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        S[k] = T[k] = R[k] = 0; Sdiag[k] = 0;
+        const int b = lane + 64 * k;
+        tc[k] = b < n ? t[b] : 4;
+    }
+    const int n_diag = m + n - 1;
+    for (int r = 0; r < n_diag; r++) {
+        const int st = r - m + 1 > 0 ? r - m + 1 : 0, en = r < n - 1 ? r : n - 1;
+        // matrix column j = 0 as seen by column b = 0 at row a = r: R = NEG, S = -2 - (a+1)
+        int cR = NEG, cS = -2 - (r + 1);
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int b = lane + 64 * k;
+            if (64 * k <= en) {
+                const int oR = R[k], oS = S[k], oT = T[k];
+                const int Rl = lane_shift_up(oR, cR, lane), Sl = lane_shift_up(oS, cS, lane);
+                cR = __shfl(oR, 63, 64); cS = __shfl(oS, 63, 64);
+                if (b >= st && b <= en) {
+                    const int a = r - b;
+                    // s(a-1, b-1): the left S this lane received one diagonal ago, or the
+                    // initialisation row / column of the matrix
+                    int sd;
+                    if (a == 0) sd = b == 0 ? 0 : -2 - b;
+                    else if (b == 0) sd = -2 - a;
+                    else sd = Sdiag[k];
+                    const int Tu = a == 0 ? NEG : oT, Su = a == 0 ? -2 - (b + 1) : oS;
+                    const int rr = (Rl + EXT > Sl + NEW) ? Rl + EXT : Sl + NEW;
+                    const int tt = (Tu + EXT > Su + NEW) ? Tu + EXT : Su + NEW;
+                    const int dg = sd + (q[a] == tc[k] ? 2 : -2);
+                    int s = dg > rr ? dg : rr;
+                    s = s > tt ? s : tt;
+                    R[k] = rr; T[k] = tt; S[k] = s;
+                    dir[(int64_t)r * n + b] = (uint8_t)((s == rr ? 1 : 0) | (s == tt ? 2 : 0));
+                }
+                Sdiag[k] = Sl; // s(a-1, b-1) of the next diagonal
+            }
+        }
+    }
+    {
+        const int kk = (n - 1) >> 6, ll = (n - 1) & 63;
+        int sc = 0;
+#pragma unroll
+        for (int k = 0; k < K; k++) { const int hv = __shfl(S[k], ll, 64); if (k == kk) sc = hv; }
+        *score = sc;
+    }
+    __syncthreads();
+    int w = m + n;
+    if (lane == 0) {
+        int i = m, j = n; // 1-based matrix indices (nw_alignment.cpp:59-74)
+        while (i > 0 || j > 0) {
+            unsigned d;
+            if (i == 0) d = 1;       // s[0][j] == r[0][j]
+            else if (j == 0) d = 2;  // s[i][0] == t[i][0]
+            else d = dir[(int64_t)(i + j - 2) * n + (j - 1)];
+            if (d & 1) { ops[--w] = 'D'; j--; }       // '-' inserted into s1 (read string)
+            else if (d & 2) { ops[--w] = 'I'; i--; }  // '-' inserted into s2 (genome string)
+            else { ops[--w] = 'M'; i--; j--; }
+        }
+    }
+    w = __shfl(w, 0, 64);
+    __syncthreads();
+    return w;
+}
+
+template <int K>
+static __device__ __forceinline__ int dp_core(bool nw, int qlen, int tlen, const DpBuf &b, uint8_t *ops, int *score)
+{
+    return nw ? dp_nw_core<K>(qlen, tlen, b.q, b.t, b.dir, ops, score) : dp_ksw2_core<K>(qlen, tlen, b.q, b.t, b.dir, ops, score);
+}
+
+#endif // __HIPCC__
+
+} // namespace mcx
+#endif

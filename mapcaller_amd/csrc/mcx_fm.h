@@ -1,0 +1,201 @@
+// mapcaller_amd/csrc/mcx_fm.h — FM-index primitives and the per-read seeding walk.
+//
+// Replaces, on the device, the reference's bwt_occ4 / bwt_2occ4 / bwt_occ / bwt_invPsi / bwt_sa
+// and BWT_Search (reference src/bwt_search.cpp:25-164) plus the greedy seeding loop
+// IdentifySimplePairs (src/ReadMapping.cpp:125-158).  Written for one read per lane: every
+// extension step is one dependent 64-byte block fetch (two when the interval straddles a
+// 128-base block), issued as four 16-byte lane loads, and the per-read loop is flattened into
+// a single state machine so that all 64 lanes of a wave issue a block fetch per iteration
+// instead of waiting for the longest search of the wave.
+#ifndef MCX_FM_H
+#define MCX_FM_H
+#include "mcx_types.h"
+
+namespace mcx {
+
+struct alignas(16) U4 { uint32_t x, y, z, w; };
+
+struct FmBlock {       // one 64-byte block of the .bwt file
+    uint64_t occ[4];   // occurrences of A,C,G,T before the block
+    uint32_t w[8];     // 128 bases, 2 bit each, MSB first
+};
+
+static inline MCX_HD void fm_load_block(const uint32_t *bwt, uint64_t blk, FmBlock &b)
+{
+    const U4 *p = (const U4 *)(bwt + (blk << 4));
+    U4 a = p[0], c = p[1], d = p[2], e = p[3];
+    b.occ[0] = (uint64_t)a.x | ((uint64_t)a.y << 32);
+    b.occ[1] = (uint64_t)a.z | ((uint64_t)a.w << 32);
+    b.occ[2] = (uint64_t)c.x | ((uint64_t)c.y << 32);
+    b.occ[3] = (uint64_t)c.z | ((uint64_t)c.w << 32);
+    b.w[0] = d.x; b.w[1] = d.y; b.w[2] = d.z; b.w[3] = d.w;
+    b.w[4] = e.x; b.w[5] = e.y; b.w[6] = e.z; b.w[7] = e.w;
+}
+
+// occurrences of each base among the first n (1..128) symbols of the block, added to occ[]
+static inline MCX_HD void fm_count4(const FmBlock &b, int n, uint64_t cnt[4])
+{
+    uint32_t t = 0, ct = 0, gt = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        int m = n - 16 * j;
+        m = m < 0 ? 0 : (m > 16 ? 16 : m);
+        uint32_t mask = 0x55555555u & (uint32_t)(~((1ull << (32 - 2 * m)) - 1));
+        uint32_t lo = b.w[j] & mask, hi = (b.w[j] >> 1) & mask;
+        t += (uint32_t)__builtin_popcount(hi & lo);
+        ct += (uint32_t)__builtin_popcount(lo);
+        gt += (uint32_t)__builtin_popcount(hi);
+    }
+    cnt[0] = b.occ[0] + ((uint32_t)n - ct - gt + t);
+    cnt[1] = b.occ[1] + (ct - t);
+    cnt[2] = b.occ[2] + (gt - t);
+    cnt[3] = b.occ[3] + t;
+}
+
+// occurrences of base c among the first n symbols (bwt_occ, bwt_search.cpp:25-47)
+static inline MCX_HD uint64_t fm_count1(const FmBlock &b, int n, int c)
+{
+    uint32_t s = 0;
+    const uint32_t xlo = (c & 1) ? 0u : 0xFFFFFFFFu, xhi = (c & 2) ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        int m = n - 16 * j;
+        m = m < 0 ? 0 : (m > 16 ? 16 : m);
+        uint32_t mask = 0x55555555u & (uint32_t)(~((1ull << (32 - 2 * m)) - 1));
+        uint32_t lo = b.w[j] ^ xlo, hi = (b.w[j] >> 1) ^ xhi;
+        s += (uint32_t)__builtin_popcount(lo & hi & mask);
+    }
+    return b.occ[c] + s;
+}
+
+// bwt_2occ4 (bwt_search.cpp:68-99) for k < l, neither equal to (u64)-1 — which is what
+// BWT_Search always passes (x1 >= 1).  n_blocks counts the 64-byte blocks touched.
+static inline MCX_HD void fm_2occ4(const IndexView &ix, uint64_t k, uint64_t l, uint64_t ck[4], uint64_t cl[4],
+                                   int &n_blocks)
+{
+    k -= (k >= ix.primary);
+    l -= (l >= ix.primary);
+    FmBlock b;
+    fm_load_block(ix.bwt, k >> 7, b);
+    fm_count4(b, (int)(k & 127) + 1, ck);
+    n_blocks = 1;
+    if ((l >> 7) != (k >> 7)) { fm_load_block(ix.bwt, l >> 7, b); n_blocks = 2; }
+    fm_count4(b, (int)(l & 127) + 1, cl);
+}
+
+// bwt_invPsi (bwt_search.cpp:101-107): one LF step, one block fetch
+static inline MCX_HD uint64_t fm_lf(const IndexView &ix, uint64_t k)
+{
+    if (k == ix.primary) return 0;
+    uint64_t x = k - (k > ix.primary);
+    FmBlock b;
+    fm_load_block(ix.bwt, x >> 7, b);
+    int c = (b.w[(x & 127) >> 4] >> ((~x & 15) << 1)) & 3;
+    // bwt_occ(k, c): k == seq_len cannot reach here with k != primary only if ... handled:
+    if (k == ix.seq_len) return ix.L2[c] + (ix.L2[c + 1] - ix.L2[c]);
+    return ix.L2[c] + fm_count1(b, (int)(x & 127) + 1, c);
+}
+
+// bwt_sa (bwt_search.cpp:109-119)
+static inline MCX_HD uint64_t fm_sa(const IndexView &ix, uint64_t k, int &lf_steps)
+{
+    if (ix.sa_full) return ix.sa_full[k];
+    uint64_t steps = 0, mask = (uint64_t)ix.sa_intv - 1;
+    while (k & mask) { ++steps; k = fm_lf(ix, k); }
+    lf_steps += (int)steps;
+    return steps + ix.sa[k / (uint64_t)ix.sa_intv];
+}
+
+// ASCII -> 0..4 (nst_nt4_table, BWT_Index/bntseq.c:40-57)
+static inline MCX_HD int nt4_code(uint8_t ch)
+{
+    switch (ch) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 4;
+    }
+}
+
+// code of 2G-coordinate p of RefSequence (bwt_index.cpp:196-215): forward strand from the
+// packed genome, reverse strand = complement of the mirrored forward base
+static inline MCX_HD int ref_code(const IndexView &ix, int64_t p)
+{
+    bool rev = p >= ix.G;
+    int64_t f = rev ? ix.G2 - 1 - p : p;
+    int b = (ix.pac[f >> 2] >> ((~f & 3) << 1)) & 3;
+    return rev ? 3 - b : b;
+}
+
+// PosChrIdMap.lower_bound(gPos): first chromosome end >= gPos, -1 past the last one
+static inline MCX_HD int end_slot(const IndexView &ix, int64_t gPos)
+{
+    int lo = 0, hi = ix.n_ends;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (ix.end_pos[mid] < gPos) lo = mid + 1; else hi = mid;
+    }
+    return lo < ix.n_ends ? lo : -1;
+}
+
+// Greedy left-to-right seeding of one read: IdentifySimplePairs (ReadMapping.cpp:125-158)
+// driving BWT_Search (bwt_search.cpp:121-164), flattened to one block fetch per iteration.
+// Hits are written as BWT rows (x0 + i); the SA kernel turns them into text positions.
+// Returns the number of hits the read produced (may exceed cap: overflow, nothing lost yet
+// because the pair is then re-run in the next tier).
+static inline MCX_HD int seed_read(const IndexView &ix, const uint8_t *codes, int rlen, Hit *hits, int cap,
+                                   int64_t &ext_steps, int64_t &blocks)
+{
+    int n_hits = 0;
+    const int stop = rlen - kMinSeedLength;
+    int p = 0, start = 0;
+    bool active = false;
+    uint64_t x0 = 0, x1 = 0, x2 = 0;
+    for (;;) {
+        if (!active) {
+            if (p >= stop) break;
+            int c = codes[p];
+            if (c > 3) { p++; continue; }
+            start = p;
+            x0 = ix.L2[c] + 1; x1 = ix.L2[3 - c] + 1; x2 = ix.L2[c + 1] - ix.L2[c];
+            active = true;
+            p++;
+        }
+        bool end = p >= rlen;
+        int c = end ? 4 : codes[p];
+        if (c > 3) end = true;
+        if (!end) {
+            uint64_t tk[4], tl[4];
+            int nb;
+            fm_2occ4(ix, x1 - 1, x1 - 1 + x2, tk, tl, nb);
+            blocks += nb;
+            int b = 3 - c;
+            uint64_t n2 = tl[b] - tk[b];
+            if (n2 == 0) end = true;
+            else {
+                // ok[3].x0 = ik.x0 + primary correction; lower bases stack on top (:143-146)
+                uint64_t n0 = x0 + ((x1 <= ix.primary && x1 + x2 - 1 >= ix.primary) ? 1 : 0);
+                for (int bb = 3; bb > b; bb--) n0 += tl[bb] - tk[bb];
+                x0 = n0; x1 = ix.L2[b] + 1 + tk[b]; x2 = n2;
+                p++;
+            }
+        }
+        if (end) {
+            int len = p - start;
+            ext_steps += len;
+            if (len >= kMinSeedLength && x2 <= (uint64_t)kOccThr) {
+                for (uint64_t i = 0; i < x2; i++) {
+                    if (n_hits < cap) { Hit h; h.gPos = (int64_t)(x0 + i); h.rPos = start; h.len = len; hits[n_hits] = h; }
+                    n_hits++;
+                }
+            }
+            p = p + 1;
+            active = false;
+        }
+    }
+    return n_hits;
+}
+
+} // namespace mcx
+#endif

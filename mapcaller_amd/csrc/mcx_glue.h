@@ -1,0 +1,823 @@
+// mapcaller_amd/csrc/mcx_glue.h — the per-pair logic between the FM-index walk and the DP
+// kernels, and after them: seed sorting, clustering, mate pairing, mate rescue, fragment
+// construction (which decides what DP jobs exist), post-DP gates, scoring, flags, MAPQ, CIGAR.
+//
+// In the reference this is host C++ over std::vector/std::string (ReadMapping.cpp,
+// ReadAlignment.cpp, AlignmentRescue.cpp, KmerAnalysis.cpp, SamReport.cpp, tools.cpp).  Here
+// it is allocation-free code over the fixed-capacity pair-state record (mcx_types.h), one pair
+// per lane, so that the whole path from reads to alignment records stays on the GPU.  Gapped
+// fragments are never materialised as strings: a fragment is (rPos,rLen,gPos,gLen,kind) plus,
+// for DP results, a column string of 'M'/'I'/'D' in the pair's ops pool; bases are fetched from
+// the encoded read and the 2-bit genome when a column has to be compared.
+//
+// Every function names the reference lines it replaces; results must be bit-identical.
+#ifndef MCX_GLUE_H
+#define MCX_GLUE_H
+#include "mcx_fm.h"
+
+namespace mcx {
+
+struct Ctx {
+    IndexView ix;
+    Params pm;
+    Caps caps;
+    Layout lay;
+    uint8_t *state;           // pair-state records
+    const uint8_t *mapq_tab;  // [(rlen_max+1) * 6]: EvaluateMAPQ for (score, score-sub in 1..5), host-computed
+    int32_t mapq_rows;
+};
+
+struct ReadRef {              // one read of the batch
+    const uint8_t *ascii;     // as given (mate 2 NOT yet flipped)
+    const uint8_t *codes;     // 0..4, mate 2 flipped
+    int32_t rlen;
+    int32_t flipped;
+};
+
+static inline MCX_HD int64_t hit_pd(const Hit &h) { return h.gPos - h.rPos; }
+
+// ------------------------------------------------------------------------------------------
+// seeds -> candidates
+// ------------------------------------------------------------------------------------------
+// tail of IdentifySimplePairs (ReadMapping.cpp:141-152): keep PosDiff > 0, sort by (PosDiff, rPos)
+static inline MCX_HD int prep_seeds(Hit *h, int n)
+{
+    int m = 0;
+    for (int i = 0; i < n; i++) if (hit_pd(h[i]) > 0) h[m++] = h[i];
+    for (int i = 1; i < m; i++) {
+        Hit key = h[i];
+        int64_t kpd = hit_pd(key);
+        int j = i - 1;
+        while (j >= 0) {
+            int64_t pd = hit_pd(h[j]);
+            if (pd > kpd || (pd == kpd && h[j].rPos > key.rPos)) { h[j + 1] = h[j]; j--; } else break;
+        }
+        h[j + 1] = key;
+    }
+    return m;
+}
+
+static inline MCX_HD int64_t boundary_of(const IndexView &ix, int64_t gPos) // GetAlignmentBoundary, tools.cpp:112-117
+{
+    int s = end_slot(ix, gPos);
+    return s < 0 ? -1 : ix.end_pos[s];
+}
+
+static inline MCX_HD void cand_init(Cand &c, int score, int first, int count, int64_t pd0)
+{
+    c.score = score; c.mate = -1; c.first = first; c.count = count; c.pd0 = pd0;
+    c.frag_off = 0; c.n_frags = 0; c.flag = 0; c.fwd = 1;
+}
+
+// SimplePairClustering (ReadMapping.cpp:194-226) with IdentifyClosestFragmentPairs (:160-192).
+// The terminal fragment pair the reference appends is index n here (gPos = PosDiff = 2G).
+static inline MCX_HD int cluster_seeds(const IndexView &ix, const Params &pm, int rlen, const Hit *h, int n,
+                                       Cand *out, int cap)
+{
+    if (n == 0) return 0;
+    int nc = 0, head = 0, score = h[0].len, thr = rlen >> 2;
+    int64_t g_end = boundary_of(ix, h[0].gPos);
+    for (int j = 1; j <= n; j++) {
+        int i = j - 1;
+        int64_t gj = j < n ? h[j].gPos : ix.G2, pdj = j < n ? hit_pd(h[j]) : ix.G2;
+        int64_t d = pdj - hit_pd(h[i]);
+        if (d < 0) d = -d;
+        if (gj > g_end || d > pm.max_pos_diff) {
+            if (score > thr) {
+                if (thr < (score >> 1)) thr = score >> 1;
+                int b = head, e = j, s = score;
+                if (score >= rlen) { // tandem repeats: best run of equal PosDiff
+                    int run_b = head, rs = h[head].len;
+                    s = 0; b = e = head;
+                    int k;
+                    for (k = head + 1; k < j; k++) {
+                        if (hit_pd(h[k]) != hit_pd(h[run_b])) {
+                            if (rs > s) { s = rs; b = run_b; e = k; }
+                            run_b = k; rs = h[k].len;
+                        } else rs += h[k].len;
+                    }
+                    if (rs > s) { s = rs; b = run_b; e = k; }
+                }
+                if (nc < cap) cand_init(out[nc], s, b, e - b, hit_pd(h[b]));
+                nc++;
+            }
+            head = j;
+            if (j < n) { g_end = boundary_of(ix, gj); score = h[j].len; }
+        } else score += h[j].len;
+    }
+    return nc;
+}
+
+static inline MCX_HD void keep_top_scores(Cand *c, int n) // RemoveRedundantAlnCan, ReadMapping.cpp:228-242
+{
+    if (n <= 1) return;
+    int best = 0;
+    for (int i = 0; i < n; i++) if (c[i].score > best) best = c[i].score;
+    for (int i = 0; i < n; i++) if (c[i].score < best) c[i].score = 0;
+}
+
+// CheckPairedAlignmentDistance (ReadMapping.cpp:244-303).  Also reports the interval of
+// EstiDistance values [lo, hi] for which every `myDist < EstiDistance` test, hence the whole
+// outcome, is unchanged — that is what lets a batch run ahead of the reference's per-chunk
+// avgDist feedback (ReadMapping.cpp:539) and still be replayed exactly.
+static inline MCX_HD int pair_by_distance(int64_t est, Cand *c1, int n1, Cand *c2, int n2, int &lo, int &hi)
+{
+    int64_t max_lt = -1, min_ge = 0x7fffffff;
+    if (n1 * n2 > 100) { keep_top_scores(c1, n1); keep_top_scores(c2, n2); }
+    int64_t top = 0;
+    for (int i = 0; i < n1; i++) {
+        c1[i].frag_off = -1; // scratch: chosen partner
+        if (c1[i].score == 0) continue;
+        int pick = -1, ps = 0;
+        for (int j = 0; j < n2; j++) {
+            if (c2[j].score == 0 || c2[j].pd0 < c1[i].pd0) continue;
+            int64_t d = c2[j].pd0 - c1[i].pd0;
+            if (d < est) {
+                if (d > max_lt) max_lt = d;
+                if (c2[j].score > ps) { pick = j; ps = c2[j].score; }
+            } else if (d < min_ge) min_ge = d;
+        }
+        c1[i].frag_off = pick;
+        if (pick >= 0) { int64_t s = (int64_t)c1[i].score + c2[pick].score; if (s > top) top = s; }
+    }
+    int paired = 0;
+    if (top > 0) {
+        for (int i = 0; i < n1; i++) {
+            int pick = c1[i].frag_off;
+            if (c1[i].score == 0 || pick < 0) continue;
+            if ((int64_t)c1[i].score + c2[pick].score == top) { paired++; c1[i].mate = pick; c2[pick].mate = i; }
+        }
+    }
+    for (int i = 0; i < n1; i++) c1[i].frag_off = 0;
+    lo = (int)(max_lt + 1);
+    hi = (int)min_ge;
+    return paired;
+}
+
+static inline MCX_HD void mask_unpaired(Cand *c1, int n1, Cand *c2, int n2) // MaskUnPairedAlnCan, ReadMapping.cpp:305-322
+{
+    int top = 0;
+    for (int i = 0; i < n1; i++)
+        if (c1[i].mate != -1 && top < c1[i].score + c2[c1[i].mate].score) top = c1[i].score + c2[c1[i].mate].score;
+    for (int i = 0; i < n1; i++)
+        if (c1[i].mate == -1 || c1[i].score + c2[c1[i].mate].score < top) c1[i].score = 0;
+    for (int j = 0; j < n2; j++)
+        if (c2[j].mate == -1 || c2[j].score + c1[c2[j].mate].score < top) c2[j].score = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// mate rescue (AlignmentRescue.cpp:28-111, KmerAnalysis.cpp:57-163)
+// ------------------------------------------------------------------------------------------
+// The reference sorts 8-mer lists and joins them; the join result, ordered by (PosDiff, rPos),
+// is exactly a scan of the (read position x window position) match matrix along diagonals, so
+// that is what is done here, on 8-mer ids laid out by position.
+#define MCX_NOKMER 0xFFFFFFFFu
+
+// the character the reference's k-mer builder sees at position i of a read
+static inline MCX_HD uint8_t read_char(const ReadRef &r, int i)
+{
+    if (!r.flipped) return r.ascii[i];
+    switch (r.ascii[r.rlen - 1 - i]) { // GetComplementaryBase, tools.cpp:3-18
+    case 'A': case 'a': return 'T';
+    case 'C': case 'c': return 'G';
+    case 'G': case 'g': return 'C';
+    case 'T': case 't': return 'A';
+    default: return 'N';
+    }
+}
+
+template <class GetCh>
+static inline MCX_HD void kmer_fill(GetCh ch, int len, uint32_t *out) // CreateKmerVecFromReadSeq, KmerAnalysis.cpp:57-103
+{
+    for (int i = 0; i < len; i++) out[i] = MCX_NOKMER;
+    uint32_t tail = 0, count = 0, head, wid;
+    while (count < (uint32_t)kKmerSize && tail < (uint32_t)len) { if (ch(tail++) != 'N') count++; else count = 0; }
+    if (count != (uint32_t)kKmerSize) return;
+    head = tail - kKmerSize;
+    wid = 0;
+    for (uint32_t i = head; i < head + kKmerSize; i++) wid = (wid << 2) + (uint32_t)nt4_code(ch(i));
+    out[head] = wid;
+    for (head += 1; tail < (uint32_t)len; head++, tail++) {
+        uint8_t c = ch(tail);
+        if (c != 'N') {
+            wid = ((wid & 0x3FFFu) << 2) + (uint32_t)nt4_code(c);
+            out[head] = wid;
+        } else {
+            count = 0; tail++;
+            while (count < (uint32_t)kKmerSize && tail < (uint32_t)len) { if (ch(tail++) != 'N') count++; else count = 0; }
+            if (count != (uint32_t)kKmerSize) break;
+            head = tail - kKmerSize;
+            wid = 0;
+            for (uint32_t i = head; i < head + kKmerSize; i++) wid = (wid << 2) + (uint32_t)nt4_code(ch(i));
+            out[head] = wid;
+        }
+    }
+}
+
+struct RescueOut { int score; int n_seeds; };
+
+// IdentifyCommonKmers + GenerateSimplePairsFromCommonKmers(thr=10) + IdentifyBestAlnCan for one
+// window: best diagonal's runs are appended to hits[] (capacity cap, current size n_hits).
+static inline MCX_HD RescueOut rescue_window(const uint32_t *kq, int qlen, const uint32_t *kg, int slen, int64_t base,
+                                             Hit *hits, int n_hits, int cap, bool &overflow)
+{
+    RescueOut best; best.score = 0; best.n_seeds = 0;
+    int best_d = 0;
+    bool have = false;
+    for (int pass = 0; pass < 2; pass++) {
+        int d_lo = pass == 0 ? -(qlen - 1) : best_d, d_hi = pass == 0 ? slen - 1 : best_d;
+        if (pass == 1 && !have) break;
+        for (int d = d_lo; d <= d_hi; d++) {
+            int r0 = d < 0 ? -d : 0, r1 = qlen - 1 < slen - 1 - d ? qlen - 1 : slen - 1 - d;
+            int total = 0, run = 0, run_start = 0, emitted = 0;
+            for (int r = r0; r <= r1 + 1; r++) {
+                bool m = r <= r1 && kq[r] != MCX_NOKMER && kq[r] == kg[r + d];
+                if (m) { if (run == 0) run_start = r; run++; }
+                else if (run > 0) {
+                    int l = kKmerSize + run - 1;
+                    if (l >= 10) {
+                        total += l;
+                        if (pass == 1) {
+                            if (n_hits + emitted < cap) {
+                                Hit h; h.rPos = run_start; h.gPos = (int64_t)(run_start + d) + base; h.len = l;
+                                hits[n_hits + emitted] = h;
+                            } else overflow = true;
+                            emitted++;
+                        }
+                    }
+                    run = 0;
+                }
+            }
+            if (pass == 0) { if (total > best.score) { best.score = total; best_d = d; have = true; } }
+            else best.n_seeds = emitted;
+        }
+    }
+    return best;
+}
+
+// AlignmentRescue (AlignmentRescue.cpp:28-111).  kq/kg: per-lane scratch of rlen_max and
+// caps.kmer_cap entries.  Windows that leave [0,2G) make the reference read outside RefSequence
+// (undefined behaviour, it crashes near the genome start); they are skipped.
+static inline MCX_HD int rescue_mate(const Ctx &cx, PairState &st, const ReadRef &r1, const ReadRef &r2, uint32_t est,
+                                     uint32_t *kq, uint32_t *kg)
+{
+    const IndexView &ix = cx.ix;
+    PairHdr &h = *st.hdr;
+    int n1 = h.n_cands[0], n2 = h.n_cands[1];
+    Cand *c1 = st.cands[0], *c2 = st.cands[1];
+    int s1 = 0, s2 = 0, paired = 0;
+    for (int i = 0; i < n1; i++) if (c1[i].score > s1) s1 = c1[i].score;
+    for (int i = 0; i < n2; i++) if (c2[i].score > s2) s2 = c2[i].score;
+    int mode;
+    if (s1 < (r1.rlen >> 2) && s2 < (r2.rlen >> 2)) return 0;
+    else if (s1 - s2 > (r2.rlen >> 2)) mode = 1;
+    else if (s2 - s1 > (r1.rlen >> 2)) mode = 2;
+    else mode = 3;
+    h.flags |= kRescueUsedEst;
+    for (int side = 0; side < 2; side++) {
+        if (side == 0 && !(mode == 1 || mode == 3)) continue;
+        if (side == 1 && !(mode == 2 || mode == 3)) continue;
+        // side 0: place read2 next to read1's candidates; side 1: the other way round
+        const ReadRef &rq = side == 0 ? r2 : r1;
+        Cand *ca = side == 0 ? c1 : c2, *cb = side == 0 ? c2 : c1;
+        int &na = side == 0 ? n1 : n2, &nb = side == 0 ? n2 : n1;
+        int sa = side == 0 ? s1 : s2, sb = side == 0 ? s2 : s1;
+        Hit *hb = st.hits[side == 0 ? 1 : 0];
+        int &nhb = h.n_hits[side == 0 ? 1 : 0];
+        int thr = sa >> 1, lim = na;
+        bool filled = false;
+        for (int ci = 0; ci < lim; ci++) {
+            Cand &c = ca[ci];
+            if (c.score < thr || c.mate != -1) continue;
+            int64_t left = side == 0 ? c.pd0 : c.pd0 - (int64_t)est;
+            int64_t right = side == 0 ? c.pd0 + est + rq.rlen : c.pd0 + rq.rlen;
+            if (right > ix.G2) right = ix.G2;
+            if (left < 0 || right >= ix.G2) continue;
+            int e1 = end_slot(ix, left), e2 = end_slot(ix, right);
+            if (e1 < 0 || e2 < 0 || ix.end_chr[e1] != ix.end_chr[e2]) continue;
+            int slen = (int)(right - left);
+            if (slen < rq.rlen) continue;
+            if (slen > cx.caps.kmer_cap) { h.flags |= kOvKmer; continue; }
+            if (!filled) { kmer_fill([&](uint32_t i) { return read_char(rq, (int)i); }, rq.rlen, kq); filled = true; }
+            kmer_fill([&](uint32_t i) { return (uint8_t)"ACGT"[ref_code(ix, left + i)]; }, slen, kg);
+            bool ov = false;
+            RescueOut ro = rescue_window(kq, rq.rlen, kg, slen, left, hb, nhb, cx.caps.hit_cap, ov);
+            if (ro.n_seeds == 0) continue;
+            if (ro.score > sb) {
+                if (ov) { h.flags |= kOvHits; continue; }
+                if (nb >= cx.caps.cand_cap) { h.flags |= kOvCands; continue; }
+                paired++;
+                c.mate = nb;
+                cand_init(cb[nb], ro.score, nhb, ro.n_seeds, hit_pd(hb[nhb]));
+                cb[nb].mate = ci;
+                nb++;
+                nhb += ro.n_seeds;
+            }
+        }
+    }
+    h.n_cands[0] = n1; h.n_cands[1] = n2;
+    return paired;
+}
+
+// ------------------------------------------------------------------------------------------
+// stage G1a: cluster both reads and pair them (ReadMapping.cpp:445-463)
+// ------------------------------------------------------------------------------------------
+static inline MCX_HD bool pair_needs_rescue(const PairHdr &h) { return h.n_paired == 0; }
+
+static inline MCX_HD void stage_cluster_pair(const Ctx &cx, int64_t pair, const ReadRef *rd, int est)
+{
+    PairState st = pair_state(cx.state, cx.lay, cx.caps, pair);
+    PairHdr &h = *st.hdr;
+    int nr = cx.pm.paired ? 2 : 1;
+    for (int s = 0; s < nr; s++) {
+        if (h.n_hits[s] > cx.caps.hit_cap) { h.flags |= kOvHits; h.n_hits[s] = 0; }
+        h.n_hits[s] = prep_seeds(st.hits[s], h.n_hits[s]);
+        int nc = cluster_seeds(cx.ix, cx.pm, rd[s].rlen, st.hits[s], h.n_hits[s], st.cands[s], cx.caps.cand_cap);
+        if (nc > cx.caps.cand_cap) { h.flags |= kOvCands; nc = 0; }
+        h.n_cands[s] = nc;
+        h.sum[s].best = -1; h.sum[s].score = 0; h.sum[s].sub = 0;
+    }
+    h.est = est; h.est_lo = 0; h.est_hi = 0x7fffffff; h.n_paired = 0;
+    if (cx.pm.paired && !(h.flags & kOvAny))
+        h.n_paired = pair_by_distance(est, st.cands[0], h.n_cands[0], st.cands[1], h.n_cands[1], h.est_lo, h.est_hi);
+}
+
+// stage R: mate rescue for pairs left unpaired (ReadMapping.cpp:463)
+static inline MCX_HD void stage_rescue(const Ctx &cx, int64_t pair, const ReadRef *rd, uint32_t *kq, uint32_t *kg)
+{
+    PairState st = pair_state(cx.state, cx.lay, cx.caps, pair);
+    PairHdr &h = *st.hdr;
+    if (!cx.pm.paired || (h.flags & kOvAny) || h.n_paired != 0) return;
+    h.n_paired = rescue_mate(cx, st, rd[0], rd[1], (uint32_t)h.est, kq, kg);
+}
+
+// ------------------------------------------------------------------------------------------
+// stage G1b: mask candidates, build fragment lists, decide DP jobs
+// (ReadMapping.cpp:469-470, ReadAlignment.cpp:306-342 up to and including ProcessNormalPair's
+// decision at :184)
+// ------------------------------------------------------------------------------------------
+static inline MCX_HD bool frag_before(const Frag &a, const Frag &b) // CompByReadPos, ReadAlignment.cpp:23-27
+{
+    return a.rPos == b.rPos ? a.gPos < b.gPos : a.rPos < b.rPos;
+}
+
+// builds the fragment list of one candidate at f[0..); returns the count, or -1 when the
+// alignment would span two chromosomes (CheckAlignmentValidity, tools.cpp:119-130)
+static inline MCX_HD int build_frags(const IndexView &ix, int rlen, const Hit *seeds, int n, Frag *f)
+{
+    for (int i = 0; i < n; i++) {
+        Frag x; x.gPos = seeds[i].gPos; x.rPos = seeds[i].rPos; x.rLen = x.gLen = seeds[i].len;
+        x.ops_off = 0; x.ops_len = 0; x.kind = kSimple; x.pad[0] = x.pad[1] = x.pad[2] = 0;
+        int j = i - 1;
+        while (j >= 0 && frag_before(x, f[j])) { f[j + 1] = f[j]; j--; } // sort by (rPos, gPos), :317
+        f[j + 1] = x;
+    }
+    // RemoveOverlaps (:38-65) then RemoveNullFragPairs (:29-36)
+    bool any = false;
+    for (int i = 0, j = 1; j < n; i++, j++) {
+        if (f[i].rPos == f[j].rPos) { any = true; f[i].rLen = f[i].gLen = 0; }
+        else if (f[i].gPos >= f[j].gPos || f[i].gPos + f[i].gLen > f[j].gPos) {
+            any = true;
+            int ov = (int)(f[i].gPos + f[i].gLen - f[j].gPos);
+            if ((f[i].rLen -= ov) < 0) f[i].rLen = 0;
+            if ((f[i].gLen -= ov) < 0) f[i].gLen = 0;
+        }
+    }
+    if (any) { int m = 0; for (int i = 0; i < n; i++) if (f[i].rLen != 0) f[m++] = f[i]; n = m; }
+    if (n == 0) return -1; // cannot happen for real seeds; treated as invalid
+    // IdentifyNormalPairs (:67-108): gap fragments between seeds and at both read ends.
+    // The reference appends and merges; gaps always sort between their neighbours, so the
+    // list is expanded in place from the back.
+    int gaps = 0;
+    for (int i = 0; i + 1 < n; i++) {
+        int rg = f[i + 1].rPos - (f[i].rPos + f[i].rLen);
+        int64_t gg = f[i + 1].gPos - (f[i].gPos + f[i].gLen);
+        if (rg > 0 || gg > 0) gaps++;
+    }
+    bool head = f[0].rPos > 0;
+    bool tail = f[n - 1].rPos + f[n - 1].rLen < rlen;
+    int total = n + gaps + (head ? 1 : 0) + (tail ? 1 : 0);
+    int w = total - 1;
+    Frag g; g.ops_off = 0; g.ops_len = 0; g.kind = kPlain; g.pad[0] = g.pad[1] = g.pad[2] = 0;
+    if (tail) {
+        g.rPos = f[n - 1].rPos + f[n - 1].rLen; g.gPos = f[n - 1].gPos + f[n - 1].gLen;
+        g.rLen = g.gLen = rlen - g.rPos;
+        f[w--] = g;
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        Frag cur = f[i];
+        f[w--] = cur;
+        if (i > 0) {
+            int rg = cur.rPos - (f[i - 1].rPos + f[i - 1].rLen); if (rg < 0) rg = 0;
+            int64_t gg = cur.gPos - (f[i - 1].gPos + f[i - 1].gLen); if (gg < 0) gg = 0;
+            if (rg > 0 || gg > 0) {
+                g.rPos = f[i - 1].rPos + f[i - 1].rLen; g.gPos = f[i - 1].gPos + f[i - 1].gLen;
+                g.rLen = rg; g.gLen = (int)gg;
+                f[w--] = g;
+            }
+        }
+    }
+    if (head) {
+        Frag &first = f[1];
+        g.rPos = 0; g.gPos = first.gPos - first.rPos; g.rLen = g.gLen = first.rPos;
+        f[0] = g;
+    }
+    // CheckAlignmentValidity
+    const Frag &a = f[0], &b = f[total - 1];
+    if (a.gPos < 0 || b.gPos + b.gLen > ix.G2) return -1;
+    int e1 = end_slot(ix, a.gPos), e2 = end_slot(ix, b.gPos + b.gLen - 1);
+    if (e1 < 0 || e2 < 0 || ix.end_pos[e1] != ix.end_pos[e2]) return -1;
+    return total;
+}
+
+// read / genome code of alignment-string position x of a fragment.  Reverse-strand fragments
+// (gPos >= G) have both strings reverse-complemented by the reference (ReadAlignment.cpp:179-183);
+// complementing both sides does not change any comparison, so only the reversal is applied.
+static inline MCX_HD int frag_read_code(const Frag &f, const uint8_t *codes, bool rev, int x)
+{
+    return codes[rev ? f.rPos + f.rLen - 1 - x : f.rPos + x];
+}
+static inline MCX_HD int frag_ref_code(const IndexView &ix, const Frag &f, bool rev, int y)
+{
+    return ref_code(ix, rev ? f.gPos + f.gLen - 1 - y : f.gPos + y);
+}
+
+struct JobSink {
+    DpJob *jobs;
+    uint32_t *count;
+    uint32_t cap;
+};
+
+static inline MCX_HD uint32_t sink_reserve(const JobSink &s, uint32_t n)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicAdd(s.count, n);
+#else
+    uint32_t o = *s.count; *s.count += n; return o;
+#endif
+}
+
+static inline MCX_HD void stage_build(const Ctx &cx, int64_t pair, const ReadRef *rd, const JobSink &sink)
+{
+    PairState st = pair_state(cx.state, cx.lay, cx.caps, pair);
+    PairHdr &h = *st.hdr;
+    h.n_frags = 0; h.n_ops = 0; h.n_jobs = 0;
+    if (h.flags & kOvAny) return;
+    int nr = cx.pm.paired ? 2 : 1;
+    if (cx.pm.paired) {
+        if (h.n_paired == 0) { keep_top_scores(st.cands[0], h.n_cands[0]); keep_top_scores(st.cands[1], h.n_cands[1]); }
+        else mask_unpaired(st.cands[0], h.n_cands[0], st.cands[1], h.n_cands[1]);
+    } else keep_top_scores(st.cands[0], h.n_cands[0]);
+
+    // local list of DP jobs of this pair (flushed to the global sink at the end)
+    int32_t *jl = (int32_t *)((uint8_t *)st.hdr + cx.lay.off_jobs);
+    int nj = 0;
+    for (int s = 0; s < nr; s++) {
+        Cand *cs = st.cands[s];
+        for (int ci = 0; ci < h.n_cands[s]; ci++) {
+            Cand &c = cs[ci];
+            c.n_frags = 0; c.frag_off = h.n_frags;
+            if (c.score == 0) continue;
+            if (h.n_frags + 2 * c.count + 2 > cx.caps.frag_cap) { h.flags |= kOvFrags; return; }
+            Frag *f = st.frags + h.n_frags;
+            int nf = build_frags(cx.ix, rd[s].rlen, st.hits[s] + c.first, c.count, f);
+            if (nf < 0) { c.score = 0; continue; }
+            c.n_frags = nf;
+            // ProcessNormalPair (:155-191): classify each gap fragment
+            for (int i = 0; i < nf; i++) {
+                Frag &x = f[i];
+                if (x.kind == kSimple) continue;
+                bool rev = x.gPos >= cx.ix.G;
+                if (x.rLen > 0 && x.gLen > 0) {
+                    bool dp = x.rLen != x.gLen;
+                    if (!dp) {
+                        int mm = 0;
+                        for (int k = 0; k < x.rLen; k++)
+                            if (frag_read_code(x, rd[s].codes, rev, k) != frag_ref_code(cx.ix, x, rev, k)) mm++;
+                        dp = mm > 1 && mm >= (int)(x.rLen * 0.2);
+                    }
+                    if (dp) {
+                        if (h.n_ops + x.rLen + x.gLen > cx.caps.ops_cap) { h.flags |= kOvOps; return; }
+                        if (nj >= cx.caps.job_cap) { h.flags |= kOvJobs; return; }
+                        x.kind = kDp; x.ops_off = h.n_ops; x.ops_len = 0;
+                        h.n_ops += x.rLen + x.gLen;
+                        jl[2 * nj] = h.n_frags + i; jl[2 * nj + 1] = s;
+                        nj++;
+                    } else { x.kind = kPlain; x.ops_len = x.rLen; }
+                } else if (x.rLen > 0) { x.kind = kIns; x.ops_len = x.rLen; }
+                else { x.kind = kDel; x.ops_len = x.gLen; }
+            }
+            h.n_frags += nf;
+        }
+    }
+    h.n_jobs = nj;
+    if (nj > 0) {
+        uint32_t base = sink_reserve(sink, (uint32_t)nj);
+        for (int k = 0; k < nj; k++) {
+            if (base + k >= sink.cap) break; // host checks count > cap and re-runs with a larger list
+            const Frag &x = st.frags[jl[2 * k]];
+            DpJob j;
+            j.pair = (uint32_t)pair; j.slot = (uint16_t)jl[2 * k + 1]; j.rev = x.gPos >= cx.ix.G ? 1 : 0;
+            j.rPos = x.rPos; j.rLen = x.rLen; j.gPos = x.gPos; j.gLen = x.gLen;
+            j.ops_off = x.ops_off; j.frag = jl[2 * k]; j.score = 0;
+            sink.jobs[base + k] = j;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// stage G2: post-DP gates, scores, best/sub-best, pair statistics, flags, MAPQ, CIGAR
+// ------------------------------------------------------------------------------------------
+// column x of a gap fragment: 'M' (both bases), 'I' (read base vs '-'), 'D' ('-' vs genome base)
+static inline MCX_HD uint8_t frag_op(const Frag &f, const uint8_t *ops, int x)
+{
+    switch (f.kind) {
+    case kPlain: return 'M';
+    case kIns: return 'I';
+    case kDel: return 'D';
+    default: return ops[f.ops_off + x];
+    }
+}
+
+// RemoveHeadingGaps (:264-283) / RemoveTailingGaps (:285-304)
+static inline MCX_HD void strip_end_gaps(Frag &f, const uint8_t *ops, bool leading, bool move_pos)
+{
+    if (f.kind != kDp) return; // only DP results can start or end with a gap column
+    int rs = 0, gs = 0, j = 0;
+    if (leading) {
+        for (; j < f.ops_len; j++) { uint8_t o = ops[f.ops_off + j]; if (o == 'D') gs++; else if (o == 'I') rs++; else break; }
+        if (j > 0) { f.ops_off += j; f.ops_len -= j; }
+    } else {
+        for (; j < f.ops_len; j++) { uint8_t o = ops[f.ops_off + f.ops_len - 1 - j]; if (o == 'D') gs++; else if (o == 'I') rs++; else break; }
+        if (j > 0) f.ops_len -= j;
+    }
+    if (j > 0) {
+        f.rLen -= rs; f.gLen -= gs;
+        if (move_pos) { f.rPos += rs; f.gPos += gs; }
+    }
+}
+
+struct ColStats { int switches, n, mis, match; };
+
+// one pass over the columns of a gap fragment: CheckLocalAlignmentQuality (:193-232),
+// EvaluateAlignmentScore (:234-245) and FindMisMatchNumber (:247-262) all read from it
+static inline MCX_HD ColStats frag_columns(const IndexView &ix, const Frag &f, const uint8_t *ops, const uint8_t *codes)
+{
+    ColStats cs; cs.switches = cs.n = cs.mis = cs.match = 0;
+    bool rev = f.gPos >= ix.G;
+    int kind = -1, ri = 0, gi = 0;
+    for (int x = 0; x < f.ops_len; x++) {
+        uint8_t o = frag_op(f, ops, x);
+        int k;
+        if (o == 'D') { k = 0; gi++; }
+        else if (o == 'I') { k = 1; ri++; }
+        else {
+            k = 2; cs.n++;
+            if (frag_read_code(f, codes, rev, ri) != frag_ref_code(ix, f, rev, gi)) cs.mis++; else cs.match++;
+            ri++; gi++;
+        }
+        if (k != kind) { kind = k; cs.switches++; }
+    }
+    return cs;
+}
+
+static inline MCX_HD bool quality_ok(const ColStats &c)
+{
+    return !(c.switches >= 4 || (c.mis >= 3 && c.mis >= (int)(c.n * 0.3)));
+}
+
+// ProduceReadAlignment from :336 on, for one read
+static inline MCX_HD void extend_read(const Ctx &cx, PairState &st, int s, const ReadRef &rd)
+{
+    const IndexView &ix = cx.ix;
+    PairHdr &h = *st.hdr;
+    ReadSum &sum = h.sum[s];
+    int max_mm = (int)(rd.rlen * cx.pm.max_mm_rate);
+    int min_score = (int)(rd.rlen * (1 - cx.pm.max_mm_rate));
+    Cand *cs = st.cands[s];
+    for (int ci = 0; ci < h.n_cands[s]; ci++) {
+        Cand &c = cs[ci];
+        if (c.score == 0) continue;
+        Frag *f = st.frags + c.frag_off;
+        int num = c.n_frags, last = num - 1;
+        bool head_ok = true, tail_ok = true;
+        int score = 0, mism = 0;
+        bool dead = false;
+        for (int i = 0; i < num; i++) {
+            Frag &x = f[i];
+            if (x.kind == kSimple) { score += x.rLen; continue; }
+            bool fwd = x.gPos < ix.G;
+            if (i == 0) {
+                strip_end_gaps(x, st.ops, fwd, true);
+                ColStats q = frag_columns(ix, x, st.ops, rd.codes);
+                if (x.ops_len >= kMinAlnBlockSize && !quality_ok(q)) {
+                    head_ok = false;
+                    x.rLen = x.gLen = 0; x.ops_len = 0; x.kind = kEmpty;
+                    x.rPos = f[i + 1].rPos; x.gPos = f[i + 1].gPos;
+                } else { score += q.match; mism += q.mis; }
+            } else if (i == last) {
+                strip_end_gaps(x, st.ops, !fwd, false);
+                ColStats q = frag_columns(ix, x, st.ops, rd.codes);
+                if (x.ops_len >= kMinAlnBlockSize && !quality_ok(q)) {
+                    tail_ok = false;
+                    x.rLen = x.gLen = 0; x.ops_len = 0; x.kind = kEmpty;
+                    x.rPos = f[i - 1].rPos + f[i - 1].rLen; x.gPos = f[i - 1].gPos + f[i - 1].gLen;
+                } else { score += q.match; mism += q.mis; }
+            } else {
+                ColStats q = frag_columns(ix, x, st.ops, rd.codes);
+                if (x.rLen >= kMinAlnBlockSize && x.gLen >= kMinAlnBlockSize && !quality_ok(q)) { dead = true; break; }
+                score += q.match; mism += q.mis;
+            }
+        }
+        if (dead || (!head_ok && !tail_ok)) { c.score = 0; continue; }
+        c.score = score;
+        if (score == 0) continue;
+        if (score < min_score && mism > max_mm) { c.score = 0; continue; }
+        c.fwd = f[0].gPos < ix.G ? 1 : 0;
+        if (!c.fwd) for (int a = 0, b = num - 1; a < b; a++, b--) { Frag t = f[a]; f[a] = f[b]; f[b] = t; }
+        if (score > sum.score) { sum.score = score; sum.best = ci; }
+        else if (score > sum.sub) sum.sub = score;
+    }
+    for (int ci = 0; ci < h.n_cands[s]; ci++) if (cs[ci].score < sum.score) cs[ci].score = 0;
+}
+
+struct Coord { int64_t pos; int32_t chr; };
+
+static inline MCX_HD Coord to_coord(const IndexView &ix, int64_t g) // DetermineCoordinate, tools.cpp:132-164
+{
+    Coord c;
+    if (g < ix.G) {
+        if (ix.n_chr == 1) { c.chr = 0; c.pos = g + 1; }
+        else { int s = end_slot(ix, g); c.chr = ix.end_chr[s]; c.pos = g + 1 - ix.chr_fwd[c.chr]; }
+    } else {
+        if (ix.n_chr == 1) { c.chr = 0; c.pos = ix.G2 - g; }
+        else { int s = end_slot(ix, g); c.chr = ix.end_chr[s]; c.pos = ix.end_pos[s] - g + 1; }
+    }
+    return c;
+}
+
+static inline MCX_HD Coord aln_coord(const IndexView &ix, const Cand &c, const Frag *frags) // GetAlnCoordinate, SamReport.cpp:121-149
+{
+    Coord k; k.pos = 0; k.chr = 0;
+    const Frag *f = frags + c.frag_off;
+    for (int i = 0; i < c.n_frags; i++)
+        if (f[i].gLen > 0) return to_coord(ix, c.fwd ? f[i].gPos : f[i].gPos + f[i].gLen - 1);
+    return k;
+}
+
+static inline MCX_HD int mapq_of(const Ctx &cx, const ReadSum &r) // EvaluateMAPQ, SamReport.cpp:86-101
+{
+    if (r.score == 0 || r.score == r.sub) return 0;
+    if (r.sub == 0 || r.score - r.sub > 5) return 60;
+    int row = r.score < cx.mapq_rows ? r.score : cx.mapq_rows - 1;
+    return cx.mapq_tab[row * 6 + (r.score - r.sub)];
+}
+
+// GenerateCIGARstring (SamReport.cpp:172-316) as BAM-style (len << 4 | op) words; op codes
+// M=0 I=1 D=2 S=4.  Returns the number of words needed (may exceed cap).
+static inline MCX_HD int cigar_of(int rlen, const Cand &c, const Frag *frags, const uint8_t *ops, uint32_t *out, int cap)
+{
+    const Frag *v = frags + c.frag_off;
+    int num = c.n_frags, n = 0, run = 0, st = -1;
+    auto put = [&](int len, int op) { if (n < cap) out[n] = ((uint32_t)len << 4) | (uint32_t)op; n++; };
+    auto flush_to = [&](int ns) { if (st != ns) { if (run > 0) put(run, st); st = ns; run = 0; } };
+    if (v[0].kind != kSimple) {
+        int clip = c.fwd ? v[0].rPos : rlen - (v[0].rPos + v[0].rLen);
+        if (clip > 0) put(clip, 4);
+    }
+    for (int i = 0; i < num; i++) {
+        const Frag &f = v[i];
+        if (f.kind == kSimple) { flush_to(0); run += f.rLen; }
+        else if (f.kind == kEmpty) continue;
+        else if (f.ops_len > 0) {
+            for (int x = 0; x < f.ops_len; x++) {
+                uint8_t o = frag_op(f, ops, x);
+                flush_to(o == 'D' ? 2 : (o == 'I' ? 1 : 0));
+                run++;
+            }
+        } else if (f.rLen > 0) { flush_to(1); run += f.rLen; }
+        else if (f.gLen > 0) { flush_to(2); run += f.gLen; }
+    }
+    if (run > 0) put(run, st);
+    int i = num - 1;
+    if (i > 0 && v[i].kind != kSimple) {
+        int clip = c.fwd ? rlen - (v[i].rPos + v[i].rLen) : v[i].rPos;
+        if (clip > 0) put(clip, 4);
+    }
+    return n;
+}
+
+// SetPairedAlignmentFlag (SamReport.cpp:26-84) for one candidate
+static inline MCX_HD int paired_flag(const Cand &c, const Cand *other, bool first, bool unique_branch)
+{
+    int fl = first ? 0x41 : 0x81;
+    if (first) fl |= c.fwd ? 0x20 : 0x10; else fl |= c.fwd ? 0x10 : 0x20;
+    if (c.mate != -1 && other[c.mate].score > 0) fl |= 0x2;
+    else {
+        if (unique_branch) { if (first) fl |= c.fwd ? 0x10 : 0x20; else fl |= c.fwd ? 0x20 : 0x10; }
+        fl |= 0x8;
+    }
+    return fl;
+}
+
+// GenCoordinatePair (ReadMapping.cpp:361-394) + the counting at :479-531
+static inline MCX_HD void pair_stats(const Ctx &cx, PairState &st)
+{
+    PairHdr &h = *st.hdr;
+    const Cand *c1 = st.cands[0], *c2 = st.cands[1];
+    int n1 = h.n_cands[0], n2 = h.n_cands[1];
+    int64_t dist = 0, g1 = 0, g2 = 0;
+    for (int i = 0; i < n1; i++) {
+        const Cand &c = c1[i];
+        if (c.score > 0 && c.mate != -1 && c2[c.mate].score > 0) {
+            g1 = st.frags[c.frag_off].gPos; g2 = st.frags[c2[c.mate].frag_off].gPos;
+            dist = g2 > g1 ? g2 - g1 : g1 - g2;
+            break;
+        }
+    }
+    if (dist == 0) {
+        int a = 0, b = 0;
+        int64_t ga = 0, gb = 0;
+        for (int i = 0; i < n1; i++) if (c1[i].score > 0) { if (a == 0) ga = st.frags[c1[i].frag_off].gPos; a++; }
+        for (int i = 0; i < n2; i++) if (c2[i].score > 0) { if (b == 0) gb = st.frags[c2[i].frag_off].gPos; b++; }
+        if (a == 1 && b == 1) { g1 = ga; g2 = gb; dist = g2 > g1 ? g2 - g1 : g1 - g2; }
+        else if (a == 0 && b >= 1) { g1 = -1; dist = g2 = gb; }
+        else if (a >= 1 && b == 0) { dist = g1 = ga; g2 = -1; }
+    }
+    h.pair_ok = 0; h.pair_dist = 0;
+    if (dist != 0 && g1 != -1 && g2 != -1) {
+        const int64_t G = cx.ix.G;
+        bool inv = (g1 < G && g2 >= G) || (g1 >= G && g2 < G);
+        if (!inv && dist <= kMinTranslocationSize) { h.pair_ok = 1; h.pair_dist = (int)dist; }
+    }
+}
+
+// one output record: the line GeneratePairedSamStream / GenerateSingleSamStream print for this
+// read in unique mode (SamReport.cpp:324-488)
+static inline MCX_HD void emit_record(const Ctx &cx, PairState &st, int s, const ReadRef *rd, AlnRec &out,
+                                      uint32_t *cig, int cig_cap)
+{
+    PairHdr &h = *st.hdr;
+    const ReadSum &me = h.sum[s];
+    out.pos = 0; out.mate_pos = 0; out.chr = -1; out.flag = 0; out.mapq = 0; out.tlen = 0;
+    out.nm = 0; out.as = 0; out.xs = 0; out.n_cigar = 0; out.fwd = 1; out.has_mate = 0;
+    const bool paired = cx.pm.paired != 0;
+    if (me.score == 0) {
+        if (!paired) { out.flag = 4; return; }
+        const ReadSum &ot = h.sum[1 - s];
+        int fl = 0x1 | 0x4 | (s == 0 ? 0x40 : 0x80);
+        if (ot.score == 0) fl |= 0x8;
+        else if (h.n_cands[1 - s] > 0) fl |= 0x30; // both strand bits, SamReport.cpp:401-402 / :449-450
+        out.flag = fl;
+        return;
+    }
+    Cand &c = st.cands[s][me.best];
+    if (paired) {
+        const Cand *oc = st.cands[1 - s];
+        // flags are set for every surviving candidate when the best score is tied; the line
+        // printed in unique mode is the first one, candidate `best`
+        c.flag = paired_flag(c, oc, s == 0, me.score > me.sub);
+    } else c.flag = c.fwd ? 0 : 0x10; // SetSingledAlignmentFlag, SamReport.cpp:7-24
+    out.flag = c.flag;
+    out.mapq = mapq_of(cx, me);
+    Coord km = aln_coord(cx.ix, c, st.frags);
+    out.chr = km.chr; out.pos = km.pos;
+    out.fwd = c.fwd;
+    out.nm = rd[s].rlen - c.score; out.as = me.score; out.xs = me.sub;
+    int nc = cigar_of(rd[s].rlen, c, st.frags, st.ops, cig, cig_cap);
+    if (nc > cig_cap) { h.flags |= kOvCigar; nc = 0; }
+    out.n_cigar = nc;
+    if (paired) {
+        const ReadSum &ot = h.sum[1 - s];
+        int j = c.mate;
+        if (j != -1 && ot.score > 0 && st.cands[1 - s][j].score == ot.score) {
+            const Cand &o = st.cands[1 - s][j];
+            Coord ko = aln_coord(cx.ix, o, st.frags);
+            // TLEN is defined from read 1's side and negated for read 2 (SamReport.cpp:428, :475)
+            const Cand &cand1 = s == 0 ? c : o;
+            int64_t p1 = s == 0 ? km.pos : ko.pos, p2 = s == 0 ? ko.pos : km.pos;
+            int dist = (int)(p2 - p1 + (cand1.fwd ? rd[1].rlen : 0 - rd[0].rlen));
+            out.tlen = s == 0 ? dist : 0 - dist;
+            out.mate_pos = ko.pos;
+            out.has_mate = 1;
+        }
+    }
+}
+
+static inline MCX_HD void stage_finish(const Ctx &cx, int64_t pair, const ReadRef *rd, AlnRec *recs, uint32_t *cigars)
+{
+    PairState st = pair_state(cx.state, cx.lay, cx.caps, pair);
+    PairHdr &h = *st.hdr;
+    int nr = cx.pm.paired ? 2 : 1;
+    if (h.flags & kOvAny) return;
+    h.mapped = 0;
+    for (int s = 0; s < nr; s++) { extend_read(cx, st, s, rd[s]); if (h.sum[s].score > 0) h.mapped++; }
+    if (cx.pm.paired) pair_stats(cx, st); else { h.pair_ok = 0; h.pair_dist = 0; }
+    for (int s = 0; s < nr; s++) {
+        int64_t r = pair * nr + s;
+        emit_record(cx, st, s, rd, recs[r], cigars + r * cx.caps.cig_cap, cx.caps.cig_cap);
+    }
+}
+
+} // namespace mcx
+#endif

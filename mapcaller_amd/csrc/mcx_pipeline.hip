@@ -1,0 +1,894 @@
+// mapcaller_amd/csrc/mcx_pipeline.hip — HIP kernels, the batch pipeline and the C ABI.
+//
+// One batch of reads goes through (all on one stream, no host round trip inside a tier):
+//   k_encode   ASCII -> 0..4 codes, mate 2 reverse-complemented        (ReadMapping.cpp:447,451)
+//   k_seed     FM-index walk, one read per lane -> BWT rows of hits    (IdentifySimplePairs/BWT_Search)
+//   k_sa       one hit per lane: BWT row -> text position              (bwt_sa)
+//   k_cluster  one pair per lane: sort, cluster, pair by distance      (SimplePairClustering, CheckPairedAlignmentDistance)
+//   k_rescue   unpaired pairs only: 8-mer mate rescue                  (AlignmentRescue)
+//   k_build    mask, fragment lists, DP job emission                   (ProduceReadAlignment up to ProcessNormalPair)
+//   k_dp<K>    one wavefront per DP job                                (ksw2_alignment / nw_alignment)
+//   k_finish   gates, scores, pair stats, flags, MAPQ, CIGAR, records  (ProduceReadAlignment tail, SamReport.cpp)
+// Pairs that overflow the tier-0 pair-state capacities are re-run in tier 1 (hard bounds).
+// The host then replays the reference's per-chunk avgDist feedback over the per-pair validity
+// intervals and re-runs only the pairs whose decision depends on the exact estimate.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mcx.h"
+#include "mcx_dp.h"
+#include "mcx_host.h"
+
+using namespace mcx;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(MCX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+extern "C" const char *mcx_last_error(void) { return g_err.c_str(); }
+extern "C" int mcx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// index
+// ---------------------------------------------------------------------------------------------
+struct mcx_index {
+    IndexView view;
+    HostIndex host;
+    int device = 0;
+    void *d_bwt = nullptr, *d_sa = nullptr, *d_sa_full = nullptr, *d_pac = nullptr;
+    void *d_end_pos = nullptr, *d_end_chr = nullptr, *d_chr_fwd = nullptr;
+    int64_t hbm_bytes = 0;
+};
+
+// Expands the sampled suffix array: the chain of LF steps that starts at a sampled row visits
+// exactly the rows whose bwt_sa() walk ends at the next sampled row, with values one lower per
+// step (SA[LF(k)] = SA[k] - 1).  One chain per lane, ~32 dependent block fetches each.
+__global__ void k_expand_sa(IndexView ix, uint64_t n_sa, uint64_t *full)
+{
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_sa) return;
+    uint64_t k = j * (uint64_t)ix.sa_intv;
+    uint64_t val = j == 0 ? ix.seq_len : ix.sa[j];
+    full[k] = j == 0 ? ~0ull : val;
+    const uint64_t mask = (uint64_t)ix.sa_intv - 1;
+    for (;;) {
+        k = fm_lf(ix, k);
+        val -= 1;
+        if ((k & mask) == 0) break;
+        full[k] = val;
+    }
+}
+
+static int upload(void **dst, const void *src, size_t bytes, size_t pad, int64_t &acc)
+{
+    HIP_TRY(hipMalloc(dst, bytes + pad));
+    if (pad) HIP_TRY(hipMemset((uint8_t *)*dst + bytes, 0, pad));
+    HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    acc += (int64_t)(bytes + pad);
+    return 0;
+}
+
+static int index_to_device(mcx_index *ix, int full_sa)
+{
+    HostIndex &h = ix->host;
+    int rc;
+    if ((rc = upload(&ix->d_bwt, h.bwt.data(), h.bwt.size() * 4, 128, ix->hbm_bytes))) return rc;
+    if ((rc = upload(&ix->d_sa, h.sa.data(), h.sa.size() * 8, 0, ix->hbm_bytes))) return rc;
+    if ((rc = upload(&ix->d_pac, h.pac.data(), h.pac.size(), 16, ix->hbm_bytes))) return rc;
+    if ((rc = upload(&ix->d_end_pos, h.end_pos.data(), h.end_pos.size() * 8, 0, ix->hbm_bytes))) return rc;
+    if ((rc = upload(&ix->d_end_chr, h.end_chr.data(), h.end_chr.size() * 4, 0, ix->hbm_bytes))) return rc;
+    if ((rc = upload(&ix->d_chr_fwd, h.chr_fwd.data(), h.chr_fwd.size() * 8, 0, ix->hbm_bytes))) return rc;
+    IndexView &v = ix->view;
+    v.bwt = (const uint32_t *)ix->d_bwt; v.sa = (const uint64_t *)ix->d_sa; v.sa_full = nullptr;
+    v.pac = (const uint8_t *)ix->d_pac;
+    v.end_pos = (const int64_t *)ix->d_end_pos; v.end_chr = (const int32_t *)ix->d_end_chr;
+    v.chr_fwd = (const int64_t *)ix->d_chr_fwd;
+    v.primary = h.primary; for (int i = 0; i < 5; i++) v.L2[i] = h.L2[i];
+    v.seq_len = h.seq_len; v.G = h.G; v.G2 = 2 * h.G;
+    v.n_ends = (int32_t)h.end_pos.size(); v.n_chr = (int32_t)h.chr_len.size(); v.sa_intv = h.sa_intv;
+    if (full_sa) {
+        size_t bytes = (size_t)(h.seq_len + 1) * 8;
+        HIP_TRY(hipMalloc(&ix->d_sa_full, bytes));
+        ix->hbm_bytes += (int64_t)bytes;
+        uint64_t n_sa = h.sa.size();
+        k_expand_sa<<<(unsigned)((n_sa + 255) / 256), 256>>>(v, n_sa, (uint64_t *)ix->d_sa_full);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        v.sa_full = (const uint64_t *)ix->d_sa_full;
+    }
+    return 0;
+}
+
+extern "C" int mcx_index_load(const char *prefix, int device, int full_sa, mcx_index **out)
+{
+    if (!prefix || !out) return fail(MCX_ERR_ARG, "mcx_index_load: null argument");
+    mcx_index *ix = new mcx_index();
+    std::string err;
+    if (!host_index_load(prefix, ix->host, err)) { delete ix; return fail(MCX_ERR_IO, err); }
+    ix->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { delete ix; return fail(MCX_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e)); }
+    int rc = index_to_device(ix, full_sa);
+    if (rc) { mcx_index_free(ix); return rc; }
+    *out = ix;
+    return 0;
+}
+
+extern "C" void mcx_index_free(mcx_index *ix)
+{
+    if (!ix) return;
+    void *p[] = {ix->d_bwt, ix->d_sa, ix->d_sa_full, ix->d_pac, ix->d_end_pos, ix->d_end_chr, ix->d_chr_fwd};
+    for (void *q : p) if (q) (void)hipFree(q);
+    delete ix;
+}
+extern "C" int64_t mcx_index_genome_size(const mcx_index *ix) { return ix->host.G; }
+extern "C" int32_t mcx_index_n_chr(const mcx_index *ix) { return (int32_t)ix->host.chr_len.size(); }
+extern "C" const char *mcx_index_chr_name(const mcx_index *ix, int32_t i) { return ix->host.chr_name[i].c_str(); }
+extern "C" int32_t mcx_index_chr_len(const mcx_index *ix, int32_t i) { return ix->host.chr_len[i]; }
+extern "C" int64_t mcx_index_hbm_bytes(const mcx_index *ix) { return ix->hbm_bytes; }
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+struct PairSel {             // which pairs a launch works on
+    const uint32_t *ids;     // batch pair id per local index (null: identity)
+    const int32_t *est;      // EstiDistance per local index
+    uint32_t n;
+};
+
+static __device__ __forceinline__ uint32_t sel_pair(const PairSel &s, uint32_t local) { return s.ids ? s.ids[local] : local; }
+
+static __device__ __forceinline__ void make_reads(const Ctx &cx, const ReadBatch &rb, uint32_t pair, ReadRef rd[2])
+{
+    const int nr = cx.pm.paired ? 2 : 1;
+    for (int s = 0; s < nr; s++) {
+        uint32_t r = pair * nr + s;
+        rd[s].ascii = rb.bases + rb.off[r];
+        rd[s].codes = rb.codes + rb.off[r];
+        rd[s].rlen = (int32_t)(rb.off[r + 1] - rb.off[r]);
+        rd[s].flipped = (cx.pm.paired && s == 1) ? 1 : 0;
+    }
+}
+
+__global__ void k_encode(ReadBatch rb, int paired)
+{
+    // one wave per read: coalesced in, coalesced out
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t r = wave; r < rb.n_reads; r += n_waves) {
+        const uint32_t o = rb.off[r], len = rb.off[r + 1] - o;
+        const bool flip = paired && (r & 1);
+        for (uint32_t i = lane; i < len; i += 64) {
+            int c = nt4_code(rb.bases[o + (flip ? len - 1 - i : i)]);
+            if (flip && c < 4) c = 3 - c;
+            rb.codes[o + i] = (uint8_t)c;
+        }
+    }
+}
+
+struct SeedOut {
+    uint2 *tasks;            // (local read, hit index) per hit to resolve
+    uint32_t *n_tasks;
+    uint32_t task_cap;
+    uint32_t *read_ext;      // per batch read: extension steps, blocks touched
+    uint32_t *read_blocks;
+};
+
+__global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel, SeedOut so)
+{
+    const int nr = cx.pm.paired ? 2 : 1;
+    const uint32_t lr = blockIdx.x * blockDim.x + threadIdx.x; // local read
+    if (lr >= sel.n * nr) return;
+    const uint32_t local = lr / nr, s = lr % nr;
+    const uint32_t pair = sel_pair(sel, local), r = pair * nr + s;
+    PairState st = pair_state(cx.state, cx.lay, cx.caps, local);
+    const uint32_t o = rb.off[r];
+    const int rlen = (int)(rb.off[r + 1] - o);
+    int64_t ext = 0, blocks = 0;
+    const int n = seed_read(cx.ix, rb.codes + o, rlen, st.hits[s], cx.caps.hit_cap, ext, blocks);
+    st.hdr->n_hits[s] = n;
+    so.read_ext[r] = (uint32_t)ext; so.read_blocks[r] = (uint32_t)blocks;
+    const int keep = n <= cx.caps.hit_cap ? n : 0; // overflowing reads are re-run in the next tier
+    if (keep > 0) {
+        const uint32_t base = atomicAdd(so.n_tasks, (uint32_t)keep);
+        for (int i = 0; i < keep; i++)
+            if (base + i < so.task_cap) so.tasks[base + i] = make_uint2(lr, (uint32_t)i);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sa(Ctx cx, SeedOut so, int paired, uint32_t *lf_total)
+{
+    const uint32_t n = min(*so.n_tasks, so.task_cap);
+    const int nr = paired ? 2 : 1;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        const uint2 task = so.tasks[t];
+        PairState st = pair_state(cx.state, cx.lay, cx.caps, task.x / nr);
+        Hit &h = st.hits[task.x % nr][task.y];
+        int lf = 0;
+        h.gPos = (int64_t)fm_sa(cx.ix, (uint64_t)h.gPos, lf);
+        if (lf_total && lf) atomicAdd(lf_total, (uint32_t)lf);
+    }
+}
+
+struct RescueList { uint32_t *ids; uint32_t *n; uint32_t cap; };
+
+__global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl)
+{
+    const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+    if (local >= sel.n) return;
+    ReadRef rd[2];
+    make_reads(cx, rb, sel_pair(sel, local), rd);
+    PairState st = pair_state(cx.state, cx.lay, cx.caps, local);
+    st.hdr->flags = 0;
+    stage_cluster_pair(cx, local, rd, sel.est[local]);
+    if (cx.pm.paired && !(st.hdr->flags & kOvAny) && st.hdr->n_paired == 0) {
+        const uint32_t at = atomicAdd(rl.n, 1u);
+        if (at < rl.cap) rl.ids[at] = local;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_rescue(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl, uint32_t *scratch,
+                                               uint32_t per_thread, uint32_t rlen_max)
+{
+    const uint32_t n = min(*rl.n, rl.cap);
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t *kq = scratch + (uint64_t)tid * per_thread, *kg = kq + rlen_max;
+    for (uint32_t i = tid; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t local = rl.ids[i];
+        ReadRef rd[2];
+        make_reads(cx, rb, sel_pair(sel, local), rd);
+        stage_rescue(cx, local, rd, kq, kg);
+    }
+}
+
+struct JobSinks { JobSink s[3]; };
+
+__global__ void __launch_bounds__(256) k_build(Ctx cx, ReadBatch rb, PairSel sel, JobSinks sinks)
+{
+    const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+    if (local >= sel.n) return;
+    ReadRef rd[2];
+    make_reads(cx, rb, sel_pair(sel, local), rd);
+    // jobs are emitted into one list here and split by size class below
+    stage_build(cx, local, rd, sinks.s[0]);
+}
+
+// moves the jobs of list 0 that need more than 64 / 256 target columns to lists 1 / 2
+__global__ void k_split_jobs(JobSinks sinks, uint32_t *unsupported)
+{
+    const uint32_t n = min(*sinks.s[0].count, sinks.s[0].cap);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        DpJob &j = sinks.s[0].jobs[i];
+        int cls = j.gLen <= 64 ? 0 : (j.gLen <= 256 ? 1 : 2);
+        if (j.gLen > 1024 || j.rLen > 2048) { atomicAdd(unsupported, 1u); j.rLen = 0; continue; }
+        if (cls == 0) continue;
+        const uint32_t at = atomicAdd(sinks.s[cls].count, 1u);
+        if (at < sinks.s[cls].cap) sinks.s[cls].jobs[at] = j;
+        j.rLen = 0; // tombstone in list 0
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(64) k_dp_sel(Ctx cx, JobSink sink, ReadBatch rb, PairSel sel, uint8_t *scratch,
+                                               uint64_t scratch_stride, uint32_t *cells)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kDpLdsSeq + kDpLdsDir];
+    uint8_t *spill = scratch + (uint64_t)blockIdx.x * scratch_stride;
+    const int nr = cx.pm.paired ? 2 : 1;
+    const int lane = threadIdx.x;
+    const uint32_t n = min(*sink.count, sink.cap);
+    for (uint32_t jb = blockIdx.x; jb < n; jb += gridDim.x) {
+        const DpJob job = sink.jobs[jb];
+        if (job.rLen == 0) continue; // moved to another size class (block-uniform)
+        const uint32_t read = sel_pair(sel, job.pair) * nr + job.slot;
+        const uint8_t *codes = rb.codes + rb.off[read];
+        const DpBuf b = dp_buffers(job.rLen, job.gLen, lds, spill);
+        // q = read fragment, t = genome fragment; both reversed on the reverse strand (the
+        // reference also complements both, which no comparison can see)
+        for (int i = lane; i < job.rLen; i += 64) b.q[i] = codes[job.rev ? job.rPos + job.rLen - 1 - i : job.rPos + i];
+        for (int i = lane; i < job.gLen; i += 64) b.t[i] = (uint8_t)ref_code(cx.ix, job.rev ? job.gPos + job.gLen - 1 - i : job.gPos + i);
+        __syncthreads();
+        PairState st = pair_state(cx.state, cx.lay, cx.caps, job.pair);
+        int score = 0;
+        const int w = dp_core<K>(cx.pm.use_nw != 0, job.rLen, job.gLen, b, st.ops + job.ops_off, &score);
+        if (lane == 0) {
+            Frag &f = st.frags[job.frag];
+            f.ops_off = job.ops_off + w;
+            f.ops_len = job.rLen + job.gLen - w;
+            sink.jobs[jb].score = score;
+            if (cells) atomicAdd(cells, (uint32_t)(job.rLen * job.gLen));
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) k_finish(Ctx cx, ReadBatch rb, PairSel sel, AlnRec *recs, uint32_t *cigars,
+                                                PairOut *pout, uint32_t *ov_ids, uint32_t *n_ov, uint32_t ov_cap)
+{
+    const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+    if (local >= sel.n) return;
+    const uint32_t pair = sel_pair(sel, local);
+    ReadRef rd[2];
+    make_reads(cx, rb, pair, rd);
+    PairState st = pair_state(cx.state, cx.lay, cx.caps, local);
+    // records are indexed by batch read; stage_finish indexes by pair*nr+s, so offset the bases
+    const int nr = cx.pm.paired ? 2 : 1;
+    AlnRec *r0 = recs + (int64_t)pair * nr - (int64_t)local * nr;
+    uint32_t *c0 = cigars + ((int64_t)pair * nr - (int64_t)local * nr) * cx.caps.cig_cap;
+    stage_finish(cx, local, rd, r0, c0);
+    const PairHdr &h = *st.hdr;
+    PairOut o;
+    o.flags = h.flags; o.est = h.est; o.est_lo = h.est_lo; o.est_hi = h.est_hi;
+    o.pair_dist = h.pair_dist; o.pair_ok = (int16_t)h.pair_ok; o.mapped = (int16_t)h.mapped;
+    pout[pair] = o;
+    if (h.flags & kOvAny) {
+        const uint32_t at = atomicAdd(n_ov, 1u);
+        if (at < ov_cap) ov_ids[at] = pair;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+struct Tier {
+    Caps caps;
+    Layout lay;
+    uint8_t *state = nullptr;
+    uint32_t max_pairs = 0;
+};
+
+enum { CNT_TASKS = 0, CNT_RESCUE, CNT_JOB0, CNT_JOB1, CNT_JOB2, CNT_OV, CNT_LF, CNT_CELLS, CNT_UNSUP, CNT_N };
+
+struct mcx_ctx {
+    const mcx_index *idx = nullptr;
+    Params pm;
+    mcx_opts opts;
+    hipStream_t stream = nullptr;
+    Tier tier[2];
+    uint64_t max_reads = 0, max_bases = 0;
+    int rlen_max = 256;
+    uint8_t *d_codes = nullptr;
+    uint2 *d_tasks = nullptr; uint32_t task_cap = 0;
+    DpJob *d_jobs[3] = {nullptr, nullptr, nullptr}; uint32_t job_cap[3] = {0, 0, 0};
+    uint32_t *d_cnt = nullptr;   // CNT_N counters
+    uint32_t *h_cnt = nullptr;   // pinned mirror
+    uint32_t *d_rescue = nullptr; uint32_t rescue_cap = 0;
+    uint32_t *d_kscratch = nullptr; uint32_t k_threads = 0, k_per_thread = 0;
+    uint8_t *d_dp_scratch[3] = {nullptr, nullptr, nullptr}; uint64_t dp_stride[3] = {0, 0, 0}; uint32_t dp_blocks[3] = {0, 0, 0};
+    uint32_t *d_ov = nullptr; uint32_t ov_cap = 0;
+    uint32_t *d_sel_ids = nullptr; int32_t *d_est = nullptr;
+    uint32_t *d_read_ext = nullptr, *d_read_blocks = nullptr;
+    PairOut *d_pout = nullptr, *h_pout = nullptr;
+    uint8_t *d_mapq = nullptr; int mapq_rows = 0;
+    // staging for the host-buffer entry point
+    uint8_t *d_bases = nullptr; uint32_t *d_off = nullptr; AlnRec *d_recs = nullptr; uint32_t *d_cig = nullptr;
+    hipEvent_t ev[10];
+};
+
+extern "C" void mcx_opts_default(mcx_opts *o)
+{
+    o->alg = 0; o->max_pos_diff = 30; o->max_mismatch_rate = 0.05f; o->max_read_len = 256; o->max_batch_reads = 1 << 20;
+}
+
+static Caps tier0_caps()
+{
+    Caps c; c.hit_cap = 48; c.cand_cap = 12; c.frag_cap = 96; c.ops_cap = 1024; c.job_cap = 16;
+    c.cig_cap = MCX_CIGAR_STRIDE; c.kmer_cap = 2048;
+    return c;
+}
+static Caps tier1_caps(int rlen_max)
+{
+    Caps c;
+    int seeds = rlen_max / (kMinSeedLength + 1) + 1;
+    c.hit_cap = seeds * kOccThr + rlen_max / 8 + 16;
+    c.cand_cap = c.hit_cap;
+    c.frag_cap = 3 * c.hit_cap + 16;
+    c.ops_cap = 96 * 1024; c.job_cap = 2048;
+    c.cig_cap = MCX_CIGAR_STRIDE; c.kmer_cap = 4096;
+    return c;
+}
+
+template <class T>
+static int dmalloc(T **p, size_t n) { HIP_TRY(hipMalloc((void **)p, n * sizeof(T))); return 0; }
+
+extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ctx **out)
+{
+    if (!idx || !out) return fail(MCX_ERR_ARG, "mcx_ctx_create: null argument");
+    mcx_opts o;
+    if (opts) o = *opts; else mcx_opts_default(&o);
+    if (o.max_read_len < 32) o.max_read_len = 32;
+    if (o.max_read_len > 1000) return fail(MCX_ERR_UNSUPPORTED, "max_read_len > 1000 is not supported");
+    if (o.max_batch_reads < 2) o.max_batch_reads = 2;
+    mcx_ctx *c = new mcx_ctx();
+    c->idx = idx; c->opts = o;
+    c->pm.max_pos_diff = o.max_pos_diff; c->pm.max_mm_rate = o.max_mismatch_rate; c->pm.use_nw = o.alg == 0; c->pm.paired = 1;
+    c->rlen_max = o.max_read_len;
+    c->max_reads = (uint64_t)o.max_batch_reads;
+    c->max_bases = c->max_reads * (uint64_t)c->rlen_max;
+    HIP_TRY(hipSetDevice(idx->device));
+    HIP_TRY(hipStreamCreate(&c->stream));
+    for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
+    int rc = 0;
+    c->tier[0].caps = tier0_caps(); c->tier[0].lay = make_layout(c->tier[0].caps); c->tier[0].max_pairs = (uint32_t)c->max_reads;
+    c->tier[1].caps = tier1_caps(c->rlen_max); c->tier[1].lay = make_layout(c->tier[1].caps);
+    c->tier[1].max_pairs = (uint32_t)std::min<uint64_t>(c->max_reads, 16384);
+    for (int t = 0; t < 2; t++)
+        if ((rc = dmalloc(&c->tier[t].state, (size_t)c->tier[t].lay.stride * c->tier[t].max_pairs))) return rc;
+    if ((rc = dmalloc(&c->d_codes, c->max_bases + 64))) return rc;
+    c->task_cap = (uint32_t)std::min<uint64_t>(c->max_reads * 24, 0x7fffffffu);
+    if ((rc = dmalloc(&c->d_tasks, c->task_cap))) return rc;
+    for (int k = 0; k < 3; k++) {
+        c->job_cap[k] = (uint32_t)std::min<uint64_t>(c->max_reads * (k == 0 ? 4 : 1) + 1024, 0x7fffffffu);
+        if ((rc = dmalloc(&c->d_jobs[k], c->job_cap[k]))) return rc;
+    }
+    if ((rc = dmalloc(&c->d_cnt, CNT_N))) return rc;
+    HIP_TRY(hipHostMalloc((void **)&c->h_cnt, CNT_N * sizeof(uint32_t)));
+    c->rescue_cap = (uint32_t)c->max_reads;
+    if ((rc = dmalloc(&c->d_rescue, c->rescue_cap))) return rc;
+    c->k_threads = 16384; c->k_per_thread = (uint32_t)c->rlen_max + (uint32_t)c->tier[1].caps.kmer_cap;
+    if ((rc = dmalloc(&c->d_kscratch, (size_t)c->k_threads * c->k_per_thread))) return rc;
+    // DP traceback spill per block: 4 KB of sequences + (qlen + tlen - 1) * tlen direction bytes
+    const uint64_t spill[3] = {kDpSpillSeq + (uint64_t)(2048 + 64) * 64, kDpSpillSeq + (uint64_t)(2048 + 256) * 256, kDpSpillSeq + (uint64_t)(2048 + 1024) * 1024};
+    const uint32_t blocks[3] = {8192, 2048, 512};
+    for (int k = 0; k < 3; k++) {
+        c->dp_stride[k] = spill[k]; c->dp_blocks[k] = blocks[k];
+        if ((rc = dmalloc(&c->d_dp_scratch[k], (size_t)spill[k] * blocks[k]))) return rc;
+    }
+    c->ov_cap = (uint32_t)c->max_reads;
+    if ((rc = dmalloc(&c->d_ov, c->ov_cap))) return rc;
+    if ((rc = dmalloc(&c->d_sel_ids, c->max_reads))) return rc;
+    if ((rc = dmalloc(&c->d_est, c->max_reads))) return rc;
+    if ((rc = dmalloc(&c->d_read_ext, c->max_reads))) return rc;
+    if ((rc = dmalloc(&c->d_read_blocks, c->max_reads))) return rc;
+    if ((rc = dmalloc(&c->d_pout, c->max_reads))) return rc;
+    HIP_TRY(hipHostMalloc((void **)&c->h_pout, c->max_reads * sizeof(PairOut)));
+    // EvaluateMAPQ (SamReport.cpp:86-101) tabulated on the host so that the double-precision
+    // log() is the host libm's, exactly as in the reference
+    c->mapq_rows = c->rlen_max + 64;
+    std::vector<uint8_t> tab((size_t)c->mapq_rows * 6, 0);
+    for (int s = 1; s < c->mapq_rows; s++)
+        for (int d = 1; d <= 5 && d < s; d++) {
+            int sub = s - d;
+            int q = (int)(30 * (1 - (float)(s - sub) / s) * log(s) + 0.4999);
+            tab[(size_t)s * 6 + d] = (uint8_t)(q > 60 ? 60 : q);
+        }
+    if ((rc = dmalloc(&c->d_mapq, tab.size()))) return rc;
+    HIP_TRY(hipMemcpy(c->d_mapq, tab.data(), tab.size(), hipMemcpyHostToDevice));
+    *out = c;
+    return 0;
+}
+
+extern "C" void mcx_ctx_free(mcx_ctx *c)
+{
+    if (!c) return;
+    void *p[] = {c->tier[0].state, c->tier[1].state, c->d_codes, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2],
+                 c->d_cnt, c->d_rescue, c->d_kscratch, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
+                 c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
+                 c->d_bases, c->d_off, c->d_recs, c->d_cig};
+    for (void *q : p) if (q) (void)hipFree(q);
+    if (c->h_cnt) (void)hipHostFree(c->h_cnt);
+    if (c->h_pout) (void)hipHostFree(c->h_pout);
+    for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static Ctx make_ctx(const mcx_ctx *c, int tier, int paired)
+{
+    Ctx cx;
+    cx.ix = c->idx->view; cx.pm = c->pm; cx.pm.paired = paired;
+    cx.caps = c->tier[tier].caps; cx.lay = c->tier[tier].lay; cx.state = c->tier[tier].state;
+    cx.mapq_tab = c->d_mapq; cx.mapq_rows = c->mapq_rows;
+    return cx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one tier over a selection of pairs
+// ---------------------------------------------------------------------------------------------
+struct StageMs { float seed, sa, cluster, rescue, build, dp, finish; };
+
+static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, PairSel sel, AlnRec *d_recs,
+                     uint32_t *d_cig, mcx_stats *stats, bool timing)
+{
+    if (sel.n == 0) return 0;
+    hipStream_t s = c->stream;
+    Ctx cx = make_ctx(c, tier, paired);
+    const int nr = paired ? 2 : 1;
+    HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
+    SeedOut so; so.tasks = c->d_tasks; so.n_tasks = c->d_cnt + CNT_TASKS; so.task_cap = c->task_cap;
+    so.read_ext = c->d_read_ext; so.read_blocks = c->d_read_blocks;
+    RescueList rl; rl.ids = c->d_rescue; rl.n = c->d_cnt + CNT_RESCUE; rl.cap = c->rescue_cap;
+    JobSinks sinks;
+    for (int k = 0; k < 3; k++) { sinks.s[k].jobs = c->d_jobs[k]; sinks.s[k].count = c->d_cnt + CNT_JOB0 + k; sinks.s[k].cap = c->job_cap[k]; }
+    const unsigned pb = (sel.n + 255) / 256, rbk = (sel.n * nr + 255) / 256;
+    int e = 0;
+    if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
+    k_seed<<<rbk, 256, 0, s>>>(cx, rb, sel, so);
+    if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
+    k_sa<<<4096, 256, 0, s>>>(cx, so, paired, c->d_cnt + CNT_LF);
+    if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
+    k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl);
+    if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
+    if (paired) k_rescue<<<c->k_threads / 64, 64, 0, s>>>(cx, rb, sel, rl, c->d_kscratch, c->k_per_thread, (uint32_t)c->rlen_max);
+    if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
+    k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks);
+    k_split_jobs<<<1024, 256, 0, s>>>(sinks, c->d_cnt + CNT_UNSUP);
+    if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
+    k_dp_sel<1><<<c->dp_blocks[0], 64, 0, s>>>(cx, sinks.s[0], rb, sel, c->d_dp_scratch[0], c->dp_stride[0], c->d_cnt + CNT_CELLS);
+    k_dp_sel<4><<<c->dp_blocks[1], 64, 0, s>>>(cx, sinks.s[1], rb, sel, c->d_dp_scratch[1], c->dp_stride[1], c->d_cnt + CNT_CELLS);
+    k_dp_sel<16><<<c->dp_blocks[2], 64, 0, s>>>(cx, sinks.s[2], rb, sel, c->d_dp_scratch[2], c->dp_stride[2], c->d_cnt + CNT_CELLS);
+    if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
+    k_finish<<<pb, 256, 0, s>>>(cx, rb, sel, d_recs, d_cig, c->d_pout, c->d_ov, c->d_cnt + CNT_OV, c->ov_cap);
+    if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t *n = c->h_cnt;
+    if (n[CNT_TASKS] > c->task_cap) return fail(MCX_ERR_CAPACITY, "seed task list overflow (more hits per read than the context was sized for)");
+    if (n[CNT_RESCUE] > c->rescue_cap) return fail(MCX_ERR_CAPACITY, "rescue list overflow");
+    for (int k = 0; k < 3; k++) if (n[CNT_JOB0 + k] > c->job_cap[k]) return fail(MCX_ERR_CAPACITY, "DP job list overflow");
+    if (n[CNT_UNSUP]) return fail(MCX_ERR_UNSUPPORTED, "a gapped fragment exceeds 2048 x 1024 cells per side");
+    if (stats) {
+        stats->sa_hits += n[CNT_TASKS];
+        stats->dp_jobs += n[CNT_JOB0]; // list 0 holds every job before the split
+        stats->dp_cells += n[CNT_CELLS];
+        if (timing) {
+            float ms[8];
+            for (int i = 0; i + 1 < e; i++) HIP_TRY(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+            stats->ms_seed += ms[0]; stats->ms_sa += ms[1]; stats->ms_cluster += ms[2]; stats->ms_rescue += ms[3];
+            stats->ms_build += ms[4]; stats->ms_dp += ms[5]; stats->ms_finish += ms[6];
+        }
+    }
+    return 0;
+}
+
+__global__ void k_fill_i32(int32_t *p, int32_t v, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__global__ void k_reduce_stats(const uint32_t *a, const uint32_t *b, uint32_t n, unsigned long long *out)
+{
+    unsigned long long sa = 0, sb = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { sa += a[i]; sb += b[i]; }
+    for (int o = 32; o > 0; o >>= 1) { sa += __shfl_down(sa, o, 64); sb += __shfl_down(sb, o, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(out, sa); atomicAdd(out + 1, sb); }
+}
+
+extern "C" void mcx_avg_init(int64_t a[4]) { a[0] = 1000; a[1] = 0; a[2] = 0; a[3] = 0; }
+
+// runs the tiers for the pairs in `ids` (null: all pairs of the batch) with per-pair estimates
+static int run_selection(mcx_ctx *c, const ReadBatch &rb, int paired, const std::vector<uint32_t> *ids,
+                         const std::vector<int32_t> *est, int32_t est_all, uint32_t n_pairs, AlnRec *d_recs,
+                         uint32_t *d_cig, mcx_stats *stats, bool timing)
+{
+    hipStream_t s = c->stream;
+    const uint32_t n = ids ? (uint32_t)ids->size() : n_pairs;
+    if (n == 0) return 0;
+    PairSel sel; sel.n = n; sel.ids = nullptr; sel.est = c->d_est;
+    if (ids) {
+        HIP_TRY(hipMemcpyAsync(c->d_sel_ids, ids->data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        sel.ids = c->d_sel_ids;
+    }
+    if (est) HIP_TRY(hipMemcpyAsync(c->d_est, est->data(), n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    else k_fill_i32<<<(n + 255) / 256, 256, 0, s>>>(c->d_est, est_all, n);
+    int rc = run_pairs(c, 0, rb, paired, sel, d_recs, d_cig, stats, timing);
+    if (rc) return rc;
+    uint32_t n_ov = c->h_cnt[CNT_OV];
+    if (n_ov == 0) return 0;
+    if (n_ov > c->ov_cap) return fail(MCX_ERR_CAPACITY, "overflow list overflow");
+    // tier 1: the overflowed pairs again, with capacities that are hard bounds for the read length
+    std::vector<uint32_t> ov(n_ov);
+    HIP_TRY(hipMemcpy(ov.data(), c->d_ov, n_ov * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::sort(ov.begin(), ov.end());
+    std::vector<int32_t> ov_est(n_ov);
+    HIP_TRY(hipMemcpy(c->h_pout, c->d_pout, (size_t)n_pairs * sizeof(PairOut), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n_ov; i++) ov_est[i] = c->h_pout[ov[i]].est;
+    if (stats) stats->tier1_pairs += n_ov;
+    for (uint32_t lo = 0; lo < n_ov; lo += c->tier[1].max_pairs) {
+        uint32_t m = std::min<uint32_t>(c->tier[1].max_pairs, n_ov - lo);
+        HIP_TRY(hipMemcpyAsync(c->d_sel_ids, ov.data() + lo, m * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->d_est, ov_est.data() + lo, m * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        PairSel s1; s1.n = m; s1.ids = c->d_sel_ids; s1.est = c->d_est;
+        rc = run_pairs(c, 1, rb, paired, s1, d_recs, d_cig, stats, false);
+        if (rc) return rc;
+        if (c->h_cnt[CNT_OV]) return fail(MCX_ERR_CAPACITY, "a pair exceeded the tier-1 capacities");
+    }
+    return 0;
+}
+
+extern "C" int mcx_map_batch_dev(mcx_ctx *c, const uint8_t *d_bases, const uint32_t *d_off, uint32_t n_reads, int paired,
+                                 int64_t avg[4], mcx_aln *d_aln, uint32_t *d_cigar, mcx_stats *stats)
+{
+    static_assert(sizeof(mcx_aln) == sizeof(AlnRec), "mcx_aln and AlnRec must have one layout");
+    if (!c || !d_bases || !d_off || !d_aln || !d_cigar || !avg) return fail(MCX_ERR_ARG, "mcx_map_batch_dev: null argument");
+    if (n_reads == 0) return 0;
+    if (n_reads > c->max_reads) return fail(MCX_ERR_ARG, "batch larger than max_batch_reads");
+    if (paired && (n_reads & 1)) return fail(MCX_ERR_ARG, "paired batch with an odd number of reads");
+    HIP_TRY(hipSetDevice(c->idx->device));
+    auto t0 = std::chrono::steady_clock::now();
+    hipStream_t s = c->stream;
+    ReadBatch rb; rb.bases = d_bases; rb.off = d_off; rb.codes = c->d_codes; rb.n_reads = n_reads;
+    uint32_t total_bases = 0;
+    HIP_TRY(hipMemcpy(&total_bases, d_off + n_reads, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (total_bases > c->max_bases) return fail(MCX_ERR_ARG, "batch holds more bases than max_batch_reads * max_read_len");
+    AlnRec *recs = (AlnRec *)d_aln;
+    HIP_TRY(hipEventRecord(c->ev[8], s));
+    k_encode<<<2048, 256, 0, s>>>(rb, paired);
+    HIP_TRY(hipEventRecord(c->ev[9], s));
+    const uint32_t n_pairs = paired ? n_reads / 2 : n_reads;
+    const int32_t est0 = (int32_t)((uint32_t)avg[0] * 1.5);
+    int rc = run_selection(c, rb, paired, nullptr, nullptr, est0, n_pairs, recs, d_cigar, stats, true);
+    if (rc) return rc;
+    if (stats) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, c->ev[8], c->ev[9])); stats->ms_encode += ms; }
+    HIP_TRY(hipMemcpy(c->h_pout, c->d_pout, (size_t)n_pairs * sizeof(PairOut), hipMemcpyDeviceToHost));
+
+    int64_t tot_pairs = avg[1], tot_dist = avg[2], mapped = 0, pairs = 0, dist_sum = 0;
+    if (paired) {
+        // replay of the reference's avgDist feedback (mcx_host.h avg_replay); pairs outside their
+        // validity interval are re-run with the exact estimate until none is left
+        if (avg[3] % kReadChunkSize) return fail(MCX_ERR_ARG, "batches must start on a 200-read chunk boundary");
+        std::vector<uint32_t> redo; std::vector<int32_t> redo_est;
+        int64_t after[4];
+        for (int iter = 0;; iter++) {
+            avg_replay(c->h_pout, n_pairs, avg, redo, redo_est, after);
+            if (redo.empty()) break;
+            if (iter == 63) return fail(MCX_ERR_CAPACITY, "avgDist replay did not converge");
+            if (stats) stats->replayed_pairs += (int64_t)redo.size();
+            rc = run_selection(c, rb, paired, &redo, &redo_est, 0, n_pairs, recs, d_cigar, stats, false);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpy(c->h_pout, c->d_pout, (size_t)n_pairs * sizeof(PairOut), hipMemcpyDeviceToHost));
+        }
+        tot_pairs = after[1]; tot_dist = after[2]; avg[0] = after[0];
+        pairs = tot_pairs - avg[1]; dist_sum = tot_dist - avg[2];
+        avg[1] = tot_pairs; avg[2] = tot_dist;
+    }
+    avg[3] += n_reads;
+    for (uint32_t p = 0; p < n_pairs; p++) mapped += c->h_pout[p].mapped;
+    if (stats) {
+        stats->reads += n_reads; stats->mapped += mapped; stats->pairs += pairs; stats->pair_dist_sum += dist_sum;
+        unsigned long long *d_sum = (unsigned long long *)c->d_cnt; // reuse (8-byte aligned, 2 words)
+        HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
+        k_reduce_stats<<<256, 256, 0, s>>>(c->d_read_ext, c->d_read_blocks, n_reads, d_sum);
+        unsigned long long hs[2];
+        HIP_TRY(hipMemcpyAsync(hs, d_sum, sizeof hs, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        stats->fm_ext_steps += (int64_t)hs[0]; stats->fm_blocks += (int64_t)hs[1];
+        stats->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return 0;
+}
+
+extern "C" int mcx_map_batch(mcx_ctx *c, const uint8_t *bases, const uint32_t *off, uint32_t n_reads, int paired,
+                             int64_t avg[4], mcx_aln *aln, uint32_t *cigar, mcx_stats *stats)
+{
+    if (!c || !bases || !off || !aln || !cigar) return fail(MCX_ERR_ARG, "mcx_map_batch: null argument");
+    if (n_reads == 0) return 0;
+    if (n_reads > c->max_reads) return fail(MCX_ERR_ARG, "batch larger than max_batch_reads");
+    HIP_TRY(hipSetDevice(c->idx->device));
+    int rc;
+    if (!c->d_bases) {
+        if ((rc = dmalloc(&c->d_bases, c->max_bases + 64))) return rc;
+        if ((rc = dmalloc(&c->d_off, c->max_reads + 1))) return rc;
+        if ((rc = dmalloc(&c->d_recs, c->max_reads))) return rc;
+        if ((rc = dmalloc(&c->d_cig, c->max_reads * MCX_CIGAR_STRIDE))) return rc;
+    }
+    if (off[n_reads] > c->max_bases) return fail(MCX_ERR_ARG, "batch holds more bases than max_batch_reads * max_read_len");
+    HIP_TRY(hipMemcpy(c->d_bases, bases, off[n_reads], hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_off, off, (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice));
+    rc = mcx_map_batch_dev(c, c->d_bases, c->d_off, n_reads, paired, avg, (mcx_aln *)c->d_recs, c->d_cig, stats);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(aln, c->d_recs, (size_t)n_reads * sizeof(AlnRec), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cigar, c->d_cig, (size_t)n_reads * MCX_CIGAR_STRIDE * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-call drop-ins: BWT_Search and nw/ksw2 alignment as batches
+// ---------------------------------------------------------------------------------------------
+__global__ void k_bwt_search(IndexView ix, const uint8_t *seqs, const uint32_t *off, const int32_t *start, uint32_t n,
+                             int32_t *len, int32_t *freq, uint64_t *loc)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *seq = seqs + off[i];
+    const int stop = (int)(off[i + 1] - off[i]);
+    // BWT_Search (bwt_search.cpp:121-164), one call
+    int p0 = start[i], c0 = seq[p0];
+    uint64_t x0 = ix.L2[c0] + 1, x1 = ix.L2[3 - c0] + 1, x2 = ix.L2[c0 + 1] - ix.L2[c0];
+    int pos;
+    for (pos = p0 + 1; pos < stop; pos++) {
+        int c = seq[pos];
+        if (c > 3) break;
+        uint64_t tk[4], tl[4]; int nb;
+        fm_2occ4(ix, x1 - 1, x1 - 1 + x2, tk, tl, nb);
+        int b = 3 - c;
+        uint64_t n2 = tl[b] - tk[b];
+        if (n2 == 0) break;
+        uint64_t n0 = x0 + ((x1 <= ix.primary && x1 + x2 - 1 >= ix.primary) ? 1 : 0);
+        for (int bb = 3; bb > b; bb--) n0 += tl[bb] - tk[bb];
+        x0 = n0; x1 = ix.L2[b] + 1 + tk[b]; x2 = n2;
+    }
+    int l = pos - p0, f = 0;
+    if (l >= kMinSeedLength && x2 <= (uint64_t)kOccThr) f = (int)x2;
+    len[i] = l; freq[i] = f;
+    for (int k = 0; k < f; k++) { int lf = 0; loc[(uint64_t)i * kOccThr + k] = fm_sa(ix, x0 + k, lf); }
+}
+
+extern "C" int mcx_bwt_search_batch(mcx_ctx *c, const uint8_t *seqs, const uint32_t *seq_off, const int32_t *start,
+                                    uint32_t n, int32_t *len, int32_t *freq, uint64_t *loc)
+{
+    if (!c || !seqs || !seq_off || !start || !len || !freq || !loc) return fail(MCX_ERR_ARG, "mcx_bwt_search_batch: null argument");
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(c->idx->device));
+    uint8_t *d_seq = nullptr; uint32_t *d_off = nullptr; int32_t *d_start = nullptr, *d_len = nullptr, *d_freq = nullptr; uint64_t *d_loc = nullptr;
+    int rc = 0;
+    size_t nb = seq_off[n];
+    if ((rc = dmalloc(&d_seq, nb + 16)) || (rc = dmalloc(&d_off, (size_t)n + 1)) || (rc = dmalloc(&d_start, n)) ||
+        (rc = dmalloc(&d_len, n)) || (rc = dmalloc(&d_freq, n)) || (rc = dmalloc(&d_loc, (size_t)n * kOccThr))) return rc;
+    HIP_TRY(hipMemcpy(d_seq, seqs, nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_off, seq_off, ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_start, start, (size_t)n * 4, hipMemcpyHostToDevice));
+    k_bwt_search<<<(n + 255) / 256, 256, 0, c->stream>>>(c->idx->view, d_seq, d_off, d_start, n, d_len, d_freq, d_loc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(len, d_len, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(freq, d_freq, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(loc, d_loc, (size_t)n * kOccThr * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d_seq); (void)hipFree(d_off); (void)hipFree(d_start); (void)hipFree(d_len); (void)hipFree(d_freq); (void)hipFree(d_loc);
+    return 0;
+}
+
+// stand-alone extension (nw_alignment / ksw2_alignment as a batch): strings come from user buffers
+struct ExtArgs {
+    const uint8_t *q, *t;
+    const uint32_t *q_off, *t_off;
+    uint8_t *ops; int32_t *ops_len, *score;
+    uint32_t n;
+    int use_nw;
+};
+
+template <int K>
+__global__ void __launch_bounds__(64) k_extend(ExtArgs a, uint8_t *scratch, uint64_t stride, int t_lo, int t_hi)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kDpLdsSeq + kDpLdsDir];
+    uint8_t *spill = scratch + (uint64_t)blockIdx.x * stride;
+    const int lane = threadIdx.x;
+    for (uint32_t jb = blockIdx.x; jb < a.n; jb += gridDim.x) {
+        const int m = (int)(a.q_off[jb + 1] - a.q_off[jb]), n = (int)(a.t_off[jb + 1] - a.t_off[jb]);
+        if (n <= t_lo || n > t_hi || m <= 0) continue;
+        const DpBuf b = dp_buffers(m, n, lds, spill);
+        for (int i = lane; i < m; i += 64) b.q[i] = (uint8_t)nt4_code(a.q[a.q_off[jb] + i]);
+        for (int i = lane; i < n; i += 64) b.t[i] = (uint8_t)nt4_code(a.t[a.t_off[jb] + i]);
+        __syncthreads();
+        uint8_t *dst = a.ops + a.q_off[jb] + a.t_off[jb];
+        int score = 0;
+        const int w = dp_core<K>(a.use_nw != 0, m, n, b, dst, &score);
+        const int L = m + n - w;
+        for (int base = 0; base < L; base += 64) { // move the string to the front of its area
+            uint8_t v = base + lane < L ? dst[w + base + lane] : 0;
+            __syncthreads();
+            if (base + lane < L) dst[base + lane] = v;
+            __syncthreads();
+        }
+        if (lane == 0) { a.ops_len[jb] = L; a.score[jb] = score; }
+    }
+}
+
+extern "C" int mcx_extend_batch(mcx_ctx *c, int alg, const uint8_t *q, const uint32_t *q_off, const uint8_t *t,
+                                const uint32_t *t_off, uint32_t n, uint8_t *ops, int32_t *ops_len, int32_t *score)
+{
+    if (!c || !q || !q_off || !t || !t_off || !ops || !ops_len || !score) return fail(MCX_ERR_ARG, "mcx_extend_batch: null argument");
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(c->idx->device));
+    for (uint32_t i = 0; i < n; i++) {
+        if (t_off[i + 1] - t_off[i] > 1024 || q_off[i + 1] - q_off[i] > 2048 || t_off[i + 1] == t_off[i] || q_off[i + 1] == q_off[i])
+            return fail(MCX_ERR_UNSUPPORTED, "mcx_extend_batch: fragments must be 1..2048 (read) x 1..1024 (genome)");
+    }
+    ExtArgs a; a.n = n; a.use_nw = alg == 0;
+    uint8_t *d_q = nullptr, *d_t = nullptr, *d_ops = nullptr; uint32_t *d_qo = nullptr, *d_to = nullptr; int32_t *d_len = nullptr, *d_sc = nullptr;
+    const size_t nq = q_off[n], nt = t_off[n];
+    int rc = 0;
+    if ((rc = dmalloc(&d_q, nq + 16)) || (rc = dmalloc(&d_t, nt + 16)) || (rc = dmalloc(&d_ops, nq + nt + 16)) ||
+        (rc = dmalloc(&d_qo, (size_t)n + 1)) || (rc = dmalloc(&d_to, (size_t)n + 1)) || (rc = dmalloc(&d_len, n)) || (rc = dmalloc(&d_sc, n))) return rc;
+    HIP_TRY(hipMemcpy(d_q, q, nq, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_t, t, nt, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_qo, q_off, ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_to, t_off, ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
+    a.q = d_q; a.t = d_t; a.q_off = d_qo; a.t_off = d_to; a.ops = d_ops; a.ops_len = d_len; a.score = d_sc;
+    k_extend<1><<<c->dp_blocks[0], 64, 0, c->stream>>>(a, c->d_dp_scratch[0], c->dp_stride[0], 0, 64);
+    k_extend<4><<<c->dp_blocks[1], 64, 0, c->stream>>>(a, c->d_dp_scratch[1], c->dp_stride[1], 64, 256);
+    k_extend<16><<<c->dp_blocks[2], 64, 0, c->stream>>>(a, c->d_dp_scratch[2], c->dp_stride[2], 256, 1024);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(ops, d_ops, nq + nt, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ops_len, d_len, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(score, d_sc, (size_t)n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_q); (void)hipFree(d_t); (void)hipFree(d_ops); (void)hipFree(d_qo); (void)hipFree(d_to); (void)hipFree(d_len); (void)hipFree(d_sc);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// files in, SAM out: MapCaller -i <prefix> -f A [-f2 B] -sam out  (main.cpp:212-321, Mapping() ReadMapping.cpp:689-747)
+// ---------------------------------------------------------------------------------------------
+extern "C" int mcx_map_files(mcx_ctx *c, const char *fq1, const char *fq2, const char *sam_path, mcx_stats *stats)
+{
+    if (!c || !fq1) return fail(MCX_ERR_ARG, "mcx_map_files: null argument");
+    ReadFile f1, f2;
+    std::string err;
+    const bool paired = fq2 && fq2[0];
+    if (!f1.open(fq1, err)) return fail(MCX_ERR_IO, err);
+    if (paired && !f2.open(fq2, err)) return fail(MCX_ERR_IO, err);
+    if (paired && f1.fastq() != f2.fastq()) return fail(MCX_ERR_IO, std::string(fq1) + " and " + fq2 + " are with different format");
+    FILE *sam = nullptr;
+    if (sam_path && sam_path[0]) {
+        sam = strcmp(sam_path, "-") == 0 ? stdout : fopen(sam_path, "w");
+        if (!sam) return fail(MCX_ERR_IO, std::string("cannot write ") + sam_path);
+        std::string hdr;
+        sam_header(c->idx->host, hdr);
+        fputs(hdr.c_str(), sam);
+    }
+    const uint64_t batch = std::max<uint64_t>(kReadChunkSize, c->max_reads / kReadChunkSize * kReadChunkSize);
+    std::vector<HostRead> reads;
+    std::vector<uint8_t> bases;
+    std::vector<uint32_t> off;
+    std::vector<AlnRec> recs;
+    std::vector<uint32_t> cig;
+    int64_t avg[4];
+    mcx_avg_init(avg);
+    std::string line;
+    int rc = 0;
+    bool eof = false;
+    while (!eof && rc == 0) {
+        reads.clear(); bases.clear(); off.assign(1, 0);
+        while (reads.size() < batch) { // GetNextChunk, GetData.cpp:85-99
+            HostRead a, b;
+            if (!f1.next(a)) { eof = true; break; }
+            reads.push_back(a);
+            if (paired) { f2.next(b); reads.push_back(b); }
+        }
+        if (reads.empty()) break;
+        for (auto &r : reads) {
+            if ((int)r.seq.size() > c->rlen_max) { rc = fail(MCX_ERR_UNSUPPORTED, "read " + r.name + " is longer than max_read_len"); break; }
+            bases.insert(bases.end(), r.seq.begin(), r.seq.end());
+            off.push_back((uint32_t)bases.size());
+        }
+        if (rc) break;
+        const uint32_t n = (uint32_t)reads.size();
+        recs.resize(n); cig.resize((size_t)n * MCX_CIGAR_STRIDE);
+        bases.resize(bases.size() + 64);
+        // a single-end batch, or an odd tail, is mapped as single reads (ReadMapping.cpp:443, :575)
+        const int as_pairs = paired && (n % 2 == 0);
+        rc = mcx_map_batch(c, bases.data(), off.data(), n, as_pairs, avg, (mcx_aln *)recs.data(), cig.data(), stats);
+        if (rc) break;
+        if (sam) {
+            for (uint32_t i = 0; i < n; i++) {
+                sam_line(c->idx->host, reads[i], as_pairs && (i & 1), f1.fastq(), recs[i], cig.data() + (size_t)i * MCX_CIGAR_STRIDE, line);
+                fputs(line.c_str(), sam); fputc('\n', sam);
+            }
+        }
+    }
+    if (sam && sam != stdout) fclose(sam);
+    return rc;
+}

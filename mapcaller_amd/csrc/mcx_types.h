@@ -1,0 +1,215 @@
+// mapcaller_amd/csrc/mcx_types.h — plain-old-data shared by the HIP kernels, the C ABI and the
+// host-side SAM writer.  No STL, no torch: everything here is laid out for HBM.
+//
+// Design: a batch of read pairs owns a fixed-capacity *pair state* record in
+// HBM.  Every stage (seeding, SA resolution, clustering/pairing, DP, scoring/CIGAR) reads and
+// writes only its own pair's record, so there are no atomics on the data path and results do
+// not depend on scheduling.  A pair that exceeds any capacity is flagged and re-run in the next
+// tier, whose capacities are hard upper bounds for the read length.
+#ifndef MCX_TYPES_H
+#define MCX_TYPES_H
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MCX_HD __host__ __device__
+#else
+#define MCX_HD
+#endif
+
+namespace mcx {
+
+// constants of the reference path (reference src/structure.h:20-25, src/bwt_search.cpp:3)
+enum : int {
+    kMinSeedLength = 16,
+    kReadChunkSize = 200,
+    kOccThr = 50,
+    kKmerSize = 8,
+    kMinAlnBlockSize = 5,
+    kMinTranslocationSize = 1000
+};
+
+// FM-index + reference, resident in HBM.  bwt/sa keep the on-disk layout of the reference
+// (src/BWT_Index/bwtindex.c:53-75): 64-byte blocks of {4 x u64 occ, 8 x u32 = 128 bases}.
+struct IndexView {
+    const uint32_t *bwt;
+    const uint64_t *sa;      // sampled every sa_intv (sa[0] = ~0)
+    const uint64_t *sa_full; // optional: every suffix-array entry (288 GB HBM makes room); may be null
+    const uint8_t *pac;      // forward genome, 2 bit/base, MSB first
+    const int64_t *end_pos;  // sorted chromosome end positions in [0,2G): PosChrIdMap keys
+    const int32_t *end_chr;  // chromosome id of each end
+    const int64_t *chr_fwd;  // FowardLocation per chromosome
+    uint64_t primary, L2[5], seq_len;
+    int64_t G, G2;
+    int32_t n_ends, n_chr, sa_intv;
+};
+
+struct Params {
+    int32_t max_pos_diff;  // -indel, main.cpp:179
+    float max_mm_rate;     // -maxmm, main.cpp:186
+    int32_t use_nw;        // -alg nw|ksw2
+    int32_t paired;        // mates interleaved (2p, 2p+1)
+};
+
+// per-tier capacities of one pair-state record
+struct Caps {
+    int32_t hit_cap;   // seed hits per read (incl. rescue seeds)
+    int32_t cand_cap;  // candidates per read
+    int32_t frag_cap;  // fragments per pair (all live candidates of both reads)
+    int32_t ops_cap;   // DP op bytes per pair
+    int32_t job_cap;   // DP jobs per pair
+    int32_t cig_cap;   // CIGAR ops per read
+    int32_t kmer_cap;  // rescue window length
+};
+
+struct Hit {          // one seed occurrence: FragPair_t with bSimple (structure.h:113-123)
+    int64_t gPos;     // K1 stores the BWT row here, K2 overwrites it with the text position
+    int32_t rPos;
+    int32_t len;
+};
+
+struct Cand {         // AlnCan_t (structure.h:125-133) as ranges into the pair state
+    int32_t score;
+    int32_t mate;     // PairedAlnCanIdx
+    int32_t first;    // first seed (index into the read's hit array)
+    int32_t count;    // number of seeds
+    int64_t pd0;      // FragPairVec[0].PosDiff while sorted by PosDiff
+    int32_t frag_off; // fragments after extension set-up
+    int32_t n_frags;
+    int32_t flag;     // SamFlag
+    int32_t fwd;      // orientation
+};
+
+enum FragKind : uint8_t {
+    kSimple = 0,  // exact seed
+    kPlain = 1,   // gap fragment, rLen == gLen, compared base by base (no DP)
+    kIns = 2,     // gLen == 0: read bases against '-'
+    kDel = 3,     // rLen == 0: '-' against genome bases
+    kDp = 4,      // gapped extension result in the ops pool
+    kEmpty = 5    // end fragment dropped by the quality gate
+};
+
+struct Frag {
+    int64_t gPos;
+    int32_t rPos, rLen, gLen;
+    int32_t ops_off;  // kDp: offset into the pair's ops pool (columns, 'M' 'I' 'D')
+    int32_t ops_len;  // current number of alignment columns (after end trimming)
+    uint8_t kind;
+    uint8_t pad[3];
+};
+
+struct DpJob {        // one ksw2/nw problem
+    uint32_t pair;
+    uint16_t slot;    // read 0/1 of the pair
+    uint16_t rev;     // fragment lies on the reverse strand: both strings reversed
+    int32_t rPos, rLen;
+    int64_t gPos;
+    int32_t gLen;
+    int32_t ops_off;  // into the pair's ops pool; capacity rLen + gLen
+    int32_t frag;     // fragment index in the pair's fragment pool
+    int32_t score;    // out: ez.score (ksw2) / final s (nw, doubled)
+};
+
+struct ReadSum {      // AlnSummary_t (structure.h:135-140)
+    int32_t best, score, sub;
+};
+
+enum PairFlags : uint32_t {
+    kOvHits = 1u, kOvCands = 2u, kOvFrags = 4u, kOvOps = 8u, kOvJobs = 16u, kOvCigar = 32u, kOvKmer = 64u,
+    kOvAny = 127u,
+    kRescueUsedEst = 256u
+};
+
+struct PairHdr {
+    uint32_t flags;
+    int32_t n_hits[2];
+    int32_t n_cands[2];
+    int32_t n_frags;
+    int32_t n_ops;
+    int32_t n_jobs;
+    int32_t est;          // EstiDistance used
+    int32_t est_lo, est_hi; // the pairing decisions hold for every EstiDistance in [lo, hi]
+    int32_t n_paired;     // return value of CheckPairedAlignmentDistance / AlignmentRescue
+    ReadSum sum[2];
+    int32_t pair_ok;      // counted in iTotalPairedNum (ReadMapping.cpp:527-531)
+    int32_t pair_dist;
+    int64_t stat_ext;     // FM extension steps (E) of both reads
+    int32_t stat_hits;    // SA hits resolved (H)
+    int32_t mapped;       // number of mapped reads in the pair
+};
+
+// one output record per read (unique mode: the reference prints exactly one line per read)
+struct AlnRec {
+    int64_t pos;        // 1-based POS (0 when unmapped)
+    int64_t mate_pos;   // PNEXT (0 = none)
+    int32_t chr;        // RNAME index (-1 = *)
+    int32_t flag;
+    int32_t mapq;
+    int32_t tlen;
+    int32_t nm, as, xs; // NM AS XS
+    int32_t n_cigar;    // ops in the cigar pool row of this read
+    int32_t fwd;        // SEQ printed as given (1) or reverse-complemented (0)
+    int32_t has_mate;   // RNEXT '=' and PNEXT/TLEN valid
+};
+
+// per-pair summary the host replays the reference's avgDist feedback from
+struct PairOut {
+    uint32_t flags;
+    int32_t est, est_lo, est_hi;
+    int32_t pair_dist;
+    int16_t pair_ok, mapped;
+};
+
+// byte offsets of the regions of a pair-state record
+struct Layout {
+    int64_t off_hits, off_cands, off_frags, off_ops, off_jobs, stride;
+};
+
+static inline MCX_HD int64_t mcx_align64(int64_t x) { return (x + 63) & ~(int64_t)63; }
+
+static inline MCX_HD Layout make_layout(const Caps &c)
+{
+    Layout l;
+    int64_t o = mcx_align64(sizeof(PairHdr));
+    l.off_hits = o;  o += mcx_align64((int64_t)2 * c.hit_cap * sizeof(Hit));
+    l.off_cands = o; o += mcx_align64((int64_t)2 * c.cand_cap * sizeof(Cand));
+    l.off_frags = o; o += mcx_align64((int64_t)c.frag_cap * sizeof(Frag));
+    l.off_jobs = o;  o += mcx_align64((int64_t)c.job_cap * sizeof(int32_t) * 2);
+    l.off_ops = o;   o += mcx_align64((int64_t)c.ops_cap);
+    l.stride = o;
+    return l;
+}
+
+struct PairState {
+    PairHdr *hdr;
+    Hit *hits[2];
+    Cand *cands[2];
+    Frag *frags;
+    uint8_t *ops;
+};
+
+static inline MCX_HD PairState pair_state(uint8_t *base, const Layout &l, const Caps &c, int64_t pair)
+{
+    uint8_t *p = base + pair * l.stride;
+    PairState s;
+    s.hdr = (PairHdr *)p;
+    s.hits[0] = (Hit *)(p + l.off_hits);
+    s.hits[1] = s.hits[0] + c.hit_cap;
+    s.cands[0] = (Cand *)(p + l.off_cands);
+    s.cands[1] = s.cands[0] + c.cand_cap;
+    s.frags = (Frag *)(p + l.off_frags);
+    s.ops = p + l.off_ops;
+    return s;
+}
+
+// a batch of reads in HBM: ASCII bases, offsets, and the 0..4 codes produced by the encode
+// kernel (mate 2 already reverse-complemented, ReadMapping.cpp:451)
+struct ReadBatch {
+    const uint8_t *bases;   // ASCII
+    const uint32_t *off;    // n_reads + 1
+    uint8_t *codes;         // same offsets
+    uint32_t n_reads;
+};
+
+} // namespace mcx
+#endif

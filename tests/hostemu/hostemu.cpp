@@ -1,0 +1,278 @@
+// tests/hostemu/hostemu.cpp — TEST HARNESS ONLY (never part of libmcx.so or any product path).
+//
+// Runs the device headers of the product (mcx_fm.h, mcx_glue.h: the code every HIP lane
+// executes) on the host, one pair after the other, with the same stage order, tiering and
+// avgDist replay as mcx_pipeline.hip.  It lets the CPU-only test suite (-m "not gpu") check the
+// seeding and per-pair logic against the reference's golden SAM without a GPU.  The wavefront DP
+// kernels cannot run here (wave shuffles, LDS); their place is taken by the oracle's DP, which is
+// legitimate in a test.  The GPU tests exercise the real kernels through the C ABI.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../mapcaller_amd/csrc/mcx_glue.h"
+#include "../../mapcaller_amd/csrc/mcx_host.h"
+#include "../../oracle/mcx_oracle.h"
+
+using namespace mcx;
+
+namespace {
+
+struct Emu {
+    HostIndex hix;
+    IndexView view;
+    Params pm;
+    std::vector<uint8_t> mapq;
+    int mapq_rows = 0;
+    Caps caps[2];
+    Layout lay[2];
+};
+
+static void set_view(Emu &e)
+{
+    IndexView &v = e.view;
+    HostIndex &h = e.hix;
+    v.bwt = h.bwt.data(); v.sa = h.sa.data(); v.sa_full = nullptr; v.pac = h.pac.data();
+    v.end_pos = h.end_pos.data(); v.end_chr = h.end_chr.data(); v.chr_fwd = h.chr_fwd.data();
+    v.primary = h.primary; for (int i = 0; i < 5; i++) v.L2[i] = h.L2[i];
+    v.seq_len = h.seq_len; v.G = h.G; v.G2 = 2 * h.G;
+    v.n_ends = (int)h.end_pos.size(); v.n_chr = (int)h.chr_len.size(); v.sa_intv = h.sa_intv;
+}
+
+struct Batch {
+    std::vector<HostRead> reads;
+    std::vector<uint8_t> bases, codes;
+    std::vector<uint32_t> off;
+    bool paired = false;
+};
+
+static void make_reads(const Batch &b, uint32_t pair, ReadRef rd[2])
+{
+    const int nr = b.paired ? 2 : 1;
+    for (int s = 0; s < nr; s++) {
+        uint32_t r = pair * nr + s;
+        rd[s].ascii = b.bases.data() + b.off[r];
+        rd[s].codes = b.codes.data() + b.off[r];
+        rd[s].rlen = (int)(b.off[r + 1] - b.off[r]);
+        rd[s].flipped = (b.paired && s == 1) ? 1 : 0;
+    }
+}
+
+// one tier over a selection of pairs; returns the batch ids of the pairs that overflowed
+static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const std::vector<uint32_t> &ids,
+                                      const std::vector<int32_t> &est, std::vector<AlnRec> &recs, std::vector<uint32_t> &cig,
+                                      std::vector<PairOut> &pout, int64_t *stats)
+{
+    const int nr = b.paired ? 2 : 1;
+    const uint32_t n = (uint32_t)ids.size();
+    std::vector<uint8_t> state((size_t)e.lay[tier].stride * n);
+    Ctx cx;
+    cx.ix = e.view; cx.pm = e.pm; cx.pm.paired = b.paired; cx.caps = e.caps[tier]; cx.lay = e.lay[tier];
+    cx.state = state.data(); cx.mapq_tab = e.mapq.data(); cx.mapq_rows = e.mapq_rows;
+    std::vector<DpJob> jobs((size_t)n * 64 + 1024);
+    uint32_t n_jobs = 0;
+    JobSink sink; sink.jobs = jobs.data(); sink.count = &n_jobs; sink.cap = (uint32_t)jobs.size();
+    std::vector<uint32_t> kq(4096), kg(e.caps[tier].kmer_cap + 16);
+    std::vector<uint32_t> ov;
+    // k_seed + k_sa
+    for (uint32_t l = 0; l < n; l++) {
+        PairState st = pair_state(cx.state, cx.lay, cx.caps, l);
+        for (int s = 0; s < nr; s++) {
+            uint32_t r = ids[l] * nr + s;
+            int64_t ext = 0, blocks = 0;
+            int nh = seed_read(cx.ix, b.codes.data() + b.off[r], (int)(b.off[r + 1] - b.off[r]), st.hits[s], cx.caps.hit_cap, ext, blocks);
+            st.hdr->n_hits[s] = nh;
+            if (stats) { stats[3] += ext; stats[8] += blocks; }
+            int keep = nh <= cx.caps.hit_cap ? nh : 0;
+            for (int i = 0; i < keep; i++) { int lf = 0; st.hits[s][i].gPos = (int64_t)fm_sa(cx.ix, (uint64_t)st.hits[s][i].gPos, lf); if (stats) { stats[4]++; stats[5] += lf; } }
+        }
+    }
+    // k_cluster, k_rescue, k_build
+    for (uint32_t l = 0; l < n; l++) {
+        ReadRef rd[2];
+        make_reads(b, ids[l], rd);
+        PairState st = pair_state(cx.state, cx.lay, cx.caps, l);
+        st.hdr->flags = 0;
+        stage_cluster_pair(cx, l, rd, est[l]);
+    }
+    for (uint32_t l = 0; l < n; l++) {
+        ReadRef rd[2];
+        make_reads(b, ids[l], rd);
+        stage_rescue(cx, l, rd, kq.data(), kg.data());
+    }
+    for (uint32_t l = 0; l < n; l++) {
+        ReadRef rd[2];
+        make_reads(b, ids[l], rd);
+        stage_build(cx, l, rd, sink);
+    }
+    if (getenv("MCX_EMU_DEBUG")) {
+        for (uint32_t l = 0; l < n; l++) {
+            PairState st = pair_state(cx.state, cx.lay, cx.caps, l);
+            fprintf(stderr, "pair %u flags %x n_paired %d est %d\n", ids[l], st.hdr->flags, st.hdr->n_paired, st.hdr->est);
+            for (int s = 0; s < nr; s++) {
+                fprintf(stderr, " read %d: hits %d cands %d\n", s, st.hdr->n_hits[s], st.hdr->n_cands[s]);
+                for (int i = 0; i < st.hdr->n_hits[s]; i++) fprintf(stderr, "   hit r=%d len=%d g=%lld pd=%lld\n", st.hits[s][i].rPos, st.hits[s][i].len, (long long)st.hits[s][i].gPos, (long long)hit_pd(st.hits[s][i]));
+                for (int i = 0; i < st.hdr->n_cands[s]; i++) {
+                    const Cand &c = st.cands[s][i];
+                    fprintf(stderr, "   cand %d score %d mate %d first %d count %d nfrags %d\n", i, c.score, c.mate, c.first, c.count, c.n_frags);
+                    for (int k = 0; k < c.n_frags; k++) { const Frag &f = st.frags[c.frag_off + k]; fprintf(stderr, "      frag kind %d r=%d rl=%d g=%lld gl=%d\n", f.kind, f.rPos, f.rLen, (long long)f.gPos, f.gLen); }
+                }
+            }
+        }
+    }
+    // DP jobs: the oracle's scalar DP stands in for the wavefront kernels
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        const DpJob &job = jobs[j];
+        PairState st = pair_state(cx.state, cx.lay, cx.caps, job.pair);
+        const uint32_t read = ids[job.pair] * nr + job.slot;
+        const uint8_t *codes = b.codes.data() + b.off[read];
+        std::string q(job.rLen, 'N'), t(job.gLen, 'N');
+        for (int i = 0; i < job.rLen; i++) q[i] = "ACGTN"[codes[job.rev ? job.rPos + job.rLen - 1 - i : job.rPos + i]];
+        for (int i = 0; i < job.gLen; i++) t[i] = "ACGTN"[ref_code(cx.ix, job.rev ? job.gPos + job.gLen - 1 - i : job.gPos + i)];
+        std::vector<char> o1(job.rLen + job.gLen + 2), o2(job.rLen + job.gLen + 2);
+        int L = cx.pm.use_nw ? mcxo_nw(q.c_str(), job.rLen, t.c_str(), job.gLen, o1.data(), o2.data(), (int)o1.size())
+                             : mcxo_ksw2(q.c_str(), job.rLen, t.c_str(), job.gLen, o1.data(), o2.data(), (int)o1.size());
+        if (L < 0) { fprintf(stderr, "hostemu: DP failed\n"); continue; }
+        // like the device kernels, right-align the column string in its reserved area
+        int w = job.rLen + job.gLen - L;
+        for (int i = 0; i < L; i++) st.ops[job.ops_off + w + i] = o1[i] == '-' ? 'D' : (o2[i] == '-' ? 'I' : 'M');
+        st.frags[job.frag].ops_off = job.ops_off + w;
+        st.frags[job.frag].ops_len = L;
+        if (stats) { stats[6]++; stats[7] += (int64_t)job.rLen * job.gLen; }
+    }
+    // k_finish
+    for (uint32_t l = 0; l < n; l++) {
+        ReadRef rd[2];
+        make_reads(b, ids[l], rd);
+        const uint32_t pair = ids[l];
+        AlnRec *r0 = recs.data() + (int64_t)pair * nr - (int64_t)l * nr;
+        uint32_t *c0 = cig.data() + ((int64_t)pair * nr - (int64_t)l * nr) * cx.caps.cig_cap;
+        stage_finish(cx, l, rd, r0, c0);
+        PairState st = pair_state(cx.state, cx.lay, cx.caps, l);
+        const PairHdr &h = *st.hdr;
+        PairOut o;
+        o.flags = h.flags; o.est = h.est; o.est_lo = h.est_lo; o.est_hi = h.est_hi;
+        o.pair_dist = h.pair_dist; o.pair_ok = (int16_t)h.pair_ok; o.mapped = (int16_t)h.mapped;
+        pout[pair] = o;
+        if (h.flags & kOvAny) ov.push_back(pair);
+    }
+    return ov;
+}
+
+static int run_selection(Emu &e, const Batch &b, const std::vector<uint32_t> &ids, const std::vector<int32_t> &est,
+                         std::vector<AlnRec> &recs, std::vector<uint32_t> &cig, std::vector<PairOut> &pout, int64_t *stats)
+{
+    std::vector<uint32_t> ov = run_tier(e, 0, b, ids, est, recs, cig, pout, stats);
+    if (ov.empty()) return 0;
+    std::sort(ov.begin(), ov.end());
+    std::vector<int32_t> ov_est(ov.size());
+    for (size_t i = 0; i < ov.size(); i++) ov_est[i] = pout[ov[i]].est;
+    if (stats) stats[9] += (int64_t)ov.size();
+    std::vector<uint32_t> ov2 = run_tier(e, 1, b, ov, ov_est, recs, cig, pout, stats);
+    return ov2.empty() ? 0 : -4;
+}
+
+} // namespace
+
+extern "C" {
+
+// tier0 = {hit_cap, cand_cap, frag_cap, ops_cap, job_cap} or null for the product defaults.
+// stats[12]: 0 reads 1 mapped 2 pairs 3 E 4 H 5 LF 6 dp jobs 7 dp cells 8 blocks 9 tier-1 pairs 10 replayed pairs
+int64_t hostemu_map_files(const char *prefix, const char *fq1, const char *fq2, int alg, const char *sam_path,
+                          int batch_reads, const int *tier0, int rlen_max, int64_t *stats)
+{
+    Emu e;
+    std::string err;
+    if (!host_index_load(prefix, e.hix, err)) { fprintf(stderr, "%s\n", err.c_str()); return -1; }
+    set_view(e);
+    e.pm.max_pos_diff = 30; e.pm.max_mm_rate = 0.05f; e.pm.use_nw = alg == 0; e.pm.paired = 1;
+    e.caps[0].hit_cap = 48; e.caps[0].cand_cap = 12; e.caps[0].frag_cap = 96; e.caps[0].ops_cap = 1024; e.caps[0].job_cap = 16;
+    e.caps[0].cig_cap = 32; e.caps[0].kmer_cap = 2048;
+    if (tier0) { e.caps[0].hit_cap = tier0[0]; e.caps[0].cand_cap = tier0[1]; e.caps[0].frag_cap = tier0[2]; e.caps[0].ops_cap = tier0[3]; e.caps[0].job_cap = tier0[4]; }
+    int seeds = rlen_max / (kMinSeedLength + 1) + 1;
+    e.caps[1].hit_cap = seeds * kOccThr + rlen_max / 8 + 16; e.caps[1].cand_cap = e.caps[1].hit_cap;
+    e.caps[1].frag_cap = 3 * e.caps[1].hit_cap + 16; e.caps[1].ops_cap = 96 * 1024; e.caps[1].job_cap = 2048;
+    e.caps[1].cig_cap = 32; e.caps[1].kmer_cap = 4096;
+    for (int t = 0; t < 2; t++) e.lay[t] = make_layout(e.caps[t]);
+    e.mapq_rows = rlen_max + 64;
+    e.mapq.assign((size_t)e.mapq_rows * 6, 0);
+    for (int s = 1; s < e.mapq_rows; s++)
+        for (int d = 1; d <= 5 && d < s; d++) {
+            int sub = s - d;
+            int q = (int)(30 * (1 - (float)(s - sub) / s) * log(s) + 0.4999);
+            e.mapq[(size_t)s * 6 + d] = (uint8_t)(q > 60 ? 60 : q);
+        }
+    ReadFile f1, f2;
+    const bool paired = fq2 && fq2[0];
+    if (!f1.open(fq1, err) || (paired && !f2.open(fq2, err))) { fprintf(stderr, "%s\n", err.c_str()); return -1; }
+    FILE *sam = nullptr;
+    if (sam_path && sam_path[0]) {
+        sam = fopen(sam_path, "w");
+        std::string hdr; sam_header(e.hix, hdr); fputs(hdr.c_str(), sam);
+    }
+    int64_t avg[4] = {1000, 0, 0, 0};
+    int64_t total = 0, mapped = 0;
+    const size_t batch = std::max(200, batch_reads / 200 * 200);
+    bool eof = false;
+    std::string line;
+    while (!eof) {
+        Batch b;
+        b.off.assign(1, 0);
+        while (b.reads.size() < batch) {
+            HostRead x, y;
+            if (!f1.next(x)) { eof = true; break; }
+            b.reads.push_back(x);
+            if (paired) { f2.next(y); b.reads.push_back(y); }
+        }
+        if (b.reads.empty()) break;
+        for (auto &r : b.reads) { b.bases.insert(b.bases.end(), r.seq.begin(), r.seq.end()); b.off.push_back((uint32_t)b.bases.size()); }
+        const uint32_t n = (uint32_t)b.reads.size();
+        b.paired = paired && (n % 2 == 0);
+        b.codes.resize(b.bases.size());
+        for (uint32_t r = 0; r < n; r++) { // k_encode
+            const uint32_t o = b.off[r], len = b.off[r + 1] - o;
+            const bool flip = b.paired && (r & 1);
+            for (uint32_t i = 0; i < len; i++) {
+                int c = nt4_code(b.bases[o + (flip ? len - 1 - i : i)]);
+                if (flip && c < 4) c = 3 - c;
+                b.codes[o + i] = (uint8_t)c;
+            }
+        }
+        const uint32_t n_pairs = b.paired ? n / 2 : n;
+        std::vector<AlnRec> recs(n);
+        std::vector<uint32_t> cig((size_t)n * 32);
+        std::vector<PairOut> pout(n_pairs);
+        std::vector<uint32_t> ids(n_pairs);
+        for (uint32_t i = 0; i < n_pairs; i++) ids[i] = i;
+        std::vector<int32_t> est(n_pairs, (int32_t)((uint32_t)avg[0] * 1.5));
+        if (run_selection(e, b, ids, est, recs, cig, pout, stats)) return -4;
+        if (b.paired) {
+            std::vector<uint32_t> redo; std::vector<int32_t> redo_est;
+            int64_t after[4];
+            for (int iter = 0;; iter++) {
+                avg_replay(pout.data(), n_pairs, avg, redo, redo_est, after);
+                if (redo.empty()) break;
+                if (iter == 63) return -5;
+                if (stats) stats[10] += (int64_t)redo.size();
+                if (run_selection(e, b, redo, redo_est, recs, cig, pout, stats)) return -4;
+            }
+            avg[0] = after[0]; avg[1] = after[1]; avg[2] = after[2];
+        }
+        avg[3] += n;
+        total += n;
+        for (uint32_t p = 0; p < n_pairs; p++) mapped += pout[p].mapped;
+        if (sam)
+            for (uint32_t i = 0; i < n; i++) {
+                sam_line(e.hix, b.reads[i], b.paired && (i & 1), f1.fastq(), recs[i], cig.data() + (size_t)i * 32, line);
+                fputs(line.c_str(), sam); fputc('\n', sam);
+            }
+    }
+    if (sam) fclose(sam);
+    if (stats) { stats[0] = total; stats[1] = mapped; stats[2] = avg[1]; }
+    return total;
+}
+
+}
