@@ -1,0 +1,250 @@
+"""ctypes binding of include/mcx.h (libmcx.so) — the only way Python reaches the hot path.
+
+There is no Python or CPU fallback: if libmcx.so is missing, or no GPU is visible when a device
+function is called, an exception is raised.  torch tensors are accepted for device buffers only
+as raw pointers (torch is plumbing for HBM allocation and torch.distributed).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmcx.so")
+CIGAR_STRIDE = 32
+
+# every symbol include/mcx.h declares
+SYMBOLS = [
+    "mcx_last_error", "mcx_device_count", "mcx_index_load", "mcx_index_build", "mcx_index_free",
+    "mcx_index_genome_size", "mcx_index_n_chr", "mcx_index_chr_name", "mcx_index_chr_len", "mcx_index_hbm_bytes",
+    "mcx_opts_default", "mcx_ctx_create", "mcx_ctx_free", "mcx_bwt_search_batch", "mcx_extend_batch",
+    "mcx_avg_init", "mcx_map_batch_dev", "mcx_map_batch", "mcx_map_files",
+]
+
+
+class McxError(RuntimeError):
+    pass
+
+
+class Opts(C.Structure):
+    _fields_ = [("alg", C.c_int32), ("max_pos_diff", C.c_int32), ("max_mismatch_rate", C.c_float),
+                ("max_read_len", C.c_int32), ("max_batch_reads", C.c_int64)]
+
+
+class Aln(C.Structure):
+    _fields_ = [("pos", C.c_int64), ("mate_pos", C.c_int64), ("chr", C.c_int32), ("flag", C.c_int32),
+                ("mapq", C.c_int32), ("tlen", C.c_int32), ("nm", C.c_int32), ("as_", C.c_int32), ("xs", C.c_int32),
+                ("n_cigar", C.c_int32), ("fwd", C.c_int32), ("has_mate", C.c_int32)]
+
+
+ALN_DTYPE = np.dtype([("pos", "<i8"), ("mate_pos", "<i8"), ("chr", "<i4"), ("flag", "<i4"), ("mapq", "<i4"),
+                      ("tlen", "<i4"), ("nm", "<i4"), ("as", "<i4"), ("xs", "<i4"), ("n_cigar", "<i4"),
+                      ("fwd", "<i4"), ("has_mate", "<i4")])
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("reads", "mapped", "pairs", "pair_dist_sum", "fm_ext_steps", "fm_blocks",
+                                         "sa_hits", "dp_jobs", "dp_cells", "tier1_pairs", "replayed_pairs")] + \
+               [(n, C.c_double) for n in ("ms_encode", "ms_seed", "ms_sa", "ms_cluster", "ms_rescue", "ms_build",
+                                          "ms_dp", "ms_finish", "ms_total")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads libmcx.so (built by ``make -C mapcaller_amd/csrc`` / ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise McxError(f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')")
+    L = C.CDLL(LIB_PATH)
+    L.mcx_last_error.restype = C.c_char_p
+    L.mcx_index_genome_size.restype = C.c_int64
+    L.mcx_index_hbm_bytes.restype = C.c_int64
+    L.mcx_index_chr_name.restype = C.c_char_p
+    L.mcx_index_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.mcx_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    for f in (L.mcx_index_free, L.mcx_ctx_free):
+        f.argtypes = [C.c_void_p]
+        f.restype = None
+    for f in (L.mcx_index_genome_size, L.mcx_index_n_chr, L.mcx_index_hbm_bytes):
+        f.argtypes = [C.c_void_p]
+    L.mcx_index_chr_name.argtypes = [C.c_void_p, C.c_int32]
+    L.mcx_index_chr_len.argtypes = [C.c_void_p, C.c_int32]
+    L.mcx_opts_default.argtypes = [C.POINTER(Opts)]
+    L.mcx_opts_default.restype = None
+    L.mcx_ctx_create.argtypes = [C.c_void_p, C.POINTER(Opts), C.POINTER(C.c_void_p)]
+    L.mcx_bwt_search_batch.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_uint32] + [C.c_void_p] * 3
+    L.mcx_extend_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_uint32] + [C.c_void_p] * 3
+    L.mcx_avg_init.argtypes = [C.POINTER(C.c_int64)]
+    L.mcx_avg_init.restype = None
+    for f in (L.mcx_map_batch_dev, L.mcx_map_batch):
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_int64), C.c_void_p,
+                      C.c_void_p, C.POINTER(Stats)]
+    L.mcx_map_files.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(Stats)]
+    _lib = L
+    return L
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise McxError(f"{what} failed ({rc}): {lib().mcx_last_error().decode()}")
+
+
+def device_count() -> int:
+    return int(lib().mcx_device_count())
+
+
+class Index:
+    """FM-index + reference resident in HBM (mcx_index_load; reference src/bwt_index.cpp:150-258)."""
+
+    def __init__(self, prefix: str, device: int = 0, full_sa: bool = False):
+        self._h = C.c_void_p()
+        _check(lib().mcx_index_load(prefix.encode(), device, int(full_sa), C.byref(self._h)), "mcx_index_load")
+        self.device = device
+
+    @staticmethod
+    def build(fasta: str, prefix: str, device: int = 0) -> None:
+        _check(lib().mcx_index_build(fasta.encode(), prefix.encode(), device), "mcx_index_build")
+
+    @property
+    def genome_size(self) -> int:
+        return int(lib().mcx_index_genome_size(self._h))
+
+    @property
+    def hbm_bytes(self) -> int:
+        return int(lib().mcx_index_hbm_bytes(self._h))
+
+    @property
+    def chromosomes(self) -> List[Tuple[str, int]]:
+        L = lib()
+        return [(L.mcx_index_chr_name(self._h, i).decode(), int(L.mcx_index_chr_len(self._h, i)))
+                for i in range(L.mcx_index_n_chr(self._h))]
+
+    def close(self):
+        if self._h:
+            lib().mcx_index_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Mapper:
+    """One mapping context (mcx_ctx): a GPU, its scratch and the reference's tunables."""
+
+    def __init__(self, index: Index, alg: str = "nw", max_read_len: int = 256, max_batch_reads: int = 1 << 20,
+                 max_pos_diff: int = 30, max_mismatch_rate: float = 0.05):
+        if alg not in ("nw", "ksw2"):
+            raise ValueError("alg must be 'nw' or 'ksw2'")
+        self.index = index
+        o = Opts()
+        lib().mcx_opts_default(C.byref(o))
+        o.alg = 0 if alg == "nw" else 1
+        o.max_read_len = max_read_len
+        o.max_batch_reads = max_batch_reads
+        o.max_pos_diff = max_pos_diff
+        o.max_mismatch_rate = max_mismatch_rate
+        self._h = C.c_void_p()
+        _check(lib().mcx_ctx_create(index._h, C.byref(o), C.byref(self._h)), "mcx_ctx_create")
+        self.avg = (C.c_int64 * 4)()
+        lib().mcx_avg_init(self.avg)
+        self.stats = Stats()
+
+    def reset(self):
+        lib().mcx_avg_init(self.avg)
+        self.stats = Stats()
+
+    # ---- whole path ---------------------------------------------------------------------
+    def map_files(self, fq1: str, fq2: Optional[str], sam: Optional[str]) -> dict:
+        st = Stats()
+        _check(lib().mcx_map_files(self._h, fq1.encode(), (fq2 or "").encode() or None, (sam or "").encode() or None,
+                                   C.byref(st)), "mcx_map_files")
+        return st.as_dict()
+
+    def map_batch(self, bases: np.ndarray, off: np.ndarray, paired: bool):
+        """Host buffers: bases uint8 ASCII (concatenated), off uint32 [n+1]. Returns (aln, cigar)."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        n = off.size - 1
+        aln = np.zeros(n, dtype=ALN_DTYPE)
+        cig = np.zeros((n, CIGAR_STRIDE), dtype=np.uint32)
+        _check(lib().mcx_map_batch(self._h, bases.ctypes.data, off.ctypes.data, n, int(paired), self.avg,
+                                   aln.ctypes.data, cig.ctypes.data, C.byref(self.stats)), "mcx_map_batch")
+        return aln, cig
+
+    def map_batch_dev(self, d_bases_ptr: int, d_off_ptr: int, n_reads: int, paired: bool, d_aln_ptr: int, d_cigar_ptr: int):
+        """Device pointers (e.g. torch.Tensor.data_ptr()); results stay in HBM."""
+        _check(lib().mcx_map_batch_dev(self._h, d_bases_ptr, d_off_ptr, n_reads, int(paired), self.avg, d_aln_ptr,
+                                       d_cigar_ptr, C.byref(self.stats)), "mcx_map_batch_dev")
+
+    # ---- per-call drop-ins --------------------------------------------------------------
+    def bwt_search(self, seqs: List[bytes], starts: List[int]):
+        """BWT_Search for many (code string, start) queries. Returns (len, freq, loc[n,50])."""
+        n = len(seqs)
+        off = np.zeros(n + 1, dtype=np.uint32)
+        off[1:] = np.cumsum([len(s) for s in seqs])
+        buf = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
+        st = np.asarray(starts, dtype=np.int32)
+        ln = np.zeros(n, dtype=np.int32)
+        fr = np.zeros(n, dtype=np.int32)
+        loc = np.zeros((n, 50), dtype=np.uint64)
+        _check(lib().mcx_bwt_search_batch(self._h, buf.ctypes.data, off.ctypes.data, st.ctypes.data, n, ln.ctypes.data,
+                                          fr.ctypes.data, loc.ctypes.data), "mcx_bwt_search_batch")
+        return ln, fr, loc
+
+    def extend(self, alg: str, qs: List[bytes], ts: List[bytes]):
+        """nw_alignment / ksw2_alignment for many (read fragment, genome fragment) pairs (ASCII).
+        Returns (list of op strings of 'M','I','D', scores)."""
+        n = len(qs)
+        qo = np.zeros(n + 1, dtype=np.uint32)
+        to = np.zeros(n + 1, dtype=np.uint32)
+        qo[1:] = np.cumsum([len(s) for s in qs])
+        to[1:] = np.cumsum([len(s) for s in ts])
+        qb = np.frombuffer(b"".join(qs), dtype=np.uint8).copy()
+        tb = np.frombuffer(b"".join(ts), dtype=np.uint8).copy()
+        ops = np.zeros(int(qo[-1]) + int(to[-1]) + 16, dtype=np.uint8)
+        ol = np.zeros(n, dtype=np.int32)
+        sc = np.zeros(n, dtype=np.int32)
+        _check(lib().mcx_extend_batch(self._h, 0 if alg == "nw" else 1, qb.ctypes.data, qo.ctypes.data, tb.ctypes.data,
+                                      to.ctypes.data, n, ops.ctypes.data, ol.ctypes.data, sc.ctypes.data), "mcx_extend_batch")
+        out = []
+        for i in range(n):
+            b = int(qo[i]) + int(to[i])
+            out.append(ops[b:b + int(ol[i])].tobytes().decode())
+        return out, sc
+
+    def close(self):
+        if self._h:
+            lib().mcx_ctx_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def apply_ops(q: str, t: str, ops: str) -> Tuple[str, str]:
+    """Gapped strings the reference's nw_alignment / ksw2_alignment would leave in s1, s2."""
+    a, b, i, j = [], [], 0, 0
+    for o in ops:
+        if o == "M":
+            a.append(q[i]); b.append(t[j]); i += 1; j += 1
+        elif o == "I":
+            a.append(q[i]); b.append("-"); i += 1
+        else:
+            a.append("-"); b.append(t[j]); j += 1
+    return "".join(a), "".join(b)

@@ -1,8 +1,10 @@
 // oracle/ref_shim.cpp — TEST INFRASTRUCTURE ONLY.
 //
-// Thin extern "C" window onto the *real* reference objects (compiled by oracle/Makefile from
-// /root/reference/src where they lie; this file is ours).  It lets tests and the golden-vector
-// generator call the reference's own functions one at a time:
+// Line-oriented driver around the *real* reference objects (compiled by oracle/Makefile from
+// /root/reference/src where they lie; this file is ours), built as oracle/_ref/mcref_tool.  It
+// lets tests and the golden-vector generator call the reference's own functions one at a time
+// (an executable rather than a shared library: the BAM-only htslib symbols that
+// ReadMapping.cpp references stay unresolved, which a dlopen would refuse):
 //
 //   BWT_Search       (reference src/bwt_search.cpp:121, declared src/structure.h:279)
 //   nw_alignment     (src/nw_alignment.cpp:18,   declared src/structure.h:289)
@@ -87,4 +89,51 @@ int mcref_ksw2_extz(const uint8_t *q, int qlen, const uint8_t *t, int tlen, int 
     return (int)c.length();
 }
 
+}
+
+// stdin protocol, one request per line, one reply line each:
+//   L <prefix>                 -> "ok <genome size>"
+//   S <start> <codes 0-4>      -> "<len> <freq> <loc>..."            BWT_Search(seq, start, strlen)
+//   D <q ascii> <t ascii>      -> "<nw a1> <nw a2> <ksw2 a1> <ksw2 a2> <ez.score> <ops reversed>"
+int main()
+{
+    char *line = NULL;
+    size_t cap = 0;
+    ssize_t n;
+    while ((n = getline(&line, &cap, stdin)) > 0) {
+        while (n > 0 && (line[n - 1] == '\n' || line[n - 1] == '\r')) line[--n] = 0;
+        if (line[0] == 'L') {
+            int rc = mcref_load_index(line + 2);
+            printf("%s %lld\n", rc == 0 ? "ok" : "fail", mcref_genome_size());
+        } else if (line[0] == 'S') {
+            int start = 0, used = 0;
+            sscanf(line + 2, "%d %n", &start, &used);
+            const char *digits = line + 2 + used;
+            int L = (int)strlen(digits);
+            std::vector<uint8_t> seq(L);
+            for (int i = 0; i < L; i++) seq[i] = (uint8_t)(digits[i] - '0');
+            int len, freq;
+            uint64_t loc[64];
+            mcref_bwt_search(seq.data(), start, L, &len, &freq, loc);
+            printf("%d %d", len, freq);
+            for (int i = 0; i < freq; i++) printf(" %llu", (unsigned long long)loc[i]);
+            printf("\n");
+        } else if (line[0] == 'D') {
+            char *q = line + 2, *t = strchr(q, ' ');
+            if (!t) { printf("bad\n"); fflush(stdout); continue; }
+            *t++ = 0;
+            int m = (int)strlen(q), k = (int)strlen(t), c = m + k + 8;
+            std::vector<char> a1(c), a2(c), b1(c), b2(c), ops(c);
+            mcref_nw(q, m, t, k, a1.data(), a2.data(), c);
+            mcref_ksw2(q, m, t, k, b1.data(), b2.data(), c);
+            std::vector<uint8_t> qc(m), tc(k);
+            for (int i = 0; i < m; i++) qc[i] = nst_nt4_table[(uint8_t)q[i]];
+            for (int i = 0; i < k; i++) tc[i] = nst_nt4_table[(uint8_t)t[i]];
+            int score = 0;
+            mcref_ksw2_extz(qc.data(), m, tc.data(), k, &score, ops.data(), c);
+            printf("%s %s %s %s %d %s\n", a1.data(), a2.data(), b1.data(), b2.data(), score, ops.data());
+        } else printf("bad\n");
+        fflush(stdout);
+    }
+    return 0;
 }

@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ with the REAL reference.
+
+Runs only in the authoring container: it needs oracle/_ref/ (``make -C oracle ref``, which
+compiles /root/reference from its own sources) — the reference itself never travels.  What is
+committed are data files: index files written by ``MapCaller index``, seeded synthetic reads,
+the SAM the reference prints for them at ``-t 1`` and per-function input/output vectors obtained
+through oracle/_ref/mcref_tool (oracle/ref_shim.cpp).
+
+    python scripts/make_golden.py
+
+Sets
+----
+toy   reference test/ref.fa (70 kb, 1 contig); 1500 pairs x 150 bp sampled from test/mut.fa
+mc    synthetic 3-contig genome with dispersed + tandem repeats and N runs; 2000 pairs x 150 bp
+se    same genome as mc; 2000 single-end FASTA reads x 100 bp with some N
+long  synthetic 2-contig genome; 600 pairs x 250 bp at 1 % sub / 1 % ins / 1 % del per base
+Each set has ref.<alg>.sam.gz for nw and ksw2.
+func  bwt_search.json (queries on the toy index) and dp.json (nw/ksw2 strings, ez.score)
+"""
+import gzip
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mapcaller_amd import synth  # noqa: E402
+
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "MapCaller")
+REF_TOOL = os.path.join(ROOT, "oracle", "_ref", "mcref_tool")
+GOLD = os.path.join(ROOT, "tests", "golden")
+SKIP = 3000  # keep clear of the genome start, where the reference's mate rescue crashes
+
+
+def sh(*cmd):
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+def gz_write(path, data: bytes):
+    with open(path, "wb") as raw:  # mtime=0 keeps the files reproducible
+        with gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as fh:
+            fh.write(data)
+
+
+def make_set(name, fasta, donor, n, rlen, paired, seed, fastq=True, **kw):
+    out = os.path.join(GOLD, name)
+    os.makedirs(out, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        prefix = os.path.join(tmp, "idx")
+        sh(REF_BIN, "index", fasta, prefix)
+        for ext in ("bwt", "sa", "pac", "ann", "amb"):
+            shutil.copy(f"{prefix}.{ext}", os.path.join(out, f"idx.{ext}"))
+        bases, _ = synth.simulate_reads(donor, n, rlen, paired, seed, skip_head=SKIP, **kw)
+        ext = "fq" if fastq else "fa"
+        f1 = os.path.join(tmp, f"r1.{ext}")
+        f2 = os.path.join(tmp, f"r2.{ext}")
+        writer = synth.write_fastq if fastq else synth.write_fasta_reads
+        if paired:
+            writer(f1, bases, 0, 2)
+            writer(f2, bases, 1, 2)
+            files = ["-f", f1, "-f2", f2]
+        else:
+            writer(f1, bases, 0, 1)
+            files = ["-f", f1]
+        gz_write(os.path.join(out, f"r1.{ext}.gz"), open(f1, "rb").read())
+        if paired:
+            gz_write(os.path.join(out, f"r2.{ext}.gz"), open(f2, "rb").read())
+        for alg in ("nw", "ksw2"):
+            sam = os.path.join(tmp, f"{alg}.sam")
+            sh(REF_BIN, "-i", prefix, *files, "-alg", alg, "-sam", sam, "-no_vcf", "-t", "1")
+            data = open(sam, "rb").read()
+            assert data.count(b"\n") >= (2 * n if paired else n), (name, alg)
+            gz_write(os.path.join(out, f"ref.{alg}.sam.gz"), data)
+    print("set", name, "done")
+
+
+class RefTool:
+    """oracle/_ref/mcref_tool (the real reference's functions behind a line protocol)."""
+
+    def __init__(self, prefix):
+        self.p = subprocess.Popen([REF_TOOL], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        assert self.ask(f"L {prefix}").startswith("ok")
+
+    def ask(self, line):
+        self.p.stdin.write(line + "\n")
+        self.p.stdin.flush()
+        return self.p.stdout.readline().rstrip("\n")
+
+    def search(self, codes, start):
+        f = self.ask(f"S {start} " + "".join(str(int(c)) for c in codes)).split()
+        return int(f[0]), int(f[1]), [int(x) for x in f[2:]]
+
+    def dp(self, q, t):
+        f = self.ask(f"D {q} {t}").split(" ")
+        return {"nw": [f[0], f[1]], "ksw2": [f[2], f[3]], "ksw2_score": int(f[4]), "ksw2_ops_rev": f[5]}
+
+
+def make_func_vectors():
+    tool = RefTool(os.path.join(GOLD, "toy", "idx"))
+    rng = np.random.default_rng(5)
+    genome = synth.read_fasta("/root/reference/test/ref.fa").codes[0].numpy()
+    # --- BWT_Search: reads cut from the genome (both strands), a few errors and Ns, random start
+    queries = []
+    for _ in range(1500):
+        L = int(rng.integers(20, 160))
+        p = int(rng.integers(0, len(genome) - L))
+        s = genome[p:p + L].copy()
+        if rng.random() < 0.5:
+            s = (3 - s)[::-1].copy()
+        for _e in range(int(rng.integers(0, 4))):
+            s[int(rng.integers(0, L))] = int(rng.integers(0, 5))
+        start = int(rng.integers(0, max(1, L - 18)))
+        if s[start] > 3:
+            s[start] = 0
+        ln, fr, loc = tool.search(s, start)
+        queries.append({"seq": "".join("ACGTN"[c] for c in s), "start": start, "len": ln, "freq": fr, "loc": loc})
+    # low-complexity queries exercise the freq > 50 / short-match branches
+    for s in ("A" * 40, "AC" * 30, "ACGT" * 20):
+        ln, fr, loc = tool.search(["ACGT".index(c) for c in s], 0)
+        queries.append({"seq": s, "start": 0, "len": ln, "freq": fr, "loc": loc})
+    json.dump(queries, open(os.path.join(GOLD, "func", "bwt_search.json"), "w"))
+    # --- DP: related string pairs of many shapes
+    cases = []
+
+    def mutate(s, rate):
+        out = []
+        for ch in s:
+            u = rng.random()
+            if u < rate:
+                out.append("ACGT"[int(rng.integers(0, 4))])
+            elif u < 2 * rate:
+                continue
+            elif u < 3 * rate:
+                out.append(ch)
+                out.append("ACGT"[int(rng.integers(0, 4))])
+            else:
+                out.append(ch)
+        return "".join(out) or "A"
+
+    shapes = [(1, 1), (1, 5), (5, 1), (2, 3), (3, 3), (8, 8), (15, 16), (16, 15), (17, 17), (29, 29), (33, 31),
+              (63, 64), (64, 64), (65, 64), (64, 65), (100, 106), (127, 129), (130, 128), (200, 208), (257, 260)]
+    for m, n in shapes * 6 + [(int(rng.integers(1, 140)), 0) for _ in range(500)]:
+        t = "".join("ACGT"[int(c)] for c in rng.integers(0, 4, max(m, 1)))
+        q = mutate(t, float(rng.choice([0.0, 0.02, 0.08, 0.2])))
+        if n:
+            q = (q * 3)[:m] if len(q) < m else q[:m]
+            t2 = "".join("ACGT"[int(c)] for c in rng.integers(0, 4, n))
+            t = (t + t2)[:n]
+        if rng.random() < 0.1:
+            i = int(rng.integers(0, len(q)))
+            q = q[:i] + "N" + q[i + 1:]
+        if rng.random() < 0.05:
+            i = int(rng.integers(0, len(t)))
+            t = t[:i] + "N" + t[i + 1:]
+        rec = {"q": q, "t": t}
+        rec.update(tool.dp(q, t))
+        cases.append(rec)
+    json.dump(cases, open(os.path.join(GOLD, "func", "dp.json"), "w"))
+    print("func vectors done:", len(queries), "searches,", len(cases), "DP cases")
+
+
+def main():
+    if not (os.path.exists(REF_BIN) and os.path.exists(REF_TOOL)):
+        sys.exit("build the reference first: make -C oracle ref")
+    os.makedirs(os.path.join(GOLD, "func"), exist_ok=True)
+    mut = synth.read_fasta("/root/reference/test/mut.fa")
+    make_set("toy", "/root/reference/test/ref.fa", mut, 1500, 150, True, seed=7,
+             frag_mean=500, frag_sd=87, frag_min=350, frag_max=650)
+    with tempfile.TemporaryDirectory() as tmp:
+        g = synth.random_genome([160000, 120000, 90000], seed=11, n_repeats=25, repeat_len=600, tandem=12, n_runs=8)
+        fa = os.path.join(tmp, "mc.fa")
+        synth.write_fasta(fa, g)
+        donor = synth.mutate_genome(g, 12)
+        make_set("mc", fa, donor, 2000, 150, True, seed=13, sub=0.01)
+        make_set("se", fa, donor, 2000, 100, False, seed=14, fastq=False, n_rate=0.002)
+        g2 = synth.random_genome([150000, 150000], seed=21, n_repeats=8, tandem=4)
+        fa2 = os.path.join(tmp, "long.fa")
+        synth.write_fasta(fa2, g2)
+        make_set("long", fa2, synth.mutate_genome(g2, 22), 600, 250, True, seed=23, sub=0.01, ins=0.01, dele=0.01)
+    make_func_vectors()
+    torch.manual_seed(0)
+
+
+if __name__ == "__main__":
+    main()

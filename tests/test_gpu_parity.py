@@ -1,0 +1,143 @@
+"""Parity tests proper: the HIP path, called through the C ABI (libmcx.so), against the
+reference's golden vectors and against the oracle on freshly seeded inputs.
+Bar: bit-exact (integer / byte / index work)."""
+import ctypes
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, ROOT, SETS, sam_diff
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    from mapcaller_amd import api as a
+    a.lib()  # raises if the HIP extension is missing: there is no fallback
+    assert a.device_count() >= 1, "no GPU visible"
+    return a
+
+
+@pytest.fixture(scope="module")
+def toy(api, golden):
+    ix = api.Index(golden["toy"]["prefix"], device=0)
+    yield ix
+    ix.close()
+
+
+def test_bwt_search_equals_reference_vectors(api, toy):
+    q = json.load(open(os.path.join(GOLD, "func", "bwt_search.json")))
+    mp = api.Mapper(toy, max_batch_reads=4096)
+    seqs = [bytes("ACGTN".index(c) for c in r["seq"]) for r in q]
+    ln, fr, loc = mp.bwt_search(seqs, [r["start"] for r in q])
+    for i, r in enumerate(q):
+        assert (int(ln[i]), int(fr[i])) == (r["len"], r["freq"]), i
+        assert [int(x) for x in loc[i, :fr[i]]] == r["loc"], i
+    mp.close()
+
+
+@pytest.mark.parametrize("alg", ["nw", "ksw2"])
+def test_extend_equals_reference_vectors(api, toy, alg):
+    cases = json.load(open(os.path.join(GOLD, "func", "dp.json")))
+    mp = api.Mapper(toy, alg=alg, max_batch_reads=4096)
+    ops, score = mp.extend(alg, [c["q"].encode() for c in cases], [c["t"].encode() for c in cases])
+    for i, c in enumerate(cases):
+        assert list(api.apply_ops(c["q"], c["t"], ops[i])) == c[alg], (i, c["q"], c["t"], ops[i])
+        if alg == "ksw2":
+            assert int(score[i]) == c["ksw2_score"], i
+            assert ops[i][::-1] == c["ksw2_ops_rev"], i
+    mp.close()
+
+
+@pytest.mark.parametrize("alg", ["nw", "ksw2"])
+@pytest.mark.parametrize("name", list(SETS))
+def test_sam_equals_reference(api, golden, tmp_path, name, alg):
+    g = golden[name]
+    ix = api.Index(g["prefix"], device=0)
+    mp = api.Mapper(ix, alg=alg, max_batch_reads=1 << 14)
+    out = str(tmp_path / "gpu.sam")
+    st = mp.map_files(g["r1"], g["r2"], out)
+    assert st["reads"] > 0
+    nd, ex = sam_diff(g["sam"][alg], out)
+    assert nd == 0, ex
+    mp.close(); ix.close()
+
+
+def test_full_suffix_array_in_hbm_gives_the_same_sam(api, golden, tmp_path):
+    g = golden["mc"]
+    ix = api.Index(g["prefix"], device=0, full_sa=True)
+    mp = api.Mapper(ix, alg="ksw2", max_batch_reads=1 << 14)
+    out = str(tmp_path / "gpu.sam")
+    mp.map_files(g["r1"], g["r2"], out)
+    nd, ex = sam_diff(g["sam"]["ksw2"], out)
+    assert nd == 0, ex
+    mp.close(); ix.close()
+
+
+def test_small_batches_follow_the_avgdist_trajectory(api, golden, tmp_path):
+    g = golden["mc"]
+    ix = api.Index(g["prefix"], device=0)
+    mp = api.Mapper(ix, alg="nw", max_batch_reads=600)
+    out = str(tmp_path / "gpu.sam")
+    mp.map_files(g["r1"], g["r2"], out)
+    nd, ex = sam_diff(g["sam"]["nw"], out)
+    assert nd == 0, ex
+    mp.close(); ix.close()
+
+
+def _oracle_sam(prefix, f1, f2, alg, out):
+    L = ctypes.CDLL(os.path.join(ROOT, "oracle", "libmcx_oracle.so"))
+    L.mcxo_index_load.restype = ctypes.c_void_p
+    L.mcxo_index_load.argtypes = [ctypes.c_char_p]
+    L.mcxo_map_files.restype = ctypes.c_int64
+    L.mcxo_map_files.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p]
+    ix = L.mcxo_index_load(prefix.encode())
+    assert ix
+    n = L.mcxo_map_files(ix, f1.encode(), (f2 or "").encode(), 0 if alg == "nw" else 1, out.encode(), 1, None)
+    assert n > 0
+    return n
+
+
+@pytest.mark.parametrize("alg,rlen,paired", [("ksw2", 150, True), ("nw", 250, True), ("ksw2", 100, False)])
+def test_fresh_seeded_input_equals_oracle(api, tmp_path, alg, rlen, paired):
+    """A 2 Mbp genome with repeats, 40 k reads: GPU SAM == oracle SAM (and == the compiled
+    reference when oracle/_ref travelled to this box)."""
+    from mapcaller_amd import synth
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "MapCaller")
+    g = synth.random_genome([900000, 700000, 400000], seed=101 + rlen, n_repeats=60, repeat_len=800, tandem=30, n_runs=10)
+    fa = str(tmp_path / "g.fa")
+    synth.write_fasta(fa, g)
+    prefix = str(tmp_path / "g")
+    if os.path.exists(ref_bin):
+        subprocess.run([ref_bin, "index", fa, prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    else:
+        api.Index.build(fa, prefix, 0)
+    donor = synth.mutate_genome(g, 7)
+    n = 20000
+    bases, _ = synth.simulate_reads(donor, n, rlen, paired, seed=5, skip_head=3000, sub=0.01, ins=0.002, dele=0.002, n_rate=0.0005)
+    if paired:
+        f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+        synth.write_fastq(f1, bases, 0, 2); synth.write_fastq(f2, bases, 1, 2)
+    else:
+        f1, f2 = str(tmp_path / "r1.fa"), None
+        synth.write_fasta_reads(f1, bases, 0, 1)
+    ix = api.Index(prefix, device=0)
+    mp = api.Mapper(ix, alg=alg, max_read_len=max(256, rlen), max_batch_reads=1 << 15)
+    out = str(tmp_path / "gpu.sam")
+    st = mp.map_files(f1, f2, out)
+    ora = str(tmp_path / "ora.sam")
+    _oracle_sam(prefix, f1, f2, alg, ora)
+    nd, ex = sam_diff(ora, out)
+    assert nd == 0, ex
+    if os.path.exists(ref_bin):
+        rs = str(tmp_path / "ref.sam")
+        cmd = [ref_bin, "-i", prefix, "-f", f1] + (["-f2", f2] if f2 else []) + ["-alg", alg, "-sam", rs, "-no_vcf", "-t", "1"]
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        nd, ex = sam_diff(rs, out)
+        assert nd == 0, ex
+    assert st["mapped"] > 0.9 * st["reads"]
+    mp.close(); ix.close()

@@ -1,0 +1,55 @@
+"""The oracle (CPU restatement) against the reference's golden vectors — this is what pins it."""
+import ctypes
+import json
+import os
+
+import pytest
+
+from conftest import GOLD, SETS, sam_diff
+
+
+@pytest.mark.parametrize("alg", ["nw", "ksw2"])
+@pytest.mark.parametrize("name", list(SETS))
+def test_oracle_sam_equals_reference(oracle_lib, golden, tmp_path, name, alg):
+    g = golden[name]
+    ix = oracle_lib.mcxo_index_load(g["prefix"].encode())
+    assert ix
+    out = str(tmp_path / "o.sam")
+    st = (ctypes.c_int64 * 8)()
+    n = oracle_lib.mcxo_map_files(ix, g["r1"].encode(), (g["r2"] or "").encode(), 0 if alg == "nw" else 1, out.encode(), 1, st)
+    oracle_lib.mcxo_index_free(ix)
+    assert n > 0
+    nd, ex = sam_diff(g["sam"][alg], out)
+    assert nd == 0, ex
+
+
+def test_oracle_bwt_search_vectors(oracle_lib, golden):
+    q = json.load(open(os.path.join(GOLD, "func", "bwt_search.json")))
+    ix = oracle_lib.mcxo_index_load(golden["toy"]["prefix"].encode())
+    ln, fr = ctypes.c_int(), ctypes.c_int()
+    loc = (ctypes.c_uint64 * 50)()
+    for rec in q:
+        codes = bytes("ACGTN".index(c) for c in rec["seq"])
+        oracle_lib.mcxo_bwt_search(ix, codes, rec["start"], len(codes), ctypes.byref(ln), ctypes.byref(fr), loc)
+        assert (ln.value, fr.value) == (rec["len"], rec["freq"])
+        assert [int(loc[i]) for i in range(fr.value)] == rec["loc"]
+    oracle_lib.mcxo_index_free(ix)
+
+
+def test_oracle_dp_vectors(oracle_lib):
+    cases = json.load(open(os.path.join(GOLD, "func", "dp.json")))
+    for rec in cases:
+        q, t = rec["q"].encode(), rec["t"].encode()
+        cap = len(q) + len(t) + 8
+        o1, o2 = ctypes.create_string_buffer(cap), ctypes.create_string_buffer(cap)
+        oracle_lib.mcxo_nw(q, len(q), t, len(t), o1, o2, cap)
+        assert [o1.value.decode(), o2.value.decode()] == rec["nw"]
+        oracle_lib.mcxo_ksw2(q, len(q), t, len(t), o1, o2, cap)
+        assert [o1.value.decode(), o2.value.decode()] == rec["ksw2"]
+        sc = ctypes.c_int()
+        ops = ctypes.create_string_buffer(cap)
+        qc = bytes("ACGTN".index(c) for c in rec["q"])
+        tc = bytes("ACGTN".index(c) for c in rec["t"])
+        oracle_lib.mcxo_ksw2_extz(qc, len(qc), tc, len(tc), ctypes.byref(sc), ops, cap)
+        assert sc.value == rec["ksw2_score"]
+        assert ops.value.decode() == rec["ksw2_ops_rev"]
