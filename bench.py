@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py — reads/s of the seed-and-extend hot path on MI355X (BASELINE.json metric).
+
+A *step* is one pass of the whole path (encode, FM-index seeding, SA resolution, clustering /
+pairing / rescue, fragment construction, wavefront DP, scoring / MAPQ / CIGAR, avgDist replay)
+over one batch of synthetic 150 bp paired-end reads that already sit in HBM; the results
+(alignment records + CIGAR words) stay in HBM.  FASTQ parsing and SAM text are outside the timed
+region.
+
+Workload: GRCh38 itself cannot be obtained offline, so the genome is synthetic — uniform random
+contigs with planted dispersed repeats — sized by --genome-mbp (default below; the GPU index
+builder handles genomes up to 2.1 Gbp) and indexed on the GPU by the product's own builder
+inside this script (not timed).  Reads follow SURVEY.md §8d: 150 bp pairs, fragment N(500,50)
+clipped to [300,800], 0.5 % substitutions, 0.1 % insertions, 0.1 % deletions per base.
+
+One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE); every rank maps its own shard of
+pairs against its own replica of the index: weak scaling, no collective on the data path.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mbp", type=float, default=1000.0, help="synthetic genome size (Mbp)")
+    ap.add_argument("--contigs", type=int, default=24)
+    ap.add_argument("--batch-pairs", type=int, default=2_000_000, help="read pairs per step and per GPU")
+    ap.add_argument("--rlen", type=int, default=150)
+    ap.add_argument("--alg", default="ksw2", choices=["nw", "ksw2"])
+    ap.add_argument("--full-sa", type=int, default=1, help="keep every suffix-array entry in HBM")
+    ap.add_argument("--cpu-pairs", type=int, default=150_000, help="pairs of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--repeats", type=int, default=2000, help="planted dispersed repeat families")
+    return ap.parse_args()
+
+
+def make_genome(args, device, seed):
+    """Uniform random contigs (human-like length spread) with planted 1 kb repeats, in HBM."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    total = int(args.genome_mbp * 1e6)
+    w = torch.linspace(2.2, 0.5, args.contigs)
+    lens = (w / w.sum() * total).long()
+    lens = (lens // 4 * 4).clamp_(min=10000)
+    codes = torch.randint(0, 4, (int(lens.sum()),), generator=g, device=device, dtype=torch.uint8)
+    if args.repeats:
+        rl = 1000
+        unit_pos = torch.randint(0, codes.numel() - rl, (args.repeats,), generator=g, device=device)
+        dst = torch.randint(0, codes.numel() - rl, (args.repeats, 3), generator=g, device=device)
+        ar = torch.arange(rl, device=device)
+        units = codes[(unit_pos[:, None] + ar[None, :])]
+        for k in range(3):  # three extra copies of every family, ~1 % diverged
+            u = units.clone()
+            m = torch.rand(u.shape, generator=g, device=device) < 0.01
+            u = torch.where(m, (u + torch.randint(1, 4, u.shape, generator=g, device=device, dtype=torch.uint8)) % 4, u)
+            codes[(dst[:, k][:, None] + ar[None, :]).reshape(-1)] = u.reshape(-1)
+    return codes, [int(x) for x in lens]
+
+
+def make_reads(codes, lens, n_pairs, rlen, seed, device):
+    from mapcaller_amd import synth
+    parts, o = [], 0
+    for L in lens:
+        parts.append(codes[o:o + L])
+        o += L
+    donor = synth.Genome([f"chr{i + 1}" for i in range(len(lens))], parts)
+    bases, _ = synth.simulate_reads(donor, n_pairs, rlen, True, seed, frag_mean=500, frag_sd=50, frag_min=300, frag_max=800,
+                                    sub=0.005, ins=0.001, dele=0.001, device=device, chunk=1 << 19, skip_head=3000)
+    return bases  # uint8 ASCII [2 n_pairs, rlen]
+
+
+def cpu_baseline(args, index, bases_sample):
+    """The CPU path on this box's host cores, on a bounded sample of the same workload, index
+    load excluded (the reference starts its clock after loading, main.cpp:376)."""
+    from mapcaller_amd import synth
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "MapCaller")
+    port_bin = os.path.join(ROOT, "oracle", "mcx_oracle")
+    cores = os.cpu_count() or 1
+    n_pairs = bases_sample.shape[0] // 2
+    with tempfile.TemporaryDirectory() as tmp:
+        prefix = os.path.join(tmp, "idx")
+        index.save(prefix)
+        f1, f2 = os.path.join(tmp, "r1.fq"), os.path.join(tmp, "r2.fq")
+        t1, t2 = os.path.join(tmp, "t1.fq"), os.path.join(tmp, "t2.fq")
+        synth.write_fastq(f1, bases_sample, 0, 2)
+        synth.write_fastq(f2, bases_sample, 1, 2)
+        synth.write_fastq(t1, bases_sample[:400], 0, 2)
+        synth.write_fastq(t2, bases_sample[:400], 1, 2)
+        if os.path.exists(ref_bin):
+            kind = "reference"
+            def run(a, b):
+                cmd = [ref_bin, "-i", prefix, "-f", a, "-f2", b, "-alg", args.alg, "-sam", os.path.join(tmp, "o.sam"), "-no_vcf", "-t", str(cores), "-log", os.path.join(tmp, "job.log")]
+                t0 = time.perf_counter()
+                subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                return time.perf_counter() - t0
+        elif os.path.exists(port_bin):
+            kind = "port"
+            def run(a, b):
+                cmd = [port_bin, "-i", prefix, "-f", a, "-f2", b, "-alg", args.alg, "-sam", os.path.join(tmp, "o.sam"), "-t", str(cores)]
+                t0 = time.perf_counter()
+                subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                return time.perf_counter() - t0
+        else:
+            return None
+        t_load = run(t1, t2)           # 200 pairs: index load + start-up
+        t_full = run(f1, f2)
+        dt = max(t_full - t_load, 1e-3)
+        return {"value": round(2 * n_pairs / dt, 1), "unit": "reads/s", "cores": cores, "kind": kind,
+                "sample": f"{n_pairs} pairs x {args.rlen} bp of the same synthetic workload, -t {cores} -alg {args.alg} -sam (file) -no_vcf; "
+                          f"wall {t_full:.1f}s minus {t_load:.1f}s index load"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=dev)
+    from mapcaller_amd import api
+
+    # ---- set-up (not timed): genome, index, reads ------------------------------------------------
+    codes, lens = make_genome(args, dev, seed=1234)
+    t0 = time.perf_counter()
+    index = api.Index.from_codes(codes.data_ptr(), lens, device=local, full_sa=bool(args.full_sa))
+    t_index = time.perf_counter() - t0
+    n_steps = args.warmup + args.steps
+    reads_per_step = 2 * args.batch_pairs
+    mapper = api.Mapper(index, alg=args.alg, max_read_len=max(256, args.rlen), max_batch_reads=reads_per_step)
+    batches = []
+    for s in range(n_steps):
+        b = make_reads(codes, lens, args.batch_pairs, args.rlen, seed=1000 * (rank + 1) + s, device=dev)
+        batches.append(b.reshape(-1).contiguous())
+    off = (torch.arange(reads_per_step + 1, device=dev, dtype=torch.int64) * args.rlen).to(torch.uint32)
+    sample = batches[0].reshape(reads_per_step, args.rlen)[: 2 * args.cpu_pairs].cpu() if (rank == 0 and world == 1 and args.cpu_pairs) else None
+    del codes
+    d_aln = torch.empty(reads_per_step * 64, dtype=torch.uint8, device=dev)
+    d_cig = torch.empty(reads_per_step * api.CIGAR_STRIDE, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def step(i):
+        mapper.map_batch_dev(batches[i].data_ptr(), off.data_ptr(), reads_per_step, True, d_aln.data_ptr(), d_cig.data_ptr())
+
+    for i in range(args.warmup):
+        step(i)
+    before = mapper.stats.as_dict()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_steps):
+        step(i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    after = mapper.stats.as_dict()
+    d = {k: after[k] - before[k] for k in after}
+
+    if rank == 0:
+        total_reads = reads_per_step * args.steps * world
+        # dominant kernel: k_seed.  Algorithmic bytes per launch (seeding term):
+        # 64 B per FM block the walk touches + the read's own bases; both counted by the kernel.
+        seed_bytes = 64.0 * d["fm_blocks"] + float(d["reads"]) * args.rlen
+        seed_ms = d["ms_seed"] / max(args.steps, 1)
+        achieved = seed_bytes / args.steps / (seed_ms * 1e-3) / 1e9 if seed_ms > 0 else 0.0
+        out = {
+            "metric": "reads/sec (150 bp PE vs GRCh38) at 1/2/4/8 MI355X; SAM CIGAR bit-exact",
+            "value": round(total_reads / dt, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64/int8", "data": "synthetic",
+            "config": {"workload": f"synthetic {args.genome_mbp:.0f} Mbp genome ({args.contigs} contigs, {args.repeats} x4 1-kb repeat families; GRCh38 unavailable offline), "
+                                   f"{args.batch_pairs} pairs x {args.rlen} bp PE per step per GPU, -alg {args.alg}",
+                       "reads_per_step_per_gpu": reads_per_step, "full_sa_in_hbm": bool(args.full_sa), "index_build_s": round(t_index, 2),
+                       "index_hbm_gb": round(index.hbm_bytes / 1e9, 2)},
+            "roofline": {"bound": "hbm", "kernel": "k_seed", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_read": round(seed_bytes / max(d["reads"], 1), 1), "avg_launch_ms": round(seed_ms, 3)},
+            "per_read": {"fm_ext_steps": round(d["fm_ext_steps"] / max(d["reads"], 1), 2), "fm_blocks": round(d["fm_blocks"] / max(d["reads"], 1), 2),
+                         "sa_hits": round(d["sa_hits"] / max(d["reads"], 1), 3), "dp_jobs": round(d["dp_jobs"] / max(d["reads"], 1), 4),
+                         "mapped_frac": round(d["mapped"] / max(d["reads"], 1), 4)},
+            "stage_ms_per_step": {k[3:]: round(d[k] / args.steps, 3) for k in d if k.startswith("ms_")},
+            "tier1_pairs": d["tier1_pairs"], "replayed_pairs": d["replayed_pairs"],
+        }
+        if sample is not None:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, index, sample)
+            except Exception as e:  # the baseline must never take the bench line down
+                out["cpu_baseline"] = {"error": str(e)[:200]}
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

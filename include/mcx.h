@@ -43,6 +43,11 @@ int mcx_index_load(const char *prefix, int device, int full_sa, mcx_index **out)
  * src/main.cpp:199-207): builds BWT/occ/SA on the GPU from a FASTA file and writes the same
  * five files. */
 int mcx_index_build(const char *fasta_path, const char *prefix, int device);
+/* The same construction for a genome that already sits in HBM (one code 0..3 per byte, contigs
+ * concatenated): builds the index in place, no files.  mcx_index_save writes the five files. */
+int mcx_index_from_codes(const uint8_t *d_codes, int32_t n_chr, const int32_t *chr_len, const char *const *chr_name,
+                         int device, int full_sa, mcx_index **out, double *build_seconds);
+int mcx_index_save(const mcx_index *, const char *prefix);
 void mcx_index_free(mcx_index *);
 int64_t mcx_index_genome_size(const mcx_index *);
 int32_t mcx_index_n_chr(const mcx_index *);

@@ -18,7 +18,7 @@ CIGAR_STRIDE = 32
 
 # every symbol include/mcx.h declares
 SYMBOLS = [
-    "mcx_last_error", "mcx_device_count", "mcx_index_load", "mcx_index_build", "mcx_index_free",
+    "mcx_last_error", "mcx_device_count", "mcx_index_load", "mcx_index_build", "mcx_index_from_codes", "mcx_index_save", "mcx_index_free",
     "mcx_index_genome_size", "mcx_index_n_chr", "mcx_index_chr_name", "mcx_index_chr_len", "mcx_index_hbm_bytes",
     "mcx_opts_default", "mcx_ctx_create", "mcx_ctx_free", "mcx_bwt_search_batch", "mcx_extend_batch",
     "mcx_avg_init", "mcx_map_batch_dev", "mcx_map_batch", "mcx_map_files",
@@ -72,6 +72,9 @@ def lib() -> C.CDLL:
     L.mcx_index_chr_name.restype = C.c_char_p
     L.mcx_index_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.mcx_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    L.mcx_index_from_codes.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_char_p), C.c_int, C.c_int,
+                                       C.POINTER(C.c_void_p), C.POINTER(C.c_double)]
+    L.mcx_index_save.argtypes = [C.c_void_p, C.c_char_p]
     for f in (L.mcx_index_free, L.mcx_ctx_free):
         f.argtypes = [C.c_void_p]
         f.restype = None
@@ -106,10 +109,29 @@ def device_count() -> int:
 class Index:
     """FM-index + reference resident in HBM (mcx_index_load; reference src/bwt_index.cpp:150-258)."""
 
-    def __init__(self, prefix: str, device: int = 0, full_sa: bool = False):
+    def __init__(self, prefix: Optional[str], device: int = 0, full_sa: bool = False):
         self._h = C.c_void_p()
-        _check(lib().mcx_index_load(prefix.encode(), device, int(full_sa), C.byref(self._h)), "mcx_index_load")
         self.device = device
+        self.build_seconds = None
+        if prefix is not None:
+            _check(lib().mcx_index_load(prefix.encode(), device, int(full_sa), C.byref(self._h)), "mcx_index_load")
+
+    @classmethod
+    def from_codes(cls, d_codes_ptr: int, chr_lens: List[int], chr_names: Optional[List[str]] = None, device: int = 0,
+                   full_sa: bool = False) -> "Index":
+        """Builds the index on the GPU from a genome already in HBM (codes 0..3, contigs concatenated)."""
+        self = cls(None, device)
+        n = len(chr_lens)
+        lens = (C.c_int32 * n)(*chr_lens)
+        names = (C.c_char_p * n)(*[(chr_names[i] if chr_names else f"chr{i + 1}").encode() for i in range(n)])
+        secs = C.c_double()
+        _check(lib().mcx_index_from_codes(d_codes_ptr, n, lens, names, device, int(full_sa), C.byref(self._h), C.byref(secs)),
+               "mcx_index_from_codes")
+        self.build_seconds = secs.value
+        return self
+
+    def save(self, prefix: str) -> None:
+        _check(lib().mcx_index_save(self._h, prefix.encode()), "mcx_index_save")
 
     @staticmethod
     def build(fasta: str, prefix: str, device: int = 0) -> None:

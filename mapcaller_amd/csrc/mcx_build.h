@@ -1,0 +1,17 @@
+// mapcaller_amd/csrc/mcx_build.h — interface between the GPU index builder and the pipeline
+#ifndef MCX_BUILD_H
+#define MCX_BUILD_H
+#include <stdint.h>
+#include <string>
+
+struct DevIndexArrays {         // device arrays in the on-disk layout of the reference's index
+    uint32_t *bwt = nullptr; uint64_t bwt_words = 0;   // words after the 40-byte .bwt header
+    uint64_t *sa = nullptr; uint64_t n_sa = 0;         // sampled every 32 rows, sa[0] = ~0
+    uint64_t *sa_full = nullptr;                       // optional: all N + 1 rows
+    uint64_t primary = 0, L2[5] = {0, 0, 0, 0, 0}, seq_len = 0;
+};
+
+// d_fwd: forward genome, one code (0..3) per byte, in HBM
+int mcx_build_suffix_index(const uint8_t *d_fwd, uint64_t G, bool want_full_sa, DevIndexArrays &out, double *seconds);
+int mcx_set_error(int code, const std::string &msg);
+#endif

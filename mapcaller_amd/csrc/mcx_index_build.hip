@@ -1,10 +1,415 @@
-// mapcaller_amd/csrc/mcx_index_build.hip — GPU construction of the BWA-compatible index
-// (replaces bwa_idx_build, reference src/BWT_Index/bwtindex.c:77-160).  Placeholder until the
-// suffix-array builder lands: reports MCX_ERR_UNSUPPORTED rather than falling back to the CPU.
+// mapcaller_amd/csrc/mcx_index_build.hip — BWA-compatible FM-index construction on the GPU.
+//
+// Replaces bwa_idx_build (reference src/BWT_Index/bwtindex.c:77-160): bns_fasta2bntseq
+// (bntseq.c:158-230) packs the FASTA, bwt_bwtgen2 builds the BWT of forward+reverse-complement
+// text on the CPU (bwt_gen.c, ~1 h for a human genome), bwt_bwtupdate_core (:53-75) interleaves
+// the occurrence counts and bwt_cal_sa (bwt.c:101-125) samples the suffix array every 32 rows.
+// The output files are byte-identical; the construction is not a port:
+//
+//   text T = X . revcomp(X) stays in HBM as one byte per base; the suffix array is built by
+//   prefix doubling with hipCUB radix sorts (first pass on 16-base packed keys, then rank
+//   pairs (r[i], r[i+h]) with h = 16, 32, ...), BWT / occ blocks / SA samples are derived by one
+//   pass over the finished array.  Everything is sized for one GPU's HBM (about 30 bytes per
+//   text position); texts of 2^32 positions or more are refused (MCX_ERR_UNSUPPORTED).
 #include <hip/hip_runtime.h>
-#include "../../include/mcx.h"
+#include <hipcub/hipcub.hpp>
 
-extern "C" int mcx_index_build(const char *, const char *, int)
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <zlib.h>
+
+#include "../../include/mcx.h"
+#include "mcx_host.h"
+#include "mcx_types.h"
+#include "mcx_build.h"
+
+using namespace mcx;
+
+
+#define HIP_TRYB(expr)                                                                            \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return mcx_set_error(MCX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+// T[i] = X[i] (i < G), T[G + i] = 3 - X[G - 1 - i]
+__global__ void k_make_text(const uint8_t *fwd, uint64_t G, uint8_t *T)
 {
-    return MCX_ERR_UNSUPPORTED;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < G; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint8_t c = fwd[i];
+        T[i] = c;
+        T[2 * G - 1 - i] = (uint8_t)(3 - c);
+    }
+}
+
+// first-pass key: 16 bases packed MSB first (positions past the end read as 0) and, below them,
+// the number of real bases (a suffix that runs into the terminator sorts before a longer one
+// with the same padded prefix)
+__global__ void k_init_keys(const uint8_t *T, uint64_t N, uint64_t *key, uint32_t *idx)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t k = 0;
+        uint64_t rem = N - i;
+        int real = rem < 16 ? (int)rem : 16;
+        for (int j = 0; j < 16; j++) k = (k << 2) | (j < real ? T[i + j] : 0);
+        key[i] = (k << 5) | (uint64_t)real;
+        idx[i] = (uint32_t)i;
+    }
+}
+
+// head[j] = j if the sorted key at j differs from its predecessor, else 0 (j = 0 is a head)
+__global__ void k_mark_heads(const uint64_t *key, uint64_t N, uint32_t *head)
+{
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < N; j += (uint64_t)gridDim.x * blockDim.x)
+        head[j] = (j == 0 || key[j] != key[j - 1]) ? (uint32_t)j : 0u;
+}
+
+// after an inclusive max-scan head[j] is the first index of j's group: rank = that + 1
+__global__ void k_scatter_rank(const uint32_t *idx, const uint32_t *head, uint64_t N, uint32_t *rank, unsigned long long *n_groups)
+{
+    unsigned long long local = 0;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < N; j += (uint64_t)gridDim.x * blockDim.x) {
+        rank[idx[j]] = head[j] + 1;
+        if (head[j] == (uint32_t)j) local++;
+    }
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(n_groups, local);
+}
+
+// doubling key for the suffix at idx[j]: (rank[i], rank[i + h]) with 0 past the end
+__global__ void k_pair_keys(const uint32_t *idx, const uint32_t *rank, uint64_t N, uint64_t h, uint64_t *key)
+{
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < N; j += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t i = idx[j];
+        uint64_t r2 = i + h < N ? rank[i + h] : 0;
+        key[j] = ((uint64_t)rank[i] << 32) | r2;
+    }
+}
+
+struct BuildOut {
+    uint32_t *bwt;      // occ-interleaved words
+    uint64_t *sa;       // sampled, sa[0] = ~0
+    uint64_t *sa_full;  // optional, N + 1 entries
+    unsigned long long *primary;
+};
+
+// Row r of the sorted matrix of T$ (r in [0, N]): row 0 is "$" (SA = N), row r >= 1 is idx[r-1].
+// BWT char of a row = T[SA - 1]; the row with SA = 0 is `primary` and is skipped in the packed
+// string, so string position m = r - (r > primary).  One thread packs 16 symbols (one word).
+__global__ void k_pack_bwt(const uint8_t *T, const uint32_t *idx, uint64_t N, uint64_t primary, uint32_t *words)
+{
+    const uint64_t n_words = (N + 15) / 16;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t v = 0;
+        for (int s = 0; s < 16; s++) {
+            uint64_t m = w * 16 + s;
+            uint32_t c = 0;
+            if (m < N) {
+                uint64_t r = m + (m >= primary);
+                uint64_t sa = r == 0 ? N : idx[r - 1];
+                c = T[sa - 1];
+            }
+            v = (v << 2) | c;
+        }
+        words[w] = v;
+    }
+}
+
+// per 128-symbol block: counts of A,C,G,T inside the block (to be prefix-summed)
+__global__ void k_block_counts(const uint32_t *words, uint64_t N, uint64_t n_blocks, uint64_t *cnt /* 4 x n_blocks, base-major */)
+{
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t c[4] = {0, 0, 0, 0};
+        for (int j = 0; j < 8; j++) {
+            uint64_t w = b * 8 + j;
+            uint64_t first = w * 16;
+            if (first >= N) break;
+            int m = N - first < 16 ? (int)(N - first) : 16;
+            uint32_t v = words[w];
+            for (int s = 0; s < m; s++) c[(v >> (30 - 2 * s)) & 3]++;
+        }
+        for (int k = 0; k < 4; k++) cnt[k * n_blocks + b] = c[k];
+    }
+}
+
+// final layout: block b = {4 x u64 exclusive prefix counts, up to 8 words}; trailing totals
+__global__ void k_interleave(const uint32_t *words, const uint64_t *excl /* 4 x n_blocks */, const uint64_t *total, uint64_t N,
+                             uint64_t n_blocks, uint32_t *out)
+{
+    const uint64_t n_words = (N + 15) / 16;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b <= n_blocks; b += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t *o = out + b * 16;
+        if (b == n_blocks) { // trailing occ block sits right after the last (possibly short) block
+            o = out + n_blocks * 8 + n_words;
+            for (int k = 0; k < 4; k++) { o[2 * k] = (uint32_t)total[k]; o[2 * k + 1] = (uint32_t)(total[k] >> 32); }
+            continue;
+        }
+        for (int k = 0; k < 4; k++) { uint64_t v = excl[k * n_blocks + b]; o[2 * k] = (uint32_t)v; o[2 * k + 1] = (uint32_t)(v >> 32); }
+        for (int j = 0; j < 8; j++) { uint64_t w = b * 8 + j; if (w < n_words) o[8 + j] = words[w]; }
+    }
+}
+
+__global__ void k_sample_sa(const uint32_t *idx, uint64_t N, int intv, uint64_t n_sa, uint64_t *sa, uint64_t *sa_full)
+{
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= N; r += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t v = r == 0 ? N : idx[r - 1];
+        if (sa_full) sa_full[r] = r == 0 ? ~0ull : v;
+        if (r % intv == 0 && r / intv < n_sa) sa[r / intv] = r == 0 ? ~0ull : v;
+    }
+}
+
+__global__ void k_find_primary(const uint32_t *idx, uint64_t N, unsigned long long *primary)
+{
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < N; j += (uint64_t)gridDim.x * blockDim.x)
+        if (idx[j] == 0) *primary = j + 1;
+}
+
+__global__ void k_count_bases(const uint8_t *T, uint64_t N, unsigned long long *cnt)
+{
+    unsigned long long c[4] = {0, 0, 0, 0};
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (uint64_t)gridDim.x * blockDim.x) c[T[i] & 3]++;
+    for (int k = 0; k < 4; k++) {
+        unsigned long long v = c[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(cnt + k, v);
+    }
+}
+
+struct MaxOp { __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; } };
+
+// ---------------------------------------------------------------------------------------------
+// builder: forward codes in HBM -> HostIndex-compatible device arrays
+// ---------------------------------------------------------------------------------------------
+int mcx_build_suffix_index(const uint8_t *d_fwd, uint64_t G, bool want_full_sa, DevIndexArrays &out, double *seconds)
+{
+    const uint64_t N = 2 * G;
+    if (N == 0) return mcx_set_error(MCX_ERR_ARG, "empty genome");
+    if (N >= 0xFFFFFFF0ull) return mcx_set_error(MCX_ERR_UNSUPPORTED, "GPU index construction handles texts below 2^32 positions (genome < 2.1 Gbp)");
+    hipEvent_t e0, e1;
+    HIP_TRYB(hipEventCreate(&e0)); HIP_TRYB(hipEventCreate(&e1));
+    HIP_TRYB(hipEventRecord(e0));
+    uint8_t *T = nullptr;
+    uint64_t *key[2] = {nullptr, nullptr};
+    uint32_t *idx[2] = {nullptr, nullptr}, *rank = nullptr, *head = nullptr;
+    unsigned long long *d_misc = nullptr; // [0] groups, [1] primary, [2..5] base counts
+    HIP_TRYB(hipMalloc(&T, N + 64));
+    HIP_TRYB(hipMemset(T + N, 0, 64));
+    for (int k = 0; k < 2; k++) { HIP_TRYB(hipMalloc(&key[k], N * 8)); HIP_TRYB(hipMalloc(&idx[k], N * 4)); }
+    HIP_TRYB(hipMalloc(&rank, N * 4));
+    HIP_TRYB(hipMalloc(&head, N * 4));
+    HIP_TRYB(hipMalloc(&d_misc, 8 * sizeof(unsigned long long)));
+    HIP_TRYB(hipMemset(d_misc, 0, 8 * sizeof(unsigned long long)));
+    const unsigned grid = 4096, block = 256;
+    k_make_text<<<grid, block>>>(d_fwd, G, T);
+    k_count_bases<<<grid, block>>>(T, N, d_misc + 2);
+    k_init_keys<<<grid, block>>>(T, N, key[0], idx[0]);
+    // temp storage for sort + scan
+    size_t sort_bytes = 0, scan_bytes = 0;
+    {
+        hipcub::DoubleBuffer<uint64_t> dk(key[0], key[1]);
+        hipcub::DoubleBuffer<uint32_t> dv(idx[0], idx[1]);
+        HIP_TRYB(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, dk, dv, (int64_t)N, 0, 64));
+        HIP_TRYB(hipcub::DeviceScan::InclusiveScan(nullptr, scan_bytes, head, head, MaxOp(), (int64_t)N));
+    }
+    void *tmp = nullptr;
+    const size_t tmp_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+    HIP_TRYB(hipMalloc(&tmp, tmp_bytes));
+    int cur = 0;
+    uint64_t h = 16;
+    for (int iter = 0;; iter++) {
+        hipcub::DoubleBuffer<uint64_t> dk(key[cur], key[1 - cur]);
+        hipcub::DoubleBuffer<uint32_t> dv(idx[cur], idx[1 - cur]);
+        size_t sb = tmp_bytes;
+        HIP_TRYB(hipcub::DeviceRadixSort::SortPairs(tmp, sb, dk, dv, (int64_t)N, 0, iter == 0 ? 37 : 64));
+        if (dk.Current() != key[cur]) cur = 1 - cur;
+        if (dv.Current() != idx[cur]) return mcx_set_error(MCX_ERR_DEVICE, "radix sort left keys and values in different buffers");
+        k_mark_heads<<<grid, block>>>(key[cur], N, head);
+        size_t cb = tmp_bytes;
+        HIP_TRYB(hipcub::DeviceScan::InclusiveScan(tmp, cb, head, head, MaxOp(), (int64_t)N));
+        HIP_TRYB(hipMemset(d_misc, 0, sizeof(unsigned long long)));
+        k_scatter_rank<<<grid, block>>>(idx[cur], head, N, rank, d_misc);
+        unsigned long long groups = 0;
+        HIP_TRYB(hipMemcpy(&groups, d_misc, sizeof groups, hipMemcpyDeviceToHost));
+        if (groups == N) break;
+        if (h >= N) return mcx_set_error(MCX_ERR_DEVICE, "suffix sorting did not converge");
+        k_pair_keys<<<grid, block>>>(idx[cur], rank, N, h, key[cur]);
+        h <<= 1;
+    }
+    // idx[cur] is the suffix array of T (without the terminator row)
+    const uint32_t *SA = idx[cur];
+    k_find_primary<<<grid, block>>>(SA, N, d_misc + 1);
+    unsigned long long misc[8];
+    HIP_TRYB(hipMemcpy(misc, d_misc, sizeof misc, hipMemcpyDeviceToHost));
+    out.primary = misc[1]; out.seq_len = N;
+    out.L2[0] = 0;
+    for (int k = 0; k < 4; k++) out.L2[k + 1] = out.L2[k] + misc[2 + k];
+    // BWT words (reuse key buffers as scratch)
+    const uint64_t n_words = (N + 15) / 16, n_blocks = (N + 127) / 128;
+    uint32_t *words = (uint32_t *)key[1 - cur];
+    k_pack_bwt<<<grid, block>>>(T, SA, N, out.primary, words);
+    uint64_t *cnt = (uint64_t *)key[cur]; // 4 x n_blocks counts, then exclusive sums in place
+    k_block_counts<<<grid, block>>>(words, N, n_blocks, cnt);
+    uint64_t *d_total = nullptr;
+    HIP_TRYB(hipMalloc(&d_total, 4 * 8));
+    for (int k = 0; k < 4; k++) {
+        size_t cb = 0;
+        HIP_TRYB(hipcub::DeviceScan::ExclusiveSum(nullptr, cb, cnt + k * n_blocks, cnt + k * n_blocks, (int64_t)n_blocks));
+        if (cb > tmp_bytes) return mcx_set_error(MCX_ERR_DEVICE, "scan scratch too small");
+        HIP_TRYB(hipcub::DeviceScan::ExclusiveSum(tmp, cb, cnt + k * n_blocks, cnt + k * n_blocks, (int64_t)n_blocks));
+    }
+    uint64_t totals[4];
+    for (int k = 0; k < 4; k++) totals[k] = misc[2 + k];
+    HIP_TRYB(hipMemcpy(d_total, totals, sizeof totals, hipMemcpyHostToDevice));
+    out.bwt_words = n_blocks * 8 + n_words + 8;
+    HIP_TRYB(hipMalloc(&out.bwt, out.bwt_words * 4 + 128));
+    HIP_TRYB(hipMemset(out.bwt, 0, out.bwt_words * 4 + 128));
+    k_interleave<<<grid, block>>>(words, cnt, d_total, N, n_blocks, out.bwt);
+    out.n_sa = (N + 32) / 32;
+    HIP_TRYB(hipMalloc(&out.sa, out.n_sa * 8));
+    if (want_full_sa) HIP_TRYB(hipMalloc(&out.sa_full, (N + 1) * 8));
+    k_sample_sa<<<grid, block>>>(SA, N, 32, out.n_sa, out.sa, out.sa_full);
+    HIP_TRYB(hipGetLastError());
+    HIP_TRYB(hipEventRecord(e1));
+    HIP_TRYB(hipDeviceSynchronize());
+    float ms = 0;
+    HIP_TRYB(hipEventElapsedTime(&ms, e0, e1));
+    if (seconds) *seconds = ms / 1000.0;
+    (void)hipFree(T); (void)hipFree(key[0]); (void)hipFree(key[1]); (void)hipFree(idx[0]); (void)hipFree(idx[1]);
+    (void)hipFree(rank); (void)hipFree(head); (void)hipFree(d_misc); (void)hipFree(tmp); (void)hipFree(d_total);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FASTA -> packed genome + .ann/.amb/.pac exactly as bns_fasta2bntseq(fp, prefix, for_only=1)
+// ---------------------------------------------------------------------------------------------
+struct FastaSeq { std::string name, comment, seq; };
+
+static bool read_fasta(const char *path, std::vector<FastaSeq> &out, std::string &err)
+{
+    gzFile g = gzopen(path, "rb");
+    if (!g) { err = std::string("cannot open ") + path; return false; }
+    gzbuffer(g, 1 << 20);
+    std::vector<char> buf(1 << 16);
+    std::string line;
+    FastaSeq *cur = nullptr;
+    for (;;) {
+        line.clear();
+        bool got = false;
+        while (gzgets(g, buf.data(), (int)buf.size())) { got = true; line += buf.data(); if (!line.empty() && line.back() == '\n') break; }
+        if (!got) break;
+        while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
+        if (!line.empty() && line[0] == '>') {
+            out.emplace_back();
+            cur = &out.back();
+            size_t i = 1;
+            while (i < line.size() && !isspace((unsigned char)line[i])) i++;
+            cur->name = line.substr(1, i - 1);
+            cur->comment = i < line.size() ? line.substr(i + 1) : std::string(); // kseq: the rest after one delimiter
+        } else if (cur) {
+            for (char c : line) if (!isspace((unsigned char)c)) cur->seq.push_back(c); // kseq keeps graphic characters only
+        }
+    }
+    gzclose(g);
+    if (out.empty()) { err = std::string(path) + " holds no FASTA record"; return false; }
+    return true;
+}
+
+extern "C" int mcx_index_build(const char *fasta_path, const char *prefix, int device)
+{
+    if (!fasta_path || !prefix) return mcx_set_error(MCX_ERR_ARG, "mcx_index_build: null argument");
+    std::vector<FastaSeq> seqs;
+    std::string err;
+    if (!read_fasta(fasta_path, seqs, err)) return mcx_set_error(MCX_ERR_IO, err);
+    HIP_TRYB(hipSetDevice(device));
+    // pack: N (anything that is not ACGT) -> lrand48() & 3 with the generator seeded by 11 (bntseq.c:171-172, :130)
+    srand48(11);
+    struct Hole { long long off; int len; char amb; };
+    std::vector<Hole> holes;
+    std::vector<uint8_t> codes;
+    struct Ann { long long off; int len, n_ambs; };
+    std::vector<Ann> anns;
+    long long l_pac = 0;
+    for (auto &s : seqs) {
+        Ann a; a.off = l_pac; a.len = (int)s.seq.size(); a.n_ambs = 0;
+        int lasts = 0;
+        for (size_t i = 0; i < s.seq.size(); i++) {
+            int ch = (unsigned char)s.seq[i];
+            int c;
+            switch (ch) { case 'A': case 'a': c = 0; break; case 'C': case 'c': c = 1; break; case 'G': case 'g': c = 2; break; case 'T': case 't': c = 3; break; default: c = 4; }
+            if (c >= 4) {
+                if (lasts == ch) holes.back().len++;
+                else { Hole h; h.off = a.off + (long long)i; h.len = 1; h.amb = (char)ch; holes.push_back(h); a.n_ambs++; }
+                c = (int)(lrand48() & 3);
+            }
+            lasts = ch;
+            codes.push_back((uint8_t)c);
+            l_pac++;
+        }
+        anns.push_back(a);
+    }
+    const uint64_t G = (uint64_t)l_pac;
+    std::string p(prefix);
+    { // .pac (bntseq.c:204-218)
+        std::vector<uint8_t> pac(G / 4 + 2, 0);
+        for (uint64_t i = 0; i < G; i++) pac[i >> 2] |= codes[i] << ((~i & 3) << 1);
+        FILE *f = fopen((p + ".pac").c_str(), "wb");
+        if (!f) return mcx_set_error(MCX_ERR_IO, "cannot write " + p + ".pac");
+        size_t nb = (G >> 2) + ((G & 3) == 0 ? 0 : 1);
+        fwrite(pac.data(), 1, nb, f);
+        uint8_t ct = 0;
+        if (G % 4 == 0) fwrite(&ct, 1, 1, f);
+        ct = (uint8_t)(G % 4);
+        fwrite(&ct, 1, 1, f);
+        fclose(f);
+    }
+    { // .ann / .amb (bns_dump, bntseq.c:60-91)
+        FILE *f = fopen((p + ".ann").c_str(), "w");
+        if (!f) return mcx_set_error(MCX_ERR_IO, "cannot write " + p + ".ann");
+        fprintf(f, "%lld %d %u\n", l_pac, (int)seqs.size(), 11u);
+        for (size_t i = 0; i < seqs.size(); i++) {
+            fprintf(f, "%d %s", 0, seqs[i].name.c_str());
+            const std::string anno = seqs[i].comment.empty() ? std::string("(null)") : seqs[i].comment;
+            fprintf(f, " %s\n", anno.c_str());
+            fprintf(f, "%lld %d %d\n", anns[i].off, anns[i].len, anns[i].n_ambs);
+        }
+        fclose(f);
+        f = fopen((p + ".amb").c_str(), "w");
+        if (!f) return mcx_set_error(MCX_ERR_IO, "cannot write " + p + ".amb");
+        fprintf(f, "%lld %d %u\n", l_pac, (int)seqs.size(), (unsigned)holes.size());
+        for (auto &h : holes) fprintf(f, "%lld %d %c\n", h.off, h.len, h.amb);
+        fclose(f);
+    }
+    uint8_t *d_fwd = nullptr;
+    HIP_TRYB(hipMalloc(&d_fwd, G + 64));
+    HIP_TRYB(hipMemcpy(d_fwd, codes.data(), G, hipMemcpyHostToDevice));
+    DevIndexArrays arr;
+    int rc = mcx_build_suffix_index(d_fwd, G, false, arr, nullptr);
+    (void)hipFree(d_fwd);
+    if (rc) return rc;
+    // .bwt: primary, L2[1..4], words (bwt_dump_bwt, bwt.c:174-184); .sa (bwt_dump_sa :186-198)
+    const uint64_t file_words = arr.bwt_words; // n_blocks*8 + n_words + 8
+    std::vector<uint32_t> words(file_words);
+    HIP_TRYB(hipMemcpy(words.data(), arr.bwt, file_words * 4, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> sa(arr.n_sa);
+    HIP_TRYB(hipMemcpy(sa.data(), arr.sa, arr.n_sa * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(arr.bwt); (void)hipFree(arr.sa);
+    FILE *f = fopen((p + ".bwt").c_str(), "wb");
+    if (!f) return mcx_set_error(MCX_ERR_IO, "cannot write " + p + ".bwt");
+    fwrite(&arr.primary, 8, 1, f); fwrite(arr.L2 + 1, 8, 4, f); fwrite(words.data(), 4, file_words, f);
+    fclose(f);
+    f = fopen((p + ".sa").c_str(), "wb");
+    if (!f) return mcx_set_error(MCX_ERR_IO, "cannot write " + p + ".sa");
+    const uint64_t intv = 32;
+    fwrite(&arr.primary, 8, 1, f); fwrite(arr.L2 + 1, 8, 4, f); fwrite(&intv, 8, 1, f); fwrite(&arr.seq_len, 8, 1, f);
+    fwrite(sa.data() + 1, 8, arr.n_sa - 1, f);
+    fclose(f);
+    return 0;
 }

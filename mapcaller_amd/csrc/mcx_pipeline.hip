@@ -25,6 +25,7 @@
 #include "../../include/mcx.h"
 #include "mcx_dp.h"
 #include "mcx_host.h"
+#include "mcx_build.h"
 
 using namespace mcx;
 
@@ -40,6 +41,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
             return fail(MCX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));   \
     } while (0)
 
+int mcx_set_error(int code, const std::string &msg) { return fail(code, msg); }
 extern "C" const char *mcx_last_error(void) { return g_err.c_str(); }
 extern "C" int mcx_device_count(void)
 {
@@ -58,6 +60,7 @@ struct mcx_index {
     void *d_bwt = nullptr, *d_sa = nullptr, *d_sa_full = nullptr, *d_pac = nullptr;
     void *d_end_pos = nullptr, *d_end_chr = nullptr, *d_chr_fwd = nullptr;
     int64_t hbm_bytes = 0;
+    uint64_t n_bwt_words = 0, n_sa = 0; // set for indexes built in HBM (mcx_index_from_codes)
 };
 
 // Expands the sampled suffix array: the chain of LF steps that starts at a sampled row visits
@@ -131,6 +134,102 @@ extern "C" int mcx_index_load(const char *prefix, int device, int full_sa, mcx_i
     int rc = index_to_device(ix, full_sa);
     if (rc) { mcx_index_free(ix); return rc; }
     *out = ix;
+    return 0;
+}
+
+__global__ void k_pack_pac(const uint8_t *codes, uint64_t G, uint8_t *pac)
+{
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < G / 4 + 1; b += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t v = 0;
+        for (int k = 0; k < 4; k++) { uint64_t i = b * 4 + k; v = (v << 2) | (i < G ? (codes[i] & 3u) : 0u); }
+        pac[b] = (uint8_t)v;
+    }
+}
+
+extern "C" int mcx_index_from_codes(const uint8_t *d_codes, int32_t n_chr, const int32_t *chr_len, const char *const *chr_name,
+                                    int device, int full_sa, mcx_index **out, double *build_seconds)
+{
+    if (!d_codes || !chr_len || n_chr <= 0 || !out) return fail(MCX_ERR_ARG, "mcx_index_from_codes: bad argument");
+    HIP_TRY(hipSetDevice(device));
+    mcx_index *ix = new mcx_index();
+    ix->device = device;
+    HostIndex &h = ix->host;
+    int64_t G = 0;
+    for (int i = 0; i < n_chr; i++) {
+        h.chr_len.push_back(chr_len[i]);
+        h.chr_name.push_back(chr_name && chr_name[i] ? chr_name[i] : ("chr" + std::to_string(i + 1)));
+        G += chr_len[i];
+    }
+    h.G = G;
+    host_index_finish(h);
+    DevIndexArrays arr;
+    int rc = mcx_build_suffix_index(d_codes, (uint64_t)G, full_sa != 0, arr, build_seconds);
+    if (rc) { delete ix; return rc; }
+    h.primary = arr.primary; for (int i = 0; i < 5; i++) h.L2[i] = arr.L2[i];
+    h.seq_len = arr.seq_len; h.sa_intv = 32;
+    ix->d_bwt = arr.bwt; ix->d_sa = arr.sa; ix->d_sa_full = arr.sa_full;
+    ix->hbm_bytes = (int64_t)(arr.bwt_words * 4 + arr.n_sa * 8 + (arr.sa_full ? (arr.seq_len + 1) * 8 : 0));
+    ix->n_bwt_words = arr.bwt_words; ix->n_sa = arr.n_sa;
+    HIP_TRY(hipMalloc(&ix->d_pac, (size_t)G / 4 + 32));
+    k_pack_pac<<<1024, 256>>>(d_codes, (uint64_t)G, (uint8_t *)ix->d_pac);
+    HIP_TRY(hipGetLastError());
+    int64_t acc = 0;
+    if ((rc = upload(&ix->d_end_pos, h.end_pos.data(), h.end_pos.size() * 8, 0, acc))) return rc;
+    if ((rc = upload(&ix->d_end_chr, h.end_chr.data(), h.end_chr.size() * 4, 0, acc))) return rc;
+    if ((rc = upload(&ix->d_chr_fwd, h.chr_fwd.data(), h.chr_fwd.size() * 8, 0, acc))) return rc;
+    ix->hbm_bytes += acc + G / 4 + 32;
+    IndexView &v = ix->view;
+    v.bwt = (const uint32_t *)ix->d_bwt; v.sa = (const uint64_t *)ix->d_sa; v.sa_full = (const uint64_t *)ix->d_sa_full;
+    v.pac = (const uint8_t *)ix->d_pac;
+    v.end_pos = (const int64_t *)ix->d_end_pos; v.end_chr = (const int32_t *)ix->d_end_chr; v.chr_fwd = (const int64_t *)ix->d_chr_fwd;
+    v.primary = h.primary; for (int i = 0; i < 5; i++) v.L2[i] = h.L2[i];
+    v.seq_len = h.seq_len; v.G = h.G; v.G2 = 2 * h.G;
+    v.n_ends = (int32_t)h.end_pos.size(); v.n_chr = (int32_t)h.chr_len.size(); v.sa_intv = 32;
+    HIP_TRY(hipDeviceSynchronize());
+    *out = ix;
+    return 0;
+}
+
+// writes <prefix>.bwt/.sa/.pac/.ann/.amb from an index built in HBM (no ambiguity holes: the
+// codes it was built from had none)
+extern "C" int mcx_index_save(const mcx_index *ix, const char *prefix)
+{
+    if (!ix || !prefix) return fail(MCX_ERR_ARG, "mcx_index_save: null argument");
+    if (!ix->n_bwt_words) return fail(MCX_ERR_ARG, "mcx_index_save: only indexes built with mcx_index_from_codes can be saved");
+    HIP_TRY(hipSetDevice(ix->device));
+    const HostIndex &h = ix->host;
+    std::string p(prefix);
+    std::vector<uint32_t> words(ix->n_bwt_words);
+    HIP_TRY(hipMemcpy(words.data(), ix->d_bwt, words.size() * 4, hipMemcpyDeviceToHost));
+    FILE *f = fopen((p + ".bwt").c_str(), "wb");
+    if (!f) return fail(MCX_ERR_IO, "cannot write " + p + ".bwt");
+    fwrite(&h.primary, 8, 1, f); fwrite(h.L2 + 1, 8, 4, f); fwrite(words.data(), 4, words.size(), f); fclose(f);
+    std::vector<uint64_t> sa(ix->n_sa);
+    HIP_TRY(hipMemcpy(sa.data(), ix->d_sa, sa.size() * 8, hipMemcpyDeviceToHost));
+    f = fopen((p + ".sa").c_str(), "wb");
+    if (!f) return fail(MCX_ERR_IO, "cannot write " + p + ".sa");
+    const uint64_t intv = 32;
+    fwrite(&h.primary, 8, 1, f); fwrite(h.L2 + 1, 8, 4, f); fwrite(&intv, 8, 1, f); fwrite(&h.seq_len, 8, 1, f);
+    fwrite(sa.data() + 1, 8, sa.size() - 1, f); fclose(f);
+    const uint64_t G = (uint64_t)h.G;
+    std::vector<uint8_t> pac(G / 4 + 1);
+    HIP_TRY(hipMemcpy(pac.data(), ix->d_pac, pac.size(), hipMemcpyDeviceToHost));
+    f = fopen((p + ".pac").c_str(), "wb");
+    if (!f) return fail(MCX_ERR_IO, "cannot write " + p + ".pac");
+    fwrite(pac.data(), 1, (G >> 2) + ((G & 3) == 0 ? 0 : 1), f);
+    uint8_t ct = 0;
+    if (G % 4 == 0) fwrite(&ct, 1, 1, f);
+    ct = (uint8_t)(G % 4); fwrite(&ct, 1, 1, f); fclose(f);
+    f = fopen((p + ".ann").c_str(), "w");
+    if (!f) return fail(MCX_ERR_IO, "cannot write " + p + ".ann");
+    fprintf(f, "%lld %d %u\n", (long long)h.G, (int)h.chr_len.size(), 11u);
+    for (size_t i = 0; i < h.chr_len.size(); i++)
+        fprintf(f, "%d %s (null)\n%lld %d %d\n", 0, h.chr_name[i].c_str(), (long long)h.chr_fwd[i], h.chr_len[i], 0);
+    fclose(f);
+    f = fopen((p + ".amb").c_str(), "w");
+    if (!f) return fail(MCX_ERR_IO, "cannot write " + p + ".amb");
+    fprintf(f, "%lld %d %u\n", (long long)h.G, (int)h.chr_len.size(), 0u);
+    fclose(f);
     return 0;
 }
 

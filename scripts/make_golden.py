@@ -57,6 +57,7 @@ def make_set(name, fasta, donor, n, rlen, paired, seed, fastq=True, **kw):
         sh(REF_BIN, "index", fasta, prefix)
         for ext in ("bwt", "sa", "pac", "ann", "amb"):
             shutil.copy(f"{prefix}.{ext}", os.path.join(out, f"idx.{ext}"))
+        gz_write(os.path.join(out, "genome.fa.gz"), open(fasta, "rb").read())
         bases, _ = synth.simulate_reads(donor, n, rlen, paired, seed, skip_head=SKIP, **kw)
         ext = "fq" if fastq else "fa"
         f1 = os.path.join(tmp, f"r1.{ext}")
@@ -74,7 +75,7 @@ def make_set(name, fasta, donor, n, rlen, paired, seed, fastq=True, **kw):
             gz_write(os.path.join(out, f"r2.{ext}.gz"), open(f2, "rb").read())
         for alg in ("nw", "ksw2"):
             sam = os.path.join(tmp, f"{alg}.sam")
-            sh(REF_BIN, "-i", prefix, *files, "-alg", alg, "-sam", sam, "-no_vcf", "-t", "1")
+            sh(REF_BIN, "-i", prefix, *files, "-alg", alg, "-sam", sam, "-no_vcf", "-t", "1", "-log", os.path.join(tmp, "job.log"))
             data = open(sam, "rb").read()
             assert data.count(b"\n") >= (2 * n if paired else n), (name, alg)
             gz_write(os.path.join(out, f"ref.{alg}.sam.gz"), data)

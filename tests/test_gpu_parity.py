@@ -136,8 +136,47 @@ def test_fresh_seeded_input_equals_oracle(api, tmp_path, alg, rlen, paired):
     if os.path.exists(ref_bin):
         rs = str(tmp_path / "ref.sam")
         cmd = [ref_bin, "-i", prefix, "-f", f1] + (["-f2", f2] if f2 else []) + ["-alg", alg, "-sam", rs, "-no_vcf", "-t", "1"]
-        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.run(cmd + ["-log", str(tmp_path / "job.log")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         nd, ex = sam_diff(rs, out)
         assert nd == 0, ex
     assert st["mapped"] > 0.9 * st["reads"]
+    mp.close(); ix.close()
+
+
+@pytest.mark.parametrize("name", ["toy", "mc", "long"])
+def test_gpu_index_builder_writes_the_reference_files(api, golden, tmp_path, name):
+    """mcx_index_build (GPU suffix sorting) against the five files `MapCaller index` wrote for the
+    same FASTA: byte-identical (mc has runs of N: the lrand48 replacement path)."""
+    import gzip
+    fa = str(tmp_path / "genome.fa")
+    open(fa, "wb").write(gzip.open(os.path.join(GOLD, name, "genome.fa.gz"), "rb").read())
+    prefix = str(tmp_path / "built")
+    api.Index.build(fa, prefix, 0)
+    for ext in ("ann", "amb", "pac", "bwt", "sa"):
+        a = open(f"{prefix}.{ext}", "rb").read()
+        b = open(os.path.join(GOLD, name, f"idx.{ext}"), "rb").read()
+        assert a == b, ext
+
+
+def test_index_built_in_hbm_maps_like_the_loaded_one(api, golden, tmp_path):
+    """Index.from_codes (genome already in HBM, full suffix array kept) -> same SAM, and its
+    saved files equal the reference's."""
+    import gzip
+    import torch
+    from mapcaller_amd import synth
+    fa = str(tmp_path / "genome.fa")
+    open(fa, "wb").write(gzip.open(os.path.join(GOLD, "long", "genome.fa.gz"), "rb").read())
+    g = synth.read_fasta(fa)
+    codes = torch.cat(g.codes).cuda()
+    ix = api.Index.from_codes(codes.data_ptr(), [int(c.numel()) for c in g.codes], g.names, device=0, full_sa=True)
+    prefix = str(tmp_path / "saved")
+    ix.save(prefix)
+    for ext in ("ann", "amb", "pac", "bwt", "sa"):
+        assert open(f"{prefix}.{ext}", "rb").read() == open(os.path.join(GOLD, "long", f"idx.{ext}"), "rb").read(), ext
+    gl = golden["long"]
+    mp = api.Mapper(ix, alg="nw", max_batch_reads=1 << 12)
+    out = str(tmp_path / "gpu.sam")
+    mp.map_files(gl["r1"], gl["r2"], out)
+    nd, ex = sam_diff(gl["sam"]["nw"], out)
+    assert nd == 0, ex
     mp.close(); ix.close()
