@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--rlen", type=int, default=150)
     ap.add_argument("--alg", default="ksw2", choices=["nw", "ksw2"])
     ap.add_argument("--full-sa", type=int, default=1, help="keep every suffix-array entry in HBM")
-    ap.add_argument("--cpu-pairs", type=int, default=150_000, help="pairs of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-pairs", type=int, default=-1,
+                    help="pairs of the CPU-baseline sample (0 = skip, -1 = about 20 s of work for this host's core count)")
     ap.add_argument("--repeats", type=int, default=2000, help="planted dispersed repeat families")
     return ap.parse_args()
 
@@ -152,7 +153,10 @@ def main():
         b = make_reads(codes, lens, args.batch_pairs, args.rlen, seed=1000 * (rank + 1) + s, device=dev)
         batches.append(b.reshape(-1).contiguous())
     off = (torch.arange(reads_per_step + 1, device=dev, dtype=torch.int64) * args.rlen).to(torch.uint32)
-    sample = batches[0].reshape(reads_per_step, args.rlen)[: 2 * args.cpu_pairs].cpu() if (rank == 0 and world == 1 and args.cpu_pairs) else None
+    cpu_pairs = args.cpu_pairs
+    if cpu_pairs < 0:  # ~20 s at ~15 k reads/s/core, bounded by one batch
+        cpu_pairs = int(min(args.batch_pairs, max(50_000, (os.cpu_count() or 1) * 15_000 * 20 // 2)))
+    sample = batches[0].reshape(reads_per_step, args.rlen)[: 2 * cpu_pairs].cpu() if (rank == 0 and world == 1 and cpu_pairs) else None
     del codes
     d_aln = torch.empty(reads_per_step * 64, dtype=torch.uint8, device=dev)
     d_cig = torch.empty(reads_per_step * api.CIGAR_STRIDE, dtype=torch.int32, device=dev)

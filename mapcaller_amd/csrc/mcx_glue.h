@@ -214,56 +214,128 @@ static inline MCX_HD void kmer_fill(GetCh ch, int len, uint32_t *out) // CreateK
     }
 }
 
-struct RescueOut { int score; int n_seeds; };
+struct RescueOut { int score; int n_seeds; int d; };
 
-// IdentifyCommonKmers + GenerateSimplePairsFromCommonKmers(thr=10) + IdentifyBestAlnCan for one
-// window: best diagonal's runs are appended to hits[] (capacity cap, current size n_hits).
-static inline MCX_HD RescueOut rescue_window(const uint32_t *kq, int qlen, const uint32_t *kg, int slen, int64_t base,
-                                             Hit *hits, int n_hits, int cap, bool &overflow)
+// one diagonal d of the (read position x window position) 8-mer match matrix: runs of
+// consecutive matches of length >= 3 are seeds of 8 + run - 1 bases
+// (GenerateSimplePairsFromCommonKmers with thr = 10, KmerAnalysis.cpp:133-163).  Returns the
+// summed seed length; with hits != null the seeds are appended (emitted counts them).
+static inline MCX_HD int diag_scan(const uint32_t *kq, int qlen, const uint32_t *kg, int slen, int d, int64_t base,
+                                   Hit *hits, int n_hits, int cap, int &emitted, bool &overflow)
 {
-    RescueOut best; best.score = 0; best.n_seeds = 0;
-    int best_d = 0;
-    bool have = false;
-    for (int pass = 0; pass < 2; pass++) {
-        int d_lo = pass == 0 ? -(qlen - 1) : best_d, d_hi = pass == 0 ? slen - 1 : best_d;
-        if (pass == 1 && !have) break;
-        for (int d = d_lo; d <= d_hi; d++) {
-            int r0 = d < 0 ? -d : 0, r1 = qlen - 1 < slen - 1 - d ? qlen - 1 : slen - 1 - d;
-            int total = 0, run = 0, run_start = 0, emitted = 0;
-            for (int r = r0; r <= r1 + 1; r++) {
-                bool m = r <= r1 && kq[r] != MCX_NOKMER && kq[r] == kg[r + d];
-                if (m) { if (run == 0) run_start = r; run++; }
-                else if (run > 0) {
-                    int l = kKmerSize + run - 1;
-                    if (l >= 10) {
-                        total += l;
-                        if (pass == 1) {
-                            if (n_hits + emitted < cap) {
-                                Hit h; h.rPos = run_start; h.gPos = (int64_t)(run_start + d) + base; h.len = l;
-                                hits[n_hits + emitted] = h;
-                            } else overflow = true;
-                            emitted++;
-                        }
-                    }
-                    run = 0;
+    const int r0 = d < 0 ? -d : 0, r1 = qlen - 1 < slen - 1 - d ? qlen - 1 : slen - 1 - d;
+    int total = 0, run = 0, run_start = 0;
+    for (int r = r0; r <= r1 + 1; r++) {
+        const bool m = r <= r1 && kq[r] != MCX_NOKMER && kq[r] == kg[r + d];
+        if (m) { if (run == 0) run_start = r; run++; }
+        else if (run > 0) {
+            const int l = kKmerSize + run - 1;
+            if (l >= 10) {
+                total += l;
+                if (hits) {
+                    if (n_hits + emitted < cap) {
+                        Hit h; h.rPos = run_start; h.gPos = (int64_t)(run_start + d) + base; h.len = l;
+                        hits[n_hits + emitted] = h;
+                    } else overflow = true;
+                    emitted++;
                 }
             }
-            if (pass == 0) { if (total > best.score) { best.score = total; best_d = d; have = true; } }
-            else best.n_seeds = emitted;
+            run = 0;
         }
     }
-    return best;
+    return total;
 }
 
-// AlignmentRescue (AlignmentRescue.cpp:28-111).  kq/kg: per-lane scratch of rlen_max and
-// caps.kmer_cap entries.  Windows that leave [0,2G) make the reference read outside RefSequence
-// (undefined behaviour, it crashes near the genome start); they are skipped.
+// Serial evaluation of one rescue window (host emulation, and the reference semantics the
+// wave-cooperative version below must reproduce): IdentifyCommonKmers +
+// GenerateSimplePairsFromCommonKmers + IdentifyBestAlnCan.
+struct RescueSerial {
+    uint32_t *kq, *kg;
+    MCX_HD bool leader() const { return true; }
+    MCX_HD void sync() const {}
+    MCX_HD void fill_query(const ReadRef &rq) const
+    {
+        kmer_fill([&](uint32_t i) { return read_char(rq, (int)i); }, rq.rlen, kq);
+    }
+    MCX_HD RescueOut window(const IndexView &ix, int64_t left, int slen, int qlen, Hit *hits, int n_hits, int cap, bool &overflow) const
+    {
+        kmer_fill([&](uint32_t i) { return (uint8_t)"ACGT"[ref_code(ix, left + i)]; }, slen, kg);
+        RescueOut best; best.score = 0; best.n_seeds = 0; best.d = 0;
+        int dummy = 0;
+        for (int d = -(qlen - 1); d <= slen - 1; d++) {
+            const int total = diag_scan(kq, qlen, kg, slen, d, left, nullptr, 0, 0, dummy, overflow);
+            if (total > best.score) { best.score = total; best.d = d; }
+        }
+        if (best.score > 0) diag_scan(kq, qlen, kg, slen, best.d, left, hits, n_hits, cap, best.n_seeds, overflow);
+        return best;
+    }
+};
+
+#if defined(__HIPCC__)
+// The same evaluation by one wavefront (the block is one wave): window 8-mers are packed in
+// parallel (the genome has no N, so the reference's rolling id is the plain 16-bit pack),
+// diagonals are dealt round-robin to the lanes, the best (largest total, then smallest
+// diagonal) is found by a wave reduction, and lane 0 emits its seeds.  kq/kg live in LDS:
+// kq[r] is a broadcast read and kg[r + d] is conflict-free across consecutive diagonals.
+struct RescueWave {
+    uint32_t *kq, *kg;
+    __device__ bool leader() const { return (threadIdx.x & 63) == 0; }
+    __device__ void sync() const { __threadfence_block(); __syncthreads(); }
+    __device__ void fill_query(const ReadRef &rq) const
+    {
+        if (leader()) kmer_fill([&](uint32_t i) { return read_char(rq, (int)i); }, rq.rlen, kq);
+        __syncthreads();
+    }
+    __device__ RescueOut window(const IndexView &ix, int64_t left, int slen, int qlen, Hit *hits, int n_hits, int cap, bool &overflow) const
+    {
+        const int lane = threadIdx.x & 63;
+        __syncthreads();
+        for (int p = lane; p < slen; p += 64) {
+            uint32_t wid = MCX_NOKMER;
+            if (p + kKmerSize <= slen) {
+                wid = 0;
+                for (int k = 0; k < kKmerSize; k++) wid = (wid << 2) | (uint32_t)ref_code(ix, left + p + k);
+            }
+            kg[p] = wid;
+        }
+        __syncthreads();
+        int best_total = 0, best_d = 0x7fffffff, dummy = 0;
+        bool ovd = false;
+        for (int d = -(qlen - 1) + lane; d <= slen - 1; d += 64) {
+            const int total = diag_scan(kq, qlen, kg, slen, d, left, nullptr, 0, 0, dummy, ovd);
+            if (total > best_total) { best_total = total; best_d = d; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const int ot = __shfl_xor(best_total, o, 64), od = __shfl_xor(best_d, o, 64);
+            if (ot > best_total || (ot == best_total && od < best_d)) { best_total = ot; best_d = od; }
+        }
+        RescueOut best; best.score = best_total; best.n_seeds = 0; best.d = best_total > 0 ? best_d : 0;
+        int ov = 0;
+        if (best_total > 0 && lane == 0) {
+            bool o2 = false;
+            diag_scan(kq, qlen, kg, slen, best.d, left, hits, n_hits, cap, best.n_seeds, o2);
+            ov = o2 ? 1 : 0;
+        }
+        best.n_seeds = __shfl(best.n_seeds, 0, 64);
+        if (__shfl(ov, 0, 64)) overflow = true;
+        return best;
+    }
+};
+#endif
+
+// AlignmentRescue (AlignmentRescue.cpp:28-111).  Every lane of the evaluating wave (or the one
+// host thread) follows the same control flow over the pair state; only the leader writes it.
+// Windows that leave [0,2G) make the reference read outside RefSequence (undefined behaviour,
+// it crashes near the genome start); they are skipped.
+template <class Eval>
 static inline MCX_HD int rescue_mate(const Ctx &cx, PairState &st, const ReadRef &r1, const ReadRef &r2, uint32_t est,
-                                     uint32_t *kq, uint32_t *kg)
+                                     const Eval &ev)
 {
     const IndexView &ix = cx.ix;
     PairHdr &h = *st.hdr;
     int n1 = h.n_cands[0], n2 = h.n_cands[1];
+    int nh[2] = {h.n_hits[0], h.n_hits[1]};
+    uint32_t add_flags = 0;
     Cand *c1 = st.cands[0], *c2 = st.cands[1];
     int s1 = 0, s2 = 0, paired = 0;
     for (int i = 0; i < n1; i++) if (c1[i].score > s1) s1 = c1[i].score;
@@ -273,7 +345,7 @@ static inline MCX_HD int rescue_mate(const Ctx &cx, PairState &st, const ReadRef
     else if (s1 - s2 > (r2.rlen >> 2)) mode = 1;
     else if (s2 - s1 > (r1.rlen >> 2)) mode = 2;
     else mode = 3;
-    h.flags |= kRescueUsedEst;
+    add_flags |= kRescueUsedEst;
     for (int side = 0; side < 2; side++) {
         if (side == 0 && !(mode == 1 || mode == 3)) continue;
         if (side == 1 && !(mode == 2 || mode == 3)) continue;
@@ -281,41 +353,48 @@ static inline MCX_HD int rescue_mate(const Ctx &cx, PairState &st, const ReadRef
         const ReadRef &rq = side == 0 ? r2 : r1;
         Cand *ca = side == 0 ? c1 : c2, *cb = side == 0 ? c2 : c1;
         int &na = side == 0 ? n1 : n2, &nb = side == 0 ? n2 : n1;
-        int sa = side == 0 ? s1 : s2, sb = side == 0 ? s2 : s1;
+        const int sa = side == 0 ? s1 : s2, sb = side == 0 ? s2 : s1;
         Hit *hb = st.hits[side == 0 ? 1 : 0];
-        int &nhb = h.n_hits[side == 0 ? 1 : 0];
-        int thr = sa >> 1, lim = na;
+        int &nhb = nh[side == 0 ? 1 : 0];
+        const int thr = sa >> 1, lim = na;
         bool filled = false;
         for (int ci = 0; ci < lim; ci++) {
-            Cand &c = ca[ci];
+            const Cand c = ca[ci];
             if (c.score < thr || c.mate != -1) continue;
-            int64_t left = side == 0 ? c.pd0 : c.pd0 - (int64_t)est;
+            const int64_t left = side == 0 ? c.pd0 : c.pd0 - (int64_t)est;
             int64_t right = side == 0 ? c.pd0 + est + rq.rlen : c.pd0 + rq.rlen;
             if (right > ix.G2) right = ix.G2;
             if (left < 0 || right >= ix.G2) continue;
-            int e1 = end_slot(ix, left), e2 = end_slot(ix, right);
+            const int e1 = end_slot(ix, left), e2 = end_slot(ix, right);
             if (e1 < 0 || e2 < 0 || ix.end_chr[e1] != ix.end_chr[e2]) continue;
-            int slen = (int)(right - left);
+            const int slen = (int)(right - left);
             if (slen < rq.rlen) continue;
-            if (slen > cx.caps.kmer_cap) { h.flags |= kOvKmer; continue; }
-            if (!filled) { kmer_fill([&](uint32_t i) { return read_char(rq, (int)i); }, rq.rlen, kq); filled = true; }
-            kmer_fill([&](uint32_t i) { return (uint8_t)"ACGT"[ref_code(ix, left + i)]; }, slen, kg);
+            if (slen > cx.caps.kmer_cap) { add_flags |= kOvKmer; continue; }
+            if (!filled) { ev.fill_query(rq); filled = true; }
             bool ov = false;
-            RescueOut ro = rescue_window(kq, rq.rlen, kg, slen, left, hb, nhb, cx.caps.hit_cap, ov);
+            const RescueOut ro = ev.window(ix, left, slen, rq.rlen, hb, nhb, cx.caps.hit_cap, ov);
             if (ro.n_seeds == 0) continue;
             if (ro.score > sb) {
-                if (ov) { h.flags |= kOvHits; continue; }
-                if (nb >= cx.caps.cand_cap) { h.flags |= kOvCands; continue; }
+                if (ov) { add_flags |= kOvHits; continue; }
+                if (nb >= cx.caps.cand_cap) { add_flags |= kOvCands; continue; }
                 paired++;
-                c.mate = nb;
-                cand_init(cb[nb], ro.score, nhb, ro.n_seeds, hit_pd(hb[nhb]));
-                cb[nb].mate = ci;
+                if (ev.leader()) {
+                    ca[ci].mate = nb;
+                    cand_init(cb[nb], ro.score, nhb, ro.n_seeds, (int64_t)ro.d + left);
+                    cb[nb].mate = ci;
+                }
                 nb++;
                 nhb += ro.n_seeds;
+                ev.sync();
             }
         }
     }
-    h.n_cands[0] = n1; h.n_cands[1] = n2;
+    if (ev.leader()) {
+        h.flags |= add_flags;
+        h.n_cands[0] = n1; h.n_cands[1] = n2;
+        h.n_hits[0] = nh[0]; h.n_hits[1] = nh[1];
+    }
+    ev.sync();
     return paired;
 }
 
@@ -343,12 +422,15 @@ static inline MCX_HD void stage_cluster_pair(const Ctx &cx, int64_t pair, const 
 }
 
 // stage R: mate rescue for pairs left unpaired (ReadMapping.cpp:463)
-static inline MCX_HD void stage_rescue(const Ctx &cx, int64_t pair, const ReadRef *rd, uint32_t *kq, uint32_t *kg)
+template <class Eval>
+static inline MCX_HD void stage_rescue(const Ctx &cx, int64_t pair, const ReadRef *rd, const Eval &ev)
 {
     PairState st = pair_state(cx.state, cx.lay, cx.caps, pair);
     PairHdr &h = *st.hdr;
     if (!cx.pm.paired || (h.flags & kOvAny) || h.n_paired != 0) return;
-    h.n_paired = rescue_mate(cx, st, rd[0], rd[1], (uint32_t)h.est, kq, kg);
+    const int np = rescue_mate(cx, st, rd[0], rd[1], (uint32_t)h.est, ev);
+    if (ev.leader()) h.n_paired = np;
+    ev.sync();
 }
 
 // ------------------------------------------------------------------------------------------

@@ -217,9 +217,13 @@ int mcx_build_suffix_index(const uint8_t *d_fwd, uint64_t G, bool want_full_sa, 
         hipcub::DoubleBuffer<uint32_t> dv(idx[0], idx[1]);
         HIP_TRYB(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, dk, dv, (int64_t)N, 0, 64));
         HIP_TRYB(hipcub::DeviceScan::InclusiveScan(nullptr, scan_bytes, head, head, MaxOp(), (int64_t)N));
+        size_t sum_bytes = 0;
+        uint64_t *dummy = key[0];
+        HIP_TRYB(hipcub::DeviceScan::ExclusiveSum(nullptr, sum_bytes, dummy, dummy, (int64_t)((N + 127) / 128)));
+        if (sum_bytes > scan_bytes) scan_bytes = sum_bytes;
     }
     void *tmp = nullptr;
-    const size_t tmp_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+    const size_t tmp_bytes = (sort_bytes > scan_bytes ? sort_bytes : scan_bytes) + 256;
     HIP_TRYB(hipMalloc(&tmp, tmp_bytes));
     int cur = 0;
     uint64_t h = 16;

@@ -346,17 +346,19 @@ __global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel s
     }
 }
 
-__global__ void __launch_bounds__(64) k_rescue(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl, uint32_t *scratch,
-                                               uint32_t per_thread, uint32_t rlen_max)
+__global__ void __launch_bounds__(64) k_rescue(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl)
 {
+    // one wavefront per unpaired pair; 8-mer ids of the read and of the window live in LDS
+    __shared__ uint32_t kq[1024];
+    __shared__ uint32_t kg[4096 + 64];
     const uint32_t n = min(*rl.n, rl.cap);
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t *kq = scratch + (uint64_t)tid * per_thread, *kg = kq + rlen_max;
-    for (uint32_t i = tid; i < n; i += gridDim.x * blockDim.x) {
+    RescueWave ev; ev.kq = kq; ev.kg = kg;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
         const uint32_t local = rl.ids[i];
         ReadRef rd[2];
         make_reads(cx, rb, sel_pair(sel, local), rd);
-        stage_rescue(cx, local, rd, kq, kg);
+        stage_rescue(cx, local, rd, ev);
+        __syncthreads();
     }
 }
 
@@ -628,7 +630,7 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
     k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
-    if (paired) k_rescue<<<c->k_threads / 64, 64, 0, s>>>(cx, rb, sel, rl, c->d_kscratch, c->k_per_thread, (uint32_t)c->rlen_max);
+    if (paired) k_rescue<<<8192, 64, 0, s>>>(cx, rb, sel, rl);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
     k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks);
     k_split_jobs<<<1024, 256, 0, s>>>(sinks, c->d_cnt + CNT_UNSUP);

@@ -223,22 +223,38 @@ def simulate_reads(donor: Genome, n: int, rlen: int, paired: bool, seed: int,
     return torch.cat(outs), torch.cat(origins)
 
 
+def _records(bases: torch.Tensor, first: int, step: int, prefix: str, fastq: bool) -> np.ndarray:
+    """Fixed-width FASTQ/FASTA records as one uint8 matrix (vectorised: tens of millions of reads)."""
+    arr = bases[first::step].cpu().numpy()
+    n, rlen = arr.shape
+    digits = max(1, len(str(max(n - 1, 0))))
+    head = (b"@" if fastq else b">") + prefix.encode() + b"_"
+    width = len(head) + digits + 1 + rlen + 1 + (2 + rlen + 1 if fastq else 0)
+    out = np.empty((n, width), dtype=np.uint8)
+    c = 0
+    out[:, c:c + len(head)] = np.frombuffer(head, dtype=np.uint8); c += len(head)
+    idx = np.arange(n, dtype=np.int64)
+    for d in range(digits):  # zero-padded decimal index
+        out[:, c + digits - 1 - d] = 48 + (idx // (10 ** d)) % 10
+    c += digits
+    out[:, c] = 10; c += 1
+    out[:, c:c + rlen] = arr; c += rlen
+    out[:, c] = 10; c += 1
+    if fastq:
+        out[:, c] = 43; out[:, c + 1] = 10; c += 2
+        out[:, c:c + rlen] = 73; c += rlen
+        out[:, c] = 10
+    return out
+
+
 def write_fastq(path: str, bases: torch.Tensor, first: int, step: int, prefix: str = "sim") -> None:
     """Rows first, first+step, ... of ``bases`` as FASTQ; read k of the file is named
-    ``<prefix>_<k>`` so that both mates of a pair share a name. Qualities are constant 'I'."""
-    arr = bases[first::step].cpu().numpy()
-    rlen = arr.shape[1]
-    qual = b"I" * rlen
-    with open(path, "wb") as fh:
-        for k in range(arr.shape[0]):
-            fh.write(b"@" + f"{prefix}_{k}".encode() + b"\n" + arr[k].tobytes() + b"\n+\n" + qual + b"\n")
+    ``<prefix>_<k, zero padded>`` so that both mates of a pair share a name. Qualities are 'I'."""
+    _records(bases, first, step, prefix, True).tofile(path)
 
 
 def write_fasta_reads(path: str, bases: torch.Tensor, first: int, step: int, prefix: str = "sim") -> None:
     """Same as write_fastq but FASTA records (no qualities).  Single-end parity tests use this:
     for reverse-strand single-end FASTQ records the reference prints a quality string whose first
     byte is uninitialised (src/SamReport.cpp:318-322)."""
-    arr = bases[first::step].cpu().numpy()
-    with open(path, "wb") as fh:
-        for k in range(arr.shape[0]):
-            fh.write(b">" + f"{prefix}_{k}".encode() + b"\n" + arr[k].tobytes() + b"\n")
+    _records(bases, first, step, prefix, False).tofile(path)

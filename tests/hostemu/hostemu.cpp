@@ -101,7 +101,8 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
     for (uint32_t l = 0; l < n; l++) {
         ReadRef rd[2];
         make_reads(b, ids[l], rd);
-        stage_rescue(cx, l, rd, kq.data(), kg.data());
+        RescueSerial ev; ev.kq = kq.data(); ev.kg = kg.data();
+        stage_rescue(cx, l, rd, ev);
     }
     for (uint32_t l = 0; l < n; l++) {
         ReadRef rd[2];
