@@ -63,6 +63,10 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    try:  # torch bundles its own HIP runtime: let it load first so that both share one copy
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise McxError(f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')")
     L = C.CDLL(LIB_PATH)

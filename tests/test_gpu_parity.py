@@ -180,3 +180,20 @@ def test_index_built_in_hbm_maps_like_the_loaded_one(api, golden, tmp_path):
     nd, ex = sam_diff(gl["sam"]["nw"], out)
     assert nd == 0, ex
     mp.close(); ix.close()
+
+
+def test_reference_driver_linked_against_libmcx(golden, tmp_path):
+    """The drop-in boundary itself: the reference's own main/ReadMapping/ReadAlignment/SamReport
+    objects linked with integration/mapcaller_dropin.cpp (BWT_Search, nw_alignment,
+    ksw2_alignment on top of libmcx.so) instead of bwt_search.o / nw_alignment.o /
+    ksw2_alignment.o.  Built by `make -C oracle dropin` where the reference checkout exists."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "MapCaller_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/MapCaller_dropin was not built (no reference checkout at build time)")
+    g = golden["toy"]
+    for alg in ("ksw2", "nw"):
+        out = str(tmp_path / f"dropin.{alg}.sam")
+        cmd = [exe, "-i", g["prefix"], "-f", g["r1"], "-f2", g["r2"], "-alg", alg, "-sam", out, "-no_vcf", "-t", "1", "-log", str(tmp_path / "job.log")]
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        nd, ex = sam_diff(g["sam"][alg], out)
+        assert nd == 0, ex
