@@ -23,11 +23,23 @@ constexpr int kDpLdsSeq = 2 * 1024;    // query + target codes in LDS (1 KB each
 constexpr int kDpLdsDir = 12 * 1024;   // traceback bytes kept in LDS per wave
 constexpr int kDpSpillSeq = 4096;      // spill area reserved for sequences (2 KB each)
 
-// value of lane (lane-1); lane 0 receives `carry`
+// value of lane (lane-1) of the W-lane group; lane 0 of the group receives `carry`
+template <int W>
 static __device__ __forceinline__ int lane_shift_up(int v, int carry, int lane)
 {
-    int s = __shfl_up(v, 1, 64);
+    int s = __shfl_up(v, 1, W);
     return lane == 0 ? carry : s;
+}
+
+// Orders the group's traceback stores before the walking lane's loads.  W = 64: the block is one
+// wave and a block barrier is exact.  W < 64: several problems share a wave and sit in divergent
+// loops, so only a wavefront-scope fence is legal — and sufficient, because a wave's LDS and
+// memory operations are issued in order.
+template <int W>
+static __device__ __forceinline__ void dp_sync()
+{
+    if (W == 64) __syncthreads();
+    else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 }
 
 struct DpBuf { uint8_t *q, *t, *dir; };
@@ -48,17 +60,17 @@ static __device__ __forceinline__ DpBuf dp_buffers(int qlen, int tlen, uint8_t *
 // column string is written back to front.  Returns its start offset in ops (all lanes);
 // length = qlen + tlen - offset; *score = ez.score.
 // ---------------------------------------------------------------------------------------------
-template <int K>
+template <int K, int W>
 static __device__ int dp_ksw2_core(int qlen, int tlen, const uint8_t *q, const uint8_t *t, uint8_t *dir, uint8_t *ops,
                                    int *score)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & (W - 1);
     const int Q = 2, QE = 3, QE2 = 6, MAX_SC = 7; // q, q+e, 2(q+e), mat[0] + 2(q+e)
     int u[K], v[K], x[K], y[K], H[K], tc[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
         u[k] = v[k] = x[k] = y[k] = 0; H[k] = -0x40000000;
-        const int tt = lane + 64 * k;
+        const int tt = lane + W * k;
         tc[k] = tt < tlen ? t[tt] : 4;
     }
     const int n_diag = qlen + tlen - 1;
@@ -67,11 +79,11 @@ static __device__ int dp_ksw2_core(int qlen, int tlen, const uint8_t *q, const u
         int cx_ = 0, cv_ = r ? Q : 0, cH_ = 0; // values entering column 0 (:163)
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            const int tt = lane + 64 * k;
-            if (64 * k <= en) { // wave-uniform
+            const int tt = lane + W * k;
+            if (W * k <= en) { // uniform over the group
                 const int ox = x[k], ov = v[k], oH = H[k];
-                const int xl = lane_shift_up(ox, cx_, lane), vl = lane_shift_up(ov, cv_, lane), Hl = lane_shift_up(oH, cH_, lane);
-                cx_ = __shfl(ox, 63, 64); cv_ = __shfl(ov, 63, 64); cH_ = __shfl(oH, 63, 64);
+                const int xl = lane_shift_up<W>(ox, cx_, lane), vl = lane_shift_up<W>(ov, cv_, lane), Hl = lane_shift_up<W>(oH, cH_, lane);
+                cx_ = __shfl(ox, W - 1, W); cv_ = __shfl(ov, W - 1, W); cH_ = __shfl(oH, W - 1, W);
                 if (tt == r) { y[k] = 0; u[k] = r ? Q : 0; } // first matrix row (:165)
                 if (tt >= st && tt <= en) {
                     const int qb = q[r - tt], tb = tc[k];
@@ -104,13 +116,13 @@ static __device__ int dp_ksw2_core(int qlen, int tlen, const uint8_t *q, const u
         }
     }
     { // ez.score = H[tlen-1] after the last diagonal
-        const int kk = (tlen - 1) >> 6, ll = (tlen - 1) & 63;
+        const int kk = (tlen - 1) / W, ll = (tlen - 1) & (W - 1);
         int sc = 0;
 #pragma unroll
-        for (int k = 0; k < K; k++) { const int hv = __shfl(H[k], ll, 64); if (k == kk) sc = hv; }
+        for (int k = 0; k < K; k++) { const int hv = __shfl(H[k], ll, W); if (k == kk) sc = hv; }
         *score = sc;
     }
-    __syncthreads();
+    dp_sync<W>();
     int w = qlen + tlen;
     if (lane == 0) {
         // ksw_backtrack (:25-68); full band: force_state never fires
@@ -127,8 +139,8 @@ static __device__ int dp_ksw2_core(int qlen, int tlen, const uint8_t *q, const u
         for (; i >= 0; --i) ops[--w] = 'D';
         for (; j >= 0; --j) ops[--w] = 'I';
     }
-    w = __shfl(w, 0, 64);
-    __syncthreads();
+    w = __shfl(w, 0, W);
+    dp_sync<W>();
     return w;
 }
 
@@ -136,16 +148,16 @@ static __device__ int dp_ksw2_core(int qlen, int tlen, const uint8_t *q, const u
 // nw: r/t/s recurrence of nw_alignment in doubled integers (all reference scores are multiples
 // of 0.5 and exact in float), equality-based traceback.  Rows i = read (q), columns j = genome.
 // ---------------------------------------------------------------------------------------------
-template <int K>
+template <int K, int W>
 static __device__ int dp_nw_core(int m, int n, const uint8_t *q, const uint8_t *t, uint8_t *dir, uint8_t *ops, int *score)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & (W - 1);
     const int NEG = -131072, EXT = -1, NEW = -3;
     int S[K], T[K], R[K], Sdiag[K], tc[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
         S[k] = T[k] = R[k] = 0; Sdiag[k] = 0;
-        const int b = lane + 64 * k;
+        const int b = lane + W * k;
         tc[k] = b < n ? t[b] : 4;
     }
     const int n_diag = m + n - 1;
@@ -155,11 +167,11 @@ static __device__ int dp_nw_core(int m, int n, const uint8_t *q, const uint8_t *
         int cR = NEG, cS = -2 - (r + 1);
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            const int b = lane + 64 * k;
-            if (64 * k <= en) {
+            const int b = lane + W * k;
+            if (W * k <= en) {
                 const int oR = R[k], oS = S[k], oT = T[k];
-                const int Rl = lane_shift_up(oR, cR, lane), Sl = lane_shift_up(oS, cS, lane);
-                cR = __shfl(oR, 63, 64); cS = __shfl(oS, 63, 64);
+                const int Rl = lane_shift_up<W>(oR, cR, lane), Sl = lane_shift_up<W>(oS, cS, lane);
+                cR = __shfl(oR, W - 1, W); cS = __shfl(oS, W - 1, W);
                 if (b >= st && b <= en) {
                     const int a = r - b;
                     // s(a-1, b-1): the left S this lane received one diagonal ago, or the
@@ -182,13 +194,13 @@ static __device__ int dp_nw_core(int m, int n, const uint8_t *q, const uint8_t *
         }
     }
     {
-        const int kk = (n - 1) >> 6, ll = (n - 1) & 63;
+        const int kk = (n - 1) / W, ll = (n - 1) & (W - 1);
         int sc = 0;
 #pragma unroll
-        for (int k = 0; k < K; k++) { const int hv = __shfl(S[k], ll, 64); if (k == kk) sc = hv; }
+        for (int k = 0; k < K; k++) { const int hv = __shfl(S[k], ll, W); if (k == kk) sc = hv; }
         *score = sc;
     }
-    __syncthreads();
+    dp_sync<W>();
     int w = m + n;
     if (lane == 0) {
         int i = m, j = n; // 1-based matrix indices (nw_alignment.cpp:59-74)
@@ -202,16 +214,20 @@ static __device__ int dp_nw_core(int m, int n, const uint8_t *q, const uint8_t *
             else { ops[--w] = 'M'; i--; j--; }
         }
     }
-    w = __shfl(w, 0, 64);
-    __syncthreads();
+    w = __shfl(w, 0, W);
+    dp_sync<W>();
     return w;
 }
 
-template <int K>
+template <int K, int W>
 static __device__ __forceinline__ int dp_core(bool nw, int qlen, int tlen, const DpBuf &b, uint8_t *ops, int *score)
 {
-    return nw ? dp_nw_core<K>(qlen, tlen, b.q, b.t, b.dir, ops, score) : dp_ksw2_core<K>(qlen, tlen, b.q, b.t, b.dir, ops, score);
+    return nw ? dp_nw_core<K, W>(qlen, tlen, b.q, b.t, b.dir, ops, score) : dp_ksw2_core<K, W>(qlen, tlen, b.q, b.t, b.dir, ops, score);
 }
+
+// small problems (the bulk: median 3 x 3, p90 15 x 16): 16 lanes each, four per wave
+constexpr int kDpSmallT = 16, kDpSmallQ = 32;
+constexpr int kDpSmallLds = 64 + (kDpSmallQ + kDpSmallT - 1) * kDpSmallT; // q(32) + t(16) + pad + dir
 
 #endif // __HIPCC__
 

@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(64) k_rescue(Ctx cx, ReadBatch rb, PairSel sel
     }
 }
 
-struct JobSinks { JobSink s[3]; };
+struct JobSinks { JobSink s[4]; };
 
 __global__ void __launch_bounds__(256) k_build(Ctx cx, ReadBatch rb, PairSel sel, JobSinks sinks)
 {
@@ -374,13 +374,14 @@ __global__ void __launch_bounds__(256) k_build(Ctx cx, ReadBatch rb, PairSel sel
     stage_build(cx, local, rd, sinks.s[0]);
 }
 
-// moves the jobs of list 0 that need more than 64 / 256 target columns to lists 1 / 2
+// list 0 keeps the small problems (16-lane groups); the others move to lists 1 / 2 / 3 by
+// target length (<= 64 / 256 / 1024 columns: 1 / 4 / 16 columns per lane of a full wave)
 __global__ void k_split_jobs(JobSinks sinks, uint32_t *unsupported)
 {
     const uint32_t n = min(*sinks.s[0].count, sinks.s[0].cap);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         DpJob &j = sinks.s[0].jobs[i];
-        int cls = j.gLen <= 64 ? 0 : (j.gLen <= 256 ? 1 : 2);
+        int cls = (j.gLen <= kDpSmallT && j.rLen <= kDpSmallQ) ? 0 : (j.gLen <= 64 ? 1 : (j.gLen <= 256 ? 2 : 3));
         if (j.gLen > 1024 || j.rLen > 2048) { atomicAdd(unsupported, 1u); j.rLen = 0; continue; }
         if (cls == 0) continue;
         const uint32_t at = atomicAdd(sinks.s[cls].count, 1u);
@@ -411,7 +412,7 @@ __global__ void __launch_bounds__(64) k_dp_sel(Ctx cx, JobSink sink, ReadBatch r
         __syncthreads();
         PairState st = pair_state(cx.state, cx.lay, cx.caps, job.pair);
         int score = 0;
-        const int w = dp_core<K>(cx.pm.use_nw != 0, job.rLen, job.gLen, b, st.ops + job.ops_off, &score);
+        const int w = dp_core<K, 64>(cx.pm.use_nw != 0, job.rLen, job.gLen, b, st.ops + job.ops_off, &score);
         if (lane == 0) {
             Frag &f = st.frags[job.frag];
             f.ops_off = job.ops_off + w;
@@ -420,6 +421,37 @@ __global__ void __launch_bounds__(64) k_dp_sel(Ctx cx, JobSink sink, ReadBatch r
             if (cells) atomicAdd(cells, (uint32_t)(job.rLen * job.gLen));
         }
         __syncthreads();
+    }
+}
+
+// four small problems per wave, sixteen per block; each 16-lane group owns 800 bytes of LDS
+__global__ void __launch_bounds__(256) k_dp_small(Ctx cx, JobSink sink, ReadBatch rb, PairSel sel, uint32_t *cells)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[16 * kDpSmallLds];
+    const int nr = cx.pm.paired ? 2 : 1;
+    const int group = threadIdx.x >> 4, lane = threadIdx.x & 15;
+    uint8_t *mine = lds + group * kDpSmallLds;
+    const uint32_t n = min(*sink.count, sink.cap);
+    for (uint32_t jb = blockIdx.x * 16 + group; jb < n; jb += gridDim.x * 16) {
+        const DpJob job = sink.jobs[jb];
+        if (job.rLen == 0) continue; // moved to a larger size class (uniform over the group)
+        const uint32_t read = sel_pair(sel, job.pair) * nr + job.slot;
+        const uint8_t *codes = rb.codes + rb.off[read];
+        DpBuf b; b.q = mine; b.t = mine + kDpSmallQ; b.dir = mine + 64;
+        for (int i = lane; i < job.rLen; i += 16) b.q[i] = codes[job.rev ? job.rPos + job.rLen - 1 - i : job.rPos + i];
+        if (lane < job.gLen) b.t[lane] = (uint8_t)ref_code(cx.ix, job.rev ? job.gPos + job.gLen - 1 - lane : job.gPos + lane);
+        dp_sync<16>();
+        PairState st = pair_state(cx.state, cx.lay, cx.caps, job.pair);
+        int score = 0;
+        const int w = dp_core<1, 16>(cx.pm.use_nw != 0, job.rLen, job.gLen, b, st.ops + job.ops_off, &score);
+        if (lane == 0) {
+            Frag &f = st.frags[job.frag];
+            f.ops_off = job.ops_off + w;
+            f.ops_len = job.rLen + job.gLen - w;
+            sink.jobs[jb].score = score;
+            if (cells) atomicAdd(cells, (uint32_t)(job.rLen * job.gLen));
+        }
+        dp_sync<16>();
     }
 }
 
@@ -458,7 +490,7 @@ struct Tier {
     uint32_t max_pairs = 0;
 };
 
-enum { CNT_TASKS = 0, CNT_RESCUE, CNT_JOB0, CNT_JOB1, CNT_JOB2, CNT_OV, CNT_LF, CNT_CELLS, CNT_UNSUP, CNT_N };
+enum { CNT_TASKS = 0, CNT_RESCUE, CNT_JOB0, CNT_JOB1, CNT_JOB2, CNT_JOB3, CNT_OV, CNT_LF, CNT_CELLS, CNT_UNSUP, CNT_N };
 
 struct mcx_ctx {
     const mcx_index *idx = nullptr;
@@ -470,7 +502,7 @@ struct mcx_ctx {
     int rlen_max = 256;
     uint8_t *d_codes = nullptr;
     uint2 *d_tasks = nullptr; uint32_t task_cap = 0;
-    DpJob *d_jobs[3] = {nullptr, nullptr, nullptr}; uint32_t job_cap[3] = {0, 0, 0};
+    DpJob *d_jobs[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t job_cap[4] = {0, 0, 0, 0};
     uint32_t *d_cnt = nullptr;   // CNT_N counters
     uint32_t *h_cnt = nullptr;   // pinned mirror
     uint32_t *d_rescue = nullptr; uint32_t rescue_cap = 0;
@@ -538,8 +570,8 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
     if ((rc = dmalloc(&c->d_codes, c->max_bases + 64))) return rc;
     c->task_cap = (uint32_t)std::min<uint64_t>(c->max_reads * 24, 0x7fffffffu);
     if ((rc = dmalloc(&c->d_tasks, c->task_cap))) return rc;
-    for (int k = 0; k < 3; k++) {
-        c->job_cap[k] = (uint32_t)std::min<uint64_t>(c->max_reads * (k == 0 ? 4 : 1) + 1024, 0x7fffffffu);
+    for (int k = 0; k < 4; k++) {
+        c->job_cap[k] = (uint32_t)std::min<uint64_t>(c->max_reads * (k == 0 ? 4 : (k == 1 ? 2 : 1)) + 1024, 0x7fffffffu);
         if ((rc = dmalloc(&c->d_jobs[k], c->job_cap[k]))) return rc;
     }
     if ((rc = dmalloc(&c->d_cnt, CNT_N))) return rc;
@@ -582,7 +614,7 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
 extern "C" void mcx_ctx_free(mcx_ctx *c)
 {
     if (!c) return;
-    void *p[] = {c->tier[0].state, c->tier[1].state, c->d_codes, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2],
+    void *p[] = {c->tier[0].state, c->tier[1].state, c->d_codes, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
                  c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
                  c->d_bases, c->d_off, c->d_recs, c->d_cig};
@@ -620,7 +652,7 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     so.read_ext = c->d_read_ext; so.read_blocks = c->d_read_blocks;
     RescueList rl; rl.ids = c->d_rescue; rl.n = c->d_cnt + CNT_RESCUE; rl.cap = c->rescue_cap;
     JobSinks sinks;
-    for (int k = 0; k < 3; k++) { sinks.s[k].jobs = c->d_jobs[k]; sinks.s[k].count = c->d_cnt + CNT_JOB0 + k; sinks.s[k].cap = c->job_cap[k]; }
+    for (int k = 0; k < 4; k++) { sinks.s[k].jobs = c->d_jobs[k]; sinks.s[k].count = c->d_cnt + CNT_JOB0 + k; sinks.s[k].cap = c->job_cap[k]; }
     const unsigned pb = (sel.n + 255) / 256, rbk = (sel.n * nr + 255) / 256;
     int e = 0;
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
@@ -635,9 +667,10 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks);
     k_split_jobs<<<1024, 256, 0, s>>>(sinks, c->d_cnt + CNT_UNSUP);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
-    k_dp_sel<1><<<c->dp_blocks[0], 64, 0, s>>>(cx, sinks.s[0], rb, sel, c->d_dp_scratch[0], c->dp_stride[0], c->d_cnt + CNT_CELLS);
-    k_dp_sel<4><<<c->dp_blocks[1], 64, 0, s>>>(cx, sinks.s[1], rb, sel, c->d_dp_scratch[1], c->dp_stride[1], c->d_cnt + CNT_CELLS);
-    k_dp_sel<16><<<c->dp_blocks[2], 64, 0, s>>>(cx, sinks.s[2], rb, sel, c->d_dp_scratch[2], c->dp_stride[2], c->d_cnt + CNT_CELLS);
+    k_dp_small<<<2560, 256, 0, s>>>(cx, sinks.s[0], rb, sel, c->d_cnt + CNT_CELLS);
+    k_dp_sel<1><<<c->dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, c->d_dp_scratch[0], c->dp_stride[0], c->d_cnt + CNT_CELLS);
+    k_dp_sel<4><<<c->dp_blocks[1], 64, 0, s>>>(cx, sinks.s[2], rb, sel, c->d_dp_scratch[1], c->dp_stride[1], c->d_cnt + CNT_CELLS);
+    k_dp_sel<16><<<c->dp_blocks[2], 64, 0, s>>>(cx, sinks.s[3], rb, sel, c->d_dp_scratch[2], c->dp_stride[2], c->d_cnt + CNT_CELLS);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
     k_finish<<<pb, 256, 0, s>>>(cx, rb, sel, d_recs, d_cig, c->d_pout, c->d_ov, c->d_cnt + CNT_OV, c->ov_cap);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
@@ -647,7 +680,7 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     const uint32_t *n = c->h_cnt;
     if (n[CNT_TASKS] > c->task_cap) return fail(MCX_ERR_CAPACITY, "seed task list overflow (more hits per read than the context was sized for)");
     if (n[CNT_RESCUE] > c->rescue_cap) return fail(MCX_ERR_CAPACITY, "rescue list overflow");
-    for (int k = 0; k < 3; k++) if (n[CNT_JOB0 + k] > c->job_cap[k]) return fail(MCX_ERR_CAPACITY, "DP job list overflow");
+    for (int k = 0; k < 4; k++) if (n[CNT_JOB0 + k] > c->job_cap[k]) return fail(MCX_ERR_CAPACITY, "DP job list overflow");
     if (n[CNT_UNSUP]) return fail(MCX_ERR_UNSUPPORTED, "a gapped fragment exceeds 2048 x 1024 cells per side");
     if (stats) {
         stats->sa_hits += n[CNT_TASKS];
@@ -885,7 +918,7 @@ __global__ void __launch_bounds__(64) k_extend(ExtArgs a, uint8_t *scratch, uint
         __syncthreads();
         uint8_t *dst = a.ops + a.q_off[jb] + a.t_off[jb];
         int score = 0;
-        const int w = dp_core<K>(a.use_nw != 0, m, n, b, dst, &score);
+        const int w = dp_core<K, 64>(a.use_nw != 0, m, n, b, dst, &score);
         const int L = m + n - w;
         for (int base = 0; base < L; base += 64) { // move the string to the front of its area
             uint8_t v = base + lane < L ? dst[w + base + lane] : 0;

@@ -1,0 +1,105 @@
+// tools/ubench_gather.hip — what does MI355X sustain for DEPENDENT random 64-byte block reads?
+// (the access pattern of the FM-index walk: every lane chases its own chain of blocks)
+//   hipcc -O3 --offload-arch=gfx950 tools/ubench_gather.hip -o tools/ubench_gather
+//   tools/ubench_gather [buffer MiB] [steps per lane]
+// modes: 0 lane-per-block 4 x 16 B   1 same, non-temporal   2 four lanes per block (one 16 B load each)
+//        3 lane-per-block, 128-B blocks (8 x 16 B)            4 lane-per-block, first 32 B only
+//        5 two independent chains per lane (ILP)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+struct alignas(16) U4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ uint64_t mix(uint64_t s, uint32_t v)
+{
+    s ^= v; s *= 0x9E3779B97F4A7C15ull; s ^= s >> 29;
+    return s;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_chase(const U4 *buf, uint64_t n_blocks, int steps, uint64_t *out)
+{
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t s = 0x1234567ull * (tid + 1), s2 = 0x7654321ull * (tid + 7);
+    uint32_t acc = 0;
+    if (MODE == 2) s = 0x1234567ull * ((tid >> 2) + 1); // the four lanes of a quad share a chain
+    for (int i = 0; i < steps; i++) {
+        if (MODE == 0 || MODE == 4 || MODE == 5) {
+            const U4 *p = buf + (s % n_blocks) * 4;
+            U4 a = p[0], b = p[1];
+            uint32_t v = a.x ^ a.w ^ b.y;
+            if (MODE != 4) { U4 c = p[2], d = p[3]; v ^= c.z ^ d.x; }
+            acc += v; s = mix(s, v);
+            if (MODE == 5) {
+                const U4 *q = buf + (s2 % n_blocks) * 4;
+                U4 a2 = q[0], b2 = q[1], c2 = q[2], d2 = q[3];
+                uint32_t v2 = a2.x ^ a2.w ^ b2.y ^ c2.z ^ d2.x;
+                acc += v2; s2 = mix(s2, v2);
+            }
+        } else if (MODE == 1) {
+            const uint32_t *p = (const uint32_t *)(buf + (s % n_blocks) * 4);
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k += 4) {
+                v ^= __builtin_nontemporal_load(p + k) ^ __builtin_nontemporal_load(p + k + 3);
+            }
+            acc += v; s = mix(s, v);
+        } else if (MODE == 2) {
+            const U4 *p = buf + (s % n_blocks) * 4 + (threadIdx.x & 3);
+            U4 a = *p;
+            uint32_t v = a.x ^ a.w;
+            v ^= __shfl_xor(v, 1, 64); v ^= __shfl_xor(v, 2, 64);
+            acc += v; s = mix(s, v);
+        } else if (MODE == 3) {
+            const U4 *p = buf + (s % (n_blocks / 2)) * 8;
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { U4 a = p[k]; v ^= a.x ^ a.w; }
+            acc += v; s = mix(s, v);
+        }
+    }
+    out[tid] = s + acc + s2;
+}
+
+template <int MODE>
+static void run(const U4 *buf, uint64_t n_blocks, int steps, uint64_t *out, int blocks, const char *name, double bytes_per_step)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    k_chase<MODE><<<blocks, 256>>>(buf, n_blocks, 8, out);
+    hipEventRecord(e0);
+    k_chase<MODE><<<blocks, 256>>>(buf, n_blocks, steps, out);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    double lanes = (double)blocks * 256;
+    double chains = MODE == 2 ? lanes / 4 : (MODE == 5 ? lanes * 2 : lanes);
+    double blk = chains * steps;
+    printf("%-44s blocks=%5d  %8.3f ms  %7.2f Gblock/s  %7.1f GB/s useful\n", name, blocks, ms, blk / ms / 1e6, blk * bytes_per_step / ms / 1e6);
+}
+
+int main(int argc, char **argv)
+{
+    size_t mib = argc > 1 ? atol(argv[1]) : 4096;
+    int steps = argc > 2 ? atoi(argv[2]) : 512;
+    uint64_t n_blocks = mib * 1024 * 1024 / 64;
+    U4 *buf; uint64_t *out;
+    hipMalloc(&buf, n_blocks * 64);
+    hipMalloc(&out, 8ull << 20);
+    std::vector<uint32_t> h(1 << 20);
+    for (auto &x : h) x = rand();
+    for (size_t o = 0; o < n_blocks * 64; o += h.size() * 4) hipMemcpy((char *)buf + o, h.data(), std::min<size_t>(h.size() * 4, n_blocks * 64 - o), hipMemcpyHostToDevice);
+    printf("buffer %zu MiB, %d dependent steps per chain\n", mib, steps);
+    for (int blocks : {1024, 2048, 4096, 8192}) {
+        run<0>(buf, n_blocks, steps, out, blocks, "0 lane-per-block 4x16B", 64);
+        run<1>(buf, n_blocks, steps, out, blocks, "1 lane-per-block non-temporal dwords", 64);
+        run<2>(buf, n_blocks, steps, out, blocks, "2 quad-per-block 1x16B per lane", 64);
+        run<3>(buf, n_blocks, steps, out, blocks, "3 lane-per-128B-block 8x16B", 128);
+        run<4>(buf, n_blocks, steps, out, blocks, "4 lane-per-block first 32B only", 32);
+        run<5>(buf, n_blocks, steps, out, blocks, "5 two chains per lane 4x16B", 64);
+    }
+    return 0;
+}
