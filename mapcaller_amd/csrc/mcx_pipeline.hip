@@ -271,16 +271,27 @@ static __device__ __forceinline__ void make_reads(const Ctx &cx, const ReadBatch
 
 __global__ void k_encode(ReadBatch rb, int paired)
 {
-    // one wave per read: coalesced in, coalesced out
+    // one wave per read, coalesced in and out; four independent byte loads per lane are issued
+    // before the first store so that a wave keeps 256 bytes in flight
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t r = wave; r < rb.n_reads; r += n_waves) {
         const uint32_t o = rb.off[r], len = rb.off[r + 1] - o;
         const bool flip = paired && (r & 1);
-        for (uint32_t i = lane; i < len; i += 64) {
-            int c = nt4_code(rb.bases[o + (flip ? len - 1 - i : i)]);
-            if (flip && c < 4) c = 3 - c;
-            rb.codes[o + i] = (uint8_t)c;
+        for (uint32_t base = 0; base < len; base += 256) {
+            uint8_t v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t i = base + lane + 64 * j;
+                v[j] = i < len ? rb.bases[o + (flip ? len - 1 - i : i)] : (uint8_t)'N';
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t i = base + lane + 64 * j;
+                int c = nt4_code(v[j]);
+                if (flip && c < 4) c = 3 - c;
+                if (i < len) rb.codes[o + i] = (uint8_t)c;
+            }
         }
     }
 }
@@ -710,6 +721,34 @@ __global__ void k_reduce_stats(const uint32_t *a, const uint32_t *b, uint32_t n,
     if ((threadIdx.x & 63) == 0) { atomicAdd(out, sa); atomicAdd(out + 1, sb); }
 }
 
+// ---- avgDist replay on the device (the host only walks the per-chunk sums) ---------------------
+// per chunk of 100 pairs: number of proper pairs and their summed distance (ReadMapping.cpp:527-531)
+__global__ void k_chunk_sums(const PairOut *po, uint32_t n_pairs, uint32_t chunk, uint32_t *ok_cnt, uint32_t *dist_sum, uint32_t *mapped)
+{
+    const uint32_t n_chunks = (n_pairs + chunk - 1) / chunk;
+    uint32_t m = 0;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += gridDim.x * blockDim.x) {
+        uint32_t ok = 0, ds = 0;
+        const uint32_t p1 = min(n_pairs, (c + 1) * chunk);
+        for (uint32_t p = c * chunk; p < p1; p++) { const PairOut o = po[p]; if (o.pair_ok) { ok++; ds += (uint32_t)o.pair_dist; } m += (uint32_t)o.mapped; }
+        ok_cnt[c] = ok; dist_sum[c] = ds;
+    }
+    for (int o = 32; o > 0; o >>= 1) m += __shfl_down(m, o, 64);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(mapped, m);
+}
+
+// pairs whose chunk estimate lies outside their validity interval -> redo list (avg_replay's test)
+__global__ void k_check_est(const PairOut *po, uint32_t n_pairs, uint32_t chunk, const int32_t *est_chunk, uint32_t *redo_ids,
+                            int32_t *redo_est, uint32_t *n_redo, uint32_t cap)
+{
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pairs; p += gridDim.x * blockDim.x) {
+        const PairOut o = po[p];
+        const int32_t e = est_chunk[p / chunk];
+        const bool ok = (o.flags & kRescueUsedEst) ? o.est == e : (e >= o.est_lo && e <= o.est_hi);
+        if (!ok) { const uint32_t at = atomicAdd(n_redo, 1u); if (at < cap) { redo_ids[at] = p; redo_est[at] = e; } }
+    }
+}
+
 extern "C" void mcx_avg_init(int64_t a[4]) { a[0] = 1000; a[1] = 0; a[2] = 0; a[3] = 0; }
 
 // runs the tiers for the pairs in `ids` (null: all pairs of the batch) with per-pair estimates
@@ -769,45 +808,79 @@ extern "C" int mcx_map_batch_dev(mcx_ctx *c, const uint8_t *d_bases, const uint3
     if (total_bases > c->max_bases) return fail(MCX_ERR_ARG, "batch holds more bases than max_batch_reads * max_read_len");
     AlnRec *recs = (AlnRec *)d_aln;
     HIP_TRY(hipEventRecord(c->ev[8], s));
-    k_encode<<<2048, 256, 0, s>>>(rb, paired);
+    k_encode<<<4096, 256, 0, s>>>(rb, paired);
     HIP_TRY(hipEventRecord(c->ev[9], s));
     const uint32_t n_pairs = paired ? n_reads / 2 : n_reads;
     const int32_t est0 = (int32_t)((uint32_t)avg[0] * 1.5);
     int rc = run_selection(c, rb, paired, nullptr, nullptr, est0, n_pairs, recs, d_cigar, stats, true);
     if (rc) return rc;
     if (stats) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, c->ev[8], c->ev[9])); stats->ms_encode += ms; }
-    HIP_TRY(hipMemcpy(c->h_pout, c->d_pout, (size_t)n_pairs * sizeof(PairOut), hipMemcpyDeviceToHost));
 
-    int64_t tot_pairs = avg[1], tot_dist = avg[2], mapped = 0, pairs = 0, dist_sum = 0;
-    if (paired) {
-        // replay of the reference's avgDist feedback (mcx_host.h avg_replay); pairs outside their
-        // validity interval are re-run with the exact estimate until none is left
-        if (avg[3] % kReadChunkSize) return fail(MCX_ERR_ARG, "batches must start on a 200-read chunk boundary");
-        std::vector<uint32_t> redo; std::vector<int32_t> redo_est;
-        int64_t after[4];
-        for (int iter = 0;; iter++) {
-            avg_replay(c->h_pout, n_pairs, avg, redo, redo_est, after);
-            if (redo.empty()) break;
-            if (iter == 63) return fail(MCX_ERR_CAPACITY, "avgDist replay did not converge");
-            if (stats) stats->replayed_pairs += (int64_t)redo.size();
-            rc = run_selection(c, rb, paired, &redo, &redo_est, 0, n_pairs, recs, d_cigar, stats, false);
-            if (rc) return rc;
-            HIP_TRY(hipMemcpy(c->h_pout, c->d_pout, (size_t)n_pairs * sizeof(PairOut), hipMemcpyDeviceToHost));
-        }
-        tot_pairs = after[1]; tot_dist = after[2]; avg[0] = after[0];
-        pairs = tot_pairs - avg[1]; dist_sum = tot_dist - avg[2];
-        avg[1] = tot_pairs; avg[2] = tot_dist;
-    }
-    avg[3] += n_reads;
-    for (uint32_t p = 0; p < n_pairs; p++) mapped += c->h_pout[p].mapped;
-    if (stats) {
-        stats->reads += n_reads; stats->mapped += mapped; stats->pairs += pairs; stats->pair_dist_sum += dist_sum;
-        unsigned long long *d_sum = (unsigned long long *)c->d_cnt; // reuse (8-byte aligned, 2 words)
+    // Replay of the reference's avgDist feedback (ReadMapping.cpp:462, :538-539; mcx_host.h).  The
+    // device reduces the batch to per-chunk sums; the host walks the chunk trajectory (a few
+    // thousand scalars); the device lists the pairs whose chunk estimate falls outside their
+    // validity interval; those are re-run with the exact estimate until none is left.
+    int64_t mapped = 0, pairs = 0, dist_sum = 0;
+    const uint32_t chunk = kReadChunkSize / 2, n_chunks = (n_pairs + chunk - 1) / chunk;
+    uint32_t *d_ok = c->d_read_ext, *d_ds = c->d_read_blocks; // per-read stat arrays are reduced below, before reuse
+    unsigned long long hs[2] = {0, 0};
+    {
+        unsigned long long *d_sum = (unsigned long long *)c->d_cnt;
         HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
         k_reduce_stats<<<256, 256, 0, s>>>(c->d_read_ext, c->d_read_blocks, n_reads, d_sum);
-        unsigned long long hs[2];
         HIP_TRY(hipMemcpyAsync(hs, d_sum, sizeof hs, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+    }
+    std::vector<uint32_t> h_ok(n_chunks), h_ds(n_chunks);
+    std::vector<int32_t> h_est(n_chunks);
+    if (paired && (avg[3] % kReadChunkSize)) return fail(MCX_ERR_ARG, "batches must start on a 200-read chunk boundary");
+    int64_t after[3] = {avg[0], avg[1], avg[2]};
+    for (int iter = 0;; iter++) {
+        HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
+        k_chunk_sums<<<(n_chunks + 255) / 256, 256, 0, s>>>(c->d_pout, n_pairs, chunk, d_ok, d_ds, c->d_cnt + CNT_LF);
+        HIP_TRY(hipMemcpyAsync(h_ok.data(), d_ok, n_chunks * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h_ds.data(), d_ds, n_chunks * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        mapped = c->h_cnt[CNT_LF];
+        if (!paired) break;
+        int64_t tp = avg[1], td = avg[2];
+        uint32_t cur = (uint32_t)avg[0];
+        for (uint32_t k = 0; k < n_chunks; k++) {
+            h_est[k] = (int32_t)(cur * 1.5);
+            tp += h_ok[k]; td += h_ds[k];
+            if (tp > 1000) cur = (uint32_t)(int)(1. * td / tp + .5);
+        }
+        after[0] = cur; after[1] = tp; after[2] = td;
+        int32_t *d_est_chunk = (int32_t *)d_ok; // the sums are on the host now
+        HIP_TRY(hipMemcpyAsync(d_est_chunk, h_est.data(), n_chunks * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
+        k_check_est<<<2048, 256, 0, s>>>(c->d_pout, n_pairs, chunk, d_est_chunk, c->d_sel_ids, c->d_est, c->d_cnt + CNT_OV, c->ov_cap);
+        HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const uint32_t n_redo = c->h_cnt[CNT_OV];
+        if (n_redo == 0) break;
+        if (n_redo > c->ov_cap) return fail(MCX_ERR_CAPACITY, "avgDist replay: redo list overflow");
+        if (iter == 63) return fail(MCX_ERR_CAPACITY, "avgDist replay did not converge");
+        if (stats) stats->replayed_pairs += (int64_t)n_redo;
+        std::vector<uint32_t> redo(n_redo); std::vector<int32_t> redo_est(n_redo);
+        HIP_TRY(hipMemcpy(redo.data(), c->d_sel_ids, n_redo * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(redo_est.data(), c->d_est, n_redo * 4, hipMemcpyDeviceToHost));
+        // the list was appended with atomics: bring it into pair order (results do not depend on it)
+        std::vector<std::pair<uint32_t, int32_t>> ord(n_redo);
+        for (uint32_t i = 0; i < n_redo; i++) ord[i] = std::make_pair(redo[i], redo_est[i]);
+        std::sort(ord.begin(), ord.end());
+        for (uint32_t i = 0; i < n_redo; i++) { redo[i] = ord[i].first; redo_est[i] = ord[i].second; }
+        rc = run_selection(c, rb, paired, &redo, &redo_est, 0, n_pairs, recs, d_cigar, stats, false);
+        if (rc) return rc;
+    }
+    if (paired) {
+        pairs = after[1] - avg[1]; dist_sum = after[2] - avg[2];
+        avg[0] = after[0]; avg[1] = after[1]; avg[2] = after[2];
+    }
+    avg[3] += n_reads;
+    if (stats) {
+        stats->reads += n_reads; stats->mapped += mapped; stats->pairs += pairs; stats->pair_dist_sum += dist_sum;
         stats->fm_ext_steps += (int64_t)hs[0]; stats->fm_blocks += (int64_t)hs[1];
         stats->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }

@@ -88,7 +88,7 @@ int main(int argc, char **argv)
     uint64_t n_blocks = mib * 1024 * 1024 / 64;
     U4 *buf; uint64_t *out;
     hipMalloc(&buf, n_blocks * 64);
-    hipMalloc(&out, 8ull << 20);
+    hipMalloc(&out, 64ull << 20);
     std::vector<uint32_t> h(1 << 20);
     for (auto &x : h) x = rand();
     for (size_t o = 0; o < n_blocks * 64; o += h.size() * 4) hipMemcpy((char *)buf + o, h.data(), std::min<size_t>(h.size() * 4, n_blocks * 64 - o), hipMemcpyHostToDevice);
