@@ -118,6 +118,40 @@ static inline MCX_HD int nt4_code(uint8_t ch)
     }
 }
 
+// One read as the kernels see it: the ASCII bases as handed over, and whether it is mate 2 of a
+// pair, which the reference reverse-complements in place before anything else
+// (ReverseOrientation, tools.cpp:45; EnCodeReadSeq, ReadMapping.cpp:404).  Codes are decoded on
+// the fly, so there is no encode pass and no second copy of the reads in HBM.
+struct ReadRef {
+    const uint8_t *ascii;
+    int32_t rlen;
+    int32_t flipped;
+};
+
+static inline MCX_HD int read_code(const ReadRef &r, int i)
+{
+    int c = nt4_code(r.ascii[r.flipped ? r.rlen - 1 - i : i]);
+    return (r.flipped && c < 4) ? 3 - c : c;
+}
+
+// sequential reader for the seeding walk: keeps the aligned 16-byte chunk that holds the current
+// base in registers, so a 150-base read costs ~10 loads instead of 150 byte loads
+struct ReadCursor {
+    U4 w;
+    uintptr_t chunk;
+};
+
+static inline MCX_HD int cursor_code(const ReadRef &r, ReadCursor &cur, int i)
+{
+    const uintptr_t a = (uintptr_t)r.ascii + (uintptr_t)(r.flipped ? r.rlen - 1 - i : i);
+    const uintptr_t ch = a & ~(uintptr_t)15;
+    if (ch != cur.chunk) { cur.w = *(const U4 *)ch; cur.chunk = ch; }
+    const unsigned k = (unsigned)(a & 15);
+    const uint32_t word = k < 8 ? (k < 4 ? cur.w.x : cur.w.y) : (k < 12 ? cur.w.z : cur.w.w);
+    int c = nt4_code((uint8_t)(word >> ((k & 3) * 8)));
+    return (r.flipped && c < 4) ? 3 - c : c;
+}
+
 // code of 2G-coordinate p of RefSequence (bwt_index.cpp:196-215): forward strand from the
 // packed genome, reverse strand = complement of the mirrored forward base
 static inline MCX_HD int ref_code(const IndexView &ix, int64_t p)
@@ -144,9 +178,11 @@ static inline MCX_HD int end_slot(const IndexView &ix, int64_t gPos)
 // Hits are written as BWT rows (x0 + i); the SA kernel turns them into text positions.
 // Returns the number of hits the read produced (may exceed cap: overflow, nothing lost yet
 // because the pair is then re-run in the next tier).
-static inline MCX_HD int seed_read(const IndexView &ix, const uint8_t *codes, int rlen, Hit *hits, int cap,
+static inline MCX_HD int seed_read(const IndexView &ix, const ReadRef &rd, Hit *hits, int cap,
                                    int64_t &ext_steps, int64_t &blocks)
 {
+    const int rlen = rd.rlen;
+    ReadCursor cur; cur.chunk = 0; cur.w.x = cur.w.y = cur.w.z = cur.w.w = 0;
     int n_hits = 0;
     const int stop = rlen - kMinSeedLength;
     int p = 0, start = 0;
@@ -155,7 +191,7 @@ static inline MCX_HD int seed_read(const IndexView &ix, const uint8_t *codes, in
     for (;;) {
         if (!active) {
             if (p >= stop) break;
-            int c = codes[p];
+            int c = cursor_code(rd, cur, p);
             if (c > 3) { p++; continue; }
             start = p;
             x0 = ix.L2[c] + 1; x1 = ix.L2[3 - c] + 1; x2 = ix.L2[c + 1] - ix.L2[c];
@@ -163,7 +199,7 @@ static inline MCX_HD int seed_read(const IndexView &ix, const uint8_t *codes, in
             p++;
         }
         bool end = p >= rlen;
-        int c = end ? 4 : codes[p];
+        int c = end ? 4 : cursor_code(rd, cur, p);
         if (c > 3) end = true;
         if (!end) {
             uint64_t tk[4], tl[4];

@@ -27,13 +27,6 @@ struct Ctx {
     int32_t mapq_rows;
 };
 
-struct ReadRef {              // one read of the batch
-    const uint8_t *ascii;     // as given (mate 2 NOT yet flipped)
-    const uint8_t *codes;     // 0..4, mate 2 flipped
-    int32_t rlen;
-    int32_t flipped;
-};
-
 static inline MCX_HD int64_t hit_pd(const Hit &h) { return h.gPos - h.rPos; }
 
 // ------------------------------------------------------------------------------------------
@@ -515,9 +508,9 @@ static inline MCX_HD int build_frags(const IndexView &ix, int rlen, const Hit *s
 // read / genome code of alignment-string position x of a fragment.  Reverse-strand fragments
 // (gPos >= G) have both strings reverse-complemented by the reference (ReadAlignment.cpp:179-183);
 // complementing both sides does not change any comparison, so only the reversal is applied.
-static inline MCX_HD int frag_read_code(const Frag &f, const uint8_t *codes, bool rev, int x)
+static inline MCX_HD int frag_read_code(const Frag &f, const ReadRef &rd, bool rev, int x)
 {
-    return codes[rev ? f.rPos + f.rLen - 1 - x : f.rPos + x];
+    return read_code(rd, rev ? f.rPos + f.rLen - 1 - x : f.rPos + x);
 }
 static inline MCX_HD int frag_ref_code(const IndexView &ix, const Frag &f, bool rev, int y)
 {
@@ -575,7 +568,7 @@ static inline MCX_HD void stage_build(const Ctx &cx, int64_t pair, const ReadRef
                     if (!dp) {
                         int mm = 0;
                         for (int k = 0; k < x.rLen; k++)
-                            if (frag_read_code(x, rd[s].codes, rev, k) != frag_ref_code(cx.ix, x, rev, k)) mm++;
+                            if (frag_read_code(x, rd[s], rev, k) != frag_ref_code(cx.ix, x, rev, k)) mm++;
                         dp = mm > 1 && mm >= (int)(x.rLen * 0.2);
                     }
                     if (dp) {
@@ -643,7 +636,7 @@ struct ColStats { int switches, n, mis, match; };
 
 // one pass over the columns of a gap fragment: CheckLocalAlignmentQuality (:193-232),
 // EvaluateAlignmentScore (:234-245) and FindMisMatchNumber (:247-262) all read from it
-static inline MCX_HD ColStats frag_columns(const IndexView &ix, const Frag &f, const uint8_t *ops, const uint8_t *codes)
+static inline MCX_HD ColStats frag_columns(const IndexView &ix, const Frag &f, const uint8_t *ops, const ReadRef &rd)
 {
     ColStats cs; cs.switches = cs.n = cs.mis = cs.match = 0;
     bool rev = f.gPos >= ix.G;
@@ -655,7 +648,7 @@ static inline MCX_HD ColStats frag_columns(const IndexView &ix, const Frag &f, c
         else if (o == 'I') { k = 1; ri++; }
         else {
             k = 2; cs.n++;
-            if (frag_read_code(f, codes, rev, ri) != frag_ref_code(ix, f, rev, gi)) cs.mis++; else cs.match++;
+            if (frag_read_code(f, rd, rev, ri) != frag_ref_code(ix, f, rev, gi)) cs.mis++; else cs.match++;
             ri++; gi++;
         }
         if (k != kind) { kind = k; cs.switches++; }
@@ -691,7 +684,7 @@ static inline MCX_HD void extend_read(const Ctx &cx, PairState &st, int s, const
             bool fwd = x.gPos < ix.G;
             if (i == 0) {
                 strip_end_gaps(x, st.ops, fwd, true);
-                ColStats q = frag_columns(ix, x, st.ops, rd.codes);
+                ColStats q = frag_columns(ix, x, st.ops, rd);
                 if (x.ops_len >= kMinAlnBlockSize && !quality_ok(q)) {
                     head_ok = false;
                     x.rLen = x.gLen = 0; x.ops_len = 0; x.kind = kEmpty;
@@ -699,14 +692,14 @@ static inline MCX_HD void extend_read(const Ctx &cx, PairState &st, int s, const
                 } else { score += q.match; mism += q.mis; }
             } else if (i == last) {
                 strip_end_gaps(x, st.ops, !fwd, false);
-                ColStats q = frag_columns(ix, x, st.ops, rd.codes);
+                ColStats q = frag_columns(ix, x, st.ops, rd);
                 if (x.ops_len >= kMinAlnBlockSize && !quality_ok(q)) {
                     tail_ok = false;
                     x.rLen = x.gLen = 0; x.ops_len = 0; x.kind = kEmpty;
                     x.rPos = f[i - 1].rPos + f[i - 1].rLen; x.gPos = f[i - 1].gPos + f[i - 1].gLen;
                 } else { score += q.match; mism += q.mis; }
             } else {
-                ColStats q = frag_columns(ix, x, st.ops, rd.codes);
+                ColStats q = frag_columns(ix, x, st.ops, rd);
                 if (x.rLen >= kMinAlnBlockSize && x.gLen >= kMinAlnBlockSize && !quality_ok(q)) { dead = true; break; }
                 score += q.match; mism += q.mis;
             }

@@ -263,36 +263,8 @@ static __device__ __forceinline__ void make_reads(const Ctx &cx, const ReadBatch
     for (int s = 0; s < nr; s++) {
         uint32_t r = pair * nr + s;
         rd[s].ascii = rb.bases + rb.off[r];
-        rd[s].codes = rb.codes + rb.off[r];
         rd[s].rlen = (int32_t)(rb.off[r + 1] - rb.off[r]);
         rd[s].flipped = (cx.pm.paired && s == 1) ? 1 : 0;
-    }
-}
-
-__global__ void k_encode(ReadBatch rb, int paired)
-{
-    // one wave per read, coalesced in and out; four independent byte loads per lane are issued
-    // before the first store so that a wave keeps 256 bytes in flight
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t r = wave; r < rb.n_reads; r += n_waves) {
-        const uint32_t o = rb.off[r], len = rb.off[r + 1] - o;
-        const bool flip = paired && (r & 1);
-        for (uint32_t base = 0; base < len; base += 256) {
-            uint8_t v[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t i = base + lane + 64 * j;
-                v[j] = i < len ? rb.bases[o + (flip ? len - 1 - i : i)] : (uint8_t)'N';
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t i = base + lane + 64 * j;
-                int c = nt4_code(v[j]);
-                if (flip && c < 4) c = 3 - c;
-                if (i < len) rb.codes[o + i] = (uint8_t)c;
-            }
-        }
     }
 }
 
@@ -312,10 +284,10 @@ __global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel,
     const uint32_t local = lr / nr, s = lr % nr;
     const uint32_t pair = sel_pair(sel, local), r = pair * nr + s;
     PairState st = pair_state(cx.state, cx.lay, cx.caps, local);
-    const uint32_t o = rb.off[r];
-    const int rlen = (int)(rb.off[r + 1] - o);
+    ReadRef rd;
+    rd.ascii = rb.bases + rb.off[r]; rd.rlen = (int)(rb.off[r + 1] - rb.off[r]); rd.flipped = (cx.pm.paired && s == 1) ? 1 : 0;
     int64_t ext = 0, blocks = 0;
-    const int n = seed_read(cx.ix, rb.codes + o, rlen, st.hits[s], cx.caps.hit_cap, ext, blocks);
+    const int n = seed_read(cx.ix, rd, st.hits[s], cx.caps.hit_cap, ext, blocks);
     st.hdr->n_hits[s] = n;
     so.read_ext[r] = (uint32_t)ext; so.read_blocks[r] = (uint32_t)blocks;
     const int keep = n <= cx.caps.hit_cap ? n : 0; // overflowing reads are re-run in the next tier
@@ -414,11 +386,12 @@ __global__ void __launch_bounds__(64) k_dp_sel(Ctx cx, JobSink sink, ReadBatch r
         const DpJob job = sink.jobs[jb];
         if (job.rLen == 0) continue; // moved to another size class (block-uniform)
         const uint32_t read = sel_pair(sel, job.pair) * nr + job.slot;
-        const uint8_t *codes = rb.codes + rb.off[read];
+        ReadRef rd;
+        rd.ascii = rb.bases + rb.off[read]; rd.rlen = (int)(rb.off[read + 1] - rb.off[read]); rd.flipped = (cx.pm.paired && job.slot == 1) ? 1 : 0;
         const DpBuf b = dp_buffers(job.rLen, job.gLen, lds, spill);
         // q = read fragment, t = genome fragment; both reversed on the reverse strand (the
         // reference also complements both, which no comparison can see)
-        for (int i = lane; i < job.rLen; i += 64) b.q[i] = codes[job.rev ? job.rPos + job.rLen - 1 - i : job.rPos + i];
+        for (int i = lane; i < job.rLen; i += 64) b.q[i] = (uint8_t)read_code(rd, job.rev ? job.rPos + job.rLen - 1 - i : job.rPos + i);
         for (int i = lane; i < job.gLen; i += 64) b.t[i] = (uint8_t)ref_code(cx.ix, job.rev ? job.gPos + job.gLen - 1 - i : job.gPos + i);
         __syncthreads();
         PairState st = pair_state(cx.state, cx.lay, cx.caps, job.pair);
@@ -447,9 +420,10 @@ __global__ void __launch_bounds__(256) k_dp_small(Ctx cx, JobSink sink, ReadBatc
         const DpJob job = sink.jobs[jb];
         if (job.rLen == 0) continue; // moved to a larger size class (uniform over the group)
         const uint32_t read = sel_pair(sel, job.pair) * nr + job.slot;
-        const uint8_t *codes = rb.codes + rb.off[read];
+        ReadRef rd;
+        rd.ascii = rb.bases + rb.off[read]; rd.rlen = (int)(rb.off[read + 1] - rb.off[read]); rd.flipped = (cx.pm.paired && job.slot == 1) ? 1 : 0;
         DpBuf b; b.q = mine; b.t = mine + kDpSmallQ; b.dir = mine + 64;
-        for (int i = lane; i < job.rLen; i += 16) b.q[i] = codes[job.rev ? job.rPos + job.rLen - 1 - i : job.rPos + i];
+        for (int i = lane; i < job.rLen; i += 16) b.q[i] = (uint8_t)read_code(rd, job.rev ? job.rPos + job.rLen - 1 - i : job.rPos + i);
         if (lane < job.gLen) b.t[lane] = (uint8_t)ref_code(cx.ix, job.rev ? job.gPos + job.gLen - 1 - lane : job.gPos + lane);
         dp_sync<16>();
         PairState st = pair_state(cx.state, cx.lay, cx.caps, job.pair);
@@ -511,7 +485,6 @@ struct mcx_ctx {
     Tier tier[2];
     uint64_t max_reads = 0, max_bases = 0;
     int rlen_max = 256;
-    uint8_t *d_codes = nullptr;
     uint2 *d_tasks = nullptr; uint32_t task_cap = 0;
     DpJob *d_jobs[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t job_cap[4] = {0, 0, 0, 0};
     uint32_t *d_cnt = nullptr;   // CNT_N counters
@@ -578,7 +551,6 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
     c->tier[1].max_pairs = (uint32_t)std::min<uint64_t>(c->max_reads, 16384);
     for (int t = 0; t < 2; t++)
         if ((rc = dmalloc(&c->tier[t].state, (size_t)c->tier[t].lay.stride * c->tier[t].max_pairs))) return rc;
-    if ((rc = dmalloc(&c->d_codes, c->max_bases + 64))) return rc;
     c->task_cap = (uint32_t)std::min<uint64_t>(c->max_reads * 24, 0x7fffffffu);
     if ((rc = dmalloc(&c->d_tasks, c->task_cap))) return rc;
     for (int k = 0; k < 4; k++) {
@@ -625,7 +597,7 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
 extern "C" void mcx_ctx_free(mcx_ctx *c)
 {
     if (!c) return;
-    void *p[] = {c->tier[0].state, c->tier[1].state, c->d_codes, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3],
+    void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
                  c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
                  c->d_bases, c->d_off, c->d_recs, c->d_cig};
@@ -802,19 +774,16 @@ extern "C" int mcx_map_batch_dev(mcx_ctx *c, const uint8_t *d_bases, const uint3
     HIP_TRY(hipSetDevice(c->idx->device));
     auto t0 = std::chrono::steady_clock::now();
     hipStream_t s = c->stream;
-    ReadBatch rb; rb.bases = d_bases; rb.off = d_off; rb.codes = c->d_codes; rb.n_reads = n_reads;
+    if ((uintptr_t)d_bases & 15) return fail(MCX_ERR_ARG, "mcx_map_batch_dev: d_bases must be 16-byte aligned");
+    ReadBatch rb; rb.bases = d_bases; rb.off = d_off; rb.n_reads = n_reads;
     uint32_t total_bases = 0;
     HIP_TRY(hipMemcpy(&total_bases, d_off + n_reads, sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (total_bases > c->max_bases) return fail(MCX_ERR_ARG, "batch holds more bases than max_batch_reads * max_read_len");
     AlnRec *recs = (AlnRec *)d_aln;
-    HIP_TRY(hipEventRecord(c->ev[8], s));
-    k_encode<<<4096, 256, 0, s>>>(rb, paired);
-    HIP_TRY(hipEventRecord(c->ev[9], s));
     const uint32_t n_pairs = paired ? n_reads / 2 : n_reads;
     const int32_t est0 = (int32_t)((uint32_t)avg[0] * 1.5);
     int rc = run_selection(c, rb, paired, nullptr, nullptr, est0, n_pairs, recs, d_cigar, stats, true);
     if (rc) return rc;
-    if (stats) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, c->ev[8], c->ev[9])); stats->ms_encode += ms; }
 
     // Replay of the reference's avgDist feedback (ReadMapping.cpp:462, :538-539; mcx_host.h).  The
     // device reduces the batch to per-chunk sums; the host walks the chunk trajectory (a few

@@ -202,12 +202,10 @@ static inline MCX_HD PairState pair_state(uint8_t *base, const Layout &l, const 
     return s;
 }
 
-// a batch of reads in HBM: ASCII bases, offsets, and the 0..4 codes produced by the encode
-// kernel (mate 2 already reverse-complemented, ReadMapping.cpp:451)
+// a batch of reads in HBM: ASCII bases and offsets, as handed over (16-byte aligned base pointer)
 struct ReadBatch {
     const uint8_t *bases;   // ASCII
     const uint32_t *off;    // n_reads + 1
-    uint8_t *codes;         // same offsets
     uint32_t n_reads;
 };
 

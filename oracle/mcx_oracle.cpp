@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1129,6 +1130,97 @@ static PairDist pair_distance(const std::vector<Cand> &c1, const std::vector<Can
     return p;
 }
 
+// ---- alignment profile (AlignmentProfile.cpp) --------------------------------------------------
+struct Discord { i64 gPos, dist; };
+
+struct Profile {
+    // MappingRecord_t (structure.h:152-163): A,C,G,T,multi_hit are 12-bit fields that saturate
+    // at MaxAlleleCount (4095); readCount is a 4-bit field; F1,R2,F2,R1 are plain uint16_t
+    std::vector<uint16_t> cnt; // 10 per position: A C G T multi_hit readCount F1 R2 F2 R1
+    std::map<i64, std::map<std::string, uint16_t>> ins, del;
+    std::map<i64, uint16_t> brk;
+    std::vector<Discord> inv, tnl;
+    int max_dup = 5, max_clip = 5; // iMaxDuplicate, MaxClipSize (main.cpp:175,:181)
+    void init(i64 G) { cnt.assign((size_t)G * 10, 0); }
+    uint16_t &at(i64 g, int k) { return cnt[(size_t)g * 10 + k]; }
+    void base(i64 g, int k) { uint16_t &v = at(g, k); if (v < 4095) v++; }
+};
+
+// one aligned column of a forward-strand character: 'A','C','G','T' count, anything else does not
+static inline void count_char(Profile &pf, i64 g, char c)
+{
+    switch (c) { case 'A': pf.base(g, 0); break; case 'C': pf.base(g, 1); break; case 'G': pf.base(g, 2); break; case 'T': pf.base(g, 3); break; }
+}
+
+// walks a gapped fragment's strings from genome position g (AlignmentProfile.cpp:130-166 / :205-241)
+static void profile_gapped(Profile &pf, const Frag &f, i64 g)
+{
+    const int len = (int)f.a1.size();
+    for (int j = 0; j < len;) {
+        if (f.a2[j] == '-') {
+            int e = 1; while (j + e < len && f.a2[j + e] == '-') e++;
+            pf.ins[g - 1][f.a1.substr(j, e)]++;
+            j += e;
+        } else if (f.a1[j] == '-') {
+            int e = 1; while (j + e < len && f.a1[j + e] == '-') e++;
+            pf.del[g - 1][f.a2.substr(j, e)]++;
+            j += e; g += e;
+        } else { count_char(pf, g, f.a1[j]); j++; g++; }
+    }
+}
+
+// UpdateProfile, AlignmentProfile.cpp:41-242
+static void update_profile(const Index &ix, Profile &pf, bool first_read, const Read &rd)
+{
+    for (const Cand &c : rd.cands) {
+        if (c.score == 0) continue;
+        const std::vector<Frag> &v = c.frags;
+        const Frag &a = v.front(), &b = v.back();
+        if (a.rLen == 0 && a.gLen == 0) {
+            if (a.rPos > 20) pf.brk[a.gPos < ix.G ? a.gPos : ix.G2 - 1 - a.gPos]++; // MinBreakPointSize :4
+            if (a.rPos > pf.max_clip) continue;
+        }
+        if (b.rLen == 0 && b.gLen == 0) {
+            if (rd.rlen - b.rPos > 20) pf.brk[b.gPos < ix.G ? b.gPos : ix.G2 - 1 - b.gPos]++;
+            if (rd.rlen - b.rPos > pf.max_clip) continue;
+        }
+        i64 g = c.fwd ? a.gPos : ix.G2 - (a.gPos + a.gLen);
+        if (pf.at(g, 5) < pf.max_dup) pf.at(g, 5)++; else continue;
+        const int strand = first_read ? (c.fwd ? 6 : 9) : (c.fwd ? 7 : 8); // F1 / R1 / R2 / F2
+        for (int i = 0; i < rd.rlen && g + i < ix.G; i++) pf.at(g + i, strand)++; // (the reference runs past the array end at the genome end)
+        for (const Frag &f : v) {
+            if (c.fwd) {
+                i64 gp = f.gPos;
+                if (f.simple) { for (int j = 0; j < f.rLen; j++) count_char(pf, gp + j, rd.seq[f.rPos + j]); }
+                else if (f.gLen == 0) pf.ins[gp - 1][f.a1]++;
+                else if (f.rLen == 0) pf.del[gp - 1][f.a2]++;
+                else profile_gapped(pf, f, gp);
+            } else {
+                if (f.simple) {
+                    i64 gp = ix.G2 - 1 - f.gPos;
+                    for (int j = 0; j < f.rLen; j++, gp--) {
+                        switch (rd.seq[f.rPos + j]) { case 'A': pf.base(gp, 3); break; case 'C': pf.base(gp, 2); break; case 'G': pf.base(gp, 1); break; case 'T': pf.base(gp, 0); break; }
+                    }
+                } else if (f.gLen == 0) pf.ins[ix.G2 - f.gPos - 1][f.a1]++;
+                else if (f.rLen == 0) pf.del[ix.G2 - f.gPos - f.gLen - 1][f.a2]++;
+                else profile_gapped(pf, f, ix.G2 - (f.gPos + f.gLen));
+            }
+        }
+    }
+}
+
+// UpdateMultiHitCount, AlignmentProfile.cpp:244-271
+static void update_multi_hit(const Index &ix, Profile &pf, const Read &rd)
+{
+    for (const Cand &c : rd.cands) {
+        if (c.score <= 0) continue;
+        const Frag &a = c.frags.front(), &b = c.frags.back();
+        i64 g0 = c.fwd ? a.gPos : ix.G2 - (a.gPos + a.gLen);
+        i64 g1 = c.fwd ? b.gPos + b.gLen : ix.G2 - b.gPos;
+        for (i64 g = g0; g < g1; g++) pf.base(g, 4);
+    }
+}
+
 // ---- input (GetData.cpp) ---------------------------------------------------------------------
 // IdentifyHeaderBegPos :3-10 / IdentifyHeaderEndPos :12-20
 static std::string trim_header(const std::string &line)
@@ -1209,6 +1301,7 @@ struct Shared {
     u32 avg_dist = 1000; // ReadMapping.cpp:20
     i64 n_reads = 0, n_mapped = 0, n_paired = 0, dist_sum = 0;
     Counters ct;
+    Profile *pf = nullptr; // -vcf bookkeeping (ReadMapping.cpp:562-573); single thread only
 };
 
 static void seed_and_cluster(const Index &ix, const Params &pm, Read &r, Counters &ct)
@@ -1225,6 +1318,7 @@ static void worker(Shared *sh)
     std::vector<Read> chunk;
     std::vector<std::string> lines;
     Counters ct;
+    Discord last_disc = {0, 0}; // the reference's DiscordPair variable lives across pairs
     for (;;) {
         chunk.clear();
         {
@@ -1259,6 +1353,23 @@ static void worker(Shared *sh)
                 if (pd.dist != 0 && pd.g1 != -1 && pd.g2 != -1) {
                     bool inv = (pd.g1 < ix.G && pd.g2 >= ix.G) || (pd.g1 >= ix.G && pd.g2 < ix.G);
                     if (!inv && pd.dist <= 1000) { pairs++; dsum += pd.dist; } // MinTranslocationSize :9
+                    if (sh->pf) { // discordant-site lists, ReadMapping.cpp:486-521 (the second branch pushes unconditionally)
+                        Profile &pf = *sh->pf;
+                        if (pd.g1 < ix.G && pd.g2 >= ix.G) {
+                            i64 d = ix.G2 - pd.g1 - pd.g2; if (d < 0) d = -d;
+                            if (d > 1000 && d < 10000000) pf.inv.push_back({pd.g1, d});
+                            last_disc = {pd.g1, d};
+                        } else if (pd.g1 >= ix.G && pd.g2 < ix.G) {
+                            i64 d = ix.G2 - pd.g1 - pd.g2; if (d < 0) d = -d;
+                            last_disc.dist = d;
+                            if (d > 1000 && d < 10000000) last_disc.gPos = pd.g2;
+                            pf.inv.push_back(last_disc);
+                        } else if (pd.dist > 1000) {
+                            last_disc.dist = pd.dist;
+                            if (pd.g1 < ix.G && pd.g2 < ix.G) { pf.tnl.push_back({pd.g1, pd.dist}); pf.tnl.push_back({pd.g2, pd.dist}); last_disc.gPos = pd.g2; }
+                            else if (pd.g1 >= ix.G && pd.g2 >= ix.G) { pf.tnl.push_back({ix.G2 - pd.g1, pd.dist}); pf.tnl.push_back({ix.G2 - pd.g2, pd.dist}); last_disc.gPos = ix.G2 - pd.g2; }
+                        }
+                    }
                 }
             }
             if (sh->sam) for (int i = 0; i < n; i += 2) sam_paired(ix, sh->pm, sh->fastq, chunk[i], chunk[i + 1], lines);
@@ -1274,6 +1385,16 @@ static void worker(Shared *sh)
         sh->n_reads += n; sh->n_mapped += mapped; sh->n_paired += pairs; sh->dist_sum += dsum;
         if (sh->n_paired > 1000) sh->avg_dist = (u32)(int)(1. * sh->dist_sum / sh->n_paired + .5); // :539
         if (sh->sam) for (auto &l : lines) { fputs(l.c_str(), sh->sam); fputc('\n', sh->sam); }
+        if (sh->pf) { // ReadMapping.cpp:562-573 / :610-620
+            const bool pe = sh->paired && n % 2 == 0;
+            for (int i = 0; i < n; i++) {
+                if (chunk[i].score == 0) continue;
+                int live = 0;
+                for (const Cand &c : chunk[i].cands) if (c.score > 0) live++;
+                if (live == 1) update_profile(ix, *sh->pf, pe ? (i % 2 == 0) : true, chunk[i]);
+                else update_multi_hit(ix, *sh->pf, chunk[i]);
+            }
+        }
     }
     std::lock_guard<std::mutex> g(sh->out_lock);
     sh->ct.ext_steps += ct.ext_steps; sh->ct.sa_hits += ct.sa_hits; sh->ct.lf_steps += ct.lf_steps;
@@ -1339,12 +1460,52 @@ int mcxo_ksw2_extz(const uint8_t *q, int qlen, const uint8_t *t, int tlen, int *
     return (int)c.size();
 }
 
+static int64_t map_files_impl(const mcxo_index *ix, const char *fq1, const char *fq2, int alg, const char *sam_path,
+                              int threads, int64_t *stats, Profile *pf);
+
 int64_t mcxo_map_files(const mcxo_index *ix, const char *fq1, const char *fq2, int alg, const char *sam_path,
                        int threads, int64_t *stats)
+{
+    return map_files_impl(ix, fq1, fq2, alg, sam_path, threads, stats, nullptr);
+}
+
+// As `MapCaller ... -vcf` would leave them after Mapping(): writes <out>.prof (10 x u16 per
+// position: A C G T multi_hit readCount F1 R2 F2 R1) and <out>.maps (insert / delete / breakpoint
+// maps and the inversion / translocation site lists), the format of oracle/_ref/mcref_tool 'P'.
+int64_t mcxo_map_files_profile(const mcxo_index *ix, const char *fq1, const char *fq2, int alg, const char *out_prefix)
+{
+    Profile pf;
+    pf.init(ix->G);
+    int64_t n = map_files_impl(ix, fq1, fq2, alg, nullptr, 1, nullptr, &pf);
+    if (n < 0) return n;
+    std::string p = std::string(out_prefix) + ".prof";
+    FILE *f = fopen(p.c_str(), "wb");
+    if (!f) return -2;
+    fwrite(pf.cnt.data(), 2, pf.cnt.size(), f);
+    fclose(f);
+    p = std::string(out_prefix) + ".maps";
+    f = fopen(p.c_str(), "w");
+    if (!f) return -2;
+    for (auto &a : pf.ins) for (auto &b : a.second) fprintf(f, "I %lld %s %d\n", (long long)a.first, b.first.c_str(), (int)b.second);
+    for (auto &a : pf.del) for (auto &b : a.second) fprintf(f, "D %lld %s %d\n", (long long)a.first, b.first.c_str(), (int)b.second);
+    for (auto &a : pf.brk) fprintf(f, "B %lld %d\n", (long long)a.first, (int)a.second);
+    // the reference sorts each worker's lists by position before merging (ReadMapping.cpp:627-643)
+    auto by_pos = [](const Discord &x, const Discord &y) { return x.gPos < y.gPos; };
+    std::stable_sort(pf.inv.begin(), pf.inv.end(), by_pos);
+    std::stable_sort(pf.tnl.begin(), pf.tnl.end(), by_pos);
+    for (auto &d : pf.inv) fprintf(f, "V %lld %lld\n", (long long)d.gPos, (long long)d.dist);
+    for (auto &d : pf.tnl) fprintf(f, "T %lld %lld\n", (long long)d.gPos, (long long)d.dist);
+    fclose(f);
+    return n;
+}
+
+static int64_t map_files_impl(const mcxo_index *ix, const char *fq1, const char *fq2, int alg, const char *sam_path,
+                              int threads, int64_t *stats, Profile *pf)
 {
     init_nt4();
     Shared sh;
     sh.ix = ix;
+    sh.pf = pf;
     sh.pm.use_nw = (alg == 0);
     if (!sh.in1.open(fq1)) return -1;
     sh.fastq = sh.in1.fastq;

@@ -91,7 +91,50 @@ int mcref_ksw2_extz(const uint8_t *q, int qlen, const uint8_t *t, int tlen, int 
 
 }
 
+// Runs the reference's own Mapping() (ReadMapping.cpp:689) with -vcf bookkeeping on and dumps what
+// UpdateProfile / UpdateMultiHitCount (AlignmentProfile.cpp:41-271) accumulated:
+//   <out>.prof : GenomeSize records of 10 x u16 {A,C,G,T,multi_hit,readCount,F1,R2,F2,R1}
+//   <out>.maps : text lines "I pos seq n" / "D pos seq n" (InsertSeqMap/DeleteSeqMap), "B pos n"
+//                (BreakPointMap), "V gPos dist" / "T gPos dist" (InversionSiteVec/TranslocationSiteVec)
+extern map<int64_t, uint16_t> BreakPointMap;
+static int run_profile(const char *fq1, const char *fq2, int ksw2, const char *out)
+{
+    ReadFileNameVec1.clear(); ReadFileNameVec2.clear();
+    ReadFileNameVec1.push_back(fq1);
+    if (fq2 && fq2[0]) ReadFileNameVec2.push_back(fq2);
+    NW_ALG = !ksw2; bVCFoutput = true; bSAMoutput = false; iThreadNum = 1; iMaxDuplicate = 5; MaxClipSize = 5;
+    static char logname[] = "/dev/null";
+    LogFileName = logname;
+    if (MappingRecordArr) delete[] MappingRecordArr;
+    MappingRecordArr = new MappingRecord_t[GenomeSize]();
+    InsertSeqMap.clear(); DeleteSeqMap.clear(); BreakPointMap.clear(); InversionSiteVec.clear(); TranslocationSiteVec.clear();
+    pthread_mutex_init(&VarLock, NULL); pthread_mutex_init(&OutputLock, NULL); pthread_mutex_init(&LibraryLock, NULL); pthread_mutex_init(&ProfileLock, NULL);
+    StartProcessTime = time(NULL);
+    Mapping();
+    string p = string(out) + ".prof";
+    FILE *f = fopen(p.c_str(), "wb");
+    if (!f) return -1;
+    for (int64_t g = 0; g < GenomeSize; g++) {
+        const MappingRecord_t &m = MappingRecordArr[g];
+        uint16_t v[10] = {(uint16_t)m.A, (uint16_t)m.C, (uint16_t)m.G, (uint16_t)m.T, (uint16_t)m.multi_hit, (uint16_t)m.readCount, m.F1, m.R2, m.F2, m.R1};
+        fwrite(v, 2, 10, f);
+    }
+    fclose(f);
+    p = string(out) + ".maps";
+    f = fopen(p.c_str(), "w");
+    for (map<int64_t, map<string, uint16_t> >::iterator a = InsertSeqMap.begin(); a != InsertSeqMap.end(); a++)
+        for (map<string, uint16_t>::iterator b = a->second.begin(); b != a->second.end(); b++) fprintf(f, "I %lld %s %d\n", (long long)a->first, b->first.c_str(), (int)b->second);
+    for (map<int64_t, map<string, uint16_t> >::iterator a = DeleteSeqMap.begin(); a != DeleteSeqMap.end(); a++)
+        for (map<string, uint16_t>::iterator b = a->second.begin(); b != a->second.end(); b++) fprintf(f, "D %lld %s %d\n", (long long)a->first, b->first.c_str(), (int)b->second);
+    for (map<int64_t, uint16_t>::iterator a = BreakPointMap.begin(); a != BreakPointMap.end(); a++) fprintf(f, "B %lld %d\n", (long long)a->first, (int)a->second);
+    for (size_t i = 0; i < InversionSiteVec.size(); i++) fprintf(f, "V %lld %lld\n", (long long)InversionSiteVec[i].gPos, (long long)InversionSiteVec[i].dist);
+    for (size_t i = 0; i < TranslocationSiteVec.size(); i++) fprintf(f, "T %lld %lld\n", (long long)TranslocationSiteVec[i].gPos, (long long)TranslocationSiteVec[i].dist);
+    fclose(f);
+    return 0;
+}
+
 // stdin protocol, one request per line, one reply line each:
+//   P <nw|ksw2> <out prefix> <fq1> [fq2]  -> "ok" after <out>.prof / <out>.maps are written
 //   L <prefix>                 -> "ok <genome size>"
 //   S <start> <codes 0-4>      -> "<len> <freq> <loc>..."            BWT_Search(seq, start, strlen)
 //   D <q ascii> <t ascii>      -> "<nw a1> <nw a2> <ksw2 a1> <ksw2 a2> <ez.score> <ops reversed>"
@@ -132,6 +175,12 @@ int main()
             int score = 0;
             mcref_ksw2_extz(qc.data(), m, tc.data(), k, &score, ops.data(), c);
             printf("%s %s %s %s %d %s\n", a1.data(), a2.data(), b1.data(), b2.data(), score, ops.data());
+        } else if (line[0] == 'P') {
+            char alg[16], out[1024], f1[1024], f2[1024];
+            f2[0] = 0;
+            int k = sscanf(line + 2, "%15s %1023s %1023s %1023s", alg, out, f1, f2);
+            int rc = k >= 3 ? run_profile(f1, f2, strcmp(alg, "ksw2") == 0, out) : -1;
+            printf("%s\n", rc == 0 ? "ok" : "fail");
         } else printf("bad\n");
         fflush(stdout);
     }

@@ -44,7 +44,7 @@ static void set_view(Emu &e)
 
 struct Batch {
     std::vector<HostRead> reads;
-    std::vector<uint8_t> bases, codes;
+    std::vector<uint8_t> bases;
     std::vector<uint32_t> off;
     bool paired = false;
 };
@@ -55,7 +55,6 @@ static void make_reads(const Batch &b, uint32_t pair, ReadRef rd[2])
     for (int s = 0; s < nr; s++) {
         uint32_t r = pair * nr + s;
         rd[s].ascii = b.bases.data() + b.off[r];
-        rd[s].codes = b.codes.data() + b.off[r];
         rd[s].rlen = (int)(b.off[r + 1] - b.off[r]);
         rd[s].flipped = (b.paired && s == 1) ? 1 : 0;
     }
@@ -83,7 +82,9 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
         for (int s = 0; s < nr; s++) {
             uint32_t r = ids[l] * nr + s;
             int64_t ext = 0, blocks = 0;
-            int nh = seed_read(cx.ix, b.codes.data() + b.off[r], (int)(b.off[r + 1] - b.off[r]), st.hits[s], cx.caps.hit_cap, ext, blocks);
+            ReadRef one;
+            one.ascii = b.bases.data() + b.off[r]; one.rlen = (int)(b.off[r + 1] - b.off[r]); one.flipped = (b.paired && s == 1) ? 1 : 0;
+            int nh = seed_read(cx.ix, one, st.hits[s], cx.caps.hit_cap, ext, blocks);
             st.hdr->n_hits[s] = nh;
             if (stats) { stats[3] += ext; stats[8] += blocks; }
             int keep = nh <= cx.caps.hit_cap ? nh : 0;
@@ -129,9 +130,10 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
         const DpJob &job = jobs[j];
         PairState st = pair_state(cx.state, cx.lay, cx.caps, job.pair);
         const uint32_t read = ids[job.pair] * nr + job.slot;
-        const uint8_t *codes = b.codes.data() + b.off[read];
+        ReadRef jr;
+        jr.ascii = b.bases.data() + b.off[read]; jr.rlen = (int)(b.off[read + 1] - b.off[read]); jr.flipped = (b.paired && job.slot == 1) ? 1 : 0;
         std::string q(job.rLen, 'N'), t(job.gLen, 'N');
-        for (int i = 0; i < job.rLen; i++) q[i] = "ACGTN"[codes[job.rev ? job.rPos + job.rLen - 1 - i : job.rPos + i]];
+        for (int i = 0; i < job.rLen; i++) q[i] = "ACGTN"[read_code(jr, job.rev ? job.rPos + job.rLen - 1 - i : job.rPos + i)];
         for (int i = 0; i < job.gLen; i++) t[i] = "ACGTN"[ref_code(cx.ix, job.rev ? job.gPos + job.gLen - 1 - i : job.gPos + i)];
         std::vector<char> o1(job.rLen + job.gLen + 2), o2(job.rLen + job.gLen + 2);
         int L = cx.pm.use_nw ? mcxo_nw(q.c_str(), job.rLen, t.c_str(), job.gLen, o1.data(), o2.data(), (int)o1.size())
@@ -230,18 +232,9 @@ int64_t hostemu_map_files(const char *prefix, const char *fq1, const char *fq2, 
         }
         if (b.reads.empty()) break;
         for (auto &r : b.reads) { b.bases.insert(b.bases.end(), r.seq.begin(), r.seq.end()); b.off.push_back((uint32_t)b.bases.size()); }
+        b.bases.resize(b.bases.size() + 64, 'N');
         const uint32_t n = (uint32_t)b.reads.size();
         b.paired = paired && (n % 2 == 0);
-        b.codes.resize(b.bases.size());
-        for (uint32_t r = 0; r < n; r++) { // k_encode
-            const uint32_t o = b.off[r], len = b.off[r + 1] - o;
-            const bool flip = b.paired && (r & 1);
-            for (uint32_t i = 0; i < len; i++) {
-                int c = nt4_code(b.bases[o + (flip ? len - 1 - i : i)]);
-                if (flip && c < 4) c = 3 - c;
-                b.codes[o + i] = (uint8_t)c;
-            }
-        }
         const uint32_t n_pairs = b.paired ? n / 2 : n;
         std::vector<AlnRec> recs(n);
         std::vector<uint32_t> cig((size_t)n * 32);
