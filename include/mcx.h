@@ -125,6 +125,29 @@ int mcx_map_batch_dev(mcx_ctx *, const uint8_t *d_bases, const uint32_t *d_off, 
 int mcx_map_batch(mcx_ctx *, const uint8_t *bases, const uint32_t *off, uint32_t n_reads, int paired,
                   int64_t avg_state[4], mcx_aln *aln, uint32_t *cigar, mcx_stats *stats);
 
+/* ---- -vcf bookkeeping -------------------------------------------------------------------------
+ * Replaces UpdateProfile / UpdateMultiHitCount (reference src/AlignmentProfile.cpp:41-271, called
+ * under ProfileLock from src/ReadMapping.cpp:562-573) and the discordant-site lists
+ * (src/ReadMapping.cpp:486-521).  d_planes: caller-owned, zero-initialised device array of
+ * 10 * GenomeSize u32 laid out [plane][position], planes A C G T multi_hit readCount F1 R2 F2 R1 —
+ * MappingRecord_t (src/structure.h:152-163) unpacked, so that several GPUs can sum their arrays
+ * with one all-reduce.  Once attached, every mcx_map_batch* call adds its reads.
+ * mcx_profile_finalize applies the reference's field widths (12-bit saturation at 4095, 16-bit
+ * wrap, duplicate cap) in place; call it once, after the last batch (and after the reduce).
+ * mcx_profile_sparse returns the insert / delete / break-point tallies ('I','D','B': one record
+ * per event, to be summed by (pos, seq)) and the inversion / translocation site records ('V','T':
+ * pos = gPos, dist in the first 8 bytes of seq).  max_dup = iMaxDuplicate (-dup, default 5),
+ * max_clip = MaxClipSize (-maxclip, default 5). */
+typedef struct mcx_sparse_rec {
+    int64_t pos;
+    uint8_t type;
+    uint8_t len;
+    char seq[54];
+} mcx_sparse_rec;
+int mcx_profile_attach(mcx_ctx *, uint32_t *d_planes, int max_dup, int max_clip);
+int mcx_profile_finalize(mcx_ctx *, uint32_t *d_planes);
+int mcx_profile_sparse(mcx_ctx *, const mcx_sparse_rec **recs, uint64_t *n);
+
 /* ---- files: MapCaller -i <prefix> -f A [-f2 B] -alg nw|ksw2 -sam out (src/main.cpp:212-321) */
 int mcx_map_files(mcx_ctx *, const char *fq1, const char *fq2, const char *sam_path, mcx_stats *stats);
 

@@ -22,6 +22,7 @@ SYMBOLS = [
     "mcx_index_genome_size", "mcx_index_n_chr", "mcx_index_chr_name", "mcx_index_chr_len", "mcx_index_hbm_bytes",
     "mcx_opts_default", "mcx_ctx_create", "mcx_ctx_free", "mcx_bwt_search_batch", "mcx_extend_batch",
     "mcx_avg_init", "mcx_map_batch_dev", "mcx_map_batch", "mcx_map_files",
+    "mcx_profile_attach", "mcx_profile_finalize", "mcx_profile_sparse",
 ]
 
 
@@ -43,6 +44,13 @@ class Aln(C.Structure):
 ALN_DTYPE = np.dtype([("pos", "<i8"), ("mate_pos", "<i8"), ("chr", "<i4"), ("flag", "<i4"), ("mapq", "<i4"),
                       ("tlen", "<i4"), ("nm", "<i4"), ("as", "<i4"), ("xs", "<i4"), ("n_cigar", "<i4"),
                       ("fwd", "<i4"), ("has_mate", "<i4")])
+
+
+class SparseRec(C.Structure):
+    _fields_ = [("pos", C.c_int64), ("type", C.c_uint8), ("len", C.c_uint8), ("seq", C.c_char * 54)]
+
+
+PLANES = ("A", "C", "G", "T", "multi_hit", "readCount", "F1", "R2", "F2", "R1")
 
 
 class Stats(C.Structure):
@@ -97,6 +105,9 @@ def lib() -> C.CDLL:
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_int64), C.c_void_p,
                       C.c_void_p, C.POINTER(Stats)]
     L.mcx_map_files.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(Stats)]
+    L.mcx_profile_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.mcx_profile_finalize.argtypes = [C.c_void_p, C.c_void_p]
+    L.mcx_profile_sparse.argtypes = [C.c_void_p, C.POINTER(C.POINTER(SparseRec)), C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -215,6 +226,30 @@ class Mapper:
         _check(lib().mcx_map_batch_dev(self._h, d_bases_ptr, d_off_ptr, n_reads, int(paired), self.avg, d_aln_ptr,
                                        d_cigar_ptr, C.byref(self.stats)), "mcx_map_batch_dev")
 
+    # ---- -vcf bookkeeping ---------------------------------------------------------------
+    def profile_attach(self, d_planes_ptr: int, max_dup: int = 5, max_clip: int = 5) -> None:
+        """d_planes: zeroed device array uint32 [10, GenomeSize] (PLANES order), caller-owned so
+        that it can be all-reduced across GPUs; every later map_batch* call accumulates into it."""
+        _check(lib().mcx_profile_attach(self._h, d_planes_ptr, max_dup, max_clip), "mcx_profile_attach")
+
+    def profile_finalize(self, d_planes_ptr: int) -> None:
+        _check(lib().mcx_profile_finalize(self._h, d_planes_ptr), "mcx_profile_finalize")
+
+    def profile_sparse(self):
+        """[(type, pos, seq or dist)]: 'I'/'D'/'B' events and 'V'/'T' discordant-site records."""
+        recs = C.POINTER(SparseRec)()
+        n = C.c_uint64()
+        _check(lib().mcx_profile_sparse(self._h, C.byref(recs), C.byref(n)), "mcx_profile_sparse")
+        out = []
+        for i in range(n.value):
+            r = recs[i]
+            t = chr(r.type)
+            if t in "VT":
+                out.append((t, int(r.pos), int.from_bytes(C.string_at(C.addressof(r) + 10, 8), "little", signed=True)))
+            else:
+                out.append((t, int(r.pos), C.string_at(C.addressof(r) + 10, r.len).decode("latin-1")))
+        return out
+
     # ---- per-call drop-ins --------------------------------------------------------------
     def bwt_search(self, seqs: List[bytes], starts: List[int]):
         """BWT_Search for many (code string, start) queries. Returns (len, freq, loc[n,50])."""
@@ -274,3 +309,32 @@ def apply_ops(q: str, t: str, ops: str) -> Tuple[str, str]:
         else:
             a.append("-"); b.append(t[j]); j += 1
     return "".join(a), "".join(b)
+
+
+def sparse_to_maps_text(sparse) -> str:
+    """The text form oracle/_ref/mcref_tool 'P' and mcxo_map_files_profile write (<out>.maps):
+    insert / delete / break-point maps in std::map order, then the inversion and translocation
+    site lists sorted by position (stable)."""
+    ins, dele, brk = {}, {}, {}
+    inv, tnl = [], []
+    for t, pos, v in sparse:
+        if t == "I":
+            ins[(pos, v)] = ins.get((pos, v), 0) + 1
+        elif t == "D":
+            dele[(pos, v)] = dele.get((pos, v), 0) + 1
+        elif t == "B":
+            brk[pos] = brk.get(pos, 0) + 1
+        elif t == "V":
+            inv.append((pos, v))
+        else:
+            tnl.append((pos, v))
+    lines = []
+    for name, m in (("I", ins), ("D", dele)):
+        for (pos, seq) in sorted(m, key=lambda k: (k[0], k[1].encode("latin-1"))):
+            lines.append(f"{name} {pos} {seq} {m[(pos, seq)]}")
+    for pos in sorted(brk):
+        lines.append(f"B {pos} {brk[pos]}")
+    for name, lst in (("V", inv), ("T", tnl)):
+        for pos, dist in sorted(lst, key=lambda k: k[0]):
+            lines.append(f"{name} {pos} {dist}")
+    return "".join(l + "\n" for l in lines)

@@ -22,6 +22,8 @@ struct Ctx {
     Params pm;
     Caps caps;
     Layout lay;
+    uint8_t *detail;          // per-read alignment detail (null unless the profile is being kept)
+    DetailLayout dlay;
     uint8_t *state;           // pair-state records
     const uint8_t *mapq_tab;  // [(rlen_max+1) * 6]: EvaluateMAPQ for (score, score-sub in 1..5), host-computed
     int32_t mapq_rows;
@@ -796,7 +798,7 @@ static inline MCX_HD int paired_flag(const Cand &c, const Cand *other, bool firs
 }
 
 // GenCoordinatePair (ReadMapping.cpp:361-394) + the counting at :479-531
-static inline MCX_HD void pair_stats(const Ctx &cx, PairState &st)
+static inline MCX_HD void pair_stats(const Ctx &cx, PairState &st, DetailHdr *dh)
 {
     PairHdr &h = *st.hdr;
     const Cand *c1 = st.cands[0], *c2 = st.cands[1];
@@ -820,10 +822,16 @@ static inline MCX_HD void pair_stats(const Ctx &cx, PairState &st)
         else if (a >= 1 && b == 0) { dist = g1 = ga; g2 = -1; }
     }
     h.pair_ok = 0; h.pair_dist = 0;
+    if (dh) { dh->disc_kind = 0; dh->disc_g1 = g1; dh->disc_g2 = g2; dh->disc_dist = dist; }
     if (dist != 0 && g1 != -1 && g2 != -1) {
         const int64_t G = cx.ix.G;
         bool inv = (g1 < G && g2 >= G) || (g1 >= G && g2 < G);
         if (!inv && dist <= kMinTranslocationSize) { h.pair_ok = 1; h.pair_dist = (int)dist; }
+        if (dh) { // which branch of ReadMapping.cpp:486-521 the pair takes when -vcf is on
+            if (g1 < G && g2 >= G) dh->disc_kind = 1;
+            else if (g1 >= G && g2 < G) dh->disc_kind = 2;
+            else if (dist > kMinTranslocationSize) dh->disc_kind = (g1 < G && g2 < G) ? 3 : 4;
+        }
     }
 }
 
@@ -879,7 +887,55 @@ static inline MCX_HD void emit_record(const Ctx &cx, PairState &st, int s, const
     }
 }
 
-static inline MCX_HD void stage_finish(const Ctx &cx, int64_t pair, const ReadRef *rd, AlnRec *recs, uint32_t *cigars)
+// copies what the profile stage needs of one read out of the pair state (which is reused by the
+// next tier / replay pass): the fragments and DP columns of its single surviving candidate, or
+// the genome ranges of all of them when it is multi-mapped (ReadMapping.cpp:566-571)
+static inline MCX_HD void write_detail(const Ctx &cx, PairState &st, int s, uint8_t *rec)
+{
+    PairHdr &h = *st.hdr;
+    DetailHdr &d = *(DetailHdr *)rec;
+    Frag *df = (Frag *)(rec + sizeof(DetailHdr));
+    uint8_t *dops = rec + cx.dlay.off_ops;
+    d.type = 0; d.n_frags = 0; d.fwd = 1; d.n_ops = 0;
+    if (h.sum[s].score == 0) return;
+    const Cand *cs = st.cands[s];
+    int live = 0, one = -1;
+    for (int i = 0; i < h.n_cands[s]; i++) if (cs[i].score > 0) { live++; one = i; }
+    if (live == 1) {
+        const Cand &c = cs[one];
+        if (c.n_frags > cx.dlay.frag_cap) { h.flags |= kOvDetail; return; }
+        d.type = 1; d.fwd = c.fwd; d.n_frags = c.n_frags;
+        int no = 0;
+        for (int i = 0; i < c.n_frags; i++) {
+            Frag f = st.frags[c.frag_off + i];
+            if (f.kind == kDp) {
+                if (no + f.ops_len > cx.dlay.ops_cap) { h.flags |= kOvDetail; d.type = 0; return; }
+                for (int x = 0; x < f.ops_len; x++) dops[no + x] = st.ops[f.ops_off + x];
+                f.ops_off = no; no += f.ops_len;
+            }
+            df[i] = f;
+        }
+        d.n_ops = no;
+    } else {
+        d.type = 2;
+        int n = 0;
+        for (int i = 0; i < h.n_cands[s]; i++) {
+            const Cand &c = cs[i];
+            if (c.score <= 0) continue;
+            if (n >= cx.dlay.frag_cap) { h.flags |= kOvDetail; d.type = 0; return; }
+            const Frag &a = st.frags[c.frag_off], &b = st.frags[c.frag_off + c.n_frags - 1];
+            const int64_t g0 = c.fwd ? a.gPos : cx.ix.G2 - (a.gPos + a.gLen);
+            const int64_t g1 = c.fwd ? b.gPos + b.gLen : cx.ix.G2 - b.gPos;
+            Frag r; r.gPos = g0; r.rPos = 0; r.rLen = (int32_t)(g1 - g0); r.gLen = 0; r.ops_off = 0; r.ops_len = 0; r.kind = kSimple;
+            r.pad[0] = r.pad[1] = r.pad[2] = 0;
+            df[n++] = r;
+        }
+        d.n_frags = n;
+    }
+}
+
+static inline MCX_HD void stage_finish(const Ctx &cx, int64_t pair, const ReadRef *rd, AlnRec *recs, uint32_t *cigars,
+                                       uint8_t *detail0)
 {
     PairState st = pair_state(cx.state, cx.lay, cx.caps, pair);
     PairHdr &h = *st.hdr;
@@ -887,10 +943,12 @@ static inline MCX_HD void stage_finish(const Ctx &cx, int64_t pair, const ReadRe
     if (h.flags & kOvAny) return;
     h.mapped = 0;
     for (int s = 0; s < nr; s++) { extend_read(cx, st, s, rd[s]); if (h.sum[s].score > 0) h.mapped++; }
-    if (cx.pm.paired) pair_stats(cx, st); else { h.pair_ok = 0; h.pair_dist = 0; }
+    DetailHdr *dh = detail0 ? (DetailHdr *)(detail0 + (pair * nr) * cx.dlay.stride) : nullptr;
+    if (cx.pm.paired) pair_stats(cx, st, dh); else { h.pair_ok = 0; h.pair_dist = 0; if (dh) dh->disc_kind = 0; }
     for (int s = 0; s < nr; s++) {
         int64_t r = pair * nr + s;
         emit_record(cx, st, s, rd, recs[r], cigars + r * cx.caps.cig_cap, cx.caps.cig_cap);
+        if (detail0) write_detail(cx, st, s, detail0 + r * cx.dlay.stride);
     }
 }
 

@@ -24,6 +24,8 @@
 
 #include "../../include/mcx.h"
 #include "mcx_dp.h"
+#include "mcx_profile.h"
+#include <hipcub/hipcub.hpp>
 #include "mcx_host.h"
 #include "mcx_build.h"
 
@@ -453,7 +455,8 @@ __global__ void __launch_bounds__(256) k_finish(Ctx cx, ReadBatch rb, PairSel se
     const int nr = cx.pm.paired ? 2 : 1;
     AlnRec *r0 = recs + (int64_t)pair * nr - (int64_t)local * nr;
     uint32_t *c0 = cigars + ((int64_t)pair * nr - (int64_t)local * nr) * cx.caps.cig_cap;
-    stage_finish(cx, local, rd, r0, c0);
+    uint8_t *d0 = cx.detail ? cx.detail + ((int64_t)pair * nr - (int64_t)local * nr) * cx.dlay.stride : nullptr;
+    stage_finish(cx, local, rd, r0, c0, d0);
     const PairHdr &h = *st.hdr;
     PairOut o;
     o.flags = h.flags; o.est = h.est; o.est_lo = h.est_lo; o.est_hi = h.est_hi;
@@ -497,6 +500,13 @@ struct mcx_ctx {
     uint32_t *d_read_ext = nullptr, *d_read_blocks = nullptr;
     PairOut *d_pout = nullptr, *h_pout = nullptr;
     uint8_t *d_mapq = nullptr; int mapq_rows = 0;
+    // -vcf bookkeeping (mcx_profile.h): caller-owned counter planes, per-read alignment detail
+    uint32_t *prof_planes = nullptr; int prof_max_dup = 5, prof_max_clip = 5;
+    uint8_t *d_detail = nullptr; DetailLayout dlay;
+    uint64_t *d_keys[2] = {nullptr, nullptr}; uint8_t *d_admit = nullptr; void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+    SparseRec *d_sparse = nullptr; uint32_t sparse_cap = 0;
+    std::vector<mcx_sparse_rec> h_sparse;
+    int64_t last_disc[2] = {0, 0}; // the reference's DiscordPair variable lives across pairs (ReadMapping.cpp:418)
     // staging for the host-buffer entry point
     uint8_t *d_bases = nullptr; uint32_t *d_off = nullptr; AlnRec *d_recs = nullptr; uint32_t *d_cig = nullptr;
     hipEvent_t ev[10];
@@ -600,7 +610,7 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
                  c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
-                 c->d_bases, c->d_off, c->d_recs, c->d_cig};
+                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse};
     for (void *q : p) if (q) (void)hipFree(q);
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
     if (c->h_pout) (void)hipHostFree(c->h_pout);
@@ -615,6 +625,7 @@ static Ctx make_ctx(const mcx_ctx *c, int tier, int paired)
     cx.ix = c->idx->view; cx.pm = c->pm; cx.pm.paired = paired;
     cx.caps = c->tier[tier].caps; cx.lay = c->tier[tier].lay; cx.state = c->tier[tier].state;
     cx.mapq_tab = c->d_mapq; cx.mapq_rows = c->mapq_rows;
+    cx.detail = c->prof_planes ? c->d_detail : nullptr; cx.dlay = c->dlay;
     return cx;
 }
 
@@ -720,6 +731,8 @@ __global__ void k_check_est(const PairOut *po, uint32_t n_pairs, uint32_t chunk,
         if (!ok) { const uint32_t at = atomicAdd(n_redo, 1u); if (at < cap) { redo_ids[at] = p; redo_est[at] = e; } }
     }
 }
+
+static int profile_batch(mcx_ctx *c, const ReadBatch &rb, int paired);
 
 extern "C" void mcx_avg_init(int64_t a[4]) { a[0] = 1000; a[1] = 0; a[2] = 0; a[3] = 0; }
 
@@ -848,6 +861,7 @@ extern "C" int mcx_map_batch_dev(mcx_ctx *c, const uint8_t *d_bases, const uint3
         avg[0] = after[0]; avg[1] = after[1]; avg[2] = after[2];
     }
     avg[3] += n_reads;
+    if (c->prof_planes) { rc = profile_batch(c, rb, paired); if (rc) return rc; }
     if (stats) {
         stats->reads += n_reads; stats->mapped += mapped; stats->pairs += pairs; stats->pair_dist_sum += dist_sum;
         stats->fm_ext_steps += (int64_t)hs[0]; stats->fm_blocks += (int64_t)hs[1];
@@ -877,6 +891,124 @@ extern "C" int mcx_map_batch(mcx_ctx *c, const uint8_t *bases, const uint32_t *o
     if (rc) return rc;
     HIP_TRY(hipMemcpy(aln, c->d_recs, (size_t)n_reads * sizeof(AlnRec), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(cigar, c->d_cig, (size_t)n_reads * MCX_CIGAR_STRIDE * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// -vcf bookkeeping: UpdateProfile / UpdateMultiHitCount for a finished batch (mcx_profile.h)
+// ---------------------------------------------------------------------------------------------
+struct DiscEv { uint32_t pair; int32_t kind; int64_t g1, g2, dist; };
+
+__global__ void k_prof_disc(const uint8_t *detail, DetailLayout dl, uint32_t n_pairs, DiscEv *out, uint32_t *n, uint32_t cap)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const DetailHdr &d = *(const DetailHdr *)(detail + (uint64_t)(2 * p) * dl.stride);
+    if (d.disc_kind == 0) return;
+    const uint32_t at = atomicAdd(n, 1u);
+    if (at < cap) { DiscEv e; e.pair = p; e.kind = d.disc_kind; e.g1 = d.disc_g1; e.g2 = d.disc_g2; e.dist = d.disc_dist; out[at] = e; }
+}
+
+extern "C" int mcx_profile_attach(mcx_ctx *c, uint32_t *d_planes, int max_dup, int max_clip)
+{
+    static_assert(sizeof(mcx_sparse_rec) == sizeof(SparseRec), "mcx_sparse_rec and SparseRec must have one layout");
+    if (!c || !d_planes) return fail(MCX_ERR_ARG, "mcx_profile_attach: null argument");
+    HIP_TRY(hipSetDevice(c->idx->device));
+    c->prof_planes = d_planes;
+    c->prof_max_dup = (max_dup <= 0 || max_dup > 15) ? 15 : max_dup; // main.cpp:240-244, :323
+    c->prof_max_clip = max_clip;
+    if (!c->d_detail) {
+        c->dlay = make_detail_layout(c->rlen_max);
+        int rc;
+        if ((rc = dmalloc(&c->d_detail, (size_t)c->dlay.stride * c->max_reads))) return rc;
+        for (int k = 0; k < 2; k++) if ((rc = dmalloc(&c->d_keys[k], c->max_reads))) return rc;
+        if ((rc = dmalloc(&c->d_admit, c->max_reads))) return rc;
+        hipcub::DoubleBuffer<uint64_t> dk(c->d_keys[0], c->d_keys[1]);
+        HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, c->sort_tmp_bytes, dk, (int64_t)c->max_reads, 0, 64));
+        HIP_TRY(hipMalloc(&c->d_sort_tmp, c->sort_tmp_bytes + 256));
+        c->sparse_cap = (uint32_t)std::min<uint64_t>(c->max_reads * 2 + 4096, 0x7fffffffu);
+        if ((rc = dmalloc(&c->d_sparse, c->sparse_cap))) return rc;
+    }
+    c->h_sparse.clear();
+    c->last_disc[0] = c->last_disc[1] = 0;
+    return 0;
+}
+
+static int profile_batch(mcx_ctx *c, const ReadBatch &rb, int paired)
+{
+    hipStream_t s = c->stream;
+    const IndexView &ix = c->idx->view;
+    ProfView pv; pv.plane = c->prof_planes; pv.G = ix.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
+    SparseSink sink; sink.recs = c->d_sparse; sink.n = c->d_cnt + CNT_TASKS; sink.cap = c->sparse_cap;
+    const uint32_t n = rb.n_reads;
+    HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(c->d_admit, 0, n, s));
+    k_prof_keys<<<(n + 255) / 256, 256, 0, s>>>(c->d_detail, c->dlay, rb, ix, pv, sink, c->d_keys[0]);
+    hipcub::DoubleBuffer<uint64_t> dk(c->d_keys[0], c->d_keys[1]);
+    size_t tb = c->sort_tmp_bytes;
+    HIP_TRY(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tb, dk, (int64_t)n, 0, 64, s));
+    k_prof_admit<<<(n + 255) / 256, 256, 0, s>>>(dk.Current(), n, pv, c->d_admit);
+    k_prof_accum<<<4096, 256, 0, s>>>(c->d_detail, c->dlay, rb, ix, pv, sink, c->d_admit, paired);
+    DiscEv *d_ev = (DiscEv *)c->d_tasks; // the SA task list is idle now
+    const uint32_t ev_cap = (uint32_t)std::min<uint64_t>((uint64_t)c->task_cap * sizeof(uint2) / sizeof(DiscEv), 0x7fffffffu);
+    if (paired) k_prof_disc<<<(n / 2 + 255) / 256, 256, 0, s>>>(c->d_detail, c->dlay, n / 2, d_ev, c->d_cnt + CNT_RESCUE, ev_cap);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t n_sp = c->h_cnt[CNT_TASKS], n_ev = c->h_cnt[CNT_RESCUE];
+    if (n_sp > c->sparse_cap || n_ev > ev_cap) return fail(MCX_ERR_CAPACITY, "profile: sparse record list overflow");
+    const size_t at = c->h_sparse.size();
+    c->h_sparse.resize(at + n_sp);
+    if (n_sp) HIP_TRY(hipMemcpy(c->h_sparse.data() + at, c->d_sparse, (size_t)n_sp * sizeof(SparseRec), hipMemcpyDeviceToHost));
+    if (n_ev) {
+        // discordant-site lists, ReadMapping.cpp:486-521, replayed in pair order because the
+        // reference's second branch pushes its DiscordPair variable whatever it last held
+        std::vector<DiscEv> ev(n_ev);
+        HIP_TRY(hipMemcpy(ev.data(), d_ev, (size_t)n_ev * sizeof(DiscEv), hipMemcpyDeviceToHost));
+        std::sort(ev.begin(), ev.end(), [](const DiscEv &a, const DiscEv &b) { return a.pair < b.pair; });
+        const int64_t G = ix.G, G2 = ix.G2;
+        auto push = [&](char type, int64_t gpos, int64_t dist) {
+            mcx_sparse_rec r; memset(&r, 0, sizeof r);
+            r.pos = gpos; r.type = (uint8_t)type; r.len = 0; memcpy(r.seq, &dist, 8);
+            c->h_sparse.push_back(r);
+        };
+        for (const DiscEv &e : ev) {
+            if (e.kind == 1) {
+                int64_t d = G2 - e.g1 - e.g2; if (d < 0) d = -d;
+                if (d > 1000 && d < 10000000) push('V', e.g1, d);
+                c->last_disc[0] = e.g1; c->last_disc[1] = d;
+            } else if (e.kind == 2) {
+                int64_t d = G2 - e.g1 - e.g2; if (d < 0) d = -d;
+                c->last_disc[1] = d;
+                if (d > 1000 && d < 10000000) c->last_disc[0] = e.g2;
+                push('V', c->last_disc[0], c->last_disc[1]);
+            } else if (e.kind == 3) {
+                push('T', e.g1, e.dist); push('T', e.g2, e.dist);
+                c->last_disc[0] = e.g2; c->last_disc[1] = e.dist;
+            } else {
+                push('T', G2 - e.g1, e.dist); push('T', G2 - e.g2, e.dist);
+                c->last_disc[0] = G2 - e.g2; c->last_disc[1] = e.dist;
+            }
+        }
+        (void)G;
+    }
+    return 0;
+}
+
+extern "C" int mcx_profile_finalize(mcx_ctx *c, uint32_t *d_planes)
+{
+    if (!c || !d_planes) return fail(MCX_ERR_ARG, "mcx_profile_finalize: null argument");
+    HIP_TRY(hipSetDevice(c->idx->device));
+    k_prof_finalize<<<4096, 256, 0, c->stream>>>(d_planes, c->idx->view.G, c->prof_max_dup);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int mcx_profile_sparse(mcx_ctx *c, const mcx_sparse_rec **recs, uint64_t *n)
+{
+    if (!c || !recs || !n) return fail(MCX_ERR_ARG, "mcx_profile_sparse: null argument");
+    *recs = c->h_sparse.data(); *n = c->h_sparse.size();
     return 0;
 }
 

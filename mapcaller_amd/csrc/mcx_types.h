@@ -116,7 +116,8 @@ struct ReadSum {      // AlnSummary_t (structure.h:135-140)
 
 enum PairFlags : uint32_t {
     kOvHits = 1u, kOvCands = 2u, kOvFrags = 4u, kOvOps = 8u, kOvJobs = 16u, kOvCigar = 32u, kOvKmer = 64u,
-    kOvAny = 127u,
+    kOvDetail = 128u,
+    kOvAny = 255u,
     kRescueUsedEst = 256u
 };
 
@@ -150,6 +151,40 @@ struct AlnRec {
     int32_t n_cigar;    // ops in the cigar pool row of this read
     int32_t fwd;        // SEQ printed as given (1) or reverse-complemented (0)
     int32_t has_mate;   // RNEXT '=' and PNEXT/TLEN valid
+};
+
+// Alignment detail of one read, written by the finish stage when the -vcf bookkeeping is on:
+// what UpdateProfile / UpdateMultiHitCount (AlignmentProfile.cpp:41-271) read from ReadItem_t.
+struct DetailHdr {
+    int32_t type;        // 0 unmapped, 1 exactly one surviving candidate, 2 several (multi-hit)
+    int32_t n_frags;     // type 1: fragments of the candidate; type 2: ranges {gPos = begin, rLen = length}
+    int32_t fwd;         // orientation of the candidate
+    int32_t n_ops;
+    int32_t disc_kind;   // read 0 of a pair: discordant-pair event of ReadMapping.cpp:486-521 (0 none, 1/2 strand mix, 3/4 distant)
+    int32_t pad;
+    int64_t disc_g1, disc_g2, disc_dist;
+};
+
+struct DetailLayout {
+    int32_t frag_cap, ops_cap;
+    int64_t off_ops, stride; // record = DetailHdr, Frag[frag_cap], ops[ops_cap]
+};
+
+static inline MCX_HD DetailLayout make_detail_layout(int rlen_max)
+{
+    DetailLayout d;
+    d.frag_cap = 64; d.ops_cap = 2 * rlen_max + 128;
+    d.off_ops = (int64_t)sizeof(DetailHdr) + (int64_t)d.frag_cap * sizeof(Frag);
+    d.stride = (d.off_ops + d.ops_cap + 63) & ~(int64_t)63;
+    return d;
+}
+
+// sparse tallies: insert / delete strings, break points (InsertSeqMap, DeleteSeqMap, BreakPointMap)
+struct SparseRec {
+    int64_t pos;
+    uint8_t type;        // 'I', 'D', 'B'
+    uint8_t len;
+    char seq[54];
 };
 
 // per-pair summary the host replays the reference's avgDist feedback from

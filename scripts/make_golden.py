@@ -15,7 +15,7 @@ toy   reference test/ref.fa (70 kb, 1 contig); 1500 pairs x 150 bp sampled from 
 mc    synthetic 3-contig genome with dispersed + tandem repeats and N runs; 2000 pairs x 150 bp
 se    same genome as mc; 2000 single-end FASTA reads x 100 bp with some N
 long  synthetic 2-contig genome; 600 pairs x 250 bp at 1 % sub / 1 % ins / 1 % del per base
-Each set has ref.<alg>.sam.gz for nw and ksw2.
+Each set has ref.<alg>.sam.gz for nw and ksw2, and for one algorithm ref.<alg>.prof.gz / .maps.gz: the\nalignment profile (10 x u16 per position) and the sparse maps the reference holds after Mapping() with -vcf on.
 func  bwt_search.json (queries on the toy index) and dp.json (nw/ksw2 strings, ez.score)
 """
 import gzip
@@ -49,7 +49,7 @@ def gz_write(path, data: bytes):
             fh.write(data)
 
 
-def make_set(name, fasta, donor, n, rlen, paired, seed, fastq=True, **kw):
+def make_set(name, fasta, donor, n, rlen, paired, seed, fastq=True, profile_alg=None, **kw):
     out = os.path.join(GOLD, name)
     os.makedirs(out, exist_ok=True)
     with tempfile.TemporaryDirectory() as tmp:
@@ -79,6 +79,14 @@ def make_set(name, fasta, donor, n, rlen, paired, seed, fastq=True, **kw):
             data = open(sam, "rb").read()
             assert data.count(b"\n") >= (2 * n if paired else n), (name, alg)
             gz_write(os.path.join(out, f"ref.{alg}.sam.gz"), data)
+        if profile_alg:
+            # what Mapping() leaves behind with -vcf on: MappingRecordArr and the sparse maps
+            tool = subprocess.Popen([REF_TOOL], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+            cmd = f"L {prefix}\nP {profile_alg} {tmp}/prof {f1} {f2 if paired else ''}\n"
+            reply = tool.communicate(cmd)[0].split()
+            assert reply[-1] == "ok", reply
+            gz_write(os.path.join(out, f"ref.{profile_alg}.prof.gz"), open(f"{tmp}/prof.prof", "rb").read())
+            gz_write(os.path.join(out, f"ref.{profile_alg}.maps.gz"), open(f"{tmp}/prof.maps", "rb").read())
     print("set", name, "done")
 
 
@@ -173,18 +181,18 @@ def main():
     os.makedirs(os.path.join(GOLD, "func"), exist_ok=True)
     mut = synth.read_fasta("/root/reference/test/mut.fa")
     make_set("toy", "/root/reference/test/ref.fa", mut, 1500, 150, True, seed=7,
-             frag_mean=500, frag_sd=87, frag_min=350, frag_max=650)
+             frag_mean=500, frag_sd=87, frag_min=350, frag_max=650, profile_alg="ksw2")
     with tempfile.TemporaryDirectory() as tmp:
         g = synth.random_genome([160000, 120000, 90000], seed=11, n_repeats=25, repeat_len=600, tandem=12, n_runs=8)
         fa = os.path.join(tmp, "mc.fa")
         synth.write_fasta(fa, g)
         donor = synth.mutate_genome(g, 12)
-        make_set("mc", fa, donor, 2000, 150, True, seed=13, sub=0.01)
-        make_set("se", fa, donor, 2000, 100, False, seed=14, fastq=False, n_rate=0.002)
+        make_set("mc", fa, donor, 2000, 150, True, seed=13, sub=0.01, profile_alg="nw")
+        make_set("se", fa, donor, 2000, 100, False, seed=14, fastq=False, n_rate=0.002, profile_alg="ksw2")
         g2 = synth.random_genome([150000, 150000], seed=21, n_repeats=8, tandem=4)
         fa2 = os.path.join(tmp, "long.fa")
         synth.write_fasta(fa2, g2)
-        make_set("long", fa2, synth.mutate_genome(g2, 22), 600, 250, True, seed=23, sub=0.01, ins=0.01, dele=0.01)
+        make_set("long", fa2, synth.mutate_genome(g2, 22), 600, 250, True, seed=23, sub=0.01, ins=0.01, dele=0.01, profile_alg="ksw2")
     make_func_vectors()
     torch.manual_seed(0)
 

@@ -37,6 +37,8 @@ def oracle_lib():
     L.mcxo_map_files.restype = ctypes.c_int64
     L.mcxo_map_files.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p,
                                  ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]
+    L.mcxo_map_files_profile.restype = ctypes.c_int64
+    L.mcxo_map_files_profile.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
     L.mcxo_bwt_search.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int,
                                   ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]
     for f in (L.mcxo_nw, L.mcxo_ksw2):
@@ -79,8 +81,10 @@ def golden(tmp_path_factory):
                     info["r1"] = str(tgt)
                 elif fn.startswith("r2."):
                     info["r2"] = str(tgt)
-                elif fn.startswith("ref."):
+                elif fn.startswith("ref.") and fn.endswith(".sam.gz"):
                     info["sam"][fn.split(".")[1]] = str(tgt)
+                elif fn.startswith("ref.") and fn.endswith(".prof.gz"):
+                    info["prof"] = (fn.split(".")[1], str(tgt), str(tgt)[:-5] + ".maps")
         info.setdefault("r2", None)
         out[name] = info
     return out

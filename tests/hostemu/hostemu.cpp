@@ -70,6 +70,7 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
     std::vector<uint8_t> state((size_t)e.lay[tier].stride * n);
     Ctx cx;
     cx.ix = e.view; cx.pm = e.pm; cx.pm.paired = b.paired; cx.caps = e.caps[tier]; cx.lay = e.lay[tier];
+    cx.detail = nullptr; cx.dlay = make_detail_layout(256);
     cx.state = state.data(); cx.mapq_tab = e.mapq.data(); cx.mapq_rows = e.mapq_rows;
     std::vector<DpJob> jobs((size_t)n * 64 + 1024);
     uint32_t n_jobs = 0;
@@ -153,7 +154,7 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
         const uint32_t pair = ids[l];
         AlnRec *r0 = recs.data() + (int64_t)pair * nr - (int64_t)l * nr;
         uint32_t *c0 = cig.data() + ((int64_t)pair * nr - (int64_t)l * nr) * cx.caps.cig_cap;
-        stage_finish(cx, l, rd, r0, c0);
+        stage_finish(cx, l, rd, r0, c0, nullptr);
         PairState st = pair_state(cx.state, cx.lay, cx.caps, l);
         const PairHdr &h = *st.hdr;
         PairOut o;

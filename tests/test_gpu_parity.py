@@ -197,3 +197,26 @@ def test_reference_driver_linked_against_libmcx(golden, tmp_path):
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
         nd, ex = sam_diff(g["sam"][alg], out)
         assert nd == 0, ex
+
+
+@pytest.mark.parametrize("name", list(SETS))
+def test_alignment_profile_equals_reference(api, golden, tmp_path, name):
+    """The -vcf bookkeeping on the GPU (k_prof_*): counter planes and sparse tallies against the
+    reference's MappingRecordArr / InsertSeqMap / DeleteSeqMap / BreakPointMap / site lists."""
+    import torch
+    g = golden[name]
+    alg, prof, maps = g["prof"]
+    ix = api.Index(g["prefix"], device=0)
+    G = ix.genome_size
+    mp = api.Mapper(ix, alg=alg, max_batch_reads=1000)  # several batches: the duplicate cap spans them
+    planes = torch.zeros((10, G), dtype=torch.int32, device="cuda")
+    mp.profile_attach(planes.data_ptr())
+    mp.map_files(g["r1"], g["r2"], None)
+    mp.profile_finalize(planes.data_ptr())
+    got = planes.t().contiguous().to(torch.uint16 if hasattr(torch, "uint16") else torch.int16).cpu().numpy().astype(np.uint16)
+    want = np.frombuffer(open(prof, "rb").read(), dtype=np.uint16).reshape(-1, 10)
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, (bad[:5], got[bad[:5, 0]], want[bad[:5, 0]])
+    text = api.sparse_to_maps_text(mp.profile_sparse())
+    assert text == open(maps, encoding="latin-1").read()
+    mp.close(); ix.close()

@@ -53,3 +53,18 @@ def test_oracle_dp_vectors(oracle_lib):
         oracle_lib.mcxo_ksw2_extz(qc, len(qc), tc, len(tc), ctypes.byref(sc), ops, cap)
         assert sc.value == rec["ksw2_score"]
         assert ops.value.decode() == rec["ksw2_ops_rev"]
+
+
+@pytest.mark.parametrize("name", list(SETS))
+def test_oracle_profile_equals_reference(oracle_lib, golden, tmp_path, name):
+    """UpdateProfile / UpdateMultiHitCount restated: the per-position counters and the sparse maps
+    against what the reference's Mapping() left behind (oracle/_ref/mcref_tool P)."""
+    g = golden[name]
+    alg, prof, maps = g["prof"]
+    ix = oracle_lib.mcxo_index_load(g["prefix"].encode())
+    out = str(tmp_path / "p")
+    n = oracle_lib.mcxo_map_files_profile(ix, g["r1"].encode(), (g["r2"] or "").encode(), 0 if alg == "nw" else 1, out.encode())
+    oracle_lib.mcxo_index_free(ix)
+    assert n > 0
+    assert open(out + ".prof", "rb").read() == open(prof, "rb").read()
+    assert open(out + ".maps", "rb").read() == open(maps, "rb").read()
