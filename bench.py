@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--cpu-pairs", type=int, default=-1,
                     help="pairs of the CPU-baseline sample (0 = skip, -1 = about 20 s of work for this host's core count)")
     ap.add_argument("--repeats", type=int, default=2000, help="planted dispersed repeat families")
+    ap.add_argument("--vcf-reduce", type=int, default=-1,
+                    help="after the timed region: accumulate the -vcf alignment profile of one batch and sum it over the "
+                         "ranks with RCCL (1 = yes, 0 = no, -1 = only when more than one GPU)")
     return ap.parse_args()
 
 
@@ -179,11 +182,36 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        from mapcaller_amd import dist as mdist_
+        dt = mdist_.max_over_ranks(dt, dev)
     after = mapper.stats.as_dict()
     d = {k: after[k] - before[k] for k in after}
+
+    # ---- the one exchange of a -vcf run (not timed): profile of one batch, RCCL sum over the ranks -----
+    vcf = None
+    do_vcf = args.vcf_reduce == 1 or (args.vcf_reduce < 0 and world > 1)
+    if do_vcf:
+        try:
+            from mapcaller_amd import dist as mdist
+            G = index.genome_size
+            planes = torch.zeros((10, G), dtype=torch.int32, device=dev)
+            mapper.profile_attach(planes.data_ptr())
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step(n_steps - 1)
+            torch.cuda.synchronize()
+            t_acc = time.perf_counter() - t1
+            sparse = mapper.profile_sparse()
+            t2 = time.perf_counter()
+            planes, merged = mdist.reduce_profile(planes, sparse)
+            torch.cuda.synchronize()
+            t_red = time.perf_counter() - t2
+            mapper.profile_finalize(planes.data_ptr())
+            vcf = {"profile_batch_ms": round(1000 * t_acc, 2), "allreduce_ms": round(1000 * t_red, 2),
+                   "allreduce_gb": round(planes.numel() * 4 / 1e9, 2), "sparse_records": len(merged),
+                   "covered_positions": int((planes[0:4].sum(0) > 0).sum().item())}
+        except Exception as e:  # never lose the bench line to the optional section
+            vcf = {"error": str(e)[:300]}
 
     if rank == 0:
         total_reads = reads_per_step * args.steps * world
@@ -210,6 +238,8 @@ def main():
             "stage_ms_per_step": {k[3:]: round(d[k] / args.steps, 3) for k in d if k.startswith("ms_")},
             "tier1_pairs": d["tier1_pairs"], "replayed_pairs": d["replayed_pairs"],
         }
+        if vcf is not None:
+            out["vcf_reduce"] = vcf
         if sample is not None:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, index, sample)

@@ -1,0 +1,69 @@
+"""The N > 1 path on CPU: world_size 2 over gloo.  Shards partition the pairs on chunk
+boundaries, the profile reduce sums the planes and concatenates the sparse tallies, and the
+summed planes finalise to the reference's field widths."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mapcaller_amd import dist as mdist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    G = 1000
+    g = torch.Generator().manual_seed(100 + rank)
+    planes = torch.randint(0, 3000, (10, G), generator=g, dtype=torch.int32)
+    planes[6:10] += 40000  # strand depths near the 16-bit wrap
+    mine = planes.clone()
+    sparse = [("I", 10 * rank + k, "AC") for k in range(3)] + [("B", 7, "")]
+    planes, merged = mdist.reduce_profile(planes, sparse)
+    lo, hi = mdist.shard_pairs(12345, rank, world)
+    t = mdist.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    if rank == 0:
+        torch.save({"sum": planes, "mine": mine, "merged": merged, "t": t}, out)
+    # every rank checks its own shard bounds
+    assert lo % 100 == 0 and (hi % 100 == 0 or hi == 12345)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (lo, hi))
+    assert gathered[0][0] == 0 and gathered[-1][1] == 12345
+    for a, b in zip(gathered, gathered[1:]):
+        assert a[1] == b[0]
+    dist.destroy_process_group()
+
+
+def test_profile_reduce_and_sharding_world2(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = torch.load(out)
+    g1 = torch.Generator().manual_seed(101)
+    other = torch.randint(0, 3000, (10, 1000), generator=g1, dtype=torch.int32)
+    other[6:10] += 40000
+    want = r["mine"] + other
+    assert torch.equal(r["sum"], want)
+    fin = mdist.finalize_planes(want.clone(), max_dup=5)
+    assert int(fin[0:5].max()) <= 4095 and int(fin[5].max()) <= 5 and int(fin[6:10].max()) <= 0xFFFF
+    assert torch.equal(fin[6], (want[6] & 0xFFFF))
+    assert len(r["merged"]) == 8 and r["merged"][0] == ("I", 0, "AC") and r["merged"][4] == ("I", 10, "AC")
+    assert r["t"] == 2.0
+
+
+def test_shards_cover_everything_for_any_world():
+    for n in (0, 1, 99, 100, 101, 12345, 2_000_000):
+        for world in (1, 2, 3, 4, 8):
+            spans = [mdist.shard_pairs(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert all(lo % 100 == 0 for lo, _ in spans)
