@@ -137,7 +137,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("MCX_FORCE_DIST"):
         import torch.distributed as dist_
         dist = dist_
         dist.init_process_group("nccl", device_id=dev)
