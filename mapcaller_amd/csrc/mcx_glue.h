@@ -525,21 +525,35 @@ struct JobSink {
     uint32_t cap;
 };
 
-static inline MCX_HD uint32_t sink_reserve(const JobSink &s, uint32_t n)
+// size class of a DP problem: 0 = 16-lane groups (target <= 16, query <= 32), 1/2/3 = one wave
+// with 1 / 4 / 16 target columns per lane (target <= 64 / 256 / 1024); -1 = refused
+static inline MCX_HD int dp_class(int rLen, int gLen)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return atomicAdd(s.count, n);
-#else
-    uint32_t o = *s.count; *s.count += n; return o;
-#endif
+    if (gLen > 1024 || rLen > 2048) return -1;
+    if (gLen <= 16 && rLen <= 32) return 0;
+    return gLen <= 64 ? 1 : (gLen <= 256 ? 2 : 3);
 }
 
-static inline MCX_HD void stage_build(const Ctx &cx, int64_t pair, const ReadRef *rd, const JobSink &sink)
+// the k-th DP problem of a pair, from its local list (written by stage_build)
+static inline MCX_HD DpJob pair_job(const Ctx &cx, int64_t pair, int k)
+{
+    PairState st = pair_state(cx.state, cx.lay, cx.caps, pair);
+    const int32_t *jl = (const int32_t *)((const uint8_t *)st.hdr + cx.lay.off_jobs);
+    const Frag &x = st.frags[jl[2 * k]];
+    DpJob j;
+    j.pair = (uint32_t)pair; j.slot = (uint16_t)jl[2 * k + 1]; j.rev = x.gPos >= cx.ix.G ? 1 : 0;
+    j.rPos = x.rPos; j.rLen = x.rLen; j.gPos = x.gPos; j.gLen = x.gLen;
+    j.ops_off = x.ops_off; j.frag = jl[2 * k]; j.score = 0;
+    return j;
+}
+
+// returns the number of DP problems the pair needs (left in its local list)
+static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef *rd)
 {
     PairState st = pair_state(cx.state, cx.lay, cx.caps, pair);
     PairHdr &h = *st.hdr;
     h.n_frags = 0; h.n_ops = 0; h.n_jobs = 0;
-    if (h.flags & kOvAny) return;
+    if (h.flags & kOvAny) return 0;
     int nr = cx.pm.paired ? 2 : 1;
     if (cx.pm.paired) {
         if (h.n_paired == 0) { keep_top_scores(st.cands[0], h.n_cands[0]); keep_top_scores(st.cands[1], h.n_cands[1]); }
@@ -555,7 +569,7 @@ static inline MCX_HD void stage_build(const Ctx &cx, int64_t pair, const ReadRef
             Cand &c = cs[ci];
             c.n_frags = 0; c.frag_off = h.n_frags;
             if (c.score == 0) continue;
-            if (h.n_frags + 2 * c.count + 2 > cx.caps.frag_cap) { h.flags |= kOvFrags; return; }
+            if (h.n_frags + 2 * c.count + 2 > cx.caps.frag_cap) { h.flags |= kOvFrags; return 0; }
             Frag *f = st.frags + h.n_frags;
             int nf = build_frags(cx.ix, rd[s].rlen, st.hits[s] + c.first, c.count, f);
             if (nf < 0) { c.score = 0; continue; }
@@ -574,8 +588,8 @@ static inline MCX_HD void stage_build(const Ctx &cx, int64_t pair, const ReadRef
                         dp = mm > 1 && mm >= (int)(x.rLen * 0.2);
                     }
                     if (dp) {
-                        if (h.n_ops + x.rLen + x.gLen > cx.caps.ops_cap) { h.flags |= kOvOps; return; }
-                        if (nj >= cx.caps.job_cap) { h.flags |= kOvJobs; return; }
+                        if (h.n_ops + x.rLen + x.gLen > cx.caps.ops_cap) { h.flags |= kOvOps; return 0; }
+                        if (nj >= cx.caps.job_cap) { h.flags |= kOvJobs; return 0; }
                         x.kind = kDp; x.ops_off = h.n_ops; x.ops_len = 0;
                         h.n_ops += x.rLen + x.gLen;
                         jl[2 * nj] = h.n_frags + i; jl[2 * nj + 1] = s;
@@ -588,18 +602,7 @@ static inline MCX_HD void stage_build(const Ctx &cx, int64_t pair, const ReadRef
         }
     }
     h.n_jobs = nj;
-    if (nj > 0) {
-        uint32_t base = sink_reserve(sink, (uint32_t)nj);
-        for (int k = 0; k < nj; k++) {
-            if (base + k >= sink.cap) break; // host checks count > cap and re-runs with a larger list
-            const Frag &x = st.frags[jl[2 * k]];
-            DpJob j;
-            j.pair = (uint32_t)pair; j.slot = (uint16_t)jl[2 * k + 1]; j.rev = x.gPos >= cx.ix.G ? 1 : 0;
-            j.rPos = x.rPos; j.rLen = x.rLen; j.gPos = x.gPos; j.gLen = x.gLen;
-            j.ops_off = x.ops_off; j.frag = jl[2 * k]; j.score = 0;
-            sink.jobs[base + k] = j;
-        }
-    }
+    return nj;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -259,6 +259,22 @@ struct PairSel {             // which pairs a launch works on
 
 static __device__ __forceinline__ uint32_t sel_pair(const PairSel &s, uint32_t local) { return s.ids ? s.ids[local] : local; }
 
+// Reserves n slots of a work list for every lane of the wave with ONE atomic: an inclusive scan
+// over the wave, the last lane adds the total.  Must be reached by all 64 lanes (n = 0 for the
+// ones with nothing to append).  The lists' order never influences a result.
+static __device__ __forceinline__ uint32_t wave_reserve(uint32_t *counter, uint32_t n)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t incl = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    const uint32_t total = __shfl(incl, 63, 64);
+    uint32_t base = 0;
+    if (lane == 63 && total) base = atomicAdd(counter, total);
+    base = __shfl(base, 63, 64);
+    return base + incl - n;
+}
+
 static __device__ __forceinline__ void make_reads(const Ctx &cx, const ReadBatch &rb, uint32_t pair, ReadRef rd[2])
 {
     const int nr = cx.pm.paired ? 2 : 1;
@@ -282,22 +298,23 @@ __global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel,
 {
     const int nr = cx.pm.paired ? 2 : 1;
     const uint32_t lr = blockIdx.x * blockDim.x + threadIdx.x; // local read
-    if (lr >= sel.n * nr) return;
-    const uint32_t local = lr / nr, s = lr % nr;
-    const uint32_t pair = sel_pair(sel, local), r = pair * nr + s;
-    PairState st = pair_state(cx.state, cx.lay, cx.caps, local);
-    ReadRef rd;
-    rd.ascii = rb.bases + rb.off[r]; rd.rlen = (int)(rb.off[r + 1] - rb.off[r]); rd.flipped = (cx.pm.paired && s == 1) ? 1 : 0;
-    int64_t ext = 0, blocks = 0;
-    const int n = seed_read(cx.ix, rd, st.hits[s], cx.caps.hit_cap, ext, blocks);
-    st.hdr->n_hits[s] = n;
-    so.read_ext[r] = (uint32_t)ext; so.read_blocks[r] = (uint32_t)blocks;
-    const int keep = n <= cx.caps.hit_cap ? n : 0; // overflowing reads are re-run in the next tier
-    if (keep > 0) {
-        const uint32_t base = atomicAdd(so.n_tasks, (uint32_t)keep);
-        for (int i = 0; i < keep; i++)
-            if (base + i < so.task_cap) so.tasks[base + i] = make_uint2(lr, (uint32_t)i);
+    const bool live = lr < sel.n * nr;
+    int keep = 0;
+    if (live) {
+        const uint32_t local = lr / nr, s = lr % nr;
+        const uint32_t pair = sel_pair(sel, local), r = pair * nr + s;
+        PairState st = pair_state(cx.state, cx.lay, cx.caps, local);
+        ReadRef rd;
+        rd.ascii = rb.bases + rb.off[r]; rd.rlen = (int)(rb.off[r + 1] - rb.off[r]); rd.flipped = (cx.pm.paired && s == 1) ? 1 : 0;
+        int64_t ext = 0, blocks = 0;
+        const int n = seed_read(cx.ix, rd, st.hits[s], cx.caps.hit_cap, ext, blocks);
+        st.hdr->n_hits[s] = n;
+        so.read_ext[r] = (uint32_t)ext; so.read_blocks[r] = (uint32_t)blocks;
+        keep = n <= cx.caps.hit_cap ? n : 0; // overflowing reads are re-run in the next tier
     }
+    const uint32_t base = wave_reserve(so.n_tasks, (uint32_t)keep);
+    for (int i = 0; i < keep; i++)
+        if (base + i < so.task_cap) so.tasks[base + i] = make_uint2(lr, (uint32_t)i);
 }
 
 __global__ void __launch_bounds__(256) k_sa(Ctx cx, SeedOut so, int paired, uint32_t *lf_total)
@@ -319,16 +336,17 @@ struct RescueList { uint32_t *ids; uint32_t *n; uint32_t cap; };
 __global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl)
 {
     const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
-    if (local >= sel.n) return;
-    ReadRef rd[2];
-    make_reads(cx, rb, sel_pair(sel, local), rd);
-    PairState st = pair_state(cx.state, cx.lay, cx.caps, local);
-    st.hdr->flags = 0;
-    stage_cluster_pair(cx, local, rd, sel.est[local]);
-    if (cx.pm.paired && !(st.hdr->flags & kOvAny) && st.hdr->n_paired == 0) {
-        const uint32_t at = atomicAdd(rl.n, 1u);
-        if (at < rl.cap) rl.ids[at] = local;
+    uint32_t need = 0;
+    if (local < sel.n) {
+        ReadRef rd[2];
+        make_reads(cx, rb, sel_pair(sel, local), rd);
+        PairState st = pair_state(cx.state, cx.lay, cx.caps, local);
+        st.hdr->flags = 0;
+        stage_cluster_pair(cx, local, rd, sel.est[local]);
+        need = (cx.pm.paired && !(st.hdr->flags & kOvAny) && st.hdr->n_paired == 0) ? 1u : 0u;
     }
+    const uint32_t at = wave_reserve(rl.n, need);
+    if (need && at < rl.cap) rl.ids[at] = local;
 }
 
 __global__ void __launch_bounds__(64) k_rescue(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl)
@@ -349,35 +367,40 @@ __global__ void __launch_bounds__(64) k_rescue(Ctx cx, ReadBatch rb, PairSel sel
 
 struct JobSinks { JobSink s[4]; };
 
-__global__ void __launch_bounds__(256) k_build(Ctx cx, ReadBatch rb, PairSel sel, JobSinks sinks)
+// fragment lists + DP problems of every pair; the problems are appended to one list per size
+// class (mcx_glue.h dp_class) with one atomic per wave and class
+__global__ void __launch_bounds__(256) k_build(Ctx cx, ReadBatch rb, PairSel sel, JobSinks sinks, uint32_t *cells, uint32_t *unsupported)
 {
     const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
-    if (local >= sel.n) return;
-    ReadRef rd[2];
-    make_reads(cx, rb, sel_pair(sel, local), rd);
-    // jobs are emitted into one list here and split by size class below
-    stage_build(cx, local, rd, sinks.s[0]);
-}
-
-// list 0 keeps the small problems (16-lane groups); the others move to lists 1 / 2 / 3 by
-// target length (<= 64 / 256 / 1024 columns: 1 / 4 / 16 columns per lane of a full wave)
-__global__ void k_split_jobs(JobSinks sinks, uint32_t *unsupported)
-{
-    const uint32_t n = min(*sinks.s[0].count, sinks.s[0].cap);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        DpJob &j = sinks.s[0].jobs[i];
-        int cls = (j.gLen <= kDpSmallT && j.rLen <= kDpSmallQ) ? 0 : (j.gLen <= 64 ? 1 : (j.gLen <= 256 ? 2 : 3));
-        if (j.gLen > 1024 || j.rLen > 2048) { atomicAdd(unsupported, 1u); j.rLen = 0; continue; }
-        if (cls == 0) continue;
-        const uint32_t at = atomicAdd(sinks.s[cls].count, 1u);
-        if (at < sinks.s[cls].cap) sinks.s[cls].jobs[at] = j;
-        j.rLen = 0; // tombstone in list 0
+    int nj = 0;
+    if (local < sel.n) {
+        ReadRef rd[2];
+        make_reads(cx, rb, sel_pair(sel, local), rd);
+        nj = stage_build(cx, local, rd);
     }
+    uint32_t per_class[4] = {0, 0, 0, 0}, my_cells = 0, bad = 0;
+    for (int k = 0; k < nj; k++) {
+        const DpJob j = pair_job(cx, local, k);
+        const int c = dp_class(j.rLen, j.gLen);
+        if (c < 0) bad++; else { per_class[c]++; my_cells += (uint32_t)(j.rLen * j.gLen); }
+    }
+    uint32_t base[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) base[c] = wave_reserve(sinks.s[c].count, per_class[c]);
+    for (int k = 0; k < nj; k++) {
+        const DpJob j = pair_job(cx, local, k);
+        const int c = dp_class(j.rLen, j.gLen);
+        if (c < 0) continue;
+        const uint32_t at = base[c]++;
+        if (at < sinks.s[c].cap) sinks.s[c].jobs[at] = j;
+    }
+    for (int o = 32; o > 0; o >>= 1) { my_cells += __shfl_down(my_cells, o, 64); bad += __shfl_down(bad, o, 64); }
+    if ((threadIdx.x & 63) == 0) { if (my_cells) atomicAdd(cells, my_cells); if (bad) atomicAdd(unsupported, bad); }
 }
 
 template <int K>
 __global__ void __launch_bounds__(64) k_dp_sel(Ctx cx, JobSink sink, ReadBatch rb, PairSel sel, uint8_t *scratch,
-                                               uint64_t scratch_stride, uint32_t *cells)
+                                               uint64_t scratch_stride)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[kDpLdsSeq + kDpLdsDir];
     uint8_t *spill = scratch + (uint64_t)blockIdx.x * scratch_stride;
@@ -386,7 +409,6 @@ __global__ void __launch_bounds__(64) k_dp_sel(Ctx cx, JobSink sink, ReadBatch r
     const uint32_t n = min(*sink.count, sink.cap);
     for (uint32_t jb = blockIdx.x; jb < n; jb += gridDim.x) {
         const DpJob job = sink.jobs[jb];
-        if (job.rLen == 0) continue; // moved to another size class (block-uniform)
         const uint32_t read = sel_pair(sel, job.pair) * nr + job.slot;
         ReadRef rd;
         rd.ascii = rb.bases + rb.off[read]; rd.rlen = (int)(rb.off[read + 1] - rb.off[read]); rd.flipped = (cx.pm.paired && job.slot == 1) ? 1 : 0;
@@ -404,14 +426,13 @@ __global__ void __launch_bounds__(64) k_dp_sel(Ctx cx, JobSink sink, ReadBatch r
             f.ops_off = job.ops_off + w;
             f.ops_len = job.rLen + job.gLen - w;
             sink.jobs[jb].score = score;
-            if (cells) atomicAdd(cells, (uint32_t)(job.rLen * job.gLen));
         }
         __syncthreads();
     }
 }
 
 // four small problems per wave, sixteen per block; each 16-lane group owns 800 bytes of LDS
-__global__ void __launch_bounds__(256) k_dp_small(Ctx cx, JobSink sink, ReadBatch rb, PairSel sel, uint32_t *cells)
+__global__ void __launch_bounds__(256) k_dp_small(Ctx cx, JobSink sink, ReadBatch rb, PairSel sel)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[16 * kDpSmallLds];
     const int nr = cx.pm.paired ? 2 : 1;
@@ -420,7 +441,6 @@ __global__ void __launch_bounds__(256) k_dp_small(Ctx cx, JobSink sink, ReadBatc
     const uint32_t n = min(*sink.count, sink.cap);
     for (uint32_t jb = blockIdx.x * 16 + group; jb < n; jb += gridDim.x * 16) {
         const DpJob job = sink.jobs[jb];
-        if (job.rLen == 0) continue; // moved to a larger size class (uniform over the group)
         const uint32_t read = sel_pair(sel, job.pair) * nr + job.slot;
         ReadRef rd;
         rd.ascii = rb.bases + rb.off[read]; rd.rlen = (int)(rb.off[read + 1] - rb.off[read]); rd.flipped = (cx.pm.paired && job.slot == 1) ? 1 : 0;
@@ -436,7 +456,6 @@ __global__ void __launch_bounds__(256) k_dp_small(Ctx cx, JobSink sink, ReadBatc
             f.ops_off = job.ops_off + w;
             f.ops_len = job.rLen + job.gLen - w;
             sink.jobs[jb].score = score;
-            if (cells) atomicAdd(cells, (uint32_t)(job.rLen * job.gLen));
         }
         dp_sync<16>();
     }
@@ -658,13 +677,12 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
     if (paired) k_rescue<<<8192, 64, 0, s>>>(cx, rb, sel, rl);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
-    k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks);
-    k_split_jobs<<<1024, 256, 0, s>>>(sinks, c->d_cnt + CNT_UNSUP);
+    k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, c->d_cnt + CNT_CELLS, c->d_cnt + CNT_UNSUP);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
-    k_dp_small<<<2560, 256, 0, s>>>(cx, sinks.s[0], rb, sel, c->d_cnt + CNT_CELLS);
-    k_dp_sel<1><<<c->dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, c->d_dp_scratch[0], c->dp_stride[0], c->d_cnt + CNT_CELLS);
-    k_dp_sel<4><<<c->dp_blocks[1], 64, 0, s>>>(cx, sinks.s[2], rb, sel, c->d_dp_scratch[1], c->dp_stride[1], c->d_cnt + CNT_CELLS);
-    k_dp_sel<16><<<c->dp_blocks[2], 64, 0, s>>>(cx, sinks.s[3], rb, sel, c->d_dp_scratch[2], c->dp_stride[2], c->d_cnt + CNT_CELLS);
+    k_dp_small<<<2560, 256, 0, s>>>(cx, sinks.s[0], rb, sel);
+    k_dp_sel<1><<<c->dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, c->d_dp_scratch[0], c->dp_stride[0]);
+    k_dp_sel<4><<<c->dp_blocks[1], 64, 0, s>>>(cx, sinks.s[2], rb, sel, c->d_dp_scratch[1], c->dp_stride[1]);
+    k_dp_sel<16><<<c->dp_blocks[2], 64, 0, s>>>(cx, sinks.s[3], rb, sel, c->d_dp_scratch[2], c->dp_stride[2]);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
     k_finish<<<pb, 256, 0, s>>>(cx, rb, sel, d_recs, d_cig, c->d_pout, c->d_ov, c->d_cnt + CNT_OV, c->ov_cap);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
@@ -678,7 +696,7 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     if (n[CNT_UNSUP]) return fail(MCX_ERR_UNSUPPORTED, "a gapped fragment exceeds 2048 x 1024 cells per side");
     if (stats) {
         stats->sa_hits += n[CNT_TASKS];
-        stats->dp_jobs += n[CNT_JOB0]; // list 0 holds every job before the split
+        stats->dp_jobs += (int64_t)n[CNT_JOB0] + n[CNT_JOB1] + n[CNT_JOB2] + n[CNT_JOB3];
         stats->dp_cells += n[CNT_CELLS];
         if (timing) {
             float ms[8];

@@ -72,9 +72,7 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
     cx.ix = e.view; cx.pm = e.pm; cx.pm.paired = b.paired; cx.caps = e.caps[tier]; cx.lay = e.lay[tier];
     cx.detail = nullptr; cx.dlay = make_detail_layout(256);
     cx.state = state.data(); cx.mapq_tab = e.mapq.data(); cx.mapq_rows = e.mapq_rows;
-    std::vector<DpJob> jobs((size_t)n * 64 + 1024);
-    uint32_t n_jobs = 0;
-    JobSink sink; sink.jobs = jobs.data(); sink.count = &n_jobs; sink.cap = (uint32_t)jobs.size();
+    std::vector<DpJob> jobs;
     std::vector<uint32_t> kq(4096), kg(e.caps[tier].kmer_cap + 16);
     std::vector<uint32_t> ov;
     // k_seed + k_sa
@@ -109,8 +107,14 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
     for (uint32_t l = 0; l < n; l++) {
         ReadRef rd[2];
         make_reads(b, ids[l], rd);
-        stage_build(cx, l, rd, sink);
+        const int nj = stage_build(cx, l, rd);
+        for (int k = 0; k < nj; k++) {
+            DpJob j = pair_job(cx, l, k);
+            if (dp_class(j.rLen, j.gLen) < 0) { fprintf(stderr, "hostemu: unsupported DP size\n"); continue; }
+            jobs.push_back(j);
+        }
     }
+    const uint32_t n_jobs = (uint32_t)jobs.size();
     if (getenv("MCX_EMU_DEBUG")) {
         for (uint32_t l = 0; l < n; l++) {
             PairState st = pair_state(cx.state, cx.lay, cx.caps, l);
