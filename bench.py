@@ -215,9 +215,10 @@ def main():
 
     if rank == 0:
         total_reads = reads_per_step * args.steps * world
-        # dominant kernel: k_seed.  Algorithmic bytes per launch (seeding term):
-        # 64 B per FM block the walk touches + the read's own bases; both counted by the kernel.
-        seed_bytes = 64.0 * d["fm_blocks"] + float(d["reads"]) * args.rlen
+        # dominant kernel: k_seed.  Algorithmic bytes per launch = SURVEY.md §8d's seeding term,
+        # 64 * 1.107 * E + rlen per read, with E (FM extension steps) counted by the kernel.  The
+        # blocks the kernel really fetches are fewer (k-mer jump table) and reported beside it.
+        seed_bytes = 64.0 * 1.107 * d["fm_ext_steps"] + float(d["reads"]) * args.rlen
         seed_ms = d["ms_seed"] / max(args.steps, 1)
         achieved = seed_bytes / args.steps / (seed_ms * 1e-3) / 1e9 if seed_ms > 0 else 0.0
         out = {

@@ -173,6 +173,39 @@ static inline MCX_HD int end_slot(const IndexView &ix, int64_t gPos)
     return lo < ix.n_ends ? lo : -1;
 }
 
+// K-mer jump table (a derived, HBM-resident cache; the search results are unchanged): entry i is
+// the bi-interval BWT_Search holds after consuming the K bases spelled by i (first base most
+// significant), or x2 = 0 when some extension inside the K-mer comes up empty.  A search that
+// starts on a K-mer present in the genome replaces its first K-1 extension steps — the ones with
+// wide intervals, two block fetches each — by one 32-byte fetch.
+static inline MCX_HD bool ktab_lookup(const IndexView &ix, uint32_t idx, uint64_t &x0, uint64_t &x1, uint64_t &x2)
+{
+    const U4 *p = (const U4 *)ix.ktab + (uint64_t)idx * 2;
+    const U4 a = p[0], b = p[1];
+    x0 = (uint64_t)a.x | ((uint64_t)a.y << 32);
+    x1 = (uint64_t)a.z | ((uint64_t)a.w << 32);
+    x2 = (uint64_t)b.x | ((uint64_t)b.y << 32);
+    return x2 != 0;
+}
+
+// what the table holds for one K-mer: BWT_Search's first K-1 extensions (bwt_search.cpp:128-151)
+static inline MCX_HD void ktab_entry(const IndexView &ix, uint32_t idx, int K, uint64_t &x0, uint64_t &x1, uint64_t &x2)
+{
+    int c = (int)((idx >> (2 * (K - 1))) & 3);
+    x0 = ix.L2[c] + 1; x1 = ix.L2[3 - c] + 1; x2 = ix.L2[c + 1] - ix.L2[c];
+    for (int j = 1; j < K && x2 != 0; j++) {
+        c = (int)((idx >> (2 * (K - 1 - j))) & 3);
+        uint64_t tk[4], tl[4];
+        int nb;
+        fm_2occ4(ix, x1 - 1, x1 - 1 + x2, tk, tl, nb);
+        const int b = 3 - c;
+        const uint64_t n2 = tl[b] - tk[b];
+        uint64_t n0 = x0 + ((x1 <= ix.primary && x1 + x2 - 1 >= ix.primary) ? 1 : 0);
+        for (int bb = 3; bb > b; bb--) n0 += tl[bb] - tk[bb];
+        x0 = n0; x1 = ix.L2[b] + 1 + tk[b]; x2 = n2;
+    }
+}
+
 // Greedy left-to-right seeding of one read: IdentifySimplePairs (ReadMapping.cpp:125-158)
 // driving BWT_Search (bwt_search.cpp:121-164), flattened to one block fetch per iteration.
 // Hits are written as BWT rows (x0 + i); the SA kernel turns them into text positions.
@@ -194,9 +227,19 @@ static inline MCX_HD int seed_read(const IndexView &ix, const ReadRef &rd, Hit *
             int c = cursor_code(rd, cur, p);
             if (c > 3) { p++; continue; }
             start = p;
-            x0 = ix.L2[c] + 1; x1 = ix.L2[3 - c] + 1; x2 = ix.L2[c + 1] - ix.L2[c];
+            bool jumped = false;
+            if (ix.ktab && p + ix.ktab_k <= rlen) {
+                uint32_t idx = (uint32_t)c;
+                bool clean = true;
+                for (int j = 1; j < ix.ktab_k; j++) {
+                    const int cj = cursor_code(rd, cur, p + j);
+                    if (cj > 3) { clean = false; break; }
+                    idx = (idx << 2) | (uint32_t)cj;
+                }
+                if (clean && ktab_lookup(ix, idx, x0, x1, x2)) { p += ix.ktab_k; jumped = true; }
+            }
+            if (!jumped) { x0 = ix.L2[c] + 1; x1 = ix.L2[3 - c] + 1; x2 = ix.L2[c + 1] - ix.L2[c]; p++; }
             active = true;
-            p++;
         }
         bool end = p >= rlen;
         int c = end ? 4 : cursor_code(rd, cur, p);

@@ -60,7 +60,7 @@ struct mcx_index {
     HostIndex host;
     int device = 0;
     void *d_bwt = nullptr, *d_sa = nullptr, *d_sa_full = nullptr, *d_pac = nullptr;
-    void *d_end_pos = nullptr, *d_end_chr = nullptr, *d_chr_fwd = nullptr;
+    void *d_end_pos = nullptr, *d_end_chr = nullptr, *d_chr_fwd = nullptr, *d_ktab = nullptr;
     int64_t hbm_bytes = 0;
     uint64_t n_bwt_words = 0, n_sa = 0; // set for indexes built in HBM (mcx_index_from_codes)
 };
@@ -84,6 +84,36 @@ __global__ void k_expand_sa(IndexView ix, uint64_t n_sa, uint64_t *full)
     }
 }
 
+__global__ void k_build_ktab(IndexView ix, int K, uint32_t *tab)
+{
+    const uint64_t n = 1ull << (2 * K);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t x0, x1, x2;
+        ktab_entry(ix, (uint32_t)i, K, x0, x1, x2);
+        U4 a, b;
+        a.x = (uint32_t)x0; a.y = (uint32_t)(x0 >> 32); a.z = (uint32_t)x1; a.w = (uint32_t)(x1 >> 32);
+        b.x = (uint32_t)x2; b.y = (uint32_t)(x2 >> 32); b.z = 0; b.w = 0;
+        if (x2 == 0) { a.x = a.y = a.z = a.w = 0; }
+        ((U4 *)tab)[2 * i] = a; ((U4 *)tab)[2 * i + 1] = b;
+    }
+}
+
+// the 12-mer jump table of the seeding walk (mcx_fm.h): 16.7 M entries, 512 MB
+static int build_ktab(mcx_index *ix)
+{
+    const int K = 12;
+    const size_t bytes = (size_t)32 << (2 * K);
+    hipError_t e = hipMalloc(&ix->d_ktab, bytes);
+    if (e != hipSuccess) { g_err = std::string("hipMalloc(ktab): ") + hipGetErrorString(e); return MCX_ERR_DEVICE; }
+    ix->view.ktab = nullptr; ix->view.ktab_k = K;
+    k_build_ktab<<<4096, 256>>>(ix->view, K, (uint32_t *)ix->d_ktab);
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) { g_err = std::string("k_build_ktab: ") + hipGetErrorString(e); return MCX_ERR_DEVICE; }
+    ix->view.ktab = (const uint32_t *)ix->d_ktab;
+    ix->hbm_bytes += (int64_t)bytes;
+    return 0;
+}
+
 static int upload(void **dst, const void *src, size_t bytes, size_t pad, int64_t &acc)
 {
     HIP_TRY(hipMalloc(dst, bytes + pad));
@@ -104,7 +134,7 @@ static int index_to_device(mcx_index *ix, int full_sa)
     if ((rc = upload(&ix->d_end_chr, h.end_chr.data(), h.end_chr.size() * 4, 0, ix->hbm_bytes))) return rc;
     if ((rc = upload(&ix->d_chr_fwd, h.chr_fwd.data(), h.chr_fwd.size() * 8, 0, ix->hbm_bytes))) return rc;
     IndexView &v = ix->view;
-    v.bwt = (const uint32_t *)ix->d_bwt; v.sa = (const uint64_t *)ix->d_sa; v.sa_full = nullptr;
+    v.bwt = (const uint32_t *)ix->d_bwt; v.sa = (const uint64_t *)ix->d_sa; v.sa_full = nullptr; v.ktab = nullptr; v.ktab_k = 0;
     v.pac = (const uint8_t *)ix->d_pac;
     v.end_pos = (const int64_t *)ix->d_end_pos; v.end_chr = (const int32_t *)ix->d_end_chr;
     v.chr_fwd = (const int64_t *)ix->d_chr_fwd;
@@ -121,7 +151,7 @@ static int index_to_device(mcx_index *ix, int full_sa)
         HIP_TRY(hipDeviceSynchronize());
         v.sa_full = (const uint64_t *)ix->d_sa_full;
     }
-    return 0;
+    return build_ktab(ix);
 }
 
 extern "C" int mcx_index_load(const char *prefix, int device, int full_sa, mcx_index **out)
@@ -181,13 +211,14 @@ extern "C" int mcx_index_from_codes(const uint8_t *d_codes, int32_t n_chr, const
     if ((rc = upload(&ix->d_chr_fwd, h.chr_fwd.data(), h.chr_fwd.size() * 8, 0, acc))) return rc;
     ix->hbm_bytes += acc + G / 4 + 32;
     IndexView &v = ix->view;
-    v.bwt = (const uint32_t *)ix->d_bwt; v.sa = (const uint64_t *)ix->d_sa; v.sa_full = (const uint64_t *)ix->d_sa_full;
+    v.bwt = (const uint32_t *)ix->d_bwt; v.sa = (const uint64_t *)ix->d_sa; v.sa_full = (const uint64_t *)ix->d_sa_full; v.ktab = nullptr; v.ktab_k = 0;
     v.pac = (const uint8_t *)ix->d_pac;
     v.end_pos = (const int64_t *)ix->d_end_pos; v.end_chr = (const int32_t *)ix->d_end_chr; v.chr_fwd = (const int64_t *)ix->d_chr_fwd;
     v.primary = h.primary; for (int i = 0; i < 5; i++) v.L2[i] = h.L2[i];
     v.seq_len = h.seq_len; v.G = h.G; v.G2 = 2 * h.G;
     v.n_ends = (int32_t)h.end_pos.size(); v.n_chr = (int32_t)h.chr_len.size(); v.sa_intv = 32;
     HIP_TRY(hipDeviceSynchronize());
+    if ((rc = build_ktab(ix))) return rc;
     *out = ix;
     return 0;
 }
@@ -238,7 +269,7 @@ extern "C" int mcx_index_save(const mcx_index *ix, const char *prefix)
 extern "C" void mcx_index_free(mcx_index *ix)
 {
     if (!ix) return;
-    void *p[] = {ix->d_bwt, ix->d_sa, ix->d_sa_full, ix->d_pac, ix->d_end_pos, ix->d_end_chr, ix->d_chr_fwd};
+    void *p[] = {ix->d_bwt, ix->d_sa, ix->d_sa_full, ix->d_pac, ix->d_end_pos, ix->d_end_chr, ix->d_chr_fwd, ix->d_ktab};
     for (void *q : p) if (q) (void)hipFree(q);
     delete ix;
 }
@@ -273,6 +304,21 @@ static __device__ __forceinline__ uint32_t wave_reserve(uint32_t *counter, uint3
     if (lane == 63 && total) base = atomicAdd(counter, total);
     base = __shfl(base, 63, 64);
     return base + incl - n;
+}
+
+// The chromosome tables (PosChrIdMap as sorted arrays) are binary-searched several times per
+// pair; each probe is a dependent load.  Blocks copy them to LDS once (when they fit) and the
+// per-pair code then searches LDS through the same pointers.
+constexpr int kLdsEnds = 1024;
+struct EndsLds { int64_t pos[kLdsEnds]; int32_t chr[kLdsEnds]; };
+
+static __device__ __forceinline__ void stage_ends(IndexView &ix, EndsLds &l)
+{
+    if (ix.n_ends <= kLdsEnds) { // uniform over the grid
+        for (int i = threadIdx.x; i < ix.n_ends; i += blockDim.x) { l.pos[i] = ix.end_pos[i]; l.chr[i] = ix.end_chr[i]; }
+        __syncthreads();
+        ix.end_pos = l.pos; ix.end_chr = l.chr;
+    }
 }
 
 static __device__ __forceinline__ void make_reads(const Ctx &cx, const ReadBatch &rb, uint32_t pair, ReadRef rd[2])
@@ -335,6 +381,8 @@ struct RescueList { uint32_t *ids; uint32_t *n; uint32_t cap; };
 
 __global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl)
 {
+    __shared__ EndsLds ends;
+    stage_ends(cx.ix, ends);
     const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t need = 0;
     if (local < sel.n) {
@@ -371,6 +419,8 @@ struct JobSinks { JobSink s[4]; };
 // class (mcx_glue.h dp_class) with one atomic per wave and class
 __global__ void __launch_bounds__(256) k_build(Ctx cx, ReadBatch rb, PairSel sel, JobSinks sinks, uint32_t *cells, uint32_t *unsupported)
 {
+    __shared__ EndsLds ends;
+    stage_ends(cx.ix, ends);
     const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
     int nj = 0;
     if (local < sel.n) {
@@ -464,6 +514,8 @@ __global__ void __launch_bounds__(256) k_dp_small(Ctx cx, JobSink sink, ReadBatc
 __global__ void __launch_bounds__(256) k_finish(Ctx cx, ReadBatch rb, PairSel sel, AlnRec *recs, uint32_t *cigars,
                                                 PairOut *pout, uint32_t *ov_ids, uint32_t *n_ov, uint32_t ov_cap)
 {
+    __shared__ EndsLds ends;
+    stage_ends(cx.ix, ends);
     const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
     if (local >= sel.n) return;
     const uint32_t pair = sel_pair(sel, local);

@@ -39,6 +39,8 @@ struct IndexView {
     const int64_t *end_pos;  // sorted chromosome end positions in [0,2G): PosChrIdMap keys
     const int32_t *end_chr;  // chromosome id of each end
     const int64_t *chr_fwd;  // FowardLocation per chromosome
+    const uint32_t *ktab;    // optional: bi-interval of every ktab_k-mer (32 B each: x0, x1, x2, pad), x2 = 0 if absent
+    int32_t ktab_k;
     uint64_t primary, L2[5], seq_len;
     int64_t G, G2;
     int32_t n_ends, n_chr, sa_intv;

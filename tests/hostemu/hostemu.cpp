@@ -26,6 +26,7 @@ struct Emu {
     IndexView view;
     Params pm;
     std::vector<uint8_t> mapq;
+    std::vector<uint32_t> ktab; // the seeding walk's K-mer jump table, here with K = 7
     int mapq_rows = 0;
     Caps caps[2];
     Layout lay[2];
@@ -40,6 +41,18 @@ static void set_view(Emu &e)
     v.primary = h.primary; for (int i = 0; i < 5; i++) v.L2[i] = h.L2[i];
     v.seq_len = h.seq_len; v.G = h.G; v.G2 = 2 * h.G;
     v.n_ends = (int)h.end_pos.size(); v.n_chr = (int)h.chr_len.size(); v.sa_intv = h.sa_intv;
+    v.ktab = nullptr; v.ktab_k = 0;
+    const int K = 7;
+    e.ktab.assign((size_t)8 << (2 * K), 0);
+    for (uint32_t i = 0; i < (1u << (2 * K)); i++) {
+        uint64_t x0, x1, x2;
+        ktab_entry(v, i, K, x0, x1, x2);
+        if (x2 == 0) continue;
+        uint32_t *w = e.ktab.data() + (size_t)i * 8;
+        w[0] = (uint32_t)x0; w[1] = (uint32_t)(x0 >> 32); w[2] = (uint32_t)x1; w[3] = (uint32_t)(x1 >> 32);
+        w[4] = (uint32_t)x2; w[5] = (uint32_t)(x2 >> 32);
+    }
+    v.ktab = e.ktab.data(); v.ktab_k = K;
 }
 
 struct Batch {
