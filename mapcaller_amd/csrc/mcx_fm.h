@@ -32,16 +32,23 @@ static inline MCX_HD void fm_load_block(const uint32_t *bwt, uint64_t blk, FmBlo
     b.w[4] = e.x; b.w[5] = e.y; b.w[6] = e.z; b.w[7] = e.w;
 }
 
+// keep-mask of word j for a count over the first n (1..128) symbols: words before the one that
+// holds symbol n-1 are kept whole, that word keeps its top `rem` symbols, later words nothing
+static inline MCX_HD uint32_t fm_word_mask(int j, int q, uint32_t last_mask)
+{
+    return j < q ? 0x55555555u : (j == q ? last_mask : 0u);
+}
+
 // occurrences of each base among the first n (1..128) symbols of the block, added to occ[]
 static inline MCX_HD void fm_count4(const FmBlock &b, int n, uint64_t cnt[4])
 {
+    const int q = (n - 1) >> 4, rem = ((n - 1) & 15) + 1;
+    const uint32_t last_mask = 0x55555555u & (0xFFFFFFFFu << (32 - 2 * rem));
     uint32_t t = 0, ct = 0, gt = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        int m = n - 16 * j;
-        m = m < 0 ? 0 : (m > 16 ? 16 : m);
-        uint32_t mask = 0x55555555u & (uint32_t)(~((1ull << (32 - 2 * m)) - 1));
-        uint32_t lo = b.w[j] & mask, hi = (b.w[j] >> 1) & mask;
+        const uint32_t mask = fm_word_mask(j, q, last_mask);
+        const uint32_t lo = b.w[j] & mask, hi = (b.w[j] >> 1) & mask;
         t += (uint32_t)__builtin_popcount(hi & lo);
         ct += (uint32_t)__builtin_popcount(lo);
         gt += (uint32_t)__builtin_popcount(hi);
@@ -55,14 +62,14 @@ static inline MCX_HD void fm_count4(const FmBlock &b, int n, uint64_t cnt[4])
 // occurrences of base c among the first n symbols (bwt_occ, bwt_search.cpp:25-47)
 static inline MCX_HD uint64_t fm_count1(const FmBlock &b, int n, int c)
 {
+    const int q = (n - 1) >> 4, rem = ((n - 1) & 15) + 1;
+    const uint32_t last_mask = 0x55555555u & (0xFFFFFFFFu << (32 - 2 * rem));
     uint32_t s = 0;
     const uint32_t xlo = (c & 1) ? 0u : 0xFFFFFFFFu, xhi = (c & 2) ? 0u : 0xFFFFFFFFu;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        int m = n - 16 * j;
-        m = m < 0 ? 0 : (m > 16 ? 16 : m);
-        uint32_t mask = 0x55555555u & (uint32_t)(~((1ull << (32 - 2 * m)) - 1));
-        uint32_t lo = b.w[j] ^ xlo, hi = (b.w[j] >> 1) ^ xhi;
+        const uint32_t mask = fm_word_mask(j, q, last_mask);
+        const uint32_t lo = b.w[j] ^ xlo, hi = (b.w[j] >> 1) ^ xhi;
         s += (uint32_t)__builtin_popcount(lo & hi & mask);
     }
     return b.occ[c] + s;
@@ -109,13 +116,12 @@ static inline MCX_HD uint64_t fm_sa(const IndexView &ix, uint64_t k, int &lf_ste
 // ASCII -> 0..4 (nst_nt4_table, BWT_Index/bntseq.c:40-57)
 static inline MCX_HD int nt4_code(uint8_t ch)
 {
-    switch (ch) {
-    case 'A': case 'a': return 0;
-    case 'C': case 'c': return 1;
-    case 'G': case 'g': return 2;
-    case 'T': case 't': return 3;
-    default: return 4;
-    }
+    // branch-free: fold case, test membership in {A,C,G,T} with a bit mask over (letter - 'A'),
+    // and hash the letter: (c >> 1) & 3 gives A0 C1 T2 G3, the xor swaps the last two
+    const unsigned c = ch & 0xDFu, d = c - 0x41u;
+    const unsigned member = d < 20u ? ((0x80045u >> d) & 1u) : 0u; // bits 0 (A), 2 (C), 6 (G), 19 (T)
+    const unsigned h = (c >> 1) & 3u;
+    return member ? (int)(h ^ (h >> 1)) : 4;
 }
 
 // One read as the kernels see it: the ASCII bases as handed over, and whether it is mate 2 of a
