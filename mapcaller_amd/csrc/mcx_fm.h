@@ -212,11 +212,22 @@ static inline MCX_HD void ktab_entry(const IndexView &ix, uint32_t idx, int K, u
     }
 }
 
+// set in Hit.len by seed_read for hits whose text position is already known (cleared by the caller
+// when it builds the SA task list)
+constexpr int32_t kHitResolved = 1 << 30;
+
 // Greedy left-to-right seeding of one read: IdentifySimplePairs (ReadMapping.cpp:125-158)
 // driving BWT_Search (bwt_search.cpp:121-164), flattened to one block fetch per iteration.
 // Hits are written as BWT rows (x0 + i); the SA kernel turns them into text positions.
 // Returns the number of hits the read produced (may exceed cap: overflow, nothing lost yet
 // because the pair is then re-run in the next tier).
+//
+// Once the interval has narrowed to a single suffix (x2 == 1) the pattern has exactly one
+// occurrence in the text, so "can it be extended by base c" is "is the next text base c": the
+// suffix is resolved to its text position once (one suffix-array fetch) and the rest of the
+// search is a direct comparison against the 2-bit genome — same length, same position, a few
+// instructions per base instead of a block fetch and a rank computation.  The hit then needs no
+// SA task (kHitResolved).
 static inline MCX_HD int seed_read(const IndexView &ix, const ReadRef &rd, Hit *hits, int cap,
                                    int64_t &ext_steps, int64_t &blocks)
 {
@@ -225,7 +236,8 @@ static inline MCX_HD int seed_read(const IndexView &ix, const ReadRef &rd, Hit *
     int n_hits = 0;
     const int stop = rlen - kMinSeedLength;
     int p = 0, start = 0;
-    bool active = false;
+    bool active = false, direct = false;
+    int64_t tpos = 0;
     uint64_t x0 = 0, x1 = 0, x2 = 0;
     for (;;) {
         if (!active) {
@@ -245,12 +257,16 @@ static inline MCX_HD int seed_read(const IndexView &ix, const ReadRef &rd, Hit *
                 if (clean && ktab_lookup(ix, idx, x0, x1, x2)) { p += ix.ktab_k; jumped = true; }
             }
             if (!jumped) { x0 = ix.L2[c] + 1; x1 = ix.L2[3 - c] + 1; x2 = ix.L2[c + 1] - ix.L2[c]; p++; }
-            active = true;
+            active = true; direct = false;
         }
         bool end = p >= rlen;
         int c = end ? 4 : cursor_code(rd, cur, p);
         if (c > 3) end = true;
-        if (!end) {
+        if (!end && x2 == 1 && !direct) { int lf = 0; tpos = (int64_t)fm_sa(ix, x0, lf); direct = true; }
+        if (!end && direct) {
+            const int64_t j = tpos + (p - start);
+            if (j >= (int64_t)ix.seq_len || ref_code(ix, j) != c) end = true; else p++;
+        } else if (!end) {
             uint64_t tk[4], tl[4];
             int nb;
             fm_2occ4(ix, x1 - 1, x1 - 1 + x2, tk, tl, nb);
@@ -270,7 +286,10 @@ static inline MCX_HD int seed_read(const IndexView &ix, const ReadRef &rd, Hit *
             int len = p - start;
             ext_steps += len;
             if (len >= kMinSeedLength && x2 <= (uint64_t)kOccThr) {
-                for (uint64_t i = 0; i < x2; i++) {
+                if (direct) {
+                    if (n_hits < cap) { Hit h; h.gPos = tpos; h.rPos = start; h.len = len | kHitResolved; hits[n_hits] = h; }
+                    n_hits++;
+                } else for (uint64_t i = 0; i < x2; i++) {
                     if (n_hits < cap) { Hit h; h.gPos = (int64_t)(x0 + i); h.rPos = start; h.len = len; hits[n_hits] = h; }
                     n_hits++;
                 }

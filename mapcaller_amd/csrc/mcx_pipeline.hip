@@ -358,9 +358,20 @@ __global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel,
         so.read_ext[r] = (uint32_t)ext; so.read_blocks[r] = (uint32_t)blocks;
         keep = n <= cx.caps.hit_cap ? n : 0; // overflowing reads are re-run in the next tier
     }
-    const uint32_t base = wave_reserve(so.n_tasks, (uint32_t)keep);
-    for (int i = 0; i < keep; i++)
-        if (base + i < so.task_cap) so.tasks[base + i] = make_uint2(lr, (uint32_t)i);
+    // SA tasks only for the hits that are still BWT rows; the others carry their text position
+    Hit *mine = nullptr;
+    int todo = 0;
+    if (keep > 0) {
+        PairState st = pair_state(cx.state, cx.lay, cx.caps, lr / nr);
+        mine = st.hits[lr % nr];
+        for (int i = 0; i < keep; i++) if (!(mine[i].len & kHitResolved)) todo++;
+    }
+    uint32_t at = wave_reserve(so.n_tasks, (uint32_t)todo);
+    for (int i = 0; i < keep; i++) {
+        if (mine[i].len & kHitResolved) { mine[i].len &= ~kHitResolved; continue; }
+        if (at < so.task_cap) so.tasks[at] = make_uint2(lr, (uint32_t)i);
+        at++;
+    }
 }
 
 __global__ void __launch_bounds__(256) k_sa(Ctx cx, SeedOut so, int paired, uint32_t *lf_total)

@@ -100,7 +100,13 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
             st.hdr->n_hits[s] = nh;
             if (stats) { stats[3] += ext; stats[8] += blocks; }
             int keep = nh <= cx.caps.hit_cap ? nh : 0;
-            for (int i = 0; i < keep; i++) { int lf = 0; st.hits[s][i].gPos = (int64_t)fm_sa(cx.ix, (uint64_t)st.hits[s][i].gPos, lf); if (stats) { stats[4]++; stats[5] += lf; } }
+            for (int i = 0; i < keep; i++) {
+                Hit &hh = st.hits[s][i];
+                if (hh.len & kHitResolved) { hh.len &= ~kHitResolved; if (stats) stats[4]++; continue; }
+                int lf = 0;
+                hh.gPos = (int64_t)fm_sa(cx.ix, (uint64_t)hh.gPos, lf);
+                if (stats) { stats[4]++; stats[5] += lf; }
+            }
         }
     }
     // k_cluster, k_rescue, k_build
