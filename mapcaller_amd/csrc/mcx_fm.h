@@ -168,6 +168,26 @@ static inline MCX_HD int ref_code(const IndexView &ix, int64_t p)
     return rev ? 3 - b : b;
 }
 
+// sequential reader of RefSequence for the direct-comparison phase of the seeding walk: keeps the
+// aligned 16-byte chunk of the 2-bit genome (64 bases) that holds the current base in registers
+struct RefCursor {
+    U4 w;
+    uintptr_t chunk;
+};
+
+static inline MCX_HD int ref_cursor_code(const IndexView &ix, RefCursor &cur, int64_t p)
+{
+    const bool rev = p >= ix.G;
+    const int64_t f = rev ? ix.G2 - 1 - p : p;
+    const uintptr_t a = (uintptr_t)ix.pac + (uintptr_t)(f >> 2);
+    const uintptr_t ch = a & ~(uintptr_t)15;
+    if (ch != cur.chunk) { cur.w = *(const U4 *)ch; cur.chunk = ch; }
+    const unsigned k = (unsigned)(a & 15);
+    const uint32_t word = k < 8 ? (k < 4 ? cur.w.x : cur.w.y) : (k < 12 ? cur.w.z : cur.w.w);
+    const int b = (int)((word >> ((k & 3) * 8 + ((~f & 3) << 1))) & 3u);
+    return rev ? 3 - b : b;
+}
+
 // PosChrIdMap.lower_bound(gPos): first chromosome end >= gPos, -1 past the last one
 static inline MCX_HD int end_slot(const IndexView &ix, int64_t gPos)
 {
@@ -233,6 +253,7 @@ static inline MCX_HD int seed_read(const IndexView &ix, const ReadRef &rd, Hit *
 {
     const int rlen = rd.rlen;
     ReadCursor cur; cur.chunk = 0; cur.w.x = cur.w.y = cur.w.z = cur.w.w = 0;
+    RefCursor rcur; rcur.chunk = 0; rcur.w.x = rcur.w.y = rcur.w.z = rcur.w.w = 0;
     int n_hits = 0;
     const int stop = rlen - kMinSeedLength;
     int p = 0, start = 0;
@@ -265,7 +286,7 @@ static inline MCX_HD int seed_read(const IndexView &ix, const ReadRef &rd, Hit *
         if (!end && x2 == 1 && !direct) { int lf = 0; tpos = (int64_t)fm_sa(ix, x0, lf); direct = true; }
         if (!end && direct) {
             const int64_t j = tpos + (p - start);
-            if (j >= (int64_t)ix.seq_len || ref_code(ix, j) != c) end = true; else p++;
+            if (j >= (int64_t)ix.seq_len || ref_cursor_code(ix, rcur, j) != c) end = true; else p++;
         } else if (!end) {
             uint64_t tk[4], tl[4];
             int nb;

@@ -89,6 +89,7 @@ bool host_index_load(const std::string &prefix, HostIndex &ix, std::string &err)
     if (!f) { err = "cannot read " + prefix + ".amb"; return false; }
     fclose(f);
     if (!read_file(prefix + ".pac", ix.pac) || (int64_t)ix.pac.size() < ix.G / 4 + 1) { err = "cannot read " + prefix + ".pac"; return false; }
+    ix.pac.resize(ix.pac.size() + 32, 0); // readers fetch aligned 16-byte chunks
     host_index_finish(ix);
     return true;
 }
