@@ -236,78 +236,171 @@ static inline MCX_HD void ktab_entry(const IndexView &ix, uint32_t idx, int K, u
 // when it builds the SA task list)
 constexpr int32_t kHitResolved = 1 << 30;
 
+// ---- packed views for the seeding walk ------------------------------------------------------
+// The read is packed once into 2-bit words (16 bases per u32, base s of a word at bits 30-2s, the
+// layout of the .pac bytes read big-endian) plus an N mask (bit 31-s of word s/32), in a small
+// per-lane scratch (LDS on the device, strided so that lanes never share a bank).  After that the
+// walk never touches the ASCII read again: the 12-mer of a search start, the next base of an
+// FM step and 16-base windows for the direct comparison are all shifts of those words.
+struct PackedRead {
+    uint32_t *w;      // lane's first word; word k at w[k * stride]
+    int stride;
+    int n_code;       // code words incl. one zero word of slack; the N-mask words follow
+};
+
+// words of scratch a read of rlen bases needs
+static inline MCX_HD int packed_words(int rlen) { return (rlen + 15) / 16 + 1 + (rlen + 31) / 32 + 1; }
+
+static inline MCX_HD void pack_read(const ReadRef &rd, PackedRead &pk)
+{
+    ReadCursor cur; cur.chunk = 0; cur.w.x = cur.w.y = cur.w.z = cur.w.w = 0;
+    const int rlen = rd.rlen, nc = (rlen + 15) >> 4, nmw = (rlen + 31) >> 5;
+    pk.n_code = nc + 1;
+    uint32_t *M = pk.w + (size_t)pk.n_code * pk.stride;
+    uint32_t cw = 0, nw = 0;
+    for (int i = 0; i < rlen; i++) {
+        const int c = cursor_code(rd, cur, i);
+        cw = (cw << 2) | (uint32_t)(c & 3);
+        nw = (nw << 1) | (c > 3 ? 1u : 0u);
+        if ((i & 15) == 15) pk.w[(i >> 4) * pk.stride] = cw;
+        if ((i & 31) == 31) M[(i >> 5) * pk.stride] = nw;
+    }
+    if (rlen & 15) pk.w[(rlen >> 4) * pk.stride] = cw << (2 * (16 - (rlen & 15)));
+    pk.w[nc * pk.stride] = 0u;
+    if (rlen & 31) M[(rlen >> 5) * pk.stride] = (nw << (32 - (rlen & 31))) | (0xFFFFFFFFu >> (rlen & 31)); // past the end counts as N
+    M[nmw * pk.stride] = 0xFFFFFFFFu;
+}
+
+// 16 bases starting at p <= rlen (MSB first); positions past the read read as 0
+static inline MCX_HD uint32_t packed_codes16(const PackedRead &pk, int p)
+{
+    const int k = p >> 4, sh = (p & 15) * 2;
+    const uint32_t hi = pk.w[k * pk.stride], lo = k + 1 < pk.n_code ? pk.w[(k + 1) * pk.stride] : 0u;
+    return sh ? (hi << sh) | (lo >> (32 - sh)) : hi;
+}
+
+// N flags of the 32 bases starting at p <= rlen (bit 31 = base p); bases past the read end are flagged
+static inline MCX_HD uint32_t packed_nmask32(const PackedRead &pk, int p, int rlen)
+{
+    const uint32_t *M = pk.w + (size_t)pk.n_code * pk.stride;
+    const int k = p >> 5, sh = p & 31, last = (rlen + 31) >> 5;
+    const uint32_t hi = M[k * pk.stride], lo = k + 1 <= last ? M[(k + 1) * pk.stride] : 0xFFFFFFFFu;
+    return sh ? (hi << sh) | (lo >> (32 - sh)) : hi;
+}
+
+// symbols f .. f+15 of the forward genome, MSB first (two big-endian words of the .pac bytes)
+static inline MCX_HD uint32_t ref_codes16_fwd(const IndexView &ix, int64_t f)
+{
+    const uint32_t *wp = (const uint32_t *)ix.pac + (f >> 4);
+    const int sh = (int)(f & 15) * 2;
+    const uint32_t hi = __builtin_bswap32(wp[0]), lo = __builtin_bswap32(wp[1]);
+    return sh ? (hi << sh) | (lo >> (32 - sh)) : hi;
+}
+
+// 16 symbols of RefSequence starting at 2G-coordinate j (bwt_index.cpp:196-215).  Forward
+// strand: a funnel shift of the packed genome.  Reverse strand: T[j+s] = 3 - X[2G-1-j-s], i.e.
+// the mirrored forward window with its symbol order reversed, complemented.  Windows that touch
+// the strand boundary or the text end are gathered base by base (past the end reads as 0).
+static inline MCX_HD uint32_t ref_codes16(const IndexView &ix, int64_t j)
+{
+    if (j + 16 <= ix.G) return ref_codes16_fwd(ix, j);
+    if (j >= ix.G && j + 16 <= ix.G2) {
+        uint32_t v = __builtin_bswap32(ref_codes16_fwd(ix, ix.G2 - 16 - j)); // reverse the 16 symbols: bytes,
+        v = ((v & 0x0F0F0F0Fu) << 4) | ((v >> 4) & 0x0F0F0F0Fu);             // nibbles,
+        v = ((v & 0x33333333u) << 2) | ((v >> 2) & 0x33333333u);             // symbol pairs
+        return ~v;
+    }
+    uint32_t v = 0;
+    for (int s = 0; s < 16; s++) v = (v << 2) | (j + s < ix.G2 ? (uint32_t)ref_code(ix, j + s) : 0u);
+    return v;
+}
+
 // Greedy left-to-right seeding of one read: IdentifySimplePairs (ReadMapping.cpp:125-158)
-// driving BWT_Search (bwt_search.cpp:121-164), flattened to one block fetch per iteration.
-// Hits are written as BWT rows (x0 + i); the SA kernel turns them into text positions.
-// Returns the number of hits the read produced (may exceed cap: overflow, nothing lost yet
-// because the pair is then re-run in the next tier).
+// driving BWT_Search (bwt_search.cpp:121-164).  Hits are written as BWT rows (x0 + i), to be
+// resolved by the SA kernel, or directly as text positions (kHitResolved).  Returns the number of
+// hits the read produced (may exceed cap: overflow, nothing lost yet because the pair is then
+// re-run in the next tier).
 //
-// Once the interval has narrowed to a single suffix (x2 == 1) the pattern has exactly one
-// occurrence in the text, so "can it be extended by base c" is "is the next text base c": the
-// suffix is resolved to its text position once (one suffix-array fetch) and the rest of the
-// search is a direct comparison against the 2-bit genome — same length, same position, a few
-// instructions per base instead of a block fetch and a rank computation.  The hit then needs no
-// SA task (kHitResolved).
-static inline MCX_HD int seed_read(const IndexView &ix, const ReadRef &rd, Hit *hits, int cap,
+// Three phases per search, each as cheap as it can be made without changing a result:
+//  1. start: if the next ktab_k bases hold no N and that k-mer occurs in the text, its bi-interval
+//     comes from the jump table (one 32-byte fetch instead of ktab_k - 1 wide-interval steps);
+//  2. FM steps (one or two 64-byte block fetches each) while the interval holds several suffixes;
+//  3. once it holds exactly one (x2 == 1) the pattern has one occurrence in the text, so "can it
+//     be extended by base c" is "is the next text base c": the suffix is resolved to its text
+//     position (one suffix-array fetch) and the rest of the search is a comparison of 16-base
+//     windows of the packed read against the 2-bit genome.  Same length, same position.
+// The loop iterates over FM steps and searches, not over bases, so that the lanes of a wave —
+// which sit at unrelated points of their reads — execute few iterations in total.
+static inline MCX_HD int seed_read(const IndexView &ix, const ReadRef &rd, PackedRead pk, Hit *hits, int cap,
                                    int64_t &ext_steps, int64_t &blocks)
 {
     const int rlen = rd.rlen;
-    ReadCursor cur; cur.chunk = 0; cur.w.x = cur.w.y = cur.w.z = cur.w.w = 0;
-    RefCursor rcur; rcur.chunk = 0; rcur.w.x = rcur.w.y = rcur.w.z = rcur.w.w = 0;
+    pack_read(rd, pk);
     int n_hits = 0;
     const int stop = rlen - kMinSeedLength;
     int p = 0, start = 0;
-    bool active = false, direct = false;
+    bool active = false;
     int64_t tpos = 0;
     uint64_t x0 = 0, x1 = 0, x2 = 0;
     for (;;) {
         if (!active) {
             if (p >= stop) break;
-            int c = cursor_code(rd, cur, p);
-            if (c > 3) { p++; continue; }
+            const uint32_t nm = packed_nmask32(pk, p, rlen);
+            if (nm & 0x80000000u) { p += nm == 0xFFFFFFFFu ? 32 : __builtin_clz(~nm); continue; } // skip N (ReadMapping.cpp:135)
             start = p;
+            const uint32_t c16 = packed_codes16(pk, p);
             bool jumped = false;
-            if (ix.ktab && p + ix.ktab_k <= rlen) {
-                uint32_t idx = (uint32_t)c;
-                bool clean = true;
-                for (int j = 1; j < ix.ktab_k; j++) {
-                    const int cj = cursor_code(rd, cur, p + j);
-                    if (cj > 3) { clean = false; break; }
-                    idx = (idx << 2) | (uint32_t)cj;
-                }
-                if (clean && ktab_lookup(ix, idx, x0, x1, x2)) { p += ix.ktab_k; jumped = true; }
-            }
-            if (!jumped) { x0 = ix.L2[c] + 1; x1 = ix.L2[3 - c] + 1; x2 = ix.L2[c + 1] - ix.L2[c]; p++; }
-            active = true; direct = false;
+            if (ix.ktab && p + ix.ktab_k <= rlen && (nm >> (32 - ix.ktab_k)) == 0)
+                if (ktab_lookup(ix, c16 >> (32 - 2 * ix.ktab_k), x0, x1, x2)) { p += ix.ktab_k; jumped = true; }
+            if (!jumped) { const int c = (int)(c16 >> 30); x0 = ix.L2[c] + 1; x1 = ix.L2[3 - c] + 1; x2 = ix.L2[c + 1] - ix.L2[c]; p++; }
+            active = true;
         }
-        bool end = p >= rlen;
-        int c = end ? 4 : cursor_code(rd, cur, p);
-        if (c > 3) end = true;
-        if (!end && x2 == 1 && !direct) { int lf = 0; tpos = (int64_t)fm_sa(ix, x0, lf); direct = true; }
-        if (!end && direct) {
-            const int64_t j = tpos + (p - start);
-            if (j >= (int64_t)ix.seq_len || ref_cursor_code(ix, rcur, j) != c) end = true; else p++;
-        } else if (!end) {
-            uint64_t tk[4], tl[4];
-            int nb;
-            fm_2occ4(ix, x1 - 1, x1 - 1 + x2, tk, tl, nb);
-            blocks += nb;
-            int b = 3 - c;
-            uint64_t n2 = tl[b] - tk[b];
-            if (n2 == 0) end = true;
+        bool end = false;
+        if (x2 == 1) { // phase 3: the rest of the search against the text itself
+            int lf = 0;
+            tpos = (int64_t)fm_sa(ix, x0, lf);
+            for (;;) {
+                const int64_t j = tpos + (p - start);
+                int64_t room = (int64_t)ix.seq_len - j;
+                if (rlen - p < room) room = rlen - p;
+                if (room <= 0) break;
+                const uint32_t x = packed_codes16(pk, p) ^ ref_codes16(ix, j);
+                uint32_t sp = packed_nmask32(pk, p, rlen) >> 16; // N flags, bit 15-s -> bit 30-2s
+                sp = (sp | (sp << 8)) & 0x00FF00FFu; sp = (sp | (sp << 4)) & 0x0F0F0F0Fu;
+                sp = (sp | (sp << 2)) & 0x33333333u; sp = (sp | (sp << 1)) & 0x55555555u;
+                const uint32_t mm = ((x | (x >> 1)) & 0x55555555u) | sp; // bit 30-2s: base s differs or is N
+                int same = mm ? (__builtin_clz(mm) >> 1) : 16;
+                if (same > room) same = (int)room;
+                p += same;
+                if (same < 16) break;
+            }
+            end = true;
+        } else { // phase 2: one FM step
+            const uint32_t nm = packed_nmask32(pk, p, rlen);
+            if (nm & 0x80000000u) end = true; // N or read end
             else {
-                // ok[3].x0 = ik.x0 + primary correction; lower bases stack on top (:143-146)
-                uint64_t n0 = x0 + ((x1 <= ix.primary && x1 + x2 - 1 >= ix.primary) ? 1 : 0);
-                for (int bb = 3; bb > b; bb--) n0 += tl[bb] - tk[bb];
-                x0 = n0; x1 = ix.L2[b] + 1 + tk[b]; x2 = n2;
-                p++;
+                const int c = (int)(packed_codes16(pk, p) >> 30);
+                uint64_t tk[4], tl[4];
+                int nb;
+                fm_2occ4(ix, x1 - 1, x1 - 1 + x2, tk, tl, nb);
+                blocks += nb;
+                const int b = 3 - c;
+                const uint64_t n2 = tl[b] - tk[b];
+                if (n2 == 0) end = true;
+                else {
+                    // ok[3].x0 = ik.x0 + primary correction; lower bases stack on top (:143-146)
+                    uint64_t n0 = x0 + ((x1 <= ix.primary && x1 + x2 - 1 >= ix.primary) ? 1 : 0);
+                    for (int bb = 3; bb > b; bb--) n0 += tl[bb] - tk[bb];
+                    x0 = n0; x1 = ix.L2[b] + 1 + tk[b]; x2 = n2;
+                    p++;
+                }
             }
         }
         if (end) {
-            int len = p - start;
+            const int len = p - start;
             ext_steps += len;
             if (len >= kMinSeedLength && x2 <= (uint64_t)kOccThr) {
-                if (direct) {
+                if (x2 == 1) {
                     if (n_hits < cap) { Hit h; h.gPos = tpos; h.rPos = start; h.len = len | kHitResolved; hits[n_hits] = h; }
                     n_hits++;
                 } else for (uint64_t i = 0; i < x2; i++) {

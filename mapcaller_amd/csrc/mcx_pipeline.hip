@@ -340,8 +340,9 @@ struct SeedOut {
     uint32_t *read_blocks;
 };
 
-__global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel, SeedOut so)
+__global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel, SeedOut so, int pk_words)
 {
+    extern __shared__ uint32_t pk_lds[]; // packed reads: word k of lane t at pk_lds[k * blockDim.x + t]
     const int nr = cx.pm.paired ? 2 : 1;
     const uint32_t lr = blockIdx.x * blockDim.x + threadIdx.x; // local read
     const bool live = lr < sel.n * nr;
@@ -353,7 +354,8 @@ __global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel,
         ReadRef rd;
         rd.ascii = rb.bases + rb.off[r]; rd.rlen = (int)(rb.off[r + 1] - rb.off[r]); rd.flipped = (cx.pm.paired && s == 1) ? 1 : 0;
         int64_t ext = 0, blocks = 0;
-        const int n = seed_read(cx.ix, rd, st.hits[s], cx.caps.hit_cap, ext, blocks);
+        PackedRead pk; pk.w = pk_lds + threadIdx.x; pk.stride = blockDim.x; pk.n_code = 0;
+        const int n = rd.rlen <= 0 || packed_words(rd.rlen) > pk_words ? 0 : seed_read(cx.ix, rd, pk, st.hits[s], cx.caps.hit_cap, ext, blocks);
         st.hdr->n_hits[s] = n;
         so.read_ext[r] = (uint32_t)ext; so.read_blocks[r] = (uint32_t)blocks;
         keep = n <= cx.caps.hit_cap ? n : 0; // overflowing reads are re-run in the next tier
@@ -729,10 +731,16 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     RescueList rl; rl.ids = c->d_rescue; rl.n = c->d_cnt + CNT_RESCUE; rl.cap = c->rescue_cap;
     JobSinks sinks;
     for (int k = 0; k < 4; k++) { sinks.s[k].jobs = c->d_jobs[k]; sinks.s[k].count = c->d_cnt + CNT_JOB0 + k; sinks.s[k].cap = c->job_cap[k]; }
-    const unsigned pb = (sel.n + 255) / 256, rbk = (sel.n * nr + 255) / 256;
+    const unsigned pb = (sel.n + 255) / 256;
     int e = 0;
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
-    k_seed<<<rbk, 256, 0, s>>>(cx, rb, sel, so);
+    {
+        // LDS for the packed reads: words per lane for the longest read x lanes; narrower blocks for long reads
+        const int pkw = packed_words(c->rlen_max);
+        const int threads = pkw * 256 * 4 <= 48 * 1024 ? 256 : (pkw * 128 * 4 <= 48 * 1024 ? 128 : 64);
+        const unsigned blocks_s = (sel.n * nr + threads - 1) / threads;
+        k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw);
+    }
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
     k_sa<<<4096, 256, 0, s>>>(cx, so, paired, c->d_cnt + CNT_LF);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));

@@ -96,7 +96,9 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
             int64_t ext = 0, blocks = 0;
             ReadRef one;
             one.ascii = b.bases.data() + b.off[r]; one.rlen = (int)(b.off[r + 1] - b.off[r]); one.flipped = (b.paired && s == 1) ? 1 : 0;
-            int nh = seed_read(cx.ix, one, st.hits[s], cx.caps.hit_cap, ext, blocks);
+            std::vector<uint32_t> pkbuf(packed_words(one.rlen) + 4);
+            PackedRead pk; pk.w = pkbuf.data(); pk.stride = 1; pk.n_code = 0;
+            int nh = seed_read(cx.ix, one, pk, st.hits[s], cx.caps.hit_cap, ext, blocks);
             st.hdr->n_hits[s] = nh;
             if (stats) { stats[3] += ext; stats[8] += blocks; }
             int keep = nh <= cx.caps.hit_cap ? nh : 0;
