@@ -97,6 +97,7 @@ typedef struct mcx_aln {
     int32_t n_cigar;   /* words in this read's row of the cigar array: len << 4 | op, M=0 I=1 D=2 S=4 */
     int32_t fwd;       /* 0: SEQ/QUAL are printed reverse-complemented / reversed */
     int32_t has_mate;  /* RNEXT '=' */
+    int32_t pad[2];    /* 64-byte records */
 } mcx_aln;
 
 typedef struct mcx_stats {

@@ -38,12 +38,12 @@ class Opts(C.Structure):
 class Aln(C.Structure):
     _fields_ = [("pos", C.c_int64), ("mate_pos", C.c_int64), ("chr", C.c_int32), ("flag", C.c_int32),
                 ("mapq", C.c_int32), ("tlen", C.c_int32), ("nm", C.c_int32), ("as_", C.c_int32), ("xs", C.c_int32),
-                ("n_cigar", C.c_int32), ("fwd", C.c_int32), ("has_mate", C.c_int32)]
+                ("n_cigar", C.c_int32), ("fwd", C.c_int32), ("has_mate", C.c_int32), ("pad", C.c_int32 * 2)]
 
 
 ALN_DTYPE = np.dtype([("pos", "<i8"), ("mate_pos", "<i8"), ("chr", "<i4"), ("flag", "<i4"), ("mapq", "<i4"),
                       ("tlen", "<i4"), ("nm", "<i4"), ("as", "<i4"), ("xs", "<i4"), ("n_cigar", "<i4"),
-                      ("fwd", "<i4"), ("has_mate", "<i4")])
+                      ("fwd", "<i4"), ("has_mate", "<i4"), ("pad", "<i4", (2,))])
 
 
 class SparseRec(C.Structure):

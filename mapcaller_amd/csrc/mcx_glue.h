@@ -671,54 +671,65 @@ static inline MCX_HD void extend_read(const Ctx &cx, PairState &st, int s, const
 {
     const IndexView &ix = cx.ix;
     PairHdr &h = *st.hdr;
-    ReadSum &sum = h.sum[s];
-    int max_mm = (int)(rd.rlen * cx.pm.max_mm_rate);
-    int min_score = (int)(rd.rlen * (1 - cx.pm.max_mm_rate));
+    ReadSum sum = h.sum[s];
+    const int max_mm = (int)(rd.rlen * cx.pm.max_mm_rate);
+    const int min_score = (int)(rd.rlen * (1 - cx.pm.max_mm_rate));
     Cand *cs = st.cands[s];
-    for (int ci = 0; ci < h.n_cands[s]; ci++) {
-        Cand &c = cs[ci];
+    const int n_cands = h.n_cands[s];
+    // structures are copied to registers, worked on, and stored back whole: a lane's memory
+    // instructions, not its bytes, are what this stage is short of
+    for (int ci = 0; ci < n_cands; ci++) {
+        Cand c = cs[ci];
         if (c.score == 0) continue;
         Frag *f = st.frags + c.frag_off;
-        int num = c.n_frags, last = num - 1;
+        const int num = c.n_frags, last = num - 1;
         bool head_ok = true, tail_ok = true;
         int score = 0, mism = 0;
         bool dead = false;
+        int64_t g_first = 0; // gPos of the first fragment after the loop
         for (int i = 0; i < num; i++) {
-            Frag &x = f[i];
+            Frag x = f[i];
+            if (i == 0) g_first = x.gPos;
             if (x.kind == kSimple) { score += x.rLen; continue; }
-            bool fwd = x.gPos < ix.G;
+            const bool fwd = x.gPos < ix.G;
             if (i == 0) {
                 strip_end_gaps(x, st.ops, fwd, true);
                 ColStats q = frag_columns(ix, x, st.ops, rd);
                 if (x.ops_len >= kMinAlnBlockSize && !quality_ok(q)) {
                     head_ok = false;
+                    const Frag nx = f[i + 1];
                     x.rLen = x.gLen = 0; x.ops_len = 0; x.kind = kEmpty;
-                    x.rPos = f[i + 1].rPos; x.gPos = f[i + 1].gPos;
+                    x.rPos = nx.rPos; x.gPos = nx.gPos;
                 } else { score += q.match; mism += q.mis; }
+                g_first = x.gPos;
+                f[i] = x;
             } else if (i == last) {
                 strip_end_gaps(x, st.ops, !fwd, false);
                 ColStats q = frag_columns(ix, x, st.ops, rd);
                 if (x.ops_len >= kMinAlnBlockSize && !quality_ok(q)) {
                     tail_ok = false;
+                    const Frag pv = f[i - 1];
                     x.rLen = x.gLen = 0; x.ops_len = 0; x.kind = kEmpty;
-                    x.rPos = f[i - 1].rPos + f[i - 1].rLen; x.gPos = f[i - 1].gPos + f[i - 1].gLen;
+                    x.rPos = pv.rPos + pv.rLen; x.gPos = pv.gPos + pv.gLen;
                 } else { score += q.match; mism += q.mis; }
+                f[i] = x;
             } else {
                 ColStats q = frag_columns(ix, x, st.ops, rd);
                 if (x.rLen >= kMinAlnBlockSize && x.gLen >= kMinAlnBlockSize && !quality_ok(q)) { dead = true; break; }
                 score += q.match; mism += q.mis;
             }
         }
-        if (dead || (!head_ok && !tail_ok)) { c.score = 0; continue; }
+        if (dead || (!head_ok && !tail_ok)) { cs[ci].score = 0; continue; }
+        if (score == 0 || (score < min_score && mism > max_mm)) { cs[ci].score = 0; continue; }
         c.score = score;
-        if (score == 0) continue;
-        if (score < min_score && mism > max_mm) { c.score = 0; continue; }
-        c.fwd = f[0].gPos < ix.G ? 1 : 0;
-        if (!c.fwd) for (int a = 0, b = num - 1; a < b; a++, b--) { Frag t = f[a]; f[a] = f[b]; f[b] = t; }
+        c.fwd = g_first < ix.G ? 1 : 0;
+        if (!c.fwd) for (int a = 0, b = num - 1; a < b; a++, b--) { const Frag t = f[a]; f[a] = f[b]; f[b] = t; }
+        cs[ci] = c;
         if (score > sum.score) { sum.score = score; sum.best = ci; }
         else if (score > sum.sub) sum.sub = score;
     }
-    for (int ci = 0; ci < h.n_cands[s]; ci++) if (cs[ci].score < sum.score) cs[ci].score = 0;
+    for (int ci = 0; ci < n_cands; ci++) if (cs[ci].score < sum.score) cs[ci].score = 0;
+    h.sum[s] = sum;
 }
 
 struct Coord { int64_t pos; int32_t chr; };
@@ -840,30 +851,33 @@ static inline MCX_HD void pair_stats(const Ctx &cx, PairState &st, DetailHdr *dh
 
 // one output record: the line GeneratePairedSamStream / GenerateSingleSamStream print for this
 // read in unique mode (SamReport.cpp:324-488)
-static inline MCX_HD void emit_record(const Ctx &cx, PairState &st, int s, const ReadRef *rd, AlnRec &out,
+static inline MCX_HD void emit_record(const Ctx &cx, PairState &st, int s, const ReadRef *rd, AlnRec &dst,
                                       uint32_t *cig, int cig_cap)
 {
     PairHdr &h = *st.hdr;
-    const ReadSum &me = h.sum[s];
+    const ReadSum me = h.sum[s];
+    AlnRec out;
     out.pos = 0; out.mate_pos = 0; out.chr = -1; out.flag = 0; out.mapq = 0; out.tlen = 0;
-    out.nm = 0; out.as = 0; out.xs = 0; out.n_cigar = 0; out.fwd = 1; out.has_mate = 0;
+    out.nm = 0; out.as = 0; out.xs = 0; out.n_cigar = 0; out.fwd = 1; out.has_mate = 0; out.pad[0] = out.pad[1] = 0;
     const bool paired = cx.pm.paired != 0;
     if (me.score == 0) {
-        if (!paired) { out.flag = 4; return; }
+        if (!paired) { out.flag = 4; dst = out; return; }
         const ReadSum &ot = h.sum[1 - s];
         int fl = 0x1 | 0x4 | (s == 0 ? 0x40 : 0x80);
         if (ot.score == 0) fl |= 0x8;
         else if (h.n_cands[1 - s] > 0) fl |= 0x30; // both strand bits, SamReport.cpp:401-402 / :449-450
         out.flag = fl;
+        dst = out;
         return;
     }
-    Cand &c = st.cands[s][me.best];
+    Cand c = st.cands[s][me.best];
     if (paired) {
         const Cand *oc = st.cands[1 - s];
         // flags are set for every surviving candidate when the best score is tied; the line
         // printed in unique mode is the first one, candidate `best`
         c.flag = paired_flag(c, oc, s == 0, me.score > me.sub);
     } else c.flag = c.fwd ? 0 : 0x10; // SetSingledAlignmentFlag, SamReport.cpp:7-24
+    st.cands[s][me.best].flag = c.flag;
     out.flag = c.flag;
     out.mapq = mapq_of(cx, me);
     Coord km = aln_coord(cx.ix, c, st.frags);
@@ -888,6 +902,7 @@ static inline MCX_HD void emit_record(const Ctx &cx, PairState &st, int s, const
             out.has_mate = 1;
         }
     }
+    dst = out;
 }
 
 // copies what the profile stage needs of one read out of the pair state (which is reused by the
@@ -941,7 +956,9 @@ static inline MCX_HD void stage_finish(const Ctx &cx, int64_t pair, const ReadRe
                                        uint8_t *detail0)
 {
     PairState st = pair_state(cx.state, cx.lay, cx.caps, pair);
-    PairHdr &h = *st.hdr;
+    PairHdr *const g_hdr = st.hdr;
+    PairHdr h = *g_hdr; // the header travels in registers through this stage and is stored back once
+    st.hdr = &h;
     int nr = cx.pm.paired ? 2 : 1;
     if (h.flags & kOvAny) return;
     h.mapped = 0;
@@ -953,6 +970,7 @@ static inline MCX_HD void stage_finish(const Ctx &cx, int64_t pair, const ReadRe
         emit_record(cx, st, s, rd, recs[r], cigars + r * cx.caps.cig_cap, cx.caps.cig_cap);
         if (detail0) write_detail(cx, st, s, detail0 + r * cx.dlay.stride);
     }
+    *g_hdr = h;
 }
 
 } // namespace mcx

@@ -64,22 +64,23 @@ struct Caps {
     int32_t kmer_cap;  // rescue window length
 };
 
-struct Hit {          // one seed occurrence: FragPair_t with bSimple (structure.h:113-123)
+struct alignas(16) Hit { // one seed occurrence: FragPair_t with bSimple (structure.h:113-123)
     int64_t gPos;     // K1 stores the BWT row here, K2 overwrites it with the text position
     int32_t rPos;
     int32_t len;
 };
 
-struct Cand {         // AlnCan_t (structure.h:125-133) as ranges into the pair state
+struct alignas(16) Cand { // AlnCan_t (structure.h:125-133) as ranges into the pair state; three 16-byte groups
     int32_t score;
     int32_t mate;     // PairedAlnCanIdx
     int32_t first;    // first seed (index into the read's hit array)
     int32_t count;    // number of seeds
-    int64_t pd0;      // FragPairVec[0].PosDiff while sorted by PosDiff
     int32_t frag_off; // fragments after extension set-up
     int32_t n_frags;
     int32_t flag;     // SamFlag
     int32_t fwd;      // orientation
+    int64_t pd0;      // FragPairVec[0].PosDiff while sorted by PosDiff
+    int64_t pad;
 };
 
 enum FragKind : uint8_t {
@@ -91,7 +92,7 @@ enum FragKind : uint8_t {
     kEmpty = 5    // end fragment dropped by the quality gate
 };
 
-struct Frag {
+struct alignas(16) Frag {
     int64_t gPos;
     int32_t rPos, rLen, gLen;
     int32_t ops_off;  // kDp: offset into the pair's ops pool (columns, 'M' 'I' 'D')
@@ -123,7 +124,7 @@ enum PairFlags : uint32_t {
     kRescueUsedEst = 256u
 };
 
-struct PairHdr {
+struct alignas(16) PairHdr {
     uint32_t flags;
     int32_t n_hits[2];
     int32_t n_cands[2];
@@ -142,7 +143,7 @@ struct PairHdr {
 };
 
 // one output record per read (unique mode: the reference prints exactly one line per read)
-struct AlnRec {
+struct alignas(16) AlnRec { // 64 bytes: four 16-byte stores
     int64_t pos;        // 1-based POS (0 when unmapped)
     int64_t mate_pos;   // PNEXT (0 = none)
     int32_t chr;        // RNAME index (-1 = *)
@@ -153,6 +154,7 @@ struct AlnRec {
     int32_t n_cigar;    // ops in the cigar pool row of this read
     int32_t fwd;        // SEQ printed as given (1) or reverse-complemented (0)
     int32_t has_mate;   // RNEXT '=' and PNEXT/TLEN valid
+    int32_t pad[2];
 };
 
 // Alignment detail of one read, written by the finish stage when the -vcf bookkeeping is on:
@@ -190,11 +192,12 @@ struct SparseRec {
 };
 
 // per-pair summary the host replays the reference's avgDist feedback from
-struct PairOut {
+struct alignas(16) PairOut { // 32 bytes: two 16-byte stores
     uint32_t flags;
     int32_t est, est_lo, est_hi;
     int32_t pair_dist;
     int16_t pair_ok, mapped;
+    int32_t pad[2];
 };
 
 // byte offsets of the regions of a pair-state record
