@@ -58,10 +58,12 @@ static inline MCX_HD int64_t boundary_of(const IndexView &ix, int64_t gPos) // G
     return s < 0 ? -1 : ix.end_pos[s];
 }
 
-static inline MCX_HD void cand_init(Cand &c, int score, int first, int count, int64_t pd0)
+static inline MCX_HD void cand_init(Cand &dst, int score, int first, int count, int64_t pd0)
 {
+    Cand c;
     c.score = score; c.mate = -1; c.first = first; c.count = count; c.pd0 = pd0;
-    c.frag_off = 0; c.n_frags = 0; c.flag = 0; c.fwd = 1;
+    c.frag_off = 0; c.n_frags = 0; c.flag = 0; c.fwd = 1; c.pad = 0;
+    dst = c; // three 16-byte stores
 }
 
 // SimplePairClustering (ReadMapping.cpp:194-226) with IdentifyClosestFragmentPairs (:160-192).
@@ -401,7 +403,8 @@ static inline MCX_HD bool pair_needs_rescue(const PairHdr &h) { return h.n_paire
 static inline MCX_HD void stage_cluster_pair(const Ctx &cx, int64_t pair, const ReadRef *rd, int est)
 {
     PairState st = pair_state(cx.state, cx.lay, cx.caps, pair);
-    PairHdr &h = *st.hdr;
+    PairHdr *const g_hdr = st.hdr;
+    PairHdr h = *g_hdr; // in registers through the stage, stored back once
     int nr = cx.pm.paired ? 2 : 1;
     for (int s = 0; s < nr; s++) {
         if (h.n_hits[s] > cx.caps.hit_cap) { h.flags |= kOvHits; h.n_hits[s] = 0; }
@@ -414,6 +417,7 @@ static inline MCX_HD void stage_cluster_pair(const Ctx &cx, int64_t pair, const 
     h.est = est; h.est_lo = 0; h.est_hi = 0x7fffffff; h.n_paired = 0;
     if (cx.pm.paired && !(h.flags & kOvAny))
         h.n_paired = pair_by_distance(est, st.cands[0], h.n_cands[0], st.cands[1], h.n_cands[1], h.est_lo, h.est_hi);
+    *g_hdr = h;
 }
 
 // stage R: mate rescue for pairs left unpaired (ReadMapping.cpp:463)
@@ -551,9 +555,10 @@ static inline MCX_HD DpJob pair_job(const Ctx &cx, int64_t pair, int k)
 static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef *rd)
 {
     PairState st = pair_state(cx.state, cx.lay, cx.caps, pair);
-    PairHdr &h = *st.hdr;
+    PairHdr *const g_hdr = st.hdr;
+    PairHdr h = *g_hdr; // in registers through the stage; every exit stores it back
     h.n_frags = 0; h.n_ops = 0; h.n_jobs = 0;
-    if (h.flags & kOvAny) return 0;
+    if (h.flags & kOvAny) { *g_hdr = h; return 0; }
     int nr = cx.pm.paired ? 2 : 1;
     if (cx.pm.paired) {
         if (h.n_paired == 0) { keep_top_scores(st.cands[0], h.n_cands[0]); keep_top_scores(st.cands[1], h.n_cands[1]); }
@@ -569,7 +574,7 @@ static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef 
             Cand &c = cs[ci];
             c.n_frags = 0; c.frag_off = h.n_frags;
             if (c.score == 0) continue;
-            if (h.n_frags + 2 * c.count + 2 > cx.caps.frag_cap) { h.flags |= kOvFrags; return 0; }
+            if (h.n_frags + 2 * c.count + 2 > cx.caps.frag_cap) { h.flags |= kOvFrags; *g_hdr = h; return 0; }
             Frag *f = st.frags + h.n_frags;
             int nf = build_frags(cx.ix, rd[s].rlen, st.hits[s] + c.first, c.count, f);
             if (nf < 0) { c.score = 0; continue; }
@@ -588,8 +593,8 @@ static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef 
                         dp = mm > 1 && mm >= (int)(x.rLen * 0.2);
                     }
                     if (dp) {
-                        if (h.n_ops + x.rLen + x.gLen > cx.caps.ops_cap) { h.flags |= kOvOps; return 0; }
-                        if (nj >= cx.caps.job_cap) { h.flags |= kOvJobs; return 0; }
+                        if (h.n_ops + x.rLen + x.gLen > cx.caps.ops_cap) { h.flags |= kOvOps; *g_hdr = h; return 0; }
+                        if (nj >= cx.caps.job_cap) { h.flags |= kOvJobs; *g_hdr = h; return 0; }
                         x.kind = kDp; x.ops_off = h.n_ops; x.ops_len = 0;
                         h.n_ops += x.rLen + x.gLen;
                         jl[2 * nj] = h.n_frags + i; jl[2 * nj + 1] = s;
@@ -602,6 +607,7 @@ static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef 
         }
     }
     h.n_jobs = nj;
+    *g_hdr = h;
     return nj;
 }
 
