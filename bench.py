@@ -30,6 +30,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "round1", "summary_2gbp_final.json")
+
+
+def pmc_traffic(args):
+    """HBM bytes one k_seed launch moved, from the committed `rocprofv3 --pmc FETCH_SIZE` /
+    `--pmc WRITE_SIZE` passes of this same command (counters cannot be read from inside the run).
+    Only returned when the workload is the one those passes profiled."""
+    if (args.genome_mbp, args.batch_pairs, args.rlen, args.alg) != (2000.0, 2_000_000, 150, "ksw2"):
+        return None
+    try:
+        with open(PMC_SUMMARY) as fh:
+            t = json.load(fh)["hbm_traffic"]["k_seed"]
+        return int(t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def parse():
@@ -37,7 +52,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome-mbp", type=float, default=1000.0, help="synthetic genome size (Mbp)")
+    ap.add_argument("--genome-mbp", type=float, default=2000.0, help="synthetic genome size (Mbp)")
     ap.add_argument("--contigs", type=int, default=24)
     ap.add_argument("--batch-pairs", type=int, default=2_000_000, help="read pairs per step and per GPU")
     ap.add_argument("--rlen", type=int, default=150)
@@ -231,7 +246,9 @@ def main():
                        "reads_per_step_per_gpu": reads_per_step, "full_sa_in_hbm": bool(args.full_sa), "index_build_s": round(t_index, 2),
                        "index_hbm_gb": round(index.hbm_bytes / 1e9, 2)},
             "roofline": {"bound": "hbm", "kernel": "k_seed", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args),
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/round1/summary_2gbp_final.json)",
+                         "algorithmic_bytes_per_launch": round(seed_bytes / max(args.steps, 1)),
                          "algorithmic_bytes_per_read": round(seed_bytes / max(d["reads"], 1), 1), "avg_launch_ms": round(seed_ms, 3)},
             "per_read": {"fm_ext_steps": round(d["fm_ext_steps"] / max(d["reads"], 1), 2), "fm_blocks": round(d["fm_blocks"] / max(d["reads"], 1), 2),
                          "sa_hits": round(d["sa_hits"] / max(d["reads"], 1), 3), "dp_jobs": round(d["dp_jobs"] / max(d["reads"], 1), 4),
