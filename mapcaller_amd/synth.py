@@ -135,6 +135,33 @@ def mutate_genome(genome: Genome, seed: int, snp: float = 0.002, indel: float = 
     return Genome([n for n in genome.names], out)
 
 
+def structural_donor(genome: Genome, seed: int, inv: Tuple[int, int, int] = (0, 20000, 3000),
+                     move: Tuple[int, int, int, int] = (1, 10000, 3000, 30000)) -> Genome:
+    """Two haplotypes of a donor (contigs doubled: all of haplotype A, then all of haplotype B) that
+    share homozygous SNPs / short indels, differ by heterozygous ones, and both carry one inversion
+    ``inv`` = (contig, start, length) and one moved segment ``move`` = (contig, start, length, new
+    start) — the events the -vcf path reports as <INV> / <TNL> break points."""
+    hap_a = mutate_genome(genome, seed, snp=0.003, indel=0.0006, max_indel=5)
+    hap_b = mutate_genome(hap_a, seed + 1, snp=0.002, indel=0.0003, max_indel=4)
+    names, codes = [], []
+    for tag, hap in (("a", hap_a), ("b", hap_b)):
+        for ci, c in enumerate(hap.codes):
+            a = c.clone()
+            if ci == inv[0]:
+                s0, ln = inv[1], inv[2]
+                seg = a[s0:s0 + ln].flip(0)
+                a[s0:s0 + ln] = torch.where(seg < 4, 3 - seg, seg)
+            if ci == move[0]:
+                s0, ln, to = move[1], move[2], move[3]
+                seg = a[s0:s0 + ln].clone()
+                rest = torch.cat([a[:s0], a[s0 + ln:]])
+                to2 = to - ln if to > s0 else to
+                a = torch.cat([rest[:to2], seg, rest[to2:]])
+            names.append(f"{hap.names[ci]}_{tag}")
+            codes.append(a)
+    return Genome(names, codes)
+
+
 def _apply_errors(src: torch.Tensor, rlen: int, sub: float, ins: float, dele: float, n_rate: float,
                   g: torch.Generator) -> torch.Tensor:
     """src: uint8 codes [n, rlen+slack]; returns codes [n, rlen] with substitutions, insertions
@@ -163,7 +190,8 @@ def _apply_errors(src: torch.Tensor, rlen: int, sub: float, ins: float, dele: fl
 def simulate_reads(donor: Genome, n: int, rlen: int, paired: bool, seed: int,
                    frag_mean: float = 500.0, frag_sd: float = 50.0, frag_min: int = 300, frag_max: int = 800,
                    sub: float = 0.005, ins: float = 0.001, dele: float = 0.001, n_rate: float = 0.0,
-                   device: str = "cpu", chunk: int = 1 << 20, skip_head: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+                   device: str = "cpu", chunk: int = 1 << 20, skip_head: int = 0,
+                   skip_contigs: Sequence[int] = (0,)) -> Tuple[torch.Tensor, torch.Tensor]:
     """Returns (bases, origin): ``bases`` uint8 ASCII [n_reads, rlen] (n_reads = 2n when paired,
     mates interleaved) and ``origin`` int64 [n_reads, 2] = (offset in the concatenated donor,
     strand) of each read's first base, for diagnostics only.
@@ -192,7 +220,10 @@ def simulate_reads(donor: Genome, n: int, rlen: int, paired: bool, seed: int,
         room = (lens[ci] - frag).clamp_(min=1)
         off = (torch.rand(m, generator=g, device=dev, dtype=torch.float64) * room.double()).long()
         if skip_head:
-            off = torch.where(ci == 0, off.clamp(min=skip_head), off)
+            first = torch.zeros_like(ci, dtype=torch.bool)
+            for k in skip_contigs:  # donor contigs that are copies of the reference's first contig
+                first |= ci == k
+            off = torch.where(first, off.clamp(min=skip_head), off)
             off = torch.minimum(off, (lens[ci] - frag).clamp_(min=0))
         frag = torch.minimum(frag, lens[ci])
         fs = starts[ci] + off  # fragment start in the concatenation

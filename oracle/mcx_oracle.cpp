@@ -1299,7 +1299,7 @@ struct Shared {
     FILE *sam = nullptr;
     std::mutex in_lock, out_lock;
     u32 avg_dist = 1000; // ReadMapping.cpp:20
-    i64 n_reads = 0, n_mapped = 0, n_paired = 0, dist_sum = 0;
+    i64 n_reads = 0, n_mapped = 0, n_paired = 0, dist_sum = 0, len_sum = 0;
     Counters ct;
     Profile *pf = nullptr; // -vcf bookkeeping (ReadMapping.cpp:562-573); single thread only
 };
@@ -1334,7 +1334,7 @@ static void worker(Shared *sh)
         int n = (int)chunk.size();
         if (n == 0) break;
         int mapped = 0, pairs = 0;
-        i64 dsum = 0;
+        i64 dsum = 0, lsum = 0;
         lines.clear();
         if (sh->paired && n % 2 == 0) {
             for (int i = 0; i < n; i += 2) {
@@ -1352,7 +1352,7 @@ static void worker(Shared *sh)
                 PairDist pd = pair_distance(r1.cands, r2.cands);
                 if (pd.dist != 0 && pd.g1 != -1 && pd.g2 != -1) {
                     bool inv = (pd.g1 < ix.G && pd.g2 >= ix.G) || (pd.g1 >= ix.G && pd.g2 < ix.G);
-                    if (!inv && pd.dist <= 1000) { pairs++; dsum += pd.dist; } // MinTranslocationSize :9
+                    if (!inv && pd.dist <= 1000) { pairs++; dsum += pd.dist; lsum += r1.rlen + r2.rlen; } // MinTranslocationSize :9, :527-531
                     if (sh->pf) { // discordant-site lists, ReadMapping.cpp:486-521 (the second branch pushes unconditionally)
                         Profile &pf = *sh->pf;
                         if (pd.g1 < ix.G && pd.g2 >= ix.G) {
@@ -1382,7 +1382,7 @@ static void worker(Shared *sh)
             if (sh->sam) for (int i = 0; i < n; i++) sam_single(ix, sh->pm, sh->fastq, chunk[i], lines);
         }
         std::lock_guard<std::mutex> g(sh->out_lock);
-        sh->n_reads += n; sh->n_mapped += mapped; sh->n_paired += pairs; sh->dist_sum += dsum;
+        sh->n_reads += n; sh->n_mapped += mapped; sh->n_paired += pairs; sh->dist_sum += dsum; sh->len_sum += lsum;
         if (sh->n_paired > 1000) sh->avg_dist = (u32)(int)(1. * sh->dist_sum / sh->n_paired + .5); // :539
         if (sh->sam) for (auto &l : lines) { fputs(l.c_str(), sh->sam); fputc('\n', sh->sam); }
         if (sh->pf) { // ReadMapping.cpp:562-573 / :610-620
@@ -1400,6 +1400,353 @@ static void worker(Shared *sh)
     sh->ct.ext_steps += ct.ext_steps; sh->ct.sa_hits += ct.sa_hits; sh->ct.lf_steps += ct.lf_steps;
     sh->ct.dp_calls += ct.dp_calls; sh->ct.dp_cells += ct.dp_cells;
 }
+
+
+// ---- variant calling (VariantCalling.cpp) -------------------------------------------------------
+struct VcfOpts {
+    int ploidy = 2, min_ad = 5, min_cnv = 50, min_gap = 50, frag_size = 500; // main.cpp:157-187
+    bool filter = false, gvcf = false, mono = false, somatic = false;
+    float freq_thr = 0.2f;
+    std::string sample = "unknown", ref_name, cmdline;
+};
+
+struct Variant { // Variant_t, structure.h:185-195; one object is reused by the scan, stale fields included
+    uint16_t DP = 0; i64 gPos = 0; std::string alt; uint16_t AD_ref = 0, AD_alt = 0; uint8_t geno = 0, qscore = 0, type = 0;
+};
+enum { vSUB = 0, vINS = 1, vDEL = 2, vINV = 3, vTNL = 4, vCNV = 5, vUMR = 6, vNOR = 10, vMON = 11 };
+
+struct Caller {
+    const Index &ix; Profile &pf; const VcfOpts &o;
+    u32 avg_rlen; int frag_size;
+    std::vector<int> depth; // BlockDepthArr
+    std::vector<Variant> vars;
+    Caller(const Index &i, Profile &p, const VcfOpts &oo, u32 rl, int fs) : ix(i), pf(p), o(oo), avg_rlen(rl), frag_size(fs) {}
+
+    int cov(i64 g) { return g >= 0 && g < ix.G ? pf.at(g, 0) + pf.at(g, 1) + pf.at(g, 2) + pf.at(g, 3) : 0; } // GetProfileColumnSize, tools.cpp:166-169
+    static uint8_t as_u8(double v) { return (uint8_t)(int)v; } // `uint8_t q = (int)(expr)` on x86-64
+    static bool by_pos(const Variant &a, const Variant &b) { return a.gPos == b.gPos ? a.type < b.type : a.gPos < b.gPos; } // CompByVarPos :50-54
+
+    // GetAreaIndFrequency :63-94
+    static int area_freq(i64 gPos, std::map<i64, std::map<std::string, uint16_t>> &m, std::string &str)
+    {
+        i64 max_pos = 0; int freq = 0, max_freq = 0;
+        str.clear();
+        for (auto a = m.lower_bound(gPos - 5), b = m.upper_bound(gPos + 5); a != b; ++a) {
+            if (std::llabs(a->first - gPos) > 5) continue;
+            for (auto &e : a->second) {
+                freq += e.second;
+                if (max_freq < e.second) { str = e.first; max_freq = e.second; max_pos = a->first; }
+                else if (max_freq == e.second && e.first.length() > str.length()) { str = e.first; max_pos = a->first; }
+            }
+        }
+        return gPos == max_pos ? freq : 0;
+    }
+
+    // DetermineGenotype :528-547
+    uint8_t genotype(int cv, int alt_reads, int alt_num)
+    {
+        if (o.ploidy == 1) return alt_reads < (int)(cv * 0.5) ? 1 : 2;
+        if (o.ploidy == 2) {
+            if (alt_num == 0) return 3;
+            if (alt_num == 1) return alt_reads < (int)(cv * 0.5) ? 4 : 5;
+            if (alt_num == 2) return 6;
+        }
+        return 0;
+    }
+
+    uint16_t ref_count(int base, i64 g) { return base < 4 ? pf.at(g, base) : 0; } // GetRefCount :516-526
+
+    void block_depth() // CalBlockReadDepth :105-121, VariantCalling() :708-711
+    {
+        i64 nb = ix.G / 100; if (nb * 100 < ix.G) nb++;
+        depth.assign((size_t)nb, 0);
+        for (i64 b = 0; b < nb; b++) {
+            i64 e = std::min<i64>(b * 100 + 100, ix.G); int sum = 0;
+            for (i64 g = b * 100; g < e; g++) sum += cov(g);
+            if (sum > 0) depth[b] = sum / 100;
+        }
+    }
+
+    void scan() // IdentifyVariants :549-680 (one thread: VariantCalling() sets iThreadNum = 1, :717)
+    {
+        Variant v; std::string ins_str, del_str;
+        std::vector<std::pair<char, int>> vec;
+        int gap = 0, dup = 0;
+        for (i64 g = 0; g < ix.G; g++) {
+            const int cv = cov(g);
+            bool normal = true;
+            const int rb = g_nt4[(uint8_t)ix.ref[g]];
+            int cov_thr = depth[g / 100] >> 1; if (cov_thr < o.min_ad) cov_thr = o.min_ad;
+            if (o.somatic && cov_thr > o.min_ad) cov_thr = o.min_ad;
+            int ins_thr = (int)(cov_thr * 0.25); if (ins_thr < o.min_ad) ins_thr = o.min_ad;
+            int del_thr = (int)(cov_thr * 0.35); if (del_thr < o.min_ad) del_thr = o.min_ad;
+            const int ins_freq = area_freq(g, pf.ins, ins_str), del_freq = area_freq(g, pf.del, del_str);
+            if (ins_freq >= ins_thr) {
+                v.gPos = g; v.type = vINS; v.DP = (uint16_t)depth[g / 100]; v.AD_alt = (uint16_t)ins_freq;
+                if (v.DP < v.AD_alt) v.DP = v.AD_alt;
+                v.alt = ins_str; v.AD_ref = v.DP - v.AD_alt; v.geno = genotype(v.DP, v.AD_alt, 1);
+                v.qscore = cv == 0 ? 0 : as_u8(100.0 * v.AD_alt / cv); // x/0 -> inf -> INT_MIN -> low byte 0
+                normal = false; vars.push_back(v);
+            }
+            if (del_freq >= del_thr) {
+                v.gPos = g; v.type = vDEL; v.DP = (uint16_t)depth[g / 100]; v.AD_alt = (uint16_t)del_freq;
+                if (v.DP < v.AD_alt) v.DP = v.AD_alt;
+                v.alt = del_str; v.AD_ref = v.DP - v.AD_alt; v.geno = genotype(v.DP, v.AD_alt, 1);
+                v.qscore = cv == 0 ? 0 : as_u8(100.0 * v.AD_alt / cv);
+                normal = false; vars.push_back(v);
+            }
+            if (cv >= cov_thr) {
+                vec.clear();
+                int freq_thr = (int)ceil(cv * (o.somatic ? 0.01 : (double)o.freq_thr)); // float FrequencyThr widened by ?: (:593)
+                if (freq_thr < o.min_ad) freq_thr = o.min_ad;
+                for (int k = 0; k < 4; k++) if (rb != k && (int)pf.at(g, k) >= freq_thr) vec.push_back(std::make_pair("ACGT"[k], (int)pf.at(g, k)));
+                v.AD_ref = ref_count(rb, g);
+                if (vec.size() == 1) {
+                    v.gPos = g; v.type = vSUB; v.DP = (uint16_t)cv; v.AD_alt = (uint16_t)vec[0].second;
+                    if ((v.geno = genotype(cv, v.AD_alt, 1)) != 0) {
+                        v.alt = std::string(1, vec[0].first);
+                        v.qscore = o.somatic ? as_u8(35.0 * v.AD_alt / (cv * 0.05)) : as_u8(35.0 * v.AD_alt / cv);
+                        normal = false; vars.push_back(v);
+                    }
+                } else if (vec.size() == 2 && vec[0].second + vec[1].second >= (int)(cv * 0.5)) { // CheckDiploidFrequency :123-128
+                    v.gPos = g; v.type = vSUB; v.DP = (uint16_t)cv; v.AD_alt = (uint16_t)(vec[0].second + vec[1].second);
+                    if ((v.geno = genotype(cv, v.AD_alt, 2)) != 0) {
+                        v.alt = std::string(1, vec[0].first) + "," + std::string(1, vec[1].first);
+                        v.qscore = o.somatic ? as_u8(35.0 * v.AD_alt / (cv * 0.05)) : as_u8(35.0 * v.AD_alt / cv);
+                        normal = false; vars.push_back(v);
+                    }
+                }
+            }
+            const int multi = pf.at(g, 4);
+            if (cv == 0 && multi == 0) { normal = false; gap++; }
+            else if (gap > 0) {
+                if (gap >= o.min_gap) { v.type = vUMR; v.gPos = g - gap; v.DP = (uint16_t)gap; vars.push_back(v); }
+                gap = 0;
+            }
+            if (cv == 0 && multi > 0) { normal = false; dup++; }
+            else if (dup > 0) {
+                if (dup > o.min_cnv) { v.type = vCNV; v.gPos = g - dup; v.DP = (uint16_t)dup; vars.push_back(v); }
+                dup = 0;
+            }
+            if (o.gvcf && normal && cv > 0) {
+                if (vars.empty() || vars.back().type != vNOR) { v.qscore = 0; v.gPos = g; v.type = vNOR; v.DP = v.AD_alt = (uint16_t)cv; v.alt.clear(); vars.push_back(v); }
+                else if (vars.back().AD_alt > cv) vars.back().AD_alt = (uint16_t)cv;
+            }
+            if (o.mono && normal && cv > 0) {
+                v.qscore = 0; v.gPos = g; v.type = vMON; v.DP = (uint16_t)cv; v.geno = genotype(cv, 0, 0); v.alt.clear();
+                v.AD_ref = ref_count(rb, g);
+                vars.push_back(v);
+            }
+        }
+        std::stable_sort(vars.begin(), vars.end(), by_pos); // no two entries share (gPos, type), so any sort agrees with :672
+    }
+
+    void drop_consecutive_nor() // RemoveConsecutiveGenomicVariant :682-694 (its iterator walk skips one comparison after an erase)
+    {
+        if (vars.size() < 2) return; // the reference would read past the end here
+        size_t i = 0, n = 1;
+        while (n < vars.size()) {
+            if (vars[i].type == vNOR && vars[n].type == vNOR) {
+                vars.erase(vars.begin() + n); i = n; n = i + 1;
+                if (i >= vars.size()) break; // (undefined in the reference: erased the last element)
+            }
+            i++; n++;
+        }
+    }
+
+    int region_cov(i64 b, i64 e) // CalRegionCov :197-208
+    {
+        if (b < 0) b = 0;
+        if (e > ix.G) e = ix.G - 1;
+        if (e < b) return 0;
+        i64 c = 0;
+        for (i64 g = b; g <= e; g++) c += cov(g); // (e == G reads one record past the array in the reference; counted as 0 here)
+        return (int)(c / (e - b + 1));
+    }
+
+    std::vector<i64> bp_cands; // IdentifyBreakPointCandidates :173-195
+    void breakpoints()
+    {
+        pf.brk.insert(std::make_pair(ix.G2, (uint16_t)0));
+        u32 total = 0; std::pair<i64, uint16_t> p(0, 0);
+        for (auto &e : pf.brk) {
+            if (e.first - p.first > (i64)avg_rlen) {
+                if (total >= 3) bp_cands.push_back(p.first);
+                p.first = e.first; total = p.second = e.second;
+            } else {
+                total += e.second;
+                if (p.second < e.second) { p.first = e.first; p.second = e.second; }
+            }
+        }
+    }
+
+    // longest run of distance classes (dist / 1000) that differ by at most one between neighbours
+    static u32 run_score(std::vector<i64> &vec, i64 sentinel)
+    {
+        std::sort(vec.begin(), vec.end()); vec.push_back(sentinel);
+        u32 best = 0, score = 1;
+        for (size_t j = 1; j < vec.size(); j++) {
+            if (vec[j] - vec[j - 1] > 1) { if (score > best) best = score; score = 1; }
+            else score++;
+        }
+        return best;
+    }
+
+    // IdentifyInversions :276-340 / IdentifyTranslocations :210-274 (the same procedure on the two site lists)
+    void discordant(const std::vector<Discord> &sites, int type)
+    {
+        auto lower = [&](i64 g) { return std::lower_bound(sites.begin(), sites.end(), g, [](const Discord &d, i64 x) { return d.gPos < x; }); };
+        auto upper = [&](i64 g) { return std::upper_bound(sites.begin(), sites.end(), g, [](i64 x, const Discord &d) { return x < d.gPos; }); };
+        std::vector<Variant> found;
+        std::vector<i64> vec;
+        for (i64 g : bp_cands) {
+            const u32 lcov = (u32)region_cov(g - frag_size, g - (avg_rlen >> 1));
+            const u32 cov_thr = (u32)(depth[(int)(g / 100)] >> 1);
+            auto i1 = lower(g - frag_size), i2 = lower(g - (i64)(avg_rlen >> 1));
+            if (i1 == sites.end() || i2 == sites.end()) continue;
+            vec.clear(); for (; i1 != i2; ++i1) vec.push_back(i1->dist / 1000);
+            const u32 ls = run_score(vec, ix.G2);
+            if (ls < cov_thr || ls < (u32)(int)(lcov * 0.5)) continue;
+            const u32 rcov = (u32)region_cov(g, g + frag_size);
+            i1 = upper(g); i2 = lower(g + frag_size);
+            if (i1 == sites.end() || i2 == sites.end()) continue;
+            vec.clear(); for (; i1 != i2; ++i1) vec.push_back(i1->dist / 1000);
+            const u32 rs = run_score(vec, ix.G2);
+            if (rs < cov_thr || rs < (u32)(int)(rcov * 0.5)) continue;
+            if (ls > 0 && rs > 0) { Variant v; v.gPos = g; v.type = (uint8_t)type; v.DP = (uint16_t)cov(g); v.AD_alt = (uint16_t)std::max(ls, rs); found.push_back(v); }
+        }
+        if (!found.empty()) { // inplace_merge :273 / :339
+            size_t mid = vars.size();
+            vars.insert(vars.end(), found.begin(), found.end());
+            std::inplace_merge(vars.begin(), vars.begin() + mid, vars.end(), by_pos);
+        }
+    }
+
+    bool nearby(int i, int dist) // CheckNearbyVariant :342-358
+    {
+        const int n = (int)vars.size();
+        if (n < 2) return false; // (the reference reads VariantVec[1] of a one-element vector)
+        if (i == 0) return vars[1].gPos - vars[0].gPos <= dist;
+        if (i == n - 1) return vars[i].gPos - vars[i - 1].gPos <= dist;
+        return vars[i + 1].gPos - vars[i].gPos <= dist || vars[i].gPos - vars[i - 1].gPos <= dist;
+    }
+
+    bool bad_haplotype(int i, int dist) // CheckBadHaplotype :360-388
+    {
+        bool r = false; const int n = (int)vars.size();
+        for (int j = i + 1; j < n; j++) {
+            if (vars[j].gPos - vars[i].gPos > dist) break;
+            if (vars[j].type == 0) {
+                int diff = std::abs((int)vars[i].AD_alt - (int)vars[j].AD_alt);
+                if (diff > 5 && (vars[i].AD_alt > vars[j].AD_alt ? vars[i].AD_alt >> 2 : vars[j].AD_alt >> 2)) r = true;
+                break;
+            }
+        }
+        for (int j = i - 1; j >= 0; j--) {
+            if (vars[i].gPos - vars[j].gPos > dist) break;
+            if (vars[j].type == 0) {
+                int diff = std::abs((int)vars[i].AD_alt - (int)vars[j].AD_alt);
+                if (diff > 10 && (vars[i].AD_alt > vars[j].AD_alt ? (int)(vars[i].AD_alt * 0.33) : (int)(vars[j].AD_alt * 0.33))) r = true;
+                break;
+            }
+        }
+        return r;
+    }
+
+    std::string filter_of(int i) // DetermineFileter :404-427
+    {
+        const Variant &v = vars[i]; std::string f;
+        if (v.qscore < 10) f += "q10;";
+        else if (v.type == vSUB && v.AD_alt < 10 && nearby(i, 10)) f += "q10;";
+        else if ((v.type == vINS || v.type == vDEL) && v.AD_alt < 5 && nearby(i, 10)) f += "q10;";
+        if (o.filter) {
+            if ((int)pf.at(v.gPos, 4) > (int)(cov(v.gPos) * 0.05)) f += "str_contraction;";
+            if (bad_haplotype(i, 100)) f += "bad_haplotype;";
+        }
+        if (f.empty()) return "PASS";
+        f.resize(f.size() - 1);
+        return f;
+    }
+
+    bool write(const char *path) // ShowMetaInfo :140-171, GenVariantCallingFile :429-500
+    {
+        static const char *GT[] = {"*", "0", "1", "0/0", "0/1", "1/1", "1/2"};
+        FILE *f = fopen(path, "w");
+        if (!f) return false;
+        fprintf(f, "##fileformat=VCFv4.2\n##reference=%s\n##source=MapCaller 0.9.9.41\n##command_line=\"%s\"\n", o.ref_name.c_str(), o.cmdline.c_str());
+        fprintf(f, "##ALT=<ID=NON_REF,Description=\"Represents any possible alternative allele at this location\">\n");
+        fprintf(f, "##INFO=<ID=RC,Number=1,Type=Integer,Description=\"Number of reads with start coordinate at this position.\">\n");
+        fprintf(f, "##INFO=<ID=NTFREQ,Number=4,Type=Integer,Description=\"base depth\">\n");
+        fprintf(f, "##INFO=<ID=END,Number=1,Type=Integer,Description=\"Last position(inclusive) of the reported block\">\n");
+        fprintf(f, "##INFO=<ID=DP,Number=1,Type=Integer,Description=\"Read depth\">\n");
+        fprintf(f, "##INFO=<ID=TYPE,Number=A,Type=String,Description=\"The type of allele, either snv, ins, del, or BP(breakpoint).\">\n");
+        fprintf(f, "##FORMAT=<ID=AD,Number=R,Type=Integer,Description=\"Allelic depths for the ref and alt alleles in the order listed\">\n");
+        fprintf(f, "##FORMAT=<ID=DP,Number=1,Type=Integer,Description=\"Approximate read depth\">\n");
+        fprintf(f, "##FORMAT=<ID=AF,Number=A,Type=Float,Description=\"Allele fractions of alternate alleles\">\n");
+        fprintf(f, "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n");
+        fprintf(f, "##FORMAT=<ID=PL,Number=G,Type=Integer,Description=\"Normalized, Phred - scaled likelihoods for genotypes as defined in the VCF specification\">\n");
+        if (o.gvcf) fprintf(f, "##FORMAT=<ID=MIN_DP,Number=1,Type=Integer,Description=\"Minimum depth in gVCF output block.\">\n");
+        fprintf(f, "##FORMAT=<ID=F1R2,Number=R,Type=Integer,Description=\"Count of reads in F1R2 pair orientation supporting each allele\">\n");
+        fprintf(f, "##FORMAT=<ID=F2R1,Number=R,Type=Integer,Description=\"Count of reads in F2R1 pair orientation supporting each allele\">\n");
+        fprintf(f, "##FORMAT=<ID=GQ,Number=1,Type=Integer,Description=\"Genotype Quality\">\n");
+        fprintf(f, "##FILTER=<ID=PASS,Description=\"All filters passed\">\n");
+        fprintf(f, "##FILTER=<ID=REF,Description=\"Genotyping model thinks this site is reference.\">\n");
+        fprintf(f, "##FILTER=<ID=BreakPoint,Description=\"It is predicted as a breakpoint\">\n");
+        fprintf(f, "##FILTER=<ID=DUP,Description=\"Duplicated regions(>=%dbp).\">\n", o.min_cnv);
+        fprintf(f, "##FILTER=<ID=Gaps,Description=\"Region without any read alignment(>=%dbp).\">\n", o.min_gap);
+        fprintf(f, "##FILTER=<ID=q10,Description=\"Confidence score below 10\">\n");
+        if (o.filter) fprintf(f, "##FILTER=<ID=bad_haplotype,Description=\"Variants with variable frequencies on same haplotype\">\n");
+        if (o.filter) fprintf(f, "##FILTER=<ID=str_contraction,Description=\"Variant appears in repetitive region\">\n");
+        for (const Chrom &c : ix.chr) fprintf(f, "##contig=<ID=%s,length=%d>\n", c.name.c_str(), c.len);
+        fprintf(f, "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n", o.sample.c_str());
+        const int n = (int)vars.size();
+        for (int i = 0; i < n; i++) {
+            const Variant &v = vars[i];
+            const i64 g = v.gPos;
+            const Coord co = to_coord(ix, g);
+            const char *chr = ix.chr[co.chr].name.c_str();
+            const char rc = ix.ref[g];
+            const std::string flt = v.type < 3 ? filter_of(i) : ".";
+            const float af = (float)(1.0 * v.AD_alt / v.DP);
+            const int F1 = pf.at(g, 6), R2 = pf.at(g, 7), F2 = pf.at(g, 8), R1 = pf.at(g, 9), RC = pf.at(g, 5);
+            if (v.type == vSUB)
+                fprintf(f, "%s\t%d\t.\t%c\t%s\t%d\t%s\tRC=%d;NTFREQ=%d,%d,%d,%d;TYPE=snv\tGT:GQ:DP:AD:AF:F1R2:F2R1\t%s:%d:%d:%d,%d:%.2f:%d,%d:%d,%d\n", chr, (int)co.pos, rc, v.alt.c_str(), v.qscore, flt.c_str(),
+                        RC, (int)pf.at(g, 0), (int)pf.at(g, 1), (int)pf.at(g, 2), (int)pf.at(g, 3), GT[v.geno], v.qscore, v.DP, v.AD_ref, v.AD_alt, af, F1, R2, F2, R1);
+            else if (v.type == vINS) {
+                if (v.alt.length() > 5) continue;
+                fprintf(f, "%s\t%d\t.\t%c\t%c%s\t%d\t%s\tRC=%d;TYPE=ins\tGT:GQ:DP:AD:AF:F1R2:F2R1\t%s:%d:%d:%d,%d:%.2f:%d,%d:%d,%d\n", chr, (int)co.pos, rc, rc, v.alt.c_str(), v.qscore, flt.c_str(),
+                        RC, GT[v.geno], v.qscore, v.DP, v.AD_ref, v.AD_alt, af, F1, R2, F2, R1);
+            } else if (v.type == vDEL) {
+                if (v.alt.length() > 5) continue;
+                fprintf(f, "%s\t%d\t.\t%c%s\t%c\t%d\t%s\tRC=%d;TYPE=del\tGT:GQ:DP:AD:AF:F1R2:F2R1\t%s:%d:%d:%d,%d:%.2f:%d,%d:%d,%d\n", chr, (int)co.pos, rc, v.alt.c_str(), rc, v.qscore, flt.c_str(),
+                        RC, GT[v.geno], v.qscore, v.DP, v.AD_ref, v.AD_alt, af, F1, R2, F2, R1);
+            } else if (v.type == vTNL) fprintf(f, "%s\t%d\t.\t%c\t<TNL>\t30\tBreakPoint\tTYPE=BP\tGT:GQ:DP:AD\t.:.:0:.\n", chr, (int)co.pos, rc);
+            else if (v.type == vINV) fprintf(f, "%s\t%d\t.\t%c\t<INV>\t30\tBreakPoint\tTYPE=BP\tGT:GQ:DP:AD\t.:.:0:.\n", chr, (int)co.pos, rc);
+            else if (v.type == vCNV) { if (v.DP >= o.min_cnv) fprintf(f, "%s\t%d\t.\t%c\t<*>\t0\tDUP\tEND=%d\tGT:GQ:DP:AD\t.:.:0:.\n", chr, (int)co.pos, rc, (int)(co.pos + v.DP - 1)); }
+            else if (v.type == vUMR) { if (v.DP >= o.min_gap) fprintf(f, "%s\t%d\t.\t%c\t<*>\t0\tGaps\tEND=%d\tGT:GQ:DP:AD\t.:.:0:.\n", chr, (int)co.pos, rc, (int)(co.pos + v.DP - 1)); }
+            else if (v.type == vNOR) {
+                i64 ge = ix.chr[co.chr].fwd_off + ix.chr[co.chr].len - 1;
+                if (i + 1 < n && vars[i + 1].gPos < ge) ge = vars[i + 1].gPos - 1;
+                fprintf(f, "%s\t%d\t.\t%c\t<*>\t0\tREF\tEND=%d;DP=%d;MIN_DP=%d\tGT:GQ:DP:AD\t.:.:0:.\n", chr, (int)co.pos, rc, (int)to_coord(ix, ge).pos, v.DP, v.AD_alt);
+            } else if (v.type == vMON)
+                fprintf(f, "%s\t%d\t.\t%c\t.\t0\tREF\tDP=%d;RC=%d;NTFREQ=%d,%d,%d,%d\tGT:F1R2:F2R1\t%s:%d,%d:%d,%d\n", chr, (int)co.pos, rc, v.DP, RC,
+                        (int)pf.at(g, 0), (int)pf.at(g, 1), (int)pf.at(g, 2), (int)pf.at(g, 3), GT[v.geno], F1, R2, F2, R1);
+        }
+        fclose(f);
+        return true;
+    }
+
+    bool run(const char *path) // VariantCalling() :696-740
+    {
+        block_depth();
+        scan();
+        if (o.gvcf) drop_consecutive_nor();
+        breakpoints();
+        if (!bp_cands.empty() && !pf.inv.empty()) discordant(pf.inv, vINV);
+        if (!bp_cands.empty() && !pf.tnl.empty()) discordant(pf.tnl, vTNL);
+        return write(path);
+    }
+};
 
 } // namespace
 
@@ -1461,7 +1808,7 @@ int mcxo_ksw2_extz(const uint8_t *q, int qlen, const uint8_t *t, int tlen, int *
 }
 
 static int64_t map_files_impl(const mcxo_index *ix, const char *fq1, const char *fq2, int alg, const char *sam_path,
-                              int threads, int64_t *stats, Profile *pf);
+                              int threads, int64_t *stats, Profile *pf, int64_t *pair_stats = nullptr);
 
 int64_t mcxo_map_files(const mcxo_index *ix, const char *fq1, const char *fq2, int alg, const char *sam_path,
                        int threads, int64_t *stats)
@@ -1499,8 +1846,47 @@ int64_t mcxo_map_files_profile(const mcxo_index *ix, const char *fq1, const char
     return n;
 }
 
+void mcxo_vcf_defaults(mcxo_vcf_opts *o)
+{
+    memset(o, 0, sizeof *o);
+    o->ploidy = 2; o->min_allele_depth = 5; o->min_cnv = 50; o->min_gap = 50; o->fragment_size = 500;
+    o->max_dup = 5; o->max_clip = 5; o->freq_thr = 0.2f; o->sample_id = "unknown";
+}
+
+// MapCaller -i <prefix> -f fq1 [-f2 fq2] -alg .. -vcf <vcf> -t 1: Mapping() then VariantCalling()
+int64_t mcxo_map_files_vcf(const mcxo_index *ix, const char *fq1, const char *fq2, int alg, const char *vcf_path, const mcxo_vcf_opts *vo)
+{
+    VcfOpts o;
+    if (vo) {
+        o.ploidy = vo->ploidy; o.min_ad = vo->min_allele_depth; o.min_cnv = vo->min_cnv; o.min_gap = vo->min_gap; o.frag_size = vo->fragment_size;
+        o.filter = vo->filter != 0; o.gvcf = vo->gvcf != 0 && !vo->monomorphic; o.mono = vo->monomorphic != 0; o.somatic = vo->somatic != 0; // main.cpp:322
+        o.freq_thr = vo->freq_thr;
+        if (vo->sample_id) o.sample = vo->sample_id;
+        if (vo->ref_name) o.ref_name = vo->ref_name;
+        if (vo->cmdline) o.cmdline = vo->cmdline;
+    }
+    Profile pf;
+    pf.init(ix->G);
+    if (vo) { pf.max_dup = (vo->max_dup <= 0 || vo->max_dup > 15) ? 15 : vo->max_dup; pf.max_clip = vo->max_clip; } // main.cpp:240-244, :323
+    int64_t ps[3] = {0, 0, 0};
+    int64_t n = map_files_impl(ix, fq1, fq2, alg, nullptr, 1, nullptr, &pf, ps);
+    if (n < 0) return n;
+    auto by_pos = [](const Discord &x, const Discord &y) { return x.gPos < y.gPos; };
+    std::stable_sort(pf.inv.begin(), pf.inv.end(), by_pos);
+    std::stable_sort(pf.tnl.begin(), pf.tnl.end(), by_pos);
+    u32 avg_rlen = 0; int frag = o.frag_size;
+    if (n > 0 && ps[0] > 0) { // ReadMapping.cpp:782-790
+        const u32 avg_dist = (u32)(int)(1. * ps[1] / ps[0] + .5);
+        avg_rlen = (u32)(int)(1. * ps[2] / (ps[0] << 1) + .5);
+        frag = (int)(avg_dist + avg_rlen);
+    }
+    Caller c(*ix, pf, o, avg_rlen, frag);
+    if (!c.run(vcf_path)) return -2;
+    return n;
+}
+
 static int64_t map_files_impl(const mcxo_index *ix, const char *fq1, const char *fq2, int alg, const char *sam_path,
-                              int threads, int64_t *stats, Profile *pf)
+                              int threads, int64_t *stats, Profile *pf, int64_t *pair_stats)
 {
     init_nt4();
     Shared sh;
@@ -1529,6 +1915,7 @@ static int64_t map_files_impl(const mcxo_index *ix, const char *fq1, const char 
         stats[3] = sh.ct.ext_steps; stats[4] = sh.ct.sa_hits; stats[5] = sh.ct.lf_steps;
         stats[6] = sh.ct.dp_calls; stats[7] = sh.ct.dp_cells;
     }
+    if (pair_stats) { pair_stats[0] = sh.n_paired; pair_stats[1] = sh.dist_sum; pair_stats[2] = sh.len_sum; }
     return sh.n_reads;
 }
 

@@ -49,6 +49,20 @@ int64_t mcxo_map_files(const mcxo_index *, const char *fq1, const char *fq2, int
 // writes <out>.prof and <out>.maps in the format of oracle/_ref/mcref_tool's P command.
 int64_t mcxo_map_files_profile(const mcxo_index *, const char *fq1, const char *fq2, int alg, const char *out_prefix);
 
+// The same run followed by VariantCalling() (reference src/VariantCalling.cpp:696-740): writes the VCF
+// of `MapCaller ... -vcf <vcf_path> -t 1`.  Option fields carry the reference's defaults when
+// filled by mcxo_vcf_defaults (src/main.cpp:157-187).  The ##reference and ##command_line header
+// lines hold whatever ref_name / cmdline say.
+typedef struct mcxo_vcf_opts {
+    int ploidy, min_allele_depth, min_cnv, min_gap, fragment_size; // -ploidy -ad -min_cnv -min_gap -size
+    int filter, gvcf, monomorphic, somatic;                        // -filter -gvcf -monomorphic -somatic
+    int max_dup, max_clip;                                         // -dup -maxclip
+    float freq_thr;                                                // FrequencyThr (0.2, no option)
+    const char *sample_id, *ref_name, *cmdline;                    // -id
+} mcxo_vcf_opts;
+void mcxo_vcf_defaults(mcxo_vcf_opts *);
+int64_t mcxo_map_files_vcf(const mcxo_index *, const char *fq1, const char *fq2, int alg, const char *vcf_path, const mcxo_vcf_opts *);
+
 #ifdef __cplusplus
 }
 #endif

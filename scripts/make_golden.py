@@ -49,7 +49,7 @@ def gz_write(path, data: bytes):
             fh.write(data)
 
 
-def make_set(name, fasta, donor, n, rlen, paired, seed, fastq=True, profile_alg=None, **kw):
+def make_set(name, fasta, donor, n, rlen, paired, seed, fastq=True, profile_alg=None, vcf_runs=(), **kw):
     out = os.path.join(GOLD, name)
     os.makedirs(out, exist_ok=True)
     with tempfile.TemporaryDirectory() as tmp:
@@ -87,6 +87,12 @@ def make_set(name, fasta, donor, n, rlen, paired, seed, fastq=True, profile_alg=
             assert reply[-1] == "ok", reply
             gz_write(os.path.join(out, f"ref.{profile_alg}.prof.gz"), open(f"{tmp}/prof.prof", "rb").read())
             gz_write(os.path.join(out, f"ref.{profile_alg}.maps.gz"), open(f"{tmp}/prof.maps", "rb").read())
+        for tag, alg, extra in vcf_runs:
+            # the whole -vcf surface: Mapping() + VariantCalling(); the two header lines that hold paths are dropped
+            vcf = os.path.join(tmp, f"{tag}.vcf")
+            sh(REF_BIN, "-i", prefix, *files, "-alg", alg, "-vcf", vcf, "-t", "1", "-log", os.path.join(tmp, "job.log"), *extra)
+            keep = [l for l in open(vcf, "rb").read().split(b"\n") if not l.startswith((b"##command_line=", b"##reference="))]
+            gz_write(os.path.join(out, f"ref.vcf.{tag}.gz"), b"\n".join(keep))
     print("set", name, "done")
 
 
@@ -181,18 +187,29 @@ def main():
     os.makedirs(os.path.join(GOLD, "func"), exist_ok=True)
     mut = synth.read_fasta("/root/reference/test/mut.fa")
     make_set("toy", "/root/reference/test/ref.fa", mut, 1500, 150, True, seed=7,
-             frag_mean=500, frag_sd=87, frag_min=350, frag_max=650, profile_alg="ksw2")
+             frag_mean=500, frag_sd=87, frag_min=350, frag_max=650, profile_alg="ksw2", vcf_runs=[("default", "ksw2", [])])
     with tempfile.TemporaryDirectory() as tmp:
         g = synth.random_genome([160000, 120000, 90000], seed=11, n_repeats=25, repeat_len=600, tandem=12, n_runs=8)
         fa = os.path.join(tmp, "mc.fa")
         synth.write_fasta(fa, g)
         donor = synth.mutate_genome(g, 12)
-        make_set("mc", fa, donor, 2000, 150, True, seed=13, sub=0.01, profile_alg="nw")
-        make_set("se", fa, donor, 2000, 100, False, seed=14, fastq=False, n_rate=0.002, profile_alg="ksw2")
+        make_set("mc", fa, donor, 2000, 150, True, seed=13, sub=0.01, profile_alg="nw", vcf_runs=[("default", "nw", [])])
+        make_set("se", fa, donor, 2000, 100, False, seed=14, fastq=False, n_rate=0.002, profile_alg="ksw2", vcf_runs=[("default", "ksw2", [])])
         g2 = synth.random_genome([150000, 150000], seed=21, n_repeats=8, tandem=4)
         fa2 = os.path.join(tmp, "long.fa")
         synth.write_fasta(fa2, g2)
-        make_set("long", fa2, synth.mutate_genome(g2, 22), 600, 250, True, seed=23, sub=0.01, ins=0.01, dele=0.01, profile_alg="ksw2")
+        make_set("long", fa2, synth.mutate_genome(g2, 22), 600, 250, True, seed=23, sub=0.01, ins=0.01, dele=0.01, profile_alg="ksw2",
+                 vcf_runs=[("default", "ksw2", [])])
+        # the -vcf surface: SNVs (homozygous and heterozygous), short indels, one inversion, one moved segment, ~30x
+        g3 = synth.random_genome([60000, 40000], seed=31, n_repeats=6, repeat_len=500, tandem=3)
+        fa3 = os.path.join(tmp, "var.fa")
+        synth.write_fasta(fa3, g3)
+        donor3 = synth.structural_donor(g3, 32)
+        make_set("var", fa3, donor3, 10000, 150, True, seed=33, skip_contigs=(0, 2), profile_alg="ksw2",
+                 frag_mean=700, frag_sd=40, frag_min=500, frag_max=900,
+                 vcf_runs=[("default", "ksw2", []), ("nw", "nw", []), ("gvcf", "ksw2", ["-gvcf"]), ("mono", "ksw2", ["-monomorphic"]),
+                           ("filter", "ksw2", ["-filter"]), ("ploidy1", "ksw2", ["-ploidy", "1"]), ("somatic", "ksw2", ["-somatic"]),
+                           ("opts", "ksw2", ["-ad", "3", "-min_gap", "20", "-min_cnv", "20", "-size", "400", "-dup", "3", "-maxclip", "10", "-id", "s1"])])
     make_func_vectors()
     torch.manual_seed(0)
 

@@ -5,7 +5,7 @@ import os
 
 import pytest
 
-from conftest import GOLD, SETS, sam_diff
+from conftest import GOLD, SETS, VCF_CASES, VCF_RUNS, VcfOpts, maps_canon, sam_diff, vcf_alg, vcf_body
 
 
 @pytest.mark.parametrize("alg", ["nw", "ksw2"])
@@ -67,4 +67,19 @@ def test_oracle_profile_equals_reference(oracle_lib, golden, tmp_path, name):
     oracle_lib.mcxo_index_free(ix)
     assert n > 0
     assert open(out + ".prof", "rb").read() == open(prof, "rb").read()
-    assert open(out + ".maps", "rb").read() == open(maps, "rb").read()
+    assert maps_canon(open(out + ".maps", encoding="latin-1").read()) == maps_canon(open(maps, encoding="latin-1").read())
+
+
+@pytest.mark.parametrize("name,tag", VCF_CASES)
+def test_oracle_vcf_equals_reference(oracle_lib, golden, tmp_path, name, tag):
+    """VariantCalling() restated (reference src/VariantCalling.cpp): the VCF of `MapCaller -vcf -t 1`
+    line for line — SNVs, indels, gaps, duplicated regions, <INV>/<TNL> break points, and the
+    -gvcf / -monomorphic / -filter / -ploidy / -somatic / threshold switches."""
+    g = golden[name]
+    ix = oracle_lib.mcxo_index_load(g["prefix"].encode())
+    out = str(tmp_path / "o.vcf")
+    opts = VcfOpts(VCF_RUNS[tag][1])
+    n = oracle_lib.mcxo_map_files_vcf(ix, g["r1"].encode(), (g["r2"] or "").encode(), 0 if vcf_alg(name, tag) == "nw" else 1, out.encode(), opts.ref)
+    oracle_lib.mcxo_index_free(ix)
+    assert n > 0
+    assert vcf_body(out) == vcf_body(g["vcf"][tag])
