@@ -102,6 +102,7 @@ typedef struct mcx_aln {
 
 typedef struct mcx_stats {
     int64_t reads, mapped, pairs, pair_dist_sum;
+    int64_t pair_len_sum;   /* ReadLengthSum: bases of the reads counted in `pairs` (ReadMapping.cpp:529-530) */
     int64_t fm_ext_steps;   /* E of SURVEY.md §8d: sum of BWT_Search lengths */
     int64_t fm_blocks;      /* 64-byte blocks the extension walk touched */
     int64_t sa_hits;        /* H: suffix-array hits resolved */
@@ -148,6 +149,39 @@ typedef struct mcx_sparse_rec {
 int mcx_profile_attach(mcx_ctx *, uint32_t *d_planes, int max_dup, int max_clip);
 int mcx_profile_finalize(mcx_ctx *, uint32_t *d_planes);
 int mcx_profile_sparse(mcx_ctx *, const mcx_sparse_rec **recs, uint64_t *n);
+
+/* Device storage for the ten planes of one genome (zero-initialised); free with mcx_planes_free. */
+int mcx_planes_alloc(const mcx_index *, uint32_t **d_planes);
+void mcx_planes_free(uint32_t *d_planes);
+
+/* ---- variant calling ---------------------------------------------------------------------------
+ * Replaces VariantCalling() (reference src/VariantCalling.cpp:696-740; called from src/main.cpp:379
+ * after Mapping()): block read depth (CalBlockReadDepth :105-121), the per-position scan for
+ * SNVs / unmapped gaps / duplicated regions / gVCF and monomorphic records (IdentifyVariants
+ * :549-680), indel calls from the insert / delete tallies (GetAreaIndFrequency :63-94), break-point
+ * candidates and <INV>/<TNL> calls (:173-340), filters and the VCF text (:404-500).
+ * The dense work runs on the GPU over the finalized planes; the sparse tallies are host maps.
+ * d_planes: the array given to mcx_profile_attach, after mcx_profile_finalize (and, on several
+ * GPUs, after the all-reduce).  recs: every record mcx_profile_sparse returned (all ranks, any
+ * order).  paired_pairs / pair_dist_sum / pair_len_sum: totals of mcx_stats over the run
+ * (iTotalPairedNum, TotalPairedDistance, ReadLengthSum; src/ReadMapping.cpp:782-790).
+ * Options hold the reference's switches; mcx_vcf_defaults fills src/main.cpp:157-187's values. */
+typedef struct mcx_vcf_opts {
+    int32_t ploidy, min_allele_depth, min_cnv, min_gap, fragment_size; /* -ploidy -ad -min_cnv -min_gap -size */
+    int32_t filter, gvcf, monomorphic, somatic;                        /* -filter -gvcf -monomorphic -somatic */
+    int32_t max_dup, max_clip;                                         /* -dup -maxclip (used by mcx_profile_attach) */
+    float freq_thr;                                                    /* FrequencyThr = 0.2 (no switch) */
+    const char *sample_id, *ref_name, *cmdline;                        /* -id; ##reference= and ##command_line= texts */
+} mcx_vcf_opts;
+typedef struct mcx_vcf_stats {
+    int64_t n_snv, n_ins, n_del, n_inv, n_tnl, n_records; /* VarNumVec (VariantCalling.cpp:730) + VCF body lines */
+    int32_t avg_read_len, fragment_size;                  /* avgReadLength, FragmentSize used for the break points */
+    double ms_depth, ms_scan, ms_total;                   /* k_vc_depth, k_vc_scan (device), whole call (wall) */
+} mcx_vcf_stats;
+void mcx_vcf_defaults(mcx_vcf_opts *);
+int mcx_call_variants(const mcx_index *, const uint32_t *d_planes, const mcx_sparse_rec *recs, uint64_t n_recs,
+                      int64_t paired_pairs, int64_t pair_dist_sum, int64_t pair_len_sum,
+                      const mcx_vcf_opts *, const char *vcf_path, mcx_vcf_stats *stats);
 
 /* ---- files: MapCaller -i <prefix> -f A [-f2 B] -alg nw|ksw2 -sam out (src/main.cpp:212-321) */
 int mcx_map_files(mcx_ctx *, const char *fq1, const char *fq2, const char *sam_path, mcx_stats *stats);

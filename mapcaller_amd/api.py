@@ -22,7 +22,8 @@ SYMBOLS = [
     "mcx_index_genome_size", "mcx_index_n_chr", "mcx_index_chr_name", "mcx_index_chr_len", "mcx_index_hbm_bytes",
     "mcx_opts_default", "mcx_ctx_create", "mcx_ctx_free", "mcx_bwt_search_batch", "mcx_extend_batch",
     "mcx_avg_init", "mcx_map_batch_dev", "mcx_map_batch", "mcx_map_files",
-    "mcx_profile_attach", "mcx_profile_finalize", "mcx_profile_sparse",
+    "mcx_profile_attach", "mcx_profile_finalize", "mcx_profile_sparse", "mcx_planes_alloc", "mcx_planes_free",
+    "mcx_vcf_defaults", "mcx_call_variants",
 ]
 
 
@@ -54,10 +55,26 @@ PLANES = ("A", "C", "G", "T", "multi_hit", "readCount", "F1", "R2", "F2", "R1")
 
 
 class Stats(C.Structure):
-    _fields_ = [(n, C.c_int64) for n in ("reads", "mapped", "pairs", "pair_dist_sum", "fm_ext_steps", "fm_blocks",
+    _fields_ = [(n, C.c_int64) for n in ("reads", "mapped", "pairs", "pair_dist_sum", "pair_len_sum", "fm_ext_steps", "fm_blocks",
                                          "sa_hits", "dp_jobs", "dp_cells", "tier1_pairs", "replayed_pairs")] + \
                [(n, C.c_double) for n in ("ms_encode", "ms_seed", "ms_sa", "ms_cluster", "ms_rescue", "ms_build",
                                           "ms_dp", "ms_finish", "ms_total")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class VcfOpts(C.Structure):
+    """mcx_vcf_opts: MapCaller's variant-calling switches (reference src/main.cpp:157-187)."""
+    _fields_ = [(n, C.c_int32) for n in ("ploidy", "min_allele_depth", "min_cnv", "min_gap", "fragment_size", "filter", "gvcf",
+                                         "monomorphic", "somatic", "max_dup", "max_clip")] + \
+               [("freq_thr", C.c_float), ("sample_id", C.c_char_p), ("ref_name", C.c_char_p), ("cmdline", C.c_char_p)]
+
+
+class VcfStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("n_snv", "n_ins", "n_del", "n_inv", "n_tnl", "n_records")] + \
+               [("avg_read_len", C.c_int32), ("fragment_size", C.c_int32)] + \
+               [(n, C.c_double) for n in ("ms_depth", "ms_scan", "ms_total")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -108,6 +125,13 @@ def lib() -> C.CDLL:
     L.mcx_profile_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.mcx_profile_finalize.argtypes = [C.c_void_p, C.c_void_p]
     L.mcx_profile_sparse.argtypes = [C.c_void_p, C.POINTER(C.POINTER(SparseRec)), C.POINTER(C.c_uint64)]
+    L.mcx_planes_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.mcx_planes_free.argtypes = [C.c_void_p]
+    L.mcx_planes_free.restype = None
+    L.mcx_vcf_defaults.argtypes = [C.POINTER(VcfOpts)]
+    L.mcx_vcf_defaults.restype = None
+    L.mcx_call_variants.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int64,
+                                    C.POINTER(VcfOpts), C.c_char_p, C.POINTER(VcfStats)]
     _lib = L
     return L
 
@@ -165,6 +189,37 @@ class Index:
         L = lib()
         return [(L.mcx_index_chr_name(self._h, i).decode(), int(L.mcx_index_chr_len(self._h, i)))
                 for i in range(L.mcx_index_n_chr(self._h))]
+
+    def call_variants(self, d_planes_ptr: int, sparse, pairs: int, pair_dist_sum: int, pair_len_sum: int, vcf_path: str,
+                      **switches) -> dict:
+        """VariantCalling() over finalized planes (reference src/VariantCalling.cpp:696-740).
+        ``sparse``: the records of Mapper.profile_sparse() (of all ranks); ``pairs`` /
+        ``pair_dist_sum`` / ``pair_len_sum``: totals of Mapper.stats.  ``switches``: fields of
+        mcx_vcf_opts (ploidy, min_allele_depth, min_cnv, min_gap, fragment_size, filter, gvcf,
+        monomorphic, somatic, sample_id, ref_name, cmdline)."""
+        o = VcfOpts()
+        lib().mcx_vcf_defaults(C.byref(o))
+        keep = []
+        for k, v in switches.items():
+            if isinstance(v, str):
+                v = v.encode()
+                keep.append(v)
+            setattr(o, k, v)
+        recs = (SparseRec * max(len(sparse), 1))()
+        for i, (t, pos, x) in enumerate(sparse):
+            r = recs[i]
+            r.pos, r.type = pos, ord(t)
+            if t in "VT":
+                r.len = 0
+                C.memmove(C.addressof(r) + 10, int(x).to_bytes(8, "little", signed=True), 8)
+            else:
+                b = x.encode("latin-1")[:54]
+                r.len = len(b)
+                C.memmove(C.addressof(r) + 10, b, len(b))
+        st = VcfStats()
+        _check(lib().mcx_call_variants(self._h, d_planes_ptr, recs, len(sparse), pairs, pair_dist_sum, pair_len_sum, C.byref(o),
+                                       vcf_path.encode(), C.byref(st)), "mcx_call_variants")
+        return st.as_dict()
 
     def close(self):
         if self._h:
@@ -247,7 +302,7 @@ class Mapper:
             if t in "VT":
                 out.append((t, int(r.pos), int.from_bytes(C.string_at(C.addressof(r) + 10, 8), "little", signed=True)))
             else:
-                out.append((t, int(r.pos), C.string_at(C.addressof(r) + 10, r.len).decode("latin-1")))
+                out.append((t, int(r.pos), C.string_at(C.addressof(r) + 10, min(r.len, 54)).decode("latin-1")))
         return out
 
     # ---- per-call drop-ins --------------------------------------------------------------

@@ -1,6 +1,7 @@
 // mapcaller_amd/csrc/mcx_main.cpp — command line with the reference's flags for the path
 // (reference src/main.cpp:154-396): MapCaller -i prefix | -r ref.fa, -f ..., -f2 ..., -alg nw|ksw2,
-// -sam out, plus `index ref.fa prefix`.  Host code only: everything heavy goes through mcx.h.
+// -sam out, -vcf out (on by default, like the reference) with the variant-calling switches, plus
+// `index ref.fa prefix`.  Host code only: everything heavy goes through mcx.h.
 #include "../../include/mcx.h"
 #include <cstdio>
 #include <cstdlib>
@@ -23,7 +24,20 @@ static void usage(const char *prog)
             "         -sam          SAM output filename ('-' = stdout)\n"
             "         -indel INT    maximal indel size [30]\n"
             "         -maxmm FLOAT  maximal mismatch rate in read alignment [0.05]\n"
-            "         -vcf / -no_vcf  variant calling is outside this path: -vcf is rejected, -no_vcf accepted\n"
+            "         -vcf          VCF output filename [output.vcf]\n"
+            "         -no_vcf       No VCF output\n"
+            "         -gvcf         GVCF mode\n"
+            "         -monomorphic  report all loci which do not have any potential alternates\n"
+            "         -ploidy INT   number of sets of chromosomes in a cell (1:monoploid, 2:diploid) [2]\n"
+            "         -size INT     sequencing fragment size [500]\n"
+            "         -ad INT       minimal ALT allele count [5]\n"
+            "         -dup INT      maximal PCR duplicates [5]\n"
+            "         -maxclip INT  maximal clip size at either ends [5]\n"
+            "         -min_cnv INT  minimal cnv size to be reported [50]\n"
+            "         -min_gap INT  minimal gap(unmapped) size to be reported [50]\n"
+            "         -filter       apply variant filters (under test)\n"
+            "         -somatic      detect somatic mutations\n"
+            "         -id STR       sample id [unknown]\n"
             "         -t INT        accepted and ignored (the GPU path has no worker threads)\n"
             "         -gpu INT      device ordinal [0]\n", prog, prog);
 }
@@ -42,7 +56,11 @@ int main(int argc, char **argv)
     mcx_opts o;
     mcx_opts_default(&o);
     int gpu = 0;
-    bool want_vcf = false, no_vcf = false;
+    bool want_vcf = true; // bVCFoutput, main.cpp:171
+    std::string vcf = "output.vcf", cmdline = argv[0];
+    mcx_vcf_opts vo;
+    mcx_vcf_defaults(&vo);
+    for (int i = 1; i < argc; i++) cmdline += std::string(" ") + argv[i];
     for (int i = 1; i < argc; i++) {
         std::string p = argv[i];
         if (p == "-i" && i + 1 < argc) prefix = argv[++i];
@@ -55,12 +73,23 @@ int main(int argc, char **argv)
         else if (p == "-maxmm" && i + 1 < argc) o.max_mismatch_rate = (float)atof(argv[++i]);
         else if (p == "-t" && i + 1 < argc) ++i;
         else if (p == "-gpu" && i + 1 < argc) gpu = atoi(argv[++i]);
-        else if (p == "-vcf" && i + 1 < argc) { ++i; want_vcf = true; }
-        else if (p == "-no_vcf") no_vcf = true;
+        else if (p == "-vcf" && i + 1 < argc) vcf = argv[++i];
+        else if (p == "-no_vcf") want_vcf = false;
+        else if (p == "-gvcf") vo.gvcf = 1;
+        else if (p == "-monomorphic") vo.monomorphic = 1;
+        else if (p == "-filter") vo.filter = 1;
+        else if (p == "-somatic") vo.somatic = 1;
+        else if (p == "-ploidy" && i + 1 < argc) { if ((vo.ploidy = atoi(argv[++i])) > 2) { vo.ploidy = 2; fprintf(stderr, "Warning! MapCaller only supports monoploid and diploid!\n"); } }
+        else if (p == "-size" && i + 1 < argc) vo.fragment_size = atoi(argv[++i]);
+        else if (p == "-ad" && i + 1 < argc) vo.min_allele_depth = atoi(argv[++i]);
+        else if (p == "-min_cnv" && i + 1 < argc) vo.min_cnv = atoi(argv[++i]);
+        else if (p == "-min_gap" && i + 1 < argc) vo.min_gap = atoi(argv[++i]);
+        else if (p == "-maxclip" && i + 1 < argc) vo.max_clip = atoi(argv[++i]);
+        else if (p == "-dup" && i + 1 < argc) { if (atoi(argv[++i]) <= 15) vo.max_dup = (int8_t)atoi(argv[i]); else fprintf(stderr, "Warning! The PCR-duplicate range is [1-15]!\n"); }
+        else if ((p == "-id" || p == "-label") && i + 1 < argc) vo.sample_id = argv[++i];
+        else if (p == "-log" && i + 1 < argc) ++i;
         else { fprintf(stderr, "Warning! Unknow parameter: %s\n", argv[i]); usage(argv[0]); return 0; }
     }
-    (void)no_vcf;
-    if (want_vcf) { fprintf(stderr, "-vcf: variant calling is not part of the accelerated path yet; run with -no_vcf\n"); return 1; }
     if (f1.empty()) { fprintf(stderr, "Warning! Please specify a valid read input!\n"); usage(argv[0]); return 0; }
     if (!f2.empty() && f1.size() != f2.size()) { fprintf(stderr, "Warning! Paired-end reads input numbers do not match!\n"); return 0; }
     std::string tmp_prefix;
@@ -80,6 +109,11 @@ int main(int argc, char **argv)
     if (rc) { fprintf(stderr, "Error! %s\n", mcx_last_error()); return 1; }
     mcx_stats st;
     memset(&st, 0, sizeof st);
+    uint32_t *planes = nullptr;
+    if (want_vcf) { // MappingRecordArr, main.cpp:366-370
+        fprintf(stderr, "Initialize the alignment profile...\n");
+        if ((rc = mcx_planes_alloc(ix, &planes)) || (rc = mcx_profile_attach(cx, planes, vo.max_dup, vo.max_clip))) { fprintf(stderr, "Error! %s\n", mcx_last_error()); return 1; }
+    }
     for (size_t k = 0; k < f1.size() && rc == 0; k++) {
         // like the reference, every library appends to the same SAM stream; only the first writes the header
         rc = mcx_map_files(cx, f1[k].c_str(), f2.empty() ? nullptr : f2[k].c_str(), sam.empty() ? nullptr : sam.c_str(), &st);
@@ -87,6 +121,21 @@ int main(int argc, char **argv)
     }
     fprintf(stderr, "All the %lld %s reads have been processed.\n%12lld reads are mapped properly.\n%12lld reads are mapped in pairs.\n",
             (long long)st.reads, f2.empty() ? "single-end" : "paired-end", (long long)st.mapped, (long long)st.pairs * 2);
+    if (want_vcf && rc == 0) { // VariantCalling(), main.cpp:379
+        const mcx_sparse_rec *recs = nullptr;
+        uint64_t n_recs = 0;
+        mcx_vcf_stats vs;
+        vo.ref_name = ref.empty() ? prefix.c_str() : ref.c_str();
+        vo.cmdline = cmdline.c_str();
+        fprintf(stderr, "Identify all variants (min_alt_allele_depth=%d)...\n", vo.min_allele_depth);
+        if ((rc = mcx_profile_finalize(cx, planes)) || (rc = mcx_profile_sparse(cx, &recs, &n_recs)) ||
+            (rc = mcx_call_variants(ix, planes, recs, n_recs, st.pairs, st.pair_dist_sum, st.pair_len_sum, &vo, vcf.c_str(), &vs)))
+            fprintf(stderr, "Error! %s\n", mcx_last_error());
+        else
+            fprintf(stderr, "\tWrite all the predicted sample variations to file [%s]...\n\t%lld(snp); %lld(ins); %lld(del); %lld(trans); %lld(inversion)\n",
+                    vcf.c_str(), (long long)vs.n_snv, (long long)vs.n_ins, (long long)vs.n_del, (long long)(vs.n_tnl >> 1), (long long)(vs.n_inv >> 1));
+    }
+    mcx_planes_free(planes);
     mcx_ctx_free(cx);
     mcx_index_free(ix);
     if (!tmp_prefix.empty()) { std::string cmd = "rm -f " + tmp_prefix + ".*"; if (system(cmd.c_str())) {} }

@@ -26,8 +26,7 @@
 #include "mcx_dp.h"
 #include "mcx_profile.h"
 #include <hipcub/hipcub.hpp>
-#include "mcx_host.h"
-#include "mcx_build.h"
+#include "mcx_internal.h"
 
 using namespace mcx;
 
@@ -55,15 +54,6 @@ extern "C" int mcx_device_count(void)
 // ---------------------------------------------------------------------------------------------
 // index
 // ---------------------------------------------------------------------------------------------
-struct mcx_index {
-    IndexView view;
-    HostIndex host;
-    int device = 0;
-    void *d_bwt = nullptr, *d_sa = nullptr, *d_sa_full = nullptr, *d_pac = nullptr;
-    void *d_end_pos = nullptr, *d_end_chr = nullptr, *d_chr_fwd = nullptr, *d_ktab = nullptr;
-    int64_t hbm_bytes = 0;
-    uint64_t n_bwt_words = 0, n_sa = 0; // set for indexes built in HBM (mcx_index_from_codes)
-};
 
 // Expands the sampled suffix array: the chain of LF steps that starts at a sampled row visits
 // exactly the rows whose bwt_sa() walk ends at the next sampled row, with values one lower per
@@ -795,15 +785,20 @@ __global__ void k_reduce_stats(const uint32_t *a, const uint32_t *b, uint32_t n,
 
 // ---- avgDist replay on the device (the host only walks the per-chunk sums) ---------------------
 // per chunk of 100 pairs: number of proper pairs and their summed distance (ReadMapping.cpp:527-531)
-__global__ void k_chunk_sums(const PairOut *po, uint32_t n_pairs, uint32_t chunk, uint32_t *ok_cnt, uint32_t *dist_sum, uint32_t *mapped)
+__global__ void k_chunk_sums(const PairOut *po, const uint32_t *off, uint32_t n_pairs, uint32_t chunk, uint32_t *ok_cnt, uint32_t *dist_sum,
+                             uint32_t *len_sum, uint32_t *mapped)
 {
     const uint32_t n_chunks = (n_pairs + chunk - 1) / chunk;
     uint32_t m = 0;
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += gridDim.x * blockDim.x) {
-        uint32_t ok = 0, ds = 0;
+        uint32_t ok = 0, ds = 0, ls = 0;
         const uint32_t p1 = min(n_pairs, (c + 1) * chunk);
-        for (uint32_t p = c * chunk; p < p1; p++) { const PairOut o = po[p]; if (o.pair_ok) { ok++; ds += (uint32_t)o.pair_dist; } m += (uint32_t)o.mapped; }
-        ok_cnt[c] = ok; dist_sum[c] = ds;
+        for (uint32_t p = c * chunk; p < p1; p++) {
+            const PairOut o = po[p];
+            if (o.pair_ok) { ok++; ds += (uint32_t)o.pair_dist; ls += off[2 * p + 2] - off[2 * p]; } // myReadLengthSum, ReadMapping.cpp:529-530
+            m += (uint32_t)o.mapped;
+        }
+        ok_cnt[c] = ok; dist_sum[c] = ds; len_sum[c] = ls;
     }
     for (int o = 32; o > 0; o >>= 1) m += __shfl_down(m, o, 64);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(mapped, m);
@@ -891,9 +886,10 @@ extern "C" int mcx_map_batch_dev(mcx_ctx *c, const uint8_t *d_bases, const uint3
     // device reduces the batch to per-chunk sums; the host walks the chunk trajectory (a few
     // thousand scalars); the device lists the pairs whose chunk estimate falls outside their
     // validity interval; those are re-run with the exact estimate until none is left.
-    int64_t mapped = 0, pairs = 0, dist_sum = 0;
+    int64_t mapped = 0, pairs = 0, dist_sum = 0, len_sum = 0;
     const uint32_t chunk = kReadChunkSize / 2, n_chunks = (n_pairs + chunk - 1) / chunk;
     uint32_t *d_ok = c->d_read_ext, *d_ds = c->d_read_blocks; // per-read stat arrays are reduced below, before reuse
+    uint32_t *d_ls = d_ds + n_chunks;                         // (2 * n_chunks <= n_reads)
     unsigned long long hs[2] = {0, 0};
     {
         unsigned long long *d_sum = (unsigned long long *)c->d_cnt;
@@ -902,15 +898,15 @@ extern "C" int mcx_map_batch_dev(mcx_ctx *c, const uint8_t *d_bases, const uint3
         HIP_TRY(hipMemcpyAsync(hs, d_sum, sizeof hs, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
-    std::vector<uint32_t> h_ok(n_chunks), h_ds(n_chunks);
+    std::vector<uint32_t> h_ok(n_chunks), h_ds(2 * (size_t)n_chunks);
     std::vector<int32_t> h_est(n_chunks);
     if (paired && (avg[3] % kReadChunkSize)) return fail(MCX_ERR_ARG, "batches must start on a 200-read chunk boundary");
     int64_t after[3] = {avg[0], avg[1], avg[2]};
     for (int iter = 0;; iter++) {
         HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
-        k_chunk_sums<<<(n_chunks + 255) / 256, 256, 0, s>>>(c->d_pout, n_pairs, chunk, d_ok, d_ds, c->d_cnt + CNT_LF);
+        k_chunk_sums<<<(n_chunks + 255) / 256, 256, 0, s>>>(c->d_pout, rb.off, n_pairs, chunk, d_ok, d_ds, d_ls, c->d_cnt + CNT_LF);
         HIP_TRY(hipMemcpyAsync(h_ok.data(), d_ok, n_chunks * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(h_ds.data(), d_ds, n_chunks * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h_ds.data(), d_ds, 2 * (size_t)n_chunks * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         mapped = c->h_cnt[CNT_LF];
@@ -947,12 +943,13 @@ extern "C" int mcx_map_batch_dev(mcx_ctx *c, const uint8_t *d_bases, const uint3
     }
     if (paired) {
         pairs = after[1] - avg[1]; dist_sum = after[2] - avg[2];
+        for (uint32_t k = 0; k < n_chunks; k++) len_sum += h_ds[n_chunks + k];
         avg[0] = after[0]; avg[1] = after[1]; avg[2] = after[2];
     }
     avg[3] += n_reads;
     if (c->prof_planes) { rc = profile_batch(c, rb, paired); if (rc) return rc; }
     if (stats) {
-        stats->reads += n_reads; stats->mapped += mapped; stats->pairs += pairs; stats->pair_dist_sum += dist_sum;
+        stats->reads += n_reads; stats->mapped += mapped; stats->pairs += pairs; stats->pair_dist_sum += dist_sum; stats->pair_len_sum += len_sum;
         stats->fm_ext_steps += (int64_t)hs[0]; stats->fm_blocks += (int64_t)hs[1];
         stats->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }

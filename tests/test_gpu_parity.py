@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLD, ROOT, SETS, maps_canon, sam_diff
+from conftest import GOLD, ROOT, SETS, VCF_CASES, VCF_RUNS, VcfOpts, maps_canon, sam_diff, vcf_alg, vcf_body
 
 pytestmark = pytest.mark.gpu
 
@@ -220,3 +220,42 @@ def test_alignment_profile_equals_reference(api, golden, tmp_path, name):
     text = api.sparse_to_maps_text(mp.profile_sparse())
     assert maps_canon(text) == maps_canon(open(maps, encoding="latin-1").read())
     mp.close(); ix.close()
+
+
+@pytest.mark.parametrize("name,tag", VCF_CASES)
+def test_vcf_equals_reference(api, golden, tmp_path, name, tag):
+    """The whole -vcf surface on the GPU: mapping with the profile attached, then mcx_call_variants
+    (k_vc_depth / k_vc_scan + sparse host logic) — the VCF of `MapCaller -vcf -t 1` line for line,
+    for every switch the golden runs cover."""
+    import torch
+    g = golden[name]
+    o = VcfOpts(VCF_RUNS[tag][1]).struct
+    ix = api.Index(g["prefix"], device=0)
+    mp = api.Mapper(ix, alg=vcf_alg(name, tag), max_batch_reads=4000)
+    planes = torch.zeros((10, ix.genome_size), dtype=torch.int32, device="cuda")
+    mp.profile_attach(planes.data_ptr(), max_dup=o.max_dup, max_clip=o.max_clip)
+    mp.map_files(g["r1"], g["r2"], None)
+    mp.profile_finalize(planes.data_ptr())
+    st = mp.stats
+    out = str(tmp_path / "o.vcf")
+    switches = {k: getattr(o, k) for k in ("ploidy", "min_allele_depth", "min_cnv", "min_gap", "fragment_size", "filter", "gvcf", "monomorphic", "somatic")}
+    res = ix.call_variants(planes.data_ptr(), mp.profile_sparse(), st.pairs, st.pair_dist_sum, st.pair_len_sum, out,
+                           sample_id=o.sample_id.decode(), ref_name="ref", cmdline="test", **switches)
+    got, want = vcf_body(out), vcf_body(g["vcf"][tag])
+    bad = [(a, b) for a, b in zip(got, want) if a != b]
+    assert not bad and len(got) == len(want), (len(got), len(want), bad[:3])
+    assert res["n_records"] == sum(1 for l in want if l and not l.startswith("#"))
+    mp.close(); ix.close()
+
+
+def test_cli_sam_and_vcf(golden, tmp_path):
+    """mapcaller-mi355x with the reference's command line (-i -f -f2 -alg -sam -vcf): both outputs
+    equal the reference's from one run."""
+    g = golden["var"]
+    exe = os.path.join(ROOT, "mapcaller_amd", "mapcaller-mi355x")
+    sam, vcf = str(tmp_path / "o.sam"), str(tmp_path / "o.vcf")
+    cmd = [exe, "-i", g["prefix"], "-f", g["r1"], "-f2", g["r2"], "-alg", "ksw2", "-sam", sam, "-vcf", vcf, "-t", "4"]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    nd, ex = sam_diff(g["sam"]["ksw2"], sam)
+    assert nd == 0, ex
+    assert vcf_body(vcf) == vcf_body(g["vcf"]["default"])
