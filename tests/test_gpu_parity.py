@@ -234,12 +234,11 @@ def test_vcf_equals_reference(api, golden, tmp_path, name, tag):
     mp = api.Mapper(ix, alg=vcf_alg(name, tag), max_batch_reads=4000)
     planes = torch.zeros((10, ix.genome_size), dtype=torch.int32, device="cuda")
     mp.profile_attach(planes.data_ptr(), max_dup=o.max_dup, max_clip=o.max_clip)
-    mp.map_files(g["r1"], g["r2"], None)
+    st = mp.map_files(g["r1"], g["r2"], None)
     mp.profile_finalize(planes.data_ptr())
-    st = mp.stats
     out = str(tmp_path / "o.vcf")
     switches = {k: getattr(o, k) for k in ("ploidy", "min_allele_depth", "min_cnv", "min_gap", "fragment_size", "filter", "gvcf", "monomorphic", "somatic")}
-    res = ix.call_variants(planes.data_ptr(), mp.profile_sparse(), st.pairs, st.pair_dist_sum, st.pair_len_sum, out,
+    res = ix.call_variants(planes.data_ptr(), mp.profile_sparse(), st["pairs"], st["pair_dist_sum"], st["pair_len_sum"], out,
                            sample_id=o.sample_id.decode(), ref_name="ref", cmdline="test", **switches)
     got, want = vcf_body(out), vcf_body(g["vcf"][tag])
     bad = [(a, b) for a, b in zip(got, want) if a != b]
