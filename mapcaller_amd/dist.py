@@ -51,6 +51,15 @@ def reduce_profile(planes: torch.Tensor, sparse: Sequence[tuple]) -> Tuple[torch
     return planes, merged
 
 
+def sum_over_ranks(values: Sequence[int], device: torch.device) -> List[int]:
+    """Run totals the variant caller needs from all shards (pairs, pair distance sum, read length sum)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [int(v) for v in values]
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [int(v) for v in t.tolist()]
+
+
 def max_over_ranks(seconds: float, device: torch.device) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return seconds

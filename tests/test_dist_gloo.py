@@ -32,8 +32,9 @@ def _worker(rank, world, port, out):
     planes, merged = mdist.reduce_profile(planes, sparse)
     lo, hi = mdist.shard_pairs(12345, rank, world)
     t = mdist.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    tot = mdist.sum_over_ranks([100 + rank, 7 * (rank + 1), 1 << 40], torch.device("cpu"))  # run totals for the variant caller
     if rank == 0:
-        torch.save({"sum": planes, "mine": mine, "merged": merged, "t": t}, out)
+        torch.save({"sum": planes, "mine": mine, "merged": merged, "t": t, "tot": tot}, out)
     # every rank checks its own shard bounds
     assert lo % 100 == 0 and (hi % 100 == 0 or hi == 12345)
     gathered = [None] * world
@@ -58,6 +59,7 @@ def test_profile_reduce_and_sharding_world2(tmp_path):
     assert torch.equal(fin[6], (want[6] & 0xFFFF))
     assert len(r["merged"]) == 8 and r["merged"][0] == ("I", 0, "AC") and r["merged"][4] == ("I", 10, "AC")
     assert r["t"] == 2.0
+    assert r["tot"] == [201, 21, 1 << 41]
 
 
 def test_shards_cover_everything_for_any_world():
