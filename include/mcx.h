@@ -185,6 +185,16 @@ int mcx_call_variants(const mcx_index *, const uint32_t *d_planes, const mcx_spa
 
 /* ---- files: MapCaller -i <prefix> -f A [-f2 B] -alg nw|ksw2 -sam out (src/main.cpp:212-321) */
 int mcx_map_files(mcx_ctx *, const char *fq1, const char *fq2, const char *sam_path, mcx_stats *stats);
+/* The same with the remaining switches of the reference's file loop (src/ReadMapping.cpp:689-760):
+ * interleaved_pairs = -p (one file holds both mates alternately), host_threads = -t (parser /
+ * formatter threads on the host; 0 = pick), append_sam: a further library of the same run (no
+ * header, append), avg_state: carries the insert-size estimate across libraries (NULL = fresh). */
+typedef struct mcx_file_opts {
+    int32_t interleaved_pairs, host_threads, append_sam, pad;
+    int64_t *avg_state; /* int64_t[4], see mcx_avg_init */
+} mcx_file_opts;
+void mcx_file_opts_default(mcx_file_opts *);
+int mcx_map_files_ex(mcx_ctx *, const char *fq1, const char *fq2, const mcx_file_opts *, const char *sam_path, mcx_stats *stats);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ SYMBOLS = [
     "mcx_last_error", "mcx_device_count", "mcx_index_load", "mcx_index_build", "mcx_index_from_codes", "mcx_index_save", "mcx_index_free",
     "mcx_index_genome_size", "mcx_index_n_chr", "mcx_index_chr_name", "mcx_index_chr_len", "mcx_index_hbm_bytes",
     "mcx_opts_default", "mcx_ctx_create", "mcx_ctx_free", "mcx_bwt_search_batch", "mcx_extend_batch",
-    "mcx_avg_init", "mcx_map_batch_dev", "mcx_map_batch", "mcx_map_files",
+    "mcx_avg_init", "mcx_map_batch_dev", "mcx_map_batch", "mcx_map_files", "mcx_map_files_ex", "mcx_file_opts_default",
     "mcx_profile_attach", "mcx_profile_finalize", "mcx_profile_sparse", "mcx_planes_alloc", "mcx_planes_free",
     "mcx_vcf_defaults", "mcx_call_variants",
 ]
@@ -62,6 +62,12 @@ class Stats(C.Structure):
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class FileOpts(C.Structure):
+    """mcx_file_opts: -p, -t, library append, insert-size state across libraries."""
+    _fields_ = [("interleaved_pairs", C.c_int32), ("host_threads", C.c_int32), ("append_sam", C.c_int32), ("pad", C.c_int32),
+                ("avg_state", C.POINTER(C.c_int64))]
 
 
 class VcfOpts(C.Structure):
@@ -122,6 +128,9 @@ def lib() -> C.CDLL:
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_int64), C.c_void_p,
                       C.c_void_p, C.POINTER(Stats)]
     L.mcx_map_files.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(Stats)]
+    L.mcx_map_files_ex.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(FileOpts), C.c_char_p, C.POINTER(Stats)]
+    L.mcx_file_opts_default.argtypes = [C.POINTER(FileOpts)]
+    L.mcx_file_opts_default.restype = None
     L.mcx_profile_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.mcx_profile_finalize.argtypes = [C.c_void_p, C.c_void_p]
     L.mcx_profile_sparse.argtypes = [C.c_void_p, C.POINTER(C.POINTER(SparseRec)), C.POINTER(C.c_uint64)]
@@ -259,10 +268,14 @@ class Mapper:
         self.stats = Stats()
 
     # ---- whole path ---------------------------------------------------------------------
-    def map_files(self, fq1: str, fq2: Optional[str], sam: Optional[str]) -> dict:
+    def map_files(self, fq1: str, fq2: Optional[str], sam: Optional[str], interleaved: bool = False, threads: int = 0) -> dict:
+        """Files in, SAM out (mcx_map_files_ex).  ``interleaved`` = -p, ``threads`` = -t."""
         st = Stats()
-        _check(lib().mcx_map_files(self._h, fq1.encode(), (fq2 or "").encode() or None, (sam or "").encode() or None,
-                                   C.byref(st)), "mcx_map_files")
+        fo = FileOpts()
+        lib().mcx_file_opts_default(C.byref(fo))
+        fo.interleaved_pairs, fo.host_threads = int(interleaved), threads
+        _check(lib().mcx_map_files_ex(self._h, fq1.encode(), (fq2 or "").encode() or None, C.byref(fo), (sam or "").encode() or None,
+                                      C.byref(st)), "mcx_map_files_ex")
         return st.as_dict()
 
     def map_batch(self, bases: np.ndarray, off: np.ndarray, paired: bool):

@@ -4,6 +4,7 @@
 #include "mcx_types.h"
 #include "mcx_host.h"
 #include "mcx_build.h"
+#include "../../include/mcx.h"
 
 struct mcx_index {
     mcx::IndexView view;
@@ -14,5 +15,10 @@ struct mcx_index {
     int64_t hbm_bytes = 0;
     uint64_t n_bwt_words = 0, n_sa = 0; // set for indexes built in HBM (mcx_index_from_codes)
 };
+
+// what the file front end (mcx_files.cpp) needs to know about a context
+const mcx_index *mcx_ctx_index(const mcx_ctx *);
+int mcx_ctx_max_read_len(const mcx_ctx *);
+uint64_t mcx_ctx_max_reads(const mcx_ctx *);
 
 #endif

@@ -38,7 +38,8 @@ static void usage(const char *prog)
             "         -filter       apply variant filters (under test)\n"
             "         -somatic      detect somatic mutations\n"
             "         -id STR       sample id [unknown]\n"
-            "         -t INT        accepted and ignored (the GPU path has no worker threads)\n"
+            "         -p            paired-end reads are interlaced in the same file\n"
+            "         -t INT        host threads that parse reads and format SAM lines [half the cores, at most 32]\n"
             "         -gpu INT      device ordinal [0]\n", prog, prog);
 }
 
@@ -56,6 +57,8 @@ int main(int argc, char **argv)
     mcx_opts o;
     mcx_opts_default(&o);
     int gpu = 0;
+    mcx_file_opts fo;
+    mcx_file_opts_default(&fo);
     bool want_vcf = true; // bVCFoutput, main.cpp:171
     std::string vcf = "output.vcf", cmdline = argv[0];
     mcx_vcf_opts vo;
@@ -71,7 +74,8 @@ int main(int argc, char **argv)
         else if (p == "-sam" && i + 1 < argc) sam = argv[++i];
         else if (p == "-indel" && i + 1 < argc) { o.max_pos_diff = atoi(argv[++i]); if (o.max_pos_diff > 100) { o.max_pos_diff = 100; fprintf(stderr, "Warning! The maximal indel size is 100!\n"); } }
         else if (p == "-maxmm" && i + 1 < argc) o.max_mismatch_rate = (float)atof(argv[++i]);
-        else if (p == "-t" && i + 1 < argc) ++i;
+        else if (p == "-t" && i + 1 < argc) { if ((fo.host_threads = atoi(argv[++i])) <= 0) { fprintf(stderr, "Warning! The thread number should be positive!\n"); fo.host_threads = 4; } }
+        else if (p == "-pair" || p == "-p") fo.interleaved_pairs = 1;
         else if (p == "-gpu" && i + 1 < argc) gpu = atoi(argv[++i]);
         else if (p == "-vcf" && i + 1 < argc) vcf = argv[++i];
         else if (p == "-no_vcf") want_vcf = false;
@@ -114,13 +118,18 @@ int main(int argc, char **argv)
         fprintf(stderr, "Initialize the alignment profile...\n");
         if ((rc = mcx_planes_alloc(ix, &planes)) || (rc = mcx_profile_attach(cx, planes, vo.max_dup, vo.max_clip))) { fprintf(stderr, "Error! %s\n", mcx_last_error()); return 1; }
     }
+    int64_t avg[4];
+    mcx_avg_init(avg); // avgDist and its totals are globals of the reference: they carry over from library to library
+    fo.avg_state = avg;
     for (size_t k = 0; k < f1.size() && rc == 0; k++) {
         // like the reference, every library appends to the same SAM stream; only the first writes the header
-        rc = mcx_map_files(cx, f1[k].c_str(), f2.empty() ? nullptr : f2[k].c_str(), sam.empty() ? nullptr : sam.c_str(), &st);
+        fo.append_sam = k > 0;
+        if (avg[3] % 200) avg[3] += 200 - avg[3] % 200; // a new library starts a new chunk
+        rc = mcx_map_files_ex(cx, f1[k].c_str(), f2.empty() ? nullptr : f2[k].c_str(), &fo, sam.empty() ? nullptr : sam.c_str(), &st);
         if (rc) fprintf(stderr, "Error! %s\n", mcx_last_error());
     }
     fprintf(stderr, "All the %lld %s reads have been processed.\n%12lld reads are mapped properly.\n%12lld reads are mapped in pairs.\n",
-            (long long)st.reads, f2.empty() ? "single-end" : "paired-end", (long long)st.mapped, (long long)st.pairs * 2);
+            (long long)st.reads, (f2.empty() && !fo.interleaved_pairs) ? "single-end" : "paired-end", (long long)st.mapped, (long long)st.pairs * 2);
     if (want_vcf && rc == 0) { // VariantCalling(), main.cpp:379
         const mcx_sparse_rec *recs = nullptr;
         uint64_t n_recs = 0;

@@ -1226,63 +1226,6 @@ extern "C" int mcx_extend_batch(mcx_ctx *c, int alg, const uint8_t *q, const uin
 // ---------------------------------------------------------------------------------------------
 // files in, SAM out: MapCaller -i <prefix> -f A [-f2 B] -sam out  (main.cpp:212-321, Mapping() ReadMapping.cpp:689-747)
 // ---------------------------------------------------------------------------------------------
-extern "C" int mcx_map_files(mcx_ctx *c, const char *fq1, const char *fq2, const char *sam_path, mcx_stats *stats)
-{
-    if (!c || !fq1) return fail(MCX_ERR_ARG, "mcx_map_files: null argument");
-    ReadFile f1, f2;
-    std::string err;
-    const bool paired = fq2 && fq2[0];
-    if (!f1.open(fq1, err)) return fail(MCX_ERR_IO, err);
-    if (paired && !f2.open(fq2, err)) return fail(MCX_ERR_IO, err);
-    if (paired && f1.fastq() != f2.fastq()) return fail(MCX_ERR_IO, std::string(fq1) + " and " + fq2 + " are with different format");
-    FILE *sam = nullptr;
-    if (sam_path && sam_path[0]) {
-        sam = strcmp(sam_path, "-") == 0 ? stdout : fopen(sam_path, "w");
-        if (!sam) return fail(MCX_ERR_IO, std::string("cannot write ") + sam_path);
-        std::string hdr;
-        sam_header(c->idx->host, hdr);
-        fputs(hdr.c_str(), sam);
-    }
-    const uint64_t batch = std::max<uint64_t>(kReadChunkSize, c->max_reads / kReadChunkSize * kReadChunkSize);
-    std::vector<HostRead> reads;
-    std::vector<uint8_t> bases;
-    std::vector<uint32_t> off;
-    std::vector<AlnRec> recs;
-    std::vector<uint32_t> cig;
-    int64_t avg[4];
-    mcx_avg_init(avg);
-    std::string line;
-    int rc = 0;
-    bool eof = false;
-    while (!eof && rc == 0) {
-        reads.clear(); bases.clear(); off.assign(1, 0);
-        while (reads.size() < batch) { // GetNextChunk, GetData.cpp:85-99
-            HostRead a, b;
-            if (!f1.next(a)) { eof = true; break; }
-            reads.push_back(a);
-            if (paired) { f2.next(b); reads.push_back(b); }
-        }
-        if (reads.empty()) break;
-        for (auto &r : reads) {
-            if ((int)r.seq.size() > c->rlen_max) { rc = fail(MCX_ERR_UNSUPPORTED, "read " + r.name + " is longer than max_read_len"); break; }
-            bases.insert(bases.end(), r.seq.begin(), r.seq.end());
-            off.push_back((uint32_t)bases.size());
-        }
-        if (rc) break;
-        const uint32_t n = (uint32_t)reads.size();
-        recs.resize(n); cig.resize((size_t)n * MCX_CIGAR_STRIDE);
-        bases.resize(bases.size() + 64);
-        // a single-end batch, or an odd tail, is mapped as single reads (ReadMapping.cpp:443, :575)
-        const int as_pairs = paired && (n % 2 == 0);
-        rc = mcx_map_batch(c, bases.data(), off.data(), n, as_pairs, avg, (mcx_aln *)recs.data(), cig.data(), stats);
-        if (rc) break;
-        if (sam) {
-            for (uint32_t i = 0; i < n; i++) {
-                sam_line(c->idx->host, reads[i], as_pairs && (i & 1), f1.fastq(), recs[i], cig.data() + (size_t)i * MCX_CIGAR_STRIDE, line);
-                fputs(line.c_str(), sam); fputc('\n', sam);
-            }
-        }
-    }
-    if (sam && sam != stdout) fclose(sam);
-    return rc;
-}
+const mcx_index *mcx_ctx_index(const mcx_ctx *c) { return c->idx; }
+int mcx_ctx_max_read_len(const mcx_ctx *c) { return c->rlen_max; }
+uint64_t mcx_ctx_max_reads(const mcx_ctx *c) { return c->max_reads; }

@@ -1295,7 +1295,8 @@ struct Shared {
     const Index *ix;
     Params pm;
     Reader in1, in2;
-    bool paired = false, fastq = true;
+    bool paired = false, fastq = true; // paired: bPairEnd (two files, or -p)
+    bool two_files = false;            // bSepLibrary
     FILE *sam = nullptr;
     std::mutex in_lock, out_lock;
     u32 avg_dist = 1000; // ReadMapping.cpp:20
@@ -1327,7 +1328,7 @@ static void worker(Shared *sh)
             while ((int)chunk.size() < kChunk) {
                 if (!sh->in1.next(a)) break;
                 chunk.push_back(a);
-                if (sh->paired) { sh->in2.next(b); chunk.push_back(b); }
+                if (sh->two_files) { sh->in2.next(b); chunk.push_back(b); }
                 else { if (!sh->in1.next(b)) break; chunk.push_back(b); }
             }
         }
@@ -1807,6 +1808,7 @@ int mcxo_ksw2_extz(const uint8_t *q, int qlen, const uint8_t *t, int tlen, int *
     return (int)c.size();
 }
 
+static thread_local bool g_interleaved = false;
 static int64_t map_files_impl(const mcxo_index *ix, const char *fq1, const char *fq2, int alg, const char *sam_path,
                               int threads, int64_t *stats, Profile *pf, int64_t *pair_stats = nullptr);
 
@@ -1814,6 +1816,15 @@ int64_t mcxo_map_files(const mcxo_index *ix, const char *fq1, const char *fq2, i
                        int threads, int64_t *stats)
 {
     return map_files_impl(ix, fq1, fq2, alg, sam_path, threads, stats, nullptr);
+}
+
+// MapCaller -p: one file, mates alternate
+int64_t mcxo_map_files_interleaved(const mcxo_index *ix, const char *fq, int alg, const char *sam_path, int64_t *stats)
+{
+    g_interleaved = true;
+    const int64_t n = map_files_impl(ix, fq, nullptr, alg, sam_path, 1, stats, nullptr);
+    g_interleaved = false;
+    return n;
 }
 
 // As `MapCaller ... -vcf` would leave them after Mapping(): writes <out>.prof (10 x u16 per
@@ -1895,7 +1906,8 @@ static int64_t map_files_impl(const mcxo_index *ix, const char *fq1, const char 
     sh.pm.use_nw = (alg == 0);
     if (!sh.in1.open(fq1)) return -1;
     sh.fastq = sh.in1.fastq;
-    if (fq2 && fq2[0]) { if (!sh.in2.open(fq2)) return -1; sh.paired = true; }
+    if (fq2 && fq2[0]) { if (!sh.in2.open(fq2)) return -1; sh.paired = sh.two_files = true; }
+    if (g_interleaved) sh.paired = true; // -p (main.cpp:300)
     if (sam_path && sam_path[0]) {
         sh.sam = fopen(sam_path, "w");
         if (!sh.sam) return -2;

@@ -44,6 +44,9 @@ int mcxo_ksw2_extz(const uint8_t *q, int qlen, const uint8_t *t, int tlen, int *
 int64_t mcxo_map_files(const mcxo_index *, const char *fq1, const char *fq2, int alg, const char *sam_path,
                        int threads, int64_t *stats);
 
+// MapCaller -p: both mates alternate in one file (reference src/main.cpp:300, src/GetData.cpp:85-99)
+int64_t mcxo_map_files_interleaved(const mcxo_index *, const char *fq, int alg, const char *sam_path, int64_t *stats);
+
 // The same run with the -vcf bookkeeping of UpdateProfile / UpdateMultiHitCount (reference
 // src/AlignmentProfile.cpp:41-271) and the discordant-site lists (src/ReadMapping.cpp:486-521):
 // writes <out>.prof and <out>.maps in the format of oracle/_ref/mcref_tool's P command.

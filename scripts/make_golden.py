@@ -96,6 +96,52 @@ def make_set(name, fasta, donor, n, rlen, paired, seed, fastq=True, profile_alg=
     print("set", name, "done")
 
 
+def make_io_set():
+    """Input-side semantics (GetData.cpp) on the toy reads: interleaved -p input with an odd tail and
+    decorated headers, multi-line FASTA, .gz files read directly, two libraries in one run."""
+    src, out = os.path.join(GOLD, "toy"), os.path.join(GOLD, "io")
+    os.makedirs(out, exist_ok=True)
+    r1 = gzip.open(os.path.join(src, "r1.fq.gz"), "rb").read().split(b"\n")
+    r2 = gzip.open(os.path.join(src, "r2.fq.gz"), "rb").read().split(b"\n")
+    n = len(r1) // 4
+    with tempfile.TemporaryDirectory() as tmp:
+        prefix = os.path.join(src, "idx")
+        log = ["-t", "1", "-no_vcf", "-log", os.path.join(tmp, "job.log")]
+        # 1. interleaved, 2999 records: the last 199-read chunk is mapped as single reads
+        recs = []
+        for i in range(n):
+            for k, r in ((1, r1), (2, r2)):
+                recs.append(b"\n".join([r[4 * i] + (b"/%d" % k if i % 3 else b" mate%d extra words" % k), r[4 * i + 1], b"+", r[4 * i + 3]]))
+        il = b"\n".join(recs[:2999]) + b"\n"
+        open(os.path.join(tmp, "il.fq"), "wb").write(il)
+        sh(REF_BIN, "-i", prefix, "-f", os.path.join(tmp, "il.fq"), "-p", "-alg", "ksw2", "-sam", os.path.join(tmp, "il.sam"), *log)
+        gz_write(os.path.join(out, "il.fq.gz"), il)
+        gz_write(os.path.join(out, "ref.il.sam.gz"), open(os.path.join(tmp, "il.sam"), "rb").read())
+        # 2. multi-line FASTA, single end
+        fa = []
+        for i in range(400):
+            seq = r1[4 * i + 1]
+            fa.append(b">" + r1[4 * i][1:] + b" len=%d" % len(seq))
+            fa += [seq[j:j + 60] for j in range(0, len(seq), 60)]
+        ml = b"\n".join(fa) + b"\n"
+        open(os.path.join(tmp, "ml.fa"), "wb").write(ml)
+        sh(REF_BIN, "-i", prefix, "-f", os.path.join(tmp, "ml.fa"), "-alg", "nw", "-sam", os.path.join(tmp, "ml.sam"), *log)
+        gz_write(os.path.join(out, "ml.fa.gz"), ml)
+        gz_write(os.path.join(out, "ref.ml.sam.gz"), open(os.path.join(tmp, "ml.sam"), "rb").read())
+        # 3. .gz inputs handed over as they are (gzGetNextEntry)
+        sh(REF_BIN, "-i", prefix, "-f", os.path.join(src, "r1.fq.gz"), "-f2", os.path.join(src, "r2.fq.gz"), "-alg", "ksw2", "-sam", os.path.join(tmp, "gz.sam"), *log)
+        gz_write(os.path.join(out, "ref.gz.sam.gz"), open(os.path.join(tmp, "gz.sam"), "rb").read())
+        # 4. two libraries in one run: one SAM stream, avgDist carried over
+        half = 4 * 700
+        for tag, r in (("1", r1), ("2", r2)):
+            open(os.path.join(tmp, f"a{tag}.fq"), "wb").write(b"\n".join(r[:half]) + b"\n")
+            open(os.path.join(tmp, f"b{tag}.fq"), "wb").write(b"\n".join(r[half:4 * n]) + b"\n")
+        sh(REF_BIN, "-i", prefix, "-f", os.path.join(tmp, "a1.fq"), os.path.join(tmp, "b1.fq"), "-f2", os.path.join(tmp, "a2.fq"), os.path.join(tmp, "b2.fq"),
+           "-alg", "ksw2", "-sam", os.path.join(tmp, "lib.sam"), *log)
+        gz_write(os.path.join(out, "ref.lib.sam.gz"), open(os.path.join(tmp, "lib.sam"), "rb").read())
+    print("set io done")
+
+
 class RefTool:
     """oracle/_ref/mcref_tool (the real reference's functions behind a line protocol)."""
 
@@ -210,6 +256,7 @@ def main():
                  vcf_runs=[("default", "ksw2", []), ("nw", "nw", []), ("gvcf", "ksw2", ["-gvcf"]), ("mono", "ksw2", ["-monomorphic"]),
                            ("filter", "ksw2", ["-filter"]), ("ploidy1", "ksw2", ["-ploidy", "1"]), ("somatic", "ksw2", ["-somatic"]),
                            ("opts", "ksw2", ["-ad", "3", "-min_gap", "20", "-min_cnv", "20", "-size", "400", "-dup", "3", "-maxclip", "10", "-id", "s1"])])
+    make_io_set()
     make_func_vectors()
     torch.manual_seed(0)
 

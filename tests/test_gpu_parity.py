@@ -258,3 +258,32 @@ def test_cli_sam_and_vcf(golden, tmp_path):
     nd, ex = sam_diff(g["sam"]["ksw2"], sam)
     assert nd == 0, ex
     assert vcf_body(vcf) == vcf_body(g["vcf"]["default"])
+
+
+def test_input_side_cases(api, io_golden, tmp_path):
+    """mcx_map_files_ex against the reference's readers (GetData.cpp): interleaved -p input with an odd
+    tail chunk and decorated headers, multi-line FASTA, .gz files handed over as they are."""
+    g = io_golden
+    ix = api.Index(g["prefix"], device=0)
+    for alg, args, kw, ref in (("ksw2", (g["il.fq"], None), {"interleaved": True}, "ref.il.sam"),
+                               ("nw", (g["ml.fa"], None), {}, "ref.ml.sam"),
+                               ("ksw2", (g["gz1"], g["gz2"]), {"threads": 3}, "ref.gz.sam")):
+        mp = api.Mapper(ix, alg=alg, max_batch_reads=1000)
+        out = str(tmp_path / (ref + ".out"))
+        mp.map_files(args[0], args[1], out, **kw)
+        nd, ex = sam_diff(g[ref], out, mask_se_reverse_qual=True)
+        assert nd == 0, (ref, ex)
+        mp.close()
+    ix.close()
+
+
+def test_cli_two_libraries(io_golden, tmp_path):
+    """-f a1 b1 -f2 a2 b2: one SAM stream, one header, the insert-size estimate carried from the first
+    library into the second (the reference's globals)."""
+    g = io_golden
+    exe = os.path.join(ROOT, "mapcaller_amd", "mapcaller-mi355x")
+    sam = str(tmp_path / "lib.sam")
+    cmd = [exe, "-i", g["prefix"], "-f", g["a1"], g["b1"], "-f2", g["a2"], g["b2"], "-alg", "ksw2", "-sam", sam, "-no_vcf"]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    nd, ex = sam_diff(g["ref.lib.sam"], sam)
+    assert nd == 0, ex

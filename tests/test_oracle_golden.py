@@ -83,3 +83,19 @@ def test_oracle_vcf_equals_reference(oracle_lib, golden, tmp_path, name, tag):
     oracle_lib.mcxo_index_free(ix)
     assert n > 0
     assert vcf_body(out) == vcf_body(g["vcf"][tag])
+
+
+def test_oracle_input_side_cases(oracle_lib, io_golden, tmp_path):
+    """GetData.cpp semantics restated: interleaved -p input whose odd 199-read tail chunk is mapped as
+    single reads, headers cut at ' ' or '/', multi-line FASTA."""
+    g = io_golden
+    ix = oracle_lib.mcxo_index_load(g["prefix"].encode())
+    out = str(tmp_path / "il.sam")
+    assert oracle_lib.mcxo_map_files_interleaved(ix, g["il.fq"].encode(), 1, out.encode(), None) == 2999
+    nd, ex = sam_diff(g["ref.il.sam"], out, mask_se_reverse_qual=True)
+    assert nd == 0, ex
+    out = str(tmp_path / "ml.sam")
+    assert oracle_lib.mcxo_map_files(ix, g["ml.fa"].encode(), b"", 0, out.encode(), 1, None) == 400
+    nd, ex = sam_diff(g["ref.ml.sam"], out)
+    assert nd == 0, ex
+    oracle_lib.mcxo_index_free(ix)
