@@ -16,6 +16,7 @@
 // odd tail chunk of interleaved input mapped as single reads (ReadMapping.cpp:442).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -162,9 +163,23 @@ struct Batch {
     Entries in[2];
     uint32_t n = 0;          // reads
     bool two_files = false, fastq = true, last = false;
-    std::vector<uint8_t> bases; std::vector<uint32_t> off; // interleaved, as mcx_map_batch wants them
-    std::vector<AlnRec> recs; std::vector<uint32_t> cig;
+    // interleaved reads as mcx_map_batch wants them, and its results: pinned host memory, allocated once per batch object
+    uint8_t *bases = nullptr; uint32_t *off = nullptr; AlnRec *recs = nullptr; uint32_t *cig = nullptr;
+    size_t cap_reads = 0, cap_bases = 0;
     std::vector<uint8_t> is_mate2;                          // mapped as the second read of a pair
+    bool reserve(size_t reads, size_t n_bases)
+    {
+        if (reads > cap_reads) {
+            mcx_pinned_free(off); mcx_pinned_free(recs); mcx_pinned_free(cig);
+            cap_reads = reads;
+            off = (uint32_t *)mcx_pinned_alloc((reads + 1) * sizeof(uint32_t));
+            recs = (AlnRec *)mcx_pinned_alloc(reads * sizeof(AlnRec));
+            cig = (uint32_t *)mcx_pinned_alloc(reads * MCX_CIGAR_STRIDE * sizeof(uint32_t));
+        }
+        if (n_bases > cap_bases) { mcx_pinned_free(bases); cap_bases = n_bases + n_bases / 8; bases = (uint8_t *)mcx_pinned_alloc(cap_bases); }
+        return off && recs && cig && bases;
+    }
+    ~Batch() { mcx_pinned_free(bases); mcx_pinned_free(off); mcx_pinned_free(recs); mcx_pinned_free(cig); }
     std::string error;
     // read r of the batch -> (file, index in that file's entries)
     void locate(uint32_t r, int &f, uint32_t &i) const { if (two_files) { f = (int)(r & 1); i = r >> 1; } else { f = 0; i = r; } }
@@ -200,10 +215,13 @@ inline char comp_char(char c) // GetComplementaryBase, tools.cpp:3-18
     }
 }
 
-struct Text { // append-only byte buffer
+struct Text { // writer over a buffer sized beforehand from an upper bound
     std::vector<char> b;
-    void put(const char *p, size_t n) { b.insert(b.end(), p, p + n); }
-    void put(char c) { b.push_back(c); }
+    char *w = nullptr;
+    void start(size_t bound) { if (b.size() < bound) b.resize(bound); w = b.data(); }
+    size_t size() const { return (size_t)(w - b.data()); }
+    void put(const char *p, size_t n) { memcpy(w, p, n); w += n; }
+    void put(char c) { *w++ = c; }
     void lit(const char *s) { put(s, strlen(s)); }
     void num(long long v)
     {
@@ -211,9 +229,15 @@ struct Text { // append-only byte buffer
         unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
         do { t[n++] = (char)('0' + u % 10); u /= 10; } while (u);
         if (v < 0) t[n++] = '-';
-        while (n) b.push_back(t[--n]);
+        while (n) *w++ = t[--n];
     }
 };
+
+// bytes one SAM line can take at most
+inline size_t sam_bound(const HostIndex &ix, size_t name_len, size_t rlen, int chr, int n_cigar)
+{
+    return name_len + 2 * rlen + (chr >= 0 ? ix.chr_name[chr].size() : 1) + 11 * (size_t)n_cigar + 160;
+}
 
 void sam_record(const HostIndex &ix, const Batch &bt, uint32_t r, Text &o)
 {
@@ -222,7 +246,7 @@ void sam_record(const HostIndex &ix, const Batch &bt, uint32_t r, Text &o)
     bt.locate(r, f, i);
     const Entries &e = bt.in[f];
     const AlnRec &rec = bt.recs[r];
-    const uint32_t *cigar = bt.cig.data() + (size_t)r * MCX_CIGAR_STRIDE;
+    const uint32_t *cigar = bt.cig + (size_t)r * MCX_CIGAR_STRIDE;
     const char *seq = (const char *)e.seq.data() + e.seq_off[i];
     const int rlen = (int)(e.seq_off[i + 1] - e.seq_off[i]);
     const char *qual = bt.fastq ? e.qual.data() + e.seq_off[i] : nullptr;
@@ -242,12 +266,12 @@ void sam_record(const HostIndex &ix, const Batch &bt, uint32_t r, Text &o)
         else o.lit("\t*\t0\t0\t");
     }
     if (!flipped && !again) o.put(seq, (size_t)rlen);
-    else if (flipped != again) for (int k = rlen - 1; k >= 0; k--) o.put(comp_char(seq[k]));
-    else for (int k = 0; k < rlen; k++) o.put(comp_char(comp_char(seq[k]))); // complemented twice: upper case, N for anything else
+    else if (flipped != again) { char *w = o.w; for (int k = rlen - 1; k >= 0; k--) *w++ = comp_char(seq[k]); o.w = w; }
+    else { char *w = o.w; for (int k = 0; k < rlen; k++) *w++ = comp_char(comp_char(seq[k])); o.w = w; } // complemented twice: upper case, N for anything else
     o.put('\t');
     if (!qual) o.put('*');
     else if (flipped == again) o.put(qual, strnlen(qual, (size_t)rlen)); // printed with %s: stops at a NUL pad
-    else for (int k = rlen - 1; k >= 0 && qual[k] != '\0'; k--) o.put(qual[k]);
+    else { char *w = o.w; for (int k = rlen - 1; k >= 0 && qual[k] != '\0'; k--) *w++ = qual[k]; o.w = w; }
     if (!mapped) o.lit("\tAS:i:0\tXS:i:0\n");
     else { o.lit("\tNM:i:"); o.num(rec.nm); o.lit("\tAS:i:"); o.num(rec.as); o.lit("\tXS:i:"); o.num(rec.xs); o.put('\n'); }
 }
@@ -285,16 +309,22 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
     mcx_avg_init(local_avg);
     int64_t *avg = opt.avg_state ? opt.avg_state : local_avg;
 
+    // busy seconds per stage (MCX_TIMING=1 prints them)
+    double t_parse = 0, t_pack = 0, t_map = 0, t_format = 0, t_write = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     typedef std::unique_ptr<Batch> BatchPtr;
-    Queue<BatchPtr> parsed(2), mapped(2);
+    Queue<BatchPtr> parsed(2), mapped(2), spare(4); // batch objects circulate: their buffers are allocated (and faulted in) once
+    for (int k = 0; k < 4; k++) spare.push(BatchPtr(new Batch));
 
     // stage 1: parse.  One thread per file fills its half of the batch.
     std::atomic<bool> abort(false);
     std::thread reader([&] {
         bool done = false;
         while (!done) {
-            BatchPtr b(new Batch);
-            b->two_files = two; b->fastq = ps[0].fastq();
+            BatchPtr b = spare.pop();
+            const auto t0 = now();
+            b->two_files = two; b->fastq = ps[0].fastq(); b->n = 0; b->last = false; b->error.clear();
             const uint32_t per_file = (uint32_t)(two ? batch_reads / 2 : batch_reads);
             b->in[0].clear(); b->in[1].clear();
             if (two) {
@@ -313,6 +343,7 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
             for (int f = 0; f < 2; f++) if (!b->in[f].error.empty()) b->error = b->in[f].error;
             if (!b->error.empty() || abort.load()) done = true;
             b->last = done;
+            t_parse += secs(t0, now());
             parsed.push(std::move(b));
         }
     });
@@ -324,17 +355,29 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
         for (;;) {
             BatchPtr b = mapped.pop();
             if (sam && b->n && write_rc == 0) {
+                const auto t0 = now();
                 slices.resize((size_t)threads);
-                for (auto &s : slices) s.b.clear();
+                for (auto &s : slices) s.w = nullptr;
                 parallel_for(b->n, threads, [&](uint32_t lo, uint32_t hi, int k) {
                     Text &t = slices[(size_t)k];
-                    t.b.reserve((size_t)(hi - lo) * 400);
+                    size_t bound = 0;
+                    for (uint32_t r = lo; r < hi; r++) {
+                        int f; uint32_t i;
+                        b->locate(r, f, i);
+                        const Entries &e = b->in[f];
+                        bound += sam_bound(hix, e.name_off[i + 1] - e.name_off[i], e.seq_off[i + 1] - e.seq_off[i], b->recs[r].chr, b->recs[r].n_cigar);
+                    }
+                    t.start(bound);
                     for (uint32_t r = lo; r < hi; r++) sam_record(hix, *b, r, t);
                 });
+                const auto t1 = now();
                 for (const Text &t : slices)
-                    if (!t.b.empty() && fwrite(t.b.data(), 1, t.b.size(), sam) != t.b.size()) write_rc = MCX_ERR_IO;
+                    if (t.w && t.size() && fwrite(t.b.data(), 1, t.size(), sam) != t.size()) write_rc = MCX_ERR_IO;
+                t_format += secs(t0, t1); t_write += secs(t1, now());
             }
-            if (b->last) break;
+            const bool stop = b->last;
+            spare.push(std::move(b));
+            if (stop) break;
         }
     });
 
@@ -347,29 +390,41 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
         if (rc) b->n = 0;
         const uint32_t n = b->n;
         if (rc == 0 && n) {
-            b->off.resize((size_t)n + 1);
+            const auto t0 = now();
+            size_t total = 0;
+            for (int f = 0; f < 2; f++) total += b->in[f].seq.size();
+            if (!b->reserve(std::max<size_t>(n, batch_reads), std::max<size_t>(total + 64, batch_reads * 160))) { rc = mcx_set_error(MCX_ERR_DEVICE, "cannot allocate pinned host memory"); b->n = 0; }
+            t_pack += secs(t0, now());
+        }
+        if (rc == 0 && n) {
+            const auto t0 = now();
             b->off[0] = 0;
-            for (uint32_t r = 0; r < n; r++) { int f; uint32_t i; b->locate(r, f, i); b->off[r + 1] = b->off[r] + (b->in[f].seq_off[i + 1] - b->in[f].seq_off[i]); }
-            b->bases.resize((size_t)b->off[n] + 64);
-            parallel_for(n, threads, [&](uint32_t lo, uint32_t hi, int) {
-                for (uint32_t r = lo; r < hi; r++) { int f; uint32_t i; b->locate(r, f, i); memcpy(b->bases.data() + b->off[r], b->in[f].seq.data() + b->in[f].seq_off[i], b->off[r + 1] - b->off[r]); }
+            if (two) for (uint32_t i = 0; i < n / 2; i++) { // mates alternate
+                b->off[2 * i + 1] = b->off[2 * i] + (b->in[0].seq_off[i + 1] - b->in[0].seq_off[i]);
+                b->off[2 * i + 2] = b->off[2 * i + 1] + (b->in[1].seq_off[i + 1] - b->in[1].seq_off[i]);
+            } else memcpy(b->off, b->in[0].seq_off.data(), ((size_t)n + 1) * sizeof(uint32_t));
+            if (two) parallel_for(n, threads, [&](uint32_t lo, uint32_t hi, int) {
+                for (uint32_t r = lo; r < hi; r++) { int f; uint32_t i; b->locate(r, f, i); memcpy(b->bases + b->off[r], b->in[f].seq.data() + b->in[f].seq_off[i], b->off[r + 1] - b->off[r]); }
             });
-            b->recs.resize(n); b->cig.resize((size_t)n * MCX_CIGAR_STRIDE); b->is_mate2.assign(n, 0);
-            // A batch is whole 200-read chunks plus, at the very end, one partial chunk; with an odd
-            // number of reads that last chunk is mapped as single reads (ReadMapping.cpp:442, :575)
+            else memcpy(b->bases, b->in[0].seq.data(), b->off[n]);
+            memset(b->bases + b->off[n], 0, 64);
+            b->is_mate2.assign(n, 0);
+            const auto t1 = now();
+            t_pack += secs(t0, t1);
             uint32_t n_pairs_reads = paired ? n : 0;
             if (paired && (n & 1)) n_pairs_reads = n / kReadChunkSize * kReadChunkSize;
             if (n_pairs_reads) {
-                rc = mcx_map_batch(c, b->bases.data(), b->off.data(), n_pairs_reads, 1, avg, (mcx_aln *)b->recs.data(), b->cig.data(), stats);
+                rc = mcx_map_batch(c, b->bases, b->off, n_pairs_reads, 1, avg, (mcx_aln *)b->recs, b->cig, stats);
                 for (uint32_t r = 1; r < n_pairs_reads; r += 2) b->is_mate2[r] = 1;
             }
             if (rc == 0 && n_pairs_reads < n) {
-                std::vector<uint32_t> off2(b->off.begin() + n_pairs_reads, b->off.end());
+                std::vector<uint32_t> off2(b->off + n_pairs_reads, b->off + n + 1);
                 const uint32_t base = off2[0];
                 for (auto &x : off2) x -= base;
-                rc = mcx_map_batch(c, b->bases.data() + base, off2.data(), n - n_pairs_reads, 0, avg, (mcx_aln *)b->recs.data() + n_pairs_reads,
-                                   b->cig.data() + (size_t)n_pairs_reads * MCX_CIGAR_STRIDE, stats);
+                rc = mcx_map_batch(c, b->bases + base, off2.data(), n - n_pairs_reads, 0, avg, (mcx_aln *)b->recs + n_pairs_reads,
+                                   b->cig + (size_t)n_pairs_reads * MCX_CIGAR_STRIDE, stats);
             }
+            t_map += secs(t1, now());
             if (rc) b->n = 0;
         }
         if (rc) abort.store(true);
@@ -379,6 +434,9 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
     }
     writer.join();
     reader.join();
+    if (getenv("MCX_TIMING"))
+        fprintf(stderr, "[mcx_map_files] busy seconds: parse %.2f | pack %.2f map %.2f | format %.2f write %.2f  (%d host threads)\n", t_parse, t_pack, t_map, t_format,
+                t_write, threads);
     if (sam && sam != stdout) { if (fclose(sam) != 0 && write_rc == 0) write_rc = MCX_ERR_IO; }
     else if (sam) fflush(sam);
     if (rc == 0 && write_rc) rc = mcx_set_error(MCX_ERR_IO, std::string("cannot write ") + (sam_path ? sam_path : ""));

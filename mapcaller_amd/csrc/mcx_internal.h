@@ -20,5 +20,7 @@ struct mcx_index {
 const mcx_index *mcx_ctx_index(const mcx_ctx *);
 int mcx_ctx_max_read_len(const mcx_ctx *);
 uint64_t mcx_ctx_max_reads(const mcx_ctx *);
+void *mcx_pinned_alloc(size_t bytes); // page-locked host memory (null on failure); mcx_pinned_free accepts null
+void mcx_pinned_free(void *);
 
 #endif

@@ -107,7 +107,7 @@ int main(int argc, char **argv)
     mcx_index *ix = nullptr;
     int rc = mcx_index_load(prefix.c_str(), gpu, 0, &ix);
     if (rc) { fprintf(stderr, "Error! %s\n", mcx_last_error()); return 1; }
-    o.max_batch_reads = 1 << 20;
+    o.max_batch_reads = 1 << 19; // per batch of the parse | map | format pipeline
     mcx_ctx *cx = nullptr;
     rc = mcx_ctx_create(ix, &o, &cx);
     if (rc) { fprintf(stderr, "Error! %s\n", mcx_last_error()); return 1; }

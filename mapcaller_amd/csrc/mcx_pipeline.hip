@@ -1229,3 +1229,5 @@ extern "C" int mcx_extend_batch(mcx_ctx *c, int alg, const uint8_t *q, const uin
 const mcx_index *mcx_ctx_index(const mcx_ctx *c) { return c->idx; }
 int mcx_ctx_max_read_len(const mcx_ctx *c) { return c->rlen_max; }
 uint64_t mcx_ctx_max_reads(const mcx_ctx *c) { return c->max_reads; }
+void *mcx_pinned_alloc(size_t bytes) { void *p = nullptr; return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
+void mcx_pinned_free(void *p) { if (p) (void)hipHostFree(p); }

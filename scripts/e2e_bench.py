@@ -52,7 +52,11 @@ def main():
 
     def run(x, y):
         t0 = time.perf_counter()
-        subprocess.run([exe, "-i", prefix, "-f", x, "-f2", y] + tail, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        r = subprocess.run([exe, "-i", prefix, "-f", x, "-f2", y] + tail, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                           env=dict(os.environ, MCX_TIMING="1"))
+        for l in r.stderr.split("\n"):
+            if l.startswith("[mcx_"):
+                print(l, file=sys.stderr)
         return time.perf_counter() - t0
     t_empty = run(e1, e2)
     t_full = run(f1, f2)
