@@ -216,7 +216,7 @@ def main():
             step(n_steps - 1)
             torch.cuda.synchronize()
             t_acc = time.perf_counter() - t1
-            sparse = mapper.profile_sparse()
+            sparse = mapper.profile_sparse_raw()
             t2 = time.perf_counter()
             planes, merged = mdist.reduce_profile(planes, sparse)
             torch.cuda.synchronize()

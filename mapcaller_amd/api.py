@@ -214,6 +214,12 @@ class Index:
                 v = v.encode()
                 keep.append(v)
             setattr(o, k, v)
+        if isinstance(sparse, np.ndarray):  # raw mcx_sparse_rec bytes
+            raw = np.ascontiguousarray(sparse, dtype=np.uint8).reshape(-1, 64)
+            st = VcfStats()
+            _check(lib().mcx_call_variants(self._h, d_planes_ptr, raw.ctypes.data, raw.shape[0], pairs, pair_dist_sum, pair_len_sum, C.byref(o),
+                                           vcf_path.encode(), C.byref(st)), "mcx_call_variants")
+            return st.as_dict()
         recs = (SparseRec * max(len(sparse), 1))()
         for i, (t, pos, x) in enumerate(sparse):
             r = recs[i]
@@ -302,6 +308,17 @@ class Mapper:
 
     def profile_finalize(self, d_planes_ptr: int) -> None:
         _check(lib().mcx_profile_finalize(self._h, d_planes_ptr), "mcx_profile_finalize")
+
+    def profile_sparse_raw(self) -> np.ndarray:
+        """The same records as they are (uint8 [n, 64] copies of mcx_sparse_rec), for all-gathers
+        and for Index.call_variants without a Python loop."""
+        recs = C.POINTER(SparseRec)()
+        n = C.c_uint64()
+        _check(lib().mcx_profile_sparse(self._h, C.byref(recs), C.byref(n)), "mcx_profile_sparse")
+        if n.value == 0:
+            return np.zeros((0, 64), dtype=np.uint8)
+        buf = (C.c_uint8 * (64 * n.value)).from_address(C.addressof(recs.contents))
+        return np.frombuffer(buf, dtype=np.uint8).reshape(n.value, 64).copy()
 
     def profile_sparse(self):
         """[(type, pos, seq or dist)]: 'I'/'D'/'B' events and 'V'/'T' discordant-site records."""

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 from typing import List, Sequence, Tuple
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -37,13 +38,30 @@ def finalize_planes(planes: torch.Tensor, max_dup: int = 5) -> torch.Tensor:
     return planes
 
 
-def reduce_profile(planes: torch.Tensor, sparse: Sequence[tuple]) -> Tuple[torch.Tensor, List[tuple]]:
-    """Sums the [10, G] counter planes over all ranks in place (all-reduce: RCCL on GPU tensors)
-    and gathers the sparse records of every rank in rank order.  Call before finalisation."""
+def reduce_profile(planes: torch.Tensor, sparse):
+    """Sums the [10, G] counter planes over all ranks in place (all-reduce: RCCL on GPU tensors),
+    one plane per call so that a collective never exceeds 2^31 elements, and gathers the sparse
+    records of every rank in rank order.  ``sparse`` is either the list of tuples of
+    Mapper.profile_sparse() or the raw uint8 [n, 64] array of Mapper.profile_sparse_raw(); the same
+    kind comes back.  Call before finalisation."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return planes, list(sparse)
-    dist.all_reduce(planes, op=dist.ReduceOp.SUM)
-    parts: List[list] = [None] * dist.get_world_size()  # type: ignore[list-item]
+        return planes, (sparse if isinstance(sparse, np.ndarray) else list(sparse))
+    for k in range(planes.shape[0]):
+        dist.all_reduce(planes[k], op=dist.ReduceOp.SUM)
+    world = dist.get_world_size()
+    if isinstance(sparse, np.ndarray):  # raw records: one padded all-gather of bytes
+        dev = planes.device
+        n = torch.tensor([sparse.shape[0]], dtype=torch.int64, device=dev)
+        counts = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(counts, n)
+        most = max(int(c.item()) for c in counts)
+        mine = torch.zeros((most, 64), dtype=torch.uint8, device=dev)
+        if sparse.shape[0]:
+            mine[: sparse.shape[0]] = torch.from_numpy(np.ascontiguousarray(sparse)).to(dev)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        return planes, np.concatenate([p[: int(c.item())].cpu().numpy() for p, c in zip(parts, counts)], axis=0)
+    parts = [None] * world
     dist.all_gather_object(parts, list(sparse))
     merged: List[tuple] = []
     for p in parts:

@@ -4,6 +4,7 @@ summed planes finalise to the reference's field widths."""
 import os
 import socket
 
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -30,6 +31,9 @@ def _worker(rank, world, port, out):
     mine = planes.clone()
     sparse = [("I", 10 * rank + k, "AC") for k in range(3)] + [("B", 7, "")]
     planes, merged = mdist.reduce_profile(planes, sparse)
+    raw = np.full((2 + rank, 64), rank + 1, dtype=np.uint8)  # raw record arrays of different lengths
+    _, raw_all = mdist.reduce_profile(torch.zeros((10, 4), dtype=torch.int32), raw)
+    assert raw_all.shape == (5, 64) and raw_all[:2].max() == 1 and raw_all[2:].min() == 2
     lo, hi = mdist.shard_pairs(12345, rank, world)
     t = mdist.max_over_ranks(1.0 + rank, torch.device("cpu"))
     tot = mdist.sum_over_ranks([100 + rank, 7 * (rank + 1), 1 << 40], torch.device("cpu"))  # run totals for the variant caller
