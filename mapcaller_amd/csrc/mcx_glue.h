@@ -274,9 +274,10 @@ struct RescueSerial {
 // diagonals are dealt round-robin to the lanes, the best (largest total, then smallest
 // diagonal) is found by a wave reduction, and lane 0 emits its seeds.  kq/kg live in LDS:
 // kq[r] is a broadcast read and kg[r + d] is conflict-free across consecutive diagonals.
-struct RescueWave {
+struct RescueWave { // one workgroup (any number of wavefronts) evaluates one pair
     uint32_t *kq, *kg;
-    __device__ bool leader() const { return (threadIdx.x & 63) == 0; }
+    int *red; // LDS scratch: 2 ints per wavefront + 4
+    __device__ bool leader() const { return threadIdx.x == 0; }
     __device__ void sync() const { __threadfence_block(); __syncthreads(); }
     __device__ void fill_query(const ReadRef &rq) const
     {
@@ -285,9 +286,9 @@ struct RescueWave {
     }
     __device__ RescueOut window(const IndexView &ix, int64_t left, int slen, int qlen, Hit *hits, int n_hits, int cap, bool &overflow) const
     {
-        const int lane = threadIdx.x & 63;
+        const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, n_waves = nt >> 6;
         __syncthreads();
-        for (int p = lane; p < slen; p += 64) {
+        for (int p = tid; p < slen; p += nt) {
             uint32_t wid = MCX_NOKMER;
             if (p + kKmerSize <= slen) {
                 wid = 0;
@@ -298,7 +299,7 @@ struct RescueWave {
         __syncthreads();
         int best_total = 0, best_d = 0x7fffffff, dummy = 0;
         bool ovd = false;
-        for (int d = -(qlen - 1) + lane; d <= slen - 1; d += 64) {
+        for (int d = -(qlen - 1) + tid; d <= slen - 1; d += nt) {
             const int total = diag_scan(kq, qlen, kg, slen, d, left, nullptr, 0, 0, dummy, ovd);
             if (total > best_total) { best_total = total; best_d = d; }
         }
@@ -306,15 +307,22 @@ struct RescueWave {
             const int ot = __shfl_xor(best_total, o, 64), od = __shfl_xor(best_d, o, 64);
             if (ot > best_total || (ot == best_total && od < best_d)) { best_total = ot; best_d = od; }
         }
-        RescueOut best; best.score = best_total; best.n_seeds = 0; best.d = best_total > 0 ? best_d : 0;
-        int ov = 0;
-        if (best_total > 0 && lane == 0) {
+        if (lane == 0) { red[2 * wave] = best_total; red[2 * wave + 1] = best_d; }
+        __syncthreads();
+        int *out = red + 2 * n_waves; // {score, d, n_seeds, overflow}
+        if (tid == 0) {
+            for (int w = 1; w < n_waves; w++) {
+                const int ot = red[2 * w], od = red[2 * w + 1];
+                if (ot > best_total || (ot == best_total && od < best_d)) { best_total = ot; best_d = od; }
+            }
+            int n_seeds = 0;
             bool o2 = false;
-            diag_scan(kq, qlen, kg, slen, best.d, left, hits, n_hits, cap, best.n_seeds, o2);
-            ov = o2 ? 1 : 0;
+            if (best_total > 0) diag_scan(kq, qlen, kg, slen, best_d, left, hits, n_hits, cap, n_seeds, o2);
+            out[0] = best_total; out[1] = best_total > 0 ? best_d : 0; out[2] = n_seeds; out[3] = o2 ? 1 : 0;
         }
-        best.n_seeds = __shfl(best.n_seeds, 0, 64);
-        if (__shfl(ov, 0, 64)) overflow = true;
+        __syncthreads();
+        RescueOut best; best.score = out[0]; best.d = out[1]; best.n_seeds = out[2];
+        if (out[3]) overflow = true;
         return best;
     }
 };

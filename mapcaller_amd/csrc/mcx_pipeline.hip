@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel,
         PackedRead pk; pk.w = pk_lds + threadIdx.x; pk.stride = blockDim.x; pk.n_code = 0;
         const int n = rd.rlen <= 0 || packed_words(rd.rlen) > pk_words ? 0 : seed_read(cx.ix, rd, pk, st.hits[s], cx.caps.hit_cap, ext, blocks);
         st.hdr->n_hits[s] = n;
-        so.read_ext[r] = (uint32_t)ext; so.read_blocks[r] = (uint32_t)blocks;
+        so.read_ext[r] = (uint32_t)ext; so.read_blocks[r] = (uint32_t)blocks | ((uint32_t)n << 20); // (blocks < 2^20; n < 2^12)
         keep = n <= cx.caps.hit_cap ? n : 0; // overflowing reads are re-run in the next tier
     }
     // SA tasks only for the hits that are still BWT rows; the others carry their text position
@@ -400,13 +400,17 @@ __global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel s
     if (need && at < rl.cap) rl.ids[at] = local;
 }
 
-__global__ void __launch_bounds__(64) k_rescue(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl)
+constexpr int kRescueThreads = 256;
+
+__global__ void __launch_bounds__(kRescueThreads) k_rescue(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl)
 {
-    // one wavefront per unpaired pair; 8-mer ids of the read and of the window live in LDS
+    // one workgroup per unpaired pair (they are few, and one pair's windows are a long serial chain
+    // for a single wavefront); 8-mer ids of the read and of the window live in LDS
     __shared__ uint32_t kq[1024];
     __shared__ uint32_t kg[4096 + 64];
+    __shared__ int red[2 * (kRescueThreads / 64) + 4];
     const uint32_t n = min(*rl.n, rl.cap);
-    RescueWave ev; ev.kq = kq; ev.kg = kg;
+    RescueWave ev; ev.kq = kq; ev.kg = kg; ev.red = red;
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
         const uint32_t local = rl.ids[i];
         ReadRef rd[2];
@@ -736,7 +740,7 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
     k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
-    if (paired) k_rescue<<<8192, 64, 0, s>>>(cx, rb, sel, rl);
+    if (paired) k_rescue<<<4096, kRescueThreads, 0, s>>>(cx, rb, sel, rl);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
     k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, c->d_cnt + CNT_CELLS, c->d_cnt + CNT_UNSUP);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
@@ -755,8 +759,10 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     if (n[CNT_RESCUE] > c->rescue_cap) return fail(MCX_ERR_CAPACITY, "rescue list overflow");
     for (int k = 0; k < 4; k++) if (n[CNT_JOB0 + k] > c->job_cap[k]) return fail(MCX_ERR_CAPACITY, "DP job list overflow");
     if (n[CNT_UNSUP]) return fail(MCX_ERR_UNSUPPORTED, "a gapped fragment exceeds 2048 x 1024 cells per side");
+    if (timing && getenv("MCX_TIMING"))
+        fprintf(stderr, "[run_pairs] pairs %u: sa tasks %u, rescue pairs %u, dp jobs by class %u %u %u %u, cells %u, overflow pairs %u\n", sel.n, n[CNT_TASKS],
+                n[CNT_RESCUE], n[CNT_JOB0], n[CNT_JOB1], n[CNT_JOB2], n[CNT_JOB3], n[CNT_CELLS], n[CNT_OV]);
     if (stats) {
-        stats->sa_hits += n[CNT_TASKS];
         stats->dp_jobs += (int64_t)n[CNT_JOB0] + n[CNT_JOB1] + n[CNT_JOB2] + n[CNT_JOB3];
         stats->dp_cells += n[CNT_CELLS];
         if (timing) {
@@ -777,10 +783,10 @@ __global__ void k_fill_i32(int32_t *p, int32_t v, uint32_t n)
 
 __global__ void k_reduce_stats(const uint32_t *a, const uint32_t *b, uint32_t n, unsigned long long *out)
 {
-    unsigned long long sa = 0, sb = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { sa += a[i]; sb += b[i]; }
-    for (int o = 32; o > 0; o >>= 1) { sa += __shfl_down(sa, o, 64); sb += __shfl_down(sb, o, 64); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(out, sa); atomicAdd(out + 1, sb); }
+    unsigned long long sa = 0, sb = 0, sh = 0; // extension steps, blocks touched, hits (H of SURVEY.md §8d)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { sa += a[i]; sb += b[i] & 0xFFFFFu; sh += b[i] >> 20; }
+    for (int o = 32; o > 0; o >>= 1) { sa += __shfl_down(sa, o, 64); sb += __shfl_down(sb, o, 64); sh += __shfl_down(sh, o, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(out, sa); atomicAdd(out + 1, sb); atomicAdd(out + 2, sh); }
 }
 
 // ---- avgDist replay on the device (the host only walks the per-chunk sums) ---------------------
@@ -890,7 +896,7 @@ extern "C" int mcx_map_batch_dev(mcx_ctx *c, const uint8_t *d_bases, const uint3
     const uint32_t chunk = kReadChunkSize / 2, n_chunks = (n_pairs + chunk - 1) / chunk;
     uint32_t *d_ok = c->d_read_ext, *d_ds = c->d_read_blocks; // per-read stat arrays are reduced below, before reuse
     uint32_t *d_ls = d_ds + n_chunks;                         // (2 * n_chunks <= n_reads)
-    unsigned long long hs[2] = {0, 0};
+    unsigned long long hs[3] = {0, 0, 0};
     {
         unsigned long long *d_sum = (unsigned long long *)c->d_cnt;
         HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
@@ -950,7 +956,7 @@ extern "C" int mcx_map_batch_dev(mcx_ctx *c, const uint8_t *d_bases, const uint3
     if (c->prof_planes) { rc = profile_batch(c, rb, paired); if (rc) return rc; }
     if (stats) {
         stats->reads += n_reads; stats->mapped += mapped; stats->pairs += pairs; stats->pair_dist_sum += dist_sum; stats->pair_len_sum += len_sum;
-        stats->fm_ext_steps += (int64_t)hs[0]; stats->fm_blocks += (int64_t)hs[1];
+        stats->fm_ext_steps += (int64_t)hs[0]; stats->fm_blocks += (int64_t)hs[1]; stats->sa_hits += (int64_t)hs[2];
         stats->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return 0;
