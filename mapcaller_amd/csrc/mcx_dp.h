@@ -45,12 +45,13 @@ static __device__ __forceinline__ void dp_sync()
 struct DpBuf { uint8_t *q, *t, *dir; };
 
 // where a (qlen x tlen) problem keeps its sequences and traceback: LDS when it fits
-static __device__ __forceinline__ DpBuf dp_buffers(int qlen, int tlen, uint8_t *lds, uint8_t *spill)
+// (lds holds lds_seq bytes for the two sequences followed by lds_dir bytes of traceback)
+static __device__ __forceinline__ DpBuf dp_buffers(int qlen, int tlen, uint8_t *lds, uint8_t *spill, int lds_seq = kDpLdsSeq, int lds_dir = kDpLdsDir)
 {
     DpBuf b;
-    if (qlen <= kDpLdsSeq / 2 && tlen <= kDpLdsSeq / 2) { b.q = lds; b.t = lds + kDpLdsSeq / 2; }
+    if (qlen <= lds_seq / 2 && tlen <= lds_seq / 2) { b.q = lds; b.t = lds + lds_seq / 2; }
     else { b.q = spill; b.t = spill + kDpSpillSeq / 2; }
-    b.dir = ((int64_t)(qlen + tlen - 1) * tlen <= kDpLdsDir) ? lds + kDpLdsSeq : spill + kDpSpillSeq;
+    b.dir = ((int64_t)(qlen + tlen - 1) * tlen <= lds_dir) ? lds + lds_seq : spill + kDpSpillSeq;
     return b;
 }
 

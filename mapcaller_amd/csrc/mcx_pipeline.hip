@@ -455,11 +455,17 @@ __global__ void __launch_bounds__(256) k_build(Ctx cx, ReadBatch rb, PairSel sel
     if ((threadIdx.x & 63) == 0) { if (my_cells) atomicAdd(cells, my_cells); if (bad) atomicAdd(unsupported, bad); }
 }
 
+// LDS per problem is sized per class: the small classes are latency-bound (a chain of dependent
+// fetches per problem), so what counts is how many problems a CU holds at once; the rare problem
+// that does not fit its class's LDS keeps its sequences / traceback in the workgroup's HBM scratch.
+template <int K> struct DpLds { static constexpr int seq = kDpLdsSeq, dir = kDpLdsDir; };
+template <> struct DpLds<1> { static constexpr int seq = 512, dir = 4096; }; // targets <= 64: e.g. 48 x 48 fits
+
 template <int K>
 __global__ void __launch_bounds__(64) k_dp_sel(Ctx cx, JobSink sink, ReadBatch rb, PairSel sel, uint8_t *scratch,
                                                uint64_t scratch_stride)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kDpLdsSeq + kDpLdsDir];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[DpLds<K>::seq + DpLds<K>::dir];
     uint8_t *spill = scratch + (uint64_t)blockIdx.x * scratch_stride;
     const int nr = cx.pm.paired ? 2 : 1;
     const int lane = threadIdx.x;
@@ -469,7 +475,7 @@ __global__ void __launch_bounds__(64) k_dp_sel(Ctx cx, JobSink sink, ReadBatch r
         const uint32_t read = sel_pair(sel, job.pair) * nr + job.slot;
         ReadRef rd;
         rd.ascii = rb.bases + rb.off[read]; rd.rlen = (int)(rb.off[read + 1] - rb.off[read]); rd.flipped = (cx.pm.paired && job.slot == 1) ? 1 : 0;
-        const DpBuf b = dp_buffers(job.rLen, job.gLen, lds, spill);
+        const DpBuf b = dp_buffers(job.rLen, job.gLen, lds, spill, DpLds<K>::seq, DpLds<K>::dir);
         // q = read fragment, t = genome fragment; both reversed on the reverse strand (the
         // reference also complements both, which no comparison can see)
         for (int i = lane; i < job.rLen; i += 64) b.q[i] = (uint8_t)read_code(rd, job.rev ? job.rPos + job.rLen - 1 - i : job.rPos + i);
@@ -572,6 +578,7 @@ struct mcx_ctx {
     uint32_t *h_cnt = nullptr;   // pinned mirror
     uint32_t *d_rescue = nullptr; uint32_t rescue_cap = 0;
     uint32_t *d_kscratch = nullptr; uint32_t k_threads = 0, k_per_thread = 0;
+    hipStream_t dp_stream[3] = {nullptr, nullptr, nullptr}; hipEvent_t dp_fork = nullptr, dp_join[3] = {nullptr, nullptr, nullptr};
     uint8_t *d_dp_scratch[3] = {nullptr, nullptr, nullptr}; uint64_t dp_stride[3] = {0, 0, 0}; uint32_t dp_blocks[3] = {0, 0, 0};
     uint32_t *d_ov = nullptr; uint32_t ov_cap = 0;
     uint32_t *d_sel_ids = nullptr; int32_t *d_est = nullptr;
@@ -632,6 +639,8 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
     c->max_bases = c->max_reads * (uint64_t)c->rlen_max;
     HIP_TRY(hipSetDevice(idx->device));
     HIP_TRY(hipStreamCreate(&c->stream));
+    for (int k = 0; k < 3; k++) { HIP_TRY(hipStreamCreateWithFlags(&c->dp_stream[k], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&c->dp_join[k], hipEventDisableTiming)); }
+    HIP_TRY(hipEventCreateWithFlags(&c->dp_fork, hipEventDisableTiming));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     int rc = 0;
     c->tier[0].caps = tier0_caps(); c->tier[0].lay = make_layout(c->tier[0].caps); c->tier[0].max_pairs = (uint32_t)c->max_reads;
@@ -694,6 +703,8 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     if (c->h_pout) (void)hipHostFree(c->h_pout);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (int k = 0; k < 3; k++) { if (c->dp_stream[k]) (void)hipStreamDestroy(c->dp_stream[k]); if (c->dp_join[k]) (void)hipEventDestroy(c->dp_join[k]); }
+    if (c->dp_fork) (void)hipEventDestroy(c->dp_fork);
     delete c;
 }
 
@@ -744,10 +755,15 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
     k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, c->d_cnt + CNT_CELLS, c->d_cnt + CNT_UNSUP);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
-    k_dp_small<<<2560, 256, 0, s>>>(cx, sinks.s[0], rb, sel);
+    // the four size classes work on disjoint job lists and are each bound by latency at modest
+    // occupancy: side streams let them share the chip instead of queueing behind one another
+    HIP_TRY(hipEventRecord(c->dp_fork, s));
+    for (int k = 0; k < 3; k++) HIP_TRY(hipStreamWaitEvent(c->dp_stream[k], c->dp_fork, 0));
     k_dp_sel<1><<<c->dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, c->d_dp_scratch[0], c->dp_stride[0]);
-    k_dp_sel<4><<<c->dp_blocks[1], 64, 0, s>>>(cx, sinks.s[2], rb, sel, c->d_dp_scratch[1], c->dp_stride[1]);
-    k_dp_sel<16><<<c->dp_blocks[2], 64, 0, s>>>(cx, sinks.s[3], rb, sel, c->d_dp_scratch[2], c->dp_stride[2]);
+    k_dp_small<<<2560, 256, 0, c->dp_stream[0]>>>(cx, sinks.s[0], rb, sel);
+    k_dp_sel<4><<<c->dp_blocks[1], 64, 0, c->dp_stream[1]>>>(cx, sinks.s[2], rb, sel, c->d_dp_scratch[1], c->dp_stride[1]);
+    k_dp_sel<16><<<c->dp_blocks[2], 64, 0, c->dp_stream[2]>>>(cx, sinks.s[3], rb, sel, c->d_dp_scratch[2], c->dp_stride[2]);
+    for (int k = 0; k < 3; k++) { HIP_TRY(hipEventRecord(c->dp_join[k], c->dp_stream[k])); HIP_TRY(hipStreamWaitEvent(s, c->dp_join[k], 0)); }
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
     k_finish<<<pb, 256, 0, s>>>(cx, rb, sel, d_recs, d_cig, c->d_pout, c->d_ov, c->d_cnt + CNT_OV, c->ov_cap);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
