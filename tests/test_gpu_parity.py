@@ -5,6 +5,7 @@ import ctypes
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -287,3 +288,41 @@ def test_cli_two_libraries(io_golden, tmp_path):
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
     nd, ex = sam_diff(g["ref.lib.sam"], sam)
     assert nd == 0, ex
+
+
+def test_full_size_genome_prefix_equals_reference(api, tmp_path):
+    """bench.py's workload at full size (2 Gbp synthetic genome: text positions beyond 2^32, the
+    12-mer jump table, the full suffix array in HBM): the index is built on the GPU, saved, and the
+    first 60 k pairs of a bench batch go through the product's file path and through the CPU checker
+    (the compiled reference at -t 1 when it travelled, else the oracle restatement).  The insert-size
+    trajectory of a prefix is the trajectory of the run, so the SAM must be identical."""
+    import argparse
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from mapcaller_amd import synth
+    dev = torch.device("cuda", 0)
+    args = argparse.Namespace(genome_mbp=2000.0, contigs=24, repeats=2000)
+    codes, lens = bench.make_genome(args, dev, seed=1234)
+    ix = api.Index.from_codes(codes.data_ptr(), lens, device=0, full_sa=True)
+    prefix = str(tmp_path / "big")
+    ix.save(prefix)
+    n_pairs = 60000
+    reads = bench.make_reads(codes, lens, n_pairs, 150, seed=1000, device=dev).reshape(2 * n_pairs, 150).cpu()
+    del codes
+    f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+    synth.write_fastq(f1, reads, 0, 2); synth.write_fastq(f2, reads, 1, 2)
+    mp = api.Mapper(ix, alg="ksw2", max_batch_reads=1 << 16)
+    out = str(tmp_path / "gpu.sam")
+    st = mp.map_files(f1, f2, out)
+    mp.close(); ix.close()
+    chk = str(tmp_path / "chk.sam")
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "MapCaller")
+    if os.path.exists(ref_bin):
+        cmd = [ref_bin, "-i", prefix, "-f", f1, "-f2", f2, "-alg", "ksw2", "-sam", chk, "-no_vcf", "-t", "1", "-log", str(tmp_path / "job.log")]
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1500)
+    else:
+        _oracle_sam(prefix, f1, f2, "ksw2", chk)
+    nd, ex = sam_diff(chk, out)
+    assert nd == 0, ex
+    assert st["mapped"] > 0.98 * st["reads"]
