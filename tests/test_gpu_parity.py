@@ -326,3 +326,45 @@ def test_full_size_genome_prefix_equals_reference(api, tmp_path):
     nd, ex = sam_diff(chk, out)
     assert nd == 0, ex
     assert st["mapped"] > 0.98 * st["reads"]
+
+
+def test_ragged_reads_equal_oracle(api, tmp_path):
+    """Read lengths from 12 to 300 in one batch (mates trimmed independently), some below the 16-base
+    seed minimum, Ns sprinkled in: GPU SAM == oracle SAM (== the reference when it is here and survives)."""
+    from mapcaller_amd import synth
+    rng = np.random.default_rng(77)
+    g = synth.random_genome([600000, 300000], seed=303, n_repeats=30, repeat_len=700, tandem=10, n_runs=6)
+    fa = str(tmp_path / "g.fa")
+    synth.write_fasta(fa, g)
+    prefix = str(tmp_path / "g")
+    api.Index.build(fa, prefix, 0)
+    n = 6000
+    bases, _ = synth.simulate_reads(synth.mutate_genome(g, 9), n, 300, True, seed=8, skip_head=3000, frag_mean=700, frag_sd=80, frag_min=350,
+                                    frag_max=1000, sub=0.01, ins=0.002, dele=0.002, n_rate=0.003)
+    arr = bases.cpu().numpy()
+    lens = rng.integers(12, 301, size=arr.shape[0])
+    lens[rng.random(arr.shape[0]) < 0.5] = 150
+    for k, path in ((0, "r1.fq"), (1, "r2.fq")):
+        with open(tmp_path / path, "wb") as fh:
+            for i in range(k, arr.shape[0], 2):
+                s = arr[i, : lens[i]].tobytes()
+                fh.write(b"@rag_%05d\n%s\n+\n%s\n" % (i // 2, s, b"F" * len(s)))
+    f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+    ix = api.Index(prefix, device=0)
+    mp = api.Mapper(ix, alg="ksw2", max_read_len=320, max_batch_reads=4000)
+    out = str(tmp_path / "gpu.sam")
+    st = mp.map_files(f1, f2, out)
+    ora = str(tmp_path / "ora.sam")
+    _oracle_sam(prefix, f1, f2, "ksw2", ora)
+    nd, ex = sam_diff(ora, out)
+    assert nd == 0, ex
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "MapCaller")
+    if os.path.exists(ref_bin):
+        rs = str(tmp_path / "ref.sam")
+        r = subprocess.run([ref_bin, "-i", prefix, "-f", f1, "-f2", f2, "-alg", "ksw2", "-sam", rs, "-no_vcf", "-t", "1", "-log", str(tmp_path / "job.log")],
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        if r.returncode == 0:
+            nd, ex = sam_diff(rs, out)
+            assert nd == 0, ex
+    assert st["mapped"] > 0.8 * st["reads"]
+    mp.close(); ix.close()
