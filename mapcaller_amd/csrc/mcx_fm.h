@@ -359,12 +359,34 @@ static inline MCX_HD int seed_read(const IndexView &ix, const ReadRef &rd, Packe
         if (x2 == 1) { // phase 3: the rest of the search against the text itself
             int lf = 0;
             tpos = (int64_t)fm_sa(ix, x0, lf);
+            // Consecutive windows overlap by one packed genome word: while the walk advances by whole
+            // windows the word is carried over, so each further window costs ONE 4-byte fetch.
+            uint32_t carry = 0;
+            int carry_dir = 0; // 0: none, +1: forward strand (carry = next window's high word), -1: reverse strand (its low word)
             for (;;) {
                 const int64_t j = tpos + (p - start);
                 int64_t room = (int64_t)ix.seq_len - j;
                 if (rlen - p < room) room = rlen - p;
                 if (room <= 0) break;
-                const uint32_t x = packed_codes16(pk, p) ^ ref_codes16(ix, j);
+                uint32_t ref;
+                if (j + 16 <= ix.G) { // forward strand: funnel shift of two big-endian words of the .pac bytes
+                    const uint32_t *wp = (const uint32_t *)ix.pac + (j >> 4);
+                    const int sh = (int)(j & 15) * 2;
+                    const uint32_t hi = carry_dir > 0 ? carry : __builtin_bswap32(wp[0]), lo = __builtin_bswap32(wp[1]);
+                    ref = sh ? (hi << sh) | (lo >> (32 - sh)) : hi;
+                    carry = lo; carry_dir = 1;
+                } else if (j >= ix.G && j + 16 <= ix.G2) { // reverse strand: the mirrored forward window, reversed and complemented
+                    const int64_t f = ix.G2 - 16 - j;
+                    const uint32_t *wp = (const uint32_t *)ix.pac + (f >> 4);
+                    const int sh = (int)(f & 15) * 2;
+                    const uint32_t hi = __builtin_bswap32(wp[0]), lo = carry_dir < 0 ? carry : __builtin_bswap32(wp[1]);
+                    uint32_t v = __builtin_bswap32(sh ? (hi << sh) | (lo >> (32 - sh)) : hi);
+                    v = ((v & 0x0F0F0F0Fu) << 4) | ((v >> 4) & 0x0F0F0F0Fu);
+                    v = ((v & 0x33333333u) << 2) | ((v >> 2) & 0x33333333u);
+                    ref = ~v;
+                    carry = hi; carry_dir = -1;
+                } else { ref = ref_codes16(ix, j); carry_dir = 0; }
+                const uint32_t x = packed_codes16(pk, p) ^ ref;
                 uint32_t sp = packed_nmask32(pk, p, rlen) >> 16; // N flags, bit 15-s -> bit 30-2s
                 sp = (sp | (sp << 8)) & 0x00FF00FFu; sp = (sp | (sp << 4)) & 0x0F0F0F0Fu;
                 sp = (sp | (sp << 2)) & 0x33333333u; sp = (sp | (sp << 1)) & 0x55555555u;
