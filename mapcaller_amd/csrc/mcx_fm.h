@@ -203,15 +203,34 @@ static inline MCX_HD int end_slot(const IndexView &ix, int64_t gPos)
 // the bi-interval BWT_Search holds after consuming the K bases spelled by i (first base most
 // significant), or x2 = 0 when some extension inside the K-mer comes up empty.  A search that
 // starts on a K-mer present in the genome replaces its first K-1 extension steps — the ones with
-// wide intervals, two block fetches each — by one 32-byte fetch.
+// wide intervals, two block fetches each — by one 16-byte fetch.  K grows with the text
+// (4^K <= seq_len / 2, at most 15), so that the interval a search leaves the table with holds only
+// a handful of suffixes and one or two FM steps reach the single-suffix phase.
+// Entry: three 40-bit numbers — words 0..2 the low halves of x0, x1, x2, word 3 their bits 32..39.
+static inline MCX_HD U4 ktab_pack(uint64_t x0, uint64_t x1, uint64_t x2)
+{
+    U4 e;
+    if (x2 == 0) { e.x = e.y = e.z = e.w = 0; return e; }
+    e.x = (uint32_t)x0; e.y = (uint32_t)x1; e.z = (uint32_t)x2;
+    e.w = (uint32_t)((x0 >> 32) & 0xFF) | ((uint32_t)((x1 >> 32) & 0xFF) << 8) | ((uint32_t)((x2 >> 32) & 0xFF) << 16);
+    return e;
+}
+
 static inline MCX_HD bool ktab_lookup(const IndexView &ix, uint32_t idx, uint64_t &x0, uint64_t &x1, uint64_t &x2)
 {
-    const U4 *p = (const U4 *)ix.ktab + (uint64_t)idx * 2;
-    const U4 a = p[0], b = p[1];
-    x0 = (uint64_t)a.x | ((uint64_t)a.y << 32);
-    x1 = (uint64_t)a.z | ((uint64_t)a.w << 32);
-    x2 = (uint64_t)b.x | ((uint64_t)b.y << 32);
+    const U4 e = ((const U4 *)ix.ktab)[idx];
+    x0 = (uint64_t)e.x | ((uint64_t)(e.w & 0xFF) << 32);
+    x1 = (uint64_t)e.y | ((uint64_t)((e.w >> 8) & 0xFF) << 32);
+    x2 = (uint64_t)e.z | ((uint64_t)((e.w >> 16) & 0xFF) << 32);
     return x2 != 0;
+}
+
+// the K the table is built with for a text of seq_len positions
+static inline int ktab_k_for(uint64_t seq_len)
+{
+    int k = 8;
+    while (k < 15 && (4ull << (2 * k)) <= seq_len / 2) k++;
+    return k;
 }
 
 // what the table holds for one K-mer: BWT_Search's first K-1 extensions (bwt_search.cpp:128-151)
@@ -240,7 +259,7 @@ constexpr int32_t kHitResolved = 1 << 30;
 // The read is packed once into 2-bit words (16 bases per u32, base s of a word at bits 30-2s, the
 // layout of the .pac bytes read big-endian) plus an N mask (bit 31-s of word s/32), in a small
 // per-lane scratch (LDS on the device, strided so that lanes never share a bank).  After that the
-// walk never touches the ASCII read again: the 12-mer of a search start, the next base of an
+// walk never touches the ASCII read again: the K-mer of a search start, the next base of an
 // FM step and 16-base windows for the direct comparison are all shifts of those words.
 struct PackedRead {
     uint32_t *w;      // lane's first word; word k at w[k * stride]
@@ -323,7 +342,7 @@ static inline MCX_HD uint32_t ref_codes16(const IndexView &ix, int64_t j)
 //
 // Three phases per search, each as cheap as it can be made without changing a result:
 //  1. start: if the next ktab_k bases hold no N and that k-mer occurs in the text, its bi-interval
-//     comes from the jump table (one 32-byte fetch instead of ktab_k - 1 wide-interval steps);
+//     comes from the jump table (one 16-byte fetch instead of ktab_k - 1 wide-interval steps);
 //  2. FM steps (one or two 64-byte block fetches each) while the interval holds several suffixes;
 //  3. once it holds exactly one (x2 == 1) the pattern has one occurrence in the text, so "can it
 //     be extended by base c" is "is the next text base c": the suffix is resolved to its text

@@ -74,29 +74,27 @@ __global__ void k_expand_sa(IndexView ix, uint64_t n_sa, uint64_t *full)
     }
 }
 
-__global__ void k_build_ktab(IndexView ix, int K, uint32_t *tab)
+__global__ void k_build_ktab(IndexView ix, int K, U4 *tab)
 {
     const uint64_t n = 1ull << (2 * K);
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t x0, x1, x2;
         ktab_entry(ix, (uint32_t)i, K, x0, x1, x2);
-        U4 a, b;
-        a.x = (uint32_t)x0; a.y = (uint32_t)(x0 >> 32); a.z = (uint32_t)x1; a.w = (uint32_t)(x1 >> 32);
-        b.x = (uint32_t)x2; b.y = (uint32_t)(x2 >> 32); b.z = 0; b.w = 0;
-        if (x2 == 0) { a.x = a.y = a.z = a.w = 0; }
-        ((U4 *)tab)[2 * i] = a; ((U4 *)tab)[2 * i + 1] = b;
+        tab[i] = ktab_pack(x0, x1, x2);
     }
 }
 
-// the 12-mer jump table of the seeding walk (mcx_fm.h): 16.7 M entries, 512 MB
+// the K-mer jump table of the seeding walk (mcx_fm.h): 16 bytes per K-mer, K from the text length
+// (MCX_KTAB_K overrides it for experiments)
 static int build_ktab(mcx_index *ix)
 {
-    const int K = 12;
-    const size_t bytes = (size_t)32 << (2 * K);
+    int K = ktab_k_for(ix->view.seq_len);
+    if (const char *e = getenv("MCX_KTAB_K")) { const int k = atoi(e); if (k >= 4 && k <= 15) K = k; }
+    const size_t bytes = (size_t)16 << (2 * K);
     hipError_t e = hipMalloc(&ix->d_ktab, bytes);
     if (e != hipSuccess) { g_err = std::string("hipMalloc(ktab): ") + hipGetErrorString(e); return MCX_ERR_DEVICE; }
     ix->view.ktab = nullptr; ix->view.ktab_k = K;
-    k_build_ktab<<<4096, 256>>>(ix->view, K, (uint32_t *)ix->d_ktab);
+    k_build_ktab<<<8192, 256>>>(ix->view, K, (U4 *)ix->d_ktab);
     e = hipDeviceSynchronize();
     if (e != hipSuccess) { g_err = std::string("k_build_ktab: ") + hipGetErrorString(e); return MCX_ERR_DEVICE; }
     ix->view.ktab = (const uint32_t *)ix->d_ktab;

@@ -43,14 +43,13 @@ static void set_view(Emu &e)
     v.n_ends = (int)h.end_pos.size(); v.n_chr = (int)h.chr_len.size(); v.sa_intv = h.sa_intv;
     v.ktab = nullptr; v.ktab_k = 0;
     const int K = 7;
-    e.ktab.assign((size_t)8 << (2 * K), 0);
+    e.ktab.assign((size_t)4 << (2 * K), 0);
     for (uint32_t i = 0; i < (1u << (2 * K)); i++) {
         uint64_t x0, x1, x2;
         ktab_entry(v, i, K, x0, x1, x2);
-        if (x2 == 0) continue;
-        uint32_t *w = e.ktab.data() + (size_t)i * 8;
-        w[0] = (uint32_t)x0; w[1] = (uint32_t)(x0 >> 32); w[2] = (uint32_t)x1; w[3] = (uint32_t)(x1 >> 32);
-        w[4] = (uint32_t)x2; w[5] = (uint32_t)(x2 >> 32);
+        const U4 p = ktab_pack(x0, x1, x2);
+        uint32_t *w = e.ktab.data() + (size_t)i * 4;
+        w[0] = p.x; w[1] = p.y; w[2] = p.z; w[3] = p.w;
     }
     v.ktab = e.ktab.data(); v.ktab_k = K;
 }
