@@ -116,7 +116,8 @@ typedef struct mcx_stats {
 
 /* Replaces the body of ReadMapping() for one batch (reference src/ReadMapping.cpp:416-646):
  * seeding, clustering, pairing, rescue, extension, scoring, flags/MAPQ/CIGAR.  d_bases: ASCII
- * reads in HBM, d_off: n_reads+1 byte offsets (device), paired: mates interleaved.
+ * reads in HBM (16-byte aligned, readable up to 32 bytes past the last base: whole 16-byte words
+ * are fetched), d_off: n_reads+1 byte offsets (device), paired: mates interleaved.
  * avg_state[4] carries the reference's running insert-size estimate across batches
  * {avgDist, iTotalPairedNum, TotalPairedDistance, reads seen} (ReadMapping.cpp:20-21,:538-539);
  * initialise with mcx_avg_init.  Results (device): d_aln[n_reads], d_cigar[n_reads*MCX_CIGAR_STRIDE]. */

@@ -350,11 +350,12 @@ static inline MCX_HD uint32_t ref_codes16(const IndexView &ix, int64_t j)
 //     windows of the packed read against the 2-bit genome.  Same length, same position.
 // The loop iterates over FM steps and searches, not over bases, so that the lanes of a wave —
 // which sit at unrelated points of their reads — execute few iterations in total.
+// (prepacked: pk already holds the read's words — the device packs whole batches in one pass)
 static inline MCX_HD int seed_read(const IndexView &ix, const ReadRef &rd, PackedRead pk, Hit *hits, int cap,
-                                   int64_t &ext_steps, int64_t &blocks)
+                                   int64_t &ext_steps, int64_t &blocks, bool prepacked = false)
 {
     const int rlen = rd.rlen;
-    pack_read(rd, pk);
+    if (!prepacked) pack_read(rd, pk);
     int n_hits = 0;
     const int stop = rlen - kMinSeedLength;
     int p = 0, start = 0;

@@ -326,7 +326,105 @@ struct SeedOut {
     uint32_t task_cap;
     uint32_t *read_ext;      // per batch read: extension steps, blocks touched
     uint32_t *read_blocks;
+    const uint32_t *packed;  // 2-bit reads of the batch (k_pack_reads), wpad words each
+    int wpad;
 };
+
+// 16 bytes from any address: two aligned 16-byte fetches and a byte funnel
+static __device__ __forceinline__ U4 load16_unaligned(const uint8_t *p)
+{
+    const uintptr_t a = (uintptr_t)p;
+    const U4 *q = (const U4 *)(a & ~(uintptr_t)15);
+    const U4 lo = q[0];
+    const unsigned sh = (unsigned)(a & 15);
+    if (sh == 0) return lo;
+    const U4 hi = q[1];
+    const unsigned qd = sh >> 2, b = sh & 3;
+    uint32_t s0, s1, s2, s3, s4;
+    switch (qd) {
+    case 0: s0 = lo.x; s1 = lo.y; s2 = lo.z; s3 = lo.w; s4 = hi.x; break;
+    case 1: s0 = lo.y; s1 = lo.z; s2 = lo.w; s3 = hi.x; s4 = hi.y; break;
+    case 2: s0 = lo.z; s1 = lo.w; s2 = hi.x; s3 = hi.y; s4 = hi.z; break;
+    default: s0 = lo.w; s1 = hi.x; s2 = hi.y; s3 = hi.z; s4 = hi.w; break;
+    }
+    U4 r;
+    r.x = __builtin_amdgcn_alignbyte(s1, s0, b); r.y = __builtin_amdgcn_alignbyte(s2, s1, b);
+    r.z = __builtin_amdgcn_alignbyte(s3, s2, b); r.w = __builtin_amdgcn_alignbyte(s4, s3, b);
+    return r;
+}
+
+// four ASCII bytes (first base in the low byte) -> 8 code bits (first base on top) and 4 N flags
+// (first base on top); `comp`: complement the bases (mate 2).  nt4_code (mcx_fm.h) on four lanes of
+// one register: fold case, A/C/G/T membership by zero-byte tests, (c >> 1) & 3 hashes A0 C1 T2 G3.
+static __device__ __forceinline__ void pack4(uint32_t w, bool comp, uint32_t &codes, uint32_t &flags)
+{
+    const uint32_t c = w & 0xDFDFDFDFu;
+    auto zero_bytes = [](uint32_t t) { return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu); }; // 0x80 where a byte is 0
+    const uint32_t member = (zero_bytes(c ^ 0x41414141u) | zero_bytes(c ^ 0x43434343u) | zero_bytes(c ^ 0x47474747u) | zero_bytes(c ^ 0x54545454u)) >> 7; // 0x01 per base
+    const uint32_t h = (c >> 1) & 0x03030303u;
+    uint32_t code = h ^ ((h >> 1) & 0x01010101u);
+    if (comp) code ^= 0x03030303u;
+    code &= member * 3u;
+    const uint32_t y = __builtin_bswap32(code), n = __builtin_bswap32(member ^ 0x01010101u);
+    codes = (y | (y >> 6) | (y >> 12) | (y >> 18)) & 0xFFu;
+    flags = (n | (n >> 7) | (n >> 14) | (n >> 21)) & 0xFu;
+}
+
+// 16 oriented bases i0 .. i0+15 of a read -> (code word, MSB first; 16 N flags, bit 15 = base i0);
+// bases past the read end give code 0 and flag 1
+static __device__ __forceinline__ void pack16(const ReadRef &rd, int i0, uint32_t &codes, uint32_t &flags)
+{
+    const int rlen = rd.rlen;
+    int n = rlen - i0; if (n > 16) n = 16;
+    codes = 0; flags = 0xFFFFu;
+    if (n <= 0) return;
+    // the span of the file's bytes under these bases: forward [i0, i0+n); mate 2 (reverse-complemented) [rlen-i0-n, rlen-i0) backwards
+    const int a0 = rd.flipped ? rlen - i0 - n : i0;
+    U4 v = load16_unaligned(rd.ascii + a0);
+    if (rd.flipped) { // byte order reversed: the span's last byte first
+        const U4 t = v;
+        v.x = __builtin_bswap32(t.w); v.y = __builtin_bswap32(t.z); v.z = __builtin_bswap32(t.y); v.w = __builtin_bswap32(t.x);
+    }
+    uint32_t c0, f0, c1, f1, c2, f2, c3, f3;
+    pack4(v.x, rd.flipped != 0, c0, f0); pack4(v.y, rd.flipped != 0, c1, f1); pack4(v.z, rd.flipped != 0, c2, f2); pack4(v.w, rd.flipped != 0, c3, f3);
+    uint32_t c = (c0 << 24) | (c1 << 16) | (c2 << 8) | c3, f = (f0 << 12) | (f1 << 8) | (f2 << 4) | f3;
+    if (n < 16) {
+        const int pad = 16 - n;
+        if (rd.flipped) { c <<= 2 * pad; f = (f << pad) & 0xFFFFu; } // the n bytes sat at the end of the reversed vector
+        else c &= ~0u << (2 * pad);
+        f |= (1u << pad) - 1u;
+        if (!rd.flipped) f &= 0xFFFFu;
+    }
+    codes = c; flags = f;
+}
+
+// The packed form of every read of a batch (mcx_fm.h pack_read: 16 bases per code word, one zero
+// word, 32 N flags per mask word, one all-ones word).  One thread per 32 bases: two 16-byte spans
+// of the file's bytes, fetched as aligned 16-byte words by neighbouring threads, so the batch is
+// packed at streaming speed instead of base by base in the seeding lanes.  Mate 2 is packed
+// reverse-complemented (ReadMapping.cpp:451).  tpr threads per read: ceil(max_read_len / 32) + 1.
+__global__ void __launch_bounds__(256) k_pack_reads(ReadBatch rb, int paired, int wpad, int tpr, uint32_t *out)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = (uint32_t)(t / (uint32_t)tpr);
+    const int m = (int)(t % (uint32_t)tpr);
+    if (r >= rb.n_reads) return;
+    ReadRef rd;
+    rd.ascii = rb.bases + rb.off[r]; rd.rlen = (int)(rb.off[r + 1] - rb.off[r]); rd.flipped = (paired && (r & 1)) ? 1 : 0;
+    const int rlen = rd.rlen, nc = (rlen + 15) >> 4, nmw = (rlen + 31) >> 5;
+    uint32_t *o = out + (uint64_t)r * wpad;
+    if (m < nmw) {
+        uint32_t c0, f0, c1, f1;
+        pack16(rd, 32 * m, c0, f0);
+        pack16(rd, 32 * m + 16, c1, f1);
+        o[2 * m] = c0;
+        if (2 * m + 1 < nc) o[2 * m + 1] = c1;
+        o[nc + 1 + m] = (f0 << 16) | f1;
+    } else if (m == nmw) {
+        o[nc] = 0u;
+        o[nc + 1 + nmw] = 0xFFFFFFFFu;
+    }
+}
 
 __global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel, SeedOut so, int pk_words)
 {
@@ -343,7 +441,20 @@ __global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel,
         rd.ascii = rb.bases + rb.off[r]; rd.rlen = (int)(rb.off[r + 1] - rb.off[r]); rd.flipped = (cx.pm.paired && s == 1) ? 1 : 0;
         int64_t ext = 0, blocks = 0;
         PackedRead pk; pk.w = pk_lds + threadIdx.x; pk.stride = blockDim.x; pk.n_code = 0;
-        const int n = rd.rlen <= 0 || packed_words(rd.rlen) > pk_words ? 0 : seed_read(cx.ix, rd, pk, st.hits[s], cx.caps.hit_cap, ext, blocks);
+        int n = 0;
+        const int need = packed_words(rd.rlen);
+        if (rd.rlen > 0 && need <= pk_words) {
+            const U4 *src = (const U4 *)(so.packed + (uint64_t)r * so.wpad);
+            for (int k = 0; k < need; k += 4) {
+                const U4 v = src[k >> 2];
+                pk.w[k * pk.stride] = v.x;
+                if (k + 1 < need) pk.w[(k + 1) * pk.stride] = v.y;
+                if (k + 2 < need) pk.w[(k + 2) * pk.stride] = v.z;
+                if (k + 3 < need) pk.w[(k + 3) * pk.stride] = v.w;
+            }
+            pk.n_code = ((rd.rlen + 15) >> 4) + 1;
+            n = seed_read(cx.ix, rd, pk, st.hits[s], cx.caps.hit_cap, ext, blocks, true);
+        }
         st.hdr->n_hits[s] = n;
         so.read_ext[r] = (uint32_t)ext; so.read_blocks[r] = (uint32_t)blocks | ((uint32_t)n << 20); // (blocks < 2^20; n < 2^12)
         keep = n <= cx.caps.hit_cap ? n : 0; // overflowing reads are re-run in the next tier
@@ -576,11 +687,13 @@ struct mcx_ctx {
     uint32_t *h_cnt = nullptr;   // pinned mirror
     uint32_t *d_rescue = nullptr; uint32_t rescue_cap = 0;
     uint32_t *d_kscratch = nullptr; uint32_t k_threads = 0, k_per_thread = 0;
+    hipEvent_t ev_pack[2] = {nullptr, nullptr};
     hipStream_t dp_stream[3] = {nullptr, nullptr, nullptr}; hipEvent_t dp_fork = nullptr, dp_join[3] = {nullptr, nullptr, nullptr};
     uint8_t *d_dp_scratch[3] = {nullptr, nullptr, nullptr}; uint64_t dp_stride[3] = {0, 0, 0}; uint32_t dp_blocks[3] = {0, 0, 0};
     uint32_t *d_ov = nullptr; uint32_t ov_cap = 0;
     uint32_t *d_sel_ids = nullptr; int32_t *d_est = nullptr;
     uint32_t *d_read_ext = nullptr, *d_read_blocks = nullptr;
+    uint32_t *d_packed = nullptr; int wpad = 0; // 2-bit form of the batch's reads
     PairOut *d_pout = nullptr, *h_pout = nullptr;
     uint8_t *d_mapq = nullptr; int mapq_rows = 0;
     // -vcf bookkeeping (mcx_profile.h): caller-owned counter planes, per-read alignment detail
@@ -639,6 +752,7 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
     HIP_TRY(hipStreamCreate(&c->stream));
     for (int k = 0; k < 3; k++) { HIP_TRY(hipStreamCreateWithFlags(&c->dp_stream[k], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&c->dp_join[k], hipEventDisableTiming)); }
     HIP_TRY(hipEventCreateWithFlags(&c->dp_fork, hipEventDisableTiming));
+    for (auto &e : c->ev_pack) HIP_TRY(hipEventCreate(&e));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     int rc = 0;
     c->tier[0].caps = tier0_caps(); c->tier[0].lay = make_layout(c->tier[0].caps); c->tier[0].max_pairs = (uint32_t)c->max_reads;
@@ -671,6 +785,8 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
     if ((rc = dmalloc(&c->d_est, c->max_reads))) return rc;
     if ((rc = dmalloc(&c->d_read_ext, c->max_reads))) return rc;
     if ((rc = dmalloc(&c->d_read_blocks, c->max_reads))) return rc;
+    c->wpad = (packed_words(c->rlen_max) + 3) & ~3;
+    if ((rc = dmalloc(&c->d_packed, c->max_reads * (uint64_t)c->wpad))) return rc;
     if ((rc = dmalloc(&c->d_pout, c->max_reads))) return rc;
     HIP_TRY(hipHostMalloc((void **)&c->h_pout, c->max_reads * sizeof(PairOut)));
     // EvaluateMAPQ (SamReport.cpp:86-101) tabulated on the host so that the double-precision
@@ -695,7 +811,7 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
                  c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
-                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse};
+                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_packed};
     for (void *q : p) if (q) (void)hipFree(q);
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
     if (c->h_pout) (void)hipHostFree(c->h_pout);
@@ -703,6 +819,7 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (int k = 0; k < 3; k++) { if (c->dp_stream[k]) (void)hipStreamDestroy(c->dp_stream[k]); if (c->dp_join[k]) (void)hipEventDestroy(c->dp_join[k]); }
     if (c->dp_fork) (void)hipEventDestroy(c->dp_fork);
+    for (auto &e : c->ev_pack) if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -731,6 +848,7 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
     SeedOut so; so.tasks = c->d_tasks; so.n_tasks = c->d_cnt + CNT_TASKS; so.task_cap = c->task_cap;
     so.read_ext = c->d_read_ext; so.read_blocks = c->d_read_blocks;
+    so.packed = c->d_packed; so.wpad = c->wpad;
     RescueList rl; rl.ids = c->d_rescue; rl.n = c->d_cnt + CNT_RESCUE; rl.cap = c->rescue_cap;
     JobSinks sinks;
     for (int k = 0; k < 4; k++) { sinks.s[k].jobs = c->d_jobs[k]; sinks.s[k].count = c->d_cnt + CNT_JOB0 + k; sinks.s[k].cap = c->job_cap[k]; }
@@ -898,6 +1016,15 @@ extern "C" int mcx_map_batch_dev(mcx_ctx *c, const uint8_t *d_bases, const uint3
     if (total_bases > c->max_bases) return fail(MCX_ERR_ARG, "batch holds more bases than max_batch_reads * max_read_len");
     AlnRec *recs = (AlnRec *)d_aln;
     const uint32_t n_pairs = paired ? n_reads / 2 : n_reads;
+    { // the batch in 2-bit form, once; every seeding pass (tiers, replay) reads it
+        hipStream_t s0 = c->stream;
+        HIP_TRY(hipEventRecord(c->ev_pack[0], s0));
+        const int tpr = (c->rlen_max + 31) / 32 + 1;
+        const uint64_t threads = (uint64_t)n_reads * (uint64_t)tpr;
+        k_pack_reads<<<(unsigned)((threads + 255) / 256), 256, 0, s0>>>(rb, paired, c->wpad, tpr, c->d_packed);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev_pack[1], s0));
+    }
     const int32_t est0 = (int32_t)((uint32_t)avg[0] * 1.5);
     int rc = run_selection(c, rb, paired, nullptr, nullptr, est0, n_pairs, recs, d_cigar, stats, true);
     if (rc) return rc;
@@ -972,6 +1099,8 @@ extern "C" int mcx_map_batch_dev(mcx_ctx *c, const uint8_t *d_bases, const uint3
         stats->reads += n_reads; stats->mapped += mapped; stats->pairs += pairs; stats->pair_dist_sum += dist_sum; stats->pair_len_sum += len_sum;
         stats->fm_ext_steps += (int64_t)hs[0]; stats->fm_blocks += (int64_t)hs[1]; stats->sa_hits += (int64_t)hs[2];
         stats->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        float ms_pack = 0;
+        if (hipEventElapsedTime(&ms_pack, c->ev_pack[0], c->ev_pack[1]) == hipSuccess) stats->ms_encode += ms_pack; // k_pack_reads
     }
     return 0;
 }
