@@ -717,6 +717,10 @@ static Caps tier0_caps()
 {
     Caps c; c.hit_cap = 48; c.cand_cap = 12; c.frag_cap = 96; c.ops_cap = 1024; c.job_cap = 16;
     c.cig_cap = MCX_CIGAR_STRIDE; c.kmer_cap = 2048;
+    if (const char *e = getenv("MCX_TIER0_CAPS")) { // experiments: "hits,cands,frags,ops"
+        int a, b, d, f;
+        if (sscanf(e, "%d,%d,%d,%d", &a, &b, &d, &f) == 4) { c.hit_cap = a; c.cand_cap = b; c.frag_cap = d; c.ops_cap = f; }
+    }
     return c;
 }
 static Caps tier1_caps(int rlen_max)
