@@ -633,7 +633,7 @@ __global__ void __launch_bounds__(256) k_dp_small(Ctx cx, JobSink sink, ReadBatc
     }
 }
 
-__global__ void __launch_bounds__(256) k_finish(Ctx cx, ReadBatch rb, PairSel sel, AlnRec *recs, uint32_t *cigars,
+__global__ void __launch_bounds__(256, 7) k_finish(Ctx cx, ReadBatch rb, PairSel sel, AlnRec *recs, uint32_t *cigars,
                                                 PairOut *pout, uint32_t *ov_ids, uint32_t *n_ov, uint32_t ov_cap)
 {
     __shared__ EndsLds ends;
