@@ -33,17 +33,20 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "round1", "summary_2gbp_final.json")
 
 
-def pmc_traffic(args):  # noqa: D401
-    """HBM bytes one k_seed launch moved, from the committed `rocprofv3 --pmc FETCH_SIZE` /
-    `--pmc WRITE_SIZE` passes of this same command (counters cannot be read from inside the run).
-    Only returned when the workload is the one those passes profiled."""
+def pmc_profile(args):
+    """What the committed rocprofv3 --pmc passes of this same command measured for one k_seed launch
+    (counters cannot be read from inside the run): HBM bytes (FETCH_SIZE + WRITE_SIZE) and L2
+    requests (TCC_HIT + TCC_MISS).  Only returned when the workload is the one those passes profiled."""
     if (args.genome_mbp, args.batch_pairs, args.rlen, args.alg) != (2000.0, 2_000_000, 150, "ksw2"):
         return None
     try:
         with open(PMC_SUMMARY) as fh:
-            t = json.load(fh)["hbm_traffic"]["k_seed"]
-        return int(t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
+            s = json.load(fh)
+        t, p = s["hbm_traffic"]["k_seed"], s["pmc"]["k_seed"]
+        return {"traffic": int(t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"]),
+                "l2_requests": int(p["TCC_HIT_sum"]["full_batch_mean"] + p["TCC_MISS_sum"]["full_batch_mean"]),
+                "wait_frac": round(p["SQ_WAIT_ANY"]["full_batch_mean"] / p["SQ_WAVE_CYCLES"]["full_batch_mean"], 3)}
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None
 
 
@@ -244,6 +247,7 @@ def main():
         # 64 * 1.107 * E + rlen per read, with E (FM extension steps) counted by the kernel.  The
         # blocks the kernel really fetches are fewer (k-mer jump table) and reported beside it.
         seed_bytes = 64.0 * 1.107 * d["fm_ext_steps"] + float(d["reads"]) * args.rlen
+        prof = pmc_profile(args) or {}
         seed_ms = d["ms_seed"] / max(args.steps, 1)
         achieved = seed_bytes / args.steps / (seed_ms * 1e-3) / 1e9 if seed_ms > 0 else 0.0
         out = {
@@ -256,14 +260,18 @@ def main():
                        "reads_per_step_per_gpu": reads_per_step, "full_sa_in_hbm": bool(args.full_sa), "index_build_s": round(t_index, 2),
                        "index_hbm_gb": round(index.hbm_bytes / 1e9, 2)},
             "roofline": {"bound": "hbm", "kernel": "k_seed", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": prof.get("traffic"),
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/round1/summary_2gbp_final.json)",
                          "algorithmic_bytes_per_launch": round(seed_bytes / max(args.steps, 1)),
                          "note": "achieved prices SURVEY 8d's seeding bytes (64*1.107*E + rlen per read: the reference's FM walk) at the measured "
                                  "launch time; the kernel reaches the same seeds through a K-mer jump table and direct genome comparison, moves far "
                                  "fewer bytes (traffic) and is bound by per-lane request rate, so frac can exceed 1 — it is a speed-of-light "
                                  "comparison with a perfect HBM-bound walk, not an HBM utilisation",
-                         "algorithmic_bytes_per_read": round(seed_bytes / max(d["reads"], 1), 1), "avg_launch_ms": round(seed_ms, 3)},
+                         "algorithmic_bytes_per_read": round(seed_bytes / max(d["reads"], 1), 1), "avg_launch_ms": round(seed_ms, 3),
+                         "measured": None if not prof else {
+                             "hbm_gbs": round(prof["traffic"] / (seed_ms * 1e-3) / 1e9, 1), "l2_requests_per_launch": prof["l2_requests"],
+                             "l2_request_rate_g_per_s": round(prof["l2_requests"] / (seed_ms * 1e-3) / 1e9, 1), "waves_waiting_frac": prof["wait_frac"],
+                             "reading": "the launch moves an eighth of the walk's bytes; waves wait on dependent fetches two thirds of the time"}},
             "per_read": {"fm_ext_steps": round(d["fm_ext_steps"] / max(d["reads"], 1), 2), "fm_blocks": round(d["fm_blocks"] / max(d["reads"], 1), 2),
                          "sa_hits": round(d["sa_hits"] / max(d["reads"], 1), 3), "dp_jobs": round(d["dp_jobs"] / max(d["reads"], 1), 4),
                          "mapped_frac": round(d["mapped"] / max(d["reads"], 1), 4)},
