@@ -1818,6 +1818,12 @@ int64_t mcxo_map_files(const mcxo_index *ix, const char *fq1, const char *fq2, i
     return map_files_impl(ix, fq1, fq2, alg, sam_path, threads, stats, nullptr);
 }
 
+// run totals VariantCalling() needs from Mapping(): out = {iTotalPairedNum, TotalPairedDistance, ReadLengthSum}
+int64_t mcxo_pair_totals(const mcxo_index *ix, const char *fq1, const char *fq2, int alg, int64_t out[3])
+{
+    return map_files_impl(ix, fq1, fq2, alg, nullptr, 1, nullptr, nullptr, out);
+}
+
 // MapCaller -p: one file, mates alternate
 int64_t mcxo_map_files_interleaved(const mcxo_index *ix, const char *fq, int alg, const char *sam_path, int64_t *stats)
 {

@@ -44,6 +44,10 @@ int mcxo_ksw2_extz(const uint8_t *q, int qlen, const uint8_t *t, int tlen, int *
 int64_t mcxo_map_files(const mcxo_index *, const char *fq1, const char *fq2, int alg, const char *sam_path,
                        int threads, int64_t *stats);
 
+// The run totals VariantCalling() takes over from Mapping() (reference src/ReadMapping.cpp:782-790):
+// out = {iTotalPairedNum, TotalPairedDistance, ReadLengthSum}.  Returns reads processed.
+int64_t mcxo_pair_totals(const mcxo_index *, const char *fq1, const char *fq2, int alg, int64_t out[3]);
+
 // MapCaller -p: both mates alternate in one file (reference src/main.cpp:300, src/GetData.cpp:85-99)
 int64_t mcxo_map_files_interleaved(const mcxo_index *, const char *fq, int alg, const char *sam_path, int64_t *stats);
 

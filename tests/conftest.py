@@ -54,6 +54,8 @@ def oracle_lib():
     L.mcxo_map_files.restype = ctypes.c_int64
     L.mcxo_map_files.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p,
                                  ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]
+    L.mcxo_pair_totals.restype = ctypes.c_int64
+    L.mcxo_pair_totals.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]
     L.mcxo_map_files_interleaved.restype = ctypes.c_int64
     L.mcxo_map_files_interleaved.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]
     L.mcxo_map_files_profile.restype = ctypes.c_int64
@@ -79,6 +81,18 @@ def hostemu_lib(oracle_lib):
     L.hostemu_map_files.restype = ctypes.c_int64
     L.hostemu_map_files.argtypes = [ctypes.c_char_p] * 3 + [ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
                                                            ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]
+    return L
+
+
+@pytest.fixture(scope="session")
+def hostemu_variants_lib():
+    import ctypes
+    d = os.path.join(ROOT, "tests", "hostemu")
+    _make(d, "libhostemu_variants.so")
+    L = ctypes.CDLL(os.path.join(d, "libhostemu_variants.so"))
+    L.hostemu_call_variants.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                        ctypes.c_void_p, ctypes.c_char_p]
+    L.hostemu_vc_error.restype = ctypes.c_char_p
     return L
 
 

@@ -5,7 +5,7 @@ import ctypes
 
 import pytest
 
-from conftest import SETS, sam_diff
+from conftest import SETS, VCF_CASES, VCF_RUNS, VcfOpts, sam_diff, vcf_alg, vcf_body
 
 
 def _run(lib, g, alg, out, batch=1 << 20, tier0=None, rlen_max=256):
@@ -41,3 +41,23 @@ def test_capacity_tiers_do_not_change_results(hostemu_lib, golden, tmp_path):
     assert st[9] > 100  # tier-1 pairs
     nd, ex = sam_diff(golden["mc"]["sam"]["nw"], out)
     assert nd == 0, ex
+
+
+@pytest.mark.parametrize("name,tag", [c for c in VCF_CASES if c[1] not in ("opts", "nw")])
+def test_variant_host_logic_equals_reference(hostemu_variants_lib, oracle_lib, golden, tmp_path, name, tag):
+    """The product's variant-calling host logic (mcx_variants_host.h: indel calls, run pairing, gVCF
+    blocks, break points, filters, VCF text) over a CPU stand-in for the dense kernels, fed with the
+    reference's own profile dump: the golden VCF line for line.  (The runs whose profile needs other
+    -dup / -maxclip / -alg values have no dump and are covered on the GPU.)"""
+    g = golden[name]
+    alg, prof, maps = g["prof"]
+    assert alg == vcf_alg(name, tag)
+    ix = oracle_lib.mcxo_index_load(g["prefix"].encode())
+    tot = (ctypes.c_int64 * 3)()
+    assert oracle_lib.mcxo_pair_totals(ix, g["r1"].encode(), (g["r2"] or "").encode(), 0 if alg == "nw" else 1, tot) > 0
+    oracle_lib.mcxo_index_free(ix)
+    out = str(tmp_path / "o.vcf")
+    opts = VcfOpts(VCF_RUNS[tag][1])
+    rc = hostemu_variants_lib.hostemu_call_variants(g["prefix"].encode(), prof.encode(), maps.encode(), tot[0], tot[1], tot[2], opts.ref, out.encode())
+    assert rc == 0, hostemu_variants_lib.hostemu_vc_error()
+    assert vcf_body(out) == vcf_body(g["vcf"][tag])
