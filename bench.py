@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — reads/s of the seed-and-extend hot path on MI355X (BASELINE.json metric).
 
-A *step* is one pass of the whole path (encode, FM-index seeding, SA resolution, clustering /
+A *step* is one pass of the whole path (2-bit packing, FM-index seeding, SA resolution, clustering /
 pairing / rescue, fragment construction, wavefront DP, scoring / MAPQ / CIGAR, avgDist replay)
 over one batch of synthetic 150 bp paired-end reads that already sit in HBM; the results
 (alignment records + CIGAR words) stay in HBM.  FASTQ parsing and SAM text are outside the timed

@@ -109,7 +109,7 @@ typedef struct mcx_stats {
     int64_t dp_jobs, dp_cells;
     int64_t tier1_pairs;    /* pairs re-run with the large capacities */
     int64_t replayed_pairs; /* pairs re-run because the avgDist trajectory moved past their validity interval */
-    double ms_encode, ms_seed, ms_sa, ms_cluster, ms_rescue, ms_build, ms_dp, ms_finish, ms_total;
+    double ms_encode /* k_pack_reads */, ms_seed, ms_sa, ms_cluster, ms_rescue, ms_build, ms_dp, ms_finish, ms_total;
 } mcx_stats;
 
 #define MCX_CIGAR_STRIDE 32 /* words per read in the dense cigar array */

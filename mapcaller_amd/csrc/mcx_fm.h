@@ -127,7 +127,7 @@ static inline MCX_HD int nt4_code(uint8_t ch)
 // One read as the kernels see it: the ASCII bases as handed over, and whether it is mate 2 of a
 // pair, which the reference reverse-complements in place before anything else
 // (ReverseOrientation, tools.cpp:45; EnCodeReadSeq, ReadMapping.cpp:404).  Codes are decoded on
-// the fly, so there is no encode pass and no second copy of the reads in HBM.
+// the fly wherever single bases are needed; the seeding walk works on the 2-bit form k_pack_reads makes.
 struct ReadRef {
     const uint8_t *ascii;
     int32_t rlen;

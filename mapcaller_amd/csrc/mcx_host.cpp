@@ -95,118 +95,8 @@ bool host_index_load(const std::string &prefix, HostIndex &ix, std::string &err)
 }
 
 // ---------------------------------------------------------------------------------------------
-// read files
+// SAM header
 // ---------------------------------------------------------------------------------------------
-bool ReadFile::open(const std::string &path, std::string &err)
-{
-    gzFile g = gzopen(path.c_str(), "rb");
-    if (!g) { err = "cannot open " + path; return false; }
-    gzbuffer(g, 1 << 20);
-    gz_ = g;
-    int c = gzgetc(g);
-    fastq_ = (c == '@'); // CheckReadFormat, GetData.cpp:22-31
-    if (c != -1) gzungetc(c, g);
-    have_pending_ = false;
-    return true;
-}
-
-void ReadFile::close()
-{
-    if (gz_) gzclose((gzFile)gz_);
-    gz_ = nullptr;
-}
-
-bool ReadFile::line(std::string &s)
-{
-    if (have_pending_) { s.swap(pending_); have_pending_ = false; return true; }
-    s.clear();
-    char buf[4096];
-    for (;;) {
-        if (!gzgets((gzFile)gz_, buf, sizeof buf)) return !s.empty();
-        s += buf;
-        if (!s.empty() && s.back() == '\n') return true;
-    }
-}
-
-// IdentifyHeaderBegPos / IdentifyHeaderEndPos, GetData.cpp:3-20
-static std::string header_of(const std::string &l)
-{
-    const int len = (int)l.size();
-    int p1 = len - 1, lim = len > 100 ? 100 : len, p2 = lim - 1;
-    for (int i = 1; i < len; i++) if (l[i] != '>' && l[i] != '@') { p1 = i; break; }
-    for (int i = 1; i < lim; i++) if (l[i] == ' ' || l[i] == '/' || !isprint((unsigned char)l[i])) { p2 = i; break; }
-    return p2 > p1 ? l.substr(p1, p2 - p1) : std::string();
-}
-
-bool ReadFile::next(HostRead &r)
-{
-    std::string l;
-    r.name.clear(); r.seq.clear(); r.qual.clear();
-    if (!line(l)) return false;
-    r.name = header_of(l);
-    if (fastq_) {
-        if (!line(l)) return false;
-        const size_t n = l.size(); // the last byte of the line is dropped (GetData.cpp:48-53)
-        r.seq = l.substr(0, n ? n - 1 : 0);
-        std::string plus, q;
-        line(plus); line(q);
-        q.resize(n, '\0');
-        r.qual = q.substr(0, n ? n - 1 : 0);
-    } else {
-        for (;;) {
-            if (!line(l)) break;
-            if (l[0] == '>') { pending_ = l; have_pending_ = true; break; }
-            if (!l.empty()) l.resize(l.size() - 1);
-            r.seq += l;
-        }
-    }
-    return !r.seq.empty();
-}
-
-// ---------------------------------------------------------------------------------------------
-// avgDist feedback
-// ---------------------------------------------------------------------------------------------
-void avg_replay(const PairOut *po, uint32_t n_pairs, const int64_t avg[4], std::vector<uint32_t> &redo,
-                std::vector<int32_t> &redo_est, int64_t avg_out[4])
-{
-    redo.clear(); redo_est.clear();
-    const uint32_t chunk = kReadChunkSize / 2;
-    int64_t tp = avg[1], td = avg[2];
-    uint32_t cur = (uint32_t)avg[0];
-    for (uint32_t p0 = 0; p0 < n_pairs; p0 += chunk) {
-        const int32_t e = (int32_t)(cur * 1.5);
-        const uint32_t p1 = n_pairs < p0 + chunk ? n_pairs : p0 + chunk;
-        for (uint32_t p = p0; p < p1; p++) {
-            const PairOut &o = po[p];
-            const bool ok = (o.flags & kRescueUsedEst) ? o.est == e : (e >= o.est_lo && e <= o.est_hi);
-            if (!ok) { redo.push_back(p); redo_est.push_back(e); }
-            if (o.pair_ok) { tp++; td += o.pair_dist; }
-        }
-        if (tp > 1000) cur = (uint32_t)(int)(1. * td / tp + .5);
-    }
-    avg_out[0] = cur; avg_out[1] = tp; avg_out[2] = td; avg_out[3] = avg[3];
-}
-
-// ---------------------------------------------------------------------------------------------
-// SAM text
-// ---------------------------------------------------------------------------------------------
-static inline char comp_char(char c) // GetComplementaryBase, tools.cpp:3-18
-{
-    switch (c) {
-    case 'A': case 'a': return 'T';
-    case 'C': case 'c': return 'G';
-    case 'G': case 'g': return 'C';
-    case 'T': case 't': return 'A';
-    default: return 'N';
-    }
-}
-
-static void revcomp(const std::string &in, std::string &out)
-{
-    out.resize(in.size());
-    for (size_t i = 0, n = in.size(); i < n; i++) out[i] = comp_char(in[n - 1 - i]);
-}
-
 void sam_header(const HostIndex &ix, std::string &out) // OutputSamHeaders, ReadMapping.cpp:101-123
 {
     out = "@PG\tID:MapCaller\tPN:MapCaller\tVN:0.9.9.41\n";
@@ -215,38 +105,6 @@ void sam_header(const HostIndex &ix, std::string &out) // OutputSamHeaders, Read
         snprintf(buf, sizeof buf, "@SQ\tSN:%s\tLN:%d\n", ix.chr_name[i].c_str(), ix.chr_len[i]);
         out += buf;
     }
-}
-
-void sam_line(const HostIndex &ix, const HostRead &rd, bool mate2_flipped, bool fastq, const AlnRec &rec,
-              const uint32_t *cigar, std::string &out)
-{
-    // The reference reverse-complements mate 2 in place before mapping (ReadMapping.cpp:451) and
-    // prints that string for forward-strand hits, its reverse complement otherwise.
-    std::string cur_seq, cur_qual, tmp;
-    if (mate2_flipped) { revcomp(rd.seq, cur_seq); cur_qual.assign(rd.qual.rbegin(), rd.qual.rend()); }
-    else { cur_seq = rd.seq; cur_qual = rd.qual; }
-    char num[128];
-    out = rd.name;
-    const bool mapped = rec.chr >= 0;
-    if (!mapped) {
-        snprintf(num, sizeof num, "\t%d\t*\t0\t0\t*\t*\t0\t0\t", rec.flag);
-        out += num; out += cur_seq; out += '\t'; out += fastq ? cur_qual : std::string("*");
-        out += "\tAS:i:0\tXS:i:0";
-        return;
-    }
-    snprintf(num, sizeof num, "\t%d\t", rec.flag); out += num;
-    out += ix.chr_name[rec.chr];
-    snprintf(num, sizeof num, "\t%lld\t%d\t", (long long)rec.pos, rec.mapq); out += num;
-    static const char opc[8] = {'M', 'I', 'D', 'N', 'S', 'H', 'P', '='};
-    for (int i = 0; i < rec.n_cigar; i++) { snprintf(num, sizeof num, "%u%c", cigar[i] >> 4, opc[cigar[i] & 7]); out += num; }
-    if (rec.has_mate) { snprintf(num, sizeof num, "\t=\t%lld\t%d\t", (long long)rec.mate_pos, rec.tlen); out += num; }
-    else out += "\t*\t0\t0\t";
-    if (rec.fwd) { out += cur_seq; out += '\t'; out += fastq ? cur_qual : std::string("*"); }
-    else {
-        revcomp(cur_seq, tmp); out += tmp; out += '\t';
-        if (fastq) { tmp.assign(cur_qual.rbegin(), cur_qual.rend()); out += tmp; } else out += '*';
-    }
-    snprintf(num, sizeof num, "\tNM:i:%d\tAS:i:%d\tXS:i:%d", rec.nm, rec.as, rec.xs); out += num;
 }
 
 } // namespace mcx

@@ -1,17 +1,18 @@
 // mapcaller_amd/csrc/mcx_pipeline.hip — HIP kernels, the batch pipeline and the C ABI.
 //
 // One batch of reads goes through (all on one stream, no host round trip inside a tier):
-//   k_encode   ASCII -> 0..4 codes, mate 2 reverse-complemented        (ReadMapping.cpp:447,451)
-//   k_seed     FM-index walk, one read per lane -> BWT rows of hits    (IdentifySimplePairs/BWT_Search)
-//   k_sa       one hit per lane: BWT row -> text position              (bwt_sa)
-//   k_cluster  one pair per lane: sort, cluster, pair by distance      (SimplePairClustering, CheckPairedAlignmentDistance)
-//   k_rescue   unpaired pairs only: 8-mer mate rescue                  (AlignmentRescue)
-//   k_build    mask, fragment lists, DP job emission                   (ProduceReadAlignment up to ProcessNormalPair)
-//   k_dp<K>    one wavefront per DP job                                (ksw2_alignment / nw_alignment)
-//   k_finish   gates, scores, pair stats, flags, MAPQ, CIGAR, records  (ProduceReadAlignment tail, SamReport.cpp)
+//   k_pack_reads  ASCII -> 2-bit words + N masks, mate 2 reverse-complemented (ReadMapping.cpp:447,451)
+//   k_seed        jump table + FM steps + direct comparison, one read per lane (IdentifySimplePairs/BWT_Search)
+//   k_sa          hits that are still BWT rows -> text positions            (bwt_sa)
+//   k_cluster     one pair per lane: sort, cluster, pair by distance        (SimplePairClustering, CheckPairedAlignmentDistance)
+//   k_rescue      unpaired pairs only, one workgroup each: 8-mer mate rescue (AlignmentRescue)
+//   k_build       mask, fragment lists, DP job emission by size class       (ProduceReadAlignment up to ProcessNormalPair)
+//   k_dp_small / k_dp_sel<K>  16-lane groups / one wavefront per DP job     (ksw2_alignment / nw_alignment)
+//   k_finish      gates, scores, pair stats, flags, MAPQ, CIGAR, records    (ProduceReadAlignment tail, SamReport.cpp)
 // Pairs that overflow the tier-0 pair-state capacities are re-run in tier 1 (hard bounds).
-// The host then replays the reference's per-chunk avgDist feedback over the per-pair validity
-// intervals and re-runs only the pairs whose decision depends on the exact estimate.
+// The reference's per-chunk avgDist feedback is then replayed: per-chunk sums on the device, the
+// trajectory on the host, and only the pairs whose decision depends on the exact estimate re-run.
+// The -vcf bookkeeping of a batch (mcx_profile.h) follows when a profile is attached.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>

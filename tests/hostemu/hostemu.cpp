@@ -15,6 +15,7 @@
 
 #include "../../mapcaller_amd/csrc/mcx_glue.h"
 #include "../../mapcaller_amd/csrc/mcx_host.h"
+#include "simple_io.h"
 #include "../../oracle/mcx_oracle.h"
 
 using namespace mcx;
