@@ -1,10 +1,8 @@
-// mapcaller_amd/csrc/mcx_host.cpp — index files, read files and SAM text on the host.
+// mapcaller_amd/csrc/mcx_host.cpp — index files and the SAM header on the host.
 //
 // Index files are the byte-compatible BWA files `MapCaller index` writes (reference
 // src/BWT_Index/bwtindex.c:77-160, src/BWT_Index/bwt.c:174-196, src/BWT_Index/bntseq.c:60-91);
-// the loader mirrors src/bwt_index.cpp:16-124 and :232-258.  Read files follow
-// src/GetData.cpp:3-146 (header trimming, 4-line FASTQ records, multi-line FASTA).  SAM lines
-// follow the printf formats of src/SamReport.cpp:338,361,405,429,431.
+// the loader mirrors src/bwt_index.cpp:16-124 and :232-258.  (Read files and SAM lines: mcx_files.cpp.)
 #include "mcx_host.h"
 #include "mcx_types.h"
 

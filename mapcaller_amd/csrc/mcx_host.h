@@ -1,5 +1,5 @@
-// mapcaller_amd/csrc/mcx_host.h — host-side pieces around the GPU path: index files, read files,
-// SAM text.  (reference src/bwt_index.cpp, src/GetData.cpp, src/SamReport.cpp:324-488 formatting)
+// mapcaller_amd/csrc/mcx_host.h — host-side pieces around the GPU path: the index files
+// (reference src/bwt_index.cpp) and the SAM header.
 #ifndef MCX_HOST_H
 #define MCX_HOST_H
 #include <stdint.h>
