@@ -8,12 +8,15 @@
 //
 //   text T = X . revcomp(X) stays in HBM as one byte per base; the suffix array is built by
 //   prefix doubling with hipCUB radix sorts (first pass on 16-base packed keys, then rank
-//   pairs (r[i], r[i+h]) with h = 16, 32, ...), BWT / occ blocks / SA samples are derived by one
-//   pass over the finished array.  Everything is sized for one GPU's HBM (about 30 bytes per
-//   text position); texts of 2^32 positions or more are refused (MCX_ERR_UNSUPPORTED).
+//   pairs (r[i], r[i+h]) with h = 16, 32, ...), bucket by bucket of the first bases so that keys
+//   stay within 64 bits and sort buffers at bucket size; BWT / occ blocks / SA samples are derived
+//   by one pass over the finished array.  Sized for one GPU's HBM (about 28 bytes per text
+//   position: a GRCh38-sized genome, 6.2 G positions, peaks near 175 GB); texts of 2^33 positions
+//   or more are refused (MCX_ERR_UNSUPPORTED).
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -49,47 +52,102 @@ __global__ void k_make_text(const uint8_t *fwd, uint64_t G, uint8_t *T)
     }
 }
 
-// first-pass key: 16 bases packed MSB first (positions past the end read as 0) and, below them,
-// the number of real bases (a suffix that runs into the terminator sorts before a longer one
-// with the same padded prefix)
-__global__ void k_init_keys(const uint8_t *T, uint64_t N, uint64_t *key, uint32_t *idx)
+// ---- suffix sorting: prefix doubling over buckets -------------------------------------------------
+// Suffix i lives in bucket b(i) = its first kb bases (positions past the end read as A): buckets are
+// in suffix order, so a suffix's rank is its bucket's base + its rank inside the bucket.  Every
+// bucket holds fewer than 2^31 suffixes, which keeps a doubling key — (rank inside the bucket,
+// global rank of the suffix h further on) — within 64 bits for texts up to 2^33 positions, and the
+// sort buffers at bucket size.  Small texts are one bucket.
+struct Buckets {
+    int kb, n;                 // bases per bucket id, number of buckets (4^kb, at most 256)
+    uint64_t base[257];        // first SA slot of each bucket; base[n] = N
+};
+
+static __device__ __forceinline__ uint32_t bucket_of(const uint8_t *T, uint64_t N, uint64_t i, int kb)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t k = 0;
-        uint64_t rem = N - i;
-        int real = rem < 16 ? (int)rem : 16;
-        for (int j = 0; j < 16; j++) k = (k << 2) | (j < real ? T[i + j] : 0);
-        key[i] = (k << 5) | (uint64_t)real;
-        idx[i] = (uint32_t)i;
+    uint32_t b = 0;
+    for (int j = 0; j < kb; j++) b = (b << 2) | (i + j < N ? T[i + j] : 0u);
+    return b;
+}
+
+__global__ void k_bucket_count(const uint8_t *T, uint64_t N, int kb, unsigned long long *count)
+{
+    __shared__ unsigned int local[256];
+    for (int k = threadIdx.x; k < 256; k += blockDim.x) local[k] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (uint64_t)gridDim.x * blockDim.x) atomicAdd(&local[bucket_of(T, N, i, kb)], 1u);
+    __syncthreads();
+    for (int k = threadIdx.x; k < 256; k += blockDim.x) if (local[k]) atomicAdd(&count[k], (unsigned long long)local[k]);
+}
+
+// positions into their buckets' SA segments (any order inside a bucket: it is sorted next); one
+// tile of 4096 positions per step, one global reservation per bucket and tile
+__global__ void __launch_bounds__(256) k_bucket_scatter(const uint8_t *T, uint64_t N, int kb, unsigned long long *cursor, uint64_t *sa)
+{
+    __shared__ unsigned int cnt[256];
+    __shared__ unsigned long long at[256];
+    const uint64_t tile = 4096, n_tiles = (N + tile - 1) / tile;
+    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        for (int k = threadIdx.x; k < 256; k += blockDim.x) cnt[k] = 0;
+        __syncthreads();
+        uint32_t mine[16], slot[16];
+        for (int s = 0; s < 16; s++) {
+            const uint64_t i = t * tile + (uint64_t)s * 256 + threadIdx.x;
+            mine[s] = 0xFFFFFFFFu;
+            if (i < N) { mine[s] = bucket_of(T, N, i, kb); slot[s] = atomicAdd(&cnt[mine[s]], 1u); }
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < 256; k += blockDim.x) if (cnt[k]) at[k] = atomicAdd(&cursor[k], (unsigned long long)cnt[k]);
+        __syncthreads();
+        for (int s = 0; s < 16; s++) {
+            const uint64_t i = t * tile + (uint64_t)s * 256 + threadIdx.x;
+            if (mine[s] != 0xFFFFFFFFu) sa[at[mine[s]] + slot[s]] = i;
+        }
+        __syncthreads();
     }
 }
 
-// head[j] = j if the sorted key at j differs from its predecessor, else 0 (j = 0 is a head)
-__global__ void k_mark_heads(const uint64_t *key, uint64_t N, uint32_t *head)
+// first-pass key of the suffix at sa[j]: 16 bases packed MSB first (positions past the end read as
+// 0) and, below them, the number of real bases (a suffix that runs into the terminator sorts before
+// a longer one with the same padded prefix)
+__global__ void k_init_keys(const uint8_t *T, uint64_t N, const uint64_t *sa, uint64_t n, uint64_t *key)
 {
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < N; j += (uint64_t)gridDim.x * blockDim.x)
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = sa[j];
+        uint64_t k = 0;
+        const uint64_t rem = N - i;
+        const int real = rem < 16 ? (int)rem : 16;
+        for (int c = 0; c < 16; c++) k = (k << 2) | (c < real ? T[i + c] : 0);
+        key[j] = (k << 5) | (uint64_t)real;
+    }
+}
+
+// head[j] = j if the sorted key at j differs from its predecessor, else 0 (j = 0 is a head); j counts inside the bucket
+__global__ void k_mark_heads(const uint64_t *key, uint64_t n, uint32_t *head)
+{
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x)
         head[j] = (j == 0 || key[j] != key[j - 1]) ? (uint32_t)j : 0u;
 }
 
-// after an inclusive max-scan head[j] is the first index of j's group: rank = that + 1
-__global__ void k_scatter_rank(const uint32_t *idx, const uint32_t *head, uint64_t N, uint32_t *rank, unsigned long long *n_groups)
+// after an inclusive max-scan head[j] is the first index of j's group: rank = bucket base + that + 1
+__global__ void k_scatter_rank(const uint64_t *sa, const uint32_t *head, uint64_t n, uint64_t base, uint64_t *rank, unsigned long long *n_groups)
 {
     unsigned long long local = 0;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < N; j += (uint64_t)gridDim.x * blockDim.x) {
-        rank[idx[j]] = head[j] + 1;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        rank[sa[j]] = base + head[j] + 1;
         if (head[j] == (uint32_t)j) local++;
     }
     for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(n_groups, local);
 }
 
-// doubling key for the suffix at idx[j]: (rank[i], rank[i + h]) with 0 past the end
-__global__ void k_pair_keys(const uint32_t *idx, const uint32_t *rank, uint64_t N, uint64_t h, uint64_t *key)
+// doubling key for the suffix at sa[j] of a bucket: (rank inside the bucket, rank[i + h]) with 0 past the end
+__global__ void k_pair_keys(const uint64_t *sa, const uint64_t *rank, uint64_t n, uint64_t base, uint64_t N, uint64_t h, uint64_t *key)
 {
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < N; j += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t i = idx[j];
-        uint64_t r2 = i + h < N ? rank[i + h] : 0;
-        key[j] = ((uint64_t)rank[i] << 32) | r2;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = sa[j];
+        const uint64_t r2 = i + h < N ? rank[i + h] : 0;
+        key[j] = ((rank[i] - base) << 33) | r2;
     }
 }
 
@@ -103,7 +161,7 @@ struct BuildOut {
 // Row r of the sorted matrix of T$ (r in [0, N]): row 0 is "$" (SA = N), row r >= 1 is idx[r-1].
 // BWT char of a row = T[SA - 1]; the row with SA = 0 is `primary` and is skipped in the packed
 // string, so string position m = r - (r > primary).  One thread packs 16 symbols (one word).
-__global__ void k_pack_bwt(const uint8_t *T, const uint32_t *idx, uint64_t N, uint64_t primary, uint32_t *words)
+__global__ void k_pack_bwt(const uint8_t *T, const uint64_t *idx, uint64_t N, uint64_t primary, uint32_t *words)
 {
     const uint64_t n_words = (N + 15) / 16;
     for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
@@ -156,7 +214,7 @@ __global__ void k_interleave(const uint32_t *words, const uint64_t *excl /* 4 x 
     }
 }
 
-__global__ void k_sample_sa(const uint32_t *idx, uint64_t N, int intv, uint64_t n_sa, uint64_t *sa, uint64_t *sa_full)
+__global__ void k_sample_sa(const uint64_t *idx, uint64_t N, int intv, uint64_t n_sa, uint64_t *sa, uint64_t *sa_full)
 {
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= N; r += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t v = r == 0 ? N : idx[r - 1];
@@ -165,7 +223,7 @@ __global__ void k_sample_sa(const uint32_t *idx, uint64_t N, int intv, uint64_t 
     }
 }
 
-__global__ void k_find_primary(const uint32_t *idx, uint64_t N, unsigned long long *primary)
+__global__ void k_find_primary(const uint64_t *idx, uint64_t N, unsigned long long *primary)
 {
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < N; j += (uint64_t)gridDim.x * blockDim.x)
         if (idx[j] == 0) *primary = j + 1;
@@ -191,74 +249,116 @@ int mcx_build_suffix_index(const uint8_t *d_fwd, uint64_t G, bool want_full_sa, 
 {
     const uint64_t N = 2 * G;
     if (N == 0) return mcx_set_error(MCX_ERR_ARG, "empty genome");
-    if (N >= 0xFFFFFFF0ull) return mcx_set_error(MCX_ERR_UNSUPPORTED, "GPU index construction handles texts below 2^32 positions (genome < 2.1 Gbp)");
+    if (N >= (1ull << 33) - 16) return mcx_set_error(MCX_ERR_UNSUPPORTED, "GPU index construction handles texts below 2^33 positions (genome < 4.29 Gbp)");
     hipEvent_t e0, e1;
     HIP_TRYB(hipEventCreate(&e0)); HIP_TRYB(hipEventCreate(&e1));
     HIP_TRYB(hipEventRecord(e0));
     uint8_t *T = nullptr;
-    uint64_t *key[2] = {nullptr, nullptr};
-    uint32_t *idx[2] = {nullptr, nullptr}, *rank = nullptr, *head = nullptr;
-    unsigned long long *d_misc = nullptr; // [0] groups, [1] primary, [2..5] base counts
+    uint64_t *sa = nullptr, *rank = nullptr, *key = nullptr, *key_alt = nullptr, *val_alt = nullptr;
+    uint32_t *head = nullptr;
+    unsigned long long *d_misc = nullptr; // [0] groups, [1] primary, [2..5] base counts, [8..263] bucket counts, [264..519] bucket cursors
     HIP_TRYB(hipMalloc(&T, N + 64));
     HIP_TRYB(hipMemset(T + N, 0, 64));
-    for (int k = 0; k < 2; k++) { HIP_TRYB(hipMalloc(&key[k], N * 8)); HIP_TRYB(hipMalloc(&idx[k], N * 4)); }
-    HIP_TRYB(hipMalloc(&rank, N * 4));
-    HIP_TRYB(hipMalloc(&head, N * 4));
-    HIP_TRYB(hipMalloc(&d_misc, 8 * sizeof(unsigned long long)));
-    HIP_TRYB(hipMemset(d_misc, 0, 8 * sizeof(unsigned long long)));
-    const unsigned grid = 4096, block = 256;
+    HIP_TRYB(hipMalloc(&d_misc, 520 * sizeof(unsigned long long)));
+    HIP_TRYB(hipMemset(d_misc, 0, 520 * sizeof(unsigned long long)));
+    const unsigned grid = 8192, block = 256;
     k_make_text<<<grid, block>>>(d_fwd, G, T);
     k_count_bases<<<grid, block>>>(T, N, d_misc + 2);
-    k_init_keys<<<grid, block>>>(T, N, key[0], idx[0]);
-    // temp storage for sort + scan
+    // buckets: one for small texts, else by the first kb bases so that every bucket stays below 2^31 suffixes
+    Buckets bk;
+    bk.kb = N < (1ull << 31) ? 0 : 2;
+    if (const char *e = getenv("MCX_BUILD_BUCKET_BASES")) { const int k = atoi(e); if (k >= 0 && k <= 4) bk.kb = k; } // (tests exercise the bucket path on small genomes)
+    unsigned long long h_count[256];
+    for (;; bk.kb++) {
+        if (bk.kb > 4) return mcx_set_error(MCX_ERR_UNSUPPORTED, "index construction: a 4-base bucket exceeds 2^31 suffixes");
+        bk.n = 1 << (2 * bk.kb);
+        HIP_TRYB(hipMemset(d_misc + 8, 0, 512 * sizeof(unsigned long long)));
+        k_bucket_count<<<grid, block>>>(T, N, bk.kb, d_misc + 8);
+        HIP_TRYB(hipMemcpy(h_count, d_misc + 8, sizeof h_count, hipMemcpyDeviceToHost));
+        unsigned long long most = 0;
+        for (int k = 0; k < bk.n; k++) most = std::max(most, h_count[k]);
+        if (most < (1ull << 31)) break;
+    }
+    uint64_t max_nb = 0;
+    bk.base[0] = 0;
+    for (int k = 0; k < bk.n; k++) { bk.base[k + 1] = bk.base[k] + h_count[k]; max_nb = std::max<uint64_t>(max_nb, h_count[k]); }
+    HIP_TRYB(hipMalloc(&sa, N * 8)); HIP_TRYB(hipMalloc(&rank, N * 8)); HIP_TRYB(hipMalloc(&key, N * 8));
+    HIP_TRYB(hipMalloc(&key_alt, max_nb * 8)); HIP_TRYB(hipMalloc(&val_alt, max_nb * 8)); HIP_TRYB(hipMalloc(&head, max_nb * 4));
+    {
+        unsigned long long cur[256];
+        for (int k = 0; k < 256; k++) cur[k] = k < bk.n ? bk.base[k] : 0;
+        HIP_TRYB(hipMemcpy(d_misc + 264, cur, sizeof cur, hipMemcpyHostToDevice));
+        k_bucket_scatter<<<grid, block>>>(T, N, bk.kb, d_misc + 264, sa);
+    }
+    // temp storage for sort + scan (sized for the largest bucket)
     size_t sort_bytes = 0, scan_bytes = 0;
     {
-        hipcub::DoubleBuffer<uint64_t> dk(key[0], key[1]);
-        hipcub::DoubleBuffer<uint32_t> dv(idx[0], idx[1]);
-        HIP_TRYB(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, dk, dv, (int64_t)N, 0, 64));
-        HIP_TRYB(hipcub::DeviceScan::InclusiveScan(nullptr, scan_bytes, head, head, MaxOp(), (int64_t)N));
+        hipcub::DoubleBuffer<uint64_t> dk(key, key_alt);
+        hipcub::DoubleBuffer<uint64_t> dv(sa, val_alt);
+        HIP_TRYB(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, dk, dv, (int64_t)max_nb, 0, 64));
+        HIP_TRYB(hipcub::DeviceScan::InclusiveScan(nullptr, scan_bytes, head, head, MaxOp(), (int64_t)max_nb));
         size_t sum_bytes = 0;
-        uint64_t *dummy = key[0];
+        uint64_t *dummy = key;
         HIP_TRYB(hipcub::DeviceScan::ExclusiveSum(nullptr, sum_bytes, dummy, dummy, (int64_t)((N + 127) / 128)));
         if (sum_bytes > scan_bytes) scan_bytes = sum_bytes;
     }
     void *tmp = nullptr;
     const size_t tmp_bytes = (sort_bytes > scan_bytes ? sort_bytes : scan_bytes) + 256;
     HIP_TRYB(hipMalloc(&tmp, tmp_bytes));
-    int cur = 0;
+    std::vector<bool> done((size_t)bk.n, false); // buckets whose suffixes are all distinct already
+    std::vector<unsigned long long> groups_of((size_t)bk.n, 0);
     uint64_t h = 16;
     for (int iter = 0;; iter++) {
-        hipcub::DoubleBuffer<uint64_t> dk(key[cur], key[1 - cur]);
-        hipcub::DoubleBuffer<uint32_t> dv(idx[cur], idx[1 - cur]);
-        size_t sb = tmp_bytes;
-        HIP_TRYB(hipcub::DeviceRadixSort::SortPairs(tmp, sb, dk, dv, (int64_t)N, 0, iter == 0 ? 37 : 64));
-        if (dk.Current() != key[cur]) cur = 1 - cur;
-        if (dv.Current() != idx[cur]) return mcx_set_error(MCX_ERR_DEVICE, "radix sort left keys and values in different buffers");
-        k_mark_heads<<<grid, block>>>(key[cur], N, head);
-        size_t cb = tmp_bytes;
-        HIP_TRYB(hipcub::DeviceScan::InclusiveScan(tmp, cb, head, head, MaxOp(), (int64_t)N));
-        HIP_TRYB(hipMemset(d_misc, 0, sizeof(unsigned long long)));
-        k_scatter_rank<<<grid, block>>>(idx[cur], head, N, rank, d_misc);
-        unsigned long long groups = 0;
-        HIP_TRYB(hipMemcpy(&groups, d_misc, sizeof groups, hipMemcpyDeviceToHost));
-        if (groups == N) break;
-        if (h >= N) return mcx_set_error(MCX_ERR_DEVICE, "suffix sorting did not converge");
-        k_pair_keys<<<grid, block>>>(idx[cur], rank, N, h, key[cur]);
-        h <<= 1;
+        // keys of every unfinished bucket first: they read the ranks of the previous round
+        for (int k = 0; k < bk.n; k++) {
+            const uint64_t nb = bk.base[k + 1] - bk.base[k];
+            if (nb == 0 || done[k]) continue;
+            if (iter == 0) k_init_keys<<<grid, block>>>(T, N, sa + bk.base[k], nb, key + bk.base[k]);
+            else k_pair_keys<<<grid, block>>>(sa + bk.base[k], rank, nb, bk.base[k], N, h, key + bk.base[k]);
+        }
+        if (iter > 0) h <<= 1;
+        unsigned long long total_groups = 0;
+        for (int k = 0; k < bk.n; k++) {
+            const uint64_t nb = bk.base[k + 1] - bk.base[k], b0 = bk.base[k];
+            if (nb == 0) continue;
+            if (done[k]) { total_groups += nb; continue; }
+            int local_bits = 1;
+            while ((1ull << local_bits) < nb + 2) local_bits++;
+            hipcub::DoubleBuffer<uint64_t> dk(key + b0, key_alt);
+            hipcub::DoubleBuffer<uint64_t> dv(sa + b0, val_alt);
+            size_t sb = tmp_bytes;
+            HIP_TRYB(hipcub::DeviceRadixSort::SortPairs(tmp, sb, dk, dv, (int64_t)nb, 0, iter == 0 ? 37 : 33 + local_bits));
+            if (dk.Current() != key + b0) HIP_TRYB(hipMemcpyAsync(key + b0, key_alt, nb * 8, hipMemcpyDeviceToDevice));
+            if (dv.Current() != sa + b0) HIP_TRYB(hipMemcpyAsync(sa + b0, val_alt, nb * 8, hipMemcpyDeviceToDevice));
+            k_mark_heads<<<grid, block>>>(key + b0, nb, head);
+            size_t cb = tmp_bytes;
+            HIP_TRYB(hipcub::DeviceScan::InclusiveScan(tmp, cb, head, head, MaxOp(), (int64_t)nb));
+            HIP_TRYB(hipMemset(d_misc, 0, sizeof(unsigned long long)));
+            k_scatter_rank<<<grid, block>>>(sa + b0, head, nb, b0, rank, d_misc);
+            unsigned long long groups = 0;
+            HIP_TRYB(hipMemcpy(&groups, d_misc, sizeof groups, hipMemcpyDeviceToHost));
+            groups_of[k] = groups;
+            total_groups += groups;
+        }
+        // a bucket is finished once its ranks are all distinct; marked after the round so that this
+        // round's keys of the other buckets saw consistent ranks
+        for (int k = 0; k < bk.n; k++) if (!done[k] && groups_of[k] == bk.base[k + 1] - bk.base[k]) done[k] = true;
+        if (total_groups == N) break;
+        if (h >= 2 * N) return mcx_set_error(MCX_ERR_DEVICE, "suffix sorting did not converge");
     }
-    // idx[cur] is the suffix array of T (without the terminator row)
-    const uint32_t *SA = idx[cur];
+    // sa is the suffix array of T (without the terminator row)
+    const uint64_t *SA = sa;
     k_find_primary<<<grid, block>>>(SA, N, d_misc + 1);
     unsigned long long misc[8];
     HIP_TRYB(hipMemcpy(misc, d_misc, sizeof misc, hipMemcpyDeviceToHost));
     out.primary = misc[1]; out.seq_len = N;
     out.L2[0] = 0;
     for (int k = 0; k < 4; k++) out.L2[k + 1] = out.L2[k] + misc[2 + k];
-    // BWT words (reuse key buffers as scratch)
+    // BWT words (the key / rank buffers are scratch now)
     const uint64_t n_words = (N + 15) / 16, n_blocks = (N + 127) / 128;
-    uint32_t *words = (uint32_t *)key[1 - cur];
+    uint32_t *words = (uint32_t *)key;
     k_pack_bwt<<<grid, block>>>(T, SA, N, out.primary, words);
-    uint64_t *cnt = (uint64_t *)key[cur]; // 4 x n_blocks counts, then exclusive sums in place
+    uint64_t *cnt = rank; // 4 x n_blocks counts, then exclusive sums in place
     k_block_counts<<<grid, block>>>(words, N, n_blocks, cnt);
     uint64_t *d_total = nullptr;
     HIP_TRYB(hipMalloc(&d_total, 4 * 8));
@@ -275,6 +375,8 @@ int mcx_build_suffix_index(const uint8_t *d_fwd, uint64_t G, bool want_full_sa, 
     HIP_TRYB(hipMalloc(&out.bwt, out.bwt_words * 4 + 128));
     HIP_TRYB(hipMemset(out.bwt, 0, out.bwt_words * 4 + 128));
     k_interleave<<<grid, block>>>(words, cnt, d_total, N, n_blocks, out.bwt);
+    HIP_TRYB(hipDeviceSynchronize());
+    (void)hipFree(key); (void)hipFree(rank); (void)hipFree(key_alt); (void)hipFree(val_alt); (void)hipFree(head); // room for the full suffix array
     out.n_sa = (N + 32) / 32;
     HIP_TRYB(hipMalloc(&out.sa, out.n_sa * 8));
     if (want_full_sa) HIP_TRYB(hipMalloc(&out.sa_full, (N + 1) * 8));
@@ -285,8 +387,7 @@ int mcx_build_suffix_index(const uint8_t *d_fwd, uint64_t G, bool want_full_sa, 
     float ms = 0;
     HIP_TRYB(hipEventElapsedTime(&ms, e0, e1));
     if (seconds) *seconds = ms / 1000.0;
-    (void)hipFree(T); (void)hipFree(key[0]); (void)hipFree(key[1]); (void)hipFree(idx[0]); (void)hipFree(idx[1]);
-    (void)hipFree(rank); (void)hipFree(head); (void)hipFree(d_misc); (void)hipFree(tmp); (void)hipFree(d_total);
+    (void)hipFree(T); (void)hipFree(sa); (void)hipFree(d_misc); (void)hipFree(tmp); (void)hipFree(d_total);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return 0;
 }

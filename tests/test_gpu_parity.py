@@ -144,11 +144,15 @@ def test_fresh_seeded_input_equals_oracle(api, tmp_path, alg, rlen, paired):
     mp.close(); ix.close()
 
 
+@pytest.mark.parametrize("bucket_bases", ["", "1", "3"])
 @pytest.mark.parametrize("name", ["toy", "mc", "long"])
-def test_gpu_index_builder_writes_the_reference_files(api, golden, tmp_path, name):
+def test_gpu_index_builder_writes_the_reference_files(api, golden, tmp_path, name, bucket_bases, monkeypatch):
     """mcx_index_build (GPU suffix sorting) against the five files `MapCaller index` wrote for the
-    same FASTA: byte-identical (mc has runs of N: the lrand48 replacement path)."""
+    same FASTA: byte-identical (mc has runs of N: the lrand48 replacement path).  bucket_bases forces
+    the bucketed sort that genome-scale texts (2^31 positions and more) take, on these small ones."""
     import gzip
+    if bucket_bases:
+        monkeypatch.setenv("MCX_BUILD_BUCKET_BASES", bucket_bases)
     fa = str(tmp_path / "genome.fa")
     open(fa, "wb").write(gzip.open(os.path.join(GOLD, name, "genome.fa.gz"), "rb").read())
     prefix = str(tmp_path / "built")
