@@ -295,8 +295,8 @@ def test_cli_two_libraries(io_golden, tmp_path):
 
 
 def test_full_size_genome_prefix_equals_reference(api, tmp_path):
-    """bench.py's workload at full size (2 Gbp synthetic genome: text positions beyond 2^32, the
-    12-mer jump table, the full suffix array in HBM): the index is built on the GPU, saved, and the
+    """bench.py's workload at full size (GRCh38-sized 3.1 Gbp synthetic genome: 6.2 G text positions,
+    the bucketed index builder, the 15-mer jump table, the full suffix array in HBM): the index is built on the GPU, saved, and the
     first 60 k pairs of a bench batch go through the product's file path and through the CPU checker
     (the compiled reference at -t 1 when it travelled, else the oracle restatement).  The insert-size
     trajectory of a prefix is the trajectory of the run, so the SAM must be identical."""
@@ -306,7 +306,7 @@ def test_full_size_genome_prefix_equals_reference(api, tmp_path):
     import bench
     from mapcaller_amd import synth
     dev = torch.device("cuda", 0)
-    args = argparse.Namespace(genome_mbp=2000.0, contigs=24, repeats=2000)
+    args = argparse.Namespace(genome_mbp=3100.0, contigs=24, repeats=2000)
     codes, lens = bench.make_genome(args, dev, seed=1234)
     ix = api.Index.from_codes(codes.data_ptr(), lens, device=0, full_sa=True)
     prefix = str(tmp_path / "big")
