@@ -19,6 +19,7 @@ pairs against its own replica of the index: weak scaling, no collective on the d
 import argparse
 import json
 import os
+import re
 import subprocess
 import sys
 import tempfile
@@ -126,23 +127,28 @@ def cpu_baseline(args, index, bases_sample):
             def run(a, b):
                 cmd = [ref_bin, "-i", prefix, "-f", a, "-f2", b, "-alg", args.alg, "-sam", os.path.join(tmp, "o.sam"), "-no_vcf", "-t", str(cores), "-log", os.path.join(tmp, "job.log")]
                 t0 = time.perf_counter()
-                subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-                return time.perf_counter() - t0
+                r = subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+                wall = time.perf_counter() - t0
+                # the reference's own clock starts after the index is loaded (main.cpp:376) and prints whole seconds
+                m = re.findall(r"have been processed in (\d+) seconds", r.stderr)
+                return wall, (int(m[-1]) if m else None)
         elif os.path.exists(port_bin):
             kind = "port"
             def run(a, b):
                 cmd = [port_bin, "-i", prefix, "-f", a, "-f2", b, "-alg", args.alg, "-sam", os.path.join(tmp, "o.sam"), "-t", str(cores)]
                 t0 = time.perf_counter()
                 subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-                return time.perf_counter() - t0
+                return time.perf_counter() - t0, None
         else:
             return None
-        t_load = run(t1, t2)           # 200 pairs: index load + start-up
-        t_full = run(f1, f2)
-        dt = max(t_full - t_load, 1e-3)
+        t_full, own = run(f1, f2)
+        if own is not None and own >= 3:
+            dt, how = float(own), f"the reference's own clock (starts after the index load): {own} s of {t_full:.1f} s wall"
+        else:
+            t_load, _ = run(t1, t2)    # 200 pairs: index load + start-up
+            dt, how = max(t_full - t_load, 1e-3), f"wall {t_full:.1f}s minus {t_load:.1f}s index load"
         return {"value": round(2 * n_pairs / dt, 1), "unit": "reads/s", "cores": cores, "kind": kind,
-                "sample": f"{n_pairs} pairs x {args.rlen} bp of the same synthetic workload, -t {cores} -alg {args.alg} -sam (file) -no_vcf; "
-                          f"wall {t_full:.1f}s minus {t_load:.1f}s index load"}
+                "sample": f"{n_pairs} pairs x {args.rlen} bp of the same synthetic workload, -t {cores} -alg {args.alg} -sam (file) -no_vcf; {how}"}
 
 
 def main():
