@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--contigs", type=int, default=24)
     ap.add_argument("--batch-pairs", type=int, default=2_000_000, help="read pairs per step and per GPU")
     ap.add_argument("--rlen", type=int, default=150)
+    ap.add_argument("--sub", type=float, default=0.005, help="per-base substitution rate of the simulated reads")
+    ap.add_argument("--ins", type=float, default=0.001, help="per-base insertion rate")
+    ap.add_argument("--dele", type=float, default=0.001, help="per-base deletion rate")
     ap.add_argument("--alg", default="ksw2", choices=["nw", "ksw2"])
     ap.add_argument("--full-sa", type=int, default=1, help="keep every suffix-array entry in HBM")
     ap.add_argument("--cpu-pairs", type=int, default=-1,
@@ -93,7 +96,7 @@ def make_genome(args, device, seed):
     return codes, [int(x) for x in lens]
 
 
-def make_reads(codes, lens, n_pairs, rlen, seed, device):
+def make_reads(codes, lens, n_pairs, rlen, seed, device, sub=0.005, ins=0.001, dele=0.001):
     from mapcaller_amd import synth
     parts, o = [], 0
     for L in lens:
@@ -101,7 +104,7 @@ def make_reads(codes, lens, n_pairs, rlen, seed, device):
         o += L
     donor = synth.Genome([f"chr{i + 1}" for i in range(len(lens))], parts)
     bases, _ = synth.simulate_reads(donor, n_pairs, rlen, True, seed, frag_mean=500, frag_sd=50, frag_min=300, frag_max=800,
-                                    sub=0.005, ins=0.001, dele=0.001, device=device, chunk=1 << 19, skip_head=3000)
+                                    sub=sub, ins=ins, dele=dele, device=device, chunk=1 << 19, skip_head=3000)
     return bases  # uint8 ASCII [2 n_pairs, rlen]
 
 
@@ -177,7 +180,7 @@ def main():
     mapper = api.Mapper(index, alg=args.alg, max_read_len=max(256, args.rlen), max_batch_reads=reads_per_step)
     batches = []
     for s in range(n_steps):
-        b = make_reads(codes, lens, args.batch_pairs, args.rlen, seed=1000 * (rank + 1) + s, device=dev)
+        b = make_reads(codes, lens, args.batch_pairs, args.rlen, seed=1000 * (rank + 1) + s, device=dev, sub=args.sub, ins=args.ins, dele=args.dele)
         batches.append(b.reshape(-1).contiguous())
     off = (torch.arange(reads_per_step + 1, device=dev, dtype=torch.int64) * args.rlen).to(torch.uint32)
     cpu_pairs = args.cpu_pairs
@@ -262,7 +265,7 @@ def main():
             "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64/int8", "data": "synthetic",
             "config": {"workload": f"synthetic GRCh38-sized genome, {args.genome_mbp:.0f} Mbp ({args.contigs} contigs, {args.repeats} x4 1-kb repeat families; GRCh38 itself is unavailable offline), "
-                                   f"{args.batch_pairs} pairs x {args.rlen} bp PE per step per GPU, -alg {args.alg}",
+                                   f"{args.batch_pairs} pairs x {args.rlen} bp PE per step per GPU (sub {args.sub}, ins {args.ins}, del {args.dele} per base), -alg {args.alg}",
                        "reads_per_step_per_gpu": reads_per_step, "full_sa_in_hbm": bool(args.full_sa), "index_build_s": round(t_index, 2),
                        "index_hbm_gb": round(index.hbm_bytes / 1e9, 2)},
             "roofline": {"bound": "hbm", "kernel": "k_seed", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -277,7 +280,7 @@ def main():
                          "measured": None if not prof else {
                              "hbm_gbs": round(prof["traffic"] / (seed_ms * 1e-3) / 1e9, 1), "l2_requests_per_launch": prof["l2_requests"],
                              "l2_request_rate_g_per_s": round(prof["l2_requests"] / (seed_ms * 1e-3) / 1e9, 1), "waves_waiting_frac": prof["wait_frac"],
-                             "reading": "the launch moves an eighth of the walk's bytes; waves wait on dependent fetches two thirds of the time"}},
+                             "reading": "the launch moves a tenth of the walk's bytes; waves wait on dependent fetches two thirds of the time"}},
             "per_read": {"fm_ext_steps": round(d["fm_ext_steps"] / max(d["reads"], 1), 2), "fm_blocks": round(d["fm_blocks"] / max(d["reads"], 1), 2),
                          "sa_hits": round(d["sa_hits"] / max(d["reads"], 1), 3), "dp_jobs": round(d["dp_jobs"] / max(d["reads"], 1), 4),
                          "mapped_frac": round(d["mapped"] / max(d["reads"], 1), 4)},

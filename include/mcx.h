@@ -94,10 +94,11 @@ typedef struct mcx_aln {
     int32_t mapq;      /* MAPQ */
     int32_t tlen;      /* TLEN */
     int32_t nm, as, xs;/* NM:i AS:i XS:i */
-    int32_t n_cigar;   /* words in this read's row of the cigar array: len << 4 | op, M=0 I=1 D=2 S=4 */
+    int32_t n_cigar;   /* CIGAR operations: len << 4 | op, M=0 I=1 D=2 S=4; the first MCX_CIGAR_STRIDE in this read's row of the cigar array */
     int32_t fwd;       /* 0: SEQ/QUAL are printed reverse-complemented / reversed */
     int32_t has_mate;  /* RNEXT '=' */
-    int32_t pad[2];    /* 64-byte records */
+    int32_t cigar_ext; /* n_cigar > MCX_CIGAR_STRIDE: word offset of operation MCX_CIGAR_STRIDE.. in the pool of mcx_cigar_ext */
+    int32_t pad;       /* 64-byte records */
 } mcx_aln;
 
 typedef struct mcx_stats {
@@ -124,6 +125,10 @@ typedef struct mcx_stats {
 void mcx_avg_init(int64_t avg_state[4]);
 int mcx_map_batch_dev(mcx_ctx *, const uint8_t *d_bases, const uint32_t *d_off, uint32_t n_reads, int paired,
                       int64_t avg_state[4], mcx_aln *d_aln, uint32_t *d_cigar, mcx_stats *stats);
+/* The few CIGARs with more than MCX_CIGAR_STRIDE operations (many indels in a long read) continue
+ * in a pool that is valid until the context's next batch: words[mcx_aln.cigar_ext ..] hold operation
+ * MCX_CIGAR_STRIDE and up.  on_device: return the device pointer instead of a host copy. */
+int mcx_cigar_ext(mcx_ctx *, int on_device, const uint32_t **words, uint64_t *n_words);
 /* same with host buffers (pinned staging inside) */
 int mcx_map_batch(mcx_ctx *, const uint8_t *bases, const uint32_t *off, uint32_t n_reads, int paired,
                   int64_t avg_state[4], mcx_aln *aln, uint32_t *cigar, mcx_stats *stats);

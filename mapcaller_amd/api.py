@@ -21,7 +21,7 @@ SYMBOLS = [
     "mcx_last_error", "mcx_device_count", "mcx_index_load", "mcx_index_build", "mcx_index_from_codes", "mcx_index_save", "mcx_index_free",
     "mcx_index_genome_size", "mcx_index_n_chr", "mcx_index_chr_name", "mcx_index_chr_len", "mcx_index_hbm_bytes",
     "mcx_opts_default", "mcx_ctx_create", "mcx_ctx_free", "mcx_bwt_search_batch", "mcx_extend_batch",
-    "mcx_avg_init", "mcx_map_batch_dev", "mcx_map_batch", "mcx_map_files", "mcx_map_files_ex", "mcx_file_opts_default",
+    "mcx_avg_init", "mcx_map_batch_dev", "mcx_map_batch", "mcx_cigar_ext", "mcx_map_files", "mcx_map_files_ex", "mcx_file_opts_default",
     "mcx_profile_attach", "mcx_profile_finalize", "mcx_profile_sparse", "mcx_planes_alloc", "mcx_planes_free",
     "mcx_vcf_defaults", "mcx_call_variants",
 ]
@@ -39,12 +39,12 @@ class Opts(C.Structure):
 class Aln(C.Structure):
     _fields_ = [("pos", C.c_int64), ("mate_pos", C.c_int64), ("chr", C.c_int32), ("flag", C.c_int32),
                 ("mapq", C.c_int32), ("tlen", C.c_int32), ("nm", C.c_int32), ("as_", C.c_int32), ("xs", C.c_int32),
-                ("n_cigar", C.c_int32), ("fwd", C.c_int32), ("has_mate", C.c_int32), ("pad", C.c_int32 * 2)]
+                ("n_cigar", C.c_int32), ("fwd", C.c_int32), ("has_mate", C.c_int32), ("cigar_ext", C.c_int32), ("pad", C.c_int32)]
 
 
 ALN_DTYPE = np.dtype([("pos", "<i8"), ("mate_pos", "<i8"), ("chr", "<i4"), ("flag", "<i4"), ("mapq", "<i4"),
                       ("tlen", "<i4"), ("nm", "<i4"), ("as", "<i4"), ("xs", "<i4"), ("n_cigar", "<i4"),
-                      ("fwd", "<i4"), ("has_mate", "<i4"), ("pad", "<i4", (2,))])
+                      ("fwd", "<i4"), ("has_mate", "<i4"), ("cigar_ext", "<i4"), ("pad", "<i4")])
 
 
 class SparseRec(C.Structure):

@@ -167,6 +167,7 @@ struct Batch {
     uint8_t *bases = nullptr; uint32_t *off = nullptr; AlnRec *recs = nullptr; uint32_t *cig = nullptr;
     size_t cap_reads = 0, cap_bases = 0;
     std::vector<uint8_t> is_mate2;                          // mapped as the second read of a pair
+    std::vector<uint32_t> cig_ext;                          // operations past a row of cig (mcx_cigar_ext), AlnRec::pad[0] = offset
     bool reserve(size_t reads, size_t n_bases)
     {
         if (reads > cap_reads) {
@@ -236,7 +237,7 @@ struct Text { // writer over a buffer sized beforehand from an upper bound
 // bytes one SAM line can take at most
 inline size_t sam_bound(const HostIndex &ix, size_t name_len, size_t rlen, int chr, int n_cigar)
 {
-    return name_len + 2 * rlen + (chr >= 0 ? ix.chr_name[chr].size() : 1) + 11 * (size_t)n_cigar + 160;
+    return name_len + 2 * rlen + (chr >= 0 ? ix.chr_name[chr].size() : 1) + 11 * (size_t)(n_cigar > 0 ? n_cigar : 0) + 160;
 }
 
 void sam_record(const HostIndex &ix, const Batch &bt, uint32_t r, Text &o)
@@ -261,7 +262,10 @@ void sam_record(const HostIndex &ix, const Batch &bt, uint32_t r, Text &o)
     else {
         const std::string &cn = ix.chr_name[rec.chr];
         o.put(cn.data(), cn.size()); o.put('\t'); o.num(rec.pos); o.put('\t'); o.num(rec.mapq); o.put('\t');
-        for (int k = 0; k < rec.n_cigar; k++) { o.num(cigar[k] >> 4); o.put(opc[cigar[k] & 7]); }
+        for (int k = 0; k < rec.n_cigar; k++) {
+            const uint32_t w = k < MCX_CIGAR_STRIDE ? cigar[k] : bt.cig_ext[(size_t)rec.pad[0] + (size_t)(k - MCX_CIGAR_STRIDE)];
+            o.num(w >> 4); o.put(opc[w & 7]);
+        }
         if (rec.has_mate) { o.lit("\t=\t"); o.num(rec.mate_pos); o.put('\t'); o.num(rec.tlen); o.put('\t'); }
         else o.lit("\t*\t0\t0\t");
     }
@@ -417,12 +421,24 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
                 rc = mcx_map_batch(c, b->bases, b->off, n_pairs_reads, 1, avg, (mcx_aln *)b->recs, b->cig, stats);
                 for (uint32_t r = 1; r < n_pairs_reads; r += 2) b->is_mate2[r] = 1;
             }
+            b->cig_ext.clear();
+            auto take_ext = [&](uint32_t first, uint32_t last) { // long CIGARs of the reads just mapped
+                const uint32_t *w = nullptr; uint64_t nw = 0;
+                int e = mcx_cigar_ext(c, 0, &w, &nw);
+                if (e || nw == 0) return e;
+                const size_t base = b->cig_ext.size();
+                b->cig_ext.insert(b->cig_ext.end(), w, w + nw);
+                if (base) for (uint32_t r = first; r < last; r++) if (b->recs[r].n_cigar > MCX_CIGAR_STRIDE) b->recs[r].pad[0] += (int32_t)base;
+                return 0;
+            };
+            if (rc == 0 && n_pairs_reads) rc = take_ext(0, n_pairs_reads);
             if (rc == 0 && n_pairs_reads < n) {
                 std::vector<uint32_t> off2(b->off + n_pairs_reads, b->off + n + 1);
                 const uint32_t base = off2[0];
                 for (auto &x : off2) x -= base;
                 rc = mcx_map_batch(c, b->bases + base, off2.data(), n - n_pairs_reads, 0, avg, (mcx_aln *)b->recs + n_pairs_reads,
                                    b->cig + (size_t)n_pairs_reads * MCX_CIGAR_STRIDE, stats);
+                if (rc == 0) rc = take_ext(n_pairs_reads, n);
             }
             t_map += secs(t1, now());
             if (rc) b->n = 0;

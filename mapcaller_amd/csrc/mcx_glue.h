@@ -27,6 +27,11 @@ struct Ctx {
     uint8_t *state;           // pair-state records
     const uint8_t *mapq_tab;  // [(rlen_max+1) * 6]: EvaluateMAPQ for (score, score-sub in 1..5), host-computed
     int32_t mapq_rows;
+    // CIGARs with more operations than a row of the dense array holds (many indels in a long read)
+    // continue in this pool; only the last tier uses it (null otherwise)
+    uint32_t *cig_ext;
+    uint32_t *cig_ext_n;      // words taken so far
+    uint32_t cig_ext_cap;
 };
 
 static inline MCX_HD int64_t hit_pd(const Hit &h) { return h.gPos - h.rPos; }
@@ -780,11 +785,16 @@ static inline MCX_HD int mapq_of(const Ctx &cx, const ReadSum &r) // EvaluateMAP
 
 // GenerateCIGARstring (SamReport.cpp:172-316) as BAM-style (len << 4 | op) words; op codes
 // M=0 I=1 D=2 S=4.  Returns the number of words needed (may exceed cap).
-static inline MCX_HD int cigar_of(int rlen, const Cand &c, const Frag *frags, const uint8_t *ops, uint32_t *out, int cap)
+// (operations beyond `cap` go to ext[0..) when ext is given; the count is returned either way)
+static inline MCX_HD int cigar_of(int rlen, const Cand &c, const Frag *frags, const uint8_t *ops, uint32_t *out, int cap, uint32_t *ext = nullptr)
 {
     const Frag *v = frags + c.frag_off;
     int num = c.n_frags, n = 0, run = 0, st = -1;
-    auto put = [&](int len, int op) { if (n < cap) out[n] = ((uint32_t)len << 4) | (uint32_t)op; n++; };
+    auto put = [&](int len, int op) {
+        const uint32_t w = ((uint32_t)len << 4) | (uint32_t)op;
+        if (n < cap) out[n] = w; else if (ext) ext[n - cap] = w;
+        n++;
+    };
     auto flush_to = [&](int ns) { if (st != ns) { if (run > 0) put(run, st); st = ns; run = 0; } };
     if (v[0].kind != kSimple) {
         int clip = c.fwd ? v[0].rPos : rlen - (v[0].rPos + v[0].rLen);
@@ -899,7 +909,20 @@ static inline MCX_HD void emit_record(const Ctx &cx, PairState &st, int s, const
     out.fwd = c.fwd;
     out.nm = rd[s].rlen - c.score; out.as = me.score; out.xs = me.sub;
     int nc = cigar_of(rd[s].rlen, c, st.frags, st.ops, cig, cig_cap);
-    if (nc > cig_cap) { h.flags |= kOvCigar; nc = 0; }
+    if (nc > cig_cap) {
+        bool kept = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (cx.cig_ext) { // the row's continuation: reserve, then write the operations past the row
+            const uint32_t at = atomicAdd(cx.cig_ext_n, (uint32_t)(nc - cig_cap));
+            if (at + (uint32_t)(nc - cig_cap) <= cx.cig_ext_cap) {
+                cigar_of(rd[s].rlen, c, st.frags, st.ops, cig, cig_cap, cx.cig_ext + at);
+                out.pad[0] = (int32_t)at;
+                kept = true;
+            }
+        }
+#endif
+        if (!kept) { h.flags |= kOvCigar; nc = 0; }
+    }
     out.n_cigar = nc;
     if (paired) {
         const ReadSum &ot = h.sum[1 - s];

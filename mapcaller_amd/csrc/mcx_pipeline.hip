@@ -695,6 +695,8 @@ struct mcx_ctx {
     uint32_t *d_sel_ids = nullptr; int32_t *d_est = nullptr;
     uint32_t *d_read_ext = nullptr, *d_read_blocks = nullptr;
     uint32_t *d_packed = nullptr; int wpad = 0; // 2-bit form of the batch's reads
+    uint32_t *d_cig_ext = nullptr, *d_cig_ext_n = nullptr, cig_ext_cap = 0; // CIGAR operations past a row of the dense array (tier 1)
+    std::vector<uint32_t> h_cig_ext;
     PairOut *d_pout = nullptr, *h_pout = nullptr;
     uint8_t *d_mapq = nullptr; int mapq_rows = 0;
     // -vcf bookkeeping (mcx_profile.h): caller-owned counter planes, per-read alignment detail
@@ -790,6 +792,10 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
     if ((rc = dmalloc(&c->d_est, c->max_reads))) return rc;
     if ((rc = dmalloc(&c->d_read_ext, c->max_reads))) return rc;
     if ((rc = dmalloc(&c->d_read_blocks, c->max_reads))) return rc;
+    c->cig_ext_cap = 1u << 22;
+    if ((rc = dmalloc(&c->d_cig_ext, c->cig_ext_cap))) return rc;
+    if ((rc = dmalloc(&c->d_cig_ext_n, 1))) return rc;
+    HIP_TRY(hipMemset(c->d_cig_ext_n, 0, sizeof(uint32_t)));
     c->wpad = (packed_words(c->rlen_max) + 3) & ~3;
     if ((rc = dmalloc(&c->d_packed, c->max_reads * (uint64_t)c->wpad))) return rc;
     if ((rc = dmalloc(&c->d_pout, c->max_reads))) return rc;
@@ -816,7 +822,7 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
                  c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
-                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_packed};
+                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_packed, c->d_cig_ext, c->d_cig_ext_n};
     for (void *q : p) if (q) (void)hipFree(q);
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
     if (c->h_pout) (void)hipHostFree(c->h_pout);
@@ -835,6 +841,7 @@ static Ctx make_ctx(const mcx_ctx *c, int tier, int paired)
     cx.caps = c->tier[tier].caps; cx.lay = c->tier[tier].lay; cx.state = c->tier[tier].state;
     cx.mapq_tab = c->d_mapq; cx.mapq_rows = c->mapq_rows;
     cx.detail = c->prof_planes ? c->d_detail : nullptr; cx.dlay = c->dlay;
+    cx.cig_ext = tier == 1 ? c->d_cig_ext : nullptr; cx.cig_ext_n = c->d_cig_ext_n; cx.cig_ext_cap = c->cig_ext_cap;
     return cx;
 }
 
@@ -842,6 +849,8 @@ static Ctx make_ctx(const mcx_ctx *c, int tier, int paired)
 // one tier over a selection of pairs
 // ---------------------------------------------------------------------------------------------
 struct StageMs { float seed, sa, cluster, rescue, build, dp, finish; };
+
+constexpr int kListOverflow = 1; // (internal) a work list of run_pairs was too short for the selection
 
 static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, PairSel sel, AlnRec *d_recs,
                      uint32_t *d_cig, mcx_stats *stats, bool timing)
@@ -892,9 +901,9 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const uint32_t *n = c->h_cnt;
-    if (n[CNT_TASKS] > c->task_cap) return fail(MCX_ERR_CAPACITY, "seed task list overflow (more hits per read than the context was sized for)");
-    if (n[CNT_RESCUE] > c->rescue_cap) return fail(MCX_ERR_CAPACITY, "rescue list overflow");
-    for (int k = 0; k < 4; k++) if (n[CNT_JOB0 + k] > c->job_cap[k]) return fail(MCX_ERR_CAPACITY, "DP job list overflow");
+    // a work list that ran over: nothing of this pass is kept, the caller maps the selection in two halves
+    if (n[CNT_TASKS] > c->task_cap || n[CNT_RESCUE] > c->rescue_cap) return kListOverflow;
+    for (int k = 0; k < 4; k++) if (n[CNT_JOB0 + k] > c->job_cap[k]) return kListOverflow;
     if (n[CNT_UNSUP]) return fail(MCX_ERR_UNSUPPORTED, "a gapped fragment exceeds 2048 x 1024 cells per side");
     if (timing && getenv("MCX_TIMING"))
         fprintf(stderr, "[run_pairs] pairs %u: sa tasks %u, rescue pairs %u, dp jobs by class %u %u %u %u, cells %u, overflow pairs %u\n", sel.n, n[CNT_TASKS],
@@ -979,6 +988,18 @@ static int run_selection(mcx_ctx *c, const ReadBatch &rb, int paired, const std:
     if (est) HIP_TRY(hipMemcpyAsync(c->d_est, est->data(), n * sizeof(int32_t), hipMemcpyHostToDevice, s));
     else k_fill_i32<<<(n + 255) / 256, 256, 0, s>>>(c->d_est, est_all, n);
     int rc = run_pairs(c, 0, rb, paired, sel, d_recs, d_cig, stats, timing);
+    if (rc == kListOverflow) {
+        // unusually many hits or DP problems per read (e.g. indel-heavy long reads): halve the selection
+        if (n < 2) return fail(MCX_ERR_CAPACITY, "work list overflow for a single pair");
+        for (int half = 0; half < 2; half++) {
+            const uint32_t lo = half ? n / 2 : 0, hi = half ? n : n / 2;
+            std::vector<uint32_t> sub_ids(hi - lo);
+            std::vector<int32_t> sub_est(hi - lo);
+            for (uint32_t i = lo; i < hi; i++) { sub_ids[i - lo] = ids ? (*ids)[i] : i; sub_est[i - lo] = est ? (*est)[i] : est_all; }
+            if ((rc = run_selection(c, rb, paired, &sub_ids, &sub_est, 0, n_pairs, d_recs, d_cig, stats, timing))) return rc;
+        }
+        return 0;
+    }
     if (rc) return rc;
     uint32_t n_ov = c->h_cnt[CNT_OV];
     if (n_ov == 0) return 0;
@@ -997,8 +1018,16 @@ static int run_selection(mcx_ctx *c, const ReadBatch &rb, int paired, const std:
         HIP_TRY(hipMemcpyAsync(c->d_est, ov_est.data() + lo, m * sizeof(int32_t), hipMemcpyHostToDevice, s));
         PairSel s1; s1.n = m; s1.ids = c->d_sel_ids; s1.est = c->d_est;
         rc = run_pairs(c, 1, rb, paired, s1, d_recs, d_cig, stats, false);
+        if (rc == kListOverflow) return fail(MCX_ERR_CAPACITY, "work list overflow in tier 1");
         if (rc) return rc;
-        if (c->h_cnt[CNT_OV]) return fail(MCX_ERR_CAPACITY, "a pair exceeded the tier-1 capacities");
+        if (c->h_cnt[CNT_OV]) {
+            uint32_t first = 0;
+            PairOut po; memset(&po, 0, sizeof po);
+            if (hipMemcpy(&first, c->d_ov, sizeof first, hipMemcpyDeviceToHost) == hipSuccess)
+                (void)hipMemcpy(&po, c->d_pout + first, sizeof po, hipMemcpyDeviceToHost);
+            return fail(MCX_ERR_CAPACITY, "a pair exceeded the tier-1 capacities (pair " + std::to_string(first) + ", overflow flags " + std::to_string(po.flags & kOvAny) +
+                                          ": 1 hits 2 candidates 4 fragments 8 ops 16 jobs 32 cigar 64 rescue window)");
+        }
     }
     return 0;
 }
@@ -1023,6 +1052,7 @@ extern "C" int mcx_map_batch_dev(mcx_ctx *c, const uint8_t *d_bases, const uint3
     const uint32_t n_pairs = paired ? n_reads / 2 : n_reads;
     { // the batch in 2-bit form, once; every seeding pass (tiers, replay) reads it
         hipStream_t s0 = c->stream;
+        HIP_TRY(hipMemsetAsync(c->d_cig_ext_n, 0, sizeof(uint32_t), s0));
         HIP_TRY(hipEventRecord(c->ev_pack[0], s0));
         const int tpr = (c->rlen_max + 31) / 32 + 1;
         const uint64_t threads = (uint64_t)n_reads * (uint64_t)tpr;
@@ -1099,6 +1129,11 @@ extern "C" int mcx_map_batch_dev(mcx_ctx *c, const uint8_t *d_bases, const uint3
         avg[0] = after[0]; avg[1] = after[1]; avg[2] = after[2];
     }
     avg[3] += n_reads;
+    {
+        uint32_t used = 0;
+        HIP_TRY(hipMemcpy(&used, c->d_cig_ext_n, sizeof used, hipMemcpyDeviceToHost));
+        if (used > c->cig_ext_cap) return fail(MCX_ERR_CAPACITY, "CIGAR continuation pool overflow");
+    }
     if (c->prof_planes) { rc = profile_batch(c, rb, paired); if (rc) return rc; }
     if (stats) {
         stats->reads += n_reads; stats->mapped += mapped; stats->pairs += pairs; stats->pair_dist_sum += dist_sum; stats->pair_len_sum += len_sum;
@@ -1380,6 +1415,20 @@ extern "C" int mcx_extend_batch(mcx_ctx *c, int alg, const uint8_t *q, const uin
 // ---------------------------------------------------------------------------------------------
 // files in, SAM out: MapCaller -i <prefix> -f A [-f2 B] -sam out  (main.cpp:212-321, Mapping() ReadMapping.cpp:689-747)
 // ---------------------------------------------------------------------------------------------
+extern "C" int mcx_cigar_ext(mcx_ctx *c, int on_device, const uint32_t **words, uint64_t *n_words)
+{
+    if (!c || !words || !n_words) return fail(MCX_ERR_ARG, "mcx_cigar_ext: null argument");
+    HIP_TRY(hipSetDevice(c->idx->device));
+    uint32_t used = 0;
+    HIP_TRY(hipMemcpy(&used, c->d_cig_ext_n, sizeof used, hipMemcpyDeviceToHost));
+    *n_words = used;
+    if (on_device) { *words = c->d_cig_ext; return 0; }
+    c->h_cig_ext.resize(used);
+    if (used) HIP_TRY(hipMemcpy(c->h_cig_ext.data(), c->d_cig_ext, (size_t)used * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *words = c->h_cig_ext.data();
+    return 0;
+}
+
 const mcx_index *mcx_ctx_index(const mcx_ctx *c) { return c->idx; }
 int mcx_ctx_max_read_len(const mcx_ctx *c) { return c->rlen_max; }
 uint64_t mcx_ctx_max_reads(const mcx_ctx *c) { return c->max_reads; }

@@ -85,6 +85,7 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
     cx.ix = e.view; cx.pm = e.pm; cx.pm.paired = b.paired; cx.caps = e.caps[tier]; cx.lay = e.lay[tier];
     cx.detail = nullptr; cx.dlay = make_detail_layout(256);
     cx.state = state.data(); cx.mapq_tab = e.mapq.data(); cx.mapq_rows = e.mapq_rows;
+    cx.cig_ext = nullptr; cx.cig_ext_n = nullptr; cx.cig_ext_cap = 0;
     std::vector<DpJob> jobs;
     std::vector<uint32_t> kq(4096), kg(e.caps[tier].kmer_cap + 16);
     std::vector<uint32_t> ov;

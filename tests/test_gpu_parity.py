@@ -372,3 +372,62 @@ def test_ragged_reads_equal_oracle(api, tmp_path):
             assert nd == 0, ex
     assert st["mapped"] > 0.8 * st["reads"]
     mp.close(); ix.close()
+
+
+def test_long_cigars_equal_oracle(api, tmp_path):
+    """Reads with a one-base deletion or insertion every 17 bases (exact 16-mers between them): the
+    alignments need 33+ CIGAR operations, more than a row of the dense cigar array holds, and continue
+    in the pool of mcx_cigar_ext — next to ordinary indel-heavy 300 bp reads (BASELINE config 5's
+    regime).  GPU SAM == oracle SAM (== the reference when it is here)."""
+    import re
+    import torch
+    from mapcaller_amd import synth
+    g = synth.random_genome([700000, 300000], seed=404, n_repeats=10, repeat_len=500)
+    fa = str(tmp_path / "g.fa")
+    synth.write_fasta(fa, g)
+    prefix = str(tmp_path / "g")
+    api.Index.build(fa, prefix, 0)
+    bases, _ = synth.simulate_reads(g, 3000, 300, True, seed=12, skip_head=3000, frag_mean=700, frag_sd=60, frag_min=400, frag_max=1000,
+                                    sub=0.001, ins=0.02, dele=0.02)
+    chrom = g.codes[0].numpy()
+    rng = np.random.default_rng(5)
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    extra = []
+    for k in range(300):  # mate 1: 17 blocks of 17 bases with one base dropped (or added) between blocks; mate 2: exact, reverse strand
+        p0 = int(rng.integers(5000, 690000))
+        blocks, p = [], p0
+        for j in range(17):
+            blocks.append(chrom[p:p + 17])
+            p += 17
+            if k % 2 == 0:
+                p += 1                                      # deletion in the read
+            elif j < 16:
+                blocks.append(np.array([(chrom[p] + 1) % 4], dtype=np.uint8))  # inserted base that differs from the next one
+        r1 = np.concatenate(blocks)[:300]
+        r1 = np.concatenate([r1, chrom[p:p + 300 - len(r1)]]) if len(r1) < 300 else r1
+        m = chrom[p0 + 500:p0 + 800]
+        r2 = (3 - m)[::-1]
+        extra += [lut[r1], lut[r2]]
+    bases = torch.cat([bases, torch.from_numpy(np.stack(extra))])
+    f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+    synth.write_fastq(f1, bases, 0, 2); synth.write_fastq(f2, bases, 1, 2)
+    for alg in ("nw", "ksw2"):
+        ix = api.Index(prefix, device=0)
+        mp = api.Mapper(ix, alg=alg, max_read_len=320, max_batch_reads=10000)
+        out = str(tmp_path / f"gpu.{alg}.sam")
+        mp.map_files(f1, f2, out)
+        ora = str(tmp_path / f"ora.{alg}.sam")
+        _oracle_sam(prefix, f1, f2, alg, ora)
+        longest = max((len(re.findall(r"\d+[MIDS]", l.split("\t")[5])) for l in open(ora) if not l.startswith("@")), default=0)
+        assert longest > 32, longest  # the case this test exists for
+        nd, ex = sam_diff(ora, out)
+        assert nd == 0, ex
+        mp.close(); ix.close()
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "MapCaller")
+    if os.path.exists(ref_bin):
+        rs = str(tmp_path / "ref.sam")
+        r = subprocess.run([ref_bin, "-i", prefix, "-f", f1, "-f2", f2, "-alg", "ksw2", "-sam", rs, "-no_vcf", "-t", "1", "-log", str(tmp_path / "job.log")],
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        if r.returncode == 0:
+            nd, ex = sam_diff(rs, str(tmp_path / "gpu.ksw2.sam"))
+            assert nd == 0, ex
