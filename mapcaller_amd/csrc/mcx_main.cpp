@@ -20,6 +20,7 @@ static void usage(const char *prog)
             "         -r STR        Reference filename (format:fa); an index is built on the GPU first\n"
             "         -f            files with #1 mates reads (format:fa, fq, fq.gz)\n"
             "         -f2           files with #2 mates reads (format:fa, fq, fq.gz)\n"
+            "         -lib STR      file with one 'reads1 [reads2]' pair of filenames per line\n"
             "         -alg STR      gapped alignment algorithm (option: nw|ksw2) [nw]\n"
             "         -sam          SAM output filename ('-' = stdout)\n"
             "         -indel INT    maximal indel size [30]\n"
@@ -70,6 +71,19 @@ int main(int argc, char **argv)
         else if (p == "-r" && i + 1 < argc) ref = argv[++i];
         else if (p == "-f") { while (++i < argc && argv[i][0] != '-') f1.push_back(argv[i]); i--; }
         else if (p == "-f2") { while (++i < argc && argv[i][0] != '-') f2.push_back(argv[i]); i--; }
+        else if (p == "-lib" && i + 1 < argc) { // ReadLibInput, main.cpp:136-152: one "file1 [file2]" per line, '#' comments, an empty line ends the list
+            FILE *lf = fopen(argv[++i], "r");
+            char line[4096], a[2048], b[2048];
+            while (lf && fgets(line, sizeof line, lf)) {
+                if (line[0] == '\n' || line[0] == '\0') break;
+                if (line[0] == '#') continue;
+                a[0] = b[0] = 0;
+                sscanf(line, "%2047s %2047s", a, b);
+                if (a[0]) f1.push_back(a);
+                if (b[0]) f2.push_back(b);
+            }
+            if (lf) fclose(lf);
+        }
         else if (p == "-alg" && i + 1 < argc) o.alg = strcmp(argv[++i], "ksw2") == 0 ? 1 : 0;
         else if (p == "-sam" && i + 1 < argc) sam = argv[++i];
         else if (p == "-indel" && i + 1 < argc) { o.max_pos_diff = atoi(argv[++i]); if (o.max_pos_diff > 100) { o.max_pos_diff = 100; fprintf(stderr, "Warning! The maximal indel size is 100!\n"); } }
