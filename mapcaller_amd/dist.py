@@ -40,14 +40,17 @@ def finalize_planes(planes: torch.Tensor, max_dup: int = 5) -> torch.Tensor:
 
 def reduce_profile(planes: torch.Tensor, sparse):
     """Sums the [10, G] counter planes over all ranks in place (all-reduce: RCCL on GPU tensors),
-    one plane per call so that a collective never exceeds 2^31 elements, and gathers the sparse
+    in pieces of 2^30 elements so that no collective's count outgrows 32 bits, and gathers the sparse
     records of every rank in rank order.  ``sparse`` is either the list of tuples of
     Mapper.profile_sparse() or the raw uint8 [n, 64] array of Mapper.profile_sparse_raw(); the same
     kind comes back.  Call before finalisation."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return planes, (sparse if isinstance(sparse, np.ndarray) else list(sparse))
+    step = 1 << 30  # elements per collective: a GRCh38-sized plane has 3.1e9, more than a 32-bit count holds
     for k in range(planes.shape[0]):
-        dist.all_reduce(planes[k], op=dist.ReduceOp.SUM)
+        row = planes[k]
+        for lo in range(0, row.numel(), step):
+            dist.all_reduce(row[lo:lo + step], op=dist.ReduceOp.SUM)
     world = dist.get_world_size()
     if isinstance(sparse, np.ndarray):  # raw records: one padded all-gather of bytes
         dev = planes.device
