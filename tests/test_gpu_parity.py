@@ -431,3 +431,23 @@ def test_long_cigars_equal_oracle(api, tmp_path):
         if r.returncode == 0:
             nd, ex = sam_diff(rs, str(tmp_path / "gpu.ksw2.sam"))
             assert nd == 0, ex
+
+
+def test_file_path_errors_are_loud(api, golden, tmp_path):
+    """No fallbacks: a missing read file, a mate file that holds fewer reads, a read longer than the
+    context was sized for — each is an error with a message, not a shorter SAM."""
+    g = golden["toy"]
+    ix = api.Index(g["prefix"], device=0)
+    mp = api.Mapper(ix, alg="ksw2", max_read_len=256, max_batch_reads=1000)
+    with pytest.raises(api.McxError, match="cannot open"):
+        mp.map_files(str(tmp_path / "nope.fq"), None, None)
+    lines = open(g["r2"], "rb").read().split(b"\n")
+    short = tmp_path / "short.fq"
+    short.write_bytes(b"\n".join(lines[:4 * 700]) + b"\n")
+    with pytest.raises(api.McxError, match="fewer reads"):
+        mp.map_files(g["r1"], str(short), str(tmp_path / "x.sam"))
+    mp.close()
+    mp = api.Mapper(ix, alg="ksw2", max_read_len=100, max_batch_reads=1000)
+    with pytest.raises(api.McxError, match="max_read_len"):
+        mp.map_files(g["r1"], g["r2"], None)
+    mp.close(); ix.close()
