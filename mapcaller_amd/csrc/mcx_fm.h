@@ -132,7 +132,6 @@ struct ReadRef {
     const uint8_t *ascii;
     int32_t rlen;
     int32_t flipped;
-    const uint32_t *packed = nullptr; // the read's 2-bit words + N masks (k_pack_reads) when the batch has them
 };
 
 static inline MCX_HD int read_code(const ReadRef &r, int i)

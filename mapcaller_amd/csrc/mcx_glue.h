@@ -536,26 +536,6 @@ static inline MCX_HD int frag_ref_code(const IndexView &ix, const Frag &f, bool 
     return ref_code(ix, rev ? f.gPos + f.gLen - 1 - y : f.gPos + y);
 }
 
-// Mismatching columns of an ungapped fragment — read bases p0.. against RefSequence j0.., L of
-// them — from the packed read and the 2-bit genome, sixteen columns per step (a read N differs from
-// every genome base, as code 4 does in the base-by-base comparison).
-static inline MCX_HD int plain_mismatches(const IndexView &ix, const ReadRef &rd, int p0, int64_t j0, int L)
-{
-    PackedRead pk; pk.w = const_cast<uint32_t *>(rd.packed); pk.stride = 1; pk.n_code = ((rd.rlen + 15) >> 4) + 1;
-    int mm = 0;
-    for (int o = 0; o < L; o += 16) {
-        const int n = L - o < 16 ? L - o : 16;
-        const uint32_t x = packed_codes16(pk, p0 + o) ^ ref_codes16(ix, j0 + o);
-        uint32_t sp = packed_nmask32(pk, p0 + o, rd.rlen) >> 16; // N flags, bit 15-s -> bit 30-2s
-        sp = (sp | (sp << 8)) & 0x00FF00FFu; sp = (sp | (sp << 4)) & 0x0F0F0F0Fu;
-        sp = (sp | (sp << 2)) & 0x33333333u; sp = (sp | (sp << 1)) & 0x55555555u;
-        uint32_t m = ((x | (x >> 1)) & 0x55555555u) | sp;
-        if (n < 16) m &= ~0u << (2 * (16 - n));
-        mm += __builtin_popcount(m);
-    }
-    return mm;
-}
-
 struct JobSink {
     DpJob *jobs;
     uint32_t *count;
@@ -621,8 +601,7 @@ static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef 
                     bool dp = x.rLen != x.gLen;
                     if (!dp) {
                         int mm = 0;
-                        if (rd[s].packed) mm = plain_mismatches(cx.ix, rd[s], x.rPos, x.gPos, x.rLen); // the same pairs of bases in either direction
-                        else for (int k = 0; k < x.rLen; k++)
+                        for (int k = 0; k < x.rLen; k++)
                             if (frag_read_code(x, rd[s], rev, k) != frag_ref_code(cx.ix, x, rev, k)) mm++;
                         dp = mm > 1 && mm >= (int)(x.rLen * 0.2);
                     }
@@ -684,11 +663,6 @@ struct ColStats { int switches, n, mis, match; };
 static inline MCX_HD ColStats frag_columns(const IndexView &ix, const Frag &f, const uint8_t *ops, const ReadRef &rd)
 {
     ColStats cs; cs.switches = cs.n = cs.mis = cs.match = 0;
-    if (f.kind == kPlain && rd.packed) { // every column pairs two bases: one run, counted sixteen columns at a time
-        cs.n = f.ops_len; cs.switches = cs.n > 0 ? 1 : 0;
-        cs.mis = plain_mismatches(ix, rd, f.rPos, f.gPos, f.ops_len); cs.match = cs.n - cs.mis;
-        return cs;
-    }
     bool rev = f.gPos >= ix.G;
     int kind = -1, ri = 0, gi = 0;
     for (int x = 0; x < f.ops_len; x++) {

@@ -318,7 +318,6 @@ static __device__ __forceinline__ void make_reads(const Ctx &cx, const ReadBatch
         rd[s].ascii = rb.bases + rb.off[r];
         rd[s].rlen = (int32_t)(rb.off[r + 1] - rb.off[r]);
         rd[s].flipped = (cx.pm.paired && s == 1) ? 1 : 0;
-        rd[s].packed = rb.packed ? rb.packed + (uint64_t)r * (uint32_t)rb.wpad : nullptr;
     }
 }
 
@@ -1046,7 +1045,6 @@ extern "C" int mcx_map_batch_dev(mcx_ctx *c, const uint8_t *d_bases, const uint3
     hipStream_t s = c->stream;
     if ((uintptr_t)d_bases & 15) return fail(MCX_ERR_ARG, "mcx_map_batch_dev: d_bases must be 16-byte aligned");
     ReadBatch rb; rb.bases = d_bases; rb.off = d_off; rb.n_reads = n_reads;
-    rb.packed = c->d_packed; rb.wpad = c->wpad;
     uint32_t total_bases = 0;
     HIP_TRY(hipMemcpy(&total_bases, d_off + n_reads, sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (total_bases > c->max_bases) return fail(MCX_ERR_ARG, "batch holds more bases than max_batch_reads * max_read_len");

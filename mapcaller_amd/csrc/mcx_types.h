@@ -247,8 +247,6 @@ struct ReadBatch {
     const uint8_t *bases;   // ASCII
     const uint32_t *off;    // n_reads + 1
     uint32_t n_reads;
-    const uint32_t *packed = nullptr; // 2-bit form of the batch (k_pack_reads), wpad words per read; null: not made
-    int32_t wpad = 0;
 };
 
 } // namespace mcx
