@@ -419,7 +419,9 @@ static inline MCX_HD void stage_cluster_pair(const Ctx &cx, int64_t pair, const 
     PairHdr *const g_hdr = st.hdr;
     PairHdr h = *g_hdr; // in registers through the stage, stored back once
     int nr = cx.pm.paired ? 2 : 1;
-    for (int s = 0; s < nr; s++) {
+    MCX_UNROLL // (written to unroll: a header indexed by a run-time mate number lives in scratch memory)
+    for (int s = 0; s < 2; s++) {
+        if (s >= nr) break;
         if (h.n_hits[s] > cx.caps.hit_cap) { h.flags |= kOvHits; h.n_hits[s] = 0; }
         h.n_hits[s] = prep_seeds(st.hits[s], h.n_hits[s]);
         int nc = cluster_seeds(cx.ix, cx.pm, rd[s].rlen, st.hits[s], h.n_hits[s], st.cands[s], cx.caps.cand_cap);

@@ -13,8 +13,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define MCX_HD __host__ __device__
+#define MCX_UNROLL _Pragma("unroll")
 #else
 #define MCX_HD
+#define MCX_UNROLL
 #endif
 
 namespace mcx {
