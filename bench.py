@@ -44,7 +44,9 @@ def pmc_profile(args):
         with open(PMC_SUMMARY) as fh:
             s = json.load(fh)
         t, p = s["hbm_traffic"]["k_seed"], s["pmc"]["k_seed"]
-        return {"traffic": int(t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"]),
+        per_kernel = {k: int(v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]) for k, v in s["hbm_traffic"].items()
+                      if k in ("k_pack_reads", "k_seed", "k_cluster", "k_build", "k_finish")}
+        return {"per_kernel": per_kernel, "traffic": int(t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"]),
                 "l2_requests": int(p["TCC_HIT_sum"]["full_batch_mean"] + p["TCC_MISS_sum"]["full_batch_mean"]),
                 "wait_frac": round(p["SQ_WAIT_ANY"]["full_batch_mean"] / p["SQ_WAVE_CYCLES"]["full_batch_mean"], 3)}
     except (OSError, KeyError, ValueError, ZeroDivisionError):
@@ -295,6 +297,12 @@ def main():
                          "sa_hits": round(d["sa_hits"] / max(d["reads"], 1), 3), "dp_jobs": round(d["dp_jobs"] / max(d["reads"], 1), 4),
                          "mapped_frac": round(d["mapped"] / max(d["reads"], 1), 4)},
             "stage_ms_per_step": {k[3:]: round(d[k] / args.steps, 3) for k in d if k.startswith("ms_")},
+            # measured HBM bytes of one launch (committed PMC passes) over the live stage time: what each big kernel really draws from HBM
+            "hbm_utilisation": None if not prof else {
+                kern: {"gbs": round(prof["per_kernel"][kern] / (d[ms] / args.steps * 1e-3) / 1e9, 1),
+                       "frac_of_peak": round(prof["per_kernel"][kern] / (d[ms] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}
+                for kern, ms in (("k_pack_reads", "ms_encode"), ("k_seed", "ms_seed"), ("k_cluster", "ms_cluster"), ("k_build", "ms_build"), ("k_finish", "ms_finish"))
+                if kern in prof.get("per_kernel", {}) and d[ms] > 0},
             "tier1_pairs": d["tier1_pairs"], "replayed_pairs": d["replayed_pairs"],
         }
         if vcf is not None:
