@@ -181,6 +181,12 @@ def main():
         dist = dist_
         dist.init_process_group("nccl", device_id=dev)
     from mapcaller_amd import api
+    if not os.path.exists(api.LIB_PATH):  # a checkout without the built artefacts: build them (never a CPU fallback)
+        if rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        if dist:
+            dist.barrier()
 
     # ---- set-up (not timed): genome, index, reads ------------------------------------------------
     codes, lens = make_genome(args, dev, seed=1234)
