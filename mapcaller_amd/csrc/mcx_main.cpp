@@ -41,7 +41,8 @@ static void usage(const char *prog)
             "         -id STR       sample id [unknown]\n"
             "         -p            paired-end reads are interlaced in the same file\n"
             "         -t INT        host threads that parse reads and format SAM lines [half the cores, at most 32]\n"
-            "         -gpu INT      device ordinal [0]\n", prog, prog);
+            "         -gpu INT      device ordinal [0]\n"
+            "         -sampled_sa   keep only the sampled suffix array in HBM (saves 8 bytes per text position, slower seeding)\n", prog, prog);
 }
 
 int main(int argc, char **argv)
@@ -57,7 +58,7 @@ int main(int argc, char **argv)
     std::vector<std::string> f1, f2;
     mcx_opts o;
     mcx_opts_default(&o);
-    int gpu = 0;
+    int gpu = 0, full_sa = 1;
     mcx_file_opts fo;
     mcx_file_opts_default(&fo);
     bool want_vcf = true; // bVCFoutput, main.cpp:171
@@ -91,6 +92,7 @@ int main(int argc, char **argv)
         else if (p == "-t" && i + 1 < argc) { if ((fo.host_threads = atoi(argv[++i])) <= 0) { fprintf(stderr, "Warning! The thread number should be positive!\n"); fo.host_threads = 4; } }
         else if (p == "-pair" || p == "-p") fo.interleaved_pairs = 1;
         else if (p == "-gpu" && i + 1 < argc) gpu = atoi(argv[++i]);
+        else if (p == "-sampled_sa") full_sa = 0;
         else if (p == "-vcf" && i + 1 < argc) vcf = argv[++i];
         else if (p == "-no_vcf") want_vcf = false;
         else if (p == "-gvcf") vo.gvcf = 1;
@@ -119,7 +121,7 @@ int main(int argc, char **argv)
     }
     if (prefix.empty()) { fprintf(stderr, "Warning! Please specify a valid reference index!\n"); usage(argv[0]); return 0; }
     mcx_index *ix = nullptr;
-    int rc = mcx_index_load(prefix.c_str(), gpu, 0, &ix);
+    int rc = mcx_index_load(prefix.c_str(), gpu, full_sa, &ix);
     if (rc) { fprintf(stderr, "Error! %s\n", mcx_last_error()); return 1; }
     o.max_batch_reads = 1 << 19; // per batch of the parse | map | format pipeline
     mcx_ctx *cx = nullptr;
