@@ -194,10 +194,16 @@ int mcx_map_files(mcx_ctx *, const char *fq1, const char *fq2, const char *sam_p
 /* The same with the remaining switches of the reference's file loop (src/ReadMapping.cpp:689-760):
  * interleaved_pairs = -p (one file holds both mates alternately), host_threads = -t (parser /
  * formatter threads on the host; 0 = pick), append_sam: a further library of the same run (no
- * header, append), avg_state: carries the insert-size estimate across libraries (NULL = fresh). */
+ * header, append), avg_state: carries the insert-size estimate across libraries (NULL = fresh).
+ * Sharding over several GPUs (one process each): the input stream is cut into batches of the
+ * context's max_batch_reads, batch k belongs to shard k % shard_count; a shard maps and writes only
+ * its batches.  no_sam_header / sam_index_path ("batch bytes" per line) let the parts be merged in
+ * input order (mapcaller_amd/run.py does). */
 typedef struct mcx_file_opts {
-    int32_t interleaved_pairs, host_threads, append_sam, pad;
+    int32_t interleaved_pairs, host_threads, append_sam, no_sam_header;
     int64_t *avg_state; /* int64_t[4], see mcx_avg_init */
+    int32_t shard_rank, shard_count; /* 0, 0: the whole input */
+    const char *sam_index_path;      /* NULL: none */
 } mcx_file_opts;
 void mcx_file_opts_default(mcx_file_opts *);
 int mcx_map_files_ex(mcx_ctx *, const char *fq1, const char *fq2, const mcx_file_opts *, const char *sam_path, mcx_stats *stats);

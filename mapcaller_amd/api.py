@@ -66,8 +66,8 @@ class Stats(C.Structure):
 
 class FileOpts(C.Structure):
     """mcx_file_opts: -p, -t, library append, insert-size state across libraries."""
-    _fields_ = [("interleaved_pairs", C.c_int32), ("host_threads", C.c_int32), ("append_sam", C.c_int32), ("pad", C.c_int32),
-                ("avg_state", C.POINTER(C.c_int64))]
+    _fields_ = [("interleaved_pairs", C.c_int32), ("host_threads", C.c_int32), ("append_sam", C.c_int32), ("no_sam_header", C.c_int32),
+                ("avg_state", C.POINTER(C.c_int64)), ("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("sam_index_path", C.c_char_p)]
 
 
 class VcfOpts(C.Structure):
@@ -274,12 +274,20 @@ class Mapper:
         self.stats = Stats()
 
     # ---- whole path ---------------------------------------------------------------------
-    def map_files(self, fq1: str, fq2: Optional[str], sam: Optional[str], interleaved: bool = False, threads: int = 0) -> dict:
-        """Files in, SAM out (mcx_map_files_ex).  ``interleaved`` = -p, ``threads`` = -t."""
+    def map_files(self, fq1: str, fq2: Optional[str], sam: Optional[str], interleaved: bool = False, threads: int = 0,
+                  shard: Optional[Tuple[int, int]] = None, sam_header: bool = True, sam_index: Optional[str] = None) -> dict:
+        """Files in, SAM out (mcx_map_files_ex).  ``interleaved`` = -p, ``threads`` = -t; ``shard`` =
+        (rank, count): map only every count-th batch of the input stream, ``sam_index``: file that
+        receives "batch bytes" per batch written (to merge the parts of a sharded run)."""
         st = Stats()
         fo = FileOpts()
         lib().mcx_file_opts_default(C.byref(fo))
         fo.interleaved_pairs, fo.host_threads = int(interleaved), threads
+        fo.no_sam_header = 0 if sam_header else 1
+        if shard:
+            fo.shard_rank, fo.shard_count = int(shard[0]), int(shard[1])
+        if sam_index:
+            fo.sam_index_path = sam_index.encode()
         _check(lib().mcx_map_files_ex(self._h, fq1.encode(), (fq2 or "").encode() or None, C.byref(fo), (sam or "").encode() or None,
                                       C.byref(st)), "mcx_map_files_ex")
         return st.as_dict()

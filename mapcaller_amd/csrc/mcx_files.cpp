@@ -162,6 +162,7 @@ private:
 struct Batch {
     Entries in[2];
     uint32_t n = 0;          // reads
+    uint64_t number = 0;     // position of the batch in the input stream
     bool two_files = false, fastq = true, last = false;
     // interleaved reads as mcx_map_batch wants them, and its results: pinned host memory, allocated once per batch object
     uint8_t *bases = nullptr; uint32_t *off = nullptr; AlnRec *recs = nullptr; uint32_t *cig = nullptr;
@@ -306,7 +307,12 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
         sam = strcmp(sam_path, "-") == 0 ? stdout : fopen(sam_path, opt.append_sam ? "a" : "w");
         if (!sam) return mcx_set_error(MCX_ERR_IO, std::string("cannot write ") + sam_path);
         setvbuf(sam, nullptr, _IOFBF, 1 << 22);
-        if (!opt.append_sam) { std::string hdr; sam_header(hix, hdr); fputs(hdr.c_str(), sam); }
+        if (!opt.append_sam && !opt.no_sam_header) { std::string hdr; sam_header(hix, hdr); fputs(hdr.c_str(), sam); }
+    }
+    FILE *sam_index = nullptr; // "batch number, bytes" per batch written: lets the parts of a sharded run be merged in input order
+    if (sam && opt.sam_index_path && opt.sam_index_path[0]) {
+        sam_index = fopen(opt.sam_index_path, "w");
+        if (!sam_index) return mcx_set_error(MCX_ERR_IO, std::string("cannot write ") + opt.sam_index_path);
     }
     const uint64_t batch_reads = std::max<uint64_t>(kReadChunkSize, mcx_ctx_max_reads(c) / kReadChunkSize * kReadChunkSize);
     int64_t local_avg[4];
@@ -323,12 +329,14 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
 
     // stage 1: parse.  One thread per file fills its half of the batch.
     std::atomic<bool> abort(false);
+    const uint64_t shard_count = opt.shard_count > 1 ? (uint64_t)opt.shard_count : 1, shard_rank = shard_count > 1 ? (uint64_t)opt.shard_rank : 0;
     std::thread reader([&] {
         bool done = false;
+        uint64_t number = 0;
         while (!done) {
             BatchPtr b = spare.pop();
             const auto t0 = now();
-            b->two_files = two; b->fastq = ps[0].fastq(); b->n = 0; b->last = false; b->error.clear();
+            b->two_files = two; b->fastq = ps[0].fastq(); b->n = 0; b->last = false; b->error.clear(); b->number = number;
             const uint32_t per_file = (uint32_t)(two ? batch_reads / 2 : batch_reads);
             b->in[0].clear(); b->in[1].clear();
             if (two) {
@@ -346,8 +354,14 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
             }
             for (int f = 0; f < 2; f++) if (!b->in[f].error.empty()) b->error = b->in[f].error;
             if (!b->error.empty() || abort.load()) done = true;
-            b->last = done;
+            // batches are dealt to the shards in turn; another shard's batch is parsed (the stream has to be
+            // walked) and dropped — unless it carries the end of the input or an error, which every shard must see
+            const bool mine = number % shard_count == shard_rank;
+            number++;
             t_parse += secs(t0, now());
+            if (!mine && !done) { spare.push(std::move(b)); continue; }
+            if (!mine && b->error.empty()) b->n = 0;
+            b->last = done;
             parsed.push(std::move(b));
         }
     });
@@ -375,8 +389,10 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
                     for (uint32_t r = lo; r < hi; r++) sam_record(hix, *b, r, t);
                 });
                 const auto t1 = now();
+                size_t bytes = 0;
                 for (const Text &t : slices)
-                    if (t.w && t.size() && fwrite(t.b.data(), 1, t.size(), sam) != t.size()) write_rc = MCX_ERR_IO;
+                    if (t.w && t.size()) { bytes += t.size(); if (fwrite(t.b.data(), 1, t.size(), sam) != t.size()) write_rc = MCX_ERR_IO; }
+                if (sam_index) fprintf(sam_index, "%llu %zu\n", (unsigned long long)b->number, bytes);
                 t_format += secs(t0, t1); t_write += secs(t1, now());
             }
             const bool stop = b->last;
@@ -453,6 +469,7 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
     if (getenv("MCX_TIMING"))
         fprintf(stderr, "[mcx_map_files] busy seconds: parse %.2f | pack %.2f map %.2f | format %.2f write %.2f  (%d host threads)\n", t_parse, t_pack, t_map, t_format,
                 t_write, threads);
+    if (sam_index) fclose(sam_index);
     if (sam && sam != stdout) { if (fclose(sam) != 0 && write_rc == 0) write_rc = MCX_ERR_IO; }
     else if (sam) fflush(sam);
     if (rc == 0 && write_rc) rc = mcx_set_error(MCX_ERR_IO, std::string("cannot write ") + (sam_path ? sam_path : ""));

@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""MapCaller's command line on one or several MI355X of a node.
+
+    python -m mapcaller_amd.run -i idx -f r1.fq [-f2 r2.fq] [-alg nw|ksw2] [-sam out.sam] [-vcf out.vcf | -no_vcf] ...
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 -m mapcaller_amd.run -i idx -f r1.fq -f2 r2.fq -sam out.sam -vcf out.vcf
+
+One process per GPU.  The input stream is cut into batches that are dealt to the ranks in turn
+(reads shard embarrassingly): every rank walks the files, maps its own batches against
+its own replica of the index and writes its part of the SAM; rank 0 puts the parts back into input
+order.  With -vcf on, the one exchange of the run follows (mapcaller_amd/dist.py): the per-position
+counter planes are summed with an RCCL all-reduce, the sparse tallies and the run totals gathered, and
+rank 0 calls the variants (mcx_call_variants).  Each shard follows its own insert-size trajectory,
+exactly as a run of the reference on that shard's reads would.
+
+Host-side glue only: parsing, mapping, SAM text and variant calling all happen behind the C ABI.
+"""
+import argparse
+import os
+import shutil
+import sys
+
+import torch
+
+from . import api, dist as mdist
+
+
+def parse(argv):
+    ap = argparse.ArgumentParser(prog="mapcaller_amd.run", add_help=True, prefix_chars="-", allow_abbrev=False)
+    ap.add_argument("-i", dest="index", required=True, help="BWT index prefix")
+    ap.add_argument("-f", dest="f1", nargs="+", required=True, help="files with #1 mates reads")
+    ap.add_argument("-f2", dest="f2", nargs="*", default=[], help="files with #2 mates reads")
+    ap.add_argument("-p", "-pair", dest="interleaved", action="store_true", help="paired-end reads are interlaced in the same file")
+    ap.add_argument("-alg", default="nw", choices=["nw", "ksw2"])
+    ap.add_argument("-sam", default=None)
+    ap.add_argument("-vcf", default="output.vcf")
+    ap.add_argument("-no_vcf", action="store_true")
+    ap.add_argument("-t", dest="threads", type=int, default=0, help="host threads per process for parsing / SAM text")
+    ap.add_argument("-batch", type=int, default=1 << 20, help="reads per batch (the unit dealt to the ranks)")
+    ap.add_argument("-maxlen", type=int, default=256, help="longest read the contexts are sized for")
+    for name, kw in (("-gvcf", {}), ("-monomorphic", {}), ("-filter", {}), ("-somatic", {})):
+        ap.add_argument(name, action="store_true", **kw)
+    ap.add_argument("-ploidy", type=int, default=2)
+    ap.add_argument("-size", type=int, default=500)
+    ap.add_argument("-ad", type=int, default=5)
+    ap.add_argument("-dup", type=int, default=5)
+    ap.add_argument("-maxclip", type=int, default=5)
+    ap.add_argument("-min_cnv", type=int, default=50)
+    ap.add_argument("-min_gap", type=int, default=50)
+    ap.add_argument("-id", dest="sample", default="unknown")
+    ap.add_argument("-backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    a = ap.parse_args(argv)
+    if a.f2 and len(a.f2) != len(a.f1):
+        ap.error("Paired-end reads input numbers do not match!")
+    return a
+
+
+def merge_sam(path, world):
+    """The ranks' parts back into input order: batch k sits in part k % world."""
+    index = []
+    for r in range(world):
+        with open(f"{path}.part{r}.idx") as fh:
+            index.append([(int(a), int(b)) for a, b in (l.split() for l in fh if l.strip())])
+    parts = [open(f"{path}.part{r}", "rb") for r in range(world)]
+    cursor = [0] * world
+    with open(path, "wb") as out:
+        # part 0 starts with the header
+        first = index[0][0][0] if index[0] else None
+        header_len = os.path.getsize(f"{path}.part0") - sum(b for _, b in index[0])
+        out.write(parts[0].read(header_len))
+        todo = sorted((k, r) for r in range(world) for k, _ in index[r])
+        sizes = [dict(ix) for ix in index]
+        for k, r in todo:
+            shutil.copyfileobj(_Limited(parts[r], sizes[r][k]), out, 1 << 24)
+    for fh in parts:
+        fh.close()
+    for r in range(world):
+        os.remove(f"{path}.part{r}")
+        os.remove(f"{path}.part{r}.idx")
+
+
+class _Limited:
+    def __init__(self, fh, n):
+        self.fh, self.n = fh, n
+
+    def read(self, k=-1):
+        if self.n <= 0:
+            return b""
+        k = self.n if k < 0 else min(k, self.n)
+        b = self.fh.read(k)
+        self.n -= len(b)
+        return b
+
+
+def main(argv=None):
+    a = parse(sys.argv[1:] if argv is None else argv)
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        sys.exit("mapcaller_amd.run needs a GPU: the hot path has no CPU fallback")
+    device = local % n_dev
+    torch.cuda.set_device(device)
+    dev = torch.device("cuda", device)
+    td = None
+    if world > 1:
+        import torch.distributed as td_
+        td = td_
+        backend = a.backend or "nccl"
+        td.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+    index = api.Index(a.index, device=device, full_sa=True)
+    mapper = api.Mapper(index, alg=a.alg, max_read_len=a.maxlen, max_batch_reads=max(200, a.batch // 200 * 200))
+    want_vcf = not a.no_vcf
+    planes = None
+    if want_vcf:
+        planes = torch.zeros((10, index.genome_size), dtype=torch.int32, device=dev)
+        mapper.profile_attach(planes.data_ptr(), max_dup=a.dup, max_clip=a.maxclip)
+    totals = {"reads": 0, "mapped": 0, "pairs": 0, "pair_dist_sum": 0, "pair_len_sum": 0}
+    for k, f1 in enumerate(a.f1):
+        f2 = a.f2[k] if a.f2 else None
+        sam = None
+        if a.sam:
+            sam = a.sam if world == 1 else f"{a.sam}.part{rank}"
+            if k > 0:
+                raise SystemExit("several libraries in one sharded run are not supported yet: run them one by one")
+        st = mapper.map_files(f1, f2, sam, interleaved=a.interleaved, threads=a.threads,
+                              shard=(rank, world) if world > 1 else None, sam_header=(rank == 0),
+                              sam_index=(sam + ".idx") if (sam and world > 1) else None)
+        for key in totals:
+            totals[key] += st[key]
+    tot = mdist.sum_over_ranks([totals[k] for k in ("reads", "mapped", "pairs", "pair_dist_sum", "pair_len_sum")], dev)
+    if td:
+        td.barrier()
+    if rank == 0 and a.sam and world > 1:
+        merge_sam(a.sam, world)
+    if want_vcf:
+        planes, sparse = mdist.reduce_profile(planes, mapper.profile_sparse_raw())
+        if rank == 0:
+            mapper.profile_finalize(planes.data_ptr())
+            vs = index.call_variants(planes.data_ptr(), sparse, tot[2], tot[3], tot[4], a.vcf, ploidy=a.ploidy, min_allele_depth=a.ad,
+                                     min_cnv=a.min_cnv, min_gap=a.min_gap, fragment_size=a.size, filter=int(a.filter), gvcf=int(a.gvcf),
+                                     monomorphic=int(a.monomorphic), somatic=int(a.somatic), sample_id=a.sample, ref_name=a.index,
+                                     cmdline=" ".join(["mapcaller_amd.run"] + (sys.argv[1:] if argv is None else list(argv))))
+            print(f"\t{vs['n_snv']}(snp); {vs['n_ins']}(ins); {vs['n_del']}(del); {vs['n_tnl'] >> 1}(trans); {vs['n_inv'] >> 1}(inversion)", file=sys.stderr)
+    if rank == 0:
+        kind = "paired-end" if (a.f2 or a.interleaved) else "single-end"
+        print(f"All the {tot[0]} {kind} reads have been processed on {world} GPU(s).\n{tot[1]:12d} reads are mapped properly.\n"
+              f"{2 * tot[2]:12d} reads are mapped in pairs.", file=sys.stderr)
+    mapper.close()
+    index.close()
+    if td:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

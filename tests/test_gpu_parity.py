@@ -454,3 +454,56 @@ def test_file_path_errors_are_loud(api, golden, tmp_path):
     with pytest.raises(api.McxError, match="max_read_len"):
         mp.map_files(g["r1"], g["r2"], None)
     mp.close(); ix.close()
+
+
+def test_sharded_run_two_ranks(golden, oracle_lib, tmp_path):
+    """mapcaller_amd.run under torchrun with two ranks (both on GPU 0, gloo so that they can share it):
+    batches of 200 pairs dealt to the ranks in turn, SAM parts merged back into input order, planes
+    all-reduced, sparse tallies gathered, variants called on rank 0.  The SAM equals what the oracle
+    gives for each shard's reads (a shard follows its own insert-size trajectory); on this small set
+    that is also the single-stream SAM, so the VCF equals the reference's."""
+    g = golden["toy"]
+    sam, vcf = str(tmp_path / "o.sam"), str(tmp_path / "o.vcf")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           "-m", "mapcaller_amd.run", "-backend", "gloo", "-i", g["prefix"], "-f", g["r1"], "-f2", g["r2"], "-alg", "ksw2", "-sam", sam, "-vcf", vcf,
+           "-batch", "400"]
+    subprocess.run(cmd, check=True, env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+    # expectation: the oracle on each shard's reads, batches put back in turn
+    l1 = open(g["r1"], "rb").read().split(b"\n")
+    l2 = open(g["r2"], "rb").read().split(b"\n")
+    n_pairs = len(l1) // 4
+    shard_lines = []
+    for r in range(2):
+        picks = [p for p in range(n_pairs) if (p // 200) % 2 == r]
+        for tag, ll in (("1", l1), ("2", l2)):
+            (tmp_path / f"s{r}_{tag}.fq").write_bytes(b"\n".join(b"\n".join(ll[4 * p:4 * p + 4]) for p in picks) + b"\n")
+        out = str(tmp_path / f"s{r}.sam")
+        ix = oracle_lib.mcxo_index_load(g["prefix"].encode())
+        assert oracle_lib.mcxo_map_files(ix, str(tmp_path / f"s{r}_1.fq").encode(), str(tmp_path / f"s{r}_2.fq").encode(), 1, out.encode(), 1, None) == 2 * len(picks)
+        oracle_lib.mcxo_index_free(ix)
+        shard_lines.append([l for l in open(out, encoding="latin-1").read().split("\n") if l and not l.startswith("@")])
+    want, at = [], [0, 0]
+    for p in range(n_pairs):
+        r = (p // 200) % 2
+        want += shard_lines[r][at[r]:at[r] + 2]
+        at[r] += 2
+    got = [l for l in open(sam, encoding="latin-1").read().split("\n") if l and not l.startswith("@")]
+    assert got == want
+    head = [l for l in open(sam, encoding="latin-1").read().split("\n") if l.startswith("@")]
+    assert head == [l for l in open(g["sam"]["ksw2"], encoding="latin-1").read().split("\n") if l.startswith("@")]
+    if got == [l for l in open(g["sam"]["ksw2"], encoding="latin-1").read().split("\n") if l and not l.startswith("@")]:
+        assert vcf_body(vcf) == vcf_body(g["vcf"]["default"])
+    else:
+        assert sum(1 for l in vcf_body(vcf) if l and not l.startswith("#")) > 100
+
+
+def test_run_module_single_gpu(golden, tmp_path):
+    """python -m mapcaller_amd.run without torchrun: one GPU, the same outputs as the reference."""
+    g = golden["var"]
+    sam, vcf = str(tmp_path / "o.sam"), str(tmp_path / "o.vcf")
+    cmd = [sys.executable, "-m", "mapcaller_amd.run", "-i", g["prefix"], "-f", g["r1"], "-f2", g["r2"], "-alg", "ksw2", "-sam", sam, "-vcf", vcf, "-gvcf"]
+    subprocess.run(cmd, check=True, env=dict(os.environ, PYTHONPATH=ROOT), cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+    nd, ex = sam_diff(g["sam"]["ksw2"], sam)
+    assert nd == 0, ex
+    assert vcf_body(vcf) == vcf_body(g["vcf"]["gvcf"])
