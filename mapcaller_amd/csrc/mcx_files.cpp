@@ -46,6 +46,15 @@ struct Entries { // reads of one file for one batch, flat
     void clear() { names.clear(); name_off.assign(1, 0); seq.clear(); seq_off.assign(1, 0); qual.clear(); last = false; error.clear(); }
 };
 
+template <typename T> class Queue { // bounded hand-over between two stages
+public:
+    explicit Queue(size_t cap) : cap_(cap) {}
+    void push(T v) { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return q_.size() < cap_; }); q_.push_back(std::move(v)); cv_.notify_all(); }
+    T pop() { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return !q_.empty(); }); T v = std::move(q_.front()); q_.pop_front(); cv_.notify_all(); return v; }
+private:
+    std::mutex m_; std::condition_variable cv_; std::deque<T> q_; size_t cap_;
+};
+
 class Parser {
 public:
     bool open(const std::string &path, std::string &err)
@@ -55,11 +64,31 @@ public:
         if (!gz_) { err = "cannot open " + path; return false; }
         gzbuffer(gz_, 1 << 20);
         buf_.resize(1 << 24);
+        // reading (and inflating) runs ahead of the line splitter on a thread of its own
+        for (int k = 0; k < 4; k++) { std::unique_ptr<Block> b(new Block); b->d.resize(kBlockBytes); free_.push(std::move(b)); }
+        feeder_ = std::thread([this] {
+            for (;;) {
+                std::unique_ptr<Block> b = free_.pop();
+                int got = stop_.load() ? 0 : gzread(gz_, b->d.data(), (unsigned)kBlockBytes);
+                b->n = got > 0 ? (size_t)got : 0;
+                const bool end = b->n == 0;
+                ready_.push(std::move(b));
+                if (end) break;
+            }
+        });
         fill();
         fastq_ = end_ > 0 && buf_[0] == '@'; // CheckReadFormat, GetData.cpp:22-31
         return true;
     }
-    ~Parser() { if (gz_) gzclose(gz_); }
+    ~Parser()
+    {
+        if (feeder_.joinable()) {
+            stop_.store(true);
+            while (!eof_) { std::unique_ptr<Block> b = ready_.pop(); if (b->n == 0) eof_ = true; else free_.push(std::move(b)); }
+            feeder_.join();
+        }
+        if (gz_) gzclose(gz_);
+    }
     bool fastq() const { return fastq_; }
 
     // appends up to `want` reads; false once the input is exhausted (Entries::last set)
@@ -72,21 +101,26 @@ public:
     }
 
 private:
+    enum : size_t { kBlockBytes = 8u << 20 };
+    struct Block { std::vector<char> d; size_t n = 0; };
     gzFile gz_ = nullptr;
     bool gz_mode_ = false, fastq_ = true, eof_ = false;
     std::vector<char> buf_;
     size_t pos_ = 0, end_ = 0;
+    Queue<std::unique_ptr<Block>> ready_{4}, free_{4};
+    std::thread feeder_;
+    std::atomic<bool> stop_{false};
 
-    void fill()
+    void fill() // one more block of input behind what is left of the buffer
     {
         if (eof_) return;
         if (pos_ > 0) { memmove(buf_.data(), buf_.data() + pos_, end_ - pos_); end_ -= pos_; pos_ = 0; }
-        if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);
-        while (end_ < buf_.size()) {
-            const int got = gzread(gz_, buf_.data() + end_, (unsigned)std::min<size_t>(buf_.size() - end_, 1u << 30));
-            if (got <= 0) { eof_ = true; break; }
-            end_ += (size_t)got;
-        }
+        std::unique_ptr<Block> b = ready_.pop();
+        if (b->n == 0) { eof_ = true; return; }
+        if (end_ + b->n > buf_.size()) buf_.resize(std::max(buf_.size() * 2, end_ + b->n));
+        memcpy(buf_.data() + end_, b->d.data(), b->n);
+        end_ += b->n;
+        free_.push(std::move(b));
     }
 
     // next line including its '\n' (getline); the .gz reader's gzgets(buffer, 1024) cuts at 1023 bytes
@@ -185,15 +219,6 @@ struct Batch {
     std::string error;
     // read r of the batch -> (file, index in that file's entries)
     void locate(uint32_t r, int &f, uint32_t &i) const { if (two_files) { f = (int)(r & 1); i = r >> 1; } else { f = 0; i = r; } }
-};
-
-template <typename T> class Queue { // bounded hand-over between two stages
-public:
-    explicit Queue(size_t cap) : cap_(cap) {}
-    void push(T v) { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return q_.size() < cap_; }); q_.push_back(std::move(v)); cv_.notify_all(); }
-    T pop() { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return !q_.empty(); }); T v = std::move(q_.front()); q_.pop_front(); cv_.notify_all(); return v; }
-private:
-    std::mutex m_; std::condition_variable cv_; std::deque<T> q_; size_t cap_;
 };
 
 template <typename F> void parallel_for(uint32_t n, int threads, F f) // f(begin, end, slice)
