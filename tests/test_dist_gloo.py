@@ -73,3 +73,21 @@ def test_shards_cover_everything_for_any_world():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert all(lo % 100 == 0 for lo, _ in spans)
+
+
+def test_merge_sam_puts_batches_back_in_input_order(tmp_path):
+    """mapcaller_amd.run.merge_sam: batch k lives in part k % world; the header comes from part 0."""
+    from mapcaller_amd.run import merge_sam
+    path = str(tmp_path / "o.sam")
+    world, n_batches = 3, 8
+    batches = [("".join(f"read{k}_{i}\tx\n" for i in range(k + 1))).encode() for k in range(n_batches)]
+    for r in range(world):
+        with open(f"{path}.part{r}", "wb") as fh, open(f"{path}.part{r}.idx", "w") as ix:
+            if r == 0:
+                fh.write(b"@PG\tID:MapCaller\n@SQ\tSN:c\tLN:9\n")
+            for k in range(r, n_batches, world):
+                fh.write(batches[k])
+                ix.write(f"{k} {len(batches[k])}\n")
+    merge_sam(path, world)
+    assert open(path, "rb").read() == b"@PG\tID:MapCaller\n@SQ\tSN:c\tLN:9\n" + b"".join(batches)
+    assert not any(os.path.exists(f"{path}.part{r}") for r in range(world))
