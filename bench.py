@@ -38,7 +38,7 @@ def pmc_profile(args):
     """What the committed rocprofv3 --pmc passes of this same command measured for one k_seed launch
     (counters cannot be read from inside the run): HBM bytes (FETCH_SIZE + WRITE_SIZE) and L2
     requests (TCC_HIT + TCC_MISS).  Only returned when the workload is the one those passes profiled."""
-    if (args.genome_mbp, args.batch_pairs, args.rlen, args.alg) != (3100.0, 2_000_000, 150, "ksw2"):
+    if (args.genome_mbp, args.batch_pairs, args.rlen, args.alg) != (3100.0, 4_000_000, 150, "ksw2"):
         return None
     try:
         with open(PMC_SUMMARY) as fh:
@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genome-mbp", type=float, default=3100.0, help="synthetic genome size (Mbp)")
     ap.add_argument("--contigs", type=int, default=24)
-    ap.add_argument("--batch-pairs", type=int, default=2_000_000, help="read pairs per step and per GPU")
+    ap.add_argument("--batch-pairs", type=int, default=4_000_000, help="read pairs per step and per GPU")
     ap.add_argument("--rlen", type=int, default=150)
     ap.add_argument("--sub", type=float, default=0.005, help="per-base substitution rate of the simulated reads")
     ap.add_argument("--ins", type=float, default=0.001, help="per-base insertion rate")
