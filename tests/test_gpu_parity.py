@@ -463,9 +463,13 @@ def test_sharded_run_two_ranks(golden, oracle_lib, tmp_path):
     gives for each shard's reads (a shard follows its own insert-size trajectory); on this small set
     that is also the single-stream SAM, so the VCF equals the reference's."""
     g = golden["toy"]
+    import socket
     sam, vcf = str(tmp_path / "o.sam"), str(tmp_path / "o.vcf")
     env = dict(os.environ, PYTHONPATH=ROOT)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            "-m", "mapcaller_amd.run", "-backend", "gloo", "-i", g["prefix"], "-f", g["r1"], "-f2", g["r2"], "-alg", "ksw2", "-sam", sam, "-vcf", vcf,
            "-batch", "400"]
     subprocess.run(cmd, check=True, env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
