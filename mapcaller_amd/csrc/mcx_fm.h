@@ -348,8 +348,6 @@ static inline MCX_HD uint32_t ref_codes16(const IndexView &ix, int64_t j)
 //     be extended by base c" is "is the next text base c": the suffix is resolved to its text
 //     position (one suffix-array fetch) and the rest of the search is a comparison of 16-base
 //     windows of the packed read against the 2-bit genome.  Same length, same position.
-// The loop iterates over FM steps and searches, not over bases, so that the lanes of a wave —
-// which sit at unrelated points of their reads — execute few iterations in total.
 // (prepacked: pk already holds the read's words — the device packs whole batches in one pass)
 static inline MCX_HD int seed_read(const IndexView &ix, const ReadRef &rd, PackedRead pk, Hit *hits, int cap,
                                    int64_t &ext_steps, int64_t &blocks, bool prepacked = false)
@@ -358,25 +356,51 @@ static inline MCX_HD int seed_read(const IndexView &ix, const ReadRef &rd, Packe
     if (!prepacked) pack_read(rd, pk);
     int n_hits = 0;
     const int stop = rlen - kMinSeedLength;
-    int p = 0, start = 0;
-    bool active = false;
-    int64_t tpos = 0;
-    uint64_t x0 = 0, x1 = 0, x2 = 0;
+    int p = 0;
+    // One search per iteration, its three phases as loops of their own: the lanes of a wave sit at
+    // unrelated points of their reads, but with this shape they run the same phase at the same time
+    // (jump-table fetches together, FM steps together, window comparisons together) instead of
+    // serialising each other's phases.
     for (;;) {
-        if (!active) {
-            if (p >= stop) break;
-            const uint32_t nm = packed_nmask32(pk, p, rlen);
-            if (nm & 0x80000000u) { p += nm == 0xFFFFFFFFu ? 32 : __builtin_clz(~nm); continue; } // skip N (ReadMapping.cpp:135)
-            start = p;
+        // next start: skip N (ReadMapping.cpp:135)
+        uint32_t nm = 0;
+        while (p < stop) {
+            nm = packed_nmask32(pk, p, rlen);
+            if (!(nm & 0x80000000u)) break;
+            p += nm == 0xFFFFFFFFu ? 32 : __builtin_clz(~nm);
+        }
+        if (p >= stop) break;
+        const int start = p;
+        uint64_t x0 = 0, x1 = 0, x2 = 0;
+        {
             const uint32_t c16 = packed_codes16(pk, p);
             bool jumped = false;
             if (ix.ktab && p + ix.ktab_k <= rlen && (nm >> (32 - ix.ktab_k)) == 0)
                 if (ktab_lookup(ix, c16 >> (32 - 2 * ix.ktab_k), x0, x1, x2)) { p += ix.ktab_k; jumped = true; }
             if (!jumped) { const int c = (int)(c16 >> 30); x0 = ix.L2[c] + 1; x1 = ix.L2[3 - c] + 1; x2 = ix.L2[c + 1] - ix.L2[c]; p++; }
-            active = true;
         }
+        // phase 2: FM steps while the interval holds several suffixes (or none: the step then ends the search)
         bool end = false;
-        if (x2 == 1) { // phase 3: the rest of the search against the text itself
+        while (x2 != 1 && !end) {
+            const uint32_t nm2 = packed_nmask32(pk, p, rlen);
+            if (nm2 & 0x80000000u) { end = true; break; } // N or read end
+            const int c = (int)(packed_codes16(pk, p) >> 30);
+            uint64_t tk[4], tl[4];
+            int nb;
+            fm_2occ4(ix, x1 - 1, x1 - 1 + x2, tk, tl, nb);
+            blocks += nb;
+            const int b = 3 - c;
+            const uint64_t n2 = tl[b] - tk[b];
+            if (n2 == 0) { end = true; break; }
+            // ok[3].x0 = ik.x0 + primary correction; lower bases stack on top (:143-146)
+            uint64_t n0 = x0 + ((x1 <= ix.primary && x1 + x2 - 1 >= ix.primary) ? 1 : 0);
+            for (int bb = 3; bb > b; bb--) n0 += tl[bb] - tk[bb];
+            x0 = n0; x1 = ix.L2[b] + 1 + tk[b]; x2 = n2;
+            p++;
+        }
+        // phase 3: exactly one suffix left — the rest of the search against the text itself
+        int64_t tpos = 0;
+        if (!end) {
             int lf = 0;
             tpos = (int64_t)fm_sa(ix, x0, lf);
             // Consecutive windows overlap by one packed genome word: while the walk advances by whole
@@ -416,43 +440,19 @@ static inline MCX_HD int seed_read(const IndexView &ix, const ReadRef &rd, Packe
                 p += same;
                 if (same < 16) break;
             }
-            end = true;
-        } else { // phase 2: one FM step
-            const uint32_t nm = packed_nmask32(pk, p, rlen);
-            if (nm & 0x80000000u) end = true; // N or read end
-            else {
-                const int c = (int)(packed_codes16(pk, p) >> 30);
-                uint64_t tk[4], tl[4];
-                int nb;
-                fm_2occ4(ix, x1 - 1, x1 - 1 + x2, tk, tl, nb);
-                blocks += nb;
-                const int b = 3 - c;
-                const uint64_t n2 = tl[b] - tk[b];
-                if (n2 == 0) end = true;
-                else {
-                    // ok[3].x0 = ik.x0 + primary correction; lower bases stack on top (:143-146)
-                    uint64_t n0 = x0 + ((x1 <= ix.primary && x1 + x2 - 1 >= ix.primary) ? 1 : 0);
-                    for (int bb = 3; bb > b; bb--) n0 += tl[bb] - tk[bb];
-                    x0 = n0; x1 = ix.L2[b] + 1 + tk[b]; x2 = n2;
-                    p++;
-                }
+        }
+        const int len = p - start;
+        ext_steps += len;
+        if (len >= kMinSeedLength && x2 <= (uint64_t)kOccThr) {
+            if (x2 == 1) {
+                if (n_hits < cap) { Hit h; h.gPos = tpos; h.rPos = start; h.len = len | kHitResolved; hits[n_hits] = h; }
+                n_hits++;
+            } else for (uint64_t i = 0; i < x2; i++) {
+                if (n_hits < cap) { Hit h; h.gPos = (int64_t)(x0 + i); h.rPos = start; h.len = len; hits[n_hits] = h; }
+                n_hits++;
             }
         }
-        if (end) {
-            const int len = p - start;
-            ext_steps += len;
-            if (len >= kMinSeedLength && x2 <= (uint64_t)kOccThr) {
-                if (x2 == 1) {
-                    if (n_hits < cap) { Hit h; h.gPos = tpos; h.rPos = start; h.len = len | kHitResolved; hits[n_hits] = h; }
-                    n_hits++;
-                } else for (uint64_t i = 0; i < x2; i++) {
-                    if (n_hits < cap) { Hit h; h.gPos = (int64_t)(x0 + i); h.rPos = start; h.len = len; hits[n_hits] = h; }
-                    n_hits++;
-                }
-            }
-            p = p + 1;
-            active = false;
-        }
+        p = p + 1;
     }
     return n_hits;
 }
