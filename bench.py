@@ -53,6 +53,15 @@ def pmc_profile(args):
         return None
 
 
+def path_roofline(d, args, reads_per_s):
+    reads = max(d["reads"], 1)
+    e, h = d["fm_ext_steps"] / reads, d["sa_hits"] / reads
+    b_read = 64.0 * (1.107 * e + 31.0 * h) + 8.0 * h + args.rlen + args.rlen / 4.0
+    gbs = reads_per_s * b_read / 1e9
+    return {"bytes_per_read": round(b_read, 1), "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "bound_reads_per_s": round(HBM_PEAK_GBS * 1e9 / b_read, 1)}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -304,6 +313,9 @@ def main():
                                  "fewer bytes (traffic) and is bound by per-lane request rate, so frac can exceed 1 — it is a speed-of-light "
                                  "comparison with a perfect HBM-bound walk, not an HBM utilisation",
                          "algorithmic_bytes_per_read": round(seed_bytes / max(d["reads"], 1), 1), "avg_launch_ms": round(seed_ms, 3),
+                         # SURVEY 8d's own figure for the whole path: achieved = reads/s x B_read against the HBM peak,
+                         # B_read = 64 (1.107 E + 31 H) + 8 H + rlen + rlen/4 with E and H counted by the kernels
+                         "path": path_roofline(d, args, total_reads / dt / world),  # per GPU
                          "measured": None if not prof else {
                              "hbm_gbs": round(prof["traffic"] / (seed_ms * 1e-3) / 1e9, 1), "l2_requests_per_launch": prof["l2_requests"],
                              "l2_request_rate_g_per_s": round(prof["l2_requests"] / (seed_ms * 1e-3) / 1e9, 1), "waves_waiting_frac": prof["wait_frac"],
