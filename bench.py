@@ -316,6 +316,9 @@ def main():
                          # SURVEY 8d's own figure for the whole path: achieved = reads/s x B_read against the HBM peak,
                          # B_read = 64 (1.107 E + 31 H) + 8 H + rlen + rlen/4 with E and H counted by the kernels
                          "path": path_roofline(d, args, total_reads / dt / world),  # per GPU
+                         # the FM walk is what SURVEY 8d's roofline is about; by launch time another kernel may be longer
+                         "longest_launch": max((("k_seed", "ms_seed"), ("k_cluster", "ms_cluster"), ("k_build", "ms_build"), ("k_finish", "ms_finish")),
+                                               key=lambda kv: d[kv[1]])[0],
                          "measured": None if not prof else {
                              "hbm_gbs": round(prof["traffic"] / (seed_ms * 1e-3) / 1e9, 1), "l2_requests_per_launch": prof["l2_requests"],
                              "l2_request_rate_g_per_s": round(prof["l2_requests"] / (seed_ms * 1e-3) / 1e9, 1), "waves_waiting_frac": prof["wait_frac"],
