@@ -463,7 +463,7 @@ static inline MCX_HD int build_frags(const IndexView &ix, int rlen, const Hit *s
 {
     for (int i = 0; i < n; i++) {
         Frag x; x.gPos = seeds[i].gPos; x.rPos = seeds[i].rPos; x.rLen = x.gLen = seeds[i].len;
-        x.ops_off = 0; x.ops_len = 0; x.kind = kSimple; x.pad[0] = x.pad[1] = x.pad[2] = 0;
+        x.ops_off = 0; x.ops_len = 0; x.kind = kSimple;
         int j = i - 1;
         while (j >= 0 && frag_before(x, f[j])) { f[j + 1] = f[j]; j--; } // sort by (rPos, gPos), :317
         f[j + 1] = x;
@@ -494,7 +494,7 @@ static inline MCX_HD int build_frags(const IndexView &ix, int rlen, const Hit *s
     bool tail = f[n - 1].rPos + f[n - 1].rLen < rlen;
     int total = n + gaps + (head ? 1 : 0) + (tail ? 1 : 0);
     int w = total - 1;
-    Frag g; g.ops_off = 0; g.ops_len = 0; g.kind = kPlain; g.pad[0] = g.pad[1] = g.pad[2] = 0;
+    Frag g; g.ops_off = 0; g.ops_len = 0; g.kind = kPlain;
     if (tail) {
         g.rPos = f[n - 1].rPos + f[n - 1].rLen; g.gPos = f[n - 1].gPos + f[n - 1].gLen;
         g.rLen = g.gLen = rlen - g.rPos;
@@ -984,7 +984,6 @@ static inline MCX_HD void write_detail(const Ctx &cx, PairState &st, int s, uint
             const int64_t g0 = c.fwd ? a.gPos : cx.ix.G2 - (a.gPos + a.gLen);
             const int64_t g1 = c.fwd ? b.gPos + b.gLen : cx.ix.G2 - b.gPos;
             Frag r; r.gPos = g0; r.rPos = 0; r.rLen = (int32_t)(g1 - g0); r.gLen = 0; r.ops_off = 0; r.ops_len = 0; r.kind = kSimple;
-            r.pad[0] = r.pad[1] = r.pad[2] = 0;
             df[n++] = r;
         }
         d.n_frags = n;

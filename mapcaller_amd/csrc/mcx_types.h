@@ -94,14 +94,21 @@ enum FragKind : uint8_t {
     kEmpty = 5    // end fragment dropped by the quality gate
 };
 
+// One fragment of a candidate's alignment in 16 bytes — one memory instruction moves it.  The
+// per-pair kernels are bound by the number of such instructions, so the fields are bit-fields sized
+// for the hard limits of the path: positions below 2^40, reads up to 1000 bases, gap fragments up to
+// 2048 x 1024, an ops pool of at most 96 KB.  Signed: lengths are decremented below zero and clamped
+// (RemoveOverlaps, ReadAlignment.cpp:38-65).
 struct alignas(16) Frag {
-    int64_t gPos;
-    int32_t rPos, rLen, gLen;
-    int32_t ops_off;  // kDp: offset into the pair's ops pool (columns, 'M' 'I' 'D')
-    int32_t ops_len;  // current number of alignment columns (after end trimming)
-    uint8_t kind;
-    uint8_t pad[3];
+    int64_t gPos : 41;
+    int64_t rPos : 11;
+    int64_t gLen : 12;
+    int64_t rLen : 13;
+    int64_t ops_off : 18;  // kDp: offset into the pair's ops pool (columns, 'M' 'I' 'D')
+    int64_t ops_len : 13;  // current number of alignment columns (after end trimming)
+    uint64_t kind : 3;
 };
+static_assert(sizeof(Frag) == 16, "Frag is one 16-byte record");
 
 struct DpJob {        // one ksw2/nw problem
     uint32_t pair;
