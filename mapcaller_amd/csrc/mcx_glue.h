@@ -67,8 +67,8 @@ static inline MCX_HD void cand_init(Cand &dst, int score, int first, int count, 
 {
     Cand c;
     c.score = score; c.mate = -1; c.first = first; c.count = count; c.pd0 = pd0;
-    c.frag_off = 0; c.n_frags = 0; c.flag = 0; c.fwd = 1; c.pad = 0;
-    dst = c; // three 16-byte stores
+    c.frag_off = 0; c.n_frags = 0; c.flag = 0; c.fwd = 1; for (int k = 0; k < 7; k++) c.pad[k] = 0;
+    dst = c; // two 16-byte stores
 }
 
 // SimplePairClustering (ReadMapping.cpp:194-226) with IdentifyClosestFragmentPairs (:160-192).

@@ -72,18 +72,19 @@ struct alignas(16) Hit { // one seed occurrence: FragPair_t with bSimple (struct
     int32_t len;
 };
 
-struct alignas(16) Cand { // AlnCan_t (structure.h:125-133) as ranges into the pair state; three 16-byte groups
-    int32_t score;
-    int32_t mate;     // PairedAlnCanIdx
-    int32_t first;    // first seed (index into the read's hit array)
-    int32_t count;    // number of seeds
-    int32_t frag_off; // fragments after extension set-up
-    int32_t n_frags;
-    int32_t flag;     // SamFlag
-    int32_t fwd;      // orientation
+struct alignas(16) Cand { // AlnCan_t (structure.h:125-133) as ranges into the pair state; two 16-byte groups
     int64_t pd0;      // FragPairVec[0].PosDiff while sorted by PosDiff
-    int64_t pad;
+    int32_t score;
+    int16_t mate;     // PairedAlnCanIdx (-1: none)
+    int16_t first;    // first seed (index into the read's hit array)
+    int16_t count;    // number of seeds
+    int16_t frag_off; // fragments after extension set-up
+    int16_t n_frags;
+    int16_t flag;     // SamFlag
+    int8_t fwd;       // orientation
+    int8_t pad[7];
 };
+static_assert(sizeof(Cand) == 32, "Cand is two 16-byte records");
 
 enum FragKind : uint8_t {
     kSimple = 0,  // exact seed
@@ -122,8 +123,8 @@ struct DpJob {        // one ksw2/nw problem
     int32_t score;    // out: ez.score (ksw2) / final s (nw, doubled)
 };
 
-struct ReadSum {      // AlnSummary_t (structure.h:135-140)
-    int32_t best, score, sub;
+struct ReadSum {      // AlnSummary_t (structure.h:135-140); scores count matched bases (at most the read length)
+    int16_t best, score, sub;
 };
 
 enum PairFlags : uint32_t {
@@ -133,23 +134,23 @@ enum PairFlags : uint32_t {
     kRescueUsedEst = 256u
 };
 
-struct alignas(16) PairHdr {
+struct alignas(16) PairHdr { // 64 bytes: four 16-byte groups
     uint32_t flags;
-    int32_t n_hits[2];
-    int32_t n_cands[2];
     int32_t n_frags;
     int32_t n_ops;
-    int32_t n_jobs;
-    int32_t est;          // EstiDistance used
+    int32_t est;            // EstiDistance used
     int32_t est_lo, est_hi; // the pairing decisions hold for every EstiDistance in [lo, hi]
-    int32_t n_paired;     // return value of CheckPairedAlignmentDistance / AlignmentRescue
-    ReadSum sum[2];
-    int32_t pair_ok;      // counted in iTotalPairedNum (ReadMapping.cpp:527-531)
     int32_t pair_dist;
-    int64_t stat_ext;     // FM extension steps (E) of both reads
-    int32_t stat_hits;    // SA hits resolved (H)
-    int32_t mapped;       // number of mapped reads in the pair
+    int16_t n_hits[2];
+    int16_t n_cands[2];
+    int16_t n_jobs;
+    int16_t n_paired;       // return value of CheckPairedAlignmentDistance / AlignmentRescue
+    int16_t pair_ok;        // counted in iTotalPairedNum (ReadMapping.cpp:527-531)
+    int16_t mapped;         // number of mapped reads in the pair
+    ReadSum sum[2];
+    int32_t pad[2];
 };
+static_assert(sizeof(PairHdr) == 64, "PairHdr is four 16-byte records");
 
 // one output record per read (unique mode: the reference prints exactly one line per read)
 struct alignas(16) AlnRec { // 64 bytes: four 16-byte stores
