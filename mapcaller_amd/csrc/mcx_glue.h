@@ -596,7 +596,7 @@ static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef 
             c.n_frags = nf;
             // ProcessNormalPair (:155-191): classify each gap fragment
             for (int i = 0; i < nf; i++) {
-                Frag &x = f[i];
+                Frag x = f[i]; // worked on in registers, stored back once
                 if (x.kind == kSimple) continue;
                 bool rev = x.gPos >= cx.ix.G;
                 if (x.rLen > 0 && x.gLen > 0) {
@@ -617,6 +617,7 @@ static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef 
                     } else { x.kind = kPlain; x.ops_len = x.rLen; }
                 } else if (x.rLen > 0) { x.kind = kIns; x.ops_len = x.rLen; }
                 else { x.kind = kDel; x.ops_len = x.gLen; }
+                f[i] = x;
             }
             h.n_frags += nf;
         }
@@ -772,8 +773,10 @@ static inline MCX_HD Coord aln_coord(const IndexView &ix, const Cand &c, const F
 {
     Coord k; k.pos = 0; k.chr = 0;
     const Frag *f = frags + c.frag_off;
-    for (int i = 0; i < c.n_frags; i++)
-        if (f[i].gLen > 0) return to_coord(ix, c.fwd ? f[i].gPos : f[i].gPos + f[i].gLen - 1);
+    for (int i = 0; i < c.n_frags; i++) {
+        const Frag x = f[i];
+        if (x.gLen > 0) return to_coord(ix, c.fwd ? x.gPos : x.gPos + x.gLen - 1);
+    }
     return k;
 }
 
@@ -803,7 +806,7 @@ static inline MCX_HD int cigar_of(int rlen, const Cand &c, const Frag *frags, co
         if (clip > 0) put(clip, 4);
     }
     for (int i = 0; i < num; i++) {
-        const Frag &f = v[i];
+        const Frag f = v[i]; // a copy: the stores of the operations below could alias a reference
         if (f.kind == kSimple) { flush_to(0); run += f.rLen; }
         else if (f.kind == kEmpty) continue;
         else if (f.ops_len > 0) {

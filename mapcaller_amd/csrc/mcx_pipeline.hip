@@ -595,9 +595,10 @@ __global__ void __launch_bounds__(64) k_dp_sel(Ctx cx, JobSink sink, ReadBatch r
         int score = 0;
         const int w = dp_core<K, 64>(cx.pm.use_nw != 0, job.rLen, job.gLen, b, st.ops + job.ops_off, &score);
         if (lane == 0) {
-            Frag &f = st.frags[job.frag];
+            Frag f = st.frags[job.frag]; // one fetch, one store (the fields share two words)
             f.ops_off = job.ops_off + w;
             f.ops_len = job.rLen + job.gLen - w;
+            st.frags[job.frag] = f;
             sink.jobs[jb].score = score;
         }
         __syncthreads();
@@ -625,9 +626,10 @@ __global__ void __launch_bounds__(256) k_dp_small(Ctx cx, JobSink sink, ReadBatc
         int score = 0;
         const int w = dp_core<1, 16>(cx.pm.use_nw != 0, job.rLen, job.gLen, b, st.ops + job.ops_off, &score);
         if (lane == 0) {
-            Frag &f = st.frags[job.frag];
+            Frag f = st.frags[job.frag]; // one fetch, one store (the fields share two words)
             f.ops_off = job.ops_off + w;
             f.ops_len = job.rLen + job.gLen - w;
+            st.frags[job.frag] = f;
             sink.jobs[jb].score = score;
         }
         dp_sync<16>();
