@@ -1276,7 +1276,7 @@ extern "C" int mcx_profile_finalize(mcx_ctx *c, uint32_t *d_planes)
 {
     if (!c || !d_planes) return fail(MCX_ERR_ARG, "mcx_profile_finalize: null argument");
     HIP_TRY(hipSetDevice(c->idx->device));
-    k_prof_finalize<<<4096, 256, 0, c->stream>>>(d_planes, c->idx->view.G, c->prof_max_dup);
+    k_prof_finalize<<<dim3(4096, kPlanes), 256, 0, c->stream>>>(d_planes, c->idx->view.G, c->prof_max_dup);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;

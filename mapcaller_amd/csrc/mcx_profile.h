@@ -174,13 +174,14 @@ __global__ void __launch_bounds__(256) k_prof_accum(const uint8_t *detail, Detai
 // after the all-reduce): 12-bit saturation, 16-bit wrap, duplicate cap
 __global__ void k_prof_finalize(uint32_t *plane, int64_t G, int max_dup)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < G * kPlanes; i += (int64_t)gridDim.x * blockDim.x) {
-        const int k = (int)(i / G);
-        uint32_t v = plane[i];
+    const int k = blockIdx.y; // one plane per grid row: no division per element
+    uint32_t *p = plane + (uint64_t)k * G;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < G; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t v = p[i];
         if (k <= kPlMulti) v = v < 4095u ? v : 4095u;
         else if (k == kPlReadCount) v = v < (uint32_t)max_dup ? v : (uint32_t)max_dup;
         else v &= 0xFFFFu;
-        plane[i] = v;
+        p[i] = v;
     }
 }
 
