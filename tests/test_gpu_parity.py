@@ -511,3 +511,51 @@ def test_run_module_single_gpu(golden, tmp_path):
     nd, ex = sam_diff(g["sam"]["ksw2"], sam)
     assert nd == 0, ex
     assert vcf_body(vcf) == vcf_body(g["vcf"]["gvcf"])
+
+
+def test_degenerate_reads_equal_oracle(api, golden, tmp_path):
+    """Reads the path has little to say about — shorter than a seed, all N, homopolymers and short
+    tandem repeats (more than 50 occurrences: BWT_Search reports none), a read that is the genome's
+    first / last bases — next to ordinary ones: GPU SAM == oracle SAM (== the reference if it survives)."""
+    import gzip
+    g = golden["mc"]
+    genome = b"".join(l for l in gzip.open(os.path.join(GOLD, "mc", "genome.fa.gz"), "rb").read().split(b"\n") if not l.startswith(b">"))
+    rng = np.random.default_rng(3)
+    reads = []
+    for n in (1, 5, 15, 16, 17, 31, 40):
+        p = int(rng.integers(5000, 100000))
+        reads.append(genome[p:p + n])
+    reads += [b"N" * 150, b"A" * 150, b"ACACACACAC" * 15, b"N" * 20 + genome[40000:40110] + b"N" * 20, genome[7000:7150].lower()]
+    reads += [genome[3000:3150], genome[len(genome) - 150:], genome[len(genome) - 151:len(genome) - 1]]
+    for k in range(40):
+        p = int(rng.integers(5000, 150000))
+        reads.append(genome[p:p + 150])
+    def rc(s):
+        return s[::-1].translate(bytes.maketrans(b"ACGTacgtN", b"TGCAtgcaN"))
+    with open(tmp_path / "r1.fq", "wb") as f1, open(tmp_path / "r2.fq", "wb") as f2:
+        for i, s in enumerate(reads):
+            s = s.replace(b"n", b"N")
+            mate = rc(genome[60000 + 300 * i: 60000 + 300 * i + 150])
+            f1.write(b"@d%03d\n%s\n+\n%s\n" % (i, s, b"I" * len(s)))
+            f2.write(b"@d%03d\n%s\n+\n%s\n" % (i, mate, b"I" * len(mate)))
+    f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+    ix = api.Index(g["prefix"], device=0)
+    for paired in (True, False):
+        for alg in ("ksw2", "nw"):
+            mp = api.Mapper(ix, alg=alg, max_batch_reads=400)
+            out = str(tmp_path / f"gpu.{alg}.{paired}.sam")
+            mp.map_files(f1, f2 if paired else None, out)
+            ora = str(tmp_path / f"ora.{alg}.{paired}.sam")
+            _oracle_sam(g["prefix"], f1, f2 if paired else None, alg, ora)
+            nd, ex = sam_diff(ora, out, mask_se_reverse_qual=True)
+            assert nd == 0, (alg, paired, ex)
+            mp.close()
+    ix.close()
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "MapCaller")
+    if os.path.exists(ref_bin):
+        rs = str(tmp_path / "ref.sam")
+        r = subprocess.run([ref_bin, "-i", g["prefix"], "-f", f1, "-f2", f2, "-alg", "ksw2", "-sam", rs, "-no_vcf", "-t", "1", "-log", str(tmp_path / "job.log")],
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        if r.returncode == 0:
+            nd, ex = sam_diff(rs, str(tmp_path / "gpu.ksw2.True.sam"))
+            assert nd == 0, ex
