@@ -559,3 +559,31 @@ def test_degenerate_reads_equal_oracle(api, golden, tmp_path):
         if r.returncode == 0:
             nd, ex = sam_diff(rs, str(tmp_path / "gpu.ksw2.True.sam"))
             assert nd == 0, ex
+
+
+def test_maximum_read_length_equals_oracle(api, tmp_path):
+    """1000 bp reads (the longest the path takes) with enough errors that seeds are sparse and gap
+    fragments run to hundreds of bases: the wide DP classes (up to 16 target columns per lane, traceback
+    spilled to HBM) and the tier-1 capacities.  GPU SAM == oracle SAM, both algorithms."""
+    from mapcaller_amd import synth
+    g = synth.random_genome([500000, 300000], seed=909, n_repeats=6, repeat_len=900)
+    fa = str(tmp_path / "g.fa")
+    synth.write_fasta(fa, g)
+    prefix = str(tmp_path / "g")
+    api.Index.build(fa, prefix, 0)
+    bases, _ = synth.simulate_reads(synth.mutate_genome(g, 4), 300, 1000, True, seed=6, skip_head=3000, frag_mean=2500, frag_sd=200, frag_min=2100,
+                                    frag_max=3200, sub=0.03, ins=0.004, dele=0.004)
+    f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+    synth.write_fastq(f1, bases, 0, 2); synth.write_fastq(f2, bases, 1, 2)
+    ix = api.Index(prefix, device=0)
+    for alg in ("ksw2", "nw"):
+        mp = api.Mapper(ix, alg=alg, max_read_len=1000, max_batch_reads=600)
+        out = str(tmp_path / f"gpu.{alg}.sam")
+        st = mp.map_files(f1, f2, out)
+        ora = str(tmp_path / f"ora.{alg}.sam")
+        _oracle_sam(prefix, f1, f2, alg, ora)
+        nd, ex = sam_diff(ora, out)
+        assert nd == 0, (alg, ex)
+        assert st["dp_jobs"] > 0
+        mp.close()
+    ix.close()
