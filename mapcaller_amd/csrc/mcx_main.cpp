@@ -3,12 +3,33 @@
 // -sam out, -vcf out (on by default, like the reference) with the variant-calling switches, plus
 // `index ref.fa prefix`.  Host code only: everything heavy goes through mcx.h.
 #include "../../include/mcx.h"
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 #include <unistd.h>
+#include <zlib.h>
+
+// longest sequence line among the first records of a read file (FASTQ: every 4th line from the 2nd;
+// FASTA: any non-header line) — sizes the contexts; a longer read further down is an error that names -maxlen
+static int sample_read_length(const std::string &path)
+{
+    gzFile f = gzopen(path.c_str(), "rb");
+    if (!f) return 0;
+    static char line[1 << 16];
+    int longest = 0, n = 0;
+    bool fastq = false;
+    while (n < 40000 && gzgets(f, line, sizeof line)) {
+        const int len = (int)strcspn(line, "\r\n");
+        if (n == 0) fastq = line[0] == '@';
+        if (fastq ? (n % 4 == 1) : (line[0] != '>')) longest = len > longest ? len : longest;
+        n++;
+    }
+    gzclose(f);
+    return longest;
+}
 
 static void usage(const char *prog)
 {
@@ -41,6 +62,7 @@ static void usage(const char *prog)
             "         -id STR       sample id [unknown]\n"
             "         -p            paired-end reads are interlaced in the same file\n"
             "         -t INT        host threads that parse reads and format SAM lines [half the cores, at most 32]\n"
+            "         -maxlen INT   longest read the run has to take [sampled from the first reads, at least 256, at most 1000]\n"
             "         -gpu INT      device ordinal [0]\n"
             "         -sampled_sa   keep only the sampled suffix array in HBM (saves 8 bytes per text position, slower seeding)\n", prog, prog);
 }
@@ -58,7 +80,7 @@ int main(int argc, char **argv)
     std::vector<std::string> f1, f2;
     mcx_opts o;
     mcx_opts_default(&o);
-    int gpu = 0, full_sa = 1;
+    int gpu = 0, full_sa = 1, maxlen = 0;
     mcx_file_opts fo;
     mcx_file_opts_default(&fo);
     bool want_vcf = true; // bVCFoutput, main.cpp:171
@@ -92,6 +114,7 @@ int main(int argc, char **argv)
         else if (p == "-t" && i + 1 < argc) { if ((fo.host_threads = atoi(argv[++i])) <= 0) { fprintf(stderr, "Warning! The thread number should be positive!\n"); fo.host_threads = 4; } }
         else if (p == "-pair" || p == "-p") fo.interleaved_pairs = 1;
         else if (p == "-gpu" && i + 1 < argc) gpu = atoi(argv[++i]);
+        else if (p == "-maxlen" && i + 1 < argc) maxlen = atoi(argv[++i]);
         else if (p == "-sampled_sa") full_sa = 0;
         else if (p == "-vcf" && i + 1 < argc) vcf = argv[++i];
         else if (p == "-no_vcf") want_vcf = false;
@@ -124,6 +147,12 @@ int main(int argc, char **argv)
     int rc = mcx_index_load(prefix.c_str(), gpu, full_sa, &ix);
     if (rc) { fprintf(stderr, "Error! %s\n", mcx_last_error()); return 1; }
     o.max_batch_reads = 1 << 19; // per batch of the parse | map | format pipeline
+    if (maxlen <= 0) {
+        for (const std::string &f : f1) maxlen = std::max(maxlen, sample_read_length(f));
+        for (const std::string &f : f2) maxlen = std::max(maxlen, sample_read_length(f));
+        maxlen = (maxlen + 63) / 64 * 64;
+    }
+    o.max_read_len = std::min(1000, std::max(256, maxlen));
     mcx_ctx *cx = nullptr;
     rc = mcx_ctx_create(ix, &o, &cx);
     if (rc) { fprintf(stderr, "Error! %s\n", mcx_last_error()); return 1; }

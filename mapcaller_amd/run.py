@@ -36,7 +36,7 @@ def parse(argv):
     ap.add_argument("-no_vcf", action="store_true")
     ap.add_argument("-t", dest="threads", type=int, default=0, help="host threads per process for parsing / SAM text")
     ap.add_argument("-batch", type=int, default=1 << 20, help="reads per batch (the unit dealt to the ranks)")
-    ap.add_argument("-maxlen", type=int, default=256, help="longest read the contexts are sized for")
+    ap.add_argument("-maxlen", type=int, default=0, help="longest read the contexts are sized for [sampled from the first reads, 256..1000]")
     for name, kw in (("-gvcf", {}), ("-monomorphic", {}), ("-filter", {}), ("-somatic", {})):
         ap.add_argument(name, action="store_true", **kw)
     ap.add_argument("-ploidy", type=int, default=2)
@@ -54,6 +54,22 @@ def parse(argv):
     return a
 
 
+def sample_read_length(path, lines=40000):
+    """Longest sequence line among the first records of a read file (sizes the contexts)."""
+    import gzip
+    opener = gzip.open if path.endswith(".gz") else open
+    longest, fastq = 0, False
+    with opener(path, "rb") as fh:
+        for n, line in enumerate(fh):
+            if n >= lines:
+                break
+            if n == 0:
+                fastq = line.startswith(b"@")
+            if (n % 4 == 1) if fastq else (not line.startswith(b">")):
+                longest = max(longest, len(line.rstrip(b"\r\n")))
+    return longest
+
+
 def merge_sam(path, world):
     """The ranks' parts back into input order: batch k sits in part k % world."""
     index = []
@@ -61,10 +77,8 @@ def merge_sam(path, world):
         with open(f"{path}.part{r}.idx") as fh:
             index.append([(int(a), int(b)) for a, b in (l.split() for l in fh if l.strip())])
     parts = [open(f"{path}.part{r}", "rb") for r in range(world)]
-    cursor = [0] * world
     with open(path, "wb") as out:
         # part 0 starts with the header
-        first = index[0][0][0] if index[0] else None
         header_len = os.path.getsize(f"{path}.part0") - sum(b for _, b in index[0])
         out.write(parts[0].read(header_len))
         todo = sorted((k, r) for r in range(world) for k, _ in index[r])
@@ -108,6 +122,8 @@ def main(argv=None):
         td = td_
         backend = a.backend or "nccl"
         td.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+    if a.maxlen <= 0:
+        a.maxlen = min(1000, max(256, (max(sample_read_length(f) for f in a.f1 + a.f2) + 63) // 64 * 64))
     index = api.Index(a.index, device=device, full_sa=True)
     mapper = api.Mapper(index, alg=a.alg, max_read_len=a.maxlen, max_batch_reads=max(200, a.batch // 200 * 200))
     want_vcf = not a.no_vcf
