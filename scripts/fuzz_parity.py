@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Randomised differential check of the product (mapcaller-mi355x on the GPU) against the CPU oracle.
+
+    python scripts/fuzz_parity.py --rounds 30 [--seed 1] [--keep DIR]
+
+Every round draws a small genome (contigs, repeats, tandem runs, N runs), a donor with SNPs/indels,
+read length, insert size, error rates, single or paired end, FASTQ or FASTA, algorithm — maps the
+reads with both and compares the SAM line by line and the VCF body.  Not part of the test suite (it
+takes minutes); a divergence prints the round's parameters and keeps its files.
+Checker use only: the oracle is the thing compared against, never a fallback.
+"""
+import argparse
+import os
+import random
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mapcaller_amd import synth  # noqa: E402
+
+EXE = os.path.join(ROOT, "mapcaller_amd", "mapcaller-mi355x")
+ORACLE = os.path.join(ROOT, "oracle", "mcx_oracle")
+
+
+def body(path, vcf=False):
+    lines = open(path, encoding="latin-1").read().split("\n")
+    if vcf:
+        return [l for l in lines if not l.startswith(("##command_line=", "##reference="))]
+    return lines
+
+
+def mask_se_reverse_qual(lines):
+    out = []
+    for l in lines:
+        f = l.split("\t")
+        if len(f) > 10 and f[1].isdigit() and (int(f[1]) & 0x11) == 0x10:
+            f[10] = "?"
+        out.append("\t".join(f))
+    return out
+
+
+def one_round(rng, tmp):
+    n_contigs = rng.randint(1, 4)
+    lens = [rng.randint(40_000, 400_000) for _ in range(n_contigs)]
+    g = synth.random_genome(lens, seed=rng.randint(1, 1 << 30), n_repeats=rng.randint(0, 30), repeat_len=rng.choice([300, 800, 2000]),
+                            tandem=rng.randint(0, 10), n_runs=rng.randint(0, 6))
+    fa = os.path.join(tmp, "g.fa")
+    synth.write_fasta(fa, g)
+    prefix = os.path.join(tmp, "idx")
+    subprocess.run([EXE, "index", fa, prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    donor = synth.mutate_genome(g, rng.randint(1, 1 << 30), snp=rng.choice([0.0, 0.002, 0.01]), indel=rng.choice([0.0, 0.0005, 0.002]))
+    rlen = rng.choice([36, 75, 100, 150, 151, 250, 300])
+    paired = rng.random() < 0.7
+    fastq = rng.random() < 0.8 or not paired
+    mean = rng.choice([250, 400, 500, 800]) + rlen
+    n = rng.randint(300, 4000)
+    p = dict(sub=rng.choice([0.0, 0.005, 0.02, 0.05]), ins=rng.choice([0.0, 0.001, 0.01]), dele=rng.choice([0.0, 0.001, 0.01]),
+             n_rate=rng.choice([0.0, 0.0, 0.003]))
+    bases, _ = synth.simulate_reads(donor, n, rlen, paired, rng.randint(1, 1 << 30), frag_mean=mean, frag_sd=rng.choice([10, 50, 120]),
+                                    frag_min=rlen + 24, frag_max=mean + 500, skip_head=3000, skip_contigs=(0,), **p)
+    ext = "fq" if fastq else "fa"
+    f1, f2 = os.path.join(tmp, f"r1.{ext}"), os.path.join(tmp, f"r2.{ext}")
+    writer = synth.write_fastq if fastq else synth.write_fasta_reads
+    if paired:
+        writer(f1, bases, 0, 2); writer(f2, bases, 1, 2)
+        files = ["-f", f1, "-f2", f2]
+    else:
+        writer(f1, bases, 0, 1)
+        files = ["-f", f1]
+    alg = rng.choice(["nw", "ksw2"])
+    vcf_flags = rng.choice([[], ["-gvcf"], ["-filter"], ["-ploidy", "1"], ["-somatic"], ["-ad", "3", "-min_gap", "20"]])
+    desc = dict(lens=lens, rlen=rlen, paired=paired, fastq=fastq, n=n, alg=alg, vcf=vcf_flags, frag_mean=mean, **p)
+    gs, gv, os_, ov = (os.path.join(tmp, x) for x in ("gpu.sam", "gpu.vcf", "ora.sam", "ora.vcf"))
+    subprocess.run([EXE, "-i", prefix, *files, "-alg", alg, "-sam", gs, "-vcf", gv, *vcf_flags], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.run([ORACLE, "-i", prefix, *files, "-alg", alg, "-sam", os_], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.run([ORACLE, "-i", prefix, *files, "-alg", alg, "-vcf", ov, *vcf_flags], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    a, b = mask_se_reverse_qual(body(gs)), mask_se_reverse_qual(body(os_))
+    sam_bad = sum(1 for x, y in zip(a, b) if x != y) + abs(len(a) - len(b))
+    va, vb = body(gv, True), body(ov, True)
+    vcf_bad = sum(1 for x, y in zip(va, vb) if x != y) + abs(len(va) - len(vb))
+    return desc, sam_bad, vcf_bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=20)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--keep", default="")
+    a = ap.parse_args()
+    rng = random.Random(a.seed)
+    bad = 0
+    for r in range(a.rounds):
+        tmp = tempfile.mkdtemp(prefix=f"fuzz{r}_")
+        try:
+            desc, sam_bad, vcf_bad = one_round(rng, tmp)
+        except subprocess.CalledProcessError as e:
+            print(f"round {r}: command failed: {e.cmd[:6]} ...", flush=True)
+            bad += 1
+            continue
+        status = "ok" if not (sam_bad or vcf_bad) else f"DIFF sam={sam_bad} vcf={vcf_bad}"
+        print(f"round {r}: {status} {desc}", flush=True)
+        if sam_bad or vcf_bad:
+            bad += 1
+            if a.keep:
+                shutil.copytree(tmp, os.path.join(a.keep, f"round{r}"), dirs_exist_ok=True)
+        shutil.rmtree(tmp, ignore_errors=True)
+    print(f"{a.rounds - bad} of {a.rounds} rounds identical")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
