@@ -206,8 +206,8 @@ def sam_diff(path_a, path_b, limit=3, mask_se_reverse_qual=False):
     """Number of differing lines (+ a few examples).  mask_se_reverse_qual: the reference prints an
     uninitialised first quality byte for reverse-strand single-end FASTQ reads (SamReport.cpp:318-322),
     so QUAL of those lines is not compared."""
-    a = open(path_a, encoding="latin-1").read().split("\n")
-    b = open(path_b, encoding="latin-1").read().split("\n")
+    a = open(path_a, "rb").read().decode("latin-1").split("\n")  # (binary: no newline translation of stray bytes)
+    b = open(path_b, "rb").read().decode("latin-1").split("\n")
     if mask_se_reverse_qual:
         a = [_mask_se_reverse_qual(l) for l in a]
         b = [_mask_se_reverse_qual(l) for l in b]
