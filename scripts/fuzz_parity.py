@@ -76,24 +76,37 @@ def sam_bytes_differ(ref_path, ora_path):
     return bad + (1 if pos != len(a) else 0)
 
 
-def one_round(rng, tmp):
-    n_contigs = rng.randint(1, 4)
-    lens = [rng.randint(40_000, 400_000) for _ in range(n_contigs)]
-    g = synth.random_genome(lens, seed=rng.randint(1, 1 << 30), n_repeats=rng.randint(0, 30), repeat_len=rng.choice([300, 800, 2000]),
-                            tandem=rng.randint(0, 10), n_runs=rng.randint(0, 6))
+def draw(rng):
+    """The parameters of one round (every random draw happens here, so a round can be replayed by number)."""
+    d = {}
+    d["lens"] = [rng.randint(40_000, 400_000) for _ in range(rng.randint(1, 4))]
+    d["genome"] = dict(seed=rng.randint(1, 1 << 30), n_repeats=rng.randint(0, 30), repeat_len=rng.choice([300, 800, 2000]),
+                       tandem=rng.randint(0, 10), n_runs=rng.randint(0, 6))
+    d["donor"] = dict(seed=rng.randint(1, 1 << 30), snp=rng.choice([0.0, 0.002, 0.01]), indel=rng.choice([0.0, 0.0005, 0.002]))
+    d["rlen"] = rng.choice([36, 75, 100, 150, 151, 250, 300])
+    d["paired"] = rng.random() < 0.7
+    d["fastq"] = rng.random() < 0.8 or not d["paired"]
+    d["frag_mean"] = rng.choice([250, 400, 500, 800]) + d["rlen"]
+    d["n"] = rng.randint(300, 4000)
+    d["err"] = dict(sub=rng.choice([0.0, 0.005, 0.02, 0.05]), ins=rng.choice([0.0, 0.001, 0.01]), dele=rng.choice([0.0, 0.001, 0.01]),
+                    n_rate=rng.choice([0.0, 0.0, 0.003]))
+    d["reads_seed"] = rng.randint(1, 1 << 30)
+    d["frag_sd"] = rng.choice([10, 50, 120])
+    d["alg"] = rng.choice(["nw", "ksw2"])
+    d["vcf"] = rng.choice([[], ["-gvcf"], ["-filter"], ["-ploidy", "1"], ["-somatic"], ["-ad", "3", "-min_gap", "20"]])
+    return d
+
+
+def one_round(d, tmp):
+    lens, rlen, paired, fastq, mean, n, p = d["lens"], d["rlen"], d["paired"], d["fastq"], d["frag_mean"], d["n"], d["err"]
+    gp = dict(d["genome"]); gseed = gp.pop("seed")
+    g = synth.random_genome(lens, seed=gseed, **gp)
     fa = os.path.join(tmp, "g.fa")
     synth.write_fasta(fa, g)
     prefix = os.path.join(tmp, "idx")
     subprocess.run([REF if MODE == "ref" else EXE, "index", fa, prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    donor = synth.mutate_genome(g, rng.randint(1, 1 << 30), snp=rng.choice([0.0, 0.002, 0.01]), indel=rng.choice([0.0, 0.0005, 0.002]))
-    rlen = rng.choice([36, 75, 100, 150, 151, 250, 300])
-    paired = rng.random() < 0.7
-    fastq = rng.random() < 0.8 or not paired
-    mean = rng.choice([250, 400, 500, 800]) + rlen
-    n = rng.randint(300, 4000)
-    p = dict(sub=rng.choice([0.0, 0.005, 0.02, 0.05]), ins=rng.choice([0.0, 0.001, 0.01]), dele=rng.choice([0.0, 0.001, 0.01]),
-             n_rate=rng.choice([0.0, 0.0, 0.003]))
-    bases, _ = synth.simulate_reads(donor, n, rlen, paired, rng.randint(1, 1 << 30), frag_mean=mean, frag_sd=rng.choice([10, 50, 120]),
+    donor = synth.mutate_genome(g, d["donor"]["seed"], snp=d["donor"]["snp"], indel=d["donor"]["indel"])
+    bases, _ = synth.simulate_reads(donor, n, rlen, paired, d["reads_seed"], frag_mean=mean, frag_sd=d["frag_sd"],
                                     frag_min=rlen + 24, frag_max=mean + 500, skip_head=3000, skip_contigs=(0,), **p)
     ext = "fq" if fastq else "fa"
     f1, f2 = os.path.join(tmp, f"r1.{ext}"), os.path.join(tmp, f"r2.{ext}")
@@ -104,8 +117,7 @@ def one_round(rng, tmp):
     else:
         writer(f1, bases, 0, 1)
         files = ["-f", f1]
-    alg = rng.choice(["nw", "ksw2"])
-    vcf_flags = rng.choice([[], ["-gvcf"], ["-filter"], ["-ploidy", "1"], ["-somatic"], ["-ad", "3", "-min_gap", "20"]])
+    alg, vcf_flags = d["alg"], d["vcf"]
     desc = dict(lens=lens, rlen=rlen, paired=paired, fastq=fastq, n=n, alg=alg, vcf=vcf_flags, frag_mean=mean, **p)
     gs, gv, os_, ov = (os.path.join(tmp, x) for x in ("gpu.sam", "gpu.vcf", "ora.sam", "ora.vcf"))
     if MODE == "ref":
@@ -130,19 +142,27 @@ def main():
     ap.add_argument("--rounds", type=int, default=20)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--keep", default="")
+    ap.add_argument("--only", type=int, default=-1, help="replay just this round of the sequence")
     ap.add_argument("--ref", action="store_true", help="compare the oracle with the compiled reference (oracle/_ref, CPU only) instead of the GPU product")
     a = ap.parse_args()
     global MODE
     MODE = "ref" if a.ref else "gpu"
     rng = random.Random(a.seed)
-    bad = 0
+    bad = ran = 0
     for r in range(a.rounds):
+        d = draw(rng)
+        if a.only >= 0 and r != a.only:
+            continue
+        ran += 1
         tmp = tempfile.mkdtemp(prefix=f"fuzz{r}_")
         try:
-            desc, sam_bad, vcf_bad = one_round(rng, tmp)
+            desc, sam_bad, vcf_bad = one_round(d, tmp)
         except subprocess.CalledProcessError as e:
-            print(f"round {r}: command failed: {e.cmd[:6]} ...", flush=True)
+            print(f"round {r}: command failed (exit {e.returncode}): {e.cmd[:6]} ... {d}", flush=True)
             bad += 1
+            if a.keep:
+                shutil.copytree(tmp, os.path.join(a.keep, f"round{r}"), dirs_exist_ok=True)
+            shutil.rmtree(tmp, ignore_errors=True)
             continue
         status = "ok" if not (sam_bad or vcf_bad) else f"DIFF sam={sam_bad} vcf={vcf_bad}"
         print(f"round {r}: {status} {desc}", flush=True)
@@ -151,7 +171,7 @@ def main():
             if a.keep:
                 shutil.copytree(tmp, os.path.join(a.keep, f"round{r}"), dirs_exist_ok=True)
         shutil.rmtree(tmp, ignore_errors=True)
-    print(f"{a.rounds - bad} of {a.rounds} rounds identical")
+    print(f"{ran - bad} of {ran} rounds identical")
     sys.exit(1 if bad else 0)
 
 
