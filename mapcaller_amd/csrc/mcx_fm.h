@@ -349,27 +349,31 @@ static inline MCX_HD uint32_t ref_codes16(const IndexView &ix, int64_t j)
 //     position (one suffix-array fetch) and the rest of the search is a comparison of 16-base
 //     windows of the packed read against the 2-bit genome.  Same length, same position.
 // (prepacked: pk already holds the read's words — the device packs whole batches in one pass)
-static inline MCX_HD int seed_read(const IndexView &ix, const ReadRef &rd, PackedRead pk, Hit *hits, int cap,
-                                   int64_t &ext_steps, int64_t &blocks, bool prepacked = false)
+// The walk comes in two pieces so that the device can hand a lane its next read as soon as it has
+// finished one (k_seed): seed_next_start, seed_search; seed_read is their plain loop.
+//
+// next search start at or after p: skips N (ReadMapping.cpp:135).  False when the read has no further search;
+// nm: N flags of the 32 bases from the start on.
+static inline MCX_HD bool seed_next_start(const PackedRead &pk, int rlen, int &p, uint32_t &nm)
 {
-    const int rlen = rd.rlen;
-    if (!prepacked) pack_read(rd, pk);
-    int n_hits = 0;
     const int stop = rlen - kMinSeedLength;
-    int p = 0;
-    // One search per iteration, its three phases as loops of their own: the lanes of a wave sit at
-    // unrelated points of their reads, but with this shape they run the same phase at the same time
-    // (jump-table fetches together, FM steps together, window comparisons together) instead of
-    // serialising each other's phases.
-    for (;;) {
-        // next start: skip N (ReadMapping.cpp:135)
-        uint32_t nm = 0;
-        while (p < stop) {
-            nm = packed_nmask32(pk, p, rlen);
-            if (!(nm & 0x80000000u)) break;
-            p += nm == 0xFFFFFFFFu ? 32 : __builtin_clz(~nm);
-        }
-        if (p >= stop) break;
+    nm = 0;
+    while (p < stop) {
+        nm = packed_nmask32(pk, p, rlen);
+        if (!(nm & 0x80000000u)) break;
+        p += nm == 0xFFFFFFFFu ? 32 : __builtin_clz(~nm);
+    }
+    return p < stop;
+}
+
+// One search of the greedy walk, from start p (found by seed_next_start) — its three phases as loops
+// of their own: the lanes of a wave sit at unrelated points of their reads, but with this shape they
+// run the same phase at the same time (jump-table fetches together, FM steps together, window
+// comparisons together) instead of serialising each other's phases.  Leaves p at the next candidate start.
+static inline MCX_HD void seed_search(const IndexView &ix, const PackedRead &pk, int rlen, uint32_t nm, int &p, Hit *hits, int cap,
+                                      int &n_hits, int64_t &ext_steps, int64_t &blocks)
+{
+    {
         const int start = p;
         uint64_t x0 = 0, x1 = 0, x2 = 0;
         {
@@ -454,6 +458,16 @@ static inline MCX_HD int seed_read(const IndexView &ix, const ReadRef &rd, Packe
         }
         p = p + 1;
     }
+}
+
+static inline MCX_HD int seed_read(const IndexView &ix, const ReadRef &rd, PackedRead pk, Hit *hits, int cap,
+                                   int64_t &ext_steps, int64_t &blocks, bool prepacked = false)
+{
+    const int rlen = rd.rlen;
+    if (!prepacked) pack_read(rd, pk);
+    int n_hits = 0, p = 0;
+    uint32_t nm;
+    while (seed_next_start(pk, rlen, p, nm)) seed_search(ix, pk, rlen, nm, p, hits, cap, n_hits, ext_steps, blocks);
     return n_hits;
 }
 

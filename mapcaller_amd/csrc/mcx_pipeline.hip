@@ -427,52 +427,71 @@ __global__ void __launch_bounds__(256) k_pack_reads(ReadBatch rb, int paired, in
     }
 }
 
+// Reads are handed to lanes as the lanes become free: a read is one to six searches, and a wave whose
+// lanes each owned one read would run as long as its longest read while most lanes idle.  A block owns
+// a pool of blockDim x kSeedReadsPerLane consecutive reads; a lane that has finished a read takes the
+// pool's next one, so that every search iteration of the wave finds (nearly) all lanes with work.
+constexpr int kSeedReadsPerLane = 4;
+
 __global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel, SeedOut so, int pk_words)
 {
     extern __shared__ uint32_t pk_lds[]; // packed reads: word k of lane t at pk_lds[k * blockDim.x + t]
+    __shared__ uint32_t next_read;
     const int nr = cx.pm.paired ? 2 : 1;
-    const uint32_t lr = blockIdx.x * blockDim.x + threadIdx.x; // local read
-    const bool live = lr < sel.n * nr;
-    int keep = 0;
-    if (live) {
-        const uint32_t local = lr / nr, s = lr % nr;
-        const uint32_t pair = sel_pair(sel, local), r = pair * nr + s;
-        PairState st = pair_state(cx.state, cx.lay, cx.caps, local);
-        ReadRef rd;
-        rd.ascii = rb.bases + rb.off[r]; rd.rlen = (int)(rb.off[r + 1] - rb.off[r]); rd.flipped = (cx.pm.paired && s == 1) ? 1 : 0;
-        int64_t ext = 0, blocks = 0;
-        PackedRead pk; pk.w = pk_lds + threadIdx.x; pk.stride = blockDim.x; pk.n_code = 0;
-        int n = 0;
-        const int need = packed_words(rd.rlen);
-        if (rd.rlen > 0 && need <= pk_words) {
-            const U4 *src = (const U4 *)(so.packed + (uint64_t)r * so.wpad);
-            for (int k = 0; k < need; k += 4) {
-                const U4 v = src[k >> 2];
-                pk.w[k * pk.stride] = v.x;
-                if (k + 1 < need) pk.w[(k + 1) * pk.stride] = v.y;
-                if (k + 2 < need) pk.w[(k + 2) * pk.stride] = v.z;
-                if (k + 3 < need) pk.w[(k + 3) * pk.stride] = v.w;
-            }
-            pk.n_code = ((rd.rlen + 15) >> 4) + 1;
-            n = seed_read(cx.ix, rd, pk, st.hits[s], cx.caps.hit_cap, ext, blocks, true);
-        }
-        st.hdr->n_hits[s] = n;
-        so.read_ext[r] = (uint32_t)ext; so.read_blocks[r] = (uint32_t)blocks | ((uint32_t)n << 20); // (blocks < 2^20; n < 2^12)
-        keep = n <= cx.caps.hit_cap ? n : 0; // overflowing reads are re-run in the next tier
-    }
-    // SA tasks only for the hits that are still BWT rows; the others carry their text position
-    Hit *mine = nullptr;
-    int todo = 0;
-    if (keep > 0) {
+    const uint32_t total = sel.n * nr;
+    const uint32_t pool0 = blockIdx.x * blockDim.x * kSeedReadsPerLane;
+    const uint32_t pool_n = min((uint32_t)(blockDim.x * kSeedReadsPerLane), total - pool0);
+    if (threadIdx.x == 0) next_read = 0;
+    __syncthreads();
+    PackedRead pk; pk.w = pk_lds + threadIdx.x; pk.stride = blockDim.x; pk.n_code = 0;
+    bool have = false;
+    uint32_t lr = 0, r = 0, nm = 0;
+    int rlen = 0, p = 0, n = 0;
+    int64_t ext = 0, blocks = 0;
+    Hit *hits = nullptr;
+    // the read is done: counters, and SA tasks for the hits that are still BWT rows (the others carry their text position)
+    auto finish_read = [&]() {
         PairState st = pair_state(cx.state, cx.lay, cx.caps, lr / nr);
-        mine = st.hits[lr % nr];
-        for (int i = 0; i < keep; i++) if (!(mine[i].len & kHitResolved)) todo++;
-    }
-    uint32_t at = wave_reserve(so.n_tasks, (uint32_t)todo);
-    for (int i = 0; i < keep; i++) {
-        if (mine[i].len & kHitResolved) { mine[i].len &= ~kHitResolved; continue; }
-        if (at < so.task_cap) so.tasks[at] = make_uint2(lr, (uint32_t)i);
-        at++;
+        st.hdr->n_hits[lr % nr] = n;
+        so.read_ext[r] = (uint32_t)ext; so.read_blocks[r] = (uint32_t)blocks | ((uint32_t)n << 20); // (blocks < 2^20; n < 2^12)
+        const int keep = n <= cx.caps.hit_cap ? n : 0; // overflowing reads are re-run in the next tier
+        int todo = 0;
+        for (int i = 0; i < keep; i++) if (!(hits[i].len & kHitResolved)) todo++;
+        uint32_t at = todo ? atomicAdd(so.n_tasks, (uint32_t)todo) : 0u;
+        for (int i = 0; i < keep; i++) {
+            if (hits[i].len & kHitResolved) { hits[i].len &= ~kHitResolved; continue; }
+            if (at < so.task_cap) so.tasks[at] = make_uint2(lr, (uint32_t)i);
+            at++;
+        }
+    };
+    for (;;) {
+        bool out = false;
+        while (!have) {
+            const uint32_t i = atomicAdd(&next_read, 1u);
+            if (i >= pool_n) { out = true; break; }
+            lr = pool0 + i;
+            r = sel_pair(sel, lr / nr) * nr + lr % nr;
+            rlen = (int)(rb.off[r + 1] - rb.off[r]);
+            hits = pair_state(cx.state, cx.lay, cx.caps, lr / nr).hits[lr % nr];
+            n = 0; p = 0; ext = 0; blocks = 0;
+            const int need = packed_words(rlen);
+            if (rlen > 0 && need <= pk_words) {
+                const U4 *src = (const U4 *)(so.packed + (uint64_t)r * so.wpad);
+                for (int k = 0; k < need; k += 4) {
+                    const U4 v = src[k >> 2];
+                    pk.w[k * pk.stride] = v.x;
+                    if (k + 1 < need) pk.w[(k + 1) * pk.stride] = v.y;
+                    if (k + 2 < need) pk.w[(k + 2) * pk.stride] = v.z;
+                    if (k + 3 < need) pk.w[(k + 3) * pk.stride] = v.w;
+                }
+                pk.n_code = ((rlen + 15) >> 4) + 1;
+                have = seed_next_start(pk, rlen, p, nm);
+            }
+            if (!have) finish_read();
+        }
+        if (out) break;
+        seed_search(cx.ix, pk, rlen, nm, p, hits, cx.caps.hit_cap, n, ext, blocks);
+        if (!seed_next_start(pk, rlen, p, nm)) { finish_read(); have = false; }
     }
 }
 
@@ -875,7 +894,7 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
         // LDS for the packed reads: words per lane for the longest read x lanes; narrower blocks for long reads
         const int pkw = packed_words(c->rlen_max);
         const int threads = pkw * 256 * 4 <= 48 * 1024 ? 256 : (pkw * 128 * 4 <= 48 * 1024 ? 128 : 64);
-        const unsigned blocks_s = (sel.n * nr + threads - 1) / threads;
+        const unsigned blocks_s = (sel.n * nr + threads * kSeedReadsPerLane - 1) / (threads * kSeedReadsPerLane);
         k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw);
     }
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
