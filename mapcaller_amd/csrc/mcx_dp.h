@@ -27,8 +27,16 @@ constexpr int kDpSpillSeq = 4096;      // spill area reserved for sequences (2 K
 template <int W>
 static __device__ __forceinline__ int lane_shift_up(int v, int carry, int lane)
 {
+    if (W == 1) return carry; // a group of one lane: the neighbour is the lane's own previous column
     int s = __shfl_up(v, 1, W);
     return lane == 0 ? carry : s;
+}
+
+// value held by lane `src` of the W-lane group
+template <int W>
+static __device__ __forceinline__ int group_pick(int v, int src)
+{
+    return W == 1 ? v : __shfl(v, src, W);
 }
 
 // Orders the group's traceback stores before the walking lane's loads.  W = 64: the block is one
@@ -84,7 +92,7 @@ static __device__ int dp_ksw2_core(int qlen, int tlen, const uint8_t *q, const u
             if (W * k <= en) { // uniform over the group
                 const int ox = x[k], ov = v[k], oH = H[k];
                 const int xl = lane_shift_up<W>(ox, cx_, lane), vl = lane_shift_up<W>(ov, cv_, lane), Hl = lane_shift_up<W>(oH, cH_, lane);
-                cx_ = __shfl(ox, W - 1, W); cv_ = __shfl(ov, W - 1, W); cH_ = __shfl(oH, W - 1, W);
+                cx_ = group_pick<W>(ox, W - 1); cv_ = group_pick<W>(ov, W - 1); cH_ = group_pick<W>(oH, W - 1);
                 if (tt == r) { y[k] = 0; u[k] = r ? Q : 0; } // first matrix row (:165)
                 if (tt >= st && tt <= en) {
                     const int qb = q[r - tt], tb = tc[k];
@@ -107,7 +115,7 @@ static __device__ int dp_ksw2_core(int qlen, int tlen, const uint8_t *q, const u
                     b = (int8_t)(b - z);
                     if (a > 0) { x[k] = a; d |= 0x08; } else x[k] = 0;
                     if (b > 0) { y[k] = b; d |= 0x10; } else y[k] = 0;
-                    dir[(int64_t)r * tlen + tt] = (uint8_t)d;
+                    dir[r * tlen + tt] = (uint8_t)d; // (at most 3071 x 1024: 32-bit offsets)
                     // H bookkeeping (:200-239); u8/v8 are unsigned bytes there
                     if (r == 0) H[k] = (int)(uint8_t)v[k] - QE - QE;
                     else if (tt == en) H[k] = en > 0 ? Hl + (int)(uint8_t)u[k] - QE : oH + (int)(uint8_t)v[k] - QE;
@@ -120,7 +128,7 @@ static __device__ int dp_ksw2_core(int qlen, int tlen, const uint8_t *q, const u
         const int kk = (tlen - 1) / W, ll = (tlen - 1) & (W - 1);
         int sc = 0;
 #pragma unroll
-        for (int k = 0; k < K; k++) { const int hv = __shfl(H[k], ll, W); if (k == kk) sc = hv; }
+        for (int k = 0; k < K; k++) { const int hv = group_pick<W>(H[k], ll); if (k == kk) sc = hv; }
         *score = sc;
     }
     dp_sync<W>();
@@ -129,7 +137,7 @@ static __device__ int dp_ksw2_core(int qlen, int tlen, const uint8_t *q, const u
         // ksw_backtrack (:25-68); full band: force_state never fires
         int i = tlen - 1, j = qlen - 1, state = 0;
         while (i >= 0 && j >= 0) {
-            const unsigned d = dir[(int64_t)(i + j) * tlen + i];
+            const unsigned d = dir[(i + j) * tlen + i];
             if (state == 0) state = d & 7;
             else if (!((d >> (state + 2)) & 1)) state = 0;
             if (state == 0) state = d & 7;
@@ -140,7 +148,7 @@ static __device__ int dp_ksw2_core(int qlen, int tlen, const uint8_t *q, const u
         for (; i >= 0; --i) ops[--w] = 'D';
         for (; j >= 0; --j) ops[--w] = 'I';
     }
-    w = __shfl(w, 0, W);
+    w = group_pick<W>(w, 0);
     dp_sync<W>();
     return w;
 }
@@ -172,7 +180,7 @@ static __device__ int dp_nw_core(int m, int n, const uint8_t *q, const uint8_t *
             if (W * k <= en) {
                 const int oR = R[k], oS = S[k], oT = T[k];
                 const int Rl = lane_shift_up<W>(oR, cR, lane), Sl = lane_shift_up<W>(oS, cS, lane);
-                cR = __shfl(oR, W - 1, W); cS = __shfl(oS, W - 1, W);
+                cR = group_pick<W>(oR, W - 1); cS = group_pick<W>(oS, W - 1);
                 if (b >= st && b <= en) {
                     const int a = r - b;
                     // s(a-1, b-1): the left S this lane received one diagonal ago, or the
@@ -188,7 +196,7 @@ static __device__ int dp_nw_core(int m, int n, const uint8_t *q, const uint8_t *
                     int s = dg > rr ? dg : rr;
                     s = s > tt ? s : tt;
                     R[k] = rr; T[k] = tt; S[k] = s;
-                    dir[(int64_t)r * n + b] = (uint8_t)((s == rr ? 1 : 0) | (s == tt ? 2 : 0));
+                    dir[r * n + b] = (uint8_t)((s == rr ? 1 : 0) | (s == tt ? 2 : 0));
                 }
                 Sdiag[k] = Sl; // s(a-1, b-1) of the next diagonal
             }
@@ -198,7 +206,7 @@ static __device__ int dp_nw_core(int m, int n, const uint8_t *q, const uint8_t *
         const int kk = (n - 1) / W, ll = (n - 1) & (W - 1);
         int sc = 0;
 #pragma unroll
-        for (int k = 0; k < K; k++) { const int hv = __shfl(S[k], ll, W); if (k == kk) sc = hv; }
+        for (int k = 0; k < K; k++) { const int hv = group_pick<W>(S[k], ll); if (k == kk) sc = hv; }
         *score = sc;
     }
     dp_sync<W>();
@@ -209,13 +217,13 @@ static __device__ int dp_nw_core(int m, int n, const uint8_t *q, const uint8_t *
             unsigned d;
             if (i == 0) d = 1;       // s[0][j] == r[0][j]
             else if (j == 0) d = 2;  // s[i][0] == t[i][0]
-            else d = dir[(int64_t)(i + j - 2) * n + (j - 1)];
+            else d = dir[(i + j - 2) * n + (j - 1)];
             if (d & 1) { ops[--w] = 'D'; j--; }       // '-' inserted into s1 (read string)
             else if (d & 2) { ops[--w] = 'I'; i--; }  // '-' inserted into s2 (genome string)
             else { ops[--w] = 'M'; i--; j--; }
         }
     }
-    w = __shfl(w, 0, W);
+    w = group_pick<W>(w, 0);
     dp_sync<W>();
     return w;
 }
@@ -226,7 +234,12 @@ static __device__ __forceinline__ int dp_core(bool nw, int qlen, int tlen, const
     return nw ? dp_nw_core<K, W>(qlen, tlen, b.q, b.t, b.dir, ops, score) : dp_ksw2_core<K, W>(qlen, tlen, b.q, b.t, b.dir, ops, score);
 }
 
-// small problems (the bulk: median 3 x 3, p90 15 x 16): 16 lanes each, four per wave
+// tiny problems (up to 8 x 8, most of the bulk: median 3 x 3): one lane each — the same recurrences with
+// K = 8 columns in the lane's registers and a group width of 1, sixty-four problems per wave
+constexpr int kDpTiny = 8;
+constexpr int kDpTinyLds = 2 * kDpTiny + (2 * kDpTiny - 1) * kDpTiny; // q(8) + t(8) + dir
+
+// small problems (p90 15 x 16): 16 lanes each, four per wave
 constexpr int kDpSmallT = 16, kDpSmallQ = 32;
 constexpr int kDpSmallLds = 64 + (kDpSmallQ + kDpSmallT - 1) * kDpSmallT; // q(32) + t(16) + pad + dir
 

@@ -549,7 +549,8 @@ __global__ void __launch_bounds__(kRescueThreads) k_rescue(Ctx cx, ReadBatch rb,
     }
 }
 
-struct JobSinks { JobSink s[4]; };
+constexpr int kDpClasses = 5; // dp_class 0..3 + 4: the tiny ones of class 0
+struct JobSinks { JobSink s[kDpClasses]; };
 
 // fragment lists + DP problems of every pair; the problems are appended to one list per size
 // class (mcx_glue.h dp_class) with one atomic per wave and class
@@ -564,18 +565,19 @@ __global__ void __launch_bounds__(256) k_build(Ctx cx, ReadBatch rb, PairSel sel
         make_reads(cx, rb, sel_pair(sel, local), rd);
         nj = stage_build(cx, local, rd);
     }
-    uint32_t per_class[4] = {0, 0, 0, 0}, my_cells = 0, bad = 0;
+    auto job_class = [](const DpJob &j) { const int c = dp_class(j.rLen, j.gLen); return (c == 0 && j.rLen <= kDpTiny && j.gLen <= kDpTiny) ? 4 : c; };
+    uint32_t per_class[kDpClasses] = {0, 0, 0, 0, 0}, my_cells = 0, bad = 0;
     for (int k = 0; k < nj; k++) {
         const DpJob j = pair_job(cx, local, k);
-        const int c = dp_class(j.rLen, j.gLen);
+        const int c = job_class(j);
         if (c < 0) bad++; else { per_class[c]++; my_cells += (uint32_t)(j.rLen * j.gLen); }
     }
-    uint32_t base[4];
+    uint32_t base[kDpClasses];
 #pragma unroll
-    for (int c = 0; c < 4; c++) base[c] = wave_reserve(sinks.s[c].count, per_class[c]);
+    for (int c = 0; c < kDpClasses; c++) base[c] = wave_reserve(sinks.s[c].count, per_class[c]);
     for (int k = 0; k < nj; k++) {
         const DpJob j = pair_job(cx, local, k);
-        const int c = dp_class(j.rLen, j.gLen);
+        const int c = job_class(j);
         if (c < 0) continue;
         const uint32_t at = base[c]++;
         if (at < sinks.s[c].cap) sinks.s[c].jobs[at] = j;
@@ -590,38 +592,81 @@ __global__ void __launch_bounds__(256) k_build(Ctx cx, ReadBatch rb, PairSel sel
 template <int K> struct DpLds { static constexpr int seq = kDpLdsSeq, dir = kDpLdsDir; };
 template <> struct DpLds<1> { static constexpr int seq = 512, dir = 4096; }; // targets <= 64: e.g. 48 x 48 fits
 
+// one problem on the W lanes of a group (W = 64: the wave; 32: a half wave): stage the two strings,
+// sweep, trace back, hand the column string to the fragment
+template <int K, int W>
+static __device__ __forceinline__ void dp_run_job(const Ctx &cx, const JobSink &sink, uint32_t jb, const DpJob &job, const ReadBatch &rb,
+                                                  const PairSel &sel, const DpBuf &b)
+{
+    const int nr = cx.pm.paired ? 2 : 1;
+    const int lane = threadIdx.x & (W - 1);
+    const uint32_t read = sel_pair(sel, job.pair) * nr + job.slot;
+    ReadRef rd;
+    rd.ascii = rb.bases + rb.off[read]; rd.rlen = (int)(rb.off[read + 1] - rb.off[read]); rd.flipped = (cx.pm.paired && job.slot == 1) ? 1 : 0;
+    // q = read fragment, t = genome fragment; both reversed on the reverse strand (the
+    // reference also complements both, which no comparison can see)
+    for (int i = lane; i < job.rLen; i += W) b.q[i] = (uint8_t)read_code(rd, job.rev ? job.rPos + job.rLen - 1 - i : job.rPos + i);
+    for (int i = lane; i < job.gLen; i += W) b.t[i] = (uint8_t)ref_code(cx.ix, job.rev ? job.gPos + job.gLen - 1 - i : job.gPos + i);
+    dp_sync<W>();
+    PairState st = pair_state(cx.state, cx.lay, cx.caps, job.pair);
+    int score = 0;
+    const int w = dp_core<K, W>(cx.pm.use_nw != 0, job.rLen, job.gLen, b, st.ops + job.ops_off, &score);
+    if (lane == 0) {
+        Frag f = st.frags[job.frag]; // one fetch, one store (the fields share two words)
+        f.ops_off = job.ops_off + w;
+        f.ops_len = job.rLen + job.gLen - w;
+        st.frags[job.frag] = f;
+        sink.jobs[jb].score = score;
+    }
+    dp_sync<W>();
+}
+
+// K = 1 (targets <= 64): two neighbouring jobs share a wave, 32 lanes each, when both have targets <= 32
+// — the class is bound by vector instructions issued, and most of its targets are that short
+constexpr int kDpHalfT = 32, kDpHalfQ = 64, kDpHalfDir = (kDpHalfQ + kDpHalfT - 1) * kDpHalfT, kDpHalfLds = kDpHalfQ + kDpHalfT + kDpHalfDir + 32;
+
 template <int K>
 __global__ void __launch_bounds__(64) k_dp_sel(Ctx cx, JobSink sink, ReadBatch rb, PairSel sel, uint8_t *scratch,
                                                uint64_t scratch_stride)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[DpLds<K>::seq + DpLds<K>::dir];
+    constexpr int kWhole = DpLds<K>::seq + DpLds<K>::dir;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[(K == 1 && 2 * kDpHalfLds > kWhole) ? 2 * kDpHalfLds : kWhole];
     uint8_t *spill = scratch + (uint64_t)blockIdx.x * scratch_stride;
-    const int nr = cx.pm.paired ? 2 : 1;
-    const int lane = threadIdx.x;
     const uint32_t n = min(*sink.count, sink.cap);
+    if (K == 1) {
+        for (uint32_t jb = blockIdx.x * 2; jb < n; jb += gridDim.x * 2) {
+            const bool two = jb + 1 < n;
+            const DpJob a = sink.jobs[jb], c = sink.jobs[two ? jb + 1 : jb];
+            auto fits = [](const DpJob &j) { return j.gLen <= kDpHalfT && j.rLen <= kDpHalfQ; };
+            if (fits(a) && fits(c)) {
+                const int half = threadIdx.x >> 5;
+                if (half == 0 || two) {
+                    uint8_t *mine = lds + half * kDpHalfLds;
+                    DpBuf b; b.q = mine; b.t = mine + kDpHalfQ; b.dir = mine + kDpHalfQ + kDpHalfT;
+                    dp_run_job<K, 32>(cx, sink, jb + half, half ? c : a, rb, sel, b);
+                }
+            } else {
+                dp_run_job<K, 64>(cx, sink, jb, a, rb, sel, dp_buffers(a.rLen, a.gLen, lds, spill, DpLds<K>::seq, DpLds<K>::dir));
+                if (two) dp_run_job<K, 64>(cx, sink, jb + 1, c, rb, sel, dp_buffers(c.rLen, c.gLen, lds, spill, DpLds<K>::seq, DpLds<K>::dir));
+            }
+        }
+        return;
+    }
     for (uint32_t jb = blockIdx.x; jb < n; jb += gridDim.x) {
         const DpJob job = sink.jobs[jb];
-        const uint32_t read = sel_pair(sel, job.pair) * nr + job.slot;
-        ReadRef rd;
-        rd.ascii = rb.bases + rb.off[read]; rd.rlen = (int)(rb.off[read + 1] - rb.off[read]); rd.flipped = (cx.pm.paired && job.slot == 1) ? 1 : 0;
-        const DpBuf b = dp_buffers(job.rLen, job.gLen, lds, spill, DpLds<K>::seq, DpLds<K>::dir);
-        // q = read fragment, t = genome fragment; both reversed on the reverse strand (the
-        // reference also complements both, which no comparison can see)
-        for (int i = lane; i < job.rLen; i += 64) b.q[i] = (uint8_t)read_code(rd, job.rev ? job.rPos + job.rLen - 1 - i : job.rPos + i);
-        for (int i = lane; i < job.gLen; i += 64) b.t[i] = (uint8_t)ref_code(cx.ix, job.rev ? job.gPos + job.gLen - 1 - i : job.gPos + i);
-        __syncthreads();
-        PairState st = pair_state(cx.state, cx.lay, cx.caps, job.pair);
-        int score = 0;
-        const int w = dp_core<K, 64>(cx.pm.use_nw != 0, job.rLen, job.gLen, b, st.ops + job.ops_off, &score);
-        if (lane == 0) {
-            Frag f = st.frags[job.frag]; // one fetch, one store (the fields share two words)
-            f.ops_off = job.ops_off + w;
-            f.ops_len = job.rLen + job.gLen - w;
-            st.frags[job.frag] = f;
-            sink.jobs[jb].score = score;
-        }
-        __syncthreads();
+        dp_run_job<K, 64>(cx, sink, jb, job, rb, sel, dp_buffers(job.rLen, job.gLen, lds, spill, DpLds<K>::seq, DpLds<K>::dir));
     }
+}
+
+// one tiny problem per lane (mcx_dp.h kDpTiny)
+__global__ void __launch_bounds__(256) k_dp_tiny(Ctx cx, JobSink sink, ReadBatch rb, PairSel sel)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[256 * kDpTinyLds];
+    uint8_t *mine = lds + threadIdx.x * kDpTinyLds;
+    DpBuf b; b.q = mine; b.t = mine + kDpTiny; b.dir = mine + 2 * kDpTiny;
+    const uint32_t n = min(*sink.count, sink.cap);
+    for (uint32_t jb = blockIdx.x * blockDim.x + threadIdx.x; jb < n; jb += gridDim.x * blockDim.x)
+        dp_run_job<kDpTiny, 1>(cx, sink, jb, sink.jobs[jb], rb, sel, b);
 }
 
 // four small problems per wave, sixteen per block; each 16-lane group owns 800 bytes of LDS
@@ -693,7 +738,7 @@ struct Tier {
     uint32_t max_pairs = 0;
 };
 
-enum { CNT_TASKS = 0, CNT_RESCUE, CNT_JOB0, CNT_JOB1, CNT_JOB2, CNT_JOB3, CNT_OV, CNT_LF, CNT_CELLS, CNT_UNSUP, CNT_N };
+enum { CNT_TASKS = 0, CNT_RESCUE, CNT_JOB0, CNT_JOB1, CNT_JOB2, CNT_JOB3, CNT_JOB4, CNT_OV, CNT_LF, CNT_CELLS, CNT_UNSUP, CNT_N };
 
 struct mcx_ctx {
     const mcx_index *idx = nullptr;
@@ -704,13 +749,13 @@ struct mcx_ctx {
     uint64_t max_reads = 0, max_bases = 0;
     int rlen_max = 256;
     uint2 *d_tasks = nullptr; uint32_t task_cap = 0;
-    DpJob *d_jobs[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t job_cap[4] = {0, 0, 0, 0};
+    DpJob *d_jobs[kDpClasses] = {nullptr, nullptr, nullptr, nullptr, nullptr}; uint32_t job_cap[kDpClasses] = {0, 0, 0, 0, 0};
     uint32_t *d_cnt = nullptr;   // CNT_N counters
     uint32_t *h_cnt = nullptr;   // pinned mirror
     uint32_t *d_rescue = nullptr; uint32_t rescue_cap = 0;
     uint32_t *d_kscratch = nullptr; uint32_t k_threads = 0, k_per_thread = 0;
     hipEvent_t ev_pack[2] = {nullptr, nullptr};
-    hipStream_t dp_stream[3] = {nullptr, nullptr, nullptr}; hipEvent_t dp_fork = nullptr, dp_join[3] = {nullptr, nullptr, nullptr};
+    hipStream_t dp_stream[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t dp_fork = nullptr, dp_join[4] = {nullptr, nullptr, nullptr, nullptr};
     uint8_t *d_dp_scratch[3] = {nullptr, nullptr, nullptr}; uint64_t dp_stride[3] = {0, 0, 0}; uint32_t dp_blocks[3] = {0, 0, 0};
     uint32_t *d_ov = nullptr; uint32_t ov_cap = 0;
     uint32_t *d_sel_ids = nullptr; int32_t *d_est = nullptr;
@@ -778,7 +823,7 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
     c->max_bases = c->max_reads * (uint64_t)c->rlen_max;
     HIP_TRY(hipSetDevice(idx->device));
     HIP_TRY(hipStreamCreate(&c->stream));
-    for (int k = 0; k < 3; k++) { HIP_TRY(hipStreamCreateWithFlags(&c->dp_stream[k], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&c->dp_join[k], hipEventDisableTiming)); }
+    for (int k = 0; k < 4; k++) { HIP_TRY(hipStreamCreateWithFlags(&c->dp_stream[k], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&c->dp_join[k], hipEventDisableTiming)); }
     HIP_TRY(hipEventCreateWithFlags(&c->dp_fork, hipEventDisableTiming));
     for (auto &e : c->ev_pack) HIP_TRY(hipEventCreate(&e));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
@@ -790,8 +835,8 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
         if ((rc = dmalloc(&c->tier[t].state, (size_t)c->tier[t].lay.stride * c->tier[t].max_pairs))) return rc;
     c->task_cap = (uint32_t)std::min<uint64_t>(c->max_reads * 24, 0x7fffffffu);
     if ((rc = dmalloc(&c->d_tasks, c->task_cap))) return rc;
-    for (int k = 0; k < 4; k++) {
-        c->job_cap[k] = (uint32_t)std::min<uint64_t>(c->max_reads * (k == 0 ? 4 : (k == 1 ? 2 : 1)) + 1024, 0x7fffffffu);
+    for (int k = 0; k < kDpClasses; k++) {
+        c->job_cap[k] = (uint32_t)std::min<uint64_t>(c->max_reads * ((k == 0 || k == 4) ? 4 : (k == 1 ? 2 : 1)) + 1024, 0x7fffffffu);
         if ((rc = dmalloc(&c->d_jobs[k], c->job_cap[k]))) return rc;
     }
     if ((rc = dmalloc(&c->d_cnt, CNT_N))) return rc;
@@ -840,7 +885,7 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
 extern "C" void mcx_ctx_free(mcx_ctx *c)
 {
     if (!c) return;
-    void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3],
+    void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3], c->d_jobs[4],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
                  c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
                  c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_packed, c->d_cig_ext, c->d_cig_ext_n};
@@ -849,7 +894,7 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     if (c->h_pout) (void)hipHostFree(c->h_pout);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    for (int k = 0; k < 3; k++) { if (c->dp_stream[k]) (void)hipStreamDestroy(c->dp_stream[k]); if (c->dp_join[k]) (void)hipEventDestroy(c->dp_join[k]); }
+    for (int k = 0; k < 4; k++) { if (c->dp_stream[k]) (void)hipStreamDestroy(c->dp_stream[k]); if (c->dp_join[k]) (void)hipEventDestroy(c->dp_join[k]); }
     if (c->dp_fork) (void)hipEventDestroy(c->dp_fork);
     for (auto &e : c->ev_pack) if (e) (void)hipEventDestroy(e);
     delete c;
@@ -886,7 +931,7 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     so.packed = c->d_packed; so.wpad = c->wpad;
     RescueList rl; rl.ids = c->d_rescue; rl.n = c->d_cnt + CNT_RESCUE; rl.cap = c->rescue_cap;
     JobSinks sinks;
-    for (int k = 0; k < 4; k++) { sinks.s[k].jobs = c->d_jobs[k]; sinks.s[k].count = c->d_cnt + CNT_JOB0 + k; sinks.s[k].cap = c->job_cap[k]; }
+    for (int k = 0; k < kDpClasses; k++) { sinks.s[k].jobs = c->d_jobs[k]; sinks.s[k].count = c->d_cnt + CNT_JOB0 + k; sinks.s[k].cap = c->job_cap[k]; }
     const unsigned pb = (sel.n + 255) / 256;
     int e = 0;
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
@@ -909,12 +954,13 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     // the four size classes work on disjoint job lists and are each bound by latency at modest
     // occupancy: side streams let them share the chip instead of queueing behind one another
     HIP_TRY(hipEventRecord(c->dp_fork, s));
-    for (int k = 0; k < 3; k++) HIP_TRY(hipStreamWaitEvent(c->dp_stream[k], c->dp_fork, 0));
+    for (int k = 0; k < 4; k++) HIP_TRY(hipStreamWaitEvent(c->dp_stream[k], c->dp_fork, 0));
     k_dp_sel<1><<<c->dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, c->d_dp_scratch[0], c->dp_stride[0]);
     k_dp_small<<<2560, 256, 0, c->dp_stream[0]>>>(cx, sinks.s[0], rb, sel);
+    k_dp_tiny<<<2048, 256, 0, c->dp_stream[3]>>>(cx, sinks.s[4], rb, sel);
     k_dp_sel<4><<<c->dp_blocks[1], 64, 0, c->dp_stream[1]>>>(cx, sinks.s[2], rb, sel, c->d_dp_scratch[1], c->dp_stride[1]);
     k_dp_sel<16><<<c->dp_blocks[2], 64, 0, c->dp_stream[2]>>>(cx, sinks.s[3], rb, sel, c->d_dp_scratch[2], c->dp_stride[2]);
-    for (int k = 0; k < 3; k++) { HIP_TRY(hipEventRecord(c->dp_join[k], c->dp_stream[k])); HIP_TRY(hipStreamWaitEvent(s, c->dp_join[k], 0)); }
+    for (int k = 0; k < 4; k++) { HIP_TRY(hipEventRecord(c->dp_join[k], c->dp_stream[k])); HIP_TRY(hipStreamWaitEvent(s, c->dp_join[k], 0)); }
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
     k_finish<<<pb, 256, 0, s>>>(cx, rb, sel, d_recs, d_cig, c->d_pout, c->d_ov, c->d_cnt + CNT_OV, c->ov_cap);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
@@ -924,13 +970,13 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     const uint32_t *n = c->h_cnt;
     // a work list that ran over: nothing of this pass is kept, the caller maps the selection in two halves
     if (n[CNT_TASKS] > c->task_cap || n[CNT_RESCUE] > c->rescue_cap) return kListOverflow;
-    for (int k = 0; k < 4; k++) if (n[CNT_JOB0 + k] > c->job_cap[k]) return kListOverflow;
+    for (int k = 0; k < kDpClasses; k++) if (n[CNT_JOB0 + k] > c->job_cap[k]) return kListOverflow;
     if (n[CNT_UNSUP]) return fail(MCX_ERR_UNSUPPORTED, "a gapped fragment exceeds 2048 x 1024 cells per side");
     if (timing && getenv("MCX_TIMING"))
-        fprintf(stderr, "[run_pairs] pairs %u: sa tasks %u, rescue pairs %u, dp jobs by class %u %u %u %u, cells %u, overflow pairs %u\n", sel.n, n[CNT_TASKS],
-                n[CNT_RESCUE], n[CNT_JOB0], n[CNT_JOB1], n[CNT_JOB2], n[CNT_JOB3], n[CNT_CELLS], n[CNT_OV]);
+        fprintf(stderr, "[run_pairs] pairs %u: sa tasks %u, rescue pairs %u, dp jobs by class (tiny) %u %u %u %u %u, cells %u, overflow pairs %u\n", sel.n, n[CNT_TASKS],
+                n[CNT_RESCUE], n[CNT_JOB4], n[CNT_JOB0], n[CNT_JOB1], n[CNT_JOB2], n[CNT_JOB3], n[CNT_CELLS], n[CNT_OV]);
     if (stats) {
-        stats->dp_jobs += (int64_t)n[CNT_JOB0] + n[CNT_JOB1] + n[CNT_JOB2] + n[CNT_JOB3];
+        stats->dp_jobs += (int64_t)n[CNT_JOB0] + n[CNT_JOB1] + n[CNT_JOB2] + n[CNT_JOB3] + n[CNT_JOB4];
         stats->dp_cells += n[CNT_CELLS];
         if (timing) {
             float ms[8];
