@@ -252,7 +252,7 @@ static inline MCX_HD void ktab_entry(const IndexView &ix, uint32_t idx, int K, u
 }
 
 // set in Hit.len by seed_read for hits whose text position is already known (cleared by the caller
-// when it builds the SA task list)
+// when it builds the SA task list); not used when the index holds the full suffix array
 constexpr int32_t kHitResolved = 1 << 30;
 
 // ---- packed views for the seeding walk ------------------------------------------------------
@@ -448,11 +448,14 @@ static inline MCX_HD void seed_search(const IndexView &ix, const PackedRead &pk,
         const int len = p - start;
         ext_steps += len;
         if (len >= kMinSeedLength && x2 <= (uint64_t)kOccThr) {
+            // with every suffix-array entry in memory a row resolves with one fetch, here and now: all hits
+            // then leave as text positions, unflagged, and nothing is left for the SA pass
+            const bool direct = ix.sa_full != nullptr;
             if (x2 == 1) {
-                if (n_hits < cap) { Hit h; h.gPos = tpos; h.rPos = start; h.len = len | kHitResolved; hits[n_hits] = h; }
+                if (n_hits < cap) { Hit h; h.gPos = tpos; h.rPos = start; h.len = direct ? len : (len | kHitResolved); hits[n_hits] = h; }
                 n_hits++;
             } else for (uint64_t i = 0; i < x2; i++) {
-                if (n_hits < cap) { Hit h; h.gPos = (int64_t)(x0 + i); h.rPos = start; h.len = len; hits[n_hits] = h; }
+                if (n_hits < cap) { Hit h; h.gPos = direct ? (int64_t)ix.sa_full[x0 + i] : (int64_t)(x0 + i); h.rPos = start; h.len = len; hits[n_hits] = h; }
                 n_hits++;
             }
         }

@@ -454,6 +454,7 @@ __global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel,
         PairState st = pair_state(cx.state, cx.lay, cx.caps, lr / nr);
         st.hdr->n_hits[lr % nr] = n;
         so.read_ext[r] = (uint32_t)ext; so.read_blocks[r] = (uint32_t)blocks | ((uint32_t)n << 20); // (blocks < 2^20; n < 2^12)
+        if (cx.ix.sa_full) return; // every hit already carries its text position (seed_search)
         const int keep = n <= cx.caps.hit_cap ? n : 0; // overflowing reads are re-run in the next tier
         int todo = 0;
         for (int i = 0; i < keep; i++) if (!(hits[i].len & kHitResolved)) todo++;
@@ -549,7 +550,7 @@ __global__ void __launch_bounds__(kRescueThreads) k_rescue(Ctx cx, ReadBatch rb,
     }
 }
 
-constexpr int kDpClasses = 5; // dp_class 0..3 + 4: the tiny ones of class 0
+constexpr int kDpClasses = 6; // dp_class 0..3 + 4: the tiny ones of class 0, 5: the short ones of class 1 (k_dp_half)
 struct JobSinks { JobSink s[kDpClasses]; };
 
 // fragment lists + DP problems of every pair; the problems are appended to one list per size
@@ -565,8 +566,8 @@ __global__ void __launch_bounds__(256) k_build(Ctx cx, ReadBatch rb, PairSel sel
         make_reads(cx, rb, sel_pair(sel, local), rd);
         nj = stage_build(cx, local, rd);
     }
-    auto job_class = [](const DpJob &j) { const int c = dp_class(j.rLen, j.gLen); return (c == 0 && j.rLen <= kDpTiny && j.gLen <= kDpTiny) ? 4 : c; };
-    uint32_t per_class[kDpClasses] = {0, 0, 0, 0, 0}, my_cells = 0, bad = 0;
+    auto job_class = [](const DpJob &j) { const int c = dp_class(j.rLen, j.gLen); return (c == 0 && j.rLen <= kDpTiny && j.gLen <= kDpTiny) ? 4 : ((c == 1 && j.gLen <= 32 && j.rLen <= 64) ? 5 : c); };
+    uint32_t per_class[kDpClasses] = {0, 0, 0, 0, 0, 0}, my_cells = 0, bad = 0;
     for (int k = 0; k < nj; k++) {
         const DpJob j = pair_job(cx, local, k);
         const int c = job_class(j);
@@ -621,41 +622,32 @@ static __device__ __forceinline__ void dp_run_job(const Ctx &cx, const JobSink &
     dp_sync<W>();
 }
 
-// K = 1 (targets <= 64): two neighbouring jobs share a wave, 32 lanes each, when both have targets <= 32
-// — the class is bound by vector instructions issued, and most of its targets are that short
-constexpr int kDpHalfT = 32, kDpHalfQ = 64, kDpHalfDir = (kDpHalfQ + kDpHalfT - 1) * kDpHalfT, kDpHalfLds = kDpHalfQ + kDpHalfT + kDpHalfDir + 32;
-
 template <int K>
 __global__ void __launch_bounds__(64) k_dp_sel(Ctx cx, JobSink sink, ReadBatch rb, PairSel sel, uint8_t *scratch,
                                                uint64_t scratch_stride)
 {
-    constexpr int kWhole = DpLds<K>::seq + DpLds<K>::dir;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[(K == 1 && 2 * kDpHalfLds > kWhole) ? 2 * kDpHalfLds : kWhole];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[DpLds<K>::seq + DpLds<K>::dir];
     uint8_t *spill = scratch + (uint64_t)blockIdx.x * scratch_stride;
     const uint32_t n = min(*sink.count, sink.cap);
-    if (K == 1) {
-        for (uint32_t jb = blockIdx.x * 2; jb < n; jb += gridDim.x * 2) {
-            const bool two = jb + 1 < n;
-            const DpJob a = sink.jobs[jb], c = sink.jobs[two ? jb + 1 : jb];
-            auto fits = [](const DpJob &j) { return j.gLen <= kDpHalfT && j.rLen <= kDpHalfQ; };
-            if (fits(a) && fits(c)) {
-                const int half = threadIdx.x >> 5;
-                if (half == 0 || two) {
-                    uint8_t *mine = lds + half * kDpHalfLds;
-                    DpBuf b; b.q = mine; b.t = mine + kDpHalfQ; b.dir = mine + kDpHalfQ + kDpHalfT;
-                    dp_run_job<K, 32>(cx, sink, jb + half, half ? c : a, rb, sel, b);
-                }
-            } else {
-                dp_run_job<K, 64>(cx, sink, jb, a, rb, sel, dp_buffers(a.rLen, a.gLen, lds, spill, DpLds<K>::seq, DpLds<K>::dir));
-                if (two) dp_run_job<K, 64>(cx, sink, jb + 1, c, rb, sel, dp_buffers(c.rLen, c.gLen, lds, spill, DpLds<K>::seq, DpLds<K>::dir));
-            }
-        }
-        return;
-    }
     for (uint32_t jb = blockIdx.x; jb < n; jb += gridDim.x) {
         const DpJob job = sink.jobs[jb];
         dp_run_job<K, 64>(cx, sink, jb, job, rb, sel, dp_buffers(job.rLen, job.gLen, lds, spill, DpLds<K>::seq, DpLds<K>::dir));
     }
+}
+
+// targets <= 32 (queries <= 64) of the one-column-per-lane class: two problems per wave, 32 lanes each — the
+// class is bound by vector instructions issued, and most of its targets are that short
+constexpr int kDpHalfT = 32, kDpHalfQ = 64, kDpHalfLds = kDpHalfQ + kDpHalfT + (kDpHalfQ + kDpHalfT - 1) * kDpHalfT + 32;
+
+__global__ void __launch_bounds__(256) k_dp_half(Ctx cx, JobSink sink, ReadBatch rb, PairSel sel)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[8 * kDpHalfLds];
+    const int group = threadIdx.x >> 5;
+    uint8_t *mine = lds + group * kDpHalfLds;
+    DpBuf b; b.q = mine; b.t = mine + kDpHalfQ; b.dir = mine + kDpHalfQ + kDpHalfT;
+    const uint32_t n = min(*sink.count, sink.cap);
+    for (uint32_t jb = blockIdx.x * 8 + group; jb < n; jb += gridDim.x * 8)
+        dp_run_job<1, 32>(cx, sink, jb, sink.jobs[jb], rb, sel, b);
 }
 
 // one tiny problem per lane (mcx_dp.h kDpTiny)
@@ -738,7 +730,11 @@ struct Tier {
     uint32_t max_pairs = 0;
 };
 
-enum { CNT_TASKS = 0, CNT_RESCUE, CNT_JOB0, CNT_JOB1, CNT_JOB2, CNT_JOB3, CNT_JOB4, CNT_OV, CNT_LF, CNT_CELLS, CNT_UNSUP, CNT_N };
+// work-list counters, one per 256 bytes: their atomics then run in different L2 channels instead of queueing on one line
+constexpr int kCntPad = 64;
+enum { CNT_TASKS = 0, CNT_RESCUE = 1 * kCntPad, CNT_JOB0 = 2 * kCntPad, CNT_JOB1 = 3 * kCntPad, CNT_JOB2 = 4 * kCntPad, CNT_JOB3 = 5 * kCntPad,
+       CNT_JOB4 = 6 * kCntPad, CNT_JOB5 = 7 * kCntPad, CNT_OV = 8 * kCntPad, CNT_LF = 9 * kCntPad, CNT_CELLS = 10 * kCntPad, CNT_UNSUP = 11 * kCntPad,
+       CNT_N = 12 * kCntPad };
 
 struct mcx_ctx {
     const mcx_index *idx = nullptr;
@@ -749,13 +745,13 @@ struct mcx_ctx {
     uint64_t max_reads = 0, max_bases = 0;
     int rlen_max = 256;
     uint2 *d_tasks = nullptr; uint32_t task_cap = 0;
-    DpJob *d_jobs[kDpClasses] = {nullptr, nullptr, nullptr, nullptr, nullptr}; uint32_t job_cap[kDpClasses] = {0, 0, 0, 0, 0};
+    DpJob *d_jobs[kDpClasses] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; uint32_t job_cap[kDpClasses] = {0, 0, 0, 0, 0, 0};
     uint32_t *d_cnt = nullptr;   // CNT_N counters
     uint32_t *h_cnt = nullptr;   // pinned mirror
     uint32_t *d_rescue = nullptr; uint32_t rescue_cap = 0;
     uint32_t *d_kscratch = nullptr; uint32_t k_threads = 0, k_per_thread = 0;
     hipEvent_t ev_pack[2] = {nullptr, nullptr};
-    hipStream_t dp_stream[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t dp_fork = nullptr, dp_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t dp_stream[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t dp_fork = nullptr, dp_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     uint8_t *d_dp_scratch[3] = {nullptr, nullptr, nullptr}; uint64_t dp_stride[3] = {0, 0, 0}; uint32_t dp_blocks[3] = {0, 0, 0};
     uint32_t *d_ov = nullptr; uint32_t ov_cap = 0;
     uint32_t *d_sel_ids = nullptr; int32_t *d_est = nullptr;
@@ -823,7 +819,7 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
     c->max_bases = c->max_reads * (uint64_t)c->rlen_max;
     HIP_TRY(hipSetDevice(idx->device));
     HIP_TRY(hipStreamCreate(&c->stream));
-    for (int k = 0; k < 4; k++) { HIP_TRY(hipStreamCreateWithFlags(&c->dp_stream[k], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&c->dp_join[k], hipEventDisableTiming)); }
+    for (int k = 0; k < 5; k++) { HIP_TRY(hipStreamCreateWithFlags(&c->dp_stream[k], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&c->dp_join[k], hipEventDisableTiming)); }
     HIP_TRY(hipEventCreateWithFlags(&c->dp_fork, hipEventDisableTiming));
     for (auto &e : c->ev_pack) HIP_TRY(hipEventCreate(&e));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
@@ -836,7 +832,7 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
     c->task_cap = (uint32_t)std::min<uint64_t>(c->max_reads * 24, 0x7fffffffu);
     if ((rc = dmalloc(&c->d_tasks, c->task_cap))) return rc;
     for (int k = 0; k < kDpClasses; k++) {
-        c->job_cap[k] = (uint32_t)std::min<uint64_t>(c->max_reads * ((k == 0 || k == 4) ? 4 : (k == 1 ? 2 : 1)) + 1024, 0x7fffffffu);
+        c->job_cap[k] = (uint32_t)std::min<uint64_t>(c->max_reads * ((k == 0 || k == 4) ? 4 : ((k == 1 || k == 5) ? 2 : 1)) + 1024, 0x7fffffffu);
         if ((rc = dmalloc(&c->d_jobs[k], c->job_cap[k]))) return rc;
     }
     if ((rc = dmalloc(&c->d_cnt, CNT_N))) return rc;
@@ -885,7 +881,7 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
 extern "C" void mcx_ctx_free(mcx_ctx *c)
 {
     if (!c) return;
-    void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3], c->d_jobs[4],
+    void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3], c->d_jobs[4], c->d_jobs[5],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
                  c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
                  c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_packed, c->d_cig_ext, c->d_cig_ext_n};
@@ -894,7 +890,7 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     if (c->h_pout) (void)hipHostFree(c->h_pout);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    for (int k = 0; k < 4; k++) { if (c->dp_stream[k]) (void)hipStreamDestroy(c->dp_stream[k]); if (c->dp_join[k]) (void)hipEventDestroy(c->dp_join[k]); }
+    for (int k = 0; k < 5; k++) { if (c->dp_stream[k]) (void)hipStreamDestroy(c->dp_stream[k]); if (c->dp_join[k]) (void)hipEventDestroy(c->dp_join[k]); }
     if (c->dp_fork) (void)hipEventDestroy(c->dp_fork);
     for (auto &e : c->ev_pack) if (e) (void)hipEventDestroy(e);
     delete c;
@@ -931,7 +927,7 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     so.packed = c->d_packed; so.wpad = c->wpad;
     RescueList rl; rl.ids = c->d_rescue; rl.n = c->d_cnt + CNT_RESCUE; rl.cap = c->rescue_cap;
     JobSinks sinks;
-    for (int k = 0; k < kDpClasses; k++) { sinks.s[k].jobs = c->d_jobs[k]; sinks.s[k].count = c->d_cnt + CNT_JOB0 + k; sinks.s[k].cap = c->job_cap[k]; }
+    for (int k = 0; k < kDpClasses; k++) { sinks.s[k].jobs = c->d_jobs[k]; sinks.s[k].count = c->d_cnt + CNT_JOB0 + k * kCntPad; sinks.s[k].cap = c->job_cap[k]; }
     const unsigned pb = (sel.n + 255) / 256;
     int e = 0;
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
@@ -954,13 +950,14 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     // the four size classes work on disjoint job lists and are each bound by latency at modest
     // occupancy: side streams let them share the chip instead of queueing behind one another
     HIP_TRY(hipEventRecord(c->dp_fork, s));
-    for (int k = 0; k < 4; k++) HIP_TRY(hipStreamWaitEvent(c->dp_stream[k], c->dp_fork, 0));
+    for (int k = 0; k < 5; k++) HIP_TRY(hipStreamWaitEvent(c->dp_stream[k], c->dp_fork, 0));
     k_dp_sel<1><<<c->dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, c->d_dp_scratch[0], c->dp_stride[0]);
     k_dp_small<<<2560, 256, 0, c->dp_stream[0]>>>(cx, sinks.s[0], rb, sel);
     k_dp_tiny<<<2048, 256, 0, c->dp_stream[3]>>>(cx, sinks.s[4], rb, sel);
+    k_dp_half<<<2048, 256, 0, c->dp_stream[4]>>>(cx, sinks.s[5], rb, sel);
     k_dp_sel<4><<<c->dp_blocks[1], 64, 0, c->dp_stream[1]>>>(cx, sinks.s[2], rb, sel, c->d_dp_scratch[1], c->dp_stride[1]);
     k_dp_sel<16><<<c->dp_blocks[2], 64, 0, c->dp_stream[2]>>>(cx, sinks.s[3], rb, sel, c->d_dp_scratch[2], c->dp_stride[2]);
-    for (int k = 0; k < 4; k++) { HIP_TRY(hipEventRecord(c->dp_join[k], c->dp_stream[k])); HIP_TRY(hipStreamWaitEvent(s, c->dp_join[k], 0)); }
+    for (int k = 0; k < 5; k++) { HIP_TRY(hipEventRecord(c->dp_join[k], c->dp_stream[k])); HIP_TRY(hipStreamWaitEvent(s, c->dp_join[k], 0)); }
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
     k_finish<<<pb, 256, 0, s>>>(cx, rb, sel, d_recs, d_cig, c->d_pout, c->d_ov, c->d_cnt + CNT_OV, c->ov_cap);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
@@ -970,13 +967,13 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     const uint32_t *n = c->h_cnt;
     // a work list that ran over: nothing of this pass is kept, the caller maps the selection in two halves
     if (n[CNT_TASKS] > c->task_cap || n[CNT_RESCUE] > c->rescue_cap) return kListOverflow;
-    for (int k = 0; k < kDpClasses; k++) if (n[CNT_JOB0 + k] > c->job_cap[k]) return kListOverflow;
+    for (int k = 0; k < kDpClasses; k++) if (n[CNT_JOB0 + k * kCntPad] > c->job_cap[k]) return kListOverflow;
     if (n[CNT_UNSUP]) return fail(MCX_ERR_UNSUPPORTED, "a gapped fragment exceeds 2048 x 1024 cells per side");
     if (timing && getenv("MCX_TIMING"))
-        fprintf(stderr, "[run_pairs] pairs %u: sa tasks %u, rescue pairs %u, dp jobs by class (tiny) %u %u %u %u %u, cells %u, overflow pairs %u\n", sel.n, n[CNT_TASKS],
-                n[CNT_RESCUE], n[CNT_JOB4], n[CNT_JOB0], n[CNT_JOB1], n[CNT_JOB2], n[CNT_JOB3], n[CNT_CELLS], n[CNT_OV]);
+        fprintf(stderr, "[run_pairs] pairs %u: sa tasks %u, rescue pairs %u, dp jobs by class (tiny) %u %u (half) %u %u %u %u, cells %u, overflow pairs %u\n", sel.n, n[CNT_TASKS],
+                n[CNT_RESCUE], n[CNT_JOB4], n[CNT_JOB0], n[CNT_JOB5], n[CNT_JOB1], n[CNT_JOB2], n[CNT_JOB3], n[CNT_CELLS], n[CNT_OV]);
     if (stats) {
-        stats->dp_jobs += (int64_t)n[CNT_JOB0] + n[CNT_JOB1] + n[CNT_JOB2] + n[CNT_JOB3] + n[CNT_JOB4];
+        stats->dp_jobs += (int64_t)n[CNT_JOB0] + n[CNT_JOB1] + n[CNT_JOB2] + n[CNT_JOB3] + n[CNT_JOB4] + n[CNT_JOB5];
         stats->dp_cells += n[CNT_CELLS];
         if (timing) {
             float ms[8];
