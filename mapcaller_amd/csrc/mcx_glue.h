@@ -42,17 +42,22 @@ static inline MCX_HD int64_t hit_pd(const Hit &h) { return h.gPos - h.rPos; }
 // tail of IdentifySimplePairs (ReadMapping.cpp:141-152): keep PosDiff > 0, sort by (PosDiff, rPos)
 static inline MCX_HD int prep_seeds(Hit *h, int n)
 {
+    // (an element is stored only when it moves: most reads have two or three seeds, already in order)
     int m = 0;
-    for (int i = 0; i < n; i++) if (hit_pd(h[i]) > 0) h[m++] = h[i];
+    for (int i = 0; i < n; i++) {
+        const Hit x = h[i];
+        if (hit_pd(x) > 0) { if (m != i) h[m] = x; m++; }
+    }
     for (int i = 1; i < m; i++) {
-        Hit key = h[i];
-        int64_t kpd = hit_pd(key);
+        const Hit key = h[i];
+        const int64_t kpd = hit_pd(key);
         int j = i - 1;
         while (j >= 0) {
-            int64_t pd = hit_pd(h[j]);
-            if (pd > kpd || (pd == kpd && h[j].rPos > key.rPos)) { h[j + 1] = h[j]; j--; } else break;
+            const Hit y = h[j];
+            const int64_t pd = hit_pd(y);
+            if (pd > kpd || (pd == kpd && y.rPos > key.rPos)) { h[j + 1] = y; j--; } else break;
         }
-        h[j + 1] = key;
+        if (j + 1 != i) h[j + 1] = key;
     }
     return m;
 }
