@@ -131,31 +131,41 @@ static inline MCX_HD int pair_by_distance(int64_t est, Cand *c1, int n1, Cand *c
 {
     int64_t max_lt = -1, min_ge = 0x7fffffff;
     if (n1 * n2 > 100) { keep_top_scores(c1, n1); keep_top_scores(c2, n2); }
-    int64_t top = 0;
-    for (int i = 0; i < n1; i++) {
-        c1[i].frag_off = -1; // scratch: chosen partner
-        if (c1[i].score == 0) continue;
-        int pick = -1, ps = 0;
+    // the partner a candidate of read 1 picks among read 2's: found twice (once for the best pair sum, once to
+    // mark the pairs that reach it) rather than parked in the candidate — fetches of lines already at hand
+    // are cheaper here than stores
+    auto partner = [&](const Cand &a, int &ps) {
+        int pick = -1;
+        ps = 0;
         for (int j = 0; j < n2; j++) {
-            if (c2[j].score == 0 || c2[j].pd0 < c1[i].pd0) continue;
-            int64_t d = c2[j].pd0 - c1[i].pd0;
+            const int sj = c2[j].score;
+            const int64_t pj = c2[j].pd0;
+            if (sj == 0 || pj < a.pd0) continue;
+            const int64_t d = pj - a.pd0;
             if (d < est) {
                 if (d > max_lt) max_lt = d;
-                if (c2[j].score > ps) { pick = j; ps = c2[j].score; }
+                if (sj > ps) { pick = j; ps = sj; }
             } else if (d < min_ge) min_ge = d;
         }
-        c1[i].frag_off = pick;
-        if (pick >= 0) { int64_t s = (int64_t)c1[i].score + c2[pick].score; if (s > top) top = s; }
+        return pick;
+    };
+    int64_t top = 0;
+    for (int i = 0; i < n1; i++) {
+        const Cand a = c1[i];
+        if (a.score == 0) continue;
+        int ps;
+        if (partner(a, ps) >= 0) { const int64_t s = (int64_t)a.score + ps; if (s > top) top = s; }
     }
     int paired = 0;
     if (top > 0) {
         for (int i = 0; i < n1; i++) {
-            int pick = c1[i].frag_off;
-            if (c1[i].score == 0 || pick < 0) continue;
-            if ((int64_t)c1[i].score + c2[pick].score == top) { paired++; c1[i].mate = pick; c2[pick].mate = i; }
+            const Cand a = c1[i];
+            if (a.score == 0) continue;
+            int ps;
+            const int pick = partner(a, ps);
+            if (pick >= 0 && (int64_t)a.score + ps == top) { paired++; c1[i].mate = pick; c2[pick].mate = i; }
         }
     }
-    for (int i = 0; i < n1; i++) c1[i].frag_off = 0;
     lo = (int)(max_lt + 1);
     hi = (int)min_ge;
     return paired;
