@@ -476,6 +476,37 @@ static inline MCX_HD bool frag_before(const Frag &a, const Frag &b) // CompByRea
 // alignment would span two chromosomes (CheckAlignmentValidity, tools.cpp:119-130)
 static inline MCX_HD int build_frags(const IndexView &ix, int rlen, const Hit *seeds, int n, Frag *f)
 {
+    int total = 0;
+    // The usual case in one pass: seeds that already come in read order, apart from each other on the read and
+    // on the genome, need no sorting, no overlap removal and no expansion in place — the list is written once,
+    // front to back, gaps included.  Anything else starts over on the general path below (same result).
+    {
+        bool plain = true;
+        int w = 0, prev_r0 = 0, pr = 0;
+        int64_t prev_g0 = 0, pg = 0;
+        Frag g; g.ops_off = 0; g.ops_len = 0; g.kind = kPlain;
+        for (int i = 0; i < n; i++) {
+            const Hit sd = seeds[i];
+            const int r0 = sd.rPos;
+            if (i == 0) {
+                if (r0 > 0) { g.rPos = 0; g.gPos = sd.gPos - r0; g.rLen = g.gLen = r0; f[w++] = g; }
+            } else {
+                const int rg = r0 - pr;
+                const int64_t gg = sd.gPos - pg;
+                if (r0 <= prev_r0 || sd.gPos <= prev_g0 || rg < 0 || gg < 0) { plain = false; break; }
+                if (rg > 0 || gg > 0) { g.rPos = pr; g.gPos = pg; g.rLen = rg; g.gLen = (int)gg; f[w++] = g; }
+            }
+            Frag x; x.gPos = sd.gPos; x.rPos = r0; x.rLen = x.gLen = sd.len;
+            x.ops_off = 0; x.ops_len = 0; x.kind = kSimple;
+            f[w++] = x;
+            prev_r0 = r0; prev_g0 = sd.gPos; pr = r0 + sd.len; pg = sd.gPos + sd.len;
+        }
+        if (plain && n > 0) {
+            if (pr < rlen) { g.rPos = pr; g.gPos = pg; g.rLen = g.gLen = rlen - pr; f[w++] = g; }
+            total = w;
+        }
+    }
+    if (total == 0) {
     for (int i = 0; i < n; i++) {
         Frag x; x.gPos = seeds[i].gPos; x.rPos = seeds[i].rPos; x.rLen = x.gLen = seeds[i].len;
         x.ops_off = 0; x.ops_len = 0; x.kind = kSimple;
@@ -507,7 +538,7 @@ static inline MCX_HD int build_frags(const IndexView &ix, int rlen, const Hit *s
     }
     bool head = f[0].rPos > 0;
     bool tail = f[n - 1].rPos + f[n - 1].rLen < rlen;
-    int total = n + gaps + (head ? 1 : 0) + (tail ? 1 : 0);
+    total = n + gaps + (head ? 1 : 0) + (tail ? 1 : 0);
     int w = total - 1;
     Frag g; g.ops_off = 0; g.ops_len = 0; g.kind = kPlain;
     if (tail) {
@@ -533,6 +564,7 @@ static inline MCX_HD int build_frags(const IndexView &ix, int rlen, const Hit *s
         g.rPos = 0; g.gPos = first.gPos - first.rPos; g.rLen = g.gLen = first.rPos;
         f[0] = g;
     }
+    } // general path
     // CheckAlignmentValidity
     const Frag &a = f[0], &b = f[total - 1];
     if (a.gPos < 0 || b.gPos + b.gLen > ix.G2) return -1;
