@@ -633,14 +633,13 @@ static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef 
     for (int s = 0; s < nr; s++) {
         Cand *cs = st.cands[s];
         for (int ci = 0; ci < h.n_cands[s]; ci++) {
-            Cand &c = cs[ci];
-            c.n_frags = 0; c.frag_off = h.n_frags;
-            if (c.score == 0) continue;
-            if (h.n_frags + 2 * c.count + 2 > cx.caps.frag_cap) { h.flags |= kOvFrags; *g_hdr = h; return 0; }
+            const Cand c = cs[ci]; // read once; what changes is stored once (frag_off and n_frags share a word)
+            if (c.score == 0) { cs[ci].frag_off = (int16_t)h.n_frags; cs[ci].n_frags = 0; continue; }
+            if (h.n_frags + 2 * c.count + 2 > cx.caps.frag_cap) { cs[ci].frag_off = (int16_t)h.n_frags; cs[ci].n_frags = 0; h.flags |= kOvFrags; *g_hdr = h; return 0; }
             Frag *f = st.frags + h.n_frags;
             int nf = build_frags(cx.ix, rd[s].rlen, st.hits[s] + c.first, c.count, f);
-            if (nf < 0) { c.score = 0; continue; }
-            c.n_frags = nf;
+            cs[ci].frag_off = (int16_t)h.n_frags; cs[ci].n_frags = (int16_t)(nf < 0 ? 0 : nf);
+            if (nf < 0) { cs[ci].score = 0; continue; }
             // ProcessNormalPair (:155-191): classify each gap fragment
             for (int i = 0; i < nf; i++) {
                 Frag x = f[i]; // worked on in registers, stored back once
@@ -689,9 +688,9 @@ static inline MCX_HD uint8_t frag_op(const Frag &f, const uint8_t *ops, int x)
 }
 
 // RemoveHeadingGaps (:264-283) / RemoveTailingGaps (:285-304)
-static inline MCX_HD void strip_end_gaps(Frag &f, const uint8_t *ops, bool leading, bool move_pos)
+static inline MCX_HD bool strip_end_gaps(Frag &f, const uint8_t *ops, bool leading, bool move_pos) // true: the fragment changed
 {
-    if (f.kind != kDp) return; // only DP results can start or end with a gap column
+    if (f.kind != kDp) return false; // only DP results can start or end with a gap column
     int rs = 0, gs = 0, j = 0;
     if (leading) {
         for (; j < f.ops_len; j++) { uint8_t o = ops[f.ops_off + j]; if (o == 'D') gs++; else if (o == 'I') rs++; else break; }
@@ -704,6 +703,7 @@ static inline MCX_HD void strip_end_gaps(Frag &f, const uint8_t *ops, bool leadi
         f.rLen -= rs; f.gLen -= gs;
         if (move_pos) { f.rPos += rs; f.gPos += gs; }
     }
+    return j > 0;
 }
 
 struct ColStats { int switches, n, mis, match; };
@@ -762,26 +762,28 @@ static inline MCX_HD void extend_read(const Ctx &cx, PairState &st, int s, const
             if (x.kind == kSimple) { score += x.rLen; continue; }
             const bool fwd = x.gPos < ix.G;
             if (i == 0) {
-                strip_end_gaps(x, st.ops, fwd, true);
+                bool changed = strip_end_gaps(x, st.ops, fwd, true);
                 ColStats q = frag_columns(ix, x, st.ops, rd);
                 if (x.ops_len >= kMinAlnBlockSize && !quality_ok(q)) {
                     head_ok = false;
                     const Frag nx = f[i + 1];
                     x.rLen = x.gLen = 0; x.ops_len = 0; x.kind = kEmpty;
                     x.rPos = nx.rPos; x.gPos = nx.gPos;
+                    changed = true;
                 } else { score += q.match; mism += q.mis; }
                 g_first = x.gPos;
-                f[i] = x;
+                if (changed) f[i] = x; // (stored only when it changed: stores are what this stage is short of)
             } else if (i == last) {
-                strip_end_gaps(x, st.ops, !fwd, false);
+                bool changed = strip_end_gaps(x, st.ops, !fwd, false);
                 ColStats q = frag_columns(ix, x, st.ops, rd);
                 if (x.ops_len >= kMinAlnBlockSize && !quality_ok(q)) {
                     tail_ok = false;
                     const Frag pv = f[i - 1];
                     x.rLen = x.gLen = 0; x.ops_len = 0; x.kind = kEmpty;
                     x.rPos = pv.rPos + pv.rLen; x.gPos = pv.gPos + pv.gLen;
+                    changed = true;
                 } else { score += q.match; mism += q.mis; }
-                f[i] = x;
+                if (changed) f[i] = x;
             } else {
                 ColStats q = frag_columns(ix, x, st.ops, rd);
                 if (x.rLen >= kMinAlnBlockSize && x.gLen >= kMinAlnBlockSize && !quality_ok(q)) { dead = true; break; }
@@ -790,14 +792,14 @@ static inline MCX_HD void extend_read(const Ctx &cx, PairState &st, int s, const
         }
         if (dead || (!head_ok && !tail_ok)) { cs[ci].score = 0; continue; }
         if (score == 0 || (score < min_score && mism > max_mm)) { cs[ci].score = 0; continue; }
-        c.score = score;
-        c.fwd = g_first < ix.G ? 1 : 0;
-        if (!c.fwd) for (int a = 0, b = num - 1; a < b; a++, b--) { const Frag t = f[a]; f[a] = f[b]; f[b] = t; }
-        cs[ci] = c;
+        const int8_t fwd = g_first < ix.G ? 1 : 0;
+        if (!fwd) for (int a = 0, b = num - 1; a < b; a++, b--) { const Frag t = f[a]; f[a] = f[b]; f[b] = t; }
+        if (score != c.score) cs[ci].score = score; // (only the fields that changed)
+        if (fwd != c.fwd) cs[ci].fwd = fwd;
         if (score > sum.score) { sum.score = score; sum.best = ci; }
         else if (score > sum.sub) sum.sub = score;
     }
-    for (int ci = 0; ci < n_cands; ci++) if (cs[ci].score < sum.score) cs[ci].score = 0;
+    if (n_cands > 1) for (int ci = 0; ci < n_cands; ci++) if (cs[ci].score < sum.score) cs[ci].score = 0;
     h.sum[s] = sum;
 }
 
@@ -953,7 +955,6 @@ static inline MCX_HD void emit_record(const Ctx &cx, PairState &st, int s, const
         // printed in unique mode is the first one, candidate `best`
         c.flag = paired_flag(c, oc, s == 0, me.score > me.sub);
     } else c.flag = c.fwd ? 0 : 0x10; // SetSingledAlignmentFlag, SamReport.cpp:7-24
-    st.cands[s][me.best].flag = c.flag;
     out.flag = c.flag;
     out.mapq = mapq_of(cx, me);
     Coord km = aln_coord(cx.ix, c, st.frags);
