@@ -1041,15 +1041,16 @@ static inline MCX_HD void write_detail(const Ctx &cx, PairState &st, int s, uint
     }
 }
 
+// (keep: where the final header goes instead of the pair state — the device's finish kernel is the last reader)
 static inline MCX_HD void stage_finish(const Ctx &cx, int64_t pair, const ReadRef *rd, AlnRec *recs, uint32_t *cigars,
-                                       uint8_t *detail0)
+                                       uint8_t *detail0, PairHdr *keep = nullptr)
 {
     PairState st = pair_state(cx.state, cx.lay, cx.caps, pair);
     PairHdr *const g_hdr = st.hdr;
     PairHdr h = *g_hdr; // the header travels in registers through this stage and is stored back once
     st.hdr = &h;
     int nr = cx.pm.paired ? 2 : 1;
-    if (h.flags & kOvAny) return;
+    if (h.flags & kOvAny) { if (keep) *keep = h; return; }
     h.mapped = 0;
     for (int s = 0; s < nr; s++) { extend_read(cx, st, s, rd[s]); if (h.sum[s].score > 0) h.mapped++; }
     DetailHdr *dh = detail0 ? (DetailHdr *)(detail0 + (pair * nr) * cx.dlay.stride) : nullptr;
@@ -1059,7 +1060,7 @@ static inline MCX_HD void stage_finish(const Ctx &cx, int64_t pair, const ReadRe
         emit_record(cx, st, s, rd, recs[r], cigars + r * cx.caps.cig_cap, cx.caps.cig_cap);
         if (detail0) write_detail(cx, st, s, detail0 + r * cx.dlay.stride);
     }
-    *g_hdr = h;
+    if (keep) *keep = h; else *g_hdr = h;
 }
 
 } // namespace mcx

@@ -702,14 +702,13 @@ __global__ void __launch_bounds__(256, 7) k_finish(Ctx cx, ReadBatch rb, PairSel
     const uint32_t pair = sel_pair(sel, local);
     ReadRef rd[2];
     make_reads(cx, rb, pair, rd);
-    PairState st = pair_state(cx.state, cx.lay, cx.caps, local);
     // records are indexed by batch read; stage_finish indexes by pair*nr+s, so offset the bases
     const int nr = cx.pm.paired ? 2 : 1;
     AlnRec *r0 = recs + (int64_t)pair * nr - (int64_t)local * nr;
     uint32_t *c0 = cigars + ((int64_t)pair * nr - (int64_t)local * nr) * cx.caps.cig_cap;
     uint8_t *d0 = cx.detail ? cx.detail + ((int64_t)pair * nr - (int64_t)local * nr) * cx.dlay.stride : nullptr;
-    stage_finish(cx, local, rd, r0, c0, d0);
-    const PairHdr &h = *st.hdr;
+    PairHdr h; // the final header stays in registers: nothing reads the pair state after this kernel
+    stage_finish(cx, local, rd, r0, c0, d0, &h);
     PairOut o;
     o.flags = h.flags; o.est = h.est; o.est_lo = h.est_lo; o.est_hi = h.est_hi;
     o.pair_dist = h.pair_dist; o.pair_ok = (int16_t)h.pair_ok; o.mapped = (int16_t)h.mapped;
