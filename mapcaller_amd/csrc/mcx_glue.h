@@ -428,11 +428,19 @@ static inline MCX_HD int rescue_mate(const Ctx &cx, PairState &st, const ReadRef
 // ------------------------------------------------------------------------------------------
 static inline MCX_HD bool pair_needs_rescue(const PairHdr &h) { return h.n_paired == 0; }
 
-static inline MCX_HD void stage_cluster_pair(const Ctx &cx, int64_t pair, const ReadRef *rd, int est)
+// (n_hits_in: the reads' hit counts when the caller has them elsewhere — the device keeps them in a per-read
+//  array, so that the seeding kernel need not touch the header and this stage need not fetch it: the stage
+//  writes every field of the header that later stages read before writing)
+static inline MCX_HD void stage_cluster_pair(const Ctx &cx, int64_t pair, const ReadRef *rd, int est, const int *n_hits_in = nullptr)
 {
     PairState st = pair_state(cx.state, cx.lay, cx.caps, pair);
     PairHdr *const g_hdr = st.hdr;
-    PairHdr h = *g_hdr; // in registers through the stage, stored back once
+    PairHdr h;
+    if (n_hits_in) {
+        h.flags = 0; h.n_frags = 0; h.n_ops = 0; h.pair_dist = 0; h.n_jobs = 0; h.pair_ok = 0; h.mapped = 0; h.pad[0] = h.pad[1] = 0;
+        h.n_hits[0] = (int16_t)n_hits_in[0]; h.n_hits[1] = (int16_t)n_hits_in[1]; h.n_cands[0] = h.n_cands[1] = 0;
+        h.sum[0].best = h.sum[1].best = -1; h.sum[0].score = h.sum[1].score = 0; h.sum[0].sub = h.sum[1].sub = 0;
+    } else h = *g_hdr; // in registers through the stage, stored back once
     int nr = cx.pm.paired ? 2 : 1;
     MCX_UNROLL // (written to unroll: a header indexed by a run-time mate number lives in scratch memory)
     for (int s = 0; s < 2; s++) {

@@ -451,8 +451,6 @@ __global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel,
     Hit *hits = nullptr;
     // the read is done: counters, and SA tasks for the hits that are still BWT rows (the others carry their text position)
     auto finish_read = [&]() {
-        PairState st = pair_state(cx.state, cx.lay, cx.caps, lr / nr);
-        st.hdr->n_hits[lr % nr] = n;
         so.read_ext[r] = (uint32_t)ext; so.read_blocks[r] = (uint32_t)blocks | ((uint32_t)n << 20); // (blocks < 2^20; n < 2^12)
         if (cx.ix.sa_full) return; // every hit already carries its text position (seed_search)
         const int keep = n <= cx.caps.hit_cap ? n : 0; // overflowing reads are re-run in the next tier
@@ -512,7 +510,7 @@ __global__ void __launch_bounds__(256) k_sa(Ctx cx, SeedOut so, int paired, uint
 
 struct RescueList { uint32_t *ids; uint32_t *n; uint32_t cap; };
 
-__global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl)
+__global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl, const uint32_t *read_blocks)
 {
     __shared__ EndsLds ends;
     stage_ends(cx.ix, ends);
@@ -522,8 +520,10 @@ __global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel s
         ReadRef rd[2];
         make_reads(cx, rb, sel_pair(sel, local), rd);
         PairState st = pair_state(cx.state, cx.lay, cx.caps, local);
-        st.hdr->flags = 0;
-        stage_cluster_pair(cx, local, rd, sel.est[local]);
+        const uint32_t pair = sel_pair(sel, local);
+        const int nr = cx.pm.paired ? 2 : 1;
+        int nh[2] = {(int)(read_blocks[pair * nr] >> 20), nr == 2 ? (int)(read_blocks[pair * nr + 1] >> 20) : 0}; // k_seed's hit counts
+        stage_cluster_pair(cx, local, rd, sel.est[local], nh);
         need = (cx.pm.paired && !(st.hdr->flags & kOvAny) && st.hdr->n_paired == 0) ? 1u : 0u;
     }
     const uint32_t at = wave_reserve(rl.n, need);
@@ -940,7 +940,7 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
     k_sa<<<4096, 256, 0, s>>>(cx, so, paired, c->d_cnt + CNT_LF);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
-    k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl);
+    k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl, so.read_blocks);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
     if (paired) k_rescue<<<4096, kRescueThreads, 0, s>>>(cx, rb, sel, rl);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
