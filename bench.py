@@ -322,7 +322,7 @@ def main():
                          "measured": None if not prof else {
                              "hbm_gbs": round(prof["traffic"] / (seed_ms * 1e-3) / 1e9, 1), "l2_requests_per_launch": prof["l2_requests"],
                              "l2_request_rate_g_per_s": round(prof["l2_requests"] / (seed_ms * 1e-3) / 1e9, 1), "waves_waiting_frac": prof["wait_frac"],
-                             "reading": "the launch moves a tenth of the walk's bytes; waves wait on dependent fetches two thirds of the time"}},
+                             "reading": "the launch moves less than a tenth of the walk's bytes; waves wait on dependent fetches two thirds of the time"}},
             "per_read": {"fm_ext_steps": round(d["fm_ext_steps"] / max(d["reads"], 1), 2), "fm_blocks": round(d["fm_blocks"] / max(d["reads"], 1), 2),
                          "sa_hits": round(d["sa_hits"] / max(d["reads"], 1), 3), "dp_jobs": round(d["dp_jobs"] / max(d["reads"], 1), 4),
                          "mapped_frac": round(d["mapped"] / max(d["reads"], 1), 4)},
