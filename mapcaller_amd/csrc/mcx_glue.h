@@ -743,6 +743,11 @@ static inline MCX_HD bool quality_ok(const ColStats &c)
     return !(c.switches >= 4 || (c.mis >= 3 && c.mis >= (int)(c.n * 0.3)));
 }
 
+// Fragment i of a candidate in alignment order.  The reference reverses the fragment vector of a
+// reverse-strand candidate (ReadAlignment.cpp:412-416); here the list stays as built and is read backwards
+// (the swaps were two stores per pair of fragments, and stores are what the finish stage is short of).
+static inline MCX_HD int frag_index(const Cand &c, int i) { return c.frag_off + (c.fwd ? i : c.n_frags - 1 - i); }
+
 // ProduceReadAlignment from :336 on, for one read
 static inline MCX_HD void extend_read(const Ctx &cx, PairState &st, int s, const ReadRef &rd)
 {
@@ -801,7 +806,6 @@ static inline MCX_HD void extend_read(const Ctx &cx, PairState &st, int s, const
         if (dead || (!head_ok && !tail_ok)) { cs[ci].score = 0; continue; }
         if (score == 0 || (score < min_score && mism > max_mm)) { cs[ci].score = 0; continue; }
         const int8_t fwd = g_first < ix.G ? 1 : 0;
-        if (!fwd) for (int a = 0, b = num - 1; a < b; a++, b--) { const Frag t = f[a]; f[a] = f[b]; f[b] = t; }
         if (score != c.score) cs[ci].score = score; // (only the fields that changed)
         if (fwd != c.fwd) cs[ci].fwd = fwd;
         if (score > sum.score) { sum.score = score; sum.best = ci; }
@@ -829,9 +833,8 @@ static inline MCX_HD Coord to_coord(const IndexView &ix, int64_t g) // Determine
 static inline MCX_HD Coord aln_coord(const IndexView &ix, const Cand &c, const Frag *frags) // GetAlnCoordinate, SamReport.cpp:121-149
 {
     Coord k; k.pos = 0; k.chr = 0;
-    const Frag *f = frags + c.frag_off;
     for (int i = 0; i < c.n_frags; i++) {
-        const Frag x = f[i];
+        const Frag x = frags[frag_index(c, i)];
         if (x.gLen > 0) return to_coord(ix, c.fwd ? x.gPos : x.gPos + x.gLen - 1);
     }
     return k;
@@ -850,7 +853,7 @@ static inline MCX_HD int mapq_of(const Ctx &cx, const ReadSum &r) // EvaluateMAP
 // (operations beyond `cap` go to ext[0..) when ext is given; the count is returned either way)
 static inline MCX_HD int cigar_of(int rlen, const Cand &c, const Frag *frags, const uint8_t *ops, uint32_t *out, int cap, uint32_t *ext = nullptr)
 {
-    const Frag *v = frags + c.frag_off;
+    auto v = [&](int i) -> Frag { return frags[frag_index(c, i)]; };
     int num = c.n_frags, n = 0, run = 0, st = -1;
     auto put = [&](int len, int op) {
         const uint32_t w = ((uint32_t)len << 4) | (uint32_t)op;
@@ -858,12 +861,15 @@ static inline MCX_HD int cigar_of(int rlen, const Cand &c, const Frag *frags, co
         n++;
     };
     auto flush_to = [&](int ns) { if (st != ns) { if (run > 0) put(run, st); st = ns; run = 0; } };
-    if (v[0].kind != kSimple) {
-        int clip = c.fwd ? v[0].rPos : rlen - (v[0].rPos + v[0].rLen);
-        if (clip > 0) put(clip, 4);
+    {
+        const Frag f0 = v(0);
+        if (f0.kind != kSimple) {
+            int clip = c.fwd ? f0.rPos : rlen - (f0.rPos + f0.rLen);
+            if (clip > 0) put(clip, 4);
+        }
     }
     for (int i = 0; i < num; i++) {
-        const Frag f = v[i]; // a copy: the stores of the operations below could alias a reference
+        const Frag f = v(i); // a copy: the stores of the operations below could alias a reference
         if (f.kind == kSimple) { flush_to(0); run += f.rLen; }
         else if (f.kind == kEmpty) continue;
         else if (f.ops_len > 0) {
@@ -876,10 +882,12 @@ static inline MCX_HD int cigar_of(int rlen, const Cand &c, const Frag *frags, co
         else if (f.gLen > 0) { flush_to(2); run += f.gLen; }
     }
     if (run > 0) put(run, st);
-    int i = num - 1;
-    if (i > 0 && v[i].kind != kSimple) {
-        int clip = c.fwd ? rlen - (v[i].rPos + v[i].rLen) : v[i].rPos;
-        if (clip > 0) put(clip, 4);
+    if (num > 1) {
+        const Frag fl = v(num - 1);
+        if (fl.kind != kSimple) {
+            int clip = c.fwd ? rlen - (fl.rPos + fl.rLen) : fl.rPos;
+            if (clip > 0) put(clip, 4);
+        }
     }
     return n;
 }
@@ -907,7 +915,7 @@ static inline MCX_HD void pair_stats(const Ctx &cx, PairState &st, DetailHdr *dh
     for (int i = 0; i < n1; i++) {
         const Cand &c = c1[i];
         if (c.score > 0 && c.mate != -1 && c2[c.mate].score > 0) {
-            g1 = st.frags[c.frag_off].gPos; g2 = st.frags[c2[c.mate].frag_off].gPos;
+            g1 = st.frags[frag_index(c, 0)].gPos; g2 = st.frags[frag_index(c2[c.mate], 0)].gPos;
             dist = g2 > g1 ? g2 - g1 : g1 - g2;
             break;
         }
@@ -915,8 +923,8 @@ static inline MCX_HD void pair_stats(const Ctx &cx, PairState &st, DetailHdr *dh
     if (dist == 0) {
         int a = 0, b = 0;
         int64_t ga = 0, gb = 0;
-        for (int i = 0; i < n1; i++) if (c1[i].score > 0) { if (a == 0) ga = st.frags[c1[i].frag_off].gPos; a++; }
-        for (int i = 0; i < n2; i++) if (c2[i].score > 0) { if (b == 0) gb = st.frags[c2[i].frag_off].gPos; b++; }
+        for (int i = 0; i < n1; i++) if (c1[i].score > 0) { if (a == 0) ga = st.frags[frag_index(c1[i], 0)].gPos; a++; }
+        for (int i = 0; i < n2; i++) if (c2[i].score > 0) { if (b == 0) gb = st.frags[frag_index(c2[i], 0)].gPos; b++; }
         if (a == 1 && b == 1) { g1 = ga; g2 = gb; dist = g2 > g1 ? g2 - g1 : g1 - g2; }
         else if (a == 0 && b >= 1) { g1 = -1; dist = g2 = gb; }
         else if (a >= 1 && b == 0) { dist = g1 = ga; g2 = -1; }
@@ -1023,7 +1031,7 @@ static inline MCX_HD void write_detail(const Ctx &cx, PairState &st, int s, uint
         d.type = 1; d.fwd = c.fwd; d.n_frags = c.n_frags;
         int no = 0;
         for (int i = 0; i < c.n_frags; i++) {
-            Frag f = st.frags[c.frag_off + i];
+            Frag f = st.frags[frag_index(c, i)];
             if (f.kind == kDp) {
                 if (no + f.ops_len > cx.dlay.ops_cap) { h.flags |= kOvDetail; d.type = 0; return; }
                 for (int x = 0; x < f.ops_len; x++) dops[no + x] = st.ops[f.ops_off + x];
@@ -1039,7 +1047,7 @@ static inline MCX_HD void write_detail(const Ctx &cx, PairState &st, int s, uint
             const Cand &c = cs[i];
             if (c.score <= 0) continue;
             if (n >= cx.dlay.frag_cap) { h.flags |= kOvDetail; d.type = 0; return; }
-            const Frag &a = st.frags[c.frag_off], &b = st.frags[c.frag_off + c.n_frags - 1];
+            const Frag &a = st.frags[frag_index(c, 0)], &b = st.frags[frag_index(c, c.n_frags - 1)];
             const int64_t g0 = c.fwd ? a.gPos : cx.ix.G2 - (a.gPos + a.gLen);
             const int64_t g1 = c.fwd ? b.gPos + b.gLen : cx.ix.G2 - b.gPos;
             Frag r; r.gPos = g0; r.rPos = 0; r.rLen = (int32_t)(g1 - g0); r.gLen = 0; r.ops_off = 0; r.ops_len = 0; r.kind = kSimple;
