@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "round1", "summary_3gbp_r1c.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "round1", "summary_3gbp_r1d.json")
 
 
 def pmc_profile(args):
@@ -306,7 +306,7 @@ def main():
                        "index_hbm_gb": round(index.hbm_bytes / 1e9, 2)},
             "roofline": {"bound": "hbm", "kernel": "k_seed", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": prof.get("traffic"),
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/round1/summary_3gbp_r1c.json)",
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/round1/summary_3gbp_r1d.json)",
                          "algorithmic_bytes_per_launch": round(seed_bytes / max(args.steps, 1)),
                          "note": "achieved prices SURVEY 8d's seeding bytes (64*1.107*E + rlen per read: the reference's FM walk) at the measured "
                                  "launch time; the kernel reaches the same seeds through a K-mer jump table and direct genome comparison, moves far "
