@@ -110,6 +110,7 @@ typedef struct mcx_stats {
     int64_t dp_jobs, dp_cells;
     int64_t tier1_pairs;    /* pairs re-run with the large capacities */
     int64_t replayed_pairs; /* pairs re-run because the avgDist trajectory moved past their validity interval */
+    int64_t halved_selections; /* times a selection of pairs was mapped in two halves because a work list ran over */
     double ms_encode /* k_pack_reads */, ms_seed, ms_sa, ms_cluster, ms_rescue, ms_build, ms_dp, ms_finish, ms_total;
 } mcx_stats;
 
@@ -133,6 +134,44 @@ int mcx_cigar_ext(mcx_ctx *, int on_device, const uint32_t **words, uint64_t *n_
 int mcx_map_batch(mcx_ctx *, const uint8_t *bases, const uint32_t *off, uint32_t n_reads, int paired,
                   int64_t avg_state[4], mcx_aln *aln, uint32_t *cigar, mcx_stats *stats);
 
+/* ---- a batch in steps: runs whose batches are mapped by several GPUs ---------------------------
+ * The reference re-estimates the insert size after every 200-read chunk (ReadMapping.cpp:462,
+ * :538-539), one trajectory over the whole input stream.  mcx_map_batch* walks it within a batch;
+ * when consecutive batches are mapped by different GPUs the trajectory has to be walked over all of
+ * them, so the batch is exposed in steps and the caller exchanges the per-chunk sums between them:
+ *   mcx_batch_begin   maps every pair with EstiDistance est0 (the best guess at hand)
+ *   mcx_batch_sums    per chunk of 100 pairs: proper pairs, their summed distance and read lengths
+ *                     (host arrays, valid until the next call on the context)
+ *   mcx_batch_replay  est_chunk[k] = the EstiDistance the single-stream run uses for chunk k: pairs
+ *                     whose outcome depends on the difference are mapped again; n_redone = how many.
+ *                     Repeat sums -> replay until no shard re-ran a pair.
+ *   mcx_batch_end     closes the batch (long-CIGAR pool, -vcf bookkeeping with local admission)
+ * read_base = reads of the run that precede this batch in input order (orders the discordant-pair
+ * events of mcx_profile_sparse across shards; must be even for paired batches). */
+int mcx_batch_begin(mcx_ctx *, const uint8_t *d_bases, const uint32_t *d_off, uint32_t n_reads, int paired, int32_t est0,
+                    int64_t read_base, mcx_aln *d_aln, uint32_t *d_cigar, mcx_stats *stats);
+int mcx_batch_sums(mcx_ctx *, uint32_t *n_chunks, const uint32_t **pairs, const uint32_t **dist, const uint32_t **len);
+int mcx_batch_replay(mcx_ctx *, const int32_t *est_chunk, uint32_t *n_redone, mcx_stats *stats);
+int mcx_batch_end(mcx_ctx *, mcx_stats *stats);
+/* The reference's walk itself (ReadMapping.cpp:538-539): state = {avgDist, iTotalPairedNum,
+ * TotalPairedDistance}; fills est_chunk[0..n_chunks) with the EstiDistance each chunk is mapped
+ * with and advances the state over the chunks. */
+void mcx_avg_walk(int64_t state[3], const uint32_t *pairs, const uint32_t *dist, uint32_t n_chunks, int32_t *est_chunk);
+
+/* ---- exchange between the shards of one run (one shard = one GPU) --------------------------------
+ * Collective: every shard calls allgather the same number of times; `bytes` is the same on every
+ * shard; recv receives size * bytes in rank order.  Host memory.  mapcaller-mi355x -gpus N provides
+ * one between its host threads, mapcaller_amd/run.py one over torch.distributed. */
+typedef struct mcx_exchange {
+    void *user;
+    int32_t rank, size;
+    int (*allgather)(void *user, const void *send, void *recv, uint64_t bytes);
+} mcx_exchange;
+/* An in-process exchange for `size` host threads of one process (one per GPU): mcx_exchange_local
+ * fills size entries of out[] that share one rendezvous; mcx_exchange_local_free releases it. */
+int mcx_exchange_local(int32_t size, mcx_exchange *out);
+void mcx_exchange_local_free(mcx_exchange *first);
+
 /* ---- -vcf bookkeeping -------------------------------------------------------------------------
  * Replaces UpdateProfile / UpdateMultiHitCount (reference src/AlignmentProfile.cpp:41-271, called
  * under ProfileLock from src/ReadMapping.cpp:562-573) and the discordant-site lists
@@ -149,12 +188,31 @@ int mcx_map_batch(mcx_ctx *, const uint8_t *bases, const uint32_t *off, uint32_t
 typedef struct mcx_sparse_rec {
     int64_t pos;
     uint8_t type;
-    uint8_t len;
-    char seq[54];
+    uint8_t len;   /* 'I','D': length of the whole string (up to 255); a string longer than seq continues in the */
+    char seq[54];  /* records that directly follow ('C': len = bytes held).  Keep a list's records in order.      */
 } mcx_sparse_rec;
 int mcx_profile_attach(mcx_ctx *, uint32_t *d_planes, int max_dup, int max_clip);
 int mcx_profile_finalize(mcx_ctx *, uint32_t *d_planes);
 int mcx_profile_sparse(mcx_ctx *, const mcx_sparse_rec **recs, uint64_t *n);
+/* For a run spread over several shards: the same tallies, but the discordant-pair events as they
+ * were seen ('E': pos = pair number in input order, len = branch of ReadMapping.cpp:486-521,
+ * seq = g1, g2, dist) instead of 'V'/'T' — the reference's second branch reports whatever the
+ * previous discordant pair of the *whole stream* left behind (ReadMapping.cpp:418, :499-505), so the
+ * events of all shards are replayed in input order by mcx_call_variants, which takes both forms. */
+int mcx_profile_sparse_shard(mcx_ctx *, const mcx_sparse_rec **recs, uint64_t *n);
+/* Duplicate cap across shards (AlignmentProfile.cpp:76-77 admits the first max_dup uniquely mapped
+ * reads per start position in input order).  Between mcx_batch_end_keys (instead of mcx_batch_end)
+ * and mcx_batch_accumulate the caller gathers the keys of all shards of the round:
+ *   mcx_batch_end_keys    closes the batch; keys (host, pinned) = (start position << 32 | read
+ *                         index in the batch) of the reads that reach the duplicate check
+ *   mcx_batch_accumulate  all_keys = the keys of every shard of the round with the index replaced
+ *                         by (slot * slot_stride + index), slots in input order; own reads are those
+ *                         of slot own_slot.  Admission is decided over all of them against the
+ *                         readCount plane, which every shard keeps for the whole run (it is the same
+ *                         on all shards and is NOT summed by the reduce); then the own reads are
+ *                         accumulated. */
+int mcx_batch_end_keys(mcx_ctx *, mcx_stats *stats, const uint64_t **keys, uint64_t *n_keys);
+int mcx_batch_accumulate(mcx_ctx *, const uint64_t *all_keys, uint64_t n_all, uint32_t slot_stride, uint32_t own_slot);
 
 /* Device storage for the ten planes of one genome (zero-initialised); free with mcx_planes_free. */
 int mcx_planes_alloc(const mcx_index *, uint32_t **d_planes);
@@ -198,14 +256,20 @@ int mcx_map_files(mcx_ctx *, const char *fq1, const char *fq2, const char *sam_p
  * Sharding over several GPUs (one process each): the input stream is cut into batches of the
  * context's max_batch_reads, batch k belongs to shard k % shard_count; a shard maps and writes only
  * its batches.  no_sam_header / sam_index_path ("batch bytes" per line) let the parts be merged in
- * input order (mapcaller_amd/run.py does). */
+ * input order (mcx_sam_merge).  avg_state must be the same on every shard when the run starts; it is
+ * again when it ends (avg_state[3] = reads of the whole input). */
 typedef struct mcx_file_opts {
     int32_t interleaved_pairs, host_threads, append_sam, no_sam_header;
     int64_t *avg_state; /* int64_t[4], see mcx_avg_init */
     int32_t shard_rank, shard_count; /* 0, 0: the whole input */
     const char *sam_index_path;      /* NULL: none */
+    const mcx_exchange *exchange;    /* required when shard_count > 1: the shards walk ONE insert-size trajectory and
+                                        decide the duplicate cap over ONE input order, so that SAM and profile equal the
+                                        single-stream run's (rank/size must equal shard_rank/shard_count) */
 } mcx_file_opts;
 void mcx_file_opts_default(mcx_file_opts *);
+/* <sam_path>.part<r> (+ .idx) of shards 0..parts-1 -> sam_path, batches in input order; removes the parts */
+int mcx_sam_merge(const char *sam_path, int32_t parts);
 int mcx_map_files_ex(mcx_ctx *, const char *fq1, const char *fq2, const mcx_file_opts *, const char *sam_path, mcx_stats *stats);
 
 #ifdef __cplusplus

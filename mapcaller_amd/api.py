@@ -24,7 +24,13 @@ SYMBOLS = [
     "mcx_avg_init", "mcx_map_batch_dev", "mcx_map_batch", "mcx_cigar_ext", "mcx_map_files", "mcx_map_files_ex", "mcx_file_opts_default",
     "mcx_profile_attach", "mcx_profile_finalize", "mcx_profile_sparse", "mcx_planes_alloc", "mcx_planes_free",
     "mcx_vcf_defaults", "mcx_call_variants",
+    "mcx_batch_begin", "mcx_batch_sums", "mcx_batch_replay", "mcx_batch_end", "mcx_avg_walk", "mcx_exchange_local", "mcx_exchange_local_free",
+    "mcx_profile_sparse_shard", "mcx_batch_end_keys", "mcx_batch_accumulate", "mcx_sam_merge",
 ]
+# include/mcx_comm.h (libmcx_comm.so: the RCCL side, loaded by the native CLI only)
+COMM_LIB_PATH = os.path.join(_HERE, "libmcx_comm.so")
+COMM_SYMBOLS = ["mcx_comm_init_all", "mcx_comm_unique_id", "mcx_comm_init_rank", "mcx_comm_free", "mcx_comm_rank", "mcx_comm_size",
+                "mcx_profile_reduce", "mcx_comm_exchange", "mcx_comm_exchange_free"]
 
 
 class McxError(RuntimeError):
@@ -56,7 +62,7 @@ PLANES = ("A", "C", "G", "T", "multi_hit", "readCount", "F1", "R2", "F2", "R1")
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("reads", "mapped", "pairs", "pair_dist_sum", "pair_len_sum", "fm_ext_steps", "fm_blocks",
-                                         "sa_hits", "dp_jobs", "dp_cells", "tier1_pairs", "replayed_pairs")] + \
+                                         "sa_hits", "dp_jobs", "dp_cells", "tier1_pairs", "replayed_pairs", "halved_selections")] + \
                [(n, C.c_double) for n in ("ms_encode", "ms_seed", "ms_sa", "ms_cluster", "ms_rescue", "ms_build",
                                           "ms_dp", "ms_finish", "ms_total")]
 
@@ -64,10 +70,50 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
+
+
+class Exchange(C.Structure):
+    """mcx_exchange: the collective the shards of one run share (all-gather of host bytes)."""
+    _fields_ = [("user", C.c_void_p), ("rank", C.c_int32), ("size", C.c_int32), ("allgather", ALLGATHER)]
+
+
+def dist_exchange(device=None) -> Exchange:
+    """An mcx_exchange over torch.distributed (backend "nccl" = RCCL: staged through ``device``;
+    "gloo": host tensors).  Keep the returned object alive while the run uses it."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    on_gpu = dist.get_backend() == "nccl"
+
+    def allgather(user, send, recv, nbytes):
+        try:
+            if nbytes == 0:
+                return 0
+            mine = torch.frombuffer((C.c_uint8 * nbytes).from_address(send), dtype=torch.uint8).clone()
+            if on_gpu:
+                mine = mine.to(device)
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            out = torch.cat(parts).cpu().contiguous()
+            C.memmove(recv, out.data_ptr(), world * nbytes)
+            return 0
+        except Exception as e:  # the C side turns this into an error on every shard
+            import sys
+            print(f"mcx exchange: {e}", file=sys.stderr)
+            return -3
+
+    x = Exchange()
+    x.user, x.rank, x.size = None, rank, world
+    x.allgather = ALLGATHER(allgather)
+    return x
+
+
 class FileOpts(C.Structure):
-    """mcx_file_opts: -p, -t, library append, insert-size state across libraries."""
+    """mcx_file_opts: -p, -t, library append, insert-size state across libraries, sharding."""
     _fields_ = [("interleaved_pairs", C.c_int32), ("host_threads", C.c_int32), ("append_sam", C.c_int32), ("no_sam_header", C.c_int32),
-                ("avg_state", C.POINTER(C.c_int64)), ("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("sam_index_path", C.c_char_p)]
+                ("avg_state", C.POINTER(C.c_int64)), ("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("sam_index_path", C.c_char_p),
+                ("exchange", C.POINTER(Exchange))]
 
 
 class VcfOpts(C.Structure):
@@ -134,6 +180,19 @@ def lib() -> C.CDLL:
     L.mcx_profile_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.mcx_profile_finalize.argtypes = [C.c_void_p, C.c_void_p]
     L.mcx_profile_sparse.argtypes = [C.c_void_p, C.POINTER(C.POINTER(SparseRec)), C.POINTER(C.c_uint64)]
+    L.mcx_profile_sparse_shard.argtypes = [C.c_void_p, C.POINTER(C.POINTER(SparseRec)), C.POINTER(C.c_uint64)]
+    L.mcx_batch_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+    L.mcx_batch_sums.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)] + [C.POINTER(C.POINTER(C.c_uint32))] * 3
+    L.mcx_batch_replay.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(Stats)]
+    L.mcx_batch_end.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.mcx_batch_end_keys.argtypes = [C.c_void_p, C.POINTER(Stats), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint64)]
+    L.mcx_batch_accumulate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]
+    L.mcx_avg_walk.argtypes = [C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.mcx_avg_walk.restype = None
+    L.mcx_exchange_local.argtypes = [C.c_int32, C.POINTER(Exchange)]
+    L.mcx_exchange_local_free.argtypes = [C.POINTER(Exchange)]
+    L.mcx_exchange_local_free.restype = None
+    L.mcx_sam_merge.argtypes = [C.c_char_p, C.c_int32]
     L.mcx_planes_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.mcx_planes_free.argtypes = [C.c_void_p]
     L.mcx_planes_free.restype = None
@@ -220,19 +279,22 @@ class Index:
             _check(lib().mcx_call_variants(self._h, d_planes_ptr, raw.ctypes.data, raw.shape[0], pairs, pair_dist_sum, pair_len_sum, C.byref(o),
                                            vcf_path.encode(), C.byref(st)), "mcx_call_variants")
             return st.as_dict()
-        recs = (SparseRec * max(len(sparse), 1))()
-        for i, (t, pos, x) in enumerate(sparse):
-            r = recs[i]
-            r.pos, r.type = pos, ord(t)
+        rows = []  # (type, pos, len byte, payload); a string longer than a record continues in 'C' records behind it
+        for t, pos, x in sparse:
             if t in "VT":
-                r.len = 0
-                C.memmove(C.addressof(r) + 10, int(x).to_bytes(8, "little", signed=True), 8)
+                rows.append((t, pos, 0, int(x).to_bytes(8, "little", signed=True)))
             else:
-                b = x.encode("latin-1")[:54]
-                r.len = len(b)
-                C.memmove(C.addressof(r) + 10, b, len(b))
+                b = x.encode("latin-1")
+                rows.append((t, pos, min(len(b), 255), b[:54]))
+                for lo in range(54, len(b), 54):
+                    rows.append(("C", pos, len(b[lo:lo + 54]), b[lo:lo + 54]))
+        recs = (SparseRec * max(len(rows), 1))()
+        for i, (t, pos, ln, payload) in enumerate(rows):
+            r = recs[i]
+            r.pos, r.type, r.len = pos, ord(t), ln
+            C.memmove(C.addressof(r) + 10, payload, len(payload))
         st = VcfStats()
-        _check(lib().mcx_call_variants(self._h, d_planes_ptr, recs, len(sparse), pairs, pair_dist_sum, pair_len_sum, C.byref(o),
+        _check(lib().mcx_call_variants(self._h, d_planes_ptr, recs, len(rows), pairs, pair_dist_sum, pair_len_sum, C.byref(o),
                                        vcf_path.encode(), C.byref(st)), "mcx_call_variants")
         return st.as_dict()
 
@@ -275,17 +337,28 @@ class Mapper:
 
     # ---- whole path ---------------------------------------------------------------------
     def map_files(self, fq1: str, fq2: Optional[str], sam: Optional[str], interleaved: bool = False, threads: int = 0,
-                  shard: Optional[Tuple[int, int]] = None, sam_header: bool = True, sam_index: Optional[str] = None) -> dict:
+                  shard: Optional[Tuple[int, int]] = None, sam_header: bool = True, sam_index: Optional[str] = None,
+                  exchange: Optional[Exchange] = None, append_sam: bool = False) -> dict:
         """Files in, SAM out (mcx_map_files_ex).  ``interleaved`` = -p, ``threads`` = -t; ``shard`` =
-        (rank, count): map only every count-th batch of the input stream, ``sam_index``: file that
-        receives "batch bytes" per batch written (to merge the parts of a sharded run)."""
+        (rank, count) with ``exchange``: map every count-th batch of the input stream while the shards
+        keep one insert-size trajectory and one duplicate-cap order; ``sam_index``: file that receives
+        "batch bytes" per batch written (to merge the parts of a sharded run, ``merge_sam``).  The
+        insert-size state (self.avg) carries over from call to call like the reference's globals
+        (a new library starts a new 200-read chunk); ``append_sam``: a further library of the same run."""
         st = Stats()
         fo = FileOpts()
         lib().mcx_file_opts_default(C.byref(fo))
         fo.interleaved_pairs, fo.host_threads = int(interleaved), threads
         fo.no_sam_header = 0 if sam_header else 1
-        if shard:
+        fo.append_sam = int(append_sam)
+        if self.avg[3] % 200:
+            self.avg[3] += 200 - self.avg[3] % 200
+        fo.avg_state = C.cast(self.avg, C.POINTER(C.c_int64))
+        if shard and shard[1] > 1:
+            if exchange is None:
+                raise ValueError("a sharded run needs an exchange (api.dist_exchange())")
             fo.shard_rank, fo.shard_count = int(shard[0]), int(shard[1])
+            fo.exchange = C.pointer(exchange)
         if sam_index:
             fo.sam_index_path = sam_index.encode()
         _check(lib().mcx_map_files_ex(self._h, fq1.encode(), (fq2 or "").encode() or None, C.byref(fo), (sam or "").encode() or None,
@@ -317,12 +390,14 @@ class Mapper:
     def profile_finalize(self, d_planes_ptr: int) -> None:
         _check(lib().mcx_profile_finalize(self._h, d_planes_ptr), "mcx_profile_finalize")
 
-    def profile_sparse_raw(self) -> np.ndarray:
+    def profile_sparse_raw(self, shard: bool = False) -> np.ndarray:
         """The same records as they are (uint8 [n, 64] copies of mcx_sparse_rec), for all-gathers
-        and for Index.call_variants without a Python loop."""
+        and for Index.call_variants without a Python loop.  ``shard``: the form for a run spread over
+        several shards (discordant-pair events 'E' instead of the sites they resolve to)."""
         recs = C.POINTER(SparseRec)()
         n = C.c_uint64()
-        _check(lib().mcx_profile_sparse(self._h, C.byref(recs), C.byref(n)), "mcx_profile_sparse")
+        f = lib().mcx_profile_sparse_shard if shard else lib().mcx_profile_sparse
+        _check(f(self._h, C.byref(recs), C.byref(n)), "mcx_profile_sparse")
         if n.value == 0:
             return np.zeros((0, 64), dtype=np.uint8)
         buf = (C.c_uint8 * (64 * n.value)).from_address(C.addressof(recs.contents))
@@ -339,6 +414,9 @@ class Mapper:
             t = chr(r.type)
             if t in "VT":
                 out.append((t, int(r.pos), int.from_bytes(C.string_at(C.addressof(r) + 10, 8), "little", signed=True)))
+            elif t == "C":  # the string of the record before continues
+                pt, pp, ps = out[-1]
+                out[-1] = (pt, pp, ps + C.string_at(C.addressof(r) + 10, min(r.len, 54)).decode("latin-1"))
             else:
                 out.append((t, int(r.pos), C.string_at(C.addressof(r) + 10, min(r.len, 54)).decode("latin-1")))
         return out

@@ -310,12 +310,247 @@ void sam_record(const HostIndex &ix, const Batch &bt, uint32_t r, Text &o)
 
 extern "C" void mcx_file_opts_default(mcx_file_opts *o) { memset(o, 0, sizeof *o); }
 
+// ---- exchange between the host threads of one process (mapcaller-mi355x -gpus N) ------------------------
+namespace {
+struct Rendezvous {
+    std::mutex m; std::condition_variable cv;
+    int size = 0, arrived = 0, left = 0;
+    uint64_t gen = 0, gen_out = 0;
+    std::vector<const void *> ptr;
+};
+struct LocalPeer { Rendezvous *rv; int rank; };
+
+int local_allgather(void *user, const void *send, void *recv, uint64_t bytes)
+{
+    LocalPeer *p = (LocalPeer *)user;
+    Rendezvous &rv = *p->rv;
+    {
+        std::unique_lock<std::mutex> l(rv.m);
+        rv.ptr[(size_t)p->rank] = send;
+        const uint64_t g = rv.gen;
+        if (++rv.arrived == rv.size) { rv.arrived = 0; rv.gen++; rv.cv.notify_all(); }
+        else rv.cv.wait(l, [&] { return rv.gen != g; });
+    }
+    for (int r = 0; r < rv.size; r++) memcpy((uint8_t *)recv + (size_t)r * bytes, rv.ptr[(size_t)r], bytes);
+    { // nobody's send buffer may change before everyone has copied it
+        std::unique_lock<std::mutex> l(rv.m);
+        const uint64_t g = rv.gen_out;
+        if (++rv.left == rv.size) { rv.left = 0; rv.gen_out++; rv.cv.notify_all(); }
+        else rv.cv.wait(l, [&] { return rv.gen_out != g; });
+    }
+    return 0;
+}
+} // namespace
+
+extern "C" int mcx_exchange_local(int32_t size, mcx_exchange *out)
+{
+    if (size < 1 || !out) return mcx_set_error(MCX_ERR_ARG, "mcx_exchange_local: bad argument");
+    Rendezvous *rv = new Rendezvous();
+    rv->size = size; rv->ptr.assign((size_t)size, nullptr);
+    LocalPeer *peers = new LocalPeer[(size_t)size];
+    for (int r = 0; r < size; r++) {
+        peers[r].rv = rv; peers[r].rank = r;
+        out[r].user = &peers[r]; out[r].rank = r; out[r].size = size; out[r].allgather = local_allgather;
+    }
+    return 0;
+}
+
+extern "C" void mcx_exchange_local_free(mcx_exchange *first)
+{
+    if (!first || !first->user) return;
+    LocalPeer *peers = (LocalPeer *)first->user; // (rank 0's entry is the head of the array)
+    delete peers[0].rv;
+    delete[] peers;
+    first->user = nullptr;
+}
+
+// The parts of a sharded run back into input order (batch k was written by shard k % parts): <sam>.part<r> with
+// <sam>.part<r>.idx ("batch bytes" per line); part 0 starts with the header.  The parts are removed.
+extern "C" int mcx_sam_merge(const char *sam_path, int32_t parts)
+{
+    if (!sam_path || parts < 1) return mcx_set_error(MCX_ERR_ARG, "mcx_sam_merge: bad argument");
+    const std::string base(sam_path);
+    struct Part { FILE *f = nullptr; std::vector<std::pair<uint64_t, uint64_t>> idx; size_t next = 0; };
+    std::vector<Part> ps((size_t)parts);
+    auto close_all = [&] { for (Part &q : ps) if (q.f) fclose(q.f); };
+    for (int r = 0; r < parts; r++) {
+        const std::string pn = base + ".part" + std::to_string(r);
+        FILE *ix = fopen((pn + ".idx").c_str(), "r");
+        ps[(size_t)r].f = fopen(pn.c_str(), "rb");
+        if (!ix || !ps[(size_t)r].f) { if (ix) fclose(ix); close_all(); return mcx_set_error(MCX_ERR_IO, "cannot read " + pn); }
+        unsigned long long k, b;
+        while (fscanf(ix, "%llu %llu", &k, &b) == 2) ps[(size_t)r].idx.push_back(std::make_pair((uint64_t)k, (uint64_t)b));
+        fclose(ix);
+    }
+    FILE *out = fopen(sam_path, "wb");
+    if (!out) { close_all(); return mcx_set_error(MCX_ERR_IO, "cannot write " + base); }
+    std::vector<char> buf(1 << 22);
+    auto copy = [&](FILE *f, uint64_t n) {
+        while (n) {
+            const size_t want = (size_t)std::min<uint64_t>(n, buf.size()), got = fread(buf.data(), 1, want, f);
+            if (got == 0 || fwrite(buf.data(), 1, got, out) != got) return false;
+            n -= got;
+        }
+        return true;
+    };
+    bool ok = true;
+    { // the header: what part 0 holds before its first batch
+        fseek(ps[0].f, 0, SEEK_END);
+        uint64_t total = (uint64_t)ftell(ps[0].f), body = 0;
+        fseek(ps[0].f, 0, SEEK_SET);
+        for (auto &e : ps[0].idx) body += e.second;
+        ok = total >= body && copy(ps[0].f, total - body);
+    }
+    for (uint64_t k = 0; ok; k++) { // batches in input order
+        Part &q = ps[(size_t)(k % (uint64_t)parts)];
+        if (q.next >= q.idx.size()) {
+            // batches without output (an empty tail) are not listed: done when no part has anything left
+            bool any = false;
+            for (Part &o : ps) if (o.next < o.idx.size()) any = true;
+            if (!any) break;
+            continue;
+        }
+        if (q.idx[q.next].first != k) continue;
+        ok = copy(q.f, q.idx[q.next].second);
+        q.next++;
+    }
+    close_all();
+    if (fclose(out) != 0) ok = false;
+    if (!ok) return mcx_set_error(MCX_ERR_IO, "cannot merge the parts of " + base);
+    for (int r = 0; r < parts; r++) { const std::string pn = base + ".part" + std::to_string(r); remove(pn.c_str()); remove((pn + ".idx").c_str()); }
+    return 0;
+}
+
+// ---- one round of a run spread over several shards ------------------------------------------------------
+// Round j holds batches j*N .. j*N+N-1, one per shard.  The shards exchange (a) what each has in the round,
+// (b) per-chunk pair sums until the ONE insert-size trajectory of the input stream (ReadMapping.cpp:462,
+// :538-539) has been walked over all of them and no shard had to re-run a pair, (c) with -vcf, the duplicate-check
+// keys, so that the cap admits reads in input order across shards (AlignmentProfile.cpp:76-77).  Every shard makes
+// the same sequence of exchange calls whatever it holds; a failing shard keeps taking part until the round's
+// next message has told the others.
+namespace {
+struct Shards {
+    const mcx_exchange *x;
+    uint32_t slot_stride;   // reads a batch holds at most
+    uint32_t cap_chunks;
+    std::vector<uint8_t> recv;
+    std::vector<uint32_t> msg;
+    std::vector<uint64_t> all_keys, pad_keys;
+    struct Head { int32_t rc; uint32_t n_pair, n_single, last; };
+
+    int gather(const void *send, size_t bytes)
+    {
+        recv.resize(bytes * (size_t)x->size);
+        return x->allgather(x->user, send, recv.data(), bytes) ? mcx_set_error(MCX_ERR_DEVICE, "the exchange between the shards failed") : 0;
+    }
+    // any shard's failure ends the run on all of them
+    int agree(int my_rc)
+    {
+        int32_t v = my_rc;
+        if (int e = gather(&v, sizeof v)) return e;
+        if (my_rc) return my_rc;
+        for (int r = 0; r < x->size; r++) { int32_t o; memcpy(&o, recv.data() + (size_t)r * sizeof o, sizeof o); if (o) return mcx_set_error(o, "shard " + std::to_string(r) + " failed"); }
+        return 0;
+    }
+
+    // closes a part of the round: -vcf bookkeeping with the keys of every shard, or the plain end
+    int finish_part(mcx_ctx *c, bool mine, bool profile, mcx_stats *stats, int rc)
+    {
+        if (!profile) { if (rc == 0 && mine) rc = mcx_batch_end(c, stats); return agree(rc); }
+        const uint64_t *keys = nullptr; uint64_t nk = 0;
+        if (rc == 0 && mine) rc = mcx_batch_end_keys(c, stats, &keys, &nk);
+        if (rc) nk = 0;
+        struct { int32_t rc; uint32_t pad; uint64_t n; } h = {rc, 0, nk}, o;
+        if (int e = gather(&h, sizeof h)) return e;
+        uint64_t most = 0, total = 0;
+        std::vector<uint64_t> cnt((size_t)x->size);
+        int bad = rc;
+        for (int r = 0; r < x->size; r++) { memcpy(&o, recv.data() + (size_t)r * sizeof o, sizeof o); cnt[(size_t)r] = o.n; most = std::max(most, o.n); total += o.n; if (!bad && o.rc) bad = mcx_set_error(o.rc, "shard " + std::to_string(r) + " failed"); }
+        if (bad) return bad;
+        if (most == 0) { if (mine) rc = mcx_batch_accumulate(c, nullptr, 0, slot_stride, (uint32_t)x->rank); return agree(rc); }
+        pad_keys.assign((size_t)most, ~0ull);
+        for (uint64_t i = 0; i < nk; i++) pad_keys[(size_t)i] = keys[i] + (uint64_t)x->rank * slot_stride; // the read's number within the round
+        if (int e = gather(pad_keys.data(), (size_t)most * sizeof(uint64_t))) return e;
+        all_keys.clear(); all_keys.reserve((size_t)total);
+        for (int r = 0; r < x->size; r++) {
+            const uint64_t *p = (const uint64_t *)(recv.data() + (size_t)r * (size_t)most * sizeof(uint64_t));
+            all_keys.insert(all_keys.end(), p, p + cnt[(size_t)r]);
+        }
+        rc = mcx_batch_accumulate(c, all_keys.data(), all_keys.size(), slot_stride, mine ? (uint32_t)x->rank : 0xFFFFFFFFu);
+        return agree(rc);
+    }
+
+    // The paired part of a round.  n = this shard's reads (0: none); avg = the run's state {avgDist, pairs, distance, reads}.
+    int pairs(mcx_ctx *c, const uint8_t *bases, const uint32_t *off, uint32_t n, int64_t read_base, int64_t avg[4], bool profile,
+              mcx_aln *aln, uint32_t *cig, mcx_stats *stats)
+    {
+        int rc = 0;
+        const uint8_t *d_bases = nullptr; const uint32_t *d_off = nullptr; mcx_aln *d_aln = nullptr; uint32_t *d_cig = nullptr;
+        if (n) {
+            rc = mcx_stage_in(c, bases, off, n, &d_bases, &d_off, &d_aln, &d_cig);
+            if (rc == 0) rc = mcx_batch_begin(c, d_bases, d_off, n, 1, (int32_t)((uint32_t)avg[0] * 1.5), read_base, d_aln, d_cig, stats);
+        }
+        const size_t words = 4 + 2 * (size_t)cap_chunks;
+        msg.assign(words, 0);
+        std::vector<int32_t> est(cap_chunks);
+        uint32_t n_redo = 0xFFFFFFFFu; // "not replayed yet"
+        int64_t st[3] = {avg[0], avg[1], avg[2]};
+        for (int iter = 0;; iter++) {
+            uint32_t nc = 0;
+            const uint32_t *ok = nullptr, *ds = nullptr;
+            if (rc == 0 && n) rc = mcx_batch_sums(c, &nc, &ok, &ds, nullptr);
+            if (rc == 0 && nc > cap_chunks) rc = mcx_set_error(MCX_ERR_ARG, "a batch holds more chunks than the shards agreed on");
+            msg[0] = (uint32_t)rc; msg[1] = rc ? 0 : nc; msg[2] = n_redo; msg[3] = 0;
+            if (rc == 0 && nc) { memcpy(&msg[4], ok, nc * 4); memcpy(&msg[4 + cap_chunks], ds, nc * 4); }
+            if (int e = gather(msg.data(), words * 4)) return e;
+            bool settled = iter > 0;
+            for (int r = 0; r < x->size; r++) {
+                const uint32_t *m = (const uint32_t *)(recv.data() + (size_t)r * words * 4);
+                if (m[0]) return rc ? rc : mcx_set_error((int32_t)m[0], "shard " + std::to_string(r) + " failed");
+                if (m[1] && m[2]) settled = false;
+            }
+            // the trajectory over the round's batches in input order; this shard keeps the estimates of its own chunks
+            st[0] = avg[0]; st[1] = avg[1]; st[2] = avg[2];
+            for (int r = 0; r < x->size; r++) {
+                const uint32_t *m = (const uint32_t *)(recv.data() + (size_t)r * words * 4);
+                mcx_avg_walk(st, m + 4, m + 4 + cap_chunks, m[1], r == x->rank ? est.data() : nullptr);
+            }
+            if (settled) break;
+            if (iter == 255) return mcx_set_error(MCX_ERR_CAPACITY, "avgDist replay did not converge");
+            n_redo = 0;
+            if (n) rc = mcx_batch_replay(c, est.data(), &n_redo, stats);
+        }
+        avg[0] = st[0]; avg[1] = st[1]; avg[2] = st[2];
+        rc = finish_part(c, n != 0, profile, stats, 0);
+        if (rc == 0 && n) rc = mcx_stage_out(c, n, aln, cig);
+        return rc;
+    }
+
+    // reads mapped one by one (single-end libraries, the odd tail of an interleaved file): no trajectory
+    int singles(mcx_ctx *c, const uint8_t *bases, const uint32_t *off, uint32_t n, int64_t read_base, bool profile, mcx_aln *aln, uint32_t *cig,
+                mcx_stats *stats)
+    {
+        int rc = 0;
+        const uint8_t *d_bases = nullptr; const uint32_t *d_off = nullptr; mcx_aln *d_aln = nullptr; uint32_t *d_cig = nullptr;
+        if (n) {
+            rc = mcx_stage_in(c, bases, off, n, &d_bases, &d_off, &d_aln, &d_cig);
+            if (rc == 0) rc = mcx_batch_begin(c, d_bases, d_off, n, 0, 0, read_base, d_aln, d_cig, stats);
+        }
+        rc = finish_part(c, n != 0 && rc == 0, profile, stats, rc);
+        if (rc == 0 && n) rc = mcx_stage_out(c, n, aln, cig);
+        return rc;
+    }
+};
+} // namespace
+
 extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, const mcx_file_opts *fo, const char *sam_path, mcx_stats *stats)
 {
     if (!c || !fq1) return mcx_set_error(MCX_ERR_ARG, "mcx_map_files: null argument");
     mcx_file_opts opt;
     mcx_file_opts_default(&opt);
     if (fo) opt = *fo;
+    if (opt.shard_count > 1 && (!opt.exchange || !opt.exchange->allgather || opt.exchange->size != opt.shard_count || opt.exchange->rank != opt.shard_rank))
+        return mcx_set_error(MCX_ERR_ARG, "mcx_map_files_ex: a sharded run needs mcx_file_opts.exchange with the shard's rank and count");
     const mcx_index *idx = mcx_ctx_index(c);
     const HostIndex &hix = idx->host;
     const int max_len = mcx_ctx_max_read_len(c);
@@ -340,6 +575,7 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
         if (!sam_index) return mcx_set_error(MCX_ERR_IO, std::string("cannot write ") + opt.sam_index_path);
     }
     const uint64_t batch_reads = std::max<uint64_t>(kReadChunkSize, mcx_ctx_max_reads(c) / kReadChunkSize * kReadChunkSize);
+
     int64_t local_avg[4];
     mcx_avg_init(local_avg);
     int64_t *avg = opt.avg_state ? opt.avg_state : local_avg;
@@ -428,6 +664,12 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
 
     // stage 2 (this thread): interleave, map on the GPU
     int rc = 0;
+    const bool sharded = shard_count > 1;
+    const bool profile = mcx_ctx_has_profile(c);
+    Shards sh;
+    sh.x = opt.exchange; sh.slot_stride = (uint32_t)batch_reads; sh.cap_chunks = (uint32_t)(batch_reads / kReadChunkSize + 2);
+    uint64_t rounds_done = 0;
+    bool dead = false; // a shard failed and every shard knows
     for (;;) {
         BatchPtr b = parsed.pop();
         const bool last = b->last;
@@ -441,6 +683,8 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
             if (!b->reserve(std::max<size_t>(n, batch_reads), std::max<size_t>(total + 64, batch_reads * 160))) { rc = mcx_set_error(MCX_ERR_DEVICE, "cannot allocate pinned host memory"); b->n = 0; }
             t_pack += secs(t0, now());
         }
+        uint32_t n_pairs_reads = 0;
+        auto t1 = now();
         if (rc == 0 && n) {
             const auto t0 = now();
             b->off[0] = 0;
@@ -454,37 +698,70 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
             else memcpy(b->bases, b->in[0].seq.data(), b->off[n]);
             memset(b->bases + b->off[n], 0, 64);
             b->is_mate2.assign(n, 0);
-            const auto t1 = now();
+            t1 = now();
             t_pack += secs(t0, t1);
-            uint32_t n_pairs_reads = paired ? n : 0;
+            n_pairs_reads = paired ? n : 0;
             if (paired && (n & 1)) n_pairs_reads = n / kReadChunkSize * kReadChunkSize;
-            if (n_pairs_reads) {
-                rc = mcx_map_batch(c, b->bases, b->off, n_pairs_reads, 1, avg, (mcx_aln *)b->recs, b->cig, stats);
-                for (uint32_t r = 1; r < n_pairs_reads; r += 2) b->is_mate2[r] = 1;
-            }
+            for (uint32_t r = 1; r < n_pairs_reads; r += 2) b->is_mate2[r] = 1;
             b->cig_ext.clear();
-            auto take_ext = [&](uint32_t first, uint32_t last) { // long CIGARs of the reads just mapped
-                const uint32_t *w = nullptr; uint64_t nw = 0;
-                int e = mcx_cigar_ext(c, 0, &w, &nw);
-                if (e || nw == 0) return e;
-                const size_t base = b->cig_ext.size();
-                b->cig_ext.insert(b->cig_ext.end(), w, w + nw);
-                if (base) for (uint32_t r = first; r < last; r++) if (b->recs[r].n_cigar > MCX_CIGAR_STRIDE) b->recs[r].pad[0] += (int32_t)base;
-                return 0;
-            };
-            if (rc == 0 && n_pairs_reads) rc = take_ext(0, n_pairs_reads);
+        }
+        auto take_ext = [&](uint32_t first, uint32_t last_read) { // long CIGARs of the reads just mapped
+            const uint32_t *w = nullptr; uint64_t nw = 0;
+            int e = mcx_cigar_ext(c, 0, &w, &nw);
+            if (e || nw == 0) return e;
+            const size_t base = b->cig_ext.size();
+            b->cig_ext.insert(b->cig_ext.end(), w, w + nw);
+            if (base) for (uint32_t r = first; r < last_read; r++) if (b->recs[r].n_cigar > MCX_CIGAR_STRIDE) b->recs[r].pad[0] += (int32_t)base;
+            return 0;
+        };
+        // the single-read part (a single-end library, or the odd tail of an interleaved file) as a batch of its own
+        std::vector<uint32_t> off2;
+        uint32_t base2 = 0;
+        if (rc == 0 && n_pairs_reads < n) {
+            off2.assign(b->off + n_pairs_reads, b->off + n + 1);
+            base2 = off2[0];
+            for (auto &x : off2) x -= base2;
+        }
+        if (!sharded) {
+            if (rc == 0 && n_pairs_reads) {
+                rc = mcx_map_batch(c, b->bases, b->off, n_pairs_reads, 1, avg, (mcx_aln *)b->recs, b->cig, stats);
+                if (rc == 0) rc = take_ext(0, n_pairs_reads);
+            }
             if (rc == 0 && n_pairs_reads < n) {
-                std::vector<uint32_t> off2(b->off + n_pairs_reads, b->off + n + 1);
-                const uint32_t base = off2[0];
-                for (auto &x : off2) x -= base;
-                rc = mcx_map_batch(c, b->bases + base, off2.data(), n - n_pairs_reads, 0, avg, (mcx_aln *)b->recs + n_pairs_reads,
+                rc = mcx_map_batch(c, b->bases + base2, off2.data(), n - n_pairs_reads, 0, avg, (mcx_aln *)b->recs + n_pairs_reads,
                                    b->cig + (size_t)n_pairs_reads * MCX_CIGAR_STRIDE, stats);
                 if (rc == 0) rc = take_ext(n_pairs_reads, n);
             }
-            t_map += secs(t1, now());
-            if (rc) b->n = 0;
+        } else if (!dead && b->number / shard_count >= rounds_done) {
+            rounds_done = b->number / shard_count + 1;
+            Shards::Head h = {rc, rc ? 0u : n_pairs_reads, rc ? 0u : n - n_pairs_reads, last ? 1u : 0u};
+            int e = sh.gather(&h, sizeof h);
+            bool any_pair = false, any_single = false;
+            uint64_t before = 0, round_total = 0;
+            if (e) rc = e;
+            else for (int r = 0; r < sh.x->size; r++) {
+                Shards::Head o; memcpy(&o, sh.recv.data() + (size_t)r * sizeof o, sizeof o);
+                if (o.rc && rc == 0) rc = mcx_set_error(o.rc, "shard " + std::to_string(r) + " failed");
+                any_pair |= o.n_pair != 0; any_single |= o.n_single != 0;
+                if (r < sh.x->rank) before += (uint64_t)o.n_pair + o.n_single;
+                round_total += (uint64_t)o.n_pair + o.n_single;
+            }
+            const int64_t round_base = avg[3];
+            if (rc == 0 && any_pair) {
+                rc = sh.pairs(c, b->bases, b->off, n_pairs_reads, round_base + (int64_t)before, avg, profile, (mcx_aln *)b->recs, b->cig, stats);
+                if (rc == 0 && n_pairs_reads) rc = take_ext(0, n_pairs_reads);
+            }
+            if (rc == 0 && any_single) {
+                const uint32_t ns = n - n_pairs_reads;
+                rc = sh.singles(c, ns ? b->bases + base2 : nullptr, ns ? off2.data() : nullptr, ns, round_base + (int64_t)before + n_pairs_reads, profile,
+                                (mcx_aln *)b->recs + n_pairs_reads, b->cig + (size_t)n_pairs_reads * MCX_CIGAR_STRIDE, stats);
+                if (rc == 0 && ns) rc = take_ext(n_pairs_reads, n);
+            }
+            avg[3] = round_base + (int64_t)round_total;
+            if (rc) dead = true;
         }
-        if (rc) abort.store(true);
+        if (n) t_map += secs(t1, now());
+        if (rc) { b->n = 0; abort.store(true); }
         b->last = last; // after an error the remaining batches pass through empty until the parser's last one
         mapped.push(std::move(b));
         if (last) break;

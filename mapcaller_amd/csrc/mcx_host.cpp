@@ -5,6 +5,7 @@
 // the loader mirrors src/bwt_index.cpp:16-124 and :232-258.  (Read files and SAM lines: mcx_files.cpp.)
 #include "mcx_host.h"
 #include "mcx_types.h"
+#include "../../include/mcx.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -106,3 +107,38 @@ void sam_header(const HostIndex &ix, std::string &out) // OutputSamHeaders, Read
 }
 
 } // namespace mcx
+
+void mcx_disc_resolve(const mcx_sparse_rec *events, size_t n, int64_t G, std::vector<mcx_sparse_rec> &out)
+{
+    std::vector<const mcx_sparse_rec *> ev;
+    for (size_t i = 0; i < n; i++) if (events[i].type == 'E') ev.push_back(events + i);
+    std::stable_sort(ev.begin(), ev.end(), [](const mcx_sparse_rec *a, const mcx_sparse_rec *b) { return a->pos < b->pos; });
+    const int64_t G2 = 2 * G;
+    int64_t last[2] = {0, 0}; // DiscordPair {gPos, dist}
+    auto push = [&](char type, int64_t gpos, int64_t dist) {
+        mcx_sparse_rec r; memset(&r, 0, sizeof r);
+        r.pos = gpos; r.type = (uint8_t)type; r.len = 0; memcpy(r.seq, &dist, 8);
+        out.push_back(r);
+    };
+    for (const mcx_sparse_rec *e : ev) {
+        int64_t g1, g2, dist;
+        memcpy(&g1, e->seq, 8); memcpy(&g2, e->seq + 8, 8); memcpy(&dist, e->seq + 16, 8);
+        const int kind = e->len;
+        if (kind == 1) {
+            int64_t d = G2 - g1 - g2; if (d < 0) d = -d;
+            if (d > 1000 && d < 10000000) push('V', g1, d);
+            last[0] = g1; last[1] = d;
+        } else if (kind == 2) {
+            int64_t d = G2 - g1 - g2; if (d < 0) d = -d;
+            last[1] = d;
+            if (d > 1000 && d < 10000000) last[0] = g2;
+            push('V', last[0], last[1]);
+        } else if (kind == 3) {
+            push('T', g1, dist); push('T', g2, dist);
+            last[0] = g2; last[1] = dist;
+        } else {
+            push('T', G2 - g1, dist); push('T', G2 - g2, dist);
+            last[0] = G2 - g2; last[1] = dist;
+        }
+    }
+}

@@ -29,4 +29,15 @@ void host_index_finish(HostIndex &ix); // fills chr_fwd / end_pos / end_chr from
 void sam_header(const HostIndex &ix, std::string &out);
 
 } // namespace mcx
+
+// Discordant-pair events ('E' records: pos = pair number in input order, len = branch, seq = g1, g2, dist) ->
+// the inversion / translocation site records ('V' / 'T') the reference pushes at ReadMapping.cpp:486-521,
+// appended to out.  Replayed in input order: the second branch pushes the DiscordPair variable with whatever
+// the previous discordant pair of the stream left in it (ReadMapping.cpp:418, :499-505).
+struct mcx_sparse_rec;
+void mcx_disc_resolve(const mcx_sparse_rec *events, size_t n, int64_t G, std::vector<mcx_sparse_rec> &out);
+
+namespace mcx {
+
+} // namespace mcx
 #endif

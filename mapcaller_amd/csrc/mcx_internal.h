@@ -20,6 +20,11 @@ struct mcx_index {
 const mcx_index *mcx_ctx_index(const mcx_ctx *);
 int mcx_ctx_max_read_len(const mcx_ctx *);
 uint64_t mcx_ctx_max_reads(const mcx_ctx *);
+// host buffers <-> the context's staging arrays in HBM, on the context's stream (stage_out waits for it)
+int mcx_stage_in(mcx_ctx *, const uint8_t *bases, const uint32_t *off, uint32_t n_reads, const uint8_t **d_bases, const uint32_t **d_off,
+                 mcx_aln **d_aln, uint32_t **d_cigar);
+int mcx_stage_out(mcx_ctx *, uint32_t n_reads, mcx_aln *aln, uint32_t *cigar);
+bool mcx_ctx_has_profile(const mcx_ctx *);
 void *mcx_pinned_alloc(size_t bytes); // page-locked host memory (null on failure); mcx_pinned_free accepts null
 void mcx_pinned_free(void *);
 

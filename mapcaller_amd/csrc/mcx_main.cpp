@@ -3,11 +3,13 @@
 // -sam out, -vcf out (on by default, like the reference) with the variant-calling switches, plus
 // `index ref.fa prefix`.  Host code only: everything heavy goes through mcx.h.
 #include "../../include/mcx.h"
+#include "../../include/mcx_comm.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 #include <unistd.h>
 #include <zlib.h>
@@ -64,6 +66,9 @@ static void usage(const char *prog)
             "         -t INT        host threads that parse reads and format SAM lines [half the cores, at most 32]\n"
             "         -maxlen INT   longest read the run has to take [sampled from the first reads, at least 256, at most 1000]\n"
             "         -gpu INT      device ordinal [0]\n"
+            "         -gpus INT     number of GPUs of this node to spread the reads over (devices 0..INT-1) [1]\n"
+            "         -devices LIST device ordinals, comma separated (instead of -gpus)\n"
+            "         -batch INT    reads per batch (the unit dealt to the GPUs) [524288]\n"
             "         -sampled_sa   keep only the sampled suffix array in HBM (saves 8 bytes per text position, slower seeding)\n", prog, prog);
 }
 
@@ -80,7 +85,9 @@ int main(int argc, char **argv)
     std::vector<std::string> f1, f2;
     mcx_opts o;
     mcx_opts_default(&o);
-    int gpu = 0, full_sa = 1, maxlen = 0;
+    int gpu = 0, full_sa = 1, maxlen = 0, n_gpus = 1;
+    long long batch_reads = 0;
+    std::vector<int32_t> devices;
     mcx_file_opts fo;
     mcx_file_opts_default(&fo);
     bool want_vcf = true; // bVCFoutput, main.cpp:171
@@ -114,6 +121,9 @@ int main(int argc, char **argv)
         else if (p == "-t" && i + 1 < argc) { if ((fo.host_threads = atoi(argv[++i])) <= 0) { fprintf(stderr, "Warning! The thread number should be positive!\n"); fo.host_threads = 4; } }
         else if (p == "-pair" || p == "-p") fo.interleaved_pairs = 1;
         else if (p == "-gpu" && i + 1 < argc) gpu = atoi(argv[++i]);
+        else if (p == "-gpus" && i + 1 < argc) n_gpus = std::max(1, atoi(argv[++i]));
+        else if (p == "-devices" && i + 1 < argc) { for (char *t = strtok(argv[++i], ","); t; t = strtok(nullptr, ",")) devices.push_back(atoi(t)); }
+        else if (p == "-batch" && i + 1 < argc) batch_reads = atoll(argv[++i]);
         else if (p == "-maxlen" && i + 1 < argc) maxlen = atoi(argv[++i]);
         else if (p == "-sampled_sa") full_sa = 0;
         else if (p == "-vcf" && i + 1 < argc) vcf = argv[++i];
@@ -135,63 +145,154 @@ int main(int argc, char **argv)
     }
     if (f1.empty()) { fprintf(stderr, "Warning! Please specify a valid read input!\n"); usage(argv[0]); return 0; }
     if (!f2.empty() && f1.size() != f2.size()) { fprintf(stderr, "Warning! Paired-end reads input numbers do not match!\n"); return 0; }
+    if (devices.empty()) for (int r = 0; r < n_gpus; r++) devices.push_back(n_gpus == 1 ? gpu : r);
+    n_gpus = (int)devices.size();
     std::string tmp_prefix;
     if (!ref.empty()) {
         tmp_prefix = "/tmp/mcx_idx_" + std::to_string((long long)getpid());
-        int rc = mcx_index_build(ref.c_str(), tmp_prefix.c_str(), gpu);
+        int rc = mcx_index_build(ref.c_str(), tmp_prefix.c_str(), devices[0]);
         if (rc) { fprintf(stderr, "index: %s (%d)\n", mcx_last_error(), rc); return 1; }
         prefix = tmp_prefix;
     }
     if (prefix.empty()) { fprintf(stderr, "Warning! Please specify a valid reference index!\n"); usage(argv[0]); return 0; }
-    mcx_index *ix = nullptr;
-    int rc = mcx_index_load(prefix.c_str(), gpu, full_sa, &ix);
-    if (rc) { fprintf(stderr, "Error! %s\n", mcx_last_error()); return 1; }
-    o.max_batch_reads = 1 << 19; // per batch of the parse | map | format pipeline
+    o.max_batch_reads = batch_reads > 0 ? batch_reads : 1 << 19; // per batch of the parse | map | format pipeline
     if (maxlen <= 0) {
         for (const std::string &f : f1) maxlen = std::max(maxlen, sample_read_length(f));
         for (const std::string &f : f2) maxlen = std::max(maxlen, sample_read_length(f));
         maxlen = (maxlen + 63) / 64 * 64;
     }
     o.max_read_len = std::min(1000, std::max(256, maxlen));
-    mcx_ctx *cx = nullptr;
-    rc = mcx_ctx_create(ix, &o, &cx);
-    if (rc) { fprintf(stderr, "Error! %s\n", mcx_last_error()); return 1; }
+
+    // One shard per GPU, one host thread each (the whole run on this thread when there is one GPU).  The input stream is
+    // cut into batches that are dealt to the shards in turn; between them the shards exchange what keeps the run equal
+    // to the single-stream one (insert-size trajectory, duplicate cap: mcx_file_opts.exchange); every shard writes its
+    // part of the SAM, shard 0 merges the parts in input order; with -vcf the counter planes are summed onto shard 0
+    // over RCCL (mcx_profile_reduce) and the sparse tallies of all shards go to its VariantCalling().
+    struct Shard {
+        int rank = 0, device = 0, rc = 0;
+        std::string err;
+        mcx_index *ix = nullptr; mcx_ctx *cx = nullptr; uint32_t *planes = nullptr;
+        mcx_stats st;
+        const mcx_sparse_rec *recs = nullptr; uint64_t n_recs = 0;
+        double reduce_s = 0;
+    };
+    std::vector<Shard> shards((size_t)n_gpus);
+    std::vector<mcx_exchange> links((size_t)n_gpus);
+    std::vector<mcx_comm *> comms((size_t)n_gpus, nullptr);
+    if (n_gpus > 1) {
+        if (mcx_exchange_local(n_gpus, links.data())) { fprintf(stderr, "Error! %s\n", mcx_last_error()); return 1; }
+        if (want_vcf && mcx_comm_init_all(n_gpus, devices.data(), comms.data())) { fprintf(stderr, "Error! %s\n", mcx_last_error()); return 1; }
+    }
+    const bool paired_run = !f2.empty() || fo.interleaved_pairs;
+    auto work = [&](int r) {
+        Shard &sh = shards[(size_t)r];
+        sh.rank = r; sh.device = devices[(size_t)r];
+        memset(&sh.st, 0, sizeof sh.st);
+        auto bad = [&](int rc) { sh.rc = rc; sh.err = mcx_last_error(); };
+        int rc = mcx_index_load(prefix.c_str(), sh.device, full_sa, &sh.ix);
+        if (rc == 0) rc = mcx_ctx_create(sh.ix, &o, &sh.cx);
+        if (rc == 0 && want_vcf) { // MappingRecordArr, main.cpp:366-370
+            if (r == 0) fprintf(stderr, "Initialize the alignment profile...\n");
+            if ((rc = mcx_planes_alloc(sh.ix, &sh.planes)) == 0) rc = mcx_profile_attach(sh.cx, sh.planes, vo.max_dup, vo.max_clip);
+        }
+        if (rc) bad(rc);
+        mcx_file_opts my = fo;
+        int64_t avg[4];
+        mcx_avg_init(avg); // avgDist and its totals are globals of the reference: they carry over from library to library
+        my.avg_state = avg;
+        if (n_gpus > 1) { my.shard_rank = r; my.shard_count = n_gpus; my.exchange = &links[(size_t)r]; }
+        for (size_t k = 0; k < f1.size(); k++) {
+            // like the reference, every library appends to the same SAM stream; only the first writes the header
+            if (avg[3] % 200) avg[3] += 200 - avg[3] % 200; // a new library starts a new chunk
+            std::string out = sam, idx_path;
+            if (n_gpus > 1 && !sam.empty()) {
+                const std::string base = k == 0 ? sam : sam + ".lib" + std::to_string(k);
+                out = base + ".part" + std::to_string(r);
+                idx_path = out + ".idx";
+                my.no_sam_header = (r != 0 || k > 0) ? 1 : 0;
+                my.append_sam = 0;
+                my.sam_index_path = idx_path.c_str();
+            } else my.append_sam = k > 0;
+            if (n_gpus > 1) { // a shard that could not even start must not leave the others waiting in the first exchange
+                int32_t mine = sh.rc;
+                std::vector<int32_t> all((size_t)n_gpus);
+                links[(size_t)r].allgather(links[(size_t)r].user, &mine, all.data(), sizeof mine);
+                bool stop = false;
+                for (int32_t v : all) if (v) stop = true;
+                if (stop) { if (!sh.rc) { sh.rc = MCX_ERR_DEVICE; sh.err = "another shard failed"; } break; }
+            } else if (sh.rc) break;
+            rc = mcx_map_files_ex(sh.cx, f1[k].c_str(), f2.empty() ? nullptr : f2[k].c_str(), &my, out.empty() ? nullptr : out.c_str(), &sh.st);
+            if (rc) bad(rc);
+            if (n_gpus > 1) { // every part of this library is complete before shard 0 merges them
+                int32_t mine = sh.rc;
+                std::vector<int32_t> all((size_t)n_gpus);
+                links[(size_t)r].allgather(links[(size_t)r].user, &mine, all.data(), sizeof mine);
+                bool stop = false;
+                for (int32_t v : all) if (v) stop = true;
+                if (stop) { if (!sh.rc) { sh.rc = MCX_ERR_DEVICE; sh.err = "another shard failed"; } break; }
+                if (r == 0 && !sam.empty()) {
+                    const std::string base = k == 0 ? sam : sam + ".lib" + std::to_string(k);
+                    if ((rc = mcx_sam_merge(base.c_str(), n_gpus))) { bad(rc); }
+                    else if (k > 0) { // append this library's lines to the run's SAM
+                        FILE *in = fopen(base.c_str(), "rb"), *dst = fopen(sam.c_str(), "ab");
+                        std::vector<char> buf(1 << 22);
+                        size_t got;
+                        while (in && dst && (got = fread(buf.data(), 1, buf.size(), in)) > 0) fwrite(buf.data(), 1, got, dst);
+                        if (in) fclose(in);
+                        if (dst) fclose(dst);
+                        remove(base.c_str());
+                    }
+                }
+            }
+        }
+        if (n_gpus > 1 && want_vcf) { // the one collective of the run; every shard takes part even after a failure elsewhere
+            bool all_ok = true;
+            int32_t mine = sh.rc;
+            std::vector<int32_t> all((size_t)n_gpus);
+            links[(size_t)r].allgather(links[(size_t)r].user, &mine, all.data(), sizeof mine);
+            for (int32_t v : all) if (v) all_ok = false;
+            if (all_ok && (rc = mcx_profile_reduce(comms[(size_t)r], sh.planes, mcx_index_genome_size(sh.ix), 0, &sh.reduce_s))) bad(rc);
+        }
+        if (sh.rc == 0 && want_vcf && (rc = (n_gpus > 1 ? mcx_profile_sparse_shard : mcx_profile_sparse)(sh.cx, &sh.recs, &sh.n_recs))) bad(rc);
+    };
+    if (n_gpus == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int r = 0; r < n_gpus; r++) pool.emplace_back(work, r);
+        for (auto &t : pool) t.join();
+    }
+    int rc = 0;
     mcx_stats st;
     memset(&st, 0, sizeof st);
-    uint32_t *planes = nullptr;
-    if (want_vcf) { // MappingRecordArr, main.cpp:366-370
-        fprintf(stderr, "Initialize the alignment profile...\n");
-        if ((rc = mcx_planes_alloc(ix, &planes)) || (rc = mcx_profile_attach(cx, planes, vo.max_dup, vo.max_clip))) { fprintf(stderr, "Error! %s\n", mcx_last_error()); return 1; }
-    }
-    int64_t avg[4];
-    mcx_avg_init(avg); // avgDist and its totals are globals of the reference: they carry over from library to library
-    fo.avg_state = avg;
-    for (size_t k = 0; k < f1.size() && rc == 0; k++) {
-        // like the reference, every library appends to the same SAM stream; only the first writes the header
-        fo.append_sam = k > 0;
-        if (avg[3] % 200) avg[3] += 200 - avg[3] % 200; // a new library starts a new chunk
-        rc = mcx_map_files_ex(cx, f1[k].c_str(), f2.empty() ? nullptr : f2[k].c_str(), &fo, sam.empty() ? nullptr : sam.c_str(), &st);
-        if (rc) fprintf(stderr, "Error! %s\n", mcx_last_error());
+    for (const Shard &sh : shards) {
+        if (sh.rc) { fprintf(stderr, "Error! %s%s\n", sh.err.c_str(), n_gpus > 1 ? (" (GPU " + std::to_string(sh.device) + ")").c_str() : ""); rc = sh.rc; }
+        st.reads += sh.st.reads; st.mapped += sh.st.mapped; st.pairs += sh.st.pairs; st.pair_dist_sum += sh.st.pair_dist_sum; st.pair_len_sum += sh.st.pair_len_sum;
     }
     fprintf(stderr, "All the %lld %s reads have been processed.\n%12lld reads are mapped properly.\n%12lld reads are mapped in pairs.\n",
-            (long long)st.reads, (f2.empty() && !fo.interleaved_pairs) ? "single-end" : "paired-end", (long long)st.mapped, (long long)st.pairs * 2);
+            (long long)st.reads, paired_run ? "paired-end" : "single-end", (long long)st.mapped, (long long)st.pairs * 2);
     if (want_vcf && rc == 0) { // VariantCalling(), main.cpp:379
-        const mcx_sparse_rec *recs = nullptr;
-        uint64_t n_recs = 0;
+        std::vector<mcx_sparse_rec> merged;
+        const mcx_sparse_rec *recs = shards[0].recs;
+        uint64_t n_recs = shards[0].n_recs;
+        if (n_gpus > 1) {
+            for (const Shard &sh : shards) merged.insert(merged.end(), sh.recs, sh.recs + sh.n_recs);
+            recs = merged.data(); n_recs = merged.size();
+            if (getenv("MCX_TIMING")) fprintf(stderr, "[mcx_profile_reduce] %.3f s on shard 0\n", shards[0].reduce_s);
+        }
         mcx_vcf_stats vs;
         vo.ref_name = ref.empty() ? prefix.c_str() : ref.c_str();
         vo.cmdline = cmdline.c_str();
         fprintf(stderr, "Identify all variants (min_alt_allele_depth=%d)...\n", vo.min_allele_depth);
-        if ((rc = mcx_profile_finalize(cx, planes)) || (rc = mcx_profile_sparse(cx, &recs, &n_recs)) ||
-            (rc = mcx_call_variants(ix, planes, recs, n_recs, st.pairs, st.pair_dist_sum, st.pair_len_sum, &vo, vcf.c_str(), &vs)))
+        if ((rc = mcx_profile_finalize(shards[0].cx, shards[0].planes)) ||
+            (rc = mcx_call_variants(shards[0].ix, shards[0].planes, recs, n_recs, st.pairs, st.pair_dist_sum, st.pair_len_sum, &vo, vcf.c_str(), &vs)))
             fprintf(stderr, "Error! %s\n", mcx_last_error());
         else
             fprintf(stderr, "\tWrite all the predicted sample variations to file [%s]...\n\t%lld(snp); %lld(ins); %lld(del); %lld(trans); %lld(inversion)\n",
                     vcf.c_str(), (long long)vs.n_snv, (long long)vs.n_ins, (long long)vs.n_del, (long long)(vs.n_tnl >> 1), (long long)(vs.n_inv >> 1));
     }
-    mcx_planes_free(planes);
-    mcx_ctx_free(cx);
-    mcx_index_free(ix);
+    for (Shard &sh : shards) { mcx_planes_free(sh.planes); mcx_ctx_free(sh.cx); mcx_index_free(sh.ix); }
+    for (mcx_comm *c : comms) mcx_comm_free(c);
+    if (n_gpus > 1) mcx_exchange_local_free(links.data());
     if (!tmp_prefix.empty()) { std::string cmd = "rm -f " + tmp_prefix + ".*"; if (system(cmd.c_str())) {} }
     return rc ? 1 : 0;
 }

@@ -735,6 +735,19 @@ enum { CNT_TASKS = 0, CNT_RESCUE = 1 * kCntPad, CNT_JOB0 = 2 * kCntPad, CNT_JOB1
        CNT_JOB4 = 6 * kCntPad, CNT_JOB5 = 7 * kCntPad, CNT_OV = 8 * kCntPad, CNT_LF = 9 * kCntPad, CNT_CELLS = 10 * kCntPad, CNT_UNSUP = 11 * kCntPad,
        CNT_N = 12 * kCntPad };
 
+struct BatchRun { // the batch between mcx_batch_begin and mcx_batch_end
+    bool open = false, sums_valid = false, keys_out = false;
+    ReadBatch rb; int paired = 0;
+    uint32_t n_pairs = 0, n_chunks = 0;
+    AlnRec *recs = nullptr; uint32_t *cig = nullptr;
+    int64_t read_base = 0, mapped = 0;
+    unsigned long long hs[3] = {0, 0, 0};
+    std::vector<uint32_t> ok, ds; // per chunk: proper pairs; summed distance, then summed read lengths
+    const uint64_t *d_sorted_keys = nullptr; uint64_t n_keys = 0; uint32_t n_sparse_keys = 0;
+    std::chrono::steady_clock::time_point t0;
+    mcx_stats *stats = nullptr;
+};
+
 struct mcx_ctx {
     const mcx_index *idx = nullptr;
     Params pm;
@@ -756,7 +769,7 @@ struct mcx_ctx {
     uint32_t *d_sel_ids = nullptr; int32_t *d_est = nullptr;
     uint32_t *d_read_ext = nullptr, *d_read_blocks = nullptr;
     uint32_t *d_packed = nullptr; int wpad = 0; // 2-bit form of the batch's reads
-    uint32_t *d_cig_ext = nullptr, *d_cig_ext_n = nullptr, cig_ext_cap = 0; // CIGAR operations past a row of the dense array (tier 1)
+    uint32_t *d_cig_ext = nullptr, cig_ext_cap = 0; // CIGAR operations past a row of the dense array (tier 1)
     std::vector<uint32_t> h_cig_ext;
     PairOut *d_pout = nullptr, *h_pout = nullptr;
     uint8_t *d_mapq = nullptr; int mapq_rows = 0;
@@ -765,8 +778,11 @@ struct mcx_ctx {
     uint8_t *d_detail = nullptr; DetailLayout dlay;
     uint64_t *d_keys[2] = {nullptr, nullptr}; uint8_t *d_admit = nullptr; void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     SparseRec *d_sparse = nullptr; uint32_t sparse_cap = 0;
-    std::vector<mcx_sparse_rec> h_sparse;
-    int64_t last_disc[2] = {0, 0}; // the reference's DiscordPair variable lives across pairs (ReadMapping.cpp:418)
+    std::vector<mcx_sparse_rec> h_sparse, h_events, h_resolved; // tallies; discordant-pair events ('E'); what mcx_profile_sparse* last returned
+    uint64_t keys_cap = 0;       // keys the sort buffers hold
+    uint64_t *h_keys = nullptr; uint64_t h_keys_cap = 0; // pinned: the batch's keys for the exchange between shards
+    uint32_t *d_batch_flags = nullptr; // [0] words taken in the long-CIGAR pool, [1] longest read of the batch
+    BatchRun run;
     // staging for the host-buffer entry point
     uint8_t *d_bases = nullptr; uint32_t *d_off = nullptr; AlnRec *d_recs = nullptr; uint32_t *d_cig = nullptr;
     hipEvent_t ev[10];
@@ -855,8 +871,8 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
     if ((rc = dmalloc(&c->d_read_blocks, c->max_reads))) return rc;
     c->cig_ext_cap = 1u << 22;
     if ((rc = dmalloc(&c->d_cig_ext, c->cig_ext_cap))) return rc;
-    if ((rc = dmalloc(&c->d_cig_ext_n, 1))) return rc;
-    HIP_TRY(hipMemset(c->d_cig_ext_n, 0, sizeof(uint32_t)));
+    if ((rc = dmalloc(&c->d_batch_flags, 4))) return rc;
+    HIP_TRY(hipMemset(c->d_batch_flags, 0, 4 * sizeof(uint32_t)));
     c->wpad = (packed_words(c->rlen_max) + 3) & ~3;
     if ((rc = dmalloc(&c->d_packed, c->max_reads * (uint64_t)c->wpad))) return rc;
     if ((rc = dmalloc(&c->d_pout, c->max_reads))) return rc;
@@ -883,10 +899,11 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3], c->d_jobs[4], c->d_jobs[5],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
                  c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
-                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_packed, c->d_cig_ext, c->d_cig_ext_n};
+                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_packed, c->d_cig_ext, c->d_batch_flags};
     for (void *q : p) if (q) (void)hipFree(q);
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
     if (c->h_pout) (void)hipHostFree(c->h_pout);
+    if (c->h_keys) (void)hipHostFree(c->h_keys);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (int k = 0; k < 5; k++) { if (c->dp_stream[k]) (void)hipStreamDestroy(c->dp_stream[k]); if (c->dp_join[k]) (void)hipEventDestroy(c->dp_join[k]); }
@@ -902,7 +919,7 @@ static Ctx make_ctx(const mcx_ctx *c, int tier, int paired)
     cx.caps = c->tier[tier].caps; cx.lay = c->tier[tier].lay; cx.state = c->tier[tier].state;
     cx.mapq_tab = c->d_mapq; cx.mapq_rows = c->mapq_rows;
     cx.detail = c->prof_planes ? c->d_detail : nullptr; cx.dlay = c->dlay;
-    cx.cig_ext = tier == 1 ? c->d_cig_ext : nullptr; cx.cig_ext_n = c->d_cig_ext_n; cx.cig_ext_cap = c->cig_ext_cap;
+    cx.cig_ext = tier == 1 ? c->d_cig_ext : nullptr; cx.cig_ext_n = c->d_batch_flags; cx.cig_ext_cap = c->cig_ext_cap;
     return cx;
 }
 
@@ -1031,9 +1048,25 @@ __global__ void k_check_est(const PairOut *po, uint32_t n_pairs, uint32_t chunk,
     }
 }
 
-static int profile_batch(mcx_ctx *c, const ReadBatch &rb, int paired);
+static int profile_keys(mcx_ctx *c);
+static int profile_foreign(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all);
+static int sort_reserve(mcx_ctx *c, uint64_t n);
+static int profile_accumulate(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all, uint32_t slot_stride, uint32_t own_slot);
 
 extern "C" void mcx_avg_init(int64_t a[4]) { a[0] = 1000; a[1] = 0; a[2] = 0; a[3] = 0; }
+
+// ReadMapping.cpp:462 / :538-539 over consecutive chunks
+extern "C" void mcx_avg_walk(int64_t st[3], const uint32_t *pairs, const uint32_t *dist, uint32_t n_chunks, int32_t *est_chunk)
+{
+    uint32_t cur = (uint32_t)st[0];
+    int64_t tp = st[1], td = st[2];
+    for (uint32_t k = 0; k < n_chunks; k++) {
+        if (est_chunk) est_chunk[k] = (int32_t)(cur * 1.5);
+        tp += pairs[k]; td += dist[k];
+        if (tp > 1000) cur = (uint32_t)(int)(1. * td / tp + .5);
+    }
+    st[0] = cur; st[1] = tp; st[2] = td;
+}
 
 // runs the tiers for the pairs in `ids` (null: all pairs of the batch) with per-pair estimates
 static int run_selection(mcx_ctx *c, const ReadBatch &rb, int paired, const std::vector<uint32_t> *ids,
@@ -1054,6 +1087,7 @@ static int run_selection(mcx_ctx *c, const ReadBatch &rb, int paired, const std:
     if (rc == kListOverflow) {
         // unusually many hits or DP problems per read (e.g. indel-heavy long reads): halve the selection
         if (n < 2) return fail(MCX_ERR_CAPACITY, "work list overflow for a single pair");
+        if (stats) stats->halved_selections++;
         for (int half = 0; half < 2; half++) {
             const uint32_t lo = half ? n / 2 : 0, hi = half ? n : n / 2;
             std::vector<uint32_t> sub_ids(hi - lo);
@@ -1095,124 +1129,230 @@ static int run_selection(mcx_ctx *c, const ReadBatch &rb, int paired, const std:
     return 0;
 }
 
-extern "C" int mcx_map_batch_dev(mcx_ctx *c, const uint8_t *d_bases, const uint32_t *d_off, uint32_t n_reads, int paired,
-                                 int64_t avg[4], mcx_aln *d_aln, uint32_t *d_cigar, mcx_stats *stats)
+// longest read of the batch (a read past max_read_len would overrun the per-read slots of every stage)
+__global__ void k_max_read_len(const uint32_t *off, uint32_t n_reads, uint32_t *out)
+{
+    uint32_t m = 0;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) m = max(m, off[r + 1] - off[r]);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_t *d_off, uint32_t n_reads, int paired, int32_t est0,
+                               int64_t read_base, mcx_aln *d_aln, uint32_t *d_cigar, mcx_stats *stats)
 {
     static_assert(sizeof(mcx_aln) == sizeof(AlnRec), "mcx_aln and AlnRec must have one layout");
-    if (!c || !d_bases || !d_off || !d_aln || !d_cigar || !avg) return fail(MCX_ERR_ARG, "mcx_map_batch_dev: null argument");
-    if (n_reads == 0) return 0;
+    if (!c || !d_bases || !d_off || !d_aln || !d_cigar) return fail(MCX_ERR_ARG, "mcx_batch_begin: null argument");
+    BatchRun &br = c->run;
+    br.open = false;
+    if (n_reads == 0) return fail(MCX_ERR_ARG, "mcx_batch_begin: empty batch");
     if (n_reads > c->max_reads) return fail(MCX_ERR_ARG, "batch larger than max_batch_reads");
     if (paired && (n_reads & 1)) return fail(MCX_ERR_ARG, "paired batch with an odd number of reads");
+    if (paired && (read_base & 1)) return fail(MCX_ERR_ARG, "paired batch at an odd read_base");
+    if ((uintptr_t)d_bases & 15) return fail(MCX_ERR_ARG, "mcx_batch_begin: d_bases must be 16-byte aligned");
     HIP_TRY(hipSetDevice(c->idx->device));
-    auto t0 = std::chrono::steady_clock::now();
+    br.t0 = std::chrono::steady_clock::now();
     hipStream_t s = c->stream;
-    if ((uintptr_t)d_bases & 15) return fail(MCX_ERR_ARG, "mcx_map_batch_dev: d_bases must be 16-byte aligned");
-    ReadBatch rb; rb.bases = d_bases; rb.off = d_off; rb.n_reads = n_reads;
-    uint32_t total_bases = 0;
-    HIP_TRY(hipMemcpy(&total_bases, d_off + n_reads, sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (total_bases > c->max_bases) return fail(MCX_ERR_ARG, "batch holds more bases than max_batch_reads * max_read_len");
-    AlnRec *recs = (AlnRec *)d_aln;
-    const uint32_t n_pairs = paired ? n_reads / 2 : n_reads;
+    br.rb.bases = d_bases; br.rb.off = d_off; br.rb.n_reads = n_reads;
+    br.paired = paired; br.read_base = read_base;
+    br.recs = (AlnRec *)d_aln; br.cig = d_cigar; br.stats = stats;
+    br.n_pairs = paired ? n_reads / 2 : n_reads;
+    br.n_chunks = (br.n_pairs + kReadChunkSize / 2 - 1) / (kReadChunkSize / 2);
+    br.mapped = 0; br.sums_valid = false;
+    { // every read must fit the slots the context was sized for
+        HIP_TRY(hipMemsetAsync(c->d_batch_flags, 0, 4 * sizeof(uint32_t), s));
+        k_max_read_len<<<512, 256, 0, s>>>(d_off, n_reads, c->d_batch_flags + 1);
+        HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_batch_flags, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (c->h_cnt[1] > (uint32_t)c->rlen_max)
+            return fail(MCX_ERR_UNSUPPORTED, "a read of " + std::to_string(c->h_cnt[1]) + " bases is longer than max_read_len (" + std::to_string(c->rlen_max) + ")");
+    }
     { // the batch in 2-bit form, once; every seeding pass (tiers, replay) reads it
-        hipStream_t s0 = c->stream;
-        HIP_TRY(hipMemsetAsync(c->d_cig_ext_n, 0, sizeof(uint32_t), s0));
-        HIP_TRY(hipEventRecord(c->ev_pack[0], s0));
+        HIP_TRY(hipEventRecord(c->ev_pack[0], s));
         const int tpr = (c->rlen_max + 31) / 32 + 1;
         const uint64_t threads = (uint64_t)n_reads * (uint64_t)tpr;
-        k_pack_reads<<<(unsigned)((threads + 255) / 256), 256, 0, s0>>>(rb, paired, c->wpad, tpr, c->d_packed);
+        k_pack_reads<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(br.rb, paired, c->wpad, tpr, c->d_packed);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(c->ev_pack[1], s0));
+        HIP_TRY(hipEventRecord(c->ev_pack[1], s));
     }
-    const int32_t est0 = (int32_t)((uint32_t)avg[0] * 1.5);
-    int rc = run_selection(c, rb, paired, nullptr, nullptr, est0, n_pairs, recs, d_cigar, stats, true);
+    int rc = run_selection(c, br.rb, paired, nullptr, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true);
     if (rc) return rc;
-
-    // Replay of the reference's avgDist feedback (ReadMapping.cpp:462, :538-539; mcx_host.h).  The
-    // device reduces the batch to per-chunk sums; the host walks the chunk trajectory (a few
-    // thousand scalars); the device lists the pairs whose chunk estimate falls outside their
-    // validity interval; those are re-run with the exact estimate until none is left.
-    int64_t mapped = 0, pairs = 0, dist_sum = 0, len_sum = 0;
-    const uint32_t chunk = kReadChunkSize / 2, n_chunks = (n_pairs + chunk - 1) / chunk;
-    uint32_t *d_ok = c->d_read_ext, *d_ds = c->d_read_blocks; // per-read stat arrays are reduced below, before reuse
-    uint32_t *d_ls = d_ds + n_chunks;                         // (2 * n_chunks <= n_reads)
-    unsigned long long hs[3] = {0, 0, 0};
-    {
+    { // seeding statistics (E, blocks, H of SURVEY.md 8d) before the per-read arrays are reused for the chunk sums
         unsigned long long *d_sum = (unsigned long long *)c->d_cnt;
         HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
         k_reduce_stats<<<256, 256, 0, s>>>(c->d_read_ext, c->d_read_blocks, n_reads, d_sum);
-        HIP_TRY(hipMemcpyAsync(hs, d_sum, sizeof hs, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(br.hs, d_sum, sizeof br.hs, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
-    std::vector<uint32_t> h_ok(n_chunks), h_ds(2 * (size_t)n_chunks);
-    std::vector<int32_t> h_est(n_chunks);
-    if (paired && (avg[3] % kReadChunkSize)) return fail(MCX_ERR_ARG, "batches must start on a 200-read chunk boundary");
-    int64_t after[3] = {avg[0], avg[1], avg[2]};
-    for (int iter = 0;; iter++) {
-        HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
-        k_chunk_sums<<<(n_chunks + 255) / 256, 256, 0, s>>>(c->d_pout, rb.off, n_pairs, chunk, d_ok, d_ds, d_ls, c->d_cnt + CNT_LF);
-        HIP_TRY(hipMemcpyAsync(h_ok.data(), d_ok, n_chunks * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(h_ds.data(), d_ds, 2 * (size_t)n_chunks * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        mapped = c->h_cnt[CNT_LF];
-        if (!paired) break;
-        int64_t tp = avg[1], td = avg[2];
-        uint32_t cur = (uint32_t)avg[0];
-        for (uint32_t k = 0; k < n_chunks; k++) {
-            h_est[k] = (int32_t)(cur * 1.5);
-            tp += h_ok[k]; td += h_ds[k];
-            if (tp > 1000) cur = (uint32_t)(int)(1. * td / tp + .5);
-        }
-        after[0] = cur; after[1] = tp; after[2] = td;
-        int32_t *d_est_chunk = (int32_t *)d_ok; // the sums are on the host now
-        HIP_TRY(hipMemcpyAsync(d_est_chunk, h_est.data(), n_chunks * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
-        k_check_est<<<2048, 256, 0, s>>>(c->d_pout, n_pairs, chunk, d_est_chunk, c->d_sel_ids, c->d_est, c->d_cnt + CNT_OV, c->ov_cap);
-        HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        const uint32_t n_redo = c->h_cnt[CNT_OV];
-        if (n_redo == 0) break;
-        if (n_redo > c->ov_cap) return fail(MCX_ERR_CAPACITY, "avgDist replay: redo list overflow");
-        if (iter == 63) return fail(MCX_ERR_CAPACITY, "avgDist replay did not converge");
-        if (stats) stats->replayed_pairs += (int64_t)n_redo;
-        std::vector<uint32_t> redo(n_redo); std::vector<int32_t> redo_est(n_redo);
-        HIP_TRY(hipMemcpy(redo.data(), c->d_sel_ids, n_redo * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(redo_est.data(), c->d_est, n_redo * 4, hipMemcpyDeviceToHost));
-        // the list was appended with atomics: bring it into pair order (results do not depend on it)
-        std::vector<std::pair<uint32_t, int32_t>> ord(n_redo);
-        for (uint32_t i = 0; i < n_redo; i++) ord[i] = std::make_pair(redo[i], redo_est[i]);
-        std::sort(ord.begin(), ord.end());
-        for (uint32_t i = 0; i < n_redo; i++) { redo[i] = ord[i].first; redo_est[i] = ord[i].second; }
-        rc = run_selection(c, rb, paired, &redo, &redo_est, 0, n_pairs, recs, d_cigar, stats, false);
-        if (rc) return rc;
-    }
-    if (paired) {
-        pairs = after[1] - avg[1]; dist_sum = after[2] - avg[2];
-        for (uint32_t k = 0; k < n_chunks; k++) len_sum += h_ds[n_chunks + k];
-        avg[0] = after[0]; avg[1] = after[1]; avg[2] = after[2];
-    }
-    avg[3] += n_reads;
+    br.open = true;
+    return 0;
+}
+
+// Replay of the reference's avgDist feedback (ReadMapping.cpp:462, :538-539).  The
+// device reduces the batch to per-chunk sums; the caller walks the chunk trajectory (a few thousand
+// scalars; over all shards when there are several); the device lists the pairs whose chunk estimate
+// falls outside their validity interval; those are re-run with the exact estimate until none is left.
+extern "C" int mcx_batch_sums(mcx_ctx *c, uint32_t *n_chunks, const uint32_t **pairs, const uint32_t **dist, const uint32_t **len)
+{
+    if (!c || !c->run.open) return fail(MCX_ERR_ARG, "mcx_batch_sums: no batch in flight");
+    BatchRun &br = c->run;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipSetDevice(c->idx->device));
+    const uint32_t nc = br.n_chunks;
+    uint32_t *d_ok = c->d_read_ext, *d_ds = c->d_read_blocks; // the per-read stat arrays were reduced by mcx_batch_begin
+    uint32_t *d_ls = d_ds + nc;                               // (2 * n_chunks <= n_reads)
+    br.ok.resize(nc); br.ds.resize(2 * (size_t)nc);
+    HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
+    k_chunk_sums<<<(nc + 255) / 256, 256, 0, s>>>(c->d_pout, br.rb.off, br.n_pairs, kReadChunkSize / 2, d_ok, d_ds, d_ls, c->d_cnt + CNT_LF);
+    HIP_TRY(hipMemcpyAsync(br.ok.data(), d_ok, nc * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(br.ds.data(), d_ds, 2 * (size_t)nc * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    br.mapped = c->h_cnt[CNT_LF];
+    br.sums_valid = true;
+    if (n_chunks) *n_chunks = nc;
+    if (pairs) *pairs = br.ok.data();
+    if (dist) *dist = br.ds.data();
+    if (len) *len = br.ds.data() + nc;
+    return 0;
+}
+
+extern "C" int mcx_batch_replay(mcx_ctx *c, const int32_t *est_chunk, uint32_t *n_redone, mcx_stats *stats)
+{
+    if (!c || !c->run.open || !est_chunk) return fail(MCX_ERR_ARG, "mcx_batch_replay: no batch in flight");
+    BatchRun &br = c->run;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipSetDevice(c->idx->device));
+    if (n_redone) *n_redone = 0;
+    if (!br.paired) return 0;
+    int32_t *d_est_chunk = (int32_t *)c->d_read_ext; // the sums are on the host
+    HIP_TRY(hipMemcpyAsync(d_est_chunk, est_chunk, br.n_chunks * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
+    k_check_est<<<2048, 256, 0, s>>>(c->d_pout, br.n_pairs, kReadChunkSize / 2, d_est_chunk, c->d_sel_ids, c->d_est, c->d_cnt + CNT_OV, c->ov_cap);
+    HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t n_redo = c->h_cnt[CNT_OV];
+    if (n_redo == 0) return 0;
+    br.sums_valid = false;
+    if (n_redo > c->ov_cap) return fail(MCX_ERR_CAPACITY, "avgDist replay: redo list overflow");
+    if (stats) stats->replayed_pairs += (int64_t)n_redo;
+    std::vector<uint32_t> redo(n_redo); std::vector<int32_t> redo_est(n_redo);
+    HIP_TRY(hipMemcpy(redo.data(), c->d_sel_ids, n_redo * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(redo_est.data(), c->d_est, n_redo * 4, hipMemcpyDeviceToHost));
+    // the list was appended with atomics: bring it into pair order (results do not depend on it)
+    std::vector<std::pair<uint32_t, int32_t>> ord(n_redo);
+    for (uint32_t i = 0; i < n_redo; i++) ord[i] = std::make_pair(redo[i], redo_est[i]);
+    std::sort(ord.begin(), ord.end());
+    for (uint32_t i = 0; i < n_redo; i++) { redo[i] = ord[i].first; redo_est[i] = ord[i].second; }
+    int rc = run_selection(c, br.rb, br.paired, &redo, &redo_est, 0, br.n_pairs, br.recs, br.cig, stats, false);
+    if (rc) return rc;
+    if (n_redone) *n_redone = n_redo;
+    return 0;
+}
+
+// what both ways of closing a batch share: the long-CIGAR pool, statistics
+static int batch_close(mcx_ctx *c, mcx_stats *stats)
+{
+    BatchRun &br = c->run;
+    int rc = 0;
+    if (!br.sums_valid && (rc = mcx_batch_sums(c, nullptr, nullptr, nullptr, nullptr))) return rc;
     {
         uint32_t used = 0;
-        HIP_TRY(hipMemcpy(&used, c->d_cig_ext_n, sizeof used, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&used, c->d_batch_flags, sizeof used, hipMemcpyDeviceToHost));
         if (used > c->cig_ext_cap) return fail(MCX_ERR_CAPACITY, "CIGAR continuation pool overflow");
     }
-    if (c->prof_planes) { rc = profile_batch(c, rb, paired); if (rc) return rc; }
     if (stats) {
-        stats->reads += n_reads; stats->mapped += mapped; stats->pairs += pairs; stats->pair_dist_sum += dist_sum; stats->pair_len_sum += len_sum;
-        stats->fm_ext_steps += (int64_t)hs[0]; stats->fm_blocks += (int64_t)hs[1]; stats->sa_hits += (int64_t)hs[2];
-        stats->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        int64_t pairs = 0, dist_sum = 0, len_sum = 0;
+        if (br.paired) for (uint32_t k = 0; k < br.n_chunks; k++) { pairs += br.ok[k]; dist_sum += br.ds[k]; len_sum += br.ds[br.n_chunks + k]; }
+        stats->reads += br.rb.n_reads; stats->mapped += br.mapped; stats->pairs += pairs; stats->pair_dist_sum += dist_sum; stats->pair_len_sum += len_sum;
+        stats->fm_ext_steps += (int64_t)br.hs[0]; stats->fm_blocks += (int64_t)br.hs[1]; stats->sa_hits += (int64_t)br.hs[2];
         float ms_pack = 0;
         if (hipEventElapsedTime(&ms_pack, c->ev_pack[0], c->ev_pack[1]) == hipSuccess) stats->ms_encode += ms_pack; // k_pack_reads
     }
     return 0;
 }
 
-extern "C" int mcx_map_batch(mcx_ctx *c, const uint8_t *bases, const uint32_t *off, uint32_t n_reads, int paired,
-                             int64_t avg[4], mcx_aln *aln, uint32_t *cigar, mcx_stats *stats)
+extern "C" int mcx_batch_end(mcx_ctx *c, mcx_stats *stats)
 {
-    if (!c || !bases || !off || !aln || !cigar) return fail(MCX_ERR_ARG, "mcx_map_batch: null argument");
+    if (!c || !c->run.open) return fail(MCX_ERR_ARG, "mcx_batch_end: no batch in flight");
+    HIP_TRY(hipSetDevice(c->idx->device));
+    int rc = batch_close(c, stats);
+    if (rc == 0 && c->prof_planes) { // one shard: the batch's own keys decide the duplicate cap
+        if ((rc = profile_keys(c)) == 0) rc = profile_accumulate(c, nullptr, 0, 0, 0);
+    }
+    c->run.open = false;
+    if (rc == 0 && stats) stats->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c->run.t0).count();
+    return rc;
+}
+
+extern "C" int mcx_batch_end_keys(mcx_ctx *c, mcx_stats *stats, const uint64_t **keys, uint64_t *n_keys)
+{
+    if (!c || !c->run.open || !keys || !n_keys) return fail(MCX_ERR_ARG, "mcx_batch_end_keys: no batch in flight");
+    if (!c->prof_planes) return fail(MCX_ERR_ARG, "mcx_batch_end_keys: no profile attached");
+    HIP_TRY(hipSetDevice(c->idx->device));
+    int rc = batch_close(c, stats);
+    if (rc == 0) rc = profile_keys(c);
+    if (rc) { c->run.open = false; return rc; }
+    // the valid keys sort to the front
+    if (c->h_keys_cap < c->run.n_keys) {
+        mcx_pinned_free(c->h_keys);
+        c->h_keys_cap = std::max<uint64_t>(c->run.n_keys, c->max_reads);
+        c->h_keys = (uint64_t *)mcx_pinned_alloc(c->h_keys_cap * sizeof(uint64_t));
+        if (!c->h_keys) { c->h_keys_cap = 0; c->run.open = false; return fail(MCX_ERR_DEVICE, "cannot allocate pinned host memory"); }
+    }
+    if (c->run.n_keys) HIP_TRY(hipMemcpy(c->h_keys, c->run.d_sorted_keys, c->run.n_keys * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    *keys = c->h_keys; *n_keys = c->run.n_keys;
+    c->run.keys_out = true;
+    return 0;
+}
+
+extern "C" int mcx_batch_accumulate(mcx_ctx *c, const uint64_t *all_keys, uint64_t n_all, uint32_t slot_stride, uint32_t own_slot)
+{
+    if (!c || !c->prof_planes) return fail(MCX_ERR_ARG, "mcx_batch_accumulate: no profile attached");
+    HIP_TRY(hipSetDevice(c->idx->device));
+    if (own_slot == 0xFFFFFFFFu) { // a shard without reads in this round: the others' admissions still count
+        if (c->run.open) return fail(MCX_ERR_ARG, "mcx_batch_accumulate: a batch is in flight");
+        return profile_foreign(c, all_keys, n_all);
+    }
+    if (!c->run.open || !c->run.keys_out) return fail(MCX_ERR_ARG, "mcx_batch_accumulate: call mcx_batch_end_keys first");
+    int rc = profile_accumulate(c, all_keys, n_all, slot_stride, own_slot);
+    c->run.open = false; c->run.keys_out = false;
+    if (rc == 0 && c->run.stats) c->run.stats->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c->run.t0).count();
+    return rc;
+}
+
+extern "C" int mcx_map_batch_dev(mcx_ctx *c, const uint8_t *d_bases, const uint32_t *d_off, uint32_t n_reads, int paired,
+                                 int64_t avg[4], mcx_aln *d_aln, uint32_t *d_cigar, mcx_stats *stats)
+{
+    if (!c || !d_bases || !d_off || !d_aln || !d_cigar || !avg) return fail(MCX_ERR_ARG, "mcx_map_batch_dev: null argument");
     if (n_reads == 0) return 0;
+    if (paired && (avg[3] % kReadChunkSize)) return fail(MCX_ERR_ARG, "batches must start on a 200-read chunk boundary");
+    int rc = mcx_batch_begin(c, d_bases, d_off, n_reads, paired, (int32_t)((uint32_t)avg[0] * 1.5), avg[3], d_aln, d_cigar, stats);
+    if (rc) return rc;
+    int64_t after[3] = {avg[0], avg[1], avg[2]};
+    if (paired) {
+        std::vector<int32_t> est(c->run.n_chunks);
+        for (int iter = 0;; iter++) {
+            uint32_t nc = 0, n_redo = 0;
+            const uint32_t *ok = nullptr, *ds = nullptr;
+            if ((rc = mcx_batch_sums(c, &nc, &ok, &ds, nullptr))) return rc;
+            after[0] = avg[0]; after[1] = avg[1]; after[2] = avg[2];
+            mcx_avg_walk(after, ok, ds, nc, est.data());
+            if ((rc = mcx_batch_replay(c, est.data(), &n_redo, stats))) return rc;
+            if (n_redo == 0) break;
+            if (iter == 63) return fail(MCX_ERR_CAPACITY, "avgDist replay did not converge");
+        }
+    }
+    if ((rc = mcx_batch_end(c, stats))) return rc;
+    avg[0] = after[0]; avg[1] = after[1]; avg[2] = after[2];
+    avg[3] += n_reads;
+    return 0;
+}
+
+// host buffers -> the context's staging arrays in HBM (what mcx_map_batch and the file front end hand the step API)
+int mcx_stage_in(mcx_ctx *c, const uint8_t *bases, const uint32_t *off, uint32_t n_reads, const uint8_t **d_bases, const uint32_t **d_off,
+                 mcx_aln **d_aln, uint32_t **d_cigar)
+{
     if (n_reads > c->max_reads) return fail(MCX_ERR_ARG, "batch larger than max_batch_reads");
     HIP_TRY(hipSetDevice(c->idx->device));
     int rc;
@@ -1223,13 +1363,31 @@ extern "C" int mcx_map_batch(mcx_ctx *c, const uint8_t *bases, const uint32_t *o
         if ((rc = dmalloc(&c->d_cig, c->max_reads * MCX_CIGAR_STRIDE))) return rc;
     }
     if (off[n_reads] > c->max_bases) return fail(MCX_ERR_ARG, "batch holds more bases than max_batch_reads * max_read_len");
-    HIP_TRY(hipMemcpy(c->d_bases, bases, off[n_reads], hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_off, off, (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice));
-    rc = mcx_map_batch_dev(c, c->d_bases, c->d_off, n_reads, paired, avg, (mcx_aln *)c->d_recs, c->d_cig, stats);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(aln, c->d_recs, (size_t)n_reads * sizeof(AlnRec), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(cigar, c->d_cig, (size_t)n_reads * MCX_CIGAR_STRIDE * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(c->d_bases, bases, off[n_reads], hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_off, off, (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    *d_bases = c->d_bases; *d_off = c->d_off; *d_aln = (mcx_aln *)c->d_recs; *d_cigar = c->d_cig;
     return 0;
+}
+
+int mcx_stage_out(mcx_ctx *c, uint32_t n_reads, mcx_aln *aln, uint32_t *cigar)
+{
+    HIP_TRY(hipSetDevice(c->idx->device));
+    HIP_TRY(hipMemcpyAsync(aln, c->d_recs, (size_t)n_reads * sizeof(AlnRec), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(cigar, c->d_cig, (size_t)n_reads * MCX_CIGAR_STRIDE * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int mcx_map_batch(mcx_ctx *c, const uint8_t *bases, const uint32_t *off, uint32_t n_reads, int paired,
+                             int64_t avg[4], mcx_aln *aln, uint32_t *cigar, mcx_stats *stats)
+{
+    if (!c || !bases || !off || !aln || !cigar) return fail(MCX_ERR_ARG, "mcx_map_batch: null argument");
+    if (n_reads == 0) return 0;
+    const uint8_t *d_bases; const uint32_t *d_off; mcx_aln *d_aln; uint32_t *d_cig;
+    int rc = mcx_stage_in(c, bases, off, n_reads, &d_bases, &d_off, &d_aln, &d_cig);
+    if (rc) return rc;
+    if ((rc = mcx_map_batch_dev(c, d_bases, d_off, n_reads, paired, avg, d_aln, d_cig, stats))) return rc;
+    return mcx_stage_out(c, n_reads, aln, cigar);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1251,6 +1409,7 @@ extern "C" int mcx_profile_attach(mcx_ctx *c, uint32_t *d_planes, int max_dup, i
 {
     static_assert(sizeof(mcx_sparse_rec) == sizeof(SparseRec), "mcx_sparse_rec and SparseRec must have one layout");
     if (!c || !d_planes) return fail(MCX_ERR_ARG, "mcx_profile_attach: null argument");
+    if (c->idx->view.G >= (int64_t)1 << 32) return fail(MCX_ERR_UNSUPPORTED, "the alignment profile takes genomes below 2^32 bases");
     HIP_TRY(hipSetDevice(c->idx->device));
     c->prof_planes = d_planes;
     c->prof_max_dup = (max_dup <= 0 || max_dup > 15) ? 15 : max_dup; // main.cpp:240-244, :323
@@ -1259,34 +1418,101 @@ extern "C" int mcx_profile_attach(mcx_ctx *c, uint32_t *d_planes, int max_dup, i
         c->dlay = make_detail_layout(c->rlen_max);
         int rc;
         if ((rc = dmalloc(&c->d_detail, (size_t)c->dlay.stride * c->max_reads))) return rc;
-        for (int k = 0; k < 2; k++) if ((rc = dmalloc(&c->d_keys[k], c->max_reads))) return rc;
         if ((rc = dmalloc(&c->d_admit, c->max_reads))) return rc;
-        hipcub::DoubleBuffer<uint64_t> dk(c->d_keys[0], c->d_keys[1]);
-        HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, c->sort_tmp_bytes, dk, (int64_t)c->max_reads, 0, 64));
-        HIP_TRY(hipMalloc(&c->d_sort_tmp, c->sort_tmp_bytes + 256));
+        if ((rc = sort_reserve(c, c->max_reads))) return rc;
         c->sparse_cap = (uint32_t)std::min<uint64_t>(c->max_reads * 2 + 4096, 0x7fffffffu);
         if ((rc = dmalloc(&c->d_sparse, c->sparse_cap))) return rc;
     }
-    c->h_sparse.clear();
-    c->last_disc[0] = c->last_disc[1] = 0;
+    c->h_sparse.clear(); c->h_events.clear(); c->h_resolved.clear();
     return 0;
 }
 
-static int profile_batch(mcx_ctx *c, const ReadBatch &rb, int paired)
+// key buffers and radix-sort scratch for n keys (grown on demand: a round's keys of all shards can outnumber a batch)
+static int sort_reserve(mcx_ctx *c, uint64_t n)
 {
+    if (n <= c->keys_cap) return 0;
+    for (int k = 0; k < 2; k++) { if (c->d_keys[k]) (void)hipFree(c->d_keys[k]); c->d_keys[k] = nullptr; }
+    if (c->d_sort_tmp) { (void)hipFree(c->d_sort_tmp); c->d_sort_tmp = nullptr; }
+    c->keys_cap = 0;
+    int rc;
+    for (int k = 0; k < 2; k++) if ((rc = dmalloc(&c->d_keys[k], n))) return rc;
+    hipcub::DoubleBuffer<uint64_t> dk(c->d_keys[0], c->d_keys[1]);
+    HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, c->sort_tmp_bytes, dk, (int64_t)n, 0, 64));
+    HIP_TRY(hipMalloc(&c->d_sort_tmp, c->sort_tmp_bytes + 256));
+    c->keys_cap = n;
+    return 0;
+}
+
+// break points, clip gate, and the sorted (start position, read) keys of the reads that reach the duplicate check
+static int profile_keys(mcx_ctx *c)
+{
+    BatchRun &br = c->run;
     hipStream_t s = c->stream;
     const IndexView &ix = c->idx->view;
     ProfView pv; pv.plane = c->prof_planes; pv.G = ix.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
     SparseSink sink; sink.recs = c->d_sparse; sink.n = c->d_cnt + CNT_TASKS; sink.cap = c->sparse_cap;
-    const uint32_t n = rb.n_reads;
+    const uint32_t n = br.rb.n_reads;
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
-    HIP_TRY(hipMemsetAsync(c->d_admit, 0, n, s));
-    k_prof_keys<<<(n + 255) / 256, 256, 0, s>>>(c->d_detail, c->dlay, rb, ix, pv, sink, c->d_keys[0]);
+    k_prof_keys<<<(n + 255) / 256, 256, 0, s>>>(c->d_detail, c->dlay, br.rb, ix, pv, sink, c->d_keys[0], c->d_cnt + CNT_OV);
     hipcub::DoubleBuffer<uint64_t> dk(c->d_keys[0], c->d_keys[1]);
     size_t tb = c->sort_tmp_bytes;
     HIP_TRY(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tb, dk, (int64_t)n, 0, 64, s));
-    k_prof_admit<<<(n + 255) / 256, 256, 0, s>>>(dk.Current(), n, pv, c->d_admit);
-    k_prof_accum<<<4096, 256, 0, s>>>(c->d_detail, c->dlay, rb, ix, pv, sink, c->d_admit, paired);
+    HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    br.d_sorted_keys = dk.Current();
+    br.n_keys = c->h_cnt[CNT_OV];       // the keys of the other reads are ~0 and sort behind them
+    br.n_sparse_keys = c->h_cnt[CNT_TASKS]; // break-point records so far; the accumulation appends behind them
+    return 0;
+}
+
+// the keys of a round this shard has no reads in: only the run's readCount moves
+static int profile_foreign(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all)
+{
+    if (n_all == 0) return 0;
+    hipStream_t s = c->stream;
+    ProfView pv; pv.plane = c->prof_planes; pv.G = c->idx->view.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
+    int rc = sort_reserve(c, n_all);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_keys[0], h_all, n_all * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    hipcub::DoubleBuffer<uint64_t> dk(c->d_keys[0], c->d_keys[1]);
+    size_t tb = c->sort_tmp_bytes;
+    HIP_TRY(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tb, dk, (int64_t)n_all, 0, 64, s));
+    k_prof_count<<<(unsigned)((n_all + 255) / 256), 256, 0, s>>>(dk.Current(), n_all, pv);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+// admission over `all` keys (null: the batch's own, already sorted on the device), then the accumulation of the own reads
+static int profile_accumulate(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all, uint32_t slot_stride, uint32_t own_slot)
+{
+    BatchRun &br = c->run;
+    hipStream_t s = c->stream;
+    const IndexView &ix = c->idx->view;
+    ProfView pv; pv.plane = c->prof_planes; pv.G = ix.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
+    SparseSink sink; sink.recs = c->d_sparse; sink.n = c->d_cnt + CNT_TASKS; sink.cap = c->sparse_cap;
+    const uint32_t n = br.rb.n_reads;
+    const int paired = br.paired;
+    const uint64_t *d_keys = br.d_sorted_keys;
+    uint64_t nk = br.n_keys;
+    uint32_t own_lo = 0;
+    if (h_all) {
+        int rc = sort_reserve(c, std::max<uint64_t>(n_all, 1)); // (invalidates br.d_sorted_keys: the own keys are part of h_all)
+        if (rc) return rc;
+        if (n_all) HIP_TRY(hipMemcpyAsync(c->d_keys[0], h_all, n_all * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        hipcub::DoubleBuffer<uint64_t> dk(c->d_keys[0], c->d_keys[1]);
+        size_t tb = c->sort_tmp_bytes;
+        if (n_all) HIP_TRY(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tb, dk, (int64_t)n_all, 0, 64, s));
+        d_keys = dk.Current(); nk = n_all; own_lo = own_slot * slot_stride;
+    }
+    HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
+    HIP_TRY(hipMemcpyAsync(c->d_cnt + CNT_TASKS, &br.n_sparse_keys, sizeof(uint32_t), hipMemcpyHostToDevice, s)); // (pageable source: copied before the call returns)
+    HIP_TRY(hipMemsetAsync(c->d_admit, 0, n, s));
+    if (nk) {
+        k_prof_admit<<<(unsigned)((nk + 255) / 256), 256, 0, s>>>(d_keys, nk, pv, c->d_admit, own_lo, n);
+        k_prof_count<<<(unsigned)((nk + 255) / 256), 256, 0, s>>>(d_keys, nk, pv);
+    }
+    k_prof_accum<<<4096, 256, 0, s>>>(c->d_detail, c->dlay, br.rb, ix, pv, sink, c->d_admit, paired);
     DiscEv *d_ev = (DiscEv *)c->d_tasks; // the SA task list is idle now
     const uint32_t ev_cap = (uint32_t)std::min<uint64_t>((uint64_t)c->task_cap * sizeof(uint2) / sizeof(DiscEv), 0x7fffffffu);
     if (paired) k_prof_disc<<<(n / 2 + 255) / 256, 256, 0, s>>>(c->d_detail, c->dlay, n / 2, d_ev, c->d_cnt + CNT_RESCUE, ev_cap);
@@ -1298,37 +1524,22 @@ static int profile_batch(mcx_ctx *c, const ReadBatch &rb, int paired)
     const size_t at = c->h_sparse.size();
     c->h_sparse.resize(at + n_sp);
     if (n_sp) HIP_TRY(hipMemcpy(c->h_sparse.data() + at, c->d_sparse, (size_t)n_sp * sizeof(SparseRec), hipMemcpyDeviceToHost));
+    for (size_t i = at; i < c->h_sparse.size(); i++)
+        if (c->h_sparse[i].type == 'X') return fail(MCX_ERR_UNSUPPORTED, "an insertion or deletion of more than " + std::to_string(sizeof(c->h_sparse[i].seq)) +
+                                                                      " bases in an alignment: its string does not fit a tally record");
     if (n_ev) {
-        // discordant-site lists, ReadMapping.cpp:486-521, replayed in pair order because the
-        // reference's second branch pushes its DiscordPair variable whatever it last held
+        // discordant-pair events, ReadMapping.cpp:486-521: kept as seen, with the pair's number in the input
+        // stream — the reference's second branch pushes its DiscordPair variable whatever the previous
+        // discordant pair left in it, so they are resolved in input order once the run is over
+        // (mcx_disc_resolve: mcx_profile_sparse for one shard, mcx_call_variants for several)
         std::vector<DiscEv> ev(n_ev);
         HIP_TRY(hipMemcpy(ev.data(), d_ev, (size_t)n_ev * sizeof(DiscEv), hipMemcpyDeviceToHost));
-        std::sort(ev.begin(), ev.end(), [](const DiscEv &a, const DiscEv &b) { return a.pair < b.pair; });
-        const int64_t G = ix.G, G2 = ix.G2;
-        auto push = [&](char type, int64_t gpos, int64_t dist) {
-            mcx_sparse_rec r; memset(&r, 0, sizeof r);
-            r.pos = gpos; r.type = (uint8_t)type; r.len = 0; memcpy(r.seq, &dist, 8);
-            c->h_sparse.push_back(r);
-        };
         for (const DiscEv &e : ev) {
-            if (e.kind == 1) {
-                int64_t d = G2 - e.g1 - e.g2; if (d < 0) d = -d;
-                if (d > 1000 && d < 10000000) push('V', e.g1, d);
-                c->last_disc[0] = e.g1; c->last_disc[1] = d;
-            } else if (e.kind == 2) {
-                int64_t d = G2 - e.g1 - e.g2; if (d < 0) d = -d;
-                c->last_disc[1] = d;
-                if (d > 1000 && d < 10000000) c->last_disc[0] = e.g2;
-                push('V', c->last_disc[0], c->last_disc[1]);
-            } else if (e.kind == 3) {
-                push('T', e.g1, e.dist); push('T', e.g2, e.dist);
-                c->last_disc[0] = e.g2; c->last_disc[1] = e.dist;
-            } else {
-                push('T', G2 - e.g1, e.dist); push('T', G2 - e.g2, e.dist);
-                c->last_disc[0] = G2 - e.g2; c->last_disc[1] = e.dist;
-            }
+            mcx_sparse_rec r; memset(&r, 0, sizeof r);
+            r.pos = br.read_base / 2 + (int64_t)e.pair; r.type = 'E'; r.len = (uint8_t)e.kind;
+            memcpy(r.seq, &e.g1, 8); memcpy(r.seq + 8, &e.g2, 8); memcpy(r.seq + 16, &e.dist, 8);
+            c->h_events.push_back(r);
         }
-        (void)G;
     }
     return 0;
 }
@@ -1346,7 +1557,18 @@ extern "C" int mcx_profile_finalize(mcx_ctx *c, uint32_t *d_planes)
 extern "C" int mcx_profile_sparse(mcx_ctx *c, const mcx_sparse_rec **recs, uint64_t *n)
 {
     if (!c || !recs || !n) return fail(MCX_ERR_ARG, "mcx_profile_sparse: null argument");
-    *recs = c->h_sparse.data(); *n = c->h_sparse.size();
+    c->h_resolved = c->h_sparse;
+    mcx_disc_resolve(c->h_events.data(), c->h_events.size(), c->idx->view.G, c->h_resolved);
+    *recs = c->h_resolved.data(); *n = c->h_resolved.size();
+    return 0;
+}
+
+extern "C" int mcx_profile_sparse_shard(mcx_ctx *c, const mcx_sparse_rec **recs, uint64_t *n)
+{
+    if (!c || !recs || !n) return fail(MCX_ERR_ARG, "mcx_profile_sparse_shard: null argument");
+    c->h_resolved = c->h_sparse;
+    c->h_resolved.insert(c->h_resolved.end(), c->h_events.begin(), c->h_events.end());
+    *recs = c->h_resolved.data(); *n = c->h_resolved.size();
     return 0;
 }
 
@@ -1483,7 +1705,7 @@ extern "C" int mcx_cigar_ext(mcx_ctx *c, int on_device, const uint32_t **words, 
     if (!c || !words || !n_words) return fail(MCX_ERR_ARG, "mcx_cigar_ext: null argument");
     HIP_TRY(hipSetDevice(c->idx->device));
     uint32_t used = 0;
-    HIP_TRY(hipMemcpy(&used, c->d_cig_ext_n, sizeof used, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&used, c->d_batch_flags, sizeof used, hipMemcpyDeviceToHost));
     *n_words = used;
     if (on_device) { *words = c->d_cig_ext; return 0; }
     c->h_cig_ext.resize(used);
@@ -1494,6 +1716,7 @@ extern "C" int mcx_cigar_ext(mcx_ctx *c, int on_device, const uint32_t **words, 
 
 const mcx_index *mcx_ctx_index(const mcx_ctx *c) { return c->idx; }
 int mcx_ctx_max_read_len(const mcx_ctx *c) { return c->rlen_max; }
+bool mcx_ctx_has_profile(const mcx_ctx *c) { return c->prof_planes != nullptr; }
 uint64_t mcx_ctx_max_reads(const mcx_ctx *c) { return c->max_reads; }
 void *mcx_pinned_alloc(size_t bytes) { void *p = nullptr; return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
 void mcx_pinned_free(void *p) { if (p) (void)hipHostFree(p); }

@@ -43,49 +43,70 @@ static __device__ __forceinline__ const DetailHdr &detail_hdr(const uint8_t *det
 }
 
 // pass 1: break points, clip gate, and the (start position, read) key of every read that reaches
-// the duplicate check (AlignmentProfile.cpp:53-77)
+// the duplicate check (AlignmentProfile.cpp:53-77); n_valid counts them (the others get ~0 and sort last)
 __global__ void k_prof_keys(const uint8_t *detail, DetailLayout dl, ReadBatch rb, IndexView ix, ProfView pv, SparseSink sink,
-                            uint64_t *keys)
+                            uint64_t *keys, uint32_t *n_valid)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rb.n_reads) return;
-    const uint8_t *rec = detail + (uint64_t)r * dl.stride;
-    const DetailHdr &d = *(const DetailHdr *)rec;
     uint64_t key = ~0ull;
-    if (d.type == 1) {
-        const Frag *f = (const Frag *)(rec + sizeof(DetailHdr));
-        const Frag &a = f[0], &b = f[d.n_frags - 1];
-        const int rlen = (int)(rb.off[r + 1] - rb.off[r]);
-        bool go = true;
-        if (a.rLen == 0 && a.gLen == 0) {
-            if (a.rPos > 20) { SparseRec s; s.pos = a.gPos < ix.G ? a.gPos : ix.G2 - 1 - a.gPos; s.type = 'B'; s.len = 0; sparse_put(sink, s); }
-            if (a.rPos > pv.max_clip) go = false;
+    if (r < rb.n_reads) {
+        const uint8_t *rec = detail + (uint64_t)r * dl.stride;
+        const DetailHdr &d = *(const DetailHdr *)rec;
+        if (d.type == 1) {
+            const Frag *f = (const Frag *)(rec + sizeof(DetailHdr));
+            const Frag &a = f[0], &b = f[d.n_frags - 1];
+            const int rlen = (int)(rb.off[r + 1] - rb.off[r]);
+            bool go = true;
+            if (a.rLen == 0 && a.gLen == 0) {
+                if (a.rPos > 20) { SparseRec s; s.pos = a.gPos < ix.G ? a.gPos : ix.G2 - 1 - a.gPos; s.type = 'B'; s.len = 0; sparse_put(sink, s); }
+                if (a.rPos > pv.max_clip) go = false;
+            }
+            if (go && b.rLen == 0 && b.gLen == 0) {
+                if (rlen - b.rPos > 20) { SparseRec s; s.pos = b.gPos < ix.G ? b.gPos : ix.G2 - 1 - b.gPos; s.type = 'B'; s.len = 0; sparse_put(sink, s); }
+                if (rlen - b.rPos > pv.max_clip) go = false;
+            }
+            if (go) {
+                const int64_t g = d.fwd ? a.gPos : ix.G2 - (a.gPos + a.gLen);
+                key = ((uint64_t)g << 32) | r;
+            }
         }
-        if (go && b.rLen == 0 && b.gLen == 0) {
-            if (rlen - b.rPos > 20) { SparseRec s; s.pos = b.gPos < ix.G ? b.gPos : ix.G2 - 1 - b.gPos; s.type = 'B'; s.len = 0; sparse_put(sink, s); }
-            if (rlen - b.rPos > pv.max_clip) go = false;
-        }
-        if (go) {
-            const int64_t g = d.fwd ? a.gPos : ix.G2 - (a.gPos + a.gLen);
-            key = ((uint64_t)g << 32) | r;
-        }
+        keys[r] = key;
     }
-    keys[r] = key;
+    const uint64_t m = __ballot(key != ~0ull);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_valid, (uint32_t)__popcll(m));
 }
 
-// pass 2 (keys sorted): a read is admitted when fewer than max_dup reads were admitted at its
-// start position before it — earlier batches (readCount plane) plus earlier reads of this batch
-__global__ void k_prof_admit(const uint64_t *keys, uint32_t n, ProfView pv, uint8_t *admit)
+// pass 2 (keys sorted by (start position, read number in input order), the reads of every shard of the
+// round among them): a read is admitted when fewer than max_dup reads were admitted at its start position
+// before it — earlier rounds (readCount plane) plus earlier reads of this round.  Only the reads
+// [own_lo, own_lo + n_own) are this shard's: their flags are written.
+__global__ void k_prof_admit(const uint64_t *keys, uint64_t n, ProfView pv, uint8_t *admit, uint32_t own_lo, uint32_t n_own)
 {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const uint64_t key = keys[j];
-    if (key == ~0ull) return;
+    const uint32_t idx = (uint32_t)key - own_lo;
+    if (idx >= n_own) return;
     const uint64_t g = key >> 32;
     int rank = 0;
-    for (int k = 1; k <= pv.max_dup && (uint32_t)k <= j; k++) { if ((keys[j - k] >> 32) == g) rank++; else break; }
+    for (int k = 1; k <= pv.max_dup && (uint64_t)k <= j; k++) { if ((keys[j - k] >> 32) == g) rank++; else break; }
     const uint32_t before = pv.plane[(uint64_t)kPlReadCount * pv.G + g];
-    admit[(uint32_t)key] = (before + (uint32_t)rank < (uint32_t)pv.max_dup) ? 1 : 0;
+    admit[idx] = (before + (uint32_t)rank < (uint32_t)pv.max_dup) ? 1 : 0;
+}
+
+// pass 2b (after every flag is out): the first key of each start position adds the round's admissions to
+// readCount — the count of the whole run, the same on every shard (`readCount < iMaxDuplicate` then ++, :76-77)
+__global__ void k_prof_count(const uint64_t *keys, uint64_t n, ProfView pv)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint64_t g = keys[j] >> 32;
+    if (j > 0 && (keys[j - 1] >> 32) == g) return;
+    uint32_t run = 1;
+    while (run < (uint32_t)pv.max_dup && j + run < n && (keys[j + run] >> 32) == g) run++;
+    uint32_t *cnt = &pv.plane[(uint64_t)kPlReadCount * pv.G + g];
+    const uint32_t v = *cnt + run;
+    *cnt = v < (uint32_t)pv.max_dup ? v : (uint32_t)pv.max_dup;
 }
 
 // the character the reference sees at alignment-string index xi of a fragment's read string
@@ -127,7 +148,6 @@ __global__ void __launch_bounds__(256) k_prof_accum(const uint8_t *detail, Detai
         const bool fwd = d.fwd != 0, first = paired ? !(r & 1) : true;
         const Frag &a = fr[0];
         const int64_t start = fwd ? a.gPos : ix.G2 - (a.gPos + a.gLen);
-        if (lane == 0) atomicAdd(&pv.plane[(uint64_t)kPlReadCount * pv.G + start], 1u);
         const int strand = first ? (fwd ? kPlF1 : kPlR1) : (fwd ? kPlR2 : kPlF2);
         for (int o = lane; o < rd.rlen; o += 64)
             if (start + o < pv.G) atomicAdd(&pv.plane[(uint64_t)strand * pv.G + start + o], 1u); // (the reference runs past the array at the genome end)
@@ -156,12 +176,18 @@ __global__ void __launch_bounds__(256) k_prof_accum(const uint8_t *detail, Detai
                 } else if (op == 'I' || op == 'D') {
                     const uint8_t prev = x == 0 ? 0 : (uni ? uni : ops[f.ops_off + x - 1]);
                     if (prev != op) { // first column of a run: this lane records it (:133-150)
-                        SparseRec s; s.pos = g0 + gi - 1; s.type = op;
                         int e = 0;
-                        for (; x + e < n_cols && (uni ? uni : ops[f.ops_off + x + e]) == op; e++)
-                            if (e < (int)sizeof(s.seq)) s.seq[e] = op == 'I' ? (char)frag_read_char(rd, f, fwd, ri + e) : "ACGT"[ref_code(ix, g0 + gi + e)];
-                        s.len = (uint8_t)(e < 255 ? e : 255);
-                        sparse_put(sink, s);
+                        while (x + e < n_cols && (uni ? uni : ops[f.ops_off + x + e]) == op) e++;
+                        // a string longer than a record continues in the records behind it ('C'); beyond 255 bases it is refused ('X')
+                        const int per = (int)sizeof(SparseRec::seq), n_rec = e > 255 ? 1 : (e + per - 1) / per;
+                        const uint32_t at = atomicAdd(sink.n, (uint32_t)n_rec);
+                        for (int k = 0; k < n_rec; k++) {
+                            SparseRec s; s.pos = g0 + gi - 1; s.type = e > 255 ? 'X' : (k == 0 ? op : 'C');
+                            const int lo = k * per, m = e > 255 ? 0 : (e - lo < per ? e - lo : per);
+                            for (int i = 0; i < m; i++) s.seq[i] = op == 'I' ? (char)frag_read_char(rd, f, fwd, ri + lo + i) : "ACGT"[ref_code(ix, g0 + gi + lo + i)];
+                            s.len = (uint8_t)(k == 0 ? (e > 255 ? 255 : e) : m);
+                            if (at + k < sink.cap) sink.recs[at + k] = s;
+                        }
                     }
                 }
                 base_r += __popcll(mR); base_g += __popcll(mG);

@@ -128,7 +128,7 @@ static inline bool by_pos(const Variant &a, const Variant &b) { return a.gPos ==
 
 // InsertSeqMap / DeleteSeqMap (AlignmentProfile.cpp:7) as one array sorted by (position, string) —
 // the iteration order of the reference's map of maps — with 16-bit counts that wrap like its uint16_t
-struct Tally { int64_t pos; uint16_t count; uint8_t len; char seq[54]; };
+struct Tally { int64_t pos; uint16_t count; std::string seq; };
 typedef std::vector<Tally> IndelMap;
 struct Clip { int64_t pos; uint16_t count; };
 struct Site { int64_t gPos, dist; };
@@ -179,29 +179,34 @@ private:
 // one record per event -> the reference's maps (AlignmentProfile.cpp:6-7) and site lists (ReadMapping.cpp:19)
 inline void Caller::fold(const mcx_sparse_rec *recs, uint64_t n)
 {
-    std::vector<uint64_t> idx[2];
+    std::vector<Tally> ev[2];
     std::vector<int64_t> clip;
+    std::vector<mcx_sparse_rec> sites; // 'V' / 'T' as given, plus the ones the 'E' events of all shards resolve to
+    bool any_event = false;
     for (uint64_t i = 0; i < n; i++) {
         const mcx_sparse_rec &r = recs[i];
         switch (r.type) {
-        case 'I': idx[0].push_back(i); break;
-        case 'D': idx[1].push_back(i); break;
+        case 'I': case 'D': {
+            Tally t; t.pos = r.pos; t.count = 1;
+            t.seq.assign(r.seq, std::min<size_t>(r.len, sizeof r.seq));
+            for (uint64_t j = i + 1; j < n && recs[j].type == 'C' && t.seq.size() < r.len; j++) // a long string continues in the records behind
+                t.seq.append(recs[j].seq, std::min<size_t>(recs[j].len, sizeof recs[j].seq));
+            ev[r.type == 'D'].push_back(std::move(t));
+            break;
+        }
         case 'B': clip.push_back(r.pos); break;
-        case 'V': case 'T': { Site s; s.gPos = r.pos; memcpy(&s.dist, r.seq, 8); (r.type == 'V' ? inv_ : tnl_).push_back(s); break; }
+        case 'V': case 'T': sites.push_back(r); break;
+        case 'E': any_event = true; break;
         }
     }
+    if (any_event) mcx_disc_resolve(recs, n, G_, sites);
+    for (const mcx_sparse_rec &r : sites) { Site s; s.gPos = r.pos; memcpy(&s.dist, r.seq, 8); (r.type == 'V' ? inv_ : tnl_).push_back(s); }
     for (int k = 0; k < 2; k++) {
-        auto len_of = [&](uint64_t i) { return std::min<size_t>(recs[i].len, sizeof recs[i].seq); };
-        std::sort(idx[k].begin(), idx[k].end(), [&](uint64_t a, uint64_t b) {
-            if (recs[a].pos != recs[b].pos) return recs[a].pos < recs[b].pos;
-            return seq_cmp(recs[a].seq, len_of(a), recs[b].seq, len_of(b)) < 0;
-        });
+        std::sort(ev[k].begin(), ev[k].end(), [](const Tally &a, const Tally &b) { return a.pos != b.pos ? a.pos < b.pos : a.seq < b.seq; });
         IndelMap &m = k == 0 ? ins_ : del_;
-        for (uint64_t i : idx[k]) {
-            const mcx_sparse_rec &r = recs[i];
-            if (!m.empty() && m.back().pos == r.pos && seq_cmp(m.back().seq, m.back().len, r.seq, len_of(i)) == 0) { m.back().count++; continue; }
-            Tally t; t.pos = r.pos; t.count = 1; t.len = (uint8_t)len_of(i); memset(t.seq, 0, sizeof t.seq); memcpy(t.seq, r.seq, t.len);
-            m.push_back(t);
+        for (Tally &t : ev[k]) {
+            if (!m.empty() && m.back().pos == t.pos && m.back().seq == t.seq) { m.back().count++; continue; }
+            m.push_back(std::move(t));
         }
     }
     std::sort(clip.begin(), clip.end());
@@ -232,7 +237,7 @@ inline int Caller::area_freq(int64_t g, const IndelMap &m, const Tally *&best)
     auto a = std::lower_bound(m.begin(), m.end(), g - 5, [](const Tally &t, int64_t x) { return t.pos < x; });
     for (; a != m.end() && a->pos <= g + 5; ++a) {
         freq += a->count;
-        if (max_freq < a->count || (max_freq == a->count && a->len > (best ? best->len : 0))) {
+        if (max_freq < a->count || (max_freq == a->count && a->seq.size() > (best ? best->seq.size() : 0))) {
             if (max_freq < a->count) max_freq = a->count;
             best = &*a; max_pos = a->pos;
         }
@@ -263,7 +268,7 @@ inline int Caller::indels()
             if (freq < thr_of[k]) continue;
             Variant v;
             v.gPos = g; v.type = k == 0 ? vINS : vDEL;
-            if (best) v.set_alt(best->seq, best->len);
+            if (best) v.set_alt(best->seq.data(), best->seq.size());
             v.AD_alt = (uint16_t)freq; v.DP = std::max((uint16_t)c.depth, v.AD_alt); v.AD_ref = v.DP - v.AD_alt;
             v.geno = genotype_of(o_.ploidy, v.DP, v.AD_alt, 1);
             v.qscore = cov == 0 ? 0 : (uint8_t)(int)(100.0 * v.AD_alt / cov); // (the reference's x/0 also ends as 0 on x86-64)

@@ -1,12 +1,14 @@
-"""Multi-GPU glue: one process per GPU, reads sharded, one exchange at the end of a run.
+"""Multi-GPU glue: one process per GPU, reads sharded, one bulk exchange at the end of a run.
 
-Reads shard embarrassingly: every rank maps a contiguous range of pairs against
-its own replica of the index, so the data path has no collective.  The only exchange is the one
-the reference's design implies when -vcf is on: the per-position counters that UpdateProfile
-accumulates (reference src/AlignmentProfile.cpp:41-271) must be summed before VariantCalling
-reads them, and the sparse tallies (insert / delete strings, break points, discordant sites)
-concatenated.  With torch.distributed's "nccl" backend that all-reduce is RCCL over xGMI; the
-same code runs on gloo for the CPU tests.
+Reads shard embarrassingly: every rank maps its batches against its own replica of
+the index.  What the ranks exchange while they map is a few KB per round (per-chunk pair sums for
+the one insert-size trajectory of the stream, duplicate-check keys: api.dist_exchange, handled
+inside mcx_map_files_ex).  The bulk exchange is the one the reference's design implies when -vcf is
+on: the per-position counters that UpdateProfile accumulates (reference
+src/AlignmentProfile.cpp:41-271) must be summed before VariantCalling reads them, and the sparse
+tallies (insert / delete strings, break points, discordant-pair events) concatenated.  With
+torch.distributed's "nccl" backend that reduce is RCCL over xGMI; the same code runs on gloo for the
+CPU tests.
 """
 from __future__ import annotations
 
@@ -38,22 +40,39 @@ def finalize_planes(planes: torch.Tensor, max_dup: int = 5) -> torch.Tensor:
     return planes
 
 
-def reduce_profile(planes: torch.Tensor, sparse):
-    """Sums the [10, G] counter planes over all ranks in place (all-reduce: RCCL on GPU tensors),
-    in pieces of 2^30 elements so that no collective's count outgrows 32 bits, and gathers the sparse
-    records of every rank in rank order.  ``sparse`` is either the list of tuples of
+READ_COUNT_PLANE = 5
+
+
+def reduce_profile(planes: torch.Tensor, sparse, root: int = 0, shared_read_count: bool = True):
+    """Sums the [10, G] counter planes of all ranks onto ``root`` (RCCL reduce on GPU tensors; only the
+    rank that calls the variants needs the sum), in pieces of 2^28 elements (1 GiB: link speed, and no
+    collective's count outgrows 32 bits), and gathers the sparse records of every rank in rank order.
+    ``shared_read_count``: the readCount plane already holds the run's count on every rank (the
+    duplicate cap was decided across shards, mcx_batch_accumulate) and is left out of the sum; pass
+    False for planes accumulated by independent runs.  ``sparse`` is either the list of tuples of
     Mapper.profile_sparse() or the raw uint8 [n, 64] array of Mapper.profile_sparse_raw(); the same
-    kind comes back.  Call before finalisation."""
+    kind comes back.  Call before finalisation.  With the gloo backend (CPU tests, several ranks on
+    one GPU) device tensors are staged through the host."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return planes, (sparse if isinstance(sparse, np.ndarray) else list(sparse))
-    step = 1 << 30  # elements per collective: a GRCh38-sized plane has 3.1e9, more than a 32-bit count holds
+    staged = dist.get_backend() != "nccl" and planes.is_cuda
+    step = 1 << 28
     for k in range(planes.shape[0]):
+        if shared_read_count and k == READ_COUNT_PLANE:
+            continue
         row = planes[k]
         for lo in range(0, row.numel(), step):
-            dist.all_reduce(row[lo:lo + step], op=dist.ReduceOp.SUM)
+            piece = row[lo:lo + step]
+            if staged:
+                h = piece.cpu()
+                dist.reduce(h, dst=root, op=dist.ReduceOp.SUM)
+                if dist.get_rank() == root:
+                    piece.copy_(h)
+            else:
+                dist.reduce(piece, dst=root, op=dist.ReduceOp.SUM)
     world = dist.get_world_size()
     if isinstance(sparse, np.ndarray):  # raw records: one padded all-gather of bytes
-        dev = planes.device
+        dev = planes.device if not staged else torch.device("cpu")
         n = torch.tensor([sparse.shape[0]], dtype=torch.int64, device=dev)
         counts = [torch.zeros_like(n) for _ in range(world)]
         dist.all_gather(counts, n)
@@ -72,11 +91,16 @@ def reduce_profile(planes: torch.Tensor, sparse):
     return planes, merged
 
 
+def _coll_device(device: torch.device) -> torch.device:
+    """Small collectives run on the device with RCCL and on the host with gloo."""
+    return device if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
 def sum_over_ranks(values: Sequence[int], device: torch.device) -> List[int]:
     """Run totals the variant caller needs from all shards (pairs, pair distance sum, read length sum)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [int(v) for v in values]
-    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [int(v) for v in t.tolist()]
 
@@ -84,6 +108,6 @@ def sum_over_ranks(values: Sequence[int], device: torch.device) -> List[int]:
 def max_over_ranks(seconds: float, device: torch.device) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return seconds
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    t = torch.tensor([seconds], dtype=torch.float64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -7,10 +7,12 @@
 One process per GPU.  The input stream is cut into batches that are dealt to the ranks in turn
 (reads shard embarrassingly): every rank walks the files, maps its own batches against
 its own replica of the index and writes its part of the SAM; rank 0 puts the parts back into input
-order.  With -vcf on, the one exchange of the run follows (mapcaller_amd/dist.py): the per-position
-counter planes are summed with an RCCL all-reduce, the sparse tallies and the run totals gathered, and
-rank 0 calls the variants (mcx_call_variants).  Each shard follows its own insert-size trajectory,
-exactly as a run of the reference on that shard's reads would.
+order.  While they map, the ranks exchange a few KB per round (api.dist_exchange) so that the run
+follows the ONE insert-size trajectory and the ONE duplicate-cap order of the input stream: SAM and
+VCF equal the single-stream run's.  With -vcf on, the bulk exchange of the run follows
+(mapcaller_amd/dist.py): the per-position counter planes are summed onto rank 0 with an RCCL reduce,
+the sparse tallies and the run totals gathered, and rank 0 calls the variants (mcx_call_variants).
+(The C++ product does the same without Python: mapcaller-mi355x -gpus N.)
 
 Host-side glue only: parsing, mapping, SAM text and variant calling all happen behind the C ABI.
 """
@@ -71,38 +73,10 @@ def sample_read_length(path, lines=40000):
 
 
 def merge_sam(path, world):
-    """The ranks' parts back into input order: batch k sits in part k % world."""
-    index = []
-    for r in range(world):
-        with open(f"{path}.part{r}.idx") as fh:
-            index.append([(int(a), int(b)) for a, b in (l.split() for l in fh if l.strip())])
-    parts = [open(f"{path}.part{r}", "rb") for r in range(world)]
-    with open(path, "wb") as out:
-        # part 0 starts with the header
-        header_len = os.path.getsize(f"{path}.part0") - sum(b for _, b in index[0])
-        out.write(parts[0].read(header_len))
-        todo = sorted((k, r) for r in range(world) for k, _ in index[r])
-        sizes = [dict(ix) for ix in index]
-        for k, r in todo:
-            shutil.copyfileobj(_Limited(parts[r], sizes[r][k]), out, 1 << 24)
-    for fh in parts:
-        fh.close()
-    for r in range(world):
-        os.remove(f"{path}.part{r}")
-        os.remove(f"{path}.part{r}.idx")
-
-
-class _Limited:
-    def __init__(self, fh, n):
-        self.fh, self.n = fh, n
-
-    def read(self, k=-1):
-        if self.n <= 0:
-            return b""
-        k = self.n if k < 0 else min(k, self.n)
-        b = self.fh.read(k)
-        self.n -= len(b)
-        return b
+    """The ranks' parts back into input order (batch k sits in part k % world): mcx_sam_merge."""
+    rc = api.lib().mcx_sam_merge(path.encode(), world)
+    if rc:
+        raise api.McxError(f"mcx_sam_merge failed ({rc}): {api.lib().mcx_last_error().decode()}")
 
 
 def main(argv=None):
@@ -132,25 +106,29 @@ def main(argv=None):
         planes = torch.zeros((10, index.genome_size), dtype=torch.int32, device=dev)
         mapper.profile_attach(planes.data_ptr(), max_dup=a.dup, max_clip=a.maxclip)
     totals = {"reads": 0, "mapped": 0, "pairs": 0, "pair_dist_sum": 0, "pair_len_sum": 0}
-    for k, f1 in enumerate(a.f1):
+    link = api.dist_exchange(dev) if world > 1 else None
+    for k, f1 in enumerate(a.f1):  # libraries one after the other, like the reference: one SAM stream, one insert-size state
         f2 = a.f2[k] if a.f2 else None
-        sam = None
+        sam, base = None, None
         if a.sam:
-            sam = a.sam if world == 1 else f"{a.sam}.part{rank}"
-            if k > 0:
-                raise SystemExit("several libraries in one sharded run are not supported yet: run them one by one")
+            base = a.sam if k == 0 else f"{a.sam}.lib{k}"
+            sam = a.sam if world == 1 else f"{base}.part{rank}"
         st = mapper.map_files(f1, f2, sam, interleaved=a.interleaved, threads=a.threads,
-                              shard=(rank, world) if world > 1 else None, sam_header=(rank == 0),
-                              sam_index=(sam + ".idx") if (sam and world > 1) else None)
+                              shard=(rank, world) if world > 1 else None, exchange=link, sam_header=(rank == 0 and k == 0),
+                              sam_index=(sam + ".idx") if (sam and world > 1) else None, append_sam=(world == 1 and k > 0))
         for key in totals:
             totals[key] += st[key]
+        if td:
+            td.barrier()
+        if rank == 0 and a.sam and world > 1:
+            merge_sam(base, world)
+            if k > 0:
+                with open(base, "rb") as src, open(a.sam, "ab") as dst:
+                    shutil.copyfileobj(src, dst, 1 << 24)
+                os.remove(base)
     tot = mdist.sum_over_ranks([totals[k] for k in ("reads", "mapped", "pairs", "pair_dist_sum", "pair_len_sum")], dev)
-    if td:
-        td.barrier()
-    if rank == 0 and a.sam and world > 1:
-        merge_sam(a.sam, world)
     if want_vcf:
-        planes, sparse = mdist.reduce_profile(planes, mapper.profile_sparse_raw())
+        planes, sparse = mdist.reduce_profile(planes, mapper.profile_sparse_raw(shard=world > 1))
         if rank == 0:
             mapper.profile_finalize(planes.data_ptr())
             vs = index.call_variants(planes.data_ptr(), sparse, tot[2], tot[3], tot[4], a.vcf, ploidy=a.ploidy, min_allele_depth=a.ad,

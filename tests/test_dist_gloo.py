@@ -1,6 +1,7 @@
 """The N > 1 path on CPU: world_size 2 over gloo.  Shards partition the pairs on chunk
-boundaries, the profile reduce sums the planes and concatenates the sparse tallies, and the
-summed planes finalise to the reference's field widths."""
+boundaries, the profile reduce sums the planes onto the root (all but readCount, which every shard
+already holds for the whole run) and concatenates the sparse tallies, the summed planes finalise to
+the reference's field widths, and the per-round exchange of a file run gathers bytes in rank order."""
 import os
 import socket
 
@@ -30,7 +31,16 @@ def _worker(rank, world, port, out):
     planes[6:10] += 40000  # strand depths near the 16-bit wrap
     mine = planes.clone()
     sparse = [("I", 10 * rank + k, "AC") for k in range(3)] + [("B", 7, "")]
-    planes, merged = mdist.reduce_profile(planes, sparse)
+    planes, merged = mdist.reduce_profile(planes, sparse, root=0)
+    # the dist_exchange the shards of a file run share: bytes of every rank in rank order, any length
+    from mapcaller_amd import api
+    link = api.dist_exchange()
+    for nbytes in (4, 1000, 0, 33):
+        send = np.full(max(nbytes, 1), 7 * rank + 1, dtype=np.uint8)
+        recv = np.zeros(max(world * nbytes, 1), dtype=np.uint8)
+        assert link.allgather(None, send.ctypes.data, recv.ctypes.data, nbytes) == 0
+        if nbytes:
+            assert recv.reshape(world, nbytes)[:, 0].tolist() == [7 * q + 1 for q in range(world)]
     raw = np.full((2 + rank, 64), rank + 1, dtype=np.uint8)  # raw record arrays of different lengths
     _, raw_all = mdist.reduce_profile(torch.zeros((10, 4), dtype=torch.int32), raw)
     assert raw_all.shape == (5, 64) and raw_all[:2].max() == 1 and raw_all[2:].min() == 2
@@ -57,6 +67,7 @@ def test_profile_reduce_and_sharding_world2(tmp_path):
     other = torch.randint(0, 3000, (10, 1000), generator=g1, dtype=torch.int32)
     other[6:10] += 40000
     want = r["mine"] + other
+    want[5] = r["mine"][5]  # the readCount plane is the run's on every rank already: not summed
     assert torch.equal(r["sum"], want)
     fin = mdist.finalize_planes(want.clone(), max_dup=5)
     assert int(fin[0:5].max()) <= 4095 and int(fin[5].max()) <= 5 and int(fin[6:10].max()) <= 0xFFFF
@@ -73,21 +84,3 @@ def test_shards_cover_everything_for_any_world():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert all(lo % 100 == 0 for lo, _ in spans)
-
-
-def test_merge_sam_puts_batches_back_in_input_order(tmp_path):
-    """mapcaller_amd.run.merge_sam: batch k lives in part k % world; the header comes from part 0."""
-    from mapcaller_amd.run import merge_sam
-    path = str(tmp_path / "o.sam")
-    world, n_batches = 3, 8
-    batches = [("".join(f"read{k}_{i}\tx\n" for i in range(k + 1))).encode() for k in range(n_batches)]
-    for r in range(world):
-        with open(f"{path}.part{r}", "wb") as fh, open(f"{path}.part{r}.idx", "w") as ix:
-            if r == 0:
-                fh.write(b"@PG\tID:MapCaller\n@SQ\tSN:c\tLN:9\n")
-            for k in range(r, n_batches, world):
-                fh.write(batches[k])
-                ix.write(f"{k} {len(batches[k])}\n")
-    merge_sam(path, world)
-    assert open(path, "rb").read() == b"@PG\tID:MapCaller\n@SQ\tSN:c\tLN:9\n" + b"".join(batches)
-    assert not any(os.path.exists(f"{path}.part{r}") for r in range(world))

@@ -456,50 +456,86 @@ def test_file_path_errors_are_loud(api, golden, tmp_path):
     mp.close(); ix.close()
 
 
-def test_sharded_run_two_ranks(golden, oracle_lib, tmp_path):
-    """mapcaller_amd.run under torchrun with two ranks (both on GPU 0, gloo so that they can share it):
-    batches of 200 pairs dealt to the ranks in turn, SAM parts merged back into input order, planes
-    all-reduced, sparse tallies gathered, variants called on rank 0.  The SAM equals what the oracle
-    gives for each shard's reads (a shard follows its own insert-size trajectory); on this small set
-    that is also the single-stream SAM, so the VCF equals the reference's."""
-    g = golden["toy"]
+def _free_port():
     import socket
-    sam, vcf = str(tmp_path / "o.sam"), str(tmp_path / "o.vcf")
-    env = dict(os.environ, PYTHONPATH=ROOT)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           "-m", "mapcaller_amd.run", "-backend", "gloo", "-i", g["prefix"], "-f", g["r1"], "-f2", g["r2"], "-alg", "ksw2", "-sam", sam, "-vcf", vcf,
-           "-batch", "400"]
-    subprocess.run(cmd, check=True, env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
-    # expectation: the oracle on each shard's reads, batches put back in turn
-    l1 = open(g["r1"], "rb").read().split(b"\n")
-    l2 = open(g["r2"], "rb").read().split(b"\n")
-    n_pairs = len(l1) // 4
-    shard_lines = []
-    for r in range(2):
-        picks = [p for p in range(n_pairs) if (p // 200) % 2 == r]
-        for tag, ll in (("1", l1), ("2", l2)):
-            (tmp_path / f"s{r}_{tag}.fq").write_bytes(b"\n".join(b"\n".join(ll[4 * p:4 * p + 4]) for p in picks) + b"\n")
-        out = str(tmp_path / f"s{r}.sam")
-        ix = oracle_lib.mcxo_index_load(g["prefix"].encode())
-        assert oracle_lib.mcxo_map_files(ix, str(tmp_path / f"s{r}_1.fq").encode(), str(tmp_path / f"s{r}_2.fq").encode(), 1, out.encode(), 1, None) == 2 * len(picks)
-        oracle_lib.mcxo_index_free(ix)
-        shard_lines.append([l for l in open(out, encoding="latin-1").read().split("\n") if l and not l.startswith("@")])
-    want, at = [], [0, 0]
-    for p in range(n_pairs):
-        r = (p // 200) % 2
-        want += shard_lines[r][at[r]:at[r] + 2]
-        at[r] += 2
-    got = [l for l in open(sam, encoding="latin-1").read().split("\n") if l and not l.startswith("@")]
-    assert got == want
-    head = [l for l in open(sam, encoding="latin-1").read().split("\n") if l.startswith("@")]
-    assert head == [l for l in open(g["sam"]["ksw2"], encoding="latin-1").read().split("\n") if l.startswith("@")]
-    if got == [l for l in open(g["sam"]["ksw2"], encoding="latin-1").read().split("\n") if l and not l.startswith("@")]:
+        return sk.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,batch", [(2, 2000), (3, 1000), (2, 400)])
+def test_sharded_run_equals_single_stream(golden, tmp_path, world, batch):
+    """mapcaller_amd.run under torchrun with several ranks (all on GPU 0, gloo so that they can share it):
+    batches dealt to the ranks in turn, one insert-size trajectory and one duplicate-cap order kept
+    across the shards by the per-round exchange, SAM parts merged back into input order, planes reduced
+    onto rank 0, sparse tallies and discordant-pair events gathered, variants called on rank 0.
+    SAM *and* VCF equal the reference's single-stream (-t 1) run on the `var` set (SNVs, indels, an
+    inversion, a moved segment; ~30x: the duplicate cap bites, the first 1000 pairs move the estimate)."""
+    g = golden["var"]
+    sam, vcf = str(tmp_path / "o.sam"), str(tmp_path / "o.vcf")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "-m", "mapcaller_amd.run", "-backend", "gloo", "-i", g["prefix"], "-f", g["r1"], "-f2", g["r2"],
+           "-alg", "ksw2", "-sam", sam, "-vcf", vcf, "-batch", str(batch)]
+    subprocess.run(cmd, check=True, env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1200)
+    nd, ex = sam_diff(g["sam"]["ksw2"], sam)
+    assert nd == 0, ex
+    assert vcf_body(vcf) == vcf_body(g["vcf"]["default"])
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f]
+
+
+@pytest.mark.parametrize("devices,batch,name,alg", [("0,0", "2000", "var", "ksw2"), ("0,0,0", "600", "var", "ksw2"), ("0,0", "400", "se", "ksw2"),
+                                                   ("0,0,0", "400", "mc", "nw")])
+def test_native_cli_several_shards_equals_single_stream(golden, tmp_path, devices, batch, name, alg):
+    """mapcaller-mi355x -devices a,b,..: one host thread and one context per shard inside one process
+    (the shards share GPU 0 here; the profile reduce then takes its in-process path instead of RCCL),
+    the exchange between host threads, the SAM parts merged by the C++ side.  Same bar: single-stream SAM and VCF,
+    on a paired set, a single-end set and a multi-contig set."""
+    g = golden[name]
+    exe = os.path.join(ROOT, "mapcaller_amd", "mapcaller-mi355x")
+    sam, vcf = str(tmp_path / "o.sam"), str(tmp_path / "o.vcf")
+    cmd = [exe, "-i", g["prefix"], "-f", g["r1"]] + (["-f2", g["r2"]] if g["r2"] else []) + ["-alg", alg, "-sam", sam, "-vcf", vcf, "-t", "2",
+                                                                                            "-devices", devices, "-batch", batch]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1200)
+    nd, ex = sam_diff(g["sam"][alg], sam, mask_se_reverse_qual=not g["r2"])
+    assert nd == 0, ex
+    if vcf_alg(name, "default") == alg:
         assert vcf_body(vcf) == vcf_body(g["vcf"]["default"])
-    else:
-        assert sum(1 for l in vcf_body(vcf) if l and not l.startswith("#")) > 100
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f]
+
+
+def test_native_cli_shards_two_libraries(io_golden, tmp_path):
+    """Two libraries over two shards: one SAM stream, the insert-size state carried from the first library into
+    the second on every shard (the reference's globals)."""
+    g = io_golden
+    exe = os.path.join(ROOT, "mapcaller_amd", "mapcaller-mi355x")
+    sam = str(tmp_path / "lib.sam")
+    cmd = [exe, "-i", g["prefix"], "-f", g["a1"], g["b1"], "-f2", g["a2"], g["b2"], "-alg", "ksw2", "-sam", sam, "-no_vcf", "-devices", "0,0", "-batch", "400"]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    nd, ex = sam_diff(g["ref.lib.sam"], sam)
+    assert nd == 0, ex
+
+
+def test_profile_reduce_over_rccl_one_rank(api, golden):
+    """libmcx_comm.so on the GPU box: a one-rank communicator through RCCL's own entry points (ncclGetUniqueId,
+    ncclCommInitRank, ncclReduce) — what a single-GPU box can exercise of the N-GPU reduce."""
+    import ctypes
+    import torch
+    L = ctypes.CDLL(api.COMM_LIB_PATH)
+    ident = (ctypes.c_uint8 * 128)()
+    assert L.mcx_comm_unique_id(ident) == 0, api.lib().mcx_last_error()
+    comm = ctypes.c_void_p()
+    assert L.mcx_comm_init_rank(ident, 0, 1, 0, ctypes.byref(comm)) == 0, api.lib().mcx_last_error()
+    G = 100_000
+    planes = torch.arange(10 * G, dtype=torch.int32, device="cuda").reshape(10, G).contiguous()
+    want = planes.clone()
+    secs = ctypes.c_double()
+    L.mcx_profile_reduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
+    assert L.mcx_profile_reduce(comm, planes.data_ptr(), G, 0, ctypes.byref(secs)) == 0, api.lib().mcx_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(planes, want)
+    L.mcx_comm_free.argtypes = [ctypes.c_void_p]
+    L.mcx_comm_free(comm)
 
 
 def test_run_module_single_gpu(golden, tmp_path):
