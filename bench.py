@@ -31,26 +31,96 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "round1", "summary_3gbp_r1d.json")
+# random 16-byte gathers from an 8 GiB table, four lanes per 64-byte block: what the chip's L2 / fabric sustains in
+# requests per second (tools/ubench_gather.hip, profiles/round1/ubench_gather_8GiB.txt: 47-48 G/s)
+GATHER_CEILING_G_PER_S = 47.5
+PMC_SUMMARY = {"human": os.path.join(ROOT, "profiles", "round2", "summary_human.json"),
+               "uniform": os.path.join(ROOT, "profiles", "round2", "summary_uniform.json")}
+STAGE_KERNEL = {"ms_encode": "k_pack_reads", "ms_seed": "k_seed", "ms_cluster": "k_cluster", "ms_rescue": "k_rescue", "ms_build": "k_build",
+                "ms_finish": "k_finish"}  # stages that are one kernel (ms_dp is six kernels on side streams)
 
 
 def pmc_profile(args):
-    """What the committed rocprofv3 --pmc passes of this same command measured for one k_seed launch
-    (counters cannot be read from inside the run): HBM bytes (FETCH_SIZE + WRITE_SIZE) and L2
-    requests (TCC_HIT + TCC_MISS).  Only returned when the workload is the one those passes profiled."""
-    if (args.genome_mbp, args.batch_pairs, args.rlen, args.alg) != (3100.0, 4_000_000, 150, "ksw2"):
+    """What the committed rocprofv3 --pmc passes of this same command measured per launch (counters cannot be read from
+    inside the run): HBM bytes (FETCH_SIZE + WRITE_SIZE) and L2 requests (TCC_HIT + TCC_MISS) per kernel.  Only returned
+    when the workload is the one those passes profiled (scripts/collect_profile.sh runs bench.py with its defaults)."""
+    if (args.genome_mbp, args.batch_pairs, args.rlen, args.alg, args.sub, args.ins, args.dele) != (3100.0, 4_000_000, 150, "ksw2", 0.005, 0.001, 0.001):
         return None
+    path = PMC_SUMMARY[args.genome]
     try:
-        with open(PMC_SUMMARY) as fh:
+        with open(path) as fh:
             s = json.load(fh)
-        t, p = s["hbm_traffic"]["k_seed"], s["pmc"]["k_seed"]
-        per_kernel = {k: int(v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]) for k, v in s["hbm_traffic"].items()
-                      if k in ("k_pack_reads", "k_seed", "k_cluster", "k_build", "k_finish")}
-        return {"per_kernel": per_kernel, "traffic": int(t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"]),
-                "l2_requests": int(p["TCC_HIT_sum"]["full_batch_mean"] + p["TCC_MISS_sum"]["full_batch_mean"]),
-                "wait_frac": round(p["SQ_WAIT_ANY"]["full_batch_mean"] / p["SQ_WAVE_CYCLES"]["full_batch_mean"], 3)}
+        out = {}
+        for k, v in s["hbm_traffic"].items():
+            e = {"traffic": int(v.get("hbm_read_bytes_per_launch", 0) + v.get("hbm_write_bytes_per_launch", 0))}
+            p = s["pmc"].get(k, {})
+            if "TCC_HIT_sum" in p and "TCC_MISS_sum" in p:
+                e["l2_requests"] = int(p["TCC_HIT_sum"]["full_batch_mean"] + p["TCC_MISS_sum"]["full_batch_mean"])
+            if "SQ_WAIT_ANY" in p and "SQ_WAVE_CYCLES" in p and p["SQ_WAVE_CYCLES"]["full_batch_mean"] > 0:
+                e["wait_frac"] = round(p["SQ_WAIT_ANY"]["full_batch_mean"] / p["SQ_WAVE_CYCLES"]["full_batch_mean"], 3)
+            out[k] = e
+        return {"kernels": out, "file": os.path.relpath(path, ROOT)}
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None
+
+
+def essential_bytes(kernel, d, args):
+    """Bytes per launch a kernel cannot avoid moving, from the run's own counters: what `frac` falls back
+    on when no PMC pass of this workload is committed, and the yardstick beside the measured traffic when one is."""
+    reads, steps = max(d["reads"], 1), max(args.steps, 1)
+    h = d["sa_hits"] / reads                                # seed hits per read
+    packed = 4.0 * ((args.rlen + 15) // 16 + (args.rlen + 31) // 32 + 2)  # 2-bit words + N masks of a read
+    per_read = {
+        "k_pack_reads": args.rlen + packed,
+        # packed read in; per 64-byte index block touched; per hit a suffix-array entry and the hit record out;
+        # the direct comparison reads the 2-bit genome under the seed (E bases / 4)
+        "k_seed": packed + 64.0 * d["fm_blocks"] / reads + (8 + 16) * h + d["fm_ext_steps"] / reads / 4.0,
+        "k_cluster": 16.0 * h + 32.0,                       # hits in, a candidate out
+        "k_build": 16.0 * h + 32.0 + 16.0 * (2 * h + 1) + 2 * args.rlen / 4.0,   # hits + candidate in, fragments out, gap bases compared
+        "k_finish": 32.0 + 16.0 * (2 * h + 1) + 2 * args.rlen / 4.0 + 64.0 + 8.0,  # candidate + fragments in, columns compared, record + CIGAR out
+        "k_rescue": 0.0,
+    }.get(kernel, 0.0)
+    return per_read * reads / steps
+
+
+def roofline(args, d, reads_per_s):
+    """`frac` = measured HBM bytes of the longest launch / its live duration / the HBM peak: at most 1 by construction.
+    The reference's own walk priced at our launch time (SURVEY 8d's figure, which can exceed 1 because the kernel does not
+    do that walk) is kept as `speed_of_light_equiv`; `request_rate` sets the L2 request rate of the gather-bound kernels
+    against what random 16-byte gathers reach on this chip."""
+    steps = max(args.steps, 1)
+    prof = pmc_profile(args)
+    ms = {STAGE_KERNEL[k]: d[k] / steps for k in STAGE_KERNEL if d.get(k, 0) > 0}
+    longest = max(ms, key=ms.get)
+    kern = prof["kernels"] if prof else {}
+    traffic = kern.get(longest, {}).get("traffic")
+    ess = essential_bytes(longest, d, args)
+    moved = traffic if traffic else ess
+    achieved = moved / (ms[longest] * 1e-3) / 1e9
+    seed_bytes = 64.0 * 1.107 * d["fm_ext_steps"] + float(d["reads"]) * args.rlen
+    seed_ms = d["ms_seed"] / steps
+    r = {"bound": "hbm", "kernel": longest, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+         "traffic_unit": None if not traffic else f"HBM bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, {prof['file']})",
+         "avg_launch_ms": round(ms[longest], 3),
+         "basis": "measured HBM bytes of the launch (committed PMC pass of this command) over the live launch time" if traffic else
+                  "no PMC pass of this workload is committed: the kernel's essential bytes (DESIGN.md §3) over the live launch time",
+         "algorithmic_bytes_per_launch": round(ess), "algorithmic_frac": round(ess / (ms[longest] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+         "per_kernel": {k: {"ms": round(ms[k], 3), "hbm_gbs": None if k not in kern else round(kern[k]["traffic"] / (ms[k] * 1e-3) / 1e9, 1),
+                            "frac_of_peak": None if k not in kern else round(kern[k]["traffic"] / (ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+                            "bytes_per_read": None if k not in kern else round(kern[k]["traffic"] / (d["reads"] / steps), 1),
+                            "essential_bytes_per_read": round(essential_bytes(k, d, args) / (d["reads"] / steps), 1)} for k in ms},
+         "request_rate": {k: {"l2_requests_per_launch": kern[k]["l2_requests"], "g_per_s": round(kern[k]["l2_requests"] / (ms[k] * 1e-3) / 1e9, 1),
+                              "ceiling_g_per_s": GATHER_CEILING_G_PER_S, "frac": round(kern[k]["l2_requests"] / (ms[k] * 1e-3) / 1e9 / GATHER_CEILING_G_PER_S, 3),
+                              "requests_per_read": round(kern[k]["l2_requests"] / (d["reads"] / steps), 2), "waves_waiting_frac": kern[k].get("wait_frac")}
+                          for k in ms if k in kern and "l2_requests" in kern[k]},
+         "speed_of_light_equiv": {"kernel": "k_seed", "bytes_per_read": round(seed_bytes / max(d["reads"], 1), 1),
+                                  "gbs": round(seed_bytes / steps / (seed_ms * 1e-3) / 1e9, 1) if seed_ms > 0 else None,
+                                  "ratio_to_peak": round(seed_bytes / steps / (seed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3) if seed_ms > 0 else None,
+                                  "note": "SURVEY 8d's seeding bytes (64*1.107*E + rlen per read: the reference's FM walk) over our launch time; not a utilisation — "
+                                          "the kernel reaches the same seeds through a K-mer jump table and direct genome comparison"},
+         "path": path_roofline(d, args, reads_per_s)}
+    return r
 
 
 def path_roofline(d, args, reads_per_s):
@@ -58,8 +128,93 @@ def path_roofline(d, args, reads_per_s):
     e, h = d["fm_ext_steps"] / reads, d["sa_hits"] / reads
     b_read = 64.0 * (1.107 * e + 31.0 * h) + 8.0 * h + args.rlen + args.rlen / 4.0
     gbs = reads_per_s * b_read / 1e9
-    return {"bytes_per_read": round(b_read, 1), "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "bound_reads_per_s": round(HBM_PEAK_GBS * 1e9 / b_read, 1)}
+    return {"bytes_per_read": round(b_read, 1), "equiv_gbs": round(gbs, 1), "ratio_to_peak": round(gbs / HBM_PEAK_GBS, 4),
+            "bound_reads_per_s": round(HBM_PEAK_GBS * 1e9 / b_read, 1),
+            "note": "SURVEY 8d's whole-path bytes of the reference's algorithm (B_read) at our rate: a speed-of-light comparison, not a utilisation"}
+
+
+def pcie_inclusive(args, mapper, batches, reads_per_step, dist, dev):
+    """The same steps with the device boundary the drop-in has: reads in pinned host memory in, records in pinned host
+    memory out (mcx_map_batch's successor with overlapped copies, Mapper.map_stream)."""
+    k = min(args.pcie_steps, len(batches))
+    host = [b.cpu().pin_memory() for b in batches[:k]]
+    off = (torch.arange(reads_per_step + 1, dtype=torch.int64) * args.rlen).to(torch.uint32).pin_memory()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_bytes = mapper.map_stream([h.data_ptr() for h in host], off.data_ptr(), reads_per_step, True)
+    dt = time.perf_counter() - t0
+    if dist:
+        from mapcaller_amd import dist as mdist_
+        dt = mdist_.max_over_ranks(dt, dev)
+    world = dist.get_world_size() if dist else 1
+    return {"value": round(k * reads_per_step * world / dt, 1), "unit": "reads/s", "steps": k, "ms_per_step": round(1000 * dt / k, 3),
+            "h2d_bytes_per_read": round(n_bytes[0] / (k * reads_per_step), 1), "d2h_bytes_per_read": round(n_bytes[1] / (k * reads_per_step), 1),
+            "note": "ASCII reads + offsets from pinned host memory, alignment records + CIGAR pool back to pinned host memory; "
+                    "copies of batch i+1 / i-1 overlap the kernels of batch i on separate HIP streams"}
+
+
+def vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, n_steps, d, dist, dev, rank, world):
+    from mapcaller_amd import api, dist as mdist
+    G = index.genome_size
+    # this leg keeps ten planes of the genome (124 GB at 3.1 Gbp) and per-read alignment detail in HBM:
+    # the timed region's context and all but one batch make room, the batch is mapped in slices
+    last = batches[n_steps - 1]
+    del batches[:]
+    mapper.close()
+    slice_reads = min(reads_per_step, 2_000_000)
+    mapper = api.Mapper(index, alg=args.alg, max_read_len=max(256, args.rlen), max_batch_reads=slice_reads)
+    planes = torch.zeros((10, G), dtype=torch.int32, device=dev)
+    mapper.profile_attach(planes.data_ptr())
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for lo in range(0, reads_per_step, slice_reads):
+        n = min(slice_reads, reads_per_step - lo)
+        mapper.map_batch_dev(last.data_ptr() + lo * args.rlen, off.data_ptr(), n, True, d_aln.data_ptr(), d_cig.data_ptr())
+    torch.cuda.synchronize()
+    t_acc = time.perf_counter() - t1
+    sparse = mapper.profile_sparse_raw(shard=world > 1)
+    if dist:
+        dist.barrier()
+    t2 = time.perf_counter()
+    # (every rank accumulated a run of its own here, so the readCount planes are summed too)
+    planes, merged = mdist.reduce_profile(planes, sparse, root=0, shared_read_count=False)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t_red = time.perf_counter() - t2
+    tot = mdist.sum_over_ranks([d["pairs"], d["pair_dist_sum"], d["pair_len_sum"]], dev)
+    gb = planes.numel() * 4 / 1e9
+    vcf = {"profile_batch_ms": round(1000 * t_acc, 2), "reduce_ms": round(1000 * t_red, 2), "reduce_gb": round(gb, 2),
+           "reduce_gbs_into_root": None if world == 1 else round(gb * (world - 1) / max(t_red, 1e-9), 1),
+           "reduce": "none (one GPU)" if world == 1 else f"RCCL reduce of {world} x ten u32 planes onto rank 0 in 1-GiB pieces",
+           "sparse_records": len(merged)}
+    if rank == 0:  # VariantCalling() runs once, on the reduced profile
+        mapper.profile_finalize(planes.data_ptr())
+        vcf["covered_positions"] = int(((planes[0] | planes[1] | planes[2] | planes[3]) > 0).sum().item())
+        with tempfile.TemporaryDirectory() as tmp:
+            vs = index.call_variants(planes.data_ptr(), merged, tot[0], tot[1], tot[2], os.path.join(tmp, "bench.vcf"),
+                                     ref_name="synthetic", cmdline="bench.py")
+        # both scans stream the planes once: 16 B (k_vc_depth) and 20 B + 2-bit base + depth word (k_vc_scan) per position
+        vcf["call_variants"] = {"ms_total": round(vs["ms_total"], 2), "k_vc_depth_ms": round(vs["ms_depth"], 3),
+                                "k_vc_scan_ms": round(vs["ms_scan"], 3), "records": vs["n_records"], "snv": vs["n_snv"],
+                                "k_vc_depth_gbs": round(16.0 * G / max(vs["ms_depth"], 1e-6) / 1e6, 1),
+                                "k_vc_scan_gbs": round(20.29 * G / max(vs["ms_scan"], 1e-6) / 1e6, 1)}
+    mapper.close()
+    return vcf
+
+
+def other_genome(args):
+    """Two steps against the other kind of synthetic genome, as a child process once this one has let go of the GPU's memory."""
+    kind = "uniform" if args.genome == "human" else "human"
+    cmd = [sys.executable, os.path.abspath(__file__), "--genome", kind, "--second-genome", "0", "--steps", "2", "--warmup", "1", "--cpu-pairs", "0",
+           "--vcf-reduce", "0", "--pcie-steps", "0", "--genome-mbp", str(args.genome_mbp), "--contigs", str(args.contigs), "--batch-pairs", str(args.batch_pairs),
+           "--rlen", str(args.rlen), "--sub", str(args.sub), "--ins", str(args.ins), "--dele", str(args.dele), "--alg", args.alg, "--full-sa", str(args.full_sa)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=900)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    o = json.loads(line)
+    return {"genome": kind, "value": o["value"], "unit": o["unit"], "steps": o["steps"], "ms_per_step": o["ms_per_step"], "workload": o["config"]["workload"],
+            "per_read": o["per_read"], "stage_ms_per_step": o["stage_ms_per_step"], "tier1_pairs": o["tier1_pairs"],
+            "roofline": {k: o["roofline"][k] for k in ("kernel", "achieved", "frac", "traffic", "basis")}}
 
 
 def parse():
@@ -78,33 +233,144 @@ def parse():
     ap.add_argument("--full-sa", type=int, default=1, help="keep every suffix-array entry in HBM")
     ap.add_argument("--cpu-pairs", type=int, default=-1,
                     help="pairs of the CPU-baseline sample (0 = skip, -1 = about 20 s of work for this host's core count)")
-    ap.add_argument("--repeats", type=int, default=2000, help="planted dispersed repeat families")
+    ap.add_argument("--repeats", type=int, default=2000, help="--genome uniform: planted dispersed repeat families")
+    ap.add_argument("--genome", default="human", choices=["human", "uniform"],
+                    help="repeat content of the synthetic genome: a human-like landscape (default) or round 1's nearly repeat-free one")
+    ap.add_argument("--second-genome", type=int, default=1,
+                    help="1: after the main run, map 2 steps against the other kind of genome as well and report them under `other_genome`")
+    ap.add_argument("--pcie-steps", type=int, default=3, help="steps of the host-buffer leg (value_pcie_inclusive); 0 = skip")
     ap.add_argument("--vcf-reduce", type=int, default=1,
                     help="after the timed region: accumulate the -vcf alignment profile of one batch and sum it over the "
                          "ranks with RCCL (1 = yes, 0 = no, -1 = only when more than one GPU)")
     return ap.parse_args()
 
 
+def _plant(codes, g, device, consensus, fam, src_off, seg_len, dst, div, chunk=1 << 26):
+    """Writes copies of family consensus sequences into the genome: copy i = consensus[fam[i]][src_off[i] : +seg_len[i]] at
+    dst[i], every base substituted with probability div[i] (each copy mutates on its own)."""
+    n = seg_len.numel()
+    starts = torch.cumsum(seg_len, 0) - seg_len
+    total = int(seg_len.sum())
+    lo_seg = 0
+    while lo_seg < n:  # whole copies per chunk
+        hi_seg = int(torch.searchsorted(starts, starts[lo_seg] + chunk).item())
+        hi_seg = max(hi_seg, lo_seg + 1)
+        sl = slice(lo_seg, hi_seg)
+        ln = seg_len[sl]
+        m = int(ln.sum())
+        seg = torch.repeat_interleave(torch.arange(hi_seg - lo_seg, device=device), ln)
+        within = torch.arange(m, device=device) - (starts[sl] - starts[lo_seg])[seg]
+        val = consensus[fam[sl][seg], src_off[sl][seg] + within]
+        mut = torch.rand(m, generator=g, device=device) < div[sl][seg]
+        val = torch.where(mut, (val + torch.randint(1, 4, (m,), generator=g, device=device, dtype=torch.uint8)) % 4, val)
+        codes[dst[sl][seg] + within] = val
+        lo_seg = hi_seg
+    return total
+
+
 def make_genome(args, device, seed):
-    """Uniform random contigs (human-like length spread) with planted 1 kb repeats, in HBM."""
+    """The synthetic stand-in for GRCh38 (which cannot be fetched offline), in HBM: contigs with a human-like length
+    spread.  --genome human (default): a repeat landscape like the human one over a uniform random background —
+    one short interspersed family at very high copy number (Alu-like), long interspersed families as truncated copies
+    (L1-like), families with copy numbers from 3 to several hundred, segmental duplications, tandem repeats and
+    low-complexity runs; copies diverge from their consensus by 1-15 %.  --genome uniform: round 1's genome (uniform
+    random with 2000 x4 planted 1-kb repeats)."""
     g = torch.Generator(device=device).manual_seed(seed)
     total = int(args.genome_mbp * 1e6)
     w = torch.linspace(2.2, 0.5, args.contigs)
     lens = (w / w.sum() * total).long()
     lens = (lens // 4 * 4).clamp_(min=10000)
-    codes = torch.randint(0, 4, (int(lens.sum()),), generator=g, device=device, dtype=torch.uint8)
-    if args.repeats:
-        rl = 1000
-        unit_pos = torch.randint(0, codes.numel() - rl, (args.repeats,), generator=g, device=device)
-        dst = torch.randint(0, codes.numel() - rl, (args.repeats, 3), generator=g, device=device)
-        ar = torch.arange(rl, device=device)
-        units = codes[(unit_pos[:, None] + ar[None, :])]
-        for k in range(3):  # three extra copies of every family, ~1 % diverged
-            u = units.clone()
-            m = torch.rand(u.shape, generator=g, device=device) < 0.01
-            u = torch.where(m, (u + torch.randint(1, 4, u.shape, generator=g, device=device, dtype=torch.uint8)) % 4, u)
-            codes[(dst[:, k][:, None] + ar[None, :]).reshape(-1)] = u.reshape(-1)
-    return codes, [int(x) for x in lens]
+    G = int(lens.sum())
+    codes = torch.randint(0, 4, (G,), generator=g, device=device, dtype=torch.uint8)
+    if args.genome == "uniform":
+        if args.repeats:
+            rl = 1000
+            unit_pos = torch.randint(0, codes.numel() - rl, (args.repeats,), generator=g, device=device)
+            dst = torch.randint(0, codes.numel() - rl, (args.repeats, 3), generator=g, device=device)
+            ar = torch.arange(rl, device=device)
+            units = codes[(unit_pos[:, None] + ar[None, :])]
+            for k in range(3):  # three extra copies of every family, ~1 % diverged
+                u = units.clone()
+                m = torch.rand(u.shape, generator=g, device=device) < 0.01
+                u = torch.where(m, (u + torch.randint(1, 4, u.shape, generator=g, device=device, dtype=torch.uint8)) % 4, u)
+                codes[(dst[:, k][:, None] + ar[None, :]).reshape(-1)] = u.reshape(-1)
+        return codes, [int(x) for x in lens], f"uniform random, {args.repeats} x4 1-kb repeat families at 1 % divergence"
+
+    def rnd(n):
+        return torch.rand(n, generator=g, device=device)
+
+    def place(consensus, fam, src_off, seg_len, div):
+        dst = (rnd(seg_len.numel()) * (G - int(seg_len.max()) - 1)).long()
+        return _plant(codes, g, device, consensus, fam, src_off, seg_len, dst, div)
+
+    planted = {}
+    # (a) segmental duplications first (later, younger repeats land inside them too): 10-50 kb blocks copied 1-4 times at 1-3 %
+    n = max(1, int(0.05 * G / 30_000 / 2.5))
+    blk = (10_000 + rnd(n) * 40_000).long()
+    src = (rnd(n) * (G - 60_000)).long()
+    copies = 1 + (rnd(n) * 4).long()
+    seg = torch.repeat_interleave(torch.arange(n, device=device), copies)
+    seg_len = blk[seg]
+    dst = (rnd(seg.numel()) * (G - 60_000)).long()
+    starts = torch.cumsum(seg_len, 0) - seg_len
+    tot = 0
+    for lo in range(0, seg.numel(), 256):  # sources are genome ranges, not a consensus table: chunks of copies
+        sl = slice(lo, min(lo + 256, seg.numel()))
+        ln = seg_len[sl]
+        m = int(ln.sum())
+        s2 = torch.repeat_interleave(torch.arange(ln.numel(), device=device), ln)
+        within = torch.arange(m, device=device) - (starts[sl] - starts[lo])[s2]
+        val = codes[src[seg[sl]][s2] + within]
+        mut = rnd(m) < (0.01 + 0.02 * rnd(ln.numel()))[s2]
+        val = torch.where(mut, (val + torch.randint(1, 4, (m,), generator=g, device=device, dtype=torch.uint8)) % 4, val)
+        codes[dst[sl][s2] + within] = val
+        tot += m
+    planted["segmental duplications, 10-50 kb x1-4 at 1-3 %"] = tot
+    # (b) families over a spectrum of copy numbers: 3 .. 300 copies (log-uniform), 1-3 kb, 2-10 % from the consensus
+    nf = max(1, int(0.10 * G / (2000 * 64)))  # (a log-uniform 3..300 averages 64 copies)
+    cons = torch.randint(0, 4, (nf, 3000), generator=g, device=device, dtype=torch.uint8)
+    flen = (1000 + rnd(nf) * 2000).long()
+    ncopy = torch.exp(rnd(nf) * (torch.log(torch.tensor(300.0)) - torch.log(torch.tensor(3.0))) + torch.log(torch.tensor(3.0))).long()
+    fam = torch.repeat_interleave(torch.arange(nf, device=device), ncopy)
+    planted["families of 3-300 copies, 1-3 kb at 2-10 %"] = place(cons, fam, torch.zeros_like(fam), flen[fam], 0.02 + 0.08 * rnd(fam.numel()))
+    # (c) long interspersed families (L1-like): 40 consensus sequences of 6 kb, truncated copies (3' ends), 2-12 %
+    nf = 40
+    cons = torch.randint(0, 4, (nf, 6000), generator=g, device=device, dtype=torch.uint8)
+    n = int(0.15 * G / 1500)
+    fam = (rnd(n) * nf).long()
+    seg_len = (300 + (rnd(n) ** 3) * 5700).long()  # most copies are short 3' fragments
+    planted["40 long families (6 kb), truncated copies at 2-12 %"] = place(cons, fam, 6000 - seg_len, seg_len, 0.02 + 0.10 * rnd(n))
+    # (d) one short family at very high copy number (Alu-like): 300 bp, 8-15 % from the consensus, poly-A tail
+    cons = torch.randint(0, 4, (1, 300), generator=g, device=device, dtype=torch.uint8)
+    cons[0, 280:] = 0
+    n = int(0.10 * G / 300)
+    fam = torch.zeros(n, dtype=torch.long, device=device)
+    planted["one 300-bp family, %d copies at 8-15 %%" % n] = place(cons, fam, torch.zeros_like(fam), torch.full((n,), 300, device=device, dtype=torch.long),
+                                                                   0.08 + 0.07 * rnd(n))
+    # (e) tandem repeats and low complexity: units of 1-6 bp (microsatellites) and 10-60 bp (minisatellites), runs of 30-600 bp, 0-5 % impure
+    n = int(0.03 * G / 150)
+    unit = torch.where(rnd(n) < 0.7, 1 + (rnd(n) * 6).long(), 10 + (rnd(n) * 50).long())
+    run = (30 + rnd(n) ** 2 * 570).long()
+    ucons = torch.randint(0, 4, (n, 60), generator=g, device=device, dtype=torch.uint8)
+    dst = (rnd(n) * (G - 700)).long()
+    starts = torch.cumsum(run, 0) - run
+    tot = 0
+    for lo in range(0, n, 1 << 18):
+        sl = slice(lo, min(lo + (1 << 18), n))
+        ln = run[sl]
+        m = int(ln.sum())
+        s2 = torch.repeat_interleave(torch.arange(ln.numel(), device=device), ln)
+        within = torch.arange(m, device=device) - (starts[sl] - starts[lo])[s2]
+        val = ucons[sl][s2, within % unit[sl][s2]]
+        mut = rnd(m) < (0.05 * rnd(ln.numel()))[s2]
+        val = torch.where(mut, (val + torch.randint(1, 4, (m,), generator=g, device=device, dtype=torch.uint8)) % 4, val)
+        codes[dst[sl][s2] + within] = val
+        tot += m
+    planted["tandem repeats / low complexity"] = tot
+    frac = sum(planted.values()) / G
+    note = "human-like repeat landscape, %.0f %% of the bases planted as repeats: " % (100 * frac) + "; ".join(
+        "%s (%.1f %%)" % (k, 100 * v / G) for k, v in planted.items())
+    return codes, [int(x) for x in lens], note
 
 
 def make_reads(codes, lens, n_pairs, rlen, seed, device, sub=0.005, ins=0.001, dele=0.001):
@@ -175,20 +441,85 @@ def cpu_baseline(args, index, bases_sample):
         return out
 
 
+def launch_ranks(args):
+    """--gpus N from a plain `python bench.py`: N ranks as fresh child processes (torch.distributed.run), started
+    before this process makes any GPU call; the children carry WORLD_SIZE and run main() below."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    have = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+    if have < args.gpus and not os.environ.get("MCX_BENCH_SHARE_GPU"):
+        sys.exit(f"bench.py --gpus {args.gpus}: this node shows {have} GPU(s)")
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd).returncode)
+
+
+class Trajectory:
+    """The run's insert-size state across the ranks (N > 1): every step is one round of the input stream — rank r maps
+    batch N*step + r — and the ranks walk ONE avgDist trajectory over the round (ReadMapping.cpp:462, :538-539), as
+    mcx_map_files_ex does for real inputs: per-chunk pair sums all-gathered over RCCL, pairs whose decision depends on the
+    exact estimate re-run, until no rank re-ran any."""
+
+    def __init__(self, dist, dev, world, rank, n_chunks):
+        self.dist, self.dev, self.world, self.rank, self.nc = dist, dev, world, rank, n_chunks
+        self.state = [1000, 0, 0]
+        self.reads = 0
+        self.cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")  # (gloo: several ranks sharing one GPU in tests)
+        self.msg = torch.zeros(1 + 2 * n_chunks, dtype=torch.int64, device=self.cdev)
+        self.all = torch.zeros((world, 1 + 2 * n_chunks), dtype=torch.int64, device=self.cdev)
+        self.exchanges = 0
+
+    def step(self, mapper, d_bases, d_off, n_reads, d_aln, d_cig):
+        from mapcaller_amd import api
+        est0 = int(float(self.state[0]) * 1.5)
+        mapper.batch_begin(d_bases, d_off, n_reads, True, est0, self.reads + self.rank * n_reads, d_aln, d_cig)
+        n_redo = -1
+        for it in range(64):
+            ok, ds, _ = mapper.batch_sums()
+            self.msg[0] = n_redo
+            self.msg[1:1 + self.nc] = torch.from_numpy(ok.astype("int64")).to(self.cdev)
+            self.msg[1 + self.nc:] = torch.from_numpy(ds.astype("int64")).to(self.cdev)
+            self.dist.all_gather(list(self.all.unbind(0)), self.msg)
+            self.exchanges += 1
+            h = self.all.cpu().numpy()
+            st = list(self.state)
+            mine = None
+            for r in range(self.world):
+                e = api.avg_walk(st, h[r, 1:1 + self.nc], h[r, 1 + self.nc:], want_est=(r == self.rank))
+                if r == self.rank:
+                    mine = e
+            if it > 0 and not h[:, 0].any():
+                break
+            n_redo = mapper.batch_replay(mine)
+        else:
+            raise RuntimeError("avgDist replay did not converge")
+        self.state = st
+        self.reads += self.world * n_reads
+        mapper.batch_end()
+
+
 def main():
     args = parse()
+    launch_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
+    n_dev = torch.cuda.device_count()
+    local = local % n_dev if os.environ.get("MCX_BENCH_SHARE_GPU") else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1 or os.environ.get("MCX_FORCE_DIST"):
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("MCX_BENCH_BACKEND", "nccl")  # "gloo" lets test ranks share one GPU (RCCL refuses that)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     from mapcaller_amd import api
     if not os.path.exists(api.LIB_PATH):  # a checkout without the built artefacts: build them (never a CPU fallback)
         if rank == 0:
@@ -198,7 +529,7 @@ def main():
             dist.barrier()
 
     # ---- set-up (not timed): genome, index, reads ------------------------------------------------
-    codes, lens = make_genome(args, dev, seed=1234)
+    codes, lens, genome_note = make_genome(args, dev, seed=1234)
     t0 = time.perf_counter()
     index = api.Index.from_codes(codes.data_ptr(), lens, device=local, full_sa=bool(args.full_sa))
     t_index = time.perf_counter() - t0
@@ -218,9 +549,13 @@ def main():
     d_aln = torch.empty(reads_per_step * 64, dtype=torch.uint8, device=dev)
     d_cig = torch.empty(reads_per_step * api.CIGAR_STRIDE, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
+    traj = Trajectory(dist, dev, world, rank, (args.batch_pairs + 99) // 100) if world > 1 else None
 
     def step(i):
-        mapper.map_batch_dev(batches[i].data_ptr(), off.data_ptr(), reads_per_step, True, d_aln.data_ptr(), d_cig.data_ptr())
+        if traj:
+            traj.step(mapper, batches[i].data_ptr(), off.data_ptr(), reads_per_step, d_aln.data_ptr(), d_cig.data_ptr())
+        else:
+            mapper.map_batch_dev(batches[i].data_ptr(), off.data_ptr(), reads_per_step, True, d_aln.data_ptr(), d_cig.data_ptr())
 
     for i in range(args.warmup):
         step(i)
@@ -241,100 +576,47 @@ def main():
     after = mapper.stats.as_dict()
     d = {k: after[k] - before[k] for k in after}
 
-    # ---- the one exchange of a -vcf run (not timed): profile of one batch, RCCL sum over the ranks -----
+    # ---- the same batches from pinned host memory, records back to pinned host memory (not `value`) ----------
+    pcie = None
+    if args.pcie_steps > 0:
+        try:
+            pcie = pcie_inclusive(args, mapper, batches, reads_per_step, dist, dev)
+        except Exception as e:
+            pcie = {"error": str(e)[:300]}
+
+    # ---- the bulk exchange of a -vcf run (not timed): profile of one batch, RCCL reduce over the ranks ------
     vcf = None
     do_vcf = args.vcf_reduce == 1 or (args.vcf_reduce < 0 and world > 1)
     if do_vcf:
         try:
-            from mapcaller_amd import dist as mdist
-            G = index.genome_size
-            # this leg keeps ten planes of the genome (124 GB at 3.1 Gbp) and per-read alignment detail in HBM:
-            # the timed region's context and all but one batch make room, the batch is mapped in slices
-            last = batches[n_steps - 1]
-            del batches[:]
-            mapper.close()
-            slice_reads = min(reads_per_step, 2_000_000)
-            mapper = api.Mapper(index, alg=args.alg, max_read_len=max(256, args.rlen), max_batch_reads=slice_reads)
-            planes = torch.zeros((10, G), dtype=torch.int32, device=dev)
-            mapper.profile_attach(planes.data_ptr())
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for lo in range(0, reads_per_step, slice_reads):
-                n = min(slice_reads, reads_per_step - lo)
-                mapper.map_batch_dev(last.data_ptr() + lo * args.rlen, off.data_ptr(), n, True, d_aln.data_ptr(), d_cig.data_ptr())
-            torch.cuda.synchronize()
-            t_acc = time.perf_counter() - t1
-            sparse = mapper.profile_sparse_raw()
-            t2 = time.perf_counter()
-            planes, merged = mdist.reduce_profile(planes, sparse)
-            torch.cuda.synchronize()
-            t_red = time.perf_counter() - t2
-            mapper.profile_finalize(planes.data_ptr())
-            tot = mdist.sum_over_ranks([d["pairs"], d["pair_dist_sum"], d["pair_len_sum"]], dev)
-            vcf = {"profile_batch_ms": round(1000 * t_acc, 2), "allreduce_ms": round(1000 * t_red, 2),
-                   "allreduce_gb": round(planes.numel() * 4 / 1e9, 2), "sparse_records": len(merged),
-                   "covered_positions": int(((planes[0] | planes[1] | planes[2] | planes[3]) > 0).sum().item())}
-            if rank == 0:  # VariantCalling() runs once, on the reduced profile
-                with tempfile.TemporaryDirectory() as tmp:
-                    vs = index.call_variants(planes.data_ptr(), merged, tot[0], tot[1], tot[2], os.path.join(tmp, "bench.vcf"),
-                                             ref_name="synthetic", cmdline="bench.py")
-                # both scans stream the planes once: 16 B (k_vc_depth) and 20 B + 2-bit base + depth word (k_vc_scan) per position
-                vcf["call_variants"] = {"ms_total": round(vs["ms_total"], 2), "k_vc_depth_ms": round(vs["ms_depth"], 3),
-                                        "k_vc_scan_ms": round(vs["ms_scan"], 3), "records": vs["n_records"], "snv": vs["n_snv"],
-                                        "k_vc_depth_gbs": round(16.0 * G / max(vs["ms_depth"], 1e-6) / 1e6, 1),
-                                        "k_vc_scan_gbs": round(20.29 * G / max(vs["ms_scan"], 1e-6) / 1e6, 1)}
+            vcf = vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, n_steps, d, dist, dev, rank, world)
+            mapper = None
         except Exception as e:  # never lose the bench line to the optional section
             vcf = {"error": str(e)[:300]}
 
     if rank == 0:
         total_reads = reads_per_step * args.steps * world
-        # dominant kernel: k_seed.  Algorithmic bytes per launch = SURVEY.md §8d's seeding term,
-        # 64 * 1.107 * E + rlen per read, with E (FM extension steps) counted by the kernel.  The
-        # blocks the kernel really fetches are fewer (k-mer jump table) and reported beside it.
-        seed_bytes = 64.0 * 1.107 * d["fm_ext_steps"] + float(d["reads"]) * args.rlen
-        prof = pmc_profile(args) or {}
-        seed_ms = d["ms_seed"] / max(args.steps, 1)
-        achieved = seed_bytes / args.steps / (seed_ms * 1e-3) / 1e9 if seed_ms > 0 else 0.0
         out = {
             "metric": "reads/sec (150 bp PE vs GRCh38) at 1/2/4/8 MI355X; SAM CIGAR bit-exact",
             "value": round(total_reads / dt, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64/int8", "data": "synthetic",
-            "config": {"workload": f"synthetic GRCh38-sized genome, {args.genome_mbp:.0f} Mbp ({args.contigs} contigs, {args.repeats} x4 1-kb repeat families; GRCh38 itself is unavailable offline), "
+            "config": {"workload": f"synthetic GRCh38-sized genome, {args.genome_mbp:.0f} Mbp ({args.contigs} contigs, {genome_note}; GRCh38 itself is unavailable offline), "
                                    f"{args.batch_pairs} pairs x {args.rlen} bp PE per step per GPU (sub {args.sub}, ins {args.ins}, del {args.dele} per base), -alg {args.alg}",
                        "reads_per_step_per_gpu": reads_per_step, "full_sa_in_hbm": bool(args.full_sa), "index_build_s": round(t_index, 2),
-                       "index_hbm_gb": round(index.hbm_bytes / 1e9, 2)},
-            "roofline": {"bound": "hbm", "kernel": "k_seed", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": prof.get("traffic"),
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/round1/summary_3gbp_r1d.json)",
-                         "algorithmic_bytes_per_launch": round(seed_bytes / max(args.steps, 1)),
-                         "note": "achieved prices SURVEY 8d's seeding bytes (64*1.107*E + rlen per read: the reference's FM walk) at the measured "
-                                 "launch time; the kernel reaches the same seeds through a K-mer jump table and direct genome comparison, moves far "
-                                 "fewer bytes (traffic) and is bound by per-lane request rate, so frac can exceed 1 — it is a speed-of-light "
-                                 "comparison with a perfect HBM-bound walk, not an HBM utilisation",
-                         "algorithmic_bytes_per_read": round(seed_bytes / max(d["reads"], 1), 1), "avg_launch_ms": round(seed_ms, 3),
-                         # SURVEY 8d's own figure for the whole path: achieved = reads/s x B_read against the HBM peak,
-                         # B_read = 64 (1.107 E + 31 H) + 8 H + rlen + rlen/4 with E and H counted by the kernels
-                         "path": path_roofline(d, args, total_reads / dt / world),  # per GPU
-                         # the FM walk is what SURVEY 8d's roofline is about; by launch time another kernel may be longer
-                         "longest_launch": max((("k_seed", "ms_seed"), ("k_cluster", "ms_cluster"), ("k_build", "ms_build"), ("k_finish", "ms_finish")),
-                                               key=lambda kv: d[kv[1]])[0],
-                         "measured": None if not prof else {
-                             "hbm_gbs": round(prof["traffic"] / (seed_ms * 1e-3) / 1e9, 1), "l2_requests_per_launch": prof["l2_requests"],
-                             "l2_request_rate_g_per_s": round(prof["l2_requests"] / (seed_ms * 1e-3) / 1e9, 1), "waves_waiting_frac": prof["wait_frac"],
-                             "reading": "the launch moves less than a tenth of the walk's bytes; waves wait on dependent fetches two thirds of the time"}},
+                       "index_hbm_gb": round(index.hbm_bytes / 1e9, 2),
+                       "multi_gpu": None if world == 1 else f"one process per GPU, index replicated, rank r maps batch {world}*step + r; one avgDist trajectory over the "
+                                                            f"ranks' batches per step (all-gather of per-chunk sums over RCCL, {traj.exchanges} exchanges in "
+                                                            f"{n_steps} steps, inside the timed region)"},
+            "roofline": roofline(args, d, total_reads / dt / world),
             "per_read": {"fm_ext_steps": round(d["fm_ext_steps"] / max(d["reads"], 1), 2), "fm_blocks": round(d["fm_blocks"] / max(d["reads"], 1), 2),
                          "sa_hits": round(d["sa_hits"] / max(d["reads"], 1), 3), "dp_jobs": round(d["dp_jobs"] / max(d["reads"], 1), 4),
                          "mapped_frac": round(d["mapped"] / max(d["reads"], 1), 4)},
             "stage_ms_per_step": {k[3:]: round(d[k] / args.steps, 3) for k in d if k.startswith("ms_")},
-            # measured HBM bytes of one launch (committed PMC passes) over the live stage time: what each big kernel really draws from HBM
-            "hbm_utilisation": None if not prof else {
-                kern: {"gbs": round(prof["per_kernel"][kern] / (d[ms] / args.steps * 1e-3) / 1e9, 1),
-                       "frac_of_peak": round(prof["per_kernel"][kern] / (d[ms] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}
-                for kern, ms in (("k_pack_reads", "ms_encode"), ("k_seed", "ms_seed"), ("k_cluster", "ms_cluster"), ("k_build", "ms_build"), ("k_finish", "ms_finish"))
-                if kern in prof.get("per_kernel", {}) and d[ms] > 0},
-            "tier1_pairs": d["tier1_pairs"], "replayed_pairs": d["replayed_pairs"],
+            "tier1_pairs": d["tier1_pairs"], "replayed_pairs": d["replayed_pairs"], "halved_selections": d["halved_selections"],
         }
+        if pcie is not None:
+            out["value_pcie_inclusive"] = pcie
         if vcf is not None:
             out["vcf_reduce"] = vcf
         if sample is not None:
@@ -342,6 +624,17 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, index, sample)
             except Exception as e:  # the baseline must never take the bench line down
                 out["cpu_baseline"] = {"error": str(e)[:200]}
+        if args.second_genome and world == 1:
+            try:
+                if mapper is not None:
+                    mapper.close()
+                del batches[:]
+                index.close()
+                del d_aln, d_cig
+                torch.cuda.empty_cache()
+                out["other_genome"] = other_genome(args)
+            except Exception as e:
+                out["other_genome"] = {"error": str(e)[:200]}
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()

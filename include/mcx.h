@@ -94,10 +94,10 @@ typedef struct mcx_aln {
     int32_t mapq;      /* MAPQ */
     int32_t tlen;      /* TLEN */
     int32_t nm, as, xs;/* NM:i AS:i XS:i */
-    int32_t n_cigar;   /* CIGAR operations: len << 4 | op, M=0 I=1 D=2 S=4; the first MCX_CIGAR_STRIDE in this read's row of the cigar array */
+    int32_t n_cigar;   /* CIGAR operations: len << 4 | op, M=0 I=1 D=2 S=4 */
     int32_t fwd;       /* 0: SEQ/QUAL are printed reverse-complemented / reversed */
     int32_t has_mate;  /* RNEXT '=' */
-    int32_t cigar_ext; /* n_cigar > MCX_CIGAR_STRIDE: word offset of operation MCX_CIGAR_STRIDE.. in the pool of mcx_cigar_ext */
+    int32_t cigar_off; /* word offset of the read's first operation in the batch's CIGAR pool */
     int32_t pad;       /* 64-byte records */
 } mcx_aln;
 
@@ -111,10 +111,12 @@ typedef struct mcx_stats {
     int64_t tier1_pairs;    /* pairs re-run with the large capacities */
     int64_t replayed_pairs; /* pairs re-run because the avgDist trajectory moved past their validity interval */
     int64_t halved_selections; /* times a selection of pairs was mapped in two halves because a work list ran over */
+    int64_t fast_pairs;     /* pairs the fused per-pair kernel mapped from seeds to records (the rest took the general path) */
     double ms_encode /* k_pack_reads */, ms_seed, ms_sa, ms_cluster, ms_rescue, ms_build, ms_dp, ms_finish, ms_total;
+    double ms_fast;         /* k_pair_fast */
 } mcx_stats;
 
-#define MCX_CIGAR_STRIDE 32 /* words per read in the dense cigar array */
+#define MCX_CIGAR_STRIDE 32 /* the CIGAR pool of a batch holds n_reads * MCX_CIGAR_STRIDE words */
 
 /* Replaces the body of ReadMapping() for one batch (reference src/ReadMapping.cpp:416-646):
  * seeding, clustering, pairing, rescue, extension, scoring, flags/MAPQ/CIGAR.  d_bases: ASCII
@@ -122,17 +124,36 @@ typedef struct mcx_stats {
  * are fetched), d_off: n_reads+1 byte offsets (device), paired: mates interleaved.
  * avg_state[4] carries the reference's running insert-size estimate across batches
  * {avgDist, iTotalPairedNum, TotalPairedDistance, reads seen} (ReadMapping.cpp:20-21,:538-539);
- * initialise with mcx_avg_init.  Results (device): d_aln[n_reads], d_cigar[n_reads*MCX_CIGAR_STRIDE]. */
+ * initialise with mcx_avg_init.  Results (device): d_aln[n_reads] and the batch's CIGAR pool d_cigar
+ * (capacity n_reads * MCX_CIGAR_STRIDE words): the operations of read r are the n_cigar words from
+ * d_cigar[d_aln[r].cigar_off] on.  The pool is filled by wavefronts in no particular order (offsets differ
+ * from run to run, contents do not); mcx_cigar_words tells how many of its words the last batch took —
+ * all a copy to the host has to move. */
 void mcx_avg_init(int64_t avg_state[4]);
 int mcx_map_batch_dev(mcx_ctx *, const uint8_t *d_bases, const uint32_t *d_off, uint32_t n_reads, int paired,
                       int64_t avg_state[4], mcx_aln *d_aln, uint32_t *d_cigar, mcx_stats *stats);
-/* The few CIGARs with more than MCX_CIGAR_STRIDE operations (many indels in a long read) continue
- * in a pool that is valid until the context's next batch: words[mcx_aln.cigar_ext ..] hold operation
- * MCX_CIGAR_STRIDE and up.  on_device: return the device pointer instead of a host copy. */
-int mcx_cigar_ext(mcx_ctx *, int on_device, const uint32_t **words, uint64_t *n_words);
+int mcx_cigar_words(mcx_ctx *, uint32_t *n_words);
 /* same with host buffers (pinned staging inside) */
 int mcx_map_batch(mcx_ctx *, const uint8_t *bases, const uint32_t *off, uint32_t n_reads, int paired,
                   int64_t avg_state[4], mcx_aln *aln, uint32_t *cigar, mcx_stats *stats);
+
+/* ---- batches from host memory with the copies overlapped with the kernels -------------------------
+ * The device boundary of the drop-in: reads arrive in (pinned) host memory, records leave to (pinned)
+ * host memory.  Three batches are in flight, each in a slot of HBM of its own: one being copied in on a
+ * copy stream, one under the kernels, one being copied out on another copy stream.
+ *   mcx_stream_submit   starts the copy of a batch to HBM and returns at once
+ *   mcx_stream_map      maps the oldest submitted batch (like mcx_map_batch_dev: the host thread drives
+ *                       the kernels), then starts the copy of its records to aln / cigar
+ *   mcx_stream_collect  waits until the oldest mapped batch has arrived in host memory
+ * so the loop  submit(i+1); map(i); collect(i-1)  keeps PCIe busy in both directions under the kernels.
+ * mcx_stream_next / mcx_stream_mapped are mcx_stream_map in two halves for callers that map the batch
+ * in steps (mcx_batch_*): the first hands out the batch's place in HBM, the second starts the copy out.
+ * bytes_in / bytes_out (may be NULL): bytes moved over the boundary so far. */
+int mcx_stream_submit(mcx_ctx *, const uint8_t *bases, const uint32_t *off, uint32_t n_reads);
+int mcx_stream_map(mcx_ctx *, int paired, int64_t avg_state[4], mcx_aln *aln, uint32_t *cigar, mcx_stats *stats);
+int mcx_stream_collect(mcx_ctx *, uint64_t *bytes_in, uint64_t *bytes_out);
+int mcx_stream_next(mcx_ctx *, const uint8_t **d_bases, const uint32_t **d_off, uint32_t *n_reads, mcx_aln **d_aln, uint32_t **d_cigar);
+int mcx_stream_mapped(mcx_ctx *, mcx_aln *aln, uint32_t *cigar);
 
 /* ---- a batch in steps: runs whose batches are mapped by several GPUs ---------------------------
  * The reference re-estimates the insert size after every 200-read chunk (ReadMapping.cpp:462,

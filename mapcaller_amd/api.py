@@ -21,11 +21,12 @@ SYMBOLS = [
     "mcx_last_error", "mcx_device_count", "mcx_index_load", "mcx_index_build", "mcx_index_from_codes", "mcx_index_save", "mcx_index_free",
     "mcx_index_genome_size", "mcx_index_n_chr", "mcx_index_chr_name", "mcx_index_chr_len", "mcx_index_hbm_bytes",
     "mcx_opts_default", "mcx_ctx_create", "mcx_ctx_free", "mcx_bwt_search_batch", "mcx_extend_batch",
-    "mcx_avg_init", "mcx_map_batch_dev", "mcx_map_batch", "mcx_cigar_ext", "mcx_map_files", "mcx_map_files_ex", "mcx_file_opts_default",
+    "mcx_avg_init", "mcx_map_batch_dev", "mcx_map_batch", "mcx_cigar_words", "mcx_map_files", "mcx_map_files_ex", "mcx_file_opts_default",
     "mcx_profile_attach", "mcx_profile_finalize", "mcx_profile_sparse", "mcx_planes_alloc", "mcx_planes_free",
     "mcx_vcf_defaults", "mcx_call_variants",
     "mcx_batch_begin", "mcx_batch_sums", "mcx_batch_replay", "mcx_batch_end", "mcx_avg_walk", "mcx_exchange_local", "mcx_exchange_local_free",
     "mcx_profile_sparse_shard", "mcx_batch_end_keys", "mcx_batch_accumulate", "mcx_sam_merge",
+    "mcx_stream_submit", "mcx_stream_map", "mcx_stream_collect", "mcx_stream_next", "mcx_stream_mapped",
 ]
 # include/mcx_comm.h (libmcx_comm.so: the RCCL side, loaded by the native CLI only)
 COMM_LIB_PATH = os.path.join(_HERE, "libmcx_comm.so")
@@ -45,12 +46,12 @@ class Opts(C.Structure):
 class Aln(C.Structure):
     _fields_ = [("pos", C.c_int64), ("mate_pos", C.c_int64), ("chr", C.c_int32), ("flag", C.c_int32),
                 ("mapq", C.c_int32), ("tlen", C.c_int32), ("nm", C.c_int32), ("as_", C.c_int32), ("xs", C.c_int32),
-                ("n_cigar", C.c_int32), ("fwd", C.c_int32), ("has_mate", C.c_int32), ("cigar_ext", C.c_int32), ("pad", C.c_int32)]
+                ("n_cigar", C.c_int32), ("fwd", C.c_int32), ("has_mate", C.c_int32), ("cigar_off", C.c_int32), ("pad", C.c_int32)]
 
 
 ALN_DTYPE = np.dtype([("pos", "<i8"), ("mate_pos", "<i8"), ("chr", "<i4"), ("flag", "<i4"), ("mapq", "<i4"),
                       ("tlen", "<i4"), ("nm", "<i4"), ("as", "<i4"), ("xs", "<i4"), ("n_cigar", "<i4"),
-                      ("fwd", "<i4"), ("has_mate", "<i4"), ("cigar_ext", "<i4"), ("pad", "<i4")])
+                      ("fwd", "<i4"), ("has_mate", "<i4"), ("cigar_off", "<i4"), ("pad", "<i4")])
 
 
 class SparseRec(C.Structure):
@@ -62,9 +63,9 @@ PLANES = ("A", "C", "G", "T", "multi_hit", "readCount", "F1", "R2", "F2", "R1")
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("reads", "mapped", "pairs", "pair_dist_sum", "pair_len_sum", "fm_ext_steps", "fm_blocks",
-                                         "sa_hits", "dp_jobs", "dp_cells", "tier1_pairs", "replayed_pairs", "halved_selections")] + \
+                                         "sa_hits", "dp_jobs", "dp_cells", "tier1_pairs", "replayed_pairs", "halved_selections", "fast_pairs")] + \
                [(n, C.c_double) for n in ("ms_encode", "ms_seed", "ms_sa", "ms_cluster", "ms_rescue", "ms_build",
-                                          "ms_dp", "ms_finish", "ms_total")]
+                                          "ms_dp", "ms_finish", "ms_total", "ms_fast")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -193,6 +194,9 @@ def lib() -> C.CDLL:
     L.mcx_exchange_local_free.argtypes = [C.POINTER(Exchange)]
     L.mcx_exchange_local_free.restype = None
     L.mcx_sam_merge.argtypes = [C.c_char_p, C.c_int32]
+    L.mcx_stream_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.mcx_stream_map.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+    L.mcx_stream_collect.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.mcx_planes_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.mcx_planes_free.argtypes = [C.c_void_p]
     L.mcx_planes_free.restype = None
@@ -366,20 +370,62 @@ class Mapper:
         return st.as_dict()
 
     def map_batch(self, bases: np.ndarray, off: np.ndarray, paired: bool):
-        """Host buffers: bases uint8 ASCII (concatenated), off uint32 [n+1]. Returns (aln, cigar)."""
+        """Host buffers: bases uint8 ASCII (concatenated), off uint32 [n+1].  Returns (aln, cigars): the records and, per
+        read, its CIGAR words (aln[r].n_cigar of them, taken out of the batch's pool at aln[r].cigar_off)."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         off = np.ascontiguousarray(off, dtype=np.uint32)
         n = off.size - 1
         aln = np.zeros(n, dtype=ALN_DTYPE)
-        cig = np.zeros((n, CIGAR_STRIDE), dtype=np.uint32)
+        pool = np.zeros(n * CIGAR_STRIDE, dtype=np.uint32)
         _check(lib().mcx_map_batch(self._h, bases.ctypes.data, off.ctypes.data, n, int(paired), self.avg,
-                                   aln.ctypes.data, cig.ctypes.data, C.byref(self.stats)), "mcx_map_batch")
-        return aln, cig
+                                   aln.ctypes.data, pool.ctypes.data, C.byref(self.stats)), "mcx_map_batch")
+        return aln, [pool[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["n_cigar"])] for a in aln]
+
+    def map_stream(self, host_bases_ptrs, host_off_ptr: int, n_reads: int, paired: bool):
+        """A sequence of equally shaped batches from pinned host memory, results to pinned host memory, the copies of one
+        batch overlapped with the kernels of its neighbours (mcx_stream_*).  Returns (bytes copied in, bytes copied out)."""
+        import torch
+        L = lib()
+        k = len(host_bases_ptrs)
+        alns = [torch.empty(n_reads * 64, dtype=torch.uint8).pin_memory() for _ in range(min(k, 3))]
+        cigs = [torch.empty(n_reads * CIGAR_STRIDE, dtype=torch.int32).pin_memory() for _ in range(min(k, 3))]
+        h2d = C.c_uint64()
+        d2h = C.c_uint64()
+        for i in range(k + 2):  # submit(i); map(i - 1); collect(i - 2)
+            if i < k:
+                _check(L.mcx_stream_submit(self._h, host_bases_ptrs[i], host_off_ptr, n_reads), "mcx_stream_submit")
+            if 1 <= i <= k:
+                j = (i - 1) % len(alns)
+                _check(L.mcx_stream_map(self._h, int(paired), self.avg, alns[j].data_ptr(), cigs[j].data_ptr(), C.byref(self.stats)), "mcx_stream_map")
+            if i >= 2:
+                _check(L.mcx_stream_collect(self._h, C.byref(h2d), C.byref(d2h)), "mcx_stream_collect")
+        return h2d.value, d2h.value
 
     def map_batch_dev(self, d_bases_ptr: int, d_off_ptr: int, n_reads: int, paired: bool, d_aln_ptr: int, d_cigar_ptr: int):
         """Device pointers (e.g. torch.Tensor.data_ptr()); results stay in HBM."""
         _check(lib().mcx_map_batch_dev(self._h, d_bases_ptr, d_off_ptr, n_reads, int(paired), self.avg, d_aln_ptr,
                                        d_cigar_ptr, C.byref(self.stats)), "mcx_map_batch_dev")
+
+    # ---- a batch in steps (runs whose batches are mapped by several GPUs) ---------------------
+    def batch_begin(self, d_bases_ptr: int, d_off_ptr: int, n_reads: int, paired: bool, est0: int, read_base: int, d_aln_ptr: int, d_cigar_ptr: int):
+        _check(lib().mcx_batch_begin(self._h, d_bases_ptr, d_off_ptr, n_reads, int(paired), est0, read_base, d_aln_ptr, d_cigar_ptr,
+                                     C.byref(self.stats)), "mcx_batch_begin")
+
+    def batch_sums(self):
+        """(pairs, dist, len) per chunk of 100 pairs: uint32 numpy views, valid until the next call on the context."""
+        n = C.c_uint32()
+        p = [C.POINTER(C.c_uint32)() for _ in range(3)]
+        _check(lib().mcx_batch_sums(self._h, C.byref(n), C.byref(p[0]), C.byref(p[1]), C.byref(p[2])), "mcx_batch_sums")
+        return tuple(np.ctypeslib.as_array(q, shape=(n.value,)) if n.value else np.zeros(0, np.uint32) for q in p)
+
+    def batch_replay(self, est_chunk: np.ndarray) -> int:
+        est_chunk = np.ascontiguousarray(est_chunk, dtype=np.int32)
+        n = C.c_uint32()
+        _check(lib().mcx_batch_replay(self._h, est_chunk.ctypes.data, C.byref(n), C.byref(self.stats)), "mcx_batch_replay")
+        return n.value
+
+    def batch_end(self):
+        _check(lib().mcx_batch_end(self._h, C.byref(self.stats)), "mcx_batch_end")
 
     # ---- -vcf bookkeeping ---------------------------------------------------------------
     def profile_attach(self, d_planes_ptr: int, max_dup: int = 5, max_clip: int = 5) -> None:
@@ -467,6 +513,17 @@ class Mapper:
             self.close()
         except Exception:
             pass
+
+
+def avg_walk(state, pairs: np.ndarray, dist: np.ndarray, want_est: bool = True):
+    """mcx_avg_walk: advances state = [avgDist, pairs, distance] over the chunks; returns the per-chunk EstiDistance."""
+    pairs = np.ascontiguousarray(pairs, dtype=np.uint32)
+    dist = np.ascontiguousarray(dist, dtype=np.uint32)
+    st = (C.c_int64 * 3)(*[int(v) for v in state[:3]])
+    est = np.zeros(pairs.size, dtype=np.int32) if want_est else None
+    lib().mcx_avg_walk(st, pairs.ctypes.data, dist.ctypes.data, pairs.size, est.ctypes.data if want_est else None)
+    state[0], state[1], state[2] = st[0], st[1], st[2]
+    return est
 
 
 def apply_ops(q: str, t: str, ops: str) -> Tuple[str, str]:

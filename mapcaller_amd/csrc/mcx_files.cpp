@@ -202,7 +202,7 @@ struct Batch {
     uint8_t *bases = nullptr; uint32_t *off = nullptr; AlnRec *recs = nullptr; uint32_t *cig = nullptr;
     size_t cap_reads = 0, cap_bases = 0;
     std::vector<uint8_t> is_mate2;                          // mapped as the second read of a pair
-    std::vector<uint32_t> cig_ext;                          // operations past a row of cig (mcx_cigar_ext), AlnRec::pad[0] = offset
+    uint32_t n_pair_reads = 0;                              // reads [0, n_pair_reads) were mapped as pairs, the rest one by one: two CIGAR pools
     bool reserve(size_t reads, size_t n_bases)
     {
         if (reads > cap_reads) {
@@ -273,7 +273,8 @@ void sam_record(const HostIndex &ix, const Batch &bt, uint32_t r, Text &o)
     bt.locate(r, f, i);
     const Entries &e = bt.in[f];
     const AlnRec &rec = bt.recs[r];
-    const uint32_t *cigar = bt.cig + (size_t)r * MCX_CIGAR_STRIDE;
+    // the batch's CIGAR pool (the single-read part of a batch has one of its own behind the pairs'), AlnRec::pad[0] = offset
+    const uint32_t *cigar = bt.cig + (r < bt.n_pair_reads ? 0 : (size_t)bt.n_pair_reads * MCX_CIGAR_STRIDE) + (size_t)rec.pad[0];
     const char *seq = (const char *)e.seq.data() + e.seq_off[i];
     const int rlen = (int)(e.seq_off[i + 1] - e.seq_off[i]);
     const char *qual = bt.fastq ? e.qual.data() + e.seq_off[i] : nullptr;
@@ -289,7 +290,7 @@ void sam_record(const HostIndex &ix, const Batch &bt, uint32_t r, Text &o)
         const std::string &cn = ix.chr_name[rec.chr];
         o.put(cn.data(), cn.size()); o.put('\t'); o.num(rec.pos); o.put('\t'); o.num(rec.mapq); o.put('\t');
         for (int k = 0; k < rec.n_cigar; k++) {
-            const uint32_t w = k < MCX_CIGAR_STRIDE ? cigar[k] : bt.cig_ext[(size_t)rec.pad[0] + (size_t)(k - MCX_CIGAR_STRIDE)];
+            const uint32_t w = cigar[k];
             o.num(w >> 4); o.put(opc[w & 7]);
         }
         if (rec.has_mate) { o.lit("\t=\t"); o.num(rec.mate_pos); o.put('\t'); o.num(rec.tlen); o.put('\t'); }
@@ -703,17 +704,8 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
             n_pairs_reads = paired ? n : 0;
             if (paired && (n & 1)) n_pairs_reads = n / kReadChunkSize * kReadChunkSize;
             for (uint32_t r = 1; r < n_pairs_reads; r += 2) b->is_mate2[r] = 1;
-            b->cig_ext.clear();
+            b->n_pair_reads = n_pairs_reads;
         }
-        auto take_ext = [&](uint32_t first, uint32_t last_read) { // long CIGARs of the reads just mapped
-            const uint32_t *w = nullptr; uint64_t nw = 0;
-            int e = mcx_cigar_ext(c, 0, &w, &nw);
-            if (e || nw == 0) return e;
-            const size_t base = b->cig_ext.size();
-            b->cig_ext.insert(b->cig_ext.end(), w, w + nw);
-            if (base) for (uint32_t r = first; r < last_read; r++) if (b->recs[r].n_cigar > MCX_CIGAR_STRIDE) b->recs[r].pad[0] += (int32_t)base;
-            return 0;
-        };
         // the single-read part (a single-end library, or the odd tail of an interleaved file) as a batch of its own
         std::vector<uint32_t> off2;
         uint32_t base2 = 0;
@@ -725,12 +717,10 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
         if (!sharded) {
             if (rc == 0 && n_pairs_reads) {
                 rc = mcx_map_batch(c, b->bases, b->off, n_pairs_reads, 1, avg, (mcx_aln *)b->recs, b->cig, stats);
-                if (rc == 0) rc = take_ext(0, n_pairs_reads);
             }
             if (rc == 0 && n_pairs_reads < n) {
                 rc = mcx_map_batch(c, b->bases + base2, off2.data(), n - n_pairs_reads, 0, avg, (mcx_aln *)b->recs + n_pairs_reads,
                                    b->cig + (size_t)n_pairs_reads * MCX_CIGAR_STRIDE, stats);
-                if (rc == 0) rc = take_ext(n_pairs_reads, n);
             }
         } else if (!dead && b->number / shard_count >= rounds_done) {
             rounds_done = b->number / shard_count + 1;
@@ -749,13 +739,11 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
             const int64_t round_base = avg[3];
             if (rc == 0 && any_pair) {
                 rc = sh.pairs(c, b->bases, b->off, n_pairs_reads, round_base + (int64_t)before, avg, profile, (mcx_aln *)b->recs, b->cig, stats);
-                if (rc == 0 && n_pairs_reads) rc = take_ext(0, n_pairs_reads);
             }
             if (rc == 0 && any_single) {
                 const uint32_t ns = n - n_pairs_reads;
                 rc = sh.singles(c, ns ? b->bases + base2 : nullptr, ns ? off2.data() : nullptr, ns, round_base + (int64_t)before + n_pairs_reads, profile,
                                 (mcx_aln *)b->recs + n_pairs_reads, b->cig + (size_t)n_pairs_reads * MCX_CIGAR_STRIDE, stats);
-                if (rc == 0 && ns) rc = take_ext(n_pairs_reads, n);
             }
             avg[3] = round_base + (int64_t)round_total;
             if (rc) dead = true;

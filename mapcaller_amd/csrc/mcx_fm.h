@@ -132,10 +132,14 @@ struct ReadRef {
     const uint8_t *ascii;
     int32_t rlen;
     int32_t flipped;
+    // optional: the read's 2-bit words as k_pack_reads leaves them (oriented: mate 2 already reverse-complemented),
+    // for reads without N — the fused per-pair kernel keeps them in LDS and never touches the ASCII bases
+    const uint32_t *codes = nullptr;
 };
 
 static inline MCX_HD int read_code(const ReadRef &r, int i)
 {
+    if (r.codes) return (int)((r.codes[i >> 4] >> (30 - 2 * (i & 15))) & 3u);
     int c = nt4_code(r.ascii[r.flipped ? r.rlen - 1 - i : i]);
     return (r.flipped && c < 4) ? 3 - c : c;
 }
@@ -164,7 +168,7 @@ static inline MCX_HD int ref_code(const IndexView &ix, int64_t p)
 {
     bool rev = p >= ix.G;
     int64_t f = rev ? ix.G2 - 1 - p : p;
-    int b = (ix.pac[f >> 2] >> ((~f & 3) << 1)) & 3;
+    int b = (ix.pac[(f >> 2) - ix.pac_base] >> ((~f & 3) << 1)) & 3;
     return rev ? 3 - b : b;
 }
 

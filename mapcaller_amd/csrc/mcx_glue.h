@@ -27,11 +27,10 @@ struct Ctx {
     uint8_t *state;           // pair-state records
     const uint8_t *mapq_tab;  // [(rlen_max+1) * 6]: EvaluateMAPQ for (score, score-sub in 1..5), host-computed
     int32_t mapq_rows;
-    // CIGARs with more operations than a row of the dense array holds (many indels in a long read)
-    // continue in this pool; only the last tier uses it (null otherwise)
-    uint32_t *cig_ext;
-    uint32_t *cig_ext_n;      // words taken so far
-    uint32_t cig_ext_cap;
+    // CIGAR operations of a batch go to one pool (BAM-style words); a read's record holds the offset of its first one
+    uint32_t *cig_pool;
+    uint32_t *cig_pool_n;     // words taken so far (device: reserved per wave with one atomic)
+    uint32_t cig_pool_cap;
 };
 
 static inline MCX_HD int64_t hit_pd(const Hit &h) { return h.gPos - h.rPos; }
@@ -301,18 +300,46 @@ struct RescueWave { // one workgroup (any number of wavefronts) evaluates one pa
     __device__ void sync() const { __threadfence_block(); __syncthreads(); }
     __device__ void fill_query(const ReadRef &rq) const
     {
-        if (leader()) kmer_fill([&](uint32_t i) { return read_char(rq, (int)i); }, rq.rlen, kq);
+        // the read's characters as codes, in parallel (kg is free until the first window); a read without N gets
+        // its 8-mer ids in parallel as well — CreateKmerVecFromReadSeq's rolling id is then the plain 16-bit pack
+        const int tid = threadIdx.x, nt = blockDim.x;
+        uint8_t *qc = (uint8_t *)kg;
+        __syncthreads();
+        int any_n = 0;
+        for (int i = tid; i < rq.rlen; i += nt) { const int c = nt4_code(read_char(rq, i)); qc[i] = (uint8_t)c; any_n |= c > 3; }
+        any_n = __syncthreads_or(any_n);
+        if (any_n) { if (leader()) kmer_fill([&](uint32_t i) { return read_char(rq, (int)i); }, rq.rlen, kq); }
+        else for (int i = tid; i < rq.rlen; i += nt) {
+            uint32_t wid = MCX_NOKMER;
+            if (i + kKmerSize <= rq.rlen) { wid = 0; for (int k = 0; k < kKmerSize; k++) wid = (wid << 2) | qc[i + k]; }
+            kq[i] = wid;
+        }
         __syncthreads();
     }
     __device__ RescueOut window(const IndexView &ix, int64_t left, int slen, int qlen, Hit *hits, int n_hits, int cap, bool &overflow) const
     {
         const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, n_waves = nt >> 6;
         __syncthreads();
+        // The window's bases come from the 2-bit genome: its bytes are copied into LDS once (behind the ids: gb) and the 8-mer
+        // ids are cut out of them, instead of eight byte fetches from HBM per position.  A window lies on one strand
+        // (AlignmentRescue checks its ends' chromosome): the reverse strand is the mirrored forward stretch, complemented.
+        uint8_t *gb = (uint8_t *)(kg + slen + 8);
+        const bool rev = left >= ix.G;
+        const int64_t f0 = rev ? ix.G2 - (left + slen) : left;
+        const int64_t b0 = f0 >> 2;
+        const int n_bytes = (int)(((f0 + slen - 1) >> 2) - b0) + 1;
+        for (int i = tid; i < n_bytes; i += nt) gb[i] = ix.pac[b0 + i];
+        __syncthreads();
+        auto base = [&](int p) -> uint32_t { // code of window position p
+            const int64_t f = rev ? f0 + (slen - 1 - p) : f0 + p;
+            const uint32_t c = (gb[(f >> 2) - b0] >> ((~f & 3) << 1)) & 3u;
+            return rev ? 3u - c : c;
+        };
         for (int p = tid; p < slen; p += nt) {
             uint32_t wid = MCX_NOKMER;
             if (p + kKmerSize <= slen) {
                 wid = 0;
-                for (int k = 0; k < kKmerSize; k++) wid = (wid << 2) | (uint32_t)ref_code(ix, left + p + k);
+                for (int k = 0; k < kKmerSize; k++) wid = (wid << 2) | base(p + k);
             }
             kg[p] = wid;
         }
@@ -749,9 +776,9 @@ static inline MCX_HD bool quality_ok(const ColStats &c)
 static inline MCX_HD int frag_index(const Cand &c, int i) { return c.frag_off + (c.fwd ? i : c.n_frags - 1 - i); }
 
 // ProduceReadAlignment from :336 on, for one read
-static inline MCX_HD void extend_read(const Ctx &cx, PairState &st, int s, const ReadRef &rd)
+// (ix: the view the read's genome bases are fetched through — cx.ix, or one whose pac points into a window held in LDS)
+static inline MCX_HD void extend_read(const Ctx &cx, const IndexView &ix, PairState &st, int s, const ReadRef &rd)
 {
-    const IndexView &ix = cx.ix;
     PairHdr &h = *st.hdr;
     ReadSum sum = h.sum[s];
     const int max_mm = (int)(rd.rlen * cx.pm.max_mm_rate);
@@ -850,14 +877,14 @@ static inline MCX_HD int mapq_of(const Ctx &cx, const ReadSum &r) // EvaluateMAP
 
 // GenerateCIGARstring (SamReport.cpp:172-316) as BAM-style (len << 4 | op) words; op codes
 // M=0 I=1 D=2 S=4.  Returns the number of words needed (may exceed cap).
-// (operations beyond `cap` go to ext[0..) when ext is given; the count is returned either way)
-static inline MCX_HD int cigar_of(int rlen, const Cand &c, const Frag *frags, const uint8_t *ops, uint32_t *out, int cap, uint32_t *ext = nullptr)
+// (out may be null with cap 0: the operations are only counted)
+static inline MCX_HD int cigar_of(int rlen, const Cand &c, const Frag *frags, const uint8_t *ops, uint32_t *out, int cap)
 {
     auto v = [&](int i) -> Frag { return frags[frag_index(c, i)]; };
     int num = c.n_frags, n = 0, run = 0, st = -1;
     auto put = [&](int len, int op) {
         const uint32_t w = ((uint32_t)len << 4) | (uint32_t)op;
-        if (n < cap) out[n] = w; else if (ext) ext[n - cap] = w;
+        if (n < cap) out[n] = w;
         n++;
     };
     auto flush_to = [&](int ns) { if (st != ns) { if (run > 0) put(run, st); st = ns; run = 0; } };
@@ -944,9 +971,10 @@ static inline MCX_HD void pair_stats(const Ctx &cx, PairState &st, DetailHdr *dh
 }
 
 // one output record: the line GeneratePairedSamStream / GenerateSingleSamStream print for this
-// read in unique mode (SamReport.cpp:324-488)
+// read in unique mode (SamReport.cpp:324-488).  cig: where the read's n_cig operations go (counted by
+// finish_scores, reserved in the batch's pool by the caller), cig_off: that place as a pool offset.
 static inline MCX_HD void emit_record(const Ctx &cx, PairState &st, int s, const ReadRef *rd, AlnRec &dst,
-                                      uint32_t *cig, int cig_cap)
+                                      uint32_t *cig, int n_cig, uint32_t cig_off)
 {
     PairHdr &h = *st.hdr;
     const ReadSum me = h.sum[s];
@@ -977,22 +1005,8 @@ static inline MCX_HD void emit_record(const Ctx &cx, PairState &st, int s, const
     out.chr = km.chr; out.pos = km.pos;
     out.fwd = c.fwd;
     out.nm = rd[s].rlen - c.score; out.as = me.score; out.xs = me.sub;
-    int nc = cigar_of(rd[s].rlen, c, st.frags, st.ops, cig, cig_cap);
-    if (nc > cig_cap) {
-        bool kept = false;
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (cx.cig_ext) { // the row's continuation: reserve, then write the operations past the row
-            const uint32_t at = atomicAdd(cx.cig_ext_n, (uint32_t)(nc - cig_cap));
-            if (at + (uint32_t)(nc - cig_cap) <= cx.cig_ext_cap) {
-                cigar_of(rd[s].rlen, c, st.frags, st.ops, cig, cig_cap, cx.cig_ext + at);
-                out.pad[0] = (int32_t)at;
-                kept = true;
-            }
-        }
-#endif
-        if (!kept) { h.flags |= kOvCigar; nc = 0; }
-    }
-    out.n_cigar = nc;
+    out.n_cigar = cig ? cigar_of(rd[s].rlen, c, st.frags, st.ops, cig, n_cig) : 0; // (null: the pool ran over; the batch fails)
+    out.pad[0] = (int32_t)cig_off;
     if (paired) {
         const ReadSum &ot = h.sum[1 - s];
         int j = c.mate;
@@ -1057,27 +1071,80 @@ static inline MCX_HD void write_detail(const Ctx &cx, PairState &st, int s, uint
     }
 }
 
-// (keep: where the final header goes instead of the pair state — the device's finish kernel is the last reader)
-static inline MCX_HD void stage_finish(const Ctx &cx, int64_t pair, const ReadRef *rd, AlnRec *recs, uint32_t *cigars,
-                                       uint8_t *detail0, PairHdr *keep = nullptr)
+// Stage G2 comes in two steps so that a wavefront can reserve the CIGAR words of its 64 pairs with one atomic in
+// between.  st.hdr points at the caller's copy of the header (registers on the device).
+// finish_scores: gates, scores, best / sub-best, pair statistics; n_cig[s] = CIGAR operations read s will print.
+static inline MCX_HD void finish_scores(const Ctx &cx, PairState &st, const ReadRef *rd, DetailHdr *dh, int n_cig[2], const IndexView *ixr = nullptr)
+{
+    PairHdr &h = *st.hdr;
+    n_cig[0] = n_cig[1] = 0;
+    if (h.flags & kOvAny) return;
+    const int nr = cx.pm.paired ? 2 : 1;
+    h.mapped = 0;
+    MCX_UNROLL
+    for (int s = 0; s < 2; s++) { if (s >= nr) break; extend_read(cx, ixr ? ixr[s] : cx.ix, st, s, rd[s]); if (h.sum[s].score > 0) h.mapped++; }
+    if (cx.pm.paired) pair_stats(cx, st, dh); else { h.pair_ok = 0; h.pair_dist = 0; if (dh) dh->disc_kind = 0; }
+    MCX_UNROLL
+    for (int s = 0; s < 2; s++) {
+        if (s >= nr) break;
+        if (h.sum[s].score > 0) n_cig[s] = cigar_of(rd[s].rlen, st.cands[s][h.sum[s].best], st.frags, st.ops, nullptr, 0);
+    }
+}
+
+// finish_records: the pair's output records (rec2[0..nr)), their CIGAR words at cig_pool + cig_off[s] (null pool: the
+// reservation failed), and the alignment detail of its reads when the profile is kept (detail2 = the pair's first record).
+static inline MCX_HD void finish_records(const Ctx &cx, PairState &st, const ReadRef *rd, AlnRec *rec2, uint32_t *cig_pool,
+                                         const uint32_t cig_off[2], const int n_cig[2], uint8_t *detail2)
+{
+    PairHdr &h = *st.hdr;
+    if (h.flags & kOvAny) return;
+    const int nr = cx.pm.paired ? 2 : 1;
+    MCX_UNROLL
+    for (int s = 0; s < 2; s++) {
+        if (s >= nr) break;
+        emit_record(cx, st, s, rd, rec2[s], cig_pool ? cig_pool + cig_off[s] : nullptr, n_cig[s], cig_off[s]);
+        if (detail2) write_detail(cx, st, s, detail2 + (int64_t)s * cx.dlay.stride);
+    }
+}
+
+// both steps for callers that take the pool's words front to back (host emulation)
+static inline MCX_HD void stage_finish(const Ctx &cx, int64_t pair, const ReadRef *rd, AlnRec *recs, uint8_t *detail0, PairHdr *keep = nullptr)
 {
     PairState st = pair_state(cx.state, cx.lay, cx.caps, pair);
     PairHdr *const g_hdr = st.hdr;
     PairHdr h = *g_hdr; // the header travels in registers through this stage and is stored back once
     st.hdr = &h;
-    int nr = cx.pm.paired ? 2 : 1;
-    if (h.flags & kOvAny) { if (keep) *keep = h; return; }
-    h.mapped = 0;
-    for (int s = 0; s < nr; s++) { extend_read(cx, st, s, rd[s]); if (h.sum[s].score > 0) h.mapped++; }
+    const int nr = cx.pm.paired ? 2 : 1;
     DetailHdr *dh = detail0 ? (DetailHdr *)(detail0 + (pair * nr) * cx.dlay.stride) : nullptr;
-    if (cx.pm.paired) pair_stats(cx, st, dh); else { h.pair_ok = 0; h.pair_dist = 0; if (dh) dh->disc_kind = 0; }
-    for (int s = 0; s < nr; s++) {
-        int64_t r = pair * nr + s;
-        emit_record(cx, st, s, rd, recs[r], cigars + r * cx.caps.cig_cap, cx.caps.cig_cap);
-        if (detail0) write_detail(cx, st, s, detail0 + r * cx.dlay.stride);
-    }
+    int n_cig[2];
+    finish_scores(cx, st, rd, dh, n_cig);
+    uint32_t off[2] = {*cx.cig_pool_n, *cx.cig_pool_n + (uint32_t)n_cig[0]};
+    const bool fits = off[1] + (uint32_t)n_cig[1] <= cx.cig_pool_cap;
+    if (fits) *cx.cig_pool_n = off[1] + (uint32_t)n_cig[1];
+    finish_records(cx, st, rd, recs + pair * nr, fits ? cx.cig_pool : nullptr, off, n_cig, detail0 ? detail0 + (pair * nr) * cx.dlay.stride : nullptr);
     if (keep) *keep = h; else *g_hdr = h;
 }
+
+#if defined(__HIPCC__)
+constexpr int kLdsEnds = 1024; // chromosome ends a block keeps in LDS
+
+// Reserves n slots of a work list for every lane of the wave with ONE atomic: an inclusive scan
+// over the wave, the last lane adds the total.  Must be reached by all 64 lanes (n = 0 for the
+// ones with nothing to append).  The lists' order never influences a result.
+static __device__ __forceinline__ uint32_t wave_reserve(uint32_t *counter, uint32_t n)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t incl = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    const uint32_t total = __shfl(incl, 63, 64);
+    uint32_t base = 0;
+    if (lane == 63 && total) base = atomicAdd(counter, total);
+    base = __shfl(base, 63, 64);
+    return base + incl - n;
+}
+
+#endif
 
 } // namespace mcx
 #endif

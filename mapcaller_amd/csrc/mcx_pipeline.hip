@@ -25,6 +25,7 @@
 
 #include "../../include/mcx.h"
 #include "mcx_dp.h"
+#include "mcx_fast.h"
 #include "mcx_profile.h"
 #include <hipcub/hipcub.hpp>
 #include "mcx_internal.h"
@@ -279,26 +280,9 @@ struct PairSel {             // which pairs a launch works on
 
 static __device__ __forceinline__ uint32_t sel_pair(const PairSel &s, uint32_t local) { return s.ids ? s.ids[local] : local; }
 
-// Reserves n slots of a work list for every lane of the wave with ONE atomic: an inclusive scan
-// over the wave, the last lane adds the total.  Must be reached by all 64 lanes (n = 0 for the
-// ones with nothing to append).  The lists' order never influences a result.
-static __device__ __forceinline__ uint32_t wave_reserve(uint32_t *counter, uint32_t n)
-{
-    const int lane = threadIdx.x & 63;
-    uint32_t incl = n;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-    const uint32_t total = __shfl(incl, 63, 64);
-    uint32_t base = 0;
-    if (lane == 63 && total) base = atomicAdd(counter, total);
-    base = __shfl(base, 63, 64);
-    return base + incl - n;
-}
-
 // The chromosome tables (PosChrIdMap as sorted arrays) are binary-searched several times per
 // pair; each probe is a dependent load.  Blocks copy them to LDS once (when they fit) and the
 // per-pair code then searches LDS through the same pointers.
-constexpr int kLdsEnds = 1024;
 struct EndsLds { int64_t pos[kLdsEnds]; int32_t chr[kLdsEnds]; };
 
 static __device__ __forceinline__ void stage_ends(IndexView &ix, EndsLds &l)
@@ -329,6 +313,8 @@ struct SeedOut {
     uint32_t *read_blocks;
     const uint32_t *packed;  // 2-bit reads of the batch (k_pack_reads), wpad words each
     int wpad;
+    Hit *fast_hits;          // the fused per-pair kernel's input: the first fast_cap seeds of every read, [read][fast_cap] (null: seeds go to the pair records)
+    int fast_cap;
 };
 
 // 16 bytes from any address: two aligned 16-byte fetches and a byte funnel
@@ -450,8 +436,10 @@ __global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel,
     int64_t ext = 0, blocks = 0;
     Hit *hits = nullptr;
     // the read is done: counters, and SA tasks for the hits that are still BWT rows (the others carry their text position)
+    uint32_t has_n = 0;
+    int cap = cx.caps.hit_cap;
     auto finish_read = [&]() {
-        so.read_ext[r] = (uint32_t)ext; so.read_blocks[r] = (uint32_t)blocks | ((uint32_t)n << 20); // (blocks < 2^20; n < 2^12)
+        so.read_ext[r] = (uint32_t)ext | (has_n << 31); so.read_blocks[r] = (uint32_t)blocks | ((uint32_t)n << 20); // (ext < 2^31; blocks < 2^20; n < 2^12)
         if (cx.ix.sa_full) return; // every hit already carries its text position (seed_search)
         const int keep = n <= cx.caps.hit_cap ? n : 0; // overflowing reads are re-run in the next tier
         int todo = 0;
@@ -471,8 +459,9 @@ __global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel,
             lr = pool0 + i;
             r = sel_pair(sel, lr / nr) * nr + lr % nr;
             rlen = (int)(rb.off[r + 1] - rb.off[r]);
-            hits = pair_state(cx.state, cx.lay, cx.caps, lr / nr).hits[lr % nr];
-            n = 0; p = 0; ext = 0; blocks = 0;
+            if (so.fast_hits) { hits = so.fast_hits + (uint64_t)r * so.fast_cap; cap = so.fast_cap; }
+            else hits = pair_state(cx.state, cx.lay, cx.caps, lr / nr).hits[lr % nr];
+            n = 0; p = 0; ext = 0; blocks = 0; has_n = 0;
             const int need = packed_words(rlen);
             if (rlen > 0 && need <= pk_words) {
                 const U4 *src = (const U4 *)(so.packed + (uint64_t)r * so.wpad);
@@ -484,12 +473,22 @@ __global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel,
                     if (k + 3 < need) pk.w[(k + 3) * pk.stride] = v.w;
                 }
                 pk.n_code = ((rlen + 15) >> 4) + 1;
+                { // does the read hold an N?  (mask words: bit 31-s of word s/32; bases past the end are flagged too)
+                    const int nmw = (rlen + 31) >> 5;
+                    uint32_t any = 0;
+                    for (int m = 0; m < nmw; m++) {
+                        uint32_t w = pk.w[(pk.n_code + m) * pk.stride];
+                        if (m == nmw - 1 && (rlen & 31)) w &= ~(0xFFFFFFFFu >> (rlen & 31));
+                        any |= w;
+                    }
+                    has_n = any ? 1u : 0u;
+                }
                 have = seed_next_start(pk, rlen, p, nm);
             }
             if (!have) finish_read();
         }
         if (out) break;
-        seed_search(cx.ix, pk, rlen, nm, p, hits, cx.caps.hit_cap, n, ext, blocks);
+        seed_search(cx.ix, pk, rlen, nm, p, hits, cap, n, ext, blocks);
         if (!seed_next_start(pk, rlen, p, nm)) { finish_read(); have = false; }
     }
 }
@@ -537,7 +536,7 @@ __global__ void __launch_bounds__(kRescueThreads) k_rescue(Ctx cx, ReadBatch rb,
     // one workgroup per unpaired pair (they are few, and one pair's windows are a long serial chain
     // for a single wavefront); 8-mer ids of the read and of the window live in LDS
     __shared__ uint32_t kq[1024];
-    __shared__ uint32_t kg[4096 + 64];
+    __shared__ uint32_t kg[4096 + 64 + 8 + (4096 + 64) / 16 + 8]; // the window's 8-mer ids, then its 2-bit bytes (RescueWave::window)
     __shared__ int red[2 * (kRescueThreads / 64) + 4];
     const uint32_t n = min(*rl.n, rl.cap);
     RescueWave ev; ev.kq = kq; ev.kg = kg; ev.red = red;
@@ -692,30 +691,43 @@ __global__ void __launch_bounds__(256) k_dp_small(Ctx cx, JobSink sink, ReadBatc
     }
 }
 
-__global__ void __launch_bounds__(256, 7) k_finish(Ctx cx, ReadBatch rb, PairSel sel, AlnRec *recs, uint32_t *cigars,
-                                                PairOut *pout, uint32_t *ov_ids, uint32_t *n_ov, uint32_t ov_cap)
+__global__ void __launch_bounds__(256, 7) k_finish(Ctx cx, ReadBatch rb, PairSel sel, AlnRec *recs, PairOut *pout, uint32_t *ov_ids, uint32_t *n_ov,
+                                                uint32_t ov_cap, uint32_t *pool_over)
 {
     __shared__ EndsLds ends;
     stage_ends(cx.ix, ends);
     const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
-    if (local >= sel.n) return;
-    const uint32_t pair = sel_pair(sel, local);
-    ReadRef rd[2];
-    make_reads(cx, rb, pair, rd);
-    // records are indexed by batch read; stage_finish indexes by pair*nr+s, so offset the bases
+    const bool active = local < sel.n; // (no early exit: the wave reserves its CIGAR words together)
     const int nr = cx.pm.paired ? 2 : 1;
-    AlnRec *r0 = recs + (int64_t)pair * nr - (int64_t)local * nr;
-    uint32_t *c0 = cigars + ((int64_t)pair * nr - (int64_t)local * nr) * cx.caps.cig_cap;
-    uint8_t *d0 = cx.detail ? cx.detail + ((int64_t)pair * nr - (int64_t)local * nr) * cx.dlay.stride : nullptr;
+    uint32_t pair = 0;
+    ReadRef rd[2];
+    PairState st;
     PairHdr h; // the final header stays in registers: nothing reads the pair state after this kernel
-    stage_finish(cx, local, rd, r0, c0, d0, &h);
+    int n_cig[2] = {0, 0};
+    uint8_t *detail2 = nullptr;
+    if (active) {
+        pair = sel_pair(sel, local);
+        make_reads(cx, rb, pair, rd);
+        st = pair_state(cx.state, cx.lay, cx.caps, local);
+        h = *st.hdr;
+        st.hdr = &h;
+        detail2 = cx.detail ? cx.detail + (int64_t)pair * nr * cx.dlay.stride : nullptr; // records are indexed by batch read
+        finish_scores(cx, st, rd, (DetailHdr *)detail2, n_cig);
+    }
+    const uint32_t want = (uint32_t)(n_cig[0] + n_cig[1]);
+    const uint32_t at = wave_reserve(cx.cig_pool_n, want);
+    if (!active) return;
+    const bool fits = at + want <= cx.cig_pool_cap;
+    if (!fits) atomicOr(pool_over, 1u);
+    const uint32_t off[2] = {at, at + (uint32_t)n_cig[0]};
+    finish_records(cx, st, rd, recs + (int64_t)pair * nr, fits ? cx.cig_pool : nullptr, off, n_cig, detail2);
     PairOut o;
     o.flags = h.flags; o.est = h.est; o.est_lo = h.est_lo; o.est_hi = h.est_hi;
     o.pair_dist = h.pair_dist; o.pair_ok = (int16_t)h.pair_ok; o.mapped = (int16_t)h.mapped;
     pout[pair] = o;
     if (h.flags & kOvAny) {
-        const uint32_t at = atomicAdd(n_ov, 1u);
-        if (at < ov_cap) ov_ids[at] = pair;
+        const uint32_t at2 = atomicAdd(n_ov, 1u);
+        if (at2 < ov_cap) ov_ids[at2] = pair;
     }
 }
 
@@ -739,7 +751,8 @@ struct BatchRun { // the batch between mcx_batch_begin and mcx_batch_end
     bool open = false, sums_valid = false, keys_out = false;
     ReadBatch rb; int paired = 0;
     uint32_t n_pairs = 0, n_chunks = 0;
-    AlnRec *recs = nullptr; uint32_t *cig = nullptr;
+    AlnRec *recs = nullptr; uint32_t *cig = nullptr; // records [n_reads]; the batch's CIGAR pool
+    uint32_t cig_cap = 0, cig_words = 0;             // its capacity (n_reads * MCX_CIGAR_STRIDE words) and, once the batch is closed, the words taken
     int64_t read_base = 0, mapped = 0;
     unsigned long long hs[3] = {0, 0, 0};
     std::vector<uint32_t> ok, ds; // per chunk: proper pairs; summed distance, then summed read lengths
@@ -769,8 +782,6 @@ struct mcx_ctx {
     uint32_t *d_sel_ids = nullptr; int32_t *d_est = nullptr;
     uint32_t *d_read_ext = nullptr, *d_read_blocks = nullptr;
     uint32_t *d_packed = nullptr; int wpad = 0; // 2-bit form of the batch's reads
-    uint32_t *d_cig_ext = nullptr, cig_ext_cap = 0; // CIGAR operations past a row of the dense array (tier 1)
-    std::vector<uint32_t> h_cig_ext;
     PairOut *d_pout = nullptr, *h_pout = nullptr;
     uint8_t *d_mapq = nullptr; int mapq_rows = 0;
     // -vcf bookkeeping (mcx_profile.h): caller-owned counter planes, per-read alignment detail
@@ -781,8 +792,20 @@ struct mcx_ctx {
     std::vector<mcx_sparse_rec> h_sparse, h_events, h_resolved; // tallies; discordant-pair events ('E'); what mcx_profile_sparse* last returned
     uint64_t keys_cap = 0;       // keys the sort buffers hold
     uint64_t *h_keys = nullptr; uint64_t h_keys_cap = 0; // pinned: the batch's keys for the exchange between shards
-    uint32_t *d_batch_flags = nullptr; // [0] words taken in the long-CIGAR pool, [1] longest read of the batch
+    uint32_t *d_batch_flags = nullptr; // [0] words taken in the batch's CIGAR pool, [1] longest read of the batch, [2] the pool ran over
+    // the fused per-pair kernel (mcx_fast.h)
+    bool fast_on = false; FastCaps fcaps; size_t fast_lds = 0;
+    Hit *d_fast_hits = nullptr; uint32_t *d_spill = nullptr; uint32_t *h_spill = nullptr;
+    hipEvent_t ev_fast[3] = {nullptr, nullptr, nullptr};
     BatchRun run;
+    // mcx_stream_*: three batches in flight (copy in | kernels | copy out), each in a slot of its own
+    struct Slot {
+        uint8_t *d_bases = nullptr; uint32_t *d_off = nullptr; AlnRec *d_recs = nullptr; uint32_t *d_cig = nullptr;
+        uint32_t n_reads = 0; int state = 0; uint64_t seq = 0; // 0 free, 1 copy in started, 2 handed to the kernels, 3 copy out started
+        hipEvent_t in_ready = nullptr, mapped = nullptr, out_done = nullptr;
+    } slot[3];
+    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
+    uint64_t stream_seq = 0, stream_bytes_in = 0, stream_bytes_out = 0;
     // staging for the host-buffer entry point
     uint8_t *d_bases = nullptr; uint32_t *d_off = nullptr; AlnRec *d_recs = nullptr; uint32_t *d_cig = nullptr;
     hipEvent_t ev[10];
@@ -841,7 +864,8 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
     int rc = 0;
     c->tier[0].caps = tier0_caps(); c->tier[0].lay = make_layout(c->tier[0].caps); c->tier[0].max_pairs = (uint32_t)c->max_reads;
     c->tier[1].caps = tier1_caps(c->rlen_max); c->tier[1].lay = make_layout(c->tier[1].caps);
-    c->tier[1].max_pairs = (uint32_t)std::min<uint64_t>(c->max_reads, 16384);
+    // (the heavy pairs of a batch in as few passes as 16 GB of records allow: a pass is bound by its slowest pair, not by its size)
+    c->tier[1].max_pairs = (uint32_t)std::max<uint64_t>(1024, std::min<uint64_t>(std::min<uint64_t>(c->max_reads, 65536), ((uint64_t)16 << 30) / (uint64_t)c->tier[1].lay.stride));
     for (int t = 0; t < 2; t++)
         if ((rc = dmalloc(&c->tier[t].state, (size_t)c->tier[t].lay.stride * c->tier[t].max_pairs))) return rc;
     c->task_cap = (uint32_t)std::min<uint64_t>(c->max_reads * 24, 0x7fffffffu);
@@ -869,8 +893,6 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
     if ((rc = dmalloc(&c->d_est, c->max_reads))) return rc;
     if ((rc = dmalloc(&c->d_read_ext, c->max_reads))) return rc;
     if ((rc = dmalloc(&c->d_read_blocks, c->max_reads))) return rc;
-    c->cig_ext_cap = 1u << 22;
-    if ((rc = dmalloc(&c->d_cig_ext, c->cig_ext_cap))) return rc;
     if ((rc = dmalloc(&c->d_batch_flags, 4))) return rc;
     HIP_TRY(hipMemset(c->d_batch_flags, 0, 4 * sizeof(uint32_t)));
     c->wpad = (packed_words(c->rlen_max) + 3) & ~3;
@@ -889,6 +911,30 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
         }
     if ((rc = dmalloc(&c->d_mapq, tab.size()))) return rc;
     HIP_TRY(hipMemcpy(c->d_mapq, tab.data(), tab.size(), hipMemcpyHostToDevice));
+    // the fused per-pair kernel: needs every suffix-array entry resident (seeds then leave k_seed as text positions)
+    // and a slice of LDS per lane that the read length decides (reads up to 16 x code_words bases take it)
+    if (idx->view.sa_full && !getenv("MCX_NO_FAST")) {
+        const int fast_rlen = std::min(c->rlen_max, 160);
+        c->fcaps = make_fast_caps(fast_rlen, idx->view.n_ends, idx->view.n_chr);
+        if (const char *e = getenv("MCX_FAST_CAPS")) { // experiments: "hits,slots"
+            int a, b;
+            if (sscanf(e, "%d,%d", &a, &b) == 2) {
+                c->fcaps.hit_cap = a; c->fcaps.slots = b;
+                c->fcaps.stride = 2 * c->fcaps.cand_cap * (int)sizeof(Cand) + 2 * c->fcaps.code_words * 4 + 2 * c->fcaps.win_words * 4 + b * 16;
+                c->fcaps.stride = (c->fcaps.stride + 15) / 16 * 16;
+                if (((c->fcaps.stride / 16) & 1) == 0) { c->fcaps.stride += 16; c->fcaps.slots++; }
+            }
+        }
+        c->fast_lds = (size_t)c->fcaps.ends_bytes + c->fcaps.wave_bytes + (size_t)64 * c->fcaps.stride;
+        if (c->fast_lds <= 160 * 1024 - 256) {
+            HIP_TRY(hipFuncSetAttribute((const void *)k_pair_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fast_lds));
+            if ((rc = dmalloc(&c->d_fast_hits, c->max_reads * (uint64_t)c->fcaps.hit_cap))) return rc;
+            if ((rc = dmalloc(&c->d_spill, c->max_reads))) return rc;
+            HIP_TRY(hipHostMalloc((void **)&c->h_spill, c->max_reads * sizeof(uint32_t)));
+            for (auto &e : c->ev_fast) HIP_TRY(hipEventCreate(&e));
+            c->fast_on = true;
+        }
+    }
     *out = c;
     return 0;
 }
@@ -899,11 +945,20 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3], c->d_jobs[4], c->d_jobs[5],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
                  c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
-                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_packed, c->d_cig_ext, c->d_batch_flags};
+                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_packed, c->d_batch_flags, c->d_fast_hits, c->d_spill};
     for (void *q : p) if (q) (void)hipFree(q);
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
     if (c->h_pout) (void)hipHostFree(c->h_pout);
     if (c->h_keys) (void)hipHostFree(c->h_keys);
+    if (c->h_spill) (void)hipHostFree(c->h_spill);
+    for (auto &e : c->ev_fast) if (e) (void)hipEventDestroy(e);
+    for (auto &sl : c->slot) {
+        void *q[] = {sl.d_bases, sl.d_off, sl.d_recs, sl.d_cig};
+        for (void *x : q) if (x) (void)hipFree(x);
+        for (hipEvent_t e : {sl.in_ready, sl.mapped, sl.out_done}) if (e) (void)hipEventDestroy(e);
+    }
+    if (c->h2d_stream) (void)hipStreamDestroy(c->h2d_stream);
+    if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (int k = 0; k < 5; k++) { if (c->dp_stream[k]) (void)hipStreamDestroy(c->dp_stream[k]); if (c->dp_join[k]) (void)hipEventDestroy(c->dp_join[k]); }
@@ -919,7 +974,7 @@ static Ctx make_ctx(const mcx_ctx *c, int tier, int paired)
     cx.caps = c->tier[tier].caps; cx.lay = c->tier[tier].lay; cx.state = c->tier[tier].state;
     cx.mapq_tab = c->d_mapq; cx.mapq_rows = c->mapq_rows;
     cx.detail = c->prof_planes ? c->d_detail : nullptr; cx.dlay = c->dlay;
-    cx.cig_ext = tier == 1 ? c->d_cig_ext : nullptr; cx.cig_ext_n = c->d_batch_flags; cx.cig_ext_cap = c->cig_ext_cap;
+    cx.cig_pool = c->run.cig; cx.cig_pool_n = c->d_batch_flags; cx.cig_pool_cap = c->run.cig_cap;
     return cx;
 }
 
@@ -940,7 +995,7 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
     SeedOut so; so.tasks = c->d_tasks; so.n_tasks = c->d_cnt + CNT_TASKS; so.task_cap = c->task_cap;
     so.read_ext = c->d_read_ext; so.read_blocks = c->d_read_blocks;
-    so.packed = c->d_packed; so.wpad = c->wpad;
+    so.packed = c->d_packed; so.wpad = c->wpad; so.fast_hits = nullptr; so.fast_cap = 0;
     RescueList rl; rl.ids = c->d_rescue; rl.n = c->d_cnt + CNT_RESCUE; rl.cap = c->rescue_cap;
     JobSinks sinks;
     for (int k = 0; k < kDpClasses; k++) { sinks.s[k].jobs = c->d_jobs[k]; sinks.s[k].count = c->d_cnt + CNT_JOB0 + k * kCntPad; sinks.s[k].cap = c->job_cap[k]; }
@@ -975,7 +1030,7 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     k_dp_sel<16><<<c->dp_blocks[2], 64, 0, c->dp_stream[2]>>>(cx, sinks.s[3], rb, sel, c->d_dp_scratch[2], c->dp_stride[2]);
     for (int k = 0; k < 5; k++) { HIP_TRY(hipEventRecord(c->dp_join[k], c->dp_stream[k])); HIP_TRY(hipStreamWaitEvent(s, c->dp_join[k], 0)); }
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
-    k_finish<<<pb, 256, 0, s>>>(cx, rb, sel, d_recs, d_cig, c->d_pout, c->d_ov, c->d_cnt + CNT_OV, c->ov_cap);
+    k_finish<<<pb, 256, 0, s>>>(cx, rb, sel, d_recs, c->d_pout, c->d_ov, c->d_cnt + CNT_OV, c->ov_cap, c->d_batch_flags + 2);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -1010,7 +1065,7 @@ __global__ void k_fill_i32(int32_t *p, int32_t v, uint32_t n)
 __global__ void k_reduce_stats(const uint32_t *a, const uint32_t *b, uint32_t n, unsigned long long *out)
 {
     unsigned long long sa = 0, sb = 0, sh = 0; // extension steps, blocks touched, hits (H of SURVEY.md §8d)
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { sa += a[i]; sb += b[i] & 0xFFFFFu; sh += b[i] >> 20; }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { sa += a[i] & 0x7FFFFFFFu; sb += b[i] & 0xFFFFFu; sh += b[i] >> 20; }
     for (int o = 32; o > 0; o >>= 1) { sa += __shfl_down(sa, o, 64); sb += __shfl_down(sb, o, 64); sh += __shfl_down(sh, o, 64); }
     if ((threadIdx.x & 63) == 0) { atomicAdd(out, sa); atomicAdd(out + 1, sb); atomicAdd(out + 2, sh); }
 }
@@ -1068,6 +1123,49 @@ extern "C" void mcx_avg_walk(int64_t st[3], const uint32_t *pairs, const uint32_
     st[0] = cur; st[1] = tp; st[2] = td;
 }
 
+// The first pass over a batch: seeding with the seeds laid out for the fused per-pair kernel, then that kernel
+// (mcx_fast.h).  spill receives the pairs it left for the general path, in pair order.
+static int run_fast(mcx_ctx *c, const ReadBatch &rb, int paired, int32_t est, uint32_t n_pairs, AlnRec *d_recs, mcx_stats *stats, std::vector<uint32_t> &spill)
+{
+    hipStream_t s = c->stream;
+    Ctx cx = make_ctx(c, 0, paired);
+    const int nr = paired ? 2 : 1;
+    HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
+    SeedOut so; so.tasks = c->d_tasks; so.n_tasks = c->d_cnt + CNT_TASKS; so.task_cap = c->task_cap;
+    so.read_ext = c->d_read_ext; so.read_blocks = c->d_read_blocks;
+    so.packed = c->d_packed; so.wpad = c->wpad; so.fast_hits = c->d_fast_hits; so.fast_cap = c->fcaps.hit_cap;
+    PairSel sel; sel.n = n_pairs; sel.ids = nullptr; sel.est = nullptr;
+    HIP_TRY(hipEventRecord(c->ev_fast[0], s));
+    {
+        const int pkw = packed_words(c->rlen_max);
+        const int threads = pkw * 256 * 4 <= 48 * 1024 ? 256 : (pkw * 128 * 4 <= 48 * 1024 ? 128 : 64);
+        const unsigned blocks_s = (n_pairs * nr + threads * kSeedReadsPerLane - 1) / (threads * kSeedReadsPerLane);
+        k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw);
+    }
+    HIP_TRY(hipEventRecord(c->ev_fast[1], s));
+    FastIn in; in.hits = c->d_fast_hits; in.packed = c->d_packed; in.wpad = c->wpad; in.read_ext = c->d_read_ext; in.read_blocks = c->d_read_blocks; in.est = est;
+    k_pair_fast<<<(n_pairs + 63) / 64, 64, c->fast_lds, s>>>(cx, rb, in, c->fcaps, n_pairs, d_recs, c->d_pout, c->d_spill, c->d_cnt + CNT_OV, c->d_batch_flags + 2);
+    HIP_TRY(hipEventRecord(c->ev_fast[2], s));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t n_sp = c->h_cnt[CNT_OV];
+    spill.resize(n_sp);
+    if (n_sp) {
+        HIP_TRY(hipMemcpy(c->h_spill, c->d_spill, (size_t)n_sp * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        spill.assign(c->h_spill, c->h_spill + n_sp);
+        std::sort(spill.begin(), spill.end()); // (listed with atomics: results do not depend on the order, the replay of a run should not either)
+    }
+    if (stats) {
+        float a = 0, b = 0;
+        HIP_TRY(hipEventElapsedTime(&a, c->ev_fast[0], c->ev_fast[1]));
+        HIP_TRY(hipEventElapsedTime(&b, c->ev_fast[1], c->ev_fast[2]));
+        stats->ms_seed += a; stats->ms_fast += b; stats->fast_pairs += (int64_t)n_pairs - n_sp;
+    }
+    if (getenv("MCX_TIMING")) fprintf(stderr, "[run_fast] pairs %u: %u left for the general path\n", n_pairs, n_sp);
+    return 0;
+}
+
 // runs the tiers for the pairs in `ids` (null: all pairs of the batch) with per-pair estimates
 static int run_selection(mcx_ctx *c, const ReadBatch &rb, int paired, const std::vector<uint32_t> *ids,
                          const std::vector<int32_t> *est, int32_t est_all, uint32_t n_pairs, AlnRec *d_recs,
@@ -1114,6 +1212,13 @@ static int run_selection(mcx_ctx *c, const ReadBatch &rb, int paired, const std:
         HIP_TRY(hipMemcpyAsync(c->d_sel_ids, ov.data() + lo, m * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(c->d_est, ov_est.data() + lo, m * sizeof(int32_t), hipMemcpyHostToDevice, s));
         PairSel s1; s1.n = m; s1.ids = c->d_sel_ids; s1.est = c->d_est;
+        if (getenv("MCX_TIMING")) { // where the time of the large-capacity tier goes (not added to the caller's stage times)
+            mcx_stats t1; memset(&t1, 0, sizeof t1);
+            rc = run_pairs(c, 1, rb, paired, s1, d_recs, d_cig, &t1, true);
+            fprintf(stderr, "[tier 1] %u pairs: seed %.2f sa %.2f cluster %.2f rescue %.2f build %.2f dp %.2f finish %.2f ms\n", m, t1.ms_seed, t1.ms_sa, t1.ms_cluster,
+                    t1.ms_rescue, t1.ms_build, t1.ms_dp, t1.ms_finish);
+            if (stats) { stats->dp_jobs += t1.dp_jobs; stats->dp_cells += t1.dp_cells; }
+        } else
         rc = run_pairs(c, 1, rb, paired, s1, d_recs, d_cig, stats, false);
         if (rc == kListOverflow) return fail(MCX_ERR_CAPACITY, "work list overflow in tier 1");
         if (rc) return rc;
@@ -1156,6 +1261,7 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
     br.rb.bases = d_bases; br.rb.off = d_off; br.rb.n_reads = n_reads;
     br.paired = paired; br.read_base = read_base;
     br.recs = (AlnRec *)d_aln; br.cig = d_cigar; br.stats = stats;
+    br.cig_cap = (uint32_t)std::min<uint64_t>((uint64_t)n_reads * MCX_CIGAR_STRIDE, 0xFFFFFFFFu); br.cig_words = 0;
     br.n_pairs = paired ? n_reads / 2 : n_reads;
     br.n_chunks = (br.n_pairs + kReadChunkSize / 2 - 1) / (kReadChunkSize / 2);
     br.mapped = 0; br.sums_valid = false;
@@ -1175,7 +1281,12 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_pack[1], s));
     }
-    int rc = run_selection(c, br.rb, paired, nullptr, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true);
+    int rc;
+    if (c->fast_on) { // the common case in one kernel; what it leaves goes through the general path
+        std::vector<uint32_t> spill;
+        if ((rc = run_fast(c, br.rb, paired, est0, br.n_pairs, br.recs, stats, spill))) return rc;
+        rc = spill.empty() ? 0 : run_selection(c, br.rb, paired, &spill, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true);
+    } else rc = run_selection(c, br.rb, paired, nullptr, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true);
     if (rc) return rc;
     { // seeding statistics (E, blocks, H of SURVEY.md 8d) before the per-read arrays are reused for the chunk sums
         unsigned long long *d_sum = (unsigned long long *)c->d_cnt;
@@ -1257,9 +1368,10 @@ static int batch_close(mcx_ctx *c, mcx_stats *stats)
     int rc = 0;
     if (!br.sums_valid && (rc = mcx_batch_sums(c, nullptr, nullptr, nullptr, nullptr))) return rc;
     {
-        uint32_t used = 0;
-        HIP_TRY(hipMemcpy(&used, c->d_batch_flags, sizeof used, hipMemcpyDeviceToHost));
-        if (used > c->cig_ext_cap) return fail(MCX_ERR_CAPACITY, "CIGAR continuation pool overflow");
+        uint32_t fl[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpy(fl, c->d_batch_flags, sizeof fl, hipMemcpyDeviceToHost));
+        if (fl[2] || fl[0] > br.cig_cap) return fail(MCX_ERR_CAPACITY, "the batch's CIGAR pool (" + std::to_string(MCX_CIGAR_STRIDE) + " operations per read on average) ran over");
+        br.cig_words = fl[0];
     }
     if (stats) {
         int64_t pairs = 0, dist_sum = 0, len_sum = 0;
@@ -1373,7 +1485,7 @@ int mcx_stage_out(mcx_ctx *c, uint32_t n_reads, mcx_aln *aln, uint32_t *cigar)
 {
     HIP_TRY(hipSetDevice(c->idx->device));
     HIP_TRY(hipMemcpyAsync(aln, c->d_recs, (size_t)n_reads * sizeof(AlnRec), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(cigar, c->d_cig, (size_t)n_reads * MCX_CIGAR_STRIDE * 4, hipMemcpyDeviceToHost, c->stream));
+    if (c->run.cig_words) HIP_TRY(hipMemcpyAsync(cigar, c->d_cig, (size_t)c->run.cig_words * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -1388,6 +1500,102 @@ extern "C" int mcx_map_batch(mcx_ctx *c, const uint8_t *bases, const uint32_t *o
     if (rc) return rc;
     if ((rc = mcx_map_batch_dev(c, d_bases, d_off, n_reads, paired, avg, d_aln, d_cig, stats))) return rc;
     return mcx_stage_out(c, n_reads, aln, cigar);
+}
+
+// ---------------------------------------------------------------------------------------------
+// batches from host memory with the copies overlapped with the kernels
+// ---------------------------------------------------------------------------------------------
+static mcx_ctx::Slot *oldest_slot(mcx_ctx *c, int state)
+{
+    mcx_ctx::Slot *best = nullptr;
+    for (auto &sl : c->slot) if (sl.state == state && (!best || sl.seq < best->seq)) best = &sl;
+    return best;
+}
+
+extern "C" int mcx_stream_submit(mcx_ctx *c, const uint8_t *bases, const uint32_t *off, uint32_t n_reads)
+{
+    if (!c || !bases || !off || n_reads == 0) return fail(MCX_ERR_ARG, "mcx_stream_submit: bad argument");
+    if (n_reads > c->max_reads) return fail(MCX_ERR_ARG, "batch larger than max_batch_reads");
+    if (off[n_reads] > c->max_bases) return fail(MCX_ERR_ARG, "batch holds more bases than max_batch_reads * max_read_len");
+    HIP_TRY(hipSetDevice(c->idx->device));
+    mcx_ctx::Slot *sl = oldest_slot(c, 0);
+    if (!sl) return fail(MCX_ERR_ARG, "mcx_stream_submit: three batches are in flight (collect one first)");
+    int rc;
+    if (!c->h2d_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+    }
+    if (!sl->d_bases) {
+        if ((rc = dmalloc(&sl->d_bases, c->max_bases + 64))) return rc;
+        if ((rc = dmalloc(&sl->d_off, c->max_reads + 1))) return rc;
+        if ((rc = dmalloc(&sl->d_recs, c->max_reads))) return rc;
+        if ((rc = dmalloc(&sl->d_cig, c->max_reads * MCX_CIGAR_STRIDE))) return rc;
+        HIP_TRY(hipEventCreateWithFlags(&sl->in_ready, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl->mapped, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl->out_done, hipEventDisableTiming));
+    }
+    HIP_TRY(hipMemcpyAsync(sl->d_bases, bases, off[n_reads], hipMemcpyHostToDevice, c->h2d_stream));
+    HIP_TRY(hipMemcpyAsync(sl->d_off, off, (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice, c->h2d_stream));
+    HIP_TRY(hipEventRecord(sl->in_ready, c->h2d_stream));
+    sl->n_reads = n_reads; sl->state = 1; sl->seq = ++c->stream_seq;
+    c->stream_bytes_in += (uint64_t)off[n_reads] + (uint64_t)(n_reads + 1) * 4;
+    return 0;
+}
+
+// the oldest submitted batch, in HBM once the context's stream gets there
+extern "C" int mcx_stream_next(mcx_ctx *c, const uint8_t **d_bases, const uint32_t **d_off, uint32_t *n_reads, mcx_aln **d_aln, uint32_t **d_cigar)
+{
+    if (!c || !d_bases || !d_off || !d_aln || !d_cigar) return fail(MCX_ERR_ARG, "mcx_stream_next: null argument");
+    HIP_TRY(hipSetDevice(c->idx->device));
+    if (oldest_slot(c, 2)) return fail(MCX_ERR_ARG, "mcx_stream_next: the previous batch was not handed back (mcx_stream_mapped)");
+    mcx_ctx::Slot *sl = oldest_slot(c, 1);
+    if (!sl) return fail(MCX_ERR_ARG, "mcx_stream_next: nothing submitted");
+    HIP_TRY(hipStreamWaitEvent(c->stream, sl->in_ready, 0));
+    sl->state = 2;
+    *d_bases = sl->d_bases; *d_off = sl->d_off; *d_aln = (mcx_aln *)sl->d_recs; *d_cigar = sl->d_cig;
+    if (n_reads) *n_reads = sl->n_reads;
+    return 0;
+}
+
+// the batch mcx_stream_next gave out is mapped: its results start their way to host memory
+extern "C" int mcx_stream_mapped(mcx_ctx *c, mcx_aln *aln, uint32_t *cigar)
+{
+    if (!c || !aln || !cigar) return fail(MCX_ERR_ARG, "mcx_stream_mapped: null argument");
+    HIP_TRY(hipSetDevice(c->idx->device));
+    mcx_ctx::Slot *sl = oldest_slot(c, 2);
+    if (!sl) return fail(MCX_ERR_ARG, "mcx_stream_mapped: no batch is being mapped");
+    HIP_TRY(hipEventRecord(sl->mapped, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->d2h_stream, sl->mapped, 0));
+    const size_t rec_bytes = (size_t)sl->n_reads * sizeof(AlnRec), cig_bytes = (size_t)c->run.cig_words * 4; // (the pool's used words only)
+    HIP_TRY(hipMemcpyAsync(aln, sl->d_recs, rec_bytes, hipMemcpyDeviceToHost, c->d2h_stream));
+    if (cig_bytes) HIP_TRY(hipMemcpyAsync(cigar, sl->d_cig, cig_bytes, hipMemcpyDeviceToHost, c->d2h_stream));
+    HIP_TRY(hipEventRecord(sl->out_done, c->d2h_stream));
+    sl->state = 3;
+    c->stream_bytes_out += rec_bytes + cig_bytes;
+    return 0;
+}
+
+extern "C" int mcx_stream_map(mcx_ctx *c, int paired, int64_t avg[4], mcx_aln *aln, uint32_t *cigar, mcx_stats *stats)
+{
+    const uint8_t *d_bases; const uint32_t *d_off; mcx_aln *d_aln; uint32_t *d_cig; uint32_t n = 0;
+    int rc = mcx_stream_next(c, &d_bases, &d_off, &n, &d_aln, &d_cig);
+    if (rc) return rc;
+    rc = mcx_map_batch_dev(c, d_bases, d_off, n, paired, avg, d_aln, d_cig, stats);
+    if (rc) { oldest_slot(c, 2)->state = 0; return rc; }
+    return mcx_stream_mapped(c, aln, cigar);
+}
+
+extern "C" int mcx_stream_collect(mcx_ctx *c, uint64_t *bytes_in, uint64_t *bytes_out)
+{
+    if (!c) return fail(MCX_ERR_ARG, "mcx_stream_collect: null argument");
+    HIP_TRY(hipSetDevice(c->idx->device));
+    mcx_ctx::Slot *sl = oldest_slot(c, 3);
+    if (!sl) return fail(MCX_ERR_ARG, "mcx_stream_collect: no mapped batch is on its way out");
+    HIP_TRY(hipEventSynchronize(sl->out_done));
+    sl->state = 0;
+    if (bytes_in) *bytes_in = c->stream_bytes_in;
+    if (bytes_out) *bytes_out = c->stream_bytes_out;
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1700,17 +1908,10 @@ extern "C" int mcx_extend_batch(mcx_ctx *c, int alg, const uint8_t *q, const uin
 // ---------------------------------------------------------------------------------------------
 // files in, SAM out: MapCaller -i <prefix> -f A [-f2 B] -sam out  (main.cpp:212-321, Mapping() ReadMapping.cpp:689-747)
 // ---------------------------------------------------------------------------------------------
-extern "C" int mcx_cigar_ext(mcx_ctx *c, int on_device, const uint32_t **words, uint64_t *n_words)
+extern "C" int mcx_cigar_words(mcx_ctx *c, uint32_t *n_words)
 {
-    if (!c || !words || !n_words) return fail(MCX_ERR_ARG, "mcx_cigar_ext: null argument");
-    HIP_TRY(hipSetDevice(c->idx->device));
-    uint32_t used = 0;
-    HIP_TRY(hipMemcpy(&used, c->d_batch_flags, sizeof used, hipMemcpyDeviceToHost));
-    *n_words = used;
-    if (on_device) { *words = c->d_cig_ext; return 0; }
-    c->h_cig_ext.resize(used);
-    if (used) HIP_TRY(hipMemcpy(c->h_cig_ext.data(), c->d_cig_ext, (size_t)used * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    *words = c->h_cig_ext.data();
+    if (!c || !n_words) return fail(MCX_ERR_ARG, "mcx_cigar_words: null argument");
+    *n_words = c->run.cig_words;
     return 0;
 }
 

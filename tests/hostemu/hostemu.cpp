@@ -31,6 +31,7 @@ struct Emu {
     int mapq_rows = 0;
     Caps caps[2];
     Layout lay[2];
+    uint32_t cig_used = 0; // words taken in the batch's CIGAR pool
 };
 
 static void set_view(Emu &e)
@@ -85,7 +86,7 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
     cx.ix = e.view; cx.pm = e.pm; cx.pm.paired = b.paired; cx.caps = e.caps[tier]; cx.lay = e.lay[tier];
     cx.detail = nullptr; cx.dlay = make_detail_layout(256);
     cx.state = state.data(); cx.mapq_tab = e.mapq.data(); cx.mapq_rows = e.mapq_rows;
-    cx.cig_ext = nullptr; cx.cig_ext_n = nullptr; cx.cig_ext_cap = 0;
+    cx.cig_pool = cig.data(); cx.cig_pool_n = &e.cig_used; cx.cig_pool_cap = (uint32_t)cig.size();
     std::vector<DpJob> jobs;
     std::vector<uint32_t> kq(4096), kg(e.caps[tier].kmer_cap + 16);
     std::vector<uint32_t> ov;
@@ -178,9 +179,8 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
         ReadRef rd[2];
         make_reads(b, ids[l], rd);
         const uint32_t pair = ids[l];
-        AlnRec *r0 = recs.data() + (int64_t)pair * nr - (int64_t)l * nr;
-        uint32_t *c0 = cig.data() + ((int64_t)pair * nr - (int64_t)l * nr) * cx.caps.cig_cap;
-        stage_finish(cx, l, rd, r0, c0, nullptr);
+        AlnRec *r0 = recs.data() + (int64_t)pair * nr - (int64_t)l * nr; // stage_finish indexes the records by l * nr + s
+        stage_finish(cx, l, rd, r0, nullptr);
         PairState st = pair_state(cx.state, cx.lay, cx.caps, l);
         const PairHdr &h = *st.hdr;
         PairOut o;
@@ -264,7 +264,8 @@ int64_t hostemu_map_files(const char *prefix, const char *fq1, const char *fq2, 
         b.paired = paired && (n % 2 == 0);
         const uint32_t n_pairs = b.paired ? n / 2 : n;
         std::vector<AlnRec> recs(n);
-        std::vector<uint32_t> cig((size_t)n * 32);
+        std::vector<uint32_t> cig((size_t)n * 64); // the batch's CIGAR pool (re-runs take new words)
+        e.cig_used = 0;
         std::vector<PairOut> pout(n_pairs);
         std::vector<uint32_t> ids(n_pairs);
         for (uint32_t i = 0; i < n_pairs; i++) ids[i] = i;
@@ -287,7 +288,7 @@ int64_t hostemu_map_files(const char *prefix, const char *fq1, const char *fq2, 
         for (uint32_t p = 0; p < n_pairs; p++) mapped += pout[p].mapped;
         if (sam)
             for (uint32_t i = 0; i < n; i++) {
-                sam_line(e.hix, b.reads[i], b.paired && (i & 1), f1.fastq(), recs[i], cig.data() + (size_t)i * 32, line);
+                sam_line(e.hix, b.reads[i], b.paired && (i & 1), f1.fastq(), recs[i], cig.data() + (size_t)recs[i].pad[0], line);
                 fputs(line.c_str(), sam); fputc('\n', sam);
             }
     }

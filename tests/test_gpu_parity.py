@@ -59,27 +59,45 @@ def test_extend_equals_reference_vectors(api, toy, alg):
 
 @pytest.mark.parametrize("alg", ["nw", "ksw2"])
 @pytest.mark.parametrize("name", list(SETS))
-def test_sam_equals_reference(api, golden, tmp_path, name, alg):
+@pytest.mark.parametrize("full_sa", [True, False])
+def test_sam_equals_reference(api, golden, tmp_path, name, alg, full_sa):
+    """The reference's -t 1 SAM on every golden set, both algorithms.  full_sa (the product's default): every
+    suffix-array entry in HBM and the fused per-pair kernel (k_pair_fast) for the pairs that fit it, the
+    general path (k_cluster / k_rescue / k_build / k_dp_* / k_finish) for the rest; without it the sampled
+    suffix array (k_sa) and the general path for everything."""
     g = golden[name]
-    ix = api.Index(g["prefix"], device=0)
+    ix = api.Index(g["prefix"], device=0, full_sa=full_sa)
     mp = api.Mapper(ix, alg=alg, max_batch_reads=1 << 14)
     out = str(tmp_path / "gpu.sam")
     st = mp.map_files(g["r1"], g["r2"], out)
     assert st["reads"] > 0
     nd, ex = sam_diff(g["sam"][alg], out)
     assert nd == 0, ex
+    if full_sa and name != "long":  # (250-base reads do not fit the fused kernel's slice of LDS: all of them take the general path)
+        assert st["fast_pairs"] > 0.5 * st["reads"] / (2 if g["r2"] else 1), st  # the fused kernel did take the bulk
+    elif not full_sa:
+        assert st["fast_pairs"] == 0
     mp.close(); ix.close()
 
 
-def test_full_suffix_array_in_hbm_gives_the_same_sam(api, golden, tmp_path):
-    g = golden["mc"]
-    ix = api.Index(g["prefix"], device=0, full_sa=True)
-    mp = api.Mapper(ix, alg="ksw2", max_batch_reads=1 << 14)
-    out = str(tmp_path / "gpu.sam")
-    mp.map_files(g["r1"], g["r2"], out)
-    nd, ex = sam_diff(g["sam"]["ksw2"], out)
-    assert nd == 0, ex
-    mp.close(); ix.close()
+def test_fused_kernel_and_general_path_agree(api, golden, tmp_path, monkeypatch):
+    """Every pair through the general path (MCX_NO_FAST) against the default split between k_pair_fast and the general
+    path: the same SAM, byte for byte, on the variant-rich set."""
+    g = golden["var"]
+    outs = []
+    for no_fast in ("1", ""):
+        if no_fast:
+            monkeypatch.setenv("MCX_NO_FAST", no_fast)
+        else:
+            monkeypatch.delenv("MCX_NO_FAST", raising=False)
+        ix = api.Index(g["prefix"], device=0, full_sa=True)
+        mp = api.Mapper(ix, alg="nw", max_batch_reads=1 << 14)
+        out = str(tmp_path / f"gpu{no_fast}.sam")
+        st = mp.map_files(g["r1"], g["r2"], out)
+        assert (st["fast_pairs"] == 0) == bool(no_fast)
+        outs.append(open(out, "rb").read())
+        mp.close(); ix.close()
+    assert outs[0] == outs[1]
 
 
 def test_small_batches_follow_the_avgdist_trajectory(api, golden, tmp_path):
@@ -214,7 +232,7 @@ def test_alignment_profile_equals_reference(api, golden, tmp_path, name):
     import torch
     g = golden[name]
     alg, prof, maps = g["prof"]
-    ix = api.Index(g["prefix"], device=0)
+    ix = api.Index(g["prefix"], device=0, full_sa=True)
     G = ix.genome_size
     mp = api.Mapper(ix, alg=alg, max_batch_reads=1000)  # several batches: the duplicate cap spans them
     planes = torch.zeros((10, G), dtype=torch.int32, device="cuda")
@@ -238,7 +256,7 @@ def test_vcf_equals_reference(api, golden, tmp_path, name, tag):
     import torch
     g = golden[name]
     o = VcfOpts(VCF_RUNS[tag][1]).struct
-    ix = api.Index(g["prefix"], device=0)
+    ix = api.Index(g["prefix"], device=0, full_sa=True)
     mp = api.Mapper(ix, alg=vcf_alg(name, tag), max_batch_reads=4000)
     planes = torch.zeros((10, ix.genome_size), dtype=torch.int32, device="cuda")
     mp.profile_attach(planes.data_ptr(), max_dup=o.max_dup, max_clip=o.max_clip)
@@ -298,7 +316,8 @@ def test_cli_two_libraries(io_golden, tmp_path):
 
 
 def test_full_size_genome_prefix_equals_reference(api, tmp_path):
-    """bench.py's workload at full size (GRCh38-sized 3.1 Gbp synthetic genome: 6.2 G text positions,
+    """bench.py's workload at full size (GRCh38-sized 3.1 Gbp synthetic genome with its human-like repeat landscape — reads with
+    hundreds of seed hits, mate rescue, the large-capacity tier: 6.2 G text positions,
     the bucketed index builder, the 15-mer jump table, the full suffix array in HBM): the index is built on the GPU, saved, and the
     first 60 k pairs of a bench batch go through the product's file path and through the CPU checker
     (the compiled reference at -t 1 when it travelled, else the oracle restatement).  The insert-size
@@ -309,8 +328,8 @@ def test_full_size_genome_prefix_equals_reference(api, tmp_path):
     import bench
     from mapcaller_amd import synth
     dev = torch.device("cuda", 0)
-    args = argparse.Namespace(genome_mbp=3100.0, contigs=24, repeats=2000)
-    codes, lens = bench.make_genome(args, dev, seed=1234)
+    args = argparse.Namespace(genome_mbp=3100.0, contigs=24, repeats=2000, genome="human")  # bench.py's default: the human-like repeat landscape
+    codes, lens, _ = bench.make_genome(args, dev, seed=1234)
     ix = api.Index.from_codes(codes.data_ptr(), lens, device=0, full_sa=True)
     prefix = str(tmp_path / "big")
     ix.save(prefix)
@@ -332,7 +351,7 @@ def test_full_size_genome_prefix_equals_reference(api, tmp_path):
         _oracle_sam(prefix, f1, f2, "ksw2", chk)
     nd, ex = sam_diff(chk, out)
     assert nd == 0, ex
-    assert st["mapped"] > 0.98 * st["reads"]
+    assert st["mapped"] > 0.95 * st["reads"]
 
 
 def test_ragged_reads_equal_oracle(api, tmp_path):
