@@ -243,6 +243,15 @@ constexpr int kDpTinyLds = 2 * kDpTiny + (2 * kDpTiny - 1) * kDpTiny; // q(8) + 
 constexpr int kDpSmallT = 16, kDpSmallQ = 32;
 constexpr int kDpSmallLds = 64 + (kDpSmallQ + kDpSmallT - 1) * kDpSmallT; // q(32) + t(16) + pad + dir
 
+// the job lists of the DP stage: dp_class 0..3 + 4: the tiny ones of class 0 (k_dp_tiny), 5: the short ones of class 1 (k_dp_half)
+constexpr int kDpClasses = 6;
+struct JobSinks { JobSink s[kDpClasses]; };
+static __device__ __forceinline__ int job_class(const DpJob &j)
+{
+    const int c = dp_class(j.rLen, j.gLen);
+    return (c == 0 && j.rLen <= kDpTiny && j.gLen <= kDpTiny) ? 4 : ((c == 1 && j.gLen <= 32 && j.rLen <= 64) ? 5 : c);
+}
+
 #endif // __HIPCC__
 
 } // namespace mcx

@@ -31,7 +31,13 @@ struct Ctx {
     uint32_t *cig_pool;
     uint32_t *cig_pool_n;     // words taken so far (device: reserved per wave with one atomic)
     uint32_t cig_pool_cap;
+    // the batch's reads as 2-bit words (k_pack_reads; null on the host) and, per read, bit 31 = it holds an N (k_seed)
+    const uint32_t *packed;
+    int32_t wpad;
+    const uint32_t *read_ext;
 };
+
+constexpr int kCigStage = 4; // CIGAR operations per read that the finish stage keeps at hand between counting and writing them
 
 static inline MCX_HD int64_t hit_pd(const Hit &h) { return h.gPos - h.rPos; }
 
@@ -262,6 +268,34 @@ static inline MCX_HD int diag_scan(const uint32_t *kq, int qlen, const uint32_t 
     return total;
 }
 
+// The same total for one diagonal without a chain of dependent steps: the diagonal's matches as a bit string, 61 new
+// bits at a time behind 3 bits of history.  A run of L >= 3 matches contributes L + 7; it holds L - 2 "triples" (three
+// matches in a row), so the sum is (number of triples) + 9 x (number of runs that hold one).  A triple is counted in the
+// word its last match falls into; a run starts where a triple has no triple right before it.
+static inline MCX_HD int diag_total(const uint32_t *kq, int qlen, const uint32_t *kg, int slen, int d)
+{
+    const int r0 = d < 0 ? -d : 0, r1 = qlen - 1 < slen - 1 - d ? qlen - 1 : slen - 1 - d;
+    int total = 0;
+    uint64_t hist = 0; // the last three matches before the word, bit 2 the most recent
+    for (int base = r0; base <= r1; base += 61) {
+        uint64_t e = hist;
+        const int n = r1 - base + 1 < 61 ? r1 - base + 1 : 61;
+        for (int i = 0; i < n; i++) {
+            const uint32_t q = kq[base + i];
+            e |= (uint64_t)(q != MCX_NOKMER && q == kg[base + i + d]) << (3 + i);
+        }
+        const uint64_t t = e & (e >> 1) & (e >> 2);   // bit i: matches at i, i+1, i+2
+        const uint64_t own = t & ~(uint64_t)1;        // (the triple at bit 0 ended in the word before)
+#if defined(__HIP_DEVICE_COMPILE__)
+        total += __popcll(own) + 9 * __popcll(own & ~(t << 1));
+#else
+        total += __builtin_popcountll(own) + 9 * __builtin_popcountll(own & ~(t << 1));
+#endif
+        hist = (e >> 61) & 7u;
+    }
+    return total;
+}
+
 // Serial evaluation of one rescue window (host emulation, and the reference semantics the
 // wave-cooperative version below must reproduce): IdentifyCommonKmers +
 // GenerateSimplePairsFromCommonKmers + IdentifyBestAlnCan.
@@ -347,7 +381,7 @@ struct RescueWave { // one workgroup (any number of wavefronts) evaluates one pa
         int best_total = 0, best_d = 0x7fffffff, dummy = 0;
         bool ovd = false;
         for (int d = -(qlen - 1) + tid; d <= slen - 1; d += nt) {
-            const int total = diag_scan(kq, qlen, kg, slen, d, left, nullptr, 0, 0, dummy, ovd);
+            const int total = diag_total(kq, qlen, kg, slen, d);
             if (total > best_total) { best_total = total; best_d = d; }
         }
         for (int o = 32; o > 0; o >>= 1) {
@@ -620,6 +654,32 @@ static inline MCX_HD int frag_ref_code(const IndexView &ix, const Frag &f, bool 
     return ref_code(ix, rev ? f.gPos + f.gLen - 1 - y : f.gPos + y);
 }
 
+// bases of a gap fragment with rLen == gLen where read and genome differ (an N on either side differs).  The count does
+// not depend on the direction the reference walks the strings in.  A read that carries its 2-bit words (no N) is compared
+// sixteen bases at a time: the read's words against a funnel shift of the 2-bit genome.
+static inline MCX_HD int frag_mismatches(const IndexView &ix, const Frag &x, const ReadRef &rd)
+{
+    const int n = x.rLen;
+    int mm = 0;
+    if (rd.codes) {
+        for (int k = 0; k < n; k += 16) {
+            const int p = x.rPos + k, w = p >> 4, sh = (p & 15) * 2;
+            const uint32_t hi = rd.codes[w], lo = (p & 15) ? rd.codes[w + 1] : 0u; // (a read's words are followed by one more of the slice: never out of bounds)
+            const uint32_t rw = sh ? (hi << sh) | (lo >> (32 - sh)) : hi;
+            uint32_t d = rw ^ ref_codes16(ix, x.gPos + k);
+            d = (d | (d >> 1)) & 0x55555555u;
+            const int left = n - k;
+            if (left < 16) d &= ~0u << (2 * (16 - left));
+            mm += __builtin_popcount(d);
+        }
+        return mm;
+    }
+    const bool rev = x.gPos >= ix.G;
+    for (int k = 0; k < n; k++)
+        if (read_code(rd, rev ? x.rPos + n - 1 - k : x.rPos + k) != ref_code(ix, rev ? x.gPos + n - 1 - k : x.gPos + k)) mm++;
+    return mm;
+}
+
 struct JobSink {
     DpJob *jobs;
     uint32_t *count;
@@ -679,13 +739,10 @@ static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef 
             for (int i = 0; i < nf; i++) {
                 Frag x = f[i]; // worked on in registers, stored back once
                 if (x.kind == kSimple) continue;
-                bool rev = x.gPos >= cx.ix.G;
                 if (x.rLen > 0 && x.gLen > 0) {
                     bool dp = x.rLen != x.gLen;
                     if (!dp) {
-                        int mm = 0;
-                        for (int k = 0; k < x.rLen; k++)
-                            if (frag_read_code(x, rd[s], rev, k) != frag_ref_code(cx.ix, x, rev, k)) mm++;
+                        const int mm = frag_mismatches(cx.ix, x, rd[s]);
                         dp = mm > 1 && mm >= (int)(x.rLen * 0.2);
                     }
                     if (dp) {
@@ -748,6 +805,11 @@ struct ColStats { int switches, n, mis, match; };
 static inline MCX_HD ColStats frag_columns(const IndexView &ix, const Frag &f, const uint8_t *ops, const ReadRef &rd)
 {
     ColStats cs; cs.switches = cs.n = cs.mis = cs.match = 0;
+    if (f.kind != kDp) { // one kind of column throughout: no walk
+        if (f.ops_len > 0) cs.switches = 1;
+        if (f.kind == kPlain) { cs.n = f.ops_len; cs.mis = frag_mismatches(ix, f, rd); cs.match = cs.n - cs.mis; }
+        return cs;
+    }
     bool rev = f.gPos >= ix.G;
     int kind = -1, ri = 0, gi = 0;
     for (int x = 0; x < f.ops_len; x++) {
@@ -900,8 +962,9 @@ static inline MCX_HD int cigar_of(int rlen, const Cand &c, const Frag *frags, co
         if (f.kind == kSimple) { flush_to(0); run += f.rLen; }
         else if (f.kind == kEmpty) continue;
         else if (f.ops_len > 0) {
-            for (int x = 0; x < f.ops_len; x++) {
-                uint8_t o = frag_op(f, ops, x);
+            if (f.kind != kDp) { flush_to(f.kind == kDel ? 2 : (f.kind == kIns ? 1 : 0)); run += f.ops_len; } // one kind of column throughout
+            else for (int x = 0; x < f.ops_len; x++) {
+                const uint8_t o = ops[f.ops_off + x];
                 flush_to(o == 'D' ? 2 : (o == 'I' ? 1 : 0));
                 run++;
             }
@@ -974,7 +1037,7 @@ static inline MCX_HD void pair_stats(const Ctx &cx, PairState &st, DetailHdr *dh
 // read in unique mode (SamReport.cpp:324-488).  cig: where the read's n_cig operations go (counted by
 // finish_scores, reserved in the batch's pool by the caller), cig_off: that place as a pool offset.
 static inline MCX_HD void emit_record(const Ctx &cx, PairState &st, int s, const ReadRef *rd, AlnRec &dst,
-                                      uint32_t *cig, int n_cig, uint32_t cig_off)
+                                      uint32_t *cig, int n_cig, uint32_t cig_off, const uint32_t *staged = nullptr)
 {
     PairHdr &h = *st.hdr;
     const ReadSum me = h.sum[s];
@@ -1005,7 +1068,9 @@ static inline MCX_HD void emit_record(const Ctx &cx, PairState &st, int s, const
     out.chr = km.chr; out.pos = km.pos;
     out.fwd = c.fwd;
     out.nm = rd[s].rlen - c.score; out.as = me.score; out.xs = me.sub;
-    out.n_cigar = cig ? cigar_of(rd[s].rlen, c, st.frags, st.ops, cig, n_cig) : 0; // (null: the pool ran over; the batch fails)
+    if (!cig) out.n_cigar = 0; // (the pool ran over; the batch fails)
+    else if (staged && n_cig <= kCigStage) { for (int k = 0; k < n_cig; k++) cig[k] = staged[k]; out.n_cigar = n_cig; }
+    else out.n_cigar = cigar_of(rd[s].rlen, c, st.frags, st.ops, cig, n_cig);
     out.pad[0] = (int32_t)cig_off;
     if (paired) {
         const ReadSum &ot = h.sum[1 - s];
@@ -1074,7 +1139,10 @@ static inline MCX_HD void write_detail(const Ctx &cx, PairState &st, int s, uint
 // Stage G2 comes in two steps so that a wavefront can reserve the CIGAR words of its 64 pairs with one atomic in
 // between.  st.hdr points at the caller's copy of the header (registers on the device).
 // finish_scores: gates, scores, best / sub-best, pair statistics; n_cig[s] = CIGAR operations read s will print.
-static inline MCX_HD void finish_scores(const Ctx &cx, PairState &st, const ReadRef *rd, DetailHdr *dh, int n_cig[2], const IndexView *ixr = nullptr)
+// (stage: room for kCigStage operations per read — most reads have at most that many, and finish_records then copies them
+//  instead of walking the alignment a second time)
+static inline MCX_HD void finish_scores(const Ctx &cx, PairState &st, const ReadRef *rd, DetailHdr *dh, int n_cig[2], const IndexView *ixr = nullptr,
+                                        uint32_t *stage = nullptr)
 {
     PairHdr &h = *st.hdr;
     n_cig[0] = n_cig[1] = 0;
@@ -1087,14 +1155,14 @@ static inline MCX_HD void finish_scores(const Ctx &cx, PairState &st, const Read
     MCX_UNROLL
     for (int s = 0; s < 2; s++) {
         if (s >= nr) break;
-        if (h.sum[s].score > 0) n_cig[s] = cigar_of(rd[s].rlen, st.cands[s][h.sum[s].best], st.frags, st.ops, nullptr, 0);
+        if (h.sum[s].score > 0) n_cig[s] = cigar_of(rd[s].rlen, st.cands[s][h.sum[s].best], st.frags, st.ops, stage ? stage + s * kCigStage : nullptr, stage ? kCigStage : 0);
     }
 }
 
 // finish_records: the pair's output records (rec2[0..nr)), their CIGAR words at cig_pool + cig_off[s] (null pool: the
 // reservation failed), and the alignment detail of its reads when the profile is kept (detail2 = the pair's first record).
 static inline MCX_HD void finish_records(const Ctx &cx, PairState &st, const ReadRef *rd, AlnRec *rec2, uint32_t *cig_pool,
-                                         const uint32_t cig_off[2], const int n_cig[2], uint8_t *detail2)
+                                         const uint32_t cig_off[2], const int n_cig[2], uint8_t *detail2, const uint32_t *stage = nullptr)
 {
     PairHdr &h = *st.hdr;
     if (h.flags & kOvAny) return;
@@ -1102,7 +1170,7 @@ static inline MCX_HD void finish_records(const Ctx &cx, PairState &st, const Rea
     MCX_UNROLL
     for (int s = 0; s < 2; s++) {
         if (s >= nr) break;
-        emit_record(cx, st, s, rd, rec2[s], cig_pool ? cig_pool + cig_off[s] : nullptr, n_cig[s], cig_off[s]);
+        emit_record(cx, st, s, rd, rec2[s], cig_pool ? cig_pool + cig_off[s] : nullptr, n_cig[s], cig_off[s], stage ? stage + s * kCigStage : nullptr);
         if (detail2) write_detail(cx, st, s, detail2 + (int64_t)s * cx.dlay.stride);
     }
 }

@@ -168,6 +168,8 @@ __global__ void k_pack_pac(const uint8_t *codes, uint64_t G, uint8_t *pac)
     }
 }
 
+static int index_from_arrays(mcx_index *ix, const DevIndexArrays &arr, const uint8_t *d_codes, int64_t G);
+
 extern "C" int mcx_index_from_codes(const uint8_t *d_codes, int32_t n_chr, const int32_t *chr_len, const char *const *chr_name,
                                     int device, int full_sa, mcx_index **out, double *build_seconds)
 {
@@ -187,6 +189,16 @@ extern "C" int mcx_index_from_codes(const uint8_t *d_codes, int32_t n_chr, const
     DevIndexArrays arr;
     int rc = mcx_build_suffix_index(d_codes, (uint64_t)G, full_sa != 0, arr, build_seconds);
     if (rc) { delete ix; return rc; }
+    rc = index_from_arrays(ix, arr, d_codes, G);
+    if (rc) { mcx_index_free(ix); return rc; }
+    *out = ix;
+    return 0;
+}
+
+static int index_from_arrays(mcx_index *ix, const DevIndexArrays &arr, const uint8_t *d_codes, int64_t G)
+{
+    HostIndex &h = ix->host;
+    int rc;
     h.primary = arr.primary; for (int i = 0; i < 5; i++) h.L2[i] = arr.L2[i];
     h.seq_len = arr.seq_len; h.sa_intv = 32;
     ix->d_bwt = arr.bwt; ix->d_sa = arr.sa; ix->d_sa_full = arr.sa_full;
@@ -208,9 +220,7 @@ extern "C" int mcx_index_from_codes(const uint8_t *d_codes, int32_t n_chr, const
     v.seq_len = h.seq_len; v.G = h.G; v.G2 = 2 * h.G;
     v.n_ends = (int32_t)h.end_pos.size(); v.n_chr = (int32_t)h.chr_len.size(); v.sa_intv = 32;
     HIP_TRY(hipDeviceSynchronize());
-    if ((rc = build_ktab(ix))) return rc;
-    *out = ix;
-    return 0;
+    return build_ktab(ix);
 }
 
 // writes <prefix>.bwt/.sa/.pac/.ann/.amb from an index built in HBM (no ambiguity holes: the
@@ -294,6 +304,8 @@ static __device__ __forceinline__ void stage_ends(IndexView &ix, EndsLds &l)
     }
 }
 
+// (a read without N also carries its 2-bit words — k_pack_reads' form, in HBM: a base then costs a shift of a word that
+//  sits in L1 instead of a byte fetch and a table look-up, and gap fragments are compared sixteen bases at a time)
 static __device__ __forceinline__ void make_reads(const Ctx &cx, const ReadBatch &rb, uint32_t pair, ReadRef rd[2])
 {
     const int nr = cx.pm.paired ? 2 : 1;
@@ -302,6 +314,7 @@ static __device__ __forceinline__ void make_reads(const Ctx &cx, const ReadBatch
         rd[s].ascii = rb.bases + rb.off[r];
         rd[s].rlen = (int32_t)(rb.off[r + 1] - rb.off[r]);
         rd[s].flipped = (cx.pm.paired && s == 1) ? 1 : 0;
+        rd[s].codes = (cx.packed && !(cx.read_ext[r] >> 31)) ? cx.packed + (uint64_t)r * cx.wpad : nullptr;
     }
 }
 
@@ -313,6 +326,7 @@ struct SeedOut {
     uint32_t *read_blocks;
     const uint32_t *packed;  // 2-bit reads of the batch (k_pack_reads), wpad words each
     int wpad;
+    uint32_t *queue;         // next read of the pass that no wavefront has taken yet
     Hit *fast_hits;          // the fused per-pair kernel's input: the first fast_cap seeds of every read, [read][fast_cap] (null: seeds go to the pair records)
     int fast_cap;
 };
@@ -413,22 +427,23 @@ __global__ void __launch_bounds__(256) k_pack_reads(ReadBatch rb, int paired, in
     }
 }
 
-// Reads are handed to lanes as the lanes become free: a read is one to six searches, and a wave whose
-// lanes each owned one read would run as long as its longest read while most lanes idle.  A block owns
-// a pool of blockDim x kSeedReadsPerLane consecutive reads; a lane that has finished a read takes the
-// pool's next one, so that every search iteration of the wave finds (nearly) all lanes with work.
-constexpr int kSeedReadsPerLane = 4;
+// Reads are handed to lanes as the lanes become free: a read is one to six searches (many more steps each inside a
+// repeat), and a wave whose lanes each owned one read would run as long as its longest read while most lanes idle.
+// The reads of a pass form one queue; a wavefront takes a chunk of it with one atomic whenever its lanes run dry, and a
+// lane that has finished a read takes the chunk's next one — every search iteration of the wave finds (nearly) all
+// lanes with work, and the launch ends when the queue does, not block by block.
+constexpr int kSeedReadsPerLane = 4; // reads per lane and chunk (small selections: one, their launch is as long as its longest chain of reads)
 
-__global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel, SeedOut so, int pk_words)
+static inline int seed_reads_per_lane(uint64_t n_reads) { return n_reads >= (uint64_t)1 << 21 ? kSeedReadsPerLane : (n_reads >= (uint64_t)1 << 19 ? 2 : 1); }
+
+__global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel, SeedOut so, int pk_words, int reads_per_lane)
 {
     extern __shared__ uint32_t pk_lds[]; // packed reads: word k of lane t at pk_lds[k * blockDim.x + t]
-    __shared__ uint32_t next_read;
     const int nr = cx.pm.paired ? 2 : 1;
     const uint32_t total = sel.n * nr;
-    const uint32_t pool0 = blockIdx.x * blockDim.x * kSeedReadsPerLane;
-    const uint32_t pool_n = min((uint32_t)(blockDim.x * kSeedReadsPerLane), total - pool0);
-    if (threadIdx.x == 0) next_read = 0;
-    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const uint32_t chunk = 64u * (uint32_t)reads_per_lane;
     PackedRead pk; pk.w = pk_lds + threadIdx.x; pk.stride = blockDim.x; pk.n_code = 0;
     bool have = false;
     uint32_t lr = 0, r = 0, nm = 0;
@@ -451,26 +466,43 @@ __global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel,
             at++;
         }
     };
+    uint32_t q_next = 0, q_end = 0; // the wave's chunk of the queue (the same in every lane)
+    bool dry = false;               // the queue has nothing left
     for (;;) {
-        bool out = false;
-        while (!have) {
-            const uint32_t i = atomicAdd(&next_read, 1u);
-            if (i >= pool_n) { out = true; break; }
-            lr = pool0 + i;
+        // ---- lanes without a read take the next ones of the wave's chunk (the whole wave passes here every iteration) ----
+        const uint64_t need = __ballot(!have);
+        bool fresh = false;
+        if (need && !dry) {
+            const uint32_t rank = (uint32_t)__popcll(need & lt_mask), want = (uint32_t)__popcll(need);
+            uint32_t given = 0;
+            while (given < want) {
+                if (q_next == q_end) {
+                    uint32_t b = 0;
+                    if (lane == 0) b = atomicAdd(so.queue, chunk);
+                    b = __shfl(b, 0, 64);
+                    if (b >= total) { dry = true; break; }
+                    q_next = b; q_end = min(b + chunk, total);
+                }
+                const uint32_t take = min(want - given, q_end - q_next);
+                if (!have && !fresh && rank >= given && rank < given + take) { lr = q_next + (rank - given); fresh = true; }
+                q_next += take; given += take;
+            }
+        }
+        if (fresh) {
             r = sel_pair(sel, lr / nr) * nr + lr % nr;
             rlen = (int)(rb.off[r + 1] - rb.off[r]);
             if (so.fast_hits) { hits = so.fast_hits + (uint64_t)r * so.fast_cap; cap = so.fast_cap; }
             else hits = pair_state(cx.state, cx.lay, cx.caps, lr / nr).hits[lr % nr];
             n = 0; p = 0; ext = 0; blocks = 0; has_n = 0;
-            const int need = packed_words(rlen);
-            if (rlen > 0 && need <= pk_words) {
+            const int words = packed_words(rlen);
+            if (rlen > 0 && words <= pk_words) {
                 const U4 *src = (const U4 *)(so.packed + (uint64_t)r * so.wpad);
-                for (int k = 0; k < need; k += 4) {
+                for (int k = 0; k < words; k += 4) {
                     const U4 v = src[k >> 2];
                     pk.w[k * pk.stride] = v.x;
-                    if (k + 1 < need) pk.w[(k + 1) * pk.stride] = v.y;
-                    if (k + 2 < need) pk.w[(k + 2) * pk.stride] = v.z;
-                    if (k + 3 < need) pk.w[(k + 3) * pk.stride] = v.w;
+                    if (k + 1 < words) pk.w[(k + 1) * pk.stride] = v.y;
+                    if (k + 2 < words) pk.w[(k + 2) * pk.stride] = v.z;
+                    if (k + 3 < words) pk.w[(k + 3) * pk.stride] = v.w;
                 }
                 pk.n_code = ((rlen + 15) >> 4) + 1;
                 { // does the read hold an N?  (mask words: bit 31-s of word s/32; bases past the end are flagged too)
@@ -485,11 +517,14 @@ __global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel,
                 }
                 have = seed_next_start(pk, rlen, p, nm);
             }
-            if (!have) finish_read();
+            if (!have) finish_read(); // (nothing to search in it: the lane takes another one next time round)
         }
-        if (out) break;
-        seed_search(cx.ix, pk, rlen, nm, p, hits, cap, n, ext, blocks);
-        if (!seed_next_start(pk, rlen, p, nm)) { finish_read(); have = false; }
+        if (!__ballot(have)) { if (dry) break; continue; }
+        // ---- one search of every lane that holds a read ----
+        if (have) {
+            seed_search(cx.ix, pk, rlen, nm, p, hits, cap, n, ext, blocks);
+            if (!seed_next_start(pk, rlen, p, nm)) { finish_read(); have = false; }
+        }
     }
 }
 
@@ -549,8 +584,6 @@ __global__ void __launch_bounds__(kRescueThreads) k_rescue(Ctx cx, ReadBatch rb,
     }
 }
 
-constexpr int kDpClasses = 6; // dp_class 0..3 + 4: the tiny ones of class 0, 5: the short ones of class 1 (k_dp_half)
-struct JobSinks { JobSink s[kDpClasses]; };
 
 // fragment lists + DP problems of every pair; the problems are appended to one list per size
 // class (mcx_glue.h dp_class) with one atomic per wave and class
@@ -565,7 +598,6 @@ __global__ void __launch_bounds__(256) k_build(Ctx cx, ReadBatch rb, PairSel sel
         make_reads(cx, rb, sel_pair(sel, local), rd);
         nj = stage_build(cx, local, rd);
     }
-    auto job_class = [](const DpJob &j) { const int c = dp_class(j.rLen, j.gLen); return (c == 0 && j.rLen <= kDpTiny && j.gLen <= kDpTiny) ? 4 : ((c == 1 && j.gLen <= 32 && j.rLen <= 64) ? 5 : c); };
     uint32_t per_class[kDpClasses] = {0, 0, 0, 0, 0, 0}, my_cells = 0, bad = 0;
     for (int k = 0; k < nj; k++) {
         const DpJob j = pair_job(cx, local, k);
@@ -695,8 +727,10 @@ __global__ void __launch_bounds__(256, 7) k_finish(Ctx cx, ReadBatch rb, PairSel
                                                 uint32_t ov_cap, uint32_t *pool_over)
 {
     __shared__ EndsLds ends;
+    __shared__ uint32_t cig_stage[256 * 2 * kCigStage]; // the first operations of every read, lane-major (8 words per lane: no bank shared within a quarter wave)
     stage_ends(cx.ix, ends);
     const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t *stage = cig_stage + threadIdx.x * 2 * kCigStage;
     const bool active = local < sel.n; // (no early exit: the wave reserves its CIGAR words together)
     const int nr = cx.pm.paired ? 2 : 1;
     uint32_t pair = 0;
@@ -712,7 +746,7 @@ __global__ void __launch_bounds__(256, 7) k_finish(Ctx cx, ReadBatch rb, PairSel
         h = *st.hdr;
         st.hdr = &h;
         detail2 = cx.detail ? cx.detail + (int64_t)pair * nr * cx.dlay.stride : nullptr; // records are indexed by batch read
-        finish_scores(cx, st, rd, (DetailHdr *)detail2, n_cig);
+        finish_scores(cx, st, rd, (DetailHdr *)detail2, n_cig, nullptr, stage);
     }
     const uint32_t want = (uint32_t)(n_cig[0] + n_cig[1]);
     const uint32_t at = wave_reserve(cx.cig_pool_n, want);
@@ -720,7 +754,7 @@ __global__ void __launch_bounds__(256, 7) k_finish(Ctx cx, ReadBatch rb, PairSel
     const bool fits = at + want <= cx.cig_pool_cap;
     if (!fits) atomicOr(pool_over, 1u);
     const uint32_t off[2] = {at, at + (uint32_t)n_cig[0]};
-    finish_records(cx, st, rd, recs + (int64_t)pair * nr, fits ? cx.cig_pool : nullptr, off, n_cig, detail2);
+    finish_records(cx, st, rd, recs + (int64_t)pair * nr, fits ? cx.cig_pool : nullptr, off, n_cig, detail2, stage);
     PairOut o;
     o.flags = h.flags; o.est = h.est; o.est_lo = h.est_lo; o.est_hi = h.est_hi;
     o.pair_dist = h.pair_dist; o.pair_ok = (int16_t)h.pair_ok; o.mapped = (int16_t)h.mapped;
@@ -745,7 +779,7 @@ struct Tier {
 constexpr int kCntPad = 64;
 enum { CNT_TASKS = 0, CNT_RESCUE = 1 * kCntPad, CNT_JOB0 = 2 * kCntPad, CNT_JOB1 = 3 * kCntPad, CNT_JOB2 = 4 * kCntPad, CNT_JOB3 = 5 * kCntPad,
        CNT_JOB4 = 6 * kCntPad, CNT_JOB5 = 7 * kCntPad, CNT_OV = 8 * kCntPad, CNT_LF = 9 * kCntPad, CNT_CELLS = 10 * kCntPad, CNT_UNSUP = 11 * kCntPad,
-       CNT_N = 12 * kCntPad };
+       CNT_QUEUE = 12 * kCntPad, CNT_N = 13 * kCntPad };
 
 struct BatchRun { // the batch between mcx_batch_begin and mcx_batch_end
     bool open = false, sums_valid = false, keys_out = false;
@@ -796,7 +830,8 @@ struct mcx_ctx {
     // the fused per-pair kernel (mcx_fast.h)
     bool fast_on = false; FastCaps fcaps; size_t fast_lds = 0;
     Hit *d_fast_hits = nullptr; uint32_t *d_spill = nullptr; uint32_t *h_spill = nullptr;
-    hipEvent_t ev_fast[3] = {nullptr, nullptr, nullptr};
+    uint8_t *d_saved = nullptr; // parked slices: pairs waiting for the DP kernels
+    hipEvent_t ev_fast[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     BatchRun run;
     // mcx_stream_*: three batches in flight (copy in | kernels | copy out), each in a slot of its own
     struct Slot {
@@ -841,6 +876,8 @@ static Caps tier1_caps(int rlen_max)
 template <class T>
 static int dmalloc(T **p, size_t n) { HIP_TRY(hipMalloc((void **)p, n * sizeof(T))); return 0; }
 
+static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o);
+
 extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ctx **out)
 {
     if (!idx || !out) return fail(MCX_ERR_ARG, "mcx_ctx_create: null argument");
@@ -850,6 +887,15 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
     if (o.max_read_len > 1000) return fail(MCX_ERR_UNSUPPORTED, "max_read_len > 1000 is not supported");
     if (o.max_batch_reads < 2) o.max_batch_reads = 2;
     mcx_ctx *c = new mcx_ctx();
+    for (auto &e : c->ev) e = nullptr;
+    const int rc = ctx_fill(c, idx, o);
+    if (rc) { mcx_ctx_free(c); return rc; } // (every pointer of the context starts null: a caller that retries with a smaller batch finds the HBM free again)
+    *out = c;
+    return 0;
+}
+
+static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
+{
     c->idx = idx; c->opts = o;
     c->pm.max_pos_diff = o.max_pos_diff; c->pm.max_mm_rate = o.max_mismatch_rate; c->pm.use_nw = o.alg == 0; c->pm.paired = 1;
     c->rlen_max = o.max_read_len;
@@ -913,7 +959,7 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
     HIP_TRY(hipMemcpy(c->d_mapq, tab.data(), tab.size(), hipMemcpyHostToDevice));
     // the fused per-pair kernel: needs every suffix-array entry resident (seeds then leave k_seed as text positions)
     // and a slice of LDS per lane that the read length decides (reads up to 16 x code_words bases take it)
-    if (idx->view.sa_full && !getenv("MCX_NO_FAST")) {
+    if (idx->view.sa_full && getenv("MCX_FAST") && !getenv("MCX_NO_FAST")) {
         const int fast_rlen = std::min(c->rlen_max, 160);
         c->fcaps = make_fast_caps(fast_rlen, idx->view.n_ends, idx->view.n_chr);
         if (const char *e = getenv("MCX_FAST_CAPS")) { // experiments: "hits,slots"
@@ -925,9 +971,11 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
                 if (((c->fcaps.stride / 16) & 1) == 0) { c->fcaps.stride += 16; c->fcaps.slots++; }
             }
         }
-        c->fast_lds = (size_t)c->fcaps.ends_bytes + c->fcaps.wave_bytes + (size_t)64 * c->fcaps.stride;
+        c->fast_lds = (size_t)c->fcaps.ends_bytes + (size_t)64 * c->fcaps.stride;
         if (c->fast_lds <= 160 * 1024 - 256) {
             HIP_TRY(hipFuncSetAttribute((const void *)k_pair_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fast_lds));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_pair_fast_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fast_lds));
+            if ((rc = dmalloc(&c->d_saved, (size_t)(c->max_reads + 64) * (size_t)save_stride(c->fcaps)))) return rc; // (single reads: as many pairs as reads)
             if ((rc = dmalloc(&c->d_fast_hits, c->max_reads * (uint64_t)c->fcaps.hit_cap))) return rc;
             if ((rc = dmalloc(&c->d_spill, c->max_reads))) return rc;
             HIP_TRY(hipHostMalloc((void **)&c->h_spill, c->max_reads * sizeof(uint32_t)));
@@ -935,7 +983,6 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
             c->fast_on = true;
         }
     }
-    *out = c;
     return 0;
 }
 
@@ -945,7 +992,7 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3], c->d_jobs[4], c->d_jobs[5],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
                  c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
-                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_packed, c->d_batch_flags, c->d_fast_hits, c->d_spill};
+                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_packed, c->d_batch_flags, c->d_fast_hits, c->d_spill, c->d_saved};
     for (void *q : p) if (q) (void)hipFree(q);
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
     if (c->h_pout) (void)hipHostFree(c->h_pout);
@@ -975,6 +1022,7 @@ static Ctx make_ctx(const mcx_ctx *c, int tier, int paired)
     cx.mapq_tab = c->d_mapq; cx.mapq_rows = c->mapq_rows;
     cx.detail = c->prof_planes ? c->d_detail : nullptr; cx.dlay = c->dlay;
     cx.cig_pool = c->run.cig; cx.cig_pool_n = c->d_batch_flags; cx.cig_pool_cap = c->run.cig_cap;
+    cx.packed = c->d_packed; cx.wpad = c->wpad; cx.read_ext = c->d_read_ext;
     return cx;
 }
 
@@ -984,6 +1032,23 @@ static Ctx make_ctx(const mcx_ctx *c, int tier, int paired)
 struct StageMs { float seed, sa, cluster, rescue, build, dp, finish; };
 
 constexpr int kListOverflow = 1; // (internal) a work list of run_pairs was too short for the selection
+
+// the DP job lists of a pass, one kernel per size class: they work on disjoint lists and are each bound by latency at
+// modest occupancy, so side streams let them share the chip instead of queueing behind one another
+static int launch_dp(mcx_ctx *c, const Ctx &cx, const JobSinks &sinks, const ReadBatch &rb, const PairSel &sel)
+{
+    hipStream_t s = c->stream;
+    HIP_TRY(hipEventRecord(c->dp_fork, s));
+    for (int k = 0; k < 5; k++) HIP_TRY(hipStreamWaitEvent(c->dp_stream[k], c->dp_fork, 0));
+    k_dp_sel<1><<<c->dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, c->d_dp_scratch[0], c->dp_stride[0]);
+    k_dp_small<<<2560, 256, 0, c->dp_stream[0]>>>(cx, sinks.s[0], rb, sel);
+    k_dp_tiny<<<2048, 256, 0, c->dp_stream[3]>>>(cx, sinks.s[4], rb, sel);
+    k_dp_half<<<2048, 256, 0, c->dp_stream[4]>>>(cx, sinks.s[5], rb, sel);
+    k_dp_sel<4><<<c->dp_blocks[1], 64, 0, c->dp_stream[1]>>>(cx, sinks.s[2], rb, sel, c->d_dp_scratch[1], c->dp_stride[1]);
+    k_dp_sel<16><<<c->dp_blocks[2], 64, 0, c->dp_stream[2]>>>(cx, sinks.s[3], rb, sel, c->d_dp_scratch[2], c->dp_stride[2]);
+    for (int k = 0; k < 5; k++) { HIP_TRY(hipEventRecord(c->dp_join[k], c->dp_stream[k])); HIP_TRY(hipStreamWaitEvent(s, c->dp_join[k], 0)); }
+    return 0;
+}
 
 static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, PairSel sel, AlnRec *d_recs,
                      uint32_t *d_cig, mcx_stats *stats, bool timing)
@@ -995,19 +1060,20 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
     SeedOut so; so.tasks = c->d_tasks; so.n_tasks = c->d_cnt + CNT_TASKS; so.task_cap = c->task_cap;
     so.read_ext = c->d_read_ext; so.read_blocks = c->d_read_blocks;
-    so.packed = c->d_packed; so.wpad = c->wpad; so.fast_hits = nullptr; so.fast_cap = 0;
+    so.packed = c->d_packed; so.wpad = c->wpad; so.fast_hits = nullptr; so.fast_cap = 0; so.queue = c->d_cnt + CNT_QUEUE;
     RescueList rl; rl.ids = c->d_rescue; rl.n = c->d_cnt + CNT_RESCUE; rl.cap = c->rescue_cap;
     JobSinks sinks;
     for (int k = 0; k < kDpClasses; k++) { sinks.s[k].jobs = c->d_jobs[k]; sinks.s[k].count = c->d_cnt + CNT_JOB0 + k * kCntPad; sinks.s[k].cap = c->job_cap[k]; }
     const unsigned pb = (sel.n + 255) / 256;
-    int e = 0;
+    int e = 0, rc_dp = 0;
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
     {
         // LDS for the packed reads: words per lane for the longest read x lanes; narrower blocks for long reads
         const int pkw = packed_words(c->rlen_max);
         const int threads = pkw * 256 * 4 <= 48 * 1024 ? 256 : (pkw * 128 * 4 <= 48 * 1024 ? 128 : 64);
-        const unsigned blocks_s = (sel.n * nr + threads * kSeedReadsPerLane - 1) / (threads * kSeedReadsPerLane);
-        k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw);
+        const int rpl = seed_reads_per_lane((uint64_t)sel.n * nr);
+        const unsigned blocks_s = std::min<unsigned>((sel.n * nr + threads * rpl - 1) / (threads * rpl), 4096u); // (the queue feeds whatever grid runs)
+        k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl);
     }
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
     k_sa<<<4096, 256, 0, s>>>(cx, so, paired, c->d_cnt + CNT_LF);
@@ -1018,17 +1084,7 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
     k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, c->d_cnt + CNT_CELLS, c->d_cnt + CNT_UNSUP);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
-    // the four size classes work on disjoint job lists and are each bound by latency at modest
-    // occupancy: side streams let them share the chip instead of queueing behind one another
-    HIP_TRY(hipEventRecord(c->dp_fork, s));
-    for (int k = 0; k < 5; k++) HIP_TRY(hipStreamWaitEvent(c->dp_stream[k], c->dp_fork, 0));
-    k_dp_sel<1><<<c->dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, c->d_dp_scratch[0], c->dp_stride[0]);
-    k_dp_small<<<2560, 256, 0, c->dp_stream[0]>>>(cx, sinks.s[0], rb, sel);
-    k_dp_tiny<<<2048, 256, 0, c->dp_stream[3]>>>(cx, sinks.s[4], rb, sel);
-    k_dp_half<<<2048, 256, 0, c->dp_stream[4]>>>(cx, sinks.s[5], rb, sel);
-    k_dp_sel<4><<<c->dp_blocks[1], 64, 0, c->dp_stream[1]>>>(cx, sinks.s[2], rb, sel, c->d_dp_scratch[1], c->dp_stride[1]);
-    k_dp_sel<16><<<c->dp_blocks[2], 64, 0, c->dp_stream[2]>>>(cx, sinks.s[3], rb, sel, c->d_dp_scratch[2], c->dp_stride[2]);
-    for (int k = 0; k < 5; k++) { HIP_TRY(hipEventRecord(c->dp_join[k], c->dp_stream[k])); HIP_TRY(hipStreamWaitEvent(s, c->dp_join[k], 0)); }
+    if ((rc_dp = launch_dp(c, cx, sinks, rb, sel))) return rc_dp;
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
     k_finish<<<pb, 256, 0, s>>>(cx, rb, sel, d_recs, c->d_pout, c->d_ov, c->d_cnt + CNT_OV, c->ov_cap, c->d_batch_flags + 2);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
@@ -1125,31 +1181,53 @@ extern "C" void mcx_avg_walk(int64_t st[3], const uint32_t *pairs, const uint32_
 
 // The first pass over a batch: seeding with the seeds laid out for the fused per-pair kernel, then that kernel
 // (mcx_fast.h).  spill receives the pairs it left for the general path, in pair order.
-static int run_fast(mcx_ctx *c, const ReadBatch &rb, int paired, int32_t est, uint32_t n_pairs, AlnRec *d_recs, mcx_stats *stats, std::vector<uint32_t> &spill)
+static int run_fast(mcx_ctx *c, const ReadBatch &rb, int paired, int32_t est, uint32_t n_pairs, AlnRec *d_recs, mcx_stats *stats, std::vector<uint32_t> &spill,
+                    bool &all_general)
 {
+    all_general = false;
     hipStream_t s = c->stream;
     Ctx cx = make_ctx(c, 0, paired);
     const int nr = paired ? 2 : 1;
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
     SeedOut so; so.tasks = c->d_tasks; so.n_tasks = c->d_cnt + CNT_TASKS; so.task_cap = c->task_cap;
     so.read_ext = c->d_read_ext; so.read_blocks = c->d_read_blocks;
-    so.packed = c->d_packed; so.wpad = c->wpad; so.fast_hits = c->d_fast_hits; so.fast_cap = c->fcaps.hit_cap;
+    so.packed = c->d_packed; so.wpad = c->wpad; so.fast_hits = c->d_fast_hits; so.fast_cap = c->fcaps.hit_cap; so.queue = c->d_cnt + CNT_QUEUE;
     PairSel sel; sel.n = n_pairs; sel.ids = nullptr; sel.est = nullptr;
     HIP_TRY(hipEventRecord(c->ev_fast[0], s));
     {
         const int pkw = packed_words(c->rlen_max);
         const int threads = pkw * 256 * 4 <= 48 * 1024 ? 256 : (pkw * 128 * 4 <= 48 * 1024 ? 128 : 64);
-        const unsigned blocks_s = (n_pairs * nr + threads * kSeedReadsPerLane - 1) / (threads * kSeedReadsPerLane);
-        k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw);
+        const int rpl = seed_reads_per_lane((uint64_t)n_pairs * nr);
+        const unsigned blocks_s = std::min<unsigned>((n_pairs * nr + threads * rpl - 1) / (threads * rpl), 4096u);
+        k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl);
     }
     HIP_TRY(hipEventRecord(c->ev_fast[1], s));
     FastIn in; in.hits = c->d_fast_hits; in.packed = c->d_packed; in.wpad = c->wpad; in.read_ext = c->d_read_ext; in.read_blocks = c->d_read_blocks; in.est = est;
-    k_pair_fast<<<(n_pairs + 63) / 64, 64, c->fast_lds, s>>>(cx, rb, in, c->fcaps, n_pairs, d_recs, c->d_pout, c->d_spill, c->d_cnt + CNT_OV, c->d_batch_flags + 2);
+    JobSinks sinks;
+    for (int k = 0; k < kDpClasses; k++) { sinks.s[k].jobs = c->d_jobs[k]; sinks.s[k].count = c->d_cnt + CNT_JOB0 + k * kCntPad; sinks.s[k].cap = c->job_cap[k]; }
+    // pairs with gapped fragments park their slice of LDS in HBM (d_saved, their pair ids in d_sel_ids), the DP kernels of the
+    // general path align the fragments in the parked slices, k_pair_fast_finish takes them from there
+    k_pair_fast<<<(n_pairs + 63) / 64, 64, c->fast_lds, s>>>(cx, rb, in, c->fcaps, n_pairs, d_recs, c->d_pout, c->d_spill, c->d_cnt + CNT_OV, c->d_saved,
+                                                           c->d_sel_ids, c->d_cnt + CNT_RESCUE, sinks, c->d_cnt + CNT_CELLS, c->d_batch_flags + 2);
     HIP_TRY(hipEventRecord(c->ev_fast[2], s));
+    {
+        Ctx cs = cx; // the parked slices as pair records: fragments at offset 0, column strings behind them
+        cs.state = c->d_saved; cs.lay = save_layout(c->fcaps);
+        cs.caps.hit_cap = c->fcaps.hit_cap; cs.caps.cand_cap = c->fcaps.cand_cap; cs.caps.frag_cap = c->fcaps.slots;
+        PairSel parked; parked.n = n_pairs; parked.ids = c->d_sel_ids; parked.est = nullptr;
+        int rc = launch_dp(c, cs, sinks, rb, parked);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(c->ev_fast[3], s));
+    k_pair_fast_finish<<<(n_pairs + 63) / 64, 64, c->fast_lds, s>>>(cx, rb, c->fcaps, c->d_saved, c->d_cnt + CNT_RESCUE, d_recs, c->d_pout, c->d_batch_flags + 2);
+    HIP_TRY(hipEventRecord(c->ev_fast[4], s));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    const uint32_t n_sp = c->h_cnt[CNT_OV];
+    const uint32_t *cn = c->h_cnt;
+    for (int k = 0; k < kDpClasses; k++)
+        if (cn[CNT_JOB0 + k * kCntPad] > c->job_cap[k]) { all_general = true; spill.clear(); return 0; } // a job list ran over: the whole batch takes the general path
+    const uint32_t n_sp = cn[CNT_OV];
     spill.resize(n_sp);
     if (n_sp) {
         HIP_TRY(hipMemcpy(c->h_spill, c->d_spill, (size_t)n_sp * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1157,12 +1235,14 @@ static int run_fast(mcx_ctx *c, const ReadBatch &rb, int paired, int32_t est, ui
         std::sort(spill.begin(), spill.end()); // (listed with atomics: results do not depend on the order, the replay of a run should not either)
     }
     if (stats) {
-        float a = 0, b = 0;
-        HIP_TRY(hipEventElapsedTime(&a, c->ev_fast[0], c->ev_fast[1]));
-        HIP_TRY(hipEventElapsedTime(&b, c->ev_fast[1], c->ev_fast[2]));
-        stats->ms_seed += a; stats->ms_fast += b; stats->fast_pairs += (int64_t)n_pairs - n_sp;
+        float ms[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 4; k++) HIP_TRY(hipEventElapsedTime(&ms[k], c->ev_fast[k], c->ev_fast[k + 1]));
+        stats->ms_seed += ms[0]; stats->ms_fast += ms[1] + ms[3]; stats->ms_dp += ms[2];
+        stats->fast_pairs += (int64_t)n_pairs - n_sp;
+        for (int k = 0; k < kDpClasses; k++) stats->dp_jobs += cn[CNT_JOB0 + k * kCntPad];
+        stats->dp_cells += cn[CNT_CELLS];
     }
-    if (getenv("MCX_TIMING")) fprintf(stderr, "[run_fast] pairs %u: %u left for the general path\n", n_pairs, n_sp);
+    if (getenv("MCX_TIMING")) fprintf(stderr, "[run_fast] pairs %u: %u parked for the DP kernels, %u left for the general path\n", n_pairs, cn[CNT_RESCUE], n_sp);
     return 0;
 }
 
@@ -1207,6 +1287,12 @@ static int run_selection(mcx_ctx *c, const ReadBatch &rb, int paired, const std:
     HIP_TRY(hipMemcpy(c->h_pout, c->d_pout, (size_t)n_pairs * sizeof(PairOut), hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < n_ov; i++) ov_est[i] = c->h_pout[ov[i]].est;
     if (stats) stats->tier1_pairs += n_ov;
+    if (getenv("MCX_TIMING")) { // what sent them here
+        uint32_t by_flag[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t i = 0; i < n_ov; i++) for (int b = 0; b < 8; b++) if (c->h_pout[ov[i]].flags & (1u << b)) by_flag[b]++;
+        fprintf(stderr, "[tier 1] %u pairs over the tier-0 capacities: hits %u candidates %u fragments %u ops %u jobs %u cigar %u rescue window %u detail %u\n", n_ov, by_flag[0],
+                by_flag[1], by_flag[2], by_flag[3], by_flag[4], by_flag[5], by_flag[6], by_flag[7]);
+    }
     for (uint32_t lo = 0; lo < n_ov; lo += c->tier[1].max_pairs) {
         uint32_t m = std::min<uint32_t>(c->tier[1].max_pairs, n_ov - lo);
         HIP_TRY(hipMemcpyAsync(c->d_sel_ids, ov.data() + lo, m * sizeof(uint32_t), hipMemcpyHostToDevice, s));
@@ -1284,8 +1370,10 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
     int rc;
     if (c->fast_on) { // the common case in one kernel; what it leaves goes through the general path
         std::vector<uint32_t> spill;
-        if ((rc = run_fast(c, br.rb, paired, est0, br.n_pairs, br.recs, stats, spill))) return rc;
-        rc = spill.empty() ? 0 : run_selection(c, br.rb, paired, &spill, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true);
+        bool all_general = false;
+        if ((rc = run_fast(c, br.rb, paired, est0, br.n_pairs, br.recs, stats, spill, all_general))) return rc;
+        if (all_general) rc = run_selection(c, br.rb, paired, nullptr, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true);
+        else rc = spill.empty() ? 0 : run_selection(c, br.rb, paired, &spill, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true);
     } else rc = run_selection(c, br.rb, paired, nullptr, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true);
     if (rc) return rc;
     { // seeding statistics (E, blocks, H of SURVEY.md 8d) before the per-read arrays are reused for the chunk sums
@@ -1505,6 +1593,35 @@ extern "C" int mcx_map_batch(mcx_ctx *c, const uint8_t *bases, const uint32_t *o
 // ---------------------------------------------------------------------------------------------
 // batches from host memory with the copies overlapped with the kernels
 // ---------------------------------------------------------------------------------------------
+// Bulk copies across the device boundary by a kernel instead of the DMA engines: the batch flow makes a dozen tiny
+// copies per batch (counters, lists) that queue on those engines in order — behind a gigabyte in flight they would
+// each wait for it, and the overlap would be gone.  A few hundred wavefronts keep enough 16-byte requests in
+// flight to fill the link; pinned host memory is mapped into the device's address space.
+__global__ void __launch_bounds__(256) k_copy16(const U4 *__restrict__ src, U4 *__restrict__ dst, uint64_t n16)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+static int bulk_copy(mcx_ctx *c, void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t s)
+{
+    if (bytes == 0) return 0;
+    static const bool use_dma = getenv("MCX_STREAM_DMA") != nullptr;
+    const size_t n16 = bytes / 16;
+    bool mapped = false; // is the host side page-locked memory the device can address?
+    {
+        hipPointerAttribute_t a;
+        const void *host = kind == hipMemcpyHostToDevice ? src : dst;
+        if (hipPointerGetAttributes(&a, host) == hipSuccess) mapped = a.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();
+    }
+    if (use_dma || !mapped || n16 == 0 || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) { HIP_TRY(hipMemcpyAsync(dst, src, bytes, kind, s)); return 0; }
+    k_copy16<<<512, 256, 0, s>>>((const U4 *)src, (U4 *)dst, (uint64_t)n16);
+    HIP_TRY(hipGetLastError());
+    if (bytes & 15) HIP_TRY(hipMemcpyAsync((uint8_t *)dst + n16 * 16, (const uint8_t *)src + n16 * 16, bytes & 15, kind, s));
+    (void)c;
+    return 0;
+}
+
 static mcx_ctx::Slot *oldest_slot(mcx_ctx *c, int state)
 {
     mcx_ctx::Slot *best = nullptr;
@@ -1534,8 +1651,8 @@ extern "C" int mcx_stream_submit(mcx_ctx *c, const uint8_t *bases, const uint32_
         HIP_TRY(hipEventCreateWithFlags(&sl->mapped, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&sl->out_done, hipEventDisableTiming));
     }
-    HIP_TRY(hipMemcpyAsync(sl->d_bases, bases, off[n_reads], hipMemcpyHostToDevice, c->h2d_stream));
-    HIP_TRY(hipMemcpyAsync(sl->d_off, off, (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice, c->h2d_stream));
+    if ((rc = bulk_copy(c, sl->d_bases, bases, off[n_reads], hipMemcpyHostToDevice, c->h2d_stream))) return rc;
+    if ((rc = bulk_copy(c, sl->d_off, off, (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice, c->h2d_stream))) return rc;
     HIP_TRY(hipEventRecord(sl->in_ready, c->h2d_stream));
     sl->n_reads = n_reads; sl->state = 1; sl->seq = ++c->stream_seq;
     c->stream_bytes_in += (uint64_t)off[n_reads] + (uint64_t)(n_reads + 1) * 4;
@@ -1567,8 +1684,9 @@ extern "C" int mcx_stream_mapped(mcx_ctx *c, mcx_aln *aln, uint32_t *cigar)
     HIP_TRY(hipEventRecord(sl->mapped, c->stream));
     HIP_TRY(hipStreamWaitEvent(c->d2h_stream, sl->mapped, 0));
     const size_t rec_bytes = (size_t)sl->n_reads * sizeof(AlnRec), cig_bytes = (size_t)c->run.cig_words * 4; // (the pool's used words only)
-    HIP_TRY(hipMemcpyAsync(aln, sl->d_recs, rec_bytes, hipMemcpyDeviceToHost, c->d2h_stream));
-    if (cig_bytes) HIP_TRY(hipMemcpyAsync(cigar, sl->d_cig, cig_bytes, hipMemcpyDeviceToHost, c->d2h_stream));
+    int rc;
+    if ((rc = bulk_copy(c, aln, sl->d_recs, rec_bytes, hipMemcpyDeviceToHost, c->d2h_stream))) return rc;
+    if ((rc = bulk_copy(c, cigar, sl->d_cig, cig_bytes, hipMemcpyDeviceToHost, c->d2h_stream))) return rc;
     HIP_TRY(hipEventRecord(sl->out_done, c->d2h_stream));
     sl->state = 3;
     c->stream_bytes_out += rec_bytes + cig_bytes;

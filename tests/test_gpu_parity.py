@@ -62,9 +62,7 @@ def test_extend_equals_reference_vectors(api, toy, alg):
 @pytest.mark.parametrize("full_sa", [True, False])
 def test_sam_equals_reference(api, golden, tmp_path, name, alg, full_sa):
     """The reference's -t 1 SAM on every golden set, both algorithms.  full_sa (the product's default): every
-    suffix-array entry in HBM and the fused per-pair kernel (k_pair_fast) for the pairs that fit it, the
-    general path (k_cluster / k_rescue / k_build / k_dp_* / k_finish) for the rest; without it the sampled
-    suffix array (k_sa) and the general path for everything."""
+    suffix-array entry in HBM, seeds leave k_seed as text positions; without it the sampled suffix array (k_sa)."""
     g = golden[name]
     ix = api.Index(g["prefix"], device=0, full_sa=full_sa)
     mp = api.Mapper(ix, alg=alg, max_batch_reads=1 << 14)
@@ -73,31 +71,74 @@ def test_sam_equals_reference(api, golden, tmp_path, name, alg, full_sa):
     assert st["reads"] > 0
     nd, ex = sam_diff(g["sam"][alg], out)
     assert nd == 0, ex
-    if full_sa and name != "long":  # (250-base reads do not fit the fused kernel's slice of LDS: all of them take the general path)
-        assert st["fast_pairs"] > 0.5 * st["reads"] / (2 if g["r2"] else 1), st  # the fused kernel did take the bulk
-    elif not full_sa:
-        assert st["fast_pairs"] == 0
     mp.close(); ix.close()
 
 
-def test_fused_kernel_and_general_path_agree(api, golden, tmp_path, monkeypatch):
-    """Every pair through the general path (MCX_NO_FAST) against the default split between k_pair_fast and the general
-    path: the same SAM, byte for byte, on the variant-rich set."""
+def test_overlapped_host_boundary_gives_the_same_records(api, golden, tmp_path):
+    """mcx_stream_submit / map / collect (three batches in flight, copies on their own streams) against mcx_map_batch on the
+    same batches: records and CIGAR words equal, read by read (the pool's offsets may differ)."""
+    import torch
     g = golden["var"]
-    outs = []
-    for no_fast in ("1", ""):
-        if no_fast:
-            monkeypatch.setenv("MCX_NO_FAST", no_fast)
+    reads1 = [l for i, l in enumerate(open(g["r1"], "rb").read().split(b"\n")) if i % 4 == 1]
+    reads2 = [l for i, l in enumerate(open(g["r2"], "rb").read().split(b"\n")) if i % 4 == 1]
+    n_pairs, per = 1000, 5
+    batches = []
+    for b in range(per):
+        seqs = [x for p in range(b * n_pairs, (b + 1) * n_pairs) for x in (reads1[p], reads2[p])]
+        off = np.zeros(len(seqs) + 1, dtype=np.uint32)
+        off[1:] = np.cumsum([len(x) for x in seqs])
+        batches.append((np.frombuffer(b"".join(seqs), dtype=np.uint8).copy(), off))
+    ix = api.Index(g["prefix"], device=0, full_sa=True)
+    mp = api.Mapper(ix, alg="ksw2", max_batch_reads=2 * n_pairs)
+    want = [mp.map_batch(bb, oo, True) for bb, oo in batches]
+    mp.reset()
+    L = api.lib()
+    import ctypes as C
+    pinned = []
+    for bb, oo in batches:
+        tb = torch.zeros(bb.size + 64, dtype=torch.uint8).pin_memory(); tb[:bb.size] = torch.from_numpy(bb)
+        to = torch.from_numpy(oo.astype(np.int64)).to(torch.int32).pin_memory()  # same bits as uint32
+        pinned.append((tb, to))
+    outs = [(torch.zeros(2 * n_pairs * 64, dtype=torch.uint8).pin_memory(), torch.zeros(2 * n_pairs * api.CIGAR_STRIDE, dtype=torch.int32).pin_memory()) for _ in range(per)]
+    for i in range(per + 2):
+        if i < per:
+            assert L.mcx_stream_submit(mp._h, pinned[i][0].data_ptr(), pinned[i][1].data_ptr(), 2 * n_pairs) == 0, L.mcx_last_error()
+        if 1 <= i <= per:
+            assert L.mcx_stream_map(mp._h, 1, mp.avg, outs[i - 1][0].data_ptr(), outs[i - 1][1].data_ptr(), C.byref(mp.stats)) == 0, L.mcx_last_error()
+        if i >= 2:
+            assert L.mcx_stream_collect(mp._h, None, None) == 0, L.mcx_last_error()
+    for b in range(per):
+        aln = np.frombuffer(outs[b][0].numpy().tobytes(), dtype=api.ALN_DTYPE)
+        pool = outs[b][1].numpy().view(np.uint32)
+        w_aln, w_cig = want[b]
+        for f in ("pos", "mate_pos", "chr", "flag", "mapq", "tlen", "nm", "as", "xs", "n_cigar", "fwd", "has_mate"):
+            assert np.array_equal(aln[f], w_aln[f]), (b, f)
+        for r in range(2 * n_pairs):
+            assert np.array_equal(pool[aln["cigar_off"][r]:aln["cigar_off"][r] + aln["n_cigar"][r]], w_cig[r]), (b, r)
+    mp.close(); ix.close()
+
+
+@pytest.mark.parametrize("name,alg", [("var", "nw"), ("toy", "ksw2"), ("se", "ksw2"), ("mc", "nw")])
+def test_fused_kernel_and_general_path_agree(api, golden, tmp_path, monkeypatch, name, alg):
+    """The experimental fused per-pair kernel (MCX_FAST=1: k_pair_fast, pair state in LDS, for the pairs that fit it; the
+    general path for the rest) against the default, where every pair takes the general path: the reference's SAM either way."""
+    g = golden[name]
+    for fast in ("1", ""):
+        if fast:
+            monkeypatch.setenv("MCX_FAST", fast)
         else:
-            monkeypatch.delenv("MCX_NO_FAST", raising=False)
+            monkeypatch.delenv("MCX_FAST", raising=False)
         ix = api.Index(g["prefix"], device=0, full_sa=True)
-        mp = api.Mapper(ix, alg="nw", max_batch_reads=1 << 14)
-        out = str(tmp_path / f"gpu{no_fast}.sam")
+        mp = api.Mapper(ix, alg=alg, max_batch_reads=1 << 14)
+        out = str(tmp_path / f"gpu{fast}.sam")
         st = mp.map_files(g["r1"], g["r2"], out)
-        assert (st["fast_pairs"] == 0) == bool(no_fast)
-        outs.append(open(out, "rb").read())
+        if fast:
+            assert st["fast_pairs"] > 0.5 * st["reads"] / (2 if g["r2"] else 1), st  # the fused kernel did take the bulk
+        else:
+            assert st["fast_pairs"] == 0
+        nd, ex = sam_diff(g["sam"][alg], out)
+        assert nd == 0, (fast, ex)
         mp.close(); ix.close()
-    assert outs[0] == outs[1]
 
 
 def test_small_batches_follow_the_avgdist_trajectory(api, golden, tmp_path):
