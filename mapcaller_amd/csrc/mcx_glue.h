@@ -327,6 +327,7 @@ struct RescueSerial {
 // diagonals are dealt round-robin to the lanes, the best (largest total, then smallest
 // diagonal) is found by a wave reduction, and lane 0 emits its seeds.  kq/kg live in LDS:
 // kq[r] is a broadcast read and kg[r + d] is conflict-free across consecutive diagonals.
+
 struct RescueWave { // one workgroup (any number of wavefronts) evaluates one pair
     uint32_t *kq, *kg;
     int *red; // LDS scratch: 2 ints per wavefront + 4
@@ -378,11 +379,43 @@ struct RescueWave { // one workgroup (any number of wavefronts) evaluates one pa
             kg[p] = wid;
         }
         __syncthreads();
-        int best_total = 0, best_d = 0x7fffffff, dummy = 0;
-        bool ovd = false;
-        for (int d = -(qlen - 1) + tid; d <= slen - 1; d += nt) {
-            const int total = diag_total(kq, qlen, kg, slen, d);
-            if (total > best_total) { best_total = total; best_d = d; }
+        int best_total = 0, best_d = 0x7fffffff;
+        // Four neighbouring diagonals per thread, walked together along the read: the window ids they need at read
+        // position r are four consecutive words of kg, three of them already at hand from r - 1 — one LDS fetch of
+        // kg and one (broadcast) of kq per four cells.  The matches of a diagonal collect as a bit string, 29 new bits
+        // behind 3 of history (diag_total's bookkeeping in 32-bit words).
+        constexpr int D = 4;
+        const int n_groups = (qlen + slen - 1 + D - 1) / D;
+        for (int g = tid; g < n_groups; g += nt) {
+            const int dbase = -(qlen - 1) + g * D;
+            uint32_t e[D], win[D];
+            int tot[D];
+#pragma unroll
+            for (int j = 0; j < D; j++) { e[j] = 0u; tot[j] = 0; }
+            auto kgv = [&](int p) -> uint32_t { return (p >= 0 && p < slen) ? kg[p] : MCX_NOKMER; };
+            const int rlo = -(dbase + D - 1) > 0 ? -(dbase + D - 1) : 0, rhi = qlen - 1 < slen - 1 - dbase ? qlen - 1 : slen - 1 - dbase;
+#pragma unroll
+            for (int j = 0; j + 1 < D; j++) win[j] = kgv(rlo + dbase + j);
+            for (int r = rlo; r <= rhi;) {
+                for (int i = 0; i < 29 && r <= rhi; i++, r++) {
+                    uint32_t q = kq[r];
+                    if (q == MCX_NOKMER) q = 0xFFFFFFFEu; // (matches nothing: ids are 16 bits, an absent window id is MCX_NOKMER)
+                    win[D - 1] = kgv(r + dbase + D - 1);
+#pragma unroll
+                    for (int j = 0; j < D; j++) e[j] |= (uint32_t)(q == win[j]) << (3 + i);
+#pragma unroll
+                    for (int j = 0; j + 1 < D; j++) win[j] = win[j + 1];
+                }
+#pragma unroll
+                for (int j = 0; j < D; j++) {
+                    const uint32_t t = e[j] & (e[j] >> 1) & (e[j] >> 2), own = t & ~1u;
+                    tot[j] += __popc(own) + 9 * __popc(own & ~(t << 1));
+                    e[j] = (e[j] >> 29) & 7u;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < D; j++)
+                if (dbase + j <= slen - 1 && tot[j] > best_total) { best_total = tot[j]; best_d = dbase + j; } // (ascending: the first of equal totals stays)
         }
         for (int o = 32; o > 0; o >>= 1) {
             const int ot = __shfl_xor(best_total, o, 64), od = __shfl_xor(best_d, o, 64);

@@ -566,12 +566,14 @@ __global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel s
 
 constexpr int kRescueThreads = 256;
 
+// KG: the longest window the tier evaluates (caps.kmer_cap)
+template <int KG>
 __global__ void __launch_bounds__(kRescueThreads) k_rescue(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl)
 {
     // one workgroup per unpaired pair (they are few, and one pair's windows are a long serial chain
     // for a single wavefront); 8-mer ids of the read and of the window live in LDS
     __shared__ uint32_t kq[1024];
-    __shared__ uint32_t kg[4096 + 64 + 8 + (4096 + 64) / 16 + 8]; // the window's 8-mer ids, then its 2-bit bytes (RescueWave::window)
+    __shared__ uint32_t kg[KG + 64 + 8 + (KG + 64) / 16 + 8]; // the window's 8-mer ids, then its 2-bit bytes (RescueWave::window)
     __shared__ int red[2 * (kRescueThreads / 64) + 4];
     const uint32_t n = min(*rl.n, rl.cap);
     RescueWave ev; ev.kq = kq; ev.kg = kg; ev.red = red;
@@ -583,7 +585,6 @@ __global__ void __launch_bounds__(kRescueThreads) k_rescue(Ctx cx, ReadBatch rb,
         __syncthreads();
     }
 }
-
 
 // fragment lists + DP problems of every pair; the problems are appended to one list per size
 // class (mcx_glue.h dp_class) with one atomic per wave and class
@@ -1080,7 +1081,10 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
     k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl, so.read_blocks);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
-    if (paired) k_rescue<<<4096, kRescueThreads, 0, s>>>(cx, rb, sel, rl);
+    if (paired) {
+        if (tier == 0) k_rescue<2048><<<4096, kRescueThreads, 0, s>>>(cx, rb, sel, rl);
+        else k_rescue<4096><<<4096, kRescueThreads, 0, s>>>(cx, rb, sel, rl);
+    }
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
     k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, c->d_cnt + CNT_CELLS, c->d_cnt + CNT_UNSUP);
     if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
