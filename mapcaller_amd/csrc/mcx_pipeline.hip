@@ -543,13 +543,16 @@ __global__ void __launch_bounds__(256) k_sa(Ctx cx, SeedOut so, int paired, uint
 }
 
 struct RescueList { uint32_t *ids; uint32_t *n; uint32_t cap; };
+// pairs that ran over the tier-0 capacities while clustering are listed right there, with their estimate: the large tier maps
+// them on a stream of its own while the rest of the pass is still under way (ids null: no such list)
+struct EarlyList { uint32_t *ids; int32_t *est; uint32_t *n; uint32_t cap; };
 
-__global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl, const uint32_t *read_blocks)
+__global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl, const uint32_t *read_blocks, EarlyList el)
 {
     __shared__ EndsLds ends;
     stage_ends(cx.ix, ends);
     const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t need = 0;
+    uint32_t need = 0, over = 0;
     if (local < sel.n) {
         ReadRef rd[2];
         make_reads(cx, rb, sel_pair(sel, local), rd);
@@ -558,10 +561,17 @@ __global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel s
         const int nr = cx.pm.paired ? 2 : 1;
         int nh[2] = {(int)(read_blocks[pair * nr] >> 20), nr == 2 ? (int)(read_blocks[pair * nr + 1] >> 20) : 0}; // k_seed's hit counts
         stage_cluster_pair(cx, local, rd, sel.est[local], nh);
-        need = (cx.pm.paired && !(st.hdr->flags & kOvAny) && st.hdr->n_paired == 0) ? 1u : 0u;
+        const uint32_t fl = st.hdr->flags;
+        need = (cx.pm.paired && !(fl & kOvAny) && st.hdr->n_paired == 0) ? 1u : 0u;
+        over = (el.ids && (fl & kOvAny)) ? 1u : 0u;
+        if (over) st.hdr->flags = fl | kDispatched; // the later stages of this tier leave the pair alone (they skip kOvAny) and k_finish writes nothing for it
     }
     const uint32_t at = wave_reserve(rl.n, need);
     if (need && at < rl.cap) rl.ids[at] = local;
+    if (el.ids) {
+        const uint32_t ea = wave_reserve(el.n, over);
+        if (over && ea < el.cap) { el.ids[ea] = sel_pair(sel, local); el.est[ea] = sel.est[local]; }
+    }
 }
 
 constexpr int kRescueThreads = 256;
@@ -738,6 +748,7 @@ __global__ void __launch_bounds__(256, 7) k_finish(Ctx cx, ReadBatch rb, PairSel
     ReadRef rd[2];
     PairState st;
     PairHdr h; // the final header stays in registers: nothing reads the pair state after this kernel
+    h.flags = 0;
     int n_cig[2] = {0, 0};
     uint8_t *detail2 = nullptr;
     if (active) {
@@ -751,7 +762,7 @@ __global__ void __launch_bounds__(256, 7) k_finish(Ctx cx, ReadBatch rb, PairSel
     }
     const uint32_t want = (uint32_t)(n_cig[0] + n_cig[1]);
     const uint32_t at = wave_reserve(cx.cig_pool_n, want);
-    if (!active) return;
+    if (!active || (h.flags & kDispatched)) return; // (a dispatched pair is the large tier's: its records and summary come from there)
     const bool fits = at + want <= cx.cig_pool_cap;
     if (!fits) atomicOr(pool_over, 1u);
     const uint32_t off[2] = {at, at + (uint32_t)n_cig[0]};
@@ -780,7 +791,23 @@ struct Tier {
 constexpr int kCntPad = 64;
 enum { CNT_TASKS = 0, CNT_RESCUE = 1 * kCntPad, CNT_JOB0 = 2 * kCntPad, CNT_JOB1 = 3 * kCntPad, CNT_JOB2 = 4 * kCntPad, CNT_JOB3 = 5 * kCntPad,
        CNT_JOB4 = 6 * kCntPad, CNT_JOB5 = 7 * kCntPad, CNT_OV = 8 * kCntPad, CNT_LF = 9 * kCntPad, CNT_CELLS = 10 * kCntPad, CNT_UNSUP = 11 * kCntPad,
-       CNT_QUEUE = 12 * kCntPad, CNT_N = 13 * kCntPad };
+       CNT_QUEUE = 12 * kCntPad, CNT_EARLY = 13 * kCntPad, CNT_N = 14 * kCntPad };
+
+// What a pass over a selection of pairs works with besides the pair records: stream, counters, work lists, DP scratch.
+// The context holds two sets, so that the large tier can map the heavy pairs of a pass (listed while the pass clusters)
+// on a stream of its own while the rest of the pass is still under way.
+struct PassRes {
+    hipStream_t stream = nullptr;
+    uint32_t *d_cnt = nullptr, *h_cnt = nullptr;
+    uint2 *d_tasks = nullptr; uint32_t task_cap = 0;
+    DpJob *d_jobs[kDpClasses] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; uint32_t job_cap[kDpClasses] = {0, 0, 0, 0, 0, 0};
+    uint32_t *d_rescue = nullptr; uint32_t rescue_cap = 0;
+    uint8_t *d_dp_scratch[3] = {nullptr, nullptr, nullptr}; uint64_t dp_stride[3] = {0, 0, 0}; uint32_t dp_blocks[3] = {0, 0, 0};
+    hipStream_t dp_stream[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t dp_fork = nullptr, dp_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t *d_ov = nullptr; uint32_t ov_cap = 0;
+    uint32_t *d_sel_ids = nullptr; int32_t *d_est = nullptr;
+    hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
 
 struct BatchRun { // the batch between mcx_batch_begin and mcx_batch_end
     bool open = false, sums_valid = false, keys_out = false;
@@ -834,6 +861,9 @@ struct mcx_ctx {
     uint8_t *d_saved = nullptr; // parked slices: pairs waiting for the DP kernels
     hipEvent_t ev_fast[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     BatchRun run;
+    PassRes t1;               // the large tier's own set (the members above are tier 0's); allocated when every suffix-array entry is resident
+    bool overlap_tiers = false;
+    hipEvent_t ev_clustered = nullptr;
     // mcx_stream_*: three batches in flight (copy in | kernels | copy out), each in a slot of its own
     struct Slot {
         uint8_t *d_bases = nullptr; uint32_t *d_off = nullptr; AlnRec *d_recs = nullptr; uint32_t *d_cig = nullptr;
@@ -958,6 +988,35 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
         }
     if ((rc = dmalloc(&c->d_mapq, tab.size()))) return rc;
     HIP_TRY(hipMemcpy(c->d_mapq, tab.data(), tab.size(), hipMemcpyHostToDevice));
+    // the large tier's own stream, counters and lists: with them it maps the heavy pairs of a pass while the pass goes on
+    // (without the full suffix array it would also need an SA task list of its own: then the tiers run one after the other)
+    if (idx->view.sa_full && !getenv("MCX_NO_TIER_OVERLAP")) {
+        PassRes &t = c->t1;
+        HIP_TRY(hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking));
+        for (int k = 0; k < 5; k++) { HIP_TRY(hipStreamCreateWithFlags(&t.dp_stream[k], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&t.dp_join[k], hipEventDisableTiming)); }
+        HIP_TRY(hipEventCreateWithFlags(&t.dp_fork, hipEventDisableTiming));
+        for (auto &e : t.ev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_clustered, hipEventDisableTiming));
+        if ((rc = dmalloc(&t.d_cnt, CNT_N))) return rc;
+        HIP_TRY(hipHostMalloc((void **)&t.h_cnt, CNT_N * sizeof(uint32_t)));
+        const uint64_t mp = c->tier[1].max_pairs;
+        for (int k = 0; k < kDpClasses; k++) {
+            t.job_cap[k] = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(mp * 16, 1u << 20), c->job_cap[k]);
+            if ((rc = dmalloc(&t.d_jobs[k], t.job_cap[k]))) return rc;
+        }
+        t.rescue_cap = (uint32_t)mp;
+        if ((rc = dmalloc(&t.d_rescue, t.rescue_cap))) return rc;
+        const uint32_t blocks1[3] = {2048, 512, 128};
+        for (int k = 0; k < 3; k++) {
+            t.dp_stride[k] = c->dp_stride[k]; t.dp_blocks[k] = blocks1[k];
+            if ((rc = dmalloc(&t.d_dp_scratch[k], (size_t)t.dp_stride[k] * t.dp_blocks[k]))) return rc;
+        }
+        t.ov_cap = (uint32_t)c->max_reads;
+        if ((rc = dmalloc(&t.d_ov, t.ov_cap))) return rc;
+        if ((rc = dmalloc(&t.d_sel_ids, c->max_reads))) return rc;
+        if ((rc = dmalloc(&t.d_est, c->max_reads))) return rc;
+        c->overlap_tiers = true;
+    }
     // the fused per-pair kernel: needs every suffix-array entry resident (seeds then leave k_seed as text positions)
     // and a slice of LDS per lane that the read length decides (reads up to 16 x code_words bases take it)
     if (idx->view.sa_full && getenv("MCX_FAST") && !getenv("MCX_NO_FAST")) {
@@ -999,6 +1058,18 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     if (c->h_pout) (void)hipHostFree(c->h_pout);
     if (c->h_keys) (void)hipHostFree(c->h_keys);
     if (c->h_spill) (void)hipHostFree(c->h_spill);
+    {
+        PassRes &t = c->t1;
+        void *q[] = {t.d_cnt, t.d_jobs[0], t.d_jobs[1], t.d_jobs[2], t.d_jobs[3], t.d_jobs[4], t.d_jobs[5], t.d_rescue, t.d_dp_scratch[0], t.d_dp_scratch[1],
+                     t.d_dp_scratch[2], t.d_ov, t.d_sel_ids, t.d_est};
+        for (void *x : q) if (x) (void)hipFree(x);
+        if (t.h_cnt) (void)hipHostFree(t.h_cnt);
+        for (auto &e : t.ev) if (e) (void)hipEventDestroy(e);
+        for (int k = 0; k < 5; k++) { if (t.dp_stream[k]) (void)hipStreamDestroy(t.dp_stream[k]); if (t.dp_join[k]) (void)hipEventDestroy(t.dp_join[k]); }
+        if (t.dp_fork) (void)hipEventDestroy(t.dp_fork);
+        if (t.stream) (void)hipStreamDestroy(t.stream);
+        if (c->ev_clustered) (void)hipEventDestroy(c->ev_clustered);
+    }
     for (auto &e : c->ev_fast) if (e) (void)hipEventDestroy(e);
     for (auto &sl : c->slot) {
         void *q[] = {sl.d_bases, sl.d_off, sl.d_recs, sl.d_cig};
@@ -1034,40 +1105,62 @@ struct StageMs { float seed, sa, cluster, rescue, build, dp, finish; };
 
 constexpr int kListOverflow = 1; // (internal) a work list of run_pairs was too short for the selection
 
+// tier 0's set: the context's own members
+static PassRes res_tier0(mcx_ctx *c)
+{
+    PassRes r;
+    r.stream = c->stream; r.d_cnt = c->d_cnt; r.h_cnt = c->h_cnt; r.d_tasks = c->d_tasks; r.task_cap = c->task_cap;
+    for (int k = 0; k < kDpClasses; k++) { r.d_jobs[k] = c->d_jobs[k]; r.job_cap[k] = c->job_cap[k]; }
+    r.d_rescue = c->d_rescue; r.rescue_cap = c->rescue_cap;
+    for (int k = 0; k < 3; k++) { r.d_dp_scratch[k] = c->d_dp_scratch[k]; r.dp_stride[k] = c->dp_stride[k]; r.dp_blocks[k] = c->dp_blocks[k]; }
+    for (int k = 0; k < 5; k++) { r.dp_stream[k] = c->dp_stream[k]; r.dp_join[k] = c->dp_join[k]; }
+    r.dp_fork = c->dp_fork; r.d_ov = c->d_ov; r.ov_cap = c->ov_cap; r.d_sel_ids = c->d_sel_ids; r.d_est = c->d_est;
+    for (int k = 0; k < 10; k++) r.ev[k] = c->ev[k];
+    return r;
+}
+
 // the DP job lists of a pass, one kernel per size class: they work on disjoint lists and are each bound by latency at
 // modest occupancy, so side streams let them share the chip instead of queueing behind one another
-static int launch_dp(mcx_ctx *c, const Ctx &cx, const JobSinks &sinks, const ReadBatch &rb, const PairSel &sel)
+static int launch_dp(const PassRes &R, const Ctx &cx, const JobSinks &sinks, const ReadBatch &rb, const PairSel &sel)
 {
-    hipStream_t s = c->stream;
-    HIP_TRY(hipEventRecord(c->dp_fork, s));
-    for (int k = 0; k < 5; k++) HIP_TRY(hipStreamWaitEvent(c->dp_stream[k], c->dp_fork, 0));
-    k_dp_sel<1><<<c->dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, c->d_dp_scratch[0], c->dp_stride[0]);
-    k_dp_small<<<2560, 256, 0, c->dp_stream[0]>>>(cx, sinks.s[0], rb, sel);
-    k_dp_tiny<<<2048, 256, 0, c->dp_stream[3]>>>(cx, sinks.s[4], rb, sel);
-    k_dp_half<<<2048, 256, 0, c->dp_stream[4]>>>(cx, sinks.s[5], rb, sel);
-    k_dp_sel<4><<<c->dp_blocks[1], 64, 0, c->dp_stream[1]>>>(cx, sinks.s[2], rb, sel, c->d_dp_scratch[1], c->dp_stride[1]);
-    k_dp_sel<16><<<c->dp_blocks[2], 64, 0, c->dp_stream[2]>>>(cx, sinks.s[3], rb, sel, c->d_dp_scratch[2], c->dp_stride[2]);
-    for (int k = 0; k < 5; k++) { HIP_TRY(hipEventRecord(c->dp_join[k], c->dp_stream[k])); HIP_TRY(hipStreamWaitEvent(s, c->dp_join[k], 0)); }
+    hipStream_t s = R.stream;
+    HIP_TRY(hipEventRecord(R.dp_fork, s));
+    for (int k = 0; k < 5; k++) HIP_TRY(hipStreamWaitEvent(R.dp_stream[k], R.dp_fork, 0));
+    k_dp_sel<1><<<R.dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, R.d_dp_scratch[0], R.dp_stride[0]);
+    k_dp_small<<<2560, 256, 0, R.dp_stream[0]>>>(cx, sinks.s[0], rb, sel);
+    k_dp_tiny<<<2048, 256, 0, R.dp_stream[3]>>>(cx, sinks.s[4], rb, sel);
+    k_dp_half<<<2048, 256, 0, R.dp_stream[4]>>>(cx, sinks.s[5], rb, sel);
+    k_dp_sel<4><<<R.dp_blocks[1], 64, 0, R.dp_stream[1]>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1]);
+    k_dp_sel<16><<<R.dp_blocks[2], 64, 0, R.dp_stream[2]>>>(cx, sinks.s[3], rb, sel, R.d_dp_scratch[2], R.dp_stride[2]);
+    for (int k = 0; k < 5; k++) { HIP_TRY(hipEventRecord(R.dp_join[k], R.dp_stream[k])); HIP_TRY(hipStreamWaitEvent(s, R.dp_join[k], 0)); }
     return 0;
 }
 
-static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, PairSel sel, AlnRec *d_recs,
-                     uint32_t *d_cig, mcx_stats *stats, bool timing)
+static int tier1_error(mcx_ctx *c, const PassRes &R);
+
+// One tier over a selection of pairs.  early (tier 0 only): the pairs that run over the tier's capacities while clustering
+// are listed on the device; once the rest of the pass is queued, the large tier maps them on its own stream — its kernels
+// are bound by their slowest pair, not by the chip, so they hide behind the pass instead of following it.
+static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb, int paired, PairSel sel, AlnRec *d_recs,
+                     uint32_t *d_cig, mcx_stats *stats, bool timing, bool early = false)
 {
     if (sel.n == 0) return 0;
-    hipStream_t s = c->stream;
+    hipStream_t s = R.stream;
     Ctx cx = make_ctx(c, tier, paired);
     const int nr = paired ? 2 : 1;
-    HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
-    SeedOut so; so.tasks = c->d_tasks; so.n_tasks = c->d_cnt + CNT_TASKS; so.task_cap = c->task_cap;
+    early = early && tier == 0 && c->overlap_tiers;
+    HIP_TRY(hipMemsetAsync(R.d_cnt, 0, CNT_N * sizeof(uint32_t), s));
+    SeedOut so; so.tasks = R.d_tasks; so.n_tasks = R.d_cnt + CNT_TASKS; so.task_cap = R.task_cap;
     so.read_ext = c->d_read_ext; so.read_blocks = c->d_read_blocks;
-    so.packed = c->d_packed; so.wpad = c->wpad; so.fast_hits = nullptr; so.fast_cap = 0; so.queue = c->d_cnt + CNT_QUEUE;
-    RescueList rl; rl.ids = c->d_rescue; rl.n = c->d_cnt + CNT_RESCUE; rl.cap = c->rescue_cap;
+    so.packed = c->d_packed; so.wpad = c->wpad; so.fast_hits = nullptr; so.fast_cap = 0; so.queue = R.d_cnt + CNT_QUEUE;
+    RescueList rl; rl.ids = R.d_rescue; rl.n = R.d_cnt + CNT_RESCUE; rl.cap = R.rescue_cap;
+    EarlyList el; el.ids = nullptr; el.est = nullptr; el.n = R.d_cnt + CNT_EARLY; el.cap = 0;
+    if (early) { el.ids = c->t1.d_sel_ids; el.est = c->t1.d_est; el.cap = (uint32_t)c->max_reads; }
     JobSinks sinks;
-    for (int k = 0; k < kDpClasses; k++) { sinks.s[k].jobs = c->d_jobs[k]; sinks.s[k].count = c->d_cnt + CNT_JOB0 + k * kCntPad; sinks.s[k].cap = c->job_cap[k]; }
+    for (int k = 0; k < kDpClasses; k++) { sinks.s[k].jobs = R.d_jobs[k]; sinks.s[k].count = R.d_cnt + CNT_JOB0 + k * kCntPad; sinks.s[k].cap = R.job_cap[k]; }
     const unsigned pb = (sel.n + 255) / 256;
-    int e = 0, rc_dp = 0;
-    if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
+    int e = 0, rc2 = 0;
+    if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     {
         // LDS for the packed reads: words per lane for the longest read x lanes; narrower blocks for long reads
         const int pkw = packed_words(c->rlen_max);
@@ -1076,44 +1169,80 @@ static int run_pairs(mcx_ctx *c, int tier, const ReadBatch &rb, int paired, Pair
         const unsigned blocks_s = std::min<unsigned>((sel.n * nr + threads * rpl - 1) / (threads * rpl), 4096u); // (the queue feeds whatever grid runs)
         k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl);
     }
-    if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
-    k_sa<<<4096, 256, 0, s>>>(cx, so, paired, c->d_cnt + CNT_LF);
-    if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
-    k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl, so.read_blocks);
-    if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
+    if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
+    if (R.d_tasks) k_sa<<<4096, 256, 0, s>>>(cx, so, paired, R.d_cnt + CNT_LF);
+    if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
+    k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl, so.read_blocks, el);
+    if (early) HIP_TRY(hipEventRecord(c->ev_clustered, s));
+    if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     if (paired) {
         if (tier == 0) k_rescue<2048><<<4096, kRescueThreads, 0, s>>>(cx, rb, sel, rl);
         else k_rescue<4096><<<4096, kRescueThreads, 0, s>>>(cx, rb, sel, rl);
     }
-    if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
-    k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, c->d_cnt + CNT_CELLS, c->d_cnt + CNT_UNSUP);
-    if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
-    if ((rc_dp = launch_dp(c, cx, sinks, rb, sel))) return rc_dp;
-    if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
-    k_finish<<<pb, 256, 0, s>>>(cx, rb, sel, d_recs, c->d_pout, c->d_ov, c->d_cnt + CNT_OV, c->ov_cap, c->d_batch_flags + 2);
-    if (timing) HIP_TRY(hipEventRecord(c->ev[e++], s));
+    if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
+    k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP);
+    if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
+    if ((rc2 = launch_dp(R, cx, sinks, rb, sel))) return rc2;
+    if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
+    k_finish<<<pb, 256, 0, s>>>(cx, rb, sel, d_recs, c->d_pout, R.d_ov, R.d_cnt + CNT_OV, R.ov_cap, c->d_batch_flags + 2);
+    if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(R.h_cnt, R.d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (early) { // the pairs k_cluster listed: through the large tier now, while the kernels above run
+        const PassRes &T = c->t1;
+        uint32_t n_early = 0;
+        HIP_TRY(hipStreamWaitEvent(T.stream, c->ev_clustered, 0));
+        HIP_TRY(hipMemcpyAsync(T.h_cnt, R.d_cnt + CNT_EARLY, sizeof(uint32_t), hipMemcpyDeviceToHost, T.stream));
+        HIP_TRY(hipStreamSynchronize(T.stream));
+        n_early = T.h_cnt[0];
+        if (n_early > el.cap) { (void)hipStreamSynchronize(s); return fail(MCX_ERR_CAPACITY, "overflow list overflow"); }
+        if (stats) stats->tier1_pairs += n_early;
+        for (uint32_t lo = 0; lo < n_early && rc2 == 0; lo += c->tier[1].max_pairs) {
+            const uint32_t m = std::min<uint32_t>(c->tier[1].max_pairs, n_early - lo);
+            PairSel s1; s1.n = m; s1.ids = T.d_sel_ids + lo; s1.est = T.d_est + lo;
+            if (getenv("MCX_TIMING")) {
+                mcx_stats t1; memset(&t1, 0, sizeof t1);
+                rc2 = run_pairs(c, 1, T, rb, paired, s1, d_recs, d_cig, &t1, true);
+                fprintf(stderr, "[tier 1, beside tier 0] %u pairs: seed %.2f sa %.2f cluster %.2f rescue %.2f build %.2f dp %.2f finish %.2f ms\n", m, t1.ms_seed, t1.ms_sa,
+                        t1.ms_cluster, t1.ms_rescue, t1.ms_build, t1.ms_dp, t1.ms_finish);
+                if (stats) { stats->dp_jobs += t1.dp_jobs; stats->dp_cells += t1.dp_cells; }
+            } else rc2 = run_pairs(c, 1, T, rb, paired, s1, d_recs, d_cig, stats, false);
+            if (rc2 == kListOverflow) rc2 = fail(MCX_ERR_CAPACITY, "work list overflow in tier 1");
+            if (rc2 == 0 && T.h_cnt[CNT_OV]) rc2 = tier1_error(c, T);
+        }
+    }
     HIP_TRY(hipStreamSynchronize(s));
-    const uint32_t *n = c->h_cnt;
+    if (rc2) return rc2;
+    const uint32_t *n = R.h_cnt;
     // a work list that ran over: nothing of this pass is kept, the caller maps the selection in two halves
-    if (n[CNT_TASKS] > c->task_cap || n[CNT_RESCUE] > c->rescue_cap) return kListOverflow;
-    for (int k = 0; k < kDpClasses; k++) if (n[CNT_JOB0 + k * kCntPad] > c->job_cap[k]) return kListOverflow;
+    if ((R.d_tasks && n[CNT_TASKS] > R.task_cap) || n[CNT_RESCUE] > R.rescue_cap) return kListOverflow;
+    for (int k = 0; k < kDpClasses; k++) if (n[CNT_JOB0 + k * kCntPad] > R.job_cap[k]) return kListOverflow;
     if (n[CNT_UNSUP]) return fail(MCX_ERR_UNSUPPORTED, "a gapped fragment exceeds 2048 x 1024 cells per side");
     if (timing && getenv("MCX_TIMING"))
-        fprintf(stderr, "[run_pairs] pairs %u: sa tasks %u, rescue pairs %u, dp jobs by class (tiny) %u %u (half) %u %u %u %u, cells %u, overflow pairs %u\n", sel.n, n[CNT_TASKS],
-                n[CNT_RESCUE], n[CNT_JOB4], n[CNT_JOB0], n[CNT_JOB5], n[CNT_JOB1], n[CNT_JOB2], n[CNT_JOB3], n[CNT_CELLS], n[CNT_OV]);
+        fprintf(stderr, "[run_pairs] pairs %u: sa tasks %u, rescue pairs %u, dp jobs by class (tiny) %u %u (half) %u %u %u %u, cells %u, overflow pairs %u (+ %u listed while clustering)\n", sel.n,
+                n[CNT_TASKS], n[CNT_RESCUE], n[CNT_JOB4], n[CNT_JOB0], n[CNT_JOB5], n[CNT_JOB1], n[CNT_JOB2], n[CNT_JOB3], n[CNT_CELLS], n[CNT_OV], n[CNT_EARLY]);
     if (stats) {
         stats->dp_jobs += (int64_t)n[CNT_JOB0] + n[CNT_JOB1] + n[CNT_JOB2] + n[CNT_JOB3] + n[CNT_JOB4] + n[CNT_JOB5];
         stats->dp_cells += n[CNT_CELLS];
         if (timing) {
             float ms[8];
-            for (int i = 0; i + 1 < e; i++) HIP_TRY(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+            for (int i = 0; i + 1 < e; i++) HIP_TRY(hipEventElapsedTime(&ms[i], R.ev[i], R.ev[i + 1]));
             stats->ms_seed += ms[0]; stats->ms_sa += ms[1]; stats->ms_cluster += ms[2]; stats->ms_rescue += ms[3];
             stats->ms_build += ms[4]; stats->ms_dp += ms[5]; stats->ms_finish += ms[6];
         }
     }
     return 0;
+}
+
+// a pair that does not even fit the large tier: say which and why
+static int tier1_error(mcx_ctx *c, const PassRes &R)
+{
+    uint32_t first = 0;
+    PairOut po; memset(&po, 0, sizeof po);
+    if (hipMemcpy(&first, R.d_ov, sizeof first, hipMemcpyDeviceToHost) == hipSuccess)
+        (void)hipMemcpy(&po, c->d_pout + first, sizeof po, hipMemcpyDeviceToHost);
+    return fail(MCX_ERR_CAPACITY, "a pair exceeded the tier-1 capacities (pair " + std::to_string(first) + ", overflow flags " + std::to_string(po.flags & kOvAny) +
+                                  ": 1 hits 2 candidates 4 fragments 8 ops 16 jobs 32 cigar 64 rescue window)");
 }
 
 __global__ void k_fill_i32(int32_t *p, int32_t v, uint32_t n)
@@ -1219,7 +1348,7 @@ static int run_fast(mcx_ctx *c, const ReadBatch &rb, int paired, int32_t est, ui
         cs.state = c->d_saved; cs.lay = save_layout(c->fcaps);
         cs.caps.hit_cap = c->fcaps.hit_cap; cs.caps.cand_cap = c->fcaps.cand_cap; cs.caps.frag_cap = c->fcaps.slots;
         PairSel parked; parked.n = n_pairs; parked.ids = c->d_sel_ids; parked.est = nullptr;
-        int rc = launch_dp(c, cs, sinks, rb, parked);
+        int rc = launch_dp(res_tier0(c), cs, sinks, rb, parked);
         if (rc) return rc;
     }
     HIP_TRY(hipEventRecord(c->ev_fast[3], s));
@@ -1265,7 +1394,8 @@ static int run_selection(mcx_ctx *c, const ReadBatch &rb, int paired, const std:
     }
     if (est) HIP_TRY(hipMemcpyAsync(c->d_est, est->data(), n * sizeof(int32_t), hipMemcpyHostToDevice, s));
     else k_fill_i32<<<(n + 255) / 256, 256, 0, s>>>(c->d_est, est_all, n);
-    int rc = run_pairs(c, 0, rb, paired, sel, d_recs, d_cig, stats, timing);
+    const PassRes R0 = res_tier0(c);
+    int rc = run_pairs(c, 0, R0, rb, paired, sel, d_recs, d_cig, stats, timing, true);
     if (rc == kListOverflow) {
         // unusually many hits or DP problems per read (e.g. indel-heavy long reads): halve the selection
         if (n < 2) return fail(MCX_ERR_CAPACITY, "work list overflow for a single pair");
@@ -1297,6 +1427,8 @@ static int run_selection(mcx_ctx *c, const ReadBatch &rb, int paired, const std:
         fprintf(stderr, "[tier 1] %u pairs over the tier-0 capacities: hits %u candidates %u fragments %u ops %u jobs %u cigar %u rescue window %u detail %u\n", n_ov, by_flag[0],
                 by_flag[1], by_flag[2], by_flag[3], by_flag[4], by_flag[5], by_flag[6], by_flag[7]);
     }
+    // (the pairs that ran over while clustering went through the large tier beside this pass already — run_pairs; what is
+    //  left ran over later: column strings, job lists)
     for (uint32_t lo = 0; lo < n_ov; lo += c->tier[1].max_pairs) {
         uint32_t m = std::min<uint32_t>(c->tier[1].max_pairs, n_ov - lo);
         HIP_TRY(hipMemcpyAsync(c->d_sel_ids, ov.data() + lo, m * sizeof(uint32_t), hipMemcpyHostToDevice, s));
@@ -1304,22 +1436,15 @@ static int run_selection(mcx_ctx *c, const ReadBatch &rb, int paired, const std:
         PairSel s1; s1.n = m; s1.ids = c->d_sel_ids; s1.est = c->d_est;
         if (getenv("MCX_TIMING")) { // where the time of the large-capacity tier goes (not added to the caller's stage times)
             mcx_stats t1; memset(&t1, 0, sizeof t1);
-            rc = run_pairs(c, 1, rb, paired, s1, d_recs, d_cig, &t1, true);
+            rc = run_pairs(c, 1, R0, rb, paired, s1, d_recs, d_cig, &t1, true);
             fprintf(stderr, "[tier 1] %u pairs: seed %.2f sa %.2f cluster %.2f rescue %.2f build %.2f dp %.2f finish %.2f ms\n", m, t1.ms_seed, t1.ms_sa, t1.ms_cluster,
                     t1.ms_rescue, t1.ms_build, t1.ms_dp, t1.ms_finish);
             if (stats) { stats->dp_jobs += t1.dp_jobs; stats->dp_cells += t1.dp_cells; }
         } else
-        rc = run_pairs(c, 1, rb, paired, s1, d_recs, d_cig, stats, false);
+        rc = run_pairs(c, 1, R0, rb, paired, s1, d_recs, d_cig, stats, false);
         if (rc == kListOverflow) return fail(MCX_ERR_CAPACITY, "work list overflow in tier 1");
         if (rc) return rc;
-        if (c->h_cnt[CNT_OV]) {
-            uint32_t first = 0;
-            PairOut po; memset(&po, 0, sizeof po);
-            if (hipMemcpy(&first, c->d_ov, sizeof first, hipMemcpyDeviceToHost) == hipSuccess)
-                (void)hipMemcpy(&po, c->d_pout + first, sizeof po, hipMemcpyDeviceToHost);
-            return fail(MCX_ERR_CAPACITY, "a pair exceeded the tier-1 capacities (pair " + std::to_string(first) + ", overflow flags " + std::to_string(po.flags & kOvAny) +
-                                          ": 1 hits 2 candidates 4 fragments 8 ops 16 jobs 32 cigar 64 rescue window)");
-        }
+        if (c->h_cnt[CNT_OV]) return tier1_error(c, R0);
     }
     return 0;
 }

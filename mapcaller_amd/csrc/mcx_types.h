@@ -132,7 +132,8 @@ enum PairFlags : uint32_t {
     kOvHits = 1u, kOvCands = 2u, kOvFrags = 4u, kOvOps = 8u, kOvJobs = 16u, kOvCigar = 32u, kOvKmer = 64u,
     kOvDetail = 128u,
     kOvAny = 255u,
-    kRescueUsedEst = 256u
+    kRescueUsedEst = 256u,
+    kDispatched = 512u  // listed for the large tier while clustering: this tier's later stages and k_finish leave it alone
 };
 
 struct alignas(16) PairHdr { // 64 bytes: four 16-byte groups
