@@ -381,22 +381,28 @@ class Mapper:
                                    aln.ctypes.data, pool.ctypes.data, C.byref(self.stats)), "mcx_map_batch")
         return aln, [pool[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["n_cigar"])] for a in aln]
 
-    def map_stream(self, host_bases_ptrs, host_off_ptr: int, n_reads: int, paired: bool):
-        """A sequence of equally shaped batches from pinned host memory, results to pinned host memory, the copies of one
-        batch overlapped with the kernels of its neighbours (mcx_stream_*).  Returns (bytes copied in, bytes copied out)."""
+    @staticmethod
+    def stream_outputs(n_reads: int, slots: int = 3):
+        """Pinned host buffers for map_stream's results: [(records uint8[n_reads * 64], CIGAR pool int32[n_reads * CIGAR_STRIDE])]."""
         import torch
+        return [(torch.empty(n_reads * 64, dtype=torch.uint8).pin_memory(), torch.empty(n_reads * CIGAR_STRIDE, dtype=torch.int32).pin_memory())
+                for _ in range(slots)]
+
+    def map_stream(self, host_bases_ptrs, host_off_ptr: int, n_reads: int, paired: bool, outputs=None):
+        """A sequence of equally shaped batches from pinned host memory, results to pinned host memory, the copies of one
+        batch overlapped with the kernels of its neighbours (mcx_stream_*).  ``outputs``: stream_outputs() (batch i lands in
+        slot i % len).  Returns (bytes copied in, bytes copied out)."""
         L = lib()
         k = len(host_bases_ptrs)
-        alns = [torch.empty(n_reads * 64, dtype=torch.uint8).pin_memory() for _ in range(min(k, 3))]
-        cigs = [torch.empty(n_reads * CIGAR_STRIDE, dtype=torch.int32).pin_memory() for _ in range(min(k, 3))]
+        outs = outputs or self.stream_outputs(n_reads, min(k, 3))
         h2d = C.c_uint64()
         d2h = C.c_uint64()
         for i in range(k + 2):  # submit(i); map(i - 1); collect(i - 2)
             if i < k:
                 _check(L.mcx_stream_submit(self._h, host_bases_ptrs[i], host_off_ptr, n_reads), "mcx_stream_submit")
             if 1 <= i <= k:
-                j = (i - 1) % len(alns)
-                _check(L.mcx_stream_map(self._h, int(paired), self.avg, alns[j].data_ptr(), cigs[j].data_ptr(), C.byref(self.stats)), "mcx_stream_map")
+                a, g = outs[(i - 1) % len(outs)]
+                _check(L.mcx_stream_map(self._h, int(paired), self.avg, a.data_ptr(), g.data_ptr(), C.byref(self.stats)), "mcx_stream_map")
             if i >= 2:
                 _check(L.mcx_stream_collect(self._h, C.byref(h2d), C.byref(d2h)), "mcx_stream_collect")
         return h2d.value, d2h.value

@@ -734,7 +734,10 @@ __global__ void __launch_bounds__(256) k_dp_small(Ctx cx, JobSink sink, ReadBatc
     }
 }
 
-__global__ void __launch_bounds__(256, 7) k_finish(Ctx cx, ReadBatch rb, PairSel sel, AlnRec *recs, PairOut *pout, uint32_t *ov_ids, uint32_t *n_ov,
+#ifndef MCX_FINISH_WAVES
+#define MCX_FINISH_WAVES 5
+#endif
+__global__ void __launch_bounds__(256, MCX_FINISH_WAVES) k_finish(Ctx cx, ReadBatch rb, PairSel sel, AlnRec *recs, PairOut *pout, uint32_t *ov_ids, uint32_t *n_ov,
                                                 uint32_t ov_cap, uint32_t *pool_over)
 {
     __shared__ EndsLds ends;
@@ -884,7 +887,7 @@ extern "C" void mcx_opts_default(mcx_opts *o)
 
 static Caps tier0_caps()
 {
-    Caps c; c.hit_cap = 48; c.cand_cap = 12; c.frag_cap = 96; c.ops_cap = 1024; c.job_cap = 16;
+    Caps c; c.hit_cap = 56; c.cand_cap = 12; c.frag_cap = 96; c.ops_cap = 1024; c.job_cap = 16; // (hit_cap above OCC_Thr: one seed at the occurrence limit plus the read's other seeds still fit)
     c.cig_cap = MCX_CIGAR_STRIDE; c.kmer_cap = 2048;
     if (const char *e = getenv("MCX_TIER0_CAPS")) { // experiments: "hits,cands,frags,ops"
         int a, b, d, f;
@@ -1722,10 +1725,10 @@ extern "C" int mcx_map_batch(mcx_ctx *c, const uint8_t *bases, const uint32_t *o
 // ---------------------------------------------------------------------------------------------
 // batches from host memory with the copies overlapped with the kernels
 // ---------------------------------------------------------------------------------------------
-// Bulk copies across the device boundary by a kernel instead of the DMA engines: the batch flow makes a dozen tiny
-// copies per batch (counters, lists) that queue on those engines in order — behind a gigabyte in flight they would
-// each wait for it, and the overlap would be gone.  A few hundred wavefronts keep enough 16-byte requests in
-// flight to fill the link; pinned host memory is mapped into the device's address space.
+// Bulk copies across the device boundary: the DMA engines by default (52 GB/s each way on the test box, and they leave the
+// CUs to the kernels).  MCX_STREAM_KERNEL_COPY=1 moves them with a kernel instead (page-locked host memory is mapped into
+// the device's address space) — measured slower next to the mapping kernels (82 ms instead of 70 ms per 8 M-read batch), kept for
+// boxes whose DMA queues are the bottleneck.
 __global__ void __launch_bounds__(256) k_copy16(const U4 *__restrict__ src, U4 *__restrict__ dst, uint64_t n16)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
@@ -1734,7 +1737,7 @@ __global__ void __launch_bounds__(256) k_copy16(const U4 *__restrict__ src, U4 *
 static int bulk_copy(mcx_ctx *c, void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t s)
 {
     if (bytes == 0) return 0;
-    static const bool use_dma = getenv("MCX_STREAM_DMA") != nullptr;
+    static const bool use_dma = getenv("MCX_STREAM_KERNEL_COPY") == nullptr;
     const size_t n16 = bytes / 16;
     bool mapped = false; // is the host side page-locked memory the device can address?
     {

@@ -576,11 +576,13 @@ def test_native_cli_shards_two_libraries(io_golden, tmp_path):
     assert nd == 0, ex
 
 
-def test_profile_reduce_over_rccl_one_rank(api, golden):
+def test_profile_reduce_over_rccl_one_rank(api, golden, monkeypatch):
     """libmcx_comm.so on the GPU box: a one-rank communicator through RCCL's own entry points (ncclGetUniqueId,
     ncclCommInitRank, ncclReduce) — what a single-GPU box can exercise of the N-GPU reduce."""
     import ctypes
     import torch
+    monkeypatch.setenv("NCCL_SOCKET_IFNAME", "lo")  # (a one-rank bootstrap has no business probing the box's other interfaces)
+    monkeypatch.setenv("NCCL_IB_DISABLE", "1")
     L = ctypes.CDLL(api.COMM_LIB_PATH)
     ident = (ctypes.c_uint8 * 128)()
     assert L.mcx_comm_unique_id(ident) == 0, api.lib().mcx_last_error()
