@@ -356,9 +356,16 @@ struct RescueWave { // one workgroup (any number of wavefronts) evaluates one pa
         const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, n_waves = nt >> 6;
         __syncthreads();
         // The window's bases come from the 2-bit genome: its bytes are copied into LDS once (behind the ids: gb) and the 8-mer
-        // ids are cut out of them, instead of eight byte fetches from HBM per position.  A window lies on one strand
-        // (AlignmentRescue checks its ends' chromosome): the reverse strand is the mirrored forward stretch, complemented.
+        // ids are cut out of them, instead of eight byte fetches from HBM per position.  A window on the reverse strand is the
+        // mirrored forward stretch, complemented.
         uint8_t *gb = (uint8_t *)(kg + slen + 8);
+        if (left < ix.G && left + slen > ix.G) { // the window runs from the end of the forward strand into the reverse strand
+            for (int p = tid; p < slen; p += nt) { // (same chromosome on both sides of G: AlignmentRescue lets it pass): base by base
+                uint32_t wid = MCX_NOKMER;
+                if (p + kKmerSize <= slen) { wid = 0; for (int k = 0; k < kKmerSize; k++) wid = (wid << 2) | (uint32_t)ref_code(ix, left + p + k); }
+                kg[p] = wid;
+            }
+        } else {
         const bool rev = left >= ix.G;
         const int64_t f0 = rev ? ix.G2 - (left + slen) : left;
         const int64_t b0 = f0 >> 2;
@@ -377,6 +384,7 @@ struct RescueWave { // one workgroup (any number of wavefronts) evaluates one pa
                 for (int k = 0; k < kKmerSize; k++) wid = (wid << 2) | base(p + k);
             }
             kg[p] = wid;
+        }
         }
         __syncthreads();
         int best_total = 0, best_d = 0x7fffffff;

@@ -315,6 +315,9 @@ static __device__ __forceinline__ void make_reads(const Ctx &cx, const ReadBatch
         rd[s].rlen = (int32_t)(rb.off[r + 1] - rb.off[r]);
         rd[s].flipped = (cx.pm.paired && s == 1) ? 1 : 0;
         rd[s].codes = (cx.packed && !(cx.read_ext[r] >> 31)) ? cx.packed + (uint64_t)r * cx.wpad : nullptr;
+#ifdef MCX_DEBUG_NO_CODES
+        rd[s].codes = nullptr;
+#endif
     }
 }
 
@@ -952,6 +955,7 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     if ((rc = dmalloc(&c->d_tasks, c->task_cap))) return rc;
     for (int k = 0; k < kDpClasses; k++) {
         c->job_cap[k] = (uint32_t)std::min<uint64_t>(c->max_reads * ((k == 0 || k == 4) ? 4 : ((k == 1 || k == 5) ? 2 : 1)) + 1024, 0x7fffffffu);
+        if (const char *e = getenv("MCX_JOB_CAP")) c->job_cap[k] = std::min<uint32_t>(c->job_cap[k], (uint32_t)std::max(1024, atoi(e))); // (tests: make the lists run over)
         if ((rc = dmalloc(&c->d_jobs[k], c->job_cap[k]))) return rc;
     }
     if ((rc = dmalloc(&c->d_cnt, CNT_N))) return rc;

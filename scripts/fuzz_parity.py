@@ -5,8 +5,8 @@
 
 Every round draws a small genome (contigs, repeats, tandem runs, N runs), a donor with SNPs/indels,
 read length, insert size, error rates, single or paired end, FASTQ or FASTA, algorithm — maps the
-reads with both and compares the SAM line by line and the VCF body.  Not part of the test suite (it
-takes minutes); a divergence prints the round's parameters and keeps its files.
+reads with both and compares the SAM line by line and the VCF body.  tests/test_gpu_parity.py runs 60 + 25
+rounds with fixed seeds; longer runs by hand.  A divergence prints the round's parameters and keeps its files.
 Checker use only: the oracle is the thing compared against, never a fallback.
 """
 import argparse
@@ -25,6 +25,7 @@ EXE = os.path.join(ROOT, "mapcaller_amd", "mapcaller-mi355x")
 ORACLE = os.path.join(ROOT, "oracle", "mcx_oracle")
 REF = os.path.join(ROOT, "oracle", "_ref", "MapCaller")
 MODE = "gpu"  # "gpu": product vs oracle (needs a GPU); "ref": oracle vs the compiled reference (CPU only: pins the oracle)
+CLI_ARGS = []  # extra switches for the product's command line (e.g. -devices 0,0,0 -batch 400: the reads dealt to three shards)
 
 
 def body(path, vcf=False):
@@ -124,7 +125,7 @@ def one_round(d, tmp):
         subprocess.run([REF, "-i", prefix, *files, "-alg", alg, "-sam", gs, "-vcf", gv, "-t", "1", "-log", os.path.join(tmp, "job.log"), *vcf_flags],
                        check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     else:
-        subprocess.run([EXE, "-i", prefix, *files, "-alg", alg, "-sam", gs, "-vcf", gv, *vcf_flags], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.run([EXE, "-i", prefix, *files, "-alg", alg, "-sam", gs, "-vcf", gv, *vcf_flags, *CLI_ARGS], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     subprocess.run([ORACLE, "-i", prefix, *files, "-alg", alg, "-sam", os_], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     subprocess.run([ORACLE, "-i", prefix, *files, "-alg", alg, "-vcf", ov, *vcf_flags], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     if MODE == "ref":
@@ -144,9 +145,11 @@ def main():
     ap.add_argument("--keep", default="")
     ap.add_argument("--only", type=int, default=-1, help="replay just this round of the sequence")
     ap.add_argument("--ref", action="store_true", help="compare the oracle with the compiled reference (oracle/_ref, CPU only) instead of the GPU product")
+    ap.add_argument("--cli-args", default="", help="extra switches for mapcaller-mi355x, space separated")
     a = ap.parse_args()
-    global MODE
+    global MODE, CLI_ARGS
     MODE = "ref" if a.ref else "gpu"
+    CLI_ARGS = a.cli_args.split()
     rng = random.Random(a.seed)
     bad = ran = 0
     for r in range(a.rounds):

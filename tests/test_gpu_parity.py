@@ -356,43 +356,119 @@ def test_cli_two_libraries(io_golden, tmp_path):
     assert nd == 0, ex
 
 
-def test_full_size_genome_prefix_equals_reference(api, tmp_path):
-    """bench.py's workload at full size (GRCh38-sized 3.1 Gbp synthetic genome with its human-like repeat landscape — reads with
-    hundreds of seed hits, mate rescue, the large-capacity tier: 6.2 G text positions,
-    the bucketed index builder, the 15-mer jump table, the full suffix array in HBM): the index is built on the GPU, saved, and the
-    first 60 k pairs of a bench batch go through the product's file path and through the CPU checker
-    (the compiled reference at -t 1 when it travelled, else the oracle restatement).  The insert-size
-    trajectory of a prefix is the trajectory of the run, so the SAM must be identical."""
+@pytest.fixture(scope="module")
+def bench_genome(api, tmp_path_factory):
+    """bench.py's workload at full size: the GRCh38-sized (3.1 Gbp, 6.2 G text positions) synthetic genome with its human-like repeat
+    landscape, indexed on the GPU (the bucketed index builder, the 15-mer jump table, the full suffix array in HBM) and saved for
+    the CPU checker.  Shared by the tests that need it: building it takes most of a minute."""
     import argparse
     import torch
     sys.path.insert(0, ROOT)
     import bench
-    from mapcaller_amd import synth
     dev = torch.device("cuda", 0)
-    args = argparse.Namespace(genome_mbp=3100.0, contigs=24, repeats=2000, genome="human")  # bench.py's default: the human-like repeat landscape
+    args = argparse.Namespace(genome_mbp=3100.0, contigs=24, repeats=2000, genome="human")  # bench.py's default
     codes, lens, _ = bench.make_genome(args, dev, seed=1234)
     ix = api.Index.from_codes(codes.data_ptr(), lens, device=0, full_sa=True)
-    prefix = str(tmp_path / "big")
+    prefix = str(tmp_path_factory.mktemp("big") / "big")
     ix.save(prefix)
-    n_pairs = 60000
-    reads = bench.make_reads(codes, lens, n_pairs, 150, seed=1000, device=dev).reshape(2 * n_pairs, 150).cpu()
-    del codes
-    f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
-    synth.write_fastq(f1, reads, 0, 2); synth.write_fastq(f2, reads, 1, 2)
-    mp = api.Mapper(ix, alg="ksw2", max_batch_reads=1 << 16)
-    out = str(tmp_path / "gpu.sam")
-    st = mp.map_files(f1, f2, out)
-    mp.close(); ix.close()
-    chk = str(tmp_path / "chk.sam")
+    yield {"codes": codes, "lens": lens, "index": ix, "prefix": prefix, "bench": bench, "dev": dev}
+    ix.close()
+
+
+def _checker_sam(prefix, f1, f2, alg, out, tmp_path):
+    """The compiled reference at -t 1 when it travelled to this box, else the oracle restatement."""
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "MapCaller")
     if os.path.exists(ref_bin):
-        cmd = [ref_bin, "-i", prefix, "-f", f1, "-f2", f2, "-alg", "ksw2", "-sam", chk, "-no_vcf", "-t", "1", "-log", str(tmp_path / "job.log")]
+        cmd = [ref_bin, "-i", prefix, "-f", f1, "-f2", f2, "-alg", alg, "-sam", out, "-no_vcf", "-t", "1", "-log", str(tmp_path / "job.log")]
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1500)
     else:
-        _oracle_sam(prefix, f1, f2, "ksw2", chk)
+        _oracle_sam(prefix, f1, f2, alg, out)
+
+
+def test_full_size_genome_prefix_equals_reference(api, bench_genome, tmp_path):
+    """BASELINE config 3 at full size: the first 60 k pairs of a bench batch (150 bp, -alg ksw2) go through the product's file path and
+    through the CPU checker.  Reads from repeats bring hundreds of seed hits, mate rescue and the large-capacity tier with them
+    (asserted).  The insert-size trajectory of a prefix is the trajectory of the run, so the SAM must be identical."""
+    from mapcaller_amd import synth
+    g = bench_genome
+    n_pairs = 60000
+    reads = g["bench"].make_reads(g["codes"], g["lens"], n_pairs, 150, seed=1000, device=g["dev"]).reshape(2 * n_pairs, 150).cpu()
+    f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+    synth.write_fastq(f1, reads, 0, 2); synth.write_fastq(f2, reads, 1, 2)
+    mp = api.Mapper(g["index"], alg="ksw2", max_batch_reads=1 << 16)
+    out = str(tmp_path / "gpu.sam")
+    st = mp.map_files(f1, f2, out)
+    mp.close()
+    chk = str(tmp_path / "chk.sam")
+    _checker_sam(g["prefix"], f1, f2, "ksw2", chk, tmp_path)
     nd, ex = sam_diff(chk, out)
     assert nd == 0, ex
     assert st["mapped"] > 0.95 * st["reads"]
+    assert st["tier1_pairs"] > 0, st  # pairs over the tier-0 capacities did go through the large tier
+
+
+def test_config5_indel_heavy_long_pairs_equal_reference(api, bench_genome, tmp_path, monkeypatch):
+    """BASELINE config 5 read literally: 250 bp pairs with 5 % indels per base (2.5 % insertions + 2.5 % deletions), -alg nw, against the
+    full-size index, 200 k pairs in ONE batch — several gapped fragments per read.  The DP job lists are held to 200 k entries here
+    (MCX_JOB_CAP; at bench.py's batch size they run over by themselves), so the pass runs over and the selection is mapped in
+    halves (asserted).  The reference's gates leave few of these reads mapped; mostly-unmapped output is the expected answer,
+    line for line."""
+    from mapcaller_amd import synth
+    g = bench_genome
+    n_pairs = 200_000
+    reads = g["bench"].make_reads(g["codes"], g["lens"], n_pairs, 250, seed=77, device=g["dev"], sub=0.005, ins=0.025, dele=0.025).reshape(2 * n_pairs, 250).cpu()
+    f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+    synth.write_fastq(f1, reads, 0, 2); synth.write_fastq(f2, reads, 1, 2)
+    monkeypatch.setenv("MCX_JOB_CAP", "200000")
+    mp = api.Mapper(g["index"], alg="nw", max_read_len=256, max_batch_reads=2 * n_pairs)
+    monkeypatch.delenv("MCX_JOB_CAP")
+    out = str(tmp_path / "gpu.sam")
+    st = mp.map_files(f1, f2, out)
+    mp.close()
+    chk = str(tmp_path / "chk.sam")
+    _checker_sam(g["prefix"], f1, f2, "nw", chk, tmp_path)
+    nd, ex = sam_diff(chk, out)
+    assert nd == 0, ex
+    assert st["dp_jobs"] > 2 * st["reads"], st       # config 5's character: several DP problems per read
+    assert st["halved_selections"] > 0, st           # the job lists did run over and the batch was mapped in halves
+    assert 0 < st["mapped"] < 0.5 * st["reads"], st
+
+
+def test_fuzz_rounds_equal_oracle():
+    """scripts/fuzz_parity.py inside the suite, bounded: 60 rounds with fixed seeds — random genomes (contigs, repeats, tandem and N runs),
+    donors, read lengths 36-300, single / paired, FASTQ / FASTA, error rates up to 5 % substitutions and 1 % indels, both algorithms, the
+    variant-calling switches — the CLI's SAM and VCF against the oracle's, line by line."""
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "--rounds", "60", "--seed", "2027"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1400)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "60 of 60 rounds identical" in r.stdout
+
+
+def test_fuzz_rounds_on_three_shards_equal_oracle():
+    """The same generator with the reads dealt to three shards (mapcaller-mi355x -devices 0,0,0, batches of 400 reads): 25 rounds — the
+    oracle is a single stream, so every round checks the shards' exchange (insert-size trajectory, duplicate cap, discordant-pair events)."""
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "--rounds", "25", "--seed", "909", "--cli-args", "-devices 0,0,0 -batch 400"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1400)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "25 of 25 rounds identical" in r.stdout
+
+
+def test_overlong_read_is_refused(api, golden):
+    """One read longer than the context's max_read_len in a batch handed over through the C ABI: refused before any kernel touches the
+    per-read slots (the file front end names the read; here the batch fails as a whole)."""
+    g = golden["toy"]
+    ix = api.Index(g["prefix"], device=0, full_sa=True)
+    mp = api.Mapper(ix, alg="ksw2", max_read_len=128, max_batch_reads=64)
+    seqs = [b"ACGT" * 25, b"ACGT" * 25, b"ACGT" * 40, b"ACGT" * 25]  # 100, 100, 160 (> 128), 100 bases
+    off = np.zeros(5, dtype=np.uint32)
+    off[1:] = np.cumsum([len(x) for x in seqs])
+    with pytest.raises(api.McxError, match="longer than max_read_len"):
+        mp.map_batch(np.frombuffer(b"".join(seqs), dtype=np.uint8).copy(), off, True)
+    ok = [b"ACGT" * 25] * 4  # the context is still usable
+    off[1:] = np.cumsum([len(x) for x in ok])
+    aln, _ = mp.map_batch(np.frombuffer(b"".join(ok), dtype=np.uint8).copy(), off, True)
+    assert len(aln) == 4
+    mp.close(); ix.close()
 
 
 def test_ragged_reads_equal_oracle(api, tmp_path):
