@@ -370,101 +370,136 @@ static inline MCX_HD bool seed_next_start(const PackedRead &pk, int rlen, int &p
     return p < stop;
 }
 
-// One search of the greedy walk, from start p (found by seed_next_start) — its three phases as loops
-// of their own: the lanes of a wave sit at unrelated points of their reads, but with this shape they
-// run the same phase at the same time (jump-table fetches together, FM steps together, window
-// comparisons together) instead of serialising each other's phases.  Leaves p at the next candidate start.
+// One search of the greedy walk, from start p (found by seed_next_start), in resumable pieces: its three phases as loops of
+// their own, each with a budget of steps.  The lanes of a wave sit at unrelated points of their reads; with this shape they
+// run the same phase at the same time (jump-table fetches together, FM steps together, window comparisons together) instead
+// of serialising each other's phases, and a lane deep inside a repeat (dozens of FM steps with a wide interval) holds the
+// others up for one budget at a time, not for its whole walk: they go on to their comparison phase, their hits and their
+// next search while it continues where it stopped.
+struct SeedWalk {
+    uint64_t x0, x1, x2;   // the bi-interval (BWT_Search's ik)
+    int64_t tpos;          // phase 2: text position of the one suffix left
+    uint32_t carry;        // phase 2: the packed genome word two consecutive windows share
+    int32_t carry_dir;     // 0: none, +1: forward strand (carry = the next window's high word), -1: reverse strand (its low word)
+    int32_t start;         // read position the search began at
+    int32_t phase;         // 0: no search under way, 1: FM steps, 2: window comparison, 3: over (hits to be taken)
+    int32_t ended;         // the FM phase met an N, the read's end or an empty extension: no comparison phase
+};
+
+// phase 0 -> 1: the start of a search at p — the jump table's entry when the next ktab_k bases hold no N and occur in the text
+static inline MCX_HD void seed_begin(const IndexView &ix, const PackedRead &pk, int rlen, uint32_t nm, int &p, SeedWalk &w)
+{
+    w.start = p; w.ended = 0; w.tpos = 0; w.carry = 0; w.carry_dir = 0;
+    const uint32_t c16 = packed_codes16(pk, p);
+    bool jumped = false;
+    if (ix.ktab && p + ix.ktab_k <= rlen && (nm >> (32 - ix.ktab_k)) == 0)
+        if (ktab_lookup(ix, c16 >> (32 - 2 * ix.ktab_k), w.x0, w.x1, w.x2)) { p += ix.ktab_k; jumped = true; }
+    if (!jumped) { const int c = (int)(c16 >> 30); w.x0 = ix.L2[c] + 1; w.x1 = ix.L2[3 - c] + 1; w.x2 = ix.L2[c + 1] - ix.L2[c]; p++; }
+    w.phase = 1;
+}
+
+// phase 1: FM steps while the interval holds several suffixes (or none: the step then ends the search); at most max_steps of them
+static inline MCX_HD void seed_fm(const IndexView &ix, const PackedRead &pk, int rlen, int &p, SeedWalk &w, int64_t &blocks, int max_steps)
+{
+    int steps = 0;
+    while (w.x2 != 1 && !w.ended && steps < max_steps) {
+        steps++;
+        const uint32_t nm2 = packed_nmask32(pk, p, rlen);
+        if (nm2 & 0x80000000u) { w.ended = 1; break; } // N or read end
+        const int c = (int)(packed_codes16(pk, p) >> 30);
+        uint64_t tk[4], tl[4];
+        int nb;
+        fm_2occ4(ix, w.x1 - 1, w.x1 - 1 + w.x2, tk, tl, nb);
+        blocks += nb;
+        const int b = 3 - c;
+        const uint64_t n2 = tl[b] - tk[b];
+        if (n2 == 0) { w.ended = 1; break; }
+        // ok[3].x0 = ik.x0 + primary correction; lower bases stack on top (:143-146)
+        uint64_t n0 = w.x0 + ((w.x1 <= ix.primary && w.x1 + w.x2 - 1 >= ix.primary) ? 1 : 0);
+        for (int bb = 3; bb > b; bb--) n0 += tl[bb] - tk[bb];
+        w.x0 = n0; w.x1 = ix.L2[b] + 1 + tk[b]; w.x2 = n2;
+        p++;
+    }
+    if (w.ended) w.phase = 3;
+    else if (w.x2 == 1) { // exactly one suffix left: the rest of the search is a comparison with the text itself
+        int lf = 0;
+        w.tpos = (int64_t)fm_sa(ix, w.x0, lf);
+        w.carry = 0; w.carry_dir = 0;
+        w.phase = 2;
+    }
+}
+
+// phase 2: the pattern has one occurrence in the text, so "can it be extended by base c" is "is the next text base c":
+// 16-base windows of the packed read against the 2-bit genome, at most max_windows of them.  Consecutive windows overlap by
+// one packed genome word: while the walk advances by whole windows the word is carried over, so each further window costs ONE
+// 4-byte fetch.
+static inline MCX_HD void seed_compare(const IndexView &ix, const PackedRead &pk, int rlen, int &p, SeedWalk &w, int max_windows)
+{
+    for (int k = 0; k < max_windows; k++) {
+        const int64_t j = w.tpos + (p - w.start);
+        int64_t room = (int64_t)ix.seq_len - j;
+        if (rlen - p < room) room = rlen - p;
+        if (room <= 0) { w.phase = 3; return; }
+        uint32_t ref;
+        if (j + 16 <= ix.G) { // forward strand: funnel shift of two big-endian words of the .pac bytes
+            const uint32_t *wp = (const uint32_t *)ix.pac + (j >> 4);
+            const int sh = (int)(j & 15) * 2;
+            const uint32_t hi = w.carry_dir > 0 ? w.carry : __builtin_bswap32(wp[0]), lo = __builtin_bswap32(wp[1]);
+            ref = sh ? (hi << sh) | (lo >> (32 - sh)) : hi;
+            w.carry = lo; w.carry_dir = 1;
+        } else if (j >= ix.G && j + 16 <= ix.G2) { // reverse strand: the mirrored forward window, reversed and complemented
+            const int64_t f = ix.G2 - 16 - j;
+            const uint32_t *wp = (const uint32_t *)ix.pac + (f >> 4);
+            const int sh = (int)(f & 15) * 2;
+            const uint32_t hi = __builtin_bswap32(wp[0]), lo = w.carry_dir < 0 ? w.carry : __builtin_bswap32(wp[1]);
+            uint32_t v = __builtin_bswap32(sh ? (hi << sh) | (lo >> (32 - sh)) : hi);
+            v = ((v & 0x0F0F0F0Fu) << 4) | ((v >> 4) & 0x0F0F0F0Fu);
+            v = ((v & 0x33333333u) << 2) | ((v >> 2) & 0x33333333u);
+            ref = ~v;
+            w.carry = hi; w.carry_dir = -1;
+        } else { ref = ref_codes16(ix, j); w.carry_dir = 0; }
+        const uint32_t x = packed_codes16(pk, p) ^ ref;
+        uint32_t sp = packed_nmask32(pk, p, rlen) >> 16; // N flags, bit 15-s -> bit 30-2s
+        sp = (sp | (sp << 8)) & 0x00FF00FFu; sp = (sp | (sp << 4)) & 0x0F0F0F0Fu;
+        sp = (sp | (sp << 2)) & 0x33333333u; sp = (sp | (sp << 1)) & 0x55555555u;
+        const uint32_t mm = ((x | (x >> 1)) & 0x55555555u) | sp; // bit 30-2s: base s differs or is N
+        int same = mm ? (__builtin_clz(mm) >> 1) : 16;
+        if (same > room) same = (int)room;
+        p += same;
+        if (same < 16) { w.phase = 3; return; }
+    }
+}
+
+// phase 3 -> 0: the search is over — its hits (BWT_Search's len >= MinSeedLength && freq <= OCC_Thr), p at the next candidate start
+static inline MCX_HD void seed_take(const IndexView &ix, int &p, SeedWalk &w, Hit *hits, int cap, int &n_hits, int64_t &ext_steps)
+{
+    const int len = p - w.start;
+    ext_steps += len;
+    if (len >= kMinSeedLength && w.x2 <= (uint64_t)kOccThr) {
+        // with every suffix-array entry in memory a row resolves with one fetch, here and now: all hits
+        // then leave as text positions, unflagged, and nothing is left for the SA pass
+        const bool direct = ix.sa_full != nullptr;
+        if (w.x2 == 1 && !w.ended) {
+            if (n_hits < cap) { Hit h; h.gPos = w.tpos; h.rPos = w.start; h.len = direct ? len : (len | kHitResolved); hits[n_hits] = h; }
+            n_hits++;
+        } else for (uint64_t i = 0; i < w.x2; i++) {
+            if (n_hits < cap) { Hit h; h.gPos = direct ? (int64_t)ix.sa_full[w.x0 + i] : (int64_t)(w.x0 + i); h.rPos = w.start; h.len = len; hits[n_hits] = h; }
+            n_hits++;
+        }
+    }
+    p = p + 1;
+    w.phase = 0;
+}
+
+// one whole search (the host emulation's form)
 static inline MCX_HD void seed_search(const IndexView &ix, const PackedRead &pk, int rlen, uint32_t nm, int &p, Hit *hits, int cap,
                                       int &n_hits, int64_t &ext_steps, int64_t &blocks)
 {
-    {
-        const int start = p;
-        uint64_t x0 = 0, x1 = 0, x2 = 0;
-        {
-            const uint32_t c16 = packed_codes16(pk, p);
-            bool jumped = false;
-            if (ix.ktab && p + ix.ktab_k <= rlen && (nm >> (32 - ix.ktab_k)) == 0)
-                if (ktab_lookup(ix, c16 >> (32 - 2 * ix.ktab_k), x0, x1, x2)) { p += ix.ktab_k; jumped = true; }
-            if (!jumped) { const int c = (int)(c16 >> 30); x0 = ix.L2[c] + 1; x1 = ix.L2[3 - c] + 1; x2 = ix.L2[c + 1] - ix.L2[c]; p++; }
-        }
-        // phase 2: FM steps while the interval holds several suffixes (or none: the step then ends the search)
-        bool end = false;
-        while (x2 != 1 && !end) {
-            const uint32_t nm2 = packed_nmask32(pk, p, rlen);
-            if (nm2 & 0x80000000u) { end = true; break; } // N or read end
-            const int c = (int)(packed_codes16(pk, p) >> 30);
-            uint64_t tk[4], tl[4];
-            int nb;
-            fm_2occ4(ix, x1 - 1, x1 - 1 + x2, tk, tl, nb);
-            blocks += nb;
-            const int b = 3 - c;
-            const uint64_t n2 = tl[b] - tk[b];
-            if (n2 == 0) { end = true; break; }
-            // ok[3].x0 = ik.x0 + primary correction; lower bases stack on top (:143-146)
-            uint64_t n0 = x0 + ((x1 <= ix.primary && x1 + x2 - 1 >= ix.primary) ? 1 : 0);
-            for (int bb = 3; bb > b; bb--) n0 += tl[bb] - tk[bb];
-            x0 = n0; x1 = ix.L2[b] + 1 + tk[b]; x2 = n2;
-            p++;
-        }
-        // phase 3: exactly one suffix left — the rest of the search against the text itself
-        int64_t tpos = 0;
-        if (!end) {
-            int lf = 0;
-            tpos = (int64_t)fm_sa(ix, x0, lf);
-            // Consecutive windows overlap by one packed genome word: while the walk advances by whole
-            // windows the word is carried over, so each further window costs ONE 4-byte fetch.
-            uint32_t carry = 0;
-            int carry_dir = 0; // 0: none, +1: forward strand (carry = next window's high word), -1: reverse strand (its low word)
-            for (;;) {
-                const int64_t j = tpos + (p - start);
-                int64_t room = (int64_t)ix.seq_len - j;
-                if (rlen - p < room) room = rlen - p;
-                if (room <= 0) break;
-                uint32_t ref;
-                if (j + 16 <= ix.G) { // forward strand: funnel shift of two big-endian words of the .pac bytes
-                    const uint32_t *wp = (const uint32_t *)ix.pac + (j >> 4);
-                    const int sh = (int)(j & 15) * 2;
-                    const uint32_t hi = carry_dir > 0 ? carry : __builtin_bswap32(wp[0]), lo = __builtin_bswap32(wp[1]);
-                    ref = sh ? (hi << sh) | (lo >> (32 - sh)) : hi;
-                    carry = lo; carry_dir = 1;
-                } else if (j >= ix.G && j + 16 <= ix.G2) { // reverse strand: the mirrored forward window, reversed and complemented
-                    const int64_t f = ix.G2 - 16 - j;
-                    const uint32_t *wp = (const uint32_t *)ix.pac + (f >> 4);
-                    const int sh = (int)(f & 15) * 2;
-                    const uint32_t hi = __builtin_bswap32(wp[0]), lo = carry_dir < 0 ? carry : __builtin_bswap32(wp[1]);
-                    uint32_t v = __builtin_bswap32(sh ? (hi << sh) | (lo >> (32 - sh)) : hi);
-                    v = ((v & 0x0F0F0F0Fu) << 4) | ((v >> 4) & 0x0F0F0F0Fu);
-                    v = ((v & 0x33333333u) << 2) | ((v >> 2) & 0x33333333u);
-                    ref = ~v;
-                    carry = hi; carry_dir = -1;
-                } else { ref = ref_codes16(ix, j); carry_dir = 0; }
-                const uint32_t x = packed_codes16(pk, p) ^ ref;
-                uint32_t sp = packed_nmask32(pk, p, rlen) >> 16; // N flags, bit 15-s -> bit 30-2s
-                sp = (sp | (sp << 8)) & 0x00FF00FFu; sp = (sp | (sp << 4)) & 0x0F0F0F0Fu;
-                sp = (sp | (sp << 2)) & 0x33333333u; sp = (sp | (sp << 1)) & 0x55555555u;
-                const uint32_t mm = ((x | (x >> 1)) & 0x55555555u) | sp; // bit 30-2s: base s differs or is N
-                int same = mm ? (__builtin_clz(mm) >> 1) : 16;
-                if (same > room) same = (int)room;
-                p += same;
-                if (same < 16) break;
-            }
-        }
-        const int len = p - start;
-        ext_steps += len;
-        if (len >= kMinSeedLength && x2 <= (uint64_t)kOccThr) {
-            // with every suffix-array entry in memory a row resolves with one fetch, here and now: all hits
-            // then leave as text positions, unflagged, and nothing is left for the SA pass
-            const bool direct = ix.sa_full != nullptr;
-            if (x2 == 1) {
-                if (n_hits < cap) { Hit h; h.gPos = tpos; h.rPos = start; h.len = direct ? len : (len | kHitResolved); hits[n_hits] = h; }
-                n_hits++;
-            } else for (uint64_t i = 0; i < x2; i++) {
-                if (n_hits < cap) { Hit h; h.gPos = direct ? (int64_t)ix.sa_full[x0 + i] : (int64_t)(x0 + i); h.rPos = start; h.len = len; hits[n_hits] = h; }
-                n_hits++;
-            }
-        }
-        p = p + 1;
-    }
+    SeedWalk w;
+    seed_begin(ix, pk, rlen, nm, p, w);
+    while (w.phase == 1) seed_fm(ix, pk, rlen, p, w, blocks, 1 << 30);
+    while (w.phase == 2) seed_compare(ix, pk, rlen, p, w, 1 << 30);
+    seed_take(ix, p, w, hits, cap, n_hits, ext_steps);
 }
 
 static inline MCX_HD int seed_read(const IndexView &ix, const ReadRef &rd, PackedRead pk, Hit *hits, int cap,

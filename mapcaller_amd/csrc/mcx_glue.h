@@ -53,16 +53,20 @@ static inline MCX_HD int prep_seeds(Hit *h, int n)
         const Hit x = h[i];
         if (hit_pd(x) > 0) { if (m != i) h[m] = x; m++; }
     }
-    for (int i = 1; i < m; i++) {
-        const Hit key = h[i];
-        const int64_t kpd = hit_pd(key);
-        int j = i - 1;
-        while (j >= 0) {
-            const Hit y = h[j];
-            const int64_t pd = hit_pd(y);
-            if (pd > kpd || (pd == kpd && y.rPos > key.rPos)) { h[j + 1] = y; j--; } else break;
+    // insertion sort; long lists (reads from repeats: hundreds of seeds in suffix-array order) first in strides, so that
+    // no element travels far one step at a time.  Equal keys are equal seeds: any order of them is the reference's.
+    for (int gap = m > 24 ? (m > 400 ? 109 : 23) : 1; gap >= 1; gap = gap > 23 ? 23 : (gap > 5 ? 5 : (gap > 1 ? 1 : 0))) {
+        for (int i = gap; i < m; i++) {
+            const Hit key = h[i];
+            const int64_t kpd = hit_pd(key);
+            int j = i - gap;
+            while (j >= 0) {
+                const Hit y = h[j];
+                const int64_t pd = hit_pd(y);
+                if (pd > kpd || (pd == kpd && y.rPos > key.rPos)) { h[j + gap] = y; j -= gap; } else break;
+            }
+            if (j + gap != i) h[j + gap] = key;
         }
-        if (j + 1 != i) h[j + 1] = key;
     }
     return m;
 }
@@ -547,10 +551,10 @@ static inline MCX_HD void stage_cluster_pair(const Ctx &cx, int64_t pair, const 
     MCX_UNROLL // (written to unroll: a header indexed by a run-time mate number lives in scratch memory)
     for (int s = 0; s < 2; s++) {
         if (s >= nr) break;
-        if (h.n_hits[s] > cx.caps.hit_cap) { h.flags |= kOvHits; h.n_hits[s] = 0; }
+        if (h.n_hits[s] > cx.caps.hit_seed) { h.flags |= kOvHits; h.n_hits[s] = 0; }
         h.n_hits[s] = prep_seeds(st.hits[s], h.n_hits[s]);
-        int nc = cluster_seeds(cx.ix, cx.pm, rd[s].rlen, st.hits[s], h.n_hits[s], st.cands[s], cx.caps.cand_cap);
-        if (nc > cx.caps.cand_cap) { h.flags |= kOvCands; nc = 0; }
+        int nc = cluster_seeds(cx.ix, cx.pm, rd[s].rlen, st.hits[s], h.n_hits[s], st.cands[s], cx.caps.cand_seed);
+        if (nc > cx.caps.cand_seed) { h.flags |= kOvCands; nc = 0; }
         h.n_cands[s] = nc;
         h.sum[s].best = -1; h.sum[s].score = 0; h.sum[s].sub = 0;
     }

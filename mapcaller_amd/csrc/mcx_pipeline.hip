@@ -437,9 +437,12 @@ __global__ void __launch_bounds__(256) k_pack_reads(ReadBatch rb, int paired, in
 // lanes with work, and the launch ends when the queue does, not block by block.
 constexpr int kSeedReadsPerLane = 4; // reads per lane and chunk (small selections: one, their launch is as long as its longest chain of reads)
 
+// FM steps a lane takes before the wave looks at its other lanes again (MCX_SEED_FM_BUDGET for experiments)
+static inline int seed_fm_budget() { static const int b = getenv("MCX_SEED_FM_BUDGET") ? std::max(1, atoi(getenv("MCX_SEED_FM_BUDGET"))) : 6; return b; }
+
 static inline int seed_reads_per_lane(uint64_t n_reads) { return n_reads >= (uint64_t)1 << 21 ? kSeedReadsPerLane : (n_reads >= (uint64_t)1 << 19 ? 2 : 1); }
 
-__global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel, SeedOut so, int pk_words, int reads_per_lane)
+__global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel, SeedOut so, int pk_words, int reads_per_lane, int fm_budget)
 {
     extern __shared__ uint32_t pk_lds[]; // packed reads: word k of lane t at pk_lds[k * blockDim.x + t]
     const int nr = cx.pm.paired ? 2 : 1;
@@ -455,11 +458,11 @@ __global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel,
     Hit *hits = nullptr;
     // the read is done: counters, and SA tasks for the hits that are still BWT rows (the others carry their text position)
     uint32_t has_n = 0;
-    int cap = cx.caps.hit_cap;
+    int cap = cx.caps.hit_seed;
     auto finish_read = [&]() {
         so.read_ext[r] = (uint32_t)ext | (has_n << 31); so.read_blocks[r] = (uint32_t)blocks | ((uint32_t)n << 20); // (ext < 2^31; blocks < 2^20; n < 2^12)
         if (cx.ix.sa_full) return; // every hit already carries its text position (seed_search)
-        const int keep = n <= cx.caps.hit_cap ? n : 0; // overflowing reads are re-run in the next tier
+        const int keep = n <= cx.caps.hit_seed ? n : 0; // overflowing reads are re-run in the next tier
         int todo = 0;
         for (int i = 0; i < keep; i++) if (!(hits[i].len & kHitResolved)) todo++;
         uint32_t at = todo ? atomicAdd(so.n_tasks, (uint32_t)todo) : 0u;
@@ -469,6 +472,7 @@ __global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel,
             at++;
         }
     };
+    SeedWalk walk; walk.phase = 0;
     uint32_t q_next = 0, q_end = 0; // the wave's chunk of the queue (the same in every lane)
     bool dry = false;               // the queue has nothing left
     for (;;) {
@@ -496,7 +500,7 @@ __global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel,
             rlen = (int)(rb.off[r + 1] - rb.off[r]);
             if (so.fast_hits) { hits = so.fast_hits + (uint64_t)r * so.fast_cap; cap = so.fast_cap; }
             else hits = pair_state(cx.state, cx.lay, cx.caps, lr / nr).hits[lr % nr];
-            n = 0; p = 0; ext = 0; blocks = 0; has_n = 0;
+            n = 0; p = 0; ext = 0; blocks = 0; has_n = 0; walk.phase = 0;
             const int words = packed_words(rlen);
             if (rlen > 0 && words <= pk_words) {
                 const U4 *src = (const U4 *)(so.packed + (uint64_t)r * so.wpad);
@@ -523,9 +527,13 @@ __global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel,
             if (!have) finish_read(); // (nothing to search in it: the lane takes another one next time round)
         }
         if (!__ballot(have)) { if (dry) break; continue; }
-        // ---- one search of every lane that holds a read ----
-        if (have) {
-            seed_search(cx.ix, pk, rlen, nm, p, hits, cap, n, ext, blocks);
+        // ---- every lane that holds a read moves its search on: each phase with a budget, so that a lane deep inside a repeat
+        //      (dozens of FM steps) holds the wave up for a few steps at a time while the others finish searches and take new reads ----
+        if (have && walk.phase == 0) seed_begin(cx.ix, pk, rlen, nm, p, walk);
+        if (have && walk.phase == 1) seed_fm(cx.ix, pk, rlen, p, walk, blocks, fm_budget);
+        if (have && walk.phase == 2) seed_compare(cx.ix, pk, rlen, p, walk, 1 << 30);
+        if (have && walk.phase == 3) {
+            seed_take(cx.ix, p, walk, hits, cap, n, ext);
             if (!seed_next_start(pk, rlen, p, nm)) { finish_read(); have = false; }
         }
     }
@@ -890,11 +898,12 @@ extern "C" void mcx_opts_default(mcx_opts *o)
 
 static Caps tier0_caps()
 {
-    Caps c; c.hit_cap = 56; c.cand_cap = 12; c.frag_cap = 96; c.ops_cap = 1024; c.job_cap = 16; // (hit_cap above OCC_Thr: one seed at the occurrence limit plus the read's other seeds still fit)
+    // (hit_seed above OCC_Thr: one seed at the occurrence limit plus the read's other seeds still fit)
+    Caps c; c.hit_cap = 64; c.hit_seed = 56; c.cand_cap = 16; c.cand_seed = 12; c.frag_cap = 96; c.ops_cap = 1024; c.job_cap = 16;
     c.cig_cap = MCX_CIGAR_STRIDE; c.kmer_cap = 2048;
     if (const char *e = getenv("MCX_TIER0_CAPS")) { // experiments: "hits,cands,frags,ops"
         int a, b, d, f;
-        if (sscanf(e, "%d,%d,%d,%d", &a, &b, &d, &f) == 4) { c.hit_cap = a; c.cand_cap = b; c.frag_cap = d; c.ops_cap = f; }
+        if (sscanf(e, "%d,%d,%d,%d", &a, &b, &d, &f) == 4) { c.hit_cap = c.hit_seed = a; c.cand_cap = c.cand_seed = b; c.frag_cap = d; c.ops_cap = f; }
     }
     return c;
 }
@@ -904,6 +913,7 @@ static Caps tier1_caps(int rlen_max)
     int seeds = rlen_max / (kMinSeedLength + 1) + 1;
     c.hit_cap = seeds * kOccThr + rlen_max / 8 + 16;
     c.cand_cap = c.hit_cap;
+    c.hit_seed = c.hit_cap; c.cand_seed = c.cand_cap; // (hard bounds already count what the rescue can add)
     c.frag_cap = 3 * c.hit_cap + 16;
     c.ops_cap = 96 * 1024; c.job_cap = 2048;
     c.cig_cap = MCX_CIGAR_STRIDE; c.kmer_cap = 4096;
@@ -1174,7 +1184,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         const int threads = pkw * 256 * 4 <= 48 * 1024 ? 256 : (pkw * 128 * 4 <= 48 * 1024 ? 128 : 64);
         const int rpl = seed_reads_per_lane((uint64_t)sel.n * nr);
         const unsigned blocks_s = std::min<unsigned>((sel.n * nr + threads * rpl - 1) / (threads * rpl), 4096u); // (the queue feeds whatever grid runs)
-        k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl);
+        k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl, seed_fm_budget());
     }
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     if (R.d_tasks) k_sa<<<4096, 256, 0, s>>>(cx, so, paired, R.d_cnt + CNT_LF);
@@ -1339,7 +1349,7 @@ static int run_fast(mcx_ctx *c, const ReadBatch &rb, int paired, int32_t est, ui
         const int threads = pkw * 256 * 4 <= 48 * 1024 ? 256 : (pkw * 128 * 4 <= 48 * 1024 ? 128 : 64);
         const int rpl = seed_reads_per_lane((uint64_t)n_pairs * nr);
         const unsigned blocks_s = std::min<unsigned>((n_pairs * nr + threads * rpl - 1) / (threads * rpl), 4096u);
-        k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl);
+        k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl, seed_fm_budget());
     }
     HIP_TRY(hipEventRecord(c->ev_fast[1], s));
     FastIn in; in.hits = c->d_fast_hits; in.packed = c->d_packed; in.wpad = c->wpad; in.read_ext = c->d_read_ext; in.read_blocks = c->d_read_blocks; in.est = est;

@@ -60,6 +60,8 @@ struct Params {
 struct Caps {
     int32_t hit_cap;   // seed hits per read (incl. rescue seeds)
     int32_t cand_cap;  // candidates per read
+    int32_t hit_seed;  // of hit_cap, what seeding may fill (the rest is room for mate rescue's seeds: a pair that runs over
+    int32_t cand_seed; // while clustering goes to the large tier beside the pass; one that runs over in the rescue has to wait for its end)
     int32_t frag_cap;  // fragments per pair (all live candidates of both reads)
     int32_t ops_cap;   // DP op bytes per pair
     int32_t job_cap;   // DP jobs per pair

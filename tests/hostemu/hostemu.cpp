@@ -226,6 +226,7 @@ int64_t hostemu_map_files(const char *prefix, const char *fq1, const char *fq2, 
     int seeds = rlen_max / (kMinSeedLength + 1) + 1;
     e.caps[1].hit_cap = seeds * kOccThr + rlen_max / 8 + 16; e.caps[1].cand_cap = e.caps[1].hit_cap;
     e.caps[1].frag_cap = 3 * e.caps[1].hit_cap + 16; e.caps[1].ops_cap = 96 * 1024; e.caps[1].job_cap = 2048;
+    for (int t = 0; t < 2; t++) { e.caps[t].hit_seed = e.caps[t].hit_cap; e.caps[t].cand_seed = e.caps[t].cand_cap; }
     e.caps[1].cig_cap = 32; e.caps[1].kmer_cap = 4096;
     for (int t = 0; t < 2; t++) e.lay[t] = make_layout(e.caps[t]);
     e.mapq_rows = rlen_max + 64;
