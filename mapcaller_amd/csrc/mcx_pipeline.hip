@@ -899,7 +899,7 @@ extern "C" void mcx_opts_default(mcx_opts *o)
 static Caps tier0_caps()
 {
     // (hit_seed above OCC_Thr: one seed at the occurrence limit plus the read's other seeds still fit)
-    Caps c; c.hit_cap = 64; c.hit_seed = 56; c.cand_cap = 16; c.cand_seed = 12; c.frag_cap = 96; c.ops_cap = 1024; c.job_cap = 16;
+    Caps c; c.hit_cap = 64; c.hit_seed = 56; c.cand_cap = 16; c.cand_seed = 12; c.frag_cap = 96; c.ops_cap = 2048; c.job_cap = 32;
     c.cig_cap = MCX_CIGAR_STRIDE; c.kmer_cap = 2048;
     if (const char *e = getenv("MCX_TIER0_CAPS")) { // experiments: "hits,cands,frags,ops"
         int a, b, d, f;
