@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 GATHER_CEILING_G_PER_S = 47.5
 PMC_SUMMARY = {"human": os.path.join(ROOT, "profiles", "round2", "summary_human.json"),
                "uniform": os.path.join(ROOT, "profiles", "round2", "summary_uniform.json")}
-STAGE_KERNEL = {"ms_encode": "k_pack_reads", "ms_seed": "k_seed", "ms_cluster": "k_cluster", "ms_rescue": "k_rescue", "ms_build": "k_build",
+STAGE_KERNEL = {"ms_encode": "k_pack_reads", "ms_seed": "k_seed", "ms_cluster": "k_cluster", "ms_rescue": "k_rescue<2048>", "ms_build": "k_build",
                 "ms_finish": "k_finish"}  # stages that are one kernel (ms_dp is six kernels on side streams)
 
 
@@ -78,7 +78,7 @@ def essential_bytes(kernel, d, args):
         "k_cluster": 16.0 * h + 32.0,                       # hits in, a candidate out
         "k_build": 16.0 * h + 32.0 + 16.0 * (2 * h + 1) + 2 * args.rlen / 4.0,   # hits + candidate in, fragments out, gap bases compared
         "k_finish": 32.0 + 16.0 * (2 * h + 1) + 2 * args.rlen / 4.0 + 64.0 + 8.0,  # candidate + fragments in, columns compared, record + CIGAR out
-        "k_rescue": 0.0,
+        "k_rescue<2048>": 0.0,
     }.get(kernel, 0.0)
     return per_read * reads / steps
 
@@ -165,6 +165,7 @@ def vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, n_s
     last = batches[n_steps - 1]
     del batches[:]
     mapper.close()
+    torch.cuda.empty_cache()  # (the caching allocator would sit on the freed batches)
     slice_reads = min(reads_per_step, 2_000_000)
     mapper = api.Mapper(index, alg=args.alg, max_read_len=max(256, args.rlen), max_batch_reads=slice_reads)
     planes = torch.zeros((10, G), dtype=torch.int32, device=dev)

@@ -899,7 +899,8 @@ extern "C" void mcx_opts_default(mcx_opts *o)
 static Caps tier0_caps()
 {
     // (hit_seed above OCC_Thr: one seed at the occurrence limit plus the read's other seeds still fit)
-    Caps c; c.hit_cap = 64; c.hit_seed = 56; c.cand_cap = 16; c.cand_seed = 12; c.frag_cap = 96; c.ops_cap = 2048; c.job_cap = 32;
+    Caps c; c.hit_cap = 88; c.hit_seed = 56; c.cand_cap = 24; c.cand_seed = 12; // (rescue adds at most one candidate per candidate of the mate)
+    c.frag_cap = 96; c.ops_cap = 2048; c.job_cap = 32;
     c.cig_cap = MCX_CIGAR_STRIDE; c.kmer_cap = 2048;
     if (const char *e = getenv("MCX_TIER0_CAPS")) { // experiments: "hits,cands,frags,ops"
         int a, b, d, f;
@@ -957,8 +958,8 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     int rc = 0;
     c->tier[0].caps = tier0_caps(); c->tier[0].lay = make_layout(c->tier[0].caps); c->tier[0].max_pairs = (uint32_t)c->max_reads;
     c->tier[1].caps = tier1_caps(c->rlen_max); c->tier[1].lay = make_layout(c->tier[1].caps);
-    // (the heavy pairs of a batch in as few passes as 16 GB of records allow: a pass is bound by its slowest pair, not by its size)
-    c->tier[1].max_pairs = (uint32_t)std::max<uint64_t>(1024, std::min<uint64_t>(std::min<uint64_t>(c->max_reads, 65536), ((uint64_t)16 << 30) / (uint64_t)c->tier[1].lay.stride));
+    // (the heavy pairs of a batch in as few passes as 8 GB of records allow: a pass is bound by its slowest pair, not by its size)
+    c->tier[1].max_pairs = (uint32_t)std::max<uint64_t>(1024, std::min<uint64_t>(std::min<uint64_t>(c->max_reads, 65536), ((uint64_t)8 << 30) / (uint64_t)c->tier[1].lay.stride));
     for (int t = 0; t < 2; t++)
         if ((rc = dmalloc(&c->tier[t].state, (size_t)c->tier[t].lay.stride * c->tier[t].max_pairs))) return rc;
     c->task_cap = (uint32_t)std::min<uint64_t>(c->max_reads * 24, 0x7fffffffu);
@@ -1230,6 +1231,25 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     }
     HIP_TRY(hipStreamSynchronize(s));
     if (rc2) return rc2;
+    if (tier == 1 && getenv("MCX_TIER1_HIST")) { // experiments: how heavy are the pairs of the large tier?
+        std::vector<PairHdr> hd(sel.n);
+        HIP_TRY(hipMemcpy2D(hd.data(), sizeof(PairHdr), c->tier[1].state, (size_t)c->tier[1].lay.stride, sizeof(PairHdr), sel.n, hipMemcpyDeviceToHost));
+        const int edges[8] = {16, 32, 64, 128, 256, 512, 1024, 1 << 30};
+        uint32_t hh[8] = {0}, hc[8] = {0}, hf[8] = {0};
+        for (const PairHdr &h : hd) {
+            const int nh = std::max(h.n_hits[0], h.n_hits[1]), nc = std::max(h.n_cands[0], h.n_cands[1]);
+            for (int b = 0; b < 8; b++) if (nh <= edges[b]) { hh[b]++; break; }
+            for (int b = 0; b < 8; b++) if (nc <= edges[b]) { hc[b]++; break; }
+            for (int b = 0; b < 8; b++) if (h.n_frags <= edges[b]) { hf[b]++; break; }
+        }
+        fprintf(stderr, "[tier 1 hist] %u pairs; per-read maximum <=16,32,64,128,256,512,1024,more: hits", sel.n);
+        for (int b = 0; b < 8; b++) fprintf(stderr, " %u", hh[b]);
+        fprintf(stderr, " | candidates");
+        for (int b = 0; b < 8; b++) fprintf(stderr, " %u", hc[b]);
+        fprintf(stderr, " | fragments");
+        for (int b = 0; b < 8; b++) fprintf(stderr, " %u", hf[b]);
+        fprintf(stderr, "\n");
+    }
     const uint32_t *n = R.h_cnt;
     // a work list that ran over: nothing of this pass is kept, the caller maps the selection in two halves
     if ((R.d_tasks && n[CNT_TASKS] > R.task_cap) || n[CNT_RESCUE] > R.rescue_cap) return kListOverflow;

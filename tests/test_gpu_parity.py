@@ -409,17 +409,17 @@ def test_full_size_genome_prefix_equals_reference(api, bench_genome, tmp_path):
 
 def test_config5_indel_heavy_long_pairs_equal_reference(api, bench_genome, tmp_path, monkeypatch):
     """BASELINE config 5 read literally: 250 bp pairs with 5 % indels per base (2.5 % insertions + 2.5 % deletions), -alg nw, against the
-    full-size index, 200 k pairs in ONE batch — several gapped fragments per read.  The DP job lists are held to 200 k entries here
+    full-size index, 100 k pairs in ONE batch — several gapped fragments per read.  The DP job lists are held to 100 k entries here
     (MCX_JOB_CAP; at bench.py's batch size they run over by themselves), so the pass runs over and the selection is mapped in
     halves (asserted).  The reference's gates leave few of these reads mapped; mostly-unmapped output is the expected answer,
     line for line."""
     from mapcaller_amd import synth
     g = bench_genome
-    n_pairs = 200_000
+    n_pairs = 100_000
     reads = g["bench"].make_reads(g["codes"], g["lens"], n_pairs, 250, seed=77, device=g["dev"], sub=0.005, ins=0.025, dele=0.025).reshape(2 * n_pairs, 250).cpu()
     f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
     synth.write_fastq(f1, reads, 0, 2); synth.write_fastq(f2, reads, 1, 2)
-    monkeypatch.setenv("MCX_JOB_CAP", "200000")
+    monkeypatch.setenv("MCX_JOB_CAP", "100000")
     mp = api.Mapper(g["index"], alg="nw", max_read_len=256, max_batch_reads=2 * n_pairs)
     monkeypatch.delenv("MCX_JOB_CAP")
     out = str(tmp_path / "gpu.sam")
