@@ -253,6 +253,7 @@ def parse():
                     help="repeat content of the synthetic genome: a human-like landscape (default) or round 1's nearly repeat-free one")
     ap.add_argument("--second-genome", type=int, default=1,
                     help="1: after the main run, map 2 steps against the other kind of genome as well and report them under `other_genome`")
+    ap.add_argument("--seed-ahead", type=int, default=1, help="1: hand the library the next batch before each step (mcx_batch_hint_next); 0: one batch at a time")
     ap.add_argument("--pcie-steps", type=int, default=6, help="steps of the host-buffer leg (value_pcie_inclusive); 0 = skip")
     ap.add_argument("--vcf-reduce", type=int, default=1,
                     help="after the timed region: accumulate the -vcf alignment profile of one batch and sum it over the "
@@ -567,6 +568,10 @@ def main():
     traj = Trajectory(dist, dev, world, rank, (args.batch_pairs + 99) // 100) if world > 1 else None
 
     def step(i):
+        # the next batch is already in HBM: its packing and seeding run beside this one's second half — except across the start of
+        # the timed region, whose first batch is seeded inside it like every other (K timed steps hold K seedings)
+        if i + 1 < n_steps and i + 1 != args.warmup and args.seed_ahead:
+            mapper.hint_next(batches[i + 1].data_ptr(), off.data_ptr(), reads_per_step, True)
         if traj:
             traj.step(mapper, batches[i].data_ptr(), off.data_ptr(), reads_per_step, d_aln.data_ptr(), d_cig.data_ptr())
         else:

@@ -416,6 +416,7 @@ __global__ void __launch_bounds__(256) k_pack_reads(ReadBatch rb, int paired, in
     ReadRef rd;
     rd.ascii = rb.bases + rb.off[r]; rd.rlen = (int)(rb.off[r + 1] - rb.off[r]); rd.flipped = (paired && (r & 1)) ? 1 : 0;
     const int rlen = rd.rlen, nc = (rlen + 15) >> 4, nmw = (rlen + 31) >> 5;
+    if (nc + 1 + nmw + 1 > wpad) return; // a read longer than the context was sized for: the batch is refused (k_max_read_len), nothing is written
     uint32_t *o = out + (uint64_t)r * wpad;
     if (m < nmw) {
         uint32_t c0, f0, c1, f1;
@@ -824,7 +825,7 @@ struct PassRes {
 };
 
 struct BatchRun { // the batch between mcx_batch_begin and mcx_batch_end
-    bool open = false, sums_valid = false, keys_out = false;
+    bool open = false, sums_valid = false, keys_out = false, seeded = false;
     ReadBatch rb; int paired = 0;
     uint32_t n_pairs = 0, n_chunks = 0;
     AlnRec *recs = nullptr; uint32_t *cig = nullptr; // records [n_reads]; the batch's CIGAR pool
@@ -875,6 +876,20 @@ struct mcx_ctx {
     uint8_t *d_saved = nullptr; // parked slices: pairs waiting for the DP kernels
     hipEvent_t ev_fast[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     BatchRun run;
+    // The next batch's packing and seeding beside the batch in flight (mcx_batch_hint_next): they need nothing of it but the
+    // seeds' place in the tier-0 records, which is free once its k_build has run.  alt: the arrays the early pass writes
+    // (2-bit reads, per-read counters); they trade places with the current ones when that batch begins.
+    struct Ahead {
+        bool hinted = false;      // a next batch is known
+        bool pending = false;     // its kernels are queued (done is recorded behind them)
+        bool valid = false;       // and nothing has overwritten the seeds since
+        const uint8_t *bases = nullptr; const uint32_t *off = nullptr; uint32_t n_reads = 0; int paired = 0;
+        hipEvent_t in_ready = nullptr; // (optional) what the next batch's reads wait for: their copy into HBM
+        hipEvent_t done = nullptr, t[3] = {nullptr, nullptr, nullptr};
+        uint32_t *d_packed = nullptr, *d_read_ext = nullptr, *d_read_blocks = nullptr, *d_queue = nullptr;
+        hipStream_t stream = nullptr;
+    } ahead;
+    hipEvent_t ev_built = nullptr;
     PassRes t1;               // the large tier's own set (the members above are tier 0's); allocated when every suffix-array entry is resident
     bool overlap_tiers = false;
     hipEvent_t ev_clustered = nullptr;
@@ -1035,6 +1050,17 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
         if ((rc = dmalloc(&t.d_est, c->max_reads))) return rc;
         c->overlap_tiers = true;
     }
+    if (idx->view.sa_full && !getenv("MCX_NO_SEED_AHEAD")) {
+        mcx_ctx::Ahead &a = c->ahead;
+        HIP_TRY(hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_built, hipEventDisableTiming));
+        for (auto &e : a.t) HIP_TRY(hipEventCreate(&e));
+        if ((rc = dmalloc(&a.d_packed, c->max_reads * (uint64_t)c->wpad))) return rc;
+        if ((rc = dmalloc(&a.d_read_ext, c->max_reads))) return rc;
+        if ((rc = dmalloc(&a.d_read_blocks, c->max_reads))) return rc;
+        if ((rc = dmalloc(&a.d_queue, 64))) return rc;
+    }
     // the fused per-pair kernel: needs every suffix-array entry resident (seeds then leave k_seed as text positions)
     // and a slice of LDS per lane that the read length decides (reads up to 16 x code_words bases take it)
     if (idx->view.sa_full && getenv("MCX_FAST") && !getenv("MCX_NO_FAST")) {
@@ -1087,6 +1113,15 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
         if (t.dp_fork) (void)hipEventDestroy(t.dp_fork);
         if (t.stream) (void)hipStreamDestroy(t.stream);
         if (c->ev_clustered) (void)hipEventDestroy(c->ev_clustered);
+    }
+    {
+        mcx_ctx::Ahead &a = c->ahead;
+        void *q[] = {a.d_packed, a.d_read_ext, a.d_read_blocks, a.d_queue};
+        for (void *x : q) if (x) (void)hipFree(x);
+        if (a.done) (void)hipEventDestroy(a.done);
+        for (auto &e : a.t) if (e) (void)hipEventDestroy(e);
+        if (a.stream) (void)hipStreamDestroy(a.stream);
+        if (c->ev_built) (void)hipEventDestroy(c->ev_built);
     }
     for (auto &e : c->ev_fast) if (e) (void)hipEventDestroy(e);
     for (auto &sl : c->slot) {
@@ -1159,14 +1194,20 @@ static int tier1_error(mcx_ctx *c, const PassRes &R);
 // One tier over a selection of pairs.  early (tier 0 only): the pairs that run over the tier's capacities while clustering
 // are listed on the device; once the rest of the pass is queued, the large tier maps them on its own stream — its kernels
 // are bound by their slowest pair, not by the chip, so they hide behind the pass instead of following it.
+static int launch_ahead(mcx_ctx *c, hipStream_t s);
+
 static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb, int paired, PairSel sel, AlnRec *d_recs,
-                     uint32_t *d_cig, mcx_stats *stats, bool timing, bool early = false)
+                     uint32_t *d_cig, mcx_stats *stats, bool timing, bool early = false, bool seeded = false)
 {
     if (sel.n == 0) return 0;
     hipStream_t s = R.stream;
     Ctx cx = make_ctx(c, tier, paired);
     const int nr = paired ? 2 : 1;
     early = early && tier == 0 && c->overlap_tiers;
+    if (tier == 0 && !seeded && c->ahead.pending) { // this pass seeds into the tier-0 records: the next batch's early seeding must be through, and what it left there is gone
+        HIP_TRY(hipStreamWaitEvent(s, c->ahead.done, 0));
+        c->ahead.valid = false;
+    }
     HIP_TRY(hipMemsetAsync(R.d_cnt, 0, CNT_N * sizeof(uint32_t), s));
     SeedOut so; so.tasks = R.d_tasks; so.n_tasks = R.d_cnt + CNT_TASKS; so.task_cap = R.task_cap;
     so.read_ext = c->d_read_ext; so.read_blocks = c->d_read_blocks;
@@ -1185,7 +1226,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         const int threads = pkw * 256 * 4 <= 48 * 1024 ? 256 : (pkw * 128 * 4 <= 48 * 1024 ? 128 : 64);
         const int rpl = seed_reads_per_lane((uint64_t)sel.n * nr);
         const unsigned blocks_s = std::min<unsigned>((sel.n * nr + threads * rpl - 1) / (threads * rpl), 4096u); // (the queue feeds whatever grid runs)
-        k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl, seed_fm_budget());
+        if (!seeded) k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl, seed_fm_budget()); // (seeded: done beside the batch before)
     }
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     if (R.d_tasks) k_sa<<<4096, 256, 0, s>>>(cx, so, paired, R.d_cnt + CNT_LF);
@@ -1200,6 +1241,8 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP);
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
+    // the seeds of this batch are spent: the next batch's packing and seeding can start beside what follows (DP, finish, the large tier)
+    if (tier == 0 && sel.ids == nullptr && c->ahead.hinted && (rc2 = launch_ahead(c, s))) return rc2;
     if ((rc2 = launch_dp(R, cx, sinks, rb, sel))) return rc2;
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     k_finish<<<pb, 256, 0, s>>>(cx, rb, sel, d_recs, c->d_pout, R.d_ov, R.d_cnt + CNT_OV, R.ov_cap, c->d_batch_flags + 2);
@@ -1349,6 +1392,58 @@ extern "C" void mcx_avg_walk(int64_t st[3], const uint32_t *pairs, const uint32_
     st[0] = cur; st[1] = tp; st[2] = td;
 }
 
+static int launch_ahead(mcx_ctx *c, hipStream_t s)
+{
+    mcx_ctx::Ahead &A = c->ahead;
+    A.hinted = false;
+    if (!A.stream || c->fast_on) return 0;
+    HIP_TRY(hipEventRecord(c->ev_built, s));
+    HIP_TRY(hipStreamWaitEvent(A.stream, c->ev_built, 0));
+    if (A.in_ready) HIP_TRY(hipStreamWaitEvent(A.stream, A.in_ready, 0));
+    HIP_TRY(hipMemsetAsync(A.d_queue, 0, 64 * sizeof(uint32_t), A.stream));
+    ReadBatch nb; nb.bases = A.bases; nb.off = A.off; nb.n_reads = A.n_reads;
+    const int nr = A.paired ? 2 : 1;
+    HIP_TRY(hipEventRecord(A.t[0], A.stream));
+    {
+        const int tpr = (c->rlen_max + 31) / 32 + 1;
+        const uint64_t threads = (uint64_t)A.n_reads * (uint64_t)tpr;
+        k_pack_reads<<<(unsigned)((threads + 255) / 256), 256, 0, A.stream>>>(nb, A.paired, c->wpad, tpr, A.d_packed);
+    }
+    HIP_TRY(hipEventRecord(A.t[1], A.stream));
+    {
+        Ctx cx = make_ctx(c, 0, A.paired);
+        SeedOut so; so.tasks = nullptr; so.n_tasks = A.d_queue + 32; so.task_cap = 0;
+        so.read_ext = A.d_read_ext; so.read_blocks = A.d_read_blocks; so.packed = A.d_packed; so.wpad = c->wpad;
+        so.fast_hits = nullptr; so.fast_cap = 0; so.queue = A.d_queue;
+        PairSel sel; sel.n = A.n_reads / nr; sel.ids = nullptr; sel.est = nullptr;
+        const int pkw = packed_words(c->rlen_max);
+        const int threads = pkw * 256 * 4 <= 48 * 1024 ? 256 : (pkw * 128 * 4 <= 48 * 1024 ? 128 : 64);
+        const int rpl = seed_reads_per_lane((uint64_t)A.n_reads);
+        const unsigned blocks_s = std::min<unsigned>((A.n_reads + threads * rpl - 1) / (threads * rpl), 4096u);
+        k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, A.stream>>>(cx, nb, sel, so, pkw, rpl, seed_fm_budget());
+    }
+    HIP_TRY(hipEventRecord(A.t[2], A.stream));
+    HIP_TRY(hipEventRecord(A.done, A.stream));
+    HIP_TRY(hipGetLastError());
+    A.pending = true; A.valid = true;
+    return 0;
+}
+
+static int hint_next(mcx_ctx *c, const uint8_t *d_bases, const uint32_t *d_off, uint32_t n_reads, int paired, hipEvent_t in_ready)
+{
+    mcx_ctx::Ahead &A = c->ahead;
+    A.hinted = false;
+    if (!A.stream || !d_bases || !d_off || n_reads == 0 || n_reads > c->max_reads || ((uintptr_t)d_bases & 15) || (paired && (n_reads & 1))) return 0;
+    A.bases = d_bases; A.off = d_off; A.n_reads = n_reads; A.paired = paired; A.in_ready = in_ready; A.hinted = true;
+    return 0;
+}
+
+extern "C" int mcx_batch_hint_next(mcx_ctx *c, const uint8_t *d_bases, const uint32_t *d_off, uint32_t n_reads, int paired)
+{
+    if (!c) return fail(MCX_ERR_ARG, "mcx_batch_hint_next: null argument");
+    return hint_next(c, d_bases, d_off, n_reads, paired, nullptr);
+}
+
 // The first pass over a batch: seeding with the seeds laid out for the fused per-pair kernel, then that kernel
 // (mcx_fast.h).  spill receives the pairs it left for the general path, in pair order.
 static int run_fast(mcx_ctx *c, const ReadBatch &rb, int paired, int32_t est, uint32_t n_pairs, AlnRec *d_recs, mcx_stats *stats, std::vector<uint32_t> &spill,
@@ -1419,7 +1514,7 @@ static int run_fast(mcx_ctx *c, const ReadBatch &rb, int paired, int32_t est, ui
 // runs the tiers for the pairs in `ids` (null: all pairs of the batch) with per-pair estimates
 static int run_selection(mcx_ctx *c, const ReadBatch &rb, int paired, const std::vector<uint32_t> *ids,
                          const std::vector<int32_t> *est, int32_t est_all, uint32_t n_pairs, AlnRec *d_recs,
-                         uint32_t *d_cig, mcx_stats *stats, bool timing)
+                         uint32_t *d_cig, mcx_stats *stats, bool timing, bool seeded = false)
 {
     hipStream_t s = c->stream;
     const uint32_t n = ids ? (uint32_t)ids->size() : n_pairs;
@@ -1432,7 +1527,7 @@ static int run_selection(mcx_ctx *c, const ReadBatch &rb, int paired, const std:
     if (est) HIP_TRY(hipMemcpyAsync(c->d_est, est->data(), n * sizeof(int32_t), hipMemcpyHostToDevice, s));
     else k_fill_i32<<<(n + 255) / 256, 256, 0, s>>>(c->d_est, est_all, n);
     const PassRes R0 = res_tier0(c);
-    int rc = run_pairs(c, 0, R0, rb, paired, sel, d_recs, d_cig, stats, timing, true);
+    int rc = run_pairs(c, 0, R0, rb, paired, sel, d_recs, d_cig, stats, timing, true, seeded && !ids);
     if (rc == kListOverflow) {
         // unusually many hits or DP problems per read (e.g. indel-heavy long reads): halve the selection
         if (n < 2) return fail(MCX_ERR_CAPACITY, "work list overflow for a single pair");
@@ -1525,7 +1620,18 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
         if (c->h_cnt[1] > (uint32_t)c->rlen_max)
             return fail(MCX_ERR_UNSUPPORTED, "a read of " + std::to_string(c->h_cnt[1]) + " bases is longer than max_read_len (" + std::to_string(c->rlen_max) + ")");
     }
-    { // the batch in 2-bit form, once; every seeding pass (tiers, replay) reads it
+    bool seeded = false;
+    if (c->ahead.pending) { // packed and seeded beside the batch before?  Then its arrays take the place of the current ones
+        mcx_ctx::Ahead &A = c->ahead;
+        HIP_TRY(hipStreamWaitEvent(s, A.done, 0));
+        if (A.valid && A.bases == d_bases && A.off == d_off && A.n_reads == n_reads && A.paired == paired && !c->fast_on) {
+            std::swap(c->d_packed, A.d_packed); std::swap(c->d_read_ext, A.d_read_ext); std::swap(c->d_read_blocks, A.d_read_blocks);
+            seeded = true;
+        }
+        A.pending = false; A.valid = false;
+    }
+    br.seeded = seeded;
+    if (!seeded) { // the batch in 2-bit form, once; every seeding pass (tiers, replay) reads it
         HIP_TRY(hipEventRecord(c->ev_pack[0], s));
         const int tpr = (c->rlen_max + 31) / 32 + 1;
         const uint64_t threads = (uint64_t)n_reads * (uint64_t)tpr;
@@ -1540,8 +1646,12 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
         if ((rc = run_fast(c, br.rb, paired, est0, br.n_pairs, br.recs, stats, spill, all_general))) return rc;
         if (all_general) rc = run_selection(c, br.rb, paired, nullptr, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true);
         else rc = spill.empty() ? 0 : run_selection(c, br.rb, paired, &spill, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true);
-    } else rc = run_selection(c, br.rb, paired, nullptr, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true);
+    } else rc = run_selection(c, br.rb, paired, nullptr, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true, seeded);
     if (rc) return rc;
+    if (seeded && stats) { // the early pass's own clock
+        float a = 0, b = 0;
+        if (hipEventElapsedTime(&a, c->ahead.t[0], c->ahead.t[1]) == hipSuccess && hipEventElapsedTime(&b, c->ahead.t[1], c->ahead.t[2]) == hipSuccess) { stats->ms_encode += a; stats->ms_seed += b; }
+    }
     { // seeding statistics (E, blocks, H of SURVEY.md 8d) before the per-read arrays are reused for the chunk sums
         unsigned long long *d_sum = (unsigned long long *)c->d_cnt;
         HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
@@ -1633,7 +1743,7 @@ static int batch_close(mcx_ctx *c, mcx_stats *stats)
         stats->reads += br.rb.n_reads; stats->mapped += br.mapped; stats->pairs += pairs; stats->pair_dist_sum += dist_sum; stats->pair_len_sum += len_sum;
         stats->fm_ext_steps += (int64_t)br.hs[0]; stats->fm_blocks += (int64_t)br.hs[1]; stats->sa_hits += (int64_t)br.hs[2];
         float ms_pack = 0;
-        if (hipEventElapsedTime(&ms_pack, c->ev_pack[0], c->ev_pack[1]) == hipSuccess) stats->ms_encode += ms_pack; // k_pack_reads
+        if (!br.seeded && hipEventElapsedTime(&ms_pack, c->ev_pack[0], c->ev_pack[1]) == hipSuccess) stats->ms_encode += ms_pack; // k_pack_reads
     }
     return 0;
 }
@@ -1864,6 +1974,7 @@ extern "C" int mcx_stream_map(mcx_ctx *c, int paired, int64_t avg[4], mcx_aln *a
     const uint8_t *d_bases; const uint32_t *d_off; mcx_aln *d_aln; uint32_t *d_cig; uint32_t n = 0;
     int rc = mcx_stream_next(c, &d_bases, &d_off, &n, &d_aln, &d_cig);
     if (rc) return rc;
+    if (mcx_ctx::Slot *nx = oldest_slot(c, 1)) hint_next(c, nx->d_bases, nx->d_off, nx->n_reads, paired, nx->in_ready); // the batch behind this one: seeded beside it
     rc = mcx_map_batch_dev(c, d_bases, d_off, n, paired, avg, d_aln, d_cig, stats);
     if (rc) { oldest_slot(c, 2)->state = 0; return rc; }
     return mcx_stream_mapped(c, aln, cigar);
