@@ -166,7 +166,7 @@ def vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, n_s
     del batches[:]
     mapper.close()
     torch.cuda.empty_cache()  # (the caching allocator would sit on the freed batches)
-    slice_reads = min(reads_per_step, 2_000_000)
+    slice_reads = min(reads_per_step, args.vcf_slice_reads)
     mapper = api.Mapper(index, alg=args.alg, max_read_len=max(256, args.rlen), max_batch_reads=slice_reads)
     planes = torch.zeros((10, G), dtype=torch.int32, device=dev)
 
@@ -184,7 +184,9 @@ def vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, n_s
     mapper.reset()
     mapper.profile_attach(planes.data_ptr())
     t_acc = map_slices()
-    sparse = mapper.profile_sparse_raw(shard=world > 1)
+    t_sp = time.perf_counter()
+    sparse = mapper.profile_sparse_raw(shard=world > 1)  # the tally records leave HBM here, once
+    t_sp = time.perf_counter() - t_sp
     if dist:
         dist.barrier()
     t2 = time.perf_counter()
@@ -197,7 +199,7 @@ def vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, n_s
     tot = mdist.sum_over_ranks([d["pairs"], d["pair_dist_sum"], d["pair_len_sum"]], dev)
     gb = planes.numel() * 4 / 1e9
     vcf = {"profile_batch_ms": round(1000 * t_acc, 2), "same_slices_without_profile_ms": round(1000 * t_plain, 2),
-           "profile_overhead_ms": round(1000 * (t_acc - t_plain), 2), "slice_reads": slice_reads,
+           "profile_overhead_ms": round(1000 * (t_acc - t_plain), 2), "slice_reads": slice_reads, "sparse_records_to_host_ms": round(1000 * t_sp, 2),
            "reduce_ms": round(1000 * t_red, 2), "reduce_gb": round(gb, 2),
            "reduce_gbs_into_root": None if world == 1 else round(gb * (world - 1) / max(t_red, 1e-9), 1),
            "reduce": "none (one GPU)" if world == 1 else f"RCCL reduce of {world} x ten u32 planes onto rank 0 in 1-GiB pieces",
@@ -253,8 +255,8 @@ def parse():
                     help="repeat content of the synthetic genome: a human-like landscape (default) or round 1's nearly repeat-free one")
     ap.add_argument("--second-genome", type=int, default=1,
                     help="1: after the main run, map 2 steps against the other kind of genome as well and report them under `other_genome`")
-    ap.add_argument("--seed-ahead", type=int, default=1, help="1: hand the library the next batch before each step (mcx_batch_hint_next); 0: one batch at a time")
     ap.add_argument("--pcie-steps", type=int, default=6, help="steps of the host-buffer leg (value_pcie_inclusive); 0 = skip")
+    ap.add_argument("--vcf-slice-reads", type=int, default=2_000_000, help="reads per mapping call in the -vcf leg")
     ap.add_argument("--vcf-reduce", type=int, default=1,
                     help="after the timed region: accumulate the -vcf alignment profile of one batch and sum it over the "
                          "ranks with RCCL (1 = yes, 0 = no, -1 = only when more than one GPU)")
@@ -568,10 +570,6 @@ def main():
     traj = Trajectory(dist, dev, world, rank, (args.batch_pairs + 99) // 100) if world > 1 else None
 
     def step(i):
-        # the next batch is already in HBM: its packing and seeding run beside this one's second half — except across the start of
-        # the timed region, whose first batch is seeded inside it like every other (K timed steps hold K seedings)
-        if i + 1 < n_steps and i + 1 != args.warmup and args.seed_ahead:
-            mapper.hint_next(batches[i + 1].data_ptr(), off.data_ptr(), reads_per_step, True)
         if traj:
             traj.step(mapper, batches[i].data_ptr(), off.data_ptr(), reads_per_step, d_aln.data_ptr(), d_cig.data_ptr())
         else:

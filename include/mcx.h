@@ -133,11 +133,6 @@ void mcx_avg_init(int64_t avg_state[4]);
 int mcx_map_batch_dev(mcx_ctx *, const uint8_t *d_bases, const uint32_t *d_off, uint32_t n_reads, int paired,
                       int64_t avg_state[4], mcx_aln *d_aln, uint32_t *d_cigar, mcx_stats *stats);
 int mcx_cigar_words(mcx_ctx *, uint32_t *n_words);
-/* The batch that will follow the next mcx_map_batch_dev / mcx_batch_begin call, already in HBM: its packing and seeding
- * then run on a stream of their own beside the second half of that call (they need nothing of the batch in flight but the
- * seeds' place in the pair records, which is free once its fragments are built), and the call that maps it finds them done.
- * Purely a hint: a different batch, or none, may follow; results never depend on it.  mcx_stream_map gives it by itself. */
-int mcx_batch_hint_next(mcx_ctx *, const uint8_t *d_bases, const uint32_t *d_off, uint32_t n_reads, int paired);
 /* same with host buffers (pinned staging inside) */
 int mcx_map_batch(mcx_ctx *, const uint8_t *bases, const uint32_t *off, uint32_t n_reads, int paired,
                   int64_t avg_state[4], mcx_aln *aln, uint32_t *cigar, mcx_stats *stats);

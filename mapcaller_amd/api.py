@@ -21,7 +21,7 @@ SYMBOLS = [
     "mcx_last_error", "mcx_device_count", "mcx_index_load", "mcx_index_build", "mcx_index_from_codes", "mcx_index_save", "mcx_index_free",
     "mcx_index_genome_size", "mcx_index_n_chr", "mcx_index_chr_name", "mcx_index_chr_len", "mcx_index_hbm_bytes",
     "mcx_opts_default", "mcx_ctx_create", "mcx_ctx_free", "mcx_bwt_search_batch", "mcx_extend_batch",
-    "mcx_avg_init", "mcx_map_batch_dev", "mcx_map_batch", "mcx_cigar_words", "mcx_batch_hint_next", "mcx_map_files", "mcx_map_files_ex", "mcx_file_opts_default",
+    "mcx_avg_init", "mcx_map_batch_dev", "mcx_map_batch", "mcx_cigar_words", "mcx_map_files", "mcx_map_files_ex", "mcx_file_opts_default",
     "mcx_profile_attach", "mcx_profile_finalize", "mcx_profile_sparse", "mcx_planes_alloc", "mcx_planes_free",
     "mcx_vcf_defaults", "mcx_call_variants",
     "mcx_batch_begin", "mcx_batch_sums", "mcx_batch_replay", "mcx_batch_end", "mcx_avg_walk", "mcx_exchange_local", "mcx_exchange_local_free",
@@ -194,7 +194,6 @@ def lib() -> C.CDLL:
     L.mcx_exchange_local_free.argtypes = [C.POINTER(Exchange)]
     L.mcx_exchange_local_free.restype = None
     L.mcx_sam_merge.argtypes = [C.c_char_p, C.c_int32]
-    L.mcx_batch_hint_next.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
     L.mcx_stream_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     L.mcx_stream_map.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.POINTER(Stats)]
     L.mcx_stream_collect.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -407,10 +406,6 @@ class Mapper:
             if i >= 2:
                 _check(L.mcx_stream_collect(self._h, C.byref(h2d), C.byref(d2h)), "mcx_stream_collect")
         return h2d.value, d2h.value
-
-    def hint_next(self, d_bases_ptr: int, d_off_ptr: int, n_reads: int, paired: bool):
-        """The batch that follows the next map_batch_dev / batch_begin call (already in HBM): packed and seeded beside it."""
-        _check(lib().mcx_batch_hint_next(self._h, d_bases_ptr, d_off_ptr, n_reads, int(paired)), "mcx_batch_hint_next")
 
     def map_batch_dev(self, d_bases_ptr: int, d_off_ptr: int, n_reads: int, paired: bool, d_aln_ptr: int, d_cigar_ptr: int):
         """Device pointers (e.g. torch.Tensor.data_ptr()); results stay in HBM."""

@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(256) k_pack_reads(ReadBatch rb, int paired, in
     ReadRef rd;
     rd.ascii = rb.bases + rb.off[r]; rd.rlen = (int)(rb.off[r + 1] - rb.off[r]); rd.flipped = (paired && (r & 1)) ? 1 : 0;
     const int rlen = rd.rlen, nc = (rlen + 15) >> 4, nmw = (rlen + 31) >> 5;
-    if (nc + 1 + nmw + 1 > wpad) return; // a read longer than the context was sized for: the batch is refused (k_max_read_len), nothing is written
+    if (nc + 1 + nmw + 1 > wpad) return; // (a read longer than the context was sized for: the batch is refused before this runs, k_max_read_len)
     uint32_t *o = out + (uint64_t)r * wpad;
     if (m < nmw) {
         uint32_t c0, f0, c1, f1;
@@ -825,7 +825,7 @@ struct PassRes {
 };
 
 struct BatchRun { // the batch between mcx_batch_begin and mcx_batch_end
-    bool open = false, sums_valid = false, keys_out = false, seeded = false;
+    bool open = false, sums_valid = false, keys_out = false;
     ReadBatch rb; int paired = 0;
     uint32_t n_pairs = 0, n_chunks = 0;
     AlnRec *recs = nullptr; uint32_t *cig = nullptr; // records [n_reads]; the batch's CIGAR pool
@@ -866,6 +866,8 @@ struct mcx_ctx {
     uint8_t *d_detail = nullptr; DetailLayout dlay;
     uint64_t *d_keys[2] = {nullptr, nullptr}; uint8_t *d_admit = nullptr; void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     SparseRec *d_sparse = nullptr; uint32_t sparse_cap = 0;
+    SparseRec *d_arch = nullptr; uint64_t arch_n = 0, arch_cap = 0, arch_limit = (uint64_t)1 << 28; // the records of the batches so far, still in HBM (at most 16 GB)
+    SparseRec *h_sparse_pin = nullptr; uint32_t sparse_pin_recs = 1u << 18; // page-locked bounce buffer for their way to the host (16 MB)
     std::vector<mcx_sparse_rec> h_sparse, h_events, h_resolved; // tallies; discordant-pair events ('E'); what mcx_profile_sparse* last returned
     uint64_t keys_cap = 0;       // keys the sort buffers hold
     uint64_t *h_keys = nullptr; uint64_t h_keys_cap = 0; // pinned: the batch's keys for the exchange between shards
@@ -876,20 +878,6 @@ struct mcx_ctx {
     uint8_t *d_saved = nullptr; // parked slices: pairs waiting for the DP kernels
     hipEvent_t ev_fast[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     BatchRun run;
-    // The next batch's packing and seeding beside the batch in flight (mcx_batch_hint_next): they need nothing of it but the
-    // seeds' place in the tier-0 records, which is free once its k_build has run.  alt: the arrays the early pass writes
-    // (2-bit reads, per-read counters); they trade places with the current ones when that batch begins.
-    struct Ahead {
-        bool hinted = false;      // a next batch is known
-        bool pending = false;     // its kernels are queued (done is recorded behind them)
-        bool valid = false;       // and nothing has overwritten the seeds since
-        const uint8_t *bases = nullptr; const uint32_t *off = nullptr; uint32_t n_reads = 0; int paired = 0;
-        hipEvent_t in_ready = nullptr; // (optional) what the next batch's reads wait for: their copy into HBM
-        hipEvent_t done = nullptr, t[3] = {nullptr, nullptr, nullptr};
-        uint32_t *d_packed = nullptr, *d_read_ext = nullptr, *d_read_blocks = nullptr, *d_queue = nullptr;
-        hipStream_t stream = nullptr;
-    } ahead;
-    hipEvent_t ev_built = nullptr;
     PassRes t1;               // the large tier's own set (the members above are tier 0's); allocated when every suffix-array entry is resident
     bool overlap_tiers = false;
     hipEvent_t ev_clustered = nullptr;
@@ -1025,8 +1013,12 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     // (without the full suffix array it would also need an SA task list of its own: then the tiers run one after the other)
     if (idx->view.sa_full && !getenv("MCX_NO_TIER_OVERLAP")) {
         PassRes &t = c->t1;
-        HIP_TRY(hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking));
-        for (int k = 0; k < 5; k++) { HIP_TRY(hipStreamCreateWithFlags(&t.dp_stream[k], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&t.dp_join[k], hipEventDisableTiming)); }
+        // its kernels are as long as their slowest pair, and the batch waits for them: their waves go first
+        int pr_lo = 0, pr_hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
+        if (getenv("MCX_TIER1_NO_PRIORITY")) pr_hi = pr_lo > 0 ? 0 : pr_lo; // (experiments)
+        HIP_TRY(hipStreamCreateWithPriority(&t.stream, hipStreamNonBlocking, pr_hi));
+        for (int k = 0; k < 5; k++) { HIP_TRY(hipStreamCreateWithPriority(&t.dp_stream[k], hipStreamNonBlocking, pr_hi)); HIP_TRY(hipEventCreateWithFlags(&t.dp_join[k], hipEventDisableTiming)); }
         HIP_TRY(hipEventCreateWithFlags(&t.dp_fork, hipEventDisableTiming));
         for (auto &e : t.ev) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_clustered, hipEventDisableTiming));
@@ -1049,17 +1041,6 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
         if ((rc = dmalloc(&t.d_sel_ids, c->max_reads))) return rc;
         if ((rc = dmalloc(&t.d_est, c->max_reads))) return rc;
         c->overlap_tiers = true;
-    }
-    if (idx->view.sa_full && !getenv("MCX_NO_SEED_AHEAD")) {
-        mcx_ctx::Ahead &a = c->ahead;
-        HIP_TRY(hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_built, hipEventDisableTiming));
-        for (auto &e : a.t) HIP_TRY(hipEventCreate(&e));
-        if ((rc = dmalloc(&a.d_packed, c->max_reads * (uint64_t)c->wpad))) return rc;
-        if ((rc = dmalloc(&a.d_read_ext, c->max_reads))) return rc;
-        if ((rc = dmalloc(&a.d_read_blocks, c->max_reads))) return rc;
-        if ((rc = dmalloc(&a.d_queue, 64))) return rc;
     }
     // the fused per-pair kernel: needs every suffix-array entry resident (seeds then leave k_seed as text positions)
     // and a slice of LDS per lane that the read length decides (reads up to 16 x code_words bases take it)
@@ -1102,6 +1083,8 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     if (c->h_pout) (void)hipHostFree(c->h_pout);
     if (c->h_keys) (void)hipHostFree(c->h_keys);
     if (c->h_spill) (void)hipHostFree(c->h_spill);
+    if (c->h_sparse_pin) (void)hipHostFree(c->h_sparse_pin);
+    if (c->d_arch) (void)hipFree(c->d_arch);
     {
         PassRes &t = c->t1;
         void *q[] = {t.d_cnt, t.d_jobs[0], t.d_jobs[1], t.d_jobs[2], t.d_jobs[3], t.d_jobs[4], t.d_jobs[5], t.d_rescue, t.d_dp_scratch[0], t.d_dp_scratch[1],
@@ -1113,15 +1096,6 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
         if (t.dp_fork) (void)hipEventDestroy(t.dp_fork);
         if (t.stream) (void)hipStreamDestroy(t.stream);
         if (c->ev_clustered) (void)hipEventDestroy(c->ev_clustered);
-    }
-    {
-        mcx_ctx::Ahead &a = c->ahead;
-        void *q[] = {a.d_packed, a.d_read_ext, a.d_read_blocks, a.d_queue};
-        for (void *x : q) if (x) (void)hipFree(x);
-        if (a.done) (void)hipEventDestroy(a.done);
-        for (auto &e : a.t) if (e) (void)hipEventDestroy(e);
-        if (a.stream) (void)hipStreamDestroy(a.stream);
-        if (c->ev_built) (void)hipEventDestroy(c->ev_built);
     }
     for (auto &e : c->ev_fast) if (e) (void)hipEventDestroy(e);
     for (auto &sl : c->slot) {
@@ -1194,20 +1168,14 @@ static int tier1_error(mcx_ctx *c, const PassRes &R);
 // One tier over a selection of pairs.  early (tier 0 only): the pairs that run over the tier's capacities while clustering
 // are listed on the device; once the rest of the pass is queued, the large tier maps them on its own stream — its kernels
 // are bound by their slowest pair, not by the chip, so they hide behind the pass instead of following it.
-static int launch_ahead(mcx_ctx *c, hipStream_t s);
-
 static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb, int paired, PairSel sel, AlnRec *d_recs,
-                     uint32_t *d_cig, mcx_stats *stats, bool timing, bool early = false, bool seeded = false)
+                     uint32_t *d_cig, mcx_stats *stats, bool timing, bool early = false)
 {
     if (sel.n == 0) return 0;
     hipStream_t s = R.stream;
     Ctx cx = make_ctx(c, tier, paired);
     const int nr = paired ? 2 : 1;
     early = early && tier == 0 && c->overlap_tiers;
-    if (tier == 0 && !seeded && c->ahead.pending) { // this pass seeds into the tier-0 records: the next batch's early seeding must be through, and what it left there is gone
-        HIP_TRY(hipStreamWaitEvent(s, c->ahead.done, 0));
-        c->ahead.valid = false;
-    }
     HIP_TRY(hipMemsetAsync(R.d_cnt, 0, CNT_N * sizeof(uint32_t), s));
     SeedOut so; so.tasks = R.d_tasks; so.n_tasks = R.d_cnt + CNT_TASKS; so.task_cap = R.task_cap;
     so.read_ext = c->d_read_ext; so.read_blocks = c->d_read_blocks;
@@ -1226,7 +1194,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         const int threads = pkw * 256 * 4 <= 48 * 1024 ? 256 : (pkw * 128 * 4 <= 48 * 1024 ? 128 : 64);
         const int rpl = seed_reads_per_lane((uint64_t)sel.n * nr);
         const unsigned blocks_s = std::min<unsigned>((sel.n * nr + threads * rpl - 1) / (threads * rpl), 4096u); // (the queue feeds whatever grid runs)
-        if (!seeded) k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl, seed_fm_budget()); // (seeded: done beside the batch before)
+        k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl, seed_fm_budget());
     }
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     if (R.d_tasks) k_sa<<<4096, 256, 0, s>>>(cx, so, paired, R.d_cnt + CNT_LF);
@@ -1241,8 +1209,6 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP);
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
-    // the seeds of this batch are spent: the next batch's packing and seeding can start beside what follows (DP, finish, the large tier)
-    if (tier == 0 && sel.ids == nullptr && c->ahead.hinted && (rc2 = launch_ahead(c, s))) return rc2;
     if ((rc2 = launch_dp(R, cx, sinks, rb, sel))) return rc2;
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     k_finish<<<pb, 256, 0, s>>>(cx, rb, sel, d_recs, c->d_pout, R.d_ov, R.d_cnt + CNT_OV, R.ov_cap, c->d_batch_flags + 2);
@@ -1392,58 +1358,6 @@ extern "C" void mcx_avg_walk(int64_t st[3], const uint32_t *pairs, const uint32_
     st[0] = cur; st[1] = tp; st[2] = td;
 }
 
-static int launch_ahead(mcx_ctx *c, hipStream_t s)
-{
-    mcx_ctx::Ahead &A = c->ahead;
-    A.hinted = false;
-    if (!A.stream || c->fast_on) return 0;
-    HIP_TRY(hipEventRecord(c->ev_built, s));
-    HIP_TRY(hipStreamWaitEvent(A.stream, c->ev_built, 0));
-    if (A.in_ready) HIP_TRY(hipStreamWaitEvent(A.stream, A.in_ready, 0));
-    HIP_TRY(hipMemsetAsync(A.d_queue, 0, 64 * sizeof(uint32_t), A.stream));
-    ReadBatch nb; nb.bases = A.bases; nb.off = A.off; nb.n_reads = A.n_reads;
-    const int nr = A.paired ? 2 : 1;
-    HIP_TRY(hipEventRecord(A.t[0], A.stream));
-    {
-        const int tpr = (c->rlen_max + 31) / 32 + 1;
-        const uint64_t threads = (uint64_t)A.n_reads * (uint64_t)tpr;
-        k_pack_reads<<<(unsigned)((threads + 255) / 256), 256, 0, A.stream>>>(nb, A.paired, c->wpad, tpr, A.d_packed);
-    }
-    HIP_TRY(hipEventRecord(A.t[1], A.stream));
-    {
-        Ctx cx = make_ctx(c, 0, A.paired);
-        SeedOut so; so.tasks = nullptr; so.n_tasks = A.d_queue + 32; so.task_cap = 0;
-        so.read_ext = A.d_read_ext; so.read_blocks = A.d_read_blocks; so.packed = A.d_packed; so.wpad = c->wpad;
-        so.fast_hits = nullptr; so.fast_cap = 0; so.queue = A.d_queue;
-        PairSel sel; sel.n = A.n_reads / nr; sel.ids = nullptr; sel.est = nullptr;
-        const int pkw = packed_words(c->rlen_max);
-        const int threads = pkw * 256 * 4 <= 48 * 1024 ? 256 : (pkw * 128 * 4 <= 48 * 1024 ? 128 : 64);
-        const int rpl = seed_reads_per_lane((uint64_t)A.n_reads);
-        const unsigned blocks_s = std::min<unsigned>((A.n_reads + threads * rpl - 1) / (threads * rpl), 4096u);
-        k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, A.stream>>>(cx, nb, sel, so, pkw, rpl, seed_fm_budget());
-    }
-    HIP_TRY(hipEventRecord(A.t[2], A.stream));
-    HIP_TRY(hipEventRecord(A.done, A.stream));
-    HIP_TRY(hipGetLastError());
-    A.pending = true; A.valid = true;
-    return 0;
-}
-
-static int hint_next(mcx_ctx *c, const uint8_t *d_bases, const uint32_t *d_off, uint32_t n_reads, int paired, hipEvent_t in_ready)
-{
-    mcx_ctx::Ahead &A = c->ahead;
-    A.hinted = false;
-    if (!A.stream || !d_bases || !d_off || n_reads == 0 || n_reads > c->max_reads || ((uintptr_t)d_bases & 15) || (paired && (n_reads & 1))) return 0;
-    A.bases = d_bases; A.off = d_off; A.n_reads = n_reads; A.paired = paired; A.in_ready = in_ready; A.hinted = true;
-    return 0;
-}
-
-extern "C" int mcx_batch_hint_next(mcx_ctx *c, const uint8_t *d_bases, const uint32_t *d_off, uint32_t n_reads, int paired)
-{
-    if (!c) return fail(MCX_ERR_ARG, "mcx_batch_hint_next: null argument");
-    return hint_next(c, d_bases, d_off, n_reads, paired, nullptr);
-}
-
 // The first pass over a batch: seeding with the seeds laid out for the fused per-pair kernel, then that kernel
 // (mcx_fast.h).  spill receives the pairs it left for the general path, in pair order.
 static int run_fast(mcx_ctx *c, const ReadBatch &rb, int paired, int32_t est, uint32_t n_pairs, AlnRec *d_recs, mcx_stats *stats, std::vector<uint32_t> &spill,
@@ -1514,7 +1428,7 @@ static int run_fast(mcx_ctx *c, const ReadBatch &rb, int paired, int32_t est, ui
 // runs the tiers for the pairs in `ids` (null: all pairs of the batch) with per-pair estimates
 static int run_selection(mcx_ctx *c, const ReadBatch &rb, int paired, const std::vector<uint32_t> *ids,
                          const std::vector<int32_t> *est, int32_t est_all, uint32_t n_pairs, AlnRec *d_recs,
-                         uint32_t *d_cig, mcx_stats *stats, bool timing, bool seeded = false)
+                         uint32_t *d_cig, mcx_stats *stats, bool timing)
 {
     hipStream_t s = c->stream;
     const uint32_t n = ids ? (uint32_t)ids->size() : n_pairs;
@@ -1527,7 +1441,7 @@ static int run_selection(mcx_ctx *c, const ReadBatch &rb, int paired, const std:
     if (est) HIP_TRY(hipMemcpyAsync(c->d_est, est->data(), n * sizeof(int32_t), hipMemcpyHostToDevice, s));
     else k_fill_i32<<<(n + 255) / 256, 256, 0, s>>>(c->d_est, est_all, n);
     const PassRes R0 = res_tier0(c);
-    int rc = run_pairs(c, 0, R0, rb, paired, sel, d_recs, d_cig, stats, timing, true, seeded && !ids);
+    int rc = run_pairs(c, 0, R0, rb, paired, sel, d_recs, d_cig, stats, timing, true);
     if (rc == kListOverflow) {
         // unusually many hits or DP problems per read (e.g. indel-heavy long reads): halve the selection
         if (n < 2) return fail(MCX_ERR_CAPACITY, "work list overflow for a single pair");
@@ -1620,18 +1534,7 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
         if (c->h_cnt[1] > (uint32_t)c->rlen_max)
             return fail(MCX_ERR_UNSUPPORTED, "a read of " + std::to_string(c->h_cnt[1]) + " bases is longer than max_read_len (" + std::to_string(c->rlen_max) + ")");
     }
-    bool seeded = false;
-    if (c->ahead.pending) { // packed and seeded beside the batch before?  Then its arrays take the place of the current ones
-        mcx_ctx::Ahead &A = c->ahead;
-        HIP_TRY(hipStreamWaitEvent(s, A.done, 0));
-        if (A.valid && A.bases == d_bases && A.off == d_off && A.n_reads == n_reads && A.paired == paired && !c->fast_on) {
-            std::swap(c->d_packed, A.d_packed); std::swap(c->d_read_ext, A.d_read_ext); std::swap(c->d_read_blocks, A.d_read_blocks);
-            seeded = true;
-        }
-        A.pending = false; A.valid = false;
-    }
-    br.seeded = seeded;
-    if (!seeded) { // the batch in 2-bit form, once; every seeding pass (tiers, replay) reads it
+    { // the batch in 2-bit form, once; every seeding pass (tiers, replay) reads it
         HIP_TRY(hipEventRecord(c->ev_pack[0], s));
         const int tpr = (c->rlen_max + 31) / 32 + 1;
         const uint64_t threads = (uint64_t)n_reads * (uint64_t)tpr;
@@ -1646,12 +1549,8 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
         if ((rc = run_fast(c, br.rb, paired, est0, br.n_pairs, br.recs, stats, spill, all_general))) return rc;
         if (all_general) rc = run_selection(c, br.rb, paired, nullptr, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true);
         else rc = spill.empty() ? 0 : run_selection(c, br.rb, paired, &spill, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true);
-    } else rc = run_selection(c, br.rb, paired, nullptr, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true, seeded);
+    } else rc = run_selection(c, br.rb, paired, nullptr, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true);
     if (rc) return rc;
-    if (seeded && stats) { // the early pass's own clock
-        float a = 0, b = 0;
-        if (hipEventElapsedTime(&a, c->ahead.t[0], c->ahead.t[1]) == hipSuccess && hipEventElapsedTime(&b, c->ahead.t[1], c->ahead.t[2]) == hipSuccess) { stats->ms_encode += a; stats->ms_seed += b; }
-    }
     { // seeding statistics (E, blocks, H of SURVEY.md 8d) before the per-read arrays are reused for the chunk sums
         unsigned long long *d_sum = (unsigned long long *)c->d_cnt;
         HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
@@ -1743,7 +1642,7 @@ static int batch_close(mcx_ctx *c, mcx_stats *stats)
         stats->reads += br.rb.n_reads; stats->mapped += br.mapped; stats->pairs += pairs; stats->pair_dist_sum += dist_sum; stats->pair_len_sum += len_sum;
         stats->fm_ext_steps += (int64_t)br.hs[0]; stats->fm_blocks += (int64_t)br.hs[1]; stats->sa_hits += (int64_t)br.hs[2];
         float ms_pack = 0;
-        if (!br.seeded && hipEventElapsedTime(&ms_pack, c->ev_pack[0], c->ev_pack[1]) == hipSuccess) stats->ms_encode += ms_pack; // k_pack_reads
+        if (hipEventElapsedTime(&ms_pack, c->ev_pack[0], c->ev_pack[1]) == hipSuccess) stats->ms_encode += ms_pack; // k_pack_reads
     }
     return 0;
 }
@@ -1974,7 +1873,6 @@ extern "C" int mcx_stream_map(mcx_ctx *c, int paired, int64_t avg[4], mcx_aln *a
     const uint8_t *d_bases; const uint32_t *d_off; mcx_aln *d_aln; uint32_t *d_cig; uint32_t n = 0;
     int rc = mcx_stream_next(c, &d_bases, &d_off, &n, &d_aln, &d_cig);
     if (rc) return rc;
-    if (mcx_ctx::Slot *nx = oldest_slot(c, 1)) hint_next(c, nx->d_bases, nx->d_off, nx->n_reads, paired, nx->in_ready); // the batch behind this one: seeded beside it
     rc = mcx_map_batch_dev(c, d_bases, d_off, n, paired, avg, d_aln, d_cig, stats);
     if (rc) { oldest_slot(c, 2)->state = 0; return rc; }
     return mcx_stream_mapped(c, aln, cigar);
@@ -2025,8 +1923,9 @@ extern "C" int mcx_profile_attach(mcx_ctx *c, uint32_t *d_planes, int max_dup, i
         if ((rc = sort_reserve(c, c->max_reads))) return rc;
         c->sparse_cap = (uint32_t)std::min<uint64_t>(c->max_reads * 2 + 4096, 0x7fffffffu);
         if ((rc = dmalloc(&c->d_sparse, c->sparse_cap))) return rc;
+        HIP_TRY(hipHostMalloc((void **)&c->h_sparse_pin, (size_t)c->sparse_pin_recs * sizeof(SparseRec)));
     }
-    c->h_sparse.clear(); c->h_events.clear(); c->h_resolved.clear();
+    c->h_sparse.clear(); c->h_events.clear(); c->h_resolved.clear(); c->arch_n = 0;
     return 0;
 }
 
@@ -2053,7 +1952,7 @@ static int profile_keys(mcx_ctx *c)
     hipStream_t s = c->stream;
     const IndexView &ix = c->idx->view;
     ProfView pv; pv.plane = c->prof_planes; pv.G = ix.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
-    SparseSink sink; sink.recs = c->d_sparse; sink.n = c->d_cnt + CNT_TASKS; sink.cap = c->sparse_cap;
+    SparseSink sink; sink.recs = c->d_sparse; sink.n = c->d_cnt + CNT_TASKS; sink.cap = c->sparse_cap; sink.refused = c->d_cnt + CNT_UNSUP;
     const uint32_t n = br.rb.n_reads;
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
     k_prof_keys<<<(n + 255) / 256, 256, 0, s>>>(c->d_detail, c->dlay, br.rb, ix, pv, sink, c->d_keys[0], c->d_cnt + CNT_OV);
@@ -2086,6 +1985,31 @@ static int profile_foreign(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all)
     return 0;
 }
 
+// the archived tally records leave HBM: through the two halves of a page-locked bounce buffer (a copy from HBM straight into
+// pageable memory runs at ~1 GB/s), the next piece in flight while this one is copied out
+static int sparse_flush(mcx_ctx *c)
+{
+    if (c->arch_n == 0) return 0;
+    hipStream_t s = c->stream;
+    const size_t at = c->h_sparse.size();
+    c->h_sparse.resize(at + c->arch_n);
+    const uint64_t half = c->sparse_pin_recs / 2;
+    const uint64_t n_piece = (c->arch_n + half - 1) / half;
+    auto start = [&](uint64_t k) -> hipError_t {
+        const uint64_t lo = k * half, m = std::min<uint64_t>(half, c->arch_n - lo);
+        return hipMemcpyAsync(c->h_sparse_pin + (k & 1) * half, c->d_arch + lo, m * sizeof(SparseRec), hipMemcpyDeviceToHost, s);
+    };
+    HIP_TRY(start(0));
+    for (uint64_t k = 0; k < n_piece; k++) {
+        HIP_TRY(hipStreamSynchronize(s));
+        if (k + 1 < n_piece) HIP_TRY(start(k + 1));
+        const uint64_t lo = k * half, m = std::min<uint64_t>(half, c->arch_n - lo);
+        memcpy((void *)(c->h_sparse.data() + at + lo), c->h_sparse_pin + (k & 1) * half, m * sizeof(SparseRec));
+    }
+    c->arch_n = 0;
+    return 0;
+}
+
 // admission over `all` keys (null: the batch's own, already sorted on the device), then the accumulation of the own reads
 static int profile_accumulate(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all, uint32_t slot_stride, uint32_t own_slot)
 {
@@ -2093,7 +2017,7 @@ static int profile_accumulate(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all,
     hipStream_t s = c->stream;
     const IndexView &ix = c->idx->view;
     ProfView pv; pv.plane = c->prof_planes; pv.G = ix.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
-    SparseSink sink; sink.recs = c->d_sparse; sink.n = c->d_cnt + CNT_TASKS; sink.cap = c->sparse_cap;
+    SparseSink sink; sink.recs = c->d_sparse; sink.n = c->d_cnt + CNT_TASKS; sink.cap = c->sparse_cap; sink.refused = c->d_cnt + CNT_UNSUP;
     const uint32_t n = br.rb.n_reads;
     const int paired = br.paired;
     const uint64_t *d_keys = br.d_sorted_keys;
@@ -2124,12 +2048,32 @@ static int profile_accumulate(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all,
     HIP_TRY(hipStreamSynchronize(s));
     const uint32_t n_sp = c->h_cnt[CNT_TASKS], n_ev = c->h_cnt[CNT_RESCUE];
     if (n_sp > c->sparse_cap || n_ev > ev_cap) return fail(MCX_ERR_CAPACITY, "profile: sparse record list overflow");
-    const size_t at = c->h_sparse.size();
-    c->h_sparse.resize(at + n_sp);
-    if (n_sp) HIP_TRY(hipMemcpy(c->h_sparse.data() + at, c->d_sparse, (size_t)n_sp * sizeof(SparseRec), hipMemcpyDeviceToHost));
-    for (size_t i = at; i < c->h_sparse.size(); i++)
-        if (c->h_sparse[i].type == 'X') return fail(MCX_ERR_UNSUPPORTED, "an insertion or deletion of more than " + std::to_string(sizeof(c->h_sparse[i].seq)) +
-                                                                      " bases in an alignment: its string does not fit a tally record");
+    if (c->h_cnt[CNT_UNSUP]) return fail(MCX_ERR_UNSUPPORTED, "an insertion or deletion of more than 255 bases in an alignment: its string does not fit a tally record");
+    // the records stay in HBM until somebody asks for them (mcx_profile_sparse*): appended to the archive on the stream
+    if (n_sp) {
+        if (c->arch_n + n_sp > c->arch_cap) {
+            const uint64_t want = std::max<uint64_t>({2 * c->arch_cap, c->arch_n + n_sp, (uint64_t)1 << 20});
+            SparseRec *grown = nullptr;
+            if (want <= c->arch_limit && hipMalloc((void **)&grown, want * sizeof(SparseRec)) == hipSuccess) {
+                if (c->arch_n) HIP_TRY(hipMemcpyAsync(grown, c->d_arch, c->arch_n * sizeof(SparseRec), hipMemcpyDeviceToDevice, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                if (c->d_arch) (void)hipFree(c->d_arch);
+                c->d_arch = grown; c->arch_cap = want;
+            } else {
+                (void)hipGetLastError();
+                int rc = sparse_flush(c); // no room for a larger archive: what it holds goes to the host now
+                if (rc) return rc;
+                if (n_sp > c->arch_cap) {
+                    if (c->d_arch) (void)hipFree(c->d_arch);
+                    c->d_arch = nullptr; c->arch_cap = 0;
+                    HIP_TRY(hipMalloc((void **)&c->d_arch, (size_t)n_sp * sizeof(SparseRec)));
+                    c->arch_cap = n_sp;
+                }
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(c->d_arch + c->arch_n, c->d_sparse, (size_t)n_sp * sizeof(SparseRec), hipMemcpyDeviceToDevice, s));
+        c->arch_n += n_sp;
+    }
     if (n_ev) {
         // discordant-pair events, ReadMapping.cpp:486-521: kept as seen, with the pair's number in the input
         // stream — the reference's second branch pushes its DiscordPair variable whatever the previous
@@ -2160,6 +2104,8 @@ extern "C" int mcx_profile_finalize(mcx_ctx *c, uint32_t *d_planes)
 extern "C" int mcx_profile_sparse(mcx_ctx *c, const mcx_sparse_rec **recs, uint64_t *n)
 {
     if (!c || !recs || !n) return fail(MCX_ERR_ARG, "mcx_profile_sparse: null argument");
+    HIP_TRY(hipSetDevice(c->idx->device));
+    if (int rc = sparse_flush(c)) return rc;
     c->h_resolved = c->h_sparse;
     mcx_disc_resolve(c->h_events.data(), c->h_events.size(), c->idx->view.G, c->h_resolved);
     *recs = c->h_resolved.data(); *n = c->h_resolved.size();
@@ -2169,6 +2115,8 @@ extern "C" int mcx_profile_sparse(mcx_ctx *c, const mcx_sparse_rec **recs, uint6
 extern "C" int mcx_profile_sparse_shard(mcx_ctx *c, const mcx_sparse_rec **recs, uint64_t *n)
 {
     if (!c || !recs || !n) return fail(MCX_ERR_ARG, "mcx_profile_sparse_shard: null argument");
+    HIP_TRY(hipSetDevice(c->idx->device));
+    if (int rc = sparse_flush(c)) return rc;
     c->h_resolved = c->h_sparse;
     c->h_resolved.insert(c->h_resolved.end(), c->h_events.begin(), c->h_events.end());
     *recs = c->h_resolved.data(); *n = c->h_resolved.size();

@@ -29,7 +29,7 @@ struct ProfView {
     int32_t max_dup, max_clip;
 };
 
-struct SparseSink { SparseRec *recs; uint32_t *n; uint32_t cap; };
+struct SparseSink { SparseRec *recs; uint32_t *n; uint32_t cap; uint32_t *refused; };
 
 static __device__ __forceinline__ void sparse_put(const SparseSink &s, const SparseRec &r)
 {
@@ -181,6 +181,7 @@ __global__ void __launch_bounds__(256) k_prof_accum(const uint8_t *detail, Detai
                         // a string longer than a record continues in the records behind it ('C'); beyond 255 bases it is refused ('X')
                         const int per = (int)sizeof(SparseRec::seq), n_rec = e > 255 ? 1 : (e + per - 1) / per;
                         const uint32_t at = atomicAdd(sink.n, (uint32_t)n_rec);
+                        if (e > 255) atomicAdd(sink.refused, 1u);
                         for (int k = 0; k < n_rec; k++) {
                             SparseRec s; s.pos = g0 + gi - 1; s.type = e > 255 ? 'X' : (k == 0 ? op : 'C');
                             const int lo = k * per, m = e > 255 ? 0 : (e - lo < per ? e - lo : per);

@@ -119,53 +119,6 @@ def test_overlapped_host_boundary_gives_the_same_records(api, golden, tmp_path):
 
 
 @pytest.mark.parametrize("name,alg", [("var", "nw"), ("toy", "ksw2"), ("se", "ksw2"), ("mc", "nw")])
-def test_seeding_ahead_gives_the_same_records(api, golden):
-    """mcx_batch_hint_next: the next batch packed and seeded beside the batch in flight.  Five batches in HBM mapped one at a time,
-    then with every next batch hinted, then with hints that name the wrong batch: the same records and CIGAR words each time."""
-    import torch
-    g = golden["var"]
-    reads1 = [l for i, l in enumerate(open(g["r1"], "rb").read().split(b"\n")) if i % 4 == 1]
-    reads2 = [l for i, l in enumerate(open(g["r2"], "rb").read().split(b"\n")) if i % 4 == 1]
-    n_pairs, per = 1000, 5
-    dev = torch.device("cuda", 0)
-    batches = []
-    for b in range(per):
-        seqs = [x for p in range(b * n_pairs, (b + 1) * n_pairs) for x in (reads1[p], reads2[p])]
-        off = np.zeros(len(seqs) + 1, dtype=np.int64)
-        off[1:] = np.cumsum([len(x) for x in seqs])
-        raw = np.frombuffer(b"".join(seqs) + b"\0" * 64, dtype=np.uint8).copy()
-        batches.append((torch.from_numpy(raw).to(dev), torch.from_numpy(off).to(torch.int32).to(dev)))
-    ix = api.Index(g["prefix"], device=0, full_sa=True)
-    n = 2 * n_pairs
-
-    def run(hint):
-        mp = api.Mapper(ix, alg="ksw2", max_batch_reads=n)
-        out = []
-        for b in range(per):
-            d_aln = torch.zeros(n * 64, dtype=torch.uint8, device=dev)
-            d_cig = torch.zeros(n * api.CIGAR_STRIDE, dtype=torch.int32, device=dev)
-            if hint == "next" and b + 1 < per:
-                mp.hint_next(batches[b + 1][0].data_ptr(), batches[b + 1][1].data_ptr(), n, True)
-            if hint == "wrong":
-                w = (b + 2) % per
-                mp.hint_next(batches[w][0].data_ptr(), batches[w][1].data_ptr(), n, True)
-            mp.map_batch_dev(batches[b][0].data_ptr(), batches[b][1].data_ptr(), n, True, d_aln.data_ptr(), d_cig.data_ptr())
-            aln = np.frombuffer(d_aln.cpu().numpy().tobytes(), dtype=api.ALN_DTYPE)
-            pool = d_cig.cpu().numpy().view(np.uint32)
-            out.append((aln, [pool[a["cigar_off"]:a["cigar_off"] + a["n_cigar"]].copy() for a in aln]))
-        mp.close()
-        return out
-
-    want = run(None)
-    for mode in ("next", "wrong"):
-        got = run(mode)
-        for b in range(per):
-            for f in ("pos", "mate_pos", "chr", "flag", "mapq", "tlen", "nm", "as", "xs", "n_cigar", "fwd", "has_mate"):
-                assert np.array_equal(got[b][0][f], want[b][0][f]), (mode, b, f)
-            assert all(np.array_equal(x, y) for x, y in zip(got[b][1], want[b][1])), (mode, b)
-    ix.close()
-
-
 def test_fused_kernel_and_general_path_agree(api, golden, tmp_path, monkeypatch, name, alg):
     """The experimental fused per-pair kernel (MCX_FAST=1: k_pair_fast, pair state in LDS, for the pairs that fit it; the
     general path for the rest) against the default, where every pair takes the general path: the reference's SAM either way."""
