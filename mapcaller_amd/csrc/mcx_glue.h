@@ -754,13 +754,14 @@ static inline MCX_HD DpJob pair_job(const Ctx &cx, int64_t pair, int k)
 }
 
 // returns the number of DP problems the pair needs (left in its local list)
-static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef *rd)
+// (flags_out: the pair's flags as the stage leaves them, for a caller that lists the pairs that ran over)
+static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef *rd, uint32_t *flags_out = nullptr)
 {
     PairState st = pair_state(cx.state, cx.lay, cx.caps, pair);
     PairHdr *const g_hdr = st.hdr;
     PairHdr h = *g_hdr; // in registers through the stage; every exit stores it back
     h.n_frags = 0; h.n_ops = 0; h.n_jobs = 0;
-    if (h.flags & kOvAny) { *g_hdr = h; return 0; }
+    if (h.flags & kOvAny) { *g_hdr = h; if (flags_out) *flags_out = h.flags; return 0; }
     int nr = cx.pm.paired ? 2 : 1;
     if (cx.pm.paired) {
         if (h.n_paired == 0) { keep_top_scores(st.cands[0], h.n_cands[0]); keep_top_scores(st.cands[1], h.n_cands[1]); }
@@ -775,7 +776,7 @@ static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef 
         for (int ci = 0; ci < h.n_cands[s]; ci++) {
             const Cand c = cs[ci]; // read once; what changes is stored once (frag_off and n_frags share a word)
             if (c.score == 0) { cs[ci].frag_off = (int16_t)h.n_frags; cs[ci].n_frags = 0; continue; }
-            if (h.n_frags + 2 * c.count + 2 > cx.caps.frag_cap) { cs[ci].frag_off = (int16_t)h.n_frags; cs[ci].n_frags = 0; h.flags |= kOvFrags; *g_hdr = h; return 0; }
+            if (h.n_frags + 2 * c.count + 2 > cx.caps.frag_cap) { cs[ci].frag_off = (int16_t)h.n_frags; cs[ci].n_frags = 0; h.flags |= kOvFrags; *g_hdr = h; if (flags_out) *flags_out = h.flags; return 0; }
             Frag *f = st.frags + h.n_frags;
             int nf = build_frags(cx.ix, rd[s].rlen, st.hits[s] + c.first, c.count, f);
             cs[ci].frag_off = (int16_t)h.n_frags; cs[ci].n_frags = (int16_t)(nf < 0 ? 0 : nf);
@@ -791,8 +792,8 @@ static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef 
                         dp = mm > 1 && mm >= (int)(x.rLen * 0.2);
                     }
                     if (dp) {
-                        if (h.n_ops + x.rLen + x.gLen > cx.caps.ops_cap) { h.flags |= kOvOps; *g_hdr = h; return 0; }
-                        if (nj >= cx.caps.job_cap) { h.flags |= kOvJobs; *g_hdr = h; return 0; }
+                        if (h.n_ops + x.rLen + x.gLen > cx.caps.ops_cap) { h.flags |= kOvOps; *g_hdr = h; if (flags_out) *flags_out = h.flags; return 0; }
+                        if (nj >= cx.caps.job_cap) { h.flags |= kOvJobs; *g_hdr = h; if (flags_out) *flags_out = h.flags; return 0; }
                         x.kind = kDp; x.ops_off = h.n_ops; x.ops_len = 0;
                         h.n_ops += x.rLen + x.gLen;
                         jl[2 * nj] = h.n_frags + i; jl[2 * nj + 1] = s;
@@ -807,6 +808,7 @@ static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef 
     }
     h.n_jobs = nj;
     *g_hdr = h;
+    if (flags_out) *flags_out = h.flags;
     return nj;
 }
 

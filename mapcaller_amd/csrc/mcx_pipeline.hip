@@ -610,16 +610,27 @@ __global__ void __launch_bounds__(kRescueThreads) k_rescue(Ctx cx, ReadBatch rb,
 
 // fragment lists + DP problems of every pair; the problems are appended to one list per size
 // class (mcx_glue.h dp_class) with one atomic per wave and class
-__global__ void __launch_bounds__(256) k_build(Ctx cx, ReadBatch rb, PairSel sel, JobSinks sinks, uint32_t *cells, uint32_t *unsupported)
+// (late: the pairs that ran over this tier's capacities since clustering — mate rescue's additions, fragment lists, DP
+//  columns, job lists — are listed like the early ones, for a second pass of the large tier beside the rest of this one)
+__global__ void __launch_bounds__(256) k_build(Ctx cx, ReadBatch rb, PairSel sel, JobSinks sinks, uint32_t *cells, uint32_t *unsupported, EarlyList late)
 {
     __shared__ EndsLds ends;
     stage_ends(cx.ix, ends);
     const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
     int nj = 0;
+    uint32_t fl = 0;
     if (local < sel.n) {
         ReadRef rd[2];
         make_reads(cx, rb, sel_pair(sel, local), rd);
-        nj = stage_build(cx, local, rd);
+        nj = stage_build(cx, local, rd, &fl);
+    }
+    const bool over = late.ids && (fl & kOvAny) && !(fl & kDispatched);
+    if (__ballot(over)) { // (a handful of pairs per batch)
+        if (over) {
+            const uint32_t at = atomicAdd(late.n, 1u);
+            // past the room kept for them the pair stays undispatched: k_finish lists it and it is mapped after the pass
+            if (at < late.cap) { late.ids[at] = sel_pair(sel, local); late.est[at] = sel.est[local]; pair_state(cx.state, cx.lay, cx.caps, local).hdr->flags = fl | kDispatched; }
+        }
     }
     uint32_t per_class[kDpClasses] = {0, 0, 0, 0, 0, 0}, my_cells = 0, bad = 0;
     for (int k = 0; k < nj; k++) {
@@ -804,9 +815,11 @@ struct Tier {
 
 // work-list counters, one per 256 bytes: their atomics then run in different L2 channels instead of queueing on one line
 constexpr int kCntPad = 64;
+constexpr uint32_t kPoutSel = 1u << 16; // pair outcomes gathered per copy (run_selection)
 enum { CNT_TASKS = 0, CNT_RESCUE = 1 * kCntPad, CNT_JOB0 = 2 * kCntPad, CNT_JOB1 = 3 * kCntPad, CNT_JOB2 = 4 * kCntPad, CNT_JOB3 = 5 * kCntPad,
        CNT_JOB4 = 6 * kCntPad, CNT_JOB5 = 7 * kCntPad, CNT_OV = 8 * kCntPad, CNT_LF = 9 * kCntPad, CNT_CELLS = 10 * kCntPad, CNT_UNSUP = 11 * kCntPad,
-       CNT_QUEUE = 12 * kCntPad, CNT_EARLY = 13 * kCntPad, CNT_N = 14 * kCntPad };
+       CNT_QUEUE = 12 * kCntPad, CNT_EARLY = 13 * kCntPad, CNT_LATE = 14 * kCntPad, CNT_N = 15 * kCntPad };
+constexpr uint32_t kLateRoom = 256; // pairs of a pass that may run over after clustering and still go through the large tier beside it
 
 // What a pass over a selection of pairs works with besides the pair records: stream, counters, work lists, DP scratch.
 // The context holds two sets, so that the large tier can map the heavy pairs of a pass (listed while the pass clusters)
@@ -859,7 +872,7 @@ struct mcx_ctx {
     uint32_t *d_sel_ids = nullptr; int32_t *d_est = nullptr;
     uint32_t *d_read_ext = nullptr, *d_read_blocks = nullptr;
     uint32_t *d_packed = nullptr; int wpad = 0; // 2-bit form of the batch's reads
-    PairOut *d_pout = nullptr, *h_pout = nullptr;
+    PairOut *d_pout = nullptr, *d_pout_sel = nullptr; // per-pair outcome of the finish stage; a gathered selection of it
     uint8_t *d_mapq = nullptr; int mapq_rows = 0;
     // -vcf bookkeeping (mcx_profile.h): caller-owned counter planes, per-read alignment detail
     uint32_t *prof_planes = nullptr; int prof_max_dup = 5, prof_max_clip = 5;
@@ -880,6 +893,9 @@ struct mcx_ctx {
     BatchRun run;
     PassRes t1;               // the large tier's own set (the members above are tier 0's); allocated when every suffix-array entry is resident
     bool overlap_tiers = false;
+    PassRes t2;               // a third set: the large tier's pass over the pairs that ran over after clustering (k_build's list)
+    hipEvent_t ev_built = nullptr, ev_late_done = nullptr;
+    bool overlap_late = false;
     hipEvent_t ev_clustered = nullptr;
     // mcx_stream_*: three batches in flight (copy in | kernels | copy out), each in a slot of its own
     struct Slot {
@@ -945,6 +961,46 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
     return 0;
 }
 
+// a set of pass resources beside the context's own (PassRes): work lists for `pairs` pairs at a time, selections of up to `sel_cap`
+static int passres_alloc(mcx_ctx *c, PassRes &t, uint64_t pairs, uint64_t sel_cap, int priority)
+{
+    int rc;
+    HIP_TRY(hipStreamCreateWithPriority(&t.stream, hipStreamNonBlocking, priority));
+    for (int k = 0; k < 5; k++) { HIP_TRY(hipStreamCreateWithPriority(&t.dp_stream[k], hipStreamNonBlocking, priority)); HIP_TRY(hipEventCreateWithFlags(&t.dp_join[k], hipEventDisableTiming)); }
+    HIP_TRY(hipEventCreateWithFlags(&t.dp_fork, hipEventDisableTiming));
+    for (auto &e : t.ev) HIP_TRY(hipEventCreate(&e));
+    if ((rc = dmalloc(&t.d_cnt, CNT_N))) return rc;
+    HIP_TRY(hipHostMalloc((void **)&t.h_cnt, CNT_N * sizeof(uint32_t)));
+    for (int k = 0; k < kDpClasses; k++) {
+        t.job_cap[k] = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(pairs * 16, 1u << 20), c->job_cap[k]);
+        if ((rc = dmalloc(&t.d_jobs[k], t.job_cap[k]))) return rc;
+    }
+    t.rescue_cap = (uint32_t)pairs;
+    if ((rc = dmalloc(&t.d_rescue, t.rescue_cap))) return rc;
+    const uint32_t blocks1[3] = {2048, 512, 128};
+    for (int k = 0; k < 3; k++) {
+        t.dp_stride[k] = c->dp_stride[k]; t.dp_blocks[k] = blocks1[k];
+        if ((rc = dmalloc(&t.d_dp_scratch[k], (size_t)t.dp_stride[k] * t.dp_blocks[k]))) return rc;
+    }
+    t.ov_cap = (uint32_t)sel_cap;
+    if ((rc = dmalloc(&t.d_ov, t.ov_cap))) return rc;
+    if ((rc = dmalloc(&t.d_sel_ids, sel_cap))) return rc;
+    if ((rc = dmalloc(&t.d_est, sel_cap))) return rc;
+    return 0;
+}
+
+static void passres_free(PassRes &t)
+{
+    void *q[] = {t.d_cnt, t.d_jobs[0], t.d_jobs[1], t.d_jobs[2], t.d_jobs[3], t.d_jobs[4], t.d_jobs[5], t.d_rescue, t.d_dp_scratch[0], t.d_dp_scratch[1],
+                 t.d_dp_scratch[2], t.d_ov, t.d_sel_ids, t.d_est};
+    for (void *x : q) if (x) (void)hipFree(x);
+    if (t.h_cnt) (void)hipHostFree(t.h_cnt);
+    for (auto &e : t.ev) if (e) (void)hipEventDestroy(e);
+    for (int k = 0; k < 5; k++) { if (t.dp_stream[k]) (void)hipStreamDestroy(t.dp_stream[k]); if (t.dp_join[k]) (void)hipEventDestroy(t.dp_join[k]); }
+    if (t.dp_fork) (void)hipEventDestroy(t.dp_fork);
+    if (t.stream) (void)hipStreamDestroy(t.stream);
+}
+
 static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
 {
     c->idx = idx; c->opts = o;
@@ -996,7 +1052,7 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     c->wpad = (packed_words(c->rlen_max) + 3) & ~3;
     if ((rc = dmalloc(&c->d_packed, c->max_reads * (uint64_t)c->wpad))) return rc;
     if ((rc = dmalloc(&c->d_pout, c->max_reads))) return rc;
-    HIP_TRY(hipHostMalloc((void **)&c->h_pout, c->max_reads * sizeof(PairOut)));
+    if ((rc = dmalloc(&c->d_pout_sel, kPoutSel))) return rc;
     // EvaluateMAPQ (SamReport.cpp:86-101) tabulated on the host so that the double-precision
     // log() is the host libm's, exactly as in the reference
     c->mapq_rows = c->rlen_max + 64;
@@ -1012,35 +1068,22 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     // the large tier's own stream, counters and lists: with them it maps the heavy pairs of a pass while the pass goes on
     // (without the full suffix array it would also need an SA task list of its own: then the tiers run one after the other)
     if (idx->view.sa_full && !getenv("MCX_NO_TIER_OVERLAP")) {
-        PassRes &t = c->t1;
         // its kernels are as long as their slowest pair, and the batch waits for them: their waves go first
+        // (human-like bench genome: 40.0 -> 37.4 ms per step)
         int pr_lo = 0, pr_hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
         if (getenv("MCX_TIER1_NO_PRIORITY")) pr_hi = pr_lo > 0 ? 0 : pr_lo; // (experiments)
-        HIP_TRY(hipStreamCreateWithPriority(&t.stream, hipStreamNonBlocking, pr_hi));
-        for (int k = 0; k < 5; k++) { HIP_TRY(hipStreamCreateWithPriority(&t.dp_stream[k], hipStreamNonBlocking, pr_hi)); HIP_TRY(hipEventCreateWithFlags(&t.dp_join[k], hipEventDisableTiming)); }
-        HIP_TRY(hipEventCreateWithFlags(&t.dp_fork, hipEventDisableTiming));
-        for (auto &e : t.ev) HIP_TRY(hipEventCreate(&e));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_clustered, hipEventDisableTiming));
-        if ((rc = dmalloc(&t.d_cnt, CNT_N))) return rc;
-        HIP_TRY(hipHostMalloc((void **)&t.h_cnt, CNT_N * sizeof(uint32_t)));
-        const uint64_t mp = c->tier[1].max_pairs;
-        for (int k = 0; k < kDpClasses; k++) {
-            t.job_cap[k] = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(mp * 16, 1u << 20), c->job_cap[k]);
-            if ((rc = dmalloc(&t.d_jobs[k], t.job_cap[k]))) return rc;
-        }
-        t.rescue_cap = (uint32_t)mp;
-        if ((rc = dmalloc(&t.d_rescue, t.rescue_cap))) return rc;
-        const uint32_t blocks1[3] = {2048, 512, 128};
-        for (int k = 0; k < 3; k++) {
-            t.dp_stride[k] = c->dp_stride[k]; t.dp_blocks[k] = blocks1[k];
-            if ((rc = dmalloc(&t.d_dp_scratch[k], (size_t)t.dp_stride[k] * t.dp_blocks[k]))) return rc;
-        }
-        t.ov_cap = (uint32_t)c->max_reads;
-        if ((rc = dmalloc(&t.d_ov, t.ov_cap))) return rc;
-        if ((rc = dmalloc(&t.d_sel_ids, c->max_reads))) return rc;
-        if ((rc = dmalloc(&t.d_est, c->max_reads))) return rc;
+        if ((rc = passres_alloc(c, c->t1, c->tier[1].max_pairs, c->max_reads, pr_hi))) return rc;
+        HIP_TRY(hipEventCreate(&c->ev_clustered));
         c->overlap_tiers = true;
+        // and a small third set for the pairs that run over after clustering: they go through the large tier while the pass's
+        // DP and finish stages run, in the last kLateRoom records of the tier, instead of in a pass of their own after it
+        if (c->tier[1].max_pairs >= 4 * kLateRoom && !getenv("MCX_NO_LATE_OVERLAP")) {
+            if ((rc = passres_alloc(c, c->t2, kLateRoom, kLateRoom, pr_hi))) return rc;
+            HIP_TRY(hipEventCreateWithFlags(&c->ev_built, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c->ev_late_done, hipEventDisableTiming));
+            c->overlap_late = true;
+        }
     }
     // the fused per-pair kernel: needs every suffix-array entry resident (seeds then leave k_seed as text positions)
     // and a slice of LDS per lane that the read length decides (reads up to 16 x code_words bases take it)
@@ -1077,26 +1120,15 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3], c->d_jobs[4], c->d_jobs[5],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
                  c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
-                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_packed, c->d_batch_flags, c->d_fast_hits, c->d_spill, c->d_saved};
+                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_pout_sel, c->d_packed, c->d_batch_flags, c->d_fast_hits, c->d_spill, c->d_saved};
     for (void *q : p) if (q) (void)hipFree(q);
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
-    if (c->h_pout) (void)hipHostFree(c->h_pout);
     if (c->h_keys) (void)hipHostFree(c->h_keys);
     if (c->h_spill) (void)hipHostFree(c->h_spill);
     if (c->h_sparse_pin) (void)hipHostFree(c->h_sparse_pin);
     if (c->d_arch) (void)hipFree(c->d_arch);
-    {
-        PassRes &t = c->t1;
-        void *q[] = {t.d_cnt, t.d_jobs[0], t.d_jobs[1], t.d_jobs[2], t.d_jobs[3], t.d_jobs[4], t.d_jobs[5], t.d_rescue, t.d_dp_scratch[0], t.d_dp_scratch[1],
-                     t.d_dp_scratch[2], t.d_ov, t.d_sel_ids, t.d_est};
-        for (void *x : q) if (x) (void)hipFree(x);
-        if (t.h_cnt) (void)hipHostFree(t.h_cnt);
-        for (auto &e : t.ev) if (e) (void)hipEventDestroy(e);
-        for (int k = 0; k < 5; k++) { if (t.dp_stream[k]) (void)hipStreamDestroy(t.dp_stream[k]); if (t.dp_join[k]) (void)hipEventDestroy(t.dp_join[k]); }
-        if (t.dp_fork) (void)hipEventDestroy(t.dp_fork);
-        if (t.stream) (void)hipStreamDestroy(t.stream);
-        if (c->ev_clustered) (void)hipEventDestroy(c->ev_clustered);
-    }
+    passres_free(c->t1); passres_free(c->t2);
+    for (hipEvent_t e : {c->ev_clustered, c->ev_built, c->ev_late_done}) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->ev_fast) if (e) (void)hipEventDestroy(e);
     for (auto &sl : c->slot) {
         void *q[] = {sl.d_bases, sl.d_off, sl.d_recs, sl.d_cig};
@@ -1164,16 +1196,22 @@ static int launch_dp(const PassRes &R, const Ctx &cx, const JobSinks &sinks, con
 }
 
 static int tier1_error(mcx_ctx *c, const PassRes &R);
+static int tier1_pass_end(mcx_ctx *c, const PassRes &T, uint32_t m, mcx_stats *t1, mcx_stats *stats, int e);
 
 // One tier over a selection of pairs.  early (tier 0 only): the pairs that run over the tier's capacities while clustering
 // are listed on the device; once the rest of the pass is queued, the large tier maps them on its own stream — its kernels
 // are bound by their slowest pair, not by the chip, so they hide behind the pass instead of following it.
+// state_off: the pass's pair records start at record state_off of the tier.  queue_only: the kernels are queued on R's stream
+// and that is all — the caller goes on and calls pass_finish() for the pass later (*queued = its timing events).
+static int pass_finish(mcx_ctx *c, int tier, const PassRes &R, uint32_t n_sel, mcx_stats *stats, bool timing, int e);
+
 static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb, int paired, PairSel sel, AlnRec *d_recs,
-                     uint32_t *d_cig, mcx_stats *stats, bool timing, bool early = false)
+                     uint32_t *d_cig, mcx_stats *stats, bool timing, bool early = false, uint32_t state_off = 0, int *queued = nullptr)
 {
     if (sel.n == 0) return 0;
     hipStream_t s = R.stream;
     Ctx cx = make_ctx(c, tier, paired);
+    cx.state += (size_t)state_off * (size_t)cx.lay.stride;
     const int nr = paired ? 2 : 1;
     early = early && tier == 0 && c->overlap_tiers;
     HIP_TRY(hipMemsetAsync(R.d_cnt, 0, CNT_N * sizeof(uint32_t), s));
@@ -1183,6 +1221,9 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     RescueList rl; rl.ids = R.d_rescue; rl.n = R.d_cnt + CNT_RESCUE; rl.cap = R.rescue_cap;
     EarlyList el; el.ids = nullptr; el.est = nullptr; el.n = R.d_cnt + CNT_EARLY; el.cap = 0;
     if (early) { el.ids = c->t1.d_sel_ids; el.est = c->t1.d_est; el.cap = (uint32_t)c->max_reads; }
+    const bool late = early && c->overlap_late;
+    EarlyList ll; ll.ids = nullptr; ll.est = nullptr; ll.n = R.d_cnt + CNT_LATE; ll.cap = 0;
+    if (late) { ll.ids = c->t2.d_sel_ids; ll.est = c->t2.d_est; ll.cap = kLateRoom; }
     JobSinks sinks;
     for (int k = 0; k < kDpClasses; k++) { sinks.s[k].jobs = R.d_jobs[k]; sinks.s[k].count = R.d_cnt + CNT_JOB0 + k * kCntPad; sinks.s[k].cap = R.job_cap[k]; }
     const unsigned pb = (sel.n + 255) / 256;
@@ -1207,7 +1248,8 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         else k_rescue<4096><<<4096, kRescueThreads, 0, s>>>(cx, rb, sel, rl);
     }
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
-    k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP);
+    k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP, ll);
+    if (late) HIP_TRY(hipEventRecord(c->ev_built, s));
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     if ((rc2 = launch_dp(R, cx, sinks, rb, sel))) return rc2;
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
@@ -1215,6 +1257,13 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(R.h_cnt, R.d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (queued) { *queued = e; return 0; }
+    hipEvent_t ev_dbg[2] = {nullptr, nullptr}; // (MCX_TIMING: when tier 0 and the large tier beside it were done)
+    if (early && getenv("MCX_TIMING")) {
+        for (int k = 0; k < 2; k++) HIP_TRY(hipEventCreate(&ev_dbg[k]));
+        HIP_TRY(hipEventRecord(ev_dbg[0], s));
+    }
+    uint32_t n_late = 0;
     if (early) { // the pairs k_cluster listed: through the large tier now, while the kernels above run
         const PassRes &T = c->t1;
         uint32_t n_early = 0;
@@ -1224,25 +1273,56 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         n_early = T.h_cnt[0];
         if (n_early > el.cap) { (void)hipStreamSynchronize(s); return fail(MCX_ERR_CAPACITY, "overflow list overflow"); }
         if (stats) stats->tier1_pairs += n_early;
-        for (uint32_t lo = 0; lo < n_early && rc2 == 0; lo += c->tier[1].max_pairs) {
-            const uint32_t m = std::min<uint32_t>(c->tier[1].max_pairs, n_early - lo);
+        const bool t1_timing = getenv("MCX_TIMING") != nullptr;
+        const uint32_t room = c->tier[1].max_pairs - (late ? kLateRoom : 0); // (the last records are the late list's)
+        mcx_stats t1;
+        uint32_t m = 0;
+        int e1 = -1, e2 = -1;
+        for (uint32_t lo = 0; lo < n_early && rc2 == 0; lo += room) {
+            // (all but the last pass are waited for here; the last one is left under way while the late list is seen to)
+            m = std::min<uint32_t>(room, n_early - lo);
+            const bool last = lo + room >= n_early;
             PairSel s1; s1.n = m; s1.ids = T.d_sel_ids + lo; s1.est = T.d_est + lo;
-            if (getenv("MCX_TIMING")) {
-                mcx_stats t1; memset(&t1, 0, sizeof t1);
-                rc2 = run_pairs(c, 1, T, rb, paired, s1, d_recs, d_cig, &t1, true);
-                fprintf(stderr, "[tier 1, beside tier 0] %u pairs: seed %.2f sa %.2f cluster %.2f rescue %.2f build %.2f dp %.2f finish %.2f ms\n", m, t1.ms_seed, t1.ms_sa,
-                        t1.ms_cluster, t1.ms_rescue, t1.ms_build, t1.ms_dp, t1.ms_finish);
-                if (stats) { stats->dp_jobs += t1.dp_jobs; stats->dp_cells += t1.dp_cells; }
-            } else rc2 = run_pairs(c, 1, T, rb, paired, s1, d_recs, d_cig, stats, false);
-            if (rc2 == kListOverflow) rc2 = fail(MCX_ERR_CAPACITY, "work list overflow in tier 1");
-            if (rc2 == 0 && T.h_cnt[CNT_OV]) rc2 = tier1_error(c, T);
+            memset(&t1, 0, sizeof t1);
+            rc2 = run_pairs(c, 1, T, rb, paired, s1, d_recs, d_cig, t1_timing ? &t1 : stats, t1_timing, false, 0, last ? &e1 : nullptr);
+            if (!last && rc2 == 0) rc2 = tier1_pass_end(c, T, m, t1_timing ? &t1 : nullptr, stats, -1);
         }
+        if (late && rc2 == 0) {
+            // what ran over after clustering (k_build's list): known once tier 0 has built; a handful of pairs, which take the
+            // large tier on the third set of resources while tier 0's DP and finish stages run
+            const PassRes &U = c->t2;
+            HIP_TRY(hipEventSynchronize(c->ev_built));
+            HIP_TRY(hipMemcpyAsync(U.h_cnt, R.d_cnt + CNT_LATE, sizeof(uint32_t), hipMemcpyDeviceToHost, U.stream));
+            HIP_TRY(hipStreamSynchronize(U.stream));
+            n_late = std::min<uint32_t>(U.h_cnt[0], kLateRoom);
+            if (n_late) {
+                PairSel s2; s2.n = n_late; s2.ids = U.d_sel_ids; s2.est = U.d_est;
+                rc2 = run_pairs(c, 1, U, rb, paired, s2, d_recs, d_cig, stats, false, false, c->tier[1].max_pairs - kLateRoom, &e2);
+                if (stats) stats->tier1_pairs += n_late;
+            }
+        }
+        if (e1 >= 0) { const int r = tier1_pass_end(c, T, m, t1_timing ? &t1 : nullptr, stats, e1); if (rc2 == 0) rc2 = r; }
+        if (e2 >= 0) { const int r = tier1_pass_end(c, c->t2, n_late, nullptr, stats, e2); if (rc2 == 0) rc2 = r; }
     }
+    if (ev_dbg[0]) HIP_TRY(hipEventRecord(ev_dbg[1], c->t1.stream));
     HIP_TRY(hipStreamSynchronize(s));
+    if (ev_dbg[0]) {
+        float a = 0, b = 0;
+        HIP_TRY(hipEventSynchronize(ev_dbg[1]));
+        HIP_TRY(hipEventElapsedTime(&a, c->ev_clustered, ev_dbg[0])); HIP_TRY(hipEventElapsedTime(&b, c->ev_clustered, ev_dbg[1]));
+        fprintf(stderr, "[run_pairs] after clustering: tier 0 done at %.2f ms, the large tier beside it by %.2f ms\n", a, b);
+        for (int k = 0; k < 2; k++) (void)hipEventDestroy(ev_dbg[k]);
+    }
     if (rc2) return rc2;
+    return pass_finish(c, tier, R, sel.n, stats, timing, e);
+}
+
+// what follows a pass once its stream has been joined: the work lists' overflow checks, counts and stage times
+static int pass_finish(mcx_ctx *c, int tier, const PassRes &R, uint32_t n_sel, mcx_stats *stats, bool timing, int e)
+{
     if (tier == 1 && getenv("MCX_TIER1_HIST")) { // experiments: how heavy are the pairs of the large tier?
-        std::vector<PairHdr> hd(sel.n);
-        HIP_TRY(hipMemcpy2D(hd.data(), sizeof(PairHdr), c->tier[1].state, (size_t)c->tier[1].lay.stride, sizeof(PairHdr), sel.n, hipMemcpyDeviceToHost));
+        std::vector<PairHdr> hd(n_sel);
+        HIP_TRY(hipMemcpy2D(hd.data(), sizeof(PairHdr), c->tier[1].state, (size_t)c->tier[1].lay.stride, sizeof(PairHdr), n_sel, hipMemcpyDeviceToHost));
         const int edges[8] = {16, 32, 64, 128, 256, 512, 1024, 1 << 30};
         uint32_t hh[8] = {0}, hc[8] = {0}, hf[8] = {0};
         for (const PairHdr &h : hd) {
@@ -1251,7 +1331,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
             for (int b = 0; b < 8; b++) if (nc <= edges[b]) { hc[b]++; break; }
             for (int b = 0; b < 8; b++) if (h.n_frags <= edges[b]) { hf[b]++; break; }
         }
-        fprintf(stderr, "[tier 1 hist] %u pairs; per-read maximum <=16,32,64,128,256,512,1024,more: hits", sel.n);
+        fprintf(stderr, "[tier 1 hist] %u pairs; per-read maximum <=16,32,64,128,256,512,1024,more: hits", n_sel);
         for (int b = 0; b < 8; b++) fprintf(stderr, " %u", hh[b]);
         fprintf(stderr, " | candidates");
         for (int b = 0; b < 8; b++) fprintf(stderr, " %u", hc[b]);
@@ -1265,7 +1345,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     for (int k = 0; k < kDpClasses; k++) if (n[CNT_JOB0 + k * kCntPad] > R.job_cap[k]) return kListOverflow;
     if (n[CNT_UNSUP]) return fail(MCX_ERR_UNSUPPORTED, "a gapped fragment exceeds 2048 x 1024 cells per side");
     if (timing && getenv("MCX_TIMING"))
-        fprintf(stderr, "[run_pairs] pairs %u: sa tasks %u, rescue pairs %u, dp jobs by class (tiny) %u %u (half) %u %u %u %u, cells %u, overflow pairs %u (+ %u listed while clustering)\n", sel.n,
+        fprintf(stderr, "[run_pairs] pairs %u: sa tasks %u, rescue pairs %u, dp jobs by class (tiny) %u %u (half) %u %u %u %u, cells %u, overflow pairs %u (+ %u listed while clustering)\n", n_sel,
                 n[CNT_TASKS], n[CNT_RESCUE], n[CNT_JOB4], n[CNT_JOB0], n[CNT_JOB5], n[CNT_JOB1], n[CNT_JOB2], n[CNT_JOB3], n[CNT_CELLS], n[CNT_OV], n[CNT_EARLY]);
     if (stats) {
         stats->dp_jobs += (int64_t)n[CNT_JOB0] + n[CNT_JOB1] + n[CNT_JOB2] + n[CNT_JOB3] + n[CNT_JOB4] + n[CNT_JOB5];
@@ -1278,6 +1358,24 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         }
     }
     return 0;
+}
+
+// end of a pass of the large tier that was left under way beside tier 0 (e: its timing events, -1: it was waited for already)
+static int tier1_pass_end(mcx_ctx *c, const PassRes &T, uint32_t m, mcx_stats *t1, mcx_stats *stats, int e)
+{
+    int rc = 0;
+    if (e >= 0) {
+        HIP_TRY(hipStreamSynchronize(T.stream));
+        rc = pass_finish(c, 1, T, m, t1 ? t1 : stats, t1 != nullptr, e);
+    }
+    if (t1) {
+        fprintf(stderr, "[tier 1, beside tier 0] %u pairs: seed %.2f sa %.2f cluster %.2f rescue %.2f build %.2f dp %.2f finish %.2f ms\n", m, t1->ms_seed, t1->ms_sa,
+                t1->ms_cluster, t1->ms_rescue, t1->ms_build, t1->ms_dp, t1->ms_finish);
+        if (stats) { stats->dp_jobs += t1->dp_jobs; stats->dp_cells += t1->dp_cells; }
+    }
+    if (rc == kListOverflow) rc = fail(MCX_ERR_CAPACITY, "work list overflow in tier 1");
+    if (rc == 0 && T.h_cnt[CNT_OV]) rc = tier1_error(c, T);
+    return rc;
 }
 
 // a pair that does not even fit the large tier: say which and why
@@ -1426,6 +1524,12 @@ static int run_fast(mcx_ctx *c, const ReadBatch &rb, int paired, int32_t est, ui
 }
 
 // runs the tiers for the pairs in `ids` (null: all pairs of the batch) with per-pair estimates
+__global__ void k_gather_pout(const PairOut *pout, const uint32_t *ids, uint32_t n, PairOut *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = pout[ids[i]];
+}
+
 static int run_selection(mcx_ctx *c, const ReadBatch &rb, int paired, const std::vector<uint32_t> *ids,
                          const std::vector<int32_t> *est, int32_t est_all, uint32_t n_pairs, AlnRec *d_recs,
                          uint32_t *d_cig, mcx_stats *stats, bool timing)
@@ -1464,12 +1568,20 @@ static int run_selection(mcx_ctx *c, const ReadBatch &rb, int paired, const std:
     HIP_TRY(hipMemcpy(ov.data(), c->d_ov, n_ov * sizeof(uint32_t), hipMemcpyDeviceToHost));
     std::sort(ov.begin(), ov.end());
     std::vector<int32_t> ov_est(n_ov);
-    HIP_TRY(hipMemcpy(c->h_pout, c->d_pout, (size_t)n_pairs * sizeof(PairOut), hipMemcpyDeviceToHost));
-    for (uint32_t i = 0; i < n_ov; i++) ov_est[i] = c->h_pout[ov[i]].est;
+    // their estimates (and flags): gathered on the device — the whole PairOut array is 128 MB at 4 M pairs
+    std::vector<PairOut> ov_out(n_ov);
+    for (uint32_t lo = 0; lo < n_ov; lo += kPoutSel) {
+        const uint32_t m = std::min<uint32_t>(kPoutSel, n_ov - lo);
+        HIP_TRY(hipMemcpyAsync(c->d_sel_ids, ov.data() + lo, m * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        k_gather_pout<<<(m + 255) / 256, 256, 0, s>>>(c->d_pout, c->d_sel_ids, m, c->d_pout_sel);
+        HIP_TRY(hipMemcpyAsync(ov_out.data() + lo, c->d_pout_sel, m * sizeof(PairOut), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    for (uint32_t i = 0; i < n_ov; i++) ov_est[i] = ov_out[i].est;
     if (stats) stats->tier1_pairs += n_ov;
     if (getenv("MCX_TIMING")) { // what sent them here
         uint32_t by_flag[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (uint32_t i = 0; i < n_ov; i++) for (int b = 0; b < 8; b++) if (c->h_pout[ov[i]].flags & (1u << b)) by_flag[b]++;
+        for (uint32_t i = 0; i < n_ov; i++) for (int b = 0; b < 8; b++) if (ov_out[i].flags & (1u << b)) by_flag[b]++;
         fprintf(stderr, "[tier 1] %u pairs over the tier-0 capacities: hits %u candidates %u fragments %u ops %u jobs %u cigar %u rescue window %u detail %u\n", n_ov, by_flag[0],
                 by_flag[1], by_flag[2], by_flag[3], by_flag[4], by_flag[5], by_flag[6], by_flag[7]);
     }
