@@ -326,36 +326,111 @@ struct RescueSerial {
 };
 
 #if defined(__HIPCC__)
-// The same evaluation by one wavefront (the block is one wave): window 8-mers are packed in
-// parallel (the genome has no N, so the reference's rolling id is the plain 16-bit pack),
-// diagonals are dealt round-robin to the lanes, the best (largest total, then smallest
-// diagonal) is found by a wave reduction, and lane 0 emits its seeds.  kq/kg live in LDS:
-// kq[r] is a broadcast read and kg[r + d] is conflict-free across consecutive diagonals.
+// The same evaluation by one workgroup, on bit planes.  Two 8-mers are equal when their eight bases are, so the 8-mer match
+// matrix of a diagonal is "eight base matches in a row": read and window are kept in LDS as two bit planes each (the low
+// and the high bit of every base, 32 bases to a word; the genome has no N, a read's N are a third plane), a diagonal's
+// base matches are ~((QL ^ WL') | (QH ^ WH')) with the window planes funnel-shifted to the diagonal — 32 rows per handful of
+// instructions instead of one id comparison per cell — and runs of eight collapse with three shift-and-AND steps.  The
+// diagonal's total then comes from the 8-mer match bits as in diag_total: a run of L >= 3 matches counts L + 7 =
+// (its L - 2 triples) + 9.  Words are walked from the read's end to its start so that what a word needs from the next one
+// (the carries of the collapses, the triple bits) is at hand.
+constexpr int kRescueQWords = 1024 / 32 + 2;                 // plane words of the longest read (+ the funnel's look-ahead)
+constexpr int rescue_wwords(int kg) { return (kg + 2 * 1056) / 32 + 4; } // window plane: pad | window | the read's overhang
+
+static __device__ __forceinline__ uint32_t even_bits16(uint32_t t) // bits 0,2,..30 of t, packed into 16
+{
+    t &= 0x55555555u; t = (t | (t >> 1)) & 0x33333333u; t = (t | (t >> 2)) & 0x0f0f0f0fu; t = (t | (t >> 4)) & 0x00ff00ffu;
+    return (t | (t >> 8)) & 0xffffu;
+}
 
 struct RescueWave { // one workgroup (any number of wavefronts) evaluates one pair
-    uint32_t *kq, *kg;
-    int *red; // LDS scratch: 2 ints per wavefront + 4
+    uint32_t *q;    // LDS: QL | QH | QV, kRescueQWords each (QV: an 8-mer of the read starts here — inside the read, no N)
+    uint32_t *w;    // LDS: WL | WH, wstride words each; window position p is bit p + pad
+    uint32_t *ew;   // LDS: the 8-mer match words of the best diagonal (kRescueQWords)
+    int wstride;
+    int *red;       // LDS scratch: 2 ints per wavefront + 4, then the flag "the read has N"
+    uint32_t *kq, *kg; // HBM scratch of the workgroup for window_ids: 1024 ids of the read; ids of the window + its 2-bit bytes
     __device__ bool leader() const { return threadIdx.x == 0; }
     __device__ void sync() const { __threadfence_block(); __syncthreads(); }
     __device__ void fill_query(const ReadRef &rq) const
     {
-        // the read's characters as codes, in parallel (kg is free until the first window); a read without N gets
-        // its 8-mer ids in parallel as well — CreateKmerVecFromReadSeq's rolling id is then the plain 16-bit pack
         const int tid = threadIdx.x, nt = blockDim.x;
-        uint8_t *qc = (uint8_t *)kg;
+        uint32_t *ql = q, *qh = q + kRescueQWords, *qn = q + 2 * kRescueQWords;
         __syncthreads();
-        int any_n = 0;
-        for (int i = tid; i < rq.rlen; i += nt) { const int c = nt4_code(read_char(rq, i)); qc[i] = (uint8_t)c; any_n |= c > 3; }
-        any_n = __syncthreads_or(any_n);
-        if (any_n) { if (leader()) kmer_fill([&](uint32_t i) { return read_char(rq, (int)i); }, rq.rlen, kq); }
-        else for (int i = tid; i < rq.rlen; i += nt) {
-            uint32_t wid = MCX_NOKMER;
-            if (i + kKmerSize <= rq.rlen) { wid = 0; for (int k = 0; k < kKmerSize; k++) wid = (wid << 2) | qc[i + k]; }
-            kq[i] = wid;
+        for (int i = tid; i < 3 * kRescueQWords; i += nt) q[i] = 0u;
+        __syncthreads();
+        for (int i = tid; i < rq.rlen; i += nt) {
+            const int c = nt4_code(read_char(rq, i));
+            const uint32_t bit = 1u << (i & 31);
+            if (c > 3) atomicOr(&qn[i >> 5], bit);
+            else { if (c & 1) atomicOr(&ql[i >> 5], bit); if (c & 2) atomicOr(&qh[i >> 5], bit); }
         }
         __syncthreads();
+        int any_n = 0;
+        for (int k = tid; k < kRescueQWords; k += nt) any_n |= qn[k] != 0u;
+        any_n = __syncthreads_or(any_n);
+        if (tid == 0) red[2 * (nt >> 6) + 4] = any_n;
+        if (any_n) { // (window_ids will be used)
+            if (leader()) kmer_fill([&](uint32_t i) { return read_char(rq, (int)i); }, rq.rlen, kq);
+            __threadfence_block();
+            __syncthreads();
+            return;
+        }
+        // a base counts when it is inside the read and not N; an 8-mer starts where eight of them follow one another
+        uint32_t v8 = 0;
+        if (tid < kRescueQWords) {
+            auto ok = [&](int k) -> uint32_t {
+                if (k >= kRescueQWords || 32 * k >= rq.rlen) return 0u;
+                const uint32_t in = rq.rlen - 32 * k >= 32 ? ~0u : ((1u << (rq.rlen - 32 * k)) - 1u);
+                return ~qn[k] & in;
+            };
+            const uint32_t v = ok(tid), vn = ok(tid + 1);
+            v8 = v;
+#pragma unroll
+            for (int j = 1; j < kKmerSize; j++) v8 &= __funnelshift_r(v, vn, j);
+        }
+        __syncthreads();
+        if (tid < kRescueQWords) qn[tid] = v8;
+        __syncthreads();
     }
-    __device__ RescueOut window(const IndexView &ix, int64_t left, int slen, int qlen, Hit *hits, int n_hits, int cap, bool &overflow) const
+    // the 8-mer match words of diagonal d, from the read's last word down; total: the diagonal's summed seed length
+    // (store: the words are kept in ew for the seeds)
+    __device__ int diagonal(int d, int qlen, int slen, int pad, bool store) const
+    {
+        const uint32_t *ql = q, *qh = q + kRescueQWords, *qv = q + 2 * kRescueQWords, *wl = w, *wh = w + wstride;
+        const int lo = d < 0 ? -d : 0, hi = qlen - kKmerSize < slen - kKmerSize - d ? qlen - kKmerSize : slen - kKmerSize - d; // rows whose 8-mers exist on both sides
+        if (hi - lo < 2) return 0;
+        const int ktop = (hi + kKmerSize - 1) >> 5, kbot = lo >> 5;
+        const int s0 = d + pad, sh = s0 & 31;
+        int i = ktop + (s0 >> 5);
+        uint32_t wl_hi = wl[i + 1], wh_hi = wh[i + 1], m_hi = 0, a_hi = 0, b_hi = 0, e_hi = 0, t_hi = 0;
+        int total = 0;
+        for (int k = ktop; k >= kbot; k--, i--) {
+            const uint32_t wl_lo = wl[i], wh_lo = wh[i];
+            const uint32_t gl = __funnelshift_r(wl_lo, wl_hi, sh), gh = __funnelshift_r(wh_lo, wh_hi, sh);
+            wl_hi = wl_lo; wh_hi = wh_lo;
+            const uint32_t m = ~((ql[k] ^ gl) | (qh[k] ^ gh));          // bases equal, rows 32k..32k+31
+            const uint32_t a = m & __funnelshift_r(m, m_hi, 1);
+            const uint32_t b = a & __funnelshift_r(a, a_hi, 2);
+            const uint32_t c = b & __funnelshift_r(b, b_hi, 4);          // eight in a row from this row on
+            m_hi = m; a_hi = a; b_hi = b;
+            const int x0 = lo - 32 * k, x1 = hi - 32 * k;
+            const uint32_t rows = (x1 < 0 || x0 > 31) ? 0u : ((~0u << (x0 > 0 ? x0 : 0)) & (~0u >> (31 - (x1 < 31 ? x1 : 31))));
+            const uint32_t e = c & qv[k] & rows;
+            if (store) ew[k] = e;
+            uint32_t t = 0;
+            if (e | e_hi) {
+                t = e & __funnelshift_r(e, e_hi, 1) & __funnelshift_r(e, e_hi, 2); // a triple starts here
+                total += __popc(t) + 9 * __popc(t & ~__funnelshift_r(t, t_hi, 1));   // + 9 per run (counted where its last triple starts)
+            }
+            t_hi = t; e_hi = e;
+        }
+        return total;
+    }
+    // the same evaluation on 8-mer ids, for a read with N: CreateKmerVecFromReadSeq's rolling id falls out of step with the
+    // positions after an N (KmerAnalysis.cpp:81-95 skips a character when it resumes), so its ids are not the read's plain
+    // 8-mers there and the planes cannot stand in for them.  kq / kg: the workgroup's scratch in HBM (such reads are rare).
+    __device__ RescueOut window_ids(const IndexView &ix, int64_t left, int slen, int qlen, Hit *hits, int n_hits, int cap, bool &overflow) const
     {
         const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, n_waves = nt >> 6;
         __syncthreads();
@@ -444,6 +519,108 @@ struct RescueWave { // one workgroup (any number of wavefronts) evaluates one pa
             int n_seeds = 0;
             bool o2 = false;
             if (best_total > 0) diag_scan(kq, qlen, kg, slen, best_d, left, hits, n_hits, cap, n_seeds, o2);
+            out[0] = best_total; out[1] = best_total > 0 ? best_d : 0; out[2] = n_seeds; out[3] = o2 ? 1 : 0;
+        }
+        __syncthreads();
+        RescueOut best; best.score = out[0]; best.d = out[1]; best.n_seeds = out[2];
+        if (out[3]) overflow = true;
+        return best;
+    }
+
+    __device__ RescueOut window(const IndexView &ix, int64_t left, int slen, int qlen, Hit *hits, int n_hits, int cap, bool &overflow) const
+    {
+        const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, n_waves = nt >> 6;
+        if (red[2 * n_waves + 4]) return window_ids(ix, left, slen, qlen, hits, n_hits, cap, overflow);
+        uint32_t *wl = w, *wh = w + wstride;
+        const int pad = ((qlen + 31) & ~31) + 32;                 // diagonals reach qlen - 1 positions before the window
+        const int n_words = (pad + slen + qlen) / 32 + 3;
+        __syncthreads();
+        for (int i = tid; i < n_words; i += nt) { wl[i] = 0u; wh[i] = 0u; }
+        __syncthreads();
+        // The window's bases come from the 2-bit genome, sixteen at a time: four bytes, their low and high bits pulled apart,
+        // OR-ed into the planes where the window has them.  A window on the reverse strand is the mirrored forward
+        // stretch, complemented.
+        if (left < ix.G && left + slen > ix.G) { // the window runs from the end of the forward strand into the reverse strand
+            for (int p = tid; p < slen; p += nt) { // (same chromosome on both sides of G: AlignmentRescue lets it pass): base by base
+                const uint32_t c = (uint32_t)ref_code(ix, left + p), bit = 1u << ((p + pad) & 31);
+                if (c & 1) atomicOr(&wl[(p + pad) >> 5], bit);
+                if (c & 2) atomicOr(&wh[(p + pad) >> 5], bit);
+            }
+        } else {
+            const bool rev = left >= ix.G;
+            const int64_t f0 = rev ? ix.G2 - (left + slen) : left;
+            const int64_t F0 = f0 & ~(int64_t)15;
+            const int n_chunks = (int)((f0 + slen - F0 + 15) >> 4);
+            const int64_t n_bytes = (ix.G + 3) >> 2;
+            for (int t = tid; t < n_chunks; t += nt) {
+                const int64_t F = F0 + 16 * (int64_t)t, b0 = F >> 2;
+                uint32_t x = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) x = (x << 8) | (b0 + j < n_bytes ? (uint32_t)ix.pac[b0 + j - ix.pac_base] : 0u);
+                // base i of the chunk (forward coordinate F + i) sits at bits 31-2i (high) and 30-2i (low): packed, bit 15 - i
+                uint32_t lo16 = even_bits16(x), hi16 = even_bits16(x >> 1);
+                const int i_lo = f0 > F ? (int)(f0 - F) : 0, i_hi = f0 + slen - 1 - F < 15 ? (int)(f0 + slen - 1 - F) : 15; // bases inside the window
+                int bit0;
+                uint32_t keep;
+                if (!rev) { // window position p = F + i - f0: bit i of the reversed halves
+                    lo16 = __brev(lo16) >> 16; hi16 = __brev(hi16) >> 16;
+                    keep = ((2u << i_hi) - 1u) & ~((1u << i_lo) - 1u);
+                    bit0 = pad + (int)(F - f0);
+                } else {    // p = f0 + slen - 1 - (F + i): bit 15 - i as packed, complemented
+                    lo16 = ~lo16; hi16 = ~hi16;
+                    keep = ((2u << (15 - i_lo)) - 1u) & ~((1u << (15 - i_hi)) - 1u);
+                    bit0 = pad + (int)(f0 + slen - 16 - F);
+                }
+                lo16 &= keep; hi16 &= keep;
+                const int wd = bit0 >> 5, s = bit0 & 31;
+                if (lo16) { atomicOr(&wl[wd], lo16 << s); if (s > 16) atomicOr(&wl[wd + 1], lo16 >> (32 - s)); }
+                if (hi16) { atomicOr(&wh[wd], hi16 << s); if (s > 16) atomicOr(&wh[wd + 1], hi16 >> (32 - s)); }
+            }
+        }
+        __syncthreads();
+        // a diagonal needs three 8-mers in a row on both sides to score at all: d in [-(qlen - 10), slen - 10]
+        int best_total = 0, best_d = 0x7fffffff;
+        const int d_lo = -(qlen - kKmerSize - 2), n_diag = slen - kKmerSize - 2 - d_lo + 1;
+        for (int g = tid; g < n_diag; g += nt) {
+            const int d = d_lo + g;
+            const int total = diagonal(d, qlen, slen, pad, false);
+            if (total > best_total) { best_total = total; best_d = d; } // (ascending: the first of equal totals stays)
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const int ot = __shfl_xor(best_total, o, 64), od = __shfl_xor(best_d, o, 64);
+            if (ot > best_total || (ot == best_total && od < best_d)) { best_total = ot; best_d = od; }
+        }
+        if (lane == 0) { red[2 * wave] = best_total; red[2 * wave + 1] = best_d; }
+        __syncthreads();
+        int *out = red + 2 * n_waves; // {score, d, n_seeds, overflow}
+        if (tid == 0) {
+            for (int wv = 1; wv < n_waves; wv++) {
+                const int ot = red[2 * wv], od = red[2 * wv + 1];
+                if (ot > best_total || (ot == best_total && od < best_d)) { best_total = ot; best_d = od; }
+            }
+            int n_seeds = 0;
+            bool o2 = false;
+            if (best_total > 0) {
+                // the seeds of the best diagonal, in read order (diag_scan on the match bits)
+                for (int k = 0; k < kRescueQWords; k++) ew[k] = 0u;
+                diagonal(best_d, qlen, slen, pad, true);
+                int run = 0, run_start = 0;
+                for (int r = 0; r <= qlen; r++) {
+                    const bool m = r < qlen && ((ew[r >> 5] >> (r & 31)) & 1u);
+                    if (m) { if (run == 0) run_start = r; run++; }
+                    else if (run > 0) {
+                        const int l = kKmerSize + run - 1;
+                        if (l >= 10) {
+                            if (n_hits + n_seeds < cap) {
+                                Hit h; h.rPos = run_start; h.gPos = (int64_t)(run_start + best_d) + left; h.len = l;
+                                hits[n_hits + n_seeds] = h;
+                            } else o2 = true;
+                            n_seeds++;
+                        }
+                        run = 0;
+                    }
+                }
+            }
             out[0] = best_total; out[1] = best_total > 0 ? best_d : 0; out[2] = n_seeds; out[3] = o2 ? 1 : 0;
         }
         __syncthreads();

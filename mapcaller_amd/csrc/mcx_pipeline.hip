@@ -587,18 +587,23 @@ __global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel s
 }
 
 constexpr int kRescueThreads = 256;
+constexpr unsigned kRescueBlocks = 4096;
+// HBM scratch per workgroup for reads with N (RescueWave::window_ids): the read's ids, the longest window's ids and bytes
+constexpr size_t kRescueScratchWords = 1024 + (4096 + 64 + 8) + (4096 + 64) / 16 + 8;
 
 // KG: the longest window the tier evaluates (caps.kmer_cap)
 template <int KG>
-__global__ void __launch_bounds__(kRescueThreads) k_rescue(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl)
+__global__ void __launch_bounds__(kRescueThreads) k_rescue(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl, uint32_t *kscratch)
 {
     // one workgroup per unpaired pair (they are few, and one pair's windows are a long serial chain
-    // for a single wavefront); 8-mer ids of the read and of the window live in LDS
-    __shared__ uint32_t kq[1024];
-    __shared__ uint32_t kg[KG + 64 + 8 + (KG + 64) / 16 + 8]; // the window's 8-mer ids, then its 2-bit bytes (RescueWave::window)
-    __shared__ int red[2 * (kRescueThreads / 64) + 4];
+    // for a single wavefront); read and window live in LDS as bit planes (RescueWave)
+    __shared__ uint32_t q[3 * kRescueQWords];
+    __shared__ uint32_t w[2 * rescue_wwords(KG)];
+    __shared__ uint32_t ew[kRescueQWords];
+    __shared__ int red[2 * (kRescueThreads / 64) + 5];
     const uint32_t n = min(*rl.n, rl.cap);
-    RescueWave ev; ev.kq = kq; ev.kg = kg; ev.red = red;
+    RescueWave ev; ev.q = q; ev.w = w; ev.ew = ew; ev.wstride = rescue_wwords(KG); ev.red = red;
+    ev.kq = kscratch + (size_t)blockIdx.x * kRescueScratchWords; ev.kg = ev.kq + 1024;
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
         const uint32_t local = rl.ids[i];
         ReadRef rd[2];
@@ -830,6 +835,7 @@ struct PassRes {
     uint2 *d_tasks = nullptr; uint32_t task_cap = 0;
     DpJob *d_jobs[kDpClasses] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; uint32_t job_cap[kDpClasses] = {0, 0, 0, 0, 0, 0};
     uint32_t *d_rescue = nullptr; uint32_t rescue_cap = 0;
+    uint32_t *d_kscratch = nullptr; // k_rescue's scratch (not owned: a third of the context's)
     uint8_t *d_dp_scratch[3] = {nullptr, nullptr, nullptr}; uint64_t dp_stride[3] = {0, 0, 0}; uint32_t dp_blocks[3] = {0, 0, 0};
     hipStream_t dp_stream[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t dp_fork = nullptr, dp_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t *d_ov = nullptr; uint32_t ov_cap = 0;
@@ -864,7 +870,7 @@ struct mcx_ctx {
     uint32_t *d_cnt = nullptr;   // CNT_N counters
     uint32_t *h_cnt = nullptr;   // pinned mirror
     uint32_t *d_rescue = nullptr; uint32_t rescue_cap = 0;
-    uint32_t *d_kscratch = nullptr; uint32_t k_threads = 0, k_per_thread = 0;
+    uint32_t *d_kscratch = nullptr; // k_rescue's scratch for reads with N
     hipEvent_t ev_pack[2] = {nullptr, nullptr};
     hipStream_t dp_stream[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t dp_fork = nullptr, dp_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     uint8_t *d_dp_scratch[3] = {nullptr, nullptr, nullptr}; uint64_t dp_stride[3] = {0, 0, 0}; uint32_t dp_blocks[3] = {0, 0, 0};
@@ -1032,8 +1038,7 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     HIP_TRY(hipHostMalloc((void **)&c->h_cnt, CNT_N * sizeof(uint32_t)));
     c->rescue_cap = (uint32_t)c->max_reads;
     if ((rc = dmalloc(&c->d_rescue, c->rescue_cap))) return rc;
-    c->k_threads = 16384; c->k_per_thread = (uint32_t)c->rlen_max + (uint32_t)c->tier[1].caps.kmer_cap;
-    if ((rc = dmalloc(&c->d_kscratch, (size_t)c->k_threads * c->k_per_thread))) return rc;
+    if ((rc = dmalloc(&c->d_kscratch, 3 * (size_t)kRescueBlocks * kRescueScratchWords))) return rc; // (one part per set of pass resources)
     // DP traceback spill per block: 4 KB of sequences + (qlen + tlen - 1) * tlen direction bytes
     const uint64_t spill[3] = {kDpSpillSeq + (uint64_t)(2048 + 64) * 64, kDpSpillSeq + (uint64_t)(2048 + 256) * 256, kDpSpillSeq + (uint64_t)(2048 + 1024) * 1024};
     const uint32_t blocks[3] = {8192, 2048, 512};
@@ -1074,12 +1079,14 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
         HIP_TRY(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
         if (getenv("MCX_TIER1_NO_PRIORITY")) pr_hi = pr_lo > 0 ? 0 : pr_lo; // (experiments)
         if ((rc = passres_alloc(c, c->t1, c->tier[1].max_pairs, c->max_reads, pr_hi))) return rc;
+        c->t1.d_kscratch = c->d_kscratch + (size_t)kRescueBlocks * kRescueScratchWords;
         HIP_TRY(hipEventCreate(&c->ev_clustered));
         c->overlap_tiers = true;
         // and a small third set for the pairs that run over after clustering: they go through the large tier while the pass's
         // DP and finish stages run, in the last kLateRoom records of the tier, instead of in a pass of their own after it
         if (c->tier[1].max_pairs >= 4 * kLateRoom && !getenv("MCX_NO_LATE_OVERLAP")) {
             if ((rc = passres_alloc(c, c->t2, kLateRoom, kLateRoom, pr_hi))) return rc;
+            c->t2.d_kscratch = c->d_kscratch + 2 * (size_t)kRescueBlocks * kRescueScratchWords;
             HIP_TRY(hipEventCreateWithFlags(&c->ev_built, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&c->ev_late_done, hipEventDisableTiming));
             c->overlap_late = true;
@@ -1170,7 +1177,7 @@ static PassRes res_tier0(mcx_ctx *c)
     PassRes r;
     r.stream = c->stream; r.d_cnt = c->d_cnt; r.h_cnt = c->h_cnt; r.d_tasks = c->d_tasks; r.task_cap = c->task_cap;
     for (int k = 0; k < kDpClasses; k++) { r.d_jobs[k] = c->d_jobs[k]; r.job_cap[k] = c->job_cap[k]; }
-    r.d_rescue = c->d_rescue; r.rescue_cap = c->rescue_cap;
+    r.d_rescue = c->d_rescue; r.rescue_cap = c->rescue_cap; r.d_kscratch = c->d_kscratch;
     for (int k = 0; k < 3; k++) { r.d_dp_scratch[k] = c->d_dp_scratch[k]; r.dp_stride[k] = c->dp_stride[k]; r.dp_blocks[k] = c->dp_blocks[k]; }
     for (int k = 0; k < 5; k++) { r.dp_stream[k] = c->dp_stream[k]; r.dp_join[k] = c->dp_join[k]; }
     r.dp_fork = c->dp_fork; r.d_ov = c->d_ov; r.ov_cap = c->ov_cap; r.d_sel_ids = c->d_sel_ids; r.d_est = c->d_est;
@@ -1244,8 +1251,8 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     if (early) HIP_TRY(hipEventRecord(c->ev_clustered, s));
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     if (paired) {
-        if (tier == 0) k_rescue<2048><<<4096, kRescueThreads, 0, s>>>(cx, rb, sel, rl);
-        else k_rescue<4096><<<4096, kRescueThreads, 0, s>>>(cx, rb, sel, rl);
+        if (tier == 0) k_rescue<2048><<<kRescueBlocks, kRescueThreads, 0, s>>>(cx, rb, sel, rl, R.d_kscratch);
+        else k_rescue<4096><<<kRescueBlocks, kRescueThreads, 0, s>>>(cx, rb, sel, rl, R.d_kscratch);
     }
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP, ll);
