@@ -52,6 +52,41 @@ static __device__ __forceinline__ void dp_sync()
 
 struct DpBuf { uint8_t *q, *t, *dir; };
 
+// The traceback lane fills the problem's DpSummary on its way from the last column to the first (out null: no summary).
+struct DpSumAcc {
+    DpSummary *out;
+    int n, mis, switches, cur, run, n_rle, pd, pi, pr, td, ti, tr;
+    bool seen_m;
+    __device__ void begin(DpSummary *o) { out = o; n = mis = switches = run = n_rle = pd = pi = pr = td = ti = tr = 0; cur = -1; seen_m = false; }
+    __device__ void flush()
+    {
+        if (run > 0) { if (n_rle < kDpRle) out->rle[kDpRle - 1 - n_rle] = ((uint32_t)run << 4) | (uint32_t)cur; n_rle++; }
+    }
+    // k: 0 'M', 1 'I', 2 'D' (the CIGAR codes); differ: an 'M' column over two different bases
+    __device__ void put(int k, int differ)
+    {
+        if (!out) return;
+        if (k != cur) { flush(); cur = k; run = 0; switches++; if (k) pr++; }
+        run++;
+        if (k == 0) {
+            n++; mis += differ;
+            if (!seen_m) { td = pd; ti = pi; tr = pr; seen_m = true; } // what came before the walk's first 'M' is the string's tail
+            pd = pi = pr = 0;
+        } else if (k == 2) pd++; else pi++;
+    }
+    __device__ void end(uint32_t cols_off, int cols_len)
+    {
+        if (!out) return;
+        flush();
+        if (!seen_m) { td = pd; ti = pi; tr = pr; }
+        out->cols_off = cols_off; out->cols_len = (uint16_t)cols_len;
+        out->n = (uint16_t)n; out->mis = (uint16_t)mis; out->switches = (uint16_t)switches;
+        out->lead_d = (uint16_t)pd; out->lead_i = (uint16_t)pi; out->lead_runs = (uint16_t)pr; // what is pending at the string's start is its head
+        out->tail_d = (uint16_t)td; out->tail_i = (uint16_t)ti; out->tail_runs = (uint16_t)tr;
+        out->n_rle = n_rle <= kDpRle ? (uint16_t)n_rle : (uint16_t)0xFFFF;
+    }
+};
+
 // where a (qlen x tlen) problem keeps its sequences and traceback: LDS when it fits
 // (lds holds lds_seq bytes for the two sequences followed by lds_dir bytes of traceback)
 static __device__ __forceinline__ DpBuf dp_buffers(int qlen, int tlen, uint8_t *lds, uint8_t *spill, int lds_seq = kDpLdsSeq, int lds_dir = kDpLdsDir)
@@ -71,7 +106,7 @@ static __device__ __forceinline__ DpBuf dp_buffers(int qlen, int tlen, uint8_t *
 // ---------------------------------------------------------------------------------------------
 template <int K, int W>
 static __device__ int dp_ksw2_core(int qlen, int tlen, const uint8_t *q, const uint8_t *t, uint8_t *dir, uint8_t *ops,
-                                   int *score)
+                                   int *score, DpSummary *sum, uint32_t ops_base)
 {
     const int lane = threadIdx.x & (W - 1);
     const int Q = 2, QE = 3, QE2 = 6, MAX_SC = 7; // q, q+e, 2(q+e), mat[0] + 2(q+e)
@@ -136,17 +171,19 @@ static __device__ int dp_ksw2_core(int qlen, int tlen, const uint8_t *q, const u
     if (lane == 0) {
         // ksw_backtrack (:25-68); full band: force_state never fires
         int i = tlen - 1, j = qlen - 1, state = 0;
+        DpSumAcc acc; acc.begin(sum);
         while (i >= 0 && j >= 0) {
             const unsigned d = dir[(i + j) * tlen + i];
             if (state == 0) state = d & 7;
             else if (!((d >> (state + 2)) & 1)) state = 0;
             if (state == 0) state = d & 7;
-            if (state == 0) { ops[--w] = 'M'; --i; --j; }
-            else if (state == 1 || state == 3) { ops[--w] = 'D'; --i; }
-            else { ops[--w] = 'I'; --j; }
+            if (state == 0) { ops[--w] = 'M'; acc.put(0, q[j] != t[i]); --i; --j; }
+            else if (state == 1 || state == 3) { ops[--w] = 'D'; acc.put(2, 0); --i; }
+            else { ops[--w] = 'I'; acc.put(1, 0); --j; }
         }
-        for (; i >= 0; --i) ops[--w] = 'D';
-        for (; j >= 0; --j) ops[--w] = 'I';
+        for (; i >= 0; --i) { ops[--w] = 'D'; acc.put(2, 0); }
+        for (; j >= 0; --j) { ops[--w] = 'I'; acc.put(1, 0); }
+        acc.end(ops_base + (uint32_t)w, qlen + tlen - w);
     }
     w = group_pick<W>(w, 0);
     dp_sync<W>();
@@ -158,7 +195,8 @@ static __device__ int dp_ksw2_core(int qlen, int tlen, const uint8_t *q, const u
 // of 0.5 and exact in float), equality-based traceback.  Rows i = read (q), columns j = genome.
 // ---------------------------------------------------------------------------------------------
 template <int K, int W>
-static __device__ int dp_nw_core(int m, int n, const uint8_t *q, const uint8_t *t, uint8_t *dir, uint8_t *ops, int *score)
+static __device__ int dp_nw_core(int m, int n, const uint8_t *q, const uint8_t *t, uint8_t *dir, uint8_t *ops, int *score, DpSummary *sum,
+                                 uint32_t ops_base)
 {
     const int lane = threadIdx.x & (W - 1);
     const int NEG = -131072, EXT = -1, NEW = -3;
@@ -213,15 +251,17 @@ static __device__ int dp_nw_core(int m, int n, const uint8_t *q, const uint8_t *
     int w = m + n;
     if (lane == 0) {
         int i = m, j = n; // 1-based matrix indices (nw_alignment.cpp:59-74)
+        DpSumAcc acc; acc.begin(sum);
         while (i > 0 || j > 0) {
             unsigned d;
             if (i == 0) d = 1;       // s[0][j] == r[0][j]
             else if (j == 0) d = 2;  // s[i][0] == t[i][0]
             else d = dir[(i + j - 2) * n + (j - 1)];
-            if (d & 1) { ops[--w] = 'D'; j--; }       // '-' inserted into s1 (read string)
-            else if (d & 2) { ops[--w] = 'I'; i--; }  // '-' inserted into s2 (genome string)
-            else { ops[--w] = 'M'; i--; j--; }
+            if (d & 1) { ops[--w] = 'D'; acc.put(2, 0); j--; }       // '-' inserted into s1 (read string)
+            else if (d & 2) { ops[--w] = 'I'; acc.put(1, 0); i--; }  // '-' inserted into s2 (genome string)
+            else { ops[--w] = 'M'; acc.put(0, q[i - 1] != t[j - 1]); i--; j--; }
         }
+        acc.end(ops_base + (uint32_t)w, m + n - w);
     }
     w = group_pick<W>(w, 0);
     dp_sync<W>();
@@ -229,9 +269,9 @@ static __device__ int dp_nw_core(int m, int n, const uint8_t *q, const uint8_t *
 }
 
 template <int K, int W>
-static __device__ __forceinline__ int dp_core(bool nw, int qlen, int tlen, const DpBuf &b, uint8_t *ops, int *score)
+static __device__ __forceinline__ int dp_core(bool nw, int qlen, int tlen, const DpBuf &b, uint8_t *ops, int *score, DpSummary *sum, uint32_t ops_base)
 {
-    return nw ? dp_nw_core<K, W>(qlen, tlen, b.q, b.t, b.dir, ops, score) : dp_ksw2_core<K, W>(qlen, tlen, b.q, b.t, b.dir, ops, score);
+    return nw ? dp_nw_core<K, W>(qlen, tlen, b.q, b.t, b.dir, ops, score, sum, ops_base) : dp_ksw2_core<K, W>(qlen, tlen, b.q, b.t, b.dir, ops, score, sum, ops_base);
 }
 
 // tiny problems (up to 8 x 8, most of the bulk: median 3 x 3): one lane each — the same recurrences with

@@ -35,6 +35,7 @@ struct Ctx {
     const uint32_t *packed;
     int32_t wpad;
     const uint32_t *read_ext;
+    int32_t dp_summary;       // the DP kernels leave a DpSummary in front of every problem's columns (stage_build reserves the room)
 };
 
 constexpr int kCigStage = 4; // CIGAR operations per read that the finish stage keeps at hand between counting and writing them
@@ -775,7 +776,7 @@ static inline MCX_HD int build_frags(const IndexView &ix, int rlen, const Hit *s
         bool plain = true;
         int w = 0, prev_r0 = 0, pr = 0;
         int64_t prev_g0 = 0, pg = 0;
-        Frag g; g.ops_off = 0; g.ops_len = 0; g.kind = kPlain;
+        Frag g; g.ops_off = 0; g.ops_len = 0; g.kind = kPlain; g.meta = 0;
         for (int i = 0; i < n; i++) {
             const Hit sd = seeds[i];
             const int r0 = sd.rPos;
@@ -788,7 +789,7 @@ static inline MCX_HD int build_frags(const IndexView &ix, int rlen, const Hit *s
                 if (rg > 0 || gg > 0) { g.rPos = pr; g.gPos = pg; g.rLen = rg; g.gLen = (int)gg; f[w++] = g; }
             }
             Frag x; x.gPos = sd.gPos; x.rPos = r0; x.rLen = x.gLen = sd.len;
-            x.ops_off = 0; x.ops_len = 0; x.kind = kSimple;
+            x.ops_off = 0; x.ops_len = 0; x.kind = kSimple; x.meta = 0;
             f[w++] = x;
             prev_r0 = r0; prev_g0 = sd.gPos; pr = r0 + sd.len; pg = sd.gPos + sd.len;
         }
@@ -800,7 +801,7 @@ static inline MCX_HD int build_frags(const IndexView &ix, int rlen, const Hit *s
     if (total == 0) {
     for (int i = 0; i < n; i++) {
         Frag x; x.gPos = seeds[i].gPos; x.rPos = seeds[i].rPos; x.rLen = x.gLen = seeds[i].len;
-        x.ops_off = 0; x.ops_len = 0; x.kind = kSimple;
+        x.ops_off = 0; x.ops_len = 0; x.kind = kSimple; x.meta = 0;
         int j = i - 1;
         while (j >= 0 && frag_before(x, f[j])) { f[j + 1] = f[j]; j--; } // sort by (rPos, gPos), :317
         f[j + 1] = x;
@@ -831,7 +832,7 @@ static inline MCX_HD int build_frags(const IndexView &ix, int rlen, const Hit *s
     bool tail = f[n - 1].rPos + f[n - 1].rLen < rlen;
     total = n + gaps + (head ? 1 : 0) + (tail ? 1 : 0);
     int w = total - 1;
-    Frag g; g.ops_off = 0; g.ops_len = 0; g.kind = kPlain;
+    Frag g; g.ops_off = 0; g.ops_len = 0; g.kind = kPlain; g.meta = 0;
     if (tail) {
         g.rPos = f[n - 1].rPos + f[n - 1].rLen; g.gPos = f[n - 1].gPos + f[n - 1].gLen;
         g.rLen = g.gLen = rlen - g.rPos;
@@ -969,10 +970,11 @@ static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef 
                         dp = mm > 1 && mm >= (int)(x.rLen * 0.2);
                     }
                     if (dp) {
-                        if (h.n_ops + x.rLen + x.gLen > cx.caps.ops_cap) { h.flags |= kOvOps; *g_hdr = h; if (flags_out) *flags_out = h.flags; return 0; }
+                        const int at = ((h.n_ops + 7) & ~7) + kDpSum; // the columns' area, behind the room for their DpSummary
+                        if (at + x.rLen + x.gLen > cx.caps.ops_cap) { h.flags |= kOvOps; *g_hdr = h; if (flags_out) *flags_out = h.flags; return 0; }
                         if (nj >= cx.caps.job_cap) { h.flags |= kOvJobs; *g_hdr = h; if (flags_out) *flags_out = h.flags; return 0; }
-                        x.kind = kDp; x.ops_off = h.n_ops; x.ops_len = 0;
-                        h.n_ops += x.rLen + x.gLen;
+                        x.kind = kDp; x.ops_off = at; x.ops_len = 0; x.meta = 0;
+                        h.n_ops = at + x.rLen + x.gLen;
                         jl[2 * nj] = h.n_frags + i; jl[2 * nj + 1] = s;
                         nj++;
                     } else { x.kind = kPlain; x.ops_len = x.rLen; }
@@ -1008,7 +1010,11 @@ static inline MCX_HD bool strip_end_gaps(Frag &f, const uint8_t *ops, bool leadi
 {
     if (f.kind != kDp) return false; // only DP results can start or end with a gap column
     int rs = 0, gs = 0, j = 0;
-    if (leading) {
+    if (f.meta) { // counted by the DP kernel
+        const DpSummary &sm = *(const DpSummary *)(ops + ((int)f.meta - 1) * 8);
+        rs = leading ? sm.lead_i : sm.tail_i; gs = leading ? sm.lead_d : sm.tail_d; j = rs + gs;
+        if (j > 0) { if (leading) f.ops_off += j; f.ops_len -= j; }
+    } else if (leading) {
         for (; j < f.ops_len; j++) { uint8_t o = ops[f.ops_off + j]; if (o == 'D') gs++; else if (o == 'I') rs++; else break; }
         if (j > 0) { f.ops_off += j; f.ops_len -= j; }
     } else {
@@ -1032,6 +1038,13 @@ static inline MCX_HD ColStats frag_columns(const IndexView &ix, const Frag &f, c
     if (f.kind != kDp) { // one kind of column throughout: no walk
         if (f.ops_len > 0) cs.switches = 1;
         if (f.kind == kPlain) { cs.n = f.ops_len; cs.mis = frag_mismatches(ix, f, rd); cs.match = cs.n - cs.mis; }
+        return cs;
+    }
+    if (f.meta) { // counted by the DP kernel; an end the gates trimmed takes its runs of gap columns with it
+        const DpSummary &sm = *(const DpSummary *)(ops + ((int)f.meta - 1) * 8);
+        cs.n = sm.n; cs.mis = sm.mis; cs.match = cs.n - cs.mis;
+        cs.switches = sm.switches - ((uint32_t)f.ops_off != sm.cols_off ? sm.lead_runs : 0)
+                                  - ((uint32_t)(f.ops_off + f.ops_len) != sm.cols_off + sm.cols_len ? sm.tail_runs : 0);
         return cs;
     }
     bool rev = f.gPos >= ix.G;
@@ -1187,6 +1200,12 @@ static inline MCX_HD int cigar_of(int rlen, const Cand &c, const Frag *frags, co
         else if (f.kind == kEmpty) continue;
         else if (f.ops_len > 0) {
             if (f.kind != kDp) { flush_to(f.kind == kDel ? 2 : (f.kind == kIns ? 1 : 0)); run += f.ops_len; } // one kind of column throughout
+            else if (f.meta && ((const DpSummary *)(ops + ((int)f.meta - 1) * 8))->n_rle != 0xFFFF) { // the runs the DP kernel left, less the trimmed ends
+                const DpSummary &sm = *(const DpSummary *)(ops + ((int)f.meta - 1) * 8);
+                const int k0 = kDpRle - sm.n_rle + ((uint32_t)f.ops_off != sm.cols_off ? sm.lead_runs : 0);
+                const int k1 = kDpRle - ((uint32_t)(f.ops_off + f.ops_len) != sm.cols_off + sm.cols_len ? sm.tail_runs : 0);
+                for (int k = k0; k < k1; k++) { const uint32_t e = sm.rle[k]; flush_to((int)(e & 15u)); run += (int)(e >> 4); }
+            }
             else for (int x = 0; x < f.ops_len; x++) {
                 const uint8_t o = ops[f.ops_off + x];
                 flush_to(o == 'D' ? 2 : (o == 'I' ? 1 : 0));
@@ -1353,7 +1372,7 @@ static inline MCX_HD void write_detail(const Ctx &cx, PairState &st, int s, uint
             const Frag &a = st.frags[frag_index(c, 0)], &b = st.frags[frag_index(c, c.n_frags - 1)];
             const int64_t g0 = c.fwd ? a.gPos : cx.ix.G2 - (a.gPos + a.gLen);
             const int64_t g1 = c.fwd ? b.gPos + b.gLen : cx.ix.G2 - b.gPos;
-            Frag r; r.gPos = g0; r.rPos = 0; r.rLen = (int32_t)(g1 - g0); r.gLen = 0; r.ops_off = 0; r.ops_len = 0; r.kind = kSimple;
+            Frag r; r.gPos = g0; r.rPos = 0; r.rLen = (int32_t)(g1 - g0); r.gLen = 0; r.ops_off = 0; r.ops_len = 0; r.kind = kSimple; r.meta = 0;
             df[n++] = r;
         }
         d.n_frags = n;

@@ -681,11 +681,13 @@ static __device__ __forceinline__ void dp_run_job(const Ctx &cx, const JobSink &
     dp_sync<W>();
     PairState st = pair_state(cx.state, cx.lay, cx.caps, job.pair);
     int score = 0;
-    const int w = dp_core<K, W>(cx.pm.use_nw != 0, job.rLen, job.gLen, b, st.ops + job.ops_off, &score);
+    DpSummary *sum = cx.dp_summary ? (DpSummary *)(st.ops + job.ops_off - kDpSum) : nullptr; // (stage_build left room for it)
+    const int w = dp_core<K, W>(cx.pm.use_nw != 0, job.rLen, job.gLen, b, st.ops + job.ops_off, &score, sum, (uint32_t)job.ops_off);
     if (lane == 0) {
         Frag f = st.frags[job.frag]; // one fetch, one store (the fields share two words)
         f.ops_off = job.ops_off + w;
         f.ops_len = job.rLen + job.gLen - w;
+        f.meta = sum ? (uint32_t)((job.ops_off - kDpSum) >> 3) + 1u : 0u;
         st.frags[job.frag] = f;
         sink.jobs[jb].score = score;
     }
@@ -750,11 +752,13 @@ __global__ void __launch_bounds__(256) k_dp_small(Ctx cx, JobSink sink, ReadBatc
         dp_sync<16>();
         PairState st = pair_state(cx.state, cx.lay, cx.caps, job.pair);
         int score = 0;
-        const int w = dp_core<1, 16>(cx.pm.use_nw != 0, job.rLen, job.gLen, b, st.ops + job.ops_off, &score);
+        DpSummary *sum = cx.dp_summary ? (DpSummary *)(st.ops + job.ops_off - kDpSum) : nullptr;
+        const int w = dp_core<1, 16>(cx.pm.use_nw != 0, job.rLen, job.gLen, b, st.ops + job.ops_off, &score, sum, (uint32_t)job.ops_off);
         if (lane == 0) {
             Frag f = st.frags[job.frag]; // one fetch, one store (the fields share two words)
             f.ops_off = job.ops_off + w;
             f.ops_len = job.rLen + job.gLen - w;
+            f.meta = sum ? (uint32_t)((job.ops_off - kDpSum) >> 3) + 1u : 0u;
             st.frags[job.frag] = f;
             sink.jobs[jb].score = score;
         }
@@ -1157,7 +1161,7 @@ static Ctx make_ctx(const mcx_ctx *c, int tier, int paired)
     Ctx cx;
     cx.ix = c->idx->view; cx.pm = c->pm; cx.pm.paired = paired;
     cx.caps = c->tier[tier].caps; cx.lay = c->tier[tier].lay; cx.state = c->tier[tier].state;
-    cx.mapq_tab = c->d_mapq; cx.mapq_rows = c->mapq_rows;
+    cx.mapq_tab = c->d_mapq; cx.mapq_rows = c->mapq_rows; cx.dp_summary = 1;
     cx.detail = c->prof_planes ? c->d_detail : nullptr; cx.dlay = c->dlay;
     cx.cig_pool = c->run.cig; cx.cig_pool_n = c->d_batch_flags; cx.cig_pool_cap = c->run.cig_cap;
     cx.packed = c->d_packed; cx.wpad = c->wpad; cx.read_ext = c->d_read_ext;
@@ -1496,7 +1500,7 @@ static int run_fast(mcx_ctx *c, const ReadBatch &rb, int paired, int32_t est, ui
     HIP_TRY(hipEventRecord(c->ev_fast[2], s));
     {
         Ctx cs = cx; // the parked slices as pair records: fragments at offset 0, column strings behind them
-        cs.state = c->d_saved; cs.lay = save_layout(c->fcaps);
+        cs.state = c->d_saved; cs.lay = save_layout(c->fcaps); cs.dp_summary = 0; // (the fused kernel's record keeps no room for summaries)
         cs.caps.hit_cap = c->fcaps.hit_cap; cs.caps.cand_cap = c->fcaps.cand_cap; cs.caps.frag_cap = c->fcaps.slots;
         PairSel parked; parked.n = n_pairs; parked.ids = c->d_sel_ids; parked.est = nullptr;
         int rc = launch_dp(res_tier0(c), cs, sinks, rb, parked);
@@ -2322,7 +2326,7 @@ __global__ void __launch_bounds__(64) k_extend(ExtArgs a, uint8_t *scratch, uint
         __syncthreads();
         uint8_t *dst = a.ops + a.q_off[jb] + a.t_off[jb];
         int score = 0;
-        const int w = dp_core<K, 64>(a.use_nw != 0, m, n, b, dst, &score);
+        const int w = dp_core<K, 64>(a.use_nw != 0, m, n, b, dst, &score, nullptr, 0u);
         const int L = m + n - w;
         for (int base = 0; base < L; base += 64) { // move the string to the front of its area
             uint8_t v = base + lane < L ? dst[w + base + lane] : 0;

@@ -111,8 +111,26 @@ struct alignas(16) Frag {
     int64_t ops_off : 18;  // kDp: offset into the pair's ops pool (columns, 'M' 'I' 'D')
     int64_t ops_len : 13;  // current number of alignment columns (after end trimming)
     uint64_t kind : 3;
+    uint64_t meta : 14;    // kDp: where the DP kernel left the fragment's DpSummary (ops pool offset / 8 + 1); 0: none, walk the columns
 };
 static_assert(sizeof(Frag) == 16, "Frag is one 16-byte record");
+
+// What the finish stage needs to know about a DP fragment's column string, left in front of the string's area by the lane
+// that traced it back (it has both sequences in LDS and visits every column anyway): the finish stage then neither walks
+// the columns (three dependent fetches per column, in a loop as long as the wave's longest fragment) nor counts CIGAR runs.
+constexpr int kDpRle = 8;    // runs kept; a string with more is walked (n_rle = 0xFFFF)
+constexpr int kDpSum = 64;   // bytes reserved in the ops pool in front of every DP problem's columns
+struct alignas(8) DpSummary {
+    uint32_t cols_off;                    // the untrimmed string: offset in the ops pool
+    uint16_t cols_len;
+    uint16_t n, mis;                      // 'M' columns; those whose bases differ (FindMisMatchNumber / CheckLocalAlignmentQuality)
+    uint16_t switches;                    // runs of one kind of column in the whole string
+    uint16_t lead_d, lead_i, lead_runs;   // gap columns and their runs before the first 'M' (RemoveHeadingGaps)
+    uint16_t tail_d, tail_i, tail_runs;   // ... after the last 'M' (RemoveTailingGaps)
+    uint16_t n_rle;                       // runs in rle[kDpRle - n_rle ..), in column order
+    uint32_t rle[kDpRle];                 // (length << 4) | op, op codes as in BAM: M = 0, I = 1, D = 2
+};
+static_assert(sizeof(DpSummary) <= kDpSum, "the summary fits the room reserved for it");
 
 struct DpJob {        // one ksw2/nw problem
     uint32_t pair;
