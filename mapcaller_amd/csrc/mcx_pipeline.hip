@@ -559,13 +559,92 @@ struct RescueList { uint32_t *ids; uint32_t *n; uint32_t cap; };
 // them on a stream of its own while the rest of the pass is still under way (ids null: no such list)
 struct EarlyList { uint32_t *ids; int32_t *est; uint32_t *n; uint32_t cap; };
 
-__global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl, const uint32_t *read_blocks, EarlyList el)
+// The per-pair kernels give every lane one pair, and a wavefront is as slow as its heaviest lane: next to a pair from a repeat
+// (dozens of hits to sort and cluster, a dozen candidates to build and score) sixty-three ordinary pairs wait.  So the pairs
+// of a pass are dealt to the lanes by weight — total seed hits, known once k_seed is done — heaviest class first: like sits
+// with like, and the long wavefronts start early.  Two small passes (count, place) make the permutation `order`.
+// (counters that many wavefronts add to sit one per 256 bytes: their atomics then run in different L2 channels instead of queueing on one line)
+constexpr int kCntPad = 64;
+constexpr int kWorkClasses = 6;
+static __device__ __forceinline__ int work_class(uint32_t hits) { return hits > 64 ? 0 : hits > 32 ? 1 : hits > 16 ? 2 : hits > 8 ? 3 : hits > 4 ? 4 : 5; }
+
+static __device__ __forceinline__ int pair_work_class(const PairSel &sel, uint32_t local, const uint32_t *read_blocks, int nr)
+{
+    const uint32_t pair = sel_pair(sel, local);
+    return work_class((read_blocks[pair * nr] >> 20) + (nr == 2 ? read_blocks[pair * nr + 1] >> 20 : 0u));
+}
+
+constexpr int kOrderTile = 16; // pairs per thread of the two passes: a block of 256 settles 4096 pairs with one global atomic per class
+
+__global__ void __launch_bounds__(256) k_order_count(PairSel sel, const uint32_t *read_blocks, int nr, uint32_t *counts)
+{
+    __shared__ uint32_t n_cls[kWorkClasses];
+    if (threadIdx.x < kWorkClasses) n_cls[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (256u * kOrderTile);
+    for (int t = 0; t < kOrderTile; t++) {
+        const uint32_t local = base + t * 256u + threadIdx.x;
+        const int cls = local < sel.n ? pair_work_class(sel, local, read_blocks, nr) : -1;
+#pragma unroll
+        for (int k = 0; k < kWorkClasses; k++) {
+            const uint64_t m = __ballot(cls == k);
+            if ((threadIdx.x & 63) == 0 && m) atomicAdd(&n_cls[k], (uint32_t)__popcll(m));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kWorkClasses && n_cls[threadIdx.x]) atomicAdd(counts + threadIdx.x * kCntPad, n_cls[threadIdx.x]);
+}
+
+// counts[k * kCntPad]: pairs of class k; counts[(8 + k) * kCntPad]: how many of them were placed so far
+__global__ void __launch_bounds__(256) k_order_place(PairSel sel, const uint32_t *read_blocks, int nr, uint32_t *counts, uint32_t *order)
+{
+    __shared__ uint32_t n_cls[kWorkClasses], at_cls[kWorkClasses];
+    if (threadIdx.x < kWorkClasses) n_cls[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (256u * kOrderTile);
+    const int lane = threadIdx.x & 63;
+    int cls[kOrderTile];
+#pragma unroll
+    for (int t = 0; t < kOrderTile; t++) {
+        const uint32_t local = base + t * 256u + threadIdx.x;
+        cls[t] = local < sel.n ? pair_work_class(sel, local, read_blocks, nr) : -1;
+#pragma unroll
+        for (int k = 0; k < kWorkClasses; k++) {
+            const uint64_t m = __ballot(cls[t] == k);
+            if (lane == 0 && m) atomicAdd(&n_cls[k], (uint32_t)__popcll(m));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kWorkClasses) { // the block's stretch of every class: where the class begins + what other blocks took before
+        uint32_t first = 0;
+        for (int k = 0; k < (int)threadIdx.x; k++) first += counts[k * kCntPad];
+        const uint32_t mine = n_cls[threadIdx.x];
+        at_cls[threadIdx.x] = first + (mine ? atomicAdd(counts + (8 + threadIdx.x) * kCntPad, mine) : 0u);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < kOrderTile; t++) {
+        const uint32_t local = base + t * 256u + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < kWorkClasses; k++) {
+            const uint64_t m = __ballot(cls[t] == k);
+            uint32_t b = 0;
+            if (lane == 0 && m) b = atomicAdd(&at_cls[k], (uint32_t)__popcll(m));
+            b = __shfl(b, 0, 64);
+            if (cls[t] == k) order[b + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = local;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl, const uint32_t *read_blocks, EarlyList el, const uint32_t *order)
 {
     __shared__ EndsLds ends;
     stage_ends(cx.ix, ends);
-    const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = slot < sel.n;
+    const uint32_t local = in ? (order ? order[slot] : slot) : 0u;
     uint32_t need = 0, over = 0;
-    if (local < sel.n) {
+    if (in) {
         ReadRef rd[2];
         make_reads(cx, rb, sel_pair(sel, local), rd);
         PairState st = pair_state(cx.state, cx.lay, cx.caps, local);
@@ -617,14 +696,17 @@ __global__ void __launch_bounds__(kRescueThreads) k_rescue(Ctx cx, ReadBatch rb,
 // class (mcx_glue.h dp_class) with one atomic per wave and class
 // (late: the pairs that ran over this tier's capacities since clustering — mate rescue's additions, fragment lists, DP
 //  columns, job lists — are listed like the early ones, for a second pass of the large tier beside the rest of this one)
-__global__ void __launch_bounds__(256) k_build(Ctx cx, ReadBatch rb, PairSel sel, JobSinks sinks, uint32_t *cells, uint32_t *unsupported, EarlyList late)
+__global__ void __launch_bounds__(256) k_build(Ctx cx, ReadBatch rb, PairSel sel, JobSinks sinks, uint32_t *cells, uint32_t *unsupported, EarlyList late,
+                                               const uint32_t *order)
 {
     __shared__ EndsLds ends;
     stage_ends(cx.ix, ends);
-    const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = slot < sel.n;
+    const uint32_t local = in ? (order ? order[slot] : slot) : 0u;
     int nj = 0;
     uint32_t fl = 0;
-    if (local < sel.n) {
+    if (in) {
         ReadRef rd[2];
         make_reads(cx, rb, sel_pair(sel, local), rd);
         nj = stage_build(cx, local, rd, &fl);
@@ -770,14 +852,15 @@ __global__ void __launch_bounds__(256) k_dp_small(Ctx cx, JobSink sink, ReadBatc
 #define MCX_FINISH_WAVES 5
 #endif
 __global__ void __launch_bounds__(256, MCX_FINISH_WAVES) k_finish(Ctx cx, ReadBatch rb, PairSel sel, AlnRec *recs, PairOut *pout, uint32_t *ov_ids, uint32_t *n_ov,
-                                                uint32_t ov_cap, uint32_t *pool_over)
+                                                uint32_t ov_cap, uint32_t *pool_over, const uint32_t *order)
 {
     __shared__ EndsLds ends;
     __shared__ uint32_t cig_stage[256 * 2 * kCigStage]; // the first operations of every read, lane-major (8 words per lane: no bank shared within a quarter wave)
     stage_ends(cx.ix, ends);
-    const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t *stage = cig_stage + threadIdx.x * 2 * kCigStage;
-    const bool active = local < sel.n; // (no early exit: the wave reserves its CIGAR words together)
+    const bool active = slot < sel.n; // (no early exit: the wave reserves its CIGAR words together)
+    const uint32_t local = active ? (order ? order[slot] : slot) : 0u;
     const int nr = cx.pm.paired ? 2 : 1;
     uint32_t pair = 0;
     ReadRef rd[2];
@@ -822,8 +905,6 @@ struct Tier {
     uint32_t max_pairs = 0;
 };
 
-// work-list counters, one per 256 bytes: their atomics then run in different L2 channels instead of queueing on one line
-constexpr int kCntPad = 64;
 constexpr uint32_t kPoutSel = 1u << 16; // pair outcomes gathered per copy (run_selection)
 enum { CNT_TASKS = 0, CNT_RESCUE = 1 * kCntPad, CNT_JOB0 = 2 * kCntPad, CNT_JOB1 = 3 * kCntPad, CNT_JOB2 = 4 * kCntPad, CNT_JOB3 = 5 * kCntPad,
        CNT_JOB4 = 6 * kCntPad, CNT_JOB5 = 7 * kCntPad, CNT_OV = 8 * kCntPad, CNT_LF = 9 * kCntPad, CNT_CELLS = 10 * kCntPad, CNT_UNSUP = 11 * kCntPad,
@@ -882,6 +963,7 @@ struct mcx_ctx {
     uint32_t *d_sel_ids = nullptr; int32_t *d_est = nullptr;
     uint32_t *d_read_ext = nullptr, *d_read_blocks = nullptr;
     uint32_t *d_packed = nullptr; int wpad = 0; // 2-bit form of the batch's reads
+    uint32_t *d_order = nullptr, *d_order_cnt = nullptr; // the pairs of a pass by weight (k_order_*)
     PairOut *d_pout = nullptr, *d_pout_sel = nullptr; // per-pair outcome of the finish stage; a gathered selection of it
     uint8_t *d_mapq = nullptr; int mapq_rows = 0;
     // -vcf bookkeeping (mcx_profile.h): caller-owned counter planes, per-read alignment detail
@@ -1062,6 +1144,8 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     if ((rc = dmalloc(&c->d_packed, c->max_reads * (uint64_t)c->wpad))) return rc;
     if ((rc = dmalloc(&c->d_pout, c->max_reads))) return rc;
     if ((rc = dmalloc(&c->d_pout_sel, kPoutSel))) return rc;
+    if ((rc = dmalloc(&c->d_order, c->max_reads))) return rc;
+    if ((rc = dmalloc(&c->d_order_cnt, 16 * kCntPad))) return rc;
     // EvaluateMAPQ (SamReport.cpp:86-101) tabulated on the host so that the double-precision
     // log() is the host libm's, exactly as in the reference
     c->mapq_rows = c->rlen_max + 64;
@@ -1131,7 +1215,7 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3], c->d_jobs[4], c->d_jobs[5],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
                  c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
-                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_pout_sel, c->d_packed, c->d_batch_flags, c->d_fast_hits, c->d_spill, c->d_saved};
+                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_pout_sel, c->d_order, c->d_order_cnt, c->d_packed, c->d_batch_flags, c->d_fast_hits, c->d_spill, c->d_saved};
     for (void *q : p) if (q) (void)hipFree(q);
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
     if (c->h_keys) (void)hipHostFree(c->h_keys);
@@ -1251,7 +1335,16 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     if (R.d_tasks) k_sa<<<4096, 256, 0, s>>>(cx, so, paired, R.d_cnt + CNT_LF);
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
-    k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl, so.read_blocks, el);
+    // the pairs in the order of their weight (k_order_*): worth two small passes when the pass is a large one
+    const uint32_t *order = nullptr;
+    if (tier == 0 && sel.n >= 65536 && c->d_order && !getenv("MCX_NO_WORK_ORDER")) {
+        const unsigned ob = (sel.n + 256 * kOrderTile - 1) / (256 * kOrderTile);
+        HIP_TRY(hipMemsetAsync(c->d_order_cnt, 0, 16 * kCntPad * sizeof(uint32_t), s));
+        k_order_count<<<ob, 256, 0, s>>>(sel, so.read_blocks, nr, c->d_order_cnt);
+        k_order_place<<<ob, 256, 0, s>>>(sel, so.read_blocks, nr, c->d_order_cnt, c->d_order);
+        order = c->d_order;
+    }
+    k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl, so.read_blocks, el, order);
     if (early) HIP_TRY(hipEventRecord(c->ev_clustered, s));
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     if (paired) {
@@ -1259,12 +1352,12 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         else k_rescue<4096><<<kRescueBlocks, kRescueThreads, 0, s>>>(cx, rb, sel, rl, R.d_kscratch);
     }
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
-    k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP, ll);
+    k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP, ll, order);
     if (late) HIP_TRY(hipEventRecord(c->ev_built, s));
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     if ((rc2 = launch_dp(R, cx, sinks, rb, sel))) return rc2;
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
-    k_finish<<<pb, 256, 0, s>>>(cx, rb, sel, d_recs, c->d_pout, R.d_ov, R.d_cnt + CNT_OV, R.ov_cap, c->d_batch_flags + 2);
+    k_finish<<<pb, 256, 0, s>>>(cx, rb, sel, d_recs, c->d_pout, R.d_ov, R.d_cnt + CNT_OV, R.ov_cap, c->d_batch_flags + 2, order);
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(R.h_cnt, R.d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
