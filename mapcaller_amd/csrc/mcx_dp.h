@@ -104,7 +104,12 @@ static __device__ __forceinline__ DpBuf dp_buffers(int qlen, int tlen, uint8_t *
 // column string is written back to front.  Returns its start offset in ops (all lanes);
 // length = qlen + tlen - offset; *score = ez.score.
 // ---------------------------------------------------------------------------------------------
-template <int K, int W>
+// SCORE: ez.score is wanted (the per-call drop-in); the pipeline only uses the column string, and the H bookkeeping
+// is a sixth of the work per cell.
+// The recurrence's values are differences bounded by the scoring constants (match 1, mismatch -1, q 2, e 1): u, v in
+// [-3, 7], x, y in [0, 7], their sums in [-6, 14] — the int8 lanes of the reference never wrap, so plain ints hold the
+// same values; only the two unsigned byte operations (:89-90) need the byte view of a negative number.
+template <int K, int W, bool SCORE>
 static __device__ int dp_ksw2_core(int qlen, int tlen, const uint8_t *q, const uint8_t *t, uint8_t *dir, uint8_t *ops,
                                    int *score, DpSummary *sum, uint32_t ops_base)
 {
@@ -133,33 +138,34 @@ static __device__ int dp_ksw2_core(int qlen, int tlen, const uint8_t *q, const u
                     const int qb = q[r - tt], tb = tc[k];
                     const int sc = (qb == 4 || tb == 4) ? 0 : (qb == tb ? 1 : -1);
                     int z = sc + QE2;
-                    int a = (int8_t)(xl + vl);
+                    int a = xl + vl;
                     const int ut = u[k];
-                    int b = (int8_t)(y[k] + ut);
+                    int b = y[k] + ut;
                     int d = a > z ? 1 : 0;                     // signed (:187)
                     z = z > a ? z : a;                         // signed max (:188)
                     if (b > z) d = 2;                          // signed (:189)
-                    unsigned zu = (uint8_t)z, bu = (uint8_t)b; // unsigned max / min (:89-90)
+                    unsigned zu = (unsigned)z & 0xFFu, bu = (unsigned)b & 0xFFu; // unsigned max / min on bytes (:89-90)
                     zu = zu > bu ? zu : bu;
                     zu = zu < (unsigned)MAX_SC ? zu : (unsigned)MAX_SC;
-                    z = (int8_t)zu;
-                    u[k] = (int8_t)(z - vl);
-                    v[k] = (int8_t)(z - ut);
-                    z = (int8_t)(z - Q);
-                    a = (int8_t)(a - z);
-                    b = (int8_t)(b - z);
+                    z = (int)zu;                               // (0..7)
+                    u[k] = z - vl;
+                    v[k] = z - ut;
+                    z = z - Q;
+                    a = a - z;
+                    b = b - z;
                     if (a > 0) { x[k] = a; d |= 0x08; } else x[k] = 0;
                     if (b > 0) { y[k] = b; d |= 0x10; } else y[k] = 0;
                     dir[r * tlen + tt] = (uint8_t)d; // (at most 3071 x 1024: 32-bit offsets)
-                    // H bookkeeping (:200-239); u8/v8 are unsigned bytes there
-                    if (r == 0) H[k] = (int)(uint8_t)v[k] - QE - QE;
-                    else if (tt == en) H[k] = en > 0 ? Hl + (int)(uint8_t)u[k] - QE : oH + (int)(uint8_t)v[k] - QE;
-                    else H[k] = oH + (int)(uint8_t)v[k] - QE;
+                    if (SCORE) { // H bookkeeping (:200-239); u8/v8 are unsigned bytes there
+                        if (r == 0) H[k] = (int)(uint8_t)v[k] - QE - QE;
+                        else if (tt == en) H[k] = en > 0 ? Hl + (int)(uint8_t)u[k] - QE : oH + (int)(uint8_t)v[k] - QE;
+                        else H[k] = oH + (int)(uint8_t)v[k] - QE;
+                    }
                 }
             }
         }
     }
-    { // ez.score = H[tlen-1] after the last diagonal
+    if (SCORE) { // ez.score = H[tlen-1] after the last diagonal
         const int kk = (tlen - 1) / W, ll = (tlen - 1) & (W - 1);
         int sc = 0;
 #pragma unroll
@@ -268,10 +274,10 @@ static __device__ int dp_nw_core(int m, int n, const uint8_t *q, const uint8_t *
     return w;
 }
 
-template <int K, int W>
+template <int K, int W, bool SCORE = false>
 static __device__ __forceinline__ int dp_core(bool nw, int qlen, int tlen, const DpBuf &b, uint8_t *ops, int *score, DpSummary *sum, uint32_t ops_base)
 {
-    return nw ? dp_nw_core<K, W>(qlen, tlen, b.q, b.t, b.dir, ops, score, sum, ops_base) : dp_ksw2_core<K, W>(qlen, tlen, b.q, b.t, b.dir, ops, score, sum, ops_base);
+    return nw ? dp_nw_core<K, W>(qlen, tlen, b.q, b.t, b.dir, ops, score, sum, ops_base) : dp_ksw2_core<K, W, SCORE>(qlen, tlen, b.q, b.t, b.dir, ops, score, sum, ops_base);
 }
 
 // tiny problems (up to 8 x 8, most of the bulk: median 3 x 3): one lane each — the same recurrences with

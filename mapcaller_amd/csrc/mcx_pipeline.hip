@@ -1278,15 +1278,19 @@ static PassRes res_tier0(mcx_ctx *c)
 static int launch_dp(const PassRes &R, const Ctx &cx, const JobSinks &sinks, const ReadBatch &rb, const PairSel &sel)
 {
     hipStream_t s = R.stream;
+    // three chains of about the same length (the runtime folds streams onto a few hardware queues anyway: more streams only
+    // make the pairing of kernels on a queue a matter of luck)
+    static const bool wide = getenv("MCX_DP_STREAMS") != nullptr; // (experiments: one stream per kernel)
+    const int n_side = wide ? 5 : 2;
     HIP_TRY(hipEventRecord(R.dp_fork, s));
-    for (int k = 0; k < 5; k++) HIP_TRY(hipStreamWaitEvent(R.dp_stream[k], R.dp_fork, 0));
+    for (int k = 0; k < n_side; k++) HIP_TRY(hipStreamWaitEvent(R.dp_stream[k], R.dp_fork, 0));
     k_dp_sel<1><<<R.dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, R.d_dp_scratch[0], R.dp_stride[0]);
     k_dp_small<<<2560, 256, 0, R.dp_stream[0]>>>(cx, sinks.s[0], rb, sel);
-    k_dp_tiny<<<2048, 256, 0, R.dp_stream[3]>>>(cx, sinks.s[4], rb, sel);
-    k_dp_half<<<2048, 256, 0, R.dp_stream[4]>>>(cx, sinks.s[5], rb, sel);
     k_dp_sel<4><<<R.dp_blocks[1], 64, 0, R.dp_stream[1]>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1]);
-    k_dp_sel<16><<<R.dp_blocks[2], 64, 0, R.dp_stream[2]>>>(cx, sinks.s[3], rb, sel, R.d_dp_scratch[2], R.dp_stride[2]);
-    for (int k = 0; k < 5; k++) { HIP_TRY(hipEventRecord(R.dp_join[k], R.dp_stream[k])); HIP_TRY(hipStreamWaitEvent(s, R.dp_join[k], 0)); }
+    k_dp_tiny<<<2048, 256, 0, wide ? R.dp_stream[3] : R.dp_stream[1]>>>(cx, sinks.s[4], rb, sel);
+    k_dp_half<<<2048, 256, 0, wide ? R.dp_stream[4] : R.dp_stream[0]>>>(cx, sinks.s[5], rb, sel);
+    k_dp_sel<16><<<R.dp_blocks[2], 64, 0, wide ? R.dp_stream[2] : s>>>(cx, sinks.s[3], rb, sel, R.d_dp_scratch[2], R.dp_stride[2]);
+    for (int k = 0; k < n_side; k++) { HIP_TRY(hipEventRecord(R.dp_join[k], R.dp_stream[k])); HIP_TRY(hipStreamWaitEvent(s, R.dp_join[k], 0)); }
     return 0;
 }
 
@@ -2419,7 +2423,7 @@ __global__ void __launch_bounds__(64) k_extend(ExtArgs a, uint8_t *scratch, uint
         __syncthreads();
         uint8_t *dst = a.ops + a.q_off[jb] + a.t_off[jb];
         int score = 0;
-        const int w = dp_core<K, 64>(a.use_nw != 0, m, n, b, dst, &score, nullptr, 0u);
+        const int w = dp_core<K, 64, true>(a.use_nw != 0, m, n, b, dst, &score, nullptr, 0u);
         const int L = m + n - w;
         for (int base = 0; base < L; base += 64) { // move the string to the front of its area
             uint8_t v = base + lane < L ? dst[w + base + lane] : 0;
