@@ -28,8 +28,10 @@ template <int W>
 static __device__ __forceinline__ int lane_shift_up(int v, int carry, int lane)
 {
     if (W == 1) return carry; // a group of one lane: the neighbour is the lane's own previous column
-    int s = __shfl_up(v, 1, W);
-    return lane == 0 ? carry : s;
+    // data-parallel primitives instead of a trip through the LDS crossbar: a lane without a source keeps `carry`
+    if (W == 16) return __builtin_amdgcn_update_dpp(carry, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    const int s = __builtin_amdgcn_update_dpp(carry, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    return (W == 64 || lane != 0) ? s : carry;
 }
 
 // value held by lane `src` of the W-lane group
