@@ -256,7 +256,7 @@ def parse():
     ap.add_argument("--second-genome", type=int, default=1,
                     help="1: after the main run, map 2 steps against the other kind of genome as well and report them under `other_genome`")
     ap.add_argument("--pcie-steps", type=int, default=6, help="steps of the host-buffer leg (value_pcie_inclusive); 0 = skip")
-    ap.add_argument("--vcf-slice-reads", type=int, default=2_000_000, help="reads per mapping call in the -vcf leg")
+    ap.add_argument("--vcf-slice-reads", type=int, default=4_000_000, help="reads per mapping call in the -vcf leg")
     ap.add_argument("--vcf-reduce", type=int, default=1,
                     help="after the timed region: accumulate the -vcf alignment profile of one batch and sum it over the "
                          "ranks with RCCL (1 = yes, 0 = no, -1 = only when more than one GPU)")

@@ -13,7 +13,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmcx.so")
+LIB_PATH = os.environ.get("MCX_LIB") or os.path.join(_HERE, "libmcx.so")  # (MCX_LIB: another build of the same library, for experiments)
 CIGAR_STRIDE = 32
 
 # every symbol include/mcx.h declares

@@ -607,6 +607,7 @@ struct RescueWave { // one workgroup (any number of wavefronts) evaluates one pa
                 diagonal(best_d, qlen, slen, pad, true);
                 int run = 0, run_start = 0;
                 for (int r = 0; r <= qlen; r++) {
+                    if (run == 0 && (r & 31) == 0 && r + 32 <= qlen && ew[r >> 5] == 0u) { r += 31; continue; } // (a word without matches)
                     const bool m = r < qlen && ((ew[r >> 5] >> (r & 31)) & 1u);
                     if (m) { if (run == 0) run_start = r; run++; }
                     else if (run > 0) {

@@ -696,7 +696,10 @@ __global__ void __launch_bounds__(kRescueThreads) k_rescue(Ctx cx, ReadBatch rb,
 // class (mcx_glue.h dp_class) with one atomic per wave and class
 // (late: the pairs that ran over this tier's capacities since clustering — mate rescue's additions, fragment lists, DP
 //  columns, job lists — are listed like the early ones, for a second pass of the large tier beside the rest of this one)
-__global__ void __launch_bounds__(256) k_build(Ctx cx, ReadBatch rb, PairSel sel, JobSinks sinks, uint32_t *cells, uint32_t *unsupported, EarlyList late,
+#ifndef MCX_BUILD_WAVES
+#define MCX_BUILD_WAVES 3
+#endif
+__global__ void __launch_bounds__(256, MCX_BUILD_WAVES) k_build(Ctx cx, ReadBatch rb, PairSel sel, JobSinks sinks, uint32_t *cells, uint32_t *unsupported, EarlyList late,
                                                const uint32_t *order)
 {
     __shared__ EndsLds ends;
