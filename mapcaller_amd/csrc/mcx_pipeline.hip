@@ -672,7 +672,10 @@ constexpr size_t kRescueScratchWords = 1024 + (4096 + 64 + 8) + (4096 + 64) / 16
 
 // KG: the longest window the tier evaluates (caps.kmer_cap)
 template <int KG>
-__global__ void __launch_bounds__(kRescueThreads) k_rescue(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl, uint32_t *kscratch)
+#ifndef MCX_RESCUE_WAVES
+#define MCX_RESCUE_WAVES 1
+#endif
+__global__ void __launch_bounds__(kRescueThreads, MCX_RESCUE_WAVES) k_rescue(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl, uint32_t *kscratch)
 {
     // one workgroup per unpaired pair (they are few, and one pair's windows are a long serial chain
     // for a single wavefront); read and window live in LDS as bit planes (RescueWave)
@@ -1344,7 +1347,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     // the pairs in the order of their weight (k_order_*): worth two small passes when the pass is a large one
     const uint32_t *order = nullptr;
-    if (tier == 0 && sel.n >= 65536 && c->d_order && !getenv("MCX_NO_WORK_ORDER")) {
+    if (tier == 0 && sel.n >= 16384 && c->d_order && !getenv("MCX_NO_WORK_ORDER")) {
         const unsigned ob = (sel.n + 256 * kOrderTile - 1) / (256 * kOrderTile);
         HIP_TRY(hipMemsetAsync(c->d_order_cnt, 0, 16 * kCntPad * sizeof(uint32_t), s));
         k_order_count<<<ob, 256, 0, s>>>(sel, so.read_blocks, nr, c->d_order_cnt);

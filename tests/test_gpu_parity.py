@@ -407,6 +407,35 @@ def test_full_size_genome_prefix_equals_reference(api, bench_genome, tmp_path):
     assert st["tier1_pairs"] > 0, st  # pairs over the tier-0 capacities did go through the large tier
 
 
+def test_large_batch_machinery_does_not_change_the_records(api, bench_genome, monkeypatch):
+    """One large batch of the bench workload (120 k pairs on the full-size genome) mapped twice: with everything that only a large
+    batch switches on — pairs dealt to the lanes by weight, the large tier beside tier 0 on its own streams, the late list's pass on
+    the third set of resources — and with all of it off (one pass after the other on one stream, which is what the small-batch tests
+    compare with the reference).  Records and CIGAR words must be equal read by read."""
+    g = bench_genome
+    n_pairs = 120000
+    reads = g["bench"].make_reads(g["codes"], g["lens"], n_pairs, 150, seed=77, device=g["dev"]).reshape(2 * n_pairs, 150).cpu().numpy()
+    bases = np.ascontiguousarray(reads).reshape(-1)
+    off = (np.arange(2 * n_pairs + 1, dtype=np.uint64) * 150).astype(np.uint32)
+
+    def run():
+        mp = api.Mapper(g["index"], alg="ksw2", max_batch_reads=2 * n_pairs)
+        aln, cig = mp.map_batch(bases, off, True)
+        st = dict(tier1=mp.stats.tier1_pairs)
+        mp.close()
+        return aln, cig, st
+
+    a_aln, a_cig, a_st = run()
+    for k in ("MCX_NO_WORK_ORDER", "MCX_NO_LATE_OVERLAP", "MCX_NO_TIER_OVERLAP"):
+        monkeypatch.setenv(k, "1")
+    b_aln, b_cig, b_st = run()
+    assert a_st["tier1"] > 0 and a_st["tier1"] == b_st["tier1"], (a_st, b_st)
+    for f in ("pos", "mate_pos", "chr", "flag", "mapq", "tlen", "nm", "as", "xs", "n_cigar", "fwd", "has_mate"):
+        assert np.array_equal(a_aln[f], b_aln[f]), f
+    for r in range(2 * n_pairs):
+        assert np.array_equal(a_cig[r], b_cig[r]), r
+
+
 def test_config5_indel_heavy_long_pairs_equal_reference(api, bench_genome, tmp_path, monkeypatch):
     """BASELINE config 5 read literally: 250 bp pairs with 5 % indels per base (2.5 % insertions + 2.5 % deletions), -alg nw, against the
     full-size index, 100 k pairs in ONE batch — several gapped fragments per read.  The DP job lists are held to 100 k entries here
