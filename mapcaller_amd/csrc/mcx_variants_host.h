@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mcx.h"
@@ -529,69 +530,100 @@ inline int Caller::write(const char *path, mcx_vcf_stats *st)
     for (size_t i = 0; i < h.chr_name.size(); i++) fprintf(f, "##contig=<ID=%s,length=%d>\n", h.chr_name[i].c_str(), h.chr_len[i]);
     fprintf(f, "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n", o_.sample_id ? o_.sample_id : "unknown");
 
+    // The records' text is made by several host threads, each over a stretch of the (ordered) records into a buffer of
+    // its own; the buffers go to the file one after the other.  (A record's line depends on its neighbours only through
+    // nearby() / bad_haplotype(), which read.)
+    const int n = (int)vars_.size();
+    const int n_thr = (int)std::max(1u, std::min(16u, std::min(std::thread::hardware_concurrency(), (unsigned)(n / 4096 + 1))));
+    std::vector<std::string> text(n_thr);
+    std::vector<mcx_vcf_stats> part(n_thr);
+    auto chr_of = [&](int64_t g) { return (int)(std::upper_bound(h.chr_fwd.begin(), h.chr_fwd.end(), g) - h.chr_fwd.begin()) - 1; }; // DetermineCoordinate, tools.cpp:132-164 (forward strand)
+    auto work = [&](int t) {
+        mcx_vcf_stats s;
+        memset(&s, 0, sizeof s);
+        std::string &out = text[t];
+        out.reserve((size_t)(n / n_thr + 1) * 96);
+        std::vector<char> line(1024);
+        auto put = [&](const char *fmt, auto... a) { // one formatted piece, appended
+            int k = snprintf(line.data(), line.size(), fmt, a...);
+            if (k >= (int)line.size()) { line.resize((size_t)k + 1); k = snprintf(line.data(), line.size(), fmt, a...); }
+            out.append(line.data(), (size_t)k);
+        };
+        std::string flt;
+        const int i_lo = (int)((int64_t)n * t / n_thr), i_hi = (int)((int64_t)n * (t + 1) / n_thr);
+        for (int i = i_lo; i < i_hi; i++) {
+            const Variant &v = vars_[i];
+            const Column &c = col[i];
+            const int ci = chr_of(v.gPos);
+            const char *chr = h.chr_name[ci].c_str();
+            const int p1 = (int)(v.gPos - h.chr_fwd[ci] + 1);
+            const char ref = "ACGT"[c.ref & 3];
+            const int cov = (int)(c.v[pA] + c.v[pC] + c.v[pG] + c.v[pT]);
+            if (v.type < 3) {
+                flt.clear();
+                if (v.qscore < 10) flt += "q10;";
+                else if (v.type == vSUB && v.AD_alt < 10 && nearby(i, 10)) flt += "q10;";
+                else if (v.type != vSUB && v.AD_alt < 5 && nearby(i, 10)) flt += "q10;";
+                if (o_.filter) {
+                    if ((int)c.v[pMulti] > (int)(cov * 0.05)) flt += "str_contraction;";
+                    if (bad_haplotype(i, 100)) flt += "bad_haplotype;";
+                }
+                if (flt.empty()) flt = "PASS"; else flt.resize(flt.size() - 1);
+            }
+            const float af = (float)(1.0 * v.AD_alt / v.DP);
+            const int rc_ = (int)c.v[pReadCount], F1 = (int)c.v[pF1], R2 = (int)c.v[pR2], F2 = (int)c.v[pF2], R1 = (int)c.v[pR1];
+            switch (v.type) {
+            case vSUB:
+                s.n_snv++; s.n_records++;
+                put("%s\t%d\t.\t%c\t%s\t%d\t%s\tRC=%d;NTFREQ=%d,%d,%d,%d;TYPE=snv\tGT:GQ:DP:AD:AF:F1R2:F2R1\t%s:%d:%d:%d,%d:%.2f:%d,%d:%d,%d\n", chr, p1, ref, v.alt,
+                        v.qscore, flt.c_str(), rc_, (int)c.v[pA], (int)c.v[pC], (int)c.v[pG], (int)c.v[pT], GT[v.geno], v.qscore, v.DP, v.AD_ref, v.AD_alt, af, F1, R2, F2, R1);
+                break;
+            case vINS: case vDEL:
+                if (v.alt_len > 5) break;
+                (v.type == vINS ? s.n_ins : s.n_del)++; s.n_records++;
+                if (v.type == vINS) put("%s\t%d\t.\t%c\t%c%s\t", chr, p1, ref, ref, v.alt);
+                else put("%s\t%d\t.\t%c%s\t%c\t", chr, p1, ref, v.alt, ref);
+                put("%d\t%s\tRC=%d;TYPE=%s\tGT:GQ:DP:AD:AF:F1R2:F2R1\t%s:%d:%d:%d,%d:%.2f:%d,%d:%d,%d\n", v.qscore, flt.c_str(), rc_, v.type == vINS ? "ins" : "del",
+                        GT[v.geno], v.qscore, v.DP, v.AD_ref, v.AD_alt, af, F1, R2, F2, R1);
+                break;
+            case vTNL: case vINV:
+                (v.type == vTNL ? s.n_tnl : s.n_inv)++; s.n_records++;
+                put("%s\t%d\t.\t%c\t<%s>\t30\tBreakPoint\tTYPE=BP\tGT:GQ:DP:AD\t.:.:0:.\n", chr, p1, ref, v.type == vTNL ? "TNL" : "INV");
+                break;
+            case vCNV: case vUMR:
+                if (v.DP < (v.type == vCNV ? o_.min_cnv : o_.min_gap)) break;
+                s.n_records++;
+                put("%s\t%d\t.\t%c\t<*>\t0\t%s\tEND=%d\tGT:GQ:DP:AD\t.:.:0:.\n", chr, p1, ref, v.type == vCNV ? "DUP" : "Gaps", p1 + v.DP - 1);
+                break;
+            case vNOR: {
+                int64_t end = h.chr_fwd[ci] + h.chr_len[ci] - 1;
+                if (i + 1 < n && vars_[i + 1].gPos < end) end = vars_[i + 1].gPos - 1;
+                const int ce = chr_of(end);
+                s.n_records++;
+                put("%s\t%d\t.\t%c\t<*>\t0\tREF\tEND=%d;DP=%d;MIN_DP=%d\tGT:GQ:DP:AD\t.:.:0:.\n", chr, p1, ref, (int)(end - h.chr_fwd[ce] + 1), v.DP, v.AD_alt);
+                break;
+            }
+            case vMON:
+                s.n_records++;
+                put("%s\t%d\t.\t%c\t.\t0\tREF\tDP=%d;RC=%d;NTFREQ=%d,%d,%d,%d\tGT:F1R2:F2R1\t%s:%d,%d:%d,%d\n", chr, p1, ref, v.DP, rc_, (int)c.v[pA], (int)c.v[pC],
+                        (int)c.v[pG], (int)c.v[pT], GT[v.geno], F1, R2, F2, R1);
+                break;
+            }
+        }
+        part[t] = s;
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < n_thr; t++) pool.emplace_back(work, t);
+        work(0);
+        for (auto &th : pool) th.join();
+    }
     mcx_vcf_stats s;
     memset(&s, 0, sizeof s);
-    const int n = (int)vars_.size();
-    auto chr_of = [&](int64_t g) { return (int)(std::upper_bound(h.chr_fwd.begin(), h.chr_fwd.end(), g) - h.chr_fwd.begin()) - 1; }; // DetermineCoordinate, tools.cpp:132-164 (forward strand)
-    std::string flt;
-    for (int i = 0; i < n; i++) {
-        const Variant &v = vars_[i];
-        const Column &c = col[i];
-        const int ci = chr_of(v.gPos);
-        const char *chr = h.chr_name[ci].c_str();
-        const int p1 = (int)(v.gPos - h.chr_fwd[ci] + 1);
-        const char ref = "ACGT"[c.ref & 3];
-        const int cov = (int)(c.v[pA] + c.v[pC] + c.v[pG] + c.v[pT]);
-        if (v.type < 3) {
-            flt.clear();
-            if (v.qscore < 10) flt += "q10;";
-            else if (v.type == vSUB && v.AD_alt < 10 && nearby(i, 10)) flt += "q10;";
-            else if (v.type != vSUB && v.AD_alt < 5 && nearby(i, 10)) flt += "q10;";
-            if (o_.filter) {
-                if ((int)c.v[pMulti] > (int)(cov * 0.05)) flt += "str_contraction;";
-                if (bad_haplotype(i, 100)) flt += "bad_haplotype;";
-            }
-            if (flt.empty()) flt = "PASS"; else flt.resize(flt.size() - 1);
-        }
-        const float af = (float)(1.0 * v.AD_alt / v.DP);
-        const int rc_ = (int)c.v[pReadCount], F1 = (int)c.v[pF1], R2 = (int)c.v[pR2], F2 = (int)c.v[pF2], R1 = (int)c.v[pR1];
-        switch (v.type) {
-        case vSUB:
-            s.n_snv++; s.n_records++;
-            fprintf(f, "%s\t%d\t.\t%c\t%s\t%d\t%s\tRC=%d;NTFREQ=%d,%d,%d,%d;TYPE=snv\tGT:GQ:DP:AD:AF:F1R2:F2R1\t%s:%d:%d:%d,%d:%.2f:%d,%d:%d,%d\n", chr, p1, ref, v.alt,
-                    v.qscore, flt.c_str(), rc_, (int)c.v[pA], (int)c.v[pC], (int)c.v[pG], (int)c.v[pT], GT[v.geno], v.qscore, v.DP, v.AD_ref, v.AD_alt, af, F1, R2, F2, R1);
-            break;
-        case vINS: case vDEL:
-            if (v.alt_len > 5) break;
-            (v.type == vINS ? s.n_ins : s.n_del)++; s.n_records++;
-            if (v.type == vINS) fprintf(f, "%s\t%d\t.\t%c\t%c%s\t", chr, p1, ref, ref, v.alt);
-            else fprintf(f, "%s\t%d\t.\t%c%s\t%c\t", chr, p1, ref, v.alt, ref);
-            fprintf(f, "%d\t%s\tRC=%d;TYPE=%s\tGT:GQ:DP:AD:AF:F1R2:F2R1\t%s:%d:%d:%d,%d:%.2f:%d,%d:%d,%d\n", v.qscore, flt.c_str(), rc_, v.type == vINS ? "ins" : "del",
-                    GT[v.geno], v.qscore, v.DP, v.AD_ref, v.AD_alt, af, F1, R2, F2, R1);
-            break;
-        case vTNL: case vINV:
-            (v.type == vTNL ? s.n_tnl : s.n_inv)++; s.n_records++;
-            fprintf(f, "%s\t%d\t.\t%c\t<%s>\t30\tBreakPoint\tTYPE=BP\tGT:GQ:DP:AD\t.:.:0:.\n", chr, p1, ref, v.type == vTNL ? "TNL" : "INV");
-            break;
-        case vCNV: case vUMR:
-            if (v.DP < (v.type == vCNV ? o_.min_cnv : o_.min_gap)) break;
-            s.n_records++;
-            fprintf(f, "%s\t%d\t.\t%c\t<*>\t0\t%s\tEND=%d\tGT:GQ:DP:AD\t.:.:0:.\n", chr, p1, ref, v.type == vCNV ? "DUP" : "Gaps", p1 + v.DP - 1);
-            break;
-        case vNOR: {
-            int64_t end = h.chr_fwd[ci] + h.chr_len[ci] - 1;
-            if (i + 1 < n && vars_[i + 1].gPos < end) end = vars_[i + 1].gPos - 1;
-            const int ce = chr_of(end);
-            s.n_records++;
-            fprintf(f, "%s\t%d\t.\t%c\t<*>\t0\tREF\tEND=%d;DP=%d;MIN_DP=%d\tGT:GQ:DP:AD\t.:.:0:.\n", chr, p1, ref, (int)(end - h.chr_fwd[ce] + 1), v.DP, v.AD_alt);
-            break;
-        }
-        case vMON:
-            s.n_records++;
-            fprintf(f, "%s\t%d\t.\t%c\t.\t0\tREF\tDP=%d;RC=%d;NTFREQ=%d,%d,%d,%d\tGT:F1R2:F2R1\t%s:%d,%d:%d,%d\n", chr, p1, ref, v.DP, rc_, (int)c.v[pA], (int)c.v[pC],
-                    (int)c.v[pG], (int)c.v[pT], GT[v.geno], F1, R2, F2, R1);
-            break;
-        }
+    for (int t = 0; t < n_thr; t++) {
+        const mcx_vcf_stats &q = part[t];
+        s.n_records += q.n_records; s.n_snv += q.n_snv; s.n_ins += q.n_ins; s.n_del += q.n_del; s.n_tnl += q.n_tnl; s.n_inv += q.n_inv;
+        if (!text[t].empty() && fwrite(text[t].data(), 1, text[t].size(), f) != text[t].size()) { fclose(f); return mcx_set_error(MCX_ERR_IO, std::string("cannot write ") + path); }
     }
     if (fclose(f) != 0) return mcx_set_error(MCX_ERR_IO, std::string("cannot write ") + path);
     if (st) { s.avg_read_len = (int32_t)avg_rlen_; s.fragment_size = frag_size_; s.ms_depth = ms_depth_; s.ms_scan = ms_scan_; *st = s; }
