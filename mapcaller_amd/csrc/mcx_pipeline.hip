@@ -750,6 +750,7 @@ __global__ void __launch_bounds__(256, MCX_BUILD_WAVES) k_build(Ctx cx, ReadBatc
 // that does not fit its class's LDS keeps its sequences / traceback in the workgroup's HBM scratch.
 template <int K> struct DpLds { static constexpr int seq = kDpLdsSeq, dir = kDpLdsDir; };
 template <> struct DpLds<1> { static constexpr int seq = 512, dir = 4096; }; // targets <= 64: e.g. 48 x 48 fits
+template <> struct DpLds<4> { static constexpr int seq = 1024, dir = 3072; }; // targets 65..256: the traceback of most does not fit 12 KB either — more problems per CU instead
 
 // one problem on the W lanes of a group (W = 64: the wave; 32: a half wave): stage the two strings,
 // sweep, trace back, hand the column string to the fragment
@@ -1133,7 +1134,7 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     if ((rc = dmalloc(&c->d_kscratch, 3 * (size_t)kRescueBlocks * kRescueScratchWords))) return rc; // (one part per set of pass resources)
     // DP traceback spill per block: 4 KB of sequences + (qlen + tlen - 1) * tlen direction bytes
     const uint64_t spill[3] = {kDpSpillSeq + (uint64_t)(2048 + 64) * 64, kDpSpillSeq + (uint64_t)(2048 + 256) * 256, kDpSpillSeq + (uint64_t)(2048 + 1024) * 1024};
-    const uint32_t blocks[3] = {8192, 2048, 512};
+    const uint32_t blocks[3] = {8192, 4096, 512};
     for (int k = 0; k < 3; k++) {
         c->dp_stride[k] = spill[k]; c->dp_blocks[k] = blocks[k];
         if ((rc = dmalloc(&c->d_dp_scratch[k], (size_t)spill[k] * blocks[k]))) return rc;
@@ -1293,9 +1294,9 @@ static int launch_dp(const PassRes &R, const Ctx &cx, const JobSinks &sinks, con
     k_dp_sel<1><<<R.dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, R.d_dp_scratch[0], R.dp_stride[0]);
     k_dp_small<<<2560, 256, 0, R.dp_stream[0]>>>(cx, sinks.s[0], rb, sel);
     k_dp_sel<4><<<R.dp_blocks[1], 64, 0, R.dp_stream[1]>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1]);
-    k_dp_tiny<<<2048, 256, 0, wide ? R.dp_stream[3] : R.dp_stream[1]>>>(cx, sinks.s[4], rb, sel);
-    k_dp_half<<<2048, 256, 0, wide ? R.dp_stream[4] : R.dp_stream[0]>>>(cx, sinks.s[5], rb, sel);
-    k_dp_sel<16><<<R.dp_blocks[2], 64, 0, wide ? R.dp_stream[2] : s>>>(cx, sinks.s[3], rb, sel, R.d_dp_scratch[2], R.dp_stride[2]);
+    k_dp_tiny<<<2048, 256, 0, wide ? R.dp_stream[3] : s>>>(cx, sinks.s[4], rb, sel);
+    k_dp_half<<<2048, 256, 0, wide ? R.dp_stream[4] : R.dp_stream[1]>>>(cx, sinks.s[5], rb, sel);
+    k_dp_sel<16><<<R.dp_blocks[2], 64, 0, wide ? R.dp_stream[2] : R.dp_stream[0]>>>(cx, sinks.s[3], rb, sel, R.d_dp_scratch[2], R.dp_stride[2]);
     for (int k = 0; k < n_side; k++) { HIP_TRY(hipEventRecord(R.dp_join[k], R.dp_stream[k])); HIP_TRY(hipStreamWaitEvent(s, R.dp_join[k], 0)); }
     return 0;
 }
