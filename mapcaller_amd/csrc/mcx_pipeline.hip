@@ -1076,7 +1076,7 @@ static int passres_alloc(mcx_ctx *c, PassRes &t, uint64_t pairs, uint64_t sel_ca
     }
     t.rescue_cap = (uint32_t)pairs;
     if ((rc = dmalloc(&t.d_rescue, t.rescue_cap))) return rc;
-    const uint32_t blocks1[3] = {2048, 512, 128};
+    const uint32_t blocks1[3] = {2048, 2048, 256};
     for (int k = 0; k < 3; k++) {
         t.dp_stride[k] = c->dp_stride[k]; t.dp_blocks[k] = blocks1[k];
         if ((rc = dmalloc(&t.d_dp_scratch[k], (size_t)t.dp_stride[k] * t.dp_blocks[k]))) return rc;
