@@ -536,47 +536,24 @@ struct RescueWave { // one workgroup (any number of wavefronts) evaluates one pa
         const int pad = ((qlen + 31) & ~31) + 32;                 // diagonals reach qlen - 1 positions before the window
         const int n_words = (pad + slen + qlen) / 32 + 3;
         __syncthreads();
-        for (int i = tid; i < n_words; i += nt) { wl[i] = 0u; wh[i] = 0u; }
-        __syncthreads();
-        // The window's bases come from the 2-bit genome, sixteen at a time: four bytes, their low and high bits pulled apart,
-        // OR-ed into the planes where the window has them.  A window on the reverse strand is the mirrored forward
-        // stretch, complemented.
-        if (left < ix.G && left + slen > ix.G) { // the window runs from the end of the forward strand into the reverse strand
-            for (int p = tid; p < slen; p += nt) { // (same chromosome on both sides of G: AlignmentRescue lets it pass): base by base
-                const uint32_t c = (uint32_t)ref_code(ix, left + p), bit = 1u << ((p + pad) & 31);
-                if (c & 1) atomicOr(&wl[(p + pad) >> 5], bit);
-                if (c & 2) atomicOr(&wh[(p + pad) >> 5], bit);
-            }
-        } else {
-            const bool rev = left >= ix.G;
-            const int64_t f0 = rev ? ix.G2 - (left + slen) : left;
-            const int64_t F0 = f0 & ~(int64_t)15;
-            const int n_chunks = (int)((f0 + slen - F0 + 15) >> 4);
-            const int64_t n_bytes = (ix.G + 3) >> 2;
-            for (int t = tid; t < n_chunks; t += nt) {
-                const int64_t F = F0 + 16 * (int64_t)t, b0 = F >> 2;
-                uint32_t x = 0;
+        // The window's planes, a word (32 positions) per thread: two 16-base stretches of the 2-bit genome (ref_codes16: either
+        // strand, and the few windows that run from one into the other), their low and high bits pulled apart.  Words before
+        // and behind the window are clear.
+        for (int j = tid; j < n_words; j += nt) {
+            uint32_t lo = 0, hi = 0;
+            const int p0 = 32 * j - pad; // window position of the word's bit 0
+            if (p0 >= 0 && p0 < slen) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) x = (x << 8) | (b0 + j < n_bytes ? (uint32_t)ix.pac[b0 + j - ix.pac_base] : 0u);
-                // base i of the chunk (forward coordinate F + i) sits at bits 31-2i (high) and 30-2i (low): packed, bit 15 - i
-                uint32_t lo16 = even_bits16(x), hi16 = even_bits16(x >> 1);
-                const int i_lo = f0 > F ? (int)(f0 - F) : 0, i_hi = f0 + slen - 1 - F < 15 ? (int)(f0 + slen - 1 - F) : 15; // bases inside the window
-                int bit0;
-                uint32_t keep;
-                if (!rev) { // window position p = F + i - f0: bit i of the reversed halves
-                    lo16 = __brev(lo16) >> 16; hi16 = __brev(hi16) >> 16;
-                    keep = ((2u << i_hi) - 1u) & ~((1u << i_lo) - 1u);
-                    bit0 = pad + (int)(F - f0);
-                } else {    // p = f0 + slen - 1 - (F + i): bit 15 - i as packed, complemented
-                    lo16 = ~lo16; hi16 = ~hi16;
-                    keep = ((2u << (15 - i_lo)) - 1u) & ~((1u << (15 - i_hi)) - 1u);
-                    bit0 = pad + (int)(f0 + slen - 16 - F);
+                for (int half = 0; half < 2; half++) {
+                    const int p = p0 + 16 * half;
+                    if (p >= slen) break;
+                    const uint32_t x = ref_codes16(ix, left + p); // base s at bits 31-2s (high), 30-2s (low)
+                    uint32_t l16 = __brev(even_bits16(x)) >> 16, h16 = __brev(even_bits16(x >> 1)) >> 16; // base s at bit s
+                    if (slen - p < 16) { const uint32_t keep = (1u << (slen - p)) - 1u; l16 &= keep; h16 &= keep; }
+                    lo |= l16 << (16 * half); hi |= h16 << (16 * half);
                 }
-                lo16 &= keep; hi16 &= keep;
-                const int wd = bit0 >> 5, s = bit0 & 31;
-                if (lo16) { atomicOr(&wl[wd], lo16 << s); if (s > 16) atomicOr(&wl[wd + 1], lo16 >> (32 - s)); }
-                if (hi16) { atomicOr(&wh[wd], hi16 << s); if (s > 16) atomicOr(&wh[wd + 1], hi16 >> (32 - s)); }
             }
+            wl[j] = lo; wh[j] = hi;
         }
         __syncthreads();
         // a diagonal needs three 8-mers in a row on both sides to score at all: d in [-(qlen - 10), slen - 10]
