@@ -359,6 +359,7 @@ struct RescueWave { // one workgroup (any number of wavefronts) evaluates one pa
         uint32_t *ql = q, *qh = q + kRescueQWords, *qn = q + 2 * kRescueQWords;
         __syncthreads();
         for (int i = tid; i < 3 * kRescueQWords; i += nt) q[i] = 0u;
+        if (tid == 0) red[0] = 0; // window()'s best-diagonal key
         __syncthreads();
         for (int i = tid; i < rq.rlen; i += nt) {
             const int c = nt4_code(read_char(rq, i));
@@ -530,7 +531,7 @@ struct RescueWave { // one workgroup (any number of wavefronts) evaluates one pa
 
     __device__ RescueOut window(const IndexView &ix, int64_t left, int slen, int qlen, Hit *hits, int n_hits, int cap, bool &overflow) const
     {
-        const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, n_waves = nt >> 6;
+        const int tid = threadIdx.x, nt = blockDim.x, n_waves = nt >> 6;
         if (red[2 * n_waves + 4]) return window_ids(ix, left, slen, qlen, hits, n_hits, cap, overflow);
         uint32_t *wl = w, *wh = w + wstride;
         const int pad = ((qlen + 31) & ~31) + 32;                 // diagonals reach qlen - 1 positions before the window
@@ -556,55 +557,52 @@ struct RescueWave { // one workgroup (any number of wavefronts) evaluates one pa
             wl[j] = lo; wh[j] = hi;
         }
         __syncthreads();
-        // a diagonal needs three 8-mers in a row on both sides to score at all: d in [-(qlen - 10), slen - 10]
-        int best_total = 0, best_d = 0x7fffffff;
+        // a diagonal needs three 8-mers in a row on both sides to score at all: d in [-(qlen - 10), slen - 10].
+        // The best one (largest total, then smallest diagonal) is found with one LDS atomic per thread, on a key made of both.
         const int d_lo = -(qlen - kKmerSize - 2), n_diag = slen - kKmerSize - 2 - d_lo + 1;
+        uint32_t my_key = 0;
         for (int g = tid; g < n_diag; g += nt) {
-            const int d = d_lo + g;
-            const int total = diagonal(d, qlen, slen, pad, false);
-            if (total > best_total) { best_total = total; best_d = d; } // (ascending: the first of equal totals stays)
+            const int total = diagonal(d_lo + g, qlen, slen, pad, false);
+            const uint32_t key = ((uint32_t)total << 13) | (uint32_t)(8191 - g); // (g < 8192: a window is at most 4096 long, a read 1000)
+            if (total > 0 && key > my_key) my_key = key;
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            const int ot = __shfl_xor(best_total, o, 64), od = __shfl_xor(best_d, o, 64);
-            if (ot > best_total || (ot == best_total && od < best_d)) { best_total = ot; best_d = od; }
-        }
-        if (lane == 0) { red[2 * wave] = best_total; red[2 * wave + 1] = best_d; }
+        uint32_t *best_key = (uint32_t *)red; // red[0]: the key (cleared again below); red[1], red[2]: seeds written, overflow
+        if (my_key) atomicMax(best_key, my_key);
         __syncthreads();
-        int *out = red + 2 * n_waves; // {score, d, n_seeds, overflow}
+        const uint32_t key = *best_key;
+        RescueOut best; best.score = (int)(key >> 13); best.d = 0; best.n_seeds = 0;
+        if (key == 0) return best; // (the key is still clear for the next window, whose first barrier comes before anybody touches it)
+        best.d = d_lo + (8191 - (int)(key & 8191u));
         if (tid == 0) {
-            for (int wv = 1; wv < n_waves; wv++) {
-                const int ot = red[2 * wv], od = red[2 * wv + 1];
-                if (ot > best_total || (ot == best_total && od < best_d)) { best_total = ot; best_d = od; }
-            }
+            const int best_d = best.d;
             int n_seeds = 0;
             bool o2 = false;
-            if (best_total > 0) {
-                // the seeds of the best diagonal, in read order (diag_scan on the match bits)
-                for (int k = 0; k < kRescueQWords; k++) ew[k] = 0u;
-                diagonal(best_d, qlen, slen, pad, true);
-                int run = 0, run_start = 0;
-                for (int r = 0; r <= qlen; r++) {
-                    if (run == 0 && (r & 31) == 0 && r + 32 <= qlen && ew[r >> 5] == 0u) { r += 31; continue; } // (a word without matches)
-                    const bool m = r < qlen && ((ew[r >> 5] >> (r & 31)) & 1u);
-                    if (m) { if (run == 0) run_start = r; run++; }
-                    else if (run > 0) {
-                        const int l = kKmerSize + run - 1;
-                        if (l >= 10) {
-                            if (n_hits + n_seeds < cap) {
-                                Hit h; h.rPos = run_start; h.gPos = (int64_t)(run_start + best_d) + left; h.len = l;
-                                hits[n_hits + n_seeds] = h;
-                            } else o2 = true;
-                            n_seeds++;
-                        }
-                        run = 0;
+            // the seeds of the best diagonal, in read order (diag_scan on the match bits)
+            for (int k = 0; k < kRescueQWords; k++) ew[k] = 0u;
+            diagonal(best_d, qlen, slen, pad, true);
+            int run = 0, run_start = 0;
+            for (int r = 0; r <= qlen; r++) {
+                if (run == 0 && (r & 31) == 0 && r + 32 <= qlen && ew[r >> 5] == 0u) { r += 31; continue; } // (a word without matches)
+                const bool m = r < qlen && ((ew[r >> 5] >> (r & 31)) & 1u);
+                if (m) { if (run == 0) run_start = r; run++; }
+                else if (run > 0) {
+                    const int l = kKmerSize + run - 1;
+                    if (l >= 10) {
+                        if (n_hits + n_seeds < cap) {
+                            Hit h; h.rPos = run_start; h.gPos = (int64_t)(run_start + best_d) + left; h.len = l;
+                            hits[n_hits + n_seeds] = h;
+                        } else o2 = true;
+                        n_seeds++;
                     }
+                    run = 0;
                 }
             }
-            out[0] = best_total; out[1] = best_total > 0 ? best_d : 0; out[2] = n_seeds; out[3] = o2 ? 1 : 0;
+            red[1] = n_seeds; red[2] = o2 ? 1 : 0;
         }
         __syncthreads();
-        RescueOut best; best.score = out[0]; best.d = out[1]; best.n_seeds = out[2];
-        if (out[3]) overflow = true;
+        best.n_seeds = red[1];
+        if (red[2]) overflow = true;
+        if (tid == 0) *best_key = 0u; // (every thread has read it; clear for the next window)
         return best;
     }
 };
