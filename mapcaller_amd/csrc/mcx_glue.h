@@ -941,8 +941,9 @@ static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef 
                 if (x.kind == kSimple) continue;
                 if (x.rLen > 0 && x.gLen > 0) {
                     bool dp = x.rLen != x.gLen;
+                    int mm = -1;
                     if (!dp) {
-                        const int mm = frag_mismatches(cx.ix, x, rd[s]);
+                        mm = frag_mismatches(cx.ix, x, rd[s]);
                         dp = mm > 1 && mm >= (int)(x.rLen * 0.2);
                     }
                     if (dp) {
@@ -953,7 +954,7 @@ static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef 
                         h.n_ops = at + x.rLen + x.gLen;
                         jl[2 * nj] = h.n_frags + i; jl[2 * nj + 1] = s;
                         nj++;
-                    } else { x.kind = kPlain; x.ops_len = x.rLen; }
+                    } else { x.kind = kPlain; x.ops_len = x.rLen; x.meta = (uint32_t)(mm + 1); } // (the count travels with the fragment: the finish stage needs it again)
                 } else if (x.rLen > 0) { x.kind = kIns; x.ops_len = x.rLen; }
                 else { x.kind = kDel; x.ops_len = x.gLen; }
                 f[i] = x;
@@ -1013,7 +1014,7 @@ static inline MCX_HD ColStats frag_columns(const IndexView &ix, const Frag &f, c
     ColStats cs; cs.switches = cs.n = cs.mis = cs.match = 0;
     if (f.kind != kDp) { // one kind of column throughout: no walk
         if (f.ops_len > 0) cs.switches = 1;
-        if (f.kind == kPlain) { cs.n = f.ops_len; cs.mis = frag_mismatches(ix, f, rd); cs.match = cs.n - cs.mis; }
+        if (f.kind == kPlain) { cs.n = f.ops_len; cs.mis = f.meta ? (int)f.meta - 1 : frag_mismatches(ix, f, rd); cs.match = cs.n - cs.mis; }
         return cs;
     }
     if (f.meta) { // counted by the DP kernel; an end the gates trimmed takes its runs of gap columns with it

@@ -111,7 +111,7 @@ struct alignas(16) Frag {
     int64_t ops_off : 18;  // kDp: offset into the pair's ops pool (columns, 'M' 'I' 'D')
     int64_t ops_len : 13;  // current number of alignment columns (after end trimming)
     uint64_t kind : 3;
-    uint64_t meta : 14;    // kDp: where the DP kernel left the fragment's DpSummary (ops pool offset / 8 + 1); 0: none, walk the columns
+    uint64_t meta : 14;    // kDp: where the DP kernel left the fragment's DpSummary (ops pool offset / 8 + 1); 0: none, walk the columns.  kPlain: mismatches + 1 as stage_build counted them (0: count again)
 };
 static_assert(sizeof(Frag) == 16, "Frag is one 16-byte record");
 
