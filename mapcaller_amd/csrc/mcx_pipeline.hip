@@ -1763,7 +1763,7 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
     }
     { // the batch in 2-bit form, once; every seeding pass (tiers, replay) reads it
         HIP_TRY(hipEventRecord(c->ev_pack[0], s));
-        const int tpr = (c->rlen_max + 31) / 32 + 1;
+        const int tpr = ((int)c->h_cnt[1] + 31) / 32 + 1; // (threads per read: for the batch's longest read, found above)
         const uint64_t threads = (uint64_t)n_reads * (uint64_t)tpr;
         k_pack_reads<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(br.rb, paired, c->wpad, tpr, c->d_packed);
         HIP_TRY(hipGetLastError());
