@@ -565,7 +565,7 @@ def main():
     sample = batches[0].reshape(reads_per_step, args.rlen)[: 2 * cpu_pairs].cpu() if (rank == 0 and world == 1 and cpu_pairs) else None
     del codes
     d_aln = torch.empty(reads_per_step * 64, dtype=torch.uint8, device=dev)
-    d_cig = torch.empty(reads_per_step * api.CIGAR_STRIDE, dtype=torch.int32, device=dev)
+    d_cig = torch.empty(api.cigar_pool_words(reads_per_step), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     traj = Trajectory(dist, dev, world, rank, (args.batch_pairs + 99) // 100) if world > 1 else None
 

@@ -111,12 +111,12 @@ typedef struct mcx_stats {
     int64_t tier1_pairs;    /* pairs re-run with the large capacities */
     int64_t replayed_pairs; /* pairs re-run because the avgDist trajectory moved past their validity interval */
     int64_t halved_selections; /* times a selection of pairs was mapped in two halves because a work list ran over */
-    int64_t fast_pairs;     /* pairs the fused per-pair kernel mapped from seeds to records (the rest took the general path) */
     double ms_encode /* k_pack_reads */, ms_seed, ms_sa, ms_cluster, ms_rescue, ms_build, ms_dp, ms_finish, ms_total;
-    double ms_fast;         /* k_pair_fast */
 } mcx_stats;
 
-#define MCX_CIGAR_STRIDE 32 /* the CIGAR pool of a batch holds n_reads * MCX_CIGAR_STRIDE words */
+#define MCX_CIGAR_STRIDE 32 /* CIGAR words per read a batch's pool has room for on average ... */
+#define MCX_CIGAR_SLACK 65536 /* ... plus this many: a batch of a few reads with long CIGARs (or re-run pairs, which take fresh words) still fits */
+#define MCX_CIGAR_POOL_WORDS(n_reads) ((size_t)(n_reads) * MCX_CIGAR_STRIDE + MCX_CIGAR_SLACK) /* the capacity every d_cigar / cigar argument must have */
 
 /* Replaces the body of ReadMapping() for one batch (reference src/ReadMapping.cpp:416-646):
  * seeding, clustering, pairing, rescue, extension, scoring, flags/MAPQ/CIGAR.  d_bases: ASCII
@@ -125,7 +125,7 @@ typedef struct mcx_stats {
  * avg_state[4] carries the reference's running insert-size estimate across batches
  * {avgDist, iTotalPairedNum, TotalPairedDistance, reads seen} (ReadMapping.cpp:20-21,:538-539);
  * initialise with mcx_avg_init.  Results (device): d_aln[n_reads] and the batch's CIGAR pool d_cigar
- * (capacity n_reads * MCX_CIGAR_STRIDE words): the operations of read r are the n_cigar words from
+ * (capacity MCX_CIGAR_POOL_WORDS(n_reads) words): the operations of read r are the n_cigar words from
  * d_cigar[d_aln[r].cigar_off] on.  The pool is filled by wavefronts in no particular order (offsets differ
  * from run to run, contents do not); mcx_cigar_words tells how many of its words the last batch took —
  * all a copy to the host has to move. */

@@ -15,6 +15,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MCX_LIB") or os.path.join(_HERE, "libmcx.so")  # (MCX_LIB: another build of the same library, for experiments)
 CIGAR_STRIDE = 32
+CIGAR_SLACK = 65536
+
+
+def cigar_pool_words(n_reads):
+    """MCX_CIGAR_POOL_WORDS (include/mcx.h): the capacity of a batch's CIGAR pool."""
+    return n_reads * CIGAR_STRIDE + CIGAR_SLACK
+
 
 # every symbol include/mcx.h declares
 SYMBOLS = [
@@ -63,9 +70,9 @@ PLANES = ("A", "C", "G", "T", "multi_hit", "readCount", "F1", "R2", "F2", "R1")
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("reads", "mapped", "pairs", "pair_dist_sum", "pair_len_sum", "fm_ext_steps", "fm_blocks",
-                                         "sa_hits", "dp_jobs", "dp_cells", "tier1_pairs", "replayed_pairs", "halved_selections", "fast_pairs")] + \
+                                         "sa_hits", "dp_jobs", "dp_cells", "tier1_pairs", "replayed_pairs", "halved_selections")] + \
                [(n, C.c_double) for n in ("ms_encode", "ms_seed", "ms_sa", "ms_cluster", "ms_rescue", "ms_build",
-                                          "ms_dp", "ms_finish", "ms_total", "ms_fast")]
+                                          "ms_dp", "ms_finish", "ms_total")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -376,16 +383,16 @@ class Mapper:
         off = np.ascontiguousarray(off, dtype=np.uint32)
         n = off.size - 1
         aln = np.zeros(n, dtype=ALN_DTYPE)
-        pool = np.zeros(n * CIGAR_STRIDE, dtype=np.uint32)
+        pool = np.zeros(cigar_pool_words(n), dtype=np.uint32)
         _check(lib().mcx_map_batch(self._h, bases.ctypes.data, off.ctypes.data, n, int(paired), self.avg,
                                    aln.ctypes.data, pool.ctypes.data, C.byref(self.stats)), "mcx_map_batch")
         return aln, [pool[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["n_cigar"])] for a in aln]
 
     @staticmethod
     def stream_outputs(n_reads: int, slots: int = 3):
-        """Pinned host buffers for map_stream's results: [(records uint8[n_reads * 64], CIGAR pool int32[n_reads * CIGAR_STRIDE])]."""
+        """Pinned host buffers for map_stream's results: [(records uint8[n_reads * 64], CIGAR pool int32[cigar_pool_words(n_reads)])]."""
         import torch
-        return [(torch.empty(n_reads * 64, dtype=torch.uint8).pin_memory(), torch.empty(n_reads * CIGAR_STRIDE, dtype=torch.int32).pin_memory())
+        return [(torch.empty(n_reads * 64, dtype=torch.uint8).pin_memory(), torch.empty(cigar_pool_words(n_reads), dtype=torch.int32).pin_memory())
                 for _ in range(slots)]
 
     def map_stream(self, host_bases_ptrs, host_off_ptr: int, n_reads: int, paired: bool, outputs=None):

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -26,6 +27,7 @@ struct Group { // ranks that share a process without RCCL (two ranks on one devi
     std::mutex m; std::condition_variable cv;
     int size = 0, arrived = 0, refs = 0;
     uint64_t gen = 0;
+    std::atomic<bool> failed{false}; // a rank of the group failed inside a collective: the others give up after the barrier
     std::vector<void *> ptr;
     void barrier()
     {
@@ -143,29 +145,39 @@ extern "C" int mcx_profile_reduce(mcx_comm *c, uint32_t *d_planes, int64_t G, in
             for (uint64_t lo = 0; lo < (uint64_t)G; lo += piece) {
                 const uint64_t cnt = std::min<uint64_t>(piece, (uint64_t)G - lo);
                 ncclResult_t e = ncclReduce(p + lo, p + lo, (size_t)cnt, ncclUint32, ncclSum, root, c->nccl, c->stream);
-                if (e != ncclSuccess) return fail_nccl("ncclReduce", e);
+                if (e != ncclSuccess) { // the peers sit in the collectives queued so far: abort the communicator so that they come back with an error
+                    rc = fail_nccl("ncclReduce", e);
+                    (void)ncclCommAbort(c->nccl); c->nccl = nullptr;
+                    return rc;
+                }
             }
         }
         hipError_t he = hipStreamSynchronize(c->stream);
-        if (he != hipSuccess) return fail_hip("hipStreamSynchronize", he);
+        if (he != hipSuccess) { rc = fail_hip("hipStreamSynchronize", he); (void)ncclCommAbort(c->nccl); c->nccl = nullptr; return rc; }
+        ncclResult_t ae = ncclSuccess;
+        if (ncclCommGetAsyncError(c->nccl, &ae) == ncclSuccess && ae != ncclSuccess) { rc = fail_nccl("ncclReduce (asynchronous)", ae); (void)ncclCommAbort(c->nccl); c->nccl = nullptr; return rc; }
     } else if (c->size > 1) { // ranks of one process on a shared device: the root adds the others' planes itself
         Group &g = *c->group;
         g.ptr[(size_t)c->rank] = d_planes;
+        // (every rank reaches both barriers whatever happens to it: a rank that returned early would leave the others waiting for ever)
         hipError_t he = hipDeviceSynchronize();
-        if (he != hipSuccess) return fail_hip("hipDeviceSynchronize", he);
+        if (he != hipSuccess) { rc = fail_hip("hipDeviceSynchronize", he); g.failed.store(true); }
         g.barrier();
-        if (c->rank == root) {
+        if (c->rank == root && !g.failed.load()) {
             for (int r = 0; r < c->size && rc == 0; r++) {
                 if (r == root) continue;
-                for (int k = 0; k < kPlanes; k++) {
+                for (int k = 0; k < kPlanes && rc == 0; k++) {
                     if (k == kReadCount) continue;
                     k_add_planes<<<4096, 256, 0, c->stream>>>(d_planes + (uint64_t)k * (uint64_t)G, (const uint32_t *)g.ptr[(size_t)r] + (uint64_t)k * (uint64_t)G, (uint64_t)G);
+                    if ((he = hipGetLastError()) != hipSuccess) rc = fail_hip("k_add_planes", he);
                 }
             }
             he = hipStreamSynchronize(c->stream);
-            if (he != hipSuccess) rc = fail_hip("k_add_planes", he);
+            if (he != hipSuccess && rc == 0) rc = fail_hip("k_add_planes", he);
+            if (rc) g.failed.store(true);
         }
         g.barrier();
+        if (rc == 0 && g.failed.load()) rc = mcx_set_error(MCX_ERR_DEVICE, "mcx_profile_reduce: another rank of the group failed");
     }
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return rc;

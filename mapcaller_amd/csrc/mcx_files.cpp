@@ -210,7 +210,7 @@ struct Batch {
             cap_reads = reads;
             off = (uint32_t *)mcx_pinned_alloc((reads + 1) * sizeof(uint32_t));
             recs = (AlnRec *)mcx_pinned_alloc(reads * sizeof(AlnRec));
-            cig = (uint32_t *)mcx_pinned_alloc(reads * MCX_CIGAR_STRIDE * sizeof(uint32_t));
+            cig = (uint32_t *)mcx_pinned_alloc((MCX_CIGAR_POOL_WORDS(reads) + MCX_CIGAR_SLACK) * sizeof(uint32_t)); // (two pools: the pairs', the single reads')
         }
         if (n_bases > cap_bases) { mcx_pinned_free(bases); cap_bases = n_bases + n_bases / 8; bases = (uint8_t *)mcx_pinned_alloc(cap_bases); }
         return off && recs && cig && bases;
@@ -274,7 +274,7 @@ void sam_record(const HostIndex &ix, const Batch &bt, uint32_t r, Text &o)
     const Entries &e = bt.in[f];
     const AlnRec &rec = bt.recs[r];
     // the batch's CIGAR pool (the single-read part of a batch has one of its own behind the pairs'), AlnRec::pad[0] = offset
-    const uint32_t *cigar = bt.cig + (r < bt.n_pair_reads ? 0 : (size_t)bt.n_pair_reads * MCX_CIGAR_STRIDE) + (size_t)rec.pad[0];
+    const uint32_t *cigar = bt.cig + (r < bt.n_pair_reads ? 0 : MCX_CIGAR_POOL_WORDS(bt.n_pair_reads)) + (size_t)rec.pad[0];
     const char *seq = (const char *)e.seq.data() + e.seq_off[i];
     const int rlen = (int)(e.seq_off[i + 1] - e.seq_off[i]);
     const char *qual = bt.fastq ? e.qual.data() + e.seq_off[i] : nullptr;
@@ -720,7 +720,7 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
             }
             if (rc == 0 && n_pairs_reads < n) {
                 rc = mcx_map_batch(c, b->bases + base2, off2.data(), n - n_pairs_reads, 0, avg, (mcx_aln *)b->recs + n_pairs_reads,
-                                   b->cig + (size_t)n_pairs_reads * MCX_CIGAR_STRIDE, stats);
+                                   b->cig + MCX_CIGAR_POOL_WORDS(n_pairs_reads), stats);
             }
         } else if (!dead && b->number / shard_count >= rounds_done) {
             rounds_done = b->number / shard_count + 1;
@@ -743,7 +743,7 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
             if (rc == 0 && any_single) {
                 const uint32_t ns = n - n_pairs_reads;
                 rc = sh.singles(c, ns ? b->bases + base2 : nullptr, ns ? off2.data() : nullptr, ns, round_base + (int64_t)before + n_pairs_reads, profile,
-                                (mcx_aln *)b->recs + n_pairs_reads, b->cig + (size_t)n_pairs_reads * MCX_CIGAR_STRIDE, stats);
+                                (mcx_aln *)b->recs + n_pairs_reads, b->cig + MCX_CIGAR_POOL_WORDS(n_pairs_reads), stats);
             }
             avg[3] = round_base + (int64_t)round_total;
             if (rc) dead = true;

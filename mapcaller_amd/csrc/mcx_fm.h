@@ -168,7 +168,7 @@ static inline MCX_HD int ref_code(const IndexView &ix, int64_t p)
 {
     bool rev = p >= ix.G;
     int64_t f = rev ? ix.G2 - 1 - p : p;
-    int b = (ix.pac[(f >> 2) - ix.pac_base] >> ((~f & 3) << 1)) & 3;
+    int b = (ix.pac[f >> 2] >> ((~f & 3) << 1)) & 3;
     return rev ? 3 - b : b;
 }
 
@@ -314,7 +314,7 @@ static inline MCX_HD uint32_t packed_nmask32(const PackedRead &pk, int p, int rl
 // symbols f .. f+15 of the forward genome, MSB first (two big-endian words of the .pac bytes)
 static inline MCX_HD uint32_t ref_codes16_fwd(const IndexView &ix, int64_t f)
 {
-    const uint32_t *wp = (const uint32_t *)(ix.pac + (((f >> 4) << 2) - ix.pac_base)); // (pac_base is a multiple of 4)
+    const uint32_t *wp = (const uint32_t *)(ix.pac + ((f >> 4) << 2));
     const int sh = (int)(f & 15) * 2;
     const uint32_t hi = __builtin_bswap32(wp[0]), lo = __builtin_bswap32(wp[1]);
     return sh ? (hi << sh) | (lo >> (32 - sh)) : hi;

@@ -126,8 +126,8 @@ void mcx_disc_resolve(const mcx_sparse_rec *events, size_t n, int64_t G, std::ve
         const int kind = e->len;
         if (kind == 1) {
             int64_t d = G2 - g1 - g2; if (d < 0) d = -d;
-            if (d > 1000 && d < 10000000) push('V', g1, d);
-            last[0] = g1; last[1] = d;
+            last[1] = d; // (.dist always, .gPos only inside the range: ReadMapping.cpp:492-496)
+            if (d > 1000 && d < 10000000) { last[0] = g1; push('V', g1, d); }
         } else if (kind == 2) {
             int64_t d = G2 - g1 - g2; if (d < 0) d = -d;
             last[1] = d;

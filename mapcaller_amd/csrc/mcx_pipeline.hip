@@ -21,11 +21,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/mcx.h"
 #include "mcx_dp.h"
-#include "mcx_fast.h"
 #include "mcx_profile.h"
 #include <hipcub/hipcub.hpp>
 #include "mcx_internal.h"
@@ -330,8 +330,6 @@ struct SeedOut {
     const uint32_t *packed;  // 2-bit reads of the batch (k_pack_reads), wpad words each
     int wpad;
     uint32_t *queue;         // next read of the pass that no wavefront has taken yet
-    Hit *fast_hits;          // the fused per-pair kernel's input: the first fast_cap seeds of every read, [read][fast_cap] (null: seeds go to the pair records)
-    int fast_cap;
 };
 
 // 16 bytes from any address: two aligned 16-byte fetches and a byte funnel
@@ -431,6 +429,150 @@ __global__ void __launch_bounds__(256) k_pack_reads(ReadBatch rb, int paired, in
     }
 }
 
+// ---- the FM steps of a wavefront, four lanes to an index block -----------------------------------------------------------
+// A lane that walks its own search fetches a 64-byte block of the index with four 16-byte loads, and the memory system sees 64
+// lanes x 4 requests to 64 different lines per step: dependent random 64-byte blocks come at 16.8 G/s that way and at 48 G/s
+// when four neighbouring lanes fetch 16 bytes each of one block (tools/ubench_gather modes 0 and 6: the second form with one
+// chain per lane, the addresses handed round the wave as below).  So the wave serves its lanes' extension steps together: the 64
+// requests (k, l, base) are transposed so that quad q of the wave holds the requests of lanes q, 16 + q, 32 + q, 48 + q, one per
+// lane; in round r the quad broadcasts request r among its lanes (DPP), each lane fetches its 16 bytes of the block(s), counts
+// the bases in the 32 symbols that fall to it (the occurrence words stay with the two lanes that fetched them), and the quad
+// adds up what the requester needs — tk[b], tl[b] - tk[b] and the sum over the bases above b — with two DPP exchanges.  Lane r of
+// the quad keeps round r's result, and one more transposition brings every result home.  Seven LDS permutes per step for the wave;
+// every block costs one 64-byte request instead of four 16-byte ones.
+template <int CTRL> static __device__ __forceinline__ uint32_t quad_mov(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+static __device__ __forceinline__ uint64_t quad_sum64(uint64_t v)
+{
+    uint64_t o = (uint64_t)quad_mov<0xB1>((uint32_t)v) | ((uint64_t)quad_mov<0xB1>((uint32_t)(v >> 32)) << 32); // lanes 1 0 3 2
+    v += o;
+    o = (uint64_t)quad_mov<0x4E>((uint32_t)v) | ((uint64_t)quad_mov<0x4E>((uint32_t)(v >> 32)) << 32);          // lanes 2 3 0 1
+    return v + o;
+}
+template <int R> static __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) { return quad_mov<R * 0x55>(v); } // every lane of the quad takes lane R's
+
+// bases among the first n symbols of a block that fall into this lane's two words (symbols 32 * part .. 32 * part + 31):
+// t = T's, ct = C's + T's, gt = G's + T's, ns = symbols counted
+static __device__ __forceinline__ void quad_count(uint32_t w0, uint32_t w1, int part, int n, uint32_t &t, uint32_t &ct, uint32_t &gt, uint32_t &ns)
+{
+    int m = n - 32 * part; m = m < 0 ? 0 : (m > 32 ? 32 : m); // symbols of mine inside the count
+    const int m0 = m > 16 ? 16 : m, m1 = m - m0;
+    const uint32_t k0 = m0 ? 0x55555555u & (0xFFFFFFFFu << (32 - 2 * m0)) : 0u, k1 = m1 ? 0x55555555u & (0xFFFFFFFFu << (32 - 2 * m1)) : 0u;
+    const uint32_t lo0 = w0 & k0, hi0 = (w0 >> 1) & k0, lo1 = w1 & k1, hi1 = (w1 >> 1) & k1;
+    t = (uint32_t)(__popc(hi0 & lo0) + __popc(hi1 & lo1));
+    ct = (uint32_t)(__popc(lo0) + __popc(lo1));
+    gt = (uint32_t)(__popc(hi0) + __popc(hi1));
+    ns = (uint32_t)m;
+}
+
+// One extension step for every lane with act set (its search holds the bi-interval w and extends by base c): BWT_Search's loop
+// body (bwt_search.cpp:134-151) with bwt_2occ4 (:68-99) done by the quads.  Returns with w moved on, or w.ended set when the
+// extension comes up empty.  Must be reached by the whole wave.
+static __device__ __forceinline__ void seed_fm_step_wave(const IndexView &ix, bool act, int c, SeedWalk &w, int64_t &blocks)
+{
+    const int lane = threadIdx.x & 63, part = lane & 3;
+    uint64_t k = w.x1 - 1, l = w.x1 - 1 + w.x2;
+    k -= (k >= ix.primary); l -= (l >= ix.primary);
+    const int b = 3 - c;
+    // the request, transposed: lane 4q + r receives that of lane 16r + q
+    const int tsrc = 16 * part + (lane >> 2);
+    const uint32_t q0 = (uint32_t)__shfl((int)(uint32_t)k, tsrc, 64), q1 = (uint32_t)__shfl((int)(uint32_t)l, tsrc, 64);
+    const uint32_t q2 = (uint32_t)__shfl((int)((uint32_t)((k >> 32) & 0xFF) | ((uint32_t)((l >> 32) & 0xFF) << 8) | ((uint32_t)b << 16) | (act ? 1u << 18 : 0u)), tsrc, 64);
+    const uint64_t am = __ballot(act);
+    const U4 *bwt4 = (const U4 *)ix.bwt;
+    U4 dk[4], dl[4];
+    auto fetch = [&](auto R, U4 &a, U4 &bb) { // round R: the quad's lanes fetch their quarters of the request's block(s)
+        constexpr int r = decltype(R)::value;
+        const uint32_t m = quad_bcast<r>(q2);
+        const uint64_t kk = (uint64_t)quad_bcast<r>(q0) | ((uint64_t)(m & 0xFF) << 32), ll = (uint64_t)quad_bcast<r>(q1) | ((uint64_t)((m >> 8) & 0xFF) << 32);
+        a.x = a.y = a.z = a.w = 0; bb = a;
+        if (m & (1u << 18)) {
+            a = bwt4[((kk >> 7) << 2) + part];
+            if ((ll >> 7) != (kk >> 7)) bb = bwt4[((ll >> 7) << 2) + part]; else bb = a;
+        }
+    };
+    // (every round's fetches are under way before the first is waited for)
+    if ((am >> 0) & 0xFFFF) fetch(std::integral_constant<int, 0>(), dk[0], dl[0]);
+    if ((am >> 16) & 0xFFFF) fetch(std::integral_constant<int, 1>(), dk[1], dl[1]);
+    if ((am >> 32) & 0xFFFF) fetch(std::integral_constant<int, 2>(), dk[2], dl[2]);
+    if ((am >> 48) & 0xFFFF) fetch(std::integral_constant<int, 3>(), dk[3], dl[3]);
+    uint64_t keep_tk = 0, keep_n2 = 0, keep_hs = 0;
+    auto serve = [&](auto R, const U4 &a, const U4 &bb) {
+        constexpr int r = decltype(R)::value;
+        const uint32_t m = quad_bcast<r>(q2);
+        const int nk = (int)(quad_bcast<r>(q0) & 127u) + 1, nl = (int)(quad_bcast<r>(q1) & 127u) + 1, rb = (int)((m >> 16) & 3u);
+        // this lane's two words of each block: lanes 2 and 3 of the quad hold the 128 symbols (x y z w each)
+        const uint32_t ax = quad_mov<0xFA>(a.x), ay = quad_mov<0xFA>(a.y), az = quad_mov<0xFA>(a.z), aw = quad_mov<0xFA>(a.w); // lanes 2 2 3 3
+        const uint32_t bx = quad_mov<0xFA>(bb.x), by = quad_mov<0xFA>(bb.y), bz = quad_mov<0xFA>(bb.z), bw = quad_mov<0xFA>(bb.w);
+        const bool odd = part & 1;
+        uint32_t tK, ctK, gtK, nsK, tL, ctL, gtL, nsL;
+        quad_count(odd ? az : ax, odd ? aw : ay, part, nk, tK, ctK, gtK, nsK);
+        quad_count(odd ? bz : bx, odd ? bw : by, part, nl, tL, ctL, gtL, nsL);
+        const int64_t pK[4] = {(int64_t)nsK - ctK - gtK + tK, (int64_t)ctK - tK, (int64_t)gtK - tK, (int64_t)tK};
+        const int64_t pL[4] = {(int64_t)nsL - ctL - gtL + tL, (int64_t)ctL - tL, (int64_t)gtL - tL, (int64_t)tL};
+        // the occurrence counts in front of the block: lane 0 of the quad holds those of A and C, lane 1 those of G and T
+        const uint64_t oK0 = (uint64_t)a.x | ((uint64_t)a.y << 32), oK1 = (uint64_t)a.z | ((uint64_t)a.w << 32);
+        const uint64_t oL0 = (uint64_t)bb.x | ((uint64_t)bb.y << 32), oL1 = (uint64_t)bb.z | ((uint64_t)bb.w << 32);
+        const int b0 = 2 * part, b1 = 2 * part + 1; // (meaningful for part < 2)
+        uint64_t ctk = (uint64_t)pK[0], cn2 = (uint64_t)(pL[0] - pK[0]), chs = 0;
+#pragma unroll
+        for (int x = 1; x < 4; x++) if (rb == x) { ctk = (uint64_t)pK[x]; cn2 = (uint64_t)(pL[x] - pK[x]); }
+#pragma unroll
+        for (int x = 1; x < 4; x++) if (x > rb) chs += (uint64_t)(pL[x] - pK[x]);
+        if (part < 2) {
+            if (rb == b0) { ctk += oK0; cn2 += oL0 - oK0; } else if (rb == b1) { ctk += oK1; cn2 += oL1 - oK1; }
+            if (b0 > rb) chs += oL0 - oK0;
+            if (b1 > rb) chs += oL1 - oK1;
+        }
+        const uint64_t s_tk = quad_sum64(ctk), s_n2 = quad_sum64(cn2), s_hs = quad_sum64(chs);
+        if (part == r) { keep_tk = s_tk; keep_n2 = s_n2; keep_hs = s_hs; }
+    };
+    if ((am >> 0) & 0xFFFF) serve(std::integral_constant<int, 0>(), dk[0], dl[0]);
+    if ((am >> 16) & 0xFFFF) serve(std::integral_constant<int, 1>(), dk[1], dl[1]);
+    if ((am >> 32) & 0xFFFF) serve(std::integral_constant<int, 2>(), dk[2], dl[2]);
+    if ((am >> 48) & 0xFFFF) serve(std::integral_constant<int, 3>(), dk[3], dl[3]);
+    // home: lane R takes what lane 4 (R & 15) + (R >> 4) kept
+    const int rsrc = 4 * (lane & 15) + (lane >> 4);
+    const uint32_t r0 = (uint32_t)__shfl((int)(uint32_t)keep_tk, rsrc, 64), r1 = (uint32_t)__shfl((int)(uint32_t)keep_n2, rsrc, 64), r2 = (uint32_t)__shfl((int)(uint32_t)keep_hs, rsrc, 64);
+    const uint32_t r3 = (uint32_t)__shfl((int)((uint32_t)((keep_tk >> 32) & 0xFF) | ((uint32_t)((keep_n2 >> 32) & 0xFF) << 8) | ((uint32_t)((keep_hs >> 32) & 0xFF) << 16)), rsrc, 64);
+    if (act) {
+        const uint64_t tkb = (uint64_t)r0 | ((uint64_t)(r3 & 0xFF) << 32), n2 = (uint64_t)r1 | ((uint64_t)((r3 >> 8) & 0xFF) << 32), hs = (uint64_t)r2 | ((uint64_t)((r3 >> 16) & 0xFF) << 32);
+        blocks += 1 + ((l >> 7) != (k >> 7) ? 1 : 0);
+        if (n2 == 0) w.ended = 1;
+        else {
+            const uint64_t n0 = w.x0 + ((w.x1 <= ix.primary && w.x1 + w.x2 - 1 >= ix.primary) ? 1 : 0) + hs; // ok[3].x0 + the bases above b (:143-146)
+            w.x0 = n0; w.x1 = ix.L2[b] + 1 + tkb; w.x2 = n2;
+        }
+    }
+}
+
+// phase 1 of the searches of a wave (seed_fm for all lanes together): up to max_steps extension steps, then the phase changes
+static __device__ __forceinline__ void seed_fm_wave(const IndexView &ix, bool mine, const PackedRead &pk, int rlen, int &p, SeedWalk &w, int64_t &blocks, int max_steps)
+{
+    for (int step = 0; step < max_steps; step++) {
+        bool act = mine && w.x2 != 1 && !w.ended;
+        int c = 0;
+        if (act) {
+            if (packed_nmask32(pk, p, rlen) & 0x80000000u) { w.ended = 1; act = false; } // N or read end
+            else c = (int)(packed_codes16(pk, p) >> 30);
+        }
+        if (!__ballot(act)) break;
+        seed_fm_step_wave(ix, act, c, w, blocks);
+        if (act && !w.ended) p++;
+    }
+    if (mine) {
+        if (w.ended) w.phase = 3;
+        else if (w.x2 == 1) { // exactly one suffix left: the rest of the search is a comparison with the text itself
+            int lf = 0;
+            w.tpos = (int64_t)fm_sa(ix, w.x0, lf);
+            w.carry = 0; w.carry_dir = 0;
+            w.phase = 2;
+        }
+    }
+}
+
 // Reads are handed to lanes as the lanes become free: a read is one to six searches (many more steps each inside a
 // repeat), and a wave whose lanes each owned one read would run as long as its longest read while most lanes idle.
 // The reads of a pass form one queue; a wavefront takes a chunk of it with one atomic whenever its lanes run dry, and a
@@ -443,7 +585,11 @@ static inline int seed_fm_budget() { static const int b = getenv("MCX_SEED_FM_BU
 
 static inline int seed_reads_per_lane(uint64_t n_reads) { return n_reads >= (uint64_t)1 << 21 ? kSeedReadsPerLane : (n_reads >= (uint64_t)1 << 19 ? 2 : 1); }
 
-__global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel, SeedOut so, int pk_words, int reads_per_lane, int fm_budget)
+#ifndef MCX_SEED_WAVES
+#define MCX_SEED_WAVES 1
+#endif
+template <bool QUAD>
+__global__ void __launch_bounds__(256, MCX_SEED_WAVES) k_seed(Ctx cx, ReadBatch rb, PairSel sel, SeedOut so, int pk_words, int reads_per_lane, int fm_budget)
 {
     extern __shared__ uint32_t pk_lds[]; // packed reads: word k of lane t at pk_lds[k * blockDim.x + t]
     const int nr = cx.pm.paired ? 2 : 1;
@@ -499,8 +645,7 @@ __global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel,
         if (fresh) {
             r = sel_pair(sel, lr / nr) * nr + lr % nr;
             rlen = (int)(rb.off[r + 1] - rb.off[r]);
-            if (so.fast_hits) { hits = so.fast_hits + (uint64_t)r * so.fast_cap; cap = so.fast_cap; }
-            else hits = pair_state(cx.state, cx.lay, cx.caps, lr / nr).hits[lr % nr];
+            hits = pair_state(cx.state, cx.lay, cx.caps, lr / nr).hits[lr % nr];
             n = 0; p = 0; ext = 0; blocks = 0; has_n = 0; walk.phase = 0;
             const int words = packed_words(rlen);
             if (rlen > 0 && words <= pk_words) {
@@ -531,7 +676,8 @@ __global__ void __launch_bounds__(256) k_seed(Ctx cx, ReadBatch rb, PairSel sel,
         // ---- every lane that holds a read moves its search on: each phase with a budget, so that a lane deep inside a repeat
         //      (dozens of FM steps) holds the wave up for a few steps at a time while the others finish searches and take new reads ----
         if (have && walk.phase == 0) seed_begin(cx.ix, pk, rlen, nm, p, walk);
-        if (have && walk.phase == 1) seed_fm(cx.ix, pk, rlen, p, walk, blocks, fm_budget);
+        if (QUAD) seed_fm_wave(cx.ix, have && walk.phase == 1, pk, rlen, p, walk, blocks, fm_budget);
+        else if (have && walk.phase == 1) seed_fm(cx.ix, pk, rlen, p, walk, blocks, fm_budget);
         if (have && walk.phase == 2) seed_compare(cx.ix, pk, rlen, p, walk, 1 << 30);
         if (have && walk.phase == 3) {
             seed_take(cx.ix, p, walk, hits, cap, n, ext);
@@ -940,7 +1086,7 @@ struct BatchRun { // the batch between mcx_batch_begin and mcx_batch_end
     ReadBatch rb; int paired = 0;
     uint32_t n_pairs = 0, n_chunks = 0;
     AlnRec *recs = nullptr; uint32_t *cig = nullptr; // records [n_reads]; the batch's CIGAR pool
-    uint32_t cig_cap = 0, cig_words = 0;             // its capacity (n_reads * MCX_CIGAR_STRIDE words) and, once the batch is closed, the words taken
+    uint32_t cig_cap = 0, cig_words = 0;             // its capacity (MCX_CIGAR_POOL_WORDS(n_reads)) and, once the batch is closed, the words taken
     int64_t read_base = 0, mapped = 0;
     unsigned long long hs[3] = {0, 0, 0};
     std::vector<uint32_t> ok, ds; // per chunk: proper pairs; summed distance, then summed read lengths
@@ -984,11 +1130,6 @@ struct mcx_ctx {
     uint64_t keys_cap = 0;       // keys the sort buffers hold
     uint64_t *h_keys = nullptr; uint64_t h_keys_cap = 0; // pinned: the batch's keys for the exchange between shards
     uint32_t *d_batch_flags = nullptr; // [0] words taken in the batch's CIGAR pool, [1] longest read of the batch, [2] the pool ran over
-    // the fused per-pair kernel (mcx_fast.h)
-    bool fast_on = false; FastCaps fcaps; size_t fast_lds = 0;
-    Hit *d_fast_hits = nullptr; uint32_t *d_spill = nullptr; uint32_t *h_spill = nullptr;
-    uint8_t *d_saved = nullptr; // parked slices: pairs waiting for the DP kernels
-    hipEvent_t ev_fast[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     BatchRun run;
     PassRes t1;               // the large tier's own set (the members above are tier 0's); allocated when every suffix-array entry is resident
     bool overlap_tiers = false;
@@ -1187,32 +1328,6 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
             c->overlap_late = true;
         }
     }
-    // the fused per-pair kernel: needs every suffix-array entry resident (seeds then leave k_seed as text positions)
-    // and a slice of LDS per lane that the read length decides (reads up to 16 x code_words bases take it)
-    if (idx->view.sa_full && getenv("MCX_FAST") && !getenv("MCX_NO_FAST")) {
-        const int fast_rlen = std::min(c->rlen_max, 160);
-        c->fcaps = make_fast_caps(fast_rlen, idx->view.n_ends, idx->view.n_chr);
-        if (const char *e = getenv("MCX_FAST_CAPS")) { // experiments: "hits,slots"
-            int a, b;
-            if (sscanf(e, "%d,%d", &a, &b) == 2) {
-                c->fcaps.hit_cap = a; c->fcaps.slots = b;
-                c->fcaps.stride = 2 * c->fcaps.cand_cap * (int)sizeof(Cand) + 2 * c->fcaps.code_words * 4 + 2 * c->fcaps.win_words * 4 + b * 16;
-                c->fcaps.stride = (c->fcaps.stride + 15) / 16 * 16;
-                if (((c->fcaps.stride / 16) & 1) == 0) { c->fcaps.stride += 16; c->fcaps.slots++; }
-            }
-        }
-        c->fast_lds = (size_t)c->fcaps.ends_bytes + (size_t)64 * c->fcaps.stride;
-        if (c->fast_lds <= 160 * 1024 - 256) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_pair_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fast_lds));
-            HIP_TRY(hipFuncSetAttribute((const void *)k_pair_fast_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fast_lds));
-            if ((rc = dmalloc(&c->d_saved, (size_t)(c->max_reads + 64) * (size_t)save_stride(c->fcaps)))) return rc; // (single reads: as many pairs as reads)
-            if ((rc = dmalloc(&c->d_fast_hits, c->max_reads * (uint64_t)c->fcaps.hit_cap))) return rc;
-            if ((rc = dmalloc(&c->d_spill, c->max_reads))) return rc;
-            HIP_TRY(hipHostMalloc((void **)&c->h_spill, c->max_reads * sizeof(uint32_t)));
-            for (auto &e : c->ev_fast) HIP_TRY(hipEventCreate(&e));
-            c->fast_on = true;
-        }
-    }
     return 0;
 }
 
@@ -1222,16 +1337,14 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3], c->d_jobs[4], c->d_jobs[5],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
                  c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
-                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_pout_sel, c->d_order, c->d_order_cnt, c->d_packed, c->d_batch_flags, c->d_fast_hits, c->d_spill, c->d_saved};
+                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_pout_sel, c->d_order, c->d_order_cnt, c->d_packed, c->d_batch_flags};
     for (void *q : p) if (q) (void)hipFree(q);
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
     if (c->h_keys) (void)hipHostFree(c->h_keys);
-    if (c->h_spill) (void)hipHostFree(c->h_spill);
     if (c->h_sparse_pin) (void)hipHostFree(c->h_sparse_pin);
     if (c->d_arch) (void)hipFree(c->d_arch);
     passres_free(c->t1); passres_free(c->t2);
     for (hipEvent_t e : {c->ev_clustered, c->ev_built, c->ev_late_done}) if (e) (void)hipEventDestroy(e);
-    for (auto &e : c->ev_fast) if (e) (void)hipEventDestroy(e);
     for (auto &sl : c->slot) {
         void *q[] = {sl.d_bases, sl.d_off, sl.d_recs, sl.d_cig};
         for (void *x : q) if (x) (void)hipFree(x);
@@ -1323,7 +1436,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     HIP_TRY(hipMemsetAsync(R.d_cnt, 0, CNT_N * sizeof(uint32_t), s));
     SeedOut so; so.tasks = R.d_tasks; so.n_tasks = R.d_cnt + CNT_TASKS; so.task_cap = R.task_cap;
     so.read_ext = c->d_read_ext; so.read_blocks = c->d_read_blocks;
-    so.packed = c->d_packed; so.wpad = c->wpad; so.fast_hits = nullptr; so.fast_cap = 0; so.queue = R.d_cnt + CNT_QUEUE;
+    so.packed = c->d_packed; so.wpad = c->wpad; so.queue = R.d_cnt + CNT_QUEUE;
     RescueList rl; rl.ids = R.d_rescue; rl.n = R.d_cnt + CNT_RESCUE; rl.cap = R.rescue_cap;
     EarlyList el; el.ids = nullptr; el.est = nullptr; el.n = R.d_cnt + CNT_EARLY; el.cap = 0;
     if (early) { el.ids = c->t1.d_sel_ids; el.est = c->t1.d_est; el.cap = (uint32_t)c->max_reads; }
@@ -1341,7 +1454,9 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         const int threads = pkw * 256 * 4 <= 48 * 1024 ? 256 : (pkw * 128 * 4 <= 48 * 1024 ? 128 : 64);
         const int rpl = seed_reads_per_lane((uint64_t)sel.n * nr);
         const unsigned blocks_s = std::min<unsigned>((sel.n * nr + threads * rpl - 1) / (threads * rpl), 4096u); // (the queue feeds whatever grid runs)
-        k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl, seed_fm_budget());
+        const bool quad = getenv("MCX_SEED_QUAD") != nullptr; // (experiments: the wave's FM steps four lanes to a block — measured slower)
+        if (quad) k_seed<true><<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl, seed_fm_budget());
+        else k_seed<false><<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl, seed_fm_budget());
     }
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     if (R.d_tasks) k_sa<<<4096, 256, 0, s>>>(cx, so, paired, R.d_cnt + CNT_LF);
@@ -1571,73 +1686,6 @@ extern "C" void mcx_avg_walk(int64_t st[3], const uint32_t *pairs, const uint32_
     st[0] = cur; st[1] = tp; st[2] = td;
 }
 
-// The first pass over a batch: seeding with the seeds laid out for the fused per-pair kernel, then that kernel
-// (mcx_fast.h).  spill receives the pairs it left for the general path, in pair order.
-static int run_fast(mcx_ctx *c, const ReadBatch &rb, int paired, int32_t est, uint32_t n_pairs, AlnRec *d_recs, mcx_stats *stats, std::vector<uint32_t> &spill,
-                    bool &all_general)
-{
-    all_general = false;
-    hipStream_t s = c->stream;
-    Ctx cx = make_ctx(c, 0, paired);
-    const int nr = paired ? 2 : 1;
-    HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
-    SeedOut so; so.tasks = c->d_tasks; so.n_tasks = c->d_cnt + CNT_TASKS; so.task_cap = c->task_cap;
-    so.read_ext = c->d_read_ext; so.read_blocks = c->d_read_blocks;
-    so.packed = c->d_packed; so.wpad = c->wpad; so.fast_hits = c->d_fast_hits; so.fast_cap = c->fcaps.hit_cap; so.queue = c->d_cnt + CNT_QUEUE;
-    PairSel sel; sel.n = n_pairs; sel.ids = nullptr; sel.est = nullptr;
-    HIP_TRY(hipEventRecord(c->ev_fast[0], s));
-    {
-        const int pkw = packed_words(c->rlen_max);
-        const int threads = pkw * 256 * 4 <= 48 * 1024 ? 256 : (pkw * 128 * 4 <= 48 * 1024 ? 128 : 64);
-        const int rpl = seed_reads_per_lane((uint64_t)n_pairs * nr);
-        const unsigned blocks_s = std::min<unsigned>((n_pairs * nr + threads * rpl - 1) / (threads * rpl), 4096u);
-        k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl, seed_fm_budget());
-    }
-    HIP_TRY(hipEventRecord(c->ev_fast[1], s));
-    FastIn in; in.hits = c->d_fast_hits; in.packed = c->d_packed; in.wpad = c->wpad; in.read_ext = c->d_read_ext; in.read_blocks = c->d_read_blocks; in.est = est;
-    JobSinks sinks;
-    for (int k = 0; k < kDpClasses; k++) { sinks.s[k].jobs = c->d_jobs[k]; sinks.s[k].count = c->d_cnt + CNT_JOB0 + k * kCntPad; sinks.s[k].cap = c->job_cap[k]; }
-    // pairs with gapped fragments park their slice of LDS in HBM (d_saved, their pair ids in d_sel_ids), the DP kernels of the
-    // general path align the fragments in the parked slices, k_pair_fast_finish takes them from there
-    k_pair_fast<<<(n_pairs + 63) / 64, 64, c->fast_lds, s>>>(cx, rb, in, c->fcaps, n_pairs, d_recs, c->d_pout, c->d_spill, c->d_cnt + CNT_OV, c->d_saved,
-                                                           c->d_sel_ids, c->d_cnt + CNT_RESCUE, sinks, c->d_cnt + CNT_CELLS, c->d_batch_flags + 2);
-    HIP_TRY(hipEventRecord(c->ev_fast[2], s));
-    {
-        Ctx cs = cx; // the parked slices as pair records: fragments at offset 0, column strings behind them
-        cs.state = c->d_saved; cs.lay = save_layout(c->fcaps); cs.dp_summary = 0; // (the fused kernel's record keeps no room for summaries)
-        cs.caps.hit_cap = c->fcaps.hit_cap; cs.caps.cand_cap = c->fcaps.cand_cap; cs.caps.frag_cap = c->fcaps.slots;
-        PairSel parked; parked.n = n_pairs; parked.ids = c->d_sel_ids; parked.est = nullptr;
-        int rc = launch_dp(res_tier0(c), cs, sinks, rb, parked);
-        if (rc) return rc;
-    }
-    HIP_TRY(hipEventRecord(c->ev_fast[3], s));
-    k_pair_fast_finish<<<(n_pairs + 63) / 64, 64, c->fast_lds, s>>>(cx, rb, c->fcaps, c->d_saved, c->d_cnt + CNT_RESCUE, d_recs, c->d_pout, c->d_batch_flags + 2);
-    HIP_TRY(hipEventRecord(c->ev_fast[4], s));
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    const uint32_t *cn = c->h_cnt;
-    for (int k = 0; k < kDpClasses; k++)
-        if (cn[CNT_JOB0 + k * kCntPad] > c->job_cap[k]) { all_general = true; spill.clear(); return 0; } // a job list ran over: the whole batch takes the general path
-    const uint32_t n_sp = cn[CNT_OV];
-    spill.resize(n_sp);
-    if (n_sp) {
-        HIP_TRY(hipMemcpy(c->h_spill, c->d_spill, (size_t)n_sp * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        spill.assign(c->h_spill, c->h_spill + n_sp);
-        std::sort(spill.begin(), spill.end()); // (listed with atomics: results do not depend on the order, the replay of a run should not either)
-    }
-    if (stats) {
-        float ms[4] = {0, 0, 0, 0};
-        for (int k = 0; k < 4; k++) HIP_TRY(hipEventElapsedTime(&ms[k], c->ev_fast[k], c->ev_fast[k + 1]));
-        stats->ms_seed += ms[0]; stats->ms_fast += ms[1] + ms[3]; stats->ms_dp += ms[2];
-        stats->fast_pairs += (int64_t)n_pairs - n_sp;
-        for (int k = 0; k < kDpClasses; k++) stats->dp_jobs += cn[CNT_JOB0 + k * kCntPad];
-        stats->dp_cells += cn[CNT_CELLS];
-    }
-    if (getenv("MCX_TIMING")) fprintf(stderr, "[run_fast] pairs %u: %u parked for the DP kernels, %u left for the general path\n", n_pairs, cn[CNT_RESCUE], n_sp);
-    return 0;
-}
-
 // runs the tiers for the pairs in `ids` (null: all pairs of the batch) with per-pair estimates
 __global__ void k_gather_pout(const PairOut *pout, const uint32_t *ids, uint32_t n, PairOut *out)
 {
@@ -1749,7 +1797,7 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
     br.rb.bases = d_bases; br.rb.off = d_off; br.rb.n_reads = n_reads;
     br.paired = paired; br.read_base = read_base;
     br.recs = (AlnRec *)d_aln; br.cig = d_cigar; br.stats = stats;
-    br.cig_cap = (uint32_t)std::min<uint64_t>((uint64_t)n_reads * MCX_CIGAR_STRIDE, 0xFFFFFFFFu); br.cig_words = 0;
+    br.cig_cap = (uint32_t)std::min<uint64_t>((uint64_t)MCX_CIGAR_POOL_WORDS(n_reads), 0xFFFFFFFFu); br.cig_words = 0;
     br.n_pairs = paired ? n_reads / 2 : n_reads;
     br.n_chunks = (br.n_pairs + kReadChunkSize / 2 - 1) / (kReadChunkSize / 2);
     br.mapped = 0; br.sums_valid = false;
@@ -1770,13 +1818,7 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
         HIP_TRY(hipEventRecord(c->ev_pack[1], s));
     }
     int rc;
-    if (c->fast_on) { // the common case in one kernel; what it leaves goes through the general path
-        std::vector<uint32_t> spill;
-        bool all_general = false;
-        if ((rc = run_fast(c, br.rb, paired, est0, br.n_pairs, br.recs, stats, spill, all_general))) return rc;
-        if (all_general) rc = run_selection(c, br.rb, paired, nullptr, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true);
-        else rc = spill.empty() ? 0 : run_selection(c, br.rb, paired, &spill, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true);
-    } else rc = run_selection(c, br.rb, paired, nullptr, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true);
+    rc = run_selection(c, br.rb, paired, nullptr, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true);
     if (rc) return rc;
     { // seeding statistics (E, blocks, H of SURVEY.md 8d) before the per-read arrays are reused for the chunk sums
         unsigned long long *d_sum = (unsigned long long *)c->d_cnt;
@@ -1860,7 +1902,7 @@ static int batch_close(mcx_ctx *c, mcx_stats *stats)
     {
         uint32_t fl[4] = {0, 0, 0, 0};
         HIP_TRY(hipMemcpy(fl, c->d_batch_flags, sizeof fl, hipMemcpyDeviceToHost));
-        if (fl[2] || fl[0] > br.cig_cap) return fail(MCX_ERR_CAPACITY, "the batch's CIGAR pool (" + std::to_string(MCX_CIGAR_STRIDE) + " operations per read on average) ran over");
+        if (fl[2] || fl[0] > br.cig_cap) return fail(MCX_ERR_CAPACITY, "the batch's CIGAR pool (" + std::to_string(MCX_CIGAR_STRIDE) + " operations per read on average + " + std::to_string(MCX_CIGAR_SLACK) + ") ran over");
         br.cig_words = fl[0];
     }
     if (stats) {
@@ -1962,7 +2004,7 @@ int mcx_stage_in(mcx_ctx *c, const uint8_t *bases, const uint32_t *off, uint32_t
         if ((rc = dmalloc(&c->d_bases, c->max_bases + 64))) return rc;
         if ((rc = dmalloc(&c->d_off, c->max_reads + 1))) return rc;
         if ((rc = dmalloc(&c->d_recs, c->max_reads))) return rc;
-        if ((rc = dmalloc(&c->d_cig, c->max_reads * MCX_CIGAR_STRIDE))) return rc;
+        if ((rc = dmalloc(&c->d_cig, MCX_CIGAR_POOL_WORDS(c->max_reads)))) return rc;
     }
     if (off[n_reads] > c->max_bases) return fail(MCX_ERR_ARG, "batch holds more bases than max_batch_reads * max_read_len");
     HIP_TRY(hipMemcpyAsync(c->d_bases, bases, off[n_reads], hipMemcpyHostToDevice, c->stream));
@@ -2048,7 +2090,7 @@ extern "C" int mcx_stream_submit(mcx_ctx *c, const uint8_t *bases, const uint32_
         if ((rc = dmalloc(&sl->d_bases, c->max_bases + 64))) return rc;
         if ((rc = dmalloc(&sl->d_off, c->max_reads + 1))) return rc;
         if ((rc = dmalloc(&sl->d_recs, c->max_reads))) return rc;
-        if ((rc = dmalloc(&sl->d_cig, c->max_reads * MCX_CIGAR_STRIDE))) return rc;
+        if ((rc = dmalloc(&sl->d_cig, MCX_CIGAR_POOL_WORDS(c->max_reads)))) return rc;
         HIP_TRY(hipEventCreateWithFlags(&sl->in_ready, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&sl->mapped, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&sl->out_done, hipEventDisableTiming));

@@ -37,8 +37,7 @@ struct IndexView {
     const uint32_t *bwt;
     const uint64_t *sa;      // sampled every sa_intv (sa[0] = ~0)
     const uint64_t *sa_full; // optional: every suffix-array entry (288 GB HBM makes room); may be null
-    const uint8_t *pac;      // forward genome, 2 bit/base, MSB first: byte i of the genome's .pac bytes at pac[i - pac_base]
-    int64_t pac_base = 0;    // 0 for the genome in HBM; a window of it held in LDS starts at this byte (mcx_fast.h) — ref_code only
+    const uint8_t *pac;      // forward genome, 2 bit/base, MSB first: the genome's .pac bytes
     const int64_t *end_pos;  // sorted chromosome end positions in [0,2G): PosChrIdMap keys
     const int32_t *end_chr;  // chromosome id of each end
     const int64_t *chr_fwd;  // FowardLocation per chromosome

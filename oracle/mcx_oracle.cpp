@@ -1358,8 +1358,8 @@ static void worker(Shared *sh)
                         Profile &pf = *sh->pf;
                         if (pd.g1 < ix.G && pd.g2 >= ix.G) {
                             i64 d = ix.G2 - pd.g1 - pd.g2; if (d < 0) d = -d;
-                            if (d > 1000 && d < 10000000) pf.inv.push_back({pd.g1, d});
-                            last_disc = {pd.g1, d};
+                            last_disc.dist = d; // (.dist always; .gPos only inside the range, :492-496)
+                            if (d > 1000 && d < 10000000) { last_disc.gPos = pd.g1; pf.inv.push_back(last_disc); }
                         } else if (pd.g1 >= ix.G && pd.g2 < ix.G) {
                             i64 d = ix.G2 - pd.g1 - pd.g2; if (d < 0) d = -d;
                             last_disc.dist = d;

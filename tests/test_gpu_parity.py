@@ -99,7 +99,7 @@ def test_overlapped_host_boundary_gives_the_same_records(api, golden, tmp_path):
         tb = torch.zeros(bb.size + 64, dtype=torch.uint8).pin_memory(); tb[:bb.size] = torch.from_numpy(bb)
         to = torch.from_numpy(oo.astype(np.int64)).to(torch.int32).pin_memory()  # same bits as uint32
         pinned.append((tb, to))
-    outs = [(torch.zeros(2 * n_pairs * 64, dtype=torch.uint8).pin_memory(), torch.zeros(2 * n_pairs * api.CIGAR_STRIDE, dtype=torch.int32).pin_memory()) for _ in range(per)]
+    outs = [(torch.zeros(2 * n_pairs * 64, dtype=torch.uint8).pin_memory(), torch.zeros(api.cigar_pool_words(2 * n_pairs), dtype=torch.int32).pin_memory()) for _ in range(per)]
     for i in range(per + 2):
         if i < per:
             assert L.mcx_stream_submit(mp._h, pinned[i][0].data_ptr(), pinned[i][1].data_ptr(), 2 * n_pairs) == 0, L.mcx_last_error()
@@ -116,29 +116,6 @@ def test_overlapped_host_boundary_gives_the_same_records(api, golden, tmp_path):
         for r in range(2 * n_pairs):
             assert np.array_equal(pool[aln["cigar_off"][r]:aln["cigar_off"][r] + aln["n_cigar"][r]], w_cig[r]), (b, r)
     mp.close(); ix.close()
-
-
-@pytest.mark.parametrize("name,alg", [("var", "nw"), ("toy", "ksw2"), ("se", "ksw2"), ("mc", "nw")])
-def test_fused_kernel_and_general_path_agree(api, golden, tmp_path, monkeypatch, name, alg):
-    """The experimental fused per-pair kernel (MCX_FAST=1: k_pair_fast, pair state in LDS, for the pairs that fit it; the
-    general path for the rest) against the default, where every pair takes the general path: the reference's SAM either way."""
-    g = golden[name]
-    for fast in ("1", ""):
-        if fast:
-            monkeypatch.setenv("MCX_FAST", fast)
-        else:
-            monkeypatch.delenv("MCX_FAST", raising=False)
-        ix = api.Index(g["prefix"], device=0, full_sa=True)
-        mp = api.Mapper(ix, alg=alg, max_batch_reads=1 << 14)
-        out = str(tmp_path / f"gpu{fast}.sam")
-        st = mp.map_files(g["r1"], g["r2"], out)
-        if fast:
-            assert st["fast_pairs"] > 0.5 * st["reads"] / (2 if g["r2"] else 1), st  # the fused kernel did take the bulk
-        else:
-            assert st["fast_pairs"] == 0
-        nd, ex = sam_diff(g["sam"][alg], out)
-        assert nd == 0, (fast, ex)
-        mp.close(); ix.close()
 
 
 def test_small_batches_follow_the_avgdist_trajectory(api, golden, tmp_path):

@@ -5,6 +5,8 @@
 // modes: 0 lane-per-block 4 x 16 B   1 same, non-temporal   2 four lanes per block (one 16 B load each)
 //        3 lane-per-block, 128-B blocks (8 x 16 B)            4 lane-per-block, first 32 B only
 //        5 two independent chains per lane (ILP)
+//        6 one chain per lane, served by the wave four lanes per block: four rounds of 16 requests, the address pulled from
+//          the requesting lane and the result pushed back with ds_bpermute (what k_seed's FM step would do)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -51,6 +53,26 @@ __global__ void __launch_bounds__(256) k_chase(const U4 *buf, uint64_t n_blocks,
             U4 a = *p;
             uint32_t v = a.x ^ a.w;
             v ^= __shfl_xor(v, 1, 64); v ^= __shfl_xor(v, 2, 64);
+            acc += v; s = mix(s, v);
+        } else if (MODE == 6) {
+            const int lane = threadIdx.x & 63;
+            const uint64_t blk = s % n_blocks;
+            const uint32_t blo = (uint32_t)blk, bhi = (uint32_t)(blk >> 32);
+            U4 d[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) { // all four rounds' fetches are issued before any is waited for
+                const int src = 16 * r + (lane >> 2);
+                const uint64_t b = (uint64_t)(uint32_t)__shfl((int)blo, src, 64) | ((uint64_t)(uint32_t)__shfl((int)bhi, src, 64) << 32);
+                d[r] = buf[b * 4 + (lane & 3)];
+            }
+            uint32_t v = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                uint32_t t = d[r].x ^ d[r].w;
+                t ^= __shfl_xor((int)t, 1, 64); t ^= __shfl_xor((int)t, 2, 64);
+                const uint32_t got = (uint32_t)__shfl((int)t, 4 * (lane & 15), 64); // the requester takes its quad's result
+                if ((lane >> 4) == r) v = got;
+            }
             acc += v; s = mix(s, v);
         } else if (MODE == 3) {
             const U4 *p = buf + (s % (n_blocks / 2)) * 8;
@@ -100,6 +122,7 @@ int main(int argc, char **argv)
         run<3>(buf, n_blocks, steps, out, blocks, "3 lane-per-128B-block 8x16B", 128);
         run<4>(buf, n_blocks, steps, out, blocks, "4 lane-per-block first 32B only", 32);
         run<5>(buf, n_blocks, steps, out, blocks, "5 two chains per lane 4x16B", 64);
+        run<6>(buf, n_blocks, steps, out, blocks, "6 lane-per-chain, quad-served in 4 rounds", 64);
     }
     return 0;
 }
