@@ -32,47 +32,119 @@ static inline MCX_HD void fm_load_block(const uint32_t *bwt, uint64_t blk, FmBlo
     b.w[4] = e.x; b.w[5] = e.y; b.w[6] = e.z; b.w[7] = e.w;
 }
 
-// keep-mask of word j for a count over the first n (1..128) symbols: words before the one that
-// holds symbol n-1 are kept whole, that word keeps its top `rem` symbols, later words nothing
-static inline MCX_HD uint32_t fm_word_mask(int j, int q, uint32_t last_mask)
+// The blocks in HBM are a *derived* form of the file's: the file keeps each occurrence count in a u64 of which 34 bits are ever
+// used, and a count over the first n symbols of a block walks up to eight words.  fm_derive_block puts, into the unused top 24
+// bits of every count, how many of that base the block's first 32, 64 and 96 symbols hold (8 bits each): a count is then the
+// stored count + one of those + a popcount over the two words of the 32-symbol stretch that holds symbol n - 1 — a quarter of
+// the vector instructions, which is what the seeding kernel is short of.  Same block size, same fetches, same results; the files
+// written by mcx_index_save carry the plain counts again (fm_plain_count).
+constexpr uint64_t kFmCountMask = (1ull << 40) - 1;
+static inline MCX_HD uint64_t fm_plain_count(uint64_t v) { return v & kFmCountMask; }
+
+static inline MCX_HD void fm_derive_block(uint32_t *blk) // the 16 words of one block, in place (idempotent)
 {
-    return j < q ? 0x55555555u : (j == q ? last_mask : 0u);
+    uint32_t cnt[4] = {0, 0, 0, 0}, at[3][4];
+    for (int j = 0; j < 6; j++) { // the first 96 symbols
+        const uint32_t w = blk[8 + j];
+        const uint32_t lo = w & 0x55555555u, hi = (w >> 1) & 0x55555555u;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t t = (uint32_t)__popc(hi & lo), c = (uint32_t)__popc(lo), g = (uint32_t)__popc(hi);
+#else
+        const uint32_t t = (uint32_t)__builtin_popcount(hi & lo), c = (uint32_t)__builtin_popcount(lo), g = (uint32_t)__builtin_popcount(hi);
+#endif
+        cnt[0] += 16 - c - g + t; cnt[1] += c - t; cnt[2] += g - t; cnt[3] += t;
+        if (j & 1) for (int x = 0; x < 4; x++) at[j >> 1][x] = cnt[x];
+    }
+    for (int x = 0; x < 4; x++) {
+        const uint32_t hi = (blk[2 * x + 1] & 0xFFu) | (at[0][x] << 8) | (at[1][x] << 16) | (at[2][x] << 24);
+        blk[2 * x + 1] = hi;
+    }
+}
+
+// the two words of the 32-symbol stretch q of a block, masked to its first m (1..32) symbols: low bits and high bits of the symbols
+static inline MCX_HD void fm_stretch(const FmBlock &b, int q, int m, uint32_t &lo0, uint32_t &hi0, uint32_t &lo1, uint32_t &hi1)
+{
+    // (values first, then the choice: a conditional between array elements is a conditional between addresses, and a block
+    //  addressed by a run-time index lives in scratch memory instead of registers)
+    const uint32_t a0 = b.w[0], a1 = b.w[1], a2 = b.w[2], a3 = b.w[3], a4 = b.w[4], a5 = b.w[5], a6 = b.w[6], a7 = b.w[7];
+    const uint32_t w0 = q == 0 ? a0 : q == 1 ? a2 : q == 2 ? a4 : a6;
+    const uint32_t w1 = q == 0 ? a1 : q == 1 ? a3 : q == 2 ? a5 : a7;
+    const int m0 = m > 16 ? 16 : m, m1 = m - m0;
+    const uint32_t k0 = 0x55555555u & (0xFFFFFFFFu << (32 - 2 * m0)), k1 = m1 ? 0x55555555u & (0xFFFFFFFFu << (32 - 2 * m1)) : 0u;
+    lo0 = w0 & k0; hi0 = (w0 >> 1) & k0; lo1 = w1 & k1; hi1 = (w1 >> 1) & k1;
+}
+
+// the count stored for base c at the start of stretch q: the block's count + what the stretches before q hold
+static inline MCX_HD uint64_t fm_stretch_base(uint64_t occ, int q)
+{
+    const uint32_t top = (uint32_t)(occ >> 32); // bits 0-7: the count's bits 32-39; 8-15, 16-23, 24-31: symbols 0-31, 0-63, 0-95
+    const uint32_t before = q ? (top >> (8 * q)) & 0xFFu : 0u;
+    return (occ & kFmCountMask) + before;
+}
+
+static inline MCX_HD int fm_popc(uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popc(v);
+#else
+    return __builtin_popcount(v);
+#endif
 }
 
 // occurrences of each base among the first n (1..128) symbols of the block, added to occ[]
 static inline MCX_HD void fm_count4(const FmBlock &b, int n, uint64_t cnt[4])
 {
-    const int q = (n - 1) >> 4, rem = ((n - 1) & 15) + 1;
-    const uint32_t last_mask = 0x55555555u & (0xFFFFFFFFu << (32 - 2 * rem));
-    uint32_t t = 0, ct = 0, gt = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const uint32_t mask = fm_word_mask(j, q, last_mask);
-        const uint32_t lo = b.w[j] & mask, hi = (b.w[j] >> 1) & mask;
-        t += (uint32_t)__builtin_popcount(hi & lo);
-        ct += (uint32_t)__builtin_popcount(lo);
-        gt += (uint32_t)__builtin_popcount(hi);
-    }
-    cnt[0] = b.occ[0] + ((uint32_t)n - ct - gt + t);
-    cnt[1] = b.occ[1] + (ct - t);
-    cnt[2] = b.occ[2] + (gt - t);
-    cnt[3] = b.occ[3] + t;
+    const int q = (n - 1) >> 5, m = n - 32 * q;
+    uint32_t lo0, hi0, lo1, hi1;
+    fm_stretch(b, q, m, lo0, hi0, lo1, hi1);
+    const uint32_t t = (uint32_t)(fm_popc(hi0 & lo0) + fm_popc(hi1 & lo1)), ct = (uint32_t)(fm_popc(lo0) + fm_popc(lo1)), gt = (uint32_t)(fm_popc(hi0) + fm_popc(hi1));
+    cnt[0] = fm_stretch_base(b.occ[0], q) + ((uint32_t)m - ct - gt + t);
+    cnt[1] = fm_stretch_base(b.occ[1], q) + (ct - t);
+    cnt[2] = fm_stretch_base(b.occ[2], q) + (gt - t);
+    cnt[3] = fm_stretch_base(b.occ[3], q) + t;
 }
 
 // occurrences of base c among the first n symbols (bwt_occ, bwt_search.cpp:25-47)
 static inline MCX_HD uint64_t fm_count1(const FmBlock &b, int n, int c)
 {
-    const int q = (n - 1) >> 4, rem = ((n - 1) & 15) + 1;
-    const uint32_t last_mask = 0x55555555u & (0xFFFFFFFFu << (32 - 2 * rem));
-    uint32_t s = 0;
-    const uint32_t xlo = (c & 1) ? 0u : 0xFFFFFFFFu, xhi = (c & 2) ? 0u : 0xFFFFFFFFu;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const uint32_t mask = fm_word_mask(j, q, last_mask);
-        const uint32_t lo = b.w[j] ^ xlo, hi = (b.w[j] >> 1) ^ xhi;
-        s += (uint32_t)__builtin_popcount(lo & hi & mask);
+    const int q = (n - 1) >> 5, m = n - 32 * q;
+    uint32_t lo0, hi0, lo1, hi1;
+    fm_stretch(b, q, m, lo0, hi0, lo1, hi1);
+    const uint32_t t = (uint32_t)(fm_popc(hi0 & lo0) + fm_popc(hi1 & lo1)), ct = (uint32_t)(fm_popc(lo0) + fm_popc(lo1)), gt = (uint32_t)(fm_popc(hi0) + fm_popc(hi1));
+    const uint32_t pc = c == 0 ? (uint32_t)m - ct - gt + t : c == 1 ? ct - t : c == 2 ? gt - t : t;
+    const uint64_t o0 = b.occ[0], o1 = b.occ[1], o2 = b.occ[2], o3 = b.occ[3];
+    const uint64_t occ = c == 0 ? o0 : c == 1 ? o1 : c == 2 ? o2 : o3;
+    return fm_stretch_base(occ, q) + pc;
+}
+
+// ---- rank records: the index as the seeding walk wants it ----------------------------------------------------------------
+// BWT_Search extends by ONE known base b per step and needs three numbers of bwt_2occ4's eight: occ(k, b), occ(l, b) - occ(k, b)
+// and the summed occ(l, c) - occ(k, c) over the bases c > b (bwt_search.cpp:134-151).  For every base b and every 32 BWT symbols
+// one 16-byte record holds exactly what those take: a bit per symbol "is b", a bit per symbol "is greater than b", and the number
+// of either among all symbols before the record (32 bits each; the one place where such a number passes 2^32 is kept beside the
+// tables).  A step is then one 16-byte fetch per end of the interval — two lane fetches where the .bwt block form takes eight —
+// and two masked popcounts per end.  The numbers are the same numbers: a derived layout (12 GB for a 3.1 Gbp genome), never a
+// different result.  Symbol s of a record is bit 31 - s.
+struct alignas(16) RankChunk { uint32_t eq, gt, n_eq, n_gt; };
+
+// even bits (0, 2, .. 30) of t, packed into 16 (bit 2i -> bit i)
+static inline MCX_HD uint32_t fm_even16(uint32_t t)
+{
+    t &= 0x55555555u; t = (t | (t >> 1)) & 0x33333333u; t = (t | (t >> 2)) & 0x0f0f0f0fu; t = (t | (t >> 4)) & 0x00ff00ffu;
+    return (t | (t >> 8)) & 0xffffu;
+}
+
+// the four records (one per base) of the 32 symbols in words w0, w1 of a block, given the counts of the four bases before them
+static inline MCX_HD void fm_rank_records(uint32_t w0, uint32_t w1, const uint64_t before[4], RankChunk out[4], uint64_t n_eq[4], uint64_t n_gt[4])
+{
+    const uint32_t L = (fm_even16(w0) << 16) | fm_even16(w1), H = (fm_even16(w0 >> 1) << 16) | fm_even16(w1 >> 1); // symbol s at bit 31 - s
+    const uint32_t eq[4] = {~H & ~L, ~H & L, H & ~L, H & L}, gt[4] = {H | L, H, H & L, 0u};
+    for (int b = 0; b < 4; b++) {
+        uint64_t above = 0;
+        for (int c = b + 1; c < 4; c++) above += before[c];
+        n_eq[b] = before[b]; n_gt[b] = above;
+        out[b].eq = eq[b]; out[b].gt = gt[b]; out[b].n_eq = (uint32_t)before[b]; out[b].n_gt = (uint32_t)above;
     }
-    return b.occ[c] + s;
 }
 
 // bwt_2occ4 (bwt_search.cpp:68-99) for k < l, neither equal to (u64)-1 — which is what
@@ -407,17 +479,38 @@ static inline MCX_HD void seed_fm(const IndexView &ix, const PackedRead &pk, int
         const uint32_t nm2 = packed_nmask32(pk, p, rlen);
         if (nm2 & 0x80000000u) { w.ended = 1; break; } // N or read end
         const int c = (int)(packed_codes16(pk, p) >> 30);
-        uint64_t tk[4], tl[4];
-        int nb;
-        fm_2occ4(ix, w.x1 - 1, w.x1 - 1 + w.x2, tk, tl, nb);
-        blocks += nb;
         const int b = 3 - c;
-        const uint64_t n2 = tl[b] - tk[b];
+        uint64_t tkb, n2, above; // occ(k, b); occ(l, b) - occ(k, b); the same difference summed over the bases above b
+        if (ix.rank) {
+            uint64_t k = w.x1 - 1, l = w.x1 - 1 + w.x2;
+            k -= (k >= ix.primary); l -= (l >= ix.primary);
+            const RankChunk *R = (const RankChunk *)ix.rank + (uint64_t)b * ix.rank_chunks;
+            const uint64_t ck = k >> 5, cl = l >> 5;
+            const RankChunk rk = R[ck];
+            RankChunk rl = rk;
+            if (cl != ck) rl = R[cl];
+            blocks += cl != ck ? 2 : 1;
+            const uint64_t x0 = ix.rank_cross[0], x1 = ix.rank_cross[1], x2 = ix.rank_cross[2], x3 = ix.rank_cross[3];
+            const uint64_t y0 = ix.rank_cross[4], y1 = ix.rank_cross[5], y2 = ix.rank_cross[6], y3 = ix.rank_cross[7];
+            const uint64_t xe = b == 0 ? x0 : b == 1 ? x1 : b == 2 ? x2 : x3, xg = b == 0 ? y0 : b == 1 ? y1 : b == 2 ? y2 : y3;
+            const uint32_t mk = 0xFFFFFFFFu << (31 - (int)(k & 31)), ml = 0xFFFFFFFFu << (31 - (int)(l & 31));
+            const uint64_t ek = (uint64_t)rk.n_eq + (uint32_t)fm_popc(rk.eq & mk) + (ck >= xe ? 1ull << 32 : 0ull);
+            const uint64_t el = (uint64_t)rl.n_eq + (uint32_t)fm_popc(rl.eq & ml) + (cl >= xe ? 1ull << 32 : 0ull);
+            const uint64_t gk = (uint64_t)rk.n_gt + (uint32_t)fm_popc(rk.gt & mk) + (ck >= xg ? 1ull << 32 : 0ull);
+            const uint64_t gl = (uint64_t)rl.n_gt + (uint32_t)fm_popc(rl.gt & ml) + (cl >= xg ? 1ull << 32 : 0ull);
+            tkb = ek; n2 = el - ek; above = gl - gk;
+        } else {
+            uint64_t tk[4], tl[4];
+            int nb;
+            fm_2occ4(ix, w.x1 - 1, w.x1 - 1 + w.x2, tk, tl, nb);
+            blocks += nb;
+            tkb = tk[b]; n2 = tl[b] - tk[b]; above = 0;
+            for (int bb = 3; bb > b; bb--) above += tl[bb] - tk[bb];
+        }
         if (n2 == 0) { w.ended = 1; break; }
         // ok[3].x0 = ik.x0 + primary correction; lower bases stack on top (:143-146)
-        uint64_t n0 = w.x0 + ((w.x1 <= ix.primary && w.x1 + w.x2 - 1 >= ix.primary) ? 1 : 0);
-        for (int bb = 3; bb > b; bb--) n0 += tl[bb] - tk[bb];
-        w.x0 = n0; w.x1 = ix.L2[b] + 1 + tk[b]; w.x2 = n2;
+        const uint64_t n0 = w.x0 + ((w.x1 <= ix.primary && w.x1 + w.x2 - 1 >= ix.primary) ? 1 : 0) + above;
+        w.x0 = n0; w.x1 = ix.L2[b] + 1 + tkb; w.x2 = n2;
         p++;
     }
     if (w.ended) w.phase = 3;
@@ -470,6 +563,60 @@ static inline MCX_HD void seed_compare(const IndexView &ix, const PackedRead &pk
     }
 }
 
+// The same phase with 64 bases of the genome per fetch instead of 16: two aligned 16-byte chunks of the 2-bit genome (128 bases)
+// hold the next 64 text positions wherever they begin, so a seed of 150 bases is confirmed in three dependent fetches, not ten —
+// and it is dependent fetches that the seeding kernel's time is made of.  Stretches that touch the strand boundary or the end
+// of the text take seed_compare's single windows.  Same comparisons, same p.
+static inline MCX_HD void seed_compare_wide(const IndexView &ix, const PackedRead &pk, int rlen, int &p, SeedWalk &w, int max_fetches)
+{
+    for (int k = 0; k < max_fetches; k++) {
+        const int64_t j = w.tpos + (p - w.start);
+        const bool fwd = j + 64 <= ix.G, rev = j >= ix.G && j + 64 <= ix.G2;
+        if (!fwd && !rev) {
+            w.carry_dir = 0;
+            seed_compare(ix, pk, rlen, p, w, 1);
+            if (w.phase == 3) return;
+            continue;
+        }
+        const int64_t f_lo = fwd ? j : ix.G2 - 64 - j;   // the forward stretch [f_lo, f_lo + 64) under the 64 text positions
+        const U4 *src = (const U4 *)ix.pac + (f_lo >> 6);
+        const U4 a = src[0], b = src[1];
+        const int oq = (int)(f_lo & 63) >> 4, sh = (int)(f_lo & 15) * 2;
+        const uint32_t W0 = __builtin_bswap32(a.x), W1 = __builtin_bswap32(a.y), W2 = __builtin_bswap32(a.z), W3 = __builtin_bswap32(a.w);
+        const uint32_t W4 = __builtin_bswap32(b.x), W5 = __builtin_bswap32(b.y), W6 = __builtin_bswap32(b.z), W7 = __builtin_bswap32(b.w);
+        uint32_t V[5]; // the five words the stretch lies in
+        V[0] = oq == 0 ? W0 : oq == 1 ? W1 : oq == 2 ? W2 : W3;
+        V[1] = oq == 0 ? W1 : oq == 1 ? W2 : oq == 2 ? W3 : W4;
+        V[2] = oq == 0 ? W2 : oq == 1 ? W3 : oq == 2 ? W4 : W5;
+        V[3] = oq == 0 ? W3 : oq == 1 ? W4 : oq == 2 ? W5 : W6;
+        V[4] = oq == 0 ? W4 : oq == 1 ? W5 : oq == 2 ? W6 : W7;
+        MCX_UNROLL
+        for (int t = 0; t < 4; t++) {
+            const int64_t jj = w.tpos + (p - w.start); // (= j + 16 t: every window before this one was whole)
+            int64_t room = (int64_t)ix.seq_len - jj;
+            if (rlen - p < room) room = rlen - p;
+            if (room <= 0) { w.phase = 3; return; }
+            const uint32_t vh = fwd ? V[t] : V[3 - t], vl = fwd ? V[t + 1] : V[4 - t]; // text window t is forward window 3 - t on the reverse strand, mirrored
+            uint32_t ref = sh ? (vh << sh) | (vl >> (32 - sh)) : vh;
+            if (!fwd) {
+                uint32_t v = __builtin_bswap32(ref);
+                v = ((v & 0x0F0F0F0Fu) << 4) | ((v >> 4) & 0x0F0F0F0Fu);
+                v = ((v & 0x33333333u) << 2) | ((v >> 2) & 0x33333333u);
+                ref = ~v;
+            }
+            const uint32_t x = packed_codes16(pk, p) ^ ref;
+            uint32_t sp = packed_nmask32(pk, p, rlen) >> 16; // N flags, bit 15-s -> bit 30-2s
+            sp = (sp | (sp << 8)) & 0x00FF00FFu; sp = (sp | (sp << 4)) & 0x0F0F0F0Fu;
+            sp = (sp | (sp << 2)) & 0x33333333u; sp = (sp | (sp << 1)) & 0x55555555u;
+            const uint32_t mm = ((x | (x >> 1)) & 0x55555555u) | sp;
+            int same = mm ? (__builtin_clz(mm) >> 1) : 16;
+            if (same > room) same = (int)room;
+            p += same;
+            if (same < 16) { w.phase = 3; return; }
+        }
+    }
+}
+
 // phase 3 -> 0: the search is over — its hits (BWT_Search's len >= MinSeedLength && freq <= OCC_Thr), p at the next candidate start
 static inline MCX_HD void seed_take(const IndexView &ix, int &p, SeedWalk &w, Hit *hits, int cap, int &n_hits, int64_t &ext_steps)
 {
@@ -482,8 +629,29 @@ static inline MCX_HD void seed_take(const IndexView &ix, int &p, SeedWalk &w, Hi
         if (w.x2 == 1 && !w.ended) {
             if (n_hits < cap) { Hit h; h.gPos = w.tpos; h.rPos = w.start; h.len = direct ? len : (len | kHitResolved); hits[n_hits] = h; }
             n_hits++;
+        } else if (direct) {
+            // the rows of the interval lie side by side in the suffix array: fetched as 16-byte pairs, four pairs at a time, every
+            // fetch of a round issued before the first hit is stored (row by row each fetch would wait for the store before it:
+            // a chain of up to fifty round trips in one lane, with the rest of the wave looking on)
+            const U4 *pairs = (const U4 *)ix.sa_full;
+            const uint64_t end = w.x0 + w.x2;
+            for (uint64_t c = w.x0 >> 1; 2 * c < end; c += 4) {
+                U4 v0 = pairs[c], v1 = v0, v2 = v0, v3 = v0;
+                if (2 * (c + 1) < end) v1 = pairs[c + 1];
+                if (2 * (c + 2) < end) v2 = pairs[c + 2];
+                if (2 * (c + 3) < end) v3 = pairs[c + 3];
+                const uint64_t row[8] = {(uint64_t)v0.x | ((uint64_t)v0.y << 32), (uint64_t)v0.z | ((uint64_t)v0.w << 32), (uint64_t)v1.x | ((uint64_t)v1.y << 32), (uint64_t)v1.z | ((uint64_t)v1.w << 32),
+                                         (uint64_t)v2.x | ((uint64_t)v2.y << 32), (uint64_t)v2.z | ((uint64_t)v2.w << 32), (uint64_t)v3.x | ((uint64_t)v3.y << 32), (uint64_t)v3.z | ((uint64_t)v3.w << 32)};
+                MCX_UNROLL
+                for (int t = 0; t < 8; t++) {
+                    const uint64_t r = 2 * c + (uint64_t)t;
+                    if (r < w.x0 || r >= end) continue;
+                    if (n_hits < cap) { Hit h; h.gPos = (int64_t)row[t]; h.rPos = w.start; h.len = len; hits[n_hits] = h; }
+                    n_hits++;
+                }
+            }
         } else for (uint64_t i = 0; i < w.x2; i++) {
-            if (n_hits < cap) { Hit h; h.gPos = direct ? (int64_t)ix.sa_full[w.x0 + i] : (int64_t)(w.x0 + i); h.rPos = w.start; h.len = len; hits[n_hits] = h; }
+            if (n_hits < cap) { Hit h; h.gPos = (int64_t)(w.x0 + i); h.rPos = w.start; h.len = len; hits[n_hits] = h; }
             n_hits++;
         }
     }
@@ -498,7 +666,7 @@ static inline MCX_HD void seed_search(const IndexView &ix, const PackedRead &pk,
     SeedWalk w;
     seed_begin(ix, pk, rlen, nm, p, w);
     while (w.phase == 1) seed_fm(ix, pk, rlen, p, w, blocks, 1 << 30);
-    while (w.phase == 2) seed_compare(ix, pk, rlen, p, w, 1 << 30);
+    while (w.phase == 2) seed_compare_wide(ix, pk, rlen, p, w, 1 << 30);
     seed_take(ix, p, w, hits, cap, n_hits, ext_steps);
 }
 

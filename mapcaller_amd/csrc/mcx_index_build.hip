@@ -379,7 +379,7 @@ int mcx_build_suffix_index(const uint8_t *d_fwd, uint64_t G, bool want_full_sa, 
     (void)hipFree(key); (void)hipFree(rank); (void)hipFree(key_alt); (void)hipFree(val_alt); (void)hipFree(head); // room for the full suffix array
     out.n_sa = (N + 32) / 32;
     HIP_TRYB(hipMalloc(&out.sa, out.n_sa * 8));
-    if (want_full_sa) HIP_TRYB(hipMalloc(&out.sa_full, (N + 1) * 8));
+    if (want_full_sa) HIP_TRYB(hipMalloc(&out.sa_full, (N + 1) * 8 + 16)); // (+16: rows are fetched in pairs, seed_take)
     k_sample_sa<<<grid, block>>>(SA, N, 32, out.n_sa, out.sa, out.sa_full);
     HIP_TRYB(hipGetLastError());
     HIP_TRYB(hipEventRecord(e1));

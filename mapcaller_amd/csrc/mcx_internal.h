@@ -11,7 +11,7 @@ struct mcx_index {
     mcx::HostIndex host;
     int device = 0;
     void *d_bwt = nullptr, *d_sa = nullptr, *d_sa_full = nullptr, *d_pac = nullptr;
-    void *d_end_pos = nullptr, *d_end_chr = nullptr, *d_chr_fwd = nullptr, *d_ktab = nullptr;
+    void *d_end_pos = nullptr, *d_end_chr = nullptr, *d_chr_fwd = nullptr, *d_ktab = nullptr, *d_rank = nullptr;
     int64_t hbm_bytes = 0;
     uint64_t n_bwt_words = 0, n_sa = 0; // set for indexes built in HBM (mcx_index_from_codes)
 };

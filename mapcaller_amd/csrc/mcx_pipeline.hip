@@ -76,6 +76,22 @@ __global__ void k_expand_sa(IndexView ix, uint64_t n_sa, uint64_t *full)
     }
 }
 
+// the derived form of the index blocks (mcx_fm.h fm_derive_block): one thread per block that holds symbols
+__global__ void k_derive_bwt(uint32_t *bwt, uint64_t n_blocks)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_blocks) fm_derive_block(bwt + (i << 4));
+}
+
+static int derive_bwt(mcx_index *ix)
+{
+    const uint64_t n_blocks = (ix->host.seq_len + 127) / 128;
+    k_derive_bwt<<<(unsigned)((n_blocks + 255) / 256), 256>>>((uint32_t *)ix->d_bwt, n_blocks);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
 __global__ void k_build_ktab(IndexView ix, int K, U4 *tab)
 {
     const uint64_t n = 1ull << (2 * K);
@@ -88,6 +104,7 @@ __global__ void k_build_ktab(IndexView ix, int K, U4 *tab)
 
 // the K-mer jump table of the seeding walk (mcx_fm.h): 16 bytes per K-mer, K from the text length
 // (MCX_KTAB_K overrides it for experiments)
+static int build_rank(mcx_index *ix);
 static int build_ktab(mcx_index *ix)
 {
     int K = ktab_k_for(ix->view.seq_len);
@@ -100,6 +117,50 @@ static int build_ktab(mcx_index *ix)
     e = hipDeviceSynchronize();
     if (e != hipSuccess) { g_err = std::string("k_build_ktab: ") + hipGetErrorString(e); return MCX_ERR_DEVICE; }
     ix->view.ktab = (const uint32_t *)ix->d_ktab;
+    ix->hbm_bytes += (int64_t)bytes;
+    return build_rank(ix);
+}
+
+// the rank records of the seeding walk (mcx_fm.h RankChunk): one thread per .bwt block, four records per base
+__global__ void k_build_rank(const uint32_t *bwt, uint64_t n_blocks, uint64_t n_chunks, RankChunk *rank, unsigned long long *cross)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_blocks) return;
+    const uint32_t *blk = bwt + (i << 4);
+    uint64_t before[4];
+    for (int c = 0; c < 4; c++) before[c] = fm_plain_count((uint64_t)blk[2 * c] | ((uint64_t)blk[2 * c + 1] << 32));
+    for (int q = 0; q < 4; q++) {
+        const uint64_t chunk = 4 * i + q;
+        if (chunk >= n_chunks) break;
+        RankChunk out[4];
+        uint64_t ne[4], ng[4];
+        fm_rank_records(blk[8 + 2 * q], blk[9 + 2 * q], before, out, ne, ng);
+        for (int b = 0; b < 4; b++) {
+            rank[(uint64_t)b * n_chunks + chunk] = out[b];
+            if (ne[b] >> 32) atomicMin(&cross[b], (unsigned long long)chunk);
+            if (ng[b] >> 32) atomicMin(&cross[4 + b], (unsigned long long)chunk);
+            before[b] += (uint64_t)__popc(out[b].eq);
+        }
+    }
+}
+
+static int build_rank(mcx_index *ix)
+{
+    if (!ix->view.sa_full || getenv("MCX_NO_RANK")) return 0; // (the walk then counts in the .bwt blocks: MCX_NO_RANK for experiments)
+    const uint64_t n_blocks = (ix->host.seq_len + 127) / 128, n_chunks = (ix->host.seq_len + 31) / 32;
+    const size_t bytes = (size_t)4 * n_chunks * sizeof(RankChunk) + 64;
+    unsigned long long *d_cross = nullptr, h_cross[8];
+    for (auto &x : h_cross) x = ~0ull;
+    hipError_t e = hipMalloc(&ix->d_rank, bytes);
+    if (e != hipSuccess) { g_err = std::string("hipMalloc(rank records): ") + hipGetErrorString(e); return MCX_ERR_DEVICE; }
+    HIP_TRY(hipMalloc((void **)&d_cross, sizeof h_cross));
+    HIP_TRY(hipMemcpy(d_cross, h_cross, sizeof h_cross, hipMemcpyHostToDevice));
+    k_build_rank<<<(unsigned)((n_blocks + 255) / 256), 256>>>((const uint32_t *)ix->d_bwt, n_blocks, n_chunks, (RankChunk *)ix->d_rank, d_cross);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(h_cross, d_cross, sizeof h_cross, hipMemcpyDeviceToHost));
+    (void)hipFree(d_cross);
+    ix->view.rank = ix->d_rank; ix->view.rank_chunks = n_chunks;
+    for (int k = 0; k < 8; k++) ix->view.rank_cross[k] = h_cross[k];
     ix->hbm_bytes += (int64_t)bytes;
     return 0;
 }
@@ -124,16 +185,17 @@ static int index_to_device(mcx_index *ix, int full_sa)
     if ((rc = upload(&ix->d_end_chr, h.end_chr.data(), h.end_chr.size() * 4, 0, ix->hbm_bytes))) return rc;
     if ((rc = upload(&ix->d_chr_fwd, h.chr_fwd.data(), h.chr_fwd.size() * 8, 0, ix->hbm_bytes))) return rc;
     IndexView &v = ix->view;
-    v.bwt = (const uint32_t *)ix->d_bwt; v.sa = (const uint64_t *)ix->d_sa; v.sa_full = nullptr; v.ktab = nullptr; v.ktab_k = 0;
+    v.bwt = (const uint32_t *)ix->d_bwt; v.sa = (const uint64_t *)ix->d_sa; v.sa_full = nullptr; v.ktab = nullptr; v.ktab_k = 0; v.rank = nullptr; v.rank_chunks = 0; for (auto &x : v.rank_cross) x = ~0ull;
     v.pac = (const uint8_t *)ix->d_pac;
     v.end_pos = (const int64_t *)ix->d_end_pos; v.end_chr = (const int32_t *)ix->d_end_chr;
     v.chr_fwd = (const int64_t *)ix->d_chr_fwd;
     v.primary = h.primary; for (int i = 0; i < 5; i++) v.L2[i] = h.L2[i];
     v.seq_len = h.seq_len; v.G = h.G; v.G2 = 2 * h.G;
     v.n_ends = (int32_t)h.end_pos.size(); v.n_chr = (int32_t)h.chr_len.size(); v.sa_intv = h.sa_intv;
+    if ((rc = derive_bwt(ix))) return rc;
     if (full_sa) {
         size_t bytes = (size_t)(h.seq_len + 1) * 8;
-        HIP_TRY(hipMalloc(&ix->d_sa_full, bytes));
+        HIP_TRY(hipMalloc(&ix->d_sa_full, bytes + 16)); // (+16: rows are fetched in pairs, seed_take)
         ix->hbm_bytes += (int64_t)bytes;
         uint64_t n_sa = h.sa.size();
         k_expand_sa<<<(unsigned)((n_sa + 255) / 256), 256>>>(v, n_sa, (uint64_t *)ix->d_sa_full);
@@ -213,13 +275,14 @@ static int index_from_arrays(mcx_index *ix, const DevIndexArrays &arr, const uin
     if ((rc = upload(&ix->d_chr_fwd, h.chr_fwd.data(), h.chr_fwd.size() * 8, 0, acc))) return rc;
     ix->hbm_bytes += acc + G / 4 + 32;
     IndexView &v = ix->view;
-    v.bwt = (const uint32_t *)ix->d_bwt; v.sa = (const uint64_t *)ix->d_sa; v.sa_full = (const uint64_t *)ix->d_sa_full; v.ktab = nullptr; v.ktab_k = 0;
+    v.bwt = (const uint32_t *)ix->d_bwt; v.sa = (const uint64_t *)ix->d_sa; v.sa_full = (const uint64_t *)ix->d_sa_full; v.ktab = nullptr; v.ktab_k = 0; v.rank = nullptr; v.rank_chunks = 0; for (auto &x : v.rank_cross) x = ~0ull;
     v.pac = (const uint8_t *)ix->d_pac;
     v.end_pos = (const int64_t *)ix->d_end_pos; v.end_chr = (const int32_t *)ix->d_end_chr; v.chr_fwd = (const int64_t *)ix->d_chr_fwd;
     v.primary = h.primary; for (int i = 0; i < 5; i++) v.L2[i] = h.L2[i];
     v.seq_len = h.seq_len; v.G = h.G; v.G2 = 2 * h.G;
     v.n_ends = (int32_t)h.end_pos.size(); v.n_chr = (int32_t)h.chr_len.size(); v.sa_intv = 32;
     HIP_TRY(hipDeviceSynchronize());
+    if ((rc = derive_bwt(ix))) return rc;
     return build_ktab(ix);
 }
 
@@ -234,6 +297,10 @@ extern "C" int mcx_index_save(const mcx_index *ix, const char *prefix)
     std::string p(prefix);
     std::vector<uint32_t> words(ix->n_bwt_words);
     HIP_TRY(hipMemcpy(words.data(), ix->d_bwt, words.size() * 4, hipMemcpyDeviceToHost));
+    { // the file holds the plain counts (the blocks in HBM carry sub-block counts in their top bits: fm_derive_block)
+        const uint64_t n_blocks = (h.seq_len + 127) / 128;
+        for (uint64_t i = 0; i < n_blocks && i * 16 + 8 <= words.size(); i++) for (int x = 0; x < 4; x++) words[i * 16 + 2 * x + 1] &= 0xFFu;
+    }
     FILE *f = fopen((p + ".bwt").c_str(), "wb");
     if (!f) return fail(MCX_ERR_IO, "cannot write " + p + ".bwt");
     fwrite(&h.primary, 8, 1, f); fwrite(h.L2 + 1, 8, 4, f); fwrite(words.data(), 4, words.size(), f); fclose(f);
@@ -269,7 +336,7 @@ extern "C" int mcx_index_save(const mcx_index *ix, const char *prefix)
 extern "C" void mcx_index_free(mcx_index *ix)
 {
     if (!ix) return;
-    void *p[] = {ix->d_bwt, ix->d_sa, ix->d_sa_full, ix->d_pac, ix->d_end_pos, ix->d_end_chr, ix->d_chr_fwd, ix->d_ktab};
+    void *p[] = {ix->d_bwt, ix->d_sa, ix->d_sa_full, ix->d_pac, ix->d_end_pos, ix->d_end_chr, ix->d_chr_fwd, ix->d_ktab, ix->d_rank};
     for (void *q : p) if (q) (void)hipFree(q);
     delete ix;
 }
@@ -429,150 +496,6 @@ __global__ void __launch_bounds__(256) k_pack_reads(ReadBatch rb, int paired, in
     }
 }
 
-// ---- the FM steps of a wavefront, four lanes to an index block -----------------------------------------------------------
-// A lane that walks its own search fetches a 64-byte block of the index with four 16-byte loads, and the memory system sees 64
-// lanes x 4 requests to 64 different lines per step: dependent random 64-byte blocks come at 16.8 G/s that way and at 48 G/s
-// when four neighbouring lanes fetch 16 bytes each of one block (tools/ubench_gather modes 0 and 6: the second form with one
-// chain per lane, the addresses handed round the wave as below).  So the wave serves its lanes' extension steps together: the 64
-// requests (k, l, base) are transposed so that quad q of the wave holds the requests of lanes q, 16 + q, 32 + q, 48 + q, one per
-// lane; in round r the quad broadcasts request r among its lanes (DPP), each lane fetches its 16 bytes of the block(s), counts
-// the bases in the 32 symbols that fall to it (the occurrence words stay with the two lanes that fetched them), and the quad
-// adds up what the requester needs — tk[b], tl[b] - tk[b] and the sum over the bases above b — with two DPP exchanges.  Lane r of
-// the quad keeps round r's result, and one more transposition brings every result home.  Seven LDS permutes per step for the wave;
-// every block costs one 64-byte request instead of four 16-byte ones.
-template <int CTRL> static __device__ __forceinline__ uint32_t quad_mov(uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
-}
-static __device__ __forceinline__ uint64_t quad_sum64(uint64_t v)
-{
-    uint64_t o = (uint64_t)quad_mov<0xB1>((uint32_t)v) | ((uint64_t)quad_mov<0xB1>((uint32_t)(v >> 32)) << 32); // lanes 1 0 3 2
-    v += o;
-    o = (uint64_t)quad_mov<0x4E>((uint32_t)v) | ((uint64_t)quad_mov<0x4E>((uint32_t)(v >> 32)) << 32);          // lanes 2 3 0 1
-    return v + o;
-}
-template <int R> static __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) { return quad_mov<R * 0x55>(v); } // every lane of the quad takes lane R's
-
-// bases among the first n symbols of a block that fall into this lane's two words (symbols 32 * part .. 32 * part + 31):
-// t = T's, ct = C's + T's, gt = G's + T's, ns = symbols counted
-static __device__ __forceinline__ void quad_count(uint32_t w0, uint32_t w1, int part, int n, uint32_t &t, uint32_t &ct, uint32_t &gt, uint32_t &ns)
-{
-    int m = n - 32 * part; m = m < 0 ? 0 : (m > 32 ? 32 : m); // symbols of mine inside the count
-    const int m0 = m > 16 ? 16 : m, m1 = m - m0;
-    const uint32_t k0 = m0 ? 0x55555555u & (0xFFFFFFFFu << (32 - 2 * m0)) : 0u, k1 = m1 ? 0x55555555u & (0xFFFFFFFFu << (32 - 2 * m1)) : 0u;
-    const uint32_t lo0 = w0 & k0, hi0 = (w0 >> 1) & k0, lo1 = w1 & k1, hi1 = (w1 >> 1) & k1;
-    t = (uint32_t)(__popc(hi0 & lo0) + __popc(hi1 & lo1));
-    ct = (uint32_t)(__popc(lo0) + __popc(lo1));
-    gt = (uint32_t)(__popc(hi0) + __popc(hi1));
-    ns = (uint32_t)m;
-}
-
-// One extension step for every lane with act set (its search holds the bi-interval w and extends by base c): BWT_Search's loop
-// body (bwt_search.cpp:134-151) with bwt_2occ4 (:68-99) done by the quads.  Returns with w moved on, or w.ended set when the
-// extension comes up empty.  Must be reached by the whole wave.
-static __device__ __forceinline__ void seed_fm_step_wave(const IndexView &ix, bool act, int c, SeedWalk &w, int64_t &blocks)
-{
-    const int lane = threadIdx.x & 63, part = lane & 3;
-    uint64_t k = w.x1 - 1, l = w.x1 - 1 + w.x2;
-    k -= (k >= ix.primary); l -= (l >= ix.primary);
-    const int b = 3 - c;
-    // the request, transposed: lane 4q + r receives that of lane 16r + q
-    const int tsrc = 16 * part + (lane >> 2);
-    const uint32_t q0 = (uint32_t)__shfl((int)(uint32_t)k, tsrc, 64), q1 = (uint32_t)__shfl((int)(uint32_t)l, tsrc, 64);
-    const uint32_t q2 = (uint32_t)__shfl((int)((uint32_t)((k >> 32) & 0xFF) | ((uint32_t)((l >> 32) & 0xFF) << 8) | ((uint32_t)b << 16) | (act ? 1u << 18 : 0u)), tsrc, 64);
-    const uint64_t am = __ballot(act);
-    const U4 *bwt4 = (const U4 *)ix.bwt;
-    U4 dk[4], dl[4];
-    auto fetch = [&](auto R, U4 &a, U4 &bb) { // round R: the quad's lanes fetch their quarters of the request's block(s)
-        constexpr int r = decltype(R)::value;
-        const uint32_t m = quad_bcast<r>(q2);
-        const uint64_t kk = (uint64_t)quad_bcast<r>(q0) | ((uint64_t)(m & 0xFF) << 32), ll = (uint64_t)quad_bcast<r>(q1) | ((uint64_t)((m >> 8) & 0xFF) << 32);
-        a.x = a.y = a.z = a.w = 0; bb = a;
-        if (m & (1u << 18)) {
-            a = bwt4[((kk >> 7) << 2) + part];
-            if ((ll >> 7) != (kk >> 7)) bb = bwt4[((ll >> 7) << 2) + part]; else bb = a;
-        }
-    };
-    // (every round's fetches are under way before the first is waited for)
-    if ((am >> 0) & 0xFFFF) fetch(std::integral_constant<int, 0>(), dk[0], dl[0]);
-    if ((am >> 16) & 0xFFFF) fetch(std::integral_constant<int, 1>(), dk[1], dl[1]);
-    if ((am >> 32) & 0xFFFF) fetch(std::integral_constant<int, 2>(), dk[2], dl[2]);
-    if ((am >> 48) & 0xFFFF) fetch(std::integral_constant<int, 3>(), dk[3], dl[3]);
-    uint64_t keep_tk = 0, keep_n2 = 0, keep_hs = 0;
-    auto serve = [&](auto R, const U4 &a, const U4 &bb) {
-        constexpr int r = decltype(R)::value;
-        const uint32_t m = quad_bcast<r>(q2);
-        const int nk = (int)(quad_bcast<r>(q0) & 127u) + 1, nl = (int)(quad_bcast<r>(q1) & 127u) + 1, rb = (int)((m >> 16) & 3u);
-        // this lane's two words of each block: lanes 2 and 3 of the quad hold the 128 symbols (x y z w each)
-        const uint32_t ax = quad_mov<0xFA>(a.x), ay = quad_mov<0xFA>(a.y), az = quad_mov<0xFA>(a.z), aw = quad_mov<0xFA>(a.w); // lanes 2 2 3 3
-        const uint32_t bx = quad_mov<0xFA>(bb.x), by = quad_mov<0xFA>(bb.y), bz = quad_mov<0xFA>(bb.z), bw = quad_mov<0xFA>(bb.w);
-        const bool odd = part & 1;
-        uint32_t tK, ctK, gtK, nsK, tL, ctL, gtL, nsL;
-        quad_count(odd ? az : ax, odd ? aw : ay, part, nk, tK, ctK, gtK, nsK);
-        quad_count(odd ? bz : bx, odd ? bw : by, part, nl, tL, ctL, gtL, nsL);
-        const int64_t pK[4] = {(int64_t)nsK - ctK - gtK + tK, (int64_t)ctK - tK, (int64_t)gtK - tK, (int64_t)tK};
-        const int64_t pL[4] = {(int64_t)nsL - ctL - gtL + tL, (int64_t)ctL - tL, (int64_t)gtL - tL, (int64_t)tL};
-        // the occurrence counts in front of the block: lane 0 of the quad holds those of A and C, lane 1 those of G and T
-        const uint64_t oK0 = (uint64_t)a.x | ((uint64_t)a.y << 32), oK1 = (uint64_t)a.z | ((uint64_t)a.w << 32);
-        const uint64_t oL0 = (uint64_t)bb.x | ((uint64_t)bb.y << 32), oL1 = (uint64_t)bb.z | ((uint64_t)bb.w << 32);
-        const int b0 = 2 * part, b1 = 2 * part + 1; // (meaningful for part < 2)
-        uint64_t ctk = (uint64_t)pK[0], cn2 = (uint64_t)(pL[0] - pK[0]), chs = 0;
-#pragma unroll
-        for (int x = 1; x < 4; x++) if (rb == x) { ctk = (uint64_t)pK[x]; cn2 = (uint64_t)(pL[x] - pK[x]); }
-#pragma unroll
-        for (int x = 1; x < 4; x++) if (x > rb) chs += (uint64_t)(pL[x] - pK[x]);
-        if (part < 2) {
-            if (rb == b0) { ctk += oK0; cn2 += oL0 - oK0; } else if (rb == b1) { ctk += oK1; cn2 += oL1 - oK1; }
-            if (b0 > rb) chs += oL0 - oK0;
-            if (b1 > rb) chs += oL1 - oK1;
-        }
-        const uint64_t s_tk = quad_sum64(ctk), s_n2 = quad_sum64(cn2), s_hs = quad_sum64(chs);
-        if (part == r) { keep_tk = s_tk; keep_n2 = s_n2; keep_hs = s_hs; }
-    };
-    if ((am >> 0) & 0xFFFF) serve(std::integral_constant<int, 0>(), dk[0], dl[0]);
-    if ((am >> 16) & 0xFFFF) serve(std::integral_constant<int, 1>(), dk[1], dl[1]);
-    if ((am >> 32) & 0xFFFF) serve(std::integral_constant<int, 2>(), dk[2], dl[2]);
-    if ((am >> 48) & 0xFFFF) serve(std::integral_constant<int, 3>(), dk[3], dl[3]);
-    // home: lane R takes what lane 4 (R & 15) + (R >> 4) kept
-    const int rsrc = 4 * (lane & 15) + (lane >> 4);
-    const uint32_t r0 = (uint32_t)__shfl((int)(uint32_t)keep_tk, rsrc, 64), r1 = (uint32_t)__shfl((int)(uint32_t)keep_n2, rsrc, 64), r2 = (uint32_t)__shfl((int)(uint32_t)keep_hs, rsrc, 64);
-    const uint32_t r3 = (uint32_t)__shfl((int)((uint32_t)((keep_tk >> 32) & 0xFF) | ((uint32_t)((keep_n2 >> 32) & 0xFF) << 8) | ((uint32_t)((keep_hs >> 32) & 0xFF) << 16)), rsrc, 64);
-    if (act) {
-        const uint64_t tkb = (uint64_t)r0 | ((uint64_t)(r3 & 0xFF) << 32), n2 = (uint64_t)r1 | ((uint64_t)((r3 >> 8) & 0xFF) << 32), hs = (uint64_t)r2 | ((uint64_t)((r3 >> 16) & 0xFF) << 32);
-        blocks += 1 + ((l >> 7) != (k >> 7) ? 1 : 0);
-        if (n2 == 0) w.ended = 1;
-        else {
-            const uint64_t n0 = w.x0 + ((w.x1 <= ix.primary && w.x1 + w.x2 - 1 >= ix.primary) ? 1 : 0) + hs; // ok[3].x0 + the bases above b (:143-146)
-            w.x0 = n0; w.x1 = ix.L2[b] + 1 + tkb; w.x2 = n2;
-        }
-    }
-}
-
-// phase 1 of the searches of a wave (seed_fm for all lanes together): up to max_steps extension steps, then the phase changes
-static __device__ __forceinline__ void seed_fm_wave(const IndexView &ix, bool mine, const PackedRead &pk, int rlen, int &p, SeedWalk &w, int64_t &blocks, int max_steps)
-{
-    for (int step = 0; step < max_steps; step++) {
-        bool act = mine && w.x2 != 1 && !w.ended;
-        int c = 0;
-        if (act) {
-            if (packed_nmask32(pk, p, rlen) & 0x80000000u) { w.ended = 1; act = false; } // N or read end
-            else c = (int)(packed_codes16(pk, p) >> 30);
-        }
-        if (!__ballot(act)) break;
-        seed_fm_step_wave(ix, act, c, w, blocks);
-        if (act && !w.ended) p++;
-    }
-    if (mine) {
-        if (w.ended) w.phase = 3;
-        else if (w.x2 == 1) { // exactly one suffix left: the rest of the search is a comparison with the text itself
-            int lf = 0;
-            w.tpos = (int64_t)fm_sa(ix, w.x0, lf);
-            w.carry = 0; w.carry_dir = 0;
-            w.phase = 2;
-        }
-    }
-}
-
 // Reads are handed to lanes as the lanes become free: a read is one to six searches (many more steps each inside a
 // repeat), and a wave whose lanes each owned one read would run as long as its longest read while most lanes idle.
 // The reads of a pass form one queue; a wavefront takes a chunk of it with one atomic whenever its lanes run dry, and a
@@ -581,15 +504,17 @@ static __device__ __forceinline__ void seed_fm_wave(const IndexView &ix, bool mi
 constexpr int kSeedReadsPerLane = 4; // reads per lane and chunk (small selections: one, their launch is as long as its longest chain of reads)
 
 // FM steps a lane takes before the wave looks at its other lanes again (MCX_SEED_FM_BUDGET for experiments)
-static inline int seed_fm_budget() { static const int b = getenv("MCX_SEED_FM_BUDGET") ? std::max(1, atoi(getenv("MCX_SEED_FM_BUDGET"))) : 6; return b; }
+static inline int seed_fm_budget() { const char *e = getenv("MCX_SEED_FM_BUDGET"); return e ? std::max(1, atoi(e)) : 6; }
 
 static inline int seed_reads_per_lane(uint64_t n_reads) { return n_reads >= (uint64_t)1 << 21 ? kSeedReadsPerLane : (n_reads >= (uint64_t)1 << 19 ? 2 : 1); }
 
 #ifndef MCX_SEED_WAVES
 #define MCX_SEED_WAVES 1
 #endif
-template <bool QUAD>
-__global__ void __launch_bounds__(256, MCX_SEED_WAVES) k_seed(Ctx cx, ReadBatch rb, PairSel sel, SeedOut so, int pk_words, int reads_per_lane, int fm_budget)
+#ifdef MCX_SEED_STATS
+__device__ unsigned long long g_seed_hist[2][24]; // reads / index blocks by blocks per read (bucket = bit length of the count)
+#endif
+__global__ void __launch_bounds__(256, MCX_SEED_WAVES) k_seed(Ctx cx, ReadBatch rb, PairSel sel, SeedOut so, int pk_words, int reads_per_lane, int fm_budget, int wide)
 {
     extern __shared__ uint32_t pk_lds[]; // packed reads: word k of lane t at pk_lds[k * blockDim.x + t]
     const int nr = cx.pm.paired ? 2 : 1;
@@ -608,6 +533,9 @@ __global__ void __launch_bounds__(256, MCX_SEED_WAVES) k_seed(Ctx cx, ReadBatch 
     int cap = cx.caps.hit_seed;
     auto finish_read = [&]() {
         so.read_ext[r] = (uint32_t)ext | (has_n << 31); so.read_blocks[r] = (uint32_t)blocks | ((uint32_t)n << 20); // (ext < 2^31; blocks < 2^20; n < 2^12)
+#ifdef MCX_SEED_STATS
+        { const int bk = blocks ? 64 - __clzll((unsigned long long)blocks) : 0; atomicAdd(&g_seed_hist[0][bk], 1ull); atomicAdd(&g_seed_hist[1][bk], (unsigned long long)blocks); }
+#endif
         if (cx.ix.sa_full) return; // every hit already carries its text position (seed_search)
         const int keep = n <= cx.caps.hit_seed ? n : 0; // overflowing reads are re-run in the next tier
         int todo = 0;
@@ -676,9 +604,8 @@ __global__ void __launch_bounds__(256, MCX_SEED_WAVES) k_seed(Ctx cx, ReadBatch 
         // ---- every lane that holds a read moves its search on: each phase with a budget, so that a lane deep inside a repeat
         //      (dozens of FM steps) holds the wave up for a few steps at a time while the others finish searches and take new reads ----
         if (have && walk.phase == 0) seed_begin(cx.ix, pk, rlen, nm, p, walk);
-        if (QUAD) seed_fm_wave(cx.ix, have && walk.phase == 1, pk, rlen, p, walk, blocks, fm_budget);
-        else if (have && walk.phase == 1) seed_fm(cx.ix, pk, rlen, p, walk, blocks, fm_budget);
-        if (have && walk.phase == 2) seed_compare(cx.ix, pk, rlen, p, walk, 1 << 30);
+        if (have && walk.phase == 1) seed_fm(cx.ix, pk, rlen, p, walk, blocks, fm_budget);
+        if (have && walk.phase == 2) { if (wide) seed_compare_wide(cx.ix, pk, rlen, p, walk, 1 << 30); else seed_compare(cx.ix, pk, rlen, p, walk, 1 << 30); }
         if (have && walk.phase == 3) {
             seed_take(cx.ix, p, walk, hits, cap, n, ext);
             if (!seed_next_start(pk, rlen, p, nm)) { finish_read(); have = false; }
@@ -1454,9 +1381,21 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         const int threads = pkw * 256 * 4 <= 48 * 1024 ? 256 : (pkw * 128 * 4 <= 48 * 1024 ? 128 : 64);
         const int rpl = seed_reads_per_lane((uint64_t)sel.n * nr);
         const unsigned blocks_s = std::min<unsigned>((sel.n * nr + threads * rpl - 1) / (threads * rpl), 4096u); // (the queue feeds whatever grid runs)
-        const bool quad = getenv("MCX_SEED_QUAD") != nullptr; // (experiments: the wave's FM steps four lanes to a block — measured slower)
-        if (quad) k_seed<true><<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl, seed_fm_budget());
-        else k_seed<false><<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl, seed_fm_budget());
+        k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl, seed_fm_budget(), getenv("MCX_SEED_NARROW") ? 0 : 1);
+#ifdef MCX_SEED_STATS
+        if (tier == 0 && sel.n > 100000) {
+            unsigned long long h[2][24];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_seed_hist), sizeof h);
+            fprintf(stderr, "[k_seed] index blocks per read, by bit length of the count: reads");
+            for (int k = 0; k < 12; k++) fprintf(stderr, " %llu", h[0][k]);
+            fprintf(stderr, " | blocks");
+            for (int k = 0; k < 12; k++) fprintf(stderr, " %llu", h[1][k]);
+            fprintf(stderr, "\n");
+            memset(h, 0, sizeof h);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_seed_hist), h, sizeof h);
+        }
+#endif
     }
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     if (R.d_tasks) k_sa<<<4096, 256, 0, s>>>(cx, so, paired, R.d_cnt + CNT_LF);

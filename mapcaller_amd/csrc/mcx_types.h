@@ -43,6 +43,11 @@ struct IndexView {
     const int64_t *chr_fwd;  // FowardLocation per chromosome
     const uint32_t *ktab;    // optional: bi-interval of every ktab_k-mer (32 B each: x0, x1, x2, pad), x2 = 0 if absent
     int32_t ktab_k;
+    // optional (derived at load, mcx_fm.h RankChunk): per base b and 32 BWT symbols one 16-byte record {which symbols equal b, which
+    // are greater, how many of either came before}: an extension step of the seeding walk is then two 16-byte fetches, not eight
+    const void *rank;        // [4][rank_chunks] records; null: the walk counts in the .bwt blocks
+    uint64_t rank_chunks;
+    uint64_t rank_cross[8];  // [b]: first chunk whose "equal" count before it is >= 2^32 (the records keep 32 bits); [4 + b]: same for "greater"
     uint64_t primary, L2[5], seq_len;
     int64_t G, G2;
     int32_t n_ends, n_chr, sa_intv;

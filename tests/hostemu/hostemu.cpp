@@ -38,12 +38,13 @@ static void set_view(Emu &e)
 {
     IndexView &v = e.view;
     HostIndex &h = e.hix;
+    for (uint64_t i = 0; i < (h.seq_len + 127) / 128; i++) fm_derive_block(h.bwt.data() + (i << 4)); // the blocks as the kernels see them
     v.bwt = h.bwt.data(); v.sa = h.sa.data(); v.sa_full = nullptr; v.pac = h.pac.data();
     v.end_pos = h.end_pos.data(); v.end_chr = h.end_chr.data(); v.chr_fwd = h.chr_fwd.data();
     v.primary = h.primary; for (int i = 0; i < 5; i++) v.L2[i] = h.L2[i];
     v.seq_len = h.seq_len; v.G = h.G; v.G2 = 2 * h.G;
     v.n_ends = (int)h.end_pos.size(); v.n_chr = (int)h.chr_len.size(); v.sa_intv = h.sa_intv;
-    v.ktab = nullptr; v.ktab_k = 0;
+    v.ktab = nullptr; v.ktab_k = 0; v.rank = nullptr; v.rank_chunks = 0;
     const int K = 7;
     e.ktab.assign((size_t)4 << (2 * K), 0);
     for (uint32_t i = 0; i < (1u << (2 * K)); i++) {
