@@ -768,6 +768,249 @@ __global__ void __launch_bounds__(kRescueThreads, MCX_RESCUE_WAVES) k_rescue(Ctx
     }
 }
 
+// ---- mate rescue, window by window ---------------------------------------------------------------------------------------
+// k_rescue gives a pair to one workgroup, which evaluates the pair's windows one after the other: a launch is as long as the
+// pair with the most candidates to try (hundreds in the large tier) and its barriers.  But a window's evaluation depends on
+// nothing but the candidate it lies beside — only *taking* the results is ordered (the mate's candidate and seed lists grow in
+// window order, AlignmentRescue.cpp:28-111).  So: k_rescue_plan lists the windows of every listed pair (one lane per pair: the
+// tests of rescue_mate up to the evaluation), k_rescue_eval evaluates the windows, one wavefront each, on bit planes in its
+// share of LDS, and k_rescue_apply takes the results pair by pair in window order (one lane per pair: the rest of rescue_mate).
+// Pairs with a read that holds an N keep k_rescue (the reference's 8-mer ids fall out of step after an N: RescueWave::window_ids).
+struct RescueTask {
+    uint32_t local;      // the pair (index in the pass)
+    uint16_t side, ci;   // side 0: read 2 next to candidate ci of read 1; side 1: the other way round
+    int32_t slen, sb;    // window length; the score a window has to beat
+    int64_t left;
+    int32_t pad[2];
+};
+static_assert(sizeof(RescueTask) == 32, "RescueTask is two 16-byte records");
+struct RescueRes { int32_t score, d, n_seeds; uint32_t seed_off; }; // (seeds: n_seeds entries of the pass's seed pool from seed_off on)
+struct RescuePlan { uint32_t local, first, n, flags; }; // a listed pair's windows [first, first + n) and the flags rescue_mate adds
+
+struct RescueWork {
+    RescueTask *tasks; RescueRes *res; Hit *seeds; RescuePlan *plans;
+    uint32_t *n_tasks, *n_plans, *n_seeds;
+    uint32_t task_cap, seed_cap; // windows the list holds; seeds the pool holds
+    uint32_t *ids_n, *n_ids_n; // pairs left to k_rescue (a read with N)
+};
+
+__global__ void __launch_bounds__(256) k_rescue_plan(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl, RescueWork rw)
+{
+    __shared__ EndsLds ends;
+    stage_ends(cx.ix, ends);
+    const IndexView &ix = cx.ix;
+    const uint32_t n = min(*rl.n, rl.cap);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t local = rl.ids[i];
+        const uint32_t pair = sel_pair(sel, local);
+        PairState st = pair_state(cx.state, cx.lay, cx.caps, local);
+        const PairHdr h = *st.hdr;
+        if ((h.flags & kOvAny) || h.n_paired != 0) continue; // (stage_rescue's test)
+        if ((cx.read_ext[2 * pair] | cx.read_ext[2 * pair + 1]) >> 31) { // a read with N: the id path
+            const uint32_t at = atomicAdd(rw.n_ids_n, 1u);
+            rw.ids_n[at] = local; // (as long as the list of listed pairs)
+            continue;
+        }
+        const int rlen[2] = {(int)(rb.off[2 * pair + 1] - rb.off[2 * pair]), (int)(rb.off[2 * pair + 2] - rb.off[2 * pair + 1])};
+        const int n1 = h.n_cands[0], n2 = h.n_cands[1];
+        const Cand *c1 = st.cands[0], *c2 = st.cands[1];
+        int s1 = 0, s2 = 0;
+        for (int k = 0; k < n1; k++) { const int sc = c1[k].score; if (sc > s1) s1 = sc; }
+        for (int k = 0; k < n2; k++) { const int sc = c2[k].score; if (sc > s2) s2 = sc; }
+        int mode;
+        if (s1 < (rlen[0] >> 2) && s2 < (rlen[1] >> 2)) continue; // rescue_mate returns 0 and leaves the pair alone
+        else if (s1 - s2 > (rlen[1] >> 2)) mode = 1;
+        else if (s2 - s1 > (rlen[0] >> 2)) mode = 2;
+        else mode = 3;
+        uint32_t flags = kRescueUsedEst;
+        const int64_t est = (int64_t)(uint32_t)h.est;
+        // two passes over the candidates: count the windows, reserve their places, write them
+        uint32_t first = 0, count = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            uint32_t at = first;
+            for (int side = 0; side < 2; side++) {
+                if (side == 0 && !(mode == 1 || mode == 3)) continue;
+                if (side == 1 && !(mode == 2 || mode == 3)) continue;
+                const int qlen = side == 0 ? rlen[1] : rlen[0];
+                const Cand *ca = side == 0 ? c1 : c2;
+                const int na = side == 0 ? n1 : n2, sa = side == 0 ? s1 : s2, sb = side == 0 ? s2 : s1;
+                const int thr = sa >> 1;
+                for (int ci = 0; ci < na; ci++) {
+                    const Cand c = ca[ci];
+                    if (c.score < thr || c.mate != -1) continue;
+                    const int64_t left = side == 0 ? c.pd0 : c.pd0 - est;
+                    int64_t right = side == 0 ? c.pd0 + est + qlen : c.pd0 + qlen;
+                    if (right > ix.G2) right = ix.G2;
+                    if (left < 0 || right >= ix.G2) continue;
+                    const int e1 = end_slot(ix, left), e2 = end_slot(ix, right);
+                    if (e1 < 0 || e2 < 0 || ix.end_chr[e1] != ix.end_chr[e2]) continue;
+                    const int slen = (int)(right - left);
+                    if (slen < qlen) continue;
+                    if (slen > cx.caps.kmer_cap) { flags |= kOvKmer; continue; }
+                    if (pass == 0) count++;
+                    else {
+                        if (at < rw.task_cap) {
+                            RescueTask t; t.local = local; t.side = (uint16_t)side; t.ci = (uint16_t)ci; t.slen = slen; t.sb = sb; t.left = left; t.pad[0] = t.pad[1] = 0;
+                            rw.tasks[at] = t;
+                        }
+                        at++;
+                    }
+                }
+            }
+            if (pass == 0) first = count ? atomicAdd(rw.n_tasks, count) : 0u;
+        }
+        RescuePlan pl; pl.local = local; pl.first = first; pl.n = count; pl.flags = flags;
+        rw.plans[atomicAdd(rw.n_plans, 1u)] = pl; // (as long as the list of listed pairs)
+    }
+}
+
+template <int KG>
+__global__ void __launch_bounds__(256) k_rescue_eval(Ctx cx, ReadBatch rb, PairSel sel, RescueWork rw)
+{
+    constexpr int kWaves = 4, kW = rescue_wwords(KG);
+    __shared__ uint32_t q_all[kWaves][3 * kRescueQWords];
+    __shared__ uint32_t w_all[kWaves][2 * kW];
+    __shared__ uint32_t ew_all[kWaves][kRescueQWords];
+    const IndexView &ix = cx.ix;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    RescueWave ev; ev.q = q_all[wv]; ev.w = w_all[wv]; ev.ew = ew_all[wv]; ev.wstride = kW; ev.red = nullptr; ev.kq = ev.kg = nullptr;
+    uint32_t *ql = ev.q, *qh = ev.q + kRescueQWords, *qv = ev.q + 2 * kRescueQWords, *wl = ev.w, *wh = ev.w + kW;
+    const uint32_t n = min(*rw.n_tasks, rw.task_cap);
+    auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    for (uint32_t t = blockIdx.x * kWaves + wv; t < n; t += gridDim.x * kWaves) {
+        const RescueTask task = rw.tasks[t];
+        const uint32_t pair = sel_pair(sel, task.local), r = 2 * pair + (task.side == 0 ? 1u : 0u);
+        const int qlen = (int)(rb.off[r + 1] - rb.off[r]), slen = task.slen;
+        const uint32_t *codes = cx.packed + (uint64_t)r * cx.wpad; // the read as mapped: mate 2 reverse-complemented (no N: k_rescue_plan)
+        wave_sync();
+        // the read's planes (base i at bit i & 31 of word i >> 5) and where a base counts (inside the read)
+        for (int k = lane; k < kRescueQWords; k += 64) {
+            uint32_t lo = 0, hi = 0, in = 0;
+            if (32 * k < qlen) {
+                const uint32_t a = codes[2 * k], b = 32 * k + 16 < qlen ? codes[2 * k + 1] : 0u;
+                lo = (__brev(even_bits16(a)) >> 16) | (__brev(even_bits16(b)) & 0xFFFF0000u);
+                hi = (__brev(even_bits16(a >> 1)) >> 16) | (__brev(even_bits16(b >> 1)) & 0xFFFF0000u);
+                in = qlen - 32 * k >= 32 ? ~0u : ((1u << (qlen - 32 * k)) - 1u);
+                lo &= in; hi &= in;
+            }
+            ql[k] = lo; qh[k] = hi; qv[k] = in;
+        }
+        wave_sync();
+        uint32_t v8 = 0;
+        if (lane < kRescueQWords) { // an 8-mer starts where eight bases of the read follow one another
+            const uint32_t v = qv[lane], vn = lane + 1 < kRescueQWords ? qv[lane + 1] : 0u;
+            v8 = v;
+#pragma unroll
+            for (int j = 1; j < kKmerSize; j++) v8 &= __funnelshift_r(v, vn, j);
+        }
+        wave_sync();
+        if (lane < kRescueQWords) qv[lane] = v8;
+        // the window's planes (RescueWave::window)
+        const int pad = ((qlen + 31) & ~31) + 32;
+        const int n_words = (pad + slen + qlen) / 32 + 3;
+        for (int j = lane; j < n_words; j += 64) {
+            uint32_t lo = 0, hi = 0;
+            const int p0 = 32 * j - pad;
+            if (p0 >= 0 && p0 < slen) {
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const int p = p0 + 16 * half;
+                    if (p >= slen) break;
+                    const uint32_t x = ref_codes16(ix, task.left + p);
+                    uint32_t l16 = __brev(even_bits16(x)) >> 16, h16 = __brev(even_bits16(x >> 1)) >> 16;
+                    if (slen - p < 16) { const uint32_t keep = (1u << (slen - p)) - 1u; l16 &= keep; h16 &= keep; }
+                    lo |= l16 << (16 * half); hi |= h16 << (16 * half);
+                }
+            }
+            wl[j] = lo; wh[j] = hi;
+        }
+        wave_sync();
+        const int d_lo = -(qlen - kKmerSize - 2), n_diag = slen - kKmerSize - 2 - d_lo + 1;
+        uint32_t key = 0;
+        for (int g = lane; g < n_diag; g += 64) {
+            const int total = ev.diagonal(d_lo + g, qlen, slen, pad, false);
+            const uint32_t k2 = ((uint32_t)total << 13) | (uint32_t)(8191 - g);
+            if (total > 0 && k2 > key) key = k2;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t other = (uint32_t)__shfl_xor((int)key, o, 64); if (other > key) key = other; }
+        RescueRes res; res.score = (int)(key >> 13); res.d = 0; res.n_seeds = 0; res.seed_off = 0;
+        if (key != 0) {
+            res.d = d_lo + (8191 - (int)(key & 8191u));
+            if (res.score > task.sb) { // (a window that does not beat the mate's best is dropped whatever its seeds)
+                for (int k = lane; k < kRescueQWords; k += 64) ev.ew[k] = 0u;
+                wave_sync();
+                if (lane == 0) {
+                    ev.diagonal(res.d, qlen, slen, pad, true);
+                    // the seeds of the diagonal (runs of three or more 8-mer matches), counted, then written to the pool
+                    Hit *out = nullptr;
+                    for (int pass = 0; pass < 2; pass++) {
+                        int n_seeds = 0, run = 0, run_start = 0;
+                        for (int rr = 0; rr <= qlen; rr++) {
+                            if (run == 0 && (rr & 31) == 0 && rr + 32 <= qlen && ev.ew[rr >> 5] == 0u) { rr += 31; continue; }
+                            const bool m = rr < qlen && ((ev.ew[rr >> 5] >> (rr & 31)) & 1u);
+                            if (m) { if (run == 0) run_start = rr; run++; }
+                            else if (run > 0) {
+                                const int l = kKmerSize + run - 1;
+                                if (l >= 10) {
+                                    if (out) { Hit h; h.rPos = run_start; h.gPos = (int64_t)(run_start + res.d) + task.left; h.len = l; out[n_seeds] = h; }
+                                    n_seeds++;
+                                }
+                                run = 0;
+                            }
+                        }
+                        if (pass == 0) {
+                            res.n_seeds = n_seeds;
+                            res.seed_off = atomicAdd(rw.n_seeds, (uint32_t)n_seeds);
+                            if ((uint64_t)res.seed_off + (uint64_t)n_seeds > rw.seed_cap) break; // (the pool ran over: the pass is repeated in halves)
+                            out = rw.seeds + res.seed_off;
+                        }
+                    }
+                }
+            }
+        }
+        if (lane == 0) rw.res[t] = res;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_rescue_apply(Ctx cx, RescueWork rw)
+{
+    const uint32_t n = *rw.n_plans;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const RescuePlan pl = rw.plans[i];
+        PairState st = pair_state(cx.state, cx.lay, cx.caps, pl.local);
+        PairHdr h = *st.hdr;
+        int nc[2] = {h.n_cands[0], h.n_cands[1]}, nh[2] = {h.n_hits[0], h.n_hits[1]};
+        uint32_t flags = pl.flags;
+        int paired = 0;
+        for (uint32_t k = 0; k < pl.n; k++) {
+            const uint32_t t = pl.first + k;
+            if (t >= rw.task_cap) break; // (the list ran over: the pass is repeated in halves)
+            const RescueRes res = rw.res[t];
+            if (res.n_seeds == 0) continue;
+            const RescueTask task = rw.tasks[t];
+            if (res.score <= task.sb) continue;
+            const int a = task.side, b = 1 - task.side; // candidate ci of read a gets a mate among read b's
+            if ((uint64_t)res.seed_off + (uint64_t)res.n_seeds > rw.seed_cap) break; // (the pool ran over)
+            if (nh[b] + res.n_seeds > cx.caps.hit_cap) { flags |= kOvHits; continue; }
+            if (nc[b] >= cx.caps.cand_cap) { flags |= kOvCands; continue; }
+            paired++;
+            const Hit *src = rw.seeds + res.seed_off;
+            Hit *hb = st.hits[b];
+            for (int s = 0; s < res.n_seeds; s++) hb[nh[b] + s] = src[s];
+            st.cands[a][task.ci].mate = (int16_t)nc[b];
+            cand_init(st.cands[b][nc[b]], res.score, nh[b], res.n_seeds, (int64_t)res.d + task.left);
+            st.cands[b][nc[b]].mate = (int16_t)task.ci;
+            nc[b]++; nh[b] += res.n_seeds;
+        }
+        h.flags |= flags;
+        h.n_cands[0] = (int16_t)nc[0]; h.n_cands[1] = (int16_t)nc[1];
+        h.n_hits[0] = (int16_t)nh[0]; h.n_hits[1] = (int16_t)nh[1];
+        h.n_paired = (int16_t)paired;
+        *st.hdr = h;
+    }
+}
+
 // fragment lists + DP problems of every pair; the problems are appended to one list per size
 // class (mcx_glue.h dp_class) with one atomic per wave and class
 // (late: the pairs that ran over this tier's capacities since clustering — mate rescue's additions, fragment lists, DP
@@ -988,7 +1231,8 @@ struct Tier {
 constexpr uint32_t kPoutSel = 1u << 16; // pair outcomes gathered per copy (run_selection)
 enum { CNT_TASKS = 0, CNT_RESCUE = 1 * kCntPad, CNT_JOB0 = 2 * kCntPad, CNT_JOB1 = 3 * kCntPad, CNT_JOB2 = 4 * kCntPad, CNT_JOB3 = 5 * kCntPad,
        CNT_JOB4 = 6 * kCntPad, CNT_JOB5 = 7 * kCntPad, CNT_OV = 8 * kCntPad, CNT_LF = 9 * kCntPad, CNT_CELLS = 10 * kCntPad, CNT_UNSUP = 11 * kCntPad,
-       CNT_QUEUE = 12 * kCntPad, CNT_EARLY = 13 * kCntPad, CNT_LATE = 14 * kCntPad, CNT_N = 15 * kCntPad };
+       CNT_QUEUE = 12 * kCntPad, CNT_EARLY = 13 * kCntPad, CNT_LATE = 14 * kCntPad, CNT_RTASK = 15 * kCntPad, CNT_RPLAN = 16 * kCntPad, CNT_RESCUE_N = 17 * kCntPad, CNT_RSEED = 18 * kCntPad,
+       CNT_N = 19 * kCntPad };
 constexpr uint32_t kLateRoom = 256; // pairs of a pass that may run over after clustering and still go through the large tier beside it
 
 // What a pass over a selection of pairs works with besides the pair records: stream, counters, work lists, DP scratch.
@@ -1001,6 +1245,8 @@ struct PassRes {
     DpJob *d_jobs[kDpClasses] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; uint32_t job_cap[kDpClasses] = {0, 0, 0, 0, 0, 0};
     uint32_t *d_rescue = nullptr; uint32_t rescue_cap = 0;
     uint32_t *d_kscratch = nullptr; // k_rescue's scratch (not owned: a third of the context's)
+    RescueTask *d_rtasks = nullptr; RescueRes *d_rres = nullptr; Hit *d_rseeds = nullptr; RescuePlan *d_rplans = nullptr; uint32_t *d_rescue_n = nullptr; // mate rescue window by window
+    uint32_t rtask_cap = 0, rseed_cap = 0;
     uint8_t *d_dp_scratch[3] = {nullptr, nullptr, nullptr}; uint64_t dp_stride[3] = {0, 0, 0}; uint32_t dp_blocks[3] = {0, 0, 0};
     hipStream_t dp_stream[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t dp_fork = nullptr, dp_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t *d_ov = nullptr; uint32_t ov_cap = 0;
@@ -1036,6 +1282,8 @@ struct mcx_ctx {
     uint32_t *h_cnt = nullptr;   // pinned mirror
     uint32_t *d_rescue = nullptr; uint32_t rescue_cap = 0;
     uint32_t *d_kscratch = nullptr; // k_rescue's scratch for reads with N
+    RescueTask *d_rtasks = nullptr; RescueRes *d_rres = nullptr; Hit *d_rseeds = nullptr; RescuePlan *d_rplans = nullptr; uint32_t *d_rescue_n = nullptr;
+    uint32_t rtask_cap = 0, rseed_cap = 0;
     hipEvent_t ev_pack[2] = {nullptr, nullptr};
     hipStream_t dp_stream[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t dp_fork = nullptr, dp_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     uint8_t *d_dp_scratch[3] = {nullptr, nullptr, nullptr}; uint64_t dp_stride[3] = {0, 0, 0}; uint32_t dp_blocks[3] = {0, 0, 0};
@@ -1128,6 +1376,23 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
     return 0;
 }
 
+struct mcx_ctx;
+// the window lists of mate rescue for a set of pass resources that lists up to `pairs` pairs
+static int rescue_alloc(mcx_ctx *c, uint64_t pairs, bool large, RescueTask **tasks, RescueRes **res, Hit **seeds, RescuePlan **plans, uint32_t **ids_n, uint32_t *task_cap, uint32_t *seed_cap)
+{
+    int rc;
+    // (the large tier's pairs have hundreds of candidates: many more windows per pair than tier 0's, whose lists stay short)
+    *task_cap = large ? 1u << 22 : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(pairs, 1u << 18), 1u << 21);
+    if (const char *e = getenv("MCX_RESCUE_TASK_CAP")) *task_cap = (uint32_t)std::max(16, atoi(e)); // (tests: make the list run over)
+    *seed_cap = *task_cap; // seeds are kept only of windows that beat the mate's best candidate: a few per pair
+    if ((rc = dmalloc(tasks, *task_cap))) return rc;
+    if ((rc = dmalloc(res, *task_cap))) return rc;
+    if ((rc = dmalloc(seeds, (size_t)*seed_cap))) return rc;
+    if ((rc = dmalloc(plans, pairs))) return rc;
+    if ((rc = dmalloc(ids_n, pairs))) return rc;
+    return 0;
+}
+
 // a set of pass resources beside the context's own (PassRes): work lists for `pairs` pairs at a time, selections of up to `sel_cap`
 static int passres_alloc(mcx_ctx *c, PassRes &t, uint64_t pairs, uint64_t sel_cap, int priority)
 {
@@ -1144,6 +1409,7 @@ static int passres_alloc(mcx_ctx *c, PassRes &t, uint64_t pairs, uint64_t sel_ca
     }
     t.rescue_cap = (uint32_t)pairs;
     if ((rc = dmalloc(&t.d_rescue, t.rescue_cap))) return rc;
+    if ((rc = rescue_alloc(c, pairs, pairs >= 4096, &t.d_rtasks, &t.d_rres, &t.d_rseeds, &t.d_rplans, &t.d_rescue_n, &t.rtask_cap, &t.rseed_cap))) return rc;
     const uint32_t blocks1[3] = {2048, 2048, 256};
     for (int k = 0; k < 3; k++) {
         t.dp_stride[k] = c->dp_stride[k]; t.dp_blocks[k] = blocks1[k];
@@ -1159,7 +1425,7 @@ static int passres_alloc(mcx_ctx *c, PassRes &t, uint64_t pairs, uint64_t sel_ca
 static void passres_free(PassRes &t)
 {
     void *q[] = {t.d_cnt, t.d_jobs[0], t.d_jobs[1], t.d_jobs[2], t.d_jobs[3], t.d_jobs[4], t.d_jobs[5], t.d_rescue, t.d_dp_scratch[0], t.d_dp_scratch[1],
-                 t.d_dp_scratch[2], t.d_ov, t.d_sel_ids, t.d_est};
+                 t.d_dp_scratch[2], t.d_ov, t.d_sel_ids, t.d_est, t.d_rtasks, t.d_rres, t.d_rseeds, t.d_rplans, t.d_rescue_n};
     for (void *x : q) if (x) (void)hipFree(x);
     if (t.h_cnt) (void)hipHostFree(t.h_cnt);
     for (auto &e : t.ev) if (e) (void)hipEventDestroy(e);
@@ -1199,6 +1465,7 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     HIP_TRY(hipHostMalloc((void **)&c->h_cnt, CNT_N * sizeof(uint32_t)));
     c->rescue_cap = (uint32_t)c->max_reads;
     if ((rc = dmalloc(&c->d_rescue, c->rescue_cap))) return rc;
+    if ((rc = rescue_alloc(c, c->max_reads, false, &c->d_rtasks, &c->d_rres, &c->d_rseeds, &c->d_rplans, &c->d_rescue_n, &c->rtask_cap, &c->rseed_cap))) return rc;
     if ((rc = dmalloc(&c->d_kscratch, 3 * (size_t)kRescueBlocks * kRescueScratchWords))) return rc; // (one part per set of pass resources)
     // DP traceback spill per block: 4 KB of sequences + (qlen + tlen - 1) * tlen direction bytes
     const uint64_t spill[3] = {kDpSpillSeq + (uint64_t)(2048 + 64) * 64, kDpSpillSeq + (uint64_t)(2048 + 256) * 256, kDpSpillSeq + (uint64_t)(2048 + 1024) * 1024};
@@ -1262,7 +1529,7 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
 {
     if (!c) return;
     void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3], c->d_jobs[4], c->d_jobs[5],
-                 c->d_cnt, c->d_rescue, c->d_kscratch, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
+                 c->d_cnt, c->d_rescue, c->d_kscratch, c->d_rtasks, c->d_rres, c->d_rseeds, c->d_rplans, c->d_rescue_n, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
                  c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
                  c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_pout_sel, c->d_order, c->d_order_cnt, c->d_packed, c->d_batch_flags};
     for (void *q : p) if (q) (void)hipFree(q);
@@ -1313,6 +1580,7 @@ static PassRes res_tier0(mcx_ctx *c)
     r.stream = c->stream; r.d_cnt = c->d_cnt; r.h_cnt = c->h_cnt; r.d_tasks = c->d_tasks; r.task_cap = c->task_cap;
     for (int k = 0; k < kDpClasses; k++) { r.d_jobs[k] = c->d_jobs[k]; r.job_cap[k] = c->job_cap[k]; }
     r.d_rescue = c->d_rescue; r.rescue_cap = c->rescue_cap; r.d_kscratch = c->d_kscratch;
+    r.d_rtasks = c->d_rtasks; r.d_rres = c->d_rres; r.d_rseeds = c->d_rseeds; r.d_rplans = c->d_rplans; r.d_rescue_n = c->d_rescue_n; r.rtask_cap = c->rtask_cap; r.rseed_cap = c->rseed_cap;
     for (int k = 0; k < 3; k++) { r.d_dp_scratch[k] = c->d_dp_scratch[k]; r.dp_stride[k] = c->dp_stride[k]; r.dp_blocks[k] = c->dp_blocks[k]; }
     for (int k = 0; k < 5; k++) { r.dp_stream[k] = c->dp_stream[k]; r.dp_join[k] = c->dp_join[k]; }
     r.dp_fork = c->dp_fork; r.d_ov = c->d_ov; r.ov_cap = c->ov_cap; r.d_sel_ids = c->d_sel_ids; r.d_est = c->d_est;
@@ -1413,8 +1681,22 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     if (early) HIP_TRY(hipEventRecord(c->ev_clustered, s));
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     if (paired) {
-        if (tier == 0) k_rescue<2048><<<kRescueBlocks, kRescueThreads, 0, s>>>(cx, rb, sel, rl, R.d_kscratch);
-        else k_rescue<4096><<<kRescueBlocks, kRescueThreads, 0, s>>>(cx, rb, sel, rl, R.d_kscratch);
+        if (getenv("MCX_RESCUE_BY_PAIR")) { // (experiments: a workgroup per pair, the pair's windows one after the other)
+            if (tier == 0) k_rescue<2048><<<kRescueBlocks, kRescueThreads, 0, s>>>(cx, rb, sel, rl, R.d_kscratch);
+            else k_rescue<4096><<<kRescueBlocks, kRescueThreads, 0, s>>>(cx, rb, sel, rl, R.d_kscratch);
+        } else {
+            RescueWork rw; rw.tasks = R.d_rtasks; rw.res = R.d_rres; rw.seeds = R.d_rseeds; rw.plans = R.d_rplans; rw.n_tasks = R.d_cnt + CNT_RTASK; rw.n_plans = R.d_cnt + CNT_RPLAN; rw.n_seeds = R.d_cnt + CNT_RSEED;
+            rw.task_cap = R.rtask_cap; rw.seed_cap = R.rseed_cap; rw.ids_n = R.d_rescue_n; rw.n_ids_n = R.d_cnt + CNT_RESCUE_N;
+            RescueList rn; rn.ids = R.d_rescue_n; rn.n = R.d_cnt + CNT_RESCUE_N; rn.cap = R.rescue_cap;
+            const unsigned gb = std::min<unsigned>(std::max<unsigned>((sel.n + 255) / 256, 1u), 1024u);
+            k_rescue_plan<<<gb, 256, 0, s>>>(cx, rb, sel, rl, rw);
+            if (tier == 0) k_rescue_eval<2048><<<4096, 256, 0, s>>>(cx, rb, sel, rw);
+            else k_rescue_eval<4096><<<4096, 256, 0, s>>>(cx, rb, sel, rw);
+            k_rescue_apply<<<gb, 256, 0, s>>>(cx, rw);
+            // the pairs with an N in a read (none in most batches: the launch then ends at once)
+            if (tier == 0) k_rescue<2048><<<256, kRescueThreads, 0, s>>>(cx, rb, sel, rn, R.d_kscratch);
+            else k_rescue<4096><<<256, kRescueThreads, 0, s>>>(cx, rb, sel, rn, R.d_kscratch);
+        }
     }
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP, ll, order);
@@ -1510,12 +1792,12 @@ static int pass_finish(mcx_ctx *c, int tier, const PassRes &R, uint32_t n_sel, m
     }
     const uint32_t *n = R.h_cnt;
     // a work list that ran over: nothing of this pass is kept, the caller maps the selection in two halves
-    if ((R.d_tasks && n[CNT_TASKS] > R.task_cap) || n[CNT_RESCUE] > R.rescue_cap) return kListOverflow;
+    if ((R.d_tasks && n[CNT_TASKS] > R.task_cap) || n[CNT_RESCUE] > R.rescue_cap || n[CNT_RTASK] > R.rtask_cap || n[CNT_RSEED] > R.rseed_cap) return kListOverflow;
     for (int k = 0; k < kDpClasses; k++) if (n[CNT_JOB0 + k * kCntPad] > R.job_cap[k]) return kListOverflow;
     if (n[CNT_UNSUP]) return fail(MCX_ERR_UNSUPPORTED, "a gapped fragment exceeds 2048 x 1024 cells per side");
     if (timing && getenv("MCX_TIMING"))
-        fprintf(stderr, "[run_pairs] pairs %u: sa tasks %u, rescue pairs %u, dp jobs by class (tiny) %u %u (half) %u %u %u %u, cells %u, overflow pairs %u (+ %u listed while clustering)\n", n_sel,
-                n[CNT_TASKS], n[CNT_RESCUE], n[CNT_JOB4], n[CNT_JOB0], n[CNT_JOB5], n[CNT_JOB1], n[CNT_JOB2], n[CNT_JOB3], n[CNT_CELLS], n[CNT_OV], n[CNT_EARLY]);
+        fprintf(stderr, "[run_pairs] pairs %u: sa tasks %u, rescue pairs %u (windows %u), dp jobs by class (tiny) %u %u (half) %u %u %u %u, cells %u, overflow pairs %u (+ %u listed while clustering)\n", n_sel,
+                n[CNT_TASKS], n[CNT_RESCUE], n[CNT_RTASK], n[CNT_JOB4], n[CNT_JOB0], n[CNT_JOB5], n[CNT_JOB1], n[CNT_JOB2], n[CNT_JOB3], n[CNT_CELLS], n[CNT_OV], n[CNT_EARLY]);
     if (stats) {
         stats->dp_jobs += (int64_t)n[CNT_JOB0] + n[CNT_JOB1] + n[CNT_JOB2] + n[CNT_JOB3] + n[CNT_JOB4] + n[CNT_JOB5];
         stats->dp_cells += n[CNT_CELLS];
