@@ -88,8 +88,9 @@ static inline MCX_HD void cand_init(Cand &dst, int score, int first, int count, 
 
 // SimplePairClustering (ReadMapping.cpp:194-226) with IdentifyClosestFragmentPairs (:160-192).
 // The terminal fragment pair the reference appends is index n here (gPos = PosDiff = 2G).
-static inline MCX_HD int cluster_seeds(const IndexView &ix, const Params &pm, int rlen, const Hit *h, int n,
-                                       Cand *out, int cap)
+// (emit(k, score, first, count, pd0): what becomes of cluster number k)
+template <class Emit>
+static inline MCX_HD int cluster_seeds_to(const IndexView &ix, const Params &pm, int rlen, const Hit *h, int n, Emit emit)
 {
     if (n == 0) return 0;
     int nc = 0, head = 0, score = h[0].len, thr = rlen >> 2;
@@ -115,7 +116,7 @@ static inline MCX_HD int cluster_seeds(const IndexView &ix, const Params &pm, in
                     }
                     if (rs > s) { s = rs; b = run_b; e = k; }
                 }
-                if (nc < cap) cand_init(out[nc], s, b, e - b, hit_pd(h[b]));
+                emit(nc, s, b, e - b, hit_pd(h[b]));
                 nc++;
             }
             head = j;
@@ -123,6 +124,12 @@ static inline MCX_HD int cluster_seeds(const IndexView &ix, const Params &pm, in
         } else score += h[j].len;
     }
     return nc;
+}
+
+static inline MCX_HD int cluster_seeds(const IndexView &ix, const Params &pm, int rlen, const Hit *h, int n,
+                                       Cand *out, int cap)
+{
+    return cluster_seeds_to(ix, pm, rlen, h, n, [&](int k, int score, int first, int count, int64_t pd0) { if (k < cap) cand_init(out[k], score, first, count, pd0); });
 }
 
 static inline MCX_HD void keep_top_scores(Cand *c, int n) // RemoveRedundantAlnCan, ReadMapping.cpp:228-242

@@ -738,6 +738,176 @@ __global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel s
     }
 }
 
+// ---- clustering and pairing of a heavy pair by a whole wavefront -----------------------------------------------------------
+// The large tier's pairs come from repeats: hundreds of seed hits per read, hundreds of candidates.  One lane that sorts 800
+// hits and pairs 300 x 300 candidates in its pair record (every step a dependent fetch from HBM) takes milliseconds, and the
+// launch is as long as its slowest lane.  Here a wavefront takes a pair: a read's hits are brought into LDS, sorted there by all
+// 64 lanes (bitonic, keys (PosDiff, rPos)), clustered by one lane out of LDS (the scan is serial by nature — its threshold
+// moves with every cluster — but a step is an LDS access now, not a trip to HBM), and the candidates of the two reads are paired
+// with the candidates of read 1 spread over the lanes.  Same functions, same results as stage_cluster_pair.
+struct ClusterLds { // per-wave arrays in dynamic LDS (cap = the tier's candidate capacity per read)
+    Hit *hits;          // [hit_cap]: the read being clustered
+    int64_t *pd[2];     // [cand_cap] per read: PosDiff of the candidate's first seed
+    int32_t *score[2];  // score (0: dropped)
+    uint32_t *span[2];  // first seed | seeds << 16
+    int32_t *mate[2];   // PairedAlnCanIdx
+    int32_t *pick;      // [cand_cap]: the partner a candidate of read 1 chose (pairing scratch)
+};
+
+static inline size_t cluster_lds_bytes(int hit_cap, int cand_cap) { return (size_t)hit_cap * sizeof(Hit) + (size_t)cand_cap * (2 * (8 + 4 + 4 + 4) + 4) + 64; }
+constexpr int kClusterSmall = 192; // hits per read up to which a pair takes the launch with the small share of LDS (more wavefronts per CU)
+
+// (hits_lo < hits <= hits_hi: the pairs of this launch, by the larger hit count of their reads; lds_hits / lds_cands: what its LDS holds)
+__global__ void __launch_bounds__(64) k_cluster_wave(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl, const uint32_t *read_blocks, int hits_lo, int hits_hi, int lds_hits,
+                                                     int lds_cands)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t cl_lds[];
+    __shared__ EndsLds ends;
+    stage_ends(cx.ix, ends);
+    const int lane = threadIdx.x;
+    const int nr = cx.pm.paired ? 2 : 1;
+    ClusterLds L;
+    {
+        uint8_t *p = cl_lds;
+        L.hits = (Hit *)p; p += (size_t)lds_hits * sizeof(Hit);
+        for (int s = 0; s < 2; s++) { L.pd[s] = (int64_t *)p; p += (size_t)lds_cands * 8; }
+        for (int s = 0; s < 2; s++) { L.score[s] = (int32_t *)p; p += (size_t)lds_cands * 4; }
+        for (int s = 0; s < 2; s++) { L.span[s] = (uint32_t *)p; p += (size_t)lds_cands * 4; }
+        for (int s = 0; s < 2; s++) { L.mate[s] = (int32_t *)p; p += (size_t)lds_cands * 4; }
+        L.pick = (int32_t *)p;
+    }
+    auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_s_barrier(); };
+    for (uint32_t local = blockIdx.x; local < sel.n; local += gridDim.x) {
+        const uint32_t pair = sel_pair(sel, local);
+        {
+            const int h0 = (int)(read_blocks[pair * nr] >> 20), h1 = nr == 2 ? (int)(read_blocks[pair * nr + 1] >> 20) : 0, hm = h0 > h1 ? h0 : h1;
+            if (hm <= hits_lo || hm > hits_hi) continue; // another launch's pair
+        }
+        PairState st = pair_state(cx.state, cx.lay, cx.caps, local);
+        uint32_t flags = 0;
+        int n_hits[2] = {0, 0}, n_cands[2] = {0, 0};
+        for (int s = 0; s < nr; s++) {
+            const uint32_t r = pair * nr + s;
+            const int rlen = (int)(rb.off[r + 1] - rb.off[r]);
+            int nh = (int)(read_blocks[r] >> 20);
+            if (nh > cx.caps.hit_seed) { flags |= kOvHits; nh = 0; }
+            Hit *g_hits = st.hits[s];
+            // the read's hits with PosDiff > 0 into LDS, closed up (IdentifySimplePairs' tail, ReadMapping.cpp:141-152)
+            wave_sync();
+            int m = 0;
+            for (int base = 0; base < nh; base += 64) {
+                const int i = base + lane;
+                Hit x; x.gPos = 0; x.rPos = 0; x.len = 0;
+                bool keep = false;
+                if (i < nh) { x = g_hits[i]; keep = hit_pd(x) > 0; }
+                const uint64_t mask = __ballot(keep);
+                if (keep) L.hits[m + __popcll(mask & ((1ull << lane) - 1ull))] = x;
+                m += __popcll(mask);
+            }
+            int P = 1;
+            while (P < m) P <<= 1;
+            for (int i = m + lane; i < P; i += 64) { Hit x; x.gPos = (int64_t)1 << 62; x.rPos = 0; x.len = 0; L.hits[i] = x; } // (sort to the end)
+            wave_sync();
+            for (int k = 2; k <= P; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = lane; i < P; i += 64) {
+                        const int o = i ^ j;
+                        if (o > i) {
+                            const Hit a = L.hits[i], b = L.hits[o];
+                            const int64_t pa = hit_pd(a), pb = hit_pd(b);
+                            const bool a_gt = pa > pb || (pa == pb && a.rPos > b.rPos);
+                            if (((i & k) == 0) == a_gt) { L.hits[i] = b; L.hits[o] = a; }
+                        }
+                    }
+                    wave_sync();
+                }
+            for (int i = lane; i < m; i += 64) g_hits[i] = L.hits[i]; // the later stages read the seeds in this order
+            // clusters: a serial scan (its threshold moves with every cluster it keeps), out of LDS
+            int nc = 0;
+            if (lane == 0)
+                nc = cluster_seeds_to(cx.ix, cx.pm, rlen, L.hits, m, [&](int k, int score, int first, int count, int64_t pd0) {
+                    if (k < cx.caps.cand_seed) { L.pd[s][k] = pd0; L.score[s][k] = score; L.span[s][k] = (uint32_t)first | ((uint32_t)count << 16); }
+                });
+            nc = __shfl(nc, 0, 64);
+            if (nc > cx.caps.cand_seed) { flags |= kOvCands; nc = 0; }
+            n_hits[s] = m; n_cands[s] = nc;
+            wave_sync();
+        }
+        for (int s = 0; s < 2; s++) for (int i = lane; i < n_cands[s]; i += 64) L.mate[s][i] = -1;
+        wave_sync();
+        // CheckPairedAlignmentDistance (pair_by_distance): read 1's candidates over the lanes
+        int n_paired = 0, lo = 0, hi = 0x7fffffff;
+        if (cx.pm.paired && !(flags & kOvAny)) {
+            const int n1 = n_cands[0], n2 = n_cands[1];
+            const int64_t est = (int64_t)sel.est[local];
+            if (n1 * n2 > 100) // RemoveRedundantAlnCan on both
+                for (int s = 0; s < 2; s++) {
+                    int best = 0;
+                    for (int i = lane; i < n_cands[s]; i += 64) best = max(best, L.score[s][i]);
+                    for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o, 64));
+                    if (n_cands[s] > 1) for (int i = lane; i < n_cands[s]; i += 64) if (L.score[s][i] < best) L.score[s][i] = 0;
+                }
+            wave_sync();
+            int64_t max_lt = -1, min_ge = 0x7fffffff, top = 0;
+            for (int i = lane; i < n1; i += 64) {
+                const int sa = L.score[0][i];
+                const int64_t pa = L.pd[0][i];
+                int pick = -1, ps = 0;
+                if (sa != 0)
+                    for (int j = 0; j < n2; j++) {
+                        const int sj = L.score[1][j];
+                        const int64_t pj = L.pd[1][j];
+                        if (sj == 0 || pj < pa) continue;
+                        const int64_t d = pj - pa;
+                        if (d < est) { if (d > max_lt) max_lt = d; if (sj > ps) { pick = j; ps = sj; } }
+                        else if (d < min_ge) min_ge = d;
+                    }
+                L.pick[i] = pick;
+                if (pick >= 0 && (int64_t)sa + ps > top) top = (int64_t)sa + ps;
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const int64_t a = __shfl_xor(max_lt, o, 64), b = __shfl_xor(min_ge, o, 64), c = __shfl_xor(top, o, 64);
+                if (a > max_lt) max_lt = a;
+                if (b < min_ge) min_ge = b;
+                if (c > top) top = c;
+            }
+            wave_sync();
+            if (top > 0)
+                for (int i = lane; i < n1; i += 64) {
+                    const int pick = L.pick[i];
+                    if (pick >= 0 && (int64_t)L.score[0][i] + L.score[1][pick] == top) {
+                        n_paired++;
+                        L.mate[0][i] = pick;
+                        atomicMax(&L.mate[1][pick], i); // (read 1's candidates are gone through in order: the last one that picks it stays)
+                    }
+                }
+            for (int o = 32; o > 0; o >>= 1) n_paired += __shfl_xor(n_paired, o, 64);
+            lo = (int)(max_lt + 1); hi = (int)min_ge;
+            wave_sync();
+        }
+        // the candidates as the later stages find them in the pair record
+        for (int s = 0; s < nr; s++)
+            for (int i = lane; i < n_cands[s]; i += 64) {
+                Cand c;
+                c.score = L.score[s][i]; c.mate = (int16_t)L.mate[s][i]; c.first = (int16_t)(L.span[s][i] & 0xFFFFu); c.count = (int16_t)(L.span[s][i] >> 16); c.pd0 = L.pd[s][i];
+                c.frag_off = 0; c.n_frags = 0; c.flag = 0; c.fwd = 1; for (int k = 0; k < 7; k++) c.pad[k] = 0;
+                st.cands[s][i] = c;
+            }
+        if (lane == 0) {
+            PairHdr h;
+            h.flags = flags; h.n_frags = 0; h.n_ops = 0; h.pair_dist = 0; h.n_jobs = 0; h.pair_ok = 0; h.mapped = 0; h.pad[0] = h.pad[1] = 0;
+            h.n_hits[0] = (int16_t)n_hits[0]; h.n_hits[1] = (int16_t)n_hits[1]; h.n_cands[0] = (int16_t)n_cands[0]; h.n_cands[1] = (int16_t)n_cands[1];
+            h.sum[0].best = h.sum[1].best = -1; h.sum[0].score = h.sum[1].score = 0; h.sum[0].sub = h.sum[1].sub = 0;
+            h.est = sel.est[local]; h.est_lo = lo; h.est_hi = hi; h.n_paired = (int16_t)n_paired;
+            *st.hdr = h;
+            if (cx.pm.paired && !(flags & kOvAny) && n_paired == 0) {
+                const uint32_t at = atomicAdd(rl.n, 1u);
+                if (at < rl.cap) rl.ids[at] = local;
+            }
+        }
+    }
+}
+
 constexpr int kRescueThreads = 256;
 constexpr unsigned kRescueBlocks = 4096;
 // HBM scratch per workgroup for reads with N (RescueWave::window_ids): the read's ids, the longest window's ids and bytes
@@ -1677,7 +1847,13 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         k_order_place<<<ob, 256, 0, s>>>(sel, so.read_blocks, nr, c->d_order_cnt, c->d_order);
         order = c->d_order;
     }
-    k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl, so.read_blocks, el, order);
+    const size_t cl_bytes = cluster_lds_bytes(cx.caps.hit_cap, cx.caps.cand_cap);
+    if (tier == 1 && cl_bytes <= 60 * 1024 && !getenv("MCX_CLUSTER_BY_LANE")) { // the large tier's pairs: a wavefront each, in two launches by size
+        const int small = std::min(kClusterSmall, cx.caps.hit_cap);
+        k_cluster_wave<<<std::min<unsigned>(sel.n, 16384u), 64, cluster_lds_bytes(small, small), s>>>(cx, rb, sel, rl, so.read_blocks, -1, small, small, small);
+        if (small < cx.caps.hit_cap)
+            k_cluster_wave<<<std::min<unsigned>(sel.n, 8192u), 64, cl_bytes, s>>>(cx, rb, sel, rl, so.read_blocks, small, 1 << 30, cx.caps.hit_cap, cx.caps.cand_cap);
+    } else k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl, so.read_blocks, el, order);
     if (early) HIP_TRY(hipEventRecord(c->ev_clustered, s));
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     if (paired) {
