@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # random 16-byte gathers from an 8 GiB table, four lanes per 64-byte block: what the chip's L2 / fabric sustains in
 # requests per second (tools/ubench_gather.hip, profiles/round1/ubench_gather_8GiB.txt: 47-48 G/s)
 GATHER_CEILING_G_PER_S = 47.5
-PMC_SUMMARY = {"human": os.path.join(ROOT, "profiles", "round2", "summary_human.json"),
-               "uniform": os.path.join(ROOT, "profiles", "round2", "summary_uniform.json")}
+PMC_SUMMARY = {"human": os.path.join(ROOT, "profiles", "round3", "summary_human.json"),
+               "uniform": os.path.join(ROOT, "profiles", "round3", "summary_uniform.json")}
 STAGE_KERNEL = {"ms_encode": "k_pack_reads", "ms_seed": "k_seed", "ms_cluster": "k_cluster", "ms_rescue": "k_rescue<2048>", "ms_build": "k_build",
                 "ms_finish": "k_finish"}  # stages that are one kernel (ms_dp is six kernels on side streams)
 
@@ -72,9 +72,9 @@ def essential_bytes(kernel, d, args):
     packed = 4.0 * ((args.rlen + 15) // 16 + (args.rlen + 31) // 32 + 2)  # 2-bit words + N masks of a read
     per_read = {
         "k_pack_reads": args.rlen + packed,
-        # packed read in; per 64-byte index block touched; per hit a suffix-array entry and the hit record out;
-        # the direct comparison reads the 2-bit genome under the seed (E bases / 4)
-        "k_seed": packed + 64.0 * d["fm_blocks"] / reads + (8 + 16) * h + d["fm_ext_steps"] / reads / 4.0,
+        # packed read in; per extension step one or two 16-byte rank records (fm_blocks counts them); per hit a suffix-array
+        # entry and the hit record out; the direct comparison reads the 2-bit genome under the seed (E bases / 4)
+        "k_seed": packed + 16.0 * d["fm_blocks"] / reads + (8 + 16) * h + d["fm_ext_steps"] / reads / 4.0,
         "k_cluster": 16.0 * h + 32.0,                       # hits in, a candidate out
         "k_build": 16.0 * h + 32.0 + 16.0 * (2 * h + 1) + 2 * args.rlen / 4.0,   # hits + candidate in, fragments out, gap bases compared
         "k_finish": 32.0 + 16.0 * (2 * h + 1) + 2 * args.rlen / 4.0 + 64.0 + 8.0,  # candidate + fragments in, columns compared, record + CIGAR out
@@ -234,6 +234,33 @@ def other_genome(args):
             "roofline": {k: o["roofline"][k] for k in ("kernel", "achieved", "frac", "traffic", "basis")}}
 
 
+def other_configs(args):
+    """BASELINE.json's configs 5 and 2, each as a child process once this one has let go of the GPU's memory: two timed steps, stage
+    times, DP cell updates per second, and the CPU baseline on a small sample of the same reads."""
+    runs = [
+        ("config 5: GRCh38-sized genome, 250 bp PE at 5 % indels per base, -alg nw",
+         ["--genome", args.genome, "--genome-mbp", str(args.genome_mbp), "--contigs", str(args.contigs), "--batch-pairs", str(args.batch_pairs), "--rlen", "250",
+          "--sub", str(args.sub), "--ins", "0.025", "--dele", "0.025", "--alg", "nw", "--cpu-pairs", "150000"]),
+        ("config 2: E. coli-sized genome (4.6 Mbp, one contig), 1 M x 100 bp SE, -alg ksw2",
+         ["--genome", "uniform", "--genome-mbp", "4.6", "--contigs", "1", "--repeats", "20", "--batch-pairs", "1000000", "--single-end", "1", "--rlen", "100",
+          "--sub", str(args.sub), "--ins", str(args.ins), "--dele", str(args.dele), "--alg", "ksw2", "--cpu-pairs", "1000000"]),
+    ]
+    res = []
+    for name, extra in runs:
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--second-genome", "0", "--other-configs", "0", "--vcf-reduce", "0",
+               "--pcie-steps", "0", "--full-sa", str(args.full_sa)] + extra
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=900)
+            o = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            res.append({"config": name, "value": o["value"], "unit": o["unit"], "steps": o["steps"], "ms_per_step": o["ms_per_step"], "workload": o["config"]["workload"],
+                        "stage_ms_per_step": o["stage_ms_per_step"], "per_read": o["per_read"], "dp": o["dp"], "tier1_pairs": o["tier1_pairs"],
+                        "halved_selections": o["halved_selections"], "cpu_baseline": o.get("cpu_baseline"),
+                        "roofline": {k: o["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "basis")}})
+        except Exception as e:
+            res.append({"config": name, "error": str(e)[:200]})
+    return res
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -256,6 +283,10 @@ def parse():
     ap.add_argument("--second-genome", type=int, default=1,
                     help="1: after the main run, map 2 steps against the other kind of genome as well and report them under `other_genome`")
     ap.add_argument("--pcie-steps", type=int, default=6, help="steps of the host-buffer leg (value_pcie_inclusive); 0 = skip")
+    ap.add_argument("--single-end", type=int, default=0, help="1: single-end reads (--batch-pairs then counts reads)")
+    ap.add_argument("--other-configs", type=int, default=1,
+                    help="1: after the main run, BASELINE.json's configs 5 (250 bp PE at 5 %% indels, -alg nw) and 2 (E. coli-sized genome, 1 M x 100 bp SE) "
+                         "as child processes, reported under `other_configs` with their stage times, DP GCUPS and CPU baselines")
     ap.add_argument("--vcf-slice-reads", type=int, default=4_000_000, help="reads per mapping call in the -vcf leg")
     ap.add_argument("--vcf-reduce", type=int, default=1,
                     help="after the timed region: accumulate the -vcf alignment profile of one batch and sum it over the "
@@ -391,16 +422,16 @@ def make_genome(args, device, seed):
     return codes, [int(x) for x in lens], note
 
 
-def make_reads(codes, lens, n_pairs, rlen, seed, device, sub=0.005, ins=0.001, dele=0.001):
+def make_reads(codes, lens, n_pairs, rlen, seed, device, sub=0.005, ins=0.001, dele=0.001, paired=True):
     from mapcaller_amd import synth
     parts, o = [], 0
     for L in lens:
         parts.append(codes[o:o + L])
         o += L
     donor = synth.Genome([f"chr{i + 1}" for i in range(len(lens))], parts)
-    bases, _ = synth.simulate_reads(donor, n_pairs, rlen, True, seed, frag_mean=500, frag_sd=50, frag_min=300, frag_max=800,
+    bases, _ = synth.simulate_reads(donor, n_pairs, rlen, paired, seed, frag_mean=500, frag_sd=50, frag_min=300, frag_max=800,
                                     sub=sub, ins=ins, dele=dele, device=device, chunk=1 << 19, skip_head=3000)
-    return bases  # uint8 ASCII [2 n_pairs, rlen]
+    return bases  # uint8 ASCII [2 n_pairs (paired) or n_pairs, rlen]
 
 
 def cpu_baseline(args, index, bases_sample):
@@ -410,20 +441,23 @@ def cpu_baseline(args, index, bases_sample):
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "MapCaller")
     port_bin = os.path.join(ROOT, "oracle", "mcx_oracle")
     cores = os.cpu_count() or 1
-    n_pairs = bases_sample.shape[0] // 2
+    se = bool(args.single_end)
+    step = 1 if se else 2
+    n_pairs = bases_sample.shape[0] // step
     with tempfile.TemporaryDirectory() as tmp:
         prefix = os.path.join(tmp, "idx")
         index.save(prefix)
         f1, f2 = os.path.join(tmp, "r1.fq"), os.path.join(tmp, "r2.fq")
         t1, t2 = os.path.join(tmp, "t1.fq"), os.path.join(tmp, "t2.fq")
-        synth.write_fastq(f1, bases_sample, 0, 2)
-        synth.write_fastq(f2, bases_sample, 1, 2)
-        synth.write_fastq(t1, bases_sample[:400], 0, 2)
-        synth.write_fastq(t2, bases_sample[:400], 1, 2)
+        synth.write_fastq(f1, bases_sample, 0, step)
+        synth.write_fastq(t1, bases_sample[:400], 0, step)
+        if not se:
+            synth.write_fastq(f2, bases_sample, 1, 2)
+            synth.write_fastq(t2, bases_sample[:400], 1, 2)
         if os.path.exists(ref_bin):
             kind = "reference"
             def run(a, b, threads=cores):
-                cmd = [ref_bin, "-i", prefix, "-f", a, "-f2", b, "-alg", args.alg, "-sam", os.path.join(tmp, "o.sam"), "-no_vcf", "-t", str(threads), "-log", os.path.join(tmp, "job.log")]
+                cmd = [ref_bin, "-i", prefix, "-f", a] + ([] if se else ["-f2", b]) + ["-alg", args.alg, "-sam", os.path.join(tmp, "o.sam"), "-no_vcf", "-t", str(threads), "-log", os.path.join(tmp, "job.log")]
                 t0 = time.perf_counter()
                 r = subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
                 wall = time.perf_counter() - t0
@@ -433,7 +467,7 @@ def cpu_baseline(args, index, bases_sample):
         elif os.path.exists(port_bin):
             kind = "port"
             def run(a, b):
-                cmd = [port_bin, "-i", prefix, "-f", a, "-f2", b, "-alg", args.alg, "-sam", os.path.join(tmp, "o.sam"), "-t", str(cores)]
+                cmd = [port_bin, "-i", prefix, "-f", a] + ([] if se else ["-f2", b]) + ["-alg", args.alg, "-sam", os.path.join(tmp, "o.sam"), "-t", str(cores)]
                 t0 = time.perf_counter()
                 subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
                 return time.perf_counter() - t0, None
@@ -445,16 +479,17 @@ def cpu_baseline(args, index, bases_sample):
         else:
             t_load, _ = run(t1, t2)    # 200 pairs: index load + start-up
             dt, how = max(t_full - t_load, 1e-3), f"wall {t_full:.1f}s minus {t_load:.1f}s index load"
-        out = {"value": round(2 * n_pairs / dt, 1), "unit": "reads/s", "cores": cores, "kind": kind,
-               "sample": f"{n_pairs} pairs x {args.rlen} bp of the same synthetic workload, -t {cores} -alg {args.alg} -sam (file) -no_vcf; {how}"}
+        out = {"value": round(step * n_pairs / dt, 1), "unit": "reads/s", "cores": cores, "kind": kind,
+               "sample": f"{n_pairs} {'reads' if se else 'pairs'} x {args.rlen} bp of the same synthetic workload, -t {cores} -alg {args.alg} -sam (file) -no_vcf; {how}"}
         if kind == "reference":  # SURVEY 8d also asks for -t 1: a smaller sample, the reference's own clock again
             n1 = min(n_pairs, 75_000)
             s1, s2 = os.path.join(tmp, "s1.fq"), os.path.join(tmp, "s2.fq")
-            synth.write_fastq(s1, bases_sample[:2 * n1], 0, 2)
-            synth.write_fastq(s2, bases_sample[:2 * n1], 1, 2)
+            synth.write_fastq(s1, bases_sample[:step * n1], 0, step)
+            if not se:
+                synth.write_fastq(s2, bases_sample[:2 * n1], 1, 2)
             _, own1 = run(s1, s2, threads=1)
             if own1:
-                out["single_thread"] = {"value": round(2 * n1 / own1, 1), "unit": "reads/s", "cores": 1,
+                out["single_thread"] = {"value": round(step * n1 / own1, 1), "unit": "reads/s", "cores": 1,
                                         "sample": f"{n1} pairs, -t 1, the reference's own clock: {own1} s"}
         return out
 
@@ -552,28 +587,29 @@ def main():
     index = api.Index.from_codes(codes.data_ptr(), lens, device=local, full_sa=bool(args.full_sa))
     t_index = time.perf_counter() - t0
     n_steps = args.warmup + args.steps
-    reads_per_step = 2 * args.batch_pairs
+    paired = not args.single_end
+    reads_per_step = (2 if paired else 1) * args.batch_pairs
     mapper = api.Mapper(index, alg=args.alg, max_read_len=max(256, args.rlen), max_batch_reads=reads_per_step)
     batches = []
     for s in range(n_steps):
-        b = make_reads(codes, lens, args.batch_pairs, args.rlen, seed=1000 * (rank + 1) + s, device=dev, sub=args.sub, ins=args.ins, dele=args.dele)
+        b = make_reads(codes, lens, args.batch_pairs, args.rlen, seed=1000 * (rank + 1) + s, device=dev, sub=args.sub, ins=args.ins, dele=args.dele, paired=paired)
         batches.append(b.reshape(-1).contiguous())
     off = (torch.arange(reads_per_step + 1, device=dev, dtype=torch.int64) * args.rlen).to(torch.uint32)
     cpu_pairs = args.cpu_pairs
     if cpu_pairs < 0:  # ~20 s at ~15 k reads/s/core, bounded by one batch
         cpu_pairs = int(min(args.batch_pairs, max(50_000, (os.cpu_count() or 1) * 15_000 * 20 // 2)))
-    sample = batches[0].reshape(reads_per_step, args.rlen)[: 2 * cpu_pairs].cpu() if (rank == 0 and world == 1 and cpu_pairs) else None
+    sample = batches[0].reshape(reads_per_step, args.rlen)[: (2 if paired else 1) * cpu_pairs].cpu() if (rank == 0 and world == 1 and cpu_pairs) else None
     del codes
     d_aln = torch.empty(reads_per_step * 64, dtype=torch.uint8, device=dev)
     d_cig = torch.empty(api.cigar_pool_words(reads_per_step), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
-    traj = Trajectory(dist, dev, world, rank, (args.batch_pairs + 99) // 100) if world > 1 else None
+    traj = Trajectory(dist, dev, world, rank, (args.batch_pairs + 99) // 100) if (world > 1 and paired) else None
 
     def step(i):
         if traj:
             traj.step(mapper, batches[i].data_ptr(), off.data_ptr(), reads_per_step, d_aln.data_ptr(), d_cig.data_ptr())
         else:
-            mapper.map_batch_dev(batches[i].data_ptr(), off.data_ptr(), reads_per_step, True, d_aln.data_ptr(), d_cig.data_ptr())
+            mapper.map_batch_dev(batches[i].data_ptr(), off.data_ptr(), reads_per_step, paired, d_aln.data_ptr(), d_cig.data_ptr())
 
     for i in range(args.warmup):
         step(i)
@@ -596,7 +632,7 @@ def main():
 
     # ---- the same batches from pinned host memory, records back to pinned host memory (not `value`) ----------
     pcie = None
-    if args.pcie_steps > 0:
+    if args.pcie_steps > 0 and paired:
         try:
             pcie = pcie_inclusive(args, mapper, batches, reads_per_step, dist, dev)
         except Exception as e:
@@ -620,7 +656,7 @@ def main():
             "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64/int8", "data": "synthetic",
             "config": {"workload": f"synthetic GRCh38-sized genome, {args.genome_mbp:.0f} Mbp ({args.contigs} contigs, {genome_note}; GRCh38 itself is unavailable offline), "
-                                   f"{args.batch_pairs} pairs x {args.rlen} bp PE per step per GPU (sub {args.sub}, ins {args.ins}, del {args.dele} per base), -alg {args.alg}",
+                                   f"{args.batch_pairs} {'pairs' if paired else 'reads'} x {args.rlen} bp {'PE' if paired else 'SE'} per step per GPU (sub {args.sub}, ins {args.ins}, del {args.dele} per base), -alg {args.alg}",
                        "reads_per_step_per_gpu": reads_per_step, "full_sa_in_hbm": bool(args.full_sa), "index_build_s": round(t_index, 2),
                        "index_hbm_gb": round(index.hbm_bytes / 1e9, 2),
                        "multi_gpu": None if world == 1 else f"one process per GPU, index replicated, rank r maps batch {world}*step + r; one avgDist trajectory over the "
@@ -632,6 +668,9 @@ def main():
                          "mapped_frac": round(d["mapped"] / max(d["reads"], 1), 4)},
             "stage_ms_per_step": {k[3:]: round(d[k] / args.steps, 3) for k in d if k.startswith("ms_")},
             "tier1_pairs": d["tier1_pairs"], "replayed_pairs": d["replayed_pairs"], "halved_selections": d["halved_selections"],
+            "dp": {"jobs": d["dp_jobs"], "cells": d["dp_cells"], "ms_per_step": round(d["ms_dp"] / args.steps, 3),
+                   "gcups": round(d["dp_cells"] / max(d["ms_dp"], 1e-9) / 1e6, 2),
+                   "note": "cell updates of all gapped-extension problems (query x target) over the time of the DP stage (six kernels on three streams)"},
         }
         if pcie is not None:
             out["value_pcie_inclusive"] = pcie
@@ -642,7 +681,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, index, sample)
             except Exception as e:  # the baseline must never take the bench line down
                 out["cpu_baseline"] = {"error": str(e)[:200]}
-        if args.second_genome and world == 1:
+        if (args.second_genome or args.other_configs) and world == 1:
             try:
                 if mapper is not None:
                     mapper.close()
@@ -650,9 +689,15 @@ def main():
                 index.close()
                 del d_aln, d_cig
                 torch.cuda.empty_cache()
-                out["other_genome"] = other_genome(args)
-            except Exception as e:
-                out["other_genome"] = {"error": str(e)[:200]}
+            except Exception:
+                pass
+            if args.second_genome:
+                try:
+                    out["other_genome"] = other_genome(args)
+                except Exception as e:
+                    out["other_genome"] = {"error": str(e)[:200]}
+            if args.other_configs:
+                out["other_configs"] = other_configs(args)
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()

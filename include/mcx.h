@@ -105,7 +105,7 @@ typedef struct mcx_stats {
     int64_t reads, mapped, pairs, pair_dist_sum;
     int64_t pair_len_sum;   /* ReadLengthSum: bases of the reads counted in `pairs` (ReadMapping.cpp:529-530) */
     int64_t fm_ext_steps;   /* E of SURVEY.md §8d: sum of BWT_Search lengths */
-    int64_t fm_blocks;      /* 64-byte blocks the extension walk touched */
+    int64_t fm_blocks;      /* index records the extension walk fetched: 16-byte rank records (64-byte .bwt blocks without the full suffix array) */
     int64_t sa_hits;        /* H: suffix-array hits resolved */
     int64_t dp_jobs, dp_cells;
     int64_t tier1_pairs;    /* pairs re-run with the large capacities */

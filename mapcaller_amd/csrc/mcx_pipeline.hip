@@ -754,7 +754,8 @@ struct ClusterLds { // per-wave arrays in dynamic LDS (cap = the tier's candidat
     int32_t *pick;      // [cand_cap]: the partner a candidate of read 1 chose (pairing scratch)
 };
 
-static inline size_t cluster_lds_bytes(int hit_cap, int cand_cap) { return (size_t)hit_cap * sizeof(Hit) + (size_t)cand_cap * (2 * (8 + 4 + 4 + 4) + 4) + 64; }
+static inline MCX_HD int cluster_sort_room(int hit_cap) { int p = 1; while (p < hit_cap) p <<= 1; return p; } // (the sort works on a power of two)
+static inline size_t cluster_lds_bytes(int hit_cap, int cand_cap) { return (size_t)cluster_sort_room(hit_cap) * sizeof(Hit) + (size_t)cand_cap * (2 * (8 + 4 + 4 + 4) + 4) + 64; }
 constexpr int kClusterSmall = 192; // hits per read up to which a pair takes the launch with the small share of LDS (more wavefronts per CU)
 
 // (hits_lo < hits <= hits_hi: the pairs of this launch, by the larger hit count of their reads; lds_hits / lds_cands: what its LDS holds)
@@ -769,7 +770,7 @@ __global__ void __launch_bounds__(64) k_cluster_wave(Ctx cx, ReadBatch rb, PairS
     ClusterLds L;
     {
         uint8_t *p = cl_lds;
-        L.hits = (Hit *)p; p += (size_t)lds_hits * sizeof(Hit);
+        L.hits = (Hit *)p; p += (size_t)cluster_sort_room(lds_hits) * sizeof(Hit);
         for (int s = 0; s < 2; s++) { L.pd[s] = (int64_t *)p; p += (size_t)lds_cands * 8; }
         for (int s = 0; s < 2; s++) { L.score[s] = (int32_t *)p; p += (size_t)lds_cands * 4; }
         for (int s = 0; s < 2; s++) { L.span[s] = (uint32_t *)p; p += (size_t)lds_cands * 4; }
