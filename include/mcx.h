@@ -150,6 +150,13 @@ int mcx_map_batch(mcx_ctx *, const uint8_t *bases, const uint32_t *off, uint32_t
  * in steps (mcx_batch_*): the first hands out the batch's place in HBM, the second starts the copy out.
  * bytes_in / bytes_out (may be NULL): bytes moved over the boundary so far. */
 int mcx_stream_submit(mcx_ctx *, const uint8_t *bases, const uint32_t *off, uint32_t n_reads);
+/* The same with the reads as a host parser packs them — a quarter of the bytes over PCIe: read r has len[r] bases, its 2-bit codes
+ * (A 0, C 1, G 2, T 3; sixteen bases to a word, the first in the top bits) are the words codes[r * row_words ..]; every byte of
+ * a read that is not one of the upper-case letters ACGT is listed in `odd` as (read << 32 | position << 8 | byte) and has
+ * code 0 in the row.  The device restores the ASCII bytes exactly (mcx_stream_next hands out the same d_bases / d_off as after
+ * mcx_stream_submit), so nothing downstream can tell the two apart.  row_words >= ceil(longest read / 16). */
+int mcx_stream_submit_packed(mcx_ctx *, const uint32_t *codes, uint32_t row_words, const uint32_t *len, uint32_t n_reads, const uint64_t *odd,
+                             uint32_t n_odd);
 int mcx_stream_map(mcx_ctx *, int paired, int64_t avg_state[4], mcx_aln *aln, uint32_t *cigar, mcx_stats *stats);
 int mcx_stream_collect(mcx_ctx *, uint64_t *bytes_in, uint64_t *bytes_out);
 int mcx_stream_next(mcx_ctx *, const uint8_t **d_bases, const uint32_t **d_off, uint32_t *n_reads, mcx_aln **d_aln, uint32_t **d_cigar);
@@ -274,23 +281,23 @@ int mcx_map_files(mcx_ctx *, const char *fq1, const char *fq2, const char *sam_p
  * interleaved_pairs = -p (one file holds both mates alternately), host_threads = -t (parser /
  * formatter threads on the host; 0 = pick), append_sam: a further library of the same run (no
  * header, append), avg_state: carries the insert-size estimate across libraries (NULL = fresh).
- * Sharding over several GPUs (one process each): the input stream is cut into batches of the
- * context's max_batch_reads, batch k belongs to shard k % shard_count; a shard maps and writes only
- * its batches.  no_sam_header / sam_index_path ("batch bytes" per line) let the parts be merged in
- * input order (mcx_sam_merge).  avg_state must be the same on every shard when the run starts; it is
- * again when it ends (avg_state[3] = reads of the whole input). */
+ * Sharding over several GPUs (one shard each — threads of one process or processes): the input stream
+ * is cut into batches of the context's max_batch_reads, batch k belongs to shard k % shard_count; a
+ * shard parses (plain FASTQ: touches) and maps only its batches, and writes their lines at their final
+ * place in sam_path — the same path on every shard: shard 0 creates the file and writes the header,
+ * the shards learn where their batches' text goes from one another (mcx_file_opts.exchange).  avg_state
+ * must be the same on every shard when the run starts; it is again when it ends (avg_state[3] = reads
+ * of the whole input). */
 typedef struct mcx_file_opts {
-    int32_t interleaved_pairs, host_threads, append_sam, no_sam_header;
+    int32_t interleaved_pairs, host_threads, append_sam, reserved0;
     int64_t *avg_state; /* int64_t[4], see mcx_avg_init */
     int32_t shard_rank, shard_count; /* 0, 0: the whole input */
-    const char *sam_index_path;      /* NULL: none */
+    const char *reserved1;
     const mcx_exchange *exchange;    /* required when shard_count > 1: the shards walk ONE insert-size trajectory and
                                         decide the duplicate cap over ONE input order, so that SAM and profile equal the
                                         single-stream run's (rank/size must equal shard_rank/shard_count) */
 } mcx_file_opts;
 void mcx_file_opts_default(mcx_file_opts *);
-/* <sam_path>.part<r> (+ .idx) of shards 0..parts-1 -> sam_path, batches in input order; removes the parts */
-int mcx_sam_merge(const char *sam_path, int32_t parts);
 int mcx_map_files_ex(mcx_ctx *, const char *fq1, const char *fq2, const mcx_file_opts *, const char *sam_path, mcx_stats *stats);
 
 #ifdef __cplusplus

@@ -23,6 +23,39 @@ def cigar_pool_words(n_reads):
     return n_reads * CIGAR_STRIDE + CIGAR_SLACK
 
 
+def pack_reads(bases, lens=None):
+    """What mcx_stream_submit_packed takes, from ASCII reads: ``bases`` a torch uint8 tensor [n_reads, rlen] (any device; ``lens``
+    optional int tensor of the reads' lengths).  Returns pinned host tensors (codes int32 [n_reads, row_words], len int32 [n_reads],
+    odd int64 [n_odd]) — 2-bit codes sixteen bases to a word, first base on top; every byte that is not one of ACGT listed with its place."""
+    import torch
+    n, rlen = bases.shape
+    row_words = (rlen + 15) // 16
+    lut = torch.zeros(256, dtype=torch.int64, device=bases.device)
+    for i, ch in enumerate(b"ACGT"):
+        lut[ch] = i
+    known = torch.zeros(256, dtype=torch.bool, device=bases.device)
+    for ch in b"ACGT":
+        known[ch] = True
+    b64 = bases.long()
+    if lens is None:
+        lens_t = torch.full((n,), rlen, dtype=torch.int64, device=bases.device)
+    else:
+        lens_t = lens.to(bases.device).long()
+    inside = torch.arange(rlen, device=bases.device)[None, :] < lens_t[:, None]
+    codes = lut[b64] * inside
+    pad = row_words * 16 - rlen
+    if pad:
+        codes = torch.nn.functional.pad(codes, (0, pad))
+    shifts = (30 - 2 * torch.arange(16, device=bases.device)).long()
+    words = (codes.reshape(n, row_words, 16) << shifts).sum(-1)
+    words = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
+    bad = (~known[b64]) & inside
+    r, pos = torch.nonzero(bad, as_tuple=True)
+    odd = (r << 32) | (pos << 8) | b64[r, pos]
+    return (words.contiguous().cpu().pin_memory(), lens_t.to(torch.int32).cpu().pin_memory(), odd.cpu().pin_memory() if odd.numel() else torch.zeros(1, dtype=torch.int64).pin_memory(),
+            int(odd.numel()), row_words)
+
+
 # every symbol include/mcx.h declares
 SYMBOLS = [
     "mcx_last_error", "mcx_device_count", "mcx_index_load", "mcx_index_build", "mcx_index_from_codes", "mcx_index_save", "mcx_index_free",
@@ -32,8 +65,8 @@ SYMBOLS = [
     "mcx_profile_attach", "mcx_profile_finalize", "mcx_profile_sparse", "mcx_planes_alloc", "mcx_planes_free",
     "mcx_vcf_defaults", "mcx_call_variants",
     "mcx_batch_begin", "mcx_batch_sums", "mcx_batch_replay", "mcx_batch_end", "mcx_avg_walk", "mcx_exchange_local", "mcx_exchange_local_free",
-    "mcx_profile_sparse_shard", "mcx_batch_end_keys", "mcx_batch_accumulate", "mcx_sam_merge",
-    "mcx_stream_submit", "mcx_stream_map", "mcx_stream_collect", "mcx_stream_next", "mcx_stream_mapped",
+    "mcx_profile_sparse_shard", "mcx_batch_end_keys", "mcx_batch_accumulate",
+    "mcx_stream_submit", "mcx_stream_submit_packed", "mcx_stream_map", "mcx_stream_collect", "mcx_stream_next", "mcx_stream_mapped",
 ]
 # include/mcx_comm.h (libmcx_comm.so: the RCCL side, loaded by the native CLI only)
 COMM_LIB_PATH = os.path.join(_HERE, "libmcx_comm.so")
@@ -119,8 +152,8 @@ def dist_exchange(device=None) -> Exchange:
 
 class FileOpts(C.Structure):
     """mcx_file_opts: -p, -t, library append, insert-size state across libraries, sharding."""
-    _fields_ = [("interleaved_pairs", C.c_int32), ("host_threads", C.c_int32), ("append_sam", C.c_int32), ("no_sam_header", C.c_int32),
-                ("avg_state", C.POINTER(C.c_int64)), ("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("sam_index_path", C.c_char_p),
+    _fields_ = [("interleaved_pairs", C.c_int32), ("host_threads", C.c_int32), ("append_sam", C.c_int32), ("reserved0", C.c_int32),
+                ("avg_state", C.POINTER(C.c_int64)), ("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("reserved1", C.c_char_p),
                 ("exchange", C.POINTER(Exchange))]
 
 
@@ -200,8 +233,8 @@ def lib() -> C.CDLL:
     L.mcx_exchange_local.argtypes = [C.c_int32, C.POINTER(Exchange)]
     L.mcx_exchange_local_free.argtypes = [C.POINTER(Exchange)]
     L.mcx_exchange_local_free.restype = None
-    L.mcx_sam_merge.argtypes = [C.c_char_p, C.c_int32]
     L.mcx_stream_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.mcx_stream_submit_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
     L.mcx_stream_map.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.POINTER(Stats)]
     L.mcx_stream_collect.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.mcx_planes_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
@@ -348,19 +381,17 @@ class Mapper:
 
     # ---- whole path ---------------------------------------------------------------------
     def map_files(self, fq1: str, fq2: Optional[str], sam: Optional[str], interleaved: bool = False, threads: int = 0,
-                  shard: Optional[Tuple[int, int]] = None, sam_header: bool = True, sam_index: Optional[str] = None,
-                  exchange: Optional[Exchange] = None, append_sam: bool = False) -> dict:
+                  shard: Optional[Tuple[int, int]] = None, exchange: Optional[Exchange] = None, append_sam: bool = False) -> dict:
         """Files in, SAM out (mcx_map_files_ex).  ``interleaved`` = -p, ``threads`` = -t; ``shard`` =
         (rank, count) with ``exchange``: map every count-th batch of the input stream while the shards
-        keep one insert-size trajectory and one duplicate-cap order; ``sam_index``: file that receives
-        "batch bytes" per batch written (to merge the parts of a sharded run, ``merge_sam``).  The
-        insert-size state (self.avg) carries over from call to call like the reference's globals
-        (a new library starts a new 200-read chunk); ``append_sam``: a further library of the same run."""
+        keep one insert-size trajectory and one duplicate-cap order, and write the batches' lines at their
+        final place in ``sam`` (the same path on every shard; shard 0 creates it).  The insert-size state
+        (self.avg) carries over from call to call like the reference's globals (a new library starts a
+        new 200-read chunk); ``append_sam``: a further library of the same run."""
         st = Stats()
         fo = FileOpts()
         lib().mcx_file_opts_default(C.byref(fo))
         fo.interleaved_pairs, fo.host_threads = int(interleaved), threads
-        fo.no_sam_header = 0 if sam_header else 1
         fo.append_sam = int(append_sam)
         if self.avg[3] % 200:
             self.avg[3] += 200 - self.avg[3] % 200
@@ -370,8 +401,6 @@ class Mapper:
                 raise ValueError("a sharded run needs an exchange (api.dist_exchange())")
             fo.shard_rank, fo.shard_count = int(shard[0]), int(shard[1])
             fo.exchange = C.pointer(exchange)
-        if sam_index:
-            fo.sam_index_path = sam_index.encode()
         _check(lib().mcx_map_files_ex(self._h, fq1.encode(), (fq2 or "").encode() or None, C.byref(fo), (sam or "").encode() or None,
                                       C.byref(st)), "mcx_map_files_ex")
         return st.as_dict()
@@ -407,6 +436,25 @@ class Mapper:
         for i in range(k + 2):  # submit(i); map(i - 1); collect(i - 2)
             if i < k:
                 _check(L.mcx_stream_submit(self._h, host_bases_ptrs[i], host_off_ptr, n_reads), "mcx_stream_submit")
+            if 1 <= i <= k:
+                a, g = outs[(i - 1) % len(outs)]
+                _check(L.mcx_stream_map(self._h, int(paired), self.avg, a.data_ptr(), g.data_ptr(), C.byref(self.stats)), "mcx_stream_map")
+            if i >= 2:
+                _check(L.mcx_stream_collect(self._h, C.byref(h2d), C.byref(d2h)), "mcx_stream_collect")
+        return h2d.value, d2h.value
+
+    def map_stream_packed(self, packed, n_reads: int, paired: bool, outputs=None):
+        """map_stream with the reads as a host parser packs them (pack_reads): ``packed`` = [(codes ptr, row_words, len ptr, odd ptr, n_odd)]
+        per batch, all in pinned host memory."""
+        L = lib()
+        k = len(packed)
+        outs = outputs or self.stream_outputs(n_reads, min(k, 3))
+        h2d = C.c_uint64()
+        d2h = C.c_uint64()
+        for i in range(k + 2):
+            if i < k:
+                codes, row_words, lens, odd, n_odd = packed[i]
+                _check(L.mcx_stream_submit_packed(self._h, codes, row_words, lens, n_reads, odd, n_odd), "mcx_stream_submit_packed")
             if 1 <= i <= k:
                 a, g = outs[(i - 1) % len(outs)]
                 _check(L.mcx_stream_map(self._h, int(paired), self.avg, a.data_ptr(), g.data_ptr(), C.byref(self.stats)), "mcx_stream_map")

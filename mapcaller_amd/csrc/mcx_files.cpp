@@ -1,15 +1,21 @@
-// mapcaller_amd/csrc/mcx_files.cpp — files in, SAM text out, around mcx_map_batch (host only).
+// mapcaller_amd/csrc/mcx_files.cpp — files in, SAM text out, around the batch API (host only).
 //
 // Replaces the reading and writing halves of the reference's ReadMapping() loop: GetNextChunk /
 // gzGetNextChunk (src/GetData.cpp:85-140) and Generate{Paired,Single}SamStream + fprintf
 // (src/SamReport.cpp:324-488, src/ReadMapping.cpp:536-546).  The reference does both per 200-read
 // chunk under locks; at GPU mapping rates they are the wall, so here
-//   * each input file has its own parser thread that splits big blocks into lines (plain files and
-//     .gz through zlib) and delivers flat arrays — no per-read allocation;
-//   * batches of up to max_batch_reads flow through a three-stage pipeline (parse | map on the GPU |
-//     format + write) so that the stages overlap;
-//   * SAM lines of a batch are formatted by a pool of host threads into per-slice buffers and
-//     written in input order.
+//   * a plain FASTQ file is mapped into memory and indexed by line count (a record is four lines from
+//     the start of the file, whatever the lines hold — GetData.cpp:45-55), in parallel; a batch is then
+//     parsed by a pool of host threads, each from the first byte of its own stretch of records, with
+//     the reads' names, bases and qualities left where they lie in the file (the SAM formatter reads
+//     them there) and the bases packed to 2 bits on the way (a quarter of the bytes cross PCIe); a
+//     shard of a several-GPU run touches only the bytes of its own batches;
+//   * .gz files and FASTA go through one sequential reader per file (zlib / multi-line records);
+//   * batches flow through parse | copy in, map, copy out (three device slots: the copies of one
+//     batch under the kernels of its neighbours) | format + write;
+//   * SAM lines are formatted by a second pool into per-slice buffers and written with positioned
+//     writes, every slice at its final place in the file — by every shard into the one output file:
+//     the shards tell each other their batches' sizes with the rounds' other messages.
 // Text semantics follow the reference byte for byte: header trimming (GetData.cpp:3-20), the last
 // byte of a FASTQ sequence line dropped (:48-53), multi-line FASTA for plain files (:56-77), the
 // 1024-byte line buffer, the '@'/'>' check and single-line FASTA of the .gz reader (:101-128), an
@@ -21,11 +27,17 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include "../../include/mcx.h"
@@ -35,15 +47,71 @@ using namespace mcx;
 
 namespace {
 
-// ---- input -------------------------------------------------------------------------------------------
-struct Entries { // reads of one file for one batch, flat
-    std::vector<char> names; std::vector<uint32_t> name_off;
-    std::vector<uint8_t> seq; std::vector<uint32_t> seq_off;
-    std::vector<char> qual; // FASTQ: parallel to seq (NUL-padded where the quality line was shorter)
-    bool last = false;      // the file ended (or delivered an empty read) after these
-    std::string error;
-    uint32_t n() const { return (uint32_t)name_off.size() - 1; }
-    void clear() { names.clear(); name_off.assign(1, 0); seq.clear(); seq_off.assign(1, 0); qual.clear(); last = false; error.clear(); }
+typedef std::chrono::steady_clock::time_point Tick;
+inline Tick now() { return std::chrono::steady_clock::now(); }
+inline double secs(Tick a, Tick b) { return std::chrono::duration<double>(b - a).count(); }
+
+// ---- a pool of host threads that lives as long as the run ---------------------------------------------------
+class Pool {
+public:
+    explicit Pool(int n) : n_(std::max(1, n))
+    {
+        for (int k = 1; k < n_; k++) th_.emplace_back([this] { work(); });
+    }
+    ~Pool()
+    {
+        { std::unique_lock<std::mutex> l(m_); stop_ = true; gen_++; cv_.notify_all(); }
+        for (auto &t : th_) t.join();
+    }
+    int size() const { return n_; }
+    // f(k) for k in [0, parts), the calling thread taking its share; returns when all are done.  One run() at a time per pool.
+    void run(int parts, const std::function<void(int)> &f)
+    {
+        if (parts <= 0) return;
+        if (parts == 1 || n_ == 1) { for (int k = 0; k < parts; k++) f(k); return; }
+        {
+            std::unique_lock<std::mutex> l(m_);
+            f_ = &f; parts_ = parts; next_.store(0); left_ = parts; gen_++;
+            cv_.notify_all();
+        }
+        drain();
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [&] { return left_ == 0; });
+        f_ = nullptr;
+    }
+private:
+    void drain()
+    {
+        for (;;) {
+            const int k = next_.fetch_add(1);
+            if (k >= parts_) break;
+            (*f_)(k);
+            std::unique_lock<std::mutex> l(m_);
+            if (--left_ == 0) done_.notify_all();
+        }
+    }
+    void work()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                if (!f_ || left_ == 0) continue;
+            }
+            drain();
+        }
+    }
+    int n_;
+    std::vector<std::thread> th_;
+    std::mutex m_; std::condition_variable cv_, done_;
+    const std::function<void(int)> *f_ = nullptr;
+    int parts_ = 0, left_ = 0;
+    std::atomic<int> next_{0};
+    uint64_t gen_ = 0;
+    bool stop_ = false;
 };
 
 template <typename T> class Queue { // bounded hand-over between two stages
@@ -51,10 +119,158 @@ public:
     explicit Queue(size_t cap) : cap_(cap) {}
     void push(T v) { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return q_.size() < cap_; }); q_.push_back(std::move(v)); cv_.notify_all(); }
     T pop() { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return !q_.empty(); }); T v = std::move(q_.front()); q_.pop_front(); cv_.notify_all(); return v; }
+    bool try_pop(T &v) { std::unique_lock<std::mutex> l(m_); if (q_.empty()) return false; v = std::move(q_.front()); q_.pop_front(); cv_.notify_all(); return true; }
 private:
     std::mutex m_; std::condition_variable cv_; std::deque<T> q_; size_t cap_;
 };
 
+// ---- input -------------------------------------------------------------------------------------------
+// One read as the formatter needs it: where its name, bases and qualities lie (offsets from View::base — the mapped file,
+// or the batch's own copy for .gz / FASTA input).
+struct Rec {
+    uint64_t name, seq, qual;
+    uint32_t rlen, q_take;  // q_take: bytes of the quality line that count (min(line, rlen), GetData.cpp:51-52; printed up to a NUL)
+    uint32_t name_len;
+};
+struct View { // the reads of one file for one batch
+    const char *base = nullptr;
+    std::vector<Rec> recs;
+    std::vector<char> own;  // .gz / FASTA: the batch's copy of names, bases, qualities
+    bool last = false;      // the file ended (or delivered an empty read) after these
+    std::string error;
+    uint32_t n() const { return (uint32_t)recs.size(); }
+    void clear() { recs.clear(); own.clear(); last = false; error.clear(); base = nullptr; }
+};
+
+// IdentifyHeaderBegPos / IdentifyHeaderEndPos, GetData.cpp:3-20
+inline void header_of(const char *l, int len, int &p1, int &p2)
+{
+    const int lim = len > 100 ? 100 : len;
+    p1 = len - 1; p2 = lim - 1;
+    for (int i = 1; i < len; i++) if (l[i] != '>' && l[i] != '@') { p1 = i; break; }
+    for (int i = 1; i < lim; i++) if (l[i] == ' ' || l[i] == '/' || !isprint((unsigned char)l[i])) { p2 = i; break; }
+}
+
+// 2-bit row for mcx_stream_submit_packed: sixteen bases to a word, the first on top; bytes that are not ACGT are listed
+inline void pack_row(const uint8_t *seq, uint32_t rlen, uint32_t read, uint32_t *row, uint32_t row_words, std::vector<uint64_t> &odd)
+{
+    static const struct Lut { uint8_t v[256]; Lut() { memset(v, 4, sizeof v); v['A'] = 0; v['C'] = 1; v['G'] = 2; v['T'] = 3; } } lut;
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < rlen; i += 16, k++) {
+        const uint32_t n = rlen - i < 16 ? rlen - i : 16;
+        uint32_t w = 0, bad = 0;
+        for (uint32_t j = 0; j < n; j++) { const uint32_t c = lut.v[seq[i + j]]; bad |= c; w |= (c & 3u) << (30 - 2 * j); }
+        if (bad & 4u) {
+            w = 0;
+            for (uint32_t j = 0; j < n; j++) {
+                const uint32_t c = lut.v[seq[i + j]];
+                if (c > 3) odd.push_back(((uint64_t)read << 32) | ((uint64_t)(i + j) << 8) | seq[i + j]);
+                else w |= c << (30 - 2 * j);
+            }
+        }
+        row[k] = w;
+    }
+    for (; k < row_words; k++) row[k] = 0;
+}
+
+// A plain FASTQ file in memory, with the line count ahead of every 64 KB of it: record r begins at line 4 r.
+class MappedFastq {
+public:
+    ~MappedFastq() { if (map_ && size_) munmap((void *)map_, size_); if (fd_ >= 0) close(fd_); }
+    bool open(const std::string &path, std::string &err)
+    {
+        fd_ = ::open(path.c_str(), O_RDONLY);
+        if (fd_ < 0) { err = "cannot open " + path; return false; }
+        struct stat st;
+        if (fstat(fd_, &st) != 0 || !S_ISREG(st.st_mode)) { err = "cannot map " + path; return false; }
+        size_ = (size_t)st.st_size;
+        if (size_) {
+            map_ = (const char *)mmap(nullptr, size_, PROT_READ, MAP_SHARED, fd_, 0);
+            if (map_ == MAP_FAILED) { map_ = nullptr; err = "cannot map " + path; return false; }
+            (void)madvise((void *)map_, size_, MADV_WILLNEED);
+        }
+        n_blocks_ = (size_ + kBlock - 1) / kBlock;
+        cnt_.assign(n_blocks_ + 1, 0);
+        return true;
+    }
+    const char *data() const { return map_; }
+    size_t n_blocks() const { return n_blocks_; }
+    // newlines of blocks [b0, b1) (the shards of a run count a share each and tell one another)
+    void count(size_t b0, size_t b1, Pool &pool)
+    {
+        const size_t n = b1 > b0 ? b1 - b0 : 0;
+        const int parts = (int)std::min<size_t>(n, (size_t)pool.size() * 4);
+        pool.run(parts, [&](int k) {
+            for (size_t b = b0 + n * (size_t)k / (size_t)parts; b < b0 + n * (size_t)(k + 1) / (size_t)parts; b++) {
+                const char *p = map_ + b * kBlock, *e = map_ + std::min(size_, (b + 1) * kBlock);
+                uint32_t c = 0;
+                while (p < e) { const char *q = (const char *)memchr(p, '\n', (size_t)(e - p)); if (!q) break; c++; p = q + 1; }
+                cnt_[b] = c;
+            }
+        });
+    }
+    uint32_t *counts() { return cnt_.data(); }
+    void finish() // prefix sums; lines of the file (an unterminated last line counts, like getline's)
+    {
+        pre_.assign(n_blocks_ + 1, 0);
+        for (size_t b = 0; b < n_blocks_; b++) pre_[b + 1] = pre_[b] + cnt_[b];
+        lines_ = pre_[n_blocks_] + ((size_ && map_[size_ - 1] != '\n') ? 1 : 0);
+    }
+    uint64_t lines() const { return lines_; }
+    // byte at which line L begins (the file's size when it has no such line)
+    size_t line_start(uint64_t L) const
+    {
+        if (L == 0) return 0;
+        size_t lo = 0, hi = n_blocks_; // the block that holds the L-th newline
+        while (lo < hi) { const size_t mid = (lo + hi) / 2; if (pre_[mid + 1] < L) lo = mid + 1; else hi = mid; }
+        if (lo >= n_blocks_) return size_;
+        uint64_t need = L - pre_[lo];
+        const char *p = map_ + lo * kBlock, *e = map_ + std::min(size_, (lo + 1) * kBlock);
+        while (need) { const char *q = (const char *)memchr(p, '\n', (size_t)(e - p)); if (!q) return size_; p = q + 1; need--; }
+        return (size_t)(p - map_);
+    }
+    // Records [r0, r1) appended to recs; stops like GetNextEntry at a missing sequence line or an empty read (false then).
+    bool parse(uint64_t r0, uint64_t r1, int max_len, std::vector<Rec> &recs, std::string &err) const
+    {
+        size_t p = line_start(4 * r0);
+        auto line = [&](const char *&l, size_t &len) { // the next line with its '\n' (getline); false at the end of the file
+            if (p >= size_) return false;
+            l = map_ + p;
+            const char *e = (const char *)memchr(l, '\n', size_ - p);
+            len = e ? (size_t)(e - l) + 1 : size_ - p;
+            p += len;
+            return true;
+        };
+        for (uint64_t r = r0; r < r1; r++) {
+            const char *l; size_t len;
+            if (!line(l, len)) return false;
+            int p1, p2;
+            header_of(l, (int)len, p1, p2);
+            Rec rec; memset(&rec, 0, sizeof rec);
+            rec.name = (uint64_t)(l - map_) + (uint64_t)p1; rec.name_len = p2 > p1 ? (uint32_t)(p2 - p1) : 0;
+            if (!line(l, len)) return false; // no sequence line
+            rec.seq = (uint64_t)(l - map_); rec.rlen = len ? (uint32_t)(len - 1) : 0; // the last byte of the line is dropped (GetData.cpp:48-53)
+            const char *q; size_t ql;
+            (void)line(q, ql);              // the '+' line
+            if (!line(q, ql)) { ql = 0; q = map_; }
+            rec.qual = (uint64_t)(q - map_); rec.q_take = (uint32_t)std::min<size_t>(ql, rec.rlen);
+            if (rec.rlen == 0) return false; // `.rlen == 0` ends the input (GetData.cpp:91)
+            if ((int)rec.rlen > max_len) { err = "read " + std::string(map_ + rec.name, rec.name_len) + " is longer than max_read_len"; return false; }
+            recs.push_back(rec);
+        }
+        return true;
+    }
+private:
+    enum : size_t { kBlock = 64u << 10 };
+    int fd_ = -1;
+    const char *map_ = nullptr;
+    size_t size_ = 0, n_blocks_ = 0;
+    std::vector<uint32_t> cnt_;
+    std::vector<uint64_t> pre_;
+    uint64_t lines_ = 0;
+};
+
+// The sequential reader: .gz through zlib, FASTA (multi-line records).
 class Parser {
 public:
     bool open(const std::string &path, std::string &err)
@@ -91,13 +307,13 @@ public:
     }
     bool fastq() const { return fastq_; }
 
-    // appends up to `want` reads; false once the input is exhausted (Entries::last set)
-    bool take(Entries &e, uint32_t want, int max_len)
+    // appends up to `want` reads (copied into v.own); false once the input is exhausted (View::last set)
+    bool take(View &v, uint32_t want, int max_len)
     {
-        for (uint32_t i = 0; i < want; i++) {
-            if (!entry(e, max_len)) { e.last = true; return false; }
-        }
-        return true;
+        bool more = true;
+        for (uint32_t i = 0; i < want && more; i++) if (!entry(v, max_len)) { v.last = true; more = false; }
+        v.base = v.own.data();
+        return more;
     }
 
 private:
@@ -139,16 +355,7 @@ private:
         return true;
     }
 
-    // IdentifyHeaderBegPos / IdentifyHeaderEndPos, GetData.cpp:3-20
-    static void header_of(const char *l, int len, int &p1, int &p2)
-    {
-        const int lim = len > 100 ? 100 : len;
-        p1 = len - 1; p2 = lim - 1;
-        for (int i = 1; i < len; i++) if (l[i] != '>' && l[i] != '@') { p1 = i; break; }
-        for (int i = 1; i < lim; i++) if (l[i] == ' ' || l[i] == '/' || !isprint((unsigned char)l[i])) { p2 = i; break; }
-    }
-
-    bool entry(Entries &e, int max_len)
+    bool entry(View &v, int max_len)
     {
         const char *p; size_t len;
         if (!line(p, len)) return false;
@@ -158,77 +365,42 @@ private:
         }
         int p1, p2;
         header_of(p, (int)len, p1, p2);
-        const size_t name_at = e.names.size();
-        if (p2 > p1) e.names.insert(e.names.end(), p + p1, p + p2);
-        const size_t seq_at = e.seq.size();
+        std::vector<char> &o = v.own;
+        const size_t name_at = o.size();
+        if (p2 > p1) o.insert(o.end(), p + p1, p + p2);
+        Rec rec; memset(&rec, 0, sizeof rec);
+        rec.name = name_at; rec.name_len = (uint32_t)(o.size() - name_at);
+        const size_t seq_at = o.size();
         size_t rlen = 0;
         if (fastq_ || gz_mode_) {
-            if (!line(p, len)) { e.names.resize(name_at); return false; }
+            if (!line(p, len)) { o.resize(name_at); return false; }
             if (gz_mode_) len = strnlen(p, len);
             rlen = len ? len - 1 : 0; // the last byte of the line is dropped (GetData.cpp:48-53, :113)
-            e.seq.insert(e.seq.end(), (const uint8_t *)p, (const uint8_t *)p + rlen);
+            o.insert(o.end(), p, p + rlen);
             if (fastq_) {
                 const char *q; size_t ql;
                 line(q, ql);
                 if (!line(q, ql)) ql = 0;
                 if (gz_mode_) ql = strnlen(q, ql);
                 const size_t take = std::min(ql, rlen);
-                e.qual.insert(e.qual.end(), q, q + take);
-                e.qual.insert(e.qual.end(), rlen - take, '\0'); // strncpy pads with NUL
+                rec.qual = o.size(); rec.q_take = (uint32_t)take;
+                o.insert(o.end(), q, q + take);
             }
         } else { // plain FASTA: every line up to the next header (GetData.cpp:56-77)
             while (line(p, len, false)) {
                 if (p[0] == '>') break;
                 pos_ += len;
-                e.seq.insert(e.seq.end(), (const uint8_t *)p, (const uint8_t *)p + len - 1);
+                o.insert(o.end(), p, p + len - 1);
             }
-            rlen = e.seq.size() - seq_at;
+            rlen = o.size() - seq_at;
         }
-        if (rlen == 0) { e.names.resize(name_at); e.seq.resize(seq_at); return false; } // `.rlen == 0` ends the input (GetData.cpp:91)
-        if ((int)rlen > max_len) { e.error = "read " + std::string(e.names.data() + name_at, e.names.size() - name_at) + " is longer than max_read_len"; return false; }
-        e.name_off.push_back((uint32_t)e.names.size());
-        e.seq_off.push_back((uint32_t)e.seq.size());
+        rec.seq = seq_at; rec.rlen = (uint32_t)rlen;
+        if (rlen == 0) { o.resize(name_at); return false; } // `.rlen == 0` ends the input (GetData.cpp:91)
+        if ((int)rlen > max_len) { v.error = "read " + std::string(o.data() + name_at, rec.name_len) + " is longer than max_read_len"; return false; }
+        v.recs.push_back(rec);
         return true;
     }
 };
-
-// ---- a batch on its way through the stages -------------------------------------------------------------
-struct Batch {
-    Entries in[2];
-    uint32_t n = 0;          // reads
-    uint64_t number = 0;     // position of the batch in the input stream
-    bool two_files = false, fastq = true, last = false;
-    // interleaved reads as mcx_map_batch wants them, and its results: pinned host memory, allocated once per batch object
-    uint8_t *bases = nullptr; uint32_t *off = nullptr; AlnRec *recs = nullptr; uint32_t *cig = nullptr;
-    size_t cap_reads = 0, cap_bases = 0;
-    std::vector<uint8_t> is_mate2;                          // mapped as the second read of a pair
-    uint32_t n_pair_reads = 0;                              // reads [0, n_pair_reads) were mapped as pairs, the rest one by one: two CIGAR pools
-    bool reserve(size_t reads, size_t n_bases)
-    {
-        if (reads > cap_reads) {
-            mcx_pinned_free(off); mcx_pinned_free(recs); mcx_pinned_free(cig);
-            cap_reads = reads;
-            off = (uint32_t *)mcx_pinned_alloc((reads + 1) * sizeof(uint32_t));
-            recs = (AlnRec *)mcx_pinned_alloc(reads * sizeof(AlnRec));
-            cig = (uint32_t *)mcx_pinned_alloc((MCX_CIGAR_POOL_WORDS(reads) + MCX_CIGAR_SLACK) * sizeof(uint32_t)); // (two pools: the pairs', the single reads')
-        }
-        if (n_bases > cap_bases) { mcx_pinned_free(bases); cap_bases = n_bases + n_bases / 8; bases = (uint8_t *)mcx_pinned_alloc(cap_bases); }
-        return off && recs && cig && bases;
-    }
-    ~Batch() { mcx_pinned_free(bases); mcx_pinned_free(off); mcx_pinned_free(recs); mcx_pinned_free(cig); }
-    std::string error;
-    // read r of the batch -> (file, index in that file's entries)
-    void locate(uint32_t r, int &f, uint32_t &i) const { if (two_files) { f = (int)(r & 1); i = r >> 1; } else { f = 0; i = r; } }
-};
-
-template <typename F> void parallel_for(uint32_t n, int threads, F f) // f(begin, end, slice)
-{
-    const int t = (int)std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)threads, (n + 4095) / 4096));
-    if (t == 1) { f(0u, n, 0); return; }
-    std::vector<std::thread> pool;
-    for (int k = 0; k < t; k++) pool.emplace_back([=] { f((uint32_t)((uint64_t)n * k / t), (uint32_t)((uint64_t)n * (k + 1) / t), k); });
-    for (auto &th : pool) th.join();
-}
 
 // ---- SAM text (GeneratePairedSamStream / GenerateSingleSamStream, SamReport.cpp:324-488) --------------------
 inline char comp_char(char c) // GetComplementaryBase, tools.cpp:3-18
@@ -246,7 +418,7 @@ struct Text { // writer over a buffer sized beforehand from an upper bound
     std::vector<char> b;
     char *w = nullptr;
     void start(size_t bound) { if (b.size() < bound) b.resize(bound); w = b.data(); }
-    size_t size() const { return (size_t)(w - b.data()); }
+    size_t size() const { return w ? (size_t)(w - b.data()) : 0; }
     void put(const char *p, size_t n) { memcpy(w, p, n); w += n; }
     void put(char c) { *w++ = c; }
     void lit(const char *s) { put(s, strlen(s)); }
@@ -260,6 +432,50 @@ struct Text { // writer over a buffer sized beforehand from an upper bound
     }
 };
 
+// ---- a batch on its way through the stages -------------------------------------------------------------
+struct Batch {
+    View in[2];
+    uint32_t n = 0;          // reads
+    uint64_t number = 0;     // position of the batch in the input stream
+    bool two_files = false, fastq = true, last = false;
+    std::string error;
+    // what crosses the device boundary, in page-locked memory (allocated once per batch object): 2-bit rows, lengths and the
+    // bytes that are not ACGT on the way in; records and CIGAR words on the way out
+    uint32_t *rows = nullptr, *lens = nullptr; uint64_t *odd = nullptr; AlnRec *recs = nullptr; uint32_t *cig = nullptr;
+    size_t cap_reads = 0, cap_rows = 0, cap_odd = 0;
+    uint32_t row_words = 0, n_odd[2] = {0, 0};
+    std::vector<uint8_t> is_mate2;   // mapped as the second read of a pair
+    uint32_t n_pair_reads = 0;       // reads [0, n_pair_reads) are mapped as pairs, the rest one by one: two parts, two CIGAR pools
+    std::vector<Text> slices;        // the batch's SAM text
+    uint64_t sam_bytes = 0;
+    bool reserve(size_t reads, size_t words_per_read)
+    {
+        if (reads > cap_reads) {
+            mcx_pinned_free(lens); mcx_pinned_free(recs); mcx_pinned_free(cig);
+            cap_reads = reads;
+            lens = (uint32_t *)mcx_pinned_alloc((reads + 1) * sizeof(uint32_t));
+            recs = (AlnRec *)mcx_pinned_alloc(reads * sizeof(AlnRec));
+            cig = (uint32_t *)mcx_pinned_alloc((MCX_CIGAR_POOL_WORDS(reads) + MCX_CIGAR_SLACK) * sizeof(uint32_t)); // (two pools: the pairs', the single reads')
+        }
+        if (reads * words_per_read > cap_rows) { mcx_pinned_free(rows); cap_rows = reads * words_per_read; rows = (uint32_t *)mcx_pinned_alloc(cap_rows * sizeof(uint32_t)); }
+        return lens && recs && cig && rows;
+    }
+    bool reserve_odd(size_t n)
+    {
+        if (n > cap_odd) { mcx_pinned_free(odd); cap_odd = n + n / 2 + 1024; odd = (uint64_t *)mcx_pinned_alloc(cap_odd * sizeof(uint64_t)); }
+        return odd != nullptr;
+    }
+    ~Batch() { mcx_pinned_free(rows); mcx_pinned_free(lens); mcx_pinned_free(odd); mcx_pinned_free(recs); mcx_pinned_free(cig); }
+    // read r of the batch -> (file, index in that file's records)
+    const Rec &rec(uint32_t r, const char *&base) const
+    {
+        const int f = two_files ? (int)(r & 1) : 0;
+        base = in[f].base;
+        return in[f].recs[two_files ? r >> 1 : r];
+    }
+    int n_parts() const { return n == 0 ? 0 : (n_pair_reads ? 1 : 0) + (n_pair_reads < n ? 1 : 0); }
+};
+
 // bytes one SAM line can take at most
 inline size_t sam_bound(const HostIndex &ix, size_t name_len, size_t rlen, int chr, int n_cigar)
 {
@@ -269,16 +485,15 @@ inline size_t sam_bound(const HostIndex &ix, size_t name_len, size_t rlen, int c
 void sam_record(const HostIndex &ix, const Batch &bt, uint32_t r, Text &o)
 {
     static const char opc[8] = {'M', 'I', 'D', 'N', 'S', 'H', 'P', '='};
-    int f; uint32_t i;
-    bt.locate(r, f, i);
-    const Entries &e = bt.in[f];
+    const char *base;
+    const Rec &e = bt.rec(r, base);
     const AlnRec &rec = bt.recs[r];
     // the batch's CIGAR pool (the single-read part of a batch has one of its own behind the pairs'), AlnRec::pad[0] = offset
     const uint32_t *cigar = bt.cig + (r < bt.n_pair_reads ? 0 : MCX_CIGAR_POOL_WORDS(bt.n_pair_reads)) + (size_t)rec.pad[0];
-    const char *seq = (const char *)e.seq.data() + e.seq_off[i];
-    const int rlen = (int)(e.seq_off[i + 1] - e.seq_off[i]);
-    const char *qual = bt.fastq ? e.qual.data() + e.seq_off[i] : nullptr;
-    o.put(e.names.data() + e.name_off[i], e.name_off[i + 1] - e.name_off[i]);
+    const char *seq = base + e.seq;
+    const int rlen = (int)e.rlen;
+    const char *qual = bt.fastq ? base + e.qual : nullptr;
+    o.put(base + e.name, e.name_len);
     const bool mapped = rec.chr >= 0;
     // The reference reverse-complements mate 2 in place before mapping (ReadMapping.cpp:451) and prints
     // that string for forward-strand hits and unmapped reads, its reverse complement otherwise.
@@ -301,8 +516,13 @@ void sam_record(const HostIndex &ix, const Batch &bt, uint32_t r, Text &o)
     else { char *w = o.w; for (int k = 0; k < rlen; k++) *w++ = comp_char(comp_char(seq[k])); o.w = w; } // complemented twice: upper case, N for anything else
     o.put('\t');
     if (!qual) o.put('*');
-    else if (flipped == again) o.put(qual, strnlen(qual, (size_t)rlen)); // printed with %s: stops at a NUL pad
-    else { char *w = o.w; for (int k = rlen - 1; k >= 0 && qual[k] != '\0'; k--) *w++ = qual[k]; o.w = w; }
+    else {
+        // the quality string as the reference holds it: q_take bytes of the line, NUL from there to the read's length (strncpy);
+        // printed with %s — and its reversed copy, when the line was short, begins with that NUL
+        const size_t ql = strnlen(qual, (size_t)e.q_take);
+        if (flipped == again) o.put(qual, ql);
+        else if (e.q_take == e.rlen) { char *w = o.w; for (int k = rlen - 1; k >= 0 && qual[k] != '\0'; k--) *w++ = qual[k]; o.w = w; }
+    }
     if (!mapped) o.lit("\tAS:i:0\tXS:i:0\n");
     else { o.lit("\tNM:i:"); o.num(rec.nm); o.lit("\tAS:i:"); o.num(rec.as); o.lit("\tXS:i:"); o.num(rec.xs); o.put('\n'); }
 }
@@ -365,70 +585,14 @@ extern "C" void mcx_exchange_local_free(mcx_exchange *first)
     first->user = nullptr;
 }
 
-// The parts of a sharded run back into input order (batch k was written by shard k % parts): <sam>.part<r> with
-// <sam>.part<r>.idx ("batch bytes" per line); part 0 starts with the header.  The parts are removed.
-extern "C" int mcx_sam_merge(const char *sam_path, int32_t parts)
-{
-    if (!sam_path || parts < 1) return mcx_set_error(MCX_ERR_ARG, "mcx_sam_merge: bad argument");
-    const std::string base(sam_path);
-    struct Part { FILE *f = nullptr; std::vector<std::pair<uint64_t, uint64_t>> idx; size_t next = 0; };
-    std::vector<Part> ps((size_t)parts);
-    auto close_all = [&] { for (Part &q : ps) if (q.f) fclose(q.f); };
-    for (int r = 0; r < parts; r++) {
-        const std::string pn = base + ".part" + std::to_string(r);
-        FILE *ix = fopen((pn + ".idx").c_str(), "r");
-        ps[(size_t)r].f = fopen(pn.c_str(), "rb");
-        if (!ix || !ps[(size_t)r].f) { if (ix) fclose(ix); close_all(); return mcx_set_error(MCX_ERR_IO, "cannot read " + pn); }
-        unsigned long long k, b;
-        while (fscanf(ix, "%llu %llu", &k, &b) == 2) ps[(size_t)r].idx.push_back(std::make_pair((uint64_t)k, (uint64_t)b));
-        fclose(ix);
-    }
-    FILE *out = fopen(sam_path, "wb");
-    if (!out) { close_all(); return mcx_set_error(MCX_ERR_IO, "cannot write " + base); }
-    std::vector<char> buf(1 << 22);
-    auto copy = [&](FILE *f, uint64_t n) {
-        while (n) {
-            const size_t want = (size_t)std::min<uint64_t>(n, buf.size()), got = fread(buf.data(), 1, want, f);
-            if (got == 0 || fwrite(buf.data(), 1, got, out) != got) return false;
-            n -= got;
-        }
-        return true;
-    };
-    bool ok = true;
-    { // the header: what part 0 holds before its first batch
-        fseek(ps[0].f, 0, SEEK_END);
-        uint64_t total = (uint64_t)ftell(ps[0].f), body = 0;
-        fseek(ps[0].f, 0, SEEK_SET);
-        for (auto &e : ps[0].idx) body += e.second;
-        ok = total >= body && copy(ps[0].f, total - body);
-    }
-    for (uint64_t k = 0; ok; k++) { // batches in input order
-        Part &q = ps[(size_t)(k % (uint64_t)parts)];
-        if (q.next >= q.idx.size()) {
-            // batches without output (an empty tail) are not listed: done when no part has anything left
-            bool any = false;
-            for (Part &o : ps) if (o.next < o.idx.size()) any = true;
-            if (!any) break;
-            continue;
-        }
-        if (q.idx[q.next].first != k) continue;
-        ok = copy(q.f, q.idx[q.next].second);
-        q.next++;
-    }
-    close_all();
-    if (fclose(out) != 0) ok = false;
-    if (!ok) return mcx_set_error(MCX_ERR_IO, "cannot merge the parts of " + base);
-    for (int r = 0; r < parts; r++) { const std::string pn = base + ".part" + std::to_string(r); remove(pn.c_str()); remove((pn + ".idx").c_str()); }
-    return 0;
-}
-
 // ---- one round of a run spread over several shards ------------------------------------------------------
 // Round j holds batches j*N .. j*N+N-1, one per shard.  The shards exchange (a) what each has in the round,
 // (b) per-chunk pair sums until the ONE insert-size trajectory of the input stream (ReadMapping.cpp:462,
 // :538-539) has been walked over all of them and no shard had to re-run a pair, (c) with -vcf, the duplicate-check
-// keys, so that the cap admits reads in input order across shards (AlignmentProfile.cpp:76-77).  Every shard makes
-// the same sequence of exchange calls whatever it holds; a failing shard keeps taking part until the round's
-// next message has told the others.
+// keys, so that the cap admits reads in input order across shards (AlignmentProfile.cpp:76-77), (d) the bytes of
+// SAM text their batches of an earlier round came to, so that every shard writes at its final place.  Every shard
+// makes the same sequence of exchange calls whatever it holds; a failing shard keeps taking part until the
+// round's next message has told the others.
 namespace {
 struct Shards {
     const mcx_exchange *x;
@@ -481,16 +645,12 @@ struct Shards {
         return agree(rc);
     }
 
-    // The paired part of a round.  n = this shard's reads (0: none); avg = the run's state {avgDist, pairs, distance, reads}.
-    int pairs(mcx_ctx *c, const uint8_t *bases, const uint32_t *off, uint32_t n, int64_t read_base, int64_t avg[4], bool profile,
-              mcx_aln *aln, uint32_t *cig, mcx_stats *stats)
+    // The paired part of a round.  n = this shard's reads (0: none), in HBM already; avg = the run's state {avgDist, pairs, distance, reads}.
+    int pairs(mcx_ctx *c, const uint8_t *d_bases, const uint32_t *d_off, uint32_t n, int64_t read_base, int64_t avg[4], bool profile,
+              mcx_aln *d_aln, uint32_t *d_cig, mcx_stats *stats)
     {
         int rc = 0;
-        const uint8_t *d_bases = nullptr; const uint32_t *d_off = nullptr; mcx_aln *d_aln = nullptr; uint32_t *d_cig = nullptr;
-        if (n) {
-            rc = mcx_stage_in(c, bases, off, n, &d_bases, &d_off, &d_aln, &d_cig);
-            if (rc == 0) rc = mcx_batch_begin(c, d_bases, d_off, n, 1, (int32_t)((uint32_t)avg[0] * 1.5), read_base, d_aln, d_cig, stats);
-        }
+        if (n) rc = mcx_batch_begin(c, d_bases, d_off, n, 1, (int32_t)((uint32_t)avg[0] * 1.5), read_base, d_aln, d_cig, stats);
         const size_t words = 4 + 2 * (size_t)cap_chunks;
         msg.assign(words, 0);
         std::vector<int32_t> est(cap_chunks);
@@ -522,25 +682,46 @@ struct Shards {
             if (n) rc = mcx_batch_replay(c, est.data(), &n_redo, stats);
         }
         avg[0] = st[0]; avg[1] = st[1]; avg[2] = st[2];
-        rc = finish_part(c, n != 0, profile, stats, 0);
-        if (rc == 0 && n) rc = mcx_stage_out(c, n, aln, cig);
-        return rc;
+        return finish_part(c, n != 0, profile, stats, 0);
     }
 
     // reads mapped one by one (single-end libraries, the odd tail of an interleaved file): no trajectory
-    int singles(mcx_ctx *c, const uint8_t *bases, const uint32_t *off, uint32_t n, int64_t read_base, bool profile, mcx_aln *aln, uint32_t *cig,
+    int singles(mcx_ctx *c, const uint8_t *d_bases, const uint32_t *d_off, uint32_t n, int64_t read_base, bool profile, mcx_aln *d_aln, uint32_t *d_cig,
                 mcx_stats *stats)
     {
         int rc = 0;
-        const uint8_t *d_bases = nullptr; const uint32_t *d_off = nullptr; mcx_aln *d_aln = nullptr; uint32_t *d_cig = nullptr;
-        if (n) {
-            rc = mcx_stage_in(c, bases, off, n, &d_bases, &d_off, &d_aln, &d_cig);
-            if (rc == 0) rc = mcx_batch_begin(c, d_bases, d_off, n, 0, 0, read_base, d_aln, d_cig, stats);
-        }
-        rc = finish_part(c, n != 0 && rc == 0, profile, stats, rc);
-        if (rc == 0 && n) rc = mcx_stage_out(c, n, aln, cig);
-        return rc;
+        if (n) rc = mcx_batch_begin(c, d_bases, d_off, n, 0, 0, read_base, d_aln, d_cig, stats);
+        return finish_part(c, n != 0 && rc == 0, profile, stats, rc);
     }
+};
+
+// what the formatter and the thread that talks to the other shards tell each other: sizes one way, places the other
+struct Places {
+    std::mutex m; std::condition_variable cv;
+    std::map<uint64_t, uint64_t> size, place; // batch number -> bytes of its text; -> where it goes
+    bool failed = false;
+    void put_size(uint64_t k, uint64_t v) { std::unique_lock<std::mutex> l(m); size[k] = v; cv.notify_all(); }
+    bool wait_size(uint64_t k, uint64_t &v) // false: the run has failed, there is no such size
+    {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return failed || size.count(k); });
+        if (!size.count(k)) return false;
+        v = size[k]; size.erase(k);
+        return true;
+    }
+    void put_place(uint64_t k, uint64_t v) { std::unique_lock<std::mutex> l(m); place[k] = v; cv.notify_all(); }
+    // the place of batch k, or of nothing at all when the run has failed (false)
+    bool wait_place(uint64_t k, uint64_t &v, bool block)
+    {
+        std::unique_lock<std::mutex> l(m);
+        if (block) cv.wait(l, [&] { return failed || place.count(k); });
+        auto it = place.find(k);
+        if (it == place.end()) return false;
+        v = it->second; place.erase(it);
+        return true;
+    }
+    void fail() { std::unique_lock<std::mutex> l(m); failed = true; cv.notify_all(); }
+    bool has_failed() { std::unique_lock<std::mutex> l(m); return failed; }
 };
 } // namespace
 
@@ -557,211 +738,449 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
     const int max_len = mcx_ctx_max_read_len(c);
     const bool two = fq2 && fq2[0];
     const bool paired = two || opt.interleaved_pairs;
-    int threads = opt.host_threads > 0 ? opt.host_threads : (int)std::min<unsigned>(32, std::max<unsigned>(1, std::thread::hardware_concurrency() / 2));
+    const uint64_t shard_count = opt.shard_count > 1 ? (uint64_t)opt.shard_count : 1, shard_rank = shard_count > 1 ? (uint64_t)opt.shard_rank : 0;
+    const bool sharded = shard_count > 1;
+    int threads = opt.host_threads > 0 ? opt.host_threads : (int)std::min<unsigned>(64, std::max<unsigned>(1, std::thread::hardware_concurrency() / 2));
     std::string err;
-    Parser ps[2];
-    if (!ps[0].open(fq1, err)) return mcx_set_error(MCX_ERR_IO, err);
-    if (two && !ps[1].open(fq2, err)) return mcx_set_error(MCX_ERR_IO, err);
-    if (two && ps[0].fastq() != ps[1].fastq()) return mcx_set_error(MCX_ERR_IO, std::string(fq1) + " and " + fq2 + " are with different format");
-    FILE *sam = nullptr;
-    if (sam_path && sam_path[0]) {
-        sam = strcmp(sam_path, "-") == 0 ? stdout : fopen(sam_path, opt.append_sam ? "a" : "w");
-        if (!sam) return mcx_set_error(MCX_ERR_IO, std::string("cannot write ") + sam_path);
-        setvbuf(sam, nullptr, _IOFBF, 1 << 22);
-        if (!opt.append_sam && !opt.no_sam_header) { std::string hdr; sam_header(hix, hdr); fputs(hdr.c_str(), sam); }
-    }
-    FILE *sam_index = nullptr; // "batch number, bytes" per batch written: lets the parts of a sharded run be merged in input order
-    if (sam && opt.sam_index_path && opt.sam_index_path[0]) {
-        sam_index = fopen(opt.sam_index_path, "w");
-        if (!sam_index) return mcx_set_error(MCX_ERR_IO, std::string("cannot write ") + opt.sam_index_path);
-    }
+    Shards sh;
     const uint64_t batch_reads = std::max<uint64_t>(kReadChunkSize, mcx_ctx_max_reads(c) / kReadChunkSize * kReadChunkSize);
+    sh.x = opt.exchange; sh.slot_stride = (uint32_t)batch_reads; sh.cap_chunks = (uint32_t)(batch_reads / kReadChunkSize + 2);
+    // (from here on a sharded run's shards leave together: whatever fails on one is told to the others)
+    int rc = 0;
+
+    // ---- the input: mapped and indexed (plain FASTQ), or a sequential reader per file ---------------------------
+    auto plain_fastq = [](const char *path) {
+        const std::string p(path);
+        if (p.size() > 3 && p.compare(p.size() - 3, 3, ".gz") == 0) return false;
+        if (getenv("MCX_SERIAL_PARSER")) return false; // (tests: the sequential reader on plain files)
+        struct stat st;
+        if (stat(path, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0) return false;
+        FILE *f = fopen(path, "rb");
+        if (!f) return false;
+        const int ch = fgetc(f);
+        fclose(f);
+        return ch == '@'; // CheckReadFormat, GetData.cpp:22-31
+    };
+    const bool mapped_input = plain_fastq(fq1) && (!two || plain_fastq(fq2));
+    Pool pool(threads);        // parse + pack
+    Pool fpool(threads);       // format + write (threads of its own: the two stages overlap)
+    MappedFastq mf[2];
+    Parser ps[2];
+    bool fastq = true;
+    if (mapped_input) {
+        for (int f = 0; f < (two ? 2 : 1) && rc == 0; f++) if (!mf[f].open(f ? fq2 : fq1, err)) rc = mcx_set_error(MCX_ERR_IO, err);
+        if (sharded && (rc = sh.agree(rc))) return rc;
+        if (rc) return rc;
+        for (int f = 0; f < (two ? 2 : 1); f++) {
+            // the line counts: every shard counts a share of the blocks, then they tell one another
+            const size_t nb = mf[f].n_blocks();
+            const size_t b0 = nb * shard_rank / shard_count, b1 = nb * (shard_rank + 1) / shard_count;
+            mf[f].count(b0, b1, pool);
+            if (sharded) {
+                const size_t most = (nb + shard_count - 1) / shard_count + 1;
+                std::vector<uint32_t> mine(most, 0);
+                memcpy(mine.data(), mf[f].counts() + b0, (b1 - b0) * sizeof(uint32_t));
+                if (int e = sh.gather(mine.data(), most * sizeof(uint32_t))) return e;
+                for (uint64_t r = 0; r < shard_count; r++) {
+                    const size_t r0 = nb * r / shard_count, r1 = nb * (r + 1) / shard_count;
+                    memcpy(mf[f].counts() + r0, sh.recv.data() + (size_t)r * most * sizeof(uint32_t), (r1 - r0) * sizeof(uint32_t));
+                }
+            }
+            mf[f].finish();
+        }
+    } else {
+        if (!ps[0].open(fq1, err)) rc = mcx_set_error(MCX_ERR_IO, err);
+        if (rc == 0 && two && !ps[1].open(fq2, err)) rc = mcx_set_error(MCX_ERR_IO, err);
+        if (rc == 0 && two && ps[0].fastq() != ps[1].fastq()) rc = mcx_set_error(MCX_ERR_IO, std::string(fq1) + " and " + fq2 + " are with different format");
+        if (sharded && (rc = sh.agree(rc))) return rc;
+        if (rc) return rc;
+        fastq = ps[0].fastq();
+    }
+
+    // ---- the output: one file, every batch's text at its final place ------------------------------------------------
+    int sam_fd = -1;
+    bool sam_stream = false; // stdout: written front to back
+    uint64_t sam_base = 0;   // where the first batch's text goes
+    if (sam_path && sam_path[0]) {
+        if (strcmp(sam_path, "-") == 0) {
+            if (sharded) rc = mcx_set_error(MCX_ERR_ARG, "a sharded run cannot write its SAM to stdout");
+            sam_fd = 1; sam_stream = true;
+        } else {
+            // shard 0 creates (or empties) the file; the others open it once that has happened
+            if (shard_rank == 0) {
+                sam_fd = ::open(sam_path, O_WRONLY | O_CREAT | (opt.append_sam ? 0 : O_TRUNC), 0644);
+                if (sam_fd < 0) rc = mcx_set_error(MCX_ERR_IO, std::string("cannot write ") + sam_path);
+            }
+            if (sharded && (rc = sh.agree(rc))) { if (sam_fd >= 0) close(sam_fd); return rc; }
+            if (shard_rank != 0) {
+                sam_fd = ::open(sam_path, O_WRONLY, 0644);
+                if (sam_fd < 0) rc = mcx_set_error(MCX_ERR_IO, std::string("cannot write ") + sam_path);
+            }
+            struct stat st;
+            if (rc == 0 && opt.append_sam && fstat(sam_fd, &st) == 0) sam_base = (uint64_t)st.st_size;
+        }
+        if (rc == 0 && !opt.append_sam) {
+            std::string hdr;
+            sam_header(hix, hdr);
+            if (shard_rank == 0) {
+                const ssize_t w = sam_stream ? write(sam_fd, hdr.data(), hdr.size()) : pwrite(sam_fd, hdr.data(), hdr.size(), 0);
+                if (w != (ssize_t)hdr.size()) rc = mcx_set_error(MCX_ERR_IO, std::string("cannot write ") + sam_path);
+            }
+            sam_base = hdr.size();
+        }
+        if (sharded) rc = sh.agree(rc);
+        if (rc) { if (sam_fd >= 0 && !sam_stream) close(sam_fd); return rc; }
+    }
 
     int64_t local_avg[4];
     mcx_avg_init(local_avg);
     int64_t *avg = opt.avg_state ? opt.avg_state : local_avg;
 
     // busy seconds per stage (MCX_TIMING=1 prints them)
-    double t_parse = 0, t_pack = 0, t_map = 0, t_format = 0, t_write = 0;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    double t_parse = 0, t_map = 0, t_format = 0, t_write = 0;
     typedef std::unique_ptr<Batch> BatchPtr;
-    Queue<BatchPtr> parsed(2), mapped(2), spare(4); // batch objects circulate: their buffers are allocated (and faulted in) once
-    for (int k = 0; k < 4; k++) spare.push(BatchPtr(new Batch));
-
-    // stage 1: parse.  One thread per file fills its half of the batch.
+    const int n_objects = 8;
+    Queue<BatchPtr> parsed(2), mapped(3), spare((size_t)n_objects); // batch objects circulate: their buffers are allocated (and faulted in) once
+    for (int k = 0; k < n_objects; k++) spare.push(BatchPtr(new Batch));
     std::atomic<bool> abort(false);
-    const uint64_t shard_count = opt.shard_count > 1 ? (uint64_t)opt.shard_count : 1, shard_rank = shard_count > 1 ? (uint64_t)opt.shard_rank : 0;
+
+    // ---- stage 1: parse + pack ---------------------------------------------------------------------------------------
     std::thread reader([&] {
         bool done = false;
         uint64_t number = 0;
+        const uint32_t per_file = (uint32_t)(two ? batch_reads / 2 : batch_reads);
+        uint64_t total_recs[2] = {0, 0};
+        if (mapped_input) for (int f = 0; f < (two ? 2 : 1); f++) total_recs[f] = (mf[f].lines() + 2) / 4; // a record needs its header and sequence lines
         while (!done) {
+            const bool mine = number % shard_count == shard_rank;
+            if (mapped_input && !mine && (number + 1) * (uint64_t)per_file < total_recs[0]) { number++; continue; } // another shard's batch: not a byte of it is touched
             BatchPtr b = spare.pop();
-            const auto t0 = now();
-            b->two_files = two; b->fastq = ps[0].fastq(); b->n = 0; b->last = false; b->error.clear(); b->number = number;
-            const uint32_t per_file = (uint32_t)(two ? batch_reads / 2 : batch_reads);
-            b->in[0].clear(); b->in[1].clear();
-            if (two) {
-                std::thread t2([&] { ps[1].take(b->in[1], per_file, max_len); });
-                ps[0].take(b->in[0], per_file, max_len);
-                t2.join();
-                // the reference stops at the first empty read of file 1 and takes whatever file 2 holds (GetData.cpp:91-93)
-                if (b->in[1].n() < b->in[0].n()) b->error = std::string(fq2) + " holds fewer reads than " + fq1;
-                b->n = 2 * b->in[0].n();
-                done = b->in[0].last;
+            const Tick t0 = now();
+            b->two_files = two; b->fastq = fastq; b->n = 0; b->last = false; b->error.clear(); b->number = number;
+            b->in[0].clear(); b->in[1].clear(); b->n_odd[0] = b->n_odd[1] = 0; b->n_pair_reads = 0;
+            if (mapped_input) {
+                const uint64_t r0 = number * per_file;
+                for (int f = 0; f < (two ? 2 : 1); f++) {
+                    View &v = b->in[f];
+                    v.base = mf[f].data();
+                    const uint64_t r1 = std::min<uint64_t>(r0 + per_file, total_recs[f]);
+                    const uint64_t cnt = r1 > r0 ? r1 - r0 : 0;
+                    if (!mine) { v.last = true; continue; } // (the input ends inside another shard's batch: an empty batch carries the news)
+                    const int parts = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pool.size(), cnt / 2048));
+                    std::vector<std::vector<Rec>> part((size_t)parts);
+                    std::vector<std::string> perr((size_t)parts);
+                    std::vector<uint8_t> ok((size_t)parts, 1);
+                    pool.run(parts, [&](int k) {
+                        const uint64_t a = r0 + cnt * (uint64_t)k / (uint64_t)parts, z = r0 + cnt * (uint64_t)(k + 1) / (uint64_t)parts;
+                        part[(size_t)k].reserve((size_t)(z - a));
+                        ok[(size_t)k] = mf[f].parse(a, z, max_len, part[(size_t)k], perr[(size_t)k]) ? 1 : 0;
+                    });
+                    size_t total = 0;
+                    for (auto &p : part) total += p.size();
+                    v.recs.reserve(total);
+                    bool stopped = false;
+                    for (int k = 0; k < parts && !stopped; k++) {
+                        v.recs.insert(v.recs.end(), part[(size_t)k].begin(), part[(size_t)k].end());
+                        if (!ok[(size_t)k]) { stopped = true; if (!perr[(size_t)k].empty()) v.error = perr[(size_t)k]; }
+                    }
+                    v.last = stopped || cnt < per_file || r1 >= total_recs[f];
+                }
             } else {
-                ps[0].take(b->in[0], per_file, max_len);
-                b->n = b->in[0].n();
-                done = b->in[0].last;
+                if (two) {
+                    std::thread t2([&] { ps[1].take(b->in[1], per_file, max_len); });
+                    ps[0].take(b->in[0], per_file, max_len);
+                    t2.join();
+                } else ps[0].take(b->in[0], per_file, max_len);
             }
+            if (two) {
+                // the reference stops at the first empty read of file 1 and takes whatever file 2 holds (GetData.cpp:91-93)
+                if (mine || !mapped_input) {
+                    if (b->in[1].n() < b->in[0].n()) b->error = std::string(fq2) + " holds fewer reads than " + fq1;
+                    if (b->in[1].n() > b->in[0].n()) b->in[1].recs.resize(b->in[0].n());
+                    b->n = 2 * b->in[0].n();
+                }
+            } else b->n = b->in[0].n();
+            done = b->in[0].last;
             for (int f = 0; f < 2; f++) if (!b->in[f].error.empty()) b->error = b->in[f].error;
             if (!b->error.empty() || abort.load()) done = true;
-            // batches are dealt to the shards in turn; another shard's batch is parsed (the stream has to be
-            // walked) and dropped — unless it carries the end of the input or an error, which every shard must see
-            const bool mine = number % shard_count == shard_rank;
+            // batches are dealt to the shards in turn; another shard's batch is dropped — unless it carries the end of the input
+            // or an error, which every shard must see (the sequential reader has to walk the stream to get past it)
             number++;
-            t_parse += secs(t0, now());
             if (!mine && !done) { spare.push(std::move(b)); continue; }
             if (!mine && b->error.empty()) b->n = 0;
+            // 2-bit rows of this shard's reads, the bytes that are not ACGT beside them
+            if (b->n && b->error.empty()) {
+                const uint32_t n = b->n;
+                uint32_t npr = paired ? n : 0; // reads mapped as pairs; the odd tail of an interleaved file is mapped read by read
+                if (paired && (n & 1)) npr = n / kReadChunkSize * kReadChunkSize;
+                b->n_pair_reads = npr;
+                uint32_t longest = 0;
+                for (int f = 0; f < (two ? 2 : 1); f++) for (const Rec &r : b->in[f].recs) longest = std::max(longest, r.rlen);
+                b->row_words = (longest + 15) / 16;
+                if (!b->reserve(std::max<size_t>(n, batch_reads), std::max<size_t>(b->row_words, ((size_t)max_len + 15) / 16))) b->error = "cannot allocate pinned host memory";
+                else {
+                    std::vector<uint64_t> all_odd[2];
+                    for (int part = 0; part < 2; part++) { // (a part's reads are numbered from 0: it is a batch of its own on the device)
+                        const uint32_t first = part ? npr : 0, cnt = part ? n - npr : npr;
+                        if (!cnt) continue;
+                        const int slices = (int)std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)pool.size(), cnt / 4096));
+                        std::vector<std::vector<uint64_t>> odd((size_t)slices);
+                        pool.run(slices, [&](int k) {
+                            const uint32_t lo = first + (uint32_t)((uint64_t)cnt * k / slices), hi = first + (uint32_t)((uint64_t)cnt * (k + 1) / slices);
+                            for (uint32_t r = lo; r < hi; r++) {
+                                const char *base;
+                                const Rec &e = b->rec(r, base);
+                                b->lens[r] = e.rlen;
+                                pack_row((const uint8_t *)base + e.seq, e.rlen, r - first, b->rows + (size_t)r * b->row_words, b->row_words, odd[(size_t)k]);
+                            }
+                        });
+                        for (auto &o : odd) all_odd[part].insert(all_odd[part].end(), o.begin(), o.end());
+                    }
+                    const size_t total = all_odd[0].size() + all_odd[1].size();
+                    if (total && !b->reserve_odd(total)) b->error = "cannot allocate pinned host memory";
+                    else if (total) {
+                        memcpy(b->odd, all_odd[0].data(), all_odd[0].size() * 8);
+                        memcpy(b->odd + all_odd[0].size(), all_odd[1].data(), all_odd[1].size() * 8);
+                    }
+                    b->n_odd[0] = (uint32_t)all_odd[0].size(); b->n_odd[1] = (uint32_t)all_odd[1].size();
+                }
+                b->is_mate2.assign(n, 0);
+                for (uint32_t r = 1; r < npr; r += 2) b->is_mate2[r] = 1;
+            }
+            if (!b->error.empty()) done = true;
             b->last = done;
+            t_parse += secs(t0, now());
             parsed.push(std::move(b));
         }
     });
 
-    // stage 3: format + write
+    // ---- stage 3: format + write -------------------------------------------------------------------------------------
     int write_rc = 0;
+    Places places;
     std::thread writer([&] {
-        std::vector<Text> slices;
-        for (;;) {
-            BatchPtr b = mapped.pop();
-            if (sam && b->n && write_rc == 0) {
-                const auto t0 = now();
-                slices.resize((size_t)threads);
-                for (auto &s : slices) s.w = nullptr;
-                parallel_for(b->n, threads, [&](uint32_t lo, uint32_t hi, int k) {
-                    Text &t = slices[(size_t)k];
+        std::deque<BatchPtr> waiting;   // (sharded) formatted, their place in the file not known yet
+        uint64_t next_place = sam_base; // one shard: the batches follow one another
+        bool stop = false;
+        auto write_out = [&](BatchPtr &b, uint64_t at) {
+            const Tick t1 = now();
+            if (sam_stream) { for (Text &t : b->slices) if (t.size() && write(sam_fd, t.b.data(), t.size()) != (ssize_t)t.size()) write_rc = MCX_ERR_IO; }
+            else if (b->sam_bytes) {
+                std::vector<uint64_t> off(b->slices.size() + 1, at);
+                for (size_t k = 0; k < b->slices.size(); k++) off[k + 1] = off[k] + b->slices[k].size();
+                std::atomic<int> bad(0);
+                fpool.run((int)b->slices.size(), [&](int k) {
+                    const Text &t = b->slices[(size_t)k];
+                    size_t done_b = 0;
+                    while (done_b < t.size()) {
+                        const ssize_t w = pwrite(sam_fd, t.b.data() + done_b, t.size() - done_b, (off_t)(off[(size_t)k] + done_b));
+                        if (w <= 0) { bad.store(1); break; }
+                        done_b += (size_t)w;
+                    }
+                });
+                if (bad.load()) write_rc = MCX_ERR_IO;
+            }
+            t_write += secs(t1, now());
+        };
+        auto flush_waiting = [&](bool block) { // batches whose place has arrived go out, oldest first
+            while (!waiting.empty()) {
+                uint64_t at = 0;
+                if (!places.wait_place(waiting.front()->number, at, block)) {
+                    if (!places.has_failed()) return; // not yet
+                    waiting.front()->sam_bytes = 0;   // the run has failed: nothing more is written
+                }
+                write_out(waiting.front(), at);
+                spare.push(std::move(waiting.front()));
+                waiting.pop_front();
+            }
+        };
+        while (!stop) {
+            BatchPtr b;
+            if (waiting.empty()) b = mapped.pop();
+            else if (!mapped.try_pop(b)) { flush_waiting(false); std::this_thread::sleep_for(std::chrono::microseconds(100)); continue; }
+            if (b->last) stop = true;
+            b->sam_bytes = 0;
+            if (sam_fd >= 0 && b->n && write_rc == 0) {
+                const Tick t0 = now();
+                const int parts = (int)std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)fpool.size(), b->n / 2048));
+                b->slices.resize((size_t)parts);
+                fpool.run(parts, [&](int k) {
+                    const uint32_t lo = (uint32_t)((uint64_t)b->n * k / parts), hi = (uint32_t)((uint64_t)b->n * (k + 1) / parts);
+                    Text &t = b->slices[(size_t)k];
                     size_t bound = 0;
                     for (uint32_t r = lo; r < hi; r++) {
-                        int f; uint32_t i;
-                        b->locate(r, f, i);
-                        const Entries &e = b->in[f];
-                        bound += sam_bound(hix, e.name_off[i + 1] - e.name_off[i], e.seq_off[i + 1] - e.seq_off[i], b->recs[r].chr, b->recs[r].n_cigar);
+                        const char *base;
+                        const Rec &e = b->rec(r, base);
+                        bound += sam_bound(hix, e.name_len, e.rlen, b->recs[r].chr, b->recs[r].n_cigar);
                     }
                     t.start(bound);
                     for (uint32_t r = lo; r < hi; r++) sam_record(hix, *b, r, t);
                 });
-                const auto t1 = now();
-                size_t bytes = 0;
-                for (const Text &t : slices)
-                    if (t.w && t.size()) { bytes += t.size(); if (fwrite(t.b.data(), 1, t.size(), sam) != t.size()) write_rc = MCX_ERR_IO; }
-                if (sam_index) fprintf(sam_index, "%llu %zu\n", (unsigned long long)b->number, bytes);
-                t_format += secs(t0, t1); t_write += secs(t1, now());
+                for (const Text &t : b->slices) b->sam_bytes += t.size();
+                t_format += secs(t0, now());
+            } else b->slices.clear();
+            if (!sharded) { // its place is behind the batch before it
+                if (sam_fd >= 0) write_out(b, next_place);
+                next_place += b->sam_bytes;
+                spare.push(std::move(b));
+            } else {
+                // (a batch that carries nothing of this shard's — the news of the input's end — has no round of its own to be placed in)
+                if (b->number % shard_count == shard_rank) { places.put_size(b->number, b->sam_bytes); waiting.push_back(std::move(b)); }
+                else spare.push(std::move(b));
+                flush_waiting(false);
             }
-            const bool stop = b->last;
-            spare.push(std::move(b));
-            if (stop) break;
         }
+        flush_waiting(true); // the places of the last rounds' text arrive with the closing exchanges
     });
 
-    // stage 2 (this thread): interleave, map on the GPU
-    int rc = 0;
-    const bool sharded = shard_count > 1;
+    // ---- stage 2 (this thread): copy in | map | copy out, three parts of batches on the device at a time ------------------
     const bool profile = mcx_ctx_has_profile(c);
-    Shards sh;
-    sh.x = opt.exchange; sh.slot_stride = (uint32_t)batch_reads; sh.cap_chunks = (uint32_t)(batch_reads / kReadChunkSize + 2);
+    int in_flight = 0;             // parts submitted and not collected yet
+    std::deque<BatchPtr> leaving;  // mapped, their last part on its way out (oldest first), with the number of parts each still waits for
+    std::deque<int> leaving_parts;
+    bool input_done = false, dead = false, ended = false; // dead: a shard failed and every shard knows; ended: the input ended in an earlier batch
     uint64_t rounds_done = 0;
-    bool dead = false; // a shard failed and every shard knows
-    for (;;) {
-        BatchPtr b = parsed.pop();
-        const bool last = b->last;
+    uint64_t place_next = sam_base;
+    std::deque<std::pair<uint64_t, bool>> rounds_unplaced; // (sharded) rounds mapped whose text sizes have not been exchanged; did this shard hold a batch of the round?
+    auto place_round = [&](uint64_t round, bool own) -> int { // the shards' batches of a round find their places in the file
+        uint64_t mine = 0;
+        if (own && !places.wait_size(round * shard_count + shard_rank, mine)) mine = 0;
+        if (int e = sh.gather(&mine, sizeof mine)) return e;
+        uint64_t at = place_next;
+        for (uint64_t r = 0; r < shard_count; r++) {
+            uint64_t v; memcpy(&v, sh.recv.data() + (size_t)r * sizeof v, sizeof v);
+            if (r == shard_rank && own) places.put_place(round * shard_count + shard_rank, at);
+            at += v;
+        }
+        place_next = at;
+        return 0;
+    };
+    auto collect_oldest = [&]() -> int { // the oldest mapped part has arrived in host memory
+        const int e = mcx_stream_collect(c, nullptr, nullptr);
+        in_flight--;
+        if (!leaving.empty() && --leaving_parts.front() == 0) { mapped.push(std::move(leaving.front())); leaving.pop_front(); leaving_parts.pop_front(); }
+        return e;
+    };
+    auto submit = [&](Batch *p) -> int {
+        const uint32_t n = p->n, npr = p->n_pair_reads;
+        int e = 0;
+        if (npr) { e = mcx_stream_submit_packed(c, p->rows, p->row_words, p->lens, npr, p->odd, p->n_odd[0]); if (e) return e; in_flight++; }
+        if (npr < n) {
+            e = mcx_stream_submit_packed(c, p->rows + (size_t)npr * p->row_words, p->row_words, p->lens + npr, n - npr, p->odd ? p->odd + p->n_odd[0] : nullptr, p->n_odd[1]);
+            if (e) return e;
+            in_flight++;
+        }
+        return 0;
+    };
+    // the batch being mapped and the one behind it (already on its way in)
+    BatchPtr cur, nxt;
+    bool cur_in = false, nxt_in = false;
+    auto take_next = [&](bool block) { // a parsed batch, its copy to the device started when there is room
+        if (nxt || input_done) return;
+        BatchPtr b;
+        if (block) b = parsed.pop(); else if (!parsed.try_pop(b)) return;
+        if (b->last) input_done = true;
         if (rc == 0 && !b->error.empty()) rc = mcx_set_error(b->error.find("max_read_len") != std::string::npos ? MCX_ERR_UNSUPPORTED : MCX_ERR_IO, b->error);
-        if (rc) b->n = 0;
-        const uint32_t n = b->n;
-        if (rc == 0 && n) {
-            const auto t0 = now();
-            size_t total = 0;
-            for (int f = 0; f < 2; f++) total += b->in[f].seq.size();
-            if (!b->reserve(std::max<size_t>(n, batch_reads), std::max<size_t>(total + 64, batch_reads * 160))) { rc = mcx_set_error(MCX_ERR_DEVICE, "cannot allocate pinned host memory"); b->n = 0; }
-            t_pack += secs(t0, now());
+        if (rc || ended) b->n = 0;
+        nxt = std::move(b); nxt_in = false;
+    };
+    auto try_submit_next = [&]() {
+        if (!nxt || nxt_in || rc) return;
+        if (nxt->n == 0) { nxt_in = true; return; }
+        if (in_flight + nxt->n_parts() > 3) return;
+        const int e = submit(nxt.get());
+        if (e) rc = e; else nxt_in = true;
+    };
+    for (;;) {
+        if (!cur) {
+            if (!nxt) { if (input_done) break; take_next(true); }
+            while (nxt && !nxt_in && rc == 0) { try_submit_next(); if (!nxt_in && rc == 0) { const int e = collect_oldest(); if (e) rc = e; } }
+            cur = std::move(nxt); cur_in = nxt_in; nxt_in = false;
+            if (rc) { cur->n = 0; abort.store(true); }
         }
-        uint32_t n_pairs_reads = 0;
-        auto t1 = now();
-        if (rc == 0 && n) {
-            const auto t0 = now();
-            b->off[0] = 0;
-            if (two) for (uint32_t i = 0; i < n / 2; i++) { // mates alternate
-                b->off[2 * i + 1] = b->off[2 * i] + (b->in[0].seq_off[i + 1] - b->in[0].seq_off[i]);
-                b->off[2 * i + 2] = b->off[2 * i + 1] + (b->in[1].seq_off[i + 1] - b->in[1].seq_off[i]);
-            } else memcpy(b->off, b->in[0].seq_off.data(), ((size_t)n + 1) * sizeof(uint32_t));
-            if (two) parallel_for(n, threads, [&](uint32_t lo, uint32_t hi, int) {
-                for (uint32_t r = lo; r < hi; r++) { int f; uint32_t i; b->locate(r, f, i); memcpy(b->bases + b->off[r], b->in[f].seq.data() + b->in[f].seq_off[i], b->off[r + 1] - b->off[r]); }
-            });
-            else memcpy(b->bases, b->in[0].seq.data(), b->off[n]);
-            memset(b->bases + b->off[n], 0, 64);
-            b->is_mate2.assign(n, 0);
-            t1 = now();
-            t_pack += secs(t0, t1);
-            n_pairs_reads = paired ? n : 0;
-            if (paired && (n & 1)) n_pairs_reads = n / kReadChunkSize * kReadChunkSize;
-            for (uint32_t r = 1; r < n_pairs_reads; r += 2) b->is_mate2[r] = 1;
-            b->n_pair_reads = n_pairs_reads;
-        }
-        // the single-read part (a single-end library, or the odd tail of an interleaved file) as a batch of its own
-        std::vector<uint32_t> off2;
-        uint32_t base2 = 0;
-        if (rc == 0 && n_pairs_reads < n) {
-            off2.assign(b->off + n_pairs_reads, b->off + n + 1);
-            base2 = off2[0];
-            for (auto &x : off2) x -= base2;
-        }
+        // the batch behind it: parsed already?  then its copy in runs under this one's kernels
+        take_next(false);
+        try_submit_next();
+        Batch *p = cur.get();
+        const Tick t1 = now();
+        // what of the batch is on the device (copied in, or on its way); after a failure it leaves the device unmapped
+        const uint32_t n_pr = cur_in ? p->n_pair_reads : 0u, n_sg = cur_in ? p->n - p->n_pair_reads : 0u;
+        int parts_out = 0;
+        const uint8_t *d_bases = nullptr; const uint32_t *d_off = nullptr; mcx_aln *d_aln = nullptr; uint32_t *d_cig = nullptr; uint32_t n_dev = 0;
+        auto part_in = [&]() { const int e = mcx_stream_next(c, &d_bases, &d_off, &n_dev, &d_aln, &d_cig); if (e && rc == 0) rc = e; return e == 0; };
+        auto part_out = [&](bool second) {
+            const int e = second ? mcx_stream_mapped(c, (mcx_aln *)p->recs + p->n_pair_reads, p->cig + MCX_CIGAR_POOL_WORDS(p->n_pair_reads)) : mcx_stream_mapped(c, (mcx_aln *)p->recs, p->cig);
+            if (e && rc == 0) rc = e;
+            if (e == 0) parts_out++;
+        };
         if (!sharded) {
-            if (rc == 0 && n_pairs_reads) {
-                rc = mcx_map_batch(c, b->bases, b->off, n_pairs_reads, 1, avg, (mcx_aln *)b->recs, b->cig, stats);
-            }
-            if (rc == 0 && n_pairs_reads < n) {
-                rc = mcx_map_batch(c, b->bases + base2, off2.data(), n - n_pairs_reads, 0, avg, (mcx_aln *)b->recs + n_pairs_reads,
-                                   b->cig + MCX_CIGAR_POOL_WORDS(n_pairs_reads), stats);
-            }
-        } else if (!dead && b->number / shard_count >= rounds_done) {
-            rounds_done = b->number / shard_count + 1;
-            Shards::Head h = {rc, rc ? 0u : n_pairs_reads, rc ? 0u : n - n_pairs_reads, last ? 1u : 0u};
+            if (n_pr && part_in()) { if (rc == 0) rc = mcx_map_batch_dev(c, d_bases, d_off, n_pr, 1, avg, d_aln, d_cig, stats); part_out(false); }
+            if (n_sg && part_in()) { if (rc == 0) rc = mcx_map_batch_dev(c, d_bases, d_off, n_sg, 0, avg, d_aln, d_cig, stats); part_out(true); }
+        } else if (!dead && !ended && p->number / shard_count >= rounds_done) {
+            rounds_done = p->number / shard_count + 1;
+            Shards::Head h = {rc, rc ? 0u : n_pr, rc ? 0u : n_sg, p->last ? 1u : 0u};
             int e = sh.gather(&h, sizeof h);
             bool any_pair = false, any_single = false;
             uint64_t before = 0, round_total = 0;
+            uint32_t my_pr = rc ? 0u : n_pr, my_sg = rc ? 0u : n_sg;
             if (e) rc = e;
-            else for (int r = 0; r < sh.x->size; r++) {
-                Shards::Head o; memcpy(&o, sh.recv.data() + (size_t)r * sizeof o, sizeof o);
-                if (o.rc && rc == 0) rc = mcx_set_error(o.rc, "shard " + std::to_string(r) + " failed");
-                any_pair |= o.n_pair != 0; any_single |= o.n_single != 0;
-                if (r < sh.x->rank) before += (uint64_t)o.n_pair + o.n_single;
-                round_total += (uint64_t)o.n_pair + o.n_single;
+            else {
+                // the input ends with the first batch of the round that says so: the batches behind it do not exist
+                int cut = sh.x->size;
+                for (int r = 0; r < sh.x->size; r++) { Shards::Head o; memcpy(&o, sh.recv.data() + (size_t)r * sizeof o, sizeof o); if (o.last && r < cut) cut = r; }
+                for (int r = 0; r < sh.x->size; r++) {
+                    Shards::Head o; memcpy(&o, sh.recv.data() + (size_t)r * sizeof o, sizeof o);
+                    if (o.rc && rc == 0) rc = mcx_set_error(o.rc, "shard " + std::to_string(r) + " failed");
+                    if (r > cut) { o.n_pair = o.n_single = 0; if (r == sh.x->rank) my_pr = my_sg = 0; }
+                    any_pair |= o.n_pair != 0; any_single |= o.n_single != 0;
+                    if (r < sh.x->rank) before += (uint64_t)o.n_pair + o.n_single;
+                    round_total += (uint64_t)o.n_pair + o.n_single;
+                }
+                if (cut < sh.x->size) { ended = true; abort.store(true); }
             }
+            if (rc) my_pr = my_sg = 0;
             const int64_t round_base = avg[3];
-            if (rc == 0 && any_pair) {
-                rc = sh.pairs(c, b->bases, b->off, n_pairs_reads, round_base + (int64_t)before, avg, profile, (mcx_aln *)b->recs, b->cig, stats);
-            }
-            if (rc == 0 && any_single) {
-                const uint32_t ns = n - n_pairs_reads;
-                rc = sh.singles(c, ns ? b->bases + base2 : nullptr, ns ? off2.data() : nullptr, ns, round_base + (int64_t)before + n_pairs_reads, profile,
-                                (mcx_aln *)b->recs + n_pairs_reads, b->cig + MCX_CIGAR_POOL_WORDS(n_pairs_reads), stats);
-            }
+            // (a part that was copied in but does not count any more — the input ended in a batch before this one — still leaves the device)
+            const bool in1 = n_pr && part_in();
+            if (rc == 0 && any_pair) rc = sh.pairs(c, d_bases, d_off, in1 ? my_pr : 0u, round_base + (int64_t)before, avg, profile, d_aln, d_cig, stats);
+            if (in1) part_out(false);
+            const bool in2 = n_sg && part_in();
+            if (rc == 0 && any_single) rc = sh.singles(c, d_bases, d_off, in2 ? my_sg : 0u, round_base + (int64_t)before + my_pr, profile, d_aln, d_cig, stats);
+            if (in2) part_out(true);
+            if (my_pr == 0 && my_sg == 0) p->n = 0; // (nothing of this batch counts)
             avg[3] = round_base + (int64_t)round_total;
             if (rc) dead = true;
+            // the text of an earlier round finds its place (two rounds later every formatter has long been through it)
+            rounds_unplaced.push_back(std::make_pair(p->number / shard_count, p->number % shard_count == shard_rank));
+            while (rounds_unplaced.size() > 2 && !dead) { const int e3 = place_round(rounds_unplaced.front().first, rounds_unplaced.front().second); rounds_unplaced.pop_front(); if (e3) { rc = e3; dead = true; } }
+        } else {
+            // (sharded, after the end of the input or a failure: what is on the device leaves it unmapped)
+            if (n_pr && part_in()) part_out(false);
+            if (n_sg && part_in()) part_out(true);
+            p->n = 0;
         }
-        if (n) t_map += secs(t1, now());
-        if (rc) { b->n = 0; abort.store(true); }
-        b->last = last; // after an error the remaining batches pass through empty until the parser's last one
-        mapped.push(std::move(b));
-        if (last) break;
+        if (p->n) t_map += secs(t1, now());
+        if (rc) { p->n = 0; abort.store(true); places.fail(); }
+        if (parts_out == 0) { // nothing on its way out: the batch goes on as it is, behind the ones that are
+            while (!leaving.empty()) { const int e = collect_oldest(); if (e && rc == 0) rc = e; }
+            mapped.push(std::move(cur));
+        } else { leaving.push_back(std::move(cur)); leaving_parts.push_back(parts_out); }
+        cur.reset(); cur_in = false;
+        // at most one batch's parts on their way out behind the one mapped next
+        while (leaving.size() > 1) { const int e = collect_oldest(); if (e && rc == 0) rc = e; }
     }
+    while (!leaving.empty()) { const int e = collect_oldest(); if (e && rc == 0) rc = e; }
+    // (sharded) the places of the last rounds' text
+    while (sharded && !rounds_unplaced.empty()) {
+        if (!dead) { const int e = place_round(rounds_unplaced.front().first, rounds_unplaced.front().second); if (e) { if (rc == 0) rc = e; dead = true; places.fail(); } }
+        rounds_unplaced.pop_front();
+    }
+    if (rc) places.fail();
     writer.join();
     reader.join();
     if (getenv("MCX_TIMING"))
-        fprintf(stderr, "[mcx_map_files] busy seconds: parse %.2f | pack %.2f map %.2f | format %.2f write %.2f  (%d host threads)\n", t_parse, t_pack, t_map, t_format,
-                t_write, threads);
-    if (sam_index) fclose(sam_index);
-    if (sam && sam != stdout) { if (fclose(sam) != 0 && write_rc == 0) write_rc = MCX_ERR_IO; }
-    else if (sam) fflush(sam);
+        fprintf(stderr, "[mcx_map_files] busy seconds: parse + pack %.2f | map %.2f | format %.2f write %.2f  (%d + %d host threads, %s input)\n", t_parse, t_map, t_format,
+                t_write, threads, threads, mapped_input ? "mapped" : "sequential");
+    if (sam_fd >= 0 && !sam_stream) { if (close(sam_fd) != 0 && write_rc == 0) write_rc = MCX_ERR_IO; }
     if (rc == 0 && write_rc) rc = mcx_set_error(MCX_ERR_IO, std::string("cannot write ") + (sam_path ? sam_path : ""));
     return rc;
 }

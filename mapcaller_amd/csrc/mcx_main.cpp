@@ -165,8 +165,8 @@ int main(int argc, char **argv)
 
     // One shard per GPU, one host thread each (the whole run on this thread when there is one GPU).  The input stream is
     // cut into batches that are dealt to the shards in turn; between them the shards exchange what keeps the run equal
-    // to the single-stream one (insert-size trajectory, duplicate cap: mcx_file_opts.exchange); every shard writes its
-    // part of the SAM, shard 0 merges the parts in input order; with -vcf the counter planes are summed onto shard 0
+    // to the single-stream one (insert-size trajectory, duplicate cap: mcx_file_opts.exchange); every shard writes
+    // its batches' lines at their final place in the one SAM file; with -vcf the counter planes are summed onto shard 0
     // over RCCL (mcx_profile_reduce) and the sparse tallies of all shards go to its VariantCalling().
     struct Shard {
         int rank = 0, device = 0, rc = 0;
@@ -204,15 +204,9 @@ int main(int argc, char **argv)
         for (size_t k = 0; k < f1.size(); k++) {
             // like the reference, every library appends to the same SAM stream; only the first writes the header
             if (avg[3] % 200) avg[3] += 200 - avg[3] % 200; // a new library starts a new chunk
-            std::string out = sam, idx_path;
-            if (n_gpus > 1 && !sam.empty()) {
-                const std::string base = k == 0 ? sam : sam + ".lib" + std::to_string(k);
-                out = base + ".part" + std::to_string(r);
-                idx_path = out + ".idx";
-                my.no_sam_header = (r != 0 || k > 0) ? 1 : 0;
-                my.append_sam = 0;
-                my.sam_index_path = idx_path.c_str();
-            } else my.append_sam = k > 0;
+            // (the shards write into the one SAM file, every batch's text at its final place: mcx_map_files_ex)
+            const std::string out = sam;
+            my.append_sam = k > 0;
             if (n_gpus > 1) { // a shard that could not even start must not leave the others waiting in the first exchange
                 int32_t mine = sh.rc;
                 std::vector<int32_t> all((size_t)n_gpus);
@@ -230,19 +224,6 @@ int main(int argc, char **argv)
                 bool stop = false;
                 for (int32_t v : all) if (v) stop = true;
                 if (stop) { if (!sh.rc) { sh.rc = MCX_ERR_DEVICE; sh.err = "another shard failed"; } break; }
-                if (r == 0 && !sam.empty()) {
-                    const std::string base = k == 0 ? sam : sam + ".lib" + std::to_string(k);
-                    if ((rc = mcx_sam_merge(base.c_str(), n_gpus))) { bad(rc); }
-                    else if (k > 0) { // append this library's lines to the run's SAM
-                        FILE *in = fopen(base.c_str(), "rb"), *dst = fopen(sam.c_str(), "ab");
-                        std::vector<char> buf(1 << 22);
-                        size_t got;
-                        while (in && dst && (got = fread(buf.data(), 1, buf.size(), in)) > 0) fwrite(buf.data(), 1, got, dst);
-                        if (in) fclose(in);
-                        if (dst) fclose(dst);
-                        remove(base.c_str());
-                    }
-                }
             }
         }
         if (n_gpus > 1 && want_vcf) { // the one collective of the run; every shard takes part even after a failure elsewhere

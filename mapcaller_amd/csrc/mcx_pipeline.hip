@@ -1486,11 +1486,13 @@ struct mcx_ctx {
     // mcx_stream_*: three batches in flight (copy in | kernels | copy out), each in a slot of its own
     struct Slot {
         uint8_t *d_bases = nullptr; uint32_t *d_off = nullptr; AlnRec *d_recs = nullptr; uint32_t *d_cig = nullptr;
+        uint32_t *d_codes = nullptr, *d_len = nullptr; uint64_t *d_odd = nullptr; uint32_t odd_cap = 0; // mcx_stream_submit_packed: what arrives; restored to d_bases / d_off
         uint32_t n_reads = 0; int state = 0; uint64_t seq = 0; // 0 free, 1 copy in started, 2 handed to the kernels, 3 copy out started
         hipEvent_t in_ready = nullptr, mapped = nullptr, out_done = nullptr;
     } slot[3];
     hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
     uint64_t stream_seq = 0, stream_bytes_in = 0, stream_bytes_out = 0;
+    void *d_scan_tmp = nullptr; size_t scan_tmp_bytes = 0; // the prefix sum of the read lengths (mcx_stream_submit_packed)
     // staging for the host-buffer entry point
     uint8_t *d_bases = nullptr; uint32_t *d_off = nullptr; AlnRec *d_recs = nullptr; uint32_t *d_cig = nullptr;
     hipEvent_t ev[10];
@@ -1702,7 +1704,7 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3], c->d_jobs[4], c->d_jobs[5],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_rtasks, c->d_rres, c->d_rseeds, c->d_rplans, c->d_rescue_n, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
                  c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
-                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_pout_sel, c->d_order, c->d_order_cnt, c->d_packed, c->d_batch_flags};
+                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_pout_sel, c->d_order, c->d_order_cnt, c->d_packed, c->d_batch_flags, c->d_scan_tmp};
     for (void *q : p) if (q) (void)hipFree(q);
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
     if (c->h_keys) (void)hipHostFree(c->h_keys);
@@ -1711,7 +1713,7 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     passres_free(c->t1); passres_free(c->t2);
     for (hipEvent_t e : {c->ev_clustered, c->ev_built, c->ev_late_done}) if (e) (void)hipEventDestroy(e);
     for (auto &sl : c->slot) {
-        void *q[] = {sl.d_bases, sl.d_off, sl.d_recs, sl.d_cig};
+        void *q[] = {sl.d_bases, sl.d_off, sl.d_recs, sl.d_cig, sl.d_codes, sl.d_len, sl.d_odd};
         for (void *x : q) if (x) (void)hipFree(x);
         for (hipEvent_t e : {sl.in_ready, sl.mapped, sl.out_done}) if (e) (void)hipEventDestroy(e);
     }
@@ -2471,12 +2473,9 @@ static mcx_ctx::Slot *oldest_slot(mcx_ctx *c, int state)
     return best;
 }
 
-extern "C" int mcx_stream_submit(mcx_ctx *c, const uint8_t *bases, const uint32_t *off, uint32_t n_reads)
+// a free slot, its HBM allocated on first use
+static int stream_slot(mcx_ctx *c, mcx_ctx::Slot **out)
 {
-    if (!c || !bases || !off || n_reads == 0) return fail(MCX_ERR_ARG, "mcx_stream_submit: bad argument");
-    if (n_reads > c->max_reads) return fail(MCX_ERR_ARG, "batch larger than max_batch_reads");
-    if (off[n_reads] > c->max_bases) return fail(MCX_ERR_ARG, "batch holds more bases than max_batch_reads * max_read_len");
-    HIP_TRY(hipSetDevice(c->idx->device));
     mcx_ctx::Slot *sl = oldest_slot(c, 0);
     if (!sl) return fail(MCX_ERR_ARG, "mcx_stream_submit: three batches are in flight (collect one first)");
     int rc;
@@ -2485,7 +2484,7 @@ extern "C" int mcx_stream_submit(mcx_ctx *c, const uint8_t *bases, const uint32_
         HIP_TRY(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
     }
     if (!sl->d_bases) {
-        if ((rc = dmalloc(&sl->d_bases, c->max_bases + 64))) return rc;
+        if ((rc = dmalloc(&sl->d_bases, c->max_bases + 16 * c->max_reads + 64))) return rc; // (+16 per read: packed rows end on a word)
         if ((rc = dmalloc(&sl->d_off, c->max_reads + 1))) return rc;
         if ((rc = dmalloc(&sl->d_recs, c->max_reads))) return rc;
         if ((rc = dmalloc(&sl->d_cig, MCX_CIGAR_POOL_WORDS(c->max_reads)))) return rc;
@@ -2493,6 +2492,99 @@ extern "C" int mcx_stream_submit(mcx_ctx *c, const uint8_t *bases, const uint32_
         HIP_TRY(hipEventCreateWithFlags(&sl->mapped, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&sl->out_done, hipEventDisableTiming));
     }
+    *out = sl;
+    return 0;
+}
+
+// 2-bit rows -> the ASCII bytes of the batch: one thread per sixteen bases (the letters ACGT; k_apply_odd puts back every other byte)
+__global__ void __launch_bounds__(256) k_unpack_reads(const uint32_t *codes, uint32_t row_words, const uint32_t *off, uint32_t n_reads, uint8_t *bases)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = (uint32_t)(t / row_words), k = (uint32_t)(t % row_words);
+    if (r >= n_reads) return;
+    const uint32_t o = off[r], rlen = off[r + 1] - o;
+    if (16 * k >= rlen) return;
+    const uint32_t w = codes[(uint64_t)r * row_words + k];
+    uint32_t q[4]; // sixteen letters, four to a word, the first in the low byte
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t c = (w >> (30 - 2 * (4 * g + i))) & 3u;
+            v |= (uint32_t)((0x54474341u >> (8 * c)) & 0xFFu) << (8 * i); // "ACGT"
+        }
+        q[g] = v;
+    }
+    uint8_t *dst = bases + o + 16 * k;
+    const uint32_t nb = rlen - 16 * k < 16 ? rlen - 16 * k : 16;
+    const uintptr_t a = (uintptr_t)dst;
+    if (nb == 16 && (a & 3) == 0) { uint32_t *d4 = (uint32_t *)dst; d4[0] = q[0]; d4[1] = q[1]; d4[2] = q[2]; d4[3] = q[3]; }
+    else if (nb == 16 && (a & 1) == 0) { uint16_t *d2 = (uint16_t *)dst; for (int i = 0; i < 8; i++) d2[i] = (uint16_t)(q[i >> 1] >> (16 * (i & 1))); }
+    else for (uint32_t i = 0; i < nb; i++) dst[i] = (uint8_t)(q[i >> 2] >> (8 * (i & 3)));
+}
+
+__global__ void k_apply_odd(const uint64_t *odd, uint32_t n_odd, const uint32_t *off, uint32_t n_reads, uint8_t *bases)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_odd) return;
+    const uint64_t e = odd[i];
+    const uint32_t r = (uint32_t)(e >> 32), pos = (uint32_t)(e >> 8) & 0xFFFFFFu;
+    if (r < n_reads && pos < off[r + 1] - off[r]) bases[off[r] + pos] = (uint8_t)e;
+}
+
+extern "C" int mcx_stream_submit_packed(mcx_ctx *c, const uint32_t *codes, uint32_t row_words, const uint32_t *len, uint32_t n_reads, const uint64_t *odd,
+                                        uint32_t n_odd)
+{
+    if (!c || !codes || !len || n_reads == 0 || row_words == 0 || (n_odd && !odd)) return fail(MCX_ERR_ARG, "mcx_stream_submit_packed: bad argument");
+    if (n_reads > c->max_reads) return fail(MCX_ERR_ARG, "batch larger than max_batch_reads");
+    const uint32_t row_max = (uint32_t)(c->rlen_max + 15) / 16;
+    if (row_words > row_max) return fail(MCX_ERR_UNSUPPORTED, "mcx_stream_submit_packed: rows are longer than max_read_len");
+    HIP_TRY(hipSetDevice(c->idx->device));
+    mcx_ctx::Slot *sl = nullptr;
+    int rc = stream_slot(c, &sl);
+    if (rc) return rc;
+    hipStream_t s = c->h2d_stream;
+    if (!sl->d_codes) {
+        if ((rc = dmalloc(&sl->d_codes, c->max_reads * (uint64_t)row_max))) return rc;
+        if ((rc = dmalloc(&sl->d_len, c->max_reads + 1))) return rc;
+    }
+    if (n_odd > sl->odd_cap) {
+        if (sl->d_odd) { HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(sl->d_odd); sl->d_odd = nullptr; }
+        sl->odd_cap = std::max<uint32_t>(n_odd + n_odd / 2, 1u << 16);
+        if ((rc = dmalloc(&sl->d_odd, sl->odd_cap))) return rc;
+    }
+    if (!c->d_scan_tmp) {
+        size_t need = 0;
+        HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, need, sl->d_len, sl->d_off + 1, (int)c->max_reads, s));
+        c->scan_tmp_bytes = need + 256;
+        HIP_TRY(hipMalloc(&c->d_scan_tmp, c->scan_tmp_bytes));
+    }
+    if ((rc = bulk_copy(c, sl->d_codes, codes, (size_t)n_reads * row_words * 4, hipMemcpyHostToDevice, s))) return rc;
+    if ((rc = bulk_copy(c, sl->d_len, len, (size_t)n_reads * 4, hipMemcpyHostToDevice, s))) return rc;
+    if (n_odd && (rc = bulk_copy(c, sl->d_odd, odd, (size_t)n_odd * 8, hipMemcpyHostToDevice, s))) return rc;
+    HIP_TRY(hipMemsetAsync(sl->d_off, 0, 4, s));
+    size_t tmp = c->scan_tmp_bytes;
+    HIP_TRY(hipcub::DeviceScan::InclusiveSum(c->d_scan_tmp, tmp, sl->d_len, sl->d_off + 1, (int)n_reads, s));
+    const uint64_t threads = (uint64_t)n_reads * row_words;
+    k_unpack_reads<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(sl->d_codes, row_words, sl->d_off, n_reads, sl->d_bases);
+    if (n_odd) k_apply_odd<<<(n_odd + 255) / 256, 256, 0, s>>>(sl->d_odd, n_odd, sl->d_off, n_reads, sl->d_bases);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(sl->in_ready, s));
+    sl->n_reads = n_reads; sl->state = 1; sl->seq = ++c->stream_seq;
+    c->stream_bytes_in += (uint64_t)n_reads * row_words * 4 + (uint64_t)n_reads * 4 + (uint64_t)n_odd * 8;
+    return 0;
+}
+
+extern "C" int mcx_stream_submit(mcx_ctx *c, const uint8_t *bases, const uint32_t *off, uint32_t n_reads)
+{
+    if (!c || !bases || !off || n_reads == 0) return fail(MCX_ERR_ARG, "mcx_stream_submit: bad argument");
+    if (n_reads > c->max_reads) return fail(MCX_ERR_ARG, "batch larger than max_batch_reads");
+    if (off[n_reads] > c->max_bases) return fail(MCX_ERR_ARG, "batch holds more bases than max_batch_reads * max_read_len");
+    HIP_TRY(hipSetDevice(c->idx->device));
+    mcx_ctx::Slot *sl = nullptr;
+    int rc = stream_slot(c, &sl);
+    if (rc) return rc;
     if ((rc = bulk_copy(c, sl->d_bases, bases, off[n_reads], hipMemcpyHostToDevice, c->h2d_stream))) return rc;
     if ((rc = bulk_copy(c, sl->d_off, off, (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice, c->h2d_stream))) return rc;
     HIP_TRY(hipEventRecord(sl->in_ready, c->h2d_stream));

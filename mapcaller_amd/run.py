@@ -72,13 +72,6 @@ def sample_read_length(path, lines=40000):
     return longest
 
 
-def merge_sam(path, world):
-    """The ranks' parts back into input order (batch k sits in part k % world): mcx_sam_merge."""
-    rc = api.lib().mcx_sam_merge(path.encode(), world)
-    if rc:
-        raise api.McxError(f"mcx_sam_merge failed ({rc}): {api.lib().mcx_last_error().decode()}")
-
-
 def main(argv=None):
     a = parse(sys.argv[1:] if argv is None else argv)
     rank = int(os.environ.get("RANK", "0"))
@@ -109,23 +102,13 @@ def main(argv=None):
     link = api.dist_exchange(dev) if world > 1 else None
     for k, f1 in enumerate(a.f1):  # libraries one after the other, like the reference: one SAM stream, one insert-size state
         f2 = a.f2[k] if a.f2 else None
-        sam, base = None, None
-        if a.sam:
-            base = a.sam if k == 0 else f"{a.sam}.lib{k}"
-            sam = a.sam if world == 1 else f"{base}.part{rank}"
-        st = mapper.map_files(f1, f2, sam, interleaved=a.interleaved, threads=a.threads,
-                              shard=(rank, world) if world > 1 else None, exchange=link, sam_header=(rank == 0 and k == 0),
-                              sam_index=(sam + ".idx") if (sam and world > 1) else None, append_sam=(world == 1 and k > 0))
+        # (the ranks write into the one SAM file, every batch's lines at their final place: mcx_map_files_ex)
+        st = mapper.map_files(f1, f2, a.sam or None, interleaved=a.interleaved, threads=a.threads,
+                              shard=(rank, world) if world > 1 else None, exchange=link, append_sam=k > 0)
         for key in totals:
             totals[key] += st[key]
         if td:
             td.barrier()
-        if rank == 0 and a.sam and world > 1:
-            merge_sam(base, world)
-            if k > 0:
-                with open(base, "rb") as src, open(a.sam, "ab") as dst:
-                    shutil.copyfileobj(src, dst, 1 << 24)
-                os.remove(base)
     tot = mdist.sum_over_ranks([totals[k] for k in ("reads", "mapped", "pairs", "pair_dist_sum", "pair_len_sum")], dev)
     if want_vcf:
         planes, sparse = mdist.reduce_profile(planes, mapper.profile_sparse_raw(shard=world > 1))

@@ -107,20 +107,3 @@ def test_local_exchange_gathers_in_rank_order():
         assert out[r] == [[(16 * rnd + q) % 256 for q in range(n)] for rnd in range(50)]
     L.mcx_exchange_local_free(links)
 
-
-def test_sam_merge_puts_batches_back_in_input_order(tmp_path):
-    """mcx_sam_merge: batch k lives in part k % parts; the header comes from part 0; the parts go away."""
-    from mapcaller_amd.run import merge_sam
-    path = str(tmp_path / "o.sam")
-    world, n_batches = 3, 8
-    batches = [("".join(f"read{k}_{i}\tx\n" for i in range(k + 1))).encode() for k in range(n_batches)]
-    for r in range(world):
-        with open(f"{path}.part{r}", "wb") as fh, open(f"{path}.part{r}.idx", "w") as ix:
-            if r == 0:
-                fh.write(b"@PG\tID:MapCaller\n@SQ\tSN:c\tLN:9\n")
-            for k in range(r, n_batches, world):
-                fh.write(batches[k])
-                ix.write(f"{k} {len(batches[k])}\n")
-    merge_sam(path, world)
-    assert open(path, "rb").read() == b"@PG\tID:MapCaller\n@SQ\tSN:c\tLN:9\n" + b"".join(batches)
-    assert not any(os.path.exists(f"{path}.part{r}") for r in range(world))

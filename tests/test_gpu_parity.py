@@ -118,6 +118,79 @@ def test_overlapped_host_boundary_gives_the_same_records(api, golden, tmp_path):
     mp.close(); ix.close()
 
 
+def test_packed_host_boundary_gives_the_same_records(api, golden, tmp_path):
+    """mcx_stream_submit_packed (2-bit rows + lengths + the list of bytes that are not ACGT, as the file front end's parser hands
+    them over) against mcx_map_batch on the same reads as ASCII — ragged lengths, N, lower case and IUPAC letters sprinkled in:
+    records and CIGAR words equal, read by read."""
+    import ctypes as C
+    import torch
+    g = golden["var"]
+    rng = np.random.default_rng(11)
+    reads1 = [l for i, l in enumerate(open(g["r1"], "rb").read().split(b"\n")) if i % 4 == 1]
+    reads2 = [l for i, l in enumerate(open(g["r2"], "rb").read().split(b"\n")) if i % 4 == 1]
+    n_pairs, per = 1000, 4
+    batches = []
+    for b in range(per):
+        seqs = []
+        for pno in range(b * n_pairs, (b + 1) * n_pairs):
+            for x in (reads1[pno], reads2[pno]):
+                x = bytearray(x[: int(rng.integers(40, len(x) + 1))] if rng.random() < 0.2 else x)
+                if rng.random() < 0.05:
+                    x[int(rng.integers(0, len(x)))] = ord("N")
+                if rng.random() < 0.03:
+                    k = int(rng.integers(0, len(x)))
+                    x[k] = ord(chr(x[k]).lower())
+                if rng.random() < 0.01:
+                    x[int(rng.integers(0, len(x)))] = ord("R")
+                seqs.append(bytes(x))
+        off = np.zeros(len(seqs) + 1, dtype=np.uint32)
+        off[1:] = np.cumsum([len(x) for x in seqs])
+        batches.append((seqs, np.frombuffer(b"".join(seqs), dtype=np.uint8).copy(), off))
+    ix = api.Index(g["prefix"], device=0, full_sa=True)
+    mp = api.Mapper(ix, alg="ksw2", max_batch_reads=2 * n_pairs)
+    want = [mp.map_batch(bb, oo, True) for _, bb, oo in batches]
+    mp.reset()
+    L = api.lib()
+    code = np.zeros(256, dtype=np.uint32)
+    for i, ch in enumerate(b"ACGT"):
+        code[ch] = i
+    packed = []
+    for seqs, _, _ in batches:
+        row_words = (max(len(x) for x in seqs) + 15) // 16
+        rows = np.zeros((len(seqs), row_words * 16), dtype=np.uint32)
+        lens = np.array([len(x) for x in seqs], dtype=np.uint32)
+        odd = []
+        for r, x in enumerate(seqs):
+            a = np.frombuffer(x, dtype=np.uint8)
+            rows[r, : len(x)] = code[a]
+            for pos in np.nonzero(~np.isin(a, np.frombuffer(b"ACGT", dtype=np.uint8)))[0]:
+                odd.append((r << 32) | (int(pos) << 8) | int(a[pos]))
+        words = (rows.reshape(len(seqs), row_words, 16).astype(np.uint64) << (30 - 2 * np.arange(16, dtype=np.uint64))).sum(-1).astype(np.uint32)
+        tw = torch.from_numpy(words.astype(np.int64)).to(torch.int32).pin_memory()
+        tl = torch.from_numpy(lens.astype(np.int64)).to(torch.int32).pin_memory()
+        to = torch.tensor(odd if odd else [0], dtype=torch.int64).pin_memory()
+        packed.append((tw, row_words, tl, to, len(odd)))
+    assert sum(p[4] for p in packed) > 50
+    outs = [(torch.zeros(2 * n_pairs * 64, dtype=torch.uint8).pin_memory(), torch.zeros(api.cigar_pool_words(2 * n_pairs), dtype=torch.int32).pin_memory()) for _ in range(per)]
+    for i in range(per + 2):
+        if i < per:
+            tw, row_words, tl, to, n_odd = packed[i]
+            assert L.mcx_stream_submit_packed(mp._h, tw.data_ptr(), row_words, tl.data_ptr(), 2 * n_pairs, to.data_ptr(), n_odd) == 0, L.mcx_last_error()
+        if 1 <= i <= per:
+            assert L.mcx_stream_map(mp._h, 1, mp.avg, outs[i - 1][0].data_ptr(), outs[i - 1][1].data_ptr(), C.byref(mp.stats)) == 0, L.mcx_last_error()
+        if i >= 2:
+            assert L.mcx_stream_collect(mp._h, None, None) == 0, L.mcx_last_error()
+    for b in range(per):
+        aln = np.frombuffer(outs[b][0].numpy().tobytes(), dtype=api.ALN_DTYPE)
+        pool = outs[b][1].numpy().view(np.uint32)
+        w_aln, w_cig = want[b]
+        for f in ("pos", "mate_pos", "chr", "flag", "mapq", "tlen", "nm", "as", "xs", "n_cigar", "fwd", "has_mate"):
+            assert np.array_equal(aln[f], w_aln[f]), (b, f)
+        for r in range(2 * n_pairs):
+            assert np.array_equal(pool[aln["cigar_off"][r]:aln["cigar_off"][r] + aln["n_cigar"][r]], w_cig[r]), (b, r)
+    mp.close(); ix.close()
+
+
 def test_small_batches_follow_the_avgdist_trajectory(api, golden, tmp_path):
     g = golden["mc"]
     ix = api.Index(g["prefix"], device=0)
