@@ -134,16 +134,21 @@ def path_roofline(d, args, reads_per_s):
 
 
 def pcie_inclusive(args, mapper, batches, reads_per_step, dist, dev):
-    """The same steps with the device boundary the drop-in has: reads in pinned host memory in, records in pinned host
-    memory out (mcx_map_batch's successor with overlapped copies, Mapper.map_stream)."""
+    """The same steps with the device boundary the drop-in has: reads in pinned host memory in — packed to 2 bits the way the
+    file front end's parser hands them over (mcx_stream_submit_packed) —, records in pinned host memory out, the copies of one
+    batch under the kernels of its neighbours (Mapper.map_stream_packed)."""
+    from mapcaller_amd import api
     k = min(args.pcie_steps, len(batches))
-    host = [b.cpu().pin_memory() for b in batches[:k]]
-    off = (torch.arange(reads_per_step + 1, dtype=torch.int64) * args.rlen).to(torch.uint32).pin_memory()
+    host = []
+    for b in batches[:k]:
+        words, lens, odd, n_odd, row_words = api.pack_reads(b.reshape(reads_per_step, args.rlen))
+        host.append((words, lens, odd, n_odd, row_words))
+    packed = [(w.data_ptr(), rw, l.data_ptr(), o.data_ptr(), n) for (w, l, o, n, rw) in host]
     outs = mapper.stream_outputs(reads_per_step, 3)  # (page-locking gigabytes takes seconds: not part of the path)
-    b0 = mapper.map_stream([host[0].data_ptr()], off.data_ptr(), reads_per_step, True, outs)  # slots in HBM, streams, events: made on first use
+    b0 = mapper.map_stream_packed(packed[:3], reads_per_step, True, outs)  # the three slots in HBM, streams, events: made on first use
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    b1 = mapper.map_stream([h.data_ptr() for h in host], off.data_ptr(), reads_per_step, True, outs)
+    b1 = mapper.map_stream_packed(packed, reads_per_step, True, outs)
     n_bytes = (b1[0] - b0[0], b1[1] - b0[1])
     dt = time.perf_counter() - t0
     if dist:
@@ -152,9 +157,48 @@ def pcie_inclusive(args, mapper, batches, reads_per_step, dist, dev):
     world = dist.get_world_size() if dist else 1
     return {"value": round(k * reads_per_step * world / dt, 1), "unit": "reads/s", "steps": k, "ms_per_step": round(1000 * dt / k, 3),
             "h2d_bytes_per_read": round(n_bytes[0] / (k * reads_per_step), 1), "d2h_bytes_per_read": round(n_bytes[1] / (k * reads_per_step), 1),
-            "note": "ASCII reads + offsets from pinned host memory, alignment records + CIGAR pool back to pinned host memory; "
-                    "copies of batch i+1 / i-1 overlap the kernels of batch i on separate HIP streams (mcx_stream_*); the first copy in and the "
-                    "last copy out of the sequence have nothing to hide behind and are part of the time"}
+            "note": "2-bit reads + lengths from pinned host memory (the form the file front end's parser hands over; the ASCII bytes are restored "
+                    "exactly on the device), alignment records + CIGAR pool back to pinned host memory; copies of batch i+1 / i-1 overlap the kernels "
+                    "of batch i on separate HIP streams (mcx_stream_*); the first copy in and the last copy out of the sequence have nothing to "
+                    "hide behind and are part of the time"}
+
+
+def file_to_file(args, index, batch, reads_per_step):
+    """FASTQ files in, SAM file out through mcx_map_files_ex — what the CLI runs once its index is loaded —, both in tmpfs: the
+    reads of one batch of the timed region as two FASTQ files, mapped in batches of --file-batch-reads."""
+    import shutil
+    from mapcaller_amd import api, synth
+    root = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    tmp = tempfile.mkdtemp(prefix="mcx_f2f_", dir=root)
+    try:
+        reads = batch.reshape(reads_per_step, args.rlen).cpu()
+        f1, f2, sam = os.path.join(tmp, "r1.fq"), os.path.join(tmp, "r2.fq"), os.path.join(tmp, "o.sam")
+        synth.write_fastq(f1, reads, 0, 2)
+        synth.write_fastq(f2, reads, 1, 2)
+        del reads
+        mp = api.Mapper(index, alg=args.alg, max_read_len=max(256, args.rlen), max_batch_reads=args.file_batch_reads)
+        runs = []
+        for _ in range(2):  # (the first run also page-locks the batch buffers and creates the output's pages)
+            mp.reset()
+            t0 = time.perf_counter()
+            st = mp.map_files(f1, f2, sam, threads=args.file_threads)
+            runs.append(time.perf_counter() - t0)
+        mp.reset()
+        t0 = time.perf_counter()
+        mp.map_files(f1, f2, None, threads=args.file_threads)  # the same without the SAM file: what the input side and the device sustain
+        t_in = time.perf_counter() - t0
+        out = {"value": round(st["reads"] / runs[1], 1), "unit": "reads/s", "reads": st["reads"], "seconds": round(runs[1], 4), "first_run_seconds": round(runs[0], 4),
+               "without_sam_output": {"value": round(st["reads"] / t_in, 1), "seconds": round(t_in, 4),
+                                      "note": "FASTQ files in, records left in host memory: parse + pack + copies + mapping; the difference is SAM text and its way into ONE "
+                                              "file (the kernel serialises writes to a file: tmpfs took 4 GB/s from 64 threads, 3 GB of text per 8 M reads)"},
+               "fastq_bytes": os.path.getsize(f1) + os.path.getsize(f2), "sam_bytes": os.path.getsize(sam), "batch_reads": args.file_batch_reads,
+               "host_threads": args.file_threads or "default (min(64, cores / 2) per pool)", "where": tmp.rsplit("/", 1)[0],
+               "note": "two plain FASTQ files -> one SAM file, index already in HBM (the CLI loads it once per run); parse + 2-bit packing, "
+                       "copies, mapping, SAM text and positioned writes overlapped (mcx_files.cpp)"}
+        mp.close()
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, n_steps, d, dist, dev, rank, world):
@@ -223,7 +267,7 @@ def other_genome(args):
     """Two steps against the other kind of synthetic genome, as a child process once this one has let go of the GPU's memory."""
     kind = "uniform" if args.genome == "human" else "human"
     cmd = [sys.executable, os.path.abspath(__file__), "--genome", kind, "--second-genome", "0", "--steps", "2", "--warmup", "1", "--cpu-pairs", "0",
-           "--vcf-reduce", "0", "--pcie-steps", str(min(args.pcie_steps, 4)), "--genome-mbp", str(args.genome_mbp), "--contigs", str(args.contigs), "--batch-pairs", str(args.batch_pairs),
+           "--vcf-reduce", "0", "--other-configs", "0", "--file-steps", "0", "--pcie-steps", str(min(args.pcie_steps, 4)), "--genome-mbp", str(args.genome_mbp), "--contigs", str(args.contigs), "--batch-pairs", str(args.batch_pairs),
            "--rlen", str(args.rlen), "--sub", str(args.sub), "--ins", str(args.ins), "--dele", str(args.dele), "--alg", args.alg, "--full-sa", str(args.full_sa)]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=900)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -248,7 +292,7 @@ def other_configs(args):
     res = []
     for name, extra in runs:
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--second-genome", "0", "--other-configs", "0", "--vcf-reduce", "0",
-               "--pcie-steps", "0", "--full-sa", str(args.full_sa)] + extra
+               "--pcie-steps", "0", "--file-steps", "0", "--full-sa", str(args.full_sa)] + extra
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=900)
             o = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -287,6 +331,9 @@ def parse():
     ap.add_argument("--other-configs", type=int, default=1,
                     help="1: after the main run, BASELINE.json's configs 5 (250 bp PE at 5 %% indels, -alg nw) and 2 (E. coli-sized genome, 1 M x 100 bp SE) "
                          "as child processes, reported under `other_configs` with their stage times, DP GCUPS and CPU baselines")
+    ap.add_argument("--file-steps", type=int, default=1, help="1: the file-to-file leg (value_file_to_file): one batch as FASTQ files in tmpfs -> SAM; 0 = skip")
+    ap.add_argument("--file-batch-reads", type=int, default=1 << 21, help="reads per batch of the file front end's pipeline")
+    ap.add_argument("--file-threads", type=int, default=0, help="host threads per pool of the file front end (0 = pick)")
     ap.add_argument("--vcf-slice-reads", type=int, default=4_000_000, help="reads per mapping call in the -vcf leg")
     ap.add_argument("--vcf-reduce", type=int, default=1,
                     help="after the timed region: accumulate the -vcf alignment profile of one batch and sum it over the "
@@ -522,29 +569,43 @@ class Trajectory:
         self.state = [1000, 0, 0]
         self.reads = 0
         self.cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")  # (gloo: several ranks sharing one GPU in tests)
+        # the message of a round: {pairs re-run last time, per-chunk proper pairs, per-chunk distance sums}; staged in page-locked
+        # memory, exchanged on the device over RCCL (one all-gather of a few tens of KB), read back into page-locked memory
+        self.h_msg = torch.zeros(1 + 2 * n_chunks, dtype=torch.int64).pin_memory()
+        self.h_all = torch.zeros(world * (1 + 2 * n_chunks), dtype=torch.int64).pin_memory()  # (flat: what all_gather_into_tensor takes on every backend)
         self.msg = torch.zeros(1 + 2 * n_chunks, dtype=torch.int64, device=self.cdev)
-        self.all = torch.zeros((world, 1 + 2 * n_chunks), dtype=torch.int64, device=self.cdev)
+        self.all = torch.zeros(world * (1 + 2 * n_chunks), dtype=torch.int64, device=self.cdev)
         self.exchanges = 0
+        self.host_s = 0.0  # time between the end of a batch's kernels and the start of the next ones: staging, all-gather, walk
 
     def step(self, mapper, d_bases, d_off, n_reads, d_aln, d_cig):
         from mapcaller_amd import api
         est0 = int(float(self.state[0]) * 1.5)
         mapper.batch_begin(d_bases, d_off, n_reads, True, est0, self.reads + self.rank * n_reads, d_aln, d_cig)
         n_redo = -1
+        hm = self.h_msg.numpy()
         for it in range(64):
             ok, ds, _ = mapper.batch_sums()
-            self.msg[0] = n_redo
-            self.msg[1:1 + self.nc] = torch.from_numpy(ok.astype("int64")).to(self.cdev)
-            self.msg[1 + self.nc:] = torch.from_numpy(ds.astype("int64")).to(self.cdev)
-            self.dist.all_gather(list(self.all.unbind(0)), self.msg)
+            t0 = time.perf_counter()
+            hm[0] = n_redo
+            hm[1:1 + self.nc] = ok
+            hm[1 + self.nc:] = ds
+            if self.cdev.type == "cuda":
+                self.msg.copy_(self.h_msg, non_blocking=True)
+                self.dist.all_gather_into_tensor(self.all, self.msg)
+                self.h_all.copy_(self.all, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+            else:
+                self.dist.all_gather_into_tensor(self.h_all, self.h_msg)
             self.exchanges += 1
-            h = self.all.cpu().numpy()
+            h = self.h_all.numpy().reshape(self.world, 1 + 2 * self.nc)
             st = list(self.state)
             mine = None
             for r in range(self.world):
                 e = api.avg_walk(st, h[r, 1:1 + self.nc], h[r, 1 + self.nc:], want_est=(r == self.rank))
                 if r == self.rank:
                     mine = e
+            self.host_s += time.perf_counter() - t0
             if it > 0 and not h[:, 0].any():
                 break
             n_redo = mapper.batch_replay(mine)
@@ -638,6 +699,14 @@ def main():
         except Exception as e:
             pcie = {"error": str(e)[:300]}
 
+    # ---- files in, SAM out (the CLI's path), one batch's reads as FASTQ in tmpfs ------------------------------------
+    f2f = None
+    if args.file_steps > 0 and paired and world == 1:
+        try:
+            f2f = file_to_file(args, index, batches[args.warmup], reads_per_step)
+        except Exception as e:
+            f2f = {"error": str(e)[:300]}
+
     # ---- the bulk exchange of a -vcf run (not timed): profile of one batch, RCCL reduce over the ranks ------
     vcf = None
     do_vcf = args.vcf_reduce == 1 or (args.vcf_reduce < 0 and world > 1)
@@ -661,7 +730,8 @@ def main():
                        "index_hbm_gb": round(index.hbm_bytes / 1e9, 2),
                        "multi_gpu": None if world == 1 else f"one process per GPU, index replicated, rank r maps batch {world}*step + r; one avgDist trajectory over the "
                                                             f"ranks' batches per step (all-gather of per-chunk sums over RCCL, {traj.exchanges} exchanges in "
-                                                            f"{n_steps} steps, inside the timed region)"},
+                                                            f"{n_steps} steps, inside the timed region)",
+                       "multi_gpu_host_ms_per_step": None if traj is None else round(1000 * traj.host_s / n_steps, 3)},
             "roofline": roofline(args, d, total_reads / dt / world),
             "per_read": {"fm_ext_steps": round(d["fm_ext_steps"] / max(d["reads"], 1), 2), "fm_blocks": round(d["fm_blocks"] / max(d["reads"], 1), 2),
                          "sa_hits": round(d["sa_hits"] / max(d["reads"], 1), 3), "dp_jobs": round(d["dp_jobs"] / max(d["reads"], 1), 4),
@@ -674,6 +744,8 @@ def main():
         }
         if pcie is not None:
             out["value_pcie_inclusive"] = pcie
+        if f2f is not None:
+            out["value_file_to_file"] = f2f
         if vcf is not None:
             out["vcf_reduce"] = vcf
         if sample is not None:

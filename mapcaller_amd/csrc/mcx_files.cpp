@@ -35,6 +35,7 @@
 #include <thread>
 #include <vector>
 #include <fcntl.h>
+#include <sys/file.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -808,12 +809,12 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
         } else {
             // shard 0 creates (or empties) the file; the others open it once that has happened
             if (shard_rank == 0) {
-                sam_fd = ::open(sam_path, O_WRONLY | O_CREAT | (opt.append_sam ? 0 : O_TRUNC), 0644);
+                sam_fd = ::open(sam_path, O_RDWR | O_CREAT | (opt.append_sam ? 0 : O_TRUNC), 0644);
                 if (sam_fd < 0) rc = mcx_set_error(MCX_ERR_IO, std::string("cannot write ") + sam_path);
             }
             if (sharded && (rc = sh.agree(rc))) { if (sam_fd >= 0) close(sam_fd); return rc; }
             if (shard_rank != 0) {
-                sam_fd = ::open(sam_path, O_WRONLY, 0644);
+                sam_fd = ::open(sam_path, O_RDWR, 0644);
                 if (sam_fd < 0) rc = mcx_set_error(MCX_ERR_IO, std::string("cannot write ") + sam_path);
             }
             struct stat st;
@@ -837,11 +838,19 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
     int64_t *avg = opt.avg_state ? opt.avg_state : local_avg;
 
     // busy seconds per stage (MCX_TIMING=1 prints them)
-    double t_parse = 0, t_map = 0, t_format = 0, t_write = 0;
+    double t_parse = 0, t_map = 0, t_format = 0, t_write = 0, t_p_lines = 0, t_p_pack = 0, t_p_wait = 0;
     typedef std::unique_ptr<Batch> BatchPtr;
-    const int n_objects = 8;
-    Queue<BatchPtr> parsed(2), mapped(3), spare((size_t)n_objects); // batch objects circulate: their buffers are allocated (and faulted in) once
-    for (int k = 0; k < n_objects; k++) spare.push(BatchPtr(new Batch));
+    // batch objects circulate: their buffers (page-locked: slow to get) are allocated once and stay with the context from call to call
+    const int n_objects = 16;
+    struct Kept { std::vector<BatchPtr> objects; };
+    void **slot = mcx_ctx_files_slot(c, [](void *p) { delete (Kept *)p; });
+    if (!*slot) *slot = new Kept();
+    Kept *kept = (Kept *)*slot;
+    Queue<BatchPtr> parsed(2), mapped(2), spare((size_t)n_objects);
+    for (int k = 0; k < n_objects; k++) {
+        if (!kept->objects.empty()) { spare.push(std::move(kept->objects.back())); kept->objects.pop_back(); }
+        else spare.push(BatchPtr(new Batch));
+    }
     std::atomic<bool> abort(false);
 
     // ---- stage 1: parse + pack ---------------------------------------------------------------------------------------
@@ -854,8 +863,10 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
         while (!done) {
             const bool mine = number % shard_count == shard_rank;
             if (mapped_input && !mine && (number + 1) * (uint64_t)per_file < total_recs[0]) { number++; continue; } // another shard's batch: not a byte of it is touched
+            const Tick tw = now();
             BatchPtr b = spare.pop();
             const Tick t0 = now();
+            t_p_wait += secs(tw, t0);
             b->two_files = two; b->fastq = fastq; b->n = 0; b->last = false; b->error.clear(); b->number = number;
             b->in[0].clear(); b->in[1].clear(); b->n_odd[0] = b->n_odd[1] = 0; b->n_pair_reads = 0;
             if (mapped_input) {
@@ -892,6 +903,7 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
                     t2.join();
                 } else ps[0].take(b->in[0], per_file, max_len);
             }
+            t_p_lines += secs(t0, now());
             if (two) {
                 // the reference stops at the first empty read of file 1 and takes whatever file 2 holds (GetData.cpp:91-93)
                 if (mine || !mapped_input) {
@@ -909,6 +921,7 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
             if (!mine && !done) { spare.push(std::move(b)); continue; }
             if (!mine && b->error.empty()) b->n = 0;
             // 2-bit rows of this shard's reads, the bytes that are not ACGT beside them
+            const Tick tp = now();
             if (b->n && b->error.empty()) {
                 const uint32_t n = b->n;
                 uint32_t npr = paired ? n : 0; // reads mapped as pairs; the odd tail of an interleaved file is mapped read by read
@@ -949,6 +962,7 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
             }
             if (!b->error.empty()) done = true;
             b->last = done;
+            t_p_pack += secs(tp, now());
             t_parse += secs(t0, now());
             parsed.push(std::move(b));
         }
@@ -967,17 +981,36 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
             else if (b->sam_bytes) {
                 std::vector<uint64_t> off(b->slices.size() + 1, at);
                 for (size_t k = 0; k < b->slices.size(); k++) off[k + 1] = off[k] + b->slices[k].size();
-                std::atomic<int> bad(0);
-                fpool.run((int)b->slices.size(), [&](int k) {
-                    const Text &t = b->slices[(size_t)k];
-                    size_t done_b = 0;
-                    while (done_b < t.size()) {
-                        const ssize_t w = pwrite(sam_fd, t.b.data() + done_b, t.size() - done_b, (off_t)(off[(size_t)k] + done_b));
-                        if (w <= 0) { bad.store(1); break; }
-                        done_b += (size_t)w;
+                // Positioned writes, every slice at its final place.  (They queue up behind the file's lock — tmpfs takes 4 GB/s
+                // however many threads write — but the other way, copying into a mapping of the file's pages, is slower still: 64
+                // threads faulting pages into one mapping reached 1.3 GB/s.  MCX_SAM_MMAP=1 keeps that path for file systems
+                // where it pays; the file then grows under a lock of its own and never shrinks: the other shards write further on.)
+                bool done_w = false;
+                if (getenv("MCX_SAM_MMAP")) {
+                    const uint64_t end = at + b->sam_bytes, page = (uint64_t)sysconf(_SC_PAGESIZE), a0 = at & ~(page - 1);
+                    struct stat st;
+                    bool ok = flock(sam_fd, LOCK_EX) == 0;
+                    if (ok) { ok = fstat(sam_fd, &st) == 0 && ((uint64_t)st.st_size >= end || ftruncate(sam_fd, (off_t)end) == 0); (void)flock(sam_fd, LOCK_UN); }
+                    char *m = ok ? (char *)mmap(nullptr, (size_t)(end - a0), PROT_READ | PROT_WRITE, MAP_SHARED, sam_fd, (off_t)a0) : (char *)MAP_FAILED;
+                    if (m != (char *)MAP_FAILED) {
+                        fpool.run((int)b->slices.size(), [&](int k) { const Text &t = b->slices[(size_t)k]; if (t.size()) memcpy(m + (off[(size_t)k] - a0), t.b.data(), t.size()); });
+                        (void)munmap(m, (size_t)(end - a0));
+                        done_w = true;
                     }
-                });
-                if (bad.load()) write_rc = MCX_ERR_IO;
+                }
+                if (!done_w) { // (a file that cannot be mapped: positioned writes)
+                    std::atomic<int> bad(0);
+                    fpool.run((int)b->slices.size(), [&](int k) {
+                        const Text &t = b->slices[(size_t)k];
+                        size_t done_b = 0;
+                        while (done_b < t.size()) {
+                            const ssize_t w = pwrite(sam_fd, t.b.data() + done_b, t.size() - done_b, (off_t)(off[(size_t)k] + done_b));
+                            if (w <= 0) { bad.store(1); break; }
+                            done_b += (size_t)w;
+                        }
+                    });
+                    if (bad.load()) write_rc = MCX_ERR_IO;
+                }
             }
             t_write += secs(t1, now());
         };
@@ -1177,9 +1210,10 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
     if (rc) places.fail();
     writer.join();
     reader.join();
+    { BatchPtr b; while (spare.try_pop(b)) kept->objects.push_back(std::move(b)); while (parsed.try_pop(b)) kept->objects.push_back(std::move(b)); while (mapped.try_pop(b)) kept->objects.push_back(std::move(b)); }
     if (getenv("MCX_TIMING"))
-        fprintf(stderr, "[mcx_map_files] busy seconds: parse + pack %.2f | map %.2f | format %.2f write %.2f  (%d + %d host threads, %s input)\n", t_parse, t_map, t_format,
-                t_write, threads, threads, mapped_input ? "mapped" : "sequential");
+        fprintf(stderr, "[mcx_map_files] busy seconds: parse + pack %.3f (lines %.3f, rows %.3f; waited for a free batch %.3f) | map %.3f | format %.3f write %.3f  (%d + %d host threads, %s input)\n",
+                t_parse, t_p_lines, t_p_pack, t_p_wait, t_map, t_format, t_write, threads, threads, mapped_input ? "mapped" : "sequential");
     if (sam_fd >= 0 && !sam_stream) { if (close(sam_fd) != 0 && write_rc == 0) write_rc = MCX_ERR_IO; }
     if (rc == 0 && write_rc) rc = mcx_set_error(MCX_ERR_IO, std::string("cannot write ") + (sam_path ? sam_path : ""));
     return rc;

@@ -25,6 +25,9 @@ int mcx_stage_in(mcx_ctx *, const uint8_t *bases, const uint32_t *off, uint32_t 
                  mcx_aln **d_aln, uint32_t **d_cigar);
 int mcx_stage_out(mcx_ctx *, uint32_t n_reads, mcx_aln *aln, uint32_t *cigar);
 bool mcx_ctx_has_profile(const mcx_ctx *);
+// something the file front end keeps with the context from call to call (its page-locked batch buffers): *slot, freed with
+// `drop` when the context goes
+void **mcx_ctx_files_slot(mcx_ctx *, void (*drop)(void *));
 void *mcx_pinned_alloc(size_t bytes); // page-locked host memory (null on failure); mcx_pinned_free accepts null
 void mcx_pinned_free(void *);
 

@@ -155,7 +155,7 @@ int main(int argc, char **argv)
         prefix = tmp_prefix;
     }
     if (prefix.empty()) { fprintf(stderr, "Warning! Please specify a valid reference index!\n"); usage(argv[0]); return 0; }
-    o.max_batch_reads = batch_reads > 0 ? batch_reads : 1 << 19; // per batch of the parse | map | format pipeline
+    o.max_batch_reads = batch_reads > 0 ? batch_reads : 1 << 21; // per batch of the parse | map | format pipeline (a batch costs a few ms of its own: fewer, larger ones)
     if (maxlen <= 0) {
         for (const std::string &f : f1) maxlen = std::max(maxlen, sample_read_length(f));
         for (const std::string &f : f2) maxlen = std::max(maxlen, sample_read_length(f));

@@ -1493,6 +1493,7 @@ struct mcx_ctx {
     hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
     uint64_t stream_seq = 0, stream_bytes_in = 0, stream_bytes_out = 0;
     void *d_scan_tmp = nullptr; size_t scan_tmp_bytes = 0; // the prefix sum of the read lengths (mcx_stream_submit_packed)
+    void *files_state = nullptr; void (*files_drop)(void *) = nullptr; // mcx_files.cpp's batch buffers (mcx_ctx_files_slot)
     // staging for the host-buffer entry point
     uint8_t *d_bases = nullptr; uint32_t *d_off = nullptr; AlnRec *d_recs = nullptr; uint32_t *d_cig = nullptr;
     hipEvent_t ev[10];
@@ -1701,6 +1702,7 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
 extern "C" void mcx_ctx_free(mcx_ctx *c)
 {
     if (!c) return;
+    if (c->files_state && c->files_drop) c->files_drop(c->files_state);
     void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3], c->d_jobs[4], c->d_jobs[5],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_rtasks, c->d_rres, c->d_rseeds, c->d_rplans, c->d_rescue_n, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
                  c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
@@ -3021,5 +3023,6 @@ const mcx_index *mcx_ctx_index(const mcx_ctx *c) { return c->idx; }
 int mcx_ctx_max_read_len(const mcx_ctx *c) { return c->rlen_max; }
 bool mcx_ctx_has_profile(const mcx_ctx *c) { return c->prof_planes != nullptr; }
 uint64_t mcx_ctx_max_reads(const mcx_ctx *c) { return c->max_reads; }
+void **mcx_ctx_files_slot(mcx_ctx *c, void (*drop)(void *)) { c->files_drop = drop; return &c->files_state; }
 void *mcx_pinned_alloc(size_t bytes) { void *p = nullptr; return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
 void mcx_pinned_free(void *p) { if (p) (void)hipHostFree(p); }

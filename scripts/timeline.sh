@@ -3,7 +3,7 @@
 # This is how the concurrency of the tiers is looked at:  gpurun -- 'bash scripts/timeline.sh [env assignments]'
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/timeline; ulimit -c 0
 for kv in "$@"; do export "$kv"; done
-timeout 900 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/timeline/kt -o kt -- python3 bench.py --steps 2 --warmup 1 --cpu-pairs 0 --vcf-reduce 0 --pcie-steps 0 --second-genome 0 > gpurun_out/timeline/kt.log 2>&1 < /dev/null
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/timeline/kt -o kt -- python3 bench.py --steps 2 --warmup 1 --cpu-pairs 0 --vcf-reduce 0 --pcie-steps 0 --second-genome 0 --other-configs 0 --file-steps 0 > gpurun_out/timeline/kt.log 2>&1 < /dev/null
 f=$(find gpurun_out/timeline/kt -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'P'
 import csv, sys

@@ -766,6 +766,26 @@ def test_run_module_single_gpu(golden, tmp_path):
     assert vcf_body(vcf) == vcf_body(g["vcf"]["gvcf"])
 
 
+def test_bench_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus 2` the way the driver runs it on a node with several GPUs — the launcher starts one rank per GPU before
+    any GPU call, the ranks walk one insert-size trajectory per step — with the two ranks sharing this box's one GPU over gloo and a
+    small genome: one JSON line, two GPUs' worth of reads, the exchange inside the timed region."""
+    env = dict(os.environ, PYTHONPATH=ROOT, MCX_BENCH_SHARE_GPU="1", MCX_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--genome", "uniform", "--genome-mbp", "20", "--contigs", "4",
+           "--repeats", "50", "--batch-pairs", "100000", "--cpu-pairs", "0", "--vcf-reduce", "0", "--pcie-steps", "0", "--second-genome", "0", "--other-configs", "0",
+           "--file-steps", "0"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == 2 and o["steps"] == 2 and o["scaling"] == "weak"
+    assert o["value"] > 0 and abs(o["value"] - 2 * 2 * 200000 / (o["ms_per_step"] * 2 / 1000)) < 0.01 * o["value"]
+    assert o["per_read"]["mapped_frac"] > 0.9
+    assert "exchanges" in o["config"]["multi_gpu"]
+    assert o["config"]["multi_gpu_host_ms_per_step"] is not None
+
+
 def test_degenerate_reads_equal_oracle(api, golden, tmp_path):
     """Reads the path has little to say about — shorter than a seed, all N, homopolymers and short
     tandem repeats (more than 50 occurrences: BWT_Search reports none), a read that is the genome's
