@@ -1187,7 +1187,7 @@ __global__ void __launch_bounds__(256) k_rescue_apply(Ctx cx, RescueWork rw)
 // (late: the pairs that ran over this tier's capacities since clustering — mate rescue's additions, fragment lists, DP
 //  columns, job lists — are listed like the early ones, for a second pass of the large tier beside the rest of this one)
 #ifndef MCX_BUILD_WAVES
-#define MCX_BUILD_WAVES 3
+#define MCX_BUILD_WAVES 5
 #endif
 __global__ void __launch_bounds__(256, MCX_BUILD_WAVES) k_build(Ctx cx, ReadBatch rb, PairSel sel, JobSinks sinks, uint32_t *cells, uint32_t *unsupported, EarlyList late,
                                                const uint32_t *order)
