@@ -1161,13 +1161,14 @@ static inline MCX_HD int mapq_of(const Ctx &cx, const ReadSum &r) // EvaluateMAP
 // GenerateCIGARstring (SamReport.cpp:172-316) as BAM-style (len << 4 | op) words; op codes
 // M=0 I=1 D=2 S=4.  Returns the number of words needed (may exceed cap).
 // (out may be null with cap 0: the operations are only counted)
-static inline MCX_HD int cigar_of(int rlen, const Cand &c, const Frag *frags, const uint8_t *ops, uint32_t *out, int cap)
+// (stride: operation k goes to out[k * stride] — the finish kernel stages them word-major in LDS, one lane beside the next)
+static inline MCX_HD int cigar_of(int rlen, const Cand &c, const Frag *frags, const uint8_t *ops, uint32_t *out, int cap, int stride = 1)
 {
     auto v = [&](int i) -> Frag { return frags[frag_index(c, i)]; };
     int num = c.n_frags, n = 0, run = 0, st = -1;
     auto put = [&](int len, int op) {
         const uint32_t w = ((uint32_t)len << 4) | (uint32_t)op;
-        if (n < cap) out[n] = w;
+        if (n < cap) out[n * stride] = w;
         n++;
     };
     auto flush_to = [&](int ns) { if (st != ns) { if (run > 0) put(run, st); st = ns; run = 0; } };
@@ -1264,7 +1265,7 @@ static inline MCX_HD void pair_stats(const Ctx &cx, PairState &st, DetailHdr *dh
 // read in unique mode (SamReport.cpp:324-488).  cig: where the read's n_cig operations go (counted by
 // finish_scores, reserved in the batch's pool by the caller), cig_off: that place as a pool offset.
 static inline MCX_HD void emit_record(const Ctx &cx, PairState &st, int s, const ReadRef *rd, AlnRec &dst,
-                                      uint32_t *cig, int n_cig, uint32_t cig_off, const uint32_t *staged = nullptr)
+                                      uint32_t *cig, int n_cig, uint32_t cig_off, const uint32_t *staged = nullptr, int stage_stride = 1)
 {
     PairHdr &h = *st.hdr;
     const ReadSum me = h.sum[s];
@@ -1296,7 +1297,7 @@ static inline MCX_HD void emit_record(const Ctx &cx, PairState &st, int s, const
     out.fwd = c.fwd;
     out.nm = rd[s].rlen - c.score; out.as = me.score; out.xs = me.sub;
     if (!cig) out.n_cigar = 0; // (the pool ran over; the batch fails)
-    else if (staged && n_cig <= kCigStage) { for (int k = 0; k < n_cig; k++) cig[k] = staged[k]; out.n_cigar = n_cig; }
+    else if (staged && n_cig <= kCigStage) { for (int k = 0; k < n_cig; k++) cig[k] = staged[k * stage_stride]; out.n_cigar = n_cig; }
     else out.n_cigar = cigar_of(rd[s].rlen, c, st.frags, st.ops, cig, n_cig);
     out.pad[0] = (int32_t)cig_off;
     if (paired) {
@@ -1369,7 +1370,7 @@ static inline MCX_HD void write_detail(const Ctx &cx, PairState &st, int s, uint
 // (stage: room for kCigStage operations per read — most reads have at most that many, and finish_records then copies them
 //  instead of walking the alignment a second time)
 static inline MCX_HD void finish_scores(const Ctx &cx, PairState &st, const ReadRef *rd, DetailHdr *dh, int n_cig[2], const IndexView *ixr = nullptr,
-                                        uint32_t *stage = nullptr)
+                                        uint32_t *stage = nullptr, int stage_stride = 1)
 {
     PairHdr &h = *st.hdr;
     n_cig[0] = n_cig[1] = 0;
@@ -1382,14 +1383,14 @@ static inline MCX_HD void finish_scores(const Ctx &cx, PairState &st, const Read
     MCX_UNROLL
     for (int s = 0; s < 2; s++) {
         if (s >= nr) break;
-        if (h.sum[s].score > 0) n_cig[s] = cigar_of(rd[s].rlen, st.cands[s][h.sum[s].best], st.frags, st.ops, stage ? stage + s * kCigStage : nullptr, stage ? kCigStage : 0);
+        if (h.sum[s].score > 0) n_cig[s] = cigar_of(rd[s].rlen, st.cands[s][h.sum[s].best], st.frags, st.ops, stage ? stage + s * kCigStage * stage_stride : nullptr, stage ? kCigStage : 0, stage_stride);
     }
 }
 
 // finish_records: the pair's output records (rec2[0..nr)), their CIGAR words at cig_pool + cig_off[s] (null pool: the
 // reservation failed), and the alignment detail of its reads when the profile is kept (detail2 = the pair's first record).
 static inline MCX_HD void finish_records(const Ctx &cx, PairState &st, const ReadRef *rd, AlnRec *rec2, uint32_t *cig_pool,
-                                         const uint32_t cig_off[2], const int n_cig[2], uint8_t *detail2, const uint32_t *stage = nullptr)
+                                         const uint32_t cig_off[2], const int n_cig[2], uint8_t *detail2, const uint32_t *stage = nullptr, int stage_stride = 1)
 {
     PairHdr &h = *st.hdr;
     if (h.flags & kOvAny) return;
@@ -1397,7 +1398,7 @@ static inline MCX_HD void finish_records(const Ctx &cx, PairState &st, const Rea
     MCX_UNROLL
     for (int s = 0; s < 2; s++) {
         if (s >= nr) break;
-        emit_record(cx, st, s, rd, rec2[s], cig_pool ? cig_pool + cig_off[s] : nullptr, n_cig[s], cig_off[s], stage ? stage + s * kCigStage : nullptr);
+        emit_record(cx, st, s, rd, rec2[s], cig_pool ? cig_pool + cig_off[s] : nullptr, n_cig[s], cig_off[s], stage ? stage + s * kCigStage * stage_stride : nullptr, stage_stride);
         if (detail2) write_detail(cx, st, s, detail2 + (int64_t)s * cx.dlay.stride);
     }
 }

@@ -1349,10 +1349,10 @@ __global__ void __launch_bounds__(256, MCX_FINISH_WAVES) k_finish(Ctx cx, ReadBa
                                                 uint32_t ov_cap, uint32_t *pool_over, const uint32_t *order)
 {
     __shared__ EndsLds ends;
-    __shared__ uint32_t cig_stage[256 * 2 * kCigStage]; // the first operations of every read, lane-major (8 words per lane: no bank shared within a quarter wave)
+    __shared__ uint32_t cig_stage[256 * 2 * kCigStage]; // the first operations of every read, word-major: word k of thread t at [k * 256 + t] (neighbouring lanes, neighbouring banks)
     stage_ends(cx.ix, ends);
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t *stage = cig_stage + threadIdx.x * 2 * kCigStage;
+    uint32_t *stage = cig_stage + threadIdx.x;
     const bool active = slot < sel.n; // (no early exit: the wave reserves its CIGAR words together)
     const uint32_t local = active ? (order ? order[slot] : slot) : 0u;
     const int nr = cx.pm.paired ? 2 : 1;
@@ -1370,7 +1370,7 @@ __global__ void __launch_bounds__(256, MCX_FINISH_WAVES) k_finish(Ctx cx, ReadBa
         h = *st.hdr;
         st.hdr = &h;
         detail2 = cx.detail ? cx.detail + (int64_t)pair * nr * cx.dlay.stride : nullptr; // records are indexed by batch read
-        finish_scores(cx, st, rd, (DetailHdr *)detail2, n_cig, nullptr, stage);
+        finish_scores(cx, st, rd, (DetailHdr *)detail2, n_cig, nullptr, stage, 256);
     }
     const uint32_t want = (uint32_t)(n_cig[0] + n_cig[1]);
     const uint32_t at = wave_reserve(cx.cig_pool_n, want);
@@ -1378,7 +1378,7 @@ __global__ void __launch_bounds__(256, MCX_FINISH_WAVES) k_finish(Ctx cx, ReadBa
     const bool fits = at + want <= cx.cig_pool_cap;
     if (!fits) atomicOr(pool_over, 1u);
     const uint32_t off[2] = {at, at + (uint32_t)n_cig[0]};
-    finish_records(cx, st, rd, recs + (int64_t)pair * nr, fits ? cx.cig_pool : nullptr, off, n_cig, detail2, stage);
+    finish_records(cx, st, rd, recs + (int64_t)pair * nr, fits ? cx.cig_pool : nullptr, off, n_cig, detail2, stage, 256);
     PairOut o;
     o.flags = h.flags; o.est = h.est; o.est_lo = h.est_lo; o.est_hi = h.est_hi;
     o.pair_dist = h.pair_dist; o.pair_ok = (int16_t)h.pair_ok; o.mapped = (int16_t)h.mapped;
