@@ -250,7 +250,11 @@ def vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, n_s
            "sparse_records": len(merged)}
     if rank == 0:  # VariantCalling() runs once, on the reduced profile
         mapper.profile_finalize(planes.data_ptr())
-        vcf["covered_positions"] = int(((planes[0] | planes[1] | planes[2] | planes[3]) > 0).sum().item())
+        cov = 0
+        for lo in range(0, G, 1 << 28):  # (in pieces: a genome-sized temporary does not fit beside the planes)
+            hi = min(G, lo + (1 << 28))
+            cov += int(((planes[0, lo:hi] | planes[1, lo:hi] | planes[2, lo:hi] | planes[3, lo:hi]) > 0).sum().item())
+        vcf["covered_positions"] = cov
         with tempfile.TemporaryDirectory() as tmp:
             vs = index.call_variants(planes.data_ptr(), merged, tot[0], tot[1], tot[2], os.path.join(tmp, "bench.vcf"),
                                      ref_name="synthetic", cmdline="bench.py")

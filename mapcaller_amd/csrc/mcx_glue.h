@@ -36,6 +36,7 @@ struct Ctx {
     int32_t wpad;
     const uint32_t *read_ext;
     int32_t dp_summary;       // the DP kernels leave a DpSummary in front of every problem's columns (stage_build reserves the room)
+    const Hit *seed_pool;     // the seeds of the candidates mate rescue added window by window (Cand::in_pool); null on the host
 };
 
 constexpr int kCigStage = 4; // CIGAR operations per read that the finish stage keeps at hand between counting and writing them
@@ -82,7 +83,7 @@ static inline MCX_HD void cand_init(Cand &dst, int score, int first, int count, 
 {
     Cand c;
     c.score = score; c.mate = -1; c.first = first; c.count = count; c.pd0 = pd0;
-    c.frag_off = 0; c.n_frags = 0; c.flag = 0; c.fwd = 1; for (int k = 0; k < 7; k++) c.pad[k] = 0;
+    c.frag_off = 0; c.n_frags = 0; c.flag = 0; c.fwd = 1; c.in_pool = 0; c.pad = 0; c.pool_off = 0;
     dst = c; // two 16-byte stores
 }
 
@@ -939,7 +940,7 @@ static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef 
             if (c.score == 0) { cs[ci].frag_off = (int16_t)h.n_frags; cs[ci].n_frags = 0; continue; }
             if (h.n_frags + 2 * c.count + 2 > cx.caps.frag_cap) { cs[ci].frag_off = (int16_t)h.n_frags; cs[ci].n_frags = 0; h.flags |= kOvFrags; *g_hdr = h; if (flags_out) *flags_out = h.flags; return 0; }
             Frag *f = st.frags + h.n_frags;
-            int nf = build_frags(cx.ix, rd[s].rlen, st.hits[s] + c.first, c.count, f);
+            int nf = build_frags(cx.ix, rd[s].rlen, c.in_pool ? cx.seed_pool + c.pool_off : st.hits[s] + c.first, c.count, f);
             cs[ci].frag_off = (int16_t)h.n_frags; cs[ci].n_frags = (int16_t)(nf < 0 ? 0 : nf);
             if (nf < 0) { cs[ci].score = 0; continue; }
             // ProcessNormalPair (:155-191): classify each gap fragment

@@ -891,7 +891,7 @@ __global__ void __launch_bounds__(64) k_cluster_wave(Ctx cx, ReadBatch rb, PairS
             for (int i = lane; i < n_cands[s]; i += 64) {
                 Cand c;
                 c.score = L.score[s][i]; c.mate = (int16_t)L.mate[s][i]; c.first = (int16_t)(L.span[s][i] & 0xFFFFu); c.count = (int16_t)(L.span[s][i] >> 16); c.pd0 = L.pd[s][i];
-                c.frag_off = 0; c.n_frags = 0; c.flag = 0; c.fwd = 1; for (int k = 0; k < 7; k++) c.pad[k] = 0;
+                c.frag_off = 0; c.n_frags = 0; c.flag = 0; c.fwd = 1; c.in_pool = 0; c.pad = 0; c.pool_off = 0;
                 st.cands[s][i] = c;
             }
         if (lane == 0) {
@@ -1163,16 +1163,16 @@ __global__ void __launch_bounds__(256) k_rescue_apply(Ctx cx, RescueWork rw)
             if (res.score <= task.sb) continue;
             const int a = task.side, b = 1 - task.side; // candidate ci of read a gets a mate among read b's
             if ((uint64_t)res.seed_off + (uint64_t)res.n_seeds > rw.seed_cap) break; // (the pool ran over)
-            if (nh[b] + res.n_seeds > cx.caps.hit_cap) { flags |= kOvHits; continue; }
             if (nc[b] >= cx.caps.cand_cap) { flags |= kOvCands; continue; }
             paired++;
-            const Hit *src = rw.seeds + res.seed_off;
-            Hit *hb = st.hits[b];
-            for (int s = 0; s < res.n_seeds; s++) hb[nh[b] + s] = src[s];
+            // the new candidate's seeds stay in the pool (stage_build reads them there): no copy, and no bound on how many
+            // seeds mate rescue may add to a read (a candidate per window, up to rlen / 11 seeds each)
             st.cands[a][task.ci].mate = (int16_t)nc[b];
-            cand_init(st.cands[b][nc[b]], res.score, nh[b], res.n_seeds, (int64_t)res.d + task.left);
-            st.cands[b][nc[b]].mate = (int16_t)task.ci;
-            nc[b]++; nh[b] += res.n_seeds;
+            Cand nw;
+            nw.score = res.score; nw.mate = (int16_t)task.ci; nw.first = 0; nw.count = (int16_t)res.n_seeds; nw.pd0 = (int64_t)res.d + task.left;
+            nw.frag_off = 0; nw.n_frags = 0; nw.flag = 0; nw.fwd = 1; nw.in_pool = 1; nw.pad = 0; nw.pool_off = (int32_t)res.seed_off;
+            st.cands[b][nc[b]] = nw;
+            nc[b]++;
         }
         h.flags |= flags;
         h.n_cands[0] = (int16_t)nc[0]; h.n_cands[1] = (int16_t)nc[1];
@@ -1558,7 +1558,7 @@ static int rescue_alloc(mcx_ctx *c, uint64_t pairs, bool large, RescueTask **tas
     // (the large tier's pairs have hundreds of candidates: many more windows per pair than tier 0's, whose lists stay short)
     *task_cap = large ? 1u << 22 : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(pairs, 1u << 18), 1u << 21);
     if (const char *e = getenv("MCX_RESCUE_TASK_CAP")) *task_cap = (uint32_t)std::max(16, atoi(e)); // (tests: make the list run over)
-    *seed_cap = *task_cap; // seeds are kept only of windows that beat the mate's best candidate: a few per pair
+    *seed_cap = large ? *task_cap * 4 : *task_cap; // seeds are kept only of windows that beat the mate's best candidate (a few per pair; a heavy pair's windows mostly do)
     if ((rc = dmalloc(tasks, *task_cap))) return rc;
     if ((rc = dmalloc(res, *task_cap))) return rc;
     if ((rc = dmalloc(seeds, (size_t)*seed_cap))) return rc;
@@ -1737,7 +1737,7 @@ static Ctx make_ctx(const mcx_ctx *c, int tier, int paired)
     cx.mapq_tab = c->d_mapq; cx.mapq_rows = c->mapq_rows; cx.dp_summary = 1;
     cx.detail = c->prof_planes ? c->d_detail : nullptr; cx.dlay = c->dlay;
     cx.cig_pool = c->run.cig; cx.cig_pool_n = c->d_batch_flags; cx.cig_pool_cap = c->run.cig_cap;
-    cx.packed = c->d_packed; cx.wpad = c->wpad; cx.read_ext = c->d_read_ext;
+    cx.packed = c->d_packed; cx.wpad = c->wpad; cx.read_ext = c->d_read_ext; cx.seed_pool = nullptr;
     return cx;
 }
 
@@ -1801,6 +1801,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     hipStream_t s = R.stream;
     Ctx cx = make_ctx(c, tier, paired);
     cx.state += (size_t)state_off * (size_t)cx.lay.stride;
+    cx.seed_pool = R.d_rseeds;
     const int nr = paired ? 2 : 1;
     early = early && tier == 0 && c->overlap_tiers;
     HIP_TRY(hipMemsetAsync(R.d_cnt, 0, CNT_N * sizeof(uint32_t), s));

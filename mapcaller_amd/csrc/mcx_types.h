@@ -89,7 +89,9 @@ struct alignas(16) Cand { // AlnCan_t (structure.h:125-133) as ranges into the p
     int16_t n_frags;
     int16_t flag;     // SamFlag
     int8_t fwd;       // orientation
-    int8_t pad[7];
+    uint8_t in_pool;  // the candidate's seeds lie in the pass's seed pool (mate rescue's additions), pool_off on, not among the read's hits
+    int16_t pad;
+    int32_t pool_off;
 };
 static_assert(sizeof(Cand) == 32, "Cand is two 16-byte records");
 

@@ -21,6 +21,9 @@ import re
 from collections import defaultdict
 
 
+STREAMING = ("k_pack_reads", "k_unpack_reads")  # kernels whose reads are wide coalesced streams
+
+
 def short(name):
     m = re.match(r"(?:void )?((?:mcx::)?k_[A-Za-z0-9_]+(?:<[^>(]*>)?)", name)
     return m.group(1) if m else None
@@ -86,7 +89,8 @@ def main():
     s = {"command": a.command,
          "note": "FETCH_SIZE/WRITE_SIZE are KiB as rocprofv3 reports them. For the scattered 16-B-per-lane reads of k_seed, "
                  "FETCH_SIZE*1024 equals TCC_MISS_sum*64 within 1 %, i.e. 64-byte fabric requests counted at 64 B: the guide's "
-                 "x2 correction (wide coalesced streams tallied as 128-B requests at 64 B) does not apply to this pattern."}
+                 "x2 correction (wide coalesced streams tallied as 128-B requests at 64 B) does not apply to this pattern; it is applied to "
+                 "the streaming kernels (" + ", ".join(STREAMING) + ")."}
     if a.trace:
         s["kernel_trace"] = read_trace(a.trace)
     if a.pmc:
@@ -96,8 +100,13 @@ def main():
             for k, cs in s["pmc"].items():
                 e = {}
                 if "FETCH_SIZE" in cs:
-                    e["hbm_read_bytes_per_launch"] = round(cs["FETCH_SIZE"]["full_batch_mean"] * 1024)
-                    e["hbm_read_bytes_per_read"] = round(cs["FETCH_SIZE"]["full_batch_mean"] * 1024 / a.reads_per_launch, 1)
+                    # wide coalesced streaming reads (16 B per lane, neighbouring lanes neighbouring addresses) are reported at half
+                    # their bytes on gfx950 (MI355X_MICROARCH.md, HBM): doubled for the kernels that read that way
+                    f = 2.0 if k in STREAMING else 1.0
+                    e["hbm_read_bytes_per_launch"] = round(f * cs["FETCH_SIZE"]["full_batch_mean"] * 1024)
+                    e["hbm_read_bytes_per_read"] = round(f * cs["FETCH_SIZE"]["full_batch_mean"] * 1024 / a.reads_per_launch, 1)
+                    if f != 1.0:
+                        e["fetch_size_correction"] = "x2 (wide coalesced streaming read)"
                 if "WRITE_SIZE" in cs:
                     e["hbm_write_bytes_per_launch"] = round(cs["WRITE_SIZE"]["full_batch_mean"] * 1024)
                     e["hbm_write_bytes_per_read"] = round(cs["WRITE_SIZE"]["full_batch_mean"] * 1024 / a.reads_per_launch, 1)

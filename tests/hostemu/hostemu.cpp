@@ -88,7 +88,7 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
     cx.detail = nullptr; cx.dlay = make_detail_layout(256);
     cx.state = state.data(); cx.mapq_tab = e.mapq.data(); cx.mapq_rows = e.mapq_rows;
     cx.cig_pool = cig.data(); cx.cig_pool_n = &e.cig_used; cx.cig_pool_cap = (uint32_t)cig.size();
-    cx.packed = nullptr; cx.wpad = 0; cx.read_ext = nullptr;
+    cx.packed = nullptr; cx.wpad = 0; cx.read_ext = nullptr; cx.seed_pool = nullptr;
     std::vector<DpJob> jobs;
     std::vector<uint32_t> kq(4096), kg(e.caps[tier].kmer_cap + 16);
     std::vector<uint32_t> ov;
