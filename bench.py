@@ -208,7 +208,8 @@ def vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, n_s
     # the timed region's context and all but one batch make room, the batch is mapped in slices
     last = batches[n_steps - 1]
     del batches[:]
-    mapper.close()
+    if mapper is not None:
+        mapper.close()
     torch.cuda.empty_cache()  # (the caching allocator would sit on the freed batches)
     slice_reads = min(reads_per_step, args.vcf_slice_reads)
     mapper = api.Mapper(index, alg=args.alg, max_read_len=max(256, args.rlen), max_batch_reads=slice_reads)
@@ -703,20 +704,29 @@ def main():
         except Exception as e:
             pcie = {"error": str(e)[:300]}
 
+    # (the legs below bring contexts and buffers of their own: the timed region's context, its device slots and all but one batch make room)
+    keep = batches[min(args.warmup, len(batches) - 1)]
+    del batches[:]
+    batches.append(keep)
+    mapper.close()
+    mapper = None
+    torch.cuda.empty_cache()
+
     # ---- files in, SAM out (the CLI's path), one batch's reads as FASTQ in tmpfs ------------------------------------
     f2f = None
     if args.file_steps > 0 and paired and world == 1:
         try:
-            f2f = file_to_file(args, index, batches[args.warmup], reads_per_step)
+            f2f = file_to_file(args, index, keep, reads_per_step)
         except Exception as e:
             f2f = {"error": str(e)[:300]}
+        torch.cuda.empty_cache()
 
     # ---- the bulk exchange of a -vcf run (not timed): profile of one batch, RCCL reduce over the ranks ------
     vcf = None
     do_vcf = args.vcf_reduce == 1 or (args.vcf_reduce < 0 and world > 1)
     if do_vcf:
         try:
-            vcf = vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, n_steps, d, dist, dev, rank, world)
+            vcf = vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, 1, d, dist, dev, rank, world)
             mapper = None
         except Exception as e:  # never lose the bench line to the optional section
             vcf = {"error": str(e)[:300]}

@@ -111,7 +111,29 @@ static __device__ __forceinline__ DpBuf dp_buffers(int qlen, int tlen, uint8_t *
 // The recurrence's values are differences bounded by the scoring constants (match 1, mismatch -1, q 2, e 1): u, v in
 // [-3, 7], x, y in [0, 7], their sums in [-6, 14] — the int8 lanes of the reference never wrap, so plain ints hold the
 // same values; only the two unsigned byte operations (:89-90) need the byte view of a negative number.
-template <int K, int W, bool SCORE>
+// ksw_backtrack (:25-68) by one lane; full band: force_state never fires.  Returns the column string's start offset in ops.
+static __device__ int dp_ksw2_trace(int qlen, int tlen, const uint8_t *q, const uint8_t *t, const uint8_t *dir, uint8_t *ops, DpSummary *sum, uint32_t ops_base)
+{
+    int w = qlen + tlen;
+    int i = tlen - 1, j = qlen - 1, state = 0;
+    DpSumAcc acc; acc.begin(sum);
+    while (i >= 0 && j >= 0) {
+        const unsigned d = dir[(i + j) * tlen + i];
+        if (state == 0) state = d & 7;
+        else if (!((d >> (state + 2)) & 1)) state = 0;
+        if (state == 0) state = d & 7;
+        if (state == 0) { ops[--w] = 'M'; acc.put(0, q[j] != t[i]); --i; --j; }
+        else if (state == 1 || state == 3) { ops[--w] = 'D'; acc.put(2, 0); --i; }
+        else { ops[--w] = 'I'; acc.put(1, 0); --j; }
+    }
+    for (; i >= 0; --i) { ops[--w] = 'D'; acc.put(2, 0); }
+    for (; j >= 0; --j) { ops[--w] = 'I'; acc.put(1, 0); }
+    acc.end(ops_base + (uint32_t)w, qlen + tlen - w);
+    return w;
+}
+
+// (TRACE false: the sweep only — the traceback bytes stay in dir for a walk of their own, dp_ksw2_trace)
+template <int K, int W, bool SCORE, bool TRACE = true>
 static __device__ int dp_ksw2_core(int qlen, int tlen, const uint8_t *q, const uint8_t *t, uint8_t *dir, uint8_t *ops,
                                    int *score, DpSummary *sum, uint32_t ops_base)
 {
@@ -174,35 +196,41 @@ static __device__ int dp_ksw2_core(int qlen, int tlen, const uint8_t *q, const u
         for (int k = 0; k < K; k++) { const int hv = group_pick<W>(H[k], ll); if (k == kk) sc = hv; }
         *score = sc;
     }
-    dp_sync<W>();
-    int w = qlen + tlen;
-    if (lane == 0) {
-        // ksw_backtrack (:25-68); full band: force_state never fires
-        int i = tlen - 1, j = qlen - 1, state = 0;
-        DpSumAcc acc; acc.begin(sum);
-        while (i >= 0 && j >= 0) {
-            const unsigned d = dir[(i + j) * tlen + i];
-            if (state == 0) state = d & 7;
-            else if (!((d >> (state + 2)) & 1)) state = 0;
-            if (state == 0) state = d & 7;
-            if (state == 0) { ops[--w] = 'M'; acc.put(0, q[j] != t[i]); --i; --j; }
-            else if (state == 1 || state == 3) { ops[--w] = 'D'; acc.put(2, 0); --i; }
-            else { ops[--w] = 'I'; acc.put(1, 0); --j; }
-        }
-        for (; i >= 0; --i) { ops[--w] = 'D'; acc.put(2, 0); }
-        for (; j >= 0; --j) { ops[--w] = 'I'; acc.put(1, 0); }
-        acc.end(ops_base + (uint32_t)w, qlen + tlen - w);
+    if (TRACE) {
+        dp_sync<W>();
+        int w = qlen + tlen;
+        if (lane == 0) w = dp_ksw2_trace(qlen, tlen, q, t, dir, ops, sum, ops_base);
+        w = group_pick<W>(w, 0);
+        dp_sync<W>();
+        return w;
     }
-    w = group_pick<W>(w, 0);
-    dp_sync<W>();
-    return w;
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
 // nw: r/t/s recurrence of nw_alignment in doubled integers (all reference scores are multiples
 // of 0.5 and exact in float), equality-based traceback.  Rows i = read (q), columns j = genome.
 // ---------------------------------------------------------------------------------------------
-template <int K, int W>
+// the traceback of nw_alignment (nw_alignment.cpp:59-74) by one lane
+static __device__ int dp_nw_trace(int m, int n, const uint8_t *q, const uint8_t *t, const uint8_t *dir, uint8_t *ops, DpSummary *sum, uint32_t ops_base)
+{
+    int w = m + n;
+    int i = m, j = n; // 1-based matrix indices
+    DpSumAcc acc; acc.begin(sum);
+    while (i > 0 || j > 0) {
+        unsigned d;
+        if (i == 0) d = 1;       // s[0][j] == r[0][j]
+        else if (j == 0) d = 2;  // s[i][0] == t[i][0]
+        else d = dir[(i + j - 2) * n + (j - 1)];
+        if (d & 1) { ops[--w] = 'D'; acc.put(2, 0); j--; }       // '-' inserted into s1 (read string)
+        else if (d & 2) { ops[--w] = 'I'; acc.put(1, 0); i--; }  // '-' inserted into s2 (genome string)
+        else { ops[--w] = 'M'; acc.put(0, q[i - 1] != t[j - 1]); i--; j--; }
+    }
+    acc.end(ops_base + (uint32_t)w, m + n - w);
+    return w;
+}
+
+template <int K, int W, bool TRACE = true>
 static __device__ int dp_nw_core(int m, int n, const uint8_t *q, const uint8_t *t, uint8_t *dir, uint8_t *ops, int *score, DpSummary *sum,
                                  uint32_t ops_base)
 {
@@ -255,31 +283,34 @@ static __device__ int dp_nw_core(int m, int n, const uint8_t *q, const uint8_t *
         for (int k = 0; k < K; k++) { const int hv = group_pick<W>(S[k], ll); if (k == kk) sc = hv; }
         *score = sc;
     }
-    dp_sync<W>();
-    int w = m + n;
-    if (lane == 0) {
-        int i = m, j = n; // 1-based matrix indices (nw_alignment.cpp:59-74)
-        DpSumAcc acc; acc.begin(sum);
-        while (i > 0 || j > 0) {
-            unsigned d;
-            if (i == 0) d = 1;       // s[0][j] == r[0][j]
-            else if (j == 0) d = 2;  // s[i][0] == t[i][0]
-            else d = dir[(i + j - 2) * n + (j - 1)];
-            if (d & 1) { ops[--w] = 'D'; acc.put(2, 0); j--; }       // '-' inserted into s1 (read string)
-            else if (d & 2) { ops[--w] = 'I'; acc.put(1, 0); i--; }  // '-' inserted into s2 (genome string)
-            else { ops[--w] = 'M'; acc.put(0, q[i - 1] != t[j - 1]); i--; j--; }
-        }
-        acc.end(ops_base + (uint32_t)w, m + n - w);
+    if (TRACE) {
+        dp_sync<W>();
+        int w = m + n;
+        if (lane == 0) w = dp_nw_trace(m, n, q, t, dir, ops, sum, ops_base);
+        w = group_pick<W>(w, 0);
+        dp_sync<W>();
+        return w;
     }
-    w = group_pick<W>(w, 0);
-    dp_sync<W>();
-    return w;
+    return 0;
 }
 
 template <int K, int W, bool SCORE = false>
 static __device__ __forceinline__ int dp_core(bool nw, int qlen, int tlen, const DpBuf &b, uint8_t *ops, int *score, DpSummary *sum, uint32_t ops_base)
 {
     return nw ? dp_nw_core<K, W>(qlen, tlen, b.q, b.t, b.dir, ops, score, sum, ops_base) : dp_ksw2_core<K, W, SCORE>(qlen, tlen, b.q, b.t, b.dir, ops, score, sum, ops_base);
+}
+
+// the sweep alone (traceback bytes to b.dir) and the walk alone (one lane), for kernels that sweep a group of problems and then
+// walk the group's tracebacks one per lane
+template <int K, int W>
+static __device__ __forceinline__ void dp_sweep(bool nw, int qlen, int tlen, const DpBuf &b, int *score)
+{
+    if (nw) (void)dp_nw_core<K, W, false>(qlen, tlen, b.q, b.t, b.dir, nullptr, score, nullptr, 0u);
+    else (void)dp_ksw2_core<K, W, false, false>(qlen, tlen, b.q, b.t, b.dir, nullptr, score, nullptr, 0u);
+}
+static __device__ __forceinline__ int dp_trace(bool nw, int qlen, int tlen, const uint8_t *q, const uint8_t *t, const uint8_t *dir, uint8_t *ops, DpSummary *sum, uint32_t ops_base)
+{
+    return nw ? dp_nw_trace(qlen, tlen, q, t, dir, ops, sum, ops_base) : dp_ksw2_trace(qlen, tlen, q, t, dir, ops, sum, ops_base);
 }
 
 // tiny problems (up to 8 x 8, most of the bulk: median 3 x 3): one lane each — the same recurrences with

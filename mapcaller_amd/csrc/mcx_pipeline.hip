@@ -1283,6 +1283,72 @@ __global__ void __launch_bounds__(64) k_dp_sel(Ctx cx, JobSink sink, ReadBatch r
     }
 }
 
+// The one-wavefront classes, a group of problems at a time.  k_dp_sel sweeps a problem and then lets lane 0 walk its traceback
+// while 63 lanes look on — as many vector instructions as the sweep itself.  Here a wavefront sweeps up to 64 problems one after
+// the other, every sweep leaving its traceback bytes (and the two strings) in the wavefront's stretch of an HBM scratch that
+// stays in L2, and then walks the 64 tracebacks at once, one per lane.  Same bytes, same walks, same column strings.
+constexpr int kDpGroup = 64;
+struct DpGroupSlot { uint32_t off; int32_t score; }; // where a problem's strings and traceback bytes lie in the wave's scratch; its sweep's score
+
+template <int K>
+__global__ void __launch_bounds__(64) k_dp_group(Ctx cx, JobSink sink, ReadBatch rb, PairSel sel, uint8_t *scratch, uint64_t scratch_stride)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[DpLds<K>::seq];
+    __shared__ DpGroupSlot slot[kDpGroup];
+    uint8_t *mine = scratch + (uint64_t)blockIdx.x * scratch_stride;
+    const uint32_t n = min(*sink.count, sink.cap);
+    const int nr = cx.pm.paired ? 2 : 1;
+    const int lane = threadIdx.x;
+    const bool nw = cx.pm.use_nw != 0;
+    for (uint32_t slice = blockIdx.x * kDpGroup; slice < n; slice += gridDim.x * kDpGroup) {
+        const uint32_t slice_end = min(slice + (uint32_t)kDpGroup, n);
+        for (uint32_t jb0 = slice; jb0 < slice_end;) {
+            // ---- the sweeps, one problem after the other, all lanes on each; the group ends when the wave's stretch of scratch is full ----
+            uint32_t used = 0;
+            int g_n = 0;
+            for (; jb0 + g_n < slice_end; g_n++) {
+                const DpJob job = sink.jobs[jb0 + g_n];
+                const uint32_t need = (uint32_t)((job.rLen + job.gLen + 15) & ~15) + (uint32_t)(job.rLen + job.gLen - 1) * (uint32_t)job.gLen;
+                if (g_n > 0 && used + need > scratch_stride) break; // (a stretch holds the largest problem of its class)
+                const uint32_t read = sel_pair(sel, job.pair) * nr + job.slot;
+                ReadRef rd;
+                rd.ascii = rb.bases + rb.off[read]; rd.rlen = (int)(rb.off[read + 1] - rb.off[read]); rd.flipped = (cx.pm.paired && job.slot == 1) ? 1 : 0;
+                uint8_t *gq = mine + used, *gt = gq + job.rLen, *gdir = gq + ((job.rLen + job.gLen + 15) & ~15);
+                DpBuf b;
+                const bool in_lds = job.rLen <= DpLds<K>::seq / 2 && job.gLen <= DpLds<K>::seq / 2;
+                b.q = in_lds ? lds : gq; b.t = in_lds ? lds + DpLds<K>::seq / 2 : gt; b.dir = gdir;
+                for (int i = lane; i < job.rLen; i += 64) { const uint8_t c = (uint8_t)read_code(rd, job.rev ? job.rPos + job.rLen - 1 - i : job.rPos + i); b.q[i] = c; if (in_lds) gq[i] = c; }
+                for (int i = lane; i < job.gLen; i += 64) { const uint8_t c = (uint8_t)ref_code(cx.ix, job.rev ? job.gPos + job.gLen - 1 - i : job.gPos + i); b.t[i] = c; if (in_lds) gt[i] = c; }
+                __syncthreads();
+                int score = 0;
+                dp_sweep<K, 64>(nw, job.rLen, job.gLen, b, &score);
+                if (lane == 0) { slot[g_n].off = used; slot[g_n].score = score; }
+                used += need;
+                __syncthreads();
+            }
+            __threadfence_block();
+            __syncthreads();
+            // ---- the walks, one problem per lane ----
+            if (lane < g_n) {
+                const uint32_t jb = jb0 + (uint32_t)lane;
+                const DpJob job = sink.jobs[jb];
+                const uint8_t *gq = mine + slot[lane].off, *gt = gq + job.rLen, *gdir = gq + ((job.rLen + job.gLen + 15) & ~15);
+                PairState st = pair_state(cx.state, cx.lay, cx.caps, job.pair);
+                DpSummary *sum = cx.dp_summary ? (DpSummary *)(st.ops + job.ops_off - kDpSum) : nullptr;
+                const int w = dp_trace(nw, job.rLen, job.gLen, gq, gt, gdir, st.ops + job.ops_off, sum, (uint32_t)job.ops_off);
+                Frag f = st.frags[job.frag];
+                f.ops_off = job.ops_off + w;
+                f.ops_len = job.rLen + job.gLen - w;
+                f.meta = sum ? (uint32_t)((job.ops_off - kDpSum) >> 3) + 1u : 0u;
+                st.frags[job.frag] = f;
+                sink.jobs[jb].score = slot[lane].score;
+            }
+            __syncthreads();
+            jb0 += (uint32_t)g_n;
+        }
+    }
+}
+
 // targets <= 32 (queries <= 64) of the one-column-per-lane class: two problems per wave, 32 lanes each — the
 // class is bound by vector instructions issued, and most of its targets are that short
 constexpr int kDpHalfT = 32, kDpHalfQ = 64, kDpHalfLds = kDpHalfQ + kDpHalfT + (kDpHalfQ + kDpHalfT - 1) * kDpHalfT + 32;
@@ -1584,7 +1650,7 @@ static int passres_alloc(mcx_ctx *c, PassRes &t, uint64_t pairs, uint64_t sel_ca
     t.rescue_cap = (uint32_t)pairs;
     if ((rc = dmalloc(&t.d_rescue, t.rescue_cap))) return rc;
     if ((rc = rescue_alloc(c, pairs, pairs >= 4096, &t.d_rtasks, &t.d_rres, &t.d_rseeds, &t.d_rplans, &t.d_rescue_n, &t.rtask_cap, &t.rseed_cap))) return rc;
-    const uint32_t blocks1[3] = {2048, 2048, 256};
+    const uint32_t blocks1[3] = {pairs >= 4096 ? 2048u : 256u, pairs >= 4096 ? 1024u : 128u, 256};
     for (int k = 0; k < 3; k++) {
         t.dp_stride[k] = c->dp_stride[k]; t.dp_blocks[k] = blocks1[k];
         if ((rc = dmalloc(&t.d_dp_scratch[k], (size_t)t.dp_stride[k] * t.dp_blocks[k]))) return rc;
@@ -1642,8 +1708,10 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     if ((rc = rescue_alloc(c, c->max_reads, false, &c->d_rtasks, &c->d_rres, &c->d_rseeds, &c->d_rplans, &c->d_rescue_n, &c->rtask_cap, &c->rseed_cap))) return rc;
     if ((rc = dmalloc(&c->d_kscratch, 3 * (size_t)kRescueBlocks * kRescueScratchWords))) return rc; // (one part per set of pass resources)
     // DP traceback spill per block: 4 KB of sequences + (qlen + tlen - 1) * tlen direction bytes
-    const uint64_t spill[3] = {kDpSpillSeq + (uint64_t)(2048 + 64) * 64, kDpSpillSeq + (uint64_t)(2048 + 256) * 256, kDpSpillSeq + (uint64_t)(2048 + 1024) * 1024};
-    const uint32_t blocks[3] = {8192, 4096, 512};
+    // (the two grouped classes: a wavefront's stretch holds the strings and traceback bytes of a group of problems — k_dp_group —,
+    //  at least those of the class's largest one)
+    const uint64_t spill[3] = {(uint64_t)1 << 20, (uint64_t)2 << 20, kDpSpillSeq + (uint64_t)(2048 + 1024) * 1024};
+    const uint32_t blocks[3] = {4096, 2048, 512};
     for (int k = 0; k < 3; k++) {
         c->dp_stride[k] = spill[k]; c->dp_blocks[k] = blocks[k];
         if ((rc = dmalloc(&c->d_dp_scratch[k], (size_t)spill[k] * blocks[k]))) return rc;
@@ -1774,9 +1842,12 @@ static int launch_dp(const PassRes &R, const Ctx &cx, const JobSinks &sinks, con
     const int n_side = wide ? 5 : 2;
     HIP_TRY(hipEventRecord(R.dp_fork, s));
     for (int k = 0; k < n_side; k++) HIP_TRY(hipStreamWaitEvent(R.dp_stream[k], R.dp_fork, 0));
-    k_dp_sel<1><<<R.dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, R.d_dp_scratch[0], R.dp_stride[0]);
+    const bool grouped = !getenv("MCX_DP_BY_WAVE"); // (experiments: a problem's traceback right behind its sweep, walked by one lane of the wave)
+    if (grouped) k_dp_group<1><<<R.dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, R.d_dp_scratch[0], R.dp_stride[0]);
+    else k_dp_sel<1><<<R.dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, R.d_dp_scratch[0], R.dp_stride[0]);
     k_dp_small<<<2560, 256, 0, R.dp_stream[0]>>>(cx, sinks.s[0], rb, sel);
-    k_dp_sel<4><<<R.dp_blocks[1], 64, 0, R.dp_stream[1]>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1]);
+    if (grouped) k_dp_group<4><<<R.dp_blocks[1], 64, 0, R.dp_stream[1]>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1]);
+    else k_dp_sel<4><<<R.dp_blocks[1], 64, 0, R.dp_stream[1]>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1]);
     k_dp_tiny<<<2048, 256, 0, wide ? R.dp_stream[3] : s>>>(cx, sinks.s[4], rb, sel);
     k_dp_half<<<2048, 256, 0, wide ? R.dp_stream[4] : R.dp_stream[1]>>>(cx, sinks.s[5], rb, sel);
     k_dp_sel<16><<<R.dp_blocks[2], 64, 0, wide ? R.dp_stream[2] : R.dp_stream[0]>>>(cx, sinks.s[3], rb, sel, R.d_dp_scratch[2], R.dp_stride[2]);
