@@ -1300,8 +1300,11 @@ __global__ void __launch_bounds__(64) k_dp_group(Ctx cx, JobSink sink, ReadBatch
     const int nr = cx.pm.paired ? 2 : 1;
     const int lane = threadIdx.x;
     const bool nw = cx.pm.use_nw != 0;
-    for (uint32_t slice = blockIdx.x * kDpGroup; slice < n; slice += gridDim.x * kDpGroup) {
-        const uint32_t slice_end = min(slice + (uint32_t)kDpGroup, n);
+    // (few problems: small groups, so that every wavefront of the launch gets some; many: whole groups of 64)
+    uint32_t group = (n + 2 * gridDim.x - 1) / (2 * gridDim.x);
+    group = group < 8 ? 8 : (group > (uint32_t)kDpGroup ? (uint32_t)kDpGroup : group);
+    for (uint32_t slice = blockIdx.x * group; slice < n; slice += gridDim.x * group) {
+        const uint32_t slice_end = min(slice + group, n);
         for (uint32_t jb0 = slice; jb0 < slice_end;) {
             // ---- the sweeps, one problem after the other, all lanes on each; the group ends when the wave's stretch of scratch is full ----
             uint32_t used = 0;
@@ -1650,7 +1653,7 @@ static int passres_alloc(mcx_ctx *c, PassRes &t, uint64_t pairs, uint64_t sel_ca
     t.rescue_cap = (uint32_t)pairs;
     if ((rc = dmalloc(&t.d_rescue, t.rescue_cap))) return rc;
     if ((rc = rescue_alloc(c, pairs, pairs >= 4096, &t.d_rtasks, &t.d_rres, &t.d_rseeds, &t.d_rplans, &t.d_rescue_n, &t.rtask_cap, &t.rseed_cap))) return rc;
-    const uint32_t blocks1[3] = {pairs >= 4096 ? 2048u : 256u, pairs >= 4096 ? 1024u : 128u, 256};
+    const uint32_t blocks1[3] = {pairs >= 4096 ? 2048u : 256u, pairs >= 4096 ? 2048u : 128u, 256};
     for (int k = 0; k < 3; k++) {
         t.dp_stride[k] = c->dp_stride[k]; t.dp_blocks[k] = blocks1[k];
         if ((rc = dmalloc(&t.d_dp_scratch[k], (size_t)t.dp_stride[k] * t.dp_blocks[k]))) return rc;
@@ -1710,8 +1713,8 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     // DP traceback spill per block: 4 KB of sequences + (qlen + tlen - 1) * tlen direction bytes
     // (the two grouped classes: a wavefront's stretch holds the strings and traceback bytes of a group of problems — k_dp_group —,
     //  at least those of the class's largest one)
-    const uint64_t spill[3] = {(uint64_t)1 << 20, (uint64_t)2 << 20, kDpSpillSeq + (uint64_t)(2048 + 1024) * 1024};
-    const uint32_t blocks[3] = {4096, 2048, 512};
+    const uint64_t spill[3] = {(uint64_t)512 << 10, (uint64_t)1 << 20, kDpSpillSeq + (uint64_t)(2048 + 1024) * 1024};
+    const uint32_t blocks[3] = {8192, 4096, 512};
     for (int k = 0; k < 3; k++) {
         c->dp_stride[k] = spill[k]; c->dp_blocks[k] = blocks[k];
         if ((rc = dmalloc(&c->d_dp_scratch[k], (size_t)spill[k] * blocks[k]))) return rc;
