@@ -206,7 +206,11 @@ void mcx_exchange_local_free(mcx_exchange *first);
  * (src/ReadMapping.cpp:486-521).  d_planes: caller-owned, zero-initialised device array of
  * 10 * GenomeSize u32 laid out [plane][position], planes A C G T multi_hit readCount F1 R2 F2 R1 —
  * MappingRecord_t (src/structure.h:152-163) unpacked, so that several GPUs can sum their arrays
- * with one all-reduce.  Once attached, every mcx_map_batch* call adds its reads.
+ * with one all-reduce.  Once attached, every mcx_map_batch* call adds its reads.  While a run is
+ * being mapped the strand and multi_hit planes (and a context-owned plane for exact-seed coverage)
+ * hold DIFFERENCES (+1 where a read starts to cover, -1 behind its end): mcx_profile_settle turns
+ * them into counts, once, after the run's last batch and BEFORE the planes are read or summed
+ * across GPUs; after it the context takes no more reads until the profile is attached again.
  * mcx_profile_finalize applies the reference's field widths (12-bit saturation at 4095, 16-bit
  * wrap, duplicate cap) in place; call it once, after the last batch (and after the reduce).
  * mcx_profile_sparse returns the insert / delete / break-point tallies ('I','D','B': one record
@@ -220,6 +224,7 @@ typedef struct mcx_sparse_rec {
     char seq[54];  /* records that directly follow ('C': len = bytes held).  Keep a list's records in order.      */
 } mcx_sparse_rec;
 int mcx_profile_attach(mcx_ctx *, uint32_t *d_planes, int max_dup, int max_clip);
+int mcx_profile_settle(mcx_ctx *);                       /* idempotent; implied by mcx_profile_finalize on the attached planes */
 int mcx_profile_finalize(mcx_ctx *, uint32_t *d_planes);
 int mcx_profile_sparse(mcx_ctx *, const mcx_sparse_rec **recs, uint64_t *n);
 /* For a run spread over several shards: the same tallies, but the discordant-pair events as they

@@ -62,7 +62,7 @@ SYMBOLS = [
     "mcx_index_genome_size", "mcx_index_n_chr", "mcx_index_chr_name", "mcx_index_chr_len", "mcx_index_hbm_bytes",
     "mcx_opts_default", "mcx_ctx_create", "mcx_ctx_free", "mcx_bwt_search_batch", "mcx_extend_batch",
     "mcx_avg_init", "mcx_map_batch_dev", "mcx_map_batch", "mcx_cigar_words", "mcx_map_files", "mcx_map_files_ex", "mcx_file_opts_default",
-    "mcx_profile_attach", "mcx_profile_finalize", "mcx_profile_sparse", "mcx_planes_alloc", "mcx_planes_free",
+    "mcx_profile_attach", "mcx_profile_settle", "mcx_profile_finalize", "mcx_profile_sparse", "mcx_planes_alloc", "mcx_planes_free",
     "mcx_vcf_defaults", "mcx_call_variants",
     "mcx_batch_begin", "mcx_batch_sums", "mcx_batch_replay", "mcx_batch_end", "mcx_avg_walk", "mcx_exchange_local", "mcx_exchange_local_free",
     "mcx_profile_sparse_shard", "mcx_batch_end_keys", "mcx_batch_accumulate",
@@ -219,6 +219,7 @@ def lib() -> C.CDLL:
     L.mcx_file_opts_default.argtypes = [C.POINTER(FileOpts)]
     L.mcx_file_opts_default.restype = None
     L.mcx_profile_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.mcx_profile_settle.argtypes = [C.c_void_p]
     L.mcx_profile_finalize.argtypes = [C.c_void_p, C.c_void_p]
     L.mcx_profile_sparse.argtypes = [C.c_void_p, C.POINTER(C.POINTER(SparseRec)), C.POINTER(C.c_uint64)]
     L.mcx_profile_sparse_shard.argtypes = [C.c_void_p, C.POINTER(C.POINTER(SparseRec)), C.POINTER(C.c_uint64)]
@@ -493,6 +494,11 @@ class Mapper:
         """d_planes: zeroed device array uint32 [10, GenomeSize] (PLANES order), caller-owned so
         that it can be all-reduced across GPUs; every later map_batch* call accumulates into it."""
         _check(lib().mcx_profile_attach(self._h, d_planes_ptr, max_dup, max_clip), "mcx_profile_attach")
+
+    def profile_settle(self) -> None:
+        """The planes kept as differences while the run is mapped become counts: once, after the last
+        batch and before the planes are read or reduced over the ranks (implied by profile_finalize)."""
+        _check(lib().mcx_profile_settle(self._h), "mcx_profile_settle")
 
     def profile_finalize(self, d_planes_ptr: int) -> None:
         _check(lib().mcx_profile_finalize(self._h, d_planes_ptr), "mcx_profile_finalize")

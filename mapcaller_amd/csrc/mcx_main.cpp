@@ -226,6 +226,7 @@ int main(int argc, char **argv)
                 if (stop) { if (!sh.rc) { sh.rc = MCX_ERR_DEVICE; sh.err = "another shard failed"; } break; }
             }
         }
+        if (want_vcf && sh.rc == 0 && (rc = mcx_profile_settle(sh.cx))) bad(rc); // differences -> counts, before anything sums or reads the planes
         if (n_gpus > 1 && want_vcf) { // the one collective of the run; every shard takes part even after a failure elsewhere
             bool all_ok = true;
             int32_t mine = sh.rc;

@@ -1497,7 +1497,7 @@ struct PassRes {
 struct BatchRun { // the batch between mcx_batch_begin and mcx_batch_end
     bool open = false, sums_valid = false, keys_out = false;
     ReadBatch rb; int paired = 0;
-    uint32_t n_pairs = 0, n_chunks = 0;
+    uint32_t n_pairs = 0, n_chunks = 0, longest = 0; // (longest read of the batch)
     AlnRec *recs = nullptr; uint32_t *cig = nullptr; // records [n_reads]; the batch's CIGAR pool
     uint32_t cig_cap = 0, cig_words = 0;             // its capacity (MCX_CIGAR_POOL_WORDS(n_reads)) and, once the batch is closed, the words taken
     int64_t read_base = 0, mapped = 0;
@@ -1536,10 +1536,14 @@ struct mcx_ctx {
     uint8_t *d_mapq = nullptr; int mapq_rows = 0;
     // -vcf bookkeeping (mcx_profile.h): caller-owned counter planes, per-read alignment detail
     uint32_t *prof_planes = nullptr; int prof_max_dup = 5, prof_max_clip = 5;
+    ColItem *d_prof_items = nullptr; uint32_t prof_items_cap = 0; // fragments whose columns k_prof_cols walks
+    uint32_t *d_prof_match = nullptr; bool prof_settled = false; // exact-seed coverage as differences (mcx_profile.h); freed by mcx_profile_settle
     uint8_t *d_detail = nullptr; DetailLayout dlay;
     uint64_t *d_keys[2] = {nullptr, nullptr}; uint8_t *d_admit = nullptr; void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     SparseRec *d_sparse = nullptr; uint32_t sparse_cap = 0;
-    SparseRec *d_arch = nullptr; uint64_t arch_n = 0, arch_cap = 0, arch_limit = (uint64_t)1 << 28; // the records of the batches so far, still in HBM (at most 16 GB)
+    struct Archive { SparseRec *d = nullptr; uint64_t n = 0, cap = 0; std::vector<mcx_sparse_rec> *host = nullptr; };
+    Archive arch, arch_ev;                      // the tally records / discordant-pair events of the batches so far, still in HBM
+    uint64_t arch_limit = (uint64_t)1 << 28;    // (at most 16 GB)
     SparseRec *h_sparse_pin = nullptr; uint32_t sparse_pin_recs = 1u << 18; // page-locked bounce buffer for their way to the host (16 MB)
     std::vector<mcx_sparse_rec> h_sparse, h_events, h_resolved; // tallies; discordant-pair events ('E'); what mcx_profile_sparse* last returned
     uint64_t keys_cap = 0;       // keys the sort buffers hold
@@ -1777,12 +1781,13 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3], c->d_jobs[4], c->d_jobs[5],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_rtasks, c->d_rres, c->d_rseeds, c->d_rplans, c->d_rescue_n, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
                  c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
-                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_pout_sel, c->d_order, c->d_order_cnt, c->d_packed, c->d_batch_flags, c->d_scan_tmp};
+                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_pout_sel, c->d_order, c->d_order_cnt, c->d_packed, c->d_batch_flags, c->d_scan_tmp, c->d_prof_match, c->d_prof_items};
     for (void *q : p) if (q) (void)hipFree(q);
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
     if (c->h_keys) (void)hipHostFree(c->h_keys);
     if (c->h_sparse_pin) (void)hipHostFree(c->h_sparse_pin);
-    if (c->d_arch) (void)hipFree(c->d_arch);
+    if (c->arch.d) (void)hipFree(c->arch.d);
+    if (c->arch_ev.d) (void)hipFree(c->arch_ev.d);
     passres_free(c->t1); passres_free(c->t2);
     for (hipEvent_t e : {c->ev_clustered, c->ev_built, c->ev_late_done}) if (e) (void)hipEventDestroy(e);
     for (auto &sl : c->slot) {
@@ -2289,6 +2294,7 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
     { // the batch in 2-bit form, once; every seeding pass (tiers, replay) reads it
         HIP_TRY(hipEventRecord(c->ev_pack[0], s));
         const int tpr = ((int)c->h_cnt[1] + 31) / 32 + 1; // (threads per read: for the batch's longest read, found above)
+        br.longest = c->h_cnt[1];
         const uint64_t threads = (uint64_t)n_reads * (uint64_t)tpr;
         k_pack_reads<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(br.rb, paired, c->wpad, tpr, c->d_packed);
         HIP_TRY(hipGetLastError());
@@ -2399,7 +2405,14 @@ extern "C" int mcx_batch_end(mcx_ctx *c, mcx_stats *stats)
     HIP_TRY(hipSetDevice(c->idx->device));
     int rc = batch_close(c, stats);
     if (rc == 0 && c->prof_planes) { // one shard: the batch's own keys decide the duplicate cap
-        if ((rc = profile_keys(c)) == 0) rc = profile_accumulate(c, nullptr, 0, 0, 0);
+        const auto t0 = std::chrono::steady_clock::now();
+        rc = profile_keys(c);
+        const auto t1 = std::chrono::steady_clock::now();
+        if (rc == 0) rc = profile_accumulate(c, nullptr, 0, 0, 0);
+        if (getenv("MCX_TIMING")) {
+            auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            fprintf(stderr, "[mcx profile] mapping %.2f ms, keys %.2f ms, accumulate %.2f ms\n", ms(c->run.t0, t0), ms(t0, t1), ms(t1, std::chrono::steady_clock::now()));
+        }
     }
     c->run.open = false;
     if (rc == 0 && stats) stats->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c->run.t0).count();
@@ -2730,16 +2743,25 @@ extern "C" int mcx_stream_collect(mcx_ctx *c, uint64_t *bytes_in, uint64_t *byte
 // ---------------------------------------------------------------------------------------------
 // -vcf bookkeeping: UpdateProfile / UpdateMultiHitCount for a finished batch (mcx_profile.h)
 // ---------------------------------------------------------------------------------------------
-struct DiscEv { uint32_t pair; int32_t kind; int64_t g1, g2, dist; };
-
-__global__ void k_prof_disc(const uint8_t *detail, DetailLayout dl, uint32_t n_pairs, DiscEv *out, uint32_t *n, uint32_t cap)
+// discordant-pair events, ReadMapping.cpp:486-521: kept as seen ('E' records: pos = the pair's number in the input stream,
+// len = kind, seq = g1, g2, dist) — the reference's second branch pushes its DiscordPair variable whatever the previous
+// discordant pair left in it, so they are resolved in input order once the run is over
+// (mcx_disc_resolve: mcx_profile_sparse for one shard, mcx_call_variants for several)
+__global__ void k_prof_disc(const uint8_t *detail, DetailLayout dl, uint32_t n_pairs, int64_t first_pair, SparseRec *out, uint32_t *n, uint32_t cap)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
     const DetailHdr &d = *(const DetailHdr *)(detail + (uint64_t)(2 * p) * dl.stride);
     if (d.disc_kind == 0) return;
     const uint32_t at = atomicAdd(n, 1u);
-    if (at < cap) { DiscEv e; e.pair = p; e.kind = d.disc_kind; e.g1 = d.disc_g1; e.g2 = d.disc_g2; e.dist = d.disc_dist; out[at] = e; }
+    if (at >= cap) return;
+    SparseRec e;
+    uint64_t *w = (uint64_t *)&e;
+    for (int k = 0; k < (int)(sizeof(SparseRec) / 8); k++) w[k] = 0;
+    e.pos = first_pair + p; e.type = 'E'; e.len = (uint8_t)d.disc_kind;
+    const int64_t v[3] = {d.disc_g1, d.disc_g2, d.disc_dist};
+    memcpy(e.seq, v, sizeof v);
+    out[at] = e;
 }
 
 extern "C" int mcx_profile_attach(mcx_ctx *c, uint32_t *d_planes, int max_dup, int max_clip)
@@ -2755,13 +2777,23 @@ extern "C" int mcx_profile_attach(mcx_ctx *c, uint32_t *d_planes, int max_dup, i
         c->dlay = make_detail_layout(c->rlen_max);
         int rc;
         if ((rc = dmalloc(&c->d_detail, (size_t)c->dlay.stride * c->max_reads))) return rc;
-        if ((rc = dmalloc(&c->d_admit, c->max_reads))) return rc;
+        if ((rc = dmalloc(&c->d_admit, c->max_reads + 4))) return rc;
+        c->prof_items_cap = (uint32_t)std::min<uint64_t>((uint64_t)c->max_reads * 4 + 1024, 0x7fffffffu);
+        if ((rc = dmalloc(&c->d_prof_items, c->prof_items_cap))) return rc;
         if ((rc = sort_reserve(c, c->max_reads))) return rc;
         c->sparse_cap = (uint32_t)std::min<uint64_t>(c->max_reads * 2 + 4096, 0x7fffffffu);
         if ((rc = dmalloc(&c->d_sparse, c->sparse_cap))) return rc;
         HIP_TRY(hipHostMalloc((void **)&c->h_sparse_pin, (size_t)c->sparse_pin_recs * sizeof(SparseRec)));
     }
-    c->h_sparse.clear(); c->h_events.clear(); c->h_resolved.clear(); c->arch_n = 0;
+    c->h_sparse.clear(); c->h_events.clear(); c->h_resolved.clear(); c->arch.n = c->arch_ev.n = 0;
+    c->arch.host = &c->h_sparse; c->arch_ev.host = &c->h_events;
+    if (!c->arch.d) { // room for the first batches' records now, not in the middle of the first batch
+        const uint64_t first = std::min<uint64_t>(std::max<uint64_t>(c->sparse_cap, (uint64_t)1 << 20), (uint64_t)1 << 22);
+        if (hipMalloc((void **)&c->arch.d, first * sizeof(SparseRec)) == hipSuccess) c->arch.cap = first; else { (void)hipGetLastError(); c->arch.d = nullptr; }
+    }
+    if (!c->d_prof_match) { int rc = dmalloc(&c->d_prof_match, (size_t)c->idx->view.G); if (rc) return rc; }
+    HIP_TRY(hipMemsetAsync(c->d_prof_match, 0, (size_t)c->idx->view.G * sizeof(uint32_t), c->stream));
+    c->prof_settled = false;
     return 0;
 }
 
@@ -2787,7 +2819,7 @@ static int profile_keys(mcx_ctx *c)
     BatchRun &br = c->run;
     hipStream_t s = c->stream;
     const IndexView &ix = c->idx->view;
-    ProfView pv; pv.plane = c->prof_planes; pv.G = ix.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
+    ProfView pv; pv.plane = c->prof_planes; pv.match = c->d_prof_match; pv.G = ix.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
     SparseSink sink; sink.recs = c->d_sparse; sink.n = c->d_cnt + CNT_TASKS; sink.cap = c->sparse_cap; sink.refused = c->d_cnt + CNT_UNSUP;
     const uint32_t n = br.rb.n_reads;
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
@@ -2808,7 +2840,7 @@ static int profile_foreign(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all)
 {
     if (n_all == 0) return 0;
     hipStream_t s = c->stream;
-    ProfView pv; pv.plane = c->prof_planes; pv.G = c->idx->view.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
+    ProfView pv; pv.plane = c->prof_planes; pv.match = c->d_prof_match; pv.G = c->idx->view.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
     int rc = sort_reserve(c, n_all);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_keys[0], h_all, n_all * sizeof(uint64_t), hipMemcpyHostToDevice, s));
@@ -2821,38 +2853,76 @@ static int profile_foreign(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all)
     return 0;
 }
 
-// the archived tally records leave HBM: through the two halves of a page-locked bounce buffer (a copy from HBM straight into
+// the archived records leave HBM: through the two halves of a page-locked bounce buffer (a copy from HBM straight into
 // pageable memory runs at ~1 GB/s), the next piece in flight while this one is copied out
-static int sparse_flush(mcx_ctx *c)
+static int archive_flush(mcx_ctx *c, mcx_ctx::Archive &a)
 {
-    if (c->arch_n == 0) return 0;
+    if (a.n == 0) return 0;
     hipStream_t s = c->stream;
-    const size_t at = c->h_sparse.size();
-    c->h_sparse.resize(at + c->arch_n);
+    std::vector<mcx_sparse_rec> &host = *a.host;
+    const size_t at = host.size();
+    host.resize(at + a.n);
     const uint64_t half = c->sparse_pin_recs / 2;
-    const uint64_t n_piece = (c->arch_n + half - 1) / half;
+    const uint64_t n_piece = (a.n + half - 1) / half;
     auto start = [&](uint64_t k) -> hipError_t {
-        const uint64_t lo = k * half, m = std::min<uint64_t>(half, c->arch_n - lo);
-        return hipMemcpyAsync(c->h_sparse_pin + (k & 1) * half, c->d_arch + lo, m * sizeof(SparseRec), hipMemcpyDeviceToHost, s);
+        const uint64_t lo = k * half, m = std::min<uint64_t>(half, a.n - lo);
+        return hipMemcpyAsync(c->h_sparse_pin + (k & 1) * half, a.d + lo, m * sizeof(SparseRec), hipMemcpyDeviceToHost, s);
     };
     HIP_TRY(start(0));
     for (uint64_t k = 0; k < n_piece; k++) {
         HIP_TRY(hipStreamSynchronize(s));
         if (k + 1 < n_piece) HIP_TRY(start(k + 1));
-        const uint64_t lo = k * half, m = std::min<uint64_t>(half, c->arch_n - lo);
-        memcpy((void *)(c->h_sparse.data() + at + lo), c->h_sparse_pin + (k & 1) * half, m * sizeof(SparseRec));
+        const uint64_t lo = k * half, m = std::min<uint64_t>(half, a.n - lo);
+        memcpy((void *)(host.data() + at + lo), c->h_sparse_pin + (k & 1) * half, m * sizeof(SparseRec));
     }
-    c->arch_n = 0;
+    a.n = 0;
+    return 0;
+}
+
+static int sparse_flush(mcx_ctx *c)
+{
+    if (int rc = archive_flush(c, c->arch)) return rc;
+    return archive_flush(c, c->arch_ev);
+}
+
+// n records at d_src join an archive (on the stream); an archive that cannot grow any more goes to the host first
+static int archive_append(mcx_ctx *c, mcx_ctx::Archive &a, const SparseRec *d_src, uint64_t n)
+{
+    if (n == 0) return 0;
+    hipStream_t s = c->stream;
+    if (a.n + n > a.cap) {
+        const uint64_t want = std::max<uint64_t>({2 * a.cap, a.n + n, &a == &c->arch ? (uint64_t)1 << 22 : (uint64_t)1 << 18});
+        SparseRec *grown = nullptr;
+        if (want <= c->arch_limit && hipMalloc((void **)&grown, want * sizeof(SparseRec)) == hipSuccess) {
+            if (a.n) HIP_TRY(hipMemcpyAsync(grown, a.d, a.n * sizeof(SparseRec), hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (a.d) (void)hipFree(a.d);
+            a.d = grown; a.cap = want;
+        } else {
+            (void)hipGetLastError();
+            int rc = archive_flush(c, a); // no room for a larger archive: what it holds goes to the host now
+            if (rc) return rc;
+            if (n > a.cap) {
+                if (a.d) (void)hipFree(a.d);
+                a.d = nullptr; a.cap = 0;
+                HIP_TRY(hipMalloc((void **)&a.d, (size_t)n * sizeof(SparseRec)));
+                a.cap = n;
+            }
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(a.d + a.n, d_src, (size_t)n * sizeof(SparseRec), hipMemcpyDeviceToDevice, s));
+    a.n += n;
     return 0;
 }
 
 // admission over `all` keys (null: the batch's own, already sorted on the device), then the accumulation of the own reads
 static int profile_accumulate(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all, uint32_t slot_stride, uint32_t own_slot)
 {
+    if (c->prof_settled) return fail(MCX_ERR_ARG, "the profile has been settled (mcx_profile_settle / _sparse / _finalize): attach it again before mapping more reads");
     BatchRun &br = c->run;
     hipStream_t s = c->stream;
     const IndexView &ix = c->idx->view;
-    ProfView pv; pv.plane = c->prof_planes; pv.G = ix.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
+    ProfView pv; pv.plane = c->prof_planes; pv.match = c->d_prof_match; pv.G = ix.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
     SparseSink sink; sink.recs = c->d_sparse; sink.n = c->d_cnt + CNT_TASKS; sink.cap = c->sparse_cap; sink.refused = c->d_cnt + CNT_UNSUP;
     const uint32_t n = br.rb.n_reads;
     const int paired = br.paired;
@@ -2870,60 +2940,67 @@ static int profile_accumulate(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all,
     }
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
     HIP_TRY(hipMemcpyAsync(c->d_cnt + CNT_TASKS, &br.n_sparse_keys, sizeof(uint32_t), hipMemcpyHostToDevice, s)); // (pageable source: copied before the call returns)
-    HIP_TRY(hipMemsetAsync(c->d_admit, 0, n, s));
+    HIP_TRY(hipMemsetAsync(c->d_admit, 0, (n + 3) & ~3u, s));
+    {
+        const int tpr = (std::max<int>((int)(br.longest ? br.longest : (uint32_t)c->rlen_max), 1) + 15) / 16;
+        const uint64_t threads = (uint64_t)n * tpr;
+        k_prof_odd<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(br.rb, tpr, c->d_admit);
+    }
     if (nk) {
         k_prof_admit<<<(unsigned)((nk + 255) / 256), 256, 0, s>>>(d_keys, nk, pv, c->d_admit, own_lo, n);
         k_prof_count<<<(unsigned)((nk + 255) / 256), 256, 0, s>>>(d_keys, nk, pv);
     }
-    k_prof_accum<<<4096, 256, 0, s>>>(c->d_detail, c->dlay, br.rb, ix, pv, sink, c->d_admit, paired);
-    DiscEv *d_ev = (DiscEv *)c->d_tasks; // the SA task list is idle now
-    const uint32_t ev_cap = (uint32_t)std::min<uint64_t>((uint64_t)c->task_cap * sizeof(uint2) / sizeof(DiscEv), 0x7fffffffu);
-    if (paired) k_prof_disc<<<(n / 2 + 255) / 256, 256, 0, s>>>(c->d_detail, c->dlay, n / 2, d_ev, c->d_cnt + CNT_RESCUE, ev_cap);
+    ColList cols; cols.items = c->d_prof_items; cols.n = c->d_cnt + CNT_RTASK; cols.cap = c->prof_items_cap;
+    k_prof_accum<<<(n + 255) / 256, 256, 0, s>>>(c->d_detail, c->dlay, br.rb, ix, pv, sink, c->d_admit, paired, cols);
+    k_prof_cols<<<4096, 256, 0, s>>>(c->d_detail, c->dlay, br.rb, ix, pv, sink, cols);
+    SparseRec *d_ev = (SparseRec *)c->d_tasks; // the SA task list is idle now
+    const uint32_t ev_cap = (uint32_t)std::min<uint64_t>((uint64_t)c->task_cap * sizeof(uint2) / sizeof(SparseRec), 0x7fffffffu);
+    if (paired) k_prof_disc<<<(n / 2 + 255) / 256, 256, 0, s>>>(c->d_detail, c->dlay, n / 2, br.read_base / 2, d_ev, c->d_cnt + CNT_RESCUE, ev_cap);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const uint32_t n_sp = c->h_cnt[CNT_TASKS], n_ev = c->h_cnt[CNT_RESCUE];
     if (n_sp > c->sparse_cap || n_ev > ev_cap) return fail(MCX_ERR_CAPACITY, "profile: sparse record list overflow");
     if (c->h_cnt[CNT_UNSUP]) return fail(MCX_ERR_UNSUPPORTED, "an insertion or deletion of more than 255 bases in an alignment: its string does not fit a tally record");
-    // the records stay in HBM until somebody asks for them (mcx_profile_sparse*): appended to the archive on the stream
-    if (n_sp) {
-        if (c->arch_n + n_sp > c->arch_cap) {
-            const uint64_t want = std::max<uint64_t>({2 * c->arch_cap, c->arch_n + n_sp, (uint64_t)1 << 20});
-            SparseRec *grown = nullptr;
-            if (want <= c->arch_limit && hipMalloc((void **)&grown, want * sizeof(SparseRec)) == hipSuccess) {
-                if (c->arch_n) HIP_TRY(hipMemcpyAsync(grown, c->d_arch, c->arch_n * sizeof(SparseRec), hipMemcpyDeviceToDevice, s));
-                HIP_TRY(hipStreamSynchronize(s));
-                if (c->d_arch) (void)hipFree(c->d_arch);
-                c->d_arch = grown; c->arch_cap = want;
-            } else {
-                (void)hipGetLastError();
-                int rc = sparse_flush(c); // no room for a larger archive: what it holds goes to the host now
-                if (rc) return rc;
-                if (n_sp > c->arch_cap) {
-                    if (c->d_arch) (void)hipFree(c->d_arch);
-                    c->d_arch = nullptr; c->arch_cap = 0;
-                    HIP_TRY(hipMalloc((void **)&c->d_arch, (size_t)n_sp * sizeof(SparseRec)));
-                    c->arch_cap = n_sp;
-                }
-            }
-        }
-        HIP_TRY(hipMemcpyAsync(c->d_arch + c->arch_n, c->d_sparse, (size_t)n_sp * sizeof(SparseRec), hipMemcpyDeviceToDevice, s));
-        c->arch_n += n_sp;
+    // the records stay in HBM until somebody asks for them (mcx_profile_sparse*)
+    const auto t_app = std::chrono::steady_clock::now();
+    if (int rc = archive_append(c, c->arch, c->d_sparse, n_sp)) return rc;
+    const int rc_ev = archive_append(c, c->arch_ev, d_ev, n_ev);
+    if (getenv("MCX_TIMING")) fprintf(stderr, "[mcx profile] %u tally records, %u events, %u listed fragments; archives %.2f ms\n", n_sp, n_ev, c->h_cnt[CNT_RTASK],
+                                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_app).count());
+    return rc_ev;
+}
+
+// the planes kept as differences become counts (mcx_profile.h): once per run, after its last batch
+extern "C" int mcx_profile_settle(mcx_ctx *c)
+{
+    if (!c) return fail(MCX_ERR_ARG, "mcx_profile_settle: null argument");
+    if (!c->prof_planes || c->prof_settled) return 0;
+    HIP_TRY(hipSetDevice(c->idx->device));
+    hipStream_t s = c->stream;
+    const IndexView &ix = c->idx->view;
+    const size_t G = (size_t)ix.G;
+    size_t tb = 0;
+    HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tb, c->d_prof_match, c->d_prof_match, G, s));
+    void *tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, tb + 256));
+    hipError_t e = hipSuccess;
+    const int diffs[5] = {kPlMulti, kPlF1, kPlR2, kPlF2, kPlR1};
+    for (int k = 0; k < 5 && e == hipSuccess; k++) {
+        uint32_t *p = c->prof_planes + (size_t)diffs[k] * G;
+        e = hipcub::DeviceScan::InclusiveSum(tmp, tb, p, p, G, s);
     }
-    if (n_ev) {
-        // discordant-pair events, ReadMapping.cpp:486-521: kept as seen, with the pair's number in the input
-        // stream — the reference's second branch pushes its DiscordPair variable whatever the previous
-        // discordant pair left in it, so they are resolved in input order once the run is over
-        // (mcx_disc_resolve: mcx_profile_sparse for one shard, mcx_call_variants for several)
-        std::vector<DiscEv> ev(n_ev);
-        HIP_TRY(hipMemcpy(ev.data(), d_ev, (size_t)n_ev * sizeof(DiscEv), hipMemcpyDeviceToHost));
-        for (const DiscEv &e : ev) {
-            mcx_sparse_rec r; memset(&r, 0, sizeof r);
-            r.pos = br.read_base / 2 + (int64_t)e.pair; r.type = 'E'; r.len = (uint8_t)e.kind;
-            memcpy(r.seq, &e.g1, 8); memcpy(r.seq + 8, &e.g2, 8); memcpy(r.seq + 16, &e.dist, 8);
-            c->h_events.push_back(r);
-        }
+    if (e == hipSuccess) e = hipcub::DeviceScan::InclusiveSum(tmp, tb, c->d_prof_match, c->d_prof_match, G, s);
+    if (e == hipSuccess) {
+        ProfView pv; pv.plane = c->prof_planes; pv.match = c->d_prof_match; pv.G = ix.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
+        k_prof_fold<<<8192, 256, 0, s>>>(ix, pv);
+        e = hipGetLastError();
     }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+    HIP_TRY(e);
+    (void)hipFree(c->d_prof_match); c->d_prof_match = nullptr; // (12 GB at 3.1 Gbp: the variant caller's scans want the room)
+    c->prof_settled = true;
     return 0;
 }
 
@@ -2931,6 +3008,7 @@ extern "C" int mcx_profile_finalize(mcx_ctx *c, uint32_t *d_planes)
 {
     if (!c || !d_planes) return fail(MCX_ERR_ARG, "mcx_profile_finalize: null argument");
     HIP_TRY(hipSetDevice(c->idx->device));
+    if (d_planes == c->prof_planes) { if (int rc = mcx_profile_settle(c)) return rc; }
     k_prof_finalize<<<dim3(4096, kPlanes), 256, 0, c->stream>>>(d_planes, c->idx->view.G, c->prof_max_dup);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -7,8 +7,16 @@
 // Here the per-position counters are ten u32 planes [k][G] (A C G T multi_hit readCount F1 R2 F2 R1)
 // in caller-owned HBM, so that a multi-GPU run can sum them with one RCCL all-reduce; the field
 // widths of the reference (12-bit saturation at 4095, 16-bit wrap, duplicate cap) are applied
-// afterwards by k_prof_finalize.  One wavefront accumulates one read: lanes are consecutive
-// alignment columns, so each atomic instruction covers a contiguous run of a plane.  The only
+// afterwards by k_prof_finalize.  One lane accumulates one read (k_prof_accum).
+//
+// Most of what a read adds is a run of +1 over consecutive positions: its strand plane over the
+// whole read, the multi-hit plane over a candidate's span, and the base planes under an exact seed
+// (where the read's base IS the reference's).  Those runs are written as differences — +1 at the
+// first position, -1 behind the last — into the strand / multi planes themselves and into one more
+// plane for "read base equals reference base" (ProfView::match, owned by the context), and
+// mcx_profile_settle turns the differences into counts once, when the run's batches are all in:
+// an inclusive scan per plane (u32 wrap-around makes the -1 exact), then match[p] is added to the
+// plane of the reference's base at p.  Two atomics per run instead of one per position.  The only
 // order-dependent rule — at most iMaxDuplicate uniquely mapped reads are admitted per start
 // position, in input order (AlignmentProfile.cpp:76-77) — is decided before accumulation by
 // sorting (start, read index) keys.  Insert / delete strings and break points are sparse
@@ -24,7 +32,8 @@ namespace mcx {
 enum { kPlA = 0, kPlC, kPlG, kPlT, kPlMulti, kPlReadCount, kPlF1, kPlR2, kPlF2, kPlR1, kPlanes };
 
 struct ProfView {
-    uint32_t *plane;  // [kPlanes][G]
+    uint32_t *plane;  // [kPlanes][G]; kPlMulti and the strand planes hold differences until mcx_profile_settle
+    uint32_t *match;  // [G] differences of "read base == reference base" coverage
     int64_t G;
     int32_t max_dup, max_clip;
 };
@@ -35,6 +44,36 @@ static __device__ __forceinline__ void sparse_put(const SparseSink &s, const Spa
 {
     const uint32_t at = atomicAdd(s.n, 1u);
     if (at < s.cap) s.recs[at] = r;
+}
+
+// A million tally records a batch, every one a fetch-and-add on the list's one counter, is a queue at one L2 channel: a
+// wavefront collects its records in LDS and takes their places in the list with one atomic (wave_sparse_flush, called where
+// the wavefront's lanes are together again).  A record that finds the LDS buffer full goes to the list directly.
+struct WaveSparse { SparseRec *buf; uint32_t *cnt; uint32_t cap; };
+
+static __device__ __forceinline__ void wave_sparse_put(const WaveSparse &w, const SparseSink &s, const SparseRec &r)
+{
+    const uint32_t at = atomicAdd(w.cnt, 1u);
+    if (at < w.cap) w.buf[at] = r;
+    else sparse_put(s, r);
+}
+
+static __device__ __forceinline__ void wave_sparse_flush(const WaveSparse &w, const SparseSink &s)
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+    const int lane = threadIdx.x & 63;
+    const uint32_t n = *w.cnt < w.cap ? *w.cnt : w.cap;
+    if (n) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(s.n, n);
+        base = (uint32_t)__shfl((int)base, 0, 64);
+        const U4 *src = (const U4 *)w.buf;
+        for (uint32_t k = lane; k < n * 4; k += 64) // (a record is four 16-byte words)
+            if (base + (k >> 2) < s.cap) ((U4 *)(s.recs + base))[k] = src[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+    if (lane == 0) *w.cnt = 0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
 }
 
 static __device__ __forceinline__ const DetailHdr &detail_hdr(const uint8_t *detail, const DetailLayout &dl, uint32_t r)
@@ -91,7 +130,7 @@ __global__ void k_prof_admit(const uint64_t *keys, uint64_t n, ProfView pv, uint
     int rank = 0;
     for (int k = 1; k <= pv.max_dup && (uint64_t)k <= j; k++) { if ((keys[j - k] >> 32) == g) rank++; else break; }
     const uint32_t before = pv.plane[(uint64_t)kPlReadCount * pv.G + g];
-    admit[idx] = (before + (uint32_t)rank < (uint32_t)pv.max_dup) ? 1 : 0;
+    admit[idx] = (uint8_t)((admit[idx] & 2) | ((before + (uint32_t)rank < (uint32_t)pv.max_dup) ? 1 : 0)); // (bit 1: k_prof_odd's)
 }
 
 // pass 2b (after every flag is out): the first key of each start position adds the round's admissions to
@@ -122,78 +161,185 @@ static __device__ __forceinline__ uint8_t frag_read_char(const ReadRef &rd, cons
     }
 }
 
-// pass 3: one wavefront per read
-__global__ void __launch_bounds__(256) k_prof_accum(const uint8_t *detail, DetailLayout dl, ReadBatch rb, IndexView ix, ProfView pv,
-                                                    SparseSink sink, const uint8_t *admit, int paired)
+// +1 over [lo, hi) of a plane kept as differences (clipped to the genome)
+static __device__ __forceinline__ void range_add(uint32_t *plane, int64_t lo, int64_t hi, int64_t G)
 {
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    for (uint32_t r = wave; r < rb.n_reads; r += n_waves) {
-        const uint8_t *rec = detail + (uint64_t)r * dl.stride;
-        const DetailHdr &d = *(const DetailHdr *)rec;
-        const Frag *fr = (const Frag *)(rec + sizeof(DetailHdr));
-        const uint8_t *ops = rec + dl.off_ops;
-        if (d.type == 2) { // UpdateMultiHitCount (:244-271)
-            for (int i = 0; i < d.n_frags; i++) {
-                const int64_t g0 = fr[i].gPos;
-                for (int o = lane; o < fr[i].rLen; o += 64)
-                    if (g0 + o >= 0 && g0 + o < pv.G) atomicAdd(&pv.plane[(uint64_t)kPlMulti * pv.G + g0 + o], 1u);
+    if (lo < 0) lo = 0;
+    if (hi > G) hi = G;
+    if (lo >= hi) return;
+    atomicAdd(plane + lo, 1u);
+    if (hi < G) atomicAdd(plane + hi, 0xFFFFFFFFu);
+}
+
+// pass 2c: which reads hold a byte that is not one of the upper-case letters ACGT (bit 1 of the read's flag byte; bit 0 is
+// the admission).  One thread per sixteen bases.
+__global__ void __launch_bounds__(256) k_prof_odd(ReadBatch rb, int tpr, uint8_t *flag)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = (uint32_t)(t / (uint32_t)tpr);
+    const int m = (int)(t % (uint32_t)tpr);
+    if (r >= rb.n_reads) return;
+    const uint32_t o = rb.off[r], len = rb.off[r + 1] - o;
+    if ((uint32_t)m * 16 >= len) return;
+    const uint8_t *b = rb.bases + o + m * 16;
+    const int n = len - m * 16 < 16 ? (int)(len - m * 16) : 16;
+    bool odd = false;
+    for (int i = 0; i < n; i++) { const uint8_t ch = b[i]; odd = odd || !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'); }
+    if (odd) atomicOr((uint32_t *)(flag + (r & ~3u)), 2u << (8 * (r & 3)));
+}
+
+// pass 3: one read per lane.  Nearly everything a read adds is a handful of runs (its strand plane over the read, the base
+// planes under each exact seed): a few scalar decisions per fragment — with a wavefront per read all 64 lanes repeated them
+// (the kernel was bound by instruction issue: 660 wave instructions a read).  The fragments whose columns have to be walked
+// one by one (gaps between seeds, DP fragments, inserts and deletions) go to a list, with everything the walk needs, and
+// k_prof_cols walks them sixteen columns at a time; a gap of up to four bases (the usual one: a single substitution) is
+// done on the spot, and so is everything once the list is full.
+struct ColItem {
+    Frag f;
+    uint32_t read, off;     // read number in the batch; where its bases start
+    int32_t rlen;
+    uint32_t flags;         // 1: forward candidate, 2: the read is a flipped mate 2
+};
+static_assert(sizeof(ColItem) == 32, "ColItem is two 16-byte words");
+struct ColList { ColItem *items; uint32_t *n; uint32_t cap; };
+
+// the columns [0, n_cols) of one fragment, lanes `me`, `me + width`, .. of a group of `width` lanes that all call this
+// (width 1: a lane by itself).  `grp_shift`: position of the group's lanes in the wavefront's ballots.
+template <int WIDTH>
+static __device__ __forceinline__ void prof_walk(const ReadRef &rd, const Frag &f, bool fwd, const uint8_t *ops, const IndexView &ix,
+                                                 const ProfView &pv, const SparseSink &sink, const WaveSparse &ws, int me, int grp_shift)
+{
+    const int64_t g0 = fwd ? f.gPos : ix.G2 - (f.gPos + f.gLen);
+    const int n_cols = (f.kind == kSimple || f.kind == kPlain || f.kind == kIns) ? f.rLen : (f.kind == kDel ? f.gLen : f.ops_len);
+    const uint8_t uni = (f.kind == kSimple || f.kind == kPlain) ? 'M' : (f.kind == kIns ? 'I' : (f.kind == kDel ? 'D' : 0));
+    const uint8_t *fo = ops + f.ops_off;
+    const uint64_t lt = ((uint64_t)1 << me) - 1, all = WIDTH == 64 ? ~0ull : (((uint64_t)1 << WIDTH) - 1);
+    int base_r = 0, base_g = 0;
+    for (int c0 = 0; c0 < n_cols; c0 += WIDTH) {
+        const int x = c0 + me;
+        const bool valid = x < n_cols;
+        const uint8_t op = valid ? (uni ? uni : fo[x]) : 0;
+        uint64_t mR, mG;
+        if (WIDTH == 1) { mR = (op == 'M' || op == 'I'); mG = (op == 'M' || op == 'D'); }
+        else { mR = (__ballot(op == 'M' || op == 'I') >> grp_shift) & all; mG = (__ballot(op == 'M' || op == 'D') >> grp_shift) & all; }
+        const int ri = base_r + __popcll(mR & lt), gi = base_g + __popcll(mG & lt);
+        if (op == 'M') {
+            int pl = -1;
+            switch (frag_read_char(rd, f, fwd, ri)) { case 'A': pl = kPlA; break; case 'C': pl = kPlC; break; case 'G': pl = kPlG; break; case 'T': pl = kPlT; break; }
+            if (pl >= 0) atomicAdd(&pv.plane[(uint64_t)pl * pv.G + g0 + gi], 1u);
+        } else if (op == 'I' || op == 'D') {
+            const uint8_t prev = x == 0 ? 0 : (uni ? uni : fo[x - 1]);
+            if (prev != op) { // first column of a run: this lane records it (:133-150)
+                int e = 0;
+                while (x + e < n_cols && (uni ? uni : fo[x + e]) == op) e++;
+                // a string longer than a record continues in the records behind it ('C'); beyond 255 bases it is refused ('X')
+                const int per = (int)sizeof(SparseRec::seq), n_rec = e > 255 ? 1 : (e + per - 1) / per;
+                if (e > 255) atomicAdd(sink.refused, 1u);
+                const uint32_t at = n_rec > 1 ? atomicAdd(sink.n, (uint32_t)n_rec) : 0u; // (a string and its continuations stay together)
+                for (int k = 0; k < n_rec; k++) {
+                    SparseRec s; s.pos = g0 + gi - 1; s.type = e > 255 ? 'X' : (k == 0 ? op : 'C');
+                    const int lo = k * per, m = e > 255 ? 0 : (e - lo < per ? e - lo : per);
+                    for (int i = 0; i < m; i++) s.seq[i] = op == 'I' ? (char)frag_read_char(rd, f, fwd, ri + lo + i) : "ACGT"[ref_code(ix, g0 + gi + lo + i)];
+                    s.len = (uint8_t)(k == 0 ? (e > 255 ? 255 : e) : m);
+                    if (n_rec == 1) wave_sparse_put(ws, sink, s);
+                    else if (at + k < sink.cap) sink.recs[at + k] = s;
+                }
             }
+        }
+        base_r += __popcll(mR); base_g += __popcll(mG);
+    }
+}
+
+static __device__ __forceinline__ void prof_read(const uint8_t *detail, const DetailLayout &dl, const ReadBatch &rb, const IndexView &ix, const ProfView &pv,
+                                                 const SparseSink &sink, const WaveSparse &ws, const uint8_t *admit, int paired, const ColList &cols, uint32_t r)
+{
+    if (r >= rb.n_reads) return;
+    const uint8_t *rec = detail + (uint64_t)r * dl.stride;
+    const DetailHdr d = *(const DetailHdr *)rec;
+    const Frag *fr = (const Frag *)(rec + sizeof(DetailHdr));
+    if (d.type == 2) { // UpdateMultiHitCount (:244-271)
+        for (int i = 0; i < d.n_frags; i++) { const Frag f = fr[i]; range_add(pv.plane + (uint64_t)kPlMulti * pv.G, f.gPos, f.gPos + f.rLen, pv.G); }
+        return;
+    }
+    const uint8_t flag = admit[r];
+    if (d.type != 1 || !(flag & 1)) return;
+    ReadRef rd;
+    const uint32_t off = rb.off[r];
+    rd.ascii = rb.bases + off; rd.rlen = (int)(rb.off[r + 1] - off); rd.flipped = (paired && (r & 1)) ? 1 : 0;
+    const bool fwd = d.fwd != 0, first = paired ? !(r & 1) : true;
+    const bool letters = !(flag & 2); // every base an upper-case ACGT: an exact seed is then a run of "read base == reference base"
+    const int strand = first ? (fwd ? kPlF1 : kPlR1) : (fwd ? kPlR2 : kPlF2);
+    for (int i = 0; i < d.n_frags; i++) {
+        const Frag f = fr[i];
+        // every fragment is walked in forward-genome coordinates, like the reference's strings
+        // after SelfComplementarySeq: g0 = first genome position under the fragment
+        const int64_t g0 = fwd ? f.gPos : ix.G2 - (f.gPos + f.gLen);
+        if (i == 0) range_add(pv.plane + (uint64_t)strand * pv.G, g0, g0 + rd.rlen, pv.G); // (the reference runs past the array at the genome end)
+        if (f.kind == kEmpty) { // an end fragment the quality gate emptied still hits the `gLen == 0` branch (:124/:193) with ""
+            SparseRec s; s.pos = g0 - 1; s.type = 'I'; s.len = 0; wave_sparse_put(ws, sink, s);
             continue;
         }
-        if (d.type != 1 || !admit[r]) continue;
-        ReadRef rd;
-        rd.ascii = rb.bases + rb.off[r]; rd.rlen = (int)(rb.off[r + 1] - rb.off[r]); rd.flipped = (paired && (r & 1)) ? 1 : 0;
-        const bool fwd = d.fwd != 0, first = paired ? !(r & 1) : true;
-        const Frag &a = fr[0];
-        const int64_t start = fwd ? a.gPos : ix.G2 - (a.gPos + a.gLen);
-        const int strand = first ? (fwd ? kPlF1 : kPlR1) : (fwd ? kPlR2 : kPlF2);
-        for (int o = lane; o < rd.rlen; o += 64)
-            if (start + o < pv.G) atomicAdd(&pv.plane[(uint64_t)strand * pv.G + start + o], 1u); // (the reference runs past the array at the genome end)
-        for (int i = 0; i < d.n_frags; i++) {
-            const Frag &f = fr[i];
-            // every fragment is walked in forward-genome coordinates, like the reference's strings
-            // after SelfComplementarySeq: g0 = first genome position under the fragment
-            const int64_t g0 = fwd ? f.gPos : ix.G2 - (f.gPos + f.gLen);
-            if (f.kind == kEmpty) { // an end fragment the quality gate emptied still hits the `gLen == 0` branch (:124/:193) with ""
-                if (lane == 0) { SparseRec s; s.pos = g0 - 1; s.type = 'I'; s.len = 0; sparse_put(sink, s); }
-                continue;
-            }
-            const int n_cols = (f.kind == kSimple || f.kind == kPlain || f.kind == kIns) ? f.rLen : (f.kind == kDel ? f.gLen : f.ops_len);
-            const uint8_t uni = (f.kind == kSimple || f.kind == kPlain) ? 'M' : (f.kind == kIns ? 'I' : (f.kind == kDel ? 'D' : 0));
-            int base_r = 0, base_g = 0;
-            for (int c0 = 0; c0 < n_cols; c0 += 64) {
-                const int x = c0 + lane;
-                const bool valid = x < n_cols;
-                const uint8_t op = valid ? (uni ? uni : ops[f.ops_off + x]) : 0;
-                const uint64_t mR = __ballot(op == 'M' || op == 'I'), mG = __ballot(op == 'M' || op == 'D');
-                const int ri = base_r + __popcll(mR & lt_mask), gi = base_g + __popcll(mG & lt_mask);
-                if (op == 'M') {
-                    int pl = -1;
-                    switch (frag_read_char(rd, f, fwd, ri)) { case 'A': pl = kPlA; break; case 'C': pl = kPlC; break; case 'G': pl = kPlG; break; case 'T': pl = kPlT; break; }
-                    if (pl >= 0) atomicAdd(&pv.plane[(uint64_t)pl * pv.G + g0 + gi], 1u);
-                } else if (op == 'I' || op == 'D') {
-                    const uint8_t prev = x == 0 ? 0 : (uni ? uni : ops[f.ops_off + x - 1]);
-                    if (prev != op) { // first column of a run: this lane records it (:133-150)
-                        int e = 0;
-                        while (x + e < n_cols && (uni ? uni : ops[f.ops_off + x + e]) == op) e++;
-                        // a string longer than a record continues in the records behind it ('C'); beyond 255 bases it is refused ('X')
-                        const int per = (int)sizeof(SparseRec::seq), n_rec = e > 255 ? 1 : (e + per - 1) / per;
-                        const uint32_t at = atomicAdd(sink.n, (uint32_t)n_rec);
-                        if (e > 255) atomicAdd(sink.refused, 1u);
-                        for (int k = 0; k < n_rec; k++) {
-                            SparseRec s; s.pos = g0 + gi - 1; s.type = e > 255 ? 'X' : (k == 0 ? op : 'C');
-                            const int lo = k * per, m = e > 255 ? 0 : (e - lo < per ? e - lo : per);
-                            for (int i = 0; i < m; i++) s.seq[i] = op == 'I' ? (char)frag_read_char(rd, f, fwd, ri + lo + i) : "ACGT"[ref_code(ix, g0 + gi + lo + i)];
-                            s.len = (uint8_t)(k == 0 ? (e > 255 ? 255 : e) : m);
-                            if (at + k < sink.cap) sink.recs[at + k] = s;
-                        }
-                    }
-                }
-                base_r += __popcll(mR); base_g += __popcll(mG);
-            }
+        if (f.kind == kSimple && letters) { range_add(pv.match, g0, g0 + f.rLen, pv.G); continue; }
+        bool here = (f.kind == kPlain || f.kind == kSimple) && f.rLen <= 4;
+        if (!here) {
+            const uint64_t m = __ballot(1); // the lanes that list a fragment now take their places with one atomic
+            const int lane = threadIdx.x & 63, leader = __ffsll((unsigned long long)m) - 1;
+            uint32_t at = 0;
+            if (lane == leader) at = atomicAdd(cols.n, (uint32_t)__popcll(m));
+            at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(m & (((uint64_t)1 << lane) - 1));
+            if (at < cols.cap) { ColItem it; it.f = f; it.read = r; it.off = off; it.rlen = rd.rlen; it.flags = (fwd ? 1u : 0u) | (rd.flipped ? 2u : 0u); cols.items[at] = it; }
+            else here = true;
         }
+        if (here) prof_walk<1>(rd, f, fwd, rec + dl.off_ops, ix, pv, sink, ws, 0, 0);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_prof_accum(const uint8_t *detail, DetailLayout dl, ReadBatch rb, IndexView ix, ProfView pv,
+                                                    SparseSink sink, const uint8_t *admit, int paired, ColList cols)
+{
+    __shared__ SparseRec s_buf[4][96];
+    __shared__ uint32_t s_cnt[4];
+    WaveSparse ws; ws.buf = s_buf[threadIdx.x >> 6]; ws.cnt = &s_cnt[threadIdx.x >> 6]; ws.cap = 96;
+    if ((threadIdx.x & 63) == 0) *ws.cnt = 0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    prof_read(detail, dl, rb, ix, pv, sink, ws, admit, paired, cols, r);
+    wave_sparse_flush(ws, sink);
+}
+
+// pass 3b: the listed fragments, one per group of sixteen lanes
+__global__ void __launch_bounds__(256) k_prof_cols(const uint8_t *detail, DetailLayout dl, ReadBatch rb, IndexView ix, ProfView pv,
+                                                   SparseSink sink, ColList cols)
+{
+    __shared__ SparseRec s_buf[4][64];
+    __shared__ uint32_t s_cnt[4];
+    WaveSparse ws; ws.buf = s_buf[threadIdx.x >> 6]; ws.cnt = &s_cnt[threadIdx.x >> 6]; ws.cap = 64;
+    if ((threadIdx.x & 63) == 0) *ws.cnt = 0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+    const uint32_t n = *cols.n < cols.cap ? *cols.n : cols.cap;
+    const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, n_groups = (gridDim.x * blockDim.x) >> 4;
+    const int me = threadIdx.x & 15, grp_shift = threadIdx.x & 48;
+    const uint32_t first = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4; // (the wavefront's first group: its lanes leave the loop together)
+    for (uint32_t k0 = first; k0 < n; k0 += n_groups) {
+        const uint32_t k = k0 + (group - first);
+        if (k < n) {
+            const ColItem it = cols.items[k];
+            ReadRef rd;
+            rd.ascii = rb.bases + it.off; rd.rlen = it.rlen; rd.flipped = (it.flags & 2) ? 1 : 0;
+            prof_walk<16>(rd, it.f, (it.flags & 1) != 0, detail + (uint64_t)it.read * dl.stride + dl.off_ops, ix, pv, sink, ws, me, grp_shift);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+        if (*ws.cnt >= ws.cap / 2) wave_sparse_flush(ws, sink);
+    }
+    wave_sparse_flush(ws, sink);
+}
+
+// mcx_profile_settle, after the scans: the exact-seed coverage joins the plane of the reference's base
+__global__ void __launch_bounds__(256) k_prof_fold(IndexView ix, ProfView pv)
+{
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < pv.G; p += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t m = pv.match[p];
+        if (m) pv.plane[(uint64_t)ref_code(ix, p) * pv.G + p] += m;
     }
 }
 

@@ -23,11 +23,13 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "mcx_variants_host.h"
 #include <hipcub/hipcub.hpp>
+#include <mutex>
 
 using namespace mcx;
 using namespace mcx_vc;
@@ -175,6 +177,61 @@ __global__ void __launch_bounds__(256) k_vc_range(const uint32_t *pl, int64_t G,
     if (lane == 0) out[i] = acc;
 }
 
+// Pageable host memory <-> device through the two halves of a page-locked buffer (a direct copy runs at 1-2 GB/s; the lists
+// here are hundreds of MB): one half is on the bus while the other is copied by the host.
+struct Bounce {
+    static constexpr size_t kHalf = (size_t)16 << 20;
+    std::mutex mu;
+    uint8_t *pin = nullptr;
+    hipStream_t stream = nullptr;
+    int ready()
+    {
+        if (pin) return 0;
+        VC_TRY(hipHostMalloc((void **)&pin, 2 * kHalf));
+        VC_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        return 0;
+    }
+};
+static Bounce g_bounce;
+
+static int copy_out(void *dst, const void *d_src, size_t bytes)
+{
+    Bounce &b = g_bounce;
+    std::lock_guard<std::mutex> lock(b.mu);
+    if (int rc = b.ready()) return rc;
+    VC_TRY(hipDeviceSynchronize()); // (the producers ran on the null stream)
+    if (bytes >= ((size_t)8 << 20)) { // fresh pages: touched by many threads now instead of by the one copy below, fault by fault
+        const size_t pages = (bytes + 4095) / 4096;
+        volatile uint8_t *d = (volatile uint8_t *)dst;
+        par_ranges(pages, vc_threads(pages, 1024), [&](unsigned, size_t lo, size_t hi) { for (size_t p = lo; p < hi; p++) d[p * 4096] = 0; });
+    }
+    const size_t n_piece = (bytes + Bounce::kHalf - 1) / Bounce::kHalf;
+    auto start = [&](size_t k) { return hipMemcpyAsync(b.pin + (k & 1) * Bounce::kHalf, (const uint8_t *)d_src + k * Bounce::kHalf, std::min(Bounce::kHalf, bytes - k * Bounce::kHalf), hipMemcpyDeviceToHost, b.stream); };
+    if (n_piece) VC_TRY(start(0));
+    for (size_t k = 0; k < n_piece; k++) {
+        VC_TRY(hipStreamSynchronize(b.stream));
+        if (k + 1 < n_piece) VC_TRY(start(k + 1));
+        memcpy((uint8_t *)dst + k * Bounce::kHalf, b.pin + (k & 1) * Bounce::kHalf, std::min(Bounce::kHalf, bytes - k * Bounce::kHalf));
+    }
+    return 0;
+}
+
+static int copy_in(void *d_dst, const void *src, size_t bytes)
+{
+    Bounce &b = g_bounce;
+    std::lock_guard<std::mutex> lock(b.mu);
+    if (int rc = b.ready()) return rc;
+    const size_t n_piece = (bytes + Bounce::kHalf - 1) / Bounce::kHalf;
+    for (size_t k = 0; k < n_piece; k++) {
+        const size_t m = std::min(Bounce::kHalf, bytes - k * Bounce::kHalf);
+        memcpy(b.pin + (k & 1) * Bounce::kHalf, (const uint8_t *)src + k * Bounce::kHalf, m); // (the copy of piece k - 1 is on the bus meanwhile)
+        if (k >= 1) VC_TRY(hipStreamSynchronize(b.stream)); // piece k - 1 has left its half; piece k - 2's half was free already
+        VC_TRY(hipMemcpyAsync((uint8_t *)d_dst + k * Bounce::kHalf, b.pin + (k & 1) * Bounce::kHalf, m, hipMemcpyHostToDevice, b.stream));
+    }
+    VC_TRY(hipStreamSynchronize(b.stream));
+    return 0;
+}
+
 template <typename T> struct DevBuf {
     T *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -186,18 +243,17 @@ class GpuProfile : public DenseProfile {
 public:
     GpuProfile(const mcx_index *ix, const uint32_t *planes) : ix_(ix), pl_(planes), G_(ix->view.G) {}
     int64_t genome_size() const override { return G_; }
-    int gather(const std::vector<int64_t> &pos, std::vector<Column> &out) override
+    int gather(const std::vector<int64_t> &pos, ColVec &out) override
     {
         out.resize(pos.size());
         if (pos.empty()) return 0;
         DevBuf<int64_t> d_pos; DevBuf<Column> d_col;
         int rc;
         if ((rc = d_pos.alloc(pos.size())) || (rc = d_col.alloc(pos.size()))) return rc;
-        VC_TRY(hipMemcpy(d_pos.p, pos.data(), pos.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        if ((rc = copy_in(d_pos.p, pos.data(), pos.size() * sizeof(int64_t)))) return rc;
         k_vc_gather<<<(unsigned)((pos.size() + 255) / 256), 256>>>(pl_, d_depth_.p, ix_->view, G_, d_pos.p, pos.size(), d_col.p);
         VC_TRY(hipGetLastError());
-        VC_TRY(hipMemcpy(out.data(), d_col.p, pos.size() * sizeof(Column), hipMemcpyDeviceToHost));
-        return 0;
+        return copy_out(out.data(), d_col.p, pos.size() * sizeof(Column));
     }
 
     int ranges(const std::vector<RangeQ> &q, std::vector<unsigned long long> &out) override
@@ -218,6 +274,7 @@ public:
     // scan produced more, by its own count
     int scan(const ScanParams &sp_in, std::vector<SiteRec> &sites, double &ms_depth_, double &ms_scan_) override
     {
+        SubLap lap;
         const int64_t nb = (G_ + kBlock - 1) / kBlock;
         int rc;
         if ((rc = d_depth_.alloc((size_t)nb))) return rc;
@@ -230,7 +287,7 @@ public:
         const ScanParams sp = sp_in;
         DevBuf<SiteRec> d_out; DevBuf<unsigned long long> d_n;
         if ((rc = d_n.alloc(1))) return rc;
-        uint64_t cap = std::max<uint64_t>(1u << 20, (uint64_t)G_ / 16);
+        uint64_t cap = std::max<uint64_t>(1u << 20, (uint64_t)G_ / 64); // (a first guess: a list that runs over is sized by its own count and the scan repeated)
         unsigned long long n = 0;
         for (int attempt = 0; attempt < 2; attempt++) {
             if ((rc = d_out.alloc(cap))) return rc;
@@ -250,24 +307,37 @@ public:
         VC_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); ms_depth_ = ms;
         VC_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); ms_scan_ = ms;
         for (auto &e : ev) (void)hipEventDestroy(e);
+        lap("scan: kernels");
         sites.resize(n);
         if (n == 0) return 0;
         if (n >= (1ull << 32)) return mcx_set_error(MCX_ERR_CAPACITY, "variant scan: more than 2^32 records");
         // bring the appended records into (position, type) order on the device
-        DevBuf<uint64_t> d_k0, d_k1; DevBuf<uint32_t> d_i0, d_i1; DevBuf<SiteRec> d_sorted; DevBuf<uint8_t> d_tmp;
-        if ((rc = d_k0.alloc(n)) || (rc = d_k1.alloc(n)) || (rc = d_i0.alloc(n)) || (rc = d_i1.alloc(n)) || (rc = d_sorted.alloc(n))) return rc;
-        const unsigned nb256 = (unsigned)((n + 255) / 256);
-        k_vc_keys<<<nb256, 256>>>(d_out.p, n, d_k0.p, d_i0.p);
-        hipcub::DoubleBuffer<uint64_t> dk(d_k0.p, d_k1.p);
-        hipcub::DoubleBuffer<uint32_t> dv(d_i0.p, d_i1.p);
+        // (one allocation for the keys, the record numbers, the sort's scratch and the ordered records: a device allocation
+        //  and its release cost milliseconds each)
         size_t tmp_bytes = 0;
-        VC_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, dk, dv, (int64_t)n, 0, 48));
-        if ((rc = d_tmp.alloc(tmp_bytes))) return rc;
-        VC_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, dk, dv, (int64_t)n, 0, 48)); // 40 position bits + 8 type bits
-        k_vc_permute<<<nb256, 256>>>(d_out.p, dv.Current(), n, d_sorted.p);
+        {
+            hipcub::DoubleBuffer<uint64_t> dk0((uint64_t *)nullptr, (uint64_t *)nullptr);
+            hipcub::DoubleBuffer<uint32_t> dv0((uint32_t *)nullptr, (uint32_t *)nullptr);
+            VC_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, dk0, dv0, (int64_t)n, 0, 48));
+        }
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t o_k0 = 0, o_k1 = o_k0 + up(n * 8), o_i0 = o_k1 + up(n * 8), o_i1 = o_i0 + up(n * 4), o_sorted = o_i1 + up(n * 4),
+                     o_tmp = o_sorted + up(n * sizeof(SiteRec)), arena_bytes = o_tmp + up(tmp_bytes);
+        DevBuf<uint8_t> arena;
+        if ((rc = arena.alloc(arena_bytes))) return rc;
+        uint64_t *k0 = (uint64_t *)(arena.p + o_k0), *k1 = (uint64_t *)(arena.p + o_k1);
+        uint32_t *i0 = (uint32_t *)(arena.p + o_i0), *i1 = (uint32_t *)(arena.p + o_i1);
+        SiteRec *d_sorted = (SiteRec *)(arena.p + o_sorted);
+        const unsigned nb256 = (unsigned)((n + 255) / 256);
+        k_vc_keys<<<nb256, 256>>>(d_out.p, n, k0, i0);
+        hipcub::DoubleBuffer<uint64_t> dk(k0, k1);
+        hipcub::DoubleBuffer<uint32_t> dv(i0, i1);
+        VC_TRY(hipcub::DeviceRadixSort::SortPairs(arena.p + o_tmp, tmp_bytes, dk, dv, (int64_t)n, 0, 48)); // 40 position bits + 8 type bits
+        k_vc_permute<<<nb256, 256>>>(d_out.p, dv.Current(), n, d_sorted);
         VC_TRY(hipGetLastError());
-        VC_TRY(hipMemcpy(sites.data(), d_sorted.p, n * sizeof(SiteRec), hipMemcpyDeviceToHost));
-        return 0;
+        VC_TRY(hipDeviceSynchronize());
+        lap("scan: order on the device");
+        return copy_out(sites.data(), d_sorted, n * sizeof(SiteRec));
     }
 
 private:

@@ -111,6 +111,7 @@ def main(argv=None):
             td.barrier()
     tot = mdist.sum_over_ranks([totals[k] for k in ("reads", "mapped", "pairs", "pair_dist_sum", "pair_len_sum")], dev)
     if want_vcf:
+        mapper.profile_settle()  # differences -> counts, before the planes are summed
         planes, sparse = mdist.reduce_profile(planes, mapper.profile_sparse_raw(shard=world > 1))
         if rank == 0:
             mapper.profile_finalize(planes.data_ptr())

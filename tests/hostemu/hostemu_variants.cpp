@@ -57,7 +57,7 @@ public:
         std::stable_sort(sites.begin(), sites.end(), [](const SiteRec &a, const SiteRec &b) { return a.pos != b.pos ? a.pos < b.pos : a.type < b.type; });
         return 0;
     }
-    int gather(const std::vector<int64_t> &pos, std::vector<Column> &out) override
+    int gather(const std::vector<int64_t> &pos, ColVec &out) override
     {
         out.resize(pos.size());
         for (size_t i = 0; i < pos.size(); i++) {

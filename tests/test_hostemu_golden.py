@@ -43,12 +43,17 @@ def test_capacity_tiers_do_not_change_results(hostemu_lib, golden, tmp_path):
     assert nd == 0, ex
 
 
+@pytest.mark.parametrize("grain", [None, "7"])
 @pytest.mark.parametrize("name,tag", [c for c in VCF_CASES if c[1] not in ("opts", "nw")])
-def test_variant_host_logic_equals_reference(hostemu_variants_lib, oracle_lib, golden, tmp_path, name, tag):
+def test_variant_host_logic_equals_reference(hostemu_variants_lib, oracle_lib, golden, tmp_path, monkeypatch, name, tag, grain):
     """The product's variant-calling host logic (mcx_variants_host.h: indel calls, run pairing, gVCF
     blocks, break points, filters, VCF text) over a CPU stand-in for the dense kernels, fed with the
     reference's own profile dump: the golden VCF line for line.  (The runs whose profile needs other
-    -dup / -maxclip / -alg values have no dump and are covered on the GPU.)"""
+    -dup / -maxclip / -alg values have no dump and are covered on the GPU.)  grain "7": the passes over the records
+    are cut into stretches of seven records for the host threads (MCX_VC_GRAIN), so that runs, strings and sorted
+    lists cross stretch borders on these small inputs as they do at genome scale."""
+    if grain:
+        monkeypatch.setenv("MCX_VC_GRAIN", grain)
     g = golden[name]
     alg, prof, maps = g["prof"]
     assert alg == vcf_alg(name, tag)
