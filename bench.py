@@ -252,13 +252,14 @@ def vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, n_s
         dist.barrier()
     t_red = time.perf_counter() - t2
     tot = mdist.sum_over_ranks([d["pairs"], d["pair_dist_sum"], d["pair_len_sum"]], dev)
-    gb = planes.numel() * 4 / 1e9
+    gb = (mdist.reduce_profile.last_bytes if world > 1 else planes.numel() // 2 * 4) / 1e9  # (one GPU: what a rank would put on the wire)
     vcf = {"profile_batch_ms": round(1000 * t_acc, 2), "same_slices_without_profile_ms": round(1000 * t_plain, 2),
            "profile_overhead_ms": round(1000 * (t_acc - t_plain), 2), "slice_reads": slice_reads, "sparse_records_to_host_ms": round(1000 * t_sp, 2),
            "settle_ms_once_per_run": round(1000 * t_settle, 2),
            "reduce_ms": round(1000 * t_red, 2), "reduce_gb": round(gb, 2),
            "reduce_gbs_into_root": None if world == 1 else round(gb * (world - 1) / max(t_red, 1e-9), 1),
-           "reduce": "none (one GPU)" if world == 1 else f"RCCL reduce of {world} x ten u32 planes onto rank 0 in 1-GiB pieces",
+           "reduce": "none (one GPU); five packed planes per rank when there are several" if world == 1 else
+                     f"RCCL reduce of {world} x {round(gb * 1e9 / (4 * G))} u32 planes onto rank 0 in 1-GiB pieces (two 16-bit counters per word where that is exact)",
            "sparse_records": len(merged)}
     if rank == 0:  # VariantCalling() runs once, on the reduced profile
         mapper.profile_finalize(planes.data_ptr())

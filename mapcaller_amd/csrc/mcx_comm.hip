@@ -43,6 +43,38 @@ __global__ void k_add_planes(uint32_t *dst, const uint32_t *src, uint64_t n)
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] += src[i];
 }
 
+// Two 16-bit counters share a u32 on the wire (the planes are 12- and 16-bit fields once finalised, mcx_profile_finalize).
+// clamp != 0: saturating counters (A C G T), every rank's value clamped to 4095 first — sixteen ranks cannot carry into the
+// high half, and min(sum of min(x, 4095), 4095) is min(sum of x, 4095).  clamp == 0: the strand counters, which wrap at 2^16;
+// used only when no low half can carry (k_low_max over all ranks, times the number of ranks, stays below 2^16).
+__global__ void k_pack_planes(uint32_t *lo, const uint32_t *hi, uint64_t n, int clamp)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t a = lo[i], b = hi[i];
+        if (clamp) { a = a < 4095u ? a : 4095u; b = b < 4095u ? b : 4095u; }
+        lo[i] = (a & 0xFFFFu) | (b << 16);
+    }
+}
+
+__global__ void k_unpack_planes(uint32_t *lo, uint32_t *hi, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t p = lo[i];
+        lo[i] = p & 0xFFFFu; hi[i] = p >> 16;
+    }
+}
+
+__global__ void k_low_max(const uint32_t *a, const uint32_t *b, uint64_t n, uint32_t *out)
+{
+    uint32_t m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t x = a[i] & 0xFFFFu, y = b[i] & 0xFFFFu;
+        m = m > x ? m : x; m = m > y ? m : y;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t other = (uint32_t)__shfl_down((int)m, o, 64); m = m > other ? m : other; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 int fail_hip(const char *what, hipError_t e) { return mcx_set_error(MCX_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); }
 int fail_nccl(const char *what, ncclResult_t e) { return mcx_set_error(MCX_ERR_DEVICE, std::string(what) + ": " + ncclGetErrorString(e)); }
 
@@ -137,21 +169,53 @@ extern "C" int mcx_profile_reduce(mcx_comm *c, uint32_t *d_planes, int64_t G, in
     int rc = comm_stream(c);
     if (rc) return rc;
     const int kPlanes = 10, kReadCount = 5;
-    if (c->size > 1 && c->nccl) {
-        const uint64_t piece = 1ull << 28;
-        for (int k = 0; k < kPlanes; k++) {
-            if (k == kReadCount) continue;
-            uint32_t *p = d_planes + (uint64_t)k * (uint64_t)G;
-            for (uint64_t lo = 0; lo < (uint64_t)G; lo += piece) {
-                const uint64_t cnt = std::min<uint64_t>(piece, (uint64_t)G - lo);
+    if (c->nccl) { // (one rank too: the same packing, collectives and unpacking — that is what a one-GPU box can test)
+        const uint64_t piece = 1ull << 28, n = (uint64_t)G;
+        auto plane = [&](int k) { return d_planes + (uint64_t)k * n; };
+        auto dead = [&](const char *what, ncclResult_t e) { // the peers sit in the collectives queued so far: abort the communicator so that they come back with an error
+            const int r = fail_nccl(what, e);
+            (void)ncclCommAbort(c->nccl); c->nccl = nullptr;
+            return r;
+        };
+        auto reduce_plane = [&](int k) -> int {
+            uint32_t *p = plane(k);
+            for (uint64_t lo = 0; lo < n; lo += piece) {
+                const uint64_t cnt = std::min<uint64_t>(piece, n - lo);
                 ncclResult_t e = ncclReduce(p + lo, p + lo, (size_t)cnt, ncclUint32, ncclSum, root, c->nccl, c->stream);
-                if (e != ncclSuccess) { // the peers sit in the collectives queued so far: abort the communicator so that they come back with an error
-                    rc = fail_nccl("ncclReduce", e);
-                    (void)ncclCommAbort(c->nccl); c->nccl = nullptr;
-                    return rc;
-                }
+                if (e != ncclSuccess) return dead("ncclReduce", e);
+            }
+            return 0;
+        };
+        enum { pA = 0, pC, pG, pT, pMulti, pRC, pF1, pR2, pF2, pR1 };
+        // can the strand planes share words?  the largest low half over all ranks decides, the same way on every rank
+        bool strands_share = false;
+        {
+            uint32_t *d_top = nullptr, top = 0;
+            hipError_t he = hipMalloc((void **)&d_top, sizeof(uint32_t));
+            if (he == hipSuccess) he = hipMemsetAsync(d_top, 0, sizeof(uint32_t), c->stream);
+            if (he != hipSuccess) { rc = fail_hip("mcx_profile_reduce", he); (void)ncclCommAbort(c->nccl); c->nccl = nullptr; return rc; }
+            k_low_max<<<4096, 256, 0, c->stream>>>(plane(pF1), plane(pF2), n, d_top);
+            ncclResult_t e = ncclAllReduce(d_top, d_top, 1, ncclUint32, ncclMax, c->nccl, c->stream);
+            if (e != ncclSuccess) { (void)hipFree(d_top); return dead("ncclAllReduce", e); }
+            he = hipMemcpyAsync(&top, d_top, sizeof top, hipMemcpyDeviceToHost, c->stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+            (void)hipFree(d_top);
+            if (he != hipSuccess) { rc = fail_hip("mcx_profile_reduce", he); (void)ncclCommAbort(c->nccl); c->nccl = nullptr; return rc; }
+            strands_share = (uint64_t)top * (uint64_t)c->size <= 0xFFFFu;
+        }
+        const bool counters_share = c->size <= 16;
+        struct Pair { int lo, hi, clamp; bool on; };
+        const Pair pairs[4] = {{pA, pC, 1, counters_share}, {pG, pT, 1, counters_share}, {pF1, pR2, 0, strands_share}, {pF2, pR1, 0, strands_share}};
+        for (const Pair &q : pairs) {
+            if (q.on) {
+                k_pack_planes<<<8192, 256, 0, c->stream>>>(plane(q.lo), plane(q.hi), n, q.clamp);
+                if ((rc = reduce_plane(q.lo))) return rc;
+                if (c->rank == root) k_unpack_planes<<<8192, 256, 0, c->stream>>>(plane(q.lo), plane(q.hi), n);
+            } else {
+                if ((rc = reduce_plane(q.lo)) || (rc = reduce_plane(q.hi))) return rc;
             }
         }
+        if ((rc = reduce_plane(pMulti))) return rc;
         hipError_t he = hipStreamSynchronize(c->stream);
         if (he != hipSuccess) { rc = fail_hip("hipStreamSynchronize", he); (void)ncclCommAbort(c->nccl); c->nccl = nullptr; return rc; }
         ncclResult_t ae = ncclSuccess;

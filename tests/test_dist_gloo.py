@@ -32,6 +32,19 @@ def _worker(rank, world, port, out):
     mine = planes.clone()
     sparse = [("I", 10 * rank + k, "AC") for k in range(3)] + [("B", 7, "")]
     planes, merged = mdist.reduce_profile(planes, sparse, root=0)
+    wire_a = mdist.reduce_profile.last_bytes  # strand depths too large to share a word: A|C, G|T packed, the other five alone
+    # a second profile whose strand depths are small (they share words too) and whose counters pass 4095 on one rank:
+    # what the root gets equals the plain sum once the field widths are applied
+    g2 = torch.Generator().manual_seed(200 + rank)
+    p2 = torch.randint(0, 9000, (10, G), generator=g2, dtype=torch.int32)
+    p2[6:10] = torch.randint(0, 30000, (4, G), generator=g2, dtype=torch.int32)
+    p2[5] = torch.randint(0, 6, (G,), generator=g2, dtype=torch.int32)
+    mine2 = p2.clone()
+    p2, _ = mdist.reduce_profile(p2, [], root=0, shared_read_count=False)
+    wire_b = mdist.reduce_profile.last_bytes
+    p3 = mine2.clone()
+    p3, _ = mdist.reduce_profile(p3, [], root=0, shared_read_count=False, packed=False)
+    wire_c = mdist.reduce_profile.last_bytes
     # the dist_exchange the shards of a file run share: bytes of every rank in rank order, any length
     from mapcaller_amd import api
     link = api.dist_exchange()
@@ -48,7 +61,7 @@ def _worker(rank, world, port, out):
     t = mdist.max_over_ranks(1.0 + rank, torch.device("cpu"))
     tot = mdist.sum_over_ranks([100 + rank, 7 * (rank + 1), 1 << 40], torch.device("cpu"))  # run totals for the variant caller
     if rank == 0:
-        torch.save({"sum": planes, "mine": mine, "merged": merged, "t": t, "tot": tot}, out)
+        torch.save({"sum": planes, "mine": mine, "merged": merged, "t": t, "tot": tot, "packed": p2, "plain": p3, "wire": (wire_a, wire_b, wire_c)}, out)
     # every rank checks its own shard bounds
     assert lo % 100 == 0 and (hi % 100 == 0 or hi == 12345)
     gathered = [None] * world
@@ -72,6 +85,9 @@ def test_profile_reduce_and_sharding_world2(tmp_path):
     fin = mdist.finalize_planes(want.clone(), max_dup=5)
     assert int(fin[0:5].max()) <= 4095 and int(fin[5].max()) <= 5 and int(fin[6:10].max()) <= 0xFFFF
     assert torch.equal(fin[6], (want[6] & 0xFFFF))
+    assert r["wire"] == (7 * 4000, 5 * 4000, 10 * 4000)  # bytes on the wire per rank: 7, 5 and 10 planes of 1000 u32
+    assert not torch.equal(r["packed"], r["plain"])  # (counters above 4095 were clamped before they travelled)
+    assert torch.equal(mdist.finalize_planes(r["packed"].clone(), max_dup=15), mdist.finalize_planes(r["plain"].clone(), max_dup=15))
     assert len(r["merged"]) == 8 and r["merged"][0] == ("I", 0, "AC") and r["merged"][4] == ("I", 10, "AC")
     assert r["t"] == 2.0
     assert r["tot"] == [201, 21, 1 << 41]

@@ -750,7 +750,18 @@ def test_profile_reduce_over_rccl_one_rank(api, golden, monkeypatch):
     L.mcx_profile_reduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
     assert L.mcx_profile_reduce(comm, planes.data_ptr(), G, 0, ctypes.byref(secs)) == 0, api.lib().mcx_last_error()
     torch.cuda.synchronize()
-    assert torch.equal(planes, want)
+    # the planes travel two to a word (A|C, G|T clamped to 4095; F1|R2, F2|R1 as 16-bit fields): what comes back equals the
+    # input once the field widths are applied, multi_hit and readCount untouched
+    assert torch.equal(planes[0:4], want[0:4].clamp(max=4095))
+    assert torch.equal(planes[4:6], want[4:6])
+    assert torch.equal(planes[6:10], want[6:10] & 0xFFFF)
+    # strand depths that could carry into the neighbour's half keep the strand planes apart
+    planes = torch.full((10, G), 70000, dtype=torch.int32, device="cuda")
+    planes[6] = 0xFFFF + 0x10000 * 3
+    want = planes.clone()
+    assert L.mcx_profile_reduce(comm, planes.data_ptr(), G, 0, ctypes.byref(secs)) == 0, api.lib().mcx_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(planes[6:10], want[6:10] & 0xFFFF) and torch.equal(planes[0:4], want[0:4].clamp(max=4095))
     L.mcx_comm_free.argtypes = [ctypes.c_void_p]
     L.mcx_comm_free(comm)
 
@@ -772,7 +783,7 @@ def test_bench_launches_its_ranks(tmp_path):
     small genome: one JSON line, two GPUs' worth of reads, the exchange inside the timed region."""
     env = dict(os.environ, PYTHONPATH=ROOT, MCX_BENCH_SHARE_GPU="1", MCX_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--genome", "uniform", "--genome-mbp", "20", "--contigs", "4",
-           "--repeats", "50", "--batch-pairs", "100000", "--cpu-pairs", "0", "--vcf-reduce", "0", "--pcie-steps", "0", "--second-genome", "0", "--other-configs", "0",
+           "--repeats", "50", "--batch-pairs", "100000", "--cpu-pairs", "0", "--vcf-reduce", "1", "--pcie-steps", "0", "--second-genome", "0", "--other-configs", "0",
            "--file-steps", "0"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -784,6 +795,10 @@ def test_bench_launches_its_ranks(tmp_path):
     assert o["per_read"]["mapped_frac"] > 0.9
     assert "exchanges" in o["config"]["multi_gpu"]
     assert o["config"]["multi_gpu_host_ms_per_step"] is not None
+    # the -vcf leg over the two ranks: differences settled, the planes summed onto rank 0 two counters to a word, variants called there
+    v = o["vcf_reduce"]
+    assert "error" not in v, v
+    assert abs(v["reduce_gb"] - 5 * 20e6 * 4 / 1e9) < 0.02 and v["call_variants"]["records"] > 0 and v["covered_positions"] > 1_000_000
 
 
 def test_degenerate_reads_equal_oracle(api, golden, tmp_path):
