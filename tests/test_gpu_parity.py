@@ -215,8 +215,29 @@ def _oracle_sam(prefix, f1, f2, alg, out):
     return n
 
 
+def _against_reference(record_property, args, out_sam, tmp_path, **diff_kw):
+    """The compiled reference (oracle/_ref/MapCaller -t 1) on the same input, where this box has it: its SAM against ours.
+    Which checker judged the test is recorded (junit property `checker`, and a line on stdout): the oracle always has; the
+    reference too unless the binary is absent or gives up on the input (it crashes on some degenerate reads)."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "MapCaller")
+    if not os.path.exists(ref_bin):
+        which = "oracle only (no compiled reference on this box)"
+    else:
+        rs = str(tmp_path / "ref.sam")
+        r = subprocess.run([ref_bin] + args + ["-sam", rs, "-no_vcf", "-t", "1", "-log", str(tmp_path / "job.log")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        if r.returncode != 0:
+            which = f"oracle only (the reference exited with {r.returncode} on this input)"
+        else:
+            nd, ex = sam_diff(rs, out_sam, **diff_kw)
+            assert nd == 0, ex
+            which = "oracle and compiled reference"
+    record_property("checker", which)
+    print(f"[checker] {which}")
+    return which
+
+
 @pytest.mark.parametrize("alg,rlen,paired", [("ksw2", 150, True), ("nw", 250, True), ("ksw2", 100, False)])
-def test_fresh_seeded_input_equals_oracle(api, tmp_path, alg, rlen, paired):
+def test_fresh_seeded_input_equals_oracle(api, tmp_path, record_property, alg, rlen, paired):
     """A 2 Mbp genome with repeats, 40 k reads: GPU SAM == oracle SAM (and == the compiled
     reference when oracle/_ref travelled to this box)."""
     from mapcaller_amd import synth
@@ -246,12 +267,8 @@ def test_fresh_seeded_input_equals_oracle(api, tmp_path, alg, rlen, paired):
     _oracle_sam(prefix, f1, f2, alg, ora)
     nd, ex = sam_diff(ora, out)
     assert nd == 0, ex
-    if os.path.exists(ref_bin):
-        rs = str(tmp_path / "ref.sam")
-        cmd = [ref_bin, "-i", prefix, "-f", f1] + (["-f2", f2] if f2 else []) + ["-alg", alg, "-sam", rs, "-no_vcf", "-t", "1"]
-        subprocess.run(cmd + ["-log", str(tmp_path / "job.log")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        nd, ex = sam_diff(rs, out)
-        assert nd == 0, ex
+    which = _against_reference(record_property, ["-i", prefix, "-f", f1] + (["-f2", f2] if f2 else []) + ["-alg", alg], out, tmp_path)
+    assert "exited" not in which, which  # (ordinary reads: the reference has no excuse here)
     assert st["mapped"] > 0.9 * st["reads"]
     mp.close(); ix.close()
 
@@ -486,6 +503,47 @@ def test_large_batch_machinery_does_not_change_the_records(api, bench_genome, mo
         assert np.array_equal(a_cig[r], b_cig[r]), r
 
 
+def test_bench_workload_keeps_its_shape(api, bench_genome):
+    """Guard rails for the numbers bench.py reports, on its own workload at a quarter of its batch (1 M pairs x 150 bp on the
+    full-size genome, reads resident in HBM): the shares of work that decide the step — pairs sent to the large-capacity tier,
+    pairs replayed for the insert-size estimate, index blocks and DP problems per read — stay where they were measured, and a
+    steady-state step stays under a bound twice its measured time (a change that doubles the step fails here, not in a
+    hand-run bench)."""
+    import time
+    import torch
+    g = bench_genome
+    n_pairs = 1_000_000
+    n = 2 * n_pairs
+    dev = g["dev"]
+    batches = [g["bench"].make_reads(g["codes"], g["lens"], n_pairs, 150, seed=4242 + k, device=dev).reshape(-1).contiguous() for k in range(3)]
+    off = (torch.arange(n + 1, device=dev, dtype=torch.int64) * 150).to(torch.uint32)
+    d_aln = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+    d_cig = torch.empty(api.cigar_pool_words(n), dtype=torch.int32, device=dev)
+    mp = api.Mapper(g["index"], alg="ksw2", max_batch_reads=n)
+    mp.map_batch_dev(batches[0].data_ptr(), off.data_ptr(), n, True, d_aln.data_ptr(), d_cig.data_ptr())  # first use: allocations, the estimate's first pairs
+    before = mp.stats.as_dict()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in batches[1:]:
+        mp.map_batch_dev(b.data_ptr(), off.data_ptr(), n, True, d_aln.data_ptr(), d_cig.data_ptr())
+    torch.cuda.synchronize()
+    ms = 1000 * (time.perf_counter() - t0) / 2
+    after = mp.stats.as_dict()
+    d = {k: after[k] - before[k] for k in after}
+    mp.close()
+    reads = d["reads"]
+    print(f"[bench shape] {ms:.2f} ms per {n} reads; tier 1 {d['tier1_pairs']}, replayed {d['replayed_pairs']}, index blocks/read {d['fm_blocks'] / reads:.2f}, "
+          f"DP problems/read {d['dp_jobs'] / reads:.3f}, mapped {d['mapped'] / reads:.4f}")
+    assert reads == 2 * n
+    assert d["mapped"] > 0.97 * reads, d
+    assert 0 < d["tier1_pairs"] < 0.02 * (reads / 2), d           # measured 0.7-0.8 %
+    assert d["replayed_pairs"] < 0.02 * (reads / 2), d           # steady state: the estimate barely moves
+    assert d["halved_selections"] == 0, d
+    assert 10 < d["fm_blocks"] / reads < 30, d                    # measured 19-20 index blocks per read
+    assert d["dp_jobs"] / reads < 1.0, d                          # measured 0.3-0.4 DP problems per read
+    assert ms < 16.0, f"{ms:.2f} ms per 2 M reads (measured 8.5 ms)"
+
+
 def test_config5_indel_heavy_long_pairs_equal_reference(api, bench_genome, tmp_path, monkeypatch):
     """BASELINE config 5 read literally: 250 bp pairs with 5 % indels per base (2.5 % insertions + 2.5 % deletions), -alg nw, against the
     full-size index, 100 k pairs in ONE batch — several gapped fragments per read.  The DP job lists are held to 100 k entries here
@@ -550,7 +608,7 @@ def test_overlong_read_is_refused(api, golden):
     mp.close(); ix.close()
 
 
-def test_ragged_reads_equal_oracle(api, tmp_path):
+def test_ragged_reads_equal_oracle(api, tmp_path, record_property):
     """Read lengths from 12 to 300 in one batch (mates trimmed independently), some below the 16-base
     seed minimum, Ns sprinkled in: GPU SAM == oracle SAM (== the reference when it is here and survives)."""
     from mapcaller_amd import synth
@@ -580,19 +638,12 @@ def test_ragged_reads_equal_oracle(api, tmp_path):
     _oracle_sam(prefix, f1, f2, "ksw2", ora)
     nd, ex = sam_diff(ora, out)
     assert nd == 0, ex
-    ref_bin = os.path.join(ROOT, "oracle", "_ref", "MapCaller")
-    if os.path.exists(ref_bin):
-        rs = str(tmp_path / "ref.sam")
-        r = subprocess.run([ref_bin, "-i", prefix, "-f", f1, "-f2", f2, "-alg", "ksw2", "-sam", rs, "-no_vcf", "-t", "1", "-log", str(tmp_path / "job.log")],
-                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        if r.returncode == 0:
-            nd, ex = sam_diff(rs, out)
-            assert nd == 0, ex
+    _against_reference(record_property, ["-i", prefix, "-f", f1, "-f2", f2, "-alg", "ksw2"], out, tmp_path)
     assert st["mapped"] > 0.8 * st["reads"]
     mp.close(); ix.close()
 
 
-def test_long_cigars_equal_oracle(api, tmp_path):
+def test_long_cigars_equal_oracle(api, tmp_path, record_property):
     """Reads with a one-base deletion or insertion every 17 bases (exact 16-mers between them): the
     alignments need 33+ CIGAR operations, more than a row of the dense cigar array holds, and continue
     in the pool of mcx_cigar_ext — next to ordinary indel-heavy 300 bp reads (BASELINE config 5's
@@ -641,14 +692,7 @@ def test_long_cigars_equal_oracle(api, tmp_path):
         nd, ex = sam_diff(ora, out)
         assert nd == 0, ex
         mp.close(); ix.close()
-    ref_bin = os.path.join(ROOT, "oracle", "_ref", "MapCaller")
-    if os.path.exists(ref_bin):
-        rs = str(tmp_path / "ref.sam")
-        r = subprocess.run([ref_bin, "-i", prefix, "-f", f1, "-f2", f2, "-alg", "ksw2", "-sam", rs, "-no_vcf", "-t", "1", "-log", str(tmp_path / "job.log")],
-                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        if r.returncode == 0:
-            nd, ex = sam_diff(rs, str(tmp_path / "gpu.ksw2.sam"))
-            assert nd == 0, ex
+    _against_reference(record_property, ["-i", prefix, "-f", f1, "-f2", f2, "-alg", "ksw2"], str(tmp_path / "gpu.ksw2.sam"), tmp_path)
 
 
 def test_file_path_errors_are_loud(api, golden, tmp_path):
@@ -801,7 +845,7 @@ def test_bench_launches_its_ranks(tmp_path):
     assert abs(v["reduce_gb"] - 5 * 20e6 * 4 / 1e9) < 0.02 and v["call_variants"]["records"] > 0 and v["covered_positions"] > 1_000_000
 
 
-def test_degenerate_reads_equal_oracle(api, golden, tmp_path):
+def test_degenerate_reads_equal_oracle(api, golden, tmp_path, record_property):
     """Reads the path has little to say about — shorter than a seed, all N, homopolymers and short
     tandem repeats (more than 50 occurrences: BWT_Search reports none), a read that is the genome's
     first / last bases — next to ordinary ones: GPU SAM == oracle SAM (== the reference if it survives)."""
@@ -839,14 +883,7 @@ def test_degenerate_reads_equal_oracle(api, golden, tmp_path):
             assert nd == 0, (alg, paired, ex)
             mp.close()
     ix.close()
-    ref_bin = os.path.join(ROOT, "oracle", "_ref", "MapCaller")
-    if os.path.exists(ref_bin):
-        rs = str(tmp_path / "ref.sam")
-        r = subprocess.run([ref_bin, "-i", g["prefix"], "-f", f1, "-f2", f2, "-alg", "ksw2", "-sam", rs, "-no_vcf", "-t", "1", "-log", str(tmp_path / "job.log")],
-                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        if r.returncode == 0:
-            nd, ex = sam_diff(rs, str(tmp_path / "gpu.ksw2.True.sam"))
-            assert nd == 0, ex
+    _against_reference(record_property, ["-i", g["prefix"], "-f", f1, "-f2", f2, "-alg", "ksw2"], str(tmp_path / "gpu.ksw2.True.sam"), tmp_path)
 
 
 def test_maximum_read_length_equals_oracle(api, tmp_path):
