@@ -846,7 +846,7 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
     void **slot = mcx_ctx_files_slot(c, [](void *p) { delete (Kept *)p; });
     if (!*slot) *slot = new Kept();
     Kept *kept = (Kept *)*slot;
-    Queue<BatchPtr> parsed(2), mapped(2), spare((size_t)n_objects);
+    Queue<BatchPtr> parsed(2), mapped(2), formatted(2), spare((size_t)n_objects);
     for (int k = 0; k < n_objects; k++) {
         if (!kept->objects.empty()) { spare.push(std::move(kept->objects.back())); kept->objects.pop_back(); }
         else spare.push(BatchPtr(new Batch));
@@ -969,7 +969,7 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
     });
 
     // ---- stage 3: format + write -------------------------------------------------------------------------------------
-    int write_rc = 0;
+    std::atomic<int> write_rc(0);
     Places places;
     std::thread writer([&] {
         std::deque<BatchPtr> waiting;   // (sharded) formatted, their place in the file not known yet
@@ -981,10 +981,11 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
             else if (b->sam_bytes) {
                 std::vector<uint64_t> off(b->slices.size() + 1, at);
                 for (size_t k = 0; k < b->slices.size(); k++) off[k + 1] = off[k] + b->slices[k].size();
-                // Positioned writes, every slice at its final place.  (They queue up behind the file's lock — tmpfs takes 4 GB/s
-                // however many threads write — but the other way, copying into a mapping of the file's pages, is slower still: 64
-                // threads faulting pages into one mapping reached 1.3 GB/s.  MCX_SAM_MMAP=1 keeps that path for file systems
-                // where it pays; the file then grows under a lock of its own and never shrinks: the other shards write further on.)
+                // Positioned writes, every slice at its final place, from this one thread: writers of one growing file queue up
+                // behind its lock and get in each other's way (tools/ubench_filewrite.cpp on the bench box's tmpfs: one thread
+                // 9 GB/s, two to thirty-two 3.5-4.2 GB/s; a mapping of the file's pages, 64 threads faulting them in: 1.3 GB/s).
+                // MCX_SAM_MMAP=1 keeps the mapping path for file systems where it pays; the file then grows under a lock of its
+                // own and never shrinks: the other shards write further on.
                 bool done_w = false;
                 if (getenv("MCX_SAM_MMAP")) {
                     const uint64_t end = at + b->sam_bytes, page = (uint64_t)sysconf(_SC_PAGESIZE), a0 = at & ~(page - 1);
@@ -993,23 +994,21 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
                     if (ok) { ok = fstat(sam_fd, &st) == 0 && ((uint64_t)st.st_size >= end || ftruncate(sam_fd, (off_t)end) == 0); (void)flock(sam_fd, LOCK_UN); }
                     char *m = ok ? (char *)mmap(nullptr, (size_t)(end - a0), PROT_READ | PROT_WRITE, MAP_SHARED, sam_fd, (off_t)a0) : (char *)MAP_FAILED;
                     if (m != (char *)MAP_FAILED) {
-                        fpool.run((int)b->slices.size(), [&](int k) { const Text &t = b->slices[(size_t)k]; if (t.size()) memcpy(m + (off[(size_t)k] - a0), t.b.data(), t.size()); });
+                        for (size_t k = 0; k < b->slices.size(); k++) { const Text &t = b->slices[k]; if (t.size()) memcpy(m + (off[k] - a0), t.b.data(), t.size()); } // (the pool belongs to the formatter)
                         (void)munmap(m, (size_t)(end - a0));
                         done_w = true;
                     }
                 }
-                if (!done_w) { // (a file that cannot be mapped: positioned writes)
-                    std::atomic<int> bad(0);
-                    fpool.run((int)b->slices.size(), [&](int k) {
-                        const Text &t = b->slices[(size_t)k];
+                if (!done_w) { // positioned writes, by this thread alone (see above)
+                    for (size_t k = 0; k < b->slices.size() && write_rc == 0; k++) {
+                        const Text &t = b->slices[k];
                         size_t done_b = 0;
                         while (done_b < t.size()) {
-                            const ssize_t w = pwrite(sam_fd, t.b.data() + done_b, t.size() - done_b, (off_t)(off[(size_t)k] + done_b));
-                            if (w <= 0) { bad.store(1); break; }
+                            const ssize_t w = pwrite(sam_fd, t.b.data() + done_b, t.size() - done_b, (off_t)(off[k] + done_b));
+                            if (w <= 0) { write_rc = MCX_ERR_IO; break; }
                             done_b += (size_t)w;
                         }
-                    });
-                    if (bad.load()) write_rc = MCX_ERR_IO;
+                    }
                 }
             }
             t_write += secs(t1, now());
@@ -1028,8 +1027,27 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
         };
         while (!stop) {
             BatchPtr b;
-            if (waiting.empty()) b = mapped.pop();
-            else if (!mapped.try_pop(b)) { flush_waiting(false); std::this_thread::sleep_for(std::chrono::microseconds(100)); continue; }
+            if (waiting.empty()) b = formatted.pop();
+            else if (!formatted.try_pop(b)) { flush_waiting(false); std::this_thread::sleep_for(std::chrono::microseconds(100)); continue; }
+            if (b->last) stop = true;
+            if (!sharded) { // its place is behind the batch before it
+                if (sam_fd >= 0) write_out(b, next_place);
+                next_place += b->sam_bytes;
+                spare.push(std::move(b));
+            } else {
+                // (a batch that carries nothing of this shard's — the news of the input's end — has no round of its own to be placed in)
+                if (b->number % shard_count == shard_rank) waiting.push_back(std::move(b));
+                else spare.push(std::move(b));
+                flush_waiting(false);
+            }
+        }
+        flush_waiting(true); // the places of the last rounds' text arrive with the closing exchanges
+    });
+    // (the text of batch i + 1 is made while batch i's is written)
+    std::thread formatter([&] {
+        bool stop = false;
+        while (!stop) {
+            BatchPtr b = mapped.pop();
             if (b->last) stop = true;
             b->sam_bytes = 0;
             if (sam_fd >= 0 && b->n && write_rc == 0) {
@@ -1051,18 +1069,9 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
                 for (const Text &t : b->slices) b->sam_bytes += t.size();
                 t_format += secs(t0, now());
             } else b->slices.clear();
-            if (!sharded) { // its place is behind the batch before it
-                if (sam_fd >= 0) write_out(b, next_place);
-                next_place += b->sam_bytes;
-                spare.push(std::move(b));
-            } else {
-                // (a batch that carries nothing of this shard's — the news of the input's end — has no round of its own to be placed in)
-                if (b->number % shard_count == shard_rank) { places.put_size(b->number, b->sam_bytes); waiting.push_back(std::move(b)); }
-                else spare.push(std::move(b));
-                flush_waiting(false);
-            }
+            if (sharded && b->number % shard_count == shard_rank) places.put_size(b->number, b->sam_bytes); // (the other shards wait for the sizes of a round)
+            formatted.push(std::move(b));
         }
-        flush_waiting(true); // the places of the last rounds' text arrive with the closing exchanges
     });
 
     // ---- stage 2 (this thread): copy in | map | copy out, three parts of batches on the device at a time ------------------
@@ -1208,14 +1217,15 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
         rounds_unplaced.pop_front();
     }
     if (rc) places.fail();
+    formatter.join();
     writer.join();
     reader.join();
     { BatchPtr b; while (spare.try_pop(b)) kept->objects.push_back(std::move(b)); while (parsed.try_pop(b)) kept->objects.push_back(std::move(b)); while (mapped.try_pop(b)) kept->objects.push_back(std::move(b)); }
     if (getenv("MCX_TIMING"))
         fprintf(stderr, "[mcx_map_files] busy seconds: parse + pack %.3f (lines %.3f, rows %.3f; waited for a free batch %.3f) | map %.3f | format %.3f write %.3f  (%d + %d host threads, %s input)\n",
                 t_parse, t_p_lines, t_p_pack, t_p_wait, t_map, t_format, t_write, threads, threads, mapped_input ? "mapped" : "sequential");
-    if (sam_fd >= 0 && !sam_stream) { if (close(sam_fd) != 0 && write_rc == 0) write_rc = MCX_ERR_IO; }
-    if (rc == 0 && write_rc) rc = mcx_set_error(MCX_ERR_IO, std::string("cannot write ") + (sam_path ? sam_path : ""));
+    if (sam_fd >= 0 && !sam_stream) { if (close(sam_fd) != 0 && write_rc.load() == 0) write_rc.store(MCX_ERR_IO); }
+    if (rc == 0 && write_rc.load()) rc = mcx_set_error(MCX_ERR_IO, std::string("cannot write ") + (sam_path ? sam_path : ""));
     return rc;
 }
 
