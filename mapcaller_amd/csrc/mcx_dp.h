@@ -208,83 +208,6 @@ static __device__ int dp_ksw2_core(int qlen, int tlen, const uint8_t *q, const u
 }
 
 // ---------------------------------------------------------------------------------------------
-// ksw2, two columns per lane.  The recurrence's values stay in [-6, 14]: two of them share a VGPR as 16-bit halves
-// and the arithmetic is the packed kind (v_pk_add_i16 / v_pk_max_i16 / ...), one instruction for both columns.  Lane t
-// of pair-slot p holds columns 2(t + W p) (low half) and 2(t + W p) + 1 (high half); the low column's left neighbour is
-// the previous lane's high half (one DPP shift and an alignbit), the high column's is the lane's own low half.
-// The sweep only: traceback bytes to dir (the form dp_ksw2_trace walks).  K2 pair-slots: targets up to 2 W K2.
-// ---------------------------------------------------------------------------------------------
-typedef short pk2 __attribute__((ext_vector_type(2)));
-static __device__ __forceinline__ pk2 pk_of(unsigned v) { return __builtin_bit_cast(pk2, v); }
-static __device__ __forceinline__ unsigned pk_bits(pk2 v) { return __builtin_bit_cast(unsigned, v); }
-static __device__ __forceinline__ pk2 pk_splat(int v) { pk2 r; r.x = (short)v; r.y = (short)v; return r; }
-static __device__ __forceinline__ pk2 pk_sel(pk2 mask, pk2 yes, pk2 no) { return (yes & mask) | (no & ~mask); } // mask halves: -1 / 0
-
-template <int K2, int W>
-static __device__ void dp_ksw2_sweep_pk(int qlen, int tlen, const uint8_t *q, const uint8_t *t, uint8_t *dir)
-{
-    const int lane = threadIdx.x & (W - 1);
-    const int Q = 2, QE2 = 6, MAX_SC = 7;
-    pk2 u[K2], v[K2], x[K2], y[K2];
-    int tc0[K2], tc1[K2];
-#pragma unroll
-    for (int k = 0; k < K2; k++) {
-        u[k] = v[k] = x[k] = y[k] = pk_splat(0);
-        const int c0 = 2 * (lane + W * k);
-        tc0[k] = c0 < tlen ? t[c0] : 4;
-        tc1[k] = c0 + 1 < tlen ? t[c0 + 1] : 4;
-    }
-    const int n_diag = qlen + tlen - 1;
-    for (int r = 0; r < n_diag; r++) {
-        const int st = r - qlen + 1 > 0 ? r - qlen + 1 : 0, en = r < tlen - 1 ? r : tlen - 1;
-        unsigned cx_ = 0, cv_ = (unsigned)(r ? Q : 0) << 16; // what enters column 0, in the high half like a neighbour's (:163)
-#pragma unroll
-        for (int k = 0; k < K2; k++) {
-            if (2 * W * k <= en) { // uniform over the group
-                const int c0 = 2 * (lane + W * k), c1 = c0 + 1;
-                const unsigned ox = pk_bits(x[k]), ov = pk_bits(v[k]);
-                const unsigned px = (unsigned)lane_shift_up<W>((int)ox, (int)cx_, lane), pv = (unsigned)lane_shift_up<W>((int)ov, (int)cv_, lane);
-                cx_ = (unsigned)group_pick<W>((int)ox, W - 1); cv_ = (unsigned)group_pick<W>((int)ov, W - 1);
-                // left neighbours: low column <- previous lane's high half, high column <- own low half (old values)
-                const pk2 xl = pk_of(__builtin_amdgcn_alignbit(ox, px, 16)), vl = pk_of(__builtin_amdgcn_alignbit(ov, pv, 16));
-                const bool a0 = c0 >= st && c0 <= en, a1 = c1 >= st && c1 <= en;
-                if (a0 || a1) {
-                    pk2 act; act.x = a0 ? (short)-1 : (short)0; act.y = a1 ? (short)-1 : (short)0;
-                    pk2 first; first.x = c0 == r ? (short)-1 : (short)0; first.y = c1 == r ? (short)-1 : (short)0; // first matrix row (:165)
-                    pk2 yk = y[k] & ~first;
-                    const pk2 ut = pk_sel(first, pk_splat(r ? Q : 0), u[k]);
-                    const int qb0 = a0 ? q[r - c0] : 4, qb1 = a1 ? q[r - c1] : 4;
-                    pk2 sc;
-                    sc.x = (short)((qb0 == 4 || tc0[k] == 4) ? 0 : (qb0 == tc0[k] ? 1 : -1));
-                    sc.y = (short)((qb1 == 4 || tc1[k] == 4) ? 0 : (qb1 == tc1[k] ? 1 : -1));
-                    pk2 z = sc + pk_splat(QE2);
-                    pk2 a = xl + vl;
-                    pk2 b = yk + ut;
-                    pk2 d = (a > z) & pk_splat(1);                                   // signed (:187)
-                    z = __builtin_elementwise_max(z, a);                             // signed max (:188)
-                    d = pk_sel(b > z, pk_splat(2), d);                               // signed (:189)
-                    // the unsigned byte max / min (:89-90): a negative b is 253..255 as a byte and wins the max; the min caps it at 7
-                    z = pk_sel(b < pk_splat(0), pk_splat(MAX_SC), __builtin_elementwise_min(__builtin_elementwise_max(z, b), pk_splat(MAX_SC)));
-                    const pk2 un = z - vl, vn = z - ut;
-                    z = z - pk_splat(Q);
-                    a = a - z;
-                    b = b - z;
-                    const pk2 ma = a > pk_splat(0), mb = b > pk_splat(0);
-                    const pk2 xn = a & ma, yn = b & mb;
-                    d = d | (ma & pk_splat(0x08)) | (mb & pk_splat(0x10));
-                    u[k] = pk_sel(act, un, ut); // (a column on its first row keeps the row's u even while it waits — it does not wait: c == r is active)
-                    v[k] = pk_sel(act, vn, v[k]);
-                    x[k] = pk_sel(act, xn, x[k]);
-                    y[k] = pk_sel(act, yn, yk);
-                    if (a0) dir[r * tlen + c0] = (uint8_t)d.x; // (at most 3071 x 1024: 32-bit offsets)
-                    if (a1) dir[r * tlen + c1] = (uint8_t)d.y;
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // nw: r/t/s recurrence of nw_alignment in doubled integers (all reference scores are multiples
 // of 0.5 and exact in float), equality-based traceback.  Rows i = read (q), columns j = genome.
 // ---------------------------------------------------------------------------------------------
@@ -379,11 +302,10 @@ static __device__ __forceinline__ int dp_core(bool nw, int qlen, int tlen, const
 
 // the sweep alone (traceback bytes to b.dir) and the walk alone (one lane), for kernels that sweep a group of problems and then
 // walk the group's tracebacks one per lane
-template <int K, int W, bool PACKED = true>
+template <int K, int W>
 static __device__ __forceinline__ void dp_sweep(bool nw, int qlen, int tlen, const DpBuf &b, int *score)
 {
     if (nw) { (void)dp_nw_core<K, W, false>(qlen, tlen, b.q, b.t, b.dir, nullptr, score, nullptr, 0u); return; }
-    if constexpr (PACKED && K >= 2 && K % 2 == 0) { dp_ksw2_sweep_pk<K / 2, W>(qlen, tlen, b.q, b.t, b.dir); return; } // several columns per lane: two per 16-bit half
     (void)dp_ksw2_core<K, W, false, false>(qlen, tlen, b.q, b.t, b.dir, nullptr, score, nullptr, 0u);
 }
 static __device__ __forceinline__ int dp_trace(bool nw, int qlen, int tlen, const uint8_t *q, const uint8_t *t, const uint8_t *dir, uint8_t *ops, DpSummary *sum, uint32_t ops_base)

@@ -1290,7 +1290,7 @@ __global__ void __launch_bounds__(64) k_dp_sel(Ctx cx, JobSink sink, ReadBatch r
 constexpr int kDpGroup = 64;
 struct DpGroupSlot { uint32_t off; int32_t score; }; // where a problem's strings and traceback bytes lie in the wave's scratch; its sweep's score
 
-template <int K, bool PACKED = true>
+template <int K>
 __global__ void __launch_bounds__(64) k_dp_group(Ctx cx, JobSink sink, ReadBatch rb, PairSel sel, uint8_t *scratch, uint64_t scratch_stride)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[DpLds<K>::seq];
@@ -1324,7 +1324,7 @@ __global__ void __launch_bounds__(64) k_dp_group(Ctx cx, JobSink sink, ReadBatch
                 for (int i = lane; i < job.gLen; i += 64) { const uint8_t c = (uint8_t)ref_code(cx.ix, job.rev ? job.gPos + job.gLen - 1 - i : job.gPos + i); b.t[i] = c; if (in_lds) gt[i] = c; }
                 __syncthreads();
                 int score = 0;
-                dp_sweep<K, 64, PACKED>(nw, job.rLen, job.gLen, b, &score);
+                dp_sweep<K, 64>(nw, job.rLen, job.gLen, b, &score);
                 if (lane == 0) { slot[g_n].off = used; slot[g_n].score = score; }
                 used += need;
                 __syncthreads();
@@ -1854,9 +1854,7 @@ static int launch_dp(const PassRes &R, const Ctx &cx, const JobSinks &sinks, con
     if (grouped) k_dp_group<1><<<R.dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, R.d_dp_scratch[0], R.dp_stride[0]);
     else k_dp_sel<1><<<R.dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, R.d_dp_scratch[0], R.dp_stride[0]);
     k_dp_small<<<2560, 256, 0, R.dp_stream[0]>>>(cx, sinks.s[0], rb, sel);
-    static const bool dp_scalar = getenv("MCX_DP_SCALAR") != nullptr; // (experiments: one column per lane everywhere)
-    if (grouped && dp_scalar) k_dp_group<4, false><<<R.dp_blocks[1], 64, 0, R.dp_stream[1]>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1]);
-    else if (grouped) k_dp_group<4><<<R.dp_blocks[1], 64, 0, R.dp_stream[1]>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1]);
+    if (grouped) k_dp_group<4><<<R.dp_blocks[1], 64, 0, R.dp_stream[1]>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1]);
     else k_dp_sel<4><<<R.dp_blocks[1], 64, 0, R.dp_stream[1]>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1]);
     k_dp_tiny<<<2048, 256, 0, wide ? R.dp_stream[3] : s>>>(cx, sinks.s[4], rb, sel);
     k_dp_half<<<2048, 256, 0, wide ? R.dp_stream[4] : R.dp_stream[1]>>>(cx, sinks.s[5], rb, sel);
