@@ -1718,7 +1718,7 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     // (the two grouped classes: a wavefront's stretch holds the strings and traceback bytes of a group of problems — k_dp_group —,
     //  at least those of the class's largest one)
     const uint64_t spill[3] = {(uint64_t)512 << 10, (uint64_t)1 << 20, kDpSpillSeq + (uint64_t)(2048 + 1024) * 1024};
-    const uint32_t blocks[3] = {8192, 4096, 512};
+    const uint32_t blocks[3] = {8192, 4096, 512}; // (the 65-256-column class at 2048 or 8192 wavefronts: the same DP stage, 3.3-3.8 ms)
     for (int k = 0; k < 3; k++) {
         c->dp_stride[k] = spill[k]; c->dp_blocks[k] = blocks[k];
         if ((rc = dmalloc(&c->d_dp_scratch[k], (size_t)spill[k] * blocks[k]))) return rc;
@@ -1856,6 +1856,8 @@ static int launch_dp(const PassRes &R, const Ctx &cx, const JobSinks &sinks, con
     k_dp_small<<<2560, 256, 0, R.dp_stream[0]>>>(cx, sinks.s[0], rb, sel);
     if (grouped) k_dp_group<4><<<R.dp_blocks[1], 64, 0, R.dp_stream[1]>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1]);
     else k_dp_sel<4><<<R.dp_blocks[1], 64, 0, R.dp_stream[1]>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1]);
+    // (the half-wave class behind the 65-256-column class looks like the long pole on a timeline; moved behind the shorter chains
+    //  the stage takes the same 3.3-3.4 ms: the kernels share the chip, the stage is the sum of their work)
     k_dp_tiny<<<2048, 256, 0, wide ? R.dp_stream[3] : s>>>(cx, sinks.s[4], rb, sel);
     k_dp_half<<<2048, 256, 0, wide ? R.dp_stream[4] : R.dp_stream[1]>>>(cx, sinks.s[5], rb, sel);
     k_dp_sel<16><<<R.dp_blocks[2], 64, 0, wide ? R.dp_stream[2] : R.dp_stream[0]>>>(cx, sinks.s[3], rb, sel, R.d_dp_scratch[2], R.dp_stride[2]);
