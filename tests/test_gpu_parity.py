@@ -645,9 +645,10 @@ def test_ragged_reads_equal_oracle(api, tmp_path, record_property):
 
 def test_long_cigars_equal_oracle(api, tmp_path, record_property):
     """Reads with a one-base deletion or insertion every 17 bases (exact 16-mers between them): the
-    alignments need 33+ CIGAR operations, more than a row of the dense cigar array holds, and continue
-    in the pool of mcx_cigar_ext — next to ordinary indel-heavy 300 bp reads (BASELINE config 5's
-    regime).  GPU SAM == oracle SAM (== the reference when it is here)."""
+    alignments need 33+ CIGAR operations, more than a read's average share of the batch's CIGAR pool
+    (MCX_CIGAR_STRIDE words per read + MCX_CIGAR_SLACK) — next to ordinary indel-heavy 300 bp reads
+    (BASELINE config 5's regime), and then by themselves in batches of ONE pair, where nothing but the
+    pool's slack holds their operations.  GPU SAM == oracle SAM (== the reference when it is here)."""
     import re
     import torch
     from mapcaller_amd import synth
@@ -693,6 +694,23 @@ def test_long_cigars_equal_oracle(api, tmp_path, record_property):
         assert nd == 0, ex
         mp.close(); ix.close()
     _against_reference(record_property, ["-i", prefix, "-f", f1, "-f2", f2, "-alg", "ksw2"], str(tmp_path / "gpu.ksw2.sam"), tmp_path)
+    # the long-CIGAR pairs alone, ONE pair per batch (mcx_map_batch on a context sized for two reads): the operations of a read
+    # with 33+ of them fit only because the pool has slack beyond its per-read share; the CIGARs are the file run's
+    sam_lines = [l.split("\t") for l in open(str(tmp_path / "gpu.ksw2.sam")) if not l.startswith("@")]
+    ix = api.Index(prefix, device=0)
+    mp = api.Mapper(ix, alg="ksw2", max_read_len=320, max_batch_reads=2)
+    n_long = 0
+    for k in range(0, 40, 2):
+        pair = np.stack(extra[k:k + 2])
+        mp.reset()  # (every call a run of its own: a batch starts on a chunk boundary)
+        aln, cig = mp.map_batch(np.ascontiguousarray(pair).reshape(-1), np.array([0, 300, 600], dtype=np.uint32), True)
+        text = "".join(f"{int(w) >> 4}{'MID?S'[int(w) & 15]}" for w in cig[0])
+        want = sam_lines[2 * (3000 + k // 2)][5]
+        if int(aln["chr"][0]) >= 0 and want != "*":
+            assert text == want, (k, text, want)
+            n_long += len(cig[0]) > 32
+    assert n_long >= 5, n_long
+    mp.close(); ix.close()
 
 
 def test_file_path_errors_are_loud(api, golden, tmp_path):
