@@ -2942,7 +2942,9 @@ static int profile_accumulate(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all,
     }
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
     HIP_TRY(hipMemcpyAsync(c->d_cnt + CNT_TASKS, &br.n_sparse_keys, sizeof(uint32_t), hipMemcpyHostToDevice, s)); // (pageable source: copied before the call returns)
-    HIP_TRY(hipMemsetAsync(c->d_admit, 0, (n + 3) & ~3u, s));
+    // (MCX_PROF_BY_COLUMN: tests — every read is treated as if it held an odd letter, so that exact seeds are walked column by
+    //  column like every other fragment; the planes must come out the same)
+    HIP_TRY(hipMemsetAsync(c->d_admit, getenv("MCX_PROF_BY_COLUMN") ? 2 : 0, (n + 3) & ~3u, s));
     {
         const int tpr = (std::max<int>((int)(br.longest ? br.longest : (uint32_t)c->rlen_max), 1) + 15) / 16;
         const uint64_t threads = (uint64_t)n * tpr;

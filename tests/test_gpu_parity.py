@@ -356,6 +356,51 @@ def test_alignment_profile_equals_reference(api, golden, tmp_path, name):
     mp.close(); ix.close()
 
 
+def test_profile_runs_equal_column_walk(api, golden, tmp_path, monkeypatch):
+    """The -vcf bookkeeping writes what a read adds as runs (+1 / -1 differences, settled once) wherever the read's letters are
+    plain; MCX_PROF_BY_COLUMN=1 makes it walk every fragment column by column instead (what it does anyway for reads with an odd
+    letter).  Both ways on the `var` reads with letters lower-cased, N and IUPAC codes sprinkled in: the ten planes and the
+    tally records must be the same — the runs, the settle and the odd-letter gate against the plain walk."""
+    import gzip
+    import torch
+    g = golden["var"]
+    rng = np.random.default_rng(11)
+
+    def spoil(src, dst):
+        op = gzip.open if src.endswith(".gz") else open
+        lines = op(src, "rt").read().split("\n")
+        for i in range(1, len(lines), 4):
+            b = bytearray(lines[i].encode())
+            if not b or rng.random() < 0.5:
+                continue  # half of the reads stay plain
+            for j in rng.integers(0, len(b), size=3):
+                b[j] = ord(chr(b[j]).lower()) if rng.random() < 0.7 else ord("NRY"[int(rng.integers(0, 3))])
+            lines[i] = b.decode()
+        open(dst, "w").write("\n".join(lines))
+
+    f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+    spoil(g["r1"], f1); spoil(g["r2"], f2)
+    ix = api.Index(g["prefix"], device=0, full_sa=True)
+    res = []
+    for by_column in (False, True):
+        if by_column:
+            monkeypatch.setenv("MCX_PROF_BY_COLUMN", "1")
+        mp = api.Mapper(ix, alg="ksw2", max_batch_reads=4000)
+        planes = torch.zeros((10, ix.genome_size), dtype=torch.int32, device="cuda")
+        mp.profile_attach(planes.data_ptr())
+        mp.map_files(f1, f2, None)
+        mp.profile_finalize(planes.data_ptr())
+        sp = mp.profile_sparse_raw().copy()
+        sp[:, 10:] *= (np.arange(54)[None, :] < sp[:, 9:10]).astype(np.uint8)
+        res.append((planes.cpu(), sorted(bytes(x) for x in sp)))
+        mp.close()
+    ix.close()
+    assert int(res[0][0][0:4].sum()) > 100000
+    for k in range(10):
+        assert torch.equal(res[0][0][k], res[1][0][k]), api.PLANES[k]
+    assert res[0][1] == res[1][1]
+
+
 @pytest.mark.parametrize("name,tag", VCF_CASES)
 def test_vcf_equals_reference(api, golden, tmp_path, name, tag):
     """The whole -vcf surface on the GPU: mapping with the profile attached, then mcx_call_variants
