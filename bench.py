@@ -237,7 +237,7 @@ def vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, n_s
     torch.cuda.synchronize()
     t_acc = map_slices()
     t_sp = time.perf_counter()
-    sparse = mapper.profile_sparse_raw(shard=world > 1)  # the tally records leave HBM here, once
+    sparse = mapper.profile_sparse_raw(shard=world > 1, copy=False)  # the tally records leave HBM here, once
     t_sp = time.perf_counter() - t_sp
     t_settle = time.perf_counter()
     mapper.profile_settle()  # once per run: the planes kept as differences become counts

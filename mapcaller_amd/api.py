@@ -503,10 +503,11 @@ class Mapper:
     def profile_finalize(self, d_planes_ptr: int) -> None:
         _check(lib().mcx_profile_finalize(self._h, d_planes_ptr), "mcx_profile_finalize")
 
-    def profile_sparse_raw(self, shard: bool = False) -> np.ndarray:
+    def profile_sparse_raw(self, shard: bool = False, copy: bool = True) -> np.ndarray:
         """The same records as they are (uint8 [n, 64] copies of mcx_sparse_rec), for all-gathers
         and for Index.call_variants without a Python loop.  ``shard``: the form for a run spread over
-        several shards (discordant-pair events 'E' instead of the sites they resolve to)."""
+        several shards (discordant-pair events 'E' instead of the sites they resolve to).  ``copy=False``:
+        a view of the library's own array — valid until the next profile_* call or close()."""
         recs = C.POINTER(SparseRec)()
         n = C.c_uint64()
         f = lib().mcx_profile_sparse_shard if shard else lib().mcx_profile_sparse
@@ -514,7 +515,8 @@ class Mapper:
         if n.value == 0:
             return np.zeros((0, 64), dtype=np.uint8)
         buf = (C.c_uint8 * (64 * n.value)).from_address(C.addressof(recs.contents))
-        return np.frombuffer(buf, dtype=np.uint8).reshape(n.value, 64).copy()
+        view = np.frombuffer(buf, dtype=np.uint8).reshape(n.value, 64)
+        return view.copy() if copy else view
 
     def profile_sparse(self):
         """[(type, pos, seq or dist)]: 'I'/'D'/'B' events and 'V'/'T' discordant-site records."""

@@ -1545,7 +1545,8 @@ struct mcx_ctx {
     Archive arch, arch_ev;                      // the tally records / discordant-pair events of the batches so far, still in HBM
     uint64_t arch_limit = (uint64_t)1 << 28;    // (at most 16 GB)
     SparseRec *h_sparse_pin = nullptr; uint32_t sparse_pin_recs = 1u << 18; // page-locked bounce buffer for their way to the host (16 MB)
-    std::vector<mcx_sparse_rec> h_sparse, h_events, h_resolved; // tallies; discordant-pair events ('E'); what mcx_profile_sparse* last returned
+    std::vector<mcx_sparse_rec> h_sparse, h_events; // tallies (followed by what the last mcx_profile_sparse* call appended for its caller: n_tally is where that starts); discordant-pair events ('E')
+    size_t n_tally = 0;
     uint64_t keys_cap = 0;       // keys the sort buffers hold
     uint64_t *h_keys = nullptr; uint64_t h_keys_cap = 0; // pinned: the batch's keys for the exchange between shards
     uint32_t *d_batch_flags = nullptr; // [0] words taken in the batch's CIGAR pool, [1] longest read of the batch, [2] the pool ran over
@@ -2787,7 +2788,7 @@ extern "C" int mcx_profile_attach(mcx_ctx *c, uint32_t *d_planes, int max_dup, i
         if ((rc = dmalloc(&c->d_sparse, c->sparse_cap))) return rc;
         HIP_TRY(hipHostMalloc((void **)&c->h_sparse_pin, (size_t)c->sparse_pin_recs * sizeof(SparseRec)));
     }
-    c->h_sparse.clear(); c->h_events.clear(); c->h_resolved.clear(); c->arch.n = c->arch_ev.n = 0;
+    c->h_sparse.clear(); c->h_events.clear(); c->n_tally = 0; c->arch.n = c->arch_ev.n = 0;
     c->arch.host = &c->h_sparse; c->arch_ev.host = &c->h_events;
     if (!c->arch.d) { // room for the first batches' records now, not in the middle of the first batch
         const uint64_t first = std::min<uint64_t>(std::max<uint64_t>(c->sparse_cap, (uint64_t)1 << 20), (uint64_t)1 << 22);
@@ -2862,8 +2863,9 @@ static int archive_flush(mcx_ctx *c, mcx_ctx::Archive &a)
     if (a.n == 0) return 0;
     hipStream_t s = c->stream;
     std::vector<mcx_sparse_rec> &host = *a.host;
-    const size_t at = host.size();
-    host.resize(at + a.n);
+    const bool tallies = &a == &c->arch;
+    if (tallies) host.resize(c->n_tally); // (what the last mcx_profile_sparse* call appended for its caller goes again)
+    host.reserve(host.size() + a.n); // (no resize: that would be one thread zeroing fresh pages before the copy touches them again)
     const uint64_t half = c->sparse_pin_recs / 2;
     const uint64_t n_piece = (a.n + half - 1) / half;
     auto start = [&](uint64_t k) -> hipError_t {
@@ -2875,14 +2877,17 @@ static int archive_flush(mcx_ctx *c, mcx_ctx::Archive &a)
         HIP_TRY(hipStreamSynchronize(s));
         if (k + 1 < n_piece) HIP_TRY(start(k + 1));
         const uint64_t lo = k * half, m = std::min<uint64_t>(half, a.n - lo);
-        memcpy((void *)(host.data() + at + lo), c->h_sparse_pin + (k & 1) * half, m * sizeof(SparseRec));
+        const mcx_sparse_rec *piece = (const mcx_sparse_rec *)(c->h_sparse_pin + (k & 1) * half);
+        host.insert(host.end(), piece, piece + m);
     }
     a.n = 0;
+    if (tallies) c->n_tally = host.size();
     return 0;
 }
 
 static int sparse_flush(mcx_ctx *c)
 {
+    c->h_sparse.resize(c->n_tally);
     if (int rc = archive_flush(c, c->arch)) return rc;
     return archive_flush(c, c->arch_ev);
 }
@@ -3024,9 +3029,8 @@ extern "C" int mcx_profile_sparse(mcx_ctx *c, const mcx_sparse_rec **recs, uint6
     if (!c || !recs || !n) return fail(MCX_ERR_ARG, "mcx_profile_sparse: null argument");
     HIP_TRY(hipSetDevice(c->idx->device));
     if (int rc = sparse_flush(c)) return rc;
-    c->h_resolved = c->h_sparse;
-    mcx_disc_resolve(c->h_events.data(), c->h_events.size(), c->idx->view.G, c->h_resolved);
-    *recs = c->h_resolved.data(); *n = c->h_resolved.size();
+    mcx_disc_resolve(c->h_events.data(), c->h_events.size(), c->idx->view.G, c->h_sparse); // (appended behind the tallies: no second copy of them)
+    *recs = c->h_sparse.data(); *n = c->h_sparse.size();
     return 0;
 }
 
@@ -3035,9 +3039,8 @@ extern "C" int mcx_profile_sparse_shard(mcx_ctx *c, const mcx_sparse_rec **recs,
     if (!c || !recs || !n) return fail(MCX_ERR_ARG, "mcx_profile_sparse_shard: null argument");
     HIP_TRY(hipSetDevice(c->idx->device));
     if (int rc = sparse_flush(c)) return rc;
-    c->h_resolved = c->h_sparse;
-    c->h_resolved.insert(c->h_resolved.end(), c->h_events.begin(), c->h_events.end());
-    *recs = c->h_resolved.data(); *n = c->h_resolved.size();
+    c->h_sparse.insert(c->h_sparse.end(), c->h_events.begin(), c->h_events.end());
+    *recs = c->h_sparse.data(); *n = c->h_sparse.size();
     return 0;
 }
 
