@@ -35,15 +35,15 @@ template <int MODE>
 static void run(uint32_t *a, uint64_t n, uint64_t updates, uint32_t *sink, const char *name, int per)
 {
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const unsigned blocks = (unsigned)((updates + 255) / 256);
     k_upd<MODE><<<blocks, 256>>>(a, n, updates / 16, sink);
-    hipEventRecord(e0);
+    (void)hipEventRecord(e0);
     k_upd<MODE><<<blocks, 256>>>(a, n, updates, sink);
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
     float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
     printf("%-64s %8.3f ms  %7.2f G lanes/s  %7.2f G updates/s\n", name, ms, updates / ms / 1e6, updates * per / ms / 1e6);
 }
 
@@ -53,8 +53,8 @@ int main(int argc, char **argv)
     const uint64_t updates = (argc > 2 ? atol(argv[2]) : 40) * 1000000ull;
     const uint64_t n = mib * 1024 * 1024 / 4;
     uint32_t *a, *sink;
-    hipMalloc(&a, n * 4); hipMalloc(&sink, 64);
-    hipMemset(a, 0, n * 4);
+    (void)hipMalloc(&a, n * 4); (void)hipMalloc(&sink, 64);
+    (void)hipMemset(a, 0, n * 4);
     printf("array %zu MiB, %llu M lanes\n", mib, (unsigned long long)(updates / 1000000));
     run<0>(a, n, updates, sink, "0 random position, one atomic add", 1);
     run<1>(a, n, updates, sink, "1 lane t at line t (a wave covers 64 consecutive lines)", 1);
