@@ -1,4 +1,5 @@
-"""How fast does the file front end take .gz FASTQ?  1 M pairs x 150 bp as two gzip files in tmpfs, mapped without SAM output.
+"""How fast does the file front end take .gz FASTQ?  1 M pairs x 150 bp as two files in tmpfs — plain, gzip, and bgzip's container
+(independent members the reader inflates side by side) — mapped without SAM output.
     python scripts/gz_rate.py"""
 import json, os, shutil, subprocess, sys, tempfile, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -6,6 +7,17 @@ import argparse
 import torch
 import bench
 from mapcaller_amd import api, synth
+
+
+def write_bgzf(path, data, block=0xff00, level=1):
+    import struct, zlib
+    with open(path, "wb") as f:
+        for i in range(0, len(data), block):
+            chunk = data[i:i + block]
+            c = zlib.compressobj(level, zlib.DEFLATED, -15)
+            comp = c.compress(chunk) + c.flush()
+            f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + comp + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+        f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
 
 
 def main():
@@ -21,10 +33,14 @@ def main():
         synth.write_fastq(f1, reads, 0, 2); synth.write_fastq(f2, reads, 1, 2)
         mp = api.Mapper(ix, alg="ksw2", max_read_len=256, max_batch_reads=1 << 20)
         out = {}
-        for tag in ("plain", "gz"):
+        p1, p2 = f1, f2
+        for tag in ("plain", "bgzf", "gz"):
+            if tag == "bgzf":
+                f1, f2 = os.path.join(tmp, "b1.fq.gz"), os.path.join(tmp, "b2.fq.gz")
+                write_bgzf(f1, open(p1, "rb").read()); write_bgzf(f2, open(p2, "rb").read())
             if tag == "gz":
-                subprocess.run(["gzip", "-1", f1, f2], check=True)
-                f1, f2 = f1 + ".gz", f2 + ".gz"
+                subprocess.run(["gzip", "-1", p1, p2], check=True)
+                f1, f2 = p1 + ".gz", p2 + ".gz"
             mp.reset(); mp.map_files(f1, f2, None)
             mp.reset()
             t = time.perf_counter()

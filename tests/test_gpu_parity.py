@@ -758,6 +758,48 @@ def test_long_cigars_equal_oracle(api, tmp_path, record_property):
     mp.close(); ix.close()
 
 
+def _write_bgzf(path, data, block=0xff00, level=6):
+    """bgzip's container: independent gzip members of at most 64 KB, each carrying its own size in a 'BC' extra field."""
+    import struct
+    import zlib
+    with open(path, "wb") as f:
+        for i in range(0, len(data), block):
+            chunk = data[i:i + block]
+            c = zlib.compressobj(level, zlib.DEFLATED, -15)
+            comp = c.compress(chunk) + c.flush()
+            f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + comp + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+        f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+
+
+def test_bgzf_input_equals_plain(api, golden, tmp_path):
+    """FASTQ in bgzip's container (independent members, inflated side by side by the reader's threads) gives the SAM the plain
+    and the ordinary .gz files give — the `var` pairs, members of 64 KB and of 3 KB (records and lines cut by member borders
+    everywhere); a file whose tail is not BGZF ends there like a damaged gzip stream does."""
+    import gzip
+    g = golden["var"]
+    raw = [gzip.open(g[k], "rb").read() if g[k].endswith(".gz") else open(g[k], "rb").read() for k in ("r1", "r2")]
+    ix = api.Index(g["prefix"], device=0)
+    mp = api.Mapper(ix, alg="ksw2", max_batch_reads=1 << 15)
+    for block in (0xff00, 3000):
+        f1, f2 = str(tmp_path / f"b{block}_1.fq.gz"), str(tmp_path / f"b{block}_2.fq.gz")
+        _write_bgzf(f1, raw[0], block); _write_bgzf(f2, raw[1], block)
+        out = str(tmp_path / f"b{block}.sam")
+        mp.reset()
+        st = mp.map_files(f1, f2, out)
+        nd, ex = sam_diff(g["sam"]["ksw2"], out)
+        assert nd == 0, (block, ex)
+        assert st["reads"] == 2 * raw[0].count(b"\n") // 4
+    # the first half of the members, then bytes that are no member: the reads of the first half come out, nothing fails
+    half = str(tmp_path / "half_1.fq.gz")
+    whole = open(str(tmp_path / "b3000_1.fq.gz"), "rb").read()
+    cut = whole.find(b"\x1f\x8b\x08\x04", len(whole) // 2)
+    open(half, "wb").write(whole[:cut] + b"not a member at all, forty bytes of it..")
+    mp.reset()
+    st = mp.map_files(half, None, str(tmp_path / "half.sam"))
+    assert 0 < st["reads"] < raw[0].count(b"\n") // 4
+    mp.close(); ix.close()
+
+
 def test_file_path_errors_are_loud(api, golden, tmp_path):
     """No fallbacks: a missing read file, a mate file that holds fewer reads, a read longer than the
     context was sized for — each is an error with a message, not a shorter SAM."""
