@@ -141,6 +141,8 @@ int main(int argc, char **argv)
         else if (p == "-dup" && i + 1 < argc) { if (atoi(argv[++i]) <= 15) vo.max_dup = (int8_t)atoi(argv[i]); else fprintf(stderr, "Warning! The PCR-duplicate range is [1-15]!\n"); }
         else if ((p == "-id" || p == "-label") && i + 1 < argc) vo.sample_id = argv[++i];
         else if (p == "-log" && i + 1 < argc) ++i;
+        else if (p == "-v" || p == "--version") { fprintf(stderr, "MapCaller v0.9.9.41 (mapcaller-mi355x)\n\n"); return 0; } // main.cpp:310-314
+        else if (p == "-m" || p == "-bam") { fprintf(stderr, "Error! %s is not supported by mapcaller-mi355x (DESIGN.md, deliberate deviations)\n", argv[i]); return 1; }
         else { fprintf(stderr, "Warning! Unknow parameter: %s\n", argv[i]); usage(argv[0]); return 0; }
     }
     if (f1.empty()) { fprintf(stderr, "Warning! Please specify a valid read input!\n"); usage(argv[0]); return 0; }
