@@ -519,6 +519,41 @@ def test_full_size_genome_prefix_equals_reference(api, bench_genome, tmp_path):
     assert st["tier1_pairs"] > 0, st  # pairs over the tier-0 capacities did go through the large tier
 
 
+def test_config2_ecoli_sized_single_end_equals_reference(api, tmp_path):
+    """BASELINE config 2 at its own size: an E. coli-sized genome (4.6 Mbp, one contig, bench.py's generator), 300 k single-end
+    reads x 100 bp (FASTA: the reference prints a stray quality byte for reverse-strand single-end FASTQ), -alg ksw2, index built on
+    the GPU and saved for the CPU checker — the compiled reference at -t 1 when it is on this box.  SAM line for line."""
+    import argparse
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from mapcaller_amd import synth
+    dev = torch.device("cuda", 0)
+    args = argparse.Namespace(genome_mbp=4.6, contigs=1, repeats=20, genome="uniform")
+    codes, lens, _ = bench.make_genome(args, dev, seed=1234)
+    ix = api.Index.from_codes(codes.data_ptr(), lens, device=0, full_sa=True)
+    prefix = str(tmp_path / "ecoli")
+    ix.save(prefix)
+    n = 300000
+    reads = bench.make_reads(codes, lens, n, 100, seed=2002, device=dev, paired=False).reshape(n, 100).cpu()
+    f1 = str(tmp_path / "r.fa")
+    synth.write_fasta_reads(f1, reads, 0, 1)
+    mp = api.Mapper(ix, alg="ksw2", max_batch_reads=1 << 17)
+    out = str(tmp_path / "gpu.sam")
+    st = mp.map_files(f1, None, out)
+    mp.close(); ix.close()
+    chk = str(tmp_path / "chk.sam")
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "MapCaller")
+    if os.path.exists(ref_bin):
+        subprocess.run([ref_bin, "-i", prefix, "-f", f1, "-alg", "ksw2", "-sam", chk, "-no_vcf", "-t", "1", "-log", str(tmp_path / "job.log")],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1500)
+    else:
+        _oracle_sam(prefix, f1, None, "ksw2", chk)
+    nd, ex = sam_diff(chk, out)
+    assert nd == 0, ex
+    assert st["reads"] == n and st["mapped"] > 0.97 * n
+
+
 def test_large_batch_machinery_does_not_change_the_records(api, bench_genome, monkeypatch):
     """One large batch of the bench workload (120 k pairs on the full-size genome) mapped twice: with everything that only a large
     batch switches on — pairs dealt to the lanes by weight, the large tier beside tier 0 on its own streams, the late list's pass on
