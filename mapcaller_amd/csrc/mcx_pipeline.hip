@@ -15,6 +15,7 @@
 // The -vcf bookkeeping of a batch (mcx_profile.h) follows when a profile is attached.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -1603,8 +1604,16 @@ static Caps tier1_caps(int rlen_max)
     return c;
 }
 
+static std::atomic<size_t> g_dmalloc_bytes(0); // (MCX_TIMING: what a context takes)
 template <class T>
-static int dmalloc(T **p, size_t n) { HIP_TRY(hipMalloc((void **)p, n * sizeof(T))); return 0; }
+static int dmalloc(T **p, size_t n, int line = __builtin_LINE())
+{
+    HIP_TRY(hipMalloc((void **)p, n * sizeof(T)));
+    g_dmalloc_bytes += n * sizeof(T);
+    static const bool log = getenv("MCX_ALLOC_LOG") != nullptr;
+    if (log && n * sizeof(T) >= ((size_t)256 << 20)) fprintf(stderr, "[mcx alloc] %8.2f GB at mcx_pipeline.hip:%d\n", (double)(n * sizeof(T)) / 1e9, line);
+    return 0;
+}
 
 static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o);
 
@@ -1618,7 +1627,9 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
     if (o.max_batch_reads < 2) o.max_batch_reads = 2;
     mcx_ctx *c = new mcx_ctx();
     for (auto &e : c->ev) e = nullptr;
+    const size_t before = g_dmalloc_bytes.load();
     const int rc = ctx_fill(c, idx, o);
+    if (getenv("MCX_TIMING")) fprintf(stderr, "[mcx_ctx_create] %.2f GB of HBM for batches of %lld reads of up to %d bases\n", (double)(g_dmalloc_bytes.load() - before) / 1e9, (long long)o.max_batch_reads, (int)o.max_read_len);
     if (rc) { mcx_ctx_free(c); return rc; } // (every pointer of the context starts null: a caller that retries with a smaller batch finds the HBM free again)
     *out = c;
     return 0;
@@ -1700,8 +1711,10 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     c->tier[1].caps = tier1_caps(c->rlen_max); c->tier[1].lay = make_layout(c->tier[1].caps);
     // (the heavy pairs of a batch in as few passes as 8 GB of records allow: a pass is bound by its slowest pair, not by its size)
     c->tier[1].max_pairs = (uint32_t)std::max<uint64_t>(1024, std::min<uint64_t>(std::min<uint64_t>(c->max_reads, 65536), ((uint64_t)8 << 30) / (uint64_t)c->tier[1].lay.stride));
-    for (int t = 0; t < 2; t++)
-        if ((rc = dmalloc(&c->tier[t].state, (size_t)c->tier[t].lay.stride * c->tier[t].max_pairs))) return rc;
+    // (tier 0's records are allocated by the first batch: a paired batch of max_reads reads is max_reads / 2 pairs, and at 8 KB a
+    //  record the other half is 33 GB at 8 M reads — only single-end batches need a record per read)
+    c->tier[0].max_pairs = 0;
+    if ((rc = dmalloc(&c->tier[1].state, (size_t)c->tier[1].lay.stride * c->tier[1].max_pairs))) return rc;
     c->task_cap = (uint32_t)std::min<uint64_t>(c->max_reads * 24, 0x7fffffffu);
     if ((rc = dmalloc(&c->d_tasks, c->task_cap))) return rc;
     for (int k = 0; k < kDpClasses; k++) {
@@ -2279,6 +2292,16 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
     HIP_TRY(hipSetDevice(c->idx->device));
     br.t0 = std::chrono::steady_clock::now();
     hipStream_t s = c->stream;
+    { // tier 0's pair records: one per pair of the largest batch of this kind
+        const uint64_t half = (c->max_reads + 1) / 2;
+        const uint64_t want = (paired || n_reads <= half) ? half : c->max_reads; // (the single-end tail of an interleaved file fits the pairs' records)
+        if (c->tier[0].max_pairs < want) {
+            HIP_TRY(hipDeviceSynchronize());
+            if (c->tier[0].state) { (void)hipFree(c->tier[0].state); c->tier[0].state = nullptr; c->tier[0].max_pairs = 0; }
+            if (int rc = dmalloc(&c->tier[0].state, (size_t)c->tier[0].lay.stride * want)) return rc;
+            c->tier[0].max_pairs = (uint32_t)want;
+        }
+    }
     br.rb.bases = d_bases; br.rb.off = d_off; br.rb.n_reads = n_reads;
     br.paired = paired; br.read_base = read_base;
     br.recs = (AlnRec *)d_aln; br.cig = d_cigar; br.stats = stats;

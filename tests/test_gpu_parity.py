@@ -468,6 +468,21 @@ def test_cli_two_libraries(io_golden, tmp_path):
     assert nd == 0, ex
 
 
+def test_eight_shards_with_full_batches_equal_single_stream(tmp_path):
+    """BASELINE config 4's shape on one GPU: the native CLI as one stream and as EIGHT shards (-devices 0,0,0,0,0,0,0,0) with batches
+    of 512 K reads — every slot of the per-round exchanges (insert-size sums, duplicate-check keys, SAM places) filled with a full
+    batch, 10x coverage so that the duplicate cap decides — over 2 M pairs on a 60 Mbp human-like genome (eight contexts and eight
+    sets of planes share this box's HBM): the 1.5 GB SAM and the VCF must be the same bytes (scripts/shard_scale.py).
+    (Placed ahead of the tests that keep the full-size index in HBM: the eight contexts need the room.)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "shard_scale.py"), "--genome-mbp", "60", "--contigs", "4", "--shards", "8"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500, env=dict(os.environ, PYTHONPATH=ROOT), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    o = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert o["runs"]["single"]["rc"] == 0 and o["runs"]["shards"]["rc"] == 0, o
+    assert o["sam_identical"] and o["vcf_identical"], o
+    assert o["runs"]["shards"]["sam_bytes"] > 1_000_000_000 and o["vcf_records"] > 0
+
+
 @pytest.fixture(scope="module")
 def bench_genome(api, tmp_path_factory):
     """bench.py's workload at full size: the GRCh38-sized (3.1 Gbp, 6.2 G text positions) synthetic genome with its human-like repeat
@@ -901,20 +916,6 @@ def test_native_cli_several_shards_equals_single_stream(golden, tmp_path, device
     if vcf_alg(name, "default") == alg:
         assert vcf_body(vcf) == vcf_body(g["vcf"]["default"])
     assert not [f for f in os.listdir(tmp_path) if ".part" in f]
-
-
-def test_eight_shards_with_full_batches_equal_single_stream(tmp_path):
-    """BASELINE config 4's shape on one GPU: the native CLI as one stream and as EIGHT shards (-devices 0,0,0,0,0,0,0,0) with batches
-    of 512 K reads — every slot of the per-round exchanges (insert-size sums, duplicate-check keys, SAM places) filled with a full
-    batch, 10x coverage so that the duplicate cap decides — over 2 M pairs on a 60 Mbp human-like genome (eight contexts and eight
-    sets of planes share this box's HBM): the 1.5 GB SAM and the VCF must be the same bytes (scripts/shard_scale.py)."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "shard_scale.py"), "--genome-mbp", "60", "--contigs", "4", "--shards", "8"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500, env=dict(os.environ, PYTHONPATH=ROOT), cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-2000:]
-    o = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert o["runs"]["single"]["rc"] == 0 and o["runs"]["shards"]["rc"] == 0, o
-    assert o["sam_identical"] and o["vcf_identical"], o
-    assert o["runs"]["shards"]["sam_bytes"] > 1_000_000_000 and o["vcf_records"] > 0
 
 
 def test_native_cli_shards_two_libraries(io_golden, tmp_path):
