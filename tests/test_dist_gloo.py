@@ -100,3 +100,34 @@ def test_shards_cover_everything_for_any_world():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert all(lo % 100 == 0 for lo, _ in spans)
+
+
+def _worker3(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    G = 777
+    g = torch.Generator().manual_seed(300 + rank)
+    p = torch.randint(0, 5000, (10, G), generator=g, dtype=torch.int32)
+    p[6:10] = torch.randint(0, 65536 // world, (4, G), generator=g, dtype=torch.int32)  # low halves that just cannot carry
+    p[6, 0] = 65535 // world                                                             # (the largest value the guard lets through)
+    mine = p.clone()
+    got, _ = mdist.reduce_profile(p, [], root=1)  # a root that is not rank 0
+    wire = mdist.reduce_profile.last_bytes
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    if rank == 1:
+        torch.save({"got": got, "all": gathered, "wire": wire}, out)
+    dist.destroy_process_group()
+
+
+def test_packed_reduce_world3_root1(tmp_path):
+    """Three ranks, the sum lands on rank 1, strand depths at the edge of what may share a word: five planes on the wire, and what
+    the root holds equals the plain sum once the field widths are applied (readCount left alone)."""
+    out = str(tmp_path / "r1.pt")
+    mp.spawn(_worker3, args=(3, _free_port(), out), nprocs=3, join=True)
+    r = torch.load(out)
+    want = r["all"][0] + r["all"][1] + r["all"][2]
+    want[5] = r["all"][1][5]
+    assert r["wire"] == 5 * 777 * 4
+    assert torch.equal(mdist.finalize_planes(r["got"].clone(), max_dup=15), mdist.finalize_planes(want.clone(), max_dup=15))
