@@ -77,6 +77,9 @@ def sam_bytes_differ(ref_path, ora_path):
     return bad + (1 if pos != len(a) else 0)
 
 
+WIDE = False  # --wide: longer reads and more of the variant-calling switches (drawn after the usual ones: the usual rounds keep their numbers)
+
+
 def draw(rng):
     """The parameters of one round (every random draw happens here, so a round can be replayed by number)."""
     d = {}
@@ -95,6 +98,14 @@ def draw(rng):
     d["frag_sd"] = rng.choice([10, 50, 120])
     d["alg"] = rng.choice(["nw", "ksw2"])
     d["vcf"] = rng.choice([[], ["-gvcf"], ["-filter"], ["-ploidy", "1"], ["-somatic"], ["-ad", "3", "-min_gap", "20"]])
+    if WIDE:
+        if rng.random() < 0.35:
+            d["rlen"] = rng.choice([400, 600, 900])
+            d["frag_mean"] = rng.choice([300, 600]) + d["rlen"]
+            d["n"] = min(d["n"], 1200)
+        extra = rng.choice([[], ["-monomorphic"], ["-dup", "2"], ["-maxclip", "12"], ["-min_cnv", "20"], ["-size", "300"], ["-gvcf", "-filter"]])
+        if not any(x in d["vcf"] for x in extra if x.startswith("-")):
+            d["vcf"] = d["vcf"] + extra
     return d
 
 
@@ -146,8 +157,10 @@ def main():
     ap.add_argument("--only", type=int, default=-1, help="replay just this round of the sequence")
     ap.add_argument("--ref", action="store_true", help="compare the oracle with the compiled reference (oracle/_ref, CPU only) instead of the GPU product")
     ap.add_argument("--cli-args", default="", help="extra switches for mapcaller-mi355x, space separated")
+    ap.add_argument("--wide", action="store_true", help="longer reads (up to 900 bp) and more variant-calling switches")
     a = ap.parse_args()
-    global MODE, CLI_ARGS
+    global MODE, CLI_ARGS, WIDE
+    WIDE = a.wide
     MODE = "ref" if a.ref else "gpu"
     CLI_ARGS = a.cli_args.split()
     rng = random.Random(a.seed)
