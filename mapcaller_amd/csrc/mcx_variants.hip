@@ -272,12 +272,13 @@ public:
 
     // block depth, then the per-position scan; the record list is sized by a first guess and, if the
     // scan produced more, by its own count
-    int scan(const ScanParams &sp_in, std::vector<SiteRec> &sites, double &ms_depth_, double &ms_scan_) override
+    int scan(const ScanParams &sp_in, SiteVec &sites, double &ms_depth_, double &ms_scan_) override
     {
         SubLap lap;
         const int64_t nb = (G_ + kBlock - 1) / kBlock;
         int rc;
         if ((rc = d_depth_.alloc((size_t)nb))) return rc;
+        lap("scan: depth array");
         hipEvent_t ev[4];
         for (auto &e : ev) VC_TRY(hipEventCreate(&e));
         VC_TRY(hipEventRecord(ev[0], 0));
@@ -290,7 +291,9 @@ public:
         uint64_t cap = std::max<uint64_t>(1u << 20, (uint64_t)G_ / 64); // (a first guess: a list that runs over is sized by its own count and the scan repeated)
         unsigned long long n = 0;
         for (int attempt = 0; attempt < 2; attempt++) {
+            lap("scan: depth kernel queued");
             if ((rc = d_out.alloc(cap))) return rc;
+            lap("scan: record list");
             VC_TRY(hipMemset(d_n.p, 0, sizeof(unsigned long long)));
             VC_TRY(hipEventRecord(ev[2], 0));
             const int64_t n_tiles = (G_ + kScanTile - 1) / kScanTile, groups = std::min<int64_t>(n_tiles, 256 * 32);
@@ -325,6 +328,7 @@ public:
                      o_tmp = o_sorted + up(n * sizeof(SiteRec)), arena_bytes = o_tmp + up(tmp_bytes);
         DevBuf<uint8_t> arena;
         if ((rc = arena.alloc(arena_bytes))) return rc;
+        lap("scan: room for the sort");
         uint64_t *k0 = (uint64_t *)(arena.p + o_k0), *k1 = (uint64_t *)(arena.p + o_k1);
         uint32_t *i0 = (uint32_t *)(arena.p + o_i0), *i1 = (uint32_t *)(arena.p + o_i1);
         SiteRec *d_sorted = (SiteRec *)(arena.p + o_sorted);
@@ -333,6 +337,7 @@ public:
         hipcub::DoubleBuffer<uint64_t> dk(k0, k1);
         hipcub::DoubleBuffer<uint32_t> dv(i0, i1);
         VC_TRY(hipcub::DeviceRadixSort::SortPairs(arena.p + o_tmp, tmp_bytes, dk, dv, (int64_t)n, 0, 48)); // 40 position bits + 8 type bits
+        if (lap.on) { VC_TRY(hipDeviceSynchronize()); lap("scan: keys + radix sort"); }
         k_vc_permute<<<nb256, 256>>>(d_out.p, dv.Current(), n, d_sorted);
         VC_TRY(hipGetLastError());
         VC_TRY(hipDeviceSynchronize());

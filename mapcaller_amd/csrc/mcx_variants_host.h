@@ -115,6 +115,7 @@ template <class T> struct NoInit : std::allocator<T> {
 
 struct Column { uint32_t v[nPlanes]; int32_t depth; uint32_t ref; }; // 48 bytes
 typedef std::vector<Column, NoInit<Column>> ColVec;
+typedef std::vector<SiteRec, NoInit<SiteRec>> SiteVec; // (millions of records copied in from the device: not zeroed first)
 struct RangeQ { int64_t beg, end; int32_t mode, pad; }; // [beg, end] inclusive; mode 0: coverage sum, 1: minimum over covered positions
 
 // the dense profile as the caller sees it
@@ -122,7 +123,7 @@ struct DenseProfile {
     virtual ~DenseProfile() {}
     virtual int64_t genome_size() const = 0;
     // block depth, then the per-position scan: SNV / monomorphic records and run boundaries in (position, type) order
-    virtual int scan(const ScanParams &sp, std::vector<SiteRec> &sites, double &ms_depth, double &ms_scan) = 0;
+    virtual int scan(const ScanParams &sp, SiteVec &sites, double &ms_depth, double &ms_scan) = 0;
     virtual int gather(const std::vector<int64_t> &pos, ColVec &out) = 0;       // columns (+ block depth, reference base) of listed positions
     virtual int ranges(const std::vector<RangeQ> &q, std::vector<unsigned long long> &out) = 0; // coverage sum / minimum over listed ranges
 };
@@ -266,11 +267,11 @@ private:
     void fold(const mcx_sparse_rec *recs, uint64_t n);
     int gather(const std::vector<int64_t> &pos, ColVec &out) { return prof_.gather(pos, out); }
     int ranges(const std::vector<RangeQ> &q, std::vector<unsigned long long> &out) { return prof_.ranges(q, out); }
-    int scan(std::vector<SiteRec> &sites);
+    int scan(SiteVec &sites);
     int indels();
-    void runs(const std::vector<SiteRec> &sites);
+    void runs(const SiteVec &sites);
     void order(VarVec &nor);
-    int normal_runs(const std::vector<SiteRec> &sites, VarVec &nor);
+    int normal_runs(const SiteVec &sites, VarVec &nor);
     void drop_consecutive_nor();
     int discordant(const std::vector<int64_t> &cands, const std::vector<Site> &sites, int type);
     int breakpoints();
@@ -367,7 +368,7 @@ inline void Caller::fold(const mcx_sparse_rec *recs, uint64_t n)
     std::sort(tnl_.begin(), tnl_.end(), lt);
 }
 
-inline int Caller::scan(std::vector<SiteRec> &sites)
+inline int Caller::scan(SiteVec &sites)
 {
     ScanParams sp;
     sp.G = G_; sp.min_ad = o_.min_allele_depth; sp.somatic = o_.somatic; sp.ploidy = o_.ploidy; sp.mono = o_.monomorphic; sp.gvcf = o_.gvcf;
@@ -441,7 +442,7 @@ inline int Caller::indels()
 // SNV / monomorphic records, and uncovered (UMR) / duplicated (CNV) runs from their boundaries
 // (:625-644).  The k-th start of a kind pairs with its k-th end; a run that reaches the genome end
 // has no end and — as in the reference — is never reported.  Lengths are kept in 16 bits like Variant_t::DP.
-inline void Caller::runs(const std::vector<SiteRec> &sites)
+inline void Caller::runs(const SiteVec &sites)
 {
     const std::vector<int64_t> indel_pos(push_pos_); // (sorted by construction)
     // Stretches of the (ordered) records go to one thread each.  A run's start and end can lie in different stretches: a
@@ -569,7 +570,7 @@ inline void Caller::order(VarVec &nor)
 // block, otherwise opens one; MIN_DP is the smallest depth of the block.  The scan delivered the
 // maximal stretches of such positions; an indel call removes its position from a stretch, and a
 // block continues from one stretch into the next when no other record was appended in between.
-inline int Caller::normal_runs(const std::vector<SiteRec> &sites, VarVec &nor)
+inline int Caller::normal_runs(const SiteVec &sites, VarVec &nor)
 {
     std::vector<int64_t> indel_pos;
     for (const Variant &v : vars_) if (v.type == vINS || v.type == vDEL) indel_pos.push_back(v.gPos); // (vars_ holds the indel calls only, in position order)
@@ -937,7 +938,7 @@ inline int Caller::run(const mcx_sparse_rec *recs, uint64_t n_recs, int64_t pair
         t_prev = now;
     };
     fold(recs, n_recs); lap("fold");
-    std::vector<SiteRec> sites;
+    SiteVec sites;
     int rc;
     if ((rc = scan(sites))) return rc;
     lap("scan+sort");

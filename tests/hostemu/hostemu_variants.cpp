@@ -33,7 +33,7 @@ public:
     int64_t genome_size() const override { return G_; }
     int cov(int64_t g) const { return (int)(pl_[g] + pl_[G_ + g] + pl_[2 * G_ + g] + pl_[3 * G_ + g]); }
 
-    int scan(const ScanParams &sp, std::vector<SiteRec> &sites, double &ms_depth, double &ms_scan) override
+    int scan(const ScanParams &sp, SiteVec &sites, double &ms_depth, double &ms_scan) override
     {
         ms_depth = ms_scan = 0;
         const int64_t nb = (G_ + kBlock - 1) / kBlock;
