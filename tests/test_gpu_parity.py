@@ -850,6 +850,26 @@ def test_bgzf_input_equals_plain(api, golden, tmp_path):
     mp.close(); ix.close()
 
 
+def test_one_context_takes_paired_then_single_end_batches(api, golden, tmp_path):
+    """A context keeps one pair record per PAIR of its largest paired batch and grows to one per read only when a single-end batch
+    needs that (tier 0's records are the largest thing a context owns).  One context sized for 8 000 reads maps the `var` pairs,
+    then mate 1 of them as single-end reads in batches of 8 000 (more reads than it has pair records: the growth), then the pairs
+    again: every SAM equals its checker's."""
+    g = golden["var"]
+    ix = api.Index(g["prefix"], device=0)
+    mp = api.Mapper(ix, alg="ksw2", max_batch_reads=8000)
+    ora_se = str(tmp_path / "ora.se.sam")
+    _oracle_sam(g["prefix"], g["r1"], None, "ksw2", ora_se)
+    for k, (f1, f2, want, kw) in enumerate(((g["r1"], g["r2"], g["sam"]["ksw2"], {}), (g["r1"], None, ora_se, {"mask_se_reverse_qual": True}),
+                                            (g["r1"], g["r2"], g["sam"]["ksw2"], {}))):
+        out = str(tmp_path / f"o{k}.sam")
+        mp.reset()
+        mp.map_files(f1, f2, out)
+        nd, ex = sam_diff(want, out, **kw)
+        assert nd == 0, (k, ex)
+    mp.close(); ix.close()
+
+
 def test_file_path_errors_are_loud(api, golden, tmp_path):
     """No fallbacks: a missing read file, a mate file that holds fewer reads, a read longer than the
     context was sized for — each is an error with a message, not a shorter SAM."""
