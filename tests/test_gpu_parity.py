@@ -401,6 +401,30 @@ def test_profile_runs_equal_column_walk(api, golden, tmp_path, monkeypatch):
     assert res[0][1] == res[1][1]
 
 
+def test_profile_refuses_reads_after_the_settle(api, golden):
+    """Once the differences have been turned into counts (profile_settle / profile_finalize) a further batch would add differences to
+    counts: the context refuses it with a message until the profile is attached again — and maps without complaint after that."""
+    import torch
+    g = golden["toy"]
+    ix = api.Index(g["prefix"], device=0)
+    mp = api.Mapper(ix, alg="ksw2", max_batch_reads=4000)
+    planes = torch.zeros((10, ix.genome_size), dtype=torch.int32, device="cuda")
+    mp.profile_attach(planes.data_ptr())
+    mp.map_files(g["r1"], g["r2"], None)
+    mp.profile_settle()
+    mp.profile_settle()  # (idempotent)
+    before = planes.clone()
+    with pytest.raises(api.McxError, match="settled"):
+        mp.map_files(g["r1"], g["r2"], None)
+    assert torch.equal(planes, before)
+    mp.profile_attach(planes.data_ptr())
+    mp.reset()
+    mp.map_files(g["r1"], g["r2"], None)
+    mp.profile_finalize(planes.data_ptr())
+    assert int(planes[0:4].sum()) > int(before[0:4].sum())
+    mp.close(); ix.close()
+
+
 @pytest.mark.parametrize("name,tag", VCF_CASES)
 def test_vcf_equals_reference(api, golden, tmp_path, name, tag):
     """The whole -vcf surface on the GPU: mapping with the profile attached, then mcx_call_variants
