@@ -247,7 +247,7 @@ def vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, n_s
         dist.barrier()
     t2 = time.perf_counter()
     # (every rank accumulated a run of its own here, so the readCount planes are summed too)
-    planes, merged = mdist.reduce_profile(planes, sparse, root=0, shared_read_count=False)
+    planes, merged = mdist.reduce_profile(planes, sparse, root=0, shared_read_count=False, mapper=mapper)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()

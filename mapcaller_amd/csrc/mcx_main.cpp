@@ -149,12 +149,18 @@ int main(int argc, char **argv)
     if (!f2.empty() && f1.size() != f2.size()) { fprintf(stderr, "Warning! Paired-end reads input numbers do not match!\n"); return 0; }
     if (devices.empty()) for (int r = 0; r < n_gpus; r++) devices.push_back(n_gpus == 1 ? gpu : r);
     n_gpus = (int)devices.size();
-    std::string tmp_prefix;
+    // -r ref.fa: the index is built for this run and removed again (main.cpp:344-349, :385-391) — on every way out, also the
+    // early ones (a failed build leaves partial files behind it)
+    struct TmpIndex {
+        std::string prefix;
+        ~TmpIndex() { if (!prefix.empty()) for (const char *ext : {".bwt", ".sa", ".pac", ".ann", ".amb"}) unlink((prefix + ext).c_str()); }
+    } tmp_index;
     if (!ref.empty()) {
-        tmp_prefix = "/tmp/mcx_idx_" + std::to_string((long long)getpid());
-        int rc = mcx_index_build(ref.c_str(), tmp_prefix.c_str(), devices[0]);
+        const char *tmp_dir = getenv("TMPDIR");
+        tmp_index.prefix = std::string(tmp_dir && tmp_dir[0] ? tmp_dir : "/tmp") + "/mcx_idx_" + std::to_string((long long)getpid());
+        int rc = mcx_index_build(ref.c_str(), tmp_index.prefix.c_str(), devices[0]);
         if (rc) { fprintf(stderr, "index: %s (%d)\n", mcx_last_error(), rc); return 1; }
-        prefix = tmp_prefix;
+        prefix = tmp_index.prefix;
     }
     if (prefix.empty()) { fprintf(stderr, "Warning! Please specify a valid reference index!\n"); usage(argv[0]); return 0; }
     o.max_batch_reads = batch_reads > 0 ? batch_reads : 1 << 21; // per batch of the parse | map | format pipeline (a batch costs a few ms of its own: fewer, larger ones)
@@ -277,6 +283,5 @@ int main(int argc, char **argv)
     for (Shard &sh : shards) { mcx_planes_free(sh.planes); mcx_ctx_free(sh.cx); mcx_index_free(sh.ix); }
     for (mcx_comm *c : comms) mcx_comm_free(c);
     if (n_gpus > 1) mcx_exchange_local_free(links.data());
-    if (!tmp_prefix.empty()) { std::string cmd = "rm -f " + tmp_prefix + ".*"; if (system(cmd.c_str())) {} }
     return rc ? 1 : 0;
 }

@@ -148,6 +148,9 @@ __global__ void k_build_rank(const uint32_t *bwt, uint64_t n_blocks, uint64_t n_
 static int build_rank(mcx_index *ix)
 {
     if (!ix->view.sa_full || getenv("MCX_NO_RANK")) return 0; // (the walk then counts in the .bwt blocks: MCX_NO_RANK for experiments)
+    // a record keeps its two running counts in 32 bits plus ONE crossing chunk per base and count (rank_cross): exact while no count
+    // passes 2^32 twice, i.e. below 2^33 symbols.  Longer texts (genomes above ~4.29 Gbp) walk the .bwt blocks, which have no such limit.
+    if (ix->host.seq_len >= ((uint64_t)1 << 33)) return 0;
     const uint64_t n_blocks = (ix->host.seq_len + 127) / 128, n_chunks = (ix->host.seq_len + 31) / 32;
     const size_t bytes = (size_t)4 * n_chunks * sizeof(RankChunk) + 64;
     unsigned long long *d_cross = nullptr, h_cross[8];
@@ -155,11 +158,14 @@ static int build_rank(mcx_index *ix)
     hipError_t e = hipMalloc(&ix->d_rank, bytes);
     if (e != hipSuccess) { g_err = std::string("hipMalloc(rank records): ") + hipGetErrorString(e); return MCX_ERR_DEVICE; }
     HIP_TRY(hipMalloc((void **)&d_cross, sizeof h_cross));
-    HIP_TRY(hipMemcpy(d_cross, h_cross, sizeof h_cross, hipMemcpyHostToDevice));
-    k_build_rank<<<(unsigned)((n_blocks + 255) / 256), 256>>>((const uint32_t *)ix->d_bwt, n_blocks, n_chunks, (RankChunk *)ix->d_rank, d_cross);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(h_cross, d_cross, sizeof h_cross, hipMemcpyDeviceToHost));
+    e = hipMemcpy(d_cross, h_cross, sizeof h_cross, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        k_build_rank<<<(unsigned)((n_blocks + 255) / 256), 256>>>((const uint32_t *)ix->d_bwt, n_blocks, n_chunks, (RankChunk *)ix->d_rank, d_cross);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(h_cross, d_cross, sizeof h_cross, hipMemcpyDeviceToHost);
     (void)hipFree(d_cross);
+    if (e != hipSuccess) return fail(MCX_ERR_DEVICE, std::string("rank records: ") + hipGetErrorString(e)); // (d_rank is the index's: mcx_index_free releases it)
     ix->view.rank = ix->d_rank; ix->view.rank_chunks = n_chunks;
     for (int k = 0; k < 8; k++) ix->view.rank_cross[k] = h_cross[k];
     ix->hbm_bytes += (int64_t)bytes;
@@ -1538,7 +1544,8 @@ struct mcx_ctx {
     // -vcf bookkeeping (mcx_profile.h): caller-owned counter planes, per-read alignment detail
     uint32_t *prof_planes = nullptr; int prof_max_dup = 5, prof_max_clip = 5;
     ColItem *d_prof_items = nullptr; uint32_t prof_items_cap = 0; // fragments whose columns k_prof_cols walks
-    uint32_t *d_prof_match = nullptr; bool prof_settled = false; // exact-seed coverage as differences (mcx_profile.h); freed by mcx_profile_settle
+    uint32_t *d_prof_match = nullptr; bool prof_settled = false, prof_broken = false; // (broken: a settle failed half way — some planes scanned, some not)
+    // exact-seed coverage as differences (mcx_profile.h); freed by mcx_profile_settle
     uint8_t *d_detail = nullptr; DetailLayout dlay;
     uint64_t *d_keys[2] = {nullptr, nullptr}; uint8_t *d_admit = nullptr; void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     SparseRec *d_sparse = nullptr; uint32_t sparse_cap = 0;
@@ -2068,6 +2075,30 @@ static int pass_finish(mcx_ctx *c, int tier, const PassRes &R, uint32_t n_sel, m
         fprintf(stderr, "\n");
     }
     const uint32_t *n = R.h_cnt;
+    if (getenv("MCX_DP_HIST") && n_sel >= 1024) { // experiments: the sizes of the pass's DP problems (query x target, by bit length), per list
+        static const char *names[kDpClasses] = {"small", "wave1", "wave4", "wave16", "tiny", "half"};
+        for (int k = 0; k < kDpClasses; k++) {
+            const uint32_t m = std::min(n[CNT_JOB0 + k * kCntPad], R.job_cap[k]);
+            if (!m) continue;
+            std::vector<DpJob> jobs(m);
+            HIP_TRY(hipMemcpy(jobs.data(), R.d_jobs[k], (size_t)m * sizeof(DpJob), hipMemcpyDeviceToHost));
+            unsigned long long hist[12][12] = {{0}}, cells = 0, diag = 0;
+            for (const DpJob &j : jobs) {
+                const int a = std::min(11, j.rLen ? 32 - __builtin_clz((unsigned)j.rLen) : 0), b = std::min(11, j.gLen ? 32 - __builtin_clz((unsigned)j.gLen) : 0);
+                hist[a][b]++; cells += (unsigned long long)j.rLen * j.gLen; diag += (unsigned long long)(j.rLen + j.gLen - 1);
+            }
+            fprintf(stderr, "[dp hist] tier %d list %s: %u problems, %llu cells (mean %.1f), mean anti-diagonals %.1f; rows = bit length of the query, columns = of the target\n", tier, names[k], m, cells,
+                    (double)cells / m, (double)diag / m);
+            for (int a = 0; a < 12; a++) {
+                bool any = false;
+                for (int b = 0; b < 12; b++) any |= hist[a][b] != 0;
+                if (!any) continue;
+                fprintf(stderr, "[dp hist]   q<2^%-2d", a);
+                for (int b = 0; b < 12; b++) fprintf(stderr, " %9llu", hist[a][b]);
+                fprintf(stderr, "\n");
+            }
+        }
+    }
     // a work list that ran over: nothing of this pass is kept, the caller maps the selection in two halves
     if ((R.d_tasks && n[CNT_TASKS] > R.task_cap) || n[CNT_RESCUE] > R.rescue_cap || n[CNT_RTASK] > R.rtask_cap || n[CNT_RSEED] > R.rseed_cap) return kListOverflow;
     for (int k = 0; k < kDpClasses; k++) if (n[CNT_JOB0 + k * kCntPad] > R.job_cap[k]) return kListOverflow;
@@ -2289,6 +2320,8 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
     if (paired && (n_reads & 1)) return fail(MCX_ERR_ARG, "paired batch with an odd number of reads");
     if (paired && (read_base & 1)) return fail(MCX_ERR_ARG, "paired batch at an odd read_base");
     if ((uintptr_t)d_bases & 15) return fail(MCX_ERR_ARG, "mcx_batch_begin: d_bases must be 16-byte aligned");
+    // (refused before anything is mapped or counted: readCount would move in profile_keys / profile_foreign before profile_accumulate refuses)
+    if (c->prof_planes && c->prof_settled) return fail(MCX_ERR_ARG, "the profile has been settled (mcx_profile_settle / _finalize): attach it again before mapping more reads");
     HIP_TRY(hipSetDevice(c->idx->device));
     br.t0 = std::chrono::steady_clock::now();
     hipStream_t s = c->stream;
@@ -2656,6 +2689,15 @@ extern "C" int mcx_stream_submit_packed(mcx_ctx *c, const uint32_t *codes, uint3
     if (n_reads > c->max_reads) return fail(MCX_ERR_ARG, "batch larger than max_batch_reads");
     const uint32_t row_max = (uint32_t)(c->rlen_max + 15) / 16;
     if (row_words > row_max) return fail(MCX_ERR_UNSUPPORTED, "mcx_stream_submit_packed: rows are longer than max_read_len");
+    { // the lengths are the caller's: k_unpack_reads / k_apply_odd write off[r] + len[r] bytes, so a length beyond its row (or the
+      // context's longest read) or a sum beyond the slot would write past the slot's bases (one pass over host memory: ~1 ms per 8 M reads)
+        const uint32_t lim = std::min<uint32_t>(row_words * 16u, (uint32_t)c->rlen_max);
+        uint32_t longest = 0;
+        uint64_t sum = 0;
+        for (uint32_t r = 0; r < n_reads; r++) { longest = std::max(longest, len[r]); sum += len[r]; }
+        if (longest > lim) return fail(MCX_ERR_ARG, "mcx_stream_submit_packed: a read is longer than its row / max_read_len");
+        if (sum > c->max_bases) return fail(MCX_ERR_ARG, "batch holds more bases than max_batch_reads * max_read_len");
+    }
     HIP_TRY(hipSetDevice(c->idx->device));
     mcx_ctx::Slot *sl = nullptr;
     int rc = stream_slot(c, &sl);
@@ -2819,7 +2861,7 @@ extern "C" int mcx_profile_attach(mcx_ctx *c, uint32_t *d_planes, int max_dup, i
     }
     if (!c->d_prof_match) { int rc = dmalloc(&c->d_prof_match, (size_t)c->idx->view.G); if (rc) return rc; }
     HIP_TRY(hipMemsetAsync(c->d_prof_match, 0, (size_t)c->idx->view.G * sizeof(uint32_t), c->stream));
-    c->prof_settled = false;
+    c->prof_settled = false; c->prof_broken = false;
     return 0;
 }
 
@@ -2948,7 +2990,7 @@ static int archive_append(mcx_ctx *c, mcx_ctx::Archive &a, const SparseRec *d_sr
 // admission over `all` keys (null: the batch's own, already sorted on the device), then the accumulation of the own reads
 static int profile_accumulate(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all, uint32_t slot_stride, uint32_t own_slot)
 {
-    if (c->prof_settled) return fail(MCX_ERR_ARG, "the profile has been settled (mcx_profile_settle / _sparse / _finalize): attach it again before mapping more reads");
+    if (c->prof_settled) return fail(MCX_ERR_ARG, "the profile has been settled (mcx_profile_settle / _finalize): attach it again before mapping more reads");
     BatchRun &br = c->run;
     hipStream_t s = c->stream;
     const IndexView &ix = c->idx->view;
@@ -3007,6 +3049,7 @@ static int profile_accumulate(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all,
 extern "C" int mcx_profile_settle(mcx_ctx *c)
 {
     if (!c) return fail(MCX_ERR_ARG, "mcx_profile_settle: null argument");
+    if (c->prof_broken) return fail(MCX_ERR_DEVICE, "an earlier mcx_profile_settle failed half way: the planes are neither differences nor counts; attach the profile again");
     if (!c->prof_planes || c->prof_settled) return 0;
     HIP_TRY(hipSetDevice(c->idx->device));
     hipStream_t s = c->stream;
@@ -3015,7 +3058,7 @@ extern "C" int mcx_profile_settle(mcx_ctx *c)
     size_t tb = 0;
     HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tb, c->d_prof_match, c->d_prof_match, G, s));
     void *tmp = nullptr;
-    HIP_TRY(hipMalloc(&tmp, tb + 256));
+    HIP_TRY(hipMalloc(&tmp, tb + 256)); // (nothing touched yet: a retry is safe)
     hipError_t e = hipSuccess;
     const int diffs[5] = {kPlMulti, kPlF1, kPlR2, kPlF2, kPlR1};
     for (int k = 0; k < 5 && e == hipSuccess; k++) {
@@ -3030,7 +3073,7 @@ extern "C" int mcx_profile_settle(mcx_ctx *c)
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(tmp);
-    HIP_TRY(e);
+    if (e != hipSuccess) { c->prof_broken = c->prof_settled = true; HIP_TRY(e); } // (a second settle must not scan the scanned planes again)
     (void)hipFree(c->d_prof_match); c->d_prof_match = nullptr; // (12 GB at 3.1 Gbp: the variant caller's scans want the room)
     c->prof_settled = true;
     return 0;

@@ -49,7 +49,7 @@ PACKED_WITH_READ_COUNT = (4, 5)        # multi_hit | readCount, when the readCou
 PACKED_WRAPPING = ((6, 7), (8, 9))     # F1|R2, F2|R1: 16-bit fields that wrap; packed when the low halves cannot carry
 
 
-def reduce_profile(planes: torch.Tensor, sparse, root: int = 0, shared_read_count: bool = True, packed: bool = True):
+def reduce_profile(planes: torch.Tensor, sparse, root: int = 0, shared_read_count: bool = True, packed: bool = True, mapper=None):
     """Sums the [10, G] counter planes of all ranks onto ``root`` (RCCL reduce on GPU tensors; only the
     rank that calls the variants needs the sum), in pieces of 2^28 elements (1 GiB: link speed, and no
     collective's count outgrows 32 bits), and gathers the sparse records of every rank in rank order.
@@ -62,10 +62,14 @@ def reduce_profile(planes: torch.Tensor, sparse, root: int = 0, shared_read_coun
     — five planes on the wire instead of nine or ten.  What the root then holds equals the plain sum once
     finalised; the planes of the other ranks are left in their packed form.  ``sparse`` is either the list
     of tuples of Mapper.profile_sparse() or the raw uint8 [n, 64] array of Mapper.profile_sparse_raw(); the
-    same kind comes back.  Call after Mapper.profile_settle() and before finalisation.  With the gloo
+    same kind comes back.  Call after Mapper.profile_settle() and before finalisation — or pass the ``mapper`` that
+    accumulated the planes and it is settled here first (idempotent): planes that still hold differences would be
+    packed into plausible-looking garbage without any error.  With the gloo
     backend (CPU tests, several ranks on one GPU) device tensors are staged through the host.
     ``reduce_profile.last_bytes``: what this rank put on the wire for the planes."""
     reduce_profile.last_bytes = 0
+    if mapper is not None:
+        mapper.profile_settle()
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return planes, (sparse if isinstance(sparse, np.ndarray) else list(sparse))
     world = dist.get_world_size()

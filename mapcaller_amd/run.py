@@ -112,7 +112,7 @@ def main(argv=None):
     tot = mdist.sum_over_ranks([totals[k] for k in ("reads", "mapped", "pairs", "pair_dist_sum", "pair_len_sum")], dev)
     if want_vcf:
         mapper.profile_settle()  # differences -> counts, before the planes are summed
-        planes, sparse = mdist.reduce_profile(planes, mapper.profile_sparse_raw(shard=world > 1))
+        planes, sparse = mdist.reduce_profile(planes, mapper.profile_sparse_raw(shard=world > 1), mapper=mapper)
         if rank == 0:
             mapper.profile_finalize(planes.data_ptr())
             vs = index.call_variants(planes.data_ptr(), sparse, tot[2], tot[3], tot[4], a.vcf, ploidy=a.ploidy, min_allele_depth=a.ad,

@@ -2,6 +2,7 @@
 reference's golden vectors and against the oracle on freshly seeded inputs.
 Bar: bit-exact (integer / byte / index work)."""
 import ctypes
+import gzip
 import json
 import os
 import subprocess
@@ -461,6 +462,35 @@ def test_cli_sam_and_vcf(golden, tmp_path):
     nd, ex = sam_diff(g["sam"]["ksw2"], sam)
     assert nd == 0, ex
     assert vcf_body(vcf) == vcf_body(g["vcf"]["default"])
+
+
+def test_cli_builds_its_index_from_the_reference_fasta(golden, tmp_path):
+    """-r ref.fa (main.cpp:217, :344-349): the CLI builds the index for the run on the GPU, maps against it and removes it again.
+    The toy set's genome is the reference's test/ref.fa: SAM and VCF must be the golden run's, and nothing may stay behind in the
+    temporary directory — neither after the run nor after a run that fails once the index exists (an unreadable read file)."""
+    g = golden["toy"]
+    exe = os.path.join(ROOT, "mapcaller_amd", "mapcaller-mi355x")
+    fa = str(tmp_path / "genome.fa")
+    open(fa, "wb").write(gzip.open(os.path.join(ROOT, "tests", "golden", "toy", "genome.fa.gz"), "rb").read())
+    scratch = tmp_path / "scratch"
+    scratch.mkdir()
+    env = dict(os.environ, TMPDIR=str(scratch))
+    sam, vcf = str(tmp_path / "o.sam"), str(tmp_path / "o.vcf")
+    cmd = [exe, "-r", fa, "-f", g["r1"], "-f2", g["r2"], "-alg", "ksw2", "-sam", sam, "-vcf", vcf, "-t", "4"]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, env=env)
+    nd, ex = sam_diff(g["sam"]["ksw2"], sam)
+    assert nd == 0, ex
+    assert vcf_body(vcf) == vcf_body(g["vcf"]["default"])
+    assert os.listdir(scratch) == [], os.listdir(scratch)
+    # an error after the build: the index files are removed on that way out too
+    r = subprocess.run([exe, "-r", fa, "-f", str(tmp_path / "missing.fq"), "-sam", str(tmp_path / "x.sam"), "-no_vcf"],
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600, env=env)
+    assert r.returncode != 0, r.stderr[-500:]
+    assert os.listdir(scratch) == [], os.listdir(scratch)
+    # and a FASTA that cannot be indexed at all
+    r = subprocess.run([exe, "-r", str(tmp_path / "missing.fa"), "-f", g["r1"], "-no_vcf"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600, env=env)
+    assert r.returncode != 0
+    assert os.listdir(scratch) == [], os.listdir(scratch)
 
 
 def test_input_side_cases(api, io_golden, tmp_path):
