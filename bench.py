@@ -305,7 +305,7 @@ def other_configs(args):
           "--sub", str(args.sub), "--ins", "0.025", "--dele", "0.025", "--alg", "nw", "--cpu-pairs", "150000"]),
         ("config 2: E. coli-sized genome (4.6 Mbp, one contig), 1 M x 100 bp SE, -alg ksw2",
          ["--genome", "uniform", "--genome-mbp", "4.6", "--contigs", "1", "--repeats", "20", "--batch-pairs", "1000000", "--single-end", "1", "--rlen", "100",
-          "--sub", str(args.sub), "--ins", str(args.ins), "--dele", str(args.dele), "--alg", "ksw2", "--cpu-pairs", "1000000"]),
+          "--sub", str(args.sub), "--ins", str(args.ins), "--dele", str(args.dele), "--alg", "ksw2", "--cpu-pairs", "20000000"]),
     ]
     res = []
     for name, extra in runs:
@@ -359,7 +359,18 @@ def parse():
     return ap.parse_args()
 
 
-def _plant(codes, g, device, consensus, fam, src_off, seg_len, dst, div, chunk=1 << 26):
+def _put_last(codes, idx, val, stamp):
+    """codes[idx] = val where copies overlap one another: the LATER element of the call wins, whatever order the scatter's
+    writes land in (plain index assignment resolves duplicate indices in no fixed order, which made the genome differ from
+    process to process).  stamp: an int32 scratch tensor as long as codes."""
+    e = torch.arange(idx.numel(), device=idx.device, dtype=torch.int32)
+    stamp.index_fill_(0, idx, -1)
+    stamp.scatter_reduce_(0, idx, e, reduce="amax")
+    keep = stamp[idx] == e
+    codes[idx[keep]] = val[keep]
+
+
+def _plant(codes, g, device, consensus, fam, src_off, seg_len, dst, div, stamp, chunk=1 << 26):
     """Writes copies of family consensus sequences into the genome: copy i = consensus[fam[i]][src_off[i] : +seg_len[i]] at
     dst[i], every base substituted with probability div[i] (each copy mutates on its own)."""
     n = seg_len.numel()
@@ -377,7 +388,7 @@ def _plant(codes, g, device, consensus, fam, src_off, seg_len, dst, div, chunk=1
         val = consensus[fam[sl][seg], src_off[sl][seg] + within]
         mut = torch.rand(m, generator=g, device=device) < div[sl][seg]
         val = torch.where(mut, (val + torch.randint(1, 4, (m,), generator=g, device=device, dtype=torch.uint8)) % 4, val)
-        codes[dst[sl][seg] + within] = val
+        _put_last(codes, dst[sl][seg] + within, val, stamp)
         lo_seg = hi_seg
     return total
 
@@ -396,6 +407,7 @@ def make_genome(args, device, seed):
     lens = (lens // 4 * 4).clamp_(min=10000)
     G = int(lens.sum())
     codes = torch.randint(0, 4, (G,), generator=g, device=device, dtype=torch.uint8)
+    stamp = torch.empty(G, dtype=torch.int32, device=device)  # (_put_last's scratch: 4 B per base, freed on return)
     if args.genome == "uniform":
         if args.repeats:
             rl = 1000
@@ -407,7 +419,7 @@ def make_genome(args, device, seed):
                 u = units.clone()
                 m = torch.rand(u.shape, generator=g, device=device) < 0.01
                 u = torch.where(m, (u + torch.randint(1, 4, u.shape, generator=g, device=device, dtype=torch.uint8)) % 4, u)
-                codes[(dst[:, k][:, None] + ar[None, :]).reshape(-1)] = u.reshape(-1)
+                _put_last(codes, (dst[:, k][:, None] + ar[None, :]).reshape(-1), u.reshape(-1), stamp)
         return codes, [int(x) for x in lens], f"uniform random, {args.repeats} x4 1-kb repeat families at 1 % divergence"
 
     def rnd(n):
@@ -415,7 +427,7 @@ def make_genome(args, device, seed):
 
     def place(consensus, fam, src_off, seg_len, div):
         dst = (rnd(seg_len.numel()) * (G - int(seg_len.max()) - 1)).long()
-        return _plant(codes, g, device, consensus, fam, src_off, seg_len, dst, div)
+        return _plant(codes, g, device, consensus, fam, src_off, seg_len, dst, div, stamp)
 
     planted = {}
     # (a) segmental duplications first (later, younger repeats land inside them too): 10-50 kb blocks copied 1-4 times at 1-3 %
@@ -437,7 +449,7 @@ def make_genome(args, device, seed):
         val = codes[src[seg[sl]][s2] + within]
         mut = rnd(m) < (0.01 + 0.02 * rnd(ln.numel()))[s2]
         val = torch.where(mut, (val + torch.randint(1, 4, (m,), generator=g, device=device, dtype=torch.uint8)) % 4, val)
-        codes[dst[sl][s2] + within] = val
+        _put_last(codes, dst[sl][s2] + within, val, stamp)
         tot += m
     planted["segmental duplications, 10-50 kb x1-4 at 1-3 %"] = tot
     # (b) families over a spectrum of copy numbers: 3 .. 300 copies (log-uniform), 1-3 kb, 2-10 % from the consensus
@@ -478,7 +490,7 @@ def make_genome(args, device, seed):
         val = ucons[sl][s2, within % unit[sl][s2]]
         mut = rnd(m) < (0.05 * rnd(ln.numel()))[s2]
         val = torch.where(mut, (val + torch.randint(1, 4, (m,), generator=g, device=device, dtype=torch.uint8)) % 4, val)
-        codes[dst[sl][s2] + within] = val
+        _put_last(codes, dst[sl][s2] + within, val, stamp)
         tot += m
     planted["tandem repeats / low complexity"] = tot
     frac = sum(planted.values()) / G
@@ -500,8 +512,11 @@ def make_reads(codes, lens, n_pairs, rlen, seed, device, sub=0.005, ins=0.001, d
 
 
 def cpu_baseline(args, index, bases_sample):
-    """The CPU path on this box's host cores, on a bounded sample of the same workload, index
-    load excluded (the reference starts its clock after loading, main.cpp:376)."""
+    """The CPU path on this box's host cores, on a bounded sample of the same workload, index load excluded (the reference
+    starts its clock after loading, main.cpp:376).  Two runs at -t <all cores>: with `-sam <file>` (the reference then formats
+    every line and pushes it through fprintf under its OutputLock, ReadMapping.cpp:536-560 — at hundreds of threads that lock,
+    not the mapping, sets the rate) and without any output (`-no_vcf`, no `-sam`: bSAMoutput stays false, :536 is skipped) —
+    `mapping_only`, the like-for-like figure beside `value`, which times kernels and writes no text either."""
     from mapcaller_amd import synth
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "MapCaller")
     port_bin = os.path.join(ROOT, "oracle", "mcx_oracle")
@@ -521,8 +536,9 @@ def cpu_baseline(args, index, bases_sample):
             synth.write_fastq(t2, bases_sample[:400], 1, 2)
         if os.path.exists(ref_bin):
             kind = "reference"
-            def run(a, b, threads=cores):
-                cmd = [ref_bin, "-i", prefix, "-f", a] + ([] if se else ["-f2", b]) + ["-alg", args.alg, "-sam", os.path.join(tmp, "o.sam"), "-no_vcf", "-t", str(threads), "-log", os.path.join(tmp, "job.log")]
+            def run(a, b, threads=cores, sam=True):
+                cmd = [ref_bin, "-i", prefix, "-f", a] + ([] if se else ["-f2", b]) + ["-alg", args.alg] + (["-sam", os.path.join(tmp, "o.sam")] if sam else []) + \
+                      ["-no_vcf", "-t", str(threads), "-log", os.path.join(tmp, "job.log")]
                 t0 = time.perf_counter()
                 r = subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
                 wall = time.perf_counter() - t0
@@ -531,22 +547,30 @@ def cpu_baseline(args, index, bases_sample):
                 return wall, (int(m[-1]) if m else None)
         elif os.path.exists(port_bin):
             kind = "port"
-            def run(a, b):
-                cmd = [port_bin, "-i", prefix, "-f", a] + ([] if se else ["-f2", b]) + ["-alg", args.alg, "-sam", os.path.join(tmp, "o.sam"), "-t", str(cores)]
+            def run(a, b, threads=cores, sam=True):
+                cmd = [port_bin, "-i", prefix, "-f", a] + ([] if se else ["-f2", b]) + ["-alg", args.alg, "-sam", os.path.join(tmp, "o.sam") if sam else "/dev/null", "-t", str(threads)]
                 t0 = time.perf_counter()
                 subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
                 return time.perf_counter() - t0, None
         else:
             return None
-        t_full, own = run(f1, f2)
-        if own is not None and own >= 3:
-            dt, how = float(own), f"the reference's own clock (starts after the index load): {own} s of {t_full:.1f} s wall"
-        else:
-            t_load, _ = run(t1, t2)    # 200 pairs: index load + start-up
-            dt, how = max(t_full - t_load, 1e-3), f"wall {t_full:.1f}s minus {t_load:.1f}s index load"
-        out = {"value": round(step * n_pairs / dt, 1), "unit": "reads/s", "cores": cores, "kind": kind,
-               "sample": f"{n_pairs} {'reads' if se else 'pairs'} x {args.rlen} bp of the same synthetic workload, -t {cores} -alg {args.alg} -sam (file) -no_vcf; {how}"}
-        if kind == "reference":  # SURVEY 8d also asks for -t 1: a smaller sample, the reference's own clock again
+        t_load, _ = run(t1, t2, sam=False)    # 200 pairs: index load + start-up (what a wall clock has to be corrected by)
+
+        def rate(sam):
+            t_full, own = run(f1, f2, sam=sam)
+            if own is not None and own >= 10:  # (whole seconds: only a long run can be read off it)
+                dt, how = float(own), f"the reference's own clock (starts after the index load): {own} s of {t_full:.1f} s wall"
+            else:
+                dt, how = max(t_full - t_load, 1e-3), f"wall {t_full:.2f} s minus {t_load:.2f} s of index load and start-up" + (f" (its own clock: {own} s)" if own is not None else "")
+            return round(step * n_pairs / dt, 1), how
+        v_sam, how_sam = rate(True)
+        what = f"{n_pairs} {'reads' if se else 'pairs'} x {args.rlen} bp of the same synthetic workload, -t {cores} -alg {args.alg}"
+        out = {"value": v_sam, "unit": "reads/s", "cores": cores, "kind": kind, "sample": f"{what} -sam (file) -no_vcf; {how_sam}"}
+        if kind == "reference":
+            v_map, how_map = rate(False)
+            out["mapping_only"] = {"value": v_map, "unit": "reads/s", "cores": cores,
+                                   "sample": f"{what} -no_vcf and no -sam: mapping alone, no SAM text (ReadMapping.cpp:536 skipped); {how_map}"}
+            # SURVEY 8d also asks for -t 1: a smaller sample, the reference's own clock again
             n1 = min(n_pairs, 75_000)
             s1, s2 = os.path.join(tmp, "s1.fq"), os.path.join(tmp, "s2.fq")
             synth.write_fastq(s1, bases_sample[:step * n1], 0, step)
@@ -555,7 +579,7 @@ def cpu_baseline(args, index, bases_sample):
             _, own1 = run(s1, s2, threads=1)
             if own1:
                 out["single_thread"] = {"value": round(step * n1 / own1, 1), "unit": "reads/s", "cores": 1,
-                                        "sample": f"{n1} pairs, -t 1, the reference's own clock: {own1} s"}
+                                        "sample": f"{n1} {'reads' if se else 'pairs'}, -t 1, -sam (file), the reference's own clock: {own1} s"}
         return out
 
 
@@ -677,7 +701,19 @@ def main():
     cpu_pairs = args.cpu_pairs
     if cpu_pairs < 0:  # ~20 s at ~15 k reads/s/core, bounded by one batch
         cpu_pairs = int(min(args.batch_pairs, max(50_000, (os.cpu_count() or 1) * 15_000 * 20 // 2)))
-    sample = batches[0].reshape(reads_per_step, args.rlen)[: (2 if paired else 1) * cpu_pairs].cpu() if (rank == 0 and world == 1 and cpu_pairs) else None
+    sample = None
+    if rank == 0 and world == 1 and cpu_pairs:
+        per = 2 if paired else 1
+        parts = [batches[0].reshape(reads_per_step, args.rlen)[: per * cpu_pairs].cpu()]
+        have = parts[0].shape[0] // per
+        k = 0
+        while have < cpu_pairs:  # (a sample larger than a batch — config 2's million reads are a third of a second of CPU work: further batches of the same kind)
+            m = min(args.batch_pairs, cpu_pairs - have)
+            parts.append(make_reads(codes, lens, m, args.rlen, seed=900_000 + k, device=dev, sub=args.sub, ins=args.ins, dele=args.dele, paired=paired).reshape(per * m, args.rlen).cpu())
+            have += m
+            k += 1
+        sample = torch.cat(parts) if len(parts) > 1 else parts[0]
+        del parts
     del codes
     d_aln = torch.empty(reads_per_step * 64, dtype=torch.uint8, device=dev)
     d_cig = torch.empty(api.cigar_pool_words(reads_per_step), dtype=torch.int32, device=dev)

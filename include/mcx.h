@@ -111,6 +111,7 @@ typedef struct mcx_stats {
     int64_t tier1_pairs;    /* pairs re-run with the large capacities */
     int64_t replayed_pairs; /* pairs re-run because the avgDist trajectory moved past their validity interval */
     int64_t halved_selections; /* times a selection of pairs was mapped in two halves because a work list ran over */
+    int64_t simple_pairs;   /* pairs (reads, single-end) that went from their seeds to their records on the straight-line path (k_simple) */
     double ms_encode /* k_pack_reads */, ms_seed, ms_sa, ms_cluster, ms_rescue, ms_build, ms_dp, ms_finish, ms_total;
 } mcx_stats;
 

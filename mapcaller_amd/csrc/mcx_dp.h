@@ -14,6 +14,7 @@
 #ifndef MCX_DP_H
 #define MCX_DP_H
 #include "mcx_glue.h"
+#include "mcx_dp_lane.h"
 
 namespace mcx {
 
@@ -53,41 +54,6 @@ static __device__ __forceinline__ void dp_sync()
 }
 
 struct DpBuf { uint8_t *q, *t, *dir; };
-
-// The traceback lane fills the problem's DpSummary on its way from the last column to the first (out null: no summary).
-struct DpSumAcc {
-    DpSummary *out;
-    int n, mis, switches, cur, run, n_rle, pd, pi, pr, td, ti, tr;
-    bool seen_m;
-    __device__ void begin(DpSummary *o) { out = o; n = mis = switches = run = n_rle = pd = pi = pr = td = ti = tr = 0; cur = -1; seen_m = false; }
-    __device__ void flush()
-    {
-        if (run > 0) { if (n_rle < kDpRle) out->rle[kDpRle - 1 - n_rle] = ((uint32_t)run << 4) | (uint32_t)cur; n_rle++; }
-    }
-    // k: 0 'M', 1 'I', 2 'D' (the CIGAR codes); differ: an 'M' column over two different bases
-    __device__ void put(int k, int differ)
-    {
-        if (!out) return;
-        if (k != cur) { flush(); cur = k; run = 0; switches++; if (k) pr++; }
-        run++;
-        if (k == 0) {
-            n++; mis += differ;
-            if (!seen_m) { td = pd; ti = pi; tr = pr; seen_m = true; } // what came before the walk's first 'M' is the string's tail
-            pd = pi = pr = 0;
-        } else if (k == 2) pd++; else pi++;
-    }
-    __device__ void end(uint32_t cols_off, int cols_len)
-    {
-        if (!out) return;
-        flush();
-        if (!seen_m) { td = pd; ti = pi; tr = pr; }
-        out->cols_off = cols_off; out->cols_len = (uint16_t)cols_len;
-        out->n = (uint16_t)n; out->mis = (uint16_t)mis; out->switches = (uint16_t)switches;
-        out->lead_d = (uint16_t)pd; out->lead_i = (uint16_t)pi; out->lead_runs = (uint16_t)pr; // what is pending at the string's start is its head
-        out->tail_d = (uint16_t)td; out->tail_i = (uint16_t)ti; out->tail_runs = (uint16_t)tr;
-        out->n_rle = n_rle <= kDpRle ? (uint16_t)n_rle : (uint16_t)0xFFFF;
-    }
-};
 
 // where a (qlen x tlen) problem keeps its sequences and traceback: LDS when it fits
 // (lds holds lds_seq bytes for the two sequences followed by lds_dir bytes of traceback)
@@ -324,7 +290,7 @@ constexpr int kDpSmallLds = 64 + (kDpSmallQ + kDpSmallT - 1) * kDpSmallT; // q(3
 
 // the job lists of the DP stage: dp_class 0..3 + 4: the tiny ones of class 0 (k_dp_tiny), 5: the short ones of class 1 (k_dp_half)
 constexpr int kDpClasses = 6;
-struct JobSinks { JobSink s[kDpClasses]; };
+struct JobSinks { JobSink s[kDpClasses]; uint32_t *unsupported; };
 static __device__ __forceinline__ int job_class(const DpJob &j)
 {
     const int c = dp_class(j.rLen, j.gLen);

@@ -27,6 +27,7 @@
 
 #include "../../include/mcx.h"
 #include "mcx_dp.h"
+#include "mcx_simple.h"
 #include "mcx_profile.h"
 #include <hipcub/hipcub.hpp>
 #include "mcx_internal.h"
@@ -648,15 +649,16 @@ constexpr int kCntPad = 64;
 constexpr int kWorkClasses = 6;
 static __device__ __forceinline__ int work_class(uint32_t hits) { return hits > 64 ? 0 : hits > 32 ? 1 : hits > 16 ? 2 : hits > 8 ? 3 : hits > 4 ? 4 : 5; }
 
-static __device__ __forceinline__ int pair_work_class(const PairSel &sel, uint32_t local, const uint32_t *read_blocks, int nr)
+static __device__ __forceinline__ int pair_work_class(const PairSel &sel, uint32_t local, const uint32_t *read_blocks, int nr, const uint8_t *done = nullptr)
 {
+    if (done && done[local]) return -1; // k_simple took the pair from its seeds to its records: no lane of the per-pair kernels for it
     const uint32_t pair = sel_pair(sel, local);
     return work_class((read_blocks[pair * nr] >> 20) + (nr == 2 ? read_blocks[pair * nr + 1] >> 20 : 0u));
 }
 
 constexpr int kOrderTile = 16; // pairs per thread of the two passes: a block of 256 settles 4096 pairs with one global atomic per class
 
-__global__ void __launch_bounds__(256) k_order_count(PairSel sel, const uint32_t *read_blocks, int nr, uint32_t *counts)
+__global__ void __launch_bounds__(256) k_order_count(PairSel sel, const uint32_t *read_blocks, int nr, uint32_t *counts, const uint8_t *done)
 {
     __shared__ uint32_t n_cls[kWorkClasses];
     if (threadIdx.x < kWorkClasses) n_cls[threadIdx.x] = 0u;
@@ -664,7 +666,7 @@ __global__ void __launch_bounds__(256) k_order_count(PairSel sel, const uint32_t
     const uint32_t base = blockIdx.x * (256u * kOrderTile);
     for (int t = 0; t < kOrderTile; t++) {
         const uint32_t local = base + t * 256u + threadIdx.x;
-        const int cls = local < sel.n ? pair_work_class(sel, local, read_blocks, nr) : -1;
+        const int cls = local < sel.n ? pair_work_class(sel, local, read_blocks, nr, done) : -1;
 #pragma unroll
         for (int k = 0; k < kWorkClasses; k++) {
             const uint64_t m = __ballot(cls == k);
@@ -676,7 +678,7 @@ __global__ void __launch_bounds__(256) k_order_count(PairSel sel, const uint32_t
 }
 
 // counts[k * kCntPad]: pairs of class k; counts[(8 + k) * kCntPad]: how many of them were placed so far
-__global__ void __launch_bounds__(256) k_order_place(PairSel sel, const uint32_t *read_blocks, int nr, uint32_t *counts, uint32_t *order)
+__global__ void __launch_bounds__(256) k_order_place(PairSel sel, const uint32_t *read_blocks, int nr, uint32_t *counts, uint32_t *order, const uint8_t *done)
 {
     __shared__ uint32_t n_cls[kWorkClasses], at_cls[kWorkClasses];
     if (threadIdx.x < kWorkClasses) n_cls[threadIdx.x] = 0u;
@@ -687,7 +689,7 @@ __global__ void __launch_bounds__(256) k_order_place(PairSel sel, const uint32_t
 #pragma unroll
     for (int t = 0; t < kOrderTile; t++) {
         const uint32_t local = base + t * 256u + threadIdx.x;
-        cls[t] = local < sel.n ? pair_work_class(sel, local, read_blocks, nr) : -1;
+        cls[t] = local < sel.n ? pair_work_class(sel, local, read_blocks, nr, done) : -1;
 #pragma unroll
         for (int k = 0; k < kWorkClasses; k++) {
             const uint64_t m = __ballot(cls[t] == k);
@@ -716,12 +718,76 @@ __global__ void __launch_bounds__(256) k_order_place(PairSel sel, const uint32_t
     }
 }
 
-__global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl, const uint32_t *read_blocks, EarlyList el, const uint32_t *order)
+// The straight-line pairs of a pass, from their seeds to their records (mcx_simple.h): one pair per lane, in pair order (their
+// work is even: no dealing by weight, and neighbouring lanes write neighbouring records).  What a lane needs — at most four
+// seeds per read, the 2-bit words of its reads, a few words of the genome under the gaps — stays in registers; the CIGAR
+// operations wait word-major in LDS until the wave has reserved its words of the pool with one atomic.  done[pair] tells the
+// per-pair kernels behind this one which pairs are left to them (k_order_*).
+__global__ void __launch_bounds__(256) k_simple(Ctx cx, ReadBatch rb, uint32_t n_pairs, const int32_t *est, const uint32_t *read_blocks, AlnRec *recs, PairOut *pout,
+                                                uint8_t *done, uint32_t *pool_over, uint32_t *n_done)
 {
     __shared__ EndsLds ends;
+    __shared__ uint32_t cig_stage[256 * 2 * kSimpleRuns]; // word k of thread t at [k * 256 + t]
+    stage_ends(cx.ix, ends);
+    const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nr = cx.pm.paired ? 2 : 1;
+    uint32_t *stage = cig_stage + threadIdx.x;
+    bool ok = pair < n_pairs;
+    SimpleRead sr[2];
+    int rl[2] = {0, 0};
+    if (ok) {
+        const PairState st = pair_state(cx.state, cx.lay, cx.caps, pair);
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            if (s >= nr || !ok) break;
+            const uint32_t r = pair * nr + s;
+            const int nh = (int)(read_blocks[r] >> 20);
+            rl[s] = (int)(rb.off[r + 1] - rb.off[r]);
+            ok = nh >= 1 && nh <= kSimpleHits && !(cx.read_ext[r] >> 31) &&
+                 simple_read(cx.ix, cx.pm, rl[s], cx.packed + (uint64_t)r * cx.wpad, st.hits[s], nh, sr[s], stage + s * kSimpleRuns * 256, 256);
+        }
+        if (ok && nr == 2) ok = simple_pair_ok(sr[0], sr[1], est[pair]);
+    }
+    const uint32_t want = ok ? (uint32_t)sr[0].n_cig + (nr == 2 ? (uint32_t)sr[1].n_cig : 0u) : 0u;
+    const uint32_t at = wave_reserve(cx.cig_pool_n, want);
+    const uint64_t took = __ballot(ok);
+    if ((threadIdx.x & 63) == 0 && took) atomicAdd(n_done, (uint32_t)__popcll(took));
+    if (pair >= n_pairs) return;
+    if (ok && at + want > cx.cig_pool_cap) { atomicOr(pool_over, 1u); ok = false; } // (the batch fails; the general path reports it)
+    done[pair] = ok ? 1 : 0;
+    if (!ok) return;
+    const uint32_t off[2] = {at, at + (uint32_t)sr[0].n_cig};
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        if (s >= nr) break;
+        for (int k = 0; k < sr[s].n_cig; k++) cx.cig_pool[off[s] + k] = stage[(s * kSimpleRuns + k) * 256];
+    }
+    AlnRec rec2[2];
+    PairOut po;
+    simple_pair(cx, nr == 2, sr[0], sr[nr - 1], rl[0], rl[nr - 1], est[pair], rec2, off, po);
+    recs[(uint64_t)pair * nr] = rec2[0];
+    if (nr == 2) recs[(uint64_t)pair * nr + 1] = rec2[1];
+    pout[pair] = po;
+}
+
+// pairs the per-pair kernels work on: all of the selection, or — with k_simple ahead of them — those the order lists (its class counts)
+static __device__ __forceinline__ uint32_t listed_pairs(const PairSel &sel, const uint32_t *order_cnt)
+{
+    if (!order_cnt) return sel.n;
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < kWorkClasses; k++) n += order_cnt[k * kCntPad];
+    return n;
+}
+
+__global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl, const uint32_t *read_blocks, EarlyList el, const uint32_t *order,
+                                                 const uint32_t *order_cnt)
+{
+    __shared__ EndsLds ends;
+    if (blockIdx.x * blockDim.x >= listed_pairs(sel, order_cnt)) return; // (uniform over the block)
     stage_ends(cx.ix, ends);
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = slot < sel.n;
+    const bool in = slot < listed_pairs(sel, order_cnt);
     const uint32_t local = in ? (order ? order[slot] : slot) : 0u;
     uint32_t need = 0, over = 0;
     if (in) {
@@ -1197,12 +1263,13 @@ __global__ void __launch_bounds__(256) k_rescue_apply(Ctx cx, RescueWork rw)
 #define MCX_BUILD_WAVES 5
 #endif
 __global__ void __launch_bounds__(256, MCX_BUILD_WAVES) k_build(Ctx cx, ReadBatch rb, PairSel sel, JobSinks sinks, uint32_t *cells, uint32_t *unsupported, EarlyList late,
-                                               const uint32_t *order)
+                                               const uint32_t *order, const uint32_t *order_cnt)
 {
     __shared__ EndsLds ends;
+    if (blockIdx.x * blockDim.x >= listed_pairs(sel, order_cnt)) return; // (uniform over the block)
     stage_ends(cx.ix, ends);
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = slot < sel.n;
+    const bool in = slot < listed_pairs(sel, order_cnt);
     const uint32_t local = in ? (order ? order[slot] : slot) : 0u;
     int nj = 0;
     uint32_t fl = 0;
@@ -1359,9 +1426,61 @@ __global__ void __launch_bounds__(64) k_dp_group(Ctx cx, JobSink sink, ReadBatch
     }
 }
 
+constexpr int kDpHalfT = 32, kDpHalfQ = 64, kDpHalfLds = kDpHalfQ + kDpHalfT + (kDpHalfQ + kDpHalfT - 1) * kDpHalfT + 32;
+// One problem per LANE (mcx_dp_lane.h): a wavefront takes 64 problems of its list at a time; the group's words (queries, strip
+// edges, packed traceback flags) lie lane-interleaved in the wavefront's stretch of scratch, laid out for the group's longest
+// query and widest target, so that every store and load of the sweep is one line per 16 lanes.  order: the list's problems by
+// size (null: as listed), so that the 64 of a group finish together.
+template <int K, bool NW>
+__global__ void __launch_bounds__(64) k_dp_lane(Ctx cx, JobSink sink, const uint32_t *order, ReadBatch rb, PairSel sel, uint32_t *scratch, uint64_t stride_words, uint32_t *unsupported)
+{
+    const uint32_t n = min(*sink.count, sink.cap);
+    const int lane = threadIdx.x;
+    const int nr = cx.pm.paired ? 2 : 1;
+    LaneMem mem; mem.base = scratch + (uint64_t)blockIdx.x * stride_words + lane; mem.stride = 64;
+    for (uint32_t g0 = blockIdx.x * 64u; g0 < n; g0 += gridDim.x * 64u) {
+        const uint32_t jb = g0 + (uint32_t)lane;
+        const bool have = jb < n;
+        const uint32_t at = have ? (order ? order[jb] : jb) : 0u;
+        DpJob job;
+        if (have) job = sink.jobs[at]; else { job.rLen = 0; job.gLen = 0; }
+        int rows = job.rLen, strips = (job.gLen + K - 1) / K;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { rows = max(rows, __shfl_xor(rows, o, 64)); strips = max(strips, __shfl_xor(strips, o, 64)); }
+        const LaneLayout l = lane_layout<K, NW>(rows, strips);
+        if ((uint64_t)l.words * 64u > stride_words) { if (lane == 0) atomicAdd(unsupported, 1u); continue; } // (cannot happen: the lists' size limits are the strides')
+        if (!have) continue;
+        const uint32_t read = sel_pair(sel, job.pair) * nr + job.slot;
+        ReadRef rd;
+        rd.ascii = rb.bases + rb.off[read]; rd.rlen = (int)(rb.off[read + 1] - rb.off[read]); rd.flipped = (cx.pm.paired && job.slot == 1) ? 1 : 0;
+        rd.codes = (cx.packed && !(cx.read_ext[read] >> 31)) ? cx.packed + (uint64_t)read * cx.wpad : nullptr;
+        sink.jobs[at].score = lane_dp_job<K, NW>(cx, mem, l, job, rd);
+    }
+}
+
+// the three short lists (job_class): tiny <= 8 x 8 in strips of 8; small: targets <= 16, queries <= 32; half: targets <= 32, queries <= 64
+static uint64_t lane_short_words(int which) // ksw2's flags take more words than nw's: sized for them
+{
+    return which == 0 ? 64ull * lane_layout<8, false>(kDpTiny, 1).words : which == 1 ? 64ull * lane_layout<16, false>(kDpSmallQ, 1).words : 64ull * lane_layout<16, false>(kDpHalfQ, 2).words;
+}
+
+// words a wavefront's stretch of scratch must hold for a list whose problems have at most `rows` query bases and `strips` strips
+template <int K>
+static uint64_t lane_stride_words(bool nw, int rows, int strips)
+{
+    return 64ull * (nw ? lane_layout<K, true>(rows, strips).words : lane_layout<K, false>(rows, strips).words);
+}
+
+template <int K>
+static void launch_dp_lane(bool nw, unsigned blocks, hipStream_t s, const Ctx &cx, const JobSink &sink, const uint32_t *order, const ReadBatch &rb, const PairSel &sel,
+                           uint32_t *scratch, uint64_t stride_words, uint32_t *unsupported)
+{
+    if (nw) k_dp_lane<K, true><<<blocks, 64, 0, s>>>(cx, sink, order, rb, sel, scratch, stride_words, unsupported);
+    else k_dp_lane<K, false><<<blocks, 64, 0, s>>>(cx, sink, order, rb, sel, scratch, stride_words, unsupported);
+}
+
 // targets <= 32 (queries <= 64) of the one-column-per-lane class: two problems per wave, 32 lanes each — the
 // class is bound by vector instructions issued, and most of its targets are that short
-constexpr int kDpHalfT = 32, kDpHalfQ = 64, kDpHalfLds = kDpHalfQ + kDpHalfT + (kDpHalfQ + kDpHalfT - 1) * kDpHalfT + 32;
 
 __global__ void __launch_bounds__(256) k_dp_half(Ctx cx, JobSink sink, ReadBatch rb, PairSel sel)
 {
@@ -1422,14 +1541,15 @@ __global__ void __launch_bounds__(256) k_dp_small(Ctx cx, JobSink sink, ReadBatc
 #define MCX_FINISH_WAVES 5
 #endif
 __global__ void __launch_bounds__(256, MCX_FINISH_WAVES) k_finish(Ctx cx, ReadBatch rb, PairSel sel, AlnRec *recs, PairOut *pout, uint32_t *ov_ids, uint32_t *n_ov,
-                                                uint32_t ov_cap, uint32_t *pool_over, const uint32_t *order)
+                                                uint32_t ov_cap, uint32_t *pool_over, const uint32_t *order, const uint32_t *order_cnt)
 {
     __shared__ EndsLds ends;
     __shared__ uint32_t cig_stage[256 * 2 * kCigStage]; // the first operations of every read, word-major: word k of thread t at [k * 256 + t] (neighbouring lanes, neighbouring banks)
+    if (blockIdx.x * blockDim.x >= listed_pairs(sel, order_cnt)) return; // (uniform over the block)
     stage_ends(cx.ix, ends);
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t *stage = cig_stage + threadIdx.x;
-    const bool active = slot < sel.n; // (no early exit: the wave reserves its CIGAR words together)
+    const bool active = slot < listed_pairs(sel, order_cnt); // (no early exit within a wave: it reserves its CIGAR words together)
     const uint32_t local = active ? (order ? order[slot] : slot) : 0u;
     const int nr = cx.pm.paired ? 2 : 1;
     uint32_t pair = 0;
@@ -1479,7 +1599,7 @@ constexpr uint32_t kPoutSel = 1u << 16; // pair outcomes gathered per copy (run_
 enum { CNT_TASKS = 0, CNT_RESCUE = 1 * kCntPad, CNT_JOB0 = 2 * kCntPad, CNT_JOB1 = 3 * kCntPad, CNT_JOB2 = 4 * kCntPad, CNT_JOB3 = 5 * kCntPad,
        CNT_JOB4 = 6 * kCntPad, CNT_JOB5 = 7 * kCntPad, CNT_OV = 8 * kCntPad, CNT_LF = 9 * kCntPad, CNT_CELLS = 10 * kCntPad, CNT_UNSUP = 11 * kCntPad,
        CNT_QUEUE = 12 * kCntPad, CNT_EARLY = 13 * kCntPad, CNT_LATE = 14 * kCntPad, CNT_RTASK = 15 * kCntPad, CNT_RPLAN = 16 * kCntPad, CNT_RESCUE_N = 17 * kCntPad, CNT_RSEED = 18 * kCntPad,
-       CNT_N = 19 * kCntPad };
+       CNT_SIMPLE = 19 * kCntPad, CNT_N = 20 * kCntPad };
 constexpr uint32_t kLateRoom = 256; // pairs of a pass that may run over after clustering and still go through the large tier beside it
 
 // What a pass over a selection of pairs works with besides the pair records: stream, counters, work lists, DP scratch.
@@ -1495,6 +1615,7 @@ struct PassRes {
     RescueTask *d_rtasks = nullptr; RescueRes *d_rres = nullptr; Hit *d_rseeds = nullptr; RescuePlan *d_rplans = nullptr; uint32_t *d_rescue_n = nullptr; // mate rescue window by window
     uint32_t rtask_cap = 0, rseed_cap = 0;
     uint8_t *d_dp_scratch[3] = {nullptr, nullptr, nullptr}; uint64_t dp_stride[3] = {0, 0, 0}; uint32_t dp_blocks[3] = {0, 0, 0};
+    uint32_t *d_dp_lane = nullptr; uint32_t dp_lane_blocks = 0; // k_dp_lane's words for the three short lists (tiny | small | half), dp_lane_blocks wavefronts each
     hipStream_t dp_stream[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t dp_fork = nullptr, dp_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t *d_ov = nullptr; uint32_t ov_cap = 0;
     uint32_t *d_sel_ids = nullptr; int32_t *d_est = nullptr;
@@ -1534,11 +1655,13 @@ struct mcx_ctx {
     hipEvent_t ev_pack[2] = {nullptr, nullptr};
     hipStream_t dp_stream[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t dp_fork = nullptr, dp_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     uint8_t *d_dp_scratch[3] = {nullptr, nullptr, nullptr}; uint64_t dp_stride[3] = {0, 0, 0}; uint32_t dp_blocks[3] = {0, 0, 0};
+    uint32_t *d_dp_lane = nullptr; uint32_t dp_lane_blocks = 0;
     uint32_t *d_ov = nullptr; uint32_t ov_cap = 0;
     uint32_t *d_sel_ids = nullptr; int32_t *d_est = nullptr;
     uint32_t *d_read_ext = nullptr, *d_read_blocks = nullptr;
     uint32_t *d_packed = nullptr; int wpad = 0; // 2-bit form of the batch's reads
     uint32_t *d_order = nullptr, *d_order_cnt = nullptr; // the pairs of a pass by weight (k_order_*)
+    uint8_t *d_done = nullptr;                           // per pair of a pass: k_simple wrote its records (the per-pair kernels skip it)
     PairOut *d_pout = nullptr, *d_pout_sel = nullptr; // per-pair outcome of the finish stage; a gathered selection of it
     uint8_t *d_mapq = nullptr; int mapq_rows = 0;
     // -vcf bookkeeping (mcx_profile.h): caller-owned counter planes, per-read alignment detail
@@ -1681,6 +1804,8 @@ static int passres_alloc(mcx_ctx *c, PassRes &t, uint64_t pairs, uint64_t sel_ca
         t.dp_stride[k] = c->dp_stride[k]; t.dp_blocks[k] = blocks1[k];
         if ((rc = dmalloc(&t.d_dp_scratch[k], (size_t)t.dp_stride[k] * t.dp_blocks[k]))) return rc;
     }
+    t.dp_lane_blocks = pairs >= 4096 ? 2048u : 256u;
+    if ((rc = dmalloc(&t.d_dp_lane, (size_t)(lane_short_words(0) + lane_short_words(1) + lane_short_words(2)) * t.dp_lane_blocks))) return rc;
     t.ov_cap = (uint32_t)sel_cap;
     if ((rc = dmalloc(&t.d_ov, t.ov_cap))) return rc;
     if ((rc = dmalloc(&t.d_sel_ids, sel_cap))) return rc;
@@ -1691,7 +1816,7 @@ static int passres_alloc(mcx_ctx *c, PassRes &t, uint64_t pairs, uint64_t sel_ca
 static void passres_free(PassRes &t)
 {
     void *q[] = {t.d_cnt, t.d_jobs[0], t.d_jobs[1], t.d_jobs[2], t.d_jobs[3], t.d_jobs[4], t.d_jobs[5], t.d_rescue, t.d_dp_scratch[0], t.d_dp_scratch[1],
-                 t.d_dp_scratch[2], t.d_ov, t.d_sel_ids, t.d_est, t.d_rtasks, t.d_rres, t.d_rseeds, t.d_rplans, t.d_rescue_n};
+                 t.d_dp_scratch[2], t.d_ov, t.d_sel_ids, t.d_est, t.d_rtasks, t.d_rres, t.d_rseeds, t.d_rplans, t.d_rescue_n, t.d_dp_lane};
     for (void *x : q) if (x) (void)hipFree(x);
     if (t.h_cnt) (void)hipHostFree(t.h_cnt);
     for (auto &e : t.ev) if (e) (void)hipEventDestroy(e);
@@ -1744,6 +1869,8 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
         c->dp_stride[k] = spill[k]; c->dp_blocks[k] = blocks[k];
         if ((rc = dmalloc(&c->d_dp_scratch[k], (size_t)spill[k] * blocks[k]))) return rc;
     }
+    c->dp_lane_blocks = 4096;
+    if ((rc = dmalloc(&c->d_dp_lane, (size_t)(lane_short_words(0) + lane_short_words(1) + lane_short_words(2)) * c->dp_lane_blocks))) return rc;
     c->ov_cap = (uint32_t)c->max_reads;
     if ((rc = dmalloc(&c->d_ov, c->ov_cap))) return rc;
     if ((rc = dmalloc(&c->d_sel_ids, c->max_reads))) return rc;
@@ -1758,6 +1885,7 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     if ((rc = dmalloc(&c->d_pout_sel, kPoutSel))) return rc;
     if ((rc = dmalloc(&c->d_order, c->max_reads))) return rc;
     if ((rc = dmalloc(&c->d_order_cnt, 16 * kCntPad))) return rc;
+    if ((rc = dmalloc(&c->d_done, c->max_reads))) return rc;
     // EvaluateMAPQ (SamReport.cpp:86-101) tabulated on the host so that the double-precision
     // log() is the host libm's, exactly as in the reference
     c->mapq_rows = c->rlen_max + 64;
@@ -1802,7 +1930,7 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3], c->d_jobs[4], c->d_jobs[5],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_rtasks, c->d_rres, c->d_rseeds, c->d_rplans, c->d_rescue_n, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
                  c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
-                 c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_pout_sel, c->d_order, c->d_order_cnt, c->d_packed, c->d_batch_flags, c->d_scan_tmp, c->d_prof_match, c->d_prof_items};
+                 c->d_dp_lane, c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_pout_sel, c->d_order, c->d_order_cnt, c->d_done, c->d_packed, c->d_batch_flags, c->d_scan_tmp, c->d_prof_match, c->d_prof_items};
     for (void *q : p) if (q) (void)hipFree(q);
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
     if (c->h_keys) (void)hipHostFree(c->h_keys);
@@ -1854,6 +1982,7 @@ static PassRes res_tier0(mcx_ctx *c)
     r.d_rescue = c->d_rescue; r.rescue_cap = c->rescue_cap; r.d_kscratch = c->d_kscratch;
     r.d_rtasks = c->d_rtasks; r.d_rres = c->d_rres; r.d_rseeds = c->d_rseeds; r.d_rplans = c->d_rplans; r.d_rescue_n = c->d_rescue_n; r.rtask_cap = c->rtask_cap; r.rseed_cap = c->rseed_cap;
     for (int k = 0; k < 3; k++) { r.d_dp_scratch[k] = c->d_dp_scratch[k]; r.dp_stride[k] = c->dp_stride[k]; r.dp_blocks[k] = c->dp_blocks[k]; }
+    r.d_dp_lane = c->d_dp_lane; r.dp_lane_blocks = c->dp_lane_blocks;
     for (int k = 0; k < 5; k++) { r.dp_stream[k] = c->dp_stream[k]; r.dp_join[k] = c->dp_join[k]; }
     r.dp_fork = c->dp_fork; r.d_ov = c->d_ov; r.ov_cap = c->ov_cap; r.d_sel_ids = c->d_sel_ids; r.d_est = c->d_est;
     for (int k = 0; k < 10; k++) r.ev[k] = c->ev[k];
@@ -1862,7 +1991,7 @@ static PassRes res_tier0(mcx_ctx *c)
 
 // the DP job lists of a pass, one kernel per size class: they work on disjoint lists and are each bound by latency at
 // modest occupancy, so side streams let them share the chip instead of queueing behind one another
-static int launch_dp(const PassRes &R, const Ctx &cx, const JobSinks &sinks, const ReadBatch &rb, const PairSel &sel)
+static int launch_dp(const PassRes &R, const Ctx &cx, const JobSinks &sinks, const ReadBatch &rb, const PairSel &sel, int rlen_max)
 {
     hipStream_t s = R.stream;
     // three chains of about the same length (the runtime folds streams onto a few hardware queues anyway: more streams only
@@ -1871,7 +2000,26 @@ static int launch_dp(const PassRes &R, const Ctx &cx, const JobSinks &sinks, con
     const int n_side = wide ? 5 : 2;
     HIP_TRY(hipEventRecord(R.dp_fork, s));
     for (int k = 0; k < n_side; k++) HIP_TRY(hipStreamWaitEvent(R.dp_stream[k], R.dp_fork, 0));
-    const bool grouped = !getenv("MCX_DP_BY_WAVE"); // (experiments: a problem's traceback right behind its sweep, walked by one lane of the wave)
+    static const bool by_wave = getenv("MCX_DP_BY_WAVE") != nullptr; // (experiments, and the A/B of the parity tests: the wavefront-per-problem kernels of mcx_dp.h)
+    if (!by_wave) {
+        // every list but the largest problems': one problem per lane (mcx_dp_lane.h).  A list's stretch of scratch per wavefront is
+        // sized for its largest possible group; the two long lists share the wavefront kernels' buffers
+        const bool nw = cx.pm.use_nw != 0;
+        uint32_t *unsup = sinks.unsupported;
+        const uint64_t w1 = lane_stride_words<16>(nw, rlen_max, 4), w2 = lane_stride_words<16>(nw, rlen_max, 16);
+        const unsigned b1 = (unsigned)std::min<uint64_t>(4096, R.dp_stride[0] * R.dp_blocks[0] / (w1 * 4)), b2 = (unsigned)std::min<uint64_t>(4096, R.dp_stride[1] * R.dp_blocks[1] / (w2 * 4));
+        if (b1 == 0 || b2 == 0) return fail(MCX_ERR_CAPACITY, "the DP scratch is too small for one group of problems");
+        launch_dp_lane<16>(nw, b1, s, cx, sinks.s[1], nullptr, rb, sel, (uint32_t *)R.d_dp_scratch[0], w1, unsup);
+        launch_dp_lane<16>(nw, b2, R.dp_stream[1], cx, sinks.s[2], nullptr, rb, sel, (uint32_t *)R.d_dp_scratch[1], w2, unsup);
+        uint32_t *p = R.d_dp_lane;
+        launch_dp_lane<8>(nw, R.dp_lane_blocks, R.dp_stream[0], cx, sinks.s[4], nullptr, rb, sel, p, lane_short_words(0), unsup);
+        p += lane_short_words(0) * R.dp_lane_blocks;
+        launch_dp_lane<16>(nw, R.dp_lane_blocks, R.dp_stream[0], cx, sinks.s[0], nullptr, rb, sel, p, lane_short_words(1), unsup);
+        p += lane_short_words(1) * R.dp_lane_blocks;
+        launch_dp_lane<16>(nw, R.dp_lane_blocks, R.dp_stream[0], cx, sinks.s[5], nullptr, rb, sel, p, lane_short_words(2), unsup);
+        k_dp_sel<16><<<R.dp_blocks[2], 64, 0, R.dp_stream[1]>>>(cx, sinks.s[3], rb, sel, R.d_dp_scratch[2], R.dp_stride[2]);
+    } else {
+    const bool grouped = !getenv("MCX_DP_UNGROUPED"); // (experiments: a problem's traceback right behind its sweep, walked by one lane of the wave)
     if (grouped) k_dp_group<1><<<R.dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, R.d_dp_scratch[0], R.dp_stride[0]);
     else k_dp_sel<1><<<R.dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, R.d_dp_scratch[0], R.dp_stride[0]);
     k_dp_small<<<2560, 256, 0, R.dp_stream[0]>>>(cx, sinks.s[0], rb, sel);
@@ -1882,6 +2030,7 @@ static int launch_dp(const PassRes &R, const Ctx &cx, const JobSinks &sinks, con
     k_dp_tiny<<<2048, 256, 0, wide ? R.dp_stream[3] : s>>>(cx, sinks.s[4], rb, sel);
     k_dp_half<<<2048, 256, 0, wide ? R.dp_stream[4] : R.dp_stream[1]>>>(cx, sinks.s[5], rb, sel);
     k_dp_sel<16><<<R.dp_blocks[2], 64, 0, wide ? R.dp_stream[2] : R.dp_stream[0]>>>(cx, sinks.s[3], rb, sel, R.d_dp_scratch[2], R.dp_stride[2]);
+    }
     for (int k = 0; k < n_side; k++) { HIP_TRY(hipEventRecord(R.dp_join[k], R.dp_stream[k])); HIP_TRY(hipStreamWaitEvent(s, R.dp_join[k], 0)); }
     return 0;
 }
@@ -1918,6 +2067,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     if (late) { ll.ids = c->t2.d_sel_ids; ll.est = c->t2.d_est; ll.cap = kLateRoom; }
     JobSinks sinks;
     for (int k = 0; k < kDpClasses; k++) { sinks.s[k].jobs = R.d_jobs[k]; sinks.s[k].count = R.d_cnt + CNT_JOB0 + k * kCntPad; sinks.s[k].cap = R.job_cap[k]; }
+    sinks.unsupported = R.d_cnt + CNT_UNSUP;
     const unsigned pb = (sel.n + 255) / 256;
     int e = 0, rc2 = 0;
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
@@ -1947,12 +2097,22 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     if (R.d_tasks) k_sa<<<4096, 256, 0, s>>>(cx, so, paired, R.d_cnt + CNT_LF);
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     // the pairs in the order of their weight (k_order_*): worth two small passes when the pass is a large one
-    const uint32_t *order = nullptr;
+    const uint32_t *order = nullptr, *order_cnt = nullptr;
     if (tier == 0 && sel.n >= 16384 && c->d_order && !getenv("MCX_NO_WORK_ORDER")) {
+        // ahead of them, on a whole batch: the straight-line pairs from their seeds to their records (k_simple); what is left is listed
+        // by weight for the per-pair kernels.  (Not with the -vcf bookkeeping — its per-read detail comes from the finish stage —, not
+        // without the suffix array in HBM — the seeds must be text positions —, not on a selection: k_simple takes pair = record.)
+        static const bool no_simple = getenv("MCX_NO_SIMPLE") != nullptr;
+        const uint8_t *done = nullptr;
+        if (!no_simple && !sel.ids && !cx.detail && cx.ix.sa_full && cx.packed) {
+            k_simple<<<pb, 256, 0, s>>>(cx, rb, sel.n, sel.est, so.read_blocks, d_recs, c->d_pout, c->d_done, c->d_batch_flags + 2, R.d_cnt + CNT_SIMPLE);
+            done = c->d_done;
+            order_cnt = c->d_order_cnt;
+        }
         const unsigned ob = (sel.n + 256 * kOrderTile - 1) / (256 * kOrderTile);
         HIP_TRY(hipMemsetAsync(c->d_order_cnt, 0, 16 * kCntPad * sizeof(uint32_t), s));
-        k_order_count<<<ob, 256, 0, s>>>(sel, so.read_blocks, nr, c->d_order_cnt);
-        k_order_place<<<ob, 256, 0, s>>>(sel, so.read_blocks, nr, c->d_order_cnt, c->d_order);
+        k_order_count<<<ob, 256, 0, s>>>(sel, so.read_blocks, nr, c->d_order_cnt, done);
+        k_order_place<<<ob, 256, 0, s>>>(sel, so.read_blocks, nr, c->d_order_cnt, c->d_order, done);
         order = c->d_order;
     }
     const size_t cl_bytes = cluster_lds_bytes(cx.caps.hit_cap, cx.caps.cand_cap);
@@ -1961,7 +2121,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         k_cluster_wave<<<std::min<unsigned>(sel.n, 16384u), 64, cluster_lds_bytes(small, small), s>>>(cx, rb, sel, rl, so.read_blocks, -1, small, small, small);
         if (small < cx.caps.hit_cap)
             k_cluster_wave<<<std::min<unsigned>(sel.n, 8192u), 64, cl_bytes, s>>>(cx, rb, sel, rl, so.read_blocks, small, 1 << 30, cx.caps.hit_cap, cx.caps.cand_cap);
-    } else k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl, so.read_blocks, el, order);
+    } else k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl, so.read_blocks, el, order, order_cnt);
     if (early) HIP_TRY(hipEventRecord(c->ev_clustered, s));
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     if (paired) {
@@ -1983,12 +2143,12 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         }
     }
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
-    k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP, ll, order);
+    k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP, ll, order, order_cnt);
     if (late) HIP_TRY(hipEventRecord(c->ev_built, s));
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
-    if ((rc2 = launch_dp(R, cx, sinks, rb, sel))) return rc2;
+    if ((rc2 = launch_dp(R, cx, sinks, rb, sel, c->rlen_max))) return rc2;
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
-    k_finish<<<pb, 256, 0, s>>>(cx, rb, sel, d_recs, c->d_pout, R.d_ov, R.d_cnt + CNT_OV, R.ov_cap, c->d_batch_flags + 2, order);
+    k_finish<<<pb, 256, 0, s>>>(cx, rb, sel, d_recs, c->d_pout, R.d_ov, R.d_cnt + CNT_OV, R.ov_cap, c->d_batch_flags + 2, order, order_cnt);
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(R.h_cnt, R.d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -2104,11 +2264,12 @@ static int pass_finish(mcx_ctx *c, int tier, const PassRes &R, uint32_t n_sel, m
     for (int k = 0; k < kDpClasses; k++) if (n[CNT_JOB0 + k * kCntPad] > R.job_cap[k]) return kListOverflow;
     if (n[CNT_UNSUP]) return fail(MCX_ERR_UNSUPPORTED, "a gapped fragment exceeds 2048 x 1024 cells per side");
     if (timing && getenv("MCX_TIMING"))
-        fprintf(stderr, "[run_pairs] pairs %u: sa tasks %u, rescue pairs %u (windows %u), dp jobs by class (tiny) %u %u (half) %u %u %u %u, cells %u, overflow pairs %u (+ %u listed while clustering)\n", n_sel,
-                n[CNT_TASKS], n[CNT_RESCUE], n[CNT_RTASK], n[CNT_JOB4], n[CNT_JOB0], n[CNT_JOB5], n[CNT_JOB1], n[CNT_JOB2], n[CNT_JOB3], n[CNT_CELLS], n[CNT_OV], n[CNT_EARLY]);
+        fprintf(stderr, "[run_pairs] pairs %u: sa tasks %u, rescue pairs %u (windows %u), dp jobs by class (tiny) %u %u (half) %u %u %u %u, cells %u, overflow pairs %u (+ %u listed while clustering), %u straight-line pairs (k_simple)\n", n_sel,
+                n[CNT_TASKS], n[CNT_RESCUE], n[CNT_RTASK], n[CNT_JOB4], n[CNT_JOB0], n[CNT_JOB5], n[CNT_JOB1], n[CNT_JOB2], n[CNT_JOB3], n[CNT_CELLS], n[CNT_OV], n[CNT_EARLY], n[CNT_SIMPLE]);
     if (stats) {
         stats->dp_jobs += (int64_t)n[CNT_JOB0] + n[CNT_JOB1] + n[CNT_JOB2] + n[CNT_JOB3] + n[CNT_JOB4] + n[CNT_JOB5];
         stats->dp_cells += n[CNT_CELLS];
+        stats->simple_pairs += n[CNT_SIMPLE];
         if (timing) {
             float ms[8];
             for (int i = 0; i + 1 < e; i++) HIP_TRY(hipEventElapsedTime(&ms[i], R.ev[i], R.ev[i + 1]));

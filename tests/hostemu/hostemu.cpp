@@ -14,6 +14,8 @@
 #include <vector>
 
 #include "../../mapcaller_amd/csrc/mcx_glue.h"
+#include "../../mapcaller_amd/csrc/mcx_dp_lane.h"
+#include "../../mapcaller_amd/csrc/mcx_simple.h"
 #include "../../mapcaller_amd/csrc/mcx_host.h"
 #include "simple_io.h"
 #include "../../oracle/mcx_oracle.h"
@@ -115,8 +117,48 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
             }
         }
     }
+    // k_simple: the straight-line pairs go from their seeds to their records at once (mcx_simple.h); the others take the stages below.
+    // MCX_EMU_NO_SIMPLE=1: every pair takes the general path (the A/B of the tests).
+    std::vector<uint8_t> done(n, 0);
+    if (tier == 0 && !getenv("MCX_EMU_NO_SIMPLE")) {
+        for (uint32_t l = 0; l < n; l++) {
+            PairState st = pair_state(cx.state, cx.lay, cx.caps, l);
+            SimpleRead sr[2];
+            uint32_t cg[2][kSimpleRuns];
+            int rl[2] = {0, 0};
+            bool ok = true;
+            std::vector<uint32_t> pkbuf[2];
+            for (int s = 0; s < nr && ok; s++) {
+                const uint32_t r = ids[l] * nr + s;
+                ReadRef one;
+                one.ascii = b.bases.data() + b.off[r]; one.rlen = (int)(b.off[r + 1] - b.off[r]); one.flipped = (b.paired && s == 1) ? 1 : 0;
+                rl[s] = one.rlen;
+                pkbuf[s].assign(packed_words(one.rlen) + 4, 0u);
+                bool has_n = false;
+                for (int i = 0; i < one.rlen; i++) { const int c = read_code(one, i); if (c > 3) has_n = true; else pkbuf[s][i >> 4] |= (uint32_t)c << (30 - 2 * (i & 15)); }
+                const int nh = st.hdr->n_hits[s];
+                ok = !has_n && nh >= 1 && nh <= kSimpleHits && simple_read(cx.ix, cx.pm, one.rlen, pkbuf[s].data(), st.hits[s], nh, sr[s], cg[s], 1);
+            }
+            if (!ok) continue;
+            const uint32_t want = (uint32_t)sr[0].n_cig + (nr == 2 ? (uint32_t)sr[1].n_cig : 0u);
+            if (e.cig_used + want > cx.cig_pool_cap) continue;
+            const uint32_t off[2] = {e.cig_used, e.cig_used + (uint32_t)sr[0].n_cig};
+            AlnRec rec2[2];
+            PairOut po;
+            if (!simple_pair(cx, nr == 2, sr[0], sr[nr - 1], rl[0], rl[nr - 1], est[l], rec2, off, po)) continue;
+            for (int s = 0; s < nr; s++) {
+                for (int k = 0; k < sr[s].n_cig; k++) cig[off[s] + k] = cg[s][k];
+                recs[(size_t)ids[l] * nr + s] = rec2[s];
+            }
+            e.cig_used += want;
+            pout[ids[l]] = po;
+            done[l] = 1;
+            if (stats) stats[11]++;
+        }
+    }
     // k_cluster, k_rescue, k_build
     for (uint32_t l = 0; l < n; l++) {
+        if (done[l]) continue;
         ReadRef rd[2];
         make_reads(b, ids[l], rd);
         PairState st = pair_state(cx.state, cx.lay, cx.caps, l);
@@ -124,12 +166,14 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
         stage_cluster_pair(cx, l, rd, est[l]);
     }
     for (uint32_t l = 0; l < n; l++) {
+        if (done[l]) continue;
         ReadRef rd[2];
         make_reads(b, ids[l], rd);
         RescueSerial ev; ev.kq = kq.data(); ev.kg = kg.data();
         stage_rescue(cx, l, rd, ev);
     }
     for (uint32_t l = 0; l < n; l++) {
+        if (done[l]) continue;
         ReadRef rd[2];
         make_reads(b, ids[l], rd);
         const int nj = stage_build(cx, l, rd);
@@ -155,13 +199,36 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
             }
         }
     }
-    // DP jobs: the oracle's scalar DP stands in for the wavefront kernels
+    // DP jobs: the product's one-problem-per-lane DP (mcx_dp_lane.h: the code every lane of k_dp_lane runs), one problem after the
+    // other with "the lane's words" a plain array; MCX_EMU_ORACLE_DP=1: the oracle's scalar DP instead (what the wavefront kernels of
+    // mcx_dp.h, which need wave shuffles and LDS, are checked against on the GPU)
+    const bool oracle_dp = getenv("MCX_EMU_ORACLE_DP") != nullptr;
+    cx.dp_summary = oracle_dp ? 0 : 1;
+    std::vector<uint32_t> words;
     for (uint32_t j = 0; j < n_jobs; j++) {
         const DpJob &job = jobs[j];
         PairState st = pair_state(cx.state, cx.lay, cx.caps, job.pair);
         const uint32_t read = ids[job.pair] * nr + job.slot;
         ReadRef jr;
         jr.ascii = b.bases.data() + b.off[read]; jr.rlen = (int)(b.off[read + 1] - b.off[read]); jr.flipped = (b.paired && job.slot == 1) ? 1 : 0;
+        if (stats) { stats[6]++; stats[7] += (int64_t)job.rLen * job.gLen; }
+        if (!oracle_dp) {
+            // the strip width the pipeline's lists would use: 8 for the tiny list, 16 otherwise (both exercised)
+            const bool tiny = job.rLen <= 8 && job.gLen <= 8;
+            const int K = tiny ? 8 : 16, strips = (job.gLen + K - 1) / K;
+            const LaneLayout l = tiny ? (cx.pm.use_nw ? lane_layout<8, true>(job.rLen, strips) : lane_layout<8, false>(job.rLen, strips))
+                                      : (cx.pm.use_nw ? lane_layout<16, true>(job.rLen, strips) : lane_layout<16, false>(job.rLen, strips));
+            words.assign(l.words + 4, 0xDEADBEEFu);
+            LaneMem mem; mem.base = words.data(); mem.stride = 1;
+            // (a read without N also goes through its 2-bit words, as on the device)
+            std::vector<uint32_t> pkbuf(packed_words(jr.rlen) + 4, 0u);
+            bool has_n = false;
+            for (int i = 0; i < jr.rlen; i++) { const int c = read_code(jr, i); if (c > 3) has_n = true; else pkbuf[i >> 4] |= (uint32_t)c << (30 - 2 * (i & 15)); }
+            if (!has_n && !getenv("MCX_EMU_NO_CODES")) jr.codes = pkbuf.data();
+            if (tiny) { if (cx.pm.use_nw) lane_dp_job<8, true>(cx, mem, l, job, jr); else lane_dp_job<8, false>(cx, mem, l, job, jr); }
+            else { if (cx.pm.use_nw) lane_dp_job<16, true>(cx, mem, l, job, jr); else lane_dp_job<16, false>(cx, mem, l, job, jr); }
+            continue;
+        }
         std::string q(job.rLen, 'N'), t(job.gLen, 'N');
         for (int i = 0; i < job.rLen; i++) q[i] = "ACGTN"[read_code(jr, job.rev ? job.rPos + job.rLen - 1 - i : job.rPos + i)];
         for (int i = 0; i < job.gLen; i++) t[i] = "ACGTN"[ref_code(cx.ix, job.rev ? job.gPos + job.gLen - 1 - i : job.gPos + i)];
@@ -174,10 +241,10 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
         for (int i = 0; i < L; i++) st.ops[job.ops_off + w + i] = o1[i] == '-' ? 'D' : (o2[i] == '-' ? 'I' : 'M');
         st.frags[job.frag].ops_off = job.ops_off + w;
         st.frags[job.frag].ops_len = L;
-        if (stats) { stats[6]++; stats[7] += (int64_t)job.rLen * job.gLen; }
     }
     // k_finish
     for (uint32_t l = 0; l < n; l++) {
+        if (done[l]) continue;
         ReadRef rd[2];
         make_reads(b, ids[l], rd);
         const uint32_t pair = ids[l];
@@ -210,6 +277,45 @@ static int run_selection(Emu &e, const Batch &b, const std::vector<uint32_t> &id
 } // namespace
 
 extern "C" {
+
+// One problem through the product's one-problem-per-lane DP (mcx_dp_lane.h) for the reference's function-level vectors:
+// q over ACGTN, t over ACGT (the 2-bit genome holds no N), strips of K = 8 or 16 columns.  ops_out: the column string
+// ('M' / 'I' / 'D', front to back, NUL-terminated, room for qlen + tlen + 1); *score: nw's final score doubled (0 for ksw2).
+// Returns the string's length, -1 for a target with a letter outside ACGT.
+int hostemu_lane_dp(int use_nw, const char *q, int qlen, const char *t, int tlen, int K, char *ops_out, int *score)
+{
+    auto code = [](char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; };
+    for (int i = 0; i < tlen; i++) if (code(t[i]) > 3) return -1;
+    const int strips = (tlen + K - 1) / K;
+    LaneLayout l;
+    if (K == 8) l = use_nw ? lane_layout<8, true>(qlen, strips) : lane_layout<8, false>(qlen, strips);
+    else l = use_nw ? lane_layout<16, true>(qlen, strips) : lane_layout<16, false>(qlen, strips);
+    std::vector<uint32_t> words(l.words + 4, 0xDEADBEEFu);
+    LaneMem mem; mem.base = words.data(); mem.stride = 1;
+    lane_stage_query(mem, l, qlen, [&](int p, uint32_t &codes, uint32_t &flags) {
+        codes = 0; flags = 0;
+        for (int k = 0; k < 16 && p + k < qlen; k++) { const int c = code(q[p + k]); codes |= (uint32_t)(c & 3) << (30 - 2 * k); flags |= (uint32_t)(c > 3) << (15 - k); }
+    });
+    auto tgt16 = [&](int b0) -> uint32_t {
+        uint32_t v = 0;
+        for (int k = 0; k < 16; k++) v = (v << 2) | (b0 + k < tlen ? (uint32_t)code(t[b0 + k]) : 0u);
+        return v;
+    };
+    std::vector<uint8_t> ops((size_t)qlen + tlen + 1, 0);
+    int w, sc = 0;
+    if (K == 8) {
+        if (use_nw) { sc = lane_sweep_nw<8>(mem, l, qlen, tlen, tgt16); w = lane_trace_nw<8>(mem, l, qlen, tlen, tgt16, ops.data(), nullptr, 0u); }
+        else { lane_sweep_ksw2<8>(mem, l, qlen, tlen, tgt16); w = lane_trace_ksw2<8>(mem, l, qlen, tlen, tgt16, ops.data(), nullptr, 0u); }
+    } else {
+        if (use_nw) { sc = lane_sweep_nw<16>(mem, l, qlen, tlen, tgt16); w = lane_trace_nw<16>(mem, l, qlen, tlen, tgt16, ops.data(), nullptr, 0u); }
+        else { lane_sweep_ksw2<16>(mem, l, qlen, tlen, tgt16); w = lane_trace_ksw2<16>(mem, l, qlen, tlen, tgt16, ops.data(), nullptr, 0u); }
+    }
+    const int L = qlen + tlen - w;
+    memcpy(ops_out, ops.data() + w, (size_t)L);
+    ops_out[L] = 0;
+    if (score) *score = sc;
+    return L;
+}
 
 // tier0 = {hit_cap, cand_cap, frag_cap, ops_cap, job_cap} or null for the product defaults.
 // stats[12]: 0 reads 1 mapped 2 pairs 3 E 4 H 5 LF 6 dp jobs 7 dp cells 8 blocks 9 tier-1 pairs 10 replayed pairs

@@ -1,11 +1,14 @@
-"""Host logic: the product's device headers (mcx_fm.h, mcx_glue.h) compiled for the host by
+"""Host logic: the product's device headers (mcx_fm.h, mcx_glue.h, mcx_dp_lane.h) compiled for the host by
 tests/hostemu, run with the product's stage order, capacity tiers and avgDist replay, against the
-reference's golden SAM.  (The wavefront DP kernels themselves are covered by the gpu tests.)"""
+reference's golden SAM and function-level vectors.  The one-problem-per-lane DP is plain per-lane code and runs
+here as it does on the GPU; the wavefront DP kernels (wave shuffles, LDS) are covered by the gpu tests."""
 import ctypes
+import json
+import os
 
 import pytest
 
-from conftest import SETS, VCF_CASES, VCF_RUNS, VcfOpts, sam_diff, vcf_alg, vcf_body
+from conftest import GOLD, SETS, VCF_CASES, VCF_RUNS, VcfOpts, sam_diff, vcf_alg, vcf_body
 
 
 def _run(lib, g, alg, out, batch=1 << 20, tier0=None, rlen_max=256):
@@ -23,6 +26,52 @@ def test_device_glue_on_host_equals_reference(hostemu_lib, golden, tmp_path, nam
     n, st = _run(hostemu_lib, golden[name], alg, out)
     assert n > 0
     nd, ex = sam_diff(golden[name]["sam"][alg], out)
+    assert nd == 0, ex
+
+
+@pytest.mark.parametrize("K", [8, 16])
+@pytest.mark.parametrize("alg", ["nw", "ksw2"])
+def test_lane_dp_equals_reference_vectors(hostemu_lib, alg, K):
+    """The one-problem-per-lane DP (strips of K columns, packed traceback flags, row-major sweep) on the reference's own
+    nw_alignment / ksw2_alignment vectors (tests/golden/func/dp.json, made by oracle/_ref/mcref_tool): the gapped strings —
+    hence every traceback flag the walk visits — and for ksw2 the reversed operation string of ksw_backtrack.  Targets with
+    an N are left out: the pipeline's targets come from the 2-bit genome."""
+    cases = json.load(open(os.path.join(GOLD, "func", "dp.json")))
+    hostemu_lib.hostemu_lane_dp.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+    done = 0
+    for c in cases:
+        q, t = c["q"].encode(), c["t"].encode()
+        buf = ctypes.create_string_buffer(len(q) + len(t) + 2)
+        sc = ctypes.c_int()
+        L = hostemu_lib.hostemu_lane_dp(1 if alg == "nw" else 0, q, len(q), t, len(t), K, buf, ctypes.byref(sc))
+        if L < 0:
+            continue
+        ops = buf.value.decode()
+        a1, a2, qi, ti = [], [], 0, 0
+        for o in ops:  # what the column string says about the two gapped strings
+            if o == "M":
+                a1.append(c["q"][qi]); a2.append(c["t"][ti]); qi += 1; ti += 1
+            elif o == "I":
+                a1.append(c["q"][qi]); a2.append("-"); qi += 1
+            else:
+                a1.append("-"); a2.append(c["t"][ti]); ti += 1
+        assert ["".join(a1), "".join(a2)] == c[alg], (c["q"], c["t"], ops)
+        if alg == "ksw2":
+            assert ops[::-1] == c["ksw2_ops_rev"]
+        done += 1
+    assert done > 550
+
+
+@pytest.mark.parametrize("switch", ["MCX_EMU_NO_CODES", "MCX_EMU_ORACLE_DP"])
+@pytest.mark.parametrize("alg", ["nw", "ksw2"])
+def test_lane_dp_inputs_and_the_scalar_dp_agree(hostemu_lib, golden, tmp_path, monkeypatch, alg, switch):
+    """The `var` set (indel-rich donors: hundreds of DP problems, both strands) with the lane DP reading its query from the
+    ASCII bases instead of the 2-bit words, and with the oracle's scalar DP in its place: the same SAM as the reference's."""
+    monkeypatch.setenv(switch, "1")
+    out = str(tmp_path / "e.sam")
+    n, st = _run(hostemu_lib, golden["var"], alg, out)
+    assert st[6] > 100  # DP problems
+    nd, ex = sam_diff(golden["var"]["sam"][alg], out)
     assert nd == 0, ex
 
 
