@@ -31,35 +31,53 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# vector-instruction issue: 256 CUs x 4 SIMD-32, a wave64 instruction every 2 cycles at 2.4 GHz = 1.23 T wave-instructions/s = 78.6 T lane-operations/s
+VALU_PEAK_TLANEOPS = 256 * 4 * 2.4e9 / 2 * 64 / 1e12
+# vector instructions of the one-problem-per-lane sweep's inner loop per cell, as compiled for gfx950 (k_dp_lane<16, nw> 340 / 16, <16, ksw2> 540 / 16: DESIGN.md section 3)
+DP_OPS_PER_CELL = {"nw": 21.0, "ksw2": 34.0}
 # random 16-byte gathers from an 8 GiB table, four lanes per 64-byte block: what the chip's L2 / fabric sustains in
 # requests per second (tools/ubench_gather.hip, profiles/round1/ubench_gather_8GiB.txt: 47-48 G/s)
 GATHER_CEILING_G_PER_S = 47.5
-PMC_SUMMARY = {"human": os.path.join(ROOT, "profiles", "round3", "summary_human.json"),
-               "uniform": os.path.join(ROOT, "profiles", "round3", "summary_uniform.json")}
-STAGE_KERNEL = {"ms_encode": "k_pack_reads", "ms_seed": "k_seed", "ms_cluster": "k_cluster", "ms_rescue": "k_rescue<2048>", "ms_build": "k_build",
-                "ms_finish": "k_finish"}  # stages that are one kernel (ms_dp is six kernels on side streams)
+# committed rocprofv3 --pmc passes, by workload: (genome kind, Mbp, pairs per step, read length, alg, sub, ins, del, single-end)
+PMC_SUMMARY = {
+    ("human", 3100.0, 4_000_000, 150, "ksw2", 0.005, 0.001, 0.001, 0): "profiles/round4/summary_human.json",
+    ("uniform", 3100.0, 4_000_000, 150, "ksw2", 0.005, 0.001, 0.001, 0): "profiles/round4/summary_uniform.json",
+    ("human", 3100.0, 4_000_000, 250, "nw", 0.005, 0.025, 0.025, 0): "profiles/round4/summary_cfg5.json",
+    ("uniform", 4.6, 1_000_000, 100, "ksw2", 0.005, 0.001, 0.001, 1): "profiles/round4/summary_cfg2.json",
+}
+STAGE_KERNEL = {"ms_encode": "k_pack_reads", "ms_seed": "k_seed", "ms_cluster": "k_cluster", "ms_rescue": "k_rescue_eval<2048>", "ms_build": "k_build",
+                "ms_finish": "k_finish"}  # stages whose time is one kernel's (ms_cluster: k_simple + k_order_* + k_cluster; ms_dp: the lists' kernels on three streams)
 
 
 def pmc_profile(args):
     """What the committed rocprofv3 --pmc passes of this same command measured per launch (counters cannot be read from
-    inside the run): HBM bytes (FETCH_SIZE + WRITE_SIZE) and L2 requests (TCC_HIT + TCC_MISS) per kernel.  Only returned
-    when the workload is the one those passes profiled (scripts/collect_profile.sh runs bench.py with its defaults)."""
-    if (args.genome_mbp, args.batch_pairs, args.rlen, args.alg, args.sub, args.ins, args.dele) != (3100.0, 4_000_000, 150, "ksw2", 0.005, 0.001, 0.001):
+    inside the run): HBM bytes (FETCH_SIZE + WRITE_SIZE), L2 requests (TCC_HIT + TCC_MISS), vector instructions and wave
+    cycles per kernel.  Only returned when the workload is one of those the passes profiled (scripts/collect_profile.sh,
+    scripts/profile_configs.sh run bench.py with exactly these arguments)."""
+    sig = (args.genome, float(args.genome_mbp), args.batch_pairs, args.rlen, args.alg, args.sub, args.ins, args.dele, int(bool(args.single_end)))
+    path = PMC_SUMMARY.get(sig)
+    if not path:
         return None
-    path = PMC_SUMMARY[args.genome]
     try:
-        with open(path) as fh:
+        with open(os.path.join(ROOT, path)) as fh:
             s = json.load(fh)
         out = {}
-        for k, v in s["hbm_traffic"].items():
+        for k, p in s["pmc"].items():
+            v = s.get("hbm_traffic", {}).get(k, {})
             e = {"traffic": int(v.get("hbm_read_bytes_per_launch", 0) + v.get("hbm_write_bytes_per_launch", 0))}
-            p = s["pmc"].get(k, {})
-            if "TCC_HIT_sum" in p and "TCC_MISS_sum" in p:
-                e["l2_requests"] = int(p["TCC_HIT_sum"]["full_batch_mean"] + p["TCC_MISS_sum"]["full_batch_mean"])
-            if "SQ_WAIT_ANY" in p and "SQ_WAVE_CYCLES" in p and p["SQ_WAVE_CYCLES"]["full_batch_mean"] > 0:
-                e["wait_frac"] = round(p["SQ_WAIT_ANY"]["full_batch_mean"] / p["SQ_WAVE_CYCLES"]["full_batch_mean"], 3)
+            get = lambda c: p[c]["full_batch_mean"] if c in p else None
+            if get("TCC_HIT_sum") is not None and get("TCC_MISS_sum") is not None:
+                e["l2_requests"] = int(get("TCC_HIT_sum") + get("TCC_MISS_sum"))
+            if get("SQ_WAIT_ANY") is not None and get("SQ_WAVE_CYCLES"):
+                e["wait_frac"] = round(get("SQ_WAIT_ANY") / get("SQ_WAVE_CYCLES"), 3)
+            if get("SQ_ACTIVE_INST_ANY") is not None and get("SQ_WAVE_CYCLES"):
+                e["issue_frac"] = round(get("SQ_ACTIVE_INST_ANY") / get("SQ_WAVE_CYCLES"), 3)
+            if get("SQ_INSTS_VALU") is not None:
+                e["valu_insts"] = get("SQ_INSTS_VALU")
+            if get("SQ_LDS_BANK_CONFLICT") is not None and get("SQ_LDS_IDX_ACTIVE"):
+                e["lds_conflict_frac"] = round(get("SQ_LDS_BANK_CONFLICT") / get("SQ_LDS_IDX_ACTIVE"), 4)
             out[k] = e
-        return {"kernels": out, "file": os.path.relpath(path, ROOT)}
+        return {"kernels": out, "file": path}
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None
 
@@ -78,37 +96,68 @@ def essential_bytes(kernel, d, args):
         "k_cluster": 16.0 * h + 32.0,                       # hits in, a candidate out
         "k_build": 16.0 * h + 32.0 + 16.0 * (2 * h + 1) + 2 * args.rlen / 4.0,   # hits + candidate in, fragments out, gap bases compared
         "k_finish": 32.0 + 16.0 * (2 * h + 1) + 2 * args.rlen / 4.0 + 64.0 + 8.0,  # candidate + fragments in, columns compared, record + CIGAR out
-        "k_rescue<2048>": 0.0,
     }.get(kernel, 0.0)
     return per_read * reads / steps
 
 
+def dp_roofline(args, d, prof):
+    """The DP stage against the chip's vector-instruction issue rate: `achieved` = cells x the sweep's instructions per cell
+    over the stage's time (the lists' kernels share the chip on three streams: the stage is the sum of their work), `traffic`
+    = the lane-operation slots the stage's kernels actually issued (SQ_INSTS_VALU x 64, committed PMC pass) — idle lanes of
+    ragged groups, staging and the tracebacks are the difference."""
+    steps = max(args.steps, 1)
+    ms = d["ms_dp"] / steps
+    cells = d["dp_cells"] / steps
+    ops = DP_OPS_PER_CELL[args.alg]
+    achieved = cells * ops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    kern = prof["kernels"] if prof else {}
+    dpk = {k: v for k, v in kern.items() if k.startswith("k_dp_")}
+    issued = sum(v.get("valu_insts", 0.0) for v in dpk.values()) * 64 if dpk else None
+    r = {"bound": "valu", "kernel": "k_dp_lane<K, alg> (one problem per lane; five lists on three streams, k_dp_sel<16> for targets above 256 bases)",
+         "achieved": round(achieved, 2), "peak": round(VALU_PEAK_TLANEOPS, 1), "unit": "T lane-ops/s", "frac": round(achieved / VALU_PEAK_TLANEOPS, 4),
+         "traffic": None if not issued else round(issued),
+         "traffic_unit": None if not issued else f"vector lane-operation slots issued per step by the DP kernels (rocprofv3 SQ_INSTS_VALU x 64, {prof['file']})",
+         "avg_launch_ms": round(ms, 3), "cells_per_step": round(cells), "ops_per_cell": ops, "gcups": round(cells / max(ms, 1e-9) / 1e6, 1),
+         "basis": "algorithmic lane-operations (cells of all problems x the sweep's vector instructions per cell) over the DP stage's live time, against "
+                  "256 CU x 4 SIMD-32 x 2.4 GHz (a wave64 instruction per 2 cycles)"}
+    if dpk:
+        r["per_kernel"] = {k: {kk: v[kk] for kk in ("issue_frac", "wait_frac", "lds_conflict_frac", "valu_insts") if kk in v} for k, v in dpk.items()}
+        if issued:
+            r["issued_frac_of_peak"] = round(issued / (ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS, 4)
+    return r
+
+
 def roofline(args, d, reads_per_s):
-    """`frac` = measured HBM bytes of the longest launch / its live duration / the HBM peak: at most 1 by construction.
-    The reference's own walk priced at our launch time (SURVEY 8d's figure, which can exceed 1 because the kernel does not
-    do that walk) is kept as `speed_of_light_equiv`; `request_rate` sets the L2 request rate of the gather-bound kernels
+    """The dominant stage's roofline.  A per-pair / seeding kernel: `frac` = measured HBM bytes of the launch / its live duration /
+    the HBM peak (at most 1 by construction).  The DP stage (the longest one of BASELINE config 5): vector-instruction issue
+    (dp_roofline).  The reference's own walk priced at our launch time (SURVEY 8d's figure, which can exceed 1 because the kernel
+    does not do that walk) is kept as `speed_of_light_equiv`; `request_rate` sets the L2 request rate of the gather-bound kernels
     against what random 16-byte gathers reach on this chip."""
     steps = max(args.steps, 1)
     prof = pmc_profile(args)
     ms = {STAGE_KERNEL[k]: d[k] / steps for k in STAGE_KERNEL if d.get(k, 0) > 0}
     longest = max(ms, key=ms.get)
     kern = prof["kernels"] if prof else {}
-    traffic = kern.get(longest, {}).get("traffic")
-    ess = essential_bytes(longest, d, args)
-    moved = traffic if traffic else ess
-    achieved = moved / (ms[longest] * 1e-3) / 1e9
     seed_bytes = 64.0 * 1.107 * d["fm_ext_steps"] + float(d["reads"]) * args.rlen
     seed_ms = d["ms_seed"] / steps
-    r = {"bound": "hbm", "kernel": longest, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-         "traffic_unit": None if not traffic else f"HBM bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, {prof['file']})",
-         "avg_launch_ms": round(ms[longest], 3),
-         "basis": "measured HBM bytes of the launch (committed PMC pass of this command) over the live launch time" if traffic else
-                  "no PMC pass of this workload is committed: the kernel's essential bytes (DESIGN.md §3) over the live launch time",
-         "algorithmic_bytes_per_launch": round(ess), "algorithmic_frac": round(ess / (ms[longest] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-         "per_kernel": {k: {"ms": round(ms[k], 3), "hbm_gbs": None if k not in kern else round(kern[k]["traffic"] / (ms[k] * 1e-3) / 1e9, 1),
-                            "frac_of_peak": None if k not in kern else round(kern[k]["traffic"] / (ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
-                            "bytes_per_read": None if k not in kern else round(kern[k]["traffic"] / (d["reads"] / steps), 1),
+    if d.get("ms_dp", 0) / steps > ms[longest]:
+        r = dp_roofline(args, d, prof)
+    else:
+        traffic = kern.get(longest, {}).get("traffic")
+        ess = essential_bytes(longest, d, args)
+        moved = traffic if traffic else ess
+        achieved = moved / (ms[longest] * 1e-3) / 1e9
+        r = {"bound": "hbm", "kernel": longest, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+             "traffic_unit": None if not traffic else f"HBM bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, {prof['file']})",
+             "avg_launch_ms": round(ms[longest], 3),
+             "basis": "measured HBM bytes of the launch (committed PMC pass of this command) over the live launch time" if traffic else
+                      "no PMC pass of this workload is committed: the kernel's essential bytes (DESIGN.md §3) over the live launch time",
+             "algorithmic_bytes_per_launch": round(ess), "algorithmic_frac": round(ess / (ms[longest] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    r.update({
+         "per_kernel": {k: {"ms": round(ms[k], 3), "hbm_gbs": None if not kern.get(k, {}).get("traffic") else round(kern[k]["traffic"] / (ms[k] * 1e-3) / 1e9, 1),
+                            "frac_of_peak": None if not kern.get(k, {}).get("traffic") else round(kern[k]["traffic"] / (ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+                            "bytes_per_read": None if not kern.get(k, {}).get("traffic") else round(kern[k]["traffic"] / (d["reads"] / steps), 1),
                             "essential_bytes_per_read": round(essential_bytes(k, d, args) / (d["reads"] / steps), 1)} for k in ms},
          "request_rate": {k: {"l2_requests_per_launch": kern[k]["l2_requests"], "g_per_s": round(kern[k]["l2_requests"] / (ms[k] * 1e-3) / 1e9, 1),
                               "ceiling_g_per_s": GATHER_CEILING_G_PER_S, "frac": round(kern[k]["l2_requests"] / (ms[k] * 1e-3) / 1e9 / GATHER_CEILING_G_PER_S, 3),
@@ -119,7 +168,7 @@ def roofline(args, d, reads_per_s):
                                   "ratio_to_peak": round(seed_bytes / steps / (seed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3) if seed_ms > 0 else None,
                                   "note": "SURVEY 8d's seeding bytes (64*1.107*E + rlen per read: the reference's FM walk) over our launch time; not a utilisation — "
                                           "the kernel reaches the same seeds through a K-mer jump table and direct genome comparison"},
-         "path": path_roofline(d, args, reads_per_s)}
+         "path": path_roofline(d, args, reads_per_s)})
     return r
 
 
@@ -317,7 +366,9 @@ def other_configs(args):
             res.append({"config": name, "value": o["value"], "unit": o["unit"], "steps": o["steps"], "ms_per_step": o["ms_per_step"], "workload": o["config"]["workload"],
                         "stage_ms_per_step": o["stage_ms_per_step"], "per_read": o["per_read"], "dp": o["dp"], "tier1_pairs": o["tier1_pairs"],
                         "halved_selections": o["halved_selections"], "cpu_baseline": o.get("cpu_baseline"),
-                        "roofline": {k: o["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "basis")}})
+                        "simple_pairs": o.get("simple_pairs"),
+                        "roofline": {k: o["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_unit", "avg_launch_ms", "gcups", "cells_per_step",
+                                                                       "ops_per_cell", "issued_frac_of_peak", "basis")}})
         except Exception as e:
             res.append({"config": name, "error": str(e)[:200]})
     return res
@@ -787,7 +838,7 @@ def main():
             "value": round(total_reads / dt, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64/int32", "dtype_note": "FM-index intervals and rank counts in u64 / u32; the DP recurrences in 32-bit registers holding ksw2's int8-range differences "
-                                                "(packed 16-bit halves were tried in the widest one-wavefront class: no gain, DESIGN.md section 9)",
+                                                "and nw's doubled scores, traceback flags packed 2 / 4 bits per cell",
             "data": "synthetic",
             "config": {"workload": f"synthetic GRCh38-sized genome, {args.genome_mbp:.0f} Mbp ({args.contigs} contigs, {genome_note}; GRCh38 itself is unavailable offline), "
                                    f"{args.batch_pairs} {'pairs' if paired else 'reads'} x {args.rlen} bp {'PE' if paired else 'SE'} per step per GPU (sub {args.sub}, ins {args.ins}, del {args.dele} per base), -alg {args.alg}",
@@ -802,10 +853,10 @@ def main():
                          "sa_hits": round(d["sa_hits"] / max(d["reads"], 1), 3), "dp_jobs": round(d["dp_jobs"] / max(d["reads"], 1), 4),
                          "mapped_frac": round(d["mapped"] / max(d["reads"], 1), 4)},
             "stage_ms_per_step": {k[3:]: round(d[k] / args.steps, 3) for k in d if k.startswith("ms_")},
-            "tier1_pairs": d["tier1_pairs"], "replayed_pairs": d["replayed_pairs"], "halved_selections": d["halved_selections"],
+            "tier1_pairs": d["tier1_pairs"], "replayed_pairs": d["replayed_pairs"], "halved_selections": d["halved_selections"], "simple_pairs": d.get("simple_pairs", 0),
             "dp": {"jobs": d["dp_jobs"], "cells": d["dp_cells"], "ms_per_step": round(d["ms_dp"] / args.steps, 3),
                    "gcups": round(d["dp_cells"] / max(d["ms_dp"], 1e-9) / 1e6, 2),
-                   "note": "cell updates of all gapped-extension problems (query x target) over the time of the DP stage (six kernels on three streams)"},
+                   "note": "cell updates of all gapped-extension problems (query x target) over the time of the DP stage (the lists' kernels on three streams)"},
         }
         if pcie is not None:
             out["value_pcie_inclusive"] = pcie

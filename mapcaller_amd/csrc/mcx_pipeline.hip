@@ -1303,7 +1303,8 @@ __global__ void __launch_bounds__(256, MCX_BUILD_WAVES) k_build(Ctx cx, ReadBatc
         if (at < sinks.s[c].cap) sinks.s[c].jobs[at] = j;
     }
     for (int o = 32; o > 0; o >>= 1) { my_cells += __shfl_down(my_cells, o, 64); bad += __shfl_down(bad, o, 64); }
-    if ((threadIdx.x & 63) == 0) { if (my_cells) atomicAdd(cells, my_cells); if (bad) atomicAdd(unsupported, bad); }
+    // (64 bits: the problems of one pass of BASELINE config 5 hold 5 x 10^10 cells)
+    if ((threadIdx.x & 63) == 0) { if (my_cells) atomicAdd((unsigned long long *)cells, (unsigned long long)my_cells); if (bad) atomicAdd(unsupported, bad); }
 }
 
 // LDS per problem is sized per class: the small classes are latency-bound (a chain of dependent
@@ -1464,6 +1465,69 @@ static uint64_t lane_short_words(int which) // ksw2's flags take more words than
     return which == 0 ? 64ull * lane_layout<8, false>(kDpTiny, 1).words : which == 1 ? 64ull * lane_layout<16, false>(kDpSmallQ, 1).words : 64ull * lane_layout<16, false>(kDpHalfQ, 2).words;
 }
 
+// ---- the problems of a long list by shape ------------------------------------------------------------------------------------
+// A wavefront of k_dp_lane runs as long as the longest query times the most strips among its 64 problems.  The two long lists
+// (targets of 17-64 and of 65-256 bases, queries of any length) are therefore dealt to the wavefronts by shape: 256 buckets of
+// (strips, query length / 16), largest first; within a bucket the problems differ by less than 16 rows.  Three small passes —
+// count per bucket, start of every bucket, place — over the list's 40-byte records; the order among equals is whatever the
+// atomics give (no result depends on it).
+constexpr int kDpBuckets = 256, kDpSortTile = 8;
+static __device__ __forceinline__ int dp_bucket(const DpJob &j, int row_shift)
+{
+    const int strips = (j.gLen + 15) >> 4, rows = min(15, j.rLen >> row_shift);
+    return (min(16, max(strips, 1)) - 1) * 16 + rows; // (0..255; the largest shapes get the largest numbers)
+}
+
+__global__ void __launch_bounds__(256) k_dp_sort_count(JobSink sink, int row_shift, uint32_t *counts)
+{
+    __shared__ uint32_t h[kDpBuckets];
+    h[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t n = min(*sink.count, sink.cap);
+    for (uint32_t base = blockIdx.x * (256u * kDpSortTile); base < n; base += gridDim.x * (256u * kDpSortTile))
+        for (int t = 0; t < kDpSortTile; t++) {
+            const uint32_t i = base + t * 256u + threadIdx.x;
+            if (i < n) atomicAdd(&h[dp_bucket(sink.jobs[i], row_shift)], 1u);
+        }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
+}
+
+// counts[0..256) -> cursor[b] = where bucket b begins when the buckets are laid out from the largest shape down
+__global__ void __launch_bounds__(256) k_dp_sort_scan(const uint32_t *counts, uint32_t *cursor)
+{
+    __shared__ uint32_t c[kDpBuckets];
+    c[threadIdx.x] = counts[kDpBuckets - 1 - threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t at = 0; for (int k = 0; k < kDpBuckets; k++) { const uint32_t m = c[k]; c[k] = at; at += m; } }
+    __syncthreads();
+    cursor[kDpBuckets - 1 - threadIdx.x] = c[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256) k_dp_sort_place(JobSink sink, int row_shift, uint32_t *cursor, uint32_t *order)
+{
+    __shared__ uint32_t h[kDpBuckets], at[kDpBuckets];
+    const uint32_t n = min(*sink.count, sink.cap);
+    for (uint32_t base = blockIdx.x * (256u * kDpSortTile); base < n; base += gridDim.x * (256u * kDpSortTile)) {
+        h[threadIdx.x] = 0u;
+        __syncthreads();
+        int b[kDpSortTile];
+        uint32_t rank[kDpSortTile];
+#pragma unroll
+        for (int t = 0; t < kDpSortTile; t++) {
+            const uint32_t i = base + t * 256u + threadIdx.x;
+            b[t] = i < n ? dp_bucket(sink.jobs[i], row_shift) : -1;
+            rank[t] = b[t] >= 0 ? atomicAdd(&h[b[t]], 1u) : 0u;
+        }
+        __syncthreads();
+        at[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]) : 0u;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < kDpSortTile; t++) if (b[t] >= 0) order[at[b[t]] + rank[t]] = base + t * 256u + threadIdx.x;
+        __syncthreads();
+    }
+}
+
 // words a wavefront's stretch of scratch must hold for a list whose problems have at most `rows` query bases and `strips` strips
 template <int K>
 static uint64_t lane_stride_words(bool nw, int rows, int strips)
@@ -1616,6 +1680,7 @@ struct PassRes {
     uint32_t rtask_cap = 0, rseed_cap = 0;
     uint8_t *d_dp_scratch[3] = {nullptr, nullptr, nullptr}; uint64_t dp_stride[3] = {0, 0, 0}; uint32_t dp_blocks[3] = {0, 0, 0};
     uint32_t *d_dp_lane = nullptr; uint32_t dp_lane_blocks = 0; // k_dp_lane's words for the three short lists (tiny | small | half), dp_lane_blocks wavefronts each
+    uint32_t *d_dp_order[2] = {nullptr, nullptr}, *d_dp_sort = nullptr; // the two long lists by shape (k_dp_sort_*): the order; 2 x (256 counts + 256 cursors)
     hipStream_t dp_stream[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t dp_fork = nullptr, dp_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t *d_ov = nullptr; uint32_t ov_cap = 0;
     uint32_t *d_sel_ids = nullptr; int32_t *d_est = nullptr;
@@ -1656,6 +1721,7 @@ struct mcx_ctx {
     hipStream_t dp_stream[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t dp_fork = nullptr, dp_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     uint8_t *d_dp_scratch[3] = {nullptr, nullptr, nullptr}; uint64_t dp_stride[3] = {0, 0, 0}; uint32_t dp_blocks[3] = {0, 0, 0};
     uint32_t *d_dp_lane = nullptr; uint32_t dp_lane_blocks = 0;
+    uint32_t *d_dp_order[2] = {nullptr, nullptr}, *d_dp_sort = nullptr;
     uint32_t *d_ov = nullptr; uint32_t ov_cap = 0;
     uint32_t *d_sel_ids = nullptr; int32_t *d_est = nullptr;
     uint32_t *d_read_ext = nullptr, *d_read_blocks = nullptr;
@@ -1806,6 +1872,8 @@ static int passres_alloc(mcx_ctx *c, PassRes &t, uint64_t pairs, uint64_t sel_ca
     }
     t.dp_lane_blocks = pairs >= 4096 ? 2048u : 256u;
     if ((rc = dmalloc(&t.d_dp_lane, (size_t)(lane_short_words(0) + lane_short_words(1) + lane_short_words(2)) * t.dp_lane_blocks))) return rc;
+    for (int k = 0; k < 2; k++) if ((rc = dmalloc(&t.d_dp_order[k], t.job_cap[1 + k]))) return rc;
+    if ((rc = dmalloc(&t.d_dp_sort, 4 * kDpBuckets))) return rc;
     t.ov_cap = (uint32_t)sel_cap;
     if ((rc = dmalloc(&t.d_ov, t.ov_cap))) return rc;
     if ((rc = dmalloc(&t.d_sel_ids, sel_cap))) return rc;
@@ -1816,7 +1884,7 @@ static int passres_alloc(mcx_ctx *c, PassRes &t, uint64_t pairs, uint64_t sel_ca
 static void passres_free(PassRes &t)
 {
     void *q[] = {t.d_cnt, t.d_jobs[0], t.d_jobs[1], t.d_jobs[2], t.d_jobs[3], t.d_jobs[4], t.d_jobs[5], t.d_rescue, t.d_dp_scratch[0], t.d_dp_scratch[1],
-                 t.d_dp_scratch[2], t.d_ov, t.d_sel_ids, t.d_est, t.d_rtasks, t.d_rres, t.d_rseeds, t.d_rplans, t.d_rescue_n, t.d_dp_lane};
+                 t.d_dp_scratch[2], t.d_ov, t.d_sel_ids, t.d_est, t.d_rtasks, t.d_rres, t.d_rseeds, t.d_rplans, t.d_rescue_n, t.d_dp_lane, t.d_dp_order[0], t.d_dp_order[1], t.d_dp_sort};
     for (void *x : q) if (x) (void)hipFree(x);
     if (t.h_cnt) (void)hipHostFree(t.h_cnt);
     for (auto &e : t.ev) if (e) (void)hipEventDestroy(e);
@@ -1871,6 +1939,8 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     }
     c->dp_lane_blocks = 4096;
     if ((rc = dmalloc(&c->d_dp_lane, (size_t)(lane_short_words(0) + lane_short_words(1) + lane_short_words(2)) * c->dp_lane_blocks))) return rc;
+    for (int k = 0; k < 2; k++) if ((rc = dmalloc(&c->d_dp_order[k], c->job_cap[1 + k]))) return rc;
+    if ((rc = dmalloc(&c->d_dp_sort, 4 * kDpBuckets))) return rc;
     c->ov_cap = (uint32_t)c->max_reads;
     if ((rc = dmalloc(&c->d_ov, c->ov_cap))) return rc;
     if ((rc = dmalloc(&c->d_sel_ids, c->max_reads))) return rc;
@@ -1930,7 +2000,7 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3], c->d_jobs[4], c->d_jobs[5],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_rtasks, c->d_rres, c->d_rseeds, c->d_rplans, c->d_rescue_n, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
                  c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
-                 c->d_dp_lane, c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_pout_sel, c->d_order, c->d_order_cnt, c->d_done, c->d_packed, c->d_batch_flags, c->d_scan_tmp, c->d_prof_match, c->d_prof_items};
+                 c->d_dp_lane, c->d_dp_order[0], c->d_dp_order[1], c->d_dp_sort, c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_pout_sel, c->d_order, c->d_order_cnt, c->d_done, c->d_packed, c->d_batch_flags, c->d_scan_tmp, c->d_prof_match, c->d_prof_items};
     for (void *q : p) if (q) (void)hipFree(q);
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
     if (c->h_keys) (void)hipHostFree(c->h_keys);
@@ -1982,7 +2052,7 @@ static PassRes res_tier0(mcx_ctx *c)
     r.d_rescue = c->d_rescue; r.rescue_cap = c->rescue_cap; r.d_kscratch = c->d_kscratch;
     r.d_rtasks = c->d_rtasks; r.d_rres = c->d_rres; r.d_rseeds = c->d_rseeds; r.d_rplans = c->d_rplans; r.d_rescue_n = c->d_rescue_n; r.rtask_cap = c->rtask_cap; r.rseed_cap = c->rseed_cap;
     for (int k = 0; k < 3; k++) { r.d_dp_scratch[k] = c->d_dp_scratch[k]; r.dp_stride[k] = c->dp_stride[k]; r.dp_blocks[k] = c->dp_blocks[k]; }
-    r.d_dp_lane = c->d_dp_lane; r.dp_lane_blocks = c->dp_lane_blocks;
+    r.d_dp_lane = c->d_dp_lane; r.dp_lane_blocks = c->dp_lane_blocks; r.d_dp_order[0] = c->d_dp_order[0]; r.d_dp_order[1] = c->d_dp_order[1]; r.d_dp_sort = c->d_dp_sort;
     for (int k = 0; k < 5; k++) { r.dp_stream[k] = c->dp_stream[k]; r.dp_join[k] = c->dp_join[k]; }
     r.dp_fork = c->dp_fork; r.d_ov = c->d_ov; r.ov_cap = c->ov_cap; r.d_sel_ids = c->d_sel_ids; r.d_est = c->d_est;
     for (int k = 0; k < 10; k++) r.ev[k] = c->ev[k];
@@ -2000,7 +2070,7 @@ static int launch_dp(const PassRes &R, const Ctx &cx, const JobSinks &sinks, con
     const int n_side = wide ? 5 : 2;
     HIP_TRY(hipEventRecord(R.dp_fork, s));
     for (int k = 0; k < n_side; k++) HIP_TRY(hipStreamWaitEvent(R.dp_stream[k], R.dp_fork, 0));
-    static const bool by_wave = getenv("MCX_DP_BY_WAVE") != nullptr; // (experiments, and the A/B of the parity tests: the wavefront-per-problem kernels of mcx_dp.h)
+    const bool by_wave = getenv("MCX_DP_BY_WAVE") != nullptr; // (experiments, and the A/B of the parity tests: the wavefront-per-problem kernels of mcx_dp.h)
     if (!by_wave) {
         // every list but the largest problems': one problem per lane (mcx_dp_lane.h).  A list's stretch of scratch per wavefront is
         // sized for its largest possible group; the two long lists share the wavefront kernels' buffers
@@ -2009,8 +2079,22 @@ static int launch_dp(const PassRes &R, const Ctx &cx, const JobSinks &sinks, con
         const uint64_t w1 = lane_stride_words<16>(nw, rlen_max, 4), w2 = lane_stride_words<16>(nw, rlen_max, 16);
         const unsigned b1 = (unsigned)std::min<uint64_t>(4096, R.dp_stride[0] * R.dp_blocks[0] / (w1 * 4)), b2 = (unsigned)std::min<uint64_t>(4096, R.dp_stride[1] * R.dp_blocks[1] / (w2 * 4));
         if (b1 == 0 || b2 == 0) return fail(MCX_ERR_CAPACITY, "the DP scratch is too small for one group of problems");
-        launch_dp_lane<16>(nw, b1, s, cx, sinks.s[1], nullptr, rb, sel, (uint32_t *)R.d_dp_scratch[0], w1, unsup);
-        launch_dp_lane<16>(nw, b2, R.dp_stream[1], cx, sinks.s[2], nullptr, rb, sel, (uint32_t *)R.d_dp_scratch[1], w2, unsup);
+        const bool by_shape = getenv("MCX_DP_NO_SORT") == nullptr; // (experiments: the lists as k_build left them)
+        const uint32_t *ord[2] = {nullptr, nullptr};
+        if (by_shape) {
+            const int row_shift = rlen_max <= 256 ? 4 : (rlen_max <= 512 ? 5 : 6); // (16 row classes cover the longest query)
+            hipStream_t st[2] = {s, R.dp_stream[1]};
+            for (int k = 0; k < 2; k++) {
+                uint32_t *counts = R.d_dp_sort + 2 * kDpBuckets * k, *cursor = counts + kDpBuckets;
+                HIP_TRY(hipMemsetAsync(counts, 0, kDpBuckets * sizeof(uint32_t), st[k]));
+                k_dp_sort_count<<<1024, 256, 0, st[k]>>>(sinks.s[1 + k], row_shift, counts);
+                k_dp_sort_scan<<<1, 256, 0, st[k]>>>(counts, cursor);
+                k_dp_sort_place<<<1024, 256, 0, st[k]>>>(sinks.s[1 + k], row_shift, cursor, R.d_dp_order[k]);
+                ord[k] = R.d_dp_order[k];
+            }
+        }
+        launch_dp_lane<16>(nw, b1, s, cx, sinks.s[1], ord[0], rb, sel, (uint32_t *)R.d_dp_scratch[0], w1, unsup);
+        launch_dp_lane<16>(nw, b2, R.dp_stream[1], cx, sinks.s[2], ord[1], rb, sel, (uint32_t *)R.d_dp_scratch[1], w2, unsup);
         uint32_t *p = R.d_dp_lane;
         launch_dp_lane<8>(nw, R.dp_lane_blocks, R.dp_stream[0], cx, sinks.s[4], nullptr, rb, sel, p, lane_short_words(0), unsup);
         p += lane_short_words(0) * R.dp_lane_blocks;
@@ -2102,7 +2186,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         // ahead of them, on a whole batch: the straight-line pairs from their seeds to their records (k_simple); what is left is listed
         // by weight for the per-pair kernels.  (Not with the -vcf bookkeeping — its per-read detail comes from the finish stage —, not
         // without the suffix array in HBM — the seeds must be text positions —, not on a selection: k_simple takes pair = record.)
-        static const bool no_simple = getenv("MCX_NO_SIMPLE") != nullptr;
+        const bool no_simple = getenv("MCX_NO_SIMPLE") != nullptr;
         const uint8_t *done = nullptr;
         if (!no_simple && !sel.ids && !cx.detail && cx.ix.sa_full && cx.packed) {
             k_simple<<<pb, 256, 0, s>>>(cx, rb, sel.n, sel.est, so.read_blocks, d_recs, c->d_pout, c->d_done, c->d_batch_flags + 2, R.d_cnt + CNT_SIMPLE);
@@ -2264,11 +2348,11 @@ static int pass_finish(mcx_ctx *c, int tier, const PassRes &R, uint32_t n_sel, m
     for (int k = 0; k < kDpClasses; k++) if (n[CNT_JOB0 + k * kCntPad] > R.job_cap[k]) return kListOverflow;
     if (n[CNT_UNSUP]) return fail(MCX_ERR_UNSUPPORTED, "a gapped fragment exceeds 2048 x 1024 cells per side");
     if (timing && getenv("MCX_TIMING"))
-        fprintf(stderr, "[run_pairs] pairs %u: sa tasks %u, rescue pairs %u (windows %u), dp jobs by class (tiny) %u %u (half) %u %u %u %u, cells %u, overflow pairs %u (+ %u listed while clustering), %u straight-line pairs (k_simple)\n", n_sel,
-                n[CNT_TASKS], n[CNT_RESCUE], n[CNT_RTASK], n[CNT_JOB4], n[CNT_JOB0], n[CNT_JOB5], n[CNT_JOB1], n[CNT_JOB2], n[CNT_JOB3], n[CNT_CELLS], n[CNT_OV], n[CNT_EARLY], n[CNT_SIMPLE]);
+        fprintf(stderr, "[run_pairs] pairs %u: sa tasks %u, rescue pairs %u (windows %u), dp jobs by class (tiny) %u %u (half) %u %u %u %u, cells %llu, overflow pairs %u (+ %u listed while clustering), %u straight-line pairs (k_simple)\n", n_sel,
+                n[CNT_TASKS], n[CNT_RESCUE], n[CNT_RTASK], n[CNT_JOB4], n[CNT_JOB0], n[CNT_JOB5], n[CNT_JOB1], n[CNT_JOB2], n[CNT_JOB3], *(const unsigned long long *)(n + CNT_CELLS), n[CNT_OV], n[CNT_EARLY], n[CNT_SIMPLE]);
     if (stats) {
         stats->dp_jobs += (int64_t)n[CNT_JOB0] + n[CNT_JOB1] + n[CNT_JOB2] + n[CNT_JOB3] + n[CNT_JOB4] + n[CNT_JOB5];
-        stats->dp_cells += n[CNT_CELLS];
+        stats->dp_cells += (int64_t)(*(const unsigned long long *)(n + CNT_CELLS));
         stats->simple_pairs += n[CNT_SIMPLE];
         if (timing) {
             float ms[8];
@@ -2545,6 +2629,13 @@ extern "C" int mcx_batch_sums(mcx_ctx *c, uint32_t *n_chunks, const uint32_t **p
     hipStream_t s = c->stream;
     HIP_TRY(hipSetDevice(c->idx->device));
     const uint32_t nc = br.n_chunks;
+    if (br.sums_valid && br.ok.size() == nc) { // nothing was re-run since the last call (the closing round of a sharded step): the sums still stand
+        if (n_chunks) *n_chunks = nc;
+        if (pairs) *pairs = br.ok.data();
+        if (dist) *dist = br.ds.data();
+        if (len) *len = br.ds.data() + nc;
+        return 0;
+    }
     uint32_t *d_ok = c->d_read_ext, *d_ds = c->d_read_blocks; // the per-read stat arrays were reduced by mcx_batch_begin
     uint32_t *d_ls = d_ds + nc;                               // (2 * n_chunks <= n_reads)
     br.ok.resize(nc); br.ds.resize(2 * (size_t)nc);

@@ -62,9 +62,23 @@ def main():
             dt = time.perf_counter() - t0
             after = mp.stats.as_dict()
             d = {k: after[k] - before[k] for k in after}
+            # what the last step left: a checksum over the records' fields (not the pool offsets: the atomics' order) and every read's CIGAR words
+            rec = d_aln.view(torch.int32).reshape(n, 16)
+            cig = d_cig
+            fields = rec[:, :14].to(torch.int64)
+            w = torch.arange(1, 15, device=dev, dtype=torch.int64)
+            chk_rec = int(((fields * w).sum(1) * (torch.arange(n, device=dev, dtype=torch.int64) % 1000003 + 1)).sum().item() & 0xFFFFFFFFFFFF)
+            n_cig = rec[:, 11].to(torch.int64)
+            first = rec[:, 14].to(torch.int64)
+            total = int(n_cig.sum().item())
+            rid = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), n_cig)
+            k_in = torch.arange(total, device=dev, dtype=torch.int64) - torch.repeat_interleave(torch.cumsum(n_cig, 0) - n_cig, n_cig)
+            words = cig[first[rid] + k_in].to(torch.int64) & 0xFFFFFFFF
+            chk_cig = int(((words * (k_in + 1)) * (rid % 1000003 + 1)).sum().item() & 0xFFFFFFFFFFFF)
             print(json.dumps({"variant": v, "ms_per_step": round(1000 * dt / a.steps, 3), "M_reads_per_s": round(n * a.steps / dt / 1e6, 1),
                               "stage_ms": {k[3:]: round(d[k] / a.steps, 3) for k in d if k.startswith("ms_")}, "tier1_pairs": d["tier1_pairs"],
-                              "mapped": d["mapped"], "fm_blocks": d["fm_blocks"], "dp_jobs": d["dp_jobs"]}), flush=True)
+                              "mapped": d["mapped"], "fm_blocks": d["fm_blocks"], "dp_jobs": d["dp_jobs"], "dp_cells": d["dp_cells"], "simple_pairs": d.get("simple_pairs"),
+                              "checksum_records": chk_rec, "checksum_cigars": chk_cig}), flush=True)
             mp.close()
             for k, _ in kv:
                 os.environ.pop(k, None)
