@@ -213,19 +213,21 @@ def pcie_inclusive(args, mapper, batches, reads_per_step, dist, dev):
                     "hide behind and are part of the time (about 18 ms per sequence at 8 M reads a step)"}
 
 
-def file_to_file(args, index, batch, reads_per_step):
+def file_to_file(args, index, kept, reads_per_step):
     """FASTQ files in, SAM file out through mcx_map_files_ex — what the CLI runs once its index is loaded —, both in tmpfs: the
-    reads of one batch of the timed region as two FASTQ files, mapped in batches of --file-batch-reads."""
+    reads of --file-batches batches of the timed region as two FASTQ files (32 M reads by default: long enough that the filling
+    and draining of the parse | map | format | write pipeline is a small part of the run), mapped in batches of --file-batch-reads."""
     import shutil
     from mapcaller_amd import api, synth
     root = "/dev/shm" if os.path.isdir("/dev/shm") else None
     tmp = tempfile.mkdtemp(prefix="mcx_f2f_", dir=root)
     try:
-        reads = batch.reshape(reads_per_step, args.rlen).cpu()
         f1, f2, sam = os.path.join(tmp, "r1.fq"), os.path.join(tmp, "r2.fq"), os.path.join(tmp, "o.sam")
-        synth.write_fastq(f1, reads, 0, 2)
-        synth.write_fastq(f2, reads, 1, 2)
-        del reads
+        for k, batch in enumerate(kept):
+            reads = batch.reshape(reads_per_step, args.rlen).cpu()
+            synth.write_fastq(f1, reads, 0, 2, prefix=f"b{k}", append=k > 0)
+            synth.write_fastq(f2, reads, 1, 2, prefix=f"b{k}", append=k > 0)
+            del reads
         mp = api.Mapper(index, alg=args.alg, max_read_len=max(256, args.rlen), max_batch_reads=args.file_batch_reads)
         runs = []
         for _ in range(2):  # (the first run also page-locks the batch buffers and creates the output's pages)
@@ -243,6 +245,7 @@ def file_to_file(args, index, batch, reads_per_step):
                                               "file (the kernel serialises writes to a file: tmpfs took 4 GB/s from 64 threads, 3 GB of text per 8 M reads)"},
                "fastq_bytes": os.path.getsize(f1) + os.path.getsize(f2), "sam_bytes": os.path.getsize(sam), "batch_reads": args.file_batch_reads,
                "host_threads": args.file_threads or "default (min(64, cores / 2) per pool)", "where": tmp.rsplit("/", 1)[0],
+               "batches_of_the_timed_region": len(kept),
                "note": "two plain FASTQ files -> one SAM file, index already in HBM (the CLI loads it once per run); parse + 2-bit packing, "
                        "copies, mapping, SAM text and positioned writes overlapped (mcx_files.cpp)"}
         mp.close()
@@ -401,6 +404,7 @@ def parse():
                     help="1: after the main run, BASELINE.json's configs 5 (250 bp PE at 5 %% indels, -alg nw) and 2 (E. coli-sized genome, 1 M x 100 bp SE) "
                          "as child processes, reported under `other_configs` with their stage times, DP GCUPS and CPU baselines")
     ap.add_argument("--file-steps", type=int, default=1, help="1: the file-to-file leg (value_file_to_file): one batch as FASTQ files in tmpfs -> SAM; 0 = skip")
+    ap.add_argument("--file-batches", type=int, default=4, help="batches of the timed region whose reads the file-to-file leg maps (4 x 8 M reads: a run at steady state)")
     ap.add_argument("--file-batch-reads", type=int, default=1 << 21, help="reads per batch of the file front end's pipeline")
     ap.add_argument("--file-threads", type=int, default=0, help="host threads per pool of the file front end (0 = pick)")
     ap.add_argument("--vcf-slice-reads", type=int, default=4_000_000, help="reads per mapping call in the -vcf leg")
@@ -806,6 +810,7 @@ def main():
 
     # (the legs below bring contexts and buffers of their own: the timed region's context, its device slots and all but one batch make room)
     keep = batches[min(args.warmup, len(batches) - 1)]
+    kept = batches[args.warmup:args.warmup + max(1, args.file_batches)] or [keep]  # the file leg's reads
     del batches[:]
     batches.append(keep)
     mapper.close()
@@ -816,10 +821,11 @@ def main():
     f2f = None
     if args.file_steps > 0 and paired and world == 1:
         try:
-            f2f = file_to_file(args, index, keep, reads_per_step)
+            f2f = file_to_file(args, index, kept, reads_per_step)
         except Exception as e:
             f2f = {"error": str(e)[:300]}
-        torch.cuda.empty_cache()
+    del kept[:]
+    torch.cuda.empty_cache()
 
     # ---- the bulk exchange of a -vcf run (not timed): profile of one batch, RCCL reduce over the ranks ------
     vcf = None

@@ -180,14 +180,19 @@ struct LaneBases {
     }
 };
 
-// the traceback of nw_alignment (nw_alignment.cpp:59-74) by the lane that swept the problem.  ops: area of m + n bytes; the
-// column string is written back to front; returns its start offset in ops.
-template <int K, class Tgt16>
-static inline MCX_HD int lane_trace_nw(const LaneMem &mem, const LaneLayout &l, int m, int n, Tgt16 tgt16, uint8_t *ops, DpSummary *sum, uint32_t ops_base)
+// The walks hand every alignment column — from the last to the first — to a sink: col(kind, differ) with kind 0 'M', 1 'I', 2 'D'
+// (the CIGAR codes) and, for 'M', whether the two bases differ (asked for only when sink.wants_bases()).
+struct OpsSink { // the pipeline's: the column string back to front into the pair's ops area + the DpSummary
+    uint8_t *ops; int w; DpSumAcc acc; bool bases;
+    MCX_HD bool wants_bases() const { return bases; }
+    MCX_HD void col(int kind, int differ) { ops[--w] = kind == 0 ? 'M' : (kind == 1 ? 'I' : 'D'); acc.put(kind, differ); }
+};
+
+// the traceback of nw_alignment (nw_alignment.cpp:59-74) by the lane that swept the problem
+template <int K, class Tgt16, class Sink>
+static inline MCX_HD void lane_walk_nw(const LaneMem &mem, const LaneLayout &l, int m, int n, Tgt16 tgt16, Sink &sink)
 {
-    int w = m + n;
     int i = m, j = n; // 1-based matrix indices
-    DpSumAcc acc; acc.begin(sum);
     LaneBases<Tgt16> bases(mem, l, tgt16);
     while (i > 0 || j > 0) {
         unsigned d;
@@ -197,12 +202,20 @@ static inline MCX_HD int lane_trace_nw(const LaneMem &mem, const LaneLayout &l, 
             const int a = i - 1, b = j - 1;
             d = (mem.get(l.off_dir + (uint32_t)((b / K) * (int)l.rows + a) * LaneDir<K, true>::words) >> (2 * (b % K))) & 3u;
         }
-        if (d & 1) { ops[--w] = 'D'; acc.put(2, 0); j--; }       // '-' inserted into s1 (read string)
-        else if (d & 2) { ops[--w] = 'I'; acc.put(1, 0); i--; }  // '-' inserted into s2 (genome string)
-        else { ops[--w] = 'M'; acc.put(0, sum ? bases.differ(i - 1, j - 1) : 0); i--; j--; }
+        if (d & 1) { sink.col(2, 0); j--; }       // '-' inserted into s1 (read string)
+        else if (d & 2) { sink.col(1, 0); i--; }  // '-' inserted into s2 (genome string)
+        else { sink.col(0, sink.wants_bases() ? bases.differ(i - 1, j - 1) : 0); i--; j--; }
     }
-    acc.end(ops_base + (uint32_t)w, m + n - w);
-    return w;
+}
+
+// ops: area of m + n bytes; the column string is written back to front; returns its start offset in ops.
+template <int K, class Tgt16>
+static inline MCX_HD int lane_trace_nw(const LaneMem &mem, const LaneLayout &l, int m, int n, Tgt16 tgt16, uint8_t *ops, DpSummary *sum, uint32_t ops_base)
+{
+    OpsSink sink; sink.ops = ops; sink.w = m + n; sink.acc.begin(sum); sink.bases = sum != nullptr;
+    lane_walk_nw<K>(mem, l, m, n, tgt16, sink);
+    sink.acc.end(ops_base + (uint32_t)sink.w, m + n - sink.w);
+    return sink.w;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -264,13 +277,11 @@ static inline MCX_HD void lane_sweep_ksw2(const LaneMem &mem, const LaneLayout &
 }
 
 // ksw_backtrack (ksw2_alignment.cpp:25-68), full band (force_state never fires); i: target index, j: query index
-template <int K, class Tgt16>
-static inline MCX_HD int lane_trace_ksw2(const LaneMem &mem, const LaneLayout &l, int qlen, int tlen, Tgt16 tgt16, uint8_t *ops, DpSummary *sum, uint32_t ops_base)
+template <int K, class Tgt16, class Sink>
+static inline MCX_HD void lane_walk_ksw2(const LaneMem &mem, const LaneLayout &l, int qlen, int tlen, Tgt16 tgt16, Sink &sink)
 {
     constexpr int DW = LaneDir<K, false>::words;
-    int w = qlen + tlen;
     int i = tlen - 1, j = qlen - 1, state = 0;
-    DpSumAcc acc; acc.begin(sum);
     LaneBases<Tgt16> bases(mem, l, tgt16);
     while (i >= 0 && j >= 0) {
         const int k = i % K;
@@ -280,14 +291,21 @@ static inline MCX_HD int lane_trace_ksw2(const LaneMem &mem, const LaneLayout &l
         if (state == 0) state = d & 7;
         else if (!((d >> (state + 2)) & 1)) state = 0;
         if (state == 0) state = d & 7;
-        if (state == 0) { ops[--w] = 'M'; acc.put(0, sum ? bases.differ(j, i) : 0); --i; --j; }
-        else if (state == 1 || state == 3) { ops[--w] = 'D'; acc.put(2, 0); --i; }
-        else { ops[--w] = 'I'; acc.put(1, 0); --j; }
+        if (state == 0) { sink.col(0, sink.wants_bases() ? bases.differ(j, i) : 0); --i; --j; }
+        else if (state == 1 || state == 3) { sink.col(2, 0); --i; }
+        else { sink.col(1, 0); --j; }
     }
-    for (; i >= 0; --i) { ops[--w] = 'D'; acc.put(2, 0); }
-    for (; j >= 0; --j) { ops[--w] = 'I'; acc.put(1, 0); }
-    acc.end(ops_base + (uint32_t)w, qlen + tlen - w);
-    return w;
+    for (; i >= 0; --i) sink.col(2, 0);
+    for (; j >= 0; --j) sink.col(1, 0);
+}
+
+template <int K, class Tgt16>
+static inline MCX_HD int lane_trace_ksw2(const LaneMem &mem, const LaneLayout &l, int qlen, int tlen, Tgt16 tgt16, uint8_t *ops, DpSummary *sum, uint32_t ops_base)
+{
+    OpsSink sink; sink.ops = ops; sink.w = qlen + tlen; sink.acc.begin(sum); sink.bases = sum != nullptr;
+    lane_walk_ksw2<K>(mem, l, qlen, tlen, tgt16, sink);
+    sink.acc.end(ops_base + (uint32_t)sink.w, qlen + tlen - sink.w);
+    return sink.w;
 }
 
 // 16 codes of an oriented read without N from position p on (2-bit words as k_pack_reads leaves them), first in the top bits;
@@ -308,6 +326,25 @@ static inline MCX_HD uint32_t lane_reverse16(uint32_t v) // the 16 two-bit symbo
     return ((v & 0x33333333u) << 2) | ((v >> 2) & 0x33333333u);
 }
 
+// The two strings of a pipeline problem as the sweeps take them.  q = read fragment, t = genome fragment; both reversed on the
+// reverse strand (the reference also complements both, which no comparison can see).
+// 16 codes of the query from its position p on, out of the read's 2-bit words (a read without N)
+static inline MCX_HD uint32_t lane_query16(const uint32_t *codes, int rPos, int qlen, bool rev, int p)
+{
+    return rev ? lane_reverse16(lane_read16(codes, rPos + qlen - 16 - p)) : lane_read16(codes, rPos + p);
+}
+// 16 codes of the target from its position b0 on.  Forward strand as it lies; reverse strand t[i] = T[gPos + gLen - 1 - i] =
+// 3 - X[f0 + i] with f0 = 2G - gPos - gLen, i.e. the mirrored forward stretch read forwards, complemented
+static inline MCX_HD uint32_t lane_target16(const IndexView &ix, int64_t gPos, int tlen, bool rev, int b0)
+{
+    if (!rev) return ref_codes16(ix, gPos + b0);
+    const int64_t f0 = ix.G2 - gPos - (int64_t)tlen;
+    if (f0 + b0 + 16 <= ix.G) return ~ref_codes16_fwd(ix, f0 + b0);
+    uint32_t v = 0;
+    for (int k = 0; k < 16; k++) v = (v << 2) | (b0 + k < tlen ? (uint32_t)ref_code(ix, gPos + tlen - 1 - (b0 + k)) : 0u);
+    return v;
+}
+
 // One DP problem of the batch pipeline, start to finish, by its lane: stage the query, sweep, walk, hand the column string to the
 // fragment (what dp_run_job does with a wavefront).  l: the group's layout (the same in every lane of the wave); mem: this lane's words.
 // q = read fragment, t = genome fragment; both reversed on the reverse strand (the reference also complements both, which no
@@ -319,11 +356,7 @@ static inline MCX_HD int lane_dp_job(const Ctx &cx, const LaneMem &mem, const La
     const int qlen = job.rLen, tlen = job.gLen;
     const bool rev = job.rev != 0;
     lane_stage_query(mem, l, qlen, [&](int p, uint32_t &codes, uint32_t &flags) {
-        if (rd.codes) {
-            flags = 0;
-            codes = rev ? lane_reverse16(lane_read16(rd.codes, job.rPos + qlen - 16 - p)) : lane_read16(rd.codes, job.rPos + p);
-            return;
-        }
+        if (rd.codes) { flags = 0; codes = lane_query16(rd.codes, job.rPos, qlen, rev, p); return; }
         codes = 0; flags = 0;
         for (int k = 0; k < 16 && p + k < qlen; k++) {
             const int c = read_code(rd, rev ? job.rPos + qlen - 1 - (p + k) : job.rPos + p + k);
@@ -331,16 +364,7 @@ static inline MCX_HD int lane_dp_job(const Ctx &cx, const LaneMem &mem, const La
             flags |= (uint32_t)(c > 3) << (15 - k);
         }
     });
-    // the genome fragment: forward strand as it lies; reverse strand t[i] = T[gPos + gLen - 1 - i] = 3 - X[f0 + i] with
-    // f0 = 2G - gPos - gLen, i.e. the mirrored forward stretch read forwards, complemented
-    const int64_t f0 = rev ? ix.G2 - job.gPos - (int64_t)tlen : job.gPos;
-    auto tgt16 = [&](int b0) -> uint32_t {
-        if (!rev) return ref_codes16(ix, f0 + b0);
-        if (f0 + b0 + 16 <= ix.G) return ~ref_codes16_fwd(ix, f0 + b0);
-        uint32_t v = 0;
-        for (int k = 0; k < 16; k++) v = (v << 2) | (b0 + k < tlen ? (uint32_t)ref_code(ix, job.gPos + tlen - 1 - (b0 + k)) : 0u);
-        return v;
-    };
+    auto tgt16 = [&](int b0) -> uint32_t { return lane_target16(ix, job.gPos, tlen, rev, b0); };
     PairState st = pair_state(cx.state, cx.lay, cx.caps, job.pair);
     DpSummary *sum = cx.dp_summary ? (DpSummary *)(st.ops + job.ops_off - kDpSum) : nullptr; // (stage_build left room for it)
     int score = 0, w;

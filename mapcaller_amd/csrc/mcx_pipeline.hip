@@ -638,7 +638,7 @@ __global__ void __launch_bounds__(256) k_sa(Ctx cx, SeedOut so, int paired, uint
 struct RescueList { uint32_t *ids; uint32_t *n; uint32_t cap; };
 // pairs that ran over the tier-0 capacities while clustering are listed right there, with their estimate: the large tier maps
 // them on a stream of its own while the rest of the pass is still under way (ids null: no such list)
-struct EarlyList { uint32_t *ids; int32_t *est; uint32_t *n; uint32_t cap; };
+struct EarlyList { uint32_t *ids; int32_t *est; uint32_t *n; uint32_t cap; uint32_t *n_hits; };
 
 // The per-pair kernels give every lane one pair, and a wavefront is as slow as its heaviest lane: next to a pair from a repeat
 // (dozens of hits to sort and cluster, a dozen candidates to build and score) sixty-three ordinary pairs wait.  So the pairs
@@ -723,11 +723,14 @@ __global__ void __launch_bounds__(256) k_order_place(PairSel sel, const uint32_t
 // seeds per read, the 2-bit words of its reads, a few words of the genome under the gaps — stays in registers; the CIGAR
 // operations wait word-major in LDS until the wave has reserved its words of the pool with one atomic.  done[pair] tells the
 // per-pair kernels behind this one which pairs are left to them (k_order_*).
+template <bool NW>
 __global__ void __launch_bounds__(256) k_simple(Ctx cx, ReadBatch rb, uint32_t n_pairs, const int32_t *est, const uint32_t *read_blocks, AlnRec *recs, PairOut *pout,
                                                 uint8_t *done, uint32_t *pool_over, uint32_t *n_done)
 {
     __shared__ EndsLds ends;
     __shared__ uint32_t cig_stage[256 * 2 * kSimpleRuns]; // word k of thread t at [k * 256 + t]
+    __shared__ uint32_t dp_words[256 * (2 + kSimpleDp)];  // the lane's words for a small gapped extension (simple_dp_layout), word-major too
+    LaneMem dpm; dpm.base = dp_words + threadIdx.x; dpm.stride = 256;
     stage_ends(cx.ix, ends);
     const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
     const int nr = cx.pm.paired ? 2 : 1;
@@ -739,12 +742,13 @@ __global__ void __launch_bounds__(256) k_simple(Ctx cx, ReadBatch rb, uint32_t n
         const PairState st = pair_state(cx.state, cx.lay, cx.caps, pair);
 #pragma unroll
         for (int s = 0; s < 2; s++) {
-            if (s >= nr || !ok) break;
-            const uint32_t r = pair * nr + s;
-            const int nh = (int)(read_blocks[r] >> 20);
-            rl[s] = (int)(rb.off[r + 1] - rb.off[r]);
-            ok = nh >= 1 && nh <= kSimpleHits && !(cx.read_ext[r] >> 31) &&
-                 simple_read(cx.ix, cx.pm, rl[s], cx.packed + (uint64_t)r * cx.wpad, st.hits[s], nh, sr[s], stage + s * kSimpleRuns * 256, 256);
+            if (s < nr && ok) {
+                const uint32_t r = pair * nr + s;
+                const int nh = (int)(read_blocks[r] >> 20);
+                rl[s] = (int)(rb.off[r + 1] - rb.off[r]);
+                ok = nh >= 1 && nh <= kSimpleHits && !(cx.read_ext[r] >> 31) &&
+                     simple_read<NW>(cx.ix, cx.pm, rl[s], cx.packed + (uint64_t)r * cx.wpad, st.hits[s], nh, sr[s], stage + s * kSimpleRuns * 256, 256, &dpm);
+            }
         }
         if (ok && nr == 2) ok = simple_pair_ok(sr[0], sr[1], est[pair]);
     }
@@ -780,14 +784,22 @@ static __device__ __forceinline__ uint32_t listed_pairs(const PairSel &sel, cons
     return n;
 }
 
+// (cls_lo .. cls_hi: with the pairs listed by weight, the launch takes the pairs of these classes only — the heavy classes go first, in
+//  a launch of their own, because every pair that can run over this tier's capacities is among them: the large tier starts on
+//  them while the light pairs, nine in ten, are still being clustered)
 __global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel sel, RescueList rl, const uint32_t *read_blocks, EarlyList el, const uint32_t *order,
-                                                 const uint32_t *order_cnt)
+                                                 const uint32_t *order_cnt, int cls_lo, int cls_hi)
 {
     __shared__ EndsLds ends;
-    if (blockIdx.x * blockDim.x >= listed_pairs(sel, order_cnt)) return; // (uniform over the block)
+    uint32_t first = 0, n_listed = listed_pairs(sel, order_cnt);
+    if (order_cnt && order) {
+        uint32_t at = 0;
+        for (int k = 0; k < kWorkClasses; k++) { if (k == cls_lo) first = at; at += order_cnt[k * kCntPad]; if (k == cls_hi) n_listed = at; }
+    }
+    if (first + blockIdx.x * blockDim.x >= n_listed) return; // (uniform over the block)
     stage_ends(cx.ix, ends);
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = slot < listed_pairs(sel, order_cnt);
+    const uint32_t slot = first + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = slot < n_listed;
     const uint32_t local = in ? (order ? order[slot] : slot) : 0u;
     uint32_t need = 0, over = 0;
     if (in) {
@@ -801,6 +813,7 @@ __global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel s
         const uint32_t fl = st.hdr->flags;
         need = (cx.pm.paired && !(fl & kOvAny) && st.hdr->n_paired == 0) ? 1u : 0u;
         over = (el.ids && (fl & kOvAny)) ? 1u : 0u;
+        if (over && (fl & kOvHits)) atomicAdd(el.n_hits, 1u); // (diagnosis: how many of the listed pairs were known to run over once k_seed was done)
         if (over) st.hdr->flags = fl | kDispatched; // the later stages of this tier leave the pair alone (they skip kOvAny) and k_finish writes nothing for it
     }
     const uint32_t at = wave_reserve(rl.n, need);
@@ -1366,12 +1379,13 @@ constexpr int kDpGroup = 64;
 struct DpGroupSlot { uint32_t off; int32_t score; }; // where a problem's strings and traceback bytes lie in the wave's scratch; its sweep's score
 
 template <int K>
-__global__ void __launch_bounds__(64) k_dp_group(Ctx cx, JobSink sink, ReadBatch rb, PairSel sel, uint8_t *scratch, uint64_t scratch_stride)
+__global__ void __launch_bounds__(64) k_dp_group(Ctx cx, JobSink sink, ReadBatch rb, PairSel sel, uint8_t *scratch, uint64_t scratch_stride, uint32_t max_n)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[DpLds<K>::seq];
     __shared__ DpGroupSlot slot[kDpGroup];
     uint8_t *mine = scratch + (uint64_t)blockIdx.x * scratch_stride;
     const uint32_t n = min(*sink.count, sink.cap);
+    if (n >= max_n) return; // (a long list: k_dp_lane's)
     const int nr = cx.pm.paired ? 2 : 1;
     const int lane = threadIdx.x;
     const bool nw = cx.pm.use_nw != 0;
@@ -1433,9 +1447,11 @@ constexpr int kDpHalfT = 32, kDpHalfQ = 64, kDpHalfLds = kDpHalfQ + kDpHalfT + (
 // query and widest target, so that every store and load of the sweep is one line per 16 lanes.  order: the list's problems by
 // size (null: as listed), so that the 64 of a group finish together.
 template <int K, bool NW>
-__global__ void __launch_bounds__(64) k_dp_lane(Ctx cx, JobSink sink, const uint32_t *order, ReadBatch rb, PairSel sel, uint32_t *scratch, uint64_t stride_words, uint32_t *unsupported)
+__global__ void __launch_bounds__(64) k_dp_lane(Ctx cx, JobSink sink, const uint32_t *order, ReadBatch rb, PairSel sel, uint32_t *scratch, uint64_t stride_words, uint32_t *unsupported,
+                                                uint32_t min_n)
 {
     const uint32_t n = min(*sink.count, sink.cap);
+    if (n < min_n) return; // (a short list: k_dp_group's)
     const int lane = threadIdx.x;
     const int nr = cx.pm.paired ? 2 : 1;
     LaneMem mem; mem.base = scratch + (uint64_t)blockIdx.x * stride_words + lane; mem.stride = 64;
@@ -1478,12 +1494,13 @@ static __device__ __forceinline__ int dp_bucket(const DpJob &j, int row_shift)
     return (min(16, max(strips, 1)) - 1) * 16 + rows; // (0..255; the largest shapes get the largest numbers)
 }
 
-__global__ void __launch_bounds__(256) k_dp_sort_count(JobSink sink, int row_shift, uint32_t *counts)
+__global__ void __launch_bounds__(256) k_dp_sort_count(JobSink sink, int row_shift, uint32_t *counts, uint32_t min_n)
 {
     __shared__ uint32_t h[kDpBuckets];
+    const uint32_t n = min(*sink.count, sink.cap);
+    if (n < min_n) return;
     h[threadIdx.x] = 0u;
     __syncthreads();
-    const uint32_t n = min(*sink.count, sink.cap);
     for (uint32_t base = blockIdx.x * (256u * kDpSortTile); base < n; base += gridDim.x * (256u * kDpSortTile))
         for (int t = 0; t < kDpSortTile; t++) {
             const uint32_t i = base + t * 256u + threadIdx.x;
@@ -1504,10 +1521,11 @@ __global__ void __launch_bounds__(256) k_dp_sort_scan(const uint32_t *counts, ui
     cursor[kDpBuckets - 1 - threadIdx.x] = c[threadIdx.x];
 }
 
-__global__ void __launch_bounds__(256) k_dp_sort_place(JobSink sink, int row_shift, uint32_t *cursor, uint32_t *order)
+__global__ void __launch_bounds__(256) k_dp_sort_place(JobSink sink, int row_shift, uint32_t *cursor, uint32_t *order, uint32_t min_n)
 {
     __shared__ uint32_t h[kDpBuckets], at[kDpBuckets];
     const uint32_t n = min(*sink.count, sink.cap);
+    if (n < min_n) return;
     for (uint32_t base = blockIdx.x * (256u * kDpSortTile); base < n; base += gridDim.x * (256u * kDpSortTile)) {
         h[threadIdx.x] = 0u;
         __syncthreads();
@@ -1537,10 +1555,10 @@ static uint64_t lane_stride_words(bool nw, int rows, int strips)
 
 template <int K>
 static void launch_dp_lane(bool nw, unsigned blocks, hipStream_t s, const Ctx &cx, const JobSink &sink, const uint32_t *order, const ReadBatch &rb, const PairSel &sel,
-                           uint32_t *scratch, uint64_t stride_words, uint32_t *unsupported)
+                           uint32_t *scratch, uint64_t stride_words, uint32_t *unsupported, uint32_t min_n)
 {
-    if (nw) k_dp_lane<K, true><<<blocks, 64, 0, s>>>(cx, sink, order, rb, sel, scratch, stride_words, unsupported);
-    else k_dp_lane<K, false><<<blocks, 64, 0, s>>>(cx, sink, order, rb, sel, scratch, stride_words, unsupported);
+    if (nw) k_dp_lane<K, true><<<blocks, 64, 0, s>>>(cx, sink, order, rb, sel, scratch, stride_words, unsupported, min_n);
+    else k_dp_lane<K, false><<<blocks, 64, 0, s>>>(cx, sink, order, rb, sel, scratch, stride_words, unsupported, min_n);
 }
 
 // targets <= 32 (queries <= 64) of the one-column-per-lane class: two problems per wave, 32 lanes each — the
@@ -1663,7 +1681,7 @@ constexpr uint32_t kPoutSel = 1u << 16; // pair outcomes gathered per copy (run_
 enum { CNT_TASKS = 0, CNT_RESCUE = 1 * kCntPad, CNT_JOB0 = 2 * kCntPad, CNT_JOB1 = 3 * kCntPad, CNT_JOB2 = 4 * kCntPad, CNT_JOB3 = 5 * kCntPad,
        CNT_JOB4 = 6 * kCntPad, CNT_JOB5 = 7 * kCntPad, CNT_OV = 8 * kCntPad, CNT_LF = 9 * kCntPad, CNT_CELLS = 10 * kCntPad, CNT_UNSUP = 11 * kCntPad,
        CNT_QUEUE = 12 * kCntPad, CNT_EARLY = 13 * kCntPad, CNT_LATE = 14 * kCntPad, CNT_RTASK = 15 * kCntPad, CNT_RPLAN = 16 * kCntPad, CNT_RESCUE_N = 17 * kCntPad, CNT_RSEED = 18 * kCntPad,
-       CNT_SIMPLE = 19 * kCntPad, CNT_N = 20 * kCntPad };
+       CNT_SIMPLE = 19 * kCntPad, CNT_EARLY_HITS = 20 * kCntPad, CNT_N = 21 * kCntPad };
 constexpr uint32_t kLateRoom = 256; // pairs of a pass that may run over after clustering and still go through the large tier beside it
 
 // What a pass over a selection of pairs works with besides the pair records: stream, counters, work lists, DP scratch.
@@ -1853,7 +1871,11 @@ static int passres_alloc(mcx_ctx *c, PassRes &t, uint64_t pairs, uint64_t sel_ca
 {
     int rc;
     HIP_TRY(hipStreamCreateWithPriority(&t.stream, hipStreamNonBlocking, priority));
-    for (int k = 0; k < 5; k++) { HIP_TRY(hipStreamCreateWithPriority(&t.dp_stream[k], hipStreamNonBlocking, priority)); HIP_TRY(hipEventCreateWithFlags(&t.dp_join[k], hipEventDisableTiming)); }
+    // side streams for the DP lists only where lists are long enough to share the chip: a stream that exists lands on one of the
+    // runtime's few hardware queues, and a queue that waits for an event holds up every stream folded onto it (the late pairs' pass
+    // once sat 4 ms behind the large tier's DP fork that way)
+    const int n_side = pairs >= 4096 ? (getenv("MCX_DP_STREAMS") ? 5 : 2) : 0;
+    for (int k = 0; k < n_side; k++) { HIP_TRY(hipStreamCreateWithPriority(&t.dp_stream[k], hipStreamNonBlocking, priority)); HIP_TRY(hipEventCreateWithFlags(&t.dp_join[k], hipEventDisableTiming)); }
     HIP_TRY(hipEventCreateWithFlags(&t.dp_fork, hipEventDisableTiming));
     for (auto &e : t.ev) HIP_TRY(hipEventCreate(&e));
     if ((rc = dmalloc(&t.d_cnt, CNT_N))) return rc;
@@ -1902,7 +1924,7 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     c->max_bases = c->max_reads * (uint64_t)c->rlen_max;
     HIP_TRY(hipSetDevice(idx->device));
     HIP_TRY(hipStreamCreate(&c->stream));
-    for (int k = 0; k < 5; k++) { HIP_TRY(hipStreamCreateWithFlags(&c->dp_stream[k], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&c->dp_join[k], hipEventDisableTiming)); }
+    for (int k = 0; k < (getenv("MCX_DP_STREAMS") ? 5 : 2); k++) { HIP_TRY(hipStreamCreateWithFlags(&c->dp_stream[k], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&c->dp_join[k], hipEventDisableTiming)); }
     HIP_TRY(hipEventCreateWithFlags(&c->dp_fork, hipEventDisableTiming));
     for (auto &e : c->ev_pack) HIP_TRY(hipEventCreate(&e));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
@@ -2061,13 +2083,20 @@ static PassRes res_tier0(mcx_ctx *c)
 
 // the DP job lists of a pass, one kernel per size class: they work on disjoint lists and are each bound by latency at
 // modest occupancy, so side streams let them share the chip instead of queueing behind one another
+// A long list is worth a lane per problem; a short one (the large tier's, a replay's, the late pairs': a few thousand problems of
+// 100 x 100 cells) is done sooner with a wavefront per problem — fewer problems than the chip has lanes, each 60 times quicker
+// that way.  The list's length is known on the device only, so both kernels are launched and the one whose turn it is not leaves at
+// once: k_dp_group below kDpLaneMin problems, k_dp_lane from there on.
+constexpr uint32_t kDpLaneMin[2] = {65536, 131072}; // targets of 17-64 bases (mean 45 x 45 cells), of 65-256 (95 x 95): two wavefronts per SIMD's worth of problems
+
 static int launch_dp(const PassRes &R, const Ctx &cx, const JobSinks &sinks, const ReadBatch &rb, const PairSel &sel, int rlen_max)
 {
     hipStream_t s = R.stream;
     // three chains of about the same length (the runtime folds streams onto a few hardware queues anyway: more streams only
-    // make the pairing of kernels on a queue a matter of luck)
-    static const bool wide = getenv("MCX_DP_STREAMS") != nullptr; // (experiments: one stream per kernel)
-    const int n_side = wide ? 5 : 2;
+    // make the pairing of kernels on a queue a matter of luck); a set of pass resources without side streams runs them in turn
+    const bool wide = R.dp_stream[4] != nullptr; // (MCX_DP_STREAMS at context creation: one stream per kernel)
+    const int n_side = wide ? 5 : (R.dp_stream[1] ? 2 : 0);
+    hipStream_t side0 = n_side ? R.dp_stream[0] : s, side1 = n_side ? R.dp_stream[1] : s;
     HIP_TRY(hipEventRecord(R.dp_fork, s));
     for (int k = 0; k < n_side; k++) HIP_TRY(hipStreamWaitEvent(R.dp_stream[k], R.dp_fork, 0));
     const bool by_wave = getenv("MCX_DP_BY_WAVE") != nullptr; // (experiments, and the A/B of the parity tests: the wavefront-per-problem kernels of mcx_dp.h)
@@ -2076,44 +2105,48 @@ static int launch_dp(const PassRes &R, const Ctx &cx, const JobSinks &sinks, con
         // sized for its largest possible group; the two long lists share the wavefront kernels' buffers
         const bool nw = cx.pm.use_nw != 0;
         uint32_t *unsup = sinks.unsupported;
+        const bool always = getenv("MCX_DP_LANE_ALWAYS") != nullptr;
+        const uint32_t lane_min[2] = {always ? 0u : kDpLaneMin[0], always ? 0u : kDpLaneMin[1]};
         const uint64_t w1 = lane_stride_words<16>(nw, rlen_max, 4), w2 = lane_stride_words<16>(nw, rlen_max, 16);
         const unsigned b1 = (unsigned)std::min<uint64_t>(4096, R.dp_stride[0] * R.dp_blocks[0] / (w1 * 4)), b2 = (unsigned)std::min<uint64_t>(4096, R.dp_stride[1] * R.dp_blocks[1] / (w2 * 4));
         if (b1 == 0 || b2 == 0) return fail(MCX_ERR_CAPACITY, "the DP scratch is too small for one group of problems");
         const bool by_shape = getenv("MCX_DP_NO_SORT") == nullptr; // (experiments: the lists as k_build left them)
         const uint32_t *ord[2] = {nullptr, nullptr};
+        hipStream_t st[2] = {s, side1};
         if (by_shape) {
             const int row_shift = rlen_max <= 256 ? 4 : (rlen_max <= 512 ? 5 : 6); // (16 row classes cover the longest query)
-            hipStream_t st[2] = {s, R.dp_stream[1]};
             for (int k = 0; k < 2; k++) {
                 uint32_t *counts = R.d_dp_sort + 2 * kDpBuckets * k, *cursor = counts + kDpBuckets;
                 HIP_TRY(hipMemsetAsync(counts, 0, kDpBuckets * sizeof(uint32_t), st[k]));
-                k_dp_sort_count<<<1024, 256, 0, st[k]>>>(sinks.s[1 + k], row_shift, counts);
+                k_dp_sort_count<<<1024, 256, 0, st[k]>>>(sinks.s[1 + k], row_shift, counts, lane_min[k]);
                 k_dp_sort_scan<<<1, 256, 0, st[k]>>>(counts, cursor);
-                k_dp_sort_place<<<1024, 256, 0, st[k]>>>(sinks.s[1 + k], row_shift, cursor, R.d_dp_order[k]);
+                k_dp_sort_place<<<1024, 256, 0, st[k]>>>(sinks.s[1 + k], row_shift, cursor, R.d_dp_order[k], lane_min[k]);
                 ord[k] = R.d_dp_order[k];
             }
         }
-        launch_dp_lane<16>(nw, b1, s, cx, sinks.s[1], ord[0], rb, sel, (uint32_t *)R.d_dp_scratch[0], w1, unsup);
-        launch_dp_lane<16>(nw, b2, R.dp_stream[1], cx, sinks.s[2], ord[1], rb, sel, (uint32_t *)R.d_dp_scratch[1], w2, unsup);
+        launch_dp_lane<16>(nw, b1, st[0], cx, sinks.s[1], ord[0], rb, sel, (uint32_t *)R.d_dp_scratch[0], w1, unsup, lane_min[0]);
+        k_dp_group<1><<<R.dp_blocks[0], 64, 0, st[0]>>>(cx, sinks.s[1], rb, sel, R.d_dp_scratch[0], R.dp_stride[0], lane_min[0]);
+        launch_dp_lane<16>(nw, b2, st[1], cx, sinks.s[2], ord[1], rb, sel, (uint32_t *)R.d_dp_scratch[1], w2, unsup, lane_min[1]);
+        k_dp_group<4><<<R.dp_blocks[1], 64, 0, st[1]>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1], lane_min[1]);
         uint32_t *p = R.d_dp_lane;
-        launch_dp_lane<8>(nw, R.dp_lane_blocks, R.dp_stream[0], cx, sinks.s[4], nullptr, rb, sel, p, lane_short_words(0), unsup);
+        launch_dp_lane<8>(nw, R.dp_lane_blocks, side0, cx, sinks.s[4], nullptr, rb, sel, p, lane_short_words(0), unsup, 0u);
         p += lane_short_words(0) * R.dp_lane_blocks;
-        launch_dp_lane<16>(nw, R.dp_lane_blocks, R.dp_stream[0], cx, sinks.s[0], nullptr, rb, sel, p, lane_short_words(1), unsup);
+        launch_dp_lane<16>(nw, R.dp_lane_blocks, side0, cx, sinks.s[0], nullptr, rb, sel, p, lane_short_words(1), unsup, 0u);
         p += lane_short_words(1) * R.dp_lane_blocks;
-        launch_dp_lane<16>(nw, R.dp_lane_blocks, R.dp_stream[0], cx, sinks.s[5], nullptr, rb, sel, p, lane_short_words(2), unsup);
-        k_dp_sel<16><<<R.dp_blocks[2], 64, 0, R.dp_stream[1]>>>(cx, sinks.s[3], rb, sel, R.d_dp_scratch[2], R.dp_stride[2]);
+        launch_dp_lane<16>(nw, R.dp_lane_blocks, side0, cx, sinks.s[5], nullptr, rb, sel, p, lane_short_words(2), unsup, 0u);
+        k_dp_sel<16><<<R.dp_blocks[2], 64, 0, side1>>>(cx, sinks.s[3], rb, sel, R.d_dp_scratch[2], R.dp_stride[2]);
     } else {
     const bool grouped = !getenv("MCX_DP_UNGROUPED"); // (experiments: a problem's traceback right behind its sweep, walked by one lane of the wave)
-    if (grouped) k_dp_group<1><<<R.dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, R.d_dp_scratch[0], R.dp_stride[0]);
+    if (grouped) k_dp_group<1><<<R.dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, R.d_dp_scratch[0], R.dp_stride[0], 0xFFFFFFFFu);
     else k_dp_sel<1><<<R.dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, R.d_dp_scratch[0], R.dp_stride[0]);
-    k_dp_small<<<2560, 256, 0, R.dp_stream[0]>>>(cx, sinks.s[0], rb, sel);
-    if (grouped) k_dp_group<4><<<R.dp_blocks[1], 64, 0, R.dp_stream[1]>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1]);
-    else k_dp_sel<4><<<R.dp_blocks[1], 64, 0, R.dp_stream[1]>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1]);
+    k_dp_small<<<2560, 256, 0, side0>>>(cx, sinks.s[0], rb, sel);
+    if (grouped) k_dp_group<4><<<R.dp_blocks[1], 64, 0, side1>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1], 0xFFFFFFFFu);
+    else k_dp_sel<4><<<R.dp_blocks[1], 64, 0, side1>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1]);
     // (the half-wave class behind the 65-256-column class looks like the long pole on a timeline; moved behind the shorter chains
     //  the stage takes the same 3.3-3.4 ms: the kernels share the chip, the stage is the sum of their work)
     k_dp_tiny<<<2048, 256, 0, wide ? R.dp_stream[3] : s>>>(cx, sinks.s[4], rb, sel);
-    k_dp_half<<<2048, 256, 0, wide ? R.dp_stream[4] : R.dp_stream[1]>>>(cx, sinks.s[5], rb, sel);
-    k_dp_sel<16><<<R.dp_blocks[2], 64, 0, wide ? R.dp_stream[2] : R.dp_stream[0]>>>(cx, sinks.s[3], rb, sel, R.d_dp_scratch[2], R.dp_stride[2]);
+    k_dp_half<<<2048, 256, 0, wide ? R.dp_stream[4] : side1>>>(cx, sinks.s[5], rb, sel);
+    k_dp_sel<16><<<R.dp_blocks[2], 64, 0, wide ? R.dp_stream[2] : side0>>>(cx, sinks.s[3], rb, sel, R.d_dp_scratch[2], R.dp_stride[2]);
     }
     for (int k = 0; k < n_side; k++) { HIP_TRY(hipEventRecord(R.dp_join[k], R.dp_stream[k])); HIP_TRY(hipStreamWaitEvent(s, R.dp_join[k], 0)); }
     return 0;
@@ -2144,10 +2177,10 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     so.read_ext = c->d_read_ext; so.read_blocks = c->d_read_blocks;
     so.packed = c->d_packed; so.wpad = c->wpad; so.queue = R.d_cnt + CNT_QUEUE;
     RescueList rl; rl.ids = R.d_rescue; rl.n = R.d_cnt + CNT_RESCUE; rl.cap = R.rescue_cap;
-    EarlyList el; el.ids = nullptr; el.est = nullptr; el.n = R.d_cnt + CNT_EARLY; el.cap = 0;
+    EarlyList el; el.ids = nullptr; el.est = nullptr; el.n = R.d_cnt + CNT_EARLY; el.cap = 0; el.n_hits = R.d_cnt + CNT_EARLY_HITS;
     if (early) { el.ids = c->t1.d_sel_ids; el.est = c->t1.d_est; el.cap = (uint32_t)c->max_reads; }
     const bool late = early && c->overlap_late;
-    EarlyList ll; ll.ids = nullptr; ll.est = nullptr; ll.n = R.d_cnt + CNT_LATE; ll.cap = 0;
+    EarlyList ll; ll.ids = nullptr; ll.est = nullptr; ll.n = R.d_cnt + CNT_LATE; ll.cap = 0; ll.n_hits = R.d_cnt + CNT_EARLY_HITS;
     if (late) { ll.ids = c->t2.d_sel_ids; ll.est = c->t2.d_est; ll.cap = kLateRoom; }
     JobSinks sinks;
     for (int k = 0; k < kDpClasses; k++) { sinks.s[k].jobs = R.d_jobs[k]; sinks.s[k].count = R.d_cnt + CNT_JOB0 + k * kCntPad; sinks.s[k].cap = R.job_cap[k]; }
@@ -2189,24 +2222,32 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         const bool no_simple = getenv("MCX_NO_SIMPLE") != nullptr;
         const uint8_t *done = nullptr;
         if (!no_simple && !sel.ids && !cx.detail && cx.ix.sa_full && cx.packed) {
-            k_simple<<<pb, 256, 0, s>>>(cx, rb, sel.n, sel.est, so.read_blocks, d_recs, c->d_pout, c->d_done, c->d_batch_flags + 2, R.d_cnt + CNT_SIMPLE);
+            if (cx.pm.use_nw) k_simple<true><<<pb, 256, 0, s>>>(cx, rb, sel.n, sel.est, so.read_blocks, d_recs, c->d_pout, c->d_done, c->d_batch_flags + 2, R.d_cnt + CNT_SIMPLE);
+            else k_simple<false><<<pb, 256, 0, s>>>(cx, rb, sel.n, sel.est, so.read_blocks, d_recs, c->d_pout, c->d_done, c->d_batch_flags + 2, R.d_cnt + CNT_SIMPLE);
             done = c->d_done;
-            order_cnt = c->d_order_cnt;
         }
+        order_cnt = c->d_order_cnt; // (the class counts: how many pairs the order lists — all of them without k_simple — and where a class begins)
         const unsigned ob = (sel.n + 256 * kOrderTile - 1) / (256 * kOrderTile);
         HIP_TRY(hipMemsetAsync(c->d_order_cnt, 0, 16 * kCntPad * sizeof(uint32_t), s));
         k_order_count<<<ob, 256, 0, s>>>(sel, so.read_blocks, nr, c->d_order_cnt, done);
         k_order_place<<<ob, 256, 0, s>>>(sel, so.read_blocks, nr, c->d_order_cnt, c->d_order, done);
         order = c->d_order;
     }
+    bool early_recorded = false;
     const size_t cl_bytes = cluster_lds_bytes(cx.caps.hit_cap, cx.caps.cand_cap);
     if (tier == 1 && cl_bytes <= 60 * 1024 && !getenv("MCX_CLUSTER_BY_LANE")) { // the large tier's pairs: a wavefront each, in two launches by size
         const int small = std::min(kClusterSmall, cx.caps.hit_cap);
         k_cluster_wave<<<std::min<unsigned>(sel.n, 16384u), 64, cluster_lds_bytes(small, small), s>>>(cx, rb, sel, rl, so.read_blocks, -1, small, small, small);
         if (small < cx.caps.hit_cap)
             k_cluster_wave<<<std::min<unsigned>(sel.n, 8192u), 64, cl_bytes, s>>>(cx, rb, sel, rl, so.read_blocks, small, 1 << 30, cx.caps.hit_cap, cx.caps.cand_cap);
-    } else k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl, so.read_blocks, el, order, order_cnt);
-    if (early) HIP_TRY(hipEventRecord(c->ev_clustered, s));
+    } else if (order && cx.caps.hit_seed >= 8 && cx.caps.cand_seed >= 8) {
+        // classes 0-3 hold every pair with more than 8 seed hits: only such a pair can run over 8 or more hits / candidates per read
+        k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl, so.read_blocks, el, order, order_cnt, 0, 3);
+        if (early) HIP_TRY(hipEventRecord(c->ev_clustered, s));
+        early_recorded = true;
+        k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl, so.read_blocks, el, order, order_cnt, 4, kWorkClasses - 1);
+    } else k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl, so.read_blocks, el, order, order_cnt, 0, kWorkClasses - 1);
+    if (early && !early_recorded) HIP_TRY(hipEventRecord(c->ev_clustered, s));
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     if (paired) {
         if (getenv("MCX_RESCUE_BY_PAIR")) { // (experiments: a workgroup per pair, the pair's windows one after the other)
@@ -2348,8 +2389,8 @@ static int pass_finish(mcx_ctx *c, int tier, const PassRes &R, uint32_t n_sel, m
     for (int k = 0; k < kDpClasses; k++) if (n[CNT_JOB0 + k * kCntPad] > R.job_cap[k]) return kListOverflow;
     if (n[CNT_UNSUP]) return fail(MCX_ERR_UNSUPPORTED, "a gapped fragment exceeds 2048 x 1024 cells per side");
     if (timing && getenv("MCX_TIMING"))
-        fprintf(stderr, "[run_pairs] pairs %u: sa tasks %u, rescue pairs %u (windows %u), dp jobs by class (tiny) %u %u (half) %u %u %u %u, cells %llu, overflow pairs %u (+ %u listed while clustering), %u straight-line pairs (k_simple)\n", n_sel,
-                n[CNT_TASKS], n[CNT_RESCUE], n[CNT_RTASK], n[CNT_JOB4], n[CNT_JOB0], n[CNT_JOB5], n[CNT_JOB1], n[CNT_JOB2], n[CNT_JOB3], *(const unsigned long long *)(n + CNT_CELLS), n[CNT_OV], n[CNT_EARLY], n[CNT_SIMPLE]);
+        fprintf(stderr, "[run_pairs] pairs %u: sa tasks %u, rescue pairs %u (windows %u), dp jobs by class (tiny) %u %u (half) %u %u %u %u, cells %llu, overflow pairs %u (+ %u listed while clustering, %u of them for their seed hits), %u straight-line pairs (k_simple)\n", n_sel,
+                n[CNT_TASKS], n[CNT_RESCUE], n[CNT_RTASK], n[CNT_JOB4], n[CNT_JOB0], n[CNT_JOB5], n[CNT_JOB1], n[CNT_JOB2], n[CNT_JOB3], *(const unsigned long long *)(n + CNT_CELLS), n[CNT_OV], n[CNT_EARLY], n[CNT_EARLY_HITS], n[CNT_SIMPLE]);
     if (stats) {
         stats->dp_jobs += (int64_t)n[CNT_JOB0] + n[CNT_JOB1] + n[CNT_JOB2] + n[CNT_JOB3] + n[CNT_JOB4] + n[CNT_JOB5];
         stats->dp_cells += (int64_t)(*(const unsigned long long *)(n + CNT_CELLS));

@@ -20,11 +20,29 @@
 #ifndef MCX_SIMPLE_H
 #define MCX_SIMPLE_H
 #include "mcx_glue.h"
+#include "mcx_dp_lane.h"
 
 namespace mcx {
 
+// (the test harness counts which exit a read takes: MCX_SIMPLE_FAIL(exit number))
+#ifndef MCX_SIMPLE_FAIL
+#define MCX_SIMPLE_FAIL(code) return false
+#endif
+
 constexpr int kSimpleHits = 4;                  // seeds per read the straight-line path takes (one 64-byte line of hits)
-constexpr int kSimpleRuns = 2 * kSimpleHits;    // CIGAR operations such a read can have (seeds and gaps alternate; equal neighbours merge)
+constexpr int kSimpleRuns = 2 * kSimpleHits;    // CIGAR operations the path keeps per read (seeds and gaps alternate, equal neighbours merge; a read that needs more leaves)
+constexpr int kSimpleDp = 8;                    // a gap between two seeds of up to kSimpleDp x kSimpleDp bases is aligned right here, by the lane (mcx_dp_lane.h)
+
+// the lane's words for such a problem: the query (two words) and one traceback word per row — no strip edges, one strip
+static inline MCX_HD LaneLayout simple_dp_layout() { LaneLayout l; l.off_q = 0; l.off_edge = 0; l.off_dir = 2; l.rows = kSimpleDp; l.words = 2 + kSimpleDp; return l; }
+
+// what the walk of such a problem leaves: the column string (2 bits a column, the LAST column in the low bits) and the counts the
+// gates and scores read (frag_columns: 'M' columns, mismatches among them, runs)
+struct SimpleCols {
+    uint32_t w = 0; int len = 0, n = 0, mis = 0, switches = 0, cur = -1;
+    MCX_HD bool wants_bases() const { return true; }
+    MCX_HD void col(int kind, int differ) { w |= (uint32_t)kind << (2 * len); len++; if (kind == 0) { n++; mis += differ; } if (kind != cur) { cur = kind; switches++; } }
+};
 
 struct SimpleRead {
     int64_t pd0;        // PosDiff of the candidate: of its first seed in (PosDiff, rPos) order
@@ -37,16 +55,18 @@ struct SimpleRead {
 
 // One read: true when it is straight-line; then `out` and cig[k * cig_stride] (k < out.n_cig) are filled.
 // hits: the read's seeds as k_seed left them (text positions), n of them (1..kSimpleHits); codes: its 2-bit words (no N).
+// dpm: simple_dp_layout().words words of this lane for the small gapped extensions (null: a gap that needs one makes the read leave).
+template <bool NW>
 static inline MCX_HD bool simple_read(const IndexView &ix, const Params &pm, int rlen, const uint32_t *codes, const Hit *hits, int n,
-                                      SimpleRead &out, uint32_t *cig, int cig_stride)
+                                      SimpleRead &out, uint32_t *cig, int cig_stride, const LaneMem *dpm)
 {
-    if (n < 1 || n > kSimpleHits || !codes) return false;
+    if (n < 1 || n > kSimpleHits || !codes) MCX_SIMPLE_FAIL(1);
     // ---- the seeds with PosDiff > 0 (IdentifySimplePairs' tail); the straight-line case needs all of them to stay
     int64_t g[kSimpleHits], pd[kSimpleHits];
     int r[kSimpleHits], len[kSimpleHits];
     MCX_UNROLL
     for (int i = 0; i < kSimpleHits; i++) {
-        if (i < n) { const Hit h = hits[i]; g[i] = h.gPos; r[i] = h.rPos; len[i] = h.len; pd[i] = h.gPos - h.rPos; if (pd[i] <= 0) return false; }
+        if (i < n) { const Hit h = hits[i]; g[i] = h.gPos; r[i] = h.rPos; len[i] = h.len; pd[i] = h.gPos - h.rPos; if (pd[i] <= 0) MCX_SIMPLE_FAIL(2); }
         else { g[i] = 0; r[i] = 0x7fffffff; len[i] = 0; pd[i] = (int64_t)1 << 62; } // (sorts behind the real ones)
     }
     // ---- one cluster (SimplePairClustering): in (PosDiff, rPos) order neighbours lie within MaxPosDiff of each other and
@@ -66,13 +86,13 @@ static inline MCX_HD bool simple_read(const IndexView &ix, const Params &pm, int
         auto cx2 = [](int64_t &a, int64_t &b) { if (a > b) { const int64_t t = a; a = b; b = t; } };
         cx2(sp[0], sp[1]); cx2(sp[2], sp[3]); cx2(sp[0], sp[2]); cx2(sp[1], sp[3]); cx2(sp[1], sp[2]);
         MCX_UNROLL
-        for (int i = 1; i < kSimpleHits; i++) if (i < n && sp[i] - sp[i - 1] > pm.max_pos_diff) return false;
+        for (int i = 1; i < kSimpleHits; i++) if (i < n && sp[i] - sp[i - 1] > pm.max_pos_diff) MCX_SIMPLE_FAIL(3);
         const int64_t g_end = boundary_of(ix, sg0);
         int score = 0;
         MCX_UNROLL
-        for (int i = 0; i < kSimpleHits; i++) if (i < n) { if (g[i] > g_end) return false; score += len[i]; }
-        if (score <= (rlen >> 2)) return false;       // no candidate at all
-        if (score >= rlen && n > 1) return false;     // the tandem-repeat branch picks a run of equal PosDiff
+        for (int i = 0; i < kSimpleHits; i++) if (i < n) { if (g[i] > g_end) MCX_SIMPLE_FAIL(4); score += len[i]; }
+        if (score <= (rlen >> 2)) MCX_SIMPLE_FAIL(5);       // no candidate at all
+        if (score >= rlen && n > 1) MCX_SIMPLE_FAIL(6);     // the tandem-repeat branch picks a run of equal PosDiff
     }
     // ---- the seeds in read order (ProduceReadAlignment sorts by (rPos, gPos), ReadAlignment.cpp:317)
     {
@@ -100,20 +120,39 @@ static inline MCX_HD bool simple_read(const IndexView &ix, const Params &pm, int
                 const uint32_t w = ((uint32_t)run_len << 4) | (uint32_t)run_op;
                 MCX_UNROLL
                 for (int k = 0; k < kSimpleRuns; k++) if (k == n_run) runs[k] = w;
-                n_run++;
+                n_run++; // (past kSimpleRuns the read leaves: checked where the last run is closed)
             }
             run_op = op; run_len = 0;
         }
         run_len += l;
     };
+    // a gap between two seeds that ProcessNormalPair hands to the gapped extension (ReadAlignment.cpp:184-187), small enough for the
+    // lane: the product's own sweep and walk (mcx_dp_lane.h, strips of 8 columns), both strings reversed on the reverse strand as the
+    // DP kernels take them; then the middle fragment's gate (:373-381), its matches, and its columns as CIGAR runs in read order
+    auto dp_gap = [&](int rp, int64_t gp, int rl_, int gl_) -> bool {
+        if (!dpm || rl_ > kSimpleDp || gl_ > kSimpleDp) MCX_SIMPLE_FAIL(18);
+        const bool rev = gp >= ix.G;
+        const LaneLayout l = simple_dp_layout();
+        dpm->put(l.off_q, lane_query16(codes, rp, rl_, rev, 0));
+        dpm->put(l.off_q + 1, 0u);
+        auto tgt16 = [&](int b0) -> uint32_t { return lane_target16(ix, gp, gl_, rev, b0); };
+        SimpleCols sc;
+        if (NW) { (void)lane_sweep_nw<kSimpleDp>(*dpm, l, rl_, gl_, tgt16); lane_walk_nw<kSimpleDp>(*dpm, l, rl_, gl_, tgt16, sc); }
+        else { lane_sweep_ksw2<kSimpleDp>(*dpm, l, rl_, gl_, tgt16); lane_walk_ksw2<kSimpleDp>(*dpm, l, rl_, gl_, tgt16, sc); }
+        if (rl_ >= kMinAlnBlockSize && gl_ >= kMinAlnBlockSize && (sc.switches >= 4 || (sc.mis >= 3 && sc.mis >= (int)(sc.n * 0.3)))) MCX_SIMPLE_FAIL(19); // the candidate would die
+        score += sc.n - sc.mis; mism += sc.mis;
+        // the string's columns: first column at bits 2 (len - 1); on the reverse strand the string runs against the read
+        for (int j = 0; j < sc.len; j++) add(1, (int)((sc.w >> (2 * (rev ? j : sc.len - 1 - j))) & 3u));
+        return true;
+    };
     // a gap fragment of equal lengths: mismatches, the DP decision (ReadAlignment.cpp:184), the gate of its place
     // (head / tail: dropped when it is long enough and bad, :343-372; in between: the whole candidate dies, :373-381)
-    auto plain_gap = [&](int rp, int64_t gp, int l) -> bool {
+    auto plain_gap = [&](int rp, int64_t gp, int l, bool middle) -> bool {
         Frag x; x.rPos = rp; x.gPos = gp; x.rLen = l; x.gLen = l; x.ops_off = 0; x.ops_len = 0; x.kind = kPlain; x.meta = 0;
         ReadRef rd; rd.ascii = nullptr; rd.rlen = rlen; rd.flipped = 0; rd.codes = codes;
         const int mm = frag_mismatches(ix, x, rd);
-        if (mm > 1 && mm >= (int)(l * 0.2)) return false;                  // a DP problem
-        if (l >= kMinAlnBlockSize && mm >= 3 && mm >= (int)(l * 0.3)) return false; // (one kind of column: switches = 1) the quality gate would fire
+        if (mm > 1 && mm >= (int)(l * 0.2)) { if (middle) return dp_gap(rp, gp, l, l); MCX_SIMPLE_FAIL(7); } // a DP problem (at a read end its string may be trimmed: the general path)
+        if (l >= kMinAlnBlockSize && mm >= 3 && mm >= (int)(l * 0.3)) MCX_SIMPLE_FAIL(8); // (one kind of column: switches = 1) the quality gate would fire
         score += l - mm; mism += mm;
         add(l, 0);
         return true;
@@ -124,35 +163,35 @@ static inline MCX_HD bool simple_read(const IndexView &ix, const Params &pm, int
     int64_t prev_g = -1;
     MCX_UNROLL
     for (int i = 0; i < kSimpleHits; i++) {
-        if (i >= n) break;
+        if (i >= n) continue;
         const int r0 = r[i];
         const int64_t g0 = g[i];
         if (i == 0) {
             g_head = g0 - r0;
-            if (r0 > 0 && !plain_gap(0, g0 - r0, r0)) return false;
+            if (r0 > 0 && !plain_gap(0, g0 - r0, r0, false)) MCX_SIMPLE_FAIL(9);
         } else {
             const int rg = r0 - pr;
             const int64_t gg = g0 - pg;
-            if (r0 <= prev_r || g0 <= prev_g || rg < 0 || gg < 0) return false; // not in order / overlapping: the general path sorts and trims
+            if (r0 <= prev_r || g0 <= prev_g || rg < 0 || gg < 0) MCX_SIMPLE_FAIL(10); // not in order / overlapping: the general path sorts and trims
             if (rg > 0 && gg > 0) {
-                if ((int64_t)rg != gg) return false;                            // a DP problem
-                if (!plain_gap(pr, pg, rg)) return false;
+                if ((int64_t)rg != gg) { if (gg > kSimpleDp || !dp_gap(pr, pg, rg, (int)gg)) MCX_SIMPLE_FAIL(11); } // a DP problem
+                else if (!plain_gap(pr, pg, rg, true)) MCX_SIMPLE_FAIL(12);
             } else if (rg > 0) add(rg, 1);                                       // read bases against '-'
-            else if (gg > 0) { if (gg >= 4096) return false; add((int)gg, 2); } // '-' against genome bases (Frag::gLen is 12 bits)
+            else if (gg > 0) { if (gg >= 4096) MCX_SIMPLE_FAIL(13); add((int)gg, 2); } // '-' against genome bases (Frag::gLen is 12 bits)
         }
         score += len[i];
         add(len[i], 0);
         prev_r = r0; prev_g = g0; pr = r0 + len[i]; pg = g0 + len[i];
     }
-    if (pr < rlen) { if (!plain_gap(pr, pg, rlen - pr)) return false; pg += rlen - pr; }
+    if (pr < rlen) { if (!plain_gap(pr, pg, rlen - pr, false)) MCX_SIMPLE_FAIL(14); pg += rlen - pr; }
     g_tail = pg;
     // CheckAlignmentValidity (tools.cpp:119-130): inside [0, 2G) and on one chromosome
-    if (g_head < 0 || g_tail > ix.G2) return false;
+    if (g_head < 0 || g_tail > ix.G2) MCX_SIMPLE_FAIL(15);
     {
         const int e1 = end_slot(ix, g_head), e2 = end_slot(ix, g_tail - 1);
-        if (e1 < 0 || e2 < 0 || ix.end_pos[e1] != ix.end_pos[e2]) return false;
+        if (e1 < 0 || e2 < 0 || ix.end_pos[e1] != ix.end_pos[e2]) MCX_SIMPLE_FAIL(16);
     }
-    if (score == 0 || (score < min_score && mism > max_mm)) return false;          // the candidate would be dropped (:392-396)
+    if (score == 0 || (score < min_score && mism > max_mm)) MCX_SIMPLE_FAIL(17);          // the candidate would be dropped (:392-396)
     // close the last run; the operations in alignment order (a reverse-strand candidate's fragments are read backwards, :412-416)
     {
         const uint32_t w = ((uint32_t)run_len << 4) | (uint32_t)run_op;
@@ -160,6 +199,7 @@ static inline MCX_HD bool simple_read(const IndexView &ix, const Params &pm, int
         for (int k = 0; k < kSimpleRuns; k++) if (k == n_run) runs[k] = w;
         n_run++;
     }
+    if (n_run > kSimpleRuns) MCX_SIMPLE_FAIL(20); // more operations than the path keeps
     const int fwd = g_head < ix.G ? 1 : 0;
     MCX_UNROLL
     for (int k = 0; k < kSimpleRuns; k++) if (k < n_run) cig[(fwd ? k : n_run - 1 - k) * cig_stride] = runs[k];

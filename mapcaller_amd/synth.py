@@ -278,10 +278,16 @@ def _records(bases: torch.Tensor, first: int, step: int, prefix: str, fastq: boo
     return out
 
 
-def write_fastq(path: str, bases: torch.Tensor, first: int, step: int, prefix: str = "sim") -> None:
+def write_fastq(path: str, bases: torch.Tensor, first: int, step: int, prefix: str = "sim", append: bool = False) -> None:
     """Rows first, first+step, ... of ``bases`` as FASTQ; read k of the file is named
-    ``<prefix>_<k, zero padded>`` so that both mates of a pair share a name. Qualities are 'I'."""
-    _records(bases, first, step, prefix, True).tofile(path)
+    ``<prefix>_<k, zero padded>`` so that both mates of a pair share a name. Qualities are 'I'.
+    ``append``: behind what the file holds (a further batch of reads under another prefix)."""
+    rec = _records(bases, first, step, prefix, True)
+    if append:
+        with open(path, "ab") as fh:
+            rec.tofile(fh)
+    else:
+        rec.tofile(path)
 
 
 def write_fasta_reads(path: str, bases: torch.Tensor, first: int, step: int, prefix: str = "sim") -> None:

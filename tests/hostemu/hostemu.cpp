@@ -15,6 +15,8 @@
 
 #include "../../mapcaller_amd/csrc/mcx_glue.h"
 #include "../../mapcaller_amd/csrc/mcx_dp_lane.h"
+static long g_simple_why[32]; // which exit of simple_read reads took (MCX_EMU_SIMPLE_WHY=1 prints the tally)
+#define MCX_SIMPLE_FAIL(code) do { g_simple_why[code]++; return false; } while (0)
 #include "../../mapcaller_amd/csrc/mcx_simple.h"
 #include "../../mapcaller_amd/csrc/mcx_host.h"
 #include "simple_io.h"
@@ -137,7 +139,13 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
                 bool has_n = false;
                 for (int i = 0; i < one.rlen; i++) { const int c = read_code(one, i); if (c > 3) has_n = true; else pkbuf[s][i >> 4] |= (uint32_t)c << (30 - 2 * (i & 15)); }
                 const int nh = st.hdr->n_hits[s];
-                ok = !has_n && nh >= 1 && nh <= kSimpleHits && simple_read(cx.ix, cx.pm, one.rlen, pkbuf[s].data(), st.hits[s], nh, sr[s], cg[s], 1);
+                if (has_n) g_simple_why[20]++; else if (nh < 1) g_simple_why[21]++; else if (nh > kSimpleHits) g_simple_why[22]++;
+                uint32_t dp_words[2 + kSimpleDp];
+                LaneMem dpm; dpm.base = dp_words; dpm.stride = 1;
+                const LaneMem *dp = getenv("MCX_EMU_SIMPLE_NO_DP") ? nullptr : &dpm;
+                ok = !has_n && nh >= 1 && nh <= kSimpleHits &&
+                     (cx.pm.use_nw ? simple_read<true>(cx.ix, cx.pm, one.rlen, pkbuf[s].data(), st.hits[s], nh, sr[s], cg[s], 1, dp)
+                                   : simple_read<false>(cx.ix, cx.pm, one.rlen, pkbuf[s].data(), st.hits[s], nh, sr[s], cg[s], 1, dp));
             }
             if (!ok) continue;
             const uint32_t want = (uint32_t)sr[0].n_cig + (nr == 2 ? (uint32_t)sr[1].n_cig : 0u);
@@ -145,7 +153,7 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
             const uint32_t off[2] = {e.cig_used, e.cig_used + (uint32_t)sr[0].n_cig};
             AlnRec rec2[2];
             PairOut po;
-            if (!simple_pair(cx, nr == 2, sr[0], sr[nr - 1], rl[0], rl[nr - 1], est[l], rec2, off, po)) continue;
+            if (!simple_pair(cx, nr == 2, sr[0], sr[nr - 1], rl[0], rl[nr - 1], est[l], rec2, off, po)) { g_simple_why[23]++; continue; }
             for (int s = 0; s < nr; s++) {
                 for (int k = 0; k < sr[s].n_cig; k++) cig[off[s] + k] = cg[s][k];
                 recs[(size_t)ids[l] * nr + s] = rec2[s];
@@ -155,6 +163,11 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
             done[l] = 1;
             if (stats) stats[11]++;
         }
+    }
+    if (getenv("MCX_EMU_SIMPLE_WHY") && tier == 0 && n > 100) {
+        fprintf(stderr, "[simple] %u pairs; reads leaving simple_read by exit:", n);
+        for (int k = 1; k < 24; k++) if (g_simple_why[k]) fprintf(stderr, " %d:%ld", k, g_simple_why[k]);
+        fprintf(stderr, " (20 N, 21 no seed, 22 more than %d seeds, 23 not paired within the estimate)\n", kSimpleHits);
     }
     // k_cluster, k_rescue, k_build
     for (uint32_t l = 0; l < n; l++) {
