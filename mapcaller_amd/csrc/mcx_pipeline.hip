@@ -405,6 +405,9 @@ struct SeedOut {
     const uint32_t *packed;  // 2-bit reads of the batch (k_pack_reads), wpad words each
     int wpad;
     uint32_t *queue;         // next read of the pass that no wavefront has taken yet
+    // the late pairs' pass: their seed hits are already there, complete, in the records of the tier that listed them (pair = record:
+    // the main pass) — a read without N takes them from there instead of searching again (null: every read is searched)
+    const uint8_t *src_state; Layout src_lay; Caps src_caps;
 };
 
 // 16 bytes from any address: two aligned 16-byte fetches and a byte funnel
@@ -480,7 +483,9 @@ static __device__ __forceinline__ void pack16(const ReadRef &rd, int i0, uint32_
 // of the file's bytes, fetched as aligned 16-byte words by neighbouring threads, so the batch is
 // packed at streaming speed instead of base by base in the seeding lanes.  Mate 2 is packed
 // reverse-complemented (ReadMapping.cpp:451).  tpr threads per read: ceil(max_read_len / 32) + 1.
-__global__ void __launch_bounds__(256) k_pack_reads(ReadBatch rb, int paired, int wpad, int tpr, uint32_t *out)
+// (any_n: set when a read of the batch holds a byte that is not one of ACGT — the passes of the large tier, which are queued after the
+//  host has looked at the batch's counters anyway, leave out the kernel for such reads when there is none)
+__global__ void __launch_bounds__(256) k_pack_reads(ReadBatch rb, int paired, int wpad, int tpr, uint32_t *out, uint32_t *any_n)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t r = (uint32_t)(t / (uint32_t)tpr);
@@ -498,6 +503,8 @@ __global__ void __launch_bounds__(256) k_pack_reads(ReadBatch rb, int paired, in
         o[2 * m] = c0;
         if (2 * m + 1 < nc) o[2 * m + 1] = c1;
         o[nc + 1 + m] = (f0 << 16) | f1;
+        const int left = rlen - 32 * m; // bases of this mask word inside the read (bit 31 = the first)
+        if (((f0 << 16) | f1) & (left >= 32 ? ~0u : ~(0xFFFFFFFFu >> left))) atomicOr(any_n, 1u);
     } else if (m == nmw) {
         o[nc] = 0u;
         o[nc + 1 + nmw] = 0xFFFFFFFFu;
@@ -584,6 +591,16 @@ __global__ void __launch_bounds__(256, MCX_SEED_WAVES) k_seed(Ctx cx, ReadBatch 
             hits = pair_state(cx.state, cx.lay, cx.caps, lr / nr).hits[lr % nr];
             n = 0; p = 0; ext = 0; blocks = 0; has_n = 0; walk.phase = 0;
             const int words = packed_words(rlen);
+            if (so.src_state && !(so.read_ext[r] >> 31)) {
+                // (the list as k_cluster left it: PosDiff > 0 only, sorted — clustering it again gives the same candidates; the entries the
+                //  filter dropped are made up by entries it drops again, so that the read's hit count, a statistic, stays what the search found)
+                const PairState src = pair_state((uint8_t *)so.src_state, so.src_lay, so.src_caps, r / nr);
+                const int m = src.hdr->n_hits[r % nr], n0 = (int)(so.read_blocks[r] >> 20);
+                for (int i = 0; i < m; i++) hits[i] = src.hits[r % nr][i];
+                Hit none; none.gPos = 0; none.rPos = 0; none.len = 0;
+                for (int i = m; i < n0; i++) hits[i] = none;
+                fresh = false; // (counters untouched: they are the search's)
+            } else
             if (rlen > 0 && words <= pk_words) {
                 const U4 *src = (const U4 *)(so.packed + (uint64_t)r * so.wpad);
                 for (int k = 0; k < words; k += 4) {
@@ -606,7 +623,7 @@ __global__ void __launch_bounds__(256, MCX_SEED_WAVES) k_seed(Ctx cx, ReadBatch 
                 }
                 have = seed_next_start(pk, rlen, p, nm);
             }
-            if (!have) finish_read(); // (nothing to search in it: the lane takes another one next time round)
+            if (!have && fresh) finish_read(); // (nothing to search in it: the lane takes another one next time round)
         }
         if (!__ballot(have)) { if (dry) break; continue; }
         // ---- every lane that holds a read moves its search on: each phase with a budget, so that a lane deep inside a repeat
@@ -815,6 +832,7 @@ __global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel s
         over = (el.ids && (fl & kOvAny)) ? 1u : 0u;
         if (over && (fl & kOvHits)) atomicAdd(el.n_hits, 1u); // (diagnosis: how many of the listed pairs were known to run over once k_seed was done)
         if (over) st.hdr->flags = fl | kDispatched; // the later stages of this tier leave the pair alone (they skip kOvAny) and k_finish writes nothing for it
+        else if (need) st.hdr->flags = fl | kAwaitRescue;
     }
     const uint32_t at = wave_reserve(rl.n, need);
     if (need && at < rl.cap) rl.ids[at] = local;
@@ -986,6 +1004,7 @@ __global__ void __launch_bounds__(64) k_cluster_wave(Ctx cx, ReadBatch rb, PairS
             h.n_hits[0] = (int16_t)n_hits[0]; h.n_hits[1] = (int16_t)n_hits[1]; h.n_cands[0] = (int16_t)n_cands[0]; h.n_cands[1] = (int16_t)n_cands[1];
             h.sum[0].best = h.sum[1].best = -1; h.sum[0].score = h.sum[1].score = 0; h.sum[0].sub = h.sum[1].sub = 0;
             h.est = sel.est[local]; h.est_lo = lo; h.est_hi = hi; h.n_paired = (int16_t)n_paired;
+            if (cx.pm.paired && !(flags & kOvAny) && n_paired == 0) h.flags |= kAwaitRescue;
             *st.hdr = h;
             if (cx.pm.paired && !(flags & kOvAny) && n_paired == 0) {
                 const uint32_t at = atomicAdd(rl.n, 1u);
@@ -1275,15 +1294,22 @@ __global__ void __launch_bounds__(256) k_rescue_apply(Ctx cx, RescueWork rw)
 #ifndef MCX_BUILD_WAVES
 #define MCX_BUILD_WAVES 5
 #endif
+// (mode 0: every listed pair.  Mate rescue touches one pair in eighty, and the other seventy-nine need nothing from it: mode 1 builds
+//  the pairs that do not await it — beside the rescue kernels, on another stream — and mode 2, once those are through, the pairs of
+//  the rescue list rl.)
 __global__ void __launch_bounds__(256, MCX_BUILD_WAVES) k_build(Ctx cx, ReadBatch rb, PairSel sel, JobSinks sinks, uint32_t *cells, uint32_t *unsupported, EarlyList late,
-                                               const uint32_t *order, const uint32_t *order_cnt)
+                                               const uint32_t *order, const uint32_t *order_cnt, int mode, RescueList rl)
 {
     __shared__ EndsLds ends;
-    if (blockIdx.x * blockDim.x >= listed_pairs(sel, order_cnt)) return; // (uniform over the block)
+    const uint32_t n_listed = mode == 2 ? min(*rl.n, rl.cap) : listed_pairs(sel, order_cnt);
+    if (blockIdx.x * blockDim.x >= n_listed) return; // (uniform over the block)
     stage_ends(cx.ix, ends);
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = slot < listed_pairs(sel, order_cnt);
-    const uint32_t local = in ? (order ? order[slot] : slot) : 0u;
+    bool in = slot < n_listed;
+    const uint32_t local = in ? (mode == 2 ? rl.ids[slot] : (order ? order[slot] : slot)) : 0u;
+    // (the rescue list's pairs are mode 2's: told by a flag the clustering set and nobody clears — the rescue, which runs beside mode 1,
+    //  rewrites those pairs' headers and candidates meanwhile)
+    if (in && mode == 1 && (pair_state(cx.state, cx.lay, cx.caps, local).hdr->flags & kAwaitRescue)) in = false;
     int nj = 0;
     uint32_t fl = 0;
     if (in) {
@@ -1681,8 +1707,10 @@ constexpr uint32_t kPoutSel = 1u << 16; // pair outcomes gathered per copy (run_
 enum { CNT_TASKS = 0, CNT_RESCUE = 1 * kCntPad, CNT_JOB0 = 2 * kCntPad, CNT_JOB1 = 3 * kCntPad, CNT_JOB2 = 4 * kCntPad, CNT_JOB3 = 5 * kCntPad,
        CNT_JOB4 = 6 * kCntPad, CNT_JOB5 = 7 * kCntPad, CNT_OV = 8 * kCntPad, CNT_LF = 9 * kCntPad, CNT_CELLS = 10 * kCntPad, CNT_UNSUP = 11 * kCntPad,
        CNT_QUEUE = 12 * kCntPad, CNT_EARLY = 13 * kCntPad, CNT_LATE = 14 * kCntPad, CNT_RTASK = 15 * kCntPad, CNT_RPLAN = 16 * kCntPad, CNT_RESCUE_N = 17 * kCntPad, CNT_RSEED = 18 * kCntPad,
-       CNT_SIMPLE = 19 * kCntPad, CNT_EARLY_HITS = 20 * kCntPad, CNT_N = 21 * kCntPad };
-constexpr uint32_t kLateRoom = 256; // pairs of a pass that may run over after clustering and still go through the large tier beside it
+       CNT_SIMPLE = 19 * kCntPad, CNT_EARLY_HITS = 20 * kCntPad, CNT_N = 21 * kCntPad,
+       // behind the counters proper, cleared with them at the start of a pass (a memset in the middle of a pass was seen to sit 1.4 ms in its queue):
+       CNT_ORDER = CNT_N, CNT_DP_SORT = CNT_ORDER + 16 * kCntPad, CNT_ALL = CNT_DP_SORT + 4 * 256 };
+constexpr uint32_t kLateRoom = 2048; // pairs of a pass that may run over after clustering and still go through the large tier beside it
 
 // What a pass over a selection of pairs works with besides the pair records: stream, counters, work lists, DP scratch.
 // The context holds two sets, so that the large tier can map the heavy pairs of a pass (listed while the pass clusters)
@@ -1698,7 +1726,7 @@ struct PassRes {
     uint32_t rtask_cap = 0, rseed_cap = 0;
     uint8_t *d_dp_scratch[3] = {nullptr, nullptr, nullptr}; uint64_t dp_stride[3] = {0, 0, 0}; uint32_t dp_blocks[3] = {0, 0, 0};
     uint32_t *d_dp_lane = nullptr; uint32_t dp_lane_blocks = 0; // k_dp_lane's words for the three short lists (tiny | small | half), dp_lane_blocks wavefronts each
-    uint32_t *d_dp_order[2] = {nullptr, nullptr}, *d_dp_sort = nullptr; // the two long lists by shape (k_dp_sort_*): the order; 2 x (256 counts + 256 cursors)
+    uint32_t *d_dp_order[2] = {nullptr, nullptr}; // the two long lists by shape (k_dp_sort_*; their bucket counts and cursors: CNT_DP_SORT)
     hipStream_t dp_stream[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t dp_fork = nullptr, dp_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t *d_ov = nullptr; uint32_t ov_cap = 0;
     uint32_t *d_sel_ids = nullptr; int32_t *d_est = nullptr;
@@ -1739,12 +1767,12 @@ struct mcx_ctx {
     hipStream_t dp_stream[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t dp_fork = nullptr, dp_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     uint8_t *d_dp_scratch[3] = {nullptr, nullptr, nullptr}; uint64_t dp_stride[3] = {0, 0, 0}; uint32_t dp_blocks[3] = {0, 0, 0};
     uint32_t *d_dp_lane = nullptr; uint32_t dp_lane_blocks = 0;
-    uint32_t *d_dp_order[2] = {nullptr, nullptr}, *d_dp_sort = nullptr;
+    uint32_t *d_dp_order[2] = {nullptr, nullptr};
     uint32_t *d_ov = nullptr; uint32_t ov_cap = 0;
     uint32_t *d_sel_ids = nullptr; int32_t *d_est = nullptr;
     uint32_t *d_read_ext = nullptr, *d_read_blocks = nullptr;
     uint32_t *d_packed = nullptr; int wpad = 0; // 2-bit form of the batch's reads
-    uint32_t *d_order = nullptr, *d_order_cnt = nullptr; // the pairs of a pass by weight (k_order_*)
+    uint32_t *d_order = nullptr; // the pairs of a pass by weight (k_order_*; their class counts: CNT_ORDER)
     uint8_t *d_done = nullptr;                           // per pair of a pass: k_simple wrote its records (the per-pair kernels skip it)
     PairOut *d_pout = nullptr, *d_pout_sel = nullptr; // per-pair outcome of the finish stage; a gathered selection of it
     uint8_t *d_mapq = nullptr; int mapq_rows = 0;
@@ -1764,7 +1792,7 @@ struct mcx_ctx {
     size_t n_tally = 0;
     uint64_t keys_cap = 0;       // keys the sort buffers hold
     uint64_t *h_keys = nullptr; uint64_t h_keys_cap = 0; // pinned: the batch's keys for the exchange between shards
-    uint32_t *d_batch_flags = nullptr; // [0] words taken in the batch's CIGAR pool, [1] longest read of the batch, [2] the pool ran over
+    uint32_t *d_batch_flags = nullptr; // [0] words taken in the batch's CIGAR pool, [1] longest read of the batch, [2] the pool ran over, [3] a read holds an N
     BatchRun run;
     PassRes t1;               // the large tier's own set (the members above are tier 0's); allocated when every suffix-array entry is resident
     bool overlap_tiers = false;
@@ -1878,7 +1906,7 @@ static int passres_alloc(mcx_ctx *c, PassRes &t, uint64_t pairs, uint64_t sel_ca
     for (int k = 0; k < n_side; k++) { HIP_TRY(hipStreamCreateWithPriority(&t.dp_stream[k], hipStreamNonBlocking, priority)); HIP_TRY(hipEventCreateWithFlags(&t.dp_join[k], hipEventDisableTiming)); }
     HIP_TRY(hipEventCreateWithFlags(&t.dp_fork, hipEventDisableTiming));
     for (auto &e : t.ev) HIP_TRY(hipEventCreate(&e));
-    if ((rc = dmalloc(&t.d_cnt, CNT_N))) return rc;
+    if ((rc = dmalloc(&t.d_cnt, CNT_ALL))) return rc;
     HIP_TRY(hipHostMalloc((void **)&t.h_cnt, CNT_N * sizeof(uint32_t)));
     for (int k = 0; k < kDpClasses; k++) {
         t.job_cap[k] = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(pairs * 16, 1u << 20), c->job_cap[k]);
@@ -1895,7 +1923,6 @@ static int passres_alloc(mcx_ctx *c, PassRes &t, uint64_t pairs, uint64_t sel_ca
     t.dp_lane_blocks = pairs >= 4096 ? 2048u : 256u;
     if ((rc = dmalloc(&t.d_dp_lane, (size_t)(lane_short_words(0) + lane_short_words(1) + lane_short_words(2)) * t.dp_lane_blocks))) return rc;
     for (int k = 0; k < 2; k++) if ((rc = dmalloc(&t.d_dp_order[k], t.job_cap[1 + k]))) return rc;
-    if ((rc = dmalloc(&t.d_dp_sort, 4 * kDpBuckets))) return rc;
     t.ov_cap = (uint32_t)sel_cap;
     if ((rc = dmalloc(&t.d_ov, t.ov_cap))) return rc;
     if ((rc = dmalloc(&t.d_sel_ids, sel_cap))) return rc;
@@ -1906,7 +1933,7 @@ static int passres_alloc(mcx_ctx *c, PassRes &t, uint64_t pairs, uint64_t sel_ca
 static void passres_free(PassRes &t)
 {
     void *q[] = {t.d_cnt, t.d_jobs[0], t.d_jobs[1], t.d_jobs[2], t.d_jobs[3], t.d_jobs[4], t.d_jobs[5], t.d_rescue, t.d_dp_scratch[0], t.d_dp_scratch[1],
-                 t.d_dp_scratch[2], t.d_ov, t.d_sel_ids, t.d_est, t.d_rtasks, t.d_rres, t.d_rseeds, t.d_rplans, t.d_rescue_n, t.d_dp_lane, t.d_dp_order[0], t.d_dp_order[1], t.d_dp_sort};
+                 t.d_dp_scratch[2], t.d_ov, t.d_sel_ids, t.d_est, t.d_rtasks, t.d_rres, t.d_rseeds, t.d_rplans, t.d_rescue_n, t.d_dp_lane, t.d_dp_order[0], t.d_dp_order[1]};
     for (void *x : q) if (x) (void)hipFree(x);
     if (t.h_cnt) (void)hipHostFree(t.h_cnt);
     for (auto &e : t.ev) if (e) (void)hipEventDestroy(e);
@@ -1931,8 +1958,12 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     int rc = 0;
     c->tier[0].caps = tier0_caps(); c->tier[0].lay = make_layout(c->tier[0].caps); c->tier[0].max_pairs = (uint32_t)c->max_reads;
     c->tier[1].caps = tier1_caps(c->rlen_max); c->tier[1].lay = make_layout(c->tier[1].caps);
-    // (the heavy pairs of a batch in as few passes as 8 GB of records allow: a pass is bound by its slowest pair, not by its size)
-    c->tier[1].max_pairs = (uint32_t)std::max<uint64_t>(1024, std::min<uint64_t>(std::min<uint64_t>(c->max_reads, 65536), ((uint64_t)8 << 30) / (uint64_t)c->tier[1].lay.stride));
+    // (the heavy pairs of a batch in as few passes as possible — a pass is bound by its slowest pair, not by its size, and passes follow
+    //  one another: BASELINE config 5 sends 4.5 % of its pairs here, five passes of 36 k pairs with 8 GB of records — with room in
+    //  proportion to the batch: 3 KB per read, 2-24 GB (MCX_TIER1_GB overrides))
+    uint64_t t1_bytes = std::min<uint64_t>(std::max<uint64_t>(c->max_reads * 3072, (uint64_t)2 << 30), (uint64_t)24 << 30);
+    if (const char *e = getenv("MCX_TIER1_GB")) t1_bytes = (uint64_t)std::max(1, atoi(e)) << 30;
+    c->tier[1].max_pairs = (uint32_t)std::max<uint64_t>(1024, std::min<uint64_t>(std::min<uint64_t>(c->max_reads, 131072), t1_bytes / (uint64_t)c->tier[1].lay.stride));
     // (tier 0's records are allocated by the first batch: a paired batch of max_reads reads is max_reads / 2 pairs, and at 8 KB a
     //  record the other half is 33 GB at 8 M reads — only single-end batches need a record per read)
     c->tier[0].max_pairs = 0;
@@ -1944,7 +1975,7 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
         if (const char *e = getenv("MCX_JOB_CAP")) c->job_cap[k] = std::min<uint32_t>(c->job_cap[k], (uint32_t)std::max(1024, atoi(e))); // (tests: make the lists run over)
         if ((rc = dmalloc(&c->d_jobs[k], c->job_cap[k]))) return rc;
     }
-    if ((rc = dmalloc(&c->d_cnt, CNT_N))) return rc;
+    if ((rc = dmalloc(&c->d_cnt, CNT_ALL))) return rc;
     HIP_TRY(hipHostMalloc((void **)&c->h_cnt, CNT_N * sizeof(uint32_t)));
     c->rescue_cap = (uint32_t)c->max_reads;
     if ((rc = dmalloc(&c->d_rescue, c->rescue_cap))) return rc;
@@ -1962,7 +1993,6 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     c->dp_lane_blocks = 4096;
     if ((rc = dmalloc(&c->d_dp_lane, (size_t)(lane_short_words(0) + lane_short_words(1) + lane_short_words(2)) * c->dp_lane_blocks))) return rc;
     for (int k = 0; k < 2; k++) if ((rc = dmalloc(&c->d_dp_order[k], c->job_cap[1 + k]))) return rc;
-    if ((rc = dmalloc(&c->d_dp_sort, 4 * kDpBuckets))) return rc;
     c->ov_cap = (uint32_t)c->max_reads;
     if ((rc = dmalloc(&c->d_ov, c->ov_cap))) return rc;
     if ((rc = dmalloc(&c->d_sel_ids, c->max_reads))) return rc;
@@ -1976,7 +2006,6 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     if ((rc = dmalloc(&c->d_pout, c->max_reads))) return rc;
     if ((rc = dmalloc(&c->d_pout_sel, kPoutSel))) return rc;
     if ((rc = dmalloc(&c->d_order, c->max_reads))) return rc;
-    if ((rc = dmalloc(&c->d_order_cnt, 16 * kCntPad))) return rc;
     if ((rc = dmalloc(&c->d_done, c->max_reads))) return rc;
     // EvaluateMAPQ (SamReport.cpp:86-101) tabulated on the host so that the double-precision
     // log() is the host libm's, exactly as in the reference
@@ -2022,7 +2051,7 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3], c->d_jobs[4], c->d_jobs[5],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_rtasks, c->d_rres, c->d_rseeds, c->d_rplans, c->d_rescue_n, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
                  c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
-                 c->d_dp_lane, c->d_dp_order[0], c->d_dp_order[1], c->d_dp_sort, c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_pout_sel, c->d_order, c->d_order_cnt, c->d_done, c->d_packed, c->d_batch_flags, c->d_scan_tmp, c->d_prof_match, c->d_prof_items};
+                 c->d_dp_lane, c->d_dp_order[0], c->d_dp_order[1], c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_pout_sel, c->d_order, c->d_done, c->d_packed, c->d_batch_flags, c->d_scan_tmp, c->d_prof_match, c->d_prof_items};
     for (void *q : p) if (q) (void)hipFree(q);
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
     if (c->h_keys) (void)hipHostFree(c->h_keys);
@@ -2074,7 +2103,7 @@ static PassRes res_tier0(mcx_ctx *c)
     r.d_rescue = c->d_rescue; r.rescue_cap = c->rescue_cap; r.d_kscratch = c->d_kscratch;
     r.d_rtasks = c->d_rtasks; r.d_rres = c->d_rres; r.d_rseeds = c->d_rseeds; r.d_rplans = c->d_rplans; r.d_rescue_n = c->d_rescue_n; r.rtask_cap = c->rtask_cap; r.rseed_cap = c->rseed_cap;
     for (int k = 0; k < 3; k++) { r.d_dp_scratch[k] = c->d_dp_scratch[k]; r.dp_stride[k] = c->dp_stride[k]; r.dp_blocks[k] = c->dp_blocks[k]; }
-    r.d_dp_lane = c->d_dp_lane; r.dp_lane_blocks = c->dp_lane_blocks; r.d_dp_order[0] = c->d_dp_order[0]; r.d_dp_order[1] = c->d_dp_order[1]; r.d_dp_sort = c->d_dp_sort;
+    r.d_dp_lane = c->d_dp_lane; r.dp_lane_blocks = c->dp_lane_blocks; r.d_dp_order[0] = c->d_dp_order[0]; r.d_dp_order[1] = c->d_dp_order[1];
     for (int k = 0; k < 5; k++) { r.dp_stream[k] = c->dp_stream[k]; r.dp_join[k] = c->dp_join[k]; }
     r.dp_fork = c->dp_fork; r.d_ov = c->d_ov; r.ov_cap = c->ov_cap; r.d_sel_ids = c->d_sel_ids; r.d_est = c->d_est;
     for (int k = 0; k < 10; k++) r.ev[k] = c->ev[k];
@@ -2116,8 +2145,7 @@ static int launch_dp(const PassRes &R, const Ctx &cx, const JobSinks &sinks, con
         if (by_shape) {
             const int row_shift = rlen_max <= 256 ? 4 : (rlen_max <= 512 ? 5 : 6); // (16 row classes cover the longest query)
             for (int k = 0; k < 2; k++) {
-                uint32_t *counts = R.d_dp_sort + 2 * kDpBuckets * k, *cursor = counts + kDpBuckets;
-                HIP_TRY(hipMemsetAsync(counts, 0, kDpBuckets * sizeof(uint32_t), st[k]));
+                uint32_t *counts = R.d_cnt + CNT_DP_SORT + 2 * kDpBuckets * k, *cursor = counts + kDpBuckets; // (cleared with the pass's counters)
                 k_dp_sort_count<<<1024, 256, 0, st[k]>>>(sinks.s[1 + k], row_shift, counts, lane_min[k]);
                 k_dp_sort_scan<<<1, 256, 0, st[k]>>>(counts, cursor);
                 k_dp_sort_place<<<1024, 256, 0, st[k]>>>(sinks.s[1 + k], row_shift, cursor, R.d_dp_order[k], lane_min[k]);
@@ -2163,7 +2191,7 @@ static int tier1_pass_end(mcx_ctx *c, const PassRes &T, uint32_t m, mcx_stats *t
 static int pass_finish(mcx_ctx *c, int tier, const PassRes &R, uint32_t n_sel, mcx_stats *stats, bool timing, int e);
 
 static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb, int paired, PairSel sel, AlnRec *d_recs,
-                     uint32_t *d_cig, mcx_stats *stats, bool timing, bool early = false, uint32_t state_off = 0, int *queued = nullptr)
+                     uint32_t *d_cig, mcx_stats *stats, bool timing, bool early = false, uint32_t state_off = 0, int *queued = nullptr, bool hits_from_tier0 = false, bool no_n_reads = false)
 {
     if (sel.n == 0) return 0;
     hipStream_t s = R.stream;
@@ -2172,10 +2200,12 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     cx.seed_pool = R.d_rseeds;
     const int nr = paired ? 2 : 1;
     early = early && tier == 0 && c->overlap_tiers;
-    HIP_TRY(hipMemsetAsync(R.d_cnt, 0, CNT_N * sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(R.d_cnt, 0, CNT_ALL * sizeof(uint32_t), s)); // (the pass's counters, the class counts of its order, the bucket counts of its DP lists)
     SeedOut so; so.tasks = R.d_tasks; so.n_tasks = R.d_cnt + CNT_TASKS; so.task_cap = R.task_cap;
     so.read_ext = c->d_read_ext; so.read_blocks = c->d_read_blocks;
     so.packed = c->d_packed; so.wpad = c->wpad; so.queue = R.d_cnt + CNT_QUEUE;
+    so.src_state = nullptr; so.src_lay = c->tier[0].lay; so.src_caps = c->tier[0].caps;
+    if (hits_from_tier0 && tier == 1 && cx.ix.sa_full && !getenv("MCX_LATE_RESEED")) so.src_state = c->tier[0].state;
     RescueList rl; rl.ids = R.d_rescue; rl.n = R.d_cnt + CNT_RESCUE; rl.cap = R.rescue_cap;
     EarlyList el; el.ids = nullptr; el.est = nullptr; el.n = R.d_cnt + CNT_EARLY; el.cap = 0; el.n_hits = R.d_cnt + CNT_EARLY_HITS;
     if (early) { el.ids = c->t1.d_sel_ids; el.est = c->t1.d_est; el.cap = (uint32_t)c->max_reads; }
@@ -2215,7 +2245,8 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     // the pairs in the order of their weight (k_order_*): worth two small passes when the pass is a large one
     const uint32_t *order = nullptr, *order_cnt = nullptr;
-    if (tier == 0 && sel.n >= 16384 && c->d_order && !getenv("MCX_NO_WORK_ORDER")) {
+    const char *order_min = getenv("MCX_ORDER_MIN"); // (tests: small batches through k_simple and the order too)
+    if (tier == 0 && sel.n >= (order_min ? (uint32_t)std::max(1, atoi(order_min)) : 16384u) && c->d_order && !getenv("MCX_NO_WORK_ORDER")) {
         // ahead of them, on a whole batch: the straight-line pairs from their seeds to their records (k_simple); what is left is listed
         // by weight for the per-pair kernels.  (Not with the -vcf bookkeeping — its per-read detail comes from the finish stage —, not
         // without the suffix array in HBM — the seeds must be text positions —, not on a selection: k_simple takes pair = record.)
@@ -2226,11 +2257,11 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
             else k_simple<false><<<pb, 256, 0, s>>>(cx, rb, sel.n, sel.est, so.read_blocks, d_recs, c->d_pout, c->d_done, c->d_batch_flags + 2, R.d_cnt + CNT_SIMPLE);
             done = c->d_done;
         }
-        order_cnt = c->d_order_cnt; // (the class counts: how many pairs the order lists — all of them without k_simple — and where a class begins)
+        uint32_t *cls_cnt = R.d_cnt + CNT_ORDER; // (cleared with the pass's counters)
+        order_cnt = cls_cnt; // (the class counts: how many pairs the order lists — all of them without k_simple — and where a class begins)
         const unsigned ob = (sel.n + 256 * kOrderTile - 1) / (256 * kOrderTile);
-        HIP_TRY(hipMemsetAsync(c->d_order_cnt, 0, 16 * kCntPad * sizeof(uint32_t), s));
-        k_order_count<<<ob, 256, 0, s>>>(sel, so.read_blocks, nr, c->d_order_cnt, done);
-        k_order_place<<<ob, 256, 0, s>>>(sel, so.read_blocks, nr, c->d_order_cnt, c->d_order, done);
+        k_order_count<<<ob, 256, 0, s>>>(sel, so.read_blocks, nr, cls_cnt, done);
+        k_order_place<<<ob, 256, 0, s>>>(sel, so.read_blocks, nr, cls_cnt, c->d_order, done);
         order = c->d_order;
     }
     bool early_recorded = false;
@@ -2240,8 +2271,10 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         k_cluster_wave<<<std::min<unsigned>(sel.n, 16384u), 64, cluster_lds_bytes(small, small), s>>>(cx, rb, sel, rl, so.read_blocks, -1, small, small, small);
         if (small < cx.caps.hit_cap)
             k_cluster_wave<<<std::min<unsigned>(sel.n, 8192u), 64, cl_bytes, s>>>(cx, rb, sel, rl, so.read_blocks, small, 1 << 30, cx.caps.hit_cap, cx.caps.cand_cap);
-    } else if (order && cx.caps.hit_seed >= 8 && cx.caps.cand_seed >= 8) {
-        // classes 0-3 hold every pair with more than 8 seed hits: only such a pair can run over 8 or more hits / candidates per read
+    } else if (order && cx.caps.hit_seed >= 8 && cx.caps.cand_seed >= 8 && getenv("MCX_CLUSTER_HEAVY_FIRST")) {
+        // (experiments: classes 0-3 hold every pair with more than 8 seed hits — only such a pair can run over 8 or more hits / candidates
+        //  per read — so the large tier could start after a launch of their own; measured: that launch alone takes 1.34 of the 1.73 ms
+        //  both take together, the large tier starts 0.2 ms earlier and the step is 0.4 ms longer)
         k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl, so.read_blocks, el, order, order_cnt, 0, 3);
         if (early) HIP_TRY(hipEventRecord(c->ev_clustered, s));
         early_recorded = true;
@@ -2249,6 +2282,10 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     } else k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl, so.read_blocks, el, order, order_cnt, 0, kWorkClasses - 1);
     if (early && !early_recorded) HIP_TRY(hipEventRecord(c->ev_clustered, s));
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
+    // mate rescue beside the build of the pairs that do not await it (k_build's modes), when the set has a side stream for it
+    const bool rescue_aside = paired && R.dp_stream[0] && !getenv("MCX_RESCUE_BY_PAIR") && !getenv("MCX_RESCUE_IN_LINE");
+    hipStream_t rs = rescue_aside ? R.dp_stream[0] : s;
+    if (rescue_aside) { HIP_TRY(hipEventRecord(R.dp_fork, s)); HIP_TRY(hipStreamWaitEvent(rs, R.dp_fork, 0)); }
     if (paired) {
         if (getenv("MCX_RESCUE_BY_PAIR")) { // (experiments: a workgroup per pair, the pair's windows one after the other)
             if (tier == 0) k_rescue<2048><<<kRescueBlocks, kRescueThreads, 0, s>>>(cx, rb, sel, rl, R.d_kscratch);
@@ -2258,17 +2295,29 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
             rw.task_cap = R.rtask_cap; rw.seed_cap = R.rseed_cap; rw.ids_n = R.d_rescue_n; rw.n_ids_n = R.d_cnt + CNT_RESCUE_N;
             RescueList rn; rn.ids = R.d_rescue_n; rn.n = R.d_cnt + CNT_RESCUE_N; rn.cap = R.rescue_cap;
             const unsigned gb = std::min<unsigned>(std::max<unsigned>((sel.n + 255) / 256, 1u), 1024u);
-            k_rescue_plan<<<gb, 256, 0, s>>>(cx, rb, sel, rl, rw);
-            if (tier == 0) k_rescue_eval<2048><<<4096, 256, 0, s>>>(cx, rb, sel, rw);
-            else k_rescue_eval<4096><<<4096, 256, 0, s>>>(cx, rb, sel, rw);
-            k_rescue_apply<<<gb, 256, 0, s>>>(cx, rw);
-            // the pairs with an N in a read (none in most batches: the launch then ends at once)
-            if (tier == 0) k_rescue<2048><<<256, kRescueThreads, 0, s>>>(cx, rb, sel, rn, R.d_kscratch);
-            else k_rescue<4096><<<256, kRescueThreads, 0, s>>>(cx, rb, sel, rn, R.d_kscratch);
+            k_rescue_plan<<<gb, 256, 0, rs>>>(cx, rb, sel, rl, rw);
+            if (tier == 0) k_rescue_eval<2048><<<4096, 256, 0, rs>>>(cx, rb, sel, rw);
+            else k_rescue_eval<4096><<<4096, 256, 0, rs>>>(cx, rb, sel, rw);
+            k_rescue_apply<<<gb, 256, 0, rs>>>(cx, rw);
+            // the pairs with an N in a read (none in most batches: the launch then ends at once — once it gets onto the chip, which beside
+            // the other tier's long-lived wavefronts took the large tier half a millisecond: left out where the batch is known to hold no N)
+            if (no_n_reads) {}
+            else if (tier == 0) k_rescue<2048><<<256, kRescueThreads, 0, rs>>>(cx, rb, sel, rn, R.d_kscratch);
+            else k_rescue<4096><<<256, kRescueThreads, 0, rs>>>(cx, rb, sel, rn, R.d_kscratch);
         }
     }
-    if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
-    k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP, ll, order, order_cnt);
+    // three time stamps: in line they bracket rescue | nothing | build, with the rescue aside build (others) | what is left of the wait for the rescue | build (its pairs)
+    if (rescue_aside) {
+        HIP_TRY(hipEventRecord(R.dp_join[0], rs));
+        k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP, ll, order, order_cnt, 1, rl);
+        if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
+        HIP_TRY(hipStreamWaitEvent(s, R.dp_join[0], 0));
+        if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
+        k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP, ll, order, order_cnt, 2, rl);
+    } else {
+        if (timing) { HIP_TRY(hipEventRecord(R.ev[e++], s)); HIP_TRY(hipEventRecord(R.ev[e++], s)); }
+        k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP, ll, order, order_cnt, 0, rl);
+    }
     if (late) HIP_TRY(hipEventRecord(c->ev_built, s));
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     if ((rc2 = launch_dp(R, cx, sinks, rb, sel, c->rlen_max))) return rc2;
@@ -2277,7 +2326,8 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(R.h_cnt, R.d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    if (queued) { *queued = e; return 0; }
+    const int e_flag = e | (rescue_aside ? 0x100 : 0); // (for pass_finish: which stage a time stamp closes)
+    if (queued) { *queued = e_flag; return 0; }
     hipEvent_t ev_dbg[2] = {nullptr, nullptr}; // (MCX_TIMING: when tier 0 and the large tier beside it were done)
     if (early && getenv("MCX_TIMING")) {
         for (int k = 0; k < 2; k++) HIP_TRY(hipEventCreate(&ev_dbg[k]));
@@ -2289,8 +2339,10 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         uint32_t n_early = 0;
         HIP_TRY(hipStreamWaitEvent(T.stream, c->ev_clustered, 0));
         HIP_TRY(hipMemcpyAsync(T.h_cnt, R.d_cnt + CNT_EARLY, sizeof(uint32_t), hipMemcpyDeviceToHost, T.stream));
+        HIP_TRY(hipMemcpyAsync(T.h_cnt + 1, c->d_batch_flags + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, T.stream)); // (k_pack_reads is long done)
         HIP_TRY(hipStreamSynchronize(T.stream));
         n_early = T.h_cnt[0];
+        const bool no_n = T.h_cnt[1] == 0;
         if (n_early > el.cap) { (void)hipStreamSynchronize(s); return fail(MCX_ERR_CAPACITY, "overflow list overflow"); }
         if (stats) stats->tier1_pairs += n_early;
         const bool t1_timing = getenv("MCX_TIMING") != nullptr;
@@ -2304,7 +2356,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
             const bool last = lo + room >= n_early;
             PairSel s1; s1.n = m; s1.ids = T.d_sel_ids + lo; s1.est = T.d_est + lo;
             memset(&t1, 0, sizeof t1);
-            rc2 = run_pairs(c, 1, T, rb, paired, s1, d_recs, d_cig, t1_timing ? &t1 : stats, t1_timing, false, 0, last ? &e1 : nullptr);
+            rc2 = run_pairs(c, 1, T, rb, paired, s1, d_recs, d_cig, t1_timing ? &t1 : stats, t1_timing, false, 0, last ? &e1 : nullptr, false, no_n);
             if (!last && rc2 == 0) rc2 = tier1_pass_end(c, T, m, t1_timing ? &t1 : nullptr, stats, -1);
         }
         if (late && rc2 == 0) {
@@ -2317,7 +2369,8 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
             n_late = std::min<uint32_t>(U.h_cnt[0], kLateRoom);
             if (n_late) {
                 PairSel s2; s2.n = n_late; s2.ids = U.d_sel_ids; s2.est = U.d_est;
-                rc2 = run_pairs(c, 1, U, rb, paired, s2, d_recs, d_cig, stats, false, false, c->tier[1].max_pairs - kLateRoom, &e2);
+                // (their seed hits are in this pass's records — pair = record when the pass is a whole batch — and complete: what ran over came later)
+                rc2 = run_pairs(c, 1, U, rb, paired, s2, d_recs, d_cig, stats, false, false, c->tier[1].max_pairs - kLateRoom, &e2, sel.ids == nullptr && state_off == 0, no_n);
                 if (stats) stats->tier1_pairs += n_late;
             }
         }
@@ -2334,7 +2387,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         for (int k = 0; k < 2; k++) (void)hipEventDestroy(ev_dbg[k]);
     }
     if (rc2) return rc2;
-    return pass_finish(c, tier, R, sel.n, stats, timing, e);
+    return pass_finish(c, tier, R, sel.n, stats, timing, e_flag);
 }
 
 // what follows a pass once its stream has been joined: the work lists' overflow checks, counts and stage times
@@ -2396,10 +2449,16 @@ static int pass_finish(mcx_ctx *c, int tier, const PassRes &R, uint32_t n_sel, m
         stats->dp_cells += (int64_t)(*(const unsigned long long *)(n + CNT_CELLS));
         stats->simple_pairs += n[CNT_SIMPLE];
         if (timing) {
-            float ms[8];
-            for (int i = 0; i + 1 < e; i++) HIP_TRY(hipEventElapsedTime(&ms[i], R.ev[i], R.ev[i + 1]));
-            stats->ms_seed += ms[0]; stats->ms_sa += ms[1]; stats->ms_cluster += ms[2]; stats->ms_rescue += ms[3];
-            stats->ms_build += ms[4]; stats->ms_dp += ms[5]; stats->ms_finish += ms[6];
+            float ms[10];
+            const bool aside = (e & 0x100) != 0;
+            const int n_ev = e & 0xFF;
+            for (int i = 0; i + 1 < n_ev; i++) HIP_TRY(hipEventElapsedTime(&ms[i], R.ev[i], R.ev[i + 1]));
+            stats->ms_seed += ms[0]; stats->ms_sa += ms[1]; stats->ms_cluster += ms[2];
+            // (run_pairs: in line ms[3] is the rescue, ms[4] nothing, ms[5] the build; with the rescue on a stream of its own ms[3] and ms[5] are the
+            //  build's two launches and ms[4] what was left to wait for the rescue)
+            if (aside) { stats->ms_build += ms[3] + ms[5]; stats->ms_rescue += ms[4]; }
+            else { stats->ms_rescue += ms[3] + ms[4]; stats->ms_build += ms[5]; }
+            stats->ms_dp += ms[6]; stats->ms_finish += ms[7];
         }
     }
     return 0;
@@ -2641,7 +2700,7 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
         const int tpr = ((int)c->h_cnt[1] + 31) / 32 + 1; // (threads per read: for the batch's longest read, found above)
         br.longest = c->h_cnt[1];
         const uint64_t threads = (uint64_t)n_reads * (uint64_t)tpr;
-        k_pack_reads<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(br.rb, paired, c->wpad, tpr, c->d_packed);
+        k_pack_reads<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(br.rb, paired, c->wpad, tpr, c->d_packed, c->d_batch_flags + 3);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_pack[1], s));
     }
@@ -2670,7 +2729,7 @@ extern "C" int mcx_batch_sums(mcx_ctx *c, uint32_t *n_chunks, const uint32_t **p
     hipStream_t s = c->stream;
     HIP_TRY(hipSetDevice(c->idx->device));
     const uint32_t nc = br.n_chunks;
-    if (br.sums_valid && br.ok.size() == nc) { // nothing was re-run since the last call (the closing round of a sharded step): the sums still stand
+    if (br.sums_valid && br.ok.size() == nc && !getenv("MCX_NO_SUMS_CACHE")) { // nothing was re-run since the last call (the closing round of a sharded step): the sums still stand
         if (n_chunks) *n_chunks = nc;
         if (pairs) *pairs = br.ok.data();
         if (dist) *dist = br.ds.data();

@@ -159,7 +159,8 @@ enum PairFlags : uint32_t {
     kOvDetail = 128u,
     kOvAny = 255u,
     kRescueUsedEst = 256u,
-    kDispatched = 512u  // listed for the large tier while clustering: this tier's later stages and k_finish leave it alone
+    kDispatched = 512u, // listed for the large tier while clustering: this tier's later stages and k_finish leave it alone
+    kAwaitRescue = 1024u // listed for mate rescue while clustering (never cleared: k_build's first launch, which runs beside the rescue, tells by it which pairs are not its own)
 };
 
 struct alignas(16) PairHdr { // 64 bytes: four 16-byte groups

@@ -75,6 +75,26 @@ def test_sam_equals_reference(api, golden, tmp_path, name, alg, full_sa):
     mp.close(); ix.close()
 
 
+@pytest.mark.parametrize("alg", ["nw", "ksw2"])
+@pytest.mark.parametrize("name", list(SETS))
+def test_sam_equals_reference_on_the_large_batch_paths(api, golden, tmp_path, monkeypatch, name, alg):
+    """The golden sets again with what only a large batch switches on forced onto their small batches (MCX_ORDER_MIN=1): the straight-line
+    pairs go from their seeds to their records in k_simple — small gaps aligned by the lane — and the rest is dealt to the per-pair kernels
+    by weight; every DP list takes the one-problem-per-lane kernels (MCX_DP_LANE_ALWAYS=1), the long ones dealt by shape.  SAM identical
+    to the reference's, and the straight-line path did take pairs."""
+    monkeypatch.setenv("MCX_ORDER_MIN", "1")
+    monkeypatch.setenv("MCX_DP_LANE_ALWAYS", "1")
+    g = golden[name]
+    ix = api.Index(g["prefix"], device=0)
+    mp = api.Mapper(ix, alg=alg, max_batch_reads=1 << 14)
+    out = str(tmp_path / "gpu.sam")
+    st = mp.map_files(g["r1"], g["r2"], out)
+    nd, ex = sam_diff(g["sam"][alg], out)
+    assert nd == 0, ex
+    assert st["simple_pairs"] > (0 if name == "long" else 0.2 * st["reads"] / (2 if g["paired"] else 1)), st
+    mp.close(); ix.close()
+
+
 def test_overlapped_host_boundary_gives_the_same_records(api, golden, tmp_path):
     """mcx_stream_submit / map / collect (three batches in flight, copies on their own streams) against mcx_map_batch on the
     same batches: records and CIGAR words equal, read by read (the pool's offsets may differ)."""
@@ -624,10 +644,12 @@ def test_config2_ecoli_sized_single_end_equals_reference(api, tmp_path):
 
 
 def test_large_batch_machinery_does_not_change_the_records(api, bench_genome, monkeypatch):
-    """One large batch of the bench workload (120 k pairs on the full-size genome) mapped twice: with everything that only a large
-    batch switches on — pairs dealt to the lanes by weight, the large tier beside tier 0 on its own streams, the late list's pass on
-    the third set of resources — and with all of it off (one pass after the other on one stream, which is what the small-batch tests
-    compare with the reference).  Records and CIGAR words must be equal read by read."""
+    """One large batch of the bench workload (120 k pairs on the full-size genome) mapped three times: with everything that only a large
+    batch switches on — the straight-line pairs through k_simple, the others dealt to the lanes by weight, the large tier beside tier 0 on
+    its own streams, mate rescue beside the build of the pairs that do not await it, the late list's pass on the third set of resources
+    taking its seed hits from tier 0 —, the same with every DP list on the one-problem-per-lane kernels, and with all of it off (one pass
+    after the other on one stream, the wavefront DP kernels: what the small-batch tests compare with the reference).  Records and CIGAR
+    words must be equal read by read."""
     g = bench_genome
     n_pairs = 120000
     reads = g["bench"].make_reads(g["codes"], g["lens"], n_pairs, 150, seed=77, device=g["dev"]).reshape(2 * n_pairs, 150).cpu().numpy()
@@ -637,19 +659,26 @@ def test_large_batch_machinery_does_not_change_the_records(api, bench_genome, mo
     def run():
         mp = api.Mapper(g["index"], alg="ksw2", max_batch_reads=2 * n_pairs)
         aln, cig = mp.map_batch(bases, off, True)
-        st = dict(tier1=mp.stats.tier1_pairs)
+        st = dict(tier1=mp.stats.tier1_pairs, simple=mp.stats.simple_pairs)
         mp.close()
         return aln, cig, st
 
     a_aln, a_cig, a_st = run()
-    for k in ("MCX_NO_WORK_ORDER", "MCX_NO_LATE_OVERLAP", "MCX_NO_TIER_OVERLAP"):
+    assert a_st["simple"] > 0.3 * n_pairs, a_st  # the straight-line path took its share
+    monkeypatch.setenv("MCX_DP_LANE_ALWAYS", "1")  # every DP list one problem per lane (at this size the long lists take the wavefront kernels)
+    c_aln, c_cig, c_st = run()
+    monkeypatch.delenv("MCX_DP_LANE_ALWAYS")
+    # everything off: no k_simple, no order, the wavefront DP kernels, the rescue in line, the late pairs searched again, the tiers one after the other
+    for k in ("MCX_NO_WORK_ORDER", "MCX_NO_LATE_OVERLAP", "MCX_NO_TIER_OVERLAP", "MCX_NO_SIMPLE", "MCX_DP_BY_WAVE", "MCX_RESCUE_IN_LINE", "MCX_LATE_RESEED"):
         monkeypatch.setenv(k, "1")
     b_aln, b_cig, b_st = run()
-    assert a_st["tier1"] > 0 and a_st["tier1"] == b_st["tier1"], (a_st, b_st)
-    for f in ("pos", "mate_pos", "chr", "flag", "mapq", "tlen", "nm", "as", "xs", "n_cigar", "fwd", "has_mate"):
-        assert np.array_equal(a_aln[f], b_aln[f]), f
-    for r in range(2 * n_pairs):
-        assert np.array_equal(a_cig[r], b_cig[r]), r
+    assert a_st["tier1"] > 0 and a_st["tier1"] == b_st["tier1"] == c_st["tier1"], (a_st, b_st, c_st)
+    assert b_st["simple"] == 0, b_st
+    for x_aln, x_cig in ((b_aln, b_cig), (c_aln, c_cig)):
+        for f in ("pos", "mate_pos", "chr", "flag", "mapq", "tlen", "nm", "as", "xs", "n_cigar", "fwd", "has_mate"):
+            assert np.array_equal(a_aln[f], x_aln[f]), f
+        for r in range(2 * n_pairs):
+            assert np.array_equal(a_cig[r], x_cig[r]), r
 
 
 def test_bench_workload_keeps_its_shape(api, bench_genome):
