@@ -935,7 +935,10 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
     double t_parse = 0, t_map = 0, t_format = 0, t_write = 0, t_p_lines = 0, t_p_pack = 0, t_p_wait = 0;
     typedef std::unique_ptr<Batch> BatchPtr;
     // batch objects circulate: their buffers (page-locked: slow to get) are allocated once and stay with the context from call to call
-    const int n_objects = 16;
+    // (one shard holds at most eleven at a time: two per queue between the stages, three on the device, one each in the reader's, the
+    //  formatter's and the writer's hands; shards wait two rounds for the places of their text: sixteen.  At -batch 2 M reads an object
+    //  pins ~0.5 GB of host memory — 6 GB a shard —, which is the host-memory bill of a run: see INTEGRATION.md)
+    const int n_objects = shard_count > 1 ? 16 : 12;
     struct Kept { std::vector<BatchPtr> objects; };
     void **slot = mcx_ctx_files_slot(c, [](void *p) { delete (Kept *)p; });
     if (!*slot) *slot = new Kept();

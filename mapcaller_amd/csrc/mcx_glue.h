@@ -921,9 +921,12 @@ static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef 
 {
     PairState st = pair_state(cx.state, cx.lay, cx.caps, pair);
     PairHdr *const g_hdr = st.hdr;
-    PairHdr h = *g_hdr; // in registers through the stage; every exit stores it back
+    PairHdr h = *g_hdr; // in registers through the stage
     h.n_frags = 0; h.n_ops = 0; h.n_jobs = 0;
-    if (h.flags & kOvAny) { *g_hdr = h; if (flags_out) *flags_out = h.flags; return 0; }
+    // every exit stores back what the stage changes — three words and a short — not the whole header (the unchanged rest would have to
+    // sit somewhere for the length of the stage: the compiler parked it in scratch memory)
+    auto put_hdr = [&]() { g_hdr->flags = h.flags; g_hdr->n_frags = h.n_frags; g_hdr->n_ops = h.n_ops; g_hdr->n_jobs = h.n_jobs; };
+    if (h.flags & kOvAny) { put_hdr(); if (flags_out) *flags_out = h.flags; return 0; }
     int nr = cx.pm.paired ? 2 : 1;
     if (cx.pm.paired) {
         if (h.n_paired == 0) { keep_top_scores(st.cands[0], h.n_cands[0]); keep_top_scores(st.cands[1], h.n_cands[1]); }
@@ -933,12 +936,14 @@ static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef 
     // local list of DP jobs of this pair (flushed to the global sink at the end)
     int32_t *jl = (int32_t *)((uint8_t *)st.hdr + cx.lay.off_jobs);
     int nj = 0;
-    for (int s = 0; s < nr; s++) {
+    MCX_UNROLL // (written to unroll: a header / read pair indexed by a run-time mate number lives in scratch memory)
+    for (int s = 0; s < 2; s++) {
+        if (s >= nr) continue;
         Cand *cs = st.cands[s];
         for (int ci = 0; ci < h.n_cands[s]; ci++) {
             const Cand c = cs[ci]; // read once; what changes is stored once (frag_off and n_frags share a word)
             if (c.score == 0) { cs[ci].frag_off = (int16_t)h.n_frags; cs[ci].n_frags = 0; continue; }
-            if (h.n_frags + 2 * c.count + 2 > cx.caps.frag_cap) { cs[ci].frag_off = (int16_t)h.n_frags; cs[ci].n_frags = 0; h.flags |= kOvFrags; *g_hdr = h; if (flags_out) *flags_out = h.flags; return 0; }
+            if (h.n_frags + 2 * c.count + 2 > cx.caps.frag_cap) { cs[ci].frag_off = (int16_t)h.n_frags; cs[ci].n_frags = 0; h.flags |= kOvFrags; put_hdr(); if (flags_out) *flags_out = h.flags; return 0; }
             Frag *f = st.frags + h.n_frags;
             int nf = build_frags(cx.ix, rd[s].rlen, c.in_pool ? cx.seed_pool + c.pool_off : st.hits[s] + c.first, c.count, f);
             cs[ci].frag_off = (int16_t)h.n_frags; cs[ci].n_frags = (int16_t)(nf < 0 ? 0 : nf);
@@ -956,8 +961,8 @@ static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef 
                     }
                     if (dp) {
                         const int at = ((h.n_ops + 7) & ~7) + kDpSum; // the columns' area, behind the room for their DpSummary
-                        if (at + x.rLen + x.gLen > cx.caps.ops_cap) { h.flags |= kOvOps; *g_hdr = h; if (flags_out) *flags_out = h.flags; return 0; }
-                        if (nj >= cx.caps.job_cap) { h.flags |= kOvJobs; *g_hdr = h; if (flags_out) *flags_out = h.flags; return 0; }
+                        if (at + x.rLen + x.gLen > cx.caps.ops_cap) { h.flags |= kOvOps; put_hdr(); if (flags_out) *flags_out = h.flags; return 0; }
+                        if (nj >= cx.caps.job_cap) { h.flags |= kOvJobs; put_hdr(); if (flags_out) *flags_out = h.flags; return 0; }
                         x.kind = kDp; x.ops_off = at; x.ops_len = 0; x.meta = 0;
                         h.n_ops = at + x.rLen + x.gLen;
                         jl[2 * nj] = h.n_frags + i; jl[2 * nj + 1] = s;
@@ -971,7 +976,7 @@ static inline MCX_HD int stage_build(const Ctx &cx, int64_t pair, const ReadRef 
         }
     }
     h.n_jobs = nj;
-    *g_hdr = h;
+    put_hdr();
     if (flags_out) *flags_out = h.flags;
     return nj;
 }

@@ -1292,7 +1292,7 @@ __global__ void __launch_bounds__(256) k_rescue_apply(Ctx cx, RescueWork rw)
 // (late: the pairs that ran over this tier's capacities since clustering — mate rescue's additions, fragment lists, DP
 //  columns, job lists — are listed like the early ones, for a second pass of the large tier beside the rest of this one)
 #ifndef MCX_BUILD_WAVES
-#define MCX_BUILD_WAVES 5
+#define MCX_BUILD_WAVES 4 // (with the light pairs gone to k_simple what is left is heavier per lane: 128 registers, no spills, beat five waves at 96 with 51 spilled)
 #endif
 // (mode 0: every listed pair.  Mate rescue touches one pair in eighty, and the other seventy-nine need nothing from it: mode 1 builds
 //  the pairs that do not await it — beside the rescue kernels, on another stream — and mode 2, once those are through, the pairs of
@@ -1325,11 +1325,14 @@ __global__ void __launch_bounds__(256, MCX_BUILD_WAVES) k_build(Ctx cx, ReadBatc
             if (at < late.cap) { late.ids[at] = sel_pair(sel, local); late.est[at] = sel.est[local]; pair_state(cx.state, cx.lay, cx.caps, local).hdr->flags = fl | kDispatched; }
         }
     }
+    // (the per-class counters are updated under a compile-time index: an array indexed by a run-time class lives in scratch memory)
     uint32_t per_class[kDpClasses] = {0, 0, 0, 0, 0, 0}, my_cells = 0, bad = 0;
     for (int k = 0; k < nj; k++) {
         const DpJob j = pair_job(cx, local, k);
         const int c = job_class(j);
-        if (c < 0) bad++; else { per_class[c]++; my_cells += (uint32_t)(j.rLen * j.gLen); }
+        if (c < 0) bad++; else my_cells += (uint32_t)(j.rLen * j.gLen);
+#pragma unroll
+        for (int q = 0; q < kDpClasses; q++) per_class[q] += c == q ? 1u : 0u;
     }
     uint32_t base[kDpClasses];
 #pragma unroll
@@ -1338,8 +1341,9 @@ __global__ void __launch_bounds__(256, MCX_BUILD_WAVES) k_build(Ctx cx, ReadBatc
         const DpJob j = pair_job(cx, local, k);
         const int c = job_class(j);
         if (c < 0) continue;
-        const uint32_t at = base[c]++;
-        if (at < sinks.s[c].cap) sinks.s[c].jobs[at] = j;
+        uint32_t at = 0;
+#pragma unroll
+        for (int q = 0; q < kDpClasses; q++) if (c == q) { at = base[q]++; if (at < sinks.s[q].cap) sinks.s[q].jobs[at] = j; }
     }
     for (int o = 32; o > 0; o >>= 1) { my_cells += __shfl_down(my_cells, o, 64); bad += __shfl_down(bad, o, 64); }
     // (64 bits: the problems of one pass of BASELINE config 5 hold 5 x 10^10 cells)
@@ -1646,7 +1650,7 @@ __global__ void __launch_bounds__(256) k_dp_small(Ctx cx, JobSink sink, ReadBatc
 }
 
 #ifndef MCX_FINISH_WAVES
-#define MCX_FINISH_WAVES 5
+#define MCX_FINISH_WAVES 4 // (109 registers, no spills; five waves at 96 spilled 16)
 #endif
 __global__ void __launch_bounds__(256, MCX_FINISH_WAVES) k_finish(Ctx cx, ReadBatch rb, PairSel sel, AlnRec *recs, PairOut *pout, uint32_t *ov_ids, uint32_t *n_ov,
                                                 uint32_t ov_cap, uint32_t *pool_over, const uint32_t *order, const uint32_t *order_cnt)

@@ -85,7 +85,7 @@ def test_sam_equals_reference_on_the_large_batch_paths(api, golden, tmp_path, mo
     monkeypatch.setenv("MCX_ORDER_MIN", "1")
     monkeypatch.setenv("MCX_DP_LANE_ALWAYS", "1")
     g = golden[name]
-    ix = api.Index(g["prefix"], device=0)
+    ix = api.Index(g["prefix"], device=0, full_sa=True)  # (k_simple takes text positions: every suffix-array entry in HBM, the product's default)
     mp = api.Mapper(ix, alg=alg, max_batch_reads=1 << 14)
     out = str(tmp_path / "gpu.sam")
     st = mp.map_files(g["r1"], g["r2"], out)
