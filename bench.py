@@ -216,8 +216,8 @@ def pcie_inclusive(args, mapper, batches, reads_per_step, dist, dev):
 
 def file_to_file(args, index, kept, reads_per_step):
     """FASTQ files in, SAM file out through mcx_map_files_ex — what the CLI runs once its index is loaded —, both in tmpfs: the
-    reads of --file-batches batches of the timed region as two FASTQ files (32 M reads by default: long enough that the filling
-    and draining of the parse | map | format | write pipeline is a small part of the run), mapped in batches of --file-batch-reads."""
+    reads of --file-batches batches of the timed region as two FASTQ files (16 M reads by default, eight batches of the pipeline: the filling
+    and draining of parse | map | format | write is a small part of the run), mapped in batches of --file-batch-reads."""
     import shutil
     from mapcaller_amd import api, synth
     root = "/dev/shm" if os.path.isdir("/dev/shm") else None
@@ -231,8 +231,10 @@ def file_to_file(args, index, kept, reads_per_step):
             del reads
         mp = api.Mapper(index, alg=args.alg, max_read_len=max(256, args.rlen), max_batch_reads=args.file_batch_reads)
         runs = []
-        for _ in range(2):  # (the first run also page-locks the batch buffers and creates the output's pages)
+        for _ in range(2):  # (the first run also page-locks the batch buffers)
             mp.reset()
+            if os.path.exists(sam):
+                os.remove(sam)  # (giving 6 GB of tmpfs pages back is the file system's business, not the run's)
             t0 = time.perf_counter()
             st = mp.map_files(f1, f2, sam, threads=args.file_threads)
             runs.append(time.perf_counter() - t0)
@@ -355,10 +357,10 @@ def other_configs(args):
     runs = [
         ("config 5: GRCh38-sized genome, 250 bp PE at 5 % indels per base, -alg nw",
          ["--genome", args.genome, "--genome-mbp", str(args.genome_mbp), "--contigs", str(args.contigs), "--batch-pairs", str(args.batch_pairs), "--rlen", "250",
-          "--sub", str(args.sub), "--ins", "0.025", "--dele", "0.025", "--alg", "nw", "--cpu-pairs", "150000"]),
+          "--sub", str(args.sub), "--ins", "0.025", "--dele", "0.025", "--alg", "nw", "--cpu-pairs", "300000", "--cpu-level", "sam"]),
         ("config 2: E. coli-sized genome (4.6 Mbp, one contig), 1 M x 100 bp SE, -alg ksw2",
          ["--genome", "uniform", "--genome-mbp", "4.6", "--contigs", "1", "--repeats", "20", "--batch-pairs", "1000000", "--single-end", "1", "--rlen", "100",
-          "--sub", str(args.sub), "--ins", str(args.ins), "--dele", str(args.dele), "--alg", "ksw2", "--cpu-pairs", "20000000"]),
+          "--sub", str(args.sub), "--ins", str(args.ins), "--dele", str(args.dele), "--alg", "ksw2", "--cpu-pairs", "20000000", "--cpu-level", "full"]),
     ]
     res = []
     for name, extra in runs:
@@ -394,6 +396,8 @@ def parse():
     ap.add_argument("--full-sa", type=int, default=1, help="keep every suffix-array entry in HBM")
     ap.add_argument("--cpu-pairs", type=int, default=-1,
                     help="pairs of the CPU-baseline sample (0 = skip, -1 = about 20 s of work for this host's core count)")
+    ap.add_argument("--cpu-level", default="two", choices=["sam", "two", "full"],
+                    help="runs of the CPU baseline: with -sam only | and without any output (mapping_only) | and at -t 1")
     ap.add_argument("--repeats", type=int, default=2000, help="--genome uniform: planted dispersed repeat families")
     ap.add_argument("--genome", default="human", choices=["human", "uniform"],
                     help="repeat content of the synthetic genome: a human-like landscape (default) or round 1's nearly repeat-free one")
@@ -405,7 +409,7 @@ def parse():
                     help="1: after the main run, BASELINE.json's configs 5 (250 bp PE at 5 %% indels, -alg nw) and 2 (E. coli-sized genome, 1 M x 100 bp SE) "
                          "as child processes, reported under `other_configs` with their stage times, DP GCUPS and CPU baselines")
     ap.add_argument("--file-steps", type=int, default=1, help="1: the file-to-file leg (value_file_to_file): one batch as FASTQ files in tmpfs -> SAM; 0 = skip")
-    ap.add_argument("--file-batches", type=int, default=4, help="batches of the timed region whose reads the file-to-file leg maps (4 x 8 M reads: a run at steady state)")
+    ap.add_argument("--file-batches", type=int, default=2, help="batches of the timed region whose reads the file-to-file leg maps (2 x 8 M reads: eight batches of the file pipeline)")
     ap.add_argument("--file-batch-reads", type=int, default=1 << 21, help="reads per batch of the file front end's pipeline")
     ap.add_argument("--file-threads", type=int, default=0, help="host threads per pool of the file front end (0 = pick)")
     ap.add_argument("--vcf-slice-reads", type=int, default=4_000_000, help="reads per mapping call in the -vcf leg")
@@ -567,91 +571,88 @@ def make_reads(codes, lens, n_pairs, rlen, seed, device, sub=0.005, ins=0.001, d
     return bases  # uint8 ASCII [2 n_pairs (paired) or n_pairs, rlen]
 
 
-def cpu_baseline(args, index, bases_sample):
-    """The CPU path on this box's host cores, on a bounded sample of the same workload, index load excluded (the reference
-    starts its clock after loading, main.cpp:376).  Two runs at -t <all cores>: with `-sam <file>` (the reference then formats
-    every line and pushes it through fprintf under its OutputLock, ReadMapping.cpp:536-560 — at hundreds of threads that lock,
-    not the mapping, sets the rate) and without any output (`-no_vcf`, no `-sam`: bSAMoutput stays false, :536 is skipped) —
-    `mapping_only`, the like-for-like figure beside `value`, which times kernels and writes no text either."""
+def cpu_prepare(args, index, bases_sample):
+    """The CPU baseline's inputs on disk — the index files as the reference loads them, the sample as FASTQ — in a directory the caller
+    removes (cpu_run works on files only: it can run beside the GPU-only legs of this script)."""
     from mapcaller_amd import synth
+    se = bool(args.single_end)
+    step = 1 if se else 2
+    tmp = tempfile.mkdtemp(prefix="mcx_cpu_")
+    prefix = os.path.join(tmp, "idx")
+    index.save(prefix)
+    st = {"tmp": tmp, "prefix": prefix, "se": se, "step": step, "n_pairs": bases_sample.shape[0] // step, "alg": args.alg, "rlen": args.rlen, "level": args.cpu_level}
+    for tag, rows in (("r", bases_sample), ("t", bases_sample[:400]), ("s", bases_sample[:step * min(st["n_pairs"], 75_000)])):
+        synth.write_fastq(os.path.join(tmp, tag + "1.fq"), rows, 0, step)
+        if not se:
+            synth.write_fastq(os.path.join(tmp, tag + "2.fq"), rows, 1, 2)
+    return st
+
+
+def cpu_run(st):
+    """The CPU path on this box's host cores, on a bounded sample of the same workload, index load excluded (the reference
+    starts its clock after loading, main.cpp:376).  At -t <all cores>: with `-sam <file>` (the reference then formats every line and
+    pushes it through fprintf under its OutputLock, ReadMapping.cpp:536-560) and — level "two" / "full" — without any output (`-no_vcf`, no
+    `-sam`: bSAMoutput stays false, :536 is skipped): `mapping_only`, the like-for-like figure beside `value`, which times kernels and writes
+    no text either.  Level "full" adds a -t 1 run on 75 k pairs; for the GRCh38-sized index every run of the reference spends
+    ~45 s loading it, so the default line leaves that one to profiles/round4/full_batch_parity.json (8 M reads at -t 1)."""
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "MapCaller")
     port_bin = os.path.join(ROOT, "oracle", "mcx_oracle")
     cores = os.cpu_count() or 1
-    se = bool(args.single_end)
-    step = 1 if se else 2
-    n_pairs = bases_sample.shape[0] // step
-    with tempfile.TemporaryDirectory() as tmp:
-        prefix = os.path.join(tmp, "idx")
-        index.save(prefix)
-        f1, f2 = os.path.join(tmp, "r1.fq"), os.path.join(tmp, "r2.fq")
-        t1, t2 = os.path.join(tmp, "t1.fq"), os.path.join(tmp, "t2.fq")
-        synth.write_fastq(f1, bases_sample, 0, step)
-        synth.write_fastq(t1, bases_sample[:400], 0, step)
-        if not se:
-            synth.write_fastq(f2, bases_sample, 1, 2)
-            synth.write_fastq(t2, bases_sample[:400], 1, 2)
-        if os.path.exists(ref_bin):
-            kind = "reference"
-            def run(a, b, threads=cores, sam=True):
-                cmd = [ref_bin, "-i", prefix, "-f", a] + ([] if se else ["-f2", b]) + ["-alg", args.alg] + (["-sam", os.path.join(tmp, "o.sam")] if sam else []) + \
-                      ["-no_vcf", "-t", str(threads), "-log", os.path.join(tmp, "job.log")]
-                t0 = time.perf_counter()
-                r = subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
-                wall = time.perf_counter() - t0
-                # the reference's own clock starts after the index is loaded (main.cpp:376) and prints whole seconds
-                m = re.findall(r"have been processed in (\d+) seconds", r.stderr)
-                return wall, (int(m[-1]) if m else None)
-        elif os.path.exists(port_bin):
-            kind = "port"
-            def run(a, b, threads=cores, sam=True):
-                cmd = [port_bin, "-i", prefix, "-f", a] + ([] if se else ["-f2", b]) + ["-alg", args.alg, "-sam", os.path.join(tmp, "o.sam") if sam else "/dev/null", "-t", str(threads)]
-                t0 = time.perf_counter()
-                subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-                return time.perf_counter() - t0, None
-        else:
-            return None
-        t_load, _ = run(t1, t2, sam=False)    # 200 pairs: index load + start-up (what a wall clock has to be corrected by)
+    tmp, prefix, se, step, n_pairs, alg = st["tmp"], st["prefix"], st["se"], st["step"], st["n_pairs"], st["alg"]
+    fq = lambda tag: (os.path.join(tmp, tag + "1.fq"), os.path.join(tmp, tag + "2.fq"))
+    if os.path.exists(ref_bin):
+        kind = "reference"
+        def run(a, b, threads=cores, sam=True):
+            cmd = [ref_bin, "-i", prefix, "-f", a] + ([] if se else ["-f2", b]) + ["-alg", alg] + (["-sam", os.path.join(tmp, "o.sam")] if sam else []) + \
+                  ["-no_vcf", "-t", str(threads), "-log", os.path.join(tmp, "job.log")]
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+            wall = time.perf_counter() - t0
+            # the reference's own clock starts after the index is loaded (main.cpp:376) and prints whole seconds
+            m = re.findall(r"have been processed in (\d+) seconds", r.stderr)
+            return wall, (int(m[-1]) if m else None)
+    elif os.path.exists(port_bin):
+        kind = "port"
+        def run(a, b, threads=cores, sam=True):
+            cmd = [port_bin, "-i", prefix, "-f", a] + ([] if se else ["-f2", b]) + ["-alg", alg, "-sam", os.path.join(tmp, "o.sam") if sam else "/dev/null", "-t", str(threads)]
+            t0 = time.perf_counter()
+            subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            return time.perf_counter() - t0, None
+    else:
+        return None
+    t_load = [None]
 
-        def rate(sam, a=f1, b=f2, reps=1):
-            t_full, own = run(a, b, sam=sam)
-            if own is not None and own >= 10:  # (whole seconds: only a long run can be read off it)
-                dt, how = float(own), f"the reference's own clock (starts after the index load): {own} s of {t_full:.1f} s wall"
-            else:
-                dt, how = max(t_full - t_load, 1e-3), f"wall {t_full:.2f} s minus {t_load:.2f} s of index load and start-up" + (f" (its own clock: {own} s)" if own is not None else "")
-            return round(reps * step * n_pairs / dt, 1), how
-        v_sam, how_sam = rate(True)
-        what = f"{n_pairs} {'reads' if se else 'pairs'} x {args.rlen} bp of the same synthetic workload, -t {cores} -alg {args.alg}"
-        out = {"value": v_sam, "unit": "reads/s", "cores": cores, "kind": kind, "sample": f"{what} -sam (file) -no_vcf; {how_sam}"}
-        if kind == "reference":
-            # (without the text the sample is seconds of work for this many cores, and the clocks at hand — whole seconds of the reference's
-            #  own, a wall clock less the index load — want tens of seconds: the sample's files several times over)
-            reps = max(1, min(8, int(3.2e7 // max(step * n_pairs, 1))))
-            m1, m2 = f1, f2
-            if reps > 1:
-                m1, m2 = os.path.join(tmp, "m1.fq"), os.path.join(tmp, "m2.fq")
-                for src, dst in ((f1, m1),) + (() if se else ((f2, m2),)):
-                    with open(dst, "wb") as out_fh:
-                        for _ in range(reps):
-                            with open(src, "rb") as in_fh:
-                                shutil.copyfileobj(in_fh, out_fh, 1 << 24)
-            v_map, how_map = rate(False, m1, m2, reps)
-            out["mapping_only"] = {"value": v_map, "unit": "reads/s", "cores": cores,
-                                   "sample": f"{what}{'' if reps == 1 else f', the files {reps} times over'}, -no_vcf and no -sam: mapping alone, no SAM text "
-                                             f"(ReadMapping.cpp:536 skipped); {how_map}"}
-            for fn in (m1, m2):
-                if reps > 1 and os.path.exists(fn):
-                    os.remove(fn)
-            # SURVEY 8d also asks for -t 1: a smaller sample, the reference's own clock again
-            n1 = min(n_pairs, 75_000)
-            s1, s2 = os.path.join(tmp, "s1.fq"), os.path.join(tmp, "s2.fq")
-            synth.write_fastq(s1, bases_sample[:step * n1], 0, step)
-            if not se:
-                synth.write_fastq(s2, bases_sample[:2 * n1], 1, 2)
-            _, own1 = run(s1, s2, threads=1)
-            if own1:
-                out["single_thread"] = {"value": round(step * n1 / own1, 1), "unit": "reads/s", "cores": 1,
-                                        "sample": f"{n1} {'reads' if se else 'pairs'}, -t 1, -sam (file), the reference's own clock: {own1} s"}
-        return out
+    def rate(sam, files, reps=1):
+        t_full, own = run(files[0], files[1], sam=sam)
+        if own is not None and own >= 5:  # (whole seconds: a run of a few seconds cannot be read off it)
+            dt, how = float(own), f"the reference's own clock (starts after the index load; whole seconds): {own} s of {t_full:.1f} s wall"
+        else:
+            if t_load[0] is None:
+                t_load[0] = run(*fq("t"), sam=False)[0]  # 200 pairs: index load + start-up (what a wall clock has to be corrected by)
+            dt, how = max(t_full - t_load[0], 1e-3), f"wall {t_full:.2f} s minus {t_load[0]:.2f} s of index load and start-up" + (f" (its own clock: {own} s)" if own is not None else "")
+        return round(reps * step * n_pairs / dt, 1), how
+    v_sam, how_sam = rate(True, fq("r"))
+    what = f"{n_pairs} {'reads' if se else 'pairs'} x {st['rlen']} bp of the same synthetic workload, -t {cores} -alg {alg}"
+    out = {"value": v_sam, "unit": "reads/s", "cores": cores, "kind": kind, "sample": f"{what} -sam (file) -no_vcf; {how_sam}"}
+    if kind == "reference" and st["level"] in ("two", "full"):
+        v_map, how_map = rate(False, fq("r"))
+        out["mapping_only"] = {"value": v_map, "unit": "reads/s", "cores": cores,
+                               "sample": f"{what}, -no_vcf and no -sam: mapping alone, no SAM text (ReadMapping.cpp:536 skipped); {how_map}"}
+    if kind == "reference" and st["level"] == "full":
+        n1 = min(n_pairs, 75_000)
+        _, own1 = run(*fq("s"), threads=1)
+        if own1:
+            out["single_thread"] = {"value": round(step * n1 / own1, 1), "unit": "reads/s", "cores": 1,
+                                    "sample": f"{n1} {'reads' if se else 'pairs'}, -t 1, -sam (file), the reference's own clock: {own1} s"}
+    return out
+
+
+def cpu_baseline(args, index, bases_sample):
+    st = cpu_prepare(args, index, bases_sample)
+    try:
+        return cpu_run(st)
+    finally:
+        shutil.rmtree(st["tmp"], ignore_errors=True)
 
 
 def launch_ranks(args):
@@ -770,8 +771,8 @@ def main():
         batches.append(b.reshape(-1).contiguous())
     off = (torch.arange(reads_per_step + 1, device=dev, dtype=torch.int64) * args.rlen).to(torch.uint32)
     cpu_pairs = args.cpu_pairs
-    if cpu_pairs < 0:  # ~20 s at ~15 k reads/s/core, bounded by one batch
-        cpu_pairs = int(min(args.batch_pairs, max(50_000, (os.cpu_count() or 1) * 15_000 * 20 // 2)))
+    if cpu_pairs < 0:  # ~20 s of the reference's clock: 15 k reads/s a core up to ~16 cores, ~240 k reads/s beyond (its locks), bounded by one batch
+        cpu_pairs = int(min(args.batch_pairs, max(50_000, min((os.cpu_count() or 1) * 15_000, 240_000) * 20 // 2)))
     sample = None
     if rank == 0 and world == 1 and cpu_pairs:
         per = 2 if paired else 1
@@ -833,15 +834,27 @@ def main():
     mapper = None
     torch.cuda.empty_cache()
 
-    # ---- files in, SAM out (the CLI's path), one batch's reads as FASTQ in tmpfs ------------------------------------
-    f2f = None
-    if args.file_steps > 0 and paired and world == 1:
+    # ---- the CPU baseline starts here, on a thread of its own: its runs of the reference (a minute each at this index size, most of it
+    #      the reference loading the index) go on beside the legs below that keep the GPU and one host thread busy; the file leg, which
+    #      wants the host's cores itself, waits for it
+    cpu_thread, cpu_box = None, {}
+    if sample is not None:
+        import threading
         try:
-            f2f = file_to_file(args, index, kept, reads_per_step)
+            cpu_st = cpu_prepare(args, index, sample)
+
+            def cpu_job():
+                try:
+                    cpu_box["out"] = cpu_run(cpu_st)
+                except Exception as e:  # the baseline must never take the bench line down
+                    cpu_box["out"] = {"error": str(e)[:200]}
+                finally:
+                    shutil.rmtree(cpu_st["tmp"], ignore_errors=True)
+            cpu_thread = threading.Thread(target=cpu_job)
+            cpu_thread.start()
         except Exception as e:
-            f2f = {"error": str(e)[:300]}
-    del kept[:]
-    torch.cuda.empty_cache()
+            cpu_box["out"] = {"error": str(e)[:200]}
+    sample = None
 
     # ---- the bulk exchange of a -vcf run (not timed): profile of one batch, RCCL reduce over the ranks ------
     vcf = None
@@ -852,6 +865,27 @@ def main():
             mapper = None
         except Exception as e:  # never lose the bench line to the optional section
             vcf = {"error": str(e)[:300]}
+        torch.cuda.empty_cache()
+
+    # ---- the other kind of genome, as a child process beside this one's index (GPU only)
+    second = None
+    if args.second_genome and world == 1 and rank == 0:
+        try:
+            second = other_genome(args)
+        except Exception as e:
+            second = {"error": str(e)[:200]}
+    if cpu_thread is not None:
+        cpu_thread.join()
+
+    # ---- files in, SAM out (the CLI's path), batches of the timed region as FASTQ in tmpfs ------------------------------------
+    f2f = None
+    if args.file_steps > 0 and paired and world == 1:
+        try:
+            f2f = file_to_file(args, index, kept, reads_per_step)
+        except Exception as e:
+            f2f = {"error": str(e)[:300]}
+    del kept[:]
+    torch.cuda.empty_cache()
 
     if rank == 0:
         total_reads = reads_per_step * args.steps * world
@@ -886,12 +920,11 @@ def main():
             out["value_file_to_file"] = f2f
         if vcf is not None:
             out["vcf_reduce"] = vcf
-        if sample is not None:
-            try:
-                out["cpu_baseline"] = cpu_baseline(args, index, sample)
-            except Exception as e:  # the baseline must never take the bench line down
-                out["cpu_baseline"] = {"error": str(e)[:200]}
-        if (args.second_genome or args.other_configs) and world == 1:
+        if "out" in cpu_box:
+            out["cpu_baseline"] = cpu_box["out"]
+        if second is not None:
+            out["other_genome"] = second
+        if args.other_configs and world == 1:
             try:
                 if mapper is not None:
                     mapper.close()
@@ -901,13 +934,7 @@ def main():
                 torch.cuda.empty_cache()
             except Exception:
                 pass
-            if args.second_genome:
-                try:
-                    out["other_genome"] = other_genome(args)
-                except Exception as e:
-                    out["other_genome"] = {"error": str(e)[:200]}
-            if args.other_configs:
-                out["other_configs"] = other_configs(args)
+            out["other_configs"] = other_configs(args)
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()

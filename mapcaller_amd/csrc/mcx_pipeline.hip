@@ -1350,6 +1350,147 @@ __global__ void __launch_bounds__(256, MCX_BUILD_WAVES) k_build(Ctx cx, ReadBatc
     if ((threadIdx.x & 63) == 0) { if (my_cells) atomicAdd((unsigned long long *)cells, (unsigned long long)my_cells); if (bad) atomicAdd(unsupported, bad); }
 }
 
+// ---- the large tier's build: a wavefront per pair ---------------------------------------------------------------------------
+// The large tier's pairs come from repeats: hundreds of candidates each, and k_build gives a pair to ONE lane, which builds them one
+// after the other — the launch is as long as that lane (1.9 ms for 30 k pairs: the step waited for it).  Here a wavefront takes the
+// pair and a lane a candidate, sixty-four at a time in the order stage_build goes through them:
+//   * scores and mates of both reads' candidates in LDS: keep_top_scores / mask_unpaired with wave-wide maxima;
+//   * a candidate's fragments go where an exclusive scan over the candidates' bounds (2 seeds + 2) puts them — holes of a fragment
+//     or two instead of the serial running count: nothing reads the pool but through a candidate's (frag_off, n_frags) —, its gap
+//     fragments are classified as ProcessNormalPair does, its DP problems counted by list;
+//   * scans over those counts give every lane its stretch of the pair's column area (64 bytes for the summary + the columns, in
+//     multiples of 8) and its places in the pass's job lists (one atomic per list and round), and the lane writes its problems there.
+// Same fragments, same kinds, same DP problems as stage_build; only where they lie in the pair's pools differs, which no result sees.
+// mode: as k_build's.
+__global__ void __launch_bounds__(64) k_build_wave(Ctx cx, ReadBatch rb, PairSel sel, JobSinks sinks, uint32_t *cells, uint32_t *unsupported, int mode, RescueList rl)
+{
+    extern __shared__ int32_t bw_lds[]; // score[2][cand_cap], mate[2][cand_cap]
+    __shared__ EndsLds ends;
+    stage_ends(cx.ix, ends);
+    const int lane = threadIdx.x;
+    const int nr = cx.pm.paired ? 2 : 1, cap = cx.caps.cand_cap;
+    int32_t *sc[2] = {bw_lds, bw_lds + cap}, *mt[2] = {bw_lds + 2 * cap, bw_lds + 3 * cap};
+    auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_s_barrier(); };
+    auto wave_max = [](int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64)); return v; };
+    auto wave_sum = [](uint32_t v) { for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64); return v; };
+    auto excl_scan = [&](uint32_t v) { uint32_t in = v; for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)in, o, 64); if (lane >= o) in += t; } return in - v; };
+    const uint32_t n_listed = mode == 2 ? min(*rl.n, rl.cap) : sel.n;
+    uint32_t my_cells = 0, bad = 0;
+    for (uint32_t slot = blockIdx.x; slot < n_listed; slot += gridDim.x) {
+        const uint32_t local = mode == 2 ? rl.ids[slot] : slot;
+        PairState st = pair_state(cx.state, cx.lay, cx.caps, local);
+        PairHdr h = *st.hdr; // (every lane the same words: one fetch)
+        if (mode == 1 && (h.flags & kAwaitRescue)) continue;
+        auto put_hdr = [&](uint32_t flags, int n_frags, int n_ops, int n_jobs) {
+            if (lane == 0) { st.hdr->flags = flags; st.hdr->n_frags = n_frags; st.hdr->n_ops = n_ops; st.hdr->n_jobs = (int16_t)n_jobs; }
+        };
+        if (h.flags & kOvAny) { put_hdr(h.flags, 0, 0, 0); continue; }
+        const int n_c[2] = {h.n_cands[0], nr == 2 ? h.n_cands[1] : 0};
+        ReadRef rd[2];
+        make_reads(cx, rb, sel_pair(sel, local), rd);
+        // ---- scores and mates into LDS; the masks of ReadMapping.cpp:469-470 (keep_top_scores / mask_unpaired)
+        wave_sync();
+        for (int s = 0; s < nr; s++) for (int i = lane; i < n_c[s]; i += 64) { const Cand c = st.cands[s][i]; sc[s][i] = c.score; mt[s][i] = c.mate; }
+        wave_sync();
+        auto keep_top = [&](int s) {
+            if (n_c[s] <= 1) return;
+            int best = 0;
+            for (int i = lane; i < n_c[s]; i += 64) best = max(best, sc[s][i]);
+            best = wave_max(best);
+            for (int i = lane; i < n_c[s]; i += 64) if (sc[s][i] < best) sc[s][i] = 0;
+        };
+        if (cx.pm.paired && h.n_paired != 0) {
+            int top = 0;
+            for (int i = lane; i < n_c[0]; i += 64) if (mt[0][i] != -1) top = max(top, sc[0][i] + sc[1][mt[0][i]]);
+            top = wave_max(top);
+            for (int i = lane; i < n_c[0]; i += 64) if (mt[0][i] == -1 || sc[0][i] + sc[1][mt[0][i]] < top) sc[0][i] = 0; // (read 2's scores are still what they were)
+            wave_sync();
+            for (int j = lane; j < n_c[1]; j += 64) if (mt[1][j] == -1 || sc[1][j] + sc[0][mt[1][j]] < top) sc[1][j] = 0;  // (read 1's as the loop above left them)
+        } else { keep_top(0); if (cx.pm.paired) keep_top(1); }
+        wave_sync();
+        // ---- the candidates, a lane each, in stage_build's order
+        uint32_t flags = h.flags, n_frags = 0, n_ops = 0, n_jobs = 0;
+        const int total = n_c[0] + n_c[1];
+        for (int base = 0; base < total && !(flags & kOvAny); base += 64) {
+            const int t = base + lane;
+            const bool mine = t < total;
+            const int s = (mine && t >= n_c[0]) ? 1 : 0, ci = mine ? t - (s ? n_c[0] : 0) : 0;
+            Cand c; c.count = 0; c.first = 0; c.in_pool = 0; c.pool_off = 0; c.score = 0;
+            bool live = false;
+            if (mine) { c = st.cands[s][ci]; live = sc[s][ci] != 0; }
+            const uint32_t bound = live ? 2u * (uint32_t)c.count + 2u : 0u;
+            const uint32_t off = n_frags + excl_scan(bound);
+            const uint32_t round_frags = wave_sum(bound);
+            if (n_frags + round_frags > (uint32_t)cx.caps.frag_cap) { flags |= kOvFrags; break; } // (uniform)
+            Frag *f = st.frags + off;
+            int nf = 0;
+            uint32_t my_ops = 0, my_cls[kDpClasses] = {0, 0, 0, 0, 0, 0};
+            if (mine) {
+                if (live) {
+                    nf = build_frags(cx.ix, rd[s].rlen, c.in_pool ? cx.seed_pool + c.pool_off : st.hits[s] + c.first, c.count, f);
+                    // ProcessNormalPair (:155-191): classify each gap fragment; a DP problem's place in the column area comes later
+                    for (int i = 0; i < nf; i++) {
+                        Frag x = f[i];
+                        if (x.kind == kSimple) continue;
+                        if (x.rLen > 0 && x.gLen > 0) {
+                            bool dp = x.rLen != x.gLen;
+                            int mm = -1;
+                            if (!dp) { mm = frag_mismatches(cx.ix, x, rd[s]); dp = mm > 1 && mm >= (int)(x.rLen * 0.2); }
+                            if (dp) {
+                                x.kind = kDp; x.ops_off = 0; x.ops_len = 0; x.meta = 0;
+                                my_ops += (uint32_t)kDpSum + (((uint32_t)(x.rLen + x.gLen) + 7u) & ~7u);
+                                DpJob j; j.rLen = x.rLen; j.gLen = x.gLen;
+                                const int q = job_class(j);
+                                if (q < 0) bad++; else my_cells += (uint32_t)(x.rLen * x.gLen);
+#pragma unroll
+                                for (int k = 0; k < kDpClasses; k++) my_cls[k] += q == k ? 1u : 0u;
+                            } else { x.kind = kPlain; x.ops_len = x.rLen; x.meta = (uint32_t)(mm + 1); }
+                        } else if (x.rLen > 0) { x.kind = kIns; x.ops_len = x.rLen; }
+                        else { x.kind = kDel; x.ops_len = x.gLen; }
+                        f[i] = x;
+                    }
+                }
+                // (what changed of the candidate: its place in the fragment pool, and its score when a mask or the validity check dropped it)
+                Cand *g = st.cands[s] + ci;
+                g->frag_off = (int16_t)off; g->n_frags = (int16_t)(nf < 0 ? 0 : nf);
+                const int new_score = (live && nf >= 0) ? c.score : 0;
+                if (new_score != c.score) g->score = new_score;
+            }
+            // ---- places: the column area of the pair, the job lists of the pass
+            uint32_t my_jobs = 0;
+#pragma unroll
+            for (int k = 0; k < kDpClasses; k++) my_jobs += my_cls[k];
+            uint32_t cur = n_ops + excl_scan(my_ops);
+            const uint32_t round_ops = wave_sum(my_ops), round_jobs = wave_sum(my_jobs);
+            if (n_ops + round_ops > (uint32_t)cx.caps.ops_cap) { flags |= kOvOps; break; }
+            if (n_jobs + round_jobs > (uint32_t)cx.caps.job_cap) { flags |= kOvJobs; break; }
+            uint32_t at_cls[kDpClasses];
+#pragma unroll
+            for (int k = 0; k < kDpClasses; k++) at_cls[k] = wave_reserve(sinks.s[k].count, my_cls[k]);
+            if (my_jobs) {
+                for (int i = 0; i < nf; i++) {
+                    Frag x = f[i];
+                    if (x.kind != kDp) continue;
+                    x.ops_off = (int64_t)(cur + (uint32_t)kDpSum);
+                    cur += (uint32_t)kDpSum + (((uint32_t)(x.rLen + x.gLen) + 7u) & ~7u);
+                    f[i] = x;
+                    DpJob j;
+                    j.pair = local; j.slot = (uint16_t)s; j.rev = x.gPos >= cx.ix.G ? 1 : 0;
+                    j.rPos = x.rPos; j.rLen = x.rLen; j.gPos = x.gPos; j.gLen = x.gLen;
+                    j.ops_off = (int32_t)x.ops_off; j.frag = (int32_t)(off + (uint32_t)i); j.score = 0;
+                    const int q = job_class(j);
+#pragma unroll
+                    for (int k = 0; k < kDpClasses; k++) if (q == k) { const uint32_t at = at_cls[k]++; if (at < sinks.s[k].cap) sinks.s[k].jobs[at] = j; }
+                }
+            }
+            n_frags += round_frags; n_ops += round_ops; n_jobs += round_jobs;
+        }
+        put_hdr(flags, (int)n_frags, (int)n_ops, (int)n_jobs);
+    }
+    my_cells = wave_sum(my_cells); bad = wave_sum(bad);
+    if (lane == 0) { if (my_cells) atomicAdd((unsigned long long *)cells, (unsigned long long)my_cells); if (bad) atomicAdd(unsupported, bad); }
+}
+
 // LDS per problem is sized per class: the small classes are latency-bound (a chain of dependent
 // fetches per problem), so what counts is how many problems a CU holds at once; the rare problem
 // that does not fit its class's LDS keeps its sequences / traceback in the workgroup's HBM scratch.
@@ -1844,7 +1985,7 @@ static Caps tier1_caps(int rlen_max)
     c.hit_cap = seeds * kOccThr + rlen_max / 8 + 16;
     c.cand_cap = c.hit_cap;
     c.hit_seed = c.hit_cap; c.cand_seed = c.cand_cap; // (hard bounds already count what the rescue can add)
-    c.frag_cap = 3 * c.hit_cap + 16;
+    c.frag_cap = 7 * c.hit_cap / 2 + 16; // (k_build_wave places a candidate's fragments by their bound, 2 seeds + 2: a sixth more room than 3 per hit)
     c.ops_cap = 96 * 1024; c.job_cap = 2048;
     c.cig_cap = MCX_CIGAR_STRIDE; c.kmer_cap = 4096;
     return c;
@@ -2311,16 +2452,23 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         }
     }
     // three time stamps: in line they bracket rescue | nothing | build, with the rescue aside build (others) | what is left of the wait for the rescue | build (its pairs)
+    // (the large tier's pairs: a wavefront each — k_build_wave; MCX_BUILD_BY_LANE: a lane each there too)
+    const size_t bw_bytes = (size_t)4 * cx.caps.cand_cap * sizeof(int32_t);
+    const bool build_wave = tier == 1 && bw_bytes <= 48 * 1024 && !getenv("MCX_BUILD_BY_LANE");
+    auto build = [&](int mode) {
+        if (build_wave) k_build_wave<<<std::min<unsigned>(sel.n, 8192u), 64, bw_bytes, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP, mode, rl);
+        else k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP, ll, order, order_cnt, mode, rl);
+    };
     if (rescue_aside) {
         HIP_TRY(hipEventRecord(R.dp_join[0], rs));
-        k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP, ll, order, order_cnt, 1, rl);
+        build(1);
         if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
         HIP_TRY(hipStreamWaitEvent(s, R.dp_join[0], 0));
         if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
-        k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP, ll, order, order_cnt, 2, rl);
+        build(2);
     } else {
         if (timing) { HIP_TRY(hipEventRecord(R.ev[e++], s)); HIP_TRY(hipEventRecord(R.ev[e++], s)); }
-        k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP, ll, order, order_cnt, 0, rl);
+        build(0);
     }
     if (late) HIP_TRY(hipEventRecord(c->ev_built, s));
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));

@@ -668,8 +668,9 @@ def test_large_batch_machinery_does_not_change_the_records(api, bench_genome, mo
     monkeypatch.setenv("MCX_DP_LANE_ALWAYS", "1")  # every DP list one problem per lane (at this size the long lists take the wavefront kernels)
     c_aln, c_cig, c_st = run()
     monkeypatch.delenv("MCX_DP_LANE_ALWAYS")
-    # everything off: no k_simple, no order, the wavefront DP kernels, the rescue in line, the late pairs searched again, the tiers one after the other
-    for k in ("MCX_NO_WORK_ORDER", "MCX_NO_LATE_OVERLAP", "MCX_NO_TIER_OVERLAP", "MCX_NO_SIMPLE", "MCX_DP_BY_WAVE", "MCX_RESCUE_IN_LINE", "MCX_LATE_RESEED"):
+    # everything off: no k_simple, no order, the wavefront DP kernels, the rescue in line, the late pairs searched again, the large tier's build a
+    # lane per pair, the tiers one after the other
+    for k in ("MCX_NO_WORK_ORDER", "MCX_NO_LATE_OVERLAP", "MCX_NO_TIER_OVERLAP", "MCX_NO_SIMPLE", "MCX_DP_BY_WAVE", "MCX_RESCUE_IN_LINE", "MCX_LATE_RESEED", "MCX_BUILD_BY_LANE"):
         monkeypatch.setenv(k, "1")
     b_aln, b_cig, b_st = run()
     assert a_st["tier1"] > 0 and a_st["tier1"] == b_st["tier1"] == c_st["tier1"], (a_st, b_st, c_st)
