@@ -340,7 +340,7 @@ def other_genome(args):
     """Two steps against the other kind of synthetic genome, as a child process once this one has let go of the GPU's memory."""
     kind = "uniform" if args.genome == "human" else "human"
     cmd = [sys.executable, os.path.abspath(__file__), "--genome", kind, "--second-genome", "0", "--steps", "2", "--warmup", "1", "--cpu-pairs", "0",
-           "--vcf-reduce", "0", "--other-configs", "0", "--file-steps", "0", "--pcie-steps", str(min(args.pcie_steps, 4)), "--genome-mbp", str(args.genome_mbp), "--contigs", str(args.contigs), "--batch-pairs", str(args.batch_pairs),
+           "--vcf-reduce", "0", "--other-configs", "0", "--file-steps", "0", "--pcie-steps", "0", "--genome-mbp", str(args.genome_mbp), "--contigs", str(args.contigs), "--batch-pairs", str(args.batch_pairs),
            "--rlen", str(args.rlen), "--sub", str(args.sub), "--ins", str(args.ins), "--dele", str(args.dele), "--alg", args.alg, "--full-sa", str(args.full_sa)]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=900)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -834,27 +834,15 @@ def main():
     mapper = None
     torch.cuda.empty_cache()
 
-    # ---- the CPU baseline starts here, on a thread of its own: its runs of the reference (a minute each at this index size, most of it
-    #      the reference loading the index) go on beside the legs below that keep the GPU and one host thread busy; the file leg, which
-    #      wants the host's cores itself, waits for it
-    cpu_thread, cpu_box = None, {}
-    if sample is not None:
-        import threading
+    # ---- files in, SAM out (the CLI's path), batches of the timed region as FASTQ in tmpfs ------------------------------------
+    f2f = None
+    if args.file_steps > 0 and paired and world == 1:
         try:
-            cpu_st = cpu_prepare(args, index, sample)
-
-            def cpu_job():
-                try:
-                    cpu_box["out"] = cpu_run(cpu_st)
-                except Exception as e:  # the baseline must never take the bench line down
-                    cpu_box["out"] = {"error": str(e)[:200]}
-                finally:
-                    shutil.rmtree(cpu_st["tmp"], ignore_errors=True)
-            cpu_thread = threading.Thread(target=cpu_job)
-            cpu_thread.start()
+            f2f = file_to_file(args, index, kept, reads_per_step)
         except Exception as e:
-            cpu_box["out"] = {"error": str(e)[:200]}
-    sample = None
+            f2f = {"error": str(e)[:300]}
+    del kept[:]
+    torch.cuda.empty_cache()
 
     # ---- the bulk exchange of a -vcf run (not timed): profile of one batch, RCCL reduce over the ranks ------
     vcf = None
@@ -866,26 +854,6 @@ def main():
         except Exception as e:  # never lose the bench line to the optional section
             vcf = {"error": str(e)[:300]}
         torch.cuda.empty_cache()
-
-    # ---- the other kind of genome, as a child process beside this one's index (GPU only)
-    second = None
-    if args.second_genome and world == 1 and rank == 0:
-        try:
-            second = other_genome(args)
-        except Exception as e:
-            second = {"error": str(e)[:200]}
-    if cpu_thread is not None:
-        cpu_thread.join()
-
-    # ---- files in, SAM out (the CLI's path), batches of the timed region as FASTQ in tmpfs ------------------------------------
-    f2f = None
-    if args.file_steps > 0 and paired and world == 1:
-        try:
-            f2f = file_to_file(args, index, kept, reads_per_step)
-        except Exception as e:
-            f2f = {"error": str(e)[:300]}
-    del kept[:]
-    torch.cuda.empty_cache()
 
     if rank == 0:
         total_reads = reads_per_step * args.steps * world
@@ -920,11 +888,14 @@ def main():
             out["value_file_to_file"] = f2f
         if vcf is not None:
             out["vcf_reduce"] = vcf
-        if "out" in cpu_box:
-            out["cpu_baseline"] = cpu_box["out"]
-        if second is not None:
-            out["other_genome"] = second
-        if args.other_configs and world == 1:
+        # (the reference at -t <all cores> beside a leg of this script starves that leg's host threads — tried: the -vcf leg's host passes took
+        #  forty times as long — so the baseline has the box to itself: two runs, most of each the reference loading the index)
+        if sample is not None:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, index, sample)
+            except Exception as e:  # the baseline must never take the bench line down
+                out["cpu_baseline"] = {"error": str(e)[:200]}
+        if (args.second_genome or args.other_configs) and world == 1:
             try:
                 if mapper is not None:
                     mapper.close()
@@ -934,7 +905,13 @@ def main():
                 torch.cuda.empty_cache()
             except Exception:
                 pass
-            out["other_configs"] = other_configs(args)
+            if args.second_genome:
+                try:
+                    out["other_genome"] = other_genome(args)
+                except Exception as e:
+                    out["other_genome"] = {"error": str(e)[:200]}
+            if args.other_configs:
+                out["other_configs"] = other_configs(args)
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()
