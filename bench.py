@@ -75,6 +75,8 @@ def pmc_profile(args):
                 e["issue_frac"] = round(get("SQ_ACTIVE_INST_ANY") / get("SQ_WAVE_CYCLES"), 3)
             if get("SQ_INSTS_VALU") is not None:
                 e["valu_insts"] = get("SQ_INSTS_VALU")
+                if "total" in p["SQ_INSTS_VALU"] and s.get("batches_mapped_by_the_pmc_runs"):  # all launches of the kernel in a step (the DP lists: several)
+                    e["valu_insts_per_step"] = p["SQ_INSTS_VALU"]["total"] / s["batches_mapped_by_the_pmc_runs"]
             if get("SQ_LDS_BANK_CONFLICT") is not None and get("SQ_LDS_IDX_ACTIVE"):
                 e["lds_conflict_frac"] = round(get("SQ_LDS_BANK_CONFLICT") / get("SQ_LDS_IDX_ACTIVE"), 4)
             out[k] = e
@@ -104,7 +106,8 @@ def essential_bytes(kernel, d, args):
 def dp_roofline(args, d, prof):
     """The DP stage against the chip's vector-instruction issue rate: `achieved` = cells x the sweep's instructions per cell
     over the stage's time (the lists' kernels share the chip on three streams: the stage is the sum of their work), `traffic`
-    = the lane-operation slots the stage's kernels actually issued (SQ_INSTS_VALU x 64, committed PMC pass) — idle lanes of
+    = the lane-operation slots the stage's kernels actually issued (SQ_INSTS_VALU x 64 summed over every DP launch of a step — the large tier's and the
+    replay's included —, committed PMC pass) — idle lanes of
     ragged groups, staging and the tracebacks are the difference."""
     steps = max(args.steps, 1)
     ms = d["ms_dp"] / steps
@@ -113,7 +116,7 @@ def dp_roofline(args, d, prof):
     achieved = cells * ops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     kern = prof["kernels"] if prof else {}
     dpk = {k: v for k, v in kern.items() if k.startswith("k_dp_")}
-    issued = sum(v.get("valu_insts", 0.0) for v in dpk.values()) * 64 if dpk else None
+    issued = sum(v.get("valu_insts_per_step", v.get("valu_insts", 0.0)) for v in dpk.values()) * 64 if dpk else None
     r = {"bound": "valu", "kernel": "k_dp_lane<K, alg> (one problem per lane; five lists on three streams, k_dp_sel<16> for targets above 256 bases)",
          "achieved": round(achieved, 2), "peak": round(VALU_PEAK_TLANEOPS, 1), "unit": "T lane-ops/s", "frac": round(achieved / VALU_PEAK_TLANEOPS, 4),
          "traffic": None if not issued else round(issued),

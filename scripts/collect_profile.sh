@@ -24,7 +24,7 @@ for set in ${PMC_SETS:+"$PMC_SETS"} "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_M
   i=$((i + 1))
   timeout 300 rocprofv3 --pmc $set --output-format csv -d $out/pmc$i -o p -- python3 bench.py --steps 2 $args > $out/pmc$i.log 2>&1 < /dev/null
 done
-python3 scripts/summarize_profile.py --trace $out/kt --pmc $out/pmc* --reads-per-launch $rpl --out $out/summary.json \
+python3 scripts/summarize_profile.py --trace $out/kt --pmc $out/pmc* --reads-per-launch $rpl --batches 3 --out $out/summary.json \
   --command "scripts/collect_profile.sh $tag $genome $extra: rocprofv3 --kernel-trace --stats | --pmc <set> (one pass per set) -- python3 bench.py --steps 3|2 $args ($rpl reads per launch)" < /dev/null
 find $out/kt -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
 rm -rf $out/kt $out/pmc[0-9]

@@ -74,7 +74,8 @@ def read_pmc(dirs):
         for c, lst in cs.items():
             tmax = max(t for t, _ in lst)
             full = [v for t, v in lst if t > 0.5 * tmax]
-            out[k][c] = {"launches": len(lst), "full_batch_mean": round(sum(full) / len(full), 2)}
+            # total: over every launch of the run (a stage made of several launches of one kernel — the DP lists — is their sum)
+            out[k][c] = {"launches": len(lst), "full_batch_mean": round(sum(full) / len(full), 2), "total": round(sum(v for _, v in lst), 2)}
     return out
 
 
@@ -83,6 +84,7 @@ def main():
     ap.add_argument("--trace")
     ap.add_argument("--pmc", nargs="*", default=[])
     ap.add_argument("--reads-per-launch", type=int, default=0)
+    ap.add_argument("--batches", type=int, default=0, help="batches the profiled command mapped (warm-up + steps): written into the summary, for per-step sums of the totals")
     ap.add_argument("--command", default="")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
@@ -91,6 +93,8 @@ def main():
                  "FETCH_SIZE*1024 equals TCC_MISS_sum*64 within 1 %, i.e. 64-byte fabric requests counted at 64 B: the guide's "
                  "x2 correction (wide coalesced streams tallied as 128-B requests at 64 B) does not apply to this pattern; it is applied to "
                  "the streaming kernels (" + ", ".join(STREAMING) + ")."}
+    if a.batches:
+        s["batches_mapped_by_the_pmc_runs"] = a.batches
     if a.trace:
         s["kernel_trace"] = read_trace(a.trace)
     if a.pmc:
