@@ -269,6 +269,7 @@ def vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, n_s
     del batches[:]
     if mapper is not None:
         mapper.close()
+    index.trim(1)             # (the pair records make room as well: 25 GB at 3.1 Gbp)
     torch.cuda.empty_cache()  # (the caching allocator would sit on the freed batches)
     slice_reads = min(reads_per_step, args.vcf_slice_reads)
     mapper = api.Mapper(index, alg=args.alg, max_read_len=max(256, args.rlen), max_batch_reads=slice_reads)
@@ -396,7 +397,7 @@ def parse():
     ap.add_argument("--ins", type=float, default=0.001, help="per-base insertion rate")
     ap.add_argument("--dele", type=float, default=0.001, help="per-base deletion rate")
     ap.add_argument("--alg", default="ksw2", choices=["nw", "ksw2"])
-    ap.add_argument("--full-sa", type=int, default=1, help="keep every suffix-array entry in HBM")
+    ap.add_argument("--full-sa", type=int, default=2, help="1: every suffix-array entry, the jump table and the rank records in HBM; 2: the pair records too (two bases per step of the seeding walk)")
     ap.add_argument("--cpu-pairs", type=int, default=-1,
                     help="pairs of the CPU-baseline sample (0 = skip, -1 = about 20 s of work for this host's core count)")
     ap.add_argument("--cpu-level", default="two", choices=["sam", "two", "full"],
@@ -762,7 +763,7 @@ def main():
     # ---- set-up (not timed): genome, index, reads ------------------------------------------------
     codes, lens, genome_note = make_genome(args, dev, seed=1234)
     t0 = time.perf_counter()
-    index = api.Index.from_codes(codes.data_ptr(), lens, device=local, full_sa=bool(args.full_sa))
+    index = api.Index.from_codes(codes.data_ptr(), lens, device=local, full_sa=int(args.full_sa))
     t_index = time.perf_counter() - t0
     n_steps = args.warmup + args.steps
     paired = not args.single_end
@@ -869,7 +870,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"synthetic GRCh38-sized genome, {args.genome_mbp:.0f} Mbp ({args.contigs} contigs, {genome_note}; GRCh38 itself is unavailable offline), "
                                    f"{args.batch_pairs} {'pairs' if paired else 'reads'} x {args.rlen} bp {'PE' if paired else 'SE'} per step per GPU (sub {args.sub}, ins {args.ins}, del {args.dele} per base), -alg {args.alg}",
-                       "reads_per_step_per_gpu": reads_per_step, "full_sa_in_hbm": bool(args.full_sa), "index_build_s": round(t_index, 2),
+                       "reads_per_step_per_gpu": reads_per_step, "full_sa_in_hbm": bool(args.full_sa), "pair_records_in_hbm": args.full_sa >= 2, "index_build_s": round(t_index, 2),
                        "index_hbm_gb": round(index.hbm_bytes / 1e9, 2),
                        "multi_gpu": None if world == 1 else f"one process per GPU, index replicated, rank r maps batch {world}*step + r; one avgDist trajectory over the "
                                                             f"ranks' batches per step (all-gather of per-chunk sums over RCCL, {traj.exchanges} exchanges in "

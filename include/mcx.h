@@ -37,8 +37,17 @@ int mcx_device_count(void);
  * Replaces bwa_idx_load + RestoreReferenceInfo (reference src/bwt_index.cpp:150-258, called
  * from src/main.cpp:350-361): parses <prefix>.bwt/.sa/.pac/.ann/.amb (the byte-compatible BWA
  * files `MapCaller index` writes) and stages them in HBM.  full_sa != 0 additionally expands
- * the 1-in-32 sampled suffix array to every row on the GPU (bwt_sa then is one 8-byte gather). */
+ * the 1-in-32 sampled suffix array to every row on the GPU (bwt_sa then is one 8-byte gather) and
+ * derives the seeding walk's jump table and rank records; full_sa = 2 adds the pair
+ * records — BWT_Search's extension (src/bwt_search.cpp:128-151) two bases per step, 4 bytes per text
+ * position (25 GB for a human genome): same searches, fewer fetches. */
+#define MCX_INDEX_SAMPLED 0
+#define MCX_INDEX_FULL 1
+#define MCX_INDEX_PAIRS 2
 int mcx_index_load(const char *prefix, int device, int full_sa, mcx_index **out);
+/* Gives back what the index holds above the level `full_sa` (MCX_INDEX_FULL: the pair records), e.g. before the
+ * alignment profile's planes are attached.  Contexts made before the call must have been freed. */
+int mcx_index_trim(mcx_index *, int full_sa);
 /* Replaces bwa_idx_build (reference src/BWT_Index/bwtindex.c:77; `MapCaller index ref.fa prefix`,
  * src/main.cpp:199-207): builds BWT/occ/SA on the GPU from a FASTA file and writes the same
  * five files. */

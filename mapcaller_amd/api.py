@@ -58,7 +58,7 @@ def pack_reads(bases, lens=None):
 
 # every symbol include/mcx.h declares
 SYMBOLS = [
-    "mcx_last_error", "mcx_device_count", "mcx_index_load", "mcx_index_build", "mcx_index_from_codes", "mcx_index_save", "mcx_index_free",
+    "mcx_last_error", "mcx_device_count", "mcx_index_load", "mcx_index_build", "mcx_index_from_codes", "mcx_index_save", "mcx_index_free", "mcx_index_trim",
     "mcx_index_genome_size", "mcx_index_n_chr", "mcx_index_chr_name", "mcx_index_chr_len", "mcx_index_hbm_bytes",
     "mcx_opts_default", "mcx_ctx_create", "mcx_ctx_free", "mcx_bwt_search_batch", "mcx_extend_batch",
     "mcx_avg_init", "mcx_map_batch_dev", "mcx_map_batch", "mcx_cigar_words", "mcx_map_files", "mcx_map_files_ex", "mcx_file_opts_default",
@@ -197,6 +197,7 @@ def lib() -> C.CDLL:
     L.mcx_index_from_codes.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_char_p), C.c_int, C.c_int,
                                        C.POINTER(C.c_void_p), C.POINTER(C.c_double)]
     L.mcx_index_save.argtypes = [C.c_void_p, C.c_char_p]
+    L.mcx_index_trim.argtypes = [C.c_void_p, C.c_int]
     for f in (L.mcx_index_free, L.mcx_ctx_free):
         f.argtypes = [C.c_void_p]
         f.restype = None
@@ -261,7 +262,8 @@ def device_count() -> int:
 class Index:
     """FM-index + reference resident in HBM (mcx_index_load; reference src/bwt_index.cpp:150-258)."""
 
-    def __init__(self, prefix: Optional[str], device: int = 0, full_sa: bool = False):
+    def __init__(self, prefix: Optional[str], device: int = 0, full_sa: int = 0):
+        # full_sa: 0 the sampled suffix array as on disk; 1 (True) every entry + jump table + rank records; 2 + the pair records
         self._h = C.c_void_p()
         self.device = device
         self.build_seconds = None
@@ -270,7 +272,7 @@ class Index:
 
     @classmethod
     def from_codes(cls, d_codes_ptr: int, chr_lens: List[int], chr_names: Optional[List[str]] = None, device: int = 0,
-                   full_sa: bool = False) -> "Index":
+                   full_sa: int = 0) -> "Index":
         """Builds the index on the GPU from a genome already in HBM (codes 0..3, contigs concatenated)."""
         self = cls(None, device)
         n = len(chr_lens)
@@ -284,6 +286,11 @@ class Index:
 
     def save(self, prefix: str) -> None:
         _check(lib().mcx_index_save(self._h, prefix.encode()), "mcx_index_save")
+
+    def trim(self, full_sa: int = 1) -> None:
+        """Gives back what the index holds above the level ``full_sa`` (1: the pair records of full_sa=2).  Mappers made
+        before must have been closed."""
+        _check(lib().mcx_index_trim(self._h, int(full_sa)), "mcx_index_trim")
 
     @staticmethod
     def build(fasta: str, prefix: str, device: int = 0) -> None:

@@ -14,4 +14,9 @@ struct DevIndexArrays {         // device arrays in the on-disk layout of the re
 // d_fwd: forward genome, one code (0..3) per byte, in HBM
 int mcx_build_suffix_index(const uint8_t *d_fwd, uint64_t G, bool want_full_sa, DevIndexArrays &out, double *seconds);
 int mcx_set_error(int code, const std::string &msg);
+// the pair records of the seeding walk (mcx_fm.h PairSlot) for an index whose full suffix array, packed genome and .bwt blocks are in
+// HBM: fills v.rank2 / rank2_c2 / rank2_lone / rank2_t0 (d_rec, d_c2: what to free); *bytes = 0 and nothing set when some pair of bases
+// occurs 2^32 times or more.  check_trials > 0: that many random intervals extended both ways on the device, an error if any differs.
+namespace mcx { struct IndexView; }
+int mcx_build_pair_records(mcx::IndexView &v, void **d_rec, void **d_c2, int64_t *bytes, int check_trials);
 #endif

@@ -275,6 +275,83 @@ static inline MCX_HD int end_slot(const IndexView &ix, int64_t gPos)
     return lo < ix.n_ends ? lo : -1;
 }
 
+// ---- pair records: the walk two bases at a time ---------------------------------------------------------------------------
+// Two consecutive extensions of BWT_Search by the bases b1, b2 (bwt_search.cpp:128-151) are one extension over the alphabet of
+// PAIRS: the suffix in row r has T[SA[r] - 1] = b1 and T[SA[r] - 2] = b2 before it exactly when it survives both steps, and rows
+// that do keep their order.  With the code c1 * 4 + c2 of its two preceding bases per stored BWT symbol,
+//     occ2(k, s)  = symbols [0, k] with code s           (what two steps add to the first row of the suffixes beginning b2 b1 ..)
+//     gt2(k, s)   = symbols [0, k] with a greater code   (the lower bases' share of the other strand's interval, ok[b].x0 :143-146,
+//                                                         both steps' at once: c1 above b1, or c1 = b1 and c2 above b2)
+// and the interval after the two steps is {x0 + [primary inside] + gt2(l) - gt2(k), first[s] + 1 + occ2(k), occ2(l) - occ2(k)}.
+// One suffix has a single base before it (the one at text position 1: its second step meets the primary row, which the second
+// step's "+1" of :143 accounts for): it has no code, counts as greater than the pairs that begin with its base or a lower one,
+// and is kept beside the table (rank2_lone, rank2_t0).
+// Layout: per 32 symbols 16 slots of 8 bytes {which symbols have a code below j, how many had before the record (low 32 bits)}
+// for j = 1..8 in the first 64-byte line and j = 8..15 in the second, so that the two numbers a step needs — below s and below
+// s + 1 — are 16 neighbouring bytes of ONE line for every s (below 0 is nothing, below 16 is every symbol with a code).  Counts
+// are kept modulo 2^32: the walk takes differences of at most the interval's width, and occ2 itself stays below 2^32 (checked
+// when the table is built).  4 bytes per text position.  The numbers are the same numbers as two single steps': never a
+// different result; a pair that comes up empty says nothing about where the search ends, and the single step is taken.
+struct alignas(8) PairSlot { uint32_t lt, n_lt; };
+struct alignas(8) PairSlot2 { PairSlot a, b; };
+constexpr int kPairNone = 16;
+
+// code of stored symbol i (needs the full suffix array); kPairNone for the lone suffix and past the text
+static inline MCX_HD int fm_pair_code(const IndexView &ix, uint64_t i, bool &lone)
+{
+    lone = false;
+    if (i >= ix.seq_len) return kPairNone;
+    const uint64_t r = i + (i >= ix.primary ? 1 : 0);
+    const uint64_t pos = r == 0 ? ix.seq_len : ix.sa_full[r];
+    if (pos < 2) { lone = pos == 1; return kPairNone; }
+    return ref_code(ix, (int64_t)pos - 1) * 4 + ref_code(ix, (int64_t)pos - 2);
+}
+
+// the record of 32 symbols with codes c[0..31]; n_lt[j] (j = 1..15): symbols with a code below j before the record, moved past it
+static inline MCX_HD void fm_pair_record(const uint8_t *c, uint64_t n_lt[16], PairSlot out[16])
+{
+    uint32_t lt = 0;
+    for (int j = 1; j < 16; j++) {
+        for (int t = 0; t < 32; t++) if (c[t] == j - 1) lt |= 0x80000000u >> t;
+        PairSlot e; e.lt = lt; e.n_lt = (uint32_t)n_lt[j];
+        if (j <= 8) out[j - 1] = e;
+        if (j >= 8) out[j] = e;
+        n_lt[j] += (uint64_t)fm_popc(lt);
+    }
+}
+
+// bwt_occ (bwt_search.cpp:36-51) for k in [0, seq_len]
+static inline MCX_HD uint64_t fm_occ(const IndexView &ix, uint64_t k, int c)
+{
+    if (k == ix.seq_len) return ix.L2[c + 1] - ix.L2[c];
+    const uint64_t x = k - (k >= ix.primary);
+    FmBlock b;
+    fm_load_block(ix.bwt, x >> 7, b);
+    return fm_count1(b, (int)(x & 127) + 1, c);
+}
+
+// first[s] for s = b1 * 4 + b2: the rows up to and including the last one before the suffixes that begin b2 b1 (the step adds 1 + occ2)
+static inline MCX_HD uint64_t fm_pair_first(const IndexView &ix, int s)
+{
+    const int b1 = s >> 2, b2 = s & 3;
+    return ix.L2[b2] + fm_occ(ix, ix.L2[b1], b2);
+}
+
+// occ2 and gt2 at stored symbol pos for the code s, modulo 2^32
+static inline MCX_HD void fm_pair_counts(const IndexView &ix, uint64_t pos, int s, uint32_t &eq, uint32_t &gt)
+{
+    const PairSlot *rec = (const PairSlot *)ix.rank2 + (pos >> 5) * 16;
+    const int t = s == 0 ? 0 : s < 8 ? s - 1 : s == 15 ? 14 : s;
+    const PairSlot2 v = *(const PairSlot2 *)(rec + t);
+    const uint32_t m = 0xFFFFFFFFu << (31 - (int)(pos & 31));
+    const uint32_t fa = v.a.n_lt + (uint32_t)fm_popc(v.a.lt & m), fb = v.b.n_lt + (uint32_t)fm_popc(v.b.lt & m);
+    const uint32_t lone = ix.rank2_lone <= pos ? 1u : 0u;
+    const uint32_t all = (uint32_t)(pos + 1) - lone; // below 16: every symbol that has a code
+    const uint32_t lo = s == 0 ? 0u : s == 15 ? fb : fa, hi = s == 0 ? fa : s == 15 ? all : fb;
+    eq = hi - lo;
+    gt = all - hi + ((lone && (s >> 2) <= ix.rank2_t0) ? 1u : 0u);
+}
+
 // K-mer jump table (a derived, HBM-resident cache; the search results are unchanged): entry i is
 // the bi-interval BWT_Search holds after consuming the K bases spelled by i (first base most
 // significant), or x2 = 0 when some extension inside the K-mer comes up empty.  A search that
@@ -325,6 +402,42 @@ static inline MCX_HD void ktab_entry(const IndexView &ix, uint32_t idx, int K, u
         for (int bb = 3; bb > b; bb--) n0 += tl[bb] - tk[bb];
         x0 = n0; x1 = ix.L2[b] + 1 + tk[b]; x2 = n2;
     }
+}
+
+// self-check of the pair records, trial t: the bi-interval of a random string of 1..12 bases extended by two random bases — the
+// pair step against two single steps in the .bwt blocks (seed_fm's arithmetic on bwt_2occ4's counts)
+static inline MCX_HD bool fm_pair_step_agrees(const IndexView &ix, uint64_t t)
+{
+    uint64_t z = (t + 1) * 0x9E3779B97F4A7C15ull;
+    z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
+    const int kk = (int)((z >> 3) % 12) + 1;
+    uint64_t x0, x1, x2;
+    ktab_entry(ix, (uint32_t)((z >> 8) & ((1ull << (2 * kk)) - 1)), kk, x0, x1, x2);
+    if (x2 == 0 || (x2 >> 32)) return true;
+    const int b1 = (int)((z >> 40) & 3), b2 = (int)((z >> 42) & 3);
+    uint64_t s0 = x0, s1 = x1, s2 = x2;
+    bool alive = true;
+    for (int step = 0; step < 2 && alive; step++) {
+        const int b = step ? b2 : b1;
+        uint64_t tk[4], tl[4];
+        int nb;
+        fm_2occ4(ix, s1 - 1, s1 - 1 + s2, tk, tl, nb);
+        const uint64_t n2 = tl[b] - tk[b];
+        if (n2 == 0) { alive = false; break; }
+        uint64_t n0 = s0 + ((s1 <= ix.primary && s1 + s2 - 1 >= ix.primary) ? 1 : 0);
+        for (int bb = 3; bb > b; bb--) n0 += tl[bb] - tk[bb];
+        s0 = n0; s1 = ix.L2[b] + 1 + tk[b]; s2 = n2;
+    }
+    const int s = b1 * 4 + b2;
+    uint64_t k = x1 - 1, l = x1 - 1 + x2;
+    k -= (k >= ix.primary); l -= (l >= ix.primary);
+    uint32_t ek, gk, el, gl;
+    fm_pair_counts(ix, k, s, ek, gk);
+    fm_pair_counts(ix, l, s, el, gl);
+    const uint32_t n2 = el - ek;
+    if (!alive) return n2 == 0;
+    return n2 == s2 && ix.rank2_c2[s] + 1 + (uint64_t)ek == s1 &&
+           x0 + ((x1 <= ix.primary && x1 + x2 - 1 >= ix.primary) ? 1 : 0) + (uint64_t)(uint32_t)(gl - gk) == s0;
 }
 
 // set in Hit.len by seed_read for hits whose text position is already known (cleared by the caller
@@ -478,8 +591,27 @@ static inline MCX_HD void seed_fm(const IndexView &ix, const PackedRead &pk, int
         steps++;
         const uint32_t nm2 = packed_nmask32(pk, p, rlen);
         if (nm2 & 0x80000000u) { w.ended = 1; break; } // N or read end
-        const int c = (int)(packed_codes16(pk, p) >> 30);
+        const uint32_t c16 = packed_codes16(pk, p);
+        const int c = (int)(c16 >> 30);
         const int b = 3 - c;
+        bool last = false; // the step after this one is known to come up empty
+        if (ix.rank2 && !(nm2 & 0x40000000u) && (w.x2 >> 32) == 0) { // this base and the next in one step (fm_pair_counts)
+            const int s = b * 4 + 3 - (int)((c16 >> 28) & 3);
+            uint64_t k = w.x1 - 1, l = w.x1 - 1 + w.x2;
+            k -= (k >= ix.primary); l -= (l >= ix.primary);
+            uint32_t ek, gk, el, gl;
+            fm_pair_counts(ix, k, s, ek, gk);
+            fm_pair_counts(ix, l, s, el, gl);
+            blocks += (k >> 5) != (l >> 5) ? 2 : 1;
+            const uint32_t n2 = el - ek;
+            if (n2 != 0) {
+                w.x0 = w.x0 + ((w.x1 <= ix.primary && w.x1 + w.x2 - 1 >= ix.primary) ? 1 : 0) + (uint64_t)(uint32_t)(gl - gk);
+                w.x1 = ix.rank2_c2[s] + 1 + (uint64_t)ek; w.x2 = n2;
+                p += 2;
+                continue;
+            }
+            last = true;
+        }
         uint64_t tkb, n2, above; // occ(k, b); occ(l, b) - occ(k, b); the same difference summed over the bases above b
         if (ix.rank) {
             uint64_t k = w.x1 - 1, l = w.x1 - 1 + w.x2;
@@ -512,6 +644,7 @@ static inline MCX_HD void seed_fm(const IndexView &ix, const PackedRead &pk, int
         const uint64_t n0 = w.x0 + ((w.x1 <= ix.primary && w.x1 + w.x2 - 1 >= ix.primary) ? 1 : 0) + above;
         w.x0 = n0; w.x1 = ix.L2[b] + 1 + tkb; w.x2 = n2;
         p++;
+        if (last) { w.ended = 1; break; }
     }
     if (w.ended) w.phase = 3;
     else if (w.x2 == 1) { // exactly one suffix left: the rest of the search is a comparison with the text itself

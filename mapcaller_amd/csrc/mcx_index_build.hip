@@ -28,6 +28,7 @@
 #include "mcx_host.h"
 #include "mcx_types.h"
 #include "mcx_build.h"
+#include "mcx_fm.h"
 
 using namespace mcx;
 
@@ -389,6 +390,131 @@ int mcx_build_suffix_index(const uint8_t *d_fwd, uint64_t G, bool want_full_sa, 
     if (seconds) *seconds = ms / 1000.0;
     (void)hipFree(T); (void)hipFree(sa); (void)hipFree(d_misc); (void)hipFree(tmp); (void)hipFree(d_total);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pair records (mcx_fm.h PairSlot): the two bases before every suffix, counted per 32 BWT symbols
+// ---------------------------------------------------------------------------------------------
+// one thread per stored symbol: its code (a byte: the records are made from these in a second pass, once the counts before
+// every workgroup's 256 symbols are known) and the workgroup's count of every code
+__global__ void __launch_bounds__(256) k_pair_codes(IndexView ix, uint8_t *codes, uint64_t *cnt, uint64_t n_groups, unsigned long long *lone)
+{
+    __shared__ uint32_t h[16];
+    if (threadIdx.x < 16) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    bool ln;
+    const int code = fm_pair_code(ix, i, ln);
+    if (ln) *lone = i;
+    codes[i] = (uint8_t)code;
+    for (int j = 0; j < 16; j++) {
+        const uint64_t m = __ballot(code == j);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(&h[j], (uint32_t)__popcll(m));
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) cnt[(uint64_t)threadIdx.x * n_groups + blockIdx.x] = h[threadIdx.x];
+}
+
+// cnt: per code the exclusive sums over the workgroups.  A wavefront makes the records of two runs of 32 symbols: lane j (1..15)
+// holds "code below j" of both as ballots, and writes slot j - 1 (j <= 8) and slot j (j >= 8) of either record
+struct PairStarts { uint64_t s[16]; };
+__global__ void __launch_bounds__(256) k_pair_records(const uint8_t *codes, const uint64_t *cnt, PairStarts st, uint64_t n_groups, PairSlot *rec)
+{
+    __shared__ uint32_t part[8][16]; // symbols with a code below j in each of the workgroup's eight runs
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const int code = codes[i];
+    uint32_t lt0 = 0, lt1 = 0;
+    for (int j = 1; j < 16; j++) {
+        const uint64_t m = __ballot(code < j); // (kPairNone is below nothing)
+        if (lane == j) { lt0 = __brev((uint32_t)m); lt1 = __brev((uint32_t)(m >> 32)); } // symbol t of a run at bit 31 - t
+    }
+    if (lane >= 1 && lane < 16) { part[2 * wave][lane] = (uint32_t)__popc(lt0); part[2 * wave + 1][lane] = (uint32_t)__popc(lt1); }
+    __syncthreads();
+    if (lane < 1 || lane >= 16) return;
+    uint64_t before = 0;
+    for (int j = 0; j < lane; j++) before += cnt[(uint64_t)j * n_groups + blockIdx.x] - st.s[j]; // (one scan over the arrays laid end to end: a code's sums start at the total of the codes below it)
+    for (int r = 0; r < 2 * wave; r++) before += part[r][lane];
+    PairSlot *out = rec + ((uint64_t)blockIdx.x * 8 + 2 * wave) * 16;
+    PairSlot e0, e1;
+    e0.lt = lt0; e0.n_lt = (uint32_t)before;
+    e1.lt = lt1; e1.n_lt = (uint32_t)(before + part[2 * wave][lane]);
+    if (lane <= 8) { out[lane - 1] = e0; out[16 + lane - 1] = e1; }
+    if (lane >= 8) { out[lane] = e0; out[16 + lane] = e1; }
+}
+
+__global__ void k_pair_first(IndexView ix, uint64_t *c2)
+{
+    if (threadIdx.x < 16) c2[threadIdx.x] = fm_pair_first(ix, (int)threadIdx.x);
+    if (threadIdx.x == 16) c2[16] = (uint64_t)ref_code(ix, 0);
+}
+
+__global__ void k_pair_check(IndexView ix, uint64_t trials, unsigned long long *bad)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < trials && !fm_pair_step_agrees(ix, t)) atomicAdd(bad, 1ull);
+}
+
+int mcx_build_pair_records(IndexView &v, void **d_rec, void **d_c2, int64_t *bytes, int check_trials)
+{
+    *d_rec = nullptr; *d_c2 = nullptr; *bytes = 0;
+    if (!v.sa_full || v.seq_len < 2) return 0;
+    const uint64_t n_groups = (v.seq_len + 255) / 256, n_chunks = n_groups * 8;
+    uint8_t *codes = nullptr;
+    uint64_t *cnt = nullptr, *c2 = nullptr;
+    unsigned long long *d_misc = nullptr;
+    void *tmp = nullptr;
+    PairSlot *rec = nullptr;
+    auto drop = [&]() { (void)hipFree(codes); (void)hipFree(cnt); (void)hipFree(d_misc); (void)hipFree(tmp); };
+    auto fail = [&](const std::string &what, hipError_t e) { drop(); (void)hipFree(rec); (void)hipFree(c2); return mcx_set_error(MCX_ERR_DEVICE, "pair records: " + what + ": " + hipGetErrorString(e)); };
+    hipError_t e;
+    if ((e = hipMalloc(&codes, n_groups * 256)) != hipSuccess) return fail("hipMalloc(codes)", e);
+    if ((e = hipMalloc(&cnt, (16 * n_groups + 1) * 8)) != hipSuccess) return fail("hipMalloc(counts)", e);
+    if ((e = hipMalloc(&d_misc, 16)) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMemset(d_misc, 0xFF, 8)) != hipSuccess || (e = hipMemset(d_misc + 1, 0, 8)) != hipSuccess) return fail("hipMemset", e);
+    k_pair_codes<<<(unsigned)n_groups, 256>>>(v, codes, cnt, n_groups, d_misc);
+    if ((e = hipGetLastError()) != hipSuccess) return fail("k_pair_codes", e);
+    size_t cb = 0;
+    if ((e = hipcub::DeviceScan::ExclusiveSum(nullptr, cb, cnt, cnt, (int64_t)(16 * n_groups + 1))) != hipSuccess) return fail("scan size", e);
+    if ((e = hipMalloc(&tmp, cb)) != hipSuccess) return fail("hipMalloc(scan)", e);
+    if ((e = hipMemset(cnt + 16 * n_groups, 0, 8)) != hipSuccess) return fail("hipMemset", e);
+    if ((e = hipcub::DeviceScan::ExclusiveSum(tmp, cb, cnt, cnt, (int64_t)(16 * n_groups + 1))) != hipSuccess) return fail("scan", e);
+    uint64_t starts[17];
+    for (int j = 0; j <= 16; j++)
+        if ((e = hipMemcpy(&starts[j], cnt + (uint64_t)j * n_groups, 8, hipMemcpyDeviceToHost)) != hipSuccess) return fail("hipMemcpy", e);
+    unsigned long long lone = 0;
+    if ((e = hipMemcpy(&lone, d_misc, 8, hipMemcpyDeviceToHost)) != hipSuccess) return fail("hipMemcpy", e);
+    for (int j = 0; j < 16; j++)
+        if ((starts[j + 1] - starts[j]) >> 32) { drop(); return 0; } // a pair of bases 2^32 times or more: the walk keeps its single steps
+    const size_t rec_bytes = (size_t)n_chunks * 16 * sizeof(PairSlot) + 64;
+    if ((e = hipMalloc(&rec, rec_bytes)) != hipSuccess) return fail("hipMalloc(records)", e);
+    if ((e = hipMalloc(&c2, 17 * 8)) != hipSuccess) return fail("hipMalloc", e);
+    PairStarts st;
+    for (int j = 0; j < 16; j++) st.s[j] = starts[j];
+    k_pair_records<<<(unsigned)n_groups, 256>>>(codes, cnt, st, n_groups, rec);
+    if ((e = hipGetLastError()) != hipSuccess) return fail("k_pair_records", e);
+    k_pair_first<<<1, 64>>>(v, c2);
+    uint64_t t0 = 0;
+    if ((e = hipMemcpy(&t0, c2 + 16, 8, hipMemcpyDeviceToHost)) != hipSuccess) return fail("k_pair_first", e);
+    drop(); codes = nullptr; cnt = nullptr; d_misc = nullptr; tmp = nullptr;
+    v.rank2 = rec; v.rank2_c2 = c2; v.rank2_lone = lone; v.rank2_t0 = (int32_t)t0;
+    if (check_trials > 0) {
+        unsigned long long bad = 0, *d_bad = nullptr;
+        if ((e = hipMalloc(&d_bad, 8)) == hipSuccess) e = hipMemset(d_bad, 0, 8);
+        if (e == hipSuccess) {
+            k_pair_check<<<(unsigned)(((uint64_t)check_trials + 255) / 256), 256>>>(v, (uint64_t)check_trials, d_bad);
+            e = hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost);
+        }
+        (void)hipFree(d_bad);
+        if (e != hipSuccess || bad) {
+            v.rank2 = nullptr; v.rank2_c2 = nullptr;
+            (void)hipFree(rec); (void)hipFree(c2);
+            if (e != hipSuccess) return mcx_set_error(MCX_ERR_DEVICE, std::string("pair records: check: ") + hipGetErrorString(e));
+            return mcx_set_error(MCX_ERR_DEVICE, "pair records: " + std::to_string(bad) + " of " + std::to_string(check_trials) + " two-base steps differ from two single steps");
+        }
+    }
+    *d_rec = rec; *d_c2 = c2; *bytes = (int64_t)rec_bytes + 17 * 8;
     return 0;
 }
 

@@ -12,6 +12,9 @@ struct mcx_index {
     int device = 0;
     void *d_bwt = nullptr, *d_sa = nullptr, *d_sa_full = nullptr, *d_pac = nullptr;
     void *d_end_pos = nullptr, *d_end_chr = nullptr, *d_chr_fwd = nullptr, *d_ktab = nullptr, *d_rank = nullptr;
+    void *d_rank2 = nullptr, *d_rank2_c2 = nullptr; // pair records (mcx_fm.h PairSlot): built when the index is made with full_sa = 2
+    int64_t rank2_bytes = 0;
+    int pair_records = 0;
     int64_t hbm_bytes = 0;
     uint64_t n_bwt_words = 0, n_sa = 0; // set for indexes built in HBM (mcx_index_from_codes)
 };

@@ -69,7 +69,9 @@ static void usage(const char *prog)
             "         -gpus INT     number of GPUs of this node to spread the reads over (devices 0..INT-1) [1]\n"
             "         -devices LIST device ordinals, comma separated (instead of -gpus)\n"
             "         -batch INT    reads per batch (the unit dealt to the GPUs) [524288]\n"
-            "         -sampled_sa   keep only the sampled suffix array in HBM (saves 8 bytes per text position, slower seeding)\n", prog, prog);
+            "         -sampled_sa   keep only the sampled suffix array in HBM (saves 8 bytes per text position, slower seeding)\n"
+            "         -two_base     keep the pair records in HBM too (4 bytes per text position: the seeding walk takes two bases per step);\n"
+            "                       implied by -no_vcf, which leaves the room\n", prog, prog);
 }
 
 int main(int argc, char **argv)
@@ -126,6 +128,7 @@ int main(int argc, char **argv)
         else if (p == "-batch" && i + 1 < argc) batch_reads = atoll(argv[++i]);
         else if (p == "-maxlen" && i + 1 < argc) maxlen = atoi(argv[++i]);
         else if (p == "-sampled_sa") full_sa = 0;
+        else if (p == "-two_base") full_sa = 2;
         else if (p == "-vcf" && i + 1 < argc) vcf = argv[++i];
         else if (p == "-no_vcf") want_vcf = false;
         else if (p == "-gvcf") vo.gvcf = 1;
@@ -192,6 +195,7 @@ int main(int argc, char **argv)
         if (want_vcf && mcx_comm_init_all(n_gpus, devices.data(), comms.data())) { fprintf(stderr, "Error! %s\n", mcx_last_error()); return 1; }
     }
     const bool paired_run = !f2.empty() || fo.interleaved_pairs;
+    if (!want_vcf && full_sa == 1) full_sa = 2; // (no planes: room for the pair records)
     auto work = [&](int r) {
         Shard &sh = shards[(size_t)r];
         sh.rank = r; sh.device = devices[(size_t)r];

@@ -170,6 +170,12 @@ static int build_rank(mcx_index *ix)
     ix->view.rank = ix->d_rank; ix->view.rank_chunks = n_chunks;
     for (int k = 0; k < 8; k++) ix->view.rank_cross[k] = h_cross[k];
     ix->hbm_bytes += (int64_t)bytes;
+    // the pair records on top (two bases per step): MCX_NO_RANK2 for experiments, MCX_RANK2_CHECK=n extends n random intervals both ways
+    if (!ix->pair_records || getenv("MCX_NO_RANK2")) return 0;
+    const char *chk = getenv("MCX_RANK2_CHECK");
+    const int rc = mcx_build_pair_records(ix->view, &ix->d_rank2, &ix->d_rank2_c2, &ix->rank2_bytes, chk ? atoi(chk) : 0);
+    if (rc) return rc;
+    ix->hbm_bytes += ix->rank2_bytes;
     return 0;
 }
 
@@ -193,7 +199,7 @@ static int index_to_device(mcx_index *ix, int full_sa)
     if ((rc = upload(&ix->d_end_chr, h.end_chr.data(), h.end_chr.size() * 4, 0, ix->hbm_bytes))) return rc;
     if ((rc = upload(&ix->d_chr_fwd, h.chr_fwd.data(), h.chr_fwd.size() * 8, 0, ix->hbm_bytes))) return rc;
     IndexView &v = ix->view;
-    v.bwt = (const uint32_t *)ix->d_bwt; v.sa = (const uint64_t *)ix->d_sa; v.sa_full = nullptr; v.ktab = nullptr; v.ktab_k = 0; v.rank = nullptr; v.rank_chunks = 0; for (auto &x : v.rank_cross) x = ~0ull;
+    v.bwt = (const uint32_t *)ix->d_bwt; v.sa = (const uint64_t *)ix->d_sa; v.sa_full = nullptr; v.ktab = nullptr; v.ktab_k = 0; v.rank = nullptr; v.rank_chunks = 0; for (auto &x : v.rank_cross) x = ~0ull; v.rank2 = nullptr; v.rank2_c2 = nullptr; v.rank2_lone = ~0ull; v.rank2_t0 = 0;
     v.pac = (const uint8_t *)ix->d_pac;
     v.end_pos = (const int64_t *)ix->d_end_pos; v.end_chr = (const int32_t *)ix->d_end_chr;
     v.chr_fwd = (const int64_t *)ix->d_chr_fwd;
@@ -223,6 +229,7 @@ extern "C" int mcx_index_load(const char *prefix, int device, int full_sa, mcx_i
     ix->device = device;
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { delete ix; return fail(MCX_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e)); }
+    ix->pair_records = full_sa >= 2;
     int rc = index_to_device(ix, full_sa);
     if (rc) { mcx_index_free(ix); return rc; }
     *out = ix;
@@ -259,6 +266,7 @@ extern "C" int mcx_index_from_codes(const uint8_t *d_codes, int32_t n_chr, const
     DevIndexArrays arr;
     int rc = mcx_build_suffix_index(d_codes, (uint64_t)G, full_sa != 0, arr, build_seconds);
     if (rc) { delete ix; return rc; }
+    ix->pair_records = full_sa >= 2;
     rc = index_from_arrays(ix, arr, d_codes, G);
     if (rc) { mcx_index_free(ix); return rc; }
     *out = ix;
@@ -283,7 +291,7 @@ static int index_from_arrays(mcx_index *ix, const DevIndexArrays &arr, const uin
     if ((rc = upload(&ix->d_chr_fwd, h.chr_fwd.data(), h.chr_fwd.size() * 8, 0, acc))) return rc;
     ix->hbm_bytes += acc + G / 4 + 32;
     IndexView &v = ix->view;
-    v.bwt = (const uint32_t *)ix->d_bwt; v.sa = (const uint64_t *)ix->d_sa; v.sa_full = (const uint64_t *)ix->d_sa_full; v.ktab = nullptr; v.ktab_k = 0; v.rank = nullptr; v.rank_chunks = 0; for (auto &x : v.rank_cross) x = ~0ull;
+    v.bwt = (const uint32_t *)ix->d_bwt; v.sa = (const uint64_t *)ix->d_sa; v.sa_full = (const uint64_t *)ix->d_sa_full; v.ktab = nullptr; v.ktab_k = 0; v.rank = nullptr; v.rank_chunks = 0; for (auto &x : v.rank_cross) x = ~0ull; v.rank2 = nullptr; v.rank2_c2 = nullptr; v.rank2_lone = ~0ull; v.rank2_t0 = 0;
     v.pac = (const uint8_t *)ix->d_pac;
     v.end_pos = (const int64_t *)ix->d_end_pos; v.end_chr = (const int32_t *)ix->d_end_chr; v.chr_fwd = (const int64_t *)ix->d_chr_fwd;
     v.primary = h.primary; for (int i = 0; i < 5; i++) v.L2[i] = h.L2[i];
@@ -344,9 +352,23 @@ extern "C" int mcx_index_save(const mcx_index *ix, const char *prefix)
 extern "C" void mcx_index_free(mcx_index *ix)
 {
     if (!ix) return;
-    void *p[] = {ix->d_bwt, ix->d_sa, ix->d_sa_full, ix->d_pac, ix->d_end_pos, ix->d_end_chr, ix->d_chr_fwd, ix->d_ktab, ix->d_rank};
+    void *p[] = {ix->d_bwt, ix->d_sa, ix->d_sa_full, ix->d_pac, ix->d_end_pos, ix->d_end_chr, ix->d_chr_fwd, ix->d_ktab, ix->d_rank, ix->d_rank2, ix->d_rank2_c2};
     for (void *q : p) if (q) (void)hipFree(q);
     delete ix;
+}
+// gives back what an index holds above `full_sa` (2 -> 1: the pair records).  Contexts made before keep their view of the index: close them first.
+extern "C" int mcx_index_trim(mcx_index *ix, int full_sa)
+{
+    if (!ix) return fail(MCX_ERR_ARG, "mcx_index_trim: null argument");
+    if (full_sa < 1) return fail(MCX_ERR_UNSUPPORTED, "mcx_index_trim: only the pair records can be released (full_sa = 1)");
+    if (full_sa >= 2 || !ix->d_rank2) return 0;
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(ix->d_rank2); (void)hipFree(ix->d_rank2_c2);
+    ix->d_rank2 = ix->d_rank2_c2 = nullptr;
+    ix->view.rank2 = nullptr; ix->view.rank2_c2 = nullptr;
+    ix->hbm_bytes -= ix->rank2_bytes; ix->rank2_bytes = 0;
+    return 0;
 }
 extern "C" int64_t mcx_index_genome_size(const mcx_index *ix) { return ix->host.G; }
 extern "C" int32_t mcx_index_n_chr(const mcx_index *ix) { return (int32_t)ix->host.chr_len.size(); }
@@ -2224,6 +2246,7 @@ static Ctx make_ctx(const mcx_ctx *c, int tier, int paired)
 {
     Ctx cx;
     cx.ix = c->idx->view; cx.pm = c->pm; cx.pm.paired = paired;
+    if (getenv("MCX_SEED_ONE_BASE")) cx.ix.rank2 = nullptr; // (experiments, tests: the walk one base per step although the pair records are there)
     cx.caps = c->tier[tier].caps; cx.lay = c->tier[tier].lay; cx.state = c->tier[tier].state;
     cx.mapq_tab = c->d_mapq; cx.mapq_rows = c->mapq_rows; cx.dp_summary = 1;
     cx.detail = c->prof_planes ? c->d_detail : nullptr; cx.dlay = c->dlay;

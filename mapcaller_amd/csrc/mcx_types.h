@@ -48,6 +48,12 @@ struct IndexView {
     const void *rank;        // [4][rank_chunks] records; null: the walk counts in the .bwt blocks
     uint64_t rank_chunks;
     uint64_t rank_cross[8];  // [b]: first chunk whose "equal" count before it is >= 2^32 (the records keep 32 bits); [4 + b]: same for "greater"
+    // optional (mcx_fm.h PairSlot): per 32 BWT symbols one 128-byte record over the sixteen PAIRS of bases that precede a suffix, so
+    // that the walk extends by two bases with one 16-byte fetch per end of the interval
+    const void *rank2;       // [rank_chunks] records; null: one base per step
+    const uint64_t *rank2_c2; // [16]: the first row of the suffixes that begin with the pair, minus one (fm_pair_first)
+    uint64_t rank2_lone;     // the stored symbol whose suffix has ONE base before it (the suffix at text position 1)
+    int32_t rank2_t0;        // that base: the text's first
     uint64_t primary, L2[5], seq_len;
     int64_t G, G2;
     int32_t n_ends, n_chr, sa_intv;

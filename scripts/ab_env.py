@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--sub", type=float, default=0.005)
     ap.add_argument("--ins", type=float, default=0.001)
     ap.add_argument("--dele", type=float, default=0.001)
+    ap.add_argument("--full-sa", type=int, default=2)
     ap.add_argument("--rounds", type=int, default=1, help="times the list of variants is gone through")
     ap.add_argument("variants", nargs="*", default=[""])
     a = ap.parse_args()
@@ -38,7 +39,7 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     codes, lens, _ = bench.make_genome(a, dev, seed=1234)
-    index = api.Index.from_codes(codes.data_ptr(), lens, device=0, full_sa=True)
+    index = api.Index.from_codes(codes.data_ptr(), lens, device=0, full_sa=a.full_sa)
     n = 2 * a.batch_pairs
     batches = [bench.make_reads(codes, lens, a.batch_pairs, a.rlen, seed=1000 + s, device=dev, sub=a.sub, ins=a.ins, dele=a.dele).reshape(-1).contiguous()
                for s in range(a.steps + 1)]

@@ -16,7 +16,7 @@ def main():
     args = bench.parse()
     dev = torch.device("cuda", 0)
     codes, lens, _ = bench.make_genome(args, dev, seed=1234)
-    index = api.Index.from_codes(codes.data_ptr(), lens, device=0, full_sa=bool(args.full_sa))
+    index = api.Index.from_codes(codes.data_ptr(), lens, device=0, full_sa=int(args.full_sa))
     G = index.genome_size
     n = 2 * args.batch_pairs
     batch = bench.make_reads(codes, lens, args.batch_pairs, args.rlen, seed=1001, device=dev, sub=args.sub, ins=args.ins, dele=args.dele, paired=True).reshape(-1).contiguous()

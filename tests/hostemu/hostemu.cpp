@@ -32,6 +32,8 @@ struct Emu {
     Params pm;
     std::vector<uint8_t> mapq;
     std::vector<uint32_t> ktab; // the seeding walk's K-mer jump table, here with K = 7
+    std::vector<uint64_t> sa_full, c2; // MCX_EMU_RANK2=1: every suffix-array entry and the pair records (two bases per step of the walk)
+    std::vector<PairSlot> rank2;
     int mapq_rows = 0;
     Caps caps[2];
     Layout lay[2];
@@ -49,6 +51,7 @@ static void set_view(Emu &e)
     v.seq_len = h.seq_len; v.G = h.G; v.G2 = 2 * h.G;
     v.n_ends = (int)h.end_pos.size(); v.n_chr = (int)h.chr_len.size(); v.sa_intv = h.sa_intv;
     v.ktab = nullptr; v.ktab_k = 0; v.rank = nullptr; v.rank_chunks = 0;
+    v.rank2 = nullptr; v.rank2_c2 = nullptr; v.rank2_lone = ~0ull; v.rank2_t0 = 0;
     const int K = 7;
     e.ktab.assign((size_t)4 << (2 * K), 0);
     for (uint32_t i = 0; i < (1u << (2 * K)); i++) {
@@ -59,6 +62,26 @@ static void set_view(Emu &e)
         w[0] = p.x; w[1] = p.y; w[2] = p.z; w[3] = p.w;
     }
     v.ktab = e.ktab.data(); v.ktab_k = K;
+    if (getenv("MCX_EMU_RANK2")) {
+        e.sa_full.assign(h.seq_len + 1, 0);
+        for (uint64_t r = 0; r <= h.seq_len; r++) { int lf = 0; e.sa_full[r] = r == 0 ? ~0ull : fm_sa(v, r, lf); }
+        v.sa_full = e.sa_full.data();
+        const uint64_t n_chunks = (h.seq_len + 31) / 32;
+        e.rank2.assign(n_chunks * 16 + 8, PairSlot{0, 0});
+        uint64_t n_lt[16] = {0};
+        for (uint64_t c = 0; c < n_chunks; c++) {
+            uint8_t code[32];
+            for (int t = 0; t < 32; t++) {
+                bool lone;
+                code[t] = (uint8_t)fm_pair_code(v, c * 32 + (uint64_t)t, lone);
+                if (lone) v.rank2_lone = c * 32 + (uint64_t)t;
+            }
+            fm_pair_record(code, n_lt, e.rank2.data() + c * 16);
+        }
+        e.c2.resize(16);
+        for (int s2 = 0; s2 < 16; s2++) e.c2[(size_t)s2] = fm_pair_first(v, s2);
+        v.rank2 = e.rank2.data(); v.rank2_c2 = e.c2.data(); v.rank2_t0 = ref_code(v, 0);
+    }
 }
 
 struct Batch {
@@ -110,6 +133,7 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
             st.hdr->n_hits[s] = nh;
             if (stats) { stats[3] += ext; stats[8] += blocks; }
             int keep = nh <= cx.caps.hit_cap ? nh : 0;
+            if (cx.ix.sa_full) keep = 0; // (every hit already is a text position)
             for (int i = 0; i < keep; i++) {
                 Hit &hh = st.hits[s][i];
                 if (hh.len & kHitResolved) { hh.len &= ~kHitResolved; if (stats) stats[4]++; continue; }
@@ -288,6 +312,20 @@ static int run_selection(Emu &e, const Batch &b, const std::vector<uint32_t> &id
 }
 
 } // namespace
+
+// the pair records' self-check (mcx_fm.h fm_pair_step_agrees) on the host: trials that disagree
+extern "C" int64_t hostemu_pair_check(const char *prefix, int64_t trials)
+{
+    Emu e;
+    std::string err;
+    if (!host_index_load(prefix, e.hix, err)) return -1;
+    setenv("MCX_EMU_RANK2", "1", 1);
+    set_view(e);
+    unsetenv("MCX_EMU_RANK2");
+    int64_t bad = 0;
+    for (int64_t t = 0; t < trials; t++) bad += fm_pair_step_agrees(e.view, (uint64_t)t) ? 0 : 1;
+    return bad;
+}
 
 extern "C" {
 

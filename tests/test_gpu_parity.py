@@ -60,11 +60,15 @@ def test_extend_equals_reference_vectors(api, toy, alg):
 
 @pytest.mark.parametrize("alg", ["nw", "ksw2"])
 @pytest.mark.parametrize("name", list(SETS))
-@pytest.mark.parametrize("full_sa", [True, False])
-def test_sam_equals_reference(api, golden, tmp_path, name, alg, full_sa):
+@pytest.mark.parametrize("full_sa", [2, True, False])
+def test_sam_equals_reference(api, golden, tmp_path, monkeypatch, name, alg, full_sa):
     """The reference's -t 1 SAM on every golden set, both algorithms.  full_sa (the product's default): every
-    suffix-array entry in HBM, seeds leave k_seed as text positions; without it the sampled suffix array (k_sa)."""
+    suffix-array entry in HBM, seeds leave k_seed as text positions; without it the sampled suffix array (k_sa); 2: the walk
+    takes two bases per step over the pair records, which check themselves when they are made (a million random intervals
+    extended both ways)."""
     g = golden[name]
+    if full_sa == 2:
+        monkeypatch.setenv("MCX_RANK2_CHECK", "1000000")
     ix = api.Index(g["prefix"], device=0, full_sa=full_sa)
     mp = api.Mapper(ix, alg=alg, max_batch_reads=1 << 14)
     out = str(tmp_path / "gpu.sam")
@@ -569,7 +573,11 @@ def bench_genome(api, tmp_path_factory):
     dev = torch.device("cuda", 0)
     args = argparse.Namespace(genome_mbp=3100.0, contigs=24, repeats=2000, genome="human")  # bench.py's default
     codes, lens, _ = bench.make_genome(args, dev, seed=1234)
-    ix = api.Index.from_codes(codes.data_ptr(), lens, device=0, full_sa=True)
+    os.environ["MCX_RANK2_CHECK"] = "4000000"  # (the pair records of bench.py's default index check themselves as they are made)
+    try:
+        ix = api.Index.from_codes(codes.data_ptr(), lens, device=0, full_sa=2)
+    finally:
+        os.environ.pop("MCX_RANK2_CHECK", None)
     prefix = str(tmp_path_factory.mktemp("big") / "big")
     ix.save(prefix)
     yield {"codes": codes, "lens": lens, "index": ix, "prefix": prefix, "bench": bench, "dev": dev}
@@ -620,7 +628,7 @@ def test_config2_ecoli_sized_single_end_equals_reference(api, tmp_path):
     dev = torch.device("cuda", 0)
     args = argparse.Namespace(genome_mbp=4.6, contigs=1, repeats=20, genome="uniform")
     codes, lens, _ = bench.make_genome(args, dev, seed=1234)
-    ix = api.Index.from_codes(codes.data_ptr(), lens, device=0, full_sa=True)
+    ix = api.Index.from_codes(codes.data_ptr(), lens, device=0, full_sa=2)
     prefix = str(tmp_path / "ecoli")
     ix.save(prefix)
     n = 300000
@@ -669,8 +677,9 @@ def test_large_batch_machinery_does_not_change_the_records(api, bench_genome, mo
     c_aln, c_cig, c_st = run()
     monkeypatch.delenv("MCX_DP_LANE_ALWAYS")
     # everything off: no k_simple, no order, the wavefront DP kernels, the rescue in line, the late pairs searched again, the large tier's build a
-    # lane per pair, the tiers one after the other
-    for k in ("MCX_NO_WORK_ORDER", "MCX_NO_LATE_OVERLAP", "MCX_NO_TIER_OVERLAP", "MCX_NO_SIMPLE", "MCX_DP_BY_WAVE", "MCX_RESCUE_IN_LINE", "MCX_LATE_RESEED", "MCX_BUILD_BY_LANE"):
+    # lane per pair, the tiers one after the other, the seeding walk one base per step
+    for k in ("MCX_NO_WORK_ORDER", "MCX_NO_LATE_OVERLAP", "MCX_NO_TIER_OVERLAP", "MCX_NO_SIMPLE", "MCX_DP_BY_WAVE", "MCX_RESCUE_IN_LINE", "MCX_LATE_RESEED", "MCX_BUILD_BY_LANE",
+              "MCX_SEED_ONE_BASE"):
         monkeypatch.setenv(k, "1")
     b_aln, b_cig, b_st = run()
     assert a_st["tier1"] > 0 and a_st["tier1"] == b_st["tier1"] == c_st["tier1"], (a_st, b_st, c_st)
@@ -718,7 +727,7 @@ def test_bench_workload_keeps_its_shape(api, bench_genome):
     assert 0 < d["tier1_pairs"] < 0.02 * (reads / 2), d           # measured 0.7-0.8 %
     assert d["replayed_pairs"] < 0.02 * (reads / 2), d           # steady state: the estimate barely moves
     assert d["halved_selections"] == 0, d
-    assert 10 < d["fm_blocks"] / reads < 30, d                    # measured 19-20 index blocks per read
+    assert 6 < d["fm_blocks"] / reads < 30, d                     # measured 19-20 index records per read one base per step
     assert d["dp_jobs"] / reads < 1.0, d                          # measured 0.3-0.4 DP problems per read
     assert ms < 16.0, f"{ms:.2f} ms per 2 M reads (measured 8.5 ms)"
 

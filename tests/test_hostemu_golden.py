@@ -75,6 +75,31 @@ def test_lane_dp_inputs_and_the_scalar_dp_agree(hostemu_lib, golden, tmp_path, m
     assert nd == 0, ex
 
 
+@pytest.mark.parametrize("name", list(SETS))
+def test_two_base_steps_of_the_walk_change_nothing(hostemu_lib, golden, tmp_path, monkeypatch, name):
+    """The seeding walk over the pair records (mcx_fm.h PairSlot: two bases per step, the full suffix array beside them) gives the
+    reference's SAM, with fewer index records fetched than the single steps take."""
+    out = str(tmp_path / "e.sam")
+    _, st1 = _run(hostemu_lib, golden[name], "ksw2", out)
+    monkeypatch.setenv("MCX_EMU_RANK2", "1")
+    n, st2 = _run(hostemu_lib, golden[name], "ksw2", out)
+    assert n > 0
+    nd, ex = sam_diff(golden[name]["sam"]["ksw2"], out)
+    assert nd == 0, ex
+    assert st2[3] == st1[3]          # the searches end where they ended: the same bases consumed
+    assert 0 < st2[8] < st1[8]       # in fewer fetches
+
+
+@pytest.mark.parametrize("name", list(SETS))
+def test_pair_records_equal_two_single_steps(hostemu_lib, golden, name):
+    """mcx_fm.h's self-check of the pair records (the one MCX_RANK2_CHECK runs on the device): the bi-intervals of random strings
+    of 1..12 bases — every width, with and without the primary row and the lone suffix inside — extended by two random bases
+    through one pair step and through two single steps in the .bwt blocks."""
+    hostemu_lib.hostemu_pair_check.restype = ctypes.c_int64
+    hostemu_lib.hostemu_pair_check.argtypes = [ctypes.c_char_p, ctypes.c_int64]
+    assert hostemu_lib.hostemu_pair_check(golden[name]["prefix"].encode(), 400000) == 0
+
+
 def test_small_batches_follow_the_avgdist_trajectory(hostemu_lib, golden, tmp_path):
     # 600-read batches: the insert-size estimate crosses batch boundaries
     out = str(tmp_path / "e.sam")
