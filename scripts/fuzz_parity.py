@@ -130,13 +130,14 @@ def one_round(d, tmp):
         writer(f1, bases, 0, 1)
         files = ["-f", f1]
     alg, vcf_flags = d["alg"], d["vcf"]
-    desc = dict(lens=lens, rlen=rlen, paired=paired, fastq=fastq, n=n, alg=alg, vcf=vcf_flags, frag_mean=mean, **p)
+    desc = dict(lens=lens, rlen=rlen, paired=paired, fastq=fastq, n=n, alg=alg, vcf=vcf_flags, frag_mean=mean, two_base=bool(d.get("two_base")), **p)
     gs, gv, os_, ov = (os.path.join(tmp, x) for x in ("gpu.sam", "gpu.vcf", "ora.sam", "ora.vcf"))
     if MODE == "ref":
         subprocess.run([REF, "-i", prefix, *files, "-alg", alg, "-sam", gs, "-vcf", gv, "-t", "1", "-log", os.path.join(tmp, "job.log"), *vcf_flags],
                        check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     else:
-        subprocess.run([EXE, "-i", prefix, *files, "-alg", alg, "-sam", gs, "-vcf", gv, *vcf_flags, *CLI_ARGS], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        walk = ["-two_base"] if d.get("two_base") else []  # every other round: the seeding walk over the pair records
+        subprocess.run([EXE, "-i", prefix, *files, "-alg", alg, "-sam", gs, "-vcf", gv, *vcf_flags, *walk, *CLI_ARGS], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     subprocess.run([ORACLE, "-i", prefix, *files, "-alg", alg, "-sam", os_], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     subprocess.run([ORACLE, "-i", prefix, *files, "-alg", alg, "-vcf", ov, *vcf_flags], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     if MODE == "ref":
@@ -167,6 +168,7 @@ def main():
     bad = ran = 0
     for r in range(a.rounds):
         d = draw(rng)
+        d["two_base"] = r % 2 == 1
         if a.only >= 0 and r != a.only:
             continue
         ran += 1

@@ -1,6 +1,9 @@
 #!/bin/bash
+# pair records: golden SAM + the full-size genome tests, then the step with and without them
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; ulimit -c 0
-timeout 900 python scripts/ab_env.py --steps 3 "" "" > gpurun_out/r4_ab7_cfg3.txt 2>/dev/null; cat gpurun_out/r4_ab7_cfg3.txt
-MCX_LIB=$PWD/mapcaller_amd/libmcx_b5.so timeout 600 python scripts/ab_env.py --steps 3 "" "" 2>/dev/null | sed "s/^/b5 /"
-timeout 3000 python -m pytest tests -m gpu -q --timeout 2400 -p no:cacheprovider 2>&1 | tail -12 > gpurun_out/r4_pytest_full.log
-tail -6 gpurun_out/r4_pytest_full.log
+timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 1400 -p no:cacheprovider -x -k "test_sam_equals_reference or full_size or large_batch_machinery or keeps_its_shape or config5 or config2 or ecoli" 2>&1 | tail -15 > gpurun_out/r4_pytest_pairs.log
+tail -8 gpurun_out/r4_pytest_pairs.log
+MCX_TIMING=1 timeout 900 python scripts/ab_env.py --steps 4 --rounds 2 "" "MCX_SEED_ONE_BASE=1" > gpurun_out/r4_ab7.txt 2> gpurun_out/r4_ab7.err
+cat gpurun_out/r4_ab7.txt; grep -i "hbm\|index" gpurun_out/r4_ab7.err | head -5
+timeout 900 python scripts/ab_env.py --steps 2 --rlen 250 --ins 0.025 --dele 0.025 --alg nw "" "MCX_SEED_ONE_BASE=1" > gpurun_out/r4_ab7_cfg5.txt 2> gpurun_out/r4_ab7_cfg5.err
+cat gpurun_out/r4_ab7_cfg5.txt
