@@ -401,19 +401,22 @@ int mcx_build_suffix_index(const uint8_t *d_fwd, uint64_t G, bool want_full_sa, 
 __global__ void __launch_bounds__(256) k_pair_codes(IndexView ix, uint8_t *codes, uint64_t *cnt, uint64_t n_groups, unsigned long long *lone)
 {
     __shared__ uint32_t h[16];
-    if (threadIdx.x < 16) h[threadIdx.x] = 0;
-    __syncthreads();
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    bool ln;
-    const int code = fm_pair_code(ix, i, ln);
-    if (ln) *lone = i;
-    codes[i] = (uint8_t)code;
-    for (int j = 0; j < 16; j++) {
-        const uint64_t m = __ballot(code == j);
-        if ((threadIdx.x & 63) == 0 && m) atomicAdd(&h[j], (uint32_t)__popcll(m));
+    for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) { // (a launch holds fewer than 2^32 threads: the groups in a loop)
+        if (threadIdx.x < 16) h[threadIdx.x] = 0;
+        __syncthreads();
+        const uint64_t i = g * 256 + threadIdx.x;
+        bool ln;
+        const int code = fm_pair_code(ix, i, ln);
+        if (ln) *lone = i;
+        codes[i] = (uint8_t)code;
+        for (int j = 0; j < 16; j++) {
+            const uint64_t m = __ballot(code == j);
+            if ((threadIdx.x & 63) == 0 && m) atomicAdd(&h[j], (uint32_t)__popcll(m));
+        }
+        __syncthreads();
+        if (threadIdx.x < 16) cnt[(uint64_t)threadIdx.x * n_groups + g] = h[threadIdx.x];
+        __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x < 16) cnt[(uint64_t)threadIdx.x * n_groups + blockIdx.x] = h[threadIdx.x];
 }
 
 // cnt: per code the exclusive sums over the workgroups.  A wavefront makes the records of two runs of 32 symbols: lane j (1..15)
@@ -421,27 +424,31 @@ __global__ void __launch_bounds__(256) k_pair_codes(IndexView ix, uint8_t *codes
 struct PairStarts { uint64_t s[16]; };
 __global__ void __launch_bounds__(256) k_pair_records(const uint8_t *codes, const uint64_t *cnt, PairStarts st, uint64_t n_groups, PairSlot *rec)
 {
-    __shared__ uint32_t part[8][16]; // symbols with a code below j in each of the workgroup's eight runs
+    __shared__ uint32_t part[8][16]; // symbols with a code below j in each of the group's eight runs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const int code = codes[i];
-    uint32_t lt0 = 0, lt1 = 0;
-    for (int j = 1; j < 16; j++) {
-        const uint64_t m = __ballot(code < j); // (kPairNone is below nothing)
-        if (lane == j) { lt0 = __brev((uint32_t)m); lt1 = __brev((uint32_t)(m >> 32)); } // symbol t of a run at bit 31 - t
+    for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const uint64_t i = g * 256 + threadIdx.x;
+        const int code = codes[i];
+        uint32_t lt0 = 0, lt1 = 0;
+        for (int j = 1; j < 16; j++) {
+            const uint64_t m = __ballot(code < j); // (kPairNone is below nothing)
+            if (lane == j) { lt0 = __brev((uint32_t)m); lt1 = __brev((uint32_t)(m >> 32)); } // symbol t of a run at bit 31 - t
+        }
+        if (lane >= 1 && lane < 16) { part[2 * wave][lane] = (uint32_t)__popc(lt0); part[2 * wave + 1][lane] = (uint32_t)__popc(lt1); }
+        __syncthreads();
+        if (lane >= 1 && lane < 16) {
+            uint64_t before = 0;
+            for (int j = 0; j < lane; j++) before += cnt[(uint64_t)j * n_groups + g] - st.s[j]; // (one scan over the arrays laid end to end: a code's sums start at the total of the codes below it)
+            for (int r = 0; r < 2 * wave; r++) before += part[r][lane];
+            PairSlot *out = rec + (g * 8 + 2 * wave) * 16;
+            PairSlot e0, e1;
+            e0.lt = lt0; e0.n_lt = (uint32_t)before;
+            e1.lt = lt1; e1.n_lt = (uint32_t)(before + part[2 * wave][lane]);
+            if (lane <= 8) { out[lane - 1] = e0; out[16 + lane - 1] = e1; }
+            if (lane >= 8) { out[lane] = e0; out[16 + lane] = e1; }
+        }
+        __syncthreads();
     }
-    if (lane >= 1 && lane < 16) { part[2 * wave][lane] = (uint32_t)__popc(lt0); part[2 * wave + 1][lane] = (uint32_t)__popc(lt1); }
-    __syncthreads();
-    if (lane < 1 || lane >= 16) return;
-    uint64_t before = 0;
-    for (int j = 0; j < lane; j++) before += cnt[(uint64_t)j * n_groups + blockIdx.x] - st.s[j]; // (one scan over the arrays laid end to end: a code's sums start at the total of the codes below it)
-    for (int r = 0; r < 2 * wave; r++) before += part[r][lane];
-    PairSlot *out = rec + ((uint64_t)blockIdx.x * 8 + 2 * wave) * 16;
-    PairSlot e0, e1;
-    e0.lt = lt0; e0.n_lt = (uint32_t)before;
-    e1.lt = lt1; e1.n_lt = (uint32_t)(before + part[2 * wave][lane]);
-    if (lane <= 8) { out[lane - 1] = e0; out[16 + lane - 1] = e1; }
-    if (lane >= 8) { out[lane] = e0; out[16 + lane] = e1; }
 }
 
 __global__ void k_pair_first(IndexView ix, uint64_t *c2)
@@ -473,7 +480,7 @@ int mcx_build_pair_records(IndexView &v, void **d_rec, void **d_c2, int64_t *byt
     if ((e = hipMalloc(&cnt, (16 * n_groups + 1) * 8)) != hipSuccess) return fail("hipMalloc(counts)", e);
     if ((e = hipMalloc(&d_misc, 16)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipMemset(d_misc, 0xFF, 8)) != hipSuccess || (e = hipMemset(d_misc + 1, 0, 8)) != hipSuccess) return fail("hipMemset", e);
-    k_pair_codes<<<(unsigned)n_groups, 256>>>(v, codes, cnt, n_groups, d_misc);
+    k_pair_codes<<<(unsigned)std::min<uint64_t>(n_groups, 1u << 20), 256>>>(v, codes, cnt, n_groups, d_misc);
     if ((e = hipGetLastError()) != hipSuccess) return fail("k_pair_codes", e);
     size_t cb = 0;
     if ((e = hipcub::DeviceScan::ExclusiveSum(nullptr, cb, cnt, cnt, (int64_t)(16 * n_groups + 1))) != hipSuccess) return fail("scan size", e);
@@ -492,7 +499,7 @@ int mcx_build_pair_records(IndexView &v, void **d_rec, void **d_c2, int64_t *byt
     if ((e = hipMalloc(&c2, 17 * 8)) != hipSuccess) return fail("hipMalloc", e);
     PairStarts st;
     for (int j = 0; j < 16; j++) st.s[j] = starts[j];
-    k_pair_records<<<(unsigned)n_groups, 256>>>(codes, cnt, st, n_groups, rec);
+    k_pair_records<<<(unsigned)std::min<uint64_t>(n_groups, 1u << 20), 256>>>(codes, cnt, st, n_groups, rec);
     if ((e = hipGetLastError()) != hipSuccess) return fail("k_pair_records", e);
     k_pair_first<<<1, 64>>>(v, c2);
     uint64_t t0 = 0;
