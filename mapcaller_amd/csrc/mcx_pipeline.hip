@@ -762,21 +762,39 @@ __global__ void __launch_bounds__(256) k_order_place(PairSel sel, const uint32_t
 // seeds per read, the 2-bit words of its reads, a few words of the genome under the gaps — stays in registers; the CIGAR
 // operations wait word-major in LDS until the wave has reserved its words of the pool with one atomic.  done[pair] tells the
 // per-pair kernels behind this one which pairs are left to them (k_order_*).
-template <bool NW>
+// A pair whose only obstacle is a small gapped extension or two (mcx_simple.h SimpleJob) writes the problems down and waits
+// (done = 2): k_simple_dp solves them one per lane, k_simple_rest makes the pass again with the results at hand.
+struct SimpleLater {        // the pairs that wait, and their problems
+    uint32_t *pairs;        // [cap]
+    SimpleJob *jobs;        // [cap * kSimpleJobs]: waiting pair i's at i * kSimpleJobs
+    SimpleRes *res;         // the same places
+    uint32_t *job_list;     // [cap * kSimpleJobs]: the places that hold a problem
+    uint32_t *n_pairs, *n_jobs;
+    uint32_t cap;
+};
+
+template <bool NW, int MODE>
 __global__ void __launch_bounds__(256) k_simple(Ctx cx, ReadBatch rb, uint32_t n_pairs, const int32_t *est, const uint32_t *read_blocks, AlnRec *recs, PairOut *pout,
-                                                uint8_t *done, uint32_t *pool_over, uint32_t *n_done)
+                                                uint8_t *done, uint32_t *pool_over, uint32_t *n_done, SimpleLater sl)
 {
     __shared__ EndsLds ends;
     __shared__ uint32_t cig_stage[256 * 2 * kSimpleRuns]; // word k of thread t at [k * 256 + t]
-    __shared__ uint32_t dp_words[256 * (2 + kSimpleDp)];  // the lane's words for a small gapped extension (simple_dp_layout), word-major too
-    LaneMem dpm; dpm.base = dp_words + threadIdx.x; dpm.stride = 256;
+    __shared__ SimpleJob job_stage[MODE == kDpCollect ? kSimpleJobs * 256 : 1]; // problem k of thread t at [k * 256 + t]
     stage_ends(cx.ix, ends);
-    const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; // collect: the pair; replay: the waiting pair
     const int nr = cx.pm.paired ? 2 : 1;
     uint32_t *stage = cig_stage + threadIdx.x;
-    bool ok = pair < n_pairs;
+    const uint32_t n_slots = MODE == kDpReplay ? min(*sl.n_pairs, sl.cap) : n_pairs;
+    bool ok = slot < n_slots;
+    const uint32_t pair = MODE == kDpReplay ? (ok ? sl.pairs[slot] : 0u) : slot;
     SimpleRead sr[2];
     int rl[2] = {0, 0};
+    SimpleDpIo io;
+    io.mode = MODE == kDpCollect && !sl.pairs ? kDpNone : MODE;
+    io.jobs = MODE == kDpCollect ? job_stage + threadIdx.x : nullptr; io.job_stride = 256;
+    io.res = MODE == kDpReplay ? sl.res + (uint64_t)slot * kSimpleJobs : nullptr;
+    io.n = 0; io.read = 0;
+    bool later = false;
     if (ok) {
         const PairState st = pair_state(cx.state, cx.lay, cx.caps, pair);
 #pragma unroll
@@ -785,19 +803,37 @@ __global__ void __launch_bounds__(256) k_simple(Ctx cx, ReadBatch rb, uint32_t n
                 const uint32_t r = pair * nr + s;
                 const int nh = (int)(read_blocks[r] >> 20);
                 rl[s] = (int)(rb.off[r + 1] - rb.off[r]);
-                ok = nh >= 1 && nh <= kSimpleHits && !(cx.read_ext[r] >> 31) &&
-                     simple_read<NW>(cx.ix, cx.pm, rl[s], cx.packed + (uint64_t)r * cx.wpad, st.hits[s], nh, sr[s], stage + s * kSimpleRuns * 256, 256, &dpm);
+                io.read = r;
+                ok = nh >= 1 && nh <= kSimpleHits && !(cx.read_ext[r] >> 31);
+                if (ok) {
+                    const int how = simple_read<NW>(cx.ix, cx.pm, rl[s], cx.packed + (uint64_t)r * cx.wpad, st.hits[s], nh, sr[s], stage + s * kSimpleRuns * 256, 256, io);
+                    ok = how != kSimpleNo;
+                    later = later || how == kSimpleLater;
+                }
             }
         }
         if (ok && nr == 2) ok = simple_pair_ok(sr[0], sr[1], est[pair]);
+    }
+    if (MODE == kDpCollect) { // the pairs that wait: a place among them, their problems into it
+        const bool wait = ok && later;
+        const uint32_t at = wave_reserve(sl.n_pairs, wait ? 1u : 0u);
+        const bool kept = wait && at < sl.cap;
+        const uint32_t jat = wave_reserve(sl.n_jobs, kept ? (uint32_t)io.n : 0u);
+        if (kept) {
+            sl.pairs[at] = pair;
+            for (int k = 0; k < io.n; k++) { sl.jobs[(uint64_t)at * kSimpleJobs + k] = job_stage[k * 256 + threadIdx.x]; sl.job_list[jat + k] = at * kSimpleJobs + (uint32_t)k; }
+            done[pair] = 2;
+        }
+        if (wait) ok = false; // (not kept: the general path)
+        later = kept;
     }
     const uint32_t want = ok ? (uint32_t)sr[0].n_cig + (nr == 2 ? (uint32_t)sr[1].n_cig : 0u) : 0u;
     const uint32_t at = wave_reserve(cx.cig_pool_n, want);
     const uint64_t took = __ballot(ok);
     if ((threadIdx.x & 63) == 0 && took) atomicAdd(n_done, (uint32_t)__popcll(took));
-    if (pair >= n_pairs) return;
+    if (slot >= n_slots) return;
     if (ok && at + want > cx.cig_pool_cap) { atomicOr(pool_over, 1u); ok = false; } // (the batch fails; the general path reports it)
-    done[pair] = ok ? 1 : 0;
+    if (!later) done[pair] = ok ? 1 : 0;
     if (!ok) return;
     const uint32_t off[2] = {at, at + (uint32_t)sr[0].n_cig};
 #pragma unroll
@@ -811,6 +847,22 @@ __global__ void __launch_bounds__(256) k_simple(Ctx cx, ReadBatch rb, uint32_t n
     recs[(uint64_t)pair * nr] = rec2[0];
     if (nr == 2) recs[(uint64_t)pair * nr + 1] = rec2[1];
     pout[pair] = po;
+}
+
+// the problems the straight-line pairs wrote down, one per lane (mcx_simple.h simple_dp_job): a strip of 16 columns, the lane's
+// traceback words word-major in LDS
+template <bool NW>
+__global__ void __launch_bounds__(256) k_simple_dp(Ctx cx, SimpleLater sl)
+{
+    constexpr int W = 2 + kSimpleDp * LaneDir<16, NW>::words;
+    __shared__ uint32_t words[W * 256];
+    const uint32_t n = min(*sl.n_jobs, sl.cap * kSimpleJobs);
+    LaneMem mem; mem.base = words + threadIdx.x; mem.stride = 256;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { // (the list's length stays on the device)
+        const uint32_t at = sl.job_list[i];
+        const SimpleJob j = sl.jobs[at];
+        sl.res[at] = simple_dp_job<NW>(cx.ix, j, cx.packed + (uint64_t)j.read * cx.wpad, mem);
+    }
 }
 
 // pairs the per-pair kernels work on: all of the selection, or — with k_simple ahead of them — those the order lists (its class counts)
@@ -1874,7 +1926,7 @@ constexpr uint32_t kPoutSel = 1u << 16; // pair outcomes gathered per copy (run_
 enum { CNT_TASKS = 0, CNT_RESCUE = 1 * kCntPad, CNT_JOB0 = 2 * kCntPad, CNT_JOB1 = 3 * kCntPad, CNT_JOB2 = 4 * kCntPad, CNT_JOB3 = 5 * kCntPad,
        CNT_JOB4 = 6 * kCntPad, CNT_JOB5 = 7 * kCntPad, CNT_OV = 8 * kCntPad, CNT_LF = 9 * kCntPad, CNT_CELLS = 10 * kCntPad, CNT_UNSUP = 11 * kCntPad,
        CNT_QUEUE = 12 * kCntPad, CNT_EARLY = 13 * kCntPad, CNT_LATE = 14 * kCntPad, CNT_RTASK = 15 * kCntPad, CNT_RPLAN = 16 * kCntPad, CNT_RESCUE_N = 17 * kCntPad, CNT_RSEED = 18 * kCntPad,
-       CNT_SIMPLE = 19 * kCntPad, CNT_EARLY_HITS = 20 * kCntPad, CNT_N = 21 * kCntPad,
+       CNT_SIMPLE = 19 * kCntPad, CNT_EARLY_HITS = 20 * kCntPad, CNT_SIMPLE_LATER = 21 * kCntPad, CNT_SIMPLE_JOBS = 22 * kCntPad, CNT_N = 23 * kCntPad,
        // behind the counters proper, cleared with them at the start of a pass (a memset in the middle of a pass was seen to sit 1.4 ms in its queue):
        CNT_ORDER = CNT_N, CNT_DP_SORT = CNT_ORDER + 16 * kCntPad, CNT_ALL = CNT_DP_SORT + 4 * 256 };
 constexpr uint32_t kLateRoom = 2048; // pairs of a pass that may run over after clustering and still go through the large tier beside it
@@ -1941,6 +1993,8 @@ struct mcx_ctx {
     uint32_t *d_packed = nullptr; int wpad = 0; // 2-bit form of the batch's reads
     uint32_t *d_order = nullptr; // the pairs of a pass by weight (k_order_*; their class counts: CNT_ORDER)
     uint8_t *d_done = nullptr;                           // per pair of a pass: k_simple wrote its records (the per-pair kernels skip it)
+    uint32_t *d_sl_pairs = nullptr, *d_sl_list = nullptr; // the straight-line pairs that wait for a small gapped extension (SimpleLater)
+    SimpleJob *d_sl_jobs = nullptr; SimpleRes *d_sl_res = nullptr; uint32_t sl_cap = 0;
     PairOut *d_pout = nullptr, *d_pout_sel = nullptr; // per-pair outcome of the finish stage; a gathered selection of it
     uint8_t *d_mapq = nullptr; int mapq_rows = 0;
     // -vcf bookkeeping (mcx_profile.h): caller-owned counter planes, per-read alignment detail
@@ -2174,6 +2228,11 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     if ((rc = dmalloc(&c->d_pout_sel, kPoutSel))) return rc;
     if ((rc = dmalloc(&c->d_order, c->max_reads))) return rc;
     if ((rc = dmalloc(&c->d_done, c->max_reads))) return rc;
+    c->sl_cap = (uint32_t)std::max<uint64_t>(c->max_reads / 4, 1024);
+    if ((rc = dmalloc(&c->d_sl_pairs, c->sl_cap))) return rc;
+    if ((rc = dmalloc(&c->d_sl_list, (uint64_t)c->sl_cap * kSimpleJobs))) return rc;
+    if ((rc = dmalloc(&c->d_sl_jobs, (uint64_t)c->sl_cap * kSimpleJobs))) return rc;
+    if ((rc = dmalloc(&c->d_sl_res, (uint64_t)c->sl_cap * kSimpleJobs))) return rc;
     // EvaluateMAPQ (SamReport.cpp:86-101) tabulated on the host so that the double-precision
     // log() is the host libm's, exactly as in the reference
     c->mapq_rows = c->rlen_max + 64;
@@ -2218,7 +2277,7 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3], c->d_jobs[4], c->d_jobs[5],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_rtasks, c->d_rres, c->d_rseeds, c->d_rplans, c->d_rescue_n, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
                  c->d_ov, c->d_sel_ids, c->d_est, c->d_read_ext, c->d_read_blocks, c->d_pout, c->d_mapq,
-                 c->d_dp_lane, c->d_dp_order[0], c->d_dp_order[1], c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_pout_sel, c->d_order, c->d_done, c->d_packed, c->d_batch_flags, c->d_scan_tmp, c->d_prof_match, c->d_prof_items};
+                 c->d_dp_lane, c->d_dp_order[0], c->d_dp_order[1], c->d_bases, c->d_off, c->d_recs, c->d_cig, c->d_detail, c->d_keys[0], c->d_keys[1], c->d_admit, c->d_sort_tmp, c->d_sparse, c->d_pout_sel, c->d_order, c->d_done, c->d_sl_pairs, c->d_sl_list, c->d_sl_jobs, c->d_sl_res, c->d_packed, c->d_batch_flags, c->d_scan_tmp, c->d_prof_match, c->d_prof_items};
     for (void *q : p) if (q) (void)hipFree(q);
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
     if (c->h_keys) (void)hipHostFree(c->h_keys);
@@ -2421,8 +2480,24 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         const bool no_simple = getenv("MCX_NO_SIMPLE") != nullptr;
         const uint8_t *done = nullptr;
         if (!no_simple && !sel.ids && !cx.detail && cx.ix.sa_full && cx.packed) {
-            if (cx.pm.use_nw) k_simple<true><<<pb, 256, 0, s>>>(cx, rb, sel.n, sel.est, so.read_blocks, d_recs, c->d_pout, c->d_done, c->d_batch_flags + 2, R.d_cnt + CNT_SIMPLE);
-            else k_simple<false><<<pb, 256, 0, s>>>(cx, rb, sel.n, sel.est, so.read_blocks, d_recs, c->d_pout, c->d_done, c->d_batch_flags + 2, R.d_cnt + CNT_SIMPLE);
+            // collect (every pair) -> solve (the problems written down) -> replay (the pairs that wrote some down); MCX_SIMPLE_NO_DP: a pair
+            // with such a problem takes the general path
+            SimpleLater sl; sl.pairs = getenv("MCX_SIMPLE_NO_DP") ? nullptr : c->d_sl_pairs; sl.jobs = c->d_sl_jobs; sl.res = c->d_sl_res; sl.job_list = c->d_sl_list;
+            sl.n_pairs = R.d_cnt + CNT_SIMPLE_LATER; sl.n_jobs = R.d_cnt + CNT_SIMPLE_JOBS; sl.cap = std::min<uint32_t>(c->sl_cap, std::max<uint32_t>(sel.n / 2, 1024u));
+            const unsigned lb = (sl.cap + 255) / 256, jb = std::min<unsigned>((sl.cap * kSimpleJobs + 255) / 256, 3072u); // (launched for what the lists may hold: their lengths stay on the device)
+            if (cx.pm.use_nw) {
+                k_simple<true, kDpCollect><<<pb, 256, 0, s>>>(cx, rb, sel.n, sel.est, so.read_blocks, d_recs, c->d_pout, c->d_done, c->d_batch_flags + 2, R.d_cnt + CNT_SIMPLE, sl);
+                if (sl.pairs) {
+                    k_simple_dp<true><<<jb, 256, 0, s>>>(cx, sl);
+                    k_simple<true, kDpReplay><<<lb, 256, 0, s>>>(cx, rb, sel.n, sel.est, so.read_blocks, d_recs, c->d_pout, c->d_done, c->d_batch_flags + 2, R.d_cnt + CNT_SIMPLE, sl);
+                }
+            } else {
+                k_simple<false, kDpCollect><<<pb, 256, 0, s>>>(cx, rb, sel.n, sel.est, so.read_blocks, d_recs, c->d_pout, c->d_done, c->d_batch_flags + 2, R.d_cnt + CNT_SIMPLE, sl);
+                if (sl.pairs) {
+                    k_simple_dp<false><<<jb, 256, 0, s>>>(cx, sl);
+                    k_simple<false, kDpReplay><<<lb, 256, 0, s>>>(cx, rb, sel.n, sel.est, so.read_blocks, d_recs, c->d_pout, c->d_done, c->d_batch_flags + 2, R.d_cnt + CNT_SIMPLE, sl);
+                }
+            }
             done = c->d_done;
         }
         uint32_t *cls_cnt = R.d_cnt + CNT_ORDER; // (cleared with the pass's counters)

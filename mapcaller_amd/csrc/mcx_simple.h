@@ -26,23 +26,65 @@ namespace mcx {
 
 // (the test harness counts which exit a read takes: MCX_SIMPLE_FAIL(exit number))
 #ifndef MCX_SIMPLE_FAIL
-#define MCX_SIMPLE_FAIL(code) return false
+#define MCX_SIMPLE_FAIL(code) return 0
+#endif
+#ifndef MCX_SIMPLE_NOTE
+#define MCX_SIMPLE_NOTE(k, l) ((void)0)
 #endif
 
 constexpr int kSimpleHits = 4;                  // seeds per read the straight-line path takes (one 64-byte line of hits)
-constexpr int kSimpleRuns = 2 * kSimpleHits;    // CIGAR operations the path keeps per read (seeds and gaps alternate, equal neighbours merge; a read that needs more leaves)
-constexpr int kSimpleDp = 8;                    // a gap between two seeds of up to kSimpleDp x kSimpleDp bases is aligned right here, by the lane (mcx_dp_lane.h)
+constexpr int kSimpleRuns = 12;                 // CIGAR operations the path keeps per read (seeds and gaps alternate, equal neighbours merge; a read that needs more leaves)
+constexpr int kSimpleDp = 16;                   // a gap of up to kSimpleDp x kSimpleDp bases — between two seeds or at a read end — is a DP problem the path takes on itself
+constexpr int kSimpleJobs = 4;                  // such problems per pair
 
-// the lane's words for such a problem: the query (two words) and one traceback word per row — no strip edges, one strip
-static inline MCX_HD LaneLayout simple_dp_layout() { LaneLayout l; l.off_q = 0; l.off_edge = 0; l.off_dir = 2; l.rows = kSimpleDp; l.words = 2 + kSimpleDp; return l; }
-
+// The path meets its DP problems in three passes, so that the problems are solved one per lane by lanes that all have one
+// (a lane that aligned its own gap would hold up the 63 beside it that have none):
+//   collect  k_simple       a gap that ProcessNormalPair hands to the gapped extension (ReadAlignment.cpp:184-187) is written down as a
+//                           SimpleJob and the pass goes on — everything that does not hang on the alignment is still decided here;
+//   solve    k_simple_dp    one problem per lane (mcx_dp_lane.h, one strip of 16 columns): the column string and its counts;
+//   replay   k_simple_rest  the same pass over the pairs that wrote problems down, taking the results in the order they were met.
+struct SimpleJob { uint32_t read; uint16_t rp; uint8_t rl, gl; int64_t gp; };   // read: pair * 2 + mate
 // what the walk of such a problem leaves: the column string (2 bits a column, the LAST column in the low bits) and the counts the
 // gates and scores read (frag_columns: 'M' columns, mismatches among them, runs)
 struct SimpleCols {
-    uint32_t w = 0; int len = 0, n = 0, mis = 0, switches = 0, cur = -1;
+    uint64_t w = 0; int len = 0, n = 0, mis = 0, switches = 0, cur = -1;
     MCX_HD bool wants_bases() const { return true; }
-    MCX_HD void col(int kind, int differ) { w |= (uint32_t)kind << (2 * len); len++; if (kind == 0) { n++; mis += differ; } if (kind != cur) { cur = kind; switches++; } }
+    MCX_HD void col(int kind, int differ) { w |= (uint64_t)kind << (2 * len); len++; if (kind == 0) { n++; mis += differ; } if (kind != cur) { cur = kind; switches++; } }
 };
+struct SimpleRes { uint64_t w; uint8_t len, n, mis, switches; uint8_t pad[4]; };
+enum : int { kDpNone = 0, kDpCollect = 1, kDpReplay = 2 };
+struct SimpleDpIo {
+    int mode;               // kDpNone: a DP gap makes the read leave
+    SimpleJob *jobs;        // collect: the pair's kSimpleJobs descriptors, problem k at jobs[k * job_stride]
+    int job_stride;
+    const SimpleRes *res;   // replay: their results
+    int n;                  // problems met so far in the pair
+    uint32_t read;          // pair * 2 + mate of the read at hand
+};
+
+// the lane's words for such a problem: the query (codes, N flags) and the traceback words of one strip of 16 columns
+template <bool NW> static inline MCX_HD LaneLayout simple_dp_layout()
+{
+    LaneLayout l; l.off_q = 0; l.off_edge = 0; l.off_dir = 2; l.rows = kSimpleDp; l.words = 2 + kSimpleDp * LaneDir<16, NW>::words; return l;
+}
+
+// solve: one problem by its lane (codes: the 2-bit words of the job's read; mem: simple_dp_layout().words words)
+template <bool NW>
+static inline MCX_HD SimpleRes simple_dp_job(const IndexView &ix, const SimpleJob &j, const uint32_t *codes, const LaneMem &mem)
+{
+    const bool rev = j.gp >= ix.G;
+    const LaneLayout l = simple_dp_layout<NW>();
+    const int rl_ = j.rl, gl_ = j.gl;
+    mem.put(l.off_q, lane_query16(codes, j.rp, rl_, rev, 0));
+    mem.put(l.off_q + 1, 0u);
+    auto tgt16 = [&](int b0) -> uint32_t { return lane_target16(ix, j.gp, gl_, rev, b0); };
+    SimpleCols sc;
+    if (NW) { (void)lane_sweep_nw<16>(mem, l, rl_, gl_, tgt16); lane_walk_nw<16>(mem, l, rl_, gl_, tgt16, sc); }
+    else { lane_sweep_ksw2<16>(mem, l, rl_, gl_, tgt16); lane_walk_ksw2<16>(mem, l, rl_, gl_, tgt16, sc); }
+    SimpleRes r; r.w = sc.w; r.len = (uint8_t)sc.len; r.n = (uint8_t)sc.n; r.mis = (uint8_t)sc.mis; r.switches = (uint8_t)sc.switches;
+    r.pad[0] = r.pad[1] = r.pad[2] = r.pad[3] = 0;
+    return r;
+}
 
 struct SimpleRead {
     int64_t pd0;        // PosDiff of the candidate: of its first seed in (PosDiff, rPos) order
@@ -53,12 +95,13 @@ struct SimpleRead {
     int32_t n_cig;      // CIGAR operations, in alignment order at cig[0 .. n_cig)
 };
 
-// One read: true when it is straight-line; then `out` and cig[k * cig_stride] (k < out.n_cig) are filled.
+// One read.  kSimpleYes: it is straight-line; `out` and cig[k * cig_stride] (k < out.n_cig) are filled.  kSimpleLater (collect only): it
+// is, but for DP problems now written down (out.pd0 is set: the pairing test does not wait).  kSimpleNo: the general path.
 // hits: the read's seeds as k_seed left them (text positions), n of them (1..kSimpleHits); codes: its 2-bit words (no N).
-// dpm: simple_dp_layout().words words of this lane for the small gapped extensions (null: a gap that needs one makes the read leave).
+enum : int { kSimpleNo = 0, kSimpleYes = 1, kSimpleLater = 2 };
 template <bool NW>
-static inline MCX_HD bool simple_read(const IndexView &ix, const Params &pm, int rlen, const uint32_t *codes, const Hit *hits, int n,
-                                      SimpleRead &out, uint32_t *cig, int cig_stride, const LaneMem *dpm)
+static inline MCX_HD int simple_read(const IndexView &ix, const Params &pm, int rlen, const uint32_t *codes, const Hit *hits, int n,
+                                     SimpleRead &out, uint32_t *cig, int cig_stride, SimpleDpIo &io)
 {
     if (n < 1 || n > kSimpleHits || !codes) MCX_SIMPLE_FAIL(1);
     // ---- the seeds with PosDiff > 0 (IdentifySimplePairs' tail); the straight-line case needs all of them to stay
@@ -126,32 +169,63 @@ static inline MCX_HD bool simple_read(const IndexView &ix, const Params &pm, int
         }
         run_len += l;
     };
-    // a gap between two seeds that ProcessNormalPair hands to the gapped extension (ReadAlignment.cpp:184-187), small enough for the
-    // lane: the product's own sweep and walk (mcx_dp_lane.h, strips of 8 columns), both strings reversed on the reverse strand as the
-    // DP kernels take them; then the middle fragment's gate (:373-381), its matches, and its columns as CIGAR runs in read order
-    auto dp_gap = [&](int rp, int64_t gp, int rl_, int gl_) -> bool {
-        if (!dpm || rl_ > kSimpleDp || gl_ > kSimpleDp) MCX_SIMPLE_FAIL(18);
+    // A gap that ProcessNormalPair hands to the gapped extension (ReadAlignment.cpp:184-187), small enough for the path: written down
+    // (collect) or its result taken (replay) — the product's own sweep and walk (mcx_dp_lane.h), both strings reversed on the reverse strand
+    // as the DP kernels take them.  place 0: between two seeds — the middle fragment's gate (:373-381), its matches, its columns as CIGAR
+    // runs in read order.  place 1 / 2: the read's first / last fragment — RemoveHeadingGaps / RemoveTailingGaps (:264-304) take the gap
+    // columns off its outer end (the read bases among them end up soft-clipped, the genome bases move the fragment's start or end), then
+    // the end's gate (:343-372: a long enough bad end is dropped), its matches, its columns.
+    bool later = false, end_dropped = false;
+    int64_t head_shift = 0, tail_shift = 0; // genome bases taken off the first fragment's start / the last one's end
+    auto dp_gap = [&](int rp, int64_t gp, int rl_, int gl_, int place) -> bool {
+        if (io.mode == kDpNone || rl_ > kSimpleDp || gl_ > kSimpleDp) { if (rl_ == gl_) MCX_SIMPLE_NOTE(2, rl_); MCX_SIMPLE_FAIL(18); }
+        if (io.n >= kSimpleJobs) MCX_SIMPLE_FAIL(18);
+        if (io.mode == kDpCollect) {
+            SimpleJob j; j.read = io.read; j.rp = (uint16_t)rp; j.rl = (uint8_t)rl_; j.gl = (uint8_t)gl_; j.gp = gp;
+            io.jobs[(io.n++) * io.job_stride] = j;
+            later = true;
+            return true;
+        }
+        const SimpleRes sc = io.res[io.n++];
         const bool rev = gp >= ix.G;
-        const LaneLayout l = simple_dp_layout();
-        dpm->put(l.off_q, lane_query16(codes, rp, rl_, rev, 0));
-        dpm->put(l.off_q + 1, 0u);
-        auto tgt16 = [&](int b0) -> uint32_t { return lane_target16(ix, gp, gl_, rev, b0); };
-        SimpleCols sc;
-        if (NW) { (void)lane_sweep_nw<kSimpleDp>(*dpm, l, rl_, gl_, tgt16); lane_walk_nw<kSimpleDp>(*dpm, l, rl_, gl_, tgt16, sc); }
-        else { lane_sweep_ksw2<kSimpleDp>(*dpm, l, rl_, gl_, tgt16); lane_walk_ksw2<kSimpleDp>(*dpm, l, rl_, gl_, tgt16, sc); }
-        if (rl_ >= kMinAlnBlockSize && gl_ >= kMinAlnBlockSize && (sc.switches >= 4 || (sc.mis >= 3 && sc.mis >= (int)(sc.n * 0.3)))) MCX_SIMPLE_FAIL(19); // the candidate would die
+        int a = 0, b = sc.len, sw = sc.switches, clip = 0; // the string's columns [a, b) stay
+        if (place) {
+            const bool lead = (place == 1) != rev; // the read's outer end is the string's start (head, forward; tail, reverse) or its end
+            int rs = 0, gs = 0, runs = 0, cur = 0;
+            for (int j = 0; j < sc.len; j++) {
+                const int k = (int)((sc.w >> (2 * (lead ? sc.len - 1 - j : j))) & 3u);
+                if (k == 0) break;
+                if (k != cur) { cur = k; runs++; }
+                if (k == 1) rs++; else gs++;
+                if (lead) a++; else b--;
+            }
+            if (a >= b) MCX_SIMPLE_FAIL(19); // nothing but gap columns
+            sw -= runs; clip = rs;
+            if (b - a >= kMinAlnBlockSize && (sw >= 4 || (sc.mis >= 3 && sc.mis >= (int)(sc.n * 0.3)))) {
+                // the end is dropped (:349-356, :364-371): an empty fragment where the neighbouring seed begins / ends, its bases soft-clipped;
+                // both ends dropped: the candidate dies
+                if (end_dropped) MCX_SIMPLE_FAIL(19);
+                end_dropped = true;
+                if (place == 1) head_shift = gl_; else tail_shift = gl_;
+                add(rl_, 4);
+                return true;
+            }
+            if (place == 1) head_shift = gs; else tail_shift = gs;
+        } else if (rl_ >= kMinAlnBlockSize && gl_ >= kMinAlnBlockSize && (sw >= 4 || (sc.mis >= 3 && sc.mis >= (int)(sc.n * 0.3)))) MCX_SIMPLE_FAIL(19); // the candidate would die
         score += sc.n - sc.mis; mism += sc.mis;
-        // the string's columns: first column at bits 2 (len - 1); on the reverse strand the string runs against the read
-        for (int j = 0; j < sc.len; j++) add(1, (int)((sc.w >> (2 * (rev ? j : sc.len - 1 - j))) & 3u));
+        // column j of the string at bits 2 (len - 1 - j); on the reverse strand the string runs against the read
+        if (place == 1 && clip > 0) add(clip, 4);
+        for (int j = a; j < b; j++) add(1, (int)((sc.w >> (2 * (rev ? j - a + (sc.len - b) : sc.len - 1 - j))) & 3u));
+        if (place == 2 && clip > 0) add(clip, 4);
         return true;
     };
     // a gap fragment of equal lengths: mismatches, the DP decision (ReadAlignment.cpp:184), the gate of its place
     // (head / tail: dropped when it is long enough and bad, :343-372; in between: the whole candidate dies, :373-381)
-    auto plain_gap = [&](int rp, int64_t gp, int l, bool middle) -> bool {
+    auto plain_gap = [&](int rp, int64_t gp, int l, int place) -> bool {
         Frag x; x.rPos = rp; x.gPos = gp; x.rLen = l; x.gLen = l; x.ops_off = 0; x.ops_len = 0; x.kind = kPlain; x.meta = 0;
         ReadRef rd; rd.ascii = nullptr; rd.rlen = rlen; rd.flipped = 0; rd.codes = codes;
         const int mm = frag_mismatches(ix, x, rd);
-        if (mm > 1 && mm >= (int)(l * 0.2)) { if (middle) return dp_gap(rp, gp, l, l); MCX_SIMPLE_FAIL(7); } // a DP problem (at a read end its string may be trimmed: the general path)
+        if (mm > 1 && mm >= (int)(l * 0.2)) { if (place) MCX_SIMPLE_NOTE(0, l); return dp_gap(rp, gp, l, l, place); } // a DP problem
         if (l >= kMinAlnBlockSize && mm >= 3 && mm >= (int)(l * 0.3)) MCX_SIMPLE_FAIL(8); // (one kind of column: switches = 1) the quality gate would fire
         score += l - mm; mism += mm;
         add(l, 0);
@@ -168,14 +242,14 @@ static inline MCX_HD bool simple_read(const IndexView &ix, const Params &pm, int
         const int64_t g0 = g[i];
         if (i == 0) {
             g_head = g0 - r0;
-            if (r0 > 0 && !plain_gap(0, g0 - r0, r0, false)) MCX_SIMPLE_FAIL(9);
+            if (r0 > 0 && !plain_gap(0, g0 - r0, r0, 1)) MCX_SIMPLE_FAIL(9);
         } else {
             const int rg = r0 - pr;
             const int64_t gg = g0 - pg;
             if (r0 <= prev_r || g0 <= prev_g || rg < 0 || gg < 0) MCX_SIMPLE_FAIL(10); // not in order / overlapping: the general path sorts and trims
             if (rg > 0 && gg > 0) {
-                if ((int64_t)rg != gg) { if (gg > kSimpleDp || !dp_gap(pr, pg, rg, (int)gg)) MCX_SIMPLE_FAIL(11); } // a DP problem
-                else if (!plain_gap(pr, pg, rg, true)) MCX_SIMPLE_FAIL(12);
+                if ((int64_t)rg != gg) { if (gg > kSimpleDp || !dp_gap(pr, pg, rg, (int)gg, 0)) { MCX_SIMPLE_NOTE(1, (int)(gg > rg ? gg : rg)); MCX_SIMPLE_FAIL(11); } } // a DP problem
+                else if (!plain_gap(pr, pg, rg, 0)) MCX_SIMPLE_FAIL(12);
             } else if (rg > 0) add(rg, 1);                                       // read bases against '-'
             else if (gg > 0) { if (gg >= 4096) MCX_SIMPLE_FAIL(13); add((int)gg, 2); } // '-' against genome bases (Frag::gLen is 12 bits)
         }
@@ -183,7 +257,7 @@ static inline MCX_HD bool simple_read(const IndexView &ix, const Params &pm, int
         add(len[i], 0);
         prev_r = r0; prev_g = g0; pr = r0 + len[i]; pg = g0 + len[i];
     }
-    if (pr < rlen) { if (!plain_gap(pr, pg, rlen - pr, false)) MCX_SIMPLE_FAIL(14); pg += rlen - pr; }
+    if (pr < rlen) { if (!plain_gap(pr, pg, rlen - pr, 2)) MCX_SIMPLE_FAIL(14); pg += rlen - pr; }
     g_tail = pg;
     // CheckAlignmentValidity (tools.cpp:119-130): inside [0, 2G) and on one chromosome
     if (g_head < 0 || g_tail > ix.G2) MCX_SIMPLE_FAIL(15);
@@ -191,6 +265,7 @@ static inline MCX_HD bool simple_read(const IndexView &ix, const Params &pm, int
         const int e1 = end_slot(ix, g_head), e2 = end_slot(ix, g_tail - 1);
         if (e1 < 0 || e2 < 0 || ix.end_pos[e1] != ix.end_pos[e2]) MCX_SIMPLE_FAIL(16);
     }
+    if (later) return kSimpleLater; // (scores, runs and the ends' shifts hang on the alignments)
     if (score == 0 || (score < min_score && mism > max_mm)) MCX_SIMPLE_FAIL(17);          // the candidate would be dropped (:392-396)
     // close the last run; the operations in alignment order (a reverse-strand candidate's fragments are read backwards, :412-416)
     {
@@ -200,21 +275,22 @@ static inline MCX_HD bool simple_read(const IndexView &ix, const Params &pm, int
         n_run++;
     }
     if (n_run > kSimpleRuns) MCX_SIMPLE_FAIL(20); // more operations than the path keeps
-    const int fwd = g_head < ix.G ? 1 : 0;
+    const int fwd = g_head + head_shift < ix.G ? 1 : 0;
     MCX_UNROLL
     for (int k = 0; k < kSimpleRuns; k++) if (k < n_run) cig[(fwd ? k : n_run - 1 - k) * cig_stride] = runs[k];
     out.score = score; out.fwd = fwd; out.n_cig = n_run;
-    // first fragment in alignment order: forward = the head (gap or seed) at g_head; reverse = the tail, which ends at g_tail.
-    // GetAlnCoordinate takes gPos (forward) or gPos + gLen - 1 (reverse) of it; GenCoordinatePair its gPos.
-    if (fwd) { out.g_first = g_head; out.g_coord = g_head; }
+    // first fragment in alignment order: forward = the head (gap or seed) at g_head, behind the genome bases its outer end lost; reverse =
+    // the tail, which ends at g_tail less what its outer end lost.  GetAlnCoordinate takes gPos (forward) or gPos + gLen - 1 (reverse)
+    // of it; GenCoordinatePair its gPos.
+    if (fwd) { out.g_first = g_head + head_shift; out.g_coord = g_head + head_shift; }
     else {
         // the last fragment in read order: the tail gap if the last seed ends before the read does, else the last seed
         int64_t last_g = 0;
         MCX_UNROLL
         for (int i = 0; i < kSimpleHits; i++) if (i == n - 1) last_g = (r[i] + len[i] < rlen) ? g[i] + len[i] : g[i];
-        out.g_first = last_g; out.g_coord = g_tail - 1;
+        out.g_first = last_g; out.g_coord = g_tail - tail_shift - 1;
     }
-    return true;
+    return kSimpleYes;
 }
 
 // CheckPairedAlignmentDistance with one candidate each: read 2's PosDiff not before read 1's and closer than the estimate

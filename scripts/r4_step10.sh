@@ -1,15 +1,9 @@
 #!/bin/bash
+# the straight-line path with its DP problems solved one per lane (collect / solve / replay): parity, then the step
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; ulimit -c 0
-timeout 3000 python -m pytest tests -m gpu -q -x --timeout 2400 -p no:cacheprovider 2>&1 | tail -8 > gpurun_out/r4_pytest_bw.log; tail -4 gpurun_out/r4_pytest_bw.log
-timeout 900 python scripts/ab_env.py --steps 3 "" "MCX_BUILD_BY_LANE=1" "" > gpurun_out/r4_ab8_cfg3.txt 2>/dev/null; cat gpurun_out/r4_ab8_cfg3.txt
-timeout 900 python scripts/ab_env.py --steps 2 --rlen 250 --ins 0.025 --dele 0.025 --alg nw "" "MCX_BUILD_BY_LANE=1" > gpurun_out/r4_ab8_cfg5.txt 2>/dev/null; cat gpurun_out/r4_ab8_cfg5.txt
-SECONDS=0; python bench.py > gpurun_out/r4_bench_try.json 2> gpurun_out/r4_bench_try.err; echo "bench: $SECONDS s"
-python - <<'P'
-import json
-o=json.loads(open('gpurun_out/r4_bench_try.json').read().strip().splitlines()[-1])
-print(o['value'], o['ms_per_step'], o['stage_ms_per_step'])
-print('pcie', o['value_pcie_inclusive'].get('value'), 'f2f', json.dumps(o['value_file_to_file'])[:300])
-print('cpu', json.dumps(o['cpu_baseline'])[:700])
-print('vcf', json.dumps(o['vcf_reduce'])[:200])
-print('other', o['other_genome'].get('value'), [ (c.get('value'), c.get('ms_per_step'), json.dumps(c.get('cpu_baseline'))[:300]) for c in o['other_configs']])
-P
+timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 1400 -p no:cacheprovider -x -k "large_batch_paths or large_batch_machinery or keeps_its_shape or full_size or config2 or fresh_seeded" 2>&1 | tail -15 > gpurun_out/r4_pytest_simple2.log
+tail -8 gpurun_out/r4_pytest_simple2.log
+MCX_TIMING=1 timeout 900 python scripts/ab_env.py --steps 4 --rounds 2 "" "MCX_SIMPLE_NO_DP=1" > gpurun_out/r4_ab8.txt 2> gpurun_out/r4_ab8.err
+cat gpurun_out/r4_ab8.txt; grep "run_pairs\] pairs 4000000" gpurun_out/r4_ab8.err | head -2
+timeout 600 python scripts/ab_env.py --steps 4 "MCX_SEED_FM_BUDGET=3" "MCX_SEED_FM_BUDGET=4" "MCX_SEED_FM_BUDGET=8" "MCX_SEED_FM_BUDGET=12" > gpurun_out/r4_ab8_budget.txt 2> gpurun_out/r4_ab8_budget.err
+cut -c1-330 gpurun_out/r4_ab8_budget.txt

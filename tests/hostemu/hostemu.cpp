@@ -17,6 +17,8 @@
 #include "../../mapcaller_amd/csrc/mcx_dp_lane.h"
 static long g_simple_why[32]; // which exit of simple_read reads took (MCX_EMU_SIMPLE_WHY=1 prints the tally)
 #define MCX_SIMPLE_FAIL(code) do { g_simple_why[code]++; return false; } while (0)
+static long g_simple_len[3][40]; // lengths at the exits that a larger in-lane DP would take: [0] end gaps (exit 7), [1] genome side of unequal gaps (11), [2] equal gaps (18)
+#define MCX_SIMPLE_NOTE(k, l) (g_simple_len[k][(l) < 39 ? (l) : 39]++)
 #include "../../mapcaller_amd/csrc/mcx_simple.h"
 #include "../../mapcaller_amd/csrc/mcx_host.h"
 #include "simple_io.h"
@@ -147,37 +149,56 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
     // MCX_EMU_NO_SIMPLE=1: every pair takes the general path (the A/B of the tests).
     std::vector<uint8_t> done(n, 0);
     if (tier == 0 && !getenv("MCX_EMU_NO_SIMPLE")) {
-        for (uint32_t l = 0; l < n; l++) {
+        // collect (k_simple) -> solve (k_simple_dp) -> replay (k_simple_rest); MCX_EMU_SIMPLE_NO_DP: a pair with a DP problem takes the general path
+        const bool with_dp = !getenv("MCX_EMU_SIMPLE_NO_DP");
+        std::vector<uint32_t> later;                 // the pairs that wait
+        std::vector<SimpleJob> jobs;                 // kSimpleJobs places per waiting pair
+        std::vector<SimpleRes> res;
+        std::vector<std::vector<uint32_t>> packed((size_t)n * 2);
+        auto pass = [&](uint32_t l, int mode, size_t slot) {
             PairState st = pair_state(cx.state, cx.lay, cx.caps, l);
             SimpleRead sr[2];
             uint32_t cg[2][kSimpleRuns];
             int rl[2] = {0, 0};
-            bool ok = true;
-            std::vector<uint32_t> pkbuf[2];
+            bool ok = true, wait = false;
+            SimpleJob mine[kSimpleJobs];
+            SimpleDpIo io; io.mode = mode; io.jobs = mine; io.job_stride = 1; io.res = mode == kDpReplay ? res.data() + slot * kSimpleJobs : nullptr; io.n = 0; io.read = 0;
             for (int s = 0; s < nr && ok; s++) {
                 const uint32_t r = ids[l] * nr + s;
                 ReadRef one;
                 one.ascii = b.bases.data() + b.off[r]; one.rlen = (int)(b.off[r + 1] - b.off[r]); one.flipped = (b.paired && s == 1) ? 1 : 0;
                 rl[s] = one.rlen;
-                pkbuf[s].assign(packed_words(one.rlen) + 4, 0u);
+                std::vector<uint32_t> &pk = packed[(size_t)l * 2 + s];
                 bool has_n = false;
-                for (int i = 0; i < one.rlen; i++) { const int c = read_code(one, i); if (c > 3) has_n = true; else pkbuf[s][i >> 4] |= (uint32_t)c << (30 - 2 * (i & 15)); }
+                if (pk.empty()) {
+                    pk.assign(packed_words(one.rlen) + 4, 0u);
+                    for (int i = 0; i < one.rlen; i++) { const int c = read_code(one, i); if (c > 3) has_n = true; else pk[i >> 4] |= (uint32_t)c << (30 - 2 * (i & 15)); }
+                    if (has_n) pk.assign(1, 0xFFFFFFFFu);
+                } else has_n = pk.size() == 1;
                 const int nh = st.hdr->n_hits[s];
-                if (has_n) g_simple_why[20]++; else if (nh < 1) g_simple_why[21]++; else if (nh > kSimpleHits) g_simple_why[22]++;
-                uint32_t dp_words[2 + kSimpleDp];
-                LaneMem dpm; dpm.base = dp_words; dpm.stride = 1;
-                const LaneMem *dp = getenv("MCX_EMU_SIMPLE_NO_DP") ? nullptr : &dpm;
-                ok = !has_n && nh >= 1 && nh <= kSimpleHits &&
-                     (cx.pm.use_nw ? simple_read<true>(cx.ix, cx.pm, one.rlen, pkbuf[s].data(), st.hits[s], nh, sr[s], cg[s], 1, dp)
-                                   : simple_read<false>(cx.ix, cx.pm, one.rlen, pkbuf[s].data(), st.hits[s], nh, sr[s], cg[s], 1, dp));
+                if (mode != kDpReplay) { if (has_n) g_simple_why[20]++; else if (nh < 1) g_simple_why[21]++; else if (nh > kSimpleHits) g_simple_why[22]++; }
+                io.read = (uint32_t)(l * 2 + s); // (here: the place of the read's words in `packed`)
+                ok = !has_n && nh >= 1 && nh <= kSimpleHits;
+                if (ok) {
+                    const int how = cx.pm.use_nw ? simple_read<true>(cx.ix, cx.pm, one.rlen, pk.data(), st.hits[s], nh, sr[s], cg[s], 1, io)
+                                                 : simple_read<false>(cx.ix, cx.pm, one.rlen, pk.data(), st.hits[s], nh, sr[s], cg[s], 1, io);
+                    ok = how != kSimpleNo;
+                    wait = wait || how == kSimpleLater;
+                }
             }
-            if (!ok) continue;
+            if (!ok) return;
+            if (nr == 2 && !simple_pair_ok(sr[0], sr[1], est[l])) { g_simple_why[23]++; return; }
+            if (wait) {
+                later.push_back(l);
+                for (int k = 0; k < kSimpleJobs; k++) { jobs.push_back(k < io.n ? mine[k] : SimpleJob{0, 0, 0, 0, 0}); }
+                return;
+            }
             const uint32_t want = (uint32_t)sr[0].n_cig + (nr == 2 ? (uint32_t)sr[1].n_cig : 0u);
-            if (e.cig_used + want > cx.cig_pool_cap) continue;
+            if (e.cig_used + want > cx.cig_pool_cap) return;
             const uint32_t off[2] = {e.cig_used, e.cig_used + (uint32_t)sr[0].n_cig};
             AlnRec rec2[2];
             PairOut po;
-            if (!simple_pair(cx, nr == 2, sr[0], sr[nr - 1], rl[0], rl[nr - 1], est[l], rec2, off, po)) { g_simple_why[23]++; continue; }
+            if (!simple_pair(cx, nr == 2, sr[0], sr[nr - 1], rl[0], rl[nr - 1], est[l], rec2, off, po)) { g_simple_why[23]++; return; }
             for (int s = 0; s < nr; s++) {
                 for (int k = 0; k < sr[s].n_cig; k++) cig[off[s] + k] = cg[s][k];
                 recs[(size_t)ids[l] * nr + s] = rec2[s];
@@ -186,12 +207,25 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
             pout[ids[l]] = po;
             done[l] = 1;
             if (stats) stats[11]++;
+        };
+        for (uint32_t l = 0; l < n; l++) pass(l, with_dp ? kDpCollect : kDpNone, 0);
+        res.resize(jobs.size());
+        for (size_t k = 0; k < jobs.size(); k++) {
+            const SimpleJob &j = jobs[k];
+            if (j.rl == 0) continue;
+            uint32_t words[2 + 2 * kSimpleDp];
+            LaneMem mem; mem.base = words; mem.stride = 1;
+            res[k] = cx.pm.use_nw ? simple_dp_job<true>(cx.ix, j, packed[j.read].data(), mem) : simple_dp_job<false>(cx.ix, j, packed[j.read].data(), mem);
         }
+        const std::vector<uint32_t> waiting = later;
+        for (size_t i = 0; i < waiting.size(); i++) pass(waiting[i], kDpReplay, i);
+        if (stats && getenv("MCX_EMU_SIMPLE_WHY")) fprintf(stderr, "[simple] %zu pairs waited for %zu problems\n", waiting.size(), (size_t)std::count_if(jobs.begin(), jobs.end(), [](const SimpleJob &j) { return j.rl != 0; }));
     }
     if (getenv("MCX_EMU_SIMPLE_WHY") && tier == 0 && n > 100) {
         fprintf(stderr, "[simple] %u pairs; reads leaving simple_read by exit:", n);
         for (int k = 1; k < 24; k++) if (g_simple_why[k]) fprintf(stderr, " %d:%ld", k, g_simple_why[k]);
         fprintf(stderr, " (20 N, 21 no seed, 22 more than %d seeds, 23 not paired within the estimate)\n", kSimpleHits);
+        for (int k = 0; k < 3; k++) { fprintf(stderr, "[simple] lengths at exit %s:", k == 0 ? "7" : k == 1 ? "11" : "18"); for (int l = 0; l < 40; l++) if (g_simple_len[k][l]) fprintf(stderr, " %d:%ld", l, g_simple_len[k][l]); fprintf(stderr, "\n"); }
     }
     // k_cluster, k_rescue, k_build
     for (uint32_t l = 0; l < n; l++) {
