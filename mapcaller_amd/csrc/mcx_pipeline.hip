@@ -2197,7 +2197,7 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
         if ((rc = dmalloc(&c->d_jobs[k], c->job_cap[k]))) return rc;
     }
     if ((rc = dmalloc(&c->d_cnt, CNT_ALL))) return rc;
-    HIP_TRY(hipHostMalloc((void **)&c->h_cnt, CNT_N * sizeof(uint32_t)));
+    HIP_TRY(hipHostMalloc((void **)&c->h_cnt, (CNT_N + 8) * sizeof(uint32_t))); // (+8: the seeding statistics of a batch, on their way to batch_close)
     c->rescue_cap = (uint32_t)c->max_reads;
     if ((rc = dmalloc(&c->d_rescue, c->rescue_cap))) return rc;
     if ((rc = rescue_alloc(c, c->max_reads, false, &c->d_rtasks, &c->d_rres, &c->d_rseeds, &c->d_rplans, &c->d_rescue_n, &c->rtask_cap, &c->rseed_cap))) return rc;
@@ -2362,7 +2362,9 @@ static int launch_dp(const PassRes &R, const Ctx &cx, const JobSinks &sinks, con
         const bool nw = cx.pm.use_nw != 0;
         uint32_t *unsup = sinks.unsupported;
         const bool always = getenv("MCX_DP_LANE_ALWAYS") != nullptr;
-        const uint32_t lane_min[2] = {always ? 0u : kDpLaneMin[0], always ? 0u : kDpLaneMin[1]};
+        uint32_t lane_min[2] = {always ? 0u : kDpLaneMin[0], always ? 0u : kDpLaneMin[1]};
+        if (const char *e = getenv("MCX_DP_LANE_MIN0")) lane_min[0] = (uint32_t)atoll(e); // (experiments)
+        if (const char *e = getenv("MCX_DP_LANE_MIN1")) lane_min[1] = (uint32_t)atoll(e);
         const uint64_t w1 = lane_stride_words<16>(nw, rlen_max, 4), w2 = lane_stride_words<16>(nw, rlen_max, 16);
         const unsigned b1 = (unsigned)std::min<uint64_t>(4096, R.dp_stride[0] * R.dp_blocks[0] / (w1 * 4)), b2 = (unsigned)std::min<uint64_t>(4096, R.dp_stride[1] * R.dp_blocks[1] / (w2 * 4));
         if (b1 == 0 || b2 == 0) return fail(MCX_ERR_CAPACITY, "the DP scratch is too small for one group of problems");
@@ -2961,8 +2963,7 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
         unsigned long long *d_sum = (unsigned long long *)c->d_cnt;
         HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
         k_reduce_stats<<<256, 256, 0, s>>>(c->d_read_ext, c->d_read_blocks, n_reads, d_sum);
-        HIP_TRY(hipMemcpyAsync(br.hs, d_sum, sizeof br.hs, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpyAsync(c->h_cnt + CNT_N, d_sum, sizeof br.hs, hipMemcpyDeviceToHost, s)); // (read by batch_close, behind the sums' synchronisation: no round trip of its own)
     }
     br.open = true;
     return 0;
@@ -3053,6 +3054,7 @@ static int batch_close(mcx_ctx *c, mcx_stats *stats)
         int64_t pairs = 0, dist_sum = 0, len_sum = 0;
         if (br.paired) for (uint32_t k = 0; k < br.n_chunks; k++) { pairs += br.ok[k]; dist_sum += br.ds[k]; len_sum += br.ds[br.n_chunks + k]; }
         stats->reads += br.rb.n_reads; stats->mapped += br.mapped; stats->pairs += pairs; stats->pair_dist_sum += dist_sum; stats->pair_len_sum += len_sum;
+        memcpy(br.hs, c->h_cnt + CNT_N, sizeof br.hs);
         stats->fm_ext_steps += (int64_t)br.hs[0]; stats->fm_blocks += (int64_t)br.hs[1]; stats->sa_hits += (int64_t)br.hs[2];
         float ms_pack = 0;
         if (hipEventElapsedTime(&ms_pack, c->ev_pack[0], c->ev_pack[1]) == hipSuccess) stats->ms_encode += ms_pack; // k_pack_reads

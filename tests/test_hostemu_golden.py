@@ -100,6 +100,28 @@ def test_pair_records_equal_two_single_steps(hostemu_lib, golden, name):
     assert hostemu_lib.hostemu_pair_check(golden[name]["prefix"].encode(), 400000) == 0
 
 
+@pytest.mark.parametrize("alg", ["nw", "ksw2"])
+@pytest.mark.parametrize("name", ["var", "long", "toy"])
+def test_straight_line_pairs_with_their_own_dp_problems(hostemu_lib, golden, tmp_path, monkeypatch, name, alg):
+    """mcx_simple.h's three passes (collect, solve, replay): pairs whose only obstacle is a small gapped extension — between two seeds or
+    at a read end, where the outer gap columns are stripped, soft-clipped or the whole end dropped — take the straight-line path; the
+    SAM is the reference's with them, without the DP problems (MCX_EMU_SIMPLE_NO_DP) and with every pair on the general path."""
+    out = str(tmp_path / "e.sam")
+    n, st = _run(hostemu_lib, golden[name], alg, out)
+    nd, ex = sam_diff(golden[name]["sam"][alg], out)
+    assert nd == 0, ex
+    monkeypatch.setenv("MCX_EMU_SIMPLE_NO_DP", "1")
+    _, st_no_dp = _run(hostemu_lib, golden[name], alg, out)
+    nd, ex = sam_diff(golden[name]["sam"][alg], out)
+    assert nd == 0, ex
+    monkeypatch.setenv("MCX_EMU_NO_SIMPLE", "1")
+    _, st_general = _run(hostemu_lib, golden[name], alg, out)
+    nd, ex = sam_diff(golden[name]["sam"][alg], out)
+    assert nd == 0, ex
+    assert st[11] > st_no_dp[11] > 0 and st_general[11] == 0, (st[11], st_no_dp[11], st_general[11])  # pairs the path took
+    assert st[6] < st_no_dp[6] <= st_general[6]                                                        # DP problems left to the general path
+
+
 def test_small_batches_follow_the_avgdist_trajectory(hostemu_lib, golden, tmp_path):
     # 600-read batches: the insert-size estimate crosses batch boundaries
     out = str(tmp_path / "e.sam")
