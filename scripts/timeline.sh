@@ -7,7 +7,7 @@ for kv in "$@"; do export "$kv"; done
 timeout 900 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/timeline${TAG:+_$TAG}/kt -o kt -- python3 bench.py --steps 2 --warmup 1 --cpu-pairs 0 --vcf-reduce 0 --pcie-steps 0 --second-genome 0 --other-configs 0 --file-steps 0 $BENCH_ARGS > gpurun_out/timeline${TAG:+_$TAG}/kt.log 2>&1 < /dev/null
 f=$(find gpurun_out/timeline${TAG:+_$TAG}/kt -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'P'
-import csv, sys
+import csv, sys, os
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 big = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_seed") and int(r.get("Grid_Size_X", r.get("Grid_Size", 0))) >= 4096 * 64]
@@ -19,7 +19,7 @@ with open(tdir + "/timeline.txt", "w") as out:
     for r in rows[max(0, i0 - 2):]:
         s = (int(r["Start_Timestamp"]) - t0) / 1e6
         e = (int(r["End_Timestamp"]) - t0) / 1e6
-        if e - s < 0.05:
+        if e - s < float(os.environ.get("MIN_MS", "0.05")):
             continue
         out.write("%8.2f %8.2f %7.2f q%s %s grid %s\n" % (s, e, e - s, r.get("Queue_Id", "?"), r["Kernel_Name"][:50], r.get("Grid_Size_X", r.get("Grid_Size", "?"))))
 print(open(tdir + "/timeline.txt").read()[:9000])
