@@ -778,12 +778,12 @@ __global__ void __launch_bounds__(256) k_simple(Ctx cx, ReadBatch rb, uint32_t n
                                                 uint8_t *done, uint32_t *pool_over, uint32_t *n_done, SimpleLater sl)
 {
     __shared__ EndsLds ends;
-    __shared__ uint32_t cig_stage[256 * 2 * kSimpleRuns]; // word k of thread t at [k * 256 + t]
-    __shared__ SimpleJob job_stage[MODE == kDpCollect ? kSimpleJobs * 256 : 1]; // problem k of thread t at [k * 256 + t]
+    __shared__ uint16_t cig_stage[256 * 2 * kSimpleRuns]; // operation k of thread t at [k * 256 + t] (16 bits: a run is at most 4095 long)
+    __shared__ uint32_t job_stage[MODE == kDpCollect ? 3 * kSimpleJobs * 256 : 1]; // word w of thread t's problem k at [(3 * k + w) * 256 + t]
     stage_ends(cx.ix, ends);
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; // collect: the pair; replay: the waiting pair
     const int nr = cx.pm.paired ? 2 : 1;
-    uint32_t *stage = cig_stage + threadIdx.x;
+    uint16_t *stage = cig_stage + threadIdx.x;
     const uint32_t n_slots = MODE == kDpReplay ? min(*sl.n_pairs, sl.cap) : n_pairs;
     bool ok = slot < n_slots;
     const uint32_t pair = MODE == kDpReplay ? (ok ? sl.pairs[slot] : 0u) : slot;
@@ -806,7 +806,7 @@ __global__ void __launch_bounds__(256) k_simple(Ctx cx, ReadBatch rb, uint32_t n
                 io.read = r;
                 ok = nh >= 1 && nh <= kSimpleHits && !(cx.read_ext[r] >> 31);
                 if (ok) {
-                    const int how = simple_read<NW>(cx.ix, cx.pm, rl[s], cx.packed + (uint64_t)r * cx.wpad, st.hits[s], nh, sr[s], stage + s * kSimpleRuns * 256, 256, io);
+                    const int how = simple_read<NW, uint16_t>(cx.ix, cx.pm, rl[s], cx.packed + (uint64_t)r * cx.wpad, st.hits[s], nh, sr[s], stage + s * kSimpleRuns * 256, 256, io);
                     ok = how != kSimpleNo;
                     later = later || how == kSimpleLater;
                 }
@@ -821,7 +821,11 @@ __global__ void __launch_bounds__(256) k_simple(Ctx cx, ReadBatch rb, uint32_t n
         const uint32_t jat = wave_reserve(sl.n_jobs, kept ? (uint32_t)io.n : 0u);
         if (kept) {
             sl.pairs[at] = pair;
-            for (int k = 0; k < io.n; k++) { sl.jobs[(uint64_t)at * kSimpleJobs + k] = job_stage[k * 256 + threadIdx.x]; sl.job_list[jat + k] = at * kSimpleJobs + (uint32_t)k; }
+            for (int k = 0; k < io.n; k++) {
+                const uint32_t *w = job_stage + (3 * k) * 256 + threadIdx.x;
+                sl.jobs[(uint64_t)at * kSimpleJobs + k] = simple_job_unpack(w[0], w[256], w[512], pair * (uint32_t)nr, nr);
+                sl.job_list[jat + k] = at * kSimpleJobs + (uint32_t)k;
+            }
             done[pair] = 2;
         }
         if (wait) ok = false; // (not kept: the general path)
@@ -839,7 +843,7 @@ __global__ void __launch_bounds__(256) k_simple(Ctx cx, ReadBatch rb, uint32_t n
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         if (s >= nr) break;
-        for (int k = 0; k < sr[s].n_cig; k++) cx.cig_pool[off[s] + k] = stage[(s * kSimpleRuns + k) * 256];
+        for (int k = 0; k < sr[s].n_cig; k++) cx.cig_pool[off[s] + k] = (uint32_t)stage[(s * kSimpleRuns + k) * 256];
     }
     AlnRec rec2[2];
     PairOut po;

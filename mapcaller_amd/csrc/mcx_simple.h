@@ -53,9 +53,18 @@ struct SimpleCols {
 };
 struct SimpleRes { uint64_t w; uint8_t len, n, mis, switches; uint8_t pad[4]; };
 enum : int { kDpNone = 0, kDpCollect = 1, kDpReplay = 2 };
+// a problem as the collecting pass leaves it (three words) -> its descriptor; first_read: the pair's first read
+static inline MCX_HD SimpleJob simple_job_unpack(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t first_read, int nr)
+{
+    SimpleJob j;
+    j.rp = (uint16_t)(w0 & 0xFFFFu); j.rl = (uint8_t)((w0 >> 16) & 31u); j.gl = (uint8_t)((w0 >> 21) & 31u);
+    j.read = nr == 2 ? (first_read & ~1u) | ((w0 >> 26) & 1u) : first_read;
+    j.gp = (int64_t)((uint64_t)w1 | ((uint64_t)w2 << 32));
+    return j;
+}
 struct SimpleDpIo {
     int mode;               // kDpNone: a DP gap makes the read leave
-    SimpleJob *jobs;        // collect: the pair's kSimpleJobs descriptors, problem k at jobs[k * job_stride]
+    uint32_t *jobs;         // collect: the pair's problems as they are met, three words each (simple_job_pack), word w of problem k at jobs[(3 * k + w) * job_stride]
     int job_stride;
     const SimpleRes *res;   // replay: their results
     int n;                  // problems met so far in the pair
@@ -99,9 +108,10 @@ struct SimpleRead {
 // is, but for DP problems now written down (out.pd0 is set: the pairing test does not wait).  kSimpleNo: the general path.
 // hits: the read's seeds as k_seed left them (text positions), n of them (1..kSimpleHits); codes: its 2-bit words (no N).
 enum : int { kSimpleNo = 0, kSimpleYes = 1, kSimpleLater = 2 };
-template <bool NW>
+// (CigT: 32-bit words, or 16-bit ones — a run is at most 4095 long: reads of up to 1000 bases, deletions below 4096)
+template <bool NW, class CigT>
 static inline MCX_HD int simple_read(const IndexView &ix, const Params &pm, int rlen, const uint32_t *codes, const Hit *hits, int n,
-                                     SimpleRead &out, uint32_t *cig, int cig_stride, SimpleDpIo &io)
+                                     SimpleRead &out, CigT *cig, int cig_stride, SimpleDpIo &io)
 {
     if (n < 1 || n > kSimpleHits || !codes) MCX_SIMPLE_FAIL(1);
     // ---- the seeds with PosDiff > 0 (IdentifySimplePairs' tail); the straight-line case needs all of them to stay
@@ -181,8 +191,9 @@ static inline MCX_HD int simple_read(const IndexView &ix, const Params &pm, int 
         if (io.mode == kDpNone || rl_ > kSimpleDp || gl_ > kSimpleDp) { if (rl_ == gl_) MCX_SIMPLE_NOTE(2, rl_); MCX_SIMPLE_FAIL(18); }
         if (io.n >= kSimpleJobs) MCX_SIMPLE_FAIL(18);
         if (io.mode == kDpCollect) {
-            SimpleJob j; j.read = io.read; j.rp = (uint16_t)rp; j.rl = (uint8_t)rl_; j.gl = (uint8_t)gl_; j.gp = gp;
-            io.jobs[(io.n++) * io.job_stride] = j;
+            uint32_t *w = io.jobs + (size_t)(3 * io.n++) * io.job_stride;
+            w[0] = (uint32_t)rp | ((uint32_t)rl_ << 16) | ((uint32_t)gl_ << 21) | ((io.read & 1u) << 26);
+            w[io.job_stride] = (uint32_t)gp; w[2 * io.job_stride] = (uint32_t)((uint64_t)gp >> 32);
             later = true;
             return true;
         }
@@ -277,7 +288,7 @@ static inline MCX_HD int simple_read(const IndexView &ix, const Params &pm, int 
     if (n_run > kSimpleRuns) MCX_SIMPLE_FAIL(20); // more operations than the path keeps
     const int fwd = g_head + head_shift < ix.G ? 1 : 0;
     MCX_UNROLL
-    for (int k = 0; k < kSimpleRuns; k++) if (k < n_run) cig[(fwd ? k : n_run - 1 - k) * cig_stride] = runs[k];
+    for (int k = 0; k < kSimpleRuns; k++) if (k < n_run) cig[(fwd ? k : n_run - 1 - k) * cig_stride] = (CigT)runs[k];
     out.score = score; out.fwd = fwd; out.n_cig = n_run;
     // first fragment in alignment order: forward = the head (gap or seed) at g_head, behind the genome bases its outer end lost; reverse =
     // the tail, which ends at g_tail less what its outer end lost.  GetAlnCoordinate takes gPos (forward) or gPos + gLen - 1 (reverse)

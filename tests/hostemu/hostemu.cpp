@@ -161,7 +161,7 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
             uint32_t cg[2][kSimpleRuns];
             int rl[2] = {0, 0};
             bool ok = true, wait = false;
-            SimpleJob mine[kSimpleJobs];
+            uint32_t mine[3 * kSimpleJobs];
             SimpleDpIo io; io.mode = mode; io.jobs = mine; io.job_stride = 1; io.res = mode == kDpReplay ? res.data() + slot * kSimpleJobs : nullptr; io.n = 0; io.read = 0;
             for (int s = 0; s < nr && ok; s++) {
                 const uint32_t r = ids[l] * nr + s;
@@ -180,8 +180,8 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
                 io.read = (uint32_t)(l * 2 + s); // (here: the place of the read's words in `packed`)
                 ok = !has_n && nh >= 1 && nh <= kSimpleHits;
                 if (ok) {
-                    const int how = cx.pm.use_nw ? simple_read<true>(cx.ix, cx.pm, one.rlen, pk.data(), st.hits[s], nh, sr[s], cg[s], 1, io)
-                                                 : simple_read<false>(cx.ix, cx.pm, one.rlen, pk.data(), st.hits[s], nh, sr[s], cg[s], 1, io);
+                    const int how = cx.pm.use_nw ? simple_read<true, uint32_t>(cx.ix, cx.pm, one.rlen, pk.data(), st.hits[s], nh, sr[s], cg[s], 1, io)
+                                                 : simple_read<false, uint32_t>(cx.ix, cx.pm, one.rlen, pk.data(), st.hits[s], nh, sr[s], cg[s], 1, io);
                     ok = how != kSimpleNo;
                     wait = wait || how == kSimpleLater;
                 }
@@ -190,7 +190,7 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
             if (nr == 2 && !simple_pair_ok(sr[0], sr[1], est[l])) { g_simple_why[23]++; return; }
             if (wait) {
                 later.push_back(l);
-                for (int k = 0; k < kSimpleJobs; k++) { jobs.push_back(k < io.n ? mine[k] : SimpleJob{0, 0, 0, 0, 0}); }
+                for (int k = 0; k < kSimpleJobs; k++) jobs.push_back(k < io.n ? simple_job_unpack(mine[3 * k], mine[3 * k + 1], mine[3 * k + 2], l * 2, 2) : SimpleJob{0, 0, 0, 0, 0}); // (read: the place of its words in `packed`)
                 return;
             }
             const uint32_t want = (uint32_t)sr[0].n_cig + (nr == 2 ? (uint32_t)sr[1].n_cig : 0u);
