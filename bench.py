@@ -765,6 +765,7 @@ def main():
     t0 = time.perf_counter()
     index = api.Index.from_codes(codes.data_ptr(), lens, device=local, full_sa=int(args.full_sa))
     t_index = time.perf_counter() - t0
+    index_gb = round(index.hbm_bytes / 1e9, 2)  # (before the -vcf leg gives the pair records back)
     n_steps = args.warmup + args.steps
     paired = not args.single_end
     reads_per_step = (2 if paired else 1) * args.batch_pairs
@@ -871,7 +872,7 @@ def main():
             "config": {"workload": f"synthetic GRCh38-sized genome, {args.genome_mbp:.0f} Mbp ({args.contigs} contigs, {genome_note}; GRCh38 itself is unavailable offline), "
                                    f"{args.batch_pairs} {'pairs' if paired else 'reads'} x {args.rlen} bp {'PE' if paired else 'SE'} per step per GPU (sub {args.sub}, ins {args.ins}, del {args.dele} per base), -alg {args.alg}",
                        "reads_per_step_per_gpu": reads_per_step, "full_sa_in_hbm": bool(args.full_sa), "pair_records_in_hbm": args.full_sa >= 2, "index_build_s": round(t_index, 2),
-                       "index_hbm_gb": round(index.hbm_bytes / 1e9, 2),
+                       "index_hbm_gb": index_gb,
                        "multi_gpu": None if world == 1 else f"one process per GPU, index replicated, rank r maps batch {world}*step + r; one avgDist trajectory over the "
                                                             f"ranks' batches per step (all-gather of per-chunk sums over RCCL, {traj.exchanges} exchanges in "
                                                             f"{n_steps} steps, inside the timed region)",
