@@ -700,7 +700,7 @@ static inline MCX_HD void seed_compare(const IndexView &ix, const PackedRead &pk
 // hold the next 64 text positions wherever they begin, so a seed of 150 bases is confirmed in three dependent fetches, not ten —
 // and it is dependent fetches that the seeding kernel's time is made of.  Stretches that touch the strand boundary or the end
 // of the text take seed_compare's single windows.  Same comparisons, same p.
-static inline MCX_HD void seed_compare_wide(const IndexView &ix, const PackedRead &pk, int rlen, int &p, SeedWalk &w, int max_fetches)
+static inline MCX_HD void seed_compare_wide64(const IndexView &ix, const PackedRead &pk, int rlen, int &p, SeedWalk &w, int max_fetches)
 {
     for (int k = 0; k < max_fetches; k++) {
         const int64_t j = w.tpos + (p - w.start);
@@ -747,6 +747,83 @@ static inline MCX_HD void seed_compare_wide(const IndexView &ix, const PackedRea
             p += same;
             if (same < 16) { w.phase = 3; return; }
         }
+    }
+}
+
+// The same again, with the chunk two consecutive fetches share kept in registers: the first fetch of a search brings 64 bases (two
+// chunks wherever the stretch begins), every further one 128 — the chunk kept from the last fetch and the two beyond it (before it,
+// on the reverse strand, where the text runs against the genome) — so a seed of 150 bases is confirmed in two dependent fetches,
+// and a fetch asks for the line its predecessor already brought half as often.  Same comparisons, same p.
+static inline MCX_HD void seed_compare_wide(const IndexView &ix, const PackedRead &pk, int rlen, int &p, SeedWalk &w, int max_fetches)
+{
+    bool have = false;   // `keep` holds the chunk the next stretch begins in (forward) / ends in (reverse)
+    U4 keep; keep.x = keep.y = keep.z = keep.w = 0u;
+    int64_t keep_at = 0; // its index among the genome's 16-byte chunks
+    for (int k = 0; k < max_fetches; k++) {
+        const int64_t j = w.tpos + (p - w.start);
+        const int nb = have ? 128 : 64;
+        const bool fwd = j + nb <= ix.G, rev = j >= ix.G && j + nb <= ix.G2;
+        if (!fwd && !rev) {
+            if (have) { have = false; continue; } // (128 bases do not fit any more: 64 may)
+            w.carry_dir = 0;
+            seed_compare(ix, pk, rlen, p, w, 1);
+            if (w.phase == 3) return;
+            continue;
+        }
+        const int64_t f_lo = fwd ? j : ix.G2 - nb - j;   // the forward stretch [f_lo, f_lo + nb) under the nb text positions
+        const int64_t at = f_lo >> 6;
+        if (have && keep_at != (fwd ? at : at + 2)) { have = false; continue; }
+        const U4 *src = (const U4 *)ix.pac + at;
+        // twelve words X0..X11 of three consecutive chunks; forward window u of the stretch lies in X[base + oq + u], X[base + oq + u + 1]:
+        //   forward, kept chunk:  X0-3 = keep, X4-11 = the two chunks behind it           reverse, kept chunk:  X0-7 = the two chunks before it, X8-11 = keep
+        //   forward, first fetch: X0-7 = the two chunks, X8-11 unused                     reverse, first fetch: X4-11 = the two chunks (so that text
+        //                                                                                 window t is V[7 - t], V[8 - t] either way), X0-3 unused
+        const U4 l0 = src[fwd && have ? 1 : 0], l1 = src[fwd && have ? 2 : 1];
+        U4 c0, c1, c2;
+        if (fwd) { if (have) { c0 = keep; c1 = l0; c2 = l1; } else { c0 = l0; c1 = l1; c2 = l1; } }
+        else { if (have) { c0 = l0; c1 = l1; c2 = keep; } else { c0 = l0; c1 = l0; c2 = l1; } }
+        const uint32_t X0 = __builtin_bswap32(c0.x), X1 = __builtin_bswap32(c0.y), X2 = __builtin_bswap32(c0.z), X3 = __builtin_bswap32(c0.w);
+        const uint32_t X4 = __builtin_bswap32(c1.x), X5 = __builtin_bswap32(c1.y), X6 = __builtin_bswap32(c1.z), X7 = __builtin_bswap32(c1.w);
+        const uint32_t X8 = __builtin_bswap32(c2.x), X9 = __builtin_bswap32(c2.y), X10 = __builtin_bswap32(c2.z), X11 = __builtin_bswap32(c2.w);
+        const int oq = (int)(f_lo & 63) >> 4, sh = (int)(f_lo & 15) * 2;
+        uint32_t V[9]; // V[u] = X[oq + u]
+        V[0] = oq == 0 ? X0 : oq == 1 ? X1 : oq == 2 ? X2 : X3;
+        V[1] = oq == 0 ? X1 : oq == 1 ? X2 : oq == 2 ? X3 : X4;
+        V[2] = oq == 0 ? X2 : oq == 1 ? X3 : oq == 2 ? X4 : X5;
+        V[3] = oq == 0 ? X3 : oq == 1 ? X4 : oq == 2 ? X5 : X6;
+        V[4] = oq == 0 ? X4 : oq == 1 ? X5 : oq == 2 ? X6 : X7;
+        V[5] = oq == 0 ? X5 : oq == 1 ? X6 : oq == 2 ? X7 : X8;
+        V[6] = oq == 0 ? X6 : oq == 1 ? X7 : oq == 2 ? X8 : X9;
+        V[7] = oq == 0 ? X7 : oq == 1 ? X8 : oq == 2 ? X9 : X10;
+        V[8] = oq == 0 ? X8 : oq == 1 ? X9 : oq == 2 ? X10 : X11;
+        const int n_win = nb >> 4;
+        MCX_UNROLL
+        for (int t = 0; t < 8; t++) {
+            if (t >= n_win) break;
+            const int64_t jj = w.tpos + (p - w.start); // (= j + 16 t: every window before this one was whole)
+            int64_t room = (int64_t)ix.seq_len - jj;
+            if (rlen - p < room) room = rlen - p;
+            if (room <= 0) { w.phase = 3; return; }
+            const uint32_t vh = fwd ? V[t] : V[7 - t], vl = fwd ? V[t + 1] : V[8 - t]; // on the reverse strand text window t is the stretch's last forward window but t, mirrored
+            uint32_t ref = sh ? (vh << sh) | (vl >> (32 - sh)) : vh;
+            if (!fwd) {
+                uint32_t v = __builtin_bswap32(ref);
+                v = ((v & 0x0F0F0F0Fu) << 4) | ((v >> 4) & 0x0F0F0F0Fu);
+                v = ((v & 0x33333333u) << 2) | ((v >> 2) & 0x33333333u);
+                ref = ~v;
+            }
+            const uint32_t x = packed_codes16(pk, p) ^ ref;
+            uint32_t sp = packed_nmask32(pk, p, rlen) >> 16; // N flags, bit 15-s -> bit 30-2s
+            sp = (sp | (sp << 8)) & 0x00FF00FFu; sp = (sp | (sp << 4)) & 0x0F0F0F0Fu;
+            sp = (sp | (sp << 2)) & 0x33333333u; sp = (sp | (sp << 1)) & 0x55555555u;
+            const uint32_t mm = ((x | (x >> 1)) & 0x55555555u) | sp;
+            int same = mm ? (__builtin_clz(mm) >> 1) : 16;
+            if (same > room) same = (int)room;
+            p += same;
+            if (same < 16) { w.phase = 3; return; }
+        }
+        // every window was whole: the next stretch begins nb positions on — in the last chunk fetched (forward), ends in the first (reverse)
+        keep = fwd ? l1 : l0; keep_at = fwd ? at + (have ? 2 : 1) : at; have = true;
     }
 }
 

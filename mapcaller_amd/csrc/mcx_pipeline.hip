@@ -652,7 +652,7 @@ __global__ void __launch_bounds__(256, MCX_SEED_WAVES) k_seed(Ctx cx, ReadBatch 
         //      (dozens of FM steps) holds the wave up for a few steps at a time while the others finish searches and take new reads ----
         if (have && walk.phase == 0) seed_begin(cx.ix, pk, rlen, nm, p, walk);
         if (have && walk.phase == 1) seed_fm(cx.ix, pk, rlen, p, walk, blocks, fm_budget);
-        if (have && walk.phase == 2) { if (wide) seed_compare_wide(cx.ix, pk, rlen, p, walk, 1 << 30); else seed_compare(cx.ix, pk, rlen, p, walk, 1 << 30); }
+        if (have && walk.phase == 2) { if (wide == 1) seed_compare_wide(cx.ix, pk, rlen, p, walk, 1 << 30); else if (wide) seed_compare_wide64(cx.ix, pk, rlen, p, walk, 1 << 30); else seed_compare(cx.ix, pk, rlen, p, walk, 1 << 30); }
         if (have && walk.phase == 3) {
             seed_take(cx.ix, p, walk, hits, cap, n, ext);
             if (!seed_next_start(pk, rlen, p, nm)) { finish_read(); have = false; }
@@ -2457,7 +2457,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         const int threads = pkw * 256 * 4 <= 48 * 1024 ? 256 : (pkw * 128 * 4 <= 48 * 1024 ? 128 : 64);
         const int rpl = seed_reads_per_lane((uint64_t)sel.n * nr);
         const unsigned blocks_s = std::min<unsigned>((sel.n * nr + threads * rpl - 1) / (threads * rpl), 4096u); // (the queue feeds whatever grid runs)
-        k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl, seed_fm_budget(), getenv("MCX_SEED_NARROW") ? 0 : 1);
+        k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl, seed_fm_budget(), getenv("MCX_SEED_NARROW") ? 0 : (getenv("MCX_SEED_WIDE64") ? 2 : 1)); // (experiments: 16 bases per fetch of the comparison phase; 64 without the kept chunk)
 #ifdef MCX_SEED_STATS
         if (tier == 0 && sel.n > 100000) {
             unsigned long long h[2][24];
