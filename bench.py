@@ -39,6 +39,10 @@ DP_OPS_PER_CELL = {"nw": 21.0, "ksw2": 34.0}
 # random 16-byte gathers from an 8 GiB table, four lanes per 64-byte block: what the chip's L2 / fabric sustains in
 # requests per second (tools/ubench_gather.hip, profiles/round1/ubench_gather_8GiB.txt: 47-48 G/s)
 GATHER_CEILING_G_PER_S = 47.5
+# the seeding walk's own pattern — every lane chases its own chain, ONE 16-byte load per 64-byte line — against the size of the table the
+# reads fall into (tools/ubench_gather.hip mode 7, profiles/round4/ubench_gather_footprint.txt): 57 G lines/s in 1 GiB, 41 in 8 GiB,
+# 37-38 from 32 to 192 GiB (the index is 110 GB)
+WALK_MISS_CEILING_G_PER_S = 37.8
 # committed rocprofv3 --pmc passes, by workload: (genome kind, Mbp, pairs per step, read length, alg, sub, ins, del, single-end)
 PMC_SUMMARY = {
     ("human", 3100.0, 4_000_000, 150, "ksw2", 0.005, 0.001, 0.001, 0): "profiles/round4/summary_human.json",
@@ -69,6 +73,7 @@ def pmc_profile(args):
             get = lambda c: p[c]["full_batch_mean"] if c in p else None
             if get("TCC_HIT_sum") is not None and get("TCC_MISS_sum") is not None:
                 e["l2_requests"] = int(get("TCC_HIT_sum") + get("TCC_MISS_sum"))
+                e["l2_misses"] = int(get("TCC_MISS_sum"))
             if get("SQ_WAIT_ANY") is not None and get("SQ_WAVE_CYCLES"):
                 e["wait_frac"] = round(get("SQ_WAIT_ANY") / get("SQ_WAVE_CYCLES"), 3)
             if get("SQ_ACTIVE_INST_ANY") is not None and get("SQ_WAVE_CYCLES"):
@@ -165,7 +170,11 @@ def roofline(args, d, reads_per_s):
                             "essential_bytes_per_read": round(essential_bytes(k, d, args) / (d["reads"] / steps), 1)} for k in ms},
          "request_rate": {k: {"l2_requests_per_launch": kern[k]["l2_requests"], "g_per_s": round(kern[k]["l2_requests"] / (ms[k] * 1e-3) / 1e9, 1),
                               "ceiling_g_per_s": GATHER_CEILING_G_PER_S, "frac": round(kern[k]["l2_requests"] / (ms[k] * 1e-3) / 1e9 / GATHER_CEILING_G_PER_S, 3),
-                              "requests_per_read": round(kern[k]["l2_requests"] / (d["reads"] / steps), 2), "waves_waiting_frac": kern[k].get("wait_frac")}
+                              "requests_per_read": round(kern[k]["l2_requests"] / (d["reads"] / steps), 2), "waves_waiting_frac": kern[k].get("wait_frac"),
+                              **({} if "l2_misses" not in kern[k] else {
+                                  "l2_misses_per_launch": kern[k]["l2_misses"], "misses_per_read": round(kern[k]["l2_misses"] / (d["reads"] / steps), 2),
+                                  "misses_g_per_s": round(kern[k]["l2_misses"] / (ms[k] * 1e-3) / 1e9, 1), "walk_miss_ceiling_g_per_s": WALK_MISS_CEILING_G_PER_S,
+                                  "miss_frac_of_ceiling": round(kern[k]["l2_misses"] / (ms[k] * 1e-3) / 1e9 / WALK_MISS_CEILING_G_PER_S, 3)})}
                           for k in ms if k in kern and "l2_requests" in kern[k]},
          "speed_of_light_equiv": {"kernel": "k_seed", "bytes_per_read": round(seed_bytes / max(d["reads"], 1), 1),
                                   "gbs": round(seed_bytes / steps / (seed_ms * 1e-3) / 1e9, 1) if seed_ms > 0 else None,

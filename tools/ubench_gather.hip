@@ -1,10 +1,11 @@
 // tools/ubench_gather.hip — what does MI355X sustain for DEPENDENT random 64-byte block reads?
 // (the access pattern of the FM-index walk: every lane chases its own chain of blocks)
 //   hipcc -O3 --offload-arch=gfx950 tools/ubench_gather.hip -o tools/ubench_gather
-//   tools/ubench_gather [buffer MiB] [steps per lane]
+//   tools/ubench_gather [buffer MiB] [steps per lane] [quick: modes 2, 4, 7 at 4096 blocks — for sweeps over the buffer size]
 // modes: 0 lane-per-block 4 x 16 B   1 same, non-temporal   2 four lanes per block (one 16 B load each)
 //        3 lane-per-block, 128-B blocks (8 x 16 B)            4 lane-per-block, first 32 B only
 //        5 two independent chains per lane (ILP)
+//        7 lane-per-block, first 16 B only (one 16-byte load per line and lane: the seeding walk's record fetch)
 //        6 one chain per lane, served by the wave four lanes per block: four rounds of 16 requests, the address pulled from
 //          the requesting lane and the result pushed back with ds_bpermute (what k_seed's FM step would do)
 #include <hip/hip_runtime.h>
@@ -74,6 +75,10 @@ __global__ void __launch_bounds__(256) k_chase(const U4 *buf, uint64_t n_blocks,
                 if ((lane >> 4) == r) v = got;
             }
             acc += v; s = mix(s, v);
+        } else if (MODE == 7) {
+            const U4 a = buf[(s % n_blocks) * 4];
+            const uint32_t v = a.x ^ a.w;
+            acc += v; s = mix(s, v);
         } else if (MODE == 3) {
             const U4 *p = buf + (s % (n_blocks / 2)) * 8;
             uint32_t v = 0;
@@ -83,6 +88,11 @@ __global__ void __launch_bounds__(256) k_chase(const U4 *buf, uint64_t n_blocks,
         }
     }
     out[tid] = s + acc + s2;
+}
+
+__global__ void k_fill(uint32_t *p, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = (uint32_t)(i * 2654435761u) ^ (uint32_t)(i >> 7);
 }
 
 template <int MODE>
@@ -111,10 +121,17 @@ int main(int argc, char **argv)
     U4 *buf; uint64_t *out;
     hipMalloc(&buf, n_blocks * 64);
     hipMalloc(&out, 64ull << 20);
-    std::vector<uint32_t> h(1 << 20);
-    for (auto &x : h) x = rand();
-    for (size_t o = 0; o < n_blocks * 64; o += h.size() * 4) hipMemcpy((char *)buf + o, h.data(), std::min<size_t>(h.size() * 4, n_blocks * 64 - o), hipMemcpyHostToDevice);
+    if (!buf || !out) { printf("allocation of %zu MiB failed\n", mib); return 1; }
+    k_fill<<<8192, 256>>>((uint32_t *)buf, n_blocks * 16);
+    hipDeviceSynchronize();
     printf("buffer %zu MiB, %d dependent steps per chain\n", mib, steps);
+    if (argc > 3) {
+        run<2>(buf, n_blocks, steps, out, 4096, "2 quad-per-block 1x16B per lane", 64);
+        run<4>(buf, n_blocks, steps, out, 4096, "4 lane-per-block first 32B only", 32);
+        run<7>(buf, n_blocks, steps, out, 4096, "7 lane-per-block first 16B only", 16);
+        run<7>(buf, n_blocks, steps, out, 16384, "7 lane-per-block first 16B only", 16);
+        return 0;
+    }
     for (int blocks : {1024, 2048, 4096, 8192}) {
         run<0>(buf, n_blocks, steps, out, blocks, "0 lane-per-block 4x16B", 64);
         run<1>(buf, n_blocks, steps, out, blocks, "1 lane-per-block non-temporal dwords", 64);
@@ -123,6 +140,7 @@ int main(int argc, char **argv)
         run<4>(buf, n_blocks, steps, out, blocks, "4 lane-per-block first 32B only", 32);
         run<5>(buf, n_blocks, steps, out, blocks, "5 two chains per lane 4x16B", 64);
         run<6>(buf, n_blocks, steps, out, blocks, "6 lane-per-chain, quad-served in 4 rounds", 64);
+        run<7>(buf, n_blocks, steps, out, blocks, "7 lane-per-block first 16B only", 16);
     }
     return 0;
 }
