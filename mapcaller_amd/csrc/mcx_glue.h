@@ -51,10 +51,19 @@ static inline MCX_HD int prep_seeds(Hit *h, int n)
 {
     // (an element is stored only when it moves: most reads have two or three seeds, already in order)
     int m = 0;
+    bool in_order = true; // the kept seeds came in (PosDiff, rPos) order: nothing to sort (a read's two or three seeds of one locus)
+    int64_t ppd = 0;
+    int prp = 0;
     for (int i = 0; i < n; i++) {
         const Hit x = h[i];
-        if (hit_pd(x) > 0) { if (m != i) h[m] = x; m++; }
+        const int64_t pd = hit_pd(x);
+        if (pd > 0) {
+            if (m > 0 && (ppd > pd || (ppd == pd && prp > x.rPos))) in_order = false;
+            if (m != i) h[m] = x;
+            m++; ppd = pd; prp = x.rPos;
+        }
     }
+    if (in_order) return m;
     // insertion sort; long lists (reads from repeats: hundreds of seeds in suffix-array order) first in strides, so that
     // no element travels far one step at a time.  Equal keys are equal seeds: any order of them is the reference's.
     for (int gap = m > 24 ? (m > 400 ? 109 : 23) : 1; gap >= 1; gap = gap > 23 ? 23 : (gap > 5 ? 5 : (gap > 1 ? 1 : 0))) {
@@ -94,12 +103,16 @@ template <class Emit>
 static inline MCX_HD int cluster_seeds_to(const IndexView &ix, const Params &pm, int rlen, const Hit *h, int n, Emit emit)
 {
     if (n == 0) return 0;
-    int nc = 0, head = 0, score = h[0].len, thr = rlen >> 2;
-    int64_t g_end = boundary_of(ix, h[0].gPos);
+    const Hit h0 = h[0];
+    int nc = 0, head = 0, score = h0.len, thr = rlen >> 2;
+    int64_t g_end = boundary_of(ix, h0.gPos);
+    int64_t pd_prev = hit_pd(h0); // of seed j - 1: every seed is fetched once
     for (int j = 1; j <= n; j++) {
-        int i = j - 1;
-        int64_t gj = j < n ? h[j].gPos : ix.G2, pdj = j < n ? hit_pd(h[j]) : ix.G2;
-        int64_t d = pdj - hit_pd(h[i]);
+        Hit hj; hj.gPos = ix.G2; hj.rPos = 0; hj.len = 0;
+        if (j < n) hj = h[j];
+        const int64_t gj = hj.gPos, pdj = j < n ? hit_pd(hj) : ix.G2;
+        int64_t d = pdj - pd_prev;
+        pd_prev = pdj;
         if (d < 0) d = -d;
         if (gj > g_end || d > pm.max_pos_diff) {
             if (score > thr) {
@@ -121,8 +134,8 @@ static inline MCX_HD int cluster_seeds_to(const IndexView &ix, const Params &pm,
                 nc++;
             }
             head = j;
-            if (j < n) { g_end = boundary_of(ix, gj); score = h[j].len; }
-        } else score += h[j].len;
+            if (j < n) { g_end = boundary_of(ix, gj); score = hj.len; }
+        } else score += hj.len;
     }
     return nc;
 }
