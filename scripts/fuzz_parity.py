@@ -25,6 +25,7 @@ EXE = os.path.join(ROOT, "mapcaller_amd", "mapcaller-mi355x")
 ORACLE = os.path.join(ROOT, "oracle", "mcx_oracle")
 REF = os.path.join(ROOT, "oracle", "_ref", "MapCaller")
 MODE = "gpu"  # "gpu": product vs oracle (needs a GPU); "ref": oracle vs the compiled reference (CPU only: pins the oracle)
+NO_VCF = False  # --no-vcf: mapping alone, the SAM compared
 CLI_ARGS = []  # extra switches for the product's command line (e.g. -devices 0,0,0 -batch 400: the reads dealt to three shards)
 
 
@@ -137,7 +138,10 @@ def one_round(d, tmp):
                        check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     else:
         walk = ["-two_base"] if d.get("two_base") else []  # every other round: the seeding walk over the pair records
-        subprocess.run([EXE, "-i", prefix, *files, "-alg", alg, "-sam", gs, "-vcf", gv, *vcf_flags, *walk, *CLI_ARGS], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        if NO_VCF:  # mapping alone: no alignment profile is kept, so the straight-line path (k_simple) is open to the pairs (with MCX_ORDER_MIN=1 on these small batches)
+            subprocess.run([EXE, "-i", prefix, *files, "-alg", alg, "-sam", gs, "-no_vcf", *walk, *CLI_ARGS], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        else:
+            subprocess.run([EXE, "-i", prefix, *files, "-alg", alg, "-sam", gs, "-vcf", gv, *vcf_flags, *walk, *CLI_ARGS], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     subprocess.run([ORACLE, "-i", prefix, *files, "-alg", alg, "-sam", os_], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     subprocess.run([ORACLE, "-i", prefix, *files, "-alg", alg, "-vcf", ov, *vcf_flags], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     if MODE == "ref":
@@ -145,6 +149,8 @@ def one_round(d, tmp):
     else:
         a, b = body(gs), body(os_)
         sam_bad = sum(1 for x, y in zip(a, b) if x != y) + abs(len(a) - len(b))
+    if NO_VCF and MODE != "ref":
+        return desc, sam_bad, 0
     va, vb = body(gv, True), body(ov, True)
     vcf_bad = sum(1 for x, y in zip(va, vb) if x != y) + abs(len(va) - len(vb))
     return desc, sam_bad, vcf_bad
@@ -158,12 +164,14 @@ def main():
     ap.add_argument("--only", type=int, default=-1, help="replay just this round of the sequence")
     ap.add_argument("--ref", action="store_true", help="compare the oracle with the compiled reference (oracle/_ref, CPU only) instead of the GPU product")
     ap.add_argument("--cli-args", default="", help="extra switches for mapcaller-mi355x, space separated")
+    ap.add_argument("--no-vcf", action="store_true", help="map with -no_vcf and compare the SAM only (opens the straight-line path to the pairs)")
     ap.add_argument("--wide", action="store_true", help="longer reads (up to 900 bp) and more variant-calling switches")
     a = ap.parse_args()
-    global MODE, CLI_ARGS, WIDE
+    global MODE, CLI_ARGS, WIDE, NO_VCF
     WIDE = a.wide
     MODE = "ref" if a.ref else "gpu"
     CLI_ARGS = a.cli_args.split()
+    NO_VCF = a.no_vcf
     rng = random.Random(a.seed)
     bad = ran = 0
     for r in range(a.rounds):
