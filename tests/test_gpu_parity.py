@@ -778,6 +778,18 @@ def test_fuzz_rounds_on_three_shards_equal_oracle():
     assert "25 of 25 rounds identical" in r.stdout
 
 
+def test_fuzz_rounds_on_the_large_batch_paths_equal_oracle(monkeypatch):
+    """The generator once more, mapping alone (`-no_vcf`: no alignment profile is kept, so the straight-line path is open to the pairs; the
+    index with its pair records) with what only a large batch switches on forced onto the small ones — k_simple with its DP problems
+    collected, solved and replayed, the order lists, every DP list on the lane kernels: 50 rounds, the SAM against the oracle's."""
+    monkeypatch.setenv("MCX_ORDER_MIN", "1")
+    monkeypatch.setenv("MCX_DP_LANE_ALWAYS", "1")
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "--rounds", "50", "--seed", "5150", "--no-vcf"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1400)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "50 of 50 rounds identical" in r.stdout
+
+
 def test_overlong_read_is_refused(api, golden):
     """One read longer than the context's max_read_len in a batch handed over through the C ABI: refused before any kernel touches the
     per-read slots (the file front end names the read; here the batch fails as a whole)."""
