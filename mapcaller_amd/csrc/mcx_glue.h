@@ -164,19 +164,23 @@ static inline MCX_HD int pair_by_distance(int64_t est, Cand *c1, int n1, Cand *c
     if (n1 * n2 > 100) { keep_top_scores(c1, n1); keep_top_scores(c2, n2); }
     // the partner a candidate of read 1 picks among read 2's: found twice (once for the best pair sum, once to
     // mark the pairs that reach it) rather than parked in the candidate — fetches of lines already at hand
-    // are cheaper here than stores
+    // are cheaper here than stores.  Both lists come in ascending PosDiff (cluster_seeds_to emits its clusters in the order of
+    // the sorted seeds), so read 2's candidates below a's PosDiff are passed once for all of read 1's (j0 only moves on), and
+    // behind the first live one at or beyond the estimate nothing can change the outcome: the same picks, the same [lo, hi]
+    // as the scan of all n1 x n2 pairs, in n1 + n2 + (pairs within the estimate) steps.
+    int j0 = 0;
     auto partner = [&](const Cand &a, int &ps) {
         int pick = -1;
         ps = 0;
-        for (int j = 0; j < n2; j++) {
+        while (j0 < n2 && c2[j0].pd0 < a.pd0) j0++;
+        for (int j = j0; j < n2; j++) {
             const int sj = c2[j].score;
-            const int64_t pj = c2[j].pd0;
-            if (sj == 0 || pj < a.pd0) continue;
-            const int64_t d = pj - a.pd0;
+            if (sj == 0) continue;
+            const int64_t d = c2[j].pd0 - a.pd0;
             if (d < est) {
                 if (d > max_lt) max_lt = d;
                 if (sj > ps) { pick = j; ps = sj; }
-            } else if (d < min_ge) min_ge = d;
+            } else { if (d < min_ge) min_ge = d; break; }
         }
         return pick;
     };
@@ -189,6 +193,7 @@ static inline MCX_HD int pair_by_distance(int64_t est, Cand *c1, int n1, Cand *c
     }
     int paired = 0;
     if (top > 0) {
+        j0 = 0;
         for (int i = 0; i < n1; i++) {
             const Cand a = c1[i];
             if (a.score == 0) continue;
