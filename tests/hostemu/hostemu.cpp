@@ -347,6 +347,56 @@ static int run_selection(Emu &e, const Batch &b, const std::vector<uint32_t> &id
 
 } // namespace
 
+// pair_by_distance (mcx_glue.h: read 2's candidates swept in PosDiff order) against the plain scan of all n1 x n2 pairs
+// (CheckPairedAlignmentDistance, ReadMapping.cpp:244-303) on random candidate lists in ascending PosDiff: trials that differ
+extern "C" int64_t hostemu_pairing_check(int64_t trials, uint64_t seed)
+{
+    auto rnd = [&]() { seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17; return seed; };
+    int64_t bad = 0;
+    for (int64_t t = 0; t < trials; t++) {
+        Cand a[2][24], b[2][24];
+        int n[2];
+        for (int s = 0; s < 2; s++) {
+            n[s] = (int)(rnd() % 13);
+            int64_t pd = (int64_t)(rnd() % 5000) + 1;
+            for (int k = 0; k < n[s]; k++) {
+                pd += (int64_t)(rnd() % 4 == 0 ? 0 : rnd() % 700);
+                cand_init(a[s][k], rnd() % 5 == 0 ? 0 : (int)(rnd() % 150) + 1, k, 1, pd);
+                b[s][k] = a[s][k];
+            }
+        }
+        const int64_t est = (int64_t)(rnd() % 1500) + 1;
+        int lo = 0, hi = 0;
+        const int paired = pair_by_distance(est, a[0], n[0], a[1], n[1], lo, hi);
+        // the plain scan
+        Cand *c1 = b[0], *c2 = b[1];
+        const int n1 = n[0], n2 = n[1];
+        int64_t max_lt = -1, min_ge = 0x7fffffff;
+        if (n1 * n2 > 100) { keep_top_scores(c1, n1); keep_top_scores(c2, n2); }
+        auto partner = [&](const Cand &x, int &ps) {
+            int pick = -1;
+            ps = 0;
+            for (int j = 0; j < n2; j++) {
+                const int sj = c2[j].score;
+                const int64_t pj = c2[j].pd0;
+                if (sj == 0 || pj < x.pd0) continue;
+                const int64_t d = pj - x.pd0;
+                if (d < est) { if (d > max_lt) max_lt = d; if (sj > ps) { pick = j; ps = sj; } }
+                else if (d < min_ge) min_ge = d;
+            }
+            return pick;
+        };
+        int64_t top = 0;
+        for (int i = 0; i < n1; i++) { if (c1[i].score == 0) continue; int ps; if (partner(c1[i], ps) >= 0) { const int64_t sc = (int64_t)c1[i].score + ps; if (sc > top) top = sc; } }
+        int want = 0;
+        if (top > 0) for (int i = 0; i < n1; i++) { if (c1[i].score == 0) continue; int ps; const int pick = partner(c1[i], ps); if (pick >= 0 && (int64_t)c1[i].score + ps == top) { want++; c1[i].mate = pick; c2[pick].mate = i; } }
+        bool same = want == paired && lo == (int)(max_lt + 1) && hi == (int)min_ge;
+        for (int s = 0; s < 2 && same; s++) for (int k = 0; k < n[s]; k++) if (a[s][k].mate != b[s][k].mate || a[s][k].score != b[s][k].score) { same = false; break; }
+        if (!same) bad++;
+    }
+    return bad;
+}
+
 // the pair records' self-check (mcx_fm.h fm_pair_step_agrees) on the host: trials that disagree
 extern "C" int64_t hostemu_pair_check(const char *prefix, int64_t trials)
 {

@@ -122,6 +122,14 @@ def test_straight_line_pairs_with_their_own_dp_problems(hostemu_lib, golden, tmp
     assert st[6] < st_no_dp[6] <= st_general[6]                                                        # DP problems left to the general path
 
 
+def test_pairing_sweep_equals_the_scan_of_all_pairs(hostemu_lib):
+    """pair_by_distance sweeps read 2's candidates in PosDiff order; on random candidate lists (ties, dead candidates, lists long enough
+    for RemoveRedundantAlnCan) it pairs the same candidates and reports the same interval of estimates as the scan of all n1 x n2 pairs."""
+    hostemu_lib.hostemu_pairing_check.restype = ctypes.c_int64
+    hostemu_lib.hostemu_pairing_check.argtypes = [ctypes.c_int64, ctypes.c_uint64]
+    assert hostemu_lib.hostemu_pairing_check(300000, 88172645463325252) == 0
+
+
 def test_small_batches_follow_the_avgdist_trajectory(hostemu_lib, golden, tmp_path):
     # 600-read batches: the insert-size estimate crosses batch boundaries
     out = str(tmp_path / "e.sam")
