@@ -347,6 +347,51 @@ static int run_selection(Emu &e, const Batch &b, const std::vector<uint32_t> &id
 
 } // namespace
 
+// the comparison phase of the seeding walk in its three forms (mcx_fm.h: seed_compare 16 bases per fetch, seed_compare_wide64 64,
+// seed_compare_wide 64 then 128 with the shared chunk kept): reads cut out of the text at random places — both strands, across the
+// strand boundary and the text's end — with a base changed or an N somewhere, compared from a random offset: trials whose forms disagree
+extern "C" int64_t hostemu_compare_check(const char *prefix, int64_t trials, uint64_t seed)
+{
+    Emu e;
+    std::string err;
+    if (!host_index_load(prefix, e.hix, err)) return -1;
+    set_view(e);
+    const IndexView &ix = e.view;
+    auto rnd = [&]() { seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17; return seed; };
+    int64_t bad = 0;
+    for (int64_t t = 0; t < trials; t++) {
+        const int rlen = 17 + (int)(rnd() % 400);
+        int64_t j0; // text position of the read's base 0
+        switch (rnd() % 4) {
+        case 0: j0 = ix.G - (int64_t)(rnd() % (uint64_t)(rlen + 40)); break;              // across the strand boundary
+        case 1: j0 = (int64_t)ix.seq_len - (int64_t)(rnd() % (uint64_t)(rlen + 40)); break; // up to (and past) the text's end
+        default: j0 = (int64_t)(rnd() % ix.seq_len); break;
+        }
+        if (j0 < 0) j0 = 0;
+        std::vector<uint8_t> ascii((size_t)rlen);
+        for (int i = 0; i < rlen; i++) ascii[(size_t)i] = "ACGT"[j0 + i < (int64_t)ix.seq_len ? ref_code(ix, j0 + i) : (int)(rnd() & 3)];
+        if (rnd() % 3) { const int at = (int)(rnd() % (uint64_t)rlen); ascii[(size_t)at] = rnd() % 4 == 0 ? 'N' : "ACGT"[(nt4_code(ascii[(size_t)at]) + 1 + (int)(rnd() % 3)) & 3]; }
+        ReadRef rd; rd.ascii = ascii.data(); rd.rlen = rlen; rd.flipped = 0; rd.codes = nullptr;
+        std::vector<uint32_t> words((size_t)packed_words(rlen) + 4);
+        PackedRead pk; pk.w = words.data(); pk.stride = 1; pk.n_code = 0;
+        pack_read(rd, pk);
+        const int start = (int)(rnd() % 8), p0 = start + (int)(rnd() % (uint64_t)(rlen - start));
+        int got[3];
+        for (int form = 0; form < 3; form++) {
+            SeedWalk w; w.x0 = w.x1 = 0; w.x2 = 1; w.tpos = j0 + start; w.carry = 0; w.carry_dir = 0; w.start = start; w.phase = 2; w.ended = 0;
+            int p = p0;
+            while (w.phase == 2) {
+                if (form == 0) seed_compare(ix, pk, rlen, p, w, 1 << 30);
+                else if (form == 1) seed_compare_wide64(ix, pk, rlen, p, w, 1 << 30);
+                else seed_compare_wide(ix, pk, rlen, p, w, 1 << 30);
+            }
+            got[form] = p;
+        }
+        if (got[0] != got[1] || got[0] != got[2]) bad++;
+    }
+    return bad;
+}
+
 // pair_by_distance (mcx_glue.h: read 2's candidates swept in PosDiff order) against the plain scan of all n1 x n2 pairs
 // (CheckPairedAlignmentDistance, ReadMapping.cpp:244-303) on random candidate lists in ascending PosDiff: trials that differ
 extern "C" int64_t hostemu_pairing_check(int64_t trials, uint64_t seed)

@@ -122,6 +122,15 @@ def test_straight_line_pairs_with_their_own_dp_problems(hostemu_lib, golden, tmp
     assert st[6] < st_no_dp[6] <= st_general[6]                                                        # DP problems left to the general path
 
 
+@pytest.mark.parametrize("name", ["toy", "mc"])
+def test_comparison_phase_forms_agree(hostemu_lib, golden, name):
+    """The seeding walk's comparison phase 16 bases per fetch, 64 per fetch and 64-then-128 with the shared chunk kept: the same end of the
+    seed for reads cut out of the text on both strands, across the strand boundary and the text's end, with a changed base or an N."""
+    hostemu_lib.hostemu_compare_check.restype = ctypes.c_int64
+    hostemu_lib.hostemu_compare_check.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_uint64]
+    assert hostemu_lib.hostemu_compare_check(golden[name]["prefix"].encode(), 200000, 2463534242) == 0
+
+
 def test_pairing_sweep_equals_the_scan_of_all_pairs(hostemu_lib):
     """pair_by_distance sweeps read 2's candidates in PosDiff order; on random candidate lists (ties, dead candidates, lists long enough
     for RemoveRedundantAlnCan) it pairs the same candidates and reports the same interval of estimates as the scan of all n1 x n2 pairs."""
