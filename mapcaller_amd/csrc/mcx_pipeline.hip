@@ -24,8 +24,6 @@
 #include <string>
 #include <type_traits>
 #include <vector>
-#include <map>
-#include <mutex>
 
 #include "../../include/mcx.h"
 #include "mcx_dp.h"
@@ -2073,37 +2071,6 @@ static Caps tier1_caps(int rlen_max)
     return c;
 }
 
-// Streams are kept when a context goes and handed to the next one: a context made after another one was closed ran 0.5-1 ms
-// per step slower — every launch of its chain began some 50 us later — when its streams were new ones (the runtime maps new
-// streams onto its hardware queues as it goes; the first context's streams got the good places).  MCX_NO_STREAM_POOL: as before.
-struct StreamKey { int device; unsigned flags; int priority; bool operator<(const StreamKey &o) const { return device != o.device ? device < o.device : (flags != o.flags ? flags < o.flags : priority < o.priority); } };
-static std::mutex g_stream_mu;
-static std::map<StreamKey, std::vector<hipStream_t>> g_stream_pool;
-static std::map<hipStream_t, StreamKey> g_stream_key;
-static hipError_t stream_get(hipStream_t *out, unsigned flags, int priority)
-{
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const StreamKey k{dev, flags, priority};
-    {
-        std::lock_guard<std::mutex> g(g_stream_mu);
-        auto &v = g_stream_pool[k];
-        if (!v.empty() && !getenv("MCX_NO_STREAM_POOL")) { *out = v.back(); v.pop_back(); return hipSuccess; }
-    }
-    const hipError_t e = hipStreamCreateWithPriority(out, flags, priority);
-    if (e == hipSuccess) { std::lock_guard<std::mutex> g(g_stream_mu); g_stream_key[*out] = k; }
-    return e;
-}
-static void stream_put(hipStream_t s)
-{
-    if (!s) return;
-    (void)hipStreamSynchronize(s);
-    std::lock_guard<std::mutex> g(g_stream_mu);
-    auto it = g_stream_key.find(s);
-    if (it == g_stream_key.end() || getenv("MCX_NO_STREAM_POOL")) { if (it != g_stream_key.end()) g_stream_key.erase(it); (void)hipStreamDestroy(s); return; }
-    g_stream_pool[it->second].push_back(s);
-}
-
 static std::atomic<size_t> g_dmalloc_bytes(0); // (MCX_TIMING: what a context takes)
 template <class T>
 static int dmalloc(T **p, size_t n, int line = __builtin_LINE())
@@ -2156,12 +2123,12 @@ static int rescue_alloc(mcx_ctx *c, uint64_t pairs, bool large, RescueTask **tas
 static int passres_alloc(mcx_ctx *c, PassRes &t, uint64_t pairs, uint64_t sel_cap, int priority)
 {
     int rc;
-    HIP_TRY(stream_get(&t.stream, hipStreamNonBlocking, priority));
+    HIP_TRY(hipStreamCreateWithPriority(&t.stream, hipStreamNonBlocking, priority));
     // side streams for the DP lists only where lists are long enough to share the chip: a stream that exists lands on one of the
     // runtime's few hardware queues, and a queue that waits for an event holds up every stream folded onto it (the late pairs' pass
     // once sat 4 ms behind the large tier's DP fork that way)
     const int n_side = pairs >= 4096 ? (getenv("MCX_DP_STREAMS") ? 5 : 2) : 0;
-    for (int k = 0; k < n_side; k++) { HIP_TRY(stream_get(&t.dp_stream[k], hipStreamNonBlocking, priority)); HIP_TRY(hipEventCreateWithFlags(&t.dp_join[k], hipEventDisableTiming)); }
+    for (int k = 0; k < n_side; k++) { HIP_TRY(hipStreamCreateWithPriority(&t.dp_stream[k], hipStreamNonBlocking, priority)); HIP_TRY(hipEventCreateWithFlags(&t.dp_join[k], hipEventDisableTiming)); }
     HIP_TRY(hipEventCreateWithFlags(&t.dp_fork, hipEventDisableTiming));
     for (auto &e : t.ev) HIP_TRY(hipEventCreate(&e));
     if ((rc = dmalloc(&t.d_cnt, CNT_ALL))) return rc;
@@ -2195,9 +2162,9 @@ static void passres_free(PassRes &t)
     for (void *x : q) if (x) (void)hipFree(x);
     if (t.h_cnt) (void)hipHostFree(t.h_cnt);
     for (auto &e : t.ev) if (e) (void)hipEventDestroy(e);
-    for (int k = 0; k < 5; k++) { stream_put(t.dp_stream[k]); if (t.dp_join[k]) (void)hipEventDestroy(t.dp_join[k]); }
+    for (int k = 0; k < 5; k++) { if (t.dp_stream[k]) (void)hipStreamDestroy(t.dp_stream[k]); if (t.dp_join[k]) (void)hipEventDestroy(t.dp_join[k]); }
     if (t.dp_fork) (void)hipEventDestroy(t.dp_fork);
-    stream_put(t.stream);
+    if (t.stream) (void)hipStreamDestroy(t.stream);
 }
 
 static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
@@ -2208,8 +2175,8 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     c->max_reads = (uint64_t)o.max_batch_reads;
     c->max_bases = c->max_reads * (uint64_t)c->rlen_max;
     HIP_TRY(hipSetDevice(idx->device));
-    HIP_TRY(stream_get(&c->stream, hipStreamDefault, 0));
-    for (int k = 0; k < (getenv("MCX_DP_STREAMS") ? 5 : 2); k++) { HIP_TRY(stream_get(&c->dp_stream[k], hipStreamNonBlocking, 0)); HIP_TRY(hipEventCreateWithFlags(&c->dp_join[k], hipEventDisableTiming)); }
+    HIP_TRY(hipStreamCreate(&c->stream));
+    for (int k = 0; k < (getenv("MCX_DP_STREAMS") ? 5 : 2); k++) { HIP_TRY(hipStreamCreateWithFlags(&c->dp_stream[k], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&c->dp_join[k], hipEventDisableTiming)); }
     HIP_TRY(hipEventCreateWithFlags(&c->dp_fork, hipEventDisableTiming));
     for (auto &e : c->ev_pack) HIP_TRY(hipEventCreate(&e));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
@@ -2328,11 +2295,11 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
         for (void *x : q) if (x) (void)hipFree(x);
         for (hipEvent_t e : {sl.in_ready, sl.mapped, sl.out_done}) if (e) (void)hipEventDestroy(e);
     }
-    stream_put(c->h2d_stream);
-    stream_put(c->d2h_stream);
+    if (c->h2d_stream) (void)hipStreamDestroy(c->h2d_stream);
+    if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
-    stream_put(c->stream);
-    for (int k = 0; k < 5; k++) { stream_put(c->dp_stream[k]); if (c->dp_join[k]) (void)hipEventDestroy(c->dp_join[k]); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (int k = 0; k < 5; k++) { if (c->dp_stream[k]) (void)hipStreamDestroy(c->dp_stream[k]); if (c->dp_join[k]) (void)hipEventDestroy(c->dp_join[k]); }
     if (c->dp_fork) (void)hipEventDestroy(c->dp_fork);
     for (auto &e : c->ev_pack) if (e) (void)hipEventDestroy(e);
     delete c;
@@ -3270,8 +3237,8 @@ static int stream_slot(mcx_ctx *c, mcx_ctx::Slot **out)
     if (!sl) return fail(MCX_ERR_ARG, "mcx_stream_submit: three batches are in flight (collect one first)");
     int rc;
     if (!c->h2d_stream) {
-        HIP_TRY(stream_get(&c->h2d_stream, hipStreamNonBlocking, 0));
-        HIP_TRY(stream_get(&c->d2h_stream, hipStreamNonBlocking, 0));
+        HIP_TRY(hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
     }
     if (!sl->d_bases) {
         if ((rc = dmalloc(&sl->d_bases, c->max_bases + 16 * c->max_reads + 64))) return rc; // (+16 per read: packed rows end on a word)
