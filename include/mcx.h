@@ -44,9 +44,10 @@ int mcx_device_count(void);
 #define MCX_INDEX_SAMPLED 0
 #define MCX_INDEX_FULL 1
 #define MCX_INDEX_PAIRS 2
+#define MCX_INDEX_PAIRS_IF_ROOM 3 /* the pair records when the device has room for them; else MCX_INDEX_FULL with one line on stderr */
 int mcx_index_load(const char *prefix, int device, int full_sa, mcx_index **out);
 /* Gives back what the index holds above the level `full_sa` (MCX_INDEX_FULL: the pair records), e.g. before the
- * alignment profile's planes are attached.  Contexts made before the call must have been freed. */
+ * alignment profile's planes are attached.  Refused (MCX_ERR_ARG) while a context of the index is alive. */
 int mcx_index_trim(mcx_index *, int full_sa);
 /* Replaces bwa_idx_build (reference src/BWT_Index/bwtindex.c:77; `MapCaller index ref.fa prefix`,
  * src/main.cpp:199-207): builds BWT/occ/SA on the GPU from a FASTA file and writes the same

@@ -101,6 +101,17 @@ class SparseRec(C.Structure):
 PLANES = ("A", "C", "G", "T", "multi_hit", "readCount", "F1", "R2", "F2", "R1")
 
 
+def planes_alloc(G: int, device):
+    """Zeroed HBM for the ten counter planes of a genome of G positions (what profile_attach takes)."""
+    import torch
+    return torch.zeros((10, G), dtype=torch.int32, device=device)
+
+
+def planes_view(planes, G: int, lo: int = 0, hi: Optional[int] = None):
+    """The positions [lo, hi) of all ten planes as int32 [10, hi - lo] (PLANES order)."""
+    return planes[:, lo:G if hi is None else hi]
+
+
 class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("reads", "mapped", "pairs", "pair_dist_sum", "pair_len_sum", "fm_ext_steps", "fm_blocks",
                                          "sa_hits", "dp_jobs", "dp_cells", "tier1_pairs", "replayed_pairs", "halved_selections", "simple_pairs")] + \

@@ -1351,7 +1351,7 @@ static inline MCX_HD void write_detail(const Ctx &cx, PairState &st, int s, uint
     DetailHdr &d = *(DetailHdr *)rec;
     Frag *df = (Frag *)(rec + sizeof(DetailHdr));
     uint8_t *dops = rec + cx.dlay.off_ops;
-    d.type = 0; d.n_frags = 0; d.fwd = 1; d.n_ops = 0;
+    d.type = 0; d.n_frags = 0; d.fwd = 1; d.n_ops = 0; d.frag0 = 0;
     if (h.sum[s].score == 0) return;
     const Cand *cs = st.cands[s];
     int live = 0, one = -1;

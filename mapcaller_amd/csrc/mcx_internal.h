@@ -5,6 +5,7 @@
 #include "mcx_host.h"
 #include "mcx_build.h"
 #include "../../include/mcx.h"
+#include <atomic>
 
 struct mcx_index {
     mcx::IndexView view;
@@ -17,6 +18,7 @@ struct mcx_index {
     int pair_records = 0;
     int64_t hbm_bytes = 0;
     uint64_t n_bwt_words = 0, n_sa = 0; // set for indexes built in HBM (mcx_index_from_codes)
+    mutable std::atomic<int> n_ctx{0};  // contexts alive on this index (mcx_ctx_create / mcx_ctx_free): mcx_index_trim refuses while there are any
 };
 
 // what the file front end (mcx_files.cpp) needs to know about a context

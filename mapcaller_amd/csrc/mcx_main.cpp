@@ -195,7 +195,7 @@ int main(int argc, char **argv)
         if (want_vcf && mcx_comm_init_all(n_gpus, devices.data(), comms.data())) { fprintf(stderr, "Error! %s\n", mcx_last_error()); return 1; }
     }
     const bool paired_run = !f2.empty() || fo.interleaved_pairs;
-    if (!want_vcf && full_sa == 1) full_sa = 2; // (no planes: room for the pair records)
+    if (!want_vcf && full_sa == 1) full_sa = MCX_INDEX_PAIRS_IF_ROOM; // (no planes: room for the pair records, usually — a device that is too full keeps the one-base walk; -two_base insists)
     auto work = [&](int r) {
         Shard &sh = shards[(size_t)r];
         sh.rank = r; sh.device = devices[(size_t)r];

@@ -174,6 +174,16 @@ static int build_rank(mcx_index *ix)
     if (!ix->pair_records || getenv("MCX_NO_RANK2")) return 0;
     const char *chk = getenv("MCX_RANK2_CHECK");
     const int rc = mcx_build_pair_records(ix->view, &ix->d_rank2, &ix->d_rank2_c2, &ix->rank2_bytes, chk ? atoi(chk) : 0);
+    if (rc && ix->pair_records == MCX_INDEX_PAIRS_IF_ROOM) {
+        // nobody asked for the records by name (the CLI without -vcf takes them when there is room): a device that is too full for them
+        // — several shards on it, a smaller part — keeps the one-base walk, which needs nothing more
+        fprintf(stderr, "[mcx] the pair records do not fit this device (%s): the seeding walk takes one base per step\n", g_err.c_str());
+        (void)hipGetLastError();
+        g_err.clear();
+        ix->d_rank2 = ix->d_rank2_c2 = nullptr; ix->rank2_bytes = 0;
+        ix->view.rank2 = nullptr; ix->view.rank2_c2 = nullptr;
+        return 0;
+    }
     if (rc) return rc;
     ix->hbm_bytes += ix->rank2_bytes;
     return 0;
@@ -229,7 +239,7 @@ extern "C" int mcx_index_load(const char *prefix, int device, int full_sa, mcx_i
     ix->device = device;
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { delete ix; return fail(MCX_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e)); }
-    ix->pair_records = full_sa >= 2;
+    ix->pair_records = full_sa >= 2 ? full_sa : 0;
     int rc = index_to_device(ix, full_sa);
     if (rc) { mcx_index_free(ix); return rc; }
     *out = ix;
@@ -266,7 +276,7 @@ extern "C" int mcx_index_from_codes(const uint8_t *d_codes, int32_t n_chr, const
     DevIndexArrays arr;
     int rc = mcx_build_suffix_index(d_codes, (uint64_t)G, full_sa != 0, arr, build_seconds);
     if (rc) { delete ix; return rc; }
-    ix->pair_records = full_sa >= 2;
+    ix->pair_records = full_sa >= 2 ? full_sa : 0;
     rc = index_from_arrays(ix, arr, d_codes, G);
     if (rc) { mcx_index_free(ix); return rc; }
     *out = ix;
@@ -362,6 +372,8 @@ extern "C" int mcx_index_trim(mcx_index *ix, int full_sa)
     if (!ix) return fail(MCX_ERR_ARG, "mcx_index_trim: null argument");
     if (full_sa < 1) return fail(MCX_ERR_UNSUPPORTED, "mcx_index_trim: only the pair records can be released (full_sa = 1)");
     if (full_sa >= 2 || !ix->d_rank2) return 0;
+    // a context keeps pointers into what goes (the view it copies per pass, a batch under way): none may be alive
+    if (ix->n_ctx.load() > 0) return fail(MCX_ERR_ARG, "mcx_index_trim: " + std::to_string(ix->n_ctx.load()) + " context(s) of this index are still open; free them first");
     HIP_TRY(hipSetDevice(ix->device));
     HIP_TRY(hipDeviceSynchronize());
     (void)hipFree(ix->d_rank2); (void)hipFree(ix->d_rank2_c2);
@@ -541,7 +553,6 @@ __global__ void __launch_bounds__(256) k_pack_reads(ReadBatch rb, int paired, in
 constexpr int kSeedReadsPerLane = 4; // reads per lane and chunk (small selections: one, their launch is as long as its longest chain of reads)
 
 // FM steps a lane takes before the wave looks at its other lanes again (MCX_SEED_FM_BUDGET for experiments)
-static inline int seed_fm_budget() { const char *e = getenv("MCX_SEED_FM_BUDGET"); return e ? std::max(1, atoi(e)) : 6; }
 
 static inline int seed_reads_per_lane(uint64_t n_reads) { return n_reads >= (uint64_t)1 << 21 ? kSeedReadsPerLane : (n_reads >= (uint64_t)1 << 19 ? 2 : 1); }
 
@@ -551,7 +562,7 @@ static inline int seed_reads_per_lane(uint64_t n_reads) { return n_reads >= (uin
 #ifdef MCX_SEED_STATS
 __device__ unsigned long long g_seed_hist[2][24]; // reads / index blocks by blocks per read (bucket = bit length of the count)
 #endif
-__global__ void __launch_bounds__(256, MCX_SEED_WAVES) k_seed(Ctx cx, ReadBatch rb, PairSel sel, SeedOut so, int pk_words, int reads_per_lane, int fm_budget, int wide)
+__global__ void __launch_bounds__(256, MCX_SEED_WAVES) k_seed(Ctx cx, ReadBatch rb, PairSel sel, SeedOut so, int pk_words, int reads_per_lane, int fm_budget)
 {
     extern __shared__ uint32_t pk_lds[]; // packed reads: word k of lane t at pk_lds[k * blockDim.x + t]
     const int nr = cx.pm.paired ? 2 : 1;
@@ -613,7 +624,9 @@ __global__ void __launch_bounds__(256, MCX_SEED_WAVES) k_seed(Ctx cx, ReadBatch 
             hits = pair_state(cx.state, cx.lay, cx.caps, lr / nr).hits[lr % nr];
             n = 0; p = 0; ext = 0; blocks = 0; has_n = 0; walk.phase = 0;
             const int words = packed_words(rlen);
-            if (so.src_state && !(so.read_ext[r] >> 31)) {
+            // (only when neither read of the pair holds an N: such a pair went through k_rescue in tier 0, whose rescue_mate appends seeds to the
+            //  N-free read's hits — the same test as k_rescue_plan's)
+            if (so.src_state && !((so.read_ext[r] | (nr == 2 ? so.read_ext[r ^ 1u] : 0u)) >> 31)) {
                 // (the list as k_cluster left it: PosDiff > 0 only, sorted — clustering it again gives the same candidates; the entries the
                 //  filter dropped are made up by entries it drops again, so that the read's hit count, a statistic, stays what the search found)
                 const PairState src = pair_state((uint8_t *)so.src_state, so.src_lay, so.src_caps, r / nr);
@@ -652,7 +665,7 @@ __global__ void __launch_bounds__(256, MCX_SEED_WAVES) k_seed(Ctx cx, ReadBatch 
         //      (dozens of FM steps) holds the wave up for a few steps at a time while the others finish searches and take new reads ----
         if (have && walk.phase == 0) seed_begin(cx.ix, pk, rlen, nm, p, walk);
         if (have && walk.phase == 1) seed_fm(cx.ix, pk, rlen, p, walk, blocks, fm_budget);
-        if (have && walk.phase == 2) { if (wide == 1) seed_compare_wide(cx.ix, pk, rlen, p, walk, 1 << 30); else if (wide) seed_compare_wide64(cx.ix, pk, rlen, p, walk, 1 << 30); else seed_compare(cx.ix, pk, rlen, p, walk, 1 << 30); }
+        if (have && walk.phase == 2) seed_compare_wide(cx.ix, pk, rlen, p, walk, 1 << 30);
         if (have && walk.phase == 3) {
             seed_take(cx.ix, p, walk, hits, cap, n, ext);
             if (!seed_next_start(pk, rlen, p, nm)) { finish_read(); have = false; }
@@ -773,7 +786,9 @@ struct SimpleLater {        // the pairs that wait, and their problems
     uint32_t cap;
 };
 
-template <bool NW, int MODE>
+// DETAIL (the -vcf bookkeeping is on): the pair's two detail records — what write_detail leaves for a read with one surviving candidate, and
+// pair_stats' discordant-pair fields in read 1's — come from here too (mcx_simple.h SimpleDetail), so that the profile does not switch the path off.
+template <bool NW, int MODE, bool DETAIL>
 __global__ void __launch_bounds__(256) k_simple(Ctx cx, ReadBatch rb, uint32_t n_pairs, const int32_t *est, const uint32_t *read_blocks, AlnRec *recs, PairOut *pout,
                                                 uint8_t *done, uint32_t *pool_over, uint32_t *n_done, SimpleLater sl)
 {
@@ -789,6 +804,7 @@ __global__ void __launch_bounds__(256) k_simple(Ctx cx, ReadBatch rb, uint32_t n
     const uint32_t pair = MODE == kDpReplay ? (ok ? sl.pairs[slot] : 0u) : slot;
     SimpleRead sr[2];
     int rl[2] = {0, 0};
+    typename std::conditional<DETAIL, SimpleDetail, SimpleNoDetail>::type det;
     SimpleDpIo io;
     io.mode = MODE == kDpCollect && !sl.pairs ? kDpNone : MODE;
     io.jobs = MODE == kDpCollect ? job_stage + threadIdx.x : nullptr; io.job_stride = 256;
@@ -806,7 +822,8 @@ __global__ void __launch_bounds__(256) k_simple(Ctx cx, ReadBatch rb, uint32_t n
                 io.read = r;
                 ok = nh >= 1 && nh <= kSimpleHits && !(cx.read_ext[r] >> 31);
                 if (ok) {
-                    const int how = simple_read<NW, uint16_t>(cx.ix, cx.pm, rl[s], cx.packed + (uint64_t)r * cx.wpad, st.hits[s], nh, sr[s], stage + s * kSimpleRuns * 256, 256, io);
+                    if constexpr (DETAIL) { uint8_t *rec = cx.detail + (uint64_t)r * cx.dlay.stride; det.frags = (Frag *)(rec + sizeof(DetailHdr)); det.ops = rec + cx.dlay.off_ops; }
+                    const int how = simple_read<NW, uint16_t>(cx.ix, cx.pm, rl[s], cx.packed + (uint64_t)r * cx.wpad, st.hits[s], nh, sr[s], stage + s * kSimpleRuns * 256, 256, io, det);
                     ok = how != kSimpleNo;
                     later = later || how == kSimpleLater;
                 }
@@ -851,6 +868,14 @@ __global__ void __launch_bounds__(256) k_simple(Ctx cx, ReadBatch rb, uint32_t n
     recs[(uint64_t)pair * nr] = rec2[0];
     if (nr == 2) recs[(uint64_t)pair * nr + 1] = rec2[1];
     pout[pair] = po;
+    if constexpr (DETAIL) {
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            if (s >= nr) break;
+            const DetailHdr d = simple_detail_hdr(cx.ix, nr == 2, s, sr[0], sr[nr - 1]);
+            *(DetailHdr *)(cx.detail + ((uint64_t)pair * nr + s) * cx.dlay.stride) = d;
+        }
+    }
 }
 
 // the problems the straight-line pairs wrote down, one per lane (mcx_simple.h simple_dp_job): a strip of 16 columns, the lane's
@@ -1440,14 +1465,15 @@ __global__ void __launch_bounds__(256, MCX_BUILD_WAVES) k_build(Ctx cx, ReadBatc
 //     multiples of 8) and its places in the pass's job lists (one atomic per list and round), and the lane writes its problems there.
 // Same fragments, same kinds, same DP problems as stage_build; only where they lie in the pair's pools differs, which no result sees.
 // mode: as k_build's.
-__global__ void __launch_bounds__(64) k_build_wave(Ctx cx, ReadBatch rb, PairSel sel, JobSinks sinks, uint32_t *cells, uint32_t *unsupported, int mode, RescueList rl)
+// lane_limit: the pairs whose bounds come to more than this are built by one lane as well (tests: 0 sends every pair that way)
+__global__ void __launch_bounds__(64) k_build_wave(Ctx cx, ReadBatch rb, PairSel sel, JobSinks sinks, uint32_t *cells, uint32_t *unsupported, int mode, RescueList rl, int lane_limit)
 {
-    extern __shared__ int32_t bw_lds[]; // score[2][cand_cap], mate[2][cand_cap]
+    extern __shared__ int32_t bw_lds[]; // score[2][cand_cap], mate[2][cand_cap], seeds[2][cand_cap]
     __shared__ EndsLds ends;
     stage_ends(cx.ix, ends);
     const int lane = threadIdx.x;
     const int nr = cx.pm.paired ? 2 : 1, cap = cx.caps.cand_cap;
-    int32_t *sc[2] = {bw_lds, bw_lds + cap}, *mt[2] = {bw_lds + 2 * cap, bw_lds + 3 * cap};
+    int32_t *sc[2] = {bw_lds, bw_lds + cap}, *mt[2] = {bw_lds + 2 * cap, bw_lds + 3 * cap}, *cn[2] = {bw_lds + 4 * cap, bw_lds + 5 * cap};
     auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_s_barrier(); };
     auto wave_max = [](int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64)); return v; };
     auto wave_sum = [](uint32_t v) { for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64); return v; };
@@ -1468,7 +1494,7 @@ __global__ void __launch_bounds__(64) k_build_wave(Ctx cx, ReadBatch rb, PairSel
         make_reads(cx, rb, sel_pair(sel, local), rd);
         // ---- scores and mates into LDS; the masks of ReadMapping.cpp:469-470 (keep_top_scores / mask_unpaired)
         wave_sync();
-        for (int s = 0; s < nr; s++) for (int i = lane; i < n_c[s]; i += 64) { const Cand c = st.cands[s][i]; sc[s][i] = c.score; mt[s][i] = c.mate; }
+        for (int s = 0; s < nr; s++) for (int i = lane; i < n_c[s]; i += 64) { const Cand c = st.cands[s][i]; sc[s][i] = c.score; mt[s][i] = c.mate; cn[s][i] = c.count; }
         wave_sync();
         auto keep_top = [&](int s) {
             if (n_c[s] <= 1) return;
@@ -1486,6 +1512,28 @@ __global__ void __launch_bounds__(64) k_build_wave(Ctx cx, ReadBatch rb, PairSel
             for (int j = lane; j < n_c[1]; j += 64) if (mt[1][j] == -1 || sc[1][j] + sc[0][mt[1][j]] < top) sc[1][j] = 0;  // (read 1's as the loop above left them)
         } else { keep_top(0); if (cx.pm.paired) keep_top(1); }
         wave_sync();
+        // ---- the fragments are placed by their bounds (2 seeds + 2 per live candidate), stage_build places them densely: when the bounds of
+        //      all live candidates fit the pool both ways fit; when they do not, the pair is built stage_build's way, by one lane — the same
+        //      fragments wherever they lie, and the same answer to "does this pair fit the tier" (a pair that does not is fatal for the batch)
+        {
+            uint32_t tb = 0;
+            for (int s = 0; s < nr; s++) for (int i = lane; i < n_c[s]; i += 64) if (sc[s][i] != 0) tb += 2u * (uint32_t)cn[s][i] + 2u;
+            tb = wave_sum(tb);
+            if (tb > (uint32_t)min(cx.caps.frag_cap, lane_limit)) {
+                if (lane == 0) {
+                    const int nj = stage_build(cx, local, rd);
+                    for (int k = 0; k < nj; k++) {
+                        const DpJob j = pair_job(cx, local, k);
+                        const int q = job_class(j);
+                        if (q < 0) { bad++; continue; }
+                        my_cells += (uint32_t)(j.rLen * j.gLen);
+#pragma unroll
+                        for (int c = 0; c < kDpClasses; c++) if (q == c) { const uint32_t at = atomicAdd(sinks.s[c].count, 1u); if (at < sinks.s[c].cap) sinks.s[c].jobs[at] = j; }
+                    }
+                }
+                continue;
+            }
+        }
         // ---- the candidates, a lane each, in stage_build's order
         uint32_t flags = h.flags, n_frags = 0, n_ops = 0, n_jobs = 0;
         const int total = n_c[0] + n_c[1];
@@ -1919,6 +1967,31 @@ __global__ void __launch_bounds__(256, MCX_FINISH_WAVES) k_finish(Ctx cx, ReadBa
 // ---------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------
+// The MCX_* switches of DESIGN §3 (none changes a result), read ONCE when a context is made: nothing in the launch path asks the
+// environment.  What was measured slower and served no test is gone (the heavy pairs clustered first, one DP stream per list, the
+// ungrouped wavefront DP, the narrow comparison windows of the seeding walk, mate rescue a workgroup per pair for every pair).
+struct Knobs {
+    bool timing = false, seed_one_base = false, dp_by_wave = false, dp_lane_always = false, late_reseed = false, no_work_order = false, no_simple = false,
+         simple_no_dp = false, cluster_by_lane = false, rescue_in_line = false, build_by_lane = false, no_sums_cache = false, prof_by_column = false,
+         tier1_hist = false, dp_hist = false, no_tier_overlap = false, no_late_overlap = false;
+    int seed_fm_budget = 6, build_wave_limit = 0x7fffffff;
+    uint32_t order_min = 16384u;
+};
+static Knobs knobs_read()
+{
+    Knobs k;
+    auto on = [](const char *name) { return getenv(name) != nullptr; };
+    k.timing = on("MCX_TIMING"); k.seed_one_base = on("MCX_SEED_ONE_BASE"); k.dp_by_wave = on("MCX_DP_BY_WAVE"); k.dp_lane_always = on("MCX_DP_LANE_ALWAYS");
+    k.late_reseed = on("MCX_LATE_RESEED"); k.no_work_order = on("MCX_NO_WORK_ORDER"); k.no_simple = on("MCX_NO_SIMPLE"); k.simple_no_dp = on("MCX_SIMPLE_NO_DP");
+    k.cluster_by_lane = on("MCX_CLUSTER_BY_LANE"); k.rescue_in_line = on("MCX_RESCUE_IN_LINE"); k.build_by_lane = on("MCX_BUILD_BY_LANE");
+    k.no_sums_cache = on("MCX_NO_SUMS_CACHE"); k.prof_by_column = on("MCX_PROF_BY_COLUMN"); k.tier1_hist = on("MCX_TIER1_HIST"); k.dp_hist = on("MCX_DP_HIST");
+    k.no_tier_overlap = on("MCX_NO_TIER_OVERLAP"); k.no_late_overlap = on("MCX_NO_LATE_OVERLAP");
+    if (const char *e = getenv("MCX_SEED_FM_BUDGET")) k.seed_fm_budget = std::max(1, atoi(e));
+    if (const char *e = getenv("MCX_BUILD_WAVE_LIMIT")) k.build_wave_limit = atoi(e); // (tests: the bound sum from which k_build_wave hands a pair to one lane)
+    if (const char *e = getenv("MCX_ORDER_MIN")) k.order_min = (uint32_t)std::max(1, atoi(e)); // (tests: small batches through k_simple and the order too)
+    return k;
+}
+
 struct Tier {
     Caps caps;
     Layout lay;
@@ -1972,6 +2045,8 @@ struct BatchRun { // the batch between mcx_batch_begin and mcx_batch_end
 
 struct mcx_ctx {
     const mcx_index *idx = nullptr;
+    bool counted = false; // (among idx->n_ctx)
+    Knobs kn;
     Params pm;
     mcx_opts opts;
     hipStream_t stream = nullptr;
@@ -2052,10 +2127,6 @@ static Caps tier0_caps()
     Caps c; c.hit_cap = 88; c.hit_seed = 56; c.cand_cap = 24; c.cand_seed = 12; // (rescue adds at most one candidate per candidate of the mate)
     c.frag_cap = 96; c.ops_cap = 2048; c.job_cap = 32;
     c.cig_cap = MCX_CIGAR_STRIDE; c.kmer_cap = 2048;
-    if (const char *e = getenv("MCX_TIER0_CAPS")) { // experiments: "hits,cands,frags,ops"
-        int a, b, d, f;
-        if (sscanf(e, "%d,%d,%d,%d", &a, &b, &d, &f) == 4) { c.hit_cap = c.hit_seed = a; c.cand_cap = c.cand_seed = b; c.frag_cap = d; c.ops_cap = f; }
-    }
     return c;
 }
 static Caps tier1_caps(int rlen_max)
@@ -2093,11 +2164,13 @@ extern "C" int mcx_ctx_create(const mcx_index *idx, const mcx_opts *opts, mcx_ct
     if (o.max_read_len > 1000) return fail(MCX_ERR_UNSUPPORTED, "max_read_len > 1000 is not supported");
     if (o.max_batch_reads < 2) o.max_batch_reads = 2;
     mcx_ctx *c = new mcx_ctx();
+    c->kn = knobs_read();
     for (auto &e : c->ev) e = nullptr;
     const size_t before = g_dmalloc_bytes.load();
     const int rc = ctx_fill(c, idx, o);
-    if (getenv("MCX_TIMING")) fprintf(stderr, "[mcx_ctx_create] %.2f GB of HBM for batches of %lld reads of up to %d bases\n", (double)(g_dmalloc_bytes.load() - before) / 1e9, (long long)o.max_batch_reads, (int)o.max_read_len);
+    if (c->kn.timing) fprintf(stderr, "[mcx_ctx_create] %.2f GB of HBM for batches of %lld reads of up to %d bases\n", (double)(g_dmalloc_bytes.load() - before) / 1e9, (long long)o.max_batch_reads, (int)o.max_read_len);
     if (rc) { mcx_ctx_free(c); return rc; } // (every pointer of the context starts null: a caller that retries with a smaller batch finds the HBM free again)
+    idx->n_ctx++; c->counted = true;
     *out = c;
     return 0;
 }
@@ -2127,7 +2200,7 @@ static int passres_alloc(mcx_ctx *c, PassRes &t, uint64_t pairs, uint64_t sel_ca
     // side streams for the DP lists only where lists are long enough to share the chip: a stream that exists lands on one of the
     // runtime's few hardware queues, and a queue that waits for an event holds up every stream folded onto it (the late pairs' pass
     // once sat 4 ms behind the large tier's DP fork that way)
-    const int n_side = pairs >= 4096 ? (getenv("MCX_DP_STREAMS") ? 5 : 2) : 0;
+    const int n_side = pairs >= 4096 ? 2 : 0;
     for (int k = 0; k < n_side; k++) { HIP_TRY(hipStreamCreateWithPriority(&t.dp_stream[k], hipStreamNonBlocking, priority)); HIP_TRY(hipEventCreateWithFlags(&t.dp_join[k], hipEventDisableTiming)); }
     HIP_TRY(hipEventCreateWithFlags(&t.dp_fork, hipEventDisableTiming));
     for (auto &e : t.ev) HIP_TRY(hipEventCreate(&e));
@@ -2176,7 +2249,7 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     c->max_bases = c->max_reads * (uint64_t)c->rlen_max;
     HIP_TRY(hipSetDevice(idx->device));
     HIP_TRY(hipStreamCreate(&c->stream));
-    for (int k = 0; k < (getenv("MCX_DP_STREAMS") ? 5 : 2); k++) { HIP_TRY(hipStreamCreateWithFlags(&c->dp_stream[k], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&c->dp_join[k], hipEventDisableTiming)); }
+    for (int k = 0; k < 2; k++) { HIP_TRY(hipStreamCreateWithFlags(&c->dp_stream[k], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&c->dp_join[k], hipEventDisableTiming)); }
     HIP_TRY(hipEventCreateWithFlags(&c->dp_fork, hipEventDisableTiming));
     for (auto &e : c->ev_pack) HIP_TRY(hipEventCreate(&e));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
@@ -2251,19 +2324,18 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     HIP_TRY(hipMemcpy(c->d_mapq, tab.data(), tab.size(), hipMemcpyHostToDevice));
     // the large tier's own stream, counters and lists: with them it maps the heavy pairs of a pass while the pass goes on
     // (without the full suffix array it would also need an SA task list of its own: then the tiers run one after the other)
-    if (idx->view.sa_full && !getenv("MCX_NO_TIER_OVERLAP")) {
+    if (idx->view.sa_full && !c->kn.no_tier_overlap) {
         // its kernels are as long as their slowest pair, and the batch waits for them: their waves go first
         // (human-like bench genome: 40.0 -> 37.4 ms per step)
         int pr_lo = 0, pr_hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
-        if (getenv("MCX_TIER1_NO_PRIORITY")) pr_hi = pr_lo > 0 ? 0 : pr_lo; // (experiments)
         if ((rc = passres_alloc(c, c->t1, c->tier[1].max_pairs, c->max_reads, pr_hi))) return rc;
         c->t1.d_kscratch = c->d_kscratch + (size_t)kRescueBlocks * kRescueScratchWords;
         HIP_TRY(hipEventCreate(&c->ev_clustered));
         c->overlap_tiers = true;
         // and a small third set for the pairs that run over after clustering: they go through the large tier while the pass's
         // DP and finish stages run, in the last kLateRoom records of the tier, instead of in a pass of their own after it
-        if (c->tier[1].max_pairs >= 4 * kLateRoom && !getenv("MCX_NO_LATE_OVERLAP")) {
+        if (c->tier[1].max_pairs >= 4 * kLateRoom && !c->kn.no_late_overlap) {
             if ((rc = passres_alloc(c, c->t2, kLateRoom, kLateRoom, pr_hi))) return rc;
             c->t2.d_kscratch = c->d_kscratch + 2 * (size_t)kRescueBlocks * kRescueScratchWords;
             HIP_TRY(hipEventCreateWithFlags(&c->ev_built, hipEventDisableTiming));
@@ -2277,6 +2349,7 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
 extern "C" void mcx_ctx_free(mcx_ctx *c)
 {
     if (!c) return;
+    if (c->counted && c->idx) c->idx->n_ctx--;
     if (c->files_state && c->files_drop) c->files_drop(c->files_state);
     void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3], c->d_jobs[4], c->d_jobs[5],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_rtasks, c->d_rres, c->d_rseeds, c->d_rplans, c->d_rescue_n, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
@@ -2309,7 +2382,7 @@ static Ctx make_ctx(const mcx_ctx *c, int tier, int paired)
 {
     Ctx cx;
     cx.ix = c->idx->view; cx.pm = c->pm; cx.pm.paired = paired;
-    if (getenv("MCX_SEED_ONE_BASE")) cx.ix.rank2 = nullptr; // (experiments, tests: the walk one base per step although the pair records are there)
+    if (c->kn.seed_one_base) cx.ix.rank2 = nullptr; // (experiments, tests: the walk one base per step although the pair records are there)
     cx.caps = c->tier[tier].caps; cx.lay = c->tier[tier].lay; cx.state = c->tier[tier].state;
     cx.mapq_tab = c->d_mapq; cx.mapq_rows = c->mapq_rows; cx.dp_summary = 1;
     cx.detail = c->prof_planes ? c->d_detail : nullptr; cx.dlay = c->dlay;
@@ -2349,35 +2422,36 @@ static PassRes res_tier0(mcx_ctx *c)
 // once: k_dp_group below kDpLaneMin problems, k_dp_lane from there on.
 constexpr uint32_t kDpLaneMin[2] = {65536, 131072}; // targets of 17-64 bases (mean 45 x 45 cells), of 65-256 (95 x 95): two wavefronts per SIMD's worth of problems
 
-static int launch_dp(const PassRes &R, const Ctx &cx, const JobSinks &sinks, const ReadBatch &rb, const PairSel &sel, int rlen_max)
+static int launch_dp(const Knobs &kn, const PassRes &R, const Ctx &cx, const JobSinks &sinks, const ReadBatch &rb, const PairSel &sel, int rlen_max)
 {
     hipStream_t s = R.stream;
     // three chains of about the same length (the runtime folds streams onto a few hardware queues anyway: more streams only
     // make the pairing of kernels on a queue a matter of luck); a set of pass resources without side streams runs them in turn
-    const bool wide = R.dp_stream[4] != nullptr; // (MCX_DP_STREAMS at context creation: one stream per kernel)
-    const int n_side = wide ? 5 : (R.dp_stream[1] ? 2 : 0);
+    const int n_side = R.dp_stream[1] ? 2 : 0;
     hipStream_t side0 = n_side ? R.dp_stream[0] : s, side1 = n_side ? R.dp_stream[1] : s;
     HIP_TRY(hipEventRecord(R.dp_fork, s));
     for (int k = 0; k < n_side; k++) HIP_TRY(hipStreamWaitEvent(R.dp_stream[k], R.dp_fork, 0));
-    const bool by_wave = getenv("MCX_DP_BY_WAVE") != nullptr; // (experiments, and the A/B of the parity tests: the wavefront-per-problem kernels of mcx_dp.h)
+    const bool by_wave = kn.dp_by_wave; // (experiments, and the A/B of the parity tests: the wavefront-per-problem kernels of mcx_dp.h)
     if (!by_wave) {
         // every list but the largest problems': one problem per lane (mcx_dp_lane.h).  A list's stretch of scratch per wavefront is
         // sized for its largest possible group; the two long lists share the wavefront kernels' buffers
         const bool nw = cx.pm.use_nw != 0;
         uint32_t *unsup = sinks.unsupported;
-        const bool always = getenv("MCX_DP_LANE_ALWAYS") != nullptr;
+        const bool always = kn.dp_lane_always;
         uint32_t lane_min[2] = {always ? 0u : kDpLaneMin[0], always ? 0u : kDpLaneMin[1]};
-        if (const char *e = getenv("MCX_DP_LANE_MIN0")) lane_min[0] = (uint32_t)atoll(e); // (experiments)
-        if (const char *e = getenv("MCX_DP_LANE_MIN1")) lane_min[1] = (uint32_t)atoll(e);
         const uint64_t w1 = lane_stride_words<16>(nw, rlen_max, 4), w2 = lane_stride_words<16>(nw, rlen_max, 16);
         const unsigned b1 = (unsigned)std::min<uint64_t>(4096, R.dp_stride[0] * R.dp_blocks[0] / (w1 * 4)), b2 = (unsigned)std::min<uint64_t>(4096, R.dp_stride[1] * R.dp_blocks[1] / (w2 * 4));
-        if (b1 == 0 || b2 == 0) return fail(MCX_ERR_CAPACITY, "the DP scratch is too small for one group of problems");
-        const bool by_shape = getenv("MCX_DP_NO_SORT") == nullptr; // (experiments: the lists as k_build left them)
+        // (a set of pass resources whose scratch does not hold one lane group for reads this long — the small sets with a large max_read_len —
+        //  leaves that list to the wavefront kernel whatever its length)
+        if (b1 == 0) lane_min[0] = 0xFFFFFFFFu;
+        if (b2 == 0) lane_min[1] = 0xFFFFFFFFu;
+        const bool by_shape = true;
         const uint32_t *ord[2] = {nullptr, nullptr};
         hipStream_t st[2] = {s, side1};
         if (by_shape) {
             const int row_shift = rlen_max <= 256 ? 4 : (rlen_max <= 512 ? 5 : 6); // (16 row classes cover the longest query)
             for (int k = 0; k < 2; k++) {
+                if (lane_min[k] == 0xFFFFFFFFu) continue;
                 uint32_t *counts = R.d_cnt + CNT_DP_SORT + 2 * kDpBuckets * k, *cursor = counts + kDpBuckets; // (cleared with the pass's counters)
                 k_dp_sort_count<<<1024, 256, 0, st[k]>>>(sinks.s[1 + k], row_shift, counts, lane_min[k]);
                 k_dp_sort_scan<<<1, 256, 0, st[k]>>>(counts, cursor);
@@ -2385,9 +2459,9 @@ static int launch_dp(const PassRes &R, const Ctx &cx, const JobSinks &sinks, con
                 ord[k] = R.d_dp_order[k];
             }
         }
-        launch_dp_lane<16>(nw, b1, st[0], cx, sinks.s[1], ord[0], rb, sel, (uint32_t *)R.d_dp_scratch[0], w1, unsup, lane_min[0]);
+        if (b1) launch_dp_lane<16>(nw, b1, st[0], cx, sinks.s[1], ord[0], rb, sel, (uint32_t *)R.d_dp_scratch[0], w1, unsup, lane_min[0]);
         k_dp_group<1><<<R.dp_blocks[0], 64, 0, st[0]>>>(cx, sinks.s[1], rb, sel, R.d_dp_scratch[0], R.dp_stride[0], lane_min[0]);
-        launch_dp_lane<16>(nw, b2, st[1], cx, sinks.s[2], ord[1], rb, sel, (uint32_t *)R.d_dp_scratch[1], w2, unsup, lane_min[1]);
+        if (b2) launch_dp_lane<16>(nw, b2, st[1], cx, sinks.s[2], ord[1], rb, sel, (uint32_t *)R.d_dp_scratch[1], w2, unsup, lane_min[1]);
         k_dp_group<4><<<R.dp_blocks[1], 64, 0, st[1]>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1], lane_min[1]);
         uint32_t *p = R.d_dp_lane;
         launch_dp_lane<8>(nw, R.dp_lane_blocks, side0, cx, sinks.s[4], nullptr, rb, sel, p, lane_short_words(0), unsup, 0u);
@@ -2397,17 +2471,14 @@ static int launch_dp(const PassRes &R, const Ctx &cx, const JobSinks &sinks, con
         launch_dp_lane<16>(nw, R.dp_lane_blocks, side0, cx, sinks.s[5], nullptr, rb, sel, p, lane_short_words(2), unsup, 0u);
         k_dp_sel<16><<<R.dp_blocks[2], 64, 0, side1>>>(cx, sinks.s[3], rb, sel, R.d_dp_scratch[2], R.dp_stride[2]);
     } else {
-    const bool grouped = !getenv("MCX_DP_UNGROUPED"); // (experiments: a problem's traceback right behind its sweep, walked by one lane of the wave)
-    if (grouped) k_dp_group<1><<<R.dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, R.d_dp_scratch[0], R.dp_stride[0], 0xFFFFFFFFu);
-    else k_dp_sel<1><<<R.dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, R.d_dp_scratch[0], R.dp_stride[0]);
+    k_dp_group<1><<<R.dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, R.d_dp_scratch[0], R.dp_stride[0], 0xFFFFFFFFu);
     k_dp_small<<<2560, 256, 0, side0>>>(cx, sinks.s[0], rb, sel);
-    if (grouped) k_dp_group<4><<<R.dp_blocks[1], 64, 0, side1>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1], 0xFFFFFFFFu);
-    else k_dp_sel<4><<<R.dp_blocks[1], 64, 0, side1>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1]);
+    k_dp_group<4><<<R.dp_blocks[1], 64, 0, side1>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1], 0xFFFFFFFFu);
     // (the half-wave class behind the 65-256-column class looks like the long pole on a timeline; moved behind the shorter chains
     //  the stage takes the same 3.3-3.4 ms: the kernels share the chip, the stage is the sum of their work)
-    k_dp_tiny<<<2048, 256, 0, wide ? R.dp_stream[3] : s>>>(cx, sinks.s[4], rb, sel);
-    k_dp_half<<<2048, 256, 0, wide ? R.dp_stream[4] : side1>>>(cx, sinks.s[5], rb, sel);
-    k_dp_sel<16><<<R.dp_blocks[2], 64, 0, wide ? R.dp_stream[2] : side0>>>(cx, sinks.s[3], rb, sel, R.d_dp_scratch[2], R.dp_stride[2]);
+    k_dp_tiny<<<2048, 256, 0, s>>>(cx, sinks.s[4], rb, sel);
+    k_dp_half<<<2048, 256, 0, side1>>>(cx, sinks.s[5], rb, sel);
+    k_dp_sel<16><<<R.dp_blocks[2], 64, 0, side0>>>(cx, sinks.s[3], rb, sel, R.d_dp_scratch[2], R.dp_stride[2]);
     }
     for (int k = 0; k < n_side; k++) { HIP_TRY(hipEventRecord(R.dp_join[k], R.dp_stream[k])); HIP_TRY(hipStreamWaitEvent(s, R.dp_join[k], 0)); }
     return 0;
@@ -2428,6 +2499,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
 {
     if (sel.n == 0) return 0;
     hipStream_t s = R.stream;
+    const Knobs &kn = c->kn;
     Ctx cx = make_ctx(c, tier, paired);
     cx.state += (size_t)state_off * (size_t)cx.lay.stride;
     cx.seed_pool = R.d_rseeds;
@@ -2438,7 +2510,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     so.read_ext = c->d_read_ext; so.read_blocks = c->d_read_blocks;
     so.packed = c->d_packed; so.wpad = c->wpad; so.queue = R.d_cnt + CNT_QUEUE;
     so.src_state = nullptr; so.src_lay = c->tier[0].lay; so.src_caps = c->tier[0].caps;
-    if (hits_from_tier0 && tier == 1 && cx.ix.sa_full && !getenv("MCX_LATE_RESEED")) so.src_state = c->tier[0].state;
+    if (hits_from_tier0 && tier == 1 && cx.ix.sa_full && !kn.late_reseed) so.src_state = c->tier[0].state;
     RescueList rl; rl.ids = R.d_rescue; rl.n = R.d_cnt + CNT_RESCUE; rl.cap = R.rescue_cap;
     EarlyList el; el.ids = nullptr; el.est = nullptr; el.n = R.d_cnt + CNT_EARLY; el.cap = 0; el.n_hits = R.d_cnt + CNT_EARLY_HITS;
     if (early) { el.ids = c->t1.d_sel_ids; el.est = c->t1.d_est; el.cap = (uint32_t)c->max_reads; }
@@ -2457,7 +2529,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         const int threads = pkw * 256 * 4 <= 48 * 1024 ? 256 : (pkw * 128 * 4 <= 48 * 1024 ? 128 : 64);
         const int rpl = seed_reads_per_lane((uint64_t)sel.n * nr);
         const unsigned blocks_s = std::min<unsigned>((sel.n * nr + threads * rpl - 1) / (threads * rpl), 4096u); // (the queue feeds whatever grid runs)
-        k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl, seed_fm_budget(), getenv("MCX_SEED_NARROW") ? 0 : (getenv("MCX_SEED_WIDE64") ? 2 : 1)); // (experiments: 16 bases per fetch of the comparison phase; 64 without the kept chunk)
+        k_seed<<<blocks_s, threads, (size_t)pkw * threads * 4, s>>>(cx, rb, sel, so, pkw, rpl, kn.seed_fm_budget);
 #ifdef MCX_SEED_STATS
         if (tier == 0 && sel.n > 100000) {
             unsigned long long h[2][24];
@@ -2478,32 +2550,28 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     // the pairs in the order of their weight (k_order_*): worth two small passes when the pass is a large one
     const uint32_t *order = nullptr, *order_cnt = nullptr;
-    const char *order_min = getenv("MCX_ORDER_MIN"); // (tests: small batches through k_simple and the order too)
-    if (tier == 0 && sel.n >= (order_min ? (uint32_t)std::max(1, atoi(order_min)) : 16384u) && c->d_order && !getenv("MCX_NO_WORK_ORDER")) {
+    if (tier == 0 && sel.n >= kn.order_min && c->d_order && !kn.no_work_order) {
         // ahead of them, on a whole batch: the straight-line pairs from their seeds to their records (k_simple); what is left is listed
-        // by weight for the per-pair kernels.  (Not with the -vcf bookkeeping — its per-read detail comes from the finish stage —, not
-        // without the suffix array in HBM — the seeds must be text positions —, not on a selection: k_simple takes pair = record.)
-        const bool no_simple = getenv("MCX_NO_SIMPLE") != nullptr;
+        // by weight for the per-pair kernels.  (Not without the suffix array in HBM — the seeds must be text positions —, not on a
+        // selection: k_simple takes pair = record.  With the -vcf bookkeeping on it writes the pairs' detail records as well.)
+        const bool no_simple = kn.no_simple;
         const uint8_t *done = nullptr;
-        if (!no_simple && !sel.ids && !cx.detail && cx.ix.sa_full && cx.packed) {
+        if (!no_simple && !sel.ids && cx.ix.sa_full && cx.packed) {
             // collect (every pair) -> solve (the problems written down) -> replay (the pairs that wrote some down); MCX_SIMPLE_NO_DP: a pair
             // with such a problem takes the general path
-            SimpleLater sl; sl.pairs = getenv("MCX_SIMPLE_NO_DP") ? nullptr : c->d_sl_pairs; sl.jobs = c->d_sl_jobs; sl.res = c->d_sl_res; sl.job_list = c->d_sl_list;
+            SimpleLater sl; sl.pairs = kn.simple_no_dp ? nullptr : c->d_sl_pairs; sl.jobs = c->d_sl_jobs; sl.res = c->d_sl_res; sl.job_list = c->d_sl_list;
             sl.n_pairs = R.d_cnt + CNT_SIMPLE_LATER; sl.n_jobs = R.d_cnt + CNT_SIMPLE_JOBS; sl.cap = std::min<uint32_t>(c->sl_cap, std::max<uint32_t>(sel.n / 2, 1024u));
             const unsigned lb = (sl.cap + 255) / 256, jb = std::min<unsigned>((sl.cap * kSimpleJobs + 255) / 256, 3072u); // (launched for what the lists may hold: their lengths stay on the device)
-            if (cx.pm.use_nw) {
-                k_simple<true, kDpCollect><<<pb, 256, 0, s>>>(cx, rb, sel.n, sel.est, so.read_blocks, d_recs, c->d_pout, c->d_done, c->d_batch_flags + 2, R.d_cnt + CNT_SIMPLE, sl);
+            auto launch = [&](auto nw, auto detail) {
+                constexpr bool NW = decltype(nw)::value, DT = decltype(detail)::value;
+                k_simple<NW, kDpCollect, DT><<<pb, 256, 0, s>>>(cx, rb, sel.n, sel.est, so.read_blocks, d_recs, c->d_pout, c->d_done, c->d_batch_flags + 2, R.d_cnt + CNT_SIMPLE, sl);
                 if (sl.pairs) {
-                    k_simple_dp<true><<<jb, 256, 0, s>>>(cx, sl);
-                    k_simple<true, kDpReplay><<<lb, 256, 0, s>>>(cx, rb, sel.n, sel.est, so.read_blocks, d_recs, c->d_pout, c->d_done, c->d_batch_flags + 2, R.d_cnt + CNT_SIMPLE, sl);
+                    k_simple_dp<NW><<<jb, 256, 0, s>>>(cx, sl);
+                    k_simple<NW, kDpReplay, DT><<<lb, 256, 0, s>>>(cx, rb, sel.n, sel.est, so.read_blocks, d_recs, c->d_pout, c->d_done, c->d_batch_flags + 2, R.d_cnt + CNT_SIMPLE, sl);
                 }
-            } else {
-                k_simple<false, kDpCollect><<<pb, 256, 0, s>>>(cx, rb, sel.n, sel.est, so.read_blocks, d_recs, c->d_pout, c->d_done, c->d_batch_flags + 2, R.d_cnt + CNT_SIMPLE, sl);
-                if (sl.pairs) {
-                    k_simple_dp<false><<<jb, 256, 0, s>>>(cx, sl);
-                    k_simple<false, kDpReplay><<<lb, 256, 0, s>>>(cx, rb, sel.n, sel.est, so.read_blocks, d_recs, c->d_pout, c->d_done, c->d_batch_flags + 2, R.d_cnt + CNT_SIMPLE, sl);
-                }
-            }
+            };
+            if (cx.pm.use_nw) { if (cx.detail) launch(std::true_type(), std::true_type()); else launch(std::true_type(), std::false_type()); }
+            else { if (cx.detail) launch(std::false_type(), std::true_type()); else launch(std::false_type(), std::false_type()); }
             done = c->d_done;
         }
         uint32_t *cls_cnt = R.d_cnt + CNT_ORDER; // (cleared with the pass's counters)
@@ -2513,33 +2581,21 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         k_order_place<<<ob, 256, 0, s>>>(sel, so.read_blocks, nr, cls_cnt, c->d_order, done);
         order = c->d_order;
     }
-    bool early_recorded = false;
     const size_t cl_bytes = cluster_lds_bytes(cx.caps.hit_cap, cx.caps.cand_cap);
-    if (tier == 1 && cl_bytes <= 60 * 1024 && !getenv("MCX_CLUSTER_BY_LANE")) { // the large tier's pairs: a wavefront each, in two launches by size
+    if (tier == 1 && cl_bytes <= 60 * 1024 && !kn.cluster_by_lane) { // the large tier's pairs: a wavefront each, in two launches by size
         const int small = std::min(kClusterSmall, cx.caps.hit_cap);
         k_cluster_wave<<<std::min<unsigned>(sel.n, 16384u), 64, cluster_lds_bytes(small, small), s>>>(cx, rb, sel, rl, so.read_blocks, -1, small, small, small);
         if (small < cx.caps.hit_cap)
             k_cluster_wave<<<std::min<unsigned>(sel.n, 8192u), 64, cl_bytes, s>>>(cx, rb, sel, rl, so.read_blocks, small, 1 << 30, cx.caps.hit_cap, cx.caps.cand_cap);
-    } else if (order && cx.caps.hit_seed >= 8 && cx.caps.cand_seed >= 8 && getenv("MCX_CLUSTER_HEAVY_FIRST")) {
-        // (experiments: classes 0-3 hold every pair with more than 8 seed hits — only such a pair can run over 8 or more hits / candidates
-        //  per read — so the large tier could start after a launch of their own; measured: that launch alone takes 1.34 of the 1.73 ms
-        //  both take together, the large tier starts 0.2 ms earlier and the step is 0.4 ms longer)
-        k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl, so.read_blocks, el, order, order_cnt, 0, 3);
-        if (early) HIP_TRY(hipEventRecord(c->ev_clustered, s));
-        early_recorded = true;
-        k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl, so.read_blocks, el, order, order_cnt, 4, kWorkClasses - 1);
     } else k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl, so.read_blocks, el, order, order_cnt, 0, kWorkClasses - 1);
-    if (early && !early_recorded) HIP_TRY(hipEventRecord(c->ev_clustered, s));
+    if (early) HIP_TRY(hipEventRecord(c->ev_clustered, s));
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     // mate rescue beside the build of the pairs that do not await it (k_build's modes), when the set has a side stream for it
-    const bool rescue_aside = paired && R.dp_stream[0] && !getenv("MCX_RESCUE_BY_PAIR") && !getenv("MCX_RESCUE_IN_LINE");
+    const bool rescue_aside = paired && R.dp_stream[0] && !kn.rescue_in_line;
     hipStream_t rs = rescue_aside ? R.dp_stream[0] : s;
     if (rescue_aside) { HIP_TRY(hipEventRecord(R.dp_fork, s)); HIP_TRY(hipStreamWaitEvent(rs, R.dp_fork, 0)); }
     if (paired) {
-        if (getenv("MCX_RESCUE_BY_PAIR")) { // (experiments: a workgroup per pair, the pair's windows one after the other)
-            if (tier == 0) k_rescue<2048><<<kRescueBlocks, kRescueThreads, 0, s>>>(cx, rb, sel, rl, R.d_kscratch);
-            else k_rescue<4096><<<kRescueBlocks, kRescueThreads, 0, s>>>(cx, rb, sel, rl, R.d_kscratch);
-        } else {
+        {
             RescueWork rw; rw.tasks = R.d_rtasks; rw.res = R.d_rres; rw.seeds = R.d_rseeds; rw.plans = R.d_rplans; rw.n_tasks = R.d_cnt + CNT_RTASK; rw.n_plans = R.d_cnt + CNT_RPLAN; rw.n_seeds = R.d_cnt + CNT_RSEED;
             rw.task_cap = R.rtask_cap; rw.seed_cap = R.rseed_cap; rw.ids_n = R.d_rescue_n; rw.n_ids_n = R.d_cnt + CNT_RESCUE_N;
             RescueList rn; rn.ids = R.d_rescue_n; rn.n = R.d_cnt + CNT_RESCUE_N; rn.cap = R.rescue_cap;
@@ -2557,10 +2613,11 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     }
     // three time stamps: in line they bracket rescue | nothing | build, with the rescue aside build (others) | what is left of the wait for the rescue | build (its pairs)
     // (the large tier's pairs: a wavefront each — k_build_wave; MCX_BUILD_BY_LANE: a lane each there too)
-    const size_t bw_bytes = (size_t)4 * cx.caps.cand_cap * sizeof(int32_t);
-    const bool build_wave = tier == 1 && bw_bytes <= 48 * 1024 && !getenv("MCX_BUILD_BY_LANE");
+    const size_t bw_bytes = (size_t)6 * cx.caps.cand_cap * sizeof(int32_t);
+    const bool build_wave = tier == 1 && bw_bytes <= 48 * 1024 && !kn.build_by_lane;
+    const int build_wave_limit = kn.build_wave_limit;
     auto build = [&](int mode) {
-        if (build_wave) k_build_wave<<<std::min<unsigned>(sel.n, 8192u), 64, bw_bytes, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP, mode, rl);
+        if (build_wave) k_build_wave<<<std::min<unsigned>(sel.n, 8192u), 64, bw_bytes, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP, mode, rl, build_wave_limit);
         else k_build<<<pb, 256, 0, s>>>(cx, rb, sel, sinks, R.d_cnt + CNT_CELLS, R.d_cnt + CNT_UNSUP, ll, order, order_cnt, mode, rl);
     };
     if (rescue_aside) {
@@ -2576,7 +2633,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     }
     if (late) HIP_TRY(hipEventRecord(c->ev_built, s));
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
-    if ((rc2 = launch_dp(R, cx, sinks, rb, sel, c->rlen_max))) return rc2;
+    if ((rc2 = launch_dp(kn, R, cx, sinks, rb, sel, c->rlen_max))) return rc2;
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     k_finish<<<pb, 256, 0, s>>>(cx, rb, sel, d_recs, c->d_pout, R.d_ov, R.d_cnt + CNT_OV, R.ov_cap, c->d_batch_flags + 2, order, order_cnt);
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
@@ -2585,7 +2642,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     const int e_flag = e | (rescue_aside ? 0x100 : 0); // (for pass_finish: which stage a time stamp closes)
     if (queued) { *queued = e_flag; return 0; }
     hipEvent_t ev_dbg[2] = {nullptr, nullptr}; // (MCX_TIMING: when tier 0 and the large tier beside it were done)
-    if (early && getenv("MCX_TIMING")) {
+    if (early && kn.timing) {
         for (int k = 0; k < 2; k++) HIP_TRY(hipEventCreate(&ev_dbg[k]));
         HIP_TRY(hipEventRecord(ev_dbg[0], s));
     }
@@ -2601,7 +2658,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         const bool no_n = T.h_cnt[1] == 0;
         if (n_early > el.cap) { (void)hipStreamSynchronize(s); return fail(MCX_ERR_CAPACITY, "overflow list overflow"); }
         if (stats) stats->tier1_pairs += n_early;
-        const bool t1_timing = getenv("MCX_TIMING") != nullptr;
+        const bool t1_timing = kn.timing;
         const uint32_t room = c->tier[1].max_pairs - (late ? kLateRoom : 0); // (the last records are the late list's)
         mcx_stats t1;
         uint32_t m = 0;
@@ -2649,7 +2706,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
 // what follows a pass once its stream has been joined: the work lists' overflow checks, counts and stage times
 static int pass_finish(mcx_ctx *c, int tier, const PassRes &R, uint32_t n_sel, mcx_stats *stats, bool timing, int e)
 {
-    if (tier == 1 && getenv("MCX_TIER1_HIST")) { // experiments: how heavy are the pairs of the large tier?
+    if (tier == 1 && c->kn.tier1_hist) { // experiments: how heavy are the pairs of the large tier?
         std::vector<PairHdr> hd(n_sel);
         HIP_TRY(hipMemcpy2D(hd.data(), sizeof(PairHdr), c->tier[1].state, (size_t)c->tier[1].lay.stride, sizeof(PairHdr), n_sel, hipMemcpyDeviceToHost));
         const int edges[8] = {16, 32, 64, 128, 256, 512, 1024, 1 << 30};
@@ -2669,7 +2726,7 @@ static int pass_finish(mcx_ctx *c, int tier, const PassRes &R, uint32_t n_sel, m
         fprintf(stderr, "\n");
     }
     const uint32_t *n = R.h_cnt;
-    if (getenv("MCX_DP_HIST") && n_sel >= 1024) { // experiments: the sizes of the pass's DP problems (query x target, by bit length), per list
+    if (c->kn.dp_hist && n_sel >= 1024) { // experiments: the sizes of the pass's DP problems (query x target, by bit length), per list
         static const char *names[kDpClasses] = {"small", "wave1", "wave4", "wave16", "tiny", "half"};
         for (int k = 0; k < kDpClasses; k++) {
             const uint32_t m = std::min(n[CNT_JOB0 + k * kCntPad], R.job_cap[k]);
@@ -2697,7 +2754,7 @@ static int pass_finish(mcx_ctx *c, int tier, const PassRes &R, uint32_t n_sel, m
     if ((R.d_tasks && n[CNT_TASKS] > R.task_cap) || n[CNT_RESCUE] > R.rescue_cap || n[CNT_RTASK] > R.rtask_cap || n[CNT_RSEED] > R.rseed_cap) return kListOverflow;
     for (int k = 0; k < kDpClasses; k++) if (n[CNT_JOB0 + k * kCntPad] > R.job_cap[k]) return kListOverflow;
     if (n[CNT_UNSUP]) return fail(MCX_ERR_UNSUPPORTED, "a gapped fragment exceeds 2048 x 1024 cells per side");
-    if (timing && getenv("MCX_TIMING"))
+    if (timing && c->kn.timing)
         fprintf(stderr, "[run_pairs] pairs %u: sa tasks %u, rescue pairs %u (windows %u), dp jobs by class (tiny) %u %u (half) %u %u %u %u, cells %llu, overflow pairs %u (+ %u listed while clustering, %u of them for their seed hits), %u straight-line pairs (k_simple)\n", n_sel,
                 n[CNT_TASKS], n[CNT_RESCUE], n[CNT_RTASK], n[CNT_JOB4], n[CNT_JOB0], n[CNT_JOB5], n[CNT_JOB1], n[CNT_JOB2], n[CNT_JOB3], *(const unsigned long long *)(n + CNT_CELLS), n[CNT_OV], n[CNT_EARLY], n[CNT_EARLY_HITS], n[CNT_SIMPLE]);
     if (stats) {
@@ -2872,7 +2929,7 @@ static int run_selection(mcx_ctx *c, const ReadBatch &rb, int paired, const std:
     }
     for (uint32_t i = 0; i < n_ov; i++) ov_est[i] = ov_out[i].est;
     if (stats) stats->tier1_pairs += n_ov;
-    if (getenv("MCX_TIMING")) { // what sent them here
+    if (c->kn.timing) { // what sent them here
         uint32_t by_flag[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (uint32_t i = 0; i < n_ov; i++) for (int b = 0; b < 8; b++) if (ov_out[i].flags & (1u << b)) by_flag[b]++;
         fprintf(stderr, "[tier 1] %u pairs over the tier-0 capacities: hits %u candidates %u fragments %u ops %u jobs %u cigar %u rescue window %u detail %u\n", n_ov, by_flag[0],
@@ -2885,7 +2942,7 @@ static int run_selection(mcx_ctx *c, const ReadBatch &rb, int paired, const std:
         HIP_TRY(hipMemcpyAsync(c->d_sel_ids, ov.data() + lo, m * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(c->d_est, ov_est.data() + lo, m * sizeof(int32_t), hipMemcpyHostToDevice, s));
         PairSel s1; s1.n = m; s1.ids = c->d_sel_ids; s1.est = c->d_est;
-        if (getenv("MCX_TIMING")) { // where the time of the large-capacity tier goes (not added to the caller's stage times)
+        if (c->kn.timing) { // where the time of the large-capacity tier goes (not added to the caller's stage times)
             mcx_stats t1; memset(&t1, 0, sizeof t1);
             rc = run_pairs(c, 1, R0, rb, paired, s1, d_recs, d_cig, &t1, true);
             fprintf(stderr, "[tier 1] %u pairs: seed %.2f sa %.2f cluster %.2f rescue %.2f build %.2f dp %.2f finish %.2f ms\n", m, t1.ms_seed, t1.ms_sa, t1.ms_cluster,
@@ -2984,7 +3041,7 @@ extern "C" int mcx_batch_sums(mcx_ctx *c, uint32_t *n_chunks, const uint32_t **p
     hipStream_t s = c->stream;
     HIP_TRY(hipSetDevice(c->idx->device));
     const uint32_t nc = br.n_chunks;
-    if (br.sums_valid && br.ok.size() == nc && !getenv("MCX_NO_SUMS_CACHE")) { // nothing was re-run since the last call (the closing round of a sharded step): the sums still stand
+    if (br.sums_valid && br.ok.size() == nc && !c->kn.no_sums_cache) { // nothing was re-run since the last call (the closing round of a sharded step): the sums still stand
         if (n_chunks) *n_chunks = nc;
         if (pairs) *pairs = br.ok.data();
         if (dist) *dist = br.ds.data();
@@ -3076,7 +3133,7 @@ extern "C" int mcx_batch_end(mcx_ctx *c, mcx_stats *stats)
         rc = profile_keys(c);
         const auto t1 = std::chrono::steady_clock::now();
         if (rc == 0) rc = profile_accumulate(c, nullptr, 0, 0, 0);
-        if (getenv("MCX_TIMING")) {
+        if (c->kn.timing) {
             auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
             fprintf(stderr, "[mcx profile] mapping %.2f ms, keys %.2f ms, accumulate %.2f ms\n", ms(c->run.t0, t0), ms(t0, t1), ms(t1, std::chrono::steady_clock::now()));
         }
@@ -3622,7 +3679,7 @@ static int profile_accumulate(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all,
     HIP_TRY(hipMemcpyAsync(c->d_cnt + CNT_TASKS, &br.n_sparse_keys, sizeof(uint32_t), hipMemcpyHostToDevice, s)); // (pageable source: copied before the call returns)
     // (MCX_PROF_BY_COLUMN: tests — every read is treated as if it held an odd letter, so that exact seeds are walked column by
     //  column like every other fragment; the planes must come out the same)
-    HIP_TRY(hipMemsetAsync(c->d_admit, getenv("MCX_PROF_BY_COLUMN") ? 2 : 0, (n + 3) & ~3u, s));
+    HIP_TRY(hipMemsetAsync(c->d_admit, c->kn.prof_by_column ? 2 : 0, (n + 3) & ~3u, s));
     {
         const int tpr = (std::max<int>((int)(br.longest ? br.longest : (uint32_t)c->rlen_max), 1) + 15) / 16;
         const uint64_t threads = (uint64_t)n * tpr;
@@ -3648,7 +3705,7 @@ static int profile_accumulate(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all,
     const auto t_app = std::chrono::steady_clock::now();
     if (int rc = archive_append(c, c->arch, c->d_sparse, n_sp)) return rc;
     const int rc_ev = archive_append(c, c->arch_ev, d_ev, n_ev);
-    if (getenv("MCX_TIMING")) fprintf(stderr, "[mcx profile] %u tally records, %u events, %u listed fragments; archives %.2f ms\n", n_sp, n_ev, c->h_cnt[CNT_RTASK],
+    if (c->kn.timing) fprintf(stderr, "[mcx profile] %u tally records, %u events, %u listed fragments; archives %.2f ms\n", n_sp, n_ev, c->h_cnt[CNT_RTASK],
                                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_app).count());
     return rc_ev;
 }

@@ -92,7 +92,7 @@ __global__ void k_prof_keys(const uint8_t *detail, DetailLayout dl, ReadBatch rb
         const uint8_t *rec = detail + (uint64_t)r * dl.stride;
         const DetailHdr &d = *(const DetailHdr *)rec;
         if (d.type == 1) {
-            const Frag *f = (const Frag *)(rec + sizeof(DetailHdr));
+            const Frag *f = (const Frag *)(rec + sizeof(DetailHdr)) + d.frag0;
             const Frag &a = f[0], &b = f[d.n_frags - 1];
             const int rlen = (int)(rb.off[r + 1] - rb.off[r]);
             bool go = true;
@@ -256,7 +256,7 @@ static __device__ __forceinline__ void prof_read(const uint8_t *detail, const De
     if (r >= rb.n_reads) return;
     const uint8_t *rec = detail + (uint64_t)r * dl.stride;
     const DetailHdr d = *(const DetailHdr *)rec;
-    const Frag *fr = (const Frag *)(rec + sizeof(DetailHdr));
+    const Frag *fr = (const Frag *)(rec + sizeof(DetailHdr)) + d.frag0;
     if (d.type == 2) { // UpdateMultiHitCount (:244-271)
         for (int i = 0; i < d.n_frags; i++) { const Frag f = fr[i]; range_add(pv.plane + (uint64_t)kPlMulti * pv.G, f.gPos, f.gPos + f.rLen, pv.G); }
         return;

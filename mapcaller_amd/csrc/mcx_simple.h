@@ -95,6 +95,43 @@ static inline MCX_HD SimpleRes simple_dp_job(const IndexView &ix, const SimpleJo
     return r;
 }
 
+// What the -vcf bookkeeping reads of a straight-line read: the record write_detail (mcx_glue.h) leaves for a read with exactly one surviving
+// candidate — its fragments in read order as extend_read leaves them (a trimmed or dropped end included), the column strings of its DP
+// fragments ('M' 'I' 'D', in the order the DP kernels leave them: against the read on the reverse strand).  simple_read hands them to a
+// sink as it meets them; a read that leaves the path half way has written fragments nobody counts (the general path writes the record).
+// The record keeps a candidate's fragments in ALIGNMENT order — a reverse-strand candidate's are read backwards (frag_index) —, the pass
+// meets them in read order: the sink fills the record's first kSimpleFrags places from the front (forward) or from the back, and the record's
+// header says where the first fragment lies (DetailHdr::frag0).  The strand is known with the first seed: the validity check at the
+// end of the pass keeps an alignment on one chromosome, hence on one strand.
+constexpr int kSimpleFrags = 2 * kSimpleHits + 1;
+struct SimpleNoDetail {
+    static constexpr bool on = false;
+    static constexpr int nf = 0, no = 0, fwd = 1;
+    MCX_HD void frag(int, int, int64_t, int, int, int, int, int) {}
+    MCX_HD int cols(uint64_t, int, int, int) { return 0; }
+    MCX_HD void begin(bool) {}
+    MCX_HD int frag0() const { return 0; }
+};
+struct SimpleDetail {
+    static constexpr bool on = true;
+    Frag *frags; uint8_t *ops; int nf, no, fwd;
+    MCX_HD void begin(bool forward) { nf = 0; no = 0; fwd = forward ? 1 : 0; }
+    MCX_HD int frag0() const { return fwd ? 0 : kSimpleFrags - nf; }
+    MCX_HD void frag(int kind, int rp, int64_t gp, int rl, int gl, int ops_off, int ops_len, int meta)
+    {
+        Frag x; x.gPos = gp; x.rPos = rp; x.gLen = gl; x.rLen = rl; x.ops_off = ops_off; x.ops_len = ops_len; x.kind = (uint64_t)kind; x.meta = (uint64_t)meta;
+        frags[fwd ? nf : kSimpleFrags - 1 - nf] = x;
+        nf++;
+    }
+    // the columns [a, b) of a SimpleRes string (column j at bits 2 (len - 1 - j)): where they went
+    MCX_HD int cols(uint64_t w, int len, int a, int b)
+    {
+        const int at = no;
+        for (int j = a; j < b; j++) ops[no++] = (uint8_t)"MID"[(w >> (2 * (len - 1 - j))) & 3u];
+        return at;
+    }
+};
+
 struct SimpleRead {
     int64_t pd0;        // PosDiff of the candidate: of its first seed in (PosDiff, rPos) order
     int64_t g_first;    // gPos of the first fragment in ALIGNMENT order (GenCoordinatePair; fwd: in read order, else the last one's)
@@ -102,6 +139,7 @@ struct SimpleRead {
     int32_t score;      // matched bases after the gates (AlnSummary score; NM = rlen - score)
     int32_t fwd;        // orientation
     int32_t n_cig;      // CIGAR operations, in alignment order at cig[0 .. n_cig)
+    int32_t n_frags, n_ops, frag0; // (with a detail sink) what it holds, and where its first fragment lies
 };
 
 // One read.  kSimpleYes: it is straight-line; `out` and cig[k * cig_stride] (k < out.n_cig) are filled.  kSimpleLater (collect only): it
@@ -109,9 +147,9 @@ struct SimpleRead {
 // hits: the read's seeds as k_seed left them (text positions), n of them (1..kSimpleHits); codes: its 2-bit words (no N).
 enum : int { kSimpleNo = 0, kSimpleYes = 1, kSimpleLater = 2 };
 // (CigT: 32-bit words, or 16-bit ones — a run is at most 4095 long: reads of up to 1000 bases, deletions below 4096)
-template <bool NW, class CigT>
+template <bool NW, class CigT, class Det>
 static inline MCX_HD int simple_read(const IndexView &ix, const Params &pm, int rlen, const uint32_t *codes, const Hit *hits, int n,
-                                     SimpleRead &out, CigT *cig, int cig_stride, SimpleDpIo &io)
+                                     SimpleRead &out, CigT *cig, int cig_stride, SimpleDpIo &io, Det &det)
 {
     if (n < 1 || n > kSimpleHits || !codes) MCX_SIMPLE_FAIL(1);
     // ---- the seeds with PosDiff > 0 (IdentifySimplePairs' tail); the straight-line case needs all of them to stay
@@ -200,9 +238,10 @@ static inline MCX_HD int simple_read(const IndexView &ix, const Params &pm, int 
         const SimpleRes sc = io.res[io.n++];
         const bool rev = gp >= ix.G;
         int a = 0, b = sc.len, sw = sc.switches, clip = 0; // the string's columns [a, b) stay
+        int rs = 0, gs = 0;                                // read / genome bases among the gap columns that come off an outer end
         if (place) {
             const bool lead = (place == 1) != rev; // the read's outer end is the string's start (head, forward; tail, reverse) or its end
-            int rs = 0, gs = 0, runs = 0, cur = 0;
+            int runs = 0, cur = 0;
             for (int j = 0; j < sc.len; j++) {
                 const int k = (int)((sc.w >> (2 * (lead ? sc.len - 1 - j : j))) & 3u);
                 if (k == 0) break;
@@ -219,11 +258,17 @@ static inline MCX_HD int simple_read(const IndexView &ix, const Params &pm, int 
                 end_dropped = true;
                 if (place == 1) head_shift = gl_; else tail_shift = gl_;
                 add(rl_, 4);
+                // (extend_read: the emptied end sits where its neighbour begins — the first seed — or ends — the last one)
+                if (place == 1) det.frag(kEmpty, rp + rl_, gp + gl_, 0, 0, 0, 0, 0); else det.frag(kEmpty, rp, gp, 0, 0, 0, 0, 0);
                 return true;
             }
             if (place == 1) head_shift = gs; else tail_shift = gs;
         } else if (rl_ >= kMinAlnBlockSize && gl_ >= kMinAlnBlockSize && (sw >= 4 || (sc.mis >= 3 && sc.mis >= (int)(sc.n * 0.3)))) MCX_SIMPLE_FAIL(19); // the candidate would die
         score += sc.n - sc.mis; mism += sc.mis;
+        if (Det::on) { // strip_end_gaps: the head moves with what it lost, the tail only shrinks
+            const int at = det.cols(sc.w, sc.len, a, b);
+            det.frag(kDp, place == 1 ? rp + rs : rp, place == 1 ? gp + gs : gp, rl_ - rs, gl_ - gs, at, b - a, 0);
+        }
         // column j of the string at bits 2 (len - 1 - j); on the reverse strand the string runs against the read
         if (place == 1 && clip > 0) add(clip, 4);
         for (int j = a; j < b; j++) add(1, (int)((sc.w >> (2 * (rev ? j - a + (sc.len - b) : sc.len - 1 - j))) & 3u));
@@ -240,6 +285,7 @@ static inline MCX_HD int simple_read(const IndexView &ix, const Params &pm, int 
         if (l >= kMinAlnBlockSize && mm >= 3 && mm >= (int)(l * 0.3)) MCX_SIMPLE_FAIL(8); // (one kind of column: switches = 1) the quality gate would fire
         score += l - mm; mism += mm;
         add(l, 0);
+        det.frag(kPlain, rp, gp, l, l, 0, l, mm + 1);
         return true;
     };
     int pr = 0;               // read / genome position behind the previous seed
@@ -253,6 +299,7 @@ static inline MCX_HD int simple_read(const IndexView &ix, const Params &pm, int 
         const int64_t g0 = g[i];
         if (i == 0) {
             g_head = g0 - r0;
+            det.begin(g_head < ix.G);
             if (r0 > 0 && !plain_gap(0, g0 - r0, r0, 1)) MCX_SIMPLE_FAIL(9);
         } else {
             const int rg = r0 - pr;
@@ -261,11 +308,12 @@ static inline MCX_HD int simple_read(const IndexView &ix, const Params &pm, int 
             if (rg > 0 && gg > 0) {
                 if ((int64_t)rg != gg) { if (gg > kSimpleDp || !dp_gap(pr, pg, rg, (int)gg, 0)) { MCX_SIMPLE_NOTE(1, (int)(gg > rg ? gg : rg)); MCX_SIMPLE_FAIL(11); } } // a DP problem
                 else if (!plain_gap(pr, pg, rg, 0)) MCX_SIMPLE_FAIL(12);
-            } else if (rg > 0) add(rg, 1);                                       // read bases against '-'
-            else if (gg > 0) { if (gg >= 4096) MCX_SIMPLE_FAIL(13); add((int)gg, 2); } // '-' against genome bases (Frag::gLen is 12 bits)
+            } else if (rg > 0) { add(rg, 1); det.frag(kIns, pr, pg, rg, 0, 0, rg, 0); }         // read bases against '-'
+            else if (gg > 0) { if (gg >= 4096) MCX_SIMPLE_FAIL(13); add((int)gg, 2); det.frag(kDel, pr, pg, 0, (int)gg, 0, (int)gg, 0); } // '-' against genome bases (Frag::gLen is 12 bits)
         }
         score += len[i];
         add(len[i], 0);
+        det.frag(kSimple, r0, g0, len[i], len[i], 0, 0, 0);
         prev_r = r0; prev_g = g0; pr = r0 + len[i]; pg = g0 + len[i];
     }
     if (pr < rlen) { if (!plain_gap(pr, pg, rlen - pr, 2)) MCX_SIMPLE_FAIL(14); pg += rlen - pr; }
@@ -287,9 +335,11 @@ static inline MCX_HD int simple_read(const IndexView &ix, const Params &pm, int 
     }
     if (n_run > kSimpleRuns) MCX_SIMPLE_FAIL(20); // more operations than the path keeps
     const int fwd = g_head + head_shift < ix.G ? 1 : 0;
+    if (Det::on && fwd != det.fwd) MCX_SIMPLE_FAIL(21); // (cannot happen: one chromosome, one strand)
     MCX_UNROLL
     for (int k = 0; k < kSimpleRuns; k++) if (k < n_run) cig[(fwd ? k : n_run - 1 - k) * cig_stride] = (CigT)runs[k];
     out.score = score; out.fwd = fwd; out.n_cig = n_run;
+    if (Det::on) { out.n_frags = det.nf; out.n_ops = det.no; out.frag0 = det.frag0(); }
     // first fragment in alignment order: forward = the head (gap or seed) at g_head, behind the genome bases its outer end lost; reverse =
     // the tail, which ends at g_tail less what its outer end lost.  GetAlnCoordinate takes gPos (forward) or gPos + gLen - 1 (reverse)
     // of it; GenCoordinatePair its gPos.
@@ -355,6 +405,25 @@ static inline MCX_HD bool simple_pair(const Ctx &cx, int paired, const SimpleRea
         rec2[s] = o;
     }
     return true;
+}
+
+// the header of read s's detail record (write_detail's for a read with one surviving candidate; in read 1's, pair_stats' account of which
+// branch of ReadMapping.cpp:486-521 the pair takes when -vcf is on)
+static inline MCX_HD DetailHdr simple_detail_hdr(const IndexView &ix, int paired, int s, const SimpleRead &a, const SimpleRead &b)
+{
+    const SimpleRead &me = s == 0 ? a : b;
+    DetailHdr d;
+    d.type = 1; d.n_frags = me.n_frags; d.fwd = me.fwd; d.n_ops = me.n_ops; d.disc_kind = 0; d.frag0 = me.frag0; d.disc_g1 = d.disc_g2 = d.disc_dist = 0;
+    if (s == 0 && paired) {
+        const int64_t g1 = a.g_first, g2 = b.g_first, dist = g2 > g1 ? g2 - g1 : g1 - g2, G = ix.G;
+        d.disc_g1 = g1; d.disc_g2 = g2; d.disc_dist = dist;
+        if (dist != 0) {
+            if (g1 < G && g2 >= G) d.disc_kind = 1;
+            else if (g1 >= G && g2 < G) d.disc_kind = 2;
+            else if (dist > kMinTranslocationSize) d.disc_kind = (g1 < G && g2 < G) ? 3 : 4;
+        }
+    }
+    return d;
 }
 
 } // namespace mcx

@@ -210,7 +210,7 @@ struct DetailHdr {
     int32_t fwd;         // orientation of the candidate
     int32_t n_ops;
     int32_t disc_kind;   // read 0 of a pair: discordant-pair event of ReadMapping.cpp:486-521 (0 none, 1/2 strand mix, 3/4 distant)
-    int32_t pad;
+    int32_t frag0;       // index of the record's first fragment (0 but for the straight-line path's reverse-strand reads: mcx_simple.h SimpleDetail)
     int64_t disc_g1, disc_g2, disc_dist;
 };
 

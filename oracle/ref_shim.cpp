@@ -97,7 +97,9 @@ int mcref_ksw2_extz(const uint8_t *q, int qlen, const uint8_t *t, int tlen, int 
 //   <out>.maps : text lines "I pos seq n" / "D pos seq n" (InsertSeqMap/DeleteSeqMap), "B pos n"
 //                (BreakPointMap), "V gPos dist" / "T gPos dist" (InversionSiteVec/TranslocationSiteVec)
 extern map<int64_t, uint16_t> BreakPointMap;
-static int run_profile(const char *fq1, const char *fq2, int ksw2, const char *out)
+// sparse != 0 (request Q): the profile of a genome too large for the dense file — only the positions
+//   with a non-zero counter, as records {int64 pos, 10 x u16} in <out>.prof.nz
+static int run_profile(const char *fq1, const char *fq2, int ksw2, const char *out, int sparse = 0)
 {
     ReadFileNameVec1.clear(); ReadFileNameVec2.clear();
     ReadFileNameVec1.push_back(fq1);
@@ -111,12 +113,18 @@ static int run_profile(const char *fq1, const char *fq2, int ksw2, const char *o
     pthread_mutex_init(&VarLock, NULL); pthread_mutex_init(&OutputLock, NULL); pthread_mutex_init(&LibraryLock, NULL); pthread_mutex_init(&ProfileLock, NULL);
     StartProcessTime = time(NULL);
     Mapping();
-    string p = string(out) + ".prof";
+    string p = string(out) + (sparse ? ".prof.nz" : ".prof");
     FILE *f = fopen(p.c_str(), "wb");
     if (!f) return -1;
     for (int64_t g = 0; g < GenomeSize; g++) {
         const MappingRecord_t &m = MappingRecordArr[g];
         uint16_t v[10] = {(uint16_t)m.A, (uint16_t)m.C, (uint16_t)m.G, (uint16_t)m.T, (uint16_t)m.multi_hit, (uint16_t)m.readCount, m.F1, m.R2, m.F2, m.R1};
+        if (sparse) {
+            bool any = false;
+            for (int k = 0; k < 10; k++) any = any || v[k] != 0;
+            if (!any) continue;
+            fwrite(&g, 8, 1, f);
+        }
         fwrite(v, 2, 10, f);
     }
     fclose(f);
@@ -135,6 +143,7 @@ static int run_profile(const char *fq1, const char *fq2, int ksw2, const char *o
 
 // stdin protocol, one request per line, one reply line each:
 //   P <nw|ksw2> <out prefix> <fq1> [fq2]  -> "ok" after <out>.prof / <out>.maps are written
+//   Q <nw|ksw2> <out prefix> <fq1> [fq2]  -> the same with <out>.prof.nz (non-zero positions only) in place of <out>.prof
 //   L <prefix>                 -> "ok <genome size>"
 //   S <start> <codes 0-4>      -> "<len> <freq> <loc>..."            BWT_Search(seq, start, strlen)
 //   D <q ascii> <t ascii>      -> "<nw a1> <nw a2> <ksw2 a1> <ksw2 a2> <ez.score> <ops reversed>"
@@ -175,11 +184,11 @@ int main()
             int score = 0;
             mcref_ksw2_extz(qc.data(), m, tc.data(), k, &score, ops.data(), c);
             printf("%s %s %s %s %d %s\n", a1.data(), a2.data(), b1.data(), b2.data(), score, ops.data());
-        } else if (line[0] == 'P') {
+        } else if (line[0] == 'P' || line[0] == 'Q') {
             char alg[16], out[1024], f1[1024], f2[1024];
             f2[0] = 0;
             int k = sscanf(line + 2, "%15s %1023s %1023s %1023s", alg, out, f1, f2);
-            int rc = k >= 3 ? run_profile(f1, f2, strcmp(alg, "ksw2") == 0, out) : -1;
+            int rc = k >= 3 ? run_profile(f1, f2, strcmp(alg, "ksw2") == 0, out, line[0] == 'Q') : -1;
             printf("%s\n", rc == 0 ? "ok" : "fail");
         } else printf("bad\n");
         fflush(stdout);

@@ -15,6 +15,7 @@
 
 #include "../../mapcaller_amd/csrc/mcx_glue.h"
 #include "../../mapcaller_amd/csrc/mcx_dp_lane.h"
+static long g_detail_checked = 0, g_detail_bad = 0; // MCX_EMU_DETAIL_CHECK: straight-line reads whose detail record was made both ways; those that differ
 static long g_simple_why[32]; // which exit of simple_read reads took (MCX_EMU_SIMPLE_WHY=1 prints the tally)
 #define MCX_SIMPLE_FAIL(code) do { g_simple_why[code]++; return false; } while (0)
 static long g_simple_len[3][40]; // lengths at the exits that a larger in-lane DP would take: [0] end gaps (exit 7), [1] genome side of unequal gaps (11), [2] equal gaps (18)
@@ -148,6 +149,12 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
     // k_simple: the straight-line pairs go from their seeds to their records at once (mcx_simple.h); the others take the stages below.
     // MCX_EMU_NO_SIMPLE=1: every pair takes the general path (the A/B of the tests).
     std::vector<uint8_t> done(n, 0);
+    // MCX_EMU_DETAIL_CHECK=1: the -vcf bookkeeping's per-read detail record made both ways — by the straight-line path (mcx_simple.h
+    // SimpleDetail, what k_simple<.., DETAIL> writes) and by the general path's write_detail / pair_stats — for every pair the straight-line
+    // path takes; such a pair then goes through the general path as well, and the two records are compared below
+    const bool detail_check = tier == 0 && getenv("MCX_EMU_DETAIL_CHECK") != nullptr;
+    std::vector<uint8_t> det_a, det_b, took(n, 0);
+    if (detail_check) { det_a.assign((size_t)cx.dlay.stride * n * nr, 0); det_b.assign((size_t)cx.dlay.stride * n * nr, 0); }
     if (tier == 0 && !getenv("MCX_EMU_NO_SIMPLE")) {
         // collect (k_simple) -> solve (k_simple_dp) -> replay (k_simple_rest); MCX_EMU_SIMPLE_NO_DP: a pair with a DP problem takes the general path
         const bool with_dp = !getenv("MCX_EMU_SIMPLE_NO_DP");
@@ -163,6 +170,8 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
             bool ok = true, wait = false;
             uint32_t mine[3 * kSimpleJobs];
             SimpleDpIo io; io.mode = mode; io.jobs = mine; io.job_stride = 1; io.res = mode == kDpReplay ? res.data() + slot * kSimpleJobs : nullptr; io.n = 0; io.read = 0;
+            SimpleNoDetail nod;
+            SimpleDetail det;
             for (int s = 0; s < nr && ok; s++) {
                 const uint32_t r = ids[l] * nr + s;
                 ReadRef one;
@@ -180,8 +189,15 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
                 io.read = (uint32_t)(l * 2 + s); // (here: the place of the read's words in `packed`)
                 ok = !has_n && nh >= 1 && nh <= kSimpleHits;
                 if (ok) {
-                    const int how = cx.pm.use_nw ? simple_read<true, uint32_t>(cx.ix, cx.pm, one.rlen, pk.data(), st.hits[s], nh, sr[s], cg[s], 1, io)
-                                                 : simple_read<false, uint32_t>(cx.ix, cx.pm, one.rlen, pk.data(), st.hits[s], nh, sr[s], cg[s], 1, io);
+                    int how;
+                    if (detail_check) {
+                        uint8_t *rec = det_a.data() + ((size_t)l * nr + s) * cx.dlay.stride;
+                        det.frags = (Frag *)(rec + sizeof(DetailHdr)); det.ops = rec + cx.dlay.off_ops;
+                        how = cx.pm.use_nw ? simple_read<true, uint32_t>(cx.ix, cx.pm, one.rlen, pk.data(), st.hits[s], nh, sr[s], cg[s], 1, io, det)
+                                           : simple_read<false, uint32_t>(cx.ix, cx.pm, one.rlen, pk.data(), st.hits[s], nh, sr[s], cg[s], 1, io, det);
+                    } else
+                        how = cx.pm.use_nw ? simple_read<true, uint32_t>(cx.ix, cx.pm, one.rlen, pk.data(), st.hits[s], nh, sr[s], cg[s], 1, io, nod)
+                                           : simple_read<false, uint32_t>(cx.ix, cx.pm, one.rlen, pk.data(), st.hits[s], nh, sr[s], cg[s], 1, io, nod);
                     ok = how != kSimpleNo;
                     wait = wait || how == kSimpleLater;
                 }
@@ -205,7 +221,10 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
             }
             e.cig_used += want;
             pout[ids[l]] = po;
-            done[l] = 1;
+            if (detail_check) { // (the pair takes the general path too)
+                for (int s = 0; s < nr; s++) *(DetailHdr *)(det_a.data() + ((size_t)l * nr + s) * cx.dlay.stride) = simple_detail_hdr(cx.ix, nr == 2, s, sr[0], sr[nr - 1]);
+                took[l] = 1;
+            } else done[l] = 1;
             if (stats) stats[11]++;
         };
         for (uint32_t l = 0; l < n; l++) pass(l, with_dp ? kDpCollect : kDpNone, 0);
@@ -320,7 +339,7 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
         make_reads(b, ids[l], rd);
         const uint32_t pair = ids[l];
         AlnRec *r0 = recs.data() + (int64_t)pair * nr - (int64_t)l * nr; // stage_finish indexes the records by l * nr + s
-        stage_finish(cx, l, rd, r0, nullptr);
+        stage_finish(cx, l, rd, r0, detail_check ? det_b.data() : nullptr);
         PairState st = pair_state(cx.state, cx.lay, cx.caps, l);
         const PairHdr &h = *st.hdr;
         PairOut o;
@@ -328,6 +347,34 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
         o.pair_dist = h.pair_dist; o.pair_ok = (int16_t)h.pair_ok; o.mapped = (int16_t)h.mapped;
         pout[pair] = o;
         if (h.flags & kOvAny) ov.push_back(pair);
+    }
+    if (detail_check) {
+        for (uint32_t l = 0; l < n; l++) {
+            if (!took[l]) continue;
+            for (int s = 0; s < nr; s++) {
+                const uint8_t *ra = det_a.data() + ((size_t)l * nr + s) * cx.dlay.stride, *rb = det_b.data() + ((size_t)l * nr + s) * cx.dlay.stride;
+                const DetailHdr &a = *(const DetailHdr *)ra, &b2 = *(const DetailHdr *)rb;
+                bool same = a.type == b2.type && a.n_frags == b2.n_frags && a.fwd == b2.fwd && a.n_ops == b2.n_ops;
+                if (s == 0) same = same && a.disc_kind == b2.disc_kind && a.disc_g1 == b2.disc_g1 && a.disc_g2 == b2.disc_g2 && a.disc_dist == b2.disc_dist;
+                const Frag *fa = (const Frag *)(ra + sizeof(DetailHdr)) + a.frag0, *fb = (const Frag *)(rb + sizeof(DetailHdr)) + b2.frag0;
+                for (int i = 0; same && i < a.n_frags; i++) {
+                    const Frag &x = fa[i], &y = fb[i];
+                    same = x.kind == y.kind && x.gPos == y.gPos && x.rPos == y.rPos && x.gLen == y.gLen && x.rLen == y.rLen;
+                    // (the columns the bookkeeping walks: ops_len of a DP fragment; the others are walked by their lengths)
+                    if (same && x.kind == kDp) same = x.ops_len == y.ops_len && memcmp(ra + cx.dlay.off_ops + x.ops_off, rb + cx.dlay.off_ops + y.ops_off, (size_t)x.ops_len) == 0;
+                }
+                g_detail_checked++;
+                if (!same) {
+                    g_detail_bad++;
+                    if (getenv("MCX_EMU_DEBUG")) {
+                        fprintf(stderr, "[detail] pair %u read %d: type %d/%d frags %d/%d fwd %d/%d ops %d/%d disc %d/%d\n", ids[l], s, a.type, b2.type, a.n_frags, b2.n_frags, a.fwd, b2.fwd, a.n_ops, b2.n_ops, a.disc_kind, b2.disc_kind);
+                        for (int i = 0; i < std::max(a.n_frags, b2.n_frags) && i < 16; i++)
+                            fprintf(stderr, "   %d: kind %d/%d r %d/%d rl %d/%d g %lld/%lld gl %d/%d cols %d/%d\n", i, (int)fa[i].kind, (int)fb[i].kind, (int)fa[i].rPos, (int)fb[i].rPos, (int)fa[i].rLen, (int)fb[i].rLen,
+                                    (long long)fa[i].gPos, (long long)fb[i].gPos, (int)fa[i].gLen, (int)fb[i].gLen, (int)fa[i].ops_len, (int)fb[i].ops_len);
+                    }
+                }
+            }
+        }
     }
     return ov;
 }
@@ -457,6 +504,9 @@ extern "C" int64_t hostemu_pair_check(const char *prefix, int64_t trials)
 }
 
 extern "C" {
+
+// MCX_EMU_DETAIL_CHECK runs so far: out[0] reads whose detail record was made both ways, out[1] those that differ; the counts start over
+void hostemu_detail_counts(int64_t out[2]) { out[0] = g_detail_checked; out[1] = g_detail_bad; g_detail_checked = g_detail_bad = 0; }
 
 // One problem through the product's one-problem-per-lane DP (mcx_dp_lane.h) for the reference's function-level vectors:
 // q over ACGTN, t over ACGT (the 2-bit genome holds no N), strips of K = 8 or 16 columns.  ops_out: the column string

@@ -358,11 +358,16 @@ def test_reference_driver_linked_against_libmcx(golden, tmp_path):
         assert nd == 0, ex
 
 
+@pytest.mark.parametrize("straight_line", [False, True])
 @pytest.mark.parametrize("name", list(SETS))
-def test_alignment_profile_equals_reference(api, golden, tmp_path, name):
+def test_alignment_profile_equals_reference(api, golden, tmp_path, monkeypatch, name, straight_line):
     """The -vcf bookkeeping on the GPU (k_prof_*): counter planes and sparse tallies against the
-    reference's MappingRecordArr / InsertSeqMap / DeleteSeqMap / BreakPointMap / site lists."""
+    reference's MappingRecordArr / InsertSeqMap / DeleteSeqMap / BreakPointMap / site lists.  straight_line: with what only a large
+    batch switches on forced onto these small ones (MCX_ORDER_MIN=1) — the straight-line pairs' detail records then come from
+    k_simple<.., DETAIL>, not from the finish stage."""
     import torch
+    if straight_line:
+        monkeypatch.setenv("MCX_ORDER_MIN", "1")
     g = golden[name]
     alg, prof, maps = g["prof"]
     ix = api.Index(g["prefix"], device=0, full_sa=True)
@@ -450,12 +455,15 @@ def test_profile_refuses_reads_after_the_settle(api, golden):
     mp.close(); ix.close()
 
 
+@pytest.mark.parametrize("straight_line", [False, True])
 @pytest.mark.parametrize("name,tag", VCF_CASES)
-def test_vcf_equals_reference(api, golden, tmp_path, name, tag):
+def test_vcf_equals_reference(api, golden, tmp_path, monkeypatch, name, tag, straight_line):
     """The whole -vcf surface on the GPU: mapping with the profile attached, then mcx_call_variants
     (k_vc_depth / k_vc_scan + sparse host logic) — the VCF of `MapCaller -vcf -t 1` line for line,
-    for every switch the golden runs cover."""
+    for every switch the golden runs cover; straight_line: with k_simple (and its detail records) forced onto the small batches."""
     import torch
+    if straight_line:
+        monkeypatch.setenv("MCX_ORDER_MIN", "1")
     g = golden[name]
     o = VcfOpts(VCF_RUNS[tag][1]).struct
     ix = api.Index(g["prefix"], device=0, full_sa=True)
@@ -616,6 +624,77 @@ def test_full_size_genome_prefix_equals_reference(api, bench_genome, tmp_path):
     assert st["tier1_pairs"] > 0, st  # pairs over the tier-0 capacities did go through the large tier
 
 
+def _nonzero_plane_records(planes, G):
+    """(positions, [n, 10] uint16) of the genome positions where any of the ten finalized planes is non-zero, in pieces (a genome-sized
+    temporary does not fit beside the planes)."""
+    import torch
+    from mapcaller_amd import api as a
+    pos, val = [], []
+    for lo in range(0, G, 1 << 27):
+        hi = min(G, lo + (1 << 27))
+        v = a.planes_view(planes, G, lo, hi)                       # [10, hi - lo] int32
+        idx = (v != 0).any(0).nonzero().reshape(-1)
+        pos.append((idx + lo).cpu().numpy())
+        val.append(v[:, idx].t().contiguous().cpu().numpy().astype(np.uint16))
+        del v, idx
+    return np.concatenate(pos), np.concatenate(val)
+
+
+def test_config4_vcf_slice_at_full_size_equals_reference(api, bench_genome, tmp_path, record_property):
+    """BASELINE config 4's per-GPU slice at full size: 200 k pairs x 150 bp of the bench workload against the 3.1 Gbp genome with the
+    -vcf bookkeeping on — profile attached, several batches (the duplicate cap spans them), pair records resident — through the product's
+    file path, then mcx_call_variants; against the compiled reference's own `-t 1 -sam -vcf` run on the same index files and its
+    MappingRecordArr / maps after Mapping() (mcref_tool Q: the positions with a non-zero counter).  SAM, the ten planes at every non-zero
+    position (positions above 2^31 among them: asserted), the insert / delete / break-point maps and site lists, and the VCF body must
+    be identical.  (main.cpp:372 new MappingRecord_t[GenomeSize], AlignmentProfile.cpp:41-271, VariantCalling.cpp:696-740.)"""
+    import torch
+    from mapcaller_amd import synth
+    ref_bin, ref_tool = os.path.join(ROOT, "oracle", "_ref", "MapCaller"), os.path.join(ROOT, "oracle", "_ref", "mcref_tool")
+    if not (os.path.exists(ref_bin) and os.path.exists(ref_tool)):
+        pytest.skip("the compiled reference did not travel to this box (the oracle's dense profile does not fit a 3.1 Gbp genome)")
+    g = bench_genome
+    ix = g["index"]
+    G = ix.genome_size
+    n_pairs = 200_000
+    reads = g["bench"].make_reads(g["codes"], g["lens"], n_pairs, 150, seed=10, device=g["dev"]).reshape(2 * n_pairs, 150).cpu()
+    f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+    synth.write_fastq(f1, reads, 0, 2); synth.write_fastq(f2, reads, 1, 2)
+    # the reference first, so that its two processes (49.6 GB of records each) are gone before the GPU side allocates
+    ref_sam, ref_vcf = str(tmp_path / "ref.sam"), str(tmp_path / "ref.vcf")
+    subprocess.run([ref_bin, "-i", g["prefix"], "-f", f1, "-f2", f2, "-alg", "ksw2", "-sam", ref_sam, "-vcf", ref_vcf, "-t", "1", "-log", str(tmp_path / "job.log")],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=2000)
+    dump = str(tmp_path / "ref")
+    r = subprocess.run([ref_tool], input=f"L {g['prefix']}\nQ ksw2 {dump} {f1} {f2}\n", text=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=2000)
+    assert r.stdout.split("\n")[1].strip() == "ok", r.stdout[-300:]
+    want = np.fromfile(dump + ".prof.nz", dtype=np.dtype([("pos", "<i8"), ("v", "<u2", (10,))]))
+    # the product: one context, batches of 128 K reads
+    mp = api.Mapper(ix, alg="ksw2", max_batch_reads=1 << 17)
+    planes = api.planes_alloc(G, "cuda:0")
+    mp.profile_attach(planes.data_ptr())
+    out = str(tmp_path / "gpu.sam")
+    st = mp.map_files(f1, f2, out)
+    mp.profile_finalize(planes.data_ptr())
+    nd, ex = sam_diff(ref_sam, out)
+    assert nd == 0, ex
+    got_pos, got_val = _nonzero_plane_records(planes, G)
+    assert got_pos.size == want.size and np.array_equal(got_pos, want["pos"]), (got_pos.size, want.size)
+    bad = np.argwhere(got_val != want["v"])
+    assert bad.size == 0, (bad[:5], got_pos[bad[:5, 0]], got_val[bad[:5, 0]], want["v"][bad[:5, 0]])
+    assert int((got_pos > (1 << 31)).sum()) > 1_000_000, "no counters above 2^31"
+    sparse = mp.profile_sparse()
+    assert maps_canon(api.sparse_to_maps_text(sparse)) == maps_canon(open(dump + ".maps", encoding="latin-1").read())
+    vcf = str(tmp_path / "gpu.vcf")
+    res = ix.call_variants(planes.data_ptr(), sparse, st["pairs"], st["pair_dist_sum"], st["pair_len_sum"], vcf, ref_name="ref", cmdline="test")
+    got, wantv = vcf_body(vcf), vcf_body(ref_vcf)
+    badv = [(a, b) for a, b in zip(got, wantv) if a != b]
+    assert not badv and len(got) == len(wantv), (len(got), len(wantv), badv[:3])
+    record_property("checker", "compiled reference")
+    print(f"[config 4 slice] {st['reads']} reads, {got_pos.size} positions with counters, {len(sparse)} tally records, {res['n_records']} VCF records: all equal to the reference's")
+    mp.close()
+    del planes
+    torch.cuda.empty_cache()
+
+
 def test_config2_ecoli_sized_single_end_equals_reference(api, tmp_path):
     """BASELINE config 2 at its own size: an E. coli-sized genome (4.6 Mbp, one contig, bench.py's generator), 300 k single-end
     reads x 100 bp (FASTA: the reference prints a stray quality byte for reverse-strand single-end FASTQ), -alg ksw2, index built on
@@ -676,15 +755,20 @@ def test_large_batch_machinery_does_not_change_the_records(api, bench_genome, mo
     monkeypatch.setenv("MCX_DP_LANE_ALWAYS", "1")  # every DP list one problem per lane (at this size the long lists take the wavefront kernels)
     c_aln, c_cig, c_st = run()
     monkeypatch.delenv("MCX_DP_LANE_ALWAYS")
+    # the large tier's build: every pair handed to one lane inside k_build_wave (what it does by itself for a pair whose fragment bounds do
+    # not fit the pool — stage_build's dense placement and overflow test)
+    monkeypatch.setenv("MCX_BUILD_WAVE_LIMIT", "0")
+    d_aln, d_cig, d_st = run()
+    monkeypatch.delenv("MCX_BUILD_WAVE_LIMIT")
     # everything off: no k_simple, no order, the wavefront DP kernels, the rescue in line, the late pairs searched again, the large tier's build a
     # lane per pair, the tiers one after the other, the seeding walk one base per step
     for k in ("MCX_NO_WORK_ORDER", "MCX_NO_LATE_OVERLAP", "MCX_NO_TIER_OVERLAP", "MCX_NO_SIMPLE", "MCX_DP_BY_WAVE", "MCX_RESCUE_IN_LINE", "MCX_LATE_RESEED", "MCX_BUILD_BY_LANE",
               "MCX_SEED_ONE_BASE"):
         monkeypatch.setenv(k, "1")
     b_aln, b_cig, b_st = run()
-    assert a_st["tier1"] > 0 and a_st["tier1"] == b_st["tier1"] == c_st["tier1"], (a_st, b_st, c_st)
+    assert a_st["tier1"] > 0 and a_st["tier1"] == b_st["tier1"] == c_st["tier1"] == d_st["tier1"], (a_st, b_st, c_st, d_st)
     assert b_st["simple"] == 0, b_st
-    for x_aln, x_cig in ((b_aln, b_cig), (c_aln, c_cig)):
+    for x_aln, x_cig in ((b_aln, b_cig), (c_aln, c_cig), (d_aln, d_cig)):
         for f in ("pos", "mate_pos", "chr", "flag", "mapq", "tlen", "nm", "as", "xs", "n_cigar", "fwd", "has_mate"):
             assert np.array_equal(a_aln[f], x_aln[f]), f
         for r in range(2 * n_pairs):
@@ -788,6 +872,17 @@ def test_fuzz_rounds_on_the_large_batch_paths_equal_oracle(monkeypatch):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1400)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "50 of 50 rounds identical" in r.stdout
+
+
+def test_fuzz_rounds_on_the_large_batch_paths_with_the_profile_equal_oracle(monkeypatch):
+    """The same with -vcf: the alignment profile is kept, the straight-line pairs' detail records come from k_simple (mcx_simple.h
+    SimpleDetail) and the others' from the finish stage: 40 rounds, SAM and VCF against the oracle's."""
+    monkeypatch.setenv("MCX_ORDER_MIN", "1")
+    monkeypatch.setenv("MCX_DP_LANE_ALWAYS", "1")
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "--rounds", "40", "--seed", "31337"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1400)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "40 of 40 rounds identical" in r.stdout
 
 
 def test_overlong_read_is_refused(api, golden):

@@ -122,6 +122,25 @@ def test_straight_line_pairs_with_their_own_dp_problems(hostemu_lib, golden, tmp
     assert st[6] < st_no_dp[6] <= st_general[6]                                                        # DP problems left to the general path
 
 
+@pytest.mark.parametrize("alg", ["nw", "ksw2"])
+@pytest.mark.parametrize("name", list(SETS))
+def test_straight_line_pairs_write_the_general_paths_detail_records(hostemu_lib, golden, tmp_path, monkeypatch, name, alg):
+    """With the -vcf bookkeeping on, the straight-line path writes the per-read detail records itself (mcx_simple.h SimpleDetail: what
+    k_simple<.., DETAIL> runs per lane) instead of leaving its pairs to the finish stage.  Every pair the path takes goes through the
+    general path as well here, and the two records of each of its reads are compared: type, orientation, every fragment (kind, read and
+    genome span) in order, the column strings of DP fragments (trimmed and dropped ends included), and in read 1's record the
+    discordant-pair fields of pair_stats (ReadMapping.cpp:486-521).  What UpdateProfile reads is then the same either way."""
+    monkeypatch.setenv("MCX_EMU_DETAIL_CHECK", "1")
+    cnt = (ctypes.c_int64 * 2)()
+    hostemu_lib.hostemu_detail_counts(cnt)  # (start over)
+    out = str(tmp_path / "e.sam")
+    n, st = _run(hostemu_lib, golden[name], alg, out)
+    nd, ex = sam_diff(golden[name]["sam"][alg], out)
+    assert nd == 0, ex
+    hostemu_lib.hostemu_detail_counts(cnt)
+    assert cnt[0] >= st[11] > 0 and cnt[1] == 0, (cnt[0], cnt[1], st[11])
+
+
 @pytest.mark.parametrize("name", ["toy", "mc"])
 def test_comparison_phase_forms_agree(hostemu_lib, golden, name):
     """The seeding walk's comparison phase 16 bases per fetch, 64 per fetch and 64-then-128 with the shared chunk kept: the same end of the
