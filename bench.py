@@ -272,17 +272,22 @@ def file_to_file(args, index, kept, reads_per_step):
 def vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, n_steps, d, dist, dev, rank, world):
     from mapcaller_amd import api, dist as mdist
     G = index.genome_size
-    # this leg keeps ten planes of the genome (124 GB at 3.1 Gbp) and per-read alignment detail in HBM:
-    # the timed region's context and all but one batch make room, the batch is mapped in slices
+    # this leg keeps the ten planes of the genome (68 GB at 3.1 Gbp; 124 GB until round 5) and per-read alignment detail in HBM:
+    # the timed region's context and all but one batch make room
     last = batches[n_steps - 1]
     del batches[:]
     if mapper is not None:
         mapper.close()
-    index.trim(1)             # (the pair records make room as well: 25 GB at 3.1 Gbp)
     torch.cuda.empty_cache()  # (the caching allocator would sit on the freed batches)
     slice_reads = min(reads_per_step, args.vcf_slice_reads)
-    mapper = api.Mapper(index, alg=args.alg, max_read_len=max(256, args.rlen), max_batch_reads=slice_reads)
-    planes = torch.zeros((10, G), dtype=torch.int32, device=dev)
+    # (the pair records stay — round 4 gave them back here, and mapped in slices of 4 M reads —; the large tier's records sized for this workload's
+    #  heavy pairs, 0.7 % of a batch, instead of config 5's 4.5 %: 8 GB instead of 24)
+    os.environ["MCX_TIER1_GB"] = str(args.vcf_tier1_gb)
+    try:
+        mapper = api.Mapper(index, alg=args.alg, max_read_len=max(256, args.rlen), max_batch_reads=slice_reads)
+    finally:
+        os.environ.pop("MCX_TIER1_GB", None)
+    planes = api.planes_alloc(G, dev)
 
     def map_slices():
         torch.cuda.synchronize()
@@ -315,36 +320,37 @@ def vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, n_s
         dist.barrier()
     t2 = time.perf_counter()
     # (every rank accumulated a run of its own here, so the readCount planes are summed too)
-    planes, merged = mdist.reduce_profile(planes, sparse, root=0, shared_read_count=False, mapper=mapper)
+    planes, merged = mdist.reduce_profile(planes, sparse, G, root=0, shared_read_count=False, mapper=mapper)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     t_red = time.perf_counter() - t2
     tot = mdist.sum_over_ranks([d["pairs"], d["pair_dist_sum"], d["pair_len_sum"]], dev)
-    gb = (mdist.reduce_profile.last_bytes if world > 1 else planes.numel() // 2 * 4) / 1e9  # (one GPU: what a rank would put on the wire)
+    gb = (mdist.reduce_profile.last_bytes if world > 1 else api.planes_stride(G) * 22) / 1e9  # (one GPU: what a rank would put on the wire, the readCount plane included here)
     vcf = {"profile_batch_ms": round(1000 * t_acc, 2), "same_slices_without_profile_ms": round(1000 * t_plain, 2),
            "profile_overhead_ms": round(1000 * (t_acc - t_plain), 2), "slice_reads": slice_reads, "sparse_records_to_host_ms": round(1000 * t_sp, 2),
            "settle_ms_once_per_run": round(1000 * t_settle, 2),
            "reduce_ms": round(1000 * t_red, 2), "reduce_gb": round(gb, 2),
            "reduce_gbs_into_root": None if world == 1 else round(gb * (world - 1) / max(t_red, 1e-9), 1),
-           "reduce": "none (one GPU); five packed planes per rank when there are several" if world == 1 else
-                     f"RCCL reduce of {world} x {round(gb * 1e9 / (4 * G))} u32 planes onto rank 0 in 1-GiB pieces (two 16-bit counters per word where that is exact)",
+           "reduce": "none (one GPU); 20-22 bytes per position and rank when there are several" if world == 1 else
+                     f"RCCL reduce of {world} x {round(gb * 1e9 / G, 1)} bytes per position onto rank 0 in 1-GiB pieces (the planes as they lie in HBM: multi_hit in 32 bits, the other nine in 16)",
            "sparse_records": len(merged)}
     if rank == 0:  # VariantCalling() runs once, on the reduced profile
         mapper.profile_finalize(planes.data_ptr())
         cov = 0
+        _, half = api.planes_parts(planes, G)
         for lo in range(0, G, 1 << 28):  # (in pieces: a genome-sized temporary does not fit beside the planes)
             hi = min(G, lo + (1 << 28))
-            cov += int(((planes[0, lo:hi] | planes[1, lo:hi] | planes[2, lo:hi] | planes[3, lo:hi]) > 0).sum().item())
+            cov += int(((half[0, lo:hi] | half[1, lo:hi] | half[2, lo:hi] | half[3, lo:hi]) != 0).sum().item())
         vcf["covered_positions"] = cov
         with tempfile.TemporaryDirectory() as tmp:
             vs = index.call_variants(planes.data_ptr(), merged, tot[0], tot[1], tot[2], os.path.join(tmp, "bench.vcf"),
                                      ref_name="synthetic", cmdline="bench.py")
-        # both scans stream the planes once: 16 B (k_vc_depth) and 20 B + 2-bit base + depth word (k_vc_scan) per position
+        # both scans stream the planes once: 8 B (k_vc_depth: A C G T in 16 bits each) and 12 B (those and multi_hit) + 2-bit base + depth word (k_vc_scan) per position
         vcf["call_variants"] = {"ms_total": round(vs["ms_total"], 2), "k_vc_depth_ms": round(vs["ms_depth"], 3),
                                 "k_vc_scan_ms": round(vs["ms_scan"], 3), "records": vs["n_records"], "snv": vs["n_snv"],
-                                "k_vc_depth_gbs": round(16.0 * G / max(vs["ms_depth"], 1e-6) / 1e6, 1),
-                                "k_vc_scan_gbs": round(20.29 * G / max(vs["ms_scan"], 1e-6) / 1e6, 1)}
+                                "k_vc_depth_gbs": round(8.0 * G / max(vs["ms_depth"], 1e-6) / 1e6, 1),
+                                "k_vc_scan_gbs": round(12.29 * G / max(vs["ms_scan"], 1e-6) / 1e6, 1)}
     mapper.close()
     return vcf
 
@@ -425,7 +431,8 @@ def parse():
     ap.add_argument("--file-batches", type=int, default=2, help="batches of the timed region whose reads the file-to-file leg maps (2 x 8 M reads: eight batches of the file pipeline)")
     ap.add_argument("--file-batch-reads", type=int, default=1 << 21, help="reads per batch of the file front end's pipeline")
     ap.add_argument("--file-threads", type=int, default=0, help="host threads per pool of the file front end (0 = pick)")
-    ap.add_argument("--vcf-slice-reads", type=int, default=4_000_000, help="reads per mapping call in the -vcf leg")
+    ap.add_argument("--vcf-slice-reads", type=int, default=8_000_000, help="reads per mapping call in the -vcf leg")
+    ap.add_argument("--vcf-tier1-gb", type=int, default=8, help="HBM for the large tier's pair records in the -vcf leg (MCX_TIER1_GB)")
     ap.add_argument("--vcf-reduce", type=int, default=1,
                     help="after the timed region: accumulate the -vcf alignment profile of one batch and sum it over the "
                          "ranks with RCCL (1 = yes, 0 = no, -1 = only when more than one GPU)")

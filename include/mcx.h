@@ -214,9 +214,12 @@ void mcx_exchange_local_free(mcx_exchange *first);
 /* ---- -vcf bookkeeping -------------------------------------------------------------------------
  * Replaces UpdateProfile / UpdateMultiHitCount (reference src/AlignmentProfile.cpp:41-271, called
  * under ProfileLock from src/ReadMapping.cpp:562-573) and the discordant-site lists
- * (src/ReadMapping.cpp:486-521).  d_planes: caller-owned, zero-initialised device array of
- * 10 * GenomeSize u32 laid out [plane][position], planes A C G T multi_hit readCount F1 R2 F2 R1 —
- * MappingRecord_t (src/structure.h:152-163) unpacked, so that several GPUs can sum their arrays
+ * (src/ReadMapping.cpp:486-521).  d_planes: caller-owned, zero-initialised device memory of
+ * mcx_planes_bytes(GenomeSize) bytes (mcx_planes_alloc makes it) — MappingRecord_t
+ * (src/structure.h:152-163) unpacked into one plane per counter, each in the width it needs, 22 bytes
+ * per position: with stride = GenomeSize rounded up to 64, first multi_hit as u32 [stride], then
+ * A C G T readCount F1 R2 F2 R1 as u16 [stride] each (mapcaller_amd/csrc/mcx_planes.h says why 16
+ * bits are exact for those nine) — so that several GPUs can sum their arrays
  * with one all-reduce.  Once attached, every mcx_map_batch* call adds its reads.  While a run is
  * being mapped the strand and multi_hit planes (and a context-owned plane for exact-seed coverage)
  * hold DIFFERENCES (+1 where a read starts to cover, -1 behind its end): mcx_profile_settle turns
@@ -258,9 +261,11 @@ int mcx_profile_sparse_shard(mcx_ctx *, const mcx_sparse_rec **recs, uint64_t *n
 int mcx_batch_end_keys(mcx_ctx *, mcx_stats *stats, const uint64_t **keys, uint64_t *n_keys);
 int mcx_batch_accumulate(mcx_ctx *, const uint64_t *all_keys, uint64_t n_all, uint32_t slot_stride, uint32_t own_slot);
 
-/* Device storage for the ten planes of one genome (zero-initialised); free with mcx_planes_free. */
+/* Device storage for the ten planes of one genome (zero-initialised); free with mcx_planes_free.
+ * mcx_planes_bytes: its size (22 bytes per position of the genome rounded up to 64 positions). */
 int mcx_planes_alloc(const mcx_index *, uint32_t **d_planes);
 void mcx_planes_free(uint32_t *d_planes);
+uint64_t mcx_planes_bytes(int64_t genome_size);
 
 /* ---- variant calling ---------------------------------------------------------------------------
  * Replaces VariantCalling() (reference src/VariantCalling.cpp:696-740; called from src/main.cpp:379

@@ -34,16 +34,17 @@ int32_t mcx_comm_rank(const mcx_comm *);
 int32_t mcx_comm_size(const mcx_comm *);
 
 /* Sums the counter planes of every rank onto `root` (ncclReduce, in pieces that fit a 32-bit count):
- * d_planes = the array given to mcx_profile_attach, 10 * genome_size u32 [plane][position].  The
- * readCount plane is left alone — with the duplicate cap decided across shards (mcx_batch_accumulate)
- * every rank already holds the run's count.  The counters are 12- and 16-bit fields once finalised,
- * so two planes travel in one u32 where that is exact: A|C and G|T clamped to 4095 on every rank first
- * (up to 16 ranks), F1|R2 and F2|R1 when no low half can carry (largest low half over all ranks x ranks
- * < 2^16; otherwise the four travel alone) — five planes (20 bytes per position) on the wire instead of
- * nine.  What the root holds afterwards equals the plain sum once finalised; the other ranks' planes are
- * left in their packed form.  Collective: every rank calls it, after its own
+ * d_planes = the memory given to mcx_profile_attach (mcx.h: multi_hit as u32, the other nine planes as
+ * u16, 22 bytes per position).  The readCount plane is left alone — with the duplicate cap decided across
+ * shards (mcx_batch_accumulate) every rank already holds the run's count.  RCCL sums no 16-bit integers, so
+ * the 16-bit planes travel as the words they lie in, two positions to a word: A C G T clamped to 4095 on
+ * every rank first (up to 16 ranks cannot carry into the neighbouring half, and the clamped sum finalises to
+ * the same value), F1 R2 F2 R1 as they are when no half can carry (the largest one over all ranks times
+ * the number of ranks is below 2^16; otherwise piece by piece with one counter per word) — 20 bytes per
+ * position on the wire.  What the root holds afterwards equals the plain sum once finalised; the other
+ * ranks' planes are scratch.  Call after
  * mcx_profile_settle (the planes must hold counts, not differences) and before
- * mcx_profile_finalize on the root.  seconds (may be NULL): wall time of the call on this rank. */
+ * mcx_profile_finalize / mcx_call_variants on the root. */
 int mcx_profile_reduce(mcx_comm *, uint32_t *d_planes, int64_t genome_size, int32_t root, double *seconds);
 
 /* An mcx_exchange (mcx.h) over the communicator, for launchers that run one process per GPU without

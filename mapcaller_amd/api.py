@@ -62,7 +62,7 @@ SYMBOLS = [
     "mcx_index_genome_size", "mcx_index_n_chr", "mcx_index_chr_name", "mcx_index_chr_len", "mcx_index_hbm_bytes",
     "mcx_opts_default", "mcx_ctx_create", "mcx_ctx_free", "mcx_bwt_search_batch", "mcx_extend_batch",
     "mcx_avg_init", "mcx_map_batch_dev", "mcx_map_batch", "mcx_cigar_words", "mcx_map_files", "mcx_map_files_ex", "mcx_file_opts_default",
-    "mcx_profile_attach", "mcx_profile_settle", "mcx_profile_finalize", "mcx_profile_sparse", "mcx_planes_alloc", "mcx_planes_free",
+    "mcx_profile_attach", "mcx_profile_settle", "mcx_profile_finalize", "mcx_profile_sparse", "mcx_planes_alloc", "mcx_planes_free", "mcx_planes_bytes",
     "mcx_vcf_defaults", "mcx_call_variants",
     "mcx_batch_begin", "mcx_batch_sums", "mcx_batch_replay", "mcx_batch_end", "mcx_avg_walk", "mcx_exchange_local", "mcx_exchange_local_free",
     "mcx_profile_sparse_shard", "mcx_batch_end_keys", "mcx_batch_accumulate",
@@ -101,15 +101,58 @@ class SparseRec(C.Structure):
 PLANES = ("A", "C", "G", "T", "multi_hit", "readCount", "F1", "R2", "F2", "R1")
 
 
+MULTI_PLANE = 4  # the one plane kept in 32 bits
+
+
+def planes_stride(G: int) -> int:
+    return (G + 63) & ~63
+
+
+def planes_words(G: int) -> int:
+    """32-bit words of the ten counter planes of a genome of G positions (mcx_planes_bytes / 4; csrc/mcx_planes.h): with
+    stride = G rounded up to 64, multi_hit as u32 [stride], then A C G T readCount F1 R2 F2 R1 as u16 [stride] each."""
+    return planes_stride(G) * 11 // 2
+
+
 def planes_alloc(G: int, device):
-    """Zeroed HBM for the ten counter planes of a genome of G positions (what profile_attach takes)."""
+    """Zeroed memory for the ten counter planes of a genome of G positions (what profile_attach takes): int32 [planes_words(G)]."""
     import torch
-    return torch.zeros((10, G), dtype=torch.int32, device=device)
+    return torch.zeros(planes_words(G), dtype=torch.int32, device=device)
+
+
+def planes_parts(planes, G: int):
+    """(multi_hit int32 [stride], the nine 16-bit planes int16 [9, stride] in the order A C G T readCount F1 R2 F2 R1): views."""
+    import torch
+    st = planes_stride(G)
+    return planes[:st], planes[st:].view(torch.int16).reshape(9, st)
 
 
 def planes_view(planes, G: int, lo: int = 0, hi: Optional[int] = None):
-    """The positions [lo, hi) of all ten planes as int32 [10, hi - lo] (PLANES order)."""
-    return planes[:, lo:G if hi is None else hi]
+    """The positions [lo, hi) of all ten planes as int32 [10, hi - lo] in PLANES order (a copy)."""
+    import torch
+    hi = G if hi is None else hi
+    multi, half = planes_parts(planes, G)
+    out = torch.empty((10, hi - lo), dtype=torch.int32, device=planes.device)
+    for k in range(10):
+        if k == MULTI_PLANE:
+            out[k] = multi[lo:hi]
+        else:
+            out[k] = half[k if k < MULTI_PLANE else k - 1, lo:hi].to(torch.int32) & 0xFFFF
+    return out
+
+
+def planes_from_rows(rows, device=None):
+    """The planes' memory for counters given as int [10, G] in PLANES order (tests): the inverse of planes_view."""
+    import torch
+    G = rows.shape[1]
+    planes = planes_alloc(G, device if device is not None else rows.device)
+    multi, half = planes_parts(planes, G)
+    multi[:G] = rows[MULTI_PLANE].to(torch.int32)
+    for k in range(10):
+        if k != MULTI_PLANE:
+            v = rows[k].to(torch.int32) & 0xFFFF
+            half[k if k < MULTI_PLANE else k - 1, :G] = torch.where(v >= 0x8000, v - 0x10000, v).to(torch.int16)
+    return planes
 
 
 class Stats(C.Structure):
@@ -253,6 +296,8 @@ def lib() -> C.CDLL:
     L.mcx_planes_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.mcx_planes_free.argtypes = [C.c_void_p]
     L.mcx_planes_free.restype = None
+    L.mcx_planes_bytes.argtypes = [C.c_int64]
+    L.mcx_planes_bytes.restype = C.c_uint64
     L.mcx_vcf_defaults.argtypes = [C.POINTER(VcfOpts)]
     L.mcx_vcf_defaults.restype = None
     L.mcx_call_variants.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int64,
@@ -509,8 +554,8 @@ class Mapper:
 
     # ---- -vcf bookkeeping ---------------------------------------------------------------
     def profile_attach(self, d_planes_ptr: int, max_dup: int = 5, max_clip: int = 5) -> None:
-        """d_planes: zeroed device array uint32 [10, GenomeSize] (PLANES order), caller-owned so
-        that it can be all-reduced across GPUs; every later map_batch* call accumulates into it."""
+        """d_planes: zeroed device memory of planes_words(GenomeSize) 32-bit words (planes_alloc), caller-owned so
+        that it can be reduced across GPUs; every later map_batch* call accumulates into it."""
         _check(lib().mcx_profile_attach(self._h, d_planes_ptr, max_dup, max_clip), "mcx_profile_attach")
 
     def profile_settle(self) -> None:

@@ -3,16 +3,18 @@
 // The reference keeps one MappingRecordArr in host memory that every mapping thread updates under
 // ProfileLock (src/AlignmentProfile.cpp:41-242, src/ReadMapping.cpp:562-573).  Here every GPU keeps its
 // own counter planes while it maps and they are summed once, onto the GPU that calls the variants:
-// ncclReduce over xGMI, nine planes of u32 (the readCount plane is already the run's on every rank).
-// xGMI is point to point, so the reduce is issued plane by plane in pieces of at most 2^28 elements
-// (1 GiB): large enough to run at link speed, small enough for a 32-bit count and to let the
-// rings of consecutive pieces overlap.
+// ncclReduce over xGMI of the planes as they lie in HBM (mcx_planes.h: multi_hit in 32 bits, the others in 16 — RCCL has no
+// 16-bit integer sum, so those travel as words of two positions; 20 bytes per position on the wire; the readCount plane is
+// already the run's on every rank).  xGMI is point to point, so the reduce is issued in pieces of at most 2^28 words
+// (1 GiB): large enough to run at link speed, small enough for a 32-bit count and to let the rings of consecutive
+// pieces overlap.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -20,6 +22,7 @@
 
 #include "../../include/mcx_comm.h"
 #include "mcx_build.h"
+#include "mcx_planes.h"
 
 namespace {
 
@@ -43,36 +46,46 @@ __global__ void k_add_planes(uint32_t *dst, const uint32_t *src, uint64_t n)
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] += src[i];
 }
 
-// Two 16-bit counters share a u32 on the wire (the planes are 12- and 16-bit fields once finalised, mcx_profile_finalize).
-// clamp != 0: saturating counters (A C G T), every rank's value clamped to 4095 first — sixteen ranks cannot carry into the
-// high half, and min(sum of min(x, 4095), 4095) is min(sum of x, 4095).  clamp == 0: the strand counters, which wrap at 2^16;
-// used only when no low half can carry (k_low_max over all ranks, times the number of ranks, stays below 2^16).
-__global__ void k_pack_planes(uint32_t *lo, const uint32_t *hi, uint64_t n, int clamp)
+// the same for words that hold two 16-bit counters (mcx_planes.h): each half by itself, modulo 2^16
+__global__ void k_add_halves(uint32_t *dst, const uint32_t *src, uint64_t n)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t a = lo[i], b = hi[i];
-        if (clamp) { a = a < 4095u ? a : 4095u; b = b < 4095u ? b : 4095u; }
-        lo[i] = (a & 0xFFFFu) | (b << 16);
+        const uint32_t a = dst[i], b = src[i];
+        dst[i] = ((a + b) & 0xFFFFu) | ((a & 0xFFFF0000u) + (b & 0xFFFF0000u));
     }
 }
 
-__global__ void k_unpack_planes(uint32_t *lo, uint32_t *hi, uint64_t n)
+// A C G T before they are summed as words: every rank's counters clamped to 4095 — sixteen ranks cannot carry into the
+// neighbouring half, and min(sum of min(x, 4095), 4095) is min(sum of x, 4095), which is what mcx_profile_finalize leaves.
+__global__ void k_clamp_halves(uint32_t *w, uint64_t n)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t p = lo[i];
-        lo[i] = p & 0xFFFFu; hi[i] = p >> 16;
+        const uint32_t v = w[i], lo = v & 0xFFFFu, hi = v >> 16;
+        if (lo > 4095u || hi > 4095u) w[i] = (lo < 4095u ? lo : 4095u) | ((hi < 4095u ? hi : 4095u) << 16);
     }
 }
 
-__global__ void k_low_max(const uint32_t *a, const uint32_t *b, uint64_t n, uint32_t *out)
+// the largest 16-bit counter among n words: the strand counters wrap at 2^16, so their words can be summed as words only when no
+// low half can carry (this maximum over all ranks, times the number of ranks, stays below 2^16)
+__global__ void k_half_max(const uint32_t *w, uint64_t n, uint32_t *out)
 {
     uint32_t m = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t x = a[i] & 0xFFFFu, y = b[i] & 0xFFFFu;
+        const uint32_t v = w[i], x = v & 0xFFFFu, y = v >> 16;
         m = m > x ? m : x; m = m > y ? m : y;
     }
     for (int o = 32; o > 0; o >>= 1) { const uint32_t other = (uint32_t)__shfl_down((int)m, o, 64); m = m > other ? m : other; }
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// when they can carry: a piece of the words widened to one counter per u32, summed, and narrowed again on the root
+__global__ void k_widen(const uint32_t *w, uint64_t n, uint32_t *out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) { const uint32_t v = w[i]; out[2 * i] = v & 0xFFFFu; out[2 * i + 1] = v >> 16; }
+}
+__global__ void k_narrow(const uint32_t *in, uint64_t n, uint32_t *w)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) w[i] = (in[2 * i] & 0xFFFFu) | (in[2 * i + 1] << 16);
 }
 
 int fail_hip(const char *what, hipError_t e) { return mcx_set_error(MCX_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); }
@@ -168,17 +181,20 @@ extern "C" int mcx_profile_reduce(mcx_comm *c, uint32_t *d_planes, int64_t G, in
     const auto t0 = std::chrono::steady_clock::now();
     int rc = comm_stream(c);
     if (rc) return rc;
-    const int kPlanes = 10, kReadCount = 5;
-    if (c->nccl) { // (one rank too: the same packing, collectives and unpacking — that is what a one-GPU box can test)
-        const uint64_t piece = 1ull << 28, n = (uint64_t)G;
-        auto plane = [&](int k) { return d_planes + (uint64_t)k * n; };
+    // the planes as words (mcx_planes.h): multi_hit one counter a word; A C G T | readCount | F1 R2 F2 R1 two positions a word
+    const mcx::PlanesView pl = mcx::planes_view(d_planes, G);
+    const uint64_t hw = pl.stride / 2; // words per 16-bit plane
+    uint32_t *acgt = (uint32_t *)pl.h(mcx::kPlA), *strands = (uint32_t *)pl.h(mcx::kPlF1);
+    if (c->nccl) { // (one rank too: the same kernels and collectives — that is what a one-GPU box can test)
+        if (c->size > 16) return mcx_set_error(MCX_ERR_UNSUPPORTED, "mcx_profile_reduce: more than 16 ranks (A C G T travel as 16-bit halves clamped to 4095)");
+        const uint64_t piece = 1ull << 28;
         auto dead = [&](const char *what, ncclResult_t e) { // the peers sit in the collectives queued so far: abort the communicator so that they come back with an error
             const int r = fail_nccl(what, e);
             (void)ncclCommAbort(c->nccl); c->nccl = nullptr;
             return r;
         };
-        auto reduce_plane = [&](int k) -> int {
-            uint32_t *p = plane(k);
+        auto dead_hip = [&](const char *what, hipError_t e) { const int r = fail_hip(what, e); (void)ncclCommAbort(c->nccl); c->nccl = nullptr; return r; };
+        auto reduce_words = [&](uint32_t *p, uint64_t n) -> int {
             for (uint64_t lo = 0; lo < n; lo += piece) {
                 const uint64_t cnt = std::min<uint64_t>(piece, n - lo);
                 ncclResult_t e = ncclReduce(p + lo, p + lo, (size_t)cnt, ncclUint32, ncclSum, root, c->nccl, c->stream);
@@ -186,38 +202,44 @@ extern "C" int mcx_profile_reduce(mcx_comm *c, uint32_t *d_planes, int64_t G, in
             }
             return 0;
         };
-        enum { pA = 0, pC, pG, pT, pMulti, pRC, pF1, pR2, pF2, pR1 };
-        // can the strand planes share words?  the largest low half over all ranks decides, the same way on every rank
+        k_clamp_halves<<<8192, 256, 0, c->stream>>>(acgt, 4 * hw);
+        if ((rc = reduce_words(acgt, 4 * hw))) return rc;
+        // can the strand counters travel as words?  the largest one over all ranks decides, the same way on every rank
         bool strands_share = false;
         {
             uint32_t *d_top = nullptr, top = 0;
             hipError_t he = hipMalloc((void **)&d_top, sizeof(uint32_t));
             if (he == hipSuccess) he = hipMemsetAsync(d_top, 0, sizeof(uint32_t), c->stream);
-            if (he != hipSuccess) { rc = fail_hip("mcx_profile_reduce", he); (void)ncclCommAbort(c->nccl); c->nccl = nullptr; return rc; }
-            k_low_max<<<4096, 256, 0, c->stream>>>(plane(pF1), plane(pF2), n, d_top);
+            if (he != hipSuccess) return dead_hip("mcx_profile_reduce", he);
+            k_half_max<<<4096, 256, 0, c->stream>>>(strands, 4 * hw, d_top);
             ncclResult_t e = ncclAllReduce(d_top, d_top, 1, ncclUint32, ncclMax, c->nccl, c->stream);
             if (e != ncclSuccess) { (void)hipFree(d_top); return dead("ncclAllReduce", e); }
             he = hipMemcpyAsync(&top, d_top, sizeof top, hipMemcpyDeviceToHost, c->stream);
             if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
             (void)hipFree(d_top);
-            if (he != hipSuccess) { rc = fail_hip("mcx_profile_reduce", he); (void)ncclCommAbort(c->nccl); c->nccl = nullptr; return rc; }
-            strands_share = (uint64_t)top * (uint64_t)c->size <= 0xFFFFu;
+            if (he != hipSuccess) return dead_hip("mcx_profile_reduce", he);
+            strands_share = (uint64_t)top * (uint64_t)c->size <= 0xFFFFu && !getenv("MCX_REDUCE_WIDE"); // (MCX_REDUCE_WIDE: tests — the other way on a box with one GPU)
         }
-        const bool counters_share = c->size <= 16;
-        struct Pair { int lo, hi, clamp; bool on; };
-        const Pair pairs[4] = {{pA, pC, 1, counters_share}, {pG, pT, 1, counters_share}, {pF1, pR2, 0, strands_share}, {pF2, pR1, 0, strands_share}};
-        for (const Pair &q : pairs) {
-            if (q.on) {
-                k_pack_planes<<<8192, 256, 0, c->stream>>>(plane(q.lo), plane(q.hi), n, q.clamp);
-                if ((rc = reduce_plane(q.lo))) return rc;
-                if (c->rank == root) k_unpack_planes<<<8192, 256, 0, c->stream>>>(plane(q.lo), plane(q.hi), n);
-            } else {
-                if ((rc = reduce_plane(q.lo)) || (rc = reduce_plane(q.hi))) return rc;
+        if (strands_share) { if ((rc = reduce_words(strands, 4 * hw))) return rc; }
+        else { // (sums of independent deep runs: a counter per word on the wire, piece by piece)
+            uint32_t *wide = nullptr;
+            const uint64_t pw = 1ull << 27; // words per piece: 2^28 counters
+            hipError_t he = hipMalloc((void **)&wide, (size_t)(2 * std::min<uint64_t>(pw, 4 * hw)) * sizeof(uint32_t));
+            if (he != hipSuccess) return dead_hip("mcx_profile_reduce (room to widen the strand planes)", he);
+            for (uint64_t lo = 0; lo < 4 * hw && rc == 0; lo += pw) {
+                const uint64_t cnt = std::min<uint64_t>(pw, 4 * hw - lo);
+                k_widen<<<8192, 256, 0, c->stream>>>(strands + lo, cnt, wide);
+                ncclResult_t e = ncclReduce(wide, wide, (size_t)(2 * cnt), ncclUint32, ncclSum, root, c->nccl, c->stream);
+                if (e != ncclSuccess) { rc = dead("ncclReduce", e); break; }
+                if (c->rank == root) k_narrow<<<8192, 256, 0, c->stream>>>(wide, cnt, strands + lo);
             }
+            if (rc == 0) (void)hipStreamSynchronize(c->stream);
+            (void)hipFree(wide);
+            if (rc) return rc;
         }
-        if ((rc = reduce_plane(pMulti))) return rc;
+        if ((rc = reduce_words(pl.multi, pl.stride))) return rc;
         hipError_t he = hipStreamSynchronize(c->stream);
-        if (he != hipSuccess) { rc = fail_hip("hipStreamSynchronize", he); (void)ncclCommAbort(c->nccl); c->nccl = nullptr; return rc; }
+        if (he != hipSuccess) return dead_hip("hipStreamSynchronize", he);
         ncclResult_t ae = ncclSuccess;
         if (ncclCommGetAsyncError(c->nccl, &ae) == ncclSuccess && ae != ncclSuccess) { rc = fail_nccl("ncclReduce (asynchronous)", ae); (void)ncclCommAbort(c->nccl); c->nccl = nullptr; return rc; }
     } else if (c->size > 1) { // ranks of one process on a shared device: the root adds the others' planes itself
@@ -230,11 +252,11 @@ extern "C" int mcx_profile_reduce(mcx_comm *c, uint32_t *d_planes, int64_t G, in
         if (c->rank == root && !g.failed.load()) {
             for (int r = 0; r < c->size && rc == 0; r++) {
                 if (r == root) continue;
-                for (int k = 0; k < kPlanes && rc == 0; k++) {
-                    if (k == kReadCount) continue;
-                    k_add_planes<<<4096, 256, 0, c->stream>>>(d_planes + (uint64_t)k * (uint64_t)G, (const uint32_t *)g.ptr[(size_t)r] + (uint64_t)k * (uint64_t)G, (uint64_t)G);
-                    if ((he = hipGetLastError()) != hipSuccess) rc = fail_hip("k_add_planes", he);
-                }
+                const mcx::PlanesView o = mcx::planes_view(g.ptr[(size_t)r], G);
+                k_add_planes<<<4096, 256, 0, c->stream>>>(pl.multi, o.multi, pl.stride);
+                k_add_halves<<<4096, 256, 0, c->stream>>>(acgt, (const uint32_t *)o.h(mcx::kPlA), 4 * hw);       // (the readCount plane between them is left alone)
+                k_add_halves<<<4096, 256, 0, c->stream>>>(strands, (const uint32_t *)o.h(mcx::kPlF1), 4 * hw);
+                if ((he = hipGetLastError()) != hipSuccess) rc = fail_hip("k_add_planes", he);
             }
             he = hipStreamSynchronize(c->stream);
             if (he != hipSuccess && rc == 0) rc = fail_hip("k_add_planes", he);

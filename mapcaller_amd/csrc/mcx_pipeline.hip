@@ -2079,7 +2079,7 @@ struct mcx_ctx {
     // -vcf bookkeeping (mcx_profile.h): caller-owned counter planes, per-read alignment detail
     uint32_t *prof_planes = nullptr; int prof_max_dup = 5, prof_max_clip = 5;
     ColItem *d_prof_items = nullptr; uint32_t prof_items_cap = 0; // fragments whose columns k_prof_cols walks
-    uint32_t *d_prof_match = nullptr; bool prof_settled = false, prof_broken = false; // (broken: a settle failed half way — some planes scanned, some not)
+    uint16_t *d_prof_match = nullptr; bool prof_settled = false, prof_broken = false; // (broken: a settle failed half way — some planes scanned, some not)
     // exact-seed coverage as differences (mcx_profile.h); freed by mcx_profile_settle
     uint8_t *d_detail = nullptr; DetailLayout dlay;
     uint64_t *d_keys[2] = {nullptr, nullptr}; uint8_t *d_admit = nullptr; void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
@@ -3524,8 +3524,9 @@ extern "C" int mcx_profile_attach(mcx_ctx *c, uint32_t *d_planes, int max_dup, i
         const uint64_t first = std::min<uint64_t>(std::max<uint64_t>(c->sparse_cap, (uint64_t)1 << 20), (uint64_t)1 << 22);
         if (hipMalloc((void **)&c->arch.d, first * sizeof(SparseRec)) == hipSuccess) c->arch.cap = first; else { (void)hipGetLastError(); c->arch.d = nullptr; }
     }
-    if (!c->d_prof_match) { int rc = dmalloc(&c->d_prof_match, (size_t)c->idx->view.G); if (rc) return rc; }
-    HIP_TRY(hipMemsetAsync(c->d_prof_match, 0, (size_t)c->idx->view.G * sizeof(uint32_t), c->stream));
+    const size_t match_n = (size_t)planes_stride(c->idx->view.G);
+    if (!c->d_prof_match) { int rc = dmalloc(&c->d_prof_match, match_n); if (rc) return rc; }
+    HIP_TRY(hipMemsetAsync(c->d_prof_match, 0, match_n * sizeof(uint16_t), c->stream));
     c->prof_settled = false; c->prof_broken = false;
     return 0;
 }
@@ -3552,7 +3553,7 @@ static int profile_keys(mcx_ctx *c)
     BatchRun &br = c->run;
     hipStream_t s = c->stream;
     const IndexView &ix = c->idx->view;
-    ProfView pv; pv.plane = c->prof_planes; pv.match = c->d_prof_match; pv.G = ix.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
+    ProfView pv; pv.pl = planes_view(c->prof_planes, ix.G); pv.match = c->d_prof_match; pv.G = ix.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
     SparseSink sink; sink.recs = c->d_sparse; sink.n = c->d_cnt + CNT_TASKS; sink.cap = c->sparse_cap; sink.refused = c->d_cnt + CNT_UNSUP;
     const uint32_t n = br.rb.n_reads;
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
@@ -3573,7 +3574,7 @@ static int profile_foreign(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all)
 {
     if (n_all == 0) return 0;
     hipStream_t s = c->stream;
-    ProfView pv; pv.plane = c->prof_planes; pv.match = c->d_prof_match; pv.G = c->idx->view.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
+    ProfView pv; pv.pl = planes_view(c->prof_planes, c->idx->view.G); pv.match = c->d_prof_match; pv.G = c->idx->view.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
     int rc = sort_reserve(c, n_all);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_keys[0], h_all, n_all * sizeof(uint64_t), hipMemcpyHostToDevice, s));
@@ -3659,7 +3660,7 @@ static int profile_accumulate(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all,
     BatchRun &br = c->run;
     hipStream_t s = c->stream;
     const IndexView &ix = c->idx->view;
-    ProfView pv; pv.plane = c->prof_planes; pv.match = c->d_prof_match; pv.G = ix.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
+    ProfView pv; pv.pl = planes_view(c->prof_planes, ix.G); pv.match = c->d_prof_match; pv.G = ix.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
     SparseSink sink; sink.recs = c->d_sparse; sink.n = c->d_cnt + CNT_TASKS; sink.cap = c->sparse_cap; sink.refused = c->d_cnt + CNT_UNSUP;
     const uint32_t n = br.rb.n_reads;
     const int paired = br.paired;
@@ -3720,26 +3721,30 @@ extern "C" int mcx_profile_settle(mcx_ctx *c)
     hipStream_t s = c->stream;
     const IndexView &ix = c->idx->view;
     const size_t G = (size_t)ix.G;
-    size_t tb = 0;
-    HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tb, c->d_prof_match, c->d_prof_match, G, s));
+    const PlanesView pl = planes_view(c->prof_planes, ix.G);
+    size_t tb = 0, tb16 = 0;
+    HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tb, pl.multi, pl.multi, G, s));
+    HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tb16, c->d_prof_match, c->d_prof_match, G, s));
+    tb = std::max(tb, tb16);
     void *tmp = nullptr;
     HIP_TRY(hipMalloc(&tmp, tb + 256)); // (nothing touched yet: a retry is safe)
-    hipError_t e = hipSuccess;
-    const int diffs[5] = {kPlMulti, kPlF1, kPlR2, kPlF2, kPlR1};
+    hipError_t e = hipcub::DeviceScan::InclusiveSum(tmp, tb, pl.multi, pl.multi, G, s);
+    // the 16-bit difference planes: their words back to two differences each (mcx_planes.h), then the scan modulo 2^16
+    uint16_t *diffs[5] = {pl.h(kPlF1), pl.h(kPlR2), pl.h(kPlF2), pl.h(kPlR1), c->d_prof_match};
     for (int k = 0; k < 5 && e == hipSuccess; k++) {
-        uint32_t *p = c->prof_planes + (size_t)diffs[k] * G;
-        e = hipcub::DeviceScan::InclusiveSum(tmp, tb, p, p, G, s);
+        k_prof_decode<<<8192, 256, 0, s>>>((uint32_t *)diffs[k], pl.stride / 2);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipcub::DeviceScan::InclusiveSum(tmp, tb, diffs[k], diffs[k], G, s);
     }
-    if (e == hipSuccess) e = hipcub::DeviceScan::InclusiveSum(tmp, tb, c->d_prof_match, c->d_prof_match, G, s);
     if (e == hipSuccess) {
-        ProfView pv; pv.plane = c->prof_planes; pv.match = c->d_prof_match; pv.G = ix.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
+        ProfView pv; pv.pl = pl; pv.match = c->d_prof_match; pv.G = ix.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
         k_prof_fold<<<8192, 256, 0, s>>>(ix, pv);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(tmp);
     if (e != hipSuccess) { c->prof_broken = c->prof_settled = true; HIP_TRY(e); } // (a second settle must not scan the scanned planes again)
-    (void)hipFree(c->d_prof_match); c->d_prof_match = nullptr; // (12 GB at 3.1 Gbp: the variant caller's scans want the room)
+    (void)hipFree(c->d_prof_match); c->d_prof_match = nullptr; // (6 GB at 3.1 Gbp: the variant caller's scans want the room)
     c->prof_settled = true;
     return 0;
 }
@@ -3749,7 +3754,7 @@ extern "C" int mcx_profile_finalize(mcx_ctx *c, uint32_t *d_planes)
     if (!c || !d_planes) return fail(MCX_ERR_ARG, "mcx_profile_finalize: null argument");
     HIP_TRY(hipSetDevice(c->idx->device));
     if (d_planes == c->prof_planes) { if (int rc = mcx_profile_settle(c)) return rc; }
-    k_prof_finalize<<<dim3(4096, kPlanes), 256, 0, c->stream>>>(d_planes, c->idx->view.G, c->prof_max_dup);
+    k_prof_finalize<<<dim3(4096, kPlanes), 256, 0, c->stream>>>(planes_view(d_planes, c->idx->view.G), c->prof_max_dup);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;

@@ -4,10 +4,11 @@
 // the reference runs serially under ProfileLock (src/ReadMapping.cpp:562-573) into a 16-byte
 // bit-field record per genome position (MappingRecord_t, src/structure.h:152-163).
 //
-// Here the per-position counters are ten u32 planes [k][G] (A C G T multi_hit readCount F1 R2 F2 R1)
-// in caller-owned HBM, so that a multi-GPU run can sum them with one RCCL all-reduce; the field
-// widths of the reference (12-bit saturation at 4095, 16-bit wrap, duplicate cap) are applied
-// afterwards by k_prof_finalize.  One lane accumulates one read (k_prof_accum).
+// Here the per-position counters are ten planes (A C G T multi_hit readCount F1 R2 F2 R1) in caller-owned
+// HBM — multi_hit 32 bits wide, the other nine 16: mcx_planes.h, 22 bytes per position —, so that a
+// multi-GPU run can sum them with plain reduces; the field widths of the reference (12-bit saturation
+// at 4095, 16-bit wrap, duplicate cap) are applied afterwards by k_prof_finalize.  One lane
+// accumulates one read (k_prof_accum).
 //
 // Most of what a read adds is a run of +1 over consecutive positions: its strand plane over the
 // whole read, the multi-hit plane over a candidate's span, and the base planes under an exact seed
@@ -24,16 +25,15 @@
 #ifndef MCX_PROFILE_H
 #define MCX_PROFILE_H
 #include "mcx_glue.h"
+#include "mcx_planes.h"
 
 namespace mcx {
 
 #if defined(__HIPCC__)
 
-enum { kPlA = 0, kPlC, kPlG, kPlT, kPlMulti, kPlReadCount, kPlF1, kPlR2, kPlF2, kPlR1, kPlanes };
-
 struct ProfView {
-    uint32_t *plane;  // [kPlanes][G]; kPlMulti and the strand planes hold differences until mcx_profile_settle
-    uint32_t *match;  // [G] differences of "read base == reference base" coverage
+    PlanesView pl;    // the ten planes (mcx_planes.h); multi_hit and the strand planes hold differences until mcx_profile_settle
+    uint16_t *match;  // [stride] differences of "read base == reference base" coverage
     int64_t G;
     int32_t max_dup, max_clip;
 };
@@ -129,7 +129,7 @@ __global__ void k_prof_admit(const uint64_t *keys, uint64_t n, ProfView pv, uint
     const uint64_t g = key >> 32;
     int rank = 0;
     for (int k = 1; k <= pv.max_dup && (uint64_t)k <= j; k++) { if ((keys[j - k] >> 32) == g) rank++; else break; }
-    const uint32_t before = pv.plane[(uint64_t)kPlReadCount * pv.G + g];
+    const uint32_t before = pv.pl.h(kPlReadCount)[g];
     admit[idx] = (uint8_t)((admit[idx] & 2) | ((before + (uint32_t)rank < (uint32_t)pv.max_dup) ? 1 : 0)); // (bit 1: k_prof_odd's)
 }
 
@@ -143,9 +143,9 @@ __global__ void k_prof_count(const uint64_t *keys, uint64_t n, ProfView pv)
     if (j > 0 && (keys[j - 1] >> 32) == g) return;
     uint32_t run = 1;
     while (run < (uint32_t)pv.max_dup && j + run < n && (keys[j + run] >> 32) == g) run++;
-    uint32_t *cnt = &pv.plane[(uint64_t)kPlReadCount * pv.G + g];
-    const uint32_t v = *cnt + run;
-    *cnt = v < (uint32_t)pv.max_dup ? v : (uint32_t)pv.max_dup;
+    uint16_t *cnt = &pv.pl.h(kPlReadCount)[g]; // (a 16-bit store: the neighbouring position's half of the word is another thread's)
+    const uint32_t v = (uint32_t)*cnt + run;
+    *cnt = (uint16_t)(v < (uint32_t)pv.max_dup ? v : (uint32_t)pv.max_dup);
 }
 
 // the character the reference sees at alignment-string index xi of a fragment's read string
@@ -161,7 +161,7 @@ static __device__ __forceinline__ uint8_t frag_read_char(const ReadRef &rd, cons
     }
 }
 
-// +1 over [lo, hi) of a plane kept as differences (clipped to the genome)
+// +1 over [lo, hi) of a plane kept as differences (clipped to the genome): the 32-bit plane, a 16-bit one
 static __device__ __forceinline__ void range_add(uint32_t *plane, int64_t lo, int64_t hi, int64_t G)
 {
     if (lo < 0) lo = 0;
@@ -169,6 +169,14 @@ static __device__ __forceinline__ void range_add(uint32_t *plane, int64_t lo, in
     if (lo >= hi) return;
     atomicAdd(plane + lo, 1u);
     if (hi < G) atomicAdd(plane + hi, 0xFFFFFFFFu);
+}
+static __device__ __forceinline__ void range_add(uint16_t *plane, int64_t lo, int64_t hi, int64_t G)
+{
+    if (lo < 0) lo = 0;
+    if (hi > G) hi = G;
+    if (lo >= hi) return;
+    half_inc(plane, (uint64_t)lo);
+    if (hi < G) half_dec(plane, (uint64_t)hi);
 }
 
 // pass 2c: which reads hold a byte that is not one of the upper-case letters ACGT (bit 1 of the read's flag byte; bit 0 is
@@ -226,7 +234,7 @@ static __device__ __forceinline__ void prof_walk(const ReadRef &rd, const Frag &
         if (op == 'M') {
             int pl = -1;
             switch (frag_read_char(rd, f, fwd, ri)) { case 'A': pl = kPlA; break; case 'C': pl = kPlC; break; case 'G': pl = kPlG; break; case 'T': pl = kPlT; break; }
-            if (pl >= 0) atomicAdd(&pv.plane[(uint64_t)pl * pv.G + g0 + gi], 1u);
+            if (pl >= 0) half_inc(pv.pl.h(pl), (uint64_t)(g0 + gi));
         } else if (op == 'I' || op == 'D') {
             const uint8_t prev = x == 0 ? 0 : (uni ? uni : fo[x - 1]);
             if (prev != op) { // first column of a run: this lane records it (:133-150)
@@ -258,7 +266,7 @@ static __device__ __forceinline__ void prof_read(const uint8_t *detail, const De
     const DetailHdr d = *(const DetailHdr *)rec;
     const Frag *fr = (const Frag *)(rec + sizeof(DetailHdr)) + d.frag0;
     if (d.type == 2) { // UpdateMultiHitCount (:244-271)
-        for (int i = 0; i < d.n_frags; i++) { const Frag f = fr[i]; range_add(pv.plane + (uint64_t)kPlMulti * pv.G, f.gPos, f.gPos + f.rLen, pv.G); }
+        for (int i = 0; i < d.n_frags; i++) { const Frag f = fr[i]; range_add(pv.pl.multi, f.gPos, f.gPos + f.rLen, pv.G); }
         return;
     }
     const uint8_t flag = admit[r];
@@ -274,7 +282,7 @@ static __device__ __forceinline__ void prof_read(const uint8_t *detail, const De
         // every fragment is walked in forward-genome coordinates, like the reference's strings
         // after SelfComplementarySeq: g0 = first genome position under the fragment
         const int64_t g0 = fwd ? f.gPos : ix.G2 - (f.gPos + f.gLen);
-        if (i == 0) range_add(pv.plane + (uint64_t)strand * pv.G, g0, g0 + rd.rlen, pv.G); // (the reference runs past the array at the genome end)
+        if (i == 0) range_add(pv.pl.h(strand), g0, g0 + rd.rlen, pv.G); // (the reference runs past the array at the genome end)
         if (f.kind == kEmpty) { // an end fragment the quality gate emptied still hits the `gLen == 0` branch (:124/:193) with ""
             SparseRec s; s.pos = g0 - 1; s.type = 'I'; s.len = 0; wave_sparse_put(ws, sink, s);
             continue;
@@ -334,27 +342,41 @@ __global__ void __launch_bounds__(256) k_prof_cols(const uint8_t *detail, Detail
     wave_sparse_flush(ws, sink);
 }
 
+// mcx_profile_settle, before the scans: the words of a 16-bit difference plane back to two differences modulo 2^16 (mcx_planes.h)
+__global__ void __launch_bounds__(256) k_prof_decode(uint32_t *words, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t w = words[i];
+        if (w) words[i] = planes_decode(w);
+    }
+}
+
 // mcx_profile_settle, after the scans: the exact-seed coverage joins the plane of the reference's base
 __global__ void __launch_bounds__(256) k_prof_fold(IndexView ix, ProfView pv)
 {
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < pv.G; p += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t m = pv.match[p];
-        if (m) pv.plane[(uint64_t)ref_code(ix, p) * pv.G + p] += m;
+        const uint16_t m = pv.match[p];
+        if (m) pv.pl.h(ref_code(ix, p))[p] += m; // (a 16-bit read-modify-write of the thread's own position)
     }
 }
 
 // field widths of MappingRecord_t, applied once all contributions are in (and, on several GPUs,
 // after the all-reduce): 12-bit saturation, 16-bit wrap, duplicate cap
-__global__ void k_prof_finalize(uint32_t *plane, int64_t G, int max_dup)
+__global__ void k_prof_finalize(PlanesView pl, int max_dup)
 {
-    const int k = blockIdx.y; // one plane per grid row: no division per element
-    uint32_t *p = plane + (uint64_t)k * G;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < G; i += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t v = p[i];
-        if (k <= kPlMulti) v = v < 4095u ? v : 4095u;
-        else if (k == kPlReadCount) v = v < (uint32_t)max_dup ? v : (uint32_t)max_dup;
-        else v &= 0xFFFFu;
-        p[i] = v;
+    const int k = blockIdx.y; // one plane per grid row: no division per element (the strand planes are 16-bit words already: nothing to do)
+    if (k == kPlMulti) {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pl.G; i += (int64_t)gridDim.x * blockDim.x) { const uint32_t v = pl.multi[i]; if (v > 4095u) pl.multi[i] = 4095u; }
+        return;
+    }
+    if (k > kPlReadCount) return;
+    const uint16_t top = (uint16_t)(k == kPlReadCount ? max_dup : 4095);
+    // two positions per thread: a word of the plane at a time
+    uint32_t *w = (uint32_t *)pl.h(k);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pl.stride / 2; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t v = w[i];
+        const uint32_t lo = v & 0xFFFFu, hi = v >> 16;
+        if (lo > top || hi > top) w[i] = (lo < top ? lo : top) | ((hi < top ? hi : top) << 16);
     }
 }
 

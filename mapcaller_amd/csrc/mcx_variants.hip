@@ -3,14 +3,14 @@
 // Replaces VariantCalling() (reference src/VariantCalling.cpp:696-740), which the reference runs on
 // ONE thread (iThreadNum = 1 forced at :717) over a 16-byte record per genome position.
 //
-// Here the dense part — everything that looks at every position — runs on the GPU over the ten u32
-// planes [plane][G] that mcx_profile_* left in HBM:
+// Here the dense part — everything that looks at every position — runs on the GPU over the ten
+// planes that mcx_profile_* left in HBM (mcx_planes.h: 22 bytes per position):
 //   k_vc_depth   one wavefront per 100-position block: BlockDepthArr             (CalBlockReadDepth :105-121)
 //   k_vc_scan    one lane per position: SNV calls, the boundaries of uncovered / duplicated runs,
 //                monomorphic records, boundaries of "normal" runs for gVCF       (IdentifyVariants :549-680)
 //   k_vc_gather  profile columns of listed positions (for the sparse host logic and the VCF text)
 //   k_vc_range   coverage sum / minimum over listed ranges                      (CalRegionCov :197-208, gVCF MIN_DP)
-// Both scans are streaming reads (16 B resp. ~21 B per position): HBM-bound.  Whatever the reference
+// Both scans are streaming reads (8 B resp. ~13 B per position): HBM-bound.  Whatever the reference
 // keeps in std::maps — insert / delete strings, clip break points, discordant pair sites — is sparse
 // and stays on the host: indel calls (GetAreaIndFrequency :63-94) are evaluated only at positions that
 // have a tally, break points (:173-340) only at candidates, each with columns fetched by k_vc_gather.
@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "mcx_variants_host.h"
+#include "mcx_planes.h"
 #include <hipcub/hipcub.hpp>
 #include <mutex>
 
@@ -42,7 +43,7 @@ using namespace mcx_vc;
 
 namespace {
 
-__global__ void __launch_bounds__(256) k_vc_depth(const uint32_t *pl, int64_t G, int64_t n_blocks, int32_t *depth)
+__global__ void __launch_bounds__(256) k_vc_depth(PlanesView pl, int64_t G, int64_t n_blocks, int32_t *depth)
 {
     const int lane = threadIdx.x & 63;
     const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -50,7 +51,7 @@ __global__ void __launch_bounds__(256) k_vc_depth(const uint32_t *pl, int64_t G,
     uint32_t sum = 0;
     for (int o = lane; o < kBlock; o += 64) {
         const int64_t g = b * kBlock + o;
-        if (g < G) sum += pl[g] + pl[(uint64_t)G + g] + pl[(uint64_t)2 * G + g] + pl[(uint64_t)3 * G + g];
+        if (g < G) sum += pl.get(kPlA, g) + pl.get(kPlC, g) + pl.get(kPlG, g) + pl.get(kPlT, g);
     }
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
     if (lane == 0) depth[b] = sum > 0 ? (int32_t)(sum / kBlock) : 0;
@@ -62,7 +63,7 @@ __global__ void __launch_bounds__(256) k_vc_depth(const uint32_t *pl, int64_t G,
 // per wavefront serialises on its L2 atomic unit (measured: 9 ns per bump, 10x the streaming time).
 enum { kScanTile = 256, kScanStage = 1024 }; // (a tile appends at most 4 x 256 records)
 
-__global__ void __launch_bounds__(kScanTile) k_vc_scan(const uint32_t *pl, const int32_t *depth, IndexView ix, ScanParams sp, SiteRec *out,
+__global__ void __launch_bounds__(kScanTile) k_vc_scan(PlanesView pl, const int32_t *depth, IndexView ix, ScanParams sp, SiteRec *out,
                                                        unsigned long long *n_out, uint64_t cap, int64_t tiles_per_group)
 {
     __shared__ SiteRec stage[kScanStage];
@@ -144,20 +145,20 @@ __global__ void k_vc_permute(const SiteRec *recs, const uint32_t *idx, uint64_t 
     if (i < n) out[i] = recs[idx[i]];
 }
 
-__global__ void k_vc_gather(const uint32_t *pl, const int32_t *depth, IndexView ix, int64_t G, const int64_t *pos, uint64_t n, Column *out)
+__global__ void k_vc_gather(PlanesView pl, const int32_t *depth, IndexView ix, int64_t G, const int64_t *pos, uint64_t n, Column *out)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int64_t g = pos[i];
     Column c;
     if (g < 0 || g >= G) { memset(&c, 0, sizeof c); out[i] = c; return; }
-    for (int k = 0; k < nPlanes; k++) c.v[k] = pl[(uint64_t)k * G + g];
+    for (int k = 0; k < nPlanes; k++) c.v[k] = pl.get(k, g);
     c.depth = depth[g / kBlock];
     c.ref = (uint32_t)ref_code(ix, g);
     out[i] = c;
 }
 
-__global__ void __launch_bounds__(256) k_vc_range(const uint32_t *pl, int64_t G, const RangeQ *q, uint64_t n, unsigned long long *out)
+__global__ void __launch_bounds__(256) k_vc_range(PlanesView pl, int64_t G, const RangeQ *q, uint64_t n, unsigned long long *out)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(256) k_vc_range(const uint32_t *pl, int64_t G,
     unsigned long long acc = rq.mode ? ~0ull : 0ull;
     for (int64_t g = rq.beg + lane; g <= rq.end; g += 64) {
         if (g < 0 || g >= G) continue;
-        const unsigned long long cov = (unsigned long long)pl[g] + pl[(uint64_t)G + g] + pl[(uint64_t)2 * G + g] + pl[(uint64_t)3 * G + g];
+        const unsigned long long cov = (unsigned long long)pl.get(kPlA, g) + pl.get(kPlC, g) + pl.get(kPlG, g) + pl.get(kPlT, g);
         if (rq.mode) { if (cov > 0 && cov < acc) acc = cov; }
         else acc += cov;
     }
@@ -241,7 +242,7 @@ template <typename T> struct DevBuf {
 // the dense half on the GPU: the ten planes in HBM behind the caller's interface
 class GpuProfile : public DenseProfile {
 public:
-    GpuProfile(const mcx_index *ix, const uint32_t *planes) : ix_(ix), pl_(planes), G_(ix->view.G) {}
+    GpuProfile(const mcx_index *ix, const uint32_t *planes) : ix_(ix), pl_(planes_view((void *)planes, ix->view.G)), G_(ix->view.G) {}
     int64_t genome_size() const override { return G_; }
     int gather(const std::vector<int64_t> &pos, ColVec &out) override
     {
@@ -347,7 +348,7 @@ public:
 
 private:
     const mcx_index *ix_;
-    const uint32_t *pl_;
+    PlanesView pl_;
     int64_t G_;
     DevBuf<int32_t> d_depth_;
 };
@@ -365,13 +366,14 @@ extern "C" int mcx_planes_alloc(const mcx_index *ix, uint32_t **d_planes)
 {
     if (!ix || !d_planes) return mcx_set_error(MCX_ERR_ARG, "mcx_planes_alloc: null argument");
     VC_TRY(hipSetDevice(ix->device));
-    const size_t bytes = (size_t)ix->view.G * nPlanes * sizeof(uint32_t);
+    const size_t bytes = (size_t)planes_bytes(ix->view.G);
     VC_TRY(hipMalloc((void **)d_planes, bytes));
     VC_TRY(hipMemset(*d_planes, 0, bytes));
     return 0;
 }
 
 extern "C" void mcx_planes_free(uint32_t *d_planes) { if (d_planes) (void)hipFree(d_planes); }
+extern "C" uint64_t mcx_planes_bytes(int64_t genome_size) { return planes_bytes(genome_size); }
 
 extern "C" int mcx_call_variants(const mcx_index *ix, const uint32_t *d_planes, const mcx_sparse_rec *recs, uint64_t n_recs,
                                  int64_t paired_pairs, int64_t pair_dist_sum, int64_t pair_len_sum,

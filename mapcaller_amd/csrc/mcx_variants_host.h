@@ -69,13 +69,15 @@ static inline MCX_HD int cov_threshold(int depth, int min_ad, int somatic)
 // What IdentifyVariants decides from one column alone: the run class (0 covered, 1 nothing mapped,
 // 2 only multi-mapped reads), the SNV call (:591-624) and whether the position can be part of a
 // "normal" stretch (covered, no SNV).
-static inline MCX_HD SiteEval eval_site(const uint32_t *pl, const int32_t *depth, const IndexView &ix, const ScanParams &sp, int64_t g)
+// (Planes: anything with get(plane, position) — the planes in HBM, mcx_planes.h PlanesView, or a host array in tests/hostemu)
+template <class Planes>
+static inline MCX_HD SiteEval eval_site(const Planes &pl, const int32_t *depth, const IndexView &ix, const ScanParams &sp, int64_t g)
 {
     SiteEval e;
     uint32_t n[4];
-    for (int k = 0; k < 4; k++) n[k] = pl[(uint64_t)k * sp.G + g];
+    for (int k = 0; k < 4; k++) n[k] = pl.get(k, g);
     const int cov = (int)(n[0] + n[1] + n[2] + n[3]);
-    e.cls = cov > 0 ? 0 : (pl[(uint64_t)pMulti * sp.G + g] == 0 ? 1 : 2);
+    e.cls = cov > 0 ? 0 : (pl.get(pMulti, g) == 0 ? 1 : 2);
     e.call = false;
     e.rec.pos = g; e.rec.type = vSUB; e.rec.geno = 0; e.rec.qscore = 0; e.rec.alt = 0xFF; e.rec.DP = (uint16_t)cov; e.rec.AD_ref = e.rec.AD_alt = 0; e.rec.pad = 0;
     const int thr = cov_threshold(depth[g / kBlock], sp.min_ad, sp.somatic);

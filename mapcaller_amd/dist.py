@@ -30,58 +30,54 @@ def shard_pairs(n_pairs: int, rank: int, world: int) -> Tuple[int, int]:
     return min(lo, n_pairs), min(hi, n_pairs)
 
 
-def finalize_planes(planes: torch.Tensor, max_dup: int = 5) -> torch.Tensor:
-    """Field widths of MappingRecord_t (reference src/structure.h:152-163) on summed counters:
-    A,C,G,T,multi_hit saturate at 4095, readCount at the duplicate cap, F1,R2,F2,R1 wrap at 2^16.
-    (torch version of k_prof_finalize, for tensors that are not attached to a Mapper.)"""
-    planes[0:5].clamp_(max=4095)
-    planes[5].clamp_(max=max_dup)
-    planes[6:10].bitwise_and_(0xFFFF)
+def finalize_planes(planes: torch.Tensor, G: int, max_dup: int = 5) -> torch.Tensor:
+    """Field widths of MappingRecord_t (reference src/structure.h:152-163) on summed counters in the planes' own layout
+    (api.planes_alloc): A,C,G,T,multi_hit saturate at 4095, readCount at the duplicate cap; F1,R2,F2,R1 are 16-bit words already.
+    (torch version of k_prof_finalize, for planes that are not attached to a Mapper.)"""
+    from . import api
+    multi, half = api.planes_parts(planes, G)
+    multi.clamp_(max=4095)
+    for slot, top in ((0, 4095), (1, 4095), (2, 4095), (3, 4095), (4, max_dup)):
+        v = half[slot].to(torch.int32) & 0xFFFF  # (int16 storage: counters from 2^15 on read back negative)
+        half[slot] = v.clamp(max=top).to(torch.int16)
     return planes
 
 
-READ_COUNT_PLANE = 5
-
-
-# two 16-bit counters share a u32 on the wire: (low plane, high plane)
-PACKED_SATURATING = ((0, 1), (2, 3))   # A|C, G|T: every rank clamps to 4095 first, so 16 ranks cannot carry into the high half
-PACKED_WITH_READ_COUNT = (4, 5)        # multi_hit | readCount, when the readCount plane is summed at all
-PACKED_WRAPPING = ((6, 7), (8, 9))     # F1|R2, F2|R1: 16-bit fields that wrap; packed when the low halves cannot carry
-
-
-def reduce_profile(planes: torch.Tensor, sparse, root: int = 0, shared_read_count: bool = True, packed: bool = True, mapper=None):
-    """Sums the [10, G] counter planes of all ranks onto ``root`` (RCCL reduce on GPU tensors; only the
-    rank that calls the variants needs the sum), in pieces of 2^28 elements (1 GiB: link speed, and no
-    collective's count outgrows 32 bits), and gathers the sparse records of every rank in rank order.
-    ``shared_read_count``: the readCount plane already holds the run's count on every rank (the
-    duplicate cap was decided across shards, mcx_batch_accumulate) and is left out of the sum; pass
-    False for planes accumulated by independent runs.  ``packed``: the counters are 12- and 16-bit fields
-    (finalize_planes), so two planes travel in one u32 — A|C, G|T and multi_hit|readCount clamped to 4095
-    on every rank first (up to 16 ranks: no carry), F1|R2 and F2|R1 when no low half can carry (the largest
-    low-half value over all ranks times the world size stays below 2^16; otherwise those four travel alone)
-    — five planes on the wire instead of nine or ten.  What the root then holds equals the plain sum once
-    finalised; the planes of the other ranks are left in their packed form.  ``sparse`` is either the list
-    of tuples of Mapper.profile_sparse() or the raw uint8 [n, 64] array of Mapper.profile_sparse_raw(); the
-    same kind comes back.  Call after Mapper.profile_settle() and before finalisation — or pass the ``mapper`` that
-    accumulated the planes and it is settled here first (idempotent): planes that still hold differences would be
-    packed into plausible-looking garbage without any error.  With the gloo
-    backend (CPU tests, several ranks on one GPU) device tensors are staged through the host.
-    ``reduce_profile.last_bytes``: what this rank put on the wire for the planes."""
+def reduce_profile(planes: torch.Tensor, sparse, G: int, root: int = 0, shared_read_count: bool = True, mapper=None):
+    """Sums the counter planes of all ranks (api.planes_alloc's layout, csrc/mcx_planes.h: multi_hit as u32, the other nine as u16)
+    onto ``root`` (RCCL reduce on GPU tensors; only the rank that calls the variants needs the sum), in pieces of 2^28 words
+    (1 GiB: link speed, and no collective's count outgrows 32 bits), and gathers the sparse records of every rank in rank order.
+    torch.distributed sums no 16-bit integers either, so the 16-bit planes travel as the int32 words they lie in, two positions
+    to a word: A C G T (and readCount, when it is summed at all) clamped on every rank first — to 4095, up to 16 ranks cannot
+    carry into the neighbouring half, and the clamped sum finalises to the same value —, F1 R2 F2 R1 as they are when no half can
+    carry (the largest one over all ranks times the world size stays below 2^16; otherwise one counter per word, piece by piece):
+    20 bytes per position on the wire.  ``shared_read_count``: the readCount plane already holds the run's count on every rank
+    (the duplicate cap was decided across shards, mcx_batch_accumulate) and is left out of the sum; pass False for planes
+    accumulated by independent runs.  What the root then holds equals the plain sum once finalised; the planes of the other
+    ranks are scratch.  ``sparse`` is either the list of tuples of Mapper.profile_sparse() or the raw uint8 [n, 64] array of
+    Mapper.profile_sparse_raw(); the same kind comes back.  Call after Mapper.profile_settle() and before finalisation — or pass
+    the ``mapper`` that accumulated the planes and it is settled here first (idempotent): planes that still hold differences
+    would be summed into plausible-looking garbage without any error.  With the gloo backend (CPU tests, several ranks on one
+    GPU) device tensors are staged through the host.  ``reduce_profile.last_bytes``: what this rank put on the wire for the planes."""
+    from . import api
     reduce_profile.last_bytes = 0
     if mapper is not None:
         mapper.profile_settle()
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return planes, (sparse if isinstance(sparse, np.ndarray) else list(sparse))
     world = dist.get_world_size()
+    if world > 16:
+        raise ValueError("reduce_profile: more than 16 ranks (A C G T travel as 16-bit halves clamped to 4095)")
     is_root = dist.get_rank() == root
     staged = dist.get_backend() != "nccl" and planes.is_cuda
     step = 1 << 28
-    G = planes.shape[1]
+    st = api.planes_stride(G)
+    multi, half = api.planes_parts(planes, G)
+    words = planes[st:].reshape(9, st // 2)  # the 16-bit planes as the int32 words they lie in
 
-    def reduce_row(k):
-        row = planes[k]
-        for lo in range(0, G, step):
-            piece = row[lo:lo + step]
+    def reduce_words(t):
+        for lo in range(0, t.numel(), step):
+            piece = t[lo:lo + step]
             if staged:
                 h = piece.cpu()
                 dist.reduce(h, dst=root, op=dist.ReduceOp.SUM)
@@ -91,52 +87,37 @@ def reduce_profile(planes: torch.Tensor, sparse, root: int = 0, shared_read_coun
                 dist.reduce(piece, dst=root, op=dist.ReduceOp.SUM)
             reduce_profile.last_bytes += piece.numel() * 4
 
-    def pack(a, b, clamp):  # in pieces: a genome-sized temporary may not fit beside the planes
-        for lo in range(0, G, step):
-            x, y = planes[a, lo:lo + step], planes[b, lo:lo + step]
-            if clamp:
-                x.clamp_(max=4095)
-                x.add_(y.clamp(max=4095) << 16)
-            else:
-                x.bitwise_and_(0xFFFF)
-                x.bitwise_or_(y << 16)
+    def clamp_halves(slot, top):  # in pieces: a genome-sized temporary may not fit beside the planes
+        for lo in range(0, st, step):
+            h = half[slot, lo:lo + step]
+            v = h.to(torch.int32) & 0xFFFF
+            h.copy_(v.clamp(max=top).to(torch.int16))
 
-    def unpack(a, b):
-        for lo in range(0, G, step):
-            x, y = planes[a, lo:lo + step], planes[b, lo:lo + step]
-            y.copy_((x >> 16) & 0xFFFF)
-            x.bitwise_and_(0xFFFF)
-
-    pairs, alone = [], []
-    if packed and world <= 16:
-        pairs += [(a, b, True) for a, b in PACKED_SATURATING]
-        if shared_read_count:
-            alone.append(4)
-        else:
-            pairs.append(PACKED_WITH_READ_COUNT + (True,))
-    else:
-        alone += [0, 1, 2, 3, 4] + ([] if shared_read_count else [READ_COUNT_PLANE])
-    wrap_ok = False
-    if packed:
-        top = torch.zeros(1, dtype=torch.int64, device=planes.device)
-        for a, _ in PACKED_WRAPPING:
-            for lo in range(0, G, step):
-                top = torch.maximum(top, (planes[a, lo:lo + step] & 0xFFFF).max().to(torch.int64).reshape(1))
-        if staged:
-            top = top.cpu()
-        dist.all_reduce(top, op=dist.ReduceOp.MAX)
-        wrap_ok = int(top.item()) * world <= 0xFFFF
-    if wrap_ok:
-        pairs += [(a, b, False) for a, b in PACKED_WRAPPING]
-    else:
-        alone += [6, 7, 8, 9]
-    for a, b, clamp in pairs:
-        pack(a, b, clamp)
-        reduce_row(a)
-        if is_root:
-            unpack(a, b)
-    for k in alone:
-        reduce_row(k)
+    for slot in (0, 1, 2, 3):
+        clamp_halves(slot, 4095)
+    reduce_words(words[0:4].reshape(-1))
+    if not shared_read_count:
+        clamp_halves(4, 4095)
+        reduce_words(words[4])
+    top = torch.zeros(1, dtype=torch.int64, device=planes.device)
+    for slot in (5, 6, 7, 8):
+        for lo in range(0, st, step):
+            top = torch.maximum(top, (half[slot, lo:lo + step].to(torch.int32) & 0xFFFF).max().to(torch.int64).reshape(1))
+    if staged:
+        top = top.cpu()
+    dist.all_reduce(top, op=dist.ReduceOp.MAX)
+    if int(top.item()) * world <= 0xFFFF:
+        reduce_words(words[5:9].reshape(-1))
+    else:  # (sums of independent deep runs: one counter per word on the wire)
+        for slot in (5, 6, 7, 8):
+            for lo in range(0, st, step):
+                h = half[slot, lo:lo + step]
+                wide = (h.to(torch.int32) & 0xFFFF).contiguous()
+                reduce_words(wide)
+                if is_root:
+                    v = wide & 0xFFFF
+                    h.copy_(torch.where(v >= 0x8000, v - 0x10000, v).to(torch.int16))
+    reduce_words(multi)
     if isinstance(sparse, np.ndarray):  # raw records: one padded all-gather of bytes
         dev = planes.device if not staged else torch.device("cpu")
         n = torch.tensor([sparse.shape[0]], dtype=torch.int64, device=dev)

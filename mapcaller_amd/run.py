@@ -96,7 +96,7 @@ def main(argv=None):
     want_vcf = not a.no_vcf
     planes = None
     if want_vcf:
-        planes = torch.zeros((10, index.genome_size), dtype=torch.int32, device=dev)
+        planes = api.planes_alloc(index.genome_size, dev)
         mapper.profile_attach(planes.data_ptr(), max_dup=a.dup, max_clip=a.maxclip)
     totals = {"reads": 0, "mapped": 0, "pairs": 0, "pair_dist_sum": 0, "pair_len_sum": 0}
     link = api.dist_exchange(dev) if world > 1 else None
@@ -112,7 +112,7 @@ def main(argv=None):
     tot = mdist.sum_over_ranks([totals[k] for k in ("reads", "mapped", "pairs", "pair_dist_sum", "pair_len_sum")], dev)
     if want_vcf:
         mapper.profile_settle()  # differences -> counts, before the planes are summed
-        planes, sparse = mdist.reduce_profile(planes, mapper.profile_sparse_raw(shard=world > 1), mapper=mapper)
+        planes, sparse = mdist.reduce_profile(planes, mapper.profile_sparse_raw(shard=world > 1), index.genome_size, mapper=mapper)
         if rank == 0:
             mapper.profile_finalize(planes.data_ptr())
             vs = index.call_variants(planes.data_ptr(), sparse, tot[2], tot[3], tot[4], a.vcf, ploidy=a.ploidy, min_allele_depth=a.ad,

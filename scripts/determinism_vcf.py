@@ -24,7 +24,7 @@ def main():
     sl = min(n, args.vcf_slice_reads)
     off = (torch.arange(sl + 1, device=dev, dtype=torch.int64) * args.rlen).to(torch.uint32)
     mapper = api.Mapper(index, alg=args.alg, max_read_len=max(256, args.rlen), max_batch_reads=sl)
-    planes = torch.zeros((10, G), dtype=torch.int32, device=dev)
+    planes = api.planes_alloc(G, dev)
     d_aln = torch.zeros(sl * 64, dtype=torch.uint8, device=dev)
     d_cig = torch.zeros(api.cigar_pool_words(sl), dtype=torch.int32, device=dev)
     starts = np.concatenate([[0], np.cumsum(lens)])
@@ -46,8 +46,9 @@ def main():
         rows = set(bytes(x) for x in sp)
         def digest(lo, hi):  # one byte per position over the ten planes
             h = torch.zeros(hi - lo, dtype=torch.int32, device=dev)
+            v = api.planes_view(planes, G, lo, hi)
             for k in range(10):
-                h += planes[k, lo:hi] * (2 * k + 3)
+                h += v[k] * (2 * k + 3)
             return (h ^ (h >> 8) ^ (h >> 16)).to(torch.uint8)
         if r == 0:
             keep = torch.empty(G, dtype=torch.uint8, device=dev)
@@ -66,7 +67,7 @@ def main():
             cnt += dif.numel()
             for p in dif[:200:8].tolist():
                 if len(first) < 24:
-                    first.append({"pos": lo + p, "this": [int(planes[k, lo + p]) for k in range(10)]})
+                    first.append({"pos": lo + p, "this": [int(x) for x in api.planes_view(planes, G, lo + p, lo + p + 1)[:, 0]]})
         out["differing_positions"] = cnt
         out["first"] = first
         # the reads of run 0 that lie over the first differing positions

@@ -46,7 +46,8 @@ public:
         sites.clear();
         int prev_cls = 0; bool prev_cand = false; // k_vc_scan, one position at a time
         for (int64_t g = 0; g < G_; g++) {
-            const SiteEval e = eval_site(pl_.data(), depth_.data(), ix_, sp, g);
+            struct { const uint32_t *p; int64_t G; uint32_t get(int k, int64_t at) const { return p[(size_t)k * G + at]; } } planes = {pl_.data(), G_};
+            const SiteEval e = eval_site(planes, depth_.data(), ix_, sp, g);
             SiteRec ev = e.rec; ev.geno = ev.qscore = 0; ev.alt = 0xFF; ev.DP = ev.AD_ref = ev.AD_alt = 0;
             if (prev_cls != 0 && e.cls != prev_cls) { ev.type = prev_cls == 1 ? eGapEnd : eDupEnd; sites.push_back(ev); }
             if (e.cls != 0 && e.cls != prev_cls) { ev.type = e.cls == 1 ? eGapStart : eDupStart; sites.push_back(ev); }

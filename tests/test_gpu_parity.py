@@ -373,11 +373,11 @@ def test_alignment_profile_equals_reference(api, golden, tmp_path, monkeypatch, 
     ix = api.Index(g["prefix"], device=0, full_sa=True)
     G = ix.genome_size
     mp = api.Mapper(ix, alg=alg, max_batch_reads=1000)  # several batches: the duplicate cap spans them
-    planes = torch.zeros((10, G), dtype=torch.int32, device="cuda")
+    planes = api.planes_alloc(G, "cuda")
     mp.profile_attach(planes.data_ptr())
     mp.map_files(g["r1"], g["r2"], None)
     mp.profile_finalize(planes.data_ptr())
-    got = planes.t().contiguous().to(torch.uint16 if hasattr(torch, "uint16") else torch.int16).cpu().numpy().astype(np.uint16)
+    got = api.planes_view(planes, G).t().contiguous().cpu().numpy().astype(np.uint16)
     want = np.frombuffer(open(prof, "rb").read(), dtype=np.uint16).reshape(-1, 10)
     bad = np.argwhere(got != want)
     assert bad.size == 0, (bad[:5], got[bad[:5, 0]], want[bad[:5, 0]])
@@ -416,13 +416,13 @@ def test_profile_runs_equal_column_walk(api, golden, tmp_path, monkeypatch):
         if by_column:
             monkeypatch.setenv("MCX_PROF_BY_COLUMN", "1")
         mp = api.Mapper(ix, alg="ksw2", max_batch_reads=4000)
-        planes = torch.zeros((10, ix.genome_size), dtype=torch.int32, device="cuda")
+        planes = api.planes_alloc(ix.genome_size, "cuda")
         mp.profile_attach(planes.data_ptr())
         mp.map_files(f1, f2, None)
         mp.profile_finalize(planes.data_ptr())
         sp = mp.profile_sparse_raw().copy()
         sp[:, 10:] *= (np.arange(54)[None, :] < sp[:, 9:10]).astype(np.uint8)
-        res.append((planes.cpu(), sorted(bytes(x) for x in sp)))
+        res.append((api.planes_view(planes, ix.genome_size).cpu(), sorted(bytes(x) for x in sp)))
         mp.close()
     ix.close()
     assert int(res[0][0][0:4].sum()) > 100000
@@ -438,7 +438,7 @@ def test_profile_refuses_reads_after_the_settle(api, golden):
     g = golden["toy"]
     ix = api.Index(g["prefix"], device=0)
     mp = api.Mapper(ix, alg="ksw2", max_batch_reads=4000)
-    planes = torch.zeros((10, ix.genome_size), dtype=torch.int32, device="cuda")
+    planes = api.planes_alloc(ix.genome_size, "cuda")
     mp.profile_attach(planes.data_ptr())
     mp.map_files(g["r1"], g["r2"], None)
     mp.profile_settle()
@@ -451,7 +451,7 @@ def test_profile_refuses_reads_after_the_settle(api, golden):
     mp.reset()
     mp.map_files(g["r1"], g["r2"], None)
     mp.profile_finalize(planes.data_ptr())
-    assert int(planes[0:4].sum()) > int(before[0:4].sum())
+    assert int(api.planes_view(planes, ix.genome_size)[0:4].sum()) > int(api.planes_view(before, ix.genome_size)[0:4].sum())
     mp.close(); ix.close()
 
 
@@ -468,7 +468,7 @@ def test_vcf_equals_reference(api, golden, tmp_path, monkeypatch, name, tag, str
     o = VcfOpts(VCF_RUNS[tag][1]).struct
     ix = api.Index(g["prefix"], device=0, full_sa=True)
     mp = api.Mapper(ix, alg=vcf_alg(name, tag), max_batch_reads=4000)
-    planes = torch.zeros((10, ix.genome_size), dtype=torch.int32, device="cuda")
+    planes = api.planes_alloc(ix.genome_size, "cuda")
     mp.profile_attach(planes.data_ptr(), max_dup=o.max_dup, max_clip=o.max_clip)
     st = mp.map_files(g["r1"], g["r2"], None)
     mp.profile_finalize(planes.data_ptr())
@@ -1163,24 +1163,29 @@ def test_profile_reduce_over_rccl_one_rank(api, golden, monkeypatch):
     comm = ctypes.c_void_p()
     assert L.mcx_comm_init_rank(ident, 0, 1, 0, ctypes.byref(comm)) == 0, api.lib().mcx_last_error()
     G = 100_000
-    planes = torch.arange(10 * G, dtype=torch.int32, device="cuda").reshape(10, G).contiguous()
-    want = planes.clone()
+    rows = (torch.arange(10 * G, dtype=torch.int64, device="cuda").reshape(10, G) % 70001).to(torch.int32)
+    rows[0:4] %= 9000    # A C G T: a count stays below 15 000 (mcx_planes.h); some above the 12-bit field
+    rows[6:10] %= 60000  # strand counters that can travel two to a word on one rank
+    planes = api.planes_from_rows(rows)
     secs = ctypes.c_double()
     L.mcx_profile_reduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
     assert L.mcx_profile_reduce(comm, planes.data_ptr(), G, 0, ctypes.byref(secs)) == 0, api.lib().mcx_last_error()
     torch.cuda.synchronize()
-    # the planes travel two to a word (A|C, G|T clamped to 4095; F1|R2, F2|R1 as 16-bit fields): what comes back equals the
-    # input once the field widths are applied, multi_hit and readCount untouched
-    assert torch.equal(planes[0:4], want[0:4].clamp(max=4095))
-    assert torch.equal(planes[4:6], want[4:6])
-    assert torch.equal(planes[6:10], want[6:10] & 0xFFFF)
-    # strand depths that could carry into the neighbour's half keep the strand planes apart
-    planes = torch.full((10, G), 70000, dtype=torch.int32, device="cuda")
-    planes[6] = 0xFFFF + 0x10000 * 3
-    want = planes.clone()
+    # the 16-bit planes travel as the words they lie in (A C G T clamped to 4095 first): what comes back equals the input once the
+    # field widths are applied, multi_hit and readCount untouched
+    got = api.planes_view(planes, G)
+    assert torch.equal(got[0:4], rows[0:4].clamp(max=4095))
+    assert torch.equal(got[4], rows[4]) and torch.equal(got[5], rows[5] & 0xFFFF)
+    assert torch.equal(got[6:10], rows[6:10])
+    # strand counters that could carry into the neighbouring half on several ranks (here: times one rank still fits, so force the wide path
+    # with a value at the top of the range on a communicator of one) — and the wide path itself: one counter per word, narrowed again
+    rows[6] = 0xFFFF
+    monkeypatch.setenv("MCX_REDUCE_WIDE", "1")
+    planes = api.planes_from_rows(rows)
     assert L.mcx_profile_reduce(comm, planes.data_ptr(), G, 0, ctypes.byref(secs)) == 0, api.lib().mcx_last_error()
     torch.cuda.synchronize()
-    assert torch.equal(planes[6:10], want[6:10] & 0xFFFF) and torch.equal(planes[0:4], want[0:4].clamp(max=4095))
+    got = api.planes_view(planes, G)
+    assert torch.equal(got[6:10], rows[6:10]) and torch.equal(got[0:4], rows[0:4].clamp(max=4095)) and torch.equal(got[4], rows[4])
     L.mcx_comm_free.argtypes = [ctypes.c_void_p]
     L.mcx_comm_free(comm)
 
