@@ -122,7 +122,9 @@ typedef struct mcx_stats {
     int64_t replayed_pairs; /* pairs re-run because the avgDist trajectory moved past their validity interval */
     int64_t halved_selections; /* times a selection of pairs was mapped in two halves because a work list ran over */
     int64_t simple_pairs;   /* pairs (reads, single-end) that went from their seeds to their records on the straight-line path (k_simple) */
-    double ms_encode /* k_pack_reads */, ms_seed, ms_sa, ms_cluster, ms_rescue, ms_build, ms_dp, ms_finish, ms_total;
+    double ms_encode /* k_pack_reads */, ms_seed, ms_sa, ms_cluster /* k_cluster alone */, ms_rescue, ms_build, ms_dp, ms_finish, ms_total;
+    double ms_simple;       /* the straight-line path: k_simple (collect), k_simple_dp, k_simple (replay) */
+    double ms_order;        /* k_order_count + k_order_place */
 } mcx_stats;
 
 #define MCX_CIGAR_STRIDE 32 /* CIGAR words per read a batch's pool has room for on average ... */

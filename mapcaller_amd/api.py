@@ -159,7 +159,7 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("reads", "mapped", "pairs", "pair_dist_sum", "pair_len_sum", "fm_ext_steps", "fm_blocks",
                                          "sa_hits", "dp_jobs", "dp_cells", "tier1_pairs", "replayed_pairs", "halved_selections", "simple_pairs")] + \
                [(n, C.c_double) for n in ("ms_encode", "ms_seed", "ms_sa", "ms_cluster", "ms_rescue", "ms_build",
-                                          "ms_dp", "ms_finish", "ms_total")]
+                                          "ms_dp", "ms_finish", "ms_total", "ms_simple", "ms_order")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

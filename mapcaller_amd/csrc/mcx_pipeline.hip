@@ -470,7 +470,8 @@ static __device__ __forceinline__ U4 load16_unaligned(const uint8_t *p)
 // four ASCII bytes (first base in the low byte) -> 8 code bits (first base on top) and 4 N flags
 // (first base on top); `comp`: complement the bases (mate 2).  nt4_code (mcx_fm.h) on four lanes of
 // one register: fold case, A/C/G/T membership by zero-byte tests, (c >> 1) & 3 hashes A0 C1 T2 G3.
-static __device__ __forceinline__ void pack4(uint32_t w, bool comp, uint32_t &codes, uint32_t &flags)
+// (lower: 4 flags likewise for bytes with bit 5 set — a lower-case letter where the byte is a base at all)
+static __device__ __forceinline__ void pack4(uint32_t w, bool comp, uint32_t &codes, uint32_t &flags, uint32_t &lower)
 {
     const uint32_t c = w & 0xDFDFDFDFu;
     auto zero_bytes = [](uint32_t t) { return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu); }; // 0x80 where a byte is 0
@@ -482,15 +483,18 @@ static __device__ __forceinline__ void pack4(uint32_t w, bool comp, uint32_t &co
     const uint32_t y = __builtin_bswap32(code), n = __builtin_bswap32(member ^ 0x01010101u);
     codes = (y | (y >> 6) | (y >> 12) | (y >> 18)) & 0xFFu;
     flags = (n | (n >> 7) | (n >> 14) | (n >> 21)) & 0xFu;
+    const uint32_t l = __builtin_bswap32((w >> 5) & 0x01010101u);
+    lower = (l | (l >> 7) | (l >> 14) | (l >> 21)) & 0xFu;
 }
 
 // 16 oriented bases i0 .. i0+15 of a read -> (code word, MSB first; 16 N flags, bit 15 = base i0);
-// bases past the read end give code 0 and flag 1
-static __device__ __forceinline__ void pack16(const ReadRef &rd, int i0, uint32_t &codes, uint32_t &flags)
+// bases past the read end give code 0 and flag 1; odd: 16 flags likewise for bytes of the read that are not an upper-case A C G T
+// (what the -vcf bookkeeping asks of a read: mcx_profile.h), 0 past the read end
+static __device__ __forceinline__ void pack16(const ReadRef &rd, int i0, uint32_t &codes, uint32_t &flags, uint32_t &odd)
 {
     const int rlen = rd.rlen;
     int n = rlen - i0; if (n > 16) n = 16;
-    codes = 0; flags = 0xFFFFu;
+    codes = 0; flags = 0xFFFFu; odd = 0;
     if (n <= 0) return;
     // the span of the file's bytes under these bases: forward [i0, i0+n); mate 2 (reverse-complemented) [rlen-i0-n, rlen-i0) backwards
     const int a0 = rd.flipped ? rlen - i0 - n : i0;
@@ -499,17 +503,17 @@ static __device__ __forceinline__ void pack16(const ReadRef &rd, int i0, uint32_
         const U4 t = v;
         v.x = __builtin_bswap32(t.w); v.y = __builtin_bswap32(t.z); v.z = __builtin_bswap32(t.y); v.w = __builtin_bswap32(t.x);
     }
-    uint32_t c0, f0, c1, f1, c2, f2, c3, f3;
-    pack4(v.x, rd.flipped != 0, c0, f0); pack4(v.y, rd.flipped != 0, c1, f1); pack4(v.z, rd.flipped != 0, c2, f2); pack4(v.w, rd.flipped != 0, c3, f3);
-    uint32_t c = (c0 << 24) | (c1 << 16) | (c2 << 8) | c3, f = (f0 << 12) | (f1 << 8) | (f2 << 4) | f3;
+    uint32_t c0, f0, c1, f1, c2, f2, c3, f3, l0, l1, l2, l3;
+    pack4(v.x, rd.flipped != 0, c0, f0, l0); pack4(v.y, rd.flipped != 0, c1, f1, l1); pack4(v.z, rd.flipped != 0, c2, f2, l2); pack4(v.w, rd.flipped != 0, c3, f3, l3);
+    uint32_t c = (c0 << 24) | (c1 << 16) | (c2 << 8) | c3, f = (f0 << 12) | (f1 << 8) | (f2 << 4) | f3, o = f | (l0 << 12) | (l1 << 8) | (l2 << 4) | l3;
     if (n < 16) {
         const int pad = 16 - n;
-        if (rd.flipped) { c <<= 2 * pad; f = (f << pad) & 0xFFFFu; } // the n bytes sat at the end of the reversed vector
-        else c &= ~0u << (2 * pad);
+        if (rd.flipped) { c <<= 2 * pad; f = (f << pad) & 0xFFFFu; o = (o << pad) & 0xFFFFu; } // the n bytes sat at the end of the reversed vector
+        else { c &= ~0u << (2 * pad); o &= ~0u << pad; }
         f |= (1u << pad) - 1u;
         if (!rd.flipped) f &= 0xFFFFu;
     }
-    codes = c; flags = f;
+    codes = c; flags = f; odd = o & 0xFFFFu;
 }
 
 // The packed form of every read of a batch (mcx_fm.h pack_read: 16 bases per code word, one zero
@@ -519,7 +523,8 @@ static __device__ __forceinline__ void pack16(const ReadRef &rd, int i0, uint32_
 // reverse-complemented (ReadMapping.cpp:451).  tpr threads per read: ceil(max_read_len / 32) + 1.
 // (any_n: set when a read of the batch holds a byte that is not one of ACGT — the passes of the large tier, which are queued after the
 //  host has looked at the batch's counters anyway, leave out the kernel for such reads when there is none)
-__global__ void __launch_bounds__(256) k_pack_reads(ReadBatch rb, int paired, int wpad, int tpr, uint32_t *out, uint32_t *any_n)
+// (odd_flag, with the -vcf bookkeeping: bit 1 of the read's flag byte is set when the read holds a byte that is not an upper-case A C G T)
+__global__ void __launch_bounds__(256) k_pack_reads(ReadBatch rb, int paired, int wpad, int tpr, uint32_t *out, uint32_t *any_n, uint8_t *odd_flag)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t r = (uint32_t)(t / (uint32_t)tpr);
@@ -531,9 +536,10 @@ __global__ void __launch_bounds__(256) k_pack_reads(ReadBatch rb, int paired, in
     if (nc + 1 + nmw + 1 > wpad) return; // (a read longer than the context was sized for: the batch is refused before this runs, k_max_read_len)
     uint32_t *o = out + (uint64_t)r * wpad;
     if (m < nmw) {
-        uint32_t c0, f0, c1, f1;
-        pack16(rd, 32 * m, c0, f0);
-        pack16(rd, 32 * m + 16, c1, f1);
+        uint32_t c0, f0, c1, f1, o0, o1;
+        pack16(rd, 32 * m, c0, f0, o0);
+        pack16(rd, 32 * m + 16, c1, f1, o1);
+        if (odd_flag && (o0 | o1)) atomicOr((uint32_t *)(odd_flag + (r & ~3u)), 2u << (8 * (r & 3)));
         o[2 * m] = c0;
         if (2 * m + 1 < nc) o[2 * m + 1] = c1;
         o[nc + 1 + m] = (f0 << 16) | f1;
@@ -1973,7 +1979,7 @@ __global__ void __launch_bounds__(256, MCX_FINISH_WAVES) k_finish(Ctx cx, ReadBa
 struct Knobs {
     bool timing = false, seed_one_base = false, dp_by_wave = false, dp_lane_always = false, late_reseed = false, no_work_order = false, no_simple = false,
          simple_no_dp = false, cluster_by_lane = false, rescue_in_line = false, build_by_lane = false, no_sums_cache = false, prof_by_column = false,
-         tier1_hist = false, dp_hist = false, no_tier_overlap = false, no_late_overlap = false;
+         tier1_hist = false, dp_hist = false, no_tier_overlap = false, no_late_overlap = false, prof_unsorted = false;
     int seed_fm_budget = 6, build_wave_limit = 0x7fffffff;
     uint32_t order_min = 16384u;
 };
@@ -1985,7 +1991,7 @@ static Knobs knobs_read()
     k.late_reseed = on("MCX_LATE_RESEED"); k.no_work_order = on("MCX_NO_WORK_ORDER"); k.no_simple = on("MCX_NO_SIMPLE"); k.simple_no_dp = on("MCX_SIMPLE_NO_DP");
     k.cluster_by_lane = on("MCX_CLUSTER_BY_LANE"); k.rescue_in_line = on("MCX_RESCUE_IN_LINE"); k.build_by_lane = on("MCX_BUILD_BY_LANE");
     k.no_sums_cache = on("MCX_NO_SUMS_CACHE"); k.prof_by_column = on("MCX_PROF_BY_COLUMN"); k.tier1_hist = on("MCX_TIER1_HIST"); k.dp_hist = on("MCX_DP_HIST");
-    k.no_tier_overlap = on("MCX_NO_TIER_OVERLAP"); k.no_late_overlap = on("MCX_NO_LATE_OVERLAP");
+    k.no_tier_overlap = on("MCX_NO_TIER_OVERLAP"); k.no_late_overlap = on("MCX_NO_LATE_OVERLAP"); k.prof_unsorted = on("MCX_PROF_UNSORTED");
     if (const char *e = getenv("MCX_SEED_FM_BUDGET")) k.seed_fm_budget = std::max(1, atoi(e));
     if (const char *e = getenv("MCX_BUILD_WAVE_LIMIT")) k.build_wave_limit = atoi(e); // (tests: the bound sum from which k_build_wave hands a pair to one lane)
     if (const char *e = getenv("MCX_ORDER_MIN")) k.order_min = (uint32_t)std::max(1, atoi(e)); // (tests: small batches through k_simple and the order too)
@@ -2026,7 +2032,7 @@ struct PassRes {
     hipStream_t dp_stream[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t dp_fork = nullptr, dp_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t *d_ov = nullptr; uint32_t ov_cap = 0;
     uint32_t *d_sel_ids = nullptr; int32_t *d_est = nullptr;
-    hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 struct BatchRun { // the batch between mcx_batch_begin and mcx_batch_end
@@ -2113,7 +2119,7 @@ struct mcx_ctx {
     void *files_state = nullptr; void (*files_drop)(void *) = nullptr; // mcx_files.cpp's batch buffers (mcx_ctx_files_slot)
     // staging for the host-buffer entry point
     uint8_t *d_bases = nullptr; uint32_t *d_off = nullptr; AlnRec *d_recs = nullptr; uint32_t *d_cig = nullptr;
-    hipEvent_t ev[10];
+    hipEvent_t ev[12];
 };
 
 extern "C" void mcx_opts_default(mcx_opts *o)
@@ -2410,7 +2416,7 @@ static PassRes res_tier0(mcx_ctx *c)
     r.d_dp_lane = c->d_dp_lane; r.dp_lane_blocks = c->dp_lane_blocks; r.d_dp_order[0] = c->d_dp_order[0]; r.d_dp_order[1] = c->d_dp_order[1];
     for (int k = 0; k < 5; k++) { r.dp_stream[k] = c->dp_stream[k]; r.dp_join[k] = c->dp_join[k]; }
     r.dp_fork = c->dp_fork; r.d_ov = c->d_ov; r.ov_cap = c->ov_cap; r.d_sel_ids = c->d_sel_ids; r.d_est = c->d_est;
-    for (int k = 0; k < 10; k++) r.ev[k] = c->ev[k];
+    for (int k = 0; k < 12; k++) r.ev[k] = c->ev[k];
     return r;
 }
 
@@ -2550,6 +2556,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     // the pairs in the order of their weight (k_order_*): worth two small passes when the pass is a large one
     const uint32_t *order = nullptr, *order_cnt = nullptr;
+    bool split = false; // (time stamps 10 and 11 were taken: the straight-line path's and the order's share of the stage before clustering)
     if (tier == 0 && sel.n >= kn.order_min && c->d_order && !kn.no_work_order) {
         // ahead of them, on a whole batch: the straight-line pairs from their seeds to their records (k_simple); what is left is listed
         // by weight for the per-pair kernels.  (Not without the suffix array in HBM — the seeds must be text positions —, not on a
@@ -2574,12 +2581,14 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
             else { if (cx.detail) launch(std::false_type(), std::true_type()); else launch(std::false_type(), std::false_type()); }
             done = c->d_done;
         }
+        if (timing) HIP_TRY(hipEventRecord(R.ev[10], s));
         uint32_t *cls_cnt = R.d_cnt + CNT_ORDER; // (cleared with the pass's counters)
         order_cnt = cls_cnt; // (the class counts: how many pairs the order lists — all of them without k_simple — and where a class begins)
         const unsigned ob = (sel.n + 256 * kOrderTile - 1) / (256 * kOrderTile);
         k_order_count<<<ob, 256, 0, s>>>(sel, so.read_blocks, nr, cls_cnt, done);
         k_order_place<<<ob, 256, 0, s>>>(sel, so.read_blocks, nr, cls_cnt, c->d_order, done);
         order = c->d_order;
+        if (timing) { HIP_TRY(hipEventRecord(R.ev[11], s)); split = true; }
     }
     const size_t cl_bytes = cluster_lds_bytes(cx.caps.hit_cap, cx.caps.cand_cap);
     if (tier == 1 && cl_bytes <= 60 * 1024 && !kn.cluster_by_lane) { // the large tier's pairs: a wavefront each, in two launches by size
@@ -2639,7 +2648,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(R.h_cnt, R.d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    const int e_flag = e | (rescue_aside ? 0x100 : 0); // (for pass_finish: which stage a time stamp closes)
+    const int e_flag = e | (rescue_aside ? 0x100 : 0) | (split ? 0x200 : 0); // (for pass_finish: which stage a time stamp closes)
     if (queued) { *queued = e_flag; return 0; }
     hipEvent_t ev_dbg[2] = {nullptr, nullptr}; // (MCX_TIMING: when tier 0 and the large tier beside it were done)
     if (early && kn.timing) {
@@ -2766,7 +2775,12 @@ static int pass_finish(mcx_ctx *c, int tier, const PassRes &R, uint32_t n_sel, m
             const bool aside = (e & 0x100) != 0;
             const int n_ev = e & 0xFF;
             for (int i = 0; i + 1 < n_ev; i++) HIP_TRY(hipEventElapsedTime(&ms[i], R.ev[i], R.ev[i + 1]));
-            stats->ms_seed += ms[0]; stats->ms_sa += ms[1]; stats->ms_cluster += ms[2];
+            stats->ms_seed += ms[0]; stats->ms_sa += ms[1];
+            if (e & 0x200) { // ev[2] .. ev[10]: the straight-line path; ev[10] .. ev[11]: the order; ev[11] .. ev[3]: k_cluster
+                float a = 0, b = 0, d = 0;
+                HIP_TRY(hipEventElapsedTime(&a, R.ev[2], R.ev[10])); HIP_TRY(hipEventElapsedTime(&b, R.ev[10], R.ev[11])); HIP_TRY(hipEventElapsedTime(&d, R.ev[11], R.ev[3]));
+                stats->ms_simple += a; stats->ms_order += b; stats->ms_cluster += d;
+            } else stats->ms_cluster += ms[2];
             // (run_pairs: in line ms[3] is the rescue, ms[4] nothing, ms[5] the build; with the rescue on a stream of its own ms[3] and ms[5] are the
             //  build's two launches and ms[4] what was left to wait for the rescue)
             if (aside) { stats->ms_build += ms[3] + ms[5]; stats->ms_rescue += ms[4]; }
@@ -3013,7 +3027,10 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
         const int tpr = ((int)c->h_cnt[1] + 31) / 32 + 1; // (threads per read: for the batch's longest read, found above)
         br.longest = c->h_cnt[1];
         const uint64_t threads = (uint64_t)n_reads * (uint64_t)tpr;
-        k_pack_reads<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(br.rb, paired, c->wpad, tpr, c->d_packed, c->d_batch_flags + 3);
+        // (the reads' flag bytes of the -vcf bookkeeping start here: bit 1 — a byte that is not an upper-case ACGT — is k_pack_reads'; MCX_PROF_BY_COLUMN:
+        //  tests — every read is treated as if it held one, so that exact seeds are walked column by column like every other fragment)
+        if (c->prof_planes) HIP_TRY(hipMemsetAsync(c->d_admit, c->kn.prof_by_column ? 2 : 0, ((size_t)n_reads + 3) & ~(size_t)3, s));
+        k_pack_reads<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(br.rb, paired, c->wpad, tpr, c->d_packed, c->d_batch_flags + 3, c->prof_planes ? c->d_admit : nullptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_pack[1], s));
     }
@@ -3557,7 +3574,9 @@ static int profile_keys(mcx_ctx *c)
     SparseSink sink; sink.recs = c->d_sparse; sink.n = c->d_cnt + CNT_TASKS; sink.cap = c->sparse_cap; sink.refused = c->d_cnt + CNT_UNSUP;
     const uint32_t n = br.rb.n_reads;
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
-    k_prof_keys<<<(n + 255) / 256, 256, 0, s>>>(c->d_detail, c->dlay, br.rb, ix, pv, sink, c->d_keys[0], c->d_cnt + CNT_OV);
+    // (the reads' flag bytes: bit 1 — a byte that is not an upper-case ACGT — was set by k_pack_reads when the batch began; bit 2 — a multi-mapped
+    //  read — is k_prof_keys'; bit 0, the admission, comes later)
+    k_prof_keys<<<(n + 255) / 256, 256, 0, s>>>(c->d_detail, c->dlay, br.rb, ix, pv, sink, c->d_keys[0], c->d_cnt + CNT_OV, c->d_admit);
     hipcub::DoubleBuffer<uint64_t> dk(c->d_keys[0], c->d_keys[1]);
     size_t tb = c->sort_tmp_bytes;
     HIP_TRY(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tb, dk, (int64_t)n, 0, 64, s));
@@ -3678,20 +3697,16 @@ static int profile_accumulate(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all,
     }
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
     HIP_TRY(hipMemcpyAsync(c->d_cnt + CNT_TASKS, &br.n_sparse_keys, sizeof(uint32_t), hipMemcpyHostToDevice, s)); // (pageable source: copied before the call returns)
-    // (MCX_PROF_BY_COLUMN: tests — every read is treated as if it held an odd letter, so that exact seeds are walked column by
-    //  column like every other fragment; the planes must come out the same)
-    HIP_TRY(hipMemsetAsync(c->d_admit, c->kn.prof_by_column ? 2 : 0, (n + 3) & ~3u, s));
-    {
-        const int tpr = (std::max<int>((int)(br.longest ? br.longest : (uint32_t)c->rlen_max), 1) + 15) / 16;
-        const uint64_t threads = (uint64_t)n * tpr;
-        k_prof_odd<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(br.rb, tpr, c->d_admit);
-    }
     if (nk) {
         k_prof_admit<<<(unsigned)((nk + 255) / 256), 256, 0, s>>>(d_keys, nk, pv, c->d_admit, own_lo, n);
         k_prof_count<<<(unsigned)((nk + 255) / 256), 256, 0, s>>>(d_keys, nk, pv);
     }
     ColList cols; cols.items = c->d_prof_items; cols.n = c->d_cnt + CNT_RTASK; cols.cap = c->prof_items_cap;
-    k_prof_accum<<<(n + 255) / 256, 256, 0, s>>>(c->d_detail, c->dlay, br.rb, ix, pv, sink, c->d_admit, paired, cols);
+    if (c->kn.prof_unsorted) k_prof_accum<<<(n + 255) / 256, 256, 0, s>>>(c->d_detail, c->dlay, br.rb, ix, pv, sink, c->d_admit, paired, cols, nullptr, 0, 0, n);
+    else {
+        if (nk) k_prof_accum<<<(unsigned)((nk + 255) / 256), 256, 0, s>>>(c->d_detail, c->dlay, br.rb, ix, pv, sink, c->d_admit, paired, cols, d_keys, nk, own_lo, n);
+        k_prof_multi<<<(n + 255) / 256, 256, 0, s>>>(c->d_detail, c->dlay, n, pv, c->d_admit);
+    }
     k_prof_cols<<<4096, 256, 0, s>>>(c->d_detail, c->dlay, br.rb, ix, pv, sink, cols);
     SparseRec *d_ev = (SparseRec *)c->d_tasks; // the SA task list is idle now
     const uint32_t ev_cap = (uint32_t)std::min<uint64_t>((uint64_t)c->task_cap * sizeof(uint2) / sizeof(SparseRec), 0x7fffffffu);

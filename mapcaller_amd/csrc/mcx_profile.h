@@ -83,14 +83,16 @@ static __device__ __forceinline__ const DetailHdr &detail_hdr(const uint8_t *det
 
 // pass 1: break points, clip gate, and the (start position, read) key of every read that reaches
 // the duplicate check (AlignmentProfile.cpp:53-77); n_valid counts them (the others get ~0 and sort last)
+// (flag: the reads' flag bytes — bit 0 the admission, bit 1 k_pack_reads', bit 2 set here for a multi-mapped read: k_prof_multi's)
 __global__ void k_prof_keys(const uint8_t *detail, DetailLayout dl, ReadBatch rb, IndexView ix, ProfView pv, SparseSink sink,
-                            uint64_t *keys, uint32_t *n_valid)
+                            uint64_t *keys, uint32_t *n_valid, uint8_t *flag)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t key = ~0ull;
     if (r < rb.n_reads) {
         const uint8_t *rec = detail + (uint64_t)r * dl.stride;
         const DetailHdr &d = *(const DetailHdr *)rec;
+        if (d.type == 2) atomicOr((uint32_t *)(flag + (r & ~3u)), 4u << (8 * (r & 3)));
         if (d.type == 1) {
             const Frag *f = (const Frag *)(rec + sizeof(DetailHdr)) + d.frag0;
             const Frag &a = f[0], &b = f[d.n_frags - 1];
@@ -130,7 +132,7 @@ __global__ void k_prof_admit(const uint64_t *keys, uint64_t n, ProfView pv, uint
     int rank = 0;
     for (int k = 1; k <= pv.max_dup && (uint64_t)k <= j; k++) { if ((keys[j - k] >> 32) == g) rank++; else break; }
     const uint32_t before = pv.pl.h(kPlReadCount)[g];
-    admit[idx] = (uint8_t)((admit[idx] & 2) | ((before + (uint32_t)rank < (uint32_t)pv.max_dup) ? 1 : 0)); // (bit 1: k_prof_odd's)
+    admit[idx] = (uint8_t)((admit[idx] & 6) | ((before + (uint32_t)rank < (uint32_t)pv.max_dup) ? 1 : 0)); // (bits 1, 2: k_pack_reads', k_prof_keys')
 }
 
 // pass 2b (after every flag is out): the first key of each start position adds the round's admissions to
@@ -179,22 +181,8 @@ static __device__ __forceinline__ void range_add(uint16_t *plane, int64_t lo, in
     if (hi < G) half_dec(plane, (uint64_t)hi);
 }
 
-// pass 2c: which reads hold a byte that is not one of the upper-case letters ACGT (bit 1 of the read's flag byte; bit 0 is
-// the admission).  One thread per sixteen bases.
-__global__ void __launch_bounds__(256) k_prof_odd(ReadBatch rb, int tpr, uint8_t *flag)
-{
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t r = (uint32_t)(t / (uint32_t)tpr);
-    const int m = (int)(t % (uint32_t)tpr);
-    if (r >= rb.n_reads) return;
-    const uint32_t o = rb.off[r], len = rb.off[r + 1] - o;
-    if ((uint32_t)m * 16 >= len) return;
-    const uint8_t *b = rb.bases + o + m * 16;
-    const int n = len - m * 16 < 16 ? (int)(len - m * 16) : 16;
-    bool odd = false;
-    for (int i = 0; i < n; i++) { const uint8_t ch = b[i]; odd = odd || !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'); }
-    if (odd) atomicOr((uint32_t *)(flag + (r & ~3u)), 2u << (8 * (r & 3)));
-}
+// (which reads hold a byte that is not one of the upper-case letters ACGT — bit 1 of the read's flag byte; bit 0 is the admission — is known
+//  since the batch was packed: k_pack_reads, mcx_pipeline.hip)
 
 // pass 3: one read per lane.  Nearly everything a read adds is a handful of runs (its strand plane over the read, the base
 // planes under each exact seed): a few scalar decisions per fragment — with a wavefront per read all 64 lanes repeated them
@@ -302,17 +290,39 @@ static __device__ __forceinline__ void prof_read(const uint8_t *detail, const De
     }
 }
 
+// keys != null: the reads in the order of their sorted (start position, read) keys — the lanes of a wavefront then add to neighbouring
+// stretches of the planes (every atomic of a read in batch order opens a line, a DRAM page and a page-table entry of its own somewhere in
+// 68 GB); the n_keys keyed reads of this shard only (own_lo .. own_lo + n_own): a multi-mapped read has no key and is k_prof_multi's.
+// keys == null: every read of the batch, in batch order (MCX_PROF_UNSORTED, the A/B of the tests).
 __global__ void __launch_bounds__(256) k_prof_accum(const uint8_t *detail, DetailLayout dl, ReadBatch rb, IndexView ix, ProfView pv,
-                                                    SparseSink sink, const uint8_t *admit, int paired, ColList cols)
+                                                    SparseSink sink, const uint8_t *admit, int paired, ColList cols,
+                                                    const uint64_t *keys, uint64_t n_keys, uint32_t own_lo, uint32_t n_own)
 {
     __shared__ SparseRec s_buf[4][96];
     __shared__ uint32_t s_cnt[4];
     WaveSparse ws; ws.buf = s_buf[threadIdx.x >> 6]; ws.cnt = &s_cnt[threadIdx.x >> 6]; ws.cap = 96;
     if ((threadIdx.x & 63) == 0) *ws.cnt = 0;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (keys) {
+        const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        r = 0xFFFFFFFFu;
+        if (j < n_keys) { const uint32_t idx = (uint32_t)keys[j] - own_lo; if (idx < n_own) r = idx; }
+    }
     prof_read(detail, dl, rb, ix, pv, sink, ws, admit, paired, cols, r);
     wave_sparse_flush(ws, sink);
+}
+
+// UpdateMultiHitCount (:244-271) for the reads k_prof_keys flagged, when k_prof_accum goes by the keys
+__global__ void __launch_bounds__(256) k_prof_multi(const uint8_t *detail, DetailLayout dl, uint32_t n_reads, ProfView pv, const uint8_t *flag)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads || !(flag[r] & 4)) return;
+    const uint8_t *rec = detail + (uint64_t)r * dl.stride;
+    const DetailHdr d = *(const DetailHdr *)rec;
+    const Frag *fr = (const Frag *)(rec + sizeof(DetailHdr)) + d.frag0;
+    if (d.type != 2) return;
+    for (int i = 0; i < d.n_frags; i++) { const Frag f = fr[i]; range_add(pv.pl.multi, f.gPos, f.gPos + f.rLen, pv.G); }
 }
 
 // pass 3b: the listed fragments, one per group of sixteen lanes
