@@ -36,6 +36,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_TLANEOPS = 256 * 4 * 2.4e9 / 2 * 64 / 1e12
 # vector instructions of the one-problem-per-lane sweep's inner loop per cell, as compiled for gfx950 (k_dp_lane<16, nw> 340 / 16, <16, ksw2> 540 / 16: DESIGN.md section 3)
 DP_OPS_PER_CELL = {"nw": 21.0, "ksw2": 34.0}
+# what the recurrences themselves ask per cell — compare, substitution score, two gap maxima, the cell maximum, the traceback flags ("roughly
+# a dozen" for ksw2's difference form): the distance between this and the compiled count is staging, unpacking and flag packing
+DP_OPS_PER_CELL_MINIMAL = {"nw": 10.0, "ksw2": 12.0}
 # random 16-byte gathers from an 8 GiB table, four lanes per 64-byte block: what the chip's L2 / fabric sustains in
 # requests per second (tools/ubench_gather.hip, profiles/round1/ubench_gather_8GiB.txt: 47-48 G/s)
 GATHER_CEILING_G_PER_S = 47.5
@@ -45,13 +48,20 @@ GATHER_CEILING_G_PER_S = 47.5
 WALK_MISS_CEILING_G_PER_S = 37.8
 # committed rocprofv3 --pmc passes, by workload: (genome kind, Mbp, pairs per step, read length, alg, sub, ins, del, single-end)
 PMC_SUMMARY = {
-    ("human", 3100.0, 4_000_000, 150, "ksw2", 0.005, 0.001, 0.001, 0): "profiles/round4/summary_human.json",
-    ("uniform", 3100.0, 4_000_000, 150, "ksw2", 0.005, 0.001, 0.001, 0): "profiles/round4/summary_uniform.json",
-    ("human", 3100.0, 4_000_000, 250, "nw", 0.005, 0.025, 0.025, 0): "profiles/round4/summary_cfg5.json",
-    ("uniform", 4.6, 1_000_000, 100, "ksw2", 0.005, 0.001, 0.001, 1): "profiles/round4/summary_cfg2.json",
+    ("human", 3100.0, 4_000_000, 150, "ksw2", 0.005, 0.001, 0.001, 0): "summary_human.json",
+    ("uniform", 3100.0, 4_000_000, 150, "ksw2", 0.005, 0.001, 0.001, 0): "summary_uniform.json",
+    ("human", 3100.0, 4_000_000, 250, "nw", 0.005, 0.025, 0.025, 0): "summary_cfg5.json",
+    ("uniform", 4.6, 1_000_000, 100, "ksw2", 0.005, 0.001, 0.001, 1): "summary_cfg2.json",
 }
-STAGE_KERNEL = {"ms_encode": "k_pack_reads", "ms_seed": "k_seed", "ms_cluster": "k_cluster", "ms_rescue": "k_rescue_eval<2048>", "ms_build": "k_build",
-                "ms_finish": "k_finish"}  # stages whose time is one kernel's (ms_cluster: k_simple + k_order_* + k_cluster; ms_dp: the lists' kernels on three streams)
+PMC_ROUNDS = ("profiles/round5", "profiles/round4")  # the newest committed pass of a workload is the one that is read
+# the stages the library times with HIP events on its own stream, and the kernel(s) each one is (tier 0 of a pass; the large tier's passes and the
+# replay run the same kernels on other streams, beside them).  A stage of ONE kernel gives that kernel's live launch time.
+STAGE_KERNELS = {"ms_encode": ["k_pack_reads"], "ms_seed": ["k_seed"],
+                 "ms_simple": ["k_simple<{nw}, 1, false>", "k_simple_dp<{nw}>", "k_simple<{nw}, 2, false>"],  # collect, solve, replay
+                 "ms_order": ["k_order_count", "k_order_place"], "ms_cluster": ["k_cluster"],
+                 "ms_rescue": ["k_rescue_plan", "k_rescue_eval<2048>", "k_rescue_apply"], "ms_build": ["k_build"], "ms_finish": ["k_finish"]}
+STEP_KERNEL_PREFIXES = ("k_pack_reads", "k_seed", "k_simple", "k_order_", "k_cluster", "k_rescue", "k_build", "k_dp_", "k_finish", "k_chunk_sums", "k_reduce_stats",
+                        "k_check_est", "k_max_read_len", "k_fill_i32", "k_sa", "k_gather_pout")  # what a step launches (not the index builder's kernels)
 
 
 def pmc_profile(args):
@@ -60,7 +70,8 @@ def pmc_profile(args):
     cycles per kernel.  Only returned when the workload is one of those the passes profiled (scripts/collect_profile.sh,
     scripts/profile_configs.sh run bench.py with exactly these arguments)."""
     sig = (args.genome, float(args.genome_mbp), args.batch_pairs, args.rlen, args.alg, args.sub, args.ins, args.dele, int(bool(args.single_end)))
-    path = PMC_SUMMARY.get(sig)
+    name = PMC_SUMMARY.get(sig)
+    path = next((os.path.join(r, name) for r in PMC_ROUNDS if name and os.path.exists(os.path.join(ROOT, r, name))), None)
     if not path:
         return None
     try:
@@ -84,6 +95,13 @@ def pmc_profile(args):
                     e["valu_insts_per_step"] = p["SQ_INSTS_VALU"]["total"] / s["batches_mapped_by_the_pmc_runs"]
             if get("SQ_LDS_BANK_CONFLICT") is not None and get("SQ_LDS_IDX_ACTIVE"):
                 e["lds_conflict_frac"] = round(get("SQ_LDS_BANK_CONFLICT") / get("SQ_LDS_IDX_ACTIVE"), 4)
+            tr = s.get("kernel_trace", {}).get(k)
+            if tr:
+                e["trace_ms"] = round(tr["full_batch_avg_us"] / 1e3, 4)  # a full-batch launch of the kernel in the committed kernel trace
+            nb = s.get("batches_mapped_by_the_pmc_runs")
+            any_counter = next(iter(p.values()), None)
+            if nb and any_counter:
+                e["launches_per_step"] = round(any_counter["launches"] / nb, 2)
             out[k] = e
         return {"kernels": out, "file": path}
     except (OSError, KeyError, ValueError, ZeroDivisionError):
@@ -126,7 +144,10 @@ def dp_roofline(args, d, prof):
          "achieved": round(achieved, 2), "peak": round(VALU_PEAK_TLANEOPS, 1), "unit": "T lane-ops/s", "frac": round(achieved / VALU_PEAK_TLANEOPS, 4),
          "traffic": None if not issued else round(issued),
          "traffic_unit": None if not issued else f"vector lane-operation slots issued per step by the DP kernels (rocprofv3 SQ_INSTS_VALU x 64, {prof['file']})",
-         "avg_launch_ms": round(ms, 3), "cells_per_step": round(cells), "ops_per_cell": ops, "gcups": round(cells / max(ms, 1e-9) / 1e6, 1),
+         "avg_launch_ms": round(ms, 3), "cells_per_step": round(cells), "ops_per_cell": ops, "ops_per_cell_is": "the vector instructions of the compiled sweep's inner loop per cell (this kernel's own count)",
+         "ops_per_cell_minimal": DP_OPS_PER_CELL_MINIMAL[args.alg],
+         "frac_at_minimal_ops": round(cells * DP_OPS_PER_CELL_MINIMAL[args.alg] / (ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS, 4) if ms > 0 else 0.0,
+         "gcups": round(cells / max(ms, 1e-9) / 1e6, 1),
          "basis": "algorithmic lane-operations (cells of all problems x the sweep's vector instructions per cell) over the DP stage's live time, against "
                   "256 CU x 4 SIMD-32 x 2.4 GHz (a wave64 instruction per 2 cycles)"}
     if dpk:
@@ -137,51 +158,83 @@ def dp_roofline(args, d, prof):
 
 
 def roofline(args, d, reads_per_s):
-    """The dominant stage's roofline.  A per-pair / seeding kernel: `frac` = measured HBM bytes of the launch / its live duration /
+    """The dominant KERNEL's roofline.  A per-pair / seeding kernel: `frac` = measured HBM bytes of the launch / its live duration /
     the HBM peak (at most 1 by construction).  The DP stage (the longest one of BASELINE config 5): vector-instruction issue
-    (dp_roofline).  The reference's own walk priced at our launch time (SURVEY 8d's figure, which can exceed 1 because the kernel
-    does not do that walk) is kept as `speed_of_light_equiv`; `request_rate` sets the L2 request rate of the gather-bound kernels
-    against what random 16-byte gathers reach on this chip."""
+    (dp_roofline).  A step that is a string of short launches (config 2) is bound by none of its kernels: `launch_bound` says so.
+    The reference's own walk priced at our launch time (SURVEY 8d's figure, which can exceed 1 because the kernel does not do that
+    walk) is kept as `speed_of_light_equiv`; `per_kernel` and `request_rate` list every kernel of a step by name — live time where
+    the library times the kernel by itself, the committed kernel trace's otherwise."""
     steps = max(args.steps, 1)
     prof = pmc_profile(args)
-    ms = {STAGE_KERNEL[k]: d[k] / steps for k in STAGE_KERNEL if d.get(k, 0) > 0}
-    longest = max(ms, key=ms.get)
     kern = prof["kernels"] if prof else {}
+    nw = "true" if args.alg == "nw" else "false"
+    stage_of, live = {}, {}
+    for st, ks in STAGE_KERNELS.items():
+        for k in ks:
+            stage_of[k.format(nw=nw)] = st
+        if len(ks) == 1 and d.get(st, 0) > 0:
+            live[ks[0]] = d[st] / steps  # (k_build: its two launches together)
+    longest = max(live, key=live.get)
+    reads_step = d["reads"] / steps
     seed_bytes = 64.0 * 1.107 * d["fm_ext_steps"] + float(d["reads"]) * args.rlen
     seed_ms = d["ms_seed"] / steps
-    if d.get("ms_dp", 0) / steps > ms[longest]:
+    step_ms = sum(d[k] for k in d if k.startswith("ms_") and k not in ("ms_total",)) / steps
+    if d.get("ms_dp", 0) / steps > live[longest]:
         r = dp_roofline(args, d, prof)
     else:
         traffic = kern.get(longest, {}).get("traffic")
         ess = essential_bytes(longest, d, args)
         moved = traffic if traffic else ess
-        achieved = moved / (ms[longest] * 1e-3) / 1e9
+        achieved = moved / (live[longest] * 1e-3) / 1e9
         r = {"bound": "hbm", "kernel": longest, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
              "traffic_unit": None if not traffic else f"HBM bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, {prof['file']})",
-             "avg_launch_ms": round(ms[longest], 3),
+             "avg_launch_ms": round(live[longest], 3),
              "basis": "measured HBM bytes of the launch (committed PMC pass of this command) over the live launch time" if traffic else
                       "no PMC pass of this workload is committed: the kernel's essential bytes (DESIGN.md §3) over the live launch time",
-             "algorithmic_bytes_per_launch": round(ess), "algorithmic_frac": round(ess / (ms[longest] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-    r.update({
-         "per_kernel": {k: {"ms": round(ms[k], 3), "hbm_gbs": None if not kern.get(k, {}).get("traffic") else round(kern[k]["traffic"] / (ms[k] * 1e-3) / 1e9, 1),
-                            "frac_of_peak": None if not kern.get(k, {}).get("traffic") else round(kern[k]["traffic"] / (ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
-                            "bytes_per_read": None if not kern.get(k, {}).get("traffic") else round(kern[k]["traffic"] / (d["reads"] / steps), 1),
-                            "essential_bytes_per_read": round(essential_bytes(k, d, args) / (d["reads"] / steps), 1)} for k in ms},
-         "request_rate": {k: {"l2_requests_per_launch": kern[k]["l2_requests"], "g_per_s": round(kern[k]["l2_requests"] / (ms[k] * 1e-3) / 1e9, 1),
-                              "ceiling_g_per_s": GATHER_CEILING_G_PER_S, "frac": round(kern[k]["l2_requests"] / (ms[k] * 1e-3) / 1e9 / GATHER_CEILING_G_PER_S, 3),
-                              "requests_per_read": round(kern[k]["l2_requests"] / (d["reads"] / steps), 2), "waves_waiting_frac": kern[k].get("wait_frac"),
-                              **({} if "l2_misses" not in kern[k] else {
-                                  "l2_misses_per_launch": kern[k]["l2_misses"], "misses_per_read": round(kern[k]["l2_misses"] / (d["reads"] / steps), 2),
-                                  "misses_g_per_s": round(kern[k]["l2_misses"] / (ms[k] * 1e-3) / 1e9, 1), "walk_miss_ceiling_g_per_s": WALK_MISS_CEILING_G_PER_S,
-                                  "miss_frac_of_ceiling": round(kern[k]["l2_misses"] / (ms[k] * 1e-3) / 1e9 / WALK_MISS_CEILING_G_PER_S, 3)})}
-                          for k in ms if k in kern and "l2_requests" in kern[k]},
-         "speed_of_light_equiv": {"kernel": "k_seed", "bytes_per_read": round(seed_bytes / max(d["reads"], 1), 1),
-                                  "gbs": round(seed_bytes / steps / (seed_ms * 1e-3) / 1e9, 1) if seed_ms > 0 else None,
-                                  "ratio_to_peak": round(seed_bytes / steps / (seed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3) if seed_ms > 0 else None,
-                                  "note": "SURVEY 8d's seeding bytes (64*1.107*E + rlen per read: the reference's FM walk) over our launch time; not a utilisation — "
-                                          "the kernel reaches the same seeds through a K-mer jump table and direct genome comparison"},
-         "path": path_roofline(d, args, reads_per_s)})
+             "algorithmic_bytes_per_launch": round(ess), "algorithmic_frac": round(ess / (live[longest] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    # every kernel of a step, by name
+    per, req, launches = {}, {}, 0.0
+    names = sorted(set(list(live) + [k for k in kern if k.startswith(STEP_KERNEL_PREFIXES)]))
+    for k in names:
+        p = kern.get(k, {})
+        ms = live.get(k) if k in live and k != "k_build" else p.get("trace_ms")  # per launch
+        launches += p.get("launches_per_step", 0.0)
+        e = {"stage": (stage_of.get(k) or ("ms_dp" if k.startswith("k_dp_") else None) or "")[3:] or None,
+             "ms_live": None if k not in live else round(live[k], 3), "ms_per_launch_trace": p.get("trace_ms"), "launches_per_step": p.get("launches_per_step")}
+        if p.get("traffic") and ms:
+            e.update({"hbm_bytes_per_launch": p["traffic"], "hbm_gbs": round(p["traffic"] / (ms * 1e-3) / 1e9, 1),
+                      "frac_of_peak": round(p["traffic"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3), "bytes_per_read": round(p["traffic"] / reads_step, 1)})
+        eb = essential_bytes(k, d, args)
+        if eb:
+            e["essential_bytes_per_read"] = round(eb / reads_step, 1)
+        for c in ("issue_frac", "wait_frac", "lds_conflict_frac"):
+            if c in p:
+                e[c] = p[c]
+        per[k] = e
+        if "l2_requests" in p and ms:
+            q = {"l2_requests_per_launch": p["l2_requests"], "g_per_s": round(p["l2_requests"] / (ms * 1e-3) / 1e9, 1), "ceiling_g_per_s": GATHER_CEILING_G_PER_S,
+                 "frac": round(p["l2_requests"] / (ms * 1e-3) / 1e9 / GATHER_CEILING_G_PER_S, 3), "requests_per_read": round(p["l2_requests"] / reads_step, 2)}
+            if "l2_misses" in p:
+                q.update({"l2_misses_per_launch": p["l2_misses"], "misses_per_read": round(p["l2_misses"] / reads_step, 2),
+                          "misses_g_per_s": round(p["l2_misses"] / (ms * 1e-3) / 1e9, 1), "walk_miss_ceiling_g_per_s": WALK_MISS_CEILING_G_PER_S,
+                          "miss_frac_of_ceiling": round(p["l2_misses"] / (ms * 1e-3) / 1e9 / WALK_MISS_CEILING_G_PER_S, 3)})
+            req[k] = q
+    r.update({"per_kernel": per, "request_rate": req,
+              "launches_per_step": round(launches, 1) if launches else None,
+              "speed_of_light_equiv": {"kernel": "k_seed", "bytes_per_read": round(seed_bytes / max(d["reads"], 1), 1),
+                                       "gbs": round(seed_bytes / steps / (seed_ms * 1e-3) / 1e9, 1) if seed_ms > 0 else None,
+                                       "ratio_to_peak": round(seed_bytes / steps / (seed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3) if seed_ms > 0 else None,
+                                       "note": "SURVEY 8d's seeding bytes (64*1.107*E + rlen per read: the reference's FM walk) over our launch time; not a utilisation — "
+                                               "the kernel reaches the same seeds through a K-mer jump table and direct genome comparison"},
+              "path": path_roofline(d, args, reads_per_s)})
+    # a step of many short launches: no kernel's roofline describes it
+    if step_ms < 4.0 and live[longest] < 0.4 * step_ms and not (d.get("ms_dp", 0) / steps > live[longest]):
+        r["launch_bound"] = {"ms_per_step": round(step_ms, 3), "longest_kernel": longest, "longest_kernel_ms": round(live[longest], 3),
+                             "launches_per_step": round(launches, 1) if launches else None,
+                             "mean_us_per_launch": round(1e3 * step_ms / launches, 1) if launches else None,
+                             "note": "the step is a string of launches of a few tens to hundreds of microseconds each on a chip that this batch does not fill: "
+                                     "it is bound by launch and tail latency, not by any kernel's traffic — `frac` of the longest kernel says nothing here"}
     return r
 
 
@@ -281,7 +334,8 @@ def vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, n_s
     slice_reads = min(reads_per_step, args.vcf_slice_reads)
     # (the pair records stay — round 4 gave them back here, and mapped in slices of 4 M reads —; the large tier's records sized for this workload's
     #  heavy pairs, 0.7 % of a batch, instead of config 5's 4.5 %: 8 GB instead of 24)
-    os.environ["MCX_TIER1_GB"] = str(args.vcf_tier1_gb)
+    if slice_reads * 3072 > args.vcf_tier1_gb << 30:  # (the library's own size for the tier: 3 KB per read of the batch, 2 - 24 GB)
+        os.environ["MCX_TIER1_GB"] = str(args.vcf_tier1_gb)
     try:
         mapper = api.Mapper(index, alg=args.alg, max_read_len=max(256, args.rlen), max_batch_reads=slice_reads)
     finally:
@@ -398,7 +452,7 @@ def other_configs(args):
                         "halved_selections": o["halved_selections"], "cpu_baseline": o.get("cpu_baseline"),
                         "simple_pairs": o.get("simple_pairs"),
                         "roofline": {k: o["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_unit", "avg_launch_ms", "gcups", "cells_per_step",
-                                                                       "ops_per_cell", "issued_frac_of_peak", "basis")}})
+                                                                       "ops_per_cell", "ops_per_cell_minimal", "frac_at_minimal_ops", "issued_frac_of_peak", "launch_bound", "launches_per_step", "basis")}})
         except Exception as e:
             res.append({"config": name, "error": str(e)[:200]})
     return res
@@ -420,7 +474,8 @@ def parse():
     ap.add_argument("--full-sa", type=int, default=2, help="1: every suffix-array entry, the jump table and the rank records in HBM; 2: the pair records too (two bases per step of the seeding walk)")
     ap.add_argument("--cpu-pairs", type=int, default=-1,
                     help="pairs of the CPU-baseline sample (0 = skip, -1 = about 20 s of work for this host's core count)")
-    ap.add_argument("--cpu-level", default="two", choices=["sam", "two", "full"],
+    ap.add_argument("--cpu-t1-pairs", type=int, default=-1, help="pairs of the -t 1 run of the CPU baseline (-1: about 20 s of its clock)")
+    ap.add_argument("--cpu-level", default="full", choices=["sam", "two", "full"],
                     help="runs of the CPU baseline: with -sam only | and without any output (mapping_only) | and at -t 1")
     ap.add_argument("--repeats", type=int, default=2000, help="--genome uniform: planted dispersed repeat families")
     ap.add_argument("--genome", default="human", choices=["human", "uniform"],
@@ -606,7 +661,10 @@ def cpu_prepare(args, index, bases_sample):
     prefix = os.path.join(tmp, "idx")
     index.save(prefix)
     st = {"tmp": tmp, "prefix": prefix, "se": se, "step": step, "n_pairs": bases_sample.shape[0] // step, "alg": args.alg, "rlen": args.rlen, "level": args.cpu_level}
-    for tag, rows in (("r", bases_sample), ("t", bases_sample[:400]), ("s", bases_sample[:step * min(st["n_pairs"], 75_000)])):
+    # the -t 1 sample: ~20 s of the reference's clock (18-19 k reads/s against a human-sized index, 75 k against a bacterial one)
+    t1 = args.cpu_t1_pairs if args.cpu_t1_pairs > 0 else (200_000 if args.genome_mbp > 100 else 1_500_000)
+    st["t1_pairs"] = min(st["n_pairs"], t1)
+    for tag, rows in (("r", bases_sample), ("t", bases_sample[:400]), ("s", bases_sample[:step * st["t1_pairs"]])):
         synth.write_fastq(os.path.join(tmp, tag + "1.fq"), rows, 0, step)
         if not se:
             synth.write_fastq(os.path.join(tmp, tag + "2.fq"), rows, 1, 2)
@@ -618,8 +676,8 @@ def cpu_run(st):
     starts its clock after loading, main.cpp:376).  At -t <all cores>: with `-sam <file>` (the reference then formats every line and
     pushes it through fprintf under its OutputLock, ReadMapping.cpp:536-560) and — level "two" / "full" — without any output (`-no_vcf`, no
     `-sam`: bSAMoutput stays false, :536 is skipped): `mapping_only`, the like-for-like figure beside `value`, which times kernels and writes
-    no text either.  Level "full" adds a -t 1 run on 75 k pairs; for the GRCh38-sized index every run of the reference spends
-    ~45 s loading it, so the default line leaves that one to profiles/round4/full_batch_parity.json (8 M reads at -t 1)."""
+    no text either.  Level "full" (the default) adds a -t 1 run on about 20 s worth of pairs (--cpu-t1-pairs); for the GRCh38-sized
+    index every run of the reference spends ~45 s loading it: three runs, about three minutes of the default line."""
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "MapCaller")
     port_bin = os.path.join(ROOT, "oracle", "mcx_oracle")
     cores = os.cpu_count() or 1
@@ -658,17 +716,19 @@ def cpu_run(st):
         return round(reps * step * n_pairs / dt, 1), how
     v_sam, how_sam = rate(True, fq("r"))
     what = f"{n_pairs} {'reads' if se else 'pairs'} x {st['rlen']} bp of the same synthetic workload, -t {cores} -alg {alg}"
-    out = {"value": v_sam, "unit": "reads/s", "cores": cores, "kind": kind, "sample": f"{what} -sam (file) -no_vcf; {how_sam}"}
+    out = {"value": v_sam, "unit": "reads/s", "cores": cores, "kind": kind, "sample": f"{what} -sam (file) -no_vcf; {how_sam}",
+           "note": "at this thread count the reference is bound by its LibraryLock reader (GetData.cpp:85-140 under ReadMapping.cpp:440), not by its output: with -sam and "
+                   "without it give the same rate; its clock prints whole seconds (+-1 s of the figure above)"}
     if kind == "reference" and st["level"] in ("two", "full"):
         v_map, how_map = rate(False, fq("r"))
         out["mapping_only"] = {"value": v_map, "unit": "reads/s", "cores": cores,
                                "sample": f"{what}, -no_vcf and no -sam: mapping alone, no SAM text (ReadMapping.cpp:536 skipped); {how_map}"}
     if kind == "reference" and st["level"] == "full":
-        n1 = min(n_pairs, 75_000)
+        n1 = st["t1_pairs"]
         _, own1 = run(*fq("s"), threads=1)
         if own1:
             out["single_thread"] = {"value": round(step * n1 / own1, 1), "unit": "reads/s", "cores": 1,
-                                    "sample": f"{n1} {'reads' if se else 'pairs'}, -t 1, -sam (file), the reference's own clock: {own1} s"}
+                                    "sample": f"{n1} {'reads' if se else 'pairs'}, -t 1, -sam (file), the reference's own clock (whole seconds): {own1} s"}
     return out
 
 

@@ -1979,7 +1979,7 @@ __global__ void __launch_bounds__(256, MCX_FINISH_WAVES) k_finish(Ctx cx, ReadBa
 struct Knobs {
     bool timing = false, seed_one_base = false, dp_by_wave = false, dp_lane_always = false, late_reseed = false, no_work_order = false, no_simple = false,
          simple_no_dp = false, cluster_by_lane = false, rescue_in_line = false, build_by_lane = false, no_sums_cache = false, prof_by_column = false,
-         tier1_hist = false, dp_hist = false, no_tier_overlap = false, no_late_overlap = false, prof_unsorted = false;
+         tier1_hist = false, dp_hist = false, no_tier_overlap = false, no_late_overlap = false;
     int seed_fm_budget = 6, build_wave_limit = 0x7fffffff;
     uint32_t order_min = 16384u;
 };
@@ -1991,7 +1991,7 @@ static Knobs knobs_read()
     k.late_reseed = on("MCX_LATE_RESEED"); k.no_work_order = on("MCX_NO_WORK_ORDER"); k.no_simple = on("MCX_NO_SIMPLE"); k.simple_no_dp = on("MCX_SIMPLE_NO_DP");
     k.cluster_by_lane = on("MCX_CLUSTER_BY_LANE"); k.rescue_in_line = on("MCX_RESCUE_IN_LINE"); k.build_by_lane = on("MCX_BUILD_BY_LANE");
     k.no_sums_cache = on("MCX_NO_SUMS_CACHE"); k.prof_by_column = on("MCX_PROF_BY_COLUMN"); k.tier1_hist = on("MCX_TIER1_HIST"); k.dp_hist = on("MCX_DP_HIST");
-    k.no_tier_overlap = on("MCX_NO_TIER_OVERLAP"); k.no_late_overlap = on("MCX_NO_LATE_OVERLAP"); k.prof_unsorted = on("MCX_PROF_UNSORTED");
+    k.no_tier_overlap = on("MCX_NO_TIER_OVERLAP"); k.no_late_overlap = on("MCX_NO_LATE_OVERLAP");
     if (const char *e = getenv("MCX_SEED_FM_BUDGET")) k.seed_fm_budget = std::max(1, atoi(e));
     if (const char *e = getenv("MCX_BUILD_WAVE_LIMIT")) k.build_wave_limit = atoi(e); // (tests: the bound sum from which k_build_wave hands a pair to one lane)
     if (const char *e = getenv("MCX_ORDER_MIN")) k.order_min = (uint32_t)std::max(1, atoi(e)); // (tests: small batches through k_simple and the order too)
@@ -2098,6 +2098,15 @@ struct mcx_ctx {
     size_t n_tally = 0;
     uint64_t keys_cap = 0;       // keys the sort buffers hold
     uint64_t *h_keys = nullptr; uint64_t h_keys_cap = 0; // pinned: the batch's keys for the exchange between shards
+    // the tail of a whole-batch pass queued behind its kernels, before the host waits for them (mcx_map_batch_dev: queue_batch_tail) — the
+    // seeding statistics, the per-chunk sums, the insert-size walk over them and the check of every pair's estimate, one copy back
+    struct Tail {
+        bool want = false, queued = false, ran = false; // asked for by the caller of this batch; queued by its pass and still standing; queued at all
+        int64_t state0[3] = {1000, 0, 0};      // avgDist, pairs, distance sum before the batch
+        uint32_t *d = nullptr;                 // device: [0..8) counters (n_redo, mapped), [8..8 + nc) the chunks' estimates
+        uint32_t *h = nullptr; uint32_t cap = 0; // page-locked: counters[8] | flags[4] | statistics (3 x u64) | ok[nc] ds[nc] ls[nc] est[nc]
+        hipEvent_t ev[2] = {nullptr, nullptr};
+    } tail;
     uint32_t *d_batch_flags = nullptr; // [0] words taken in the batch's CIGAR pool, [1] longest read of the batch, [2] the pool ran over, [3] a read holds an N
     BatchRun run;
     PassRes t1;               // the large tier's own set (the members above are tier 0's); allocated when every suffix-array entry is resident
@@ -2368,7 +2377,9 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     if (c->arch.d) (void)hipFree(c->arch.d);
     if (c->arch_ev.d) (void)hipFree(c->arch_ev.d);
     passres_free(c->t1); passres_free(c->t2);
-    for (hipEvent_t e : {c->ev_clustered, c->ev_built, c->ev_late_done}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {c->ev_clustered, c->ev_built, c->ev_late_done, c->tail.ev[0], c->tail.ev[1]}) if (e) (void)hipEventDestroy(e);
+    if (c->tail.d) (void)hipFree(c->tail.d);
+    if (c->tail.h) (void)hipHostFree(c->tail.h);
     for (auto &sl : c->slot) {
         void *q[] = {sl.d_bases, sl.d_off, sl.d_recs, sl.d_cig, sl.d_codes, sl.d_len, sl.d_odd};
         for (void *x : q) if (x) (void)hipFree(x);
@@ -2499,6 +2510,7 @@ static int tier1_pass_end(mcx_ctx *c, const PassRes &T, uint32_t m, mcx_stats *t
 // state_off: the pass's pair records start at record state_off of the tier.  queue_only: the kernels are queued on R's stream
 // and that is all — the caller goes on and calls pass_finish() for the pass later (*queued = its timing events).
 static int pass_finish(mcx_ctx *c, int tier, const PassRes &R, uint32_t n_sel, mcx_stats *stats, bool timing, int e);
+static int queue_batch_tail(mcx_ctx *c);
 
 static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb, int paired, PairSel sel, AlnRec *d_recs,
                      uint32_t *d_cig, mcx_stats *stats, bool timing, bool early = false, uint32_t state_off = 0, int *queued = nullptr, bool hits_from_tier0 = false, bool no_n_reads = false)
@@ -2696,10 +2708,13 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
                 if (stats) stats->tier1_pairs += n_late;
             }
         }
+        // (everything of the batch is queued: what follows its kernels goes behind them now, before the host waits for any of the passes)
+        if (rc2 == 0 && c->tail.want && !sel.ids && state_off == 0) rc2 = queue_batch_tail(c);
         if (e1 >= 0) { const int r = tier1_pass_end(c, T, m, t1_timing ? &t1 : nullptr, stats, e1); if (rc2 == 0) rc2 = r; }
         if (e2 >= 0) { const int r = tier1_pass_end(c, c->t2, n_late, nullptr, stats, e2); if (rc2 == 0) rc2 = r; }
     }
     if (ev_dbg[0]) HIP_TRY(hipEventRecord(ev_dbg[1], c->t1.stream));
+    if (!early && tier == 0 && rc2 == 0 && c->tail.want && !sel.ids && state_off == 0) rc2 = queue_batch_tail(c);
     HIP_TRY(hipStreamSynchronize(s));
     if (ev_dbg[0]) {
         float a = 0, b = 0;
@@ -2867,6 +2882,79 @@ __global__ void k_check_est(const PairOut *po, uint32_t n_pairs, uint32_t chunk,
     }
 }
 
+// mcx_avg_walk on the device: the estimate every chunk of the batch is checked against.  The walk is no chain: the estimate before chunk k is
+// the run's when the batch began (k = 0, or no more than 1000 proper pairs so far — the count only grows, so nothing moved it yet) or the
+// rounded mean over everything before k (ReadMapping.cpp:538-539) — prefix sums of the chunks' pairs and distances.  One block: a stretch of
+// chunks per thread, the stretches' sums scanned in LDS.
+__global__ void __launch_bounds__(1024) k_avg_walk(const uint32_t *ok, const uint32_t *ds, uint32_t nc, long long cur0, long long tp0, long long td0, int32_t *est_chunk)
+{
+    __shared__ long long s_tp[1024], s_td[1024];
+    const uint32_t per = (nc + 1023u) / 1024u, lo = min(nc, threadIdx.x * per), hi = min(nc, lo + per);
+    long long tp = 0, td = 0;
+    for (uint32_t k = lo; k < hi; k++) { tp += ok[k]; td += ds[k]; }
+    s_tp[threadIdx.x] = tp; s_td[threadIdx.x] = td;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long a = tp0, b = td0;
+        for (int i = 0; i < 1024; i++) { const long long x = s_tp[i], y = s_td[i]; s_tp[i] = a; s_td[i] = b; a += x; b += y; }
+    }
+    __syncthreads();
+    tp = s_tp[threadIdx.x]; td = s_td[threadIdx.x];
+    for (uint32_t k = lo; k < hi; k++) {
+        uint32_t cur = (uint32_t)cur0;
+        if (k > 0 && tp > 1000) cur = (uint32_t)(int)(1. * (double)td / (double)tp + .5);
+        est_chunk[k] = (int32_t)(cur * 1.5);
+        tp += ok[k]; td += ds[k];
+    }
+}
+
+// What follows the kernels of a whole-batch pass, queued behind them BEFORE the host waits for the pass (the large tier's passes beside
+// it included: their streams' events) instead of in three round trips after it: the seeding statistics, the per-chunk sums, the walk
+// and the check of every pair's estimate against its chunk's, everything the host wants of them in one copy to page-locked memory.
+// Used when the pass went the plain way (no halved selection, no pair left over for the large tier afterwards: run_selection);
+// the caller walks the sums itself too (a few thousand scalars) and takes the device's list only when both walks agree.
+static int queue_batch_tail(mcx_ctx *c)
+{
+    BatchRun &br = c->run;
+    mcx_ctx::Tail &t = c->tail;
+    hipStream_t s = c->stream;
+    const uint32_t nc = br.n_chunks, n_reads = br.rb.n_reads;
+    const uint32_t words = 8 + 4 + 6 + 4 * nc;
+    if (t.cap < words) {
+        if (t.d) (void)hipFree(t.d);
+        if (t.h) (void)hipHostFree(t.h);
+        t.d = nullptr; t.h = nullptr; t.cap = 0;
+        const uint32_t want = 8 + 4 + 6 + 4 * (uint32_t)((c->max_reads + kReadChunkSize / 2 - 1) / (kReadChunkSize / 2));
+        HIP_TRY(hipMalloc((void **)&t.d, (size_t)want * 4));
+        HIP_TRY(hipHostMalloc((void **)&t.h, (size_t)want * 4));
+        t.cap = want;
+        for (auto &e : t.ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (c->overlap_tiers) { // the passes of the large tier beside this one write records and outcomes of their own pairs
+        HIP_TRY(hipEventRecord(t.ev[0], c->t1.stream)); HIP_TRY(hipStreamWaitEvent(s, t.ev[0], 0));
+        if (c->overlap_late) { HIP_TRY(hipEventRecord(t.ev[1], c->t2.stream)); HIP_TRY(hipStreamWaitEvent(s, t.ev[1], 0)); }
+    }
+    uint32_t *d_ok = c->d_read_ext, *d_ds = c->d_read_blocks, *d_ls = d_ds + nc; // (the per-read statistics are reduced first: as mcx_batch_sums has it)
+    unsigned long long *d_sum = (unsigned long long *)(t.d + 2); // counters [2..8): three 64-bit sums
+    int32_t *d_est = (int32_t *)(t.d + 8);
+    HIP_TRY(hipMemsetAsync(t.d, 0, 8 * sizeof(uint32_t), s));
+    k_reduce_stats<<<256, 256, 0, s>>>(c->d_read_ext, c->d_read_blocks, n_reads, d_sum);
+    k_chunk_sums<<<(nc + 255) / 256, 256, 0, s>>>(c->d_pout, br.rb.off, br.n_pairs, kReadChunkSize / 2, d_ok, d_ds, d_ls, t.d + 1);
+    if (br.paired) {
+        k_avg_walk<<<1, 1024, 0, s>>>(d_ok, d_ds, nc, (long long)t.state0[0], (long long)t.state0[1], (long long)t.state0[2], d_est);
+        k_check_est<<<2048, 256, 0, s>>>(c->d_pout, br.n_pairs, kReadChunkSize / 2, d_est, c->d_sel_ids, c->d_est, t.d, c->ov_cap);
+    }
+    HIP_TRY(hipGetLastError());
+    uint32_t *h = t.h;
+    HIP_TRY(hipMemcpyAsync(h, t.d, 8 * 4, hipMemcpyDeviceToHost, s));                       // n_redo, mapped, statistics
+    HIP_TRY(hipMemcpyAsync(h + 8, c->d_batch_flags, 4 * 4, hipMemcpyDeviceToHost, s));      // the CIGAR pool's words, its overflow flag
+    HIP_TRY(hipMemcpyAsync(h + 18, d_ok, (size_t)nc * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h + 18 + nc, d_ds, 2 * (size_t)nc * 4, hipMemcpyDeviceToHost, s)); // (distance sums, then length sums)
+    if (br.paired) HIP_TRY(hipMemcpyAsync(h + 18 + 3 * nc, d_est, (size_t)nc * 4, hipMemcpyDeviceToHost, s));
+    t.queued = t.ran = true;
+    return 0;
+}
+
 static int profile_keys(mcx_ctx *c);
 static int profile_foreign(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all);
 static int sort_reserve(mcx_ctx *c, uint64_t n);
@@ -2910,6 +2998,8 @@ static int run_selection(mcx_ctx *c, const ReadBatch &rb, int paired, const std:
     else k_fill_i32<<<(n + 255) / 256, 256, 0, s>>>(c->d_est, est_all, n);
     const PassRes R0 = res_tier0(c);
     int rc = run_pairs(c, 0, R0, rb, paired, sel, d_recs, d_cig, stats, timing, true);
+    // (the batch's tail, if the pass queued it, stands only when the pass is all there was: no halves, no pairs left for the large tier)
+    if (rc != 0 || c->h_cnt[CNT_OV] != 0) c->tail.queued = false;
     if (rc == kListOverflow) {
         // unusually many hits or DP problems per read (e.g. indel-heavy long reads): halve the selection
         if (n < 2) return fail(MCX_ERR_CAPACITY, "work list overflow for a single pair");
@@ -3014,6 +3104,7 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
     br.n_pairs = paired ? n_reads / 2 : n_reads;
     br.n_chunks = (br.n_pairs + kReadChunkSize / 2 - 1) / (kReadChunkSize / 2);
     br.mapped = 0; br.sums_valid = false;
+    c->tail.queued = c->tail.ran = false;
     { // every read must fit the slots the context was sized for
         HIP_TRY(hipMemsetAsync(c->d_batch_flags, 0, 4 * sizeof(uint32_t), s));
         k_max_read_len<<<512, 256, 0, s>>>(d_off, n_reads, c->d_batch_flags + 1);
@@ -3037,7 +3128,8 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
     int rc;
     rc = run_selection(c, br.rb, paired, nullptr, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true);
     if (rc) return rc;
-    { // seeding statistics (E, blocks, H of SURVEY.md 8d) before the per-read arrays are reused for the chunk sums
+    if (c->tail.ran) memcpy(c->h_cnt + CNT_N, c->tail.h + 2, sizeof br.hs); // (the pass queued the batch's tail: the statistics came with it, before the per-read arrays were reused)
+    else { // seeding statistics (E, blocks, H of SURVEY.md 8d) before the per-read arrays are reused for the chunk sums
         unsigned long long *d_sum = (unsigned long long *)c->d_cnt;
         HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
         k_reduce_stats<<<256, 256, 0, s>>>(c->d_read_ext, c->d_read_blocks, n_reads, d_sum);
@@ -3083,6 +3175,7 @@ extern "C" int mcx_batch_sums(mcx_ctx *c, uint32_t *n_chunks, const uint32_t **p
     return 0;
 }
 
+static int replay_listed(mcx_ctx *c, uint32_t n_redo, mcx_stats *stats);
 extern "C" int mcx_batch_replay(mcx_ctx *c, const int32_t *est_chunk, uint32_t *n_redone, mcx_stats *stats)
 {
     if (!c || !c->run.open || !est_chunk) return fail(MCX_ERR_ARG, "mcx_batch_replay: no batch in flight");
@@ -3099,7 +3192,17 @@ extern "C" int mcx_batch_replay(mcx_ctx *c, const int32_t *est_chunk, uint32_t *
     HIP_TRY(hipStreamSynchronize(s));
     const uint32_t n_redo = c->h_cnt[CNT_OV];
     if (n_redo == 0) return 0;
+    if (int rc = replay_listed(c, n_redo, stats)) return rc;
+    if (n_redone) *n_redone = n_redo;
+    return 0;
+}
+
+// the pairs k_check_est listed (d_sel_ids, d_est: n_redo of them) through the path again, with their chunk's estimate
+static int replay_listed(mcx_ctx *c, uint32_t n_redo, mcx_stats *stats)
+{
+    BatchRun &br = c->run;
     br.sums_valid = false;
+    c->tail.queued = false; // (what the batch's tail brought is no longer the batch's state)
     if (n_redo > c->ov_cap) return fail(MCX_ERR_CAPACITY, "avgDist replay: redo list overflow");
     if (stats) stats->replayed_pairs += (int64_t)n_redo;
     std::vector<uint32_t> redo(n_redo); std::vector<int32_t> redo_est(n_redo);
@@ -3110,10 +3213,7 @@ extern "C" int mcx_batch_replay(mcx_ctx *c, const int32_t *est_chunk, uint32_t *
     for (uint32_t i = 0; i < n_redo; i++) ord[i] = std::make_pair(redo[i], redo_est[i]);
     std::sort(ord.begin(), ord.end());
     for (uint32_t i = 0; i < n_redo; i++) { redo[i] = ord[i].first; redo_est[i] = ord[i].second; }
-    int rc = run_selection(c, br.rb, br.paired, &redo, &redo_est, 0, br.n_pairs, br.recs, br.cig, stats, false);
-    if (rc) return rc;
-    if (n_redone) *n_redone = n_redo;
-    return 0;
+    return run_selection(c, br.rb, br.paired, &redo, &redo_est, 0, br.n_pairs, br.recs, br.cig, stats, false);
 }
 
 // what both ways of closing a batch share: the long-CIGAR pool, statistics
@@ -3124,7 +3224,8 @@ static int batch_close(mcx_ctx *c, mcx_stats *stats)
     if (!br.sums_valid && (rc = mcx_batch_sums(c, nullptr, nullptr, nullptr, nullptr))) return rc;
     {
         uint32_t fl[4] = {0, 0, 0, 0};
-        HIP_TRY(hipMemcpy(fl, c->d_batch_flags, sizeof fl, hipMemcpyDeviceToHost));
+        if (c->tail.queued) memcpy(fl, c->tail.h + 8, sizeof fl); // (nothing ran since the batch's tail was copied back)
+        else HIP_TRY(hipMemcpy(fl, c->d_batch_flags, sizeof fl, hipMemcpyDeviceToHost));
         if (fl[2] || fl[0] > br.cig_cap) return fail(MCX_ERR_CAPACITY, "the batch's CIGAR pool (" + std::to_string(MCX_CIGAR_STRIDE) + " operations per read on average + " + std::to_string(MCX_CIGAR_SLACK) + ") ran over");
         br.cig_words = fl[0];
     }
@@ -3202,9 +3303,20 @@ extern "C" int mcx_map_batch_dev(mcx_ctx *c, const uint8_t *d_bases, const uint3
     if (!c || !d_bases || !d_off || !d_aln || !d_cigar || !avg) return fail(MCX_ERR_ARG, "mcx_map_batch_dev: null argument");
     if (n_reads == 0) return 0;
     if (paired && (avg[3] % kReadChunkSize)) return fail(MCX_ERR_ARG, "batches must start on a 200-read chunk boundary");
+    // (one stream, one trajectory: what follows the batch's kernels — statistics, per-chunk sums, the walk, the check of every pair's estimate —
+    //  is queued behind them by the pass itself, queue_batch_tail)
+    c->tail.want = true; c->tail.state0[0] = avg[0]; c->tail.state0[1] = avg[1]; c->tail.state0[2] = avg[2];
     int rc = mcx_batch_begin(c, d_bases, d_off, n_reads, paired, (int32_t)((uint32_t)avg[0] * 1.5), avg[3], d_aln, d_cigar, stats);
+    c->tail.want = false;
     if (rc) return rc;
     int64_t after[3] = {avg[0], avg[1], avg[2]};
+    bool tail = c->tail.queued;
+    if (tail) { // the sums are here already (and the mapped reads' count, the CIGAR pool's state)
+        BatchRun &br = c->run;
+        const uint32_t nc = br.n_chunks, *h = c->tail.h;
+        br.ok.assign(h + 18, h + 18 + nc); br.ds.assign(h + 18 + nc, h + 18 + 3 * nc);
+        br.mapped = h[1]; br.sums_valid = true;
+    }
     if (paired) {
         std::vector<int32_t> est(c->run.n_chunks);
         for (int iter = 0;; iter++) {
@@ -3213,6 +3325,14 @@ extern "C" int mcx_map_batch_dev(mcx_ctx *c, const uint8_t *d_bases, const uint3
             if ((rc = mcx_batch_sums(c, &nc, &ok, &ds, nullptr))) return rc;
             after[0] = avg[0]; after[1] = avg[1]; after[2] = avg[2];
             mcx_avg_walk(after, ok, ds, nc, est.data());
+            if (tail && iter == 0 && memcmp(est.data(), c->tail.h + 18 + 3 * nc, (size_t)nc * 4) == 0) {
+                // the device walked the same trajectory: its list of the pairs whose estimate moved is the list
+                n_redo = c->tail.h[0];
+                if (n_redo && (rc = replay_listed(c, n_redo, stats))) return rc;
+                if (n_redo == 0) break;
+                continue;
+            }
+            if (tail && iter == 0 && c->kn.timing) fprintf(stderr, "[mcx] the device's walk of the batch's chunks differs from the host's: the host's is taken\n");
             if ((rc = mcx_batch_replay(c, est.data(), &n_redo, stats))) return rc;
             if (n_redo == 0) break;
             if (iter == 63) return fail(MCX_ERR_CAPACITY, "avgDist replay did not converge");
@@ -3574,9 +3694,7 @@ static int profile_keys(mcx_ctx *c)
     SparseSink sink; sink.recs = c->d_sparse; sink.n = c->d_cnt + CNT_TASKS; sink.cap = c->sparse_cap; sink.refused = c->d_cnt + CNT_UNSUP;
     const uint32_t n = br.rb.n_reads;
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
-    // (the reads' flag bytes: bit 1 — a byte that is not an upper-case ACGT — was set by k_pack_reads when the batch began; bit 2 — a multi-mapped
-    //  read — is k_prof_keys'; bit 0, the admission, comes later)
-    k_prof_keys<<<(n + 255) / 256, 256, 0, s>>>(c->d_detail, c->dlay, br.rb, ix, pv, sink, c->d_keys[0], c->d_cnt + CNT_OV, c->d_admit);
+    k_prof_keys<<<(n + 255) / 256, 256, 0, s>>>(c->d_detail, c->dlay, br.rb, ix, pv, sink, c->d_keys[0], c->d_cnt + CNT_OV);
     hipcub::DoubleBuffer<uint64_t> dk(c->d_keys[0], c->d_keys[1]);
     size_t tb = c->sort_tmp_bytes;
     HIP_TRY(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tb, dk, (int64_t)n, 0, 64, s));
@@ -3702,11 +3820,7 @@ static int profile_accumulate(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all,
         k_prof_count<<<(unsigned)((nk + 255) / 256), 256, 0, s>>>(d_keys, nk, pv);
     }
     ColList cols; cols.items = c->d_prof_items; cols.n = c->d_cnt + CNT_RTASK; cols.cap = c->prof_items_cap;
-    if (c->kn.prof_unsorted) k_prof_accum<<<(n + 255) / 256, 256, 0, s>>>(c->d_detail, c->dlay, br.rb, ix, pv, sink, c->d_admit, paired, cols, nullptr, 0, 0, n);
-    else {
-        if (nk) k_prof_accum<<<(unsigned)((nk + 255) / 256), 256, 0, s>>>(c->d_detail, c->dlay, br.rb, ix, pv, sink, c->d_admit, paired, cols, d_keys, nk, own_lo, n);
-        k_prof_multi<<<(n + 255) / 256, 256, 0, s>>>(c->d_detail, c->dlay, n, pv, c->d_admit);
-    }
+    k_prof_accum<<<(n + 255) / 256, 256, 0, s>>>(c->d_detail, c->dlay, br.rb, ix, pv, sink, c->d_admit, paired, cols); // (bit 1 of a flag byte: k_pack_reads')
     k_prof_cols<<<4096, 256, 0, s>>>(c->d_detail, c->dlay, br.rb, ix, pv, sink, cols);
     SparseRec *d_ev = (SparseRec *)c->d_tasks; // the SA task list is idle now
     const uint32_t ev_cap = (uint32_t)std::min<uint64_t>((uint64_t)c->task_cap * sizeof(uint2) / sizeof(SparseRec), 0x7fffffffu);

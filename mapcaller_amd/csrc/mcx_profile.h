@@ -83,16 +83,14 @@ static __device__ __forceinline__ const DetailHdr &detail_hdr(const uint8_t *det
 
 // pass 1: break points, clip gate, and the (start position, read) key of every read that reaches
 // the duplicate check (AlignmentProfile.cpp:53-77); n_valid counts them (the others get ~0 and sort last)
-// (flag: the reads' flag bytes — bit 0 the admission, bit 1 k_pack_reads', bit 2 set here for a multi-mapped read: k_prof_multi's)
 __global__ void k_prof_keys(const uint8_t *detail, DetailLayout dl, ReadBatch rb, IndexView ix, ProfView pv, SparseSink sink,
-                            uint64_t *keys, uint32_t *n_valid, uint8_t *flag)
+                            uint64_t *keys, uint32_t *n_valid)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t key = ~0ull;
     if (r < rb.n_reads) {
         const uint8_t *rec = detail + (uint64_t)r * dl.stride;
         const DetailHdr &d = *(const DetailHdr *)rec;
-        if (d.type == 2) atomicOr((uint32_t *)(flag + (r & ~3u)), 4u << (8 * (r & 3)));
         if (d.type == 1) {
             const Frag *f = (const Frag *)(rec + sizeof(DetailHdr)) + d.frag0;
             const Frag &a = f[0], &b = f[d.n_frags - 1];
@@ -132,7 +130,7 @@ __global__ void k_prof_admit(const uint64_t *keys, uint64_t n, ProfView pv, uint
     int rank = 0;
     for (int k = 1; k <= pv.max_dup && (uint64_t)k <= j; k++) { if ((keys[j - k] >> 32) == g) rank++; else break; }
     const uint32_t before = pv.pl.h(kPlReadCount)[g];
-    admit[idx] = (uint8_t)((admit[idx] & 6) | ((before + (uint32_t)rank < (uint32_t)pv.max_dup) ? 1 : 0)); // (bits 1, 2: k_pack_reads', k_prof_keys')
+    admit[idx] = (uint8_t)((admit[idx] & 2) | ((before + (uint32_t)rank < (uint32_t)pv.max_dup) ? 1 : 0)); // (bit 1: k_pack_reads')
 }
 
 // pass 2b (after every flag is out): the first key of each start position adds the round's admissions to
@@ -290,39 +288,20 @@ static __device__ __forceinline__ void prof_read(const uint8_t *detail, const De
     }
 }
 
-// keys != null: the reads in the order of their sorted (start position, read) keys — the lanes of a wavefront then add to neighbouring
-// stretches of the planes (every atomic of a read in batch order opens a line, a DRAM page and a page-table entry of its own somewhere in
-// 68 GB); the n_keys keyed reads of this shard only (own_lo .. own_lo + n_own): a multi-mapped read has no key and is k_prof_multi's.
-// keys == null: every read of the batch, in batch order (MCX_PROF_UNSORTED, the A/B of the tests).
+// (the reads in the order of their sorted start keys instead — the lanes of a wavefront then add to neighbouring stretches of the planes —
+//  was measured in round 5: 30.38 against 30.46 ms per batch; the kernel is bound by the lines its atomics open, ~24 G line fills and
+//  write-backs a second, wherever they lie)
 __global__ void __launch_bounds__(256) k_prof_accum(const uint8_t *detail, DetailLayout dl, ReadBatch rb, IndexView ix, ProfView pv,
-                                                    SparseSink sink, const uint8_t *admit, int paired, ColList cols,
-                                                    const uint64_t *keys, uint64_t n_keys, uint32_t own_lo, uint32_t n_own)
+                                                    SparseSink sink, const uint8_t *admit, int paired, ColList cols)
 {
     __shared__ SparseRec s_buf[4][96];
     __shared__ uint32_t s_cnt[4];
     WaveSparse ws; ws.buf = s_buf[threadIdx.x >> 6]; ws.cnt = &s_cnt[threadIdx.x >> 6]; ws.cap = 96;
     if ((threadIdx.x & 63) == 0) *ws.cnt = 0;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (keys) {
-        const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        r = 0xFFFFFFFFu;
-        if (j < n_keys) { const uint32_t idx = (uint32_t)keys[j] - own_lo; if (idx < n_own) r = idx; }
-    }
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     prof_read(detail, dl, rb, ix, pv, sink, ws, admit, paired, cols, r);
     wave_sparse_flush(ws, sink);
-}
-
-// UpdateMultiHitCount (:244-271) for the reads k_prof_keys flagged, when k_prof_accum goes by the keys
-__global__ void __launch_bounds__(256) k_prof_multi(const uint8_t *detail, DetailLayout dl, uint32_t n_reads, ProfView pv, const uint8_t *flag)
-{
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads || !(flag[r] & 4)) return;
-    const uint8_t *rec = detail + (uint64_t)r * dl.stride;
-    const DetailHdr d = *(const DetailHdr *)rec;
-    const Frag *fr = (const Frag *)(rec + sizeof(DetailHdr)) + d.frag0;
-    if (d.type != 2) return;
-    for (int i = 0; i < d.n_frags; i++) { const Frag f = fr[i]; range_add(pv.pl.multi, f.gPos, f.gPos + f.rLen, pv.G); }
 }
 
 // pass 3b: the listed fragments, one per group of sixteen lanes
