@@ -365,6 +365,7 @@ def vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, n_s
     mapper.profile_attach(planes.data_ptr())
     t_first = map_batch(first)
     t_acc = sum(map_batch(b) for b in timed) / len(timed)
+    hbm_free, hbm_total = torch.cuda.mem_get_info(dev)  # (the leg is the fullest the device gets: index, planes, a full-batch context, the per-read detail)
     t_sp = time.perf_counter()
     sparse = mapper.profile_sparse_raw(shard=world > 1, copy=False)  # the tally records leave HBM here, once
     t_sp = time.perf_counter() - t_sp
@@ -385,7 +386,7 @@ def vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, n_s
     gb = (mdist.reduce_profile.last_bytes if world > 1 else api.planes_stride(G) * 22) / 1e9  # (one GPU: what a rank would put on the wire, the readCount plane included here)
     vcf = {"profile_batch_ms": round(1000 * t_acc, 2), "same_batches_without_profile_ms": round(1000 * t_plain, 2),
            "profile_overhead_ms": round(1000 * (t_acc - t_plain), 2), "first_batch_of_the_run_ms": round(1000 * t_first, 2),
-           "batches": 1 + len(timed), "slice_reads": slice_reads, "pair_records_kept": bool(args.full_sa >= 2), "tier1_gb": args.vcf_tier1_gb,
+           "batches": 1 + len(timed), "hbm_free_gb": round(hbm_free / 1e9, 1), "hbm_total_gb": round(hbm_total / 1e9, 1), "slice_reads": slice_reads, "pair_records_kept": bool(args.full_sa >= 2), "tier1_gb": args.vcf_tier1_gb,
            "note": "per batch of the run in its steady state (the estimate carried from batch to batch, as in the timed region): mean over the batches behind "
                    "the first; planes and sparse records hold all of them", "sparse_records_to_host_ms": round(1000 * t_sp, 2),
            "settle_ms_once_per_run": round(1000 * t_settle, 2),
@@ -760,22 +761,22 @@ def launch_ranks(args):
 class Trajectory:
     """The run's insert-size state across the ranks (N > 1): every step is one round of the input stream — rank r maps
     batch N*step + r — and the ranks walk ONE avgDist trajectory over the round (ReadMapping.cpp:462, :538-539), as
-    mcx_map_files_ex does for real inputs: per-chunk pair sums all-gathered over RCCL, pairs whose decision depends on the
-    exact estimate re-run, until no rank re-ran any."""
+    mcx_map_files_ex does for real inputs.  What crosses the ranks is three numbers a rank and exchange — pairs re-run, proper
+    pairs, their summed distance (mcx_batch_totals) —: the walk has a closed form, so a rank checks its own chunks on the device from
+    the round's state plus the totals of the ranks before it (mcx_batch_check) and re-runs the pairs whose estimate moved, until no
+    rank re-ran any.  (Round 4 sent every chunk's sums — 640 KB a rank at 4 M pairs — and walked them on the host.)"""
 
     def __init__(self, dist, dev, world, rank, n_chunks):
         self.dist, self.dev, self.world, self.rank, self.nc = dist, dev, world, rank, n_chunks
         self.state = [1000, 0, 0]
         self.reads = 0
         self.cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")  # (gloo: several ranks sharing one GPU in tests)
-        # the message of a round: {pairs re-run last time, per-chunk proper pairs, per-chunk distance sums}; staged in page-locked
-        # memory, exchanged on the device over RCCL (one all-gather of a few tens of KB), read back into page-locked memory
-        self.h_msg = torch.zeros(1 + 2 * n_chunks, dtype=torch.int64).pin_memory()
-        self.h_all = torch.zeros(world * (1 + 2 * n_chunks), dtype=torch.int64).pin_memory()  # (flat: what all_gather_into_tensor takes on every backend)
-        self.msg = torch.zeros(1 + 2 * n_chunks, dtype=torch.int64, device=self.cdev)
-        self.all = torch.zeros(world * (1 + 2 * n_chunks), dtype=torch.int64, device=self.cdev)
+        self.h_msg = torch.zeros(3, dtype=torch.int64).pin_memory()
+        self.h_all = torch.zeros(world * 3, dtype=torch.int64).pin_memory()  # (flat: what all_gather_into_tensor takes on every backend)
+        self.msg = torch.zeros(3, dtype=torch.int64, device=self.cdev)
+        self.all = torch.zeros(world * 3, dtype=torch.int64, device=self.cdev)
         self.exchanges = 0
-        self.host_s = 0.0  # time between the end of a batch's kernels and the start of the next ones: staging, all-gather, walk
+        self.host_s = 0.0  # time between the end of a batch's kernels and the start of the next ones: staging, all-gather, bookkeeping
 
     def step(self, mapper, d_bases, d_off, n_reads, d_aln, d_cig):
         from mapcaller_amd import api
@@ -784,11 +785,9 @@ class Trajectory:
         n_redo = -1
         hm = self.h_msg.numpy()
         for it in range(64):
-            ok, ds, _ = mapper.batch_sums()
+            pairs, dsum = mapper.batch_totals()
             t0 = time.perf_counter()
-            hm[0] = n_redo
-            hm[1:1 + self.nc] = ok
-            hm[1 + self.nc:] = ds
+            hm[0], hm[1], hm[2] = n_redo, pairs, dsum
             if self.cdev.type == "cuda":
                 self.msg.copy_(self.h_msg, non_blocking=True)
                 self.dist.all_gather_into_tensor(self.all, self.msg)
@@ -797,20 +796,15 @@ class Trajectory:
             else:
                 self.dist.all_gather_into_tensor(self.h_all, self.h_msg)
             self.exchanges += 1
-            h = self.h_all.numpy().reshape(self.world, 1 + 2 * self.nc)
-            st = list(self.state)
-            mine = None
-            for r in range(self.world):
-                e = api.avg_walk(st, h[r, 1:1 + self.nc], h[r, 1 + self.nc:], want_est=(r == self.rank))
-                if r == self.rank:
-                    mine = e
+            h = self.h_all.numpy().reshape(self.world, 3)
+            before = [self.state[0], self.state[1] + int(h[:self.rank, 1].sum()), self.state[2] + int(h[:self.rank, 2].sum())]
             self.host_s += time.perf_counter() - t0
             if it > 0 and not h[:, 0].any():
                 break
-            n_redo = mapper.batch_replay(mine)
+            n_redo = mapper.batch_check(before, self.rank == 0)
         else:
             raise RuntimeError("avgDist replay did not converge")
-        self.state = st
+        api.avg_advance(self.state, int(h[:, 1].sum()), int(h[:, 2].sum()), self.world * self.nc)
         self.reads += self.world * n_reads
         mapper.batch_end()
 
@@ -957,7 +951,7 @@ def main():
                        "reads_per_step_per_gpu": reads_per_step, "full_sa_in_hbm": bool(args.full_sa), "pair_records_in_hbm": args.full_sa >= 2, "index_build_s": round(t_index, 2),
                        "index_hbm_gb": index_gb,
                        "multi_gpu": None if world == 1 else f"one process per GPU, index replicated, rank r maps batch {world}*step + r; one avgDist trajectory over the "
-                                                            f"ranks' batches per step (all-gather of per-chunk sums over RCCL, {traj.exchanges} exchanges in "
+                                                            f"ranks' batches per step (all-gather of three numbers a rank over RCCL — pairs re-run, proper pairs, summed distance —, {traj.exchanges} exchanges in "
                                                             f"{n_steps} steps, inside the timed region)",
                        "multi_gpu_host_ms_per_step": None if traj is None else round(1000 * traj.host_s / n_steps, 3)},
             "roofline": roofline(args, d, total_reads / dt / world),

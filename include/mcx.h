@@ -198,6 +198,20 @@ int mcx_batch_end(mcx_ctx *, mcx_stats *stats);
  * TotalPairedDistance}; fills est_chunk[0..n_chunks) with the EstiDistance each chunk is mapped
  * with and advances the state over the chunks. */
 void mcx_avg_walk(int64_t state[3], const uint32_t *pairs, const uint32_t *dist, uint32_t n_chunks, int32_t *est_chunk);
+/* The same feedback with nothing but TOTALS between the shards of a run (24 bytes a shard and round instead of its per-chunk
+ * sums): the walk has a closed form — the estimate before a chunk is the round's starting one, or, once more than 1000 proper
+ * pairs lie before the chunk, the rounded mean distance over everything before it — so a shard needs of the shards before
+ * it (in input order) only how many proper pairs they held and at which summed distance.
+ *   mcx_batch_totals  {proper pairs, summed distance} of the batch as it stands
+ *   mcx_batch_check   state_before = {avgDist at the round's start, pairs and distance before this batch's first chunk (the
+ *                     round's starting totals + those of the shards before this one)}; first_of_round: the batch is the
+ *                     round's first (its first chunk takes avgDist as it is).  The chunks' estimates are made on the device,
+ *                     the pairs whose estimate moved are listed and re-run (as mcx_batch_replay does); *n_redone.
+ *   mcx_avg_advance   the state after a round: state += totals; avgDist follows when the round held a chunk at all
+ * A round: begin, then { totals -> exchange -> check } until no shard re-ran a pair, then advance and end. */
+int mcx_batch_totals(mcx_ctx *, int64_t totals[2]);
+int mcx_batch_check(mcx_ctx *, const int64_t state_before[3], int first_of_round, uint32_t *n_redone, mcx_stats *stats);
+void mcx_avg_advance(int64_t state[3], int64_t pairs, int64_t dist, int64_t n_chunks);
 
 /* ---- exchange between the shards of one run (one shard = one GPU) --------------------------------
  * Collective: every shard calls allgather the same number of times; `bytes` is the same on every

@@ -64,7 +64,7 @@ SYMBOLS = [
     "mcx_avg_init", "mcx_map_batch_dev", "mcx_map_batch", "mcx_cigar_words", "mcx_map_files", "mcx_map_files_ex", "mcx_file_opts_default",
     "mcx_profile_attach", "mcx_profile_settle", "mcx_profile_finalize", "mcx_profile_sparse", "mcx_planes_alloc", "mcx_planes_free", "mcx_planes_bytes",
     "mcx_vcf_defaults", "mcx_call_variants",
-    "mcx_batch_begin", "mcx_batch_sums", "mcx_batch_replay", "mcx_batch_end", "mcx_avg_walk", "mcx_exchange_local", "mcx_exchange_local_free",
+    "mcx_batch_begin", "mcx_batch_sums", "mcx_batch_replay", "mcx_batch_end", "mcx_avg_walk", "mcx_batch_totals", "mcx_batch_check", "mcx_avg_advance", "mcx_exchange_local", "mcx_exchange_local_free",
     "mcx_profile_sparse_shard", "mcx_batch_end_keys", "mcx_batch_accumulate",
     "mcx_stream_submit", "mcx_stream_submit_packed", "mcx_stream_map", "mcx_stream_collect", "mcx_stream_next", "mcx_stream_mapped",
 ]
@@ -286,6 +286,10 @@ def lib() -> C.CDLL:
     L.mcx_batch_accumulate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]
     L.mcx_avg_walk.argtypes = [C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.mcx_avg_walk.restype = None
+    L.mcx_batch_totals.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.mcx_batch_check.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_uint32), C.POINTER(Stats)]
+    L.mcx_avg_advance.argtypes = [C.POINTER(C.c_int64), C.c_int64, C.c_int64, C.c_int64]
+    L.mcx_avg_advance.restype = None
     L.mcx_exchange_local.argtypes = [C.c_int32, C.POINTER(Exchange)]
     L.mcx_exchange_local_free.argtypes = [C.POINTER(Exchange)]
     L.mcx_exchange_local_free.restype = None
@@ -549,6 +553,20 @@ class Mapper:
         _check(lib().mcx_batch_replay(self._h, est_chunk.ctypes.data, C.byref(n), C.byref(self.stats)), "mcx_batch_replay")
         return n.value
 
+    def batch_totals(self) -> Tuple[int, int]:
+        """(proper pairs, their summed distance) of the batch as it stands: what the shards of a round tell each other."""
+        t = (C.c_int64 * 2)()
+        _check(lib().mcx_batch_totals(self._h, t), "mcx_batch_totals")
+        return int(t[0]), int(t[1])
+
+    def batch_check(self, state_before, first_of_round: bool) -> int:
+        """The chunks of the batch against the trajectory that starts from ``state_before`` = (avgDist at the round's start, pairs and
+        distance before this batch's first chunk); the pairs whose estimate moved are re-run.  Returns how many."""
+        st = (C.c_int64 * 3)(*[int(v) for v in state_before])
+        n = C.c_uint32()
+        _check(lib().mcx_batch_check(self._h, st, 1 if first_of_round else 0, C.byref(n), C.byref(self.stats)), "mcx_batch_check")
+        return n.value
+
     def batch_end(self):
         _check(lib().mcx_batch_end(self._h, C.byref(self.stats)), "mcx_batch_end")
 
@@ -645,6 +663,14 @@ class Mapper:
             self.close()
         except Exception:
             pass
+
+
+def avg_advance(state, pairs: int, dist: int, n_chunks: int):
+    """The trajectory's state after a round that held ``pairs`` proper pairs at the summed distance ``dist`` (in place: a list of three)."""
+    st = (C.c_int64 * 3)(*[int(v) for v in state])
+    lib().mcx_avg_advance(st, int(pairs), int(dist), int(n_chunks))
+    state[0], state[1], state[2] = int(st[0]), int(st[1]), int(st[2])
+    return state
 
 
 def avg_walk(state, pairs: np.ndarray, dist: np.ndarray, want_est: bool = True):

@@ -78,6 +78,16 @@ __global__ void k_half_max(const uint32_t *w, uint64_t n, uint32_t *out)
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
+// the scattered reduce: the slices of this rank's share that the peers sent (slice j of `in` at j * stride), summed word by word
+__global__ void k_sum_slices(const uint32_t *in, int n_slices, uint64_t stride, uint64_t n, uint32_t *out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t v = 0;
+        for (int j = 0; j < n_slices; j++) v += in[(uint64_t)j * stride + i];
+        out[i] = v;
+    }
+}
+
 // when they can carry: a piece of the words widened to one counter per u32, summed, and narrowed again on the root
 __global__ void k_widen(const uint32_t *w, uint64_t n, uint32_t *out)
 {
@@ -194,11 +204,54 @@ extern "C" int mcx_profile_reduce(mcx_comm *c, uint32_t *d_planes, int64_t G, in
             return r;
         };
         auto dead_hip = [&](const char *what, hipError_t e) { const int r = fail_hip(what, e); (void)ncclCommAbort(c->nccl); c->nccl = nullptr; return r; };
+        // Two ways for a piece of words onto the root.  One ncclReduce: a ring or tree of RCCL's choosing, every byte of the piece crosses ONE
+        // inbound link of the root.  Scattered (three ranks and more; MCX_REDUCE_SCATTER=1 / 0 decides otherwise): the piece cut into one slice
+        // per rank, the slices exchanged all to all — xGMI is a full mesh of point-to-point links, so all of a GPU's links carry a slice at once —,
+        // summed by their owners, the sums sent to the root over all of its links: 2 x piece / ranks per link instead of the piece.
+        const char *sc_env = getenv("MCX_REDUCE_SCATTER");
+        const bool scatter = sc_env ? atoi(sc_env) != 0 : c->size >= 3;
+        uint32_t *tmp = nullptr;
+        const uint64_t per_max = (piece + (uint64_t)c->size - 1) / (uint64_t)c->size;
+        if (scatter) {
+            hipError_t he = hipMalloc((void **)&tmp, (size_t)((uint64_t)(c->size + 1) * per_max) * sizeof(uint32_t));
+            if (he != hipSuccess) return dead_hip("mcx_profile_reduce (room for the scattered slices)", he);
+        }
+        struct Free { uint32_t *&p; ~Free() { if (p) (void)hipFree(p); } } free_tmp{tmp};
         auto reduce_words = [&](uint32_t *p, uint64_t n) -> int {
             for (uint64_t lo = 0; lo < n; lo += piece) {
                 const uint64_t cnt = std::min<uint64_t>(piece, n - lo);
-                ncclResult_t e = ncclReduce(p + lo, p + lo, (size_t)cnt, ncclUint32, ncclSum, root, c->nccl, c->stream);
-                if (e != ncclSuccess) return dead("ncclReduce", e);
+                if (!scatter) {
+                    ncclResult_t e = ncclReduce(p + lo, p + lo, (size_t)cnt, ncclUint32, ncclSum, root, c->nccl, c->stream);
+                    if (e != ncclSuccess) return dead("ncclReduce", e);
+                    continue;
+                }
+                const uint64_t per = (cnt + (uint64_t)c->size - 1) / (uint64_t)c->size;
+                auto len = [&](int j) { const uint64_t o = (uint64_t)j * per; return o < cnt ? std::min<uint64_t>(per, cnt - o) : 0ull; };
+                uint32_t *own = tmp + (uint64_t)c->size * per_max;
+                const uint64_t mine = len(c->rank);
+                ncclResult_t e = ncclGroupStart();
+                for (int j = 0; j < c->size && e == ncclSuccess; j++) {
+                    if (j == c->rank) continue;
+                    if (len(j)) e = ncclSend(p + lo + (uint64_t)j * per, (size_t)len(j), ncclUint32, j, c->nccl, c->stream);
+                    if (e == ncclSuccess && mine) e = ncclRecv(tmp + (uint64_t)j * per_max, (size_t)mine, ncclUint32, j, c->nccl, c->stream);
+                }
+                if (e == ncclSuccess) e = ncclGroupEnd(); else (void)ncclGroupEnd();
+                if (e != ncclSuccess) return dead("ncclSend / ncclRecv (slices)", e);
+                if (mine) {
+                    hipError_t he = hipMemcpyAsync(tmp + (uint64_t)c->rank * per_max, p + lo + (uint64_t)c->rank * per, (size_t)mine * 4, hipMemcpyDeviceToDevice, c->stream);
+                    if (he != hipSuccess) return dead_hip("hipMemcpyAsync", he);
+                    k_sum_slices<<<4096, 256, 0, c->stream>>>(tmp, c->size, per_max, mine, own);
+                }
+                e = ncclGroupStart();
+                if (c->rank == root) {
+                    for (int j = 0; j < c->size && e == ncclSuccess; j++) if (j != root && len(j)) e = ncclRecv(p + lo + (uint64_t)j * per, (size_t)len(j), ncclUint32, j, c->nccl, c->stream);
+                } else if (mine) e = ncclSend(own, (size_t)mine, ncclUint32, root, c->nccl, c->stream);
+                if (e == ncclSuccess) e = ncclGroupEnd(); else (void)ncclGroupEnd();
+                if (e != ncclSuccess) return dead("ncclSend / ncclRecv (sums)", e);
+                if (c->rank == root && mine) {
+                    hipError_t he = hipMemcpyAsync(p + lo + (uint64_t)root * per, own, (size_t)mine * 4, hipMemcpyDeviceToDevice, c->stream);
+                    if (he != hipSuccess) return dead_hip("hipMemcpyAsync", he);
+                }
             }
             return 0;
         };

@@ -746,35 +746,35 @@ struct Shards {
     {
         int rc = 0;
         if (n) rc = mcx_batch_begin(c, d_bases, d_off, n, 1, (int32_t)((uint32_t)avg[0] * 1.5), read_base, d_aln, d_cig, stats);
-        const size_t words = 4 + 2 * (size_t)cap_chunks;
-        msg.assign(words, 0);
-        std::vector<int32_t> est(cap_chunks);
+        // What the shards tell each other per exchange: {status, chunks, pairs re-run, -, proper pairs, their summed distance} — totals, not the
+        // chunks' sums: the walk has a closed form (mcx_batch_check), so a shard checks its own chunks on the device from the round's state plus the
+        // totals of the shards before it in input order.
+        struct Msg { uint32_t rc, n_chunks, n_redo, pad; int64_t pairs, dist; } mine, o;
         uint32_t n_redo = 0xFFFFFFFFu; // "not replayed yet"
         int64_t st[3] = {avg[0], avg[1], avg[2]};
         for (int iter = 0;; iter++) {
             uint32_t nc = 0;
-            const uint32_t *ok = nullptr, *ds = nullptr;
-            if (rc == 0 && n) rc = mcx_batch_sums(c, &nc, &ok, &ds, nullptr);
-            if (rc == 0 && nc > cap_chunks) rc = mcx_set_error(MCX_ERR_ARG, "a batch holds more chunks than the shards agreed on");
-            msg[0] = (uint32_t)rc; msg[1] = rc ? 0 : nc; msg[2] = n_redo; msg[3] = 0;
-            if (rc == 0 && nc) { memcpy(&msg[4], ok, nc * 4); memcpy(&msg[4 + cap_chunks], ds, nc * 4); }
-            if (int e = gather(msg.data(), words * 4)) return e;
+            int64_t tot[2] = {0, 0};
+            if (rc == 0 && n) rc = mcx_batch_sums(c, &nc, nullptr, nullptr, nullptr);
+            if (rc == 0 && n) rc = mcx_batch_totals(c, tot);
+            mine.rc = (uint32_t)rc; mine.n_chunks = rc ? 0 : nc; mine.n_redo = n_redo; mine.pad = 0; mine.pairs = tot[0]; mine.dist = tot[1];
+            if (int e = gather(&mine, sizeof mine)) return e;
             bool settled = iter > 0;
+            int64_t before[3] = {avg[0], avg[1], avg[2]}, all_pairs = 0, all_dist = 0, all_chunks = 0;
+            bool first = true; // no shard before this one holds a chunk
             for (int r = 0; r < x->size; r++) {
-                const uint32_t *m = (const uint32_t *)(recv.data() + (size_t)r * words * 4);
-                if (m[0]) return rc ? rc : mcx_set_error((int32_t)m[0], "shard " + std::to_string(r) + " failed");
-                if (m[1] && m[2]) settled = false;
+                memcpy(&o, recv.data() + (size_t)r * sizeof o, sizeof o);
+                if (o.rc) return rc ? rc : mcx_set_error((int32_t)o.rc, "shard " + std::to_string(r) + " failed");
+                if (o.n_chunks && o.n_redo) settled = false;
+                if (r < x->rank) { before[1] += o.pairs; before[2] += o.dist; if (o.n_chunks) first = false; }
+                all_pairs += o.pairs; all_dist += o.dist; all_chunks += o.n_chunks;
             }
-            // the trajectory over the round's batches in input order; this shard keeps the estimates of its own chunks
             st[0] = avg[0]; st[1] = avg[1]; st[2] = avg[2];
-            for (int r = 0; r < x->size; r++) {
-                const uint32_t *m = (const uint32_t *)(recv.data() + (size_t)r * words * 4);
-                mcx_avg_walk(st, m + 4, m + 4 + cap_chunks, m[1], r == x->rank ? est.data() : nullptr);
-            }
+            mcx_avg_advance(st, all_pairs, all_dist, all_chunks);
             if (settled) break;
             if (iter == 255) return mcx_set_error(MCX_ERR_CAPACITY, "avgDist replay did not converge");
             n_redo = 0;
-            if (n) rc = mcx_batch_replay(c, est.data(), &n_redo, stats);
+            if (n) rc = mcx_batch_check(c, before, first ? 1 : 0, &n_redo, stats);
         }
         avg[0] = st[0]; avg[1] = st[1]; avg[2] = st[2];
         return finish_part(c, n != 0, profile, stats, 0);

@@ -2511,6 +2511,7 @@ static int tier1_pass_end(mcx_ctx *c, const PassRes &T, uint32_t m, mcx_stats *t
 // and that is all — the caller goes on and calls pass_finish() for the pass later (*queued = its timing events).
 static int pass_finish(mcx_ctx *c, int tier, const PassRes &R, uint32_t n_sel, mcx_stats *stats, bool timing, int e);
 static int queue_batch_tail(mcx_ctx *c);
+static int tail_reserve(mcx_ctx *c);
 
 static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb, int paired, PairSel sel, AlnRec *d_recs,
                      uint32_t *d_cig, mcx_stats *stats, bool timing, bool early = false, uint32_t state_off = 0, int *queued = nullptr, bool hits_from_tier0 = false, bool no_n_reads = false)
@@ -2886,7 +2887,9 @@ __global__ void k_check_est(const PairOut *po, uint32_t n_pairs, uint32_t chunk,
 // the run's when the batch began (k = 0, or no more than 1000 proper pairs so far — the count only grows, so nothing moved it yet) or the
 // rounded mean over everything before k (ReadMapping.cpp:538-539) — prefix sums of the chunks' pairs and distances.  One block: a stretch of
 // chunks per thread, the stretches' sums scanned in LDS.
-__global__ void __launch_bounds__(1024) k_avg_walk(const uint32_t *ok, const uint32_t *ds, uint32_t nc, long long cur0, long long tp0, long long td0, int32_t *est_chunk)
+// (first: the batch is the first of its round — of a run on one stream, every batch —: its first chunk takes cur0 as it is; a batch behind
+//  others of the round starts from their totals, tp0 / td0 then hold them too)
+__global__ void __launch_bounds__(1024) k_avg_walk(const uint32_t *ok, const uint32_t *ds, uint32_t nc, long long cur0, long long tp0, long long td0, int first, int32_t *est_chunk)
 {
     __shared__ long long s_tp[1024], s_td[1024];
     const uint32_t per = (nc + 1023u) / 1024u, lo = min(nc, threadIdx.x * per), hi = min(nc, lo + per);
@@ -2902,7 +2905,7 @@ __global__ void __launch_bounds__(1024) k_avg_walk(const uint32_t *ok, const uin
     tp = s_tp[threadIdx.x]; td = s_td[threadIdx.x];
     for (uint32_t k = lo; k < hi; k++) {
         uint32_t cur = (uint32_t)cur0;
-        if (k > 0 && tp > 1000) cur = (uint32_t)(int)(1. * (double)td / (double)tp + .5);
+        if ((k > 0 || !first) && tp > 1000) cur = (uint32_t)(int)(1. * (double)td / (double)tp + .5);
         est_chunk[k] = (int32_t)(cur * 1.5);
         tp += ok[k]; td += ds[k];
     }
@@ -2913,23 +2916,25 @@ __global__ void __launch_bounds__(1024) k_avg_walk(const uint32_t *ok, const uin
 // and the check of every pair's estimate against its chunk's, everything the host wants of them in one copy to page-locked memory.
 // Used when the pass went the plain way (no halved selection, no pair left over for the large tier afterwards: run_selection);
 // the caller walks the sums itself too (a few thousand scalars) and takes the device's list only when both walks agree.
+static int tail_reserve(mcx_ctx *c)
+{
+    mcx_ctx::Tail &t = c->tail;
+    const uint32_t want = 8 + 4 + 6 + 4 * (uint32_t)((c->max_reads + kReadChunkSize / 2 - 1) / (kReadChunkSize / 2));
+    if (t.cap >= want) return 0;
+    HIP_TRY(hipMalloc((void **)&t.d, (size_t)want * 4));
+    HIP_TRY(hipHostMalloc((void **)&t.h, (size_t)want * 4));
+    t.cap = want;
+    for (auto &e : t.ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return 0;
+}
+
 static int queue_batch_tail(mcx_ctx *c)
 {
     BatchRun &br = c->run;
     mcx_ctx::Tail &t = c->tail;
     hipStream_t s = c->stream;
     const uint32_t nc = br.n_chunks, n_reads = br.rb.n_reads;
-    const uint32_t words = 8 + 4 + 6 + 4 * nc;
-    if (t.cap < words) {
-        if (t.d) (void)hipFree(t.d);
-        if (t.h) (void)hipHostFree(t.h);
-        t.d = nullptr; t.h = nullptr; t.cap = 0;
-        const uint32_t want = 8 + 4 + 6 + 4 * (uint32_t)((c->max_reads + kReadChunkSize / 2 - 1) / (kReadChunkSize / 2));
-        HIP_TRY(hipMalloc((void **)&t.d, (size_t)want * 4));
-        HIP_TRY(hipHostMalloc((void **)&t.h, (size_t)want * 4));
-        t.cap = want;
-        for (auto &e : t.ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
+    if (int rc = tail_reserve(c)) return rc;
     if (c->overlap_tiers) { // the passes of the large tier beside this one write records and outcomes of their own pairs
         HIP_TRY(hipEventRecord(t.ev[0], c->t1.stream)); HIP_TRY(hipStreamWaitEvent(s, t.ev[0], 0));
         if (c->overlap_late) { HIP_TRY(hipEventRecord(t.ev[1], c->t2.stream)); HIP_TRY(hipStreamWaitEvent(s, t.ev[1], 0)); }
@@ -2941,7 +2946,7 @@ static int queue_batch_tail(mcx_ctx *c)
     k_reduce_stats<<<256, 256, 0, s>>>(c->d_read_ext, c->d_read_blocks, n_reads, d_sum);
     k_chunk_sums<<<(nc + 255) / 256, 256, 0, s>>>(c->d_pout, br.rb.off, br.n_pairs, kReadChunkSize / 2, d_ok, d_ds, d_ls, t.d + 1);
     if (br.paired) {
-        k_avg_walk<<<1, 1024, 0, s>>>(d_ok, d_ds, nc, (long long)t.state0[0], (long long)t.state0[1], (long long)t.state0[2], d_est);
+        k_avg_walk<<<1, 1024, 0, s>>>(d_ok, d_ds, nc, (long long)t.state0[0], (long long)t.state0[1], (long long)t.state0[2], 1, d_est);
         k_check_est<<<2048, 256, 0, s>>>(c->d_pout, br.n_pairs, kReadChunkSize / 2, d_est, c->d_sel_ids, c->d_est, t.d, c->ov_cap);
     }
     HIP_TRY(hipGetLastError());
@@ -3214,6 +3219,53 @@ static int replay_listed(mcx_ctx *c, uint32_t n_redo, mcx_stats *stats)
     std::sort(ord.begin(), ord.end());
     for (uint32_t i = 0; i < n_redo; i++) { redo[i] = ord[i].first; redo_est[i] = ord[i].second; }
     return run_selection(c, br.rb, br.paired, &redo, &redo_est, 0, br.n_pairs, br.recs, br.cig, stats, false);
+}
+
+// The same feedback for a run on several shards with nothing but totals on the wire: a shard's chunks are checked against the
+// trajectory that starts from the round's state plus the totals of the shards before it — the walk has a closed form (k_avg_walk), so nobody
+// needs anybody else's chunks.
+extern "C" int mcx_batch_totals(mcx_ctx *c, int64_t totals[2])
+{
+    if (!c || !totals) return fail(MCX_ERR_ARG, "mcx_batch_totals: null argument");
+    totals[0] = totals[1] = 0;
+    if (!c->run.open) return fail(MCX_ERR_ARG, "mcx_batch_totals: no batch in flight");
+    uint32_t nc = 0;
+    const uint32_t *ok = nullptr, *ds = nullptr;
+    if (int rc = mcx_batch_sums(c, &nc, &ok, &ds, nullptr)) return rc;
+    for (uint32_t k = 0; k < nc; k++) { totals[0] += ok[k]; totals[1] += ds[k]; }
+    return 0;
+}
+
+extern "C" int mcx_batch_check(mcx_ctx *c, const int64_t state_before[3], int first_of_round, uint32_t *n_redone, mcx_stats *stats)
+{
+    if (!c || !state_before || !c->run.open) return fail(MCX_ERR_ARG, "mcx_batch_check: no batch in flight");
+    BatchRun &br = c->run;
+    if (n_redone) *n_redone = 0;
+    if (!br.paired) return 0;
+    HIP_TRY(hipSetDevice(c->idx->device));
+    int rc;
+    if (!br.sums_valid && (rc = mcx_batch_sums(c, nullptr, nullptr, nullptr, nullptr))) return rc; // (the chunk sums lie in d_read_ext / d_read_blocks behind it)
+    if ((rc = tail_reserve(c))) return rc;
+    hipStream_t s = c->stream;
+    int32_t *d_est = (int32_t *)(c->tail.d + 8);
+    HIP_TRY(hipMemsetAsync(c->tail.d, 0, 8 * sizeof(uint32_t), s));
+    k_avg_walk<<<1, 1024, 0, s>>>(c->d_read_ext, c->d_read_blocks, br.n_chunks, (long long)state_before[0], (long long)state_before[1], (long long)state_before[2], first_of_round ? 1 : 0, d_est);
+    k_check_est<<<2048, 256, 0, s>>>(c->d_pout, br.n_pairs, kReadChunkSize / 2, d_est, c->d_sel_ids, c->d_est, c->tail.d, c->ov_cap);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->tail.h, c->tail.d, 8 * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t n_redo = c->tail.h[0];
+    if (n_redo == 0) return 0;
+    if ((rc = replay_listed(c, n_redo, stats))) return rc;
+    if (n_redone) *n_redone = n_redo;
+    return 0;
+}
+
+// the state after a round whose batches held `pairs` proper pairs at the summed distance `dist` (mcx_avg_walk's end state in closed form)
+extern "C" void mcx_avg_advance(int64_t st[3], int64_t pairs, int64_t dist, int64_t n_chunks)
+{
+    st[1] += pairs; st[2] += dist;
+    if (n_chunks > 0 && st[1] > 1000) st[0] = (int64_t)(uint32_t)(int)(1. * (double)st[2] / (double)st[1] + .5);
 }
 
 // what both ways of closing a batch share: the long-CIGAR pool, statistics
@@ -3775,6 +3827,7 @@ static int archive_append(mcx_ctx *c, mcx_ctx::Archive &a, const SparseRec *d_sr
             a.d = grown; a.cap = want;
         } else {
             (void)hipGetLastError();
+            if (c->kn.timing) fprintf(stderr, "[mcx profile] no room in HBM for a larger record archive (%llu records wanted): what it holds goes to the host now, batch by batch from here on\n", (unsigned long long)want);
             int rc = archive_flush(c, a); // no room for a larger archive: what it holds goes to the host now
             if (rc) return rc;
             if (n > a.cap) {

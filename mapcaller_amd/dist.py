@@ -43,7 +43,7 @@ def finalize_planes(planes: torch.Tensor, G: int, max_dup: int = 5) -> torch.Ten
     return planes
 
 
-def reduce_profile(planes: torch.Tensor, sparse, G: int, root: int = 0, shared_read_count: bool = True, mapper=None):
+def reduce_profile(planes: torch.Tensor, sparse, G: int, root: int = 0, shared_read_count: bool = True, mapper=None, via: str = "auto"):
     """Sums the counter planes of all ranks (api.planes_alloc's layout, csrc/mcx_planes.h: multi_hit as u32, the other nine as u16)
     onto ``root`` (RCCL reduce on GPU tensors; only the rank that calls the variants needs the sum), in pieces of 2^28 words
     (1 GiB: link speed, and no collective's count outgrows 32 bits), and gathers the sparse records of every rank in rank order.
@@ -58,7 +58,11 @@ def reduce_profile(planes: torch.Tensor, sparse, G: int, root: int = 0, shared_r
     Mapper.profile_sparse_raw(); the same kind comes back.  Call after Mapper.profile_settle() and before finalisation — or pass
     the ``mapper`` that accumulated the planes and it is settled here first (idempotent): planes that still hold differences
     would be summed into plausible-looking garbage without any error.  With the gloo backend (CPU tests, several ranks on one
-    GPU) device tensors are staged through the host.  ``reduce_profile.last_bytes``: what this rank put on the wire for the planes."""
+    GPU) device tensors are staged through the host.  ``reduce_profile.last_bytes``: what this rank put on the wire for the planes.
+    ``via``: "reduce" — one reduce onto the root per piece (a ring or tree of RCCL's choosing: every byte of the planes crosses the
+    root's ONE inbound link of that ring) — or "scatter": every piece cut into one slice per rank, the slices exchanged all to all
+    (xGMI is a full mesh of point-to-point links: all of a GPU's links carry a slice at once), summed by their owners and gathered
+    onto the root over all of its links — 2 x planes / world per link instead of planes; "auto": "scatter" from three ranks on."""
     from . import api
     reduce_profile.last_bytes = 0
     if mapper is not None:
@@ -75,9 +79,27 @@ def reduce_profile(planes: torch.Tensor, sparse, G: int, root: int = 0, shared_r
     multi, half = api.planes_parts(planes, G)
     words = planes[st:].reshape(9, st // 2)  # the 16-bit planes as the int32 words they lie in
 
+    scatter = via == "scatter" or (via == "auto" and world > 2)
+    rank = dist.get_rank()
+
     def reduce_words(t):
         for lo in range(0, t.numel(), step):
             piece = t[lo:lo + step]
+            if scatter:
+                # slice j of the piece goes to rank j; every rank sums the slices it receives and the owners' sums are gathered onto the root
+                n = piece.numel()
+                per = (n + world - 1) // world
+                send = torch.zeros(world * per, dtype=piece.dtype, device="cpu" if staged else piece.device)
+                send[:n] = piece.cpu() if staged else piece
+                recv = torch.empty_like(send)
+                dist.all_to_all_single(recv, send)
+                mine = recv.view(world, per).sum(0, dtype=torch.int32)
+                parts = [torch.empty_like(mine) for _ in range(world)] if is_root else None
+                dist.gather(mine, parts, dst=root)
+                if is_root:
+                    piece.copy_(torch.cat(parts)[:n])
+                reduce_profile.last_bytes += (world - 1) * per * 4 + (0 if is_root else per * 4)
+                continue
             if staged:
                 h = piece.cpu()
                 dist.reduce(h, dst=root, op=dist.ReduceOp.SUM)

@@ -124,10 +124,13 @@ def _worker3(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from mapcaller_amd import api
     G = 777
-    got, _ = mdist.reduce_profile(api.planes_from_rows(_rows3(rank, world, G)), [], G, root=1)  # a root that is not rank 0
+    got, _ = mdist.reduce_profile(api.planes_from_rows(_rows3(rank, world, G)), [], G, root=1, via="reduce")  # a root that is not rank 0
     wire = mdist.reduce_profile.last_bytes
+    # the same sum with the pieces scattered over the ranks, summed by their owners and gathered onto the root (what three ranks and more take)
+    got2, _ = mdist.reduce_profile(api.planes_from_rows(_rows3(rank, world, G)), [], G, root=1)
+    wire2 = mdist.reduce_profile.last_bytes
     if rank == 1:
-        torch.save({"got": got, "wire": wire}, out)
+        torch.save({"got": got, "wire": wire, "scattered": got2, "wire_scattered": wire2}, out)
     dist.destroy_process_group()
 
 
@@ -142,3 +145,6 @@ def test_reduce_world3_root1(tmp_path):
     assert r["wire"] == 20 * api.planes_stride(G)
     got = api.planes_view(mdist.finalize_planes(r["got"].clone(), G, max_dup=15), G)
     assert torch.equal(got, _expected([_rows3(q, 3, G) for q in range(3)], 1, True, 15))
+    # scattered: the root holds the same planes; it sent two thirds of every piece (and received as much, then the owners' sums)
+    assert torch.equal(r["scattered"], r["got"])
+    assert 0 < r["wire_scattered"] <= 20 * api.planes_stride(G) * 2 // 3 + 64

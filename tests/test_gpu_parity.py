@@ -1177,6 +1177,14 @@ def test_profile_reduce_over_rccl_one_rank(api, golden, monkeypatch):
     assert torch.equal(got[0:4], rows[0:4].clamp(max=4095))
     assert torch.equal(got[4], rows[4]) and torch.equal(got[5], rows[5] & 0xFFFF)
     assert torch.equal(got[6:10], rows[6:10])
+    # the same through the scattered form of the reduce (what three ranks and more take: slices exchanged all to all, summed by their owners,
+    # gathered onto the root — with one rank: its own slice through the same kernels and groups)
+    monkeypatch.setenv("MCX_REDUCE_SCATTER", "1")
+    planes = api.planes_from_rows(rows)
+    assert L.mcx_profile_reduce(comm, planes.data_ptr(), G, 0, ctypes.byref(secs)) == 0, api.lib().mcx_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(api.planes_view(planes, G), got)
+    monkeypatch.delenv("MCX_REDUCE_SCATTER")
     # strand counters that could carry into the neighbouring half on several ranks (here: times one rank still fits, so force the wide path
     # with a value at the top of the range on a communicator of one) — and the wide path itself: one counter per word, narrowed again
     rows[6] = 0xFFFF
