@@ -179,7 +179,13 @@ def roofline(args, d, reads_per_s):
     seed_bytes = 64.0 * 1.107 * d["fm_ext_steps"] + float(d["reads"]) * args.rlen
     seed_ms = d["ms_seed"] / steps
     step_ms = sum(d[k] for k in d if k.startswith("ms_") and k not in ("ms_total",)) / steps
-    if d.get("ms_dp", 0) / steps > live[longest]:
+    dp_ms = d.get("ms_dp", 0) / steps
+    launch_bound = step_ms < 4.0 and max(live[longest], dp_ms) < 0.4 * step_ms  # a string of short launches: no kernel's (or stage's) roofline describes the step
+    if launch_bound:
+        r = {"bound": "launch", "kernel": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+             "basis": "the step is a string of launches of a few tens to hundreds of microseconds each on a chip that this batch does not fill: it is bound by launch "
+                      "and tail latency, not by any kernel's traffic or arithmetic (see launch_bound)"}
+    elif dp_ms > live[longest]:
         r = dp_roofline(args, d, prof)
     else:
         traffic = kern.get(longest, {}).get("traffic")
@@ -229,8 +235,8 @@ def roofline(args, d, reads_per_s):
                                                "the kernel reaches the same seeds through a K-mer jump table and direct genome comparison"},
               "path": path_roofline(d, args, reads_per_s)})
     # a step of many short launches: no kernel's roofline describes it
-    if step_ms < 4.0 and live[longest] < 0.4 * step_ms and not (d.get("ms_dp", 0) / steps > live[longest]):
-        r["launch_bound"] = {"ms_per_step": round(step_ms, 3), "longest_kernel": longest, "longest_kernel_ms": round(live[longest], 3),
+    if launch_bound:
+        r["launch_bound"] = {"ms_per_step": round(step_ms, 3), "longest_kernel": longest, "longest_kernel_ms": round(live[longest], 3), "dp_stage_ms": round(dp_ms, 3),
                              "launches_per_step": round(launches, 1) if launches else None,
                              "mean_us_per_launch": round(1e3 * step_ms / launches, 1) if launches else None,
                              "note": "the step is a string of launches of a few tens to hundreds of microseconds each on a chip that this batch does not fill: "

@@ -2897,12 +2897,13 @@ __global__ void __launch_bounds__(1024) k_avg_walk(const uint32_t *ok, const uin
     for (uint32_t k = lo; k < hi; k++) { tp += ok[k]; td += ds[k]; }
     s_tp[threadIdx.x] = tp; s_td[threadIdx.x] = td;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        long long a = tp0, b = td0;
-        for (int i = 0; i < 1024; i++) { const long long x = s_tp[i], y = s_td[i]; s_tp[i] = a; s_td[i] = b; a += x; b += y; }
+    for (int o = 1; o < 1024; o <<= 1) { // inclusive scan over the stretches' sums
+        const long long a = (int)threadIdx.x >= o ? s_tp[threadIdx.x - o] : 0, b = (int)threadIdx.x >= o ? s_td[threadIdx.x - o] : 0;
+        __syncthreads();
+        s_tp[threadIdx.x] += a; s_td[threadIdx.x] += b;
+        __syncthreads();
     }
-    __syncthreads();
-    tp = s_tp[threadIdx.x]; td = s_td[threadIdx.x];
+    tp = tp0 + s_tp[threadIdx.x] - tp; td = td0 + s_td[threadIdx.x] - td; // what lies before this thread's stretch
     for (uint32_t k = lo; k < hi; k++) {
         uint32_t cur = (uint32_t)cur0;
         if ((k > 0 || !first) && tp > 1000) cur = (uint32_t)(int)(1. * (double)td / (double)tp + .5);

@@ -1235,7 +1235,8 @@ def test_bench_launches_its_ranks(tmp_path, n_ranks):
     # readCount plane of independent runs is summed too), variants called there
     v = o["vcf_reduce"]
     assert "error" not in v, v
-    assert abs(v["reduce_gb"] - 22 * 20e6 / 1e9) < 0.02 and v["call_variants"]["records"] > 0 and v["covered_positions"] > 1_000_000 * (1 if n_ranks == 2 else 3)
+    # (two ranks: one reduce per piece, 22 bytes per position; eight: the pieces scattered, the root sends seven eighths of them)
+    assert abs(v["reduce_gb"] - 22 * 20e6 / 1e9 * (1 if n_ranks == 2 else (n_ranks - 1) / n_ranks)) < 0.02 and v["call_variants"]["records"] > 0 and v["covered_positions"] > 1_000_000 * (1 if n_ranks == 2 else 3)
 
 
 def test_degenerate_reads_equal_oracle(api, golden, tmp_path, record_property):
