@@ -110,7 +110,7 @@ static int build_rank(mcx_index *ix);
 static int build_ktab(mcx_index *ix)
 {
     int K = ktab_k_for(ix->view.seq_len);
-    if (const char *e = getenv("MCX_KTAB_K")) { const int k = atoi(e); if (k >= 4 && k <= 15) K = k; }
+    if (const char *e = getenv("MCX_KTAB_K")) { const int k = atoi(e); if (k >= 4 && k <= 16) K = k; } // (16: 69 GB — one pair step fewer per search; no room for it beside the -vcf planes)
     const size_t bytes = (size_t)16 << (2 * K);
     hipError_t e = hipMalloc(&ix->d_ktab, bytes);
     if (e != hipSuccess) { g_err = std::string("hipMalloc(ktab): ") + hipGetErrorString(e); return MCX_ERR_DEVICE; }
@@ -696,7 +696,10 @@ __global__ void __launch_bounds__(256) k_sa(Ctx cx, SeedOut so, int paired, uint
 struct RescueList { uint32_t *ids; uint32_t *n; uint32_t cap; };
 // pairs that ran over the tier-0 capacities while clustering are listed right there, with their estimate: the large tier maps
 // them on a stream of its own while the rest of the pass is still under way (ids null: no such list)
-struct EarlyList { uint32_t *ids; int32_t *est; uint32_t *n; uint32_t cap; uint32_t *n_hits; };
+// (done / host / any_n: the launch's last workgroup writes the list's length — and whether the batch holds a read with an N — into page-locked host
+//  memory, so that the host, which drives the large tier for the listed pairs, needs no copy of its own behind the kernel: such a copy is a blit
+//  kernel that waits for a free CU on a chip the pass is filling — 0.3 to 0.9 ms before the large tier's first kernel could start)
+struct EarlyList { uint32_t *ids; int32_t *est; uint32_t *n; uint32_t cap; uint32_t *n_hits; uint32_t *done; volatile uint32_t *host; const uint32_t *any_n; };
 
 // The per-pair kernels give every lane one pair, and a wavefront is as slow as its heaviest lane: next to a pair from a repeat
 // (dozens of hits to sort and cluster, a dozen candidates to build and score) sixty-three ordinary pairs wait.  So the pairs
@@ -922,10 +925,11 @@ __global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel s
         uint32_t at = 0;
         for (int k = 0; k < kWorkClasses; k++) { if (k == cls_lo) first = at; at += order_cnt[k * kCntPad]; if (k == cls_hi) n_listed = at; }
     }
-    if (first + blockIdx.x * blockDim.x >= n_listed) return; // (uniform over the block)
-    stage_ends(cx.ix, ends);
+    const bool idle = first + blockIdx.x * blockDim.x >= n_listed; // (uniform over the block: nothing listed for it)
+    if (idle && !el.host) return;
+    if (!idle) stage_ends(cx.ix, ends);
     const uint32_t slot = first + blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = slot < n_listed;
+    const bool in = !idle && slot < n_listed;
     const uint32_t local = in ? (order ? order[slot] : slot) : 0u;
     uint32_t need = 0, over = 0;
     if (in) {
@@ -948,6 +952,17 @@ __global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel s
     if (el.ids) {
         const uint32_t ea = wave_reserve(el.n, over);
         if (over && ea < el.cap) { el.ids[ea] = sel_pair(sel, local); el.est[ea] = sel.est[local]; }
+    }
+    if (el.host) { // the last workgroup to get here tells the host how many pairs the large tier has to map
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(el.done, 1u) == gridDim.x - 1) {
+                __threadfence();
+                el.host[0] = atomicAdd(el.n, 0u); el.host[1] = *el.any_n;
+                __threadfence_system();
+            }
+        }
     }
 }
 
@@ -2009,7 +2024,7 @@ constexpr uint32_t kPoutSel = 1u << 16; // pair outcomes gathered per copy (run_
 enum { CNT_TASKS = 0, CNT_RESCUE = 1 * kCntPad, CNT_JOB0 = 2 * kCntPad, CNT_JOB1 = 3 * kCntPad, CNT_JOB2 = 4 * kCntPad, CNT_JOB3 = 5 * kCntPad,
        CNT_JOB4 = 6 * kCntPad, CNT_JOB5 = 7 * kCntPad, CNT_OV = 8 * kCntPad, CNT_LF = 9 * kCntPad, CNT_CELLS = 10 * kCntPad, CNT_UNSUP = 11 * kCntPad,
        CNT_QUEUE = 12 * kCntPad, CNT_EARLY = 13 * kCntPad, CNT_LATE = 14 * kCntPad, CNT_RTASK = 15 * kCntPad, CNT_RPLAN = 16 * kCntPad, CNT_RESCUE_N = 17 * kCntPad, CNT_RSEED = 18 * kCntPad,
-       CNT_SIMPLE = 19 * kCntPad, CNT_EARLY_HITS = 20 * kCntPad, CNT_SIMPLE_LATER = 21 * kCntPad, CNT_SIMPLE_JOBS = 22 * kCntPad, CNT_N = 23 * kCntPad,
+       CNT_SIMPLE = 19 * kCntPad, CNT_EARLY_HITS = 20 * kCntPad, CNT_SIMPLE_LATER = 21 * kCntPad, CNT_SIMPLE_JOBS = 22 * kCntPad, CNT_CLUSTER_DONE = 23 * kCntPad, CNT_N = 24 * kCntPad,
        // behind the counters proper, cleared with them at the start of a pass (a memset in the middle of a pass was seen to sit 1.4 ms in its queue):
        CNT_ORDER = CNT_N, CNT_DP_SORT = CNT_ORDER + 16 * kCntPad, CNT_ALL = CNT_DP_SORT + 4 * 256 };
 constexpr uint32_t kLateRoom = 2048; // pairs of a pass that may run over after clustering and still go through the large tier beside it
@@ -2111,6 +2126,7 @@ struct mcx_ctx {
     BatchRun run;
     PassRes t1;               // the large tier's own set (the members above are tier 0's); allocated when every suffix-array entry is resident
     bool overlap_tiers = false;
+    volatile uint32_t *h_early = nullptr; uint32_t *d_early = nullptr; // page-locked words the clustering kernel's last workgroup writes (EarlyList::host): the host's view and the device's
     PassRes t2;               // a third set: the large tier's pass over the pairs that ran over after clustering (k_build's list)
     hipEvent_t ev_built = nullptr, ev_late_done = nullptr;
     bool overlap_late = false;
@@ -2118,7 +2134,7 @@ struct mcx_ctx {
     // mcx_stream_*: three batches in flight (copy in | kernels | copy out), each in a slot of its own
     struct Slot {
         uint8_t *d_bases = nullptr; uint32_t *d_off = nullptr; AlnRec *d_recs = nullptr; uint32_t *d_cig = nullptr;
-        uint32_t *d_codes = nullptr, *d_len = nullptr; uint64_t *d_odd = nullptr; uint32_t odd_cap = 0; // mcx_stream_submit_packed: what arrives; restored to d_bases / d_off
+        uint32_t *d_codes = nullptr, *d_len = nullptr, *d_err = nullptr; uint64_t *d_odd = nullptr; uint32_t odd_cap = 0; // mcx_stream_submit_packed: what arrives; restored to d_bases / d_off
         uint32_t n_reads = 0; int state = 0; uint64_t seq = 0; // 0 free, 1 copy in started, 2 handed to the kernels, 3 copy out started
         hipEvent_t in_ready = nullptr, mapped = nullptr, out_done = nullptr;
     } slot[3];
@@ -2348,6 +2364,11 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
         c->t1.d_kscratch = c->d_kscratch + (size_t)kRescueBlocks * kRescueScratchWords;
         HIP_TRY(hipEventCreate(&c->ev_clustered));
         c->overlap_tiers = true;
+        {
+            void *h = nullptr, *d = nullptr;
+            if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) { c->h_early = (volatile uint32_t *)h; c->d_early = (uint32_t *)d; }
+            else { (void)hipGetLastError(); if (h) (void)hipHostFree(h); } // (without it: the copies behind the kernel, as before)
+        }
         // and a small third set for the pairs that run over after clustering: they go through the large tier while the pass's
         // DP and finish stages run, in the last kLateRoom records of the tier, instead of in a pass of their own after it
         if (c->tier[1].max_pairs >= 4 * kLateRoom && !c->kn.no_late_overlap) {
@@ -2378,10 +2399,11 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     if (c->arch_ev.d) (void)hipFree(c->arch_ev.d);
     passres_free(c->t1); passres_free(c->t2);
     for (hipEvent_t e : {c->ev_clustered, c->ev_built, c->ev_late_done, c->tail.ev[0], c->tail.ev[1]}) if (e) (void)hipEventDestroy(e);
+    if (c->h_early) (void)hipHostFree((void *)c->h_early);
     if (c->tail.d) (void)hipFree(c->tail.d);
     if (c->tail.h) (void)hipHostFree(c->tail.h);
     for (auto &sl : c->slot) {
-        void *q[] = {sl.d_bases, sl.d_off, sl.d_recs, sl.d_cig, sl.d_codes, sl.d_len, sl.d_odd};
+        void *q[] = {sl.d_bases, sl.d_off, sl.d_recs, sl.d_cig, sl.d_codes, sl.d_len, sl.d_odd, sl.d_err};
         for (void *x : q) if (x) (void)hipFree(x);
         for (hipEvent_t e : {sl.in_ready, sl.mapped, sl.out_done}) if (e) (void)hipEventDestroy(e);
     }
@@ -2531,10 +2553,13 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     so.src_state = nullptr; so.src_lay = c->tier[0].lay; so.src_caps = c->tier[0].caps;
     if (hits_from_tier0 && tier == 1 && cx.ix.sa_full && !kn.late_reseed) so.src_state = c->tier[0].state;
     RescueList rl; rl.ids = R.d_rescue; rl.n = R.d_cnt + CNT_RESCUE; rl.cap = R.rescue_cap;
-    EarlyList el; el.ids = nullptr; el.est = nullptr; el.n = R.d_cnt + CNT_EARLY; el.cap = 0; el.n_hits = R.d_cnt + CNT_EARLY_HITS;
-    if (early) { el.ids = c->t1.d_sel_ids; el.est = c->t1.d_est; el.cap = (uint32_t)c->max_reads; }
+    EarlyList el; el.ids = nullptr; el.est = nullptr; el.n = R.d_cnt + CNT_EARLY; el.cap = 0; el.n_hits = R.d_cnt + CNT_EARLY_HITS; el.done = nullptr; el.host = nullptr; el.any_n = nullptr;
+    if (early) {
+        el.ids = c->t1.d_sel_ids; el.est = c->t1.d_est; el.cap = (uint32_t)c->max_reads;
+        if (c->h_early) { el.done = R.d_cnt + CNT_CLUSTER_DONE; el.host = c->d_early; el.any_n = c->d_batch_flags + 3; }
+    }
     const bool late = early && c->overlap_late;
-    EarlyList ll; ll.ids = nullptr; ll.est = nullptr; ll.n = R.d_cnt + CNT_LATE; ll.cap = 0; ll.n_hits = R.d_cnt + CNT_EARLY_HITS;
+    EarlyList ll; ll.ids = nullptr; ll.est = nullptr; ll.n = R.d_cnt + CNT_LATE; ll.cap = 0; ll.n_hits = R.d_cnt + CNT_EARLY_HITS; ll.done = nullptr; ll.host = nullptr; ll.any_n = nullptr;
     if (late) { ll.ids = c->t2.d_sel_ids; ll.est = c->t2.d_est; ll.cap = kLateRoom; }
     JobSinks sinks;
     for (int k = 0; k < kDpClasses; k++) { sinks.s[k].jobs = R.d_jobs[k]; sinks.s[k].count = R.d_cnt + CNT_JOB0 + k * kCntPad; sinks.s[k].cap = R.job_cap[k]; }
@@ -2673,11 +2698,16 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         const PassRes &T = c->t1;
         uint32_t n_early = 0;
         HIP_TRY(hipStreamWaitEvent(T.stream, c->ev_clustered, 0));
-        HIP_TRY(hipMemcpyAsync(T.h_cnt, R.d_cnt + CNT_EARLY, sizeof(uint32_t), hipMemcpyDeviceToHost, T.stream));
-        HIP_TRY(hipMemcpyAsync(T.h_cnt + 1, c->d_batch_flags + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, T.stream)); // (k_pack_reads is long done)
-        HIP_TRY(hipStreamSynchronize(T.stream));
-        n_early = T.h_cnt[0];
-        const bool no_n = T.h_cnt[1] == 0;
+        bool no_n;
+        if (el.host) { // k_cluster's last workgroup wrote both numbers into page-locked memory
+            HIP_TRY(hipEventSynchronize(c->ev_clustered));
+            n_early = c->h_early[0]; no_n = c->h_early[1] == 0;
+        } else {
+            HIP_TRY(hipMemcpyAsync(T.h_cnt, R.d_cnt + CNT_EARLY, sizeof(uint32_t), hipMemcpyDeviceToHost, T.stream));
+            HIP_TRY(hipMemcpyAsync(T.h_cnt + 1, c->d_batch_flags + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, T.stream)); // (k_pack_reads is long done)
+            HIP_TRY(hipStreamSynchronize(T.stream));
+            n_early = T.h_cnt[0]; no_n = T.h_cnt[1] == 0;
+        }
         if (n_early > el.cap) { (void)hipStreamSynchronize(s); return fail(MCX_ERR_CAPACITY, "overflow list overflow"); }
         if (stats) stats->tier1_pairs += n_early;
         const bool t1_timing = kn.timing;
@@ -3501,12 +3531,18 @@ static int stream_slot(mcx_ctx *c, mcx_ctx::Slot **out)
 }
 
 // 2-bit rows -> the ASCII bytes of the batch: one thread per sixteen bases (the letters ACGT; k_apply_odd puts back every other byte)
-__global__ void __launch_bounds__(256) k_unpack_reads(const uint32_t *codes, uint32_t row_words, const uint32_t *off, uint32_t n_reads, uint8_t *bases)
+// (the lengths are the caller's: one beyond its row or the context's longest read — lim —, or a sum beyond the slot — max_bases —, is flagged in
+//  *err and nothing is written for it; mcx_stream_next refuses the batch.  Round 4 walked the lengths on the host before the copy: a
+//  millisecond per 8 M reads with the GPU idle.)
+__global__ void __launch_bounds__(256) k_unpack_reads(const uint32_t *codes, uint32_t row_words, const uint32_t *off, uint32_t n_reads, uint8_t *bases,
+                                                      uint64_t max_bases, uint32_t lim, uint32_t *err)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t r = (uint32_t)(t / row_words), k = (uint32_t)(t % row_words);
     if (r >= n_reads) return;
     const uint32_t o = off[r], rlen = off[r + 1] - o;
+    if (rlen > lim || off[r + 1] < o) { if (k == 0) atomicOr(err, 1u); return; }
+    if ((uint64_t)o + rlen > max_bases) { if (k == 0) atomicOr(err, 2u); return; }
     if (16 * k >= rlen) return;
     const uint32_t w = codes[(uint64_t)r * row_words + k];
     uint32_t q[4]; // sixteen letters, four to a word, the first in the low byte
@@ -3528,13 +3564,13 @@ __global__ void __launch_bounds__(256) k_unpack_reads(const uint32_t *codes, uin
     else for (uint32_t i = 0; i < nb; i++) dst[i] = (uint8_t)(q[i >> 2] >> (8 * (i & 3)));
 }
 
-__global__ void k_apply_odd(const uint64_t *odd, uint32_t n_odd, const uint32_t *off, uint32_t n_reads, uint8_t *bases)
+__global__ void k_apply_odd(const uint64_t *odd, uint32_t n_odd, const uint32_t *off, uint32_t n_reads, uint8_t *bases, uint64_t max_bases)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_odd) return;
     const uint64_t e = odd[i];
     const uint32_t r = (uint32_t)(e >> 32), pos = (uint32_t)(e >> 8) & 0xFFFFFFu;
-    if (r < n_reads && pos < off[r + 1] - off[r]) bases[off[r] + pos] = (uint8_t)e;
+    if (r < n_reads && off[r + 1] >= off[r] && pos < off[r + 1] - off[r] && (uint64_t)off[r] + pos < max_bases) bases[off[r] + pos] = (uint8_t)e;
 }
 
 extern "C" int mcx_stream_submit_packed(mcx_ctx *c, const uint32_t *codes, uint32_t row_words, const uint32_t *len, uint32_t n_reads, const uint64_t *odd,
@@ -3544,15 +3580,6 @@ extern "C" int mcx_stream_submit_packed(mcx_ctx *c, const uint32_t *codes, uint3
     if (n_reads > c->max_reads) return fail(MCX_ERR_ARG, "batch larger than max_batch_reads");
     const uint32_t row_max = (uint32_t)(c->rlen_max + 15) / 16;
     if (row_words > row_max) return fail(MCX_ERR_UNSUPPORTED, "mcx_stream_submit_packed: rows are longer than max_read_len");
-    { // the lengths are the caller's: k_unpack_reads / k_apply_odd write off[r] + len[r] bytes, so a length beyond its row (or the
-      // context's longest read) or a sum beyond the slot would write past the slot's bases (one pass over host memory: ~1 ms per 8 M reads)
-        const uint32_t lim = std::min<uint32_t>(row_words * 16u, (uint32_t)c->rlen_max);
-        uint32_t longest = 0;
-        uint64_t sum = 0;
-        for (uint32_t r = 0; r < n_reads; r++) { longest = std::max(longest, len[r]); sum += len[r]; }
-        if (longest > lim) return fail(MCX_ERR_ARG, "mcx_stream_submit_packed: a read is longer than its row / max_read_len");
-        if (sum > c->max_bases) return fail(MCX_ERR_ARG, "batch holds more bases than max_batch_reads * max_read_len");
-    }
     HIP_TRY(hipSetDevice(c->idx->device));
     mcx_ctx::Slot *sl = nullptr;
     int rc = stream_slot(c, &sl);
@@ -3561,6 +3588,7 @@ extern "C" int mcx_stream_submit_packed(mcx_ctx *c, const uint32_t *codes, uint3
     if (!sl->d_codes) {
         if ((rc = dmalloc(&sl->d_codes, c->max_reads * (uint64_t)row_max))) return rc;
         if ((rc = dmalloc(&sl->d_len, c->max_reads + 1))) return rc;
+        if ((rc = dmalloc(&sl->d_err, 1))) return rc;
     }
     if (n_odd > sl->odd_cap) {
         if (sl->d_odd) { HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(sl->d_odd); sl->d_odd = nullptr; }
@@ -3580,8 +3608,10 @@ extern "C" int mcx_stream_submit_packed(mcx_ctx *c, const uint32_t *codes, uint3
     size_t tmp = c->scan_tmp_bytes;
     HIP_TRY(hipcub::DeviceScan::InclusiveSum(c->d_scan_tmp, tmp, sl->d_len, sl->d_off + 1, (int)n_reads, s));
     const uint64_t threads = (uint64_t)n_reads * row_words;
-    k_unpack_reads<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(sl->d_codes, row_words, sl->d_off, n_reads, sl->d_bases);
-    if (n_odd) k_apply_odd<<<(n_odd + 255) / 256, 256, 0, s>>>(sl->d_odd, n_odd, sl->d_off, n_reads, sl->d_bases);
+    HIP_TRY(hipMemsetAsync(sl->d_err, 0, 4, s));
+    k_unpack_reads<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(sl->d_codes, row_words, sl->d_off, n_reads, sl->d_bases, c->max_bases,
+                                                                   std::min<uint32_t>(row_words * 16u, (uint32_t)c->rlen_max), sl->d_err);
+    if (n_odd) k_apply_odd<<<(n_odd + 255) / 256, 256, 0, s>>>(sl->d_odd, n_odd, sl->d_off, n_reads, sl->d_bases, c->max_bases);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sl->in_ready, s));
     sl->n_reads = n_reads; sl->state = 1; sl->seq = ++c->stream_seq;
@@ -3598,6 +3628,7 @@ extern "C" int mcx_stream_submit(mcx_ctx *c, const uint8_t *bases, const uint32_
     mcx_ctx::Slot *sl = nullptr;
     int rc = stream_slot(c, &sl);
     if (rc) return rc;
+    if (sl->d_err) HIP_TRY(hipMemsetAsync(sl->d_err, 0, 4, c->h2d_stream)); // (the slot once took 2-bit rows: nothing of that batch's verdict is this one's)
     if ((rc = bulk_copy(c, sl->d_bases, bases, off[n_reads], hipMemcpyHostToDevice, c->h2d_stream))) return rc;
     if ((rc = bulk_copy(c, sl->d_off, off, (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice, c->h2d_stream))) return rc;
     HIP_TRY(hipEventRecord(sl->in_ready, c->h2d_stream));
@@ -3615,6 +3646,14 @@ extern "C" int mcx_stream_next(mcx_ctx *c, const uint8_t **d_bases, const uint32
     mcx_ctx::Slot *sl = oldest_slot(c, 1);
     if (!sl) return fail(MCX_ERR_ARG, "mcx_stream_next: nothing submitted");
     HIP_TRY(hipStreamWaitEvent(c->stream, sl->in_ready, 0));
+    if (sl->d_err) { // a batch that came as 2-bit rows: what k_unpack_reads thought of the caller's lengths
+        HIP_TRY(hipMemcpyAsync(c->h_cnt, sl->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->h_cnt[0]) {
+            sl->state = 0;
+            return fail(MCX_ERR_ARG, (c->h_cnt[0] & 1u) ? "mcx_stream_submit_packed: a read is longer than its row / max_read_len" : "batch holds more bases than max_batch_reads * max_read_len");
+        }
+    }
     sl->state = 2;
     *d_bases = sl->d_bases; *d_off = sl->d_off; *d_aln = (mcx_aln *)sl->d_recs; *d_cigar = sl->d_cig;
     if (n_reads) *n_reads = sl->n_reads;

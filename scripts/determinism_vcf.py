@@ -23,7 +23,11 @@ def main():
     del codes
     sl = min(n, args.vcf_slice_reads)
     off = (torch.arange(sl + 1, device=dev, dtype=torch.int64) * args.rlen).to(torch.uint32)
+    import os
+    if sl * 3072 > args.vcf_tier1_gb << 30:  # (as bench.py's -vcf leg: the large tier sized for this workload, so that everything fits beside the planes)
+        os.environ["MCX_TIER1_GB"] = str(args.vcf_tier1_gb)
     mapper = api.Mapper(index, alg=args.alg, max_read_len=max(256, args.rlen), max_batch_reads=sl)
+    os.environ.pop("MCX_TIER1_GB", None)
     planes = api.planes_alloc(G, dev)
     d_aln = torch.zeros(sl * 64, dtype=torch.uint8, device=dev)
     d_cig = torch.zeros(api.cigar_pool_words(sl), dtype=torch.int32, device=dev)

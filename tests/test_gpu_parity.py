@@ -213,6 +213,17 @@ def test_packed_host_boundary_gives_the_same_records(api, golden, tmp_path):
             assert np.array_equal(aln[f], w_aln[f]), (b, f)
         for r in range(2 * n_pairs):
             assert np.array_equal(pool[aln["cigar_off"][r]:aln["cigar_off"][r] + aln["n_cigar"][r]], w_cig[r]), (b, r)
+    # a length the caller got wrong — longer than the read's row — is refused before anything is mapped (the lengths are checked on the
+    # device, where the rows are turned back into bytes; nothing is written for such a read), and the context goes on with the next batch
+    tw, row_words, tl, to, n_odd = packed[0]
+    bad = tl.clone(); bad[7] = row_words * 16 + 1
+    bad = bad.pin_memory()
+    assert L.mcx_stream_submit_packed(mp._h, tw.data_ptr(), row_words, bad.data_ptr(), 2 * n_pairs, to.data_ptr(), n_odd) == 0, L.mcx_last_error()
+    assert L.mcx_stream_map(mp._h, 1, mp.avg, outs[0][0].data_ptr(), outs[0][1].data_ptr(), C.byref(mp.stats)) != 0
+    assert b"longer than its row" in L.mcx_last_error()
+    assert L.mcx_stream_submit_packed(mp._h, tw.data_ptr(), row_words, tl.data_ptr(), 2 * n_pairs, to.data_ptr(), n_odd) == 0, L.mcx_last_error()
+    assert L.mcx_stream_map(mp._h, 1, mp.avg, outs[0][0].data_ptr(), outs[0][1].data_ptr(), C.byref(mp.stats)) == 0, L.mcx_last_error()
+    assert L.mcx_stream_collect(mp._h, None, None) == 0, L.mcx_last_error()
     mp.close(); ix.close()
 
 
@@ -602,26 +613,31 @@ def _checker_sam(prefix, f1, f2, alg, out, tmp_path):
         _oracle_sam(prefix, f1, f2, alg, out)
 
 
-def test_full_size_genome_prefix_equals_reference(api, bench_genome, tmp_path):
-    """BASELINE config 3 at full size: the first 60 k pairs of a bench batch (150 bp, -alg ksw2) go through the product's file path and
-    through the CPU checker.  Reads from repeats bring hundreds of seed hits, mate rescue and the large-capacity tier with them
-    (asserted).  The insert-size trajectory of a prefix is the trajectory of the run, so the SAM must be identical."""
+def test_full_size_genome_prefix_equals_reference(api, bench_genome, tmp_path, record_property):
+    """BASELINE config 3 at full size: the first MILLION pairs of a bench batch (150 bp, -alg ksw2) as ONE batch of 2 M reads through the
+    product's file path — everything only a large batch switches on: the straight-line pairs through k_simple, the others dealt to the
+    lanes by weight, the large tier beside tier 0, mate rescue beside the build, the late pairs' pass, the batch's tail queued behind its
+    kernels — and through the CPU checker (the compiled reference at -t 1: two minutes; round 4's suite compared 60 k pairs).  Reads from
+    repeats bring hundreds of seed hits, mate rescue and the large-capacity tier with them (asserted).  The insert-size trajectory of a
+    prefix is the trajectory of the run, so the SAM must be identical."""
     from mapcaller_amd import synth
     g = bench_genome
-    n_pairs = 60000
+    n_pairs = 1_000_000 if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "MapCaller")) else 60_000  # (the oracle restatement is slower than the reference)
     reads = g["bench"].make_reads(g["codes"], g["lens"], n_pairs, 150, seed=1000, device=g["dev"]).reshape(2 * n_pairs, 150).cpu()
     f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
     synth.write_fastq(f1, reads, 0, 2); synth.write_fastq(f2, reads, 1, 2)
-    mp = api.Mapper(g["index"], alg="ksw2", max_batch_reads=1 << 16)
+    mp = api.Mapper(g["index"], alg="ksw2", max_batch_reads=2 * n_pairs)
     out = str(tmp_path / "gpu.sam")
-    st = mp.map_files(f1, f2, out)
+    st = mp.map_files(f1, f2, out)  # (a batch of the file path is the context's max_batch_reads: the whole input here)
     mp.close()
     chk = str(tmp_path / "chk.sam")
     _checker_sam(g["prefix"], f1, f2, "ksw2", chk, tmp_path)
     nd, ex = sam_diff(chk, out)
     assert nd == 0, ex
-    assert st["mapped"] > 0.95 * st["reads"]
+    assert st["reads"] == 2 * n_pairs and st["mapped"] > 0.95 * st["reads"]
     assert st["tier1_pairs"] > 0, st  # pairs over the tier-0 capacities did go through the large tier
+    assert n_pairs < 100_000 or st["simple_pairs"] > 0.3 * n_pairs, st  # the straight-line path took its share
+    record_property("pairs", n_pairs)
 
 
 def _nonzero_plane_records(planes, G):
