@@ -696,10 +696,7 @@ __global__ void __launch_bounds__(256) k_sa(Ctx cx, SeedOut so, int paired, uint
 struct RescueList { uint32_t *ids; uint32_t *n; uint32_t cap; };
 // pairs that ran over the tier-0 capacities while clustering are listed right there, with their estimate: the large tier maps
 // them on a stream of its own while the rest of the pass is still under way (ids null: no such list)
-// (done / host / any_n: the launch's last workgroup writes the list's length — and whether the batch holds a read with an N — into page-locked host
-//  memory, so that the host, which drives the large tier for the listed pairs, needs no copy of its own behind the kernel: such a copy is a blit
-//  kernel that waits for a free CU on a chip the pass is filling — 0.3 to 0.9 ms before the large tier's first kernel could start)
-struct EarlyList { uint32_t *ids; int32_t *est; uint32_t *n; uint32_t cap; uint32_t *n_hits; uint32_t *done; volatile uint32_t *host; const uint32_t *any_n; };
+struct EarlyList { uint32_t *ids; int32_t *est; uint32_t *n; uint32_t cap; uint32_t *n_hits; };
 
 // The per-pair kernels give every lane one pair, and a wavefront is as slow as its heaviest lane: next to a pair from a repeat
 // (dozens of hits to sort and cluster, a dozen candidates to build and score) sixty-three ordinary pairs wait.  So the pairs
@@ -925,11 +922,10 @@ __global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel s
         uint32_t at = 0;
         for (int k = 0; k < kWorkClasses; k++) { if (k == cls_lo) first = at; at += order_cnt[k * kCntPad]; if (k == cls_hi) n_listed = at; }
     }
-    const bool idle = first + blockIdx.x * blockDim.x >= n_listed; // (uniform over the block: nothing listed for it)
-    if (idle && !el.host) return;
-    if (!idle) stage_ends(cx.ix, ends);
+    if (first + blockIdx.x * blockDim.x >= n_listed) return; // (uniform over the block)
+    stage_ends(cx.ix, ends);
     const uint32_t slot = first + blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = !idle && slot < n_listed;
+    const bool in = slot < n_listed;
     const uint32_t local = in ? (order ? order[slot] : slot) : 0u;
     uint32_t need = 0, over = 0;
     if (in) {
@@ -953,17 +949,15 @@ __global__ void __launch_bounds__(256) k_cluster(Ctx cx, ReadBatch rb, PairSel s
         const uint32_t ea = wave_reserve(el.n, over);
         if (over && ea < el.cap) { el.ids[ea] = sel_pair(sel, local); el.est[ea] = sel.est[local]; }
     }
-    if (el.host) { // the last workgroup to get here tells the host how many pairs the large tier has to map
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __threadfence();
-            if (atomicAdd(el.done, 1u) == gridDim.x - 1) {
-                __threadfence();
-                el.host[0] = atomicAdd(el.n, 0u); el.host[1] = *el.any_n;
-                __threadfence_system();
-            }
-        }
-    }
+}
+
+// behind k_cluster on its stream: the list's length — and whether the batch holds a read with an N — into page-locked host memory, so that the host,
+// which drives the large tier for the listed pairs, needs no copy of its own behind the kernel (such a copy is a blit kernel that waits for a free CU on a chip
+// the pass is filling: 0.3 to 0.9 ms before the large tier's first kernel could start).  (Counting the clustering kernel's workgroups as they end, so
+// that the last one could write the words, cost the kernel 0.5 ms: 15 000 atomics on one address.)
+__global__ void k_publish_early(const uint32_t *n, const uint32_t *any_n, volatile uint32_t *host)
+{
+    if (threadIdx.x == 0) { host[0] = *n; host[1] = *any_n; __threadfence_system(); }
 }
 
 // ---- clustering and pairing of a heavy pair by a whole wavefront -----------------------------------------------------------
@@ -2024,7 +2018,7 @@ constexpr uint32_t kPoutSel = 1u << 16; // pair outcomes gathered per copy (run_
 enum { CNT_TASKS = 0, CNT_RESCUE = 1 * kCntPad, CNT_JOB0 = 2 * kCntPad, CNT_JOB1 = 3 * kCntPad, CNT_JOB2 = 4 * kCntPad, CNT_JOB3 = 5 * kCntPad,
        CNT_JOB4 = 6 * kCntPad, CNT_JOB5 = 7 * kCntPad, CNT_OV = 8 * kCntPad, CNT_LF = 9 * kCntPad, CNT_CELLS = 10 * kCntPad, CNT_UNSUP = 11 * kCntPad,
        CNT_QUEUE = 12 * kCntPad, CNT_EARLY = 13 * kCntPad, CNT_LATE = 14 * kCntPad, CNT_RTASK = 15 * kCntPad, CNT_RPLAN = 16 * kCntPad, CNT_RESCUE_N = 17 * kCntPad, CNT_RSEED = 18 * kCntPad,
-       CNT_SIMPLE = 19 * kCntPad, CNT_EARLY_HITS = 20 * kCntPad, CNT_SIMPLE_LATER = 21 * kCntPad, CNT_SIMPLE_JOBS = 22 * kCntPad, CNT_CLUSTER_DONE = 23 * kCntPad, CNT_N = 24 * kCntPad,
+       CNT_SIMPLE = 19 * kCntPad, CNT_EARLY_HITS = 20 * kCntPad, CNT_SIMPLE_LATER = 21 * kCntPad, CNT_SIMPLE_JOBS = 22 * kCntPad, CNT_N = 23 * kCntPad,
        // behind the counters proper, cleared with them at the start of a pass (a memset in the middle of a pass was seen to sit 1.4 ms in its queue):
        CNT_ORDER = CNT_N, CNT_DP_SORT = CNT_ORDER + 16 * kCntPad, CNT_ALL = CNT_DP_SORT + 4 * 256 };
 constexpr uint32_t kLateRoom = 2048; // pairs of a pass that may run over after clustering and still go through the large tier beside it
@@ -2067,6 +2061,7 @@ struct BatchRun { // the batch between mcx_batch_begin and mcx_batch_end
 struct mcx_ctx {
     const mcx_index *idx = nullptr;
     bool counted = false; // (among idx->n_ctx)
+    bool lens_checked = false; // the batch about to begin holds no read longer than max_read_len (mcx_stream_next says so for batches that came as 2-bit rows)
     Knobs kn;
     Params pm;
     mcx_opts opts;
@@ -2126,7 +2121,7 @@ struct mcx_ctx {
     BatchRun run;
     PassRes t1;               // the large tier's own set (the members above are tier 0's); allocated when every suffix-array entry is resident
     bool overlap_tiers = false;
-    volatile uint32_t *h_early = nullptr; uint32_t *d_early = nullptr; // page-locked words the clustering kernel's last workgroup writes (EarlyList::host): the host's view and the device's
+    volatile uint32_t *h_early = nullptr; uint32_t *d_early = nullptr; // page-locked words k_publish_early writes behind the clustering kernel: the host's view and the device's
     PassRes t2;               // a third set: the large tier's pass over the pairs that ran over after clustering (k_build's list)
     hipEvent_t ev_built = nullptr, ev_late_done = nullptr;
     bool overlap_late = false;
@@ -2136,6 +2131,7 @@ struct mcx_ctx {
         uint8_t *d_bases = nullptr; uint32_t *d_off = nullptr; AlnRec *d_recs = nullptr; uint32_t *d_cig = nullptr;
         uint32_t *d_codes = nullptr, *d_len = nullptr, *d_err = nullptr; uint64_t *d_odd = nullptr; uint32_t odd_cap = 0; // mcx_stream_submit_packed: what arrives; restored to d_bases / d_off
         uint32_t n_reads = 0; int state = 0; uint64_t seq = 0; // 0 free, 1 copy in started, 2 handed to the kernels, 3 copy out started
+        bool lens_checked = false; // the batch came as 2-bit rows: no read is longer than the context's slots (k_unpack_reads / k_neutralize saw to it)
         hipEvent_t in_ready = nullptr, mapped = nullptr, out_done = nullptr;
     } slot[3];
     hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
@@ -2553,13 +2549,10 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     so.src_state = nullptr; so.src_lay = c->tier[0].lay; so.src_caps = c->tier[0].caps;
     if (hits_from_tier0 && tier == 1 && cx.ix.sa_full && !kn.late_reseed) so.src_state = c->tier[0].state;
     RescueList rl; rl.ids = R.d_rescue; rl.n = R.d_cnt + CNT_RESCUE; rl.cap = R.rescue_cap;
-    EarlyList el; el.ids = nullptr; el.est = nullptr; el.n = R.d_cnt + CNT_EARLY; el.cap = 0; el.n_hits = R.d_cnt + CNT_EARLY_HITS; el.done = nullptr; el.host = nullptr; el.any_n = nullptr;
-    if (early) {
-        el.ids = c->t1.d_sel_ids; el.est = c->t1.d_est; el.cap = (uint32_t)c->max_reads;
-        if (c->h_early) { el.done = R.d_cnt + CNT_CLUSTER_DONE; el.host = c->d_early; el.any_n = c->d_batch_flags + 3; }
-    }
+    EarlyList el; el.ids = nullptr; el.est = nullptr; el.n = R.d_cnt + CNT_EARLY; el.cap = 0; el.n_hits = R.d_cnt + CNT_EARLY_HITS;
+    if (early) { el.ids = c->t1.d_sel_ids; el.est = c->t1.d_est; el.cap = (uint32_t)c->max_reads; }
     const bool late = early && c->overlap_late;
-    EarlyList ll; ll.ids = nullptr; ll.est = nullptr; ll.n = R.d_cnt + CNT_LATE; ll.cap = 0; ll.n_hits = R.d_cnt + CNT_EARLY_HITS; ll.done = nullptr; ll.host = nullptr; ll.any_n = nullptr;
+    EarlyList ll; ll.ids = nullptr; ll.est = nullptr; ll.n = R.d_cnt + CNT_LATE; ll.cap = 0; ll.n_hits = R.d_cnt + CNT_EARLY_HITS;
     if (late) { ll.ids = c->t2.d_sel_ids; ll.est = c->t2.d_est; ll.cap = kLateRoom; }
     JobSinks sinks;
     for (int k = 0; k < kDpClasses; k++) { sinks.s[k].jobs = R.d_jobs[k]; sinks.s[k].count = R.d_cnt + CNT_JOB0 + k * kCntPad; sinks.s[k].cap = R.job_cap[k]; }
@@ -2635,6 +2628,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         if (small < cx.caps.hit_cap)
             k_cluster_wave<<<std::min<unsigned>(sel.n, 8192u), 64, cl_bytes, s>>>(cx, rb, sel, rl, so.read_blocks, small, 1 << 30, cx.caps.hit_cap, cx.caps.cand_cap);
     } else k_cluster<<<pb, 256, 0, s>>>(cx, rb, sel, rl, so.read_blocks, el, order, order_cnt, 0, kWorkClasses - 1);
+    if (early && c->h_early) k_publish_early<<<1, 64, 0, s>>>(R.d_cnt + CNT_EARLY, c->d_batch_flags + 3, c->d_early);
     if (early) HIP_TRY(hipEventRecord(c->ev_clustered, s));
     if (timing) HIP_TRY(hipEventRecord(R.ev[e++], s));
     // mate rescue beside the build of the pairs that do not await it (k_build's modes), when the set has a side stream for it
@@ -2699,7 +2693,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         uint32_t n_early = 0;
         HIP_TRY(hipStreamWaitEvent(T.stream, c->ev_clustered, 0));
         bool no_n;
-        if (el.host) { // k_cluster's last workgroup wrote both numbers into page-locked memory
+        if (c->h_early) { // k_publish_early wrote both numbers into page-locked memory
             HIP_TRY(hipEventSynchronize(c->ev_clustered));
             n_early = c->h_early[0]; no_n = c->h_early[1] == 0;
         } else {
@@ -3141,8 +3135,11 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
     br.n_chunks = (br.n_pairs + kReadChunkSize / 2 - 1) / (kReadChunkSize / 2);
     br.mapped = 0; br.sums_valid = false;
     c->tail.queued = c->tail.ran = false;
-    { // every read must fit the slots the context was sized for
-        HIP_TRY(hipMemsetAsync(c->d_batch_flags, 0, 4 * sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(c->d_batch_flags, 0, 4 * sizeof(uint32_t), s));
+    const bool vouched = c->lens_checked;
+    c->lens_checked = false; // (said of this batch only)
+    if (vouched) c->h_cnt[1] = (uint32_t)c->rlen_max; // (vouched for: no kernel, no wait at the start of the step — under the copies of the neighbouring batches such a wait takes milliseconds)
+    else { // every read must fit the slots the context was sized for
         k_max_read_len<<<512, 256, 0, s>>>(d_off, n_reads, c->d_batch_flags + 1);
         HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_batch_flags, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -3483,6 +3480,8 @@ __global__ void __launch_bounds__(256) k_copy16(const U4 *__restrict__ src, U4 *
 static int bulk_copy(mcx_ctx *c, void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t s)
 {
     if (bytes == 0) return 0;
+    // (MCX_STREAM_KERNEL_COPY: this library's own copy kernel over the mapped host memory instead of the runtime's copies — round 5 tried it for the way out
+    //  alone, on grids of 16 / 48 / 128 workgroups, next to the mapping kernels: 23.7 / 26.1 / 27.2 ms per step against the runtime's 20.6)
     static const bool use_dma = getenv("MCX_STREAM_KERNEL_COPY") == nullptr;
     const size_t n16 = bytes / 16;
     bool mapped = false; // is the host side page-locked memory the device can address?
@@ -3573,6 +3572,14 @@ __global__ void k_apply_odd(const uint64_t *odd, uint32_t n_odd, const uint32_t 
     if (r < n_reads && off[r + 1] >= off[r] && pos < off[r + 1] - off[r] && (uint64_t)off[r] + pos < max_bases) bases[off[r] + pos] = (uint8_t)e;
 }
 
+// a batch whose lengths k_unpack_reads refused maps nothing: every read becomes empty, so that no kernel behind this one meets a length it was not sized
+// for — the host hears of it when it next looks (mcx_stream_map), not before the batch's first kernel: no wait at the start of a step
+__global__ void __launch_bounds__(256) k_neutralize(uint32_t *off, uint32_t n_reads, const uint32_t *err)
+{
+    if (*err == 0) return;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r <= n_reads; r += gridDim.x * blockDim.x) off[r] = 0;
+}
+
 extern "C" int mcx_stream_submit_packed(mcx_ctx *c, const uint32_t *codes, uint32_t row_words, const uint32_t *len, uint32_t n_reads, const uint64_t *odd,
                                         uint32_t n_odd)
 {
@@ -3612,7 +3619,9 @@ extern "C" int mcx_stream_submit_packed(mcx_ctx *c, const uint32_t *codes, uint3
     k_unpack_reads<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(sl->d_codes, row_words, sl->d_off, n_reads, sl->d_bases, c->max_bases,
                                                                    std::min<uint32_t>(row_words * 16u, (uint32_t)c->rlen_max), sl->d_err);
     if (n_odd) k_apply_odd<<<(n_odd + 255) / 256, 256, 0, s>>>(sl->d_odd, n_odd, sl->d_off, n_reads, sl->d_bases, c->max_bases);
+    k_neutralize<<<256, 256, 0, s>>>(sl->d_off, n_reads, sl->d_err);
     HIP_TRY(hipGetLastError());
+    sl->lens_checked = true;
     HIP_TRY(hipEventRecord(sl->in_ready, s));
     sl->n_reads = n_reads; sl->state = 1; sl->seq = ++c->stream_seq;
     c->stream_bytes_in += (uint64_t)n_reads * row_words * 4 + (uint64_t)n_reads * 4 + (uint64_t)n_odd * 8;
@@ -3629,6 +3638,7 @@ extern "C" int mcx_stream_submit(mcx_ctx *c, const uint8_t *bases, const uint32_
     int rc = stream_slot(c, &sl);
     if (rc) return rc;
     if (sl->d_err) HIP_TRY(hipMemsetAsync(sl->d_err, 0, 4, c->h2d_stream)); // (the slot once took 2-bit rows: nothing of that batch's verdict is this one's)
+    sl->lens_checked = false;
     if ((rc = bulk_copy(c, sl->d_bases, bases, off[n_reads], hipMemcpyHostToDevice, c->h2d_stream))) return rc;
     if ((rc = bulk_copy(c, sl->d_off, off, (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice, c->h2d_stream))) return rc;
     HIP_TRY(hipEventRecord(sl->in_ready, c->h2d_stream));
@@ -3646,14 +3656,7 @@ extern "C" int mcx_stream_next(mcx_ctx *c, const uint8_t **d_bases, const uint32
     mcx_ctx::Slot *sl = oldest_slot(c, 1);
     if (!sl) return fail(MCX_ERR_ARG, "mcx_stream_next: nothing submitted");
     HIP_TRY(hipStreamWaitEvent(c->stream, sl->in_ready, 0));
-    if (sl->d_err) { // a batch that came as 2-bit rows: what k_unpack_reads thought of the caller's lengths
-        HIP_TRY(hipMemcpyAsync(c->h_cnt, sl->d_err, 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if (c->h_cnt[0]) {
-            sl->state = 0;
-            return fail(MCX_ERR_ARG, (c->h_cnt[0] & 1u) ? "mcx_stream_submit_packed: a read is longer than its row / max_read_len" : "batch holds more bases than max_batch_reads * max_read_len");
-        }
-    }
+    c->lens_checked = sl->lens_checked; // (for the mcx_batch_begin that follows: no need to look for an over-long read, nor to wait for the answer)
     sl->state = 2;
     *d_bases = sl->d_bases; *d_off = sl->d_off; *d_aln = (mcx_aln *)sl->d_recs; *d_cigar = sl->d_cig;
     if (n_reads) *n_reads = sl->n_reads;
@@ -3685,7 +3688,13 @@ extern "C" int mcx_stream_map(mcx_ctx *c, int paired, int64_t avg[4], mcx_aln *a
     int rc = mcx_stream_next(c, &d_bases, &d_off, &n, &d_aln, &d_cig);
     if (rc) return rc;
     rc = mcx_map_batch_dev(c, d_bases, d_off, n, paired, avg, d_aln, d_cig, stats);
-    if (rc) { oldest_slot(c, 2)->state = 0; return rc; }
+    mcx_ctx::Slot *sl = oldest_slot(c, 2);
+    if (rc == 0 && sl->lens_checked) { // what k_unpack_reads thought of the caller's lengths (a refused batch was mapped as empty reads)
+        uint32_t err = 0;
+        HIP_TRY(hipMemcpy(&err, sl->d_err, 4, hipMemcpyDeviceToHost));
+        if (err) rc = fail(MCX_ERR_ARG, (err & 1u) ? "mcx_stream_submit_packed: a read is longer than its row / max_read_len" : "batch holds more bases than max_batch_reads * max_read_len");
+    }
+    if (rc) { sl->state = 0; return rc; }
     return mcx_stream_mapped(c, aln, cigar);
 }
 
