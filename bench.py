@@ -266,11 +266,11 @@ def pcie_inclusive(args, mapper, batches, reads_per_step, dist, dev):
         host.append((words, lens, odd, n_odd, row_words))
     packed = [(w.data_ptr(), rw, l.data_ptr(), o.data_ptr(), n) for (w, l, o, n, rw) in host]
     packed = [packed[i % len(packed)] for i in range(k)]  # (more steps than resident batches: the batches come round again)
-    outs = mapper.stream_outputs(reads_per_step, 3)  # (page-locking gigabytes takes seconds: not part of the path)
-    b0 = mapper.map_stream_packed(packed[:3], reads_per_step, True, outs)  # the three slots in HBM, streams, events: made on first use
+    outs = mapper.stream_outputs(reads_per_step, 3, 32)  # (page-locking gigabytes takes seconds: not part of the path)
+    b0 = mapper.map_stream_packed(packed[:3], reads_per_step, True, outs, out32=True)  # the three slots in HBM, streams, events: made on first use
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    b1 = mapper.map_stream_packed(packed, reads_per_step, True, outs)
+    b1 = mapper.map_stream_packed(packed, reads_per_step, True, outs, out32=True)
     n_bytes = (b1[0] - b0[0], b1[1] - b0[1])
     dt = time.perf_counter() - t0
     if dist:
@@ -280,7 +280,8 @@ def pcie_inclusive(args, mapper, batches, reads_per_step, dist, dev):
     return {"value": round(k * reads_per_step * world / dt, 1), "unit": "reads/s", "steps": k, "ms_per_step": round(1000 * dt / k, 3),
             "h2d_bytes_per_read": round(n_bytes[0] / (k * reads_per_step), 1), "d2h_bytes_per_read": round(n_bytes[1] / (k * reads_per_step), 1),
             "note": "2-bit reads + lengths from pinned host memory (the form the file front end's parser hands over; the ASCII bytes are restored "
-                    "exactly on the device), alignment records + CIGAR pool back to pinned host memory; copies of batch i+1 / i-1 overlap the kernels "
+                    "exactly on the device), alignment records (32 bytes each: mcx_aln32, packed on the device — at 64 the copy out outlasted the stretch of the next step in which "
+                    "the host waits for nothing, and the step took 20.5 instead of 17.3 ms) + CIGAR pool back to pinned host memory; copies of batch i+1 / i-1 overlap the kernels "
                     "of batch i on separate HIP streams (mcx_stream_*); the first copy in and the last copy out of the sequence have nothing to "
                     "hide behind and are part of the time (about 18 ms per sequence at 8 M reads a step)"}
 

@@ -111,6 +111,30 @@ typedef struct mcx_aln {
     int32_t pad;       /* 64-byte records */
 } mcx_aln;
 
+/* The same record in 32 bytes, for the way out of HBM (mcx_stream_map32 / mcx_stream_mapped32): at 64 bytes a read the copy of a
+ * batch's records outlasts the part of the next batch's step in which the host has nothing to wait for, and every wait behind it takes
+ * milliseconds (the device boundary).  Positions below 2^40, at most 65 535 contigs, reads of up to 1000 bases:
+ * the path's own limits.  mcx_aln_unpack gives the 64-byte form back. */
+typedef struct mcx_aln32 {
+    uint32_t pos_lo, mate_lo;   /* POS, PNEXT: low 32 bits */
+    uint8_t pos_hi, mate_hi;    /* ... bits 32-39 */
+    uint8_t mapq;
+    uint8_t bits;               /* 1: fwd, 2: has_mate */
+    int32_t tlen;
+    uint16_t flag;
+    uint16_t chr;               /* 0xFFFF = '*' */
+    int16_t nm, as, xs;
+    uint16_t n_cigar;
+    uint32_t cigar_off;
+} mcx_aln32;
+static inline void mcx_aln_unpack(const mcx_aln32 *p, mcx_aln *o)
+{
+    o->pos = (int64_t)p->pos_lo | ((int64_t)p->pos_hi << 32); o->mate_pos = (int64_t)p->mate_lo | ((int64_t)p->mate_hi << 32);
+    o->chr = p->chr == 0xFFFFu ? -1 : (int32_t)p->chr; o->flag = p->flag; o->mapq = p->mapq; o->tlen = p->tlen;
+    o->nm = p->nm; o->as = p->as; o->xs = p->xs; o->n_cigar = p->n_cigar; o->fwd = p->bits & 1; o->has_mate = (p->bits >> 1) & 1;
+    o->cigar_off = (int32_t)p->cigar_off; o->pad = 0;
+}
+
 typedef struct mcx_stats {
     int64_t reads, mapped, pairs, pair_dist_sum;
     int64_t pair_len_sum;   /* ReadLengthSum: bases of the reads counted in `pairs` (ReadMapping.cpp:529-530) */
@@ -174,6 +198,9 @@ int mcx_stream_map(mcx_ctx *, int paired, int64_t avg_state[4], mcx_aln *aln, ui
 int mcx_stream_collect(mcx_ctx *, uint64_t *bytes_in, uint64_t *bytes_out);
 int mcx_stream_next(mcx_ctx *, const uint8_t **d_bases, const uint32_t **d_off, uint32_t *n_reads, mcx_aln **d_aln, uint32_t **d_cigar);
 int mcx_stream_mapped(mcx_ctx *, mcx_aln *aln, uint32_t *cigar);
+/* mcx_stream_map / mcx_stream_mapped with the records leaving HBM in 32 bytes each (packed on the device, half the bytes across PCIe) */
+int mcx_stream_map32(mcx_ctx *, int paired, int64_t avg_state[4], mcx_aln32 *aln, uint32_t *cigar, mcx_stats *stats);
+int mcx_stream_mapped32(mcx_ctx *, mcx_aln32 *aln, uint32_t *cigar);
 
 /* ---- a batch in steps: runs whose batches are mapped by several GPUs ---------------------------
  * The reference re-estimates the insert size after every 200-read chunk (ReadMapping.cpp:462,

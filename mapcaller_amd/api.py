@@ -67,6 +67,7 @@ SYMBOLS = [
     "mcx_batch_begin", "mcx_batch_sums", "mcx_batch_replay", "mcx_batch_end", "mcx_avg_walk", "mcx_batch_totals", "mcx_batch_check", "mcx_avg_advance", "mcx_exchange_local", "mcx_exchange_local_free",
     "mcx_profile_sparse_shard", "mcx_batch_end_keys", "mcx_batch_accumulate",
     "mcx_stream_submit", "mcx_stream_submit_packed", "mcx_stream_map", "mcx_stream_collect", "mcx_stream_next", "mcx_stream_mapped",
+    "mcx_stream_map32", "mcx_stream_mapped32",
 ]
 # include/mcx_comm.h (libmcx_comm.so: the RCCL side, loaded by the native CLI only)
 COMM_LIB_PATH = os.path.join(_HERE, "libmcx_comm.so")
@@ -87,6 +88,23 @@ class Aln(C.Structure):
     _fields_ = [("pos", C.c_int64), ("mate_pos", C.c_int64), ("chr", C.c_int32), ("flag", C.c_int32),
                 ("mapq", C.c_int32), ("tlen", C.c_int32), ("nm", C.c_int32), ("as_", C.c_int32), ("xs", C.c_int32),
                 ("n_cigar", C.c_int32), ("fwd", C.c_int32), ("has_mate", C.c_int32), ("cigar_off", C.c_int32), ("pad", C.c_int32)]
+
+
+ALN32_DTYPE = np.dtype([("pos_lo", "<u4"), ("mate_lo", "<u4"), ("pos_hi", "u1"), ("mate_hi", "u1"), ("mapq", "u1"), ("bits", "u1"), ("tlen", "<i4"), ("flag", "<u2"),
+                        ("chr", "<u2"), ("nm", "<i2"), ("as", "<i2"), ("xs", "<i2"), ("n_cigar", "<u2"), ("cigar_off", "<u4")])  # mcx_aln32
+
+
+def aln32_unpack(a32: np.ndarray) -> np.ndarray:
+    """mcx_aln_unpack (include/mcx.h) over an array of mcx_aln32 records: the 64-byte form."""
+    o = np.zeros(a32.shape, dtype=ALN_DTYPE)
+    o["pos"] = a32["pos_lo"].astype(np.int64) | (a32["pos_hi"].astype(np.int64) << 32)
+    o["mate_pos"] = a32["mate_lo"].astype(np.int64) | (a32["mate_hi"].astype(np.int64) << 32)
+    o["chr"] = np.where(a32["chr"] == 0xFFFF, -1, a32["chr"].astype(np.int32))
+    for f in ("flag", "mapq", "tlen", "nm", "as", "xs", "n_cigar", "cigar_off"):
+        o[f] = a32[f]
+    o["fwd"] = a32["bits"] & 1
+    o["has_mate"] = (a32["bits"] >> 1) & 1
+    return o
 
 
 ALN_DTYPE = np.dtype([("pos", "<i8"), ("mate_pos", "<i8"), ("chr", "<i4"), ("flag", "<i4"), ("mapq", "<i4"),
@@ -296,6 +314,8 @@ def lib() -> C.CDLL:
     L.mcx_stream_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     L.mcx_stream_submit_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
     L.mcx_stream_map.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+    L.mcx_stream_map32.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+    L.mcx_stream_mapped32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.mcx_stream_collect.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.mcx_planes_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.mcx_planes_free.argtypes = [C.c_void_p]
@@ -486,10 +506,11 @@ class Mapper:
         return aln, [pool[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["n_cigar"])] for a in aln]
 
     @staticmethod
-    def stream_outputs(n_reads: int, slots: int = 3):
-        """Pinned host buffers for map_stream's results: [(records uint8[n_reads * 64], CIGAR pool int32[cigar_pool_words(n_reads)])]."""
+    def stream_outputs(n_reads: int, slots: int = 3, record_bytes: int = 64):
+        """Pinned host buffers for map_stream's results: [(records uint8[n_reads * record_bytes], CIGAR pool int32[cigar_pool_words(n_reads)])];
+        record_bytes = 32: the records as mcx_aln32 (map_stream_packed(..., out32=True): half the bytes on the way out)."""
         import torch
-        return [(torch.empty(n_reads * 64, dtype=torch.uint8).pin_memory(), torch.empty(cigar_pool_words(n_reads), dtype=torch.int32).pin_memory())
+        return [(torch.empty(n_reads * record_bytes, dtype=torch.uint8).pin_memory(), torch.empty(cigar_pool_words(n_reads), dtype=torch.int32).pin_memory())
                 for _ in range(slots)]
 
     def map_stream(self, host_bases_ptrs, host_off_ptr: int, n_reads: int, paired: bool, outputs=None):
@@ -511,21 +532,22 @@ class Mapper:
                 _check(L.mcx_stream_collect(self._h, C.byref(h2d), C.byref(d2h)), "mcx_stream_collect")
         return h2d.value, d2h.value
 
-    def map_stream_packed(self, packed, n_reads: int, paired: bool, outputs=None):
+    def map_stream_packed(self, packed, n_reads: int, paired: bool, outputs=None, out32: bool = False):
         """map_stream with the reads as a host parser packs them (pack_reads): ``packed`` = [(codes ptr, row_words, len ptr, odd ptr, n_odd)]
         per batch, all in pinned host memory."""
         L = lib()
         k = len(packed)
-        outs = outputs or self.stream_outputs(n_reads, min(k, 3))
+        outs = outputs or self.stream_outputs(n_reads, min(k, 3), 32 if out32 else 64)
         h2d = C.c_uint64()
         d2h = C.c_uint64()
+        stream_map = L.mcx_stream_map32 if out32 else L.mcx_stream_map
         for i in range(k + 2):
             if i < k:
                 codes, row_words, lens, odd, n_odd = packed[i]
                 _check(L.mcx_stream_submit_packed(self._h, codes, row_words, lens, n_reads, odd, n_odd), "mcx_stream_submit_packed")
             if 1 <= i <= k:
                 a, g = outs[(i - 1) % len(outs)]
-                _check(L.mcx_stream_map(self._h, int(paired), self.avg, a.data_ptr(), g.data_ptr(), C.byref(self.stats)), "mcx_stream_map")
+                _check(stream_map(self._h, int(paired), self.avg, a.data_ptr(), g.data_ptr(), C.byref(self.stats)), "mcx_stream_map")
             if i >= 2:
                 _check(L.mcx_stream_collect(self._h, C.byref(h2d), C.byref(d2h)), "mcx_stream_collect")
         return h2d.value, d2h.value

@@ -536,7 +536,7 @@ struct Batch {
     std::string error;
     // what crosses the device boundary, in page-locked memory (allocated once per batch object): 2-bit rows, lengths and the
     // bytes that are not ACGT on the way in; records and CIGAR words on the way out
-    uint32_t *rows = nullptr, *lens = nullptr; uint64_t *odd = nullptr; AlnRec *recs = nullptr; uint32_t *cig = nullptr;
+    uint32_t *rows = nullptr, *lens = nullptr; uint64_t *odd = nullptr; mcx_aln32 *recs = nullptr; uint32_t *cig = nullptr; // (the records as they cross PCIe: 32 bytes each)
     size_t cap_reads = 0, cap_rows = 0, cap_odd = 0;
     uint32_t row_words = 0, n_odd[2] = {0, 0};
     std::vector<uint8_t> is_mate2;   // mapped as the second read of a pair
@@ -549,7 +549,7 @@ struct Batch {
             mcx_pinned_free(lens); mcx_pinned_free(recs); mcx_pinned_free(cig);
             cap_reads = reads;
             lens = (uint32_t *)mcx_pinned_alloc((reads + 1) * sizeof(uint32_t));
-            recs = (AlnRec *)mcx_pinned_alloc(reads * sizeof(AlnRec));
+            recs = (mcx_aln32 *)mcx_pinned_alloc(reads * sizeof(mcx_aln32));
             cig = (uint32_t *)mcx_pinned_alloc((MCX_CIGAR_POOL_WORDS(reads) + MCX_CIGAR_SLACK) * sizeof(uint32_t)); // (two pools: the pairs', the single reads')
         }
         if (reads * words_per_read > cap_rows) { mcx_pinned_free(rows); cap_rows = reads * words_per_read; rows = (uint32_t *)mcx_pinned_alloc(cap_rows * sizeof(uint32_t)); }
@@ -582,9 +582,10 @@ void sam_record(const HostIndex &ix, const Batch &bt, uint32_t r, Text &o)
     static const char opc[8] = {'M', 'I', 'D', 'N', 'S', 'H', 'P', '='};
     const char *base;
     const Rec &e = bt.rec(r, base);
-    const AlnRec &rec = bt.recs[r];
-    // the batch's CIGAR pool (the single-read part of a batch has one of its own behind the pairs'), AlnRec::pad[0] = offset
-    const uint32_t *cigar = bt.cig + (r < bt.n_pair_reads ? 0 : MCX_CIGAR_POOL_WORDS(bt.n_pair_reads)) + (size_t)rec.pad[0];
+    mcx_aln rec;
+    mcx_aln_unpack(&bt.recs[r], &rec);
+    // the batch's CIGAR pool (the single-read part of a batch has one of its own behind the pairs'), cigar_off = the read's place in it
+    const uint32_t *cigar = bt.cig + (r < bt.n_pair_reads ? 0 : MCX_CIGAR_POOL_WORDS(bt.n_pair_reads)) + (size_t)(uint32_t)rec.cigar_off;
     const char *seq = base + e.seq;
     const int rlen = (int)e.rlen;
     const char *qual = bt.fastq ? base + e.qual : nullptr;
@@ -1158,7 +1159,7 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
                     for (uint32_t r = lo; r < hi; r++) {
                         const char *base;
                         const Rec &e = b->rec(r, base);
-                        bound += sam_bound(hix, e.name_len, e.rlen, b->recs[r].chr, b->recs[r].n_cigar);
+                        bound += sam_bound(hix, e.name_len, e.rlen, b->recs[r].chr == 0xFFFFu ? -1 : (int)b->recs[r].chr, b->recs[r].n_cigar);
                     }
                     t.start(bound);
                     for (uint32_t r = lo; r < hi; r++) sam_record(hix, *b, r, t);
@@ -1247,7 +1248,7 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
         const uint8_t *d_bases = nullptr; const uint32_t *d_off = nullptr; mcx_aln *d_aln = nullptr; uint32_t *d_cig = nullptr; uint32_t n_dev = 0;
         auto part_in = [&]() { const int e = mcx_stream_next(c, &d_bases, &d_off, &n_dev, &d_aln, &d_cig); if (e && rc == 0) rc = e; return e == 0; };
         auto part_out = [&](bool second) {
-            const int e = second ? mcx_stream_mapped(c, (mcx_aln *)p->recs + p->n_pair_reads, p->cig + MCX_CIGAR_POOL_WORDS(p->n_pair_reads)) : mcx_stream_mapped(c, (mcx_aln *)p->recs, p->cig);
+            const int e = second ? mcx_stream_mapped32(c, p->recs + p->n_pair_reads, p->cig + MCX_CIGAR_POOL_WORDS(p->n_pair_reads)) : mcx_stream_mapped32(c, p->recs, p->cig);
             if (e && rc == 0) rc = e;
             if (e == 0) parts_out++;
         };

@@ -2129,6 +2129,7 @@ struct mcx_ctx {
     // mcx_stream_*: three batches in flight (copy in | kernels | copy out), each in a slot of its own
     struct Slot {
         uint8_t *d_bases = nullptr; uint32_t *d_off = nullptr; AlnRec *d_recs = nullptr; uint32_t *d_cig = nullptr;
+        mcx_aln32 *d_recs32 = nullptr; // the records in 32 bytes each for their way out (mcx_stream_mapped32)
         uint32_t *d_codes = nullptr, *d_len = nullptr, *d_err = nullptr; uint64_t *d_odd = nullptr; uint32_t odd_cap = 0; // mcx_stream_submit_packed: what arrives; restored to d_bases / d_off
         uint32_t n_reads = 0; int state = 0; uint64_t seq = 0; // 0 free, 1 copy in started, 2 handed to the kernels, 3 copy out started
         bool lens_checked = false; // the batch came as 2-bit rows: no read is longer than the context's slots (k_unpack_reads / k_neutralize saw to it)
@@ -2399,7 +2400,7 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     if (c->tail.d) (void)hipFree(c->tail.d);
     if (c->tail.h) (void)hipHostFree(c->tail.h);
     for (auto &sl : c->slot) {
-        void *q[] = {sl.d_bases, sl.d_off, sl.d_recs, sl.d_cig, sl.d_codes, sl.d_len, sl.d_odd, sl.d_err};
+        void *q[] = {sl.d_bases, sl.d_off, sl.d_recs, sl.d_cig, sl.d_codes, sl.d_len, sl.d_odd, sl.d_err, sl.d_recs32};
         for (void *x : q) if (x) (void)hipFree(x);
         for (hipEvent_t e : {sl.in_ready, sl.mapped, sl.out_done}) if (e) (void)hipEventDestroy(e);
     }
@@ -3682,7 +3683,47 @@ extern "C" int mcx_stream_mapped(mcx_ctx *c, mcx_aln *aln, uint32_t *cigar)
     return 0;
 }
 
-extern "C" int mcx_stream_map(mcx_ctx *c, int paired, int64_t avg[4], mcx_aln *aln, uint32_t *cigar, mcx_stats *stats)
+// the records of a mapped batch in 32 bytes each (mcx_aln32, include/mcx.h) for their way to the host
+__global__ void __launch_bounds__(256) k_pack_recs(const AlnRec *recs, uint32_t n, mcx_aln32 *out)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const AlnRec a = recs[r];
+    mcx_aln32 o;
+    o.pos_lo = (uint32_t)a.pos; o.pos_hi = (uint8_t)((uint64_t)a.pos >> 32); o.mate_lo = (uint32_t)a.mate_pos; o.mate_hi = (uint8_t)((uint64_t)a.mate_pos >> 32);
+    o.mapq = (uint8_t)a.mapq; o.bits = (uint8_t)((a.fwd ? 1 : 0) | (a.has_mate ? 2 : 0)); o.tlen = a.tlen; o.flag = (uint16_t)a.flag;
+    o.chr = a.chr < 0 ? (uint16_t)0xFFFFu : (uint16_t)a.chr; o.nm = (int16_t)a.nm; o.as = (int16_t)a.as; o.xs = (int16_t)a.xs;
+    o.n_cigar = (uint16_t)a.n_cigar; o.cigar_off = (uint32_t)a.pad[0];
+    ((U4 *)out)[2 * (uint64_t)r] = ((const U4 *)&o)[0]; ((U4 *)out)[2 * (uint64_t)r + 1] = ((const U4 *)&o)[1];
+}
+
+extern "C" int mcx_stream_mapped32(mcx_ctx *c, mcx_aln32 *aln, uint32_t *cigar)
+{
+    static_assert(sizeof(mcx_aln32) == 32, "mcx_aln32 is two 16-byte words");
+    if (!c || !aln || !cigar) return fail(MCX_ERR_ARG, "mcx_stream_mapped32: null argument");
+    HIP_TRY(hipSetDevice(c->idx->device));
+    mcx_ctx::Slot *sl = oldest_slot(c, 2);
+    if (!sl) return fail(MCX_ERR_ARG, "mcx_stream_mapped32: no batch is being mapped");
+    if (c->idx->view.n_chr >= 0xFFFF || (c->idx->view.G2 >> 40)) return fail(MCX_ERR_UNSUPPORTED, "mcx_stream_mapped32: more than 65534 contigs or positions beyond 2^40 (use mcx_stream_mapped)");
+    int rc;
+    if (!sl->d_recs32 && (rc = dmalloc(&sl->d_recs32, c->max_reads))) return rc;
+    k_pack_recs<<<(sl->n_reads + 255) / 256, 256, 0, c->stream>>>(sl->d_recs, sl->n_reads, sl->d_recs32); // (a read's operations are at most MCX_CIGAR_STRIDE x the pool's slack: far below 2^16)
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(sl->mapped, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->d2h_stream, sl->mapped, 0));
+    const size_t rec_bytes = (size_t)sl->n_reads * sizeof(mcx_aln32), cig_bytes = (size_t)c->run.cig_words * 4; // (the pool's used words only)
+    if ((rc = bulk_copy(c, aln, sl->d_recs32, rec_bytes, hipMemcpyDeviceToHost, c->d2h_stream))) return rc;
+    if ((rc = bulk_copy(c, cigar, sl->d_cig, cig_bytes, hipMemcpyDeviceToHost, c->d2h_stream))) return rc;
+    HIP_TRY(hipEventRecord(sl->out_done, c->d2h_stream));
+    sl->state = 3;
+    c->stream_bytes_out += rec_bytes + cig_bytes;
+    return 0;
+}
+
+static int stream_map(mcx_ctx *c, int paired, int64_t avg[4], mcx_aln *aln, mcx_aln32 *aln32, uint32_t *cigar, mcx_stats *stats);
+extern "C" int mcx_stream_map32(mcx_ctx *c, int paired, int64_t avg[4], mcx_aln32 *aln, uint32_t *cigar, mcx_stats *stats) { return stream_map(c, paired, avg, nullptr, aln, cigar, stats); }
+extern "C" int mcx_stream_map(mcx_ctx *c, int paired, int64_t avg[4], mcx_aln *aln, uint32_t *cigar, mcx_stats *stats) { return stream_map(c, paired, avg, aln, nullptr, cigar, stats); }
+static int stream_map(mcx_ctx *c, int paired, int64_t avg[4], mcx_aln *aln, mcx_aln32 *aln32, uint32_t *cigar, mcx_stats *stats)
 {
     const uint8_t *d_bases; const uint32_t *d_off; mcx_aln *d_aln; uint32_t *d_cig; uint32_t n = 0;
     int rc = mcx_stream_next(c, &d_bases, &d_off, &n, &d_aln, &d_cig);
@@ -3695,7 +3736,7 @@ extern "C" int mcx_stream_map(mcx_ctx *c, int paired, int64_t avg[4], mcx_aln *a
         if (err) rc = fail(MCX_ERR_ARG, (err & 1u) ? "mcx_stream_submit_packed: a read is longer than its row / max_read_len" : "batch holds more bases than max_batch_reads * max_read_len");
     }
     if (rc) { sl->state = 0; return rc; }
-    return mcx_stream_mapped(c, aln, cigar);
+    return aln32 ? mcx_stream_mapped32(c, aln32, cigar) : mcx_stream_mapped(c, aln, cigar);
 }
 
 extern "C" int mcx_stream_collect(mcx_ctx *c, uint64_t *bytes_in, uint64_t *bytes_out)

@@ -196,17 +196,18 @@ def test_packed_host_boundary_gives_the_same_records(api, golden, tmp_path):
         to = torch.tensor(odd if odd else [0], dtype=torch.int64).pin_memory()
         packed.append((tw, row_words, tl, to, len(odd)))
     assert sum(p[4] for p in packed) > 50
-    outs = [(torch.zeros(2 * n_pairs * 64, dtype=torch.uint8).pin_memory(), torch.zeros(api.cigar_pool_words(2 * n_pairs), dtype=torch.int32).pin_memory()) for _ in range(per)]
+    # (the records leave HBM as mcx_aln32 — 32 bytes each, packed on the device — and are unpacked here as mcx_aln_unpack does)
+    outs = [(torch.zeros(2 * n_pairs * 32, dtype=torch.uint8).pin_memory(), torch.zeros(api.cigar_pool_words(2 * n_pairs), dtype=torch.int32).pin_memory()) for _ in range(per)]
     for i in range(per + 2):
         if i < per:
             tw, row_words, tl, to, n_odd = packed[i]
             assert L.mcx_stream_submit_packed(mp._h, tw.data_ptr(), row_words, tl.data_ptr(), 2 * n_pairs, to.data_ptr(), n_odd) == 0, L.mcx_last_error()
         if 1 <= i <= per:
-            assert L.mcx_stream_map(mp._h, 1, mp.avg, outs[i - 1][0].data_ptr(), outs[i - 1][1].data_ptr(), C.byref(mp.stats)) == 0, L.mcx_last_error()
+            assert L.mcx_stream_map32(mp._h, 1, mp.avg, outs[i - 1][0].data_ptr(), outs[i - 1][1].data_ptr(), C.byref(mp.stats)) == 0, L.mcx_last_error()
         if i >= 2:
             assert L.mcx_stream_collect(mp._h, None, None) == 0, L.mcx_last_error()
     for b in range(per):
-        aln = np.frombuffer(outs[b][0].numpy().tobytes(), dtype=api.ALN_DTYPE)
+        aln = api.aln32_unpack(np.frombuffer(outs[b][0].numpy().tobytes(), dtype=api.ALN32_DTYPE))
         pool = outs[b][1].numpy().view(np.uint32)
         w_aln, w_cig = want[b]
         for f in ("pos", "mate_pos", "chr", "flag", "mapq", "tlen", "nm", "as", "xs", "n_cigar", "fwd", "has_mate"):
@@ -219,10 +220,10 @@ def test_packed_host_boundary_gives_the_same_records(api, golden, tmp_path):
     bad = tl.clone(); bad[7] = row_words * 16 + 1
     bad = bad.pin_memory()
     assert L.mcx_stream_submit_packed(mp._h, tw.data_ptr(), row_words, bad.data_ptr(), 2 * n_pairs, to.data_ptr(), n_odd) == 0, L.mcx_last_error()
-    assert L.mcx_stream_map(mp._h, 1, mp.avg, outs[0][0].data_ptr(), outs[0][1].data_ptr(), C.byref(mp.stats)) != 0
+    assert L.mcx_stream_map32(mp._h, 1, mp.avg, outs[0][0].data_ptr(), outs[0][1].data_ptr(), C.byref(mp.stats)) != 0
     assert b"longer than its row" in L.mcx_last_error()
     assert L.mcx_stream_submit_packed(mp._h, tw.data_ptr(), row_words, tl.data_ptr(), 2 * n_pairs, to.data_ptr(), n_odd) == 0, L.mcx_last_error()
-    assert L.mcx_stream_map(mp._h, 1, mp.avg, outs[0][0].data_ptr(), outs[0][1].data_ptr(), C.byref(mp.stats)) == 0, L.mcx_last_error()
+    assert L.mcx_stream_map32(mp._h, 1, mp.avg, outs[0][0].data_ptr(), outs[0][1].data_ptr(), C.byref(mp.stats)) == 0, L.mcx_last_error()
     assert L.mcx_stream_collect(mp._h, None, None) == 0, L.mcx_last_error()
     mp.close(); ix.close()
 
