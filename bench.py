@@ -264,6 +264,13 @@ def pcie_inclusive(args, mapper, batches, reads_per_step, dist, dev):
     for b in batches[:min(k, len(batches))]:
         words, lens, odd, n_odd, row_words = api.pack_reads(b.reshape(reads_per_step, args.rlen))
         host.append((words, lens, odd, n_odd, row_words))
+    nd = getattr(args, "native_dir", None)
+    if nd:  # the same batches for the process on the system's runtime (native_boundary below)
+        meta = json.load(open(os.path.join(nd, "meta.json")))
+        meta["batches"] = [{"row_words": rw, "n_odd": n} for (_, _, _, n, rw) in host]
+        for i, (w, l, o, _, _) in enumerate(host):
+            w.numpy().tofile(os.path.join(nd, f"batch{i}.words")); l.numpy().tofile(os.path.join(nd, f"batch{i}.lens")); o.numpy().tofile(os.path.join(nd, f"batch{i}.odd"))
+        json.dump(meta, open(os.path.join(nd, "meta.json"), "w"))
     packed = [(w.data_ptr(), rw, l.data_ptr(), o.data_ptr(), n) for (w, l, o, n, rw) in host]
     packed = [packed[i % len(packed)] for i in range(k)]  # (more steps than resident batches: the batches come round again)
     outs = mapper.stream_outputs(reads_per_step, 3, 32)  # (page-locking gigabytes takes seconds: not part of the path)
@@ -284,6 +291,21 @@ def pcie_inclusive(args, mapper, batches, reads_per_step, dist, dev):
                     "the host waits for nothing, and the step took 20.5 instead of 17.3 ms) + CIGAR pool back to pinned host memory; copies of batch i+1 / i-1 overlap the kernels "
                     "of batch i on separate HIP streams (mcx_stream_*); the first copy in and the last copy out of the sequence have nothing to "
                     "hide behind and are part of the time (about 18 ms per sequence at 8 M reads a step)"}
+
+
+def native_boundary(args, in_process):
+    """value_pcie_inclusive's steps from a process that runs on the system's HIP runtime (python -m mapcaller_amd.boundary: libmcx.so through
+    ctypes, no torch) — the situation of a C/C++ host: the CLI, the reference with INTEGRATION.md's binding.  This process has let go of the GPU's memory."""
+    r = subprocess.run([sys.executable, "-m", "mapcaller_amd.boundary", args.native_dir], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.abspath(__file__)))
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if not lines:
+        return {"error": (r.stderr or r.stdout)[-300:]}
+    o = json.loads(lines[-1])
+    o["note"] = ("the same batches, steps and buffers as value_pcie_inclusive from a process of its own on the system's HIP runtime (%s; this process runs on the one torch's wheel carries, "
+                 "%s, which puts the copies of both directions on one SDMA engine: 320 MB in + 256 MB out take 10.6 ms together there, 5.96 ms on the system's — "
+                 "scripts/probe/d2h_probe.*); in-process figure: %s ms per step" % (o.get("hip_runtime_version"), torch.version.hip, in_process.get("ms_per_step") if in_process else None))
+    return o
 
 
 def file_to_file(args, index, kept, reads_per_step):
@@ -490,7 +512,9 @@ def parse():
                     help="repeat content of the synthetic genome: a human-like landscape (default) or round 1's nearly repeat-free one")
     ap.add_argument("--second-genome", type=int, default=1,
                     help="1: after the main run, map 2 steps against the other kind of genome as well and report them under `other_genome`")
-    ap.add_argument("--pcie-steps", type=int, default=18, help="steps of the host-buffer leg (value_pcie_inclusive), over the timed region's batches in turn; 0 = skip")
+    ap.add_argument("--native-boundary", type=int, default=1, help="the host-buffer leg once more from a process on the system's HIP runtime (mapcaller_amd/boundary.py: no torch in it), "
+                                                                   "after this one has let go of the GPU's memory; N = 1 only; 0 = skip")
+    ap.add_argument("--pcie-steps", type=int, default=36, help="steps of the host-buffer leg (value_pcie_inclusive), over the timed region's batches in turn; 0 = skip")
     ap.add_argument("--single-end", type=int, default=0, help="1: single-end reads (--batch-pairs then counts reads)")
     ap.add_argument("--other-configs", type=int, default=1,
                     help="1: after the main run, BASELINE.json's configs 5 (250 bp PE at 5 %% indels, -alg nw) and 2 (E. coli-sized genome, 1 M x 100 bp SE) "
@@ -844,6 +868,15 @@ def main():
 
     # ---- set-up (not timed): genome, index, reads ------------------------------------------------
     codes, lens, genome_note = make_genome(args, dev, seed=1234)
+    native_dir = None
+    if args.native_boundary and args.pcie_steps > 0 and world == 1 and not args.single_end and os.path.isdir("/dev/shm"):
+        native_dir = tempfile.mkdtemp(prefix="mcx_boundary_", dir="/dev/shm")  # what the other process's run is made of: the genome now, the packed batches by pcie_inclusive
+        args.native_dir = native_dir
+        import atexit
+        atexit.register(shutil.rmtree, native_dir, True)
+        codes.cpu().numpy().tofile(os.path.join(native_dir, "genome.u8"))
+        json.dump({"chr_lens": [int(x) for x in lens], "alg": args.alg, "rlen": args.rlen, "reads": 2 * args.batch_pairs, "steps": args.pcie_steps, "full_sa": int(args.full_sa)},
+                  open(os.path.join(native_dir, "meta.json"), "w"))
     t0 = time.perf_counter()
     index = api.Index.from_codes(codes.data_ptr(), lens, device=local, full_sa=int(args.full_sa))
     t_index = time.perf_counter() - t0
@@ -984,7 +1017,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, index, sample)
             except Exception as e:  # the baseline must never take the bench line down
                 out["cpu_baseline"] = {"error": str(e)[:200]}
-        if (args.second_genome or args.other_configs) and world == 1:
+        nd = getattr(args, "native_dir", None)
+        if (args.second_genome or args.other_configs or nd) and world == 1:
             try:
                 if mapper is not None:
                     mapper.close()
@@ -994,6 +1028,11 @@ def main():
                 torch.cuda.empty_cache()
             except Exception:
                 pass
+            if nd and pcie is not None and "error" not in pcie:
+                try:
+                    pcie["system_runtime"] = native_boundary(args, pcie)
+                except Exception as e:
+                    pcie["system_runtime"] = {"error": str(e)[:200]}
             if args.second_genome:
                 try:
                     out["other_genome"] = other_genome(args)

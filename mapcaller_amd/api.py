@@ -253,10 +253,11 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    try:  # torch bundles its own HIP runtime: let it load first so that both share one copy
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    if not os.environ.get("MCX_NO_TORCH"):  # (a host without torch in it — mapcaller_amd/boundary.py — runs on the system's runtime, which libmcx.so links)
+        try:  # torch bundles its own HIP runtime: let it load first so that both share one copy
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise McxError(f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')")
     L = C.CDLL(LIB_PATH)

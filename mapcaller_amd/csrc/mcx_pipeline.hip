@@ -3483,7 +3483,9 @@ static int bulk_copy(mcx_ctx *c, void *dst, const void *src, size_t bytes, hipMe
     if (bytes == 0) return 0;
     // (MCX_STREAM_KERNEL_COPY: this library's own copy kernel over the mapped host memory instead of the runtime's copies — round 5 tried it for the way out
     //  alone, on grids of 16 / 48 / 128 workgroups, next to the mapping kernels: 23.7 / 26.1 / 27.2 ms per step against the runtime's 20.6)
-    static const bool use_dma = getenv("MCX_STREAM_KERNEL_COPY") == nullptr;
+    static const char *mode = getenv("MCX_STREAM_KERNEL_COPY"); // ("in" / "out": one direction alone)
+    static const int blocks = getenv("MCX_COPY_BLOCKS") ? atoi(getenv("MCX_COPY_BLOCKS")) : 512;
+    const bool use_dma = mode == nullptr || (!strcmp(mode, "in") && kind != hipMemcpyHostToDevice) || (!strcmp(mode, "out") && kind != hipMemcpyDeviceToHost);
     const size_t n16 = bytes / 16;
     bool mapped = false; // is the host side page-locked memory the device can address?
     {
@@ -3493,7 +3495,7 @@ static int bulk_copy(mcx_ctx *c, void *dst, const void *src, size_t bytes, hipMe
         else (void)hipGetLastError();
     }
     if (use_dma || !mapped || n16 == 0 || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) { HIP_TRY(hipMemcpyAsync(dst, src, bytes, kind, s)); return 0; }
-    k_copy16<<<512, 256, 0, s>>>((const U4 *)src, (U4 *)dst, (uint64_t)n16);
+    k_copy16<<<blocks, 256, 0, s>>>((const U4 *)src, (U4 *)dst, (uint64_t)n16);
     HIP_TRY(hipGetLastError());
     if (bytes & 15) HIP_TRY(hipMemcpyAsync((uint8_t *)dst + n16 * 16, (const uint8_t *)src + n16 * 16, bytes & 15, kind, s));
     (void)c;
