@@ -340,6 +340,7 @@ def file_to_file(args, index, kept, reads_per_step):
                "without_sam_output": {"value": round(st["reads"] / t_in, 1), "seconds": round(t_in, 4),
                                       "note": "FASTQ files in, records left in host memory: parse + pack + copies + mapping; the difference is SAM text and its way into ONE "
                                               "file (the kernel serialises writes to a file: tmpfs took 4 GB/s from 64 threads, 3 GB of text per 8 M reads)"},
+               "device_stage_ms_per_batch": {k[3:]: round(st[k] / max(1, -(-st["reads"] // args.file_batch_reads)), 3) for k in st if k.startswith("ms_")},
                "fastq_bytes": os.path.getsize(f1) + os.path.getsize(f2), "sam_bytes": os.path.getsize(sam), "batch_reads": args.file_batch_reads,
                "host_threads": args.file_threads or "default (min(64, cores / 2) per pool)", "where": tmp.rsplit("/", 1)[0],
                "batches_of_the_timed_region": len(kept),
@@ -703,16 +704,55 @@ def cpu_prepare(args, index, bases_sample):
     return st
 
 
+def usable_cpus():
+    """The CPUs this process is given: the affinity mask cut by the cgroup's CPU-time share (cpu.max — the bench box says 1600000 100000 on a machine
+    of 256 hardware threads: sixteen; what runs beyond the share is put to sleep for the rest of each 100 ms period).  mcx_cpus.h does the same for the library's host threads."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    share = None
+    own = ""
+    try:
+        for line in open("/proc/self/cgroup"):
+            if line.startswith("0::"):
+                own = line[3:].strip()
+    except OSError:
+        pass
+    p = own
+    while True:
+        for f in ("/sys/fs/cgroup" + p + "/cpu.max",):
+            try:
+                q, per = open(f).read().split()[:2]
+                if q != "max" and float(per) > 0:
+                    share = min(share, float(q) / float(per)) if share else float(q) / float(per)
+            except (OSError, ValueError):
+                pass
+        if p in ("", "/"):
+            break
+        p = p[:p.rfind("/")]
+    try:
+        q, per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            share = min(share, q / per) if share else q / per
+    except (OSError, ValueError):
+        pass
+    if share:
+        n = min(n, max(1, int(share + 0.5)))
+    return max(1, n)
+
+
 def cpu_run(st):
     """The CPU path on this box's host cores, on a bounded sample of the same workload, index load excluded (the reference
-    starts its clock after loading, main.cpp:376).  At -t <all cores>: with `-sam <file>` (the reference then formats every line and
+    starts its clock after loading, main.cpp:376).  At -t <the CPUs the box gives, usable_cpus()>: with `-sam <file>` (the reference then formats every line and
     pushes it through fprintf under its OutputLock, ReadMapping.cpp:536-560) and — level "two" / "full" — without any output (`-no_vcf`, no
     `-sam`: bSAMoutput stays false, :536 is skipped): `mapping_only`, the like-for-like figure beside `value`, which times kernels and writes
     no text either.  Level "full" (the default) adds a -t 1 run on about 20 s worth of pairs (--cpu-t1-pairs); for the GRCh38-sized
     index every run of the reference spends ~45 s loading it: three runs, about three minutes of the default line."""
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "MapCaller")
     port_bin = os.path.join(ROOT, "oracle", "mcx_oracle")
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()  # (-t <what the box gives>: at -t <hardware threads> under a CPU-time share the reference spends most of each period asleep)
     tmp, prefix, se, step, n_pairs, alg = st["tmp"], st["prefix"], st["se"], st["step"], st["n_pairs"], st["alg"]
     fq = lambda tag: (os.path.join(tmp, tag + "1.fq"), os.path.join(tmp, tag + "2.fq"))
     if os.path.exists(ref_bin):
@@ -748,9 +788,9 @@ def cpu_run(st):
         return round(reps * step * n_pairs / dt, 1), how
     v_sam, how_sam = rate(True, fq("r"))
     what = f"{n_pairs} {'reads' if se else 'pairs'} x {st['rlen']} bp of the same synthetic workload, -t {cores} -alg {alg}"
-    out = {"value": v_sam, "unit": "reads/s", "cores": cores, "kind": kind, "sample": f"{what} -sam (file) -no_vcf; {how_sam}",
-           "note": "at this thread count the reference is bound by its LibraryLock reader (GetData.cpp:85-140 under ReadMapping.cpp:440), not by its output: with -sam and "
-                   "without it give the same rate; its clock prints whole seconds (+-1 s of the figure above)"}
+    out = {"value": v_sam, "unit": "reads/s", "cores": cores, "hardware_threads": os.cpu_count(), "kind": kind, "sample": f"{what} -sam (file) -no_vcf; {how_sam}",
+           "note": "-t = the CPUs the box gives this process (usable_cpus(): affinity and the cgroup's CPU-time share; the machine has %d hardware threads) — rounds 1-4 ran it at "
+                   "-t <hardware threads>, which a CPU-time share turns into sleeping; its clock prints whole seconds (+-1 s of the figure above)" % (os.cpu_count() or 1)}
     if kind == "reference" and st["level"] in ("two", "full"):
         v_map, how_map = rate(False, fq("r"))
         out["mapping_only"] = {"value": v_map, "unit": "reads/s", "cores": cores,
@@ -892,7 +932,7 @@ def main():
     off = (torch.arange(reads_per_step + 1, device=dev, dtype=torch.int64) * args.rlen).to(torch.uint32)
     cpu_pairs = args.cpu_pairs
     if cpu_pairs < 0:  # ~20 s of the reference's clock: 15 k reads/s a core up to ~16 cores, ~240 k reads/s beyond (its locks), bounded by one batch
-        cpu_pairs = int(min(args.batch_pairs, max(50_000, min((os.cpu_count() or 1) * 15_000, 240_000) * 20 // 2)))
+        cpu_pairs = int(min(args.batch_pairs, max(50_000, min(usable_cpus() * 15_000, 240_000) * 20 // 2)))
     sample = None
     if rank == 0 and world == 1 and cpu_pairs:
         per = 2 if paired else 1

@@ -40,9 +40,11 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <immintrin.h>
 
 #include "../../include/mcx.h"
 #include "mcx_internal.h"
+#include "mcx_cpus.h"
 
 using namespace mcx;
 
@@ -133,9 +135,29 @@ struct Rec {
     uint32_t rlen, q_take;  // q_take: bytes of the quality line that count (min(line, rlen), GetData.cpp:51-52; printed up to a NUL)
     uint32_t name_len;
 };
+// the records of a View: plain memory that is not cleared when it is handed out (a batch object's 40 MB of them would be written twice)
+class RecBuf {
+public:
+    RecBuf() {}
+    RecBuf(const RecBuf &) = delete;
+    RecBuf &operator=(const RecBuf &) = delete;
+    ~RecBuf() { free(p_); }
+    size_t size() const { return n_; }
+    void clear() { n_ = 0; }
+    bool reserve(size_t n) { if (n > cap_) { Rec *q = (Rec *)realloc(p_, n * sizeof(Rec)); if (!q) return false; p_ = q; cap_ = n; } return true; }
+    void resize(size_t n) { if (reserve(n)) n_ = n; } // (new entries are the caller's to write)
+    void push_back(const Rec &r) { if (n_ == cap_ && !reserve(cap_ ? cap_ * 2 : 4096)) return; p_[n_++] = r; }
+    Rec &operator[](size_t i) { return p_[i]; }
+    const Rec &operator[](size_t i) const { return p_[i]; }
+    Rec *data() { return p_; }
+    const Rec *begin() const { return p_; }
+    const Rec *end() const { return p_ + n_; }
+private:
+    Rec *p_ = nullptr; size_t n_ = 0, cap_ = 0;
+};
 struct View { // the reads of one file for one batch
     const char *base = nullptr;
-    std::vector<Rec> recs;
+    RecBuf recs;
     std::vector<char> own;  // .gz / FASTA: the batch's copy of names, bases, qualities
     bool last = false;      // the file ended (or delivered an empty read) after these
     std::string error;
@@ -153,25 +175,47 @@ inline void header_of(const char *l, int len, int &p1, int &p2)
 }
 
 // 2-bit row for mcx_stream_submit_packed: sixteen bases to a word, the first on top; bytes that are not ACGT are listed
-inline void pack_row(const uint8_t *seq, uint32_t rlen, uint32_t read, uint32_t *row, uint32_t row_words, std::vector<uint64_t> &odd)
+inline uint32_t pack_word(const uint8_t *seq, uint32_t i, uint32_t n, uint32_t read, std::vector<uint64_t> &odd) // bases [i, i + n), n <= 16
 {
     static const struct Lut { uint8_t v[256]; Lut() { memset(v, 4, sizeof v); v['A'] = 0; v['C'] = 1; v['G'] = 2; v['T'] = 3; } } lut;
-    uint32_t k = 0;
-    for (uint32_t i = 0; i < rlen; i += 16, k++) {
-        const uint32_t n = rlen - i < 16 ? rlen - i : 16;
-        uint32_t w = 0, bad = 0;
-        for (uint32_t j = 0; j < n; j++) { const uint32_t c = lut.v[seq[i + j]]; bad |= c; w |= (c & 3u) << (30 - 2 * j); }
-        if (bad & 4u) {
-            w = 0;
-            for (uint32_t j = 0; j < n; j++) {
-                const uint32_t c = lut.v[seq[i + j]];
-                if (c > 3) odd.push_back(((uint64_t)read << 32) | ((uint64_t)(i + j) << 8) | seq[i + j]);
-                else w |= c << (30 - 2 * j);
-            }
+    uint32_t w = 0, bad = 0;
+    for (uint32_t j = 0; j < n; j++) { const uint32_t c = lut.v[seq[i + j]]; bad |= c; w |= (c & 3u) << (30 - 2 * j); }
+    if (bad & 4u) {
+        w = 0;
+        for (uint32_t j = 0; j < n; j++) {
+            const uint32_t c = lut.v[seq[i + j]];
+            if (c > 3) odd.push_back(((uint64_t)read << 32) | ((uint64_t)(i + j) << 8) | seq[i + j]);
+            else w |= c << (30 - 2 * j);
         }
-        row[k] = w;
     }
+    return w;
+}
+inline void pack_row_plain(const uint8_t *seq, uint32_t rlen, uint32_t read, uint32_t *row, uint32_t row_words, std::vector<uint64_t> &odd)
+{
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < rlen; i += 16, k++) row[k] = pack_word(seq, i, rlen - i < 16 ? rlen - i : 16, read, odd);
     for (; k < row_words; k++) row[k] = 0;
+}
+// the same sixteen bases at a time: of A C G T, ((c >> 1) ^ (c >> 2)) & 3 is the code; the two-bit fields gathered by pext
+__attribute__((target("sse2,bmi2"))) inline void pack_row_bmi2(const uint8_t *seq, uint32_t rlen, uint32_t read, uint32_t *row, uint32_t row_words, std::vector<uint64_t> &odd)
+{
+    const __m128i cA = _mm_set1_epi8('A'), cC = _mm_set1_epi8('C'), cG = _mm_set1_epi8('G'), cT = _mm_set1_epi8('T'), three = _mm_set1_epi8(3);
+    uint32_t k = 0, i = 0;
+    for (; i + 16 <= rlen; i += 16, k++) {
+        const __m128i c = _mm_loadu_si128((const __m128i *)(seq + i));
+        const __m128i known = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(c, cA), _mm_cmpeq_epi8(c, cC)), _mm_or_si128(_mm_cmpeq_epi8(c, cG), _mm_cmpeq_epi8(c, cT)));
+        if (_mm_movemask_epi8(known) != 0xFFFF) { row[k] = pack_word(seq, i, 16, read, odd); continue; }
+        const __m128i code = _mm_and_si128(_mm_xor_si128(_mm_srli_epi16(c, 1), _mm_srli_epi16(c, 2)), three); // (what the 16-bit shifts carry across bytes lands above bit 1)
+        const uint64_t lo = (uint64_t)_mm_cvtsi128_si64(code), hi = (uint64_t)_mm_cvtsi128_si64(_mm_unpackhi_epi64(code, code));
+        row[k] = ((uint32_t)_pext_u64(__builtin_bswap64(lo), 0x0303030303030303ull) << 16) | (uint32_t)_pext_u64(__builtin_bswap64(hi), 0x0303030303030303ull);
+    }
+    if (i < rlen) { row[k++] = pack_word(seq, i, rlen - i, read, odd); }
+    for (; k < row_words; k++) row[k] = 0;
+}
+inline void pack_row(const uint8_t *seq, uint32_t rlen, uint32_t read, uint32_t *row, uint32_t row_words, std::vector<uint64_t> &odd)
+{
+    static const bool wide = __builtin_cpu_supports("bmi2") && !getenv("MCX_PLAIN_PACK");
+    if (wide) pack_row_bmi2(seq, rlen, read, row, row_words, odd); else pack_row_plain(seq, rlen, read, row, row_words, odd);
 }
 
 // A plain FASTQ file in memory, with the line count ahead of every 64 KB of it: record r begins at line 4 r.
@@ -195,6 +239,7 @@ public:
         return true;
     }
     const char *data() const { return map_; }
+    size_t bytes() const { return size_; }
     size_t n_blocks() const { return n_blocks_; }
     // newlines of blocks [b0, b1) (the shards of a run count a share each and tell one another)
     void count(size_t b0, size_t b1, Pool &pool)
@@ -230,9 +275,10 @@ public:
         while (need) { const char *q = (const char *)memchr(p, '\n', (size_t)(e - p)); if (!q) return size_; p = q + 1; need--; }
         return (size_t)(p - map_);
     }
-    // Records [r0, r1) appended to recs; stops like GetNextEntry at a missing sequence line or an empty read (false then).
-    bool parse(uint64_t r0, uint64_t r1, int max_len, std::vector<Rec> &recs, std::string &err) const
+    // Records [r0, r1) into out[0 ..), their number in n_out; stops like GetNextEntry at a missing sequence line or an empty read (false then).
+    bool parse(uint64_t r0, uint64_t r1, int max_len, Rec *out, size_t &n_out, std::string &err) const
     {
+        n_out = 0;
         size_t p = line_start(4 * r0);
         auto line = [&](const char *&l, size_t &len) { // the next line with its '\n' (getline); false at the end of the file
             if (p >= size_) return false;
@@ -257,7 +303,7 @@ public:
             rec.qual = (uint64_t)(q - map_); rec.q_take = (uint32_t)std::min<size_t>(ql, rec.rlen);
             if (rec.rlen == 0) return false; // `.rlen == 0` ends the input (GetData.cpp:91)
             if ((int)rec.rlen > max_len) { err = "read " + std::string(map_ + rec.name, rec.name_len) + " is longer than max_read_len"; return false; }
-            recs.push_back(rec);
+            out[n_out++] = rec;
         }
         return true;
     }
@@ -374,7 +420,7 @@ private:
     }
     void feed_bgzf()
     {
-        Pool pool((int)std::max(2u, std::min(8u, std::thread::hardware_concurrency() / 8)));
+        Pool pool((int)std::max(2u, std::min(8u, mcx_usable_cpus() / 4)));
         struct Task { const uint8_t *src; uint32_t clen, isize, crc; size_t dst; };
         std::vector<Task> tasks;
         size_t o = 0;
@@ -836,7 +882,9 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
     const bool paired = two || opt.interleaved_pairs;
     const uint64_t shard_count = opt.shard_count > 1 ? (uint64_t)opt.shard_count : 1, shard_rank = shard_count > 1 ? (uint64_t)opt.shard_rank : 0;
     const bool sharded = shard_count > 1;
-    int threads = opt.host_threads > 0 ? opt.host_threads : (int)std::min<unsigned>(64, std::max<unsigned>(1, std::thread::hardware_concurrency() / 2));
+    // (two pools of this size — parse + pack, format — beside the mapper's and the writer's threads: three quarters of the CPUs the process may use each;
+    //  the pools take turns more than they overlap.  On the bench box's 16-CPU share: 6 / 8 / 12 / 16 / 24 / 64 threads a pool -> 10.6 / 10.9 / 13.2 / 12.2 / 10.9 / 10.2 M reads/s to SAM)
+    int threads = opt.host_threads > 0 ? opt.host_threads : (int)std::min<unsigned>(64, std::max<unsigned>(1, mcx_usable_cpus() * 3 / 4));
     std::string err;
     Shards sh;
     const uint64_t batch_reads = std::max<uint64_t>(kReadChunkSize, mcx_ctx_max_reads(c) / kReadChunkSize * kReadChunkSize);
@@ -858,6 +906,8 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
         return ch == '@'; // CheckReadFormat, GetData.cpp:22-31
     };
     const bool mapped_input = plain_fastq(fq1) && (!two || plain_fastq(fq2));
+    const Tick t_begin = now();
+    double w_open = 0, w_first_parsed = 0, w_reader = 0, w_mapped = 0, w_first_mapped = 0; // wall seconds since t_begin (MCX_TIMING)
     Pool pool(threads);        // parse + pack
     Pool fpool(threads);       // format + write (threads of its own: the two stages overlap)
     MappedFastq mf[2];
@@ -931,9 +981,11 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
     int64_t local_avg[4];
     mcx_avg_init(local_avg);
     int64_t *avg = opt.avg_state ? opt.avg_state : local_avg;
+    w_open = secs(t_begin, now());
 
     // busy seconds per stage (MCX_TIMING=1 prints them)
-    double t_parse = 0, t_map = 0, t_format = 0, t_write = 0, t_p_lines = 0, t_p_pack = 0, t_p_wait = 0;
+    double t_parse = 0, t_map = 0, t_format = 0, t_write = 0, t_p_lines = 0, t_p_pack = 0, t_p_wait = 0, t_p_push = 0, t_m_take = 0, t_m_collect = 0, t_f_push = 0, t_m_in = 0, t_m_dev = 0, t_m_out = 0, t_m_submit = 0;
+    std::vector<double> each_dev; // (MCX_TIMING) mcx_map_batch_dev, batch by batch
     typedef std::unique_ptr<Batch> BatchPtr;
     // batch objects circulate: their buffers (page-locked: slow to get) are allocated once and stay with the context from call to call
     // (one shard holds at most eleven at a time: two per queue between the stages, three on the device, one each in the reader's, the
@@ -968,31 +1020,43 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
             b->two_files = two; b->fastq = fastq; b->n = 0; b->last = false; b->error.clear(); b->number = number;
             b->in[0].clear(); b->in[1].clear(); b->n_odd[0] = b->n_odd[1] = 0; b->n_pair_reads = 0;
             if (mapped_input) {
+                // the records of both files in one pass of the pool, every share written where it belongs
                 const uint64_t r0 = number * per_file;
-                for (int f = 0; f < (two ? 2 : 1); f++) {
+                const int nf = two ? 2 : 1;
+                uint64_t cnt[2] = {0, 0}, r1[2] = {0, 0};
+                int parts[2] = {0, 0};
+                for (int f = 0; f < nf; f++) {
                     View &v = b->in[f];
                     v.base = mf[f].data();
-                    const uint64_t r1 = std::min<uint64_t>(r0 + per_file, total_recs[f]);
-                    const uint64_t cnt = r1 > r0 ? r1 - r0 : 0;
+                    r1[f] = std::min<uint64_t>(r0 + per_file, total_recs[f]);
+                    cnt[f] = r1[f] > r0 ? r1[f] - r0 : 0;
                     if (!mine) { v.last = true; continue; } // (the input ends inside another shard's batch: an empty batch carries the news)
-                    const int parts = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pool.size(), cnt / 2048));
-                    std::vector<std::vector<Rec>> part((size_t)parts);
-                    std::vector<std::string> perr((size_t)parts);
-                    std::vector<uint8_t> ok((size_t)parts, 1);
-                    pool.run(parts, [&](int k) {
-                        const uint64_t a = r0 + cnt * (uint64_t)k / (uint64_t)parts, z = r0 + cnt * (uint64_t)(k + 1) / (uint64_t)parts;
-                        part[(size_t)k].reserve((size_t)(z - a));
-                        ok[(size_t)k] = mf[f].parse(a, z, max_len, part[(size_t)k], perr[(size_t)k]) ? 1 : 0;
-                    });
-                    size_t total = 0;
-                    for (auto &p : part) total += p.size();
-                    v.recs.reserve(total);
+                    parts[f] = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pool.size(), cnt[f] / 2048));
+                    v.recs.resize((size_t)cnt[f]);
+                    if (v.recs.size() != cnt[f]) { v.error = "out of memory"; parts[f] = 0; }
+                }
+                const int all = parts[0] + parts[1];
+                std::vector<size_t> got((size_t)std::max(all, 1), 0);
+                std::vector<std::string> perr((size_t)std::max(all, 1));
+                std::vector<uint8_t> ok((size_t)std::max(all, 1), 1);
+                if (all) pool.run(all, [&](int t) {
+                    const int f = t < parts[0] ? 0 : 1, k = f ? t - parts[0] : t;
+                    const uint64_t a = cnt[f] * (uint64_t)k / (uint64_t)parts[f], z = cnt[f] * (uint64_t)(k + 1) / (uint64_t)parts[f];
+                    ok[(size_t)t] = mf[f].parse(r0 + a, r0 + z, max_len, b->in[f].recs.data() + a, got[(size_t)t], perr[(size_t)t]) ? 1 : 0;
+                });
+                for (int f = 0; f < nf; f++) {
+                    if (!parts[f]) continue;
+                    View &v = b->in[f];
                     bool stopped = false;
-                    for (int k = 0; k < parts && !stopped; k++) {
-                        v.recs.insert(v.recs.end(), part[(size_t)k].begin(), part[(size_t)k].end());
-                        if (!ok[(size_t)k]) { stopped = true; if (!perr[(size_t)k].empty()) v.error = perr[(size_t)k]; }
+                    for (int k = 0; k < parts[f] && !stopped; k++) {
+                        const size_t t = (size_t)(f ? parts[0] + k : k);
+                        if (!ok[t]) { // the records end inside this share: those before the stop count, nothing behind them
+                            stopped = true;
+                            if (!perr[t].empty()) v.error = perr[t];
+                            v.recs.resize((size_t)(cnt[f] * (uint64_t)k / (uint64_t)parts[f]) + got[t]);
+                        }
                     }
-                    v.last = stopped || cnt < per_file || r1 >= total_recs[f];
+                    v.last = stopped || cnt[f] < per_file || r1[f] >= total_recs[f];
                 }
             } else {
                 if (two) {
@@ -1026,7 +1090,16 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
                 if (paired && (n & 1)) npr = n / kReadChunkSize * kReadChunkSize;
                 b->n_pair_reads = npr;
                 uint32_t longest = 0;
-                for (int f = 0; f < (two ? 2 : 1); f++) for (const Rec &r : b->in[f].recs) longest = std::max(longest, r.rlen);
+                {
+                    const int slices = (int)std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)pool.size(), n / 4096));
+                    std::vector<uint32_t> most((size_t)slices, 0);
+                    pool.run(slices, [&](int k) {
+                        uint32_t m = 0;
+                        for (uint32_t r = (uint32_t)((uint64_t)n * k / slices); r < (uint32_t)((uint64_t)n * (k + 1) / slices); r++) { const char *base; m = std::max(m, b->rec(r, base).rlen); }
+                        most[(size_t)k] = m;
+                    });
+                    for (uint32_t m : most) longest = std::max(longest, m);
+                }
                 b->row_words = (longest + 15) / 16;
                 if (!b->reserve(std::max<size_t>(n, batch_reads), std::max<size_t>(b->row_words, ((size_t)max_len + 15) / 16))) b->error = "cannot allocate pinned host memory";
                 else {
@@ -1062,8 +1135,12 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
             b->last = done;
             t_p_pack += secs(tp, now());
             t_parse += secs(t0, now());
+            if (w_first_parsed == 0) w_first_parsed = secs(t_begin, now());
+            const Tick tq = now();
             parsed.push(std::move(b));
+            t_p_push += secs(tq, now());
         }
+        w_reader = secs(t_begin, now());
     });
 
     // ---- stage 3: format + write -------------------------------------------------------------------------------------
@@ -1080,8 +1157,10 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
                 std::vector<uint64_t> off(b->slices.size() + 1, at);
                 for (size_t k = 0; k < b->slices.size(); k++) off[k + 1] = off[k] + b->slices[k].size();
                 // Positioned writes, every slice at its final place, from this one thread: writers of one growing file queue up
-                // behind its lock and get in each other's way (tools/ubench_filewrite.cpp on the bench box's tmpfs: one thread
-                // 9 GB/s, two to thirty-two 3.5-4.2 GB/s; a mapping of the file's pages, 64 threads faulting them in: 1.3 GB/s).
+                // behind its lock and get in each other's way (tools/ubench_filewrite.cpp on the bench box's tmpfs, a gigabyte of source text:
+                // one thread 5.7 GB/s, two to sixteen 3.4-5.1; into pages that exist already 8.8 GB/s — but laying them out ahead of the
+                // writer with fallocate(KEEP_SIZE) from a thread of its own, 128 MB at a time, made runs slower as often as faster, 1.17 / 1.59 s
+                // against 1.31 / 1.28 for 6 GB of text: the two take the file's lock in turns; memcpy into a mapping of a sparse file 3.5-4.5 GB/s).
                 // MCX_SAM_MMAP=1 keeps the mapping path for file systems where it pays; the file then grows under a lock of its
                 // own and never shrinks: the other shards write further on.
                 bool done_w = false;
@@ -1166,9 +1245,11 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
                 });
                 for (const Text &t : b->slices) b->sam_bytes += t.size();
                 t_format += secs(t0, now());
-            } else b->slices.clear();
+            } else for (Text &t : b->slices) t.w = nullptr; // (no text of this batch; the buffers stay with the object)
             if (sharded && b->number % shard_count == shard_rank) places.put_size(b->number, b->sam_bytes); // (the other shards wait for the sizes of a round)
+            const Tick tq = now();
             formatted.push(std::move(b));
+            t_f_push += secs(tq, now());
         }
     });
 
@@ -1195,7 +1276,9 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
         return 0;
     };
     auto collect_oldest = [&]() -> int { // the oldest mapped part has arrived in host memory
+        const Tick tq = now();
         const int e = mcx_stream_collect(c, nullptr, nullptr);
+        t_m_collect += secs(tq, now());
         in_flight--;
         if (!leaving.empty() && --leaving_parts.front() == 0) { mapped.push(std::move(leaving.front())); leaving.pop_front(); leaving_parts.pop_front(); }
         return e;
@@ -1217,7 +1300,9 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
     auto take_next = [&](bool block) { // a parsed batch, its copy to the device started when there is room
         if (nxt || input_done) return;
         BatchPtr b;
+        const Tick tq = now();
         if (block) b = parsed.pop(); else if (!parsed.try_pop(b)) return;
+        t_m_take += secs(tq, now());
         if (b->last) input_done = true;
         if (rc == 0 && !b->error.empty()) rc = mcx_set_error(b->error.find("max_read_len") != std::string::npos ? MCX_ERR_UNSUPPORTED : MCX_ERR_IO, b->error);
         if (rc || ended) b->n = 0;
@@ -1227,7 +1312,9 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
         if (!nxt || nxt_in || rc) return;
         if (nxt->n == 0) { nxt_in = true; return; }
         if (in_flight + nxt->n_parts() > 3) return;
+        const Tick tq = now();
         const int e = submit(nxt.get());
+        t_m_submit += secs(tq, now());
         if (e) rc = e; else nxt_in = true;
     };
     for (;;) {
@@ -1246,14 +1333,16 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
         const uint32_t n_pr = cur_in ? p->n_pair_reads : 0u, n_sg = cur_in ? p->n - p->n_pair_reads : 0u;
         int parts_out = 0;
         const uint8_t *d_bases = nullptr; const uint32_t *d_off = nullptr; mcx_aln *d_aln = nullptr; uint32_t *d_cig = nullptr; uint32_t n_dev = 0;
-        auto part_in = [&]() { const int e = mcx_stream_next(c, &d_bases, &d_off, &n_dev, &d_aln, &d_cig); if (e && rc == 0) rc = e; return e == 0; };
+        auto part_in = [&]() { const Tick tq = now(); const int e = mcx_stream_next(c, &d_bases, &d_off, &n_dev, &d_aln, &d_cig); t_m_in += secs(tq, now()); if (e && rc == 0) rc = e; return e == 0; };
         auto part_out = [&](bool second) {
+            const Tick tq = now();
             const int e = second ? mcx_stream_mapped32(c, p->recs + p->n_pair_reads, p->cig + MCX_CIGAR_POOL_WORDS(p->n_pair_reads)) : mcx_stream_mapped32(c, p->recs, p->cig);
+            t_m_out += secs(tq, now());
             if (e && rc == 0) rc = e;
             if (e == 0) parts_out++;
         };
         if (!sharded) {
-            if (n_pr && part_in()) { if (rc == 0) rc = mcx_map_batch_dev(c, d_bases, d_off, n_pr, 1, avg, d_aln, d_cig, stats); part_out(false); }
+            if (n_pr && part_in()) { const Tick tq = now(); if (rc == 0) rc = mcx_map_batch_dev(c, d_bases, d_off, n_pr, 1, avg, d_aln, d_cig, stats); t_m_dev += secs(tq, now()); each_dev.push_back(secs(tq, now())); part_out(false); }
             if (n_sg && part_in()) { if (rc == 0) rc = mcx_map_batch_dev(c, d_bases, d_off, n_sg, 0, avg, d_aln, d_cig, stats); part_out(true); }
         } else if (!dead && !ended && p->number / shard_count >= rounds_done) {
             rounds_done = p->number / shard_count + 1;
@@ -1299,6 +1388,7 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
             p->n = 0;
         }
         if (p->n) t_map += secs(t1, now());
+        if (w_first_mapped == 0) w_first_mapped = secs(t_begin, now());
         if (rc) { p->n = 0; abort.store(true); places.fail(); }
         if (parts_out == 0) { // nothing on its way out: the batch goes on as it is, behind the ones that are
             while (!leaving.empty()) { const int e = collect_oldest(); if (e && rc == 0) rc = e; }
@@ -1315,13 +1405,22 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
         rounds_unplaced.pop_front();
     }
     if (rc) places.fail();
+    w_mapped = secs(t_begin, now());
     formatter.join();
     writer.join();
     reader.join();
     { BatchPtr b; while (spare.try_pop(b)) kept->objects.push_back(std::move(b)); while (parsed.try_pop(b)) kept->objects.push_back(std::move(b)); while (mapped.try_pop(b)) kept->objects.push_back(std::move(b)); }
+    if (getenv("MCX_TIMING")) {
+        std::string e;
+        for (size_t k = 0; k < each_dev.size() && k < 24; k++) e += " " + std::to_string((int)(each_dev[k] * 1e4) / 10.0).substr(0, 5);
+        fprintf(stderr, "[mcx_map_files] mcx_map_batch_dev, ms per batch:%s\n", e.c_str());
+    }
     if (getenv("MCX_TIMING"))
         fprintf(stderr, "[mcx_map_files] busy seconds: parse + pack %.3f (lines %.3f, rows %.3f; waited for a free batch %.3f) | map %.3f | format %.3f write %.3f  (%d + %d host threads, %s input)\n",
-                t_parse, t_p_lines, t_p_pack, t_p_wait, t_map, t_format, t_write, threads, threads, mapped_input ? "mapped" : "sequential");
+                t_parse, t_p_lines, t_p_pack, t_p_wait, t_map, t_format, t_write, threads, threads, mapped_input ? "mapped" : "sequential"),
+        fprintf(stderr, "[mcx_map_files] waits: reader for room behind it %.3f | mapper for a parsed batch %.3f, for copies out %.3f | formatter for the writer %.3f || mapper's calls: submit %.3f, next %.3f, map_batch_dev %.3f, mapped %.3f\n", t_p_push, t_m_take, t_m_collect, t_f_push, t_m_submit, t_m_in, t_m_dev, t_m_out),
+        fprintf(stderr, "[mcx_map_files] wall seconds: input opened and indexed %.3f | first batch parsed %.3f, mapped %.3f | last batch parsed %.3f, mapped %.3f | all written %.3f\n",
+                w_open, w_first_parsed, w_first_mapped, w_reader, w_mapped, secs(t_begin, now()));
     if (sam_fd >= 0 && !sam_stream) { if (close(sam_fd) != 0 && write_rc.load() == 0) write_rc.store(MCX_ERR_IO); }
     if (rc == 0 && write_rc.load()) rc = mcx_set_error(MCX_ERR_IO, std::string("cannot write ") + (sam_path ? sam_path : ""));
     return rc;

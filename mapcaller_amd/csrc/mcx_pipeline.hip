@@ -2054,7 +2054,7 @@ struct BatchRun { // the batch between mcx_batch_begin and mcx_batch_end
     unsigned long long hs[3] = {0, 0, 0};
     std::vector<uint32_t> ok, ds; // per chunk: proper pairs; summed distance, then summed read lengths
     const uint64_t *d_sorted_keys = nullptr; uint64_t n_keys = 0; uint32_t n_sparse_keys = 0;
-    std::chrono::steady_clock::time_point t0;
+    std::chrono::steady_clock::time_point t0, t_begun; double ms_setup = 0; // (t_begun, ms_setup: MCX_TIMING)
     mcx_stats *stats = nullptr;
 };
 
@@ -2170,6 +2170,17 @@ static Caps tier1_caps(int rlen_max)
     return c;
 }
 
+// (MCX_TIMING) a host wait that took long says so
+template <typename F>
+static inline hipError_t timed_wait(bool on, const char *what, int line, F &&f)
+{
+    if (!on) return f();
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = f();
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (ms > 15) fprintf(stderr, "[mcx] %.1f ms in %s (line %d)\n", ms, what, line);
+    return e;
+}
 static std::atomic<size_t> g_dmalloc_bytes(0); // (MCX_TIMING: what a context takes)
 template <class T>
 static int dmalloc(T **p, size_t n, int line = __builtin_LINE())
@@ -2695,7 +2706,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         HIP_TRY(hipStreamWaitEvent(T.stream, c->ev_clustered, 0));
         bool no_n;
         if (c->h_early) { // k_publish_early wrote both numbers into page-locked memory
-            HIP_TRY(hipEventSynchronize(c->ev_clustered));
+            HIP_TRY(timed_wait(kn.timing, "wait for k_cluster (the early list's length)", __LINE__, [&] { return hipEventSynchronize(c->ev_clustered); }));
             n_early = c->h_early[0]; no_n = c->h_early[1] == 0;
         } else {
             HIP_TRY(hipMemcpyAsync(T.h_cnt, R.d_cnt + CNT_EARLY, sizeof(uint32_t), hipMemcpyDeviceToHost, T.stream));
@@ -2723,7 +2734,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
             // what ran over after clustering (k_build's list): known once tier 0 has built; a handful of pairs, which take the
             // large tier on the third set of resources while tier 0's DP and finish stages run
             const PassRes &U = c->t2;
-            HIP_TRY(hipEventSynchronize(c->ev_built));
+            HIP_TRY(timed_wait(kn.timing, "wait for k_build (the late list's length)", __LINE__, [&] { return hipEventSynchronize(c->ev_built); }));
             HIP_TRY(hipMemcpyAsync(U.h_cnt, R.d_cnt + CNT_LATE, sizeof(uint32_t), hipMemcpyDeviceToHost, U.stream));
             HIP_TRY(hipStreamSynchronize(U.stream));
             n_late = std::min<uint32_t>(U.h_cnt[0], kLateRoom);
@@ -2741,7 +2752,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     }
     if (ev_dbg[0]) HIP_TRY(hipEventRecord(ev_dbg[1], c->t1.stream));
     if (!early && tier == 0 && rc2 == 0 && c->tail.want && !sel.ids && state_off == 0) rc2 = queue_batch_tail(c);
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(timed_wait(kn.timing, "wait for the pass's stream", __LINE__, [&] { return hipStreamSynchronize(s); }));
     if (ev_dbg[0]) {
         float a = 0, b = 0;
         HIP_TRY(hipEventSynchronize(ev_dbg[1]));
@@ -3160,7 +3171,9 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
         HIP_TRY(hipEventRecord(c->ev_pack[1], s));
     }
     int rc;
+    br.ms_setup = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - br.t0).count();
     rc = run_selection(c, br.rb, paired, nullptr, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true);
+    br.t_begun = std::chrono::steady_clock::now();
     if (rc) return rc;
     if (c->tail.ran) memcpy(c->h_cnt + CNT_N, c->tail.h + 2, sizeof br.hs); // (the pass queued the batch's tail: the statistics came with it, before the per-read arrays were reused)
     else { // seeding statistics (E, blocks, H of SURVEY.md 8d) before the per-read arrays are reused for the chunk sums
@@ -3387,6 +3400,7 @@ extern "C" int mcx_map_batch_dev(mcx_ctx *c, const uint8_t *d_bases, const uint3
     // (one stream, one trajectory: what follows the batch's kernels — statistics, per-chunk sums, the walk, the check of every pair's estimate —
     //  is queued behind them by the pass itself, queue_batch_tail)
     c->tail.want = true; c->tail.state0[0] = avg[0]; c->tail.state0[1] = avg[1]; c->tail.state0[2] = avg[2];
+    const auto t_in = std::chrono::steady_clock::now();
     int rc = mcx_batch_begin(c, d_bases, d_off, n_reads, paired, (int32_t)((uint32_t)avg[0] * 1.5), avg[3], d_aln, d_cigar, stats);
     c->tail.want = false;
     if (rc) return rc;
@@ -3409,17 +3423,27 @@ extern "C" int mcx_map_batch_dev(mcx_ctx *c, const uint8_t *d_bases, const uint3
             if (tail && iter == 0 && memcmp(est.data(), c->tail.h + 18 + 3 * nc, (size_t)nc * 4) == 0) {
                 // the device walked the same trajectory: its list of the pairs whose estimate moved is the list
                 n_redo = c->tail.h[0];
+                const auto tq = std::chrono::steady_clock::now();
                 if (n_redo && (rc = replay_listed(c, n_redo, stats))) return rc;
+                if (n_redo && c->kn.timing) fprintf(stderr, "[mcx] avgDist: %u pairs of the batch re-run (the device's list), %.2f ms\n", n_redo, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq).count());
                 if (n_redo == 0) break;
                 continue;
             }
             if (tail && iter == 0 && c->kn.timing) fprintf(stderr, "[mcx] the device's walk of the batch's chunks differs from the host's: the host's is taken\n");
+            const auto tq = std::chrono::steady_clock::now();
             if ((rc = mcx_batch_replay(c, est.data(), &n_redo, stats))) return rc;
+            if (c->kn.timing && (n_redo || iter)) fprintf(stderr, "[mcx] avgDist: pass %d, %u pairs re-run, %.2f ms\n", iter, n_redo, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq).count());
             if (n_redo == 0) break;
             if (iter == 63) return fail(MCX_ERR_CAPACITY, "avgDist replay did not converge");
         }
     }
+    const auto t_loop = std::chrono::steady_clock::now();
     if ((rc = mcx_batch_end(c, stats))) return rc;
+    if (c->kn.timing) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        const auto t_out = std::chrono::steady_clock::now();
+        if (ms(t_in, t_out) > 30) fprintf(stderr, "[mcx] a slow batch (%u reads): set-up %.2f ms, first pass %.2f ms, avgDist %.2f ms, closing %.2f ms\n", n_reads, c->run.ms_setup, ms(t_in, c->run.t_begun) - c->run.ms_setup, ms(c->run.t_begun, t_loop), ms(t_loop, t_out));
+    }
     avg[0] = after[0]; avg[1] = after[1]; avg[2] = after[2];
     avg[3] += n_reads;
     return 0;

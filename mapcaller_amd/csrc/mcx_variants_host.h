@@ -19,6 +19,7 @@
 
 #include "../../include/mcx.h"
 #include "mcx_internal.h"
+#include "mcx_cpus.h"
 #include "mcx_fm.h"
 
 namespace mcx_vc {
@@ -184,7 +185,7 @@ struct SubLap {
 // ---- host threads for the passes over millions of records --------------------------------------------
 static inline unsigned vc_threads(size_t n, size_t grain)
 {
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned hw = mcx_usable_cpus(); // (the CPUs the process is given, not the machine's)
     if (const char *e = getenv("MCX_VC_GRAIN")) grain = (size_t)std::max(1, atoi(e)); // (tests: many short stretches on small inputs)
     return (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)hw, (size_t)32, n / std::max<size_t>(grain, 1) + 1}));
 }
