@@ -883,8 +883,9 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
     const uint64_t shard_count = opt.shard_count > 1 ? (uint64_t)opt.shard_count : 1, shard_rank = shard_count > 1 ? (uint64_t)opt.shard_rank : 0;
     const bool sharded = shard_count > 1;
     // (two pools of this size — parse + pack, format — beside the mapper's and the writer's threads: three quarters of the CPUs the process may use each;
-    //  the pools take turns more than they overlap.  On the bench box's 16-CPU share: 6 / 8 / 12 / 16 / 24 / 64 threads a pool -> 10.6 / 10.9 / 13.2 / 12.2 / 10.9 / 10.2 M reads/s to SAM)
-    int threads = opt.host_threads > 0 ? opt.host_threads : (int)std::min<unsigned>(64, std::max<unsigned>(1, mcx_usable_cpus() * 3 / 4));
+    //  the pools take turns more than they overlap.  On the bench box's 16-CPU share: 6 / 8 / 12 / 16 / 24 / 64 threads a pool -> 10.6 / 10.9 / 13.2 / 12.2 / 10.9 / 10.2 M reads/s to SAM.
+    //  The shards of a run share the host: each takes its part.)
+    int threads = opt.host_threads > 0 ? opt.host_threads : (int)std::min<unsigned>(64, std::max<unsigned>(1, mcx_usable_cpus() * 3 / 4 / (unsigned)shard_count));
     std::string err;
     Shards sh;
     const uint64_t batch_reads = std::max<uint64_t>(kReadChunkSize, mcx_ctx_max_reads(c) / kReadChunkSize * kReadChunkSize);
