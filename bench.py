@@ -394,7 +394,19 @@ def vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, n_s
     mapper.reset()
     mapper.profile_attach(planes.data_ptr())
     t_first = map_batch(first)
-    t_acc = sum(map_batch(b) for b in timed) / len(timed)
+    # (a batch's bookkeeping is queued behind it and runs under the next batch's kernels: the batches follow one another without a wait in between; the time
+    #  of a batch in the run's steady state is the time between two calls' returns; what is left of the last batch's bookkeeping when its call returns is the tail)
+    torch.cuda.synchronize()
+    marks = [time.perf_counter()]
+    for b in timed:
+        for lo in range(0, reads_per_step, slice_reads):
+            n = min(slice_reads, reads_per_step - lo)
+            mapper.map_batch_dev(b.data_ptr() + lo * args.rlen, off.data_ptr(), n, True, d_aln.data_ptr(), d_cig.data_ptr())
+        marks.append(time.perf_counter())
+    torch.cuda.synchronize()
+    t_tail = time.perf_counter() - marks[-1]
+    t_acc = (marks[-1] - marks[1]) / (len(marks) - 2) if len(marks) > 2 else marks[-1] - marks[0] + t_tail
+    t_seq = (marks[-1] - marks[0] + t_tail) / len(timed)
     hbm_free, hbm_total = torch.cuda.mem_get_info(dev)  # (the leg is the fullest the device gets: index, planes, a full-batch context, the per-read detail)
     t_sp = time.perf_counter()
     sparse = mapper.profile_sparse_raw(shard=world > 1, copy=False)  # the tally records leave HBM here, once
@@ -415,7 +427,7 @@ def vcf_leg(args, index, mapper, batches, off, d_aln, d_cig, reads_per_step, n_s
     tot = mdist.sum_over_ranks([d["pairs"], d["pair_dist_sum"], d["pair_len_sum"]], dev)
     gb = (mdist.reduce_profile.last_bytes if world > 1 else api.planes_stride(G) * 22) / 1e9  # (one GPU: what a rank would put on the wire, the readCount plane included here)
     vcf = {"profile_batch_ms": round(1000 * t_acc, 2), "same_batches_without_profile_ms": round(1000 * t_plain, 2),
-           "profile_overhead_ms": round(1000 * (t_acc - t_plain), 2), "first_batch_of_the_run_ms": round(1000 * t_first, 2),
+           "profile_overhead_ms": round(1000 * (t_acc - t_plain), 2), "batches_timed": len(timed), "sequence_ms_per_batch_tail_included": round(1000 * t_seq, 2), "last_batch_bookkeeping_tail_ms": round(1000 * t_tail, 2), "first_batch_of_the_run_ms": round(1000 * t_first, 2),
            "batches": 1 + len(timed), "hbm_free_gb": round(hbm_free / 1e9, 1), "hbm_total_gb": round(hbm_total / 1e9, 1), "slice_reads": slice_reads, "pair_records_kept": bool(args.full_sa >= 2), "tier1_gb": args.vcf_tier1_gb,
            "note": "per batch of the run in its steady state (the estimate carried from batch to batch, as in the timed region): mean over the batches behind "
                    "the first; planes and sparse records hold all of them", "sparse_records_to_host_ms": round(1000 * t_sp, 2),
@@ -988,7 +1000,7 @@ def main():
     # (the legs below bring contexts and buffers of their own: the timed region's context, its device slots and all but one batch make room)
     keep = batches[min(args.warmup, len(batches) - 1)]
     kept = batches[args.warmup:args.warmup + max(1, args.file_batches)] or [keep]  # the file leg's reads
-    vcf_batches = (batches[args.warmup:args.warmup + 3] or [keep]) if (args.vcf_reduce == 1 or (args.vcf_reduce < 0 and world > 1)) else []  # the -vcf leg's
+    vcf_batches = (batches[args.warmup:args.warmup + 5] or [keep]) if (args.vcf_reduce == 1 or (args.vcf_reduce < 0 and world > 1)) else []  # the -vcf leg's
     del batches[:]
     batches.append(keep)
     mapper.close()

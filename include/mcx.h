@@ -273,7 +273,13 @@ void mcx_exchange_local_free(mcx_exchange *first);
  * mcx_profile_sparse returns the insert / delete / break-point tallies ('I','D','B': one record
  * per event, to be summed by (pos, seq)) and the inversion / translocation site records ('V','T':
  * pos = gPos, dist in the first 8 bytes of seq).  max_dup = iMaxDuplicate (-dup, default 5),
- * max_clip = MaxClipSize (-maxclip, default 5). */
+ * max_clip = MaxClipSize (-maxclip, default 5).
+ * On one shard the bookkeeping of a batch — duplicate check, the planes' updates, the tallies — is QUEUED behind the batch
+ * when its call returns and runs under the next batch's kernels (a second set of per-read detail records and a copy of the
+ * batch's reads in the context: the caller's buffers are the caller's again on return); mcx_profile_settle / _finalize /
+ * _sparse*, the next batch's end and mcx_ctx_free wait for it — the planes are not to be read before one of them, as before.
+ * Errors of a batch's bookkeeping (a list that ran over) come back from the next of these calls.  Without room in HBM for
+ * the second set, or with MCX_NO_PROF_OVERLAP=1, it runs inside the batch's call. */
 typedef struct mcx_sparse_rec {
     int64_t pos;
     uint8_t type;

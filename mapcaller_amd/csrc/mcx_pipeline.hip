@@ -1988,7 +1988,7 @@ __global__ void __launch_bounds__(256, MCX_FINISH_WAVES) k_finish(Ctx cx, ReadBa
 struct Knobs {
     bool timing = false, seed_one_base = false, dp_by_wave = false, dp_lane_always = false, late_reseed = false, no_work_order = false, no_simple = false,
          simple_no_dp = false, cluster_by_lane = false, rescue_in_line = false, build_by_lane = false, no_sums_cache = false, prof_by_column = false,
-         tier1_hist = false, dp_hist = false, no_tier_overlap = false, no_late_overlap = false;
+         tier1_hist = false, dp_hist = false, no_tier_overlap = false, no_late_overlap = false, no_prof_overlap = false;
     int seed_fm_budget = 6, build_wave_limit = 0x7fffffff;
     uint32_t order_min = 16384u;
 };
@@ -2000,7 +2000,7 @@ static Knobs knobs_read()
     k.late_reseed = on("MCX_LATE_RESEED"); k.no_work_order = on("MCX_NO_WORK_ORDER"); k.no_simple = on("MCX_NO_SIMPLE"); k.simple_no_dp = on("MCX_SIMPLE_NO_DP");
     k.cluster_by_lane = on("MCX_CLUSTER_BY_LANE"); k.rescue_in_line = on("MCX_RESCUE_IN_LINE"); k.build_by_lane = on("MCX_BUILD_BY_LANE");
     k.no_sums_cache = on("MCX_NO_SUMS_CACHE"); k.prof_by_column = on("MCX_PROF_BY_COLUMN"); k.tier1_hist = on("MCX_TIER1_HIST"); k.dp_hist = on("MCX_DP_HIST");
-    k.no_tier_overlap = on("MCX_NO_TIER_OVERLAP"); k.no_late_overlap = on("MCX_NO_LATE_OVERLAP");
+    k.no_tier_overlap = on("MCX_NO_TIER_OVERLAP"); k.no_late_overlap = on("MCX_NO_LATE_OVERLAP"); k.no_prof_overlap = on("MCX_NO_PROF_OVERLAP");
     if (const char *e = getenv("MCX_SEED_FM_BUDGET")) k.seed_fm_budget = std::max(1, atoi(e));
     if (const char *e = getenv("MCX_BUILD_WAVE_LIMIT")) k.build_wave_limit = atoi(e); // (tests: the bound sum from which k_build_wave hands a pair to one lane)
     if (const char *e = getenv("MCX_ORDER_MIN")) k.order_min = (uint32_t)std::max(1, atoi(e)); // (tests: small batches through k_simple and the order too)
@@ -2098,6 +2098,16 @@ struct mcx_ctx {
     uint16_t *d_prof_match = nullptr; bool prof_settled = false, prof_broken = false; // (broken: a settle failed half way — some planes scanned, some not)
     // exact-seed coverage as differences (mcx_profile.h); freed by mcx_profile_settle
     uint8_t *d_detail = nullptr; DetailLayout dlay;
+    // One shard: a batch's bookkeeping is queued behind its mapping on a stream of its own and runs under the NEXT batch's kernels.  What the
+    // mapping writes for it exists twice (detail records, flag bytes: the sets change places when a batch's bookkeeping is queued), the batch's reads are kept
+    // in a copy of the context's (the caller's buffer is the caller's again when the call returns), and the bookkeeping has counters and an event list of its own.
+    struct ProfLater {
+        bool have = false, pending = false, kept_now = false; // the resources exist; a batch's bookkeeping is queued and the host has not looked at its counts; the batch in flight has its reads kept
+        hipStream_t stream = nullptr, keep_stream = nullptr; hipEvent_t go = nullptr, done = nullptr, kept = nullptr, begun = nullptr;
+        uint8_t *d_detail_alt = nullptr, *d_admit_alt = nullptr, *d_keep_bases = nullptr, *d_keep_bases_alt = nullptr; uint32_t *d_keep_off = nullptr, *d_keep_off_alt = nullptr;
+        uint32_t *d_cnt = nullptr, *h_cnt = nullptr; SparseRec *d_ev = nullptr; uint32_t ev_cap = 0;
+        std::chrono::steady_clock::time_point t_queued;
+    } later;
     uint64_t *d_keys[2] = {nullptr, nullptr}; uint8_t *d_admit = nullptr; void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     SparseRec *d_sparse = nullptr; uint32_t sparse_cap = 0;
     struct Archive { SparseRec *d = nullptr; uint64_t n = 0, cap = 0; std::vector<mcx_sparse_rec> *host = nullptr; };
@@ -2407,6 +2417,15 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     if (c->arch_ev.d) (void)hipFree(c->arch_ev.d);
     passres_free(c->t1); passres_free(c->t2);
     for (hipEvent_t e : {c->ev_clustered, c->ev_built, c->ev_late_done, c->tail.ev[0], c->tail.ev[1]}) if (e) (void)hipEventDestroy(e);
+    {
+        auto &L = c->later;
+        if (L.stream) (void)hipStreamSynchronize(L.stream);
+        for (void *q : {(void *)L.d_detail_alt, (void *)L.d_admit_alt, (void *)L.d_keep_bases, (void *)L.d_keep_off, (void *)L.d_keep_bases_alt, (void *)L.d_keep_off_alt, (void *)L.d_cnt, (void *)L.d_ev}) if (q) (void)hipFree(q);
+        if (L.h_cnt) (void)hipHostFree(L.h_cnt);
+        for (hipEvent_t e : {L.go, L.done, L.kept, L.begun}) if (e) (void)hipEventDestroy(e);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+        if (L.keep_stream) (void)hipStreamDestroy(L.keep_stream);
+    }
     if (c->h_early) (void)hipHostFree((void *)c->h_early);
     if (c->tail.d) (void)hipFree(c->tail.d);
     if (c->tail.h) (void)hipHostFree(c->tail.h);
@@ -2998,6 +3017,9 @@ static int queue_batch_tail(mcx_ctx *c)
 }
 
 static int profile_keys(mcx_ctx *c);
+static int profile_queue(mcx_ctx *c);
+static int profile_collect(mcx_ctx *c);
+static int archive_append(mcx_ctx *c, mcx_ctx::Archive &a, const SparseRec *d_src, uint64_t n, hipStream_t on = nullptr);
 static int profile_foreign(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all);
 static int sort_reserve(mcx_ctx *c, uint64_t n);
 static int profile_accumulate(mcx_ctx *c, const uint64_t *h_all, uint64_t n_all, uint32_t slot_stride, uint32_t own_slot);
@@ -3112,6 +3134,19 @@ __global__ void k_max_read_len(const uint32_t *off, uint32_t n_reads, uint32_t *
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
+__global__ void k_zero_but(uint32_t *cnt, int n, int keep_a, int keep_b)
+{
+    for (int k = threadIdx.x; k < n; k += blockDim.x) if (k != keep_a && k != keep_b) cnt[k] = 0;
+}
+
+// a batch's reads into the context's own copy (bases 16 bytes at a time: d_bases is 16-byte aligned, the copy's room ends on a multiple of 16)
+__global__ void k_keep_reads(const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, uint32_t n_reads, uint8_t *__restrict__ to_bases, uint32_t *__restrict__ to_off)
+{
+    const uint64_t total = off[n_reads], n16 = (total + 15) / 16, T = (uint64_t)gridDim.x * blockDim.x, t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint64_t i = t; i < n16; i += T) ((U4 *)to_bases)[i] = ((const U4 *)bases)[i];
+    for (uint64_t i = t; i <= n_reads; i += T) to_off[i] = off[i];
+}
+
 extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_t *d_off, uint32_t n_reads, int paired, int32_t est0,
                                int64_t read_base, mcx_aln *d_aln, uint32_t *d_cigar, mcx_stats *stats)
 {
@@ -3169,6 +3204,16 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
         k_pack_reads<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(br.rb, paired, c->wpad, tpr, c->d_packed, c->d_batch_flags + 3, c->prof_planes ? c->d_admit : nullptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_pack[1], s));
+    }
+    c->later.kept_now = false;
+    if (c->prof_planes && c->later.have && c->tail.want) { // (mcx_map_batch_dev's batches: one shard.)  The batch's reads for its bookkeeping, which runs when this call has long returned: copied beside the first kernels
+        auto &L = c->later;
+        L.kept_now = true;
+        HIP_TRY(hipEventRecord(L.begun, s)); // (behind what the stream waits for: the batch's reads are in place)
+        HIP_TRY(hipStreamWaitEvent(L.keep_stream, L.begun, 0));
+        k_keep_reads<<<2048, 256, 0, L.keep_stream>>>(d_bases, d_off, n_reads, L.d_keep_bases, L.d_keep_off);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(L.kept, L.keep_stream));
     }
     int rc;
     br.ms_setup = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - br.t0).count();
@@ -3340,7 +3385,8 @@ extern "C" int mcx_batch_end(mcx_ctx *c, mcx_stats *stats)
     if (!c || !c->run.open) return fail(MCX_ERR_ARG, "mcx_batch_end: no batch in flight");
     HIP_TRY(hipSetDevice(c->idx->device));
     int rc = batch_close(c, stats);
-    if (rc == 0 && c->prof_planes) { // one shard: the batch's own keys decide the duplicate cap
+    if (rc == 0 && c->prof_planes && c->later.have && c->later.kept_now) rc = profile_queue(c); // one shard: the batch's own keys decide the duplicate cap — behind the batch, under the next one's kernels
+    else if (rc == 0 && c->prof_planes && (rc = profile_collect(c)) == 0) {
         const auto t0 = std::chrono::steady_clock::now();
         rc = profile_keys(c);
         const auto t1 = std::chrono::steady_clock::now();
@@ -3360,6 +3406,7 @@ extern "C" int mcx_batch_end_keys(mcx_ctx *c, mcx_stats *stats, const uint64_t *
     if (!c || !c->run.open || !keys || !n_keys) return fail(MCX_ERR_ARG, "mcx_batch_end_keys: no batch in flight");
     if (!c->prof_planes) return fail(MCX_ERR_ARG, "mcx_batch_end_keys: no profile attached");
     HIP_TRY(hipSetDevice(c->idx->device));
+    if (int e = profile_collect(c)) { c->run.open = false; return e; }
     int rc = batch_close(c, stats);
     if (rc == 0) rc = profile_keys(c);
     if (rc) { c->run.open = false; return rc; }
@@ -3380,6 +3427,7 @@ extern "C" int mcx_batch_accumulate(mcx_ctx *c, const uint64_t *all_keys, uint64
 {
     if (!c || !c->prof_planes) return fail(MCX_ERR_ARG, "mcx_batch_accumulate: no profile attached");
     HIP_TRY(hipSetDevice(c->idx->device));
+    if (int e = profile_collect(c)) return e;
     if (own_slot == 0xFFFFFFFFu) { // a shard without reads in this round: the others' admissions still count
         if (c->run.open) return fail(MCX_ERR_ARG, "mcx_batch_accumulate: a batch is in flight");
         return profile_foreign(c, all_keys, n_all);
@@ -3808,6 +3856,7 @@ extern "C" int mcx_profile_attach(mcx_ctx *c, uint32_t *d_planes, int max_dup, i
     if (!c || !d_planes) return fail(MCX_ERR_ARG, "mcx_profile_attach: null argument");
     if (c->idx->view.G >= (int64_t)1 << 32) return fail(MCX_ERR_UNSUPPORTED, "the alignment profile takes genomes below 2^32 bases");
     HIP_TRY(hipSetDevice(c->idx->device));
+    if (c->later.pending) { (void)hipStreamSynchronize(c->later.stream); c->later.pending = false; } // (a profile that is given up with a batch's bookkeeping on its way)
     c->prof_planes = d_planes;
     c->prof_max_dup = (max_dup <= 0 || max_dup > 15) ? 15 : max_dup; // main.cpp:240-244, :323
     c->prof_max_clip = max_clip;
@@ -3822,6 +3871,27 @@ extern "C" int mcx_profile_attach(mcx_ctx *c, uint32_t *d_planes, int max_dup, i
         c->sparse_cap = (uint32_t)std::min<uint64_t>(c->max_reads * 2 + 4096, 0x7fffffffu);
         if ((rc = dmalloc(&c->d_sparse, c->sparse_cap))) return rc;
         HIP_TRY(hipHostMalloc((void **)&c->h_sparse_pin, (size_t)c->sparse_pin_recs * sizeof(SparseRec)));
+        if (!c->kn.no_prof_overlap) { // a second set of what a batch's mapping writes for the bookkeeping, if HBM has the room (without it: the bookkeeping inside the call, as before)
+            auto &L = c->later;
+            L.ev_cap = (uint32_t)std::min<uint64_t>(c->max_reads / 2 + 4096, 0x7fffffffu);
+            // (a stream of the lowest priority: queues of a priority of their own in the runtime — a stream of the default priority may share a hardware queue with the
+            //  context's main stream, and then the bookkeeping runs before the next batch's kernels, not under them — and the mapping goes first where both want the chip)
+            int prio_low = 0, prio_high = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+            bool ok = hipMalloc((void **)&L.d_detail_alt, (size_t)c->dlay.stride * c->max_reads) == hipSuccess && hipMalloc((void **)&L.d_admit_alt, c->max_reads + 4) == hipSuccess &&
+                      hipMalloc((void **)&L.d_keep_bases, c->max_bases + 64) == hipSuccess && hipMalloc((void **)&L.d_keep_off, (c->max_reads + 1) * sizeof(uint32_t)) == hipSuccess &&
+                      hipMalloc((void **)&L.d_keep_bases_alt, c->max_bases + 64) == hipSuccess && hipMalloc((void **)&L.d_keep_off_alt, (c->max_reads + 1) * sizeof(uint32_t)) == hipSuccess &&
+                      hipMalloc((void **)&L.d_cnt, CNT_N * sizeof(uint32_t)) == hipSuccess && hipMalloc((void **)&L.d_ev, (size_t)L.ev_cap * sizeof(SparseRec)) == hipSuccess &&
+                      hipHostMalloc((void **)&L.h_cnt, CNT_N * sizeof(uint32_t)) == hipSuccess &&
+                      hipStreamCreateWithPriority(&L.stream, hipStreamNonBlocking, prio_low) == hipSuccess && hipStreamCreateWithPriority(&L.keep_stream, hipStreamNonBlocking, prio_low) == hipSuccess;
+            for (hipEvent_t *e : {&L.go, &L.done, &L.kept, &L.begun}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+            if (!ok) {
+                (void)hipGetLastError();
+                for (void **q : {(void **)&L.d_detail_alt, (void **)&L.d_admit_alt, (void **)&L.d_keep_bases, (void **)&L.d_keep_off, (void **)&L.d_keep_bases_alt, (void **)&L.d_keep_off_alt, (void **)&L.d_cnt, (void **)&L.d_ev}) if (*q) { (void)hipFree(*q); *q = nullptr; }
+                if (c->kn.timing) fprintf(stderr, "[mcx profile] no room in HBM for a second set of detail records: a batch's bookkeeping runs inside its call\n");
+            }
+            L.have = ok;
+        }
     }
     c->h_sparse.clear(); c->h_events.clear(); c->n_tally = 0; c->arch.n = c->arch_ev.n = 0;
     c->arch.host = &c->h_sparse; c->arch_ev.host = &c->h_events;
@@ -3849,6 +3919,68 @@ static int sort_reserve(mcx_ctx *c, uint64_t n)
     HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, c->sort_tmp_bytes, dk, (int64_t)n, 0, 64));
     HIP_TRY(hipMalloc(&c->d_sort_tmp, c->sort_tmp_bytes + 256));
     c->keys_cap = n;
+    return 0;
+}
+
+// What the host has to do about a queued batch's bookkeeping once it is through: overflow checks, the records into the archives.
+static int profile_collect(mcx_ctx *c)
+{
+    auto &L = c->later;
+    if (!L.pending) return 0;
+    L.pending = false;
+    HIP_TRY(hipEventSynchronize(L.done));
+    const uint32_t n_sp = L.h_cnt[CNT_TASKS], n_ev = L.h_cnt[CNT_RESCUE];
+    if (n_sp > c->sparse_cap || n_ev > L.ev_cap) return fail(MCX_ERR_CAPACITY, "profile: sparse record list overflow");
+    if (L.h_cnt[CNT_UNSUP]) return fail(MCX_ERR_UNSUPPORTED, "an insertion or deletion of more than 255 bases in an alignment: its string does not fit a tally record");
+    if (int rc = archive_append(c, c->arch, c->d_sparse, n_sp, L.stream)) return rc;
+    if (int rc = archive_append(c, c->arch_ev, L.d_ev, n_ev, L.stream)) return rc;
+    HIP_TRY(hipStreamSynchronize(L.stream)); // (the archives are read on the context's stream; the lists are the next batch's to fill)
+    if (c->kn.timing) fprintf(stderr, "[mcx profile] %u tally records, %u events, %u listed fragments (queued behind the batch; looked at %.2f ms later)\n", n_sp, n_ev, L.h_cnt[CNT_RTASK],
+                              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - L.t_queued).count());
+    return 0;
+}
+
+// One shard: the whole bookkeeping of the batch just mapped — keys, sort, admission, accumulation — queued on the bookkeeping's stream; nothing of it is
+// waited for here.  The number of keys stays on the device (k_prof_admit / k_prof_count take it from there), the break-point records' count stays where
+// k_prof_keys left it.  The next batch's mapping writes the other set of detail records and flag bytes.
+static int profile_queue(mcx_ctx *c)
+{
+    if (c->prof_settled) return fail(MCX_ERR_ARG, "the profile has been settled (mcx_profile_settle / _finalize): attach it again before mapping more reads");
+    if (int rc = profile_collect(c)) return rc; // (the batch before this one: through long ago, it ran under this batch's kernels)
+    auto &L = c->later;
+    BatchRun &br = c->run;
+    hipStream_t ps = L.stream;
+    const IndexView &ix = c->idx->view;
+    ProfView pv; pv.pl = planes_view(c->prof_planes, ix.G); pv.match = c->d_prof_match; pv.G = ix.G; pv.max_dup = c->prof_max_dup; pv.max_clip = c->prof_max_clip;
+    SparseSink sink; sink.recs = c->d_sparse; sink.n = L.d_cnt + CNT_TASKS; sink.cap = c->sparse_cap; sink.refused = L.d_cnt + CNT_UNSUP;
+    const uint32_t n = br.rb.n_reads;
+    ReadBatch rb; rb.bases = L.d_keep_bases; rb.off = L.d_keep_off; rb.n_reads = n;
+    HIP_TRY(hipEventSynchronize(L.kept)); // (the caller's buffer is the caller's again: the copy was made beside the batch's first kernels)
+    HIP_TRY(hipEventRecord(L.go, c->stream));
+    HIP_TRY(hipStreamWaitEvent(ps, L.go, 0));
+    HIP_TRY(hipMemsetAsync(L.d_cnt, 0, CNT_N * sizeof(uint32_t), ps));
+    k_prof_keys<<<(n + 255) / 256, 256, 0, ps>>>(c->d_detail, c->dlay, rb, ix, pv, sink, c->d_keys[0], L.d_cnt + CNT_OV);
+    hipcub::DoubleBuffer<uint64_t> dk(c->d_keys[0], c->d_keys[1]);
+    size_t tb = c->sort_tmp_bytes;
+    HIP_TRY(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tb, dk, (int64_t)n, 0, 64, ps));
+    const uint64_t *d_keys = dk.Current(); // (the keys of the reads that do not reach the duplicate check are ~0 and sort behind the others)
+    // the counters of the second half start at zero, but for the two the first half hands over: the keys' number, the break-point records'
+    static_assert(CNT_OV < CNT_N && CNT_TASKS < CNT_N, "counter indices");
+    k_zero_but<<<1, 64, 0, ps>>>(L.d_cnt, CNT_N, CNT_OV, CNT_TASKS);
+    k_prof_admit<<<(n + 255) / 256, 256, 0, ps>>>(d_keys, 0, pv, c->d_admit, 0u, n, L.d_cnt + CNT_OV);
+    k_prof_count<<<(n + 255) / 256, 256, 0, ps>>>(d_keys, 0, pv, L.d_cnt + CNT_OV);
+    ColList cols; cols.items = c->d_prof_items; cols.n = L.d_cnt + CNT_RTASK; cols.cap = c->prof_items_cap;
+    // (a smaller grid for the two — 512 to 4096 workgroups, the batch walked in strides — changes nothing: 28.8-29.3 ms per batch either way; what the bookkeeping
+    //  and the mapping beside it share is the memory system's rate of scattered line transfers, not the CUs)
+    k_prof_accum<<<(n + 255) / 256, 256, 0, ps>>>(c->d_detail, c->dlay, rb, ix, pv, sink, c->d_admit, br.paired, cols);
+    k_prof_cols<<<4096, 256, 0, ps>>>(c->d_detail, c->dlay, rb, ix, pv, sink, cols);
+    if (br.paired) k_prof_disc<<<(n / 2 + 255) / 256, 256, 0, ps>>>(c->d_detail, c->dlay, n / 2, br.read_base / 2, L.d_ev, L.d_cnt + CNT_RESCUE, L.ev_cap);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(L.h_cnt, L.d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, ps));
+    HIP_TRY(hipEventRecord(L.done, ps));
+    L.pending = true; L.t_queued = std::chrono::steady_clock::now();
+    std::swap(c->d_detail, L.d_detail_alt); std::swap(c->d_admit, L.d_admit_alt); // the next batch's mapping writes the other set,
+    std::swap(L.d_keep_bases, L.d_keep_bases_alt); std::swap(L.d_keep_off, L.d_keep_off_alt); // its reads are kept in the other copy
     return 0;
 }
 
@@ -3923,16 +4055,17 @@ static int archive_flush(mcx_ctx *c, mcx_ctx::Archive &a)
 
 static int sparse_flush(mcx_ctx *c)
 {
+    if (int rc = profile_collect(c)) return rc;
     c->h_sparse.resize(c->n_tally);
     if (int rc = archive_flush(c, c->arch)) return rc;
     return archive_flush(c, c->arch_ev);
 }
 
 // n records at d_src join an archive (on the stream); an archive that cannot grow any more goes to the host first
-static int archive_append(mcx_ctx *c, mcx_ctx::Archive &a, const SparseRec *d_src, uint64_t n)
+static int archive_append(mcx_ctx *c, mcx_ctx::Archive &a, const SparseRec *d_src, uint64_t n, hipStream_t on)
 {
     if (n == 0) return 0;
-    hipStream_t s = c->stream;
+    hipStream_t s = on ? on : c->stream;
     if (a.n + n > a.cap) {
         const uint64_t want = std::max<uint64_t>({2 * a.cap, a.n + n, &a == &c->arch ? (uint64_t)1 << 22 : (uint64_t)1 << 18});
         SparseRec *grown = nullptr;
@@ -4016,6 +4149,7 @@ extern "C" int mcx_profile_settle(mcx_ctx *c)
     if (c->prof_broken) return fail(MCX_ERR_DEVICE, "an earlier mcx_profile_settle failed half way: the planes are neither differences nor counts; attach the profile again");
     if (!c->prof_planes || c->prof_settled) return 0;
     HIP_TRY(hipSetDevice(c->idx->device));
+    if (int rc = profile_collect(c)) return rc; // (the last batch's bookkeeping)
     hipStream_t s = c->stream;
     const IndexView &ix = c->idx->view;
     const size_t G = (size_t)ix.G;

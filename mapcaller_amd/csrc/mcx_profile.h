@@ -119,9 +119,11 @@ __global__ void k_prof_keys(const uint8_t *detail, DetailLayout dl, ReadBatch rb
 // round among them): a read is admitted when fewer than max_dup reads were admitted at its start position
 // before it — earlier rounds (readCount plane) plus earlier reads of this round.  Only the reads
 // [own_lo, own_lo + n_own) are this shard's: their flags are written.
-__global__ void k_prof_admit(const uint64_t *keys, uint64_t n, ProfView pv, uint8_t *admit, uint32_t own_lo, uint32_t n_own)
+// (n_dev: the number of keys where the host has not looked at it — a batch's bookkeeping queued behind its mapping; the grid then covers the batch's reads)
+__global__ void k_prof_admit(const uint64_t *keys, uint64_t n, ProfView pv, uint8_t *admit, uint32_t own_lo, uint32_t n_own, const uint32_t *n_dev = nullptr)
 {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n = *n_dev;
     if (j >= n) return;
     const uint64_t key = keys[j];
     const uint32_t idx = (uint32_t)key - own_lo;
@@ -135,9 +137,10 @@ __global__ void k_prof_admit(const uint64_t *keys, uint64_t n, ProfView pv, uint
 
 // pass 2b (after every flag is out): the first key of each start position adds the round's admissions to
 // readCount — the count of the whole run, the same on every shard (`readCount < iMaxDuplicate` then ++, :76-77)
-__global__ void k_prof_count(const uint64_t *keys, uint64_t n, ProfView pv)
+__global__ void k_prof_count(const uint64_t *keys, uint64_t n, ProfView pv, const uint32_t *n_dev = nullptr)
 {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n = *n_dev;
     if (j >= n) return;
     const uint64_t g = keys[j] >> 32;
     if (j > 0 && (keys[j - 1] >> 32) == g) return;
