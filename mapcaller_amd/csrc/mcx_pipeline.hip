@@ -2102,7 +2102,7 @@ struct mcx_ctx {
     // mapping writes for it exists twice (detail records, flag bytes: the sets change places when a batch's bookkeeping is queued), the batch's reads are kept
     // in a copy of the context's (the caller's buffer is the caller's again when the call returns), and the bookkeeping has counters and an event list of its own.
     struct ProfLater {
-        bool have = false, pending = false, kept_now = false; // the resources exist; a batch's bookkeeping is queued and the host has not looked at its counts; the batch in flight has its reads kept
+        bool have = false, tried = false, pending = false, kept_now = false; // the resources exist; a batch's bookkeeping is queued and the host has not looked at its counts; the batch in flight has its reads kept
         hipStream_t stream = nullptr, keep_stream = nullptr; hipEvent_t go = nullptr, done = nullptr, kept = nullptr, begun = nullptr;
         uint8_t *d_detail_alt = nullptr, *d_admit_alt = nullptr, *d_keep_bases = nullptr, *d_keep_bases_alt = nullptr; uint32_t *d_keep_off = nullptr, *d_keep_off_alt = nullptr;
         uint32_t *d_cnt = nullptr, *h_cnt = nullptr; SparseRec *d_ev = nullptr; uint32_t ev_cap = 0;
@@ -3871,27 +3871,6 @@ extern "C" int mcx_profile_attach(mcx_ctx *c, uint32_t *d_planes, int max_dup, i
         c->sparse_cap = (uint32_t)std::min<uint64_t>(c->max_reads * 2 + 4096, 0x7fffffffu);
         if ((rc = dmalloc(&c->d_sparse, c->sparse_cap))) return rc;
         HIP_TRY(hipHostMalloc((void **)&c->h_sparse_pin, (size_t)c->sparse_pin_recs * sizeof(SparseRec)));
-        if (!c->kn.no_prof_overlap) { // a second set of what a batch's mapping writes for the bookkeeping, if HBM has the room (without it: the bookkeeping inside the call, as before)
-            auto &L = c->later;
-            L.ev_cap = (uint32_t)std::min<uint64_t>(c->max_reads / 2 + 4096, 0x7fffffffu);
-            // (a stream of the lowest priority: queues of a priority of their own in the runtime — a stream of the default priority may share a hardware queue with the
-            //  context's main stream, and then the bookkeeping runs before the next batch's kernels, not under them — and the mapping goes first where both want the chip)
-            int prio_low = 0, prio_high = 0;
-            (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-            bool ok = hipMalloc((void **)&L.d_detail_alt, (size_t)c->dlay.stride * c->max_reads) == hipSuccess && hipMalloc((void **)&L.d_admit_alt, c->max_reads + 4) == hipSuccess &&
-                      hipMalloc((void **)&L.d_keep_bases, c->max_bases + 64) == hipSuccess && hipMalloc((void **)&L.d_keep_off, (c->max_reads + 1) * sizeof(uint32_t)) == hipSuccess &&
-                      hipMalloc((void **)&L.d_keep_bases_alt, c->max_bases + 64) == hipSuccess && hipMalloc((void **)&L.d_keep_off_alt, (c->max_reads + 1) * sizeof(uint32_t)) == hipSuccess &&
-                      hipMalloc((void **)&L.d_cnt, CNT_N * sizeof(uint32_t)) == hipSuccess && hipMalloc((void **)&L.d_ev, (size_t)L.ev_cap * sizeof(SparseRec)) == hipSuccess &&
-                      hipHostMalloc((void **)&L.h_cnt, CNT_N * sizeof(uint32_t)) == hipSuccess &&
-                      hipStreamCreateWithPriority(&L.stream, hipStreamNonBlocking, prio_low) == hipSuccess && hipStreamCreateWithPriority(&L.keep_stream, hipStreamNonBlocking, prio_low) == hipSuccess;
-            for (hipEvent_t *e : {&L.go, &L.done, &L.kept, &L.begun}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
-            if (!ok) {
-                (void)hipGetLastError();
-                for (void **q : {(void **)&L.d_detail_alt, (void **)&L.d_admit_alt, (void **)&L.d_keep_bases, (void **)&L.d_keep_off, (void **)&L.d_keep_bases_alt, (void **)&L.d_keep_off_alt, (void **)&L.d_cnt, (void **)&L.d_ev}) if (*q) { (void)hipFree(*q); *q = nullptr; }
-                if (c->kn.timing) fprintf(stderr, "[mcx profile] no room in HBM for a second set of detail records: a batch's bookkeeping runs inside its call\n");
-            }
-            L.have = ok;
-        }
     }
     c->h_sparse.clear(); c->h_events.clear(); c->n_tally = 0; c->arch.n = c->arch_ev.n = 0;
     c->arch.host = &c->h_sparse; c->arch_ev.host = &c->h_events;
@@ -3900,8 +3879,46 @@ extern "C" int mcx_profile_attach(mcx_ctx *c, uint32_t *d_planes, int max_dup, i
         if (hipMalloc((void **)&c->arch.d, first * sizeof(SparseRec)) == hipSuccess) c->arch.cap = first; else { (void)hipGetLastError(); c->arch.d = nullptr; }
     }
     const size_t match_n = (size_t)planes_stride(c->idx->view.G);
-    if (!c->d_prof_match) { int rc = dmalloc(&c->d_prof_match, match_n); if (rc) return rc; }
+    if (!c->d_prof_match) {
+        int rc = dmalloc(&c->d_prof_match, match_n);
+        if (rc && c->later.have) { // the device has filled up since the second set was taken: it goes back, the bookkeeping runs inside the batches' calls from here on
+            auto &L = c->later;
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(L.stream); (void)hipStreamSynchronize(L.keep_stream);
+            for (void **q : {(void **)&L.d_detail_alt, (void **)&L.d_admit_alt, (void **)&L.d_keep_bases, (void **)&L.d_keep_off, (void **)&L.d_keep_bases_alt, (void **)&L.d_keep_off_alt, (void **)&L.d_ev}) if (*q) { (void)hipFree(*q); *q = nullptr; }
+            L.have = false;
+            if (c->kn.timing) fprintf(stderr, "[mcx profile] the second set of detail records goes back: the device has no room for the coverage plane beside it\n");
+            rc = dmalloc(&c->d_prof_match, match_n);
+        }
+        if (rc) return rc;
+    }
     HIP_TRY(hipMemsetAsync(c->d_prof_match, 0, match_n * sizeof(uint16_t), c->stream));
+    if (!c->kn.no_prof_overlap && !c->later.have && !c->later.tried) { // a second set of what a batch's mapping writes for the bookkeeping, if HBM has the room (without it: the bookkeeping inside the call, as before)
+        auto &L = c->later;
+        L.tried = true;
+        L.ev_cap = (uint32_t)std::min<uint64_t>(c->max_reads / 2 + 4096, 0x7fffffffu);
+        // (a stream of the lowest priority: queues of a priority of their own in the runtime — a stream of the default priority may share a hardware queue with the
+        //  context's main stream, and then the bookkeeping runs before the next batch's kernels, not under them — and the mapping goes first where both want the chip)
+        int prio_low = 0, prio_high = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+        size_t hbm_free = 0, hbm_all = 0;
+        (void)hipMemGetInfo(&hbm_free, &hbm_all);
+        const size_t second_set = (size_t)c->dlay.stride * c->max_reads + 2 * (c->max_bases + 4 * c->max_reads) + (size_t)L.ev_cap * sizeof(SparseRec);
+        // (what is left afterwards has to hold the record archive's growth and the caller's own buffers: four gigabytes at least)
+        bool ok = hbm_free > second_set + ((size_t)4 << 30) && hipMalloc((void **)&L.d_detail_alt, (size_t)c->dlay.stride * c->max_reads) == hipSuccess && hipMalloc((void **)&L.d_admit_alt, c->max_reads + 4) == hipSuccess &&
+                  hipMalloc((void **)&L.d_keep_bases, c->max_bases + 64) == hipSuccess && hipMalloc((void **)&L.d_keep_off, (c->max_reads + 1) * sizeof(uint32_t)) == hipSuccess &&
+                  hipMalloc((void **)&L.d_keep_bases_alt, c->max_bases + 64) == hipSuccess && hipMalloc((void **)&L.d_keep_off_alt, (c->max_reads + 1) * sizeof(uint32_t)) == hipSuccess &&
+                  hipMalloc((void **)&L.d_cnt, CNT_N * sizeof(uint32_t)) == hipSuccess && hipMalloc((void **)&L.d_ev, (size_t)L.ev_cap * sizeof(SparseRec)) == hipSuccess &&
+                  hipHostMalloc((void **)&L.h_cnt, CNT_N * sizeof(uint32_t)) == hipSuccess &&
+                  hipStreamCreateWithPriority(&L.stream, hipStreamNonBlocking, prio_low) == hipSuccess && hipStreamCreateWithPriority(&L.keep_stream, hipStreamNonBlocking, prio_low) == hipSuccess;
+        for (hipEvent_t *e : {&L.go, &L.done, &L.kept, &L.begun}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            for (void **q : {(void **)&L.d_detail_alt, (void **)&L.d_admit_alt, (void **)&L.d_keep_bases, (void **)&L.d_keep_off, (void **)&L.d_keep_bases_alt, (void **)&L.d_keep_off_alt, (void **)&L.d_cnt, (void **)&L.d_ev}) if (*q) { (void)hipFree(*q); *q = nullptr; }
+            if (c->kn.timing) fprintf(stderr, "[mcx profile] no room in HBM for a second set of detail records: a batch's bookkeeping runs inside its call\n");
+        }
+        L.have = ok;
+    }
     c->prof_settled = false; c->prof_broken = false;
     return 0;
 }
