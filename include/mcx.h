@@ -194,6 +194,13 @@ int mcx_stream_submit(mcx_ctx *, const uint8_t *bases, const uint32_t *off, uint
  * mcx_stream_submit), so nothing downstream can tell the two apart.  row_words >= ceil(longest read / 16). */
 int mcx_stream_submit_packed(mcx_ctx *, const uint32_t *codes, uint32_t row_words, const uint32_t *len, uint32_t n_reads, const uint64_t *odd,
                              uint32_t n_odd);
+/* One read's row for mcx_stream_submit_packed, the way the file front end makes it (host code, no device involved; sixteen bases at a time where the
+ * CPU has BMI2): row[0 .. row_words) written, the read's bytes that are not upper-case ACGT appended to odd[*n_odd ..] as (read << 32 | position << 8 | byte)
+ * while *n_odd < odd_cap.  Returns how many such bytes the read holds (more than were room for: the caller's list was too short). */
+uint32_t mcx_pack_row(const uint8_t *seq, uint32_t rlen, uint32_t read, uint32_t *row, uint32_t row_words, uint64_t *odd, uint32_t odd_cap, uint32_t *n_odd);
+/* The CPUs the host side counts on when it sizes its thread pools: the affinity mask, cut by the cgroup's CPU-time share (cpu.max / cfs_quota) — not the
+ * machine's hardware threads; MCX_HOST_CPUS=n overrides. */
+uint32_t mcx_host_cpus(void);
 int mcx_stream_map(mcx_ctx *, int paired, int64_t avg_state[4], mcx_aln *aln, uint32_t *cigar, mcx_stats *stats);
 int mcx_stream_collect(mcx_ctx *, uint64_t *bytes_in, uint64_t *bytes_out);
 int mcx_stream_next(mcx_ctx *, const uint8_t **d_bases, const uint32_t **d_off, uint32_t *n_reads, mcx_aln **d_aln, uint32_t **d_cigar);

@@ -10,7 +10,8 @@ scripts/probe/d2h_probe.hip).  A C/C++ host — the CLI, the reference with the 
 situation; this module measures that one: libmcx.so through ctypes, numpy, nothing else.
 
 <dir> holds what bench.py wrote: genome.u8 (codes 0..3), meta.json ({"chr_lens", "alg", "rlen", "reads", "steps", "full_sa",
-"batches": [{"row_words", "n_odd"}]}), batch<i>.words / .lens / .odd.  Prints one JSON line."""
+"batches": [{"row_words", "n_odd"}]}), batch<i>.words / .lens / .odd.  Prints one JSON line.  (Tests: "prefix" instead of the genome — an
+index on disk —, and "dump": a file that takes the last batch's records as they arrived, 32 bytes each.)"""
 from __future__ import annotations
 
 import ctypes as C
@@ -47,13 +48,17 @@ def main(d: str) -> None:
     meta = json.load(open(os.path.join(d, "meta.json")))
     ver = C.c_int()
     hip.hipRuntimeGetVersion(C.byref(ver))
-    codes = np.fromfile(os.path.join(d, "genome.u8"), dtype=np.uint8)
-    dp = C.c_void_p()
-    ok(hip.hipMalloc(C.byref(dp), codes.nbytes), "hipMalloc")
-    ok(hip.hipMemcpy(dp, codes.ctypes.data, codes.nbytes, 1), "hipMemcpy")
-    index = api.Index.from_codes(dp.value, meta["chr_lens"], device=0, full_sa=meta["full_sa"])
-    ok(hip.hipFree(dp), "hipFree")
-    del codes
+    if meta.get("prefix"):
+        index = api.Index(meta["prefix"], device=0, full_sa=bool(meta["full_sa"]))
+        index.build_seconds = 0.0
+    else:
+        codes = np.fromfile(os.path.join(d, "genome.u8"), dtype=np.uint8)
+        dp = C.c_void_p()
+        ok(hip.hipMalloc(C.byref(dp), codes.nbytes), "hipMalloc")
+        ok(hip.hipMemcpy(dp, codes.ctypes.data, codes.nbytes, 1), "hipMemcpy")
+        index = api.Index.from_codes(dp.value, meta["chr_lens"], device=0, full_sa=meta["full_sa"])
+        ok(hip.hipFree(dp), "hipFree")
+        del codes
     n = meta["reads"]
     mapper = api.Mapper(index, alg=meta["alg"], max_read_len=max(256, meta["rlen"]), max_batch_reads=n)
     packed = []
@@ -80,6 +85,8 @@ def main(d: str) -> None:
     b1 = mapper.map_stream_packed(packed, n, True, outs, out32=True)
     dt = time.perf_counter() - t0
     recs = np.ctypeslib.as_array(C.cast(outs[(k - 1) % 3][0].p, C.POINTER(C.c_uint8)), shape=(n * 32,)).view(api.ALN32_DTYPE)
+    if meta.get("dump"):
+        recs.tofile(meta["dump"])
     print(json.dumps({"value": round(k * n / dt, 1), "unit": "reads/s", "steps": k, "ms_per_step": round(1000 * dt / k, 3),
                       "h2d_bytes_per_read": round((b1[0] - b0[0]) / (k * n), 1), "d2h_bytes_per_read": round((b1[1] - b0[1]) / (k * n), 1),
                       "hip_runtime_version": ver.value, "index_build_s": round(index.build_seconds, 2),

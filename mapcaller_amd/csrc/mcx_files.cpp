@@ -673,6 +673,16 @@ void sam_record(const HostIndex &ix, const Batch &bt, uint32_t r, Text &o)
 
 extern "C" void mcx_file_opts_default(mcx_file_opts *o) { memset(o, 0, sizeof *o); }
 
+extern "C" uint32_t mcx_pack_row(const uint8_t *seq, uint32_t rlen, uint32_t read, uint32_t *row, uint32_t row_words, uint64_t *odd, uint32_t odd_cap, uint32_t *n_odd)
+{
+    std::vector<uint64_t> o;
+    pack_row(seq, rlen, read, row, row_words, o);
+    for (uint64_t v : o) if (odd && n_odd && *n_odd < odd_cap) odd[(*n_odd)++] = v;
+    return (uint32_t)o.size();
+}
+
+extern "C" uint32_t mcx_host_cpus(void) { return mcx_usable_cpus(); }
+
 // ---- exchange between the host threads of one process (mapcaller-mi355x -gpus N) ------------------------
 namespace {
 struct Rendezvous {

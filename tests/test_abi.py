@@ -108,3 +108,70 @@ def test_local_exchange_gathers_in_rank_order():
         assert out[r] == [[(16 * rnd + q) % 256 for q in range(n)] for rnd in range(50)]
     L.mcx_exchange_local_free(links)
 
+
+
+def test_pack_row_wide_form_equals_the_plain_one():
+    """mcx_pack_row (the file front end's 2-bit rows, sixteen bases at a time with pext where the CPU has BMI2) against a plain Python
+    restatement of include/mcx.h's rule — and against the library's own base-by-base form (MCX_PLAIN_PACK=1, a process of its own: the
+    choice is made once).  Reads of every length up to 300 with lower-case letters, N and other bytes sprinkled in."""
+    import subprocess, sys
+    code = r'''
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, %r)
+lib = ctypes.CDLL(%r)
+lib.mcx_pack_row.restype = ctypes.c_uint32
+lib.mcx_pack_row.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+rng = np.random.default_rng(11)
+alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+noise = np.frombuffer(b"acgtNnRY.*\n", dtype=np.uint8)
+code = {65: 0, 67: 1, 71: 2, 84: 3}
+out = []
+for rlen in list(range(1, 301)) + [150] * 200:
+    seq = alpha[rng.integers(0, 4, rlen)].copy()
+    if rng.random() < 0.4:
+        k = rng.integers(0, rlen, max(1, rlen // 20))
+        seq[k] = noise[rng.integers(0, len(noise), len(k))]
+    rw = (rlen + 15) // 16 + int(rng.integers(0, 2))
+    row = np.full(rw + 1, 0xDEADBEEF, dtype=np.uint32)
+    odd = np.zeros(400, dtype=np.uint64); n_odd = ctypes.c_uint32(0)
+    got = lib.mcx_pack_row(seq.tobytes(), rlen, 7, row.ctypes.data, rw, odd.ctypes.data, 400, ctypes.byref(n_odd))
+    want = np.zeros(rw, dtype=np.uint64); want_odd = []
+    for i, b in enumerate(seq.tolist()):
+        if b in code: want[i // 16] |= code[b] << (30 - 2 * (i %% 16))
+        else: want_odd.append((7 << 32) | (i << 8) | b)
+    assert got == len(want_odd) == n_odd.value, (rlen, got, len(want_odd))
+    assert row[rw] == 0xDEADBEEF and (row[:rw] == want.astype(np.uint32)).all(), rlen
+    assert odd[:got].tolist() == want_odd, rlen
+    out.append(row[:rw].tobytes() + odd[:got].tobytes())
+import hashlib
+print(hashlib.sha1(b"".join(out)).hexdigest())
+''' % (ROOT, _built("libmcx.so"))
+    digests = []
+    for env in ({}, {"MCX_PLAIN_PACK": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests.append(r.stdout.strip())
+    assert digests[0] == digests[1] and len(digests[0]) == 40
+
+
+def test_host_cpus_is_what_the_process_is_given():
+    """mcx_host_cpus: never more than the affinity mask, cut by a cgroup CPU-time share when there is one, overridden by MCX_HOST_CPUS."""
+    import subprocess, sys
+    code = "import ctypes; L = ctypes.CDLL(%r); L.mcx_host_cpus.restype = ctypes.c_uint32; print(L.mcx_host_cpus())" % _built("libmcx.so")
+    run = lambda env: int(subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, stdout=subprocess.PIPE, text=True, timeout=120, check=True).stdout)
+    n = run({})
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+    share = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        share = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    if share:
+        assert n <= max(1, int(share + 0.5))
+    assert run({"MCX_HOST_CPUS": "3"}) == 3
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench_cpus = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import bench; print(bench.usable_cpus())" % ROOT], stdout=subprocess.PIPE, text=True, timeout=300, check=True).stdout
+    assert int(bench_cpus) == n  # (bench.py runs the reference at -t <the same count>)

@@ -1323,3 +1323,74 @@ def test_maximum_read_length_equals_oracle(api, tmp_path):
         assert st["dp_jobs"] > 0
         mp.close()
     ix.close()
+
+
+@pytest.mark.gpu
+def test_host_without_torch_gets_the_same_records_over_the_boundary(api, golden, tmp_path):
+    """python -m mapcaller_amd.boundary — libmcx.so through ctypes in a process that never loads torch, i.e. on the system's HIP runtime
+    like a C/C++ host (bench.py's value_pcie_inclusive.system_runtime) — against this process (torch's runtime) on the same packed batches:
+    the last batch's 32-byte records equal, field by field; and the child did run on the system's runtime."""
+    import torch
+    g = golden["var"]
+    reads1 = [l for i, l in enumerate(open(g["r1"], "rb").read().split(b"\n")) if i % 4 == 1]
+    reads2 = [l for i, l in enumerate(open(g["r2"], "rb").read().split(b"\n")) if i % 4 == 1]
+    rlen = min(min(len(x) for x in reads1[:4000]), min(len(x) for x in reads2[:4000]))
+    n_pairs, k = 1000, 4
+    packed, host, meta_b = [], [], []
+    for b in range(k):
+        rows = np.stack([np.frombuffer(x[:rlen], dtype=np.uint8) for pno in range(b * n_pairs, (b + 1) * n_pairs) for x in (reads1[pno], reads2[pno])])
+        w, l, o, n_odd, rw = api.pack_reads(torch.from_numpy(rows.copy()))
+        host.append((w, l, o))
+        packed.append((w.data_ptr(), rw, l.data_ptr(), o.data_ptr(), n_odd))
+        w.numpy().tofile(tmp_path / f"batch{b}.words"); l.numpy().tofile(tmp_path / f"batch{b}.lens"); o.numpy().tofile(tmp_path / f"batch{b}.odd")
+        meta_b.append({"row_words": rw, "n_odd": n_odd})
+    n = 2 * n_pairs
+    json.dump({"prefix": g["prefix"], "alg": "ksw2", "rlen": rlen, "reads": n, "steps": k, "full_sa": 1, "batches": meta_b, "dump": str(tmp_path / "recs.bin")},
+              open(tmp_path / "meta.json", "w"))
+    ix = api.Index(g["prefix"], device=0, full_sa=True)
+    mp = api.Mapper(ix, alg="ksw2", max_batch_reads=n)
+    outs = mp.stream_outputs(n, 3, 32)
+    mp.map_stream_packed(packed[:3], n, True, outs, out32=True)  # (the child's warm-up sequence: the insert-size estimate is carried along)
+    mp.map_stream_packed(packed, n, True, outs, out32=True)
+    here = outs[(k - 1) % 3][0].numpy().view(api.ALN32_DTYPE).copy()
+    mp.close(); ix.close()
+    r = subprocess.run([sys.executable, "-m", "mapcaller_amd.boundary", str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                       cwd=os.path.join(os.path.dirname(__file__), ".."))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    there = np.fromfile(tmp_path / "recs.bin", dtype=api.ALN32_DTYPE)
+    assert there.shape == here.shape
+    for f in api.ALN32_DTYPE.names:  # (cigar_off is a place in the batch's CIGAR pool, taken with an atomic: the one field that may differ run to run)
+        if f != "cigar_off":
+            assert (there[f] == here[f]).all(), f
+    assert line["mapped_frac_last_batch"] > 0.9
+    v = subprocess.run([sys.executable, "-c", "import ctypes as C; L = C.CDLL('/opt/rocm/lib/libamdhip64.so.7'); v = C.c_int(); L.hipRuntimeGetVersion(C.byref(v)); print(v.value)"],
+                       stdout=subprocess.PIPE, text=True, timeout=120, check=True).stdout  # (a process of its own: this one has torch's runtime loaded)
+    assert line["hip_runtime_version"] == int(v)  # not the one torch's wheel carries
+
+
+@pytest.mark.gpu
+def test_bookkeeping_behind_the_batch_equals_bookkeeping_inside_the_call(api, golden, monkeypatch, capfd):
+    """One shard: a batch's -vcf bookkeeping is queued behind it and runs under the next batch's kernels (the default), or runs inside the batch's call
+    (MCX_NO_PROF_OVERLAP=1, and whenever HBM has no room for the second set of detail records).  The `var` reads in batches of 1000 both ways: the ten
+    finalized planes and the tally records equal — and the first way did queue (MCX_TIMING says so), the second did not."""
+    g = golden["var"]
+    monkeypatch.setenv("MCX_TIMING", "1")
+    got = []
+    for inside in (False, True):
+        if inside:
+            monkeypatch.setenv("MCX_NO_PROF_OVERLAP", "1")
+        ix = api.Index(g["prefix"], device=0, full_sa=True)
+        mp = api.Mapper(ix, alg="ksw2", max_batch_reads=1000)
+        planes = api.planes_alloc(ix.genome_size, "cuda")
+        mp.profile_attach(planes.data_ptr())
+        capfd.readouterr()
+        mp.map_files(g["r1"], g["r2"], None)
+        mp.profile_finalize(planes.data_ptr())
+        text = api.sparse_to_maps_text(mp.profile_sparse())
+        err = capfd.readouterr().err
+        assert ("queued behind the batch" in err) == (not inside)
+        got.append((api.planes_view(planes, ix.genome_size).cpu().numpy().copy(), maps_canon(text)))
+        mp.close(); ix.close()
+    assert (got[0][0] == got[1][0]).all()
+    assert got[0][1] == got[1][1]
