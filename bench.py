@@ -339,10 +339,10 @@ def file_to_file(args, index, kept, reads_per_step):
         out = {"value": round(st["reads"] / runs[1], 1), "unit": "reads/s", "reads": st["reads"], "seconds": round(runs[1], 4), "first_run_seconds": round(runs[0], 4),
                "without_sam_output": {"value": round(st["reads"] / t_in, 1), "seconds": round(t_in, 4),
                                       "note": "FASTQ files in, records left in host memory: parse + pack + copies + mapping; the difference is SAM text and its way into ONE "
-                                              "file (the kernel serialises writes to a file: tmpfs took 4 GB/s from 64 threads, 3 GB of text per 8 M reads)"},
+                                              "file (writers of one file queue behind its lock: one writer of a growing tmpfs file gets 5.7-6.6 GB/s on this box, 3 GB of text per 8 M reads)"},
                "device_stage_ms_per_batch": {k[3:]: round(st[k] / max(1, -(-st["reads"] // args.file_batch_reads)), 3) for k in st if k.startswith("ms_")},
                "fastq_bytes": os.path.getsize(f1) + os.path.getsize(f2), "sam_bytes": os.path.getsize(sam), "batch_reads": args.file_batch_reads,
-               "host_threads": args.file_threads or "default (min(64, cores / 2) per pool)", "where": tmp.rsplit("/", 1)[0],
+               "host_threads": args.file_threads or "default (three quarters of the CPUs the process is given per pool: %d of usable_cpus() = %d)" % (max(1, usable_cpus() * 3 // 4), usable_cpus()), "where": tmp.rsplit("/", 1)[0],
                "batches_of_the_timed_region": len(kept),
                "note": "two plain FASTQ files -> one SAM file, index already in HBM (the CLI loads it once per run); parse + 2-bit packing, "
                        "copies, mapping, SAM text and positioned writes overlapped (mcx_files.cpp)"}

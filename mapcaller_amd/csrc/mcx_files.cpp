@@ -218,6 +218,19 @@ inline void pack_row(const uint8_t *seq, uint32_t rlen, uint32_t read, uint32_t 
     if (wide) pack_row_bmi2(seq, rlen, read, row, row_words, odd); else pack_row_plain(seq, rlen, read, row, row_words, odd);
 }
 
+// the next '\n' in [p, e), or nullptr: FASTQ lines are a few bytes to a few hundred, so sixteen bytes at a time from the first byte on (memchr's set-up costs more than the search)
+inline const char *find_nl(const char *p, const char *e)
+{
+    const __m128i nl = _mm_set1_epi8('\n');
+    while (p + 16 <= e) {
+        const int m = _mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)p), nl));
+        if (m) return p + __builtin_ctz((unsigned)m);
+        p += 16;
+    }
+    for (; p < e; p++) if (*p == '\n') return p;
+    return nullptr;
+}
+
 // A plain FASTQ file in memory, with the line count ahead of every 64 KB of it: record r begins at line 4 r.
 class MappedFastq {
 public:
@@ -283,7 +296,7 @@ public:
         auto line = [&](const char *&l, size_t &len) { // the next line with its '\n' (getline); false at the end of the file
             if (p >= size_) return false;
             l = map_ + p;
-            const char *e = (const char *)memchr(l, '\n', size_ - p);
+            const char *e = find_nl(l, map_ + size_);
             len = e ? (size_t)(e - l) + 1 : size_ - p;
             p += len;
             return true;
