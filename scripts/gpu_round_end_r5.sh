@@ -1,4 +1,5 @@
 #!/bin/bash
+# round end: the whole GPU suite, the determinism record of the -vcf planes, the default bench line (gpurun -- bash scripts/gpu_round_end_r5.sh)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; ulimit -c 0
 SECONDS=0
 timeout 2700 python -m pytest tests -m gpu -q --timeout 2400 -p no:cacheprovider > gpurun_out/r5_full_test.log 2>&1
