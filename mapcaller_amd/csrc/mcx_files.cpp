@@ -433,7 +433,7 @@ private:
     }
     void feed_bgzf()
     {
-        Pool pool((int)std::max(2u, std::min(8u, mcx_usable_cpus() / 4)));
+        Pool pool((int)std::max(2u, std::min(8u, mcx_usable_cpus() / 2)));
         struct Task { const uint8_t *src; uint32_t clen, isize, crc; size_t dst; };
         std::vector<Task> tasks;
         size_t o = 0;
