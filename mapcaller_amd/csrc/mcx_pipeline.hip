@@ -1988,7 +1988,7 @@ __global__ void __launch_bounds__(256, MCX_FINISH_WAVES) k_finish(Ctx cx, ReadBa
 struct Knobs {
     bool timing = false, seed_one_base = false, dp_by_wave = false, dp_lane_always = false, late_reseed = false, no_work_order = false, no_simple = false,
          simple_no_dp = false, cluster_by_lane = false, rescue_in_line = false, build_by_lane = false, no_sums_cache = false, prof_by_column = false,
-         tier1_hist = false, dp_hist = false, no_tier_overlap = false, no_late_overlap = false, no_prof_overlap = false;
+         tier1_hist = false, dp_hist = false, no_tier_overlap = false, no_late_overlap = false, no_prof_overlap = false, no_prepack = false;
     int seed_fm_budget = 6, build_wave_limit = 0x7fffffff;
     uint32_t order_min = 16384u;
 };
@@ -2001,6 +2001,14 @@ static Knobs knobs_read()
     k.cluster_by_lane = on("MCX_CLUSTER_BY_LANE"); k.rescue_in_line = on("MCX_RESCUE_IN_LINE"); k.build_by_lane = on("MCX_BUILD_BY_LANE");
     k.no_sums_cache = on("MCX_NO_SUMS_CACHE"); k.prof_by_column = on("MCX_PROF_BY_COLUMN"); k.tier1_hist = on("MCX_TIER1_HIST"); k.dp_hist = on("MCX_DP_HIST");
     k.no_tier_overlap = on("MCX_NO_TIER_OVERLAP"); k.no_late_overlap = on("MCX_NO_LATE_OVERLAP"); k.no_prof_overlap = on("MCX_NO_PROF_OVERLAP");
+    { // a batch packed on its way in (mcx_stream_submit_packed) pays on runtimes whose copies in and out overlap: 16.2-16.3 against 16.7-16.8 ms per step on ROCm 7.2's; on
+      // one that puts both directions on one SDMA engine (HIP 7.0, what torch's wheel carries) the copy in ends late and the longer chain behind it reaches into the next
+      // step: 17.5 against 17.1.  MCX_PREPACK=0/1 decides by hand.
+        int ver = 0;
+        (void)hipRuntimeGetVersion(&ver);
+        const char *e = getenv("MCX_PREPACK");
+        k.no_prepack = e ? atoi(e) == 0 : ver < 70200000;
+    }
     if (const char *e = getenv("MCX_SEED_FM_BUDGET")) k.seed_fm_budget = std::max(1, atoi(e));
     if (const char *e = getenv("MCX_BUILD_WAVE_LIMIT")) k.build_wave_limit = atoi(e); // (tests: the bound sum from which k_build_wave hands a pair to one lane)
     if (const char *e = getenv("MCX_ORDER_MIN")) k.order_min = (uint32_t)std::max(1, atoi(e)); // (tests: small batches through k_simple and the order too)
@@ -2062,6 +2070,10 @@ struct mcx_ctx {
     const mcx_index *idx = nullptr;
     bool counted = false; // (among idx->n_ctx)
     bool lens_checked = false; // the batch about to begin holds no read longer than max_read_len (mcx_stream_next says so for batches that came as 2-bit rows)
+    // ... and is packed already (mcx_stream_submit_packed packed it behind its copy in, under the batch before it): where, from which bytes, mated or not, and its any-N word
+    struct PrePacked { const uint32_t *packed = nullptr; const uint8_t *bases = nullptr; int paired = 0; const uint32_t *any_n = nullptr; } pre;
+    int last_paired = 1;                 // what the last batch was mapped as: the guess a batch on its way in is packed under
+    const uint32_t *packed_now = nullptr; // the 2-bit form the batch in flight is mapped from (d_packed, or a slot's)
     Knobs kn;
     Params pm;
     mcx_opts opts;
@@ -2143,6 +2155,7 @@ struct mcx_ctx {
         uint32_t *d_codes = nullptr, *d_len = nullptr, *d_err = nullptr; uint64_t *d_odd = nullptr; uint32_t odd_cap = 0; // mcx_stream_submit_packed: what arrives; restored to d_bases / d_off
         uint32_t n_reads = 0; int state = 0; uint64_t seq = 0; // 0 free, 1 copy in started, 2 handed to the kernels, 3 copy out started
         bool lens_checked = false; // the batch came as 2-bit rows: no read is longer than the context's slots (k_unpack_reads / k_neutralize saw to it)
+        uint32_t *d_prepack = nullptr, *d_any_n = nullptr; bool prepacked = false; int pre_paired = 0; // k_pack_reads' output made on the way in
         hipEvent_t in_ready = nullptr, mapped = nullptr, out_done = nullptr;
     } slot[3];
     hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
@@ -2430,7 +2443,7 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     if (c->tail.d) (void)hipFree(c->tail.d);
     if (c->tail.h) (void)hipHostFree(c->tail.h);
     for (auto &sl : c->slot) {
-        void *q[] = {sl.d_bases, sl.d_off, sl.d_recs, sl.d_cig, sl.d_codes, sl.d_len, sl.d_odd, sl.d_err, sl.d_recs32};
+        void *q[] = {sl.d_bases, sl.d_off, sl.d_recs, sl.d_cig, sl.d_codes, sl.d_len, sl.d_odd, sl.d_err, sl.d_recs32, sl.d_prepack, sl.d_any_n};
         for (void *x : q) if (x) (void)hipFree(x);
         for (hipEvent_t e : {sl.in_ready, sl.mapped, sl.out_done}) if (e) (void)hipEventDestroy(e);
     }
@@ -2453,7 +2466,7 @@ static Ctx make_ctx(const mcx_ctx *c, int tier, int paired)
     cx.mapq_tab = c->d_mapq; cx.mapq_rows = c->mapq_rows; cx.dp_summary = 1;
     cx.detail = c->prof_planes ? c->d_detail : nullptr; cx.dlay = c->dlay;
     cx.cig_pool = c->run.cig; cx.cig_pool_n = c->d_batch_flags; cx.cig_pool_cap = c->run.cig_cap;
-    cx.packed = c->d_packed; cx.wpad = c->wpad; cx.read_ext = c->d_read_ext; cx.seed_pool = nullptr;
+    cx.packed = c->packed_now ? c->packed_now : c->d_packed; cx.wpad = c->wpad; cx.read_ext = c->d_read_ext; cx.seed_pool = nullptr;
     return cx;
 }
 
@@ -2576,7 +2589,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
     HIP_TRY(hipMemsetAsync(R.d_cnt, 0, CNT_ALL * sizeof(uint32_t), s)); // (the pass's counters, the class counts of its order, the bucket counts of its DP lists)
     SeedOut so; so.tasks = R.d_tasks; so.n_tasks = R.d_cnt + CNT_TASKS; so.task_cap = R.task_cap;
     so.read_ext = c->d_read_ext; so.read_blocks = c->d_read_blocks;
-    so.packed = c->d_packed; so.wpad = c->wpad; so.queue = R.d_cnt + CNT_QUEUE;
+    so.packed = c->packed_now ? c->packed_now : c->d_packed; so.wpad = c->wpad; so.queue = R.d_cnt + CNT_QUEUE;
     so.src_state = nullptr; so.src_lay = c->tier[0].lay; so.src_caps = c->tier[0].caps;
     if (hits_from_tier0 && tier == 1 && cx.ix.sa_full && !kn.late_reseed) so.src_state = c->tier[0].state;
     RescueList rl; rl.ids = R.d_rescue; rl.n = R.d_cnt + CNT_RESCUE; rl.cap = R.rescue_cap;
@@ -3185,6 +3198,9 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
     HIP_TRY(hipMemsetAsync(c->d_batch_flags, 0, 4 * sizeof(uint32_t), s));
     const bool vouched = c->lens_checked;
     c->lens_checked = false; // (said of this batch only)
+    const mcx_ctx::PrePacked pre = c->pre;
+    c->pre = mcx_ctx::PrePacked();
+    c->last_paired = paired ? 1 : 0;
     if (vouched) c->h_cnt[1] = (uint32_t)c->rlen_max; // (vouched for: no kernel, no wait at the start of the step — under the copies of the neighbouring batches such a wait takes milliseconds)
     else { // every read must fit the slots the context was sized for
         k_max_read_len<<<512, 256, 0, s>>>(d_off, n_reads, c->d_batch_flags + 1);
@@ -3201,7 +3217,14 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
         // (the reads' flag bytes of the -vcf bookkeeping start here: bit 1 — a byte that is not an upper-case ACGT — is k_pack_reads'; MCX_PROF_BY_COLUMN:
         //  tests — every read is treated as if it held one, so that exact seeds are walked column by column like every other fragment)
         if (c->prof_planes) HIP_TRY(hipMemsetAsync(c->d_admit, c->kn.prof_by_column ? 2 : 0, ((size_t)n_reads + 3) & ~(size_t)3, s));
-        k_pack_reads<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(br.rb, paired, c->wpad, tpr, c->d_packed, c->d_batch_flags + 3, c->prof_planes ? c->d_admit : nullptr);
+        if (vouched && pre.packed && pre.bases == d_bases && pre.paired == (paired ? 1 : 0) && !c->prof_planes) {
+            // packed on its way in, under the batch before it (mcx_stream_submit_packed): the step starts with the search; the any-N word comes along
+            c->packed_now = pre.packed;
+            HIP_TRY(hipMemcpyAsync(c->d_batch_flags + 3, pre.any_n, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        } else {
+            c->packed_now = c->d_packed;
+            k_pack_reads<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(br.rb, paired, c->wpad, tpr, c->d_packed, c->d_batch_flags + 3, c->prof_planes ? c->d_admit : nullptr);
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_pack[1], s));
     }
@@ -3697,6 +3720,21 @@ extern "C" int mcx_stream_submit_packed(mcx_ctx *c, const uint32_t *codes, uint3
     k_neutralize<<<256, 256, 0, s>>>(sl->d_off, n_reads, sl->d_err);
     HIP_TRY(hipGetLastError());
     sl->lens_checked = true;
+    // the batch's 2-bit form for the kernels, made here — behind its copy in, under the batch before it — instead of at the start of its own step (0.76 ms of
+    // the step per 8 M reads).  Mated or not is a guess (what the last batch was); a wrong one, or a profile attached meanwhile, and the step packs as before.
+    sl->prepacked = false;
+    if (!c->prof_planes && !c->kn.no_prepack) {
+        if (!sl->d_prepack) {
+            if ((rc = dmalloc(&sl->d_prepack, c->max_reads * (uint64_t)c->wpad))) return rc;
+            if ((rc = dmalloc(&sl->d_any_n, 1))) return rc;
+        }
+        ReadBatch rb; rb.bases = sl->d_bases; rb.off = sl->d_off; rb.n_reads = n_reads;
+        const int tpr = (c->rlen_max + 31) / 32 + 1;
+        HIP_TRY(hipMemsetAsync(sl->d_any_n, 0, 4, s));
+        k_pack_reads<<<(unsigned)(((uint64_t)n_reads * (uint64_t)tpr + 255) / 256), 256, 0, s>>>(rb, c->last_paired, c->wpad, tpr, sl->d_prepack, sl->d_any_n, nullptr);
+        HIP_TRY(hipGetLastError());
+        sl->prepacked = true; sl->pre_paired = c->last_paired;
+    }
     HIP_TRY(hipEventRecord(sl->in_ready, s));
     sl->n_reads = n_reads; sl->state = 1; sl->seq = ++c->stream_seq;
     c->stream_bytes_in += (uint64_t)n_reads * row_words * 4 + (uint64_t)n_reads * 4 + (uint64_t)n_odd * 8;
@@ -3713,7 +3751,7 @@ extern "C" int mcx_stream_submit(mcx_ctx *c, const uint8_t *bases, const uint32_
     int rc = stream_slot(c, &sl);
     if (rc) return rc;
     if (sl->d_err) HIP_TRY(hipMemsetAsync(sl->d_err, 0, 4, c->h2d_stream)); // (the slot once took 2-bit rows: nothing of that batch's verdict is this one's)
-    sl->lens_checked = false;
+    sl->lens_checked = false; sl->prepacked = false;
     if ((rc = bulk_copy(c, sl->d_bases, bases, off[n_reads], hipMemcpyHostToDevice, c->h2d_stream))) return rc;
     if ((rc = bulk_copy(c, sl->d_off, off, (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice, c->h2d_stream))) return rc;
     HIP_TRY(hipEventRecord(sl->in_ready, c->h2d_stream));
@@ -3732,6 +3770,8 @@ extern "C" int mcx_stream_next(mcx_ctx *c, const uint8_t **d_bases, const uint32
     if (!sl) return fail(MCX_ERR_ARG, "mcx_stream_next: nothing submitted");
     HIP_TRY(hipStreamWaitEvent(c->stream, sl->in_ready, 0));
     c->lens_checked = sl->lens_checked; // (for the mcx_batch_begin that follows: no need to look for an over-long read, nor to wait for the answer)
+    c->pre = mcx_ctx::PrePacked();
+    if (sl->prepacked) { c->pre.packed = sl->d_prepack; c->pre.bases = sl->d_bases; c->pre.paired = sl->pre_paired; c->pre.any_n = sl->d_any_n; }
     sl->state = 2;
     *d_bases = sl->d_bases; *d_off = sl->d_off; *d_aln = (mcx_aln *)sl->d_recs; *d_cigar = sl->d_cig;
     if (n_reads) *n_reads = sl->n_reads;
