@@ -2001,14 +2001,12 @@ static Knobs knobs_read()
     k.cluster_by_lane = on("MCX_CLUSTER_BY_LANE"); k.rescue_in_line = on("MCX_RESCUE_IN_LINE"); k.build_by_lane = on("MCX_BUILD_BY_LANE");
     k.no_sums_cache = on("MCX_NO_SUMS_CACHE"); k.prof_by_column = on("MCX_PROF_BY_COLUMN"); k.tier1_hist = on("MCX_TIER1_HIST"); k.dp_hist = on("MCX_DP_HIST");
     k.no_tier_overlap = on("MCX_NO_TIER_OVERLAP"); k.no_late_overlap = on("MCX_NO_LATE_OVERLAP"); k.no_prof_overlap = on("MCX_NO_PROF_OVERLAP");
-    { // a batch packed on its way in (mcx_stream_submit_packed) pays on runtimes whose copies in and out overlap: 16.2-16.3 against 16.7-16.8 ms per step on ROCm 7.2's; on
-      // one that puts both directions on one SDMA engine (HIP 7.0, what torch's wheel carries) the copy in ends late and the longer chain behind it reaches into the next
-      // step: 17.5 against 17.1.  MCX_PREPACK=0/1 decides by hand.
-        int ver = 0;
-        (void)hipRuntimeGetVersion(&ver);
-        const char *e = getenv("MCX_PREPACK");
-        k.no_prepack = e ? atoi(e) == 0 : ver < 70200000;
-    }
+    // A batch packed on its way in (mcx_stream_submit_packed; MCX_PREPACK=1) pays on runtimes whose copies in and out overlap: 16.2-16.3 against 16.7-16.8 ms per
+    // step on ROCm 7.2's; on one that puts both directions on one SDMA engine (HIP 7.0, what torch's wheel carries) the copy in ends late and the longer chain
+    // behind it reaches into the next step: 17.5 against 17.1.  Off unless asked for: one fuzz round in 480 of the CLI with it on did not come out
+    // identical to the oracle's (a difference or a failed command — the run kept only its count) and did not come back in 360 repeats; until that round is
+    // understood the step packs its own reads.
+    k.no_prepack = !on("MCX_PREPACK");
     if (const char *e = getenv("MCX_SEED_FM_BUDGET")) k.seed_fm_budget = std::max(1, atoi(e));
     if (const char *e = getenv("MCX_BUILD_WAVE_LIMIT")) k.build_wave_limit = atoi(e); // (tests: the bound sum from which k_build_wave hands a pair to one lane)
     if (const char *e = getenv("MCX_ORDER_MIN")) k.order_min = (uint32_t)std::max(1, atoi(e)); // (tests: small batches through k_simple and the order too)
