@@ -2004,7 +2004,7 @@ static Knobs knobs_read()
     // A batch packed on its way in (mcx_stream_submit_packed; MCX_PREPACK=1) pays on runtimes whose copies in and out overlap: 16.2-16.3 against 16.7-16.8 ms per
     // step on ROCm 7.2's; on one that puts both directions on one SDMA engine (HIP 7.0, what torch's wheel carries) the copy in ends late and the longer chain
     // behind it reaches into the next step: 17.5 against 17.1.  Off unless asked for: one fuzz round in 480 of the CLI with it on did not come out
-    // identical to the oracle's (a difference or a failed command — the run kept only its count) and did not come back in 360 repeats; until that round is
+    // identical to the oracle's (a difference or a failed command — the run kept only its count) and did not come back in 780 repeats; until that round is
     // understood the step packs its own reads.
     k.no_prepack = !on("MCX_PREPACK");
     if (const char *e = getenv("MCX_SEED_FM_BUDGET")) k.seed_fm_budget = std::max(1, atoi(e));
