@@ -266,11 +266,14 @@ def pcie_inclusive(args, mapper, batches, reads_per_step, dist, dev):
         host.append((words, lens, odd, n_odd, row_words))
     nd = getattr(args, "native_dir", None)
     if nd:  # the same batches for the process on the system's runtime (native_boundary below)
-        meta = json.load(open(os.path.join(nd, "meta.json")))
-        meta["batches"] = [{"row_words": rw, "n_odd": n} for (_, _, _, n, rw) in host]
-        for i, (w, l, o, _, _) in enumerate(host):
-            w.numpy().tofile(os.path.join(nd, f"batch{i}.words")); l.numpy().tofile(os.path.join(nd, f"batch{i}.lens")); o.numpy().tofile(os.path.join(nd, f"batch{i}.odd"))
-        json.dump(meta, open(os.path.join(nd, "meta.json"), "w"))
+        try:
+            meta = json.load(open(os.path.join(nd, "meta.json")))
+            meta["batches"] = [{"row_words": rw, "n_odd": n} for (_, _, _, n, rw) in host]
+            for i, (w, l, o, _, _) in enumerate(host):
+                w.numpy().tofile(os.path.join(nd, f"batch{i}.words")); l.numpy().tofile(os.path.join(nd, f"batch{i}.lens")); o.numpy().tofile(os.path.join(nd, f"batch{i}.odd"))
+            json.dump(meta, open(os.path.join(nd, "meta.json"), "w"))
+        except OSError:
+            args.native_dir = None
     packed = [(w.data_ptr(), rw, l.data_ptr(), o.data_ptr(), n) for (w, l, o, n, rw) in host]
     packed = [packed[i % len(packed)] for i in range(k)]  # (more steps than resident batches: the batches come round again)
     outs = mapper.stream_outputs(reads_per_step, 3, 32)  # (page-locking gigabytes takes seconds: not part of the path)
@@ -926,13 +929,16 @@ def main():
     codes, lens, genome_note = make_genome(args, dev, seed=1234)
     native_dir = None
     if args.native_boundary and args.pcie_steps > 0 and world == 1 and not args.single_end and os.path.isdir("/dev/shm"):
-        native_dir = tempfile.mkdtemp(prefix="mcx_boundary_", dir="/dev/shm")  # what the other process's run is made of: the genome now, the packed batches by pcie_inclusive
-        args.native_dir = native_dir
-        import atexit
-        atexit.register(shutil.rmtree, native_dir, True)
-        codes.cpu().numpy().tofile(os.path.join(native_dir, "genome.u8"))
-        json.dump({"chr_lens": [int(x) for x in lens], "alg": args.alg, "rlen": args.rlen, "reads": 2 * args.batch_pairs, "steps": args.pcie_steps, "full_sa": int(args.full_sa)},
-                  open(os.path.join(native_dir, "meta.json"), "w"))
+        try:  # (a tmpfs too small for the genome: the leg from the other process is left out, nothing else)
+            native_dir = tempfile.mkdtemp(prefix="mcx_boundary_", dir="/dev/shm")  # what the other process's run is made of: the genome now, the packed batches by pcie_inclusive
+            import atexit
+            atexit.register(shutil.rmtree, native_dir, True)
+            codes.cpu().numpy().tofile(os.path.join(native_dir, "genome.u8"))
+            json.dump({"chr_lens": [int(x) for x in lens], "alg": args.alg, "rlen": args.rlen, "reads": 2 * args.batch_pairs, "steps": args.pcie_steps, "full_sa": int(args.full_sa)},
+                      open(os.path.join(native_dir, "meta.json"), "w"))
+            args.native_dir = native_dir
+        except OSError:
+            native_dir = None
     t0 = time.perf_counter()
     index = api.Index.from_codes(codes.data_ptr(), lens, device=local, full_sa=int(args.full_sa))
     t_index = time.perf_counter() - t0
