@@ -64,6 +64,20 @@ STEP_KERNEL_PREFIXES = ("k_pack_reads", "k_seed", "k_simple", "k_order_", "k_clu
                         "k_check_est", "k_max_read_len", "k_fill_i32", "k_sa", "k_gather_pout")  # what a step launches (not the index builder's kernels)
 
 
+def kernel_source_sha():
+    """What the device code is made of, as one hash: the committed PMC summaries carry it (scripts/summarize_profile.py --source-sha), and a summary made
+    from other sources than the ones this run was built from is not this run's traffic."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "mapcaller_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_profile(args):
     """What the committed rocprofv3 --pmc passes of this same command measured per launch (counters cannot be read from
     inside the run): HBM bytes (FETCH_SIZE + WRITE_SIZE), L2 requests (TCC_HIT + TCC_MISS), vector instructions and wave
@@ -103,7 +117,8 @@ def pmc_profile(args):
             if nb and any_counter:
                 e["launches_per_step"] = round(any_counter["launches"] / nb, 2)
             out[k] = e
-        return {"kernels": out, "file": path}
+        sha = s.get("kernel_source_sha")
+        return {"kernels": out, "file": path, "source_sha": sha, "stale": bool(sha) and sha != kernel_source_sha()}
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None
 
@@ -166,6 +181,11 @@ def roofline(args, d, reads_per_s):
     the library times the kernel by itself, the committed kernel trace's otherwise."""
     steps = max(args.steps, 1)
     prof = pmc_profile(args)
+    stale = bool(prof and prof.get("stale"))
+    if stale:  # counters of other kernel sources: not this run's bytes — said, and not used
+        print(f"bench.py: {prof['file']} was collected from kernel sources {prof['source_sha']}, this tree is {kernel_source_sha()}: its traffic is NOT used "
+              "(re-run scripts/collect_profile.sh)", file=sys.stderr)
+        stale_file, prof = prof["file"], None
     kern = prof["kernels"] if prof else {}
     nw = "true" if args.alg == "nw" else "false"
     stage_of, live = {}, {}
@@ -195,6 +215,7 @@ def roofline(args, d, reads_per_s):
         r = {"bound": "hbm", "kernel": longest, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
              "traffic_unit": None if not traffic else f"HBM bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, {prof['file']})",
+             "traffic_from": None if not traffic else f"{prof['file']} (committed rocprofv3 --pmc pass of this command, kernel sources {prof.get('source_sha') or 'not recorded'}); the duration is live",
              "avg_launch_ms": round(live[longest], 3),
              "basis": "measured HBM bytes of the launch (committed PMC pass of this command) over the live launch time" if traffic else
                       "no PMC pass of this workload is committed: the kernel's essential bytes (DESIGN.md §3) over the live launch time",
@@ -226,6 +247,8 @@ def roofline(args, d, reads_per_s):
                           "misses_g_per_s": round(p["l2_misses"] / (ms * 1e-3) / 1e9, 1), "walk_miss_ceiling_g_per_s": WALK_MISS_CEILING_G_PER_S,
                           "miss_frac_of_ceiling": round(p["l2_misses"] / (ms * 1e-3) / 1e9 / WALK_MISS_CEILING_G_PER_S, 3)})
             req[k] = q
+    if stale:
+        r["traffic_stale"] = f"{stale_file} predates the kernel sources of this build"
     r.update({"per_kernel": per, "request_rate": req,
               "launches_per_step": round(launches, 1) if launches else None,
               "speed_of_light_equiv": {"kernel": "k_seed", "bytes_per_read": round(seed_bytes / max(d["reads"], 1), 1),
@@ -464,7 +487,7 @@ def other_genome(args):
     """Two steps against the other kind of synthetic genome, as a child process once this one has let go of the GPU's memory."""
     kind = "uniform" if args.genome == "human" else "human"
     cmd = [sys.executable, os.path.abspath(__file__), "--genome", kind, "--second-genome", "0", "--steps", "2", "--warmup", "1", "--cpu-pairs", "0",
-           "--vcf-reduce", "0", "--other-configs", "0", "--file-steps", "0", "--pcie-steps", "0", "--genome-mbp", str(args.genome_mbp), "--contigs", str(args.contigs), "--batch-pairs", str(args.batch_pairs),
+           "--vcf-reduce", "0", "--other-configs", "0", "--file-steps", "0", "--pcie-steps", "0", "--full-line", "1", "--detail-stdout", "0", "--detail-tag", "other_genome", "--genome-mbp", str(args.genome_mbp), "--contigs", str(args.contigs), "--batch-pairs", str(args.batch_pairs),
            "--rlen", str(args.rlen), "--sub", str(args.sub), "--ins", str(args.ins), "--dele", str(args.dele), "--alg", args.alg, "--full-sa", str(args.full_sa)]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=900)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -489,7 +512,7 @@ def other_configs(args):
     res = []
     for name, extra in runs:
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--second-genome", "0", "--other-configs", "0", "--vcf-reduce", "0",
-               "--pcie-steps", "0", "--file-steps", "0", "--full-sa", str(args.full_sa)] + extra
+               "--pcie-steps", "0", "--file-steps", "0", "--full-line", "1", "--detail-stdout", "0", "--detail-tag", "cfg" + name.split(":")[0].split()[-1], "--full-sa", str(args.full_sa)] + extra
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=900)
             o = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -502,6 +525,103 @@ def other_configs(args):
         except Exception as e:
             res.append({"config": name, "error": str(e)[:200]})
     return res
+
+
+LINE_LIMIT = 6000  # bytes of the final stdout line: the driver keeps the last 8 KB of stdout, and a line it cannot see whole it cannot parse (round 5: 33.6 KB, `parsed: null`)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None} if isinstance(d, dict) else None
+
+
+def compact_line(out, detail_path=None):
+    """The ONE line the driver parses: the contract's keys, the dominant kernel's roofline and the CPU baseline as numbers, the other legs as
+    their headline figures.  Everything else — per-kernel tables, request rates, the prose — is the detail record (`detail`: its path; also printed
+    as an earlier stdout line).  Never longer than LINE_LIMIT: sections are dropped from the end of `order` until it fits."""
+    cfg = out.get("config", {})
+    wl = cfg.get("workload", "")
+    wl = re.sub(r" \(\d+ contigs, .*?; GRCh38 itself is unavailable offline\)", " (synthetic: GRCh38 is unavailable offline; repeat landscape in the detail record)", wl)
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {"workload": wl[:400], **(_pick(cfg, ("reads_per_step_per_gpu", "index_hbm_gb", "multi_gpu_host_ms_per_step")) or {})}
+    line["config"]["multi_gpu"] = None if not cfg.get("multi_gpu") else str(cfg["multi_gpu"])[:260]
+    r = out.get("roofline") or {}
+    line["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic")}
+    line["roofline"].update(_pick(r, ("traffic_from", "traffic_stale", "avg_launch_ms", "algorithmic_bytes_per_launch", "algorithmic_frac", "gcups", "ops_per_cell", "frac_at_minimal_ops",
+                                      "launches_per_step")) or {})
+    if isinstance(line["roofline"].get("kernel"), str):
+        line["roofline"]["kernel"] = line["roofline"]["kernel"][:80]
+    if r.get("launch_bound"):
+        line["roofline"]["launch_bound"] = _pick(r["launch_bound"], ("ms_per_step", "longest_kernel", "longest_kernel_ms", "launches_per_step", "mean_us_per_launch"))
+    c = out.get("cpu_baseline")
+    if isinstance(c, dict):
+        line["cpu_baseline"] = _pick(c, ("value", "unit", "cores", "kind", "error")) or {}
+        if "sample" in c:
+            line["cpu_baseline"]["sample"] = str(c["sample"])[:200]
+        for sub in ("mapping_only", "single_thread"):
+            if isinstance(c.get(sub), dict):
+                line["cpu_baseline"][sub] = _pick(c[sub], ("value", "cores"))
+    line["stage_ms_per_step"] = out.get("stage_ms_per_step")
+    line["per_read"] = out.get("per_read")
+    optional = {}
+    p = out.get("value_pcie_inclusive")
+    if isinstance(p, dict):
+        optional["value_pcie_inclusive"] = _pick(p, ("value", "unit", "steps", "ms_per_step", "h2d_bytes_per_read", "d2h_bytes_per_read", "error")) or {}
+        if isinstance(p.get("system_runtime"), dict):
+            optional["value_pcie_inclusive"]["system_runtime"] = _pick(p["system_runtime"], ("value", "ms_per_step", "error"))
+    f = out.get("value_file_to_file")
+    if isinstance(f, dict):
+        optional["value_file_to_file"] = _pick(f, ("value", "unit", "reads", "seconds", "error")) or {}
+        if isinstance(f.get("without_sam_output"), dict):
+            optional["value_file_to_file"]["without_sam_output"] = f["without_sam_output"].get("value")
+    v = out.get("vcf_reduce")
+    if isinstance(v, dict):
+        optional["vcf_reduce"] = _pick(v, ("profile_batch_ms", "same_batches_without_profile_ms", "hbm_free_gb", "reduce_ms", "reduce_gb", "reduce_gbs_into_root", "sparse_records", "error")) or {}
+        if isinstance(v.get("call_variants"), dict):
+            optional["vcf_reduce"]["call_variants_ms"] = v["call_variants"].get("ms_total")
+    g = out.get("other_genome")
+    if isinstance(g, dict):
+        optional["other_genome"] = _pick(g, ("genome", "value", "ms_per_step", "error"))
+    oc = out.get("other_configs")
+    if isinstance(oc, list):
+        optional["other_configs"] = []
+        for e in oc:
+            x = {"config": str(e.get("config", ""))[:90]}
+            x.update(_pick(e, ("value", "unit", "ms_per_step", "error")) or {})
+            if isinstance(e.get("roofline"), dict):
+                x["roofline"] = _pick(e["roofline"], ("bound", "frac", "achieved", "peak", "unit", "gcups", "frac_at_minimal_ops"))
+            if isinstance(e.get("cpu_baseline"), dict):
+                x["cpu_baseline"] = _pick(e["cpu_baseline"], ("value", "cores", "kind"))
+            if isinstance(e.get("stage_ms_per_step"), dict):
+                x["stage_ms_per_step"] = e["stage_ms_per_step"]
+            optional["other_configs"].append(x)
+    if detail_path:
+        line["detail"] = detail_path
+    order = ["value_pcie_inclusive", "value_file_to_file", "vcf_reduce", "other_configs", "other_genome"]
+    for k in order:
+        if k in optional:
+            line[k] = optional[k]
+    for k in reversed(order + ["per_read", "stage_ms_per_step"]):  # (cannot happen with the sections as they are; a guard, not a plan)
+        if len(json.dumps(line)) <= LINE_LIMIT:
+            break
+        line.pop(k, None)
+    return line
+
+
+def emit(out, args):
+    """Detail record first (a file under --detail-dir; with --detail-stdout 1 also an earlier stdout line that does not start with `{`), then the compact line LAST."""
+    path = None
+    try:
+        os.makedirs(args.detail_dir, exist_ok=True)
+        path = os.path.join(args.detail_dir, "bench_detail.json" if not args.detail_tag else f"bench_detail_{args.detail_tag}.json")
+        with open(path, "w") as fh:
+            json.dump(out, fh)
+        path = os.path.relpath(path, ROOT) if os.path.abspath(path).startswith(ROOT) else path
+    except OSError:
+        path = None
+    if args.detail_stdout:
+        print("BENCH_DETAIL " + json.dumps(out), flush=True)
+    line = json.dumps(out if args.full_line else compact_line(out, path))
+    print(line, flush=True)
 
 
 def parse():
@@ -544,6 +664,10 @@ def parse():
     ap.add_argument("--vcf-reduce", type=int, default=1,
                     help="after the timed region: accumulate the -vcf alignment profile of one batch and sum it over the "
                          "ranks with RCCL (1 = yes, 0 = no, -1 = only when more than one GPU)")
+    ap.add_argument("--detail-dir", default=os.path.join(ROOT, "gpurun_out"), help="where the detail record (every section in full) is written; the final line names it")
+    ap.add_argument("--detail-tag", default="", help="suffix of the detail record's file name")
+    ap.add_argument("--detail-stdout", type=int, default=0, help="1: the detail record also as an earlier stdout line (`BENCH_DETAIL {...}`); off by default — nothing but the final line goes to stdout")
+    ap.add_argument("--full-line", type=int, default=0, help="1: the final line is the detail record itself (what the child processes of this script read)")
     return ap.parse_args()
 
 
@@ -1105,7 +1229,7 @@ def main():
                     out["other_genome"] = {"error": str(e)[:200]}
             if args.other_configs:
                 out["other_configs"] = other_configs(args)
-        print(json.dumps(out), flush=True)
+        emit(out, args)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

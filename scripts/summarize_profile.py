@@ -93,6 +93,13 @@ def main():
                  "FETCH_SIZE*1024 equals TCC_MISS_sum*64 within 1 %, i.e. 64-byte fabric requests counted at 64 B: the guide's "
                  "x2 correction (wide coalesced streams tallied as 128-B requests at 64 B) does not apply to this pattern; it is applied to "
                  "the streaming kernels (" + ", ".join(STREAMING) + ")."}
+    try:  # the kernel sources the profiled build was made from (bench.py refuses a summary whose hash is not its own tree's)
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        s["kernel_source_sha"] = bench.kernel_source_sha()
+    except Exception:
+        pass
     if a.batches:
         s["batches_mapped_by_the_pmc_runs"] = a.batches
     if a.trace:
