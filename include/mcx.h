@@ -191,7 +191,11 @@ int mcx_stream_submit(mcx_ctx *, const uint8_t *bases, const uint32_t *off, uint
  * (A 0, C 1, G 2, T 3; sixteen bases to a word, the first in the top bits) are the words codes[r * row_words ..]; every byte of
  * a read that is not one of the upper-case letters ACGT is listed in `odd` as (read << 32 | position << 8 | byte) and has
  * code 0 in the row.  The device restores the ASCII bytes exactly (mcx_stream_next hands out the same d_bases / d_off as after
- * mcx_stream_submit), so nothing downstream can tell the two apart.  row_words >= ceil(longest read / 16). */
+ * mcx_stream_submit), so nothing downstream can tell the two apart.  row_words >= ceil(longest read / 16).
+ * DEFERRED ERROR: the lengths are checked on the device by the kernel that restores the bytes (no wait at the start of the step).  A batch with a read longer
+ * than its row / max_read_len, or with more bases than the slot holds, is mapped as n_reads EMPTY reads (every record unmapped) and refused after the fact with
+ * MCX_ERR_ARG: by mcx_stream_map / mcx_stream_map32 when they return, and — for the two-half form mcx_stream_next + mcx_map_batch_dev / mcx_batch_* +
+ * mcx_stream_mapped / _mapped32 — by the mcx_stream_collect that hands the batch's records over (the slot is released either way; its records are not results). */
 int mcx_stream_submit_packed(mcx_ctx *, const uint32_t *codes, uint32_t row_words, const uint32_t *len, uint32_t n_reads, const uint64_t *odd,
                              uint32_t n_odd);
 /* One read's row for mcx_stream_submit_packed, the way the file front end makes it (host code, no device involved; sixteen bases at a time where the

@@ -1,0 +1,354 @@
+// mapcaller_amd/csrc/mcx_dp_lane2.h — gapped extension, TWO PROBLEMS PER LANE in 16-bit halves.
+//
+// The same recurrences, flags and walks as mcx_dp_lane.h (ksw_extz2_sse + ksw_backtrack, reference
+// src/ksw2_alignment.cpp:25-248 — whose core is 16 int8 lanes per instruction, macros :74-95; nw_alignment,
+// src/nw_alignment.cpp:18-83), with the arithmetic the reference's own vectors have: every value of both
+// recurrences fits sixteen bits (ksw2's differences lie in [-8, 14]; nw's doubled scores are bounded by
+// 3 (m + n) + 4, far below 2^15 for any problem the lists hold), so a 32-bit register carries the same cell
+// of TWO problems — problem A in the low half, problem B in the high half — and one v_pk_*_i16 / _u16
+// instruction of gfx950 advances both.  Nothing crosses halves: an instruction's two results never meet.
+//
+//  * the strip / row order, the strip's right edge parked per row, the lane-interleaved words are
+//    mcx_dp_lane.h's; what a lane keeps is laid out for both problems (LaneLayout2);
+//  * a comparison becomes arithmetic, because gfx9 has no packed compare: "a > b" = min_u16(max_i16(a - b, 0), 1),
+//    "max moved" = min_u16(new - old, 1); the traceback bits of a row are shifted into 16-bit accumulators
+//    (acc = acc * 2 + bit, one v_pk_mad_u16) and permuted into one (nw) / two (ksw2) words per problem at
+//    the row's end, so that a walk step costs what it cost before;
+//  * nw runs on s~[i][j] = s[i][j] - (i + j): a diagonal step then adds 0 or -4 (one multiply-add from the
+//    mismatch bit), the two gap steps add -2 / -4; equalities between the three candidates of a cell — all the
+//    traceback asks — are untouched by a shift common to the three, and the sentinel for "no gap state yet"
+//    becomes one that fits sixteen bits and still loses every maximum (kNeg2);
+//  * ksw2's unsigned-byte max / min (ksw2_alignment.cpp:89-90) is the unsigned 16-bit max / min here: a negative
+//    sum is large in either width and the minimum with 7 follows, a non-negative one is the same number.
+//
+// A half whose problem is shorter or narrower than its neighbour's computes cells nobody reads (rows past its
+// query, columns past its target, strips past its last): every cell depends on its left, upper and upper-left
+// neighbours only, so nothing flows back, and 16-bit wrap-around in such cells is harmless.
+//
+// The host build (tests/hostemu: the reference's 620 function-level vectors, the golden SAM sets) runs the same
+// code with the packed instructions spelt out in C.
+#ifndef MCX_DP_LANE2_H
+#define MCX_DP_LANE2_H
+#include "mcx_dp_lane.h"
+
+namespace mcx {
+
+// ---- the packed 16-bit instructions this file is written in ------------------------------------------------------------------
+// On the device: clang's two-element vectors and element-wise builtins, which select v_pk_add_u16 / v_pk_sub_i16 / v_pk_max_i16 / v_pk_max_u16 /
+// v_pk_min_u16 / v_pk_mad_u16 one for one — PROVIDED the optimiser cannot see the constants 1, 2 and -4: left to itself it turns min(x, 1) into two
+// compares, two selects and a v_perm_b32, and x * 2 + b into a shift and an or.  Those constants therefore come out of opaque() (an empty asm: no
+// instruction, but nothing is known about the value afterwards), once per sweep, and sit in registers.  (Inline assembly for the instructions themselves
+// was the first form: the hazard recogniser then assumes a 16-bit destination-select write behind every one and puts an s_nop between dependent pairs —
+// 154 per row of sixteen cells.)
+namespace pk {
+static inline MCX_HD uint32_t join(uint32_t lo, uint32_t hi) { return (lo & 0xFFFFu) | (hi << 16); }
+static inline MCX_HD uint32_t dup(int v) { return join((uint32_t)v, (uint32_t)v); }
+static inline MCX_HD int lo(uint32_t v) { return (int)(int16_t)(v & 0xFFFFu); }
+static inline MCX_HD int hi(uint32_t v) { return (int)(int16_t)(v >> 16); }
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef short s2v __attribute__((ext_vector_type(2)));
+typedef unsigned short u2v __attribute__((ext_vector_type(2)));
+#define MCX_AS_S(x) __builtin_bit_cast(::mcx::pk::s2v, (uint32_t)(x))
+#define MCX_AS_U(x) __builtin_bit_cast(::mcx::pk::u2v, (uint32_t)(x))
+#define MCX_BC(x) __builtin_bit_cast(uint32_t, (x))
+static __device__ __forceinline__ uint32_t opaque(uint32_t c) { asm("" : "+v"(c)); return c; }
+static __device__ __forceinline__ uint32_t add(uint32_t a, uint32_t b) { return MCX_BC(MCX_AS_U(a) + MCX_AS_U(b)); }
+static __device__ __forceinline__ uint32_t sub(uint32_t a, uint32_t b) { return MCX_BC(MCX_AS_U(a) - MCX_AS_U(b)); }
+static __device__ __forceinline__ uint32_t max_i(uint32_t a, uint32_t b) { return MCX_BC(__builtin_elementwise_max(MCX_AS_S(a), MCX_AS_S(b))); }
+static __device__ __forceinline__ uint32_t max_u(uint32_t a, uint32_t b) { return MCX_BC(__builtin_elementwise_max(MCX_AS_U(a), MCX_AS_U(b))); }
+static __device__ __forceinline__ uint32_t min_u(uint32_t a, uint32_t b) { return MCX_BC(__builtin_elementwise_min(MCX_AS_U(a), MCX_AS_U(b))); }
+// a * b + c (the low sixteen bits of each half: the same for signed and unsigned)
+static __device__ __forceinline__ uint32_t mad(uint32_t a, uint32_t b, uint32_t c) { return MCX_BC(MCX_AS_U(a) * MCX_AS_U(b) + MCX_AS_U(c)); }
+#undef MCX_AS_S
+#undef MCX_AS_U
+#undef MCX_BC
+#else
+static inline uint32_t opaque(uint32_t c) { return c; }
+template <class F> static inline uint32_t each(uint32_t a, uint32_t b, F f) { return join((uint32_t)f(lo(a), lo(b)), (uint32_t)f(hi(a), hi(b))); }
+static inline uint32_t add(uint32_t a, uint32_t b) { return each(a, b, [](int x, int y) { return x + y; }); }
+static inline uint32_t sub(uint32_t a, uint32_t b) { return each(a, b, [](int x, int y) { return x - y; }); }
+static inline uint32_t max_i(uint32_t a, uint32_t b) { return each(a, b, [](int x, int y) { return x > y ? x : y; }); }
+static inline uint32_t max_u(uint32_t a, uint32_t b) { return each(a, b, [](int x, int y) { const unsigned p = (unsigned)x & 0xFFFFu, q = (unsigned)y & 0xFFFFu; return (int)(p > q ? p : q); }); }
+static inline uint32_t min_u(uint32_t a, uint32_t b) { return each(a, b, [](int x, int y) { const unsigned p = (unsigned)x & 0xFFFFu, q = (unsigned)y & 0xFFFFu; return (int)(p < q ? p : q); }); }
+static inline uint32_t mad(uint32_t a, uint32_t b, uint32_t c) { return join((uint32_t)(lo(a) * lo(b) + lo(c)), (uint32_t)(hi(a) * hi(b) + hi(c))); }
+#endif
+template <int C> static inline MCX_HD uint32_t addc(uint32_t a) { return add(a, dup(C)); } // (an inline constant of the instruction)
+} // namespace pk
+
+constexpr int kNeg2 = -16000; // "no gap state yet" in sixteen bits: below every score of a problem with m + n <= 4000, and 2 (n + 1) above -2^15
+
+// where a lane keeps the words of its two problems (the same offsets in every lane of the wave: the group's longest query and widest target)
+struct LaneLayout2 {
+    uint32_t off_q;    // one word per row: the two query codes of the row (0..3, 4 = N), A low / B high
+    uint32_t off_edge; // two words per row: the strip's right edge (nw: R, S; ksw2: x, v), each A low / B high
+    uint32_t off_dir;  // traceback words: ((strip * rows + row) * DW + problem * DW / 2 ...)
+    uint32_t rows;     // row pitch (the group's longest query)
+    uint32_t words;    // total
+};
+template <bool NW> struct LaneDir2 { static constexpr int per_problem = NW ? 1 : 2, words = 2 * per_problem; };
+
+template <int K, bool NW>
+static inline MCX_HD LaneLayout2 lane_layout2(int rows, int strips)
+{
+    LaneLayout2 l;
+    l.rows = (uint32_t)rows;
+    l.off_q = 0;
+    l.off_edge = (uint32_t)rows;
+    l.off_dir = l.off_edge + 2u * (uint32_t)rows;
+    l.words = l.off_dir + (uint32_t)strips * (uint32_t)rows * (uint32_t)LaneDir2<NW>::words;
+    return l;
+}
+
+// the two queries into the lane's words.  code(h, p): the code (0..3, 4 for N) of problem h's query position p (asked for p < its length only)
+template <class Code>
+static inline MCX_HD void lane_stage_query2(const LaneMem &m, const LaneLayout2 &l, int qlen_a, int qlen_b, Code code)
+{
+    const int rows = qlen_a > qlen_b ? qlen_a : qlen_b;
+    for (int p = 0; p < rows; p++) m.put(l.off_q + (uint32_t)p, pk::join(p < qlen_a ? (uint32_t)code(0, p) : 0u, p < qlen_b ? (uint32_t)code(1, p) : 0u));
+}
+
+// sixteen codes of a query (2-bit fields, first in the top bits) + N flags (bit 15 first) -> its rows' halves, sixteen rows at a time
+template <class Get16A, class Get16B>
+static inline MCX_HD void lane_stage_query2_words(const LaneMem &m, const LaneLayout2 &l, int qlen_a, int qlen_b, Get16A get_a, Get16B get_b)
+{
+    const int rows = qlen_a > qlen_b ? qlen_a : qlen_b;
+    for (int p0 = 0; p0 < rows; p0 += 16) {
+        uint32_t ca = 0, na = 0, cb = 0, nb = 0;
+        if (p0 < qlen_a) get_a(p0, ca, na);
+        if (p0 < qlen_b) get_b(p0, cb, nb);
+        const int n = rows - p0 < 16 ? rows - p0 : 16;
+        for (int k = 0; k < n; k++) {
+            const uint32_t a = ((na >> (15 - k)) & 1u) ? 4u : (ca >> (30 - 2 * k)) & 3u, b = ((nb >> (15 - k)) & 1u) ? 4u : (cb >> (30 - 2 * k)) & 3u;
+            m.put(l.off_q + (uint32_t)(p0 + k), a | (b << 16));
+        }
+    }
+}
+
+// the K target codes of a strip, one register per column, A low / B high
+template <int K>
+static inline MCX_HD void lane_targets2(uint32_t ta, uint32_t tb, uint32_t (&T)[K])
+{
+    MCX_UNROLL
+    for (int k = 0; k < K; k++) T[k] = ((ta >> (30 - 2 * k)) & 3u) | (((tb >> (30 - 2 * k)) & 3u) << 16);
+}
+
+// ---------------------------------------------------------------------------------------------
+// nw.  tgt_a / tgt_b (b0): the problem's target codes b0 .. b0+15 as 2-bit fields, first in the top bits.
+// A row of a strip leaves one word per problem: bit (K-1-k) = "s != r" of column k (0: a 'D' column), bit 16 + (K-1-k) = "s != t".
+// Returns the two final scores s[m][n] (doubled, as lane_sweep_nw) in *score_a / *score_b.
+// ---------------------------------------------------------------------------------------------
+template <int K, class TgtA, class TgtB>
+static inline MCX_HD void lane_sweep_nw2(const LaneMem &mem, const LaneLayout2 &l, int m_a, int n_a, int m_b, int n_b, TgtA tgt_a, TgtB tgt_b, int *score_a, int *score_b)
+{
+    static_assert(K == 8 || K == 16, "a strip is 8 or 16 columns");
+    const int m = m_a > m_b ? m_a : m_b, n = n_a > n_b ? n_a : n_b;
+    const int strips = (n + K - 1) / K;
+    const uint32_t NEG = pk::dup(kNeg2);
+    const uint32_t ONE = pk::opaque(pk::dup(1)), TWO = pk::opaque(pk::dup(2)), M4 = pk::opaque(pk::dup(-4));
+    uint32_t fin = 0; // s~[m][n] of either half, caught where its row and column pass
+    for (int s = 0; s < strips; s++) {
+        const int b0 = s * K;
+        uint32_t TG[K];
+        lane_targets2<K>(tgt_a(b0), tgt_b(b0), TG);
+        uint32_t S[K], T[K];
+        MCX_UNROLL
+        for (int k = 0; k < K; k++) { S[k] = pk::dup(-2 - 2 * (b0 + k + 1)); T[k] = NEG; } // row 0: s~[0][j] = -2 - 2j, t[0][j] = "none"
+        uint32_t diag_next = pk::dup(b0 == 0 ? 0 : -2 - 2 * b0); // s~[0][b0]
+        const bool more = s + 1 < strips;
+        const int ka = (n_a - 1) - b0, kb = (n_b - 1) - b0; // the column of the strip that is the problem's last (outside 0..K-1: not in this strip)
+        for (int a = 0; a < m; a++) {
+            const uint32_t q = mem.get(l.off_q + (uint32_t)a);
+            uint32_t Rl, Sl;
+            if (b0 == 0) { Rl = NEG; Sl = pk::dup(-2 - 2 * (a + 1)); } // r[i][0], s~[i][0]
+            else { Rl = mem.get(l.off_edge + 2u * (uint32_t)a); Sl = mem.get(l.off_edge + 2u * (uint32_t)a + 1u); }
+            uint32_t diag = diag_next;
+            diag_next = Sl; // s~[i][b0] is the next row's upper-left neighbour
+            uint32_t fr = 0, ft = 0;
+            MCX_UNROLL
+            for (int k = 0; k < K; k++) {
+                const uint32_t rr = pk::max_i(pk::addc<-2>(Rl), pk::addc<-4>(Sl));
+                const uint32_t tt = pk::max_i(pk::addc<-2>(T[k]), pk::addc<-4>(S[k]));
+                const uint32_t mm = pk::min_u(TG[k] ^ q, ONE);      // 1 = the bases differ (a query N, code 4, differs from every genome base)
+                const uint32_t dg = pk::mad(mm, M4, diag);          // +2 / -2 of the doubled scores, less the diagonal's 2
+                const uint32_t sc = pk::max_i(pk::max_i(dg, rr), tt);
+                fr = pk::mad(fr, TWO, pk::min_u(pk::sub(sc, rr), ONE)); // sc >= rr: the difference is 0 exactly when they are equal
+                ft = pk::mad(ft, TWO, pk::min_u(pk::sub(sc, tt), ONE));
+                diag = S[k];
+                S[k] = sc; T[k] = tt; Rl = rr; Sl = sc;
+            }
+            const uint32_t at = l.off_dir + (uint32_t)(s * (int)l.rows + a) * LaneDir2<true>::words;
+            mem.put(at, (fr & 0xFFFFu) | (ft << 16));
+            mem.put(at + 1u, (fr >> 16) | (ft & 0xFFFF0000u));
+            if (more) { mem.put(l.off_edge + 2u * (uint32_t)a, Rl); mem.put(l.off_edge + 2u * (uint32_t)a + 1u, Sl); }
+            if (a == m_a - 1 && ka >= 0 && ka < K) { MCX_UNROLL for (int k = 0; k < K; k++) if (k == ka) fin = (fin & 0xFFFF0000u) | (S[k] & 0xFFFFu); }
+            if (a == m_b - 1 && kb >= 0 && kb < K) { MCX_UNROLL for (int k = 0; k < K; k++) if (k == kb) fin = (fin & 0xFFFFu) | (S[k] & 0xFFFF0000u); }
+        }
+    }
+    *score_a = pk::lo(fin) + m_a + n_a;
+    *score_b = pk::hi(fin) + m_b + n_b;
+}
+
+// "query base qi differs from target base tj" of problem h for the walks' mismatch counts
+template <class Tgt16>
+struct LaneBases2 {
+    const LaneMem &mem; const LaneLayout2 &l; Tgt16 tgt16; int h;
+    int ct = -1;
+    uint32_t tw = 0;
+    MCX_HD LaneBases2(const LaneMem &m, const LaneLayout2 &lay, Tgt16 t, int half) : mem(m), l(lay), tgt16(t), h(half) {}
+    MCX_HD int differ(int qi, int tj)
+    {
+        if ((tj >> 4) != ct) { ct = tj >> 4; tw = tgt16(ct * 16); }
+        const uint32_t qb = (mem.get(l.off_q + (uint32_t)qi) >> (16 * h)) & 7u, tb = (tw >> (30 - 2 * (tj & 15))) & 3u;
+        return qb != tb ? 1 : 0;
+    }
+};
+
+// nw_alignment's traceback (nw_alignment.cpp:59-74) of problem h by the lane that swept it
+template <int K, class Tgt16, class Sink>
+static inline MCX_HD void lane_walk_nw2(const LaneMem &mem, const LaneLayout2 &l, int h, int m, int n, Tgt16 tgt16, Sink &sink)
+{
+    int i = m, j = n; // 1-based matrix indices
+    LaneBases2<Tgt16> bases(mem, l, tgt16, h);
+    while (i > 0 || j > 0) {
+        unsigned d;
+        if (i == 0) d = 1;
+        else if (j == 0) d = 2;
+        else {
+            const int a = i - 1, b = j - 1, sh = K - 1 - (b % K);
+            const uint32_t w = mem.get(l.off_dir + (uint32_t)((b / K) * (int)l.rows + a) * LaneDir2<true>::words + (uint32_t)h);
+            d = (((w >> sh) & 1u) ^ 1u) | ((((w >> (16 + sh)) & 1u) ^ 1u) << 1);
+        }
+        if (d & 1) { sink.col(2, 0); j--; }
+        else if (d & 2) { sink.col(1, 0); i--; }
+        else { sink.col(0, sink.wants_bases() ? bases.differ(i - 1, j - 1) : 0); i--; j--; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ksw2 (m=5 q=2 e=1).  A row of a strip leaves two words per problem: word 0 = "a > z" bits | "b > z" bits << 16 (the state: the
+// second wins), word 1 = the x / y extension bits the same way; column k at bit K-1-k.
+// ---------------------------------------------------------------------------------------------
+template <int K, class TgtA, class TgtB>
+static inline MCX_HD void lane_sweep_ksw2_2(const LaneMem &mem, const LaneLayout2 &l, int qlen_a, int tlen_a, int qlen_b, int tlen_b, TgtA tgt_a, TgtB tgt_b)
+{
+    static_assert(K == 8 || K == 16, "a strip is 8 or 16 columns");
+    const int Q = 2;
+    const uint32_t ONE = pk::opaque(pk::dup(1)), TWO = pk::opaque(pk::dup(2)), SEVEN = pk::opaque(pk::dup(7));
+    const int qlen = qlen_a > qlen_b ? qlen_a : qlen_b, tlen = tlen_a > tlen_b ? tlen_a : tlen_b;
+    const int strips = (tlen + K - 1) / K;
+    for (int s = 0; s < strips; s++) {
+        const int b0 = s * K;
+        uint32_t TG[K];
+        lane_targets2<K>(tgt_a(b0), tgt_b(b0), TG);
+        uint32_t U[K], Y[K];
+        MCX_UNROLL
+        for (int k = 0; k < K; k++) { U[k] = pk::dup((b0 + k) ? Q : 0); Y[k] = 0; } // the first matrix row (ksw2_alignment.cpp:165)
+        const bool more = s + 1 < strips;
+        for (int a = 0; a < qlen; a++) {
+            const uint32_t q = mem.get(l.off_q + (uint32_t)a);
+            // the row's substitution scores + q + 2e as 7 - 2 mm, or 6 whatever the target where the query holds an N (score 0: :150-158)
+            const uint32_t is_n = (q >> 2) & 0x00010001u;
+            const uint32_t c1 = pk::add(pk::add(is_n, is_n), pk::dup(-2)), c0 = pk::sub(pk::dup(7), is_n);
+            uint32_t xl, vl;
+            if (b0 == 0) { xl = 0; vl = pk::dup(a ? Q : 0); } // values entering column 0 (:163)
+            else { xl = mem.get(l.off_edge + 2u * (uint32_t)a); vl = mem.get(l.off_edge + 2u * (uint32_t)a + 1u); }
+            uint32_t f1 = 0, f2 = 0, fx = 0, fy = 0;
+            MCX_UNROLL
+            for (int k = 0; k < K; k++) {
+                const uint32_t mm = pk::min_u(TG[k] ^ q, ONE);
+                const uint32_t z0 = pk::mad(mm, c1, c0);
+                uint32_t av = pk::add(xl, vl);
+                const uint32_t ut = U[k];
+                uint32_t bv = pk::add(Y[k], ut);
+                const uint32_t z1 = pk::max_i(z0, av);                                        // signed max (:188)
+                f1 = pk::mad(f1, TWO, pk::min_u(pk::sub(z1, z0), ONE));                        // a > z (:187): the maximum moved
+                f2 = pk::mad(f2, TWO, pk::min_u(pk::max_i(pk::sub(bv, z1), 0u), ONE));         // b > z, signed (:189)
+                const uint32_t z = pk::min_u(pk::max_u(z1, bv), SEVEN);                        // unsigned max, then min with max_sc (:89-90, :190-191)
+                const uint32_t un = pk::sub(z, vl), vn = pk::sub(z, ut);
+                const uint32_t zq = pk::addc<-2>(z);
+                av = pk::sub(av, zq); bv = pk::sub(bv, zq);
+                const uint32_t xn = pk::max_i(av, 0u), yn = pk::max_i(bv, 0u);
+                fx = pk::mad(fx, TWO, pk::min_u(xn, ONE));
+                fy = pk::mad(fy, TWO, pk::min_u(yn, ONE));
+                U[k] = un; Y[k] = yn; xl = xn; vl = vn;
+            }
+            const uint32_t at = l.off_dir + (uint32_t)(s * (int)l.rows + a) * LaneDir2<false>::words;
+            mem.put(at, (f1 & 0xFFFFu) | (f2 << 16));
+            mem.put(at + 1u, (fx & 0xFFFFu) | (fy << 16));
+            mem.put(at + 2u, (f1 >> 16) | (f2 & 0xFFFF0000u));
+            mem.put(at + 3u, (fx >> 16) | (fy & 0xFFFF0000u));
+            if (more) { mem.put(l.off_edge + 2u * (uint32_t)a, xl); mem.put(l.off_edge + 2u * (uint32_t)a + 1u, vl); }
+        }
+    }
+}
+
+// ksw_backtrack (ksw2_alignment.cpp:25-68) of problem h, full band; i: target index, j: query index
+template <int K, class Tgt16, class Sink>
+static inline MCX_HD void lane_walk_ksw2_2(const LaneMem &mem, const LaneLayout2 &l, int h, int qlen, int tlen, Tgt16 tgt16, Sink &sink)
+{
+    int i = tlen - 1, j = qlen - 1, state = 0;
+    LaneBases2<Tgt16> bases(mem, l, tgt16, h);
+    while (i >= 0 && j >= 0) {
+        const int sh = K - 1 - (i % K);
+        const uint32_t at = l.off_dir + (uint32_t)((i / K) * (int)l.rows + j) * LaneDir2<false>::words + 2u * (uint32_t)h;
+        const uint32_t w0 = mem.get(at), w1 = mem.get(at + 1u);
+        const unsigned st = ((w0 >> (16 + sh)) & 1u) ? 2u : ((w0 >> sh) & 1u);
+        const unsigned d = st | (((w1 >> sh) & 1u) << 3) | (((w1 >> (16 + sh)) & 1u) << 4); // the reference's byte: state in bits 0-2, extension bits 3 and 4
+        if (state == 0) state = d & 7;
+        else if (!((d >> (state + 2)) & 1)) state = 0;
+        if (state == 0) state = d & 7;
+        if (state == 0) { sink.col(0, sink.wants_bases() ? bases.differ(j, i) : 0); --i; --j; }
+        else if (state == 1 || state == 3) { sink.col(2, 0); --i; }
+        else { sink.col(1, 0); --j; }
+    }
+    for (; i >= 0; --i) sink.col(2, 0);
+    for (; j >= 0; --j) sink.col(1, 0);
+}
+
+// Two DP problems of the batch pipeline, start to finish, by their lane (what lane_dp_job does for one).  have_b false: the lane holds one
+// problem (the list's last, odd one).  scores[2]: nw's s[m][n] doubled (ksw2: 0, as before).
+template <int K, bool NW>
+static inline MCX_HD void lane_dp_job2(const Ctx &cx, const LaneMem &mem, const LaneLayout2 &l, const DpJob &job_a, const ReadRef &rd_a, bool have_b, const DpJob &job_b,
+                                       const ReadRef &rd_b, int scores[2])
+{
+    const IndexView &ix = cx.ix;
+    const DpJob *jobs[2] = {&job_a, &job_b};
+    const ReadRef *rds[2] = {&rd_a, &rd_b};
+    const int qa = job_a.rLen, ta = job_a.gLen, qb = have_b ? job_b.rLen : 0, tb = have_b ? job_b.gLen : 0;
+    auto get16 = [&](int h, int p, uint32_t &codes, uint32_t &flags) {
+        const DpJob &job = *jobs[h];
+        const ReadRef &rd = *rds[h];
+        const bool rev = job.rev != 0;
+        if (rd.codes) { flags = 0; codes = lane_query16(rd.codes, job.rPos, job.rLen, rev, p); return; }
+        codes = 0; flags = 0;
+        for (int k = 0; k < 16 && p + k < job.rLen; k++) {
+            const int c = read_code(rd, rev ? job.rPos + job.rLen - 1 - (p + k) : job.rPos + p + k);
+            codes |= (uint32_t)(c & 3) << (30 - 2 * k);
+            flags |= (uint32_t)(c > 3) << (15 - k);
+        }
+    };
+    lane_stage_query2_words(mem, l, qa, qb, [&](int p, uint32_t &c, uint32_t &f) { get16(0, p, c, f); }, [&](int p, uint32_t &c, uint32_t &f) { get16(1, p, c, f); });
+    auto tgt_a = [&](int b0) -> uint32_t { return b0 < ta ? lane_target16(ix, job_a.gPos, ta, job_a.rev != 0, b0) : 0u; };
+    auto tgt_b = [&](int b0) -> uint32_t { return b0 < tb ? lane_target16(ix, job_b.gPos, tb, job_b.rev != 0, b0) : 0u; };
+    scores[0] = scores[1] = 0;
+    if (NW) lane_sweep_nw2<K>(mem, l, qa, ta, qb, tb, tgt_a, tgt_b, &scores[0], &scores[1]);
+    else lane_sweep_ksw2_2<K>(mem, l, qa, ta, qb, tb, tgt_a, tgt_b);
+    for (int h = 0; h < (have_b ? 2 : 1); h++) {
+        const DpJob &job = *jobs[h];
+        const int qlen = job.rLen, tlen = job.gLen;
+        PairState st = pair_state(cx.state, cx.lay, cx.caps, job.pair);
+        DpSummary *sum = cx.dp_summary ? (DpSummary *)(st.ops + job.ops_off - kDpSum) : nullptr; // (stage_build left room for it)
+        OpsSink sink; sink.ops = st.ops + job.ops_off; sink.w = qlen + tlen; sink.acc.begin(sum); sink.bases = sum != nullptr;
+        if (h == 0) { if (NW) lane_walk_nw2<K>(mem, l, 0, qlen, tlen, tgt_a, sink); else lane_walk_ksw2_2<K>(mem, l, 0, qlen, tlen, tgt_a, sink); }
+        else { if (NW) lane_walk_nw2<K>(mem, l, 1, qlen, tlen, tgt_b, sink); else lane_walk_ksw2_2<K>(mem, l, 1, qlen, tlen, tgt_b, sink); }
+        sink.acc.end((uint32_t)job.ops_off + (uint32_t)sink.w, qlen + tlen - sink.w);
+        Frag f = st.frags[job.frag]; // one fetch, one store (the fields share two words)
+        f.ops_off = job.ops_off + sink.w;
+        f.ops_len = qlen + tlen - sink.w;
+        f.meta = sum ? (uint32_t)((job.ops_off - kDpSum) >> 3) + 1u : 0u;
+        st.frags[job.frag] = f;
+    }
+}
+
+} // namespace mcx
+#endif

@@ -27,6 +27,7 @@
 
 #include "../../include/mcx.h"
 #include "mcx_dp.h"
+#include "mcx_dp_lane2.h"
 #include "mcx_simple.h"
 #include "mcx_profile.h"
 #include <hipcub/hipcub.hpp>
@@ -1787,10 +1788,53 @@ __global__ void __launch_bounds__(64) k_dp_lane(Ctx cx, JobSink sink, const uint
     }
 }
 
-// the three short lists (job_class): tiny <= 8 x 8 in strips of 8; small: targets <= 16, queries <= 32; half: targets <= 32, queries <= 64
-static uint64_t lane_short_words(int which) // ksw2's flags take more words than nw's: sized for them
+// TWO problems per lane (mcx_dp_lane2.h): a wavefront takes 128 problems of its list at a time, lane l the neighbours 2l and 2l + 1 of the (shape-sorted)
+// list; every value of both recurrences in the sixteen bits it needs, problem A in the low half of a register and problem B in the high one, so that one
+// v_pk_*_i16 instruction advances both — the arithmetic width of the reference's own vectors (ksw2_alignment.cpp:70-248: sixteen int8 lanes).  Same words
+// per problem in the wavefront's stretch of scratch, same column strings and summaries as k_dp_lane (MCX_DP_X1=1 runs that one: the A/B of the parity tests).
+template <int K, bool NW>
+__global__ void __launch_bounds__(64) k_dp_lane2(Ctx cx, JobSink sink, const uint32_t *order, ReadBatch rb, PairSel sel, uint32_t *scratch, uint64_t stride_words, uint32_t *unsupported,
+                                                 uint32_t min_n)
 {
-    return which == 0 ? 64ull * lane_layout<8, false>(kDpTiny, 1).words : which == 1 ? 64ull * lane_layout<16, false>(kDpSmallQ, 1).words : 64ull * lane_layout<16, false>(kDpHalfQ, 2).words;
+    const uint32_t n = min(*sink.count, sink.cap);
+    if (n < min_n) return; // (a short list: k_dp_group's)
+    const int lane = threadIdx.x;
+    const int nr = cx.pm.paired ? 2 : 1;
+    LaneMem mem; mem.base = scratch + (uint64_t)blockIdx.x * stride_words + lane; mem.stride = 64;
+    for (uint32_t g0 = blockIdx.x * 128u; g0 < n; g0 += gridDim.x * 128u) {
+        const uint32_t ja = g0 + 2u * (uint32_t)lane, jb = ja + 1u;
+        const bool have_a = ja < n, have_b = jb < n;
+        const uint32_t at_a = have_a ? (order ? order[ja] : ja) : 0u, at_b = have_b ? (order ? order[jb] : jb) : at_a;
+        DpJob job_a, job_b;
+        if (have_a) job_a = sink.jobs[at_a]; else { job_a.rLen = 0; job_a.gLen = 0; }
+        if (have_b) job_b = sink.jobs[at_b]; else job_b = job_a;
+        int rows = max(job_a.rLen, job_b.rLen), strips = (max(job_a.gLen, job_b.gLen) + K - 1) / K;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { rows = max(rows, __shfl_xor(rows, o, 64)); strips = max(strips, __shfl_xor(strips, o, 64)); }
+        const LaneLayout2 l = lane_layout2<K, NW>(rows, strips);
+        if ((uint64_t)l.words * 64u > stride_words) { if (lane == 0) atomicAdd(unsupported, 1u); continue; } // (cannot happen: the lists' size limits are the strides')
+        if (!have_a) continue;
+        ReadRef rd[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const DpJob &job = h ? job_b : job_a;
+            const uint32_t read = sel_pair(sel, job.pair) * nr + job.slot;
+            rd[h].ascii = rb.bases + rb.off[read]; rd[h].rlen = (int)(rb.off[read + 1] - rb.off[read]); rd[h].flipped = (cx.pm.paired && job.slot == 1) ? 1 : 0;
+            rd[h].codes = (cx.packed && !(cx.read_ext[read] >> 31)) ? cx.packed + (uint64_t)read * cx.wpad : nullptr;
+        }
+        int sc[2];
+        lane_dp_job2<K, NW>(cx, mem, l, job_a, rd[0], have_b, job_b, rd[1], sc);
+        sink.jobs[at_a].score = sc[0];
+        if (have_b) sink.jobs[at_b].score = sc[1];
+    }
+}
+
+// the three short lists (job_class): tiny <= 8 x 8 in strips of 8; small: targets <= 16, queries <= 32; half: targets <= 32, queries <= 64
+static uint64_t lane_short_words(int which) // ksw2's flags take more words than nw's: sized for them; a lane of k_dp_lane2 keeps two problems
+{
+    const uint64_t one = which == 0 ? 64ull * lane_layout<8, false>(kDpTiny, 1).words : which == 1 ? 64ull * lane_layout<16, false>(kDpSmallQ, 1).words : 64ull * lane_layout<16, false>(kDpHalfQ, 2).words;
+    const uint64_t two = which == 0 ? 64ull * lane_layout2<8, false>(kDpTiny, 1).words : which == 1 ? 64ull * lane_layout2<16, false>(kDpSmallQ, 1).words : 64ull * lane_layout2<16, false>(kDpHalfQ, 2).words;
+    return std::max(one, two);
 }
 
 // ---- the problems of a long list by shape ------------------------------------------------------------------------------------
@@ -1860,15 +1904,21 @@ __global__ void __launch_bounds__(256) k_dp_sort_place(JobSink sink, int row_shi
 
 // words a wavefront's stretch of scratch must hold for a list whose problems have at most `rows` query bases and `strips` strips
 template <int K>
-static uint64_t lane_stride_words(bool nw, int rows, int strips)
+static uint64_t lane_stride_words(bool nw, int rows, int strips, bool x2)
 {
+    if (x2) return 64ull * (nw ? lane_layout2<K, true>(rows, strips).words : lane_layout2<K, false>(rows, strips).words);
     return 64ull * (nw ? lane_layout<K, true>(rows, strips).words : lane_layout<K, false>(rows, strips).words);
 }
 
 template <int K>
-static void launch_dp_lane(bool nw, unsigned blocks, hipStream_t s, const Ctx &cx, const JobSink &sink, const uint32_t *order, const ReadBatch &rb, const PairSel &sel,
+static void launch_dp_lane(bool nw, bool x2, unsigned blocks, hipStream_t s, const Ctx &cx, const JobSink &sink, const uint32_t *order, const ReadBatch &rb, const PairSel &sel,
                            uint32_t *scratch, uint64_t stride_words, uint32_t *unsupported, uint32_t min_n)
 {
+    if (x2) {
+        if (nw) k_dp_lane2<K, true><<<blocks, 64, 0, s>>>(cx, sink, order, rb, sel, scratch, stride_words, unsupported, min_n);
+        else k_dp_lane2<K, false><<<blocks, 64, 0, s>>>(cx, sink, order, rb, sel, scratch, stride_words, unsupported, min_n);
+        return;
+    }
     if (nw) k_dp_lane<K, true><<<blocks, 64, 0, s>>>(cx, sink, order, rb, sel, scratch, stride_words, unsupported, min_n);
     else k_dp_lane<K, false><<<blocks, 64, 0, s>>>(cx, sink, order, rb, sel, scratch, stride_words, unsupported, min_n);
 }
@@ -1986,7 +2036,7 @@ __global__ void __launch_bounds__(256, MCX_FINISH_WAVES) k_finish(Ctx cx, ReadBa
 // environment.  What was measured slower and served no test is gone (the heavy pairs clustered first, one DP stream per list, the
 // ungrouped wavefront DP, the narrow comparison windows of the seeding walk, mate rescue a workgroup per pair for every pair).
 struct Knobs {
-    bool timing = false, seed_one_base = false, dp_by_wave = false, dp_lane_always = false, late_reseed = false, no_work_order = false, no_simple = false,
+    bool timing = false, seed_one_base = false, dp_by_wave = false, dp_lane_always = false, dp_x1 = false, late_reseed = false, no_work_order = false, no_simple = false,
          simple_no_dp = false, cluster_by_lane = false, rescue_in_line = false, build_by_lane = false, no_sums_cache = false, prof_by_column = false,
          tier1_hist = false, dp_hist = false, no_tier_overlap = false, no_late_overlap = false, no_prof_overlap = false, no_prepack = false;
     int seed_fm_budget = 6, build_wave_limit = 0x7fffffff;
@@ -1996,7 +2046,7 @@ static Knobs knobs_read()
 {
     Knobs k;
     auto on = [](const char *name) { return getenv(name) != nullptr; };
-    k.timing = on("MCX_TIMING"); k.seed_one_base = on("MCX_SEED_ONE_BASE"); k.dp_by_wave = on("MCX_DP_BY_WAVE"); k.dp_lane_always = on("MCX_DP_LANE_ALWAYS");
+    k.timing = on("MCX_TIMING"); k.seed_one_base = on("MCX_SEED_ONE_BASE"); k.dp_by_wave = on("MCX_DP_BY_WAVE"); k.dp_lane_always = on("MCX_DP_LANE_ALWAYS"); k.dp_x1 = on("MCX_DP_X1");
     k.late_reseed = on("MCX_LATE_RESEED"); k.no_work_order = on("MCX_NO_WORK_ORDER"); k.no_simple = on("MCX_NO_SIMPLE"); k.simple_no_dp = on("MCX_SIMPLE_NO_DP");
     k.cluster_by_lane = on("MCX_CLUSTER_BY_LANE"); k.rescue_in_line = on("MCX_RESCUE_IN_LINE"); k.build_by_lane = on("MCX_BUILD_BY_LANE");
     k.no_sums_cache = on("MCX_NO_SUMS_CACHE"); k.prof_by_column = on("MCX_PROF_BY_COLUMN"); k.tier1_hist = on("MCX_TIER1_HIST"); k.dp_hist = on("MCX_DP_HIST");
@@ -2068,6 +2118,7 @@ struct mcx_ctx {
     const mcx_index *idx = nullptr;
     bool counted = false; // (among idx->n_ctx)
     bool lens_checked = false; // the batch about to begin holds no read longer than max_read_len (mcx_stream_next says so for batches that came as 2-bit rows)
+    const uint32_t *lens_checked_off = nullptr; const uint8_t *lens_checked_bases = nullptr; // ... said of THESE buffers (the slot's) and of no others
     // ... and is packed already (mcx_stream_submit_packed packed it behind its copy in, under the batch before it): where, from which bytes, mated or not, and its any-N word
     struct PrePacked { const uint32_t *packed = nullptr; const uint8_t *bases = nullptr; int paired = 0; const uint32_t *any_n = nullptr; } pre;
     int last_paired = 1;                 // what the last batch was mapped as: the guess a batch on its way in is packed under
@@ -2153,6 +2204,7 @@ struct mcx_ctx {
         uint32_t *d_codes = nullptr, *d_len = nullptr, *d_err = nullptr; uint64_t *d_odd = nullptr; uint32_t odd_cap = 0; // mcx_stream_submit_packed: what arrives; restored to d_bases / d_off
         uint32_t n_reads = 0; int state = 0; uint64_t seq = 0; // 0 free, 1 copy in started, 2 handed to the kernels, 3 copy out started
         bool lens_checked = false; // the batch came as 2-bit rows: no read is longer than the context's slots (k_unpack_reads / k_neutralize saw to it)
+        uint32_t *h_err = nullptr; // pinned: d_err's word on its way out with the batch's records (mcx_stream_mapped / _mapped32 -> mcx_stream_collect)
         uint32_t *d_prepack = nullptr, *d_any_n = nullptr; bool prepacked = false; int pre_paired = 0; // k_pack_reads' output made on the way in
         hipEvent_t in_ready = nullptr, mapped = nullptr, out_done = nullptr;
     } slot[3];
@@ -2443,6 +2495,7 @@ extern "C" void mcx_ctx_free(mcx_ctx *c)
     for (auto &sl : c->slot) {
         void *q[] = {sl.d_bases, sl.d_off, sl.d_recs, sl.d_cig, sl.d_codes, sl.d_len, sl.d_odd, sl.d_err, sl.d_recs32, sl.d_prepack, sl.d_any_n};
         for (void *x : q) if (x) (void)hipFree(x);
+        if (sl.h_err) (void)hipHostFree(sl.h_err);
         for (hipEvent_t e : {sl.in_ready, sl.mapped, sl.out_done}) if (e) (void)hipEventDestroy(e);
     }
     if (c->h2d_stream) (void)hipStreamDestroy(c->h2d_stream);
@@ -2516,7 +2569,9 @@ static int launch_dp(const Knobs &kn, const PassRes &R, const Ctx &cx, const Job
         uint32_t *unsup = sinks.unsupported;
         const bool always = kn.dp_lane_always;
         uint32_t lane_min[2] = {always ? 0u : kDpLaneMin[0], always ? 0u : kDpLaneMin[1]};
-        const uint64_t w1 = lane_stride_words<16>(nw, rlen_max, 4), w2 = lane_stride_words<16>(nw, rlen_max, 16);
+        // two problems per lane in 16-bit halves (k_dp_lane2) wherever the scores fit them with room to spare: queries + targets far below kNeg2's reach
+        const bool x2 = !kn.dp_x1 && rlen_max + 256 <= 3000;
+        const uint64_t w1 = lane_stride_words<16>(nw, rlen_max, 4, x2), w2 = lane_stride_words<16>(nw, rlen_max, 16, x2);
         const unsigned b1 = (unsigned)std::min<uint64_t>(4096, R.dp_stride[0] * R.dp_blocks[0] / (w1 * 4)), b2 = (unsigned)std::min<uint64_t>(4096, R.dp_stride[1] * R.dp_blocks[1] / (w2 * 4));
         // (a set of pass resources whose scratch does not hold one lane group for reads this long — the small sets with a large max_read_len —
         //  leaves that list to the wavefront kernel whatever its length)
@@ -2536,16 +2591,16 @@ static int launch_dp(const Knobs &kn, const PassRes &R, const Ctx &cx, const Job
                 ord[k] = R.d_dp_order[k];
             }
         }
-        if (b1) launch_dp_lane<16>(nw, b1, st[0], cx, sinks.s[1], ord[0], rb, sel, (uint32_t *)R.d_dp_scratch[0], w1, unsup, lane_min[0]);
+        if (b1) launch_dp_lane<16>(nw, x2, b1, st[0], cx, sinks.s[1], ord[0], rb, sel, (uint32_t *)R.d_dp_scratch[0], w1, unsup, lane_min[0]);
         k_dp_group<1><<<R.dp_blocks[0], 64, 0, st[0]>>>(cx, sinks.s[1], rb, sel, R.d_dp_scratch[0], R.dp_stride[0], lane_min[0]);
-        if (b2) launch_dp_lane<16>(nw, b2, st[1], cx, sinks.s[2], ord[1], rb, sel, (uint32_t *)R.d_dp_scratch[1], w2, unsup, lane_min[1]);
+        if (b2) launch_dp_lane<16>(nw, x2, b2, st[1], cx, sinks.s[2], ord[1], rb, sel, (uint32_t *)R.d_dp_scratch[1], w2, unsup, lane_min[1]);
         k_dp_group<4><<<R.dp_blocks[1], 64, 0, st[1]>>>(cx, sinks.s[2], rb, sel, R.d_dp_scratch[1], R.dp_stride[1], lane_min[1]);
         uint32_t *p = R.d_dp_lane;
-        launch_dp_lane<8>(nw, R.dp_lane_blocks, side0, cx, sinks.s[4], nullptr, rb, sel, p, lane_short_words(0), unsup, 0u);
+        launch_dp_lane<8>(nw, x2, R.dp_lane_blocks, side0, cx, sinks.s[4], nullptr, rb, sel, p, lane_short_words(0), unsup, 0u);
         p += lane_short_words(0) * R.dp_lane_blocks;
-        launch_dp_lane<16>(nw, R.dp_lane_blocks, side0, cx, sinks.s[0], nullptr, rb, sel, p, lane_short_words(1), unsup, 0u);
+        launch_dp_lane<16>(nw, x2, R.dp_lane_blocks, side0, cx, sinks.s[0], nullptr, rb, sel, p, lane_short_words(1), unsup, 0u);
         p += lane_short_words(1) * R.dp_lane_blocks;
-        launch_dp_lane<16>(nw, R.dp_lane_blocks, side0, cx, sinks.s[5], nullptr, rb, sel, p, lane_short_words(2), unsup, 0u);
+        launch_dp_lane<16>(nw, x2, R.dp_lane_blocks, side0, cx, sinks.s[5], nullptr, rb, sel, p, lane_short_words(2), unsup, 0u);
         k_dp_sel<16><<<R.dp_blocks[2], 64, 0, side1>>>(cx, sinks.s[3], rb, sel, R.d_dp_scratch[2], R.dp_stride[2]);
     } else {
     k_dp_group<1><<<R.dp_blocks[0], 64, 0, s>>>(cx, sinks.s[1], rb, sel, R.d_dp_scratch[0], R.dp_stride[0], 0xFFFFFFFFu);
@@ -3162,7 +3217,13 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
                                int64_t read_base, mcx_aln *d_aln, uint32_t *d_cigar, mcx_stats *stats)
 {
     static_assert(sizeof(mcx_aln) == sizeof(AlnRec), "mcx_aln and AlnRec must have one layout");
-    if (!c || !d_bases || !d_off || !d_aln || !d_cigar) return fail(MCX_ERR_ARG, "mcx_batch_begin: null argument");
+    if (!c) return fail(MCX_ERR_ARG, "mcx_batch_begin: null argument");
+    // what mcx_stream_next said of the batch it gave out: taken here, before anything can return, so that no later batch inherits it; it counts for the slot's own buffers only
+    const bool vouched = c->lens_checked && d_off && d_off == c->lens_checked_off && d_bases == c->lens_checked_bases;
+    c->lens_checked = false; c->lens_checked_off = nullptr; c->lens_checked_bases = nullptr;
+    const mcx_ctx::PrePacked pre = c->pre;
+    c->pre = mcx_ctx::PrePacked();
+    if (!d_bases || !d_off || !d_aln || !d_cigar) return fail(MCX_ERR_ARG, "mcx_batch_begin: null argument");
     BatchRun &br = c->run;
     br.open = false;
     if (n_reads == 0) return fail(MCX_ERR_ARG, "mcx_batch_begin: empty batch");
@@ -3194,10 +3255,6 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
     br.mapped = 0; br.sums_valid = false;
     c->tail.queued = c->tail.ran = false;
     HIP_TRY(hipMemsetAsync(c->d_batch_flags, 0, 4 * sizeof(uint32_t), s));
-    const bool vouched = c->lens_checked;
-    c->lens_checked = false; // (said of this batch only)
-    const mcx_ctx::PrePacked pre = c->pre;
-    c->pre = mcx_ctx::PrePacked();
     c->last_paired = paired ? 1 : 0;
     if (vouched) c->h_cnt[1] = (uint32_t)c->rlen_max; // (vouched for: no kernel, no wait at the start of the step — under the copies of the neighbouring batches such a wait takes milliseconds)
     else { // every read must fit the slots the context was sized for
@@ -3463,9 +3520,11 @@ extern "C" int mcx_batch_accumulate(mcx_ctx *c, const uint64_t *all_keys, uint64
 extern "C" int mcx_map_batch_dev(mcx_ctx *c, const uint8_t *d_bases, const uint32_t *d_off, uint32_t n_reads, int paired,
                                  int64_t avg[4], mcx_aln *d_aln, uint32_t *d_cigar, mcx_stats *stats)
 {
-    if (!c || !d_bases || !d_off || !d_aln || !d_cigar || !avg) return fail(MCX_ERR_ARG, "mcx_map_batch_dev: null argument");
-    if (n_reads == 0) return 0;
-    if (paired && (avg[3] % kReadChunkSize)) return fail(MCX_ERR_ARG, "batches must start on a 200-read chunk boundary");
+    if (!c) return fail(MCX_ERR_ARG, "mcx_map_batch_dev: null argument");
+    auto unvouch = [&]() { c->lens_checked = false; c->lens_checked_off = nullptr; c->lens_checked_bases = nullptr; c->pre = mcx_ctx::PrePacked(); }; // (a return before mcx_batch_begin: nothing said of this batch outlives it)
+    if (!d_bases || !d_off || !d_aln || !d_cigar || !avg) { unvouch(); return fail(MCX_ERR_ARG, "mcx_map_batch_dev: null argument"); }
+    if (n_reads == 0) { unvouch(); return 0; }
+    if (paired && (avg[3] % kReadChunkSize)) { unvouch(); return fail(MCX_ERR_ARG, "batches must start on a 200-read chunk boundary"); }
     // (one stream, one trajectory: what follows the batch's kernels — statistics, per-chunk sums, the walk, the check of every pair's estimate —
     //  is queued behind them by the pass itself, queue_batch_tail)
     c->tail.want = true; c->tail.state0[0] = avg[0]; c->tail.state0[1] = avg[1]; c->tail.state0[2] = avg[2];
@@ -3692,6 +3751,8 @@ extern "C" int mcx_stream_submit_packed(mcx_ctx *c, const uint32_t *codes, uint3
         if ((rc = dmalloc(&sl->d_codes, c->max_reads * (uint64_t)row_max))) return rc;
         if ((rc = dmalloc(&sl->d_len, c->max_reads + 1))) return rc;
         if ((rc = dmalloc(&sl->d_err, 1))) return rc;
+        HIP_TRY(hipHostMalloc((void **)&sl->h_err, sizeof(uint32_t)));
+        *sl->h_err = 0;
     }
     if (n_odd > sl->odd_cap) {
         if (sl->d_odd) { HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(sl->d_odd); sl->d_odd = nullptr; }
@@ -3768,6 +3829,7 @@ extern "C" int mcx_stream_next(mcx_ctx *c, const uint8_t **d_bases, const uint32
     if (!sl) return fail(MCX_ERR_ARG, "mcx_stream_next: nothing submitted");
     HIP_TRY(hipStreamWaitEvent(c->stream, sl->in_ready, 0));
     c->lens_checked = sl->lens_checked; // (for the mcx_batch_begin that follows: no need to look for an over-long read, nor to wait for the answer)
+    c->lens_checked_off = sl->d_off; c->lens_checked_bases = sl->d_bases;
     c->pre = mcx_ctx::PrePacked();
     if (sl->prepacked) { c->pre.packed = sl->d_prepack; c->pre.bases = sl->d_bases; c->pre.paired = sl->pre_paired; c->pre.any_n = sl->d_any_n; }
     sl->state = 2;
@@ -3789,6 +3851,7 @@ extern "C" int mcx_stream_mapped(mcx_ctx *c, mcx_aln *aln, uint32_t *cigar)
     int rc;
     if ((rc = bulk_copy(c, aln, sl->d_recs, rec_bytes, hipMemcpyDeviceToHost, c->d2h_stream))) return rc;
     if ((rc = bulk_copy(c, cigar, sl->d_cig, cig_bytes, hipMemcpyDeviceToHost, c->d2h_stream))) return rc;
+    if (sl->lens_checked) HIP_TRY(hipMemcpyAsync(sl->h_err, sl->d_err, 4, hipMemcpyDeviceToHost, c->d2h_stream)); // what k_unpack_reads thought of the caller's lengths: mcx_stream_collect reads it
     HIP_TRY(hipEventRecord(sl->out_done, c->d2h_stream));
     sl->state = 3;
     c->stream_bytes_out += rec_bytes + cig_bytes;
@@ -3826,6 +3889,7 @@ extern "C" int mcx_stream_mapped32(mcx_ctx *c, mcx_aln32 *aln, uint32_t *cigar)
     const size_t rec_bytes = (size_t)sl->n_reads * sizeof(mcx_aln32), cig_bytes = (size_t)c->run.cig_words * 4; // (the pool's used words only)
     if ((rc = bulk_copy(c, aln, sl->d_recs32, rec_bytes, hipMemcpyDeviceToHost, c->d2h_stream))) return rc;
     if ((rc = bulk_copy(c, cigar, sl->d_cig, cig_bytes, hipMemcpyDeviceToHost, c->d2h_stream))) return rc;
+    if (sl->lens_checked) HIP_TRY(hipMemcpyAsync(sl->h_err, sl->d_err, 4, hipMemcpyDeviceToHost, c->d2h_stream));
     HIP_TRY(hipEventRecord(sl->out_done, c->d2h_stream));
     sl->state = 3;
     c->stream_bytes_out += rec_bytes + cig_bytes;
@@ -3861,6 +3925,12 @@ extern "C" int mcx_stream_collect(mcx_ctx *c, uint64_t *bytes_in, uint64_t *byte
     sl->state = 0;
     if (bytes_in) *bytes_in = c->stream_bytes_in;
     if (bytes_out) *bytes_out = c->stream_bytes_out;
+    if (sl->lens_checked && sl->h_err && *sl->h_err) { // the two-half form (mcx_stream_next + mcx_map_batch_dev / mcx_batch_* + mcx_stream_mapped): the refusal arrives with the records
+        const uint32_t err = *sl->h_err;
+        *sl->h_err = 0;
+        return fail(MCX_ERR_ARG, (err & 1u) ? "mcx_stream_submit_packed: a read is longer than its row / max_read_len (the batch was mapped as empty reads)"
+                                            : "mcx_stream_submit_packed: the batch holds more bases than max_batch_reads * max_read_len (it was mapped as empty reads)");
+    }
     return 0;
 }
 

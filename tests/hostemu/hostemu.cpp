@@ -15,6 +15,7 @@
 
 #include "../../mapcaller_amd/csrc/mcx_glue.h"
 #include "../../mapcaller_amd/csrc/mcx_dp_lane.h"
+#include "../../mapcaller_amd/csrc/mcx_dp_lane2.h"
 static long g_detail_checked = 0, g_detail_bad = 0; // MCX_EMU_DETAIL_CHECK: straight-line reads whose detail record was made both ways; those that differ
 static long g_simple_why[32]; // which exit of simple_read reads took (MCX_EMU_SIMPLE_WHY=1 prints the tally)
 #define MCX_SIMPLE_FAIL(code) do { g_simple_why[code]++; return false; } while (0)
@@ -295,7 +296,36 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
     const bool oracle_dp = getenv("MCX_EMU_ORACLE_DP") != nullptr;
     cx.dp_summary = oracle_dp ? 0 : 1;
     std::vector<uint32_t> words;
-    for (uint32_t j = 0; j < n_jobs; j++) {
+    // the lists' kernels take two problems per lane (mcx_dp_lane2.h: k_dp_lane2): neighbours of the list share a lane here too — whatever their shapes —
+    // unless MCX_EMU_DP_X1 asks for the one-problem-per-lane form (k_dp_lane, the A/B)
+    const bool dp_x2 = !oracle_dp && !getenv("MCX_EMU_DP_X1");
+    for (uint32_t j = 0; dp_x2 && j < n_jobs; j += 2) {
+        const bool have_b = j + 1 < n_jobs;
+        const DpJob &ja = jobs[j], &jb = jobs[have_b ? j + 1 : j];
+        ReadRef rr[2];
+        std::vector<uint32_t> pkbuf[2];
+        for (int h = 0; h < (have_b ? 2 : 1); h++) {
+            const DpJob &job = h ? jb : ja;
+            const uint32_t read = ids[job.pair] * nr + job.slot;
+            ReadRef &jr = rr[h];
+            jr.ascii = b.bases.data() + b.off[read]; jr.rlen = (int)(b.off[read + 1] - b.off[read]); jr.flipped = (b.paired && job.slot == 1) ? 1 : 0;
+            if (stats) { stats[6]++; stats[7] += (int64_t)job.rLen * job.gLen; }
+            pkbuf[h].assign(packed_words(jr.rlen) + 4, 0u);
+            bool has_n = false;
+            for (int i = 0; i < jr.rlen; i++) { const int c = read_code(jr, i); if (c > 3) has_n = true; else pkbuf[h][i >> 4] |= (uint32_t)c << (30 - 2 * (i & 15)); }
+            if (!has_n && !getenv("MCX_EMU_NO_CODES")) jr.codes = pkbuf[h].data();
+        }
+        const bool tiny = ja.rLen <= 8 && ja.gLen <= 8 && (!have_b || (jb.rLen <= 8 && jb.gLen <= 8));
+        const int K = tiny ? 8 : 16, rows = std::max(ja.rLen, have_b ? jb.rLen : 0), strips = (std::max(ja.gLen, have_b ? jb.gLen : 0) + K - 1) / K;
+        const LaneLayout2 l = tiny ? (cx.pm.use_nw ? lane_layout2<8, true>(rows, strips) : lane_layout2<8, false>(rows, strips))
+                                   : (cx.pm.use_nw ? lane_layout2<16, true>(rows, strips) : lane_layout2<16, false>(rows, strips));
+        words.assign(l.words + 4, 0xDEADBEEFu);
+        LaneMem mem; mem.base = words.data(); mem.stride = 1;
+        int sc[2];
+        if (tiny) { if (cx.pm.use_nw) lane_dp_job2<8, true>(cx, mem, l, ja, rr[0], have_b, jb, rr[have_b ? 1 : 0], sc); else lane_dp_job2<8, false>(cx, mem, l, ja, rr[0], have_b, jb, rr[have_b ? 1 : 0], sc); }
+        else { if (cx.pm.use_nw) lane_dp_job2<16, true>(cx, mem, l, ja, rr[0], have_b, jb, rr[have_b ? 1 : 0], sc); else lane_dp_job2<16, false>(cx, mem, l, ja, rr[0], have_b, jb, rr[have_b ? 1 : 0], sc); }
+    }
+    for (uint32_t j = 0; !dp_x2 && j < n_jobs; j++) {
         const DpJob &job = jobs[j];
         PairState st = pair_state(cx.state, cx.lay, cx.caps, job.pair);
         const uint32_t read = ids[job.pair] * nr + job.slot;
@@ -545,6 +575,52 @@ int hostemu_lane_dp(int use_nw, const char *q, int qlen, const char *t, int tlen
     ops_out[L] = 0;
     if (score) *score = sc;
     return L;
+}
+
+// Two problems in ONE lane through the two-problems-per-lane DP (mcx_dp_lane2.h: 16-bit halves), for the same vectors: problem A in the low halves,
+// problem B in the high ones, whatever their shapes.  ops_a / ops_b, score[2] as hostemu_lane_dp; len[2] = the strings' lengths.  Returns 0, -1 for a
+// target with a letter outside ACGT.
+int hostemu_lane_dp2(int use_nw, const char *qa, int qlen_a, const char *ta, int tlen_a, const char *qb, int qlen_b, const char *tb, int tlen_b, int K,
+                     char *ops_a, char *ops_b, int *score, int *len)
+{
+    auto code = [](char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; };
+    for (int i = 0; i < tlen_a; i++) if (code(ta[i]) > 3) return -1;
+    for (int i = 0; i < tlen_b; i++) if (code(tb[i]) > 3) return -1;
+    const int rows = std::max(qlen_a, qlen_b), strips = (std::max(tlen_a, tlen_b) + K - 1) / K;
+    LaneLayout2 l;
+    if (K == 8) l = use_nw ? lane_layout2<8, true>(rows, strips) : lane_layout2<8, false>(rows, strips);
+    else l = use_nw ? lane_layout2<16, true>(rows, strips) : lane_layout2<16, false>(rows, strips);
+    std::vector<uint32_t> words(l.words + 4, 0xDEADBEEFu);
+    LaneMem mem; mem.base = words.data(); mem.stride = 1;
+    const char *qs[2] = {qa, qb}, *ts[2] = {ta, tb};
+    const int ql[2] = {qlen_a, qlen_b}, tl[2] = {tlen_a, tlen_b};
+    lane_stage_query2(mem, l, qlen_a, qlen_b, [&](int h, int p) { return code(qs[h][p]); });
+    auto tgt = [&](int h, int b0) -> uint32_t {
+        uint32_t v = 0;
+        for (int k = 0; k < 16; k++) v = (v << 2) | (b0 + k < tl[h] ? (uint32_t)code(ts[h][b0 + k]) : 0u);
+        return v;
+    };
+    auto tgt_a = [&](int b0) { return tgt(0, b0); };
+    auto tgt_b = [&](int b0) { return tgt(1, b0); };
+    score[0] = score[1] = 0;
+    if (K == 8) { if (use_nw) lane_sweep_nw2<8>(mem, l, qlen_a, tlen_a, qlen_b, tlen_b, tgt_a, tgt_b, &score[0], &score[1]); else lane_sweep_ksw2_2<8>(mem, l, qlen_a, tlen_a, qlen_b, tlen_b, tgt_a, tgt_b); }
+    else { if (use_nw) lane_sweep_nw2<16>(mem, l, qlen_a, tlen_a, qlen_b, tlen_b, tgt_a, tgt_b, &score[0], &score[1]); else lane_sweep_ksw2_2<16>(mem, l, qlen_a, tlen_a, qlen_b, tlen_b, tgt_a, tgt_b); }
+    char *outs[2] = {ops_a, ops_b};
+    for (int h = 0; h < 2; h++) {
+        std::vector<uint8_t> ops((size_t)ql[h] + tl[h] + 1, 0);
+        OpsSink sink; sink.ops = ops.data(); sink.w = ql[h] + tl[h]; sink.acc.begin(nullptr); sink.bases = false;
+        if (K == 8) {
+            if (use_nw) { if (h) lane_walk_nw2<8>(mem, l, 1, ql[h], tl[h], tgt_b, sink); else lane_walk_nw2<8>(mem, l, 0, ql[h], tl[h], tgt_a, sink); }
+            else { if (h) lane_walk_ksw2_2<8>(mem, l, 1, ql[h], tl[h], tgt_b, sink); else lane_walk_ksw2_2<8>(mem, l, 0, ql[h], tl[h], tgt_a, sink); }
+        } else {
+            if (use_nw) { if (h) lane_walk_nw2<16>(mem, l, 1, ql[h], tl[h], tgt_b, sink); else lane_walk_nw2<16>(mem, l, 0, ql[h], tl[h], tgt_a, sink); }
+            else { if (h) lane_walk_ksw2_2<16>(mem, l, 1, ql[h], tl[h], tgt_b, sink); else lane_walk_ksw2_2<16>(mem, l, 0, ql[h], tl[h], tgt_a, sink); }
+        }
+        len[h] = ql[h] + tl[h] - sink.w;
+        memcpy(outs[h], ops.data() + sink.w, (size_t)len[h]);
+        outs[h][len[h]] = 0;
+    }
+    return 0;
 }
 
 // tier0 = {hit_cap, cand_cap, frag_cap, ops_cap, job_cap} or null for the product defaults.

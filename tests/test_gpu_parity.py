@@ -225,6 +225,35 @@ def test_packed_host_boundary_gives_the_same_records(api, golden, tmp_path):
     assert L.mcx_stream_submit_packed(mp._h, tw.data_ptr(), row_words, tl.data_ptr(), 2 * n_pairs, to.data_ptr(), n_odd) == 0, L.mcx_last_error()
     assert L.mcx_stream_map32(mp._h, 1, mp.avg, outs[0][0].data_ptr(), outs[0][1].data_ptr(), C.byref(mp.stats)) == 0, L.mcx_last_error()
     assert L.mcx_stream_collect(mp._h, None, None) == 0, L.mcx_last_error()
+    # the same wrong length through the two halves (mcx_stream_next + mcx_map_batch_dev + mcx_stream_mapped32, what the file front end and the sharded
+    # path call): the refusal arrives with the records, from mcx_stream_collect — round 5 returned 0 here with every read unmapped
+    for fn in ("mcx_stream_next", "mcx_stream_mapped32"):
+        getattr(L, fn).restype = C.c_int
+    L.mcx_stream_next.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+    L.mcx_stream_mapped32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    mp.reset()
+    assert L.mcx_stream_submit_packed(mp._h, tw.data_ptr(), row_words, bad.data_ptr(), 2 * n_pairs, to.data_ptr(), n_odd) == 0, L.mcx_last_error()
+    db, do, da, dc, nr = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint32()
+    assert L.mcx_stream_next(mp._h, C.byref(db), C.byref(do), C.byref(nr), C.byref(da), C.byref(dc)) == 0, L.mcx_last_error()
+    mp.map_batch_dev(db.value, do.value, nr.value, True, da.value, dc.value)
+    assert L.mcx_stream_mapped32(mp._h, outs[0][0].data_ptr(), outs[0][1].data_ptr()) == 0, L.mcx_last_error()
+    assert L.mcx_stream_collect(mp._h, None, None) != 0
+    assert b"longer than its row" in L.mcx_last_error() and b"empty reads" in L.mcx_last_error()
+    # ... and what was said of that slot's buffers is said of no other batch: a device batch with an over-long read right after
+    # mcx_stream_next (whose vouching the call above never took up) is still looked at
+    mp.reset()
+    assert L.mcx_stream_submit_packed(mp._h, tw.data_ptr(), row_words, tl.data_ptr(), 2 * n_pairs, to.data_ptr(), n_odd) == 0, L.mcx_last_error()
+    assert L.mcx_stream_next(mp._h, C.byref(db), C.byref(do), C.byref(nr), C.byref(da), C.byref(dc)) == 0, L.mcx_last_error()
+    long_off = torch.tensor([0, 400, 800], dtype=torch.int32, device="cuda")  # two reads of 400 bases in a context of 256
+    long_bases = torch.full((800 + 64,), ord("A"), dtype=torch.uint8, device="cuda")
+    with pytest.raises(api.McxError, match="longer than max_read_len"):
+        mp.map_batch_dev(long_bases.data_ptr(), long_off.data_ptr(), 2, True, da.value, dc.value)
+    mp.map_batch_dev(db.value, do.value, nr.value, True, da.value, dc.value)  # the slot's own batch, looked at like any other now
+    assert L.mcx_stream_mapped32(mp._h, outs[0][0].data_ptr(), outs[0][1].data_ptr()) == 0, L.mcx_last_error()
+    assert L.mcx_stream_collect(mp._h, None, None) == 0, L.mcx_last_error()
+    aln = api.aln32_unpack(np.frombuffer(outs[0][0].numpy().tobytes(), dtype=api.ALN32_DTYPE))
+    for f in ("pos", "flag", "mapq", "n_cigar"):
+        assert np.array_equal(aln[f], want[0][0][f]), f
     mp.close(); ix.close()
 
 

@@ -62,7 +62,55 @@ def test_lane_dp_equals_reference_vectors(hostemu_lib, alg, K):
     assert done > 550
 
 
-@pytest.mark.parametrize("switch", ["MCX_EMU_NO_CODES", "MCX_EMU_ORACLE_DP"])
+def _gapped(c, ops):
+    a1, a2, qi, ti = [], [], 0, 0
+    for o in ops:  # what the column string says about the two gapped strings
+        if o == "M":
+            a1.append(c["q"][qi]); a2.append(c["t"][ti]); qi += 1; ti += 1
+        elif o == "I":
+            a1.append(c["q"][qi]); a2.append("-"); qi += 1
+        else:
+            a1.append("-"); a2.append(c["t"][ti]); ti += 1
+    return ["".join(a1), "".join(a2)]
+
+
+@pytest.mark.parametrize("K", [8, 16])
+@pytest.mark.parametrize("alg", ["nw", "ksw2"])
+def test_two_problems_per_lane_dp_equals_the_reference_vectors(hostemu_lib, alg, K):
+    """The two-problems-per-lane DP (mcx_dp_lane2.h: 16-bit halves, the arithmetic of k_dp_lane2 with the packed instructions spelt out in C) on the
+    reference's function-level vectors: every vector shares its lane once with its neighbour of the list and once with a vector of another
+    shape (a third of the list away), once in the low half and once in the high one — the gapped strings of nw_alignment / ksw2_alignment, for ksw2
+    the reversed operation string of ksw_backtrack, for nw the final score against the one-problem-per-lane sweep's."""
+    cases = [c for c in json.load(open(os.path.join(GOLD, "func", "dp.json"))) if set(c["t"]) <= set("ACGT")]
+    L = hostemu_lib
+    L.hostemu_lane_dp2.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
+                                   ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    L.hostemu_lane_dp.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+    use_nw = 1 if alg == "nw" else 0
+    n, done, shapes = len(cases), 0, set()
+    for i, a in enumerate(cases):
+        for b in (cases[(i + 1) % n], cases[(i + n // 3) % n]):
+            for lo, hi in ((a, b), (b, a)):
+                qa, ta, qb, tb = lo["q"].encode(), lo["t"].encode(), hi["q"].encode(), hi["t"].encode()
+                oa, ob = ctypes.create_string_buffer(len(qa) + len(ta) + 2), ctypes.create_string_buffer(len(qb) + len(tb) + 2)
+                sc, ln = (ctypes.c_int * 2)(), (ctypes.c_int * 2)()
+                assert L.hostemu_lane_dp2(use_nw, qa, len(qa), ta, len(ta), qb, len(qb), tb, len(tb), K, oa, ob, sc, ln) == 0
+                for c, o, k in ((lo, oa, 0), (hi, ob, 1)):
+                    ops = o.value.decode()
+                    assert len(ops) == ln[k]
+                    assert _gapped(c, ops) == c[alg], (k, c["q"], c["t"], ops)
+                    if alg == "ksw2":
+                        assert ops[::-1] == c["ksw2_ops_rev"]
+                    else:
+                        buf, s1 = ctypes.create_string_buffer(len(c["q"]) + len(c["t"]) + 2), ctypes.c_int()
+                        L.hostemu_lane_dp(1, c["q"].encode(), len(c["q"]), c["t"].encode(), len(c["t"]), K, buf, ctypes.byref(s1))
+                        assert s1.value == sc[k]
+                shapes.add((len(qa) > len(qb), len(ta) > len(tb)))
+                done += 1
+    assert done > 2000 and len(shapes) == 4  # (every combination of longer / shorter query and target in either half)
+
+
+@pytest.mark.parametrize("switch", ["MCX_EMU_NO_CODES", "MCX_EMU_ORACLE_DP", "MCX_EMU_DP_X1"])
 @pytest.mark.parametrize("alg", ["nw", "ksw2"])
 def test_lane_dp_inputs_and_the_scalar_dp_agree(hostemu_lib, golden, tmp_path, monkeypatch, alg, switch):
     """The `var` set (indel-rich donors: hundreds of DP problems, both strands) with the lane DP reading its query from the
