@@ -562,6 +562,7 @@ def compact_line(out, detail_path=None):
                 line["cpu_baseline"][sub] = _pick(c[sub], ("value", "cores"))
     line["stage_ms_per_step"] = out.get("stage_ms_per_step")
     line["per_read"] = out.get("per_read")
+    line.update(_pick(out, ("simple_pairs", "tier1_pairs", "replayed_pairs", "halved_selections")) or {})
     optional = {}
     p = out.get("value_pcie_inclusive")
     if isinstance(p, dict):
@@ -575,9 +576,10 @@ def compact_line(out, detail_path=None):
             optional["value_file_to_file"]["without_sam_output"] = f["without_sam_output"].get("value")
     v = out.get("vcf_reduce")
     if isinstance(v, dict):
-        optional["vcf_reduce"] = _pick(v, ("profile_batch_ms", "same_batches_without_profile_ms", "hbm_free_gb", "reduce_ms", "reduce_gb", "reduce_gbs_into_root", "sparse_records", "error")) or {}
+        optional["vcf_reduce"] = _pick(v, ("profile_batch_ms", "same_batches_without_profile_ms", "hbm_free_gb", "reduce_ms", "reduce_gb", "reduce_gbs_into_root", "sparse_records", "covered_positions", "error")) or {}
         if isinstance(v.get("call_variants"), dict):
             optional["vcf_reduce"]["call_variants_ms"] = v["call_variants"].get("ms_total")
+            optional["vcf_reduce"]["call_variants_records"] = v["call_variants"].get("records")
     g = out.get("other_genome")
     if isinstance(g, dict):
         optional["other_genome"] = _pick(g, ("genome", "value", "ms_per_step", "error"))
@@ -1179,9 +1181,8 @@ def main():
                                    f"{args.batch_pairs} {'pairs' if paired else 'reads'} x {args.rlen} bp {'PE' if paired else 'SE'} per step per GPU (sub {args.sub}, ins {args.ins}, del {args.dele} per base), -alg {args.alg}",
                        "reads_per_step_per_gpu": reads_per_step, "full_sa_in_hbm": bool(args.full_sa), "pair_records_in_hbm": args.full_sa >= 2, "index_build_s": round(t_index, 2),
                        "index_hbm_gb": index_gb,
-                       "multi_gpu": None if world == 1 else f"one process per GPU, index replicated, rank r maps batch {world}*step + r; one avgDist trajectory over the "
-                                                            f"ranks' batches per step (all-gather of three numbers a rank over RCCL — pairs re-run, proper pairs, summed distance —, {traj.exchanges} exchanges in "
-                                                            f"{n_steps} steps, inside the timed region)",
+                       "multi_gpu": None if world == 1 else f"one process per GPU, index replicated, rank r maps batch {world}*step + r; one avgDist trajectory per step over the ranks' batches: "
+                                                            f"{traj.exchanges} exchanges in {n_steps} steps, inside the timed region (all-gather of three numbers a rank over RCCL: pairs re-run, proper pairs, summed distance)",
                        "multi_gpu_host_ms_per_step": None if traj is None else round(1000 * traj.host_s / n_steps, 3)},
             "roofline": roofline(args, d, total_reads / dt / world),
             "per_read": {"fm_ext_steps": round(d["fm_ext_steps"] / max(d["reads"], 1), 2), "fm_blocks": round(d["fm_blocks"] / max(d["reads"], 1), 2),

@@ -58,6 +58,8 @@ int mcx_index_build(const char *fasta_path, const char *prefix, int device);
 int mcx_index_from_codes(const uint8_t *d_codes, int32_t n_chr, const int32_t *chr_len, const char *const *chr_name,
                          int device, int full_sa, mcx_index **out, double *build_seconds);
 int mcx_index_save(const mcx_index *, const char *prefix);
+/* Releases the index's HBM at once.  Contexts of the index that are still alive must not map any more; freeing them afterwards is allowed (the index's
+ * host object stays until the last of them is gone). */
 void mcx_index_free(mcx_index *);
 int64_t mcx_index_genome_size(const mcx_index *);
 int32_t mcx_index_n_chr(const mcx_index *);
@@ -76,6 +78,21 @@ typedef struct mcx_opts {
 void mcx_opts_default(mcx_opts *);
 
 int mcx_ctx_create(const mcx_index *, const mcx_opts *, mcx_ctx **out);
+/* The same with everything the run will take from the device taken at once — the context, tier 0's pair records (otherwise allocated by the first batch),
+ * and with_profile != 0: the counter planes (mcx_planes_alloc -> *planes; free with mcx_planes_free) and the bookkeeping's buffers (mcx_profile_attach with
+ * max_dup / max_clip) — and, when that leaves less than 4 GB of HBM, degraded in a fixed order until it fits, each step said on stderr: the index gives its
+ * pair records back (mcx_index_trim), then max_batch_reads is halved, repeatedly (whole 200-read chunks, down to 128 K reads).  *fit (may be NULL) says
+ * what was done; the caller cuts its run into batches of fit->max_batch_reads.  paired: the run's batches are read pairs (half the pair records).
+ * Replaces the reference's `new MappingRecord_t[GenomeSize]` (main.cpp:366-370), which has the host's memory to fall back on. */
+typedef struct mcx_fit {
+    int32_t pair_records_trimmed; /* 1: mcx_index_trim was applied */
+    int32_t batch_halvings;       /* how often max_batch_reads was halved */
+    int32_t single_detail_set;    /* 1: no second set of detail records — a batch's -vcf bookkeeping runs inside its call */
+    int32_t pad;
+    int64_t max_batch_reads;      /* what the context was made for */
+    int64_t hbm_free_bytes;       /* free HBM with everything allocated */
+} mcx_fit;
+int mcx_ctx_create_fit(mcx_index *, const mcx_opts *, int with_profile, int paired, int max_dup, int max_clip, mcx_ctx **out, uint32_t **planes, mcx_fit *fit);
 void mcx_ctx_free(mcx_ctx *);
 
 /* ---- per-call drop-ins ------------------------------------------------------------------

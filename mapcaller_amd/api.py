@@ -60,7 +60,7 @@ def pack_reads(bases, lens=None):
 SYMBOLS = [
     "mcx_last_error", "mcx_device_count", "mcx_pack_row", "mcx_host_cpus", "mcx_index_load", "mcx_index_build", "mcx_index_from_codes", "mcx_index_save", "mcx_index_free", "mcx_index_trim",
     "mcx_index_genome_size", "mcx_index_n_chr", "mcx_index_chr_name", "mcx_index_chr_len", "mcx_index_hbm_bytes",
-    "mcx_opts_default", "mcx_ctx_create", "mcx_ctx_free", "mcx_bwt_search_batch", "mcx_extend_batch",
+    "mcx_opts_default", "mcx_ctx_create", "mcx_ctx_create_fit", "mcx_ctx_free", "mcx_bwt_search_batch", "mcx_extend_batch",
     "mcx_avg_init", "mcx_map_batch_dev", "mcx_map_batch", "mcx_cigar_words", "mcx_map_files", "mcx_map_files_ex", "mcx_file_opts_default",
     "mcx_profile_attach", "mcx_profile_settle", "mcx_profile_finalize", "mcx_profile_sparse", "mcx_planes_alloc", "mcx_planes_free", "mcx_planes_bytes",
     "mcx_vcf_defaults", "mcx_call_variants",
@@ -82,6 +82,11 @@ class McxError(RuntimeError):
 class Opts(C.Structure):
     _fields_ = [("alg", C.c_int32), ("max_pos_diff", C.c_int32), ("max_mismatch_rate", C.c_float),
                 ("max_read_len", C.c_int32), ("max_batch_reads", C.c_int64)]
+
+
+class Fit(C.Structure):  # mcx_fit
+    _fields_ = [("pair_records_trimmed", C.c_int32), ("batch_halvings", C.c_int32), ("single_detail_set", C.c_int32), ("pad", C.c_int32),
+                ("max_batch_reads", C.c_int64), ("hbm_free_bytes", C.c_int64)]
 
 
 class Aln(C.Structure):
@@ -281,6 +286,7 @@ def lib() -> C.CDLL:
     L.mcx_opts_default.argtypes = [C.POINTER(Opts)]
     L.mcx_opts_default.restype = None
     L.mcx_ctx_create.argtypes = [C.c_void_p, C.POINTER(Opts), C.POINTER(C.c_void_p)]
+    L.mcx_ctx_create_fit.argtypes = [C.c_void_p, C.POINTER(Opts), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(Fit)]
     L.mcx_bwt_search_batch.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_uint32] + [C.c_void_p] * 3
     L.mcx_extend_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_uint32] + [C.c_void_p] * 3
     L.mcx_avg_init.argtypes = [C.POINTER(C.c_int64)]
@@ -463,6 +469,22 @@ class Mapper:
         self.avg = (C.c_int64 * 4)()
         lib().mcx_avg_init(self.avg)
         self.stats = Stats()
+
+    @staticmethod
+    def fit_plan(index: Index, alg: str = "nw", max_read_len: int = 256, max_batch_reads: int = 1 << 20, with_profile: bool = False, paired: bool = True) -> dict:
+        """What mcx_ctx_create_fit makes of this run on this device — everything the run takes allocated at once (context, tier 0's pair records, with_profile:
+        planes and bookkeeping buffers), degraded until 4 GB of HBM stay free: pair records trimmed (the INDEX is changed: mcx_index_trim), batch halved —
+        then given back.  Returns the mcx_fit record as a dict; the caller sizes its Mapper with ["max_batch_reads"]."""
+        o = Opts()
+        lib().mcx_opts_default(C.byref(o))
+        o.alg = 0 if alg == "nw" else 1
+        o.max_read_len, o.max_batch_reads = max_read_len, max_batch_reads
+        h, planes, fit = C.c_void_p(), C.c_void_p(), Fit()
+        _check(lib().mcx_ctx_create_fit(index._h, C.byref(o), int(with_profile), int(paired), 0, 5, C.byref(h), C.byref(planes) if with_profile else None, C.byref(fit)), "mcx_ctx_create_fit")
+        if planes.value:
+            lib().mcx_planes_free(planes)
+        lib().mcx_ctx_free(h)
+        return {k: int(getattr(fit, k)) for k, _ in Fit._fields_ if k != "pad"}
 
     def reset(self):
         lib().mcx_avg_init(self.avg)

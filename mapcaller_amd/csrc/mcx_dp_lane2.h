@@ -156,11 +156,20 @@ static inline MCX_HD void lane_sweep_nw2(const LaneMem &mem, const LaneLayout2 &
         uint32_t diag_next = pk::dup(b0 == 0 ? 0 : -2 - 2 * b0); // s~[0][b0]
         const bool more = s + 1 < strips;
         const int ka = (n_a - 1) - b0, kb = (n_b - 1) - b0; // the column of the strip that is the problem's last (outside 0..K-1: not in this strip)
+        // (a row's words — its query codes, the edge the strip before left — are fetched while the row BEFORE it is computed: fetched at the row's own
+        //  start they are a wait of several hundred cycles per row with nothing of the lane's own to fill it, and the kernel spent 70 % of its wave-cycles
+        //  there (rocprofv3 SQ_WAIT_ANY, profiles/round6).  Row a + 1's edge words are still the strip before's when row a runs: a row stores its own at its end.)
+        uint32_t q_nx = mem.get(l.off_q), r_nx = 0, s_nx = 0;
+        if (b0 != 0) { r_nx = mem.get(l.off_edge); s_nx = mem.get(l.off_edge + 1u); }
         for (int a = 0; a < m; a++) {
-            const uint32_t q = mem.get(l.off_q + (uint32_t)a);
+            const uint32_t q = q_nx;
             uint32_t Rl, Sl;
             if (b0 == 0) { Rl = NEG; Sl = pk::dup(-2 - 2 * (a + 1)); } // r[i][0], s~[i][0]
-            else { Rl = mem.get(l.off_edge + 2u * (uint32_t)a); Sl = mem.get(l.off_edge + 2u * (uint32_t)a + 1u); }
+            else { Rl = r_nx; Sl = s_nx; }
+            if (a + 1 < m) {
+                q_nx = mem.get(l.off_q + (uint32_t)(a + 1));
+                if (b0 != 0) { r_nx = mem.get(l.off_edge + 2u * (uint32_t)(a + 1)); s_nx = mem.get(l.off_edge + 2u * (uint32_t)(a + 1) + 1u); }
+            }
             uint32_t diag = diag_next;
             diag_next = Sl; // s~[i][b0] is the next row's upper-left neighbour
             uint32_t fr = 0, ft = 0;
@@ -188,18 +197,44 @@ static inline MCX_HD void lane_sweep_nw2(const LaneMem &mem, const LaneLayout2 &
     *score_b = pk::hi(fin) + m_b + n_b;
 }
 
-// "query base qi differs from target base tj" of problem h for the walks' mismatch counts
+// What a walk reads of its problem, four rows at a time: the traceback words of rows top .. top - 3 of one strip and the rows' query codes, fetched
+// together when the walk leaves the window (it moves up a row or stays: one wait per four rows instead of one — or, with the query code, two — per
+// column; the walk is a chain of dependent fetches with nothing between them).  Held in named registers and picked by comparison: an array indexed
+// by a run-time row would live in scratch memory.
+template <bool NW>
+struct LaneWindow2 {
+    const LaneMem &mem; const LaneLayout2 &l; int h;
+    int strip = -1, top = -1;
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    MCX_HD LaneWindow2(const LaneMem &m, const LaneLayout2 &lay, int half) : mem(m), l(lay), h(half) {}
+    MCX_HD void at(int s, int row)
+    {
+        if (s == strip && row <= top && row > top - 4) return;
+        strip = s; top = row;
+        constexpr uint32_t W = LaneDir2<NW>::words, P = LaneDir2<NW>::per_problem;
+        const uint32_t base = l.off_dir + (uint32_t)(s * (int)l.rows) * W + (uint32_t)h * P;
+        const int r1 = row > 0 ? row - 1 : 0, r2 = row > 1 ? row - 2 : 0, r3 = row > 2 ? row - 3 : 0; // (above row 0: row 0 again, never picked)
+        a0 = mem.get(base + (uint32_t)row * W); a1 = mem.get(base + (uint32_t)r1 * W); a2 = mem.get(base + (uint32_t)r2 * W); a3 = mem.get(base + (uint32_t)r3 * W);
+        if (!NW) { b0 = mem.get(base + (uint32_t)row * W + 1u); b1 = mem.get(base + (uint32_t)r1 * W + 1u); b2 = mem.get(base + (uint32_t)r2 * W + 1u); b3 = mem.get(base + (uint32_t)r3 * W + 1u); }
+        q0 = mem.get(l.off_q + (uint32_t)row); q1 = mem.get(l.off_q + (uint32_t)r1); q2 = mem.get(l.off_q + (uint32_t)r2); q3 = mem.get(l.off_q + (uint32_t)r3);
+    }
+    MCX_HD uint32_t pick(int row, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) const { const int d = top - row; return d == 0 ? x0 : (d == 1 ? x1 : (d == 2 ? x2 : x3)); }
+    MCX_HD uint32_t w0(int row) const { return pick(row, a0, a1, a2, a3); }
+    MCX_HD uint32_t w1(int row) const { return pick(row, b0, b1, b2, b3); }
+    MCX_HD uint32_t qcode(int row) const { return (pick(row, q0, q1, q2, q3) >> (16 * h)) & 7u; }
+};
+
+// "the query base of this row differs from target base tj" of a walk's problem, for the mismatch counts
 template <class Tgt16>
 struct LaneBases2 {
-    const LaneMem &mem; const LaneLayout2 &l; Tgt16 tgt16; int h;
+    Tgt16 tgt16;
     int ct = -1;
     uint32_t tw = 0;
-    MCX_HD LaneBases2(const LaneMem &m, const LaneLayout2 &lay, Tgt16 t, int half) : mem(m), l(lay), tgt16(t), h(half) {}
-    MCX_HD int differ(int qi, int tj)
+    MCX_HD LaneBases2(Tgt16 t) : tgt16(t) {}
+    MCX_HD int differ(uint32_t qb, int tj)
     {
         if ((tj >> 4) != ct) { ct = tj >> 4; tw = tgt16(ct * 16); }
-        const uint32_t qb = (mem.get(l.off_q + (uint32_t)qi) >> (16 * h)) & 7u, tb = (tw >> (30 - 2 * (tj & 15))) & 3u;
-        return qb != tb ? 1 : 0;
+        return qb != ((tw >> (30 - 2 * (tj & 15))) & 3u) ? 1 : 0;
     }
 };
 
@@ -208,19 +243,21 @@ template <int K, class Tgt16, class Sink>
 static inline MCX_HD void lane_walk_nw2(const LaneMem &mem, const LaneLayout2 &l, int h, int m, int n, Tgt16 tgt16, Sink &sink)
 {
     int i = m, j = n; // 1-based matrix indices
-    LaneBases2<Tgt16> bases(mem, l, tgt16, h);
+    LaneBases2<Tgt16> bases(tgt16);
+    LaneWindow2<true> win(mem, l, h);
     while (i > 0 || j > 0) {
         unsigned d;
         if (i == 0) d = 1;
         else if (j == 0) d = 2;
         else {
             const int a = i - 1, b = j - 1, sh = K - 1 - (b % K);
-            const uint32_t w = mem.get(l.off_dir + (uint32_t)((b / K) * (int)l.rows + a) * LaneDir2<true>::words + (uint32_t)h);
+            win.at(b / K, a);
+            const uint32_t w = win.w0(a);
             d = (((w >> sh) & 1u) ^ 1u) | ((((w >> (16 + sh)) & 1u) ^ 1u) << 1);
         }
         if (d & 1) { sink.col(2, 0); j--; }
         else if (d & 2) { sink.col(1, 0); i--; }
-        else { sink.col(0, sink.wants_bases() ? bases.differ(i - 1, j - 1) : 0); i--; j--; }
+        else { sink.col(0, sink.wants_bases() ? bases.differ(win.qcode(i - 1), j - 1) : 0); i--; j--; } // (d == 0 only where the window was set for this cell)
     }
 }
 
@@ -244,14 +281,20 @@ static inline MCX_HD void lane_sweep_ksw2_2(const LaneMem &mem, const LaneLayout
         MCX_UNROLL
         for (int k = 0; k < K; k++) { U[k] = pk::dup((b0 + k) ? Q : 0); Y[k] = 0; } // the first matrix row (ksw2_alignment.cpp:165)
         const bool more = s + 1 < strips;
+        uint32_t q_nx = mem.get(l.off_q), x_nx = 0, v_nx = 0; // (the next row's words under this row's cells: lane_sweep_nw2)
+        if (b0 != 0) { x_nx = mem.get(l.off_edge); v_nx = mem.get(l.off_edge + 1u); }
         for (int a = 0; a < qlen; a++) {
-            const uint32_t q = mem.get(l.off_q + (uint32_t)a);
+            const uint32_t q = q_nx;
             // the row's substitution scores + q + 2e as 7 - 2 mm, or 6 whatever the target where the query holds an N (score 0: :150-158)
             const uint32_t is_n = (q >> 2) & 0x00010001u;
             const uint32_t c1 = pk::add(pk::add(is_n, is_n), pk::dup(-2)), c0 = pk::sub(pk::dup(7), is_n);
             uint32_t xl, vl;
             if (b0 == 0) { xl = 0; vl = pk::dup(a ? Q : 0); } // values entering column 0 (:163)
-            else { xl = mem.get(l.off_edge + 2u * (uint32_t)a); vl = mem.get(l.off_edge + 2u * (uint32_t)a + 1u); }
+            else { xl = x_nx; vl = v_nx; }
+            if (a + 1 < qlen) {
+                q_nx = mem.get(l.off_q + (uint32_t)(a + 1));
+                if (b0 != 0) { x_nx = mem.get(l.off_edge + 2u * (uint32_t)(a + 1)); v_nx = mem.get(l.off_edge + 2u * (uint32_t)(a + 1) + 1u); }
+            }
             uint32_t f1 = 0, f2 = 0, fx = 0, fy = 0;
             MCX_UNROLL
             for (int k = 0; k < K; k++) {
@@ -287,17 +330,18 @@ template <int K, class Tgt16, class Sink>
 static inline MCX_HD void lane_walk_ksw2_2(const LaneMem &mem, const LaneLayout2 &l, int h, int qlen, int tlen, Tgt16 tgt16, Sink &sink)
 {
     int i = tlen - 1, j = qlen - 1, state = 0;
-    LaneBases2<Tgt16> bases(mem, l, tgt16, h);
+    LaneBases2<Tgt16> bases(tgt16);
+    LaneWindow2<false> win(mem, l, h);
     while (i >= 0 && j >= 0) {
         const int sh = K - 1 - (i % K);
-        const uint32_t at = l.off_dir + (uint32_t)((i / K) * (int)l.rows + j) * LaneDir2<false>::words + 2u * (uint32_t)h;
-        const uint32_t w0 = mem.get(at), w1 = mem.get(at + 1u);
+        win.at(i / K, j);
+        const uint32_t w0 = win.w0(j), w1 = win.w1(j);
         const unsigned st = ((w0 >> (16 + sh)) & 1u) ? 2u : ((w0 >> sh) & 1u);
         const unsigned d = st | (((w1 >> sh) & 1u) << 3) | (((w1 >> (16 + sh)) & 1u) << 4); // the reference's byte: state in bits 0-2, extension bits 3 and 4
         if (state == 0) state = d & 7;
         else if (!((d >> (state + 2)) & 1)) state = 0;
         if (state == 0) state = d & 7;
-        if (state == 0) { sink.col(0, sink.wants_bases() ? bases.differ(j, i) : 0); --i; --j; }
+        if (state == 0) { sink.col(0, sink.wants_bases() ? bases.differ(win.qcode(j), i) : 0); --i; --j; }
         else if (state == 1 || state == 3) { sink.col(2, 0); --i; }
         else { sink.col(1, 0); --j; }
     }

@@ -145,8 +145,8 @@ public:
     size_t size() const { return n_; }
     void clear() { n_ = 0; }
     bool reserve(size_t n) { if (n > cap_) { Rec *q = (Rec *)realloc(p_, n * sizeof(Rec)); if (!q) return false; p_ = q; cap_ = n; } return true; }
-    void resize(size_t n) { if (reserve(n)) n_ = n; } // (new entries are the caller's to write)
-    void push_back(const Rec &r) { if (n_ == cap_ && !reserve(cap_ ? cap_ * 2 : 4096)) return; p_[n_++] = r; }
+    bool resize(size_t n) { if (!reserve(n)) return false; n_ = n; return true; } // (new entries are the caller's to write)
+    bool push_back(const Rec &r) { if (n_ == cap_ && !reserve(cap_ ? cap_ * 2 : 4096)) return false; p_[n_++] = r; return true; } // false: out of memory — the caller says so (a record dropped in silence would shift mate 1 against mate 2)
     Rec &operator[](size_t i) { return p_[i]; }
     const Rec &operator[](size_t i) const { return p_[i]; }
     Rec *data() { return p_; }
@@ -551,7 +551,7 @@ private:
         rec.seq = seq_at; rec.rlen = (uint32_t)rlen;
         if (rlen == 0) { o.resize(name_at); return false; } // `.rlen == 0` ends the input (GetData.cpp:91)
         if ((int)rlen > max_len) { v.error = "read " + std::string(o.data() + name_at, rec.name_len) + " is longer than max_read_len"; return false; }
-        v.recs.push_back(rec);
+        if (!v.recs.push_back(rec)) { v.error = "out of memory for the batch's read records"; o.resize(name_at); return false; }
         return true;
     }
 };
@@ -817,15 +817,16 @@ struct Shards {
         int rc = 0;
         if (n) rc = mcx_batch_begin(c, d_bases, d_off, n, 1, (int32_t)((uint32_t)avg[0] * 1.5), read_base, d_aln, d_cig, stats);
         // What the shards tell each other per exchange: {status, chunks, pairs re-run, -, proper pairs, their summed distance} — totals, not the
-        // chunks' sums: the walk has a closed form (mcx_batch_check), so a shard checks its own chunks on the device from the round's state plus the
-        // totals of the shards before it in input order.
+        // chunks' sums: a shard walks its own chunks from the round's state plus the totals of the shards before it in input order (below).
         struct Msg { uint32_t rc, n_chunks, n_redo, pad; int64_t pairs, dist; } mine, o;
         uint32_t n_redo = 0xFFFFFFFFu; // "not replayed yet"
         int64_t st[3] = {avg[0], avg[1], avg[2]};
+        std::vector<int32_t> est;
         for (int iter = 0;; iter++) {
             uint32_t nc = 0;
             int64_t tot[2] = {0, 0};
-            if (rc == 0 && n) rc = mcx_batch_sums(c, &nc, nullptr, nullptr, nullptr);
+            const uint32_t *ok = nullptr, *ds = nullptr;
+            if (rc == 0 && n) rc = mcx_batch_sums(c, &nc, &ok, &ds, nullptr);
             if (rc == 0 && n) rc = mcx_batch_totals(c, tot);
             mine.rc = (uint32_t)rc; mine.n_chunks = rc ? 0 : nc; mine.n_redo = n_redo; mine.pad = 0; mine.pairs = tot[0]; mine.dist = tot[1];
             if (int e = gather(&mine, sizeof mine)) return e;
@@ -844,7 +845,22 @@ struct Shards {
             if (settled) break;
             if (iter == 255) return mcx_set_error(MCX_ERR_CAPACITY, "avgDist replay did not converge");
             n_redo = 0;
-            if (n) rc = mcx_batch_check(c, before, first ? 1 : 0, &n_redo, stats);
+            if (n) {
+                // this shard's chunks walked HERE, from the round's state plus the totals of the shards before it (ReadMapping.cpp:462, :538-539): the
+                // estimate a chunk is paired with is the state before it, re-estimated once a thousand proper pairs have been seen — not at the round's
+                // very first chunk, whose estimate is the state the round began with.  The device checks every pair against the list and re-runs the
+                // ones whose estimate moved (mcx_batch_replay).  (Round 5 left the walk to the device here — mcx_batch_check, closed form — with nothing
+                // on the host to hold it against; the one-shard path has always compared the two.)
+                est.resize(nc);
+                uint32_t cur = (uint32_t)before[0];
+                int64_t tp = before[1], td = before[2];
+                for (uint32_t k = 0; k < nc; k++) {
+                    if ((k > 0 || !first) && tp > 1000) cur = (uint32_t)(int)(1. * td / tp + .5);
+                    est[k] = (int32_t)(cur * 1.5);
+                    tp += ok[k]; td += ds[k];
+                }
+                rc = mcx_batch_replay(c, est.data(), &n_redo, stats);
+            }
         }
         avg[0] = st[0]; avg[1] = st[1]; avg[2] = st[2];
         return finish_part(c, n != 0, profile, stats, 0);

@@ -19,6 +19,7 @@ struct mcx_index {
     int64_t hbm_bytes = 0;
     uint64_t n_bwt_words = 0, n_sa = 0; // set for indexes built in HBM (mcx_index_from_codes)
     mutable std::atomic<int> n_ctx{0};  // contexts alive on this index (mcx_ctx_create / mcx_ctx_free): mcx_index_trim refuses while there are any
+    mutable std::atomic<bool> orphan{false}; // mcx_index_free was called while contexts were alive: the last mcx_ctx_free deletes this object
 };
 
 // what the file front end (mcx_files.cpp) needs to know about a context

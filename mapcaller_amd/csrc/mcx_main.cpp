@@ -202,12 +202,21 @@ int main(int argc, char **argv)
         memset(&sh.st, 0, sizeof sh.st);
         auto bad = [&](int rc) { sh.rc = rc; sh.err = mcx_last_error(); };
         int rc = mcx_index_load(prefix.c_str(), sh.device, full_sa, &sh.ix);
-        if (rc == 0) rc = mcx_ctx_create(sh.ix, &o, &sh.cx);
-        if (rc == 0 && want_vcf) { // MappingRecordArr, main.cpp:366-370
-            if (r == 0) fprintf(stderr, "Initialize the alignment profile...\n");
-            if ((rc = mcx_planes_alloc(sh.ix, &sh.planes)) == 0) rc = mcx_profile_attach(sh.cx, sh.planes, vo.max_dup, vo.max_clip);
+        mcx_fit fit;
+        memset(&fit, 0, sizeof fit);
+        if (rc == 0) {
+            // the context, tier 0's pair records and — MappingRecordArr, main.cpp:366-370 — the planes and the bookkeeping's buffers, all taken here, fitted to
+            // what the device has left (a genome larger than GRCh38, -two_base, a long -maxlen: smaller batches instead of a failed allocation in the first batch)
+            if (want_vcf && r == 0) fprintf(stderr, "Initialize the alignment profile...\n");
+            rc = mcx_ctx_create_fit(sh.ix, &o, want_vcf ? 1 : 0, paired_run ? 1 : 0, vo.max_dup, vo.max_clip, &sh.cx, want_vcf ? &sh.planes : nullptr, &fit);
         }
         if (rc) bad(rc);
+        if (n_gpus > 1) { // the shards cut ONE input stream into batches: they must agree on the batch
+            int64_t mine = sh.rc ? -1 : fit.max_batch_reads;
+            std::vector<int64_t> all((size_t)n_gpus);
+            links[(size_t)r].allgather(links[(size_t)r].user, &mine, all.data(), sizeof mine);
+            for (int64_t v : all) if (v >= 0 && mine >= 0 && v != mine && !sh.rc) { sh.rc = MCX_ERR_DEVICE; sh.err = "the shards' devices have room for different batch sizes (" + std::to_string((long long)mine) + " / " + std::to_string((long long)v) + " reads): give -batch"; }
+        }
         mcx_file_opts my = fo;
         int64_t avg[4];
         mcx_avg_init(avg); // avgDist and its totals are globals of the reference: they carry over from library to library

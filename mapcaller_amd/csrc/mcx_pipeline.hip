@@ -365,6 +365,10 @@ extern "C" void mcx_index_free(mcx_index *ix)
     if (!ix) return;
     void *p[] = {ix->d_bwt, ix->d_sa, ix->d_sa_full, ix->d_pac, ix->d_end_pos, ix->d_end_chr, ix->d_chr_fwd, ix->d_ktab, ix->d_rank, ix->d_rank2, ix->d_rank2_c2};
     for (void *q : p) if (q) (void)hipFree(q);
+    // (a caller that frees the index before its contexts — allowed: a context that is only freed afterwards touches no device memory of the index — leaves
+    //  the host object to the last mcx_ctx_free, which still counts itself out of it)
+    ix->d_bwt = ix->d_sa = ix->d_sa_full = ix->d_pac = ix->d_end_pos = ix->d_end_chr = ix->d_chr_fwd = ix->d_ktab = ix->d_rank = ix->d_rank2 = ix->d_rank2_c2 = nullptr;
+    if (ix->n_ctx.load() > 0) { ix->orphan.store(true); return; }
     delete ix;
 }
 // gives back what an index holds above `full_sa` (2 -> 1: the pair records).  Contexts made before keep their view of the index: close them first.
@@ -2466,7 +2470,7 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
 extern "C" void mcx_ctx_free(mcx_ctx *c)
 {
     if (!c) return;
-    if (c->counted && c->idx) c->idx->n_ctx--;
+    if (c->counted && c->idx && --c->idx->n_ctx == 0 && c->idx->orphan.load()) delete c->idx; // (the index was freed first: its host object waited for this)
     if (c->files_state && c->files_drop) c->files_drop(c->files_state);
     void *p[] = {c->tier[0].state, c->tier[1].state, c->d_tasks, c->d_jobs[0], c->d_jobs[1], c->d_jobs[2], c->d_jobs[3], c->d_jobs[4], c->d_jobs[5],
                  c->d_cnt, c->d_rescue, c->d_kscratch, c->d_rtasks, c->d_rres, c->d_rseeds, c->d_rplans, c->d_rescue_n, c->d_dp_scratch[0], c->d_dp_scratch[1], c->d_dp_scratch[2],
@@ -3061,9 +3065,12 @@ static int queue_batch_tail(mcx_ctx *c)
         HIP_TRY(hipEventRecord(t.ev[0], c->t1.stream)); HIP_TRY(hipStreamWaitEvent(s, t.ev[0], 0));
         if (c->overlap_late) { HIP_TRY(hipEventRecord(t.ev[1], c->t2.stream)); HIP_TRY(hipStreamWaitEvent(s, t.ev[1], 0)); }
     }
-    uint32_t *d_ok = c->d_read_ext, *d_ds = c->d_read_blocks, *d_ls = d_ds + nc; // (the per-read statistics are reduced first: as mcx_batch_sums has it)
+    // (the sums in the tail's own words, behind the walk's estimates: the per-read statistics stay as the passes left them — a batch whose tail does not
+    //  stand in the end, because pairs went on to the large tier or the selection was halved, reduces them again once every pass has run, like a batch
+    //  without a tail: round 5 took the tail's snapshot then, made before those passes searched their reads again)
     unsigned long long *d_sum = (unsigned long long *)(t.d + 2); // counters [2..8): three 64-bit sums
     int32_t *d_est = (int32_t *)(t.d + 8);
+    uint32_t *d_ok = t.d + 8 + nc, *d_ds = d_ok + nc, *d_ls = d_ds + nc;
     HIP_TRY(hipMemsetAsync(t.d, 0, 8 * sizeof(uint32_t), s));
     k_reduce_stats<<<256, 256, 0, s>>>(c->d_read_ext, c->d_read_blocks, n_reads, d_sum);
     k_chunk_sums<<<(nc + 255) / 256, 256, 0, s>>>(c->d_pout, br.rb.off, br.n_pairs, kReadChunkSize / 2, d_ok, d_ds, d_ls, t.d + 1);
@@ -3213,6 +3220,20 @@ __global__ void k_keep_reads(const uint8_t *__restrict__ bases, const uint32_t *
     for (uint64_t i = t; i <= n_reads; i += T) to_off[i] = off[i];
 }
 
+// tier 0's pair records: one per pair of the largest batch of this kind (allocated by the first batch that needs them, or ahead of it by mcx_ctx_create_fit)
+static int reserve_tier0(mcx_ctx *c, int paired, uint64_t n_reads)
+{
+    const uint64_t half = (c->max_reads + 1) / 2;
+    const uint64_t want = (paired || n_reads <= half) ? half : c->max_reads; // (the single-end tail of an interleaved file fits the pairs' records)
+    if (c->tier[0].max_pairs < want) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (c->tier[0].state) { (void)hipFree(c->tier[0].state); c->tier[0].state = nullptr; c->tier[0].max_pairs = 0; }
+        if (int rc = dmalloc(&c->tier[0].state, (size_t)c->tier[0].lay.stride * want)) return rc;
+        c->tier[0].max_pairs = (uint32_t)want;
+    }
+    return 0;
+}
+
 extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_t *d_off, uint32_t n_reads, int paired, int32_t est0,
                                int64_t read_base, mcx_aln *d_aln, uint32_t *d_cigar, mcx_stats *stats)
 {
@@ -3236,16 +3257,7 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
     HIP_TRY(hipSetDevice(c->idx->device));
     br.t0 = std::chrono::steady_clock::now();
     hipStream_t s = c->stream;
-    { // tier 0's pair records: one per pair of the largest batch of this kind
-        const uint64_t half = (c->max_reads + 1) / 2;
-        const uint64_t want = (paired || n_reads <= half) ? half : c->max_reads; // (the single-end tail of an interleaved file fits the pairs' records)
-        if (c->tier[0].max_pairs < want) {
-            HIP_TRY(hipDeviceSynchronize());
-            if (c->tier[0].state) { (void)hipFree(c->tier[0].state); c->tier[0].state = nullptr; c->tier[0].max_pairs = 0; }
-            if (int rc = dmalloc(&c->tier[0].state, (size_t)c->tier[0].lay.stride * want)) return rc;
-            c->tier[0].max_pairs = (uint32_t)want;
-        }
-    }
+    if (int rc = reserve_tier0(c, paired, n_reads)) return rc;
     br.rb.bases = d_bases; br.rb.off = d_off; br.rb.n_reads = n_reads;
     br.paired = paired; br.read_base = read_base;
     br.recs = (AlnRec *)d_aln; br.cig = d_cigar; br.stats = stats;
@@ -3298,7 +3310,7 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
     rc = run_selection(c, br.rb, paired, nullptr, nullptr, est0, br.n_pairs, br.recs, d_cigar, stats, true);
     br.t_begun = std::chrono::steady_clock::now();
     if (rc) return rc;
-    if (c->tail.ran) memcpy(c->h_cnt + CNT_N, c->tail.h + 2, sizeof br.hs); // (the pass queued the batch's tail: the statistics came with it, before the per-read arrays were reused)
+    if (c->tail.queued) memcpy(c->h_cnt + CNT_N, c->tail.h + 2, sizeof br.hs); // (the pass queued the batch's tail and it stands: the statistics came with it)
     else { // seeding statistics (E, blocks, H of SURVEY.md 8d) before the per-read arrays are reused for the chunk sums
         unsigned long long *d_sum = (unsigned long long *)c->d_cnt;
         HIP_TRY(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(uint32_t), s));
@@ -4029,6 +4041,65 @@ extern "C" int mcx_profile_attach(mcx_ctx *c, uint32_t *d_planes, int max_dup, i
     }
     c->prof_settled = false; c->prof_broken = false;
     return 0;
+}
+
+// A context — and, for a -vcf run, the planes and the bookkeeping's buffers — sized to what the device has left (the -vcf leg at 3.1 Gbp left
+// 5.4 GB of 309, and a larger genome met a bare hipMalloc failure in the middle of its first batch).  Everything the run will take is taken HERE: the context,
+// tier 0's pair records (otherwise the first batch's), the planes, the detail records.  When that does not fit with kFitMargin to spare — the record
+// archive's growth, the caller's own batches, the stream slots — the run is degraded in a fixed order, each step said on stderr in one line:
+//   1. the index gives its pair records back (mcx_index_trim: the seeding walk takes one base per step, 24.8 GB at 3.1 Gbp);
+//   2. max_batch_reads is halved, again and again (down to 128 K reads);
+// (a second set of detail records, which lets a batch's bookkeeping run under the next batch, is only ever taken when there is room: mcx_profile_attach).
+// MCX_HBM_RESERVE_GB=n (tests): n GB of the device count as taken.
+constexpr size_t kFitMargin = (size_t)4 << 30;
+extern "C" int mcx_ctx_create_fit(mcx_index *ix, const mcx_opts *opts, int with_profile, int paired, int max_dup, int max_clip, mcx_ctx **out, uint32_t **planes, mcx_fit *fit)
+{
+    if (!ix || !out || (with_profile && !planes)) return fail(MCX_ERR_ARG, "mcx_ctx_create_fit: null argument");
+    mcx_opts o;
+    if (opts) o = *opts; else mcx_opts_default(&o);
+    mcx_fit f; memset(&f, 0, sizeof f);
+    size_t reserve = 0;
+    if (const char *e = getenv("MCX_HBM_RESERVE_GB")) reserve = (size_t)(atof(e) * (double)((size_t)1 << 30));
+    HIP_TRY(hipSetDevice(ix->device));
+    for (;;) {
+        mcx_ctx *c = nullptr;
+        uint32_t *pl = nullptr;
+        int rc = mcx_ctx_create(ix, &o, &c);
+        if (rc == 0) rc = reserve_tier0(c, paired, (uint64_t)o.max_batch_reads);
+        if (rc == 0 && with_profile) {
+            rc = mcx_planes_alloc(ix, &pl);
+            if (rc == 0) rc = mcx_profile_attach(c, pl, max_dup, max_clip);
+        }
+        size_t hbm_free = 0, hbm_all = 0;
+        (void)hipMemGetInfo(&hbm_free, &hbm_all);
+        hbm_free = hbm_free > reserve ? hbm_free - reserve : 0;
+        const bool fits = rc == 0 && hbm_free >= kFitMargin;
+        if (fits) {
+            f.max_batch_reads = o.max_batch_reads; f.hbm_free_bytes = (int64_t)hbm_free; f.single_detail_set = with_profile && !c->later.have;
+            if (fit) *fit = f;
+            *out = c;
+            if (planes) *planes = pl;
+            return 0;
+        }
+        const std::string why = rc ? std::string(mcx_last_error()) : std::to_string((double)hbm_free / 1e9).substr(0, 5) + " GB of HBM would be left";
+        (void)hipGetLastError(); // (an allocation that failed is no error of the run)
+        if (pl) mcx_planes_free(pl);
+        if (c) mcx_ctx_free(c);
+        if (rc && rc != MCX_ERR_DEVICE) return rc; // (not a matter of room)
+        if (ix->d_rank2) {
+            if ((rc = mcx_index_trim(ix, 1))) return rc;
+            f.pair_records_trimmed = 1;
+            fprintf(stderr, "[mcx fit] %s with batches of %lld reads: the index gives its pair records back (the seeding walk takes one base per step)\n", why.c_str(), (long long)o.max_batch_reads);
+            continue;
+        }
+        if (o.max_batch_reads > ((int64_t)1 << 17)) {
+            o.max_batch_reads = std::max<int64_t>((int64_t)1 << 17, (o.max_batch_reads / 2 + 199) / 200 * 200); // (whole 200-read chunks: a caller that cuts its run into batches of this size keeps the chunk boundaries)
+            f.batch_halvings++;
+            fprintf(stderr, "[mcx fit] %s: batches of %lld reads instead\n", why.c_str(), (long long)o.max_batch_reads);
+            continue;
+        }
+        return fail(MCX_ERR_DEVICE, "mcx_ctx_create_fit: the device has no room for this run even with batches of " + std::to_string((long long)o.max_batch_reads) + " reads and without the pair records (" + why + ")");
+    }
 }
 
 // key buffers and radix-sort scratch for n keys (grown on demand: a round's keys of all shards can outnumber a batch)

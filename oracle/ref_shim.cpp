@@ -99,20 +99,8 @@ int mcref_ksw2_extz(const uint8_t *q, int qlen, const uint8_t *t, int tlen, int 
 extern map<int64_t, uint16_t> BreakPointMap;
 // sparse != 0 (request Q): the profile of a genome too large for the dense file — only the positions
 //   with a non-zero counter, as records {int64 pos, 10 x u16} in <out>.prof.nz
-static int run_profile(const char *fq1, const char *fq2, int ksw2, const char *out, int sparse = 0)
+static int dump_profile(const char *out, int sparse)
 {
-    ReadFileNameVec1.clear(); ReadFileNameVec2.clear();
-    ReadFileNameVec1.push_back(fq1);
-    if (fq2 && fq2[0]) ReadFileNameVec2.push_back(fq2);
-    NW_ALG = !ksw2; bVCFoutput = true; bSAMoutput = false; iThreadNum = 1; iMaxDuplicate = 5; MaxClipSize = 5;
-    static char logname[] = "/dev/null";
-    LogFileName = logname;
-    if (MappingRecordArr) delete[] MappingRecordArr;
-    MappingRecordArr = new MappingRecord_t[GenomeSize]();
-    InsertSeqMap.clear(); DeleteSeqMap.clear(); BreakPointMap.clear(); InversionSiteVec.clear(); TranslocationSiteVec.clear();
-    pthread_mutex_init(&VarLock, NULL); pthread_mutex_init(&OutputLock, NULL); pthread_mutex_init(&LibraryLock, NULL); pthread_mutex_init(&ProfileLock, NULL);
-    StartProcessTime = time(NULL);
-    Mapping();
     string p = string(out) + (sparse ? ".prof.nz" : ".prof");
     FILE *f = fopen(p.c_str(), "wb");
     if (!f) return -1;
@@ -141,9 +129,40 @@ static int run_profile(const char *fq1, const char *fq2, int ksw2, const char *o
     return 0;
 }
 
+static int run_profile(const char *fq1, const char *fq2, int ksw2, const char *out, int sparse = 0)
+{
+    ReadFileNameVec1.clear(); ReadFileNameVec2.clear();
+    ReadFileNameVec1.push_back(fq1);
+    if (fq2 && fq2[0]) ReadFileNameVec2.push_back(fq2);
+    NW_ALG = !ksw2; bVCFoutput = true; bSAMoutput = false; iThreadNum = 1; iMaxDuplicate = 5; MaxClipSize = 5;
+    static char logname[] = "/dev/null";
+    LogFileName = logname;
+    if (MappingRecordArr) delete[] MappingRecordArr;
+    MappingRecordArr = new MappingRecord_t[GenomeSize]();
+    InsertSeqMap.clear(); DeleteSeqMap.clear(); BreakPointMap.clear(); InversionSiteVec.clear(); TranslocationSiteVec.clear();
+    pthread_mutex_init(&VarLock, NULL); pthread_mutex_init(&OutputLock, NULL); pthread_mutex_init(&LibraryLock, NULL); pthread_mutex_init(&ProfileLock, NULL);
+    StartProcessTime = time(NULL);
+    Mapping();
+    return dump_profile(out, sparse);
+}
+
+// Request R: ONE run of the reference's own main() (main.cpp:154-395, compiled into this tool as mapcaller_ref_main) — index load, Mapping() with `-sam`,
+// VariantCalling() with `-vcf` — with the accumulated profile and maps dumped in between: main_lib.o is compiled with -DVariantCalling=mcref_vc_hook
+// (oracle/Makefile), so the call at main.cpp:380 arrives here first.  Saves the tests a second index load and a second mapping pass at 3.1 Gbp.
+extern int mapcaller_ref_main(int argc, char *argv[]);
+static string g_hook_out;
+static int g_hook_sparse = 0, g_hook_rc = 0;
+void mcref_vc_hook()
+{
+    if (!g_hook_out.empty()) g_hook_rc = dump_profile(g_hook_out.c_str(), g_hook_sparse);
+    VariantCalling();
+}
+
 // stdin protocol, one request per line, one reply line each:
 //   P <nw|ksw2> <out prefix> <fq1> [fq2]  -> "ok" after <out>.prof / <out>.maps are written
 //   Q <nw|ksw2> <out prefix> <fq1> [fq2]  -> the same with <out>.prof.nz (non-zero positions only) in place of <out>.prof
+//   R <nw|ksw2> <out prefix> <index prefix> <sam> <vcf> <fq1> [fq2] -> the reference's whole main() at -t 1 with -sam / -vcf, <out>.prof.nz / <out>.maps dumped
+//                                 between Mapping() and VariantCalling() (a process of its own: main() loads and frees the index itself)
 //   L <prefix>                 -> "ok <genome size>"
 //   S <start> <codes 0-4>      -> "<len> <freq> <loc>..."            BWT_Search(seq, start, strlen)
 //   D <q ascii> <t ascii>      -> "<nw a1> <nw a2> <ksw2 a1> <ksw2 a2> <ez.score> <ops reversed>"
@@ -190,6 +209,19 @@ int main()
             int k = sscanf(line + 2, "%15s %1023s %1023s %1023s", alg, out, f1, f2);
             int rc = k >= 3 ? run_profile(f1, f2, strcmp(alg, "ksw2") == 0, out, line[0] == 'Q') : -1;
             printf("%s\n", rc == 0 ? "ok" : "fail");
+        } else if (line[0] == 'R') {
+            char alg[16], out[1024], idx[1024], sam[1024], vcf[1024], f1[1024], f2[1024];
+            f2[0] = 0;
+            int k = sscanf(line + 2, "%15s %1023s %1023s %1023s %1023s %1023s %1023s", alg, out, idx, sam, vcf, f1, f2);
+            if (k < 6 || g_loaded) { printf("fail\n"); fflush(stdout); continue; } // (main() loads the index itself: not after L)
+            g_hook_out = out; g_hook_sparse = 1; g_hook_rc = 0;
+            static char a0[] = "MapCaller", ai[] = "-i", af[] = "-f", af2[] = "-f2", aa[] = "-alg", as[] = "-sam", av[] = "-vcf", at[] = "-t", one[] = "1", al[] = "-log", devnull[] = "/dev/null";
+            std::vector<char *> argv = {a0, ai, idx, af, f1};
+            if (f2[0]) { argv.push_back(af2); argv.push_back(f2); }
+            for (char *x : {aa, alg, as, sam, av, vcf, at, one, al, devnull}) argv.push_back(x);
+            int rc = mapcaller_ref_main((int)argv.size(), argv.data());
+            g_hook_out.clear();
+            printf("%s\n", rc == 0 && g_hook_rc == 0 ? "ok" : "fail");
         } else printf("bad\n");
         fflush(stdout);
     }

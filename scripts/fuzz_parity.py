@@ -10,6 +10,7 @@ rounds with fixed seeds; longer runs by hand.  A divergence prints the round's p
 Checker use only: the oracle is the thing compared against, never a fallback.
 """
 import argparse
+import json
 import os
 import random
 import shutil
@@ -156,11 +157,26 @@ def one_round(d, tmp):
     return desc, sam_bad, vcf_bad
 
 
+def keep(tmp, to, d, a):
+    """A round that differed: its files (genome, index, reads, both SAMs / VCFs) and how it was run, where the next look can find them."""
+    try:
+        os.makedirs(os.path.dirname(to), exist_ok=True)
+        shutil.copytree(tmp, to, dirs_exist_ok=True)
+        with open(os.path.join(to, "HOW.json"), "w") as fh:
+            json.dump({"draw": d, "argv": sys.argv, "cli_args": CLI_ARGS, "no_vcf": NO_VCF, "wide": WIDE, "mode": MODE,
+                       "env": {k: v for k, v in os.environ.items() if k.startswith("MCX_")}}, fh, default=str, indent=1)
+        print(f"  kept in {to}", flush=True)
+    except OSError as e:
+        print(f"  (could not keep the round: {e})", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=20)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--keep", default="")
+    ap.add_argument("--keep", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "fuzz_fail"),
+                    help="where a round that differs (or fails) leaves its inputs and both outputs — ON by default since round 6: round 5 lost its one differing round "
+                         "(gpurun_out/ comes back from the GPU box); '' = keep nothing")
     ap.add_argument("--only", type=int, default=-1, help="replay just this round of the sequence")
     ap.add_argument("--ref", action="store_true", help="compare the oracle with the compiled reference (oracle/_ref, CPU only) instead of the GPU product")
     ap.add_argument("--cli-args", default="", help="extra switches for mapcaller-mi355x, space separated")
@@ -181,21 +197,22 @@ def main():
             continue
         ran += 1
         tmp = tempfile.mkdtemp(prefix=f"fuzz{r}_")
+        keep_to = os.path.join(a.keep, f"seed{a.seed}_round{r}") if a.keep else ""
         try:
             desc, sam_bad, vcf_bad = one_round(d, tmp)
         except subprocess.CalledProcessError as e:
             print(f"round {r}: command failed (exit {e.returncode}): {e.cmd[:6]} ... {d}", flush=True)
             bad += 1
-            if a.keep:
-                shutil.copytree(tmp, os.path.join(a.keep, f"round{r}"), dirs_exist_ok=True)
+            if keep_to:
+                keep(tmp, keep_to, d, a)
             shutil.rmtree(tmp, ignore_errors=True)
             continue
         status = "ok" if not (sam_bad or vcf_bad) else f"DIFF sam={sam_bad} vcf={vcf_bad}"
         print(f"round {r}: {status} {desc}", flush=True)
         if sam_bad or vcf_bad:
             bad += 1
-            if a.keep:
-                shutil.copytree(tmp, os.path.join(a.keep, f"round{r}"), dirs_exist_ok=True)
+            if keep_to:
+                keep(tmp, keep_to, d, a)
         shutil.rmtree(tmp, ignore_errors=True)
     print(f"{ran - bad} of {ran} rounds identical")
     sys.exit(1 if bad else 0)

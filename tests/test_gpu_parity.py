@@ -537,6 +537,48 @@ def test_cli_sam_and_vcf(golden, tmp_path):
     assert vcf_body(vcf) == vcf_body(g["vcf"]["default"])
 
 
+def test_run_is_fitted_to_the_hbm_that_is_left(api, golden, tmp_path):
+    """mcx_ctx_create_fit (the -vcf leg left 5.4 GB of 309 and a larger genome met a bare hipMalloc failure): with most of the device
+    declared taken (MCX_HBM_RESERVE_GB: all but 10 GB of what is free), a -vcf context for batches of a million reads over an index with pair records
+    gives the pair records back first and then halves its batch until 4 GB stay free — said on stderr — and the CLI, which sizes its run the same
+    way, still writes the golden SAM and VCF.  Without the cap nothing is degraded."""
+    import torch
+    g = golden["var"]
+    ix = api.Index(g["prefix"], device=0, full_sa=2)
+    plain = api.Mapper.fit_plan(ix, alg="ksw2", max_batch_reads=1 << 20, with_profile=True)
+    assert plain["pair_records_trimmed"] == 0 and plain["batch_halvings"] == 0 and plain["max_batch_reads"] == 1 << 20 and plain["hbm_free_bytes"] > 4 << 30
+    free_gb = torch.cuda.mem_get_info(0)[0] / (1 << 30)
+    os.environ["MCX_HBM_RESERVE_GB"] = "%.2f" % (free_gb - 10.0)
+    try:
+        plan = api.Mapper.fit_plan(ix, alg="ksw2", max_batch_reads=1 << 20, with_profile=True)
+    finally:
+        os.environ.pop("MCX_HBM_RESERVE_GB", None)
+    assert plan["pair_records_trimmed"] == 1 and plan["batch_halvings"] >= 1, plan
+    assert (1 << 17) <= plan["max_batch_reads"] < (1 << 20) and plan["max_batch_reads"] % 200 == 0 and plan["hbm_free_bytes"] >= 4 << 30, plan
+    mp = api.Mapper(ix, alg="ksw2", max_batch_reads=plan["max_batch_reads"])  # (the trimmed index maps as before: one base per step)
+    out = str(tmp_path / "gpu.sam")
+    mp.map_files(g["r1"], g["r2"], out)
+    nd, ex = sam_diff(g["sam"]["ksw2"], out)
+    assert nd == 0, ex
+    mp.close(); ix.close()
+    torch.cuda.empty_cache()
+    free_gb = torch.cuda.mem_get_info(0)[0] / (1 << 30)
+    exe = os.path.join(ROOT, "mapcaller_amd", "mapcaller-mi355x")
+    sam, vcf = str(tmp_path / "o.sam"), str(tmp_path / "o.vcf")
+    env = dict(os.environ, MCX_HBM_RESERVE_GB="%.2f" % (free_gb - 12.0))
+    r = subprocess.run([exe, "-i", g["prefix"], "-f", g["r1"], "-f2", g["r2"], "-alg", "ksw2", "-sam", sam, "-vcf", vcf, "-t", "4", "-two_base"], stdout=subprocess.DEVNULL,
+                       stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert "[mcx fit]" in r.stderr and "pair records back" in r.stderr and "reads instead" in r.stderr, r.stderr[-1500:]
+    nd, ex = sam_diff(g["sam"]["ksw2"], sam)
+    assert nd == 0, ex
+    assert vcf_body(vcf) == vcf_body(g["vcf"]["default"])
+    # a device with no room at all: refused in words, not in the middle of a batch
+    env = dict(os.environ, MCX_HBM_RESERVE_GB="%.2f" % (free_gb + 1.0))
+    r = subprocess.run([exe, "-i", g["prefix"], "-f", g["r1"], "-f2", g["r2"], "-sam", sam, "-vcf", vcf], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "no room for this run" in r.stderr, r.stderr[-800:]
+
+
 def test_cli_builds_its_index_from_the_reference_fasta(golden, tmp_path):
     """-r ref.fa (main.cpp:217, :344-349): the CLI builds the index for the run on the GPU, maps against it and removes it again.
     The toy set's genome is the reference's test/ref.fa: SAM and VCF must be the golden run's, and nothing may stay behind in the
@@ -644,15 +686,15 @@ def _checker_sam(prefix, f1, f2, alg, out, tmp_path):
 
 
 def test_full_size_genome_prefix_equals_reference(api, bench_genome, tmp_path, record_property):
-    """BASELINE config 3 at full size: the first MILLION pairs of a bench batch (150 bp, -alg ksw2) as ONE batch of 2 M reads through the
+    """BASELINE config 3 at full size: the first 600 k pairs of a bench batch (150 bp, -alg ksw2) as ONE batch of 1.2 M reads through the
     product's file path — everything only a large batch switches on: the straight-line pairs through k_simple, the others dealt to the
     lanes by weight, the large tier beside tier 0, mate rescue beside the build, the late pairs' pass, the batch's tail queued behind its
-    kernels — and through the CPU checker (the compiled reference at -t 1: two minutes; round 4's suite compared 60 k pairs).  Reads from
+    kernels — and through the CPU checker (the compiled reference at -t 1: a minute and a half; round 5's suite compared a million pairs in two).  Reads from
     repeats bring hundreds of seed hits, mate rescue and the large-capacity tier with them (asserted).  The insert-size trajectory of a
     prefix is the trajectory of the run, so the SAM must be identical."""
     from mapcaller_amd import synth
     g = bench_genome
-    n_pairs = 1_000_000 if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "MapCaller")) else 60_000  # (the oracle restatement is slower than the reference)
+    n_pairs = 600_000 if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "MapCaller")) else 60_000  # (the oracle restatement is slower than the reference; a million pairs — a minute more of the checker's -t 1 clock — is scripts/full_batch_parity.py's)
     reads = g["bench"].make_reads(g["codes"], g["lens"], n_pairs, 150, seed=1000, device=g["dev"]).reshape(2 * n_pairs, 150).cpu()
     f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
     synth.write_fastq(f1, reads, 0, 2); synth.write_fastq(f2, reads, 1, 2)
@@ -690,7 +732,7 @@ def test_config4_vcf_slice_at_full_size_equals_reference(api, bench_genome, tmp_
     """BASELINE config 4's per-GPU slice at full size: 200 k pairs x 150 bp of the bench workload against the 3.1 Gbp genome with the
     -vcf bookkeeping on — profile attached, several batches (the duplicate cap spans them), pair records resident — through the product's
     file path, then mcx_call_variants; against the compiled reference's own `-t 1 -sam -vcf` run on the same index files and its
-    MappingRecordArr / maps after Mapping() (mcref_tool Q: the positions with a non-zero counter).  SAM, the ten planes at every non-zero
+    MappingRecordArr / maps after Mapping() (mcref_tool R: its main() once, the positions with a non-zero counter dumped before VariantCalling()).  SAM, the ten planes at every non-zero
     position (positions above 2^31 among them: asserted), the insert / delete / break-point maps and site lists, and the VCF body must
     be identical.  (main.cpp:372 new MappingRecord_t[GenomeSize], AlignmentProfile.cpp:41-271, VariantCalling.cpp:696-740.)"""
     import torch
@@ -705,13 +747,11 @@ def test_config4_vcf_slice_at_full_size_equals_reference(api, bench_genome, tmp_
     reads = g["bench"].make_reads(g["codes"], g["lens"], n_pairs, 150, seed=10, device=g["dev"]).reshape(2 * n_pairs, 150).cpu()
     f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
     synth.write_fastq(f1, reads, 0, 2); synth.write_fastq(f2, reads, 1, 2)
-    # the reference first, so that its two processes (49.6 GB of records each) are gone before the GPU side allocates
-    ref_sam, ref_vcf = str(tmp_path / "ref.sam"), str(tmp_path / "ref.vcf")
-    subprocess.run([ref_bin, "-i", g["prefix"], "-f", f1, "-f2", f2, "-alg", "ksw2", "-sam", ref_sam, "-vcf", ref_vcf, "-t", "1", "-log", str(tmp_path / "job.log")],
-                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=2000)
-    dump = str(tmp_path / "ref")
-    r = subprocess.run([ref_tool], input=f"L {g['prefix']}\nQ ksw2 {dump} {f1} {f2}\n", text=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=2000)
-    assert r.stdout.split("\n")[1].strip() == "ok", r.stdout[-300:]
+    # the reference first, so that its process (49.6 GB of records) is gone before the GPU side allocates: ONE run of its own main() at -t 1 with -sam and -vcf,
+    # the profile and maps dumped between Mapping() and VariantCalling() (mcref_tool R: tests/test_oracle_golden.py holds it to the plain binary and to Q)
+    ref_sam, ref_vcf, dump = str(tmp_path / "ref.sam"), str(tmp_path / "ref.vcf"), str(tmp_path / "ref")
+    r = subprocess.run([ref_tool], input=f"R ksw2 {dump} {g['prefix']} {ref_sam} {ref_vcf} {f1} {f2}\n", text=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=2000)
+    assert r.stdout.strip().split("\n")[-1].strip() == "ok", r.stdout[-300:]
     want = np.fromfile(dump + ".prof.nz", dtype=np.dtype([("pos", "<i8"), ("v", "<u2", (10,))]))
     # the product: one context, batches of 128 K reads
     mp = api.Mapper(ix, alg="ksw2", max_batch_reads=1 << 17)
@@ -890,45 +930,45 @@ def test_config5_indel_heavy_long_pairs_equal_reference(api, bench_genome, tmp_p
 
 
 def test_fuzz_rounds_equal_oracle():
-    """scripts/fuzz_parity.py inside the suite, bounded: 60 rounds with fixed seeds — random genomes (contigs, repeats, tandem and N runs),
+    """scripts/fuzz_parity.py inside the suite, bounded: 30 rounds with fixed seeds (the long runs are scripts/fuzz_r6.sh's; a round that differs leaves its files in gpurun_out/fuzz_fail) — random genomes (contigs, repeats, tandem and N runs),
     donors, read lengths 36-300, single / paired, FASTQ / FASTA, error rates up to 5 % substitutions and 1 % indels, both algorithms, the
     variant-calling switches — the CLI's SAM and VCF against the oracle's, line by line."""
-    cmd = [sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "--rounds", "60", "--seed", "2027"]
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "--rounds", "30", "--seed", "2027"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1400)
     assert r.returncode == 0, r.stdout[-3000:]
-    assert "60 of 60 rounds identical" in r.stdout
+    assert "30 of 30 rounds identical" in r.stdout
 
 
 def test_fuzz_rounds_on_three_shards_equal_oracle():
-    """The same generator with the reads dealt to three shards (mapcaller-mi355x -devices 0,0,0, batches of 400 reads): 25 rounds — the
+    """The same generator with the reads dealt to three shards (mapcaller-mi355x -devices 0,0,0, batches of 400 reads): 20 rounds — the
     oracle is a single stream, so every round checks the shards' exchange (insert-size trajectory, duplicate cap, discordant-pair events)."""
-    cmd = [sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "--rounds", "25", "--seed", "909", "--cli-args", "-devices 0,0,0 -batch 400"]
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "--rounds", "20", "--seed", "909", "--cli-args", "-devices 0,0,0 -batch 400"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1400)
     assert r.returncode == 0, r.stdout[-3000:]
-    assert "25 of 25 rounds identical" in r.stdout
+    assert "20 of 20 rounds identical" in r.stdout
 
 
 def test_fuzz_rounds_on_the_large_batch_paths_equal_oracle(monkeypatch):
     """The generator once more, mapping alone (`-no_vcf`: no alignment profile is kept, so the straight-line path is open to the pairs; the
     index with its pair records) with what only a large batch switches on forced onto the small ones — k_simple with its DP problems
-    collected, solved and replayed, the order lists, every DP list on the lane kernels: 50 rounds, the SAM against the oracle's."""
+    collected, solved and replayed, the order lists, every DP list on the lane kernels (two problems per lane): 25 rounds, the SAM against the oracle's."""
     monkeypatch.setenv("MCX_ORDER_MIN", "1")
     monkeypatch.setenv("MCX_DP_LANE_ALWAYS", "1")
-    cmd = [sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "--rounds", "50", "--seed", "5150", "--no-vcf"]
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "--rounds", "25", "--seed", "5150", "--no-vcf"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1400)
     assert r.returncode == 0, r.stdout[-3000:]
-    assert "50 of 50 rounds identical" in r.stdout
+    assert "25 of 25 rounds identical" in r.stdout
 
 
 def test_fuzz_rounds_on_the_large_batch_paths_with_the_profile_equal_oracle(monkeypatch):
     """The same with -vcf: the alignment profile is kept, the straight-line pairs' detail records come from k_simple (mcx_simple.h
-    SimpleDetail) and the others' from the finish stage: 40 rounds, SAM and VCF against the oracle's."""
+    SimpleDetail) and the others' from the finish stage: 12 rounds, SAM and VCF against the oracle's."""
     monkeypatch.setenv("MCX_ORDER_MIN", "1")
     monkeypatch.setenv("MCX_DP_LANE_ALWAYS", "1")
-    cmd = [sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "--rounds", "40", "--seed", "31337"]
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "--rounds", "12", "--seed", "31337"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1400)
     assert r.returncode == 0, r.stdout[-3000:]
-    assert "40 of 40 rounds identical" in r.stdout
+    assert "12 of 12 rounds identical" in r.stdout
 
 
 def test_overlong_read_is_refused(api, golden):
@@ -1267,7 +1307,10 @@ def test_bench_launches_its_ranks(tmp_path, n_ranks):
            "--repeats", "50", "--batch-pairs", str(pairs), "--cpu-pairs", "0", "--vcf-reduce", "1", "--pcie-steps", "0", "--second-genome", "0", "--other-configs", "0",
            "--file-steps", "0"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
-    assert r.returncode == 0, r.stderr[-2000:]
+    if r.returncode != 0:  # (the launcher's summary fills the tail of stderr: the failing rank's own words are further up — kept whole where the box's files come back from)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        open(os.path.join(ROOT, "gpurun_out", f"bench_ranks_{n_ranks}.stderr.txt"), "w").write(r.stderr)
+    assert r.returncode == 0, [l for l in r.stderr.splitlines() if "Error" in l or "error" in l or "Traceback" in l][:12] + [r.stderr[-1500:]]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     o = json.loads(lines[0])
@@ -1282,7 +1325,11 @@ def test_bench_launches_its_ranks(tmp_path, n_ranks):
     v = o["vcf_reduce"]
     assert "error" not in v, v
     # (two ranks: one reduce per piece, 22 bytes per position; eight: the pieces scattered, the root sends seven eighths of them)
-    assert abs(v["reduce_gb"] - 22 * 20e6 / 1e9 * (1 if n_ranks == 2 else (n_ranks - 1) / n_ranks)) < 0.02 and v["call_variants"]["records"] > 0 and v["covered_positions"] > 1_000_000 * (1 if n_ranks == 2 else 3)
+    assert abs(v["reduce_gb"] - 22 * 20e6 / 1e9 * (1 if n_ranks == 2 else (n_ranks - 1) / n_ranks)) < 0.02 and v["call_variants_records"] > 0 and v["covered_positions"] > 1_000_000 * (1 if n_ranks == 2 else 3)
+    # the line is the compact record the driver parses (round 5's 33.6 KB line came back unparsed); everything else is in the detail record it names
+    assert len(lines[0]) < 6000 and "per_kernel" not in o["roofline"]
+    detail = json.load(open(os.path.join(ROOT, o["detail"])))
+    assert detail["value"] == o["value"] and "per_kernel" in detail["roofline"] and detail["vcf_reduce"]["call_variants"]["records"] == v["call_variants_records"]
 
 
 def test_degenerate_reads_equal_oracle(api, golden, tmp_path, record_property):

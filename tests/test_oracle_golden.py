@@ -5,6 +5,8 @@ import os
 
 import pytest
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 from conftest import GOLD, SETS, VCF_CASES, VCF_RUNS, VcfOpts, maps_canon, sam_diff, vcf_alg, vcf_body
 
 
@@ -99,3 +101,28 @@ def test_oracle_input_side_cases(oracle_lib, io_golden, tmp_path):
     nd, ex = sam_diff(g["ref.ml.sam"], out)
     assert nd == 0, ex
     oracle_lib.mcxo_index_free(ix)
+
+
+def test_ref_tool_whole_run_equals_the_plain_binary(golden, tmp_path):
+    """mcref_tool's request R — the reference's own main() once, -sam and -vcf, with the accumulated profile and maps dumped between Mapping() and
+    VariantCalling() through a hook at main.cpp:380 (oracle/Makefile: -DVariantCalling=mcref_vc_hook for main_lib.o) — against the plain binary's SAM
+    and VCF and request Q's dump of the same reads: the one reference pass the full-size config-4 test compares the GPU with is the reference."""
+    import gzip
+    import subprocess
+    ref_bin, ref_tool = os.path.join(ROOT, "oracle", "_ref", "MapCaller"), os.path.join(ROOT, "oracle", "_ref", "mcref_tool")
+    if not (os.path.exists(ref_bin) and os.path.exists(ref_tool)):
+        pytest.skip("oracle/_ref is not built here")
+    g = golden["var"]
+    a_sam, a_vcf, b_sam, b_vcf = (str(tmp_path / n) for n in ("a.sam", "a.vcf", "b.sam", "b.vcf"))
+    subprocess.run([ref_bin, "-i", g["prefix"], "-f", g["r1"], "-f2", g["r2"], "-alg", "ksw2", "-sam", a_sam, "-vcf", a_vcf, "-t", "1", "-log", os.devnull],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    r = subprocess.run([ref_tool], input=f"R ksw2 {tmp_path}/r {g['prefix']} {b_sam} {b_vcf} {g['r1']} {g['r2']}\n", text=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+    assert r.stdout.strip().split("\n")[-1] == "ok", r.stdout[-300:]
+    r = subprocess.run([ref_tool], input=f"L {g['prefix']}\nQ ksw2 {tmp_path}/q {g['r1']} {g['r2']}\n", text=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+    assert r.stdout.strip().split("\n")[-1] == "ok", r.stdout[-300:]
+    assert open(a_sam, "rb").read() == open(b_sam, "rb").read()
+    body = lambda p: [l for l in open(p) if not l.startswith("##")]
+    assert body(a_vcf) == body(b_vcf) and len(body(a_vcf)) > 10
+    for ext in (".prof.nz", ".maps"):
+        assert open(f"{tmp_path}/r{ext}", "rb").read() == open(f"{tmp_path}/q{ext}", "rb").read()
+    assert os.path.getsize(f"{tmp_path}/r.prof.nz") > 100_000
