@@ -91,6 +91,7 @@ typedef struct mcx_fit {
     int32_t pad;
     int64_t max_batch_reads;      /* what the context was made for */
     int64_t hbm_free_bytes;       /* free HBM with everything allocated */
+    int64_t hbm_taken_bytes;      /* what the run's allocations took (context, pair records of tier 0, planes, bookkeeping) */
 } mcx_fit;
 int mcx_ctx_create_fit(mcx_index *, const mcx_opts *, int with_profile, int paired, int max_dup, int max_clip, mcx_ctx **out, uint32_t **planes, mcx_fit *fit);
 void mcx_ctx_free(mcx_ctx *);
@@ -222,6 +223,11 @@ uint32_t mcx_pack_row(const uint8_t *seq, uint32_t rlen, uint32_t read, uint32_t
 /* The CPUs the host side counts on when it sizes its thread pools: the affinity mask, cut by the cgroup's CPU-time share (cpu.max / cfs_quota) — not the
  * machine's hardware threads; MCX_HOST_CPUS=n overrides. */
 uint32_t mcx_host_cpus(void);
+/* The file front end's reader for ordinary .gz input by itself (replaces gzGetNextChunk's gzgets, src/GetData.cpp:101-146, for plain gzip streams): the stream is
+ * cut into stretches of stretch_bytes compressed bytes (0: 2 MB), block starts are searched for in them, `threads` stretches are inflated side by side and the
+ * 32 KB windows between them filled in afterwards (mapcaller_amd/csrc/mcx_pgz.h).  The text goes to out[0 .. cap) as far as it fits (out may be NULL); returns
+ * its whole length, -1 when the file cannot be read or is no gzip file, -2 when the stream is damaged (*n_out: the bytes delivered before that). */
+int64_t mcx_gz_inflate(const char *path, int threads, uint64_t stretch_bytes, uint8_t *out, uint64_t cap, uint64_t *n_out);
 int mcx_stream_map(mcx_ctx *, int paired, int64_t avg_state[4], mcx_aln *aln, uint32_t *cigar, mcx_stats *stats);
 int mcx_stream_collect(mcx_ctx *, uint64_t *bytes_in, uint64_t *bytes_out);
 int mcx_stream_next(mcx_ctx *, const uint8_t **d_bases, const uint32_t **d_off, uint32_t *n_reads, mcx_aln **d_aln, uint32_t **d_cigar);

@@ -58,7 +58,7 @@ def pack_reads(bases, lens=None):
 
 # every symbol include/mcx.h declares
 SYMBOLS = [
-    "mcx_last_error", "mcx_device_count", "mcx_pack_row", "mcx_host_cpus", "mcx_index_load", "mcx_index_build", "mcx_index_from_codes", "mcx_index_save", "mcx_index_free", "mcx_index_trim",
+    "mcx_last_error", "mcx_device_count", "mcx_pack_row", "mcx_host_cpus", "mcx_gz_inflate", "mcx_index_load", "mcx_index_build", "mcx_index_from_codes", "mcx_index_save", "mcx_index_free", "mcx_index_trim",
     "mcx_index_genome_size", "mcx_index_n_chr", "mcx_index_chr_name", "mcx_index_chr_len", "mcx_index_hbm_bytes",
     "mcx_opts_default", "mcx_ctx_create", "mcx_ctx_create_fit", "mcx_ctx_free", "mcx_bwt_search_batch", "mcx_extend_batch",
     "mcx_avg_init", "mcx_map_batch_dev", "mcx_map_batch", "mcx_cigar_words", "mcx_map_files", "mcx_map_files_ex", "mcx_file_opts_default",
@@ -86,7 +86,7 @@ class Opts(C.Structure):
 
 class Fit(C.Structure):  # mcx_fit
     _fields_ = [("pair_records_trimmed", C.c_int32), ("batch_halvings", C.c_int32), ("single_detail_set", C.c_int32), ("pad", C.c_int32),
-                ("max_batch_reads", C.c_int64), ("hbm_free_bytes", C.c_int64)]
+                ("max_batch_reads", C.c_int64), ("hbm_free_bytes", C.c_int64), ("hbm_taken_bytes", C.c_int64)]
 
 
 class Aln(C.Structure):

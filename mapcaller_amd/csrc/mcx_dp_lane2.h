@@ -82,6 +82,7 @@ struct LaneLayout2 {
     uint32_t off_q;    // one word per row: the two query codes of the row (0..3, 4 = N), A low / B high
     uint32_t off_edge; // two words per row: the strip's right edge (nw: R, S; ksw2: x, v), each A low / B high
     uint32_t off_dir;  // traceback words: ((strip * rows + row) * DW + problem * DW / 2 ...)
+    uint32_t off_t;    // two words per strip: the sixteen target codes the strip began with (A, B), kept for the walks' mismatch counts
     uint32_t rows;     // row pitch (the group's longest query)
     uint32_t words;    // total
 };
@@ -95,7 +96,8 @@ static inline MCX_HD LaneLayout2 lane_layout2(int rows, int strips)
     l.off_q = 0;
     l.off_edge = (uint32_t)rows;
     l.off_dir = l.off_edge + 2u * (uint32_t)rows;
-    l.words = l.off_dir + (uint32_t)strips * (uint32_t)rows * (uint32_t)LaneDir2<NW>::words;
+    l.off_t = l.off_dir + (uint32_t)strips * (uint32_t)rows * (uint32_t)LaneDir2<NW>::words;
+    l.words = l.off_t + 2u * (uint32_t)strips;
     return l;
 }
 
@@ -146,10 +148,14 @@ static inline MCX_HD void lane_sweep_nw2(const LaneMem &mem, const LaneLayout2 &
     const uint32_t NEG = pk::dup(kNeg2);
     const uint32_t ONE = pk::opaque(pk::dup(1)), TWO = pk::opaque(pk::dup(2)), M4 = pk::opaque(pk::dup(-4));
     uint32_t fin = 0; // s~[m][n] of either half, caught where its row and column pass
+    uint32_t ta_nx = tgt_a(0), tb_nx = tgt_b(0);
     for (int s = 0; s < strips; s++) {
         const int b0 = s * K;
+        const uint32_t ta = ta_nx, tb = tb_nx;
+        if (s + 1 < strips) { ta_nx = tgt_a(b0 + K); tb_nx = tgt_b(b0 + K); } // (the next strip's target codes — a fetch from the genome — under this strip's rows)
+        mem.put(l.off_t + 2u * (uint32_t)s, ta); mem.put(l.off_t + 2u * (uint32_t)s + 1u, tb); // (for the walks)
         uint32_t TG[K];
-        lane_targets2<K>(tgt_a(b0), tgt_b(b0), TG);
+        lane_targets2<K>(ta, tb, TG);
         uint32_t S[K], T[K];
         MCX_UNROLL
         for (int k = 0; k < K; k++) { S[k] = pk::dup(-2 - 2 * (b0 + k + 1)); T[k] = NEG; } // row 0: s~[0][j] = -2 - 2j, t[0][j] = "none"
@@ -201,15 +207,16 @@ static inline MCX_HD void lane_sweep_nw2(const LaneMem &mem, const LaneLayout2 &
 // together when the walk leaves the window (it moves up a row or stays: one wait per four rows instead of one — or, with the query code, two — per
 // column; the walk is a chain of dependent fetches with nothing between them).  Held in named registers and picked by comparison: an array indexed
 // by a run-time row would live in scratch memory.
-template <bool NW>
+template <int K, bool NW>
 struct LaneWindow2 {
     const LaneMem &mem; const LaneLayout2 &l; int h;
     int strip = -1, top = -1;
-    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0, tw = 0;
     MCX_HD LaneWindow2(const LaneMem &m, const LaneLayout2 &lay, int half) : mem(m), l(lay), h(half) {}
     MCX_HD void at(int s, int row)
     {
         if (s == strip && row <= top && row > top - 4) return;
+        if (s != strip) tw = mem.get(l.off_t + 2u * (uint32_t)s + (uint32_t)h); // the strip's target codes as the sweep fetched them
         strip = s; top = row;
         constexpr uint32_t W = LaneDir2<NW>::words, P = LaneDir2<NW>::per_problem;
         const uint32_t base = l.off_dir + (uint32_t)(s * (int)l.rows) * W + (uint32_t)h * P;
@@ -221,43 +228,95 @@ struct LaneWindow2 {
     MCX_HD uint32_t pick(int row, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) const { const int d = top - row; return d == 0 ? x0 : (d == 1 ? x1 : (d == 2 ? x2 : x3)); }
     MCX_HD uint32_t w0(int row) const { return pick(row, a0, a1, a2, a3); }
     MCX_HD uint32_t w1(int row) const { return pick(row, b0, b1, b2, b3); }
-    MCX_HD uint32_t qcode(int row) const { return (pick(row, q0, q1, q2, q3) >> (16 * h)) & 7u; }
+    // "the query base of this row differs from target base tj" (tj in the window's strip): a query N (code 4) differs from every genome base
+    MCX_HD int differ(int row, int tj) const { return ((pick(row, q0, q1, q2, q3) >> (16 * h)) & 7u) != ((tw >> (30 - 2 * (tj - strip * K))) & 3u) ? 1 : 0; }
 };
 
-// "the query base of this row differs from target base tj" of a walk's problem, for the mismatch counts
-template <class Tgt16>
-struct LaneBases2 {
-    Tgt16 tgt16;
-    int ct = -1;
-    uint32_t tw = 0;
-    MCX_HD LaneBases2(Tgt16 t) : tgt16(t) {}
-    MCX_HD int differ(uint32_t qb, int tj)
+// the column string of a walk, back to front, four columns to a store (a walk is a chain of dependent fetches, and on this chip a fetch waits for the
+// stores issued before it as well: a byte per store and column was one more thing every fetch of the chain queued behind)
+struct OpsSink2 {
+    uint8_t *ops; int w; uint32_t word; DpSumAcc acc; bool bases;
+    MCX_HD void begin(uint8_t *area, int len, DpSummary *sum) { ops = area; w = len; word = 0; acc.begin(sum); bases = sum != nullptr; }
+    MCX_HD bool wants_bases() const { return bases; }
+    MCX_HD void col(int kind, int differ)
     {
-        if ((tj >> 4) != ct) { ct = tj >> 4; tw = tgt16(ct * 16); }
-        return qb != ((tw >> (30 - 2 * (tj & 15))) & 3u) ? 1 : 0;
+        --w;
+        word |= (uint32_t)(kind == 0 ? 'M' : (kind == 1 ? 'I' : 'D')) << (8 * (w & 3));
+        if ((w & 3) == 0) { *(uint32_t *)(ops + w) = word; word = 0; } // (the area starts on an 8-byte boundary of the pair's pool and is rounded up to one: stage_build)
+        acc.put(kind, differ);
+    }
+    MCX_HD void end(uint32_t ops_base, int len)
+    {
+        for (int k = w; k & 3; k++) ops[k] = (uint8_t)(word >> (8 * (k & 3))); // the string's first columns, short of a word
+        acc.end(ops_base + (uint32_t)w, len - w);
     }
 };
 
-// nw_alignment's traceback (nw_alignment.cpp:59-74) of problem h by the lane that swept it
-template <int K, class Tgt16, class Sink>
-static inline MCX_HD void lane_walk_nw2(const LaneMem &mem, const LaneLayout2 &l, int h, int m, int n, Tgt16 tgt16, Sink &sink)
-{
-    int i = m, j = n; // 1-based matrix indices
-    LaneBases2<Tgt16> bases(tgt16);
-    LaneWindow2<true> win(mem, l, h);
-    while (i > 0 || j > 0) {
-        unsigned d;
-        if (i == 0) d = 1;
-        else if (j == 0) d = 2;
-        else {
-            const int a = i - 1, b = j - 1, sh = K - 1 - (b % K);
-            win.at(b / K, a);
-            const uint32_t w = win.w0(a);
-            d = (((w >> sh) & 1u) ^ 1u) | ((((w >> (16 + sh)) & 1u) ^ 1u) << 1);
+// One problem's walk as a state machine, so that a lane's two walks advance together — the words either needs next are fetched before either is used:
+// two chains of dependent fetches in flight instead of one after the other.
+// nw: nw_alignment's traceback (nw_alignment.cpp:59-74); ksw2: ksw_backtrack (ksw2_alignment.cpp:25-68), full band; i: target index, j: query index.
+template <int K, bool NW>
+struct LaneWalk2 {
+    LaneWindow2<K, NW> win;
+    OpsSink2 sink;
+    int i, j, state;
+    bool live;
+    MCX_HD LaneWalk2(const LaneMem &m, const LaneLayout2 &lay, int half) : win(m, lay, half), i(0), j(0), state(0), live(false) {}
+    MCX_HD void begin(int qlen, int tlen, uint8_t *area, DpSummary *sum)
+    {
+        sink.begin(area, qlen + tlen, sum);
+        if (NW) { i = qlen; j = tlen; live = i > 0 || j > 0; } // 1-based matrix indices
+        else { i = tlen - 1; j = qlen - 1; live = true; state = 0; }
+    }
+    // the cell the next step reads (if any): its window in place — fetched now when it is not
+    MCX_HD void look()
+    {
+        if (!live) return;
+        if (NW) { if (i > 0 && j > 0) win.at((j - 1) / K, i - 1); }
+        else if (i >= 0 && j >= 0) win.at(i / K, j);
+    }
+    MCX_HD void step()
+    {
+        if (!live) return;
+        if (NW) {
+            unsigned d;
+            if (i == 0) d = 1;        // s[0][j] == r[0][j]
+            else if (j == 0) d = 2;   // s[i][0] == t[i][0]
+            else {
+                const int a = i - 1, b = j - 1, sh = K - 1 - (b % K);
+                const uint32_t w = win.w0(a);
+                d = (((w >> sh) & 1u) ^ 1u) | ((((w >> (16 + sh)) & 1u) ^ 1u) << 1);
+            }
+            if (d & 1) { sink.col(2, 0); j--; }
+            else if (d & 2) { sink.col(1, 0); i--; }
+            else { sink.col(0, sink.wants_bases() ? win.differ(i - 1, j - 1) : 0); i--; j--; }
+            live = i > 0 || j > 0;
+        } else {
+            if (i >= 0 && j >= 0) {
+                const int sh = K - 1 - (i % K);
+                const uint32_t w0 = win.w0(j), w1 = win.w1(j);
+                const unsigned st = ((w0 >> (16 + sh)) & 1u) ? 2u : ((w0 >> sh) & 1u);
+                const unsigned d = st | (((w1 >> sh) & 1u) << 3) | (((w1 >> (16 + sh)) & 1u) << 4); // the reference's byte: state in bits 0-2, extension bits 3 and 4
+                if (state == 0) state = d & 7;
+                else if (!((d >> (state + 2)) & 1)) state = 0;
+                if (state == 0) state = d & 7;
+                if (state == 0) { sink.col(0, sink.wants_bases() ? win.differ(j, i) : 0); --i; --j; }
+                else if (state == 1 || state == 3) { sink.col(2, 0); --i; }
+                else { sink.col(1, 0); --j; }
+            } else if (i >= 0) { sink.col(2, 0); --i; }
+            else { sink.col(1, 0); --j; }
+            live = i >= 0 || j >= 0;
         }
-        if (d & 1) { sink.col(2, 0); j--; }
-        else if (d & 2) { sink.col(1, 0); i--; }
-        else { sink.col(0, sink.wants_bases() ? bases.differ(win.qcode(i - 1), j - 1) : 0); i--; j--; } // (d == 0 only where the window was set for this cell)
+    }
+};
+
+// both walks of a lane (have_b false: one)
+template <int K, bool NW>
+static inline MCX_HD void lane_walk2(LaneWalk2<K, NW> &wa, LaneWalk2<K, NW> &wb)
+{
+    while (wa.live || wb.live) {
+        wa.look(); wb.look();
+        wa.step(); wb.step();
     }
 }
 
@@ -273,10 +332,14 @@ static inline MCX_HD void lane_sweep_ksw2_2(const LaneMem &mem, const LaneLayout
     const uint32_t ONE = pk::opaque(pk::dup(1)), TWO = pk::opaque(pk::dup(2)), SEVEN = pk::opaque(pk::dup(7));
     const int qlen = qlen_a > qlen_b ? qlen_a : qlen_b, tlen = tlen_a > tlen_b ? tlen_a : tlen_b;
     const int strips = (tlen + K - 1) / K;
+    uint32_t ta_nx = tgt_a(0), tb_nx = tgt_b(0);
     for (int s = 0; s < strips; s++) {
         const int b0 = s * K;
+        const uint32_t ta = ta_nx, tb = tb_nx;
+        if (s + 1 < strips) { ta_nx = tgt_a(b0 + K); tb_nx = tgt_b(b0 + K); }
+        mem.put(l.off_t + 2u * (uint32_t)s, ta); mem.put(l.off_t + 2u * (uint32_t)s + 1u, tb);
         uint32_t TG[K];
-        lane_targets2<K>(tgt_a(b0), tgt_b(b0), TG);
+        lane_targets2<K>(ta, tb, TG);
         uint32_t U[K], Y[K];
         MCX_UNROLL
         for (int k = 0; k < K; k++) { U[k] = pk::dup((b0 + k) ? Q : 0); Y[k] = 0; } // the first matrix row (ksw2_alignment.cpp:165)
@@ -325,30 +388,6 @@ static inline MCX_HD void lane_sweep_ksw2_2(const LaneMem &mem, const LaneLayout
     }
 }
 
-// ksw_backtrack (ksw2_alignment.cpp:25-68) of problem h, full band; i: target index, j: query index
-template <int K, class Tgt16, class Sink>
-static inline MCX_HD void lane_walk_ksw2_2(const LaneMem &mem, const LaneLayout2 &l, int h, int qlen, int tlen, Tgt16 tgt16, Sink &sink)
-{
-    int i = tlen - 1, j = qlen - 1, state = 0;
-    LaneBases2<Tgt16> bases(tgt16);
-    LaneWindow2<false> win(mem, l, h);
-    while (i >= 0 && j >= 0) {
-        const int sh = K - 1 - (i % K);
-        win.at(i / K, j);
-        const uint32_t w0 = win.w0(j), w1 = win.w1(j);
-        const unsigned st = ((w0 >> (16 + sh)) & 1u) ? 2u : ((w0 >> sh) & 1u);
-        const unsigned d = st | (((w1 >> sh) & 1u) << 3) | (((w1 >> (16 + sh)) & 1u) << 4); // the reference's byte: state in bits 0-2, extension bits 3 and 4
-        if (state == 0) state = d & 7;
-        else if (!((d >> (state + 2)) & 1)) state = 0;
-        if (state == 0) state = d & 7;
-        if (state == 0) { sink.col(0, sink.wants_bases() ? bases.differ(win.qcode(j), i) : 0); --i; --j; }
-        else if (state == 1 || state == 3) { sink.col(2, 0); --i; }
-        else { sink.col(1, 0); --j; }
-    }
-    for (; i >= 0; --i) sink.col(2, 0);
-    for (; j >= 0; --j) sink.col(1, 0);
-}
-
 // Two DP problems of the batch pipeline, start to finish, by their lane (what lane_dp_job does for one).  have_b false: the lane holds one
 // problem (the list's last, odd one).  scores[2]: nw's s[m][n] doubled (ksw2: 0, as before).
 template <int K, bool NW>
@@ -356,12 +395,8 @@ static inline MCX_HD void lane_dp_job2(const Ctx &cx, const LaneMem &mem, const 
                                        const ReadRef &rd_b, int scores[2])
 {
     const IndexView &ix = cx.ix;
-    const DpJob *jobs[2] = {&job_a, &job_b};
-    const ReadRef *rds[2] = {&rd_a, &rd_b};
     const int qa = job_a.rLen, ta = job_a.gLen, qb = have_b ? job_b.rLen : 0, tb = have_b ? job_b.gLen : 0;
-    auto get16 = [&](int h, int p, uint32_t &codes, uint32_t &flags) {
-        const DpJob &job = *jobs[h];
-        const ReadRef &rd = *rds[h];
+    auto get16 = [&](const DpJob &job, const ReadRef &rd, int p, uint32_t &codes, uint32_t &flags) {
         const bool rev = job.rev != 0;
         if (rd.codes) { flags = 0; codes = lane_query16(rd.codes, job.rPos, job.rLen, rev, p); return; }
         codes = 0; flags = 0;
@@ -371,26 +406,34 @@ static inline MCX_HD void lane_dp_job2(const Ctx &cx, const LaneMem &mem, const 
             flags |= (uint32_t)(c > 3) << (15 - k);
         }
     };
-    lane_stage_query2_words(mem, l, qa, qb, [&](int p, uint32_t &c, uint32_t &f) { get16(0, p, c, f); }, [&](int p, uint32_t &c, uint32_t &f) { get16(1, p, c, f); });
+    lane_stage_query2_words(mem, l, qa, qb, [&](int p, uint32_t &c, uint32_t &f) { get16(job_a, rd_a, p, c, f); }, [&](int p, uint32_t &c, uint32_t &f) { get16(job_b, rd_b, p, c, f); });
     auto tgt_a = [&](int b0) -> uint32_t { return b0 < ta ? lane_target16(ix, job_a.gPos, ta, job_a.rev != 0, b0) : 0u; };
     auto tgt_b = [&](int b0) -> uint32_t { return b0 < tb ? lane_target16(ix, job_b.gPos, tb, job_b.rev != 0, b0) : 0u; };
     scores[0] = scores[1] = 0;
     if (NW) lane_sweep_nw2<K>(mem, l, qa, ta, qb, tb, tgt_a, tgt_b, &scores[0], &scores[1]);
     else lane_sweep_ksw2_2<K>(mem, l, qa, ta, qb, tb, tgt_a, tgt_b);
-    for (int h = 0; h < (have_b ? 2 : 1); h++) {
-        const DpJob &job = *jobs[h];
-        const int qlen = job.rLen, tlen = job.gLen;
-        PairState st = pair_state(cx.state, cx.lay, cx.caps, job.pair);
-        DpSummary *sum = cx.dp_summary ? (DpSummary *)(st.ops + job.ops_off - kDpSum) : nullptr; // (stage_build left room for it)
-        OpsSink sink; sink.ops = st.ops + job.ops_off; sink.w = qlen + tlen; sink.acc.begin(sum); sink.bases = sum != nullptr;
-        if (h == 0) { if (NW) lane_walk_nw2<K>(mem, l, 0, qlen, tlen, tgt_a, sink); else lane_walk_ksw2_2<K>(mem, l, 0, qlen, tlen, tgt_a, sink); }
-        else { if (NW) lane_walk_nw2<K>(mem, l, 1, qlen, tlen, tgt_b, sink); else lane_walk_ksw2_2<K>(mem, l, 1, qlen, tlen, tgt_b, sink); }
-        sink.acc.end((uint32_t)job.ops_off + (uint32_t)sink.w, qlen + tlen - sink.w);
-        Frag f = st.frags[job.frag]; // one fetch, one store (the fields share two words)
-        f.ops_off = job.ops_off + sink.w;
-        f.ops_len = qlen + tlen - sink.w;
-        f.meta = sum ? (uint32_t)((job.ops_off - kDpSum) >> 3) + 1u : 0u;
-        st.frags[job.frag] = f;
+    LaneWalk2<K, NW> wa(mem, l, 0), wb(mem, l, 1);
+    PairState st_a = pair_state(cx.state, cx.lay, cx.caps, job_a.pair), st_b = pair_state(cx.state, cx.lay, cx.caps, job_b.pair);
+    DpSummary *sum_a = cx.dp_summary ? (DpSummary *)(st_a.ops + job_a.ops_off - kDpSum) : nullptr; // (stage_build left room for it)
+    DpSummary *sum_b = cx.dp_summary ? (DpSummary *)(st_b.ops + job_b.ops_off - kDpSum) : nullptr;
+    wa.begin(qa, ta, st_a.ops + job_a.ops_off, sum_a);
+    if (have_b) wb.begin(qb, tb, st_b.ops + job_b.ops_off, sum_b);
+    lane_walk2(wa, wb);
+    {
+        wa.sink.end((uint32_t)job_a.ops_off, qa + ta);
+        Frag f = st_a.frags[job_a.frag]; // one fetch, one store (the fields share two words)
+        f.ops_off = job_a.ops_off + wa.sink.w;
+        f.ops_len = qa + ta - wa.sink.w;
+        f.meta = sum_a ? (uint32_t)((job_a.ops_off - kDpSum) >> 3) + 1u : 0u;
+        st_a.frags[job_a.frag] = f;
+    }
+    if (have_b) {
+        wb.sink.end((uint32_t)job_b.ops_off, qb + tb);
+        Frag f = st_b.frags[job_b.frag];
+        f.ops_off = job_b.ops_off + wb.sink.w;
+        f.ops_len = qb + tb - wb.sink.w;
+        f.meta = sum_b ? (uint32_t)((job_b.ops_off - kDpSum) >> 3) + 1u : 0u;
+        st_b.frags[job_b.frag] = f;
     }
 }
 

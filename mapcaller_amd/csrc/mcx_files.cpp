@@ -40,6 +40,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#include "mcx_pgz.h"
 #include <immintrin.h>
 
 #include "../../include/mcx.h"
@@ -340,9 +341,12 @@ public:
         for (int k = 0; k < 4; k++) { std::unique_ptr<Block> b(new Block); b->d.resize(kBlockBytes); free_.push(std::move(b)); }
         if (gz_mode_ && map_bgzf(path)) {
             // BGZF (bgzip, samtools): a gzip file made of independent members of at most 64 KB, each saying how long it is — the
-            // members of a stretch are inflated side by side by a few threads (a plain gzip stream has no such entry points and
-            // keeps zlib's one thread: 0.5 GB/s of text)
+            // members of a stretch are inflated side by side by a few threads
             feeder_ = std::thread([this] { feed_bgzf(); });
+        } else if (gz_mode_ && !getenv("MCX_GZ_SERIAL") && map_gz(path)) {
+            // an ordinary gzip stream (what real FASTQ comes as): no entry points, so block starts are searched for and the stretches between them
+            // inflated side by side against windows that are filled in afterwards (mcx_pgz.h) — zlib's one thread gives 0.5 GB/s of text per file
+            feeder_ = std::thread([this] { feed_pgz(); });
         } else {
             gz_ = gzopen(path.c_str(), "rb");
             if (!gz_) { err = "cannot open " + path; return false; }
@@ -430,6 +434,42 @@ private:
         }
         close(fd);
         return ok;
+    }
+    bool map_gz(const std::string &path)
+    {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= 18;
+        if (ok) {
+            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            ok = m != MAP_FAILED;
+            if (ok) {
+                if (pgz::gzip_header((const uint8_t *)m, (size_t)st.st_size)) { map_ = (const uint8_t *)m; map_size_ = (size_t)st.st_size; }
+                else { munmap(m, (size_t)st.st_size); ok = false; } // (not a gzip file after all: zlib's reader passes such bytes through, as the reference's does)
+            }
+        }
+        close(fd);
+        return ok;
+    }
+    void feed_pgz()
+    {
+        Pool pool((int)std::max(2u, std::min(12u, mcx_usable_cpus() * 3 / 8)));
+        pgz::Reader rd;
+        pgz::Text text;
+        bool ok = rd.open(map_, map_size_, pool.size(), (size_t)2 << 20, [&](int n, const std::function<void(int)> &f) { pool.run(n, f); });
+        while (ok && !stop_.load() && rd.next(text)) {
+            for (size_t o = 0; o < text.size() && !stop_.load();) {
+                std::unique_ptr<Block> b = free_.pop();
+                const size_t m = std::min<size_t>(text.size() - o, kBlockBytes);
+                memcpy(b->d.data(), text.data() + o, m);
+                b->n = m; o += m;
+                ready_.push(std::move(b));
+            }
+        }
+        std::unique_ptr<Block> b = free_.pop(); // the end of the input (a damaged stream ends it where it stops making sense, as gzread's error does)
+        b->n = 0;
+        ready_.push(std::move(b));
     }
     void feed_bgzf()
     {
@@ -1469,4 +1509,33 @@ extern "C" int mcx_map_files_ex(mcx_ctx *c, const char *fq1, const char *fq2, co
 extern "C" int mcx_map_files(mcx_ctx *c, const char *fq1, const char *fq2, const char *sam_path, mcx_stats *stats)
 {
     return mcx_map_files_ex(c, fq1, fq2, nullptr, sam_path, stats);
+}
+
+// The file front end's parallel inflater on a file by itself (tests, scripts/gz_rate.py): the text of `path` into out[0 .. cap) as far as it fits; returns the
+// text's whole length, -1 when the file cannot be mapped or is no gzip file, -2 when the stream is damaged (*n_out: what was delivered before that).
+extern "C" int64_t mcx_gz_inflate(const char *path, int threads, uint64_t stretch_bytes, uint8_t *out, uint64_t cap, uint64_t *n_out)
+{
+    if (n_out) *n_out = 0;
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return -1;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 18) { close(fd); return -1; }
+    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return -1;
+    int64_t total = 0;
+    {
+        Pool pool(std::max(1, threads));
+        mcx::pgz::Reader rd;
+        mcx::pgz::Text text;
+        if (!rd.open((const uint8_t *)m, (size_t)st.st_size, pool.size(), stretch_bytes ? (size_t)stretch_bytes : (size_t)2 << 20, [&](int n, const std::function<void(int)> &f) { pool.run(n, f); })) total = -1;
+        while (total >= 0 && rd.next(text)) {
+            if (out && (uint64_t)total < cap) memcpy(out + total, text.data(), (size_t)std::min<uint64_t>(text.size(), cap - (uint64_t)total));
+            total += (int64_t)text.size();
+        }
+        if (n_out) *n_out = (uint64_t)std::max<int64_t>(total, 0);
+        if (rd.failed()) total = total < 0 ? -1 : -2;
+    }
+    munmap(m, (size_t)st.st_size);
+    return total;
 }

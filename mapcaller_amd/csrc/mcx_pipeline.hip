@@ -2113,6 +2113,7 @@ struct BatchRun { // the batch between mcx_batch_begin and mcx_batch_end
     int64_t read_base = 0, mapped = 0;
     unsigned long long hs[3] = {0, 0, 0};
     std::vector<uint32_t> ok, ds; // per chunk: proper pairs; summed distance, then summed read lengths
+    const uint32_t *d_ok = nullptr, *d_ds = nullptr; // ... and where they lie on the device while sums_valid (the batch's tail keeps them in its own words, mcx_batch_sums in the per-read arrays)
     const uint64_t *d_sorted_keys = nullptr; uint64_t n_keys = 0; uint32_t n_sparse_keys = 0;
     std::chrono::steady_clock::time_point t0, t_begun; double ms_setup = 0; // (t_begun, ms_setup: MCX_TIMING)
     mcx_stats *stats = nullptr;
@@ -3086,6 +3087,7 @@ static int queue_batch_tail(mcx_ctx *c)
     HIP_TRY(hipMemcpyAsync(h + 18 + nc, d_ds, 2 * (size_t)nc * 4, hipMemcpyDeviceToHost, s)); // (distance sums, then length sums)
     if (br.paired) HIP_TRY(hipMemcpyAsync(h + 18 + 3 * nc, d_est, (size_t)nc * 4, hipMemcpyDeviceToHost, s));
     t.queued = t.ran = true;
+    br.d_ok = d_ok; br.d_ds = d_ds;
     return 0;
 }
 
@@ -3264,7 +3266,7 @@ extern "C" int mcx_batch_begin(mcx_ctx *c, const uint8_t *d_bases, const uint32_
     br.cig_cap = (uint32_t)std::min<uint64_t>((uint64_t)MCX_CIGAR_POOL_WORDS(n_reads), 0xFFFFFFFFu); br.cig_words = 0;
     br.n_pairs = paired ? n_reads / 2 : n_reads;
     br.n_chunks = (br.n_pairs + kReadChunkSize / 2 - 1) / (kReadChunkSize / 2);
-    br.mapped = 0; br.sums_valid = false;
+    br.mapped = 0; br.sums_valid = false; br.d_ok = br.d_ds = nullptr;
     c->tail.queued = c->tail.ran = false;
     HIP_TRY(hipMemsetAsync(c->d_batch_flags, 0, 4 * sizeof(uint32_t), s));
     c->last_paired = paired ? 1 : 0;
@@ -3349,7 +3351,7 @@ extern "C" int mcx_batch_sums(mcx_ctx *c, uint32_t *n_chunks, const uint32_t **p
     HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_cnt, CNT_N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     br.mapped = c->h_cnt[CNT_LF];
-    br.sums_valid = true;
+    br.sums_valid = true; br.d_ok = d_ok; br.d_ds = d_ds;
     if (n_chunks) *n_chunks = nc;
     if (pairs) *pairs = br.ok.data();
     if (dist) *dist = br.ds.data();
@@ -3421,12 +3423,12 @@ extern "C" int mcx_batch_check(mcx_ctx *c, const int64_t state_before[3], int fi
     if (!br.paired) return 0;
     HIP_TRY(hipSetDevice(c->idx->device));
     int rc;
-    if (!br.sums_valid && (rc = mcx_batch_sums(c, nullptr, nullptr, nullptr, nullptr))) return rc; // (the chunk sums lie in d_read_ext / d_read_blocks behind it)
+    if ((!br.sums_valid || !br.d_ok) && (rc = mcx_batch_sums(c, nullptr, nullptr, nullptr, nullptr))) return rc; // (the chunk sums lie at br.d_ok / br.d_ds behind it)
     if ((rc = tail_reserve(c))) return rc;
     hipStream_t s = c->stream;
     int32_t *d_est = (int32_t *)(c->tail.d + 8);
     HIP_TRY(hipMemsetAsync(c->tail.d, 0, 8 * sizeof(uint32_t), s));
-    k_avg_walk<<<1, 1024, 0, s>>>(c->d_read_ext, c->d_read_blocks, br.n_chunks, (long long)state_before[0], (long long)state_before[1], (long long)state_before[2], first_of_round ? 1 : 0, d_est);
+    k_avg_walk<<<1, 1024, 0, s>>>(br.d_ok, br.d_ds, br.n_chunks, (long long)state_before[0], (long long)state_before[1], (long long)state_before[2], first_of_round ? 1 : 0, d_est);
     k_check_est<<<2048, 256, 0, s>>>(c->d_pout, br.n_pairs, kReadChunkSize / 2, d_est, c->d_sel_ids, c->d_est, c->tail.d, c->ov_cap);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->tail.h, c->tail.d, 8 * 4, hipMemcpyDeviceToHost, s));
@@ -4050,7 +4052,7 @@ extern "C" int mcx_profile_attach(mcx_ctx *c, uint32_t *d_planes, int max_dup, i
 //   1. the index gives its pair records back (mcx_index_trim: the seeding walk takes one base per step, 24.8 GB at 3.1 Gbp);
 //   2. max_batch_reads is halved, again and again (down to 128 K reads);
 // (a second set of detail records, which lets a batch's bookkeeping run under the next batch, is only ever taken when there is room: mcx_profile_attach).
-// MCX_HBM_RESERVE_GB=n (tests): n GB of the device count as taken.
+// MCX_HBM_CAP_GB=n (tests): the run may take n GB, whatever the device has free.
 constexpr size_t kFitMargin = (size_t)4 << 30;
 extern "C" int mcx_ctx_create_fit(mcx_index *ix, const mcx_opts *opts, int with_profile, int paired, int max_dup, int max_clip, mcx_ctx **out, uint32_t **planes, mcx_fit *fit)
 {
@@ -4058,24 +4060,26 @@ extern "C" int mcx_ctx_create_fit(mcx_index *ix, const mcx_opts *opts, int with_
     mcx_opts o;
     if (opts) o = *opts; else mcx_opts_default(&o);
     mcx_fit f; memset(&f, 0, sizeof f);
-    size_t reserve = 0;
-    if (const char *e = getenv("MCX_HBM_RESERVE_GB")) reserve = (size_t)(atof(e) * (double)((size_t)1 << 30));
+    size_t cap = 0; // MCX_HBM_CAP_GB=n (tests): the run may take n GB of the device, whatever is free
+    if (const char *e = getenv("MCX_HBM_CAP_GB")) cap = (size_t)(atof(e) * (double)((size_t)1 << 30));
     HIP_TRY(hipSetDevice(ix->device));
     for (;;) {
         mcx_ctx *c = nullptr;
         uint32_t *pl = nullptr;
+        size_t free0 = 0, hbm_free = 0, hbm_all = 0;
+        (void)hipMemGetInfo(&free0, &hbm_all);
         int rc = mcx_ctx_create(ix, &o, &c);
         if (rc == 0) rc = reserve_tier0(c, paired, (uint64_t)o.max_batch_reads);
         if (rc == 0 && with_profile) {
             rc = mcx_planes_alloc(ix, &pl);
             if (rc == 0) rc = mcx_profile_attach(c, pl, max_dup, max_clip);
         }
-        size_t hbm_free = 0, hbm_all = 0;
         (void)hipMemGetInfo(&hbm_free, &hbm_all);
-        hbm_free = hbm_free > reserve ? hbm_free - reserve : 0;
+        const size_t took = free0 > hbm_free ? free0 - hbm_free : 0;
+        if (cap) hbm_free = std::min(hbm_free, cap > took ? cap - took : 0);
         const bool fits = rc == 0 && hbm_free >= kFitMargin;
         if (fits) {
-            f.max_batch_reads = o.max_batch_reads; f.hbm_free_bytes = (int64_t)hbm_free; f.single_detail_set = with_profile && !c->later.have;
+            f.max_batch_reads = o.max_batch_reads; f.hbm_free_bytes = (int64_t)hbm_free; f.hbm_taken_bytes = (int64_t)took; f.single_detail_set = with_profile && !c->later.have;
             if (fit) *fit = f;
             *out = c;
             if (planes) *planes = pl;

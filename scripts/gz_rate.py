@@ -39,14 +39,30 @@ def main():
                 f1, f2 = os.path.join(tmp, "b1.fq.gz"), os.path.join(tmp, "b2.fq.gz")
                 write_bgzf(f1, open(p1, "rb").read()); write_bgzf(f2, open(p2, "rb").read())
             if tag == "gz":
-                subprocess.run(["gzip", "-1", p1, p2], check=True)
+                subprocess.run(["gzip", "-6", p1, p2], check=True)
                 f1, f2 = p1 + ".gz", p2 + ".gz"
-            mp.reset(); mp.map_files(f1, f2, None)
-            mp.reset()
-            t = time.perf_counter()
-            st = mp.map_files(f1, f2, None)
-            dt = time.perf_counter() - t
-            out[tag] = {"reads_per_s": round(st["reads"] / dt), "seconds": round(dt, 3), "bytes": os.path.getsize(f1) + os.path.getsize(f2)}
+            for variant in (("gz", "gz_zlib_one_thread") if tag == "gz" else (tag,)):
+                if variant == "gz_zlib_one_thread":
+                    os.environ["MCX_GZ_SERIAL"] = "1"  # (the reader of rounds 1-5: zlib's gzread on a thread of its own per file)
+                try:
+                    mp.reset(); mp.map_files(f1, f2, None)
+                    mp.reset()
+                    t = time.perf_counter()
+                    st = mp.map_files(f1, f2, None)
+                    dt = time.perf_counter() - t
+                finally:
+                    os.environ.pop("MCX_GZ_SERIAL", None)
+                out[variant] = {"reads_per_s": round(st["reads"] / dt), "seconds": round(dt, 3), "bytes": os.path.getsize(f1) + os.path.getsize(f2)}
+            if tag == "gz":  # the reader by itself: text per second
+                import ctypes as C
+                L = api.lib()
+                L.mcx_gz_inflate.restype = C.c_int64
+                L.mcx_gz_inflate.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+                for th in (1, 2, 4, 6, 8, 12, 16):
+                    t = time.perf_counter()
+                    n = L.mcx_gz_inflate(f1.encode(), th, 2 << 20, None, 0, None)
+                    dt = time.perf_counter() - t
+                    out.setdefault("inflate_alone_mb_per_s", {})[str(th)] = round(n / dt / 1e6)
         mp.close()
         print(json.dumps(out))
     finally:

@@ -606,19 +606,26 @@ int hostemu_lane_dp2(int use_nw, const char *qa, int qlen_a, const char *ta, int
     if (K == 8) { if (use_nw) lane_sweep_nw2<8>(mem, l, qlen_a, tlen_a, qlen_b, tlen_b, tgt_a, tgt_b, &score[0], &score[1]); else lane_sweep_ksw2_2<8>(mem, l, qlen_a, tlen_a, qlen_b, tlen_b, tgt_a, tgt_b); }
     else { if (use_nw) lane_sweep_nw2<16>(mem, l, qlen_a, tlen_a, qlen_b, tlen_b, tgt_a, tgt_b, &score[0], &score[1]); else lane_sweep_ksw2_2<16>(mem, l, qlen_a, tlen_a, qlen_b, tlen_b, tgt_a, tgt_b); }
     char *outs[2] = {ops_a, ops_b};
-    for (int h = 0; h < 2; h++) {
-        std::vector<uint8_t> ops((size_t)ql[h] + tl[h] + 1, 0);
-        OpsSink sink; sink.ops = ops.data(); sink.w = ql[h] + tl[h]; sink.acc.begin(nullptr); sink.bases = false;
-        if (K == 8) {
-            if (use_nw) { if (h) lane_walk_nw2<8>(mem, l, 1, ql[h], tl[h], tgt_b, sink); else lane_walk_nw2<8>(mem, l, 0, ql[h], tl[h], tgt_a, sink); }
-            else { if (h) lane_walk_ksw2_2<8>(mem, l, 1, ql[h], tl[h], tgt_b, sink); else lane_walk_ksw2_2<8>(mem, l, 0, ql[h], tl[h], tgt_a, sink); }
-        } else {
-            if (use_nw) { if (h) lane_walk_nw2<16>(mem, l, 1, ql[h], tl[h], tgt_b, sink); else lane_walk_nw2<16>(mem, l, 0, ql[h], tl[h], tgt_a, sink); }
-            else { if (h) lane_walk_ksw2_2<16>(mem, l, 1, ql[h], tl[h], tgt_b, sink); else lane_walk_ksw2_2<16>(mem, l, 0, ql[h], tl[h], tgt_a, sink); }
+    std::vector<uint32_t> area[2]; // (word-aligned, rounded up: the walks store four columns at a time)
+    for (int h = 0; h < 2; h++) area[h].assign(((size_t)ql[h] + tl[h]) / 4 + 4, 0u);
+    auto walk = [&](auto &wa, auto &wb) {
+        wa.begin(ql[0], tl[0], (uint8_t *)area[0].data(), nullptr);
+        wb.begin(ql[1], tl[1], (uint8_t *)area[1].data(), nullptr);
+        lane_walk2(wa, wb);
+        wa.sink.end(0u, ql[0] + tl[0]); wb.sink.end(0u, ql[1] + tl[1]);
+        const int ws[2] = {wa.sink.w, wb.sink.w};
+        for (int h = 0; h < 2; h++) {
+            len[h] = ql[h] + tl[h] - ws[h];
+            memcpy(outs[h], (const uint8_t *)area[h].data() + ws[h], (size_t)len[h]);
+            outs[h][len[h]] = 0;
         }
-        len[h] = ql[h] + tl[h] - sink.w;
-        memcpy(outs[h], ops.data() + sink.w, (size_t)len[h]);
-        outs[h][len[h]] = 0;
+    };
+    if (K == 8) {
+        if (use_nw) { LaneWalk2<8, true> wa(mem, l, 0), wb(mem, l, 1); walk(wa, wb); }
+        else { LaneWalk2<8, false> wa(mem, l, 0), wb(mem, l, 1); walk(wa, wb); }
+    } else {
+        if (use_nw) { LaneWalk2<16, true> wa(mem, l, 0), wb(mem, l, 1); walk(wa, wb); }
+        else { LaneWalk2<16, false> wa(mem, l, 0), wb(mem, l, 1); walk(wa, wb); }
     }
     return 0;
 }
