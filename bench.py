@@ -34,11 +34,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # vector-instruction issue: 256 CUs x 4 SIMD-32, a wave64 instruction every 2 cycles at 2.4 GHz = 1.23 T wave-instructions/s = 78.6 T lane-operations/s
 VALU_PEAK_TLANEOPS = 256 * 4 * 2.4e9 / 2 * 64 / 1e12
-# vector instructions of the one-problem-per-lane sweep's inner loop per cell, as compiled for gfx950 (k_dp_lane<16, nw> 340 / 16, <16, ksw2> 540 / 16: DESIGN.md section 3)
-DP_OPS_PER_CELL = {"nw": 21.0, "ksw2": 34.0}
-# what the recurrences themselves ask per cell — compare, substitution score, two gap maxima, the cell maximum, the traceback flags ("roughly
-# a dozen" for ksw2's difference form): the distance between this and the compiled count is staging, unpacking and flag packing
-DP_OPS_PER_CELL_MINIMAL = {"nw": 10.0, "ksw2": 12.0}
+# vector instructions of the sweep's inner loop per cell, as compiled for gfx950.  Two problems per lane in 16-bit halves (k_dp_lane2, the default since round 6): a row of a strip
+# is 283 (nw) / 454 (ksw2) vector instructions for its 2 x 16 cells; one problem per lane (k_dp_lane, MCX_DP_X1=1): 340 / 16 and 540 / 16
+DP_OPS_PER_CELL = {"nw": 8.84, "ksw2": 14.19}
+DP_OPS_PER_CELL_X1 = {"nw": 21.0, "ksw2": 34.0}
+# what the packed recurrences themselves ask per cell — 17 (nw) / 26 (ksw2) v_pk_* instructions per pair of cells, mcx_dp_lane2.h —: the distance between this and the
+# compiled count is the row's fetches and stores, the flag words' packing and the loop
+DP_OPS_PER_CELL_MINIMAL = {"nw": 8.5, "ksw2": 13.0}
 # random 16-byte gathers from an 8 GiB table, four lanes per 64-byte block: what the chip's L2 / fabric sustains in
 # requests per second (tools/ubench_gather.hip, profiles/round1/ubench_gather_8GiB.txt: 47-48 G/s)
 GATHER_CEILING_G_PER_S = 47.5
@@ -53,7 +55,7 @@ PMC_SUMMARY = {
     ("human", 3100.0, 4_000_000, 250, "nw", 0.005, 0.025, 0.025, 0): "summary_cfg5.json",
     ("uniform", 4.6, 1_000_000, 100, "ksw2", 0.005, 0.001, 0.001, 1): "summary_cfg2.json",
 }
-PMC_ROUNDS = ("profiles/round5", "profiles/round4")  # the newest committed pass of a workload is the one that is read
+PMC_ROUNDS = ("profiles/round6", "profiles/round5", "profiles/round4")  # the newest committed pass of a workload is the one that is read
 # the stages the library times with HIP events on its own stream, and the kernel(s) each one is (tier 0 of a pass; the large tier's passes and the
 # replay run the same kernels on other streams, beside them).  A stage of ONE kernel gives that kernel's live launch time.
 STAGE_KERNELS = {"ms_encode": ["k_pack_reads"], "ms_seed": ["k_seed"],
@@ -71,7 +73,10 @@ def kernel_source_sha():
     import hashlib
     h = hashlib.sha256()
     src = os.path.join(ROOT, "mapcaller_amd", "csrc")
+    host_only = {"mcx_pgz.h", "mcx_cpus.h", "mcx_variants_host.h"}  # (read by no kernel: the .gz reader, the CPU count, the variant caller's host passes)
     for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h"))):
+        if os.path.basename(f) in host_only:
+            continue
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())
@@ -150,12 +155,13 @@ def dp_roofline(args, d, prof):
     steps = max(args.steps, 1)
     ms = d["ms_dp"] / steps
     cells = d["dp_cells"] / steps
-    ops = DP_OPS_PER_CELL[args.alg]
+    x1 = bool(os.environ.get("MCX_DP_X1"))
+    ops = (DP_OPS_PER_CELL_X1 if x1 else DP_OPS_PER_CELL)[args.alg]
     achieved = cells * ops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     kern = prof["kernels"] if prof else {}
     dpk = {k: v for k, v in kern.items() if k.startswith("k_dp_")}
     issued = sum(v.get("valu_insts_per_step", v.get("valu_insts", 0.0)) for v in dpk.values()) * 64 if dpk else None
-    r = {"bound": "valu", "kernel": "k_dp_lane<K, alg> (one problem per lane; five lists on three streams, k_dp_sel<16> for targets above 256 bases)",
+    r = {"bound": "valu", "kernel": ("k_dp_lane<K, alg> (one problem per lane" if x1 else "k_dp_lane2<K, alg> (two problems per lane in 16-bit halves") + "; five lists on three streams, k_dp_sel<16> for targets above 256 bases)",
          "achieved": round(achieved, 2), "peak": round(VALU_PEAK_TLANEOPS, 1), "unit": "T lane-ops/s", "frac": round(achieved / VALU_PEAK_TLANEOPS, 4),
          "traffic": None if not issued else round(issued),
          "traffic_unit": None if not issued else f"vector lane-operation slots issued per step by the DP kernels (rocprofv3 SQ_INSTS_VALU x 64, {prof['file']})",
@@ -1232,8 +1238,15 @@ def main():
                 out["other_configs"] = other_configs(args)
         emit(out, args)
     if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        # (everything is measured and printed: leaving must not fail the run.  Over gloo — test ranks sharing one GPU — a rank that is through the barrier and closes its
+        #  sockets while its neighbours are still inside it gives them "Connection closed by peer": seen once in three 8-rank runs of the suite.  A rank waits a moment
+        #  before it leaves, and a peer that has already left is no error here.)
+        try:
+            dist.barrier()
+            time.sleep(0.5 if dist.get_backend() == "gloo" else 0.0)
+            dist.destroy_process_group()
+        except RuntimeError as e:
+            print(f"bench.py: rank {rank} left behind a peer that had already gone ({str(e)[:120]})", file=sys.stderr)
 
 
 if __name__ == "__main__":

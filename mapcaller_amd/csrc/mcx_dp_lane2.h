@@ -140,7 +140,8 @@ static inline MCX_HD void lane_targets2(uint32_t ta, uint32_t tb, uint32_t (&T)[
 // Returns the two final scores s[m][n] (doubled, as lane_sweep_nw) in *score_a / *score_b.
 // ---------------------------------------------------------------------------------------------
 template <int K, class TgtA, class TgtB>
-static inline MCX_HD void lane_sweep_nw2(const LaneMem &mem, const LaneLayout2 &l, int m_a, int n_a, int m_b, int n_b, TgtA tgt_a, TgtB tgt_b, int *score_a, int *score_b)
+static inline MCX_HD void lane_sweep_nw2(const LaneMem &mem, const LaneLayout2 &l, int m_a, int n_a, int m_b, int n_b, TgtA tgt_a, TgtB tgt_b, int *score_a, int *score_b,
+                                         uint32_t ta0, uint32_t tb0) // ta0 / tb0 = tgt_a(0) / tgt_b(0): fetched by the caller together with everything else a problem starts from
 {
     static_assert(K == 8 || K == 16, "a strip is 8 or 16 columns");
     const int m = m_a > m_b ? m_a : m_b, n = n_a > n_b ? n_a : n_b;
@@ -148,7 +149,7 @@ static inline MCX_HD void lane_sweep_nw2(const LaneMem &mem, const LaneLayout2 &
     const uint32_t NEG = pk::dup(kNeg2);
     const uint32_t ONE = pk::opaque(pk::dup(1)), TWO = pk::opaque(pk::dup(2)), M4 = pk::opaque(pk::dup(-4));
     uint32_t fin = 0; // s~[m][n] of either half, caught where its row and column pass
-    uint32_t ta_nx = tgt_a(0), tb_nx = tgt_b(0);
+    uint32_t ta_nx = ta0, tb_nx = tb0;
     for (int s = 0; s < strips; s++) {
         const int b0 = s * K;
         const uint32_t ta = ta_nx, tb = tb_nx;
@@ -325,14 +326,14 @@ static inline MCX_HD void lane_walk2(LaneWalk2<K, NW> &wa, LaneWalk2<K, NW> &wb)
 // second wins), word 1 = the x / y extension bits the same way; column k at bit K-1-k.
 // ---------------------------------------------------------------------------------------------
 template <int K, class TgtA, class TgtB>
-static inline MCX_HD void lane_sweep_ksw2_2(const LaneMem &mem, const LaneLayout2 &l, int qlen_a, int tlen_a, int qlen_b, int tlen_b, TgtA tgt_a, TgtB tgt_b)
+static inline MCX_HD void lane_sweep_ksw2_2(const LaneMem &mem, const LaneLayout2 &l, int qlen_a, int tlen_a, int qlen_b, int tlen_b, TgtA tgt_a, TgtB tgt_b, uint32_t ta0, uint32_t tb0)
 {
     static_assert(K == 8 || K == 16, "a strip is 8 or 16 columns");
     const int Q = 2;
     const uint32_t ONE = pk::opaque(pk::dup(1)), TWO = pk::opaque(pk::dup(2)), SEVEN = pk::opaque(pk::dup(7));
     const int qlen = qlen_a > qlen_b ? qlen_a : qlen_b, tlen = tlen_a > tlen_b ? tlen_a : tlen_b;
     const int strips = (tlen + K - 1) / K;
-    uint32_t ta_nx = tgt_a(0), tb_nx = tgt_b(0);
+    uint32_t ta_nx = ta0, tb_nx = tb0;
     for (int s = 0; s < strips; s++) {
         const int b0 = s * K;
         const uint32_t ta = ta_nx, tb = tb_nx;
@@ -406,14 +407,18 @@ static inline MCX_HD void lane_dp_job2(const Ctx &cx, const LaneMem &mem, const 
             flags |= (uint32_t)(c > 3) << (15 - k);
         }
     };
-    lane_stage_query2_words(mem, l, qa, qb, [&](int p, uint32_t &c, uint32_t &f) { get16(job_a, rd_a, p, c, f); }, [&](int p, uint32_t &c, uint32_t &f) { get16(job_b, rd_b, p, c, f); });
     auto tgt_a = [&](int b0) -> uint32_t { return b0 < ta ? lane_target16(ix, job_a.gPos, ta, job_a.rev != 0, b0) : 0u; };
     auto tgt_b = [&](int b0) -> uint32_t { return b0 < tb ? lane_target16(ix, job_b.gPos, tb, job_b.rev != 0, b0) : 0u; };
-    scores[0] = scores[1] = 0;
-    if (NW) lane_sweep_nw2<K>(mem, l, qa, ta, qb, tb, tgt_a, tgt_b, &scores[0], &scores[1]);
-    else lane_sweep_ksw2_2<K>(mem, l, qa, ta, qb, tb, tgt_a, tgt_b);
-    LaneWalk2<K, NW> wa(mem, l, 0), wb(mem, l, 1);
+    // everything the two problems start from that lies in HBM, asked for at once, before the first store (a fetch behind a store to memory that may be the
+    // same waits for it): the first strip's target codes, the fragments the results go to — the queries' words follow in the staging loop
     PairState st_a = pair_state(cx.state, cx.lay, cx.caps, job_a.pair), st_b = pair_state(cx.state, cx.lay, cx.caps, job_b.pair);
+    const uint32_t ta0 = tgt_a(0), tb0 = tgt_b(0);
+    Frag fr_a = st_a.frags[job_a.frag], fr_b = st_b.frags[job_b.frag]; // one fetch, one store each (the fields share two words)
+    lane_stage_query2_words(mem, l, qa, qb, [&](int p, uint32_t &c, uint32_t &f) { get16(job_a, rd_a, p, c, f); }, [&](int p, uint32_t &c, uint32_t &f) { get16(job_b, rd_b, p, c, f); });
+    scores[0] = scores[1] = 0;
+    if (NW) lane_sweep_nw2<K>(mem, l, qa, ta, qb, tb, tgt_a, tgt_b, &scores[0], &scores[1], ta0, tb0);
+    else lane_sweep_ksw2_2<K>(mem, l, qa, ta, qb, tb, tgt_a, tgt_b, ta0, tb0);
+    LaneWalk2<K, NW> wa(mem, l, 0), wb(mem, l, 1);
     DpSummary *sum_a = cx.dp_summary ? (DpSummary *)(st_a.ops + job_a.ops_off - kDpSum) : nullptr; // (stage_build left room for it)
     DpSummary *sum_b = cx.dp_summary ? (DpSummary *)(st_b.ops + job_b.ops_off - kDpSum) : nullptr;
     wa.begin(qa, ta, st_a.ops + job_a.ops_off, sum_a);
@@ -421,7 +426,7 @@ static inline MCX_HD void lane_dp_job2(const Ctx &cx, const LaneMem &mem, const 
     lane_walk2(wa, wb);
     {
         wa.sink.end((uint32_t)job_a.ops_off, qa + ta);
-        Frag f = st_a.frags[job_a.frag]; // one fetch, one store (the fields share two words)
+        Frag f = fr_a;
         f.ops_off = job_a.ops_off + wa.sink.w;
         f.ops_len = qa + ta - wa.sink.w;
         f.meta = sum_a ? (uint32_t)((job_a.ops_off - kDpSum) >> 3) + 1u : 0u;
@@ -429,7 +434,7 @@ static inline MCX_HD void lane_dp_job2(const Ctx &cx, const LaneMem &mem, const 
     }
     if (have_b) {
         wb.sink.end((uint32_t)job_b.ops_off, qb + tb);
-        Frag f = st_b.frags[job_b.frag];
+        Frag f = fr_b;
         f.ops_off = job_b.ops_off + wb.sink.w;
         f.ops_len = qb + tb - wb.sink.w;
         f.meta = sum_b ? (uint32_t)((job_b.ops_off - kDpSum) >> 3) + 1u : 0u;

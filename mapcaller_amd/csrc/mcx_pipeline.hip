@@ -1434,10 +1434,11 @@ __global__ void __launch_bounds__(256, MCX_BUILD_WAVES) k_build(Ctx cx, ReadBatc
     //  rewrites those pairs' headers and candidates meanwhile)
     if (in && mode == 1 && (pair_state(cx.state, cx.lay, cx.caps, local).hdr->flags & kAwaitRescue)) in = false;
     int nj = 0;
-    uint32_t fl = 0;
+    uint32_t fl = 0, n_mask = 0; // n_mask: bit s = read s of the pair holds a byte that is not ACGT (a DP problem of it says so: DpJob::score on its way in)
     if (in) {
         ReadRef rd[2];
         make_reads(cx, rb, sel_pair(sel, local), rd);
+        n_mask = (rd[0].codes ? 0u : 1u) | ((cx.pm.paired && !rd[1].codes) ? 2u : 0u);
         nj = stage_build(cx, local, rd, &fl);
     }
     const bool over = late.ids && (fl & kOvAny) && !(fl & kDispatched);
@@ -1461,7 +1462,8 @@ __global__ void __launch_bounds__(256, MCX_BUILD_WAVES) k_build(Ctx cx, ReadBatc
 #pragma unroll
     for (int c = 0; c < kDpClasses; c++) base[c] = wave_reserve(sinks.s[c].count, per_class[c]);
     for (int k = 0; k < nj; k++) {
-        const DpJob j = pair_job(cx, local, k);
+        DpJob j = pair_job(cx, local, k);
+        j.score = (int32_t)((n_mask >> j.slot) & 1u);
         const int c = job_class(j);
         if (c < 0) continue;
         uint32_t at = 0;
@@ -1543,7 +1545,8 @@ __global__ void __launch_bounds__(64) k_build_wave(Ctx cx, ReadBatch rb, PairSel
                 if (lane == 0) {
                     const int nj = stage_build(cx, local, rd);
                     for (int k = 0; k < nj; k++) {
-                        const DpJob j = pair_job(cx, local, k);
+                        DpJob j = pair_job(cx, local, k);
+                        j.score = rd[j.slot].codes ? 0 : 1;
                         const int q = job_class(j);
                         if (q < 0) { bad++; continue; }
                         my_cells += (uint32_t)(j.rLen * j.gLen);
@@ -1623,7 +1626,7 @@ __global__ void __launch_bounds__(64) k_build_wave(Ctx cx, ReadBatch rb, PairSel
                     DpJob j;
                     j.pair = local; j.slot = (uint16_t)s; j.rev = x.gPos >= cx.ix.G ? 1 : 0;
                     j.rPos = x.rPos; j.rLen = x.rLen; j.gPos = x.gPos; j.gLen = x.gLen;
-                    j.ops_off = (int32_t)x.ops_off; j.frag = (int32_t)(off + (uint32_t)i); j.score = 0;
+                    j.ops_off = (int32_t)x.ops_off; j.frag = (int32_t)(off + (uint32_t)i); j.score = rd[s].codes ? 0 : 1;
                     const int q = job_class(j);
 #pragma unroll
                     for (int k = 0; k < kDpClasses; k++) if (q == k) { const uint32_t at = at_cls[k]++; if (at < sinks.s[k].cap) sinks.s[k].jobs[at] = j; }
@@ -1823,8 +1826,10 @@ __global__ void __launch_bounds__(64) k_dp_lane2(Ctx cx, JobSink sink, const uin
         for (int h = 0; h < 2; h++) {
             const DpJob &job = h ? job_b : job_a;
             const uint32_t read = sel_pair(sel, job.pair) * nr + job.slot;
-            rd[h].ascii = rb.bases + rb.off[read]; rd[h].rlen = (int)(rb.off[read + 1] - rb.off[read]); rd[h].flipped = (cx.pm.paired && job.slot == 1) ? 1 : 0;
-            rd[h].codes = (cx.packed && !(cx.read_ext[read] >> 31)) ? cx.packed + (uint64_t)read * cx.wpad : nullptr;
+            rd[h].flipped = (cx.pm.paired && job.slot == 1) ? 1 : 0;
+            // (the job says whether its read holds an N — k_build knew —: a read without one is its 2-bit words and nothing else, no look at its offsets or its flags)
+            if (cx.packed && job.score == 0) { rd[h].codes = cx.packed + (uint64_t)read * cx.wpad; rd[h].ascii = nullptr; rd[h].rlen = 0; }
+            else { rd[h].codes = nullptr; rd[h].ascii = rb.bases + rb.off[read]; rd[h].rlen = (int)(rb.off[read + 1] - rb.off[read]); }
         }
         int sc[2];
         lane_dp_job2<K, NW>(cx, mem, l, job_a, rd[0], have_b, job_b, rd[1], sc);

@@ -153,7 +153,7 @@ struct DpJob {        // one ksw2/nw problem
     int32_t gLen;
     int32_t ops_off;  // into the pair's ops pool; capacity rLen + gLen
     int32_t frag;     // fragment index in the pair's fragment pool
-    int32_t score;    // out: ez.score (ksw2) / final s (nw, doubled)
+    int32_t score;    // in: 1 = the read holds a byte that is not ACGT (its 2-bit words are not used: k_dp_lane2 then needs no look at the read's own words); out: ez.score (ksw2) / final s (nw, doubled)
 };
 
 struct ReadSum {      // AlnSummary_t (structure.h:135-140); scores count matched bases (at most the read length)

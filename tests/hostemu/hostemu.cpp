@@ -603,8 +603,8 @@ int hostemu_lane_dp2(int use_nw, const char *qa, int qlen_a, const char *ta, int
     auto tgt_a = [&](int b0) { return tgt(0, b0); };
     auto tgt_b = [&](int b0) { return tgt(1, b0); };
     score[0] = score[1] = 0;
-    if (K == 8) { if (use_nw) lane_sweep_nw2<8>(mem, l, qlen_a, tlen_a, qlen_b, tlen_b, tgt_a, tgt_b, &score[0], &score[1]); else lane_sweep_ksw2_2<8>(mem, l, qlen_a, tlen_a, qlen_b, tlen_b, tgt_a, tgt_b); }
-    else { if (use_nw) lane_sweep_nw2<16>(mem, l, qlen_a, tlen_a, qlen_b, tlen_b, tgt_a, tgt_b, &score[0], &score[1]); else lane_sweep_ksw2_2<16>(mem, l, qlen_a, tlen_a, qlen_b, tlen_b, tgt_a, tgt_b); }
+    if (K == 8) { if (use_nw) lane_sweep_nw2<8>(mem, l, qlen_a, tlen_a, qlen_b, tlen_b, tgt_a, tgt_b, &score[0], &score[1], tgt_a(0), tgt_b(0)); else lane_sweep_ksw2_2<8>(mem, l, qlen_a, tlen_a, qlen_b, tlen_b, tgt_a, tgt_b, tgt_a(0), tgt_b(0)); }
+    else { if (use_nw) lane_sweep_nw2<16>(mem, l, qlen_a, tlen_a, qlen_b, tlen_b, tgt_a, tgt_b, &score[0], &score[1], tgt_a(0), tgt_b(0)); else lane_sweep_ksw2_2<16>(mem, l, qlen_a, tlen_a, qlen_b, tlen_b, tgt_a, tgt_b, tgt_a(0), tgt_b(0)); }
     char *outs[2] = {ops_a, ops_b};
     std::vector<uint32_t> area[2]; // (word-aligned, rounded up: the walks store four columns at a time)
     for (int h = 0; h < 2; h++) area[h].assign(((size_t)ql[h] + tl[h]) / 4 + 4, 0u);
