@@ -365,7 +365,6 @@ public:
         }
         fill();
         fastq_ = end_ > 0 && buf_[0] == '@'; // CheckReadFormat, GetData.cpp:22-31
-        if (gz_mode_ && fastq_ && !getenv("MCX_GZ_SERIAL") && !getenv("MCX_SERIAL_PARSER")) par_.reset(new Pool((int)std::max(2u, std::min(4u, mcx_usable_cpus() / 4))));
         return true;
     }
     ~Parser()
@@ -383,10 +382,6 @@ public:
     // appends up to `want` reads (copied into v.own); false once the input is exhausted (View::last set)
     bool take(View &v, uint32_t want, int max_len)
     {
-        if (par_ && gz_mode_ && fastq_ && v.recs.size() == 0 && v.own.empty()) {
-            const int r = take_parallel(v, want, max_len);
-            if (r >= 0) return r != 0; // (-1: this stretch holds something the reference's reader treats in its own way — it goes line by line, below)
-        }
         bool more = true;
         for (uint32_t i = 0; i < want && more; i++) if (!entry(v, max_len)) { v.last = true; more = false; }
         v.base = v.own.data();
@@ -394,96 +389,6 @@ public:
     }
 
 private:
-    // `want` FASTQ records of an inflated stream, located and parsed by several threads (round 6: with the stream inflated at gigabytes a second the line splitter
-    // — one thread, a memchr and three copies per record — was the reader's wall).  A record is four lines whatever they hold (GetData.cpp:101-128), so once the
-    // buffer holds 4 x want newlines the threads count lines per stretch, find their first record by the counts and parse in place; the batch keeps ONE copy of the
-    // stretch of text (names, bases, qualities are offsets into it).  Whatever the reference's reader would treat in a way of its own — a NUL byte (gzgets' lines are
-    // C strings), a line of 1023 bytes or more (its buffer), a record that does not begin with '@', an empty or over-long read, the end of the input within the batch —
-    // sends the whole stretch the serial way (-1), which reproduces it.  Returns 1: `want` records delivered, more may follow.
-    int take_parallel(View &v, uint32_t want, int max_len)
-    {
-        if (want == 0) return -1;
-        const uint64_t need = 4ull * want;
-        // enough text: newlines are counted as the blocks arrive (what was counted stays counted: offsets relative to pos_)
-        for (;;) {
-            const char *b = buf_.data() + pos_;
-            const size_t avail = end_ - pos_;
-            while (counted_ < avail && lines_seen_ < need) {
-                const char *q = (const char *)memchr(b + counted_, '\n', avail - counted_);
-                if (!q) { counted_ = avail; break; }
-                counted_ = (size_t)(q - b) + 1; lines_seen_++;
-            }
-            if (lines_seen_ >= need) break;
-            if (eof_) { counted_ = 0; lines_seen_ = 0; return -1; } // the input ends within this batch: the serial reader knows what its tail means
-            const size_t before = pos_;
-            fill();
-            (void)before; // (fill() moves the unread text to the buffer's front: offsets relative to pos_ stand)
-        }
-        const size_t len = counted_; // the stretch: `want` records, ending behind their last newline
-        const char *text = buf_.data() + pos_;
-        counted_ = 0; lines_seen_ = 0;
-        if (memchr(text, 0, len)) return -1;
-        const int T = par_->size();
-        // lines per slice, then records per thread from the counts
-        std::vector<uint64_t> cnt((size_t)T + 1, 0);
-        par_->run(T, [&](int t) {
-            const char *p = text + len * (size_t)t / (size_t)T, *e = text + len * (size_t)(t + 1) / (size_t)T;
-            uint64_t c = 0;
-            while (p < e) { const char *q = (const char *)memchr(p, '\n', (size_t)(e - p)); if (!q) break; c++; p = q + 1; }
-            cnt[(size_t)t + 1] = c;
-        });
-        for (int t = 0; t < T; t++) cnt[(size_t)t + 1] += cnt[(size_t)t];
-        if (cnt[(size_t)T] != need) return -1;
-        if (!v.recs.resize(want)) { v.error = "out of memory for the batch's read records"; return 0; }
-        std::atomic<int> odd(0);
-        Rec *out = v.recs.data();
-        par_->run(T, [&](int t) {
-            const uint64_t r0 = (uint64_t)want * (uint64_t)t / (uint64_t)T, r1 = (uint64_t)want * (uint64_t)(t + 1) / (uint64_t)T;
-            if (r0 == r1) return;
-            // where line 4 r0 begins: behind newline number 4 r0, which lies in the slice whose running count reaches it
-            const uint64_t L = 4 * r0;
-            size_t at = 0;
-            if (L) {
-                int sl = 0;
-                while (cnt[(size_t)sl + 1] < L) sl++;
-                const char *p = text + len * (size_t)sl / (size_t)T, *e = text + len;
-                uint64_t k = L - cnt[(size_t)sl];
-                while (k) { const char *q = (const char *)memchr(p, '\n', (size_t)(e - p)); p = q + 1; k--; }
-                at = (size_t)(p - text);
-            }
-            auto line = [&](const char *&l, size_t &n) { l = text + at; const char *q = find_nl(l, text + len); n = (size_t)(q - l) + 1; at += n; };
-            for (uint64_t r = r0; r < r1; r++) {
-                const char *l; size_t n;
-                line(l, n);
-                if (n >= 1023 || (l[0] != '@' && l[0] != '>')) { odd.store(1); return; }
-                int p1, p2;
-                header_of(l, (int)n, p1, p2);
-                Rec rec; memset(&rec, 0, sizeof rec);
-                rec.name = (uint64_t)(l - text) + (uint64_t)p1; rec.name_len = p2 > p1 ? (uint32_t)(p2 - p1) : 0;
-                line(l, n);
-                if (n >= 1023) { odd.store(1); return; }
-                rec.seq = (uint64_t)(l - text); rec.rlen = (uint32_t)(n - 1); // the last byte of the line is dropped (GetData.cpp:48-53, :113)
-                const char *q; size_t ql;
-                line(q, ql);
-                if (ql >= 1023) { odd.store(1); return; }
-                line(q, ql);
-                if (ql >= 1023) { odd.store(1); return; }
-                rec.qual = (uint64_t)(q - text); rec.q_take = (uint32_t)std::min<size_t>(ql, rec.rlen);
-                if (rec.rlen == 0 || (int)rec.rlen > max_len) { odd.store(1); return; }
-                out[r] = rec;
-            }
-        });
-        if (odd.load()) { v.recs.clear(); return -1; }
-        v.own.resize(len);
-        par_->run(T, [&](int t) { const size_t a = len * (size_t)t / (size_t)T, z = len * (size_t)(t + 1) / (size_t)T; memcpy(v.own.data() + a, text + a, z - a); });
-        v.base = v.own.data();
-        pos_ += len;
-        return 1;
-    }
-    std::unique_ptr<Pool> par_;
-    size_t counted_ = 0;       // bytes behind pos_ whose newlines are counted
-    uint64_t lines_seen_ = 0;  // ... and how many those were
-
     enum : size_t { kBlockBytes = 8u << 20 };
     struct Block { std::vector<char> d; size_t n = 0; };
     gzFile gz_ = nullptr;
