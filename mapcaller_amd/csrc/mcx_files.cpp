@@ -172,7 +172,7 @@ inline void header_of(const char *l, int len, int &p1, int &p2)
     const int lim = len > 100 ? 100 : len;
     p1 = len - 1; p2 = lim - 1;
     for (int i = 1; i < len; i++) if (l[i] != '>' && l[i] != '@') { p1 = i; break; }
-    for (int i = 1; i < lim; i++) if (l[i] == ' ' || l[i] == '/' || !isprint((unsigned char)l[i])) { p2 = i; break; }
+    for (int i = 1; i < lim; i++) { const unsigned char c = (unsigned char)l[i]; if (c <= ' ' || c == '/' || c >= 0x7f) { p2 = i; break; } } // (' ', '/', or not printable: isprint in the C locale is 0x20..0x7e)
 }
 
 // 2-bit row for mcx_stream_submit_packed: sixteen bases to a word, the first on top; bytes that are not ACGT are listed
@@ -383,7 +383,11 @@ public:
     bool take(View &v, uint32_t want, int max_len)
     {
         bool more = true;
-        for (uint32_t i = 0; i < want && more; i++) if (!entry(v, max_len)) { v.last = true; more = false; }
+        if (v.own.capacity() < (size_t)want * 64) v.own.reserve((size_t)want * (size_t)(own_per_rec_ + 16)); // (what the last batch's records took: no growth by doubling, no copies)
+        const size_t own0 = v.own.size();
+        uint32_t got = 0;
+        for (uint32_t i = 0; i < want && more; i++) { if (!entry(v, max_len)) { v.last = true; more = false; } else got++; }
+        if (got) own_per_rec_ = (v.own.size() - own0) / got + 1;
         v.base = v.own.data();
         return more;
     }
@@ -392,7 +396,8 @@ private:
     enum : size_t { kBlockBytes = 8u << 20 };
     struct Block { std::vector<char> d; size_t n = 0; };
     gzFile gz_ = nullptr;
-    bool gz_mode_ = false, fastq_ = true, eof_ = false;
+    bool gz_mode_ = false, fastq_ = true, eof_ = false, has_nul_ = false;
+    size_t own_per_rec_ = 340; // bytes of names, bases and qualities a record of the last batch took
     std::vector<char> buf_;
     size_t pos_ = 0, end_ = 0;
     Queue<std::unique_ptr<Block>> ready_{4}, free_{4};
@@ -529,6 +534,7 @@ private:
         if (b->n == 0) { eof_ = true; return; }
         if (end_ + b->n > buf_.size()) buf_.resize(std::max(buf_.size() * 2, end_ + b->n));
         memcpy(buf_.data() + end_, b->d.data(), b->n);
+        if (!has_nul_ && memchr(b->d.data(), 0, b->n)) has_nul_ = true; // (gzgets' lines are C strings: a NUL cuts one short — looked for per block, not per line)
         end_ += b->n;
         free_.push(std::move(b));
     }
@@ -539,7 +545,7 @@ private:
         for (;;) {
             const size_t avail = end_ - pos_;
             const size_t lim = gz_mode_ ? std::min<size_t>(avail, 1023) : avail;
-            const char *nl = lim ? (const char *)memchr(buf_.data() + pos_, '\n', lim) : nullptr;
+            const char *nl = lim ? find_nl(buf_.data() + pos_, buf_.data() + pos_ + lim) : nullptr; // (lines of tens to hundreds of bytes: memchr's set-up costs more than the search)
             if (nl) { p = buf_.data() + pos_; len = (size_t)(nl - p) + 1; break; }
             if (gz_mode_ && avail >= 1023) { p = buf_.data() + pos_; len = 1023; break; }
             if (eof_) { if (avail == 0) return false; p = buf_.data() + pos_; len = avail; break; }
@@ -554,7 +560,7 @@ private:
         const char *p; size_t len;
         if (!line(p, len)) return false;
         if (gz_mode_) { // gzGetNextEntry :101-128 (strlen semantics: a line is a C string)
-            len = strnlen(p, len);
+            if (has_nul_) len = strnlen(p, len);
             if (len == 0 || (p[0] != '@' && p[0] != '>')) return false;
         }
         int p1, p2;
@@ -568,14 +574,14 @@ private:
         size_t rlen = 0;
         if (fastq_ || gz_mode_) {
             if (!line(p, len)) { o.resize(name_at); return false; }
-            if (gz_mode_) len = strnlen(p, len);
+            if (gz_mode_ && has_nul_) len = strnlen(p, len);
             rlen = len ? len - 1 : 0; // the last byte of the line is dropped (GetData.cpp:48-53, :113)
             o.insert(o.end(), p, p + rlen);
             if (fastq_) {
                 const char *q; size_t ql;
                 line(q, ql);
                 if (!line(q, ql)) ql = 0;
-                if (gz_mode_) ql = strnlen(q, ql);
+                if (gz_mode_ && has_nul_) ql = strnlen(q, ql);
                 const size_t take = std::min(ql, rlen);
                 rec.qual = o.size(); rec.q_take = (uint32_t)take;
                 o.insert(o.end(), q, q + take);
