@@ -114,6 +114,10 @@ def pmc_profile(args):
                     e["valu_insts_per_step"] = p["SQ_INSTS_VALU"]["total"] / s["batches_mapped_by_the_pmc_runs"]
             if get("SQ_LDS_BANK_CONFLICT") is not None and get("SQ_LDS_IDX_ACTIVE"):
                 e["lds_conflict_frac"] = round(get("SQ_LDS_BANK_CONFLICT") / get("SQ_LDS_IDX_ACTIVE"), 4)
+            if s.get("batches_mapped_by_the_pmc_runs") and "FETCH_SIZE" in p and "WRITE_SIZE" in p and "total" in p["FETCH_SIZE"] and "total" in p["WRITE_SIZE"]:
+                # every launch of the kernel in a step (FETCH_SIZE / WRITE_SIZE are KiB; their two passes map the same batches)
+                e["hbm_bytes_per_step"] = (p["FETCH_SIZE"]["total"] + p["WRITE_SIZE"]["total"]) * 1024.0 / s["batches_mapped_by_the_pmc_runs"]
+                e["hbm_written_per_step"] = p["WRITE_SIZE"]["total"] * 1024.0 / s["batches_mapped_by_the_pmc_runs"]
             tr = s.get("kernel_trace", {}).get(k)
             if tr:
                 e["trace_ms"] = round(tr["full_batch_avg_us"] / 1e3, 4)  # a full-batch launch of the kernel in the committed kernel trace
@@ -175,6 +179,23 @@ def dp_roofline(args, d, prof):
         r["per_kernel"] = {k: {kk: v[kk] for kk in ("issue_frac", "wait_frac", "lds_conflict_frac", "valu_insts") if kk in v} for k, v in dpk.items()}
         if issued:
             r["issued_frac_of_peak"] = round(issued / (ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS, 4)
+    # Two problems per lane halved the stage's instructions, and what it moves became the nearer wall: the lanes' words — traceback bits, strip edges, query codes, a
+    # few GB live at once, far more than L2 holds — go out to HBM and come back.  When the committed PMC pass has the stage's bytes and they are the larger fraction of
+    # their peak, the line's roofline is the memory one and the instruction view stays beside it.
+    hbm = sum(v.get("hbm_bytes_per_step", 0.0) for v in dpk.values()) if dpk else 0.0
+    if hbm and ms > 0:
+        gbs = hbm / (ms * 1e-3) / 1e9
+        valu = {k: r[k] for k in ("achieved", "peak", "unit", "frac", "traffic", "traffic_unit", "ops_per_cell", "ops_per_cell_minimal", "frac_at_minimal_ops", "issued_frac_of_peak") if k in r}
+        r["valu_issue"] = valu
+        if gbs / HBM_PEAK_GBS > r["frac"]:
+            algorithmic = cells * (0.25 if args.alg == "nw" else 0.5) * 2 + cells * 0.25 * 2  # traceback bits written and read once; strip edges (two 16-bit values per row and 16 columns) written and read
+            r.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": round(hbm),
+                      "traffic_unit": f"HBM bytes per step of all DP kernels (rocprofv3 FETCH_SIZE + WRITE_SIZE over every launch, {prof['file']}); "
+                                      f"{round(sum(v.get('hbm_written_per_step', 0.0) for v in dpk.values()) / 1e9, 1)} GB of them written",
+                      "algorithmic_bytes_per_launch": round(algorithmic), "algorithmic_frac": round(algorithmic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "basis": "measured HBM bytes of the stage's kernels (committed PMC pass of this command) over the stage's live time; `algorithmic`: traceback bits and strip "
+                               "edges of the problems' own cells, written and read once — the rest is cells of padding (rows and strips of a wave's longest problem, 16-column strips) and "
+                               "what does not stay in L2 between its store and its fetch"})
     return r
 
 
@@ -527,7 +548,8 @@ def other_configs(args):
                         "halved_selections": o["halved_selections"], "cpu_baseline": o.get("cpu_baseline"),
                         "simple_pairs": o.get("simple_pairs"),
                         "roofline": {k: o["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_unit", "avg_launch_ms", "gcups", "cells_per_step",
-                                                                       "ops_per_cell", "ops_per_cell_minimal", "frac_at_minimal_ops", "issued_frac_of_peak", "launch_bound", "launches_per_step", "basis")}})
+                                                                       "ops_per_cell", "ops_per_cell_minimal", "frac_at_minimal_ops", "issued_frac_of_peak", "launch_bound", "launches_per_step", "basis", "valu_issue",
+                                                                       "algorithmic_bytes_per_launch", "algorithmic_frac")}})
         except Exception as e:
             res.append({"config": name, "error": str(e)[:200]})
     return res
@@ -554,6 +576,8 @@ def compact_line(out, detail_path=None):
     line["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic")}
     line["roofline"].update(_pick(r, ("traffic_from", "traffic_stale", "avg_launch_ms", "algorithmic_bytes_per_launch", "algorithmic_frac", "gcups", "ops_per_cell", "frac_at_minimal_ops",
                                       "launches_per_step")) or {})
+    if isinstance(r.get("valu_issue"), dict):
+        line["roofline"]["valu_issue"] = _pick(r["valu_issue"], ("achieved", "peak", "unit", "frac", "ops_per_cell"))
     if isinstance(line["roofline"].get("kernel"), str):
         line["roofline"]["kernel"] = line["roofline"]["kernel"][:80]
     if r.get("launch_bound"):
@@ -596,7 +620,9 @@ def compact_line(out, detail_path=None):
             x = {"config": str(e.get("config", ""))[:90]}
             x.update(_pick(e, ("value", "unit", "ms_per_step", "error")) or {})
             if isinstance(e.get("roofline"), dict):
-                x["roofline"] = _pick(e["roofline"], ("bound", "frac", "achieved", "peak", "unit", "gcups", "frac_at_minimal_ops"))
+                x["roofline"] = _pick(e["roofline"], ("bound", "frac", "achieved", "peak", "unit", "gcups", "frac_at_minimal_ops", "algorithmic_frac"))
+                if isinstance(e["roofline"].get("valu_issue"), dict):
+                    x["roofline"]["valu_issue_frac"] = e["roofline"]["valu_issue"].get("frac")
             if isinstance(e.get("cpu_baseline"), dict):
                 x["cpu_baseline"] = _pick(e["cpu_baseline"], ("value", "cores", "kind"))
             if isinstance(e.get("stage_ms_per_step"), dict):

@@ -59,6 +59,9 @@ static __device__ __forceinline__ uint32_t max_u(uint32_t a, uint32_t b) { retur
 static __device__ __forceinline__ uint32_t min_u(uint32_t a, uint32_t b) { return MCX_BC(__builtin_elementwise_min(MCX_AS_U(a), MCX_AS_U(b))); }
 // a * b + c (the low sixteen bits of each half: the same for signed and unsigned)
 static __device__ __forceinline__ uint32_t mad(uint32_t a, uint32_t b, uint32_t c) { return MCX_BC(MCX_AS_U(a) * MCX_AS_U(b) + MCX_AS_U(c)); }
+// either half two bits up; two bits down with its sign (together: a half's low fourteen bits as a signed number)
+static __device__ __forceinline__ uint32_t shl2(uint32_t a) { return MCX_BC(MCX_AS_U(a) << (::mcx::pk::u2v)(2)); }
+static __device__ __forceinline__ uint32_t sar2(uint32_t a) { return MCX_BC(MCX_AS_S(a) >> (::mcx::pk::s2v)(2)); }
 #undef MCX_AS_S
 #undef MCX_AS_U
 #undef MCX_BC
@@ -71,6 +74,8 @@ static inline uint32_t max_i(uint32_t a, uint32_t b) { return each(a, b, [](int 
 static inline uint32_t max_u(uint32_t a, uint32_t b) { return each(a, b, [](int x, int y) { const unsigned p = (unsigned)x & 0xFFFFu, q = (unsigned)y & 0xFFFFu; return (int)(p > q ? p : q); }); }
 static inline uint32_t min_u(uint32_t a, uint32_t b) { return each(a, b, [](int x, int y) { const unsigned p = (unsigned)x & 0xFFFFu, q = (unsigned)y & 0xFFFFu; return (int)(p < q ? p : q); }); }
 static inline uint32_t mad(uint32_t a, uint32_t b, uint32_t c) { return join((uint32_t)(lo(a) * lo(b) + lo(c)), (uint32_t)(hi(a) * hi(b) + hi(c))); }
+static inline uint32_t shl2(uint32_t a) { return join((uint32_t)lo(a) << 2, (uint32_t)hi(a) << 2); }
+static inline uint32_t sar2(uint32_t a) { return join((uint32_t)(lo(a) >> 2), (uint32_t)(hi(a) >> 2)); }
 #endif
 template <int C> static inline MCX_HD uint32_t addc(uint32_t a) { return add(a, dup(C)); } // (an inline constant of the instruction)
 } // namespace pk
@@ -80,7 +85,7 @@ constexpr int kNeg2 = -16000; // "no gap state yet" in sixteen bits: below every
 // where a lane keeps the words of its two problems (the same offsets in every lane of the wave: the group's longest query and widest target)
 struct LaneLayout2 {
     uint32_t off_q;    // one word per row: the two query codes of the row (0..3, 4 = N), A low / B high
-    uint32_t off_edge; // two words per row: the strip's right edge (nw: R, S; ksw2: x, v), each A low / B high
+    uint32_t off_edge; // one word per row: the strip's right edge of both problems, A low / B high (nw: s~ in fourteen bits under min(s - r, 2); ksw2: x | (v + 8) << 8)
     uint32_t off_dir;  // traceback words: ((strip * rows + row) * DW + problem * DW / 2 ...)
     uint32_t off_t;    // two words per strip: the sixteen target codes the strip began with (A, B), kept for the walks' mismatch counts
     uint32_t rows;     // row pitch (the group's longest query)
@@ -95,7 +100,7 @@ static inline MCX_HD LaneLayout2 lane_layout2(int rows, int strips)
     l.rows = (uint32_t)rows;
     l.off_q = 0;
     l.off_edge = (uint32_t)rows;
-    l.off_dir = l.off_edge + 2u * (uint32_t)rows;
+    l.off_dir = l.off_edge + (uint32_t)rows;
     l.off_t = l.off_dir + (uint32_t)strips * (uint32_t)rows * (uint32_t)LaneDir2<NW>::words;
     l.words = l.off_t + 2u * (uint32_t)strips;
     return l;
@@ -166,16 +171,20 @@ static inline MCX_HD void lane_sweep_nw2(const LaneMem &mem, const LaneLayout2 &
         // (a row's words — its query codes, the edge the strip before left — are fetched while the row BEFORE it is computed: fetched at the row's own
         //  start they are a wait of several hundred cycles per row with nothing of the lane's own to fill it, and the kernel spent 70 % of its wave-cycles
         //  there (rocprofv3 SQ_WAIT_ANY, profiles/round6).  Row a + 1's edge words are still the strip before's when row a runs: a row stores its own at its end.)
-        uint32_t q_nx = mem.get(l.off_q), r_nx = 0, s_nx = 0;
-        if (b0 != 0) { r_nx = mem.get(l.off_edge); s_nx = mem.get(l.off_edge + 1u); }
+        // The edge a strip leaves for the next one, per row and problem, in ONE half-word: what the next column asks of (r, s) is max(r - 1, s - 3) (in s~: r~ - 2, s~ - 4),
+        // and wherever s - r >= 2 that is s - 3 whatever r is — so s~ and min(s - r, 2) carry it exactly: s~ in fourteen bits (a cell's s~ is never below -2 (i + j) - 2 —
+        // mismatches down the diagonal and one gap — and launch_dp() keeps m + n within 3000) under the two bits of the difference.  Half the edge words of the first form: the DP stage moves 100 GB a step at config 5
+        // (rocprofv3 FETCH_SIZE + WRITE_SIZE), most of it these words and the traceback bits on their way out to HBM and back.
+        uint32_t q_nx = mem.get(l.off_q), e_nx = 0;
+        if (b0 != 0) e_nx = mem.get(l.off_edge);
         for (int a = 0; a < m; a++) {
             const uint32_t q = q_nx;
             uint32_t Rl, Sl;
             if (b0 == 0) { Rl = NEG; Sl = pk::dup(-2 - 2 * (a + 1)); } // r[i][0], s~[i][0]
-            else { Rl = r_nx; Sl = s_nx; }
+            else { Sl = pk::sar2(pk::shl2(e_nx)); Rl = pk::sub(Sl, (e_nx >> 14) & 0x00030003u); }
             if (a + 1 < m) {
                 q_nx = mem.get(l.off_q + (uint32_t)(a + 1));
-                if (b0 != 0) { r_nx = mem.get(l.off_edge + 2u * (uint32_t)(a + 1)); s_nx = mem.get(l.off_edge + 2u * (uint32_t)(a + 1) + 1u); }
+                if (b0 != 0) e_nx = mem.get(l.off_edge + (uint32_t)(a + 1));
             }
             uint32_t diag = diag_next;
             diag_next = Sl; // s~[i][b0] is the next row's upper-left neighbour
@@ -195,7 +204,7 @@ static inline MCX_HD void lane_sweep_nw2(const LaneMem &mem, const LaneLayout2 &
             const uint32_t at = l.off_dir + (uint32_t)(s * (int)l.rows + a) * LaneDir2<true>::words;
             mem.put(at, (fr & 0xFFFFu) | (ft << 16));
             mem.put(at + 1u, (fr >> 16) | (ft & 0xFFFF0000u));
-            if (more) { mem.put(l.off_edge + 2u * (uint32_t)a, Rl); mem.put(l.off_edge + 2u * (uint32_t)a + 1u, Sl); }
+            if (more) mem.put(l.off_edge + (uint32_t)a, (Sl & 0x3FFF3FFFu) | (pk::min_u(pk::sub(Sl, Rl), TWO) << 14));
             if (a == m_a - 1 && ka >= 0 && ka < K) { MCX_UNROLL for (int k = 0; k < K; k++) if (k == ka) fin = (fin & 0xFFFF0000u) | (S[k] & 0xFFFFu); }
             if (a == m_b - 1 && kb >= 0 && kb < K) { MCX_UNROLL for (int k = 0; k < K; k++) if (k == kb) fin = (fin & 0xFFFFu) | (S[k] & 0xFFFF0000u); }
         }
@@ -345,8 +354,8 @@ static inline MCX_HD void lane_sweep_ksw2_2(const LaneMem &mem, const LaneLayout
         MCX_UNROLL
         for (int k = 0; k < K; k++) { U[k] = pk::dup((b0 + k) ? Q : 0); Y[k] = 0; } // the first matrix row (ksw2_alignment.cpp:165)
         const bool more = s + 1 < strips;
-        uint32_t q_nx = mem.get(l.off_q), x_nx = 0, v_nx = 0; // (the next row's words under this row's cells: lane_sweep_nw2)
-        if (b0 != 0) { x_nx = mem.get(l.off_edge); v_nx = mem.get(l.off_edge + 1u); }
+        uint32_t q_nx = mem.get(l.off_q), e_nx = 0; // (the next row's words under this row's cells: lane_sweep_nw2; the edge of both problems in one word: x | (v + 8) << 8 per half)
+        if (b0 != 0) e_nx = mem.get(l.off_edge);
         for (int a = 0; a < qlen; a++) {
             const uint32_t q = q_nx;
             // the row's substitution scores + q + 2e as 7 - 2 mm, or 6 whatever the target where the query holds an N (score 0: :150-158)
@@ -354,10 +363,10 @@ static inline MCX_HD void lane_sweep_ksw2_2(const LaneMem &mem, const LaneLayout
             const uint32_t c1 = pk::add(pk::add(is_n, is_n), pk::dup(-2)), c0 = pk::sub(pk::dup(7), is_n);
             uint32_t xl, vl;
             if (b0 == 0) { xl = 0; vl = pk::dup(a ? Q : 0); } // values entering column 0 (:163)
-            else { xl = x_nx; vl = v_nx; }
+            else { xl = e_nx & 0x00FF00FFu; vl = pk::sub((e_nx >> 8) & 0x00FF00FFu, pk::dup(8)); }
             if (a + 1 < qlen) {
                 q_nx = mem.get(l.off_q + (uint32_t)(a + 1));
-                if (b0 != 0) { x_nx = mem.get(l.off_edge + 2u * (uint32_t)(a + 1)); v_nx = mem.get(l.off_edge + 2u * (uint32_t)(a + 1) + 1u); }
+                if (b0 != 0) e_nx = mem.get(l.off_edge + (uint32_t)(a + 1));
             }
             uint32_t f1 = 0, f2 = 0, fx = 0, fy = 0;
             MCX_UNROLL
@@ -384,7 +393,7 @@ static inline MCX_HD void lane_sweep_ksw2_2(const LaneMem &mem, const LaneLayout
             mem.put(at + 1u, (fx & 0xFFFFu) | (fy << 16));
             mem.put(at + 2u, (f1 >> 16) | (f2 & 0xFFFF0000u));
             mem.put(at + 3u, (fx >> 16) | (fy & 0xFFFF0000u));
-            if (more) { mem.put(l.off_edge + 2u * (uint32_t)a, xl); mem.put(l.off_edge + 2u * (uint32_t)a + 1u, vl); }
+            if (more) mem.put(l.off_edge + (uint32_t)a, (xl & 0x00FF00FFu) | ((pk::add(vl, pk::dup(8)) & 0x00FF00FFu) << 8));
         }
     }
 }

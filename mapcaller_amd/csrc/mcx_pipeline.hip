@@ -1847,16 +1847,18 @@ static uint64_t lane_short_words(int which) // ksw2's flags take more words than
 }
 
 // ---- the problems of a long list by shape ------------------------------------------------------------------------------------
-// A wavefront of k_dp_lane runs as long as the longest query times the most strips among its 64 problems.  The two long lists
-// (targets of 17-64 and of 65-256 bases, queries of any length) are therefore dealt to the wavefronts by shape: 256 buckets of
-// (strips, query length / 16), largest first; within a bucket the problems differ by less than 16 rows.  Three small passes —
-// count per bucket, start of every bucket, place — over the list's 40-byte records; the order among equals is whatever the
-// atomics give (no result depends on it).
-constexpr int kDpBuckets = 256, kDpSortTile = 8;
+// A wavefront of k_dp_lane runs as long as the longest query times the most strips among its problems.  The two long lists
+// (targets of 17-64 and of 65-256 bases, queries of any length) are therefore dealt to the wavefronts by shape: 1024 buckets of
+// (strips, query length in 64 classes), largest first; within a bucket the problems differ by less than 4 rows for reads of up
+// to 256 bases (8 / 16 rows for longer ones).  With the 16 row classes this began with, a wavefront's rows were the class's
+// largest — 7.5 rows above its problems' mean, a sixth of the cells of config 5's 45-row problems computed for nothing.  Three
+// small passes — count per bucket, start of every bucket, place — over the list's 40-byte records; the order among equals is
+// whatever the atomics give (no result depends on it).
+constexpr int kDpBuckets = 1024, kDpRowClasses = 64, kDpSortTile = 8;
 static __device__ __forceinline__ int dp_bucket(const DpJob &j, int row_shift)
 {
-    const int strips = (j.gLen + 15) >> 4, rows = min(15, j.rLen >> row_shift);
-    return (min(16, max(strips, 1)) - 1) * 16 + rows; // (0..255; the largest shapes get the largest numbers)
+    const int strips = (j.gLen + 15) >> 4, rows = min(kDpRowClasses - 1, j.rLen >> row_shift);
+    return (min(16, max(strips, 1)) - 1) * kDpRowClasses + rows; // (0..1023; the largest shapes get the largest numbers)
 }
 
 __global__ void __launch_bounds__(256) k_dp_sort_count(JobSink sink, int row_shift, uint32_t *counts, uint32_t min_n)
@@ -1864,7 +1866,7 @@ __global__ void __launch_bounds__(256) k_dp_sort_count(JobSink sink, int row_shi
     __shared__ uint32_t h[kDpBuckets];
     const uint32_t n = min(*sink.count, sink.cap);
     if (n < min_n) return;
-    h[threadIdx.x] = 0u;
+    for (int b = threadIdx.x; b < kDpBuckets; b += 256) h[b] = 0u;
     __syncthreads();
     for (uint32_t base = blockIdx.x * (256u * kDpSortTile); base < n; base += gridDim.x * (256u * kDpSortTile))
         for (int t = 0; t < kDpSortTile; t++) {
@@ -1872,18 +1874,24 @@ __global__ void __launch_bounds__(256) k_dp_sort_count(JobSink sink, int row_shi
             if (i < n) atomicAdd(&h[dp_bucket(sink.jobs[i], row_shift)], 1u);
         }
     __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
+    for (int b = threadIdx.x; b < kDpBuckets; b += 256) if (h[b]) atomicAdd(&counts[b], h[b]);
 }
 
-// counts[0..256) -> cursor[b] = where bucket b begins when the buckets are laid out from the largest shape down
+// counts[0..1024) -> cursor[b] = where bucket b begins when the buckets are laid out from the largest shape down
 __global__ void __launch_bounds__(256) k_dp_sort_scan(const uint32_t *counts, uint32_t *cursor)
 {
-    __shared__ uint32_t c[kDpBuckets];
-    c[threadIdx.x] = counts[kDpBuckets - 1 - threadIdx.x];
+    __shared__ uint32_t c[kDpBuckets], part[256];
+    constexpr int per = kDpBuckets / 256;
+    // thread t owns the buckets kDpBuckets-1 - (per t .. per t + per-1): the largest shapes first
+    uint32_t mine[per], sum = 0;
+    for (int k = 0; k < per; k++) { mine[k] = counts[kDpBuckets - 1 - (per * (int)threadIdx.x + k)]; sum += mine[k]; }
+    part[threadIdx.x] = sum;
     __syncthreads();
-    if (threadIdx.x == 0) { uint32_t at = 0; for (int k = 0; k < kDpBuckets; k++) { const uint32_t m = c[k]; c[k] = at; at += m; } }
+    if (threadIdx.x == 0) { uint32_t at = 0; for (int k = 0; k < 256; k++) { const uint32_t m = part[k]; part[k] = at; at += m; } }
     __syncthreads();
-    cursor[kDpBuckets - 1 - threadIdx.x] = c[threadIdx.x];
+    uint32_t at = part[threadIdx.x];
+    for (int k = 0; k < per; k++) { c[per * threadIdx.x + k] = at; at += mine[k]; }
+    for (int k = 0; k < per; k++) cursor[kDpBuckets - 1 - (per * (int)threadIdx.x + k)] = c[per * threadIdx.x + k];
 }
 
 __global__ void __launch_bounds__(256) k_dp_sort_place(JobSink sink, int row_shift, uint32_t *cursor, uint32_t *order, uint32_t min_n)
@@ -1892,7 +1900,7 @@ __global__ void __launch_bounds__(256) k_dp_sort_place(JobSink sink, int row_shi
     const uint32_t n = min(*sink.count, sink.cap);
     if (n < min_n) return;
     for (uint32_t base = blockIdx.x * (256u * kDpSortTile); base < n; base += gridDim.x * (256u * kDpSortTile)) {
-        h[threadIdx.x] = 0u;
+        for (int b = threadIdx.x; b < kDpBuckets; b += 256) h[b] = 0u;
         __syncthreads();
         int b[kDpSortTile];
         uint32_t rank[kDpSortTile];
@@ -1903,7 +1911,7 @@ __global__ void __launch_bounds__(256) k_dp_sort_place(JobSink sink, int row_shi
             rank[t] = b[t] >= 0 ? atomicAdd(&h[b[t]], 1u) : 0u;
         }
         __syncthreads();
-        at[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]) : 0u;
+        for (int q = threadIdx.x; q < kDpBuckets; q += 256) at[q] = h[q] ? atomicAdd(&cursor[q], h[q]) : 0u;
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < kDpSortTile; t++) if (b[t] >= 0) order[at[b[t]] + rank[t]] = base + t * 256u + threadIdx.x;
@@ -2085,7 +2093,7 @@ enum { CNT_TASKS = 0, CNT_RESCUE = 1 * kCntPad, CNT_JOB0 = 2 * kCntPad, CNT_JOB1
        CNT_QUEUE = 12 * kCntPad, CNT_EARLY = 13 * kCntPad, CNT_LATE = 14 * kCntPad, CNT_RTASK = 15 * kCntPad, CNT_RPLAN = 16 * kCntPad, CNT_RESCUE_N = 17 * kCntPad, CNT_RSEED = 18 * kCntPad,
        CNT_SIMPLE = 19 * kCntPad, CNT_EARLY_HITS = 20 * kCntPad, CNT_SIMPLE_LATER = 21 * kCntPad, CNT_SIMPLE_JOBS = 22 * kCntPad, CNT_N = 23 * kCntPad,
        // behind the counters proper, cleared with them at the start of a pass (a memset in the middle of a pass was seen to sit 1.4 ms in its queue):
-       CNT_ORDER = CNT_N, CNT_DP_SORT = CNT_ORDER + 16 * kCntPad, CNT_ALL = CNT_DP_SORT + 4 * 256 };
+       CNT_ORDER = CNT_N, CNT_DP_SORT = CNT_ORDER + 16 * kCntPad, CNT_ALL = CNT_DP_SORT + 4 * kDpBuckets };
 constexpr uint32_t kLateRoom = 2048; // pairs of a pass that may run over after clustering and still go through the large tier beside it
 
 // What a pass over a selection of pairs works with besides the pair records: stream, counters, work lists, DP scratch.
@@ -2579,7 +2587,8 @@ static int launch_dp(const Knobs &kn, const PassRes &R, const Ctx &cx, const Job
         uint32_t *unsup = sinks.unsupported;
         const bool always = kn.dp_lane_always;
         uint32_t lane_min[2] = {always ? 0u : kDpLaneMin[0], always ? 0u : kDpLaneMin[1]};
-        // two problems per lane in 16-bit halves (k_dp_lane2) wherever the scores fit them with room to spare: queries + targets far below kNeg2's reach
+        // two problems per lane in 16-bit halves (k_dp_lane2) wherever the scores fit them with room to spare: queries + targets far below kNeg2's reach, and a cell's
+        // s~ (never below -2 (i + j) - 2: mismatches down the diagonal and one gap) within the fourteen bits a strip's edge word keeps of it
         const bool x2 = !kn.dp_x1 && rlen_max + 256 <= 3000;
         const uint64_t w1 = lane_stride_words<16>(nw, rlen_max, 4, x2), w2 = lane_stride_words<16>(nw, rlen_max, 16, x2);
         const unsigned b1 = (unsigned)std::min<uint64_t>(4096, R.dp_stride[0] * R.dp_blocks[0] / (w1 * 4)), b2 = (unsigned)std::min<uint64_t>(4096, R.dp_stride[1] * R.dp_blocks[1] / (w2 * 4));
@@ -2591,7 +2600,7 @@ static int launch_dp(const Knobs &kn, const PassRes &R, const Ctx &cx, const Job
         const uint32_t *ord[2] = {nullptr, nullptr};
         hipStream_t st[2] = {s, side1};
         if (by_shape) {
-            const int row_shift = rlen_max <= 256 ? 4 : (rlen_max <= 512 ? 5 : 6); // (16 row classes cover the longest query)
+            const int row_shift = rlen_max <= 256 ? 2 : (rlen_max <= 512 ? 3 : (rlen_max <= 1024 ? 4 : 6)); // (64 row classes cover the longest query)
             for (int k = 0; k < 2; k++) {
                 if (lane_min[k] == 0xFFFFFFFFu) continue;
                 uint32_t *counts = R.d_cnt + CNT_DP_SORT + 2 * kDpBuckets * k, *cursor = counts + kDpBuckets; // (cleared with the pass's counters)

@@ -299,6 +299,9 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
     // the lists' kernels take two problems per lane (mcx_dp_lane2.h: k_dp_lane2): neighbours of the list share a lane here too — whatever their shapes —
     // unless MCX_EMU_DP_X1 asks for the one-problem-per-lane form (k_dp_lane, the A/B)
     const bool dp_x2 = !oracle_dp && !getenv("MCX_EMU_DP_X1");
+    if (const char *dump = getenv("MCX_EMU_DUMP_JOBS")) { // (the shapes of the batch's problems, for sizing the lists' kernels: scripts/dp_shapes.py)
+        if (FILE *f = fopen(dump, "a")) { for (uint32_t j = 0; j < n_jobs; j++) fprintf(f, "%d %d\n", (int)jobs[j].rLen, (int)jobs[j].gLen); fclose(f); }
+    }
     for (uint32_t j = 0; dp_x2 && j < n_jobs; j += 2) {
         const bool have_b = j + 1 < n_jobs;
         const DpJob &ja = jobs[j], &jb = jobs[have_b ? j + 1 : j];
