@@ -2055,7 +2055,7 @@ __global__ void __launch_bounds__(256, MCX_FINISH_WAVES) k_finish(Ctx cx, ReadBa
 struct Knobs {
     bool timing = false, seed_one_base = false, dp_by_wave = false, dp_lane_always = false, dp_x1 = false, late_reseed = false, no_work_order = false, no_simple = false,
          simple_no_dp = false, cluster_by_lane = false, rescue_in_line = false, build_by_lane = false, no_sums_cache = false, prof_by_column = false,
-         tier1_hist = false, dp_hist = false, no_tier_overlap = false, no_late_overlap = false, no_prof_overlap = false, no_prepack = false;
+         tier1_hist = false, dp_hist = false, no_tier_overlap = false, no_late_overlap = false, no_prof_overlap = false, no_prepack = false, no_tier1_grow = false;
     int seed_fm_budget = 6, build_wave_limit = 0x7fffffff;
     uint32_t order_min = 16384u;
 };
@@ -2067,7 +2067,7 @@ static Knobs knobs_read()
     k.late_reseed = on("MCX_LATE_RESEED"); k.no_work_order = on("MCX_NO_WORK_ORDER"); k.no_simple = on("MCX_NO_SIMPLE"); k.simple_no_dp = on("MCX_SIMPLE_NO_DP");
     k.cluster_by_lane = on("MCX_CLUSTER_BY_LANE"); k.rescue_in_line = on("MCX_RESCUE_IN_LINE"); k.build_by_lane = on("MCX_BUILD_BY_LANE");
     k.no_sums_cache = on("MCX_NO_SUMS_CACHE"); k.prof_by_column = on("MCX_PROF_BY_COLUMN"); k.tier1_hist = on("MCX_TIER1_HIST"); k.dp_hist = on("MCX_DP_HIST");
-    k.no_tier_overlap = on("MCX_NO_TIER_OVERLAP"); k.no_late_overlap = on("MCX_NO_LATE_OVERLAP"); k.no_prof_overlap = on("MCX_NO_PROF_OVERLAP");
+    k.no_tier_overlap = on("MCX_NO_TIER_OVERLAP"); k.no_late_overlap = on("MCX_NO_LATE_OVERLAP"); k.no_prof_overlap = on("MCX_NO_PROF_OVERLAP"); k.no_tier1_grow = on("MCX_NO_TIER1_GROW");
     // A batch packed on its way in (mcx_stream_submit_packed; MCX_PREPACK=1) pays on runtimes whose copies in and out overlap: 16.2-16.3 against 16.7-16.8 ms per
     // step on ROCm 7.2's; on one that puts both directions on one SDMA engine (HIP 7.0, what torch's wheel carries) the copy in ends late and the longer chain
     // behind it reaches into the next step: 17.5 against 17.1.  Off unless asked for: one fuzz round in 480 of the CLI with it on did not come out
@@ -2085,6 +2085,7 @@ struct Tier {
     Layout lay;
     uint8_t *state = nullptr;
     uint32_t max_pairs = 0;
+    uint32_t grow_to = 0; // the large tier: how many pair records it may grow to when a batch's heavy pairs do not fit one pass (tier1_grow; 0 = fixed)
 };
 
 constexpr uint32_t kPoutSel = 1u << 16; // pair outcomes gathered per copy (run_selection)
@@ -2390,8 +2391,12 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     //  one another: BASELINE config 5 sends 4.5 % of its pairs here, five passes of 36 k pairs with 8 GB of records — with room in
     //  proportion to the batch: 3 KB per read, 2-24 GB (MCX_TIER1_GB overrides))
     uint64_t t1_bytes = std::min<uint64_t>(std::max<uint64_t>(c->max_reads * 3072, (uint64_t)2 << 30), (uint64_t)24 << 30);
+    const uint64_t t1_limit = std::min<uint64_t>(c->max_reads, 262144);
     if (const char *e = getenv("MCX_TIER1_GB")) t1_bytes = (uint64_t)std::max(1, atoi(e)) << 30;
-    c->tier[1].max_pairs = (uint32_t)std::max<uint64_t>(1024, std::min<uint64_t>(std::min<uint64_t>(c->max_reads, 131072), t1_bytes / (uint64_t)c->tier[1].lay.stride));
+    else if (const char *e2 = getenv("MCX_TIER1_START_GB")) t1_bytes = (uint64_t)std::max(1, atoi(e2)) << 30; // (tests: a small start that may grow)
+    c->tier[1].max_pairs = (uint32_t)std::max<uint64_t>(1024, std::min<uint64_t>(t1_limit, t1_bytes / (uint64_t)c->tier[1].lay.stride));
+    // (a batch whose heavy pairs do not fit these records in one pass makes them grow, HBM permitting: tier1_grow().  A size that was asked for stays)
+    c->tier[1].grow_to = getenv("MCX_TIER1_GB") || c->kn.no_tier1_grow ? 0u : (uint32_t)std::max<uint64_t>(t1_limit, c->tier[1].max_pairs);
     // (tier 0's records are allocated by the first batch: a paired batch of max_reads reads is max_reads / 2 pairs, and at 8 KB a
     //  record the other half is 33 GB at 8 M reads — only single-end batches need a record per read)
     c->tier[0].max_pairs = 0;
@@ -2459,7 +2464,7 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
         // (human-like bench genome: 40.0 -> 37.4 ms per step)
         int pr_lo = 0, pr_hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
-        if ((rc = passres_alloc(c, c->t1, c->tier[1].max_pairs, c->max_reads, pr_hi))) return rc;
+        if ((rc = passres_alloc(c, c->t1, std::max(c->tier[1].max_pairs, c->tier[1].grow_to), c->max_reads, pr_hi))) return rc; // (lists for as many pairs as the records may grow to)
         c->t1.d_kscratch = c->d_kscratch + (size_t)kRescueBlocks * kRescueScratchWords;
         HIP_TRY(hipEventCreate(&c->ev_clustered));
         c->overlap_tiers = true;
@@ -2569,6 +2574,44 @@ static PassRes res_tier0(mcx_ctx *c)
 // that way.  The list's length is known on the device only, so both kernels are launched and the one whose turn it is not leaves at
 // once: k_dp_group below kDpLaneMin problems, k_dp_lane from there on.
 constexpr uint32_t kDpLaneMin[2] = {65536, 131072}; // targets of 17-64 bases (mean 45 x 45 cells), of 65-256 (95 x 95): two wavefronts per SIMD's worth of problems
+
+// The large tier's records grow when a batch sends it more pairs than one pass holds.  Its passes follow one another, each as long as its slowest pair,
+// and only the first runs beside tier 0: BASELINE config 5 (185 k heavy pairs of 4 M, 260 KB of records each) took two passes of 99 k and 86 k with the
+// 24 GB the context starts with, the second one alone on the chip for 17 ms after tier 0 had finished — one pass of 185 k: 117.2 -> 108.5 ms a step.
+// Called between passes (nothing of the tier is under way: every earlier pass was waited for by tier1_pass_end), with the batch's tier-0 kernels queued:
+// hipFree waits for the device, once or twice in a run.  Grows only into HBM that is free beyond kGrowKeep, so that what a caller allocates later (a
+// profile's planes are attached before the first batch; a second set of detail records is not) still finds room; never shrinks.
+constexpr uint64_t kGrowKeep = (uint64_t)16 << 30;
+static int tier1_grow(mcx_ctx *c, uint64_t pairs_wanted)
+{
+    Tier &t = c->tier[1];
+    if (!t.grow_to || pairs_wanted <= t.max_pairs || t.max_pairs >= t.grow_to) return 0;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (const char *e = getenv("MCX_HBM_CAP_GB")) { // (tests: as if the device had this much)
+        const uint64_t cap = (uint64_t)std::max(1, atoi(e)) << 30, used = total_b - free_b;
+        free_b = cap > used ? cap - used : 0;
+    }
+    const uint64_t have = (uint64_t)t.lay.stride * t.max_pairs;
+    uint64_t want = std::min<uint64_t>(t.grow_to, pairs_wanted + pairs_wanted / 8 + 1024); // (an eighth more: the next batch's count differs a little)
+    const uint64_t room = free_b + have > kGrowKeep ? (free_b + have - kGrowKeep) / (uint64_t)t.lay.stride : 0;
+    want = std::min(want, room);
+    if (want < pairs_wanted || want <= t.max_pairs) return 0; // (not in one pass anyway: what is there stays)
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(t.state)); t.state = nullptr;
+    uint8_t *p = nullptr;
+    if (hipMalloc((void **)&p, (size_t)t.lay.stride * want) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipMalloc((void **)&p, (size_t)have) != hipSuccess) { (void)hipGetLastError(); t.max_pairs = 0; return fail(MCX_ERR_DEVICE, "the large tier's records: out of device memory"); }
+        t.state = p; t.grow_to = 0;
+        return 0;
+    }
+    if (c->kn.timing || getenv("MCX_ALLOC_LOG")) fprintf(stderr, "[mcx] the large tier's records grow from %u to %llu pairs (%.1f -> %.1f GB): %llu heavy pairs in this batch\n",
+                                                       t.max_pairs, (unsigned long long)want, (double)have / 1e9, (double)t.lay.stride * want / 1e9, (unsigned long long)pairs_wanted);
+    g_dmalloc_bytes += (size_t)t.lay.stride * want - have;
+    t.state = p; t.max_pairs = (uint32_t)want;
+    return 0;
+}
 
 static int launch_dp(const Knobs &kn, const PassRes &R, const Ctx &cx, const JobSinks &sinks, const ReadBatch &rb, const PairSel &sel, int rlen_max)
 {
@@ -2821,6 +2864,7 @@ static int run_pairs(mcx_ctx *c, int tier, const PassRes &R, const ReadBatch &rb
         if (n_early > el.cap) { (void)hipStreamSynchronize(s); return fail(MCX_ERR_CAPACITY, "overflow list overflow"); }
         if (stats) stats->tier1_pairs += n_early;
         const bool t1_timing = kn.timing;
+        if (n_early + (late ? kLateRoom : 0) > c->tier[1].max_pairs) { if (int r = tier1_grow(c, (uint64_t)n_early + (late ? kLateRoom : 0))) { (void)hipStreamSynchronize(s); return r; } }
         const uint32_t room = c->tier[1].max_pairs - (late ? kLateRoom : 0); // (the last records are the late list's)
         mcx_stats t1;
         uint32_t m = 0;
