@@ -2211,6 +2211,8 @@ struct mcx_ctx {
     BatchRun run;
     PassRes t1;               // the large tier's own set (the members above are tier 0's); allocated when every suffix-array entry is resident
     bool overlap_tiers = false;
+    bool dp_grown = false; // dp_scratch_grow() has had its one attempt
+    uint32_t job2_seen = 0; // the longest 65-256-column DP list of a tier-0 pass so far
     volatile uint32_t *h_early = nullptr; uint32_t *d_early = nullptr; // page-locked words k_publish_early writes behind the clustering kernel: the host's view and the device's
     PassRes t2;               // a third set: the large tier's pass over the pairs that ran over after clustering (k_build's list)
     hipEvent_t ev_built = nullptr, ev_late_done = nullptr;
@@ -2393,7 +2395,7 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     uint64_t t1_bytes = std::min<uint64_t>(std::max<uint64_t>(c->max_reads * 3072, (uint64_t)2 << 30), (uint64_t)24 << 30);
     const uint64_t t1_limit = std::min<uint64_t>(c->max_reads, 262144);
     if (const char *e = getenv("MCX_TIER1_GB")) t1_bytes = (uint64_t)std::max(1, atoi(e)) << 30;
-    else if (const char *e2 = getenv("MCX_TIER1_START_GB")) t1_bytes = (uint64_t)std::max(1, atoi(e2)) << 30; // (tests: a small start that may grow)
+    else if (const char *e2 = getenv("MCX_TIER1_START_GB")) t1_bytes = (uint64_t)(std::max(0.05, atof(e2)) * (double)(1 << 30)); // (tests: a small start that may grow)
     c->tier[1].max_pairs = (uint32_t)std::max<uint64_t>(1024, std::min<uint64_t>(t1_limit, t1_bytes / (uint64_t)c->tier[1].lay.stride));
     // (a batch whose heavy pairs do not fit these records in one pass makes them grow, HBM permitting: tier1_grow().  A size that was asked for stays)
     c->tier[1].grow_to = getenv("MCX_TIER1_GB") || c->kn.no_tier1_grow ? 0u : (uint32_t)std::max<uint64_t>(t1_limit, c->tier[1].max_pairs);
@@ -2418,7 +2420,8 @@ static int ctx_fill(mcx_ctx *c, const mcx_index *idx, const mcx_opts &o)
     // (the two grouped classes: a wavefront's stretch holds the strings and traceback bytes of a group of problems — k_dp_group —,
     //  at least those of the class's largest one)
     const uint64_t spill[3] = {(uint64_t)512 << 10, (uint64_t)1 << 20, kDpSpillSeq + (uint64_t)(2048 + 1024) * 1024};
-    const uint32_t blocks[3] = {8192, 4096, 512}; // (the 65-256-column class at 2048 or 8192 wavefronts: the same DP stage, 3.3-3.8 ms)
+    uint32_t blocks[3] = {8192, 4096, 512}; // (the 65-256-column class at 2048 or 8192 wavefronts: the same DP stage, 3.3-3.8 ms)
+    if (const char *e = getenv("MCX_DP_BLOCKS1")) blocks[1] = (uint32_t)std::max(256, atoi(e)); // (experiments; a size that was asked for stays: dp_scratch_grow)
     for (int k = 0; k < 3; k++) {
         c->dp_stride[k] = spill[k]; c->dp_blocks[k] = blocks[k];
         if ((rc = dmalloc(&c->d_dp_scratch[k], (size_t)spill[k] * blocks[k]))) return rc;
@@ -2610,6 +2613,43 @@ static int tier1_grow(mcx_ctx *c, uint64_t pairs_wanted)
                                                        t.max_pairs, (unsigned long long)want, (double)have / 1e9, (double)t.lay.stride * want / 1e9, (unsigned long long)pairs_wanted);
     g_dmalloc_bytes += (size_t)t.lay.stride * want - have;
     t.state = p; t.max_pairs = (uint32_t)want;
+    return 0;
+}
+
+// The scratch of the 65-256-column list grows when a batch fills it.  A wavefront of k_dp_lane2 keeps the traceback bits of its 128 problems in a stretch
+// sized for the list's largest shape (2.2 MB at 250 bp), and the 4 GB a context starts with hold 1920 of them — fewer than two per SIMD, and this list's
+// kernel is the DP stage's last to end at config 5 (1.3 M problems: 106.8 / 109.6 ms a step with 4 GB, 100.8 / 102.9 with 8).  Called from batch_close()
+// with the batch's own kernels through; into HBM that is free beyond kGrowKeep, at most 12 GB, once.
+static int dp_scratch_grow(mcx_ctx *c, uint32_t list_len)
+{
+    if (c->dp_grown || getenv("MCX_DP_BLOCKS1") || c->kn.no_tier1_grow) return 0;
+    const bool nw = c->pm.use_nw != 0;
+    const uint64_t w2 = lane_stride_words<16>(nw, c->rlen_max, 16, true) * 4; // bytes a wavefront's stretch takes
+    const uint64_t have = c->dp_stride[1] * c->dp_blocks[1];
+    uint64_t enough = 2 * 128 * (have / w2); // (fewer than two groups per wavefront there is room for: short enough)
+    if (const char *e = getenv("MCX_DP_GROW_MIN")) enough = (uint64_t)std::max(0, atoi(e)); // (tests)
+    if ((uint64_t)list_len <= enough) return 0;
+    c->dp_grown = true; // (one attempt)
+    const uint64_t want_bytes = std::min<uint64_t>(4096 * w2, (uint64_t)12 << 30);
+    const uint32_t want = (uint32_t)((want_bytes + c->dp_stride[1] - 1) / c->dp_stride[1]);
+    if (want <= c->dp_blocks[1]) return 0;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (const char *e = getenv("MCX_HBM_CAP_GB")) { const uint64_t cap = (uint64_t)std::max(1, atoi(e)) << 30, used = total_b - free_b; free_b = cap > used ? cap - used : 0; }
+    if (free_b + have < (uint64_t)want * c->dp_stride[1] + kGrowKeep) return 0;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(c->d_dp_scratch[1])); c->d_dp_scratch[1] = nullptr;
+    uint8_t *p = nullptr;
+    uint32_t got = want;
+    if (hipMalloc((void **)&p, (size_t)want * c->dp_stride[1]) != hipSuccess) {
+        (void)hipGetLastError();
+        got = c->dp_blocks[1];
+        if (hipMalloc((void **)&p, (size_t)have) != hipSuccess) { (void)hipGetLastError(); return fail(MCX_ERR_DEVICE, "the DP lists' scratch: out of device memory"); }
+    }
+    if (got != c->dp_blocks[1] && (c->kn.timing || getenv("MCX_ALLOC_LOG")))
+        fprintf(stderr, "[mcx] the 65-256-column DP list's scratch grows from %.1f to %.1f GB: %u problems in this batch\n", (double)have / 1e9, (double)got * c->dp_stride[1] / 1e9, list_len);
+    g_dmalloc_bytes += (size_t)got * c->dp_stride[1] - have;
+    c->d_dp_scratch[1] = p; c->dp_blocks[1] = got;
     return 0;
 }
 
@@ -2959,6 +2999,7 @@ static int pass_finish(mcx_ctx *c, int tier, const PassRes &R, uint32_t n_sel, m
             }
         }
     }
+    if (tier == 0 && !c->dp_grown) c->job2_seen = std::max(c->job2_seen, n[CNT_JOB2]); // (batch_close: dp_scratch_grow)
     // a work list that ran over: nothing of this pass is kept, the caller maps the selection in two halves
     if ((R.d_tasks && n[CNT_TASKS] > R.task_cap) || n[CNT_RESCUE] > R.rescue_cap || n[CNT_RTASK] > R.rtask_cap || n[CNT_RSEED] > R.rseed_cap) return kListOverflow;
     for (int k = 0; k < kDpClasses; k++) if (n[CNT_JOB0 + k * kCntPad] > R.job_cap[k]) return kListOverflow;
@@ -3527,6 +3568,7 @@ static int batch_close(mcx_ctx *c, mcx_stats *stats)
         float ms_pack = 0;
         if (hipEventElapsedTime(&ms_pack, c->ev_pack[0], c->ev_pack[1]) == hipSuccess) stats->ms_encode += ms_pack; // k_pack_reads
     }
+    if (!c->dp_grown && c->job2_seen) return dp_scratch_grow(c, c->job2_seen); // (the batch is through: nothing holds the scratch)
     return 0;
 }
 

@@ -994,36 +994,39 @@ def test_config5_indel_heavy_long_pairs_equal_reference(api, bench_genome, tmp_p
     assert 0 < st["mapped"] < 0.5 * st["reads"], st
 
 
-def test_large_tier_records_grow_to_take_a_batch_in_one_pass(api, bench_genome, tmp_path, monkeypatch, capfd):
+def test_large_tier_records_and_dp_scratch_grow_with_the_batches(api, bench_genome, tmp_path, monkeypatch, capfd):
     """A batch that sends the large tier more pairs than its records hold makes them grow (tier1_grow: config 5 at bench.py's size has 185 k such pairs
-    and started with room for 99 k — the second pass ran alone after tier 0).  120 k pairs of config 5's kind with 1 GB of records to start with (4 k
-    pairs): the SAM of the run that grows equals, byte for byte, the one of a run that keeps the 1 GB and takes several passes; the growth is
+    and started with room for 99 k — the second pass ran alone after tier 0), and a batch whose 65-256-column DP list is long makes that list's scratch
+    grow for the batches after it (dp_scratch_grow).  160 k pairs of config 5's kind in two batches, 0.5 GB of records to start with (2 k pairs) and the
+    list's threshold lowered: the SAM of the run that grows equals, byte for byte, the one of a run that keeps what it started with; each growth is
     reported once; a device made to look full (MCX_HBM_CAP_GB) keeps what it has and still maps the same."""
     from mapcaller_amd import synth
     g = bench_genome
-    n_pairs = 120_000
+    n_pairs = 160_000
     reads = g["bench"].make_reads(g["codes"], g["lens"], n_pairs, 250, seed=78, device=g["dev"], sub=0.005, ins=0.025, dele=0.025).reshape(2 * n_pairs, 250).cpu()
     f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
     synth.write_fastq(f1, reads, 0, 2); synth.write_fastq(f2, reads, 1, 2)
     monkeypatch.setenv("MCX_ALLOC_LOG", "1")
+    monkeypatch.setenv("MCX_DP_GROW_MIN", "1000")
     outs, logs, stats = [], [], []
     for mode in ("grow", "fixed", "full"):
-        monkeypatch.delenv("MCX_TIER1_GB", raising=False); monkeypatch.delenv("MCX_HBM_CAP_GB", raising=False)
-        monkeypatch.setenv("MCX_TIER1_START_GB", "1")
+        monkeypatch.delenv("MCX_TIER1_GB", raising=False); monkeypatch.delenv("MCX_HBM_CAP_GB", raising=False); monkeypatch.delenv("MCX_NO_TIER1_GROW", raising=False)
+        monkeypatch.setenv("MCX_TIER1_START_GB", "0.5")
         if mode == "fixed":
-            monkeypatch.delenv("MCX_TIER1_START_GB"); monkeypatch.setenv("MCX_TIER1_GB", "1")
+            monkeypatch.delenv("MCX_TIER1_START_GB"); monkeypatch.setenv("MCX_TIER1_GB", "1"); monkeypatch.setenv("MCX_NO_TIER1_GROW", "1")
         if mode == "full":
             monkeypatch.setenv("MCX_HBM_CAP_GB", "1")
         capfd.readouterr()
-        mp = api.Mapper(g["index"], alg="nw", max_read_len=256, max_batch_reads=2 * n_pairs)
+        mp = api.Mapper(g["index"], alg="nw", max_read_len=256, max_batch_reads=n_pairs)  # two batches of 80 k pairs
         out = str(tmp_path / f"{mode}.sam")
         stats.append(mp.map_files(f1, f2, out))
         mp.close()
         logs.append(capfd.readouterr().err)
         outs.append(open(out, "rb").read())
-    assert stats[0]["tier1_pairs"] > 4096 - 2048, stats[0]  # more heavy pairs than the 1 GB holds beside the late pairs' room
+    assert stats[0]["tier1_pairs"] > 2 * 2100, stats[0]  # more heavy pairs a batch than the 0.5 GB holds
     assert logs[0].count("the large tier's records grow") == 1, logs[0][-2000:]
-    assert "records grow" not in logs[1] and "records grow" not in logs[2]
+    assert logs[0].count("DP list's scratch grows") == 1, logs[0][-2000:]
+    assert "grow" not in logs[1] and "grow" not in logs[2], (logs[1][-1000:], logs[2][-1000:])
     assert outs[0] == outs[1] == outs[2]
     assert len(outs[0]) > 10_000_000
 
