@@ -64,10 +64,12 @@ struct DpSumAcc {
 };
 
 struct LaneMem {
-    uint32_t *base; // word 0 of this lane
+    uint32_t *base;  // word 0 of lane 0: the same for every lane of the wavefront, so that a fetch is "scalar base + 32-bit byte offset" — one register and one
+                     // instruction per address where a per-lane pointer took two of each (a window fetch of a walk holds a dozen addresses at once)
     uint32_t stride; // words between consecutive words of a lane (64 on the device: lanes interleaved; 1 on the host)
-    MCX_HD uint32_t get(uint32_t w) const { return base[(size_t)w * stride]; }
-    MCX_HD void put(uint32_t w, uint32_t v) const { base[(size_t)w * stride] = v; }
+    uint32_t lane;   // this lane's place among them (0 on the host)
+    MCX_HD uint32_t get(uint32_t w) const { return *(const uint32_t *)((const char *)base + (w * stride + lane) * 4u); } // (a stretch is a few MB: the offset fits)
+    MCX_HD void put(uint32_t w, uint32_t v) const { *(uint32_t *)((char *)base + (w * stride + lane) * 4u) = v; }
 };
 
 // where a group of problems keeps its words (the same for every lane of the wave: offsets come from the group's largest problem)

@@ -31,6 +31,12 @@
 #define MCX_DP_LANE2_H
 #include "mcx_dp_lane.h"
 
+#if defined(__HIPCC__)
+#define MCX_HDI __host__ __device__ __forceinline__
+#else
+#define MCX_HDI inline
+#endif
+
 namespace mcx {
 
 // ---- the packed 16-bit instructions this file is written in ------------------------------------------------------------------
@@ -213,57 +219,99 @@ static inline MCX_HD void lane_sweep_nw2(const LaneMem &mem, const LaneLayout2 &
     *score_b = pk::hi(fin) + m_b + n_b;
 }
 
-// What a walk reads of its problem, four rows at a time: the traceback words of rows top .. top - 3 of one strip and the rows' query codes, fetched
-// together when the walk leaves the window (it moves up a row or stays: one wait per four rows instead of one — or, with the query code, two — per
-// column; the walk is a chain of dependent fetches with nothing between them).  Held in named registers and picked by comparison: an array indexed
-// by a run-time row would live in scratch memory.
+// What a walk reads of its problem: a window of 8 x 8 cells — rows r0 .. r0 - 7, columns c0 .. c0 - 7, the cell the walk stands on at its upper end — taken
+// in by EVERY lane of the wavefront at the same step, every eighth one.  A step moves up a row, left a column or both, so the eight steps that follow stay
+// inside the window and touch no memory but the column string they write.  (The first form fetched when a lane left its window, four and then eight rows of
+// one strip: with 128 walks to a wavefront some lane left its window at nearly every step, and the whole wavefront ran the fetch and waited for it each
+// time — the walks were 11-13 of config 5's 39 ms DP stage, scripts/gpu_r6_walk.sh, and the larger window changed nothing.)  A row of the window is ONE
+// register: the columns may lie in two strips, whose words are put side by side (column k of a strip is bit K-1-k) and cut to the window's eight columns,
+// bit t = column c0 - t; nw: "s == r" bits | "s == t" bits << 8; ksw2: a > z | b > z << 8 | x | y extension bits << 16 / << 24.  Rows picked by
+// comparison: an array indexed by a run-time row would live in scratch memory.
 template <int K, bool NW>
 struct LaneWindow2 {
+    static constexpr int N = 8;
     const LaneMem &mem; const LaneLayout2 &l; int h;
-    int strip = -1, top = -1;
-    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0, tw = 0;
+    int r0 = 0, c0 = 0, s0 = 0;
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, w6 = 0, w7 = 0;
+    uint32_t qp = 0, tw = 0, tp = 0; // the rows' query codes of this problem, three bits each (row r0 - k at bit 3 k); the target codes of strip s0 and of the one before
     MCX_HD LaneWindow2(const LaneMem &m, const LaneLayout2 &lay, int half) : mem(m), l(lay), h(half) {}
-    MCX_HD void at(int s, int row)
+    // a row's word from the strips' words (prv: the strip before's, or anything where the window does not reach into it: pm = 0 then)
+    static MCX_HDI uint32_t cut(uint32_t cur, uint32_t prv, uint32_t pm, int sh)
     {
-        if (s == strip && row <= top && row > top - 4) return;
-        if (s != strip) tw = mem.get(l.off_t + 2u * (uint32_t)s + (uint32_t)h); // the strip's target codes as the sweep fetched them
-        strip = s; top = row;
-        constexpr uint32_t W = LaneDir2<NW>::words, P = LaneDir2<NW>::per_problem;
-        const uint32_t base = l.off_dir + (uint32_t)(s * (int)l.rows) * W + (uint32_t)h * P;
-        const int r1 = row > 0 ? row - 1 : 0, r2 = row > 1 ? row - 2 : 0, r3 = row > 2 ? row - 3 : 0; // (above row 0: row 0 again, never picked)
-        a0 = mem.get(base + (uint32_t)row * W); a1 = mem.get(base + (uint32_t)r1 * W); a2 = mem.get(base + (uint32_t)r2 * W); a3 = mem.get(base + (uint32_t)r3 * W);
-        if (!NW) { b0 = mem.get(base + (uint32_t)row * W + 1u); b1 = mem.get(base + (uint32_t)r1 * W + 1u); b2 = mem.get(base + (uint32_t)r2 * W + 1u); b3 = mem.get(base + (uint32_t)r3 * W + 1u); }
-        q0 = mem.get(l.off_q + (uint32_t)row); q1 = mem.get(l.off_q + (uint32_t)r1); q2 = mem.get(l.off_q + (uint32_t)r2); q3 = mem.get(l.off_q + (uint32_t)r3);
+        prv &= pm;
+        return (((((prv & 0xFFFFu) << K) | (cur & 0xFFFFu)) >> sh) & 0xFFu) | ((((((prv >> 16) << K) | (cur >> 16)) >> sh) & 0xFFu) << 8);
     }
-    MCX_HD uint32_t pick(int row, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) const { const int d = top - row; return d == 0 ? x0 : (d == 1 ? x1 : (d == 2 ? x2 : x3)); }
-    MCX_HD uint32_t w0(int row) const { return pick(row, a0, a1, a2, a3); }
-    MCX_HD uint32_t w1(int row) const { return pick(row, b0, b1, b2, b3); }
-    // "the query base of this row differs from target base tj" (tj in the window's strip): a query N (code 4) differs from every genome base
-    MCX_HD int differ(int row, int tj) const { return ((pick(row, q0, q1, q2, q3) >> (16 * h)) & 7u) != ((tw >> (30 - 2 * (tj - strip * K))) & 3u) ? 1 : 0; }
+    MCX_HDI void fetch(int row, int col)
+    {
+        constexpr uint32_t W = LaneDir2<NW>::words, P = LaneDir2<NW>::per_problem;
+        const int s = col / K, sh = K - 1 - (col % K);
+        const bool prev = s > 0 && col - (N - 1) < s * K; // the window reaches into the strip before
+        const uint32_t pm = prev ? 0xFFFFFFFFu : 0u;
+        r0 = row; c0 = col; s0 = s;
+        // every fetch is issued before any of them is used, whether the strip before is needed or not (a fetch under a condition is a branch, and the
+        // eight rows' fetches behind eight branches waited for one another: the stage took 61 ms that way instead of 39): without it the same word twice
+        const uint32_t base_s = l.off_dir + (uint32_t)(s * (int)l.rows) * W + (uint32_t)h * P, base_p = prev ? base_s - l.rows * W : base_s;
+        auto up = [&](int k) -> uint32_t { return (uint32_t)(row > k ? row - k : 0) ; }; // (above row 0: row 0 again, never picked)
+        const uint32_t r1 = up(1), r2 = up(2), r3 = up(3), r4 = up(4), r5 = up(5), r6 = up(6), r7 = up(7);
+        const uint32_t c_0 = mem.get(base_s + (uint32_t)row * W), c_1 = mem.get(base_s + r1 * W), c_2 = mem.get(base_s + r2 * W), c_3 = mem.get(base_s + r3 * W),
+                       c_4 = mem.get(base_s + r4 * W), c_5 = mem.get(base_s + r5 * W), c_6 = mem.get(base_s + r6 * W), c_7 = mem.get(base_s + r7 * W);
+        const uint32_t p_0 = mem.get(base_p + (uint32_t)row * W), p_1 = mem.get(base_p + r1 * W), p_2 = mem.get(base_p + r2 * W), p_3 = mem.get(base_p + r3 * W),
+                       p_4 = mem.get(base_p + r4 * W), p_5 = mem.get(base_p + r5 * W), p_6 = mem.get(base_p + r6 * W), p_7 = mem.get(base_p + r7 * W);
+        const uint32_t q0 = mem.get(l.off_q + (uint32_t)row), q1 = mem.get(l.off_q + r1), q2 = mem.get(l.off_q + r2), q3 = mem.get(l.off_q + r3),
+                       q4 = mem.get(l.off_q + r4), q5 = mem.get(l.off_q + r5), q6 = mem.get(l.off_q + r6), q7 = mem.get(l.off_q + r7);
+        tw = mem.get(l.off_t + 2u * (uint32_t)s + (uint32_t)h); // the strips' target codes as the sweep fetched them
+        tp = mem.get(l.off_t + 2u * (uint32_t)(prev ? s - 1 : s) + (uint32_t)h);
+        w0 = cut(c_0, p_0, pm, sh); w1 = cut(c_1, p_1, pm, sh); w2 = cut(c_2, p_2, pm, sh); w3 = cut(c_3, p_3, pm, sh);
+        w4 = cut(c_4, p_4, pm, sh); w5 = cut(c_5, p_5, pm, sh); w6 = cut(c_6, p_6, pm, sh); w7 = cut(c_7, p_7, pm, sh);
+        if (!NW) { // the extension bits: the second word of a row
+            const uint32_t d_0 = mem.get(base_s + (uint32_t)row * W + 1u), d_1 = mem.get(base_s + r1 * W + 1u), d_2 = mem.get(base_s + r2 * W + 1u), d_3 = mem.get(base_s + r3 * W + 1u),
+                           d_4 = mem.get(base_s + r4 * W + 1u), d_5 = mem.get(base_s + r5 * W + 1u), d_6 = mem.get(base_s + r6 * W + 1u), d_7 = mem.get(base_s + r7 * W + 1u);
+            const uint32_t e_0 = mem.get(base_p + (uint32_t)row * W + 1u), e_1 = mem.get(base_p + r1 * W + 1u), e_2 = mem.get(base_p + r2 * W + 1u), e_3 = mem.get(base_p + r3 * W + 1u),
+                           e_4 = mem.get(base_p + r4 * W + 1u), e_5 = mem.get(base_p + r5 * W + 1u), e_6 = mem.get(base_p + r6 * W + 1u), e_7 = mem.get(base_p + r7 * W + 1u);
+            w0 |= cut(d_0, e_0, pm, sh) << 16; w1 |= cut(d_1, e_1, pm, sh) << 16; w2 |= cut(d_2, e_2, pm, sh) << 16; w3 |= cut(d_3, e_3, pm, sh) << 16;
+            w4 |= cut(d_4, e_4, pm, sh) << 16; w5 |= cut(d_5, e_5, pm, sh) << 16; w6 |= cut(d_6, e_6, pm, sh) << 16; w7 |= cut(d_7, e_7, pm, sh) << 16;
+        }
+        const int qs = 16 * h;
+        qp = ((q0 >> qs) & 7u) | (((q1 >> qs) & 7u) << 3) | (((q2 >> qs) & 7u) << 6) | (((q3 >> qs) & 7u) << 9) | (((q4 >> qs) & 7u) << 12) | (((q5 >> qs) & 7u) << 15)
+           | (((q6 >> qs) & 7u) << 18) | (((q7 >> qs) & 7u) << 21);
+    }
+    // the window's word of a row, shifted so that the cell's own bits are bits 0, 8, 16 and 24
+    // (the eight words by value: a choice among the FIELDS becomes a fetch from a chosen address, and the walk's state then lives in scratch memory)
+    static MCX_HDI uint32_t pick(int d, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4, uint32_t x5, uint32_t x6, uint32_t x7)
+    {
+        const uint32_t lo = (d & 2) ? ((d & 1) ? x3 : x2) : ((d & 1) ? x1 : x0), hi = (d & 2) ? ((d & 1) ? x7 : x6) : ((d & 1) ? x5 : x4);
+        return (d & 4) ? hi : lo;
+    }
+    MCX_HDI uint32_t cell(int row, int col) const { return pick(r0 - row, w0, w1, w2, w3, w4, w5, w6, w7) >> (c0 - col); }
+    // "the query base of this row differs from the target base of this column": a query N (code 4) differs from every genome base
+    MCX_HDI int differ(int row, int col) const
+    {
+        const uint32_t t = tw ^ ((tw ^ tp) & (col >= s0 * K ? 0u : 0xFFFFFFFFu)); // (not "cond ? tw : tp": a choice between two fields becomes a fetch from a chosen address, and the walk's state then lives in memory)
+        return ((qp >> (3 * (r0 - row))) & 7u) != ((t >> (30 - 2 * (col % K))) & 3u) ? 1 : 0;
+    }
 };
 
 // the column string of a walk, back to front, four columns to a store (a walk is a chain of dependent fetches, and on this chip a fetch waits for the
 // stores issued before it as well: a byte per store and column was one more thing every fetch of the chain queued behind)
 struct OpsSink2 {
     uint8_t *ops; int w; uint32_t word; DpSumAcc acc; bool bases;
-    MCX_HD void begin(uint8_t *area, int len, DpSummary *sum) { ops = area; w = len; word = 0; acc.begin(sum); bases = sum != nullptr; }
+    MCX_HDI void begin(uint8_t *area, int len, DpSummary *sum) { ops = area; w = len; word = 0; acc.begin(sum); bases = sum != nullptr; }
     MCX_HD bool wants_bases() const { return bases; }
-    MCX_HD void col(int kind, int differ)
+    MCX_HDI void col(int kind, int differ)
     {
         --w;
         word |= (uint32_t)(kind == 0 ? 'M' : (kind == 1 ? 'I' : 'D')) << (8 * (w & 3));
         if ((w & 3) == 0) { *(uint32_t *)(ops + w) = word; word = 0; } // (the area starts on an 8-byte boundary of the pair's pool and is rounded up to one: stage_build)
         acc.put(kind, differ);
     }
-    MCX_HD void end(uint32_t ops_base, int len)
+    MCX_HDI void end(uint32_t ops_base, int len)
     {
         for (int k = w; k & 3; k++) ops[k] = (uint8_t)(word >> (8 * (k & 3))); // the string's first columns, short of a word
         acc.end(ops_base + (uint32_t)w, len - w);
     }
 };
 
-// One problem's walk as a state machine, so that a lane's two walks advance together — the words either needs next are fetched before either is used:
-// two chains of dependent fetches in flight instead of one after the other.
+// One problem's walk as a state machine, so that a lane's two walks — and the wavefront's 128 — advance together.
 // nw: nw_alignment's traceback (nw_alignment.cpp:59-74); ksw2: ksw_backtrack (ksw2_alignment.cpp:25-68), full band; i: target index, j: query index.
 template <int K, bool NW>
 struct LaneWalk2 {
@@ -272,20 +320,20 @@ struct LaneWalk2 {
     int i, j, state;
     bool live;
     MCX_HD LaneWalk2(const LaneMem &m, const LaneLayout2 &lay, int half) : win(m, lay, half), i(0), j(0), state(0), live(false) {}
-    MCX_HD void begin(int qlen, int tlen, uint8_t *area, DpSummary *sum)
+    MCX_HDI void begin(int qlen, int tlen, uint8_t *area, DpSummary *sum)
     {
         sink.begin(area, qlen + tlen, sum);
         if (NW) { i = qlen; j = tlen; live = i > 0 || j > 0; } // 1-based matrix indices
         else { i = tlen - 1; j = qlen - 1; live = true; state = 0; }
     }
-    // the cell the next step reads (if any): its window in place — fetched now when it is not
-    MCX_HD void look()
+    // the window from the cell the next step reads (a walk that has reached the matrix's edge stays on it and reads nothing more)
+    MCX_HDI void fetch()
     {
         if (!live) return;
-        if (NW) { if (i > 0 && j > 0) win.at((j - 1) / K, i - 1); }
-        else if (i >= 0 && j >= 0) win.at(i / K, j);
+        if (NW) { if (i > 0 && j > 0) win.fetch(i - 1, j - 1); }
+        else if (i >= 0 && j >= 0) win.fetch(j, i);
     }
-    MCX_HD void step()
+    MCX_HDI void step()
     {
         if (!live) return;
         if (NW) {
@@ -293,9 +341,8 @@ struct LaneWalk2 {
             if (i == 0) d = 1;        // s[0][j] == r[0][j]
             else if (j == 0) d = 2;   // s[i][0] == t[i][0]
             else {
-                const int a = i - 1, b = j - 1, sh = K - 1 - (b % K);
-                const uint32_t w = win.w0(a);
-                d = (((w >> sh) & 1u) ^ 1u) | ((((w >> (16 + sh)) & 1u) ^ 1u) << 1);
+                const uint32_t w = win.cell(i - 1, j - 1);
+                d = ((w & 1u) ^ 1u) | ((((w >> 8) & 1u) ^ 1u) << 1);
             }
             if (d & 1) { sink.col(2, 0); j--; }
             else if (d & 2) { sink.col(1, 0); i--; }
@@ -303,10 +350,9 @@ struct LaneWalk2 {
             live = i > 0 || j > 0;
         } else {
             if (i >= 0 && j >= 0) {
-                const int sh = K - 1 - (i % K);
-                const uint32_t w0 = win.w0(j), w1 = win.w1(j);
-                const unsigned st = ((w0 >> (16 + sh)) & 1u) ? 2u : ((w0 >> sh) & 1u);
-                const unsigned d = st | (((w1 >> sh) & 1u) << 3) | (((w1 >> (16 + sh)) & 1u) << 4); // the reference's byte: state in bits 0-2, extension bits 3 and 4
+                const uint32_t w = win.cell(j, i);
+                const unsigned st = ((w >> 8) & 1u) ? 2u : (w & 1u);
+                const unsigned d = st | (((w >> 16) & 1u) << 3) | (((w >> 24) & 1u) << 4); // the reference's byte: state in bits 0-2, extension bits 3 and 4
                 if (state == 0) state = d & 7;
                 else if (!((d >> (state + 2)) & 1)) state = 0;
                 if (state == 0) state = d & 7;
@@ -320,12 +366,12 @@ struct LaneWalk2 {
     }
 };
 
-// both walks of a lane (have_b false: one)
+// both walks of a lane (have_b false: one); every eighth step all of them take their windows in
 template <int K, bool NW>
-static inline MCX_HD void lane_walk2(LaneWalk2<K, NW> &wa, LaneWalk2<K, NW> &wb)
+static MCX_HDI void lane_walk2(LaneWalk2<K, NW> &wa, LaneWalk2<K, NW> &wb)
 {
-    while (wa.live || wb.live) {
-        wa.look(); wb.look();
+    for (int n = 0; wa.live || wb.live; n++) {
+        if ((n & (LaneWindow2<K, NW>::N - 1)) == 0) { wa.fetch(); wb.fetch(); }
         wa.step(); wb.step();
     }
 }
@@ -432,7 +478,9 @@ static inline MCX_HD void lane_dp_job2(const Ctx &cx, const LaneMem &mem, const 
     DpSummary *sum_b = cx.dp_summary ? (DpSummary *)(st_b.ops + job_b.ops_off - kDpSum) : nullptr;
     wa.begin(qa, ta, st_a.ops + job_a.ops_off, sum_a);
     if (have_b) wb.begin(qb, tb, st_b.ops + job_b.ops_off, sum_b);
+#ifndef MCX_DBG_SKIP_WALK // (an experiment's build: what the walks cost — the results are not alignments then)
     lane_walk2(wa, wb);
+#endif
     {
         wa.sink.end((uint32_t)job_a.ops_off, qa + ta);
         Frag f = fr_a;

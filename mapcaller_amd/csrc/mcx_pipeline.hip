@@ -897,7 +897,7 @@ __global__ void __launch_bounds__(256) k_simple_dp(Ctx cx, SimpleLater sl)
     constexpr int W = 2 + kSimpleDp * LaneDir<16, NW>::words;
     __shared__ uint32_t words[W * 256];
     const uint32_t n = min(*sl.n_jobs, sl.cap * kSimpleJobs);
-    LaneMem mem; mem.base = words + threadIdx.x; mem.stride = 256;
+    LaneMem mem; mem.base = words; mem.stride = 256; mem.lane = threadIdx.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { // (the list's length stays on the device)
         const uint32_t at = sl.job_list[i];
         const SimpleJob j = sl.jobs[at];
@@ -1774,7 +1774,7 @@ __global__ void __launch_bounds__(64) k_dp_lane(Ctx cx, JobSink sink, const uint
     if (n < min_n) return; // (a short list: k_dp_group's)
     const int lane = threadIdx.x;
     const int nr = cx.pm.paired ? 2 : 1;
-    LaneMem mem; mem.base = scratch + (uint64_t)blockIdx.x * stride_words + lane; mem.stride = 64;
+    LaneMem mem; mem.base = scratch + (uint64_t)blockIdx.x * stride_words; mem.stride = 64; mem.lane = (uint32_t)lane;
     for (uint32_t g0 = blockIdx.x * 64u; g0 < n; g0 += gridDim.x * 64u) {
         const uint32_t jb = g0 + (uint32_t)lane;
         const bool have = jb < n;
@@ -1807,7 +1807,7 @@ __global__ void __launch_bounds__(64) k_dp_lane2(Ctx cx, JobSink sink, const uin
     if (n < min_n) return; // (a short list: k_dp_group's)
     const int lane = threadIdx.x;
     const int nr = cx.pm.paired ? 2 : 1;
-    LaneMem mem; mem.base = scratch + (uint64_t)blockIdx.x * stride_words + lane; mem.stride = 64;
+    LaneMem mem; mem.base = scratch + (uint64_t)blockIdx.x * stride_words; mem.stride = 64; mem.lane = (uint32_t)lane;
     for (uint32_t g0 = blockIdx.x * 128u; g0 < n; g0 += gridDim.x * 128u) {
         const uint32_t ja = g0 + 2u * (uint32_t)lane, jb = ja + 1u;
         const bool have_a = ja < n, have_b = jb < n;

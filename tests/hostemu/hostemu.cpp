@@ -234,7 +234,7 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
             const SimpleJob &j = jobs[k];
             if (j.rl == 0) continue;
             uint32_t words[2 + 2 * kSimpleDp];
-            LaneMem mem; mem.base = words; mem.stride = 1;
+            LaneMem mem; mem.base = words; mem.stride = 1; mem.lane = 0;
             res[k] = cx.pm.use_nw ? simple_dp_job<true>(cx.ix, j, packed[j.read].data(), mem) : simple_dp_job<false>(cx.ix, j, packed[j.read].data(), mem);
         }
         const std::vector<uint32_t> waiting = later;
@@ -323,7 +323,7 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
         const LaneLayout2 l = tiny ? (cx.pm.use_nw ? lane_layout2<8, true>(rows, strips) : lane_layout2<8, false>(rows, strips))
                                    : (cx.pm.use_nw ? lane_layout2<16, true>(rows, strips) : lane_layout2<16, false>(rows, strips));
         words.assign(l.words + 4, 0xDEADBEEFu);
-        LaneMem mem; mem.base = words.data(); mem.stride = 1;
+        LaneMem mem; mem.base = words.data(); mem.stride = 1; mem.lane = 0;
         int sc[2];
         if (tiny) { if (cx.pm.use_nw) lane_dp_job2<8, true>(cx, mem, l, ja, rr[0], have_b, jb, rr[have_b ? 1 : 0], sc); else lane_dp_job2<8, false>(cx, mem, l, ja, rr[0], have_b, jb, rr[have_b ? 1 : 0], sc); }
         else { if (cx.pm.use_nw) lane_dp_job2<16, true>(cx, mem, l, ja, rr[0], have_b, jb, rr[have_b ? 1 : 0], sc); else lane_dp_job2<16, false>(cx, mem, l, ja, rr[0], have_b, jb, rr[have_b ? 1 : 0], sc); }
@@ -342,7 +342,7 @@ static std::vector<uint32_t> run_tier(Emu &e, int tier, const Batch &b, const st
             const LaneLayout l = tiny ? (cx.pm.use_nw ? lane_layout<8, true>(job.rLen, strips) : lane_layout<8, false>(job.rLen, strips))
                                       : (cx.pm.use_nw ? lane_layout<16, true>(job.rLen, strips) : lane_layout<16, false>(job.rLen, strips));
             words.assign(l.words + 4, 0xDEADBEEFu);
-            LaneMem mem; mem.base = words.data(); mem.stride = 1;
+            LaneMem mem; mem.base = words.data(); mem.stride = 1; mem.lane = 0;
             // (a read without N also goes through its 2-bit words, as on the device)
             std::vector<uint32_t> pkbuf(packed_words(jr.rlen) + 4, 0u);
             bool has_n = false;
@@ -554,7 +554,7 @@ int hostemu_lane_dp(int use_nw, const char *q, int qlen, const char *t, int tlen
     if (K == 8) l = use_nw ? lane_layout<8, true>(qlen, strips) : lane_layout<8, false>(qlen, strips);
     else l = use_nw ? lane_layout<16, true>(qlen, strips) : lane_layout<16, false>(qlen, strips);
     std::vector<uint32_t> words(l.words + 4, 0xDEADBEEFu);
-    LaneMem mem; mem.base = words.data(); mem.stride = 1;
+    LaneMem mem; mem.base = words.data(); mem.stride = 1; mem.lane = 0;
     lane_stage_query(mem, l, qlen, [&](int p, uint32_t &codes, uint32_t &flags) {
         codes = 0; flags = 0;
         for (int k = 0; k < 16 && p + k < qlen; k++) { const int c = code(q[p + k]); codes |= (uint32_t)(c & 3) << (30 - 2 * k); flags |= (uint32_t)(c > 3) << (15 - k); }
@@ -594,7 +594,7 @@ int hostemu_lane_dp2(int use_nw, const char *qa, int qlen_a, const char *ta, int
     if (K == 8) l = use_nw ? lane_layout2<8, true>(rows, strips) : lane_layout2<8, false>(rows, strips);
     else l = use_nw ? lane_layout2<16, true>(rows, strips) : lane_layout2<16, false>(rows, strips);
     std::vector<uint32_t> words(l.words + 4, 0xDEADBEEFu);
-    LaneMem mem; mem.base = words.data(); mem.stride = 1;
+    LaneMem mem; mem.base = words.data(); mem.stride = 1; mem.lane = 0;
     const char *qs[2] = {qa, qb}, *ts[2] = {ta, tb};
     const int ql[2] = {qlen_a, qlen_b}, tl[2] = {tlen_a, tlen_b};
     lane_stage_query2(mem, l, qlen_a, qlen_b, [&](int h, int p) { return code(qs[h][p]); });
