@@ -327,11 +327,13 @@ struct LaneWalk2 {
         else { i = tlen - 1; j = qlen - 1; live = true; state = 0; }
     }
     // the window from the cell the next step reads (a walk that has reached the matrix's edge stays on it and reads nothing more)
+    // (taken in whether the walk needs it or not — cell (0, 0) then: a fetch under a condition is a branch, and the lane's two windows behind two branches
+    //  are two waits where one will do)
     MCX_HDI void fetch()
     {
-        if (!live) return;
-        if (NW) { if (i > 0 && j > 0) win.fetch(i - 1, j - 1); }
-        else if (i >= 0 && j >= 0) win.fetch(j, i);
+        const bool need = live && (NW ? (i > 0 && j > 0) : (i >= 0 && j >= 0));
+        const int row = NW ? i - 1 : j, col = NW ? j - 1 : i;
+        win.fetch(need ? row : 0, need ? col : 0);
     }
     MCX_HDI void step()
     {
