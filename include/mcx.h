@@ -77,6 +77,11 @@ typedef struct mcx_opts {
 } mcx_opts;
 void mcx_opts_default(mcx_opts *);
 
+/* A context's HBM: what mcx_ctx_create takes (itemised on stderr with MCX_ALLOC_LOG=1), tier 0's pair records with the first batch, and — only while more
+ * than 16 GB of the device stay free after it — two growths on demand, each said on stderr under MCX_ALLOC_LOG / MCX_TIMING: the large tier's pair records
+ * when a batch sends it more pairs than one pass holds (3 KB per read of the batch to start with, 2-24 GB; up to 262144 pairs), and the scratch of the
+ * 65-256-column DP list after a batch that fills it (4 GB -> at most 12 GB, once).  MCX_NO_TIER1_GROW=1 keeps both as created; a size asked for with
+ * MCX_TIER1_GB is kept too.  Results do not depend on either (tests/test_gpu_parity.py: the SAM of a run that grows equals one that does not). */
 int mcx_ctx_create(const mcx_index *, const mcx_opts *, mcx_ctx **out);
 /* The same with everything the run will take from the device taken at once — the context, tier 0's pair records (otherwise allocated by the first batch),
  * and with_profile != 0: the counter planes (mcx_planes_alloc -> *planes; free with mcx_planes_free) and the bookkeeping's buffers (mcx_profile_attach with

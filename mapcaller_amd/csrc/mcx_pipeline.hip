@@ -1270,6 +1270,7 @@ __global__ void __launch_bounds__(256) k_rescue_eval(Ctx cx, ReadBatch rb, PairS
     __shared__ uint32_t q_all[kWaves][3 * kRescueQWords];
     __shared__ uint32_t w_all[kWaves][2 * kW];
     __shared__ uint32_t ew_all[kWaves][kRescueQWords];
+    __shared__ uint16_t ss_all[kWaves][128]; // where the seeds of a window's best diagonal begin (a read of 1024 bases has at most 94)
     const IndexView &ix = cx.ix;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     RescueWave ev; ev.q = q_all[wv]; ev.w = w_all[wv]; ev.ew = ew_all[wv]; ev.wstride = kW; ev.red = nullptr; ev.kq = ev.kg = nullptr;
@@ -1339,31 +1340,44 @@ __global__ void __launch_bounds__(256) k_rescue_eval(Ctx cx, ReadBatch rb, PairS
             if (res.score > task.sb) { // (a window that does not beat the mate's best is dropped whatever its seeds)
                 for (int k = lane; k < kRescueQWords; k += 64) ev.ew[k] = 0u;
                 wave_sync();
-                if (lane == 0) {
-                    ev.diagonal(res.d, qlen, slen, pad, true);
-                    // the seeds of the diagonal (runs of three or more 8-mer matches), counted, then written to the pool
-                    Hit *out = nullptr;
-                    for (int pass = 0; pass < 2; pass++) {
-                        int n_seeds = 0, run = 0, run_start = 0;
-                        for (int rr = 0; rr <= qlen; rr++) {
-                            if (run == 0 && (rr & 31) == 0 && rr + 32 <= qlen && ev.ew[rr >> 5] == 0u) { rr += 31; continue; }
-                            const bool m = rr < qlen && ((ev.ew[rr >> 5] >> (rr & 31)) & 1u);
-                            if (m) { if (run == 0) run_start = rr; run++; }
-                            else if (run > 0) {
-                                const int l = kKmerSize + run - 1;
-                                if (l >= 10) {
-                                    if (out) { Hit h; h.rPos = run_start; h.gPos = (int64_t)(run_start + res.d) + task.left; h.len = l; out[n_seeds] = h; }
-                                    n_seeds++;
-                                }
-                                run = 0;
-                            }
-                        }
-                        if (pass == 0) {
-                            res.n_seeds = n_seeds;
-                            res.seed_off = atomicAdd(rw.n_seeds, (uint32_t)n_seeds);
-                            if ((uint64_t)res.seed_off + (uint64_t)n_seeds > rw.seed_cap) break; // (the pool ran over: the pass is repeated in halves)
-                            out = rw.seeds + res.seed_off;
-                        }
+                if (lane == 0) ev.diagonal(res.d, qlen, slen, pad, true); // the best diagonal's 8-mer match words, a word per 32 rows
+                wave_sync();
+                // The seeds of the diagonal: runs of three or more 8-mer matches (ten or more matching bases), in the order of their rows.  A lane per
+                // word: where such a run begins and where it ends are two bit masks, the j-th beginning and the j-th end of the wavefront are one run's, and
+                // two counts summed across the lanes number them.  (One lane walked the read's rows before, twice — counting, then writing —, a dependent
+                // LDS read per row: some 7 000 instructions of a wavefront's time per window that beat its mate, more than the window's 1 300 diagonals cost.)
+                uint32_t S = 0, E = 0;
+                if (lane < kRescueQWords) {
+                    const uint32_t e0 = ev.ew[lane], e1 = lane + 1 < kRescueQWords ? ev.ew[lane + 1] : 0u, ep = lane > 0 ? ev.ew[lane - 1] : 0u;
+                    const uint32_t t = e0 & __funnelshift_r(e0, e1, 1) & __funnelshift_r(e0, e1, 2); // a triple of matches begins here
+                    const uint32_t t_before = (ep >> 31) & e0 & (e0 >> 1) & 1u;                      // ... at the last row of the word before
+                    const uint32_t t_after = e1 & (e1 >> 1) & (e1 >> 2) & 1u;                         // ... at the first row of the word after
+                    S = t & ~((t << 1) | t_before);
+                    E = t & ~((t >> 1) | (t_after << 31));
+                }
+                const int cs = __popc(S), ce = __popc(E);
+                int is = cs, ie = ce;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int vs = __shfl_up(is, o, 64), ve = __shfl_up(ie, o, 64);
+                    if (lane >= o) { is += vs; ie += ve; }
+                }
+                const int n_seeds = __shfl(is, 63, 64);
+                uint32_t off = 0;
+                if (lane == 0) off = atomicAdd(rw.n_seeds, (uint32_t)n_seeds);
+                off = (uint32_t)__shfl((int)off, 0, 64);
+                res.n_seeds = n_seeds; res.seed_off = off;
+                if ((uint64_t)off + (uint64_t)n_seeds <= rw.seed_cap) { // (else the pool ran over: the pass is repeated in halves)
+                    uint16_t *ss = ss_all[wv];
+                    int j = is - cs;
+                    for (uint32_t m = S; m; m &= m - 1u) ss[j++] = (uint16_t)(32 * lane + __ffs((int)m) - 1);
+                    wave_sync();
+                    Hit *out = rw.seeds + off;
+                    j = ie - ce;
+                    for (uint32_t m = E; m; m &= m - 1u, j++) {
+                        const int start = ss[j], end = 32 * lane + __ffs((int)m) - 1; // the run's first and last triple: its 8-mer matches end two rows later
+                        Hit h; h.rPos = start; h.gPos = (int64_t)(start + res.d) + task.left; h.len = end - start + 1 + kKmerSize + 1;
+                        out[j] = h;
                     }
                 }
             }
