@@ -538,7 +538,8 @@ def other_configs(args):
     ]
     res = []
     for name, extra in runs:
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--second-genome", "0", "--other-configs", "0", "--vcf-reduce", "0",
+        # (two warm-up batches: the first makes the large tier's records and — when it ends — the long DP list's scratch grow to the workload, mcx.h; the second runs on them)
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "2", "--second-genome", "0", "--other-configs", "0", "--vcf-reduce", "0",
                "--pcie-steps", "0", "--file-steps", "0", "--full-line", "1", "--detail-stdout", "0", "--detail-tag", "cfg" + name.split(":")[0].split()[-1], "--full-sa", str(args.full_sa)] + extra
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=900)
