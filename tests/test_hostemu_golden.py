@@ -110,6 +110,58 @@ def test_two_problems_per_lane_dp_equals_the_reference_vectors(hostemu_lib, alg,
     assert done > 2000 and len(shapes) == 4  # (every combination of longer / shorter query and target in either half)
 
 
+@pytest.mark.parametrize("K", [8, 16])
+@pytest.mark.parametrize("alg", ["nw", "ksw2"])
+def test_two_problems_per_lane_dp_equals_one_per_lane_on_random_shapes(hostemu_lib, alg, K):
+    """Seeded random problems — a query and a target that descend from one sequence by substitutions, insertions and deletions, 1 to 300 by 1 to 256 bases
+    (one to sixteen strips, walks that cross strips and window edges at every offset), now and then an N in the query — through the two-problems-per-lane
+    DP, each pair of neighbours sharing a lane both ways round: the column strings and nw's score equal the one-problem-per-lane form's, which the
+    reference's vectors hold (above)."""
+    import random
+    rng = random.Random(20261004 + K + (0 if alg == "nw" else 1))
+    L = hostemu_lib
+    L.hostemu_lane_dp2.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
+                                   ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    L.hostemu_lane_dp.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+    use_nw = 1 if alg == "nw" else 0
+    max_t = 8 * K if K == 8 else 256
+
+    def problem():
+        n = rng.randint(1, max_t)
+        t = "".join(rng.choice("ACGT") for _ in range(n))
+        rate = rng.choice([0.0, 0.02, 0.05, 0.15])
+        q = []
+        for ch in t:
+            r = rng.random()
+            if r < rate / 3: continue                                   # deletion
+            if r < 2 * rate / 3: q.append(rng.choice("ACGT"))            # insertion before
+            q.append(rng.choice("ACGT") if rng.random() < rate else ch)  # substitution
+        if rng.random() < 0.2: q = q[: rng.randint(1, max(1, len(q)))]   # ragged: a short query against a long target
+        if rng.random() < 0.2: q = q + [rng.choice("ACGT") for _ in range(rng.randint(1, 40))]
+        q = q[:300] or ["A"]
+        if rng.random() < 0.1: q[rng.randrange(len(q))] = "N"
+        return "".join(q), t
+
+    def one(q, t):
+        buf, sc = ctypes.create_string_buffer(len(q) + len(t) + 2), ctypes.c_int()
+        ln = L.hostemu_lane_dp(use_nw, q.encode(), len(q), t.encode(), len(t), K, buf, ctypes.byref(sc))
+        return buf.value.decode(), sc.value, ln
+
+    probs = [problem() for _ in range(1500)]
+    ref = [one(q, t) for q, t in probs]
+    for i in range(len(probs)):
+        j = (i + 1) % len(probs)
+        (qa, ta), (qb, tb) = probs[i], probs[j]
+        oa, ob = ctypes.create_string_buffer(len(qa) + len(ta) + 2), ctypes.create_string_buffer(len(qb) + len(tb) + 2)
+        sc, ln = (ctypes.c_int * 2)(), (ctypes.c_int * 2)()
+        assert L.hostemu_lane_dp2(use_nw, qa.encode(), len(qa), ta.encode(), len(ta), qb.encode(), len(qb), tb.encode(), len(tb), K, oa, ob, sc, ln) == 0
+        for k, (o, r) in enumerate(((oa, ref[i]), (ob, ref[j]))):
+            assert o.value.decode() == r[0], (k, probs[i if k == 0 else j])
+            assert ln[k] == r[2]
+            if alg == "nw":
+                assert sc[k] == r[1]
+
+
 @pytest.mark.parametrize("switch", ["MCX_EMU_NO_CODES", "MCX_EMU_ORACLE_DP", "MCX_EMU_DP_X1"])
 @pytest.mark.parametrize("alg", ["nw", "ksw2"])
 def test_lane_dp_inputs_and_the_scalar_dp_agree(hostemu_lib, golden, tmp_path, monkeypatch, alg, switch):
