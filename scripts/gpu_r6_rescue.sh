@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6: mate rescue — the windows evaluated on the diagonals an 8-mer table points at, against every diagonal (MCX_RESCUE_SCAN_ALL=1): parity subset, config 5, the headline
+# round 6: mate rescue — the parity subset and the two timings that went with every change of k_rescue_eval (the seeds by all lanes: kept; the 8-mer table that picked the diagonals, whose A/B switch MCX_RESCUE_SCAN_ALL this script still sets: not kept, the switch is gone with it — DESIGN.md §3)
 mkdir -p gpurun_out/r6r; cd "$GRAFT_REPO_ROOT"; ulimit -c 0
 timeout 1200 python3 -m pytest tests -m gpu -x -q -k "golden or sam_equals_reference or config5 or large_batch or fuzz_rounds or rescue or config2 or fresh_seeded or long_cigars or ragged or sharded" > gpurun_out/r6r/parity.log 2>&1 < /dev/null
 tail -3 gpurun_out/r6r/parity.log
