@@ -337,8 +337,7 @@ public:
     bool open(const std::string &path, std::string &err)
     {
         gz_mode_ = path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0; // ReadMapping.cpp:709
-        buf_.resize(1 << 24);
-        for (int k = 0; k < 4; k++) { std::unique_ptr<Block> b(new Block); b->d.resize(kBlockBytes); free_.push(std::move(b)); }
+        for (int k = 0; k < 4; k++) { std::unique_ptr<Block> b(new Block); b->d.resize(kHead + kBlockBytes); free_.push(std::move(b)); } // (one with the feeder, one with the splitter, two on their way)
         if (gz_mode_ && map_bgzf(path)) {
             // BGZF (bgzip, samtools): a gzip file made of independent members of at most 64 KB, each saying how long it is — the
             // members of a stretch are inflated side by side by a few threads
@@ -355,8 +354,9 @@ public:
             feeder_ = std::thread([this] {
                 for (;;) {
                     std::unique_ptr<Block> b = free_.pop();
-                    int got = stop_.load() ? 0 : gzread(gz_, b->d.data(), (unsigned)kBlockBytes);
+                    int got = stop_.load() ? 0 : gzread(gz_, b->text(), (unsigned)kBlockBytes);
                     b->n = got > 0 ? (size_t)got : 0;
+                    b->look_for_nul();
                     const bool end = b->n == 0;
                     ready_.push(std::move(b));
                     if (end) break;
@@ -364,13 +364,14 @@ public:
             });
         }
         fill();
-        fastq_ = end_ > 0 && buf_[0] == '@'; // CheckReadFormat, GetData.cpp:22-31
+        fastq_ = end_ > pos_ && *pos_ == '@'; // CheckReadFormat, GetData.cpp:22-31
         return true;
     }
     ~Parser()
     {
         if (feeder_.joinable()) {
             stop_.store(true);
+            if (cur_) { free_.push(std::move(cur_)); pos_ = end_ = nullptr; } // (the feeder may be waiting for a block to fill)
             while (!eof_) { std::unique_ptr<Block> b = ready_.pop(); if (b->n == 0) eof_ = true; else free_.push(std::move(b)); }
             feeder_.join();
         }
@@ -393,13 +394,21 @@ public:
     }
 
 private:
-    enum : size_t { kBlockBytes = 8u << 20 };
-    struct Block { std::vector<char> d; size_t n = 0; };
+    // A block of text on its way from the feeder to the line splitter: kBlockBytes of it behind kHead bytes of room, into which the splitter moves what the
+    // block before left unfinished (a line's beginning, a record's first lines) — the lines are then cut where the feeder put them.  (Until round 6 every block
+    // was copied once more, into the splitter's own buffer, and searched for a NUL there: both on the one thread per file that the .gz rate hangs on.)
+    enum : size_t { kBlockBytes = 8u << 20, kHead = 64u << 10 };
+    struct Block {
+        std::vector<char> d; size_t n = 0; bool nul = false;
+        char *text() { return d.data() + kHead; }
+        void look_for_nul() { nul = n && memchr(text(), 0, n) != nullptr; } // (gzgets' lines are C strings: a NUL cuts one short — looked for per block, by the feeder)
+    };
     gzFile gz_ = nullptr;
     bool gz_mode_ = false, fastq_ = true, eof_ = false, has_nul_ = false;
     size_t own_per_rec_ = 340; // bytes of names, bases and qualities a record of the last batch took
-    std::vector<char> buf_;
-    size_t pos_ = 0, end_ = 0;
+    std::unique_ptr<Block> cur_;             // the block the splitter is in
+    const char *pos_ = nullptr, *end_ = nullptr; // what is left of it (with the carried-over bytes in front)
+    std::vector<char> long_;                 // a line or record tail longer than kHead (a FASTA line of megabytes): block and tail put together here
     Queue<std::unique_ptr<Block>> ready_{4}, free_{4};
     std::thread feeder_;
     std::atomic<bool> stop_{false};
@@ -467,8 +476,9 @@ private:
             for (size_t o = 0; o < text.size() && !stop_.load();) {
                 std::unique_ptr<Block> b = free_.pop();
                 const size_t m = std::min<size_t>(text.size() - o, kBlockBytes);
-                memcpy(b->d.data(), text.data() + o, m);
+                memcpy(b->text(), text.data() + o, m);
                 b->n = m; o += m;
+                b->look_for_nul();
                 ready_.push(std::move(b));
             }
         }
@@ -501,7 +511,7 @@ private:
                 tasks.push_back(t);
                 total += isize; o += size;
             }
-            char *out = b->d.data();
+            char *out = b->text();
             pool.run((int)tasks.size(), [&](int k) {
                 const Task &t = tasks[(size_t)k];
                 if (t.isize == 0) return; // (the empty member that ends a BGZF file)
@@ -517,6 +527,7 @@ private:
             if (bad.load()) total = 0; // (a damaged stretch is not handed on)
             if (total == 0 && !bad.load() && !last && o < map_size_) { free_.push(std::move(b)); continue; } // (empty members in the middle of a file)
             b->n = total;
+            b->look_for_nul();
             const bool end = total == 0;
             ready_.push(std::move(b));
             if (end) return;
@@ -526,29 +537,40 @@ private:
         ready_.push(std::move(b));
     }
 
-    void fill() // one more block of input behind what is left of the buffer
+    void fill() // one more block of input behind what is left of this one
     {
         if (eof_) return;
-        if (pos_ > 0) { memmove(buf_.data(), buf_.data() + pos_, end_ - pos_); end_ -= pos_; pos_ = 0; }
         std::unique_ptr<Block> b = ready_.pop();
-        if (b->n == 0) { eof_ = true; return; }
-        if (end_ + b->n > buf_.size()) buf_.resize(std::max(buf_.size() * 2, end_ + b->n));
-        memcpy(buf_.data() + end_, b->d.data(), b->n);
-        if (!has_nul_ && memchr(b->d.data(), 0, b->n)) has_nul_ = true; // (gzgets' lines are C strings: a NUL cuts one short — looked for per block, not per line)
-        end_ += b->n;
-        free_.push(std::move(b));
+        if (b->n == 0) { eof_ = true; free_.push(std::move(b)); return; } // (what is left stays where it is: pos_ .. end_)
+        const size_t left = (size_t)(end_ - pos_);
+        if (b->nul) has_nul_ = true;
+        if (left <= kHead) {
+            if (left) memcpy(b->text() - left, pos_, left);
+            pos_ = b->text() - left; end_ = b->text() + b->n;
+            if (cur_) free_.push(std::move(cur_));
+            cur_ = std::move(b);
+            long_.clear();
+        } else { // (rare: more left over than a block has room for in front)
+            std::vector<char> both(left + b->n);
+            memcpy(both.data(), pos_, left);
+            memcpy(both.data() + left, b->text(), b->n);
+            long_.swap(both);
+            pos_ = long_.data(); end_ = long_.data() + long_.size();
+            if (cur_) free_.push(std::move(cur_));
+            free_.push(std::move(b));
+        }
     }
 
     // next line including its '\n' (getline); the .gz reader's gzgets(buffer, 1024) cuts at 1023 bytes
     bool line(const char *&p, size_t &len, bool consume = true)
     {
         for (;;) {
-            const size_t avail = end_ - pos_;
+            const size_t avail = (size_t)(end_ - pos_);
             const size_t lim = gz_mode_ ? std::min<size_t>(avail, 1023) : avail;
-            const char *nl = lim ? find_nl(buf_.data() + pos_, buf_.data() + pos_ + lim) : nullptr; // (lines of tens to hundreds of bytes: memchr's set-up costs more than the search)
-            if (nl) { p = buf_.data() + pos_; len = (size_t)(nl - p) + 1; break; }
-            if (gz_mode_ && avail >= 1023) { p = buf_.data() + pos_; len = 1023; break; }
-            if (eof_) { if (avail == 0) return false; p = buf_.data() + pos_; len = avail; break; }
+            const char *nl = lim ? find_nl(pos_, pos_ + lim) : nullptr; // (lines of tens to hundreds of bytes: memchr's set-up costs more than the search)
+            if (nl) { p = pos_; len = (size_t)(nl - p) + 1; break; }
+            if (gz_mode_ && avail >= 1023) { p = pos_; len = 1023; break; }
+            if (eof_) { if (avail == 0) return false; p = pos_; len = avail; break; }
             fill();
         }
         if (consume) pos_ += len;
