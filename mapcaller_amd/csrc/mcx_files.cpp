@@ -470,17 +470,23 @@ private:
     {
         Pool pool((int)std::max(2u, std::min(12u, mcx_usable_cpus() * 3 / 8)));
         pgz::Reader rd;
-        pgz::Text text;
-        bool ok = rd.open(map_, map_size_, pool.size(), (size_t)2 << 20, [&](int n, const std::function<void(int)> &f) { pool.run(n, f); });
-        while (ok && !stop_.load() && rd.next(text)) {
-            for (size_t o = 0; o < text.size() && !stop_.load();) {
+        pgz::Text text[2];
+        bool have = rd.open(map_, map_size_, pool.size(), (size_t)2 << 20, [&](int n, const std::function<void(int)> &f) { pool.run(n, f); }) && rd.next(text[0]);
+        for (int cur = 0; have && !stop_.load(); cur ^= 1) {
+            // the next round is inflated while this round's text goes into the blocks (the pool stood still meanwhile: a tenth of the reader's time)
+            bool more = false;
+            std::thread ahead([&] { more = rd.next(text[cur ^ 1]); });
+            const pgz::Text &t = text[cur];
+            for (size_t o = 0; o < t.size() && !stop_.load();) {
                 std::unique_ptr<Block> b = free_.pop();
-                const size_t m = std::min<size_t>(text.size() - o, kBlockBytes);
-                memcpy(b->text(), text.data() + o, m);
+                const size_t m = std::min<size_t>(t.size() - o, kBlockBytes);
+                memcpy(b->text(), t.data() + o, m);
                 b->n = m; o += m;
                 b->look_for_nul();
                 ready_.push(std::move(b));
             }
+            ahead.join();
+            have = more;
         }
         std::unique_ptr<Block> b = free_.pop(); // the end of the input (a damaged stream ends it where it stops making sense, as gzread's error does)
         b->n = 0;
